@@ -1,0 +1,160 @@
+"""ctypes front-end of oracle/liboracle.so -- TEST INFRASTRUCTURE ONLY.
+
+Importers allowed: tests/, __graft_entry__.smoke(), bench.py's cpu_baseline leg.  The product package must
+never import this module (tests/test_abi.py greps for that).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "liboracle.so")
+MAXK = 16
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+
+
+def build(force=False):
+    """compile liboracle.so (and, when /root/reference is present, the reference driver)."""
+    if force or not os.path.exists(LIB_PATH) or any(
+            os.path.getmtime(os.path.join(HERE, f)) > os.path.getmtime(LIB_PATH)
+            for f in os.listdir(HERE) if f.endswith(".cpp") and f != "ref_driver.cpp"):
+        subprocess.run(["make", "-C", HERE, "liboracle.so"], check=True, stdout=subprocess.DEVNULL)
+    if os.path.isdir("/root/reference/FoamYade") and os.path.exists("/opt/conda/lib/libmpi.so"):
+        subprocess.run(["make", "-C", HERE, "ref"], check=True, stdout=subprocess.DEVNULL)
+
+
+class StepArgs(C.Structure):
+    _fields_ = [
+        ("nx", C.c_int), ("ny", C.c_int), ("nz", C.c_int), ("Nc", C.c_int),
+        ("dx", C.c_double), ("bbmin", C.c_double * 3), ("bbmax", C.c_double * 3),
+        ("C", _dp), ("V", _dp), ("pre", _ip),
+        ("U", _dp), ("gradP", _dp), ("vGrad", _dp), ("divT", _dp),
+        ("uSourceDrag", _dp), ("alpha", _dp), ("uSource", _dp), ("uParticle", _dp),
+        ("gaussian", C.c_int), ("rhoP", C.c_double), ("rhoF", C.c_double), ("nu", C.c_double),
+        ("nbatch", C.c_int), ("off", _ip), ("records", _dp),
+        ("k", _ip), ("ids", _ip), ("w", _dp), ("chain_len", _ip), ("force", _dp), ("found", _ip),
+        ("threads", C.c_int),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        L = C.CDLL(LIB_PATH)
+        L.orc_build_tree.argtypes = [C.c_int, _dp, _ip]
+        L.orc_build_tree.restype = C.c_int
+        L.orc_range_search.argtypes = [C.c_int, _dp, _ip, C.c_int, _dp, C.c_int, C.c_double, _ip, _ip, _ip]
+        L.orc_range_search.restype = C.c_long
+        L.orc_nearest_cell.argtypes = [C.c_int, _dp, _ip, C.c_int, _dp, C.c_int, _ip]
+        L.orc_particle_action.argtypes = [C.POINTER(StepArgs)]
+        L.orc_set_source_zero.argtypes = [C.c_int, C.c_int, _dp, _dp, _dp, _dp]
+        _lib = L
+    return _lib
+
+
+def _d(a):
+    assert a.dtype == np.float64 and a.flags.c_contiguous
+    return a.ctypes.data_as(_dp)
+
+
+def _i(a):
+    assert a.dtype == np.int32 and a.flags.c_contiguous
+    return a.ctypes.data_as(_ip)
+
+
+def build_tree(centres):
+    centres = np.ascontiguousarray(centres, dtype=np.float64)
+    pre = np.empty(centres.shape[0], dtype=np.int32)
+    n = lib().orc_build_tree(centres.shape[0], _d(centres), _i(pre))
+    assert n == centres.shape[0]
+    return pre
+
+
+def range_search(centres, pre, pos, rng):
+    """pos (Np,3) or records (Np,10).  returns k, ids(Np,16), chain_len, visits"""
+    pos = np.ascontiguousarray(pos, dtype=np.float64)
+    n = pos.shape[0]
+    k = np.zeros(n, dtype=np.int32)
+    ids = np.full((n, MAXK), -1, dtype=np.int32)
+    chain = np.zeros(n, dtype=np.int32)
+    visits = lib().orc_range_search(centres.shape[0], _d(centres), _i(pre), n, _d(pos), pos.shape[1], float(rng),
+                                    _i(k), _i(ids), _i(chain))
+    return k, ids, chain, visits
+
+
+def nearest_cell(centres, pre, pos):
+    pos = np.ascontiguousarray(pos, dtype=np.float64)
+    cell = np.empty(pos.shape[0], dtype=np.int32)
+    lib().orc_nearest_cell(centres.shape[0], _d(centres), _i(pre), pos.shape[0], _d(pos), pos.shape[1], _i(cell))
+    return cell
+
+
+class Mesh:
+    """uniform hex block, blockMesh order (same convention as tests/golden_cases.py)"""
+
+    def __init__(self, nx, ny, nz, dx, origin=(0.0, 0.0, 0.0), centres=None, pre=None):
+        self.nx, self.ny, self.nz, self.dx = nx, ny, nz, float(dx)
+        self.origin = tuple(float(o) for o in origin)
+        self.Nc = nx * ny * nz
+        if centres is None:
+            i = np.arange(nx, dtype=np.float64); j = np.arange(ny, dtype=np.float64); k = np.arange(nz, dtype=np.float64)
+            Cc = np.empty((nz, ny, nx, 3))
+            Cc[..., 0] = (self.origin[0] + (i + 0.5) * dx)[None, None, :]
+            Cc[..., 1] = (self.origin[1] + (j + 0.5) * dx)[None, :, None]
+            Cc[..., 2] = (self.origin[2] + (k + 0.5) * dx)[:, None, None]
+            centres = Cc.reshape(-1, 3)
+        self.C = np.ascontiguousarray(centres, dtype=np.float64)
+        self.V = np.full(self.Nc, dx * dx * dx, dtype=np.float64)
+        self.bbmin = np.array(self.origin, dtype=np.float64)
+        self.bbmax = np.array([self.origin[0] + nx * dx, self.origin[1] + ny * dx, self.origin[2] + nz * dx])
+        self.pre = build_tree(self.C) if pre is None else np.ascontiguousarray(pre, dtype=np.int32)
+
+
+def particle_action(mesh: Mesh, fields: dict, mutable: dict, records, batch_off, gaussian, rhoP, rhoF, nu, threads=1):
+    """FoamYade::setParticleAction without MPI.  `mutable` arrays (alpha, uParticle, uSourceDrag, uSource) are
+    updated in place.  returns dict(k, ids, w, chain_len, force, found)."""
+    records = np.ascontiguousarray(records, dtype=np.float64).reshape(-1, 10)
+    n = records.shape[0]
+    off = np.ascontiguousarray(batch_off, dtype=np.int32)
+    out = dict(k=np.zeros(n, np.int32), ids=np.full((n, MAXK), -1, np.int32), w=np.zeros((n, MAXK)),
+               chain_len=np.zeros(n, np.int32), force=np.zeros((n, 6)), found=np.zeros(n, np.int32))
+    a = StepArgs()
+    a.nx, a.ny, a.nz, a.Nc, a.dx = mesh.nx, mesh.ny, mesh.nz, mesh.Nc, mesh.dx
+    for q in range(3):
+        a.bbmin[q] = mesh.bbmin[q]
+        a.bbmax[q] = mesh.bbmax[q]
+    a.C, a.V, a.pre = _d(mesh.C), _d(mesh.V), _i(mesh.pre)
+    keep = []
+    for nm in ("U", "gradP", "vGrad", "divT"):
+        arr = np.ascontiguousarray(fields[nm], dtype=np.float64)
+        keep.append(arr)
+        setattr(a, nm, _d(arr))
+    for nm in ("uSourceDrag", "alpha", "uSource", "uParticle"):
+        setattr(a, nm, _d(mutable[nm]))
+    a.gaussian, a.rhoP, a.rhoF, a.nu = int(gaussian), float(rhoP), float(rhoF), float(nu)
+    a.nbatch, a.off, a.records = len(off) - 1, _i(off), _d(records)
+    a.k, a.ids, a.w, a.chain_len = _i(out["k"]), _i(out["ids"]), _d(out["w"]), _i(out["chain_len"])
+    a.force, a.found = _d(out["force"]), _i(out["found"])
+    a.threads = int(threads)
+    lib().orc_particle_action(C.byref(a))
+    return out
+
+
+def fresh_mutable(Nc):
+    """state after FoamYade::initFields (FoamYade.C:56-68)"""
+    return dict(uSourceDrag=np.zeros(Nc), alpha=np.ones(Nc), uSource=np.zeros((Nc, 3)), uParticle=np.zeros((Nc, 3)))
+
+
+def set_source_zero(mutable, gaussian):
+    Nc = mutable["alpha"].shape[0]
+    lib().orc_set_source_zero(Nc, int(gaussian), _d(mutable["uSourceDrag"]), _d(mutable["alpha"]),
+                              _d(mutable["uSource"]), _d(mutable["uParticle"]))

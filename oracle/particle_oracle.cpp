@@ -1,0 +1,432 @@
+// ORACLE / TEST INFRASTRUCTURE ONLY.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
+// may load this; the product library never links, includes or calls anything in oracle/.
+//
+// CPU restatement of the reference's particle path: k-d tree over cell centres, "range" locate, Gaussian
+// weights, void-fraction / particle-velocity deposition, drag + Archimedes (+ Stokes point force/torque),
+// momentum-source back-scatter.  Every function cites the reference lines it follows
+// (paths relative to /root/reference/FoamYade/).  Parity status: PINNED -- tests/test_oracle_golden.py checks
+// it against tests/golden/*.npz, which were produced by running the reference's own FoamYade.C / meshTree.C
+// (oracle/_ref/ref_driver, built by `make -C oracle ref`).
+//
+// Differences from the reference that are deliberate and result-neutral:
+//   * tree stored as a preorder array (shape depends only on n: node = element n/2, meshTree.C:27-31);
+//   * buildCellPartList's linear search (FoamYade.C:276-282) replaced by a dense per-cell accumulator that
+//     adds contributions in the same (particle, stencil-slot) order => bit-identical sums, O(pairs);
+//   * the 13th push into the bounded queue reads container[12] one past size() (meshTree.H:66-68, UB);
+//     we define it as "append, never evict" and report chain_len so callers can exclude those particles.
+// Compile with -ffp-contract=off: the reference binary (x86-64 baseline, -O2) contains no fused multiply-adds.
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <utility>
+#include <vector>
+
+namespace {
+
+const int MAXK = 16;            // output slot width (reference nominal bound 12, observed max 14)
+
+struct Elem { double x[3]; int id; };
+
+// meshTree.H:45-55 cmpvec
+struct CmpAxis {
+    int a;
+    bool operator()(const Elem& p, const Elem& q) const { return p.x[a] < q.x[a]; }
+};
+
+// meshTree.C:19-37 recursive_build_tree + meshTree.C:46-51 get_median, in place on [lo,hi):
+// nth_element on a sub-range sees the same element sequence as the reference's copied pv1/pv2 vectors.
+void build_rec(Elem* pts, int lo, int hi, int depth, int* out, int& pos) {
+    if (lo == hi) return;                                   // meshTree.C:22
+    const int axis = depth % 3;                             // meshTree.C:24
+    const int md = lo + (hi - lo) / 2;                      // meshTree.C:27
+    std::nth_element(pts + lo, pts + md, pts + hi, CmpAxis{axis});   // meshTree.C:50
+    out[pos++] = pts[md].id;                                // meshTree.C:28 (preorder: node, left, right)
+    build_rec(pts, lo, md, depth + 1, out, pos);            // meshTree.C:33
+    build_rec(pts, md + 1, hi, depth + 1, out, pos);        // meshTree.C:34
+}
+
+struct Tree {
+    int n;
+    const double* C;     // Nc*3 cell centres (mesh.C())
+    const int* pre;      // preorder cell ids
+};
+
+// meshTree.C:54-64 distance(): loop over 3 components, dist += ds*ds
+inline double dist2(const double* a, const double* b) {
+    double d = 0.0;
+    for (int i = 0; i < 3; ++i) { double ds = b[i] - a[i]; d += ds * ds; }
+    return d;
+}
+
+// meshTree.H:58-93 pqueue
+struct PQueue {
+    unsigned maxbound; double maxdist;
+    std::vector<std::pair<int, double> > c;   // (preorder offset, d2)
+    const int* pre;
+    int pushes = 0; bool ub = false;
+    bool incontainer(int off) const {          // meshTree.H:80-90 (compares cell ids)
+        for (auto& e : c) if (pre[e.first] == pre[off]) return true;
+        return false;
+    }
+    void push_node(int off, double d) {        // meshTree.H:64-78
+        if (c.size() == maxbound) {
+            // reference: if (container[maxbound].second > d && !incontainer) {pop_back; push_back; sort;}
+            // container[maxbound] is out of bounds -> undefined; we take the branch as NOT taken.
+            if (!incontainer(off)) ub = true;
+        }
+        if (!incontainer(off)) {
+            c.push_back(std::make_pair(off, d));
+            std::stable_sort(c.begin(), c.end(), [](const std::pair<int, double>& a, const std::pair<int, double>& b) { return a.second < b.second; });
+            ++pushes;
+        }
+    }
+};
+
+struct Search {
+    const Tree& t; const double* v; PQueue& pq; long visits;
+    // meshTree.C:182-238 nnearest.  Subtree = preorder range [o, o+n); returns best offset or -1 for NULL.
+    int nnearest(int o, int n, int best, double best_dist, int depth) {
+        if (n == 0) return -1;                                           // :185
+        ++visits;
+        int best1 = best; double dist_l = best_dist;                     // :187-188
+        const double* p = t.C + 3 * (size_t)t.pre[o];
+        double distsq = dist2(p, v);                                     // :190 distance(node->p, v)
+        if (distsq < best_dist) {                                        // :192
+            dist_l = distsq; best1 = o;
+            if (dist_l < pq.maxdist) pq.push_node(best1, dist_l);        // :195-196
+        }
+        const int axis = depth % 3;                                      // :199
+        const double df = p[axis] - v[axis];                             // :200
+        const double df2 = df * df;
+        const int nl = n / 2, nr = n - nl - 1;
+        int next_o, next_n, other_o, other_n;
+        if (df > 0.0) { next_o = o + 1; next_n = nl; other_o = o + 1 + nl; other_n = nr; }   // :206-208
+        else          { next_o = o + 1 + nl; next_n = nr; other_o = o + 1; other_n = nl; }   // :209-212
+        depth = depth + 1;
+        int nextN = nnearest(next_o, next_n, best1, dist_l, depth);      // :214
+        if (nextN >= 0) {
+            distsq = dist2(t.C + 3 * (size_t)t.pre[nextN], v);           // :216
+            if (distsq < dist_l) {
+                dist_l = distsq; best1 = nextN;
+                if (dist_l < pq.maxdist) pq.push_node(best1, dist_l);    // :220-221
+            }
+        }
+        if (df2 < dist_l) {                                              // :225
+            int nextM = nnearest(other_o, other_n, best1, dist_l, depth);
+            if (nextM >= 0) {
+                distsq = dist2(t.C + 3 * (size_t)t.pre[nextM], v);
+                if (distsq < dist_l) {
+                    dist_l = distsq; best1 = nextM;
+                    if (dist_l < pq.maxdist) pq.push_node(best1, dist_l);
+                }
+            }
+        }
+        return best1;                                                    // :237
+    }
+};
+
+// meshTree.C:148-179 nnearestCellsRange(v, range, true): ids sorted by d2 ascending; empty => "not found"
+int range_search(const Tree& t, const double* v, double range, int* ids, int* chain_len, long* visits) {
+    PQueue pq; pq.maxbound = 12; pq.pre = t.pre;                         // :153-154
+    pq.maxdist = (range * range) + (0.25 * range * range);               // :155
+    double dist = dist2(t.C + 3 * (size_t)t.pre[0], v);                  // :156 distance(root->p, px)
+    Search s{t, v, pq, 0};
+    s.nnearest(0, t.n, 0, dist, 0);                                      // :157
+    int k = (int)pq.c.size();
+    if (chain_len) *chain_len = pq.pushes;
+    if (visits) *visits += s.visits;
+    for (int i = 0; i < k && i < MAXK; ++i) ids[i] = t.pre[pq.c[i].first];   // :163-168
+    return k;
+}
+
+// meshTree.C:66-135 nearestCell (unused by FoamYade; kept for the NN locate tests)
+struct NN {
+    const Tree& t; const double* v;
+    int rec(int o, int n, int best, double best_dist, int depth) {
+        if (n == 0) return -1;
+        int best1 = best; double dist_l = best_dist;
+        const double* p = t.C + 3 * (size_t)t.pre[o];
+        double distsq = dist2(p, v);
+        if (distsq < best_dist) { dist_l = distsq; best1 = o; }
+        const int axis = depth % 3;
+        const double df = p[axis] - v[axis], df2 = df * df;
+        const int nl = n / 2, nr = n - nl - 1;
+        int next_o, next_n, other_o, other_n;
+        if (df > 0.0) { next_o = o + 1; next_n = nl; other_o = o + 1 + nl; other_n = nr; }
+        else          { next_o = o + 1 + nl; next_n = nr; other_o = o + 1; other_n = nl; }
+        depth = depth + 1;
+        int a = rec(next_o, next_n, best1, dist_l, depth);
+        if (a >= 0) { distsq = dist2(t.C + 3 * (size_t)t.pre[a], v); if (distsq < dist_l) { dist_l = distsq; best1 = a; } }
+        if (df2 < dist_l) {
+            int b = rec(other_o, other_n, best1, dist_l, depth);
+            if (b >= 0) { distsq = dist2(t.C + 3 * (size_t)t.pre[b], v); if (distsq < dist_l) { dist_l = distsq; best1 = b; } }
+        }
+        return best1;
+    }
+};
+
+struct V3 { double x, y, z; };
+inline V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline V3 operator-(V3 a) { return {-a.x, -a.y, -a.z}; }
+inline V3 operator*(double s, V3 a) { return {s * a.x, s * a.y, s * a.z}; }
+inline V3 operator*(V3 a, double s) { return {a.x * s, a.y * s, a.z * s}; }
+inline V3 operator/(V3 a, double s) { return {a.x / s, a.y / s, a.z / s}; }
+inline double mag(V3 a) { return std::sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }
+inline V3 ld(const double* p, int c) { return {p[3 * (size_t)c], p[3 * (size_t)c + 1], p[3 * (size_t)c + 2]}; }
+inline void st(double* p, int c, V3 v) { p[3 * (size_t)c] = v.x; p[3 * (size_t)c + 1] = v.y; p[3 * (size_t)c + 2] = v.z; }
+
+}  // namespace
+
+extern "C" {
+
+// meshTree.C:9-17 build_tree.  out_pre[Nc] = cell ids in preorder.
+int orc_build_tree(int Nc, const double* C, int* out_pre) {
+    std::vector<Elem> pts((size_t)Nc);
+    for (int c = 0; c < Nc; ++c) { pts[c].x[0] = C[3 * (size_t)c]; pts[c].x[1] = C[3 * (size_t)c + 1]; pts[c].x[2] = C[3 * (size_t)c + 2]; pts[c].id = c; }
+    int pos = 0;
+    build_rec(pts.data(), 0, Nc, 0, out_pre, pos);
+    return pos;
+}
+
+// nnearestCellsRange over many points.  pos: Np x 3 with row stride `stride` doubles.
+// k[Np], ids[Np*16] (-1 padded), chain_len[Np] (pushes; > 12 => reference behaviour undefined).  Returns node visits.
+long orc_range_search(int Nc, const double* C, const int* pre, int Np, const double* pos, int stride, double range,
+                      int* k, int* ids, int* chain_len) {
+    Tree t{Nc, C, pre};
+    long visits = 0;
+#pragma omp parallel for schedule(dynamic, 1024) reduction(+ : visits)
+    for (int i = 0; i < Np; ++i) {
+        int* id = ids + (size_t)i * MAXK;
+        for (int q = 0; q < MAXK; ++q) id[q] = -1;
+        long v = 0;
+        k[i] = range_search(t, pos + (size_t)i * stride, range, id, chain_len ? chain_len + i : nullptr, &v);
+        visits += v;
+    }
+    return visits;
+}
+
+void orc_nearest_cell(int Nc, const double* C, const int* pre, int Np, const double* pos, int stride, int* cell) {
+    Tree t{Nc, C, pre};
+#pragma omp parallel for schedule(dynamic, 1024)
+    for (int i = 0; i < Np; ++i) {
+        const double* v = pos + (size_t)i * stride;
+        NN s{t, v};
+        double d = dist2(C + 3 * (size_t)pre[0], v);
+        int b = s.rec(0, Nc, 0, d, 0);
+        cell[i] = pre[b];
+    }
+}
+
+// uniform-hex stand-in for polyMesh::findCell -- identical to oracle/shim/fvCFD.H fvMesh::findCell
+int orc_find_cell(int nx, int ny, int nz, double dx, const double* bbmin, const double* bbmax, const double* p) {
+    if (p[0] < bbmin[0] || p[1] < bbmin[1] || p[2] < bbmin[2] || p[0] > bbmax[0] || p[1] > bbmax[1] || p[2] > bbmax[2]) return -1;
+    int i = std::min(nx - 1, (int)((p[0] - bbmin[0]) / dx));
+    int j = std::min(ny - 1, (int)((p[1] - bbmin[1]) / dx));
+    int k = std::min(nz - 1, (int)((p[2] - bbmin[2]) / dx));
+    return i + nx * (j + ny * k);
+}
+
+struct orc_step_args {
+    // mesh
+    int nx, ny, nz, Nc;
+    double dx;
+    double bbmin[3], bbmax[3];
+    const double* C;        // Nc*3
+    const double* V;        // Nc
+    const int* pre;         // Nc preorder ids (orc_build_tree)
+    // read-only fields
+    const double* U;        // Nc*3
+    const double* gradP;    // Nc*3
+    const double* vGrad;    // Nc*9
+    const double* divT;     // Nc*3
+    // mutable fields (in/out)
+    double* uSourceDrag;    // Nc
+    double* alpha;          // Nc
+    double* uSource;        // Nc*3
+    double* uParticle;      // Nc*3
+    // scalars
+    int gaussian;
+    double rhoP, rhoF, nu;
+    // particles: nbatch yade procs, batch b owns records [off[b], off[b+1])
+    int nbatch;
+    const int* off;
+    const double* records;  // Ntot*10
+    // per-particle outputs (global numbering)
+    int* k;                 // Ntot
+    int* ids;               // Ntot*16
+    double* w;              // Ntot*16
+    int* chain_len;         // Ntot
+    double* force;          // Ntot*6   (zeros when not found, FoamYade.C:142)
+    int* found;             // Ntot     (1 / -1, FoamYade.C:141,222)
+    int threads;            // OpenMP threads for the (order-independent) locate phase; <=1 serial
+};
+
+// FoamYade.C:605-632 setParticleAction, minus the MPI calls (the wire protocol is exercised separately).
+void orc_particle_action(orc_step_args* a) {
+    const int Nc = a->Nc;
+    Tree t{Nc, a->C, a->pre};
+    // FoamYade.C:69-72 (initFields)
+    const double interpRange = 4 * std::pow(a->V[0], 1.0 / 3.0);
+    const double sigmaInterp = interpRange * 0.42460;
+    const double interpRangeCu = std::pow(interpRange, 3.0);
+    const double sigmaPi = 1.0 / (std::pow(2 * M_PI * sigmaInterp * sigmaInterp, 1.5));
+    const double small = 1e-09;                                          // FoamYade.H:67
+    const double rhoF = a->rhoF, nu = a->nu;
+
+    std::vector<double> pVolAcc; std::vector<double> uPAcc; std::vector<unsigned char> touched; std::vector<int> touchList;
+    if (a->gaussian) { pVolAcc.assign(Nc, 0.0); uPAcc.assign(3 * (size_t)Nc, 0.0); touched.assign(Nc, 0); }
+
+    for (int b = 0; b < a->nbatch; ++b) {
+        const int lo = a->off[b], hi = a->off[b + 1];
+        // ---- locateAllParticles (FoamYade.C:186-233)
+#pragma omp parallel for schedule(dynamic, 512) if (a->threads > 1) num_threads(a->threads > 1 ? a->threads : 1)
+        for (int p = lo; p < hi; ++p) {
+            const double* r = a->records + 10 * (size_t)p;
+            int* id = a->ids + (size_t)p * MAXK;
+            for (int q = 0; q < MAXK; ++q) { id[q] = -1; a->w[(size_t)p * MAXK + q] = 0.0; }
+            for (int q = 0; q < 6; ++q) a->force[6 * (size_t)p + q] = 0.0;
+            a->chain_len[p] = 0;
+            int kk;
+            if (a->gaussian) kk = range_search(t, r, interpRange, id, a->chain_len + p, nullptr);   // FoamYade.C:256
+            else {                                                                                    // FoamYade.C:250-253
+                int c = orc_find_cell(a->nx, a->ny, a->nz, a->dx, a->bbmin, a->bbmax, r);
+                kk = 0; if (c > -1) { id[0] = c; kk = 1; }
+            }
+            a->k[p] = kk;
+            a->found[p] = (kk > 0 && id[0] > -1) ? 1 : -1;                                            // FoamYade.C:204,222
+        }
+        if (a->gaussian) {
+            // ---- calcInterpWeightGaussian (FoamYade.C:293-316)
+            for (int p = lo; p < hi; ++p) {
+                if (a->found[p] != 1) continue;
+                const double* r = a->records + 10 * (size_t)p;
+                const int kk = std::min(a->k[p], MAXK);
+                double allwt = 0.0;
+                double* w = a->w + (size_t)p * MAXK; const int* id = a->ids + (size_t)p * MAXK;
+                for (int i = 0; i < kk; ++i) {
+                    const double ds1 = a->C[3 * (size_t)id[i]] - r[0];
+                    const double ds2 = a->C[3 * (size_t)id[i] + 1] - r[1];
+                    const double ds3 = a->C[3 * (size_t)id[i] + 2] - r[2];
+                    const double distsq = (ds1 * ds1) + (ds2 * ds2) + (ds3 * ds3);                   // :307
+                    const double weight = std::exp(-distsq / (2 * std::pow(sigmaInterp, 2))) * interpRangeCu * sigmaPi;   // :308
+                    allwt += weight; w[i] = weight;
+                }
+                for (int i = 0; i < kk; ++i) w[i] = w[i] / allwt;                                    // :312-314
+            }
+            // ---- buildCellPartList (FoamYade.C:261-290), dense accumulate in (particle, slot) order
+            for (int c : touchList) { touched[c] = 0; }
+            touchList.clear();
+            for (int p = lo; p < hi; ++p) {
+                if (a->found[p] != 1) continue;
+                const double* r = a->records + 10 * (size_t)p;
+                const double dia = 2 * r[9];                                                          // :219
+                const double pVol = M_PI * std::pow(dia, 3.0) / 6.0;                                  // FoamYade.H:36
+                const V3 vel{r[3], r[4], r[5]};
+                const int kk = std::min(a->k[p], MAXK);
+                for (int i = 0; i < kk; ++i) {
+                    const int c = a->ids[(size_t)p * MAXK + i]; const double weight = a->w[(size_t)p * MAXK + i];
+                    const V3 uc = (weight * vel) * pVol;                                              // :272 / :279 (same value)
+                    if (!touched[c]) { touched[c] = 1; touchList.push_back(c); pVolAcc[c] = pVol * weight; st(uPAcc.data(), c, uc); }
+                    else { pVolAcc[c] += (pVol * weight); st(uPAcc.data(), c, ld(uPAcc.data(), c) + uc); }
+                }
+            }
+            // ---- setCellVolFraction (FoamYade.C:318-328): assignment on touched cells only
+            for (int c : touchList) {
+                const double pvolC = 1.0 - (pVolAcc[c] / a->V[c]);
+                a->alpha[c] = ((pvolC > 0.10) ? pvolC : 0.10);
+                st(a->uParticle, c, ld(uPAcc.data(), c) / a->V[c]);
+            }
+            // ---- calcHydroForce (FoamYade.C:331-344): hydroDragForce then archimedesForce, particle order
+            for (int p = lo; p < hi; ++p) {
+                if (a->found[p] != 1) continue;
+                const double* r = a->records + 10 * (size_t)p;
+                const double dia = 2 * r[9];
+                const double vol = M_PI * std::pow(dia, 3.0) / 6.0;
+                const V3 linVel{r[3], r[4], r[5]};
+                const int kk = std::min(a->k[p], MAXK);
+                const int* id = a->ids + (size_t)p * MAXK; const double* w = a->w + (size_t)p * MAXK;
+                V3 hydroForce{0, 0, 0};
+                {   // hydroDragForce FoamYade.C:354-389
+                    V3 uf{0, 0, 0}; double alpha_f = 0.0, pv = 0.0;
+                    for (int i = 0; i < kk; ++i) {
+                        uf = uf + (ld(a->U, id[i]) * w[i]);
+                        alpha_f += (a->alpha[id[i]] * w[i]);
+                        pv += (vol * w[i]);
+                    }
+                    const double alpha_p = 1 - alpha_f;
+                    const V3 urelvel = (uf - linVel);
+                    const double magUR = mag(urelvel);
+                    const double Re = small + ((magUR * dia) / nu);
+                    const double cd = Re < 1000 ? (24 / (Re)) * (1 + (0.15 * std::pow(Re, 0.687))) : 0.44;
+                    double coeff;
+                    if (alpha_f > 0.8) {
+                        coeff = 0.75 * cd * alpha_f * alpha_p * rhoF * magUR * std::pow(alpha_f, -2.65);
+                    } else {
+                        double cf1 = 150 * ((alpha_p * alpha_p) / alpha_f) * ((nu * rhoF) / (dia * dia));
+                        double cf2 = 1.75 * alpha_p * rhoF * (1 / dia) * magUR;
+                        coeff = cf1 + cf2;
+                    }
+                    const V3 hf = (pv) * coeff * urelvel * (1 / (alpha_p));
+                    hydroForce = hydroForce + hf;
+                    for (int i = 0; i < kk; ++i) {
+                        a->uSourceDrag[id[i]] += (-coeff * w[i] * (1 / rhoF));
+                        st(a->uSource, id[i], ld(a->uSource, id[i]) + ((-coeff * w[i] * ld(a->uParticle, id[i])) / (rhoF)));
+                    }
+                }
+                {   // archimedesForce FoamYade.C:415-435
+                    V3 divt{0, 0, 0}, pg{0, 0, 0}; double pv = 0.0;
+                    for (int i = 0; i < kk; ++i) {
+                        pv += (vol * w[i]);
+                        divt = divt + (2.0 * nu * ld(a->divT, id[i]) * w[i] * rhoF);
+                        pg = pg + (ld(a->gradP, id[i]) * w[i]);
+                    }
+                    const V3 f = pv * (-pg + divt);
+                    hydroForce = hydroForce + f;
+                    for (int i = 0; i < kk; ++i) {
+                        const double ooCellVol = 1. / (a->V[id[i]] * rhoF);
+                        st(a->uSource, id[i], ld(a->uSource, id[i]) + (-f * w[i] * ooCellVol));
+                    }
+                }
+                double* F = a->force + 6 * (size_t)p;
+                F[0] = hydroForce.x; F[1] = hydroForce.y; F[2] = hydroForce.z;      // torque stays 0 (FoamYade.C:618)
+            }
+        } else {
+            // ---- point force: calcHydroForce -> stokesDragForce, then calcHydroTorque -> stokesDragTorque
+            for (int p = lo; p < hi; ++p) {                                           // FoamYade.C:437-444
+                if (a->found[p] != 1) continue;
+                const double* r = a->records + 10 * (size_t)p;
+                const int c = a->ids[(size_t)p * MAXK];
+                const double dia = 2 * r[9];
+                const V3 uFluid = ld(a->U, c);
+                const double coeff = 3 * M_PI * (dia)*nu * rhoF;
+                const double ooCellVol = 1. / (a->V[c] * rhoF);
+                const V3 hf = coeff * (uFluid - V3{r[3], r[4], r[5]});
+                st(a->uSource, c, ld(a->uSource, c) + (-1 * ooCellVol * hf));
+                double* F = a->force + 6 * (size_t)p; F[0] = hf.x; F[1] = hf.y; F[2] = hf.z;
+            }
+            for (int p = lo; p < hi; ++p) {                                           // FoamYade.C:446-453
+                if (a->found[p] != 1) continue;
+                const double* r = a->records + 10 * (size_t)p;
+                const int c = a->ids[(size_t)p * MAXK];
+                const double dia = 2 * r[9];
+                const double* G = a->vGrad + 9 * (size_t)c;                           // xx xy xz yx yy yz zx zy zz
+                const double s1 = G[7] - G[5], s2 = G[6] - G[2], s3 = G[3] - G[1];    // zy-yz, zx-xz, yx-xy
+                const V3 wfluid{s1, s2, s3};
+                const V3 T = M_PI * (std::pow(dia, 3)) * (wfluid - V3{r[6], r[7], r[8]}) * nu * rhoF;
+                double* F = a->force + 6 * (size_t)p; F[3] = T.x; F[4] = T.y; F[5] = T.z;
+            }
+        }
+    }
+}
+
+// FoamYade.C:556-566 setSourceZero / FoamYade.C:56-68 initFields (field part)
+void orc_set_source_zero(int Nc, int gaussian, double* uSourceDrag, double* alpha, double* uSource, double* uParticle) {
+    for (int c = 0; c < Nc; ++c) {
+        uSource[3 * (size_t)c] = uSource[3 * (size_t)c + 1] = uSource[3 * (size_t)c + 2] = 0.0;
+        if (gaussian) { alpha[c] = 1.0; uSourceDrag[c] = 0.0; uParticle[3 * (size_t)c] = uParticle[3 * (size_t)c + 1] = uParticle[3 * (size_t)c + 2] = 0.0; }
+    }
+}
+
+}  // extern "C"
