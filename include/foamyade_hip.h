@@ -1,0 +1,201 @@
+/* foamyade_hip.h -- C-ABI of libfoamyade_hip.so: the MI355X-native drop-in for the hot path of
+ * dpkn31/Yade-OpenFOAM-coupling (class Foam::FoamYade + the icoFoamYade / pimpleFoamYade loop bodies).
+ *
+ * Plain C: pointers and sizes only, no C++/torch types, int status codes, never throws.
+ * Every entry point names the reference interface it replaces (paths relative to /root/reference).
+ *
+ * Two objects:
+ *   fy_ctx     <->  Foam::FoamYade            FoamYade/FoamYade.H:57-161   (coupling engine, particle half)
+ *   fy_solver  <->  the solver executables    icoFoamYade/icoFoamYade.C:38-154, pimpleFoamYade/pimpleFoamYade.C:40-119
+ *                                             (+UcEqn.H, pEqn.H, CourantNo.H, continuityErrs.H, createFields.H)
+ *
+ * Memory layout at the boundary is OpenFOAM's: scalar = double, label = int, vector = 3 contiguous doubles
+ * (xyzxyz...), tensor = 9 contiguous doubles row-major xx xy xz yx yy yz zx zy zz (FoamYade.C:450,472-474).
+ * Particle records are the wire layout: 10 doubles [x y z vx vy vz wx wy wz radius] (FoamYade.C:190-219);
+ * force records 6 doubles [Fx Fy Fz Tx Ty Tz] (FoamYade.C:492-498).
+ */
+#ifndef FOAMYADE_HIP_H
+#define FOAMYADE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FY_ABI_VERSION 1
+
+/* ---- status codes ------------------------------------------------------------------------------------ */
+enum {
+    FY_OK = 0,
+    FY_ERR_INVALID = 1,     /* bad argument / call order */
+    FY_ERR_NO_DEVICE = 2,   /* no gfx950 device visible: the product NEVER falls back to a CPU path */
+    FY_ERR_HIP = 3,         /* a HIP runtime call failed; see fy_last_error() */
+    FY_ERR_TRANSPORT = 4,   /* a transport callback returned non-zero */
+    FY_ERR_UNSUPPORTED = 5,
+    FY_ERR_NOT_CONVERGED = 6
+};
+const char* fy_last_error(void);      /* thread-local text of the last failure */
+int fy_abi_version(void);
+int fy_device_count(void);            /* number of visible HIP devices (0 on a CPU-only host) */
+
+/* ---- where a caller-owned array lives ------------------------------------------------------------------ */
+enum { FY_MEM_HOST = 0, FY_MEM_DEVICE = 1 };
+
+/* ---- mesh: what FoamYade reads from fvMesh (mesh.C(), mesh.V(), mesh.points(); FoamYade.H:121, FoamYade.C:69,86,304) */
+typedef struct fy_mesh_desc {
+    int32_t n_cells;
+    const double* centres;      /* [n_cells][3]  mesh.C(), HOST memory (read once at create) */
+    const double* volumes;      /* [n_cells]     mesh.V(), HOST memory */
+    double bbox_min[3];         /* bounding box of mesh.points() (FoamYade.C:82-94) */
+    double bbox_max[3];
+    /* Uniform hex block in blockMesh order (cell = i + nx*(j + ny*k)).  Required for point-force mode, where it
+     * stands in for polyMesh::findCell (FoamYade.C:251), and for fy_solver.  Set nx = 0 for "unstructured". */
+    int32_t nx, ny, nz;
+    double dx;
+    double origin[3];
+} fy_mesh_desc;
+
+/* ---- the twelve constructor arguments of Foam::FoamYade (FoamYade.H:106-117), minus mesh and the bool ---- */
+typedef struct fy_field_ptrs {
+    int32_t location;           /* FY_MEM_HOST: staged over PCIe each step; FY_MEM_DEVICE: used in place */
+    const double* U;            /* [n][3] */
+    const double* gradP;        /* [n][3] */
+    const double* vGrad;        /* [n][9] */
+    const double* divT;         /* [n][3] */
+    const double* ddtU;         /* [n][3]  (only consumer is the unreachable addedMassForce, FoamYade.C:392-413) */
+    double g[3];                /* uniformDimensionedVectorField g */
+    double* uSourceDrag;        /* [n]     read-write */
+    double* alpha;              /* [n]     read-write */
+    double* uSource;            /* [n][3]  read-write */
+    double* uParticle;          /* [n][3]  read-write */
+} fy_field_ptrs;
+
+/* ---- transport: the MPI calls FoamYade.C makes, as callbacks, so that this library does not link an MPI -- */
+/* datatype / op selectors for the callbacks */
+enum { FY_T_INT = 0, FY_T_DOUBLE = 1 };
+enum { FY_OP_MAX = 0, FY_OP_SUM = 1 };
+/* All callbacks return 0 on success.  "world" = MPI_COMM_WORLD (Yade ranks first, README.md:29, FoamYade.C:28-43),
+ * "local" = PstreamGlobals::MPI_COMM_FOAM (FoamYade.C:21-22). */
+typedef struct fy_transport {
+    void* user;
+    int32_t world_rank, world_size;     /* FoamYade.C:24-25 */
+    int32_t local_rank, local_size;     /* FoamYade.C:21-22 */
+    int (*send)(void* user, const void* buf, int count, int dtype, int dest, int tag);              /* MPI_Send / Isend+Wait */
+    int (*recv)(void* user, void* buf, int count, int dtype, int src, int tag);                     /* MPI_Recv */
+    int (*bcast_world)(void* user, void* buf, int count, int dtype, int root);                      /* MPI_Bcast(WORLD) */
+    int (*bcast_local)(void* user, void* buf, int count, int dtype, int root);                      /* MPI_Bcast(MPI_COMM_FOAM) */
+    int (*allreduce_world)(void* user, const void* in, void* out, int count, int dtype, int op);    /* MPI_Allreduce(WORLD) */
+} fy_transport;
+
+typedef struct fy_ctx fy_ctx;
+
+/* Foam::FoamYade::FoamYade(...) FoamYade.H:106-122 -> getRankSize() FoamYade.C:18-53:
+ * rank discovery, k-d tree build over mesh.C() (meshTree.C:9-37), bbox send to every Yade rank in parallel-Yade
+ * mode (FoamYade.C:77-111), initFields (FoamYade.C:56-73).
+ * transport == NULL selects "direct" mode: no wire traffic; particles are handed over with
+ * fy_set_particles_* and forces read back with fy_get_forces_* (used by fy_solver, the tests and bench.py). */
+int fy_create(const fy_mesh_desc* mesh, const fy_field_ptrs* fields, int gaussian_interp,
+              const fy_transport* transport, int device_ordinal, fy_ctx** out);
+/* FoamYade::setScalarProperties FoamYade.C:9-11 */
+int fy_set_scalar_properties(fy_ctx*, double rhoP, double rhoF, double nu);
+/* FoamYade::setParticleAction FoamYade.C:605-632 (blocking).  On return alpha, uParticle, uSourceDrag, uSource hold
+ * this step's values and (with a transport) found flags / forces / dt have been exchanged with Yade. */
+int fy_set_particle_action(fy_ctx*, double dt);
+/* FoamYade::setSourceZero FoamYade.C:556-566 */
+int fy_set_source_zero(fy_ctx*);
+/* FoamYade::~FoamYade FoamYade.H:160 */
+int fy_destroy(fy_ctx*);
+
+/* ---- direct mode (no Yade peer): one call per "Yade proc" batch, batches are processed in index order exactly
+ *      like the loop over inCommProcs (FoamYade.C:612-628) ------------------------------------------------- */
+int fy_set_num_batches(fy_ctx*, int nbatch);
+int fy_set_particles_host(fy_ctx*, int batch, const double* records, int64_t n);     /* copies (H2D) */
+int fy_set_particles_device(fy_ctx*, int batch, const double* d_records, int64_t n); /* borrows the device pointer */
+int fy_get_forces_host(fy_ctx*, int batch, double* out_forces /* [n][6] */);
+int fy_get_found_host(fy_ctx*, int batch, int32_t* out_found /* [n], 1 / -1 as foundBuff FoamYade.C:141,222 */);
+const double* fy_forces_device(fy_ctx*, int batch);
+/* per-particle stencil of the last step, for parity tests: k[n], ids[n][16] (-1 padded, ascending d2, ids[0] =
+ * inCell FoamYade.C:208), weights[n][16] (FoamYade.C:293-316), chain_len[n] (>12 => reference behaviour is undefined,
+ * meshTree.H:66-68; we append and never evict) */
+int fy_get_stencils_host(fy_ctx*, int batch, int32_t* k, int32_t* ids, double* weights, int32_t* chain_len);
+/* k-d tree in preorder (node, left subtree, right subtree): cell ids, for parity with meshTree.C:19-37 */
+int fy_get_tree_preorder(fy_ctx*, int32_t* out_ids /* [n_cells] */);
+/* read / write any of the ctx's cell fields by name ("alpha","uParticle","uSourceDrag","uSource","U","gradP","vGrad","divT") */
+int fy_read_field_host(fy_ctx*, const char* name, double* out);
+int fy_write_field_host(fy_ctx*, const char* name, const double* in);
+double fy_yade_dt(fy_ctx*);           /* yadeDT received in exchangeDT (FoamYade.C:537-553) */
+double fy_interp_range(fy_ctx*);      /* interpRange = 4*cbrt(V[0]) (FoamYade.C:69) */
+
+/* per-phase device timings of the last fy_set_particle_action, milliseconds (HIP events on the ctx stream) */
+typedef struct fy_particle_timings {
+    double h2d, bin, locate_deposit, finalize, force, d2h, total;
+    int64_t n_particles, n_pairs;     /* n_pairs = sum of k */
+} fy_particle_timings;
+int fy_get_particle_timings(fy_ctx*, fy_particle_timings* out);
+int fy_enable_timing(fy_ctx*, int on);
+
+/* ======================================================================================================== */
+/* fy_solver: the time-loop bodies of icoFoamYade (PISO, point force) and pimpleFoamYade (PIMPLE, 4-way).  */
+/* ======================================================================================================== */
+enum { FY_SOLVER_ICO = 0, FY_SOLVER_PIMPLE = 1 };
+/* boundary patches of the block, in this order */
+enum { FY_XMIN = 0, FY_XMAX = 1, FY_YMIN = 2, FY_YMAX = 3, FY_ZMIN = 4, FY_ZMAX = 5 };
+enum { FY_BC_U_FIXED_VALUE = 0, FY_BC_U_ZERO_GRADIENT = 1 };
+enum { FY_BC_P_ZERO_GRADIENT = 0, FY_BC_P_FIXED_VALUE = 1, FY_BC_P_FIXED_FLUX = 2 };
+enum { FY_PSOLVER_PCG_JACOBI = 0, FY_PSOLVER_PCG_MG = 1 };
+
+typedef struct fy_case_desc {
+    int32_t solver;                 /* FY_SOLVER_ICO | FY_SOLVER_PIMPLE */
+    int32_t nx, ny, nz;
+    double dx;
+    double origin[3];
+    double dt;                      /* controlDict deltaT */
+    double nu;                      /* transportProperties nu (icoFoamYade/createFields.H:29-33) */
+    double rho_fluid, rho_particle; /* fluidDensity|rho.<phase>, partDensity */
+    double g[3];                    /* constant/g */
+    int32_t u_bc[6];  double u_value[6][3];
+    int32_t p_bc[6];  double p_value[6];
+    /* fvSolution PISO / PIMPLE dictionaries (icoFoamYade/createFields.H:166-169, pimpleFoamYade/createFields.H:83-86) */
+    int32_t n_outer_correctors;     /* PIMPLE nOuterCorrectors (1 for PISO) */
+    int32_t n_correctors;           /* nCorrectors */
+    int32_t n_non_orth_correctors;  /* nNonOrthogonalCorrectors */
+    int32_t momentum_predictor;
+    int32_t p_ref_cell; double p_ref_value;
+    /* linear solver controls: p, pFinal, U */
+    int32_t p_solver;               /* FY_PSOLVER_* */
+    double p_tol, p_rel_tol, p_final_tol, p_final_rel_tol; int32_t p_max_iter;
+    double u_tol, u_rel_tol; int32_t u_max_iter;
+} fy_case_desc;
+
+typedef struct fy_solver fy_solver;
+
+typedef struct fy_step_stats {
+    double courant_mean, courant_max;                   /* CourantNo.H:32-49 */
+    double cont_err_sum_local, cont_err_global, cont_err_cumulative;   /* continuityErrs.H:32-46 */
+    int32_t p_iters_total, p_solves, u_iters_total;
+    double p_initial_residual, p_final_residual;
+    double ms_particle, ms_momentum, ms_pressure, ms_other, ms_total;
+} fy_step_stats;
+
+void fy_case_defaults(fy_case_desc* c, int solver);
+int fy_solver_create(const fy_case_desc* c, const fy_transport* transport, int device_ordinal, fy_solver** out);
+fy_ctx* fy_solver_coupling(fy_solver*);                 /* the yadeCoupling object (icoFoamYade.C:54, pimpleFoamYade.C:54) */
+int fy_solver_step(fy_solver*);                         /* one pass of the while(runTime.loop()) body */
+int fy_solver_get_stats(fy_solver*, fy_step_stats* out);
+/* names: "U" [n][3], "p" [n], "phi_x" [(nx+1)*ny*nz], "phi_y", "phi_z", plus every fy_ctx field name */
+int fy_solver_read_field_host(fy_solver*, const char* name, double* out);
+int fy_solver_write_field_host(fy_solver*, const char* name, const double* in);
+int fy_solver_destroy(fy_solver*);
+
+/* ---- kernel-level entry points used by the roofline bench and the operator parity tests ------------------ */
+/* y = A x for the symmetric 7-point pressure matrix (diag, ux, uy, uz) currently held by the solver; x,y host arrays */
+int fy_solver_apply_p_matrix_host(fy_solver*, const double* x, double* y);
+/* time `reps` launches of the pEqn Laplacian apply (the roofline kernel) with HIP events on the solver stream; returns avg ms */
+int fy_solver_time_p_apply(fy_solver*, int reps, double* avg_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FOAMYADE_HIP_H */

@@ -1,0 +1,54 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads, exports every symbol include/foamyade_hip.h declares,
+fails loudly without a GPU, and the product never reaches into oracle/."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+
+def declared_functions():
+    src = open(os.path.join(ROOT, "include", "foamyade_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(fy_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol(product):
+    product.build()
+    L = ctypes.CDLL(product.LIB_PATH)
+    names = declared_functions()
+    assert len(names) >= 30
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, f"declared in include/foamyade_hip.h but not exported: {missing}"
+    assert L.fy_abi_version() == 1
+
+
+def test_no_cpu_fallback_without_device(product):
+    """on a host without a HIP device fy_create must fail with FY_ERR_NO_DEVICE, not compute on the CPU."""
+    L = product.lib()
+    if L.fy_device_count() > 0:
+        pytest.skip("a GPU is visible here")
+    import numpy as np
+    m = product.BlockMesh(4, 4, 4, 0.1)
+    z3 = np.zeros((m.n_cells, 3)); z1 = np.zeros(m.n_cells); z9 = np.zeros((m.n_cells, 9))
+    with pytest.raises(product.FoamYadeError) as e:
+        product.FoamYade(m, z3, z3.copy(), z9, z3.copy(), z3.copy(), (0, 0, 0), z1, z1.copy(), z3.copy(), z3.copy(), True)
+    assert "error 2" in str(e.value)
+
+
+def test_product_never_touches_the_oracle():
+    pkg = os.path.join(ROOT, "yade-openfoam-coupling_amd")
+    hits = subprocess.run(["grep", "-rIl", "-E", r"oracle/|liboracle|import oracle|from oracle", pkg, os.path.join(ROOT, "include")],
+                          capture_output=True, text=True).stdout.split()
+    hits = [h for h in hits if "/build/" not in h and "/lib/" not in h]
+    # comments that merely say "never includes anything from oracle/" are fine; code references are not
+    bad = []
+    for h in hits:
+        for line in open(h, errors="ignore"):
+            s = line.strip()
+            if re.search(r"oracle", s) and not (s.startswith("//") or s.startswith("#") or s.startswith("*") or s.startswith('"""') or "never" in s):
+                bad.append((h, s))
+    assert not bad, bad

@@ -1,0 +1,286 @@
+"""Python mirror of the reference's interface for the hot path, over the C-ABI of libfoamyade_hip.so.
+
+The product is the shared library (HIP kernels + C++ host code, `csrc/`, ABI in `include/foamyade_hip.h`); this module
+is only the ctypes stub a Python caller (tests, bench.py) needs.  Names follow the reference:
+
+    FoamYade(mesh, U, gradP, vGrad, divT, ddtU, g, uSourceDrag, alpha, uSource, uParticle, gaussianInterp)
+        .setScalarProperties(rhoP, rhoF, nu)   FoamYade.C:9-11
+        .setParticleAction(dt)                 FoamYade.C:605-632
+        .setSourceZero()                       FoamYade.C:556-566
+
+There is no CPU fallback: if the library is missing or no HIP device is visible, construction raises.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(_HERE)
+LIB_PATH = os.path.join(_HERE, "lib", "libfoamyade_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+MAXK = 16
+
+FY_OK = 0
+FY_ERR_NO_DEVICE = 2
+FY_MEM_HOST, FY_MEM_DEVICE = 0, 1
+FY_T_INT, FY_T_DOUBLE = 0, 1
+FY_OP_MAX, FY_OP_SUM = 0, 1
+FY_SOLVER_ICO, FY_SOLVER_PIMPLE = 0, 1
+FY_BC_U_FIXED_VALUE, FY_BC_U_ZERO_GRADIENT = 0, 1
+FY_BC_P_ZERO_GRADIENT, FY_BC_P_FIXED_VALUE, FY_BC_P_FIXED_FLUX = 0, 1, 2
+FY_PSOLVER_PCG_JACOBI, FY_PSOLVER_PCG_MG = 0, 1
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+
+
+class FoamYadeError(RuntimeError):
+    pass
+
+
+def build(verbose=False):
+    """compile libfoamyade_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    out = None if verbose else subprocess.DEVNULL
+    subprocess.run(["make", "-C", CSRC, "all"], check=True, stdout=out)
+    return LIB_PATH
+
+
+class MeshDesc(C.Structure):
+    _fields_ = [("n_cells", C.c_int32), ("centres", _dp), ("volumes", _dp), ("bbox_min", C.c_double * 3),
+                ("bbox_max", C.c_double * 3), ("nx", C.c_int32), ("ny", C.c_int32), ("nz", C.c_int32), ("dx", C.c_double),
+                ("origin", C.c_double * 3)]
+
+
+class FieldPtrs(C.Structure):
+    _fields_ = [("location", C.c_int32), ("U", _dp), ("gradP", _dp), ("vGrad", _dp), ("divT", _dp), ("ddtU", _dp),
+                ("g", C.c_double * 3), ("uSourceDrag", _dp), ("alpha", _dp), ("uSource", _dp), ("uParticle", _dp)]
+
+
+_SEND = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int)
+_RECV = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int)
+_BCAST = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int)
+_ALLRED = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int)
+
+
+class Transport(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("world_rank", C.c_int32), ("world_size", C.c_int32), ("local_rank", C.c_int32),
+                ("local_size", C.c_int32), ("send", _SEND), ("recv", _RECV), ("bcast_world", _BCAST),
+                ("bcast_local", _BCAST), ("allreduce_world", _ALLRED)]
+
+
+class ParticleTimings(C.Structure):
+    _fields_ = [("h2d", C.c_double), ("bin", C.c_double), ("locate_deposit", C.c_double), ("finalize", C.c_double),
+                ("force", C.c_double), ("d2h", C.c_double), ("total", C.c_double), ("n_particles", C.c_int64),
+                ("n_pairs", C.c_int64)]
+
+
+class CaseDesc(C.Structure):
+    _fields_ = [("solver", C.c_int32), ("nx", C.c_int32), ("ny", C.c_int32), ("nz", C.c_int32), ("dx", C.c_double),
+                ("origin", C.c_double * 3), ("dt", C.c_double), ("nu", C.c_double), ("rho_fluid", C.c_double),
+                ("rho_particle", C.c_double), ("g", C.c_double * 3),
+                ("u_bc", C.c_int32 * 6), ("u_value", (C.c_double * 3) * 6),
+                ("p_bc", C.c_int32 * 6), ("p_value", C.c_double * 6),
+                ("n_outer_correctors", C.c_int32), ("n_correctors", C.c_int32), ("n_non_orth_correctors", C.c_int32),
+                ("momentum_predictor", C.c_int32), ("p_ref_cell", C.c_int32), ("p_ref_value", C.c_double),
+                ("p_solver", C.c_int32), ("p_tol", C.c_double), ("p_rel_tol", C.c_double), ("p_final_tol", C.c_double),
+                ("p_final_rel_tol", C.c_double), ("p_max_iter", C.c_int32),
+                ("u_tol", C.c_double), ("u_rel_tol", C.c_double), ("u_max_iter", C.c_int32)]
+
+
+class StepStats(C.Structure):
+    _fields_ = [("courant_mean", C.c_double), ("courant_max", C.c_double), ("cont_err_sum_local", C.c_double),
+                ("cont_err_global", C.c_double), ("cont_err_cumulative", C.c_double),
+                ("p_iters_total", C.c_int32), ("p_solves", C.c_int32), ("u_iters_total", C.c_int32),
+                ("p_initial_residual", C.c_double), ("p_final_residual", C.c_double),
+                ("ms_particle", C.c_double), ("ms_momentum", C.c_double), ("ms_pressure", C.c_double),
+                ("ms_other", C.c_double), ("ms_total", C.c_double)]
+
+
+_lib = None
+
+
+def lib():
+    """load the product library; raises if it has not been built (no silent fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FoamYadeError(f"{LIB_PATH} is missing: run __graft_entry__.build() (there is no CPU fallback)")
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.fy_last_error.restype = C.c_char_p
+    L.fy_create.argtypes = [C.POINTER(MeshDesc), C.POINTER(FieldPtrs), C.c_int, C.POINTER(Transport), C.c_int, C.POINTER(vp)]
+    L.fy_set_scalar_properties.argtypes = [vp, C.c_double, C.c_double, C.c_double]
+    L.fy_set_particle_action.argtypes = [vp, C.c_double]
+    L.fy_set_source_zero.argtypes = [vp]
+    L.fy_destroy.argtypes = [vp]
+    L.fy_set_num_batches.argtypes = [vp, C.c_int]
+    L.fy_set_particles_host.argtypes = [vp, C.c_int, _dp, C.c_int64]
+    L.fy_set_particles_device.argtypes = [vp, C.c_int, vp, C.c_int64]
+    L.fy_get_forces_host.argtypes = [vp, C.c_int, _dp]
+    L.fy_get_found_host.argtypes = [vp, C.c_int, _ip]
+    L.fy_forces_device.argtypes = [vp, C.c_int]
+    L.fy_forces_device.restype = vp
+    L.fy_get_stencils_host.argtypes = [vp, C.c_int, _ip, _ip, _dp, _ip]
+    L.fy_get_tree_preorder.argtypes = [vp, _ip]
+    L.fy_read_field_host.argtypes = [vp, C.c_char_p, _dp]
+    L.fy_write_field_host.argtypes = [vp, C.c_char_p, _dp]
+    L.fy_yade_dt.argtypes = [vp]
+    L.fy_yade_dt.restype = C.c_double
+    L.fy_interp_range.argtypes = [vp]
+    L.fy_interp_range.restype = C.c_double
+    L.fy_get_particle_timings.argtypes = [vp, C.POINTER(ParticleTimings)]
+    L.fy_enable_timing.argtypes = [vp, C.c_int]
+    L.fy_case_defaults.argtypes = [C.POINTER(CaseDesc), C.c_int]
+    L.fy_case_defaults.restype = None
+    L.fy_solver_create.argtypes = [C.POINTER(CaseDesc), C.POINTER(Transport), C.c_int, C.POINTER(vp)]
+    L.fy_solver_coupling.argtypes = [vp]
+    L.fy_solver_coupling.restype = vp
+    L.fy_solver_step.argtypes = [vp]
+    L.fy_solver_get_stats.argtypes = [vp, C.POINTER(StepStats)]
+    L.fy_solver_read_field_host.argtypes = [vp, C.c_char_p, _dp]
+    L.fy_solver_write_field_host.argtypes = [vp, C.c_char_p, _dp]
+    L.fy_solver_destroy.argtypes = [vp]
+    L.fy_solver_apply_p_matrix_host.argtypes = [vp, _dp, _dp]
+    L.fy_solver_time_p_apply.argtypes = [vp, C.c_int, _dp]
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != FY_OK:
+        raise FoamYadeError(f"libfoamyade_hip error {rc}: {lib().fy_last_error().decode()}")
+
+
+def _d(a):
+    assert a.dtype == np.float64 and a.flags.c_contiguous, "need C-contiguous float64"
+    return a.ctypes.data_as(_dp)
+
+
+def _i(a):
+    assert a.dtype == np.int32 and a.flags.c_contiguous
+    return a.ctypes.data_as(_ip)
+
+
+class BlockMesh:
+    """what FoamYade reads from fvMesh, for a uniform hex block in blockMesh order (cell = i + nx*(j + ny*k))."""
+
+    def __init__(self, nx, ny, nz, dx, origin=(0.0, 0.0, 0.0)):
+        self.nx, self.ny, self.nz, self.dx = int(nx), int(ny), int(nz), float(dx)
+        self.origin = tuple(float(o) for o in origin)
+        self.n_cells = self.nx * self.ny * self.nz
+        i = np.arange(nx, dtype=np.float64); j = np.arange(ny, dtype=np.float64); k = np.arange(nz, dtype=np.float64)
+        Cc = np.empty((nz, ny, nx, 3))
+        Cc[..., 0] = (self.origin[0] + (i + 0.5) * self.dx)[None, None, :]
+        Cc[..., 1] = (self.origin[1] + (j + 0.5) * self.dx)[None, :, None]
+        Cc[..., 2] = (self.origin[2] + (k + 0.5) * self.dx)[:, None, None]
+        self.C = np.ascontiguousarray(Cc.reshape(-1, 3))                       # mesh.C()
+        self.V = np.full(self.n_cells, self.dx * self.dx * self.dx)            # mesh.V()
+        self.bbox_min = np.array(self.origin)
+        self.bbox_max = np.array([self.origin[0] + nx * self.dx, self.origin[1] + ny * self.dx, self.origin[2] + nz * self.dx])
+
+    def desc(self):
+        m = MeshDesc()
+        m.n_cells = self.n_cells
+        m.centres, m.volumes = _d(self.C), _d(self.V)
+        for q in range(3):
+            m.bbox_min[q], m.bbox_max[q], m.origin[q] = self.bbox_min[q], self.bbox_max[q], self.origin[q]
+        m.nx, m.ny, m.nz, m.dx = self.nx, self.ny, self.nz, self.dx
+        return m
+
+
+class FoamYade:
+    """Foam::FoamYade (FoamYade.H:57-161) over the C-ABI.  Field arguments are numpy arrays (host; staged per step) that
+    stay owned by the caller, exactly like the reference's field references."""
+
+    def __init__(self, mesh, U, gradP, vGrad, divT, ddtU, g, uSourceDrag, alpha, uSource, uParticle, gaussianInterp,
+                 transport=None, device=0):
+        L = lib()
+        self._keep = [mesh, U, gradP, vGrad, divT, ddtU, uSourceDrag, alpha, uSource, uParticle, transport]
+        f = FieldPtrs()
+        f.location = FY_MEM_HOST
+        f.U, f.gradP, f.vGrad, f.divT = _d(U), _d(gradP), _d(vGrad), _d(divT)
+        f.ddtU = _d(ddtU) if ddtU is not None else None
+        for q in range(3):
+            f.g[q] = float(g[q])
+        f.uSourceDrag, f.alpha, f.uSource, f.uParticle = _d(uSourceDrag), _d(alpha), _d(uSource), _d(uParticle)
+        self._h = C.c_void_p()
+        self.mesh = mesh
+        self.gaussian = bool(gaussianInterp)
+        md = mesh.desc()
+        _check(L.fy_create(C.byref(md), C.byref(f), int(self.gaussian), C.byref(transport) if transport is not None else None,
+                           int(device), C.byref(self._h)))
+        self._batch_n = []
+
+    # ---- the reference's public methods
+    def setScalarProperties(self, rhoP, rhoF, nu):
+        _check(lib().fy_set_scalar_properties(self._h, float(rhoP), float(rhoF), float(nu)))
+
+    def setParticleAction(self, dt):
+        _check(lib().fy_set_particle_action(self._h, float(dt)))
+
+    def setSourceZero(self):
+        _check(lib().fy_set_source_zero(self._h))
+
+    # ---- direct mode (no Yade peer)
+    def setParticles(self, batches):
+        """batches: list of (n,10) float64 record arrays, one per Yade proc, processed in order."""
+        L = lib()
+        _check(L.fy_set_num_batches(self._h, len(batches)))
+        self._batch_n = []
+        for b, rec in enumerate(batches):
+            rec = np.ascontiguousarray(rec, dtype=np.float64).reshape(-1, 10)
+            _check(L.fy_set_particles_host(self._h, b, _d(rec), rec.shape[0]))
+            self._batch_n.append(rec.shape[0])
+
+    def forces(self, batch=0):
+        n = self._batch_n[batch]
+        out = np.zeros((n, 6))
+        _check(lib().fy_get_forces_host(self._h, batch, _d(out)))
+        return out
+
+    def found(self, batch=0):
+        n = self._batch_n[batch]
+        out = np.zeros(n, dtype=np.int32)
+        _check(lib().fy_get_found_host(self._h, batch, _i(out)))
+        return out
+
+    def stencils(self, batch=0):
+        n = self._batch_n[batch]
+        k = np.zeros(n, np.int32); ids = np.full((n, MAXK), -1, np.int32); w = np.zeros((n, MAXK)); chain = np.zeros(n, np.int32)
+        _check(lib().fy_get_stencils_host(self._h, batch, _i(k), _i(ids), _d(w), _i(chain)))
+        return k, ids, w, chain
+
+    def tree_preorder(self):
+        out = np.zeros(self.mesh.n_cells, dtype=np.int32)
+        _check(lib().fy_get_tree_preorder(self._h, _i(out)))
+        return out
+
+    def enable_timing(self, on=True):
+        _check(lib().fy_enable_timing(self._h, int(on)))
+
+    def timings(self):
+        t = ParticleTimings()
+        _check(lib().fy_get_particle_timings(self._h, C.byref(t)))
+        return {n: getattr(t, n) for n, _ in ParticleTimings._fields_}
+
+    @property
+    def yadeDT(self):
+        return lib().fy_yade_dt(self._h)
+
+    @property
+    def interpRange(self):
+        return lib().fy_interp_range(self._h)
+
+    def close(self):
+        if self._h:
+            lib().fy_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

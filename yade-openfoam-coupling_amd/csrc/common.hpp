@@ -1,0 +1,100 @@
+// Shared host-side helpers for libfoamyade_hip.so (product code; never includes anything from oracle/).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/foamyade_hip.h"
+
+namespace fy {
+
+// thread-local last-error text behind fy_last_error()
+std::string& last_error();
+int fail(int code, const char* fmt, ...);
+
+#define FY_HIP(expr)                                                                                      \
+    do {                                                                                                  \
+        hipError_t _e = (expr);                                                                           \
+        if (_e != hipSuccess)                                                                             \
+            return ::fy::fail(FY_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+#define FY_TRY(expr)                 \
+    do {                             \
+        int _rc = (expr);            \
+        if (_rc != FY_OK) return _rc; \
+    } while (0)
+
+// Owning device allocation.  All product state lives in HBM; there is no host fallback.
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    // grow-only (keeps the allocation across steps; sized for the largest batch seen)
+    int reserve(size_t count) {
+        if (count <= n) return FY_OK;
+        release();
+        size_t cap = count + count / 8 + 64;
+        hipError_t e = hipMalloc((void**)&p, cap * sizeof(T));
+        if (e != hipSuccess) {
+            p = nullptr;
+            return fail(FY_ERR_HIP, "hipMalloc(%zu bytes) failed: %s", cap * sizeof(T), hipGetErrorString(e));
+        }
+        n = cap;
+        return FY_OK;
+    }
+    int alloc_exact(size_t count) {
+        release();
+        if (count == 0) return FY_OK;
+        hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
+        if (e != hipSuccess) {
+            p = nullptr;
+            return fail(FY_ERR_HIP, "hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
+        }
+        n = count;
+        return FY_OK;
+    }
+};
+
+struct EventTimer {
+    hipEvent_t a = nullptr, b = nullptr;
+    bool armed = false;
+    int init() {
+        FY_HIP(hipEventCreate(&a));
+        FY_HIP(hipEventCreate(&b));
+        return FY_OK;
+    }
+    void destroy() {
+        if (a) (void)hipEventDestroy(a);
+        if (b) (void)hipEventDestroy(b);
+        a = b = nullptr;
+    }
+    void start(hipStream_t s) { (void)hipEventRecord(a, s); armed = true; }
+    void stop(hipStream_t s) { (void)hipEventRecord(b, s); }
+    double ms() {
+        if (!armed) return 0.0;
+        float t = 0.f;
+        (void)hipEventSynchronize(b);
+        (void)hipEventElapsedTime(&t, a, b);
+        armed = false;
+        return (double)t;
+    }
+};
+
+inline unsigned div_up(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
+
+}  // namespace fy

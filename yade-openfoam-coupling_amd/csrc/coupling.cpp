@@ -1,0 +1,548 @@
+// fy_ctx: MI355X-native replacement of Foam::FoamYade (FoamYade/FoamYade.{H,C}).  Host orchestration + wire protocol;
+// all arithmetic runs in the HIP kernels of particle_kernels.hip.  There is no CPU compute path: without a HIP
+// device fy_create fails with FY_ERR_NO_DEVICE.
+#include "coupling.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <thread>
+
+namespace fy {
+
+std::string& last_error() {
+    static thread_local std::string e;
+    return e;
+}
+
+int fail(int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    last_error() = buf;
+    return code;
+}
+
+// wire tags, FoamYade.H:60-66
+static const int TAG_SZ_BUFF = 1003, TAG_GRID_BBOX = 1001, TAG_YADE_DATA = 1002, TAG_FORCE = 1005, TAG_SEARCH_RES = 1004,
+                 TAG_FLUID_DT = 1050, TAG_YADE_DT = 1060;
+
+#define FY_TR(expr)                                                                             \
+    do {                                                                                        \
+        if ((expr) != 0) return fail(FY_ERR_TRANSPORT, "transport call failed: %s", #expr);     \
+    } while (0)
+
+int Coupling::create(const fy_mesh_desc* m, const fy_field_ptrs* f, int gaussian_interp, const fy_transport* tr, int device_ordinal) {
+    if (!m || !f || m->n_cells <= 0 || !m->centres || !m->volumes) return fail(FY_ERR_INVALID, "fy_create: bad mesh/fields");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(FY_ERR_NO_DEVICE, "no HIP device visible: libfoamyade_hip has no CPU path");
+    if (device_ordinal < 0 || device_ordinal >= ndev) return fail(FY_ERR_INVALID, "device ordinal %d out of range (%d devices)", device_ordinal, ndev);
+    device = device_ordinal;
+    FY_HIP(hipSetDevice(device));
+    FY_HIP(hipStreamCreate(&stream));
+    owns_stream = true;
+    mesh = *m;
+    mesh.centres = nullptr; mesh.volumes = nullptr;   // not retained
+    n_cells = m->n_cells;
+    gaussian = gaussian_interp != 0;
+    structured = m->nx > 0;
+    if (!gaussian && !structured) return fail(FY_ERR_UNSUPPORTED, "point-force mode needs the structured block description (findCell stand-in)");
+    if (structured && (int64_t)m->nx * m->ny * m->nz != m->n_cells) return fail(FY_ERR_INVALID, "nx*ny*nz != n_cells");
+    if (tr) { transport = *tr; has_transport = true; }
+
+    // ---- getRankSize, FoamYade.C:18-53
+    if (has_transport) {
+        comm_sz_diff = std::abs(transport.world_size - transport.local_size);   // FoamYade.C:28
+        serial_yade = (comm_sz_diff == 1);                                      // FoamYade.C:31
+    } else {
+        comm_sz_diff = 0; serial_yade = true;
+    }
+
+    // ---- mshTree.build_tree(), FoamYade.C:33 (always, also in point-force mode: quirk Q6 kept for get_tree parity)
+    {
+        std::vector<KdNode> nodes;
+        unsigned hw = std::thread::hardware_concurrency();
+        build_kdtree_preorder(m->centres, n_cells, nodes, (int)std::min(hw ? hw : 1u, 8u));
+        tree_levels = kdtree_levels(n_cells);
+        FY_TRY(d_tree.alloc_exact(nodes.size()));
+        FY_HIP(hipMemcpyAsync(d_tree.p, nodes.data(), nodes.size() * sizeof(KdNode), hipMemcpyHostToDevice, stream));
+        FY_HIP(hipStreamSynchronize(stream));
+    }
+    FY_TRY(d_vol.alloc_exact(n_cells));
+    FY_HIP(hipMemcpyAsync(d_vol.p, m->volumes, (size_t)n_cells * sizeof(double), hipMemcpyHostToDevice, stream));
+    v0 = m->volumes[0];
+
+    // ---- fields
+    fields = *f;
+    fields_on_host = (f->location == FY_MEM_HOST);
+    if (fields_on_host) {
+        FY_TRY(own_U.alloc_exact(3 * (size_t)n_cells)); FY_TRY(own_gradP.alloc_exact(3 * (size_t)n_cells));
+        FY_TRY(own_vGrad.alloc_exact(9 * (size_t)n_cells)); FY_TRY(own_divT.alloc_exact(3 * (size_t)n_cells));
+        FY_TRY(own_uSourceDrag.alloc_exact(n_cells)); FY_TRY(own_alpha.alloc_exact(n_cells));
+        FY_TRY(own_uSource.alloc_exact(3 * (size_t)n_cells)); FY_TRY(own_uParticle.alloc_exact(3 * (size_t)n_cells));
+        dU = own_U.p; dGradP = own_gradP.p; dVGrad = own_vGrad.p; dDivT = own_divT.p;
+        dUSourceDrag = own_uSourceDrag.p; dAlpha = own_alpha.p; dUSource = own_uSource.p; dUParticle = own_uParticle.p;
+        // the caller's current content of the two fields point mode never touches must survive the round trip
+        FY_TRY(stage_mutable_in());
+    } else {
+        dU = f->U; dGradP = f->gradP; dVGrad = f->vGrad; dDivT = f->divT;
+        dUSourceDrag = f->uSourceDrag; dAlpha = f->alpha; dUSource = f->uSource; dUParticle = f->uParticle;
+    }
+    if (!dU || !dUSource || !dAlpha) return fail(FY_ERR_INVALID, "fy_create: U, uSource and alpha are required");
+    if (gaussian && (!dGradP || !dDivT || !dUSourceDrag || !dUParticle)) return fail(FY_ERR_INVALID, "gaussian mode needs gradP, divT, uSourceDrag, uParticle");
+    if (!gaussian && !dVGrad) return fail(FY_ERR_INVALID, "point-force mode needs vGrad");
+
+    if (gaussian) {
+        FY_TRY(d_pvol_acc.alloc_exact(n_cells)); FY_TRY(d_up_acc.alloc_exact(3 * (size_t)n_cells)); FY_TRY(d_touched.alloc_exact(n_cells));
+        FY_HIP(hipMemsetAsync(d_pvol_acc.p, 0, (size_t)n_cells * sizeof(double), stream));
+        FY_HIP(hipMemsetAsync(d_up_acc.p, 0, 3 * (size_t)n_cells * sizeof(double), stream));
+        FY_HIP(hipMemsetAsync(d_touched.p, 0, (size_t)n_cells, stream));
+    }
+
+    // ---- binning grid (locality only)
+    {
+        const double h0 = structured ? m->dx : std::cbrt(v0);
+        const double h = 2.0 * h0;
+        bins.ox = m->bbox_min[0]; bins.oy = m->bbox_min[1]; bins.oz = m->bbox_min[2];
+        bins.inv_h = 1.0 / h;
+        auto nb = [&](int a) { double e = (m->bbox_max[a] - m->bbox_min[a]) / h; int v = (int)std::ceil(e - 1e-9); return std::max(v, 1); };
+        bins.nbx = nb(0); bins.nby = nb(1); bins.nbz = nb(2);
+        bins.bx4 = (bins.nbx + 3) / 4; bins.by4 = (bins.nby + 3) / 4;
+        const int bz4 = (bins.nbz + 3) / 4;
+        const uint64_t nk = (uint64_t)bins.bx4 * bins.by4 * bz4 * 64ull;
+        if (nk > (1ull << 30)) return fail(FY_ERR_UNSUPPORTED, "bin grid too large");
+        bins.nkeys = (uint32_t)nk;
+        FY_TRY(d_hist.alloc_exact(bins.nkeys));
+        FY_TRY(d_tile_sums.alloc_exact((bins.nkeys + 2047u) / 2048u + 1));
+    }
+    for (auto& t : timers) FY_TRY(t.init());
+
+    // ---- parallel Yade: yadeProcs + sendMeshBbox, FoamYade.C:35-45,77-111
+    if (has_transport && !serial_yade) {
+        double bbox[6] = {m->bbox_min[0], m->bbox_min[1], m->bbox_min[2], m->bbox_max[0], m->bbox_max[1], m->bbox_max[2]};
+        for (int rnk = 0; rnk != comm_sz_diff; ++rnk) FY_TR(transport.send(transport.user, bbox, 6, FY_T_DOUBLE, rnk, TAG_GRID_BBOX));
+    }
+    if (!has_transport || serial_yade) set_num_batches(1);     // FoamYade.C:46-50: one YadeProc{yRank = 0}
+
+    FY_TRY(init_fields());
+    FY_HIP(hipStreamSynchronize(stream));
+    created = true;
+    return FY_OK;
+}
+
+// FoamYade::initFields FoamYade.C:56-73
+int Coupling::init_fields() {
+    FY_TRY(launch_set_source_zero(stream, n_cells, gaussian ? 1 : 0, dUSourceDrag, dAlpha, dUSource, dUParticle));
+    FY_TRY(launch_fill_f64(stream, dAlpha, n_cells, 1.0));                 // `alpha = 1.0` in both modes, FoamYade.C:68
+    interp_range = 4 * std::pow(v0, 1.0 / 3.0);                            // FoamYade.C:69
+    sigma_interp = interp_range * 0.42460;                                 // FoamYade.C:70
+    interp_range_cu = std::pow(interp_range, 3.0);                         // FoamYade.C:71
+    sigma_pi = 1.0 / (std::pow(2 * M_PI * sigma_interp * sigma_interp, 1.5));   // FoamYade.C:72
+    if (fields_on_host) FY_TRY(stage_mutable_out());
+    return FY_OK;
+}
+
+int Coupling::stage_mutable_in() {
+    const size_t n = (size_t)n_cells * sizeof(double);
+    if (fields.uSourceDrag) FY_HIP(hipMemcpyAsync(own_uSourceDrag.p, fields.uSourceDrag, n, hipMemcpyHostToDevice, stream));
+    if (fields.alpha) FY_HIP(hipMemcpyAsync(own_alpha.p, fields.alpha, n, hipMemcpyHostToDevice, stream));
+    if (fields.uSource) FY_HIP(hipMemcpyAsync(own_uSource.p, fields.uSource, 3 * n, hipMemcpyHostToDevice, stream));
+    if (fields.uParticle) FY_HIP(hipMemcpyAsync(own_uParticle.p, fields.uParticle, 3 * n, hipMemcpyHostToDevice, stream));
+    return FY_OK;
+}
+
+int Coupling::stage_mutable_out() {
+    const size_t n = (size_t)n_cells * sizeof(double);
+    if (fields.alpha) FY_HIP(hipMemcpyAsync(fields.alpha, own_alpha.p, n, hipMemcpyDeviceToHost, stream));
+    if (fields.uSource) FY_HIP(hipMemcpyAsync(fields.uSource, own_uSource.p, 3 * n, hipMemcpyDeviceToHost, stream));
+    if (gaussian) {
+        if (fields.uSourceDrag) FY_HIP(hipMemcpyAsync(fields.uSourceDrag, own_uSourceDrag.p, n, hipMemcpyDeviceToHost, stream));
+        if (fields.uParticle) FY_HIP(hipMemcpyAsync(fields.uParticle, own_uParticle.p, 3 * n, hipMemcpyDeviceToHost, stream));
+    }
+    FY_HIP(hipStreamSynchronize(stream));
+    return FY_OK;
+}
+
+int Coupling::stage_readonly_in() {
+    const size_t n = (size_t)n_cells * sizeof(double);
+    FY_HIP(hipMemcpyAsync(own_U.p, fields.U, 3 * n, hipMemcpyHostToDevice, stream));
+    if (gaussian) {
+        FY_HIP(hipMemcpyAsync(own_gradP.p, fields.gradP, 3 * n, hipMemcpyHostToDevice, stream));
+        FY_HIP(hipMemcpyAsync(own_divT.p, fields.divT, 3 * n, hipMemcpyHostToDevice, stream));
+    } else {
+        FY_HIP(hipMemcpyAsync(own_vGrad.p, fields.vGrad, 9 * n, hipMemcpyHostToDevice, stream));
+    }
+    return FY_OK;
+}
+
+void Coupling::set_num_batches(int nb) {
+    while ((int)batches.size() < nb) batches.emplace_back(new Batch());
+    n_batches = nb;
+}
+
+int Coupling::ensure_batch(Batch& b, int64_t n) {
+    b.n = n;
+    if (n == 0) return FY_OK;
+    const size_t cap = (size_t)n;
+    FY_TRY(b.force.reserve(6 * cap));
+    FY_TRY(b.found.reserve(cap));
+    if (gaussian) {
+        if (b.cap < cap) {
+            const size_t c2 = cap + cap / 8 + 64;
+            FY_TRY(b.soa.alloc_exact(7 * c2)); FY_TRY(b.orig.alloc_exact(c2)); FY_TRY(b.chain.alloc_exact(c2));
+            FY_TRY(b.ids.alloc_exact((size_t)kMaxK * c2)); FY_TRY(b.w.alloc_exact((size_t)kMaxK * c2));
+            FY_TRY(b.key.alloc_exact(c2)); FY_TRY(b.rank.alloc_exact(c2));
+            b.cap = c2;
+        }
+    } else {
+        FY_TRY(b.incell.reserve(cap));
+    }
+    return FY_OK;
+}
+
+ParticleSoA Coupling::soa_of(Batch& b) {
+    ParticleSoA p;
+    double* s = b.soa.p;
+    p.px = s; p.py = s + b.cap; p.pz = s + 2 * b.cap; p.vx = s + 3 * b.cap; p.vy = s + 4 * b.cap; p.vz = s + 5 * b.cap; p.rad = s + 6 * b.cap;
+    p.orig = b.orig.p; p.chain_len = b.chain.p; p.ids = b.ids.p; p.w = b.w.p; p.cap = b.cap;
+    return p;
+}
+
+int Coupling::set_particles_host(int bi, const double* rec, int64_t n) {
+    if (bi < 0 || bi >= n_batches || n < 0 || (n > 0 && !rec)) return fail(FY_ERR_INVALID, "fy_set_particles_host: bad batch/arguments");
+    Batch& b = *batches[bi];
+    FY_TRY(b.rec_own.reserve(10 * (size_t)std::max<int64_t>(n, 1)));
+    if (n) FY_HIP(hipMemcpyAsync(b.rec_own.p, rec, 10 * (size_t)n * sizeof(double), hipMemcpyHostToDevice, stream));
+    b.d_rec = b.rec_own.p;
+    return ensure_batch(b, n);
+}
+
+int Coupling::set_particles_device(int bi, const double* d_rec, int64_t n) {
+    if (bi < 0 || bi >= n_batches || n < 0 || (n > 0 && !d_rec)) return fail(FY_ERR_INVALID, "fy_set_particles_device: bad batch/arguments");
+    Batch& b = *batches[bi];
+    b.d_rec = d_rec;
+    return ensure_batch(b, n);
+}
+
+// the device part of setParticleAction for one Yade proc (FoamYade.C:612-628 loop body)
+int Coupling::run_batch(Batch& b) {
+    if (b.n == 0) return FY_OK;
+    ForceParams fp{rhoF, nu, 1e-09};
+    if (gaussian) {
+        ParticleSoA p = soa_of(b);
+        if (timing) timers[T_BIN].start(stream);
+        FY_HIP(hipMemsetAsync(d_hist.p, 0, (size_t)bins.nkeys * sizeof(uint32_t), stream));
+        FY_TRY(launch_bin_count(stream, b.d_rec, b.n, bins, b.key.p, b.rank.p, d_hist.p));
+        FY_TRY(launch_exclusive_scan_u32(stream, d_hist.p, bins.nkeys, d_tile_sums.p));
+        FY_TRY(launch_bin_scatter(stream, b.d_rec, b.n, b.key.p, b.rank.p, d_hist.p, d_tile_sums.p, p));
+        if (timing) { timers[T_BIN].stop(stream); timers[T_LOCATE].start(stream); }
+        GaussParams gp;
+        gp.maxdist = (interp_range * interp_range) + (0.25 * interp_range * interp_range);   // meshTree.C:155
+        gp.two_sigma2 = 2 * std::pow(sigma_interp, 2);                                         // FoamYade.C:308
+        gp.range_cu = interp_range_cu; gp.sigma_pi = sigma_pi;
+        FY_TRY(launch_locate_deposit(stream, d_tree.p, n_cells, tree_levels, nullptr, p, b.n, gp, d_pvol_acc.p, d_up_acc.p, d_touched.p));
+        if (timing) { timers[T_LOCATE].stop(stream); timers[T_FINALIZE].start(stream); }
+        FY_TRY(launch_finalize_cells(stream, n_cells, d_vol.p, d_pvol_acc.p, d_up_acc.p, d_touched.p, dAlpha, dUParticle));
+        if (timing) { timers[T_FINALIZE].stop(stream); timers[T_FORCE].start(stream); }
+        FY_TRY(launch_force_gaussian(stream, p, b.n, fp, d_vol.p, dU, dAlpha, dUParticle, dGradP, dDivT, dUSourceDrag, dUSource,
+                                     b.force.p, b.found.p));
+        if (timing) timers[T_FORCE].stop(stream);
+    } else {
+        BlockGeom g;
+        for (int a = 0; a < 3; ++a) { g.bbmin[a] = mesh.bbox_min[a]; g.bbmax[a] = mesh.bbox_max[a]; }
+        g.dx = mesh.dx; g.nx = mesh.nx; g.ny = mesh.ny; g.nz = mesh.nz;
+        if (timing) timers[T_FORCE].start(stream);
+        FY_TRY(launch_point_force(stream, b.d_rec, b.n, g, fp, d_vol.p, dU, dVGrad, dUSource, b.force.p, b.found.p, b.incell.p));
+        if (timing) timers[T_FORCE].stop(stream);
+    }
+    return FY_OK;
+}
+
+// FoamYade::setParticleAction FoamYade.C:605-632
+int Coupling::set_particle_action(double dt) {
+    if (!created) return fail(FY_ERR_INVALID, "fy_set_particle_action before fy_create");
+    FY_HIP(hipSetDevice(device));
+    delta_t = dt;                                                          // FoamYade.C:607
+    tm = fy_particle_timings{};
+    if (timing) timers[T_TOTAL].start(stream);
+
+    // ---- receive particles
+    if (has_transport) {
+        if (timing) timers[T_H2D].start(stream);
+        if (!serial_yade) FY_TRY(recv_yade_intrs());                       // FoamYade.C:609
+        else FY_TRY(recv_serial());                                        // FoamYade.C:173-184
+        if (timing) timers[T_H2D].stop(stream);
+    }
+    if (fields_on_host) { FY_TRY(stage_readonly_in()); FY_TRY(stage_mutable_in()); }
+
+    // ---- locate + deposit + finalize + force, one Yade proc after the other (FoamYade.C:612-628)
+    for (int bi = 0; bi < n_batches; ++bi) FY_TRY(run_batch(*batches[bi]));
+
+    if (fields_on_host) FY_TRY(stage_mutable_out());
+
+    // ---- send results
+    if (has_transport) {
+        if (timing) timers[T_D2H].start(stream);
+        FY_TRY(send_results());                                            // FoamYade.C:228,239-243,487-535
+        if (timing) timers[T_D2H].stop(stream);
+        FY_TRY(exchange_dt());                                             // FoamYade.C:537-553
+    }
+    if (timing) {
+        timers[T_TOTAL].stop(stream);
+        FY_HIP(hipStreamSynchronize(stream));
+        tm.h2d = timers[T_H2D].ms(); tm.bin = timers[T_BIN].ms(); tm.locate_deposit = timers[T_LOCATE].ms();
+        tm.finalize = timers[T_FINALIZE].ms(); tm.force = timers[T_FORCE].ms(); tm.d2h = timers[T_D2H].ms(); tm.total = timers[T_TOTAL].ms();
+        for (int bi = 0; bi < n_batches; ++bi) tm.n_particles += batches[bi]->n;
+    }
+    return FY_OK;
+}
+
+// serial Yade: Bcast N, Bcast 10N doubles (FoamYade.C:176-183)
+int Coupling::recv_serial() {
+    int N = 0;
+    FY_TR(transport.bcast_world(transport.user, &N, 1, FY_T_INT, 0));
+    if (N < 0) return fail(FY_ERR_TRANSPORT, "negative particle count from Yade");
+    Batch& b = *batches[0];
+    b.yrank = 0;
+    b.h_rec.resize(10 * (size_t)N);
+    if (N) FY_TR(transport.bcast_world(transport.user, b.h_rec.data(), 10 * N, FY_T_DOUBLE, 0));
+    return set_particles_host(0, b.h_rec.data(), N);
+}
+
+// parallel Yade: counts from every worker, then records from the intersecting ones (FoamYade.C:114-155)
+int Coupling::recv_yade_intrs() {
+    const int W = comm_sz_diff - 1;
+    std::vector<int> counts((size_t)transport.local_size);
+    std::vector<std::pair<int, int> > in_comm;       // (yRank, n)
+    for (int w = 0; w < W; ++w) {
+        const int yrank = w + 1;                                            // FoamYade.C:40: the Yade master sends nothing
+        FY_TR(transport.recv(transport.user, counts.data(), transport.local_size, FY_T_INT, yrank, TAG_SZ_BUFF));
+        if (counts[(size_t)transport.local_rank] > 0) in_comm.emplace_back(yrank, counts[(size_t)transport.local_rank]);
+    }
+    set_num_batches((int)in_comm.size());
+    for (size_t q = 0; q < in_comm.size(); ++q) {
+        Batch& b = *batches[q];
+        b.yrank = in_comm[q].first;
+        const int n = in_comm[q].second;
+        b.h_rec.resize(10 * (size_t)n);
+        FY_TR(transport.recv(transport.user, b.h_rec.data(), 10 * n, FY_T_DOUBLE, b.yrank, TAG_YADE_DATA));
+        FY_TRY(set_particles_host((int)q, b.h_rec.data(), n));
+    }
+    return FY_OK;
+}
+
+int Coupling::send_results() {
+    for (int bi = 0; bi < n_batches; ++bi) {
+        Batch& b = *batches[bi];
+        b.h_found.resize((size_t)b.n); b.h_force.resize(6 * (size_t)b.n);
+        if (b.n) {
+            FY_HIP(hipMemcpyAsync(b.h_found.data(), b.found.p, (size_t)b.n * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+            FY_HIP(hipMemcpyAsync(b.h_force.data(), b.force.p, 6 * (size_t)b.n * sizeof(double), hipMemcpyDeviceToHost, stream));
+        }
+    }
+    FY_HIP(hipStreamSynchronize(stream));
+    if (serial_yade) {
+        Batch& b = *batches[0];
+        const int N = (int)b.n;
+        send_ranks.assign((size_t)N, -1);
+        for (int np = 0; np < N; ++np) {                                    // one MAX all-reduce PER PARTICLE, FoamYade.C:202,223,228
+            int found = (b.h_found[(size_t)np] == 1) ? transport.world_rank : 0;
+            FY_TR(transport.allreduce_world(transport.user, &found, &send_ranks[(size_t)np], 1, FY_T_INT, FY_OP_MAX));
+        }
+        if (gaussian) {                                                     // 6 SUM all-reduces per particle, FoamYade.C:510-516
+            for (int np = 0; np < N; ++np)
+                for (int j = 0; j < 6; ++j) {
+                    double dummy = 0.0;
+                    FY_TR(transport.allreduce_world(transport.user, &b.h_force[6 * (size_t)np + j], &dummy, 1, FY_T_DOUBLE, FY_OP_SUM));
+                }
+        } else {                                                            // owner sends 6 doubles to rank 0, FoamYade.C:519-531
+            for (int np = 0; np < N; ++np)
+                if (send_ranks[(size_t)np] == transport.world_rank)
+                    FY_TR(transport.send(transport.user, &b.h_force[6 * (size_t)np], 6, FY_T_DOUBLE, 0, TAG_FORCE));
+        }
+    } else {
+        for (int bi = 0; bi < n_batches; ++bi) {                            // FoamYade.C:239-243
+            Batch& b = *batches[bi];
+            FY_TR(transport.send(transport.user, b.h_found.data(), (int)b.n, FY_T_INT, b.yrank, TAG_SEARCH_RES));
+        }
+        for (int bi = 0; bi < n_batches; ++bi) {                            // FoamYade.C:504-507
+            Batch& b = *batches[bi];
+            FY_TR(transport.send(transport.user, b.h_force.data(), 6 * (int)b.n, FY_T_DOUBLE, b.yrank, TAG_FORCE));
+        }
+    }
+    return FY_OK;
+}
+
+// FoamYade::exchangeDT FoamYade.C:537-553
+int Coupling::exchange_dt() {
+    if (transport.local_rank == 0) FY_TR(transport.send(transport.user, &delta_t, 1, FY_T_DOUBLE, 0, TAG_FLUID_DT));
+    if (!serial_yade) {
+        if (transport.local_rank == 0) FY_TR(transport.recv(transport.user, &yade_dt, 1, FY_T_DOUBLE, 0, TAG_YADE_DT));
+        FY_TR(transport.bcast_local(transport.user, &yade_dt, 1, FY_T_DOUBLE, 0));
+    } else {
+        FY_TR(transport.bcast_world(transport.user, &yade_dt, 1, FY_T_DOUBLE, 0));
+    }
+    return FY_OK;
+}
+
+// FoamYade::setSourceZero FoamYade.C:556-566 + clearInCommProcs FoamYade.C:568-580
+int Coupling::set_source_zero() {
+    if (!created) return fail(FY_ERR_INVALID, "fy_set_source_zero before fy_create");
+    FY_HIP(hipSetDevice(device));
+    FY_TRY(launch_set_source_zero(stream, n_cells, gaussian ? 1 : 0, dUSourceDrag, dAlpha, dUSource, dUParticle));
+    if (fields_on_host) FY_TRY(stage_mutable_out());
+    if (has_transport && !serial_yade) n_batches = 0;                       // FoamYade.C:577
+    return FY_OK;
+}
+
+int Coupling::get_forces_host(int bi, double* out) {
+    if (bi < 0 || bi >= (int)batches.size() || !out) return fail(FY_ERR_INVALID, "fy_get_forces_host: bad batch");
+    Batch& b = *batches[bi];
+    if (b.n) FY_HIP(hipMemcpyAsync(out, b.force.p, 6 * (size_t)b.n * sizeof(double), hipMemcpyDeviceToHost, stream));
+    FY_HIP(hipStreamSynchronize(stream));
+    return FY_OK;
+}
+
+int Coupling::get_found_host(int bi, int32_t* out) {
+    if (bi < 0 || bi >= (int)batches.size() || !out) return fail(FY_ERR_INVALID, "fy_get_found_host: bad batch");
+    Batch& b = *batches[bi];
+    if (b.n) FY_HIP(hipMemcpyAsync(out, b.found.p, (size_t)b.n * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+    FY_HIP(hipStreamSynchronize(stream));
+    return FY_OK;
+}
+
+int Coupling::get_stencils_host(int bi, int32_t* k, int32_t* ids, double* w, int32_t* chain) {
+    if (bi < 0 || bi >= (int)batches.size() || !k || !ids || !w || !chain) return fail(FY_ERR_INVALID, "fy_get_stencils_host: bad arguments");
+    Batch& b = *batches[bi];
+    if (b.n == 0) return FY_OK;
+    const size_t n = (size_t)b.n;
+    DevBuf<int32_t> dk, dids, dchain; DevBuf<double> dw;
+    FY_TRY(dk.alloc_exact(n)); FY_TRY(dids.alloc_exact(kMaxK * n)); FY_TRY(dchain.alloc_exact(n)); FY_TRY(dw.alloc_exact(kMaxK * n));
+    if (gaussian) {
+        FY_TRY(launch_unpack_stencils(stream, soa_of(b), b.n, dk.p, dids.p, dw.p, dchain.p));
+        FY_HIP(hipMemcpyAsync(k, dk.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+        FY_HIP(hipMemcpyAsync(ids, dids.p, kMaxK * n * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+        FY_HIP(hipMemcpyAsync(w, dw.p, kMaxK * n * sizeof(double), hipMemcpyDeviceToHost, stream));
+        FY_HIP(hipMemcpyAsync(chain, dchain.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+        FY_HIP(hipStreamSynchronize(stream));
+    } else {
+        std::vector<int32_t> incell(n);
+        FY_HIP(hipMemcpyAsync(incell.data(), b.incell.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+        FY_HIP(hipStreamSynchronize(stream));
+        for (size_t i = 0; i < n; ++i) {
+            for (int q = 0; q < kMaxK; ++q) { ids[i * kMaxK + q] = -1; w[i * kMaxK + q] = 0.0; }
+            k[i] = incell[i] >= 0 ? 1 : 0; chain[i] = k[i];
+            if (k[i]) ids[i * kMaxK] = incell[i];
+        }
+    }
+    return FY_OK;
+}
+
+int Coupling::get_tree_preorder(int32_t* out) {
+    if (!out) return fail(FY_ERR_INVALID, "null output");
+    std::vector<KdNode> nodes((size_t)n_cells);
+    FY_HIP(hipMemcpyAsync(nodes.data(), d_tree.p, nodes.size() * sizeof(KdNode), hipMemcpyDeviceToHost, stream));
+    FY_HIP(hipStreamSynchronize(stream));
+    for (int32_t c = 0; c < n_cells; ++c) out[c] = nodes[(size_t)c].id;
+    return FY_OK;
+}
+
+int Coupling::field_by_name(const char* name, double** p, size_t* count) {
+    const std::string s = name ? name : "";
+    const size_t n = (size_t)n_cells;
+    if (s == "alpha") { *p = dAlpha; *count = n; }
+    else if (s == "uSourceDrag") { *p = dUSourceDrag; *count = n; }
+    else if (s == "uSource") { *p = dUSource; *count = 3 * n; }
+    else if (s == "uParticle") { *p = dUParticle; *count = 3 * n; }
+    else if (s == "U") { *p = const_cast<double*>(dU); *count = 3 * n; }
+    else if (s == "gradP") { *p = const_cast<double*>(dGradP); *count = 3 * n; }
+    else if (s == "divT") { *p = const_cast<double*>(dDivT); *count = 3 * n; }
+    else if (s == "vGrad") { *p = const_cast<double*>(dVGrad); *count = 9 * n; }
+    else return fail(FY_ERR_INVALID, "unknown field '%s'", s.c_str());
+    if (!*p) return fail(FY_ERR_INVALID, "field '%s' was not supplied", s.c_str());
+    return FY_OK;
+}
+
+int Coupling::read_field_host(const char* name, double* out) {
+    double* p; size_t cnt;
+    FY_TRY(field_by_name(name, &p, &cnt));
+    FY_HIP(hipMemcpyAsync(out, p, cnt * sizeof(double), hipMemcpyDeviceToHost, stream));
+    FY_HIP(hipStreamSynchronize(stream));
+    return FY_OK;
+}
+
+int Coupling::write_field_host(const char* name, const double* in) {
+    double* p; size_t cnt;
+    FY_TRY(field_by_name(name, &p, &cnt));
+    FY_HIP(hipMemcpyAsync(p, in, cnt * sizeof(double), hipMemcpyHostToDevice, stream));
+    FY_HIP(hipStreamSynchronize(stream));
+    return FY_OK;
+}
+
+Coupling::~Coupling() {
+    if (device >= 0) (void)hipSetDevice(device);
+    for (auto& t : timers) t.destroy();
+    for (auto* b : batches) delete b;
+    if (owns_stream && stream) (void)hipStreamDestroy(stream);
+}
+
+}  // namespace fy
+
+// ================================================================================================ C ABI
+using fy::Coupling;
+struct fy_ctx { Coupling c; };
+
+extern "C" {
+
+const char* fy_last_error(void) { return fy::last_error().c_str(); }
+int fy_abi_version(void) { return FY_ABI_VERSION; }
+int fy_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int fy_create(const fy_mesh_desc* mesh, const fy_field_ptrs* fields, int gaussian_interp, const fy_transport* transport,
+              int device_ordinal, fy_ctx** out) {
+    if (!out) return fy::fail(FY_ERR_INVALID, "fy_create: null out");
+    *out = nullptr;
+    fy_ctx* c = new (std::nothrow) fy_ctx();
+    if (!c) return fy::fail(FY_ERR_INVALID, "out of host memory");
+    int rc = c->c.create(mesh, fields, gaussian_interp, transport, device_ordinal);
+    if (rc != FY_OK) { delete c; return rc; }
+    *out = c;
+    return FY_OK;
+}
+
+#define FY_CTX(c) if (!(c)) return fy::fail(FY_ERR_INVALID, "null fy_ctx")
+
+int fy_set_scalar_properties(fy_ctx* c, double rhoP, double rhoF, double nu) { FY_CTX(c); c->c.rhoP = rhoP; c->c.rhoF = rhoF; c->c.nu = nu; return FY_OK; }
+int fy_set_particle_action(fy_ctx* c, double dt) { FY_CTX(c); return c->c.set_particle_action(dt); }
+int fy_set_source_zero(fy_ctx* c) { FY_CTX(c); return c->c.set_source_zero(); }
+int fy_destroy(fy_ctx* c) { delete c; return FY_OK; }
+int fy_set_num_batches(fy_ctx* c, int nb) {
+    FY_CTX(c);
+    if (nb < 0) return fy::fail(FY_ERR_INVALID, "negative batch count");
+    c->c.set_num_batches(nb);
+    return FY_OK;
+}
+int fy_set_particles_host(fy_ctx* c, int batch, const double* rec, int64_t n) { FY_CTX(c); return c->c.set_particles_host(batch, rec, n); }
+int fy_set_particles_device(fy_ctx* c, int batch, const double* rec, int64_t n) { FY_CTX(c); return c->c.set_particles_device(batch, rec, n); }
+int fy_get_forces_host(fy_ctx* c, int batch, double* out) { FY_CTX(c); return c->c.get_forces_host(batch, out); }
+int fy_get_found_host(fy_ctx* c, int batch, int32_t* out) { FY_CTX(c); return c->c.get_found_host(batch, out); }
+const double* fy_forces_device(fy_ctx* c, int batch) {
+    if (!c || batch < 0 || batch >= (int)c->c.batches.size()) return nullptr;
+    return c->c.batches[(size_t)batch]->force.p;
+}
+int fy_get_stencils_host(fy_ctx* c, int batch, int32_t* k, int32_t* ids, double* w, int32_t* chain) { FY_CTX(c); return c->c.get_stencils_host(batch, k, ids, w, chain); }
+int fy_get_tree_preorder(fy_ctx* c, int32_t* out) { FY_CTX(c); return c->c.get_tree_preorder(out); }
+int fy_read_field_host(fy_ctx* c, const char* name, double* out) { FY_CTX(c); return c->c.read_field_host(name, out); }
+int fy_write_field_host(fy_ctx* c, const char* name, const double* in) { FY_CTX(c); return c->c.write_field_host(name, in); }
+double fy_yade_dt(fy_ctx* c) { return c ? c->c.yade_dt : 0.0; }
+double fy_interp_range(fy_ctx* c) { return c ? c->c.interp_range : 0.0; }
+int fy_get_particle_timings(fy_ctx* c, fy_particle_timings* out) { FY_CTX(c); if (!out) return fy::fail(FY_ERR_INVALID, "null out"); *out = c->c.tm; return FY_OK; }
+int fy_enable_timing(fy_ctx* c, int on) { FY_CTX(c); c->c.timing = on != 0; return FY_OK; }
+
+}  // extern "C"

@@ -1,0 +1,95 @@
+// Coupling = the state behind fy_ctx (mirror of Foam::FoamYade, FoamYade/FoamYade.H:57-161).
+#pragma once
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "common.hpp"
+#include "kdtree.hpp"
+#include "particle_kernels.hpp"
+
+namespace fy {
+
+// one "Yade proc" worth of particles (FoamYade.H:41-55 YadeProc)
+struct Batch {
+    int64_t n = 0;
+    int yrank = 0;                       // world rank of the Yade proc
+    const double* d_rec = nullptr;       // device records [n][10] (borrowed, or rec_own)
+    DevBuf<double> rec_own;
+    size_t cap = 0;                      // leading dimension of the SoA / stencil arrays
+    DevBuf<double> soa;                  // 7 * cap : px py pz vx vy vz rad (binned order)
+    DevBuf<int32_t> orig, chain, ids, found, incell;
+    DevBuf<double> w, force;
+    DevBuf<uint32_t> key, rank;
+    std::vector<double> h_rec, h_force;  // wire staging
+    std::vector<int32_t> h_found;
+};
+
+struct Coupling {
+    // ---- configuration
+    int device = -1;
+    hipStream_t stream = nullptr;
+    bool owns_stream = false;
+    bool created = false;
+    fy_mesh_desc mesh{};
+    int32_t n_cells = 0;
+    bool gaussian = false, structured = false;
+    bool has_transport = false;
+    fy_transport transport{};
+    int comm_sz_diff = 0;                // FoamYade.H:74
+    bool serial_yade = true;             // FoamYade.H:91
+    double rhoP = 0, rhoF = 0, nu = 0;   // FoamYade.H:83-85
+    double delta_t = 0, yade_dt = 0;     // FoamYade.H:94-95
+    double v0 = 0, interp_range = 0, sigma_interp = 0, interp_range_cu = 0, sigma_pi = 0;   // FoamYade.H:96-99
+    std::vector<int> send_ranks;         // FoamYade.H:70
+
+    // ---- device state
+    DevBuf<KdNode> d_tree;
+    int tree_levels = 0;
+    DevBuf<double> d_vol;
+    fy_field_ptrs fields{};
+    bool fields_on_host = false;
+    DevBuf<double> own_U, own_gradP, own_vGrad, own_divT, own_uSourceDrag, own_alpha, own_uSource, own_uParticle;
+    const double *dU = nullptr, *dGradP = nullptr, *dVGrad = nullptr, *dDivT = nullptr;
+    double *dUSourceDrag = nullptr, *dAlpha = nullptr, *dUSource = nullptr, *dUParticle = nullptr;
+    DevBuf<double> d_pvol_acc, d_up_acc;           // per-batch deposit accumulators (pVolContrib / uParticleContrib)
+    DevBuf<unsigned char> d_touched;
+    BinGrid bins{};
+    DevBuf<uint32_t> d_hist, d_tile_sums;
+    std::vector<Batch*> batches;
+    int n_batches = 0;
+
+    // ---- timing
+    enum { T_H2D = 0, T_BIN, T_LOCATE, T_FINALIZE, T_FORCE, T_D2H, T_TOTAL, T_COUNT };
+    EventTimer timers[T_COUNT];
+    bool timing = false;
+    fy_particle_timings tm{};
+
+    ~Coupling();
+    int create(const fy_mesh_desc* m, const fy_field_ptrs* f, int gaussian_interp, const fy_transport* tr, int device_ordinal);
+    int init_fields();
+    int stage_mutable_in();
+    int stage_mutable_out();
+    int stage_readonly_in();
+    void set_num_batches(int nb);
+    int ensure_batch(Batch& b, int64_t n);
+    ParticleSoA soa_of(Batch& b);
+    int set_particles_host(int bi, const double* rec, int64_t n);
+    int set_particles_device(int bi, const double* d_rec, int64_t n);
+    int run_batch(Batch& b);
+    int set_particle_action(double dt);
+    int recv_serial();
+    int recv_yade_intrs();
+    int send_results();
+    int exchange_dt();
+    int set_source_zero();
+    int get_forces_host(int bi, double* out);
+    int get_found_host(int bi, int32_t* out);
+    int get_stencils_host(int bi, int32_t* k, int32_t* ids, double* w, int32_t* chain);
+    int get_tree_preorder(int32_t* out);
+    int field_by_name(const char* name, double** p, size_t* count);
+    int read_field_host(const char* name, double* out);
+    int write_field_host(const char* name, const double* in);
+};
+
+}  // namespace fy

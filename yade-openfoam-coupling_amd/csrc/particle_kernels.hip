@@ -1,0 +1,499 @@
+// Particle half of the hot path as hand-written HIP for gfx950 (MI355X, wave64).
+//
+//   bin_count / scan / bin_scatter   AoS wire records -> spatially binned SoA (locality only; results independent)
+//   locate_deposit                   meshTree::nnearestCellsRange (meshTree.C:148-238) as a flat per-lane DFS over the
+//                                    preorder tree with an LDS stack, fused with calcInterpWeightGaussian
+//                                    (FoamYade.C:293-316) and buildCellPartList's deposition (FoamYade.C:261-290)
+//   finalize_cells                   setCellVolFraction (FoamYade.C:318-328)
+//   force_gaussian                   hydroDragForce + archimedesForce + source back-scatter (FoamYade.C:354-389,415-435)
+//   point_force                      findCell + stokesDragForce + stokesDragTorque (FoamYade.C:248-253,437-453)
+//
+// All arithmetic is FP64 in the reference's operation order; the file is compiled with -ffp-contract=off so that the
+// distance comparisons that steer the tree walk are bit-identical to the CPU reference (index work must be exact).
+// Everything here is HBM/L2-latency bound: no MFMA (there is no dense contraction on this path).
+#include "particle_kernels.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include "common.hpp"
+
+namespace fy {
+namespace {
+
+constexpr int kWave = 64;
+
+__device__ __forceinline__ void atomic_add_f64(double* p, double v) {
+    // global_atomic_add_f64, no return value, device (agent) scope
+    unsafeAtomicAdd(p, v);
+}
+
+// ------------------------------------------------------------------------------------------------ binning
+__device__ __forceinline__ uint32_t bin_key(const BinGrid& g, double x, double y, double z) {
+    int bx = (int)floor((x - g.ox) * g.inv_h);
+    int by = (int)floor((y - g.oy) * g.inv_h);
+    int bz = (int)floor((z - g.oz) * g.inv_h);
+    bx = min(max(bx, 0), g.nbx - 1);
+    by = min(max(by, 0), g.nby - 1);
+    bz = min(max(bz, 0), g.nbz - 1);
+    const uint32_t brick = ((uint32_t)(bz >> 2) * g.by4 + (uint32_t)(by >> 2)) * g.bx4 + (uint32_t)(bx >> 2);
+    const uint32_t local = ((uint32_t)(bz & 3) << 4) | ((uint32_t)(by & 3) << 2) | (uint32_t)(bx & 3);
+    return brick * 64u + local;
+}
+
+__global__ __launch_bounds__(256) void k_bin_count(const double* __restrict__ rec, int64_t n, BinGrid g,
+                                                   uint32_t* __restrict__ key, uint32_t* __restrict__ rank,
+                                                   uint32_t* __restrict__ hist) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double* r = rec + 10 * i;
+    const uint32_t k = bin_key(g, r[0], r[1], r[2]);
+    key[i] = k;
+    rank[i] = atomicAdd(&hist[k], 1u);
+}
+
+// exclusive scan of 2048-element tiles; tile totals go to block_sums (scanned in place by k_scan_sums)
+__global__ __launch_bounds__(256) void k_scan_tiles(uint32_t* __restrict__ data, uint32_t n, uint32_t* __restrict__ block_sums) {
+    __shared__ uint32_t wave_tot[4];
+    const uint32_t base = blockIdx.x * 2048u + threadIdx.x * 8u;
+    uint32_t v[8];
+    uint32_t t = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const uint32_t x = (base + j < n) ? data[base + j] : 0u;
+        v[j] = t;
+        t += x;
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t inc = t;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += y;
+    }
+    if (lane == 63) wave_tot[wv] = inc;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int q = 0; q < wv; ++q) woff += wave_tot[q];
+    const uint32_t excl = woff + inc - t;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        if (base + j < n) data[base + j] = excl + v[j];
+    if (threadIdx.x == 255) block_sums[blockIdx.x] = woff + inc;
+}
+
+__global__ __launch_bounds__(1024) void k_scan_sums(uint32_t* __restrict__ sums, uint32_t nb) {
+    __shared__ uint32_t wave_tot[16];
+    const uint32_t per = (nb + 1023u) / 1024u;
+    const uint32_t lo = threadIdx.x * per;
+    uint32_t t = 0;
+    for (uint32_t j = 0; j < per; ++j)
+        if (lo + j < nb) t += sums[lo + j];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t inc = t;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += y;
+    }
+    if (lane == 63) wave_tot[wv] = inc;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int q = 0; q < wv; ++q) woff += wave_tot[q];
+    uint32_t run = woff + inc - t;
+    for (uint32_t j = 0; j < per; ++j)
+        if (lo + j < nb) {
+            const uint32_t x = sums[lo + j];
+            sums[lo + j] = run;
+            run += x;
+        }
+}
+
+__global__ __launch_bounds__(256) void k_bin_scatter(const double* __restrict__ rec, int64_t n, const uint32_t* __restrict__ key,
+                                                     const uint32_t* __restrict__ rank, const uint32_t* __restrict__ start,
+                                                     const uint32_t* __restrict__ tile_off, ParticleSoA p) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t k = key[i];
+    const size_t d = (size_t)start[k] + tile_off[k >> 11] + rank[i];
+    const double* r = rec + 10 * i;
+    p.px[d] = r[0]; p.py[d] = r[1]; p.pz[d] = r[2];
+    p.vx[d] = r[3]; p.vy[d] = r[4]; p.vz[d] = r[5];
+    p.rad[d] = r[9];
+    p.orig[d] = (int32_t)i;
+}
+
+// ------------------------------------------------------------------------------------------------ locate + deposit
+// One lane per particle, one wave per 64-particle chunk of the binned order.  Per-lane DFS stack lives in LDS as
+// [level][lane] uint4 = {offset, size | axis<<30, df2 (2 dwords)}: 16 B * 64 lanes = one 1 KiB row per level, and the bank of an
+// entry depends on the lane only, so lanes at different levels never conflict.
+__global__ __launch_bounds__(kWave) void k_locate_deposit(const KdNode* __restrict__ tree, int32_t n_cells, ParticleSoA p,
+                                                          int64_t n, GaussParams gp, double* __restrict__ pvol_acc,
+                                                          double* __restrict__ up_acc, unsigned char* __restrict__ touched) {
+    extern __shared__ __attribute__((aligned(16))) uint4 stack[];
+    const int lane = threadIdx.x;
+    const int64_t i = (int64_t)blockIdx.x * kWave + lane;
+    if (i >= n) return;
+    const double qx = p.px[i], qy = p.py[i], qz = p.pz[i];
+
+    // meshTree.C:156: dist = distance(root->p, px); the root itself can never enter the queue (x < x is false)
+    double best;
+    {
+        const KdNode r = tree[0];
+        const double a = qx - r.x, b = qy - r.y, c = qz - r.z;
+        best = a * a;
+        best += b * b;
+        best += c * c;
+    }
+    int chain = 0;
+    int sp = 0;
+    uint32_t o = 0, nn = (uint32_t)n_cells, axis = 0;
+    for (;;) {
+        if (nn == 0) {
+            bool got = false;
+            while (sp > 0) {
+                --sp;
+                const uint4 e = stack[sp * kWave + lane];
+                const double df2 = __hiloint2double((int)e.w, (int)e.z);
+                if (df2 < best) {          // meshTree.C:225, evaluated when the near subtree has returned
+                    o = e.x; nn = e.y & 0x3fffffffu; axis = e.y >> 30;
+                    got = true;
+                    break;
+                }
+            }
+            if (!got) break;
+        }
+        const KdNode nd = tree[o];
+        const double a = qx - nd.x, b = qy - nd.y, c = qz - nd.z;
+        double d = a * a;                    // meshTree.C:54-64: dist += ds*ds over x, y, z
+        d += b * b;
+        d += c * c;
+        if (d < best) {                      // meshTree.C:192 (and the re-push on return is a no-op: same id)
+            best = d;
+            if (d < gp.maxdist) {            // meshTree.C:195
+                const size_t slot = (size_t)(chain & (kMaxK - 1)) * p.cap + (size_t)i;
+                p.ids[slot] = nd.id;
+                p.w[slot] = d;               // squared distance parked here until the weights are formed below
+                ++chain;
+            }
+        }
+        const double df = (axis == 0 ? nd.x - qx : (axis == 1 ? nd.y - qy : nd.z - qz));   // meshTree.C:200
+        const double df2 = df * df;
+        const uint32_t nl = nn >> 1, nr = nn - nl - 1;
+        uint32_t near_o, near_n, far_o, far_n;
+        if (df > 0.0) { near_o = o + 1; near_n = nl; far_o = o + 1 + nl; far_n = nr; }      // meshTree.C:206-208
+        else          { near_o = o + 1 + nl; near_n = nr; far_o = o + 1; far_n = nl; }      // meshTree.C:209-212
+        axis = (axis == 2 ? 0 : axis + 1);
+        // best only decreases, so a far side that already fails df2 < best can never pass later
+        if (far_n > 0 && df2 < best) {
+            uint4 e;
+            e.x = far_o; e.y = far_n | (axis << 30);
+            e.z = (uint32_t)__double2loint(df2); e.w = (uint32_t)__double2hiint(df2);
+            stack[sp * kWave + lane] = e;
+            ++sp;
+        }
+        o = near_o; nn = near_n;
+    }
+    p.chain_len[i] = chain;
+    const int k = chain < kMaxK ? chain : kMaxK;
+    if (k == 0) return;                      // "not found": FoamYade.C:204
+
+    // calcInterpWeightGaussian FoamYade.C:301-314, slots visited in ascending-d2 order (= reverse push order)
+    double allwt = 0.0;
+    for (int t = 0; t < k; ++t) {
+        const size_t slot = (size_t)((chain - 1 - t) & (kMaxK - 1)) * p.cap + (size_t)i;
+        const double distsq = p.w[slot];
+        const double weight = exp(-distsq / gp.two_sigma2) * gp.range_cu * gp.sigma_pi;
+        allwt += weight;
+        p.w[slot] = weight;
+    }
+    // buildCellPartList FoamYade.C:265-288: pVol*w and (w*v)*pVol into the per-batch accumulators
+    const double dia = 2 * p.rad[i];                                  // FoamYade.C:219
+    const double pVol = M_PI * pow(dia, 3.0) / 6.0;                   // FoamYade.H:36
+    const double vx = p.vx[i], vy = p.vy[i], vz = p.vz[i];
+    for (int t = 0; t < k; ++t) {
+        const size_t slot = (size_t)((chain - 1 - t) & (kMaxK - 1)) * p.cap + (size_t)i;
+        const double weight = p.w[slot] / allwt;
+        p.w[slot] = weight;
+        const int32_t cid = p.ids[slot];
+        atomic_add_f64(&pvol_acc[cid], pVol * weight);
+        atomic_add_f64(&up_acc[3 * (size_t)cid + 0], (weight * vx) * pVol);
+        atomic_add_f64(&up_acc[3 * (size_t)cid + 1], (weight * vy) * pVol);
+        atomic_add_f64(&up_acc[3 * (size_t)cid + 2], (weight * vz) * pVol);
+        touched[cid] = 1;
+    }
+}
+
+// setCellVolFraction FoamYade.C:318-328: assignment on the cells this batch touched; accumulators reset for the next batch
+__global__ __launch_bounds__(256) void k_finalize_cells(int32_t n_cells, const double* __restrict__ vol, double* __restrict__ pvol_acc,
+                                                        double* __restrict__ up_acc, unsigned char* __restrict__ touched,
+                                                        double* __restrict__ alpha, double* __restrict__ uParticle) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= n_cells) return;
+    if (!touched[c]) return;
+    touched[c] = 0;
+    const double V = vol[c];
+    const double pvolC = 1.0 - (pvol_acc[c] / V);
+    alpha[c] = ((pvolC > 0.10) ? pvolC : 0.10);
+    double* up = up_acc + 3 * (size_t)c;
+    double* o = uParticle + 3 * (size_t)c;
+    o[0] = up[0] / V; o[1] = up[1] / V; o[2] = up[2] / V;
+    pvol_acc[c] = 0.0; up[0] = 0.0; up[1] = 0.0; up[2] = 0.0;
+}
+
+// ------------------------------------------------------------------------------------------------ force + back-scatter
+__global__ __launch_bounds__(256) void k_force_gaussian(ParticleSoA p, int64_t n, ForceParams fp, const double* __restrict__ vol,
+                                                        const double* __restrict__ U, const double* __restrict__ alpha,
+                                                        const double* __restrict__ uParticle, const double* __restrict__ gradP,
+                                                        const double* __restrict__ divT, double* __restrict__ uSourceDrag,
+                                                        double* __restrict__ uSource, double* __restrict__ force_out,
+                                                        int32_t* __restrict__ found_out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int chain = p.chain_len[i];
+    const int k = chain < kMaxK ? chain : kMaxK;
+    const int32_t orig = p.orig[i];
+    double* F = force_out + 6 * (size_t)orig;
+    if (k == 0) {                                   // zeros for particles nobody located (FoamYade.C:142)
+        F[0] = F[1] = F[2] = F[3] = F[4] = F[5] = 0.0;
+        found_out[orig] = -1;
+        return;
+    }
+    found_out[orig] = 1;
+    const double rhoF = fp.rhoF, nu = fp.nu;
+    const double dia = 2 * p.rad[i];
+    const double volp = M_PI * pow(dia, 3.0) / 6.0;
+    const double lvx = p.vx[i], lvy = p.vy[i], lvz = p.vz[i];
+
+    // hydroDragForce FoamYade.C:358-365 and archimedesForce FoamYade.C:416-424 share one gather pass
+    double ufx = 0, ufy = 0, ufz = 0, alpha_f = 0.0, pv = 0.0;
+    double dtx = 0, dty = 0, dtz = 0, pgx = 0, pgy = 0, pgz = 0;
+    const double two_nu = 2.0 * nu;
+    for (int t = 0; t < k; ++t) {
+        const size_t slot = (size_t)((chain - 1 - t) & (kMaxK - 1)) * p.cap + (size_t)i;
+        const int32_t c = p.ids[slot];
+        const double w = p.w[slot];
+        const double* u = U + 3 * (size_t)c;
+        ufx += (u[0] * w); ufy += (u[1] * w); ufz += (u[2] * w);
+        alpha_f += (alpha[c] * w);
+        pv += (volp * w);
+        const double* dt = divT + 3 * (size_t)c;
+        dtx = dtx + (((two_nu * dt[0]) * w) * rhoF);
+        dty = dty + (((two_nu * dt[1]) * w) * rhoF);
+        dtz = dtz + (((two_nu * dt[2]) * w) * rhoF);
+        const double* g = gradP + 3 * (size_t)c;
+        pgx = pgx + (g[0] * w); pgy = pgy + (g[1] * w); pgz = pgz + (g[2] * w);
+    }
+    const double alpha_p = 1 - alpha_f;                                             // FoamYade.C:366
+    const double urx = ufx - lvx, ury = ufy - lvy, urz = ufz - lvz;
+    const double magUR = sqrt(urx * urx + ury * ury + urz * urz);
+    const double Re = fp.small + ((magUR * dia) / nu);                              // FoamYade.C:370
+    const double cd = Re < 1000 ? (24 / (Re)) * (1 + (0.15 * pow(Re, 0.687))) : 0.44;
+    double coeff;
+    if (alpha_f > 0.8) {                                                            // FoamYade.C:373-374
+        coeff = 0.75 * cd * alpha_f * alpha_p * rhoF * magUR * pow(alpha_f, -2.65);
+    } else {                                                                        // FoamYade.C:376-378
+        const double cf1 = 150 * ((alpha_p * alpha_p) / alpha_f) * ((nu * rhoF) / (dia * dia));
+        const double cf2 = 1.75 * alpha_p * rhoF * (1 / dia) * magUR;
+        coeff = cf1 + cf2;
+    }
+    const double s1 = pv * coeff, ia = 1 / (alpha_p);                               // FoamYade.C:381
+    const double hfx = (s1 * urx) * ia, hfy = (s1 * ury) * ia, hfz = (s1 * urz) * ia;
+    const double afx = pv * (-pgx + dtx), afy = pv * (-pgy + dty), afz = pv * (-pgz + dtz);   // FoamYade.C:426
+    F[0] = (0.0 + hfx) + afx; F[1] = (0.0 + hfy) + afy; F[2] = (0.0 + hfz) + afz;   // FoamYade.C:382,427
+    F[3] = 0.0; F[4] = 0.0; F[5] = 0.0;                                             // Gaussian torque disabled, FoamYade.C:618
+
+    const double irho = 1 / rhoF;
+    for (int t = 0; t < k; ++t) {
+        const size_t slot = (size_t)((chain - 1 - t) & (kMaxK - 1)) * p.cap + (size_t)i;
+        const int32_t c = p.ids[slot];
+        const double w = p.w[slot];
+        const double cw = -coeff * w;
+        atomic_add_f64(&uSourceDrag[c], cw * irho);                                 // FoamYade.C:385
+        const double* up = uParticle + 3 * (size_t)c;
+        const double ooCellVol = 1. / (vol[c] * rhoF);                              // FoamYade.C:432
+        // FoamYade.C:386 (drag part, NOT divided by V) + FoamYade.C:433 (Archimedes part), one atomic per component
+        atomic_add_f64(&uSource[3 * (size_t)c + 0], ((cw * up[0]) / rhoF) + ((-afx * w) * ooCellVol));
+        atomic_add_f64(&uSource[3 * (size_t)c + 1], ((cw * up[1]) / rhoF) + ((-afy * w) * ooCellVol));
+        atomic_add_f64(&uSource[3 * (size_t)c + 2], ((cw * up[2]) / rhoF) + ((-afz * w) * ooCellVol));
+    }
+}
+
+// sorted chain-order stencil storage -> [n][16] ascending-d2 rows in wire order (parity tests only)
+__global__ __launch_bounds__(256) void k_unpack_stencils(ParticleSoA p, int64_t n, int32_t* __restrict__ k_out, int32_t* __restrict__ ids,
+                                                         double* __restrict__ w, int32_t* __restrict__ chain_out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int chain = p.chain_len[i];
+    const int k = chain < kMaxK ? chain : kMaxK;
+    const size_t orig = (size_t)p.orig[i];
+    k_out[orig] = chain;       // the reference's container also grows past 12 (meshTree.H:74-77)
+    chain_out[orig] = chain;
+    for (int t = 0; t < kMaxK; ++t) {
+        if (t < k) {
+            const size_t slot = (size_t)((chain - 1 - t) & (kMaxK - 1)) * p.cap + (size_t)i;
+            ids[orig * kMaxK + t] = p.ids[slot];
+            w[orig * kMaxK + t] = p.w[slot];
+        } else {
+            ids[orig * kMaxK + t] = -1;
+            w[orig * kMaxK + t] = 0.0;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ point force
+__global__ __launch_bounds__(256) void k_point_force(const double* __restrict__ rec, int64_t n, BlockGeom g, ForceParams fp,
+                                                     const double* __restrict__ vol, const double* __restrict__ U,
+                                                     const double* __restrict__ vGrad, double* __restrict__ uSource,
+                                                     double* __restrict__ force_out, int32_t* __restrict__ found_out,
+                                                     int32_t* __restrict__ incell_out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double* r = rec + 10 * i;
+    const double x = r[0], y = r[1], z = r[2];
+    double* F = force_out + 6 * (size_t)i;
+    // uniform-block stand-in for mesh.findCell (FoamYade.C:251): inside the closed bounding box, floor((p-min)/dx) clamped
+    const bool outside = (x < g.bbmin[0] || y < g.bbmin[1] || z < g.bbmin[2] || x > g.bbmax[0] || y > g.bbmax[1] || z > g.bbmax[2]);
+    if (outside || !(x == x) || !(y == y) || !(z == z)) {
+        F[0] = F[1] = F[2] = F[3] = F[4] = F[5] = 0.0;
+        found_out[i] = -1;
+        incell_out[i] = -1;
+        return;
+    }
+    const int ci = min(g.nx - 1, (int)((x - g.bbmin[0]) / g.dx));
+    const int cj = min(g.ny - 1, (int)((y - g.bbmin[1]) / g.dx));
+    const int ck = min(g.nz - 1, (int)((z - g.bbmin[2]) / g.dx));
+    const int c = ci + g.nx * (cj + g.ny * ck);
+    found_out[i] = 1;
+    incell_out[i] = c;
+    const double dia = 2 * r[9];
+    const double rhoF = fp.rhoF, nu = fp.nu;
+    // stokesDragForce FoamYade.C:437-444
+    const double coeff = 3 * M_PI * (dia)*nu * rhoF;
+    const double ooCellVol = 1. / (vol[c] * rhoF);
+    const double* u = U + 3 * (size_t)c;
+    const double hx = coeff * (u[0] - r[3]), hy = coeff * (u[1] - r[4]), hz = coeff * (u[2] - r[5]);
+    const double m = -1 * ooCellVol;
+    atomic_add_f64(&uSource[3 * (size_t)c + 0], m * hx);
+    atomic_add_f64(&uSource[3 * (size_t)c + 1], m * hy);
+    atomic_add_f64(&uSource[3 * (size_t)c + 2], m * hz);
+    F[0] = hx; F[1] = hy; F[2] = hz;
+    // stokesDragTorque FoamYade.C:446-453: wfluid = (zy - yz, zx - xz, yx - xy)
+    const double* G = vGrad + 9 * (size_t)c;
+    const double s1 = G[7] - G[5], s2 = G[6] - G[2], s3 = G[3] - G[1];
+    const double pd3 = M_PI * (pow(dia, 3.0));
+    F[3] = ((pd3 * (s1 - r[6])) * nu) * rhoF;
+    F[4] = ((pd3 * (s2 - r[7])) * nu) * rhoF;
+    F[5] = ((pd3 * (s3 - r[8])) * nu) * rhoF;
+}
+
+__global__ __launch_bounds__(256) void k_fill_f64(double* __restrict__ p, size_t n, double v) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// setSourceZero FoamYade.C:556-564
+__global__ __launch_bounds__(256) void k_set_source_zero(int32_t n_cells, int gaussian, double* __restrict__ uSourceDrag,
+                                                         double* __restrict__ alpha, double* __restrict__ uSource,
+                                                         double* __restrict__ uParticle) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= n_cells) return;
+    double* s = uSource + 3 * (size_t)c;
+    s[0] = 0.0; s[1] = 0.0; s[2] = 0.0;
+    if (gaussian) {
+        alpha[c] = 1.0;
+        uSourceDrag[c] = 0.0;
+        double* u = uParticle + 3 * (size_t)c;
+        u[0] = 0.0; u[1] = 0.0; u[2] = 0.0;
+    }
+}
+
+#define FY_LAUNCH_CHECK()                                                                                     \
+    do {                                                                                                      \
+        hipError_t _e = hipGetLastError();                                                                    \
+        if (_e != hipSuccess) return fail(FY_ERR_HIP, "kernel launch failed: %s (%s:%d)", hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+}  // namespace
+
+int launch_bin_count(hipStream_t s, const double* rec, int64_t n, BinGrid g, uint32_t* key, uint32_t* rank, uint32_t* hist) {
+    if (n <= 0) return FY_OK;
+    hipLaunchKernelGGL(k_bin_count, dim3(div_up(n, 256)), dim3(256), 0, s, rec, n, g, key, rank, hist);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+
+int launch_exclusive_scan_u32(hipStream_t s, uint32_t* data, uint32_t n, uint32_t* block_sums) {
+    if (n == 0) return FY_OK;
+    const uint32_t nb = (n + 2047u) / 2048u;
+    hipLaunchKernelGGL(k_scan_tiles, dim3(nb), dim3(256), 0, s, data, n, block_sums);
+    FY_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, s, block_sums, nb);
+    FY_LAUNCH_CHECK();
+    return FY_OK;   // the tile offsets stay separate: consumers add block_sums[i >> 11]
+}
+
+int launch_bin_scatter(hipStream_t s, const double* rec, int64_t n, const uint32_t* key, const uint32_t* rank,
+                       const uint32_t* start, const uint32_t* tile_off, ParticleSoA p) {
+    if (n <= 0) return FY_OK;
+    hipLaunchKernelGGL(k_bin_scatter, dim3(div_up(n, 256)), dim3(256), 0, s, rec, n, key, rank, start, tile_off, p);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+
+int launch_locate_deposit(hipStream_t s, const KdNode* tree, int32_t n_cells, int levels, const double* /*centres*/,
+                          ParticleSoA p, int64_t n, GaussParams gp, double* pvol_acc, double* up_acc, unsigned char* touched) {
+    if (n <= 0) return FY_OK;
+    const size_t lds = (size_t)(levels + 1) * kWave * sizeof(uint4);
+    hipLaunchKernelGGL(k_locate_deposit, dim3(div_up(n, kWave)), dim3(kWave), lds, s, tree, n_cells, p, n, gp, pvol_acc, up_acc, touched);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+
+int launch_finalize_cells(hipStream_t s, int32_t n_cells, const double* vol, double* pvol_acc, double* up_acc,
+                          unsigned char* touched, double* alpha, double* uParticle) {
+    hipLaunchKernelGGL(k_finalize_cells, dim3(div_up(n_cells, 256)), dim3(256), 0, s, n_cells, vol, pvol_acc, up_acc, touched, alpha, uParticle);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+
+int launch_force_gaussian(hipStream_t s, ParticleSoA p, int64_t n, ForceParams fp, const double* vol, const double* U,
+                          const double* alpha, const double* uParticle, const double* gradP, const double* divT,
+                          double* uSourceDrag, double* uSource, double* force_out, int32_t* found_out) {
+    if (n <= 0) return FY_OK;
+    hipLaunchKernelGGL(k_force_gaussian, dim3(div_up(n, 256)), dim3(256), 0, s, p, n, fp, vol, U, alpha, uParticle, gradP, divT,
+                       uSourceDrag, uSource, force_out, found_out);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+
+int launch_unpack_stencils(hipStream_t s, ParticleSoA p, int64_t n, int32_t* k, int32_t* ids, double* w, int32_t* chain) {
+    if (n <= 0) return FY_OK;
+    hipLaunchKernelGGL(k_unpack_stencils, dim3(div_up(n, 256)), dim3(256), 0, s, p, n, k, ids, w, chain);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+
+int launch_point_force(hipStream_t s, const double* rec, int64_t n, BlockGeom g, ForceParams fp, const double* vol,
+                       const double* U, const double* vGrad, double* uSource, double* force_out, int32_t* found_out,
+                       int32_t* incell_out) {
+    if (n <= 0) return FY_OK;
+    hipLaunchKernelGGL(k_point_force, dim3(div_up(n, 256)), dim3(256), 0, s, rec, n, g, fp, vol, U, vGrad, uSource, force_out, found_out, incell_out);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+
+int launch_fill_f64(hipStream_t s, double* p, size_t n, double v) {
+    if (n == 0) return FY_OK;
+    hipLaunchKernelGGL(k_fill_f64, dim3(div_up(n, 256)), dim3(256), 0, s, p, n, v);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+
+int launch_set_source_zero(hipStream_t s, int32_t n_cells, int gaussian, double* uSourceDrag, double* alpha, double* uSource,
+                           double* uParticle) {
+    hipLaunchKernelGGL(k_set_source_zero, dim3(div_up(n_cells, 256)), dim3(256), 0, s, n_cells, gaussian, uSourceDrag, alpha, uSource, uParticle);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+
+}  // namespace fy

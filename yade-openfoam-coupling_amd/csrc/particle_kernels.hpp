@@ -1,0 +1,72 @@
+// Launchers of the particle-half HIP kernels (bin -> locate+weights+deposit -> finalize -> force+scatter).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "kdtree.hpp"
+
+namespace fy {
+
+constexpr int kMaxK = 16;          // stencil slots kept per particle (reference nominal bound 12, observed max 14)
+
+// spatial binning grid used only to give waves spatially coherent particles (results do not depend on it)
+struct BinGrid {
+    double ox, oy, oz, inv_h;      // bin = floor((p - o) * inv_h), clamped
+    int nbx, nby, nbz;             // bins per axis
+    int bx4, by4;                  // bricks (4x4x4 bins) per axis in x and y
+    uint32_t nkeys;                // padded key space
+};
+
+struct GaussParams {
+    double maxdist;                // 1.25 * range^2            meshTree.C:155
+    double two_sigma2;             // 2 * pow(sigmaInterp, 2)   FoamYade.C:308
+    double range_cu;               // interpRangeCu             FoamYade.C:71
+    double sigma_pi;               // sigmaPi                   FoamYade.C:72
+};
+
+struct ForceParams {
+    double rhoF, nu, small;        // FoamYade.H:67,83-85
+};
+
+// sorted SoA particle arrays + per-particle stencil storage for one batch
+struct ParticleSoA {
+    double *px, *py, *pz, *vx, *vy, *vz, *rad;
+    int32_t* orig;                 // original (wire) index
+    int32_t* chain_len;            // pushes into the improvement chain (k = min(chain_len, 16))
+    int32_t* ids;                  // [16][cap]  chain order, slot = push index & 15
+    double* w;                     // [16][cap]  normalised weights, same slots
+    size_t cap;                    // leading dimension
+};
+
+int launch_bin_count(hipStream_t s, const double* rec, int64_t n, BinGrid g, uint32_t* key, uint32_t* rank, uint32_t* hist);
+int launch_exclusive_scan_u32(hipStream_t s, uint32_t* data, uint32_t n, uint32_t* block_sums /* >= ceil(n/2048)+1 */);
+// after the scan `data` holds tile-local exclusive offsets and `block_sums` the exclusive tile offsets:
+// start(key) = data[key] + block_sums[key >> 11]
+int launch_bin_scatter(hipStream_t s, const double* rec, int64_t n, const uint32_t* key, const uint32_t* rank,
+                       const uint32_t* start, const uint32_t* tile_off, ParticleSoA p);
+
+int launch_locate_deposit(hipStream_t s, const KdNode* tree, int32_t n_cells, int levels, const double* centres,
+                          ParticleSoA p, int64_t n, GaussParams gp, double* pvol_acc, double* up_acc,
+                          unsigned char* touched);
+int launch_finalize_cells(hipStream_t s, int32_t n_cells, const double* vol, double* pvol_acc, double* up_acc,
+                          unsigned char* touched, double* alpha, double* uParticle);
+int launch_force_gaussian(hipStream_t s, ParticleSoA p, int64_t n, ForceParams fp, const double* vol, const double* U,
+                          const double* alpha, const double* uParticle, const double* gradP, const double* divT,
+                          double* uSourceDrag, double* uSource, double* force_out, int32_t* found_out);
+int launch_unpack_stencils(hipStream_t s, ParticleSoA p, int64_t n, int32_t* k, int32_t* ids, double* w, int32_t* chain);
+
+// point-force mode (icoFoamYade): findCell on the uniform block + Stokes drag/torque + source scatter
+struct BlockGeom {
+    double bbmin[3], bbmax[3], dx;
+    int nx, ny, nz;
+};
+int launch_point_force(hipStream_t s, const double* rec, int64_t n, BlockGeom g, ForceParams fp, const double* vol,
+                       const double* U, const double* vGrad, double* uSource, double* force_out, int32_t* found_out,
+                       int32_t* incell_out);
+
+int launch_fill_f64(hipStream_t s, double* p, size_t n, double v);
+int launch_set_source_zero(hipStream_t s, int32_t n_cells, int gaussian, double* uSourceDrag, double* alpha,
+                           double* uSource, double* uParticle);
+
+}  // namespace fy
