@@ -164,6 +164,20 @@ def _i(a):
     return a.ctypes.data_as(_ip)
 
 
+def _is_device(a):
+    return hasattr(a, "data_ptr")        # a torch tensor: used purely as an HBM allocation
+
+
+def _fptr(a):
+    """numpy array -> host pointer; CUDA/HIP torch tensor (float64, contiguous) -> device pointer"""
+    if a is None:
+        return None
+    if _is_device(a):
+        assert a.is_cuda and a.is_contiguous() and a.element_size() == 8
+        return C.cast(C.c_void_p(a.data_ptr()), _dp)
+    return _d(a)
+
+
 class BlockMesh:
     """what FoamYade reads from fvMesh, for a uniform hex block in blockMesh order (cell = i + nx*(j + ny*k))."""
 
@@ -200,12 +214,12 @@ class FoamYade:
         L = lib()
         self._keep = [mesh, U, gradP, vGrad, divT, ddtU, uSourceDrag, alpha, uSource, uParticle, transport]
         f = FieldPtrs()
-        f.location = FY_MEM_HOST
-        f.U, f.gradP, f.vGrad, f.divT = _d(U), _d(gradP), _d(vGrad), _d(divT)
-        f.ddtU = _d(ddtU) if ddtU is not None else None
+        f.location = FY_MEM_DEVICE if _is_device(U) else FY_MEM_HOST
+        f.U, f.gradP, f.vGrad, f.divT = _fptr(U), _fptr(gradP), _fptr(vGrad), _fptr(divT)
+        f.ddtU = _fptr(ddtU)
         for q in range(3):
             f.g[q] = float(g[q])
-        f.uSourceDrag, f.alpha, f.uSource, f.uParticle = _d(uSourceDrag), _d(alpha), _d(uSource), _d(uParticle)
+        f.uSourceDrag, f.alpha, f.uSource, f.uParticle = _fptr(uSourceDrag), _fptr(alpha), _fptr(uSource), _fptr(uParticle)
         self._h = C.c_void_p()
         self.mesh = mesh
         self.gaussian = bool(gaussianInterp)
@@ -234,6 +248,18 @@ class FoamYade:
             rec = np.ascontiguousarray(rec, dtype=np.float64).reshape(-1, 10)
             _check(L.fy_set_particles_host(self._h, b, _d(rec), rec.shape[0]))
             self._batch_n.append(rec.shape[0])
+
+    def setParticlesDevice(self, batches):
+        """batches: list of CUDA/HIP float64 tensors (n,10) already resident in HBM (borrowed, not copied)."""
+        L = lib()
+        _check(L.fy_set_num_batches(self._h, len(batches)))
+        self._batch_n = []
+        self._keep_rec = list(batches)
+        for b, rec in enumerate(batches):
+            assert rec.is_cuda and rec.is_contiguous() and rec.element_size() == 8
+            n = rec.numel() // 10
+            _check(L.fy_set_particles_device(self._h, b, C.c_void_p(rec.data_ptr()), n))
+            self._batch_n.append(n)
 
     def forces(self, batch=0):
         n = self._batch_n[batch]
