@@ -1,0 +1,741 @@
+// ORACLE / TEST INFRASTRUCTURE ONLY.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this.
+//
+// CPU restatement of the FV half of the hot path: the loop bodies of icoFoamYade (icoFoamYade/icoFoamYade.C:65-149)
+// and pimpleFoamYade (pimpleFoamYade/pimpleFoamYade.C:60-114, UcEqn.H:3-33, pEqn.H:1-50, CourantNo.H:32-49,
+// continuityErrs.H:32-46) on a uniform hex block (blockMesh order, cell = i + nx*(j + ny*k)).
+//
+// PARITY UNPINNED.  The control flow above is the reference's, but every operator it calls (fvm::ddt/div/laplacian/Sp,
+// fvc::grad/div/flux/interpolate/reconstruct/ddtCorr, fvMatrix::A/H/flux/relax/setReference, the linear solvers) lives
+// in OpenFOAM-6 (libfiniteVolume/libOpenFOAM; README.md:17, icoFoamYade/Make/options:12-19), which is not vendored in
+// /root/reference, not installed here, and the reference ships no case, test or golden data for it.  The operators are
+// restated from OpenFOAM-6's published semantics (Euler ddt, Gauss linear grad/div/laplacian on an orthogonal uniform
+// mesh, EulerDdtScheme::fvcDdtPhiCorr, fvMatrix::H/A/relax/setReference, lduMatrix L1-normalised residuals, PCG) and
+// validated by known-answer flows in tests/test_fv_oracle.py, never by comparison with OpenFOAM output.
+// Deliberate departures, all documented in DESIGN.md: momentum equations are solved with Jacobi sweeps instead of
+// symGaussSeidel, pressure with PCG + geometric multigrid (or Jacobi) instead of DIC/GAMG -- sequential sweeps do not map
+// to a GPU, and the same algorithm on both sides lets tests compare CPU and GPU fields tightly.
+//
+// Conventions: face arrays are +axis oriented; phi_x has (nx+1)*ny*nz entries (face i between cells i-1 and i), etc.
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+extern "C" {
+// must match oracle.py FvCase
+struct orc_fv_case {
+    int solver;                  // 0 ico, 1 pimple
+    int nx, ny, nz;
+    double dx;
+    double origin[3];
+    double dt, nu, rho_fluid, rho_particle;
+    double g[3];
+    int u_bc[6];                 // 0 fixedValue, 1 zeroGradient
+    double u_value[6][3];
+    int p_bc[6];                 // 0 zeroGradient, 1 fixedValue, 2 fixedFluxPressure
+    double p_value[6];
+    int n_outer, n_corr, n_non_orth, momentum_predictor;
+    int p_ref_cell; double p_ref_value;
+    int p_solver;                // 0 PCG+Jacobi, 1 PCG+MG
+    double p_tol, p_rel_tol, p_final_tol, p_final_rel_tol; int p_max_iter;
+    double u_tol, u_rel_tol; int u_max_iter;
+};
+struct orc_fv_stats {
+    double courant_mean, courant_max, cont_sum_local, cont_global, cont_cumulative;
+    int p_iters_total, p_solves, u_iters_total;
+    double p_initial_residual, p_final_residual;
+};
+}
+
+namespace {
+
+typedef std::vector<double> vec;
+const double SMALL = 1e-15;      // OpenFOAM `small` for double
+const double VSMALL = 1e-300;
+
+struct MgLevel {
+    int nx, ny, nz, N;
+    vec diag, ux, uy, uz;        // symmetric 7-point: (A x)_c = diag_c x_c - sum_f u_f x_nb ; u_* stored at the owner (low) cell
+    vec x, b, r;
+};
+
+struct Fv {
+    orc_fv_case cs;
+    int nx, ny, nz, Nc, n[3], stride[3];
+    double dx, Af, V;
+    bool pimple;
+    int threads = 1;
+    // state
+    vec U, Uold, p, alpha, alphaOld, uSource, uSourceDrag, uParticle, gradP, divT, vGrad, ddtU;
+    vec phi[3], phiOld[3], psn[3];           // psn: d p / d axis on fixedFluxPressure boundary faces
+    // work
+    vec diag, an[6], src, rAU, HbyA, alphaf[3], phiHbyA[3], phiForces[3], rAUf[3], pflux[3], bmom, Sc, divG;
+    std::vector<MgLevel> mg;
+    vec pb, pr, pw, pp, pz;
+    orc_fv_stats st{};
+    double cumulativeContErr = 0.0;
+
+    int fsize(int d) const { return d == 0 ? (nx + 1) * ny * nz : d == 1 ? nx * (ny + 1) * nz : nx * ny * (nz + 1); }
+    inline int cid(int i, int j, int k) const { return i + nx * (j + ny * k); }
+    inline int fid(int d, int i, int j, int k) const {
+        return d == 0 ? i + (nx + 1) * (j + ny * k) : d == 1 ? i + nx * (j + (ny + 1) * k) : i + nx * (j + ny * k);
+    }
+    // face of cell (i,j,k) in direction d, side s (0 low, 1 high)
+    inline int cface(int d, int s, int i, int j, int k) const {
+        return fid(d, i + (d == 0 ? s : 0), j + (d == 1 ? s : 0), k + (d == 2 ? s : 0));
+    }
+    inline bool onb(int d, int s, int i, int j, int k) const {
+        const int q = d == 0 ? i : d == 1 ? j : k;
+        return s ? q == n[d] - 1 : q == 0;
+    }
+
+    void init(const orc_fv_case& c) {
+        cs = c; nx = c.nx; ny = c.ny; nz = c.nz; Nc = nx * ny * nz; dx = c.dx; Af = dx * dx; V = dx * dx * dx;
+        n[0] = nx; n[1] = ny; n[2] = nz; stride[0] = 1; stride[1] = nx; stride[2] = nx * ny;
+        pimple = c.solver == 1;
+        U.assign(3 * (size_t)Nc, 0.0); Uold = U; p.assign(Nc, 0.0); alpha.assign(Nc, 1.0); alphaOld = alpha;
+        uSource.assign(3 * (size_t)Nc, 0.0); uSourceDrag.assign(Nc, 0.0); uParticle.assign(3 * (size_t)Nc, 0.0);
+        gradP.assign(3 * (size_t)Nc, 0.0); divT.assign(3 * (size_t)Nc, 0.0); vGrad.assign(9 * (size_t)Nc, 0.0); ddtU.assign(3 * (size_t)Nc, 0.0);
+        for (int d = 0; d < 3; ++d) {
+            phi[d].assign(fsize(d), 0.0); phiOld[d] = phi[d]; psn[d].assign(fsize(d), 0.0);
+            alphaf[d].assign(fsize(d), 1.0); phiHbyA[d].assign(fsize(d), 0.0); phiForces[d].assign(fsize(d), 0.0);
+            rAUf[d].assign(fsize(d), 0.0); pflux[d].assign(fsize(d), 0.0);
+        }
+        diag.assign(Nc, 0.0); for (auto& a : an) a.assign(Nc, 0.0);
+        src.assign(3 * (size_t)Nc, 0.0); rAU.assign(Nc, 0.0); HbyA.assign(3 * (size_t)Nc, 0.0); bmom.assign(3 * (size_t)Nc, 0.0);
+        Sc.assign(Nc, 0.0); divG.assign(3 * (size_t)Nc, 0.0);
+        pb.assign(Nc, 0.0); pr = pb; pw = pb; pp = pb; pz = pb;
+        build_mg_shapes();
+        // createPhi: phi = linearInterpolate(U) & Sf (icoFoamYade/createFields.H:151, pimpleFoamYade/createFields.H:70-81)
+        flux_of(U, phi);
+    }
+
+    // ---- boundary values ----------------------------------------------------------------------------------
+    inline void Ub(const vec& F, int c, int patch, double* out) const {          // velocity-like field with U's BCs
+        if (cs.u_bc[patch] == 0) { out[0] = cs.u_value[patch][0]; out[1] = cs.u_value[patch][1]; out[2] = cs.u_value[patch][2]; }
+        else { out[0] = F[3 * (size_t)c]; out[1] = F[3 * (size_t)c + 1]; out[2] = F[3 * (size_t)c + 2]; }
+    }
+    inline double pbv(int c, int d, int s, int face) const {                     // boundary value of p
+        const int patch = 2 * d + s;
+        if (cs.p_bc[patch] == 1) return cs.p_value[patch];
+        if (cs.p_bc[patch] == 2) return p[c] + (s ? 0.5 : -0.5) * dx * psn[d][face];
+        return p[c];
+    }
+    bool need_reference() const { for (int q = 0; q < 6; ++q) if (cs.p_bc[q] == 1) return false; return true; }
+
+    // fvc::flux(F) = linearInterpolate(F) & Sf, boundary value from U's BCs (used for U and HbyA)
+    void flux_of(const vec& F, vec* out) const {
+        for (int d = 0; d < 3; ++d)
+            for (int k = 0; k < nz + (d == 2); ++k) for (int j = 0; j < ny + (d == 1); ++j) for (int i = 0; i < nx + (d == 0); ++i) {
+                const int q = d == 0 ? i : d == 1 ? j : k;
+                const int f = fid(d, i, j, k);
+                double v;
+                if (q == 0) { double b[3]; Ub(F, cid(i, j, k), 2 * d, b); v = b[d]; }
+                else if (q == n[d]) { double b[3]; const int c = cid(i - (d == 0), j - (d == 1), k - (d == 2)); Ub(F, c, 2 * d + 1, b); v = b[d]; }
+                else { const int c = cid(i, j, k); v = 0.5 * (F[3 * (size_t)(c - stride[d]) + d] + F[3 * (size_t)c + d]); }
+                out[d][f] = v * Af;
+            }
+    }
+
+    // fvc::grad(p), Gauss linear
+    void grad_p(vec& G) const {
+#pragma omp parallel for num_threads(threads) collapse(2)
+        for (int k = 0; k < nz; ++k) for (int j = 0; j < ny; ++j) for (int i = 0; i < nx; ++i) {
+            const int c = cid(i, j, k);
+            for (int d = 0; d < 3; ++d) {
+                double fv[2];
+                for (int s = 0; s < 2; ++s) {
+                    if (onb(d, s, i, j, k)) fv[s] = pbv(c, d, s, cface(d, s, i, j, k));
+                    else fv[s] = 0.5 * (p[c] + p[c + (s ? stride[d] : -stride[d])]);
+                }
+                G[3 * (size_t)c + d] = (fv[1] - fv[0]) / dx;
+            }
+        }
+    }
+
+    // fvc::grad(U): T[3*i + j] = d_i U_j  (row-major xx xy xz ...), Gauss linear
+    void grad_U(const vec& F, vec& T) const {
+#pragma omp parallel for num_threads(threads) collapse(2)
+        for (int k = 0; k < nz; ++k) for (int j = 0; j < ny; ++j) for (int i = 0; i < nx; ++i) {
+            const int c = cid(i, j, k);
+            for (int d = 0; d < 3; ++d) {
+                double fv[2][3];
+                for (int s = 0; s < 2; ++s) {
+                    if (onb(d, s, i, j, k)) Ub(F, c, 2 * d + s, fv[s]);
+                    else { const int nb = c + (s ? stride[d] : -stride[d]); for (int q = 0; q < 3; ++q) fv[s][q] = 0.5 * (F[3 * (size_t)c + q] + F[3 * (size_t)nb + q]); }
+                }
+                for (int q = 0; q < 3; ++q) T[9 * (size_t)c + 3 * d + q] = (fv[1][q] - fv[0][q]) / dx;
+            }
+        }
+    }
+
+    // alphacf = fvc::interpolate(alphac) (pimpleFoamYade.C:84); boundary value 1 (calculated patch, set by `alpha = 1.0`, FoamYade.C:68)
+    void interp_alpha() {
+        for (int d = 0; d < 3; ++d)
+            for (int k = 0; k < nz + (d == 2); ++k) for (int j = 0; j < ny + (d == 1); ++j) for (int i = 0; i < nx + (d == 0); ++i) {
+                const int q = d == 0 ? i : d == 1 ? j : k;
+                const int f = fid(d, i, j, k);
+                if (q == 0 || q == n[d]) alphaf[d][f] = 1.0;
+                else { const int c = cid(i, j, k); alphaf[d][f] = 0.5 * (alpha[c - stride[d]] + alpha[c]); }
+            }
+    }
+
+    // CourantNo.H:32-49 (pimple) / OpenFOAM CourantNo.H (ico, icoFoamYade.C:68)
+    void courant() {
+        double mx = 0.0, sum = 0.0;
+        for (int k = 0; k < nz; ++k) for (int j = 0; j < ny; ++j) for (int i = 0; i < nx; ++i) {
+            double s = 0.0;
+            for (int d = 0; d < 3; ++d) for (int sd = 0; sd < 2; ++sd) s += std::fabs(phi[d][cface(d, sd, i, j, k)]);
+            mx = std::max(mx, s / V); sum += s;
+        }
+        st.courant_max = 0.5 * mx * cs.dt;
+        st.courant_mean = 0.5 * (sum / (V * Nc)) * cs.dt;
+    }
+
+    // pre-coupling fields, pimpleFoamYade.C:73-76: gradP = grad(p); divT = 2 nu laplacian(alphac, Uc); vGrad = grad(Uc)
+    void pre_coupling_fields() {
+        grad_U(U, vGrad);                                   // icoFoamYade.C:71 / pimpleFoamYade.C:76
+        if (!pimple) return;
+        grad_p(gradP);
+        interp_alpha();                                     // alphac is 1 here (reset by setSourceZero), kept general
+#pragma omp parallel for num_threads(threads) collapse(2)
+        for (int k = 0; k < nz; ++k) for (int j = 0; j < ny; ++j) for (int i = 0; i < nx; ++i) {
+            const int c = cid(i, j, k);
+            double acc[3] = {0, 0, 0};
+            for (int d = 0; d < 3; ++d) for (int s = 0; s < 2; ++s) {
+                const double af = alphaf[d][cface(d, s, i, j, k)];
+                if (onb(d, s, i, j, k)) {
+                    double b[3]; Ub(U, c, 2 * d + s, b);
+                    for (int q = 0; q < 3; ++q) acc[q] += af * Af * (b[q] - U[3 * (size_t)c + q]) / (0.5 * dx);
+                } else {
+                    const int nb = c + (s ? stride[d] : -stride[d]);
+                    for (int q = 0; q < 3; ++q) acc[q] += af * Af * (U[3 * (size_t)nb + q] - U[3 * (size_t)c + q]) / dx;
+                }
+            }
+            for (int q = 0; q < 3; ++q) divT[3 * (size_t)c + q] = 2 * cs.nu * (acc[q] / V);
+        }
+    }
+
+    // ---- momentum matrix ------------------------------------------------------------------------------------
+    // ico:    fvm::ddt(U) + fvm::div(phi,U) - fvm::laplacian(nu,U) == uSource                      (icoFoamYade.C:79-85)
+    // pimple: fvm::ddt(a,Uc) + fvm::div(aPhi,Uc) - fvm::Sp(fvc::ddt(a)+fvc::div(aPhi),Uc) + divDevRhoReff(Uc) == fvm::Sp(uSourceDrag,Uc)
+    //                                                                                              (UcEqn.H:3-10), then relax() (UcEqn.H:12)
+    // an[2*d+s] = coefficient of the neighbour across face (d,s); src excludes any pressure term.
+    void assemble_momentum() {
+        const double nu = cs.nu, dt = cs.dt;
+        if (pimple) {
+            // explicit part of divDevRhoReff: + fvc::div(alpha nu dev2(T(grad U))) on the RHS (laminar Stokes model)
+            grad_U(U, vGrad);
+            vec G(9 * (size_t)Nc);
+            for (int c = 0; c < Nc; ++c) {
+                const double* T = &vGrad[9 * (size_t)c];
+                const double tr = T[0] + T[4] + T[8];
+                for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b)
+                    G[9 * (size_t)c + 3 * a + b] = alpha[c] * nu * (T[3 * b + a] - (a == b ? (2.0 / 3.0) * tr : 0.0));
+            }
+#pragma omp parallel for num_threads(threads) collapse(2)
+            for (int k = 0; k < nz; ++k) for (int j = 0; j < ny; ++j) for (int i = 0; i < nx; ++i) {
+                const int c = cid(i, j, k);
+                double acc[3] = {0, 0, 0};
+                for (int d = 0; d < 3; ++d) {
+                    double fv[2][3];
+                    for (int s = 0; s < 2; ++s) {
+                        if (onb(d, s, i, j, k)) for (int q = 0; q < 3; ++q) fv[s][q] = G[9 * (size_t)c + 3 * d + q];
+                        else { const int nb = c + (s ? stride[d] : -stride[d]); for (int q = 0; q < 3; ++q) fv[s][q] = 0.5 * (G[9 * (size_t)c + 3 * d + q] + G[9 * (size_t)nb + 3 * d + q]); }
+                    }
+                    for (int q = 0; q < 3; ++q) acc[q] += (fv[1][q] - fv[0][q]) / dx;
+                }
+                for (int q = 0; q < 3; ++q) divG[3 * (size_t)c + q] = acc[q];
+            }
+        }
+#pragma omp parallel for num_threads(threads) collapse(2)
+        for (int k = 0; k < nz; ++k) for (int j = 0; j < ny; ++j) for (int i = 0; i < nx; ++i) {
+            const int c = cid(i, j, k);
+            const double aP = pimple ? alpha[c] : 1.0, aP0 = pimple ? alphaOld[c] : 1.0;
+            double dg = aP * V / dt;                                         // fvm::ddt
+            double s3[3];
+            for (int q = 0; q < 3; ++q) s3[q] = aP0 * V * Uold[3 * (size_t)c + q] / dt;
+            double divAPhi = 0.0;
+            for (int d = 0; d < 3; ++d) for (int s = 0; s < 2; ++s) {
+                const int f = cface(d, s, i, j, k);
+                const double af = pimple ? alphaf[d][f] : 1.0;
+                const double phio = (s ? 1.0 : -1.0) * af * phi[d][f];       // outward (alpha-weighted) flux
+                divAPhi += phio;
+                const double gam = nu * af * dx;                             // (alpha nu)_f |Sf| / |d|
+                if (onb(d, s, i, j, k)) {
+                    an[2 * d + s][c] = 0.0;
+                    const int patch = 2 * d + s;
+                    if (cs.u_bc[patch] == 0) {                               // fixedValue
+                        const double gb = 2.0 * gam;
+                        dg += gb;
+                        for (int q = 0; q < 3; ++q) s3[q] += (-phio + gb) * cs.u_value[patch][q];
+                    } else {                                                 // zeroGradient
+                        dg += phio;
+                    }
+                } else {
+                    dg += 0.5 * phio + gam;
+                    an[2 * d + s][c] = 0.5 * phio - gam;
+                }
+            }
+            if (pimple) {
+                const double S = (alpha[c] - alphaOld[c]) / dt + divAPhi / V;   // fvc::ddt(alphac) + fvc::div(alphaPhic)
+                Sc[c] = S;
+                dg -= V * S;                                                 // - fvm::Sp(S, Uc)
+                dg -= V * uSourceDrag[c];                                    // == fvm::Sp(uSourceDrag, Uc)
+                for (int q = 0; q < 3; ++q) s3[q] += V * divG[3 * (size_t)c + q];
+            } else {
+                for (int q = 0; q < 3; ++q) s3[q] += V * uSource[3 * (size_t)c + q];   // == uSource
+            }
+            if (pimple) {
+                // fvMatrix::relax(1): enforce diagonal dominance, D = max(|D|, sum|offdiag|), source += (D_new - D_old) psi
+                double so = 0.0; for (int q = 0; q < 6; ++q) so += std::fabs(an[q][c]);
+                const double dn = std::max(std::fabs(dg), so);
+                for (int q = 0; q < 3; ++q) s3[q] += (dn - dg) * U[3 * (size_t)c + q];
+                dg = dn;
+            }
+            diag[c] = dg;
+            for (int q = 0; q < 3; ++q) src[3 * (size_t)c + q] = s3[q];
+            rAU[c] = 1.0 / (dg / V);                                         // 1/UEqn.A()
+        }
+    }
+
+    // lduMatrix residual normalisation: sum(|A psi - A xbar| + |b - A xbar|) + 1e-20
+    // Jacobi solve of diag*x + sum an*x_nb = b for the 3 components (stand-in for smoothSolver symGaussSeidel)
+    int solve_momentum(const vec& b) {
+        vec x = U, xn(3 * (size_t)Nc), Ax(3 * (size_t)Nc);
+        auto apply = [&](const vec& v, vec& out) {
+#pragma omp parallel for num_threads(threads) collapse(2)
+            for (int k = 0; k < nz; ++k) for (int j = 0; j < ny; ++j) for (int i = 0; i < nx; ++i) {
+                const int c = cid(i, j, k);
+                double acc[3] = {diag[c] * v[3 * (size_t)c], diag[c] * v[3 * (size_t)c + 1], diag[c] * v[3 * (size_t)c + 2]};
+                for (int d = 0; d < 3; ++d) for (int s = 0; s < 2; ++s) if (!onb(d, s, i, j, k)) {
+                    const int nb = c + (s ? stride[d] : -stride[d]); const double a = an[2 * d + s][c];
+                    for (int q = 0; q < 3; ++q) acc[q] += a * v[3 * (size_t)nb + q];
+                }
+                for (int q = 0; q < 3; ++q) out[3 * (size_t)c + q] = acc[q];
+            }
+        };
+        double norm[3], res0[3] = {0, 0, 0};
+        {
+            double xbar[3] = {0, 0, 0};
+            for (int c = 0; c < Nc; ++c) for (int q = 0; q < 3; ++q) xbar[q] += x[3 * (size_t)c + q];
+            for (int q = 0; q < 3; ++q) xbar[q] /= Nc;
+            apply(x, Ax);
+            vec ones(3 * (size_t)Nc); for (int c = 0; c < Nc; ++c) for (int q = 0; q < 3; ++q) ones[3 * (size_t)c + q] = xbar[q];
+            vec Aref(3 * (size_t)Nc); apply(ones, Aref);
+            for (int q = 0; q < 3; ++q) { norm[q] = 0; }
+            for (int c = 0; c < Nc; ++c) for (int q = 0; q < 3; ++q) {
+                const size_t e = 3 * (size_t)c + q;
+                norm[q] += std::fabs(Ax[e] - Aref[e]) + std::fabs(b[e] - Aref[e]);
+                res0[q] += std::fabs(b[e] - Ax[e]);
+            }
+            for (int q = 0; q < 3; ++q) { norm[q] += 1e-20; res0[q] /= norm[q]; }
+        }
+        auto conv = [&](const double* r) {
+            for (int q = 0; q < 3; ++q) if (!(r[q] < cs.u_tol || (cs.u_rel_tol > 0 && r[q] < cs.u_rel_tol * res0[q]))) return false;
+            return true;
+        };
+        int it = 0;
+        double res[3] = {res0[0], res0[1], res0[2]};
+        while (!conv(res) && it < cs.u_max_iter) {
+#pragma omp parallel for num_threads(threads) collapse(2)
+            for (int k = 0; k < nz; ++k) for (int j = 0; j < ny; ++j) for (int i = 0; i < nx; ++i) {
+                const int c = cid(i, j, k);
+                double acc[3] = {b[3 * (size_t)c], b[3 * (size_t)c + 1], b[3 * (size_t)c + 2]};
+                for (int d = 0; d < 3; ++d) for (int s = 0; s < 2; ++s) if (!onb(d, s, i, j, k)) {
+                    const int nb = c + (s ? stride[d] : -stride[d]); const double a = an[2 * d + s][c];
+                    for (int q = 0; q < 3; ++q) acc[q] -= a * x[3 * (size_t)nb + q];
+                }
+                for (int q = 0; q < 3; ++q) xn[3 * (size_t)c + q] = acc[q] / diag[c];
+            }
+            x.swap(xn);
+            ++it;
+            apply(x, Ax);
+            for (int q = 0; q < 3; ++q) res[q] = 0;
+            for (int c = 0; c < Nc; ++c) for (int q = 0; q < 3; ++q) res[q] += std::fabs(b[3 * (size_t)c + q] - Ax[3 * (size_t)c + q]);
+            for (int q = 0; q < 3; ++q) res[q] /= norm[q];
+        }
+        U = x;
+        return it;
+    }
+
+    // H() / V and HbyA = rAU * H with constrainHbyA (icoFoamYade.C:99-100, pEqn.H:2)
+    void compute_HbyA() {
+#pragma omp parallel for num_threads(threads) collapse(2)
+        for (int k = 0; k < nz; ++k) for (int j = 0; j < ny; ++j) for (int i = 0; i < nx; ++i) {
+            const int c = cid(i, j, k);
+            double acc[3] = {src[3 * (size_t)c], src[3 * (size_t)c + 1], src[3 * (size_t)c + 2]};
+            for (int d = 0; d < 3; ++d) for (int s = 0; s < 2; ++s) if (!onb(d, s, i, j, k)) {
+                const int nb = c + (s ? stride[d] : -stride[d]); const double a = an[2 * d + s][c];
+                for (int q = 0; q < 3; ++q) acc[q] -= a * U[3 * (size_t)nb + q];
+            }
+            for (int q = 0; q < 3; ++q) HbyA[3 * (size_t)c + q] = rAU[c] * (acc[q] / V);
+        }
+    }
+
+    // rAUf = interpolate(rAU) (boundary: extrapolated cell value); pimple keeps rAUcf separately from alphacf
+    void interp_rAU() {
+        for (int d = 0; d < 3; ++d)
+            for (int k = 0; k < nz + (d == 2); ++k) for (int j = 0; j < ny + (d == 1); ++j) for (int i = 0; i < nx + (d == 0); ++i) {
+                const int q = d == 0 ? i : d == 1 ? j : k;
+                const int f = fid(d, i, j, k);
+                if (q == 0) rAUf[d][f] = rAU[cid(i, j, k)];
+                else if (q == n[d]) rAUf[d][f] = rAU[cid(i - (d == 0), j - (d == 1), k - (d == 2))];
+                else { const int c = cid(i, j, k); rAUf[d][f] = 0.5 * (rAU[c - stride[d]] + rAU[c]); }
+            }
+    }
+
+    // phicForces = fvc::flux(rAUc*uSource) + rAUcf*(g & Sf)   (UcEqn.H:17-20); uSource's calculated boundary value is 0
+    void compute_phi_forces() {
+        for (int d = 0; d < 3; ++d)
+            for (int k = 0; k < nz + (d == 2); ++k) for (int j = 0; j < ny + (d == 1); ++j) for (int i = 0; i < nx + (d == 0); ++i) {
+                const int q = d == 0 ? i : d == 1 ? j : k;
+                const int f = fid(d, i, j, k);
+                double fl = 0.0;
+                if (q != 0 && q != n[d]) { const int c = cid(i, j, k), cm = c - stride[d]; fl = 0.5 * (rAU[cm] * uSource[3 * (size_t)cm + d] + rAU[c] * uSource[3 * (size_t)c + d]) * Af; }
+                phiForces[d][f] = fl + rAUf[d][f] * (cs.g[d] * Af);
+            }
+    }
+
+    // phiHbyA = fvc::flux(HbyA) + [alphacf*]rAUf*fvc::ddtCorr(U, phi) [+ phicForces]   (icoFoamYade.C:101-106, pEqn.H:4-18)
+    void compute_phiHbyA() {
+        flux_of(HbyA, phiHbyA);
+        const double rDt = 1.0 / cs.dt;
+        for (int d = 0; d < 3; ++d)
+            for (int k = 0; k < nz + (d == 2); ++k) for (int j = 0; j < ny + (d == 1); ++j) for (int i = 0; i < nx + (d == 0); ++i) {
+                const int q = d == 0 ? i : d == 1 ? j : k;
+                const int f = fid(d, i, j, k);
+                double uf;   // (Sf & U.oldTime()_f)
+                bool fixes = false;
+                if (q == 0) { const int patch = 2 * d; fixes = cs.u_bc[patch] == 0; double b[3]; Ub(Uold, cid(i, j, k), patch, b); uf = b[d] * Af; }
+                else if (q == n[d]) { const int patch = 2 * d + 1; fixes = cs.u_bc[patch] == 0; double b[3]; Ub(Uold, cid(i - (d == 0), j - (d == 1), k - (d == 2)), patch, b); uf = b[d] * Af; }
+                else { const int c = cid(i, j, k); uf = 0.5 * (Uold[3 * (size_t)(c - stride[d]) + d] + Uold[3 * (size_t)c + d]) * Af; }
+                const double phiCorr = phiOld[d][f] - uf;
+                // EulerDdtScheme::fvcDdtPhiCoeff: 1 - min(|phiCorr| / (|phi| + small), 1); 0 where U fixes the value
+                double coef = fixes ? 0.0 : 1.0 - std::min(std::fabs(phiCorr) / (std::fabs(phiOld[d][f]) + SMALL), 1.0);
+                double add = rAUf[d][f] * (coef * rDt * phiCorr);
+                if (pimple) add *= alphaf[d][f];
+                phiHbyA[d][f] += add;
+                if (pimple) phiHbyA[d][f] += phiForces[d][f];
+            }
+        // adjustPhi(phiHbyA, U, p): only the closed-domain / fixed-pressure-outlet cases are supported, where it is a no-op.
+        // constrainPressure for fixedFluxPressure patches: snGrad(p) = (phiHbyA - (Sf & U_b)) / (magSf * rAUf), so that the
+        // corrected boundary flux phiHbyA - rAUf |Sf| snGrad(p) equals Sf & U_b.
+        for (int d = 0; d < 3; ++d) for (int s = 0; s < 2; ++s) {
+            const int patch = 2 * d + s;
+            if (cs.p_bc[patch] != 2) continue;
+            const int q = s ? n[d] : 0;
+            const int e1 = d == 0 ? ny : nx, e2 = d == 2 ? ny : nz;
+            for (int b2 = 0; b2 < e2; ++b2) for (int b1 = 0; b1 < e1; ++b1) {
+                int i, j, k;
+                if (d == 0) { i = q; j = b1; k = b2; } else if (d == 1) { i = b1; j = q; k = b2; } else { i = b1; j = b2; k = q; }
+                const int f = fid(d, i, j, k);
+                const int c = cid(i - (d == 0 && s), j - (d == 1 && s), k - (d == 2 && s));
+                double ub[3]; Ub(U, c, patch, ub);
+                const double target = ub[d] * Af;
+                psn[d][f] = (phiHbyA[d][f] - target) / (rAUf[d][f] * Af);     // d p / d axis at the face
+            }
+        }
+    }
+
+    // ---- pressure matrix (SPD form): sum_f g_f (p_P - p_nb) [+ g_b (p_P - p_b)] = -(div term) -------------------
+    void assemble_pressure(MgLevel& L) {
+#pragma omp parallel for num_threads(threads) collapse(2)
+        for (int k = 0; k < nz; ++k) for (int j = 0; j < ny; ++j) for (int i = 0; i < nx; ++i) {
+            const int c = cid(i, j, k);
+            double dg = 0.0, rhs = 0.0;
+            for (int d = 0; d < 3; ++d) for (int s = 0; s < 2; ++s) {
+                const int f = cface(d, s, i, j, k);
+                const double af = pimple ? alphaf[d][f] : 1.0;
+                double ph = (s ? 1.0 : -1.0) * af * phiHbyA[d][f];
+                if (onb(d, s, i, j, k) && cs.p_bc[2 * d + s] == 2)           // fixed-gradient source of the laplacian
+                    ph = (s ? 1.0 : -1.0) * af * (phiHbyA[d][f] - rAUf[d][f] * Af * psn[d][f]);
+                rhs -= ph;
+                if (onb(d, s, i, j, k)) {
+                    const int patch = 2 * d + s;
+                    if (cs.p_bc[patch] == 1) { const double gb = 2.0 * af * rAUf[d][f] * dx; dg += gb; rhs += gb * cs.p_value[patch]; }
+                    if (s) (d == 0 ? L.ux : d == 1 ? L.uy : L.uz)[c] = 0.0;
+                } else {
+                    const double g = af * rAUf[d][f] * dx;
+                    dg += g;
+                    if (s) (d == 0 ? L.ux : d == 1 ? L.uy : L.uz)[c] = g;
+                }
+            }
+            if (pimple) rhs -= V * (alpha[c] - alphaOld[c]) / cs.dt;          // fvc::ddt(alphac), pEqn.H:30
+            L.diag[c] = dg; pb[c] = rhs;
+        }
+        if (need_reference()) {                                              // fvMatrix::setReference
+            const int c = cs.p_ref_cell;
+            pb[c] += L.diag[c] * cs.p_ref_value;
+            L.diag[c] += L.diag[c];
+        }
+    }
+
+    static void apply(const MgLevel& L, const vec& x, vec& y, int threads) {
+        const int nx = L.nx, ny = L.ny, nz = L.nz, sx = 1, sy = nx, sz = nx * ny;
+#pragma omp parallel for num_threads(threads) collapse(2)
+        for (int k = 0; k < nz; ++k) for (int j = 0; j < ny; ++j) for (int i = 0; i < nx; ++i) {
+            const int c = i + nx * (j + ny * k);
+            double a = L.diag[c] * x[c];
+            if (i > 0) a -= L.ux[c - sx] * x[c - sx];
+            if (i < nx - 1) a -= L.ux[c] * x[c + sx];
+            if (j > 0) a -= L.uy[c - sy] * x[c - sy];
+            if (j < ny - 1) a -= L.uy[c] * x[c + sy];
+            if (k > 0) a -= L.uz[c - sz] * x[c - sz];
+            if (k < nz - 1) a -= L.uz[c] * x[c + sz];
+            y[c] = a;
+        }
+    }
+
+    void build_mg_shapes() {
+        mg.clear();
+        int ax = nx, ay = ny, az = nz;
+        for (;;) {
+            MgLevel L; L.nx = ax; L.ny = ay; L.nz = az; L.N = ax * ay * az;
+            L.diag.assign(L.N, 0.0); L.ux = L.diag; L.uy = L.diag; L.uz = L.diag; L.x = L.diag; L.b = L.diag; L.r = L.diag;
+            mg.push_back(L);
+            if (cs.p_solver != 1) break;
+            if (L.N <= 256 || (ax <= 2 && ay <= 2 && az <= 2)) break;
+            ax = (ax + 1) / 2; ay = (ay + 1) / 2; az = (az + 1) / 2;
+        }
+    }
+
+    // A_coarse = 1/2 P^T A P with piecewise-constant P over 2x2x2 aggregates (the 1/2 makes it equal to re-discretisation)
+    void coarsen_operators() {
+        for (size_t l = 0; l + 1 < mg.size(); ++l) {
+            const MgLevel& F = mg[l]; MgLevel& Cc = mg[l + 1];
+            std::fill(Cc.diag.begin(), Cc.diag.end(), 0.0); std::fill(Cc.ux.begin(), Cc.ux.end(), 0.0);
+            std::fill(Cc.uy.begin(), Cc.uy.end(), 0.0); std::fill(Cc.uz.begin(), Cc.uz.end(), 0.0);
+            for (int k = 0; k < F.nz; ++k) for (int j = 0; j < F.ny; ++j) for (int i = 0; i < F.nx; ++i) {
+                const int c = i + F.nx * (j + F.ny * k);
+                const int I = i >> 1, J = j >> 1, K = k >> 1;
+                const int C = I + Cc.nx * (J + Cc.ny * K);
+                Cc.diag[C] += 0.5 * F.diag[c];
+                if (i < F.nx - 1) { if (((i + 1) >> 1) == I) Cc.diag[C] -= F.ux[c]; else Cc.ux[C] += 0.5 * F.ux[c]; }   // -2 * 0.5 * g for internal faces
+                if (j < F.ny - 1) { if (((j + 1) >> 1) == J) Cc.diag[C] -= F.uy[c]; else Cc.uy[C] += 0.5 * F.uy[c]; }
+                if (k < F.nz - 1) { if (((k + 1) >> 1) == K) Cc.diag[C] -= F.uz[c]; else Cc.uz[C] += 0.5 * F.uz[c]; }
+            }
+        }
+    }
+
+    static void jacobi(const MgLevel& L, vec& x, const vec& b, vec& tmp, int sweeps, bool zero_guess, int threads) {
+        const double w = 0.8;
+        for (int s = 0; s < sweeps; ++s) {
+            if (s == 0 && zero_guess) { for (int c = 0; c < L.N; ++c) x[c] = w * b[c] / L.diag[c]; continue; }
+            apply(L, x, tmp, threads);
+            for (int c = 0; c < L.N; ++c) x[c] += w * (b[c] - tmp[c]) / L.diag[c];
+        }
+    }
+
+    void vcycle(size_t l) {
+        MgLevel& L = mg[l];
+        if (l + 1 == mg.size()) { jacobi(L, L.x, L.b, L.r, 40, true, 1); return; }
+        jacobi(L, L.x, L.b, L.r, 2, true, threads);
+        vec& r = L.r;
+        apply(L, L.x, r, threads);
+        for (int c = 0; c < L.N; ++c) r[c] = L.b[c] - r[c];
+        MgLevel& Cc = mg[l + 1];
+        std::fill(Cc.b.begin(), Cc.b.end(), 0.0);
+        for (int k = 0; k < L.nz; ++k) for (int j = 0; j < L.ny; ++j) for (int i = 0; i < L.nx; ++i)
+            Cc.b[(i >> 1) + Cc.nx * ((j >> 1) + Cc.ny * (k >> 1))] += r[i + L.nx * (j + L.ny * k)];
+        vcycle(l + 1);
+        for (int k = 0; k < L.nz; ++k) for (int j = 0; j < L.ny; ++j) for (int i = 0; i < L.nx; ++i)
+            L.x[i + L.nx * (j + L.ny * k)] += Cc.x[(i >> 1) + Cc.nx * ((j >> 1) + Cc.ny * (k >> 1))];
+        jacobi(L, L.x, L.b, L.r, 2, false, threads);
+    }
+
+    void precondition(const vec& r, vec& z) {
+        MgLevel& L = mg[0];
+        if (cs.p_solver == 1) { L.b = r; vcycle(0); z = L.x; }
+        else for (int c = 0; c < Nc; ++c) z[c] = r[c] / L.diag[c];
+    }
+
+    // OpenFOAM PCG.C, with lduMatrix::solver normFactor; returns iterations
+    int solve_pressure(bool final_iter) {
+        MgLevel& L = mg[0];
+        const double tol = final_iter ? cs.p_final_tol : cs.p_tol, rel = final_iter ? cs.p_final_rel_tol : cs.p_rel_tol;
+        vec& wA = pw; vec& rA = pr; vec& pA = pp; vec& zA = pz;
+        apply(L, p, wA, threads);
+        double xbar = 0; for (int c = 0; c < Nc; ++c) xbar += p[c]; xbar /= Nc;
+        { vec ones(Nc, xbar); apply(L, ones, pA, threads); }
+        double norm = 0, res = 0;
+        for (int c = 0; c < Nc; ++c) { norm += std::fabs(wA[c] - pA[c]) + std::fabs(pb[c] - pA[c]); rA[c] = pb[c] - wA[c]; res += std::fabs(rA[c]); }
+        norm += 1e-20; res /= norm;
+        const double res0 = res;
+        st.p_initial_residual = res0;
+        int it = 0;
+        double wArAold = 1.0;
+        auto converged = [&](double r) { return r < tol || (rel > 0 && r < rel * res0); };
+        if (!converged(res)) {
+            do {
+                precondition(rA, zA);
+                double wArA = 0; for (int c = 0; c < Nc; ++c) wArA += zA[c] * rA[c];
+                if (it == 0) for (int c = 0; c < Nc; ++c) pA[c] = zA[c];
+                else { const double beta = wArA / wArAold; for (int c = 0; c < Nc; ++c) pA[c] = zA[c] + beta * pA[c]; }
+                apply(L, pA, wA, threads);
+                double wApA = 0; for (int c = 0; c < Nc; ++c) wApA += wA[c] * pA[c];
+                const double al = wArA / wApA;
+                res = 0;
+                for (int c = 0; c < Nc; ++c) { p[c] += al * pA[c]; rA[c] -= al * wA[c]; res += std::fabs(rA[c]); }
+                res /= norm;
+                wArAold = wArA;
+            } while (++it < cs.p_max_iter && !converged(res));
+        }
+        st.p_final_residual = res;
+        st.p_iters_total += it; st.p_solves += 1;
+        return it;
+    }
+
+    // pEqn.flux(): g_f (p_hi - p_lo), +axis oriented, incl. fixedValue boundaries; fixedFlux boundaries carry what removes the forcing
+    void pressure_flux(const MgLevel& L) {
+        for (int d = 0; d < 3; ++d)
+            for (int k = 0; k < nz + (d == 2); ++k) for (int j = 0; j < ny + (d == 1); ++j) for (int i = 0; i < nx + (d == 0); ++i) {
+                const int q = d == 0 ? i : d == 1 ? j : k;
+                const int f = fid(d, i, j, k);
+                const double af = pimple ? alphaf[d][f] : 1.0;
+                double fl = 0.0;
+                if (q == 0 || q == n[d]) {
+                    const int s = q == 0 ? 0 : 1, patch = 2 * d + s;
+                    const int c = cid(i - (d == 0 && s), j - (d == 1 && s), k - (d == 2 && s));
+                    if (cs.p_bc[patch] == 1) { const double gb = 2.0 * af * rAUf[d][f] * dx; fl = s ? gb * (cs.p_value[patch] - p[c]) : gb * (p[c] - cs.p_value[patch]); }
+                    else if (cs.p_bc[patch] == 2) fl = af * rAUf[d][f] * Af * psn[d][f];
+                } else {
+                    const int c = cid(i, j, k);
+                    fl = af * rAUf[d][f] * dx * (p[c] - p[c - stride[d]]);
+                }
+                pflux[d][f] = fl;
+            }
+    }
+
+    void continuity_errors() {
+        double sl = 0, gl = 0;
+        for (int k = 0; k < nz; ++k) for (int j = 0; j < ny; ++j) for (int i = 0; i < nx; ++i) {
+            const int c = cid(i, j, k);
+            double dv = 0;
+            for (int d = 0; d < 3; ++d) for (int s = 0; s < 2; ++s) { const int f = cface(d, s, i, j, k); dv += (s ? 1.0 : -1.0) * (pimple ? alphaf[d][f] : 1.0) * phi[d][f]; }
+            double ce = dv / V;
+            if (pimple) ce += (alpha[c] - alphaOld[c]) / cs.dt;
+            sl += std::fabs(ce) * V; gl += ce * V;
+        }
+        const double tv = V * Nc;
+        st.cont_sum_local = cs.dt * sl / tv; st.cont_global = cs.dt * gl / tv;
+        cumulativeContErr += st.cont_global; st.cont_cumulative = cumulativeContErr;
+    }
+
+    // fvc::reconstruct(s_f) on the uniform block: per axis (s_{f+} + s_{f-}) / (2 |Sf|)
+    // ---- one PISO/PIMPLE corrector (icoFoamYade.C:97-140 / pEqn.H) -------------------------------------------
+    void corrector(bool final_inner) {
+        compute_HbyA();
+        if (!pimple) interp_rAU();
+        compute_phiHbyA();
+        MgLevel& L = mg[0];
+        for (int no = 0; no <= cs.n_non_orth; ++no) {
+            assemble_pressure(L);
+            if (cs.p_solver == 1) coarsen_operators();
+            solve_pressure(final_inner && no == cs.n_non_orth);
+            if (no == cs.n_non_orth) {
+                pressure_flux(L);
+                for (int d = 0; d < 3; ++d) for (size_t f = 0; f < phi[d].size(); ++f)
+                    phi[d][f] = phiHbyA[d][f] - pflux[d][f] / (pimple ? alphaf[d][f] : 1.0);      // icoFoamYade.C:129, pEqn.H:39
+            }
+        }
+        continuity_errors();                                                 // icoFoamYade.C:134, pEqn.H:50
+        if (!pimple) {
+            grad_p(gradP);                                                   // U = HbyA - rAU*fvc::grad(p), icoFoamYade.C:136
+            for (int c = 0; c < Nc; ++c) for (int q = 0; q < 3; ++q) U[3 * (size_t)c + q] = HbyA[3 * (size_t)c + q] - rAU[c] * gradP[3 * (size_t)c + q];
+        } else {
+            // Uc = HbyA + rAUc*fvc::reconstruct((phicForces - pEqn.flux()/alphacf)/rAUcf), pEqn.H:43-45
+#pragma omp parallel for num_threads(threads) collapse(2)
+            for (int k = 0; k < nz; ++k) for (int j = 0; j < ny; ++j) for (int i = 0; i < nx; ++i) {
+                const int c = cid(i, j, k);
+                for (int d = 0; d < 3; ++d) {
+                    double sm = 0;
+                    for (int s = 0; s < 2; ++s) { const int f = cface(d, s, i, j, k); sm += (phiForces[d][f] - pflux[d][f] / alphaf[d][f]) / rAUf[d][f]; }
+                    U[3 * (size_t)c + d] = HbyA[3 * (size_t)c + d] + rAU[c] * (sm / (2.0 * Af));
+                }
+            }
+        }
+    }
+
+    // ---- one pass of the while(runTime.loop()) body, with the coupling call injected by the caller --------------
+    void step_begin() {            // up to (excluding) yadeCoupling.setParticleAction
+        st = orc_fv_stats{}; st.cont_cumulative = cumulativeContErr;
+        courant();                                                           // icoFoamYade.C:68, pimpleFoamYade.C:63
+        // runTime++ : old-time fields (U.oldTime(), phi.oldTime(), alphac.oldTime())
+        Uold = U; for (int d = 0; d < 3; ++d) phiOld[d] = phi[d]; alphaOld = alpha;
+        pre_coupling_fields();                                               // icoFoamYade.C:71, pimpleFoamYade.C:73-76
+    }
+    void step_end() {              // everything after setParticleAction, up to (excluding) setSourceZero
+        if (pimple) interp_alpha();                                          // pimpleFoamYade.C:83-85 (alphaPhic is formed on the fly)
+        const int nOuter = pimple ? std::max(cs.n_outer, 1) : 1;
+        for (int outer = 0; outer < nOuter; ++outer) {
+            assemble_momentum();
+            if (pimple) { interp_rAU(); compute_phi_forces(); }
+            if (cs.momentum_predictor) {
+                if (!pimple) {                                               // solve(UEqn == -fvc::grad(p)), icoFoamYade.C:91-94
+                    grad_p(gradP);
+                    for (int c = 0; c < Nc; ++c) for (int q = 0; q < 3; ++q) bmom[3 * (size_t)c + q] = src[3 * (size_t)c + q] - V * gradP[3 * (size_t)c + q];
+                } else {                                                     // UcEqn.H:22-33
+                    for (int k = 0; k < nz; ++k) for (int j = 0; j < ny; ++j) for (int i = 0; i < nx; ++i) {
+                        const int c = cid(i, j, k);
+                        for (int d = 0; d < 3; ++d) {
+                            double sm = 0;
+                            for (int s = 0; s < 2; ++s) {
+                                const int f = cface(d, s, i, j, k);
+                                double sng;   // snGrad(p) along +axis
+                                if (onb(d, s, i, j, k)) { const double pbd = pbv(c, d, s, f); sng = s ? (pbd - p[c]) / (0.5 * dx) : (p[c] - pbd) / (0.5 * dx); }
+                                else sng = s ? (p[c + stride[d]] - p[c]) / dx : (p[c] - p[c - stride[d]]) / dx;
+                                sm += phiForces[d][f] / rAUf[d][f] - sng * Af;
+                            }
+                            bmom[3 * (size_t)c + d] = src[3 * (size_t)c + d] + V * (sm / (2.0 * Af));
+                        }
+                    }
+                }
+                st.u_iters_total += solve_momentum(bmom);
+            }
+            for (int corr = 0; corr < cs.n_corr; ++corr) corrector(outer == nOuter - 1 && corr == cs.n_corr - 1);
+        }
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+void* orc_fv_create(const orc_fv_case* c) { Fv* f = new Fv(); f->init(*c); return f; }
+void orc_fv_destroy(void* h) { delete (Fv*)h; }
+void orc_fv_set_threads(void* h, int t) { ((Fv*)h)->threads = t < 1 ? 1 : t; }
+
+static vec* fv_field(Fv* f, const char* name) {
+    const std::string s = name;
+    if (s == "U") return &f->U; if (s == "p") return &f->p; if (s == "alpha") return &f->alpha; if (s == "uSource") return &f->uSource;
+    if (s == "uSourceDrag") return &f->uSourceDrag; if (s == "uParticle") return &f->uParticle; if (s == "gradP") return &f->gradP;
+    if (s == "divT") return &f->divT; if (s == "vGrad") return &f->vGrad; if (s == "phi_x") return &f->phi[0]; if (s == "phi_y") return &f->phi[1];
+    if (s == "phi_z") return &f->phi[2]; if (s == "rAU") return &f->rAU; if (s == "HbyA") return &f->HbyA; if (s == "p_rhs") return &f->pb;
+    if (s == "p_diag") return &f->mg[0].diag; if (s == "p_ux") return &f->mg[0].ux; if (s == "p_uy") return &f->mg[0].uy; if (s == "p_uz") return &f->mg[0].uz;
+    if (s == "mom_diag") return &f->diag; if (s == "mom_src") return &f->src;
+    return nullptr;
+}
+int orc_fv_field_size(void* h, const char* name) { vec* v = fv_field((Fv*)h, name); return v ? (int)v->size() : -1; }
+int orc_fv_get(void* h, const char* name, double* out) { vec* v = fv_field((Fv*)h, name); if (!v) return 1; std::memcpy(out, v->data(), v->size() * sizeof(double)); return 0; }
+int orc_fv_set(void* h, const char* name, const double* in) {
+    Fv* f = (Fv*)h; vec* v = fv_field(f, name); if (!v) return 1;
+    std::memcpy(v->data(), in, v->size() * sizeof(double));
+    if (std::string(name) == "U") f->flux_of(f->U, f->phi);   // createPhi
+    return 0;
+}
+double* orc_fv_ptr(void* h, const char* name) { vec* v = fv_field((Fv*)h, name); return v ? v->data() : nullptr; }
+void orc_fv_step_begin(void* h) { ((Fv*)h)->step_begin(); }
+void orc_fv_step_end(void* h) { ((Fv*)h)->step_end(); }
+void orc_fv_get_stats(void* h, orc_fv_stats* out) { *out = ((Fv*)h)->st; }
+// y = A x with the current pressure matrix (level 0)
+void orc_fv_apply_p(void* h, const double* x, double* y) {
+    Fv* f = (Fv*)h; vec xv(x, x + f->Nc), yv(f->Nc);
+    Fv::apply(f->mg[0], xv, yv, f->threads);
+    std::memcpy(y, yv.data(), yv.size() * sizeof(double));
+}
+
+}  // extern "C"

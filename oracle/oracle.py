@@ -158,3 +158,151 @@ def set_source_zero(mutable, gaussian):
     Nc = mutable["alpha"].shape[0]
     lib().orc_set_source_zero(Nc, int(gaussian), _d(mutable["uSourceDrag"]), _d(mutable["alpha"]),
                               _d(mutable["uSource"]), _d(mutable["uParticle"]))
+
+
+# =====================================================================================================================
+# FV half (parity unpinned -- see oracle/fv_oracle.cpp header)
+# =====================================================================================================================
+class FvCase(C.Structure):
+    _fields_ = [("solver", C.c_int), ("nx", C.c_int), ("ny", C.c_int), ("nz", C.c_int), ("dx", C.c_double),
+                ("origin", C.c_double * 3), ("dt", C.c_double), ("nu", C.c_double), ("rho_fluid", C.c_double),
+                ("rho_particle", C.c_double), ("g", C.c_double * 3),
+                ("u_bc", C.c_int * 6), ("u_value", (C.c_double * 3) * 6), ("p_bc", C.c_int * 6), ("p_value", C.c_double * 6),
+                ("n_outer", C.c_int), ("n_corr", C.c_int), ("n_non_orth", C.c_int), ("momentum_predictor", C.c_int),
+                ("p_ref_cell", C.c_int), ("p_ref_value", C.c_double), ("p_solver", C.c_int),
+                ("p_tol", C.c_double), ("p_rel_tol", C.c_double), ("p_final_tol", C.c_double), ("p_final_rel_tol", C.c_double),
+                ("p_max_iter", C.c_int), ("u_tol", C.c_double), ("u_rel_tol", C.c_double), ("u_max_iter", C.c_int)]
+
+
+class FvStats(C.Structure):
+    _fields_ = [("courant_mean", C.c_double), ("courant_max", C.c_double), ("cont_sum_local", C.c_double),
+                ("cont_global", C.c_double), ("cont_cumulative", C.c_double), ("p_iters_total", C.c_int),
+                ("p_solves", C.c_int), ("u_iters_total", C.c_int), ("p_initial_residual", C.c_double),
+                ("p_final_residual", C.c_double)]
+
+
+U_FIXED, U_ZEROGRAD = 0, 1
+P_ZEROGRAD, P_FIXED, P_FIXEDFLUX = 0, 1, 2
+XMIN, XMAX, YMIN, YMAX, ZMIN, ZMAX = range(6)
+
+
+def fv_case(solver, nx, ny, nz, dx, dt, nu, rho_f=1000.0, rho_p=2650.0, g=(0, 0, 0), u_bc=None, u_val=None, p_bc=None,
+            p_val=None, n_outer=1, n_corr=2, p_solver=1, origin=(0, 0, 0), momentum_predictor=1, p_tol=1e-6, p_rel_tol=0.05,
+            p_final_tol=1e-6, p_final_rel_tol=0.0, u_tol=1e-5, u_rel_tol=0.0, p_max_iter=1000, u_max_iter=1000, p_ref_cell=0,
+            p_ref_value=0.0, n_non_orth=0):
+    """documented defaults = the icoFoam cavity / DPMFoam tutorial settings of SURVEY.md Appendix C"""
+    c = FvCase()
+    c.solver, c.nx, c.ny, c.nz, c.dx, c.dt, c.nu = solver, nx, ny, nz, dx, dt, nu
+    c.rho_fluid, c.rho_particle = rho_f, rho_p
+    for q in range(3):
+        c.origin[q] = origin[q]
+        c.g[q] = g[q]
+    u_bc = u_bc or [U_FIXED] * 6
+    u_val = u_val or [(0, 0, 0)] * 6
+    p_bc = p_bc or [P_ZEROGRAD] * 6
+    p_val = p_val or [0.0] * 6
+    for q in range(6):
+        c.u_bc[q] = u_bc[q]
+        c.p_bc[q] = p_bc[q]
+        c.p_value[q] = p_val[q]
+        for a in range(3):
+            c.u_value[q][a] = u_val[q][a]
+    c.n_outer, c.n_corr, c.n_non_orth, c.momentum_predictor = n_outer, n_corr, n_non_orth, momentum_predictor
+    c.p_ref_cell, c.p_ref_value, c.p_solver = p_ref_cell, p_ref_value, p_solver
+    c.p_tol, c.p_rel_tol, c.p_final_tol, c.p_final_rel_tol, c.p_max_iter = p_tol, p_rel_tol, p_final_tol, p_final_rel_tol, p_max_iter
+    c.u_tol, c.u_rel_tol, c.u_max_iter = u_tol, u_rel_tol, u_max_iter
+    return c
+
+
+_fv_ready = False
+
+
+def _fv_lib():
+    global _fv_ready
+    L = lib()
+    if not _fv_ready:
+        L.orc_fv_create.argtypes = [C.POINTER(FvCase)]
+        L.orc_fv_create.restype = C.c_void_p
+        L.orc_fv_destroy.argtypes = [C.c_void_p]
+        L.orc_fv_set_threads.argtypes = [C.c_void_p, C.c_int]
+        L.orc_fv_field_size.argtypes = [C.c_void_p, C.c_char_p]
+        L.orc_fv_get.argtypes = [C.c_void_p, C.c_char_p, _dp]
+        L.orc_fv_set.argtypes = [C.c_void_p, C.c_char_p, _dp]
+        L.orc_fv_ptr.argtypes = [C.c_void_p, C.c_char_p]
+        L.orc_fv_ptr.restype = _dp
+        L.orc_fv_step_begin.argtypes = [C.c_void_p]
+        L.orc_fv_step_end.argtypes = [C.c_void_p]
+        L.orc_fv_get_stats.argtypes = [C.c_void_p, C.POINTER(FvStats)]
+        L.orc_fv_apply_p.argtypes = [C.c_void_p, _dp, _dp]
+        _fv_ready = True
+    return L
+
+
+class FvSolver:
+    """icoFoamYade / pimpleFoamYade time loop on the CPU (oracle).  step(records) = one pass of the loop body."""
+
+    def __init__(self, case: FvCase, threads=1):
+        self.case = case
+        self.L = _fv_lib()
+        self.h = self.L.orc_fv_create(C.byref(case))
+        self.L.orc_fv_set_threads(self.h, threads)
+        self.Nc = case.nx * case.ny * case.nz
+        self.gaussian = case.solver == 1
+        self.mesh = None
+        self.threads = threads
+
+    def view(self, name):
+        """numpy view of the oracle's own storage (no copy)"""
+        n = self.L.orc_fv_field_size(self.h, name.encode())
+        assert n >= 0, name
+        return np.ctypeslib.as_array(self.L.orc_fv_ptr(self.h, name.encode()), shape=(n,))
+
+    def get(self, name):
+        return self.view(name).copy()
+
+    def set(self, name, arr):
+        arr = np.ascontiguousarray(arr, dtype=np.float64).ravel()
+        assert self.L.orc_fv_set(self.h, name.encode(), _d(arr)) == 0
+
+    def stats(self):
+        s = FvStats()
+        self.L.orc_fv_get_stats(self.h, C.byref(s))
+        return {n: getattr(s, n) for n, _ in FvStats._fields_}
+
+    def step(self, records=None):
+        """records: (n,10) particle records or None (no particles).  Returns the per-particle force array or None."""
+        self.L.orc_fv_step_begin(self.h)
+        out = None
+        if records is not None:
+            c = self.case
+            if self.mesh is None:
+                self.mesh = Mesh(c.nx, c.ny, c.nz, c.dx, tuple(c.origin))
+            fields = dict(U=self.view("U").reshape(-1, 3), gradP=self.view("gradP").reshape(-1, 3),
+                          vGrad=self.view("vGrad").reshape(-1, 9), divT=self.view("divT").reshape(-1, 3))
+            mut = dict(uSourceDrag=self.view("uSourceDrag"), alpha=self.view("alpha"),
+                       uSource=self.view("uSource").reshape(-1, 3), uParticle=self.view("uParticle").reshape(-1, 3))
+            n = records.shape[0]
+            out = particle_action(self.mesh, fields, mut, records, np.array([0, n], np.int32), self.gaussian,
+                                  c.rho_particle, c.rho_fluid, c.nu, threads=self.threads)
+        self.L.orc_fv_step_end(self.h)
+        # yadeCoupling.setSourceZero() (icoFoamYade.C:147, pimpleFoamYade.C:109)
+        self.L.orc_set_source_zero(self.Nc, int(self.gaussian), _d(self.view("uSourceDrag")), _d(self.view("alpha")),
+                                   _d(self.view("uSource")), _d(self.view("uParticle")))
+        return out
+
+    def apply_p(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.empty_like(x)
+        self.L.orc_fv_apply_p(self.h, _d(x), _d(y))
+        return y
+
+    def close(self):
+        if self.h:
+            self.L.orc_fv_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
