@@ -665,10 +665,16 @@ struct Fv {
         st = orc_fv_stats{}; st.cont_cumulative = cumulativeContErr;
         courant();                                                           // icoFoamYade.C:68, pimpleFoamYade.C:63
         // runTime++ : old-time fields (U.oldTime(), phi.oldTime(), alphac.oldTime())
-        Uold = U; for (int d = 0; d < 3; ++d) phiOld[d] = phi[d]; alphaOld = alpha;
+        Uold = U; for (int d = 0; d < 3; ++d) phiOld[d] = phi[d];
         pre_coupling_fields();                                               // icoFoamYade.C:71, pimpleFoamYade.C:73-76
     }
     void step_end() {              // everything after setParticleAction, up to (excluding) setSourceZero
+        // alphac.oldTime(): OpenFOAM captures old-time values lazily, at the first *tracked* access of a field in a new time
+        // step (GeometricField::storeOldTimes, called from oldTime() and from the non-const accessors).  FoamYade writes alpha
+        // through UList::operator[] (FoamYade.C:324,560), which is untracked, so the first tracked access of alphac in a step is
+        // alphac.correctBoundaryConditions() at pimpleFoamYade.C:83 -- AFTER setParticleAction.  Hence alphac.oldTime() equals
+        // this step's alpha and fvc::ddt(alphac) == 0 in the reference.  [OF-6 semantics restated from memory; parity unpinned]
+        alphaOld = alpha;
         if (pimple) interp_alpha();                                          // pimpleFoamYade.C:83-85 (alphaPhic is formed on the fly)
         const int nOuter = pimple ? std::max(cs.n_outer, 1) : 1;
         for (int outer = 0; outer < nOuter; ++outer) {

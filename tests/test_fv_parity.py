@@ -1,0 +1,109 @@
+"""GPU parity of the FV half: fy_solver (HIP, through the C-ABI) vs the CPU oracle (oracle/fv_oracle.cpp) on the same cases.
+
+FV PARITY IS UNPINNED against the reference (its FV arithmetic is OpenFOAM-6 library code, absent here); the oracle is validated by
+known-answer flows in tests/test_fv_oracle.py and this file checks that the HIP path reproduces the oracle.  Tolerances: both sides
+run the same algorithm in FP64, differing in reduction order (and therefore, rarely, by one solver iteration), so fields agree to
+the linear-solver tolerance, not to the bit."""
+import numpy as np
+import pytest
+
+import golden_cases as gc
+
+pytestmark = pytest.mark.gpu
+
+XMIN, XMAX, YMIN, YMAX, ZMIN, ZMAX = range(6)
+
+
+def both(product, oracle, solver, nx, ny, nz, dx, dt, nu, **kw):
+    u_bc = kw.pop("u_bc", None); u_val = kw.pop("u_val", None); p_bc = kw.pop("p_bc", None); p_val = kw.pop("p_val", None)
+    g = kw.pop("g", (0, 0, 0)); p_solver = kw.pop("p_solver", 1)
+    oc = oracle.fv_case(solver, nx, ny, nz, dx, dt, nu, g=g, u_bc=u_bc, u_val=u_val, p_bc=p_bc, p_val=p_val, p_solver=p_solver, **kw)
+    pk = dict(kw)
+    if "n_outer" in pk: pk["n_outer_correctors"] = pk.pop("n_outer")
+    if "n_corr" in pk: pk["n_correctors"] = pk.pop("n_corr")
+    pc = product.make_case(solver, nx, ny, nz, dx, dt, nu, g=g, u_bc=u_bc, u_val=u_val, p_bc=p_bc, p_val=p_val, p_solver=p_solver, **pk)
+    return oracle.FvSolver(oc), product.Solver(pc)
+
+
+def cavity_bcs():
+    u_val = [(0, 0, 0)] * 6
+    u_val[YMAX] = (1.0, 0, 0)
+    return dict(u_bc=[0] * 6, u_val=u_val)
+
+
+def compare(o, s, names=("U", "p", "phi_x", "phi_y", "phi_z"), rtol=2e-6):
+    for nm in names:
+        a, b = s.get(nm), o.get(nm)
+        sc = np.abs(b).max() + 1e-300
+        assert np.abs(a - b).max() <= rtol * sc, (nm, np.abs(a - b).max() / sc)
+
+
+@pytest.mark.parametrize("solver", [0, 1])
+@pytest.mark.parametrize("p_solver", [0, 1])
+def test_cavity_steps_match_oracle(product, oracle, solver, p_solver):
+    n = 20
+    o, s = both(product, oracle, solver, n, n, n, 1.0 / n, 0.4 / n, 0.01, p_solver=p_solver, **cavity_bcs())
+    for step in range(6):
+        o.step(); s.step()
+        so, ss = o.stats(), s.stats()
+        assert abs(so["p_iters_total"] - ss["p_iters_total"]) <= 2
+        assert abs(so["u_iters_total"] - ss["u_iters_total"]) <= 1
+        assert np.isclose(so["courant_max"], ss["courant_max"], rtol=1e-6)
+    compare(o, s)
+    assert ss["cont_err_sum_local"] < 1e-5
+
+
+def test_operator_level_parity(product, oracle):
+    """one step from a non-trivial state; compare the assembled matrices and the SpMV, which do not depend on solver iterations"""
+    nx, ny, nz = 14, 10, 6
+    u_bc = [1, 1, 0, 0, 0, 0]
+    p_bc = [1, 1, 0, 0, 0, 0]
+    o, s = both(product, oracle, 0, nx, ny, nz, 0.05, 0.01, 0.02, u_bc=u_bc, p_bc=p_bc, p_val=[0.3, 0.0, 0, 0, 0, 0])
+    rs = np.random.RandomState(3)
+    U0 = rs.rand(nx * ny * nz, 3) * 0.2
+    o.set("U", U0); s.set("U", U0)
+    o.step(); s.step()
+    for nm in ("p_diag", "p_ux", "p_uy", "p_uz", "mom_diag", "rAU"):
+        np.testing.assert_allclose(s.get(nm), o.get(nm), rtol=1e-9, atol=0, err_msg=nm)
+    x = rs.rand(nx * ny * nz)
+    np.testing.assert_allclose(s.apply_p(x), o.apply_p(x), rtol=1e-12, atol=1e-14 * np.abs(o.get("p_diag")).max())
+    compare(o, s)
+
+
+def test_odd_dims_multigrid(product, oracle):
+    o, s = both(product, oracle, 1, 13, 9, 7, 0.02, 0.004, 0.005, **cavity_bcs())
+    for _ in range(4):
+        o.step(); s.step()
+    compare(o, s)
+
+
+def test_hydrostatic_fixed_flux(product, oracle):
+    n = 12
+    o, s = both(product, oracle, 1, n, n, n, 0.1 / n, 1e-3, 1e-6, g=(0, 0, -9.81), p_bc=[2] * 6)
+    for _ in range(3):
+        o.step(); s.step()
+    assert np.abs(s.get("U")).max() < 1e-8
+    p = s.get("p").reshape(n, n, n)
+    np.testing.assert_allclose((p[2:] - p[:-2]) / (2 * 0.1 / n), -9.81, rtol=1e-5)
+    compare(o, s, names=("p",), rtol=1e-5)
+
+
+@pytest.mark.parametrize("solver", [0, 1])
+def test_coupled_steps_match_oracle(product, oracle, solver):
+    """full loop body with particles: locate/interpolate/drag/back-scatter + PISO/PIMPLE, three coupled steps"""
+    n = 16
+    dx = 0.1 / n
+    kw = dict(g=(0, 0, -9.81), p_bc=[2] * 6) if solver == 1 else cavity_bcs()
+    nu = 1e-5 if solver == 1 else 0.01
+    o, s = both(product, oracle, solver, n, n, n, dx, 2e-4, nu, **kw)
+    case = gc.Case("cpl", n, n, n, 0.1, gaussian=solver, np_=3000, seed=9, cluster=150, fast=20, outside=20, vel_scale=0.05)
+    for step in range(3):
+        rec = gc.particle_records(case, step)
+        fo = o.step(rec)["force"]
+        s.set_particles(rec)
+        s.step()
+        fs = s.forces()
+        sc = np.abs(fo).max()
+        assert np.abs(fs - fo).max() <= 1e-6 * sc, np.abs(fs - fo).max() / sc
+    compare(o, s, rtol=1e-5)
+    assert np.abs(s.get("U")).max() > 0

@@ -310,3 +310,126 @@ class FoamYade:
             self.close()
         except Exception:
             pass
+
+
+def case_defaults(solver):
+    """fy_case_defaults: the documented icoFoam-cavity / DPMFoam-tutorial settings (the reference ships no case)."""
+    c = CaseDesc()
+    lib().fy_case_defaults(C.byref(c), int(solver))
+    return c
+
+
+def make_case(solver, nx, ny, nz, dx, dt, nu, rho_f=1000.0, rho_p=2650.0, g=(0, 0, 0), u_bc=None, u_val=None, p_bc=None,
+              p_val=None, origin=(0, 0, 0), **kw):
+    c = case_defaults(solver)
+    c.nx, c.ny, c.nz, c.dx, c.dt, c.nu, c.rho_fluid, c.rho_particle = nx, ny, nz, dx, dt, nu, rho_f, rho_p
+    for q in range(3):
+        c.g[q] = g[q]
+        c.origin[q] = origin[q]
+    for q in range(6):
+        if u_bc is not None:
+            c.u_bc[q] = u_bc[q]
+        if p_bc is not None:
+            c.p_bc[q] = p_bc[q]
+        if p_val is not None:
+            c.p_value[q] = p_val[q]
+        if u_val is not None:
+            for a in range(3):
+                c.u_value[q][a] = u_val[q][a]
+    for k, v in kw.items():
+        assert hasattr(c, k), k
+        setattr(c, k, v)
+    return c
+
+
+class Solver:
+    """the icoFoamYade / pimpleFoamYade executables' time loop (icoFoamYade.C:65-149, pimpleFoamYade.C:60-114): step() is one
+    pass of the loop body, including yadeCoupling.setParticleAction and setSourceZero."""
+
+    def __init__(self, case: CaseDesc, transport=None, device=0):
+        self.case = case
+        self._h = C.c_void_p()
+        self._keep = transport
+        _check(lib().fy_solver_create(C.byref(case), C.byref(transport) if transport is not None else None, int(device), C.byref(self._h)))
+        self.n_cells = case.nx * case.ny * case.nz
+        self._cpl = C.c_void_p(lib().fy_solver_coupling(self._h))
+        self._batch_n = []
+
+    def _size(self, name):
+        c = self.case
+        n = self.n_cells
+        return {"U": 3 * n, "HbyA": 3 * n, "mom_src": 3 * n, "uSource": 3 * n, "uParticle": 3 * n, "gradP": 3 * n, "divT": 3 * n,
+                "vGrad": 9 * n, "phi_x": (c.nx + 1) * c.ny * c.nz, "phi_y": c.nx * (c.ny + 1) * c.nz,
+                "phi_z": c.nx * c.ny * (c.nz + 1)}.get(name, n)
+
+    def get(self, name):
+        out = np.zeros(self._size(name))
+        _check(lib().fy_solver_read_field_host(self._h, name.encode(), _d(out)))
+        return out
+
+    def set(self, name, arr):
+        arr = np.ascontiguousarray(arr, dtype=np.float64).ravel()
+        assert arr.size == self._size(name)
+        _check(lib().fy_solver_write_field_host(self._h, name.encode(), _d(arr)))
+
+    def set_particles(self, records):
+        """direct mode: the particle records the next step() will couple with ((n,10) host array, or None for none)"""
+        L = lib()
+        _check(L.fy_set_num_batches(self._cpl, 1))
+        if records is None:
+            rec = np.zeros((0, 10))
+        else:
+            rec = np.ascontiguousarray(records, dtype=np.float64).reshape(-1, 10)
+        _check(L.fy_set_particles_host(self._cpl, 0, _d(rec) if rec.size else None, rec.shape[0]))
+        self._batch_n = [rec.shape[0]]
+
+    def set_particles_device(self, rec):
+        L = lib()
+        _check(L.fy_set_num_batches(self._cpl, 1))
+        n = rec.numel() // 10
+        self._keep_rec = rec
+        _check(L.fy_set_particles_device(self._cpl, 0, C.c_void_p(rec.data_ptr()), n))
+        self._batch_n = [n]
+
+    def forces(self):
+        out = np.zeros((self._batch_n[0], 6))
+        _check(lib().fy_get_forces_host(self._cpl, 0, _d(out)))
+        return out
+
+    def step(self):
+        _check(lib().fy_solver_step(self._h))
+
+    def stats(self):
+        s = StepStats()
+        _check(lib().fy_solver_get_stats(self._h, C.byref(s)))
+        return {n: getattr(s, n) for n, _ in StepStats._fields_}
+
+    def apply_p(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.empty_like(x)
+        _check(lib().fy_solver_apply_p_matrix_host(self._h, _d(x), _d(y)))
+        return y
+
+    def time_p_apply(self, reps=50):
+        ms = C.c_double()
+        _check(lib().fy_solver_time_p_apply(self._h, int(reps), C.byref(ms)))
+        return ms.value
+
+    def coupling_timings(self):
+        t = ParticleTimings()
+        _check(lib().fy_get_particle_timings(self._cpl, C.byref(t)))
+        return {n: getattr(t, n) for n, _ in ParticleTimings._fields_}
+
+    def enable_particle_timing(self, on=True):
+        _check(lib().fy_enable_timing(self._cpl, int(on)))
+
+    def close(self):
+        if self._h:
+            lib().fy_solver_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

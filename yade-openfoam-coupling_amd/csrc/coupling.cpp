@@ -41,8 +41,8 @@ int Coupling::create(const fy_mesh_desc* m, const fy_field_ptrs* f, int gaussian
     if (device_ordinal < 0 || device_ordinal >= ndev) return fail(FY_ERR_INVALID, "device ordinal %d out of range (%d devices)", device_ordinal, ndev);
     device = device_ordinal;
     FY_HIP(hipSetDevice(device));
-    FY_HIP(hipStreamCreate(&stream));
-    owns_stream = true;
+    if (ext_stream) { stream = ext_stream; owns_stream = false; }
+    else { FY_HIP(hipStreamCreate(&stream)); owns_stream = true; }
     mesh = *m;
     mesh.centres = nullptr; mesh.volumes = nullptr;   // not retained
     n_cells = m->n_cells;
@@ -492,7 +492,6 @@ Coupling::~Coupling() {
 
 // ================================================================================================ C ABI
 using fy::Coupling;
-struct fy_ctx { Coupling c; };
 
 extern "C" {
 

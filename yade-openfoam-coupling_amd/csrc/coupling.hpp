@@ -29,6 +29,7 @@ struct Coupling {
     // ---- configuration
     int device = -1;
     hipStream_t stream = nullptr;
+    hipStream_t ext_stream = nullptr;    // set before create() to run on a caller-owned stream (fy_solver does)
     bool owns_stream = false;
     bool created = false;
     fy_mesh_desc mesh{};
@@ -93,3 +94,5 @@ struct Coupling {
 };
 
 }  // namespace fy
+
+struct fy_ctx { fy::Coupling c; };

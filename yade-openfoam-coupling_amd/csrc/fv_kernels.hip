@@ -1,0 +1,952 @@
+// FV half of the hot path as hand-written HIP for gfx950: the finite-volume operators behind icoFoamYade.C:65-149 and
+// pimpleFoamYade.C:60-114 / UcEqn.H / pEqn.H on a uniform hex block.  One lane per cell (or per face), consecutive lanes on
+// consecutive x-cells => every array access is a coalesced stream; y/z neighbours are re-reads served by L2.  FP64, no MFMA.
+// Operator semantics follow OpenFOAM-6 (see DESIGN.md "FV discretisation"); parity for this half is UNPINNED (no OpenFOAM here).
+#include "fv_kernels.hpp"
+
+#include "common.hpp"
+
+namespace fy {
+namespace {
+
+constexpr double kSmall = 1e-15;     // OpenFOAM `small`
+
+// ------------------------------------------------------------------------------------------------ index helpers
+__device__ __forceinline__ void ijk_of(const FvGeo& g, int c, int& i, int& j, int& k) {
+    i = c % g.nx;
+    const int t = c / g.nx;
+    j = t % g.ny;
+    k = t / g.ny;
+}
+__device__ __forceinline__ int stride_of(const FvGeo& g, int d) { return d == 0 ? 1 : d == 1 ? g.nx : g.nx * g.ny; }
+__device__ __forceinline__ int ndim(const FvGeo& g, int d) { return d == 0 ? g.nx : d == 1 ? g.ny : g.nz; }
+__device__ __forceinline__ int fid(const FvGeo& g, int d, int i, int j, int k) {
+    return d == 0 ? i + (g.nx + 1) * (j + g.ny * k) : d == 1 ? i + g.nx * (j + (g.ny + 1) * k) : i + g.nx * (j + g.ny * k);
+}
+__device__ __forceinline__ int cface(const FvGeo& g, int d, int s, int i, int j, int k) {
+    return fid(g, d, i + (d == 0 ? s : 0), j + (d == 1 ? s : 0), k + (d == 2 ? s : 0));
+}
+__device__ __forceinline__ bool onb(const FvGeo& g, int d, int s, int i, int j, int k) {
+    const int q = d == 0 ? i : d == 1 ? j : k;
+    return s ? q == ndim(g, d) - 1 : q == 0;
+}
+__device__ __forceinline__ void Ub(const FvGeo& g, const double* F, int c, int patch, double* out) {
+    if (g.u_bc[patch] == 0) { out[0] = g.u_val[patch][0]; out[1] = g.u_val[patch][1]; out[2] = g.u_val[patch][2]; }
+    else { out[0] = F[3 * (size_t)c]; out[1] = F[3 * (size_t)c + 1]; out[2] = F[3 * (size_t)c + 2]; }
+}
+__device__ __forceinline__ double pbv(const FvGeo& g, const double* p, const CFace3& psn, int c, int d, int s, int face) {
+    const int patch = 2 * d + s;
+    if (g.p_bc[patch] == 1) return g.p_val[patch];
+    if (g.p_bc[patch] == 2) return p[c] + (s ? 0.5 : -0.5) * g.dx * psn.a[d][face];
+    return p[c];
+}
+// XCD-aware block order (guide T1): block b runs on XCD b % 8; give every XCD one contiguous z-slab of the grid so that the
+// y/z-neighbour re-reads of a stencil hit that XCD's own L2.  Pure speed: any mapping is correct.
+__device__ __forceinline__ int swz_block(int bid, int nblk) {
+    if (nblk % 8) return bid;
+    return (bid % 8) * (nblk / 8) + bid / 8;
+}
+
+// ------------------------------------------------------------------------------------------------ block reductions (256 threads)
+template <int N>
+__device__ __forceinline__ void block_reduce_store(double (&v)[N], const int (&is_max)[N], double* partials) {
+    __shared__ double sh[4][N];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+        double x = v[q];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double y = __shfl_down(x, o, 64);
+            x = is_max[q] ? fmax(x, y) : x + y;
+        }
+        if (lane == 0) sh[wv][q] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x < N) {
+        const int q = threadIdx.x;
+        double x = sh[0][q];
+        for (int w = 1; w < 4; ++w) x = is_max[q] ? fmax(x, sh[w][q]) : x + sh[w][q];
+        partials[(size_t)q * kRedBlocks + blockIdx.x] = x;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_reduce_finalize(const double* __restrict__ partials, int nblocks, const int* __restrict__ ops,
+                                                         double* __restrict__ out) {
+    __shared__ double sh[4];
+    const int slot = blockIdx.x;
+    const int mx = ops ? ops[slot] : 0;
+    double x = mx ? -1e300 : 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += 256) {
+        const double y = partials[(size_t)slot * kRedBlocks + b];
+        x = mx ? fmax(x, y) : x + y;
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double y = __shfl_down(x, o, 64);
+        x = mx ? fmax(x, y) : x + y;
+    }
+    if (lane == 0) sh[wv] = x;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double r = sh[0];
+        for (int w = 1; w < 4; ++w) r = mx ? fmax(r, sh[w]) : r + sh[w];
+        out[slot] = r;
+    }
+}
+
+// every reducing kernel runs with exactly kRedBlocks blocks (grid-stride), so each slot always has kRedBlocks valid partials
+// and the fold order -- hence the result -- is fixed from run to run
+inline int red_grid(size_t) { return kRedBlocks; }
+
+// ------------------------------------------------------------------------------------------------ face kernels
+// generic face iteration: thread -> (d fixed per launch, face index f) -> (i,j,k) of the face
+__device__ __forceinline__ bool face_ijk(const FvGeo& g, int d, size_t f, int& i, int& j, int& k) {
+    const int ex = g.nx + (d == 0), ey = g.ny + (d == 1), ez = g.nz + (d == 2);
+    if (f >= (size_t)ex * ey * ez) return false;
+    i = (int)(f % ex);
+    const size_t t = f / ex;
+    j = (int)(t % ey);
+    k = (int)(t / ey);
+    return true;
+}
+
+// fvc::flux(F) = linearInterpolate(F) & Sf with U's boundary conditions (createPhi; flux(HbyA) with constrainHbyA)
+__device__ __forceinline__ double face_flux_vec(const FvGeo& g, const double* F, int d, int i, int j, int k) {
+    const int q = d == 0 ? i : d == 1 ? j : k;
+    double v;
+    if (q == 0) { double b[3]; Ub(g, F, i + g.nx * (j + g.ny * k), 2 * d, b); v = b[d]; }
+    else if (q == ndim(g, d)) { double b[3]; const int c = (i - (d == 0)) + g.nx * ((j - (d == 1)) + g.ny * (k - (d == 2))); Ub(g, F, c, 2 * d + 1, b); v = b[d]; }
+    else { const int c = i + g.nx * (j + g.ny * k); v = 0.5 * (F[3 * (size_t)(c - stride_of(g, d)) + d] + F[3 * (size_t)c + d]); }
+    return v * g.Af;
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void k_flux_of(FvGeo g, const double* __restrict__ F, double* __restrict__ out) {
+    const size_t f = (size_t)blockIdx.x * 256 + threadIdx.x;
+    int i, j, k;
+    if (!face_ijk(g, D, f, i, j, k)) return;
+    out[f] = face_flux_vec(g, F, D, i, j, k);
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void k_interp_alpha(FvGeo g, const double* __restrict__ alpha, double* __restrict__ af) {
+    const size_t f = (size_t)blockIdx.x * 256 + threadIdx.x;
+    int i, j, k;
+    if (!face_ijk(g, D, f, i, j, k)) return;
+    const int q = D == 0 ? i : D == 1 ? j : k;
+    if (q == 0 || q == ndim(g, D)) af[f] = 1.0;     // calculated patch, value 1 (`alpha = 1.0`, FoamYade.C:68)
+    else { const int c = i + g.nx * (j + g.ny * k); af[f] = 0.5 * (alpha[c - stride_of(g, D)] + alpha[c]); }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void k_interp_rAU(FvGeo g, const double* __restrict__ rAU, double* __restrict__ rf) {
+    const size_t f = (size_t)blockIdx.x * 256 + threadIdx.x;
+    int i, j, k;
+    if (!face_ijk(g, D, f, i, j, k)) return;
+    const int q = D == 0 ? i : D == 1 ? j : k;
+    if (q == 0) rf[f] = rAU[i + g.nx * (j + g.ny * k)];
+    else if (q == ndim(g, D)) rf[f] = rAU[(i - (D == 0)) + g.nx * ((j - (D == 1)) + g.ny * (k - (D == 2)))];
+    else { const int c = i + g.nx * (j + g.ny * k); rf[f] = 0.5 * (rAU[c - stride_of(g, D)] + rAU[c]); }
+}
+
+// phicForces = fvc::flux(rAUc*uSource) + rAUcf*(g & Sf)   UcEqn.H:17-20 (uSource's calculated boundary value is 0)
+template <int D>
+__global__ __launch_bounds__(256) void k_phi_forces(FvGeo g, const double* __restrict__ rAU, const double* __restrict__ rAUf,
+                                                    const double* __restrict__ uSource, double* __restrict__ out) {
+    const size_t f = (size_t)blockIdx.x * 256 + threadIdx.x;
+    int i, j, k;
+    if (!face_ijk(g, D, f, i, j, k)) return;
+    const int q = D == 0 ? i : D == 1 ? j : k;
+    double fl = 0.0;
+    if (q != 0 && q != ndim(g, D)) {
+        const int c = i + g.nx * (j + g.ny * k), cm = c - stride_of(g, D);
+        fl = 0.5 * (rAU[cm] * uSource[3 * (size_t)cm + D] + rAU[c] * uSource[3 * (size_t)c + D]) * g.Af;
+    }
+    out[f] = fl + rAUf[f] * (g.g[D] * g.Af);
+}
+
+// phiHbyA = fvc::flux(HbyA) + [alphacf*]rAUf*fvc::ddtCorr(U, phi) [+ phicForces]; constrainPressure on fixedFluxPressure patches
+// (icoFoamYade.C:101-111, pEqn.H:4-21).  ddtCorr = EulerDdtScheme::fvcDdtPhiCorr with fvcDdtPhiCoeff.
+template <int D>
+__global__ __launch_bounds__(256) void k_phiHbyA(FvGeo g, const double* __restrict__ HbyA, const double* __restrict__ U,
+                                                 const double* __restrict__ Uold, const double* __restrict__ phiOld,
+                                                 const double* __restrict__ rAUf, const double* __restrict__ alphaf,
+                                                 const double* __restrict__ phiForces, double* __restrict__ out, double* __restrict__ psn) {
+    const size_t f = (size_t)blockIdx.x * 256 + threadIdx.x;
+    int i, j, k;
+    if (!face_ijk(g, D, f, i, j, k)) return;
+    const int q = D == 0 ? i : D == 1 ? j : k;
+    double v = face_flux_vec(g, HbyA, D, i, j, k);
+    double uf;
+    bool fixes = false;
+    int bpatch = -1, bc = -1;
+    if (q == 0) { bpatch = 2 * D; bc = i + g.nx * (j + g.ny * k); }
+    else if (q == ndim(g, D)) { bpatch = 2 * D + 1; bc = (i - (D == 0)) + g.nx * ((j - (D == 1)) + g.ny * (k - (D == 2))); }
+    if (bpatch >= 0) { fixes = g.u_bc[bpatch] == 0; double b[3]; Ub(g, Uold, bc, bpatch, b); uf = b[D] * g.Af; }
+    else { const int c = i + g.nx * (j + g.ny * k); uf = 0.5 * (Uold[3 * (size_t)(c - stride_of(g, D)) + D] + Uold[3 * (size_t)c + D]) * g.Af; }
+    const double po = phiOld[f];
+    const double phiCorr = po - uf;
+    const double coef = fixes ? 0.0 : 1.0 - fmin(fabs(phiCorr) / (fabs(po) + kSmall), 1.0);
+    double add = rAUf[f] * (coef * (1.0 / g.dt) * phiCorr);
+    if (g.pimple) add *= alphaf[f];
+    v += add;
+    if (g.pimple) v += phiForces[f];
+    out[f] = v;
+    if (bpatch >= 0 && g.p_bc[bpatch] == 2) {
+        double ub[3]; Ub(g, U, bc, bpatch, ub);
+        psn[f] = (v - ub[D] * g.Af) / (rAUf[f] * g.Af);
+    }
+}
+
+// pEqn.flux() and phi = phiHbyA - pEqn.flux()[/alphacf]   (icoFoamYade.C:129, pEqn.H:39)
+template <int D>
+__global__ __launch_bounds__(256) void k_flux_correct(FvGeo g, const double* __restrict__ p, const double* __restrict__ phiHbyA,
+                                                      const double* __restrict__ rAUf, const double* __restrict__ alphaf,
+                                                      const double* __restrict__ psn, double* __restrict__ pflux, double* __restrict__ phi) {
+    const size_t f = (size_t)blockIdx.x * 256 + threadIdx.x;
+    int i, j, k;
+    if (!face_ijk(g, D, f, i, j, k)) return;
+    const int q = D == 0 ? i : D == 1 ? j : k;
+    const double af = g.pimple ? alphaf[f] : 1.0;
+    double fl = 0.0;
+    if (q == 0 || q == ndim(g, D)) {
+        const int s = q == 0 ? 0 : 1, patch = 2 * D + s;
+        const int c = (i - (D == 0 && s)) + g.nx * ((j - (D == 1 && s)) + g.ny * (k - (D == 2 && s)));
+        if (g.p_bc[patch] == 1) { const double gb = 2.0 * af * rAUf[f] * g.dx; fl = s ? gb * (g.p_val[patch] - p[c]) : gb * (p[c] - g.p_val[patch]); }
+        else if (g.p_bc[patch] == 2) fl = af * rAUf[f] * g.Af * psn[f];
+    } else {
+        const int c = i + g.nx * (j + g.ny * k);
+        fl = af * rAUf[f] * g.dx * (p[c] - p[c - stride_of(g, D)]);
+    }
+    pflux[f] = fl;
+    phi[f] = phiHbyA[f] - fl / af;
+}
+
+// ------------------------------------------------------------------------------------------------ cell kernels
+// CourantNo.H:32-49: sumPhi = fvc::surfaceSum(mag(phi)); slots: 0 = max(sumPhi/V), 1 = sum(sumPhi)
+__global__ __launch_bounds__(256) void k_courant(FvGeo g, CFace3 phi, double* __restrict__ partials) {
+    double v[2] = {0.0, 0.0};
+    for (int c = blockIdx.x * 256 + threadIdx.x; c < g.Nc; c += gridDim.x * 256) {
+        int i, j, k; ijk_of(g, c, i, j, k);
+        double s = 0.0;
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+#pragma unroll
+            for (int sd = 0; sd < 2; ++sd) s += fabs(phi.a[d][cface(g, d, sd, i, j, k)]);
+        v[0] = fmax(v[0], s / g.V);
+        v[1] += s;
+    }
+    const int mx[2] = {1, 0};
+    block_reduce_store<2>(v, mx, partials);
+}
+
+// vGrad = fvc::grad(U) (icoFoamYade.C:71, pimpleFoamYade.C:76); pimple also gradP = fvc::grad(p) (:74) and
+// divT = 2 nu fvc::laplacian(alphac, Uc) (:75)
+__global__ __launch_bounds__(256) void k_pre_coupling(FvGeo g, const double* __restrict__ U, const double* __restrict__ p,
+                                                      const double* __restrict__ alpha, CFace3 psn, double* __restrict__ vGrad,
+                                                      double* __restrict__ gradP, double* __restrict__ divT) {
+    const int c = swz_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
+    if (c >= g.Nc) return;
+    int i, j, k; ijk_of(g, c, i, j, k);
+    const double uc[3] = {U[3 * (size_t)c], U[3 * (size_t)c + 1], U[3 * (size_t)c + 2]};
+    double lap[3] = {0, 0, 0};
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        double fv[2][3], fp[2] = {0, 0};
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            if (onb(g, d, s, i, j, k)) {
+                Ub(g, U, c, 2 * d + s, fv[s]);
+                if (g.pimple) {
+                    fp[s] = pbv(g, p, psn, c, d, s, cface(g, d, s, i, j, k));
+                    for (int q = 0; q < 3; ++q) lap[q] += 1.0 * g.Af * (fv[s][q] - uc[q]) / (0.5 * g.dx);     // alphaf = 1 on the boundary
+                }
+            } else {
+                const int nb = c + (s ? stride_of(g, d) : -stride_of(g, d));
+                const double un[3] = {U[3 * (size_t)nb], U[3 * (size_t)nb + 1], U[3 * (size_t)nb + 2]};
+                for (int q = 0; q < 3; ++q) fv[s][q] = 0.5 * (uc[q] + un[q]);
+                if (g.pimple) {
+                    fp[s] = 0.5 * (p[c] + p[nb]);
+                    const double af = 0.5 * (alpha[c] + alpha[nb]);
+                    for (int q = 0; q < 3; ++q) lap[q] += af * g.Af * (un[q] - uc[q]) / g.dx;
+                }
+            }
+        }
+        for (int q = 0; q < 3; ++q) vGrad[9 * (size_t)c + 3 * d + q] = (fv[1][q] - fv[0][q]) / g.dx;
+        if (g.pimple) gradP[3 * (size_t)c + d] = (fp[1] - fp[0]) / g.dx;
+    }
+    if (g.pimple)
+        for (int q = 0; q < 3; ++q) divT[3 * (size_t)c + q] = 2 * g.nu * (lap[q] / g.V);
+}
+
+// explicit part of divDevRhoReff (laminar Stokes): G = alpha nu dev2(T(grad U))
+__global__ __launch_bounds__(256) void k_stress_G(FvGeo g, const double* __restrict__ vGrad, const double* __restrict__ alpha, double* __restrict__ G) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= g.Nc) return;
+    const double* T = vGrad + 9 * (size_t)c;
+    double t[9];
+    for (int q = 0; q < 9; ++q) t[q] = T[q];
+    const double tr = t[0] + t[4] + t[8];
+    const double an = alpha[c] * g.nu;
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) G[9 * (size_t)c + 3 * a + b] = an * (t[3 * b + a] - (a == b ? (2.0 / 3.0) * tr : 0.0));
+}
+
+__global__ __launch_bounds__(256) void k_div_G(FvGeo g, const double* __restrict__ G, double* __restrict__ divG) {
+    const int c = swz_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
+    if (c >= g.Nc) return;
+    int i, j, k; ijk_of(g, c, i, j, k);
+    double acc[3] = {0, 0, 0};
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        double fv[2][3];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            if (onb(g, d, s, i, j, k)) for (int q = 0; q < 3; ++q) fv[s][q] = G[9 * (size_t)c + 3 * d + q];
+            else { const int nb = c + (s ? stride_of(g, d) : -stride_of(g, d)); for (int q = 0; q < 3; ++q) fv[s][q] = 0.5 * (G[9 * (size_t)c + 3 * d + q] + G[9 * (size_t)nb + 3 * d + q]); }
+        }
+        for (int q = 0; q < 3; ++q) acc[q] += (fv[1][q] - fv[0][q]) / g.dx;
+    }
+    for (int q = 0; q < 3; ++q) divG[3 * (size_t)c + q] = acc[q];
+}
+
+// UEqn (icoFoamYade.C:79-85) / UcEqn + relax (UcEqn.H:3-12): diag, 6 neighbour coefficients, source (no pressure term), rAU = 1/A
+__global__ __launch_bounds__(256) void k_assemble_momentum(FvGeo g, const double* __restrict__ U, const double* __restrict__ Uold,
+                                                           const double* __restrict__ alpha, const double* __restrict__ alphaOld, CFace3 alphaf,
+                                                           CFace3 phi, const double* __restrict__ uSource, const double* __restrict__ uSourceDrag,
+                                                           const double* __restrict__ divG, Mom7 M, double* __restrict__ src, double* __restrict__ rAU) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= g.Nc) return;
+    int i, j, k; ijk_of(g, c, i, j, k);
+    const double nu = g.nu, dt = g.dt, V = g.V;
+    const bool pim = g.pimple != 0;
+    const double aP = pim ? alpha[c] : 1.0, aP0 = pim ? alphaOld[c] : 1.0;
+    double dg = aP * V / dt;
+    double s3[3];
+    for (int q = 0; q < 3; ++q) s3[q] = aP0 * V * Uold[3 * (size_t)c + q] / dt;
+    double divAPhi = 0.0, an[6];
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int f = cface(g, d, s, i, j, k);
+            const double af = pim ? alphaf.a[d][f] : 1.0;
+            const double phio = (s ? 1.0 : -1.0) * af * phi.a[d][f];
+            divAPhi += phio;
+            const double gam = nu * af * g.dx;
+            if (onb(g, d, s, i, j, k)) {
+                an[2 * d + s] = 0.0;
+                const int patch = 2 * d + s;
+                if (g.u_bc[patch] == 0) {
+                    const double gb = 2.0 * gam;
+                    dg += gb;
+                    for (int q = 0; q < 3; ++q) s3[q] += (-phio + gb) * g.u_val[patch][q];
+                } else {
+                    dg += phio;
+                }
+            } else {
+                dg += 0.5 * phio + gam;
+                an[2 * d + s] = 0.5 * phio - gam;
+            }
+        }
+    if (pim) {
+        const double S = (alpha[c] - alphaOld[c]) / dt + divAPhi / V;
+        dg -= V * S;
+        dg -= V * uSourceDrag[c];
+        for (int q = 0; q < 3; ++q) s3[q] += V * divG[3 * (size_t)c + q];
+        double so = 0.0;
+        for (int q = 0; q < 6; ++q) so += fabs(an[q]);
+        const double dn = fmax(fabs(dg), so);                 // fvMatrix::relax(1): diagonal dominance
+        for (int q = 0; q < 3; ++q) s3[q] += (dn - dg) * U[3 * (size_t)c + q];
+        dg = dn;
+    } else {
+        for (int q = 0; q < 3; ++q) s3[q] += V * uSource[3 * (size_t)c + q];
+    }
+    M.diag[c] = dg;
+    for (int q = 0; q < 6; ++q) M.an[q][c] = an[q];
+    for (int q = 0; q < 3; ++q) src[3 * (size_t)c + q] = s3[q];
+    rAU[c] = 1.0 / (dg / V);
+}
+
+// RHS of the momentum predictor: ico  src - V grad(p)            (icoFoamYade.C:91-94)
+//                                pimple src + V reconstruct(phicForces/rAUcf - snGrad(p) magSf)   (UcEqn.H:22-33)
+__global__ __launch_bounds__(256) void k_bmom(FvGeo g, const double* __restrict__ src, const double* __restrict__ p, CFace3 psn,
+                                              CFace3 phiForces, CFace3 rAUf, double* __restrict__ bmom) {
+    const int c = swz_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
+    if (c >= g.Nc) return;
+    int i, j, k; ijk_of(g, c, i, j, k);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        if (!g.pimple) {
+            double fv[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                if (onb(g, d, s, i, j, k)) fv[s] = pbv(g, p, psn, c, d, s, cface(g, d, s, i, j, k));
+                else fv[s] = 0.5 * (p[c] + p[c + (s ? stride_of(g, d) : -stride_of(g, d))]);
+            }
+            bmom[3 * (size_t)c + d] = src[3 * (size_t)c + d] - g.V * ((fv[1] - fv[0]) / g.dx);
+        } else {
+            double sm = 0;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int f = cface(g, d, s, i, j, k);
+                double sng;
+                if (onb(g, d, s, i, j, k)) { const double pbd = pbv(g, p, psn, c, d, s, f); sng = s ? (pbd - p[c]) / (0.5 * g.dx) : (p[c] - pbd) / (0.5 * g.dx); }
+                else sng = s ? (p[c + stride_of(g, d)] - p[c]) / g.dx : (p[c] - p[c - stride_of(g, d)]) / g.dx;
+                sm += phiForces.a[d][f] / rAUf.a[d][f] - sng * g.Af;
+            }
+            bmom[3 * (size_t)c + d] = src[3 * (size_t)c + d] + g.V * (sm / (2.0 * g.Af));
+        }
+    }
+}
+
+// One fused Jacobi pass over the 3 velocity components: with x the current iterate, accumulate the L1 residual |b - A x|
+// (slots 0..2), the lduMatrix normalisation sum |A x - A xbar| + |b - A xbar| (slots 3..5) and write the next iterate xn.
+__global__ __launch_bounds__(256) void k_mom_pass(FvGeo g, Mom7 M, const double* __restrict__ b, const double* __restrict__ x,
+                                                  double* __restrict__ xn, const double* __restrict__ xbar, double* __restrict__ partials) {
+    double v[6] = {0, 0, 0, 0, 0, 0};
+    const double xb[3] = {xbar[0], xbar[1], xbar[2]};
+    for (int c = blockIdx.x * 256 + threadIdx.x; c < g.Nc; c += gridDim.x * 256) {
+        int i, j, k; ijk_of(g, c, i, j, k);
+        const double dg = M.diag[c];
+        double off[3] = {0, 0, 0}, rowsum = dg;
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+                if (!onb(g, d, s, i, j, k)) {
+                    const int nb = c + (s ? stride_of(g, d) : -stride_of(g, d));
+                    const double a = M.an[2 * d + s][c];
+                    rowsum += a;
+                    for (int q = 0; q < 3; ++q) off[q] += a * x[3 * (size_t)nb + q];
+                }
+        for (int q = 0; q < 3; ++q) {
+            const double bq = b[3 * (size_t)c + q];
+            const double Ax = dg * x[3 * (size_t)c + q] + off[q];
+            const double Aref = rowsum * xb[q];
+            v[q] += fabs(bq - Ax);
+            v[3 + q] += fabs(Ax - Aref) + fabs(bq - Aref);
+            xn[3 * (size_t)c + q] = (bq - off[q]) / dg;
+        }
+    }
+    const int mx[6] = {0, 0, 0, 0, 0, 0};
+    block_reduce_store<6>(v, mx, partials);
+}
+
+__global__ __launch_bounds__(256) void k_sum3(const double* __restrict__ x, int n, double* __restrict__ partials) {
+    double v[3] = {0, 0, 0};
+    for (int c = blockIdx.x * 256 + threadIdx.x; c < n; c += gridDim.x * 256)
+        for (int q = 0; q < 3; ++q) v[q] += x[3 * (size_t)c + q];
+    const int mx[3] = {0, 0, 0};
+    block_reduce_store<3>(v, mx, partials);
+}
+
+// HbyA = rAU * UEqn.H() (icoFoamYade.C:100, pEqn.H:2)
+__global__ __launch_bounds__(256) void k_HbyA(FvGeo g, Mom7 M, const double* __restrict__ src, const double* __restrict__ U,
+                                              const double* __restrict__ rAU, double* __restrict__ HbyA) {
+    const int c = swz_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
+    if (c >= g.Nc) return;
+    int i, j, k; ijk_of(g, c, i, j, k);
+    double acc[3] = {src[3 * (size_t)c], src[3 * (size_t)c + 1], src[3 * (size_t)c + 2]};
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+            if (!onb(g, d, s, i, j, k)) {
+                const int nb = c + (s ? stride_of(g, d) : -stride_of(g, d));
+                const double a = M.an[2 * d + s][c];
+                for (int q = 0; q < 3; ++q) acc[q] -= a * U[3 * (size_t)nb + q];
+            }
+    const double r = rAU[c];
+    for (int q = 0; q < 3; ++q) HbyA[3 * (size_t)c + q] = r * (acc[q] / g.V);
+}
+
+// pEqn in SPD form: sum_f g_f (p_P - p_nb) [+ g_b (p_P - p_b)] = -(ddt(alpha) V + sum_out alphaf phiHbyA)   (icoFoamYade.C:118-123, pEqn.H:26-33)
+__global__ __launch_bounds__(256) void k_assemble_pressure(FvGeo g, CFace3 phiHbyA, CFace3 rAUf, CFace3 alphaf, CFace3 psn,
+                                                           const double* __restrict__ alpha, const double* __restrict__ alphaOld, PMat A,
+                                                           double* __restrict__ rhs) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= g.Nc) return;
+    int i, j, k; ijk_of(g, c, i, j, k);
+    double dg = 0.0, r = 0.0, up[3] = {0, 0, 0};
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int f = cface(g, d, s, i, j, k);
+            const double af = g.pimple ? alphaf.a[d][f] : 1.0;
+            const double rf = rAUf.a[d][f];
+            double ph = (s ? 1.0 : -1.0) * af * phiHbyA.a[d][f];
+            const bool b = onb(g, d, s, i, j, k);
+            if (b && g.p_bc[2 * d + s] == 2) ph = (s ? 1.0 : -1.0) * af * (phiHbyA.a[d][f] - rf * g.Af * psn.a[d][f]);
+            r -= ph;
+            if (b) {
+                const int patch = 2 * d + s;
+                if (g.p_bc[patch] == 1) { const double gb = 2.0 * af * rf * g.dx; dg += gb; r += gb * g.p_val[patch]; }
+            } else {
+                const double gg = af * rf * g.dx;
+                dg += gg;
+                if (s) up[d] = gg;
+            }
+        }
+    if (g.pimple) r -= g.V * (alpha[c] - alphaOld[c]) / g.dt;
+    if (g.need_ref && c == g.p_ref_cell) { r += dg * g.p_ref_value; dg += dg; }      // fvMatrix::setReference
+    A.diag[c] = dg; A.ux[c] = up[0]; A.uy[c] = up[1]; A.uz[c] = up[2];
+    rhs[c] = r;
+}
+
+// continuityErrs.H:32-46: contErr = [ddt(alpha) +] div([alphaf] phi); slots 0 = sum |contErr| V, 1 = sum contErr V
+__global__ __launch_bounds__(256) void k_cont_err(FvGeo g, CFace3 phi, CFace3 alphaf, const double* __restrict__ alpha,
+                                                  const double* __restrict__ alphaOld, double* __restrict__ partials) {
+    double v[2] = {0, 0};
+    for (int c = blockIdx.x * 256 + threadIdx.x; c < g.Nc; c += gridDim.x * 256) {
+        int i, j, k; ijk_of(g, c, i, j, k);
+        double dv = 0;
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) { const int f = cface(g, d, s, i, j, k); dv += (s ? 1.0 : -1.0) * (g.pimple ? alphaf.a[d][f] : 1.0) * phi.a[d][f]; }
+        double ce = dv / g.V;
+        if (g.pimple) ce += (alpha[c] - alphaOld[c]) / g.dt;
+        v[0] += fabs(ce) * g.V;
+        v[1] += ce * g.V;
+    }
+    const int mx[2] = {0, 0};
+    block_reduce_store<2>(v, mx, partials);
+}
+
+// ico:    U = HbyA - rAU*fvc::grad(p)                                                         icoFoamYade.C:136
+// pimple: Uc = HbyA + rAUc*fvc::reconstruct((phicForces - pEqn.flux()/alphacf)/rAUcf)         pEqn.H:43-45
+__global__ __launch_bounds__(256) void k_U_correct(FvGeo g, const double* __restrict__ HbyA, const double* __restrict__ rAU,
+                                                   const double* __restrict__ p, CFace3 psn, CFace3 phiForces, CFace3 pflux, CFace3 alphaf,
+                                                   CFace3 rAUf, double* __restrict__ U) {
+    const int c = swz_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
+    if (c >= g.Nc) return;
+    int i, j, k; ijk_of(g, c, i, j, k);
+    const double r = rAU[c];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        if (!g.pimple) {
+            double fv[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                if (onb(g, d, s, i, j, k)) fv[s] = pbv(g, p, psn, c, d, s, cface(g, d, s, i, j, k));
+                else fv[s] = 0.5 * (p[c] + p[c + (s ? stride_of(g, d) : -stride_of(g, d))]);
+            }
+            U[3 * (size_t)c + d] = HbyA[3 * (size_t)c + d] - r * ((fv[1] - fv[0]) / g.dx);
+        } else {
+            double sm = 0;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) { const int f = cface(g, d, s, i, j, k); sm += (phiForces.a[d][f] - pflux.a[d][f] / alphaf.a[d][f]) / rAUf.a[d][f]; }
+            U[3 * (size_t)c + d] = HbyA[3 * (size_t)c + d] + r * (sm / (2.0 * g.Af));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ pressure solver
+// y = A x.  The pEqn Laplacian apply: 48 algorithmic bytes per cell (diag 8 + ux,uy,uz 24 + x 8 + y 8); the low-side
+// coefficients ux[c-1], uy[c-nx], uz[c-nx*ny] and the six neighbour x values are re-reads served by L1/L2.
+// High-side boundary faces store 0, so the wrapped low-side reads (e.g. ux[c-1] at i = 0) multiply by 0 and only the
+// array ends need an index guard.
+__device__ __forceinline__ double p_row(const PMat& A, const double* __restrict__ x, int c) {
+    const int sy = A.nx, sz = A.nx * A.ny;
+    double a = A.diag[c] * x[c];
+    if (c >= 1) a -= A.ux[c - 1] * x[c - 1];
+    if (c + 1 < A.N) a -= A.ux[c] * x[c + 1];
+    if (c >= sy) a -= A.uy[c - sy] * x[c - sy];
+    if (c + sy < A.N) a -= A.uy[c] * x[c + sy];
+    if (c >= sz) a -= A.uz[c - sz] * x[c - sz];
+    if (c + sz < A.N) a -= A.uz[c] * x[c + sz];
+    return a;
+}
+
+__global__ __launch_bounds__(256) void k_p_apply(PMat A, const double* __restrict__ x, double* __restrict__ y) {
+    const int c = swz_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
+    if (c >= A.N) return;
+    y[c] = p_row(A, x, c);
+}
+
+__global__ __launch_bounds__(256) void k_p_apply_dot(PMat A, const double* __restrict__ x, double* __restrict__ y, double* __restrict__ partials) {
+    double v[1] = {0};
+    for (int c = blockIdx.x * 256 + threadIdx.x; c < A.N; c += gridDim.x * 256) {
+        const double a = p_row(A, x, c);
+        y[c] = a;
+        v[0] += a * x[c];
+    }
+    const int mx[1] = {0};
+    block_reduce_store<1>(v, mx, partials);
+}
+
+// r = b - A x ; slot 0 = sum|r| ; slot 1 = sum(|A x - A xbar| + |b - A xbar|)   (lduMatrix::solver::normFactor)
+__global__ __launch_bounds__(256) void k_p_init(PMat A, const double* __restrict__ b, const double* __restrict__ x, double xbar,
+                                                double* __restrict__ r, double* __restrict__ partials) {
+    double v[2] = {0, 0};
+    const int sy = A.nx, sz = A.nx * A.ny;
+    for (int c = blockIdx.x * 256 + threadIdx.x; c < A.N; c += gridDim.x * 256) {
+        const double Ax = p_row(A, x, c);
+        double rs = A.diag[c];
+        if (c >= 1) rs -= A.ux[c - 1];
+        if (c + 1 < A.N) rs -= A.ux[c];
+        if (c >= sy) rs -= A.uy[c - sy];
+        if (c + sy < A.N) rs -= A.uy[c];
+        if (c >= sz) rs -= A.uz[c - sz];
+        if (c + sz < A.N) rs -= A.uz[c];
+        const double Aref = rs * xbar;
+        const double rr = b[c] - Ax;
+        r[c] = rr;
+        v[0] += fabs(rr);
+        v[1] += fabs(Ax - Aref) + fabs(b[c] - Aref);
+    }
+    const int mx[2] = {0, 0};
+    block_reduce_store<2>(v, mx, partials);
+}
+
+__global__ __launch_bounds__(256) void k_dot(int n, const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ partials) {
+    double v[1] = {0};
+    for (int c = blockIdx.x * 256 + threadIdx.x; c < n; c += gridDim.x * 256) v[0] += a[c] * b[c];
+    const int mx[1] = {0};
+    block_reduce_store<1>(v, mx, partials);
+}
+
+// sc[0] = wArA, sc[1] = wArAold, sc[2] = wApA
+__global__ __launch_bounds__(256) void k_pcg_update_p(int n, const double* __restrict__ z, double* __restrict__ p, const double* __restrict__ sc, int first) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= n) return;
+    if (first) p[c] = z[c];
+    else { const double beta = sc[0] / sc[1]; p[c] = z[c] + beta * p[c]; }
+}
+
+__global__ __launch_bounds__(256) void k_pcg_update_xr(int n, double* __restrict__ x, double* __restrict__ r, const double* __restrict__ p,
+                                                       const double* __restrict__ w, const double* __restrict__ sc, double* __restrict__ partials) {
+    double v[1] = {0};
+    const double al = sc[0] / sc[2];
+    for (int c = blockIdx.x * 256 + threadIdx.x; c < n; c += gridDim.x * 256) {
+        x[c] += al * p[c];
+        const double rr = r[c] - al * w[c];
+        r[c] = rr;
+        v[0] += fabs(rr);
+    }
+    const int mx[1] = {0};
+    block_reduce_store<1>(v, mx, partials);
+}
+
+__global__ __launch_bounds__(256) void k_jacobi_precond(PMat A, const double* __restrict__ r, double* __restrict__ z) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < A.N) z[c] = r[c] / A.diag[c];
+}
+
+// A_coarse = 1/2 P^T A P, piecewise-constant P over 2x2x2 aggregates (gather form: one thread per coarse cell)
+__global__ __launch_bounds__(256) void k_mg_coarsen(PMat F, PMat C) {
+    const int cc = blockIdx.x * 256 + threadIdx.x;
+    if (cc >= C.N) return;
+    const int I = cc % C.nx, t = cc / C.nx, J = t % C.ny, K = t / C.ny;
+    double dg = 0, ux = 0, uy = 0, uz = 0;
+    for (int dk = 0; dk < 2; ++dk) {
+        const int k = 2 * K + dk; if (k >= F.nz) break;
+        for (int dj = 0; dj < 2; ++dj) {
+            const int j = 2 * J + dj; if (j >= F.ny) break;
+            for (int di = 0; di < 2; ++di) {
+                const int i = 2 * I + di; if (i >= F.nx) break;
+                const int c = i + F.nx * (j + F.ny * k);
+                dg += 0.5 * F.diag[c];
+                if (i < F.nx - 1) { if (di == 0) dg -= F.ux[c]; else ux += 0.5 * F.ux[c]; }
+                if (j < F.ny - 1) { if (dj == 0) dg -= F.uy[c]; else uy += 0.5 * F.uy[c]; }
+                if (k < F.nz - 1) { if (dk == 0) dg -= F.uz[c]; else uz += 0.5 * F.uz[c]; }
+            }
+        }
+    }
+    C.diag[cc] = dg; C.ux[cc] = ux; C.uy[cc] = uy; C.uz[cc] = uz;
+}
+
+__global__ __launch_bounds__(256) void k_mg_smooth_first(PMat A, const double* __restrict__ b, double* __restrict__ x, double w) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < A.N) x[c] = w * b[c] / A.diag[c];
+}
+
+__global__ __launch_bounds__(256) void k_mg_smooth(PMat A, const double* __restrict__ b, const double* __restrict__ x, double* __restrict__ xn, double w) {
+    const int c = swz_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
+    if (c >= A.N) return;
+    xn[c] = x[c] + w * (b[c] - p_row(A, x, c)) / A.diag[c];
+}
+
+__global__ __launch_bounds__(256) void k_mg_residual_restrict(PMat A, const double* __restrict__ b, const double* __restrict__ x, PMat C,
+                                                              double* __restrict__ bc) {
+    const int cc = blockIdx.x * 256 + threadIdx.x;
+    if (cc >= C.N) return;
+    const int I = cc % C.nx, t = cc / C.nx, J = t % C.ny, K = t / C.ny;
+    double acc = 0;
+    for (int dk = 0; dk < 2; ++dk) {
+        const int k = 2 * K + dk; if (k >= A.nz) break;
+        for (int dj = 0; dj < 2; ++dj) {
+            const int j = 2 * J + dj; if (j >= A.ny) break;
+            for (int di = 0; di < 2; ++di) {
+                const int i = 2 * I + di; if (i >= A.nx) break;
+                const int c = i + A.nx * (j + A.ny * k);
+                acc += b[c] - p_row(A, x, c);
+            }
+        }
+    }
+    bc[cc] = acc;
+}
+
+__global__ __launch_bounds__(256) void k_mg_prolong_add(PMat A, double* __restrict__ x, PMat C, const double* __restrict__ xc) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= A.N) return;
+    const int i = c % A.nx, t = c / A.nx, j = t % A.ny, k = t / A.ny;
+    x[c] += xc[(i >> 1) + C.nx * ((j >> 1) + C.ny * (k >> 1))];
+}
+
+// coarsest level (N <= 1024): all sweeps inside one workgroup
+__global__ __launch_bounds__(1024) void k_mg_coarse_solve(PMat A, const double* __restrict__ b, double* __restrict__ x, double* __restrict__ tmp,
+                                                          int sweeps, double w) {
+    const int c = threadIdx.x;
+    const bool act = c < A.N;
+    double* cur = x;
+    double* nxt = tmp;
+    if (act) cur[c] = w * b[c] / A.diag[c];
+    __syncthreads();
+    for (int s = 1; s < sweeps; ++s) {
+        if (act) nxt[c] = cur[c] + w * (b[c] - p_row(A, cur, c)) / A.diag[c];
+        __syncthreads();
+        double* t = cur; cur = nxt; nxt = t;
+    }
+    if (cur != x) { if (act) x[c] = cur[c]; }
+}
+
+__global__ __launch_bounds__(256) void k_copy(double* __restrict__ dst, const double* __restrict__ src, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+
+#define FY_LAUNCH_CHECK()                                                                                     \
+    do {                                                                                                      \
+        hipError_t _e = hipGetLastError();                                                                    \
+        if (_e != hipSuccess) return fail(FY_ERR_HIP, "kernel launch failed: %s (%s:%d)", hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+}  // namespace
+
+static const int g_last_red_blocks = kRedBlocks;
+
+int launch_reduce_finalize(hipStream_t s, const double* partials, int nslots, const int* ops, double* out) {
+    hipLaunchKernelGGL(k_reduce_finalize, dim3(nslots), dim3(256), 0, s, partials, g_last_red_blocks, ops, out);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+
+int launch_flux_of(hipStream_t s, FvGeo g, const double* F, Face3 out) {
+    hipLaunchKernelGGL(k_flux_of<0>, dim3(div_up(fv_fsize(g, 0), 256)), dim3(256), 0, s, g, F, out.a[0]);
+    hipLaunchKernelGGL(k_flux_of<1>, dim3(div_up(fv_fsize(g, 1), 256)), dim3(256), 0, s, g, F, out.a[1]);
+    hipLaunchKernelGGL(k_flux_of<2>, dim3(div_up(fv_fsize(g, 2), 256)), dim3(256), 0, s, g, F, out.a[2]);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+
+int launch_courant(hipStream_t s, FvGeo g, CFace3 phi, double* partials) {
+    hipLaunchKernelGGL(k_courant, dim3(g_last_red_blocks), dim3(256), 0, s, g, phi, partials);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+
+int launch_pre_coupling(hipStream_t s, FvGeo g, const double* U, const double* p, const double* alpha, CFace3 psn, double* vGrad,
+                        double* gradP, double* divT) {
+    hipLaunchKernelGGL(k_pre_coupling, dim3(div_up(g.Nc, 256)), dim3(256), 0, s, g, U, p, alpha, psn, vGrad, gradP, divT);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+
+int launch_interp_alpha(hipStream_t s, FvGeo g, const double* alpha, Face3 af) {
+    hipLaunchKernelGGL(k_interp_alpha<0>, dim3(div_up(fv_fsize(g, 0), 256)), dim3(256), 0, s, g, alpha, af.a[0]);
+    hipLaunchKernelGGL(k_interp_alpha<1>, dim3(div_up(fv_fsize(g, 1), 256)), dim3(256), 0, s, g, alpha, af.a[1]);
+    hipLaunchKernelGGL(k_interp_alpha<2>, dim3(div_up(fv_fsize(g, 2), 256)), dim3(256), 0, s, g, alpha, af.a[2]);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+
+int launch_stress_G(hipStream_t s, FvGeo g, const double* vGrad, const double* alpha, double* G) {
+    hipLaunchKernelGGL(k_stress_G, dim3(div_up(g.Nc, 256)), dim3(256), 0, s, g, vGrad, alpha, G);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+
+int launch_div_G(hipStream_t s, FvGeo g, const double* G, double* divG) {
+    hipLaunchKernelGGL(k_div_G, dim3(div_up(g.Nc, 256)), dim3(256), 0, s, g, G, divG);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+
+int launch_assemble_momentum(hipStream_t s, FvGeo g, const double* U, const double* Uold, const double* alpha, const double* alphaOld,
+                             CFace3 alphaf, CFace3 phi, const double* uSource, const double* uSourceDrag, const double* divG, Mom7 M,
+                             double* src, double* rAU) {
+    hipLaunchKernelGGL(k_assemble_momentum, dim3(div_up(g.Nc, 256)), dim3(256), 0, s, g, U, Uold, alpha, alphaOld, alphaf, phi, uSource,
+                       uSourceDrag, divG, M, src, rAU);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+
+int launch_interp_rAU(hipStream_t s, FvGeo g, const double* rAU, Face3 rf) {
+    hipLaunchKernelGGL(k_interp_rAU<0>, dim3(div_up(fv_fsize(g, 0), 256)), dim3(256), 0, s, g, rAU, rf.a[0]);
+    hipLaunchKernelGGL(k_interp_rAU<1>, dim3(div_up(fv_fsize(g, 1), 256)), dim3(256), 0, s, g, rAU, rf.a[1]);
+    hipLaunchKernelGGL(k_interp_rAU<2>, dim3(div_up(fv_fsize(g, 2), 256)), dim3(256), 0, s, g, rAU, rf.a[2]);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+
+int launch_phi_forces(hipStream_t s, FvGeo g, const double* rAU, CFace3 rAUf, const double* uSource, Face3 out) {
+    hipLaunchKernelGGL(k_phi_forces<0>, dim3(div_up(fv_fsize(g, 0), 256)), dim3(256), 0, s, g, rAU, rAUf.a[0], uSource, out.a[0]);
+    hipLaunchKernelGGL(k_phi_forces<1>, dim3(div_up(fv_fsize(g, 1), 256)), dim3(256), 0, s, g, rAU, rAUf.a[1], uSource, out.a[1]);
+    hipLaunchKernelGGL(k_phi_forces<2>, dim3(div_up(fv_fsize(g, 2), 256)), dim3(256), 0, s, g, rAU, rAUf.a[2], uSource, out.a[2]);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+
+int launch_bmom(hipStream_t s, FvGeo g, const double* src, const double* p, CFace3 psn, CFace3 phiForces, CFace3 rAUf, double* bmom) {
+    hipLaunchKernelGGL(k_bmom, dim3(div_up(g.Nc, 256)), dim3(256), 0, s, g, src, p, psn, phiForces, rAUf, bmom);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+
+int launch_mom_pass(hipStream_t s, FvGeo g, Mom7 M, const double* b, const double* x, double* xn, const double* xbar, double* partials) {
+    hipLaunchKernelGGL(k_mom_pass, dim3(g_last_red_blocks), dim3(256), 0, s, g, M, b, x, xn, xbar, partials);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+
+int launch_sum3(hipStream_t s, const double* x, int n, double* partials) {
+    hipLaunchKernelGGL(k_sum3, dim3(g_last_red_blocks), dim3(256), 0, s, x, n, partials);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+
+int launch_HbyA(hipStream_t s, FvGeo g, Mom7 M, const double* src, const double* U, const double* rAU, double* HbyA) {
+    hipLaunchKernelGGL(k_HbyA, dim3(div_up(g.Nc, 256)), dim3(256), 0, s, g, M, src, U, rAU, HbyA);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+
+int launch_phiHbyA(hipStream_t s, FvGeo g, const double* HbyA, const double* U, const double* Uold, CFace3 phiOld, CFace3 rAUf,
+                   CFace3 alphaf, CFace3 phiForces, Face3 out, Face3 psn) {
+    hipLaunchKernelGGL(k_phiHbyA<0>, dim3(div_up(fv_fsize(g, 0), 256)), dim3(256), 0, s, g, HbyA, U, Uold, phiOld.a[0], rAUf.a[0], alphaf.a[0], phiForces.a[0], out.a[0], psn.a[0]);
+    hipLaunchKernelGGL(k_phiHbyA<1>, dim3(div_up(fv_fsize(g, 1), 256)), dim3(256), 0, s, g, HbyA, U, Uold, phiOld.a[1], rAUf.a[1], alphaf.a[1], phiForces.a[1], out.a[1], psn.a[1]);
+    hipLaunchKernelGGL(k_phiHbyA<2>, dim3(div_up(fv_fsize(g, 2), 256)), dim3(256), 0, s, g, HbyA, U, Uold, phiOld.a[2], rAUf.a[2], alphaf.a[2], phiForces.a[2], out.a[2], psn.a[2]);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+
+int launch_assemble_pressure(hipStream_t s, FvGeo g, CFace3 phiHbyA, CFace3 rAUf, CFace3 alphaf, CFace3 psn, const double* alpha,
+                             const double* alphaOld, PMat A, double* rhs) {
+    hipLaunchKernelGGL(k_assemble_pressure, dim3(div_up(g.Nc, 256)), dim3(256), 0, s, g, phiHbyA, rAUf, alphaf, psn, alpha, alphaOld, A, rhs);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+
+int launch_flux_correct(hipStream_t s, FvGeo g, const double* p, CFace3 phiHbyA, CFace3 rAUf, CFace3 alphaf, CFace3 psn, Face3 pflux, Face3 phi) {
+    hipLaunchKernelGGL(k_flux_correct<0>, dim3(div_up(fv_fsize(g, 0), 256)), dim3(256), 0, s, g, p, phiHbyA.a[0], rAUf.a[0], alphaf.a[0], psn.a[0], pflux.a[0], phi.a[0]);
+    hipLaunchKernelGGL(k_flux_correct<1>, dim3(div_up(fv_fsize(g, 1), 256)), dim3(256), 0, s, g, p, phiHbyA.a[1], rAUf.a[1], alphaf.a[1], psn.a[1], pflux.a[1], phi.a[1]);
+    hipLaunchKernelGGL(k_flux_correct<2>, dim3(div_up(fv_fsize(g, 2), 256)), dim3(256), 0, s, g, p, phiHbyA.a[2], rAUf.a[2], alphaf.a[2], psn.a[2], pflux.a[2], phi.a[2]);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+
+int launch_cont_err(hipStream_t s, FvGeo g, CFace3 phi, CFace3 alphaf, const double* alpha, const double* alphaOld, double* partials) {
+    hipLaunchKernelGGL(k_cont_err, dim3(g_last_red_blocks), dim3(256), 0, s, g, phi, alphaf, alpha, alphaOld, partials);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+
+int launch_U_correct(hipStream_t s, FvGeo g, const double* HbyA, const double* rAU, const double* p, CFace3 psn, CFace3 phiForces,
+                     CFace3 pflux, CFace3 alphaf, CFace3 rAUf, double* U) {
+    hipLaunchKernelGGL(k_U_correct, dim3(div_up(g.Nc, 256)), dim3(256), 0, s, g, HbyA, rAU, p, psn, phiForces, pflux, alphaf, rAUf, U);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+
+int launch_p_apply(hipStream_t s, PMat A, const double* x, double* y) {
+    hipLaunchKernelGGL(k_p_apply, dim3(div_up(A.N, 256)), dim3(256), 0, s, A, x, y);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+
+int launch_p_apply_dot(hipStream_t s, PMat A, const double* x, double* y, double* partials) {
+    hipLaunchKernelGGL(k_p_apply_dot, dim3(g_last_red_blocks), dim3(256), 0, s, A, x, y, partials);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+
+int launch_p_init(hipStream_t s, PMat A, const double* b, const double* x, double xbar, double* r, double* partials) {
+    hipLaunchKernelGGL(k_p_init, dim3(g_last_red_blocks), dim3(256), 0, s, A, b, x, xbar, r, partials);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+
+int launch_dot(hipStream_t s, int n, const double* a, const double* b, double* partials) {
+    hipLaunchKernelGGL(k_dot, dim3(g_last_red_blocks), dim3(256), 0, s, n, a, b, partials);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+
+int launch_pcg_update_p(hipStream_t s, int n, const double* z, double* p, const double* sc, int first) {
+    hipLaunchKernelGGL(k_pcg_update_p, dim3(div_up(n, 256)), dim3(256), 0, s, n, z, p, sc, first);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+
+int launch_pcg_update_xr(hipStream_t s, int n, double* x, double* r, const double* p, const double* w, const double* sc, double* partials) {
+    hipLaunchKernelGGL(k_pcg_update_xr, dim3(g_last_red_blocks), dim3(256), 0, s, n, x, r, p, w, sc, partials);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+
+int launch_jacobi_precond(hipStream_t s, PMat A, const double* r, double* z) {
+    hipLaunchKernelGGL(k_jacobi_precond, dim3(div_up(A.N, 256)), dim3(256), 0, s, A, r, z);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+
+int launch_mg_coarsen(hipStream_t s, PMat F, PMat C) {
+    hipLaunchKernelGGL(k_mg_coarsen, dim3(div_up(C.N, 256)), dim3(256), 0, s, F, C);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+
+int launch_mg_smooth_first(hipStream_t s, PMat A, const double* b, double* x, double w) {
+    hipLaunchKernelGGL(k_mg_smooth_first, dim3(div_up(A.N, 256)), dim3(256), 0, s, A, b, x, w);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+
+int launch_mg_smooth(hipStream_t s, PMat A, const double* b, const double* x, double* xn, double w) {
+    hipLaunchKernelGGL(k_mg_smooth, dim3(div_up(A.N, 256)), dim3(256), 0, s, A, b, x, xn, w);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+
+int launch_mg_residual_restrict(hipStream_t s, PMat A, const double* b, const double* x, PMat C, double* bc) {
+    hipLaunchKernelGGL(k_mg_residual_restrict, dim3(div_up(C.N, 256)), dim3(256), 0, s, A, b, x, C, bc);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+
+int launch_mg_prolong_add(hipStream_t s, PMat A, double* x, PMat C, const double* xc) {
+    hipLaunchKernelGGL(k_mg_prolong_add, dim3(div_up(A.N, 256)), dim3(256), 0, s, A, x, C, xc);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+
+int launch_mg_coarse_solve(hipStream_t s, PMat A, const double* b, double* x, double* tmp, int sweeps, double w) {
+    if (A.N > 1024) return fail(FY_ERR_INVALID, "coarsest multigrid level too large (%d cells)", A.N);
+    hipLaunchKernelGGL(k_mg_coarse_solve, dim3(1), dim3(1024), 0, s, A, b, x, tmp, sweeps, w);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+
+int launch_copy_f64(hipStream_t s, double* dst, const double* src, size_t n) {
+    if (!n) return FY_OK;
+    hipLaunchKernelGGL(k_copy, dim3(div_up(n, 256)), dim3(256), 0, s, dst, src, n);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+
+}  // namespace fy

@@ -1,0 +1,89 @@
+// Launchers of the FV-half HIP kernels: the operators that icoFoamYade.C:65-149 / pimpleFoamYade.C:60-114 (+UcEqn.H, pEqn.H,
+// CourantNo.H, continuityErrs.H) invoke, restated for a uniform hex block (blockMesh order) as coalesced FP64 stencil kernels.
+// No MFMA anywhere: every kernel is bandwidth bound.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace fy {
+
+// geometry + boundary conditions, passed by value to every kernel
+struct FvGeo {
+    int nx, ny, nz, Nc;
+    double dx, Af, V;
+    int u_bc[6];            // FY_BC_U_*
+    double u_val[6][3];
+    int p_bc[6];            // FY_BC_P_*
+    double p_val[6];
+    int pimple;
+    double dt, nu;
+    double g[3];
+    int need_ref, p_ref_cell;
+    double p_ref_value;
+};
+
+struct Face3 { double* a[3]; };           // +axis oriented face arrays (x: (nx+1)*ny*nz, y: nx*(ny+1)*nz, z: nx*ny*(nz+1))
+struct CFace3 { const double* a[3]; };
+struct Mom7 { double* diag; double* an[6]; };   // momentum matrix: diag + neighbour coefficient across face 2*d+s
+
+// symmetric 7-point pressure matrix of one multigrid level: (A x)_c = diag_c x_c - sum u_f x_nb, u_* stored at the owner (low) cell
+struct PMat {
+    int nx, ny, nz, N;
+    double *diag, *ux, *uy, *uz;
+};
+
+constexpr int kRedBlocks = 1024;          // grid cap of the reduction kernels (partials per slot)
+
+inline size_t fv_fsize(const FvGeo& g, int d) {
+    return d == 0 ? (size_t)(g.nx + 1) * g.ny * g.nz : d == 1 ? (size_t)g.nx * (g.ny + 1) * g.nz : (size_t)g.nx * g.ny * (g.nz + 1);
+}
+
+// ---- reductions: kernels write per-block partials to scratch[slot*kRedBlocks + block]; finalize folds them in fixed order
+int launch_reduce_finalize(hipStream_t s, const double* partials, int nslots, const int* ops /*0 sum,1 max (device)*/, double* out);
+
+// ---- field operators
+int launch_flux_of(hipStream_t s, FvGeo g, const double* F, Face3 out);                                   // fvc::flux(F), createPhi
+int launch_courant(hipStream_t s, FvGeo g, CFace3 phi, double* partials);                                  // slots 0 (max) 1 (sum)
+int launch_pre_coupling(hipStream_t s, FvGeo g, const double* U, const double* p, const double* alpha, CFace3 psn,
+                        double* vGrad, double* gradP, double* divT);
+int launch_interp_alpha(hipStream_t s, FvGeo g, const double* alpha, Face3 alphaf);
+int launch_stress_G(hipStream_t s, FvGeo g, const double* vGrad, const double* alpha, double* G);
+int launch_div_G(hipStream_t s, FvGeo g, const double* G, double* divG);
+int launch_assemble_momentum(hipStream_t s, FvGeo g, const double* U, const double* Uold, const double* alpha, const double* alphaOld,
+                             CFace3 alphaf, CFace3 phi, const double* uSource, const double* uSourceDrag, const double* divG,
+                             Mom7 M, double* src, double* rAU);
+int launch_interp_rAU(hipStream_t s, FvGeo g, const double* rAU, Face3 rAUf);
+int launch_phi_forces(hipStream_t s, FvGeo g, const double* rAU, CFace3 rAUf, const double* uSource, Face3 phiForces);
+int launch_bmom(hipStream_t s, FvGeo g, const double* src, const double* p, CFace3 psn, CFace3 phiForces, CFace3 rAUf, double* bmom);
+// one fused Jacobi pass: residual sums of x (slots 0..2), norm-factor sums (slots 3..5, uses xbar[3]) and xn = next iterate
+int launch_mom_pass(hipStream_t s, FvGeo g, Mom7 M, const double* b, const double* x, double* xn, const double* xbar, double* partials);
+int launch_sum3(hipStream_t s, const double* x, int n, double* partials);                                  // slots 0..2 = component sums
+int launch_HbyA(hipStream_t s, FvGeo g, Mom7 M, const double* src, const double* U, const double* rAU, double* HbyA);
+int launch_phiHbyA(hipStream_t s, FvGeo g, const double* HbyA, const double* U, const double* Uold, CFace3 phiOld, CFace3 rAUf,
+                   CFace3 alphaf, CFace3 phiForces, Face3 phiHbyA, Face3 psn);
+int launch_assemble_pressure(hipStream_t s, FvGeo g, CFace3 phiHbyA, CFace3 rAUf, CFace3 alphaf, CFace3 psn, const double* alpha,
+                             const double* alphaOld, PMat A, double* rhs);
+int launch_flux_correct(hipStream_t s, FvGeo g, const double* p, CFace3 phiHbyA, CFace3 rAUf, CFace3 alphaf, CFace3 psn, Face3 pflux, Face3 phi);
+int launch_cont_err(hipStream_t s, FvGeo g, CFace3 phi, CFace3 alphaf, const double* alpha, const double* alphaOld, double* partials);   // slots 0,1
+int launch_U_correct(hipStream_t s, FvGeo g, const double* HbyA, const double* rAU, const double* p, CFace3 psn, CFace3 phiForces,
+                     CFace3 pflux, CFace3 alphaf, CFace3 rAUf, double* U);
+
+// ---- pressure solver building blocks
+int launch_p_apply(hipStream_t s, PMat A, const double* x, double* y);                                     // y = A x (the roofline kernel)
+int launch_p_apply_dot(hipStream_t s, PMat A, const double* x, double* y, double* partials);              // + slot 0 = x.y
+int launch_p_init(hipStream_t s, PMat A, const double* b, const double* x, double xbar, double* r, double* partials);   // r = b - A x; slots 0 |r|, 1 norm
+int launch_dot(hipStream_t s, int n, const double* a, const double* b, double* partials);                  // slot 0
+int launch_pcg_update_p(hipStream_t s, int n, const double* z, double* p, const double* sc, int first);    // p = z + (sc[0]/sc[1]) p
+int launch_pcg_update_xr(hipStream_t s, int n, double* x, double* r, const double* p, const double* w, const double* sc, double* partials);   // alpha = sc[0]/sc[2]; slot 0 = sum|r|
+int launch_jacobi_precond(hipStream_t s, PMat A, const double* r, double* z);
+int launch_mg_coarsen(hipStream_t s, PMat F, PMat C);
+int launch_mg_smooth_first(hipStream_t s, PMat A, const double* b, double* x, double w);                   // x = w b / diag
+int launch_mg_smooth(hipStream_t s, PMat A, const double* b, const double* x, double* xn, double w);      // xn = x + w (b - A x)/diag
+int launch_mg_residual_restrict(hipStream_t s, PMat A, const double* b, const double* x, PMat C, double* bc);   // bc = P^T (b - A x)
+int launch_mg_prolong_add(hipStream_t s, PMat A, double* x, PMat C, const double* xc);
+int launch_mg_coarse_solve(hipStream_t s, PMat A, const double* b, double* x, double* tmp, int sweeps, double w);
+
+int launch_copy_f64(hipStream_t s, double* dst, const double* src, size_t n);
+
+}  // namespace fy

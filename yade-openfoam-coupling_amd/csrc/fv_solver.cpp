@@ -1,14 +1,420 @@
-// placeholder until the FV half lands: every fy_solver_* symbol of include/foamyade_hip.h is exported and fails loudly
-#include "common.hpp"
+// fy_solver: the time-loop bodies of icoFoamYade (icoFoamYade/icoFoamYade.C:65-149) and pimpleFoamYade
+// (pimpleFoamYade/pimpleFoamYade.C:60-114 + UcEqn.H + pEqn.H) driving the HIP kernels of fv_kernels.hip, with the coupling
+// engine (fy_ctx) sharing the same device-resident fields and stream.  Host code only sequences kernels and reads back the
+// handful of scalars the control flow needs (residuals, Courant number, continuity errors).
+#include <algorithm>
+#include <cmath>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "coupling.hpp"
+#include "fv_kernels.hpp"
+
+namespace fy {
+
+struct MgLev {
+    PMat A{};
+    DevBuf<double> diag, ux, uy, uz, x0, x1, b;
+    double* xcur = nullptr;      // holds the level's current iterate
+    double* xalt = nullptr;
+    const double* bptr = nullptr;
+};
+
+struct Solver {
+    fy_case_desc cs{};
+    FvGeo g{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    fy_ctx* cpl = nullptr;
+    bool pimple = false;
+    int Nc = 0;
+
+    DevBuf<double> U, Uold, p, alpha, alphaOld, uSource, uSourceDrag, uParticle, gradP, divT, vGrad, ddtU;
+    DevBuf<double> phi[3], phiOld[3], psn[3], alphaf[3], phiHbyA[3], phiForces[3], rAUf[3], pflux[3];
+    DevBuf<double> mdiag, man[6], src, rAU, HbyA, bmom, Gt, divG, xscr;
+    std::vector<std::unique_ptr<MgLev> > mg;
+    DevBuf<double> prhs, pr, pw, pp, pzj;
+    DevBuf<double> partials, red_out, sc, xbar3;
+    DevBuf<int> ops_courant;
+    fy_step_stats st{};
+    double cumulative_cont_err = 0.0;
+    EventTimer tim[4];      // particle, momentum, pressure, total
+    bool timing = true;
+
+    Face3 F3(DevBuf<double>* a) { Face3 f; for (int d = 0; d < 3; ++d) f.a[d] = a[d].p; return f; }
+    CFace3 C3(DevBuf<double>* a) { CFace3 f; for (int d = 0; d < 3; ++d) f.a[d] = a[d].p; return f; }
+    Mom7 M7() { Mom7 m; m.diag = mdiag.p; for (int q = 0; q < 6; ++q) m.an[q] = man[q].p; return m; }
+
+    ~Solver() {
+        if (cpl) fy_destroy(cpl);
+        for (auto& t : tim) t.destroy();
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+
+    int zero(DevBuf<double>& b) { FY_HIP(hipMemsetAsync(b.p, 0, b.n * sizeof(double), stream)); return FY_OK; }
+
+    int create(const fy_case_desc* c, const fy_transport* tr, int dev) {
+        if (!c || c->nx <= 0 || c->ny <= 0 || c->nz <= 0 || !(c->dx > 0) || !(c->dt > 0)) return fail(FY_ERR_INVALID, "fy_solver_create: bad case");
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(FY_ERR_NO_DEVICE, "no HIP device visible: libfoamyade_hip has no CPU path");
+        if (dev < 0 || dev >= ndev) return fail(FY_ERR_INVALID, "device ordinal out of range");
+        cs = *c; device = dev; pimple = c->solver == FY_SOLVER_PIMPLE;
+        FY_HIP(hipSetDevice(device));
+        FY_HIP(hipStreamCreate(&stream));
+        Nc = c->nx * c->ny * c->nz;
+        g.nx = c->nx; g.ny = c->ny; g.nz = c->nz; g.Nc = Nc; g.dx = c->dx; g.Af = c->dx * c->dx; g.V = c->dx * c->dx * c->dx;
+        g.pimple = pimple ? 1 : 0; g.dt = c->dt; g.nu = c->nu;
+        bool need_ref = true;
+        for (int q = 0; q < 6; ++q) {
+            g.u_bc[q] = c->u_bc[q]; g.p_bc[q] = c->p_bc[q]; g.p_val[q] = c->p_value[q];
+            for (int a = 0; a < 3; ++a) g.u_val[q][a] = c->u_value[q][a];
+            if (c->p_bc[q] == FY_BC_P_FIXED_VALUE) need_ref = false;
+        }
+        for (int a = 0; a < 3; ++a) g.g[a] = c->g[a];
+        g.need_ref = need_ref ? 1 : 0; g.p_ref_cell = c->p_ref_cell; g.p_ref_value = c->p_ref_value;
+        if (c->p_ref_cell < 0 || c->p_ref_cell >= Nc) return fail(FY_ERR_INVALID, "pRefCell out of range");
+
+        const size_t n = (size_t)Nc;
+        DevBuf<double>* v3[] = {&U, &Uold, &uSource, &uParticle, &gradP, &divT, &ddtU, &src, &HbyA, &bmom, &divG, &xscr};
+        for (auto* b : v3) { FY_TRY(b->alloc_exact(3 * n)); FY_TRY(zero(*b)); }
+        DevBuf<double>* v1[] = {&p, &alpha, &alphaOld, &uSourceDrag, &mdiag, &rAU, &prhs, &pr, &pw, &pp, &pzj};
+        for (auto* b : v1) { FY_TRY(b->alloc_exact(n)); FY_TRY(zero(*b)); }
+        for (auto& b : man) { FY_TRY(b.alloc_exact(n)); FY_TRY(zero(b)); }
+        FY_TRY(vGrad.alloc_exact(9 * n)); FY_TRY(zero(vGrad));
+        FY_TRY(Gt.alloc_exact(9 * n)); FY_TRY(zero(Gt));
+        for (int d = 0; d < 3; ++d) {
+            DevBuf<double>* fs[] = {&phi[d], &phiOld[d], &psn[d], &alphaf[d], &phiHbyA[d], &phiForces[d], &rAUf[d], &pflux[d]};
+            for (auto* b : fs) { FY_TRY(b->alloc_exact(fv_fsize(g, d))); FY_TRY(zero(*b)); }
+            FY_TRY(launch_fill_f64(stream, alphaf[d].p, alphaf[d].n, 1.0));
+        }
+        FY_TRY(launch_fill_f64(stream, alpha.p, n, 1.0));
+        FY_TRY(launch_fill_f64(stream, alphaOld.p, n, 1.0));
+        FY_TRY(partials.alloc_exact(8 * (size_t)kRedBlocks)); FY_TRY(red_out.alloc_exact(8)); FY_TRY(sc.alloc_exact(4)); FY_TRY(xbar3.alloc_exact(3));
+        FY_TRY(zero(partials)); FY_TRY(zero(sc));
+        FY_TRY(ops_courant.alloc_exact(2));
+        { const int h[2] = {1, 0}; FY_HIP(hipMemcpyAsync(ops_courant.p, h, sizeof(h), hipMemcpyHostToDevice, stream)); FY_HIP(hipStreamSynchronize(stream)); }
+
+        // multigrid hierarchy: 2x2x2 aggregation down to <= 256 cells
+        int ax = g.nx, ay = g.ny, az = g.nz;
+        for (;;) {
+            std::unique_ptr<MgLev> L(new MgLev());
+            L->A.nx = ax; L->A.ny = ay; L->A.nz = az; L->A.N = ax * ay * az;
+            const size_t m = (size_t)L->A.N;
+            DevBuf<double>* bs[] = {&L->diag, &L->ux, &L->uy, &L->uz, &L->x0, &L->x1, &L->b};
+            for (auto* b : bs) { FY_TRY(b->alloc_exact(m)); FY_TRY(zero(*b)); }
+            L->A.diag = L->diag.p; L->A.ux = L->ux.p; L->A.uy = L->uy.p; L->A.uz = L->uz.p;
+            L->xcur = L->x0.p; L->xalt = L->x1.p; L->bptr = L->b.p;
+            const int N = L->A.N;
+            mg.push_back(std::move(L));
+            if (cs.p_solver != FY_PSOLVER_PCG_MG) break;
+            if (N <= 256 || (ax <= 2 && ay <= 2 && az <= 2)) break;
+            ax = (ax + 1) / 2; ay = (ay + 1) / 2; az = (az + 1) / 2;
+        }
+        if (mg.back()->A.N > 1024 && cs.p_solver == FY_PSOLVER_PCG_MG) return fail(FY_ERR_UNSUPPORTED, "coarsest multigrid level too large");
+        for (auto& t : tim) FY_TRY(t.init());
+
+        // the coupling object shares the solver's device fields and stream (icoFoamYade.C:54, pimpleFoamYade.C:54)
+        {
+            std::vector<double> C(3 * n), V(n, g.V);
+            for (int k = 0; k < g.nz; ++k) for (int j = 0; j < g.ny; ++j) for (int i = 0; i < g.nx; ++i) {
+                const size_t cc = (size_t)i + (size_t)g.nx * (j + (size_t)g.ny * k);
+                C[3 * cc] = c->origin[0] + (i + 0.5) * c->dx; C[3 * cc + 1] = c->origin[1] + (j + 0.5) * c->dx; C[3 * cc + 2] = c->origin[2] + (k + 0.5) * c->dx;
+            }
+            fy_mesh_desc md{};
+            md.n_cells = Nc; md.centres = C.data(); md.volumes = V.data();
+            md.nx = g.nx; md.ny = g.ny; md.nz = g.nz; md.dx = c->dx;
+            for (int a = 0; a < 3; ++a) { md.origin[a] = c->origin[a]; md.bbox_min[a] = c->origin[a]; }
+            md.bbox_max[0] = c->origin[0] + g.nx * c->dx; md.bbox_max[1] = c->origin[1] + g.ny * c->dx; md.bbox_max[2] = c->origin[2] + g.nz * c->dx;
+            fy_field_ptrs fp{};
+            fp.location = FY_MEM_DEVICE;
+            fp.U = U.p; fp.gradP = gradP.p; fp.vGrad = vGrad.p; fp.divT = divT.p; fp.ddtU = ddtU.p;
+            for (int a = 0; a < 3; ++a) fp.g[a] = c->g[a];
+            fp.uSourceDrag = uSourceDrag.p; fp.alpha = alpha.p; fp.uSource = uSource.p; fp.uParticle = uParticle.p;
+            cpl = new (std::nothrow) fy_ctx();
+            if (!cpl) return fail(FY_ERR_INVALID, "out of host memory");
+            cpl->c.ext_stream = stream;
+            FY_TRY(cpl->c.create(&md, &fp, pimple ? 1 : 0, tr, device));      // gaussianInterp: false for ico, true for pimple (icoFoamYade.C:53, pimpleFoamYade.C:53)
+            cpl->c.rhoP = c->rho_particle; cpl->c.rhoF = c->rho_fluid; cpl->c.nu = c->nu;   // setScalarProperties (icoFoamYade.C:55)
+        }
+        FY_TRY(launch_flux_of(stream, g, U.p, F3(phi)));                     // createPhi
+        FY_HIP(hipStreamSynchronize(stream));
+        return FY_OK;
+    }
+
+    int reduce_read(int nslots, const int* d_ops, double* h) {
+        FY_TRY(launch_reduce_finalize(stream, partials.p, nslots, d_ops, red_out.p));
+        FY_HIP(hipMemcpyAsync(h, red_out.p, nslots * sizeof(double), hipMemcpyDeviceToHost, stream));
+        FY_HIP(hipStreamSynchronize(stream));
+        return FY_OK;
+    }
+
+    // ---- momentum predictor: Jacobi sweeps with lduMatrix-style L1 residual control (stand-in for smoothSolver) ----------
+    int solve_momentum(int* iters) {
+        double h[6];
+        FY_TRY(launch_sum3(stream, U.p, Nc, partials.p));
+        FY_TRY(reduce_read(3, nullptr, h));
+        double xb[3] = {h[0] / Nc, h[1] / Nc, h[2] / Nc};
+        FY_HIP(hipMemcpyAsync(xbar3.p, xb, sizeof(xb), hipMemcpyHostToDevice, stream));
+        double* xc = U.p; double* xn = xscr.p;
+        double norm[3] = {1, 1, 1}, res0[3] = {0, 0, 0}, res[3];
+        int it = 0;
+        for (;;) {
+            FY_TRY(launch_mom_pass(stream, g, M7(), bmom.p, xc, xn, xbar3.p, partials.p));
+            FY_TRY(reduce_read(6, nullptr, h));
+            if (it == 0) for (int q = 0; q < 3; ++q) { norm[q] = h[3 + q] + 1e-20; res0[q] = h[q] / norm[q]; }
+            bool conv = true;
+            for (int q = 0; q < 3; ++q) {
+                res[q] = h[q] / norm[q];
+                if (!(res[q] < cs.u_tol || (cs.u_rel_tol > 0 && res[q] < cs.u_rel_tol * res0[q]))) conv = false;
+            }
+            if (conv || it >= cs.u_max_iter) break;
+            std::swap(xc, xn);
+            ++it;
+        }
+        if (xc != U.p) FY_TRY(launch_copy_f64(stream, U.p, xc, 3 * (size_t)Nc));
+        *iters = it;
+        return FY_OK;
+    }
+
+    // ---- multigrid V(2,2) with damped Jacobi, used as the PCG preconditioner ------------------------------------------
+    int vcycle(size_t l) {
+        const double w = 0.8;
+        MgLev& L = *mg[l];
+        if (l + 1 == mg.size()) {
+            FY_TRY(launch_mg_coarse_solve(stream, L.A, L.bptr, L.x0.p, L.x1.p, 40, w));
+            L.xcur = L.x0.p; L.xalt = L.x1.p;
+            return FY_OK;
+        }
+        MgLev& Cc = *mg[l + 1];
+        FY_TRY(launch_mg_smooth_first(stream, L.A, L.bptr, L.xcur, w));
+        FY_TRY(launch_mg_smooth(stream, L.A, L.bptr, L.xcur, L.xalt, w)); std::swap(L.xcur, L.xalt);
+        FY_TRY(launch_mg_residual_restrict(stream, L.A, L.bptr, L.xcur, Cc.A, Cc.b.p));
+        Cc.bptr = Cc.b.p;
+        FY_TRY(vcycle(l + 1));
+        FY_TRY(launch_mg_prolong_add(stream, L.A, L.xcur, Cc.A, Cc.xcur));
+        FY_TRY(launch_mg_smooth(stream, L.A, L.bptr, L.xcur, L.xalt, w)); std::swap(L.xcur, L.xalt);
+        FY_TRY(launch_mg_smooth(stream, L.A, L.bptr, L.xcur, L.xalt, w)); std::swap(L.xcur, L.xalt);
+        return FY_OK;
+    }
+
+    // OpenFOAM PCG.C with lduMatrix::solver::normFactor; preconditioner = MG V-cycle or Jacobi
+    int solve_pressure(bool final_iter) {
+        MgLev& L = *mg[0];
+        const double tol = final_iter ? cs.p_final_tol : cs.p_tol, rel = final_iter ? cs.p_final_rel_tol : cs.p_rel_tol;
+        double h[2];
+        // xbar = average(p) for lduMatrix::solver::normFactor: sum(p) as a dot product with a ones vector (pzj is free here)
+        FY_TRY(launch_fill_f64(stream, pzj.p, Nc, 1.0));
+        FY_TRY(launch_dot(stream, Nc, p.p, pzj.p, partials.p));
+        FY_TRY(reduce_read(1, nullptr, h));
+        const double xbar = h[0] / Nc;
+        FY_TRY(launch_p_init(stream, L.A, prhs.p, p.p, xbar, pr.p, partials.p));
+        FY_TRY(reduce_read(2, nullptr, h));
+        const double norm = h[1] + 1e-20;
+        double res = h[0] / norm;
+        const double res0 = res;
+        st.p_initial_residual = res0;
+        auto converged = [&](double r) { return r < tol || (rel > 0 && r < rel * res0); };
+        int it = 0;
+        if (!converged(res)) {
+            do {
+                const double* z;
+                if (cs.p_solver == FY_PSOLVER_PCG_MG) { L.bptr = pr.p; FY_TRY(vcycle(0)); z = L.xcur; }
+                else { FY_TRY(launch_jacobi_precond(stream, L.A, pr.p, pzj.p)); z = pzj.p; }
+                FY_TRY(launch_dot(stream, Nc, z, pr.p, partials.p));
+                FY_TRY(launch_reduce_finalize(stream, partials.p, 1, nullptr, sc.p + 0));              // wArA
+                FY_TRY(launch_pcg_update_p(stream, Nc, z, pp.p, sc.p, it == 0 ? 1 : 0));
+                FY_TRY(launch_p_apply_dot(stream, L.A, pp.p, pw.p, partials.p));
+                FY_TRY(launch_reduce_finalize(stream, partials.p, 1, nullptr, sc.p + 2));              // wApA
+                FY_TRY(launch_pcg_update_xr(stream, Nc, p.p, pr.p, pp.p, pw.p, sc.p, partials.p));
+                FY_HIP(hipMemcpyAsync(sc.p + 1, sc.p + 0, sizeof(double), hipMemcpyDeviceToDevice, stream));   // wArAold = wArA
+                FY_TRY(reduce_read(1, nullptr, h));
+                res = h[0] / norm;
+            } while (++it < cs.p_max_iter && !converged(res));
+        }
+        st.p_final_residual = res;
+        st.p_iters_total += it; st.p_solves += 1;
+        return FY_OK;
+    }
+
+    // ---- one PISO / PIMPLE corrector (icoFoamYade.C:97-140, pEqn.H) ----------------------------------------------------
+    int corrector(bool final_inner) {
+        FY_TRY(launch_HbyA(stream, g, M7(), src.p, U.p, rAU.p, HbyA.p));
+        if (!pimple) FY_TRY(launch_interp_rAU(stream, g, rAU.p, F3(rAUf)));
+        FY_TRY(launch_phiHbyA(stream, g, HbyA.p, U.p, Uold.p, C3(phiOld), C3(rAUf), C3(alphaf), C3(phiForces), F3(phiHbyA), F3(psn)));
+        MgLev& L = *mg[0];
+        if (timing) tim[2].start(stream);
+        for (int no = 0; no <= cs.n_non_orth_correctors; ++no) {
+            FY_TRY(launch_assemble_pressure(stream, g, C3(phiHbyA), C3(rAUf), C3(alphaf), C3(psn), alpha.p, alphaOld.p, L.A, prhs.p));
+            for (size_t l = 0; l + 1 < mg.size(); ++l) FY_TRY(launch_mg_coarsen(stream, mg[l]->A, mg[l + 1]->A));
+            FY_TRY(solve_pressure(final_inner && no == cs.n_non_orth_correctors));
+            if (no == cs.n_non_orth_correctors)
+                FY_TRY(launch_flux_correct(stream, g, p.p, C3(phiHbyA), C3(rAUf), C3(alphaf), C3(psn), F3(pflux), F3(phi)));
+        }
+        if (timing) { tim[2].stop(stream); st.ms_pressure += tim[2].ms(); }
+        double h[2];
+        FY_TRY(launch_cont_err(stream, g, C3(phi), C3(alphaf), alpha.p, alphaOld.p, partials.p));
+        FY_TRY(reduce_read(2, nullptr, h));
+        const double tv = g.V * Nc;
+        st.cont_err_sum_local = cs.dt * h[0] / tv; st.cont_err_global = cs.dt * h[1] / tv;
+        cumulative_cont_err += st.cont_err_global; st.cont_err_cumulative = cumulative_cont_err;
+        FY_TRY(launch_U_correct(stream, g, HbyA.p, rAU.p, p.p, C3(psn), C3(phiForces), C3(pflux), C3(alphaf), C3(rAUf), U.p));
+        return FY_OK;
+    }
+
+    // ---- one pass of the while (runTime.loop()) body ---------------------------------------------------------------------
+    int step() {
+        FY_HIP(hipSetDevice(device));
+        st = fy_step_stats{}; st.cont_err_cumulative = cumulative_cont_err;
+        if (timing) tim[3].start(stream);
+        double h[2];
+        FY_TRY(launch_courant(stream, g, C3(phi), partials.p));                               // icoFoamYade.C:68, pimpleFoamYade.C:63
+        FY_TRY(reduce_read(2, ops_courant.p, h));
+        st.courant_max = 0.5 * h[0] * cs.dt; st.courant_mean = 0.5 * (h[1] / (g.V * Nc)) * cs.dt;
+        // runTime++ : store old-time fields
+        FY_TRY(launch_copy_f64(stream, Uold.p, U.p, 3 * (size_t)Nc));
+        for (int d = 0; d < 3; ++d) FY_TRY(launch_copy_f64(stream, phiOld[d].p, phi[d].p, phi[d].n));
+        FY_TRY(launch_pre_coupling(stream, g, U.p, p.p, alpha.p, C3(psn), vGrad.p, gradP.p, divT.p));   // icoFoamYade.C:71, pimpleFoamYade.C:73-76
+
+        if (timing) tim[0].start(stream);
+        FY_TRY(cpl->c.set_particle_action(cs.dt));                                            // icoFoamYade.C:74, pimpleFoamYade.C:78
+        if (timing) { tim[0].stop(stream); }
+
+        // alphac.oldTime() is captured lazily by OpenFOAM at alphac.correctBoundaryConditions() (pimpleFoamYade.C:83), i.e. after
+        // FoamYade wrote alpha through untracked operator[]: old == current, fvc::ddt(alphac) == 0
+        FY_TRY(launch_copy_f64(stream, alphaOld.p, alpha.p, Nc));
+        if (pimple) FY_TRY(launch_interp_alpha(stream, g, alpha.p, F3(alphaf)));              // pimpleFoamYade.C:83-85
+        const int nOuter = pimple ? std::max(cs.n_outer_correctors, 1) : 1;
+        for (int outer = 0; outer < nOuter; ++outer) {
+            if (timing) tim[1].start(stream);
+            if (pimple) {
+                if (outer > 0) FY_TRY(launch_pre_coupling(stream, g, U.p, p.p, alpha.p, C3(psn), vGrad.p, gradP.p, divT.p));
+                FY_TRY(launch_stress_G(stream, g, vGrad.p, alpha.p, Gt.p));
+                FY_TRY(launch_div_G(stream, g, Gt.p, divG.p));
+            }
+            FY_TRY(launch_assemble_momentum(stream, g, U.p, Uold.p, alpha.p, alphaOld.p, C3(alphaf), C3(phi), uSource.p, uSourceDrag.p,
+                                            divG.p, M7(), src.p, rAU.p));
+            if (pimple) {
+                FY_TRY(launch_interp_rAU(stream, g, rAU.p, F3(rAUf)));
+                FY_TRY(launch_phi_forces(stream, g, rAU.p, C3(rAUf), uSource.p, F3(phiForces)));
+            }
+            if (cs.momentum_predictor) {
+                FY_TRY(launch_bmom(stream, g, src.p, p.p, C3(psn), C3(phiForces), C3(rAUf), bmom.p));
+                int it = 0;
+                FY_TRY(solve_momentum(&it));
+                st.u_iters_total += it;
+            }
+            if (timing) { tim[1].stop(stream); st.ms_momentum += tim[1].ms(); }
+            for (int corr = 0; corr < cs.n_correctors; ++corr) FY_TRY(corrector(outer == nOuter - 1 && corr == cs.n_correctors - 1));
+        }
+        FY_TRY(cpl->c.set_source_zero());                                                     // icoFoamYade.C:147, pimpleFoamYade.C:109
+        if (timing) {
+            tim[3].stop(stream);
+            FY_HIP(hipStreamSynchronize(stream));
+            st.ms_particle = tim[0].ms();
+            st.ms_total = tim[3].ms();
+            st.ms_other = st.ms_total - st.ms_particle - st.ms_momentum - st.ms_pressure;
+        } else {
+            FY_HIP(hipStreamSynchronize(stream));
+        }
+        return FY_OK;
+    }
+
+    int field(const char* name, double** ptr, size_t* count) {
+        const std::string s = name ? name : "";
+        const size_t n = (size_t)Nc;
+        struct E { const char* nm; double* p; size_t c; };
+        const E tab[] = {{"U", U.p, 3 * n}, {"p", p.p, n}, {"phi_x", phi[0].p, phi[0].n}, {"phi_y", phi[1].p, phi[1].n}, {"phi_z", phi[2].p, phi[2].n},
+                         {"rAU", rAU.p, n}, {"HbyA", HbyA.p, 3 * n}, {"p_rhs", prhs.p, n}, {"p_diag", mg[0]->diag.p, n}, {"p_ux", mg[0]->ux.p, n},
+                         {"p_uy", mg[0]->uy.p, n}, {"p_uz", mg[0]->uz.p, n}, {"mom_diag", mdiag.p, n}, {"mom_src", src.p, 3 * n},
+                         {"alpha", alpha.p, n}, {"uSource", uSource.p, 3 * n}, {"uSourceDrag", uSourceDrag.p, n}, {"uParticle", uParticle.p, 3 * n},
+                         {"gradP", gradP.p, 3 * n}, {"divT", divT.p, 3 * n}, {"vGrad", vGrad.p, 9 * n}};
+        for (const E& e : tab) if (s == e.nm) { *ptr = e.p; *count = e.c; return FY_OK; }
+        return fail(FY_ERR_INVALID, "unknown solver field '%s'", s.c_str());
+    }
+};
+
+}  // namespace fy
+
+struct fy_solver { fy::Solver s; };
+
 extern "C" {
-void fy_case_defaults(fy_case_desc* c, int solver) { if (c) { std::memset(c, 0, sizeof(*c)); c->solver = solver; } }
-int fy_solver_create(const fy_case_desc*, const fy_transport*, int, fy_solver** out) { if (out) *out = nullptr; return fy::fail(FY_ERR_UNSUPPORTED, "fy_solver not built yet"); }
-fy_ctx* fy_solver_coupling(fy_solver*) { return nullptr; }
-int fy_solver_step(fy_solver*) { return fy::fail(FY_ERR_UNSUPPORTED, "fy_solver not built yet"); }
-int fy_solver_get_stats(fy_solver*, fy_step_stats*) { return fy::fail(FY_ERR_UNSUPPORTED, "fy_solver not built yet"); }
-int fy_solver_read_field_host(fy_solver*, const char*, double*) { return fy::fail(FY_ERR_UNSUPPORTED, "fy_solver not built yet"); }
-int fy_solver_write_field_host(fy_solver*, const char*, const double*) { return fy::fail(FY_ERR_UNSUPPORTED, "fy_solver not built yet"); }
-int fy_solver_destroy(fy_solver*) { return FY_OK; }
-int fy_solver_apply_p_matrix_host(fy_solver*, const double*, double*) { return fy::fail(FY_ERR_UNSUPPORTED, "fy_solver not built yet"); }
-int fy_solver_time_p_apply(fy_solver*, int, double*) { return fy::fail(FY_ERR_UNSUPPORTED, "fy_solver not built yet"); }
+
+// documented defaults: icoFoam cavity / DPMFoam tutorial settings (the reference ships no case)
+void fy_case_defaults(fy_case_desc* c, int solver) {
+    if (!c) return;
+    std::memset(c, 0, sizeof(*c));
+    c->solver = solver;
+    c->nx = c->ny = c->nz = 32; c->dx = 0.1 / 32; c->dt = 0.005; c->nu = 0.01; c->rho_fluid = 1000.0; c->rho_particle = 2650.0;
+    for (int q = 0; q < 6; ++q) { c->u_bc[q] = FY_BC_U_FIXED_VALUE; c->p_bc[q] = FY_BC_P_ZERO_GRADIENT; }
+    c->n_outer_correctors = 1; c->n_correctors = 2; c->n_non_orth_correctors = 0; c->momentum_predictor = 1;
+    c->p_ref_cell = 0; c->p_ref_value = 0.0;
+    c->p_solver = FY_PSOLVER_PCG_MG;
+    c->p_tol = 1e-6; c->p_rel_tol = 0.05; c->p_final_tol = 1e-6; c->p_final_rel_tol = 0.0; c->p_max_iter = 1000;
+    c->u_tol = 1e-5; c->u_rel_tol = 0.0; c->u_max_iter = 1000;
 }
+
+int fy_solver_create(const fy_case_desc* c, const fy_transport* tr, int device_ordinal, fy_solver** out) {
+    if (!out) return fy::fail(FY_ERR_INVALID, "null out");
+    *out = nullptr;
+    fy_solver* s = new (std::nothrow) fy_solver();
+    if (!s) return fy::fail(FY_ERR_INVALID, "out of host memory");
+    int rc = s->s.create(c, tr, device_ordinal);
+    if (rc != FY_OK) { delete s; return rc; }
+    *out = s;
+    return FY_OK;
+}
+
+#define FY_S(s) if (!(s)) return fy::fail(FY_ERR_INVALID, "null fy_solver")
+
+fy_ctx* fy_solver_coupling(fy_solver* s) { return s ? s->s.cpl : nullptr; }
+int fy_solver_step(fy_solver* s) { FY_S(s); return s->s.step(); }
+int fy_solver_get_stats(fy_solver* s, fy_step_stats* out) { FY_S(s); if (!out) return fy::fail(FY_ERR_INVALID, "null out"); *out = s->s.st; return FY_OK; }
+
+int fy_solver_read_field_host(fy_solver* s, const char* name, double* out) {
+    FY_S(s);
+    double* p; size_t n;
+    FY_TRY(s->s.field(name, &p, &n));
+    FY_HIP(hipMemcpyAsync(out, p, n * sizeof(double), hipMemcpyDeviceToHost, s->s.stream));
+    FY_HIP(hipStreamSynchronize(s->s.stream));
+    return FY_OK;
+}
+
+int fy_solver_write_field_host(fy_solver* s, const char* name, const double* in) {
+    FY_S(s);
+    double* p; size_t n;
+    FY_TRY(s->s.field(name, &p, &n));
+    FY_HIP(hipMemcpyAsync(p, in, n * sizeof(double), hipMemcpyHostToDevice, s->s.stream));
+    if (std::string(name) == "U") FY_TRY(fy::launch_flux_of(s->s.stream, s->s.g, s->s.U.p, s->s.F3(s->s.phi)));   // createPhi
+    FY_HIP(hipStreamSynchronize(s->s.stream));
+    return FY_OK;
+}
+
+int fy_solver_destroy(fy_solver* s) { delete s; return FY_OK; }
+
+int fy_solver_apply_p_matrix_host(fy_solver* s, const double* x, double* y) {
+    FY_S(s);
+    fy::Solver& S = s->s;
+    FY_HIP(hipMemcpyAsync(S.pp.p, x, (size_t)S.Nc * sizeof(double), hipMemcpyHostToDevice, S.stream));
+    FY_TRY(fy::launch_p_apply(S.stream, S.mg[0]->A, S.pp.p, S.pw.p));
+    FY_HIP(hipMemcpyAsync(y, S.pw.p, (size_t)S.Nc * sizeof(double), hipMemcpyDeviceToHost, S.stream));
+    FY_HIP(hipStreamSynchronize(S.stream));
+    return FY_OK;
+}
+
+int fy_solver_time_p_apply(fy_solver* s, int reps, double* avg_ms) {
+    FY_S(s);
+    if (reps < 1 || !avg_ms) return fy::fail(FY_ERR_INVALID, "bad arguments");
+    fy::Solver& S = s->s;
+    fy::EventTimer t;
+    FY_TRY(t.init());
+    for (int i = 0; i < 3; ++i) FY_TRY(fy::launch_p_apply(S.stream, S.mg[0]->A, S.pp.p, S.pw.p));
+    t.start(S.stream);
+    for (int i = 0; i < reps; ++i) FY_TRY(fy::launch_p_apply(S.stream, S.mg[0]->A, S.pp.p, S.pw.p));
+    t.stop(S.stream);
+    *avg_ms = t.ms() / reps;
+    t.destroy();
+    return FY_OK;
+}
+
+}  // extern "C"
