@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""Headline benchmark: coupled CFD-DEM steps/s at BASELINE.json configs[2] ("C3"):
+pimpleFoamYade 4-way coupling, 10 M particles, 160^3 = 4 096 000 cells, one MI355X.
+
+A "step" is one pass of pimpleFoamYade's time-loop body (pimpleFoamYade.C:60-114): Courant number, pre-coupling fields,
+FoamYade::setParticleAction (k-d locate, Gaussian weights, void-fraction deposit, drag + Archimedes, momentum-source
+back-scatter for every particle), UcEqn assembly + momentum predictor, nCorrectors pressure correctors (PCG + multigrid),
+continuity errors, setSourceZero.  Particle records and all fields are resident in HBM when the timed region starts
+(the reference receives particles over MPI on the host; the PCIe-inclusive figure is discussed in DESIGN.md, never here).
+
+Contract: python bench.py --gpus N --steps K --warmup W ; for N>1 launched by torch.distributed.run, one rank per GPU.
+Round 1 shards nothing across GPUs yet: N>1 runs N independent replicas of the whole workload (`"parallelism": "replicas"`)
+-- the z-slab decomposition with RCCL halos is the next step and is NOT claimed here.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s copy-achievable)
+
+
+def c3_case(prod, n, dt, p_solver):
+    """closed box, no-slip walls, g = (0,0,-9.81), nu = 1e-6, rho_p = 2650, rho_f = 1000, PIMPLE nOuter 1 nCorr 2,
+    fixedFluxPressure walls (what a DPMFoam case with gravity uses)."""
+    dx = 1.0 / n
+    return prod.make_case(prod.FY_SOLVER_PIMPLE, n, n, n, dx, dt, 1e-6, rho_f=1000.0, rho_p=2650.0, g=(0.0, 0.0, -9.81),
+                          u_bc=[prod.FY_BC_U_FIXED_VALUE] * 6, u_val=[(0, 0, 0)] * 6, p_bc=[prod.FY_BC_P_FIXED_FLUX] * 6,
+                          n_outer_correctors=1, n_correctors=2, p_solver=p_solver)
+
+
+def c3_particles(torch, n_part, n, seed, device):
+    """Np particles uniform in the lower 60 % of the unit box, r = 0.2 dx, at rest."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    dx = 1.0 / n
+    rec = torch.zeros(n_part, 10, dtype=torch.float64)
+    rec[:, 0:3] = torch.rand(n_part, 3, dtype=torch.float64, generator=g)
+    rec[:, 2] *= 0.6
+    rec[:, 9] = 0.2 * dx
+    return rec.to(device).contiguous()
+
+
+def cpu_baseline(n_sample, ppc, dt, threads):
+    """the CPU oracle (a faithful port of the reference's path, kind = "port") on a bounded sample of the same workload"""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as orc
+    orc.build()
+    dx = 1.0 / n_sample
+    case = orc.fv_case(1, n_sample, n_sample, n_sample, dx, dt, 1e-6, g=(0, 0, -9.81), p_bc=[orc.P_FIXEDFLUX] * 6, n_outer=1, n_corr=2, p_solver=1)
+    nc = n_sample ** 3
+    n_part = int(round(ppc * nc))
+    rs = np.random.RandomState(3)
+    rec = np.zeros((n_part, 10))
+    rec[:, 0:3] = rs.random_sample((n_part, 3))
+    rec[:, 2] *= 0.6
+    rec[:, 9] = 0.2 * dx
+    out = {}
+    for th in sorted(set([1, threads])):
+        s = orc.FvSolver(case, threads=th)
+        s.mesh = orc.Mesh(n_sample, n_sample, n_sample, dx)     # tree build is construction-time work, not timed (as on the GPU side)
+        s.step(rec)                                              # warm-up step
+        t0 = time.time()
+        k = 0
+        while k < 2 or (time.time() - t0 < 6.0 and k < 8):
+            s.step(rec)
+            k += 1
+        out[th] = (time.time() - t0) / k
+        s.close()
+    return out, nc, n_part
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--n", type=int, default=160, help="cells per edge (C3 = 160)")
+    ap.add_argument("--particles", type=int, default=10_000_000)
+    ap.add_argument("--dt", type=float, default=1e-4)
+    ap.add_argument("--p-solver", type=int, default=1, help="0 PCG+Jacobi, 1 PCG+multigrid")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-n", type=int, default=64)
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, f"WORLD_SIZE {world} != --gpus {args.gpus}"
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the product has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    prod = ge.load_product()
+    case = c3_case(prod, args.n, args.dt, args.p_solver)
+    solver = prod.Solver(case, device=local_rank)
+    rec = c3_particles(torch, args.particles, args.n, 3 + rank, dev)
+    solver.set_particles_device(rec)
+    solver.enable_particle_timing(True)
+    nc = args.n ** 3
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        solver.step()
+    solver.enable_kernel_timing(True)
+    acc = dict(particle=0.0, locate=0.0, force=0.0, bin=0.0, momentum=0.0, pressure=0.0, other=0.0, p_iters=0, u_iters=0)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        solver.step()
+        st = solver.stats(); ct = solver.coupling_timings()
+        acc["particle"] += st["ms_particle"]; acc["momentum"] += st["ms_momentum"]; acc["pressure"] += st["ms_pressure"]; acc["other"] += st["ms_other"]
+        acc["locate"] += ct["locate_deposit"]; acc["force"] += ct["force"]; acc["bin"] += ct["bin"]
+        acc["p_iters"] += st["p_iters_total"]; acc["u_iters"] += st["u_iters_total"]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    K = args.steps
+    steps_per_s = world * K / elapsed
+    # ---- per-kernel clocks (HIP events on the launch stream, collected inside the timed region)
+    kern = {}
+    smooth_ms, smooth_n = solver.kernel_timing("mg_smooth_l0")
+    apply_ms, apply_n = solver.kernel_timing("p_apply_dot")
+    mom_ms, mom_n = solver.kernel_timing("mom_pass")
+    np_part = args.particles
+    cand = {
+        # name: (total ms over the timed steps, launches, algorithmic bytes per launch, description)
+        # compulsory bytes (DESIGN.md "algorithmic bytes"): kbar = 5.46 stencil cells per particle, 12 B per (id, weight) pair
+        "k_locate_deposit": (acc["locate"], K, (60.0 + 12.0 * 5.46) * np_part + 65.0 * nc,
+                             "k-d locate + Gaussian weights + deposit: SoA particle 60 B, stencil out 12 B/pair, accumulators RMW 64 B/cell + flag"),
+        "k_force_gaussian": (acc["force"], K, (64.0 + 12.0 * 5.46 + 52.0) * np_part + 176.0 * nc,
+                             "drag + Archimedes + back-scatter: particle 64 B + stencil 12 B/pair in, force 52 B out, cell fields 112 B read + 64 B RMW"),
+        "k_mg_smooth(level 0)": (smooth_ms, smooth_n, 56.0 * nc, "pEqn Laplacian apply fused with the damped-Jacobi update: 48 B/cell (diag, 3 upper, x, y) + b 8"),
+        "k_p_apply_dot": (apply_ms, apply_n, 48.0 * nc, "pEqn Laplacian apply y = A p (+ p.Ap) inside PCG: 48 B/cell"),
+        "k_mom_pass": (mom_ms, mom_n, (7 * 8 + 24 * 3) * nc, "fused momentum Jacobi pass: 7 coeffs + b,x,xn (3 comps)"),
+    }
+    for nm, (ms, nl, bytes_per, desc) in cand.items():
+        if nl:
+            avg = ms / nl
+            kern[nm] = dict(total_ms=ms, launches=int(nl), avg_ms=avg, achieved_GBps=bytes_per / (avg * 1e-3) / 1e9, alg_bytes=bytes_per, what=desc)
+    dominant = max(kern, key=lambda k: kern[k]["total_ms"]) if kern else None
+    lap = "k_mg_smooth(level 0)" if "k_mg_smooth(level 0)" in kern else "k_p_apply_dot"
+
+    def roof(name):
+        k = kern[name]
+        return {"kernel": name, "bound": "hbm", "achieved": round(k["achieved_GBps"], 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(k["achieved_GBps"] / HBM_PEAK_GBPS, 4), "traffic": None, "avg_launch_ms": round(k["avg_ms"], 4),
+                "launches": k["launches"], "algorithmic_bytes_per_launch": k["alg_bytes"], "what": k["what"]}
+
+    out = {
+        "metric": "coupled_steps_per_sec (pimpleFoamYade 4-way, 10M particles / 4M cells)" if (args.n == 160 and args.particles == 10_000_000)
+        else f"coupled_steps_per_sec (pimpleFoamYade 4-way, {args.particles} particles / {nc} cells)",
+        "value": round(steps_per_s, 4), "unit": "steps/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / K, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "particle_steps_per_sec": round(steps_per_s * np_part, 1),
+        "config": {"workload": "C3: pimpleFoamYade Gaussian 4-way coupling, 160^3 = 4,096,000-cell closed box, 10,000,000 particles in the lower 60 %"
+                   if (args.n == 160 and args.particles == 10_000_000) else f"reduced C3-like case {args.n}^3 cells / {args.particles} particles",
+                   "cells": nc, "particles": np_part, "dt": args.dt, "pimple": {"nOuterCorrectors": 1, "nCorrectors": 2},
+                   "p_solver": "PCG+MG V(2,2) damped Jacobi" if args.p_solver == 1 else "PCG+Jacobi",
+                   "p_tol": [case.p_tol, case.p_rel_tol, case.p_final_tol, case.p_final_rel_tol],
+                   "parallelism": "single GPU" if world == 1 else f"replicas x{world} (no cross-GPU sharding yet)"},
+        "per_step_ms": {k: round(acc[k] / K, 3) for k in ("particle", "bin", "locate", "force", "momentum", "pressure", "other")},
+        "p_iters_per_step": acc["p_iters"] / K, "u_iters_per_step": acc["u_iters"] / K,
+        "roofline": roof(dominant) if dominant else None,
+        "roofline_pEqn_laplacian": roof(lap) if lap in kern else None,
+        "kernels": {k: {"avg_ms": round(v["avg_ms"], 4), "launches": v["launches"], "GBps": round(v["achieved_GBps"], 1)} for k, v in kern.items()},
+    }
+    if rank == 0 and not args.no_cpu_baseline and world == 1:
+        th = os.cpu_count() or 1
+        ppc = args.particles / nc
+        per, snc, snp = cpu_baseline(args.cpu_sample_n, ppc, args.dt, th)
+        best_th = min(per, key=lambda k: per[k])
+        scale = snc / nc                                   # linear-in-size extrapolation to the bench workload
+        out["cpu_baseline"] = {
+            "value": round((1.0 / per[best_th]) * scale, 6), "unit": "steps/s", "cores": int(best_th), "kind": "port",
+            "single_thread_value": round((1.0 / per[1]) * scale, 6),
+            "sample": f"same workload at {args.cpu_sample_n}^3 cells / {snp} particles ({snc / nc:.4f} of the bench size), CPU oracle (port of the "
+                      f"reference path, de-quadraticised deposit), measured {per[best_th]:.2f} s/step on {best_th} threads ({per[1]:.2f} s/step on 1); "
+                      f"value = measured steps/s x {scale:.5f} (linear-in-size extrapolation)"}
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -195,6 +195,12 @@ int fy_solver_apply_p_matrix_host(fy_solver*, const double* x, double* y);
 /* time `reps` launches of the pEqn Laplacian apply (the roofline kernel) with HIP events on the solver stream; returns avg ms */
 int fy_solver_time_p_apply(fy_solver*, int reps, double* avg_ms);
 
+/* per-kernel HIP-event clocks on the solver stream, accumulated over steps since the last enable(1):
+ * kernel = "mg_smooth_l0" (pEqn Laplacian apply fused with the damped-Jacobi update, fine level), "p_apply_dot" (pEqn Laplacian
+ * apply + p.Ap inside PCG), "mom_pass" (fused momentum Jacobi pass) */
+int fy_solver_enable_kernel_timing(fy_solver*, int on);
+int fy_solver_get_kernel_timing(fy_solver*, const char* kernel, double* total_ms, int64_t* launches);
+
 #ifdef __cplusplus
 }
 #endif

@@ -145,6 +145,8 @@ def lib():
     L.fy_solver_destroy.argtypes = [vp]
     L.fy_solver_apply_p_matrix_host.argtypes = [vp, _dp, _dp]
     L.fy_solver_time_p_apply.argtypes = [vp, C.c_int, _dp]
+    L.fy_solver_enable_kernel_timing.argtypes = [vp, C.c_int]
+    L.fy_solver_get_kernel_timing.argtypes = [vp, C.c_char_p, _dp, C.POINTER(C.c_int64)]
     _lib = L
     return L
 
@@ -414,6 +416,15 @@ class Solver:
         ms = C.c_double()
         _check(lib().fy_solver_time_p_apply(self._h, int(reps), C.byref(ms)))
         return ms.value
+
+    def enable_kernel_timing(self, on=True):
+        _check(lib().fy_solver_enable_kernel_timing(self._h, int(on)))
+
+    def kernel_timing(self, name):
+        """(total_ms, launches) of one instrumented kernel since enable_kernel_timing(True)"""
+        ms = C.c_double(); n = C.c_int64()
+        _check(lib().fy_solver_get_kernel_timing(self._h, name.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
 
     def coupling_timings(self):
         t = ParticleTimings()

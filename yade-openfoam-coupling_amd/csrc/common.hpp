@@ -95,6 +95,32 @@ struct EventTimer {
     }
 };
 
+// accumulating per-kernel clock: one HIP event pair per launch, recorded on the launch stream, harvested once per step
+struct KernelClock {
+    std::vector<hipEvent_t> a, b;
+    size_t used = 0;
+    double total_ms = 0.0;
+    int64_t launches = 0;
+    bool on = false;
+    void begin(hipStream_t s) {
+        if (!on) return;
+        if (used == a.size()) { hipEvent_t x, y; (void)hipEventCreate(&x); (void)hipEventCreate(&y); a.push_back(x); b.push_back(y); }
+        (void)hipEventRecord(a[used], s);
+    }
+    void end(hipStream_t s) {
+        if (!on) return;
+        (void)hipEventRecord(b[used], s);
+        ++used;
+    }
+    void collect() {       // call after the stream has been synchronised
+        for (size_t i = 0; i < used; ++i) { float t = 0.f; (void)hipEventElapsedTime(&t, a[i], b[i]); total_ms += t; }
+        launches += (int64_t)used;
+        used = 0;
+    }
+    void reset() { used = 0; total_ms = 0.0; launches = 0; }
+    void destroy() { for (auto e : a) (void)hipEventDestroy(e); for (auto e : b) (void)hipEventDestroy(e); a.clear(); b.clear(); }
+};
+
 inline unsigned div_up(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
 
 }  // namespace fy

@@ -41,6 +41,8 @@ struct Solver {
     double cumulative_cont_err = 0.0;
     EventTimer tim[4];      // particle, momentum, pressure, total
     bool timing = true;
+    enum { KC_MG_SMOOTH0 = 0, KC_P_APPLY_DOT, KC_MOM_PASS, KC_COUNT };
+    KernelClock kc[KC_COUNT];
 
     Face3 F3(DevBuf<double>* a) { Face3 f; for (int d = 0; d < 3; ++d) f.a[d] = a[d].p; return f; }
     CFace3 C3(DevBuf<double>* a) { CFace3 f; for (int d = 0; d < 3; ++d) f.a[d] = a[d].p; return f; }
@@ -49,6 +51,7 @@ struct Solver {
     ~Solver() {
         if (cpl) fy_destroy(cpl);
         for (auto& t : tim) t.destroy();
+        for (auto& k : kc) k.destroy();
         if (stream) (void)hipStreamDestroy(stream);
     }
 
@@ -160,7 +163,9 @@ struct Solver {
         double norm[3] = {1, 1, 1}, res0[3] = {0, 0, 0}, res[3];
         int it = 0;
         for (;;) {
+            kc[KC_MOM_PASS].begin(stream);
             FY_TRY(launch_mom_pass(stream, g, M7(), bmom.p, xc, xn, xbar3.p, partials.p));
+            kc[KC_MOM_PASS].end(stream);
             FY_TRY(reduce_read(6, nullptr, h));
             if (it == 0) for (int q = 0; q < 3; ++q) { norm[q] = h[3 + q] + 1e-20; res0[q] = h[q] / norm[q]; }
             bool conv = true;
@@ -178,6 +183,14 @@ struct Solver {
     }
 
     // ---- multigrid V(2,2) with damped Jacobi, used as the PCG preconditioner ------------------------------------------
+    int smooth(size_t l, MgLev& L, double w) {
+        if (l == 0) kc[KC_MG_SMOOTH0].begin(stream);
+        FY_TRY(launch_mg_smooth(stream, L.A, L.bptr, L.xcur, L.xalt, w));
+        if (l == 0) kc[KC_MG_SMOOTH0].end(stream);
+        std::swap(L.xcur, L.xalt);
+        return FY_OK;
+    }
+
     int vcycle(size_t l) {
         const double w = 0.8;
         MgLev& L = *mg[l];
@@ -188,13 +201,13 @@ struct Solver {
         }
         MgLev& Cc = *mg[l + 1];
         FY_TRY(launch_mg_smooth_first(stream, L.A, L.bptr, L.xcur, w));
-        FY_TRY(launch_mg_smooth(stream, L.A, L.bptr, L.xcur, L.xalt, w)); std::swap(L.xcur, L.xalt);
+        FY_TRY(smooth(l, L, w));
         FY_TRY(launch_mg_residual_restrict(stream, L.A, L.bptr, L.xcur, Cc.A, Cc.b.p));
         Cc.bptr = Cc.b.p;
         FY_TRY(vcycle(l + 1));
         FY_TRY(launch_mg_prolong_add(stream, L.A, L.xcur, Cc.A, Cc.xcur));
-        FY_TRY(launch_mg_smooth(stream, L.A, L.bptr, L.xcur, L.xalt, w)); std::swap(L.xcur, L.xalt);
-        FY_TRY(launch_mg_smooth(stream, L.A, L.bptr, L.xcur, L.xalt, w)); std::swap(L.xcur, L.xalt);
+        FY_TRY(smooth(l, L, w));
+        FY_TRY(smooth(l, L, w));
         return FY_OK;
     }
 
@@ -224,7 +237,9 @@ struct Solver {
                 FY_TRY(launch_dot(stream, Nc, z, pr.p, partials.p));
                 FY_TRY(launch_reduce_finalize(stream, partials.p, 1, nullptr, sc.p + 0));              // wArA
                 FY_TRY(launch_pcg_update_p(stream, Nc, z, pp.p, sc.p, it == 0 ? 1 : 0));
+                kc[KC_P_APPLY_DOT].begin(stream);
                 FY_TRY(launch_p_apply_dot(stream, L.A, pp.p, pw.p, partials.p));
+                kc[KC_P_APPLY_DOT].end(stream);
                 FY_TRY(launch_reduce_finalize(stream, partials.p, 1, nullptr, sc.p + 2));              // wApA
                 FY_TRY(launch_pcg_update_xr(stream, Nc, p.p, pr.p, pp.p, pw.p, sc.p, partials.p));
                 FY_HIP(hipMemcpyAsync(sc.p + 1, sc.p + 0, sizeof(double), hipMemcpyDeviceToDevice, stream));   // wArAold = wArA
@@ -314,6 +329,7 @@ struct Solver {
             st.ms_particle = tim[0].ms();
             st.ms_total = tim[3].ms();
             st.ms_other = st.ms_total - st.ms_particle - st.ms_momentum - st.ms_pressure;
+            for (auto& k : kc) k.collect();
         } else {
             FY_HIP(hipStreamSynchronize(stream));
         }
@@ -414,6 +430,21 @@ int fy_solver_time_p_apply(fy_solver* s, int reps, double* avg_ms) {
     t.stop(S.stream);
     *avg_ms = t.ms() / reps;
     t.destroy();
+    return FY_OK;
+}
+
+int fy_solver_enable_kernel_timing(fy_solver* s, int on) {
+    FY_S(s);
+    for (auto& k : s->s.kc) { k.reset(); k.on = on != 0; }
+    return FY_OK;
+}
+
+int fy_solver_get_kernel_timing(fy_solver* s, const char* kernel, double* total_ms, int64_t* launches) {
+    FY_S(s);
+    const std::string k = kernel ? kernel : "";
+    int idx = k == "mg_smooth_l0" ? fy::Solver::KC_MG_SMOOTH0 : k == "p_apply_dot" ? fy::Solver::KC_P_APPLY_DOT : k == "mom_pass" ? fy::Solver::KC_MOM_PASS : -1;
+    if (idx < 0 || !total_ms || !launches) return fy::fail(FY_ERR_INVALID, "unknown kernel clock '%s'", k.c_str());
+    *total_ms = s->s.kc[idx].total_ms; *launches = s->s.kc[idx].launches;
     return FY_OK;
 }
 
