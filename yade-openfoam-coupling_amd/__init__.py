@@ -18,7 +18,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
-LIB_PATH = os.path.join(_HERE, "lib", "libfoamyade_hip.so")
+LIB_PATH = os.environ.get("FOAMYADE_HIP_LIB") or os.path.join(_HERE, "lib", "libfoamyade_hip.so")   # override: A/B builds only
 CSRC = os.path.join(_HERE, "csrc")
 MAXK = 16
 

@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <thread>
 
 namespace fy {
@@ -68,6 +69,30 @@ int Coupling::create(const fy_mesh_desc* m, const fy_field_ptrs* f, int gaussian
         tree_levels = kdtree_levels(n_cells);
         FY_TRY(d_tree.alloc_exact(nodes.size()));
         FY_HIP(hipMemcpyAsync(d_tree.p, nodes.data(), nodes.size() * sizeof(KdNode), hipMemcpyHostToDevice, stream));
+        // implicit-coordinate nodes: legal only if EVERY centre equals origin + (i + 0.5) * dx bit for bit (checked here, so a
+        // real OpenFOAM mesh whose centres come from pyramid decomposition simply keeps the explicit path)
+        std::vector<uint32_t> packed;
+        if (structured && getenv("FOAMYADE_EXPLICIT_TREE") == nullptr && m->nx <= 1024 && m->ny <= 1024 && m->nz <= 1024) {
+            bool exact = true;
+            for (int k = 0; k < m->nz && exact; ++k) for (int j = 0; j < m->ny && exact; ++j) for (int i = 0; i < m->nx; ++i) {
+                const size_t c = (size_t)i + (size_t)m->nx * (j + (size_t)m->ny * k);
+                const double x = m->origin[0] + ((double)i + 0.5) * m->dx, y = m->origin[1] + ((double)j + 0.5) * m->dx, z = m->origin[2] + ((double)k + 0.5) * m->dx;
+                if (x != m->centres[3 * c] || y != m->centres[3 * c + 1] || z != m->centres[3 * c + 2]) { exact = false; break; }
+            }
+            if (exact) {
+                packed.resize(nodes.size());
+                for (size_t q = 0; q < nodes.size(); ++q) {
+                    const int id = nodes[q].id;
+                    const int i = id % m->nx, j = (id / m->nx) % m->ny, k = id / (m->nx * m->ny);
+                    packed[q] = (uint32_t)i | ((uint32_t)j << 10) | ((uint32_t)k << 20);
+                }
+                FY_TRY(d_tree_packed.alloc_exact(packed.size()));
+                FY_HIP(hipMemcpyAsync(d_tree_packed.p, packed.data(), packed.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+                implicit.ox = m->origin[0]; implicit.oy = m->origin[1]; implicit.oz = m->origin[2]; implicit.dx = m->dx;
+                implicit.nx = m->nx; implicit.ny = m->ny;
+                use_implicit = true;
+            }
+        }
         FY_HIP(hipStreamSynchronize(stream));
     }
     FY_TRY(d_vol.alloc_exact(n_cells));
@@ -242,8 +267,10 @@ int Coupling::run_batch(Batch& b) {
         gp.maxdist = (interp_range * interp_range) + (0.25 * interp_range * interp_range);   // meshTree.C:155
         gp.two_sigma2 = 2 * std::pow(sigma_interp, 2);                                         // FoamYade.C:308
         gp.range_cu = interp_range_cu; gp.sigma_pi = sigma_pi;
-        FY_TRY(launch_locate_deposit(stream, d_tree.p, n_cells, tree_levels, nullptr, p, b.n, gp, d_pvol_acc.p, d_up_acc.p, d_touched.p));
+        FY_TRY(launch_locate_deposit(stream, d_tree.p, use_implicit ? d_tree_packed.p : nullptr, implicit, n_cells, tree_levels, p, b.n, gp,
+                                     d_pvol_acc.p, d_up_acc.p, d_touched.p));
         if (timing) { timers[T_LOCATE].stop(stream); timers[T_FINALIZE].start(stream); }
+        FY_TRY(launch_deposit(stream, p, b.n, d_pvol_acc.p, d_up_acc.p, d_touched.p));
         FY_TRY(launch_finalize_cells(stream, n_cells, d_vol.p, d_pvol_acc.p, d_up_acc.p, d_touched.p, dAlpha, dUParticle));
         if (timing) { timers[T_FINALIZE].stop(stream); timers[T_FORCE].start(stream); }
         FY_TRY(launch_force_gaussian(stream, p, b.n, fp, d_vol.p, dU, dAlpha, dUParticle, dGradP, dDivT, dUSourceDrag, dUSource,

@@ -46,6 +46,9 @@ struct Coupling {
 
     // ---- device state
     DevBuf<KdNode> d_tree;
+    DevBuf<uint32_t> d_tree_packed;      // implicit-coordinate nodes, only when the block's centres are exactly o + (i+0.5)*dx
+    ImplicitGeom implicit{};
+    bool use_implicit = false;
     int tree_levels = 0;
     DevBuf<double> d_vol;
     fy_field_ptrs fields{};

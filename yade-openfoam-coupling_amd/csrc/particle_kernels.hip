@@ -22,9 +22,25 @@ namespace {
 
 constexpr int kWave = 64;
 
+// Block order.  An XCD-aware remap (guide T1: block b runs on XCD b % 8, give each XCD a contiguous run of the binned
+// particle order) was measured on MI355X and LOSES here: locate+deposit 14.5 -> 16.1 ms, force 10.0 -> 10.8 ms at 10 M
+// particles, because the FP64 atomics of a spatially compact run pile onto few memory channels.  Round-robin stays.
+#if defined(FY_EXP_SWZ)
+__device__ __forceinline__ int64_t swz_block(int64_t bid, int64_t nblk) { return (bid % 8) * (nblk / 8) + bid / 8; }
+#define FY_BLOCK(b, n) swz_block((b), (n))
+#else
+#define FY_BLOCK(b, n) (b)
+#endif
+
 __device__ __forceinline__ void atomic_add_f64(double* p, double v) {
+#if defined(FY_EXP_NO_ATOMICS)
+    if (v == 1.2345e300) *p = v;     // experiment build: keep the operands live, issue nothing
+#elif defined(FY_EXP_L2_ATOMICS)
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // timing experiment only
+#else
     // global_atomic_add_f64, no return value, device (agent) scope
     unsafeAtomicAdd(p, v);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ binning
@@ -126,19 +142,51 @@ __global__ __launch_bounds__(256) void k_bin_scatter(const double* __restrict__ 
 // One lane per particle, one wave per 64-particle chunk of the binned order.  Per-lane DFS stack lives in LDS as
 // [level][lane] uint4 = {offset, size | axis<<30, df2 (2 dwords)}: 16 B * 64 lanes = one 1 KiB row per level, and the bank of an
 // entry depends on the lane only, so lanes at different levels never conflict.
-__global__ __launch_bounds__(kWave) void k_locate_deposit(const KdNode* __restrict__ tree, int32_t n_cells, ParticleSoA p,
+// Node fetch.  Explicit: 32-byte {x,y,z,id} records (any mesh).  Implicit: for a uniform hex block whose centres were verified
+// at create time to equal origin + (i + 0.5) * dx bit for bit, a node is just the packed (i,j,k) of its cell -- 4 bytes, 16 nodes
+// per 64-byte line instead of 2 -- and the centre is recomputed with the same two IEEE operations (contraction is off).
+// The divergent bottom-of-tree loads are what bound this kernel (one L1 tag lookup per distinct line per instruction), so
+// trading ~12 FP64 ALU ops for 8x fewer lines is the MI355X-shaped choice.
+struct NodeVal { double x, y, z; int32_t id; };
+
+template <bool IMPLICIT>
+__device__ __forceinline__ NodeVal fetch_node(const KdNode* __restrict__ tree, const uint32_t* __restrict__ packed, const ImplicitGeom& ig, uint32_t o) {
+    NodeVal v;
+    if constexpr (IMPLICIT) {
+        const uint32_t q = packed[o];
+        const int i = (int)(q & 1023u), j = (int)((q >> 10) & 1023u), k = (int)(q >> 20);
+        v.x = ig.ox + ((double)i + 0.5) * ig.dx;
+        v.y = ig.oy + ((double)j + 0.5) * ig.dx;
+        v.z = ig.oz + ((double)k + 0.5) * ig.dx;
+        v.id = i + ig.nx * (j + ig.ny * k);
+    } else {
+        const KdNode nd = tree[o];
+        v.x = nd.x; v.y = nd.y; v.z = nd.z; v.id = nd.id;
+    }
+    return v;
+}
+
+template <bool IMPLICIT>
+__global__ __launch_bounds__(kWave) void k_locate_deposit(const KdNode* __restrict__ tree, const uint32_t* __restrict__ packed, ImplicitGeom ig,
+                                                          int32_t n_cells, ParticleSoA p,
                                                           int64_t n, GaussParams gp, double* __restrict__ pvol_acc,
                                                           double* __restrict__ up_acc, unsigned char* __restrict__ touched) {
+#if defined(FY_EXP_SCRATCH_STACK)
+    uint4 stack_priv[28];
+#define STK(sp_) stack_priv[(sp_)]
+#else
     extern __shared__ __attribute__((aligned(16))) uint4 stack[];
+#define STK(sp_) stack[(sp_) * kWave + lane]
+#endif
     const int lane = threadIdx.x;
-    const int64_t i = (int64_t)blockIdx.x * kWave + lane;
+    const int64_t i = FY_BLOCK((int64_t)blockIdx.x, (int64_t)gridDim.x) * kWave + lane;
     if (i >= n) return;
     const double qx = p.px[i], qy = p.py[i], qz = p.pz[i];
 
     // meshTree.C:156: dist = distance(root->p, px); the root itself can never enter the queue (x < x is false)
     double best;
     {
-        const KdNode r = tree[0];
+        const NodeVal r = fetch_node<IMPLICIT>(tree, packed, ig, 0u);
         const double a = qx - r.x, b = qy - r.y, c = qz - r.z;
         best = a * a;
         best += b * b;
@@ -152,7 +200,7 @@ __global__ __launch_bounds__(kWave) void k_locate_deposit(const KdNode* __restri
             bool got = false;
             while (sp > 0) {
                 --sp;
-                const uint4 e = stack[sp * kWave + lane];
+                const uint4 e = STK(sp);
                 const double df2 = __hiloint2double((int)e.w, (int)e.z);
                 if (df2 < best) {          // meshTree.C:225, evaluated when the near subtree has returned
                     o = e.x; nn = e.y & 0x3fffffffu; axis = e.y >> 30;
@@ -162,7 +210,7 @@ __global__ __launch_bounds__(kWave) void k_locate_deposit(const KdNode* __restri
             }
             if (!got) break;
         }
-        const KdNode nd = tree[o];
+        const NodeVal nd = fetch_node<IMPLICIT>(tree, packed, ig, o);
         const double a = qx - nd.x, b = qy - nd.y, c = qz - nd.z;
         double d = a * a;                    // meshTree.C:54-64: dist += ds*ds over x, y, z
         d += b * b;
@@ -188,7 +236,7 @@ __global__ __launch_bounds__(kWave) void k_locate_deposit(const KdNode* __restri
             uint4 e;
             e.x = far_o; e.y = far_n | (axis << 30);
             e.z = (uint32_t)__double2loint(df2); e.w = (uint32_t)__double2hiint(df2);
-            stack[sp * kWave + lane] = e;
+            STK(sp) = e;
             ++sp;
         }
         o = near_o; nn = near_n;
@@ -206,19 +254,79 @@ __global__ __launch_bounds__(kWave) void k_locate_deposit(const KdNode* __restri
         allwt += weight;
         p.w[slot] = weight;
     }
-    // buildCellPartList FoamYade.C:265-288: pVol*w and (w*v)*pVol into the per-batch accumulators
-    const double dia = 2 * p.rad[i];                                  // FoamYade.C:219
-    const double pVol = M_PI * pow(dia, 3.0) / 6.0;                   // FoamYade.H:36
-    const double vx = p.vx[i], vy = p.vy[i], vz = p.vz[i];
-    for (int t = 0; t < k; ++t) {
+    for (int t = 0; t < k; ++t) {                                     // FoamYade.C:312-314
         const size_t slot = (size_t)((chain - 1 - t) & (kMaxK - 1)) * p.cap + (size_t)i;
-        const double weight = p.w[slot] / allwt;
-        p.w[slot] = weight;
-        const int32_t cid = p.ids[slot];
-        atomic_add_f64(&pvol_acc[cid], pVol * weight);
-        atomic_add_f64(&up_acc[3 * (size_t)cid + 0], (weight * vx) * pVol);
-        atomic_add_f64(&up_acc[3 * (size_t)cid + 1], (weight * vy) * pVol);
-        atomic_add_f64(&up_acc[3 * (size_t)cid + 2], (weight * vz) * pVol);
+        p.w[slot] = p.w[slot] / allwt;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ LDS aggregation of scatters
+// Binned particles that share a workgroup also share most of their stencil cells (measured on the C3 cloud: 8.4 (particle, cell)
+// pairs per distinct cell in a 256-particle block, 12 in a 1024-particle block).  FP64 global atomics are what bounds the scatter
+// phases (force kernel: 10.0 ms with, 2.1 ms without them at 10 M particles), so every workgroup first sums its contributions
+// per cell in an LDS hash table (ds_add_f64) and only the per-cell totals go out as global_atomic_add_f64.
+constexpr uint32_t kAggEmpty = 0xffffffffu;
+
+template <int LOG2SLOTS>
+__device__ __forceinline__ int agg_slot(uint32_t* keys, uint32_t cell) {
+    uint32_t h = (cell * 2654435761u) >> (32 - LOG2SLOTS);
+#pragma unroll 1
+    for (int pr = 0; pr < 24; ++pr) {
+        const uint32_t old = atomicCAS(&keys[h], kAggEmpty, cell);
+        if (old == kAggEmpty || old == cell) return (int)h;
+        h = (h + 1) & ((1u << LOG2SLOTS) - 1u);
+    }
+    return -1;      // table crowded: caller falls back to a direct global atomic
+}
+
+__device__ __forceinline__ void lds_add_f64(double* p, double v) { unsafeAtomicAdd(p, v); }   // ds_add_f64
+
+// buildCellPartList FoamYade.C:265-288: pVol*w and (w*v)*pVol per (particle, cell) pair into the per-batch accumulators
+constexpr int kDepThreads = 512, kDepLog2 = 11;      // 2048 slots x (4 + 32) B = 72 KiB of LDS
+__global__ __launch_bounds__(kDepThreads) void k_deposit(ParticleSoA p, int64_t n, double* __restrict__ pvol_acc, double* __restrict__ up_acc,
+                                                          unsigned char* __restrict__ touched) {
+    __shared__ uint32_t keys[1 << kDepLog2];
+    __shared__ double vals[(1 << kDepLog2) * 4];
+    for (int q = threadIdx.x; q < (1 << kDepLog2); q += kDepThreads) {
+        keys[q] = kAggEmpty;
+        vals[4 * q] = 0.0; vals[4 * q + 1] = 0.0; vals[4 * q + 2] = 0.0; vals[4 * q + 3] = 0.0;
+    }
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * kDepThreads + threadIdx.x;
+    if (i < n) {
+        const int chain = p.chain_len[i];
+        const int k = chain < kMaxK ? chain : kMaxK;
+        if (k > 0) {
+            const double dia = 2 * p.rad[i];                                  // FoamYade.C:219
+            const double pVol = M_PI * pow(dia, 3.0) / 6.0;                   // FoamYade.H:36
+            const double vx = p.vx[i], vy = p.vy[i], vz = p.vz[i];
+            for (int t = 0; t < k; ++t) {
+                const size_t slot = (size_t)((chain - 1 - t) & (kMaxK - 1)) * p.cap + (size_t)i;
+                const double weight = p.w[slot];
+                const int32_t cid = p.ids[slot];
+                const double c0 = pVol * weight, c1 = (weight * vx) * pVol, c2 = (weight * vy) * pVol, c3 = (weight * vz) * pVol;
+                const int h = agg_slot<kDepLog2>(keys, (uint32_t)cid);
+                if (h >= 0) {
+                    lds_add_f64(&vals[4 * h], c0); lds_add_f64(&vals[4 * h + 1], c1);
+                    lds_add_f64(&vals[4 * h + 2], c2); lds_add_f64(&vals[4 * h + 3], c3);
+                } else {
+                    atomic_add_f64(&pvol_acc[cid], c0);
+                    atomic_add_f64(&up_acc[3 * (size_t)cid + 0], c1);
+                    atomic_add_f64(&up_acc[3 * (size_t)cid + 1], c2);
+                    atomic_add_f64(&up_acc[3 * (size_t)cid + 2], c3);
+                    touched[cid] = 1;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < (1 << kDepLog2); q += kDepThreads) {
+        const uint32_t cid = keys[q];
+        if (cid == kAggEmpty) continue;
+        atomic_add_f64(&pvol_acc[cid], vals[4 * q]);
+        atomic_add_f64(&up_acc[3 * (size_t)cid + 0], vals[4 * q + 1]);
+        atomic_add_f64(&up_acc[3 * (size_t)cid + 1], vals[4 * q + 2]);
+        atomic_add_f64(&up_acc[3 * (size_t)cid + 2], vals[4 * q + 3]);
         touched[cid] = 1;
     }
 }
@@ -241,80 +349,108 @@ __global__ __launch_bounds__(256) void k_finalize_cells(int32_t n_cells, const d
 }
 
 // ------------------------------------------------------------------------------------------------ force + back-scatter
-__global__ __launch_bounds__(256) void k_force_gaussian(ParticleSoA p, int64_t n, ForceParams fp, const double* __restrict__ vol,
-                                                        const double* __restrict__ U, const double* __restrict__ alpha,
-                                                        const double* __restrict__ uParticle, const double* __restrict__ gradP,
-                                                        const double* __restrict__ divT, double* __restrict__ uSourceDrag,
-                                                        double* __restrict__ uSource, double* __restrict__ force_out,
-                                                        int32_t* __restrict__ found_out) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const int chain = p.chain_len[i];
-    const int k = chain < kMaxK ? chain : kMaxK;
-    const int32_t orig = p.orig[i];
-    double* F = force_out + 6 * (size_t)orig;
-    if (k == 0) {                                   // zeros for particles nobody located (FoamYade.C:142)
-        F[0] = F[1] = F[2] = F[3] = F[4] = F[5] = 0.0;
-        found_out[orig] = -1;
-        return;
+constexpr int kForceThreads = 512, kForceLog2 = 11;
+__global__ __launch_bounds__(kForceThreads) void k_force_gaussian(ParticleSoA p, int64_t n, ForceParams fp, const double* __restrict__ vol,
+                                                                  const double* __restrict__ U, const double* __restrict__ alpha,
+                                                                  const double* __restrict__ uParticle, const double* __restrict__ gradP,
+                                                                  const double* __restrict__ divT, double* __restrict__ uSourceDrag,
+                                                                  double* __restrict__ uSource, double* __restrict__ force_out,
+                                                                  int32_t* __restrict__ found_out) {
+    __shared__ uint32_t keys[1 << kForceLog2];
+    __shared__ double vals[(1 << kForceLog2) * 4];
+    for (int q = threadIdx.x; q < (1 << kForceLog2); q += kForceThreads) {
+        keys[q] = kAggEmpty;
+        vals[4 * q] = 0.0; vals[4 * q + 1] = 0.0; vals[4 * q + 2] = 0.0; vals[4 * q + 3] = 0.0;
     }
-    found_out[orig] = 1;
-    const double rhoF = fp.rhoF, nu = fp.nu;
-    const double dia = 2 * p.rad[i];
-    const double volp = M_PI * pow(dia, 3.0) / 6.0;
-    const double lvx = p.vx[i], lvy = p.vy[i], lvz = p.vz[i];
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * kForceThreads + threadIdx.x;
+    if (i < n) {
+        const int chain = p.chain_len[i];
+        const int k = chain < kMaxK ? chain : kMaxK;
+        const int32_t orig = p.orig[i];
+        double* F = force_out + 6 * (size_t)orig;
+        if (k == 0) {                                   // zeros for particles nobody located (FoamYade.C:142)
+            F[0] = F[1] = F[2] = F[3] = F[4] = F[5] = 0.0;
+            found_out[orig] = -1;
+        } else {
+            found_out[orig] = 1;
+            const double rhoF = fp.rhoF, nu = fp.nu;
+            const double dia = 2 * p.rad[i];
+            const double volp = M_PI * pow(dia, 3.0) / 6.0;
+            const double lvx = p.vx[i], lvy = p.vy[i], lvz = p.vz[i];
 
-    // hydroDragForce FoamYade.C:358-365 and archimedesForce FoamYade.C:416-424 share one gather pass
-    double ufx = 0, ufy = 0, ufz = 0, alpha_f = 0.0, pv = 0.0;
-    double dtx = 0, dty = 0, dtz = 0, pgx = 0, pgy = 0, pgz = 0;
-    const double two_nu = 2.0 * nu;
-    for (int t = 0; t < k; ++t) {
-        const size_t slot = (size_t)((chain - 1 - t) & (kMaxK - 1)) * p.cap + (size_t)i;
-        const int32_t c = p.ids[slot];
-        const double w = p.w[slot];
-        const double* u = U + 3 * (size_t)c;
-        ufx += (u[0] * w); ufy += (u[1] * w); ufz += (u[2] * w);
-        alpha_f += (alpha[c] * w);
-        pv += (volp * w);
-        const double* dt = divT + 3 * (size_t)c;
-        dtx = dtx + (((two_nu * dt[0]) * w) * rhoF);
-        dty = dty + (((two_nu * dt[1]) * w) * rhoF);
-        dtz = dtz + (((two_nu * dt[2]) * w) * rhoF);
-        const double* g = gradP + 3 * (size_t)c;
-        pgx = pgx + (g[0] * w); pgy = pgy + (g[1] * w); pgz = pgz + (g[2] * w);
-    }
-    const double alpha_p = 1 - alpha_f;                                             // FoamYade.C:366
-    const double urx = ufx - lvx, ury = ufy - lvy, urz = ufz - lvz;
-    const double magUR = sqrt(urx * urx + ury * ury + urz * urz);
-    const double Re = fp.small + ((magUR * dia) / nu);                              // FoamYade.C:370
-    const double cd = Re < 1000 ? (24 / (Re)) * (1 + (0.15 * pow(Re, 0.687))) : 0.44;
-    double coeff;
-    if (alpha_f > 0.8) {                                                            // FoamYade.C:373-374
-        coeff = 0.75 * cd * alpha_f * alpha_p * rhoF * magUR * pow(alpha_f, -2.65);
-    } else {                                                                        // FoamYade.C:376-378
-        const double cf1 = 150 * ((alpha_p * alpha_p) / alpha_f) * ((nu * rhoF) / (dia * dia));
-        const double cf2 = 1.75 * alpha_p * rhoF * (1 / dia) * magUR;
-        coeff = cf1 + cf2;
-    }
-    const double s1 = pv * coeff, ia = 1 / (alpha_p);                               // FoamYade.C:381
-    const double hfx = (s1 * urx) * ia, hfy = (s1 * ury) * ia, hfz = (s1 * urz) * ia;
-    const double afx = pv * (-pgx + dtx), afy = pv * (-pgy + dty), afz = pv * (-pgz + dtz);   // FoamYade.C:426
-    F[0] = (0.0 + hfx) + afx; F[1] = (0.0 + hfy) + afy; F[2] = (0.0 + hfz) + afz;   // FoamYade.C:382,427
-    F[3] = 0.0; F[4] = 0.0; F[5] = 0.0;                                             // Gaussian torque disabled, FoamYade.C:618
+            // hydroDragForce FoamYade.C:358-365 and archimedesForce FoamYade.C:416-424 share one gather pass
+            double ufx = 0, ufy = 0, ufz = 0, alpha_f = 0.0, pv = 0.0;
+            double dtx = 0, dty = 0, dtz = 0, pgx = 0, pgy = 0, pgz = 0;
+            const double two_nu = 2.0 * nu;
+            for (int t = 0; t < k; ++t) {
+                const size_t slot = (size_t)((chain - 1 - t) & (kMaxK - 1)) * p.cap + (size_t)i;
+                const int32_t c = p.ids[slot];
+                const double w = p.w[slot];
+                const double* u = U + 3 * (size_t)c;
+                ufx += (u[0] * w); ufy += (u[1] * w); ufz += (u[2] * w);
+                alpha_f += (alpha[c] * w);
+                pv += (volp * w);
+                const double* dt = divT + 3 * (size_t)c;
+                dtx = dtx + (((two_nu * dt[0]) * w) * rhoF);
+                dty = dty + (((two_nu * dt[1]) * w) * rhoF);
+                dtz = dtz + (((two_nu * dt[2]) * w) * rhoF);
+                const double* g = gradP + 3 * (size_t)c;
+                pgx = pgx + (g[0] * w); pgy = pgy + (g[1] * w); pgz = pgz + (g[2] * w);
+            }
+            const double alpha_p = 1 - alpha_f;                                             // FoamYade.C:366
+            const double urx = ufx - lvx, ury = ufy - lvy, urz = ufz - lvz;
+            const double magUR = sqrt(urx * urx + ury * ury + urz * urz);
+            const double Re = fp.small + ((magUR * dia) / nu);                              // FoamYade.C:370
+            const double cd = Re < 1000 ? (24 / (Re)) * (1 + (0.15 * pow(Re, 0.687))) : 0.44;
+            double coeff;
+            if (alpha_f > 0.8) {                                                            // FoamYade.C:373-374
+                coeff = 0.75 * cd * alpha_f * alpha_p * rhoF * magUR * pow(alpha_f, -2.65);
+            } else {                                                                        // FoamYade.C:376-378
+                const double cf1 = 150 * ((alpha_p * alpha_p) / alpha_f) * ((nu * rhoF) / (dia * dia));
+                const double cf2 = 1.75 * alpha_p * rhoF * (1 / dia) * magUR;
+                coeff = cf1 + cf2;
+            }
+            const double s1 = pv * coeff, ia = 1 / (alpha_p);                               // FoamYade.C:381
+            const double hfx = (s1 * urx) * ia, hfy = (s1 * ury) * ia, hfz = (s1 * urz) * ia;
+            const double afx = pv * (-pgx + dtx), afy = pv * (-pgy + dty), afz = pv * (-pgz + dtz);   // FoamYade.C:426
+            F[0] = (0.0 + hfx) + afx; F[1] = (0.0 + hfy) + afy; F[2] = (0.0 + hfz) + afz;   // FoamYade.C:382,427
+            F[3] = 0.0; F[4] = 0.0; F[5] = 0.0;                                             // Gaussian torque disabled, FoamYade.C:618
 
-    const double irho = 1 / rhoF;
-    for (int t = 0; t < k; ++t) {
-        const size_t slot = (size_t)((chain - 1 - t) & (kMaxK - 1)) * p.cap + (size_t)i;
-        const int32_t c = p.ids[slot];
-        const double w = p.w[slot];
-        const double cw = -coeff * w;
-        atomic_add_f64(&uSourceDrag[c], cw * irho);                                 // FoamYade.C:385
-        const double* up = uParticle + 3 * (size_t)c;
-        const double ooCellVol = 1. / (vol[c] * rhoF);                              // FoamYade.C:432
-        // FoamYade.C:386 (drag part, NOT divided by V) + FoamYade.C:433 (Archimedes part), one atomic per component
-        atomic_add_f64(&uSource[3 * (size_t)c + 0], ((cw * up[0]) / rhoF) + ((-afx * w) * ooCellVol));
-        atomic_add_f64(&uSource[3 * (size_t)c + 1], ((cw * up[1]) / rhoF) + ((-afy * w) * ooCellVol));
-        atomic_add_f64(&uSource[3 * (size_t)c + 2], ((cw * up[2]) / rhoF) + ((-afz * w) * ooCellVol));
+            const double irho = 1 / rhoF;
+            for (int t = 0; t < k; ++t) {
+                const size_t slot = (size_t)((chain - 1 - t) & (kMaxK - 1)) * p.cap + (size_t)i;
+                const int32_t c = p.ids[slot];
+                const double w = p.w[slot];
+                const double cw = -coeff * w;
+                const double* up = uParticle + 3 * (size_t)c;
+                const double ooCellVol = 1. / (vol[c] * rhoF);                              // FoamYade.C:432
+                // FoamYade.C:385 ; FoamYade.C:386 (drag part, NOT divided by V) + FoamYade.C:433 (Archimedes part)
+                const double c0 = cw * irho;
+                const double c1 = ((cw * up[0]) / rhoF) + ((-afx * w) * ooCellVol);
+                const double c2 = ((cw * up[1]) / rhoF) + ((-afy * w) * ooCellVol);
+                const double c3 = ((cw * up[2]) / rhoF) + ((-afz * w) * ooCellVol);
+                const int h = agg_slot<kForceLog2>(keys, (uint32_t)c);
+                if (h >= 0) {
+                    lds_add_f64(&vals[4 * h], c0); lds_add_f64(&vals[4 * h + 1], c1);
+                    lds_add_f64(&vals[4 * h + 2], c2); lds_add_f64(&vals[4 * h + 3], c3);
+                } else {
+                    atomic_add_f64(&uSourceDrag[c], c0);
+                    atomic_add_f64(&uSource[3 * (size_t)c + 0], c1);
+                    atomic_add_f64(&uSource[3 * (size_t)c + 1], c2);
+                    atomic_add_f64(&uSource[3 * (size_t)c + 2], c3);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < (1 << kForceLog2); q += kForceThreads) {
+        const uint32_t c = keys[q];
+        if (c == kAggEmpty) continue;
+        atomic_add_f64(&uSourceDrag[c], vals[4 * q]);
+        atomic_add_f64(&uSource[3 * (size_t)c + 0], vals[4 * q + 1]);
+        atomic_add_f64(&uSource[3 * (size_t)c + 1], vals[4 * q + 2]);
+        atomic_add_f64(&uSource[3 * (size_t)c + 2], vals[4 * q + 3]);
     }
 }
 
@@ -440,11 +576,24 @@ int launch_bin_scatter(hipStream_t s, const double* rec, int64_t n, const uint32
     return FY_OK;
 }
 
-int launch_locate_deposit(hipStream_t s, const KdNode* tree, int32_t n_cells, int levels, const double* /*centres*/,
+int launch_locate_deposit(hipStream_t s, const KdNode* tree, const uint32_t* packed, ImplicitGeom ig, int32_t n_cells, int levels,
                           ParticleSoA p, int64_t n, GaussParams gp, double* pvol_acc, double* up_acc, unsigned char* touched) {
     if (n <= 0) return FY_OK;
+#if defined(FY_EXP_SCRATCH_STACK)
+    const size_t lds = 0; (void)levels;
+#else
     const size_t lds = (size_t)(levels + 1) * kWave * sizeof(uint4);
-    hipLaunchKernelGGL(k_locate_deposit, dim3(div_up(n, kWave)), dim3(kWave), lds, s, tree, n_cells, p, n, gp, pvol_acc, up_acc, touched);
+#endif
+    const dim3 grid((div_up(n, kWave) + 7u) & ~7u);
+    if (packed) hipLaunchKernelGGL(k_locate_deposit<true>, grid, dim3(kWave), lds, s, tree, packed, ig, n_cells, p, n, gp, pvol_acc, up_acc, touched);
+    else hipLaunchKernelGGL(k_locate_deposit<false>, grid, dim3(kWave), lds, s, tree, packed, ig, n_cells, p, n, gp, pvol_acc, up_acc, touched);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+
+int launch_deposit(hipStream_t s, ParticleSoA p, int64_t n, double* pvol_acc, double* up_acc, unsigned char* touched) {
+    if (n <= 0) return FY_OK;
+    hipLaunchKernelGGL(k_deposit, dim3(div_up(n, kDepThreads)), dim3(kDepThreads), 0, s, p, n, pvol_acc, up_acc, touched);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }
@@ -460,7 +609,7 @@ int launch_force_gaussian(hipStream_t s, ParticleSoA p, int64_t n, ForceParams f
                           const double* alpha, const double* uParticle, const double* gradP, const double* divT,
                           double* uSourceDrag, double* uSource, double* force_out, int32_t* found_out) {
     if (n <= 0) return FY_OK;
-    hipLaunchKernelGGL(k_force_gaussian, dim3(div_up(n, 256)), dim3(256), 0, s, p, n, fp, vol, U, alpha, uParticle, gradP, divT,
+    hipLaunchKernelGGL(k_force_gaussian, dim3(div_up(n, kForceThreads)), dim3(kForceThreads), 0, s, p, n, fp, vol, U, alpha, uParticle, gradP, divT,
                        uSourceDrag, uSource, force_out, found_out);
     FY_LAUNCH_CHECK();
     return FY_OK;

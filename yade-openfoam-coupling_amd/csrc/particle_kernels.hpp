@@ -46,9 +46,16 @@ int launch_exclusive_scan_u32(hipStream_t s, uint32_t* data, uint32_t n, uint32_
 int launch_bin_scatter(hipStream_t s, const double* rec, int64_t n, const uint32_t* key, const uint32_t* rank,
                        const uint32_t* start, const uint32_t* tile_off, ParticleSoA p);
 
-int launch_locate_deposit(hipStream_t s, const KdNode* tree, int32_t n_cells, int levels, const double* centres,
+// implicit-coordinate tree (uniform hex block verified at create time): node = packed (i | j << 10 | k << 20)
+struct ImplicitGeom {
+    double ox, oy, oz, dx;
+    int nx, ny;
+};
+// packed == nullptr selects the explicit 32-byte-node path
+int launch_locate_deposit(hipStream_t s, const KdNode* tree, const uint32_t* packed, ImplicitGeom ig, int32_t n_cells, int levels,
                           ParticleSoA p, int64_t n, GaussParams gp, double* pvol_acc, double* up_acc,
                           unsigned char* touched);
+int launch_deposit(hipStream_t s, ParticleSoA p, int64_t n, double* pvol_acc, double* up_acc, unsigned char* touched);
 int launch_finalize_cells(hipStream_t s, int32_t n_cells, const double* vol, double* pvol_acc, double* up_acc,
                           unsigned char* touched, double* alpha, double* uParticle);
 int launch_force_gaussian(hipStream_t s, ParticleSoA p, int64_t n, ForceParams fp, const double* vol, const double* U,
