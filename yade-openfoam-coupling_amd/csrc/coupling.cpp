@@ -267,10 +267,9 @@ int Coupling::run_batch(Batch& b) {
         gp.maxdist = (interp_range * interp_range) + (0.25 * interp_range * interp_range);   // meshTree.C:155
         gp.two_sigma2 = 2 * std::pow(sigma_interp, 2);                                         // FoamYade.C:308
         gp.range_cu = interp_range_cu; gp.sigma_pi = sigma_pi;
-        FY_TRY(launch_locate_deposit(stream, d_tree.p, use_implicit ? d_tree_packed.p : nullptr, implicit, n_cells, tree_levels, p, b.n, gp,
-                                     d_pvol_acc.p, d_up_acc.p, d_touched.p));
+        FY_TRY(launch_locate(stream, d_tree.p, use_implicit ? d_tree_packed.p : nullptr, implicit, n_cells, tree_levels, p, b.n, gp));
         if (timing) { timers[T_LOCATE].stop(stream); timers[T_FINALIZE].start(stream); }
-        FY_TRY(launch_deposit(stream, p, b.n, d_pvol_acc.p, d_up_acc.p, d_touched.p));
+        FY_TRY(launch_deposit(stream, p, b.n, gp, d_pvol_acc.p, d_up_acc.p, d_touched.p));
         FY_TRY(launch_finalize_cells(stream, n_cells, d_vol.p, d_pvol_acc.p, d_up_acc.p, d_touched.p, dAlpha, dUParticle));
         if (timing) { timers[T_FINALIZE].stop(stream); timers[T_FORCE].start(stream); }
         FY_TRY(launch_force_gaussian(stream, p, b.n, fp, d_vol.p, dU, dAlpha, dUParticle, dGradP, dDivT, dUSourceDrag, dUSource,

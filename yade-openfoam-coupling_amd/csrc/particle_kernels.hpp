@@ -51,11 +51,11 @@ struct ImplicitGeom {
     double ox, oy, oz, dx;
     int nx, ny;
 };
-// packed == nullptr selects the explicit 32-byte-node path
-int launch_locate_deposit(hipStream_t s, const KdNode* tree, const uint32_t* packed, ImplicitGeom ig, int32_t n_cells, int levels,
-                          ParticleSoA p, int64_t n, GaussParams gp, double* pvol_acc, double* up_acc,
-                          unsigned char* touched);
-int launch_deposit(hipStream_t s, ParticleSoA p, int64_t n, double* pvol_acc, double* up_acc, unsigned char* touched);
+// packed == nullptr selects the explicit 32-byte-node path.  Leaves chain ids and squared distances (in the weight slots).
+int launch_locate(hipStream_t s, const KdNode* tree, const uint32_t* packed, ImplicitGeom ig, int32_t n_cells, int levels,
+                  ParticleSoA p, int64_t n, GaussParams gp);
+// forms the normalised Gaussian weights from the parked squared distances, then deposits (LDS-aggregated)
+int launch_deposit(hipStream_t s, ParticleSoA p, int64_t n, GaussParams gp, double* pvol_acc, double* up_acc, unsigned char* touched);
 int launch_finalize_cells(hipStream_t s, int32_t n_cells, const double* vol, double* pvol_acc, double* up_acc,
                           unsigned char* touched, double* alpha, double* uParticle);
 int launch_force_gaussian(hipStream_t s, ParticleSoA p, int64_t n, ForceParams fp, const double* vol, const double* U,
