@@ -172,17 +172,27 @@ __device__ __forceinline__ NodeVal fetch_node(const KdNode* __restrict__ tree, c
 // One loop iteration = at most one pop and one node visit per lane; the Gaussian weights are formed later, at full width,
 // by k_deposit -- here the squared distance of every chain member is parked in its weight slot.
 constexpr int kLocPPB = 1024;
+#ifndef FY_LOC_REFILL
+#define FY_LOC_REFILL 12
+#endif
+constexpr int kLocRefill = FY_LOC_REFILL;    // refill once this many lanes are idle
+
+// DFS stack entry.  Explicit nodes: 16 B {far offset, far size | axis << 30, df2}.  Implicit nodes: 8 B -- the far side's df2 is
+// NOT stored; the entry carries the parent's 10-bit lattice index along the split axis and df2 = (o + (idx + 0.5) dx - q)^2 is
+// recomputed at pop time with the same IEEE operations, bit for bit.  Halving the entry doubles the waves a CU can hold
+// (LDS: levels x 64 lanes x entry), and this kernel is latency bound.
+//   implicit entry: bits 0..25 far offset | 26..51 far size | 52..53 axis of the far child | 54..63 parent index on the split axis
+template <bool IMPLICIT> struct StackEntry;
+template <> struct StackEntry<false> { typedef uint4 type; };
+template <> struct StackEntry<true> { typedef unsigned long long type; };
 
 template <bool IMPLICIT>
 __global__ __launch_bounds__(kWave) void k_locate(const KdNode* __restrict__ tree, const uint32_t* __restrict__ packed, ImplicitGeom ig,
                                                   int32_t n_cells, ParticleSoA p, int64_t n, double maxdist) {
-#if defined(FY_EXP_SCRATCH_STACK)
-    uint4 stack_priv[28];
-#define STK(sp_) stack_priv[(sp_)]
-#else
-    extern __shared__ __attribute__((aligned(16))) uint4 stack[];
+    typedef typename StackEntry<IMPLICIT>::type entry_t;
+    extern __shared__ __attribute__((aligned(16))) unsigned char stack_raw[];
+    entry_t* stack = reinterpret_cast<entry_t*>(stack_raw);
 #define STK(sp_) stack[(sp_) * kWave + lane]
-#endif
     const int lane = threadIdx.x;
     const int64_t base = (int64_t)blockIdx.x * kLocPPB;
     const int64_t end = (base + kLocPPB < n) ? base + kLocPPB : n;
@@ -195,9 +205,10 @@ __global__ __launch_bounds__(kWave) void k_locate(const KdNode* __restrict__ tre
     int chain = 0, sp = 0;
     uint32_t o = 0, nn = 0, axis = 0;
     for (;;) {
-        // ---- hand new particles to idle lanes
+        // ---- hand new particles to idle lanes (batched: the refill code is wave-wide, so wait until it pays)
         const unsigned long long idle = __ballot(!active);
-        if (idle != 0ull && next < end) {
+        const int n_idle = __popcll(idle);
+        if (next < end && (n_idle >= kLocRefill || n_idle == kWave)) {
             const int rank = __popcll(idle & ((1ull << lane) - 1ull));
             const int64_t cand = next + rank;
             if (!active && cand < end) {
@@ -211,25 +222,52 @@ __global__ __launch_bounds__(kWave) void k_locate(const KdNode* __restrict__ tre
                 chain = 0; sp = 0; o = 0; nn = (uint32_t)n_cells; axis = 0;
                 active = true;
             }
-            next += __popcll(idle);
+            next += n_idle;
+        } else if (n_idle == kWave) {
+            break;                                       // nothing running, nothing left
         }
-        if (__ballot(active) == 0ull) break;
         if (active) {
             if (nn == 0) {
-                if (sp == 0) {
-                    p.chain_len[i] = chain;              // walk finished; k = min(chain, 16)
-                    active = false;
-                } else {
-                    --sp;
-                    const uint4 e = STK(sp);
-                    const double df2 = __hiloint2double((int)e.w, (int)e.z);
-                    if (df2 < best) {                    // meshTree.C:225, evaluated when the near subtree has returned
-                        o = e.x; nn = e.y & 0x3fffffffu; axis = e.y >> 30;
+                // up to two pops per iteration: most popped far sides fail df2 < best and would waste the visit slot
+#pragma unroll
+                for (int attempt = 0; attempt < 2; ++attempt) {
+                    if (nn != 0) break;
+                    if (sp == 0) {
+                        if (active) { p.chain_len[i] = chain; active = false; }    // walk finished; k = min(chain, 16)
+                        break;
                     }
+                    --sp;
+                    const entry_t e = STK(sp);
+                    double df2;
+                    uint32_t eo, en, ea;
+                    if constexpr (IMPLICIT) {
+                        eo = (uint32_t)(e & 0x3ffffffull); en = (uint32_t)((e >> 26) & 0x3ffffffull); ea = (uint32_t)((e >> 52) & 3ull);
+                        const int idx = (int)(e >> 54);
+                        const uint32_t pa = (ea == 0 ? 2u : ea - 1u);               // the parent's split axis
+                        const double org = (pa == 0 ? ig.ox : (pa == 1 ? ig.oy : ig.oz));
+                        const double qq = (pa == 0 ? qx : (pa == 1 ? qy : qz));
+                        const double df = (org + ((double)idx + 0.5) * ig.dx) - qq;
+                        df2 = df * df;
+                    } else {
+                        eo = e.x; en = e.y & 0x3fffffffu; ea = e.y >> 30;
+                        df2 = __hiloint2double((int)e.w, (int)e.z);
+                    }
+                    if (df2 < best) { o = eo; nn = en; axis = ea; }                  // meshTree.C:225, evaluated when the near subtree has returned
                 }
             }
             if (active && nn != 0) {
-                const NodeVal nd = fetch_node<IMPLICIT>(tree, packed, ig, o);
+                uint32_t pk = 0;
+                NodeVal nd;
+                if constexpr (IMPLICIT) {
+                    pk = packed[o];
+                    const int ci = (int)(pk & 1023u), cj = (int)((pk >> 10) & 1023u), ck = (int)(pk >> 20);
+                    nd.x = ig.ox + ((double)ci + 0.5) * ig.dx;
+                    nd.y = ig.oy + ((double)cj + 0.5) * ig.dx;
+                    nd.z = ig.oz + ((double)ck + 0.5) * ig.dx;
+                    nd.id = ci + ig.nx * (cj + ig.ny * ck);
+                } else {
+                    nd = fetch_node<false>(tree, packed, ig, o);
+                }
                 const double a = qx - nd.x, b = qy - nd.y, c = qz - nd.z;
                 double d = a * a;                    // meshTree.C:54-64: dist += ds*ds over x, y, z
                 d += b * b;
@@ -249,19 +287,26 @@ __global__ __launch_bounds__(kWave) void k_locate(const KdNode* __restrict__ tre
                 uint32_t near_o, near_n, far_o, far_n;
                 if (df > 0.0) { near_o = o + 1; near_n = nl; far_o = o + 1 + nl; far_n = nr; }      // meshTree.C:206-208
                 else          { near_o = o + 1 + nl; near_n = nr; far_o = o + 1; far_n = nl; }      // meshTree.C:209-212
+                const uint32_t paxis = axis;
                 axis = (axis == 2 ? 0 : axis + 1);
                 // best only decreases, so a far side that already fails df2 < best can never pass later
                 if (far_n > 0 && df2 < best) {
-                    uint4 e;
-                    e.x = far_o; e.y = far_n | (axis << 30);
-                    e.z = (uint32_t)__double2loint(df2); e.w = (uint32_t)__double2hiint(df2);
-                    STK(sp) = e;
+                    if constexpr (IMPLICIT) {
+                        const unsigned long long idx = (paxis == 0 ? (pk & 1023u) : (paxis == 1 ? ((pk >> 10) & 1023u) : (pk >> 20)));
+                        STK(sp) = (unsigned long long)far_o | ((unsigned long long)far_n << 26) | ((unsigned long long)axis << 52) | (idx << 54);
+                    } else {
+                        uint4 e;
+                        e.x = far_o; e.y = far_n | (axis << 30);
+                        e.z = (uint32_t)__double2loint(df2); e.w = (uint32_t)__double2hiint(df2);
+                        STK(sp) = e;
+                    }
                     ++sp;
                 }
                 o = near_o; nn = near_n;
             }
         }
     }
+#undef STK
 }
 
 // ------------------------------------------------------------------------------------------------ LDS aggregation of scatters
@@ -593,11 +638,9 @@ int launch_bin_scatter(hipStream_t s, const double* rec, int64_t n, const uint32
 int launch_locate(hipStream_t s, const KdNode* tree, const uint32_t* packed, ImplicitGeom ig, int32_t n_cells, int levels,
                   ParticleSoA p, int64_t n, GaussParams gp) {
     if (n <= 0) return FY_OK;
-#if defined(FY_EXP_SCRATCH_STACK)
-    const size_t lds = 0; (void)levels;
-#else
-    const size_t lds = (size_t)(levels + 1) * kWave * sizeof(uint4);
-#endif
+    // implicit entries are 8 B (needs offsets and sizes < 2^26), explicit ones 16 B
+    if (packed && n_cells >= (1 << 26)) return fail(FY_ERR_UNSUPPORTED, "implicit-coordinate tree limited to 2^26 cells");
+    const size_t lds = (size_t)(levels + 1) * kWave * (packed ? sizeof(unsigned long long) : sizeof(uint4));
     const dim3 grid(div_up(n, kLocPPB));
     if (packed) hipLaunchKernelGGL(k_locate<true>, grid, dim3(kWave), lds, s, tree, packed, ig, n_cells, p, n, gp.maxdist);
     else hipLaunchKernelGGL(k_locate<false>, grid, dim3(kWave), lds, s, tree, packed, ig, n_cells, p, n, gp.maxdist);
