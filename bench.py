@@ -77,6 +77,21 @@ def cpu_baseline(n_sample, ppc, dt, threads):
     return out, nc, n_part
 
 
+def max_over_ranks(elapsed, dist, device):
+    """the contract's timing rule: the slowest rank defines the step time (works with nccl on GPUs and gloo on CPU)"""
+    if dist is None:
+        return elapsed
+    import torch
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def aggregate_value(world, steps, elapsed):
+    """whole-job throughput: every rank ran `steps` coupled steps in `elapsed` (max over ranks) seconds"""
+    return world * steps / elapsed
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -134,13 +149,10 @@ def main():
         acc["p_iters"] += st["p_iters_total"]; acc["u_iters"] += st["u_iters_total"]
     barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(elapsed, dist, dev)
 
     K = args.steps
-    steps_per_s = world * K / elapsed
+    steps_per_s = aggregate_value(world, K, elapsed)
     # ---- per-kernel clocks (HIP events on the launch stream, collected inside the timed region)
     kern = {}
     smooth_ms, smooth_n = solver.kernel_timing("mg_smooth_l0")

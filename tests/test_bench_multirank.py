@@ -1,0 +1,39 @@
+"""N > 1 path of bench.py on CPU: two gloo ranks, the timing rule (max over ranks) and the whole-job aggregate.
+(Round 1 shards nothing across GPUs: ranks are replicas, so this is all the cross-rank logic there is.)"""
+import os
+import subprocess
+import sys
+import textwrap
+
+from conftest import ROOT
+
+WORKER = textwrap.dedent("""
+    import os, sys, json
+    sys.path.insert(0, %r)
+    import torch, torch.distributed as dist
+    import bench
+    dist.init_process_group(backend="gloo")
+    r = dist.get_rank()
+    elapsed = 1.0 + 0.5 * r                      # rank 1 is the slow one
+    e = bench.max_over_ranks(elapsed, dist, torch.device("cpu"))
+    v = bench.aggregate_value(dist.get_world_size(), 10, e)
+    if r == 0:
+        print(json.dumps({"elapsed": e, "value": v}))
+    dist.barrier()
+    dist.destroy_process_group()
+""")
+
+
+def test_two_gloo_ranks_take_the_max(tmp_path):
+    script = tmp_path / "w.py"
+    script.write_text(WORKER % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29617", str(script)], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    import json
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1                        # only rank 0 prints
+    j = json.loads(line[0])
+    assert j["elapsed"] == 1.5
+    assert abs(j["value"] - 2 * 10 / 1.5) < 1e-12
