@@ -13,6 +13,10 @@
 
 namespace fy {
 
+// coarsest multigrid level: solved by damped-Jacobi sweeps inside one 1024-thread workgroup (every level below ~20^3 is
+// launch-bound on the GPU; stopping at <= 1024 cells was tried and LOST: 40 sweeps no longer solve that level, +20 % PCG iterations)
+constexpr int kMgCoarsest = 256;
+
 struct MgLev {
     PMat A{};
     DevBuf<double> diag, ux, uy, uz, x0, x1, b;
@@ -98,7 +102,7 @@ struct Solver {
         FY_TRY(ops_courant.alloc_exact(2));
         { const int h[2] = {1, 0}; FY_HIP(hipMemcpyAsync(ops_courant.p, h, sizeof(h), hipMemcpyHostToDevice, stream)); FY_HIP(hipStreamSynchronize(stream)); }
 
-        // multigrid hierarchy: 2x2x2 aggregation down to <= 256 cells
+        // multigrid hierarchy: 2x2x2 aggregation down to <= kMgCoarsest cells
         int ax = g.nx, ay = g.ny, az = g.nz;
         for (;;) {
             std::unique_ptr<MgLev> L(new MgLev());
@@ -111,7 +115,7 @@ struct Solver {
             const int N = L->A.N;
             mg.push_back(std::move(L));
             if (cs.p_solver != FY_PSOLVER_PCG_MG) break;
-            if (N <= 256 || (ax <= 2 && ay <= 2 && az <= 2)) break;
+            if (N <= kMgCoarsest || (ax <= 2 && ay <= 2 && az <= 2)) break;
             ax = (ax + 1) / 2; ay = (ay + 1) / 2; az = (az + 1) / 2;
         }
         if (mg.back()->A.N > 1024 && cs.p_solver == FY_PSOLVER_PCG_MG) return fail(FY_ERR_UNSUPPORTED, "coarsest multigrid level too large");

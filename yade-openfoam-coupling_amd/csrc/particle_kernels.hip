@@ -124,18 +124,26 @@ __global__ __launch_bounds__(1024) void k_scan_sums(uint32_t* __restrict__ sums,
         }
 }
 
-__global__ __launch_bounds__(256) void k_bin_scatter(const double* __restrict__ rec, int64_t n, const uint32_t* __restrict__ key,
-                                                     const uint32_t* __restrict__ rank, const uint32_t* __restrict__ start,
-                                                     const uint32_t* __restrict__ tile_off, ParticleSoA p) {
+// Counting-sort placement in two steps: the scatter writes ONLY the 4-byte source index to the sorted position (random 4-B
+// writes), then a gather pass reads whole 80-byte records at random and writes the SoA arrays coalesced.  Scattering the seven
+// doubles directly (10 M x 8 random 8-byte writes) measured 1.28 ms at 10 M particles; random reads are far cheaper than random writes.
+__global__ __launch_bounds__(256) void k_bin_scatter(int64_t n, const uint32_t* __restrict__ key, const uint32_t* __restrict__ rank,
+                                                     const uint32_t* __restrict__ start, const uint32_t* __restrict__ tile_off,
+                                                     int32_t* __restrict__ orig) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const uint32_t k = key[i];
     const size_t d = (size_t)start[k] + tile_off[k >> 11] + rank[i];
-    const double* r = rec + 10 * i;
+    orig[d] = (int32_t)i;
+}
+
+__global__ __launch_bounds__(256) void k_bin_gather(const double* __restrict__ rec, int64_t n, ParticleSoA p) {
+    const int64_t d = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (d >= n) return;
+    const double* r = rec + 10 * (size_t)p.orig[d];
     p.px[d] = r[0]; p.py[d] = r[1]; p.pz[d] = r[2];
     p.vx[d] = r[3]; p.vy[d] = r[4]; p.vz[d] = r[5];
     p.rad[d] = r[9];
-    p.orig[d] = (int32_t)i;
 }
 
 // ------------------------------------------------------------------------------------------------ locate + deposit
@@ -630,7 +638,9 @@ int launch_exclusive_scan_u32(hipStream_t s, uint32_t* data, uint32_t n, uint32_
 int launch_bin_scatter(hipStream_t s, const double* rec, int64_t n, const uint32_t* key, const uint32_t* rank,
                        const uint32_t* start, const uint32_t* tile_off, ParticleSoA p) {
     if (n <= 0) return FY_OK;
-    hipLaunchKernelGGL(k_bin_scatter, dim3(div_up(n, 256)), dim3(256), 0, s, rec, n, key, rank, start, tile_off, p);
+    hipLaunchKernelGGL(k_bin_scatter, dim3(div_up(n, 256)), dim3(256), 0, s, n, key, rank, start, tile_off, p.orig);
+    FY_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_bin_gather, dim3(div_up(n, 256)), dim3(256), 0, s, rec, n, p);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }
