@@ -195,6 +195,29 @@ int fy_solver_apply_p_matrix_host(fy_solver*, const double* x, double* y);
 /* time `reps` launches of the pEqn Laplacian apply (the roofline kernel) with HIP events on the solver stream; returns avg ms */
 int fy_solver_time_p_apply(fy_solver*, int reps, double* avg_ms);
 
+/* ======================================================================================================== */
+/* Multi-GPU: z-slab decomposition of the block, one slab per rank.                          */
+/* ======================================================================================================== */
+/* A communicator carries the neighbour exchanges (FV halos 1 plane, particle halos 5 planes, reverse sums), the tiny all-reduces
+ * (Krylov scalars, Courant number, continuity errors) and the all-gather of the coarse multigrid level.
+ *   fy_comm_create_rccl        one process per GPU over RCCL/xGMI; `id128` = the 128 bytes from fy_rccl_unique_id() on rank 0,
+ *                              distributed by the launcher (bench.py uses torch.distributed for that)
+ *   fy_comm_create_local_group n "virtual slabs" inside ONE process (one host thread per slab, device-to-device copies): the same
+ *                              solver code, used to test the decomposition on a single-GPU box
+ * The reference's equivalent is OpenFOAM's own domain decomposition (`-parallel`, README.md:29) [OF-6, not in the reference]. */
+typedef struct fy_comm fy_comm;
+int fy_rccl_unique_id(void* out128);
+int fy_comm_create_rccl(int rank, int size, const void* id128, int device_ordinal, fy_comm** out);
+int fy_comm_create_local_group(int n, fy_comm** out /* [n] */);
+int fy_comm_destroy(fy_comm*);
+int fy_comm_rank(fy_comm*);
+int fy_comm_size(fy_comm*);
+/* `c` describes the GLOBAL block; rank r owns z-planes [r*nz/size, (r+1)*nz/size) (nz/size must be even and >= the particle halo).
+ * Collective: every rank of the communicator must call it, and later fy_solver_step, together.  Field accessors then address the
+ * rank's OWNED cells only.  Each rank is given the particles that lie inside its own slab. */
+int fy_solver_create_slab(const fy_case_desc* c, const fy_transport* transport, int device_ordinal, fy_comm* comm, fy_solver** out);
+int fy_solver_local_cells(fy_solver*);
+
 /* per-kernel HIP-event clocks on the solver stream, accumulated over steps since the last enable(1):
  * kernel = "mg_smooth_l0" (pEqn Laplacian apply fused with the damped-Jacobi update, fine level), "p_apply_dot" (pEqn Laplacian
  * apply + p.Ap inside PCG), "mom_pass" (fused momentum Jacobi pass) */

@@ -1,0 +1,86 @@
+"""z-slab decomposition tested with N virtual slabs on ONE GPU: the solver code is the one each RCCL rank runs, only
+the communicator back-end differs (device-to-device copies between threads instead of ncclSend/ncclRecv).  A decomposed run must
+reproduce the single-domain run: bit-for-bit where no reduction order changes, to solver tolerance otherwise."""
+import numpy as np
+import pytest
+
+import golden_cases as gc
+
+pytestmark = pytest.mark.gpu
+
+
+def cavity(product, solver, n, nz, p_solver=1, **kw):
+    u_val = [(0, 0, 0)] * 6
+    u_val[3] = (1.0, 0, 0)
+    return product.make_case(solver, n, n, nz, 1.0 / n, 0.4 / n, 0.01, u_bc=[0] * 6, u_val=u_val, p_solver=p_solver, **kw)
+
+
+def compare(a, b, names, rtol):
+    for nm in names:
+        x, y = a.get(nm), b.get(nm)
+        sc = np.abs(y).max() + 1e-300
+        assert x.shape == y.shape, nm
+        assert np.abs(x - y).max() <= rtol * sc, (nm, np.abs(x - y).max() / sc)
+
+
+@pytest.mark.parametrize("solver", [0, 1])
+@pytest.mark.parametrize("n_slabs,p_solver", [(2, 0), (2, 1), (4, 1)])
+def test_fv_slabs_match_single_domain(product, solver, n_slabs, p_solver):
+    n, nz = 16, 40 if solver == 1 else 16            # pimple slabs must be at least 5 planes thick (particle halo), even
+    if solver == 1:
+        nz = 20 * (n_slabs // 2) * 2 if n_slabs > 2 else 24
+    case = cavity(product, solver, n, nz, p_solver=p_solver)
+    one = product.Solver(case)
+    many = product.VirtualSlabs(case, n_slabs)
+    rs = np.random.RandomState(5)
+    U0 = rs.rand(n * n * nz, 3) * 0.1
+    one.set("U", U0); many.set("U", U0)
+    for _ in range(4):
+        one.step(); many.step()
+        so, sm = one.stats(), many.stats()
+        for r in range(n_slabs):                     # every rank sees the same all-reduced scalars
+            assert sm[r]["p_iters_total"] == sm[0]["p_iters_total"]
+            assert sm[r]["courant_max"] == sm[0]["courant_max"]
+        assert abs(so["p_iters_total"] - sm[0]["p_iters_total"]) <= 2
+        assert np.isclose(so["courant_max"], sm[0]["courant_max"], rtol=1e-12)
+    compare(many, one, ("U", "p", "phi_x", "phi_y", "phi_z"), 5e-6)
+    many.close(); one.close()
+
+
+def test_first_step_operators_are_identical(product):
+    """before any iterative solve the decomposition must be exact: matrices and the SpMV do not depend on reduction order"""
+    n, nz = 12, 16
+    case = cavity(product, 0, n, nz, p_solver=0)
+    one = product.Solver(case); many = product.VirtualSlabs(case, 2)
+    rs = np.random.RandomState(7)
+    U0 = rs.rand(n * n * nz, 3) * 0.2
+    one.set("U", U0); many.set("U", U0)
+    one.step(); many.step()
+    for nm in ("p_diag", "p_ux", "p_uy", "p_uz", "mom_diag", "rAU"):
+        np.testing.assert_array_equal(many.get(nm), one.get(nm), err_msg=nm)
+    many.close(); one.close()
+
+
+@pytest.mark.parametrize("solver,n_slabs", [(1, 2), (1, 3), (0, 2)])
+def test_coupled_slabs_match_single_domain(product, solver, n_slabs):
+    """particles near slab interfaces: deposits/gathers reach up to 5 planes into the neighbours"""
+    n = 12
+    nz = 12 * n_slabs
+    dx = 0.1 / n
+    kw = dict(g=(0, 0, -9.81), p_bc=[2] * 6) if solver == 1 else {}
+    u_val = [(0, 0, 0)] * 6
+    if solver == 0:
+        u_val[3] = (1.0, 0, 0)
+    case = product.make_case(solver, n, n, nz, dx, 2e-4, 1e-5 if solver else 0.01, u_bc=[0] * 6, u_val=u_val, **kw)
+    one = product.Solver(case); many = product.VirtualSlabs(case, n_slabs)
+    gcase = gc.Case("s", n, n, nz, 0.1, gaussian=solver, np_=4000, seed=21, cluster=200, fast=20, vel_scale=0.05)
+    for step in range(3):
+        rec = gc.particle_records(gcase, step)
+        rec = rec[(rec[:, 2] > 0) & (rec[:, 2] < nz * dx)]          # keep the probes inside the block in z
+        one.set_particles(rec); many.set_particles(rec)
+        one.step(); many.step()
+        fo, fm = one.forces(), many.forces()
+        sc = np.abs(fo).max()
+        assert np.abs(fm - fo).max() <= 1e-6 * sc, np.abs(fm - fo).max() / sc
+    compare(many, one, ("U", "p", "alpha", "uSource") if solver else ("U", "p"), 1e-5)
+    many.close(); one.close()

@@ -145,6 +145,14 @@ def lib():
     L.fy_solver_destroy.argtypes = [vp]
     L.fy_solver_apply_p_matrix_host.argtypes = [vp, _dp, _dp]
     L.fy_solver_time_p_apply.argtypes = [vp, C.c_int, _dp]
+    L.fy_rccl_unique_id.argtypes = [C.c_void_p]
+    L.fy_comm_create_rccl.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(vp)]
+    L.fy_comm_create_local_group.argtypes = [C.c_int, C.POINTER(vp)]
+    L.fy_comm_destroy.argtypes = [vp]
+    L.fy_comm_rank.argtypes = [vp]
+    L.fy_comm_size.argtypes = [vp]
+    L.fy_solver_create_slab.argtypes = [C.POINTER(CaseDesc), C.POINTER(Transport), C.c_int, vp, C.POINTER(vp)]
+    L.fy_solver_local_cells.argtypes = [vp]
     L.fy_solver_enable_kernel_timing.argtypes = [vp, C.c_int]
     L.fy_solver_get_kernel_timing.argtypes = [vp, C.c_char_p, _dp, C.POINTER(C.c_int64)]
     _lib = L
@@ -348,12 +356,21 @@ class Solver:
     """the icoFoamYade / pimpleFoamYade executables' time loop (icoFoamYade.C:65-149, pimpleFoamYade.C:60-114): step() is one
     pass of the loop body, including yadeCoupling.setParticleAction and setSourceZero."""
 
-    def __init__(self, case: CaseDesc, transport=None, device=0):
+    def __init__(self, case: CaseDesc, transport=None, device=0, comm=None):
+        """comm: a communicator handle (c_void_p) for z-slab mode -- the case then describes the GLOBAL block and this object is
+        one rank's slab (collective construction); None = single domain"""
         self.case = case
         self._h = C.c_void_p()
         self._keep = transport
-        _check(lib().fy_solver_create(C.byref(case), C.byref(transport) if transport is not None else None, int(device), C.byref(self._h)))
-        self.n_cells = case.nx * case.ny * case.nz
+        tr = C.byref(transport) if transport is not None else None
+        if comm is None:
+            _check(lib().fy_solver_create(C.byref(case), tr, int(device), C.byref(self._h)))
+            self.n_slabs, self.rank = 1, 0
+        else:
+            _check(lib().fy_solver_create_slab(C.byref(case), tr, int(device), comm, C.byref(self._h)))
+            self.n_slabs, self.rank = lib().fy_comm_size(comm), lib().fy_comm_rank(comm)
+        self.nz_local = case.nz // self.n_slabs
+        self.n_cells = case.nx * case.ny * self.nz_local        # owned cells
         self._cpl = C.c_void_p(lib().fy_solver_coupling(self._h))
         self._batch_n = []
 
@@ -361,8 +378,8 @@ class Solver:
         c = self.case
         n = self.n_cells
         return {"U": 3 * n, "HbyA": 3 * n, "mom_src": 3 * n, "uSource": 3 * n, "uParticle": 3 * n, "gradP": 3 * n, "divT": 3 * n,
-                "vGrad": 9 * n, "phi_x": (c.nx + 1) * c.ny * c.nz, "phi_y": c.nx * (c.ny + 1) * c.nz,
-                "phi_z": c.nx * c.ny * (c.nz + 1)}.get(name, n)
+                "vGrad": 9 * n, "phi_x": (c.nx + 1) * c.ny * self.nz_local, "phi_y": c.nx * (c.ny + 1) * self.nz_local,
+                "phi_z": c.nx * c.ny * (self.nz_local + 1)}.get(name, n)
 
     def get(self, name):
         out = np.zeros(self._size(name))
@@ -444,3 +461,96 @@ class Solver:
             self.close()
         except Exception:
             pass
+
+
+def rccl_unique_id():
+    buf = (C.c_char * 128)()
+    _check(lib().fy_rccl_unique_id(buf))
+    return bytes(buf)
+
+
+def rccl_comm(rank, size, id128, device):
+    h = C.c_void_p()
+    buf = (C.c_char * 128).from_buffer_copy(id128)
+    _check(lib().fy_comm_create_rccl(int(rank), int(size), buf, int(device), C.byref(h)))
+    return h
+
+
+class VirtualSlabs:
+    """N z-slabs of one block as N Solver objects inside this process (LocalComm back-end, one thread per slab): the test double
+    of the one-process-per-GPU RCCL deployment -- identical solver code, only the communicator differs."""
+
+    def __init__(self, case: CaseDesc, n_slabs, device=0):
+        import threading
+        self._threading = threading
+        self.case, self.n = case, int(n_slabs)
+        arr = (C.c_void_p * self.n)()
+        _check(lib().fy_comm_create_local_group(self.n, arr))
+        self.comms = [C.c_void_p(arr[r]) for r in range(self.n)]
+        self.solvers = [None] * self.n
+        self._each(lambda r: self.solvers.__setitem__(r, Solver(case, device=device, comm=self.comms[r])))
+        self.nz_local = case.nz // self.n
+
+    def _each(self, fn):
+        """run fn(rank) on one thread per slab (the calls are collective and block on each other)"""
+        errs = []
+
+        def run(r):
+            try:
+                fn(r)
+            except Exception as e:          # noqa: BLE001
+                errs.append((r, e))
+        ts = [self._threading.Thread(target=run, args=(r,)) for r in range(self.n)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        if errs:
+            raise errs[0][1]
+
+    def step(self):
+        self._each(lambda r: self.solvers[r].step())
+
+    def get(self, name):
+        """global field assembled from the slabs' owned parts (cell fields and phi_z; x/y face fields concatenate likewise)"""
+        parts = [s.get(name) for s in self.solvers]
+        if name == "phi_z":      # interface planes are held by both neighbours: keep the lower slab's copy
+            pl = self.case.nx * self.case.ny
+            return np.concatenate([p[:-pl] for p in parts[:-1]] + [parts[-1]])
+        return np.concatenate(parts)
+
+    def set(self, name, arr):
+        arr = np.ascontiguousarray(arr, dtype=np.float64).ravel()
+        sizes = [s._size(name) for s in self.solvers]
+        assert name != "phi_z" and sum(sizes) == arr.size
+        offs = np.concatenate([[0], np.cumsum(sizes)])
+        self._each(lambda r: self.solvers[r].set(name, arr[offs[r]:offs[r + 1]]))
+
+    def set_particles(self, records):
+        """split the records by the slab their z lies in (every rank gets exactly the particles inside its own slab)"""
+        c = self.case
+        rec = np.zeros((0, 10)) if records is None else np.ascontiguousarray(records, dtype=np.float64).reshape(-1, 10)
+        z = (rec[:, 2] - c.origin[2]) / c.dx
+        owner = np.clip(np.floor(z / self.nz_local).astype(int), 0, self.n - 1)
+        self._owner_idx = [np.nonzero(owner == r)[0] for r in range(self.n)]
+        for r, s in enumerate(self.solvers):
+            s.set_particles(rec[self._owner_idx[r]])
+        self._n_part = rec.shape[0]
+
+    def forces(self):
+        out = np.zeros((self._n_part, 6))
+        for r, s in enumerate(self.solvers):
+            if len(self._owner_idx[r]):
+                out[self._owner_idx[r]] = s.forces()
+        return out
+
+    def stats(self):
+        return [s.stats() for s in self.solvers]
+
+    def close(self):
+        for s in self.solvers:
+            if s is not None:
+                s.close()
+        for cm in self.comms:
+            lib().fy_comm_destroy(cm)
+        self.solvers, self.comms = [], []

@@ -1,0 +1,47 @@
+// Slab communicator: what the z-slab decomposition needs from "the other GPUs" (SURVEY.md 8e):
+//   * neighbour exchange of contiguous z-plane blocks (FV halos 1 plane, particle halos 5 planes, reverse sums),
+//   * tiny all-reduces (Krylov scalars, Courant number, continuity errors, residual norms),
+//   * an all-gather (coarse multigrid right-hand sides).
+// Two back-ends behind one interface:
+//   RcclComm   one process per GPU, RCCL (ncclSend/ncclRecv/ncclAllReduce/ncclAllGather) on the solver's stream over xGMI;
+//              librccl is dlopen()ed on first use so the library still loads on hosts without it;
+//   LocalComm  N "virtual slabs" inside one process (one host thread per slab, device-to-device copies, host barriers): the
+//              same solver code runs unmodified, which is how the decomposition is tested on a single-GPU box.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+namespace fy {
+
+struct Comm {
+    int rank = 0, size = 1;
+    virtual ~Comm() {}
+    bool has_down() const { return rank > 0; }           // neighbour owning the planes below mine
+    bool has_up() const { return rank + 1 < size; }
+    // send `count` doubles starting at send_up to the upper neighbour (it receives them at ITS recv_from_down), and so on.
+    // Pointers for a missing neighbour are ignored.
+    virtual int neighbour_exchange(hipStream_t s, const double* send_up, double* recv_from_down, const double* send_down,
+                                   double* recv_from_up, size_t count) = 0;
+    virtual int allreduce(hipStream_t s, double* dev, int n, bool is_max) = 0;   // in place; identical result on every rank
+    virtual int allgather(hipStream_t s, const double* send, double* recv, size_t count_per_rank) = 0;
+    virtual int barrier(hipStream_t s) = 0;
+};
+
+struct SelfComm : Comm {                                   // size 1: every call is a no-op
+    int neighbour_exchange(hipStream_t, const double*, double*, const double*, double*, size_t) override { return 0; }
+    int allreduce(hipStream_t, double*, int, bool) override { return 0; }
+    int allgather(hipStream_t s, const double* send, double* recv, size_t n) override;
+    int barrier(hipStream_t) override { return 0; }
+};
+
+// LocalComm group: create `n` communicators that talk to each other inside this process
+int local_comm_group_create(int n, Comm** out /* [n] */);
+// RCCL: unique id = 128 opaque bytes produced on rank 0 (fy_rccl_unique_id) and broadcast by the launcher
+int rccl_unique_id(void* out128);
+int rccl_comm_create(int rank, int size, const void* id128, int device, Comm** out);
+
+}  // namespace fy
+
+struct fy_comm { fy::Comm* c; };

@@ -95,13 +95,21 @@ int Coupling::create(const fy_mesh_desc* m, const fy_field_ptrs* f, int gaussian
         }
         FY_HIP(hipStreamSynchronize(stream));
     }
-    FY_TRY(d_vol.alloc_exact(n_cells));
-    FY_HIP(hipMemcpyAsync(d_vol.p, m->volumes, (size_t)n_cells * sizeof(double), hipMemcpyHostToDevice, stream));
     v0 = m->volumes[0];
+    n_field = slab.active ? (int64_t)slab.n_store : (int64_t)n_cells;
+    FY_TRY(d_vol.alloc_exact((size_t)n_field));
+    if (slab.active) {
+        if (!structured) return fail(FY_ERR_UNSUPPORTED, "slab mode needs the structured block description");
+        FY_TRY(launch_fill_f64(stream, d_vol.p, (size_t)n_field, v0));        // uniform block
+        FY_TRY(halo_tmp.alloc_exact(2 * (size_t)slab.gz * slab.plane * 3));
+    } else {
+        FY_HIP(hipMemcpyAsync(d_vol.p, m->volumes, (size_t)n_cells * sizeof(double), hipMemcpyHostToDevice, stream));
+    }
 
     // ---- fields
     fields = *f;
     fields_on_host = (f->location == FY_MEM_HOST);
+    if (slab.active && fields_on_host) return fail(FY_ERR_UNSUPPORTED, "slab mode works on device-resident fields only");
     if (fields_on_host) {
         FY_TRY(own_U.alloc_exact(3 * (size_t)n_cells)); FY_TRY(own_gradP.alloc_exact(3 * (size_t)n_cells));
         FY_TRY(own_vGrad.alloc_exact(9 * (size_t)n_cells)); FY_TRY(own_divT.alloc_exact(3 * (size_t)n_cells));
@@ -120,10 +128,11 @@ int Coupling::create(const fy_mesh_desc* m, const fy_field_ptrs* f, int gaussian
     if (!gaussian && !dVGrad) return fail(FY_ERR_INVALID, "point-force mode needs vGrad");
 
     if (gaussian) {
-        FY_TRY(d_pvol_acc.alloc_exact(n_cells)); FY_TRY(d_up_acc.alloc_exact(3 * (size_t)n_cells)); FY_TRY(d_touched.alloc_exact(n_cells));
-        FY_HIP(hipMemsetAsync(d_pvol_acc.p, 0, (size_t)n_cells * sizeof(double), stream));
-        FY_HIP(hipMemsetAsync(d_up_acc.p, 0, 3 * (size_t)n_cells * sizeof(double), stream));
-        FY_HIP(hipMemsetAsync(d_touched.p, 0, (size_t)n_cells, stream));
+        const size_t nf = (size_t)n_field;
+        FY_TRY(d_pvol_acc.alloc_exact(nf)); FY_TRY(d_up_acc.alloc_exact(3 * nf)); FY_TRY(d_touched.alloc_exact(nf));
+        FY_HIP(hipMemsetAsync(d_pvol_acc.p, 0, nf * sizeof(double), stream));
+        FY_HIP(hipMemsetAsync(d_up_acc.p, 0, 3 * nf * sizeof(double), stream));
+        FY_HIP(hipMemsetAsync(d_touched.p, 0, nf, stream));
     }
 
     // ---- binning grid (locality only)
@@ -159,8 +168,8 @@ int Coupling::create(const fy_mesh_desc* m, const fy_field_ptrs* f, int gaussian
 
 // FoamYade::initFields FoamYade.C:56-73
 int Coupling::init_fields() {
-    FY_TRY(launch_set_source_zero(stream, n_cells, gaussian ? 1 : 0, dUSourceDrag, dAlpha, dUSource, dUParticle));
-    FY_TRY(launch_fill_f64(stream, dAlpha, n_cells, 1.0));                 // `alpha = 1.0` in both modes, FoamYade.C:68
+    FY_TRY(launch_set_source_zero(stream, (int32_t)n_field, gaussian ? 1 : 0, dUSourceDrag, dAlpha, dUSource, dUParticle));
+    FY_TRY(launch_fill_f64(stream, dAlpha, (size_t)n_field, 1.0));         // `alpha = 1.0` in both modes, FoamYade.C:68
     interp_range = 4 * std::pow(v0, 1.0 / 3.0);                            // FoamYade.C:69
     sigma_interp = interp_range * 0.42460;                                 // FoamYade.C:70
     interp_range_cu = std::pow(interp_range, 3.0);                         // FoamYade.C:71
@@ -253,7 +262,7 @@ int Coupling::set_particles_device(int bi, const double* d_rec, int64_t n) {
 
 // the device part of setParticleAction for one Yade proc (FoamYade.C:612-628 loop body)
 int Coupling::run_batch(Batch& b) {
-    if (b.n == 0) return FY_OK;
+    if (b.n == 0 && !slab.active) return FY_OK;      // (in slab mode the halo exchanges are collective: every rank walks the same path)
     ForceParams fp{rhoF, nu, 1e-09};
     if (gaussian) {
         ParticleSoA p = soa_of(b);
@@ -269,18 +278,32 @@ int Coupling::run_batch(Batch& b) {
         gp.range_cu = interp_range_cu; gp.sigma_pi = sigma_pi;
         FY_TRY(launch_locate(stream, d_tree.p, use_implicit ? d_tree_packed.p : nullptr, implicit, n_cells, tree_levels, p, b.n, gp));
         if (timing) { timers[T_LOCATE].stop(stream); timers[T_FINALIZE].start(stream); }
-        FY_TRY(launch_deposit(stream, p, b.n, gp, d_pvol_acc.p, d_up_acc.p, d_touched.p));
-        FY_TRY(launch_finalize_cells(stream, n_cells, d_vol.p, d_pvol_acc.p, d_up_acc.p, d_touched.p, dAlpha, dUParticle));
+        const CellWindow cw{slab.active ? slab.base : 0, n_field};
+        FY_TRY(launch_deposit(stream, p, b.n, gp, cw, d_pvol_acc.p, d_up_acc.p, d_touched.p));
+        if (slab.active) {      // contributions that landed in ghost planes belong to the neighbours: send them home and add
+            FY_TRY(halo_reverse_add(d_pvol_acc.p, 1, d_touched.p));
+            FY_TRY(halo_reverse_add(d_up_acc.p, 3, nullptr));
+        }
+        FY_TRY(launch_finalize_cells(stream, (int32_t)n_field, d_vol.p, d_pvol_acc.p, d_up_acc.p, d_touched.p, dAlpha, dUParticle));
+        if (slab.active) {      // the gathers below reach gz planes into the neighbours
+            FY_TRY(halo_fwd(dAlpha, 1, slab.gz));
+            FY_TRY(halo_fwd(dUParticle, 3, slab.gz));
+        }
         if (timing) { timers[T_FINALIZE].stop(stream); timers[T_FORCE].start(stream); }
-        FY_TRY(launch_force_gaussian(stream, p, b.n, fp, d_vol.p, dU, dAlpha, dUParticle, dGradP, dDivT, dUSourceDrag, dUSource,
+        FY_TRY(launch_force_gaussian(stream, p, b.n, fp, cw, d_vol.p, dU, dAlpha, dUParticle, dGradP, dDivT, dUSourceDrag, dUSource,
                                      b.force.p, b.found.p));
+        if (slab.active) {
+            FY_TRY(halo_reverse_add(dUSourceDrag, 1, nullptr));
+            FY_TRY(halo_reverse_add(dUSource, 3, nullptr));
+        }
         if (timing) timers[T_FORCE].stop(stream);
     } else {
         BlockGeom g;
         for (int a = 0; a < 3; ++a) { g.bbmin[a] = mesh.bbox_min[a]; g.bbmax[a] = mesh.bbox_max[a]; }
         g.dx = mesh.dx; g.nx = mesh.nx; g.ny = mesh.ny; g.nz = mesh.nz;
         if (timing) timers[T_FORCE].start(stream);
-        FY_TRY(launch_point_force(stream, b.d_rec, b.n, g, fp, d_vol.p, dU, dVGrad, dUSource, b.force.p, b.found.p, b.incell.p));
+        const CellWindow cw{slab.active ? slab.base : 0, n_field};
+        FY_TRY(launch_point_force(stream, b.d_rec, b.n, g, fp, cw, d_vol.p, dU, dVGrad, dUSource, b.force.p, b.found.p, b.incell.p));
         if (timing) timers[T_FORCE].stop(stream);
     }
     return FY_OK;
@@ -305,6 +328,7 @@ int Coupling::set_particle_action(double dt) {
 
     // ---- locate + deposit + finalize + force, one Yade proc after the other (FoamYade.C:612-628)
     for (int bi = 0; bi < n_batches; ++bi) FY_TRY(run_batch(*batches[bi]));
+    if (slab.active && gaussian) FY_TRY(halo_fwd(dUSource, 3, 1));       // UcEqn.H:17-20 interpolates rAUc*uSource across the interface
 
     if (fields_on_host) FY_TRY(stage_mutable_out());
 
@@ -413,11 +437,35 @@ int Coupling::exchange_dt() {
     return FY_OK;
 }
 
+// slab halos of a cell array with ncomp interleaved components: refresh w ghost planes per side from the owners
+int Coupling::halo_fwd(double* f, int ncomp, int w) {
+    const size_t P = slab.plane * (size_t)ncomp;
+    return slab.comm->neighbour_exchange(stream, f + (size_t)(slab.gz + slab.nz - w) * P, f + (size_t)(slab.gz - w) * P,
+                                         f + (size_t)slab.gz * P, f + (size_t)(slab.gz + slab.nz) * P, (size_t)w * P);
+}
+
+// ... and the reverse: what this rank accumulated in its ghost planes goes to the owners, who add it; ghost planes are then cleared
+int Coupling::halo_reverse_add(double* f, int ncomp, unsigned char* mark) {
+    const size_t P = slab.plane * (size_t)ncomp, cnt = (size_t)slab.gz * P;
+    double* gh_lo = f;
+    double* gh_hi = f + (size_t)(slab.gz + slab.nz) * P;
+    double* own_lo = f + (size_t)slab.gz * P;
+    double* own_hi = f + (size_t)slab.nz * P;                      // the last gz owned planes
+    double* tmp_a = halo_tmp.p;
+    double* tmp_b = halo_tmp.p + (size_t)slab.gz * slab.plane * 3;
+    FY_TRY(slab.comm->neighbour_exchange(stream, gh_hi, tmp_a, gh_lo, tmp_b, cnt));
+    if (slab.comm->has_down()) FY_TRY(launch_add_mark(stream, own_lo, tmp_a, cnt, mark ? mark + (size_t)slab.gz * slab.plane : nullptr));
+    if (slab.comm->has_up()) FY_TRY(launch_add_mark(stream, own_hi, tmp_b, cnt, mark ? mark + (size_t)slab.nz * slab.plane : nullptr));
+    FY_HIP(hipMemsetAsync(gh_lo, 0, cnt * sizeof(double), stream));
+    FY_HIP(hipMemsetAsync(gh_hi, 0, cnt * sizeof(double), stream));
+    return FY_OK;
+}
+
 // FoamYade::setSourceZero FoamYade.C:556-566 + clearInCommProcs FoamYade.C:568-580
 int Coupling::set_source_zero() {
     if (!created) return fail(FY_ERR_INVALID, "fy_set_source_zero before fy_create");
     FY_HIP(hipSetDevice(device));
-    FY_TRY(launch_set_source_zero(stream, n_cells, gaussian ? 1 : 0, dUSourceDrag, dAlpha, dUSource, dUParticle));
+    FY_TRY(launch_set_source_zero(stream, (int32_t)n_field, gaussian ? 1 : 0, dUSourceDrag, dAlpha, dUSource, dUParticle));
     if (fields_on_host) FY_TRY(stage_mutable_out());
     if (has_transport && !serial_yade) n_batches = 0;                       // FoamYade.C:577
     return FY_OK;
@@ -477,7 +525,7 @@ int Coupling::get_tree_preorder(int32_t* out) {
 
 int Coupling::field_by_name(const char* name, double** p, size_t* count) {
     const std::string s = name ? name : "";
-    const size_t n = (size_t)n_cells;
+    const size_t n = (size_t)n_field;
     if (s == "alpha") { *p = dAlpha; *count = n; }
     else if (s == "uSourceDrag") { *p = dUSourceDrag; *count = n; }
     else if (s == "uSource") { *p = dUSource; *count = 3 * n; }

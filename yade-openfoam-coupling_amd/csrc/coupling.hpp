@@ -4,6 +4,7 @@
 #include <string>
 #include <vector>
 
+#include "comm.hpp"
 #include "common.hpp"
 #include "kdtree.hpp"
 #include "particle_kernels.hpp"
@@ -25,7 +26,20 @@ struct Batch {
     std::vector<int32_t> h_found;
 };
 
+// z-slab mode (set by fy_solver before create()): the k-d tree spans the GLOBAL block, every cell array is this rank's slab
+// storage (owned planes + gz ghost planes per side); a global cell id maps to storage index id - base.
+struct SlabInfo {
+    bool active = false;
+    Comm* comm = nullptr;
+    int gz = 0, nz = 0;
+    size_t plane = 0, n_store = 0;
+    int64_t base = 0;
+};
+
 struct Coupling {
+    SlabInfo slab;
+    int64_t n_field = 0;                 // length of the cell arrays (n_cells, or slab.n_store)
+    DevBuf<double> halo_tmp;             // 2 x gz x plane x 3 staging for reverse-halo sums
     // ---- configuration
     int device = -1;
     hipStream_t stream = nullptr;
@@ -87,6 +101,8 @@ struct Coupling {
     int send_results();
     int exchange_dt();
     int set_source_zero();
+    int halo_fwd(double* f, int ncomp, int w);
+    int halo_reverse_add(double* f, int ncomp, unsigned char* mark);
     int get_forces_host(int bi, double* out);
     int get_found_host(int bi, int32_t* out);
     int get_stencils_host(int bi, int32_t* k, int32_t* ids, double* w, int32_t* chain);

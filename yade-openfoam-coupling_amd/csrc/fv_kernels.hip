@@ -12,12 +12,14 @@ namespace {
 constexpr double kSmall = 1e-15;     // OpenFOAM `small`
 
 // ------------------------------------------------------------------------------------------------ index helpers
-__device__ __forceinline__ void ijk_of(const FvGeo& g, int c, int& i, int& j, int& k) {
-    i = c % g.nx;
-    const int t = c / g.nx;
-    j = t % g.ny;
-    k = t / g.ny;
+// t = owned-cell number in [0, Nc): lattice coordinates (k local) and storage index c = t + c0
+__device__ __forceinline__ void ijk_of(const FvGeo& g, int t, int& i, int& j, int& k) {
+    i = t % g.nx;
+    const int q = t / g.nx;
+    j = q % g.ny;
+    k = q / g.ny;
 }
+__device__ __forceinline__ int cidx(const FvGeo& g, int i, int j, int k) { return i + g.nx * (j + g.ny * (k + g.gz)); }
 __device__ __forceinline__ int stride_of(const FvGeo& g, int d) { return d == 0 ? 1 : d == 1 ? g.nx : g.nx * g.ny; }
 __device__ __forceinline__ int ndim(const FvGeo& g, int d) { return d == 0 ? g.nx : d == 1 ? g.ny : g.nz; }
 __device__ __forceinline__ int fid(const FvGeo& g, int d, int i, int j, int k) {
@@ -26,10 +28,15 @@ __device__ __forceinline__ int fid(const FvGeo& g, int d, int i, int j, int k) {
 __device__ __forceinline__ int cface(const FvGeo& g, int d, int s, int i, int j, int k) {
     return fid(g, d, i + (d == 0 ? s : 0), j + (d == 1 ? s : 0), k + (d == 2 ? s : 0));
 }
+// is face (d, s) of owned cell (i,j,k) on a PHYSICAL boundary?  (slab interfaces in z are interior faces)
 __device__ __forceinline__ bool onb(const FvGeo& g, int d, int s, int i, int j, int k) {
-    const int q = d == 0 ? i : d == 1 ? j : k;
+    if (d == 2) { const int kg = k + g.kglob0; return s ? kg == g.nzglob - 1 : kg == 0; }
+    const int q = d == 0 ? i : j;
     return s ? q == ndim(g, d) - 1 : q == 0;
 }
+// face coordinate q along d (0..ndim): physical low / high boundary?
+__device__ __forceinline__ bool face_low_b(const FvGeo& g, int d, int q) { return d == 2 ? (q + g.kglob0 == 0) : (q == 0); }
+__device__ __forceinline__ bool face_high_b(const FvGeo& g, int d, int q) { return d == 2 ? (q + g.kglob0 == g.nzglob) : (q == ndim(g, d)); }
 __device__ __forceinline__ void Ub(const FvGeo& g, const double* F, int c, int patch, double* out) {
     if (g.u_bc[patch] == 0) { out[0] = g.u_val[patch][0]; out[1] = g.u_val[patch][1]; out[2] = g.u_val[patch][2]; }
     else { out[0] = F[3 * (size_t)c]; out[1] = F[3 * (size_t)c + 1]; out[2] = F[3 * (size_t)c + 2]; }
@@ -101,7 +108,7 @@ __global__ __launch_bounds__(256) void k_reduce_finalize(const double* __restric
 inline int red_grid(size_t) { return kRedBlocks; }
 
 // ------------------------------------------------------------------------------------------------ face kernels
-// generic face iteration: thread -> (d fixed per launch, face index f) -> (i,j,k) of the face
+// generic face iteration: thread -> (d fixed per launch, face index f) -> local (i,j,k) of the face
 __device__ __forceinline__ bool face_ijk(const FvGeo& g, int d, size_t f, int& i, int& j, int& k) {
     const int ex = g.nx + (d == 0), ey = g.ny + (d == 1), ez = g.nz + (d == 2);
     if (f >= (size_t)ex * ey * ez) return false;
@@ -116,9 +123,9 @@ __device__ __forceinline__ bool face_ijk(const FvGeo& g, int d, size_t f, int& i
 __device__ __forceinline__ double face_flux_vec(const FvGeo& g, const double* F, int d, int i, int j, int k) {
     const int q = d == 0 ? i : d == 1 ? j : k;
     double v;
-    if (q == 0) { double b[3]; Ub(g, F, i + g.nx * (j + g.ny * k), 2 * d, b); v = b[d]; }
-    else if (q == ndim(g, d)) { double b[3]; const int c = (i - (d == 0)) + g.nx * ((j - (d == 1)) + g.ny * (k - (d == 2))); Ub(g, F, c, 2 * d + 1, b); v = b[d]; }
-    else { const int c = i + g.nx * (j + g.ny * k); v = 0.5 * (F[3 * (size_t)(c - stride_of(g, d)) + d] + F[3 * (size_t)c + d]); }
+    if (face_low_b(g, d, q)) { double b[3]; Ub(g, F, cidx(g, i, j, k), 2 * d, b); v = b[d]; }
+    else if (face_high_b(g, d, q)) { double b[3]; Ub(g, F, cidx(g, i - (d == 0), j - (d == 1), k - (d == 2)), 2 * d + 1, b); v = b[d]; }
+    else { const int c = cidx(g, i, j, k); v = 0.5 * (F[3 * (size_t)(c - stride_of(g, d)) + d] + F[3 * (size_t)c + d]); }
     return v * g.Af;
 }
 
@@ -136,8 +143,8 @@ __global__ __launch_bounds__(256) void k_interp_alpha(FvGeo g, const double* __r
     int i, j, k;
     if (!face_ijk(g, D, f, i, j, k)) return;
     const int q = D == 0 ? i : D == 1 ? j : k;
-    if (q == 0 || q == ndim(g, D)) af[f] = 1.0;     // calculated patch, value 1 (`alpha = 1.0`, FoamYade.C:68)
-    else { const int c = i + g.nx * (j + g.ny * k); af[f] = 0.5 * (alpha[c - stride_of(g, D)] + alpha[c]); }
+    if (face_low_b(g, D, q) || face_high_b(g, D, q)) af[f] = 1.0;     // calculated patch, value 1 (`alpha = 1.0`, FoamYade.C:68)
+    else { const int c = cidx(g, i, j, k); af[f] = 0.5 * (alpha[c - stride_of(g, D)] + alpha[c]); }
 }
 
 template <int D>
@@ -146,9 +153,9 @@ __global__ __launch_bounds__(256) void k_interp_rAU(FvGeo g, const double* __res
     int i, j, k;
     if (!face_ijk(g, D, f, i, j, k)) return;
     const int q = D == 0 ? i : D == 1 ? j : k;
-    if (q == 0) rf[f] = rAU[i + g.nx * (j + g.ny * k)];
-    else if (q == ndim(g, D)) rf[f] = rAU[(i - (D == 0)) + g.nx * ((j - (D == 1)) + g.ny * (k - (D == 2)))];
-    else { const int c = i + g.nx * (j + g.ny * k); rf[f] = 0.5 * (rAU[c - stride_of(g, D)] + rAU[c]); }
+    if (face_low_b(g, D, q)) rf[f] = rAU[cidx(g, i, j, k)];
+    else if (face_high_b(g, D, q)) rf[f] = rAU[cidx(g, i - (D == 0), j - (D == 1), k - (D == 2))];
+    else { const int c = cidx(g, i, j, k); rf[f] = 0.5 * (rAU[c - stride_of(g, D)] + rAU[c]); }
 }
 
 // phicForces = fvc::flux(rAUc*uSource) + rAUcf*(g & Sf)   UcEqn.H:17-20 (uSource's calculated boundary value is 0)
@@ -160,8 +167,8 @@ __global__ __launch_bounds__(256) void k_phi_forces(FvGeo g, const double* __res
     if (!face_ijk(g, D, f, i, j, k)) return;
     const int q = D == 0 ? i : D == 1 ? j : k;
     double fl = 0.0;
-    if (q != 0 && q != ndim(g, D)) {
-        const int c = i + g.nx * (j + g.ny * k), cm = c - stride_of(g, D);
+    if (!face_low_b(g, D, q) && !face_high_b(g, D, q)) {
+        const int c = cidx(g, i, j, k), cm = c - stride_of(g, D);
         fl = 0.5 * (rAU[cm] * uSource[3 * (size_t)cm + D] + rAU[c] * uSource[3 * (size_t)c + D]) * g.Af;
     }
     out[f] = fl + rAUf[f] * (g.g[D] * g.Af);
@@ -182,10 +189,10 @@ __global__ __launch_bounds__(256) void k_phiHbyA(FvGeo g, const double* __restri
     double uf;
     bool fixes = false;
     int bpatch = -1, bc = -1;
-    if (q == 0) { bpatch = 2 * D; bc = i + g.nx * (j + g.ny * k); }
-    else if (q == ndim(g, D)) { bpatch = 2 * D + 1; bc = (i - (D == 0)) + g.nx * ((j - (D == 1)) + g.ny * (k - (D == 2))); }
+    if (face_low_b(g, D, q)) { bpatch = 2 * D; bc = cidx(g, i, j, k); }
+    else if (face_high_b(g, D, q)) { bpatch = 2 * D + 1; bc = cidx(g, i - (D == 0), j - (D == 1), k - (D == 2)); }
     if (bpatch >= 0) { fixes = g.u_bc[bpatch] == 0; double b[3]; Ub(g, Uold, bc, bpatch, b); uf = b[D] * g.Af; }
-    else { const int c = i + g.nx * (j + g.ny * k); uf = 0.5 * (Uold[3 * (size_t)(c - stride_of(g, D)) + D] + Uold[3 * (size_t)c + D]) * g.Af; }
+    else { const int c = cidx(g, i, j, k); uf = 0.5 * (Uold[3 * (size_t)(c - stride_of(g, D)) + D] + Uold[3 * (size_t)c + D]) * g.Af; }
     const double po = phiOld[f];
     const double phiCorr = po - uf;
     const double coef = fixes ? 0.0 : 1.0 - fmin(fabs(phiCorr) / (fabs(po) + kSmall), 1.0);
@@ -211,13 +218,14 @@ __global__ __launch_bounds__(256) void k_flux_correct(FvGeo g, const double* __r
     const int q = D == 0 ? i : D == 1 ? j : k;
     const double af = g.pimple ? alphaf[f] : 1.0;
     double fl = 0.0;
-    if (q == 0 || q == ndim(g, D)) {
-        const int s = q == 0 ? 0 : 1, patch = 2 * D + s;
-        const int c = (i - (D == 0 && s)) + g.nx * ((j - (D == 1 && s)) + g.ny * (k - (D == 2 && s)));
+    const bool lo = face_low_b(g, D, q), hi = face_high_b(g, D, q);
+    if (lo || hi) {
+        const int s = lo ? 0 : 1, patch = 2 * D + s;
+        const int c = cidx(g, i - (D == 0 && s), j - (D == 1 && s), k - (D == 2 && s));
         if (g.p_bc[patch] == 1) { const double gb = 2.0 * af * rAUf[f] * g.dx; fl = s ? gb * (g.p_val[patch] - p[c]) : gb * (p[c] - g.p_val[patch]); }
         else if (g.p_bc[patch] == 2) fl = af * rAUf[f] * g.Af * psn[f];
     } else {
-        const int c = i + g.nx * (j + g.ny * k);
+        const int c = cidx(g, i, j, k);
         fl = af * rAUf[f] * g.dx * (p[c] - p[c - stride_of(g, D)]);
     }
     pflux[f] = fl;
@@ -228,8 +236,8 @@ __global__ __launch_bounds__(256) void k_flux_correct(FvGeo g, const double* __r
 // CourantNo.H:32-49: sumPhi = fvc::surfaceSum(mag(phi)); slots: 0 = max(sumPhi/V), 1 = sum(sumPhi)
 __global__ __launch_bounds__(256) void k_courant(FvGeo g, CFace3 phi, double* __restrict__ partials) {
     double v[2] = {0.0, 0.0};
-    for (int c = blockIdx.x * 256 + threadIdx.x; c < g.Nc; c += gridDim.x * 256) {
-        int i, j, k; ijk_of(g, c, i, j, k);
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < g.Nc; t += gridDim.x * 256) {
+        int i, j, k; ijk_of(g, t, i, j, k);
         double s = 0.0;
 #pragma unroll
         for (int d = 0; d < 3; ++d)
@@ -247,9 +255,10 @@ __global__ __launch_bounds__(256) void k_courant(FvGeo g, CFace3 phi, double* __
 __global__ __launch_bounds__(256) void k_pre_coupling(FvGeo g, const double* __restrict__ U, const double* __restrict__ p,
                                                       const double* __restrict__ alpha, CFace3 psn, double* __restrict__ vGrad,
                                                       double* __restrict__ gradP, double* __restrict__ divT) {
-    const int c = swz_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
-    if (c >= g.Nc) return;
-    int i, j, k; ijk_of(g, c, i, j, k);
+    const int t = swz_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
+    if (t >= g.Nc) return;
+    int i, j, k; ijk_of(g, t, i, j, k);
+    const int c = t + g.c0;
     const double uc[3] = {U[3 * (size_t)c], U[3 * (size_t)c + 1], U[3 * (size_t)c + 2]};
     double lap[3] = {0, 0, 0};
 #pragma unroll
@@ -283,21 +292,23 @@ __global__ __launch_bounds__(256) void k_pre_coupling(FvGeo g, const double* __r
 
 // explicit part of divDevRhoReff (laminar Stokes): G = alpha nu dev2(T(grad U))
 __global__ __launch_bounds__(256) void k_stress_G(FvGeo g, const double* __restrict__ vGrad, const double* __restrict__ alpha, double* __restrict__ G) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= g.Nc) return;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= g.Nc) return;
+    const int c = t + g.c0;
     const double* T = vGrad + 9 * (size_t)c;
-    double t[9];
-    for (int q = 0; q < 9; ++q) t[q] = T[q];
-    const double tr = t[0] + t[4] + t[8];
+    double tt[9];
+    for (int q = 0; q < 9; ++q) tt[q] = T[q];
+    const double tr = tt[0] + tt[4] + tt[8];
     const double an = alpha[c] * g.nu;
     for (int a = 0; a < 3; ++a)
-        for (int b = 0; b < 3; ++b) G[9 * (size_t)c + 3 * a + b] = an * (t[3 * b + a] - (a == b ? (2.0 / 3.0) * tr : 0.0));
+        for (int b = 0; b < 3; ++b) G[9 * (size_t)c + 3 * a + b] = an * (tt[3 * b + a] - (a == b ? (2.0 / 3.0) * tr : 0.0));
 }
 
 __global__ __launch_bounds__(256) void k_div_G(FvGeo g, const double* __restrict__ G, double* __restrict__ divG) {
-    const int c = swz_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
-    if (c >= g.Nc) return;
-    int i, j, k; ijk_of(g, c, i, j, k);
+    const int t = swz_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
+    if (t >= g.Nc) return;
+    int i, j, k; ijk_of(g, t, i, j, k);
+    const int c = t + g.c0;
     double acc[3] = {0, 0, 0};
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
@@ -317,9 +328,10 @@ __global__ __launch_bounds__(256) void k_assemble_momentum(FvGeo g, const double
                                                            const double* __restrict__ alpha, const double* __restrict__ alphaOld, CFace3 alphaf,
                                                            CFace3 phi, const double* __restrict__ uSource, const double* __restrict__ uSourceDrag,
                                                            const double* __restrict__ divG, Mom7 M, double* __restrict__ src, double* __restrict__ rAU) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= g.Nc) return;
-    int i, j, k; ijk_of(g, c, i, j, k);
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= g.Nc) return;
+    int i, j, k; ijk_of(g, t, i, j, k);
+    const int c = t + g.c0;
     const double nu = g.nu, dt = g.dt, V = g.V;
     const bool pim = g.pimple != 0;
     const double aP = pim ? alpha[c] : 1.0, aP0 = pim ? alphaOld[c] : 1.0;
@@ -374,9 +386,10 @@ __global__ __launch_bounds__(256) void k_assemble_momentum(FvGeo g, const double
 //                                pimple src + V reconstruct(phicForces/rAUcf - snGrad(p) magSf)   (UcEqn.H:22-33)
 __global__ __launch_bounds__(256) void k_bmom(FvGeo g, const double* __restrict__ src, const double* __restrict__ p, CFace3 psn,
                                               CFace3 phiForces, CFace3 rAUf, double* __restrict__ bmom) {
-    const int c = swz_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
-    if (c >= g.Nc) return;
-    int i, j, k; ijk_of(g, c, i, j, k);
+    const int t = swz_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
+    if (t >= g.Nc) return;
+    int i, j, k; ijk_of(g, t, i, j, k);
+    const int c = t + g.c0;
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
         if (!g.pimple) {
@@ -408,8 +421,9 @@ __global__ __launch_bounds__(256) void k_mom_pass(FvGeo g, Mom7 M, const double*
                                                   double* __restrict__ xn, const double* __restrict__ xbar, double* __restrict__ partials) {
     double v[6] = {0, 0, 0, 0, 0, 0};
     const double xb[3] = {xbar[0], xbar[1], xbar[2]};
-    for (int c = blockIdx.x * 256 + threadIdx.x; c < g.Nc; c += gridDim.x * 256) {
-        int i, j, k; ijk_of(g, c, i, j, k);
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < g.Nc; t += gridDim.x * 256) {
+        int i, j, k; ijk_of(g, t, i, j, k);
+        const int c = t + g.c0;
         const double dg = M.diag[c];
         double off[3] = {0, 0, 0}, rowsum = dg;
 #pragma unroll
@@ -435,6 +449,7 @@ __global__ __launch_bounds__(256) void k_mom_pass(FvGeo g, Mom7 M, const double*
     block_reduce_store<6>(v, mx, partials);
 }
 
+// component sums over a contiguous range of n vectors starting at x
 __global__ __launch_bounds__(256) void k_sum3(const double* __restrict__ x, int n, double* __restrict__ partials) {
     double v[3] = {0, 0, 0};
     for (int c = blockIdx.x * 256 + threadIdx.x; c < n; c += gridDim.x * 256)
@@ -446,9 +461,10 @@ __global__ __launch_bounds__(256) void k_sum3(const double* __restrict__ x, int 
 // HbyA = rAU * UEqn.H() (icoFoamYade.C:100, pEqn.H:2)
 __global__ __launch_bounds__(256) void k_HbyA(FvGeo g, Mom7 M, const double* __restrict__ src, const double* __restrict__ U,
                                               const double* __restrict__ rAU, double* __restrict__ HbyA) {
-    const int c = swz_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
-    if (c >= g.Nc) return;
-    int i, j, k; ijk_of(g, c, i, j, k);
+    const int t = swz_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
+    if (t >= g.Nc) return;
+    int i, j, k; ijk_of(g, t, i, j, k);
+    const int c = t + g.c0;
     double acc[3] = {src[3 * (size_t)c], src[3 * (size_t)c + 1], src[3 * (size_t)c + 2]};
 #pragma unroll
     for (int d = 0; d < 3; ++d)
@@ -467,9 +483,10 @@ __global__ __launch_bounds__(256) void k_HbyA(FvGeo g, Mom7 M, const double* __r
 __global__ __launch_bounds__(256) void k_assemble_pressure(FvGeo g, CFace3 phiHbyA, CFace3 rAUf, CFace3 alphaf, CFace3 psn,
                                                            const double* __restrict__ alpha, const double* __restrict__ alphaOld, PMat A,
                                                            double* __restrict__ rhs) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= g.Nc) return;
-    int i, j, k; ijk_of(g, c, i, j, k);
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= g.Nc) return;
+    int i, j, k; ijk_of(g, t, i, j, k);
+    const int c = t + g.c0;
     double dg = 0.0, r = 0.0, up[3] = {0, 0, 0};
 #pragma unroll
     for (int d = 0; d < 3; ++d)
@@ -492,17 +509,27 @@ __global__ __launch_bounds__(256) void k_assemble_pressure(FvGeo g, CFace3 phiHb
             }
         }
     if (g.pimple) r -= g.V * (alpha[c] - alphaOld[c]) / g.dt;
-    if (g.need_ref && c == g.p_ref_cell) { r += dg * g.p_ref_value; dg += dg; }      // fvMatrix::setReference
+    // fvMatrix::setReference: p_ref_cell is a GLOBAL cell number (i + nx*(j + ny*kglob))
+    if (g.need_ref && (i + g.nx * (j + g.ny * (k + g.kglob0))) == g.p_ref_cell) { r += dg * g.p_ref_value; dg += dg; }
     A.diag[c] = dg; A.ux[c] = up[0]; A.uy[c] = up[1]; A.uz[c] = up[2];
     rhs[c] = r;
+}
+
+// slab interface below the first owned plane: its z-face coefficient goes to the ghost cell under it (read by p_row as uz[c - sz])
+__global__ __launch_bounds__(256) void k_p_ghost_uz(FvGeo g, CFace3 rAUf, CFace3 alphaf, PMat A) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= g.nx * g.ny) return;
+    const double af = g.pimple ? alphaf.a[2][t] : 1.0;           // z-face plane kf = 0
+    A.uz[g.c0 - g.nx * g.ny + t] = af * rAUf.a[2][t] * g.dx;
 }
 
 // continuityErrs.H:32-46: contErr = [ddt(alpha) +] div([alphaf] phi); slots 0 = sum |contErr| V, 1 = sum contErr V
 __global__ __launch_bounds__(256) void k_cont_err(FvGeo g, CFace3 phi, CFace3 alphaf, const double* __restrict__ alpha,
                                                   const double* __restrict__ alphaOld, double* __restrict__ partials) {
     double v[2] = {0, 0};
-    for (int c = blockIdx.x * 256 + threadIdx.x; c < g.Nc; c += gridDim.x * 256) {
-        int i, j, k; ijk_of(g, c, i, j, k);
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < g.Nc; t += gridDim.x * 256) {
+        int i, j, k; ijk_of(g, t, i, j, k);
+        const int c = t + g.c0;
         double dv = 0;
 #pragma unroll
         for (int d = 0; d < 3; ++d)
@@ -522,9 +549,10 @@ __global__ __launch_bounds__(256) void k_cont_err(FvGeo g, CFace3 phi, CFace3 al
 __global__ __launch_bounds__(256) void k_U_correct(FvGeo g, const double* __restrict__ HbyA, const double* __restrict__ rAU,
                                                    const double* __restrict__ p, CFace3 psn, CFace3 phiForces, CFace3 pflux, CFace3 alphaf,
                                                    CFace3 rAUf, double* __restrict__ U) {
-    const int c = swz_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
-    if (c >= g.Nc) return;
-    int i, j, k; ijk_of(g, c, i, j, k);
+    const int t = swz_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
+    if (t >= g.Nc) return;
+    int i, j, k; ijk_of(g, t, i, j, k);
+    const int c = t + g.c0;
     const double r = rAU[c];
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
@@ -549,28 +577,42 @@ __global__ __launch_bounds__(256) void k_U_correct(FvGeo g, const double* __rest
 // y = A x.  The pEqn Laplacian apply: 48 algorithmic bytes per cell (diag 8 + ux,uy,uz 24 + x 8 + y 8); the low-side
 // coefficients ux[c-1], uy[c-nx], uz[c-nx*ny] and the six neighbour x values are re-reads served by L1/L2.
 // High-side boundary faces store 0, so the wrapped low-side reads (e.g. ux[c-1] at i = 0) multiply by 0 and only the
-// array ends need an index guard.
+// array ends need an index guard.  c is a STORAGE index; with ghost planes the z-neighbours always exist (their coefficient
+// is 0 on a physical boundary, the interface coefficient otherwise) and the ghost x values come from the halo exchange.
 __device__ __forceinline__ double p_row(const PMat& A, const double* __restrict__ x, int c) {
     const int sy = A.nx, sz = A.nx * A.ny;
     double a = A.diag[c] * x[c];
     if (c >= 1) a -= A.ux[c - 1] * x[c - 1];
-    if (c + 1 < A.N) a -= A.ux[c] * x[c + 1];
+    if (c + 1 < A.ntot) a -= A.ux[c] * x[c + 1];
     if (c >= sy) a -= A.uy[c - sy] * x[c - sy];
-    if (c + sy < A.N) a -= A.uy[c] * x[c + sy];
+    if (c + sy < A.ntot) a -= A.uy[c] * x[c + sy];
     if (c >= sz) a -= A.uz[c - sz] * x[c - sz];
-    if (c + sz < A.N) a -= A.uz[c] * x[c + sz];
+    if (c + sz < A.ntot) a -= A.uz[c] * x[c + sz];
     return a;
+}
+__device__ __forceinline__ double p_rowsum(const PMat& A, int c) {
+    const int sy = A.nx, sz = A.nx * A.ny;
+    double rs = A.diag[c];
+    if (c >= 1) rs -= A.ux[c - 1];
+    if (c + 1 < A.ntot) rs -= A.ux[c];
+    if (c >= sy) rs -= A.uy[c - sy];
+    if (c + sy < A.ntot) rs -= A.uy[c];
+    if (c >= sz) rs -= A.uz[c - sz];
+    if (c + sz < A.ntot) rs -= A.uz[c];
+    return rs;
 }
 
 __global__ __launch_bounds__(256) void k_p_apply(PMat A, const double* __restrict__ x, double* __restrict__ y) {
-    const int c = swz_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
-    if (c >= A.N) return;
+    const int t = swz_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
+    if (t >= A.N) return;
+    const int c = t + A.c0;
     y[c] = p_row(A, x, c);
 }
 
 __global__ __launch_bounds__(256) void k_p_apply_dot(PMat A, const double* __restrict__ x, double* __restrict__ y, double* __restrict__ partials) {
     double v[1] = {0};
-    for (int c = blockIdx.x * 256 + threadIdx.x; c < A.N; c += gridDim.x * 256) {
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < A.N; t += gridDim.x * 256) {
+        const int c = t + A.c0;
         const double a = p_row(A, x, c);
         y[c] = a;
         v[0] += a * x[c];
@@ -580,20 +622,14 @@ __global__ __launch_bounds__(256) void k_p_apply_dot(PMat A, const double* __res
 }
 
 // r = b - A x ; slot 0 = sum|r| ; slot 1 = sum(|A x - A xbar| + |b - A xbar|)   (lduMatrix::solver::normFactor)
-__global__ __launch_bounds__(256) void k_p_init(PMat A, const double* __restrict__ b, const double* __restrict__ x, double xbar,
-                                                double* __restrict__ r, double* __restrict__ partials) {
+__global__ __launch_bounds__(256) void k_p_init(PMat A, const double* __restrict__ b, const double* __restrict__ x, const double* __restrict__ xbar_dev,
+                                                double inv_n, double* __restrict__ r, double* __restrict__ partials) {
     double v[2] = {0, 0};
-    const int sy = A.nx, sz = A.nx * A.ny;
-    for (int c = blockIdx.x * 256 + threadIdx.x; c < A.N; c += gridDim.x * 256) {
+    const double xbar = xbar_dev[0] * inv_n;
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < A.N; t += gridDim.x * 256) {
+        const int c = t + A.c0;
         const double Ax = p_row(A, x, c);
-        double rs = A.diag[c];
-        if (c >= 1) rs -= A.ux[c - 1];
-        if (c + 1 < A.N) rs -= A.ux[c];
-        if (c >= sy) rs -= A.uy[c - sy];
-        if (c + sy < A.N) rs -= A.uy[c];
-        if (c >= sz) rs -= A.uz[c - sz];
-        if (c + sz < A.N) rs -= A.uz[c];
-        const double Aref = rs * xbar;
+        const double Aref = p_rowsum(A, c) * xbar;
         const double rr = b[c] - Ax;
         r[c] = rr;
         v[0] += fabs(rr);
@@ -603,26 +639,29 @@ __global__ __launch_bounds__(256) void k_p_init(PMat A, const double* __restrict
     block_reduce_store<2>(v, mx, partials);
 }
 
-__global__ __launch_bounds__(256) void k_dot(int n, const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ partials) {
+// dot product / plain sum over the owned range [c0, c0 + n) of arrays given by their storage base
+__global__ __launch_bounds__(256) void k_dot(int n, int c0, const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ partials) {
     double v[1] = {0};
-    for (int c = blockIdx.x * 256 + threadIdx.x; c < n; c += gridDim.x * 256) v[0] += a[c] * b[c];
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < n; t += gridDim.x * 256) v[0] += a[t + c0] * (b ? b[t + c0] : 1.0);
     const int mx[1] = {0};
     block_reduce_store<1>(v, mx, partials);
 }
 
 // sc[0] = wArA, sc[1] = wArAold, sc[2] = wApA
-__global__ __launch_bounds__(256) void k_pcg_update_p(int n, const double* __restrict__ z, double* __restrict__ p, const double* __restrict__ sc, int first) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= n) return;
+__global__ __launch_bounds__(256) void k_pcg_update_p(int n, int c0, const double* __restrict__ z, double* __restrict__ p, const double* __restrict__ sc, int first) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    const int c = t + c0;
     if (first) p[c] = z[c];
     else { const double beta = sc[0] / sc[1]; p[c] = z[c] + beta * p[c]; }
 }
 
-__global__ __launch_bounds__(256) void k_pcg_update_xr(int n, double* __restrict__ x, double* __restrict__ r, const double* __restrict__ p,
+__global__ __launch_bounds__(256) void k_pcg_update_xr(int n, int c0, double* __restrict__ x, double* __restrict__ r, const double* __restrict__ p,
                                                        const double* __restrict__ w, const double* __restrict__ sc, double* __restrict__ partials) {
     double v[1] = {0};
     const double al = sc[0] / sc[2];
-    for (int c = blockIdx.x * 256 + threadIdx.x; c < n; c += gridDim.x * 256) {
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < n; t += gridDim.x * 256) {
+        const int c = t + c0;
         x[c] += al * p[c];
         const double rr = r[c] - al * w[c];
         r[c] = rr;
@@ -633,15 +672,16 @@ __global__ __launch_bounds__(256) void k_pcg_update_xr(int n, double* __restrict
 }
 
 __global__ __launch_bounds__(256) void k_jacobi_precond(PMat A, const double* __restrict__ r, double* __restrict__ z) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c < A.N) z[c] = r[c] / A.diag[c];
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < A.N) { const int c = t + A.c0; z[c] = r[c] / A.diag[c]; }
 }
 
-// A_coarse = 1/2 P^T A P, piecewise-constant P over 2x2x2 aggregates (gather form: one thread per coarse cell)
+// A_coarse = 1/2 P^T A P, piecewise-constant P over 2x2x2 aggregates (gather form: one thread per owned coarse cell).
+// The z-face above the top owned fine plane is a slab interface (or a physical boundary with coefficient 0): always "crossing".
 __global__ __launch_bounds__(256) void k_mg_coarsen(PMat F, PMat C) {
-    const int cc = blockIdx.x * 256 + threadIdx.x;
-    if (cc >= C.N) return;
-    const int I = cc % C.nx, t = cc / C.nx, J = t % C.ny, K = t / C.ny;
+    const int tc = blockIdx.x * 256 + threadIdx.x;
+    if (tc >= C.N) return;
+    const int I = tc % C.nx, q = tc / C.nx, J = q % C.ny, K = q / C.ny;
     double dg = 0, ux = 0, uy = 0, uz = 0;
     for (int dk = 0; dk < 2; ++dk) {
         const int k = 2 * K + dk; if (k >= F.nz) break;
@@ -649,33 +689,51 @@ __global__ __launch_bounds__(256) void k_mg_coarsen(PMat F, PMat C) {
             const int j = 2 * J + dj; if (j >= F.ny) break;
             for (int di = 0; di < 2; ++di) {
                 const int i = 2 * I + di; if (i >= F.nx) break;
-                const int c = i + F.nx * (j + F.ny * k);
+                const int c = F.c0 + i + F.nx * (j + F.ny * k);
                 dg += 0.5 * F.diag[c];
-                if (i < F.nx - 1) { if (di == 0) dg -= F.ux[c]; else ux += 0.5 * F.ux[c]; }
-                if (j < F.ny - 1) { if (dj == 0) dg -= F.uy[c]; else uy += 0.5 * F.uy[c]; }
-                if (k < F.nz - 1) { if (dk == 0) dg -= F.uz[c]; else uz += 0.5 * F.uz[c]; }
+                if (di == 0 && i + 1 < F.nx) dg -= F.ux[c]; else ux += 0.5 * F.ux[c];
+                if (dj == 0 && j + 1 < F.ny) dg -= F.uy[c]; else uy += 0.5 * F.uy[c];
+                if (dk == 0 && k + 1 < F.nz) dg -= F.uz[c]; else uz += 0.5 * F.uz[c];
             }
         }
     }
+    const int cc = tc + C.c0;
     C.diag[cc] = dg; C.ux[cc] = ux; C.uy[cc] = uy; C.uz[cc] = uz;
 }
 
+// coarse ghost plane under the first owned coarse plane: uz = 1/2 sum of the fine ghost-plane uz of its 2x2 footprint
+__global__ __launch_bounds__(256) void k_mg_coarsen_ghost(PMat F, PMat C) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= C.nx * C.ny) return;
+    const int I = t % C.nx, J = t / C.nx;
+    double uz = 0;
+    for (int dj = 0; dj < 2; ++dj) {
+        const int j = 2 * J + dj; if (j >= F.ny) break;
+        for (int di = 0; di < 2; ++di) {
+            const int i = 2 * I + di; if (i >= F.nx) break;
+            uz += 0.5 * F.uz[F.c0 - F.nx * F.ny + i + F.nx * j];
+        }
+    }
+    C.uz[C.c0 - C.nx * C.ny + t] = uz;
+}
+
 __global__ __launch_bounds__(256) void k_mg_smooth_first(PMat A, const double* __restrict__ b, double* __restrict__ x, double w) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c < A.N) x[c] = w * b[c] / A.diag[c];
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < A.N) { const int c = t + A.c0; x[c] = w * b[c] / A.diag[c]; }
 }
 
 __global__ __launch_bounds__(256) void k_mg_smooth(PMat A, const double* __restrict__ b, const double* __restrict__ x, double* __restrict__ xn, double w) {
-    const int c = swz_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
-    if (c >= A.N) return;
+    const int t = swz_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
+    if (t >= A.N) return;
+    const int c = t + A.c0;
     xn[c] = x[c] + w * (b[c] - p_row(A, x, c)) / A.diag[c];
 }
 
 __global__ __launch_bounds__(256) void k_mg_residual_restrict(PMat A, const double* __restrict__ b, const double* __restrict__ x, PMat C,
                                                               double* __restrict__ bc) {
-    const int cc = blockIdx.x * 256 + threadIdx.x;
-    if (cc >= C.N) return;
-    const int I = cc % C.nx, t = cc / C.nx, J = t % C.ny, K = t / C.ny;
+    const int tc = blockIdx.x * 256 + threadIdx.x;
+    if (tc >= C.N) return;
+    const int I = tc % C.nx, q = tc / C.nx, J = q % C.ny, K = q / C.ny;
     double acc = 0;
     for (int dk = 0; dk < 2; ++dk) {
         const int k = 2 * K + dk; if (k >= A.nz) break;
@@ -683,22 +741,22 @@ __global__ __launch_bounds__(256) void k_mg_residual_restrict(PMat A, const doub
             const int j = 2 * J + dj; if (j >= A.ny) break;
             for (int di = 0; di < 2; ++di) {
                 const int i = 2 * I + di; if (i >= A.nx) break;
-                const int c = i + A.nx * (j + A.ny * k);
+                const int c = A.c0 + i + A.nx * (j + A.ny * k);
                 acc += b[c] - p_row(A, x, c);
             }
         }
     }
-    bc[cc] = acc;
+    bc[tc + C.c0] = acc;
 }
 
 __global__ __launch_bounds__(256) void k_mg_prolong_add(PMat A, double* __restrict__ x, PMat C, const double* __restrict__ xc) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= A.N) return;
-    const int i = c % A.nx, t = c / A.nx, j = t % A.ny, k = t / A.ny;
-    x[c] += xc[(i >> 1) + C.nx * ((j >> 1) + C.ny * (k >> 1))];
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= A.N) return;
+    const int i = t % A.nx, q = t / A.nx, j = q % A.ny, k = q / A.ny;
+    x[t + A.c0] += xc[C.c0 + (i >> 1) + C.nx * ((j >> 1) + C.ny * (k >> 1))];
 }
 
-// coarsest level (N <= 1024): all sweeps inside one workgroup
+// coarsest level (N <= 1024, never distributed: c0 = 0): all sweeps inside one workgroup
 __global__ __launch_bounds__(1024) void k_mg_coarse_solve(PMat A, const double* __restrict__ b, double* __restrict__ x, double* __restrict__ tmp,
                                                           int sweeps, double w) {
     const int c = threadIdx.x;
@@ -718,6 +776,11 @@ __global__ __launch_bounds__(1024) void k_mg_coarse_solve(PMat A, const double* 
 __global__ __launch_bounds__(256) void k_copy(double* __restrict__ dst, const double* __restrict__ src, size_t n) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) dst[i] = src[i];
+}
+
+__global__ __launch_bounds__(256) void k_add(double* __restrict__ y, const double* __restrict__ x, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) y[i] += x[i];
 }
 
 #define FY_LAUNCH_CHECK()                                                                                     \
@@ -875,26 +938,26 @@ int launch_p_apply_dot(hipStream_t s, PMat A, const double* x, double* y, double
     return FY_OK;
 }
 
-int launch_p_init(hipStream_t s, PMat A, const double* b, const double* x, double xbar, double* r, double* partials) {
-    hipLaunchKernelGGL(k_p_init, dim3(g_last_red_blocks), dim3(256), 0, s, A, b, x, xbar, r, partials);
+int launch_p_init(hipStream_t s, PMat A, const double* b, const double* x, const double* xsum_dev, double inv_n, double* r, double* partials) {
+    hipLaunchKernelGGL(k_p_init, dim3(g_last_red_blocks), dim3(256), 0, s, A, b, x, xsum_dev, inv_n, r, partials);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }
 
-int launch_dot(hipStream_t s, int n, const double* a, const double* b, double* partials) {
-    hipLaunchKernelGGL(k_dot, dim3(g_last_red_blocks), dim3(256), 0, s, n, a, b, partials);
+int launch_dot(hipStream_t s, int n, int c0, const double* a, const double* b, double* partials) {
+    hipLaunchKernelGGL(k_dot, dim3(g_last_red_blocks), dim3(256), 0, s, n, c0, a, b, partials);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }
 
-int launch_pcg_update_p(hipStream_t s, int n, const double* z, double* p, const double* sc, int first) {
-    hipLaunchKernelGGL(k_pcg_update_p, dim3(div_up(n, 256)), dim3(256), 0, s, n, z, p, sc, first);
+int launch_pcg_update_p(hipStream_t s, int n, int c0, const double* z, double* p, const double* sc, int first) {
+    hipLaunchKernelGGL(k_pcg_update_p, dim3(div_up(n, 256)), dim3(256), 0, s, n, c0, z, p, sc, first);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }
 
-int launch_pcg_update_xr(hipStream_t s, int n, double* x, double* r, const double* p, const double* w, const double* sc, double* partials) {
-    hipLaunchKernelGGL(k_pcg_update_xr, dim3(g_last_red_blocks), dim3(256), 0, s, n, x, r, p, w, sc, partials);
+int launch_pcg_update_xr(hipStream_t s, int n, int c0, double* x, double* r, const double* p, const double* w, const double* sc, double* partials) {
+    hipLaunchKernelGGL(k_pcg_update_xr, dim3(g_last_red_blocks), dim3(256), 0, s, n, c0, x, r, p, w, sc, partials);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }
@@ -936,6 +999,7 @@ int launch_mg_prolong_add(hipStream_t s, PMat A, double* x, PMat C, const double
 }
 
 int launch_mg_coarse_solve(hipStream_t s, PMat A, const double* b, double* x, double* tmp, int sweeps, double w) {
+    if (A.c0 != 0) return fail(FY_ERR_INVALID, "the coarsest multigrid level must be replicated (no ghost planes)");
     if (A.N > 1024) return fail(FY_ERR_INVALID, "coarsest multigrid level too large (%d cells)", A.N);
     hipLaunchKernelGGL(k_mg_coarse_solve, dim3(1), dim3(1024), 0, s, A, b, x, tmp, sweeps, w);
     FY_LAUNCH_CHECK();
@@ -945,6 +1009,25 @@ int launch_mg_coarse_solve(hipStream_t s, PMat A, const double* b, double* x, do
 int launch_copy_f64(hipStream_t s, double* dst, const double* src, size_t n) {
     if (!n) return FY_OK;
     hipLaunchKernelGGL(k_copy, dim3(div_up(n, 256)), dim3(256), 0, s, dst, src, n);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+
+int launch_p_ghost_uz(hipStream_t s, FvGeo g, CFace3 rAUf, CFace3 alphaf, PMat A) {
+    hipLaunchKernelGGL(k_p_ghost_uz, dim3(div_up((size_t)g.nx * g.ny, 256)), dim3(256), 0, s, g, rAUf, alphaf, A);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+
+int launch_mg_coarsen_ghost(hipStream_t s, PMat F, PMat C) {
+    hipLaunchKernelGGL(k_mg_coarsen_ghost, dim3(div_up((size_t)C.nx * C.ny, 256)), dim3(256), 0, s, F, C);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+
+int launch_add_f64(hipStream_t s, double* y, const double* x, size_t n) {
+    if (!n) return FY_OK;
+    hipLaunchKernelGGL(k_add, dim3(div_up(n, 256)), dim3(256), 0, s, y, x, n);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }

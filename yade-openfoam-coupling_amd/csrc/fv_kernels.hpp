@@ -9,8 +9,14 @@
 namespace fy {
 
 // geometry + boundary conditions, passed by value to every kernel
+// z-slab decomposition: a rank owns nz consecutive z-planes of a global block of nzglob planes; every CELL array
+// carries gz ghost planes below and above them (storage index c = i + nx*(j + ny*(k + gz)), owned cells are the contiguous range
+// [c0, c0 + Nc)).  FACE arrays have no ghosts: the interface face planes are computed redundantly by both neighbours.
+// Single domain: gz = 0, c0 = 0, kglob0 = 0, nzglob = nz.
 struct FvGeo {
-    int nx, ny, nz, Nc;
+    int nx, ny, nz, Nc;     // local owned extent
+    int gz, c0;             // ghost planes per side, storage index of the first owned cell (= gz*nx*ny)
+    int kglob0, nzglob;     // global k of the first owned plane, global number of planes
     double dx, Af, V;
     int u_bc[6];            // FY_BC_U_*
     double u_val[6][3];
@@ -29,7 +35,8 @@ struct Mom7 { double* diag; double* an[6]; };   // momentum matrix: diag + neigh
 
 // symmetric 7-point pressure matrix of one multigrid level: (A x)_c = diag_c x_c - sum u_f x_nb, u_* stored at the owner (low) cell
 struct PMat {
-    int nx, ny, nz, N;
+    int nx, ny, nz, N;      // owned extent of this level
+    int c0, ntot;           // storage index of the first owned cell, storage size (owned + ghost planes)
     double *diag, *ux, *uy, *uz;
 };
 
@@ -72,10 +79,11 @@ int launch_U_correct(hipStream_t s, FvGeo g, const double* HbyA, const double* r
 // ---- pressure solver building blocks
 int launch_p_apply(hipStream_t s, PMat A, const double* x, double* y);                                     // y = A x (the roofline kernel)
 int launch_p_apply_dot(hipStream_t s, PMat A, const double* x, double* y, double* partials);              // + slot 0 = x.y
-int launch_p_init(hipStream_t s, PMat A, const double* b, const double* x, double xbar, double* r, double* partials);   // r = b - A x; slots 0 |r|, 1 norm
-int launch_dot(hipStream_t s, int n, const double* a, const double* b, double* partials);                  // slot 0
-int launch_pcg_update_p(hipStream_t s, int n, const double* z, double* p, const double* sc, int first);    // p = z + (sc[0]/sc[1]) p
-int launch_pcg_update_xr(hipStream_t s, int n, double* x, double* r, const double* p, const double* w, const double* sc, double* partials);   // alpha = sc[0]/sc[2]; slot 0 = sum|r|
+// r = b - A x; slots 0 |r|, 1 norm factor; xbar = xsum_dev[0] * inv_n stays on the device (it is an all-reduced sum)
+int launch_p_init(hipStream_t s, PMat A, const double* b, const double* x, const double* xsum_dev, double inv_n, double* r, double* partials);
+int launch_dot(hipStream_t s, int n, int c0, const double* a, const double* b /* nullptr: sum(a) */, double* partials);   // slot 0, over [c0, c0+n)
+int launch_pcg_update_p(hipStream_t s, int n, int c0, const double* z, double* p, const double* sc, int first);    // p = z + (sc[0]/sc[1]) p
+int launch_pcg_update_xr(hipStream_t s, int n, int c0, double* x, double* r, const double* p, const double* w, const double* sc, double* partials);   // alpha = sc[0]/sc[2]; slot 0 = sum|r|
 int launch_jacobi_precond(hipStream_t s, PMat A, const double* r, double* z);
 int launch_mg_coarsen(hipStream_t s, PMat F, PMat C);
 int launch_mg_smooth_first(hipStream_t s, PMat A, const double* b, double* x, double w);                   // x = w b / diag
@@ -85,5 +93,10 @@ int launch_mg_prolong_add(hipStream_t s, PMat A, double* x, PMat C, const double
 int launch_mg_coarse_solve(hipStream_t s, PMat A, const double* b, double* x, double* tmp, int sweeps, double w);
 
 int launch_copy_f64(hipStream_t s, double* dst, const double* src, size_t n);
+// slab interfaces: coefficient of the z-face below the first owned plane, stored at the ghost cell under it (what p_row reads as uz[c - sz])
+int launch_p_ghost_uz(hipStream_t s, FvGeo g, CFace3 rAUf, CFace3 alphaf, PMat A);
+int launch_mg_coarsen_ghost(hipStream_t s, PMat F, PMat C);
+// y += x on a contiguous range (reverse-halo accumulation)
+int launch_add_f64(hipStream_t s, double* y, const double* x, size_t n);
 
 }  // namespace fy

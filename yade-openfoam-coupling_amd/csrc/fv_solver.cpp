@@ -2,12 +2,18 @@
 // (pimpleFoamYade/pimpleFoamYade.C:60-114 + UcEqn.H + pEqn.H) driving the HIP kernels of fv_kernels.hip, with the coupling
 // engine (fy_ctx) sharing the same device-resident fields and stream.  Host code only sequences kernels and reads back the
 // handful of scalars the control flow needs (residuals, Courant number, continuity errors).
+//
+// Multi-GPU: the block is cut into z-slabs, one per rank (fy::Comm, comm.hpp).  Cell arrays carry gz ghost planes per side; a
+// halo exchange precedes every kernel that reads a z-neighbour of a field that changed; reductions are all-reduced on the device;
+// multigrid levels whose 2x2x2 aggregates stay inside a slab are distributed, the coarse remainder is all-gathered and solved
+// redundantly (bit-identically) on every rank.  With one rank every communication call is a no-op and gz = 0.
 #include <algorithm>
 #include <cmath>
 #include <memory>
 #include <string>
 #include <vector>
 
+#include "comm.hpp"
 #include "coupling.hpp"
 #include "fv_kernels.hpp"
 
@@ -16,11 +22,15 @@ namespace fy {
 // coarsest multigrid level: solved by damped-Jacobi sweeps inside one 1024-thread workgroup (every level below ~20^3 is
 // launch-bound on the GPU; stopping at <= 1024 cells was tried and LOST: 40 sweeps no longer solve that level, +20 % PCG iterations)
 constexpr int kMgCoarsest = 256;
+constexpr int kMgReplicateBelow = 65536;      // a distributed hierarchy hands over to the replicated one at <= this many global cells
 
 struct MgLev {
     PMat A{};
+    bool distributed = false;     // owned z-slab + 1 ghost plane per side (only when comm->size > 1)
+    int gz = 0;
+    size_t plane = 0;
     DevBuf<double> diag, ux, uy, uz, x0, x1, b;
-    double* xcur = nullptr;      // holds the level's current iterate
+    double* xcur = nullptr;       // holds the level's current iterate
     double* xalt = nullptr;
     const double* bptr = nullptr;
 };
@@ -32,12 +42,18 @@ struct Solver {
     hipStream_t stream = nullptr;
     fy_ctx* cpl = nullptr;
     bool pimple = false;
-    int Nc = 0;
+    int Nc = 0;                   // owned cells
+    size_t nstore = 0, plane = 0; // storage cells (owned + ghost planes), cells per z-plane
+    int64_t Nglob = 0;
+    Comm* comm = nullptr;
+    SelfComm self_comm;
 
     DevBuf<double> U, Uold, p, alpha, alphaOld, uSource, uSourceDrag, uParticle, gradP, divT, vGrad, ddtU;
     DevBuf<double> phi[3], phiOld[3], psn[3], alphaf[3], phiHbyA[3], phiForces[3], rAUf[3], pflux[3];
     DevBuf<double> mdiag, man[6], src, rAU, HbyA, bmom, Gt, divG, xscr;
     std::vector<std::unique_ptr<MgLev> > mg;
+    size_t mg_rep = 0;            // first replicated level (== mg.size() when nothing is replicated)
+    DevBuf<double> rep_stage;     // local slice of the first replicated level before the all-gather (rhs / operator arrays)
     DevBuf<double> prhs, pr, pw, pp, pzj;
     DevBuf<double> partials, red_out, sc, xbar3;
     DevBuf<int> ops_courant;
@@ -59,18 +75,45 @@ struct Solver {
         if (stream) (void)hipStreamDestroy(stream);
     }
 
-    int zero(DevBuf<double>& b) { FY_HIP(hipMemsetAsync(b.p, 0, b.n * sizeof(double), stream)); return FY_OK; }
+    int zero(DevBuf<double>& b) { if (b.n) FY_HIP(hipMemsetAsync(b.p, 0, b.n * sizeof(double), stream)); return FY_OK; }
 
-    int create(const fy_case_desc* c, const fy_transport* tr, int dev) {
+    // ---- slab halos -----------------------------------------------------------------------------------------------------
+    // refresh w ghost planes per side of a cell array with `ncomp` interleaved components (planes are contiguous in memory)
+    int halo(double* f, int ncomp, size_t pl, int nzl, int gzl, int w) {
+        if (comm->size == 1) return FY_OK;
+        const size_t P = pl * (size_t)ncomp;
+        double* own_lo = f + (size_t)gzl * P;
+        double* own_hi = f + (size_t)(gzl + nzl - w) * P;
+        double* gh_lo = f + (size_t)(gzl - w) * P;
+        double* gh_hi = f + (size_t)(gzl + nzl) * P;
+        return comm->neighbour_exchange(stream, own_hi, gh_lo, own_lo, gh_hi, (size_t)w * P);
+    }
+    int halo_cells(DevBuf<double>& f, int ncomp, int w) { return halo(f.p, ncomp, plane, g.nz, g.gz, w); }
+    int halo_level(MgLev& L, double* x) { return L.distributed ? halo(x, 1, L.plane, L.A.nz, L.gz, 1) : FY_OK; }
+
+    int create(const fy_case_desc* c, const fy_transport* tr, int dev, Comm* cm) {
         if (!c || c->nx <= 0 || c->ny <= 0 || c->nz <= 0 || !(c->dx > 0) || !(c->dt > 0)) return fail(FY_ERR_INVALID, "fy_solver_create: bad case");
         int ndev = 0;
         if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(FY_ERR_NO_DEVICE, "no HIP device visible: libfoamyade_hip has no CPU path");
         if (dev < 0 || dev >= ndev) return fail(FY_ERR_INVALID, "device ordinal out of range");
         cs = *c; device = dev; pimple = c->solver == FY_SOLVER_PIMPLE;
+        comm = cm ? cm : &self_comm;
         FY_HIP(hipSetDevice(device));
         FY_HIP(hipStreamCreate(&stream));
-        Nc = c->nx * c->ny * c->nz;
-        g.nx = c->nx; g.ny = c->ny; g.nz = c->nz; g.Nc = Nc; g.dx = c->dx; g.Af = c->dx * c->dx; g.V = c->dx * c->dx * c->dx;
+        // ---- slab extents: the case describes the GLOBAL block; rank r owns planes [r*nz, (r+1)*nz)
+        const int S = comm->size;
+        if (c->nz % S != 0) return fail(FY_ERR_INVALID, "nz (%d) must be divisible by the number of slabs (%d)", c->nz, S);
+        const int nzl = c->nz / S;
+        if (S > 1 && (nzl % 2 != 0 || nzl < 2)) return fail(FY_ERR_INVALID, "each slab needs an even number (>= 2) of z-planes, got %d", nzl);
+        // ghost width: 1 plane for the FV stencils; the Gaussian stencil reaches sqrt(1.25)*4 dx = 4.47 dx => 5 planes
+        const int gz = S == 1 ? 0 : (pimple ? 5 : 1);
+        if (S > 1 && nzl < gz) return fail(FY_ERR_INVALID, "slab thinner (%d planes) than the particle halo (%d)", nzl, gz);
+        plane = (size_t)c->nx * c->ny;
+        Nc = (int)(plane * nzl);
+        nstore = plane * (size_t)(nzl + 2 * gz);
+        Nglob = (int64_t)plane * c->nz;
+        g.nx = c->nx; g.ny = c->ny; g.nz = nzl; g.Nc = Nc; g.gz = gz; g.c0 = (int)(plane * gz); g.kglob0 = comm->rank * nzl; g.nzglob = c->nz;
+        g.dx = c->dx; g.Af = c->dx * c->dx; g.V = c->dx * c->dx * c->dx;
         g.pimple = pimple ? 1 : 0; g.dt = c->dt; g.nu = c->nu;
         bool need_ref = true;
         for (int q = 0; q < 6; ++q) {
@@ -80,9 +123,9 @@ struct Solver {
         }
         for (int a = 0; a < 3; ++a) g.g[a] = c->g[a];
         g.need_ref = need_ref ? 1 : 0; g.p_ref_cell = c->p_ref_cell; g.p_ref_value = c->p_ref_value;
-        if (c->p_ref_cell < 0 || c->p_ref_cell >= Nc) return fail(FY_ERR_INVALID, "pRefCell out of range");
+        if (c->p_ref_cell < 0 || c->p_ref_cell >= Nglob) return fail(FY_ERR_INVALID, "pRefCell out of range");
 
-        const size_t n = (size_t)Nc;
+        const size_t n = nstore;
         DevBuf<double>* v3[] = {&U, &Uold, &uSource, &uParticle, &gradP, &divT, &ddtU, &src, &HbyA, &bmom, &divG, &xscr};
         for (auto* b : v3) { FY_TRY(b->alloc_exact(3 * n)); FY_TRY(zero(*b)); }
         DevBuf<double>* v1[] = {&p, &alpha, &alphaOld, &uSourceDrag, &mdiag, &rAU, &prhs, &pr, &pw, &pp, &pzj};
@@ -97,42 +140,71 @@ struct Solver {
         }
         FY_TRY(launch_fill_f64(stream, alpha.p, n, 1.0));
         FY_TRY(launch_fill_f64(stream, alphaOld.p, n, 1.0));
+        FY_TRY(launch_fill_f64(stream, rAU.p, n, 1.0));            // ghost planes must hold finite values before the first exchange
         FY_TRY(partials.alloc_exact(8 * (size_t)kRedBlocks)); FY_TRY(red_out.alloc_exact(8)); FY_TRY(sc.alloc_exact(4)); FY_TRY(xbar3.alloc_exact(3));
-        FY_TRY(zero(partials)); FY_TRY(zero(sc));
+        FY_TRY(zero(partials)); FY_TRY(zero(sc)); FY_TRY(zero(red_out));
         FY_TRY(ops_courant.alloc_exact(2));
         { const int h[2] = {1, 0}; FY_HIP(hipMemcpyAsync(ops_courant.p, h, sizeof(h), hipMemcpyHostToDevice, stream)); FY_HIP(hipStreamSynchronize(stream)); }
 
-        // multigrid hierarchy: 2x2x2 aggregation down to <= kMgCoarsest cells
-        int ax = g.nx, ay = g.ny, az = g.nz;
-        for (;;) {
-            std::unique_ptr<MgLev> L(new MgLev());
-            L->A.nx = ax; L->A.ny = ay; L->A.nz = az; L->A.N = ax * ay * az;
-            const size_t m = (size_t)L->A.N;
-            DevBuf<double>* bs[] = {&L->diag, &L->ux, &L->uy, &L->uz, &L->x0, &L->x1, &L->b};
-            for (auto* b : bs) { FY_TRY(b->alloc_exact(m)); FY_TRY(zero(*b)); }
-            L->A.diag = L->diag.p; L->A.ux = L->ux.p; L->A.uy = L->uy.p; L->A.uz = L->uz.p;
-            L->xcur = L->x0.p; L->xalt = L->x1.p; L->bptr = L->b.p;
-            const int N = L->A.N;
-            mg.push_back(std::move(L));
-            if (cs.p_solver != FY_PSOLVER_PCG_MG) break;
-            if (N <= kMgCoarsest || (ax <= 2 && ay <= 2 && az <= 2)) break;
-            ax = (ax + 1) / 2; ay = (ay + 1) / 2; az = (az + 1) / 2;
+        // ---- multigrid hierarchy: 2x2x2 aggregation down to <= kMgCoarsest cells.  With several slabs the levels whose aggregates
+        // stay inside a slab keep the slab layout (+1 ghost plane); from the first level with <= kMgReplicateBelow global cells (or
+        // whose parent has an odd plane count) on, the hierarchy is replicated on every rank.
+        {
+            int ax = g.nx, ay = g.ny, az_loc = g.nz, az_glob = c->nz;
+            bool dist = S > 1;
+            size_t lvl = 0;
+            mg_rep = (size_t)-1;
+            for (;;) {
+                std::unique_ptr<MgLev> L(new MgLev());
+                L->distributed = dist;
+                L->gz = dist ? (lvl == 0 ? g.gz : 1) : 0;       // level 0 shares the layout of the solver's cell vectors (p, r, ...)
+                L->plane = (size_t)ax * ay;
+                const int nzv = dist ? az_loc : az_glob;
+                L->A.nx = ax; L->A.ny = ay; L->A.nz = nzv; L->A.N = (int)(L->plane * nzv);
+                L->A.c0 = (int)(L->plane * L->gz); L->A.ntot = (int)(L->plane * (nzv + 2 * L->gz));
+                const size_t m = (size_t)L->A.ntot;
+                DevBuf<double>* bs[] = {&L->diag, &L->ux, &L->uy, &L->uz, &L->x0, &L->x1, &L->b};
+                for (auto* b : bs) { FY_TRY(b->alloc_exact(m)); FY_TRY(zero(*b)); }
+                FY_TRY(launch_fill_f64(stream, L->diag.p, m, 1.0));          // never divide by an unset ghost diagonal
+                L->A.diag = L->diag.p; L->A.ux = L->ux.p; L->A.uy = L->uy.p; L->A.uz = L->uz.p;
+                L->xcur = L->x0.p; L->xalt = L->x1.p; L->bptr = L->b.p;
+                const int64_t Ng = (int64_t)L->plane * az_glob;
+                if (!dist && mg_rep == (size_t)-1 && S > 1) mg_rep = lvl;
+                mg.push_back(std::move(L));
+                if (cs.p_solver != FY_PSOLVER_PCG_MG) break;
+                if (Ng <= kMgCoarsest || (ax <= 2 && ay <= 2 && az_glob <= 2)) break;
+                // next level
+                const int nax = (ax + 1) / 2, nay = (ay + 1) / 2, naz_glob = (az_glob + 1) / 2;
+                if (dist) {
+                    const int64_t nNg = (int64_t)nax * nay * naz_glob;
+                    if (az_loc % 2 != 0) return fail(FY_ERR_UNSUPPORTED, "slab plane count %d cannot be aggregated", az_loc);
+                    az_loc /= 2;                                         // the slice of the next level this rank's cells aggregate to
+                    if (az_loc % 2 != 0 || az_loc < 2 || nNg <= kMgReplicateBelow) dist = false;   // next level: replicated
+                }
+                ax = nax; ay = nay; az_glob = naz_glob;
+                ++lvl;
+            }
+            if (mg_rep == (size_t)-1) mg_rep = mg.size();
+            if (S > 1 && cs.p_solver == FY_PSOLVER_PCG_MG && mg_rep >= mg.size()) return fail(FY_ERR_UNSUPPORTED, "multigrid hierarchy never became replicable");
+            if (mg.back()->A.N > 1024 && cs.p_solver == FY_PSOLVER_PCG_MG) return fail(FY_ERR_UNSUPPORTED, "coarsest multigrid level too large");
+            if (mg_rep < mg.size()) FY_TRY(rep_stage.alloc_exact(4 * ((size_t)mg[mg_rep]->A.N / S + 8)));
         }
-        if (mg.back()->A.N > 1024 && cs.p_solver == FY_PSOLVER_PCG_MG) return fail(FY_ERR_UNSUPPORTED, "coarsest multigrid level too large");
         for (auto& t : tim) FY_TRY(t.init());
 
-        // the coupling object shares the solver's device fields and stream (icoFoamYade.C:54, pimpleFoamYade.C:54)
+        // the coupling object shares the solver's device fields and stream (icoFoamYade.C:54, pimpleFoamYade.C:54); its tree spans
+        // the GLOBAL block (the improvement chain depends on the whole tree), its cell arrays are this slab's storage
         {
-            std::vector<double> C(3 * n), V(n, g.V);
-            for (int k = 0; k < g.nz; ++k) for (int j = 0; j < g.ny; ++j) for (int i = 0; i < g.nx; ++i) {
+            const size_t ng = (size_t)Nglob;
+            std::vector<double> C(3 * ng), V(ng, g.V);
+            for (int k = 0; k < c->nz; ++k) for (int j = 0; j < g.ny; ++j) for (int i = 0; i < g.nx; ++i) {
                 const size_t cc = (size_t)i + (size_t)g.nx * (j + (size_t)g.ny * k);
                 C[3 * cc] = c->origin[0] + (i + 0.5) * c->dx; C[3 * cc + 1] = c->origin[1] + (j + 0.5) * c->dx; C[3 * cc + 2] = c->origin[2] + (k + 0.5) * c->dx;
             }
             fy_mesh_desc md{};
-            md.n_cells = Nc; md.centres = C.data(); md.volumes = V.data();
-            md.nx = g.nx; md.ny = g.ny; md.nz = g.nz; md.dx = c->dx;
+            md.n_cells = (int32_t)Nglob; md.centres = C.data(); md.volumes = V.data();
+            md.nx = g.nx; md.ny = g.ny; md.nz = c->nz; md.dx = c->dx;
             for (int a = 0; a < 3; ++a) { md.origin[a] = c->origin[a]; md.bbox_min[a] = c->origin[a]; }
-            md.bbox_max[0] = c->origin[0] + g.nx * c->dx; md.bbox_max[1] = c->origin[1] + g.ny * c->dx; md.bbox_max[2] = c->origin[2] + g.nz * c->dx;
+            md.bbox_max[0] = c->origin[0] + g.nx * c->dx; md.bbox_max[1] = c->origin[1] + g.ny * c->dx; md.bbox_max[2] = c->origin[2] + c->nz * c->dx;
             fy_field_ptrs fp{};
             fp.location = FY_MEM_DEVICE;
             fp.U = U.p; fp.gradP = gradP.p; fp.vGrad = vGrad.p; fp.divT = divT.p; fp.ddtU = ddtU.p;
@@ -141,36 +213,49 @@ struct Solver {
             cpl = new (std::nothrow) fy_ctx();
             if (!cpl) return fail(FY_ERR_INVALID, "out of host memory");
             cpl->c.ext_stream = stream;
+            if (S > 1) {
+                cpl->c.slab.active = true; cpl->c.slab.comm = comm; cpl->c.slab.gz = gz; cpl->c.slab.nz = nzl; cpl->c.slab.plane = plane;
+                cpl->c.slab.n_store = nstore; cpl->c.slab.base = ((int64_t)g.kglob0 - gz) * (int64_t)plane;
+            }
             FY_TRY(cpl->c.create(&md, &fp, pimple ? 1 : 0, tr, device));      // gaussianInterp: false for ico, true for pimple (icoFoamYade.C:53, pimpleFoamYade.C:53)
             cpl->c.rhoP = c->rho_particle; cpl->c.rhoF = c->rho_fluid; cpl->c.nu = c->nu;   // setScalarProperties (icoFoamYade.C:55)
         }
+        FY_TRY(halo_cells(U, 3, 1));
         FY_TRY(launch_flux_of(stream, g, U.p, F3(phi)));                     // createPhi
         FY_HIP(hipStreamSynchronize(stream));
         return FY_OK;
     }
 
-    int reduce_read(int nslots, const int* d_ops, double* h) {
-        FY_TRY(launch_reduce_finalize(stream, partials.p, nslots, d_ops, red_out.p));
+    // fold the block partials, all-reduce over the slabs, read back
+    int reduce_read(int nslots, bool courant, double* h) {
+        FY_TRY(launch_reduce_finalize(stream, partials.p, nslots, courant ? ops_courant.p : nullptr, red_out.p));
+        if (courant) { FY_TRY(comm->allreduce(stream, red_out.p, 1, true)); FY_TRY(comm->allreduce(stream, red_out.p + 1, 1, false)); }
+        else FY_TRY(comm->allreduce(stream, red_out.p, nslots, false));
         FY_HIP(hipMemcpyAsync(h, red_out.p, nslots * sizeof(double), hipMemcpyDeviceToHost, stream));
         FY_HIP(hipStreamSynchronize(stream));
         return FY_OK;
+    }
+    int reduce_to_device(double* dst) {          // one slot, stays on the device (PCG scalars)
+        FY_TRY(launch_reduce_finalize(stream, partials.p, 1, nullptr, dst));
+        return comm->allreduce(stream, dst, 1, false);
     }
 
     // ---- momentum predictor: Jacobi sweeps with lduMatrix-style L1 residual control (stand-in for smoothSolver) ----------
     int solve_momentum(int* iters) {
         double h[6];
-        FY_TRY(launch_sum3(stream, U.p, Nc, partials.p));
-        FY_TRY(reduce_read(3, nullptr, h));
-        double xb[3] = {h[0] / Nc, h[1] / Nc, h[2] / Nc};
+        FY_TRY(launch_sum3(stream, U.p + 3 * (size_t)g.c0, Nc, partials.p));
+        FY_TRY(reduce_read(3, false, h));
+        double xb[3] = {h[0] / (double)Nglob, h[1] / (double)Nglob, h[2] / (double)Nglob};
         FY_HIP(hipMemcpyAsync(xbar3.p, xb, sizeof(xb), hipMemcpyHostToDevice, stream));
         double* xc = U.p; double* xn = xscr.p;
         double norm[3] = {1, 1, 1}, res0[3] = {0, 0, 0}, res[3];
         int it = 0;
         for (;;) {
+            FY_TRY(halo(xc, 3, plane, g.nz, g.gz, 1));
             kc[KC_MOM_PASS].begin(stream);
             FY_TRY(launch_mom_pass(stream, g, M7(), bmom.p, xc, xn, xbar3.p, partials.p));
             kc[KC_MOM_PASS].end(stream);
-            FY_TRY(reduce_read(6, nullptr, h));
+            FY_TRY(reduce_read(6, false, h));
             if (it == 0) for (int q = 0; q < 3; ++q) { norm[q] = h[3 + q] + 1e-20; res0[q] = h[q] / norm[q]; }
             bool conv = true;
             for (int q = 0; q < 3; ++q) {
@@ -181,18 +266,26 @@ struct Solver {
             std::swap(xc, xn);
             ++it;
         }
-        if (xc != U.p) FY_TRY(launch_copy_f64(stream, U.p, xc, 3 * (size_t)Nc));
+        if (xc != U.p) FY_TRY(launch_copy_f64(stream, U.p + 3 * (size_t)g.c0, xc + 3 * (size_t)g.c0, 3 * (size_t)Nc));
         *iters = it;
         return FY_OK;
     }
 
     // ---- multigrid V(2,2) with damped Jacobi, used as the PCG preconditioner ------------------------------------------
     int smooth(size_t l, MgLev& L, double w) {
+        FY_TRY(halo_level(L, L.xcur));
         if (l == 0) kc[KC_MG_SMOOTH0].begin(stream);
         FY_TRY(launch_mg_smooth(stream, L.A, L.bptr, L.xcur, L.xalt, w));
         if (l == 0) kc[KC_MG_SMOOTH0].end(stream);
         std::swap(L.xcur, L.xalt);
         return FY_OK;
+    }
+
+    // the slice of the (replicated) level `Cc` that this rank's distributed parent `L` aggregates to, as a stand-alone PMat
+    PMat slice_of(const MgLev& L, const MgLev& Cc) const {
+        PMat loc = Cc.A;
+        loc.nz = L.A.nz / 2; loc.N = (int)(Cc.plane * (size_t)loc.nz); loc.c0 = 0; loc.ntot = loc.N;
+        return loc;
     }
 
     int vcycle(size_t l) {
@@ -206,12 +299,48 @@ struct Solver {
         MgLev& Cc = *mg[l + 1];
         FY_TRY(launch_mg_smooth_first(stream, L.A, L.bptr, L.xcur, w));
         FY_TRY(smooth(l, L, w));
-        FY_TRY(launch_mg_residual_restrict(stream, L.A, L.bptr, L.xcur, Cc.A, Cc.b.p));
+        FY_TRY(halo_level(L, L.xcur));
+        const bool handover = L.distributed && !Cc.distributed;
+        if (handover) {
+            // hand-over to the replicated hierarchy: restrict into the local slice, all-gather the coarse right-hand side
+            PMat loc = slice_of(L, Cc);
+            FY_TRY(launch_mg_residual_restrict(stream, L.A, L.bptr, L.xcur, loc, rep_stage.p));
+            FY_TRY(comm->allgather(stream, rep_stage.p, Cc.b.p, (size_t)loc.N));
+        } else {
+            FY_TRY(launch_mg_residual_restrict(stream, L.A, L.bptr, L.xcur, Cc.A, Cc.b.p));
+        }
         Cc.bptr = Cc.b.p;
         FY_TRY(vcycle(l + 1));
-        FY_TRY(launch_mg_prolong_add(stream, L.A, L.xcur, Cc.A, Cc.xcur));
+        if (handover) {
+            PMat loc = Cc.A;                      // this rank's slice of the replicated coarse solution
+            loc.c0 = (int)(Cc.plane * (size_t)(L.A.nz / 2) * (size_t)comm->rank);
+            FY_TRY(launch_mg_prolong_add(stream, L.A, L.xcur, loc, Cc.xcur));
+        } else {
+            FY_TRY(launch_mg_prolong_add(stream, L.A, L.xcur, Cc.A, Cc.xcur));
+        }
         FY_TRY(smooth(l, L, w));
         FY_TRY(smooth(l, L, w));
+        return FY_OK;
+    }
+
+    // coarse operators: A_{l+1} = 1/2 P^T A_l P level by level; the first replicated level is all-gathered from the slabs' slices
+    int build_coarse_operators() {
+        for (size_t l = 0; l + 1 < mg.size(); ++l) {
+            MgLev& F = *mg[l]; MgLev& Cc = *mg[l + 1];
+            if (F.distributed && !Cc.distributed) {
+                PMat loc = slice_of(F, Cc);
+                const size_t cnt = (size_t)loc.N;
+                loc.diag = rep_stage.p; loc.ux = rep_stage.p + cnt; loc.uy = rep_stage.p + 2 * cnt; loc.uz = rep_stage.p + 3 * cnt;
+                FY_TRY(launch_mg_coarsen(stream, F.A, loc));
+                FY_TRY(comm->allgather(stream, loc.diag, Cc.A.diag, cnt));
+                FY_TRY(comm->allgather(stream, loc.ux, Cc.A.ux, cnt));
+                FY_TRY(comm->allgather(stream, loc.uy, Cc.A.uy, cnt));
+                FY_TRY(comm->allgather(stream, loc.uz, Cc.A.uz, cnt));
+            } else {
+                FY_TRY(launch_mg_coarsen(stream, F.A, Cc.A));
+                if (Cc.distributed && comm->has_down()) FY_TRY(launch_mg_coarsen_ghost(stream, F.A, Cc.A));
+            }
+        }
         return FY_OK;
     }
 
@@ -220,13 +349,12 @@ struct Solver {
         MgLev& L = *mg[0];
         const double tol = final_iter ? cs.p_final_tol : cs.p_tol, rel = final_iter ? cs.p_final_rel_tol : cs.p_rel_tol;
         double h[2];
-        // xbar = average(p) for lduMatrix::solver::normFactor: sum(p) as a dot product with a ones vector (pzj is free here)
-        FY_TRY(launch_fill_f64(stream, pzj.p, Nc, 1.0));
-        FY_TRY(launch_dot(stream, Nc, p.p, pzj.p, partials.p));
-        FY_TRY(reduce_read(1, nullptr, h));
-        const double xbar = h[0] / Nc;
-        FY_TRY(launch_p_init(stream, L.A, prhs.p, p.p, xbar, pr.p, partials.p));
-        FY_TRY(reduce_read(2, nullptr, h));
+        // xbar = average(p) for lduMatrix::solver::normFactor: sum(p) over the owned cells, all-reduced, kept on the device
+        FY_TRY(launch_dot(stream, Nc, g.c0, p.p, nullptr, partials.p));
+        FY_TRY(reduce_to_device(sc.p + 3));
+        FY_TRY(halo_cells(p, 1, 1));
+        FY_TRY(launch_p_init(stream, L.A, prhs.p, p.p, sc.p + 3, 1.0 / (double)Nglob, pr.p, partials.p));
+        FY_TRY(reduce_read(2, false, h));
         const double norm = h[1] + 1e-20;
         double res = h[0] / norm;
         const double res0 = res;
@@ -238,16 +366,17 @@ struct Solver {
                 const double* z;
                 if (cs.p_solver == FY_PSOLVER_PCG_MG) { L.bptr = pr.p; FY_TRY(vcycle(0)); z = L.xcur; }
                 else { FY_TRY(launch_jacobi_precond(stream, L.A, pr.p, pzj.p)); z = pzj.p; }
-                FY_TRY(launch_dot(stream, Nc, z, pr.p, partials.p));
-                FY_TRY(launch_reduce_finalize(stream, partials.p, 1, nullptr, sc.p + 0));              // wArA
-                FY_TRY(launch_pcg_update_p(stream, Nc, z, pp.p, sc.p, it == 0 ? 1 : 0));
+                FY_TRY(launch_dot(stream, Nc, g.c0, z, pr.p, partials.p));
+                FY_TRY(reduce_to_device(sc.p + 0));                                                   // wArA
+                FY_TRY(launch_pcg_update_p(stream, Nc, g.c0, z, pp.p, sc.p, it == 0 ? 1 : 0));
+                FY_TRY(halo_cells(pp, 1, 1));
                 kc[KC_P_APPLY_DOT].begin(stream);
                 FY_TRY(launch_p_apply_dot(stream, L.A, pp.p, pw.p, partials.p));
                 kc[KC_P_APPLY_DOT].end(stream);
-                FY_TRY(launch_reduce_finalize(stream, partials.p, 1, nullptr, sc.p + 2));              // wApA
-                FY_TRY(launch_pcg_update_xr(stream, Nc, p.p, pr.p, pp.p, pw.p, sc.p, partials.p));
+                FY_TRY(reduce_to_device(sc.p + 2));                                                   // wApA
+                FY_TRY(launch_pcg_update_xr(stream, Nc, g.c0, p.p, pr.p, pp.p, pw.p, sc.p, partials.p));
                 FY_HIP(hipMemcpyAsync(sc.p + 1, sc.p + 0, sizeof(double), hipMemcpyDeviceToDevice, stream));   // wArAold = wArA
-                FY_TRY(reduce_read(1, nullptr, h));
+                FY_TRY(reduce_read(1, false, h));
                 res = h[0] / norm;
             } while (++it < cs.p_max_iter && !converged(res));
         }
@@ -258,23 +387,28 @@ struct Solver {
 
     // ---- one PISO / PIMPLE corrector (icoFoamYade.C:97-140, pEqn.H) ----------------------------------------------------
     int corrector(bool final_inner) {
+        FY_TRY(halo_cells(U, 3, 1));
         FY_TRY(launch_HbyA(stream, g, M7(), src.p, U.p, rAU.p, HbyA.p));
-        if (!pimple) FY_TRY(launch_interp_rAU(stream, g, rAU.p, F3(rAUf)));
+        if (!pimple) { FY_TRY(halo_cells(rAU, 1, 1)); FY_TRY(launch_interp_rAU(stream, g, rAU.p, F3(rAUf))); }
+        FY_TRY(halo_cells(HbyA, 3, 1));
         FY_TRY(launch_phiHbyA(stream, g, HbyA.p, U.p, Uold.p, C3(phiOld), C3(rAUf), C3(alphaf), C3(phiForces), F3(phiHbyA), F3(psn)));
         MgLev& L = *mg[0];
         if (timing) tim[2].start(stream);
         for (int no = 0; no <= cs.n_non_orth_correctors; ++no) {
             FY_TRY(launch_assemble_pressure(stream, g, C3(phiHbyA), C3(rAUf), C3(alphaf), C3(psn), alpha.p, alphaOld.p, L.A, prhs.p));
-            for (size_t l = 0; l + 1 < mg.size(); ++l) FY_TRY(launch_mg_coarsen(stream, mg[l]->A, mg[l + 1]->A));
+            if (L.distributed && comm->has_down()) FY_TRY(launch_p_ghost_uz(stream, g, C3(rAUf), C3(alphaf), L.A));
+            FY_TRY(build_coarse_operators());
             FY_TRY(solve_pressure(final_inner && no == cs.n_non_orth_correctors));
-            if (no == cs.n_non_orth_correctors)
+            if (no == cs.n_non_orth_correctors) {
+                FY_TRY(halo_cells(p, 1, 1));
                 FY_TRY(launch_flux_correct(stream, g, p.p, C3(phiHbyA), C3(rAUf), C3(alphaf), C3(psn), F3(pflux), F3(phi)));
+            }
         }
         if (timing) { tim[2].stop(stream); st.ms_pressure += tim[2].ms(); }
         double h[2];
         FY_TRY(launch_cont_err(stream, g, C3(phi), C3(alphaf), alpha.p, alphaOld.p, partials.p));
-        FY_TRY(reduce_read(2, nullptr, h));
-        const double tv = g.V * Nc;
+        FY_TRY(reduce_read(2, false, h));
+        const double tv = g.V * (double)Nglob;
         st.cont_err_sum_local = cs.dt * h[0] / tv; st.cont_err_global = cs.dt * h[1] / tv;
         cumulative_cont_err += st.cont_err_global; st.cont_err_cumulative = cumulative_cont_err;
         FY_TRY(launch_U_correct(stream, g, HbyA.p, rAU.p, p.p, C3(psn), C3(phiForces), C3(pflux), C3(alphaf), C3(rAUf), U.p));
@@ -288,34 +422,42 @@ struct Solver {
         if (timing) tim[3].start(stream);
         double h[2];
         FY_TRY(launch_courant(stream, g, C3(phi), partials.p));                               // icoFoamYade.C:68, pimpleFoamYade.C:63
-        FY_TRY(reduce_read(2, ops_courant.p, h));
-        st.courant_max = 0.5 * h[0] * cs.dt; st.courant_mean = 0.5 * (h[1] / (g.V * Nc)) * cs.dt;
-        // runTime++ : store old-time fields
-        FY_TRY(launch_copy_f64(stream, Uold.p, U.p, 3 * (size_t)Nc));
+        FY_TRY(reduce_read(2, true, h));
+        st.courant_max = 0.5 * h[0] * cs.dt; st.courant_mean = 0.5 * (h[1] / (g.V * (double)Nglob)) * cs.dt;
+        // runTime++ : store old-time fields (whole storage, ghost planes included)
+        FY_TRY(halo_cells(U, 3, 1));
+        FY_TRY(halo_cells(p, 1, 1));
+        FY_TRY(halo_cells(alpha, 1, 1));
+        FY_TRY(launch_copy_f64(stream, Uold.p, U.p, 3 * nstore));
         for (int d = 0; d < 3; ++d) FY_TRY(launch_copy_f64(stream, phiOld[d].p, phi[d].p, phi[d].n));
         FY_TRY(launch_pre_coupling(stream, g, U.p, p.p, alpha.p, C3(psn), vGrad.p, gradP.p, divT.p));   // icoFoamYade.C:71, pimpleFoamYade.C:73-76
 
         if (timing) tim[0].start(stream);
+        if (g.gz > 1) {                      // the particle gathers reach gz planes into the neighbours
+            FY_TRY(halo_cells(U, 3, g.gz)); FY_TRY(halo_cells(gradP, 3, g.gz)); FY_TRY(halo_cells(divT, 3, g.gz));
+        }
         FY_TRY(cpl->c.set_particle_action(cs.dt));                                            // icoFoamYade.C:74, pimpleFoamYade.C:78
         if (timing) { tim[0].stop(stream); }
 
         // alphac.oldTime() is captured lazily by OpenFOAM at alphac.correctBoundaryConditions() (pimpleFoamYade.C:83), i.e. after
         // FoamYade wrote alpha through untracked operator[]: old == current, fvc::ddt(alphac) == 0
-        FY_TRY(launch_copy_f64(stream, alphaOld.p, alpha.p, Nc));
-        if (pimple) FY_TRY(launch_interp_alpha(stream, g, alpha.p, F3(alphaf)));              // pimpleFoamYade.C:83-85
+        FY_TRY(launch_copy_f64(stream, alphaOld.p, alpha.p, nstore));
+        if (pimple) FY_TRY(launch_interp_alpha(stream, g, alpha.p, F3(alphaf)));              // pimpleFoamYade.C:83-85 (alpha ghosts refreshed by the coupling)
         const int nOuter = pimple ? std::max(cs.n_outer_correctors, 1) : 1;
         for (int outer = 0; outer < nOuter; ++outer) {
             if (timing) tim[1].start(stream);
             if (pimple) {
-                if (outer > 0) FY_TRY(launch_pre_coupling(stream, g, U.p, p.p, alpha.p, C3(psn), vGrad.p, gradP.p, divT.p));
+                if (outer > 0) { FY_TRY(halo_cells(U, 3, 1)); FY_TRY(launch_pre_coupling(stream, g, U.p, p.p, alpha.p, C3(psn), vGrad.p, gradP.p, divT.p)); }
                 FY_TRY(launch_stress_G(stream, g, vGrad.p, alpha.p, Gt.p));
+                FY_TRY(halo_cells(Gt, 9, 1));
                 FY_TRY(launch_div_G(stream, g, Gt.p, divG.p));
             }
             FY_TRY(launch_assemble_momentum(stream, g, U.p, Uold.p, alpha.p, alphaOld.p, C3(alphaf), C3(phi), uSource.p, uSourceDrag.p,
                                             divG.p, M7(), src.p, rAU.p));
             if (pimple) {
+                FY_TRY(halo_cells(rAU, 1, 1));
                 FY_TRY(launch_interp_rAU(stream, g, rAU.p, F3(rAUf)));
-                FY_TRY(launch_phi_forces(stream, g, rAU.p, C3(rAUf), uSource.p, F3(phiForces)));
+                FY_TRY(launch_phi_forces(stream, g, rAU.p, C3(rAUf), uSource.p, F3(phiForces)));     // uSource ghosts refreshed by the coupling
             }
             if (cs.momentum_predictor) {
                 FY_TRY(launch_bmom(stream, g, src.p, p.p, C3(psn), C3(phiForces), C3(rAUf), bmom.p));
@@ -340,16 +482,23 @@ struct Solver {
         return FY_OK;
     }
 
+    // field lookup; cell fields are returned/accepted as the OWNED part only (ghost planes are an implementation detail)
     int field(const char* name, double** ptr, size_t* count) {
         const std::string s = name ? name : "";
         const size_t n = (size_t)Nc;
-        struct E { const char* nm; double* p; size_t c; };
-        const E tab[] = {{"U", U.p, 3 * n}, {"p", p.p, n}, {"phi_x", phi[0].p, phi[0].n}, {"phi_y", phi[1].p, phi[1].n}, {"phi_z", phi[2].p, phi[2].n},
-                         {"rAU", rAU.p, n}, {"HbyA", HbyA.p, 3 * n}, {"p_rhs", prhs.p, n}, {"p_diag", mg[0]->diag.p, n}, {"p_ux", mg[0]->ux.p, n},
-                         {"p_uy", mg[0]->uy.p, n}, {"p_uz", mg[0]->uz.p, n}, {"mom_diag", mdiag.p, n}, {"mom_src", src.p, 3 * n},
-                         {"alpha", alpha.p, n}, {"uSource", uSource.p, 3 * n}, {"uSourceDrag", uSourceDrag.p, n}, {"uParticle", uParticle.p, 3 * n},
-                         {"gradP", gradP.p, 3 * n}, {"divT", divT.p, 3 * n}, {"vGrad", vGrad.p, 9 * n}};
-        for (const E& e : tab) if (s == e.nm) { *ptr = e.p; *count = e.c; return FY_OK; }
+        struct E { const char* nm; double* p; size_t c; int comp; };
+        const E tab[] = {{"U", U.p, 3 * n, 3}, {"p", p.p, n, 1}, {"phi_x", phi[0].p, phi[0].n, 0}, {"phi_y", phi[1].p, phi[1].n, 0}, {"phi_z", phi[2].p, phi[2].n, 0},
+                         {"rAU", rAU.p, n, 1}, {"HbyA", HbyA.p, 3 * n, 3}, {"p_rhs", prhs.p, n, 1}, {"mom_diag", mdiag.p, n, 1}, {"mom_src", src.p, 3 * n, 3},
+                         {"alpha", alpha.p, n, 1}, {"uSource", uSource.p, 3 * n, 3}, {"uSourceDrag", uSourceDrag.p, n, 1}, {"uParticle", uParticle.p, 3 * n, 3},
+                         {"gradP", gradP.p, 3 * n, 3}, {"divT", divT.p, 3 * n, 3}, {"vGrad", vGrad.p, 9 * n, 9}};
+        for (const E& e : tab) if (s == e.nm) {
+            *ptr = e.p + (size_t)e.comp * g.c0;          // skip the ghost planes below the owned range (comp = 0: face array)
+            *count = e.c;
+            return FY_OK;
+        }
+        MgLev& L = *mg[0];
+        const struct { const char* nm; double* p; } pm[] = {{"p_diag", L.diag.p}, {"p_ux", L.ux.p}, {"p_uy", L.uy.p}, {"p_uz", L.uz.p}};
+        for (auto& e : pm) if (s == e.nm) { *ptr = e.p + L.A.c0; *count = n; return FY_OK; }
         return fail(FY_ERR_INVALID, "unknown solver field '%s'", s.c_str());
     }
 };
@@ -374,27 +523,57 @@ void fy_case_defaults(fy_case_desc* c, int solver) {
     c->u_tol = 1e-5; c->u_rel_tol = 0.0; c->u_max_iter = 1000;
 }
 
-int fy_solver_create(const fy_case_desc* c, const fy_transport* tr, int device_ordinal, fy_solver** out) {
+static int solver_create_impl(const fy_case_desc* c, const fy_transport* tr, int device_ordinal, fy::Comm* cm, fy_solver** out) {
     if (!out) return fy::fail(FY_ERR_INVALID, "null out");
     *out = nullptr;
     fy_solver* s = new (std::nothrow) fy_solver();
     if (!s) return fy::fail(FY_ERR_INVALID, "out of host memory");
-    int rc = s->s.create(c, tr, device_ordinal);
+    int rc = s->s.create(c, tr, device_ordinal, cm);
     if (rc != FY_OK) { delete s; return rc; }
     *out = s;
     return FY_OK;
 }
+
+int fy_solver_create(const fy_case_desc* c, const fy_transport* tr, int device_ordinal, fy_solver** out) {
+    return solver_create_impl(c, tr, device_ordinal, nullptr, out);
+}
+
+int fy_solver_create_slab(const fy_case_desc* c, const fy_transport* tr, int device_ordinal, fy_comm* comm, fy_solver** out) {
+    if (!comm || !comm->c) return fy::fail(FY_ERR_INVALID, "null communicator");
+    return solver_create_impl(c, tr, device_ordinal, comm->c, out);
+}
+
+int fy_comm_create_local_group(int n, fy_comm** out) {
+    if (n < 1 || !out) return fy::fail(FY_ERR_INVALID, "bad arguments");
+    std::vector<fy::Comm*> cs((size_t)n);
+    FY_TRY(fy::local_comm_group_create(n, cs.data()));
+    for (int r = 0; r < n; ++r) { out[r] = new fy_comm(); out[r]->c = cs[(size_t)r]; }
+    return FY_OK;
+}
+int fy_rccl_unique_id(void* out128) { return fy::rccl_unique_id(out128); }
+int fy_comm_create_rccl(int rank, int size, const void* id128, int device, fy_comm** out) {
+    if (!out) return fy::fail(FY_ERR_INVALID, "null out");
+    fy::Comm* c = nullptr;
+    FY_TRY(fy::rccl_comm_create(rank, size, id128, device, &c));
+    *out = new fy_comm(); (*out)->c = c;
+    return FY_OK;
+}
+int fy_comm_destroy(fy_comm* c) { if (c) { delete c->c; delete c; } return FY_OK; }
+int fy_comm_rank(fy_comm* c) { return c && c->c ? c->c->rank : -1; }
+int fy_comm_size(fy_comm* c) { return c && c->c ? c->c->size : -1; }
 
 #define FY_S(s) if (!(s)) return fy::fail(FY_ERR_INVALID, "null fy_solver")
 
 fy_ctx* fy_solver_coupling(fy_solver* s) { return s ? s->s.cpl : nullptr; }
 int fy_solver_step(fy_solver* s) { FY_S(s); return s->s.step(); }
 int fy_solver_get_stats(fy_solver* s, fy_step_stats* out) { FY_S(s); if (!out) return fy::fail(FY_ERR_INVALID, "null out"); *out = s->s.st; return FY_OK; }
+int fy_solver_local_cells(fy_solver* s) { return s ? s->s.Nc : -1; }
 
 int fy_solver_read_field_host(fy_solver* s, const char* name, double* out) {
     FY_S(s);
     double* p; size_t n;
     FY_TRY(s->s.field(name, &p, &n));
+    FY_HIP(hipSetDevice(s->s.device));
     FY_HIP(hipMemcpyAsync(out, p, n * sizeof(double), hipMemcpyDeviceToHost, s->s.stream));
     FY_HIP(hipStreamSynchronize(s->s.stream));
     return FY_OK;
@@ -404,8 +583,12 @@ int fy_solver_write_field_host(fy_solver* s, const char* name, const double* in)
     FY_S(s);
     double* p; size_t n;
     FY_TRY(s->s.field(name, &p, &n));
+    FY_HIP(hipSetDevice(s->s.device));
     FY_HIP(hipMemcpyAsync(p, in, n * sizeof(double), hipMemcpyHostToDevice, s->s.stream));
-    if (std::string(name) == "U") FY_TRY(fy::launch_flux_of(s->s.stream, s->s.g, s->s.U.p, s->s.F3(s->s.phi)));   // createPhi
+    if (std::string(name) == "U") {           // createPhi (collective when there are several slabs)
+        FY_TRY(s->s.halo_cells(s->s.U, 3, 1));
+        FY_TRY(fy::launch_flux_of(s->s.stream, s->s.g, s->s.U.p, s->s.F3(s->s.phi)));
+    }
     FY_HIP(hipStreamSynchronize(s->s.stream));
     return FY_OK;
 }
@@ -415,9 +598,11 @@ int fy_solver_destroy(fy_solver* s) { delete s; return FY_OK; }
 int fy_solver_apply_p_matrix_host(fy_solver* s, const double* x, double* y) {
     FY_S(s);
     fy::Solver& S = s->s;
-    FY_HIP(hipMemcpyAsync(S.pp.p, x, (size_t)S.Nc * sizeof(double), hipMemcpyHostToDevice, S.stream));
+    FY_HIP(hipSetDevice(S.device));
+    FY_HIP(hipMemcpyAsync(S.pp.p + S.g.c0, x, (size_t)S.Nc * sizeof(double), hipMemcpyHostToDevice, S.stream));
+    FY_TRY(S.halo_cells(S.pp, 1, 1));
     FY_TRY(fy::launch_p_apply(S.stream, S.mg[0]->A, S.pp.p, S.pw.p));
-    FY_HIP(hipMemcpyAsync(y, S.pw.p, (size_t)S.Nc * sizeof(double), hipMemcpyDeviceToHost, S.stream));
+    FY_HIP(hipMemcpyAsync(y, S.pw.p + S.g.c0, (size_t)S.Nc * sizeof(double), hipMemcpyDeviceToHost, S.stream));
     FY_HIP(hipStreamSynchronize(S.stream));
     return FY_OK;
 }

@@ -340,7 +340,7 @@ __device__ __forceinline__ void lds_add_f64(double* p, double v) { unsafeAtomicA
 
 // buildCellPartList FoamYade.C:265-288: pVol*w and (w*v)*pVol per (particle, cell) pair into the per-batch accumulators
 constexpr int kDepThreads = 512, kDepLog2 = 11;      // 2048 slots x (4 + 32) B = 72 KiB of LDS
-__global__ __launch_bounds__(kDepThreads) void k_deposit(ParticleSoA p, int64_t n, GaussParams gp, double* __restrict__ pvol_acc,
+__global__ __launch_bounds__(kDepThreads) void k_deposit(ParticleSoA p, int64_t n, GaussParams gp, CellWindow cw, double* __restrict__ pvol_acc,
                                                           double* __restrict__ up_acc, unsigned char* __restrict__ touched) {
     __shared__ uint32_t keys[1 << kDepLog2];
     __shared__ double vals[(1 << kDepLog2) * 4];
@@ -370,7 +370,9 @@ __global__ __launch_bounds__(kDepThreads) void k_deposit(ParticleSoA p, int64_t 
                 const size_t slot = (size_t)((chain - 1 - t) & (kMaxK - 1)) * p.cap + (size_t)i;
                 const double weight = p.w[slot] / allwt;                      // FoamYade.C:312-314
                 p.w[slot] = weight;
-                const int32_t cid = p.ids[slot];
+                const int64_t cl = (int64_t)p.ids[slot] - cw.base;          // storage index (slab window)
+                if (cl < 0 || cl >= cw.n_field) continue;
+                const int32_t cid = (int32_t)cl;
                 const double c0 = pVol * weight, c1 = (weight * vx) * pVol, c2 = (weight * vy) * pVol, c3 = (weight * vz) * pVol;
                 const int h = agg_slot<kDepLog2>(keys, (uint32_t)cid);
                 if (h >= 0) {
@@ -417,7 +419,7 @@ __global__ __launch_bounds__(256) void k_finalize_cells(int32_t n_cells, const d
 
 // ------------------------------------------------------------------------------------------------ force + back-scatter
 constexpr int kForceThreads = 512, kForceLog2 = 11;
-__global__ __launch_bounds__(kForceThreads) void k_force_gaussian(ParticleSoA p, int64_t n, ForceParams fp, const double* __restrict__ vol,
+__global__ __launch_bounds__(kForceThreads) void k_force_gaussian(ParticleSoA p, int64_t n, ForceParams fp, CellWindow cw, const double* __restrict__ vol,
                                                                   const double* __restrict__ U, const double* __restrict__ alpha,
                                                                   const double* __restrict__ uParticle, const double* __restrict__ gradP,
                                                                   const double* __restrict__ divT, double* __restrict__ uSourceDrag,
@@ -452,7 +454,9 @@ __global__ __launch_bounds__(kForceThreads) void k_force_gaussian(ParticleSoA p,
             const double two_nu = 2.0 * nu;
             for (int t = 0; t < k; ++t) {
                 const size_t slot = (size_t)((chain - 1 - t) & (kMaxK - 1)) * p.cap + (size_t)i;
-                const int32_t c = p.ids[slot];
+                const int64_t cl = (int64_t)p.ids[slot] - cw.base;
+                if (cl < 0 || cl >= cw.n_field) continue;
+                const int32_t c = (int32_t)cl;
                 const double w = p.w[slot];
                 const double* u = U + 3 * (size_t)c;
                 ufx += (u[0] * w); ufy += (u[1] * w); ufz += (u[2] * w);
@@ -487,16 +491,18 @@ __global__ __launch_bounds__(kForceThreads) void k_force_gaussian(ParticleSoA p,
             const double irho = 1 / rhoF;
             for (int t = 0; t < k; ++t) {
                 const size_t slot = (size_t)((chain - 1 - t) & (kMaxK - 1)) * p.cap + (size_t)i;
-                const int32_t c = p.ids[slot];
+                const int64_t cl = (int64_t)p.ids[slot] - cw.base;
+                if (cl < 0 || cl >= cw.n_field) continue;
+                const int32_t c = (int32_t)cl;
                 const double w = p.w[slot];
-                const double cw = -coeff * w;
+                const double cwt = -coeff * w;
                 const double* up = uParticle + 3 * (size_t)c;
                 const double ooCellVol = 1. / (vol[c] * rhoF);                              // FoamYade.C:432
                 // FoamYade.C:385 ; FoamYade.C:386 (drag part, NOT divided by V) + FoamYade.C:433 (Archimedes part)
-                const double c0 = cw * irho;
-                const double c1 = ((cw * up[0]) / rhoF) + ((-afx * w) * ooCellVol);
-                const double c2 = ((cw * up[1]) / rhoF) + ((-afy * w) * ooCellVol);
-                const double c3 = ((cw * up[2]) / rhoF) + ((-afz * w) * ooCellVol);
+                const double c0 = cwt * irho;
+                const double c1 = ((cwt * up[0]) / rhoF) + ((-afx * w) * ooCellVol);
+                const double c2 = ((cwt * up[1]) / rhoF) + ((-afy * w) * ooCellVol);
+                const double c3 = ((cwt * up[2]) / rhoF) + ((-afz * w) * ooCellVol);
                 const int h = agg_slot<kForceLog2>(keys, (uint32_t)c);
                 if (h >= 0) {
                     lds_add_f64(&vals[4 * h], c0); lds_add_f64(&vals[4 * h + 1], c1);
@@ -544,7 +550,7 @@ __global__ __launch_bounds__(256) void k_unpack_stencils(ParticleSoA p, int64_t 
 }
 
 // ------------------------------------------------------------------------------------------------ point force
-__global__ __launch_bounds__(256) void k_point_force(const double* __restrict__ rec, int64_t n, BlockGeom g, ForceParams fp,
+__global__ __launch_bounds__(256) void k_point_force(const double* __restrict__ rec, int64_t n, BlockGeom g, ForceParams fp, CellWindow cw,
                                                      const double* __restrict__ vol, const double* __restrict__ U,
                                                      const double* __restrict__ vGrad, double* __restrict__ uSource,
                                                      double* __restrict__ force_out, int32_t* __restrict__ found_out,
@@ -565,9 +571,12 @@ __global__ __launch_bounds__(256) void k_point_force(const double* __restrict__ 
     const int ci = min(g.nx - 1, (int)((x - g.bbmin[0]) / g.dx));
     const int cj = min(g.ny - 1, (int)((y - g.bbmin[1]) / g.dx));
     const int ck = min(g.nz - 1, (int)((z - g.bbmin[2]) / g.dx));
-    const int c = ci + g.nx * (cj + g.ny * ck);
+    const int cglob = ci + g.nx * (cj + g.ny * ck);
     found_out[i] = 1;
-    incell_out[i] = c;
+    incell_out[i] = cglob;
+    const int64_t cl = (int64_t)cglob - cw.base;
+    if (cl < 0 || cl >= cw.n_field) { F[0] = F[1] = F[2] = F[3] = F[4] = F[5] = 0.0; return; }   // not in this slab's window
+    const int c = (int)cl;
     const double dia = 2 * r[9];
     const double rhoF = fp.rhoF, nu = fp.nu;
     // stokesDragForce FoamYade.C:437-444
@@ -587,6 +596,15 @@ __global__ __launch_bounds__(256) void k_point_force(const double* __restrict__ 
     F[3] = ((pd3 * (s1 - r[6])) * nu) * rhoF;
     F[4] = ((pd3 * (s2 - r[7])) * nu) * rhoF;
     F[5] = ((pd3 * (s3 - r[8])) * nu) * rhoF;
+}
+
+// reverse-halo accumulation: y += x, and flag the cells that received something (stands in for the neighbour's touched flags)
+__global__ __launch_bounds__(256) void k_add_mark(double* __restrict__ y, const double* __restrict__ x, size_t n, unsigned char* __restrict__ mark) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double v = x[i];
+    y[i] += v;
+    if (mark && v != 0.0) mark[i] = 1;
 }
 
 __global__ __launch_bounds__(256) void k_fill_f64(double* __restrict__ p, size_t n, double v) {
@@ -658,9 +676,9 @@ int launch_locate(hipStream_t s, const KdNode* tree, const uint32_t* packed, Imp
     return FY_OK;
 }
 
-int launch_deposit(hipStream_t s, ParticleSoA p, int64_t n, GaussParams gp, double* pvol_acc, double* up_acc, unsigned char* touched) {
+int launch_deposit(hipStream_t s, ParticleSoA p, int64_t n, GaussParams gp, CellWindow cw, double* pvol_acc, double* up_acc, unsigned char* touched) {
     if (n <= 0) return FY_OK;
-    hipLaunchKernelGGL(k_deposit, dim3(div_up(n, kDepThreads)), dim3(kDepThreads), 0, s, p, n, gp, pvol_acc, up_acc, touched);
+    hipLaunchKernelGGL(k_deposit, dim3(div_up(n, kDepThreads)), dim3(kDepThreads), 0, s, p, n, gp, cw, pvol_acc, up_acc, touched);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }
@@ -672,11 +690,11 @@ int launch_finalize_cells(hipStream_t s, int32_t n_cells, const double* vol, dou
     return FY_OK;
 }
 
-int launch_force_gaussian(hipStream_t s, ParticleSoA p, int64_t n, ForceParams fp, const double* vol, const double* U,
+int launch_force_gaussian(hipStream_t s, ParticleSoA p, int64_t n, ForceParams fp, CellWindow cw, const double* vol, const double* U,
                           const double* alpha, const double* uParticle, const double* gradP, const double* divT,
                           double* uSourceDrag, double* uSource, double* force_out, int32_t* found_out) {
     if (n <= 0) return FY_OK;
-    hipLaunchKernelGGL(k_force_gaussian, dim3(div_up(n, kForceThreads)), dim3(kForceThreads), 0, s, p, n, fp, vol, U, alpha, uParticle, gradP, divT,
+    hipLaunchKernelGGL(k_force_gaussian, dim3(div_up(n, kForceThreads)), dim3(kForceThreads), 0, s, p, n, fp, cw, vol, U, alpha, uParticle, gradP, divT,
                        uSourceDrag, uSource, force_out, found_out);
     FY_LAUNCH_CHECK();
     return FY_OK;
@@ -689,11 +707,18 @@ int launch_unpack_stencils(hipStream_t s, ParticleSoA p, int64_t n, int32_t* k, 
     return FY_OK;
 }
 
-int launch_point_force(hipStream_t s, const double* rec, int64_t n, BlockGeom g, ForceParams fp, const double* vol,
+int launch_point_force(hipStream_t s, const double* rec, int64_t n, BlockGeom g, ForceParams fp, CellWindow cw, const double* vol,
                        const double* U, const double* vGrad, double* uSource, double* force_out, int32_t* found_out,
                        int32_t* incell_out) {
     if (n <= 0) return FY_OK;
-    hipLaunchKernelGGL(k_point_force, dim3(div_up(n, 256)), dim3(256), 0, s, rec, n, g, fp, vol, U, vGrad, uSource, force_out, found_out, incell_out);
+    hipLaunchKernelGGL(k_point_force, dim3(div_up(n, 256)), dim3(256), 0, s, rec, n, g, fp, cw, vol, U, vGrad, uSource, force_out, found_out, incell_out);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+
+int launch_add_mark(hipStream_t s, double* y, const double* x, size_t n, unsigned char* mark) {
+    if (n == 0) return FY_OK;
+    hipLaunchKernelGGL(k_add_mark, dim3(div_up(n, 256)), dim3(256), 0, s, y, x, n, mark);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }

@@ -55,10 +55,13 @@ struct ImplicitGeom {
 int launch_locate(hipStream_t s, const KdNode* tree, const uint32_t* packed, ImplicitGeom ig, int32_t n_cells, int levels,
                   ParticleSoA p, int64_t n, GaussParams gp);
 // forms the normalised Gaussian weights from the parked squared distances, then deposits (LDS-aggregated)
-int launch_deposit(hipStream_t s, ParticleSoA p, int64_t n, GaussParams gp, double* pvol_acc, double* up_acc, unsigned char* touched);
+// cell arrays are indexed with (global cell id - cell_base) and hold n_field cells (slab storage); ids outside are skipped
+struct CellWindow { int64_t base; int64_t n_field; };
+int launch_deposit(hipStream_t s, ParticleSoA p, int64_t n, GaussParams gp, CellWindow cw, double* pvol_acc, double* up_acc, unsigned char* touched);
+int launch_add_mark(hipStream_t s, double* y, const double* x, size_t n, unsigned char* mark /* nullable; set where x != 0 */);
 int launch_finalize_cells(hipStream_t s, int32_t n_cells, const double* vol, double* pvol_acc, double* up_acc,
                           unsigned char* touched, double* alpha, double* uParticle);
-int launch_force_gaussian(hipStream_t s, ParticleSoA p, int64_t n, ForceParams fp, const double* vol, const double* U,
+int launch_force_gaussian(hipStream_t s, ParticleSoA p, int64_t n, ForceParams fp, CellWindow cw, const double* vol, const double* U,
                           const double* alpha, const double* uParticle, const double* gradP, const double* divT,
                           double* uSourceDrag, double* uSource, double* force_out, int32_t* found_out);
 int launch_unpack_stencils(hipStream_t s, ParticleSoA p, int64_t n, int32_t* k, int32_t* ids, double* w, int32_t* chain);
@@ -68,7 +71,7 @@ struct BlockGeom {
     double bbmin[3], bbmax[3], dx;
     int nx, ny, nz;
 };
-int launch_point_force(hipStream_t s, const double* rec, int64_t n, BlockGeom g, ForceParams fp, const double* vol,
+int launch_point_force(hipStream_t s, const double* rec, int64_t n, BlockGeom g, ForceParams fp, CellWindow cw, const double* vol,
                        const double* U, const double* vGrad, double* uSource, double* force_out, int32_t* found_out,
                        int32_t* incell_out);
 
