@@ -9,9 +9,11 @@ continuity errors, setSourceZero.  Particle records and all fields are resident 
 (the reference receives particles over MPI on the host; the PCIe-inclusive figure is discussed in DESIGN.md, never here).
 
 Contract: python bench.py --gpus N --steps K --warmup W ; for N>1 launched by torch.distributed.run, one rank per GPU.
-Round 1 shards nothing across GPUs yet: N>1 runs N independent replicas of the whole workload (`"parallelism": "replicas"`)
--- the z-slab decomposition with RCCL halos is the next step and is NOT claimed here.
-Rank 0 prints ONE JSON line.
+N > 1 is ONE coupled simulation cut into N z-slabs (SURVEY.md 8e, config C4 weak series): a 160 x 160 x (160 N) box, each rank owns a
+160^3 slab and the 10 M particles inside it; FV halos (1 plane), particle halos (5 planes), reverse-halo sums, Krylov scalars and the
+coarse multigrid level travel over RCCL/xGMI (csrc/comm.cpp).  Weak scaling: per-GPU work is fixed as N grows.
+`value` counts C3-sized slab-steps per second over the whole job (= N x coupled steps/s of the N-slab box; identical to coupled
+steps/s at N = 1).  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -28,22 +30,23 @@ import __graft_entry__ as ge  # noqa: E402
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s copy-achievable)
 
 
-def c3_case(prod, n, dt, p_solver):
+def c3_case(prod, n, dt, p_solver, n_slabs=1):
     """closed box, no-slip walls, g = (0,0,-9.81), nu = 1e-6, rho_p = 2650, rho_f = 1000, PIMPLE nOuter 1 nCorr 2,
-    fixedFluxPressure walls (what a DPMFoam case with gravity uses)."""
+    fixedFluxPressure walls (what a DPMFoam case with gravity uses).  n_slabs > 1: the C4 weak-scaling box, n x n x (n * n_slabs)."""
     dx = 1.0 / n
-    return prod.make_case(prod.FY_SOLVER_PIMPLE, n, n, n, dx, dt, 1e-6, rho_f=1000.0, rho_p=2650.0, g=(0.0, 0.0, -9.81),
+    return prod.make_case(prod.FY_SOLVER_PIMPLE, n, n, n * n_slabs, dx, dt, 1e-6, rho_f=1000.0, rho_p=2650.0, g=(0.0, 0.0, -9.81),
                           u_bc=[prod.FY_BC_U_FIXED_VALUE] * 6, u_val=[(0, 0, 0)] * 6, p_bc=[prod.FY_BC_P_FIXED_FLUX] * 6,
                           n_outer_correctors=1, n_correctors=2, p_solver=p_solver)
 
 
-def c3_particles(torch, n_part, n, seed, device):
-    """Np particles uniform in the lower 60 % of the unit box, r = 0.2 dx, at rest."""
+def c3_particles(torch, n_part, n, seed, device, slab=0):
+    """Np particles uniform in the lower 60 % of this rank's unit-cube slab, r = 0.2 dx, at rest."""
     g = torch.Generator(device="cpu").manual_seed(seed)
     dx = 1.0 / n
     rec = torch.zeros(n_part, 10, dtype=torch.float64)
     rec[:, 0:3] = torch.rand(n_part, 3, dtype=torch.float64, generator=g)
     rec[:, 2] *= 0.6
+    rec[:, 2] += float(slab)
     rec[:, 9] = 0.2 * dx
     return rec.to(device).contiguous()
 
@@ -103,6 +106,7 @@ def main():
     ap.add_argument("--p-solver", type=int, default=1, help="0 PCG+Jacobi, 1 PCG+multigrid")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-n", type=int, default=64)
+    ap.add_argument("--force-rccl", action="store_true", help="use the RCCL communicator even with one rank (smoke test of the RCCL path)")
     args = ap.parse_args()
 
     import torch
@@ -122,12 +126,25 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     prod = ge.load_product()
-    case = c3_case(prod, args.n, args.dt, args.p_solver)
-    solver = prod.Solver(case, device=local_rank)
-    rec = c3_particles(torch, args.particles, args.n, 3 + rank, dev)
+    case = c3_case(prod, args.n, args.dt, args.p_solver, world)
+    comm = None
+    if world > 1 or args.force_rccl:
+        # one RCCL communicator for the slab exchanges; the 128-byte unique id travels over torch.distributed
+        os.environ.setdefault("FOAMYADE_TREE_CACHE_DIR", "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp")
+        idt = torch.zeros(128, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            import glob
+            for f in glob.glob(os.path.join(os.environ["FOAMYADE_TREE_CACHE_DIR"], "fy_tree_*.lock")):      # stale locks of a crashed run
+                os.remove(f)
+            idt = torch.tensor(list(prod.rccl_unique_id()), dtype=torch.uint8, device=dev)
+        if dist is not None:
+            dist.broadcast(idt, 0)
+        comm = prod.rccl_comm(rank, world, bytes(idt.cpu().tolist()), local_rank)
+    solver = prod.Solver(case, device=local_rank, comm=comm)
+    rec = c3_particles(torch, args.particles, args.n, 3 + rank, dev, slab=rank)
     solver.set_particles_device(rec)
     solver.enable_particle_timing(True)
-    nc = args.n ** 3
+    nc = args.n ** 3                      # cells per rank (one C3-sized slab)
 
     def barrier():
         torch.cuda.synchronize()
@@ -184,18 +201,20 @@ def main():
                 "launches": k["launches"], "algorithmic_bytes_per_launch": k["alg_bytes"], "what": k["what"]}
 
     out = {
-        "metric": "coupled_steps_per_sec (pimpleFoamYade 4-way, 10M particles / 4M cells)" if (args.n == 160 and args.particles == 10_000_000)
+        "metric": "coupled_steps_per_sec (pimpleFoamYade 4-way, 10M particles / 4M cells per GPU)" if (args.n == 160 and args.particles == 10_000_000)
         else f"coupled_steps_per_sec (pimpleFoamYade 4-way, {args.particles} particles / {nc} cells)",
         "value": round(steps_per_s, 4), "unit": "steps/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / K, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "particle_steps_per_sec": round(steps_per_s * np_part, 1),
+        "coupled_steps_per_sec_of_the_whole_box": round(steps_per_s / world, 4),
         "config": {"workload": "C3: pimpleFoamYade Gaussian 4-way coupling, 160^3 = 4,096,000-cell closed box, 10,000,000 particles in the lower 60 %"
                    if (args.n == 160 and args.particles == 10_000_000) else f"reduced C3-like case {args.n}^3 cells / {args.particles} particles",
                    "cells": nc, "particles": np_part, "dt": args.dt, "pimple": {"nOuterCorrectors": 1, "nCorrectors": 2},
                    "p_solver": "PCG+MG V(2,2) damped Jacobi" if args.p_solver == 1 else "PCG+Jacobi",
                    "p_tol": [case.p_tol, case.p_rel_tol, case.p_final_tol, case.p_final_rel_tol],
-                   "parallelism": "single GPU" if world == 1 else f"replicas x{world} (no cross-GPU sharding yet)"},
+                   "parallelism": "single GPU" if world == 1 else f"{world} z-slabs of one {args.n}x{args.n}x{args.n * world} box, RCCL halos + all-reduces over xGMI",
+                   "global_cells": nc * world, "global_particles": np_part * world},
         "per_step_ms": {k: round(acc[k] / K, 3) for k in ("particle", "bin", "locate", "force", "momentum", "pressure", "other")},
         "p_iters_per_step": acc["p_iters"] / K, "u_iters_per_step": acc["u_iters"] / K,
         "roofline": roof(dominant) if dominant else None,
@@ -214,8 +233,13 @@ def main():
             "sample": f"same workload at {args.cpu_sample_n}^3 cells / {snp} particles ({snc / nc:.4f} of the bench size), CPU oracle (port of the "
                       f"reference path, de-quadraticised deposit), measured {per[best_th]:.2f} s/step on {best_th} threads ({per[1]:.2f} s/step on 1); "
                       f"value = measured steps/s x {scale:.5f} (linear-in-size extrapolation)"}
+    if dist is not None:
+        dist.barrier()
     if rank == 0:
-        print(json.dumps(out))
+        import ctypes
+        ctypes.CDLL(None).fflush(None)          # RCCL prints a version banner through C stdio: get it out BEFORE the JSON line
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -5,7 +5,9 @@
 
 #include <algorithm>
 #include <cmath>
+#include <chrono>
 #include <cstdlib>
+#include <functional>
 #include <thread>
 
 namespace fy {
@@ -63,37 +65,80 @@ int Coupling::create(const fy_mesh_desc* m, const fy_field_ptrs* f, int gaussian
 
     // ---- mshTree.build_tree(), FoamYade.C:33 (always, also in point-force mode: quirk Q6 kept for get_tree parity)
     {
-        std::vector<KdNode> nodes;
-        unsigned hw = std::thread::hardware_concurrency();
-        build_kdtree_preorder(m->centres, n_cells, nodes, (int)std::min(hw ? hw : 1u, 8u));
-        tree_levels = kdtree_levels(n_cells);
-        FY_TRY(d_tree.alloc_exact(nodes.size()));
-        FY_HIP(hipMemcpyAsync(d_tree.p, nodes.data(), nodes.size() * sizeof(KdNode), hipMemcpyHostToDevice, stream));
         // implicit-coordinate nodes: legal only if EVERY centre equals origin + (i + 0.5) * dx bit for bit (checked here, so a
         // real OpenFOAM mesh whose centres come from pyramid decomposition simply keeps the explicit path)
-        std::vector<uint32_t> packed;
-        if (structured && getenv("FOAMYADE_EXPLICIT_TREE") == nullptr && m->nx <= 1024 && m->ny <= 1024 && m->nz <= 1024) {
-            bool exact = true;
+        bool exact = structured && getenv("FOAMYADE_EXPLICIT_TREE") == nullptr && m->nx <= 1024 && m->ny <= 1024 && m->nz <= 4096 &&
+                     n_cells < (1 << 25);
+        if (exact)
             for (int k = 0; k < m->nz && exact; ++k) for (int j = 0; j < m->ny && exact; ++j) for (int i = 0; i < m->nx; ++i) {
                 const size_t c = (size_t)i + (size_t)m->nx * (j + (size_t)m->ny * k);
                 const double x = m->origin[0] + ((double)i + 0.5) * m->dx, y = m->origin[1] + ((double)j + 0.5) * m->dx, z = m->origin[2] + ((double)k + 0.5) * m->dx;
                 if (x != m->centres[3 * c] || y != m->centres[3 * c + 1] || z != m->centres[3 * c + 2]) { exact = false; break; }
             }
-            if (exact) {
-                packed.resize(nodes.size());
-                for (size_t q = 0; q < nodes.size(); ++q) {
-                    const int id = nodes[q].id;
-                    const int i = id % m->nx, j = (id / m->nx) % m->ny, k = id / (m->nx * m->ny);
-                    packed[q] = (uint32_t)i | ((uint32_t)j << 10) | ((uint32_t)k << 20);
-                }
-                FY_TRY(d_tree_packed.alloc_exact(packed.size()));
-                FY_HIP(hipMemcpyAsync(d_tree_packed.p, packed.data(), packed.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-                implicit.ox = m->origin[0]; implicit.oy = m->origin[1]; implicit.oz = m->origin[2]; implicit.dx = m->dx;
-                implicit.nx = m->nx; implicit.ny = m->ny;
-                use_implicit = true;
+        // The tree is a pure function of the centres.  Several ranks of one node (z-slab mode: every rank holds the tree of the
+        // GLOBAL block) may share it through a cache directory instead of each running the 25-level nth_element recursion:
+        // FOAMYADE_TREE_CACHE_DIR=/dev/shm ; the first rank to create the lock file builds and publishes, the others wait.
+        std::vector<int32_t> pre;      // preorder cell ids
+        std::string cache;
+        if (exact) if (const char* dir = getenv("FOAMYADE_TREE_CACHE_DIR")) {
+            char nm[256];
+            snprintf(nm, sizeof(nm), "%s/fy_tree_%dx%dx%d_%016llx.bin", dir, m->nx, m->ny, m->nz,
+                     (unsigned long long)(std::hash<double>()(m->dx) ^ (std::hash<double>()(m->origin[0]) << 1) ^ (std::hash<double>()(m->origin[1]) << 2) ^ (std::hash<double>()(m->origin[2]) << 3)));
+            cache = nm;
+        }
+        auto load_cache = [&]() -> bool {
+            FILE* f = fopen(cache.c_str(), "rb");
+            if (!f) return false;
+            pre.resize((size_t)n_cells);
+            const bool ok = fread(pre.data(), sizeof(int32_t), (size_t)n_cells, f) == (size_t)n_cells;
+            fclose(f);
+            return ok;
+        };
+        bool have = false;
+        if (!cache.empty()) {
+            have = load_cache();
+            if (!have) {
+                const std::string lock = cache + ".lock";
+                FILE* lf = fopen(lock.c_str(), "wx");            // exclusive create: the winner builds
+                if (!lf) {
+                    for (int spin = 0; spin < 36000 && !have; ++spin) { std::this_thread::sleep_for(std::chrono::milliseconds(50)); have = load_cache(); }
+                } else fclose(lf);
             }
         }
-        FY_HIP(hipStreamSynchronize(stream));
+        std::vector<KdNode> nodes;
+        if (!have) {
+            unsigned hw = std::thread::hardware_concurrency();
+            build_kdtree_preorder(m->centres, n_cells, nodes, (int)std::min(hw ? hw : 1u, 8u));
+            pre.resize((size_t)n_cells);
+            for (size_t q = 0; q < nodes.size(); ++q) pre[q] = nodes[q].id;
+            if (!cache.empty()) {
+                const std::string tmp = cache + ".tmp";
+                if (FILE* f = fopen(tmp.c_str(), "wb")) { fwrite(pre.data(), sizeof(int32_t), pre.size(), f); fclose(f); rename(tmp.c_str(), cache.c_str()); }
+            }
+        }
+        tree_levels = kdtree_levels(n_cells);
+        if (exact) {
+            std::vector<uint32_t> packed((size_t)n_cells);
+            for (size_t q = 0; q < packed.size(); ++q) {
+                const int id = pre[q];
+                const int i = id % m->nx, j = (id / m->nx) % m->ny, k = id / (m->nx * m->ny);
+                packed[q] = (uint32_t)i | ((uint32_t)j << 10) | ((uint32_t)k << 20);
+            }
+            FY_TRY(d_tree_packed.alloc_exact(packed.size()));
+            FY_HIP(hipMemcpyAsync(d_tree_packed.p, packed.data(), packed.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+            implicit.ox = m->origin[0]; implicit.oy = m->origin[1]; implicit.oz = m->origin[2]; implicit.dx = m->dx;
+            implicit.nx = m->nx; implicit.ny = m->ny;
+            use_implicit = true;
+            FY_HIP(hipStreamSynchronize(stream));
+        } else {
+            if (nodes.empty()) {                                 // (cache hit on a non-implicit mesh cannot happen: caching needs `exact`)
+                build_kdtree_preorder(m->centres, n_cells, nodes, 1);
+            }
+            FY_TRY(d_tree.alloc_exact(nodes.size()));
+            FY_HIP(hipMemcpyAsync(d_tree.p, nodes.data(), nodes.size() * sizeof(KdNode), hipMemcpyHostToDevice, stream));
+            FY_HIP(hipStreamSynchronize(stream));
+        }
+        h_tree_pre.swap(pre);
     }
     v0 = m->volumes[0];
     n_field = slab.active ? (int64_t)slab.n_store : (int64_t)n_cells;
@@ -516,10 +561,7 @@ int Coupling::get_stencils_host(int bi, int32_t* k, int32_t* ids, double* w, int
 
 int Coupling::get_tree_preorder(int32_t* out) {
     if (!out) return fail(FY_ERR_INVALID, "null output");
-    std::vector<KdNode> nodes((size_t)n_cells);
-    FY_HIP(hipMemcpyAsync(nodes.data(), d_tree.p, nodes.size() * sizeof(KdNode), hipMemcpyDeviceToHost, stream));
-    FY_HIP(hipStreamSynchronize(stream));
-    for (int32_t c = 0; c < n_cells; ++c) out[c] = nodes[(size_t)c].id;
+    std::memcpy(out, h_tree_pre.data(), h_tree_pre.size() * sizeof(int32_t));
     return FY_OK;
 }
 

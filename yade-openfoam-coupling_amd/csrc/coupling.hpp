@@ -64,6 +64,7 @@ struct Coupling {
     ImplicitGeom implicit{};
     bool use_implicit = false;
     int tree_levels = 0;
+    std::vector<int32_t> h_tree_pre;     // preorder cell ids (host copy; fy_get_tree_preorder, tree cache)
     DevBuf<double> d_vol;
     fy_field_ptrs fields{};
     bool fields_on_host = false;

@@ -162,7 +162,7 @@ __device__ __forceinline__ NodeVal fetch_node(const KdNode* __restrict__ tree, c
     NodeVal v;
     if constexpr (IMPLICIT) {
         const uint32_t q = packed[o];
-        const int i = (int)(q & 1023u), j = (int)((q >> 10) & 1023u), k = (int)(q >> 20);
+        const int i = (int)(q & 1023u), j = (int)((q >> 10) & 1023u), k = (int)(q >> 20);     // 10 + 10 + 12 bits
         v.x = ig.ox + ((double)i + 0.5) * ig.dx;
         v.y = ig.oy + ((double)j + 0.5) * ig.dx;
         v.z = ig.oz + ((double)k + 0.5) * ig.dx;
@@ -189,7 +189,8 @@ constexpr int kLocRefill = FY_LOC_REFILL;    // refill once this many lanes are 
 // NOT stored; the entry carries the parent's 10-bit lattice index along the split axis and df2 = (o + (idx + 0.5) dx - q)^2 is
 // recomputed at pop time with the same IEEE operations, bit for bit.  Halving the entry doubles the waves a CU can hold
 // (LDS: levels x 64 lanes x entry), and this kernel is latency bound.
-//   implicit entry: bits 0..25 far offset | 26..51 far size | 52..53 axis of the far child | 54..63 parent index on the split axis
+//   implicit entry: bits 0..24 far offset | 25..49 far size | 50..51 axis of the far child | 52..63 parent index on the split axis
+//   (offsets and sizes < 2^25 = 33.5 M nodes, lattice index < 4096: covers the 32.8 M-cell C5 block and 1280-plane weak-scaling boxes)
 template <bool IMPLICIT> struct StackEntry;
 template <> struct StackEntry<false> { typedef uint4 type; };
 template <> struct StackEntry<true> { typedef unsigned long long type; };
@@ -249,8 +250,8 @@ __global__ __launch_bounds__(kWave) void k_locate(const KdNode* __restrict__ tre
                     double df2;
                     uint32_t eo, en, ea;
                     if constexpr (IMPLICIT) {
-                        eo = (uint32_t)(e & 0x3ffffffull); en = (uint32_t)((e >> 26) & 0x3ffffffull); ea = (uint32_t)((e >> 52) & 3ull);
-                        const int idx = (int)(e >> 54);
+                        eo = (uint32_t)(e & 0x1ffffffull); en = (uint32_t)((e >> 25) & 0x1ffffffull); ea = (uint32_t)((e >> 50) & 3ull);
+                        const int idx = (int)(e >> 52);
                         const uint32_t pa = (ea == 0 ? 2u : ea - 1u);               // the parent's split axis
                         const double org = (pa == 0 ? ig.ox : (pa == 1 ? ig.oy : ig.oz));
                         const double qq = (pa == 0 ? qx : (pa == 1 ? qy : qz));
@@ -301,7 +302,7 @@ __global__ __launch_bounds__(kWave) void k_locate(const KdNode* __restrict__ tre
                 if (far_n > 0 && df2 < best) {
                     if constexpr (IMPLICIT) {
                         const unsigned long long idx = (paxis == 0 ? (pk & 1023u) : (paxis == 1 ? ((pk >> 10) & 1023u) : (pk >> 20)));
-                        STK(sp) = (unsigned long long)far_o | ((unsigned long long)far_n << 26) | ((unsigned long long)axis << 52) | (idx << 54);
+                        STK(sp) = (unsigned long long)far_o | ((unsigned long long)far_n << 25) | ((unsigned long long)axis << 50) | (idx << 52);
                     } else {
                         uint4 e;
                         e.x = far_o; e.y = far_n | (axis << 30);
@@ -667,7 +668,7 @@ int launch_locate(hipStream_t s, const KdNode* tree, const uint32_t* packed, Imp
                   ParticleSoA p, int64_t n, GaussParams gp) {
     if (n <= 0) return FY_OK;
     // implicit entries are 8 B (needs offsets and sizes < 2^26), explicit ones 16 B
-    if (packed && n_cells >= (1 << 26)) return fail(FY_ERR_UNSUPPORTED, "implicit-coordinate tree limited to 2^26 cells");
+    if (packed && n_cells >= (1 << 25)) return fail(FY_ERR_UNSUPPORTED, "implicit-coordinate tree limited to 2^25 cells");
     const size_t lds = (size_t)(levels + 1) * kWave * (packed ? sizeof(unsigned long long) : sizeof(uint4));
     const dim3 grid(div_up(n, kLocPPB));
     if (packed) hipLaunchKernelGGL(k_locate<true>, grid, dim3(kWave), lds, s, tree, packed, ig, n_cells, p, n, gp.maxdist);
