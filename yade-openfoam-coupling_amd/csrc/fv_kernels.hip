@@ -74,7 +74,7 @@ __device__ __forceinline__ void block_reduce_store(double (&v)[N], const int (&i
         const int q = threadIdx.x;
         double x = sh[0][q];
         for (int w = 1; w < 4; ++w) x = is_max[q] ? fmax(x, sh[w][q]) : x + sh[w][q];
-        partials[(size_t)q * kRedBlocks + blockIdx.x] = x;
+        partials[(size_t)q * gridDim.x + blockIdx.x] = x;
     }
 }
 
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void k_reduce_finalize(const double* __restric
     const int mx = ops ? ops[slot] : 0;
     double x = mx ? -1e300 : 0.0;
     for (int b = threadIdx.x; b < nblocks; b += 256) {
-        const double y = partials[(size_t)slot * kRedBlocks + b];
+        const double y = partials[(size_t)slot * nblocks + b];
         x = mx ? fmax(x, y) : x + y;
     }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -103,9 +103,10 @@ __global__ __launch_bounds__(256) void k_reduce_finalize(const double* __restric
     }
 }
 
-// every reducing kernel runs with exactly kRedBlocks blocks (grid-stride), so each slot always has kRedBlocks valid partials
-// and the fold order -- hence the result -- is fixed from run to run
-inline int red_grid(size_t) { return kRedBlocks; }
+// Reducing kernels: one thread per cell (like the plain stencil kernels -- a 1024-block grid-stride loop reached only ~3 TB/s where
+// the one-thread-per-cell smoother reaches 5.4), XCD-aware block order, one partial per block; k_reduce_finalize folds the
+// red_blocks(n) partials of a slot in a fixed order, so results are reproducible from run to run.
+#define FY_RED_LOOP(t, n) const int t = swz_block(blockIdx.x, gridDim.x) * 256 + (int)threadIdx.x; if (t < (n))
 
 // ------------------------------------------------------------------------------------------------ face kernels
 // generic face iteration: thread -> (d fixed per launch, face index f) -> local (i,j,k) of the face
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(256) void k_flux_correct(FvGeo g, const double* __r
 // CourantNo.H:32-49: sumPhi = fvc::surfaceSum(mag(phi)); slots: 0 = max(sumPhi/V), 1 = sum(sumPhi)
 __global__ __launch_bounds__(256) void k_courant(FvGeo g, CFace3 phi, double* __restrict__ partials) {
     double v[2] = {0.0, 0.0};
-    for (int t = blockIdx.x * 256 + threadIdx.x; t < g.Nc; t += gridDim.x * 256) {
+    FY_RED_LOOP(t, g.Nc) {
         int i, j, k; ijk_of(g, t, i, j, k);
         double s = 0.0;
 #pragma unroll
@@ -421,7 +422,7 @@ __global__ __launch_bounds__(256) void k_mom_pass(FvGeo g, Mom7 M, const double*
                                                   double* __restrict__ xn, const double* __restrict__ xbar, double* __restrict__ partials) {
     double v[6] = {0, 0, 0, 0, 0, 0};
     const double xb[3] = {xbar[0], xbar[1], xbar[2]};
-    for (int t = blockIdx.x * 256 + threadIdx.x; t < g.Nc; t += gridDim.x * 256) {
+    FY_RED_LOOP(t, g.Nc) {
         int i, j, k; ijk_of(g, t, i, j, k);
         const int c = t + g.c0;
         const double dg = M.diag[c];
@@ -452,7 +453,7 @@ __global__ __launch_bounds__(256) void k_mom_pass(FvGeo g, Mom7 M, const double*
 // component sums over a contiguous range of n vectors starting at x
 __global__ __launch_bounds__(256) void k_sum3(const double* __restrict__ x, int n, double* __restrict__ partials) {
     double v[3] = {0, 0, 0};
-    for (int c = blockIdx.x * 256 + threadIdx.x; c < n; c += gridDim.x * 256)
+    FY_RED_LOOP(c, n)
         for (int q = 0; q < 3; ++q) v[q] += x[3 * (size_t)c + q];
     const int mx[3] = {0, 0, 0};
     block_reduce_store<3>(v, mx, partials);
@@ -527,7 +528,7 @@ __global__ __launch_bounds__(256) void k_p_ghost_uz(FvGeo g, CFace3 rAUf, CFace3
 __global__ __launch_bounds__(256) void k_cont_err(FvGeo g, CFace3 phi, CFace3 alphaf, const double* __restrict__ alpha,
                                                   const double* __restrict__ alphaOld, double* __restrict__ partials) {
     double v[2] = {0, 0};
-    for (int t = blockIdx.x * 256 + threadIdx.x; t < g.Nc; t += gridDim.x * 256) {
+    FY_RED_LOOP(t, g.Nc) {
         int i, j, k; ijk_of(g, t, i, j, k);
         const int c = t + g.c0;
         double dv = 0;
@@ -611,7 +612,7 @@ __global__ __launch_bounds__(256) void k_p_apply(PMat A, const double* __restric
 
 __global__ __launch_bounds__(256) void k_p_apply_dot(PMat A, const double* __restrict__ x, double* __restrict__ y, double* __restrict__ partials) {
     double v[1] = {0};
-    for (int t = blockIdx.x * 256 + threadIdx.x; t < A.N; t += gridDim.x * 256) {
+    FY_RED_LOOP(t, A.N) {
         const int c = t + A.c0;
         const double a = p_row(A, x, c);
         y[c] = a;
@@ -626,7 +627,7 @@ __global__ __launch_bounds__(256) void k_p_init(PMat A, const double* __restrict
                                                 double inv_n, double* __restrict__ r, double* __restrict__ partials) {
     double v[2] = {0, 0};
     const double xbar = xbar_dev[0] * inv_n;
-    for (int t = blockIdx.x * 256 + threadIdx.x; t < A.N; t += gridDim.x * 256) {
+    FY_RED_LOOP(t, A.N) {
         const int c = t + A.c0;
         const double Ax = p_row(A, x, c);
         const double Aref = p_rowsum(A, c) * xbar;
@@ -642,7 +643,7 @@ __global__ __launch_bounds__(256) void k_p_init(PMat A, const double* __restrict
 // dot product / plain sum over the owned range [c0, c0 + n) of arrays given by their storage base
 __global__ __launch_bounds__(256) void k_dot(int n, int c0, const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ partials) {
     double v[1] = {0};
-    for (int t = blockIdx.x * 256 + threadIdx.x; t < n; t += gridDim.x * 256) v[0] += a[t + c0] * (b ? b[t + c0] : 1.0);
+    FY_RED_LOOP(t, n) v[0] += a[t + c0] * (b ? b[t + c0] : 1.0);
     const int mx[1] = {0};
     block_reduce_store<1>(v, mx, partials);
 }
@@ -660,7 +661,7 @@ __global__ __launch_bounds__(256) void k_pcg_update_xr(int n, int c0, double* __
                                                        const double* __restrict__ w, const double* __restrict__ sc, double* __restrict__ partials) {
     double v[1] = {0};
     const double al = sc[0] / sc[2];
-    for (int t = blockIdx.x * 256 + threadIdx.x; t < n; t += gridDim.x * 256) {
+    FY_RED_LOOP(t, n) {
         const int c = t + c0;
         x[c] += al * p[c];
         const double rr = r[c] - al * w[c];
@@ -791,10 +792,8 @@ __global__ __launch_bounds__(256) void k_add(double* __restrict__ y, const doubl
 
 }  // namespace
 
-static const int g_last_red_blocks = kRedBlocks;
-
-int launch_reduce_finalize(hipStream_t s, const double* partials, int nslots, const int* ops, double* out) {
-    hipLaunchKernelGGL(k_reduce_finalize, dim3(nslots), dim3(256), 0, s, partials, g_last_red_blocks, ops, out);
+int launch_reduce_finalize(hipStream_t s, const double* partials, int n_cells, int nslots, const int* ops, double* out) {
+    hipLaunchKernelGGL(k_reduce_finalize, dim3(nslots), dim3(256), 0, s, partials, red_blocks(n_cells), ops, out);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }
@@ -808,7 +807,7 @@ int launch_flux_of(hipStream_t s, FvGeo g, const double* F, Face3 out) {
 }
 
 int launch_courant(hipStream_t s, FvGeo g, CFace3 phi, double* partials) {
-    hipLaunchKernelGGL(k_courant, dim3(g_last_red_blocks), dim3(256), 0, s, g, phi, partials);
+    hipLaunchKernelGGL(k_courant, dim3(red_blocks(g.Nc)), dim3(256), 0, s, g, phi, partials);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }
@@ -872,13 +871,13 @@ int launch_bmom(hipStream_t s, FvGeo g, const double* src, const double* p, CFac
 }
 
 int launch_mom_pass(hipStream_t s, FvGeo g, Mom7 M, const double* b, const double* x, double* xn, const double* xbar, double* partials) {
-    hipLaunchKernelGGL(k_mom_pass, dim3(g_last_red_blocks), dim3(256), 0, s, g, M, b, x, xn, xbar, partials);
+    hipLaunchKernelGGL(k_mom_pass, dim3(red_blocks(g.Nc)), dim3(256), 0, s, g, M, b, x, xn, xbar, partials);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }
 
 int launch_sum3(hipStream_t s, const double* x, int n, double* partials) {
-    hipLaunchKernelGGL(k_sum3, dim3(g_last_red_blocks), dim3(256), 0, s, x, n, partials);
+    hipLaunchKernelGGL(k_sum3, dim3(red_blocks(n)), dim3(256), 0, s, x, n, partials);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }
@@ -914,7 +913,7 @@ int launch_flux_correct(hipStream_t s, FvGeo g, const double* p, CFace3 phiHbyA,
 }
 
 int launch_cont_err(hipStream_t s, FvGeo g, CFace3 phi, CFace3 alphaf, const double* alpha, const double* alphaOld, double* partials) {
-    hipLaunchKernelGGL(k_cont_err, dim3(g_last_red_blocks), dim3(256), 0, s, g, phi, alphaf, alpha, alphaOld, partials);
+    hipLaunchKernelGGL(k_cont_err, dim3(red_blocks(g.Nc)), dim3(256), 0, s, g, phi, alphaf, alpha, alphaOld, partials);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }
@@ -933,19 +932,19 @@ int launch_p_apply(hipStream_t s, PMat A, const double* x, double* y) {
 }
 
 int launch_p_apply_dot(hipStream_t s, PMat A, const double* x, double* y, double* partials) {
-    hipLaunchKernelGGL(k_p_apply_dot, dim3(g_last_red_blocks), dim3(256), 0, s, A, x, y, partials);
+    hipLaunchKernelGGL(k_p_apply_dot, dim3(red_blocks(A.N)), dim3(256), 0, s, A, x, y, partials);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }
 
 int launch_p_init(hipStream_t s, PMat A, const double* b, const double* x, const double* xsum_dev, double inv_n, double* r, double* partials) {
-    hipLaunchKernelGGL(k_p_init, dim3(g_last_red_blocks), dim3(256), 0, s, A, b, x, xsum_dev, inv_n, r, partials);
+    hipLaunchKernelGGL(k_p_init, dim3(red_blocks(A.N)), dim3(256), 0, s, A, b, x, xsum_dev, inv_n, r, partials);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }
 
 int launch_dot(hipStream_t s, int n, int c0, const double* a, const double* b, double* partials) {
-    hipLaunchKernelGGL(k_dot, dim3(g_last_red_blocks), dim3(256), 0, s, n, c0, a, b, partials);
+    hipLaunchKernelGGL(k_dot, dim3(red_blocks(n)), dim3(256), 0, s, n, c0, a, b, partials);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }
@@ -957,7 +956,7 @@ int launch_pcg_update_p(hipStream_t s, int n, int c0, const double* z, double* p
 }
 
 int launch_pcg_update_xr(hipStream_t s, int n, int c0, double* x, double* r, const double* p, const double* w, const double* sc, double* partials) {
-    hipLaunchKernelGGL(k_pcg_update_xr, dim3(g_last_red_blocks), dim3(256), 0, s, n, c0, x, r, p, w, sc, partials);
+    hipLaunchKernelGGL(k_pcg_update_xr, dim3(red_blocks(n)), dim3(256), 0, s, n, c0, x, r, p, w, sc, partials);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }

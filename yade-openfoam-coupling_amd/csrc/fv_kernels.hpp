@@ -40,14 +40,15 @@ struct PMat {
     double *diag, *ux, *uy, *uz;
 };
 
-constexpr int kRedBlocks = 1024;          // grid cap of the reduction kernels (partials per slot)
+// reducing kernels emit one partial per 256-cell block; the count is rounded up to a multiple of 8 for the XCD-aware block order
+inline int red_blocks(int n) { return (((n + 255) / 256) + 7) & ~7; }
 
 inline size_t fv_fsize(const FvGeo& g, int d) {
     return d == 0 ? (size_t)(g.nx + 1) * g.ny * g.nz : d == 1 ? (size_t)g.nx * (g.ny + 1) * g.nz : (size_t)g.nx * g.ny * (g.nz + 1);
 }
 
-// ---- reductions: kernels write per-block partials to scratch[slot*kRedBlocks + block]; finalize folds them in fixed order
-int launch_reduce_finalize(hipStream_t s, const double* partials, int nslots, const int* ops /*0 sum,1 max (device)*/, double* out);
+// ---- reductions: kernels over n cells write per-block partials to scratch[slot*red_blocks(n) + block]; finalize folds them in fixed order
+int launch_reduce_finalize(hipStream_t s, const double* partials, int n_cells, int nslots, const int* ops /*0 sum,1 max (device)*/, double* out);
 
 // ---- field operators
 int launch_flux_of(hipStream_t s, FvGeo g, const double* F, Face3 out);                                   // fvc::flux(F), createPhi

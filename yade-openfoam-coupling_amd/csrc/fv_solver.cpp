@@ -141,7 +141,7 @@ struct Solver {
         FY_TRY(launch_fill_f64(stream, alpha.p, n, 1.0));
         FY_TRY(launch_fill_f64(stream, alphaOld.p, n, 1.0));
         FY_TRY(launch_fill_f64(stream, rAU.p, n, 1.0));            // ghost planes must hold finite values before the first exchange
-        FY_TRY(partials.alloc_exact(8 * (size_t)kRedBlocks)); FY_TRY(red_out.alloc_exact(8)); FY_TRY(sc.alloc_exact(4)); FY_TRY(xbar3.alloc_exact(3));
+        FY_TRY(partials.alloc_exact(8 * (size_t)red_blocks(Nc))); FY_TRY(red_out.alloc_exact(8)); FY_TRY(sc.alloc_exact(4)); FY_TRY(xbar3.alloc_exact(3));
         FY_TRY(zero(partials)); FY_TRY(zero(sc)); FY_TRY(zero(red_out));
         FY_TRY(ops_courant.alloc_exact(2));
         { const int h[2] = {1, 0}; FY_HIP(hipMemcpyAsync(ops_courant.p, h, sizeof(h), hipMemcpyHostToDevice, stream)); FY_HIP(hipStreamSynchronize(stream)); }
@@ -228,7 +228,7 @@ struct Solver {
 
     // fold the block partials, all-reduce over the slabs, read back
     int reduce_read(int nslots, bool courant, double* h) {
-        FY_TRY(launch_reduce_finalize(stream, partials.p, nslots, courant ? ops_courant.p : nullptr, red_out.p));
+        FY_TRY(launch_reduce_finalize(stream, partials.p, Nc, nslots, courant ? ops_courant.p : nullptr, red_out.p));
         if (courant) { FY_TRY(comm->allreduce(stream, red_out.p, 1, true)); FY_TRY(comm->allreduce(stream, red_out.p + 1, 1, false)); }
         else FY_TRY(comm->allreduce(stream, red_out.p, nslots, false));
         FY_HIP(hipMemcpyAsync(h, red_out.p, nslots * sizeof(double), hipMemcpyDeviceToHost, stream));
@@ -236,7 +236,7 @@ struct Solver {
         return FY_OK;
     }
     int reduce_to_device(double* dst) {          // one slot, stays on the device (PCG scalars)
-        FY_TRY(launch_reduce_finalize(stream, partials.p, 1, nullptr, dst));
+        FY_TRY(launch_reduce_finalize(stream, partials.p, Nc, 1, nullptr, dst));
         return comm->allreduce(stream, dst, 1, false);
     }
 
