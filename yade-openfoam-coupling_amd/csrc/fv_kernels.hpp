@@ -92,6 +92,10 @@ int launch_mg_smooth(hipStream_t s, PMat A, const double* b, const double* x, do
 int launch_mg_residual_restrict(hipStream_t s, PMat A, const double* b, const double* x, PMat C, double* bc);   // bc = P^T (b - A x)
 int launch_mg_prolong_add(hipStream_t s, PMat A, double* x, PMat C, const double* xc);
 int launch_mg_coarse_solve(hipStream_t s, PMat A, const double* b, double* x, double* tmp, int sweeps, double w);
+// the whole V-cycle below a size threshold in one workgroup; level l result: x1[l] (x0 for the coarsest / a single-level tail)
+constexpr int kMgTailMax = 6;
+constexpr int kMgTailCells = 1024;   // measured: at 8000 cells one workgroup (137 us) is SLOWER than the ~20 separate launches it replaces
+int launch_mg_tail(hipStream_t s, const PMat* A, double* const* x0, double* const* x1, double* const* b, int n, double w, int coarse_sweeps);
 
 int launch_copy_f64(hipStream_t s, double* dst, const double* src, size_t n);
 // slab interfaces: coefficient of the z-face below the first owned plane, stored at the ghost cell under it (what p_row reads as uz[c - sz])

@@ -291,6 +291,18 @@ struct Solver {
     int vcycle(size_t l) {
         const double w = 0.8;
         MgLev& L = *mg[l];
+        if (!L.distributed && L.A.N <= kMgTailCells && mg.size() - l <= (size_t)kMgTailMax) {
+            // the rest of the hierarchy fits one workgroup: one launch instead of ~8 per level (b of this level is already in place)
+            PMat A[kMgTailMax]; double* x0[kMgTailMax]; double* x1[kMgTailMax]; double* b[kMgTailMax];
+            const int n = (int)(mg.size() - l);
+            for (int q = 0; q < n; ++q) {
+                MgLev& M = *mg[l + (size_t)q];
+                A[q] = M.A; x0[q] = M.x0.p; x1[q] = M.x1.p; b[q] = q == 0 ? const_cast<double*>(L.bptr) : M.b.p;
+            }
+            FY_TRY(launch_mg_tail(stream, A, x0, x1, b, n, w, 40));
+            L.xcur = n > 1 ? L.x1.p : L.x0.p; L.xalt = n > 1 ? L.x0.p : L.x1.p;
+            return FY_OK;
+        }
         if (l + 1 == mg.size()) {
             FY_TRY(launch_mg_coarse_solve(stream, L.A, L.bptr, L.x0.p, L.x1.p, 40, w));
             L.xcur = L.x0.p; L.xalt = L.x1.p;
