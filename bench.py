@@ -155,14 +155,14 @@ def main():
     for _ in range(args.warmup):
         solver.step()
     solver.enable_kernel_timing(True)
-    acc = dict(particle=0.0, locate=0.0, force=0.0, bin=0.0, momentum=0.0, pressure=0.0, other=0.0, p_iters=0, u_iters=0)
+    acc = dict(particle=0.0, locate=0.0, force=0.0, bin=0.0, depfin=0.0, momentum=0.0, pressure=0.0, other=0.0, p_iters=0, u_iters=0)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         solver.step()
         st = solver.stats(); ct = solver.coupling_timings()
         acc["particle"] += st["ms_particle"]; acc["momentum"] += st["ms_momentum"]; acc["pressure"] += st["ms_pressure"]; acc["other"] += st["ms_other"]
-        acc["locate"] += ct["locate_deposit"]; acc["force"] += ct["force"]; acc["bin"] += ct["bin"]
+        acc["locate"] += ct["locate_deposit"]; acc["force"] += ct["force"]; acc["bin"] += ct["bin"]; acc["depfin"] += ct["finalize"]
         acc["p_iters"] += st["p_iters_total"]; acc["u_iters"] += st["u_iters_total"]
     barrier()
     elapsed = time.perf_counter() - t0
@@ -176,17 +176,29 @@ def main():
     apply_ms, apply_n = solver.kernel_timing("p_apply_dot")
     mom_ms, mom_n = solver.kernel_timing("mom_pass")
     np_part = args.particles
+    dep_ms = max(acc["depfin"], 0.0)
     cand = {
-        # name: (total ms over the timed steps, launches, algorithmic bytes per launch, description)
-        # compulsory bytes (DESIGN.md "algorithmic bytes"): kbar = 5.46 stencil cells per particle, 12 B per (id, weight) pair
-        "k_locate_deposit": (acc["locate"], K, (60.0 + 12.0 * 5.46) * np_part + 65.0 * nc,
-                             "k-d locate + Gaussian weights + deposit: SoA particle 60 B, stencil out 12 B/pair, accumulators RMW 64 B/cell + flag"),
+        # name: (total ms over the timed steps, launches, algorithmic bytes per launch, description) -- DESIGN.md section 3;
+        # kbar = 5.46 stencil cells per particle, 12 B per (id, weight) pair
+        "k_locate": (acc["locate"], K, (24.0 + 4.0 + 12.0 * 5.46) * np_part,
+                     "k-d 'range' locate (improvement chain of one NN DFS): position 24 B in, chain length 4 B + 12 B/pair out; latency/issue bound, not HBM"),
+        "k_deposit+k_finalize_cells": (dep_ms, K, (60.0 + 2 * 12.0 * 5.46) * np_part + 65.0 * nc,
+                                       "Gaussian weights + void-fraction deposit (LDS-aggregated atomics) + alpha/uParticle finalize"),
         "k_force_gaussian": (acc["force"], K, (64.0 + 12.0 * 5.46 + 52.0) * np_part + 176.0 * nc,
                              "drag + Archimedes + back-scatter: particle 64 B + stencil 12 B/pair in, force 52 B out, cell fields 112 B read + 64 B RMW"),
         "k_mg_smooth(level 0)": (smooth_ms, smooth_n, 56.0 * nc, "pEqn Laplacian apply fused with the damped-Jacobi update: 48 B/cell (diag, 3 upper, x, y) + b 8"),
         "k_p_apply_dot": (apply_ms, apply_n, 48.0 * nc, "pEqn Laplacian apply y = A p (+ p.Ap) inside PCG: 48 B/cell"),
         "k_mom_pass": (mom_ms, mom_n, (7 * 8 + 24 * 3) * nc, "fused momentum Jacobi pass: 7 coeffs + b,x,xn (3 comps)"),
     }
+    # HBM traffic per launch from the committed PMC passes of this same command (tools/pmc_traffic.py; null if absent)
+    traffic = {}
+    for cand_file in sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1:]:
+        try:
+            traffic = {k: v.get("hbm_bytes_per_launch") for k, v in json.load(open(cand_file))["kernels"].items()}
+        except Exception:
+            traffic = {}
+    if not (args.n == 160 and args.particles == 10_000_000 and world == 1):
+        traffic = {}            # the PMC passes were taken on the default single-GPU workload only
     for nm, (ms, nl, bytes_per, desc) in cand.items():
         if nl:
             avg = ms / nl
@@ -197,7 +209,7 @@ def main():
     def roof(name):
         k = kern[name]
         return {"kernel": name, "bound": "hbm", "achieved": round(k["achieved_GBps"], 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(k["achieved_GBps"] / HBM_PEAK_GBPS, 4), "traffic": None, "avg_launch_ms": round(k["avg_ms"], 4),
+                "frac": round(k["achieved_GBps"] / HBM_PEAK_GBPS, 4), "traffic": traffic.get(name.split("+")[0]), "avg_launch_ms": round(k["avg_ms"], 4),
                 "launches": k["launches"], "algorithmic_bytes_per_launch": k["alg_bytes"], "what": k["what"]}
 
     out = {
@@ -215,7 +227,7 @@ def main():
                    "p_tol": [case.p_tol, case.p_rel_tol, case.p_final_tol, case.p_final_rel_tol],
                    "parallelism": "single GPU" if world == 1 else f"{world} z-slabs of one {args.n}x{args.n}x{args.n * world} box, RCCL halos + all-reduces over xGMI",
                    "global_cells": nc * world, "global_particles": np_part * world},
-        "per_step_ms": {k: round(acc[k] / K, 3) for k in ("particle", "bin", "locate", "force", "momentum", "pressure", "other")},
+        "per_step_ms": {k: round(acc[k] / K, 3) for k in ("particle", "bin", "locate", "depfin", "force", "momentum", "pressure", "other")},
         "p_iters_per_step": acc["p_iters"] / K, "u_iters_per_step": acc["u_iters"] / K,
         "roofline": roof(dominant) if dominant else None,
         "roofline_pEqn_laplacian": roof(lap) if lap in kern else None,
