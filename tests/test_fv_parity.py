@@ -107,3 +107,49 @@ def test_coupled_steps_match_oracle(product, oracle, solver):
         assert np.abs(fs - fo).max() <= 1e-6 * sc, np.abs(fs - fo).max() / sc
     compare(o, s, rtol=1e-5)
     assert np.abs(s.get("U")).max() > 0
+
+
+def test_c2_channel_inlet_outlet_point_force(product, oracle):
+    """BASELINE configs[1] in miniature: icoFoamYade point force in a channel -- inlet fixedValue U = (1,0,0), outlet zeroGradient U
+    with p = 0, no-slip walls"""
+    nx, ny, nz = 24, 12, 6
+    dx = 2.0 / 200 * (200 / nx) / 1.0 * 0.1
+    u_bc = [0, 1, 0, 0, 0, 0]
+    u_val = [(1.0, 0, 0)] + [(0, 0, 0)] * 5
+    p_bc = [0, 1, 0, 0, 0, 0]
+    o, s = both(product, oracle, 0, nx, ny, nz, dx, 0.2 * dx, 1e-3, u_bc=u_bc, u_val=u_val, p_bc=p_bc, p_val=[0.0] * 6)
+    case = gc.Case("c2", nx, ny, nz, nx * dx, gaussian=0, np_=2000, seed=2, radius_dx=0.15, vel_scale=0.2)
+    for step in range(4):
+        rec = gc.particle_records(case, step)
+        fo = o.step(rec)["force"]
+        s.set_particles(rec); s.step()
+        sc = np.abs(fo).max()
+        assert np.abs(s.forces() - fo).max() <= 1e-6 * sc
+    compare(o, s, rtol=1e-5)
+    U = s.get("U").reshape(nz, ny, nx, 3)
+    assert U[nz // 2, ny // 2, :, 0].min() > 0.5            # the inflow has filled the channel
+
+
+def test_c5_fluidized_bed_bcs(product, oracle):
+    """BASELINE configs[4] in miniature: pimpleFoamYade 4-way, bottom inlet fixedValue U = (0,0,Uin), top outlet p = 0 with
+    zeroGradient U, no-slip side walls, gravity, dense particle layer in the lower third"""
+    n, nz = 10, 20
+    dx = 0.05 / n
+    u_bc = [0, 0, 0, 0, 0, 1]
+    u_val = [(0, 0, 0)] * 4 + [(0, 0, 0.05)] + [(0, 0, 0)]
+    p_bc = [2, 2, 2, 2, 2, 1]
+    o, s = both(product, oracle, 1, n, n, nz, dx, 1e-4, 1e-5, g=(0, 0, -9.81), u_bc=u_bc, u_val=u_val, p_bc=p_bc, p_val=[0.0] * 6)
+    rs = np.random.RandomState(5)
+    npart = 4000
+    rec = np.zeros((npart, 10))
+    rec[:, 0:2] = rs.random_sample((npart, 2)) * n * dx
+    rec[:, 2] = rs.random_sample(npart) * (nz * dx / 3.0)
+    rec[:, 3:6] = (rs.random_sample((npart, 3)) - 0.5) * 0.02
+    rec[:, 9] = 0.2 * dx
+    for step in range(3):
+        fo = o.step(rec)["force"]
+        s.set_particles(rec); s.step()
+        sc = np.abs(fo).max()
+        assert np.abs(s.forces() - fo).max() <= 1e-6 * sc
+    compare(o, s, rtol=1e-5)
+    assert np.abs(fo).max() > 0 and np.abs(s.get("U")).max() > 0       # (alpha itself is reset by setSourceZero at the end of a step)

@@ -22,25 +22,13 @@ namespace {
 
 constexpr int kWave = 64;
 
-// Block order.  An XCD-aware remap (guide T1: block b runs on XCD b % 8, give each XCD a contiguous run of the binned
-// particle order) was measured on MI355X and LOSES here: locate+deposit 14.5 -> 16.1 ms, force 10.0 -> 10.8 ms at 10 M
-// particles, because the FP64 atomics of a spatially compact run pile onto few memory channels.  Round-robin stays.
-#if defined(FY_EXP_SWZ)
-__device__ __forceinline__ int64_t swz_block(int64_t bid, int64_t nblk) { return (bid % 8) * (nblk / 8) + bid / 8; }
-#define FY_BLOCK(b, n) swz_block((b), (n))
-#else
-#define FY_BLOCK(b, n) (b)
-#endif
+// Block order: plain round-robin.  An XCD-aware remap (guide T1: block b runs on XCD b % 8, give each XCD a contiguous run of the
+// binned particle order) was measured on MI355X and LOSES for the particle kernels: locate+deposit 14.5 -> 16.1 ms, force 10.0 ->
+// 10.8 ms at 10 M particles, because the FP64 atomics of a spatially compact run pile onto few memory channels.
 
 __device__ __forceinline__ void atomic_add_f64(double* p, double v) {
-#if defined(FY_EXP_NO_ATOMICS)
-    if (v == 1.2345e300) *p = v;     // experiment build: keep the operands live, issue nothing
-#elif defined(FY_EXP_L2_ATOMICS)
-    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // timing experiment only
-#else
-    // global_atomic_add_f64, no return value, device (agent) scope
+    // global_atomic_add_f64, no return value, device (agent) scope.  (Workgroup-scope atomics were measured: no faster.)
     unsafeAtomicAdd(p, v);
-#endif
 }
 
 // ------------------------------------------------------------------------------------------------ binning
