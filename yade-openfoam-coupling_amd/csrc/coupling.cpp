@@ -197,6 +197,7 @@ int Coupling::create(const fy_mesh_desc* m, const fy_field_ptrs* f, int gaussian
         FY_TRY(d_tile_sums.alloc_exact((bins.nkeys + 2047u) / 2048u + 1));
     }
     for (auto& t : timers) FY_TRY(t.init());
+    if (const char* e = getenv("FOAMYADE_REBIN_INTERVAL")) rebin_interval = std::max(1, atoi(e));
 
     // ---- parallel Yade: yadeProcs + sendMeshBbox, FoamYade.C:35-45,77-111
     if (has_transport && !serial_yade) {
@@ -274,6 +275,7 @@ int Coupling::ensure_batch(Batch& b, int64_t n) {
             FY_TRY(b.ids.alloc_exact((size_t)kMaxK * c2)); FY_TRY(b.w.alloc_exact((size_t)kMaxK * c2));
             FY_TRY(b.key.alloc_exact(c2)); FY_TRY(b.rank.alloc_exact(c2));
             b.cap = c2;
+            b.binned_n = -1;          // fresh arrays: the old placement is gone
         }
     } else {
         FY_TRY(b.incell.reserve(cap));
@@ -312,10 +314,19 @@ int Coupling::run_batch(Batch& b) {
     if (gaussian) {
         ParticleSoA p = soa_of(b);
         if (timing) timers[T_BIN].start(stream);
-        FY_HIP(hipMemsetAsync(d_hist.p, 0, (size_t)bins.nkeys * sizeof(uint32_t), stream));
-        FY_TRY(launch_bin_count(stream, b.d_rec, b.n, bins, b.key.p, b.rank.p, d_hist.p));
-        FY_TRY(launch_exclusive_scan_u32(stream, d_hist.p, bins.nkeys, d_tile_sums.p));
-        FY_TRY(launch_bin_scatter(stream, b.d_rec, b.n, b.key.p, b.rank.p, d_hist.p, d_tile_sums.p, p));
+        // The binned order only buys locality -- every result is independent of it -- and particles move a fraction of a cell per
+        // coupling step, so the placement of an earlier step stays nearly as good: the counting sort runs every rebin_interval
+        // steps (or when the particle count changes), in between the records are just gathered through the old permutation.
+        if (b.binned_n != b.n || b.bin_age >= rebin_interval) {
+            FY_HIP(hipMemsetAsync(d_hist.p, 0, (size_t)bins.nkeys * sizeof(uint32_t), stream));
+            FY_TRY(launch_bin_count(stream, b.d_rec, b.n, bins, b.key.p, b.rank.p, d_hist.p));
+            FY_TRY(launch_exclusive_scan_u32(stream, d_hist.p, bins.nkeys, d_tile_sums.p));
+            FY_TRY(launch_bin_scatter(stream, b.d_rec, b.n, b.key.p, b.rank.p, d_hist.p, d_tile_sums.p, p));
+            b.binned_n = b.n; b.bin_age = 1;
+        } else {
+            FY_TRY(launch_bin_gather(stream, b.d_rec, b.n, p));
+            ++b.bin_age;
+        }
         if (timing) { timers[T_BIN].stop(stream); timers[T_LOCATE].start(stream); }
         GaussParams gp;
         gp.maxdist = (interp_range * interp_range) + (0.25 * interp_range * interp_range);   // meshTree.C:155

@@ -22,6 +22,8 @@ struct Batch {
     DevBuf<int32_t> orig, chain, ids, found, incell;
     DevBuf<double> w, force;
     DevBuf<uint32_t> key, rank;
+    int64_t binned_n = -1;               // particle count the current placement (orig) was computed for
+    int bin_age = 0;                     // steps since it was computed
     std::vector<double> h_rec, h_force;  // wire staging
     std::vector<int32_t> h_found;
 };
@@ -74,6 +76,7 @@ struct Coupling {
     DevBuf<double> d_pvol_acc, d_up_acc;           // per-batch deposit accumulators (pVolContrib / uParticleContrib)
     DevBuf<unsigned char> d_touched;
     BinGrid bins{};
+    int rebin_interval = 8;              // full counting sort every this many steps (FOAMYADE_REBIN_INTERVAL; 1 = every step)
     DevBuf<uint32_t> d_hist, d_tile_sums;
     std::vector<Batch*> batches;
     int n_batches = 0;

@@ -655,6 +655,13 @@ int launch_bin_scatter(hipStream_t s, const double* rec, int64_t n, const uint32
     return FY_OK;
 }
 
+int launch_bin_gather(hipStream_t s, const double* rec, int64_t n, ParticleSoA p) {
+    if (n <= 0) return FY_OK;
+    hipLaunchKernelGGL(k_bin_gather, dim3(div_up(n, 256)), dim3(256), 0, s, rec, n, p);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+
 int launch_locate(hipStream_t s, const KdNode* tree, const uint32_t* packed, ImplicitGeom ig, int32_t n_cells, int levels,
                   ParticleSoA p, int64_t n, GaussParams gp) {
     if (n <= 0) return FY_OK;

@@ -51,6 +51,8 @@ struct ImplicitGeom {
     double ox, oy, oz, dx;
     int nx, ny;
 };
+// re-use the placement (p.orig) of an earlier step: only gather the records into the SoA arrays
+int launch_bin_gather(hipStream_t s, const double* rec, int64_t n, ParticleSoA p);
 // packed == nullptr selects the explicit 32-byte-node path.  Leaves chain ids and squared distances (in the weight slots).
 int launch_locate(hipStream_t s, const KdNode* tree, const uint32_t* packed, ImplicitGeom ig, int32_t n_cells, int levels,
                   ParticleSoA p, int64_t n, GaussParams gp);
