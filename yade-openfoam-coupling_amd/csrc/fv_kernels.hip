@@ -255,15 +255,20 @@ __global__ __launch_bounds__(256) void k_courant(FvGeo g, CFace3 phi, double* __
 
 // vGrad = fvc::grad(U) (icoFoamYade.C:71, pimpleFoamYade.C:76); pimple also gradP = fvc::grad(p) (:74) and
 // divT = 2 nu fvc::laplacian(alphac, Uc) (:75)
+// In pimple mode the only consumer of grad(U) is the explicit stress term of divDevRhoReff (the Gaussian torque that would read vGrad
+// is disabled in the reference, FoamYade.C:618), so the kernel can emit G = alpha nu dev2(T(grad U)) directly (Gout != nullptr) and
+// skip the 72 B/cell vGrad store (write_vgrad = 0): one stencil pass instead of two plus a tensor round trip through HBM.
 __global__ __launch_bounds__(256) void k_pre_coupling(FvGeo g, const double* __restrict__ U, const double* __restrict__ p,
                                                       const double* __restrict__ alpha, CFace3 psn, double* __restrict__ vGrad,
-                                                      double* __restrict__ gradP, double* __restrict__ divT) {
+                                                      double* __restrict__ gradP, double* __restrict__ divT, double* __restrict__ Gout,
+                                                      int write_vgrad, int write_pfields) {
     const int t = swz_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
     if (t >= g.Nc) return;
     int i, j, k; ijk_of(g, t, i, j, k);
     const int c = t + g.c0;
+    const bool pf = g.pimple && write_pfields;          // gradP and divT wanted
     const double uc[3] = {U[3 * (size_t)c], U[3 * (size_t)c + 1], U[3 * (size_t)c + 2]};
-    double lap[3] = {0, 0, 0};
+    double lap[3] = {0, 0, 0}, T[9];
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
         double fv[2][3], fp[2] = {0, 0};
@@ -271,7 +276,7 @@ __global__ __launch_bounds__(256) void k_pre_coupling(FvGeo g, const double* __r
         for (int s = 0; s < 2; ++s) {
             if (onb(g, d, s, i, j, k)) {
                 Ub(g, U, c, 2 * d + s, fv[s]);
-                if (g.pimple) {
+                if (pf) {
                     fp[s] = pbv(g, p, psn, c, d, s, cface(g, d, s, i, j, k));
                     for (int q = 0; q < 3; ++q) lap[q] += 1.0 * g.Af * (fv[s][q] - uc[q]) / (0.5 * g.dx);     // alphaf = 1 on the boundary
                 }
@@ -279,18 +284,26 @@ __global__ __launch_bounds__(256) void k_pre_coupling(FvGeo g, const double* __r
                 const int nb = c + (s ? stride_of(g, d) : -stride_of(g, d));
                 const double un[3] = {U[3 * (size_t)nb], U[3 * (size_t)nb + 1], U[3 * (size_t)nb + 2]};
                 for (int q = 0; q < 3; ++q) fv[s][q] = 0.5 * (uc[q] + un[q]);
-                if (g.pimple) {
+                if (pf) {
                     fp[s] = 0.5 * (p[c] + p[nb]);
                     const double af = 0.5 * (alpha[c] + alpha[nb]);
                     for (int q = 0; q < 3; ++q) lap[q] += af * g.Af * (un[q] - uc[q]) / g.dx;
                 }
             }
         }
-        for (int q = 0; q < 3; ++q) vGrad[9 * (size_t)c + 3 * d + q] = (fv[1][q] - fv[0][q]) / g.dx;
-        if (g.pimple) gradP[3 * (size_t)c + d] = (fp[1] - fp[0]) / g.dx;
+        for (int q = 0; q < 3; ++q) T[3 * d + q] = (fv[1][q] - fv[0][q]) / g.dx;
+        if (pf) gradP[3 * (size_t)c + d] = (fp[1] - fp[0]) / g.dx;
     }
-    if (g.pimple)
+    if (write_vgrad)
+        for (int q = 0; q < 9; ++q) vGrad[9 * (size_t)c + q] = T[q];
+    if (pf)
         for (int q = 0; q < 3; ++q) divT[3 * (size_t)c + q] = 2 * g.nu * (lap[q] / g.V);
+    if (Gout) {
+        const double tr = T[0] + T[4] + T[8];
+        const double an = alpha[c] * g.nu;
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) Gout[9 * (size_t)c + 3 * a + b] = an * (T[3 * b + a] - (a == b ? (2.0 / 3.0) * tr : 0.0));
+    }
 }
 
 // explicit part of divDevRhoReff (laminar Stokes): G = alpha nu dev2(T(grad U))
@@ -921,8 +934,8 @@ int launch_courant(hipStream_t s, FvGeo g, CFace3 phi, double* partials) {
 }
 
 int launch_pre_coupling(hipStream_t s, FvGeo g, const double* U, const double* p, const double* alpha, CFace3 psn, double* vGrad,
-                        double* gradP, double* divT) {
-    hipLaunchKernelGGL(k_pre_coupling, dim3(div_up(g.Nc, 256)), dim3(256), 0, s, g, U, p, alpha, psn, vGrad, gradP, divT);
+                        double* gradP, double* divT, double* Gout, int write_vgrad, int write_pfields) {
+    hipLaunchKernelGGL(k_pre_coupling, dim3(div_up(g.Nc, 256)), dim3(256), 0, s, g, U, p, alpha, psn, vGrad, gradP, divT, Gout, write_vgrad, write_pfields);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }

@@ -442,7 +442,9 @@ struct Solver {
         FY_TRY(halo_cells(alpha, 1, 1));
         FY_TRY(launch_copy_f64(stream, Uold.p, U.p, 3 * nstore));
         for (int d = 0; d < 3; ++d) FY_TRY(launch_copy_f64(stream, phiOld[d].p, phi[d].p, phi[d].n));
-        FY_TRY(launch_pre_coupling(stream, g, U.p, p.p, alpha.p, C3(psn), vGrad.p, gradP.p, divT.p));   // icoFoamYade.C:71, pimpleFoamYade.C:73-76
+        // icoFoamYade.C:71, pimpleFoamYade.C:73-76.  pimple: alpha is 1 here (reset by setSourceZero), so G is re-formed after the
+        // coupling call with this step's alpha; only gradP / divT are needed now.
+        FY_TRY(launch_pre_coupling(stream, g, U.p, p.p, alpha.p, C3(psn), vGrad.p, gradP.p, divT.p, nullptr, pimple ? 0 : 1, 1));
 
         if (timing) tim[0].start(stream);
         if (g.gz > 1) {                      // the particle gathers reach gz planes into the neighbours
@@ -459,8 +461,9 @@ struct Solver {
         for (int outer = 0; outer < nOuter; ++outer) {
             if (timing) tim[1].start(stream);
             if (pimple) {
-                if (outer > 0) { FY_TRY(halo_cells(U, 3, 1)); FY_TRY(launch_pre_coupling(stream, g, U.p, p.p, alpha.p, C3(psn), vGrad.p, gradP.p, divT.p)); }
-                FY_TRY(launch_stress_G(stream, g, vGrad.p, alpha.p, Gt.p));
+                // explicit stress term of divDevRhoReff from the CURRENT U and this step's alpha (one fused stencil pass)
+                if (outer > 0) FY_TRY(halo_cells(U, 3, 1));
+                FY_TRY(launch_pre_coupling(stream, g, U.p, p.p, alpha.p, C3(psn), vGrad.p, gradP.p, divT.p, Gt.p, 0, 0));
                 FY_TRY(halo_cells(Gt, 9, 1));
                 FY_TRY(launch_div_G(stream, g, Gt.p, divG.p));
             }
