@@ -64,7 +64,7 @@ typedef struct fy_field_ptrs {
     const double* gradP;        /* [n][3] */
     const double* vGrad;        /* [n][9] */
     const double* divT;         /* [n][3] */
-    const double* ddtU;         /* [n][3]  (only consumer is the unreachable addedMassForce, FoamYade.C:392-413) */
+    const double* ddtU;         /* [n][3]  (only consumer is addedMassForce, FoamYade.C:392-413: see fy_set_force_models) */
     double g[3];                /* uniformDimensionedVectorField g */
     double* uSourceDrag;        /* [n]     read-write */
     double* alpha;              /* [n]     read-write */
@@ -100,6 +100,16 @@ int fy_create(const fy_mesh_desc* mesh, const fy_field_ptrs* fields, int gaussia
               const fy_transport* transport, int device_ordinal, fy_ctx** out);
 /* FoamYade::setScalarProperties FoamYade.C:9-11 */
 int fy_set_scalar_properties(fy_ctx*, double rhoP, double rhoF, double nu);
+/* The two Gaussian-mode force models FoamYade carries WITHOUT a live call site; both are off by default, which is the shipped
+ * behaviour.  Enabling one is what re-enabling it in the reference would do:
+ *   FY_FORCE_GAUSSIAN_TORQUE  calcHydroTorque's Gaussian branch, FoamYade.C:465-479 (its call is commented out at FoamYade.C:618);
+ *                             reads fields.vGrad and the angular velocity of the records; fills force[3..5]
+ *   FY_FORCE_ADDED_MASS       addedMassForce, FoamYade.C:392-413 (never called): reads fields.ddtU and the dt passed to
+ *                             fy_set_particle_action; adds to force[0..2] and back-scatters into uSource
+ * Returns FY_ERR_INVALID in point-force mode or when the field a model needs was not supplied to fy_create. */
+#define FY_FORCE_ADDED_MASS 1u
+#define FY_FORCE_GAUSSIAN_TORQUE 2u
+int fy_set_force_models(fy_ctx*, unsigned flags);
 /* FoamYade::setParticleAction FoamYade.C:605-632 (blocking).  On return alpha, uParticle, uSourceDrag, uSource hold
  * this step's values and (with a transport) found flags / forces / dt have been exchanged with Yade. */
 int fy_set_particle_action(fy_ctx*, double dt);
@@ -187,6 +197,8 @@ int fy_solver_get_stats(fy_solver*, fy_step_stats* out);
 /* names: "U" [n][3], "p" [n], "phi_x" [(nx+1)*ny*nz], "phi_y", "phi_z", plus every fy_ctx field name */
 int fy_solver_read_field_host(fy_solver*, const char* name, double* out);
 int fy_solver_write_field_host(fy_solver*, const char* name, const double* in);
+/* number of doubles fy_solver_read/write_field_host move for `name` on this rank (owned cells / local faces) */
+int fy_solver_field_count(fy_solver*, const char* name, int64_t* count);
 int fy_solver_destroy(fy_solver*);
 
 /* ---- kernel-level entry points used by the roofline bench and the operator parity tests ------------------ */

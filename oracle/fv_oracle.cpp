@@ -200,6 +200,22 @@ struct Fv {
     void pre_coupling_fields() {
         grad_U(U, vGrad);                                   // icoFoamYade.C:71 / pimpleFoamYade.C:76
         if (!pimple) return;
+        // pimpleFoamYade.C:73  ddtU_f = fvc::ddt(Uc) + fvc::div(phic, Uc).  At this point of the loop Uc has not been written since
+        // runTime++, so Uc.oldTime() (stored on this very access) equals Uc and the Euler fvc::ddt term is exactly zero [OF-6
+        // GeometricField::storeOldTimes]; what remains is the Gauss-linear convective term.  (icoFoamYade never computes ddtU_f.)
+#pragma omp parallel for num_threads(threads) collapse(2)
+        for (int k = 0; k < nz; ++k) for (int j = 0; j < ny; ++j) for (int i = 0; i < nx; ++i) {
+            const int c = cid(i, j, k);
+            double acc[3] = {0, 0, 0};
+            for (int d = 0; d < 3; ++d) for (int s = 0; s < 2; ++s) {
+                const double flux = (s ? 1.0 : -1.0) * phi[d][cface(d, s, i, j, k)];
+                double uf[3];
+                if (onb(d, s, i, j, k)) Ub(U, c, 2 * d + s, uf);
+                else { const int nb = c + (s ? stride[d] : -stride[d]); for (int q = 0; q < 3; ++q) uf[q] = 0.5 * (U[3 * (size_t)c + q] + U[3 * (size_t)nb + q]); }
+                for (int q = 0; q < 3; ++q) acc[q] += flux * uf[q];
+            }
+            for (int q = 0; q < 3; ++q) ddtU[3 * (size_t)c + q] = acc[q] / V;
+        }
         grad_p(gradP);
         interp_alpha();                                     // alphac is 1 here (reset by setSourceZero), kept general
 #pragma omp parallel for num_threads(threads) collapse(2)
@@ -720,7 +736,7 @@ static vec* fv_field(Fv* f, const char* name) {
     const std::string s = name;
     if (s == "U") return &f->U; if (s == "p") return &f->p; if (s == "alpha") return &f->alpha; if (s == "uSource") return &f->uSource;
     if (s == "uSourceDrag") return &f->uSourceDrag; if (s == "uParticle") return &f->uParticle; if (s == "gradP") return &f->gradP;
-    if (s == "divT") return &f->divT; if (s == "vGrad") return &f->vGrad; if (s == "phi_x") return &f->phi[0]; if (s == "phi_y") return &f->phi[1];
+    if (s == "divT") return &f->divT; if (s == "vGrad") return &f->vGrad; if (s == "ddtU") return &f->ddtU; if (s == "phi_x") return &f->phi[0]; if (s == "phi_y") return &f->phi[1];
     if (s == "phi_z") return &f->phi[2]; if (s == "rAU") return &f->rAU; if (s == "HbyA") return &f->HbyA; if (s == "p_rhs") return &f->pb;
     if (s == "p_diag") return &f->mg[0].diag; if (s == "p_ux") return &f->mg[0].ux; if (s == "p_uy") return &f->mg[0].uy; if (s == "p_uz") return &f->mg[0].uz;
     if (s == "mom_diag") return &f->diag; if (s == "mom_src") return &f->src;

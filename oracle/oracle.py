@@ -57,6 +57,8 @@ def lib():
         L.orc_nearest_cell.argtypes = [C.c_int, _dp, _ip, C.c_int, _dp, C.c_int, _ip]
         L.orc_particle_action.argtypes = [C.POINTER(StepArgs)]
         L.orc_set_source_zero.argtypes = [C.c_int, C.c_int, _dp, _dp, _dp, _dp]
+        L.orc_extra_force_models.argtypes = [C.POINTER(StepArgs), _dp, C.c_double, C.c_int]
+        L.orc_extra_force_models.restype = None
         _lib = L
     return _lib
 
@@ -119,9 +121,15 @@ class Mesh:
         self.pre = build_tree(self.C) if pre is None else np.ascontiguousarray(pre, dtype=np.int32)
 
 
-def particle_action(mesh: Mesh, fields: dict, mutable: dict, records, batch_off, gaussian, rhoP, rhoF, nu, threads=1):
+FORCE_ADDED_MASS, FORCE_GAUSSIAN_TORQUE = 1, 2
+
+
+def particle_action(mesh: Mesh, fields: dict, mutable: dict, records, batch_off, gaussian, rhoP, rhoF, nu, threads=1,
+                    force_models=0, dt=None):
     """FoamYade::setParticleAction without MPI.  `mutable` arrays (alpha, uParticle, uSourceDrag, uSource) are
-    updated in place.  returns dict(k, ids, w, chain_len, force, found)."""
+    updated in place.  returns dict(k, ids, w, chain_len, force, found).
+    force_models != 0 additionally applies the reference's call-site-less models (FoamYade.C:392-413, 465-479) on top
+    (needs fields["ddtU"] and dt for the added mass)."""
     records = np.ascontiguousarray(records, dtype=np.float64).reshape(-1, 10)
     n = records.shape[0]
     off = np.ascontiguousarray(batch_off, dtype=np.int32)
@@ -146,6 +154,9 @@ def particle_action(mesh: Mesh, fields: dict, mutable: dict, records, batch_off,
     a.force, a.found = _d(out["force"]), _i(out["found"])
     a.threads = int(threads)
     lib().orc_particle_action(C.byref(a))
+    if force_models:
+        ddt = np.ascontiguousarray(fields["ddtU"], dtype=np.float64)
+        lib().orc_extra_force_models(C.byref(a), _d(ddt), C.c_double(float(dt)), int(force_models))
     return out
 
 
@@ -278,12 +289,14 @@ class FvSolver:
             if self.mesh is None:
                 self.mesh = Mesh(c.nx, c.ny, c.nz, c.dx, tuple(c.origin))
             fields = dict(U=self.view("U").reshape(-1, 3), gradP=self.view("gradP").reshape(-1, 3),
-                          vGrad=self.view("vGrad").reshape(-1, 9), divT=self.view("divT").reshape(-1, 3))
+                          vGrad=self.view("vGrad").reshape(-1, 9), divT=self.view("divT").reshape(-1, 3),
+                          ddtU=self.view("ddtU").reshape(-1, 3))
             mut = dict(uSourceDrag=self.view("uSourceDrag"), alpha=self.view("alpha"),
                        uSource=self.view("uSource").reshape(-1, 3), uParticle=self.view("uParticle").reshape(-1, 3))
             n = records.shape[0]
             out = particle_action(self.mesh, fields, mut, records, np.array([0, n], np.int32), self.gaussian,
-                                  c.rho_particle, c.rho_fluid, c.nu, threads=self.threads)
+                                  c.rho_particle, c.rho_fluid, c.nu, threads=self.threads,
+                                  force_models=getattr(self, "force_models", 0), dt=c.dt)
         self.L.orc_fv_step_end(self.h)
         # yadeCoupling.setSourceZero() (icoFoamYade.C:147, pimpleFoamYade.C:109)
         self.L.orc_set_source_zero(self.Nc, int(self.gaussian), _d(self.view("uSourceDrag")), _d(self.view("alpha")),

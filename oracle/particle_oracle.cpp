@@ -421,6 +421,60 @@ void orc_particle_action(orc_step_args* a) {
     }
 }
 
+// The two force models the reference carries without a live call site, applied ON TOP of orc_particle_action's outputs in the
+// order oracle/ref_driver.cpp calls the reference's own methods: calcHydroTorque's Gaussian branch for every located particle
+// (FoamYade.C:465-479; its call is commented out at FoamYade.C:618), then addedMassForce per particle (FoamYade.C:392-413).
+// flags: 1 = added mass, 2 = Gaussian torque.  `a` must still hold the k / ids / w / force / found outputs of the step.
+void orc_extra_force_models(orc_step_args* a, const double* ddtU, double deltaT, int flags) {
+    if (!a->gaussian) return;
+    const double rhoF = a->rhoF, rhoP = a->rhoP, nu = a->nu;
+    const int ntot = a->off[a->nbatch];
+    if (flags & 2) {
+        for (int p = 0; p < ntot; ++p) {
+            if (a->found[p] != 1) continue;
+            const double* r = a->records + 10 * (size_t)p;
+            const double dia = 2 * r[9];
+            const int kk = std::min(a->k[p], MAXK);
+            const int* id = a->ids + (size_t)p * MAXK; const double* w = a->w + (size_t)p * MAXK;
+            double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+            for (int i = 0; i < kk; ++i) {
+                const double* G = a->vGrad + 9 * (size_t)id[i];                          // xx xy xz yx yy yz zx zy zz
+                s1 += ((G[5] - G[7]) * w[i]);                                            // yz - zy  (:472; the point model has zy - yz, :450)
+                s2 += ((G[6] - G[2]) * w[i]);                                            // zx - xz  (:473)
+                s3 += ((G[3] - G[1]) * w[i]);                                            // yx - xy  (:474)
+            }
+            const V3 wfluid{s1, s2, s3};
+            const V3 T = M_PI * (std::pow(dia, 3)) * (wfluid - V3{r[6], r[7], r[8]}) * nu * rhoF;   // :478
+            double* F = a->force + 6 * (size_t)p;
+            F[3] = F[3] + T.x; F[4] = F[4] + T.y; F[5] = F[5] + T.z;
+        }
+    }
+    if (flags & 1) {
+        for (int p = 0; p < ntot; ++p) {
+            if (a->found[p] != 1) continue;
+            const double* r = a->records + 10 * (size_t)p;
+            const double dia = 2 * r[9];
+            const double vol = M_PI * std::pow(dia, 3.0) / 6.0;
+            const V3 linVel{r[3], r[4], r[5]};
+            const int kk = std::min(a->k[p], MAXK);
+            const int* id = a->ids + (size_t)p * MAXK; const double* w = a->w + (size_t)p * MAXK;
+            V3 ddtUf{0, 0, 0}; double pv = 0.0;
+            for (int i = 0; i < kk; ++i) {
+                pv += (vol * w[i]);                                                      // :399
+                ddtUf = ddtUf + (ld(ddtU, id[i]) * w[i]);                                // :400
+            }
+            pv = pv / (unsigned)kk;                                                      // :402  (divided by the stencil SIZE)
+            const V3 f = pv * (ddtUf - (linVel / deltaT)) * rhoP;                        // :403
+            double* F = a->force + 6 * (size_t)p;
+            F[0] = F[0] + f.x; F[1] = F[1] + f.y; F[2] = F[2] + f.z;                     // :404
+            for (int i = 0; i < kk; ++i) {
+                const double ooCellVol = 1. / (a->V[id[i]] * rhoF);                      // :409
+                st(a->uSource, id[i], ld(a->uSource, id[i]) + (-f * w[i] * ooCellVol));  // :410
+            }
+        }
+    }
+}
+
 // FoamYade.C:556-566 setSourceZero / FoamYade.C:56-68 initFields (field part)
 void orc_set_source_zero(int Nc, int gaussian, double* uSourceDrag, double* alpha, double* uSource, double* uParticle) {
     for (int c = 0; c < Nc; ++c) {

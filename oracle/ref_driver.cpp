@@ -234,6 +234,26 @@ void foam_rank(const std::string& dir, const Meta& m) {
         double ydt = fy.yadeDT;
         write_bin(dir + "/" + sfx("foam_yadedt", s), &ydt, 1);
 
+        if (m.gaussian) {
+            // The two force models the reference ships WITHOUT a live call site: Gaussian calcHydroTorque (its call is commented
+            // out at FoamYade.C:618) and addedMassForce (FoamYade.C:392-413, never called).  Called here on the particles the
+            // step just processed, so that the optional fy_set_force_models() path has reference outputs to be checked against.
+            for (const auto& yp : fy.inCommProcs) fy.calcHydroTorque(yp.get());
+            for (const auto& yp : fy.inCommProcs) for (const auto& prt : yp->foundParticles) fy.addedMassForce(prt.get());
+            std::vector<double> FX((size_t)Np * 6, 0.0);
+            for (const auto& yp : fy.inCommProcs) {
+                int lo = 0, hi = Np;
+                if (m.nYade > 1) split(Np, W, yp->yRank - 1, lo, hi);
+                for (const auto& prt : yp->foundParticles) {
+                    const size_t gi = (size_t)(lo + prt->indx);
+                    FX[6 * gi + 0] = prt->hydroForce.x(); FX[6 * gi + 1] = prt->hydroForce.y(); FX[6 * gi + 2] = prt->hydroForce.z();
+                    FX[6 * gi + 3] = prt->hydroTorque.x(); FX[6 * gi + 4] = prt->hydroTorque.y(); FX[6 * gi + 5] = prt->hydroTorque.z();
+                }
+            }
+            write_bin(dir + "/" + sfx("part_forcex", s), FX.data(), FX.size());
+            write_bin(dir + "/" + sfx("uSourcex", s), &uSource.f[0].v[0], 3 * (size_t)Nc);
+        }
+
         fy.setSourceZero();
         if (s == m.nsteps - 1) {
             write_bin(dir + "/zero_alpha.bin", alpha.f.data(), (size_t)Nc);

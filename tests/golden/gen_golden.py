@@ -85,6 +85,12 @@ def build_case(c: gc.Case):
                 idx, val = sparse(a, dflt)
                 out[f"{nm}_idx_s{s}"] = idx
                 out[f"{nm}_val_s{s}"] = val
+            if c.gaussian:
+                # optional force models (Gaussian torque + added mass) applied ON TOP of the step, see ref_driver.cpp
+                out[f"forcex_s{s}"] = rd(wd, f"part_forcex_s{s}.bin", np.float64, (Np, 6))
+                idx, val = sparse(rd(wd, f"uSourcex_s{s}.bin", np.float64, (Nc, 3)), 0.0)
+                out[f"uSourcex_idx_s{s}"] = idx
+                out[f"uSourcex_val_s{s}"] = val
             out[f"foam_yadedt_s{s}"] = rd(wd, f"foam_yadedt_s{s}.bin", np.float64)
             out[f"wire_fluiddt_s{s}"] = rd(wd, f"wire_fluiddt_s{s}.bin", np.float64)
             if c.n_yade == 1:

@@ -109,6 +109,31 @@ def test_coupled_steps_match_oracle(product, oracle, solver):
     assert np.abs(s.get("U")).max() > 0
 
 
+def test_coupled_steps_with_optional_force_models(product, oracle):
+    """pimple loop with fy_set_force_models(added mass | Gaussian torque): ddtU_f (pimpleFoamYade.C:73) and vGrad feed the models"""
+    n = 16
+    dx = 0.1 / n
+    o, s = both(product, oracle, 1, n, n, n, dx, 2e-4, 1e-5, g=(0, 0, -9.81), p_bc=[2] * 6)
+    flags = product.FORCE_ADDED_MASS | product.FORCE_GAUSSIAN_TORQUE
+    o.force_models = flags
+    s.set_force_models(flags)
+    case = gc.Case("cplx", n, n, n, 0.1, gaussian=1, np_=3000, seed=11, cluster=150, fast=20, outside=20, vel_scale=0.05)
+    for step in range(3):
+        rec = gc.particle_records(case, step)
+        fo = o.step(rec)["force"]
+        s.set_particles(rec)
+        s.step()
+        fs = s.forces()
+        for cols in (slice(0, 3), slice(3, 6)):
+            sc = np.abs(fo[:, cols]).max()
+            assert sc > 0
+            assert np.abs(fs[:, cols] - fo[:, cols]).max() <= 1e-6 * sc, (cols, np.abs(fs[:, cols] - fo[:, cols]).max() / sc)
+        if step > 0:
+            d_o, d_s = o.get("ddtU"), s.get("ddtU")
+            assert np.abs(d_o).max() > 0 and np.abs(d_s - d_o).max() <= 1e-5 * np.abs(d_o).max()
+    compare(o, s, rtol=1e-5)
+
+
 def test_c2_channel_inlet_outlet_point_force(product, oracle):
     """BASELINE configs[1] in miniature: icoFoamYade point force in a channel -- inlet fixedValue U = (1,0,0), outlet zeroGradient U
     with p = 0, no-slip walls"""

@@ -66,6 +66,32 @@ def test_particle_action_matches_reference(oracle, name):
         assert np.all(mut["uSource"] == 0.0)
 
 
+@pytest.mark.parametrize("name", [c.name for c in gc.CASES if c.gaussian])
+def test_optional_force_models_match_reference(oracle, name):
+    """Gaussian calcHydroTorque (FoamYade.C:465-479) + addedMassForce (FoamYade.C:392-413): the reference's own methods
+    were called on top of every step by oracle/ref_driver.cpp; the oracle's restatement must reproduce them."""
+    c = gc.CASES_BY_NAME[name]
+    g = gu.load(name)
+    fields = gu.check_inputs_reproducible(c, g)
+    mesh = oracle.Mesh(c.nx, c.ny, c.nz, c.dx, c.origin)
+    mut = oracle.fresh_mutable(mesh.Nc)
+    for s in range(c.nsteps):
+        rec = g[f"records_s{s}"]
+        out = oracle.particle_action(mesh, fields, mut, rec, gu.batch_offsets(c, rec.shape[0]), c.gaussian, c.rhoP, c.rhoF, c.nu,
+                                     force_models=oracle.FORCE_ADDED_MASS | oracle.FORCE_GAUSSIAN_TORQUE, dt=c.dt)
+        ub = out["chain_len"] > 12
+        ok = ~ub
+        fref = g[f"forcex_s{s}"]
+        assert np.abs(fref[:, 3:]).max() > 0 and not np.array_equal(fref[:, :3], g[f"force_s{s}"][:, :3])   # both models acted
+        for cols in (slice(0, 3), slice(3, 6)):
+            scale = np.abs(fref[:, cols]).max()
+            np.testing.assert_allclose(out["force"][ok][:, cols], fref[ok][:, cols], rtol=gu.RTOL_ORACLE, atol=1e-14 * scale)
+        if not ub.any():
+            ref = gu.dense(g, "uSourcex", s, mesh.Nc, 3, 0.0)
+            np.testing.assert_allclose(mut["uSource"], ref, rtol=1e-12, atol=1e-14 * np.abs(ref).max())
+        oracle.set_source_zero(mut, c.gaussian)
+
+
 def test_golden_covers_the_branches():
     """the fixtures must exercise: k=0 (root quirk), outside-but-found (Q8), alpha floor, Ergun branch, Re>1000."""
     c = gc.CASES_BY_NAME["g32_serial"]

@@ -88,6 +88,53 @@ def test_set_particle_action_matches_reference(product, oracle, name):
     fy.close()
 
 
+@pytest.mark.parametrize("name", [c.name for c in gc.CASES if c.gaussian])
+def test_optional_force_models_match_reference(product, name):
+    """fy_set_force_models: Gaussian calcHydroTorque (FoamYade.C:465-479) + addedMassForce (FoamYade.C:392-413) against what the
+    reference's own methods produced when oracle/ref_driver.cpp called them on top of each step."""
+    c = gc.CASES_BY_NAME[name]
+    g = gu.load(name)
+    fields = gu.check_inputs_reproducible(c, g)
+    mut = seeded_mutable(c.ncells)
+    mesh, fy = make_engine(product, c, fields, mut)
+    fy.setForceModels(product.FORCE_ADDED_MASS | product.FORCE_GAUSSIAN_TORQUE)
+    for s in range(c.nsteps):
+        rec = g[f"records_s{s}"]
+        off = gu.batch_offsets(c, rec.shape[0])
+        fy.setParticles([rec[off[b]:off[b + 1]] for b in range(len(off) - 1)])
+        fy.setParticleAction(c.dt)
+        chain = np.concatenate([fy.stencils(b)[3] for b in range(len(off) - 1)])
+        F = np.concatenate([fy.forces(b) for b in range(len(off) - 1)])
+        ok = chain <= 12
+        fref = g[f"forcex_s{s}"]
+        assert_close(F[ok][:, :3], fref[ok][:, :3], gu.RTOL_GPU, "force incl. added mass")
+        assert_close(F[ok][:, 3:], fref[ok][:, 3:], gu.RTOL_GPU, "Gaussian torque")
+        if np.all(ok):
+            assert_close(mut["uSource"], gu.dense(g, "uSourcex", s, c.ncells, 3, 0.0), gu.RTOL_GPU, "uSource incl. added mass")
+            # the models leave the other three fields alone
+            for nm, comps, dflt in (("alpha", 1, 1.0), ("uSourceDrag", 1, 0.0), ("uParticle", 3, 0.0)):
+                assert_close(mut[nm], gu.dense(g, nm, s, c.ncells, comps, dflt), gu.RTOL_GPU, nm)
+        fy.setSourceZero()
+    # switching them off again restores the shipped behaviour
+    fy.setForceModels(0)
+    rec = g["records_s0"]
+    off = gu.batch_offsets(c, rec.shape[0])
+    fy.setParticles([rec[off[b]:off[b + 1]] for b in range(len(off) - 1)])
+    fy.setParticleAction(c.dt)
+    F = np.concatenate([fy.forces(b) for b in range(len(off) - 1)])
+    chain = np.concatenate([fy.stencils(b)[3] for b in range(len(off) - 1)])
+    assert_close(F[chain <= 12], g["force_s0"][chain <= 12], gu.RTOL_GPU, "force, models off")
+    fy.close()
+
+
+def test_force_models_rejected_in_point_mode(product):
+    c = gc.CASES_BY_NAME["p32_serial_c1"]
+    mesh, fy = make_engine(product, c, gc.fluid_fields(c), seeded_mutable(c.ncells))
+    with pytest.raises(product.FoamYadeError):
+        fy.setForceModels(product.FORCE_ADDED_MASS)
+    fy.close()
+
+
 @pytest.mark.parametrize("dims,npart,gaussian", [((48, 40, 36), 60000, 1), ((64, 64, 64), 200000, 1), ((50, 30, 20), 50000, 0)])
 def test_against_oracle_seeded(product, oracle, dims, npart, gaussian):
     """sizes the oracle finishes in seconds; inputs are seeded, nothing reads /root/reference"""

@@ -24,6 +24,7 @@ MAXK = 16
 
 FY_OK = 0
 FY_ERR_NO_DEVICE = 2
+FORCE_ADDED_MASS, FORCE_GAUSSIAN_TORQUE = 1, 2        # fy_set_force_models flags
 FY_MEM_HOST, FY_MEM_DEVICE = 0, 1
 FY_T_INT, FY_T_DOUBLE = 0, 1
 FY_OP_MAX, FY_OP_SUM = 0, 1
@@ -114,6 +115,7 @@ def lib():
     L.fy_create.argtypes = [C.POINTER(MeshDesc), C.POINTER(FieldPtrs), C.c_int, C.POINTER(Transport), C.c_int, C.POINTER(vp)]
     L.fy_set_scalar_properties.argtypes = [vp, C.c_double, C.c_double, C.c_double]
     L.fy_set_particle_action.argtypes = [vp, C.c_double]
+    L.fy_set_force_models.argtypes = [vp, C.c_uint]
     L.fy_set_source_zero.argtypes = [vp]
     L.fy_destroy.argtypes = [vp]
     L.fy_set_num_batches.argtypes = [vp, C.c_int]
@@ -141,6 +143,7 @@ def lib():
     L.fy_solver_step.argtypes = [vp]
     L.fy_solver_get_stats.argtypes = [vp, C.POINTER(StepStats)]
     L.fy_solver_read_field_host.argtypes = [vp, C.c_char_p, _dp]
+    L.fy_solver_field_count.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int64)]
     L.fy_solver_write_field_host.argtypes = [vp, C.c_char_p, _dp]
     L.fy_solver_destroy.argtypes = [vp]
     L.fy_solver_apply_p_matrix_host.argtypes = [vp, _dp, _dp]
@@ -244,6 +247,11 @@ class FoamYade:
 
     def setParticleAction(self, dt):
         _check(lib().fy_set_particle_action(self._h, float(dt)))
+
+    def setForceModels(self, flags):
+        """opt-in models the reference has no call site for: FORCE_ADDED_MASS (FoamYade.C:392-413) | FORCE_GAUSSIAN_TORQUE
+        (FoamYade.C:465-479, commented out at :618)"""
+        _check(lib().fy_set_force_models(self._h, int(flags)))
 
     def setSourceZero(self):
         _check(lib().fy_set_source_zero(self._h))
@@ -375,11 +383,9 @@ class Solver:
         self._batch_n = []
 
     def _size(self, name):
-        c = self.case
-        n = self.n_cells
-        return {"U": 3 * n, "HbyA": 3 * n, "mom_src": 3 * n, "uSource": 3 * n, "uParticle": 3 * n, "gradP": 3 * n, "divT": 3 * n,
-                "vGrad": 9 * n, "phi_x": (c.nx + 1) * c.ny * self.nz_local, "phi_y": c.nx * (c.ny + 1) * self.nz_local,
-                "phi_z": c.nx * c.ny * (self.nz_local + 1)}.get(name, n)
+        cnt = C.c_int64(0)
+        _check(lib().fy_solver_field_count(self._h, name.encode(), C.byref(cnt)))
+        return cnt.value
 
     def get(self, name):
         out = np.zeros(self._size(name))
@@ -390,6 +396,10 @@ class Solver:
         arr = np.ascontiguousarray(arr, dtype=np.float64).ravel()
         assert arr.size == self._size(name)
         _check(lib().fy_solver_write_field_host(self._h, name.encode(), _d(arr)))
+
+    def set_force_models(self, flags):
+        """fy_set_force_models on the embedded coupling object (Gaussian torque / added mass, off by default)"""
+        _check(lib().fy_set_force_models(self._cpl, int(flags)))
 
     def set_particles(self, records):
         """direct mode: the particle records the next step() will couple with ((n,10) host array, or None for none)"""

@@ -165,7 +165,7 @@ int Coupling::create(const fy_mesh_desc* m, const fy_field_ptrs* f, int gaussian
         // the caller's current content of the two fields point mode never touches must survive the round trip
         FY_TRY(stage_mutable_in());
     } else {
-        dU = f->U; dGradP = f->gradP; dVGrad = f->vGrad; dDivT = f->divT;
+        dU = f->U; dGradP = f->gradP; dVGrad = f->vGrad; dDivT = f->divT; dDdtU = f->ddtU;
         dUSourceDrag = f->uSourceDrag; dAlpha = f->alpha; dUSource = f->uSource; dUParticle = f->uParticle;
     }
     if (!dU || !dUSource || !dAlpha) return fail(FY_ERR_INVALID, "fy_create: U, uSource and alpha are required");
@@ -251,9 +251,26 @@ int Coupling::stage_readonly_in() {
     if (gaussian) {
         FY_HIP(hipMemcpyAsync(own_gradP.p, fields.gradP, 3 * n, hipMemcpyHostToDevice, stream));
         FY_HIP(hipMemcpyAsync(own_divT.p, fields.divT, 3 * n, hipMemcpyHostToDevice, stream));
+        if (force_models & FY_FORCE_GAUSSIAN_TORQUE) FY_HIP(hipMemcpyAsync(own_vGrad.p, fields.vGrad, 9 * n, hipMemcpyHostToDevice, stream));
+        if (force_models & FY_FORCE_ADDED_MASS) FY_HIP(hipMemcpyAsync(own_ddtU.p, fields.ddtU, 3 * n, hipMemcpyHostToDevice, stream));
     } else {
         FY_HIP(hipMemcpyAsync(own_vGrad.p, fields.vGrad, 9 * n, hipMemcpyHostToDevice, stream));
     }
+    return FY_OK;
+}
+
+// Opt-in force models without a call site in the reference (see foamyade_hip.h)
+int Coupling::set_force_models(unsigned flags) {
+    if (!created) return fail(FY_ERR_INVALID, "fy_set_force_models before fy_create");
+    if (flags & ~(FY_FORCE_ADDED_MASS | FY_FORCE_GAUSSIAN_TORQUE)) return fail(FY_ERR_INVALID, "fy_set_force_models: unknown flag");
+    if (flags && !gaussian) return fail(FY_ERR_INVALID, "fy_set_force_models: Gaussian mode only (point mode always runs stokesDragTorque)");
+    if ((flags & FY_FORCE_GAUSSIAN_TORQUE) && !(fields_on_host ? fields.vGrad : dVGrad)) return fail(FY_ERR_INVALID, "Gaussian torque needs vGrad");
+    if ((flags & FY_FORCE_ADDED_MASS) && !(fields_on_host ? fields.ddtU : dDdtU)) return fail(FY_ERR_INVALID, "added mass needs ddtU");
+    if (fields_on_host && (flags & FY_FORCE_ADDED_MASS) && !own_ddtU.p) {
+        FY_TRY(own_ddtU.alloc_exact(3 * (size_t)n_cells));
+        dDdtU = own_ddtU.p;
+    }
+    force_models = flags;
     return FY_OK;
 }
 
@@ -310,7 +327,7 @@ int Coupling::set_particles_device(int bi, const double* d_rec, int64_t n) {
 // the device part of setParticleAction for one Yade proc (FoamYade.C:612-628 loop body)
 int Coupling::run_batch(Batch& b) {
     if (b.n == 0 && !slab.active) return FY_OK;      // (in slab mode the halo exchanges are collective: every rank walks the same path)
-    ForceParams fp{rhoF, nu, 1e-09};
+    ForceParams fp{rhoF, nu, 1e-09, rhoP, delta_t, force_models};
     if (gaussian) {
         ParticleSoA p = soa_of(b);
         if (timing) timers[T_BIN].start(stream);
@@ -346,8 +363,8 @@ int Coupling::run_batch(Batch& b) {
             FY_TRY(halo_fwd(dUParticle, 3, slab.gz));
         }
         if (timing) { timers[T_FINALIZE].stop(stream); timers[T_FORCE].start(stream); }
-        FY_TRY(launch_force_gaussian(stream, p, b.n, fp, cw, d_vol.p, dU, dAlpha, dUParticle, dGradP, dDivT, dUSourceDrag, dUSource,
-                                     b.force.p, b.found.p));
+        FY_TRY(launch_force_gaussian(stream, p, b.n, fp, cw, d_vol.p, dU, dAlpha, dUParticle, dGradP, dDivT, dVGrad, dDdtU, b.d_rec,
+                                     dUSourceDrag, dUSource, b.force.p, b.found.p));
         if (slab.active) {
             FY_TRY(halo_reverse_add(dUSourceDrag, 1, nullptr));
             FY_TRY(halo_reverse_add(dUSource, 3, nullptr));
@@ -586,6 +603,7 @@ int Coupling::field_by_name(const char* name, double** p, size_t* count) {
     else if (s == "U") { *p = const_cast<double*>(dU); *count = 3 * n; }
     else if (s == "gradP") { *p = const_cast<double*>(dGradP); *count = 3 * n; }
     else if (s == "divT") { *p = const_cast<double*>(dDivT); *count = 3 * n; }
+    else if (s == "ddtU") { *p = const_cast<double*>(dDdtU); *count = 3 * n; }
     else if (s == "vGrad") { *p = const_cast<double*>(dVGrad); *count = 9 * n; }
     else return fail(FY_ERR_INVALID, "unknown field '%s'", s.c_str());
     if (!*p) return fail(FY_ERR_INVALID, "field '%s' was not supplied", s.c_str());
@@ -645,6 +663,7 @@ int fy_create(const fy_mesh_desc* mesh, const fy_field_ptrs* fields, int gaussia
 #define FY_CTX(c) if (!(c)) return fy::fail(FY_ERR_INVALID, "null fy_ctx")
 
 int fy_set_scalar_properties(fy_ctx* c, double rhoP, double rhoF, double nu) { FY_CTX(c); c->c.rhoP = rhoP; c->c.rhoF = rhoF; c->c.nu = nu; return FY_OK; }
+int fy_set_force_models(fy_ctx* c, unsigned flags) { FY_CTX(c); return c->c.set_force_models(flags); }
 int fy_set_particle_action(fy_ctx* c, double dt) { FY_CTX(c); return c->c.set_particle_action(dt); }
 int fy_set_source_zero(fy_ctx* c) { FY_CTX(c); return c->c.set_source_zero(); }
 int fy_destroy(fy_ctx* c) { delete c; return FY_OK; }

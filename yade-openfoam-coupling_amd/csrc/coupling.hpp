@@ -70,8 +70,9 @@ struct Coupling {
     DevBuf<double> d_vol;
     fy_field_ptrs fields{};
     bool fields_on_host = false;
-    DevBuf<double> own_U, own_gradP, own_vGrad, own_divT, own_uSourceDrag, own_alpha, own_uSource, own_uParticle;
-    const double *dU = nullptr, *dGradP = nullptr, *dVGrad = nullptr, *dDivT = nullptr;
+    DevBuf<double> own_U, own_gradP, own_vGrad, own_divT, own_ddtU, own_uSourceDrag, own_alpha, own_uSource, own_uParticle;
+    const double *dU = nullptr, *dGradP = nullptr, *dVGrad = nullptr, *dDivT = nullptr, *dDdtU = nullptr;
+    unsigned force_models = 0;           // FY_FORCE_*: the reference's call-site-less models (off = shipped behaviour)
     double *dUSourceDrag = nullptr, *dAlpha = nullptr, *dUSource = nullptr, *dUParticle = nullptr;
     DevBuf<double> d_pvol_acc, d_up_acc;           // per-batch deposit accumulators (pVolContrib / uParticleContrib)
     DevBuf<unsigned char> d_touched;
@@ -99,6 +100,7 @@ struct Coupling {
     int set_particles_host(int bi, const double* rec, int64_t n);
     int set_particles_device(int bi, const double* d_rec, int64_t n);
     int run_batch(Batch& b);
+    int set_force_models(unsigned flags);
     int set_particle_action(double dt);
     int recv_serial();
     int recv_yade_intrs();

@@ -261,14 +261,14 @@ __global__ __launch_bounds__(256) void k_courant(FvGeo g, CFace3 phi, double* __
 __global__ __launch_bounds__(256) void k_pre_coupling(FvGeo g, const double* __restrict__ U, const double* __restrict__ p,
                                                       const double* __restrict__ alpha, CFace3 psn, double* __restrict__ vGrad,
                                                       double* __restrict__ gradP, double* __restrict__ divT, double* __restrict__ Gout,
-                                                      int write_vgrad, int write_pfields) {
+                                                      int write_vgrad, int write_pfields, CFace3 phi, double* __restrict__ ddtU) {
     const int t = swz_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
     if (t >= g.Nc) return;
     int i, j, k; ijk_of(g, t, i, j, k);
     const int c = t + g.c0;
     const bool pf = g.pimple && write_pfields;          // gradP and divT wanted
     const double uc[3] = {U[3 * (size_t)c], U[3 * (size_t)c + 1], U[3 * (size_t)c + 2]};
-    double lap[3] = {0, 0, 0}, T[9];
+    double lap[3] = {0, 0, 0}, T[9], conv[3] = {0, 0, 0};
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
         double fv[2][3], fp[2] = {0, 0};
@@ -293,7 +293,18 @@ __global__ __launch_bounds__(256) void k_pre_coupling(FvGeo g, const double* __r
         }
         for (int q = 0; q < 3; ++q) T[3 * d + q] = (fv[1][q] - fv[0][q]) / g.dx;
         if (pf) gradP[3 * (size_t)c + d] = (fp[1] - fp[0]) / g.dx;
+        if (ddtU) {     // fvc::div(phic, Uc), Gauss linear: the face values are the ones the gradient just used
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const double flux = (s ? 1.0 : -1.0) * phi.a[d][cface(g, d, s, i, j, k)];
+                for (int q = 0; q < 3; ++q) conv[q] += flux * fv[s][q];
+            }
+        }
     }
+    // pimpleFoamYade.C:73 ddtU_f = fvc::ddt(Uc) + fvc::div(phic, Uc); the ddt term is identically zero there (Uc.oldTime() is
+    // stored on that access, before Uc is written in the new step), only consumer: addedMassForce (fy_set_force_models)
+    if (ddtU)
+        for (int q = 0; q < 3; ++q) ddtU[3 * (size_t)c + q] = conv[q] / g.V;
     if (write_vgrad)
         for (int q = 0; q < 9; ++q) vGrad[9 * (size_t)c + q] = T[q];
     if (pf)
@@ -934,8 +945,9 @@ int launch_courant(hipStream_t s, FvGeo g, CFace3 phi, double* partials) {
 }
 
 int launch_pre_coupling(hipStream_t s, FvGeo g, const double* U, const double* p, const double* alpha, CFace3 psn, double* vGrad,
-                        double* gradP, double* divT, double* Gout, int write_vgrad, int write_pfields) {
-    hipLaunchKernelGGL(k_pre_coupling, dim3(div_up(g.Nc, 256)), dim3(256), 0, s, g, U, p, alpha, psn, vGrad, gradP, divT, Gout, write_vgrad, write_pfields);
+                        double* gradP, double* divT, double* Gout, int write_vgrad, int write_pfields, CFace3 phi, double* ddtU) {
+    hipLaunchKernelGGL(k_pre_coupling, dim3(div_up(g.Nc, 256)), dim3(256), 0, s, g, U, p, alpha, psn, vGrad, gradP, divT, Gout, write_vgrad, write_pfields,
+                       phi, ddtU);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }

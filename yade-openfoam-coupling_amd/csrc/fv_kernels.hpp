@@ -54,9 +54,10 @@ int launch_reduce_finalize(hipStream_t s, const double* partials, int n_cells, i
 int launch_flux_of(hipStream_t s, FvGeo g, const double* F, Face3 out);                                   // fvc::flux(F), createPhi
 int launch_courant(hipStream_t s, FvGeo g, CFace3 phi, double* partials);                                  // slots 0 (max) 1 (sum)
 // Gout != nullptr: also emit the laminar stress tensor alpha nu dev2(T(grad U)); write_vgrad = 0 skips the vGrad store,
-// write_pfields = 0 skips gradP / divT (pimple only)
+// write_pfields = 0 skips gradP / divT (pimple only); ddtU != nullptr: also ddtU_f = fvc::div(phi, U) (pimpleFoamYade.C:73)
 int launch_pre_coupling(hipStream_t s, FvGeo g, const double* U, const double* p, const double* alpha, CFace3 psn,
-                        double* vGrad, double* gradP, double* divT, double* Gout, int write_vgrad, int write_pfields);
+                        double* vGrad, double* gradP, double* divT, double* Gout, int write_vgrad, int write_pfields,
+                        CFace3 phi = CFace3{}, double* ddtU = nullptr);
 int launch_interp_alpha(hipStream_t s, FvGeo g, const double* alpha, Face3 alphaf);
 int launch_stress_G(hipStream_t s, FvGeo g, const double* vGrad, const double* alpha, double* G);
 int launch_div_G(hipStream_t s, FvGeo g, const double* G, double* divG);

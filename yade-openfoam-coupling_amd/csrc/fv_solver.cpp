@@ -444,11 +444,17 @@ struct Solver {
         for (int d = 0; d < 3; ++d) FY_TRY(launch_copy_f64(stream, phiOld[d].p, phi[d].p, phi[d].n));
         // icoFoamYade.C:71, pimpleFoamYade.C:73-76.  pimple: alpha is 1 here (reset by setSourceZero), so G is re-formed after the
         // coupling call with this step's alpha; only gradP / divT are needed now.
-        FY_TRY(launch_pre_coupling(stream, g, U.p, p.p, alpha.p, C3(psn), vGrad.p, gradP.p, divT.p, nullptr, pimple ? 0 : 1, 1));
+        // the opt-in force models (fy_set_force_models on fy_solver_coupling()) read vGrad / ddtU_f, which the shipped path never does
+        const unsigned fm = cpl->c.force_models;
+        const bool want_vgrad = !pimple || (fm & FY_FORCE_GAUSSIAN_TORQUE), want_ddtU = pimple && (fm & FY_FORCE_ADDED_MASS);
+        FY_TRY(launch_pre_coupling(stream, g, U.p, p.p, alpha.p, C3(psn), vGrad.p, gradP.p, divT.p, nullptr, want_vgrad ? 1 : 0, 1, C3(phi),
+                                   want_ddtU ? ddtU.p : nullptr));
 
         if (timing) tim[0].start(stream);
         if (g.gz > 1) {                      // the particle gathers reach gz planes into the neighbours
             FY_TRY(halo_cells(U, 3, g.gz)); FY_TRY(halo_cells(gradP, 3, g.gz)); FY_TRY(halo_cells(divT, 3, g.gz));
+            if (fm & FY_FORCE_GAUSSIAN_TORQUE) FY_TRY(halo_cells(vGrad, 9, g.gz));
+            if (want_ddtU) FY_TRY(halo_cells(ddtU, 3, g.gz));
         }
         FY_TRY(cpl->c.set_particle_action(cs.dt));                                            // icoFoamYade.C:74, pimpleFoamYade.C:78
         if (timing) { tim[0].stop(stream); }
@@ -505,7 +511,7 @@ struct Solver {
         const E tab[] = {{"U", U.p, 3 * n, 3}, {"p", p.p, n, 1}, {"phi_x", phi[0].p, phi[0].n, 0}, {"phi_y", phi[1].p, phi[1].n, 0}, {"phi_z", phi[2].p, phi[2].n, 0},
                          {"rAU", rAU.p, n, 1}, {"HbyA", HbyA.p, 3 * n, 3}, {"p_rhs", prhs.p, n, 1}, {"mom_diag", mdiag.p, n, 1}, {"mom_src", src.p, 3 * n, 3},
                          {"alpha", alpha.p, n, 1}, {"uSource", uSource.p, 3 * n, 3}, {"uSourceDrag", uSourceDrag.p, n, 1}, {"uParticle", uParticle.p, 3 * n, 3},
-                         {"gradP", gradP.p, 3 * n, 3}, {"divT", divT.p, 3 * n, 3}, {"vGrad", vGrad.p, 9 * n, 9}};
+                         {"gradP", gradP.p, 3 * n, 3}, {"divT", divT.p, 3 * n, 3}, {"vGrad", vGrad.p, 9 * n, 9}, {"ddtU", ddtU.p, 3 * n, 3}};
         for (const E& e : tab) if (s == e.nm) {
             *ptr = e.p + (size_t)e.comp * g.c0;          // skip the ghost planes below the owned range (comp = 0: face array)
             *count = e.c;
@@ -583,6 +589,15 @@ fy_ctx* fy_solver_coupling(fy_solver* s) { return s ? s->s.cpl : nullptr; }
 int fy_solver_step(fy_solver* s) { FY_S(s); return s->s.step(); }
 int fy_solver_get_stats(fy_solver* s, fy_step_stats* out) { FY_S(s); if (!out) return fy::fail(FY_ERR_INVALID, "null out"); *out = s->s.st; return FY_OK; }
 int fy_solver_local_cells(fy_solver* s) { return s ? s->s.Nc : -1; }
+
+int fy_solver_field_count(fy_solver* s, const char* name, int64_t* count) {
+    FY_S(s);
+    if (!count) return fy::fail(FY_ERR_INVALID, "null count");
+    double* p; size_t n;
+    FY_TRY(s->s.field(name, &p, &n));
+    *count = (int64_t)n;
+    return FY_OK;
+}
 
 int fy_solver_read_field_host(fy_solver* s, const char* name, double* out) {
     FY_S(s);

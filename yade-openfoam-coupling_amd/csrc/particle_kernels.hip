@@ -414,7 +414,9 @@ constexpr int kForceThreads = 512, kForceLog2 = 11;
 __global__ __launch_bounds__(kForceThreads) void k_force_gaussian(ParticleSoA p, int64_t n, ForceParams fp, CellWindow cw, const double* __restrict__ vol,
                                                                   const double* __restrict__ U, const double* __restrict__ alpha,
                                                                   const double* __restrict__ uParticle, const double* __restrict__ gradP,
-                                                                  const double* __restrict__ divT, double* __restrict__ uSourceDrag,
+                                                                  const double* __restrict__ divT, const double* __restrict__ vGrad,
+                                                                  const double* __restrict__ ddtU, const double* __restrict__ rec,
+                                                                  double* __restrict__ uSourceDrag,
                                                                   double* __restrict__ uSource, double* __restrict__ force_out,
                                                                   int32_t* __restrict__ found_out) {
     __shared__ uint32_t keys[1 << kForceLog2];
@@ -477,8 +479,43 @@ __global__ __launch_bounds__(kForceThreads) void k_force_gaussian(ParticleSoA p,
             const double s1 = pv * coeff, ia = 1 / (alpha_p);                               // FoamYade.C:381
             const double hfx = (s1 * urx) * ia, hfy = (s1 * ury) * ia, hfz = (s1 * urz) * ia;
             const double afx = pv * (-pgx + dtx), afy = pv * (-pgy + dty), afz = pv * (-pgz + dtz);   // FoamYade.C:426
-            F[0] = (0.0 + hfx) + afx; F[1] = (0.0 + hfy) + afy; F[2] = (0.0 + hfz) + afz;   // FoamYade.C:382,427
-            F[3] = 0.0; F[4] = 0.0; F[5] = 0.0;                                             // Gaussian torque disabled, FoamYade.C:618
+            double fx = (0.0 + hfx) + afx, fy_ = (0.0 + hfy) + afy, fz = (0.0 + hfz) + afz;   // FoamYade.C:382,427
+            double tqx = 0.0, tqy = 0.0, tqz = 0.0;                                         // Gaussian torque disabled, FoamYade.C:618
+            double amx = 0.0, amy = 0.0, amz = 0.0;
+            if (fp.models) {                                                                // uniform: off in the shipped reference
+                double s1 = 0, s2 = 0, s3 = 0, dux = 0, duy = 0, duz = 0, pva = 0.0;
+                for (int t = 0; t < k; ++t) {
+                    const size_t slot = (size_t)((chain - 1 - t) & (kMaxK - 1)) * p.cap + (size_t)i;
+                    const int64_t cl = (int64_t)p.ids[slot] - cw.base;
+                    if (cl < 0 || cl >= cw.n_field) continue;
+                    const double w = p.w[slot];
+                    if (fp.models & FY_FORCE_GAUSSIAN_TORQUE) {                             // calcHydroTorque FoamYade.C:468-476
+                        const double* G = vGrad + 9 * (size_t)cl;                           // xx xy xz yx yy yz zx zy zz
+                        s1 += ((G[5] - G[7]) * w); s2 += ((G[6] - G[2]) * w); s3 += ((G[3] - G[1]) * w);
+                    }
+                    if (fp.models & FY_FORCE_ADDED_MASS) {                                  // addedMassForce FoamYade.C:396-401
+                        const double* d = ddtU + 3 * (size_t)cl;
+                        pva += (volp * w);
+                        dux = dux + (d[0] * w); duy = duy + (d[1] * w); duz = duz + (d[2] * w);
+                    }
+                }
+                if (fp.models & FY_FORCE_GAUSSIAN_TORQUE) {                                 // FoamYade.C:477-478
+                    const double* r = rec + 10 * (size_t)orig;
+                    const double c3 = M_PI * (pow(dia, 3.0));
+                    tqx = 0.0 + (((c3 * (s1 - r[6])) * nu) * rhoF);
+                    tqy = 0.0 + (((c3 * (s2 - r[7])) * nu) * rhoF);
+                    tqz = 0.0 + (((c3 * (s3 - r[8])) * nu) * rhoF);
+                }
+                if (fp.models & FY_FORCE_ADDED_MASS) {                                      // FoamYade.C:402-404
+                    pva = pva / (double)(unsigned)k;
+                    amx = (pva * (dux - (lvx / fp.delta_t))) * fp.rhoP;
+                    amy = (pva * (duy - (lvy / fp.delta_t))) * fp.rhoP;
+                    amz = (pva * (duz - (lvz / fp.delta_t))) * fp.rhoP;
+                    fx = fx + amx; fy_ = fy_ + amy; fz = fz + amz;
+                }
+            }
+            F[0] = fx; F[1] = fy_; F[2] = fz;
+            F[3] = tqx; F[4] = tqy; F[5] = tqz;
 
             const double irho = 1 / rhoF;
             for (int t = 0; t < k; ++t) {
@@ -492,9 +529,12 @@ __global__ __launch_bounds__(kForceThreads) void k_force_gaussian(ParticleSoA p,
                 const double ooCellVol = 1. / (vol[c] * rhoF);                              // FoamYade.C:432
                 // FoamYade.C:385 ; FoamYade.C:386 (drag part, NOT divided by V) + FoamYade.C:433 (Archimedes part)
                 const double c0 = cwt * irho;
-                const double c1 = ((cwt * up[0]) / rhoF) + ((-afx * w) * ooCellVol);
-                const double c2 = ((cwt * up[1]) / rhoF) + ((-afy * w) * ooCellVol);
-                const double c3 = ((cwt * up[2]) / rhoF) + ((-afz * w) * ooCellVol);
+                double c1 = ((cwt * up[0]) / rhoF) + ((-afx * w) * ooCellVol);
+                double c2 = ((cwt * up[1]) / rhoF) + ((-afy * w) * ooCellVol);
+                double c3 = ((cwt * up[2]) / rhoF) + ((-afz * w) * ooCellVol);
+                if (fp.models & FY_FORCE_ADDED_MASS) {                                      // FoamYade.C:406-411
+                    c1 = c1 + ((-amx * w) * ooCellVol); c2 = c2 + ((-amy * w) * ooCellVol); c3 = c3 + ((-amz * w) * ooCellVol);
+                }
                 const int h = agg_slot<kForceLog2>(keys, (uint32_t)c);
                 if (h >= 0) {
                     lds_add_f64(&vals[4 * h], c0); lds_add_f64(&vals[4 * h + 1], c1);
@@ -691,10 +731,11 @@ int launch_finalize_cells(hipStream_t s, int32_t n_cells, const double* vol, dou
 
 int launch_force_gaussian(hipStream_t s, ParticleSoA p, int64_t n, ForceParams fp, CellWindow cw, const double* vol, const double* U,
                           const double* alpha, const double* uParticle, const double* gradP, const double* divT,
+                          const double* vGrad, const double* ddtU, const double* rec,
                           double* uSourceDrag, double* uSource, double* force_out, int32_t* found_out) {
     if (n <= 0) return FY_OK;
     hipLaunchKernelGGL(k_force_gaussian, dim3(div_up(n, kForceThreads)), dim3(kForceThreads), 0, s, p, n, fp, cw, vol, U, alpha, uParticle, gradP, divT,
-                       uSourceDrag, uSource, force_out, found_out);
+                       vGrad, ddtU, rec, uSourceDrag, uSource, force_out, found_out);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }

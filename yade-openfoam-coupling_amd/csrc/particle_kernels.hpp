@@ -27,6 +27,8 @@ struct GaussParams {
 
 struct ForceParams {
     double rhoF, nu, small;        // FoamYade.H:67,83-85
+    double rhoP, delta_t;          // FoamYade.H:83,94 (added mass only)
+    unsigned models;               // FY_FORCE_* : the reference's call-site-less models, off by default
 };
 
 // sorted SoA particle arrays + per-particle stencil storage for one batch
@@ -65,6 +67,7 @@ int launch_finalize_cells(hipStream_t s, int32_t n_cells, const double* vol, dou
                           unsigned char* touched, double* alpha, double* uParticle);
 int launch_force_gaussian(hipStream_t s, ParticleSoA p, int64_t n, ForceParams fp, CellWindow cw, const double* vol, const double* U,
                           const double* alpha, const double* uParticle, const double* gradP, const double* divT,
+                          const double* vGrad, const double* ddtU, const double* rec,
                           double* uSourceDrag, double* uSource, double* force_out, int32_t* found_out);
 int launch_unpack_stencils(hipStream_t s, ParticleSoA p, int64_t n, int32_t* k, int32_t* ids, double* w, int32_t* chain);
 
