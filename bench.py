@@ -180,8 +180,8 @@ def main():
     cand = {
         # name: (total ms over the timed steps, launches, algorithmic bytes per launch, description) -- DESIGN.md section 3;
         # kbar = 5.46 stencil cells per particle, 12 B per (id, weight) pair
-        "k_locate": (acc["locate"], K, (24.0 + 4.0 + 12.0 * 5.46) * np_part,
-                     "k-d 'range' locate (improvement chain of one NN DFS): position 24 B in, chain length 4 B + 12 B/pair out; latency/issue bound, not HBM"),
+        "k_locate": (acc["locate"], K, (24.0 + 8.0 + 4.0 + 12.0 * 5.46) * np_part,
+                     "k-d 'range' locate (improvement chain of one NN DFS): position 24 B + per-cell start entry 8 B in, chain length 4 B + 12 B/pair out; latency/issue bound, not HBM"),
         "k_deposit+k_finalize_cells": (dep_ms, K, (60.0 + 2 * 12.0 * 5.46) * np_part + 65.0 * nc,
                                        "Gaussian weights + void-fraction deposit (LDS-aggregated atomics) + alpha/uParticle finalize"),
         "k_force_gaussian": (acc["force"], K, (64.0 + 12.0 * 5.46 + 52.0) * np_part + 176.0 * nc,

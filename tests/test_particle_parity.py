@@ -165,3 +165,39 @@ def test_against_oracle_seeded(product, oracle, dims, npart, gaussian):
         assert_close(mut[nm], omut[nm], gu.RTOL_GPU, nm)
     assert np.array_equal(mut["alpha"] == 0.1, omut["alpha"] == 0.1)
     fy.close()
+
+
+@pytest.mark.parametrize("dims", [(96, 80, 64), (33, 47, 29)])
+def test_locate_on_lattice_positions(product, oracle, dims):
+    """k_locate starts every walk at a node precomputed per CELL (k_build_locate_start).  Queries that sit exactly on cell faces,
+    edges, corners and centres (where the cell assignment is ambiguous and squared distances tie), next to the tree's top-level split
+    planes, on and just outside the block's boundary: stencil ids and chain lengths must equal the oracle's, bit for bit."""
+    nx, ny, nz = dims
+    c = gc.Case("lattice", nx, ny, nz, 0.25, origin=(-0.3, 0.2, 0.0), gaussian=1, np_=10, seed=5)
+    rng = np.random.default_rng(123)
+    n = 60000
+    ijk = np.stack([rng.integers(0, nx + 1, n), rng.integers(0, ny + 1, n), rng.integers(0, nz + 1, n)], axis=1).astype(np.float64)
+    frac = rng.choice([0.0, 0.5, 1.0], size=(n, 3))                      # faces / centres
+    jitter = rng.choice([0.0, 0.0, 1e-13, -1e-13, 1e-3, -1e-3], size=(n, 3))
+    pos = np.asarray(c.origin) + (ijk + frac * (rng.random((n, 1)) < 0.8) + rng.random((n, 3)) * (frac == 0.5) * 0.0 + jitter) * c.dx
+    # a band around the mid-planes (the root and its children split there)
+    mid = np.asarray(c.origin) + (np.array([nx, ny, nz]) * 0.5 + rng.normal(0, 1.5, (n // 4, 3))) * c.dx
+    pos[: n // 4] = mid
+    rec = np.zeros((n, 10))
+    rec[:, 0:3] = pos
+    rec[:, 3:6] = rng.normal(0, 0.05, (n, 3))
+    rec[:, 9] = 0.02 * c.dx
+    fields = gc.fluid_fields(c)
+    mut = seeded_mutable(c.ncells)
+    mesh, fy = make_engine(product, c, fields, mut)
+    om = oracle.Mesh(nx, ny, nz, c.dx, c.origin)
+    omut = oracle.fresh_mutable(c.ncells)
+    ref = oracle.particle_action(om, fields, omut, rec, np.array([0, n], np.int32), 1, c.rhoP, c.rhoF, c.nu, threads=8)
+    fy.setParticles([rec])
+    fy.setParticleAction(c.dt)
+    k, ids, w, chain = fy.stencils(0)
+    assert np.array_equal(chain, ref["chain_len"])
+    assert np.array_equal(k, ref["k"])
+    assert np.array_equal(ids, ref["ids"])
+    assert (k > 0).sum() > 0.9 * n and (k == 0).sum() > 0
+    fy.close()

@@ -127,7 +127,7 @@ int Coupling::create(const fy_mesh_desc* m, const fy_field_ptrs* f, int gaussian
             FY_TRY(d_tree_packed.alloc_exact(packed.size()));
             FY_HIP(hipMemcpyAsync(d_tree_packed.p, packed.data(), packed.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
             implicit.ox = m->origin[0]; implicit.oy = m->origin[1]; implicit.oz = m->origin[2]; implicit.dx = m->dx;
-            implicit.nx = m->nx; implicit.ny = m->ny;
+            implicit.nx = m->nx; implicit.ny = m->ny; implicit.nz = m->nz;
             use_implicit = true;
             FY_HIP(hipStreamSynchronize(stream));
         } else {
@@ -349,7 +349,13 @@ int Coupling::run_batch(Batch& b) {
         gp.maxdist = (interp_range * interp_range) + (0.25 * interp_range * interp_range);   // meshTree.C:155
         gp.two_sigma2 = 2 * std::pow(sigma_interp, 2);                                         // FoamYade.C:308
         gp.range_cu = interp_range_cu; gp.sigma_pi = sigma_pi;
-        FY_TRY(launch_locate(stream, d_tree.p, use_implicit ? d_tree_packed.p : nullptr, implicit, n_cells, tree_levels, p, b.n, gp));
+        static const bool no_start = getenv("FOAMYADE_NO_LOCATE_START") != nullptr;      // A/B switch
+        if (use_implicit && !no_start && !d_loc_start.p) {
+            FY_TRY(d_loc_start.alloc_exact((size_t)n_cells));
+            FY_TRY(launch_build_locate_start(stream, d_tree_packed.p, implicit, n_cells, gp.maxdist, d_loc_start.p));
+        }
+        FY_TRY(launch_locate(stream, d_tree.p, use_implicit ? d_tree_packed.p : nullptr, implicit, n_cells, tree_levels, p, b.n, gp,
+                             use_implicit ? d_loc_start.p : nullptr));
         if (timing) { timers[T_LOCATE].stop(stream); timers[T_FINALIZE].start(stream); }
         const CellWindow cw{slab.active ? slab.base : 0, n_field};
         FY_TRY(launch_deposit(stream, p, b.n, gp, cw, d_pvol_acc.p, d_up_acc.p, d_touched.p));

@@ -63,6 +63,7 @@ struct Coupling {
     // ---- device state
     DevBuf<KdNode> d_tree;
     DevBuf<uint32_t> d_tree_packed;      // implicit-coordinate nodes, only when the block's centres are exactly o + (i+0.5)*dx
+    DevBuf<unsigned long long> d_loc_start;   // per-cell traversal start (implicit trees; launch_build_locate_start), built at the first Gaussian step
     ImplicitGeom implicit{};
     bool use_implicit = false;
     int tree_levels = 0;

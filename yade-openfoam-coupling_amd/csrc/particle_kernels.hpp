@@ -51,13 +51,17 @@ int launch_bin_scatter(hipStream_t s, const double* rec, int64_t n, const uint32
 // implicit-coordinate tree (uniform hex block verified at create time): node = packed (i | j << 10 | k << 20)
 struct ImplicitGeom {
     double ox, oy, oz, dx;
-    int nx, ny;
+    int nx, ny, nz;
 };
 // re-use the placement (p.orig) of an earlier step: only gather the records into the SoA arrays
 int launch_bin_gather(hipStream_t s, const double* rec, int64_t n, ParticleSoA p);
 // packed == nullptr selects the explicit 32-byte-node path.  Leaves chain ids and squared distances (in the weight slots).
+// start (implicit trees only, may be nullptr): per-cell traversal start built by launch_build_locate_start
 int launch_locate(hipStream_t s, const KdNode* tree, const uint32_t* packed, ImplicitGeom ig, int32_t n_cells, int levels,
-                  ParticleSoA p, int64_t n, GaussParams gp);
+                  ParticleSoA p, int64_t n, GaussParams gp, const unsigned long long* start = nullptr);
+// For every cell of the block: the deepest tree node a walk for a query inside that cell is guaranteed to reach with an empty
+// stack and an empty chain (entry: offset | size << 25 | axis << 50).  See k_build_locate_start.
+int launch_build_locate_start(hipStream_t s, const uint32_t* packed, ImplicitGeom ig, int32_t n_cells, double maxdist, unsigned long long* start);
 // forms the normalised Gaussian weights from the parked squared distances, then deposits (LDS-aggregated)
 // cell arrays are indexed with (global cell id - cell_base) and hold n_field cells (slab storage); ids outside are skipped
 struct CellWindow { int64_t base; int64_t n_field; };
