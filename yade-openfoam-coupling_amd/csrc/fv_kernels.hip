@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256) void k_courant(FvGeo g, CFace3 phi, double* __
         for (int d = 0; d < 3; ++d)
 #pragma unroll
             for (int sd = 0; sd < 2; ++sd) s += fabs(phi.a[d][cface(g, d, sd, i, j, k)]);
-        v[0] = fmax(v[0], s / g.V);
+        v[0] = fmax(v[0], s * g.rV);
         v[1] += s;
     }
     const int mx[2] = {1, 0};
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256) void k_pre_coupling(FvGeo g, const double* __r
                 Ub(g, U, c, 2 * d + s, fv[s]);
                 if (pf) {
                     fp[s] = pbv(g, p, psn, c, d, s, cface(g, d, s, i, j, k));
-                    for (int q = 0; q < 3; ++q) lap[q] += 1.0 * g.Af * (fv[s][q] - uc[q]) / (0.5 * g.dx);     // alphaf = 1 on the boundary
+                    for (int q = 0; q < 3; ++q) lap[q] += 1.0 * g.Af * (fv[s][q] - uc[q]) * g.rhdx;     // alphaf = 1 on the boundary
                 }
             } else {
                 const int nb = c + (s ? stride_of(g, d) : -stride_of(g, d));
@@ -287,12 +287,12 @@ __global__ __launch_bounds__(256) void k_pre_coupling(FvGeo g, const double* __r
                 if (pf) {
                     fp[s] = 0.5 * (p[c] + p[nb]);
                     const double af = 0.5 * (alpha[c] + alpha[nb]);
-                    for (int q = 0; q < 3; ++q) lap[q] += af * g.Af * (un[q] - uc[q]) / g.dx;
+                    for (int q = 0; q < 3; ++q) lap[q] += af * g.Af * (un[q] - uc[q]) * g.rdx;
                 }
             }
         }
-        for (int q = 0; q < 3; ++q) T[3 * d + q] = (fv[1][q] - fv[0][q]) / g.dx;
-        if (pf) gradP[3 * (size_t)c + d] = (fp[1] - fp[0]) / g.dx;
+        for (int q = 0; q < 3; ++q) T[3 * d + q] = (fv[1][q] - fv[0][q]) * g.rdx;
+        if (pf) gradP[3 * (size_t)c + d] = (fp[1] - fp[0]) * g.rdx;
         if (ddtU) {     // fvc::div(phic, Uc), Gauss linear: the face values are the ones the gradient just used
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
@@ -304,11 +304,11 @@ __global__ __launch_bounds__(256) void k_pre_coupling(FvGeo g, const double* __r
     // pimpleFoamYade.C:73 ddtU_f = fvc::ddt(Uc) + fvc::div(phic, Uc); the ddt term is identically zero there (Uc.oldTime() is
     // stored on that access, before Uc is written in the new step), only consumer: addedMassForce (fy_set_force_models)
     if (ddtU)
-        for (int q = 0; q < 3; ++q) ddtU[3 * (size_t)c + q] = conv[q] / g.V;
+        for (int q = 0; q < 3; ++q) ddtU[3 * (size_t)c + q] = conv[q] * g.rV;
     if (write_vgrad)
         for (int q = 0; q < 9; ++q) vGrad[9 * (size_t)c + q] = T[q];
     if (pf)
-        for (int q = 0; q < 3; ++q) divT[3 * (size_t)c + q] = 2 * g.nu * (lap[q] / g.V);
+        for (int q = 0; q < 3; ++q) divT[3 * (size_t)c + q] = 2 * g.nu * (lap[q] * g.rV);
     if (Gout) {
         const double tr = T[0] + T[4] + T[8];
         const double an = alpha[c] * g.nu;
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(256) void k_div_G(FvGeo g, const double* __restrict
             if (onb(g, d, s, i, j, k)) for (int q = 0; q < 3; ++q) fv[s][q] = G[9 * (size_t)c + 3 * d + q];
             else { const int nb = c + (s ? stride_of(g, d) : -stride_of(g, d)); for (int q = 0; q < 3; ++q) fv[s][q] = 0.5 * (G[9 * (size_t)c + 3 * d + q] + G[9 * (size_t)nb + 3 * d + q]); }
         }
-        for (int q = 0; q < 3; ++q) acc[q] += (fv[1][q] - fv[0][q]) / g.dx;
+        for (int q = 0; q < 3; ++q) acc[q] += (fv[1][q] - fv[0][q]) * g.rdx;
     }
     for (int q = 0; q < 3; ++q) divG[3 * (size_t)c + q] = acc[q];
 }
@@ -426,15 +426,15 @@ __global__ __launch_bounds__(256) void k_bmom(FvGeo g, const double* __restrict_
                 if (onb(g, d, s, i, j, k)) fv[s] = pbv(g, p, psn, c, d, s, cface(g, d, s, i, j, k));
                 else fv[s] = 0.5 * (p[c] + p[c + (s ? stride_of(g, d) : -stride_of(g, d))]);
             }
-            bmom[3 * (size_t)c + d] = src[3 * (size_t)c + d] - g.V * ((fv[1] - fv[0]) / g.dx);
+            bmom[3 * (size_t)c + d] = src[3 * (size_t)c + d] - g.V * ((fv[1] - fv[0]) * g.rdx);
         } else {
             double sm = 0;
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const int f = cface(g, d, s, i, j, k);
                 double sng;
-                if (onb(g, d, s, i, j, k)) { const double pbd = pbv(g, p, psn, c, d, s, f); sng = s ? (pbd - p[c]) / (0.5 * g.dx) : (p[c] - pbd) / (0.5 * g.dx); }
-                else sng = s ? (p[c + stride_of(g, d)] - p[c]) / g.dx : (p[c] - p[c - stride_of(g, d)]) / g.dx;
+                if (onb(g, d, s, i, j, k)) { const double pbd = pbv(g, p, psn, c, d, s, f); sng = s ? (pbd - p[c]) * g.rhdx : (p[c] - pbd) * g.rhdx; }
+                else sng = s ? (p[c + stride_of(g, d)] - p[c]) * g.rdx : (p[c] - p[c - stride_of(g, d)]) * g.rdx;
                 sm += phiForces.a[d][f] / rAUf.a[d][f] - sng * g.Af;
             }
             bmom[3 * (size_t)c + d] = src[3 * (size_t)c + d] + g.V * (sm / (2.0 * g.Af));
@@ -503,7 +503,7 @@ __global__ __launch_bounds__(256) void k_HbyA(FvGeo g, Mom7 M, const double* __r
                 for (int q = 0; q < 3; ++q) acc[q] -= a * U[3 * (size_t)nb + q];
             }
     const double r = rAU[c];
-    for (int q = 0; q < 3; ++q) HbyA[3 * (size_t)c + q] = r * (acc[q] / g.V);
+    for (int q = 0; q < 3; ++q) HbyA[3 * (size_t)c + q] = r * (acc[q] * g.rV);
 }
 
 // pEqn in SPD form: sum_f g_f (p_P - p_nb) [+ g_b (p_P - p_b)] = -(ddt(alpha) V + sum_out alphaf phiHbyA)   (icoFoamYade.C:118-123, pEqn.H:26-33)
@@ -562,7 +562,7 @@ __global__ __launch_bounds__(256) void k_cont_err(FvGeo g, CFace3 phi, CFace3 al
         for (int d = 0; d < 3; ++d)
 #pragma unroll
             for (int s = 0; s < 2; ++s) { const int f = cface(g, d, s, i, j, k); dv += (s ? 1.0 : -1.0) * (g.pimple ? alphaf.a[d][f] : 1.0) * phi.a[d][f]; }
-        double ce = dv / g.V;
+        double ce = dv * g.rV;
         if (g.pimple) ce += (alpha[c] - alphaOld[c]) / g.dt;
         v[0] += fabs(ce) * g.V;
         v[1] += ce * g.V;
@@ -590,7 +590,7 @@ __global__ __launch_bounds__(256) void k_U_correct(FvGeo g, const double* __rest
                 if (onb(g, d, s, i, j, k)) fv[s] = pbv(g, p, psn, c, d, s, cface(g, d, s, i, j, k));
                 else fv[s] = 0.5 * (p[c] + p[c + (s ? stride_of(g, d) : -stride_of(g, d))]);
             }
-            U[3 * (size_t)c + d] = HbyA[3 * (size_t)c + d] - r * ((fv[1] - fv[0]) / g.dx);
+            U[3 * (size_t)c + d] = HbyA[3 * (size_t)c + d] - r * ((fv[1] - fv[0]) * g.rdx);
         } else {
             double sm = 0;
 #pragma unroll

@@ -18,6 +18,7 @@ struct FvGeo {
     int gz, c0;             // ghost planes per side, storage index of the first owned cell (= gz*nx*ny)
     int kglob0, nzglob;     // global k of the first owned plane, global number of planes
     double dx, Af, V;
+    double rdx, rhdx, rV;   // 1/dx, 1/(dx/2), 1/V: the uniform block's deltaCoeffs and reciprocal volume (one FP64 multiply instead of a ~60-cycle divide per use)
     int u_bc[6];            // FY_BC_U_*
     double u_val[6][3];
     int p_bc[6];            // FY_BC_P_*

@@ -114,6 +114,7 @@ struct Solver {
         Nglob = (int64_t)plane * c->nz;
         g.nx = c->nx; g.ny = c->ny; g.nz = nzl; g.Nc = Nc; g.gz = gz; g.c0 = (int)(plane * gz); g.kglob0 = comm->rank * nzl; g.nzglob = c->nz;
         g.dx = c->dx; g.Af = c->dx * c->dx; g.V = c->dx * c->dx * c->dx;
+        g.rdx = 1.0 / g.dx; g.rhdx = 1.0 / (0.5 * g.dx); g.rV = 1.0 / g.V;
         g.pimple = pimple ? 1 : 0; g.dt = c->dt; g.nu = c->nu;
         bool need_ref = true;
         for (int q = 0; q < 6; ++q) {

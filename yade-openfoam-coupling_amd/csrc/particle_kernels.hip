@@ -394,18 +394,27 @@ __global__ __launch_bounds__(kDepThreads) void k_deposit(ParticleSoA p, int64_t 
             const double pVol = M_PI * pow(dia, 3.0) / 6.0;                   // FoamYade.H:36
             const double vx = p.vx[i], vy = p.vy[i], vz = p.vz[i];
             // calcInterpWeightGaussian FoamYade.C:301-314, slots visited in ascending-d2 order (= reverse push order)
+            // the unnormalised weights stay in registers (k <= 12 < kMaxK, fully unrolled so that wt[] is not indexed dynamically):
+            // every weight slot is read once (d2) and written once (w) instead of being rewritten in place in between
             double allwt = 0.0;
-            for (int t = 0; t < k; ++t) {
-                const size_t slot = (size_t)((chain - 1 - t) & (kMaxK - 1)) * p.cap + (size_t)i;
-                const double distsq = p.w[slot];
-                const double weight = exp(-distsq / gp.two_sigma2) * gp.range_cu * gp.sigma_pi;
-                allwt += weight;
-                p.w[slot] = weight;
+            double wt[kMaxK];
+#pragma unroll
+            for (int t = 0; t < kMaxK; ++t) {
+                wt[t] = 0.0;
+                if (t < k) {
+                    const size_t slot = (size_t)((chain - 1 - t) & (kMaxK - 1)) * p.cap + (size_t)i;
+                    const double distsq = p.w[slot];
+                    wt[t] = exp(-distsq / gp.two_sigma2) * gp.range_cu * gp.sigma_pi;
+                    allwt += wt[t];
+                }
             }
+#pragma unroll
+            for (int t = 0; t < kMaxK; ++t)
+                if (t < k) p.w[(size_t)((chain - 1 - t) & (kMaxK - 1)) * p.cap + (size_t)i] = wt[t] / allwt;   // FoamYade.C:312-314
+#pragma unroll 1
             for (int t = 0; t < k; ++t) {
                 const size_t slot = (size_t)((chain - 1 - t) & (kMaxK - 1)) * p.cap + (size_t)i;
-                const double weight = p.w[slot] / allwt;                      // FoamYade.C:312-314
-                p.w[slot] = weight;
+                const double weight = p.w[slot];                              // just written by this lane (L2 hit)
                 const int64_t cl = (int64_t)p.ids[slot] - cw.base;          // storage index (slab window)
                 if (cl < 0 || cl >= cw.n_field) continue;
                 const int32_t cid = (int32_t)cl;
