@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256) void k_pre_coupling(FvGeo g, const double* __r
     const int c = t + g.c0;
     const bool pf = g.pimple && write_pfields;          // gradP and divT wanted
     const double uc[3] = {U[3 * (size_t)c], U[3 * (size_t)c + 1], U[3 * (size_t)c + 2]};
-    double lap[3] = {0, 0, 0}, T[9], conv[3] = {0, 0, 0};
+    double lap[3] = {0, 0, 0}, T[9], conv[3] = {0, 0, 0}, gp3[3] = {0, 0, 0};
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
         double fv[2][3], fp[2] = {0, 0};
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(256) void k_pre_coupling(FvGeo g, const double* __r
             }
         }
         for (int q = 0; q < 3; ++q) T[3 * d + q] = (fv[1][q] - fv[0][q]) * g.rdx;
-        if (pf) gradP[3 * (size_t)c + d] = (fp[1] - fp[0]) * g.rdx;
+        if (pf) gp3[d] = (fp[1] - fp[0]) * g.rdx;
         if (ddtU) {     // fvc::div(phic, Uc), Gauss linear: the face values are the ones the gradient just used
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
@@ -307,6 +307,8 @@ __global__ __launch_bounds__(256) void k_pre_coupling(FvGeo g, const double* __r
         for (int q = 0; q < 3; ++q) ddtU[3 * (size_t)c + q] = conv[q] * g.rV;
     if (write_vgrad)
         for (int q = 0; q < 9; ++q) vGrad[9 * (size_t)c + q] = T[q];
+    if (pf)
+        for (int q = 0; q < 3; ++q) gradP[3 * (size_t)c + q] = gp3[q];
     if (pf)
         for (int q = 0; q < 3; ++q) divT[3 * (size_t)c + q] = 2 * g.nu * (lap[q] * g.rV);
     if (Gout) {
@@ -417,6 +419,7 @@ __global__ __launch_bounds__(256) void k_bmom(FvGeo g, const double* __restrict_
     if (t >= g.Nc) return;
     int i, j, k; ijk_of(g, t, i, j, k);
     const int c = t + g.c0;
+    double out[3];      // stored together at the end: component stores issued far apart reach HBM as three partial-line writes
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
         if (!g.pimple) {
@@ -426,7 +429,7 @@ __global__ __launch_bounds__(256) void k_bmom(FvGeo g, const double* __restrict_
                 if (onb(g, d, s, i, j, k)) fv[s] = pbv(g, p, psn, c, d, s, cface(g, d, s, i, j, k));
                 else fv[s] = 0.5 * (p[c] + p[c + (s ? stride_of(g, d) : -stride_of(g, d))]);
             }
-            bmom[3 * (size_t)c + d] = src[3 * (size_t)c + d] - g.V * ((fv[1] - fv[0]) * g.rdx);
+            out[d] = src[3 * (size_t)c + d] - g.V * ((fv[1] - fv[0]) * g.rdx);
         } else {
             double sm = 0;
 #pragma unroll
@@ -437,9 +440,10 @@ __global__ __launch_bounds__(256) void k_bmom(FvGeo g, const double* __restrict_
                 else sng = s ? (p[c + stride_of(g, d)] - p[c]) * g.rdx : (p[c] - p[c - stride_of(g, d)]) * g.rdx;
                 sm += phiForces.a[d][f] / rAUf.a[d][f] - sng * g.Af;
             }
-            bmom[3 * (size_t)c + d] = src[3 * (size_t)c + d] + g.V * (sm / (2.0 * g.Af));
+            out[d] = src[3 * (size_t)c + d] + g.V * (sm / (2.0 * g.Af));
         }
     }
+    for (int d = 0; d < 3; ++d) bmom[3 * (size_t)c + d] = out[d];
 }
 
 // One fused Jacobi pass over the 3 velocity components: with x the current iterate, accumulate the L1 residual |b - A x|
@@ -581,6 +585,7 @@ __global__ __launch_bounds__(256) void k_U_correct(FvGeo g, const double* __rest
     int i, j, k; ijk_of(g, t, i, j, k);
     const int c = t + g.c0;
     const double r = rAU[c];
+    double out[3];      // see k_bmom
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
         if (!g.pimple) {
@@ -590,14 +595,15 @@ __global__ __launch_bounds__(256) void k_U_correct(FvGeo g, const double* __rest
                 if (onb(g, d, s, i, j, k)) fv[s] = pbv(g, p, psn, c, d, s, cface(g, d, s, i, j, k));
                 else fv[s] = 0.5 * (p[c] + p[c + (s ? stride_of(g, d) : -stride_of(g, d))]);
             }
-            U[3 * (size_t)c + d] = HbyA[3 * (size_t)c + d] - r * ((fv[1] - fv[0]) * g.rdx);
+            out[d] = HbyA[3 * (size_t)c + d] - r * ((fv[1] - fv[0]) * g.rdx);
         } else {
             double sm = 0;
 #pragma unroll
             for (int s = 0; s < 2; ++s) { const int f = cface(g, d, s, i, j, k); sm += (phiForces.a[d][f] - pflux.a[d][f] / alphaf.a[d][f]) / rAUf.a[d][f]; }
-            U[3 * (size_t)c + d] = HbyA[3 * (size_t)c + d] + r * (sm / (2.0 * g.Af));
+            out[d] = HbyA[3 * (size_t)c + d] + r * (sm / (2.0 * g.Af));
         }
     }
+    for (int d = 0; d < 3; ++d) U[3 * (size_t)c + d] = out[d];
 }
 
 // ------------------------------------------------------------------------------------------------ pressure solver
