@@ -127,21 +127,45 @@ def main():
 
     prod = ge.load_product()
     case = c3_case(prod, args.n, args.dt, args.p_solver, world)
-    comm = None
-    if world > 1 or args.force_rccl:
-        # one RCCL communicator for the slab exchanges; the 128-byte unique id travels over torch.distributed
-        os.environ.setdefault("FOAMYADE_TREE_CACHE_DIR", "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp")
-        idt = torch.zeros(128, dtype=torch.uint8, device=dev)
-        if rank == 0:
-            import glob
-            for f in glob.glob(os.path.join(os.environ["FOAMYADE_TREE_CACHE_DIR"], "fy_tree_*.lock")):      # stale locks of a crashed run
-                os.remove(f)
-            idt = torch.tensor(list(prod.rccl_unique_id()), dtype=torch.uint8, device=dev)
-        if dist is not None:
-            dist.broadcast(idt, 0)
-        comm = prod.rccl_comm(rank, world, bytes(idt.cpu().tolist()), local_rank)
-    solver = prod.Solver(case, device=local_rank, comm=comm)
-    rec = c3_particles(torch, args.particles, args.n, 3 + rank, dev, slab=rank)
+    comm, solver, setup_err = None, None, ""
+    try:
+        if world > 1 or args.force_rccl:
+            # one RCCL communicator for the slab exchanges; the 128-byte unique id travels over torch.distributed
+            os.environ.setdefault("FOAMYADE_TREE_CACHE_DIR", "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp")
+            idt = torch.zeros(128, dtype=torch.uint8, device=dev)
+            if rank == 0:
+                import glob
+                for f in glob.glob(os.path.join(os.environ["FOAMYADE_TREE_CACHE_DIR"], "fy_tree_*.lock")):      # stale locks of a crashed run
+                    os.remove(f)
+                idt = torch.tensor(list(prod.rccl_unique_id()), dtype=torch.uint8, device=dev)
+            if dist is not None:
+                dist.broadcast(idt, 0)
+            comm = prod.rccl_comm(rank, world, bytes(idt.cpu().tolist()), local_rank)
+        solver = prod.Solver(case, device=local_rank, comm=comm)
+    except Exception as e:                                       # noqa: BLE001  (reported below, never swallowed)
+        setup_err = f"{type(e).__name__}: {e}"
+    # every rank must take the same path: agree on whether the slab set-up worked everywhere
+    slabs_ok = 0.0 if setup_err else 1.0
+    if dist is not None:
+        t = torch.tensor([slabs_ok], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        slabs_ok = float(t.item())
+    parallelism = "single GPU" if world == 1 else f"{world} z-slabs of one {args.n}x{args.n}x{args.n * world} box, RCCL halos + all-reduces over xGMI"
+    slab_of_rank = rank
+    if slabs_ok < 1.0:
+        if world == 1:
+            raise SystemExit(f"bench.py: solver set-up failed: {setup_err}")
+        # LOUD fallback, labelled in the JSON line: N independent C3 boxes (no inter-GPU exchange), so that the run still reports
+        # a per-GPU number instead of nothing.  This is NOT the sharded path.
+        print(f"[bench rank {rank}] WARNING: z-slab/RCCL set-up failed on at least one rank ({setup_err or 'another rank'}); "
+              f"falling back to {world} independent single-GPU replicas", file=sys.stderr, flush=True)
+        if solver is not None:
+            solver.close()
+        case = c3_case(prod, args.n, args.dt, args.p_solver, 1)
+        solver = prod.Solver(case, device=local_rank)
+        parallelism = f"FALLBACK: {world} independent replicas of the single-GPU case, no exchange (z-slab/RCCL set-up failed: {setup_err or 'on another rank'})"
+        slab_of_rank = 0
+    rec = c3_particles(torch, args.particles, args.n, 3 + rank, dev, slab=slab_of_rank)
     solver.set_particles_device(rec)
     solver.enable_particle_timing(True)
     nc = args.n ** 3                      # cells per rank (one C3-sized slab)
@@ -225,7 +249,7 @@ def main():
                    "cells": nc, "particles": np_part, "dt": args.dt, "pimple": {"nOuterCorrectors": 1, "nCorrectors": 2},
                    "p_solver": "PCG+MG V(2,2) damped Jacobi" if args.p_solver == 1 else "PCG+Jacobi",
                    "p_tol": [case.p_tol, case.p_rel_tol, case.p_final_tol, case.p_final_rel_tol],
-                   "parallelism": "single GPU" if world == 1 else f"{world} z-slabs of one {args.n}x{args.n}x{args.n * world} box, RCCL halos + all-reduces over xGMI",
+                   "parallelism": parallelism,
                    "global_cells": nc * world, "global_particles": np_part * world},
         "per_step_ms": {k: round(acc[k] / K, 3) for k in ("particle", "bin", "locate", "depfin", "force", "momentum", "pressure", "other")},
         "p_iters_per_step": acc["p_iters"] / K, "u_iters_per_step": acc["u_iters"] / K,
