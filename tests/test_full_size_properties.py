@@ -1,0 +1,134 @@
+"""The hot path at BASELINE.json's FULL size (config C3: 160^3 = 4 096 000 cells, 10 M particles), through the C-ABI, checked with
+properties that do not need a reference run of that size (the CPU oracle would take minutes per step there):
+
+  partition of unity      sum_t w[p][t] == 1 for every located particle                        (FoamYade.C:312-314)
+  stencil structure       ids in ascending-distance order, all inside sqrt(maxdist), the first one is the cell that contains the
+                          particle (the nearest centre), no repeats                             (meshTree.C:148-238)
+  deposit                 alpha and uParticle of all 4 M cells equal an independent host accumulation of the 54.6 M (particle, cell)
+                          pairs, 0.1 floor included; no solid volume is lost                    (FoamYade.C:261-290, 318-328)
+  determinism             a second setParticleAction on the same inputs: identical stencils, fields equal to rounding
+  FV known answer         quiescent closed box under gravity at 160^3: U stays zero, p is hydrostatic, continuity error ~ 0
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+N = 160
+NP = 10_000_000
+
+
+def c3_records(seed=3):
+    rs = np.random.Generator(np.random.PCG64(seed))
+    dx = 1.0 / N
+    rec = np.zeros((NP, 10))
+    rec[:, 0:3] = rs.random((NP, 3))
+    rec[:, 2] *= 0.6
+    rec[:, 3:6] = rs.normal(0.0, 0.05, (NP, 3))
+    rec[:, 9] = 0.2 * dx
+    return rec
+
+
+def test_particle_path_properties_at_c3_size(product):
+    dx = 1.0 / N
+    Nc = N ** 3
+    fields = dict(U=np.zeros((Nc, 3)), gradP=np.zeros((Nc, 3)), vGrad=np.zeros((Nc, 9)), divT=np.zeros((Nc, 3)), ddtU=np.zeros((Nc, 3)))
+    fields["U"][:, 0] = 0.1
+    fields["gradP"][:, 2] = -9810.0
+    mut = dict(uSourceDrag=np.zeros(Nc), alpha=np.zeros(Nc), uSource=np.zeros((Nc, 3)), uParticle=np.zeros((Nc, 3)))
+    mesh = product.BlockMesh(N, N, N, dx, (0.0, 0.0, 0.0))
+    fy = product.FoamYade(mesh, fields["U"], fields["gradP"], fields["vGrad"], fields["divT"], fields["ddtU"], (0, 0, -9.81),
+                          mut["uSourceDrag"], mut["alpha"], mut["uSource"], mut["uParticle"], True)
+    fy.setScalarProperties(2650.0, 1000.0, 1e-6)
+    rec = c3_records()
+    fy.setParticles([rec])
+    fy.setParticleAction(1e-4)
+    k, ids, w, chain = fy.stencils(0)
+    F = fy.forces(0)
+    found = fy.found(0)
+    alpha1, uP1, uS1 = mut["alpha"].copy(), mut["uParticle"].copy(), mut["uSource"].copy()
+
+    # ---- every particle of this cloud lies inside the block: all located, except those inside the tree's root cell (quirk Q2)
+    root = int(fy.tree_preorder()[0])
+    cell_of = (np.minimum((rec[:, 0] / dx).astype(np.int64), N - 1) + N * (np.minimum((rec[:, 1] / dx).astype(np.int64), N - 1)
+               + N * np.minimum((rec[:, 2] / dx).astype(np.int64), N - 1)))
+    assert np.array_equal(found == 1, k > 0)
+    assert np.array_equal(k == 0, cell_of == root)
+    ok = (k > 0) & (chain <= 12)
+    assert ok.sum() > 0.999 * NP
+    assert 5.3 < k[ok].mean() < 5.6                                  # k-bar = 5.46 on a uniform block
+
+    # ---- partition of unity
+    valid = np.arange(16)[None, :] < k[:, None]
+    wsum = np.where(valid, w, 0.0).sum(axis=1)
+    np.testing.assert_allclose(wsum[ok], 1.0, rtol=0, atol=1e-12)
+    assert np.all(w[valid] > 0)
+
+    # ---- stencil structure, in chunks (10 M x 16 distances)
+    maxdist = 1.25 * (4 * dx) ** 2
+    for lo in range(0, NP, 2_000_000):
+        sl = slice(lo, min(lo + 2_000_000, NP))
+        idc = ids[sl].astype(np.int64)
+        v = valid[sl]
+        ci, cj, ck = idc % N, (idc // N) % N, idc // (N * N)
+        d2 = (((ci + 0.5) * dx - rec[sl, 0:1]) ** 2 + ((cj + 0.5) * dx - rec[sl, 1:2]) ** 2) + ((ck + 0.5) * dx - rec[sl, 2:3]) ** 2
+        d2 = np.where(v, d2, np.inf)
+        o = ok[sl]
+        with np.errstate(invalid="ignore"):                          # inf - inf in the unused tail of a row
+            assert np.all(np.diff(d2[o], axis=1)[v[o][:, 1:]] > 0)   # strictly ascending: an improvement chain has no ties or repeats
+        assert np.all(d2[o][v[o]] < maxdist)
+        inner = o & (cell_of[sl] != root)
+        assert np.array_equal(idc[inner, 0], cell_of[sl][inner])     # nearest centre = the containing cell
+        # weights are the normalised Gaussian of those distances
+        sig = 4 * dx * 0.42460
+        g = np.where(v, np.exp(-np.where(v, d2, 0.0) / (2 * sig * sig)), 0.0)
+        g /= np.maximum(g.sum(axis=1, keepdims=True), 1e-300)
+        np.testing.assert_allclose(np.where(v, w[sl], 0.0)[o], g[o], rtol=1e-9, atol=1e-15)
+
+    # ---- the deposit against an independent host accumulation of all (particle, cell) pairs (FoamYade.C:261-290, 318-328).
+    # The improvement chain makes tree ancestors "hub" cells that collect weight from every particle within sqrt(maxdist), so a few
+    # cells do saturate at the 0.1 floor even at this loading: the floor is part of the check.
+    V = dx ** 3
+    pvol = np.pi * (2 * rec[:, 9]) ** 3 / 6.0
+    flat_ids = ids[valid].astype(np.int64)
+    wp = (w * pvol[:, None])[valid]
+    acc = np.bincount(flat_ids, weights=wp, minlength=Nc)
+    touched = np.bincount(flat_ids, minlength=Nc) > 0
+    alpha_ref = np.where(touched, np.maximum(1.0 - acc / V, 0.10), 1.0)
+    np.testing.assert_allclose(alpha1, alpha_ref, rtol=1e-10, atol=1e-12)
+    assert (alpha1 == 0.1).sum() > 0 and (alpha1 == 1.0).sum() > 0.3 * Nc          # hubs floored; the upper 40 % of the box is empty
+    np.testing.assert_allclose(acc.sum(), pvol[k > 0].sum(), rtol=1e-10)           # partition of unity again: no solid volume is lost
+    for a in range(3):
+        up = np.bincount(flat_ids, weights=wp * np.repeat(rec[:, 3 + a], k), minlength=Nc) / V
+        np.testing.assert_allclose(uP1[:, a], up, rtol=1e-9, atol=1e-12 * np.abs(up).max())
+    assert np.all(F[k == 0] == 0.0) and np.all(np.isfinite(F)) and np.all(F[:, 3:] == 0.0)
+    assert np.abs(F[ok, :3]).max() > 0
+
+    # ---- determinism: same inputs again (alpha etc. were NOT reset: setCellVolFraction assigns, uSource accumulates)
+    fy.setSourceZero()
+    assert np.all(mut["alpha"] == 1.0) and np.all(mut["uSource"] == 0.0)
+    fy.setParticleAction(1e-4)
+    k2, ids2, w2, chain2 = fy.stencils(0)
+    assert np.array_equal(k2, k) and np.array_equal(ids2, ids) and np.array_equal(chain2, chain) and np.array_equal(w2, w)
+    np.testing.assert_allclose(mut["alpha"], alpha1, rtol=1e-12)
+    np.testing.assert_allclose(mut["uSource"], uS1, rtol=1e-9, atol=1e-9 * np.abs(uS1).max())
+    np.testing.assert_allclose(fy.forces(0), F, rtol=1e-9, atol=1e-12 * np.abs(F).max())
+    fy.close()
+
+
+def test_hydrostatic_box_at_c3_size(product):
+    """quiescent closed box, no-slip walls, fixedFluxPressure, g = -9.81 e_z at 160^3: the discrete hydrostatic state is a fixed point"""
+    dx = 1.0 / N
+    case = product.make_case(product.FY_SOLVER_PIMPLE, N, N, N, dx, 1e-4, 1e-6, rho_f=1000.0, rho_p=2650.0, g=(0.0, 0.0, -9.81),
+                             u_bc=[product.FY_BC_U_FIXED_VALUE] * 6, u_val=[(0, 0, 0)] * 6, p_bc=[product.FY_BC_P_FIXED_FLUX] * 6,
+                             n_outer_correctors=1, n_correctors=2, p_solver=1)
+    s = product.Solver(case)
+    for _ in range(2):
+        s.step()
+    st = s.stats()
+    # the pressure solves stop at a normalised residual of 1e-6 (p_final_tol), which bounds how exactly the flux balance is met
+    assert np.abs(s.get("U")).max() < 5e-6
+    p = s.get("p").reshape(N, N, N)
+    np.testing.assert_allclose((p[2:] - p[:-2]) / (2 * dx), -9.81, rtol=1e-3)      # same bound: solver tolerance, not discretisation
+    assert abs(st["cont_err_global"]) < 1e-9 and st["p_iters_total"] < 40
+    s.close()
