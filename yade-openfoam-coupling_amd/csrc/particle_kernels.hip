@@ -229,6 +229,7 @@ __global__ __launch_bounds__(kWave) void k_locate(const KdNode* __restrict__ tre
     const int64_t end = (base + kLocPPB < n) ? base + kLocPPB : n;
     int64_t next = base;                               // wave-uniform cursor into [base, end)
     const NodeVal root = fetch_node<IMPLICIT>(tree, packed, ig, 0u);
+    const double hdx = 0.5 * ig.dx;
 
     bool active = false;
     int64_t i = 0;
@@ -287,7 +288,7 @@ __global__ __launch_bounds__(kWave) void k_locate(const KdNode* __restrict__ tre
                         const uint32_t pa = (ea == 0 ? 2u : ea - 1u);               // the parent's split axis
                         const double org = (pa == 0 ? ig.ox : (pa == 1 ? ig.oy : ig.oz));
                         const double qq = (pa == 0 ? qx : (pa == 1 ? qy : qz));
-                        const double df = (org + ((double)idx + 0.5) * ig.dx) - qq;
+                        const double df = (org + (double)(2 * idx + 1) * hdx) - qq;
                         df2 = df * df;
                     } else {
                         eo = e.x; en = e.y & 0x3fffffffu; ea = e.y >> 30;
@@ -302,9 +303,11 @@ __global__ __launch_bounds__(kWave) void k_locate(const KdNode* __restrict__ tre
                 if constexpr (IMPLICIT) {
                     pk = packed[o];
                     const int ci = (int)(pk & 1023u), cj = (int)((pk >> 10) & 1023u), ck = (int)(pk >> 20);
-                    nd.x = ig.ox + ((double)ci + 0.5) * ig.dx;
-                    nd.y = ig.oy + ((double)cj + 0.5) * ig.dx;
-                    nd.z = ig.oz + ((double)ck + 0.5) * ig.dx;
+                    // (2i + 1) * (dx / 2) is the same real number as (i + 0.5) * dx and both factors are exact, so the rounded
+                    // product is the same double: one FP64 add less per axis
+                    nd.x = ig.ox + (double)(2 * ci + 1) * hdx;
+                    nd.y = ig.oy + (double)(2 * cj + 1) * hdx;
+                    nd.z = ig.oz + (double)(2 * ck + 1) * hdx;
                     nd.id = ci + ig.nx * (cj + ig.ny * ck);
                 } else {
                     nd = fetch_node<false>(tree, packed, ig, o);
@@ -326,7 +329,7 @@ __global__ __launch_bounds__(kWave) void k_locate(const KdNode* __restrict__ tre
                 // meshTree.C:200: df = node[axis] - q[axis] = -(q[axis] - node[axis]) exactly, so df*df is the squared term already
                 // formed for the distance and df > 0 <=> (q - node)[axis] < 0 -- same bits, three subtractions and a multiply fewer
                 const double mdf = (axis == 0 ? a : (axis == 1 ? b : c));
-                const double df2 = (axis == 0 ? aa : (axis == 1 ? bb : cc));
+                const double df2 = mdf * mdf;        // == aa / bb / cc of that axis, one multiply instead of a second three-way select
                 const uint32_t nl = nn >> 1, nr = nn - nl - 1;
                 uint32_t near_o, near_n, far_o, far_n;
                 if (mdf < 0.0) { near_o = o + 1; near_n = nl; far_o = o + 1 + nl; far_n = nr; }     // meshTree.C:206-208
