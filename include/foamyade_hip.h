@@ -221,6 +221,8 @@ typedef struct fy_comm fy_comm;
 int fy_rccl_unique_id(void* out128);
 int fy_comm_create_rccl(int rank, int size, const void* id128, int device_ordinal, fy_comm** out);
 int fy_comm_create_local_group(int n, fy_comm** out /* [n] */);
+/* diagnostic: calls made through this communicator so far: {neighbour exchanges, all-reduces, all-gathers, bytes sent to neighbours} */
+int fy_comm_stats(fy_comm*, uint64_t* out4);
 int fy_comm_destroy(fy_comm*);
 int fy_comm_rank(fy_comm*);
 int fy_comm_size(fy_comm*);

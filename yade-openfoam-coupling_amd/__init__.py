@@ -152,6 +152,7 @@ def lib():
     L.fy_comm_create_rccl.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(vp)]
     L.fy_comm_create_local_group.argtypes = [C.c_int, C.POINTER(vp)]
     L.fy_comm_destroy.argtypes = [vp]
+    L.fy_comm_stats.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.fy_comm_rank.argtypes = [vp]
     L.fy_comm_size.argtypes = [vp]
     L.fy_solver_create_slab.argtypes = [C.POINTER(CaseDesc), C.POINTER(Transport), C.c_int, vp, C.POINTER(vp)]
@@ -556,6 +557,12 @@ class VirtualSlabs:
 
     def stats(self):
         return [s.stats() for s in self.solvers]
+
+    def comm_stats(self, rank=0):
+        """(neighbour exchanges, all-reduces, all-gathers, bytes sent) issued so far by one slab's communicator"""
+        out = (C.c_uint64 * 4)()
+        _check(lib().fy_comm_stats(self.comms[rank], out))
+        return tuple(int(v) for v in out)
 
     def close(self):
         for s in self.solvers:

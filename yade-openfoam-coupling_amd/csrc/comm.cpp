@@ -46,6 +46,7 @@ struct LocalComm : Comm {
     std::shared_ptr<LocalShared> sh;
     int neighbour_exchange(hipStream_t s, const double* send_up, double* recv_from_down, const double* send_down, double* recv_from_up,
                            size_t count) override {
+        ++n_exchange; exchange_bytes += count * sizeof(double) * (size_t)((has_up() ? 1 : 0) + (has_down() ? 1 : 0));
         FY_HIP(hipStreamSynchronize(s));                       // my planes are final
         sh->send_up[rank] = send_up; sh->send_down[rank] = send_down;
         sh->bar.wait();
@@ -56,6 +57,7 @@ struct LocalComm : Comm {
         return FY_OK;
     }
     int allreduce(hipStream_t s, double* dev, int n, bool is_max) override {
+        ++n_allreduce;
         std::vector<double>& mine = sh->red[rank];
         mine.resize((size_t)n);
         FY_HIP(hipMemcpyAsync(mine.data(), dev, n * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -70,6 +72,7 @@ struct LocalComm : Comm {
         return FY_OK;
     }
     int allgather(hipStream_t s, const double* send, double* recv, size_t cnt) override {
+        ++n_allgather;
         FY_HIP(hipStreamSynchronize(s));
         sh->gather_src[rank] = send;
         sh->bar.wait();
@@ -159,6 +162,7 @@ struct RcclComm : Comm {
     // pairing cannot deadlock whatever order the ranks reach this call in.
     int neighbour_exchange(hipStream_t s, const double* send_up, double* recv_from_down, const double* send_down, double* recv_from_up,
                            size_t count) override {
+        ++n_exchange; exchange_bytes += count * sizeof(double) * (size_t)((has_up() ? 1 : 0) + (has_down() ? 1 : 0));
         FY_NCCL(A->GroupStart());
         if (has_up() && send_up) FY_NCCL(A->Send(send_up, count, kNcclDouble, rank + 1, comm, s));
         if (has_down() && recv_from_down) FY_NCCL(A->Recv(recv_from_down, count, kNcclDouble, rank - 1, comm, s));
@@ -168,10 +172,12 @@ struct RcclComm : Comm {
         return FY_OK;
     }
     int allreduce(hipStream_t s, double* dev, int n, bool is_max) override {
+        ++n_allreduce;
         FY_NCCL(A->AllReduce(dev, dev, (size_t)n, kNcclDouble, is_max ? kNcclMax : kNcclSum, comm, s));
         return FY_OK;
     }
     int allgather(hipStream_t s, const double* send, double* recv, size_t cnt) override {
+        ++n_allgather;
         FY_NCCL(A->AllGather(send, recv, cnt, kNcclDouble, comm, s));
         return FY_OK;
     }

@@ -17,6 +17,7 @@ namespace fy {
 
 struct Comm {
     int rank = 0, size = 1;
+    uint64_t n_exchange = 0, n_allreduce = 0, n_allgather = 0, exchange_bytes = 0;   // call counters (fy_comm_stats)
     virtual ~Comm() {}
     bool has_down() const { return rank > 0; }           // neighbour owning the planes below mine
     bool has_up() const { return rank + 1 < size; }

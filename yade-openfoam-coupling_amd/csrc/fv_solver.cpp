@@ -581,6 +581,11 @@ int fy_comm_create_rccl(int rank, int size, const void* id128, int device, fy_co
     return FY_OK;
 }
 int fy_comm_destroy(fy_comm* c) { if (c) { delete c->c; delete c; } return FY_OK; }
+int fy_comm_stats(fy_comm* c, uint64_t* out4) {
+    if (!c || !c->c || !out4) return fy::fail(FY_ERR_INVALID, "fy_comm_stats: null argument");
+    out4[0] = c->c->n_exchange; out4[1] = c->c->n_allreduce; out4[2] = c->c->n_allgather; out4[3] = c->c->exchange_bytes;
+    return FY_OK;
+}
 int fy_comm_rank(fy_comm* c) { return c && c->c ? c->c->rank : -1; }
 int fy_comm_size(fy_comm* c) { return c && c->c ? c->c->size : -1; }
 
