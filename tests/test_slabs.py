@@ -90,3 +90,36 @@ def test_coupled_slabs_match_single_domain(product, solver, n_slabs, models):
             assert sc > 0 and np.abs(fm[:, cols] - fo[:, cols]).max() <= 1e-6 * sc, (cols, np.abs(fm[:, cols] - fo[:, cols]).max() / sc)
     compare(many, one, ("U", "p", "alpha", "uSource") if solver else ("U", "p"), 1e-5)
     many.close(); one.close()
+
+
+@pytest.mark.parametrize("solver,n_slabs", [(1, 2), (1, 3), (0, 2)])
+def test_particle_ownership_when_every_slab_gets_all_particles(product, solver, n_slabs):
+    """owner = the slab that holds the particle's containing cell.  Every rank is handed the FULL record set (the
+    reference's serial-Yade broadcast); exactly one locates each particle, the others report found = -1 and zero force, and the
+    coupled result equals the single-domain run."""
+    n = 12
+    nz = 12 * n_slabs
+    dx = 0.1 / n
+    kw = dict(g=(0, 0, -9.81), p_bc=[2] * 6) if solver == 1 else {}
+    u_val = [(0, 0, 0)] * 6
+    if solver == 0:
+        u_val[3] = (1.0, 0, 0)
+    case = product.make_case(solver, n, n, nz, dx, 2e-4, 1e-5 if solver else 0.01, u_bc=[0] * 6, u_val=u_val, **kw)
+    one = product.Solver(case); many = product.VirtualSlabs(case, n_slabs)
+    gcase = gc.Case("s", n, n, nz, 0.1, gaussian=solver, np_=4000, seed=33, cluster=200, fast=20, outside=30, vel_scale=0.05)
+    for step in range(2):
+        rec = gc.particle_records(gcase, step)
+        # particles exactly on a slab interface and just outside the block in z are part of the set
+        rec[10:14, 2] = (nz // n_slabs) * dx
+        rec[14, 2] = -0.4 * dx
+        rec[15, 2] = nz * dx + 0.4 * dx
+        one.set_particles(rec); many.set_particles_all(rec)
+        one.step(); many.step()
+        found = np.stack([s.found() for s in many.solvers])
+        assert np.all((found == 1).sum(axis=0) <= 1)                                  # never two owners
+        assert np.array_equal((found == 1).sum(axis=0) == 1, one.found() == 1)        # located somewhere <=> located in the single domain
+        fo, fm = one.forces(), many.forces()
+        sc = np.abs(fo).max()
+        assert np.abs(fm - fo).max() <= 1e-6 * sc, np.abs(fm - fo).max() / sc
+    compare(many, one, ("U", "p", "alpha", "uSource") if solver else ("U", "p"), 1e-5)
+    many.close(); one.close()

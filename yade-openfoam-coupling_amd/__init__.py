@@ -426,6 +426,11 @@ class Solver:
         _check(lib().fy_get_forces_host(self._cpl, 0, _d(out)))
         return out
 
+    def found(self):
+        out = np.zeros(self._batch_n[0], dtype=np.int32)
+        _check(lib().fy_get_found_host(self._cpl, 0, _i(out)))
+        return out
+
     def step(self):
         _check(lib().fy_solver_step(self._h))
 
@@ -548,7 +553,18 @@ class VirtualSlabs:
             s.set_particles(rec[self._owner_idx[r]])
         self._n_part = rec.shape[0]
 
+    def set_particles_all(self, records):
+        """hand EVERY slab the full record set (what the reference's serial-Yade broadcast does, FoamYade.C:176-183): each rank
+        locates only the particles whose containing cell lies in its own planes (SlabOwn), all others are 'not found' there"""
+        rec = np.zeros((0, 10)) if records is None else np.ascontiguousarray(records, dtype=np.float64).reshape(-1, 10)
+        for s in self.solvers:
+            s.set_particles(rec)
+        self._owner_idx = None
+        self._n_part = rec.shape[0]
+
     def forces(self):
+        if self._owner_idx is None:          # full set everywhere: non-owners hold zeros, the sum is the serial protocol's all-reduce
+            return sum(s.forces() for s in self.solvers)
         out = np.zeros((self._n_part, 6))
         for r, s in enumerate(self.solvers):
             if len(self._owner_idx[r]):

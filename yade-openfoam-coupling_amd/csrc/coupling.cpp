@@ -355,7 +355,7 @@ int Coupling::run_batch(Batch& b) {
             FY_TRY(launch_build_locate_start(stream, d_tree_packed.p, implicit, n_cells, gp.maxdist, d_loc_start.p));
         }
         FY_TRY(launch_locate(stream, d_tree.p, use_implicit ? d_tree_packed.p : nullptr, implicit, n_cells, tree_levels, p, b.n, gp,
-                             use_implicit ? d_loc_start.p : nullptr));
+                             use_implicit ? d_loc_start.p : nullptr, slab_own()));
         if (timing) { timers[T_LOCATE].stop(stream); timers[T_FINALIZE].start(stream); }
         const CellWindow cw{slab.active ? slab.base : 0, n_field};
         FY_TRY(launch_deposit(stream, p, b.n, gp, cw, d_pvol_acc.p, d_up_acc.p, d_touched.p));
@@ -382,7 +382,7 @@ int Coupling::run_batch(Batch& b) {
         g.dx = mesh.dx; g.nx = mesh.nx; g.ny = mesh.ny; g.nz = mesh.nz;
         if (timing) timers[T_FORCE].start(stream);
         const CellWindow cw{slab.active ? slab.base : 0, n_field};
-        FY_TRY(launch_point_force(stream, b.d_rec, b.n, g, fp, cw, d_vol.p, dU, dVGrad, dUSource, b.force.p, b.found.p, b.incell.p));
+        FY_TRY(launch_point_force(stream, b.d_rec, b.n, g, fp, cw, d_vol.p, dU, dVGrad, dUSource, b.force.p, b.found.p, b.incell.p, slab_own()));
         if (timing) timers[T_FORCE].stop(stream);
     }
     return FY_OK;

@@ -36,6 +36,7 @@ struct SlabInfo {
     int gz = 0, nz = 0;
     size_t plane = 0, n_store = 0;
     int64_t base = 0;
+    int kglob0 = 0, nzglob = 0;          // global k of the first owned plane, global plane count (particle ownership)
 };
 
 struct Coupling {
@@ -100,6 +101,7 @@ struct Coupling {
     ParticleSoA soa_of(Batch& b);
     int set_particles_host(int bi, const double* rec, int64_t n);
     int set_particles_device(int bi, const double* d_rec, int64_t n);
+    SlabOwn slab_own() const { return SlabOwn{slab.active ? 1 : 0, slab.kglob0, slab.kglob0 + slab.nz, slab.nzglob, mesh.origin[2], mesh.dx}; }
     int run_batch(Batch& b);
     int set_force_models(unsigned flags);
     int set_particle_action(double dt);

@@ -217,6 +217,7 @@ struct Solver {
             if (S > 1) {
                 cpl->c.slab.active = true; cpl->c.slab.comm = comm; cpl->c.slab.gz = gz; cpl->c.slab.nz = nzl; cpl->c.slab.plane = plane;
                 cpl->c.slab.n_store = nstore; cpl->c.slab.base = ((int64_t)g.kglob0 - gz) * (int64_t)plane;
+                cpl->c.slab.kglob0 = g.kglob0; cpl->c.slab.nzglob = g.nzglob;
             }
             FY_TRY(cpl->c.create(&md, &fp, pimple ? 1 : 0, tr, device));      // gaussianInterp: false for ico, true for pimple (icoFoamYade.C:53, pimpleFoamYade.C:53)
             cpl->c.rhoP = c->rho_particle; cpl->c.rhoF = c->rho_fluid; cpl->c.nu = c->nu;   // setScalarProperties (icoFoamYade.C:55)

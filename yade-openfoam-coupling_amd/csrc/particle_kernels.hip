@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) void k_build_locate_start(const uint32_t* __re
 template <bool IMPLICIT>
 __global__ __launch_bounds__(kWave) void k_locate(const KdNode* __restrict__ tree, const uint32_t* __restrict__ packed, ImplicitGeom ig,
                                                   int32_t n_cells, ParticleSoA p, int64_t n, double maxdist,
-                                                  const unsigned long long* __restrict__ start) {
+                                                  const unsigned long long* __restrict__ start, SlabOwn own) {
     typedef typename StackEntry<IMPLICIT>::type entry_t;
     extern __shared__ __attribute__((aligned(16))) unsigned char stack_raw[];
     entry_t* stack = reinterpret_cast<entry_t*>(stack_raw);
@@ -263,6 +263,11 @@ __global__ __launch_bounds__(kWave) void k_locate(const KdNode* __restrict__ tre
                     }
                 }
                 active = true;
+                if (own.active) {                                // another slab's particle: not located here (k = 0)
+                    int kz = (int)floor((qz - own.oz) / own.dx);
+                    kz = min(max(kz, 0), own.nzglob - 1);
+                    if (!(qz == qz) || kz < own.k0 || kz >= own.k1) { p.chain_len[i] = 0; active = false; }
+                }
             }
             next += n_idle;
         } else if (n_idle == kWave) {
@@ -642,7 +647,7 @@ __global__ __launch_bounds__(256) void k_point_force(const double* __restrict__ 
                                                      const double* __restrict__ vol, const double* __restrict__ U,
                                                      const double* __restrict__ vGrad, double* __restrict__ uSource,
                                                      double* __restrict__ force_out, int32_t* __restrict__ found_out,
-                                                     int32_t* __restrict__ incell_out) {
+                                                     int32_t* __restrict__ incell_out, SlabOwn own) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const double* r = rec + 10 * i;
@@ -659,6 +664,12 @@ __global__ __launch_bounds__(256) void k_point_force(const double* __restrict__ 
     const int ci = min(g.nx - 1, (int)((x - g.bbmin[0]) / g.dx));
     const int cj = min(g.ny - 1, (int)((y - g.bbmin[1]) / g.dx));
     const int ck = min(g.nz - 1, (int)((z - g.bbmin[2]) / g.dx));
+    if (own.active && (ck < own.k0 || ck >= own.k1)) {         // in another slab's planes: that rank owns it
+        F[0] = F[1] = F[2] = F[3] = F[4] = F[5] = 0.0;
+        found_out[i] = -1;
+        incell_out[i] = -1;
+        return;
+    }
     const int cglob = ci + g.nx * (cj + g.ny * ck);
     found_out[i] = 1;
     incell_out[i] = cglob;
@@ -766,14 +777,14 @@ int launch_build_locate_start(hipStream_t s, const uint32_t* packed, ImplicitGeo
 }
 
 int launch_locate(hipStream_t s, const KdNode* tree, const uint32_t* packed, ImplicitGeom ig, int32_t n_cells, int levels,
-                  ParticleSoA p, int64_t n, GaussParams gp, const unsigned long long* start) {
+                  ParticleSoA p, int64_t n, GaussParams gp, const unsigned long long* start, SlabOwn own) {
     if (n <= 0) return FY_OK;
     // implicit entries are 8 B (needs offsets and sizes < 2^26), explicit ones 16 B
     if (packed && n_cells >= (1 << 25)) return fail(FY_ERR_UNSUPPORTED, "implicit-coordinate tree limited to 2^25 cells");
     const size_t lds = (size_t)(levels + 1) * kWave * (packed ? sizeof(unsigned long long) : sizeof(uint4));
     const dim3 grid(div_up(n, kLocPPB));
-    if (packed) hipLaunchKernelGGL(k_locate<true>, grid, dim3(kWave), lds, s, tree, packed, ig, n_cells, p, n, gp.maxdist, start);
-    else hipLaunchKernelGGL(k_locate<false>, grid, dim3(kWave), lds, s, tree, packed, ig, n_cells, p, n, gp.maxdist, nullptr);
+    if (packed) hipLaunchKernelGGL(k_locate<true>, grid, dim3(kWave), lds, s, tree, packed, ig, n_cells, p, n, gp.maxdist, start, own);
+    else hipLaunchKernelGGL(k_locate<false>, grid, dim3(kWave), lds, s, tree, packed, ig, n_cells, p, n, gp.maxdist, nullptr, own);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }
@@ -812,9 +823,9 @@ int launch_unpack_stencils(hipStream_t s, ParticleSoA p, int64_t n, int32_t* k, 
 
 int launch_point_force(hipStream_t s, const double* rec, int64_t n, BlockGeom g, ForceParams fp, CellWindow cw, const double* vol,
                        const double* U, const double* vGrad, double* uSource, double* force_out, int32_t* found_out,
-                       int32_t* incell_out) {
+                       int32_t* incell_out, SlabOwn own) {
     if (n <= 0) return FY_OK;
-    hipLaunchKernelGGL(k_point_force, dim3(div_up(n, 256)), dim3(256), 0, s, rec, n, g, fp, cw, vol, U, vGrad, uSource, force_out, found_out, incell_out);
+    hipLaunchKernelGGL(k_point_force, dim3(div_up(n, 256)), dim3(256), 0, s, rec, n, g, fp, cw, vol, U, vGrad, uSource, force_out, found_out, incell_out, own);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }

@@ -49,6 +49,14 @@ int launch_bin_scatter(hipStream_t s, const double* rec, int64_t n, const uint32
                        const uint32_t* start, const uint32_t* tile_off, ParticleSoA p);
 
 // implicit-coordinate tree (uniform hex block verified at create time): node = packed (i | j << 10 | k << 20)
+// z-slab ownership: a rank that is handed particles of the whole block -- what the reference's serial-Yade broadcast
+// does (FoamYade.C:176-183) -- locates only those whose containing (nearest) cell lies in its own planes [k0, k1); every other
+// particle is "not found" here (found = -1, zero force), exactly one rank owns each particle.  active = 0: single domain.
+struct SlabOwn {
+    int active, k0, k1, nzglob;
+    double oz, dx;
+};
+
 struct ImplicitGeom {
     double ox, oy, oz, dx;
     int nx, ny, nz;
@@ -58,7 +66,7 @@ int launch_bin_gather(hipStream_t s, const double* rec, int64_t n, ParticleSoA p
 // packed == nullptr selects the explicit 32-byte-node path.  Leaves chain ids and squared distances (in the weight slots).
 // start (implicit trees only, may be nullptr): per-cell traversal start built by launch_build_locate_start
 int launch_locate(hipStream_t s, const KdNode* tree, const uint32_t* packed, ImplicitGeom ig, int32_t n_cells, int levels,
-                  ParticleSoA p, int64_t n, GaussParams gp, const unsigned long long* start = nullptr);
+                  ParticleSoA p, int64_t n, GaussParams gp, const unsigned long long* start = nullptr, SlabOwn own = SlabOwn{});
 // For every cell of the block: the deepest tree node a walk for a query inside that cell is guaranteed to reach with an empty
 // stack and an empty chain (entry: offset | size << 25 | axis << 50).  See k_build_locate_start.
 int launch_build_locate_start(hipStream_t s, const uint32_t* packed, ImplicitGeom ig, int32_t n_cells, double maxdist, unsigned long long* start);
@@ -82,7 +90,7 @@ struct BlockGeom {
 };
 int launch_point_force(hipStream_t s, const double* rec, int64_t n, BlockGeom g, ForceParams fp, CellWindow cw, const double* vol,
                        const double* U, const double* vGrad, double* uSource, double* force_out, int32_t* found_out,
-                       int32_t* incell_out);
+                       int32_t* incell_out, SlabOwn own = SlabOwn{});
 
 int launch_fill_f64(hipStream_t s, double* p, size_t n, double v);
 int launch_set_source_zero(hipStream_t s, int32_t n_cells, int gaussian, double* uSourceDrag, double* alpha,
