@@ -324,6 +324,13 @@ int Coupling::set_particles_device(int bi, const double* d_rec, int64_t n) {
     return ensure_batch(b, n);
 }
 
+int Coupling::ensure_found(Batch& b) {
+    if (!b.found_stale) return FY_OK;
+    FY_TRY(launch_found_from_chain(stream, soa_of(b), b.n, b.found.p));
+    b.found_stale = false;
+    return FY_OK;
+}
+
 // the device part of setParticleAction for one Yade proc (FoamYade.C:612-628 loop body)
 int Coupling::run_batch(Batch& b) {
     if (b.n == 0 && !slab.active) return FY_OK;      // (in slab mode the halo exchanges are collective: every rank walks the same path)
@@ -371,6 +378,7 @@ int Coupling::run_batch(Batch& b) {
         if (timing) { timers[T_FINALIZE].stop(stream); timers[T_FORCE].start(stream); }
         FY_TRY(launch_force_gaussian(stream, p, b.n, fp, cw, d_vol.p, dU, dAlpha, dUParticle, dGradP, dDivT, dVGrad, dDdtU, b.d_rec,
                                      dUSourceDrag, dUSource, b.force.p, b.found.p));
+        b.found_stale = true;
         if (slab.active) {
             FY_TRY(halo_reverse_add(dUSourceDrag, 1, nullptr));
             FY_TRY(halo_reverse_add(dUSource, 3, nullptr));
@@ -467,6 +475,7 @@ int Coupling::send_results() {
         Batch& b = *batches[bi];
         b.h_found.resize((size_t)b.n); b.h_force.resize(6 * (size_t)b.n);
         if (b.n) {
+            FY_TRY(ensure_found(b));
             FY_HIP(hipMemcpyAsync(b.h_found.data(), b.found.p, (size_t)b.n * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
             FY_HIP(hipMemcpyAsync(b.h_force.data(), b.force.p, 6 * (size_t)b.n * sizeof(double), hipMemcpyDeviceToHost, stream));
         }
@@ -561,6 +570,7 @@ int Coupling::get_forces_host(int bi, double* out) {
 int Coupling::get_found_host(int bi, int32_t* out) {
     if (bi < 0 || bi >= (int)batches.size() || !out) return fail(FY_ERR_INVALID, "fy_get_found_host: bad batch");
     Batch& b = *batches[bi];
+    FY_TRY(ensure_found(b));
     if (b.n) FY_HIP(hipMemcpyAsync(out, b.found.p, (size_t)b.n * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
     FY_HIP(hipStreamSynchronize(stream));
     return FY_OK;

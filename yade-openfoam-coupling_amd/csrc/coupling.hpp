@@ -22,6 +22,7 @@ struct Batch {
     DevBuf<int32_t> orig, chain, ids, found, incell;
     DevBuf<double> w, force;
     DevBuf<uint32_t> key, rank;
+    bool found_stale = false;            // Gaussian mode: `found` is formed lazily from the chain lengths (ensure_found)
     int64_t binned_n = -1;               // particle count the current placement (orig) was computed for
     int bin_age = 0;                     // steps since it was computed
     std::vector<double> h_rec, h_force;  // wire staging
@@ -102,6 +103,7 @@ struct Coupling {
     int set_particles_host(int bi, const double* rec, int64_t n);
     int set_particles_device(int bi, const double* d_rec, int64_t n);
     SlabOwn slab_own() const { return SlabOwn{slab.active ? 1 : 0, slab.kglob0, slab.kglob0 + slab.nz, slab.nzglob, mesh.origin[2], mesh.dx}; }
+    int ensure_found(Batch& b);
     int run_batch(Batch& b);
     int set_force_models(unsigned flags);
     int set_particle_action(double dt);

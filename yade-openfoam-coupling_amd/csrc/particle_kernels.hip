@@ -495,9 +495,7 @@ __global__ __launch_bounds__(kForceThreads) void k_force_gaussian(ParticleSoA p,
         double* F = force_out + 6 * (size_t)orig;
         if (k == 0) {                                   // zeros for particles nobody located (FoamYade.C:142)
             F[0] = F[1] = F[2] = F[3] = F[4] = F[5] = 0.0;
-            found_out[orig] = -1;
         } else {
-            found_out[orig] = 1;
             const double rhoF = fp.rhoF, nu = fp.nu;
             const double dia = 2 * p.rad[i];
             const double volp = M_PI * pow(dia, 3.0) / 6.0;
@@ -618,6 +616,13 @@ __global__ __launch_bounds__(kForceThreads) void k_force_gaussian(ParticleSoA p,
         atomic_add_f64(&uSource[3 * (size_t)c + 1], vals[4 * q + 2]);
         atomic_add_f64(&uSource[3 * (size_t)c + 2], vals[4 * q + 3]);
     }
+}
+
+// found flags in wire order (FoamYade.C:141,204,222): 1 if the particle has a stencil, -1 otherwise.  Only the parallel-Yade
+// protocol and the tests read them, so they are formed on demand instead of as 10 M scattered 4-byte stores in every force pass.
+__global__ __launch_bounds__(256) void k_found_from_chain(ParticleSoA p, int64_t n, int32_t* __restrict__ found_out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) found_out[p.orig[i]] = p.chain_len[i] > 0 ? 1 : -1;
 }
 
 // sorted chain-order stencil storage -> [n][16] ascending-d2 rows in wire order (parity tests only)
@@ -810,6 +815,13 @@ int launch_force_gaussian(hipStream_t s, ParticleSoA p, int64_t n, ForceParams f
     if (n <= 0) return FY_OK;
     hipLaunchKernelGGL(k_force_gaussian, dim3(div_up(n, kForceThreads)), dim3(kForceThreads), 0, s, p, n, fp, cw, vol, U, alpha, uParticle, gradP, divT,
                        vGrad, ddtU, rec, uSourceDrag, uSource, force_out, found_out);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+
+int launch_found_from_chain(hipStream_t s, ParticleSoA p, int64_t n, int32_t* found) {
+    if (n <= 0) return FY_OK;
+    hipLaunchKernelGGL(k_found_from_chain, dim3(div_up(n, 256)), dim3(256), 0, s, p, n, found);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }

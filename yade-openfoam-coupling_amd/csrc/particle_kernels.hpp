@@ -81,6 +81,8 @@ int launch_force_gaussian(hipStream_t s, ParticleSoA p, int64_t n, ForceParams f
                           const double* alpha, const double* uParticle, const double* gradP, const double* divT,
                           const double* vGrad, const double* ddtU, const double* rec,
                           double* uSourceDrag, double* uSource, double* force_out, int32_t* found_out);
+// Gaussian mode: found flags in wire order from the chain lengths (launch_force_gaussian no longer writes found_out)
+int launch_found_from_chain(hipStream_t s, ParticleSoA p, int64_t n, int32_t* found);
 int launch_unpack_stencils(hipStream_t s, ParticleSoA p, int64_t n, int32_t* k, int32_t* ids, double* w, int32_t* chain);
 
 // point-force mode (icoFoamYade): findCell on the uniform block + Stokes drag/torque + source scatter
