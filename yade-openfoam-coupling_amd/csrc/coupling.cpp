@@ -334,7 +334,7 @@ int Coupling::ensure_found(Batch& b) {
 // the device part of setParticleAction for one Yade proc (FoamYade.C:612-628 loop body)
 int Coupling::run_batch(Batch& b) {
     if (b.n == 0 && !slab.active) return FY_OK;      // (in slab mode the halo exchanges are collective: every rank walks the same path)
-    ForceParams fp{rhoF, nu, 1e-09, rhoP, delta_t, force_models};
+    ForceParams fp{rhoF, nu, 1e-09, rhoP, delta_t, force_models, 0};
     if (gaussian) {
         ParticleSoA p = soa_of(b);
         if (timing) timers[T_BIN].start(stream);
@@ -376,6 +376,17 @@ int Coupling::run_batch(Batch& b) {
             FY_TRY(halo_fwd(dUParticle, 3, slab.gz));
         }
         if (timing) { timers[T_FINALIZE].stop(stream); timers[T_FORCE].start(stream); }
+        // Gaussian torque is identically zero unless the opt-in model is on (FoamYade.C:618): zero the records once per buffer,
+        // afterwards the kernel stores only the force half of each (permuted, 48-byte) record
+        if (force_models & FY_FORCE_GAUSSIAN_TORQUE) {
+            b.torque_zero_buf = nullptr;
+        } else {
+            if (b.torque_zero_buf != b.force.p || b.torque_zero_n < b.n) {
+                FY_HIP(hipMemsetAsync(b.force.p, 0, 6 * (size_t)b.n * sizeof(double), stream));
+                b.torque_zero_buf = b.force.p; b.torque_zero_n = b.n;
+            }
+            fp.torque_prezeroed = 1;
+        }
         FY_TRY(launch_force_gaussian(stream, p, b.n, fp, cw, d_vol.p, dU, dAlpha, dUParticle, dGradP, dDivT, dVGrad, dDdtU, b.d_rec,
                                      dUSourceDrag, dUSource, b.force.p, b.found.p));
         b.found_stale = true;

@@ -22,6 +22,8 @@ struct Batch {
     DevBuf<int32_t> orig, chain, ids, found, incell;
     DevBuf<double> w, force;
     DevBuf<uint32_t> key, rank;
+    const double* torque_zero_buf = nullptr;   // force buffer whose torque slots [0, torque_zero_n) are known to be zero
+    int64_t torque_zero_n = 0;
     bool found_stale = false;            // Gaussian mode: `found` is formed lazily from the chain lengths (ensure_found)
     int64_t binned_n = -1;               // particle count the current placement (orig) was computed for
     int bin_age = 0;                     // steps since it was computed

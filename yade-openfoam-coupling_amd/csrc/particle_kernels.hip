@@ -494,7 +494,8 @@ __global__ __launch_bounds__(kForceThreads) void k_force_gaussian(ParticleSoA p,
         const int32_t orig = p.orig[i];
         double* F = force_out + 6 * (size_t)orig;
         if (k == 0) {                                   // zeros for particles nobody located (FoamYade.C:142)
-            F[0] = F[1] = F[2] = F[3] = F[4] = F[5] = 0.0;
+            F[0] = F[1] = F[2] = 0.0;
+            if (!fp.torque_prezeroed) { F[3] = F[4] = F[5] = 0.0; }
         } else {
             const double rhoF = fp.rhoF, nu = fp.nu;
             const double dia = 2 * p.rad[i];
@@ -574,7 +575,7 @@ __global__ __launch_bounds__(kForceThreads) void k_force_gaussian(ParticleSoA p,
                 }
             }
             F[0] = fx; F[1] = fy_; F[2] = fz;
-            F[3] = tqx; F[4] = tqy; F[5] = tqz;
+            if (!fp.torque_prezeroed) { F[3] = tqx; F[4] = tqy; F[5] = tqz; }    // permuted 48-byte records: half the store traffic when the torque is identically zero
 
             const double irho = 1 / rhoF;
             for (int t = 0; t < k; ++t) {

@@ -29,6 +29,7 @@ struct ForceParams {
     double rhoF, nu, small;        // FoamYade.H:67,83-85
     double rhoP, delta_t;          // FoamYade.H:83,94 (added mass only)
     unsigned models;               // FY_FORCE_* : the reference's call-site-less models, off by default
+    int torque_prezeroed;          // the torque half of every force record is already zero (and stays so): store the force half only
 };
 
 // sorted SoA particle arrays + per-particle stencil storage for one batch
