@@ -734,12 +734,31 @@ void orc_fv_set_threads(void* h, int t) { ((Fv*)h)->threads = t < 1 ? 1 : t; }
 
 static vec* fv_field(Fv* f, const char* name) {
     const std::string s = name;
-    if (s == "U") return &f->U; if (s == "p") return &f->p; if (s == "alpha") return &f->alpha; if (s == "uSource") return &f->uSource;
-    if (s == "uSourceDrag") return &f->uSourceDrag; if (s == "uParticle") return &f->uParticle; if (s == "gradP") return &f->gradP;
-    if (s == "divT") return &f->divT; if (s == "vGrad") return &f->vGrad; if (s == "ddtU") return &f->ddtU; if (s == "phi_x") return &f->phi[0]; if (s == "phi_y") return &f->phi[1];
-    if (s == "phi_z") return &f->phi[2]; if (s == "rAU") return &f->rAU; if (s == "HbyA") return &f->HbyA; if (s == "p_rhs") return &f->pb;
-    if (s == "p_diag") return &f->mg[0].diag; if (s == "p_ux") return &f->mg[0].ux; if (s == "p_uy") return &f->mg[0].uy; if (s == "p_uz") return &f->mg[0].uz;
-    if (s == "mom_diag") return &f->diag; if (s == "mom_src") return &f->src;
+    const struct { const char* nm; vec* v; } tab[] = {
+        {"U", &f->U},
+        {"p", &f->p},
+        {"alpha", &f->alpha},
+        {"uSource", &f->uSource},
+        {"uSourceDrag", &f->uSourceDrag},
+        {"uParticle", &f->uParticle},
+        {"gradP", &f->gradP},
+        {"divT", &f->divT},
+        {"vGrad", &f->vGrad},
+        {"ddtU", &f->ddtU},
+        {"phi_x", &f->phi[0]},
+        {"phi_y", &f->phi[1]},
+        {"phi_z", &f->phi[2]},
+        {"rAU", &f->rAU},
+        {"HbyA", &f->HbyA},
+        {"p_rhs", &f->pb},
+        {"p_diag", &f->mg[0].diag},
+        {"p_ux", &f->mg[0].ux},
+        {"p_uy", &f->mg[0].uy},
+        {"p_uz", &f->mg[0].uz},
+        {"mom_diag", &f->diag},
+        {"mom_src", &f->src},
+    };
+    for (const auto& e : tab) if (s == e.nm) return e.v;
     return nullptr;
 }
 int orc_fv_field_size(void* h, const char* name) { vec* v = fv_field((Fv*)h, name); return v ? (int)v->size() : -1; }
