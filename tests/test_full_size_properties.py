@@ -132,3 +132,36 @@ def test_hydrostatic_box_at_c3_size(product):
     np.testing.assert_allclose((p[2:] - p[:-2]) / (2 * dx), -9.81, rtol=1e-3)      # same bound: solver tolerance, not discretisation
     assert abs(st["cont_err_global"]) < 1e-9 and st["p_iters_total"] < 40
     s.close()
+
+
+def test_two_slabs_at_weak_scaling_size(product, tmp_path, monkeypatch):
+    """the N = 2 configuration of bench.py (one 160 x 160 x 320 box in two z-slabs of 160^3) with the in-process communicator, against
+    the same box as a single domain: the slab logic (5-plane particle halos, reverse sums, distributed + replicated multigrid levels,
+    ownership) at the plane sizes and level counts the multi-GPU run really has"""
+    monkeypatch.setenv("FOAMYADE_TREE_CACHE_DIR", str(tmp_path))       # the 8.2 M-node global tree is built once, not three times
+    dx = 1.0 / N
+    nz = 2 * N
+    case = product.make_case(product.FY_SOLVER_PIMPLE, N, N, nz, dx, 1e-4, 1e-6, rho_f=1000.0, rho_p=2650.0, g=(0.0, 0.0, -9.81),
+                             u_bc=[product.FY_BC_U_FIXED_VALUE] * 6, u_val=[(0, 0, 0)] * 6, p_bc=[product.FY_BC_P_FIXED_FLUX] * 6,
+                             n_outer_correctors=1, n_correctors=2, p_solver=1)
+    rs = np.random.Generator(np.random.PCG64(11))
+    npart = 6_000_000
+    rec = np.zeros((npart, 10))
+    rec[:, 0:2] = rs.random((npart, 2))
+    rec[:, 2] = 0.7 + 0.6 * rs.random(npart)                           # a band across the interface at z = 1
+    rec[:, 3:6] = rs.normal(0.0, 0.02, (npart, 3))
+    rec[:, 9] = 0.2 * dx
+    one = product.Solver(case)
+    many = product.VirtualSlabs(case, 2)
+    for _ in range(2):
+        one.set_particles(rec); many.set_particles(rec)
+        one.step(); many.step()
+    fo, fm = one.forces(), many.forces()
+    sc = np.abs(fo).max()
+    assert np.abs(fm - fo).max() <= 1e-6 * sc, np.abs(fm - fo).max() / sc
+    for nm, tol in (("U", 1e-5), ("p", 1e-5), ("alpha", 1e-9)):
+        a, b = many.get(nm), one.get(nm)
+        assert np.abs(a - b).max() <= tol * np.abs(b).max(), (nm, np.abs(a - b).max() / np.abs(b).max())
+    so, sm = one.stats(), many.stats()[0]
+    assert abs(sm["p_iters_total"] - so["p_iters_total"]) <= 2
+    many.close(); one.close()

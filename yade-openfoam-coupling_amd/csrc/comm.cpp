@@ -37,21 +37,26 @@ struct Barrier {
 struct LocalShared {
     int n;
     Barrier bar;
-    std::vector<const double*> send_up, send_down, gather_src;
+    std::vector<const Comm::Xchg*> lists;
+    std::vector<const double*> gather_src;
     std::vector<std::vector<double> > red;     // per-rank host staging for all-reduce
-    explicit LocalShared(int n_) : n(n_), bar(n_), send_up(n_), send_down(n_), gather_src(n_), red(n_) {}
+    explicit LocalShared(int n_) : n(n_), bar(n_), lists(n_), gather_src(n_), red(n_) {}
 };
 
 struct LocalComm : Comm {
     std::shared_ptr<LocalShared> sh;
-    int neighbour_exchange(hipStream_t s, const double* send_up, double* recv_from_down, const double* send_down, double* recv_from_up,
-                           size_t count) override {
-        ++n_exchange; exchange_bytes += count * sizeof(double) * (size_t)((has_up() ? 1 : 0) + (has_down() ? 1 : 0));
+    int exchange_many(hipStream_t s, const Xchg* x, size_t n) override {
+        ++n_exchange;
+        for (size_t q = 0; q < n; ++q) exchange_bytes += x[q].count * sizeof(double) * (size_t)((has_up() ? 1 : 0) + (has_down() ? 1 : 0));
         FY_HIP(hipStreamSynchronize(s));                       // my planes are final
-        sh->send_up[rank] = send_up; sh->send_down[rank] = send_down;
+        sh->lists[rank] = x;                                   // every rank posts the same number of items in the same order
         sh->bar.wait();
-        if (has_down() && recv_from_down) FY_HIP(hipMemcpyAsync(recv_from_down, sh->send_up[rank - 1], count * sizeof(double), hipMemcpyDeviceToDevice, s));
-        if (has_up() && recv_from_up) FY_HIP(hipMemcpyAsync(recv_from_up, sh->send_down[rank + 1], count * sizeof(double), hipMemcpyDeviceToDevice, s));
+        for (size_t q = 0; q < n; ++q) {
+            if (has_down() && x[q].recv_from_down)
+                FY_HIP(hipMemcpyAsync(x[q].recv_from_down, sh->lists[rank - 1][q].send_up, x[q].count * sizeof(double), hipMemcpyDeviceToDevice, s));
+            if (has_up() && x[q].recv_from_up)
+                FY_HIP(hipMemcpyAsync(x[q].recv_from_up, sh->lists[rank + 1][q].send_down, x[q].count * sizeof(double), hipMemcpyDeviceToDevice, s));
+        }
         FY_HIP(hipStreamSynchronize(s));
         sh->bar.wait();                                        // nobody overwrites a send buffer that is still being read
         return FY_OK;
@@ -160,14 +165,16 @@ struct RcclComm : Comm {
     ~RcclComm() override { if (A && comm && A->CommDestroy) A->CommDestroy(comm); }
     // Both directions in ONE group: every rank posts all its sends and receives before any of them has to complete, so the
     // pairing cannot deadlock whatever order the ranks reach this call in.
-    int neighbour_exchange(hipStream_t s, const double* send_up, double* recv_from_down, const double* send_down, double* recv_from_up,
-                           size_t count) override {
-        ++n_exchange; exchange_bytes += count * sizeof(double) * (size_t)((has_up() ? 1 : 0) + (has_down() ? 1 : 0));
+    int exchange_many(hipStream_t s, const Xchg* x, size_t n) override {
+        ++n_exchange;
         FY_NCCL(A->GroupStart());
-        if (has_up() && send_up) FY_NCCL(A->Send(send_up, count, kNcclDouble, rank + 1, comm, s));
-        if (has_down() && recv_from_down) FY_NCCL(A->Recv(recv_from_down, count, kNcclDouble, rank - 1, comm, s));
-        if (has_down() && send_down) FY_NCCL(A->Send(send_down, count, kNcclDouble, rank - 1, comm, s));
-        if (has_up() && recv_from_up) FY_NCCL(A->Recv(recv_from_up, count, kNcclDouble, rank + 1, comm, s));
+        for (size_t q = 0; q < n; ++q) {
+            exchange_bytes += x[q].count * sizeof(double) * (size_t)((has_up() ? 1 : 0) + (has_down() ? 1 : 0));
+            if (has_up() && x[q].send_up) FY_NCCL(A->Send(x[q].send_up, x[q].count, kNcclDouble, rank + 1, comm, s));
+            if (has_down() && x[q].recv_from_down) FY_NCCL(A->Recv(x[q].recv_from_down, x[q].count, kNcclDouble, rank - 1, comm, s));
+            if (has_down() && x[q].send_down) FY_NCCL(A->Send(x[q].send_down, x[q].count, kNcclDouble, rank - 1, comm, s));
+            if (has_up() && x[q].recv_from_up) FY_NCCL(A->Recv(x[q].recv_from_up, x[q].count, kNcclDouble, rank + 1, comm, s));
+        }
         FY_NCCL(A->GroupEnd());
         return FY_OK;
     }

@@ -12,6 +12,7 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <vector>
 
 namespace fy {
 
@@ -22,16 +23,33 @@ struct Comm {
     bool has_down() const { return rank > 0; }           // neighbour owning the planes below mine
     bool has_up() const { return rank + 1 < size; }
     // send `count` doubles starting at send_up to the upper neighbour (it receives them at ITS recv_from_down), and so on.
-    // Pointers for a missing neighbour are ignored.
-    virtual int neighbour_exchange(hipStream_t s, const double* send_up, double* recv_from_down, const double* send_down,
-                                   double* recv_from_up, size_t count) = 0;
+    // Pointers for a missing neighbour are ignored.  Between group_begin() and group_end() the calls are only recorded and then
+    // issued as ONE exchange (one RCCL group = one launch and one round of handshakes for fields that travel together); nothing may
+    // depend on the received planes before group_end().
+    struct Xchg { const double* send_up; double* recv_from_down; const double* send_down; double* recv_from_up; size_t count; };
+    int neighbour_exchange(hipStream_t s, const double* send_up, double* recv_from_down, const double* send_down, double* recv_from_up,
+                           size_t count) {
+        const Xchg x{send_up, recv_from_down, send_down, recv_from_up, count};
+        if (grouping) { pending.push_back(x); return 0; }
+        return exchange_many(s, &x, 1);
+    }
+    void group_begin() { grouping = true; }
+    int group_end(hipStream_t s) {
+        grouping = false;
+        const int rc = pending.empty() ? 0 : exchange_many(s, pending.data(), pending.size());
+        pending.clear();
+        return rc;
+    }
+    virtual int exchange_many(hipStream_t s, const Xchg* x, size_t n) = 0;
+    std::vector<Xchg> pending;
+    bool grouping = false;
     virtual int allreduce(hipStream_t s, double* dev, int n, bool is_max) = 0;   // in place; identical result on every rank
     virtual int allgather(hipStream_t s, const double* send, double* recv, size_t count_per_rank) = 0;
     virtual int barrier(hipStream_t s) = 0;
 };
 
 struct SelfComm : Comm {                                   // size 1: every call is a no-op
-    int neighbour_exchange(hipStream_t, const double*, double*, const double*, double*, size_t) override { return 0; }
+    int exchange_many(hipStream_t, const Xchg*, size_t) override { return 0; }
     int allreduce(hipStream_t, double*, int, bool) override { return 0; }
     int allgather(hipStream_t s, const double* send, double* recv, size_t n) override;
     int barrier(hipStream_t) override { return 0; }

@@ -146,7 +146,7 @@ int Coupling::create(const fy_mesh_desc* m, const fy_field_ptrs* f, int gaussian
     if (slab.active) {
         if (!structured) return fail(FY_ERR_UNSUPPORTED, "slab mode needs the structured block description");
         FY_TRY(launch_fill_f64(stream, d_vol.p, (size_t)n_field, v0));        // uniform block
-        FY_TRY(halo_tmp.alloc_exact(2 * (size_t)slab.gz * slab.plane * 3));
+        FY_TRY(halo_tmp.alloc_exact(2 * (size_t)slab.gz * slab.plane * 4));   // both directions x (1 + 3) components of a grouped reverse sum
     } else {
         FY_HIP(hipMemcpyAsync(d_vol.p, m->volumes, (size_t)n_cells * sizeof(double), hipMemcpyHostToDevice, stream));
     }
@@ -367,13 +367,14 @@ int Coupling::run_batch(Batch& b) {
         const CellWindow cw{slab.active ? slab.base : 0, n_field};
         FY_TRY(launch_deposit(stream, p, b.n, gp, cw, d_pvol_acc.p, d_up_acc.p, d_touched.p));
         if (slab.active) {      // contributions that landed in ghost planes belong to the neighbours: send them home and add
-            FY_TRY(halo_reverse_add(d_pvol_acc.p, 1, d_touched.p));
-            FY_TRY(halo_reverse_add(d_up_acc.p, 3, nullptr));
+            FY_TRY(halo_reverse_add2(d_pvol_acc.p, 1, d_touched.p, d_up_acc.p, 3));
         }
         FY_TRY(launch_finalize_cells(stream, (int32_t)n_field, d_vol.p, d_pvol_acc.p, d_up_acc.p, d_touched.p, dAlpha, dUParticle));
         if (slab.active) {      // the gathers below reach gz planes into the neighbours
+            slab.comm->group_begin();
             FY_TRY(halo_fwd(dAlpha, 1, slab.gz));
             FY_TRY(halo_fwd(dUParticle, 3, slab.gz));
+            FY_TRY(slab.comm->group_end(stream));
         }
         if (timing) { timers[T_FINALIZE].stop(stream); timers[T_FORCE].start(stream); }
         // Gaussian torque is identically zero unless the opt-in model is on (FoamYade.C:618): zero the records once per buffer,
@@ -391,8 +392,7 @@ int Coupling::run_batch(Batch& b) {
                                      dUSourceDrag, dUSource, b.force.p, b.found.p));
         b.found_stale = true;
         if (slab.active) {
-            FY_TRY(halo_reverse_add(dUSourceDrag, 1, nullptr));
-            FY_TRY(halo_reverse_add(dUSource, 3, nullptr));
+            FY_TRY(halo_reverse_add2(dUSourceDrag, 1, nullptr, dUSource, 3));
         }
         if (timing) timers[T_FORCE].stop(stream);
     } else {
@@ -544,19 +544,26 @@ int Coupling::halo_fwd(double* f, int ncomp, int w) {
 }
 
 // ... and the reverse: what this rank accumulated in its ghost planes goes to the owners, who add it; ghost planes are then cleared
-int Coupling::halo_reverse_add(double* f, int ncomp, unsigned char* mark) {
-    const size_t P = slab.plane * (size_t)ncomp, cnt = (size_t)slab.gz * P;
-    double* gh_lo = f;
-    double* gh_hi = f + (size_t)(slab.gz + slab.nz) * P;
-    double* own_lo = f + (size_t)slab.gz * P;
-    double* own_hi = f + (size_t)slab.nz * P;                      // the last gz owned planes
-    double* tmp_a = halo_tmp.p;
-    double* tmp_b = halo_tmp.p + (size_t)slab.gz * slab.plane * 3;
-    FY_TRY(slab.comm->neighbour_exchange(stream, gh_hi, tmp_a, gh_lo, tmp_b, cnt));
-    if (slab.comm->has_down()) FY_TRY(launch_add_mark(stream, own_lo, tmp_a, cnt, mark ? mark + (size_t)slab.gz * slab.plane : nullptr));
-    if (slab.comm->has_up()) FY_TRY(launch_add_mark(stream, own_hi, tmp_b, cnt, mark ? mark + (size_t)slab.nz * slab.plane : nullptr));
-    FY_HIP(hipMemsetAsync(gh_lo, 0, cnt * sizeof(double), stream));
-    FY_HIP(hipMemsetAsync(gh_hi, 0, cnt * sizeof(double), stream));
+int Coupling::halo_reverse_add2(double* f1, int nc1, unsigned char* mark1, double* f2, int nc2) {
+    // f1 and f2 (nc1 + nc2 <= 4 components) travel in ONE grouped exchange
+    struct It { double* f; int nc; unsigned char* mark; double *tmp_a, *tmp_b; } it[2] = {{f1, nc1, mark1, nullptr, nullptr}, {f2, nc2, nullptr, nullptr, nullptr}};
+    double* tmp = halo_tmp.p;
+    slab.comm->group_begin();
+    for (It& t : it) {
+        const size_t P = slab.plane * (size_t)t.nc, cnt = (size_t)slab.gz * P;
+        t.tmp_a = tmp; t.tmp_b = tmp + cnt; tmp += 2 * cnt;
+        FY_TRY(slab.comm->neighbour_exchange(stream, t.f + (size_t)(slab.gz + slab.nz) * P, t.tmp_a, t.f, t.tmp_b, cnt));
+    }
+    FY_TRY(slab.comm->group_end(stream));
+    for (It& t : it) {
+        const size_t P = slab.plane * (size_t)t.nc, cnt = (size_t)slab.gz * P;
+        double* own_lo = t.f + (size_t)slab.gz * P;
+        double* own_hi = t.f + (size_t)slab.nz * P;                  // the last gz owned planes
+        if (slab.comm->has_down()) FY_TRY(launch_add_mark(stream, own_lo, t.tmp_a, cnt, t.mark ? t.mark + (size_t)slab.gz * slab.plane : nullptr));
+        if (slab.comm->has_up()) FY_TRY(launch_add_mark(stream, own_hi, t.tmp_b, cnt, t.mark ? t.mark + (size_t)slab.nz * slab.plane : nullptr));
+        FY_HIP(hipMemsetAsync(t.f, 0, cnt * sizeof(double), stream));
+        FY_HIP(hipMemsetAsync(t.f + (size_t)(slab.gz + slab.nz) * P, 0, cnt * sizeof(double), stream));
+    }
     return FY_OK;
 }
 

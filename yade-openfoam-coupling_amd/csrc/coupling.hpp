@@ -115,7 +115,7 @@ struct Coupling {
     int exchange_dt();
     int set_source_zero();
     int halo_fwd(double* f, int ncomp, int w);
-    int halo_reverse_add(double* f, int ncomp, unsigned char* mark);
+    int halo_reverse_add2(double* f1, int nc1, unsigned char* mark1, double* f2, int nc2);
     int get_forces_host(int bi, double* out);
     int get_found_host(int bi, int32_t* out);
     int get_stencils_host(int bi, int32_t* k, int32_t* ids, double* w, int32_t* chain);

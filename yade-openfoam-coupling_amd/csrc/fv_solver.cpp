@@ -22,7 +22,8 @@ namespace fy {
 // coarsest multigrid level: solved by damped-Jacobi sweeps inside one 1024-thread workgroup (every level below ~20^3 is
 // launch-bound on the GPU; stopping at <= 1024 cells was tried and LOST: 40 sweeps no longer solve that level, +20 % PCG iterations)
 constexpr int kMgCoarsest = 256;
-constexpr int kMgReplicateBelow = 65536;      // a distributed hierarchy hands over to the replicated one at <= this many global cells
+constexpr int kMgReplicateBelow = 1 << 20;    // a distributed hierarchy hands over to the replicated one at <= this many GLOBAL cells: every
+                                              // distributed level costs 4 neighbour exchanges per V-cycle, a replicated 1 M-cell level ~15 us per kernel
 
 struct MgLev {
     PMat A{};
@@ -439,9 +440,11 @@ struct Solver {
         FY_TRY(reduce_read(2, true, h));
         st.courant_max = 0.5 * h[0] * cs.dt; st.courant_mean = 0.5 * (h[1] / (g.V * (double)Nglob)) * cs.dt;
         // runTime++ : store old-time fields (whole storage, ghost planes included)
-        FY_TRY(halo_cells(U, 3, 1));
+        comm->group_begin();                    // one exchange: U goes with the full particle-halo width straight away
+        FY_TRY(halo_cells(U, 3, g.gz > 1 ? g.gz : 1));
         FY_TRY(halo_cells(p, 1, 1));
         FY_TRY(halo_cells(alpha, 1, 1));
+        FY_TRY(comm->group_end(stream));
         FY_TRY(launch_copy_f64(stream, Uold.p, U.p, 3 * nstore));
         for (int d = 0; d < 3; ++d) FY_TRY(launch_copy_f64(stream, phiOld[d].p, phi[d].p, phi[d].n));
         // icoFoamYade.C:71, pimpleFoamYade.C:73-76.  pimple: alpha is 1 here (reset by setSourceZero), so G is re-formed after the
@@ -454,9 +457,11 @@ struct Solver {
 
         if (timing) tim[0].start(stream);
         if (g.gz > 1) {                      // the particle gathers reach gz planes into the neighbours
-            FY_TRY(halo_cells(U, 3, g.gz)); FY_TRY(halo_cells(gradP, 3, g.gz)); FY_TRY(halo_cells(divT, 3, g.gz));
+            comm->group_begin();
+            FY_TRY(halo_cells(gradP, 3, g.gz)); FY_TRY(halo_cells(divT, 3, g.gz));
             if (fm & FY_FORCE_GAUSSIAN_TORQUE) FY_TRY(halo_cells(vGrad, 9, g.gz));
             if (want_ddtU) FY_TRY(halo_cells(ddtU, 3, g.gz));
+            FY_TRY(comm->group_end(stream));
         }
         FY_TRY(cpl->c.set_particle_action(cs.dt));                                            // icoFoamYade.C:74, pimpleFoamYade.C:78
         if (timing) { tim[0].stop(stream); }
