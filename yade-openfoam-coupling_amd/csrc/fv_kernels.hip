@@ -812,6 +812,7 @@ __global__ __launch_bounds__(256) void k_mg_residual_restrict_tiled(PMat A, cons
 // pre-smoothing, restriction, coarsest solve, prolongation and post-smoothing of up to kMgTailMax levels separated by
 // __syncthreads() instead of kernel boundaries.  Those levels are launch/latency bound (4-15 us per launch for microseconds of
 // work, ~24 launches per V-cycle); arithmetic and operation order are exactly those of the per-level kernels.
+constexpr int kMgCoarseMax = 256;     // = the hierarchy's kMgCoarsest: the coarsest level a single wave solves out of LDS
 struct MgTail {
     int n;                       // levels in the tail (level 0 of the tail is the finest of them)
     PMat A[kMgTailMax];
@@ -852,21 +853,74 @@ __global__ __launch_bounds__(1024) void k_mg_tail(MgTail T, double w, int coarse
         }
         __syncthreads();
     }
-    // ---- coarsest level: damped-Jacobi sweeps from a zero guess, result in x0
+    // ---- coarsest level (<= kMgCoarseMax cells): damped-Jacobi sweeps from a zero guess, result in x0.  ONE wave does all sweeps out of
+    // LDS: 40 sweeps behind a 16-wave workgroup barrier each cost ~48 of this kernel's 55 us; inside a single wave the LDS operations
+    // are ordered by the hardware and no barrier is needed at all.  Same arithmetic in the same order as the multi-wave loop.
     {
         const int l = T.n - 1;
         const PMat A = T.A[l];
         const double* b = T.b[l];
-        double* cur = T.x0[l];
-        double* nxt = T.x1[l];
-        for (int c = tid; c < A.N; c += 1024) cur[c] = w * b[c] / A.diag[c];
-        __syncthreads();
-        for (int s = 1; s < coarse_sweeps; ++s) {
-            for (int c = tid; c < A.N; c += 1024) nxt[c] = cur[c] + w * (b[c] - p_row(A, cur, c)) / A.diag[c];
+        __shared__ double c_dg[kMgCoarseMax], c_ux[kMgCoarseMax], c_uy[kMgCoarseMax], c_uz[kMgCoarseMax], c_b[kMgCoarseMax];
+        __shared__ double c_x[2][kMgCoarseMax];
+        if (A.N <= kMgCoarseMax) {
+            if (tid < 64) {
+                const int N = A.N, sy = A.nx, sz = A.nx * A.ny;
+                for (int c = tid; c < N; c += 64) {
+                    c_dg[c] = A.diag[c]; c_ux[c] = A.ux[c]; c_uy[c] = A.uy[c]; c_uz[c] = A.uz[c]; c_b[c] = b[c];
+                    c_x[0][c] = w * b[c] / A.diag[c];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
+                int cur = 0;
+                constexpr int R = kMgCoarseMax / 64;                    // cells per lane, processed together: their dependent FP64 chains
+                for (int s = 1; s < coarse_sweeps; ++s) {               // (7 multiply-subtracts + a division) overlap instead of queueing
+                    const double* xc = c_x[cur];
+                    double* xn = c_x[cur ^ 1];
+                    double a[R], xo[R];
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const int c = tid + 64 * r;
+                        a[r] = 0.0; xo[r] = 0.0;
+                        if (c < N) {
+                            // p_row in the same order; the guarded terms are loaded from clamped addresses and selected, so the seven
+                            // LDS reads go out together instead of one per divergent branch (that serialisation was the sweep's cost)
+                            const int xm = max(c - 1, 0), xp = min(c + 1, N - 1), ym = max(c - sy, 0), yp = min(c + sy, N - 1);
+                            const int zm = max(c - sz, 0), zp = min(c + sz, N - 1);
+                            xo[r] = xc[c];
+                            const double t0 = c_ux[xm] * xc[xm], t1 = c_ux[c] * xc[xp], t2 = c_uy[ym] * xc[ym], t3 = c_uy[c] * xc[yp];
+                            const double t4 = c_uz[zm] * xc[zm], t5 = c_uz[c] * xc[zp];
+                            double v = c_dg[c] * xo[r];
+                            v = (c >= 1) ? v - t0 : v;
+                            v = (c + 1 < N) ? v - t1 : v;
+                            v = (c >= sy) ? v - t2 : v;
+                            v = (c + sy < N) ? v - t3 : v;
+                            v = (c >= sz) ? v - t4 : v;
+                            v = (c + sz < N) ? v - t5 : v;
+                            a[r] = v;
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const int c = tid + 64 * r;
+                        if (c < N) xn[c] = xo[r] + w * (c_b[c] - a[r]) / c_dg[c];
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
+                    cur ^= 1;
+                }
+                for (int c = tid; c < N; c += 64) T.x0[l][c] = c_x[cur][c];
+            }
             __syncthreads();
-            double* t = cur; cur = nxt; nxt = t;
+        } else {
+            double* cur = T.x0[l];
+            double* nxt = T.x1[l];
+            for (int c = tid; c < A.N; c += 1024) cur[c] = w * b[c] / A.diag[c];
+            __syncthreads();
+            for (int s = 1; s < coarse_sweeps; ++s) {
+                for (int c = tid; c < A.N; c += 1024) nxt[c] = cur[c] + w * (b[c] - p_row(A, cur, c)) / A.diag[c];
+                __syncthreads();
+                double* t = cur; cur = nxt; nxt = t;
+            }
+            if (cur != T.x0[l]) { for (int c = tid; c < A.N; c += 1024) T.x0[l][c] = cur[c]; __syncthreads(); }
         }
-        if (cur != T.x0[l]) { for (int c = tid; c < A.N; c += 1024) T.x0[l][c] = cur[c]; __syncthreads(); }
     }
     // ---- up: prolongation + two post-smoothing sweeps; a level's result ends in x1 (the coarsest's in x0)
     for (int l = T.n - 2; l >= 0; --l) {
