@@ -613,14 +613,19 @@ __global__ __launch_bounds__(256) void k_U_correct(FvGeo g, const double* __rest
 // array ends need an index guard.  c is a STORAGE index; with ghost planes the z-neighbours always exist (their coefficient
 // is 0 on a physical boundary, the interface coefficient otherwise) and the ghost x values come from the halo exchange.
 __device__ __forceinline__ double p_row(const PMat& A, const double* __restrict__ x, int c) {
-    const int sy = A.nx, sz = A.nx * A.ny;
+    // Guarded terms are loaded from clamped (always valid) addresses and SELECTED: written as `if (c >= 1) a -= ...` every guard
+    // becomes a divergent branch with its loads inside, i.e. seven dependent memory round trips per row instead of one.
+    const int sy = A.nx, sz = A.nx * A.ny, last = A.ntot - 1;
+    const int xm = max(c - 1, 0), xp = min(c + 1, last), ym = max(c - sy, 0), yp = min(c + sy, last), zm = max(c - sz, 0), zp = min(c + sz, last);
+    const double uxc = A.ux[c], uyc = A.uy[c], uzc = A.uz[c];
+    const double t0 = A.ux[xm] * x[xm], t1 = uxc * x[xp], t2 = A.uy[ym] * x[ym], t3 = uyc * x[yp], t4 = A.uz[zm] * x[zm], t5 = uzc * x[zp];
     double a = A.diag[c] * x[c];
-    if (c >= 1) a -= A.ux[c - 1] * x[c - 1];
-    if (c + 1 < A.ntot) a -= A.ux[c] * x[c + 1];
-    if (c >= sy) a -= A.uy[c - sy] * x[c - sy];
-    if (c + sy < A.ntot) a -= A.uy[c] * x[c + sy];
-    if (c >= sz) a -= A.uz[c - sz] * x[c - sz];
-    if (c + sz < A.ntot) a -= A.uz[c] * x[c + sz];
+    a = (c >= 1) ? a - t0 : a;
+    a = (c + 1 < A.ntot) ? a - t1 : a;
+    a = (c >= sy) ? a - t2 : a;
+    a = (c + sy < A.ntot) ? a - t3 : a;
+    a = (c >= sz) ? a - t4 : a;
+    a = (c + sz < A.ntot) ? a - t5 : a;
     return a;
 }
 __device__ __forceinline__ double p_rowsum(const PMat& A, int c) {
