@@ -760,6 +760,29 @@ __global__ __launch_bounds__(256) void k_mg_smooth_first(PMat A, const double* _
     if (t < A.N) { const int c = t + A.c0; x[c] = w * b[c] / A.diag[c]; }
 }
 
+// smooth_first + one smooth in a single pass (non-distributed levels >= 1, which are launch-latency bound): the neighbours' first iterate
+// x1 = w b / diag is recomputed inline instead of being stored and re-read -- the same operations on the same operands, so x2 is bit-identical
+__global__ __launch_bounds__(256) void k_mg_smooth_two_from_zero(PMat A, const double* __restrict__ b, double* __restrict__ xn, double w) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= A.N) return;
+    const int c = t + A.c0;
+    const int sy = A.nx, sz = A.nx * A.ny, last = A.ntot - 1;
+    const int xm = max(c - 1, 0), xp = min(c + 1, last), ym = max(c - sy, 0), yp = min(c + sy, last), zm = max(c - sz, 0), zp = min(c + sz, last);
+    const double dc = A.diag[c], bc = b[c];
+    const double x1c = w * bc / dc;
+    const double t0 = A.ux[xm] * (w * b[xm] / A.diag[xm]), t1 = A.ux[c] * (w * b[xp] / A.diag[xp]);
+    const double t2 = A.uy[ym] * (w * b[ym] / A.diag[ym]), t3 = A.uy[c] * (w * b[yp] / A.diag[yp]);
+    const double t4 = A.uz[zm] * (w * b[zm] / A.diag[zm]), t5 = A.uz[c] * (w * b[zp] / A.diag[zp]);
+    double a = dc * x1c;                                   // p_row(A, x1, c), same order
+    a = (c >= 1) ? a - t0 : a;
+    a = (c + 1 < A.ntot) ? a - t1 : a;
+    a = (c >= sy) ? a - t2 : a;
+    a = (c + sy < A.ntot) ? a - t3 : a;
+    a = (c >= sz) ? a - t4 : a;
+    a = (c + sz < A.ntot) ? a - t5 : a;
+    xn[c] = x1c + w * (bc - a) / dc;
+}
+
 __global__ __launch_bounds__(256) void k_mg_smooth(PMat A, const double* __restrict__ b, const double* __restrict__ x, double* __restrict__ xn, double w) {
     const int t = swz_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
     if (t >= A.N) return;
@@ -1173,6 +1196,12 @@ int launch_mg_coarsen(hipStream_t s, PMat F, PMat C) {
 
 int launch_mg_smooth_first(hipStream_t s, PMat A, const double* b, double* x, double w) {
     hipLaunchKernelGGL(k_mg_smooth_first, dim3(div_up(A.N, 256)), dim3(256), 0, s, A, b, x, w);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+
+int launch_mg_smooth_two_from_zero(hipStream_t s, PMat A, const double* b, double* xn, double w) {
+    hipLaunchKernelGGL(k_mg_smooth_two_from_zero, dim3(div_up(A.N, 256)), dim3(256), 0, s, A, b, xn, w);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }

@@ -312,8 +312,13 @@ struct Solver {
             return FY_OK;
         }
         MgLev& Cc = *mg[l + 1];
-        FY_TRY(launch_mg_smooth_first(stream, L.A, L.bptr, L.xcur, w));
-        FY_TRY(smooth(l, L, w));
+        if (l >= 1 && !L.distributed) {
+            // small levels are launch-latency bound: first iterate and first sweep in one pass (bit-identical, see the kernel)
+            FY_TRY(launch_mg_smooth_two_from_zero(stream, L.A, L.bptr, L.xcur, w));
+        } else {
+            FY_TRY(launch_mg_smooth_first(stream, L.A, L.bptr, L.xcur, w));
+            FY_TRY(smooth(l, L, w));
+        }
         FY_TRY(halo_level(L, L.xcur));
         const bool handover = L.distributed && !Cc.distributed;
         if (handover) {
