@@ -57,6 +57,8 @@ struct Solver {
     DevBuf<double> rep_stage;     // local slice of the first replicated level before the all-gather (rhs / operator arrays)
     DevBuf<double> prhs, pr, pw, pp, pzj;
     DevBuf<double> partials, red_out, sc, xbar3;
+    double* red_host = nullptr;           // 8 doubles of mapped pinned host memory (+ its device alias): reduce_read's landing zone
+    double* red_host_dev = nullptr;
     DevBuf<int> ops_courant;
     fy_step_stats st{};
     double cumulative_cont_err = 0.0;
@@ -73,6 +75,7 @@ struct Solver {
         if (cpl) fy_destroy(cpl);
         for (auto& t : tim) t.destroy();
         for (auto& k : kc) k.destroy();
+        if (red_host) (void)hipHostFree(red_host);
         if (stream) (void)hipStreamDestroy(stream);
     }
 
@@ -145,6 +148,11 @@ struct Solver {
         FY_TRY(launch_fill_f64(stream, rAU.p, n, 1.0));            // ghost planes must hold finite values before the first exchange
         FY_TRY(partials.alloc_exact(8 * (size_t)red_blocks(Nc))); FY_TRY(red_out.alloc_exact(8)); FY_TRY(sc.alloc_exact(4)); FY_TRY(xbar3.alloc_exact(3));
         FY_TRY(zero(partials)); FY_TRY(zero(sc)); FY_TRY(zero(red_out));
+        if (hipHostMalloc((void**)&red_host, 8 * sizeof(double), hipHostMallocMapped) == hipSuccess) {
+            if (hipHostGetDevicePointer((void**)&red_host_dev, red_host, 0) != hipSuccess) { (void)hipHostFree(red_host); red_host = nullptr; }
+        } else {
+            red_host = nullptr;              // fall back to the copy path
+        }
         FY_TRY(ops_courant.alloc_exact(2));
         { const int h[2] = {1, 0}; FY_HIP(hipMemcpyAsync(ops_courant.p, h, sizeof(h), hipMemcpyHostToDevice, stream)); FY_HIP(hipStreamSynchronize(stream)); }
 
@@ -231,6 +239,13 @@ struct Solver {
 
     // fold the block partials, all-reduce over the slabs, read back
     int reduce_read(int nslots, bool courant, double* h) {
+        if (comm->size == 1 && red_host) {
+            // single domain: the fold writes straight into mapped pinned host memory -- no device-to-host blit per read-back
+            FY_TRY(launch_reduce_finalize(stream, partials.p, Nc, nslots, courant ? ops_courant.p : nullptr, red_host_dev));
+            FY_HIP(hipStreamSynchronize(stream));
+            for (int q = 0; q < nslots; ++q) h[q] = red_host[q];
+            return FY_OK;
+        }
         FY_TRY(launch_reduce_finalize(stream, partials.p, Nc, nslots, courant ? ops_courant.p : nullptr, red_out.p));
         if (courant) { FY_TRY(comm->allreduce(stream, red_out.p, 1, true)); FY_TRY(comm->allreduce(stream, red_out.p + 1, 1, false)); }
         else FY_TRY(comm->allreduce(stream, red_out.p, nslots, false));
