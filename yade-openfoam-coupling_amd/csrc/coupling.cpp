@@ -141,6 +141,8 @@ int Coupling::create(const fy_mesh_desc* m, const fy_field_ptrs* f, int gaussian
         h_tree_pre.swap(pre);
     }
     v0 = m->volumes[0];
+    vol_uniform = true;
+    for (int32_t c = 1; c < n_cells && vol_uniform; ++c) vol_uniform = (m->volumes[c] == v0);
     n_field = slab.active ? (int64_t)slab.n_store : (int64_t)n_cells;
     FY_TRY(d_vol.alloc_exact((size_t)n_field));
     if (slab.active) {
@@ -334,7 +336,7 @@ int Coupling::ensure_found(Batch& b) {
 // the device part of setParticleAction for one Yade proc (FoamYade.C:612-628 loop body)
 int Coupling::run_batch(Batch& b) {
     if (b.n == 0 && !slab.active) return FY_OK;      // (in slab mode the halo exchanges are collective: every rank walks the same path)
-    ForceParams fp{rhoF, nu, 1e-09, rhoP, delta_t, force_models, 0};
+    ForceParams fp{rhoF, nu, 1e-09, rhoP, delta_t, force_models, 0, vol_uniform ? v0 : 0.0};
     if (gaussian) {
         ParticleSoA p = soa_of(b);
         if (timing) timers[T_BIN].start(stream);

@@ -61,6 +61,7 @@ struct Coupling {
     bool serial_yade = true;             // FoamYade.H:91
     double rhoP = 0, rhoF = 0, nu = 0;   // FoamYade.H:83-85
     double delta_t = 0, yade_dt = 0;     // FoamYade.H:94-95
+    bool vol_uniform = false;            // every cell volume equals v0 (checked at create)
     double v0 = 0, interp_range = 0, sigma_interp = 0, interp_range_cu = 0, sigma_pi = 0;   // FoamYade.H:96-99
     std::vector<int> send_ranks;         // FoamYade.H:70
 

@@ -578,6 +578,9 @@ __global__ __launch_bounds__(kForceThreads) void k_force_gaussian(ParticleSoA p,
             if (!fp.torque_prezeroed) { F[3] = tqx; F[4] = tqy; F[5] = tqz; }    // permuted 48-byte records: half the store traffic when the torque is identically zero
 
             const double irho = 1 / rhoF;
+            // the force pass is bound by the vector-memory pipeline (TA ~80 % busy, VALU 12 %): a uniform block's cell volume is a
+            // constant, not a gather
+            const double ooUniform = fp.uniform_vol > 0 ? 1. / (fp.uniform_vol * rhoF) : 0.0;
             for (int t = 0; t < k; ++t) {
                 const size_t slot = (size_t)((chain - 1 - t) & (kMaxK - 1)) * p.cap + (size_t)i;
                 const int64_t cl = (int64_t)p.ids[slot] - cw.base;
@@ -586,7 +589,7 @@ __global__ __launch_bounds__(kForceThreads) void k_force_gaussian(ParticleSoA p,
                 const double w = p.w[slot];
                 const double cwt = -coeff * w;
                 const double* up = uParticle + 3 * (size_t)c;
-                const double ooCellVol = 1. / (vol[c] * rhoF);                              // FoamYade.C:432
+                const double ooCellVol = fp.uniform_vol > 0 ? ooUniform : 1. / (vol[c] * rhoF);  // FoamYade.C:432
                 // FoamYade.C:385 ; FoamYade.C:386 (drag part, NOT divided by V) + FoamYade.C:433 (Archimedes part)
                 const double c0 = cwt * irho;
                 double c1 = ((cwt * up[0]) / rhoF) + ((-afx * w) * ooCellVol);

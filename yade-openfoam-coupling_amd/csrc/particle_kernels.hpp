@@ -30,6 +30,7 @@ struct ForceParams {
     double rhoP, delta_t;          // FoamYade.H:83,94 (added mass only)
     unsigned models;               // FY_FORCE_* : the reference's call-site-less models, off by default
     int torque_prezeroed;          // the torque half of every force record is already zero (and stays so): store the force half only
+    double uniform_vol;            // > 0: every cell has this volume (structured block) -- the back-scatter does not gather V[c]
 };
 
 // sorted SoA particle arrays + per-particle stencil storage for one batch
