@@ -201,6 +201,38 @@ int fy_solver_write_field_host(fy_solver*, const char* name, const double* in);
 int fy_solver_field_count(fy_solver*, const char* name, int64_t* count);
 int fy_solver_destroy(fy_solver*);
 
+/* By default fy_solver_step ends with yadeCoupling.setSourceZero() (icoFoamYade.C:147, pimpleFoamYade.C:109).  The reference calls
+ * runTime.write() just BEFORE that (icoFoamYade.C:142, pimpleFoamYade.C:107), i.e. what it writes is the step's alpha / uSource.  With
+ * hold = 1 the reset is deferred to the start of the next fy_solver_step (the same sequence), so that a caller can read or write
+ * those fields in between. */
+int fy_solver_hold_sources(fy_solver*, int hold);
+
+/* ---- OpenFOAM case directories (what the reference's executables get from runTime / mesh / the field constructors, createFields.H
+ * of both solvers, and give back with runTime.write()).  Supported subset: ONE axis-aligned blockMesh hex block of uniform cubes whose
+ * six sides are covered by `boundary` patches; velocity patches fixedValue (uniform) / noSlip / zeroGradient; pressure patches
+ * zeroGradient / fixedValue (uniform) / fixedFluxPressure; internalField uniform or nonuniform; fixed deltaT.  Everything else is
+ * refused with FY_ERR_UNSUPPORTED and a message naming file and keyword.
+ *   system/blockMeshDict, system/controlDict, system/fvSolution (PISO | PIMPLE, solvers.p / pFinal / U),
+ *   constant/transportProperties (nu, partDensity, fluidDensity | continuousPhaseName + rho.<phase>), constant/g,
+ *   <startTime>/U | U.<phase>, <startTime>/p */
+typedef struct fy_foam_case fy_foam_case;
+typedef struct fy_foam_case_info {
+    double start_time, end_time, delta_t;
+    int32_t write_interval_steps;          /* writeInterval in steps (writeControl timeStep, or runTime / deltaT) */
+    int64_t n_cells;
+    char u_name[64];                       /* "U" (icoFoamYade) or "U.<continuousPhaseName>" (pimpleFoamYade/createFields.H:35-45) */
+    char phase[32];
+    char start_name[32];                   /* name of the start time directory as written in controlDict */
+    char patch_of_side[6][64];             /* blockMesh patch on the XMIN, XMAX, YMIN, YMAX, ZMIN, ZMAX side */
+} fy_foam_case_info;
+int fy_foam_case_open(const char* case_dir, int solver /* FY_SOLVER_ICO | FY_SOLVER_PIMPLE */, fy_foam_case** out);
+int fy_foam_case_desc(const fy_foam_case*, fy_case_desc* out);                   /* ready for fy_solver_create */
+int fy_foam_case_info_get(const fy_foam_case*, fy_foam_case_info* out);
+int fy_foam_case_initial_fields(const fy_foam_case*, double* U /* [n][3] or NULL */, double* p /* [n] or NULL */);
+/* runTime.write(): <case>/<time_name>/{U | U.<phase>, p [, alpha.<phase>]} as ASCII volFields with the case's own patch entries */
+int fy_foam_case_write_time(const fy_foam_case*, fy_solver*, const char* time_name);
+int fy_foam_case_close(fy_foam_case*);
+
 /* ---- kernel-level entry points used by the roofline bench and the operator parity tests ------------------ */
 /* y = A x for the symmetric 7-point pressure matrix (diag, ux, uy, uz) currently held by the solver; x,y host arrays */
 int fy_solver_apply_p_matrix_host(fy_solver*, const double* x, double* y);

@@ -90,6 +90,12 @@ class CaseDesc(C.Structure):
                 ("u_tol", C.c_double), ("u_rel_tol", C.c_double), ("u_max_iter", C.c_int32)]
 
 
+class FoamCaseInfo(C.Structure):
+    _fields_ = [("start_time", C.c_double), ("end_time", C.c_double), ("delta_t", C.c_double), ("write_interval_steps", C.c_int32),
+                ("n_cells", C.c_int64), ("u_name", C.c_char * 64), ("phase", C.c_char * 32), ("start_name", C.c_char * 32),
+                ("patch_of_side", (C.c_char * 64) * 6)]
+
+
 class StepStats(C.Structure):
     _fields_ = [("courant_mean", C.c_double), ("courant_max", C.c_double), ("cont_err_sum_local", C.c_double),
                 ("cont_err_global", C.c_double), ("cont_err_cumulative", C.c_double),
@@ -144,6 +150,13 @@ def lib():
     L.fy_solver_get_stats.argtypes = [vp, C.POINTER(StepStats)]
     L.fy_solver_read_field_host.argtypes = [vp, C.c_char_p, _dp]
     L.fy_solver_field_count.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int64)]
+    L.fy_solver_hold_sources.argtypes = [vp, C.c_int]
+    L.fy_foam_case_open.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp)]
+    L.fy_foam_case_desc.argtypes = [vp, C.POINTER(CaseDesc)]
+    L.fy_foam_case_info_get.argtypes = [vp, C.POINTER(FoamCaseInfo)]
+    L.fy_foam_case_initial_fields.argtypes = [vp, _dp, _dp]
+    L.fy_foam_case_write_time.argtypes = [vp, vp, C.c_char_p]
+    L.fy_foam_case_close.argtypes = [vp]
     L.fy_solver_write_field_host.argtypes = [vp, C.c_char_p, _dp]
     L.fy_solver_destroy.argtypes = [vp]
     L.fy_solver_apply_p_matrix_host.argtypes = [vp, _dp, _dp]
@@ -398,6 +411,10 @@ class Solver:
         assert arr.size == self._size(name)
         _check(lib().fy_solver_write_field_host(self._h, name.encode(), _d(arr)))
 
+    def hold_sources(self, on=True):
+        """defer the step's closing setSourceZero to the start of the next step (runTime.write() sees this step's alpha / uSource)"""
+        _check(lib().fy_solver_hold_sources(self._h, int(on)))
+
     def set_force_models(self, flags):
         """fy_set_force_models on the embedded coupling object (Gaussian torque / added mass, off by default)"""
         _check(lib().fy_set_force_models(self._cpl, int(flags)))
@@ -490,6 +507,37 @@ def rccl_comm(rank, size, id128, device):
     buf = (C.c_char * 128).from_buffer_copy(id128)
     _check(lib().fy_comm_create_rccl(int(rank), int(size), buf, int(device), C.byref(h)))
     return h
+
+
+class FoamCase:
+    """an OpenFOAM case directory as icoFoamYade / pimpleFoamYade would open it (fy_foam_case_*): .case is the CaseDesc for Solver(),
+    .initial_fields() the start-time U and p, .write(solver, time_name) = runTime.write()"""
+
+    def __init__(self, case_dir, solver):
+        h = C.c_void_p()
+        _check(lib().fy_foam_case_open(str(case_dir).encode(), int(solver), C.byref(h)))
+        self._h = h
+        self.case = CaseDesc()
+        _check(lib().fy_foam_case_desc(self._h, C.byref(self.case)))
+        info = FoamCaseInfo()
+        _check(lib().fy_foam_case_info_get(self._h, C.byref(info)))
+        self.start_time, self.end_time, self.delta_t = info.start_time, info.end_time, info.delta_t
+        self.write_interval_steps, self.n_cells = info.write_interval_steps, info.n_cells
+        self.u_name, self.phase, self.start_name = info.u_name.decode(), info.phase.decode(), info.start_name.decode()
+        self.patch_of_side = [bytes(info.patch_of_side[s]).split(b"\0", 1)[0].decode() for s in range(6)]
+
+    def initial_fields(self):
+        U = np.zeros((self.n_cells, 3)); p = np.zeros(self.n_cells)
+        _check(lib().fy_foam_case_initial_fields(self._h, _d(U), _d(p)))
+        return U, p
+
+    def write(self, solver, time_name):
+        _check(lib().fy_foam_case_write_time(self._h, solver._h, str(time_name).encode()))
+
+    def close(self):
+        if self._h:
+            lib().fy_foam_case_close(self._h)
+            self._h = None
 
 
 class VirtualSlabs:

@@ -1,0 +1,424 @@
+// OpenFOAM case directories for fy_solver: what icoFoamYade / pimpleFoamYade get from OpenFOAM's runTime / mesh / field
+// constructors (icoFoamYade.C:38-46, createFields.H of both solvers) and give back with runTime.write() (icoFoamYade.C:142,
+// pimpleFoamYade.C:107), for the one mesh class this library computes on: a single axis-aligned blockMesh hex block of uniform cubes.
+//   read   system/blockMeshDict  (vertices, one `hex` block, simpleGrading (1 1 1), `boundary` patches -> the 6 box sides)
+//          system/controlDict    (startTime, endTime, deltaT, writeControl, writeInterval)
+//          system/fvSolution     (PISO | PIMPLE controls, solvers.p / pFinal / U tolerances)
+//          constant/transportProperties (nu, partDensity, fluidDensity | continuousPhaseName + rho.<phase>), constant/g
+//          <startTime>/U | U.<phase>, <startTime>/p  (boundary types fixedValue / noSlip / zeroGradient / fixedFluxPressure;
+//                                                    internalField uniform or nonuniform)
+//   write  <time>/U | U.<phase>, p, and in Gaussian mode alpha.<phase>: ASCII volFields with the case's own patch entries
+// Anything outside that subset is refused with FY_ERR_UNSUPPORTED and a message naming the file and keyword -- never guessed.
+#include <sys/stat.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "common.hpp"
+#include "foam_dict.hpp"
+
+struct fy_foam_case {
+    std::string dir;
+    int solver = FY_SOLVER_ICO;
+    fy_case_desc desc{};
+    std::string phase, u_name, start_name;
+    double start_time = 0, end_time = 0;
+    int write_interval_steps = 0;
+    std::string patch_of_side[6];               // blockMesh patch name covering XMIN, XMAX, YMIN, YMAX, ZMIN, ZMAX
+    std::vector<std::string> patch_order;       // patch names in blockMeshDict order (one side each here)
+    std::string u_bc_text[6], p_bc_text[6];     // the boundaryField entries as read, re-emitted on write
+    std::vector<double> U0, p0;                 // internalField of the start time
+};
+
+namespace {
+
+using fy::fail;
+using fy::FoamDict;
+
+std::string join(const std::string& a, const std::string& b) { return a + "/" + b; }
+
+int need_file(const std::string& path, FoamDict* d) {
+    std::string err;
+    if (!fy::foam_parse_file(path, d, &err)) return fail(FY_ERR_INVALID, "%s", err.c_str());
+    return FY_OK;
+}
+
+// `name { ... } name { ... }` inside a token list -> named dictionaries, in order
+int named_dicts(const std::vector<std::string>& tok, const std::string& what, std::vector<std::pair<std::string, FoamDict> >* out) {
+    size_t i = 0;
+    double cnt;
+    if (i < tok.size() && fy::foam_tok_is_number(tok[i], &cnt)) ++i;
+    if (i >= tok.size() || tok[i] != "(") return fail(FY_ERR_INVALID, "%s: expected a list", what.c_str());
+    ++i;
+    while (i < tok.size() && tok[i] != ")") {
+        const std::string name = tok[i++];
+        if (i >= tok.size() || tok[i] != "{") return fail(FY_ERR_INVALID, "%s: expected '{' after '%s'", what.c_str(), name.c_str());
+        int depth = 0;
+        std::string text;
+        for (; i < tok.size(); ++i) {
+            if (tok[i] == "{") { if (depth++ == 0) continue; }
+            if (tok[i] == "}") { if (--depth == 0) { ++i; break; } }
+            text += tok[i];
+            text += ' ';
+        }
+        if (depth != 0) return fail(FY_ERR_INVALID, "%s: unbalanced braces in '%s'", what.c_str(), name.c_str());
+        FoamDict d;
+        std::string err;
+        if (!fy::foam_parse(text, &d, &err)) return fail(FY_ERR_INVALID, "%s: patch '%s': %s", what.c_str(), name.c_str(), err.c_str());
+        out->emplace_back(name, d);
+    }
+    return FY_OK;
+}
+
+bool near(double a, double b, double scale) { return std::fabs(a - b) <= 1e-9 * scale; }
+
+int read_block_mesh(fy_foam_case* c) {
+    const std::string path = join(c->dir, "system/blockMeshDict");
+    FoamDict d;
+    FY_TRY(need_file(path, &d));
+    double scale = 1.0;
+    if (!d.scalar("convertToMeters", &scale)) d.scalar("scale", &scale);
+    const auto* vt = d.tokens("vertices");
+    std::vector<double> v;
+    if (!vt || !fy::foam_read_list(*vt, 0, 3, &v) || v.size() != 24)
+        return fail(FY_ERR_UNSUPPORTED, "%s: need exactly 8 vertices (one hex block)", path.c_str());
+    for (double& x : v) x *= scale;
+    const auto* bt = d.tokens("blocks");
+    // ( hex ( 0 1 2 3 4 5 6 7 ) ( nx ny nz ) simpleGrading ( 1 1 1 ) )
+    if (!bt || bt->size() < 24 || (*bt)[0] != "(" || (*bt)[1] != "hex") return fail(FY_ERR_UNSUPPORTED, "%s: blocks must hold one 'hex' block", path.c_str());
+    int hv[8], nn[3];
+    size_t i = 2;
+    if ((*bt)[i++] != "(") return fail(FY_ERR_INVALID, "%s: malformed hex vertex list", path.c_str());
+    for (int q = 0; q < 8; ++q) { double x; if (!fy::foam_tok_is_number((*bt)[i++], &x)) return fail(FY_ERR_INVALID, "%s: malformed hex vertex list", path.c_str()); hv[q] = (int)x; }
+    if ((*bt)[i++] != ")" || (*bt)[i++] != "(") return fail(FY_ERR_INVALID, "%s: malformed hex cell counts", path.c_str());
+    for (int q = 0; q < 3; ++q) { double x; if (!fy::foam_tok_is_number((*bt)[i++], &x)) return fail(FY_ERR_INVALID, "%s: malformed hex cell counts", path.c_str()); nn[q] = (int)x; }
+    if ((*bt)[i++] != ")") return fail(FY_ERR_INVALID, "%s: malformed hex cell counts", path.c_str());
+    if ((*bt)[i] != "simpleGrading") return fail(FY_ERR_UNSUPPORTED, "%s: only simpleGrading (1 1 1) is supported", path.c_str());
+    for (size_t q = i + 2; q < i + 5 && q < bt->size(); ++q) { double g; if (!fy::foam_tok_is_number((*bt)[q], &g) || g != 1.0) return fail(FY_ERR_UNSUPPORTED, "%s: graded blocks are not supported (uniform cubes only)", path.c_str()); }
+    size_t close = i + 6;
+    if (close >= bt->size() || (*bt)[close] != ")") return fail(FY_ERR_UNSUPPORTED, "%s: exactly one block is supported", path.c_str());
+    for (int q = 0; q < 8; ++q) if (hv[q] < 0 || hv[q] > 7) return fail(FY_ERR_INVALID, "%s: hex vertex label out of range", path.c_str());
+    auto P = [&](int q, int a) { return v[3 * (size_t)hv[q] + a]; };
+    // blockMesh's hex: 0-1 = local x, 0-3 = local y, 0-4 = local z; require them to be +x, +y, +z of an axis-aligned box
+    const double L[3] = {P(1, 0) - P(0, 0), P(3, 1) - P(0, 1), P(4, 2) - P(0, 2)};
+    const double scl = std::fabs(L[0]) + std::fabs(L[1]) + std::fabs(L[2]);
+    const int bits[8][3] = {{0, 0, 0}, {1, 0, 0}, {1, 1, 0}, {0, 1, 0}, {0, 0, 1}, {1, 0, 1}, {1, 1, 1}, {0, 1, 1}};
+    for (int q = 0; q < 8; ++q)
+        for (int a = 0; a < 3; ++a)
+            if (!near(P(q, a), P(0, a) + bits[q][a] * L[a], scl)) return fail(FY_ERR_UNSUPPORTED, "%s: the block must be an axis-aligned box with the standard hex vertex order", path.c_str());
+    if (!(L[0] > 0 && L[1] > 0 && L[2] > 0) || nn[0] < 1 || nn[1] < 1 || nn[2] < 1) return fail(FY_ERR_INVALID, "%s: degenerate block", path.c_str());
+    const double dx = L[0] / nn[0];
+    if (!near(L[1] / nn[1], dx, dx) || !near(L[2] / nn[2], dx, dx)) return fail(FY_ERR_UNSUPPORTED, "%s: cells must be cubes (dx = %g, dy = %g, dz = %g)", path.c_str(), dx, L[1] / nn[1], L[2] / nn[2]);
+    c->desc.nx = nn[0]; c->desc.ny = nn[1]; c->desc.nz = nn[2]; c->desc.dx = dx;
+    for (int a = 0; a < 3; ++a) c->desc.origin[a] = P(0, a);
+
+    const auto* bd = d.tokens("boundary");
+    if (!bd) return fail(FY_ERR_UNSUPPORTED, "%s: no 'boundary' list (the old 'patches' syntax is not supported)", path.c_str());
+    std::vector<std::pair<std::string, FoamDict> > patches;
+    FY_TRY(named_dicts(*bd, path + ": boundary", &patches));
+    for (auto& pd : patches) {
+        const auto* ft = pd.second.tokens("faces");
+        std::vector<double> f;
+        if (!ft) return fail(FY_ERR_INVALID, "%s: patch '%s' has no faces", path.c_str(), pd.first.c_str());
+        // ( (a b c d) (a b c d) ... ): read as 4-component tuples
+        if (!fy::foam_read_list(*ft, 0, 4, &f) || f.empty()) return fail(FY_ERR_INVALID, "%s: patch '%s': malformed faces list", path.c_str(), pd.first.c_str());
+        std::string ty;
+        if (pd.second.word("type", &ty) && (ty == "empty" || ty == "cyclic" || ty == "symmetryPlane" || ty == "symmetry" || ty == "wedge"))
+            return fail(FY_ERR_UNSUPPORTED, "%s: patch '%s' of type '%s' is not supported (3-D wall / patch sides only)", path.c_str(), pd.first.c_str(), ty.c_str());
+        for (size_t q = 0; q + 3 < f.size(); q += 4) {
+            int side = -1;
+            for (int a = 0; a < 3 && side < 0; ++a)
+                for (int s = 0; s < 2 && side < 0; ++s) {
+                    bool all = true;
+                    for (int m = 0; m < 4; ++m) {
+                        const int vi = (int)f[q + m];
+                        if (vi < 0 || vi > 7) return fail(FY_ERR_INVALID, "%s: patch '%s': vertex label out of range", path.c_str(), pd.first.c_str());
+                        all = all && near(v[3 * (size_t)vi + a], P(0, a) + s * L[a], scl);
+                    }
+                    if (all) side = 2 * a + s;
+                }
+            if (side < 0) return fail(FY_ERR_UNSUPPORTED, "%s: patch '%s' has a face that is not a side of the block", path.c_str(), pd.first.c_str());
+            if (!c->patch_of_side[side].empty()) return fail(FY_ERR_INVALID, "%s: block side %d is covered twice", path.c_str(), side);
+            c->patch_of_side[side] = pd.first;
+        }
+        c->patch_order.push_back(pd.first);
+    }
+    for (int s = 0; s < 6; ++s)
+        if (c->patch_of_side[s].empty()) return fail(FY_ERR_INVALID, "%s: block side %d belongs to no patch", path.c_str(), s);
+    return FY_OK;
+}
+
+std::string entry_text(const FoamDict& d) {
+    std::string t;
+    for (const std::string& k : d.order) {
+        const auto* tk = d.tokens(k);
+        if (!tk) continue;
+        t += "        " + k;
+        for (const std::string& s : *tk) t += " " + s;
+        t += ";\n";
+    }
+    return t;
+}
+
+int read_internal(const FoamDict& f, const std::string& path, int ncomp, size_t ncell, std::vector<double>* out) {
+    const auto* t = f.tokens("internalField");
+    if (!t || t->empty()) return fail(FY_ERR_INVALID, "%s: no internalField", path.c_str());
+    out->assign(ncell * (size_t)ncomp, 0.0);
+    if ((*t)[0] == "uniform") {
+        double v[3] = {0, 0, 0};
+        if (ncomp == 1) { if (t->size() < 2 || !fy::foam_tok_is_number((*t)[1], &v[0])) return fail(FY_ERR_INVALID, "%s: malformed uniform internalField", path.c_str()); }
+        else if (!f.vector3("internalField", v)) return fail(FY_ERR_INVALID, "%s: malformed uniform internalField", path.c_str());
+        for (size_t c = 0; c < ncell; ++c) for (int q = 0; q < ncomp; ++q) (*out)[c * ncomp + q] = v[q];
+        return FY_OK;
+    }
+    if ((*t)[0] == "nonuniform" && t->size() > 2) {
+        std::vector<double> v;
+        if (!fy::foam_read_list(*t, 2, ncomp, &v) || v.size() != ncell * (size_t)ncomp)
+            return fail(FY_ERR_INVALID, "%s: nonuniform internalField does not hold %zu values", path.c_str(), ncell);
+        out->swap(v);
+        return FY_OK;
+    }
+    return fail(FY_ERR_UNSUPPORTED, "%s: internalField must be 'uniform' or 'nonuniform List<...>'", path.c_str());
+}
+
+int read_fields(fy_foam_case* c) {
+    const size_t ncell = (size_t)c->desc.nx * c->desc.ny * c->desc.nz;
+    {
+        const std::string path = join(c->dir, c->start_name + "/" + c->u_name);
+        FoamDict f;
+        FY_TRY(need_file(path, &f));
+        FY_TRY(read_internal(f, path, 3, ncell, &c->U0));
+        const FoamDict* bf = f.subdict("boundaryField");
+        if (!bf) return fail(FY_ERR_INVALID, "%s: no boundaryField", path.c_str());
+        for (int s = 0; s < 6; ++s) {
+            const FoamDict* pd = bf->subdict(c->patch_of_side[s]);
+            std::string ty;
+            if (!pd || !pd->word("type", &ty)) return fail(FY_ERR_INVALID, "%s: boundaryField has no (typed) entry for patch '%s'", path.c_str(), c->patch_of_side[s].c_str());
+            c->u_bc_text[s] = entry_text(*pd);
+            for (int q = 0; q < 3; ++q) c->desc.u_value[s][q] = 0.0;
+            if (ty == "fixedValue") {
+                c->desc.u_bc[s] = FY_BC_U_FIXED_VALUE;
+                const auto* vt = pd->tokens("value");
+                if (!vt || vt->empty() || (*vt)[0] != "uniform" || !pd->vector3("value", c->desc.u_value[s]))
+                    return fail(FY_ERR_UNSUPPORTED, "%s: patch '%s': fixedValue needs 'value uniform (x y z)'", path.c_str(), c->patch_of_side[s].c_str());
+            } else if (ty == "noSlip") {
+                c->desc.u_bc[s] = FY_BC_U_FIXED_VALUE;
+            } else if (ty == "zeroGradient") {
+                c->desc.u_bc[s] = FY_BC_U_ZERO_GRADIENT;
+            } else {
+                return fail(FY_ERR_UNSUPPORTED, "%s: patch '%s': velocity boundary type '%s' is not supported (fixedValue, noSlip, zeroGradient)", path.c_str(),
+                            c->patch_of_side[s].c_str(), ty.c_str());
+            }
+        }
+    }
+    {
+        const std::string path = join(c->dir, c->start_name + "/p");
+        FoamDict f;
+        FY_TRY(need_file(path, &f));
+        FY_TRY(read_internal(f, path, 1, ncell, &c->p0));
+        const FoamDict* bf = f.subdict("boundaryField");
+        if (!bf) return fail(FY_ERR_INVALID, "%s: no boundaryField", path.c_str());
+        for (int s = 0; s < 6; ++s) {
+            const FoamDict* pd = bf->subdict(c->patch_of_side[s]);
+            std::string ty;
+            if (!pd || !pd->word("type", &ty)) return fail(FY_ERR_INVALID, "%s: boundaryField has no (typed) entry for patch '%s'", path.c_str(), c->patch_of_side[s].c_str());
+            c->p_bc_text[s] = entry_text(*pd);
+            c->desc.p_value[s] = 0.0;
+            if (ty == "zeroGradient") c->desc.p_bc[s] = FY_BC_P_ZERO_GRADIENT;
+            else if (ty == "fixedFluxPressure") c->desc.p_bc[s] = FY_BC_P_FIXED_FLUX;
+            else if (ty == "fixedValue") {
+                c->desc.p_bc[s] = FY_BC_P_FIXED_VALUE;
+                const auto* vt = pd->tokens("value");
+                if (!vt || vt->size() < 2 || (*vt)[0] != "uniform" || !fy::foam_tok_is_number((*vt)[1], &c->desc.p_value[s]))
+                    return fail(FY_ERR_UNSUPPORTED, "%s: patch '%s': fixedValue needs 'value uniform <p>'", path.c_str(), c->patch_of_side[s].c_str());
+            } else {
+                return fail(FY_ERR_UNSUPPORTED, "%s: patch '%s': pressure boundary type '%s' is not supported (zeroGradient, fixedValue, fixedFluxPressure)", path.c_str(),
+                            c->patch_of_side[s].c_str(), ty.c_str());
+            }
+        }
+    }
+    return FY_OK;
+}
+
+int read_controls(fy_foam_case* c) {
+    {
+        const std::string path = join(c->dir, "system/controlDict");
+        FoamDict d;
+        FY_TRY(need_file(path, &d));
+        if (!d.scalar("deltaT", &c->desc.dt) || !(c->desc.dt > 0)) return fail(FY_ERR_INVALID, "%s: deltaT missing or not positive", path.c_str());
+        if (!d.scalar("endTime", &c->end_time)) return fail(FY_ERR_INVALID, "%s: endTime missing", path.c_str());
+        c->start_time = 0.0; c->start_name = "0";
+        std::string from;
+        if (d.word("startFrom", &from) && from != "startTime") return fail(FY_ERR_UNSUPPORTED, "%s: startFrom %s is not supported (startTime only)", path.c_str(), from.c_str());
+        if (d.word("startTime", &c->start_name)) d.scalar("startTime", &c->start_time);
+        std::string wc = "timeStep";
+        d.word("writeControl", &wc);
+        double wi = 0;
+        d.scalar("writeInterval", &wi);
+        if (wc == "timeStep") c->write_interval_steps = (int)wi;
+        else if (wc == "runTime" || wc == "adjustableRunTime") c->write_interval_steps = (int)std::llround(wi / c->desc.dt);
+        else return fail(FY_ERR_UNSUPPORTED, "%s: writeControl %s is not supported", path.c_str(), wc.c_str());
+        bool adj = false;
+        if (d.boolean("adjustTimeStep", &adj) && adj) return fail(FY_ERR_UNSUPPORTED, "%s: adjustTimeStep is not supported (the reference solvers run at fixed deltaT)", path.c_str());
+    }
+    {
+        const std::string path = join(c->dir, "constant/transportProperties");
+        FoamDict d;
+        FY_TRY(need_file(path, &d));
+        if (!d.scalar("nu", &c->desc.nu)) return fail(FY_ERR_INVALID, "%s: nu missing (createFields.H: transportProperties.lookup(\"nu\"))", path.c_str());
+        if (!d.scalar("partDensity", &c->desc.rho_particle)) return fail(FY_ERR_INVALID, "%s: partDensity missing (createFields.H)", path.c_str());
+        c->phase.clear();
+        c->u_name = "U";
+        if (c->solver == FY_SOLVER_PIMPLE) {
+            // pimpleFoamYade/createFields.H:3-15,91-99: continuousPhaseName and rho.<phase>
+            if (!d.word("continuousPhaseName", &c->phase)) return fail(FY_ERR_INVALID, "%s: continuousPhaseName missing (pimpleFoamYade/createFields.H:3-15)", path.c_str());
+            c->u_name = "U." + c->phase;
+            if (!d.scalar("rho." + c->phase, &c->desc.rho_fluid)) return fail(FY_ERR_INVALID, "%s: rho.%s missing (pimpleFoamYade/createFields.H:91-99)", path.c_str(), c->phase.c_str());
+        } else {
+            if (!d.scalar("fluidDensity", &c->desc.rho_fluid)) return fail(FY_ERR_INVALID, "%s: fluidDensity missing (icoFoamYade/createFields.H:41-46)", path.c_str());
+        }
+    }
+    {
+        const std::string path = join(c->dir, "constant/g");
+        FoamDict d;
+        FY_TRY(need_file(path, &d));          // readGravitationalAcceleration.H (createFields.H:1 of both solvers)
+        if (!d.vector3("value", c->desc.g)) return fail(FY_ERR_INVALID, "%s: 'value (gx gy gz)' missing", path.c_str());
+    }
+    {
+        const std::string path = join(c->dir, "system/fvSolution");
+        FoamDict d;
+        FY_TRY(need_file(path, &d));
+        const char* alg = c->solver == FY_SOLVER_PIMPLE ? "PIMPLE" : "PISO";
+        const FoamDict* a = d.subdict(alg);
+        if (!a) return fail(FY_ERR_INVALID, "%s: no %s dictionary", path.c_str(), alg);
+        a->integer("nCorrectors", &c->desc.n_correctors);
+        a->integer("nNonOrthogonalCorrectors", &c->desc.n_non_orth_correctors);
+        a->integer("nOuterCorrectors", &c->desc.n_outer_correctors);
+        bool mp;
+        if (a->boolean("momentumPredictor", &mp)) c->desc.momentum_predictor = mp ? 1 : 0;
+        a->integer("pRefCell", &c->desc.p_ref_cell);
+        a->scalar("pRefValue", &c->desc.p_ref_value);
+        const FoamDict* sv = d.subdict("solvers");
+        if (!sv) return fail(FY_ERR_INVALID, "%s: no solvers dictionary", path.c_str());
+        const FoamDict* ps = sv->subdict("p");
+        if (!ps) return fail(FY_ERR_INVALID, "%s: solvers.p missing", path.c_str());
+        ps->scalar("tolerance", &c->desc.p_tol); ps->scalar("relTol", &c->desc.p_rel_tol); ps->integer("maxIter", &c->desc.p_max_iter);
+        std::string sname, pre;
+        ps->word("solver", &sname); ps->word("preconditioner", &pre);
+        c->desc.p_solver = (sname == "GAMG" || pre == "GAMG") ? FY_PSOLVER_PCG_MG : FY_PSOLVER_PCG_JACOBI;    // the two pressure solvers this library has
+        c->desc.p_final_tol = c->desc.p_tol; c->desc.p_final_rel_tol = 0.0;
+        if (const FoamDict* pf = sv->subdict("pFinal")) { pf->scalar("tolerance", &c->desc.p_final_tol); pf->scalar("relTol", &c->desc.p_final_rel_tol); }
+        const FoamDict* us = sv->subdict(c->u_name);
+        if (!us)
+            for (const std::string& k : sv->order)
+                if (k.find(c->u_name) != std::string::npos || (k.find("U") != std::string::npos && k.find("Final") == std::string::npos)) { us = sv->subdict(k); if (us) break; }
+        if (us) { us->scalar("tolerance", &c->desc.u_tol); us->scalar("relTol", &c->desc.u_rel_tol); us->integer("maxIter", &c->desc.u_max_iter); }
+    }
+    return FY_OK;
+}
+
+int write_field(const fy_foam_case* c, const std::string& tdir, const std::string& tname, const std::string& name, const char* cls, const char* dims, int ncomp,
+                const std::vector<double>& v, const std::string bc_text[6], const char* default_bc) {
+    const std::string path = tdir + "/" + name;
+    FILE* f = std::fopen(path.c_str(), "w");
+    if (!f) return fail(FY_ERR_INVALID, "cannot write %s", path.c_str());
+    const size_t n = v.size() / (size_t)ncomp;
+    std::fprintf(f, "FoamFile\n{\n    version     2.0;\n    format      ascii;\n    class       %s;\n    location    \"%s\";\n    object      %s;\n}\n\n", cls, tname.c_str(), name.c_str());
+    std::fprintf(f, "dimensions      %s;\n\ninternalField   nonuniform List<%s> %zu\n(\n", dims, ncomp == 3 ? "vector" : "scalar", n);
+    for (size_t q = 0; q < n; ++q) {
+        if (ncomp == 3) std::fprintf(f, "(%.17g %.17g %.17g)\n", v[3 * q], v[3 * q + 1], v[3 * q + 2]);
+        else std::fprintf(f, "%.17g\n", v[q]);
+    }
+    std::fprintf(f, ")\n;\n\nboundaryField\n{\n");
+    for (const std::string& pn : c->patch_order) {
+        int side = -1;
+        for (int s = 0; s < 6; ++s) if (c->patch_of_side[s] == pn) side = s;
+        std::fprintf(f, "    %s\n    {\n%s    }\n", pn.c_str(), (bc_text && side >= 0 && !bc_text[side].empty()) ? bc_text[side].c_str() : default_bc);
+    }
+    std::fprintf(f, "}\n");
+    std::fclose(f);
+    return FY_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fy_foam_case_open(const char* case_dir, int solver, fy_foam_case** out) {
+    if (!case_dir || !out) return fail(FY_ERR_INVALID, "fy_foam_case_open: null argument");
+    if (solver != FY_SOLVER_ICO && solver != FY_SOLVER_PIMPLE) return fail(FY_ERR_INVALID, "fy_foam_case_open: solver must be FY_SOLVER_ICO or FY_SOLVER_PIMPLE");
+    *out = nullptr;
+    fy_foam_case* c = new (std::nothrow) fy_foam_case();
+    if (!c) return fail(FY_ERR_INVALID, "out of host memory");
+    c->dir = case_dir;
+    c->solver = solver;
+    fy_case_defaults(&c->desc, solver);
+    int rc = read_block_mesh(c);
+    if (rc == FY_OK) rc = read_controls(c);
+    if (rc == FY_OK) rc = read_fields(c);
+    if (rc != FY_OK) { delete c; return rc; }
+    *out = c;
+    return FY_OK;
+}
+
+int fy_foam_case_desc(const fy_foam_case* c, fy_case_desc* out) {
+    if (!c || !out) return fail(FY_ERR_INVALID, "fy_foam_case_desc: null argument");
+    *out = c->desc;
+    return FY_OK;
+}
+
+int fy_foam_case_info_get(const fy_foam_case* c, fy_foam_case_info* out) {
+    if (!c || !out) return fail(FY_ERR_INVALID, "fy_foam_case_info_get: null argument");
+    std::memset(out, 0, sizeof(*out));
+    out->start_time = c->start_time; out->end_time = c->end_time; out->delta_t = c->desc.dt;
+    out->write_interval_steps = c->write_interval_steps;
+    out->n_cells = (int64_t)c->desc.nx * c->desc.ny * c->desc.nz;
+    std::snprintf(out->u_name, sizeof(out->u_name), "%s", c->u_name.c_str());
+    std::snprintf(out->phase, sizeof(out->phase), "%s", c->phase.c_str());
+    std::snprintf(out->start_name, sizeof(out->start_name), "%s", c->start_name.c_str());
+    for (int s = 0; s < 6; ++s) std::snprintf(out->patch_of_side[s], sizeof(out->patch_of_side[s]), "%s", c->patch_of_side[s].c_str());
+    return FY_OK;
+}
+
+int fy_foam_case_initial_fields(const fy_foam_case* c, double* U, double* p) {
+    if (!c) return fail(FY_ERR_INVALID, "fy_foam_case_initial_fields: null case");
+    if (U) std::memcpy(U, c->U0.data(), c->U0.size() * sizeof(double));
+    if (p) std::memcpy(p, c->p0.data(), c->p0.size() * sizeof(double));
+    return FY_OK;
+}
+
+int fy_foam_case_write_time(const fy_foam_case* c, fy_solver* s, const char* time_name) {
+    if (!c || !s || !time_name || !*time_name) return fail(FY_ERR_INVALID, "fy_foam_case_write_time: null argument");
+    const std::string tdir = join(c->dir, time_name);
+    if (mkdir(tdir.c_str(), 0777) != 0) {
+        struct stat st;
+        if (stat(tdir.c_str(), &st) != 0 || !S_ISDIR(st.st_mode)) return fail(FY_ERR_INVALID, "cannot create %s", tdir.c_str());
+    }
+    const size_t n = (size_t)c->desc.nx * c->desc.ny * c->desc.nz;
+    int64_t cnt = 0;
+    FY_TRY(fy_solver_field_count(s, "p", &cnt));
+    if ((size_t)cnt != n) return fail(FY_ERR_UNSUPPORTED, "fy_foam_case_write_time: the solver is one slab of a decomposed case; gather the slabs first");
+    std::vector<double> U(3 * n), p(n);
+    FY_TRY(fy_solver_read_field_host(s, "U", U.data()));
+    FY_TRY(fy_solver_read_field_host(s, "p", p.data()));
+    FY_TRY(write_field(c, tdir, time_name, c->u_name, "volVectorField", "[0 1 -1 0 0 0 0]", 3, U, c->u_bc_text, "        type            zeroGradient;\n"));
+    FY_TRY(write_field(c, tdir, time_name, "p", "volScalarField", "[0 2 -2 0 0 0 0]", 1, p, c->p_bc_text, "        type            zeroGradient;\n"));
+    if (c->solver == FY_SOLVER_PIMPLE) {
+        // alphac is AUTO_WRITE (pimpleFoamYade/createFields.H:139-150) and is written BEFORE setSourceZero resets it (pimpleFoamYade.C:106-108):
+        // run the solver with fy_solver_hold_sources(s, 1) to get that
+        std::vector<double> a(n);
+        FY_TRY(fy_solver_read_field_host(s, "alpha", a.data()));
+        FY_TRY(write_field(c, tdir, time_name, "alpha." + c->phase, "volScalarField", "[0 0 0 0 0 0 0]", 1, a, nullptr, "        type            zeroGradient;\n"));
+    }
+    return FY_OK;
+}
+
+int fy_foam_case_close(fy_foam_case* c) {
+    delete c;
+    return FY_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,206 @@
+// See foam_dict.hpp.  Host-only code (no HIP): part of libfoamyade_hip.so so that the case reader is reachable through the C-ABI.
+#include "foam_dict.hpp"
+
+#include <cctype>
+#include <cstdlib>
+#include <fstream>
+#include <sstream>
+
+namespace fy {
+
+namespace {
+
+struct Tok { std::string s; int line; };
+
+bool tokenize(const std::string& t, std::vector<Tok>* out, std::string* err) {
+    size_t i = 0, n = t.size();
+    int line = 1;
+    while (i < n) {
+        const char c = t[i];
+        if (c == '\n') { ++line; ++i; continue; }
+        if (std::isspace((unsigned char)c)) { ++i; continue; }
+        if (c == '/' && i + 1 < n && t[i + 1] == '/') { while (i < n && t[i] != '\n') ++i; continue; }
+        if (c == '/' && i + 1 < n && t[i + 1] == '*') {
+            i += 2;
+            while (i + 1 < n && !(t[i] == '*' && t[i + 1] == '/')) { if (t[i] == '\n') ++line; ++i; }
+            if (i + 1 >= n) { *err = "unterminated /* comment"; return false; }
+            i += 2;
+            continue;
+        }
+        if (c == '{' || c == '}' || c == '(' || c == ')' || c == '[' || c == ']' || c == ';') { out->push_back({std::string(1, c), line}); ++i; continue; }
+        if (c == '"') {
+            size_t j = i + 1;
+            while (j < n && t[j] != '"') { if (t[j] == '\n') ++line; ++j; }
+            if (j >= n) { *err = "unterminated string at line " + std::to_string(line); return false; }
+            out->push_back({t.substr(i + 1, j - i - 1), line});
+            i = j + 1;
+            continue;
+        }
+        if (c == '#') { *err = "directive '#...' at line " + std::to_string(line) + " is not supported"; return false; }
+        size_t j = i;
+        while (j < n && !std::isspace((unsigned char)t[j]) && t[j] != '{' && t[j] != '}' && t[j] != '(' && t[j] != ')' && t[j] != '[' && t[j] != ']' &&
+               t[j] != ';' && t[j] != '"')
+            ++j;
+        out->push_back({t.substr(i, j - i), line});
+        i = j;
+    }
+    return true;
+}
+
+bool parse_dict(const std::vector<Tok>& tk, size_t* pos, bool top, FoamDict* d, std::string* err) {
+    while (*pos < tk.size()) {
+        const Tok& k = tk[*pos];
+        if (k.s == "}") {
+            if (top) { *err = "unexpected '}' at line " + std::to_string(k.line); return false; }
+            ++*pos;
+            return true;
+        }
+        if (k.s == ";") { ++*pos; continue; }
+        if (k.s == "{" || k.s == ")" || k.s == "]") { *err = "unexpected '" + k.s + "' at line " + std::to_string(k.line); return false; }
+        // a top-level bare list (e.g. a field file that is just a list) is not something the case reader needs
+        std::string key = k.s;
+        ++*pos;
+        if (*pos >= tk.size()) { *err = "keyword '" + key + "' at end of file (line " + std::to_string(k.line) + ")"; return false; }
+        FoamDict::Entry en;
+        if (tk[*pos].s == "{") {
+            ++*pos;
+            en.sub.reset(new FoamDict());
+            if (!parse_dict(tk, pos, false, en.sub.get(), err)) return false;
+        } else {
+            int depth = 0;
+            for (;;) {
+                if (*pos >= tk.size()) { *err = "entry '" + key + "' (line " + std::to_string(k.line) + ") is not terminated by ';'"; return false; }
+                const std::string& s = tk[*pos].s;
+                if (s == "(" || s == "[") ++depth;
+                if (s == ")" || s == "]") --depth;
+                if (depth < 0) { *err = "unbalanced ')' in entry '" + key + "' at line " + std::to_string(tk[*pos].line); return false; }
+                if (s == "{" && depth > 0) {
+                    // dictionaries inside lists (blockMeshDict `boundary ( name { ... } ... )`): keep them as tokens; the consumer
+                    // re-parses the slice
+                }
+                if (s == ";" && depth == 0) { ++*pos; break; }
+                if ((s == "{" || s == "}") && depth == 0) { *err = "unexpected '" + s + "' in entry '" + key + "' at line " + std::to_string(tk[*pos].line); return false; }
+                en.tok.push_back(s);
+                ++*pos;
+            }
+        }
+        if (!d->e.count(key)) d->order.push_back(key);
+        d->e[key] = en;
+    }
+    if (!top) { *err = "missing '}' at end of file"; return false; }
+    return true;
+}
+
+}  // namespace
+
+const FoamDict* FoamDict::subdict(const std::string& k) const {
+    auto it = e.find(k);
+    return (it == e.end() || !it->second.sub) ? nullptr : it->second.sub.get();
+}
+const std::vector<std::string>* FoamDict::tokens(const std::string& k) const {
+    auto it = e.find(k);
+    return (it == e.end() || it->second.sub) ? nullptr : &it->second.tok;
+}
+
+bool foam_tok_is_number(const std::string& t, double* v) {
+    if (t.empty()) return false;
+    char* end = nullptr;
+    const double x = std::strtod(t.c_str(), &end);
+    if (end == t.c_str() || *end != '\0') return false;
+    if (v) *v = x;
+    return true;
+}
+
+bool FoamDict::scalar(const std::string& k, double* out) const {
+    const auto* t = tokens(k);
+    if (!t) return false;
+    int depth = 0;
+    bool found = false;
+    for (const std::string& s : *t) {                 // the last number outside [ ] and ( )
+        if (s == "[" || s == "(") { ++depth; continue; }
+        if (s == "]" || s == ")") { --depth; continue; }
+        double v;
+        if (depth == 0 && foam_tok_is_number(s, &v)) { *out = v; found = true; }
+    }
+    return found;
+}
+bool FoamDict::integer(const std::string& k, int* out) const {
+    double v;
+    if (!scalar(k, &v)) return false;
+    *out = (int)v;
+    return (double)*out == v;
+}
+bool FoamDict::word(const std::string& k, std::string* out) const {
+    const auto* t = tokens(k);
+    if (!t || t->empty()) return false;
+    *out = (*t)[0];
+    return true;
+}
+bool FoamDict::boolean(const std::string& k, bool* out) const {
+    std::string w;
+    if (!word(k, &w)) return false;
+    if (w == "yes" || w == "on" || w == "true" || w == "y" || w == "t") { *out = true; return true; }
+    if (w == "no" || w == "off" || w == "false" || w == "n" || w == "f" || w == "none") { *out = false; return true; }
+    return false;
+}
+bool FoamDict::vector3(const std::string& k, double out[3]) const {
+    const auto* t = tokens(k);
+    if (!t) return false;
+    for (size_t i = 0; i + 4 < t->size() + 1; ++i) {                      // first "( a b c )"
+        if ((*t)[i] != "(" || i + 4 >= t->size() || (*t)[i + 4] != ")") continue;
+        double v[3];
+        if (foam_tok_is_number((*t)[i + 1], &v[0]) && foam_tok_is_number((*t)[i + 2], &v[1]) && foam_tok_is_number((*t)[i + 3], &v[2])) {
+            out[0] = v[0]; out[1] = v[1]; out[2] = v[2];
+            return true;
+        }
+    }
+    return false;
+}
+
+bool foam_read_list(const std::vector<std::string>& tok, size_t i, int ncomp, std::vector<double>* out) {
+    double cnt = -1;
+    if (i < tok.size() && foam_tok_is_number(tok[i], &cnt)) ++i;         // optional element count
+    if (i >= tok.size() || tok[i] != "(") return false;
+    ++i;
+    out->clear();
+    while (i < tok.size() && tok[i] != ")") {
+        if (ncomp == 1) {
+            double v;
+            if (!foam_tok_is_number(tok[i], &v)) return false;
+            out->push_back(v);
+            ++i;
+        } else {
+            if (tok[i] != "(") return false;
+            ++i;
+            for (int c = 0; c < ncomp; ++c, ++i) {
+                double v;
+                if (i >= tok.size() || !foam_tok_is_number(tok[i], &v)) return false;
+                out->push_back(v);
+            }
+            if (i >= tok.size() || tok[i] != ")") return false;
+            ++i;
+        }
+    }
+    if (i >= tok.size()) return false;
+    if (cnt >= 0 && (size_t)cnt * (size_t)ncomp != out->size()) return false;
+    return true;
+}
+
+bool foam_parse(const std::string& text, FoamDict* out, std::string* err) {
+    std::vector<Tok> tk;
+    if (!tokenize(text, &tk, err)) return false;
+    size_t pos = 0;
+    return parse_dict(tk, &pos, true, out, err);
+}
+
+bool foam_parse_file(const std::string& path, FoamDict* out, std::string* err) {
+    std::ifstream f(path);
+    if (!f) { *err = "cannot open " + path; return false; }
+    std::stringstream ss;
+    ss << f.rdbuf();
+    std::string e2;
+    if (!foam_parse(ss.str(), out, &e2)) { *err = path + ": " + e2; return false; }
+    return true;
+}
+
+}  // namespace fy

@@ -1,0 +1,99 @@
+// foamYadeHip: the time loop of the reference's executables (icoFoamYade/icoFoamYade.C:36-153, pimpleFoamYade/pimpleFoamYade.C:38-118)
+// over an OpenFOAM case directory, on the C-ABI of libfoamyade_hip.so:
+//
+//     foamYadeHip -solver ico|pimple [-case DIR] [-device N]
+//
+// read the case (fy_foam_case_open), create the solver, then  while (runTime.loop()) { step; runTime.write(); setSourceZero }.
+// Built with -DFY_WITH_MPI (make mpi -> foamYadeHip_mpi) it is launched like the reference, MPMD next to Yade ("mpiexec -n 1 yade ... :
+// -n 1 foamYadeHip_mpi ...", README.md:29 of the reference) and talks to Yade's FoamCoupling engine through fy_mpi_transport_create;
+// without MPI it runs the fluid alone (no particles), which is what the reference does when Yade sends none.
+// This file is host glue only: no arithmetic of the path lives here.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/foamyade_hip.h"
+#ifdef FY_WITH_MPI
+#include <mpi.h>
+
+#include "../../include/foamyade_mpi.h"
+#endif
+
+static int die(const char* what) {
+    std::fprintf(stderr, "foamYadeHip: %s: %s\n", what, fy_last_error());
+    return 1;
+}
+
+int main(int argc, char** argv) {
+    std::string dir = ".", solver_name;
+    int device = 0;
+    for (int i = 1; i < argc; ++i) {
+        const std::string a = argv[i];
+        if (a == "-case" && i + 1 < argc) dir = argv[++i];
+        else if (a == "-solver" && i + 1 < argc) solver_name = argv[++i];
+        else if (a == "-device" && i + 1 < argc) device = std::atoi(argv[++i]);
+        else { std::fprintf(stderr, "usage: foamYadeHip -solver ico|pimple [-case DIR] [-device N]\n"); return 2; }
+    }
+    if (solver_name != "ico" && solver_name != "pimple") { std::fprintf(stderr, "foamYadeHip: -solver ico|pimple is required\n"); return 2; }
+    const int solver = solver_name == "ico" ? FY_SOLVER_ICO : FY_SOLVER_PIMPLE;
+
+    fy_transport tr{};
+    const fy_transport* trp = nullptr;
+#ifdef FY_WITH_MPI
+    MPI_Init(&argc, &argv);
+    int world = 1, wrank = 0;
+    MPI_Comm_size(MPI_COMM_WORLD, &world);
+    MPI_Comm_rank(MPI_COMM_WORLD, &wrank);
+    // Yade ranks come first in MPI_COMM_WORLD (README.md:29, FoamYade.C:28); this build runs ONE fluid rank, the rest is Yade
+    const int n_yade = world - 1;
+    if (wrank != world - 1) { std::fprintf(stderr, "foamYadeHip_mpi must be the last rank of the MPMD launch\n"); MPI_Abort(MPI_COMM_WORLD, 2); }
+    if (n_yade > 0) {
+        if (fy_mpi_transport_create(n_yade, &tr) != FY_OK) return die("fy_mpi_transport_create");
+        trp = &tr;
+    }
+#endif
+
+    fy_foam_case* fc = nullptr;
+    if (fy_foam_case_open(dir.c_str(), solver, &fc) != FY_OK) return die("reading the case");
+    fy_case_desc cd;
+    fy_foam_case_info info;
+    fy_foam_case_desc(fc, &cd);
+    fy_foam_case_info_get(fc, &info);
+    std::printf("Create mesh: %d x %d x %d cells of %g m, %s on the six sides x- x+ y- y+ z- z+: %s %s %s %s %s %s\n", cd.nx, cd.ny, cd.nz, cd.dx,
+                "patches", info.patch_of_side[0], info.patch_of_side[1], info.patch_of_side[2], info.patch_of_side[3], info.patch_of_side[4], info.patch_of_side[5]);
+    fy_solver* s = nullptr;
+    if (fy_solver_create(&cd, trp, device, &s) != FY_OK) return die("fy_solver_create");
+    {
+        std::vector<double> U(3 * (size_t)info.n_cells), p((size_t)info.n_cells);
+        fy_foam_case_initial_fields(fc, U.data(), p.data());
+        if (fy_solver_write_field_host(s, "p", p.data()) != FY_OK || fy_solver_write_field_host(s, "U", U.data()) != FY_OK) return die("initial fields");
+    }
+    fy_solver_hold_sources(s, 1);                       // runTime.write() comes before setSourceZero (icoFoamYade.C:142-147)
+
+    std::printf("\nStarting time loop\n\n");
+    const long n_steps = std::lround((info.end_time - info.start_time) / info.delta_t);
+    for (long k = 1; k <= n_steps; ++k) {
+        const double t = info.start_time + (double)k * info.delta_t;
+        char tname[64];
+        std::snprintf(tname, sizeof(tname), "%.12g", t);
+        if (fy_solver_step(s) != FY_OK) return die("fy_solver_step");
+        fy_step_stats st;
+        fy_solver_get_stats(s, &st);
+        std::printf("Time = %s\n\nCourant Number mean: %g max: %g\n", tname, st.courant_mean, st.courant_max);
+        std::printf("pressure: %d solves, %d iterations, initial residual %g, final residual %g\n", st.p_solves, st.p_iters_total, st.p_initial_residual, st.p_final_residual);
+        std::printf("time step continuity errors : sum local = %g, global = %g, cumulative = %g\n\n", st.cont_err_sum_local, st.cont_err_global, st.cont_err_cumulative);
+        if (info.write_interval_steps > 0 && k % info.write_interval_steps == 0)
+            if (fy_foam_case_write_time(fc, s, tname) != FY_OK) return die("writing the time directory");
+    }
+    std::printf("End\n");
+    fy_solver_destroy(s);
+    fy_foam_case_close(fc);
+#ifdef FY_WITH_MPI
+    if (trp) fy_mpi_transport_destroy(&tr);
+    MPI_Finalize();
+#endif
+    return 0;
+}

@@ -57,6 +57,7 @@ struct Solver {
     DevBuf<double> rep_stage;     // local slice of the first replicated level before the all-gather (rhs / operator arrays)
     DevBuf<double> prhs, pr, pw, pp, pzj;
     DevBuf<double> partials, red_out, sc, xbar3;
+    bool hold_sources = false, sources_pending = false;
     double* red_host = nullptr;           // 8 doubles of mapped pinned host memory (+ its device alias): reduce_read's landing zone
     double* red_host_dev = nullptr;
     DevBuf<int> ops_courant;
@@ -455,6 +456,7 @@ struct Solver {
         FY_HIP(hipSetDevice(device));
         st = fy_step_stats{}; st.cont_err_cumulative = cumulative_cont_err;
         if (timing) tim[3].start(stream);
+        if (sources_pending) { FY_TRY(cpl->c.set_source_zero()); sources_pending = false; }   // the previous step's deferred setSourceZero
         double h[2];
         FY_TRY(launch_courant(stream, g, C3(phi), partials.p));                               // icoFoamYade.C:68, pimpleFoamYade.C:63
         FY_TRY(reduce_read(2, true, h));
@@ -516,7 +518,8 @@ struct Solver {
             if (timing) { tim[1].stop(stream); st.ms_momentum += tim[1].ms(); }
             for (int corr = 0; corr < cs.n_correctors; ++corr) FY_TRY(corrector(outer == nOuter - 1 && corr == cs.n_correctors - 1));
         }
-        FY_TRY(cpl->c.set_source_zero());                                                     // icoFoamYade.C:147, pimpleFoamYade.C:109
+        if (hold_sources) sources_pending = true;                                              // reset deferred to the next step (fy_solver_hold_sources)
+        else FY_TRY(cpl->c.set_source_zero());                                                // icoFoamYade.C:147, pimpleFoamYade.C:109
         if (timing) {
             tim[3].stop(stream);
             FY_HIP(hipStreamSynchronize(stream));
@@ -621,6 +624,13 @@ fy_ctx* fy_solver_coupling(fy_solver* s) { return s ? s->s.cpl : nullptr; }
 int fy_solver_step(fy_solver* s) { FY_S(s); return s->s.step(); }
 int fy_solver_get_stats(fy_solver* s, fy_step_stats* out) { FY_S(s); if (!out) return fy::fail(FY_ERR_INVALID, "null out"); *out = s->s.st; return FY_OK; }
 int fy_solver_local_cells(fy_solver* s) { return s ? s->s.Nc : -1; }
+
+int fy_solver_hold_sources(fy_solver* s, int hold) {
+    FY_S(s);
+    s->s.hold_sources = hold != 0;
+    if (!hold && s->s.sources_pending) { FY_HIP(hipSetDevice(s->s.device)); FY_TRY(s->s.cpl->c.set_source_zero()); s->s.sources_pending = false; }
+    return FY_OK;
+}
 
 int fy_solver_field_count(fy_solver* s, const char* name, int64_t* count) {
     FY_S(s);
