@@ -41,3 +41,42 @@ def test_serial_yade_over_mpi(tmp_path, name):
     assert np.fromfile(os.path.join(d, "foam_yadedt.bin"))[0] == 1.25e-5
     a = np.fromfile(os.path.join(d, "foam_alpha.bin"))
     np.testing.assert_allclose(a, gu.dense(g, "alpha", 0, c.ncells, 1, 1.0), rtol=gu.RTOL_GPU)
+
+
+FAKE_YADE = os.path.join(ROOT, "tests", "native", "fake_yade")
+RUNNER = os.path.join(ROOT, "yade-openfoam-coupling_amd", "bin", "foamYadeHip_mpi")
+
+
+@pytest.mark.skipif(not (os.path.exists(MPIEXEC) and os.path.exists(FAKE_YADE) and os.path.exists(RUNNER)), reason="no MPI launcher / binaries (run __graft_entry__.build())")
+def test_foamYadeHip_mpi_next_to_a_serial_yade(product, tmp_path):
+    """the whole stack the way the reference is launched (README.md:29): `mpiexec -n 1 <yade> : -n 1 <solver> -case ...` -- a serial-Yade
+    peer over real MPI, the executable, the OpenFOAM case reader, the PIMPLE loop and the HIP kernels; the forces Yade receives in the
+    last step equal those of the library driven directly with the same particles"""
+    import shutil
+    case_src = os.path.join(ROOT, "tests", "golden", "cases", "bed_pimple")
+    dst = tmp_path / "bed"
+    shutil.copytree(case_src, dst)
+    fc = product.FoamCase(dst, 1)
+    c = fc.case
+    rs = np.random.RandomState(8)
+    rec = np.zeros((2500, 10))
+    rec[:, 0:2] = -0.03 + 0.06 * rs.random_sample((2500, 2)); rec[:, 2] = 0.06 * rs.random_sample(2500)
+    rec[:, 3:6] = 0.01 * rs.standard_normal((2500, 3)); rec[:, 9] = 0.2 * c.dx
+    rec.tofile(tmp_path / "records.bin")
+    nsteps = int(round((fc.end_time - fc.start_time) / fc.delta_t))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([MPIEXEC, "-n", "1", FAKE_YADE, str(tmp_path / "records.bin"), "1", str(nsteps), str(tmp_path / "force.bin"), ":",
+                          "-n", "1", RUNNER, "-solver", "pimple", "-case", str(dst)], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "End" in out.stdout
+    F = np.fromfile(tmp_path / "force.bin").reshape(-1, 6)
+    s = product.Solver(c)
+    for _ in range(nsteps):
+        s.set_particles(rec)
+        s.step()
+    Fr = s.forces()
+    sc = np.abs(Fr).max()
+    assert sc > 0
+    np.testing.assert_allclose(F, Fr, rtol=1e-8, atol=1e-10 * sc)
+    assert sorted(d for d in os.listdir(dst) if d[0].isdigit()) == ["0", "0.001", "0.002"]
+    s.close(); fc.close()
