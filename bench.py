@@ -80,6 +80,57 @@ def cpu_baseline(n_sample, ppc, dt, threads):
     return out, nc, n_part
 
 
+def cpu_reference_as_written(n_sample=32, n_part=80000):
+    """The reference's OWN particle path (FoamYade.C + meshTree.C compiled unmodified into oracle/_ref/ref_driver by `make -C oracle ref`)
+    under mpiexec with a fake serial Yade: as written, i.e. quadratic buildCellPartList and one MPI_Allreduce per particle and force
+    component.  Particle half only -- the reference's FV half is OpenFOAM library code and cannot be built here.  Per-step time =
+    (wall of a 3-step run - wall of a 1-step run) / 2, which cancels tree build, file I/O and MPI start-up.  Returns None when the
+    prebuilt driver or the MPI launcher is not there."""
+    import shutil
+    import subprocess
+    import tempfile
+    drv = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
+    mpiexec = "/opt/conda/bin/mpiexec"
+    if not (os.path.exists(drv) and os.path.exists(mpiexec)):
+        return None
+    dx = 1.0 / n_sample
+    nc = n_sample ** 3
+    rs = np.random.RandomState(5)
+    rec = np.zeros((n_part, 10))
+    rec[:, 0:3] = rs.random_sample((n_part, 3))
+    rec[:, 2] *= 0.6
+    rec[:, 9] = 0.2 * dx
+    walls = {}
+    try:
+        for nsteps in (1, 3):
+            d = tempfile.mkdtemp(prefix="fy_ref_")
+            try:
+                meta = [n_sample, n_sample, n_sample, repr(dx), 0.0, 0.0, 0.0, 1, 1, nsteps, 2650.0, 1000.0, 1e-6, 1e-4, 0.0, 0.0, -9.81]
+                open(os.path.join(d, "meta.txt"), "w").write(" ".join(str(m) for m in meta) + "\n")
+                for nm, comps in (("U", 3), ("gradP", 3), ("divT", 3), ("ddtU", 3), ("vGrad", 9)):
+                    a = np.zeros((nc, comps))
+                    if nm == "U":
+                        a[:, 0] = 0.1
+                    if nm == "gradP":
+                        a[:, 2] = -9810.0
+                    a.tofile(os.path.join(d, nm + ".bin"))
+                for st in range(nsteps):
+                    rec.tofile(os.path.join(d, f"records_s{st}.bin"))
+                t0 = time.time()
+                subprocess.run([mpiexec, "-n", "1", drv, d, ":", "-n", "1", drv, d], check=True, timeout=600, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                walls[nsteps] = time.time() - t0
+            finally:
+                shutil.rmtree(d, ignore_errors=True)
+    except Exception as e:                                        # noqa: BLE001  (a missing/failed reference run is reported, not fatal)
+        return {"error": f"{type(e).__name__}: {e}"}
+    per_step = max((walls[3] - walls[1]) / 2.0, 1e-9)
+    return {"kind": "reference", "what": "FoamYade::setParticleAction AS WRITTEN (FoamYade.C + meshTree.C compiled unmodified; quadratic "
+            "buildCellPartList, per-particle MPI_Allreduce to a fake serial Yade); particle half only, 1 core",
+            "sample": f"{n_part} particles in the lower 60 % of a {n_sample}^3 box ({n_part / (0.6 * n_sample ** 3):.2f} per cell there; C3 has 4.07)",
+            "s_per_step": round(per_step, 4), "particle_steps_per_sec": round(n_part / per_step, 1),
+            "note": "not extrapolated to C3: the deposit is quadratic in the number of touched cells, so the as-written code does not reach that size"}
+
+
 def max_over_ranks(elapsed, dist, device):
     """the contract's timing rule: the slowest rank defines the step time (works with nccl on GPUs and gloo on CPU)"""
     if dist is None:
@@ -269,6 +320,12 @@ def main():
             "sample": f"same workload at {args.cpu_sample_n}^3 cells / {snp} particles ({snc / nc:.4f} of the bench size), CPU oracle (port of the "
                       f"reference path, de-quadraticised deposit), measured {per[best_th]:.2f} s/step on {best_th} threads ({per[1]:.2f} s/step on 1); "
                       f"value = measured steps/s x {scale:.5f} (linear-in-size extrapolation)"}
+        ref = cpu_reference_as_written()
+        if ref is not None:
+            out["cpu_reference_as_written"] = ref
+            pp = args.particles * steps_per_s
+            if "particle_steps_per_sec" in ref:
+                ref["gpu_particle_steps_per_sec_whole_coupled_step"] = round(pp, 1)
     if dist is not None:
         dist.barrier()
     if rank == 0:
