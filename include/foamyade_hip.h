@@ -213,6 +213,7 @@ int fy_solver_hold_sources(fy_solver*, int hold);
  * zeroGradient / fixedValue (uniform) / fixedFluxPressure; internalField uniform or nonuniform; fixed deltaT.  Everything else is
  * refused with FY_ERR_UNSUPPORTED and a message naming file and keyword.
  *   system/blockMeshDict, system/controlDict, system/fvSolution (PISO | PIMPLE, solvers.p / pFinal / U),
+ *   system/fvSchemes (must ask for Euler / Gauss linear / linear / corrected|orthogonal: what the solver implements),
  *   constant/transportProperties (nu, partDensity, fluidDensity | continuousPhaseName + rho.<phase>), constant/g,
  *   <startTime>/U | U.<phase>, <startTime>/p */
 typedef struct fy_foam_case fy_foam_case;

@@ -64,6 +64,8 @@ def test_bed_case_is_read_like_pimpleFoamYade_would(prod):
     (("constant/transportProperties", "fluidDensity", "fluidDensityX"), "fluidDensity"),
     (("system/fvSolution", "PISO", "SIMPLE"), "PISO"),
     (("0/U", "value           uniform (1 0 0);", "#include \"lid\""), "not supported"),
+    (("system/fvSchemes", "div(phi,U)       Gauss linear;", "div(phi,U)       Gauss linearUpwind grad(U);"), "div(phi,U)"),
+    (("system/fvSchemes", "default Euler;", "default CrankNicolson 0.9;"), "ddtSchemes"),
 ])
 def test_what_is_outside_the_supported_subset_is_refused_by_name(prod, tmp_path, edit, needle):
     dst = tmp_path / "case"

@@ -288,6 +288,34 @@ int read_controls(fy_foam_case* c) {
         if (!d.vector3("value", c->desc.g)) return fail(FY_ERR_INVALID, "%s: 'value (gx gy gz)' missing", path.c_str());
     }
     {
+        // the discretisation is fixed in this library (Euler ddt, Gauss linear grad / div / laplacian, linear
+        // interpolation, orthogonal snGrad): a case that asks for anything else would be silently mis-solved, so it is refused
+        const std::string path = join(c->dir, "system/fvSchemes");
+        FoamDict d;
+        FY_TRY(need_file(path, &d));
+        struct Want { const char* dict; const char* must; const char* alt; const char* forbid; };
+        const Want wants[] = {{"ddtSchemes", "Euler", nullptr, nullptr},
+                              {"gradSchemes", "linear", nullptr, "Limited"},
+                              {"divSchemes", "linear", nullptr, "pwind"},            // upwind, linearUpwind, limitedLinear ...
+                              {"laplacianSchemes", "linear", nullptr, nullptr},
+                              {"interpolationSchemes", "linear", nullptr, "pwind"},
+                              {"snGradSchemes", "corrected", "orthogonal", nullptr}};   // corrected == uncorrected == orthogonal on this mesh
+        for (const Want& w : wants) {
+            const FoamDict* sd = d.subdict(w.dict);
+            if (!sd) return fail(FY_ERR_INVALID, "%s: %s missing", path.c_str(), w.dict);
+            for (const std::string& k : sd->order) {
+                const auto* tk = sd->tokens(k);
+                if (!tk) continue;
+                std::string joined;
+                for (const std::string& t : *tk) joined += t + " ";
+                const bool ok = (joined.find(w.must) != std::string::npos || (w.alt && joined.find(w.alt) != std::string::npos) || joined.find("none") == 0) &&
+                                !(w.forbid && joined.find(w.forbid) != std::string::npos) && joined.find("limited") == std::string::npos &&
+                                joined.find("vanLeer") == std::string::npos && joined.find("QUICK") == std::string::npos;
+                if (!ok) return fail(FY_ERR_UNSUPPORTED, "%s: %s.%s = '%s' is not supported (this library discretises with Euler / Gauss linear only)", path.c_str(), w.dict, k.c_str(), joined.c_str());
+            }
+        }
+    }
+    {
         const std::string path = join(c->dir, "system/fvSolution");
         FoamDict d;
         FY_TRY(need_file(path, &d));

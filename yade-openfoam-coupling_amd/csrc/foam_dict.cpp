@@ -37,10 +37,15 @@ bool tokenize(const std::string& t, std::vector<Tok>* out, std::string* err) {
             continue;
         }
         if (c == '#') { *err = "directive '#...' at line " + std::to_string(line) + " is not supported"; return false; }
+        // a word; like OpenFOAM's, a word that starts with a letter may carry balanced parentheses: div(phi,U), grad(U), interpolate(HbyA)
         size_t j = i;
-        while (j < n && !std::isspace((unsigned char)t[j]) && t[j] != '{' && t[j] != '}' && t[j] != '(' && t[j] != ')' && t[j] != '[' && t[j] != ']' &&
-               t[j] != ';' && t[j] != '"')
+        int depth = 0;
+        const bool alpha = std::isalpha((unsigned char)c) != 0;
+        while (j < n && !std::isspace((unsigned char)t[j]) && t[j] != '{' && t[j] != '}' && t[j] != '[' && t[j] != ']' && t[j] != ';' && t[j] != '"') {
+            if (t[j] == '(') { if (!alpha || j == i) break; ++depth; }
+            if (t[j] == ')') { if (depth == 0) break; --depth; }
             ++j;
+        }
         out->push_back({t.substr(i, j - i), line});
         i = j;
     }
