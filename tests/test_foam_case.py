@@ -157,3 +157,37 @@ def test_foamYadeHip_executable_runs_the_cavity_case(prod, tmp_path):
     for o in (fc, fc2):
         o.close()
     s.close()
+
+
+def test_dictionary_syntax_variants_are_understood(prod, tmp_path):
+    """counted and compact lists, block comments inside lists, dimensioned scalars with and without the repeated name, a nonuniform
+    start field, runTime write control -- the same case must come out"""
+    dst = tmp_path / "case"
+    shutil.copytree(os.path.join(CASES, "cavity_ico"), dst)
+    ref = prod.FoamCase(dst, prod.FY_SOLVER_ICO)
+    bm = (dst / "system/blockMeshDict").read_text()
+    bm = bm.replace("vertices\n(", "vertices 8\n(   /* eight corners,\n   counted list */").replace("(0 0 0) (1 0 0)", "(0 0 0)(1 0 0) /* no blank between tuples */")
+    (dst / "system/blockMeshDict").write_text(bm)
+    tp = (dst / "constant/transportProperties").read_text().replace("nu              nu [0 2 -1 0 0 0 0] 0.01;", "nu              [0 2 -1 0 0 0 0] 1e-2;")
+    tp = tp.replace("partDensity     partDensity [1 -3 0 0 0 0 0] 2650;", "partDensity     2650.0;")
+    (dst / "constant/transportProperties").write_text(tp)
+    cd = (dst / "system/controlDict").read_text().replace("writeControl    timeStep;", "writeControl    runTime;").replace("writeInterval   5;", "writeInterval   0.025;")
+    (dst / "system/controlDict").write_text(cd)
+    n = ref.n_cells
+    vals = np.arange(n, dtype=np.float64) * 1e-3
+    ptxt = (dst / "0/p").read_text().replace("internalField   uniform 0;", "internalField   nonuniform List<scalar> %d\n(\n%s\n)\n;" % (n, "\n".join(repr(float(v)) for v in vals)))
+    (dst / "0/p").write_text(ptxt)
+    fc = prod.FoamCase(dst, prod.FY_SOLVER_ICO)
+    a, b = fc.case, ref.case
+    for f in ("nx", "ny", "nz", "dx", "dt", "nu", "rho_particle", "rho_fluid", "n_correctors", "p_solver", "p_tol", "p_rel_tol"):
+        assert getattr(a, f) == getattr(b, f), f
+    assert fc.write_interval_steps == 5 and fc.patch_of_side == ref.patch_of_side
+    U, p = fc.initial_fields()
+    np.testing.assert_array_equal(p, vals)
+    # a nonuniform list of the wrong length is an error, not a truncation
+    (dst / "0/p").write_text(ptxt.replace("List<scalar> %d" % n, "List<scalar> %d" % (n - 1)))
+    with pytest.raises(prod.FoamYadeError) as e:
+        prod.FoamCase(dst, prod.FY_SOLVER_ICO)
+    assert "internalField" in str(e.value)
+    for o in (fc, ref):
+        o.close()
