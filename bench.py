@@ -297,7 +297,7 @@ def main():
         "particle_steps_per_sec": round(steps_per_s * np_part, 1),
         "coupled_steps_per_sec_of_the_whole_box": round(steps_per_s / world, 4),
         "config": {"workload": "C3: pimpleFoamYade Gaussian 4-way coupling, 160^3 = 4,096,000-cell closed box, 10,000,000 particles in the lower 60 %"
-                   if (args.n == 160 and args.particles == 10_000_000) else f"reduced C3-like case {args.n}^3 cells / {args.particles} particles",
+                   if (args.n == 160 and args.particles == 10_000_000) else f"non-default C3-like case {args.n}^3 cells / {args.particles} particles",
                    "cells": nc, "particles": np_part, "dt": args.dt, "pimple": {"nOuterCorrectors": 1, "nCorrectors": 2},
                    "p_solver": "PCG+MG V(2,2) damped Jacobi" if args.p_solver == 1 else "PCG+Jacobi",
                    "p_tol": [case.p_tol, case.p_rel_tol, case.p_final_tol, case.p_final_rel_tol],
