@@ -59,6 +59,12 @@ CASES = [
     Case("p32_serial_c1", 32, 32, 32, 0.1, gaussian=0, np_=1000, seed=12345, nu=0.01, dt=0.005, radius_dx=0.1,
          outside=16),
     Case("p16_parallel2", 16, 16, 16, 0.1, gaussian=0, np_=500, seed=17, n_yade=3, nsteps=2, nu=0.01, outside=10),
+    # second batch: shapes the first seven do not have
+    Case("g24x18x10_parallel5", 24, 18, 10, 0.36, origin=(-0.2, -0.1, 0.05), np_=1100, seed=21, n_yade=6, nsteps=2, cluster=100, fast=15,
+         outside=15, nu=2e-6),                                         # non-cubic block, five parallel-Yade workers, two steps
+    Case("g48_serial", 48, 48, 48, 0.12, np_=1400, seed=22, cluster=120, fast=20, outside=20),          # 110 592 cells: a 17-level tree
+    Case("g9x7x5_odd", 9, 7, 5, 0.09, origin=(0.5, -0.5, 0.0), np_=300, seed=23, cluster=40, fast=5, outside=10),   # odd extents: median ties everywhere
+    Case("p20x12x8_parallel4", 20, 12, 8, 0.2, origin=(0.0, 0.1, -0.3), gaussian=0, np_=700, seed=24, n_yade=5, nsteps=2, nu=0.005, outside=12),
 ]
 CASES_BY_NAME = {c.name: c for c in CASES}
 
