@@ -41,6 +41,8 @@ struct Solver {
     FvGeo g{};
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t comm_stream = nullptr;     // halo exchanges that overlap interior stencil work run here (slab mode)
+    hipEvent_t ev_ready = nullptr, ev_halo = nullptr;
     fy_ctx* cpl = nullptr;
     bool pimple = false;
     int Nc = 0;                   // owned cells
@@ -58,6 +60,7 @@ struct Solver {
     DevBuf<double> prhs, pr, pw, pp, pzj;
     DevBuf<double> partials, red_out, sc, xbar3;
     bool hold_sources = false, sources_pending = false;
+    bool overlap_halos = true;            // FOAMYADE_NO_HALO_OVERLAP=1: serial schedule (A/B switch, same results)
     double* red_host = nullptr;           // 8 doubles of mapped pinned host memory (+ its device alias): reduce_read's landing zone
     double* red_host_dev = nullptr;
     DevBuf<int> ops_courant;
@@ -76,6 +79,9 @@ struct Solver {
         if (cpl) fy_destroy(cpl);
         for (auto& t : tim) t.destroy();
         for (auto& k : kc) k.destroy();
+        if (ev_ready) (void)hipEventDestroy(ev_ready);
+        if (ev_halo) (void)hipEventDestroy(ev_halo);
+        if (comm_stream) (void)hipStreamDestroy(comm_stream);
         if (red_host) (void)hipHostFree(red_host);
         if (stream) (void)hipStreamDestroy(stream);
     }
@@ -84,14 +90,15 @@ struct Solver {
 
     // ---- slab halos -----------------------------------------------------------------------------------------------------
     // refresh w ghost planes per side of a cell array with `ncomp` interleaved components (planes are contiguous in memory)
-    int halo(double* f, int ncomp, size_t pl, int nzl, int gzl, int w) {
+    int halo(double* f, int ncomp, size_t pl, int nzl, int gzl, int w, hipStream_t on = nullptr) {
         if (comm->size == 1) return FY_OK;
+        if (!on) on = stream;
         const size_t P = pl * (size_t)ncomp;
         double* own_lo = f + (size_t)gzl * P;
         double* own_hi = f + (size_t)(gzl + nzl - w) * P;
         double* gh_lo = f + (size_t)(gzl - w) * P;
         double* gh_hi = f + (size_t)(gzl + nzl) * P;
-        return comm->neighbour_exchange(stream, own_hi, gh_lo, own_lo, gh_hi, (size_t)w * P);
+        return comm->neighbour_exchange(on, own_hi, gh_lo, own_lo, gh_hi, (size_t)w * P);
     }
     int halo_cells(DevBuf<double>& f, int ncomp, int w) { return halo(f.p, ncomp, plane, g.nz, g.gz, w); }
     int halo_level(MgLev& L, double* x) { return L.distributed ? halo(x, 1, L.plane, L.A.nz, L.gz, 1) : FY_OK; }
@@ -105,6 +112,10 @@ struct Solver {
         comm = cm ? cm : &self_comm;
         FY_HIP(hipSetDevice(device));
         FY_HIP(hipStreamCreate(&stream));
+        FY_HIP(hipStreamCreateWithFlags(&comm_stream, hipStreamNonBlocking));
+        FY_HIP(hipEventCreateWithFlags(&ev_ready, hipEventDisableTiming));
+        FY_HIP(hipEventCreateWithFlags(&ev_halo, hipEventDisableTiming));
+        overlap_halos = getenv("FOAMYADE_NO_HALO_OVERLAP") == nullptr;
         // ---- slab extents: the case describes the GLOBAL block; rank r owns planes [r*nz, (r+1)*nz)
         const int S = comm->size;
         if (c->nz % S != 0) return fail(FY_ERR_INVALID, "nz (%d) must be divisible by the number of slabs (%d)", c->nz, S);
@@ -292,6 +303,25 @@ struct Solver {
 
     // ---- multigrid V(2,2) with damped Jacobi, used as the PCG preconditioner ------------------------------------------
     int smooth(size_t l, MgLev& L, double w) {
+        if (L.distributed && overlap_halos && L.A.nz >= 4) {
+            // Halo exchange overlapped with interior stencil work: the sweep over the planes that need no ghost values starts at
+            // once on `stream`, the one-plane exchange of x runs meanwhile on comm_stream, and the two boundary planes are swept
+            // when it has landed.  Same arithmetic per cell, so the result is the serial schedule's bit for bit.
+            const int pl = (int)L.plane;
+            FY_HIP(hipEventRecord(ev_ready, stream));                      // x is final
+            FY_HIP(hipStreamWaitEvent(comm_stream, ev_ready, 0));
+            PMat in = L.A; in.c0 += pl; in.N -= 2 * pl;
+            FY_TRY(launch_mg_smooth(stream, in, L.bptr, L.xcur, L.xalt, w));
+            FY_TRY(halo(L.xcur, 1, L.plane, L.A.nz, L.gz, 1, comm_stream));
+            FY_HIP(hipEventRecord(ev_halo, comm_stream));
+            FY_HIP(hipStreamWaitEvent(stream, ev_halo, 0));
+            PMat lo = L.A; lo.N = pl;
+            PMat hi = L.A; hi.c0 += (L.A.nz - 1) * pl; hi.N = pl;
+            FY_TRY(launch_mg_smooth(stream, lo, L.bptr, L.xcur, L.xalt, w));
+            FY_TRY(launch_mg_smooth(stream, hi, L.bptr, L.xcur, L.xalt, w));
+            std::swap(L.xcur, L.xalt);
+            return FY_OK;
+        }
         FY_TRY(halo_level(L, L.xcur));
         if (l == 0) kc[KC_MG_SMOOTH0].begin(stream);
         FY_TRY(launch_mg_smooth(stream, L.A, L.bptr, L.xcur, L.xalt, w));
