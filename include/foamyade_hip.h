@@ -124,6 +124,13 @@ int fy_set_num_batches(fy_ctx*, int nbatch);
 int fy_set_particles_host(fy_ctx*, int batch, const double* records, int64_t n);     /* copies (H2D) */
 int fy_set_particles_device(fy_ctx*, int batch, const double* d_records, int64_t n); /* borrows the device pointer */
 int fy_get_forces_host(fy_ctx*, int batch, double* out_forces /* [n][6] */);
+/* z-slab mode (fy_solver_create_slab): hand the particles of batch 0 whose containing cell now lies in a neighbour's planes to that
+ * neighbour over the slab communicator (ncclSend / ncclRecv in one group under RCCL -- the path the halos take), compact the rest.  A
+ * particle moves at most one slab per call.  d_tags (device, optional): one int64 per record, e.g. the DEM's particle id; it travels with
+ * the record and is rewritten in the new local order (tag_capacity entries available).  Afterwards the records are library-owned
+ * (fy_get_particles_host reads them back).  Collective.  Single domain: a no-op. */
+int fy_migrate_particles(fy_ctx*, int64_t* d_tags, int64_t tag_capacity, int64_t* n_local_out);
+int fy_get_particles_host(fy_ctx*, int batch, double* records_out /* [n][10] or NULL */, int64_t* n_out);
 int fy_get_found_host(fy_ctx*, int batch, int32_t* out_found /* [n], 1 / -1 as foundBuff FoamYade.C:141,222 */);
 const double* fy_forces_device(fy_ctx*, int batch);
 /* per-particle stencil of the last step, for parity tests: k[n], ids[n][16] (-1 padded, ascending d2, ids[0] =

@@ -123,3 +123,66 @@ def test_particle_ownership_when_every_slab_gets_all_particles(product, solver, 
         assert np.abs(fm - fo).max() <= 1e-6 * sc, np.abs(fm - fo).max() / sc
     compare(many, one, ("U", "p", "alpha", "uSource") if solver else ("U", "p"), 1e-5)
     many.close(); one.close()
+
+
+@pytest.mark.parametrize("solver,n_slabs", [(1, 2), (1, 3), (0, 2)])
+def test_particles_migrate_between_slabs(product, solver, n_slabs):
+    """BASELINE north star: 'particles that cross slabs migrate via the same RCCL path'.  Each slab starts with its own particles; they
+    random-walk (up to ~1.5 planes per step) across the interfaces; fy_migrate_particles hands the leavers to the neighbour that now
+    owns them.  After every migration each slab holds exactly the particles inside its planes, no tag is lost or duplicated, and the
+    coupled step equals the single-domain run on the same cloud."""
+    n = 12
+    nz = 12 * n_slabs
+    dx = 0.1 / n
+    kw = dict(g=(0, 0, -9.81), p_bc=[2] * 6) if solver == 1 else {}
+    u_val = [(0, 0, 0)] * 6
+    if solver == 0:
+        u_val[3] = (1.0, 0, 0)
+    case = product.make_case(solver, n, n, nz, dx, 2e-4, 1e-5 if solver else 0.01, u_bc=[0] * 6, u_val=u_val, **kw)
+    one = product.Solver(case); many = product.VirtualSlabs(case, n_slabs)
+    rs = np.random.RandomState(3)
+    npart = 3000
+    rec = np.zeros((npart, 10))
+    rec[:, 0:2] = 0.1 * rs.random_sample((npart, 2))
+    rec[:, 2] = nz * dx * (0.05 + 0.9 * rs.random_sample(npart))
+    rec[:, 3:6] = 0.02 * rs.standard_normal((npart, 3)); rec[:, 9] = 0.2 * dx
+    tags = np.arange(npart, dtype=np.int64) + 1000
+    slab_h = (nz // n_slabs) * dx
+    owner = np.clip(np.floor(rec[:, 2] / slab_h).astype(int), 0, n_slabs - 1)
+    local_tags = [tags[owner == r] for r in range(n_slabs)]
+    for r, s in enumerate(many.solvers):
+        s.set_particles(rec[owner == r])
+    moved_total = 0
+    for step in range(4):
+        # the DEM moves the particles: every slab updates ITS records in place (here on the host), some leave its planes
+        pos = {}
+        new_local = []
+        for r, s in enumerate(many.solvers):
+            mine = s.particles()
+            assert mine.shape[0] == local_tags[r].size
+            mine[:, 2] = np.clip(mine[:, 2] + 1.5 * dx * rs.standard_normal(mine.shape[0]), 0.01 * dx, nz * dx - 0.01 * dx)
+            s.set_particles(mine)
+            new_local.append(mine)
+        local_tags = many.migrate(local_tags)
+        allrec = np.zeros((npart, 10)); seen = np.zeros(npart, dtype=int)
+        for r, s in enumerate(many.solvers):
+            mine = s.particles()
+            assert mine.shape[0] == local_tags[r].size
+            kz = np.clip(np.floor(mine[:, 2] / dx).astype(int), 0, nz - 1)
+            assert np.all(kz // (nz // n_slabs) == r)                   # everybody is where its particles are
+            allrec[local_tags[r] - 1000] = mine
+            seen[local_tags[r] - 1000] += 1
+            moved_total += int((np.floor(np.concatenate(new_local)[:, 2] / slab_h).astype(int) != np.repeat(np.arange(n_slabs), [a.shape[0] for a in new_local])).sum()) if r == 0 else 0
+        assert np.all(seen == 1)                                        # conservation of the population
+        one.set_particles(allrec)
+        one.step(); many.step()
+        fo = one.forces()
+        fm = np.zeros_like(fo)
+        for r, s in enumerate(many.solvers):
+            if local_tags[r].size:
+                fm[local_tags[r] - 1000] = s.forces()
+        sc = np.abs(fo).max()
+        assert np.abs(fm - fo).max() <= 1e-6 * sc, np.abs(fm - fo).max() / sc
+    assert moved_total > 20                                             # the walk really crossed interfaces
+    compare(many, one, ("U", "p", "alpha", "uSource") if solver else ("U", "p"), 1e-5)
+    many.close(); one.close()

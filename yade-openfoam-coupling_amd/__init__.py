@@ -129,6 +129,8 @@ def lib():
     L.fy_set_particles_device.argtypes = [vp, C.c_int, vp, C.c_int64]
     L.fy_get_forces_host.argtypes = [vp, C.c_int, _dp]
     L.fy_get_found_host.argtypes = [vp, C.c_int, _ip]
+    L.fy_migrate_particles.argtypes = [vp, vp, C.c_int64, C.POINTER(C.c_int64)]
+    L.fy_get_particles_host.argtypes = [vp, C.c_int, _dp, C.POINTER(C.c_int64)]
     L.fy_forces_device.argtypes = [vp, C.c_int]
     L.fy_forces_device.restype = vp
     L.fy_get_stencils_host.argtypes = [vp, C.c_int, _ip, _ip, _dp, _ip]
@@ -174,6 +176,21 @@ def lib():
     L.fy_solver_get_kernel_timing.argtypes = [vp, C.c_char_p, _dp, C.POINTER(C.c_int64)]
     _lib = L
     return L
+
+
+_hip_rt = None
+
+
+def _hip():
+    """the HIP runtime through ctypes (the stub needs a few bytes of device scratch for particle tags; no torch involved)"""
+    global _hip_rt
+    if _hip_rt is None:
+        _hip_rt = C.CDLL("libamdhip64.so")
+        _hip_rt.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+        _hip_rt.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        _hip_rt.hipFree.argtypes = [C.c_void_p]
+        _hip_rt.hipSetDevice.argtypes = [C.c_int]
+    return _hip_rt
 
 
 def _check(rc):
@@ -394,6 +411,7 @@ class Solver:
         self.nz_local = case.nz // self.n_slabs
         self.n_cells = case.nx * case.ny * self.nz_local        # owned cells
         self._cpl = C.c_void_p(lib().fy_solver_coupling(self._h))
+        self.device = int(device)
         self._batch_n = []
 
     def _size(self, name):
@@ -410,6 +428,40 @@ class Solver:
         arr = np.ascontiguousarray(arr, dtype=np.float64).ravel()
         assert arr.size == self._size(name)
         _check(lib().fy_solver_write_field_host(self._h, name.encode(), _d(arr)))
+
+    def particles(self):
+        """the records of batch 0 as the library holds them now (after a migration: this slab's new population)"""
+        n = C.c_int64(0)
+        _check(lib().fy_get_particles_host(self._cpl, 0, None, C.byref(n)))
+        out = np.zeros((n.value, 10))
+        if n.value:
+            _check(lib().fy_get_particles_host(self._cpl, 0, _d(out), C.byref(n)))
+        self._batch_n[0:1] = [n.value]
+        return out
+
+    def migrate(self, tags=None, capacity=None):
+        """fy_migrate_particles (slab mode, collective): returns (n_local, tags of the new local population or None)"""
+        n = C.c_int64(0)
+        if tags is None:
+            _check(lib().fy_migrate_particles(self._cpl, None, 0, C.byref(n)))
+            self._batch_n[0:1] = [n.value]
+            return n.value, None
+        tags = np.ascontiguousarray(tags, dtype=np.int64)
+        cap = int(capacity if capacity is not None else 2 * tags.size + 1024)
+        hip = _hip()
+        buf = C.c_void_p()
+        if hip.hipSetDevice(self.device) != 0 or hip.hipMalloc(C.byref(buf), C.c_size_t(8 * cap)) != 0:
+            raise FoamYadeError("hipMalloc for the tag buffer failed")
+        try:
+            hip.hipMemcpy(buf, tags.ctypes.data_as(C.c_void_p), C.c_size_t(8 * tags.size), 1)          # hipMemcpyHostToDevice
+            _check(lib().fy_migrate_particles(self._cpl, buf, cap, C.byref(n)))
+            out = np.zeros(n.value, dtype=np.int64)
+            if n.value:
+                hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), buf, C.c_size_t(8 * n.value), 2)        # hipMemcpyDeviceToHost
+        finally:
+            hip.hipFree(buf)
+        self._batch_n[0:1] = [n.value]
+        return n.value, out
 
     def hold_sources(self, on=True):
         """defer the step's closing setSourceZero to the start of the next step (runTime.write() sees this step's alpha / uSource)"""
@@ -609,6 +661,12 @@ class VirtualSlabs:
             s.set_particles(rec)
         self._owner_idx = None
         self._n_part = rec.shape[0]
+
+    def migrate(self, tags_per_slab):
+        """collective fy_migrate_particles; tags_per_slab: list of int64 arrays; returns the new per-slab tag arrays"""
+        out = [None] * self.n
+        self._each(lambda r: out.__setitem__(r, self.solvers[r].migrate(tags_per_slab[r])[1]))
+        return out
 
     def forces(self):
         if self._owner_idx is None:          # full set everywhere: non-owners hold zeros, the sum is the serial protocol's all-reduce

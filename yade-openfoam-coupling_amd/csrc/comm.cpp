@@ -47,15 +47,19 @@ struct LocalComm : Comm {
     std::shared_ptr<LocalShared> sh;
     int exchange_many(hipStream_t s, const Xchg* x, size_t n) override {
         ++n_exchange;
-        for (size_t q = 0; q < n; ++q) exchange_bytes += x[q].count * sizeof(double) * (size_t)((has_up() ? 1 : 0) + (has_down() ? 1 : 0));
+        for (size_t q = 0; q < n; ++q) exchange_bytes += sizeof(double) * ((has_up() ? x[q].su() : 0) + (has_down() ? x[q].sd() : 0));
         FY_HIP(hipStreamSynchronize(s));                       // my planes are final
         sh->lists[rank] = x;                                   // every rank posts the same number of items in the same order
         sh->bar.wait();
         for (size_t q = 0; q < n; ++q) {
-            if (has_down() && x[q].recv_from_down)
-                FY_HIP(hipMemcpyAsync(x[q].recv_from_down, sh->lists[rank - 1][q].send_up, x[q].count * sizeof(double), hipMemcpyDeviceToDevice, s));
-            if (has_up() && x[q].recv_from_up)
-                FY_HIP(hipMemcpyAsync(x[q].recv_from_up, sh->lists[rank + 1][q].send_down, x[q].count * sizeof(double), hipMemcpyDeviceToDevice, s));
+            if (has_down() && x[q].recv_from_down && x[q].rd()) {
+                if (sh->lists[rank - 1][q].su() != x[q].rd()) return fail(FY_ERR_TRANSPORT, "neighbour exchange: send/receive sizes differ");
+                FY_HIP(hipMemcpyAsync(x[q].recv_from_down, sh->lists[rank - 1][q].send_up, x[q].rd() * sizeof(double), hipMemcpyDeviceToDevice, s));
+            }
+            if (has_up() && x[q].recv_from_up && x[q].ru()) {
+                if (sh->lists[rank + 1][q].sd() != x[q].ru()) return fail(FY_ERR_TRANSPORT, "neighbour exchange: send/receive sizes differ");
+                FY_HIP(hipMemcpyAsync(x[q].recv_from_up, sh->lists[rank + 1][q].send_down, x[q].ru() * sizeof(double), hipMemcpyDeviceToDevice, s));
+            }
         }
         FY_HIP(hipStreamSynchronize(s));
         sh->bar.wait();                                        // nobody overwrites a send buffer that is still being read
@@ -169,11 +173,11 @@ struct RcclComm : Comm {
         ++n_exchange;
         FY_NCCL(A->GroupStart());
         for (size_t q = 0; q < n; ++q) {
-            exchange_bytes += x[q].count * sizeof(double) * (size_t)((has_up() ? 1 : 0) + (has_down() ? 1 : 0));
-            if (has_up() && x[q].send_up) FY_NCCL(A->Send(x[q].send_up, x[q].count, kNcclDouble, rank + 1, comm, s));
-            if (has_down() && x[q].recv_from_down) FY_NCCL(A->Recv(x[q].recv_from_down, x[q].count, kNcclDouble, rank - 1, comm, s));
-            if (has_down() && x[q].send_down) FY_NCCL(A->Send(x[q].send_down, x[q].count, kNcclDouble, rank - 1, comm, s));
-            if (has_up() && x[q].recv_from_up) FY_NCCL(A->Recv(x[q].recv_from_up, x[q].count, kNcclDouble, rank + 1, comm, s));
+            exchange_bytes += sizeof(double) * ((has_up() ? x[q].su() : 0) + (has_down() ? x[q].sd() : 0));
+            if (has_up() && x[q].send_up && x[q].su()) FY_NCCL(A->Send(x[q].send_up, x[q].su(), kNcclDouble, rank + 1, comm, s));
+            if (has_down() && x[q].recv_from_down && x[q].rd()) FY_NCCL(A->Recv(x[q].recv_from_down, x[q].rd(), kNcclDouble, rank - 1, comm, s));
+            if (has_down() && x[q].send_down && x[q].sd()) FY_NCCL(A->Send(x[q].send_down, x[q].sd(), kNcclDouble, rank - 1, comm, s));
+            if (has_up() && x[q].recv_from_up && x[q].ru()) FY_NCCL(A->Recv(x[q].recv_from_up, x[q].ru(), kNcclDouble, rank + 1, comm, s));
         }
         FY_NCCL(A->GroupEnd());
         return FY_OK;

@@ -26,10 +26,28 @@ struct Comm {
     // Pointers for a missing neighbour are ignored.  Between group_begin() and group_end() the calls are only recorded and then
     // issued as ONE exchange (one RCCL group = one launch and one round of handshakes for fields that travel together); nothing may
     // depend on the received planes before group_end().
-    struct Xchg { const double* send_up; double* recv_from_down; const double* send_down; double* recv_from_up; size_t count; };
+    // count: doubles per direction; n_* (all zero = use `count` for every direction) give each transfer its own size -- a rank's
+    // recv_from_down size must equal its lower neighbour's send_up size (particle migration: the sizes were exchanged first)
+    struct Xchg {
+        const double* send_up; double* recv_from_down; const double* send_down; double* recv_from_up; size_t count;
+        size_t n_send_up = 0, n_recv_down = 0, n_send_down = 0, n_recv_up = 0;
+        bool sized() const { return n_send_up || n_recv_down || n_send_down || n_recv_up; }
+        size_t su() const { return sized() ? n_send_up : count; }
+        size_t rd() const { return sized() ? n_recv_down : count; }
+        size_t sd() const { return sized() ? n_send_down : count; }
+        size_t ru() const { return sized() ? n_recv_up : count; }
+    };
     int neighbour_exchange(hipStream_t s, const double* send_up, double* recv_from_down, const double* send_down, double* recv_from_up,
                            size_t count) {
-        const Xchg x{send_up, recv_from_down, send_down, recv_from_up, count};
+        Xchg x{send_up, recv_from_down, send_down, recv_from_up, count};
+        if (grouping) { pending.push_back(x); return 0; }
+        return exchange_many(s, &x, 1);
+    }
+    int neighbour_exchange_sized(hipStream_t s, const double* send_up, size_t n_send_up, double* recv_from_down, size_t n_recv_down,
+                                 const double* send_down, size_t n_send_down, double* recv_from_up, size_t n_recv_up) {
+        Xchg x{send_up, recv_from_down, send_down, recv_from_up, 0};
+        x.n_send_up = n_send_up; x.n_recv_down = n_recv_down; x.n_send_down = n_send_down; x.n_recv_up = n_recv_up;
+        if (!x.sized()) return 0;
         if (grouping) { pending.push_back(x); return 0; }
         return exchange_many(s, &x, 1);
     }

@@ -326,6 +326,58 @@ int Coupling::set_particles_device(int bi, const double* d_rec, int64_t n) {
     return ensure_batch(b, n);
 }
 
+// Particles that crossed into a neighbour's planes go there over the slab communicator (the same path as the halos: ncclSend/ncclRecv
+// in one group under RCCL), the rest is compacted; a particle moves at most one slab per call.  Works on batch 0; afterwards the
+// records live in library-owned storage (b.rec_own), whatever they were before.  Collective over the slabs.
+int Coupling::migrate(int64_t* d_tags, int64_t tag_capacity, int64_t* n_out) {
+    if (!created) return fail(FY_ERR_INVALID, "migrate before create");
+    if (n_batches != 1) return fail(FY_ERR_INVALID, "particle migration works on a single batch (direct mode)");
+    FY_HIP(hipSetDevice(device));
+    Batch& b = *batches[0];
+    if (!slab.active) { if (n_out) *n_out = b.n; return FY_OK; }
+    const int64_t n = b.n;
+    const size_t cap = 11 * (size_t)std::max<int64_t>(n, 1);
+    FY_TRY(mig_stay.reserve(cap + cap / 4)); FY_TRY(mig_up.reserve(cap)); FY_TRY(mig_down.reserve(cap));
+    FY_TRY(mig_counters.reserve(4)); FY_TRY(mig_cnt.reserve(4));
+    FY_HIP(hipMemsetAsync(mig_counters.p, 0, 4 * sizeof(unsigned int), stream));
+    FY_TRY(launch_migrate_pack(stream, b.d_rec, d_tags, n, slab_own(), mig_counters.p, mig_stay.p, mig_up.p, mig_down.p));
+    unsigned int hc[4] = {0, 0, 0, 0};
+    FY_HIP(hipMemcpyAsync(hc, mig_counters.p, 4 * sizeof(unsigned int), hipMemcpyDeviceToHost, stream));
+    FY_HIP(hipStreamSynchronize(stream));
+    const size_t n_stay = hc[0], n_up = slab.comm->has_up() ? hc[1] : 0, n_down = slab.comm->has_down() ? hc[2] : 0;
+    if ((hc[1] && !slab.comm->has_up()) || (hc[2] && !slab.comm->has_down())) return fail(FY_ERR_INVALID, "migrate: ownership rule sent a particle past the end of the block");
+    // sizes first ...
+    const double sc[2] = {(double)n_up, (double)n_down};
+    FY_HIP(hipMemcpyAsync(mig_cnt.p, sc, sizeof(sc), hipMemcpyHostToDevice, stream));
+    FY_HIP(hipMemsetAsync(mig_cnt.p + 2, 0, 2 * sizeof(double), stream));
+    FY_TRY(slab.comm->neighbour_exchange(stream, mig_cnt.p, mig_cnt.p + 2, mig_cnt.p + 1, mig_cnt.p + 3, 1));
+    double rc[2] = {0, 0};
+    FY_HIP(hipMemcpyAsync(rc, mig_cnt.p + 2, sizeof(rc), hipMemcpyDeviceToHost, stream));
+    FY_HIP(hipStreamSynchronize(stream));
+    const size_t from_down = (size_t)rc[0], from_up = (size_t)rc[1];
+    const size_t n_new = n_stay + from_down + from_up;
+    if (11 * n_new > mig_stay.n) {                          // grow, keeping the stayers
+        DevBuf<double> bigger;
+        FY_TRY(bigger.reserve(11 * n_new + 11 * n_new / 4));
+        FY_HIP(hipMemcpyAsync(bigger.p, mig_stay.p, 11 * n_stay * sizeof(double), hipMemcpyDeviceToDevice, stream));
+        FY_HIP(hipStreamSynchronize(stream));
+        std::swap(bigger.p, mig_stay.p); std::swap(bigger.n, mig_stay.n);
+    }
+    // ... then the payloads, appended behind the stayers
+    FY_TRY(slab.comm->neighbour_exchange_sized(stream, mig_up.p, 11 * n_up, mig_stay.p + 11 * n_stay, 11 * from_down, mig_down.p, 11 * n_down,
+                                               mig_stay.p + 11 * (n_stay + from_down), 11 * from_up));
+    if (d_tags && (int64_t)n_new > tag_capacity) return fail(FY_ERR_INVALID, "migrate: tag array holds %lld entries, %zu needed", (long long)tag_capacity, n_new);
+    FY_TRY(b.rec_own.reserve(10 * std::max<size_t>(n_new, 1)));
+    FY_TRY(launch_migrate_unpack(stream, mig_stay.p, (int64_t)n_new, b.rec_own.p, d_tags));
+    b.d_rec = b.rec_own.p;
+    FY_TRY(ensure_batch(b, (int64_t)n_new));
+    b.binned_n = -1;                                       // a new population: bin it afresh
+    b.torque_zero_buf = nullptr;
+    FY_HIP(hipStreamSynchronize(stream));
+    if (n_out) *n_out = (int64_t)n_new;
+    return FY_OK;
+}
+
 int Coupling::ensure_found(Batch& b) {
     if (!b.found_stale) return FY_OK;
     FY_TRY(launch_found_from_chain(stream, soa_of(b), b.n, b.found.p));
@@ -712,6 +764,19 @@ int fy_set_num_batches(fy_ctx* c, int nb) {
 int fy_set_particles_host(fy_ctx* c, int batch, const double* rec, int64_t n) { FY_CTX(c); return c->c.set_particles_host(batch, rec, n); }
 int fy_set_particles_device(fy_ctx* c, int batch, const double* rec, int64_t n) { FY_CTX(c); return c->c.set_particles_device(batch, rec, n); }
 int fy_get_forces_host(fy_ctx* c, int batch, double* out) { FY_CTX(c); return c->c.get_forces_host(batch, out); }
+int fy_migrate_particles(fy_ctx* c, int64_t* d_tags, int64_t tag_capacity, int64_t* n_local_out) { FY_CTX(c); return c->c.migrate(d_tags, tag_capacity, n_local_out); }
+int fy_get_particles_host(fy_ctx* c, int batch, double* out, int64_t* n_out) {
+    FY_CTX(c);
+    if (batch < 0 || batch >= (int)c->c.batches.size()) return fy::fail(FY_ERR_INVALID, "fy_get_particles_host: bad batch");
+    fy::Batch& b = *c->c.batches[batch];
+    if (n_out) *n_out = b.n;
+    if (out && b.n) {
+        FY_HIP(hipSetDevice(c->c.device));
+        FY_HIP(hipMemcpyAsync(out, b.d_rec, 10 * (size_t)b.n * sizeof(double), hipMemcpyDeviceToHost, c->c.stream));
+        FY_HIP(hipStreamSynchronize(c->c.stream));
+    }
+    return FY_OK;
+}
 int fy_get_found_host(fy_ctx* c, int batch, int32_t* out) { FY_CTX(c); return c->c.get_found_host(batch, out); }
 const double* fy_forces_device(fy_ctx* c, int batch) {
     if (!c || batch < 0 || batch >= (int)c->c.batches.size()) return nullptr;

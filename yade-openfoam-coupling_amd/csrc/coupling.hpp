@@ -106,6 +106,9 @@ struct Coupling {
     int set_particles_host(int bi, const double* rec, int64_t n);
     int set_particles_device(int bi, const double* d_rec, int64_t n);
     SlabOwn slab_own() const { return SlabOwn{slab.active ? 1 : 0, slab.kglob0, slab.kglob0 + slab.nz, slab.nzglob, mesh.origin[2], mesh.dx}; }
+    int migrate(int64_t* d_tags, int64_t tag_capacity, int64_t* n_out);
+    DevBuf<double> mig_stay, mig_up, mig_down, mig_cnt;
+    DevBuf<unsigned int> mig_counters;
     int ensure_found(Batch& b);
     int run_batch(Batch& b);
     int set_force_models(unsigned flags);

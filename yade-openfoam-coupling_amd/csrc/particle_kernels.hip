@@ -622,6 +622,33 @@ __global__ __launch_bounds__(kForceThreads) void k_force_gaussian(ParticleSoA p,
     }
 }
 
+// ---- particle migration between z-slabs: records whose containing cell now lies in a neighbour's planes are packed for
+// that neighbour, the others compacted; 11 doubles per particle = the wire record + its tag (an int64 carried as a bit pattern)
+__global__ __launch_bounds__(256) void k_migrate_pack(const double* __restrict__ rec, const int64_t* __restrict__ tags, int64_t n, SlabOwn own,
+                                                      unsigned int* __restrict__ counters, double* __restrict__ stay, double* __restrict__ up,
+                                                      double* __restrict__ down) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double* r = rec + 10 * i;
+    const double z = r[2];
+    int kz = (int)floor((z - own.oz) / own.dx);
+    kz = min(max(kz, 0), own.nzglob - 1);
+    const int dest = !(z == z) ? 0 : (kz >= own.k1 ? 1 : (kz < own.k0 ? 2 : 0));      // NaN stays (and is never located)
+    double* out = dest == 0 ? stay : (dest == 1 ? up : down);
+    const unsigned int pos = atomicAdd(&counters[dest], 1u);
+    double* o = out + 11 * (size_t)pos;
+    for (int q = 0; q < 10; ++q) o[q] = r[q];
+    o[10] = __longlong_as_double(tags ? (long long)tags[i] : (long long)-1);
+}
+
+__global__ __launch_bounds__(256) void k_migrate_unpack(const double* __restrict__ packed, int64_t n, double* __restrict__ rec, int64_t* __restrict__ tags) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double* r = packed + 11 * i;
+    for (int q = 0; q < 10; ++q) rec[10 * i + q] = r[q];
+    if (tags) tags[i] = (int64_t)__double_as_longlong(r[10]);
+}
+
 // found flags in wire order (FoamYade.C:141,204,222): 1 if the particle has a stencil, -1 otherwise.  Only the parallel-Yade
 // protocol and the tests read them, so they are formed on demand instead of as 10 M scattered 4-byte stores in every force pass.
 __global__ __launch_bounds__(256) void k_found_from_chain(ParticleSoA p, int64_t n, int32_t* __restrict__ found_out) {
@@ -819,6 +846,20 @@ int launch_force_gaussian(hipStream_t s, ParticleSoA p, int64_t n, ForceParams f
     if (n <= 0) return FY_OK;
     hipLaunchKernelGGL(k_force_gaussian, dim3(div_up(n, kForceThreads)), dim3(kForceThreads), 0, s, p, n, fp, cw, vol, U, alpha, uParticle, gradP, divT,
                        vGrad, ddtU, rec, uSourceDrag, uSource, force_out, found_out);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+
+int launch_migrate_pack(hipStream_t s, const double* rec, const int64_t* tags, int64_t n, SlabOwn own, unsigned int* counters, double* stay, double* up, double* down) {
+    if (n <= 0) return FY_OK;
+    hipLaunchKernelGGL(k_migrate_pack, dim3(div_up(n, 256)), dim3(256), 0, s, rec, tags, n, own, counters, stay, up, down);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+
+int launch_migrate_unpack(hipStream_t s, const double* packed, int64_t n, double* rec, int64_t* tags) {
+    if (n <= 0) return FY_OK;
+    hipLaunchKernelGGL(k_migrate_unpack, dim3(div_up(n, 256)), dim3(256), 0, s, packed, n, rec, tags);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }

@@ -83,6 +83,9 @@ int launch_force_gaussian(hipStream_t s, ParticleSoA p, int64_t n, ForceParams f
                           const double* alpha, const double* uParticle, const double* gradP, const double* divT,
                           const double* vGrad, const double* ddtU, const double* rec,
                           double* uSourceDrag, double* uSource, double* force_out, int32_t* found_out);
+// z-slab migration: classify by owner slab and pack (11 doubles per particle: record + tag bits); counters = {stay, up, down}
+int launch_migrate_pack(hipStream_t s, const double* rec, const int64_t* tags, int64_t n, SlabOwn own, unsigned int* counters, double* stay, double* up, double* down);
+int launch_migrate_unpack(hipStream_t s, const double* packed, int64_t n, double* rec, int64_t* tags);
 // Gaussian mode: found flags in wire order from the chain lengths (launch_force_gaussian no longer writes found_out)
 int launch_found_from_chain(hipStream_t s, ParticleSoA p, int64_t n, int32_t* found);
 int launch_unpack_stencils(hipStream_t s, ParticleSoA p, int64_t n, int32_t* k, int32_t* ids, double* w, int32_t* chain);
