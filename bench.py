@@ -30,11 +30,12 @@ import __graft_entry__ as ge  # noqa: E402
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s copy-achievable)
 
 
-def c3_case(prod, n, dt, p_solver, n_slabs=1):
+def c3_case(prod, n, dt, p_solver, n_slabs=1, strong=False):
     """closed box, no-slip walls, g = (0,0,-9.81), nu = 1e-6, rho_p = 2650, rho_f = 1000, PIMPLE nOuter 1 nCorr 2,
-    fixedFluxPressure walls (what a DPMFoam case with gravity uses).  n_slabs > 1: the C4 weak-scaling box, n x n x (n * n_slabs)."""
+    fixedFluxPressure walls (what a DPMFoam case with gravity uses).  n_slabs > 1: the weak-scaling box n x n x (n * n_slabs), or with
+    strong=True the C3 box itself (BASELINE configs[3]); the solver cuts either into n_slabs z-slabs."""
     dx = 1.0 / n
-    return prod.make_case(prod.FY_SOLVER_PIMPLE, n, n, n * n_slabs, dx, dt, 1e-6, rho_f=1000.0, rho_p=2650.0, g=(0.0, 0.0, -9.81),
+    return prod.make_case(prod.FY_SOLVER_PIMPLE, n, n, n if strong else n * n_slabs, dx, dt, 1e-6, rho_f=1000.0, rho_p=2650.0, g=(0.0, 0.0, -9.81),
                           u_bc=[prod.FY_BC_U_FIXED_VALUE] * 6, u_val=[(0, 0, 0)] * 6, p_bc=[prod.FY_BC_P_FIXED_FLUX] * 6,
                           n_outer_correctors=1, n_correctors=2, p_solver=p_solver)
 
@@ -47,6 +48,21 @@ def c3_particles(torch, n_part, n, seed, device, slab=0):
     rec[:, 0:3] = torch.rand(n_part, 3, dtype=torch.float64, generator=g)
     rec[:, 2] *= 0.6
     rec[:, 2] += float(slab)
+    rec[:, 9] = 0.2 * dx
+    return rec.to(device).contiguous()
+
+
+def c3_particles_strong(torch, n_part, n, device, rank, world):
+    """BASELINE configs[3]: the ONE C3 cloud (seed 3, lower 60 % of the unit box); this rank keeps the particles inside its z-slab.  The upper
+    slabs hold few or none -- that imbalance is the configuration's, not an artefact."""
+    g = torch.Generator(device="cpu").manual_seed(3)
+    dx = 1.0 / n
+    pos = torch.rand(n_part, 3, dtype=torch.float64, generator=g)
+    pos[:, 2] *= 0.6
+    h = 1.0 / world
+    mine = (pos[:, 2] >= rank * h) & (pos[:, 2] < (rank + 1) * h)
+    rec = torch.zeros(int(mine.sum()), 10, dtype=torch.float64)
+    rec[:, 0:3] = pos[mine]
     rec[:, 9] = 0.2 * dx
     return rec.to(device).contiguous()
 
@@ -158,6 +174,7 @@ def main():
     ap.add_argument("--p-solver", type=int, default=1, help="0 PCG+Jacobi, 1 PCG+multigrid")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-n", type=int, default=64)
+    ap.add_argument("--strong", action="store_true", help="N > 1: cut the ONE C3 box into N slabs (BASELINE configs[3]) instead of growing it (weak, the default)")
     ap.add_argument("--force-rccl", action="store_true", help="use the RCCL communicator even with one rank (smoke test of the RCCL path)")
     args = ap.parse_args()
 
@@ -178,7 +195,8 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     prod = ge.load_product()
-    case = c3_case(prod, args.n, args.dt, args.p_solver, world)
+    strong = bool(args.strong and world > 1)
+    case = c3_case(prod, args.n, args.dt, args.p_solver, world, strong)
     comm, solver, setup_err = None, None, ""
     try:
         if world > 1 or args.force_rccl:
@@ -202,7 +220,7 @@ def main():
         t = torch.tensor([slabs_ok], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         slabs_ok = float(t.item())
-    parallelism = "single GPU" if world == 1 else f"{world} z-slabs of one {args.n}x{args.n}x{args.n * world} box, RCCL halos + all-reduces over xGMI"
+    parallelism = "single GPU" if world == 1 else f"{world} z-slabs of one {args.n}x{args.n}x{args.n if strong else args.n * world} box, RCCL halos + all-reduces over xGMI"
     slab_of_rank = rank
     if slabs_ok < 1.0:
         if world == 1:
@@ -217,10 +235,14 @@ def main():
         solver = prod.Solver(case, device=local_rank)
         parallelism = f"FALLBACK: {world} independent replicas of the single-GPU case, no exchange (z-slab/RCCL set-up failed: {setup_err or 'on another rank'})"
         slab_of_rank = 0
-    rec = c3_particles(torch, args.particles, args.n, 3 + rank, dev, slab=slab_of_rank)
+    if strong and slabs_ok >= 1.0:
+        rec = c3_particles_strong(torch, args.particles, args.n, dev, rank, world)
+    else:
+        strong = False
+        rec = c3_particles(torch, args.particles, args.n, 3 + rank, dev, slab=slab_of_rank)
     solver.set_particles_device(rec)
     solver.enable_particle_timing(True)
-    nc = args.n ** 3                      # cells per rank (one C3-sized slab)
+    nc = args.n ** 3 // (world if strong else 1)      # cells per rank
 
     def barrier():
         torch.cuda.synchronize()
@@ -245,13 +267,13 @@ def main():
     elapsed = max_over_ranks(elapsed, dist, dev)
 
     K = args.steps
-    steps_per_s = aggregate_value(world, K, elapsed)
+    steps_per_s = K / elapsed if strong else aggregate_value(world, K, elapsed)      # strong: steps of the one box; weak: slab-steps
     # ---- per-kernel clocks (HIP events on the launch stream, collected inside the timed region)
     kern = {}
     smooth_ms, smooth_n = solver.kernel_timing("mg_smooth_l0")
     apply_ms, apply_n = solver.kernel_timing("p_apply_dot")
     mom_ms, mom_n = solver.kernel_timing("mom_pass")
-    np_part = args.particles
+    np_part = int(rec.shape[0]) if strong else args.particles      # particles of this rank
     dep_ms = max(acc["depfin"], 0.0)
     cand = {
         # name: (total ms over the timed steps, launches, algorithmic bytes per launch, description) -- DESIGN.md section 3;
@@ -292,17 +314,17 @@ def main():
         "metric": "coupled_steps_per_sec (pimpleFoamYade 4-way, 10M particles / 4M cells per GPU)" if (args.n == 160 and args.particles == 10_000_000)
         else f"coupled_steps_per_sec (pimpleFoamYade 4-way, {args.particles} particles / {nc} cells)",
         "value": round(steps_per_s, 4), "unit": "steps/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
-        "ms_per_step": round(1e3 * elapsed / K, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": round(1e3 * elapsed / K, 3), "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "particle_steps_per_sec": round(steps_per_s * np_part, 1),
-        "coupled_steps_per_sec_of_the_whole_box": round(steps_per_s / world, 4),
+        "particle_steps_per_sec": round(steps_per_s * (args.particles if strong else np_part), 1),
+        "coupled_steps_per_sec_of_the_whole_box": round(steps_per_s if strong else steps_per_s / world, 4),
         "config": {"workload": "C3: pimpleFoamYade Gaussian 4-way coupling, 160^3 = 4,096,000-cell closed box, 10,000,000 particles in the lower 60 %"
                    if (args.n == 160 and args.particles == 10_000_000) else f"non-default C3-like case {args.n}^3 cells / {args.particles} particles",
                    "cells": nc, "particles": np_part, "dt": args.dt, "pimple": {"nOuterCorrectors": 1, "nCorrectors": 2},
                    "p_solver": "PCG+MG V(2,2) damped Jacobi" if args.p_solver == 1 else "PCG+Jacobi",
                    "p_tol": [case.p_tol, case.p_rel_tol, case.p_final_tol, case.p_final_rel_tol],
                    "parallelism": parallelism,
-                   "global_cells": nc * world, "global_particles": np_part * world},
+                   "global_cells": nc * world, "global_particles": args.particles if strong else np_part * world},
         "per_step_ms": {k: round(acc[k] / K, 3) for k in ("particle", "bin", "locate", "depfin", "force", "momentum", "pressure", "other")},
         "p_iters_per_step": acc["p_iters"] / K, "u_iters_per_step": acc["u_iters"] / K,
         "roofline": roof(dominant) if dominant else None,
