@@ -172,3 +172,87 @@ def test_wire_protocol_matches_reference(product, name):
         fy.setSourceZero()
         yade.next_step()
     fy.close()
+
+
+def _engine(prod, c, yade, fields, mut):
+    mesh = prod.BlockMesh(c.nx, c.ny, c.nz, c.dx, c.origin)
+    fy = prod.FoamYade(mesh, fields["U"], fields["gradP"], fields["vGrad"], fields["divT"], fields["ddtU"], c.g, mut["uSourceDrag"],
+                       mut["alpha"], mut["uSource"], mut["uParticle"], bool(c.gaussian), transport=yade.T)
+    fy.setScalarProperties(c.rhoP, c.rhoF, c.nu)
+    return fy
+
+
+def test_serial_yade_with_no_particles(product):
+    """N = 0 from a serial Yade: the reference still issues both broadcasts (FoamYade.C:176,181 -- the second with count 0), no
+    per-particle collectives, and the dt handshake; the fields stay at their reset values"""
+    c = gc.CASES_BY_NAME["g16_serial_2step"]
+    g = gu.load(c.name)
+    fields = gc.fluid_fields(c)
+    yade = FakeYade(product, c, g, [np.zeros((0, 10)), g["records_s0"]])
+    Nc = c.ncells
+    mut = dict(uSourceDrag=np.full(Nc, 5.0), alpha=np.zeros(Nc), uSource=np.full((Nc, 3), 3.0), uParticle=np.full((Nc, 3), 4.0))
+    fy = _engine(product, c, yade, fields, mut)
+    fy.setParticleAction(c.dt)
+    assert yade.log == [("bcast_world", 1, 0, 0, -1), ("bcast_world", 0, 1, 0, -1), ("send", 1, 1, 0, TAG_FDT), ("bcast_world", 1, 1, 0, -1)]
+    assert np.all(mut["alpha"] == 1.0) and np.all(mut["uSource"] == 0.0) and np.all(mut["uSourceDrag"] == 0.0)
+    fy.setSourceZero()
+    # ... and the next step, with particles, is the golden one
+    yade.next_step()
+    fy.setParticleAction(c.dt)
+    n = g["records_s0"].shape[0]
+    got = np.array(yade.allred_dbl).reshape(n, 6)
+    fref = g["wire_force_s0"]
+    np.testing.assert_allclose(got, fref, rtol=gu.RTOL_GPU, atol=gu.RTOL_GPU * 1e-3 * np.abs(fref).max())
+    fy.close()
+
+
+class LopsidedYade(FakeYade):
+    """parallel Yade whose LAST worker has no particle for this solver rank (numParticlesProc = 0, FoamYade.C:127-128)"""
+
+    def worker_slice(self, w):
+        n = self.records[self.step].shape[0]
+        if w == self.W - 1:
+            return n, n
+        lo, hi = gc.split_range(n, self.W - 1, w)
+        return lo, hi
+
+
+def test_parallel_yade_worker_without_particles_is_skipped(product):
+    """a worker that reports zero particles is not in inCommProcs: no data receive from it, no found / force send to it
+    (FoamYade.C:127-155, 239-243, 504-507); the others are served as usual"""
+    c = gc.CASES_BY_NAME["g16_parallel3"]
+    g = gu.load(c.name)
+    fields = gc.fluid_fields(c)
+    recs = [g["records_s0"]]
+    yade = LopsidedYade(product, c, g, recs)
+    Nc = c.ncells
+    mut = dict(uSourceDrag=np.full(Nc, 5.0), alpha=np.zeros(Nc), uSource=np.full((Nc, 3), 3.0), uParticle=np.full((Nc, 3), 4.0))
+    fy = _engine(product, c, yade, fields, mut)
+    yade.log.clear(); yade.sent.clear()
+    fy.setParticleAction(c.dt)
+    W = yade.W
+    idle = W                                    # world rank of the worker without particles (workers are ranks 1..W)
+    kinds = [(e[0], e[3], e[4]) for e in yade.log]
+    assert [k for k in kinds if k[0] == "recv" and k[2] == TAG_SZ] == [("recv", r, TAG_SZ) for r in range(1, W + 1)]      # every worker is asked
+    assert ("recv", idle, TAG_DATA) not in kinds and ("send", idle, TAG_RES) not in kinds and ("send", idle, TAG_FORCE) not in kinds
+    n = recs[0].shape[0]
+    F = np.zeros((n, 6)); found = np.zeros(n, dtype=int)
+    for w in range(W - 1):
+        lo, hi = yade.worker_slice(w)
+        F[lo:hi] = yade.sent[(TAG_FORCE, w + 1)][0].reshape(-1, 6)
+        found[lo:hi] = yade.sent[(TAG_RES, w + 1)][0]
+    # same particles, differently split over the workers: the per-particle forces are those of the golden run up to the
+    # order in which the batches deposit (setCellVolFraction is an assignment per batch, FoamYade.C:318-328), so compare found flags
+    # exactly and forces of the FIRST batch only against a direct run with the same batches
+    np.testing.assert_array_equal(found, np.where(g["k_s0"].astype(int) > 0, 1, -1))
+    mut2 = dict(uSourceDrag=np.zeros(Nc), alpha=np.ones(Nc), uSource=np.zeros((Nc, 3)), uParticle=np.zeros((Nc, 3)))
+    mesh = product.BlockMesh(c.nx, c.ny, c.nz, c.dx, c.origin)
+    ref = product.FoamYade(mesh, fields["U"], fields["gradP"], fields["vGrad"], fields["divT"], fields["ddtU"], c.g, mut2["uSourceDrag"],
+                           mut2["alpha"], mut2["uSource"], mut2["uParticle"], True)
+    ref.setScalarProperties(c.rhoP, c.rhoF, c.nu)
+    batches = [recs[0][slice(*yade.worker_slice(w))] for w in range(W - 1)]
+    ref.setParticles(batches)
+    ref.setParticleAction(c.dt)
+    Fref = np.concatenate([ref.forces(b) for b in range(W - 1)])
+    np.testing.assert_allclose(F, Fref, rtol=1e-9, atol=1e-12 * np.abs(Fref).max())
+    fy.close(); ref.close()

@@ -509,7 +509,10 @@ int Coupling::recv_serial() {
     Batch& b = *batches[0];
     b.yrank = 0;
     b.h_rec.resize(10 * (size_t)N);
-    if (N) FY_TR(transport.bcast_world(transport.user, b.h_rec.data(), 10 * N, FY_T_DOUBLE, 0));
+    // the reference broadcasts the record buffer unconditionally (FoamYade.C:181), also when it is empty: a collective has to be
+    // matched by every rank, so the zero-count call is issued too
+    double none = 0.0;
+    FY_TR(transport.bcast_world(transport.user, N ? b.h_rec.data() : &none, 10 * N, FY_T_DOUBLE, 0));
     return set_particles_host(0, b.h_rec.data(), N);
 }
 
