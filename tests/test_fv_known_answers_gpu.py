@@ -1,0 +1,73 @@
+"""Known-answer flows on the PRODUCT (HIP path through the C-ABI), at resolutions the CPU oracle cannot afford in a test: the FV half has
+no reference build to be pinned against (OpenFOAM-6 is absent), so besides 'HIP == oracle' (tests/test_fv_parity.py) the product itself
+is held to physics -- Ghia, Ghia & Shin (1982) for the lid-driven cavity at Re = 100, the analytic Poiseuille profile, and second-order
+convergence of the discretisation towards it."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+XMIN, XMAX, YMIN, YMAX, ZMIN, ZMAX = range(6)
+# Ghia, Ghia & Shin (1982), Table I, Re = 100: u along the vertical centre line x = 0.5
+GHIA_Y = np.array([0.0547, 0.0625, 0.0703, 0.1016, 0.1719, 0.2813, 0.4531, 0.5000, 0.6172, 0.7344, 0.8516, 0.9531, 0.9609, 0.9688, 0.9766])
+GHIA_U = np.array([-0.03717, -0.04192, -0.04775, -0.06434, -0.10150, -0.15662, -0.21090, -0.20581, -0.13641, 0.00332, 0.23151,
+                   0.68717, 0.73722, 0.78871, 0.84123])
+
+
+@pytest.mark.parametrize("solver", [0, 1])
+def test_cavity_re100_matches_ghia_at_128(product, solver):
+    n = 128
+    dx = 1.0 / n
+    u_val = [(0, 0, 0)] * 6
+    u_val[YMAX] = (1.0, 0, 0)
+    case = product.make_case(solver, n, n, 2, dx, 0.4 * dx, 0.01, u_bc=[0, 0, 0, 0, 1, 1], u_val=u_val, p_solver=1)   # z sides zero-gradient: 2-D flow
+    s = product.Solver(case)
+    prev = None
+    for it in range(12000):
+        s.step()
+        if it % 250 == 249:
+            U = s.get("U").reshape(2, n, n, 3)[0]
+            if prev is not None and np.abs(U - prev).max() < 2e-6:
+                break
+            prev = U
+    U = s.get("U").reshape(2, n, n, 3)
+    assert np.abs(U[0] - U[1]).max() < 1e-6 and np.abs(U[..., 2]).max() < 1e-6          # it stayed two-dimensional (to solver tolerance)
+    yc = (np.arange(n) + 0.5) / n
+    uc = 0.5 * (U[0, :, n // 2 - 1, 0] + U[0, :, n // 2, 0])                             # x = 0.5 lies on a face
+    err = np.abs(np.interp(GHIA_Y, yc, uc) - GHIA_U)
+    assert err.max() < 0.006, err                                                       # 32^2 in the oracle test: 0.02
+    st = s.stats()
+    assert st["cont_err_sum_local"] < 1e-6 and st["courant_max"] < 1.0
+    s.close()
+
+
+def poiseuille_error(product, solver, ny):
+    """pressure-driven plane channel: u(y) = G / (2 nu) y (H - y), H = 1, G = dp / L (kinematic)"""
+    nx = 8
+    dx = 1.0 / ny
+    nu, G = 0.05, 0.4
+    L = nx * dx
+    u_bc = [1, 1, 0, 0, 1, 1]
+    p_bc = [1, 1, 0, 0, 0, 0]
+    case = product.make_case(solver, nx, ny, 2, dx, 0.2 * dx / 1.0, nu, u_bc=u_bc, p_bc=p_bc, p_val=[G * L, 0.0, 0, 0, 0, 0], p_solver=1)
+    s = product.Solver(case)
+    prev = None
+    for it in range(60000):
+        s.step()
+        if it % 500 == 499:
+            u = s.get("U").reshape(2, ny, nx, 3)[0, :, nx // 2, 0]
+            if prev is not None and np.abs(u - prev).max() < 1e-9:
+                break
+            prev = u
+    y = (np.arange(ny) + 0.5) * dx
+    exact = G / (2 * nu) * y * (1.0 - y)
+    u = s.get("U").reshape(2, ny, nx, 3)[0, :, nx // 2, 0]
+    s.close()
+    return np.abs(u - exact).max() / exact.max()
+
+
+@pytest.mark.parametrize("solver", [0, 1])
+def test_poiseuille_profile_and_second_order_convergence(product, solver):
+    e1, e2 = poiseuille_error(product, solver, 16), poiseuille_error(product, solver, 32)
+    assert e2 < 2e-3
+    assert 3.0 < e1 / e2 < 5.0, (e1, e2)            # halving dx divides the error by ~4
