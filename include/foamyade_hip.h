@@ -163,6 +163,8 @@ enum { FY_BC_U_FIXED_VALUE = 0, FY_BC_U_ZERO_GRADIENT = 1 };
 enum { FY_BC_P_ZERO_GRADIENT = 0, FY_BC_P_FIXED_VALUE = 1, FY_BC_P_FIXED_FLUX = 2 };
 enum { FY_PSOLVER_PCG_JACOBI = 0, FY_PSOLVER_PCG_MG = 1 };
 
+#define FY_CONVECTION_LINEAR 0
+#define FY_CONVECTION_UPWIND 1
 typedef struct fy_case_desc {
     int32_t solver;                 /* FY_SOLVER_ICO | FY_SOLVER_PIMPLE */
     int32_t nx, ny, nz;
@@ -184,6 +186,7 @@ typedef struct fy_case_desc {
     int32_t p_solver;               /* FY_PSOLVER_* */
     double p_tol, p_rel_tol, p_final_tol, p_final_rel_tol; int32_t p_max_iter;
     double u_tol, u_rel_tol; int32_t u_max_iter;
+    int32_t convection_scheme;             /* divSchemes for div(phi,U): FY_CONVECTION_LINEAR (Gauss linear, default) | FY_CONVECTION_UPWIND (Gauss upwind) */
 } fy_case_desc;
 
 typedef struct fy_solver fy_solver;
@@ -220,7 +223,8 @@ int fy_solver_hold_sources(fy_solver*, int hold);
  * zeroGradient / fixedValue (uniform) / fixedFluxPressure; internalField uniform or nonuniform; fixed deltaT.  Everything else is
  * refused with FY_ERR_UNSUPPORTED and a message naming file and keyword.
  *   system/blockMeshDict, system/controlDict, system/fvSolution (PISO | PIMPLE, solvers.p / pFinal / U),
- *   system/fvSchemes (must ask for Euler / Gauss linear / linear / corrected|orthogonal: what the solver implements),
+ *   system/fvSchemes (must ask for Euler / Gauss linear / linear / corrected|orthogonal, div(phi,U) Gauss linear | Gauss upwind:
+ *   what the solver implements),
  *   constant/transportProperties (nu, partDensity, fluidDensity | continuousPhaseName + rho.<phase>), constant/g,
  *   <startTime>/U | U.<phase>, <startTime>/p */
 typedef struct fy_foam_case fy_foam_case;

@@ -42,6 +42,7 @@ struct orc_fv_case {
     int p_solver;                // 0 PCG+Jacobi, 1 PCG+MG
     double p_tol, p_rel_tol, p_final_tol, p_final_rel_tol; int p_max_iter;
     double u_tol, u_rel_tol; int u_max_iter;
+    int convection_scheme;      // 0 Gauss linear, 1 Gauss upwind
 };
 struct orc_fv_stats {
     double courant_mean, courant_max, cont_sum_local, cont_global, cont_cumulative;
@@ -293,8 +294,10 @@ struct Fv {
                         dg += phio;
                     }
                 } else {
-                    dg += 0.5 * phio + gam;
-                    an[2 * d + s][c] = 0.5 * phio - gam;
+                    const double cP = cs.convection_scheme == 1 ? std::max(phio, 0.0) : 0.5 * phio;
+                    const double cN = cs.convection_scheme == 1 ? std::min(phio, 0.0) : 0.5 * phio;
+                    dg += cP + gam;
+                    an[2 * d + s][c] = cN - gam;
                 }
             }
             if (pimple) {

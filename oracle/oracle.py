@@ -182,7 +182,7 @@ class FvCase(C.Structure):
                 ("n_outer", C.c_int), ("n_corr", C.c_int), ("n_non_orth", C.c_int), ("momentum_predictor", C.c_int),
                 ("p_ref_cell", C.c_int), ("p_ref_value", C.c_double), ("p_solver", C.c_int),
                 ("p_tol", C.c_double), ("p_rel_tol", C.c_double), ("p_final_tol", C.c_double), ("p_final_rel_tol", C.c_double),
-                ("p_max_iter", C.c_int), ("u_tol", C.c_double), ("u_rel_tol", C.c_double), ("u_max_iter", C.c_int)]
+                ("p_max_iter", C.c_int), ("u_tol", C.c_double), ("u_rel_tol", C.c_double), ("u_max_iter", C.c_int), ("convection_scheme", C.c_int)]
 
 
 class FvStats(C.Structure):
@@ -199,7 +199,7 @@ XMIN, XMAX, YMIN, YMAX, ZMIN, ZMAX = range(6)
 
 def fv_case(solver, nx, ny, nz, dx, dt, nu, rho_f=1000.0, rho_p=2650.0, g=(0, 0, 0), u_bc=None, u_val=None, p_bc=None,
             p_val=None, n_outer=1, n_corr=2, p_solver=1, origin=(0, 0, 0), momentum_predictor=1, p_tol=1e-6, p_rel_tol=0.05,
-            p_final_tol=1e-6, p_final_rel_tol=0.0, u_tol=1e-5, u_rel_tol=0.0, p_max_iter=1000, u_max_iter=1000, p_ref_cell=0,
+            p_final_tol=1e-6, p_final_rel_tol=0.0, u_tol=1e-5, u_rel_tol=0.0, p_max_iter=1000, u_max_iter=1000, convection_scheme=0, p_ref_cell=0,
             p_ref_value=0.0, n_non_orth=0):
     """documented defaults = the icoFoam cavity / DPMFoam tutorial settings of SURVEY.md Appendix C"""
     c = FvCase()
@@ -222,6 +222,7 @@ def fv_case(solver, nx, ny, nz, dx, dt, nu, rho_f=1000.0, rho_p=2650.0, g=(0, 0,
     c.p_ref_cell, c.p_ref_value, c.p_solver = p_ref_cell, p_ref_value, p_solver
     c.p_tol, c.p_rel_tol, c.p_final_tol, c.p_final_rel_tol, c.p_max_iter = p_tol, p_rel_tol, p_final_tol, p_final_rel_tol, p_max_iter
     c.u_tol, c.u_rel_tol, c.u_max_iter = u_tol, u_rel_tol, u_max_iter
+    c.convection_scheme = int(convection_scheme)
     return c
 
 

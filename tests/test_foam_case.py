@@ -191,3 +191,18 @@ def test_dictionary_syntax_variants_are_understood(prod, tmp_path):
     assert "internalField" in str(e.value)
     for o in (fc, ref):
         o.close()
+
+
+def test_gauss_upwind_is_read_as_the_upwind_scheme(prod, tmp_path):
+    dst = tmp_path / "case"
+    shutil.copytree(os.path.join(CASES, "bed_pimple"), dst)
+    f = dst / "system/fvSchemes"
+    f.write_text(f.read_text().replace("div(phi,U)       Gauss linear;", "div(phi,U)       Gauss upwind;").replace("div(alphaPhic,Uc) Gauss linear;", "div(alphaPhic,Uc) Gauss upwind;"))
+    fc = prod.FoamCase(dst, prod.FY_SOLVER_PIMPLE)
+    assert fc.case.convection_scheme == prod.FY_CONVECTION_UPWIND
+    fc.close()
+    f.write_text(f.read_text().replace("div(phi,U)       Gauss upwind;", "div(phi,U)       Gauss linear;"))        # one of each: refused
+    with pytest.raises(prod.FoamYadeError) as e:
+        prod.FoamCase(dst, prod.FY_SOLVER_PIMPLE)
+    assert "mixes" in str(e.value)
+    assert prod.FoamCase(os.path.join(CASES, "bed_pimple"), prod.FY_SOLVER_PIMPLE).case.convection_scheme == prod.FY_CONVECTION_LINEAR

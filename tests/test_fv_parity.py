@@ -134,6 +134,32 @@ def test_coupled_steps_with_optional_force_models(product, oracle):
     compare(o, s, rtol=1e-5)
 
 
+@pytest.mark.parametrize("solver", [0, 1])
+def test_upwind_convection_matches_oracle(product, oracle, solver):
+    """divSchemes Gauss upwind (fy_case_desc.convection_scheme): HIP path vs oracle, coupled steps at a cell Peclet number of ~30"""
+    n = 16
+    dx = 0.1 / n
+    kw = dict(g=(0, 0, -9.81), p_bc=[2] * 6) if solver == 1 else cavity_bcs()
+    u_val = [(0, 0, 0)] * 6
+    u_val[YMAX] = (0.5, 0, 0)
+    kw.setdefault("u_bc", [0] * 6); kw["u_val"] = u_val
+    o, s = both(product, oracle, solver, n, n, n, dx, 2e-4, 1e-4, convection_scheme=1, **kw)
+    case = gc.Case("cplu", n, n, n, 0.1, gaussian=solver, np_=2000, seed=19, cluster=100, fast=10, vel_scale=0.05)
+    for step in range(4):
+        rec = gc.particle_records(case, step)
+        o.step(rec)
+        s.set_particles(rec)
+        s.step()
+    compare(o, s, rtol=1e-5)
+    # and it is a different discretisation from the default
+    o2, s2 = both(product, oracle, solver, n, n, n, dx, 2e-4, 1e-4, **kw)
+    for step in range(4):
+        s2.set_particles(gc.particle_records(case, step))
+        s2.step()
+    assert np.abs(s2.get("U") - s.get("U")).max() > 1e-4 * np.abs(s.get("U")).max()
+    o2.close(); s2.close()
+
+
 def test_c2_channel_inlet_outlet_point_force(product, oracle):
     """BASELINE configs[1] in miniature: icoFoamYade point force in a channel -- inlet fixedValue U = (1,0,0), outlet zeroGradient U
     with p = 0, no-slip walls"""

@@ -32,6 +32,7 @@ FY_SOLVER_ICO, FY_SOLVER_PIMPLE = 0, 1
 FY_BC_U_FIXED_VALUE, FY_BC_U_ZERO_GRADIENT = 0, 1
 FY_BC_P_ZERO_GRADIENT, FY_BC_P_FIXED_VALUE, FY_BC_P_FIXED_FLUX = 0, 1, 2
 FY_PSOLVER_PCG_JACOBI, FY_PSOLVER_PCG_MG = 0, 1
+FY_CONVECTION_LINEAR, FY_CONVECTION_UPWIND = 0, 1
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)
@@ -87,7 +88,7 @@ class CaseDesc(C.Structure):
                 ("momentum_predictor", C.c_int32), ("p_ref_cell", C.c_int32), ("p_ref_value", C.c_double),
                 ("p_solver", C.c_int32), ("p_tol", C.c_double), ("p_rel_tol", C.c_double), ("p_final_tol", C.c_double),
                 ("p_final_rel_tol", C.c_double), ("p_max_iter", C.c_int32),
-                ("u_tol", C.c_double), ("u_rel_tol", C.c_double), ("u_max_iter", C.c_int32)]
+                ("u_tol", C.c_double), ("u_rel_tol", C.c_double), ("u_max_iter", C.c_int32), ("convection_scheme", C.c_int32)]
 
 
 class FoamCaseInfo(C.Structure):

@@ -388,8 +388,11 @@ __global__ __launch_bounds__(256) void k_assemble_momentum(FvGeo g, const double
                     dg += phio;
                 }
             } else {
-                dg += 0.5 * phio + gam;
-                an[2 * d + s] = 0.5 * phio - gam;
+                // fvm::div(phi, U): Gauss linear puts half the face flux on either side; Gauss upwind takes the whole of an
+                // outgoing flux on the diagonal and the whole of an incoming one on the neighbour [OF-6 gaussConvectionScheme]
+                const double cP = g.upwind ? fmax(phio, 0.0) : 0.5 * phio, cN = g.upwind ? fmin(phio, 0.0) : 0.5 * phio;
+                dg += cP + gam;
+                an[2 * d + s] = cN - gam;
             }
         }
     if (pim) {

@@ -24,6 +24,7 @@ struct FvGeo {
     int p_bc[6];            // FY_BC_P_*
     double p_val[6];
     int pimple;
+    int upwind;             // div(phi,U): 0 Gauss linear, 1 Gauss upwind (first order, bounded)
     double dt, nu;
     double g[3];
     int need_ref, p_ref_cell;
