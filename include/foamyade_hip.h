@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define FY_ABI_VERSION 1
+#define FY_ABI_VERSION 2
 
 /* ---- status codes ------------------------------------------------------------------------------------ */
 enum {
