@@ -165,6 +165,7 @@ enum { FY_PSOLVER_PCG_JACOBI = 0, FY_PSOLVER_PCG_MG = 1 };
 
 #define FY_CONVECTION_LINEAR 0
 #define FY_CONVECTION_UPWIND 1
+#define FY_CONVECTION_LINEAR_UPWIND 2
 typedef struct fy_case_desc {
     int32_t solver;                 /* FY_SOLVER_ICO | FY_SOLVER_PIMPLE */
     int32_t nx, ny, nz;
@@ -186,7 +187,7 @@ typedef struct fy_case_desc {
     int32_t p_solver;               /* FY_PSOLVER_* */
     double p_tol, p_rel_tol, p_final_tol, p_final_rel_tol; int32_t p_max_iter;
     double u_tol, u_rel_tol; int32_t u_max_iter;
-    int32_t convection_scheme;             /* divSchemes for div(phi,U): FY_CONVECTION_LINEAR (Gauss linear, default) | FY_CONVECTION_UPWIND (Gauss upwind) */
+    int32_t convection_scheme;             /* divSchemes for div(phi,U): FY_CONVECTION_LINEAR (Gauss linear, default) | _UPWIND (Gauss upwind) | _LINEAR_UPWIND (Gauss linearUpwind, unlimited) */
 } fy_case_desc;
 
 typedef struct fy_solver fy_solver;
@@ -223,7 +224,7 @@ int fy_solver_hold_sources(fy_solver*, int hold);
  * zeroGradient / fixedValue (uniform) / fixedFluxPressure; internalField uniform or nonuniform; fixed deltaT.  Everything else is
  * refused with FY_ERR_UNSUPPORTED and a message naming file and keyword.
  *   system/blockMeshDict, system/controlDict, system/fvSolution (PISO | PIMPLE, solvers.p / pFinal / U),
- *   system/fvSchemes (must ask for Euler / Gauss linear / linear / corrected|orthogonal, div(phi,U) Gauss linear | Gauss upwind:
+ *   system/fvSchemes (must ask for Euler / Gauss linear / linear / corrected|orthogonal, div(phi,U) Gauss linear | upwind | linearUpwind grad(U):
  *   what the solver implements),
  *   constant/transportProperties (nu, partDensity, fluidDensity | continuousPhaseName + rho.<phase>), constant/g,
  *   <startTime>/U | U.<phase>, <startTime>/p */

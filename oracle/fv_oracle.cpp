@@ -42,7 +42,7 @@ struct orc_fv_case {
     int p_solver;                // 0 PCG+Jacobi, 1 PCG+MG
     double p_tol, p_rel_tol, p_final_tol, p_final_rel_tol; int p_max_iter;
     double u_tol, u_rel_tol; int u_max_iter;
-    int convection_scheme;      // 0 Gauss linear, 1 Gauss upwind
+    int convection_scheme;      // 0 Gauss linear, 1 Gauss upwind, 2 Gauss linearUpwind (unlimited, Gauss-linear gradient)
 };
 struct orc_fv_stats {
     double courant_mean, courant_max, cont_sum_local, cont_global, cont_cumulative;
@@ -294,10 +294,19 @@ struct Fv {
                         dg += phio;
                     }
                 } else {
-                    const double cP = cs.convection_scheme == 1 ? std::max(phio, 0.0) : 0.5 * phio;
-                    const double cN = cs.convection_scheme == 1 ? std::min(phio, 0.0) : 0.5 * phio;
+                    const bool up = cs.convection_scheme != 0;               // 1 upwind, 2 linearUpwind (implicit part = upwind)
+                    const double cP = up ? std::max(phio, 0.0) : 0.5 * phio;
+                    const double cN = up ? std::min(phio, 0.0) : 0.5 * phio;
                     dg += cP + gam;
                     an[2 * d + s][c] = cN - gam;
+                    if (cs.convection_scheme == 2) {
+                        // linearUpwind [OF-6 linearUpwind::correction]: face value = upwind cell value + (C_f - C_upwind) . grad(U)_upwind,
+                        // the second term explicit (deferred correction) with the Gauss-linear gradient of the current U
+                        const int nb = c + (s ? stride[d] : -stride[d]);
+                        const int uw = phio > 0.0 ? c : nb;
+                        const double half = (phio > 0.0 ? (s ? 0.5 : -0.5) : (s ? -0.5 : 0.5)) * dx;
+                        for (int q = 0; q < 3; ++q) s3[q] -= phio * (half * vGrad[9 * (size_t)uw + 3 * d + q]);
+                    }
                 }
             }
             if (pimple) {

@@ -64,7 +64,7 @@ def test_bed_case_is_read_like_pimpleFoamYade_would(prod):
     (("constant/transportProperties", "fluidDensity", "fluidDensityX"), "fluidDensity"),
     (("system/fvSolution", "PISO", "SIMPLE"), "PISO"),
     (("0/U", "value           uniform (1 0 0);", "#include \"lid\""), "not supported"),
-    (("system/fvSchemes", "div(phi,U)       Gauss linear;", "div(phi,U)       Gauss linearUpwind grad(U);"), "div(phi,U)"),
+    (("system/fvSchemes", "div(phi,U)       Gauss linear;", "div(phi,U)       Gauss limitedLinear 1;"), "div(phi,U)"),
     (("system/fvSchemes", "default Euler;", "default CrankNicolson 0.9;"), "ddtSchemes"),
 ])
 def test_what_is_outside_the_supported_subset_is_refused_by_name(prod, tmp_path, edit, needle):
@@ -206,3 +206,9 @@ def test_gauss_upwind_is_read_as_the_upwind_scheme(prod, tmp_path):
         prod.FoamCase(dst, prod.FY_SOLVER_PIMPLE)
     assert "mixes" in str(e.value)
     assert prod.FoamCase(os.path.join(CASES, "bed_pimple"), prod.FY_SOLVER_PIMPLE).case.convection_scheme == prod.FY_CONVECTION_LINEAR
+    f.write_text(f.read_text().replace("div(phi,U)       Gauss linear;", "div(phi,U)       Gauss linearUpwind grad(U);").replace("div(alphaPhic,Uc) Gauss upwind;", "div(alphaPhic,Uc) Gauss linearUpwind grad(Uc);"))
+    assert prod.FoamCase(dst, prod.FY_SOLVER_PIMPLE).case.convection_scheme == prod.FY_CONVECTION_LINEAR_UPWIND
+    f.write_text(f.read_text().replace("Gauss linearUpwind grad(U);", "Gauss linearUpwindV grad(U);"))                    # a different limiter: refused
+    with pytest.raises(prod.FoamYadeError) as e:
+        prod.FoamCase(dst, prod.FY_SOLVER_PIMPLE)
+    assert "divSchemes" in str(e.value)

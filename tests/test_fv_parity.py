@@ -134,16 +134,18 @@ def test_coupled_steps_with_optional_force_models(product, oracle):
     compare(o, s, rtol=1e-5)
 
 
+@pytest.mark.parametrize("scheme", [1, 2])
 @pytest.mark.parametrize("solver", [0, 1])
-def test_upwind_convection_matches_oracle(product, oracle, solver):
-    """divSchemes Gauss upwind (fy_case_desc.convection_scheme): HIP path vs oracle, coupled steps at a cell Peclet number of ~30"""
+def test_upwind_convection_matches_oracle(product, oracle, solver, scheme):
+    """divSchemes Gauss upwind / Gauss linearUpwind grad(U) (fy_case_desc.convection_scheme = 1 / 2): HIP path vs oracle, coupled steps
+    at a cell Peclet number of ~30"""
     n = 16
     dx = 0.1 / n
     kw = dict(g=(0, 0, -9.81), p_bc=[2] * 6) if solver == 1 else cavity_bcs()
     u_val = [(0, 0, 0)] * 6
     u_val[YMAX] = (0.5, 0, 0)
     kw.setdefault("u_bc", [0] * 6); kw["u_val"] = u_val
-    o, s = both(product, oracle, solver, n, n, n, dx, 2e-4, 1e-4, convection_scheme=1, **kw)
+    o, s = both(product, oracle, solver, n, n, n, dx, 2e-4, 1e-4, convection_scheme=scheme, **kw)
     case = gc.Case("cplu", n, n, n, 0.1, gaussian=solver, np_=2000, seed=19, cluster=100, fast=10, vel_scale=0.05)
     for step in range(4):
         rec = gc.particle_records(case, step)

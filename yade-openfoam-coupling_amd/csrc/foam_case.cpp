@@ -296,7 +296,7 @@ int read_controls(fy_foam_case* c) {
         struct Want { const char* dict; const char* must; const char* alt; const char* forbid; };
         const Want wants[] = {{"ddtSchemes", "Euler", nullptr, nullptr},
                               {"gradSchemes", "linear", nullptr, "Limited"},
-                              {"divSchemes", "linear", "upwind", "inearUpwind"},     // Gauss linear | Gauss upwind; not linearUpwind, limitedLinear ...
+                              {"divSchemes", "linear", "upwind", "UpwindV"},         // Gauss linear | upwind | linearUpwind grad(U); not linearUpwindV, limitedLinear ...
                               {"laplacianSchemes", "linear", nullptr, nullptr},
                               {"interpolationSchemes", "linear", nullptr, "pwind"},
                               {"snGradSchemes", "corrected", "orthogonal", nullptr}};   // corrected == uncorrected == orthogonal on this mesh
@@ -312,10 +312,11 @@ int read_controls(fy_foam_case* c) {
                 const bool ok = (joined.find(w.must) != std::string::npos || (w.alt && joined.find(w.alt) != std::string::npos) || joined.find("none") == 0) &&
                                 !(w.forbid && joined.find(w.forbid) != std::string::npos) && joined.find("limited") == std::string::npos &&
                                 joined.find("vanLeer") == std::string::npos && joined.find("QUICK") == std::string::npos;
-                if (!ok) return fail(FY_ERR_UNSUPPORTED, "%s: %s.%s = '%s' is not supported (Euler; Gauss linear, and Gauss upwind for div(phi,U), only)", path.c_str(), w.dict, k.c_str(), joined.c_str());
+                if (!ok) return fail(FY_ERR_UNSUPPORTED, "%s: %s.%s = '%s' is not supported (Euler; Gauss linear; div(phi,U) Gauss linear | upwind | linearUpwind)", path.c_str(), w.dict, k.c_str(), joined.c_str());
                 if (std::string(w.dict) == "divSchemes" && joined.find("none") != 0) {
-                    const int sch = joined.find("upwind") != std::string::npos ? FY_CONVECTION_UPWIND : FY_CONVECTION_LINEAR;
-                    if (n_div++ && sch != c->desc.convection_scheme) return fail(FY_ERR_UNSUPPORTED, "%s: divSchemes mixes linear and upwind entries", path.c_str());
+                    const int sch = joined.find("inearUpwind") != std::string::npos ? FY_CONVECTION_LINEAR_UPWIND
+                                  : joined.find("upwind") != std::string::npos ? FY_CONVECTION_UPWIND : FY_CONVECTION_LINEAR;
+                    if (n_div++ && sch != c->desc.convection_scheme) return fail(FY_ERR_UNSUPPORTED, "%s: divSchemes mixes different convection schemes", path.c_str());
                     c->desc.convection_scheme = sch;
                 }
             }

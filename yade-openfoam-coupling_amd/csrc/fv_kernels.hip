@@ -356,7 +356,8 @@ __global__ __launch_bounds__(256) void k_div_G(FvGeo g, const double* __restrict
 __global__ __launch_bounds__(256) void k_assemble_momentum(FvGeo g, const double* __restrict__ U, const double* __restrict__ Uold,
                                                            const double* __restrict__ alpha, const double* __restrict__ alphaOld, CFace3 alphaf,
                                                            CFace3 phi, const double* __restrict__ uSource, const double* __restrict__ uSourceDrag,
-                                                           const double* __restrict__ divG, Mom7 M, double* __restrict__ src, double* __restrict__ rAU) {
+                                                           const double* __restrict__ divG, const double* __restrict__ vGrad, Mom7 M,
+                                                           double* __restrict__ src, double* __restrict__ rAU) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= g.Nc) return;
     int i, j, k; ijk_of(g, t, i, j, k);
@@ -393,6 +394,13 @@ __global__ __launch_bounds__(256) void k_assemble_momentum(FvGeo g, const double
                 const double cP = g.upwind ? fmax(phio, 0.0) : 0.5 * phio, cN = g.upwind ? fmin(phio, 0.0) : 0.5 * phio;
                 dg += cP + gam;
                 an[2 * d + s] = cN - gam;
+                if (g.upwind == 2) {
+                    // linearUpwind: implicit upwind + explicit (C_f - C_upwind) . grad(U)_upwind with the current Gauss-linear gradient
+                    const int nb = c + (s ? stride_of(g, d) : -stride_of(g, d));
+                    const int uw = phio > 0.0 ? c : nb;
+                    const double half = (phio > 0.0 ? (s ? 0.5 : -0.5) : (s ? -0.5 : 0.5)) * g.dx;
+                    for (int q = 0; q < 3; ++q) s3[q] -= phio * (half * vGrad[9 * (size_t)uw + 3 * d + q]);
+                }
             }
         }
     if (pim) {
@@ -1064,10 +1072,10 @@ int launch_div_G(hipStream_t s, FvGeo g, const double* G, double* divG) {
 }
 
 int launch_assemble_momentum(hipStream_t s, FvGeo g, const double* U, const double* Uold, const double* alpha, const double* alphaOld,
-                             CFace3 alphaf, CFace3 phi, const double* uSource, const double* uSourceDrag, const double* divG, Mom7 M,
-                             double* src, double* rAU) {
+                             CFace3 alphaf, CFace3 phi, const double* uSource, const double* uSourceDrag, const double* divG, const double* vGrad,
+                             Mom7 M, double* src, double* rAU) {
     hipLaunchKernelGGL(k_assemble_momentum, dim3(div_up(g.Nc, 256)), dim3(256), 0, s, g, U, Uold, alpha, alphaOld, alphaf, phi, uSource,
-                       uSourceDrag, divG, M, src, rAU);
+                       uSourceDrag, divG, vGrad, M, src, rAU);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }

@@ -24,7 +24,7 @@ struct FvGeo {
     int p_bc[6];            // FY_BC_P_*
     double p_val[6];
     int pimple;
-    int upwind;             // div(phi,U): 0 Gauss linear, 1 Gauss upwind (first order, bounded)
+    int upwind;             // div(phi,U): 0 Gauss linear, 1 Gauss upwind (first order, bounded), 2 Gauss linearUpwind (upwind + explicit gradient correction)
     double dt, nu;
     double g[3];
     int need_ref, p_ref_cell;
@@ -65,7 +65,7 @@ int launch_stress_G(hipStream_t s, FvGeo g, const double* vGrad, const double* a
 int launch_div_G(hipStream_t s, FvGeo g, const double* G, double* divG);
 int launch_assemble_momentum(hipStream_t s, FvGeo g, const double* U, const double* Uold, const double* alpha, const double* alphaOld,
                              CFace3 alphaf, CFace3 phi, const double* uSource, const double* uSourceDrag, const double* divG,
-                             Mom7 M, double* src, double* rAU);
+                             const double* vGrad /* grad(U) of the current iterate: linearUpwind only */, Mom7 M, double* src, double* rAU);
 int launch_interp_rAU(hipStream_t s, FvGeo g, const double* rAU, Face3 rAUf);
 int launch_phi_forces(hipStream_t s, FvGeo g, const double* rAU, CFace3 rAUf, const double* uSource, Face3 phiForces);
 int launch_bmom(hipStream_t s, FvGeo g, const double* src, const double* p, CFace3 psn, CFace3 phiForces, CFace3 rAUf, double* bmom);

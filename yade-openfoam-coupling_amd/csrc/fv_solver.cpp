@@ -104,7 +104,7 @@ struct Solver {
     int halo_level(MgLev& L, double* x) { return L.distributed ? halo(x, 1, L.plane, L.A.nz, L.gz, 1) : FY_OK; }
 
     int create(const fy_case_desc* c, const fy_transport* tr, int dev, Comm* cm) {
-        if (c && c->convection_scheme != FY_CONVECTION_LINEAR && c->convection_scheme != FY_CONVECTION_UPWIND) return fail(FY_ERR_INVALID, "fy_solver_create: unknown convection_scheme");
+        if (c && (c->convection_scheme < FY_CONVECTION_LINEAR || c->convection_scheme > FY_CONVECTION_LINEAR_UPWIND)) return fail(FY_ERR_INVALID, "fy_solver_create: unknown convection_scheme");
         if (!c || c->nx <= 0 || c->ny <= 0 || c->nz <= 0 || !(c->dx > 0) || !(c->dt > 0)) return fail(FY_ERR_INVALID, "fy_solver_create: bad case");
         int ndev = 0;
         if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(FY_ERR_NO_DEVICE, "no HIP device visible: libfoamyade_hip has no CPU path");
@@ -131,7 +131,7 @@ struct Solver {
         Nglob = (int64_t)plane * c->nz;
         g.nx = c->nx; g.ny = c->ny; g.nz = nzl; g.Nc = Nc; g.gz = gz; g.c0 = (int)(plane * gz); g.kglob0 = comm->rank * nzl; g.nzglob = c->nz;
         g.dx = c->dx; g.Af = c->dx * c->dx; g.V = c->dx * c->dx * c->dx;
-        g.upwind = c->convection_scheme == FY_CONVECTION_UPWIND ? 1 : 0;
+        g.upwind = c->convection_scheme;          // 0 linear, 1 upwind, 2 linearUpwind
         g.rdx = 1.0 / g.dx; g.rhdx = 1.0 / (0.5 * g.dx); g.rV = 1.0 / g.V;
         g.pimple = pimple ? 1 : 0; g.dt = c->dt; g.nu = c->nu;
         bool need_ref = true;
@@ -530,12 +530,13 @@ struct Solver {
             if (pimple) {
                 // explicit stress term of divDevRhoReff from the CURRENT U and this step's alpha (one fused stencil pass)
                 if (outer > 0) FY_TRY(halo_cells(U, 3, 1));
-                FY_TRY(launch_pre_coupling(stream, g, U.p, p.p, alpha.p, C3(psn), vGrad.p, gradP.p, divT.p, Gt.p, 0, 0));
+                FY_TRY(launch_pre_coupling(stream, g, U.p, p.p, alpha.p, C3(psn), vGrad.p, gradP.p, divT.p, Gt.p, g.upwind == 2 ? 1 : 0, 0));
                 FY_TRY(halo_cells(Gt, 9, 1));
                 FY_TRY(launch_div_G(stream, g, Gt.p, divG.p));
             }
+            if (g.upwind == 2) FY_TRY(halo_cells(vGrad, 9, 1));      // linearUpwind reads grad(U) of the upwind neighbour (ico: written at step start)
             FY_TRY(launch_assemble_momentum(stream, g, U.p, Uold.p, alpha.p, alphaOld.p, C3(alphaf), C3(phi), uSource.p, uSourceDrag.p,
-                                            divG.p, M7(), src.p, rAU.p));
+                                            divG.p, vGrad.p, M7(), src.p, rAU.p));
             if (pimple) {
                 FY_TRY(halo_cells(rAU, 1, 1));
                 FY_TRY(launch_interp_rAU(stream, g, rAU.p, F3(rAUf)));
