@@ -144,6 +144,10 @@ int fy_read_field_host(fy_ctx*, const char* name, double* out);
 int fy_write_field_host(fy_ctx*, const char* name, const double* in);
 double fy_yade_dt(fy_ctx*);           /* yadeDT received in exchangeDT (FoamYade.C:537-553) */
 double fy_interp_range(fy_ctx*);      /* interpRange = 4*cbrt(V[0]) (FoamYade.C:69) */
+/* Gaussian locate on a uniform block: how many particles of the last fy_set_particle_action were NOT placed through the per-(cell,
+ * octant) candidate lists and took the plain tree walk instead (within 8e-6 dx of a cell face, outside the block, list overflow);
+ * -1 when the lists are not in use (explicit tree, FOAMYADE_NO_LOCATE_LISTS, no memory).  Same results either way. */
+long long fy_locate_walk_count(fy_ctx*);
 
 /* per-phase device timings of the last fy_set_particle_action, milliseconds (HIP events on the ctx stream) */
 typedef struct fy_particle_timings {

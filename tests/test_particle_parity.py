@@ -164,6 +164,8 @@ def test_against_oracle_seeded(product, oracle, dims, npart, gaussian):
     for nm in ("alpha", "uSource") + (("uSourceDrag", "uParticle") if gaussian else ()):
         assert_close(mut[nm], omut[nm], gu.RTOL_GPU, nm)
     assert np.array_equal(mut["alpha"] == 0.1, omut["alpha"] == 0.1)
+    if gaussian:      # the candidate lists did the work: only the 500 particles outside the block (and the odd one on a face) were walked
+        assert 0 <= fy.locate_walk_count <= 600, fy.locate_walk_count
     fy.close()
 
 
@@ -200,4 +202,41 @@ def test_locate_on_lattice_positions(product, oracle, dims):
     assert np.array_equal(k, ref["k"])
     assert np.array_equal(ids, ref["ids"])
     assert (k > 0).sum() > 0.9 * n and (k == 0).sum() > 0
+    assert fy.locate_walk_count > 0.3 * n          # on-face queries are the walk's (k_locate_lists hands them over)
+    fy.close()
+
+
+@pytest.mark.parametrize("dims,origin", [((40, 40, 40), (0.0, 0.0, 0.0)), ((37, 52, 21), (-3.3, 12.7, 0.4)), ((12, 9, 7), (0.1, 0.1, 0.1))])
+def test_locate_lists_equal_the_walk(product, oracle, dims, origin):
+    """k_locate_lists scans a per-(cell, octant) candidate list instead of walking the tree.  Queries spread over the cells, and bands
+    that straddle what decides its path -- the 8e-6 dx hand-over distance from a face, the octant planes through the cell centre
+    (+-1e-13 .. 1e-3 dx and exactly on them) -- must give the oracle's chains bit for bit, whichever kernel took them."""
+    nx, ny, nz = dims
+    c = gc.Case("lists", nx, ny, nz, 0.2, origin=origin, gaussian=1, np_=10, seed=5)
+    rng = np.random.default_rng(321)
+    n = 80000
+    ijk = np.stack([rng.integers(0, nx, n), rng.integers(0, ny, n), rng.integers(0, nz, n)], axis=1).astype(np.float64)
+    t = rng.random((n, 3))
+    band = rng.choice([1e-13, 1e-9, 1e-6, 4e-6, 7.9e-6, 8.1e-6, 1.6e-5, 1e-4, 1e-3], size=(n, 3)) * rng.choice([-1.0, 1.0], size=(n, 3))
+    kind = rng.integers(0, 4, size=(n, 3))                     # 0/1: anywhere, 2: next to a face, 3: next to the centre plane
+    t = np.where(kind == 2, np.where(band > 0, band, 1.0 + band), t)
+    t = np.where(kind == 3, 0.5 + band * (rng.random((n, 3)) < 0.9), t)
+    pos = np.asarray(c.origin) + (ijk + t) * c.dx
+    rec = np.zeros((n, 10))
+    rec[:, 0:3] = pos
+    rec[:, 3:6] = rng.normal(0, 0.05, (n, 3))
+    rec[:, 9] = 0.02 * c.dx
+    fields = gc.fluid_fields(c)
+    mesh, fy = make_engine(product, c, fields, seeded_mutable(c.ncells))
+    om = oracle.Mesh(nx, ny, nz, c.dx, c.origin)
+    ref = oracle.particle_action(om, fields, oracle.fresh_mutable(c.ncells), rec, np.array([0, n], np.int32), 1, c.rhoP, c.rhoF, c.nu, threads=8)
+    fy.setParticles([rec])
+    fy.setParticleAction(c.dt)
+    k, ids, w, chain = fy.stencils(0)
+    assert np.array_equal(chain, ref["chain_len"])
+    assert np.array_equal(k, ref["k"])
+    assert np.array_equal(ids, ref["ids"])
+    assert_close(w, ref["w"], gu.RTOL_GPU, "weights")
+    walked = fy.locate_walk_count
+    assert 0.05 * n < walked < 0.6 * n, walked            # both kernels took a share
     fy.close()

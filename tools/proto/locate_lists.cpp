@@ -1,0 +1,165 @@
+// Prototype (host): per-(cell, octant) candidate lists for the k-d "range" locate, checked against the plain walk.
+//   g++ -O2 -std=c++17 -I../../yade-openfoam-coupling_amd/csrc locate_lists.cpp ../../yade-openfoam-coupling_amd/csrc/kdtree.cpp -o /tmp/locate_lists -lpthread
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <vector>
+#include "kdtree.hpp"
+using namespace fy;
+
+static int NX, NY, NZ; static double OX, OY, OZ, DX;
+static std::vector<uint32_t> packed;
+struct Pair { int id; double d; };
+
+static std::vector<Pair> walk(double qx, double qy, double qz, double maxdist, int* visits) {
+    std::vector<Pair> chain; const double hdx = 0.5 * DX;
+    struct E { uint32_t o, n, axis; int idx; };
+    std::vector<E> st;
+    uint32_t o = 0, nn = (uint32_t)packed.size(), axis = 0;
+    double best;
+    { uint32_t pk = packed[0]; int ci = pk & 1023, cj = (pk >> 10) & 1023, ck = pk >> 20;
+      double a = qx - (OX + (double)(2 * ci + 1) * hdx), b = qy - (OY + (double)(2 * cj + 1) * hdx), c = qz - (OZ + (double)(2 * ck + 1) * hdx);
+      best = a * a; best += b * b; best += c * c; }
+    for (;;) {
+        if (nn == 0) {
+            if (st.empty()) break;
+            E e = st.back(); st.pop_back();
+            uint32_t pa = e.axis == 0 ? 2 : e.axis - 1;
+            double org = pa == 0 ? OX : pa == 1 ? OY : OZ, qq = pa == 0 ? qx : pa == 1 ? qy : qz;
+            double df = (org + (double)(2 * e.idx + 1) * hdx) - qq;
+            if (df * df < best) { o = e.o; nn = e.n; axis = e.axis; }
+            continue;
+        }
+        ++*visits;
+        uint32_t pk = packed[o]; int ci = pk & 1023, cj = (pk >> 10) & 1023, ck = pk >> 20;
+        double a = qx - (OX + (double)(2 * ci + 1) * hdx), b = qy - (OY + (double)(2 * cj + 1) * hdx), c = qz - (OZ + (double)(2 * ck + 1) * hdx);
+        double d = a * a; d += b * b; d += c * c;
+        if (d < best) { best = d; if (d < maxdist && o != 0) chain.push_back({ci + NX * (cj + NY * ck), d}); }
+        double mdf = axis == 0 ? a : axis == 1 ? b : c, df2 = mdf * mdf;
+        uint32_t nl = nn >> 1, nr = nn - nl - 1, near_o, near_n, far_o, far_n;
+        if (mdf < 0) { near_o = o + 1; near_n = nl; far_o = o + 1 + nl; far_n = nr; } else { near_o = o + 1 + nl; near_n = nr; far_o = o + 1; far_n = nl; }
+        int idx = axis == 0 ? ci : axis == 1 ? cj : ck;
+        axis = axis == 2 ? 0 : axis + 1;
+        if (far_n > 0 && df2 < best) st.push_back({far_o, far_n, axis, idx});
+        o = near_o; nn = near_n;
+    }
+    return chain;
+}
+
+// ---- list builder, lattice units (cell centre of index i at coordinate i)
+constexpr double EPS = 1e-6, MARGIN = 1e-9;
+struct Box { double lo[3], hi[3]; };
+struct Cand { int x[3]; bool noemit; };
+static inline double ax_min2(double lo, double hi, double x) { double g = x < lo ? lo - x : (x > hi ? x - hi : 0.0); return g * g; }
+static inline double ax_max2(double lo, double hi, double x) { double g = std::fmax(std::fabs(lo - x), std::fabs(hi - x)); return g * g; }
+// max over the box of d(Y,q) - d(X,q)
+static double maxdiff(const Box& B, const int* Y, const int* X) {
+    double s = 0;
+    for (int a = 0; a < 3; ++a) {
+        const double k = (double)(X[a] - Y[a]);                 // (q-Y)^2 - (q-X)^2 = (X-Y)(2q - X - Y)
+        const double f_lo = k * (2 * B.lo[a] - X[a] - Y[a]), f_hi = k * (2 * B.hi[a] - X[a] - Y[a]);
+        s += std::fmax(f_lo, f_hi);
+    }
+    return s;
+}
+// max over the box of d(Y,q) - (q_a - P)^2
+static double maxdiff_plane(const Box& B, const int* Y, int a, int P) {
+    double s = 0;
+    for (int b = 0; b < 3; ++b) {
+        if (b == a) { const double k = (double)(P - Y[a]); s += std::fmax(k * (2 * B.lo[a] - P - Y[a]), k * (2 * B.hi[a] - P - Y[a])); }
+        else s += ax_max2(B.lo[b], B.hi[b], Y[b]);
+    }
+    return s;
+}
+static long g_bvisits = 0;
+static void build_list(const int* c, int oct, double md, std::vector<Cand>& L) {
+    Box B;
+    for (int a = 0; a < 3; ++a) { if ((oct >> a) & 1) { B.lo[a] = c[a] - EPS; B.hi[a] = c[a] + 0.5 - EPS; } else { B.lo[a] = c[a] - 0.5 + EPS; B.hi[a] = c[a] + EPS; } }
+    struct E { uint32_t o, n, axis; int pa, P; };
+    std::vector<E> st;
+    uint32_t o = 0, nn = (uint32_t)packed.size(), axis = 0;
+    L.clear();
+    for (;;) {
+        if (nn == 0) {
+            if (st.empty()) break;
+            E e = st.back(); st.pop_back();
+            bool prune = ax_min2(B.lo[e.pa], B.hi[e.pa], e.P) >= md + MARGIN;
+            for (size_t y = 0; y < L.size() && !prune; ++y) prune = maxdiff_plane(B, L[y].x, e.pa, e.P) <= -MARGIN;
+            if (!prune) { o = e.o; nn = e.n; axis = e.axis; }
+            continue;
+        }
+        ++g_bvisits;
+        uint32_t pk = packed[o]; int X[3] = {(int)(pk & 1023), (int)((pk >> 10) & 1023), (int)(pk >> 20)};
+        double dmin = 0; for (int a = 0; a < 3; ++a) dmin += ax_min2(B.lo[a], B.hi[a], X[a]);
+        if (dmin < md + MARGIN) {
+            bool dom = false;
+            for (size_t y = 0; y < L.size() && !dom; ++y) dom = maxdiff(B, L[y].x, X) <= -MARGIN;
+            if (!dom) L.push_back({{X[0], X[1], X[2]}, o == 0});
+        }
+        bool left_near = X[axis] != c[axis] ? c[axis] < X[axis] : !((oct >> axis) & 1);
+        uint32_t nl = nn >> 1, nr = nn - nl - 1, near_o, near_n, far_o, far_n;
+        if (left_near) { near_o = o + 1; near_n = nl; far_o = o + 1 + nl; far_n = nr; } else { near_o = o + 1 + nl; near_n = nr; far_o = o + 1; far_n = nl; }
+        const int pa = axis, P = X[axis];
+        axis = axis == 2 ? 0 : axis + 1;
+        if (far_n > 0) st.push_back({far_o, far_n, axis, pa, P});
+        o = near_o; nn = near_n;
+    }
+}
+static std::vector<Pair> scan(const std::vector<Cand>& L, double qx, double qy, double qz, double maxdist) {
+    std::vector<Pair> chain; const double hdx = 0.5 * DX; double best = 1e300;
+    for (const Cand& k : L) {
+        double a = qx - (OX + (double)(2 * k.x[0] + 1) * hdx), b = qy - (OY + (double)(2 * k.x[1] + 1) * hdx), c = qz - (OZ + (double)(2 * k.x[2] + 1) * hdx);
+        double d = a * a; d += b * b; d += c * c;
+        if (d < best) { best = d; if (d < maxdist && !k.noemit) chain.push_back({k.x[0] + NX * (k.x[1] + NY * k.x[2]), d}); }
+    }
+    return chain;
+}
+
+int main(int argc, char** argv) {
+    NX = argc > 1 ? atoi(argv[1]) : 40; NY = argc > 2 ? atoi(argv[2]) : NX; NZ = argc > 3 ? atoi(argv[3]) : NX;
+    const int ncellsample = argc > 4 ? atoi(argv[4]) : 2000, qper = 64;
+    DX = 0.1 / NX; OX = -0.013; OY = 0.21; OZ = 0.0; if (getenv("BIGO")) { OX = 1234.567; OY = -777.1; OZ = 99.9; }
+    const int n = NX * NY * NZ;
+    std::vector<double> cen(3 * (size_t)n);
+    for (int k = 0; k < NZ; ++k) for (int j = 0; j < NY; ++j) for (int i = 0; i < NX; ++i) { size_t c = i + NX * (j + (size_t)NY * k); cen[3 * c] = OX + (i + 0.5) * DX; cen[3 * c + 1] = OY + (j + 0.5) * DX; cen[3 * c + 2] = OZ + (k + 0.5) * DX; }
+    std::vector<KdNode> nodes; build_kdtree_preorder(cen.data(), n, nodes, 8);
+    packed.resize(n);
+    for (int q = 0; q < n; ++q) { int id = nodes[q].id; packed[q] = (uint32_t)(id % NX) | ((uint32_t)((id / NX) % NY) << 10) | ((uint32_t)(id / (NX * NY)) << 20); }
+    const double range = 4 * DX, maxdist = range * range + 0.25 * range * range, md = maxdist / (DX * DX);
+    std::mt19937_64 rng(7); std::uniform_real_distribution<double> U(0, 1);
+    long hist[64] = {0}, nlist = 0, bad = 0, nq = 0, wv = 0, maxlen = 0; double sumlen = 0, sumchain = 0;
+    std::vector<Cand> L;
+    for (int s = 0; s < ncellsample; ++s) {
+        int c[3] = {(int)(U(rng) * NX), (int)(U(rng) * NY), (int)(U(rng) * NZ)};
+        if (s % 4 == 0) for (int a = 0; a < 3; ++a) if (U(rng) < 0.5) c[a] = U(rng) < 0.5 ? 0 : (a == 0 ? NX : a == 1 ? NY : NZ) - 1;   // boundary cells too
+        for (int oct = 0; oct < 8; ++oct) {
+            build_list(c, oct, md, L);
+            ++nlist; sumlen += L.size(); hist[std::min<size_t>(L.size(), 63)]++; if ((long)L.size() > maxlen) maxlen = L.size();
+            for (int t = 0; t < qper; ++t) {
+                double q[3];
+                for (int a = 0; a < 3; ++a) {
+                    double f = U(rng) * (0.5 - 4e-6) + 2e-6;          // inside the shrunk half
+                    if (t < 8) f = (t & 1) ? 2.0e-6 : 0.5 - 2.0e-6;                      // extremes
+                    const double org = a == 0 ? OX : a == 1 ? OY : OZ;
+                    q[a] = ((oct >> a) & 1) ? org + (c[a] + 0.5 + f) * DX : org + (c[a] + 0.5 - f) * DX;
+                    if (t == 9) q[a] = org + (double)(2 * c[a] + 1) * (0.5 * DX);         // the centre itself
+                    // octant bit must agree with the exact compare
+                    const double cc = org + (double)(2 * c[a] + 1) * (0.5 * DX);
+                    const bool hi = !(q[a] - cc < 0);
+                    if (hi != (bool)((oct >> a) & 1)) { q[a] = cc + (((oct >> a) & 1) ? 1 : -1) * 1e-9 * DX; }
+                }
+                int v = 0;
+                auto A = walk(q[0], q[1], q[2], maxdist, &v), Bc = scan(L, q[0], q[1], q[2], maxdist);
+                wv += v; ++nq; sumchain += A.size();
+                bool same = A.size() == Bc.size();
+                for (size_t k = 0; same && k < A.size(); ++k) same = A[k].id == Bc[k].id && A[k].d == Bc[k].d;
+                if (!same) { if (bad < 5) { printf("MISMATCH cell %d %d %d oct %d: walk %zu list %zu (L=%zu)\n", c[0], c[1], c[2], oct, A.size(), Bc.size(), L.size()); } ++bad; }
+            }
+        }
+    }
+    printf("%dx%dx%d: lists %ld, mean len %.2f, max %ld; builder visits/list %.1f; walk visits/query %.1f, mean chain %.2f; queries %ld, mismatches %ld\n", NX, NY, NZ, nlist, sumlen / nlist, maxlen,
+           (double)g_bvisits / nlist, (double)wv / nq, sumchain / nq, nq, bad);
+    for (int k = 0; k < 64; ++k) if (hist[k]) printf("  len %2d: %ld\n", k, hist[k]);
+    return bad != 0;
+}

@@ -142,6 +142,8 @@ def lib():
     L.fy_yade_dt.restype = C.c_double
     L.fy_interp_range.argtypes = [vp]
     L.fy_interp_range.restype = C.c_double
+    L.fy_locate_walk_count.argtypes = [vp]
+    L.fy_locate_walk_count.restype = C.c_longlong
     L.fy_get_particle_timings.argtypes = [vp, C.POINTER(ParticleTimings)]
     L.fy_enable_timing.argtypes = [vp, C.c_int]
     L.fy_case_defaults.argtypes = [C.POINTER(CaseDesc), C.c_int]
@@ -349,6 +351,11 @@ class FoamYade:
     @property
     def interpRange(self):
         return lib().fy_interp_range(self._h)
+
+    @property
+    def locate_walk_count(self):
+        """particles of the last step's (last batch's) Gaussian locate that took the tree walk instead of the candidate lists; -1: lists not in use"""
+        return lib().fy_locate_walk_count(self._h)
 
     def close(self):
         if self._h:

@@ -415,8 +415,25 @@ int Coupling::run_batch(Batch& b) {
             FY_TRY(d_loc_start.alloc_exact((size_t)n_cells));
             FY_TRY(launch_build_locate_start(stream, d_tree_packed.p, implicit, n_cells, gp.maxdist, d_loc_start.p));
         }
+        // candidate lists: 384 B per cell; valid while the rounding of a coordinate stays far below the builder's margins
+        static const bool no_lists = getenv("FOAMYADE_NO_LOCATE_LISTS") != nullptr;      // A/B switch
+        if (use_implicit && !no_lists && !loc_lists_tried) {
+            loc_lists_tried = true;
+            const double ext = std::max({std::fabs(implicit.ox), std::fabs(implicit.oy), std::fabs(implicit.oz), std::fabs(implicit.ox + implicit.nx * implicit.dx),
+                                         std::fabs(implicit.oy + implicit.ny * implicit.dx), std::fabs(implicit.oz + implicit.nz * implicit.dx)});
+            if (ext / implicit.dx <= 1e6 && d_loc_lists.alloc_exact((size_t)n_cells * 8 * kLocateListLen) == FY_OK && d_loc_fb_n.alloc_exact(1) == FY_OK) {
+                FY_TRY(launch_build_locate_lists(stream, d_tree_packed.p, implicit, n_cells, gp.maxdist, d_loc_lists.p));
+            } else {
+                d_loc_lists.release();               // not enough memory (or far-from-origin coordinates): the walk does all particles
+            }
+        }
+        LocateLists ll{};
+        if (use_implicit && d_loc_lists.p) {
+            if (d_loc_fb.n < (size_t)b.n) FY_TRY(d_loc_fb.alloc_exact((size_t)b.n + (size_t)b.n / 8));
+            ll = LocateLists{d_loc_lists.p, d_loc_fb.p, d_loc_fb_n.p};
+        }
         FY_TRY(launch_locate(stream, d_tree.p, use_implicit ? d_tree_packed.p : nullptr, implicit, n_cells, tree_levels, p, b.n, gp,
-                             use_implicit ? d_loc_start.p : nullptr, slab_own()));
+                             use_implicit ? d_loc_start.p : nullptr, slab_own(), ll));
         if (timing) { timers[T_LOCATE].stop(stream); timers[T_FINALIZE].start(stream); }
         const CellWindow cw{slab.active ? slab.base : 0, n_field};
         FY_TRY(launch_deposit(stream, p, b.n, gp, cw, d_pvol_acc.p, d_up_acc.p, d_touched.p));
@@ -791,6 +808,12 @@ int fy_read_field_host(fy_ctx* c, const char* name, double* out) { FY_CTX(c); re
 int fy_write_field_host(fy_ctx* c, const char* name, const double* in) { FY_CTX(c); return c->c.write_field_host(name, in); }
 double fy_yade_dt(fy_ctx* c) { return c ? c->c.yade_dt : 0.0; }
 double fy_interp_range(fy_ctx* c) { return c ? c->c.interp_range : 0.0; }
+long long fy_locate_walk_count(fy_ctx* c) {
+    if (!c || !c->c.d_loc_lists.p || !c->c.d_loc_fb_n.p) return -1;
+    unsigned int n = 0;
+    if (hipStreamSynchronize(c->c.stream) != hipSuccess || hipMemcpy(&n, c->c.d_loc_fb_n.p, sizeof(n), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return (long long)n;
+}
 int fy_get_particle_timings(fy_ctx* c, fy_particle_timings* out) { FY_CTX(c); if (!out) return fy::fail(FY_ERR_INVALID, "null out"); *out = c->c.tm; return FY_OK; }
 int fy_enable_timing(fy_ctx* c, int on) { FY_CTX(c); c->c.timing = on != 0; return FY_OK; }
 

@@ -69,6 +69,10 @@ struct Coupling {
     DevBuf<KdNode> d_tree;
     DevBuf<uint32_t> d_tree_packed;      // implicit-coordinate nodes, only when the block's centres are exactly o + (i+0.5)*dx
     DevBuf<unsigned long long> d_loc_start;   // per-cell traversal start (implicit trees; launch_build_locate_start), built at the first Gaussian step
+    DevBuf<unsigned short> d_loc_lists;       // per-(cell, octant) candidate lists (implicit trees; launch_build_locate_lists), built with it
+    DevBuf<int32_t> d_loc_fb;                 // particles the lists do not cover (work list of the walk) + their count
+    DevBuf<unsigned int> d_loc_fb_n;
+    bool loc_lists_tried = false;
     ImplicitGeom implicit{};
     bool use_implicit = false;
     int tree_levels = 0;

@@ -216,17 +216,189 @@ __global__ __launch_bounds__(256) void k_build_locate_start(const uint32_t* __re
     start[c] = (unsigned long long)o | ((unsigned long long)nn << 25) | ((unsigned long long)axis << 50);
 }
 
+// ------------------------------------------------------------------------------------------------ candidate lists
+// What the walk below produces is, exactly, the sequence of strict running minima of d(node, q) over the tree's nodes in near-first
+// DFS order, kept where d < maxdist (meshTree.C:192-196): a far side is skipped only when df2 >= best (meshTree.C:225), every node
+// behind it has d >= df2 in floating point too (the squared axis term is one of d's three non-negative addends and rounding is
+// monotone), so a skipped subtree holds no improvement.  On the lattice that order is a function of (cell, octant) alone: the side
+// taken at an ancestor whose lattice index on its split axis differs from the query cell's is decided by the cell, and where the
+// index is the same the ancestor's coordinate IS the cell centre's (same expression, same bits), so the side is the octant bit
+// `!(q - centre < 0)`.  Hence, per (cell, octant), ONE list of the nodes that can be a running minimum for some q of that octant, in
+// DFS order; a particle evaluates d for ~7 listed nodes with the reference's operations instead of walking ~38 tree nodes with a
+// stack.  k_build_locate_lists simulates the walk over the octant box B:
+//   * a node enters the list unless it is outside the range for every q in B, or an earlier listed node Y is closer for every q in B
+//     (d(Y,q) - d(X,q) is linear in q: its maximum over B is a sum of per-axis endpoint values).  A node left out this way never
+//     lowers the running minimum below what Y already did and is never pushed, so the scan's `best` and chain are the walk's;
+//   * a far side is skipped when it is out of range for all of B or some listed Y has d(Y,q) <= (q_a - plane)^2 on all of B -- a
+//     superset of what the reference visits for any single q; extra nodes have d >= best and change nothing.
+// All comparisons carry a margin (kListMargin, lattice units^2) far above the rounding of d (<= 1e-9 for |coordinate| / dx <= 1e6,
+// enforced by the caller), and B is the half cell shrunk by kListEps at the faces: particles closer than 2 kListEps dx to a cell face
+// (where floor() and the nearest centre may disagree by an ulp), outside the block, or in an octant whose list overflowed, are
+// handed to the plain walk (k_locate with a work list).  The root is listed with a no-emit flag (it sets `best` but is never pushed,
+// meshTree.C:156).  Verified against the walk on every golden case and by tools/proto/locate_lists.cpp (host prototype).
+constexpr int kListLen = kLocateListLen;              // 24 codes per (cell, octant): 48 B = three 16-byte loads
+constexpr double kListEps = 4e-6, kListMargin = 1e-8;
+constexpr uint32_t kListEnd = 0xffffu, kListOverflow = 0xfffeu, kListNoEmit = 0x1000u;
+
+__device__ __forceinline__ double ax_min2(double lo, double hi, double x) { const double g = x < lo ? lo - x : (x > hi ? x - hi : 0.0); return g * g; }
+__device__ __forceinline__ double ax_max2(double lo, double hi, double x) { const double g = fmax(fabs(lo - x), fabs(hi - x)); return g * g; }
+
+__global__ __launch_bounds__(256) void k_build_locate_lists(const uint32_t* __restrict__ packed, ImplicitGeom ig, int32_t n_cells, double md,
+                                                            unsigned short* __restrict__ lists) {
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (size_t)n_cells * 8) return;
+    const int cell = (int)(t >> 3), oct = (int)(t & 7);
+    const int c[3] = {cell % ig.nx, (cell / ig.nx) % ig.ny, cell / (ig.nx * ig.ny)};
+    double lo[3], hi[3];
+    for (int a = 0; a < 3; ++a) {
+        if ((oct >> a) & 1) { lo[a] = c[a] - kListEps; hi[a] = c[a] + 0.5 - kListEps; }
+        else { lo[a] = c[a] - 0.5 + kListEps; hi[a] = c[a] + kListEps; }
+    }
+    unsigned long long st[28];                       // offset | size << 25 | axis << 50 | parent index on its split axis << 52
+    uint32_t kept[kListLen];
+    int nk = 0, sp = 0;
+    bool overflow = false;
+    uint32_t o = 0, nn = (uint32_t)n_cells, axis = 0;
+    for (;;) {
+        if (nn == 0) {
+            if (sp == 0) break;
+            const unsigned long long e = st[--sp];
+            const uint32_t ea = (uint32_t)((e >> 50) & 3ull), pa = (ea == 0 ? 2u : ea - 1u);
+            const int P = (int)(e >> 52);
+            bool prune = ax_min2(lo[pa], hi[pa], (double)P) >= md + kListMargin;
+            for (int y = 0; y < nk && !prune; ++y) {
+                const int Y[3] = {(int)(kept[y] & 1023u), (int)((kept[y] >> 10) & 1023u), (int)(kept[y] >> 20)};
+                double sdiff = 0.0;                  // max over B of d(Y,q) - (q_pa - P)^2
+                for (int b = 0; b < 3; ++b) {
+                    if (b == (int)pa) { const double k = (double)(P - Y[b]); sdiff += fmax(k * (2 * lo[b] - P - Y[b]), k * (2 * hi[b] - P - Y[b])); }
+                    else sdiff += ax_max2(lo[b], hi[b], (double)Y[b]);
+                }
+                prune = sdiff <= -kListMargin;
+            }
+            if (!prune) { o = (uint32_t)(e & 0x1ffffffull); nn = (uint32_t)((e >> 25) & 0x1ffffffull); axis = ea; }
+            continue;
+        }
+        const uint32_t pk = packed[o];
+        const int X[3] = {(int)(pk & 1023u), (int)((pk >> 10) & 1023u), (int)(pk >> 20)};
+        double dmin = 0.0;
+        for (int a = 0; a < 3; ++a) dmin += ax_min2(lo[a], hi[a], (double)X[a]);
+        if (dmin < md + kListMargin) {
+            bool dom = false;
+            for (int y = 0; y < nk && !dom; ++y) {
+                const int Y[3] = {(int)(kept[y] & 1023u), (int)((kept[y] >> 10) & 1023u), (int)(kept[y] >> 20)};
+                double sdiff = 0.0;                  // max over B of d(Y,q) - d(X,q); per axis (q-Y)^2 - (q-X)^2 = (X-Y)(2q - X - Y)
+                for (int a = 0; a < 3; ++a) {
+                    const double k = (double)(X[a] - Y[a]);
+                    sdiff += fmax(k * (2 * lo[a] - X[a] - Y[a]), k * (2 * hi[a] - X[a] - Y[a]));
+                }
+                dom = sdiff <= -kListMargin;
+            }
+            if (!dom) {
+                if (nk < kListLen) {
+                    const int di = X[0] - c[0] + 8, dj = X[1] - c[1] + 8, dk = X[2] - c[2] + 8;
+                    if ((unsigned)di > 15u || (unsigned)dj > 15u || (unsigned)dk > 15u) overflow = true;      // cannot happen for a range < 7.5 cells
+                    kept[nk] = pk;
+                    lists[t * kListLen + nk] = (unsigned short)((uint32_t)di | ((uint32_t)dj << 4) | ((uint32_t)dk << 8) | (o == 0 ? kListNoEmit : 0u));
+                    ++nk;
+                } else {
+                    overflow = true;
+                }
+            }
+        }
+        const bool left_near = X[axis] != c[axis] ? c[axis] < X[axis] : !((oct >> axis) & 1);
+        const uint32_t nl = nn >> 1, nr = nn - nl - 1u;
+        uint32_t near_o, near_n, far_o, far_n;
+        if (left_near) { near_o = o + 1u; near_n = nl; far_o = o + 1u + nl; far_n = nr; }
+        else           { near_o = o + 1u + nl; near_n = nr; far_o = o + 1u; far_n = nl; }
+        const unsigned long long P = (unsigned long long)X[axis];
+        axis = (axis == 2u ? 0u : axis + 1u);
+        if (far_n > 0 && sp < 28) st[sp++] = (unsigned long long)far_o | ((unsigned long long)far_n << 25) | ((unsigned long long)axis << 50) | (P << 52);
+        else if (far_n > 0) overflow = true;
+        o = near_o; nn = near_n;
+    }
+    if (nk < kListLen) lists[t * kListLen + nk] = (unsigned short)kListEnd;
+    if (overflow) lists[t * kListLen] = (unsigned short)kListOverflow;
+}
+
+// one lane per particle; particles the lists do not cover are appended to (fb_list, fb_count) for the walk
+__global__ __launch_bounds__(256) void k_locate_lists(const unsigned short* __restrict__ lists, ImplicitGeom ig, ParticleSoA p, int64_t n, double maxdist,
+                                                      SlabOwn own, int32_t* __restrict__ fb_list, unsigned int* __restrict__ fb_count) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double qx = p.px[i], qy = p.py[i], qz = p.pz[i];
+    if (own.active) {                                    // another slab's particle: not located here (k = 0)
+        int kz = (int)floor((qz - own.oz) / own.dx);
+        kz = min(max(kz, 0), own.nzglob - 1);
+        if (!(qz == qz) || kz < own.k0 || kz >= own.k1) { p.chain_len[i] = 0; return; }
+    }
+    const double hdx = 0.5 * ig.dx;
+    const double sx = (qx - ig.ox) / ig.dx, sy = (qy - ig.oy) / ig.dx, sz = (qz - ig.oz) / ig.dx;
+    const double fx = floor(sx), fy_ = floor(sy), fz = floor(sz);
+    const double tx = sx - fx, ty = sy - fy_, tz = sz - fz;
+    const double tlo = 2 * kListEps, thi = 1.0 - 2 * kListEps;
+    bool ok = fx >= 0 && fx < ig.nx && fy_ >= 0 && fy_ < ig.ny && fz >= 0 && fz < ig.nz &&
+              tx >= tlo && tx <= thi && ty >= tlo && ty <= thi && tz >= tlo && tz <= thi;      // (false for NaN)
+    const int ci = (int)fx, cj = (int)fy_, ck = (int)fz;
+    const uint4* row = nullptr;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (ok) {
+        const double cx = ig.ox + (double)(2 * ci + 1) * hdx, cy = ig.oy + (double)(2 * cj + 1) * hdx, cz = ig.oz + (double)(2 * ck + 1) * hdx;
+        const int oct = (qx - cx < 0.0 ? 0 : 1) | (qy - cy < 0.0 ? 0 : 2) | (qz - cz < 0.0 ? 0 : 4);
+        const size_t cell = (size_t)ci + (size_t)ig.nx * ((size_t)cj + (size_t)ig.ny * (size_t)ck);
+        row = reinterpret_cast<const uint4*>(lists + (cell * 8 + (size_t)oct) * kListLen);
+        v = row[0];
+        ok = (v.x & 0xffffu) != kListOverflow;
+    }
+    if (!ok) {
+        const unsigned int at = atomicAdd(fb_count, 1u);
+        fb_list[at] = (int32_t)i;
+        return;
+    }
+    double best = 1e300;
+    int chain = 0;
+    for (int ch = 0; ch < kListLen / 8; ++ch) {
+        if (ch) v = row[ch];
+        const uint32_t wds[4] = {v.x, v.y, v.z, v.w};
+        bool done = false;
+#pragma unroll
+        for (int h = 0; h < 8; ++h) {
+            const uint32_t code = (wds[h >> 1] >> ((h & 1) * 16)) & 0xffffu;
+            if (code == kListEnd) { done = true; break; }
+            const int ni = ci + (int)(code & 15u) - 8, nj = cj + (int)((code >> 4) & 15u) - 8, nk = ck + (int)((code >> 8) & 15u) - 8;
+            const double a = qx - (ig.ox + (double)(2 * ni + 1) * hdx), b = qy - (ig.oy + (double)(2 * nj + 1) * hdx),
+                         c = qz - (ig.oz + (double)(2 * nk + 1) * hdx);
+            double d = a * a;                        // meshTree.C:54-64: dist += ds*ds over x, y, z
+            d += b * b;
+            d += c * c;
+            if (d < best) {                          // meshTree.C:192
+                best = d;
+                if (d < maxdist && !(code & kListNoEmit)) {       // meshTree.C:195; the root is never pushed (meshTree.C:156)
+                    const size_t slot = (size_t)(chain & (kMaxK - 1)) * p.cap + (size_t)i;
+                    p.ids[slot] = ni + ig.nx * (nj + ig.ny * nk);
+                    p.w[slot] = d;
+                    ++chain;
+                }
+            }
+        }
+        if (done) break;
+    }
+    p.chain_len[i] = chain;
+}
+
 template <bool IMPLICIT>
 __global__ __launch_bounds__(kWave) void k_locate(const KdNode* __restrict__ tree, const uint32_t* __restrict__ packed, ImplicitGeom ig,
                                                   int32_t n_cells, ParticleSoA p, int64_t n, double maxdist,
-                                                  const unsigned long long* __restrict__ start, SlabOwn own) {
+                                                  const unsigned long long* __restrict__ start, SlabOwn own,
+                                                  const int32_t* __restrict__ work, const unsigned int* __restrict__ work_n) {
     typedef typename StackEntry<IMPLICIT>::type entry_t;
     extern __shared__ __attribute__((aligned(16))) unsigned char stack_raw[];
     entry_t* stack = reinterpret_cast<entry_t*>(stack_raw);
 #define STK(sp_) stack[(sp_) * kWave + lane]
     const int lane = threadIdx.x;
-    const int64_t base = (int64_t)blockIdx.x * kLocPPB;
-    const int64_t end = (base + kLocPPB < n) ? base + kLocPPB : n;
+    // work list (k_locate_lists' leftovers): the waves share its entries evenly; otherwise a wave owns kLocPPB consecutive particles
+    int64_t base = (int64_t)blockIdx.x * kLocPPB, per = kLocPPB;
+    if (work) { n = (int64_t)*work_n; per = (n + gridDim.x - 1) / gridDim.x; base = (int64_t)blockIdx.x * per; }
+    const int64_t end = (base + per < n) ? base + per : n;
     int64_t next = base;                               // wave-uniform cursor into [base, end)
     const NodeVal root = fetch_node<IMPLICIT>(tree, packed, ig, 0u);
     const double hdx = 0.5 * ig.dx;
@@ -244,7 +416,7 @@ __global__ __launch_bounds__(kWave) void k_locate(const KdNode* __restrict__ tre
             const int rank = __popcll(idle & ((1ull << lane) - 1ull));
             const int64_t cand = next + rank;
             if (!active && cand < end) {
-                i = cand;
+                i = work ? (int64_t)work[cand] : cand;
                 qx = p.px[i]; qy = p.py[i]; qz = p.pz[i];
                 // meshTree.C:156: dist = distance(root->p, px); the root itself can never enter the queue (x < x is false)
                 const double a = qx - root.x, b = qy - root.y, c = qz - root.z;
@@ -813,14 +985,31 @@ int launch_build_locate_start(hipStream_t s, const uint32_t* packed, ImplicitGeo
 }
 
 int launch_locate(hipStream_t s, const KdNode* tree, const uint32_t* packed, ImplicitGeom ig, int32_t n_cells, int levels,
-                  ParticleSoA p, int64_t n, GaussParams gp, const unsigned long long* start, SlabOwn own) {
+                  ParticleSoA p, int64_t n, GaussParams gp, const unsigned long long* start, SlabOwn own, LocateLists ll) {
     if (n <= 0) return FY_OK;
     // implicit entries are 8 B (needs offsets and sizes < 2^26), explicit ones 16 B
     if (packed && n_cells >= (1 << 25)) return fail(FY_ERR_UNSUPPORTED, "implicit-coordinate tree limited to 2^25 cells");
     const size_t lds = (size_t)(levels + 1) * kWave * (packed ? sizeof(unsigned long long) : sizeof(uint4));
     const dim3 grid(div_up(n, kLocPPB));
-    if (packed) hipLaunchKernelGGL(k_locate<true>, grid, dim3(kWave), lds, s, tree, packed, ig, n_cells, p, n, gp.maxdist, start, own);
-    else hipLaunchKernelGGL(k_locate<false>, grid, dim3(kWave), lds, s, tree, packed, ig, n_cells, p, n, gp.maxdist, nullptr, own);
+    if (packed && ll.lists) {
+        // the lists place almost every particle; the walk below takes what is left (usually nothing: its waves read a zero count and exit)
+        FY_HIP(hipMemsetAsync(ll.fb_count, 0, sizeof(unsigned int), s));
+        hipLaunchKernelGGL(k_locate_lists, dim3(div_up(n, 256)), dim3(256), 0, s, ll.lists, ig, p, n, gp.maxdist, own, ll.fb_list, ll.fb_count);
+        FY_LAUNCH_CHECK();
+        const dim3 wgrid((unsigned)std::min<int64_t>(div_up(n, kLocPPB), 2048));
+        hipLaunchKernelGGL(k_locate<true>, wgrid, dim3(kWave), lds, s, tree, packed, ig, n_cells, p, n, gp.maxdist, start, SlabOwn{}, ll.fb_list, ll.fb_count);
+    } else if (packed) {
+        hipLaunchKernelGGL(k_locate<true>, grid, dim3(kWave), lds, s, tree, packed, ig, n_cells, p, n, gp.maxdist, start, own, nullptr, nullptr);
+    } else {
+        hipLaunchKernelGGL(k_locate<false>, grid, dim3(kWave), lds, s, tree, packed, ig, n_cells, p, n, gp.maxdist, nullptr, own, nullptr, nullptr);
+    }
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+
+int launch_build_locate_lists(hipStream_t s, const uint32_t* packed, ImplicitGeom ig, int32_t n_cells, double maxdist, unsigned short* lists) {
+    const double md_cells = maxdist / (ig.dx * ig.dx);
+    hipLaunchKernelGGL(k_build_locate_lists, dim3(div_up((int64_t)n_cells * 8, 256)), dim3(256), 0, s, packed, ig, n_cells, md_cells, lists);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }

@@ -67,8 +67,19 @@ struct ImplicitGeom {
 int launch_bin_gather(hipStream_t s, const double* rec, int64_t n, ParticleSoA p);
 // packed == nullptr selects the explicit 32-byte-node path.  Leaves chain ids and squared distances (in the weight slots).
 // start (implicit trees only, may be nullptr): per-cell traversal start built by launch_build_locate_start
+// ll.lists (implicit trees only, may be nullptr): per-(cell, octant) candidate lists built by launch_build_locate_lists; the walk then
+// only takes the particles the lists do not cover (ll.fb_list: one int32 per particle, ll.fb_count: one counter)
+struct LocateLists {
+    const unsigned short* lists;
+    int32_t* fb_list;
+    unsigned int* fb_count;
+};
+constexpr int kLocateListLen = 24;       // codes (2 B) per (cell, octant)
 int launch_locate(hipStream_t s, const KdNode* tree, const uint32_t* packed, ImplicitGeom ig, int32_t n_cells, int levels,
-                  ParticleSoA p, int64_t n, GaussParams gp, const unsigned long long* start = nullptr, SlabOwn own = SlabOwn{});
+                  ParticleSoA p, int64_t n, GaussParams gp, const unsigned long long* start = nullptr, SlabOwn own = SlabOwn{},
+                  LocateLists ll = LocateLists{});
+// lists: n_cells * 8 * kLocateListLen codes.  See k_build_locate_lists for what a list is and why scanning it reproduces the walk.
+int launch_build_locate_lists(hipStream_t s, const uint32_t* packed, ImplicitGeom ig, int32_t n_cells, double maxdist, unsigned short* lists);
 // For every cell of the block: the deepest tree node a walk for a query inside that cell is guaranteed to reach with an empty
 // stack and an empty chain (entry: offset | size << 25 | axis << 50).  See k_build_locate_start.
 int launch_build_locate_start(hipStream_t s, const uint32_t* packed, ImplicitGeom ig, int32_t n_cells, double maxdist, unsigned long long* start);
