@@ -432,11 +432,18 @@ int Coupling::run_batch(Batch& b) {
             if (d_loc_fb.n < (size_t)b.n) FY_TRY(d_loc_fb.alloc_exact((size_t)b.n + (size_t)b.n / 8));
             ll = LocateLists{d_loc_lists.p, d_loc_fb.p, d_loc_fb_n.p};
         }
-        FY_TRY(launch_locate(stream, d_tree.p, use_implicit ? d_tree_packed.p : nullptr, implicit, n_cells, tree_levels, p, b.n, gp,
-                             use_implicit ? d_loc_start.p : nullptr, slab_own(), ll));
-        if (timing) { timers[T_LOCATE].stop(stream); timers[T_FINALIZE].start(stream); }
         const CellWindow cw{slab.active ? slab.base : 0, n_field};
-        FY_TRY(launch_deposit(stream, p, b.n, gp, cw, d_pvol_acc.p, d_up_acc.p, d_touched.p));
+        static const bool unfused = getenv("FOAMYADE_UNFUSED_DEPOSIT") != nullptr;      // A/B switch: k_locate_lists + k_deposit
+        if (unfused) {
+            FY_TRY(launch_locate(stream, d_tree.p, use_implicit ? d_tree_packed.p : nullptr, implicit, n_cells, tree_levels, p, b.n, gp,
+                                 use_implicit ? d_loc_start.p : nullptr, slab_own(), ll));
+            if (timing) { timers[T_LOCATE].stop(stream); timers[T_FINALIZE].start(stream); }
+            FY_TRY(launch_deposit(stream, p, b.n, gp, cw, d_pvol_acc.p, d_up_acc.p, d_touched.p));
+        } else {
+            FY_TRY(launch_locate_deposit(stream, d_tree.p, use_implicit ? d_tree_packed.p : nullptr, implicit, n_cells, tree_levels, p, b.n, gp,
+                                         use_implicit ? d_loc_start.p : nullptr, slab_own(), ll, cw, d_pvol_acc.p, d_up_acc.p, d_touched.p));
+            if (timing) { timers[T_LOCATE].stop(stream); timers[T_FINALIZE].start(stream); }
+        }
         if (slab.active) {      // contributions that landed in ghost planes belong to the neighbours: send them home and add
             FY_TRY(halo_reverse_add2(d_pvol_acc.p, 1, d_touched.p, d_up_acc.p, 3));
         }

@@ -556,17 +556,48 @@ __device__ __forceinline__ void lds_add_f64(double* p, double v) { unsafeAtomicA
 
 // buildCellPartList FoamYade.C:265-288: pVol*w and (w*v)*pVol per (particle, cell) pair into the per-batch accumulators
 constexpr int kDepThreads = 512, kDepLog2 = 11;      // 2048 slots x (4 + 32) B = 72 KiB of LDS
+// one (particle, cell) contribution into the workgroup's table (or straight to memory when the table is crowded)
+__device__ __forceinline__ void deposit_pair(uint32_t* keys, double* vals, int32_t cid, double c0, double c1, double c2, double c3,
+                                             double* __restrict__ pvol_acc, double* __restrict__ up_acc, unsigned char* __restrict__ touched) {
+    const int h = agg_slot<kDepLog2>(keys, (uint32_t)cid);
+    if (h >= 0) {
+        lds_add_f64(&vals[4 * h], c0); lds_add_f64(&vals[4 * h + 1], c1);
+        lds_add_f64(&vals[4 * h + 2], c2); lds_add_f64(&vals[4 * h + 3], c3);
+    } else {
+        atomic_add_f64(&pvol_acc[cid], c0);
+        atomic_add_f64(&up_acc[3 * (size_t)cid + 0], c1);
+        atomic_add_f64(&up_acc[3 * (size_t)cid + 1], c2);
+        atomic_add_f64(&up_acc[3 * (size_t)cid + 2], c3);
+        touched[cid] = 1;
+    }
+}
+__device__ __forceinline__ void deposit_flush(const uint32_t* keys, const double* vals, double* __restrict__ pvol_acc, double* __restrict__ up_acc,
+                                              unsigned char* __restrict__ touched) {
+    for (int q = threadIdx.x; q < (1 << kDepLog2); q += kDepThreads) {
+        const uint32_t cid = keys[q];
+        if (cid == kAggEmpty) continue;
+        atomic_add_f64(&pvol_acc[cid], vals[4 * q]);
+        atomic_add_f64(&up_acc[3 * (size_t)cid + 0], vals[4 * q + 1]);
+        atomic_add_f64(&up_acc[3 * (size_t)cid + 1], vals[4 * q + 2]);
+        atomic_add_f64(&up_acc[3 * (size_t)cid + 2], vals[4 * q + 3]);
+        touched[cid] = 1;
+    }
+}
+
+// work != nullptr: the particles listed there (k_locate_deposit's leftovers, placed by the walk), shared by a fixed grid
 __global__ __launch_bounds__(kDepThreads) void k_deposit(ParticleSoA p, int64_t n, GaussParams gp, CellWindow cw, double* __restrict__ pvol_acc,
-                                                          double* __restrict__ up_acc, unsigned char* __restrict__ touched) {
+                                                          double* __restrict__ up_acc, unsigned char* __restrict__ touched,
+                                                          const int32_t* __restrict__ work, const unsigned int* __restrict__ work_n) {
     __shared__ uint32_t keys[1 << kDepLog2];
     __shared__ double vals[(1 << kDepLog2) * 4];
+    if (work) { n = (int64_t)*work_n; if ((int64_t)blockIdx.x * kDepThreads >= n) return; }      // (block-uniform)
     for (int q = threadIdx.x; q < (1 << kDepLog2); q += kDepThreads) {
         keys[q] = kAggEmpty;
         vals[4 * q] = 0.0; vals[4 * q + 1] = 0.0; vals[4 * q + 2] = 0.0; vals[4 * q + 3] = 0.0;
     }
     __syncthreads();
-    const int64_t i = (int64_t)blockIdx.x * kDepThreads + threadIdx.x;
-    if (i < n) {
+    for (int64_t idx = (int64_t)blockIdx.x * kDepThreads + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * kDepThreads) {
+        const int64_t i = work ? (int64_t)work[idx] : idx;
         const int chain = p.chain_len[i];
         const int k = chain < kMaxK ? chain : kMaxK;
         if (k > 0) {
@@ -599,30 +630,128 @@ __global__ __launch_bounds__(kDepThreads) void k_deposit(ParticleSoA p, int64_t 
                 if (cl < 0 || cl >= cw.n_field) continue;
                 const int32_t cid = (int32_t)cl;
                 const double c0 = pVol * weight, c1 = (weight * vx) * pVol, c2 = (weight * vy) * pVol, c3 = (weight * vz) * pVol;
-                const int h = agg_slot<kDepLog2>(keys, (uint32_t)cid);
-                if (h >= 0) {
-                    lds_add_f64(&vals[4 * h], c0); lds_add_f64(&vals[4 * h + 1], c1);
-                    lds_add_f64(&vals[4 * h + 2], c2); lds_add_f64(&vals[4 * h + 3], c3);
-                } else {
-                    atomic_add_f64(&pvol_acc[cid], c0);
-                    atomic_add_f64(&up_acc[3 * (size_t)cid + 0], c1);
-                    atomic_add_f64(&up_acc[3 * (size_t)cid + 1], c2);
-                    atomic_add_f64(&up_acc[3 * (size_t)cid + 2], c3);
-                    touched[cid] = 1;
+                deposit_pair(keys, vals, cid, c0, c1, c2, c3, pvol_acc, up_acc, touched);
+            }
+        }
+    }
+    __syncthreads();
+    deposit_flush(keys, vals, pvol_acc, up_acc, touched);
+}
+
+// k_locate_lists and k_deposit in one pass over the particles: the list scan keeps the unnormalised Gaussian weight of every listed
+// node in a register (zero where the node did not enter the chain; slots are static because the scan is unrolled), so the chain's
+// squared distances never travel through memory: ids and NORMALISED weights are stored once, for k_force_gaussian.  Same arithmetic
+// as the two kernels: allwt adds the weights from the last push to the first (adding the zeros in between is exact).
+__global__ __launch_bounds__(kDepThreads) void k_locate_deposit(const unsigned short* __restrict__ lists, ImplicitGeom ig, ParticleSoA p, int64_t n,
+                                                                 GaussParams gp, SlabOwn own, CellWindow cw, double* __restrict__ pvol_acc,
+                                                                 double* __restrict__ up_acc, unsigned char* __restrict__ touched,
+                                                                 int32_t* __restrict__ fb_list, unsigned int* __restrict__ fb_count) {
+    __shared__ uint32_t keys[1 << kDepLog2];
+    __shared__ double vals[(1 << kDepLog2) * 4];
+    for (int q = threadIdx.x; q < (1 << kDepLog2); q += kDepThreads) {
+        keys[q] = kAggEmpty;
+        vals[4 * q] = 0.0; vals[4 * q + 1] = 0.0; vals[4 * q + 2] = 0.0; vals[4 * q + 3] = 0.0;
+    }
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * kDepThreads + threadIdx.x;
+    if (i < n) {
+        const double qx = p.px[i], qy = p.py[i], qz = p.pz[i];
+        bool mine = true;
+        if (own.active) {                                    // another slab's particle: not located here (k = 0)
+            int kz = (int)floor((qz - own.oz) / own.dx);
+            kz = min(max(kz, 0), own.nzglob - 1);
+            if (!(qz == qz) || kz < own.k0 || kz >= own.k1) { p.chain_len[i] = 0; mine = false; }
+        }
+        if (mine) {
+            const double hdx = 0.5 * ig.dx;
+            const double sx = (qx - ig.ox) / ig.dx, sy = (qy - ig.oy) / ig.dx, sz = (qz - ig.oz) / ig.dx;
+            const double fx = floor(sx), fy_ = floor(sy), fz = floor(sz);
+            const double tx = sx - fx, ty = sy - fy_, tz = sz - fz;
+            const double tlo = 2 * kListEps, thi = 1.0 - 2 * kListEps;
+            bool ok = fx >= 0 && fx < ig.nx && fy_ >= 0 && fy_ < ig.ny && fz >= 0 && fz < ig.nz &&
+                      tx >= tlo && tx <= thi && ty >= tlo && ty <= thi && tz >= tlo && tz <= thi;      // (false for NaN)
+            const int ci = (int)fx, cj = (int)fy_, ck = (int)fz;
+            uint4 v[kListLen / 8];
+#pragma unroll
+            for (int ch = 0; ch < kListLen / 8; ++ch) v[ch] = make_uint4(kListEnd | (kListEnd << 16), 0, 0, 0);
+            if (ok) {
+                const double cx = ig.ox + (double)(2 * ci + 1) * hdx, cy = ig.oy + (double)(2 * cj + 1) * hdx, cz = ig.oz + (double)(2 * ck + 1) * hdx;
+                const int oct = (qx - cx < 0.0 ? 0 : 1) | (qy - cy < 0.0 ? 0 : 2) | (qz - cz < 0.0 ? 0 : 4);
+                const size_t cell = (size_t)ci + (size_t)ig.nx * ((size_t)cj + (size_t)ig.ny * (size_t)ck);
+                const uint4* row = reinterpret_cast<const uint4*>(lists + (cell * 8 + (size_t)oct) * kListLen);
+                v[0] = row[0];
+                ok = (v[0].x & 0xffffu) != kListOverflow;
+                if (ok) {
+                    // the second and third chunk only where the list goes on (its last code is not the end mark)
+                    if ((v[0].w >> 16) != kListEnd) { v[1] = row[1]; if ((v[1].w >> 16) != kListEnd) v[2] = row[2]; }
+                }
+            }
+            if (!ok) {
+                const unsigned int at = atomicAdd(fb_count, 1u);
+                fb_list[at] = (int32_t)i;
+            } else {
+                double best = 1e300, wt[kListLen];
+                uint32_t emitted = 0;
+                bool done = false;
+#pragma unroll
+                for (int h = 0; h < kListLen; ++h) {
+                    wt[h] = 0.0;
+                    const uint4 vv = v[h >> 3];
+                    const uint32_t wd = ((h >> 1) & 3) == 0 ? vv.x : (((h >> 1) & 3) == 1 ? vv.y : (((h >> 1) & 3) == 2 ? vv.z : vv.w));
+                    const uint32_t code = (wd >> ((h & 1) * 16)) & 0xffffu;
+                    if (code == kListEnd) done = true;
+                    if (!done) {
+                        const int ni = ci + (int)(code & 15u) - 8, nj = cj + (int)((code >> 4) & 15u) - 8, nk = ck + (int)((code >> 8) & 15u) - 8;
+                        const double a = qx - (ig.ox + (double)(2 * ni + 1) * hdx), b = qy - (ig.oy + (double)(2 * nj + 1) * hdx),
+                                     c = qz - (ig.oz + (double)(2 * nk + 1) * hdx);
+                        double d = a * a;                    // meshTree.C:54-64
+                        d += b * b;
+                        d += c * c;
+                        if (d < best) {                      // meshTree.C:192
+                            best = d;
+                            if (d < gp.maxdist && !(code & kListNoEmit)) {       // meshTree.C:195; the root is never pushed
+                                wt[h] = exp(-d / gp.two_sigma2) * gp.range_cu * gp.sigma_pi;     // FoamYade.C:308
+                                emitted |= 1u << h;
+                            }
+                        }
+                    }
+                }
+                const int chain = __popc(emitted);
+                p.chain_len[i] = chain;
+                if (chain > 0) {
+                    double allwt = 0.0;
+#pragma unroll
+                    for (int h = kListLen - 1; h >= 0; --h) allwt += wt[h];       // last push first (FoamYade.C:301-311)
+                    const double dia = 2 * p.rad[i];                                  // FoamYade.C:219
+                    const double pVol = M_PI * pow(dia, 3.0) / 6.0;                   // FoamYade.H:36
+                    const double vx = p.vx[i], vy = p.vy[i], vz = p.vz[i];
+                    int pos = 0;
+#pragma unroll
+                    for (int h = 0; h < kListLen; ++h) {
+                        if (emitted & (1u << h)) {
+                            const uint4 vv = v[h >> 3];
+                            const uint32_t wd = ((h >> 1) & 3) == 0 ? vv.x : (((h >> 1) & 3) == 1 ? vv.y : (((h >> 1) & 3) == 2 ? vv.z : vv.w));
+                            const uint32_t code = (wd >> ((h & 1) * 16)) & 0xffffu;
+                            const int ni = ci + (int)(code & 15u) - 8, nj = cj + (int)((code >> 4) & 15u) - 8, nk = ck + (int)((code >> 8) & 15u) - 8;
+                            const int32_t id = ni + ig.nx * (nj + ig.ny * nk);
+                            const double weight = wt[h] / allwt;                      // FoamYade.C:312-314
+                            const size_t slot = (size_t)(pos & (kMaxK - 1)) * p.cap + (size_t)i;
+                            p.ids[slot] = id;
+                            p.w[slot] = weight;
+                            ++pos;
+                            const int64_t cl = (int64_t)id - cw.base;                 // storage index (slab window)
+                            if (cl >= 0 && cl < cw.n_field) {
+                                const double c0 = pVol * weight, c1 = (weight * vx) * pVol, c2 = (weight * vy) * pVol, c3 = (weight * vz) * pVol;
+                                deposit_pair(keys, vals, (int32_t)cl, c0, c1, c2, c3, pvol_acc, up_acc, touched);
+                            }
+                        }
+                    }
                 }
             }
         }
     }
     __syncthreads();
-    for (int q = threadIdx.x; q < (1 << kDepLog2); q += kDepThreads) {
-        const uint32_t cid = keys[q];
-        if (cid == kAggEmpty) continue;
-        atomic_add_f64(&pvol_acc[cid], vals[4 * q]);
-        atomic_add_f64(&up_acc[3 * (size_t)cid + 0], vals[4 * q + 1]);
-        atomic_add_f64(&up_acc[3 * (size_t)cid + 1], vals[4 * q + 2]);
-        atomic_add_f64(&up_acc[3 * (size_t)cid + 2], vals[4 * q + 3]);
-        touched[cid] = 1;
-    }
+    deposit_flush(keys, vals, pvol_acc, up_acc, touched);
 }
 
 // setCellVolFraction FoamYade.C:318-328: assignment on the cells this batch touched; accumulators reset for the next batch
@@ -1014,9 +1143,33 @@ int launch_build_locate_lists(hipStream_t s, const uint32_t* packed, ImplicitGeo
     return FY_OK;
 }
 
+int launch_locate_deposit(hipStream_t s, const KdNode* tree, const uint32_t* packed, ImplicitGeom ig, int32_t n_cells, int levels, ParticleSoA p, int64_t n,
+                          GaussParams gp, const unsigned long long* start, SlabOwn own, LocateLists ll, CellWindow cw, double* pvol_acc, double* up_acc,
+                          unsigned char* touched) {
+    if (n <= 0) return FY_OK;
+    if (!(packed && ll.lists)) {
+        FY_TRY(launch_locate(s, tree, packed, ig, n_cells, levels, p, n, gp, start, own, LocateLists{}));
+        return launch_deposit(s, p, n, gp, cw, pvol_acc, up_acc, touched);
+    }
+    if (n_cells >= (1 << 25)) return fail(FY_ERR_UNSUPPORTED, "implicit-coordinate tree limited to 2^25 cells");
+    // the lists place and deposit almost every particle; the walk + k_deposit pair takes what is left (usually nothing: zero count, exit)
+    FY_HIP(hipMemsetAsync(ll.fb_count, 0, sizeof(unsigned int), s));
+    hipLaunchKernelGGL(k_locate_deposit, dim3(div_up(n, kDepThreads)), dim3(kDepThreads), 0, s, ll.lists, ig, p, n, gp, own, cw, pvol_acc, up_acc, touched,
+                       ll.fb_list, ll.fb_count);
+    FY_LAUNCH_CHECK();
+    const size_t lds = (size_t)(levels + 1) * kWave * sizeof(unsigned long long);
+    const dim3 wgrid((unsigned)std::min<int64_t>(div_up(n, kLocPPB), 2048));
+    hipLaunchKernelGGL(k_locate<true>, wgrid, dim3(kWave), lds, s, tree, packed, ig, n_cells, p, n, gp.maxdist, start, SlabOwn{}, ll.fb_list, ll.fb_count);
+    FY_LAUNCH_CHECK();
+    const dim3 dgrid((unsigned)std::min<int64_t>(div_up(n, kDepThreads), 512));
+    hipLaunchKernelGGL(k_deposit, dgrid, dim3(kDepThreads), 0, s, p, n, gp, cw, pvol_acc, up_acc, touched, ll.fb_list, ll.fb_count);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+
 int launch_deposit(hipStream_t s, ParticleSoA p, int64_t n, GaussParams gp, CellWindow cw, double* pvol_acc, double* up_acc, unsigned char* touched) {
     if (n <= 0) return FY_OK;
-    hipLaunchKernelGGL(k_deposit, dim3(div_up(n, kDepThreads)), dim3(kDepThreads), 0, s, p, n, gp, cw, pvol_acc, up_acc, touched);
+    hipLaunchKernelGGL(k_deposit, dim3(div_up(n, kDepThreads)), dim3(kDepThreads), 0, s, p, n, gp, cw, pvol_acc, up_acc, touched, nullptr, nullptr);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }

@@ -87,6 +87,11 @@ int launch_build_locate_start(hipStream_t s, const uint32_t* packed, ImplicitGeo
 // cell arrays are indexed with (global cell id - cell_base) and hold n_field cells (slab storage); ids outside are skipped
 struct CellWindow { int64_t base; int64_t n_field; };
 int launch_deposit(hipStream_t s, ParticleSoA p, int64_t n, GaussParams gp, CellWindow cw, double* pvol_acc, double* up_acc, unsigned char* touched);
+// launch_locate + launch_deposit; with candidate lists (ll.lists) both run as ONE pass (k_locate_deposit) and the chain's squared
+// distances never reach memory
+int launch_locate_deposit(hipStream_t s, const KdNode* tree, const uint32_t* packed, ImplicitGeom ig, int32_t n_cells, int levels, ParticleSoA p, int64_t n,
+                          GaussParams gp, const unsigned long long* start, SlabOwn own, LocateLists ll, CellWindow cw, double* pvol_acc, double* up_acc,
+                          unsigned char* touched);
 int launch_add_mark(hipStream_t s, double* y, const double* x, size_t n, unsigned char* mark /* nullable; set where x != 0 */);
 int launch_finalize_cells(hipStream_t s, int32_t n_cells, const double* vol, double* pvol_acc, double* up_acc,
                           unsigned char* touched, double* alpha, double* uParticle);
