@@ -253,14 +253,14 @@ def main():
     for _ in range(args.warmup):
         solver.step()
     solver.enable_kernel_timing(True)
-    acc = dict(particle=0.0, locate=0.0, force=0.0, bin=0.0, depfin=0.0, momentum=0.0, pressure=0.0, other=0.0, p_iters=0, u_iters=0)
+    acc = dict(particle=0.0, locate_deposit=0.0, force=0.0, bin=0.0, finalize=0.0, momentum=0.0, pressure=0.0, other=0.0, p_iters=0, u_iters=0)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         solver.step()
         st = solver.stats(); ct = solver.coupling_timings()
         acc["particle"] += st["ms_particle"]; acc["momentum"] += st["ms_momentum"]; acc["pressure"] += st["ms_pressure"]; acc["other"] += st["ms_other"]
-        acc["locate"] += ct["locate_deposit"]; acc["force"] += ct["force"]; acc["bin"] += ct["bin"]; acc["depfin"] += ct["finalize"]
+        acc["locate_deposit"] += ct["locate_deposit"]; acc["force"] += ct["force"]; acc["bin"] += ct["bin"]; acc["finalize"] += ct["finalize"]
         acc["p_iters"] += st["p_iters_total"]; acc["u_iters"] += st["u_iters_total"]
     barrier()
     elapsed = time.perf_counter() - t0
@@ -274,14 +274,15 @@ def main():
     apply_ms, apply_n = solver.kernel_timing("p_apply_dot")
     mom_ms, mom_n = solver.kernel_timing("mom_pass")
     np_part = int(rec.shape[0]) if strong else args.particles      # particles of this rank
-    dep_ms = max(acc["depfin"], 0.0)
+    dep_ms = max(acc["finalize"], 0.0)
     cand = {
         # name: (total ms over the timed steps, launches, algorithmic bytes per launch, description) -- DESIGN.md section 3;
         # kbar = 5.46 stencil cells per particle, 12 B per (id, weight) pair
-        "k_locate": (acc["locate"], K, (24.0 + 8.0 + 4.0 + 12.0 * 5.46) * np_part,
-                     "k-d 'range' locate (improvement chain of one NN DFS): position 24 B + per-cell start entry 8 B in, chain length 4 B + 12 B/pair out; latency/issue bound, not HBM"),
-        "k_deposit+k_finalize_cells": (dep_ms, K, (60.0 + 2 * 12.0 * 5.46) * np_part + 65.0 * nc,
-                                       "Gaussian weights + void-fraction deposit (LDS-aggregated atomics) + alpha/uParticle finalize"),
+        # one pass since the candidate lists: positions 24 + velocity 24 + radius 8 + (cell, octant) list 2 B x 7.6 codes in,
+        # chain length 4 + 12 B/pair out, 65 B per touched cell (accumulators + alpha/uParticle in k_finalize_cells)
+        "k_locate_deposit+k_finalize_cells": (acc["locate_deposit"] + dep_ms, K, (24.0 + 24.0 + 8.0 + 15.2 + 4.0 + 12.0 * 5.46) * np_part + 65.0 * nc,
+                     "k-d 'range' locate through per-(cell, octant) candidate lists + Gaussian weights + void-fraction deposit (LDS-aggregated "
+                     "atomics) in one pass, then alpha/uParticle finalize"),
         "k_force_gaussian": (acc["force"], K, (64.0 + 12.0 * 5.46 + 52.0) * np_part + 176.0 * nc,
                              "drag + Archimedes + back-scatter: particle 64 B + stencil 12 B/pair in, force 52 B out, cell fields 112 B read + 64 B RMW"),
         "k_mg_smooth(level 0)": (smooth_ms, smooth_n, 56.0 * nc, "pEqn Laplacian apply fused with the damped-Jacobi update: 48 B/cell (diag, 3 upper, x, y) + b 8"),
@@ -325,7 +326,7 @@ def main():
                    "p_tol": [case.p_tol, case.p_rel_tol, case.p_final_tol, case.p_final_rel_tol],
                    "parallelism": parallelism,
                    "global_cells": nc * world, "global_particles": args.particles if strong else np_part * world},
-        "per_step_ms": {k: round(acc[k] / K, 3) for k in ("particle", "bin", "locate", "depfin", "force", "momentum", "pressure", "other")},
+        "per_step_ms": {k: round(acc[k] / K, 3) for k in ("particle", "bin", "locate_deposit", "finalize", "force", "momentum", "pressure", "other")},
         "p_iters_per_step": acc["p_iters"] / K, "u_iters_per_step": acc["u_iters"] / K,
         "roofline": roof(dominant) if dominant else None,
         "roofline_pEqn_laplacian": roof(lap) if lap in kern else None,

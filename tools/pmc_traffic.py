@@ -16,7 +16,9 @@ import sys
 
 
 def classify(name, grid, nc):
-    if "k_locate" in name: return "k_locate"
+    if "k_locate_deposit" in name: return "k_locate_deposit"
+    if "k_locate_lists" in name: return "k_locate_lists"
+    if "k_locate" in name: return "k_locate(walk)"
     if "k_force_gaussian" in name: return "k_force_gaussian"
     if "k_deposit" in name: return "k_deposit"
     if "k_p_apply_dot" in name: return "k_p_apply_dot"
@@ -43,7 +45,7 @@ def main():
     for k, v in res.items():
         f, w = v.get("FETCH_SIZE_KiB_per_launch", 0.0), v.get("WRITE_SIZE_KiB_per_launch", 0.0)
         v["hbm_bytes_per_launch"] = (2.0 * f + w) * 1024.0
-        v["read_correction"] = "x2 (gfx950 wide-coalesced rule)" + ("; upper bound: gather-dominated" if k in ("k_force_gaussian", "k_deposit", "k_locate") else "")
+        v["read_correction"] = "x2 (gfx950 wide-coalesced rule)" + ("; upper bound: gather-dominated" if k in ("k_force_gaussian", "k_deposit", "k_locate_deposit", "k_locate_lists", "k_locate(walk)") else "")
     json.dump({"unit": "bytes", "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes of bench.py --steps 3 --warmup 1", "kernels": res},
               open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))
