@@ -141,10 +141,7 @@ __global__ __launch_bounds__(256) void k_flux_of(FvGeo g, const double* __restri
 }
 
 template <int D>
-__global__ __launch_bounds__(256) void k_interp_alpha(FvGeo g, const double* __restrict__ alpha, double* __restrict__ af) {
-    const size_t f = (size_t)blockIdx.x * 256 + threadIdx.x;
-    int i, j, k;
-    if (!face_ijk(g, D, f, i, j, k)) return;
+__device__ __forceinline__ void interp_alpha_face(const FvGeo& g, size_t f, int i, int j, int k, const double* __restrict__ alpha, double* __restrict__ af) {
     const int q = D == 0 ? i : D == 1 ? j : k;
     if (face_low_b(g, D, q) || face_high_b(g, D, q)) af[f] = 1.0;     // calculated patch, value 1 (`alpha = 1.0`, FoamYade.C:68)
     else { const int c = cidx(g, i, j, k); af[f] = 0.5 * (alpha[c - stride_of(g, D)] + alpha[c]); }
@@ -177,16 +174,58 @@ __global__ __launch_bounds__(256) void k_phi_forces(FvGeo g, const double* __res
     out[f] = fl + rAUf[f] * (g.g[D] * g.Af);
 }
 
+// Every face of the block exactly once from a cell-centred sweep: an owned cell does its three low faces, and the high face where it
+// is the last cell of its row / column / slab.  One pass over the cell fields instead of one per direction (the three per-direction
+// launches each pulled the whole AoS vector fields through for one component: 264 -> 168 B/cell for phiHbyA); same arithmetic per face.
+#define FY_CELL_FACES(g, i, j, k, CALL)                     \
+    do {                                                    \
+        CALL(0, i, j, k); if (i == g.nx - 1) CALL(0, i + 1, j, k); \
+        CALL(1, i, j, k); if (j == g.ny - 1) CALL(1, i, j + 1, k); \
+        CALL(2, i, j, k); if (k == g.nz - 1) CALL(2, i, j, k + 1); \
+    } while (0)
+
+// rAUcf = fvc::interpolate(rAUc) and phicForces in one cell-centred sweep (UcEqn.H:15-20): k_interp_rAU<D> + k_phi_forces<D>, D = 0..2
+template <int D>
+__device__ __forceinline__ void rAUf_phi_forces_face(const FvGeo& g, size_t f, int i, int j, int k, const double* __restrict__ rAU,
+                                                     const double* __restrict__ uSource, double* __restrict__ rf, double* __restrict__ out) {
+    const int q = D == 0 ? i : D == 1 ? j : k;
+    double r, fl = 0.0;
+    if (face_low_b(g, D, q)) r = rAU[cidx(g, i, j, k)];
+    else if (face_high_b(g, D, q)) r = rAU[cidx(g, i - (D == 0), j - (D == 1), k - (D == 2))];
+    else {
+        const int c = cidx(g, i, j, k), cm = c - stride_of(g, D);
+        const double rm = rAU[cm], rc = rAU[c];
+        r = 0.5 * (rm + rc);
+        fl = 0.5 * (rm * uSource[3 * (size_t)cm + D] + rc * uSource[3 * (size_t)c + D]) * g.Af;
+    }
+    rf[f] = r;
+    out[f] = fl + r * (g.g[D] * g.Af);
+}
+__global__ __launch_bounds__(256) void k_rAUf_phi_forces_cells(FvGeo g, const double* __restrict__ rAU, const double* __restrict__ uSource, Face3 rf, Face3 out) {
+    const int t = swz_block(blockIdx.x, gridDim.x) * 256 + (int)threadIdx.x;
+    if (t >= g.Nc) return;
+    int i, j, k; ijk_of(g, t, i, j, k);
+#define FY_CALL(D, fi, fj, fk) { const size_t f = (size_t)fid(g, D, fi, fj, fk); rAUf_phi_forces_face<D>(g, f, fi, fj, fk, rAU, uSource, rf.a[D], out.a[D]); }
+    FY_CELL_FACES(g, i, j, k, FY_CALL);
+#undef FY_CALL
+}
+
+__global__ __launch_bounds__(256) void k_interp_alpha_cells(FvGeo g, const double* __restrict__ alpha, Face3 af) {
+    const int t = swz_block(blockIdx.x, gridDim.x) * 256 + (int)threadIdx.x;
+    if (t >= g.Nc) return;
+    int i, j, k; ijk_of(g, t, i, j, k);
+#define FY_CALL(D, fi, fj, fk) { const size_t f = (size_t)fid(g, D, fi, fj, fk); interp_alpha_face<D>(g, f, fi, fj, fk, alpha, af.a[D]); }
+    FY_CELL_FACES(g, i, j, k, FY_CALL);
+#undef FY_CALL
+}
+
 // phiHbyA = fvc::flux(HbyA) + [alphacf*]rAUf*fvc::ddtCorr(U, phi) [+ phicForces]; constrainPressure on fixedFluxPressure patches
 // (icoFoamYade.C:101-111, pEqn.H:4-21).  ddtCorr = EulerDdtScheme::fvcDdtPhiCorr with fvcDdtPhiCoeff.
 template <int D>
-__global__ __launch_bounds__(256) void k_phiHbyA(FvGeo g, const double* __restrict__ HbyA, const double* __restrict__ U,
-                                                 const double* __restrict__ Uold, const double* __restrict__ phiOld,
-                                                 const double* __restrict__ rAUf, const double* __restrict__ alphaf,
-                                                 const double* __restrict__ phiForces, double* __restrict__ out, double* __restrict__ psn) {
-    const size_t f = (size_t)blockIdx.x * 256 + threadIdx.x;
-    int i, j, k;
-    if (!face_ijk(g, D, f, i, j, k)) return;
+__device__ __forceinline__ void phiHbyA_face(const FvGeo& g, size_t f, int i, int j, int k, const double* __restrict__ HbyA, const double* __restrict__ U,
+                                             const double* __restrict__ Uold, const double* __restrict__ phiOld,
+                                             const double* __restrict__ rAUf, const double* __restrict__ alphaf,
+                                             const double* __restrict__ phiForces, double* __restrict__ out, double* __restrict__ psn) {
     const int q = D == 0 ? i : D == 1 ? j : k;
     double v = face_flux_vec(g, HbyA, D, i, j, k);
     double uf;
@@ -208,6 +247,18 @@ __global__ __launch_bounds__(256) void k_phiHbyA(FvGeo g, const double* __restri
         double ub[3]; Ub(g, U, bc, bpatch, ub);
         psn[f] = (v - ub[D] * g.Af) / (rAUf[f] * g.Af);
     }
+}
+
+__global__ __launch_bounds__(256) void k_phiHbyA_cells(FvGeo g, const double* __restrict__ HbyA, const double* __restrict__ U,
+                                                       const double* __restrict__ Uold, CFace3 phiOld, CFace3 rAUf, CFace3 alphaf,
+                                                       CFace3 phiForces, Face3 out, Face3 psn) {
+    const int t = swz_block(blockIdx.x, gridDim.x) * 256 + (int)threadIdx.x;
+    if (t >= g.Nc) return;
+    int i, j, k; ijk_of(g, t, i, j, k);
+#define FY_CALL(D, fi, fj, fk) { const size_t f = (size_t)fid(g, D, fi, fj, fk); \
+        phiHbyA_face<D>(g, f, fi, fj, fk, HbyA, U, Uold, phiOld.a[D], rAUf.a[D], alphaf.a[D], phiForces.a[D], out.a[D], psn.a[D]); }
+    FY_CELL_FACES(g, i, j, k, FY_CALL);
+#undef FY_CALL
 }
 
 // pEqn.flux() and phi = phiHbyA - pEqn.flux()[/alphacf]   (icoFoamYade.C:129, pEqn.H:39)
@@ -1052,9 +1103,7 @@ int launch_pre_coupling(hipStream_t s, FvGeo g, const double* U, const double* p
 }
 
 int launch_interp_alpha(hipStream_t s, FvGeo g, const double* alpha, Face3 af) {
-    hipLaunchKernelGGL(k_interp_alpha<0>, dim3(div_up(fv_fsize(g, 0), 256)), dim3(256), 0, s, g, alpha, af.a[0]);
-    hipLaunchKernelGGL(k_interp_alpha<1>, dim3(div_up(fv_fsize(g, 1), 256)), dim3(256), 0, s, g, alpha, af.a[1]);
-    hipLaunchKernelGGL(k_interp_alpha<2>, dim3(div_up(fv_fsize(g, 2), 256)), dim3(256), 0, s, g, alpha, af.a[2]);
+    hipLaunchKernelGGL(k_interp_alpha_cells, dim3(div_up(g.Nc, 256)), dim3(256), 0, s, g, alpha, af);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }
@@ -1122,9 +1171,13 @@ int launch_HbyA(hipStream_t s, FvGeo g, Mom7 M, const double* src, const double*
 
 int launch_phiHbyA(hipStream_t s, FvGeo g, const double* HbyA, const double* U, const double* Uold, CFace3 phiOld, CFace3 rAUf,
                    CFace3 alphaf, CFace3 phiForces, Face3 out, Face3 psn) {
-    hipLaunchKernelGGL(k_phiHbyA<0>, dim3(div_up(fv_fsize(g, 0), 256)), dim3(256), 0, s, g, HbyA, U, Uold, phiOld.a[0], rAUf.a[0], alphaf.a[0], phiForces.a[0], out.a[0], psn.a[0]);
-    hipLaunchKernelGGL(k_phiHbyA<1>, dim3(div_up(fv_fsize(g, 1), 256)), dim3(256), 0, s, g, HbyA, U, Uold, phiOld.a[1], rAUf.a[1], alphaf.a[1], phiForces.a[1], out.a[1], psn.a[1]);
-    hipLaunchKernelGGL(k_phiHbyA<2>, dim3(div_up(fv_fsize(g, 2), 256)), dim3(256), 0, s, g, HbyA, U, Uold, phiOld.a[2], rAUf.a[2], alphaf.a[2], phiForces.a[2], out.a[2], psn.a[2]);
+    hipLaunchKernelGGL(k_phiHbyA_cells, dim3(div_up(g.Nc, 256)), dim3(256), 0, s, g, HbyA, U, Uold, phiOld, rAUf, alphaf, phiForces, out, psn);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+
+int launch_rAUf_phi_forces(hipStream_t s, FvGeo g, const double* rAU, const double* uSource, Face3 rf, Face3 out) {
+    hipLaunchKernelGGL(k_rAUf_phi_forces_cells, dim3(div_up(g.Nc, 256)), dim3(256), 0, s, g, rAU, uSource, rf, out);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }

@@ -68,6 +68,8 @@ int launch_assemble_momentum(hipStream_t s, FvGeo g, const double* U, const doub
                              const double* vGrad /* grad(U) of the current iterate: linearUpwind only */, Mom7 M, double* src, double* rAU);
 int launch_interp_rAU(hipStream_t s, FvGeo g, const double* rAU, Face3 rAUf);
 int launch_phi_forces(hipStream_t s, FvGeo g, const double* rAU, CFace3 rAUf, const double* uSource, Face3 phiForces);
+// launch_interp_rAU + launch_phi_forces as one cell-centred sweep (same values)
+int launch_rAUf_phi_forces(hipStream_t s, FvGeo g, const double* rAU, const double* uSource, Face3 rf, Face3 out);
 int launch_bmom(hipStream_t s, FvGeo g, const double* src, const double* p, CFace3 psn, CFace3 phiForces, CFace3 rAUf, double* bmom);
 // one fused Jacobi pass: residual sums of x (slots 0..2), norm-factor sums (slots 3..5, uses xbar[3]) and xn = next iterate
 int launch_mom_pass(hipStream_t s, FvGeo g, Mom7 M, const double* b, const double* x, double* xn, const double* xbar, double* partials);

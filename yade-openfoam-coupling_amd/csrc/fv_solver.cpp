@@ -539,8 +539,7 @@ struct Solver {
                                             divG.p, vGrad.p, M7(), src.p, rAU.p));
             if (pimple) {
                 FY_TRY(halo_cells(rAU, 1, 1));
-                FY_TRY(launch_interp_rAU(stream, g, rAU.p, F3(rAUf)));
-                FY_TRY(launch_phi_forces(stream, g, rAU.p, C3(rAUf), uSource.p, F3(phiForces)));     // uSource ghosts refreshed by the coupling
+                FY_TRY(launch_rAUf_phi_forces(stream, g, rAU.p, uSource.p, F3(rAUf), F3(phiForces)));  // uSource ghosts refreshed by the coupling
             }
             if (cs.momentum_predictor) {
                 FY_TRY(launch_bmom(stream, g, src.p, p.p, C3(psn), C3(phiForces), C3(rAUf), bmom.p));
