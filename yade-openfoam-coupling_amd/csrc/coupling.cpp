@@ -185,7 +185,8 @@ int Coupling::create(const fy_mesh_desc* m, const fy_field_ptrs* f, int gaussian
     // ---- binning grid (locality only)
     {
         const double h0 = structured ? m->dx : std::cbrt(v0);
-        const double h = 2.0 * h0;
+        const char* be = getenv("FOAMYADE_BIN_EDGE");                  // in cells; locality only (2: measured optimum)
+        const double h = (be && atof(be) > 0 ? atof(be) : 2.0) * h0;
         bins.ox = m->bbox_min[0]; bins.oy = m->bbox_min[1]; bins.oz = m->bbox_min[2];
         bins.inv_h = 1.0 / h;
         auto nb = [&](int a) { double e = (m->bbox_max[a] - m->bbox_min[a]) / h; int v = (int)std::ceil(e - 1e-9); return std::max(v, 1); };

@@ -360,8 +360,9 @@ struct Solver {
             return FY_OK;
         }
         MgLev& Cc = *mg[l + 1];
-        if (l >= 1 && !L.distributed) {
-            // small levels are launch-latency bound: first iterate and first sweep in one pass (bit-identical, see the kernel)
+        if (!L.distributed) {
+            // first iterate and first sweep in one pass (bit-identical, see the kernel): one launch fewer on the latency-bound small
+            // levels, and on level 0 the first iterate never travels through memory (pressure 2.25 -> 2.21 ms)
             FY_TRY(launch_mg_smooth_two_from_zero(stream, L.A, L.bptr, L.xcur, w));
         } else {
             FY_TRY(launch_mg_smooth_first(stream, L.A, L.bptr, L.xcur, w));
