@@ -52,6 +52,7 @@ struct Solver {
     SelfComm self_comm;
 
     DevBuf<double> U, Uold, p, alpha, alphaOld, uSource, uSourceDrag, uParticle, gradP, divT, vGrad, ddtU;
+    bool rAU_new = true;        // rAU was (re)assembled since the last corrector: rAUf and the coarse pressure operators are stale
     DevBuf<double> phi[3], phiOld[3], psn[3], alphaf[3], phiHbyA[3], phiForces[3], rAUf[3], pflux[3];
     DevBuf<double> mdiag, man[6], src, rAU, HbyA, bmom, Gt, divG, xscr;
     std::vector<std::unique_ptr<MgLev> > mg;
@@ -458,7 +459,9 @@ struct Solver {
     int corrector(bool final_inner) {
         FY_TRY(halo_cells(U, 3, 1));
         FY_TRY(launch_HbyA(stream, g, M7(), src.p, U.p, rAU.p, HbyA.p));
-        if (!pimple) { FY_TRY(halo_cells(rAU, 1, 1)); FY_TRY(launch_interp_rAU(stream, g, rAU.p, F3(rAUf))); }
+        // rAU (hence rAUf and the pressure matrix rAUf*alphaf) belongs to the momentum matrix: it only changes when that is assembled,
+        // not between the PISO correctors of one assembly
+        if (!pimple && rAU_new) { FY_TRY(halo_cells(rAU, 1, 1)); FY_TRY(launch_interp_rAU(stream, g, rAU.p, F3(rAUf))); }
         FY_TRY(halo_cells(HbyA, 3, 1));
         FY_TRY(launch_phiHbyA(stream, g, HbyA.p, U.p, Uold.p, C3(phiOld), C3(rAUf), C3(alphaf), C3(phiForces), F3(phiHbyA), F3(psn)));
         MgLev& L = *mg[0];
@@ -466,7 +469,8 @@ struct Solver {
         for (int no = 0; no <= cs.n_non_orth_correctors; ++no) {
             FY_TRY(launch_assemble_pressure(stream, g, C3(phiHbyA), C3(rAUf), C3(alphaf), C3(psn), alpha.p, alphaOld.p, L.A, prhs.p));
             if (L.distributed && comm->has_down()) FY_TRY(launch_p_ghost_uz(stream, g, C3(rAUf), C3(alphaf), L.A));
-            FY_TRY(build_coarse_operators());
+            if (rAU_new) FY_TRY(build_coarse_operators());        // same matrix as in the previous corrector otherwise: only the right-hand side moved
+            rAU_new = false;
             FY_TRY(solve_pressure(final_inner && no == cs.n_non_orth_correctors));
             if (no == cs.n_non_orth_correctors) {
                 FY_TRY(halo_cells(p, 1, 1));
@@ -538,6 +542,7 @@ struct Solver {
             if (g.upwind == 2) FY_TRY(halo_cells(vGrad, 9, 1));      // linearUpwind reads grad(U) of the upwind neighbour (ico: written at step start)
             FY_TRY(launch_assemble_momentum(stream, g, U.p, Uold.p, alpha.p, alphaOld.p, C3(alphaf), C3(phi), uSource.p, uSourceDrag.p,
                                             divG.p, vGrad.p, M7(), src.p, rAU.p));
+            rAU_new = true;
             if (pimple) {
                 FY_TRY(halo_cells(rAU, 1, 1));
                 FY_TRY(launch_rAUf_phi_forces(stream, g, rAU.p, uSource.p, F3(rAUf), F3(phiForces)));  // uSource ghosts refreshed by the coupling
