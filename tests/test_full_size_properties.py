@@ -57,6 +57,9 @@ def test_particle_path_properties_at_c3_size(product):
     ok = (k > 0) & (chain <= 12)
     assert ok.sum() > 0.999 * NP
     assert 5.3 < k[ok].mean() < 5.6                                  # k-bar = 5.46 on a uniform block
+    # the candidate lists placed all but a handful (random positions land within 8e-6 dx of a cell face with probability ~5e-5)
+    walked = fy.locate_walk_count
+    assert walked == -1 or 0 <= walked < 2e-4 * NP, walked
 
     # ---- partition of unity
     valid = np.arange(16)[None, :] < k[:, None]

@@ -541,6 +541,11 @@ class Solver:
         _check(lib().fy_get_particle_timings(self._cpl, C.byref(t)))
         return {n: getattr(t, n) for n, _ in ParticleTimings._fields_}
 
+    @property
+    def locate_walk_count(self):
+        """see FoamYade.locate_walk_count"""
+        return lib().fy_locate_walk_count(self._cpl)
+
     def enable_particle_timing(self, on=True):
         _check(lib().fy_enable_timing(self._cpl, int(on)))
 
