@@ -21,6 +21,8 @@ __device__ __forceinline__ void ijk_of(const FvGeo& g, int t, int& i, int& j, in
 }
 __device__ __forceinline__ int cidx(const FvGeo& g, int i, int j, int k) { return i + g.nx * (j + g.ny * (k + g.gz)); }
 __device__ __forceinline__ int stride_of(const FvGeo& g, int d) { return d == 0 ? 1 : d == 1 ? g.nx : g.nx * g.ny; }
+// doubles between the rows of the stress tensor field G (stored as three vec3 fields over the whole storage, ghost planes included)
+__device__ __forceinline__ size_t g_row_stride(const FvGeo& g) { return 3 * (size_t)g.nx * g.ny * (size_t)(g.nz + 2 * g.gz); }
 __device__ __forceinline__ int ndim(const FvGeo& g, int d) { return d == 0 ? g.nx : d == 1 ? g.ny : g.nz; }
 __device__ __forceinline__ int fid(const FvGeo& g, int d, int i, int j, int k) {
     return d == 0 ? i + (g.nx + 1) * (j + g.ny * k) : d == 1 ? i + g.nx * (j + (g.ny + 1) * k) : i + g.nx * (j + g.ny * k);
@@ -365,8 +367,11 @@ __global__ __launch_bounds__(256) void k_pre_coupling(FvGeo g, const double* __r
     if (Gout) {
         const double tr = T[0] + T[4] + T[8];
         const double an = alpha[c] * g.nu;
+        // stored BY ROWS (three vec3 arrays): k_div_G takes row d from the +-d neighbours only, so it streams 24-byte records
+        // instead of picking 24 bytes out of 72-byte ones (fewer lines per load instruction, and the z-planes it re-reads fit L2)
+        const size_t rs = g_row_stride(g);
         for (int a = 0; a < 3; ++a)
-            for (int b = 0; b < 3; ++b) Gout[9 * (size_t)c + 3 * a + b] = an * (T[3 * b + a] - (a == b ? (2.0 / 3.0) * tr : 0.0));
+            for (int b = 0; b < 3; ++b) Gout[(size_t)a * rs + 3 * (size_t)c + b] = an * (T[3 * b + a] - (a == b ? (2.0 / 3.0) * tr : 0.0));
     }
 }
 
@@ -381,7 +386,7 @@ __global__ __launch_bounds__(256) void k_stress_G(FvGeo g, const double* __restr
     const double tr = tt[0] + tt[4] + tt[8];
     const double an = alpha[c] * g.nu;
     for (int a = 0; a < 3; ++a)
-        for (int b = 0; b < 3; ++b) G[9 * (size_t)c + 3 * a + b] = an * (tt[3 * b + a] - (a == b ? (2.0 / 3.0) * tr : 0.0));
+        for (int b = 0; b < 3; ++b) G[(size_t)a * g_row_stride(g) + 3 * (size_t)c + b] = an * (tt[3 * b + a] - (a == b ? (2.0 / 3.0) * tr : 0.0));
 }
 
 __global__ __launch_bounds__(256) void k_div_G(FvGeo g, const double* __restrict__ G, double* __restrict__ divG) {
@@ -395,8 +400,9 @@ __global__ __launch_bounds__(256) void k_div_G(FvGeo g, const double* __restrict
         double fv[2][3];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            if (onb(g, d, s, i, j, k)) for (int q = 0; q < 3; ++q) fv[s][q] = G[9 * (size_t)c + 3 * d + q];
-            else { const int nb = c + (s ? stride_of(g, d) : -stride_of(g, d)); for (int q = 0; q < 3; ++q) fv[s][q] = 0.5 * (G[9 * (size_t)c + 3 * d + q] + G[9 * (size_t)nb + 3 * d + q]); }
+            const double* Gd = G + (size_t)d * g_row_stride(g);           // row d of the tensor field
+            if (onb(g, d, s, i, j, k)) for (int q = 0; q < 3; ++q) fv[s][q] = Gd[3 * (size_t)c + q];
+            else { const int nb = c + (s ? stride_of(g, d) : -stride_of(g, d)); for (int q = 0; q < 3; ++q) fv[s][q] = 0.5 * (Gd[3 * (size_t)c + q] + Gd[3 * (size_t)nb + q]); }
         }
         for (int q = 0; q < 3; ++q) acc[q] += (fv[1][q] - fv[0][q]) * g.rdx;
     }

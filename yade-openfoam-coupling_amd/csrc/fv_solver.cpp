@@ -536,7 +536,7 @@ struct Solver {
                 // explicit stress term of divDevRhoReff from the CURRENT U and this step's alpha (one fused stencil pass)
                 if (outer > 0) FY_TRY(halo_cells(U, 3, 1));
                 FY_TRY(launch_pre_coupling(stream, g, U.p, p.p, alpha.p, C3(psn), vGrad.p, gradP.p, divT.p, Gt.p, g.upwind == 2 ? 1 : 0, 0));
-                FY_TRY(halo_cells(Gt, 9, 1));
+                FY_TRY(halo(Gt.p + 2 * 3 * nstore, 3, plane, g.nz, g.gz, 1));     // G is stored by rows; only row z is read across the slab faces
                 FY_TRY(launch_div_G(stream, g, Gt.p, divG.p));
             }
             if (g.upwind == 2) FY_TRY(halo_cells(vGrad, 9, 1));      // linearUpwind reads grad(U) of the upwind neighbour (ico: written at step start)
