@@ -51,7 +51,9 @@ struct Solver {
     Comm* comm = nullptr;
     SelfComm self_comm;
 
-    DevBuf<double> U, Uold, p, alpha, alphaOld, uSource, uSourceDrag, uParticle, gradP, divT, vGrad, ddtU;
+    DevBuf<double> U, Uold, p, alpha, uSource, uSourceDrag, uParticle, gradP, divT, vGrad, ddtU;
+    bool phi_fresh = true;      // phi holds the current flux (false between the start-of-step exchange with phiOld and the first flux correction)
+    CFace3 phi_now() const { return phi_fresh ? CFace3{{phi[0].p, phi[1].p, phi[2].p}} : CFace3{{phiOld[0].p, phiOld[1].p, phiOld[2].p}}; }
     bool rAU_new = true;        // rAU was (re)assembled since the last corrector: rAUf and the coarse pressure operators are stale
     DevBuf<double> phi[3], phiOld[3], psn[3], alphaf[3], phiHbyA[3], phiForces[3], rAUf[3], pflux[3];
     DevBuf<double> mdiag, man[6], src, rAU, HbyA, bmom, Gt, divG, xscr;
@@ -148,7 +150,7 @@ struct Solver {
         const size_t n = nstore;
         DevBuf<double>* v3[] = {&U, &Uold, &uSource, &uParticle, &gradP, &divT, &ddtU, &src, &HbyA, &bmom, &divG, &xscr};
         for (auto* b : v3) { FY_TRY(b->alloc_exact(3 * n)); FY_TRY(zero(*b)); }
-        DevBuf<double>* v1[] = {&p, &alpha, &alphaOld, &uSourceDrag, &mdiag, &rAU, &prhs, &pr, &pw, &pp, &pzj};
+        DevBuf<double>* v1[] = {&p, &alpha, &uSourceDrag, &mdiag, &rAU, &prhs, &pr, &pw, &pp, &pzj};
         for (auto* b : v1) { FY_TRY(b->alloc_exact(n)); FY_TRY(zero(*b)); }
         for (auto& b : man) { FY_TRY(b.alloc_exact(n)); FY_TRY(zero(b)); }
         FY_TRY(vGrad.alloc_exact(9 * n)); FY_TRY(zero(vGrad));
@@ -159,7 +161,6 @@ struct Solver {
             FY_TRY(launch_fill_f64(stream, alphaf[d].p, alphaf[d].n, 1.0));
         }
         FY_TRY(launch_fill_f64(stream, alpha.p, n, 1.0));
-        FY_TRY(launch_fill_f64(stream, alphaOld.p, n, 1.0));
         FY_TRY(launch_fill_f64(stream, rAU.p, n, 1.0));            // ghost planes must hold finite values before the first exchange
         FY_TRY(partials.alloc_exact(8 * (size_t)red_blocks(Nc))); FY_TRY(red_out.alloc_exact(8)); FY_TRY(sc.alloc_exact(4)); FY_TRY(xbar3.alloc_exact(3));
         FY_TRY(zero(partials)); FY_TRY(zero(sc)); FY_TRY(zero(red_out));
@@ -467,7 +468,7 @@ struct Solver {
         MgLev& L = *mg[0];
         if (timing) tim[2].start(stream);
         for (int no = 0; no <= cs.n_non_orth_correctors; ++no) {
-            FY_TRY(launch_assemble_pressure(stream, g, C3(phiHbyA), C3(rAUf), C3(alphaf), C3(psn), alpha.p, alphaOld.p, L.A, prhs.p));
+            FY_TRY(launch_assemble_pressure(stream, g, C3(phiHbyA), C3(rAUf), C3(alphaf), C3(psn), alpha.p, /* alphaOld */ alpha.p, L.A, prhs.p));
             if (L.distributed && comm->has_down()) FY_TRY(launch_p_ghost_uz(stream, g, C3(rAUf), C3(alphaf), L.A));
             if (rAU_new) FY_TRY(build_coarse_operators());        // same matrix as in the previous corrector otherwise: only the right-hand side moved
             rAU_new = false;
@@ -475,11 +476,12 @@ struct Solver {
             if (no == cs.n_non_orth_correctors) {
                 FY_TRY(halo_cells(p, 1, 1));
                 FY_TRY(launch_flux_correct(stream, g, p.p, C3(phiHbyA), C3(rAUf), C3(alphaf), C3(psn), F3(pflux), F3(phi)));
+                phi_fresh = true;
             }
         }
         if (timing) { tim[2].stop(stream); st.ms_pressure += tim[2].ms(); }
         double h[2];
-        FY_TRY(launch_cont_err(stream, g, C3(phi), C3(alphaf), alpha.p, alphaOld.p, partials.p));
+        FY_TRY(launch_cont_err(stream, g, C3(phi), C3(alphaf), alpha.p, /* alphaOld */ alpha.p, partials.p));
         FY_TRY(reduce_read(2, false, h));
         const double tv = g.V * (double)Nglob;
         st.cont_err_sum_local = cs.dt * h[0] / tv; st.cont_err_global = cs.dt * h[1] / tv;
@@ -505,13 +507,20 @@ struct Solver {
         FY_TRY(halo_cells(alpha, 1, 1));
         FY_TRY(comm->group_end(stream));
         FY_TRY(launch_copy_f64(stream, Uold.p, U.p, 3 * nstore));
-        for (int d = 0; d < 3; ++d) FY_TRY(launch_copy_f64(stream, phiOld[d].p, phi[d].p, phi[d].n));
+        // phi.oldTime(): the flux arrays trade places instead of being copied -- what was phi is phiOld now, and until the first
+        // flux correction of this step rewrites phi (every face of it) the current flux is read from phiOld (phi_now())
+        if (cs.n_correctors > 0) {
+            for (int d = 0; d < 3; ++d) { std::swap(phi[d].p, phiOld[d].p); std::swap(phi[d].n, phiOld[d].n); }
+            phi_fresh = false;
+        } else {
+            for (int d = 0; d < 3; ++d) FY_TRY(launch_copy_f64(stream, phiOld[d].p, phi[d].p, phi[d].n));
+        }
         // icoFoamYade.C:71, pimpleFoamYade.C:73-76.  pimple: alpha is 1 here (reset by setSourceZero), so G is re-formed after the
         // coupling call with this step's alpha; only gradP / divT are needed now.
         // the opt-in force models (fy_set_force_models on fy_solver_coupling()) read vGrad / ddtU_f, which the shipped path never does
         const unsigned fm = cpl->c.force_models;
         const bool want_vgrad = !pimple || (fm & FY_FORCE_GAUSSIAN_TORQUE), want_ddtU = pimple && (fm & FY_FORCE_ADDED_MASS);
-        FY_TRY(launch_pre_coupling(stream, g, U.p, p.p, alpha.p, C3(psn), vGrad.p, gradP.p, divT.p, nullptr, want_vgrad ? 1 : 0, 1, C3(phi),
+        FY_TRY(launch_pre_coupling(stream, g, U.p, p.p, alpha.p, C3(psn), vGrad.p, gradP.p, divT.p, nullptr, want_vgrad ? 1 : 0, 1, phi_now(),
                                    want_ddtU ? ddtU.p : nullptr));
 
         if (timing) tim[0].start(stream);
@@ -526,8 +535,9 @@ struct Solver {
         if (timing) { tim[0].stop(stream); }
 
         // alphac.oldTime() is captured lazily by OpenFOAM at alphac.correctBoundaryConditions() (pimpleFoamYade.C:83), i.e. after
-        // FoamYade wrote alpha through untracked operator[]: old == current, fvc::ddt(alphac) == 0
-        FY_TRY(launch_copy_f64(stream, alphaOld.p, alpha.p, nstore));
+        // FoamYade wrote alpha through untracked operator[]: old == current, fvc::ddt(alphac) == 0.
+        // The kernels keep their alphaOld argument (the term is written out as in UcEqn.H:5 / pEqn.H:30); it is handed the same array
+        // -- what a copy taken here would hold, without the copy or a second stream of reads.
         if (pimple) FY_TRY(launch_interp_alpha(stream, g, alpha.p, F3(alphaf)));              // pimpleFoamYade.C:83-85 (alpha ghosts refreshed by the coupling)
         const int nOuter = pimple ? std::max(cs.n_outer_correctors, 1) : 1;
         for (int outer = 0; outer < nOuter; ++outer) {
@@ -540,7 +550,7 @@ struct Solver {
                 FY_TRY(launch_div_G(stream, g, Gt.p, divG.p));
             }
             if (g.upwind == 2) FY_TRY(halo_cells(vGrad, 9, 1));      // linearUpwind reads grad(U) of the upwind neighbour (ico: written at step start)
-            FY_TRY(launch_assemble_momentum(stream, g, U.p, Uold.p, alpha.p, alphaOld.p, C3(alphaf), C3(phi), uSource.p, uSourceDrag.p,
+            FY_TRY(launch_assemble_momentum(stream, g, U.p, Uold.p, alpha.p, /* alphaOld */ alpha.p, C3(alphaf), phi_now(), uSource.p, uSourceDrag.p,
                                             divG.p, vGrad.p, M7(), src.p, rAU.p));
             rAU_new = true;
             if (pimple) {
