@@ -21,6 +21,7 @@ def both(product, oracle, solver, nx, ny, nz, dx, dt, nu, **kw):
     pk = dict(kw)
     if "n_outer" in pk: pk["n_outer_correctors"] = pk.pop("n_outer")
     if "n_corr" in pk: pk["n_correctors"] = pk.pop("n_corr")
+    if "n_non_orth" in pk: pk["n_non_orth_correctors"] = pk.pop("n_non_orth")
     pc = product.make_case(solver, nx, ny, nz, dx, dt, nu, g=g, u_bc=u_bc, u_val=u_val, p_bc=p_bc, p_val=p_val, p_solver=p_solver, **pk)
     return oracle.FvSolver(oc), product.Solver(pc)
 
@@ -206,3 +207,27 @@ def test_c5_fluidized_bed_bcs(product, oracle):
         assert np.abs(s.forces() - fo).max() <= 1e-6 * sc
     compare(o, s, rtol=1e-5)
     assert np.abs(fo).max() > 0 and np.abs(s.get("U")).max() > 0       # (alpha itself is reset by setSourceZero at the end of a step)
+
+
+@pytest.mark.parametrize("solver,n_outer,n_corr,n_non_orth", [(1, 2, 1, 0), (1, 3, 2, 0), (1, 1, 3, 1), (0, 1, 1, 0), (0, 1, 3, 1)])
+def test_corrector_counts_match_oracle(product, oracle, solver, n_outer, n_corr, n_non_orth):
+    """pisoControl / pimpleControl loop counts other than the stock nOuter = 1, nCorr = 2 (icoFoamYade.C:97, pimpleFoamYade.C:91-105):
+    the second outer iteration assembles its momentum matrix from the flux the first one corrected (the product exchanges phi and
+    phiOld at the start of a step and reads the current flux from wherever it is), and one momentum assembly's correctors share rAUf
+    and the coarse pressure operators."""
+    n = 16
+    dx = 0.1 / n
+    kw = dict(g=(0, 0, -9.81), p_bc=[2] * 6) if solver == 1 else cavity_bcs()
+    u_val = [(0, 0, 0)] * 6
+    u_val[YMAX] = (0.3, 0, 0)
+    kw.setdefault("u_bc", [0] * 6); kw["u_val"] = u_val
+    o, s = both(product, oracle, solver, n, n, n, dx, 2e-4, 1e-4, n_outer=n_outer, n_corr=n_corr, n_non_orth=n_non_orth, **kw)
+    case = gc.Case("cnt", n, n, n, 0.1, gaussian=solver, np_=1500, seed=23, cluster=100, fast=10, vel_scale=0.05)
+    for step in range(4):
+        rec = gc.particle_records(case, step)
+        o.step(rec)
+        s.set_particles(rec)
+        s.step()
+        so, ss = o.stats(), s.stats()
+        assert so["p_solves"] == ss["p_solves"] == n_outer * n_corr * (n_non_orth + 1)
+    compare(o, s, rtol=1e-5)
