@@ -160,22 +160,6 @@ __global__ __launch_bounds__(256) void k_interp_rAU(FvGeo g, const double* __res
     else { const int c = cidx(g, i, j, k); rf[f] = 0.5 * (rAU[c - stride_of(g, D)] + rAU[c]); }
 }
 
-// phicForces = fvc::flux(rAUc*uSource) + rAUcf*(g & Sf)   UcEqn.H:17-20 (uSource's calculated boundary value is 0)
-template <int D>
-__global__ __launch_bounds__(256) void k_phi_forces(FvGeo g, const double* __restrict__ rAU, const double* __restrict__ rAUf,
-                                                    const double* __restrict__ uSource, double* __restrict__ out) {
-    const size_t f = (size_t)blockIdx.x * 256 + threadIdx.x;
-    int i, j, k;
-    if (!face_ijk(g, D, f, i, j, k)) return;
-    const int q = D == 0 ? i : D == 1 ? j : k;
-    double fl = 0.0;
-    if (!face_low_b(g, D, q) && !face_high_b(g, D, q)) {
-        const int c = cidx(g, i, j, k), cm = c - stride_of(g, D);
-        fl = 0.5 * (rAU[cm] * uSource[3 * (size_t)cm + D] + rAU[c] * uSource[3 * (size_t)c + D]) * g.Af;
-    }
-    out[f] = fl + rAUf[f] * (g.g[D] * g.Af);
-}
-
 // Every face of the block exactly once from a cell-centred sweep: an owned cell does its three low faces, and the high face where it
 // is the last cell of its row / column / slab.  One pass over the cell fields instead of one per direction (the three per-direction
 // launches each pulled the whole AoS vector fields through for one component: 264 -> 168 B/cell for phiHbyA); same arithmetic per face.
@@ -186,7 +170,8 @@ __global__ __launch_bounds__(256) void k_phi_forces(FvGeo g, const double* __res
         CALL(2, i, j, k); if (k == g.nz - 1) CALL(2, i, j, k + 1); \
     } while (0)
 
-// rAUcf = fvc::interpolate(rAUc) and phicForces in one cell-centred sweep (UcEqn.H:15-20): k_interp_rAU<D> + k_phi_forces<D>, D = 0..2
+// rAUcf = fvc::interpolate(rAUc) and phicForces = fvc::flux(rAUc*uSource) + rAUcf*(g & Sf) in one cell-centred sweep (UcEqn.H:15-20;
+// uSource's calculated boundary value is 0)
 template <int D>
 __device__ __forceinline__ void rAUf_phi_forces_face(const FvGeo& g, size_t f, int i, int j, int k, const double* __restrict__ rAU,
                                                      const double* __restrict__ uSource, double* __restrict__ rf, double* __restrict__ out) {
@@ -375,20 +360,7 @@ __global__ __launch_bounds__(256) void k_pre_coupling(FvGeo g, const double* __r
     }
 }
 
-// explicit part of divDevRhoReff (laminar Stokes): G = alpha nu dev2(T(grad U))
-__global__ __launch_bounds__(256) void k_stress_G(FvGeo g, const double* __restrict__ vGrad, const double* __restrict__ alpha, double* __restrict__ G) {
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= g.Nc) return;
-    const int c = t + g.c0;
-    const double* T = vGrad + 9 * (size_t)c;
-    double tt[9];
-    for (int q = 0; q < 9; ++q) tt[q] = T[q];
-    const double tr = tt[0] + tt[4] + tt[8];
-    const double an = alpha[c] * g.nu;
-    for (int a = 0; a < 3; ++a)
-        for (int b = 0; b < 3; ++b) G[(size_t)a * g_row_stride(g) + 3 * (size_t)c + b] = an * (tt[3 * b + a] - (a == b ? (2.0 / 3.0) * tr : 0.0));
-}
-
+// divergence of the explicit part of divDevRhoReff (laminar Stokes), G = alpha nu dev2(T(grad U)) formed by k_pre_coupling, stored by rows
 __global__ __launch_bounds__(256) void k_div_G(FvGeo g, const double* __restrict__ G, double* __restrict__ divG) {
     const int t = swz_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
     if (t >= g.Nc) return;
@@ -1114,12 +1086,6 @@ int launch_interp_alpha(hipStream_t s, FvGeo g, const double* alpha, Face3 af) {
     return FY_OK;
 }
 
-int launch_stress_G(hipStream_t s, FvGeo g, const double* vGrad, const double* alpha, double* G) {
-    hipLaunchKernelGGL(k_stress_G, dim3(div_up(g.Nc, 256)), dim3(256), 0, s, g, vGrad, alpha, G);
-    FY_LAUNCH_CHECK();
-    return FY_OK;
-}
-
 int launch_div_G(hipStream_t s, FvGeo g, const double* G, double* divG) {
     hipLaunchKernelGGL(k_div_G, dim3(div_up(g.Nc, 256)), dim3(256), 0, s, g, G, divG);
     FY_LAUNCH_CHECK();
@@ -1139,14 +1105,6 @@ int launch_interp_rAU(hipStream_t s, FvGeo g, const double* rAU, Face3 rf) {
     hipLaunchKernelGGL(k_interp_rAU<0>, dim3(div_up(fv_fsize(g, 0), 256)), dim3(256), 0, s, g, rAU, rf.a[0]);
     hipLaunchKernelGGL(k_interp_rAU<1>, dim3(div_up(fv_fsize(g, 1), 256)), dim3(256), 0, s, g, rAU, rf.a[1]);
     hipLaunchKernelGGL(k_interp_rAU<2>, dim3(div_up(fv_fsize(g, 2), 256)), dim3(256), 0, s, g, rAU, rf.a[2]);
-    FY_LAUNCH_CHECK();
-    return FY_OK;
-}
-
-int launch_phi_forces(hipStream_t s, FvGeo g, const double* rAU, CFace3 rAUf, const double* uSource, Face3 out) {
-    hipLaunchKernelGGL(k_phi_forces<0>, dim3(div_up(fv_fsize(g, 0), 256)), dim3(256), 0, s, g, rAU, rAUf.a[0], uSource, out.a[0]);
-    hipLaunchKernelGGL(k_phi_forces<1>, dim3(div_up(fv_fsize(g, 1), 256)), dim3(256), 0, s, g, rAU, rAUf.a[1], uSource, out.a[1]);
-    hipLaunchKernelGGL(k_phi_forces<2>, dim3(div_up(fv_fsize(g, 2), 256)), dim3(256), 0, s, g, rAU, rAUf.a[2], uSource, out.a[2]);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }

@@ -61,14 +61,13 @@ int launch_pre_coupling(hipStream_t s, FvGeo g, const double* U, const double* p
                         double* vGrad, double* gradP, double* divT, double* Gout, int write_vgrad, int write_pfields,
                         CFace3 phi = CFace3{}, double* ddtU = nullptr);
 int launch_interp_alpha(hipStream_t s, FvGeo g, const double* alpha, Face3 alphaf);
-int launch_stress_G(hipStream_t s, FvGeo g, const double* vGrad, const double* alpha, double* G);
+// G: three vec3 fields (rows of the tensor) over the whole storage, as k_pre_coupling writes them
 int launch_div_G(hipStream_t s, FvGeo g, const double* G, double* divG);
 int launch_assemble_momentum(hipStream_t s, FvGeo g, const double* U, const double* Uold, const double* alpha, const double* alphaOld,
                              CFace3 alphaf, CFace3 phi, const double* uSource, const double* uSourceDrag, const double* divG,
                              const double* vGrad /* grad(U) of the current iterate: linearUpwind only */, Mom7 M, double* src, double* rAU);
 int launch_interp_rAU(hipStream_t s, FvGeo g, const double* rAU, Face3 rAUf);
-int launch_phi_forces(hipStream_t s, FvGeo g, const double* rAU, CFace3 rAUf, const double* uSource, Face3 phiForces);
-// launch_interp_rAU + launch_phi_forces as one cell-centred sweep (same values)
+// rAUf = interpolate(rAU) and phiForces (UcEqn.H:15-20) as one cell-centred sweep
 int launch_rAUf_phi_forces(hipStream_t s, FvGeo g, const double* rAU, const double* uSource, Face3 rf, Face3 out);
 int launch_bmom(hipStream_t s, FvGeo g, const double* src, const double* p, CFace3 psn, CFace3 phiForces, CFace3 rAUf, double* bmom);
 // one fused Jacobi pass: residual sums of x (slots 0..2), norm-factor sums (slots 3..5, uses xbar[3]) and xn = next iterate
