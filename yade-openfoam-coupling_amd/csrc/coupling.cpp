@@ -215,6 +215,30 @@ int Coupling::create(const fy_mesh_desc* m, const fy_field_ptrs* f, int gaussian
     return FY_OK;
 }
 
+// per-cell start nodes of the walk and per-(cell, octant) candidate lists (implicit trees, Gaussian mode): built once per mesh, at
+// create time (init_fields) so that no step pays for them; see k_build_locate_start / k_build_locate_lists
+int Coupling::ensure_locate_tables(double maxdist) {
+    if (!use_implicit) return FY_OK;
+    static const bool no_start = getenv("FOAMYADE_NO_LOCATE_START") != nullptr;      // A/B switch
+    if (!no_start && !d_loc_start.p) {
+        FY_TRY(d_loc_start.alloc_exact((size_t)n_cells));
+        FY_TRY(launch_build_locate_start(stream, d_tree_packed.p, implicit, n_cells, maxdist, d_loc_start.p));
+    }
+    // candidate lists: 384 B per cell; valid while the rounding of a coordinate stays far below the builder's margins
+    static const bool no_lists = getenv("FOAMYADE_NO_LOCATE_LISTS") != nullptr;      // A/B switch
+    if (!no_lists && !loc_lists_tried) {
+        loc_lists_tried = true;
+        const double ext = std::max({std::fabs(implicit.ox), std::fabs(implicit.oy), std::fabs(implicit.oz), std::fabs(implicit.ox + implicit.nx * implicit.dx),
+                                     std::fabs(implicit.oy + implicit.ny * implicit.dx), std::fabs(implicit.oz + implicit.nz * implicit.dx)});
+        if (ext / implicit.dx <= 1e6 && d_loc_lists.alloc_exact((size_t)n_cells * 8 * kLocateListLen) == FY_OK && d_loc_fb_n.alloc_exact(1) == FY_OK) {
+            FY_TRY(launch_build_locate_lists(stream, d_tree_packed.p, implicit, n_cells, maxdist, d_loc_lists.p));
+        } else {
+            d_loc_lists.release();               // not enough memory (or far-from-origin coordinates): the walk does all particles
+        }
+    }
+    return FY_OK;
+}
+
 // FoamYade::initFields FoamYade.C:56-73
 int Coupling::init_fields() {
     FY_TRY(launch_set_source_zero(stream, (int32_t)n_field, gaussian ? 1 : 0, dUSourceDrag, dAlpha, dUSource, dUParticle));
@@ -224,6 +248,7 @@ int Coupling::init_fields() {
     interp_range_cu = std::pow(interp_range, 3.0);                         // FoamYade.C:71
     sigma_pi = 1.0 / (std::pow(2 * M_PI * sigma_interp * sigma_interp, 1.5));   // FoamYade.C:72
     if (fields_on_host) FY_TRY(stage_mutable_out());
+    if (gaussian) FY_TRY(ensure_locate_tables((interp_range * interp_range) + (0.25 * interp_range * interp_range)));   // maxdist, meshTree.C:155
     return FY_OK;
 }
 
@@ -411,23 +436,7 @@ int Coupling::run_batch(Batch& b) {
         gp.maxdist = (interp_range * interp_range) + (0.25 * interp_range * interp_range);   // meshTree.C:155
         gp.two_sigma2 = 2 * std::pow(sigma_interp, 2);                                         // FoamYade.C:308
         gp.range_cu = interp_range_cu; gp.sigma_pi = sigma_pi;
-        static const bool no_start = getenv("FOAMYADE_NO_LOCATE_START") != nullptr;      // A/B switch
-        if (use_implicit && !no_start && !d_loc_start.p) {
-            FY_TRY(d_loc_start.alloc_exact((size_t)n_cells));
-            FY_TRY(launch_build_locate_start(stream, d_tree_packed.p, implicit, n_cells, gp.maxdist, d_loc_start.p));
-        }
-        // candidate lists: 384 B per cell; valid while the rounding of a coordinate stays far below the builder's margins
-        static const bool no_lists = getenv("FOAMYADE_NO_LOCATE_LISTS") != nullptr;      // A/B switch
-        if (use_implicit && !no_lists && !loc_lists_tried) {
-            loc_lists_tried = true;
-            const double ext = std::max({std::fabs(implicit.ox), std::fabs(implicit.oy), std::fabs(implicit.oz), std::fabs(implicit.ox + implicit.nx * implicit.dx),
-                                         std::fabs(implicit.oy + implicit.ny * implicit.dx), std::fabs(implicit.oz + implicit.nz * implicit.dx)});
-            if (ext / implicit.dx <= 1e6 && d_loc_lists.alloc_exact((size_t)n_cells * 8 * kLocateListLen) == FY_OK && d_loc_fb_n.alloc_exact(1) == FY_OK) {
-                FY_TRY(launch_build_locate_lists(stream, d_tree_packed.p, implicit, n_cells, gp.maxdist, d_loc_lists.p));
-            } else {
-                d_loc_lists.release();               // not enough memory (or far-from-origin coordinates): the walk does all particles
-            }
-        }
+        FY_TRY(ensure_locate_tables(gp.maxdist));
         LocateLists ll{};
         if (use_implicit && d_loc_lists.p) {
             if (d_loc_fb.n < (size_t)b.n) FY_TRY(d_loc_fb.alloc_exact((size_t)b.n + (size_t)b.n / 8));

@@ -73,6 +73,7 @@ struct Coupling {
     DevBuf<int32_t> d_loc_fb;                 // particles the lists do not cover (work list of the walk) + their count
     DevBuf<unsigned int> d_loc_fb_n;
     bool loc_lists_tried = false;
+    int ensure_locate_tables(double maxdist);
     ImplicitGeom implicit{};
     bool use_implicit = false;
     int tree_levels = 0;
