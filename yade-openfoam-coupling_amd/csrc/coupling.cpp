@@ -230,8 +230,12 @@ int Coupling::ensure_locate_tables(double maxdist) {
         loc_lists_tried = true;
         const double ext = std::max({std::fabs(implicit.ox), std::fabs(implicit.oy), std::fabs(implicit.oz), std::fabs(implicit.ox + implicit.nx * implicit.dx),
                                      std::fabs(implicit.oy + implicit.ny * implicit.dx), std::fabs(implicit.oz + implicit.nz * implicit.dx)});
-        if (ext / implicit.dx <= 1e6 && d_loc_lists.alloc_exact((size_t)n_cells * 8 * kLocateListLen) == FY_OK && d_loc_fb_n.alloc_exact(1) == FY_OK) {
-            FY_TRY(launch_build_locate_lists(stream, d_tree_packed.p, implicit, n_cells, maxdist, d_loc_lists.p));
+        // a slab only ever places particles whose cell lies in its own planes (SlabOwn): lists for those cells only
+        const int64_t pl = (int64_t)implicit.nx * implicit.ny;
+        loc_cell0 = slab.active ? (int32_t)((int64_t)slab.kglob0 * pl) : 0;
+        loc_n_listed = slab.active ? (int32_t)((int64_t)slab.nz * pl) : n_cells;
+        if (ext / implicit.dx <= 1e6 && d_loc_lists.alloc_exact((size_t)loc_n_listed * 8 * kLocateListLen) == FY_OK && d_loc_fb_n.alloc_exact(1) == FY_OK) {
+            FY_TRY(launch_build_locate_lists(stream, d_tree_packed.p, implicit, n_cells, maxdist, d_loc_lists.p, loc_cell0, loc_n_listed));
         } else {
             d_loc_lists.release();               // not enough memory (or far-from-origin coordinates): the walk does all particles
         }
@@ -440,7 +444,7 @@ int Coupling::run_batch(Batch& b) {
         LocateLists ll{};
         if (use_implicit && d_loc_lists.p) {
             if (d_loc_fb.n < (size_t)b.n) FY_TRY(d_loc_fb.alloc_exact((size_t)b.n + (size_t)b.n / 8));
-            ll = LocateLists{d_loc_lists.p, d_loc_fb.p, d_loc_fb_n.p};
+            ll = LocateLists{d_loc_lists.p, d_loc_fb.p, d_loc_fb_n.p, loc_cell0, loc_n_listed};
         }
         const CellWindow cw{slab.active ? slab.base : 0, n_field};
         static const bool unfused = getenv("FOAMYADE_UNFUSED_DEPOSIT") != nullptr;      // A/B switch: k_locate_lists + k_deposit

@@ -73,6 +73,7 @@ struct Coupling {
     DevBuf<int32_t> d_loc_fb;                 // particles the lists do not cover (work list of the walk) + their count
     DevBuf<unsigned int> d_loc_fb_n;
     bool loc_lists_tried = false;
+    int32_t loc_cell0 = 0, loc_n_listed = 0;  // cells the lists cover (a slab: its own planes)
     int ensure_locate_tables(double maxdist);
     ImplicitGeom implicit{};
     bool use_implicit = false;

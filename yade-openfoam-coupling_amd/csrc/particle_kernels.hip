@@ -244,10 +244,10 @@ __device__ __forceinline__ double ax_min2(double lo, double hi, double x) { cons
 __device__ __forceinline__ double ax_max2(double lo, double hi, double x) { const double g = fmax(fabs(lo - x), fabs(hi - x)); return g * g; }
 
 __global__ __launch_bounds__(256) void k_build_locate_lists(const uint32_t* __restrict__ packed, ImplicitGeom ig, int32_t n_cells, double md,
-                                                            unsigned short* __restrict__ lists) {
-    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (t >= (size_t)n_cells * 8) return;
-    const int cell = (int)(t >> 3), oct = (int)(t & 7);
+                                                            unsigned short* __restrict__ lists, int32_t cell0, int32_t n_listed) {
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;       // list number: (cell - cell0) * 8 + octant, cells [cell0, cell0 + n_listed)
+    if (t >= (size_t)n_listed * 8) return;
+    const int cell = cell0 + (int)(t >> 3), oct = (int)(t & 7);
     const int c[3] = {cell % ig.nx, (cell / ig.nx) % ig.ny, cell / (ig.nx * ig.ny)};
     double lo[3], hi[3];
     for (int a = 0; a < 3; ++a) {
@@ -321,8 +321,10 @@ __global__ __launch_bounds__(256) void k_build_locate_lists(const uint32_t* __re
 }
 
 // one lane per particle; particles the lists do not cover are appended to (fb_list, fb_count) for the walk
-__global__ __launch_bounds__(256) void k_locate_lists(const unsigned short* __restrict__ lists, ImplicitGeom ig, ParticleSoA p, int64_t n, double maxdist,
-                                                      SlabOwn own, int32_t* __restrict__ fb_list, unsigned int* __restrict__ fb_count) {
+__global__ __launch_bounds__(256) void k_locate_lists(LocateLists ll, ImplicitGeom ig, ParticleSoA p, int64_t n, double maxdist, SlabOwn own) {
+    const unsigned short* __restrict__ lists = ll.lists;
+    int32_t* __restrict__ fb_list = ll.fb_list;
+    unsigned int* __restrict__ fb_count = ll.fb_count;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const double qx = p.px[i], qy = p.py[i], qz = p.pz[i];
@@ -344,10 +346,13 @@ __global__ __launch_bounds__(256) void k_locate_lists(const unsigned short* __re
     if (ok) {
         const double cx = ig.ox + (double)(2 * ci + 1) * hdx, cy = ig.oy + (double)(2 * cj + 1) * hdx, cz = ig.oz + (double)(2 * ck + 1) * hdx;
         const int oct = (qx - cx < 0.0 ? 0 : 1) | (qy - cy < 0.0 ? 0 : 2) | (qz - cz < 0.0 ? 0 : 4);
-        const size_t cell = (size_t)ci + (size_t)ig.nx * ((size_t)cj + (size_t)ig.ny * (size_t)ck);
-        row = reinterpret_cast<const uint4*>(lists + (cell * 8 + (size_t)oct) * kListLen);
-        v = row[0];
-        ok = (v.x & 0xffffu) != kListOverflow;
+        const int64_t cell = (int64_t)ci + (int64_t)ig.nx * ((int64_t)cj + (int64_t)ig.ny * (int64_t)ck) - ll.cell0;
+        ok = cell >= 0 && cell < ll.n_listed;                    // (a slab lists its own planes only)
+        if (ok) {
+            row = reinterpret_cast<const uint4*>(lists + ((size_t)cell * 8 + (size_t)oct) * kListLen);
+            v = row[0];
+            ok = (v.x & 0xffffu) != kListOverflow;
+        }
     }
     if (!ok) {
         const unsigned int at = atomicAdd(fb_count, 1u);
@@ -642,10 +647,12 @@ __global__ __launch_bounds__(kDepThreads) void k_deposit(ParticleSoA p, int64_t 
 // node in a register (zero where the node did not enter the chain; slots are static because the scan is unrolled), so the chain's
 // squared distances never travel through memory: ids and NORMALISED weights are stored once, for k_force_gaussian.  Same arithmetic
 // as the two kernels: allwt adds the weights from the last push to the first (adding the zeros in between is exact).
-__global__ __launch_bounds__(kDepThreads) void k_locate_deposit(const unsigned short* __restrict__ lists, ImplicitGeom ig, ParticleSoA p, int64_t n,
+__global__ __launch_bounds__(kDepThreads) void k_locate_deposit(LocateLists ll, ImplicitGeom ig, ParticleSoA p, int64_t n,
                                                                  GaussParams gp, SlabOwn own, CellWindow cw, double* __restrict__ pvol_acc,
-                                                                 double* __restrict__ up_acc, unsigned char* __restrict__ touched,
-                                                                 int32_t* __restrict__ fb_list, unsigned int* __restrict__ fb_count) {
+                                                                 double* __restrict__ up_acc, unsigned char* __restrict__ touched) {
+    const unsigned short* __restrict__ lists = ll.lists;
+    int32_t* __restrict__ fb_list = ll.fb_list;
+    unsigned int* __restrict__ fb_count = ll.fb_count;
     __shared__ uint32_t keys[1 << kDepLog2];
     __shared__ double vals[(1 << kDepLog2) * 4];
     for (int q = threadIdx.x; q < (1 << kDepLog2); q += kDepThreads) {
@@ -677,10 +684,13 @@ __global__ __launch_bounds__(kDepThreads) void k_locate_deposit(const unsigned s
             if (ok) {
                 const double cx = ig.ox + (double)(2 * ci + 1) * hdx, cy = ig.oy + (double)(2 * cj + 1) * hdx, cz = ig.oz + (double)(2 * ck + 1) * hdx;
                 const int oct = (qx - cx < 0.0 ? 0 : 1) | (qy - cy < 0.0 ? 0 : 2) | (qz - cz < 0.0 ? 0 : 4);
-                const size_t cell = (size_t)ci + (size_t)ig.nx * ((size_t)cj + (size_t)ig.ny * (size_t)ck);
-                const uint4* row = reinterpret_cast<const uint4*>(lists + (cell * 8 + (size_t)oct) * kListLen);
-                v[0] = row[0];
-                ok = (v[0].x & 0xffffu) != kListOverflow;
+                const int64_t cell = (int64_t)ci + (int64_t)ig.nx * ((int64_t)cj + (int64_t)ig.ny * (int64_t)ck) - ll.cell0;
+                ok = cell >= 0 && cell < ll.n_listed;            // (a slab lists its own planes only)
+                const uint4* row = reinterpret_cast<const uint4*>(lists + ((size_t)(ok ? cell : 0) * 8 + (size_t)oct) * kListLen);
+                if (ok) {
+                    v[0] = row[0];
+                    ok = (v[0].x & 0xffffu) != kListOverflow;
+                }
                 if (ok) {
                     // the second and third chunk only where the list goes on (its last code is not the end mark)
                     if ((v[0].w >> 16) != kListEnd) { v[1] = row[1]; if ((v[1].w >> 16) != kListEnd) v[2] = row[2]; }
@@ -1123,7 +1133,7 @@ int launch_locate(hipStream_t s, const KdNode* tree, const uint32_t* packed, Imp
     if (packed && ll.lists) {
         // the lists place almost every particle; the walk below takes what is left (usually nothing: its waves read a zero count and exit)
         FY_HIP(hipMemsetAsync(ll.fb_count, 0, sizeof(unsigned int), s));
-        hipLaunchKernelGGL(k_locate_lists, dim3(div_up(n, 256)), dim3(256), 0, s, ll.lists, ig, p, n, gp.maxdist, own, ll.fb_list, ll.fb_count);
+        hipLaunchKernelGGL(k_locate_lists, dim3(div_up(n, 256)), dim3(256), 0, s, ll, ig, p, n, gp.maxdist, own);
         FY_LAUNCH_CHECK();
         const dim3 wgrid((unsigned)std::min<int64_t>(div_up(n, kLocPPB), 2048));
         hipLaunchKernelGGL(k_locate<true>, wgrid, dim3(kWave), lds, s, tree, packed, ig, n_cells, p, n, gp.maxdist, start, SlabOwn{}, ll.fb_list, ll.fb_count);
@@ -1136,9 +1146,10 @@ int launch_locate(hipStream_t s, const KdNode* tree, const uint32_t* packed, Imp
     return FY_OK;
 }
 
-int launch_build_locate_lists(hipStream_t s, const uint32_t* packed, ImplicitGeom ig, int32_t n_cells, double maxdist, unsigned short* lists) {
+int launch_build_locate_lists(hipStream_t s, const uint32_t* packed, ImplicitGeom ig, int32_t n_cells, double maxdist, unsigned short* lists,
+                              int32_t cell0, int32_t n_listed) {
     const double md_cells = maxdist / (ig.dx * ig.dx);
-    hipLaunchKernelGGL(k_build_locate_lists, dim3(div_up((int64_t)n_cells * 8, 256)), dim3(256), 0, s, packed, ig, n_cells, md_cells, lists);
+    hipLaunchKernelGGL(k_build_locate_lists, dim3(div_up((int64_t)n_listed * 8, 256)), dim3(256), 0, s, packed, ig, n_cells, md_cells, lists, cell0, n_listed);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }
@@ -1154,8 +1165,7 @@ int launch_locate_deposit(hipStream_t s, const KdNode* tree, const uint32_t* pac
     if (n_cells >= (1 << 25)) return fail(FY_ERR_UNSUPPORTED, "implicit-coordinate tree limited to 2^25 cells");
     // the lists place and deposit almost every particle; the walk + k_deposit pair takes what is left (usually nothing: zero count, exit)
     FY_HIP(hipMemsetAsync(ll.fb_count, 0, sizeof(unsigned int), s));
-    hipLaunchKernelGGL(k_locate_deposit, dim3(div_up(n, kDepThreads)), dim3(kDepThreads), 0, s, ll.lists, ig, p, n, gp, own, cw, pvol_acc, up_acc, touched,
-                       ll.fb_list, ll.fb_count);
+    hipLaunchKernelGGL(k_locate_deposit, dim3(div_up(n, kDepThreads)), dim3(kDepThreads), 0, s, ll, ig, p, n, gp, own, cw, pvol_acc, up_acc, touched);
     FY_LAUNCH_CHECK();
     const size_t lds = (size_t)(levels + 1) * kWave * sizeof(unsigned long long);
     const dim3 wgrid((unsigned)std::min<int64_t>(div_up(n, kLocPPB), 2048));

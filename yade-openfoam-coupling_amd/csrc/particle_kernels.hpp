@@ -73,13 +73,15 @@ struct LocateLists {
     const unsigned short* lists;
     int32_t* fb_list;
     unsigned int* fb_count;
+    int32_t cell0, n_listed;             // the lists cover cells [cell0, cell0 + n_listed): the whole block, or a slab's own planes
 };
 constexpr int kLocateListLen = 24;       // codes (2 B) per (cell, octant)
 int launch_locate(hipStream_t s, const KdNode* tree, const uint32_t* packed, ImplicitGeom ig, int32_t n_cells, int levels,
                   ParticleSoA p, int64_t n, GaussParams gp, const unsigned long long* start = nullptr, SlabOwn own = SlabOwn{},
                   LocateLists ll = LocateLists{});
-// lists: n_cells * 8 * kLocateListLen codes.  See k_build_locate_lists for what a list is and why scanning it reproduces the walk.
-int launch_build_locate_lists(hipStream_t s, const uint32_t* packed, ImplicitGeom ig, int32_t n_cells, double maxdist, unsigned short* lists);
+// lists: n_listed * 8 * kLocateListLen codes, for the cells [cell0, cell0 + n_listed).  See k_build_locate_lists for what a list is and why scanning it reproduces the walk.
+int launch_build_locate_lists(hipStream_t s, const uint32_t* packed, ImplicitGeom ig, int32_t n_cells, double maxdist, unsigned short* lists,
+                              int32_t cell0, int32_t n_listed);
 // For every cell of the block: the deepest tree node a walk for a query inside that cell is guaranteed to reach with an empty
 // stack and an empty chain (entry: offset | size << 25 | axis << 50).  See k_build_locate_start.
 int launch_build_locate_start(hipStream_t s, const uint32_t* packed, ImplicitGeom ig, int32_t n_cells, double maxdist, unsigned long long* start);
