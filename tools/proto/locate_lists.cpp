@@ -1,4 +1,5 @@
-// Prototype (host): per-(cell, octant) candidate lists for the k-d "range" locate, checked against the plain walk.
+// Host restatement of k_build_locate_lists / k_locate_lists (particle_kernels.hip): per-(cell, octant) candidate lists for the k-d
+// "range" locate, checked against the plain walk on random and extreme queries.  Test infrastructure (tests/test_locate_lists_host.py).
 //   g++ -O2 -std=c++17 -I../../yade-openfoam-coupling_amd/csrc locate_lists.cpp ../../yade-openfoam-coupling_amd/csrc/kdtree.cpp -o /tmp/locate_lists -lpthread
 #include <cmath>
 #include <cstdio>
@@ -48,7 +49,7 @@ static std::vector<Pair> walk(double qx, double qy, double qz, double maxdist, i
 }
 
 // ---- list builder, lattice units (cell centre of index i at coordinate i)
-constexpr double EPS = 1e-6, MARGIN = 1e-9;
+constexpr double EPS = 4e-6, MARGIN = 1e-8;      // = kListEps, kListMargin of particle_kernels.hip
 struct Box { double lo[3], hi[3]; };
 struct Cand { int x[3]; bool noemit; };
 static inline double ax_min2(double lo, double hi, double x) { double g = x < lo ? lo - x : (x > hi ? x - hi : 0.0); return g * g; }
@@ -139,8 +140,8 @@ int main(int argc, char** argv) {
             for (int t = 0; t < qper; ++t) {
                 double q[3];
                 for (int a = 0; a < 3; ++a) {
-                    double f = U(rng) * (0.5 - 4e-6) + 2e-6;          // inside the shrunk half
-                    if (t < 8) f = (t & 1) ? 2.0e-6 : 0.5 - 2.0e-6;                      // extremes
+                    double f = U(rng) * (0.5 - 1.6e-5) + 8e-6;         // inside the shrunk half (the kernel hands over anything closer than 8e-6 dx to a face)
+                    if (t < 8) f = (t & 1) ? 1e-9 : 0.5 - 8.0e-6;                         // extremes: next to the centre plane / at the hand-over distance from the face
                     const double org = a == 0 ? OX : a == 1 ? OY : OZ;
                     q[a] = ((oct >> a) & 1) ? org + (c[a] + 0.5 + f) * DX : org + (c[a] + 0.5 - f) * DX;
                     if (t == 9) q[a] = org + (double)(2 * c[a] + 1) * (0.5 * DX);         // the centre itself
