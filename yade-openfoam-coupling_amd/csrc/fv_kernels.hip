@@ -489,9 +489,11 @@ __global__ __launch_bounds__(256) void k_bmom(FvGeo g, const double* __restrict_
 // One fused Jacobi pass over the 3 velocity components: with x the current iterate, accumulate the L1 residual |b - A x|
 // (slots 0..2), the lduMatrix normalisation sum |A x - A xbar| + |b - A xbar| (slots 3..5) and write the next iterate xn.
 __global__ __launch_bounds__(256) void k_mom_pass(FvGeo g, Mom7 M, const double* __restrict__ b, const double* __restrict__ x,
-                                                  double* __restrict__ xn, const double* __restrict__ xbar, double* __restrict__ partials) {
+                                                  double* __restrict__ xn, const double* __restrict__ xsum, double n_glob, double* __restrict__ partials) {
     double v[6] = {0, 0, 0, 0, 0, 0};
-    const double xb[3] = {xbar[0], xbar[1], xbar[2]};
+    // xbar = average(x) (lduMatrix::solver::normFactor): the component sums stay on the device (k_sum3 + fold [+ all-reduce]); dividing
+    // them here saves the host round trip the average used to make
+    const double xb[3] = {xsum[0] / n_glob, xsum[1] / n_glob, xsum[2] / n_glob};
     FY_RED_LOOP(t, g.Nc) {
         int i, j, k; ijk_of(g, t, i, j, k);
         const int c = t + g.c0;
@@ -1115,8 +1117,8 @@ int launch_bmom(hipStream_t s, FvGeo g, const double* src, const double* p, CFac
     return FY_OK;
 }
 
-int launch_mom_pass(hipStream_t s, FvGeo g, Mom7 M, const double* b, const double* x, double* xn, const double* xbar, double* partials) {
-    hipLaunchKernelGGL(k_mom_pass, dim3(red_blocks(g.Nc)), dim3(256), 0, s, g, M, b, x, xn, xbar, partials);
+int launch_mom_pass(hipStream_t s, FvGeo g, Mom7 M, const double* b, const double* x, double* xn, const double* xsum, double n_glob, double* partials) {
+    hipLaunchKernelGGL(k_mom_pass, dim3(red_blocks(g.Nc)), dim3(256), 0, s, g, M, b, x, xn, xsum, n_glob, partials);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }

@@ -71,7 +71,8 @@ int launch_interp_rAU(hipStream_t s, FvGeo g, const double* rAU, Face3 rAUf);
 int launch_rAUf_phi_forces(hipStream_t s, FvGeo g, const double* rAU, const double* uSource, Face3 rf, Face3 out);
 int launch_bmom(hipStream_t s, FvGeo g, const double* src, const double* p, CFace3 psn, CFace3 phiForces, CFace3 rAUf, double* bmom);
 // one fused Jacobi pass: residual sums of x (slots 0..2), norm-factor sums (slots 3..5, uses xbar[3]) and xn = next iterate
-int launch_mom_pass(hipStream_t s, FvGeo g, Mom7 M, const double* b, const double* x, double* xn, const double* xbar, double* partials);
+int launch_mom_pass(hipStream_t s, FvGeo g, Mom7 M, const double* b, const double* x, double* xn, const double* xsum /* [3] component sums of x (device) */,
+                    double n_glob, double* partials);
 int launch_sum3(hipStream_t s, const double* x, int n, double* partials);                                  // slots 0..2 = component sums
 int launch_HbyA(hipStream_t s, FvGeo g, Mom7 M, const double* src, const double* U, const double* rAU, double* HbyA);
 int launch_phiHbyA(hipStream_t s, FvGeo g, const double* HbyA, const double* U, const double* Uold, CFace3 phiOld, CFace3 rAUf,

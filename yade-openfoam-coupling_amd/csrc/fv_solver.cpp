@@ -64,7 +64,7 @@ struct Solver {
     DevBuf<double> partials, red_out, sc, xbar3;
     bool hold_sources = false, sources_pending = false;
     bool overlap_halos = true;            // FOAMYADE_NO_HALO_OVERLAP=1: serial schedule (A/B switch, same results)
-    double* red_host = nullptr;           // 8 doubles of mapped pinned host memory (+ its device alias): reduce_read's landing zone
+    double* red_host = nullptr;           // mapped pinned host memory (+ its device alias): reduce_read's landing zone (8 doubles) + deferred slots
     double* red_host_dev = nullptr;
     DevBuf<int> ops_courant;
     fy_step_stats st{};
@@ -164,7 +164,7 @@ struct Solver {
         FY_TRY(launch_fill_f64(stream, rAU.p, n, 1.0));            // ghost planes must hold finite values before the first exchange
         FY_TRY(partials.alloc_exact(8 * (size_t)red_blocks(Nc))); FY_TRY(red_out.alloc_exact(8)); FY_TRY(sc.alloc_exact(4)); FY_TRY(xbar3.alloc_exact(3));
         FY_TRY(zero(partials)); FY_TRY(zero(sc)); FY_TRY(zero(red_out));
-        if (hipHostMalloc((void**)&red_host, 8 * sizeof(double), hipHostMallocMapped) == hipSuccess) {
+        if (hipHostMalloc((void**)&red_host, (kDeferBase + kDeferMax) * sizeof(double), hipHostMallocMapped) == hipSuccess) {
             if (hipHostGetDevicePointer((void**)&red_host_dev, red_host, 0) != hipSuccess) { (void)hipHostFree(red_host); red_host = nullptr; }
         } else {
             red_host = nullptr;              // fall back to the copy path
@@ -269,6 +269,29 @@ struct Solver {
         FY_HIP(hipStreamSynchronize(stream));
         return FY_OK;
     }
+    // Diagnostics nobody branches on (Courant number, continuity errors): same fold [+ all-reduce], but the values land in their own
+    // slots of the pinned buffer and are read after the step's final synchronisation instead of stalling the stream here.
+    // Returns false when there is no slot left (the caller then reads at once).
+    static constexpr int kDeferBase = 8, kDeferMax = 56;          // red_host: 8 immediate + 56 deferred doubles
+    int n_deferred = 0;
+    bool reduce_deferred(int nslots, bool courant, int* slot, int* rc) {
+        *rc = FY_OK;
+        if (!red_host || n_deferred + nslots > kDeferMax) return false;
+        *slot = kDeferBase + n_deferred;
+        n_deferred += nslots;
+        if (comm->size == 1) {
+            *rc = launch_reduce_finalize(stream, partials.p, Nc, nslots, courant ? ops_courant.p : nullptr, red_host_dev + *slot);
+            return true;
+        }
+        *rc = launch_reduce_finalize(stream, partials.p, Nc, nslots, courant ? ops_courant.p : nullptr, red_out.p);
+        if (*rc == FY_OK) {
+            if (courant) { *rc = comm->allreduce(stream, red_out.p, 1, true); if (*rc == FY_OK) *rc = comm->allreduce(stream, red_out.p + 1, 1, false); }
+            else *rc = comm->allreduce(stream, red_out.p, nslots, false);
+        }
+        if (*rc == FY_OK && hipMemcpyAsync(red_host + *slot, red_out.p, nslots * sizeof(double), hipMemcpyDeviceToHost, stream) != hipSuccess)
+            *rc = fail(FY_ERR_HIP, "deferred read-back failed");
+        return true;
+    }
     int reduce_to_device(double* dst) {          // one slot, stays on the device (PCG scalars)
         FY_TRY(launch_reduce_finalize(stream, partials.p, Nc, 1, nullptr, dst));
         return comm->allreduce(stream, dst, 1, false);
@@ -277,17 +300,17 @@ struct Solver {
     // ---- momentum predictor: Jacobi sweeps with lduMatrix-style L1 residual control (stand-in for smoothSolver) ----------
     int solve_momentum(int* iters) {
         double h[6];
+        // sum(U) per component for xbar = average(U): folded (and all-reduced) on the device, divided where it is used
         FY_TRY(launch_sum3(stream, U.p + 3 * (size_t)g.c0, Nc, partials.p));
-        FY_TRY(reduce_read(3, false, h));
-        double xb[3] = {h[0] / (double)Nglob, h[1] / (double)Nglob, h[2] / (double)Nglob};
-        FY_HIP(hipMemcpyAsync(xbar3.p, xb, sizeof(xb), hipMemcpyHostToDevice, stream));
+        FY_TRY(launch_reduce_finalize(stream, partials.p, Nc, 3, nullptr, xbar3.p));
+        FY_TRY(comm->allreduce(stream, xbar3.p, 3, false));
         double* xc = U.p; double* xn = xscr.p;
         double norm[3] = {1, 1, 1}, res0[3] = {0, 0, 0}, res[3];
         int it = 0;
         for (;;) {
             FY_TRY(halo(xc, 3, plane, g.nz, g.gz, 1));
             kc[KC_MOM_PASS].begin(stream);
-            FY_TRY(launch_mom_pass(stream, g, M7(), bmom.p, xc, xn, xbar3.p, partials.p));
+            FY_TRY(launch_mom_pass(stream, g, M7(), bmom.p, xc, xn, xbar3.p, (double)Nglob, partials.p));
             kc[KC_MOM_PASS].end(stream);
             FY_TRY(reduce_read(6, false, h));
             if (it == 0) for (int q = 0; q < 3; ++q) { norm[q] = h[3 + q] + 1e-20; res0[q] = h[q] / norm[q]; }
@@ -482,13 +505,21 @@ struct Solver {
         if (timing) { tim[2].stop(stream); st.ms_pressure += tim[2].ms(); }
         double h[2];
         FY_TRY(launch_cont_err(stream, g, C3(phi), C3(alphaf), alpha.p, /* alphaOld */ alpha.p, partials.p));
-        FY_TRY(reduce_read(2, false, h));
-        const double tv = g.V * (double)Nglob;
-        st.cont_err_sum_local = cs.dt * h[0] / tv; st.cont_err_global = cs.dt * h[1] / tv;
-        cumulative_cont_err += st.cont_err_global; st.cont_err_cumulative = cumulative_cont_err;
+        int slot = 0, rc = FY_OK;
+        if (reduce_deferred(2, false, &slot, &rc)) { FY_TRY(rc); cont_slots.push_back(slot); }
+        else { FY_TRY(reduce_read(2, false, h)); note_cont_err(h); }
         FY_TRY(launch_U_correct(stream, g, HbyA.p, rAU.p, p.p, C3(psn), C3(phiForces), C3(pflux), C3(alphaf), C3(rAUf), U.p));
         return FY_OK;
     }
+
+    std::vector<int> cont_slots;     // deferred continuity-error read-backs of this step, in corrector order
+    int courant_slot = -1;
+    void note_cont_err(const double* h) {      // continuityErrs.H:36-46
+        const double tv = g.V * (double)Nglob;
+        st.cont_err_sum_local = cs.dt * h[0] / tv; st.cont_err_global = cs.dt * h[1] / tv;
+        cumulative_cont_err += st.cont_err_global; st.cont_err_cumulative = cumulative_cont_err;
+    }
+    void note_courant(const double* h) { st.courant_max = 0.5 * h[0] * cs.dt; st.courant_mean = 0.5 * (h[1] / (g.V * (double)Nglob)) * cs.dt; }
 
     // ---- one pass of the while (runTime.loop()) body ---------------------------------------------------------------------
     int step() {
@@ -498,8 +529,12 @@ struct Solver {
         if (sources_pending) { FY_TRY(cpl->c.set_source_zero()); sources_pending = false; }   // the previous step's deferred setSourceZero
         double h[2];
         FY_TRY(launch_courant(stream, g, C3(phi), partials.p));                               // icoFoamYade.C:68, pimpleFoamYade.C:63
-        FY_TRY(reduce_read(2, true, h));
-        st.courant_max = 0.5 * h[0] * cs.dt; st.courant_mean = 0.5 * (h[1] / (g.V * (double)Nglob)) * cs.dt;
+        n_deferred = 0; cont_slots.clear(); courant_slot = -1;
+        {
+            int slot = 0, rc = FY_OK;
+            if (reduce_deferred(2, true, &slot, &rc)) { FY_TRY(rc); courant_slot = slot; }
+            else { FY_TRY(reduce_read(2, true, h)); note_courant(h); }
+        }
         // runTime++ : store old-time fields (whole storage, ghost planes included)
         comm->group_begin();                    // one exchange: U goes with the full particle-halo width straight away
         FY_TRY(halo_cells(U, 3, g.gz > 1 ? g.gz : 1));
@@ -568,15 +603,15 @@ struct Solver {
         }
         if (hold_sources) sources_pending = true;                                              // reset deferred to the next step (fy_solver_hold_sources)
         else FY_TRY(cpl->c.set_source_zero());                                                // icoFoamYade.C:147, pimpleFoamYade.C:109
+        if (timing) tim[3].stop(stream);
+        FY_HIP(hipStreamSynchronize(stream));
+        if (courant_slot >= 0) note_courant(red_host + courant_slot);                         // the deferred diagnostics have landed
+        for (int sl : cont_slots) note_cont_err(red_host + sl);
         if (timing) {
-            tim[3].stop(stream);
-            FY_HIP(hipStreamSynchronize(stream));
             st.ms_particle = tim[0].ms();
             st.ms_total = tim[3].ms();
             st.ms_other = st.ms_total - st.ms_particle - st.ms_momentum - st.ms_pressure;
             for (auto& k : kc) k.collect();
-        } else {
-            FY_HIP(hipStreamSynchronize(stream));
         }
         return FY_OK;
     }
