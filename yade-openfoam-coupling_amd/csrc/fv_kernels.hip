@@ -82,8 +82,10 @@ __device__ __forceinline__ void block_reduce_store(double (&v)[N], const int (&i
 
 // fold the per-block partials of one slot per workgroup, in a fixed order: 1024 threads stride over the partials (16 000 of them at
 // 160^3), then a shuffle + LDS tree.  (256 threads took 17 us per call x 23 calls per step.)
+// flag != nullptr (out and flag in mapped host memory): the result is followed by a system-scope fence and flag[slot] = seq, which is
+// what the host spins on instead of waiting for the stream to drain (a stream synchronisation costs ~15 us of idle GPU per read-back).
 __global__ __launch_bounds__(1024) void k_reduce_finalize(const double* __restrict__ partials, int nblocks, const int* __restrict__ ops,
-                                                          double* __restrict__ out) {
+                                                          double* __restrict__ out, unsigned long long* flag, unsigned long long seq) {
     __shared__ double sh[16];
     const int slot = blockIdx.x;
     const int mx = ops ? ops[slot] : 0;
@@ -104,6 +106,10 @@ __global__ __launch_bounds__(1024) void k_reduce_finalize(const double* __restri
         double r = sh[0];
         for (int w = 1; w < 16; ++w) r = mx ? fmax(r, sh[w]) : r + sh[w];
         out[slot] = r;
+        if (flag) {
+            __threadfence_system();
+            __hip_atomic_store(&flag[slot], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
@@ -1054,8 +1060,9 @@ __global__ __launch_bounds__(256) void k_add(double* __restrict__ y, const doubl
 
 }  // namespace
 
-int launch_reduce_finalize(hipStream_t s, const double* partials, int n_cells, int nslots, const int* ops, double* out) {
-    hipLaunchKernelGGL(k_reduce_finalize, dim3(nslots), dim3(1024), 0, s, partials, red_blocks(n_cells), ops, out);
+int launch_reduce_finalize(hipStream_t s, const double* partials, int n_cells, int nslots, const int* ops, double* out, unsigned long long* flag,
+                           unsigned long long seq) {
+    hipLaunchKernelGGL(k_reduce_finalize, dim3(nslots), dim3(1024), 0, s, partials, red_blocks(n_cells), ops, out, flag, seq);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }

@@ -50,7 +50,9 @@ inline size_t fv_fsize(const FvGeo& g, int d) {
 }
 
 // ---- reductions: kernels over n cells write per-block partials to scratch[slot*red_blocks(n) + block]; finalize folds them in fixed order
-int launch_reduce_finalize(hipStream_t s, const double* partials, int n_cells, int nslots, const int* ops /*0 sum,1 max (device)*/, double* out);
+// flag/seq (mapped host memory, optional): flag[slot] = seq is stored, system scope, after out[slot] -- the host may spin on it
+int launch_reduce_finalize(hipStream_t s, const double* partials, int n_cells, int nslots, const int* ops /*0 sum,1 max (device)*/, double* out,
+                           unsigned long long* flag = nullptr, unsigned long long seq = 0);
 
 // ---- field operators
 int launch_flux_of(hipStream_t s, FvGeo g, const double* F, Face3 out);                                   // fvc::flux(F), createPhi

@@ -66,6 +66,9 @@ struct Solver {
     bool overlap_halos = true;            // FOAMYADE_NO_HALO_OVERLAP=1: serial schedule (A/B switch, same results)
     double* red_host = nullptr;           // mapped pinned host memory (+ its device alias): reduce_read's landing zone (8 doubles) + deferred slots
     double* red_host_dev = nullptr;
+    unsigned long long* red_flag = nullptr;      // 8 arrival flags (mapped pinned) the host spins on, and their device alias
+    unsigned long long* red_flag_dev = nullptr;
+    unsigned long long red_seq = 0;
     DevBuf<int> ops_courant;
     fy_step_stats st{};
     double cumulative_cont_err = 0.0;
@@ -86,6 +89,7 @@ struct Solver {
         if (ev_halo) (void)hipEventDestroy(ev_halo);
         if (comm_stream) (void)hipStreamDestroy(comm_stream);
         if (red_host) (void)hipHostFree(red_host);
+        if (red_flag) (void)hipHostFree(red_flag);
         if (stream) (void)hipStreamDestroy(stream);
     }
 
@@ -168,6 +172,14 @@ struct Solver {
             if (hipHostGetDevicePointer((void**)&red_host_dev, red_host, 0) != hipSuccess) { (void)hipHostFree(red_host); red_host = nullptr; }
         } else {
             red_host = nullptr;              // fall back to the copy path
+        }
+        const char* np_env = getenv("FOAMYADE_NO_POLLED_READBACK");                           // A/B switch: stream synchronisation instead
+        const bool no_poll = np_env && *np_env;
+        if (red_host && !no_poll && hipHostMalloc((void**)&red_flag, 8 * sizeof(unsigned long long), hipHostMallocMapped) == hipSuccess) {
+            for (int q = 0; q < 8; ++q) red_flag[q] = 0;
+            if (hipHostGetDevicePointer((void**)&red_flag_dev, red_flag, 0) != hipSuccess) { (void)hipHostFree(red_flag); red_flag = nullptr; }
+        } else {
+            red_flag = nullptr;
         }
         FY_TRY(ops_courant.alloc_exact(2));
         { const int h[2] = {1, 0}; FY_HIP(hipMemcpyAsync(ops_courant.p, h, sizeof(h), hipMemcpyHostToDevice, stream)); FY_HIP(hipStreamSynchronize(stream)); }
@@ -257,6 +269,23 @@ struct Solver {
     int reduce_read(int nslots, bool courant, double* h) {
         if (comm->size == 1 && red_host) {
             // single domain: the fold writes straight into mapped pinned host memory -- no device-to-host blit per read-back
+            if (red_flag && nslots <= 8) {
+                // spin on the flags the fold stores behind its results; everything enqueued before it has completed by then (in-order stream)
+                const unsigned long long seq = ++red_seq;
+                FY_TRY(launch_reduce_finalize(stream, partials.p, Nc, nslots, courant ? ops_courant.p : nullptr, red_host_dev, red_flag_dev, seq));
+                for (int q = 0; q < nslots; ++q) {
+                    unsigned long spins = 0;
+                    while (__atomic_load_n(&red_flag[q], __ATOMIC_ACQUIRE) != seq) {
+                        if ((++spins & 0xfffu) == 0) {                      // every 4096 polls: is the stream still alive?
+                            const hipError_t e = hipStreamQuery(stream);
+                            if (e == hipSuccess) { if (__atomic_load_n(&red_flag[q], __ATOMIC_ACQUIRE) == seq) break; return fail(FY_ERR_HIP, "reduction flag never arrived"); }
+                            if (e != hipErrorNotReady) return fail(FY_ERR_HIP, "stream failed while waiting for a reduction: %s", hipGetErrorString(e));
+                        }
+                    }
+                    h[q] = red_host[q];
+                }
+                return FY_OK;
+            }
             FY_TRY(launch_reduce_finalize(stream, partials.p, Nc, nslots, courant ? ops_courant.p : nullptr, red_host_dev));
             FY_HIP(hipStreamSynchronize(stream));
             for (int q = 0; q < nslots; ++q) h[q] = red_host[q];
