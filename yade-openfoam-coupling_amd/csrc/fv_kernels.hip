@@ -743,9 +743,11 @@ __global__ __launch_bounds__(256) void k_pcg_update_p(int n, int c0, const doubl
 }
 
 __global__ __launch_bounds__(256) void k_pcg_update_xr(int n, int c0, double* __restrict__ x, double* __restrict__ r, const double* __restrict__ p,
-                                                       const double* __restrict__ w, const double* __restrict__ sc, double* __restrict__ partials) {
+                                                       const double* __restrict__ w, double* __restrict__ sc, double* __restrict__ partials) {
     double v[1] = {0};
     const double al = sc[0] / sc[2];
+    // wArAold = wArA for the next iteration's beta (PCG.C): nothing in this kernel reads sc[1], and k_pcg_update_p runs after it
+    if (blockIdx.x == 0 && threadIdx.x == 0) sc[1] = sc[0];
     FY_RED_LOOP(t, n) {
         const int c = t + c0;
         x[c] += al * p[c];
@@ -1213,7 +1215,7 @@ int launch_pcg_update_p(hipStream_t s, int n, int c0, const double* z, double* p
     return FY_OK;
 }
 
-int launch_pcg_update_xr(hipStream_t s, int n, int c0, double* x, double* r, const double* p, const double* w, const double* sc, double* partials) {
+int launch_pcg_update_xr(hipStream_t s, int n, int c0, double* x, double* r, const double* p, const double* w, double* sc, double* partials) {
     hipLaunchKernelGGL(k_pcg_update_xr, dim3(red_blocks(n)), dim3(256), 0, s, n, c0, x, r, p, w, sc, partials);
     FY_LAUNCH_CHECK();
     return FY_OK;

@@ -93,7 +93,7 @@ int launch_p_apply_dot(hipStream_t s, PMat A, const double* x, double* y, double
 int launch_p_init(hipStream_t s, PMat A, const double* b, const double* x, const double* xsum_dev, double inv_n, double* r, double* partials);
 int launch_dot(hipStream_t s, int n, int c0, const double* a, const double* b /* nullptr: sum(a) */, double* partials);   // slot 0, over [c0, c0+n)
 int launch_pcg_update_p(hipStream_t s, int n, int c0, const double* z, double* p, const double* sc, int first);    // p = z + (sc[0]/sc[1]) p
-int launch_pcg_update_xr(hipStream_t s, int n, int c0, double* x, double* r, const double* p, const double* w, const double* sc, double* partials);   // alpha = sc[0]/sc[2]; slot 0 = sum|r|
+int launch_pcg_update_xr(hipStream_t s, int n, int c0, double* x, double* r, const double* p, const double* w, double* sc /* sc[1] = sc[0] on the way out */, double* partials);   // alpha = sc[0]/sc[2]; slot 0 = sum|r|
 int launch_jacobi_precond(hipStream_t s, PMat A, const double* r, double* z);
 int launch_mg_coarsen(hipStream_t s, PMat F, PMat C);
 int launch_mg_smooth_first(hipStream_t s, PMat A, const double* b, double* x, double w);                   // x = w b / diag

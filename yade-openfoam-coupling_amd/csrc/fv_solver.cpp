@@ -498,7 +498,6 @@ struct Solver {
                 kc[KC_P_APPLY_DOT].end(stream);
                 FY_TRY(reduce_to_device(sc.p + 2));                                                   // wApA
                 FY_TRY(launch_pcg_update_xr(stream, Nc, g.c0, p.p, pr.p, pp.p, pw.p, sc.p, partials.p));
-                FY_HIP(hipMemcpyAsync(sc.p + 1, sc.p + 0, sizeof(double), hipMemcpyDeviceToDevice, stream));   // wArAold = wArA
                 FY_TRY(reduce_read(1, false, h));
                 res = h[0] / norm;
             } while (++it < cs.p_max_iter && !converged(res));
