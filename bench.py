@@ -268,7 +268,10 @@ def main():
 
     K = args.steps
     steps_per_s = K / elapsed if strong else aggregate_value(world, K, elapsed)      # strong: steps of the one box; weak: slab-steps
-    # ---- per-kernel clocks (HIP events on the launch stream, collected inside the timed region)
+    # ---- per-kernel clocks (HIP events on the launch stream, collected inside the timed region).  The FV kernel clocks SAMPLE: the first
+    # launch of a category in each step is timed (every launch of a category does the same work; an event record between two kernels
+    # idles the stream for 5 - 10 us, so timing all ~15 launches per step would slow the step it measures by ~2 %): `launches` below =
+    # timed launches
     kern = {}
     smooth_ms, smooth_n = solver.kernel_timing("mg_smooth_l0")
     apply_ms, apply_n = solver.kernel_timing("p_apply_dot")
