@@ -504,6 +504,7 @@ int Coupling::set_particle_action(double dt) {
     if (!created) return fail(FY_ERR_INVALID, "fy_set_particle_action before fy_create");
     FY_HIP(hipSetDevice(device));
     delta_t = dt;                                                          // FoamYade.C:607
+    FY_TRY(collect_timings());                                            // (the previous call's, before its events are recorded again)
     tm = fy_particle_timings{};
     if (timing) timers[T_TOTAL].start(stream);
 
@@ -531,11 +532,18 @@ int Coupling::set_particle_action(double dt) {
     }
     if (timing) {
         timers[T_TOTAL].stop(stream);
-        FY_HIP(hipStreamSynchronize(stream));
-        tm.h2d = timers[T_H2D].ms(); tm.bin = timers[T_BIN].ms(); tm.locate_deposit = timers[T_LOCATE].ms();
-        tm.finalize = timers[T_FINALIZE].ms(); tm.force = timers[T_FORCE].ms(); tm.d2h = timers[T_D2H].ms(); tm.total = timers[T_TOTAL].ms();
+        timings_pending = true;          // read when asked for (fy_get_particle_timings): reading here would drain the stream mid-step
         for (int bi = 0; bi < n_batches; ++bi) tm.n_particles += batches[bi]->n;
     }
+    return FY_OK;
+}
+
+int Coupling::collect_timings() {
+    if (!timings_pending) return FY_OK;
+    timings_pending = false;
+    FY_HIP(hipStreamSynchronize(stream));
+    tm.h2d = timers[T_H2D].ms(); tm.bin = timers[T_BIN].ms(); tm.locate_deposit = timers[T_LOCATE].ms();
+    tm.finalize = timers[T_FINALIZE].ms(); tm.force = timers[T_FORCE].ms(); tm.d2h = timers[T_D2H].ms(); tm.total = timers[T_TOTAL].ms();
     return FY_OK;
 }
 
@@ -835,7 +843,13 @@ long long fy_locate_walk_count(fy_ctx* c) {
     if (hipStreamSynchronize(c->c.stream) != hipSuccess || hipMemcpy(&n, c->c.d_loc_fb_n.p, sizeof(n), hipMemcpyDeviceToHost) != hipSuccess) return -1;
     return (long long)n;
 }
-int fy_get_particle_timings(fy_ctx* c, fy_particle_timings* out) { FY_CTX(c); if (!out) return fy::fail(FY_ERR_INVALID, "null out"); *out = c->c.tm; return FY_OK; }
+int fy_get_particle_timings(fy_ctx* c, fy_particle_timings* out) {
+    FY_CTX(c);
+    if (!out) return fy::fail(FY_ERR_INVALID, "null out");
+    FY_TRY(c->c.collect_timings());
+    *out = c->c.tm;
+    return FY_OK;
+}
 int fy_enable_timing(fy_ctx* c, int on) { FY_CTX(c); c->c.timing = on != 0; return FY_OK; }
 
 }  // extern "C"

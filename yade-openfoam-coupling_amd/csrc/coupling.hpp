@@ -119,6 +119,8 @@ struct Coupling {
     int run_batch(Batch& b);
     int set_force_models(unsigned flags);
     int set_particle_action(double dt);
+    bool timings_pending = false;        // the last call's phase events have not been read yet
+    int collect_timings();
     int recv_serial();
     int recv_yade_intrs();
     int send_results();

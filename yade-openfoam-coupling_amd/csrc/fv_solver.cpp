@@ -72,7 +72,9 @@ struct Solver {
     DevBuf<int> ops_courant;
     fy_step_stats st{};
     double cumulative_cont_err = 0.0;
-    EventTimer tim[4];      // particle, momentum, pressure, total
+    EventTimer tim[4];      // particle, (unused), (unused), total
+    KernelClock clk_mom, clk_pres;   // momentum / pressure phases: one event pair per outer iteration / corrector, read after the step's final
+                                     // synchronisation (reading a phase time on the spot stalls the host until the phase has drained)
     bool timing = true;
     enum { KC_MG_SMOOTH0 = 0, KC_P_APPLY_DOT, KC_MOM_PASS, KC_COUNT };
     KernelClock kc[KC_COUNT];
@@ -517,7 +519,7 @@ struct Solver {
         FY_TRY(halo_cells(HbyA, 3, 1));
         FY_TRY(launch_phiHbyA(stream, g, HbyA.p, U.p, Uold.p, C3(phiOld), C3(rAUf), C3(alphaf), C3(phiForces), F3(phiHbyA), F3(psn)));
         MgLev& L = *mg[0];
-        if (timing) tim[2].start(stream);
+        clk_pres.begin(stream);
         for (int no = 0; no <= cs.n_non_orth_correctors; ++no) {
             FY_TRY(launch_assemble_pressure(stream, g, C3(phiHbyA), C3(rAUf), C3(alphaf), C3(psn), alpha.p, /* alphaOld */ alpha.p, L.A, prhs.p));
             if (L.distributed && comm->has_down()) FY_TRY(launch_p_ghost_uz(stream, g, C3(rAUf), C3(alphaf), L.A));
@@ -530,7 +532,7 @@ struct Solver {
                 phi_fresh = true;
             }
         }
-        if (timing) { tim[2].stop(stream); st.ms_pressure += tim[2].ms(); }
+        clk_pres.end(stream);
         double h[2];
         FY_TRY(launch_cont_err(stream, g, C3(phi), C3(alphaf), alpha.p, /* alphaOld */ alpha.p, partials.p));
         int slot = 0, rc = FY_OK;
@@ -553,6 +555,7 @@ struct Solver {
     int step() {
         FY_HIP(hipSetDevice(device));
         st = fy_step_stats{}; st.cont_err_cumulative = cumulative_cont_err;
+        clk_mom.on = clk_pres.on = timing; clk_mom.per_collect = clk_pres.per_collect = 1024; clk_mom.reset(); clk_pres.reset();
         if (timing) tim[3].start(stream);
         if (sources_pending) { FY_TRY(cpl->c.set_source_zero()); sources_pending = false; }   // the previous step's deferred setSourceZero
         double h[2];
@@ -604,7 +607,7 @@ struct Solver {
         if (pimple) FY_TRY(launch_interp_alpha(stream, g, alpha.p, F3(alphaf)));              // pimpleFoamYade.C:83-85 (alpha ghosts refreshed by the coupling)
         const int nOuter = pimple ? std::max(cs.n_outer_correctors, 1) : 1;
         for (int outer = 0; outer < nOuter; ++outer) {
-            if (timing) tim[1].start(stream);
+            clk_mom.begin(stream);
             if (pimple) {
                 // explicit stress term of divDevRhoReff from the CURRENT U and this step's alpha (one fused stencil pass)
                 if (outer > 0) FY_TRY(halo_cells(U, 3, 1));
@@ -626,7 +629,7 @@ struct Solver {
                 FY_TRY(solve_momentum(&it));
                 st.u_iters_total += it;
             }
-            if (timing) { tim[1].stop(stream); st.ms_momentum += tim[1].ms(); }
+            clk_mom.end(stream);
             for (int corr = 0; corr < cs.n_correctors; ++corr) FY_TRY(corrector(outer == nOuter - 1 && corr == cs.n_correctors - 1));
         }
         if (hold_sources) sources_pending = true;                                              // reset deferred to the next step (fy_solver_hold_sources)
@@ -636,6 +639,8 @@ struct Solver {
         if (courant_slot >= 0) note_courant(red_host + courant_slot);                         // the deferred diagnostics have landed
         for (int sl : cont_slots) note_cont_err(red_host + sl);
         if (timing) {
+            clk_mom.collect(); clk_pres.collect();
+            st.ms_momentum = clk_mom.total_ms; st.ms_pressure = clk_pres.total_ms;
             st.ms_particle = tim[0].ms();
             st.ms_total = tim[3].ms();
             st.ms_other = st.ms_total - st.ms_particle - st.ms_momentum - st.ms_pressure;
