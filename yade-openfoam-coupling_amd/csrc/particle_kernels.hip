@@ -561,6 +561,16 @@ __device__ __forceinline__ void lds_add_f64(double* p, double v) { unsafeAtomicA
 
 // buildCellPartList FoamYade.C:265-288: pVol*w and (w*v)*pVol per (particle, cell) pair into the per-batch accumulators
 constexpr int kDepThreads = 512, kDepLog2 = 11;      // 2048 slots x (4 + 32) B = 72 KiB of LDS
+// table crowded (practically never): straight to memory.  Out of line -- k_locate_deposit inlines deposit_pair 24 times
+__device__ __attribute__((noinline)) void deposit_direct(int32_t cid, double c0, double c1, double c2, double c3, double* __restrict__ pvol_acc,
+                                                         double* __restrict__ up_acc, unsigned char* __restrict__ touched) {
+    atomic_add_f64(&pvol_acc[cid], c0);
+    atomic_add_f64(&up_acc[3 * (size_t)cid + 0], c1);
+    atomic_add_f64(&up_acc[3 * (size_t)cid + 1], c2);
+    atomic_add_f64(&up_acc[3 * (size_t)cid + 2], c3);
+    touched[cid] = 1;
+}
+
 // one (particle, cell) contribution into the workgroup's table (or straight to memory when the table is crowded)
 __device__ __forceinline__ void deposit_pair(uint32_t* keys, double* vals, int32_t cid, double c0, double c1, double c2, double c3,
                                              double* __restrict__ pvol_acc, double* __restrict__ up_acc, unsigned char* __restrict__ touched) {
@@ -569,11 +579,7 @@ __device__ __forceinline__ void deposit_pair(uint32_t* keys, double* vals, int32
         lds_add_f64(&vals[4 * h], c0); lds_add_f64(&vals[4 * h + 1], c1);
         lds_add_f64(&vals[4 * h + 2], c2); lds_add_f64(&vals[4 * h + 3], c3);
     } else {
-        atomic_add_f64(&pvol_acc[cid], c0);
-        atomic_add_f64(&up_acc[3 * (size_t)cid + 0], c1);
-        atomic_add_f64(&up_acc[3 * (size_t)cid + 1], c2);
-        atomic_add_f64(&up_acc[3 * (size_t)cid + 2], c3);
-        touched[cid] = 1;
+        deposit_direct(cid, c0, c1, c2, c3, pvol_acc, up_acc, touched);
     }
 }
 __device__ __forceinline__ void deposit_flush(const uint32_t* keys, const double* vals, double* __restrict__ pvol_acc, double* __restrict__ up_acc,
