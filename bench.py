@@ -163,6 +163,37 @@ def aggregate_value(world, steps, elapsed):
     return world * steps / elapsed
 
 
+def rccl_selftest_child(args):
+    """child of rccl_preflight: join the throw-away communicator, run the library's known-answer pattern, exit 0 / 3"""
+    rank, world, local_rank = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+    prod = ge.load_product()
+    try:
+        comm = prod.rccl_comm(rank, world, bytes.fromhex(args.rccl_selftest), local_rank)
+        prod.comm_selftest(comm, local_rank)
+    except Exception as e:                                                   # noqa: BLE001
+        print(f"[rccl self-test rank {rank}] {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+        raise SystemExit(3)
+    raise SystemExit(0)
+
+
+def rccl_preflight(prod, torch, dist, dev, rank, world, timeout=120):
+    """Before a multi-GPU run commits to the library's RCCL communicator: the same operations the slab solver issues (grouped neighbour
+    send/recv of two fields, sum / max all-reduce, all-gather), with known answers, in THROW-AWAY child processes -- one per rank, on a
+    communicator of their own -- so that a fabric or library that cannot carry the pattern shows up as an error or a time-out here and
+    the run falls back (labelled) instead of hanging.  Returns "" or what went wrong on this rank."""
+    import subprocess
+    idt = torch.zeros(128, dtype=torch.uint8, device=dev)
+    if rank == 0:
+        idt = torch.tensor(list(prod.rccl_unique_id()), dtype=torch.uint8, device=dev)
+    dist.broadcast(idt, 0)
+    cmd = [sys.executable, os.path.abspath(__file__), "--rccl-selftest", bytes(idt.cpu().tolist()).hex(), "--gpus", str(world)]
+    try:
+        r = subprocess.run(cmd, env=dict(os.environ), capture_output=True, text=True, timeout=timeout)
+        return "" if r.returncode == 0 else f"RCCL self-test failed (rc {r.returncode}): {(r.stderr or r.stdout).strip()[-300:]}"
+    except subprocess.TimeoutExpired:
+        return f"RCCL self-test did not finish within {timeout} s"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -176,7 +207,10 @@ def main():
     ap.add_argument("--cpu-sample-n", type=int, default=64)
     ap.add_argument("--strong", action="store_true", help="N > 1: cut the ONE C3 box into N slabs (BASELINE configs[3]) instead of growing it (weak, the default)")
     ap.add_argument("--force-rccl", action="store_true", help="use the RCCL communicator even with one rank (smoke test of the RCCL path)")
+    ap.add_argument("--rccl-selftest", default="", help=argparse.SUPPRESS)     # child mode: hex of the 128-byte RCCL id (see rccl_preflight)
     args = ap.parse_args()
+    if args.rccl_selftest:
+        rccl_selftest_child(args)
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -199,6 +233,12 @@ def main():
     case = c3_case(prod, args.n, args.dt, args.p_solver, world, strong)
     comm, solver, setup_err = None, None, ""
     try:
+        if world > 1 and not os.environ.get("FOAMYADE_BENCH_NO_PREFLIGHT"):
+            why = rccl_preflight(prod, torch, dist, dev, rank, world)
+            t = torch.tensor([0.0 if why else 1.0], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)                  # every rank must take the same path
+            if float(t.item()) < 1.0:
+                raise RuntimeError(why or "RCCL self-test failed on another rank")
         if world > 1 or args.force_rccl:
             # one RCCL communicator for the slab exchanges; the 128-byte unique id travels over torch.distributed
             os.environ.setdefault("FOAMYADE_TREE_CACHE_DIR", "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp")

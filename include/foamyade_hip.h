@@ -272,6 +272,9 @@ int fy_comm_create_rccl(int rank, int size, const void* id128, int device_ordina
 int fy_comm_create_local_group(int n, fy_comm** out /* [n] */);
 /* diagnostic: calls made through this communicator so far: {neighbour exchanges, all-reduces, all-gathers, bytes sent to neighbours} */
 int fy_comm_stats(fy_comm*, uint64_t* out4);
+/* collective known-answer run of every operation the slab solver uses on this communicator (a grouped two-field neighbour exchange, sum and
+ * max all-reduce, all-gather); bench.py runs it in throw-away processes before it commits a multi-GPU run to the communicator */
+int fy_comm_selftest(fy_comm*, int device_ordinal);
 int fy_comm_destroy(fy_comm*);
 int fy_comm_rank(fy_comm*);
 int fy_comm_size(fy_comm*);

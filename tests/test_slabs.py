@@ -186,3 +186,35 @@ def test_particles_migrate_between_slabs(product, solver, n_slabs):
     assert moved_total > 20                                             # the walk really crossed interfaces
     compare(many, one, ("U", "p", "alpha", "uSource") if solver else ("U", "p"), 1e-5)
     many.close(); one.close()
+
+
+@pytest.mark.parametrize("n", [1, 2, 3])
+def test_comm_selftest_on_a_local_group(product, n):
+    """fy_comm_selftest: the known-answer run of the slab solver's communication pattern (grouped two-field neighbour exchange, sum / max
+    all-reduce, all-gather) that bench.py sends through RCCL in throw-away processes before a multi-GPU run -- here over the in-process
+    communicators, one host thread per rank"""
+    import threading
+    comms = product.local_comm_group(n)
+    errs = [None] * n
+
+    def run(r):
+        try:
+            product.comm_selftest(comms[r], 0)
+        except Exception as e:                                   # noqa: BLE001
+            errs[r] = e
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(n)]
+    for t in ts: t.start()
+    for t in ts: t.join(120)
+    assert not any(t.is_alive() for t in ts)
+    assert errs == [None] * n, errs
+
+
+def test_rccl_selftest_child_mode_of_the_bench(product):
+    """the child process bench.py's rccl_preflight spawns per rank, here as a world of one: RCCL communicator from a unique id, known-answer
+    pattern, exit code 0"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--rccl-selftest", product.rccl_unique_id().hex(), "--gpus", "1"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-2000:]

@@ -171,6 +171,7 @@ def lib():
     L.fy_comm_create_local_group.argtypes = [C.c_int, C.POINTER(vp)]
     L.fy_comm_destroy.argtypes = [vp]
     L.fy_comm_stats.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.fy_comm_selftest.argtypes = [vp, C.c_int]
     L.fy_comm_rank.argtypes = [vp]
     L.fy_comm_size.argtypes = [vp]
     L.fy_solver_create_slab.argtypes = [C.POINTER(CaseDesc), C.POINTER(Transport), C.c_int, vp, C.POINTER(vp)]
@@ -572,6 +573,18 @@ def rccl_comm(rank, size, id128, device):
     buf = (C.c_char * 128).from_buffer_copy(id128)
     _check(lib().fy_comm_create_rccl(int(rank), int(size), buf, int(device), C.byref(h)))
     return h
+
+
+def comm_selftest(comm, device=0):
+    """collective known-answer run of the operations the slab solver uses on this communicator (fy_comm_selftest); raises on a mismatch"""
+    _check(lib().fy_comm_selftest(comm, int(device)))
+
+
+def local_comm_group(n):
+    """n communicators talking to each other inside this process (fy_comm_create_local_group), one per host thread"""
+    arr = (C.c_void_p * n)()
+    _check(lib().fy_comm_create_local_group(int(n), arr))
+    return [C.c_void_p(arr[r]) for r in range(n)]
 
 
 class FoamCase:

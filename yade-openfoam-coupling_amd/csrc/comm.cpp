@@ -1,5 +1,7 @@
 #include "comm.hpp"
 
+#include <algorithm>
+
 #include <dlfcn.h>
 
 #include <condition_variable>
@@ -221,6 +223,56 @@ int rccl_comm_create(int rank, int size, const void* id128, int device, Comm** o
     int r = A->CommInitRank(&c->comm, size, id, rank);
     if (r != 0) { delete c; return fail(FY_ERR_TRANSPORT, "ncclCommInitRank failed: %s", A->GetErrorString ? A->GetErrorString(r) : "?"); }
     *out = c;
+    return FY_OK;
+}
+
+
+// Exercise every operation the slab solver uses on this communicator with known values: two fields in ONE grouped neighbour exchange
+// (both directions), a sum and a max all-reduce, an all-gather.  Collective: every rank of the communicator calls it.  Meant to run in a
+// throw-away process before the real run commits to the communicator (bench.py), so that a fabric that cannot carry the pattern shows
+// up as an error or a time-out there instead of as a hung benchmark.
+int comm_selftest(Comm* c, int device) {
+    if (!c) return fail(FY_ERR_INVALID, "null communicator");
+    FY_HIP(hipSetDevice(device));
+    hipStream_t s = nullptr;
+    FY_HIP(hipStreamCreate(&s));
+    const size_t n = 25600;                       // one 160 x 160 plane
+    const int R = c->rank, S = c->size;
+    std::vector<double> h(8 * n), out(8 * n + 64 + 8 * (size_t)S);
+    for (int f = 0; f < 2; ++f) for (size_t q = 0; q < n; ++q) { h[(2 * f) * n + q] = 1000.0 * R + 10.0 * f + 1.0 + 1e-3 * (double)q; h[(2 * f + 1) * n + q] = 1000.0 * R + 10.0 * f + 2.0 + 1e-3 * (double)q; }
+    DevBuf<double> d, red, gat;
+    FY_TRY(d.alloc_exact(8 * n)); FY_TRY(red.alloc_exact(8)); FY_TRY(gat.alloc_exact(8 * (size_t)S + 8));
+    FY_HIP(hipMemcpyAsync(d.p, h.data(), 4 * n * sizeof(double), hipMemcpyHostToDevice, s));          // [f][up|down] send planes
+    FY_HIP(hipMemsetAsync(d.p + 4 * n, 0, 4 * n * sizeof(double), s));                                // [f][from_down|from_up] receive planes
+    c->group_begin();
+    for (int f = 0; f < 2; ++f)
+        FY_TRY(c->neighbour_exchange(s, d.p + (2 * f) * n, d.p + (4 + 2 * f) * n, d.p + (2 * f + 1) * n, d.p + (4 + 2 * f + 1) * n, n));
+    FY_TRY(c->group_end(s));
+    const double r0[4] = {(double)(R + 1), 0.5 * (double)R, -3.0, (double)((R * 7) % S)};
+    FY_HIP(hipMemcpyAsync(red.p, r0, sizeof(r0), hipMemcpyHostToDevice, s));
+    FY_TRY(c->allreduce(s, red.p, 3, false));
+    FY_TRY(c->allreduce(s, red.p + 3, 1, true));
+    const double g0[8] = {1.0 * R, 2.0 * R, 3.0 * R, 4.0 * R, 5.0 * R, 6.0 * R, 7.0 * R, 8.0 * R};
+    FY_HIP(hipMemcpyAsync(gat.p + 8 * (size_t)S, g0, sizeof(g0), hipMemcpyHostToDevice, s));
+    FY_TRY(c->allgather(s, gat.p + 8 * (size_t)S, gat.p, 8));
+    FY_HIP(hipMemcpyAsync(out.data(), d.p, 8 * n * sizeof(double), hipMemcpyDeviceToHost, s));
+    FY_HIP(hipMemcpyAsync(out.data() + 8 * n, red.p, 4 * sizeof(double), hipMemcpyDeviceToHost, s));
+    FY_HIP(hipMemcpyAsync(out.data() + 8 * n + 64, gat.p, 8 * (size_t)S * sizeof(double), hipMemcpyDeviceToHost, s));
+    FY_HIP(hipStreamSynchronize(s));
+    (void)hipStreamDestroy(s);
+    for (int f = 0; f < 2; ++f) for (size_t q = 0; q < n; q += 997) {
+        // what my lower neighbour sent UP lands in from_down, what my upper neighbour sent DOWN lands in from_up
+        const double want_dn = c->has_down() ? 1000.0 * (R - 1) + 10.0 * f + 1.0 + 1e-3 * (double)q : 0.0;
+        const double want_up = c->has_up() ? 1000.0 * (R + 1) + 10.0 * f + 2.0 + 1e-3 * (double)q : 0.0;
+        if (out[(4 + 2 * f) * n + q] != want_dn || out[(4 + 2 * f + 1) * n + q] != want_up)
+            return fail(FY_ERR_TRANSPORT, "comm self-test: neighbour exchange delivered wrong data on rank %d (field %d, element %zu)", R, f, q);
+    }
+    double s0 = 0, s1 = 0, mx = -1;
+    for (int r = 0; r < S; ++r) { s0 += r + 1; s1 += 0.5 * r; mx = std::max(mx, (double)((r * 7) % S)); }
+    const double* ro = out.data() + 8 * n;
+    if (ro[0] != s0 || ro[1] != s1 || ro[2] != -3.0 * S || ro[3] != mx) return fail(FY_ERR_TRANSPORT, "comm self-test: all-reduce wrong on rank %d", R);
+    for (int r = 0; r < S; ++r) for (int q = 0; q < 8; ++q)
+        if (out[8 * n + 64 + 8 * (size_t)r + q] != (double)(q + 1) * r) return fail(FY_ERR_TRANSPORT, "comm self-test: all-gather wrong on rank %d", R);
     return FY_OK;
 }
 

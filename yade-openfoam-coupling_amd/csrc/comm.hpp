@@ -78,6 +78,8 @@ int local_comm_group_create(int n, Comm** out /* [n] */);
 // RCCL: unique id = 128 opaque bytes produced on rank 0 (fy_rccl_unique_id) and broadcast by the launcher
 int rccl_unique_id(void* out128);
 int rccl_comm_create(int rank, int size, const void* id128, int device, Comm** out);
+// known-answer run of every operation the slab solver uses (grouped two-field neighbour exchange, sum / max all-reduce, all-gather); collective
+int comm_selftest(Comm* c, int device);
 
 }  // namespace fy
 

@@ -731,6 +731,7 @@ int fy_comm_stats(fy_comm* c, uint64_t* out4) {
     out4[0] = c->c->n_exchange; out4[1] = c->c->n_allreduce; out4[2] = c->c->n_allgather; out4[3] = c->c->exchange_bytes;
     return FY_OK;
 }
+int fy_comm_selftest(fy_comm* c, int device_ordinal) { if (!c || !c->c) return fy::fail(FY_ERR_INVALID, "null communicator"); return fy::comm_selftest(c->c, device_ordinal); }
 int fy_comm_rank(fy_comm* c) { return c && c->c ? c->c->rank : -1; }
 int fy_comm_size(fy_comm* c) { return c && c->c ? c->c->size : -1; }
 
