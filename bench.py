@@ -176,11 +176,11 @@ def rccl_selftest_child(args):
     raise SystemExit(0)
 
 
-def rccl_preflight(prod, torch, dist, dev, rank, world, timeout=120):
+def rccl_preflight(prod, torch, dist, dev, rank, world, timeout=180):
     """Before a multi-GPU run commits to the library's RCCL communicator: the same operations the slab solver issues (grouped neighbour
     send/recv of two fields, sum / max all-reduce, all-gather), with known answers, in THROW-AWAY child processes -- one per rank, on a
-    communicator of their own -- so that a fabric or library that cannot carry the pattern shows up as an error or a time-out here and
-    the run falls back (labelled) instead of hanging.  Returns "" or what went wrong on this rank."""
+    communicator of their own -- so that a fabric or library that cannot carry the pattern shows up here: a TIME-OUT makes the run fall back (labelled) instead
+    of hanging; an error is only reported (the real set-up catches its own).  Returns "" or why this rank wants the fallback."""
     import subprocess
     idt = torch.zeros(128, dtype=torch.uint8, device=dev)
     if rank == 0:
@@ -189,9 +189,11 @@ def rccl_preflight(prod, torch, dist, dev, rank, world, timeout=120):
     cmd = [sys.executable, os.path.abspath(__file__), "--rccl-selftest", bytes(idt.cpu().tolist()).hex(), "--gpus", str(world)]
     try:
         r = subprocess.run(cmd, env=dict(os.environ), capture_output=True, text=True, timeout=timeout)
-        return "" if r.returncode == 0 else f"RCCL self-test failed (rc {r.returncode}): {(r.stderr or r.stdout).strip()[-300:]}"
+        if r.returncode != 0:      # an ERROR is not decisive (the real set-up below reports its own errors and falls back by itself): say so, go on
+            print(f"[bench rank {rank}] RCCL self-test failed (rc {r.returncode}): {(r.stderr or r.stdout).strip()[-300:]}", file=sys.stderr, flush=True)
+        return ""
     except subprocess.TimeoutExpired:
-        return f"RCCL self-test did not finish within {timeout} s"
+        return f"RCCL self-test did not finish within {timeout} s"          # a HANG is: the real run would hang the same way
 
 
 def main():
