@@ -296,8 +296,10 @@ struct Solver {
         FY_TRY(launch_reduce_finalize(stream, partials.p, Nc, nslots, courant ? ops_courant.p : nullptr, red_out.p));
         if (courant) { FY_TRY(comm->allreduce(stream, red_out.p, 1, true)); FY_TRY(comm->allreduce(stream, red_out.p + 1, 1, false)); }
         else FY_TRY(comm->allreduce(stream, red_out.p, nslots, false));
-        FY_HIP(hipMemcpyAsync(h, red_out.p, nslots * sizeof(double), hipMemcpyDeviceToHost, stream));
+        double* land = (red_host && nslots <= 8) ? red_host : h;          // pinned landing zone: a pageable destination makes the copy a staged, blocking one
+        FY_HIP(hipMemcpyAsync(land, red_out.p, nslots * sizeof(double), hipMemcpyDeviceToHost, stream));
         FY_HIP(hipStreamSynchronize(stream));
+        if (land != h) for (int q = 0; q < nslots; ++q) h[q] = land[q];
         return FY_OK;
     }
     // Diagnostics nobody branches on (Courant number, continuity errors): same fold [+ all-reduce], but the values land in their own
