@@ -833,6 +833,21 @@ __global__ __launch_bounds__(256) void k_mg_smooth_two_from_zero(PMat A, const d
     xn[c] = x1c + w * (bc - a) / dc;
 }
 
+// the last level-0 sweep of a V-cycle used as PCG preconditioner: z = xn, and PCG wants z.r next -- r is this level's b, already in a
+// register -- so the block partials of the dot product (k_dot's, same blocks, same order) come out of the same pass
+__global__ __launch_bounds__(256) void k_mg_smooth_dot(PMat A, const double* __restrict__ b, const double* __restrict__ x, double* __restrict__ xn, double w,
+                                                       double* __restrict__ partials) {
+    double v[1] = {0};
+    FY_RED_LOOP(t, A.N) {
+        const int c = t + A.c0;
+        const double bc = b[c];
+        const double z = x[c] + w * (bc - p_row(A, x, c)) / A.diag[c];
+        xn[c] = z;
+        v[0] += z * bc;
+    }
+    const int mx[1] = {0};
+    block_reduce_store<1>(v, mx, partials);
+}
 __global__ __launch_bounds__(256) void k_mg_smooth(PMat A, const double* __restrict__ b, const double* __restrict__ x, double* __restrict__ xn, double w) {
     const int t = swz_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
     if (t >= A.N) return;
@@ -1241,6 +1256,12 @@ int launch_mg_smooth_first(hipStream_t s, PMat A, const double* b, double* x, do
 
 int launch_mg_smooth_two_from_zero(hipStream_t s, PMat A, const double* b, double* xn, double w) {
     hipLaunchKernelGGL(k_mg_smooth_two_from_zero, dim3(div_up(A.N, 256)), dim3(256), 0, s, A, b, xn, w);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+
+int launch_mg_smooth_dot(hipStream_t s, PMat A, const double* b, const double* x, double* xn, double w, double* partials) {
+    hipLaunchKernelGGL(k_mg_smooth_dot, dim3(red_blocks(A.N)), dim3(256), 0, s, A, b, x, xn, w, partials);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }

@@ -98,7 +98,9 @@ int launch_jacobi_precond(hipStream_t s, PMat A, const double* r, double* z);
 int launch_mg_coarsen(hipStream_t s, PMat F, PMat C);
 int launch_mg_smooth_first(hipStream_t s, PMat A, const double* b, double* x, double w);                   // x = w b / diag
 int launch_mg_smooth_two_from_zero(hipStream_t s, PMat A, const double* b, double* xn, double w);      // smooth_first + smooth fused (bit-identical)
-int launch_mg_smooth(hipStream_t s, PMat A, const double* b, const double* x, double* xn, double w);      // xn = x + w (b - A x)/diag
+int launch_mg_smooth(hipStream_t s, PMat A, const double* b, const double* x, double* xn, double w);
+// the same sweep + the block partials of xn . b (slot 0), what launch_dot(xn, b) would leave there
+int launch_mg_smooth_dot(hipStream_t s, PMat A, const double* b, const double* x, double* xn, double w, double* partials);      // xn = x + w (b - A x)/diag
 int launch_mg_residual_restrict(hipStream_t s, PMat A, const double* b, const double* x, PMat C, double* bc);   // bc = P^T (b - A x)
 int launch_mg_prolong_add(hipStream_t s, PMat A, double* x, PMat C, const double* xc);
 int launch_mg_coarse_solve(hipStream_t s, PMat A, const double* b, double* x, double* tmp, int sweeps, double w);

@@ -362,7 +362,7 @@ struct Solver {
     }
 
     // ---- multigrid V(2,2) with damped Jacobi, used as the PCG preconditioner ------------------------------------------
-    int smooth(size_t l, MgLev& L, double w) {
+    int smooth(size_t l, MgLev& L, double w, bool with_dot = false) {
         if (L.distributed && overlap_halos && L.A.nz >= 4) {
             // Halo exchange overlapped with interior stencil work: the sweep over the planes that need no ghost values starts at
             // once on `stream`, the one-plane exchange of x runs meanwhile on comm_stream, and the two boundary planes are swept
@@ -383,6 +383,11 @@ struct Solver {
             return FY_OK;
         }
         FY_TRY(halo_level(L, L.xcur));
+        if (with_dot) {                                    // (single domain only: the caller checks)
+            FY_TRY(launch_mg_smooth_dot(stream, L.A, L.bptr, L.xcur, L.xalt, w, partials.p));
+            std::swap(L.xcur, L.xalt);
+            return FY_OK;
+        }
         if (l == 0) kc[KC_MG_SMOOTH0].begin(stream);
         FY_TRY(launch_mg_smooth(stream, L.A, L.bptr, L.xcur, L.xalt, w));
         if (l == 0) kc[KC_MG_SMOOTH0].end(stream);
@@ -446,9 +451,12 @@ struct Solver {
             FY_TRY(launch_mg_prolong_add(stream, L.A, L.xcur, Cc.A, Cc.xcur));
         }
         FY_TRY(smooth(l, L, w));
-        FY_TRY(smooth(l, L, w));
+        // the last sweep of the whole cycle also leaves the partials of z.r where PCG's launch_dot would (vcycle_dot_done)
+        vcycle_dot_done = l == 0 && want_vcycle_dot && !L.distributed && L.A.N == Nc && L.A.c0 == g.c0;
+        FY_TRY(smooth(l, L, w, vcycle_dot_done));
         return FY_OK;
     }
+    bool want_vcycle_dot = false, vcycle_dot_done = false;
 
     // coarse operators: A_{l+1} = 1/2 P^T A_l P level by level; the first replicated level is all-gathered from the slabs' slices
     int build_coarse_operators() {
@@ -491,9 +499,10 @@ struct Solver {
         if (!converged(res)) {
             do {
                 const double* z;
-                if (cs.p_solver == FY_PSOLVER_PCG_MG) { L.bptr = pr.p; FY_TRY(vcycle(0)); z = L.xcur; }
+                vcycle_dot_done = false;
+                if (cs.p_solver == FY_PSOLVER_PCG_MG) { L.bptr = pr.p; want_vcycle_dot = true; FY_TRY(vcycle(0)); want_vcycle_dot = false; z = L.xcur; }
                 else { FY_TRY(launch_jacobi_precond(stream, L.A, pr.p, pzj.p)); z = pzj.p; }
-                FY_TRY(launch_dot(stream, Nc, g.c0, z, pr.p, partials.p));
+                if (!vcycle_dot_done) FY_TRY(launch_dot(stream, Nc, g.c0, z, pr.p, partials.p));
                 FY_TRY(reduce_to_device(sc.p + 0));                                                   // wArA
                 FY_TRY(launch_pcg_update_p(stream, Nc, g.c0, z, pp.p, sc.p, it == 0 ? 1 : 0));
                 FY_TRY(halo_cells(pp, 1, 1));
