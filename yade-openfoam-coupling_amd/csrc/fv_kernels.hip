@@ -49,6 +49,29 @@ __device__ __forceinline__ double pbv(const FvGeo& g, const double* p, const CFa
     if (g.p_bc[patch] == 2) return p[c] + (s ? 0.5 : -0.5) * g.dx * psn.a[d][face];
     return p[c];
 }
+// Value held by the previous / next lane of the wave (undefined in lane 0 / 63): one DPP move per dword.  A wave's lanes are consecutive
+// x-cells, so the x-neighbours of a stencil are already in registers next door -- two more full-wave loads of an AoS vector field
+// (24 cache lines each way for the address unit) become two single-lane loads at the wave's ends.
+__device__ __forceinline__ double wave_prev(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);      // wave_shr:1
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_next(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false);      // wave_shl:1
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// x-neighbours of an AoS vector field from the neighbouring lanes; call in wave-uniform control flow (every lane that holds a cell)
+__device__ __forceinline__ void x_neighbours3(const double* __restrict__ F, int c, int i, int nx, const double (&own)[3], double (&L)[3], double (&R)[3]) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { L[q] = wave_prev(own[q]); R[q] = wave_next(own[q]); }
+    if (lane == 0 && i > 0) for (int q = 0; q < 3; ++q) L[q] = F[3 * (size_t)(c - 1) + q];
+    if (lane == 63 && i + 1 < nx) for (int q = 0; q < 3; ++q) R[q] = F[3 * (size_t)(c + 1) + q];
+}
 // XCD-aware block order (guide T1): block b runs on XCD b % 8; give every XCD one contiguous z-slab of the grid so that the
 // y/z-neighbour re-reads of a stencil hit that XCD's own L2.  Pure speed: any mapping is correct.
 __device__ __forceinline__ int swz_block(int bid, int nblk) {
@@ -312,6 +335,15 @@ __global__ __launch_bounds__(256) void k_pre_coupling(FvGeo g, const double* __r
     const int c = t + g.c0;
     const bool pf = g.pimple && write_pfields;          // gradP and divT wanted
     const double uc[3] = {U[3 * (size_t)c], U[3 * (size_t)c + 1], U[3 * (size_t)c + 2]};
+    // x-neighbours from the neighbouring lanes (wave_prev / wave_next); the wave's end lanes fetch theirs
+    const int lane = threadIdx.x & 63;
+    const double pc = pf ? p[c] : 0.0, ac = pf ? alpha[c] : 0.0;
+    double ux[2][3], px[2], ax[2];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { ux[0][q] = wave_prev(uc[q]); ux[1][q] = wave_next(uc[q]); }
+    px[0] = wave_prev(pc); px[1] = wave_next(pc); ax[0] = wave_prev(ac); ax[1] = wave_next(ac);
+    if (lane == 0 && i > 0) { for (int q = 0; q < 3; ++q) ux[0][q] = U[3 * (size_t)(c - 1) + q]; if (pf) { px[0] = p[c - 1]; ax[0] = alpha[c - 1]; } }
+    if (lane == 63 && i + 1 < g.nx) { for (int q = 0; q < 3; ++q) ux[1][q] = U[3 * (size_t)(c + 1) + q]; if (pf) { px[1] = p[c + 1]; ax[1] = alpha[c + 1]; } }
     double lap[3] = {0, 0, 0}, T[9], conv[3] = {0, 0, 0}, gp3[3] = {0, 0, 0};
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
@@ -326,11 +358,13 @@ __global__ __launch_bounds__(256) void k_pre_coupling(FvGeo g, const double* __r
                 }
             } else {
                 const int nb = c + (s ? stride_of(g, d) : -stride_of(g, d));
-                const double un[3] = {U[3 * (size_t)nb], U[3 * (size_t)nb + 1], U[3 * (size_t)nb + 2]};
+                double un[3], pn = 0.0, an = 0.0;
+                if (d == 0) { un[0] = ux[s][0]; un[1] = ux[s][1]; un[2] = ux[s][2]; pn = px[s]; an = ax[s]; }
+                else { un[0] = U[3 * (size_t)nb]; un[1] = U[3 * (size_t)nb + 1]; un[2] = U[3 * (size_t)nb + 2]; if (pf) { pn = p[nb]; an = alpha[nb]; } }
                 for (int q = 0; q < 3; ++q) fv[s][q] = 0.5 * (uc[q] + un[q]);
                 if (pf) {
-                    fp[s] = 0.5 * (p[c] + p[nb]);
-                    const double af = 0.5 * (alpha[c] + alpha[nb]);
+                    fp[s] = 0.5 * (pc + pn);
+                    const double af = 0.5 * (ac + an);
                     for (int q = 0; q < 3; ++q) lap[q] += af * g.Af * (un[q] - uc[q]) * g.rdx;
                 }
             }
@@ -373,13 +407,19 @@ __global__ __launch_bounds__(256) void k_div_G(FvGeo g, const double* __restrict
     int i, j, k; ijk_of(g, t, i, j, k);
     const int c = t + g.c0;
     double acc[3] = {0, 0, 0};
+    const double g0[3] = {G[3 * (size_t)c], G[3 * (size_t)c + 1], G[3 * (size_t)c + 2]};      // row x at this cell; its x-neighbours come from the lanes next door
+    double gx[2][3];
+    x_neighbours3(G, c, i, g.nx, g0, gx[0], gx[1]);
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
         double fv[2][3];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const double* Gd = G + (size_t)d * g_row_stride(g);           // row d of the tensor field
-            if (onb(g, d, s, i, j, k)) for (int q = 0; q < 3; ++q) fv[s][q] = Gd[3 * (size_t)c + q];
+            if (d == 0) {
+                if (onb(g, d, s, i, j, k)) for (int q = 0; q < 3; ++q) fv[s][q] = g0[q];
+                else for (int q = 0; q < 3; ++q) fv[s][q] = 0.5 * (g0[q] + gx[s][q]);
+            } else if (onb(g, d, s, i, j, k)) for (int q = 0; q < 3; ++q) fv[s][q] = Gd[3 * (size_t)c + q];
             else { const int nb = c + (s ? stride_of(g, d) : -stride_of(g, d)); for (int q = 0; q < 3; ++q) fv[s][q] = 0.5 * (Gd[3 * (size_t)c + q] + Gd[3 * (size_t)nb + q]); }
         }
         for (int q = 0; q < 3; ++q) acc[q] += (fv[1][q] - fv[0][q]) * g.rdx;
@@ -505,6 +545,9 @@ __global__ __launch_bounds__(256) void k_mom_pass(FvGeo g, Mom7 M, const double*
         const int c = t + g.c0;
         const double dg = M.diag[c];
         double off[3] = {0, 0, 0}, rowsum = dg;
+        const double xc[3] = {x[3 * (size_t)c], x[3 * (size_t)c + 1], x[3 * (size_t)c + 2]};
+        double xx[2][3];
+        x_neighbours3(x, c, i, g.nx, xc, xx[0], xx[1]);
 #pragma unroll
         for (int d = 0; d < 3; ++d)
 #pragma unroll
@@ -513,11 +556,12 @@ __global__ __launch_bounds__(256) void k_mom_pass(FvGeo g, Mom7 M, const double*
                     const int nb = c + (s ? stride_of(g, d) : -stride_of(g, d));
                     const double a = M.an[2 * d + s][c];
                     rowsum += a;
-                    for (int q = 0; q < 3; ++q) off[q] += a * x[3 * (size_t)nb + q];
+                    if (d == 0) for (int q = 0; q < 3; ++q) off[q] += a * xx[s][q];
+                    else for (int q = 0; q < 3; ++q) off[q] += a * x[3 * (size_t)nb + q];
                 }
         for (int q = 0; q < 3; ++q) {
             const double bq = b[3 * (size_t)c + q];
-            const double Ax = dg * x[3 * (size_t)c + q] + off[q];
+            const double Ax = dg * xc[q] + off[q];
             const double Aref = rowsum * xb[q];
             v[q] += fabs(bq - Ax);
             v[3 + q] += fabs(Ax - Aref) + fabs(bq - Aref);
