@@ -87,6 +87,7 @@ struct Solver {
         if (cpl) fy_destroy(cpl);
         for (auto& t : tim) t.destroy();
         for (auto& k : kc) k.destroy();
+        clk_mom.destroy(); clk_pres.destroy();
         if (ev_ready) (void)hipEventDestroy(ev_ready);
         if (ev_halo) (void)hipEventDestroy(ev_halo);
         if (comm_stream) (void)hipStreamDestroy(comm_stream);
