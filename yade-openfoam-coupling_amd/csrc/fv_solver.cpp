@@ -306,7 +306,7 @@ struct Solver {
     // Diagnostics nobody branches on (Courant number, continuity errors): same fold [+ all-reduce], but the values land in their own
     // slots of the pinned buffer and are read after the step's final synchronisation instead of stalling the stream here.
     // Returns false when there is no slot left (the caller then reads at once).
-    static constexpr int kDeferBase = 8, kDeferMax = 56;          // red_host: 8 immediate + 56 deferred doubles
+    static constexpr int kDeferBase = 8, kDeferMax = 2 + 2 * 255; // red_host: 8 immediate doubles + Courant + 255 correctors' continuity errors
     int n_deferred = 0;
     bool reduce_deferred(int nslots, bool courant, int* slot, int* rc) {
         *rc = FY_OK;
