@@ -212,3 +212,22 @@ def test_gauss_upwind_is_read_as_the_upwind_scheme(prod, tmp_path):
     with pytest.raises(prod.FoamYadeError) as e:
         prod.FoamCase(dst, prod.FY_SOLVER_PIMPLE)
     assert "divSchemes" in str(e.value)
+
+
+def test_upwind_convection_next_to_the_linear_stress_term_is_read(prod, tmp_path):
+    """a realistic pimpleFoamYade fvSchemes: upwinded convection plus the (always Gauss linear) explicit stress term of divDevRhoReff;
+    only the convection keys select the scheme, and an upwinded non-convection entry is refused by name"""
+    dst = tmp_path / "case"
+    shutil.copytree(os.path.join(CASES, "bed_pimple"), dst)
+    f = dst / "system/fvSchemes"
+    stress = "    div(((alpha*nuEff)*dev2(T(grad(U))))) Gauss linear;\n"
+    txt = f.read_text().replace("div(phi,U)       Gauss linear;", "div(phi,U)       Gauss upwind;").replace(
+        "div(alphaPhic,Uc) Gauss linear;", "div(alphaPhic,Uc) Gauss upwind;\n" + stress)
+    f.write_text(txt)
+    fc = prod.FoamCase(dst, prod.FY_SOLVER_PIMPLE)
+    assert fc.case.convection_scheme == prod.FY_CONVECTION_UPWIND
+    fc.close()
+    f.write_text(txt.replace(stress, stress.replace("Gauss linear", "Gauss upwind")))
+    with pytest.raises(prod.FoamYadeError) as e:
+        prod.FoamCase(dst, prod.FY_SOLVER_PIMPLE)
+    assert "must be Gauss linear" in str(e.value)

@@ -47,7 +47,8 @@ struct Comm {
                                  const double* send_down, size_t n_send_down, double* recv_from_up, size_t n_recv_up) {
         Xchg x{send_up, recv_from_down, send_down, recv_from_up, 0};
         x.n_send_up = n_send_up; x.n_recv_down = n_recv_down; x.n_send_down = n_send_down; x.n_recv_up = n_recv_up;
-        if (!x.sized()) return 0;
+        // (no early return when all four sizes are zero: the exchange is collective -- LocalComm pairs host barriers -- and an unsized
+        //  entry already reads as four zero counts)
         if (grouping) { pending.push_back(x); return 0; }
         return exchange_many(s, &x, 1);
     }

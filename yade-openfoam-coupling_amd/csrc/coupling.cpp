@@ -62,6 +62,10 @@ int Coupling::create(const fy_mesh_desc* m, const fy_field_ptrs* f, int gaussian
     } else {
         comm_sz_diff = 0; serial_yade = true;
     }
+    // z-slabs issue their halo / reverse-halo collectives once per batch, and with parallel Yade the batch count (= intersecting Yade
+    // workers, FoamYade.C:114-155) differs from rank to rank: the slabs' collective calls would not pair up
+    if (slab.active && has_transport && !serial_yade)
+        return fail(FY_ERR_UNSUPPORTED, "z-slab mode with a parallel-Yade transport is not supported (per-rank batch counts would unpair the slab collectives)");
 
     // ---- mshTree.build_tree(), FoamYade.C:33 (always, also in point-force mode: quirk Q6 kept for get_tree parity)
     {
@@ -90,19 +94,26 @@ int Coupling::create(const fy_mesh_desc* m, const fy_field_ptrs* f, int gaussian
             FILE* f = fopen(cache.c_str(), "rb");
             if (!f) return false;
             pre.resize((size_t)n_cells);
-            const bool ok = fread(pre.data(), sizeof(int32_t), (size_t)n_cells, f) == (size_t)n_cells;
+            bool ok = fread(pre.data(), sizeof(int32_t), (size_t)n_cells, f) == (size_t)n_cells && fgetc(f) == EOF;
             fclose(f);
+            // a foreign or truncated file must not turn into out-of-range packed (i,j,k): every id is a cell of THIS block
+            for (size_t q = 0; ok && q < pre.size(); ++q) ok = pre[q] >= 0 && pre[q] < n_cells;
+            if (!ok) pre.clear();
             return ok;
         };
-        bool have = false;
+        bool have = false, hold_lock = false;
+        const std::string lock = cache + ".lock";
         if (!cache.empty()) {
             have = load_cache();
             if (!have) {
-                const std::string lock = cache + ".lock";
                 FILE* lf = fopen(lock.c_str(), "wx");            // exclusive create: the winner builds
-                if (!lf) {
-                    for (int spin = 0; spin < 36000 && !have; ++spin) { std::this_thread::sleep_for(std::chrono::milliseconds(50)); have = load_cache(); }
-                } else fclose(lf);
+                if (lf) { fclose(lf); hold_lock = true; }
+                else {
+                    // somebody else is building: wait for the file, but never longer than the build itself would take (a lock left
+                    // behind by a crashed run must not stall later runs) -- after that this rank simply builds its own copy
+                    const int max_spins = 20 * 60;                // 60 s
+                    for (int spin = 0; spin < max_spins && !have; ++spin) { std::this_thread::sleep_for(std::chrono::milliseconds(50)); have = load_cache(); }
+                }
             }
         }
         std::vector<KdNode> nodes;
@@ -111,11 +122,17 @@ int Coupling::create(const fy_mesh_desc* m, const fy_field_ptrs* f, int gaussian
             build_kdtree_preorder(m->centres, n_cells, nodes, (int)std::min(hw ? hw : 1u, 8u));
             pre.resize((size_t)n_cells);
             for (size_t q = 0; q < nodes.size(); ++q) pre[q] = nodes[q].id;
-            if (!cache.empty()) {
+            if (hold_lock) {                                      // publish: complete file first, then the atomic rename
                 const std::string tmp = cache + ".tmp";
-                if (FILE* f = fopen(tmp.c_str(), "wb")) { fwrite(pre.data(), sizeof(int32_t), pre.size(), f); fclose(f); rename(tmp.c_str(), cache.c_str()); }
+                bool ok = false;
+                if (FILE* f = fopen(tmp.c_str(), "wb")) {
+                    ok = fwrite(pre.data(), sizeof(int32_t), pre.size(), f) == pre.size();
+                    ok = (fclose(f) == 0) && ok;
+                }
+                if (!ok || rename(tmp.c_str(), cache.c_str()) != 0) remove(tmp.c_str());
             }
         }
+        if (hold_lock) remove(lock.c_str());                      // whether or not the build was published
         tree_levels = kdtree_levels(n_cells);
         if (exact) {
             std::vector<uint32_t> packed((size_t)n_cells);

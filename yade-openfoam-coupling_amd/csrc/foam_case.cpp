@@ -316,6 +316,14 @@ int read_controls(fy_foam_case* c) {
                 if (std::string(w.dict) == "divSchemes" && joined.find("none") != 0) {
                     const int sch = joined.find("inearUpwind") != std::string::npos ? FY_CONVECTION_LINEAR_UPWIND
                                   : joined.find("upwind") != std::string::npos ? FY_CONVECTION_UPWIND : FY_CONVECTION_LINEAR;
+                    // only the convection terms select the scheme (icoFoamYade.C:82 div(phi,U), UcEqn.H:5-6 div(alphaPhic,Uc), or `default`);
+                    // every other entry (the explicit stress term div(((alpha*nuEff)*dev2(T(grad(U))))) ...) must be plain Gauss linear
+                    const bool convection = k == "default" || k == "div(phi,U)" || k == "div(alphaPhic,Uc)" || k == "div(phic,Uc)";
+                    if (!convection) {
+                        if (sch != FY_CONVECTION_LINEAR) return fail(FY_ERR_UNSUPPORTED, "%s: divSchemes.%s = '%s': only the convection terms may be upwinded, this one must be Gauss linear", path.c_str(), k.c_str(), joined.c_str());
+                        continue;
+                    }
+                    if (k == "default") { if (!n_div) c->desc.convection_scheme = sch; continue; }      // a named convection entry overrides it
                     if (n_div++ && sch != c->desc.convection_scheme) return fail(FY_ERR_UNSUPPORTED, "%s: divSchemes mixes different convection schemes", path.c_str());
                     c->desc.convection_scheme = sch;
                 }
