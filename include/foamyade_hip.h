@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define FY_ABI_VERSION 2
+#define FY_ABI_VERSION 3
 
 /* ---- status codes ------------------------------------------------------------------------------------ */
 enum {
@@ -153,6 +153,11 @@ long long fy_locate_walk_count(fy_ctx*);
 typedef struct fy_particle_timings {
     double h2d, bin, locate_deposit, finalize, force, d2h, total;
     int64_t n_particles, n_pairs;     /* n_pairs = sum of k */
+    /* drop-in path (a transport is attached; all 0 otherwise).  h2d / d2h above then hold the whole receive / send phases as the
+       compute stream saw them; the four below split them: time on the PCIe copy stream and host time inside the transport calls */
+    double copy_in, copy_out;         /* first H2D start .. last H2D end, first D2H start .. last D2H end (copy stream, ms) */
+    double wire_recv, wire_send;      /* host wall time in the transport's record / result calls (ms) */
+    int64_t bytes_in, bytes_out;      /* bytes that crossed PCIe in each direction (records; forces + found flags) */
 } fy_particle_timings;
 int fy_get_particle_timings(fy_ctx*, fy_particle_timings* out);
 int fy_enable_timing(fy_ctx*, int on);

@@ -6,8 +6,8 @@ root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmcp"
 data = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(root + "/s*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        m = re.search(r"(k_\w+)", r["Kernel_Name"])
-        if m and m.group(1) in ("k_force_gaussian", "k_locate_deposit", "k_bin_gather"):
+        m = re.search(r"(k_\w+(?:<\d>)?)", r["Kernel_Name"])
+        if m and re.sub(r"<\d>", "", m.group(1)) in ("k_force_gaussian", "k_locate_deposit", "k_bin_gather", "k_pack_cells"):
             data[m.group(1)][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in data.items():
     av = {n: sum(v) / len(v) for n, v in d.items()}
@@ -18,4 +18,5 @@ for k, d in data.items():
     print("   VALU active / busy cycles:", pct("SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES"), "| VMEM:", pct("SQ_ACTIVE_INST_VMEM", "SQ_BUSY_CYCLES"), "| LDS:", pct("SQ_ACTIVE_INST_LDS", "SQ_BUSY_CYCLES"))
     print("   wave cycles waiting:", pct("SQ_WAIT_ANY", "SQ_WAVE_CYCLES"), "| LDS bank conflict share of LDS cycles:", pct("SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"))
     print("   VALU / VMEM-read / VMEM-write / SALU instructions:", *(f"{av.get(n, float('nan')):.3g}" for n in ("SQ_INSTS_VALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_SALU")))
+    print("   duration-ish: GUI active cycles", f"{g:.3g}", "| TCP->TCC read latency per req:", f"{av.get('TCP_TCC_READ_REQ_LATENCY_sum', float('nan')) / max(av.get('TCP_TCC_READ_REQ_sum', 1), 1):.0f}", "| TCP pending stall", f"{av.get('TCP_PENDING_STALL_CYCLES_sum', float('nan')):.3g}", "| TA data stall", f"{av.get('TCP_TCP_TA_DATA_STALL_CYCLES_sum', float('nan')):.3g}", "| TCC busy", f"{av.get('TCC_BUSY_sum', float('nan')):.3g}", "| TCC EA rd", f"{av.get('TCC_EA0_RDREQ_sum', float('nan')):.3g}")
     print("   L2 requests / atomics:", f"{av.get('TCC_REQ_sum', float('nan')):.3g}", f"{av.get('TCC_ATOMIC_sum', float('nan')):.3g}", "| TCP accesses / TCC read req:", f"{av.get('TCP_TOTAL_CACHE_ACCESSES_sum', float('nan')):.3g}", f"{av.get('TCP_TCC_READ_REQ_sum', float('nan')):.3g}")

@@ -70,6 +70,38 @@ struct DevBuf {
     }
 };
 
+// Owning PINNED host allocation (hipHostMalloc): the staging side of every host<->device copy on the drop-in path.  Copies from or to
+// pageable memory are staged by the runtime through its own small pinned buffers and block the caller; from pinned memory they run
+// at PCIe rate, asynchronously, on whatever stream they are put on.
+template <class T>
+struct HostBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    HostBuf() = default;
+    HostBuf(const HostBuf&) = delete;
+    HostBuf& operator=(const HostBuf&) = delete;
+    ~HostBuf() { release(); }
+    void release() {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    T* data() { return p; }
+    T& operator[](size_t i) { return p[i]; }
+    int reserve(size_t count) {          // grow-only, contents not kept
+        if (count <= n) return FY_OK;
+        release();
+        const size_t cap = count + count / 8 + 64;
+        hipError_t e = hipHostMalloc((void**)&p, cap * sizeof(T), hipHostMallocDefault);
+        if (e != hipSuccess) {
+            p = nullptr;
+            return fail(FY_ERR_HIP, "hipHostMalloc(%zu bytes) failed: %s", cap * sizeof(T), hipGetErrorString(e));
+        }
+        n = cap;
+        return FY_OK;
+    }
+};
+
 struct EventTimer {
     hipEvent_t a = nullptr, b = nullptr;
     bool armed = false;

@@ -197,6 +197,16 @@ int Coupling::create(const fy_mesh_desc* m, const fy_field_ptrs* f, int gaussian
         FY_HIP(hipMemsetAsync(d_pvol_acc.p, 0, nf * sizeof(double), stream));
         FY_HIP(hipMemsetAsync(d_up_acc.p, 0, 3 * nf * sizeof(double), stream));
         FY_HIP(hipMemsetAsync(d_touched.p, 0, nf, stream));
+        FY_TRY(d_cellrec.alloc_exact(8 * nf)); FY_TRY(d_drag_acc.alloc_exact(nf));
+        FY_HIP(hipMemsetAsync(d_cellrec.p, 0, 8 * nf * sizeof(double), stream));
+        FY_HIP(hipMemsetAsync(d_drag_acc.p, 0, nf * sizeof(double), stream));
+        if (const char* e = getenv("FOAMYADE_FORCE_SPLIT")) force_split = atoi(e) != 0;
+        if (getenv("FOAMYADE_NO_TILE_FLUSH")) tile_flush = false;
+        if (getenv("FOAMYADE_NO_SIDE_STREAM") == nullptr) {
+            FY_HIP(hipStreamCreateWithFlags(&side.stream, hipStreamNonBlocking));
+            FY_HIP(hipEventCreateWithFlags(&side.fork, hipEventDisableTiming));
+            FY_HIP(hipEventCreateWithFlags(&side.join, hipEventDisableTiming));
+        }
     }
 
     // ---- binning grid (locality only)
@@ -218,6 +228,19 @@ int Coupling::create(const fy_mesh_desc* m, const fy_field_ptrs* f, int gaussian
     }
     for (auto& t : timers) FY_TRY(t.init());
     if (const char* e = getenv("FOAMYADE_REBIN_INTERVAL")) rebin_interval = std::max(1, atoi(e));
+    if (has_transport || fields_on_host) {
+        FY_HIP(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+    }
+    if (fields_on_host && getenv("FOAMYADE_NO_HOST_REGISTER") == nullptr) {
+        // the caller's field arrays live as long as this object (FoamYade.H:76-90 holds references to them): pin them in place so that the
+        // per-step staging copies run at PCIe rate.  Best effort -- an array that cannot be registered is simply copied as pageable.
+        const size_t nb = (size_t)n_cells * sizeof(double);
+        struct { const void* p; size_t bytes; } arr[] = {{f->U, 3 * nb}, {f->gradP, 3 * nb}, {f->vGrad, 9 * nb}, {f->divT, 3 * nb}, {f->ddtU, 3 * nb},
+                                                         {f->uSourceDrag, nb}, {f->alpha, nb}, {f->uSource, 3 * nb}, {f->uParticle, 3 * nb}};
+        for (auto& a : arr)
+            if (a.p && hipHostRegister(const_cast<void*>(a.p), a.bytes, hipHostRegisterDefault) == hipSuccess) registered.push_back(const_cast<void*>(a.p));
+        (void)hipGetLastError();
+    }
 
     // ---- parallel Yade: yadeProcs + sendMeshBbox, FoamYade.C:35-45,77-111
     if (has_transport && !serial_yade) {
@@ -340,6 +363,20 @@ int Coupling::ensure_batch(Batch& b, int64_t n) {
             FY_TRY(b.soa.alloc_exact(7 * c2)); FY_TRY(b.orig.alloc_exact(c2)); FY_TRY(b.chain.alloc_exact(c2));
             FY_TRY(b.ids.alloc_exact((size_t)kMaxK * c2)); FY_TRY(b.w.alloc_exact((size_t)kMaxK * c2));
             FY_TRY(b.key.alloc_exact(c2)); FY_TRY(b.rank.alloc_exact(c2));
+            if (force_split) FY_TRY(b.fscr.alloc_exact(4 * c2));
+            if (tile_flush && structured) {
+                const size_t nt = (size_t)tile_grid().n_tiles();
+                for (int w = 0; w < 2; ++w) {
+                    FY_TRY(b.tb_off[w].alloc_exact(nt)); FY_TRY(b.tb_cap[w].alloc_exact(nt)); FY_TRY(b.tb_fill[w].alloc_exact(nt));
+                    FY_HIP(hipMemsetAsync(b.tb_off[w].p, 0, nt * sizeof(uint32_t), stream));
+                    FY_HIP(hipMemsetAsync(b.tb_cap[w].p, 0, nt * sizeof(uint32_t), stream));
+                    FY_HIP(hipMemsetAsync(b.tb_fill[w].p, 0, nt * sizeof(uint32_t), stream));
+                }
+                // entry pool: a workgroup's table holds ~1 entry per 10 pairs (measured 8 - 12), i.e. ~0.55 per particle at k = 5.5; two per
+                // particle leave room for poorly aggregating clouds, and whatever does not fit simply goes out as atomics
+                const size_t pool = 2 * c2 + 136 * nt;
+                if (tile_cell.n < pool) { FY_TRY(tile_cell.alloc_exact(pool)); FY_TRY(tile_val.alloc_exact(4 * pool)); }
+            }
             b.cap = c2;
             b.binned_n = -1;          // fresh arrays: the old placement is gone
         }
@@ -357,11 +394,54 @@ ParticleSoA Coupling::soa_of(Batch& b) {
     return p;
 }
 
+TileGrid Coupling::tile_grid() const {
+    TileGrid tg{};
+    tg.nx = mesh.nx; tg.ny = mesh.ny;
+    tg.nzs = (int)(n_field / ((int64_t)mesh.nx * mesh.ny));             // planes of the storage block (a slab: owned + ghost planes)
+    tg.ntx = (tg.nx + kTileEdge - 1) / kTileEdge; tg.nty = (tg.ny + kTileEdge - 1) / kTileEdge; tg.ntz = (tg.nzs + kTileEdge - 1) / kTileEdge;
+    return tg;
+}
+
+// which = 0: the void-fraction deposit's flush, 1: the momentum-source back-scatter's
+TileBuckets Coupling::buckets_of(Batch& b, int which) {
+    TileBuckets tb{};
+    if (!tile_flush || !b.tb_off[which].p || !tile_cell.p) return tb;
+    tb.cell = tile_cell.p; tb.val = tile_val.p;
+    tb.off = b.tb_off[which].p; tb.cap = b.tb_cap[which].p; tb.fill = b.tb_fill[which].p;
+    tb.pool = (uint32_t)std::min<size_t>(tile_cell.n, 0xfffffff0u);
+    tb.tg = tile_grid();
+    return tb;
+}
+
 int Coupling::set_particles_host(int bi, const double* rec, int64_t n) {
     if (bi < 0 || bi >= n_batches || n < 0 || (n > 0 && !rec)) return fail(FY_ERR_INVALID, "fy_set_particles_host: bad batch/arguments");
     Batch& b = *batches[bi];
     FY_TRY(b.rec_own.reserve(10 * (size_t)std::max<int64_t>(n, 1)));
     if (n) FY_HIP(hipMemcpyAsync(b.rec_own.p, rec, 10 * (size_t)n * sizeof(double), hipMemcpyHostToDevice, stream));
+    b.d_rec = b.rec_own.p;
+    return ensure_batch(b, n);
+}
+
+int Coupling::ensure_batch_events(Batch& b) {
+    if (b.events) return FY_OK;
+    FY_TRY(b.t_in.init()); FY_TRY(b.t_out.init());
+    FY_HIP(hipEventCreateWithFlags(&b.ev_ready, hipEventDisableTiming));
+    b.events = true;
+    return FY_OK;
+}
+
+// records that the transport has just delivered into the batch's pinned staging buffer: H2D on the copy stream (so that it overlaps the
+// kernels of the batches received before, which are already running on the compute stream); the compute stream waits for the event
+int Coupling::upload_batch(Batch& b, int64_t n) {
+    FY_TRY(ensure_batch_events(b));
+    FY_TRY(b.rec_own.reserve(10 * (size_t)std::max<int64_t>(n, 1)));
+    b.t_in.start(copy_stream);
+    if (n) {
+        FY_HIP(hipMemcpyAsync(b.rec_own.p, b.h_rec.p, 10 * (size_t)n * sizeof(double), hipMemcpyHostToDevice, copy_stream));
+        tm.bytes_in += 10 * n * (int64_t)sizeof(double);
+    }
+    b.t_in.stop(copy_stream);
+    FY_HIP(hipStreamWaitEvent(stream, b.t_in.b, 0));
     b.d_rec = b.rec_own.p;
     return ensure_batch(b, n);
 }
@@ -465,25 +545,37 @@ int Coupling::run_batch(Batch& b) {
         }
         const CellWindow cw{slab.active ? slab.base : 0, n_field};
         static const bool unfused = getenv("FOAMYADE_UNFUSED_DEPOSIT") != nullptr;      // A/B switch: k_locate_lists + k_deposit
+        // the scatters' tables are flushed into per-tile buckets sized from the demand they counted in this batch's last step
+        const TileBuckets tbD = buckets_of(b, 0), tbB = buckets_of(b, 1);
+        FY_TRY(launch_tile_caps(stream, tbD, tbB));
         if (unfused) {
             FY_TRY(launch_locate(stream, d_tree.p, use_implicit ? d_tree_packed.p : nullptr, implicit, n_cells, tree_levels, p, b.n, gp,
                                  use_implicit ? d_loc_start.p : nullptr, slab_own(), ll));
             if (timing) { timers[T_LOCATE].stop(stream); timers[T_FINALIZE].start(stream); }
-            FY_TRY(launch_deposit(stream, p, b.n, gp, cw, d_pvol_acc.p, d_up_acc.p, d_touched.p));
+            FY_TRY(launch_deposit(stream, p, b.n, gp, cw, d_pvol_acc.p, d_up_acc.p, d_touched.p, tbD));
         } else {
             FY_TRY(launch_locate_deposit(stream, d_tree.p, use_implicit ? d_tree_packed.p : nullptr, implicit, n_cells, tree_levels, p, b.n, gp,
-                                         use_implicit ? d_loc_start.p : nullptr, slab_own(), ll, cw, d_pvol_acc.p, d_up_acc.p, d_touched.p));
+                                         use_implicit ? d_loc_start.p : nullptr, slab_own(), ll, cw, d_pvol_acc.p, d_up_acc.p, d_touched.p, tbD, side));
             if (timing) { timers[T_LOCATE].stop(stream); timers[T_FINALIZE].start(stream); }
         }
+        // The force pass gathers U, alpha and the Archimedes term from one packed record per cell.  U / gradP / divT do not change during the
+        // call and the alpha slot follows k_finalize_cells, so the records are built once per call -- here, where the pack runs beside the
+        // walk's leftovers on the side stream
+        if (!cellrec_fresh) {
+            FY_TRY(launch_pack_cells(stream, n_field, dU, dAlpha, dGradP, dDivT, d_vol.p, nu, rhoF, d_cellrec.p));
+            cellrec_fresh = true;
+        }
+        if (side.stream && ll.lists && !unfused) FY_HIP(hipStreamWaitEvent(stream, side.join, 0));
+        FY_TRY(launch_tile_reduce(stream, tbD, d_pvol_acc.p, d_up_acc.p, d_touched.p));
         if (slab.active) {      // contributions that landed in ghost planes belong to the neighbours: send them home and add
             FY_TRY(halo_reverse_add2(d_pvol_acc.p, 1, d_touched.p, d_up_acc.p, 3));
         }
-        FY_TRY(launch_finalize_cells(stream, (int32_t)n_field, d_vol.p, d_pvol_acc.p, d_up_acc.p, d_touched.p, dAlpha, dUParticle));
-        if (slab.active) {      // the gathers below reach gz planes into the neighbours
-            slab.comm->group_begin();
+        FY_TRY(launch_finalize_cells(stream, (int32_t)n_field, d_vol.p, d_pvol_acc.p, d_up_acc.p, d_touched.p, dAlpha, dUParticle, d_cellrec.p));
+        if (slab.active) {      // the gathers below reach gz planes into the neighbours (alpha only: uParticle is applied per cell by its owner, k_fold_sources)
             FY_TRY(halo_fwd(dAlpha, 1, slab.gz));
-            FY_TRY(halo_fwd(dUParticle, 3, slab.gz));
-            FY_TRY(slab.comm->group_end(stream));
+            const int64_t gcells = (int64_t)slab.gz * (int64_t)slab.plane;
+            FY_TRY(launch_patch_rec_alpha(stream, 0, gcells, dAlpha, d_cellrec.p));
+            FY_TRY(launch_patch_rec_alpha(stream, (int64_t)(slab.gz + slab.nz) * (int64_t)slab.plane, gcells, dAlpha, d_cellrec.p));
         }
         if (timing) { timers[T_FINALIZE].stop(stream); timers[T_FORCE].start(stream); }
         // Gaussian torque is identically zero unless the opt-in model is on (FoamYade.C:618): zero the records once per buffer,
@@ -497,12 +589,15 @@ int Coupling::run_batch(Batch& b) {
             }
             fp.torque_prezeroed = 1;
         }
-        FY_TRY(launch_force_gaussian(stream, p, b.n, fp, cw, d_vol.p, dU, dAlpha, dUParticle, dGradP, dDivT, dVGrad, dDdtU, b.d_rec,
-                                     dUSourceDrag, dUSource, b.force.p, b.found.p));
+        FY_TRY(launch_force_gaussian(stream, p, b.n, fp, cw, d_vol.p, d_cellrec.p, dVGrad, dDdtU, b.d_rec, force_split ? b.fscr.p : nullptr,
+                                     d_drag_acc.p, dUSource, b.force.p, tbB));
+        FY_TRY(launch_tile_reduce(stream, tbB, d_drag_acc.p, dUSource, nullptr));
         b.found_stale = true;
         if (slab.active) {
-            FY_TRY(halo_reverse_add2(dUSourceDrag, 1, nullptr, dUSource, 3));
+            FY_TRY(halo_reverse_add2(d_drag_acc.p, 1, nullptr, dUSource, 3));
         }
+        // FoamYade.C:385-386 per cell: uSourceDrag += D, uSource += uParticle * D (this batch's uParticle: the owner's, after its finalize)
+        FY_TRY(launch_fold_sources(stream, n_field, d_drag_acc.p, dUParticle, dUSourceDrag, dUSource));
         if (timing) timers[T_FORCE].stop(stream);
     } else {
         BlockGeom g;
@@ -525,26 +620,28 @@ int Coupling::set_particle_action(double dt) {
     tm = fy_particle_timings{};
     if (timing) timers[T_TOTAL].start(stream);
 
-    // ---- receive particles
-    if (has_transport) {
-        if (timing) timers[T_H2D].start(stream);
-        if (!serial_yade) FY_TRY(recv_yade_intrs());                       // FoamYade.C:609
-        else FY_TRY(recv_serial());                                        // FoamYade.C:173-184
-        if (timing) timers[T_H2D].stop(stream);
-    }
+    // the force pass gathers U, alpha and the Archimedes term from one packed record per cell; U / gradP / divT do not change during
+    // the call and alpha follows k_finalize_cells, so the records are built once here
     if (fields_on_host) { FY_TRY(stage_readonly_in()); FY_TRY(stage_mutable_in()); }
+    cellrec_fresh = false;
 
-    // ---- locate + deposit + finalize + force, one Yade proc after the other (FoamYade.C:612-628)
-    for (int bi = 0; bi < n_batches; ++bi) FY_TRY(run_batch(*batches[bi]));
+    // ---- receive particles, and per Yade proc: locate + deposit + finalize + force (FoamYade.C:609, 612-628).  With a transport every
+    // batch is processed as soon as its records have landed, so the kernels of batch q run while the host waits for batch q + 1 on the
+    // wire and while its records cross PCIe on the copy stream; results are the reference's (one Yade proc after the other).
+    wire_recv_ms = wire_send_ms = 0.0;
+    if (has_transport) {
+        if (!serial_yade) FY_TRY(recv_yade_intrs());                       // FoamYade.C:609 (runs the batches itself)
+        else { FY_TRY(recv_serial()); FY_TRY(run_batch(*batches[0])); }    // FoamYade.C:173-184
+    } else {
+        for (int bi = 0; bi < n_batches; ++bi) FY_TRY(run_batch(*batches[bi]));
+    }
     if (slab.active && gaussian) FY_TRY(halo_fwd(dUSource, 3, 1));       // UcEqn.H:17-20 interpolates rAUc*uSource across the interface
 
     if (fields_on_host) FY_TRY(stage_mutable_out());
 
     // ---- send results
     if (has_transport) {
-        if (timing) timers[T_D2H].start(stream);
         FY_TRY(send_results());                                            // FoamYade.C:228,239-243,487-535
-        if (timing) timers[T_D2H].stop(stream);
         FY_TRY(exchange_dt());                                             // FoamYade.C:537-553
     }
     if (timing) {
@@ -559,10 +656,23 @@ int Coupling::collect_timings() {
     if (!timings_pending) return FY_OK;
     timings_pending = false;
     FY_HIP(hipStreamSynchronize(stream));
-    tm.h2d = timers[T_H2D].ms(); tm.bin = timers[T_BIN].ms(); tm.locate_deposit = timers[T_LOCATE].ms();
-    tm.finalize = timers[T_FINALIZE].ms(); tm.force = timers[T_FORCE].ms(); tm.d2h = timers[T_D2H].ms(); tm.total = timers[T_TOTAL].ms();
+    tm.bin = timers[T_BIN].ms(); tm.locate_deposit = timers[T_LOCATE].ms();
+    tm.finalize = timers[T_FINALIZE].ms(); tm.force = timers[T_FORCE].ms(); tm.total = timers[T_TOTAL].ms();
+    if (copy_stream) {
+        FY_HIP(hipStreamSynchronize(copy_stream));
+        for (auto* b : batches) if (b->events) { tm.copy_in += b->t_in.ms(); tm.copy_out += b->t_out.ms(); }
+    }
+    tm.h2d = tm.copy_in; tm.d2h = tm.copy_out;              // the PCIe copies themselves (sum over the batches), on the copy stream
+    tm.wire_recv = wire_recv_ms; tm.wire_send = wire_send_ms;
     return FY_OK;
 }
+
+namespace {
+struct WallClock {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    double ms() const { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+};
+}  // namespace
 
 // serial Yade: Bcast N, Bcast 10N doubles (FoamYade.C:176-183)
 int Coupling::recv_serial() {
@@ -571,15 +681,18 @@ int Coupling::recv_serial() {
     if (N < 0) return fail(FY_ERR_TRANSPORT, "negative particle count from Yade");
     Batch& b = *batches[0];
     b.yrank = 0;
-    b.h_rec.resize(10 * (size_t)N);
+    FY_TRY(b.h_rec.reserve(10 * (size_t)std::max(N, 1)));
     // the reference broadcasts the record buffer unconditionally (FoamYade.C:181), also when it is empty: a collective has to be
     // matched by every rank, so the zero-count call is issued too
     double none = 0.0;
+    const WallClock wc;
     FY_TR(transport.bcast_world(transport.user, N ? b.h_rec.data() : &none, 10 * N, FY_T_DOUBLE, 0));
-    return set_particles_host(0, b.h_rec.data(), N);
+    wire_recv_ms += wc.ms();
+    return upload_batch(b, N);
 }
 
-// parallel Yade: counts from every worker, then records from the intersecting ones (FoamYade.C:114-155)
+// parallel Yade: counts from every worker, then records from the intersecting ones (FoamYade.C:114-155); each batch's kernels are
+// enqueued as soon as its records are on their way to the device
 int Coupling::recv_yade_intrs() {
     const int W = comm_sz_diff - 1;
     std::vector<int> counts((size_t)transport.local_size);
@@ -594,26 +707,40 @@ int Coupling::recv_yade_intrs() {
         Batch& b = *batches[q];
         b.yrank = in_comm[q].first;
         const int n = in_comm[q].second;
-        b.h_rec.resize(10 * (size_t)n);
+        FY_TRY(b.h_rec.reserve(10 * (size_t)n));
+        const WallClock wc;
         FY_TR(transport.recv(transport.user, b.h_rec.data(), 10 * n, FY_T_DOUBLE, b.yrank, TAG_YADE_DATA));
-        FY_TRY(set_particles_host((int)q, b.h_rec.data(), n));
+        wire_recv_ms += wc.ms();
+        FY_TRY(upload_batch(b, n));
+        FY_TRY(run_batch(b));
     }
     return FY_OK;
 }
 
 int Coupling::send_results() {
+    // D2H of every batch's found flags and forces on the copy stream, each behind the event that says its results are final; the
+    // host then hands batch after batch to the transport as its copy lands (the copy of batch q + 1 overlaps the send of batch q)
     for (int bi = 0; bi < n_batches; ++bi) {
         Batch& b = *batches[bi];
-        b.h_found.resize((size_t)b.n); b.h_force.resize(6 * (size_t)b.n);
+        FY_TRY(ensure_batch_events(b));
+        FY_TRY(b.h_found.reserve((size_t)std::max<int64_t>(b.n, 1))); FY_TRY(b.h_force.reserve(6 * (size_t)std::max<int64_t>(b.n, 1)));
         if (b.n) {
             FY_TRY(ensure_found(b));
-            FY_HIP(hipMemcpyAsync(b.h_found.data(), b.found.p, (size_t)b.n * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
-            FY_HIP(hipMemcpyAsync(b.h_force.data(), b.force.p, 6 * (size_t)b.n * sizeof(double), hipMemcpyDeviceToHost, stream));
+            FY_HIP(hipEventRecord(b.ev_ready, stream));
+            FY_HIP(hipStreamWaitEvent(copy_stream, b.ev_ready, 0));
         }
+        b.t_out.start(copy_stream);
+        if (b.n) {
+            FY_HIP(hipMemcpyAsync(b.h_found.data(), b.found.p, (size_t)b.n * sizeof(int32_t), hipMemcpyDeviceToHost, copy_stream));
+            FY_HIP(hipMemcpyAsync(b.h_force.data(), b.force.p, 6 * (size_t)b.n * sizeof(double), hipMemcpyDeviceToHost, copy_stream));
+            tm.bytes_out += b.n * (int64_t)(sizeof(int32_t) + 6 * sizeof(double));
+        }
+        b.t_out.stop(copy_stream);
     }
-    FY_HIP(hipStreamSynchronize(stream));
     if (serial_yade) {
         Batch& b = *batches[0];
+        FY_HIP(hipEventSynchronize(b.t_out.b));
+        const WallClock wc;
         const int N = (int)b.n;
         send_ranks.assign((size_t)N, -1);
         for (int np = 0; np < N; ++np) {                                    // one MAX all-reduce PER PARTICLE, FoamYade.C:202,223,228
@@ -631,14 +758,20 @@ int Coupling::send_results() {
                 if (send_ranks[(size_t)np] == transport.world_rank)
                     FY_TR(transport.send(transport.user, &b.h_force[6 * (size_t)np], 6, FY_T_DOUBLE, 0, TAG_FORCE));
         }
+        wire_send_ms += wc.ms();
     } else {
         for (int bi = 0; bi < n_batches; ++bi) {                            // FoamYade.C:239-243
             Batch& b = *batches[bi];
+            FY_HIP(hipEventSynchronize(b.t_out.b));
+            const WallClock wc;
             FY_TR(transport.send(transport.user, b.h_found.data(), (int)b.n, FY_T_INT, b.yrank, TAG_SEARCH_RES));
+            wire_send_ms += wc.ms();
         }
         for (int bi = 0; bi < n_batches; ++bi) {                            // FoamYade.C:504-507
             Batch& b = *batches[bi];
+            const WallClock wc;
             FY_TR(transport.send(transport.user, b.h_force.data(), 6 * (int)b.n, FY_T_DOUBLE, b.yrank, TAG_FORCE));
+            wire_send_ms += wc.ms();
         }
     }
     return FY_OK;
@@ -784,6 +917,11 @@ Coupling::~Coupling() {
     if (device >= 0) (void)hipSetDevice(device);
     for (auto& t : timers) t.destroy();
     for (auto* b : batches) delete b;
+    for (void* r : registered) (void)hipHostUnregister(r);
+    if (side.fork) (void)hipEventDestroy(side.fork);
+    if (side.join) (void)hipEventDestroy(side.join);
+    if (side.stream) (void)hipStreamDestroy(side.stream);
+    if (copy_stream) (void)hipStreamDestroy(copy_stream);
     if (owns_stream && stream) (void)hipStreamDestroy(stream);
 }
 

@@ -22,13 +22,21 @@ struct Batch {
     DevBuf<int32_t> orig, chain, ids, found, incell;
     DevBuf<double> w, force;
     DevBuf<uint32_t> key, rank;
+    DevBuf<double> fscr;                 // 4 * cap: {coeff, b} per particle between the two kernels of the split force pass (A/B switch)
     const double* torque_zero_buf = nullptr;   // force buffer whose torque slots [0, torque_zero_n) are known to be zero
     int64_t torque_zero_n = 0;
     bool found_stale = false;            // Gaussian mode: `found` is formed lazily from the chain lengths (ensure_found)
     int64_t binned_n = -1;               // particle count the current placement (orig) was computed for
     int bin_age = 0;                     // steps since it was computed
-    std::vector<double> h_rec, h_force;  // wire staging
-    std::vector<int32_t> h_found;
+    // tile buckets of the two scatters' flushes (TileBuckets): per-tile offsets / capacities / demand counters of this batch's population;
+    // [0] void-fraction deposit, [1] momentum-source back-scatter.  The entry pool itself is shared (Coupling::tile_cell / tile_val).
+    DevBuf<uint32_t> tb_off[2], tb_cap[2], tb_fill[2];
+    HostBuf<double> h_rec, h_force;      // wire staging (pinned: H2D / D2H at PCIe rate, asynchronous on the copy stream)
+    HostBuf<int32_t> h_found;
+    EventTimer t_in, t_out;              // the batch's H2D / D2H copies on the copy stream (their end events are what the compute stream / the host wait for)
+    hipEvent_t ev_ready = nullptr;       // results final on the compute stream
+    bool events = false;
+    ~Batch() { t_in.destroy(); t_out.destroy(); if (ev_ready) (void)hipEventDestroy(ev_ready); }
 };
 
 // z-slab mode (set by fy_solver before create()): the k-d tree spans the GLOBAL block, every cell array is this rank's slab
@@ -75,6 +83,12 @@ struct Coupling {
     bool loc_lists_tried = false;
     int32_t loc_cell0 = 0, loc_n_listed = 0;  // cells the lists cover (a slab: its own planes)
     int ensure_locate_tables(double maxdist);
+    DevBuf<uint32_t> tile_cell;          // entry pool of the tile buckets (one flush at a time uses it)
+    DevBuf<double> tile_val;
+    SideStream side{};                   // the walk's leftovers run here, beside the cell-record pack
+    bool tile_flush = true;              // FOAMYADE_NO_TILE_FLUSH=1: the scatters flush with global atomics (round-1 behaviour, A/B switch)
+    TileGrid tile_grid() const;
+    TileBuckets buckets_of(Batch& b, int which);
     ImplicitGeom implicit{};
     bool use_implicit = false;
     int tree_levels = 0;
@@ -87,12 +101,23 @@ struct Coupling {
     unsigned force_models = 0;           // FY_FORCE_*: the reference's call-site-less models (off = shipped behaviour)
     double *dUSourceDrag = nullptr, *dAlpha = nullptr, *dUSource = nullptr, *dUParticle = nullptr;
     DevBuf<double> d_pvol_acc, d_up_acc;           // per-batch deposit accumulators (pVolContrib / uParticleContrib)
+    bool cellrec_fresh = false;                    // d_cellrec was packed in this setParticleAction call
+    DevBuf<double> d_cellrec;                      // 8 doubles per cell: what the force pass gathers (k_pack_cells), rebuilt every setParticleAction
+    DevBuf<double> d_drag_acc;                     // per-batch sum of -coeff w / rho_f per cell, folded into uSourceDrag / uSource by k_fold_sources
+    bool force_split = false;                      // FOAMYADE_FORCE_SPLIT=1: gather and back-scatter of the force pass as two kernels (A/B switch)
     DevBuf<unsigned char> d_touched;
     BinGrid bins{};
     int rebin_interval = 8;              // full counting sort every this many steps (FOAMYADE_REBIN_INTERVAL; 1 = every step)
     DevBuf<uint32_t> d_hist, d_tile_sums;
     std::vector<Batch*> batches;
     int n_batches = 0;
+
+    // ---- drop-in path (host-resident peer): pinned staging, copies on their own stream, overlapped with the kernels of the other batches
+    hipStream_t copy_stream = nullptr;
+    double wire_recv_ms = 0, wire_send_ms = 0;  // host wall time inside the transport's data calls (the MPI side)
+    std::vector<void*> registered;              // caller-owned FY_MEM_HOST field arrays pinned in place (hipHostRegister)
+    int ensure_batch_events(Batch& b);
+    int upload_batch(Batch& b, int64_t n);      // pinned h_rec -> rec_own on the copy stream; the compute stream waits for it
 
     // ---- timing
     enum { T_H2D = 0, T_BIN, T_LOCATE, T_FINALIZE, T_FORCE, T_D2H, T_TOTAL, T_COUNT };

@@ -15,6 +15,9 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace fy {
@@ -559,8 +562,168 @@ __device__ __forceinline__ int agg_slot(uint32_t* keys, uint32_t cell) {
 
 __device__ __forceinline__ void lds_add_f64(double* p, double v) { unsafeAtomicAdd(p, v); }   // ds_add_f64
 
+// ------------------------------------------------------------------------------------------------ tile buckets (see particle_kernels.hpp)
+// storage cell index -> (tile, cell inside the tile)
+__device__ __forceinline__ void tile_of(const TileGrid& tg, uint32_t cl, uint32_t* tile, uint32_t* local) {
+    const uint32_t i = cl % (uint32_t)tg.nx, r = cl / (uint32_t)tg.nx;
+    const uint32_t j = r % (uint32_t)tg.ny, k = r / (uint32_t)tg.ny;
+    *tile = (i >> 3) + (uint32_t)tg.ntx * ((j >> 3) + (uint32_t)tg.nty * (k >> 3));
+    *local = (i & 7u) | ((j & 7u) << 3) | ((k & 7u) << 6);
+}
+
+// k_tile_caps: block b serves bucket set b.  cap[t] = demand x 1.25 + 128, offsets by an exclusive scan, clamped to the pool; demand reset
+__global__ __launch_bounds__(1024) void k_tile_caps(TileBuckets s0, TileBuckets s1) {
+    const TileBuckets tb = blockIdx.x == 0 ? s0 : s1;
+    if (!tb.cell) return;
+    const int n_tiles = tb.tg.n_tiles();
+    __shared__ uint32_t wave_tot[16];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int base = 0; base < n_tiles; base += 1024) {
+        const int t = base + (int)threadIdx.x;
+        uint32_t want = 0;
+        if (t < n_tiles) {
+            const uint32_t need = tb.fill[t];
+            want = need ? ((need + (need >> 2) + 128u + 7u) & ~7u) : 0u;      // a tile nobody wrote to last step keeps no room (its first entries go out as atomics)
+            tb.fill[t] = 0;
+        }
+        uint32_t inc = want;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t y = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += y;
+        }
+        if (lane == 63) wave_tot[wv] = inc;
+        __syncthreads();
+        uint32_t woff = carry;
+        for (int q = 0; q < wv; ++q) woff += wave_tot[q];
+        uint32_t start = woff + inc - want;
+        if (t < n_tiles) {
+            // the pool is finite: a tile that no longer fits gets what is left (its excess goes out as atomics)
+            if (start > tb.pool) start = tb.pool;
+            const uint32_t room = tb.pool - start;
+            tb.off[t] = start;
+            tb.cap[t] = want < room ? want : room;
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = woff + inc;
+        __syncthreads();
+    }
+}
+
+// A workgroup's aggregation table -> the tiles' buckets.  Per table entry: which tile, and the entry's rank among this workgroup's
+// entries for that tile (a 128-slot LDS map: a workgroup's stencils reach a few dozen tiles); one returning global atomic per
+// (workgroup, tile) claims the run; plain stores.  What finds no room (bucket full, map full, or no buckets at all) is added with
+// the four global atomics.  Every thread of the workgroup calls this (it synchronises).
+constexpr int kTileMap = 128;
+struct TileMapLds { uint32_t tile[kTileMap], cnt[kTileMap], base[kTileMap]; };
+
+template <int NSLOTS, int NTHREADS>
+__device__ __forceinline__ void flush_table(const uint32_t* keys, const double* vals, TileMapLds& m, const TileBuckets& tb, double* __restrict__ dst0,
+                                            double* __restrict__ dst3, unsigned char* __restrict__ touched) {
+    static_assert(NSLOTS % NTHREADS == 0, "table slots per thread");
+    constexpr int R = NSLOTS / NTHREADS;
+    uint32_t pr[R];                                         // map slot << 16 | rank; 0xffffffff: empty table slot; 0xfffffffe: no room in the map
+#pragma unroll
+    for (int r = 0; r < R; ++r) pr[r] = keys[threadIdx.x + r * NTHREADS] == kAggEmpty ? 0xffffffffu : 0xfffffffeu;
+    if (tb.cell) {                                          // (uniform)
+        for (int q = threadIdx.x; q < kTileMap; q += NTHREADS) { m.tile[q] = kAggEmpty; m.cnt[q] = 0; }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (pr[r] == 0xffffffffu) continue;
+            uint32_t tile, local;
+            tile_of(tb.tg, keys[threadIdx.x + r * NTHREADS], &tile, &local);
+            uint32_t h = (tile * 2654435761u) >> 25;        // 7 bits
+#pragma unroll 1
+            for (int probe = 0; probe < kTileMap; ++probe) {
+                const uint32_t old = atomicCAS(&m.tile[h], kAggEmpty, tile);
+                if (old == kAggEmpty || old == tile) { pr[r] = (h << 16) | atomicAdd(&m.cnt[h], 1u); break; }
+                h = (h + 1) & (kTileMap - 1);
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < kTileMap && m.tile[threadIdx.x] != kAggEmpty)
+            m.base[threadIdx.x] = atomicAdd(&tb.fill[m.tile[threadIdx.x]], m.cnt[threadIdx.x]);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        if (pr[r] == 0xffffffffu) continue;
+        const int q = threadIdx.x + r * NTHREADS;
+        const uint32_t c = keys[q];
+        const double v0 = vals[4 * q], v1 = vals[4 * q + 1], v2 = vals[4 * q + 2], v3 = vals[4 * q + 3];
+        bool placed = false;
+        if (pr[r] != 0xfffffffeu) {
+            const uint32_t slot = pr[r] >> 16, rank = pr[r] & 0xffffu;
+            const uint32_t tile = m.tile[slot], pos = m.base[slot] + rank;
+            if (pos < tb.cap[tile]) {
+                uint32_t t2, local;
+                tile_of(tb.tg, c, &t2, &local);
+                const size_t at = (size_t)tb.off[tile] + pos;
+                tb.cell[at] = local;
+                double2* o = reinterpret_cast<double2*>(tb.val + 4 * at);
+                o[0] = make_double2(v0, v1);
+                o[1] = make_double2(v2, v3);
+                placed = true;
+            }
+        }
+        if (!placed) {
+            atomic_add_f64(&dst0[c], v0);
+            atomic_add_f64(&dst3[3 * (size_t)c + 0], v1);
+            atomic_add_f64(&dst3[3 * (size_t)c + 1], v2);
+            atomic_add_f64(&dst3[3 * (size_t)c + 2], v3);
+            if (touched) touched[c] = 1;
+        }
+    }
+}
+
+// One workgroup per tile of 8 x 8 x 8 cells: the tile's bucket is summed into a dense LDS accumulator (ds_add_f64: ~37 x the global
+// atomics' rate), then the tile goes to the cell arrays with plain read-modify-writes -- this workgroup is the tile's only writer.
+__global__ __launch_bounds__(256) void k_tile_reduce(TileBuckets tb, double* __restrict__ dst0, double* __restrict__ dst3, unsigned char* __restrict__ touched) {
+    __shared__ double acc[kTileCells * 4];
+    const uint32_t tile = blockIdx.x;
+    uint32_t cnt = tb.fill[tile];
+    const uint32_t cap = tb.cap[tile];
+    if (cnt > cap) cnt = cap;
+    if (cnt == 0) return;                                   // (block-uniform)
+    for (int q = threadIdx.x; q < kTileCells * 4; q += 256) acc[q] = 0.0;
+    __syncthreads();
+    const size_t off = tb.off[tile];
+    for (uint32_t j = threadIdx.x; j < cnt; j += 256) {
+        const uint32_t l = tb.cell[off + j];
+        const double2* v = reinterpret_cast<const double2*>(tb.val + 4 * (off + j));
+        const double2 v0 = v[0], v1 = v[1];
+        double* a = acc + 4 * l;
+        lds_add_f64(a, v0.x); lds_add_f64(a + 1, v0.y); lds_add_f64(a + 2, v1.x); lds_add_f64(a + 3, v1.y);
+    }
+    __syncthreads();
+    const TileGrid& tg = tb.tg;
+    const int ti = (int)(tile % (uint32_t)tg.ntx), tj = (int)((tile / (uint32_t)tg.ntx) % (uint32_t)tg.nty), tk = (int)(tile / (uint32_t)(tg.ntx * tg.nty));
+    for (int l = threadIdx.x; l < kTileCells; l += 256) {
+        const int i = ti * 8 + (l & 7), j = tj * 8 + ((l >> 3) & 7), k = tk * 8 + (l >> 6);
+        if (i >= tg.nx || j >= tg.ny || k >= tg.nzs) continue;
+        const double a0 = acc[4 * l], a1 = acc[4 * l + 1], a2 = acc[4 * l + 2], a3 = acc[4 * l + 3];
+        if (a0 == 0.0 && a1 == 0.0 && a2 == 0.0 && a3 == 0.0) continue;
+        const size_t c = (size_t)i + (size_t)tg.nx * ((size_t)j + (size_t)tg.ny * (size_t)k);
+        dst0[c] += a0;
+        double* d = dst3 + 3 * c;
+        const double d0 = d[0] + a1, d1 = d[1] + a2, d2 = d[2] + a3;
+        d[0] = d0; d[1] = d1; d[2] = d2;
+        if (touched) touched[c] = 1;
+    }
+}
+
 // buildCellPartList FoamYade.C:265-288: pVol*w and (w*v)*pVol per (particle, cell) pair into the per-batch accumulators
-constexpr int kDepThreads = 512, kDepLog2 = 11;      // 2048 slots x (4 + 32) B = 72 KiB of LDS
+#ifndef FY_DEP_THREADS
+#define FY_DEP_THREADS 512
+#endif
+#ifndef FY_DEP_LOG2
+#define FY_DEP_LOG2 10
+#endif
+constexpr int kDepThreads = FY_DEP_THREADS, kDepLog2 = FY_DEP_LOG2;      // 1024 slots x (4 + 32) B = 36 KiB of LDS (2048: 1.46 vs 1.36 ms for k_locate_deposit -- occupancy)
 // table crowded (practically never): straight to memory.  Out of line -- k_locate_deposit inlines deposit_pair 24 times
 __device__ __attribute__((noinline)) void deposit_direct(int32_t cid, double c0, double c1, double c2, double c3, double* __restrict__ pvol_acc,
                                                          double* __restrict__ up_acc, unsigned char* __restrict__ touched) {
@@ -582,25 +745,13 @@ __device__ __forceinline__ void deposit_pair(uint32_t* keys, double* vals, int32
         deposit_direct(cid, c0, c1, c2, c3, pvol_acc, up_acc, touched);
     }
 }
-__device__ __forceinline__ void deposit_flush(const uint32_t* keys, const double* vals, double* __restrict__ pvol_acc, double* __restrict__ up_acc,
-                                              unsigned char* __restrict__ touched) {
-    for (int q = threadIdx.x; q < (1 << kDepLog2); q += kDepThreads) {
-        const uint32_t cid = keys[q];
-        if (cid == kAggEmpty) continue;
-        atomic_add_f64(&pvol_acc[cid], vals[4 * q]);
-        atomic_add_f64(&up_acc[3 * (size_t)cid + 0], vals[4 * q + 1]);
-        atomic_add_f64(&up_acc[3 * (size_t)cid + 1], vals[4 * q + 2]);
-        atomic_add_f64(&up_acc[3 * (size_t)cid + 2], vals[4 * q + 3]);
-        touched[cid] = 1;
-    }
-}
-
 // work != nullptr: the particles listed there (k_locate_deposit's leftovers, placed by the walk), shared by a fixed grid
 __global__ __launch_bounds__(kDepThreads) void k_deposit(ParticleSoA p, int64_t n, GaussParams gp, CellWindow cw, double* __restrict__ pvol_acc,
                                                           double* __restrict__ up_acc, unsigned char* __restrict__ touched,
-                                                          const int32_t* __restrict__ work, const unsigned int* __restrict__ work_n) {
+                                                          const int32_t* __restrict__ work, const unsigned int* __restrict__ work_n, TileBuckets tb) {
     __shared__ uint32_t keys[1 << kDepLog2];
     __shared__ double vals[(1 << kDepLog2) * 4];
+    __shared__ TileMapLds tmap;
     if (work) { n = (int64_t)*work_n; if ((int64_t)blockIdx.x * kDepThreads >= n) return; }      // (block-uniform)
     for (int q = threadIdx.x; q < (1 << kDepLog2); q += kDepThreads) {
         keys[q] = kAggEmpty;
@@ -646,7 +797,7 @@ __global__ __launch_bounds__(kDepThreads) void k_deposit(ParticleSoA p, int64_t 
         }
     }
     __syncthreads();
-    deposit_flush(keys, vals, pvol_acc, up_acc, touched);
+    flush_table<(1 << kDepLog2), kDepThreads>(keys, vals, tmap, tb, pvol_acc, up_acc, touched);
 }
 
 // k_locate_lists and k_deposit in one pass over the particles: the list scan keeps the unnormalised Gaussian weight of every listed
@@ -655,12 +806,13 @@ __global__ __launch_bounds__(kDepThreads) void k_deposit(ParticleSoA p, int64_t 
 // as the two kernels: allwt adds the weights from the last push to the first (adding the zeros in between is exact).
 __global__ __launch_bounds__(kDepThreads) void k_locate_deposit(LocateLists ll, ImplicitGeom ig, ParticleSoA p, int64_t n,
                                                                  GaussParams gp, SlabOwn own, CellWindow cw, double* __restrict__ pvol_acc,
-                                                                 double* __restrict__ up_acc, unsigned char* __restrict__ touched) {
+                                                                 double* __restrict__ up_acc, unsigned char* __restrict__ touched, TileBuckets tb) {
     const unsigned short* __restrict__ lists = ll.lists;
     int32_t* __restrict__ fb_list = ll.fb_list;
     unsigned int* __restrict__ fb_count = ll.fb_count;
     __shared__ uint32_t keys[1 << kDepLog2];
     __shared__ double vals[(1 << kDepLog2) * 4];
+    __shared__ TileMapLds tmap;
     for (int q = threadIdx.x; q < (1 << kDepLog2); q += kDepThreads) {
         keys[q] = kAggEmpty;
         vals[4 * q] = 0.0; vals[4 * q + 1] = 0.0; vals[4 * q + 2] = 0.0; vals[4 * q + 3] = 0.0;
@@ -767,20 +919,22 @@ __global__ __launch_bounds__(kDepThreads) void k_locate_deposit(LocateLists ll, 
         }
     }
     __syncthreads();
-    deposit_flush(keys, vals, pvol_acc, up_acc, touched);
+    flush_table<(1 << kDepLog2), kDepThreads>(keys, vals, tmap, tb, pvol_acc, up_acc, touched);
 }
 
 // setCellVolFraction FoamYade.C:318-328: assignment on the cells this batch touched; accumulators reset for the next batch
 __global__ __launch_bounds__(256) void k_finalize_cells(int32_t n_cells, const double* __restrict__ vol, double* __restrict__ pvol_acc,
                                                         double* __restrict__ up_acc, unsigned char* __restrict__ touched,
-                                                        double* __restrict__ alpha, double* __restrict__ uParticle) {
+                                                        double* __restrict__ alpha, double* __restrict__ uParticle, double* __restrict__ R) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= n_cells) return;
     if (!touched[c]) return;
     touched[c] = 0;
     const double V = vol[c];
     const double pvolC = 1.0 - (pvol_acc[c] / V);
-    alpha[c] = ((pvolC > 0.10) ? pvolC : 0.10);
+    const double a = ((pvolC > 0.10) ? pvolC : 0.10);
+    alpha[c] = a;
+    if (R) R[8 * (size_t)c + 3] = a;       // the force pass reads alpha out of the packed cell record (k_pack_cells)
     double* up = up_acc + 3 * (size_t)c;
     double* o = uParticle + 3 * (size_t)c;
     o[0] = up[0] / V; o[1] = up[1] / V; o[2] = up[2] / V;
@@ -788,154 +942,222 @@ __global__ __launch_bounds__(256) void k_finalize_cells(int32_t n_cells, const d
 }
 
 // ------------------------------------------------------------------------------------------------ force + back-scatter
-constexpr int kForceThreads = 512, kForceLog2 = 11;
-__global__ __launch_bounds__(kForceThreads) void k_force_gaussian(ParticleSoA p, int64_t n, ForceParams fp, CellWindow cw, const double* __restrict__ vol,
-                                                                  const double* __restrict__ U, const double* __restrict__ alpha,
-                                                                  const double* __restrict__ uParticle, const double* __restrict__ gradP,
-                                                                  const double* __restrict__ divT, const double* __restrict__ vGrad,
-                                                                  const double* __restrict__ ddtU, const double* __restrict__ rec,
-                                                                  double* __restrict__ uSourceDrag,
-                                                                  double* __restrict__ uSource, double* __restrict__ force_out,
-                                                                  int32_t* __restrict__ found_out) {
-    __shared__ uint32_t keys[1 << kForceLog2];
-    __shared__ double vals[(1 << kForceLog2) * 4];
-    for (int q = threadIdx.x; q < (1 << kForceLog2); q += kForceThreads) {
-        keys[q] = kAggEmpty;
-        vals[4 * q] = 0.0; vals[4 * q + 1] = 0.0; vals[4 * q + 2] = 0.0; vals[4 * q + 3] = 0.0;
+// What bounded the round-1 force pass was the vector-memory pipeline: 13 eight-byte gathers per (particle, cell) pair out of five
+// cell arrays (U, alpha, gradP, divT and -- in the back-scatter loop -- uParticle), 632 M L1 accesses per launch.  Two changes:
+//   * the interpolated cell data comes from ONE 64-byte record per cell, CellRec = {U[3], alpha, A[3], V} with
+//     A = 2 nu rho_f divT - gradP (the two Archimedes terms of FoamYade.C:416-426 are both interpolated with the same weights, so their
+//     per-cell combination is interpolated instead): four 16-byte loads per pair, all from one line, instead of ten 8-byte ones from four;
+//   * the drag share of the momentum source, uSource[c] += -coeff w uParticle[c] / rho_f (FoamYade.C:386), has the per-CELL factor
+//     uParticle[c]; it is pulled out of the per-pair loop: the pairs only accumulate D[c] = sum -coeff w / rho_f (which is the
+//     reference's uSourceDrag contribution, FoamYade.C:385) and k_fold_sources adds D to uSourceDrag and uParticle[c] * D[c] to uSource once
+//     per cell -- no uParticle gather per pair.  The Archimedes share -f w / (V rho_f) (FoamYade.C:433) goes into uSource directly.
+// Rounding differs from the per-pair form in the last bits only (same terms, summed in another association): covered by the 1e-10 bar.
+constexpr int kRecDoubles = 8;      // CellRec: Ux Uy Uz alpha | Ax Ay Az V
+
+__global__ __launch_bounds__(256) void k_pack_cells(int64_t n_field, const double* __restrict__ U, const double* __restrict__ alpha,
+                                                    const double* __restrict__ gradP, const double* __restrict__ divT,
+                                                    const double* __restrict__ vol, double two_nu, double rhoF, double* __restrict__ R) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= n_field) return;
+    const double* u = U + 3 * (size_t)c;
+    const double* g = gradP + 3 * (size_t)c;
+    const double* d = divT + 3 * (size_t)c;
+    const double u0 = u[0], u1 = u[1], u2 = u[2];
+    // FoamYade.C:421-426: -gradP w + ((2 nu divT) w) rho_f, per cell
+    const double a0 = ((two_nu * d[0]) * rhoF) - g[0], a1 = ((two_nu * d[1]) * rhoF) - g[1], a2 = ((two_nu * d[2]) * rhoF) - g[2];
+    double2* r = reinterpret_cast<double2*>(R + kRecDoubles * (size_t)c);
+    r[0] = make_double2(u0, u1);
+    r[1] = make_double2(u2, alpha[c]);
+    r[2] = make_double2(a0, a1);
+    r[3] = make_double2(a2, vol[c]);
+}
+
+// alpha of the listed cells only (ghost planes after their halo exchange)
+__global__ __launch_bounds__(256) void k_patch_rec_alpha(int64_t c0, int64_t n, const double* __restrict__ alpha, double* __restrict__ R) {
+    const int64_t c = c0 + (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c < c0 + n) R[kRecDoubles * (size_t)c + 3] = alpha[c];
+}
+
+// after all pairs of a batch: uSourceDrag += D, uSource += uParticle * D (FoamYade.C:385-386), D reset for the next batch
+__global__ __launch_bounds__(256) void k_fold_sources(int64_t n_field, double* __restrict__ drag_acc, const double* __restrict__ uParticle,
+                                                      double* __restrict__ uSourceDrag, double* __restrict__ uSource) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= n_field) return;
+    const double D = drag_acc[c];
+    if (D == 0.0) return;
+    drag_acc[c] = 0.0;
+    uSourceDrag[c] += D;
+    const double* up = uParticle + 3 * (size_t)c;
+    double* s = uSource + 3 * (size_t)c;
+    const double s0 = s[0] + (up[0] * D), s1 = s[1] + (up[1] * D), s2 = s[2] + (up[2] * D);
+    s[0] = s0; s[1] = s1; s[2] = s2;
+}
+
+// per-particle part of hydroDragForce + archimedesForce (+ the opt-in models) from the interpolated values (FoamYade.C:366-382, 426-427,
+// 402-404, 477-478); returns the drag coefficient and the Archimedes (+ added-mass) force whose reaction is scattered, stores F
+struct Interp { double ufx, ufy, ufz, alpha_f, pv, sax, say, saz; };
+struct ModelSums { double t1, t2, t3, dux, duy, duz, pva; };
+struct ParticleForce { double coeff, bx, by, bz; };
+
+__device__ __forceinline__ ParticleForce force_law(const ForceParams& fp, const Interp& s, const ModelSums& ms, int k, double dia, double lvx, double lvy,
+                                                   double lvz, const double* __restrict__ rec_orig, double* __restrict__ F) {
+    const double rhoF = fp.rhoF, nu = fp.nu;
+    const double alpha_p = 1 - s.alpha_f;                                             // FoamYade.C:366
+    const double urx = s.ufx - lvx, ury = s.ufy - lvy, urz = s.ufz - lvz;
+    const double magUR = sqrt(urx * urx + ury * ury + urz * urz);
+    const double Re = fp.small + ((magUR * dia) / nu);                                // FoamYade.C:370
+    const double cd = Re < 1000 ? (24 / (Re)) * (1 + (0.15 * pow(Re, 0.687))) : 0.44;
+    double coeff;
+    if (s.alpha_f > 0.8) {                                                            // FoamYade.C:373-374
+        coeff = 0.75 * cd * s.alpha_f * alpha_p * rhoF * magUR * pow(s.alpha_f, -2.65);
+    } else {                                                                          // FoamYade.C:376-378
+        const double cf1 = 150 * ((alpha_p * alpha_p) / s.alpha_f) * ((nu * rhoF) / (dia * dia));
+        const double cf2 = 1.75 * alpha_p * rhoF * (1 / dia) * magUR;
+        coeff = cf1 + cf2;
     }
-    __syncthreads();
-    const int64_t i = (int64_t)blockIdx.x * kForceThreads + threadIdx.x;
+    const double s1 = s.pv * coeff, ia = 1 / (alpha_p);                               // FoamYade.C:381
+    const double hfx = (s1 * urx) * ia, hfy = (s1 * ury) * ia, hfz = (s1 * urz) * ia;
+    const double afx = s.pv * s.sax, afy = s.pv * s.say, afz = s.pv * s.saz;          // FoamYade.C:426
+    double fx = (0.0 + hfx) + afx, fy_ = (0.0 + hfy) + afy, fz = (0.0 + hfz) + afz;   // FoamYade.C:382,427
+    double tqx = 0.0, tqy = 0.0, tqz = 0.0;                                           // Gaussian torque disabled, FoamYade.C:618
+    ParticleForce r{coeff, afx, afy, afz};
+    if (fp.models & FY_FORCE_GAUSSIAN_TORQUE) {                                       // FoamYade.C:477-478
+        const double c3 = M_PI * (pow(dia, 3.0));
+        tqx = 0.0 + (((c3 * (ms.t1 - rec_orig[6])) * nu) * rhoF);
+        tqy = 0.0 + (((c3 * (ms.t2 - rec_orig[7])) * nu) * rhoF);
+        tqz = 0.0 + (((c3 * (ms.t3 - rec_orig[8])) * nu) * rhoF);
+    }
+    if (fp.models & FY_FORCE_ADDED_MASS) {                                            // FoamYade.C:402-404
+        const double pva = ms.pva / (double)(unsigned)k;
+        const double amx = (pva * (ms.dux - (lvx / fp.delta_t))) * fp.rhoP;
+        const double amy = (pva * (ms.duy - (lvy / fp.delta_t))) * fp.rhoP;
+        const double amz = (pva * (ms.duz - (lvz / fp.delta_t))) * fp.rhoP;
+        fx = fx + amx; fy_ = fy_ + amy; fz = fz + amz;
+        r.bx = r.bx + amx; r.by = r.by + amy; r.bz = r.bz + amz;                      // FoamYade.C:406-411: same -f w / (V rho_f) reaction
+    }
+    F[0] = fx; F[1] = fy_; F[2] = fz;
+    if (!fp.torque_prezeroed) { F[3] = tqx; F[4] = tqy; F[5] = tqz; }    // permuted 48-byte records: half the store traffic when the torque is identically zero
+    return r;
+}
+
+__device__ __forceinline__ void interp_add(Interp& s, const double* __restrict__ R, int64_t cl, double w, double volp) {
+    const double2* r = reinterpret_cast<const double2*>(R + kRecDoubles * (size_t)cl);
+    const double2 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
+    s.ufx += (r0.x * w); s.ufy += (r0.y * w); s.ufz += (r1.x * w);                    // FoamYade.C:361-365
+    s.alpha_f += (r1.y * w);
+    s.pv += (volp * w);
+    s.sax += (r2.x * w); s.say += (r2.y * w); s.saz += (r3.x * w);                    // FoamYade.C:421-424 (per-cell combination, k_pack_cells)
+}
+
+__device__ __forceinline__ void model_add(ModelSums& ms, const ForceParams& fp, const double* __restrict__ vGrad, const double* __restrict__ ddtU, int64_t cl,
+                                          double w, double volp) {
+    if (fp.models & FY_FORCE_GAUSSIAN_TORQUE) {                                       // calcHydroTorque FoamYade.C:468-476
+        const double* G = vGrad + 9 * (size_t)cl;                                     // xx xy xz yx yy yz zx zy zz
+        ms.t1 += ((G[5] - G[7]) * w); ms.t2 += ((G[6] - G[2]) * w); ms.t3 += ((G[3] - G[1]) * w);
+    }
+    if (fp.models & FY_FORCE_ADDED_MASS) {                                            // addedMassForce FoamYade.C:396-401
+        const double* d = ddtU + 3 * (size_t)cl;
+        ms.pva += (volp * w);
+        ms.dux = ms.dux + (d[0] * w); ms.duy = ms.duy + (d[1] * w); ms.duz = ms.duz + (d[2] * w);
+    }
+}
+
+// MODE 0: gather + force + back-scatter in one kernel, one lane per particle (LDS aggregation table per workgroup, flushed to the tile buckets)
+// MODE 1: gather + force only, {coeff, b} parked per particle in `scr` (no LDS)
+// MODE 2: back-scatter only, from `scr`
+#ifndef FY_FORCE_THREADS
+#define FY_FORCE_THREADS 512
+#endif
+#ifndef FY_FORCE_LOG2
+#define FY_FORCE_LOG2 10
+#endif
+constexpr int kForceThreads = FY_FORCE_THREADS, kForceLog2 = FY_FORCE_LOG2;
+template <int MODE>
+__global__ __launch_bounds__(MODE == 1 ? 256 : kForceThreads) void k_force_gaussian(
+        ParticleSoA p, int64_t n, ForceParams fp, CellWindow cw, const double* __restrict__ vol, const double* __restrict__ R,
+        const double* __restrict__ vGrad, const double* __restrict__ ddtU, const double* __restrict__ rec, double* __restrict__ scr,
+        double* __restrict__ drag_acc, double* __restrict__ uSource, double* __restrict__ force_out, TileBuckets tb) {
+    constexpr int kThreads = MODE == 1 ? 256 : kForceThreads;
+    constexpr int kSlots = MODE == 1 ? 256 : (1 << kForceLog2);
+    __shared__ uint32_t keys[MODE == 1 ? 1 : kSlots];
+    __shared__ double vals[MODE == 1 ? 1 : kSlots * 4];
+    __shared__ TileMapLds tmap;
+    if constexpr (MODE != 1) {
+        for (int q = threadIdx.x; q < kSlots; q += kThreads) {
+            keys[q] = kAggEmpty;
+            vals[4 * q] = 0.0; vals[4 * q + 1] = 0.0; vals[4 * q + 2] = 0.0; vals[4 * q + 3] = 0.0;
+        }
+        __syncthreads();
+    }
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     if (i < n) {
         const int chain = p.chain_len[i];
         const int k = chain < kMaxK ? chain : kMaxK;
-        const int32_t orig = p.orig[i];
-        double* F = force_out + 6 * (size_t)orig;
-        if (k == 0) {                                   // zeros for particles nobody located (FoamYade.C:142)
-            F[0] = F[1] = F[2] = 0.0;
-            if (!fp.torque_prezeroed) { F[3] = F[4] = F[5] = 0.0; }
-        } else {
-            const double rhoF = fp.rhoF, nu = fp.nu;
-            const double dia = 2 * p.rad[i];
-            const double volp = M_PI * pow(dia, 3.0) / 6.0;
-            const double lvx = p.vx[i], lvy = p.vy[i], lvz = p.vz[i];
-
-            // hydroDragForce FoamYade.C:358-365 and archimedesForce FoamYade.C:416-424 share one gather pass
-            double ufx = 0, ufy = 0, ufz = 0, alpha_f = 0.0, pv = 0.0;
-            double dtx = 0, dty = 0, dtz = 0, pgx = 0, pgy = 0, pgz = 0;
-            const double two_nu = 2.0 * nu;
-            for (int t = 0; t < k; ++t) {
-                const size_t slot = (size_t)((chain - 1 - t) & (kMaxK - 1)) * p.cap + (size_t)i;
-                const int64_t cl = (int64_t)p.ids[slot] - cw.base;
-                if (cl < 0 || cl >= cw.n_field) continue;
-                const int32_t c = (int32_t)cl;
-                const double w = p.w[slot];
-                const double* u = U + 3 * (size_t)c;
-                ufx += (u[0] * w); ufy += (u[1] * w); ufz += (u[2] * w);
-                alpha_f += (alpha[c] * w);
-                pv += (volp * w);
-                const double* dt = divT + 3 * (size_t)c;
-                dtx = dtx + (((two_nu * dt[0]) * w) * rhoF);
-                dty = dty + (((two_nu * dt[1]) * w) * rhoF);
-                dtz = dtz + (((two_nu * dt[2]) * w) * rhoF);
-                const double* g = gradP + 3 * (size_t)c;
-                pgx = pgx + (g[0] * w); pgy = pgy + (g[1] * w); pgz = pgz + (g[2] * w);
-            }
-            const double alpha_p = 1 - alpha_f;                                             // FoamYade.C:366
-            const double urx = ufx - lvx, ury = ufy - lvy, urz = ufz - lvz;
-            const double magUR = sqrt(urx * urx + ury * ury + urz * urz);
-            const double Re = fp.small + ((magUR * dia) / nu);                              // FoamYade.C:370
-            const double cd = Re < 1000 ? (24 / (Re)) * (1 + (0.15 * pow(Re, 0.687))) : 0.44;
-            double coeff;
-            if (alpha_f > 0.8) {                                                            // FoamYade.C:373-374
-                coeff = 0.75 * cd * alpha_f * alpha_p * rhoF * magUR * pow(alpha_f, -2.65);
-            } else {                                                                        // FoamYade.C:376-378
-                const double cf1 = 150 * ((alpha_p * alpha_p) / alpha_f) * ((nu * rhoF) / (dia * dia));
-                const double cf2 = 1.75 * alpha_p * rhoF * (1 / dia) * magUR;
-                coeff = cf1 + cf2;
-            }
-            const double s1 = pv * coeff, ia = 1 / (alpha_p);                               // FoamYade.C:381
-            const double hfx = (s1 * urx) * ia, hfy = (s1 * ury) * ia, hfz = (s1 * urz) * ia;
-            const double afx = pv * (-pgx + dtx), afy = pv * (-pgy + dty), afz = pv * (-pgz + dtz);   // FoamYade.C:426
-            double fx = (0.0 + hfx) + afx, fy_ = (0.0 + hfy) + afy, fz = (0.0 + hfz) + afz;   // FoamYade.C:382,427
-            double tqx = 0.0, tqy = 0.0, tqz = 0.0;                                         // Gaussian torque disabled, FoamYade.C:618
-            double amx = 0.0, amy = 0.0, amz = 0.0;
-            if (fp.models) {                                                                // uniform: off in the shipped reference
-                double s1 = 0, s2 = 0, s3 = 0, dux = 0, duy = 0, duz = 0, pva = 0.0;
+        ParticleForce pf{0.0, 0.0, 0.0, 0.0};
+        if constexpr (MODE != 2) {
+            const int32_t orig = p.orig[i];
+            double* F = force_out + 6 * (size_t)orig;
+            if (k == 0) {                                   // zeros for particles nobody located (FoamYade.C:142)
+                F[0] = F[1] = F[2] = 0.0;
+                if (!fp.torque_prezeroed) { F[3] = F[4] = F[5] = 0.0; }
+            } else {
+                const double dia = 2 * p.rad[i];
+                const double volp = M_PI * pow(dia, 3.0) / 6.0;
+                // hydroDragForce FoamYade.C:358-365 and archimedesForce FoamYade.C:416-424 share one gather pass over the cell records
+                Interp s{0, 0, 0, 0, 0, 0, 0, 0};
+                ModelSums ms{0, 0, 0, 0, 0, 0, 0};
                 for (int t = 0; t < k; ++t) {
                     const size_t slot = (size_t)((chain - 1 - t) & (kMaxK - 1)) * p.cap + (size_t)i;
                     const int64_t cl = (int64_t)p.ids[slot] - cw.base;
                     if (cl < 0 || cl >= cw.n_field) continue;
-                    const double w = p.w[slot];
-                    if (fp.models & FY_FORCE_GAUSSIAN_TORQUE) {                             // calcHydroTorque FoamYade.C:468-476
-                        const double* G = vGrad + 9 * (size_t)cl;                           // xx xy xz yx yy yz zx zy zz
-                        s1 += ((G[5] - G[7]) * w); s2 += ((G[6] - G[2]) * w); s3 += ((G[3] - G[1]) * w);
+                    interp_add(s, R, cl, p.w[slot], volp);
+                }
+                if (fp.models)                              // uniform: off in the shipped reference
+                    for (int t = 0; t < k; ++t) {
+                        const size_t slot = (size_t)((chain - 1 - t) & (kMaxK - 1)) * p.cap + (size_t)i;
+                        const int64_t cl = (int64_t)p.ids[slot] - cw.base;
+                        if (cl < 0 || cl >= cw.n_field) continue;
+                        model_add(ms, fp, vGrad, ddtU, cl, p.w[slot], volp);
                     }
-                    if (fp.models & FY_FORCE_ADDED_MASS) {                                  // addedMassForce FoamYade.C:396-401
-                        const double* d = ddtU + 3 * (size_t)cl;
-                        pva += (volp * w);
-                        dux = dux + (d[0] * w); duy = duy + (d[1] * w); duz = duz + (d[2] * w);
-                    }
-                }
-                if (fp.models & FY_FORCE_GAUSSIAN_TORQUE) {                                 // FoamYade.C:477-478
-                    const double* r = rec + 10 * (size_t)orig;
-                    const double c3 = M_PI * (pow(dia, 3.0));
-                    tqx = 0.0 + (((c3 * (s1 - r[6])) * nu) * rhoF);
-                    tqy = 0.0 + (((c3 * (s2 - r[7])) * nu) * rhoF);
-                    tqz = 0.0 + (((c3 * (s3 - r[8])) * nu) * rhoF);
-                }
-                if (fp.models & FY_FORCE_ADDED_MASS) {                                      // FoamYade.C:402-404
-                    pva = pva / (double)(unsigned)k;
-                    amx = (pva * (dux - (lvx / fp.delta_t))) * fp.rhoP;
-                    amy = (pva * (duy - (lvy / fp.delta_t))) * fp.rhoP;
-                    amz = (pva * (duz - (lvz / fp.delta_t))) * fp.rhoP;
-                    fx = fx + amx; fy_ = fy_ + amy; fz = fz + amz;
-                }
+                pf = force_law(fp, s, ms, k, dia, p.vx[i], p.vy[i], p.vz[i], rec + 10 * (size_t)orig, F);
             }
-            F[0] = fx; F[1] = fy_; F[2] = fz;
-            if (!fp.torque_prezeroed) { F[3] = tqx; F[4] = tqy; F[5] = tqz; }    // permuted 48-byte records: half the store traffic when the torque is identically zero
-
-            const double irho = 1 / rhoF;
-            // the force pass is bound by the vector-memory pipeline (TA ~80 % busy, VALU 12 %): a uniform block's cell volume is a
-            // constant, not a gather
-            const double ooUniform = fp.uniform_vol > 0 ? 1. / (fp.uniform_vol * rhoF) : 0.0;
-            for (int t = 0; t < k; ++t) {
-                const size_t slot = (size_t)((chain - 1 - t) & (kMaxK - 1)) * p.cap + (size_t)i;
-                const int64_t cl = (int64_t)p.ids[slot] - cw.base;
-                if (cl < 0 || cl >= cw.n_field) continue;
-                const int32_t c = (int32_t)cl;
-                const double w = p.w[slot];
-                const double cwt = -coeff * w;
-                const double* up = uParticle + 3 * (size_t)c;
-                const double ooCellVol = fp.uniform_vol > 0 ? ooUniform : 1. / (vol[c] * rhoF);  // FoamYade.C:432
-                // FoamYade.C:385 ; FoamYade.C:386 (drag part, NOT divided by V) + FoamYade.C:433 (Archimedes part)
-                const double c0 = cwt * irho;
-                double c1 = ((cwt * up[0]) / rhoF) + ((-afx * w) * ooCellVol);
-                double c2 = ((cwt * up[1]) / rhoF) + ((-afy * w) * ooCellVol);
-                double c3 = ((cwt * up[2]) / rhoF) + ((-afz * w) * ooCellVol);
-                if (fp.models & FY_FORCE_ADDED_MASS) {                                      // FoamYade.C:406-411
-                    c1 = c1 + ((-amx * w) * ooCellVol); c2 = c2 + ((-amy * w) * ooCellVol); c3 = c3 + ((-amz * w) * ooCellVol);
-                }
-                const int h = agg_slot<kForceLog2>(keys, (uint32_t)c);
-                if (h >= 0) {
-                    lds_add_f64(&vals[4 * h], c0); lds_add_f64(&vals[4 * h + 1], c1);
-                    lds_add_f64(&vals[4 * h + 2], c2); lds_add_f64(&vals[4 * h + 3], c3);
-                } else {
-                    atomic_add_f64(&uSourceDrag[c], c0);
-                    atomic_add_f64(&uSource[3 * (size_t)c + 0], c1);
-                    atomic_add_f64(&uSource[3 * (size_t)c + 1], c2);
-                    atomic_add_f64(&uSource[3 * (size_t)c + 2], c3);
+            if constexpr (MODE == 1) {
+                scr[i] = pf.coeff; scr[p.cap + i] = pf.bx; scr[2 * p.cap + i] = pf.by; scr[3 * p.cap + i] = pf.bz;
+            }
+        } else {
+            pf.coeff = scr[i]; pf.bx = scr[p.cap + i]; pf.by = scr[2 * p.cap + i]; pf.bz = scr[3 * p.cap + i];
+        }
+        if constexpr (MODE != 1) {
+            if (k > 0) {
+                const double irho = 1 / fp.rhoF;
+                // a uniform block's cell volume is a constant, not a gather
+                const double ooUniform = fp.uniform_vol > 0 ? 1. / (fp.uniform_vol * fp.rhoF) : 0.0;
+                for (int t = 0; t < k; ++t) {
+                    const size_t slot = (size_t)((chain - 1 - t) & (kMaxK - 1)) * p.cap + (size_t)i;
+                    const int64_t cl = (int64_t)p.ids[slot] - cw.base;
+                    if (cl < 0 || cl >= cw.n_field) continue;
+                    const int32_t c = (int32_t)cl;
+                    const double w = p.w[slot];
+                    const double ooCellVol = fp.uniform_vol > 0 ? ooUniform : 1. / (vol[c] * fp.rhoF);  // FoamYade.C:432
+                    const double c0 = (-pf.coeff * w) * irho;                                      // FoamYade.C:385 (and, times uParticle[c], :386)
+                    const double c1 = (-pf.bx * w) * ooCellVol, c2 = (-pf.by * w) * ooCellVol, c3 = (-pf.bz * w) * ooCellVol;   // FoamYade.C:433, 406-411
+                    const int h = agg_slot<kForceLog2>(keys, (uint32_t)c);
+                    if (h >= 0) {
+                        lds_add_f64(&vals[4 * h], c0); lds_add_f64(&vals[4 * h + 1], c1);
+                        lds_add_f64(&vals[4 * h + 2], c2); lds_add_f64(&vals[4 * h + 3], c3);
+                    } else {
+                        atomic_add_f64(&drag_acc[c], c0);
+                        atomic_add_f64(&uSource[3 * (size_t)c + 0], c1);
+                        atomic_add_f64(&uSource[3 * (size_t)c + 1], c2);
+                        atomic_add_f64(&uSource[3 * (size_t)c + 2], c3);
+                    }
                 }
             }
         }
     }
-    __syncthreads();
-    for (int q = threadIdx.x; q < (1 << kForceLog2); q += kForceThreads) {
-        const uint32_t c = keys[q];
-        if (c == kAggEmpty) continue;
-        atomic_add_f64(&uSourceDrag[c], vals[4 * q]);
-        atomic_add_f64(&uSource[3 * (size_t)c + 0], vals[4 * q + 1]);
-        atomic_add_f64(&uSource[3 * (size_t)c + 1], vals[4 * q + 2]);
-        atomic_add_f64(&uSource[3 * (size_t)c + 2], vals[4 * q + 3]);
+    if constexpr (MODE != 1) {
+        __syncthreads();
+        flush_table<kSlots, kThreads>(keys, vals, tmap, tb, drag_acc, uSource, nullptr);
     }
 }
 
@@ -1162,48 +1384,98 @@ int launch_build_locate_lists(hipStream_t s, const uint32_t* packed, ImplicitGeo
 
 int launch_locate_deposit(hipStream_t s, const KdNode* tree, const uint32_t* packed, ImplicitGeom ig, int32_t n_cells, int levels, ParticleSoA p, int64_t n,
                           GaussParams gp, const unsigned long long* start, SlabOwn own, LocateLists ll, CellWindow cw, double* pvol_acc, double* up_acc,
-                          unsigned char* touched) {
+                          unsigned char* touched, TileBuckets tb, SideStream side) {
     if (n <= 0) return FY_OK;
     if (!(packed && ll.lists)) {
         FY_TRY(launch_locate(s, tree, packed, ig, n_cells, levels, p, n, gp, start, own, LocateLists{}));
-        return launch_deposit(s, p, n, gp, cw, pvol_acc, up_acc, touched);
+        return launch_deposit(s, p, n, gp, cw, pvol_acc, up_acc, touched, tb);
     }
     if (n_cells >= (1 << 25)) return fail(FY_ERR_UNSUPPORTED, "implicit-coordinate tree limited to 2^25 cells");
     // the lists place and deposit almost every particle; the walk + k_deposit pair takes what is left (usually nothing: zero count, exit)
     FY_HIP(hipMemsetAsync(ll.fb_count, 0, sizeof(unsigned int), s));
-    hipLaunchKernelGGL(k_locate_deposit, dim3(div_up(n, kDepThreads)), dim3(kDepThreads), 0, s, ll, ig, p, n, gp, own, cw, pvol_acc, up_acc, touched);
+    hipLaunchKernelGGL(k_locate_deposit, dim3(div_up(n, kDepThreads)), dim3(kDepThreads), 0, s, ll, ig, p, n, gp, own, cw, pvol_acc, up_acc, touched, tb);
     FY_LAUNCH_CHECK();
+    // The leftovers (~5e-5 of the particles: within 8e-6 dx of a cell face) are two latency-bound launches, ~0.2 ms for a few hundred
+    // particles.  With a side stream they run beside whatever the caller enqueues next on `s` (the cell-record pack); the caller waits
+    // for side.join before anything reads the deposit.  Their few thousand contributions go out as plain atomics (no tile buckets).
+    hipStream_t w = s;
+    if (side.stream) {
+        FY_HIP(hipEventRecord(side.fork, s));
+        FY_HIP(hipStreamWaitEvent(side.stream, side.fork, 0));
+        w = side.stream;
+    }
     const size_t lds = (size_t)(levels + 1) * kWave * sizeof(unsigned long long);
     const dim3 wgrid((unsigned)std::min<int64_t>(div_up(n, kLocPPB), 2048));
-    hipLaunchKernelGGL(k_locate<true>, wgrid, dim3(kWave), lds, s, tree, packed, ig, n_cells, p, n, gp.maxdist, start, SlabOwn{}, ll.fb_list, ll.fb_count);
+    hipLaunchKernelGGL(k_locate<true>, wgrid, dim3(kWave), lds, w, tree, packed, ig, n_cells, p, n, gp.maxdist, start, SlabOwn{}, ll.fb_list, ll.fb_count);
     FY_LAUNCH_CHECK();
-    const dim3 dgrid((unsigned)std::min<int64_t>(div_up(n, kDepThreads), 512));
-    hipLaunchKernelGGL(k_deposit, dgrid, dim3(kDepThreads), 0, s, p, n, gp, cw, pvol_acc, up_acc, touched, ll.fb_list, ll.fb_count);
+    const dim3 dgrid((unsigned)std::min<int64_t>(div_up(n, kDepThreads), 64));
+    hipLaunchKernelGGL(k_deposit, dgrid, dim3(kDepThreads), 0, w, p, n, gp, cw, pvol_acc, up_acc, touched, ll.fb_list, ll.fb_count, TileBuckets{});
     FY_LAUNCH_CHECK();
+    if (side.stream) FY_HIP(hipEventRecord(side.join, side.stream));
     return FY_OK;
 }
 
-int launch_deposit(hipStream_t s, ParticleSoA p, int64_t n, GaussParams gp, CellWindow cw, double* pvol_acc, double* up_acc, unsigned char* touched) {
+int launch_deposit(hipStream_t s, ParticleSoA p, int64_t n, GaussParams gp, CellWindow cw, double* pvol_acc, double* up_acc, unsigned char* touched, TileBuckets tb) {
     if (n <= 0) return FY_OK;
-    hipLaunchKernelGGL(k_deposit, dim3(div_up(n, kDepThreads)), dim3(kDepThreads), 0, s, p, n, gp, cw, pvol_acc, up_acc, touched, nullptr, nullptr);
+    hipLaunchKernelGGL(k_deposit, dim3(div_up(n, kDepThreads)), dim3(kDepThreads), 0, s, p, n, gp, cw, pvol_acc, up_acc, touched, nullptr, nullptr, tb);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }
 
 int launch_finalize_cells(hipStream_t s, int32_t n_cells, const double* vol, double* pvol_acc, double* up_acc,
-                          unsigned char* touched, double* alpha, double* uParticle) {
-    hipLaunchKernelGGL(k_finalize_cells, dim3(div_up(n_cells, 256)), dim3(256), 0, s, n_cells, vol, pvol_acc, up_acc, touched, alpha, uParticle);
+                          unsigned char* touched, double* alpha, double* uParticle, double* R) {
+    hipLaunchKernelGGL(k_finalize_cells, dim3(div_up(n_cells, 256)), dim3(256), 0, s, n_cells, vol, pvol_acc, up_acc, touched, alpha, uParticle, R);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }
 
-int launch_force_gaussian(hipStream_t s, ParticleSoA p, int64_t n, ForceParams fp, CellWindow cw, const double* vol, const double* U,
-                          const double* alpha, const double* uParticle, const double* gradP, const double* divT,
-                          const double* vGrad, const double* ddtU, const double* rec,
-                          double* uSourceDrag, double* uSource, double* force_out, int32_t* found_out) {
+int launch_pack_cells(hipStream_t s, int64_t n_field, const double* U, const double* alpha, const double* gradP, const double* divT, const double* vol,
+                      double nu, double rhoF, double* R) {
+    if (n_field <= 0) return FY_OK;
+    hipLaunchKernelGGL(k_pack_cells, dim3(div_up(n_field, 256)), dim3(256), 0, s, n_field, U, alpha, gradP, divT, vol, 2.0 * nu, rhoF, R);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+
+int launch_patch_rec_alpha(hipStream_t s, int64_t c0, int64_t n, const double* alpha, double* R) {
     if (n <= 0) return FY_OK;
-    hipLaunchKernelGGL(k_force_gaussian, dim3(div_up(n, kForceThreads)), dim3(kForceThreads), 0, s, p, n, fp, cw, vol, U, alpha, uParticle, gradP, divT,
-                       vGrad, ddtU, rec, uSourceDrag, uSource, force_out, found_out);
+    hipLaunchKernelGGL(k_patch_rec_alpha, dim3(div_up(n, 256)), dim3(256), 0, s, c0, n, alpha, R);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+
+int launch_fold_sources(hipStream_t s, int64_t n_field, double* drag_acc, const double* uParticle, double* uSourceDrag, double* uSource) {
+    if (n_field <= 0) return FY_OK;
+    hipLaunchKernelGGL(k_fold_sources, dim3(div_up(n_field, 256)), dim3(256), 0, s, n_field, drag_acc, uParticle, uSourceDrag, uSource);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+
+int launch_force_gaussian(hipStream_t s, ParticleSoA p, int64_t n, ForceParams fp, CellWindow cw, const double* vol, const double* R,
+                          const double* vGrad, const double* ddtU, const double* rec, double* scr, double* drag_acc, double* uSource,
+                          double* force_out, TileBuckets tb) {
+    if (n <= 0) return FY_OK;
+    if (scr) {      // two kernels: the gathers without an LDS table, then the back-scatter (A/B switch)
+        hipLaunchKernelGGL(k_force_gaussian<1>, dim3(div_up(n, 256)), dim3(256), 0, s, p, n, fp, cw, vol, R, vGrad, ddtU, rec, scr, drag_acc, uSource, force_out, tb);
+        FY_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_force_gaussian<2>, dim3(div_up(n, kForceThreads)), dim3(kForceThreads), 0, s, p, n, fp, cw, vol, R, vGrad, ddtU, rec, scr, drag_acc, uSource, force_out, tb);
+    } else {
+        hipLaunchKernelGGL(k_force_gaussian<0>, dim3(div_up(n, kForceThreads)), dim3(kForceThreads), 0, s, p, n, fp, cw, vol, R, vGrad, ddtU, rec, scr, drag_acc, uSource, force_out, tb);
+    }
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+
+int launch_tile_caps(hipStream_t s, TileBuckets a, TileBuckets b) {
+    if (!a.cell && !b.cell) return FY_OK;
+    hipLaunchKernelGGL(k_tile_caps, dim3(2), dim3(1024), 0, s, a, b);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+
+int launch_tile_reduce(hipStream_t s, TileBuckets tb, double* dst0, double* dst3, unsigned char* touched) {
+    if (!tb.cell) return FY_OK;
+    hipLaunchKernelGGL(k_tile_reduce, dim3((unsigned)tb.tg.n_tiles()), dim3(256), 0, s, tb, dst0, dst3, touched);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }

@@ -85,22 +85,57 @@ int launch_build_locate_lists(hipStream_t s, const uint32_t* packed, ImplicitGeo
 // For every cell of the block: the deepest tree node a walk for a query inside that cell is guaranteed to reach with an empty
 // stack and an empty chain (entry: offset | size << 25 | axis << 50).  See k_build_locate_start.
 int launch_build_locate_start(hipStream_t s, const uint32_t* packed, ImplicitGeom ig, int32_t n_cells, double maxdist, unsigned long long* start);
-// forms the normalised Gaussian weights from the parked squared distances, then deposits (LDS-aggregated)
 // cell arrays are indexed with (global cell id - cell_base) and hold n_field cells (slab storage); ids outside are skipped
 struct CellWindow { int64_t base; int64_t n_field; };
-int launch_deposit(hipStream_t s, ParticleSoA p, int64_t n, GaussParams gp, CellWindow cw, double* pvol_acc, double* up_acc, unsigned char* touched);
+
+// ---- cell-tile ownership of the scatters' flush.  Global FP64 atomics run at ~23 G/s on MI355X whatever their locality or packing
+// (tools/micro/atomic_rate.hip): the 21.8 M flush atomics of ONE LDS-hashed scatter at C3 are 0.93 ms -- that, not the gathers, is what
+// bounded k_locate_deposit and k_force_gaussian in round 1 -- while LDS FP64 atomics run at ~850 G/s (tools/micro/lds_atomic_rate.hip) and
+// plain stores at > 200 G/s.  So a workgroup no longer adds its aggregation table to the cell arrays itself: it hands every table
+// entry {cell, 4 partial sums} to the TILE (8 x 8 x 8 cells of the storage block) the cell lies in -- the entries are counted per tile
+// in LDS, ONE returning global atomic per (workgroup, tile) claims a run in the tile's bucket, plain stores fill it -- and
+// k_tile_reduce, one workgroup per tile and the tile's only writer, sums its bucket into a dense 16 KiB LDS accumulator and adds it to
+// the cell arrays with plain read-modify-writes.  ~0.5 M global atomics per scatter instead of 21.8 M.
+// A bucket's capacity is last step's demand x 1.25 + 128 entries (k_tile_caps); an entry that does not fit is added with the four
+// global atomics of round 1, so the first step of a population runs on atomics and counts, and nothing is ever dropped.
+constexpr int kTileEdge = 8, kTileCells = 512;
+struct TileGrid { int nx, ny, nzs, ntx, nty, ntz; __host__ __device__ int n_tiles() const { return ntx * nty * ntz; } };
+struct TileBuckets {               // all null: flush with global atomics (round-1 behaviour)
+    uint32_t* cell;                // [pool] cell index inside the tile
+    double* val;                   // [pool][4] the workgroup's partial sums for that cell
+    uint32_t* off;                 // [tiles] first entry of the tile's bucket
+    uint32_t* cap;                 // [tiles] its capacity
+    uint32_t* fill;                // [tiles] entries asked for this step (may exceed cap: the excess went out as atomics)
+    uint32_t pool;
+    TileGrid tg;
+};
+// capacities / offsets for this step from the demand counted last step, demand counters reset (two bucket sets in one launch)
+int launch_tile_caps(hipStream_t s, TileBuckets a, TileBuckets b);
+// dst0[c] += sum of the tile's entries' first value, dst3[c][0..2] += the other three; touched[c] = 1 where something arrived (nullable)
+int launch_tile_reduce(hipStream_t s, TileBuckets tb, double* dst0, double* dst3, unsigned char* touched);
+
+// a second stream for work that may run beside the caller's next launches: forked from the main stream at `fork`, done at `join`
+struct SideStream { hipStream_t stream; hipEvent_t fork, join; };
+// forms the normalised Gaussian weights from the parked squared distances, then deposits (LDS-aggregated)
+int launch_deposit(hipStream_t s, ParticleSoA p, int64_t n, GaussParams gp, CellWindow cw, double* pvol_acc, double* up_acc, unsigned char* touched, TileBuckets tb = TileBuckets{});
 // launch_locate + launch_deposit; with candidate lists (ll.lists) both run as ONE pass (k_locate_deposit) and the chain's squared
 // distances never reach memory
 int launch_locate_deposit(hipStream_t s, const KdNode* tree, const uint32_t* packed, ImplicitGeom ig, int32_t n_cells, int levels, ParticleSoA p, int64_t n,
                           GaussParams gp, const unsigned long long* start, SlabOwn own, LocateLists ll, CellWindow cw, double* pvol_acc, double* up_acc,
-                          unsigned char* touched);
+                          unsigned char* touched, TileBuckets tb = TileBuckets{}, SideStream side = SideStream{});
 int launch_add_mark(hipStream_t s, double* y, const double* x, size_t n, unsigned char* mark /* nullable; set where x != 0 */);
 int launch_finalize_cells(hipStream_t s, int32_t n_cells, const double* vol, double* pvol_acc, double* up_acc,
-                          unsigned char* touched, double* alpha, double* uParticle);
-int launch_force_gaussian(hipStream_t s, ParticleSoA p, int64_t n, ForceParams fp, CellWindow cw, const double* vol, const double* U,
-                          const double* alpha, const double* uParticle, const double* gradP, const double* divT,
-                          const double* vGrad, const double* ddtU, const double* rec,
-                          double* uSourceDrag, double* uSource, double* force_out, int32_t* found_out);
+                          unsigned char* touched, double* alpha, double* uParticle, double* R /* nullable: cell records whose alpha slot follows */);
+// the force pass gathers one 64-byte record per stencil cell: {U[3], alpha, A[3] = 2 nu rho_f divT - gradP, V} (k_pack_cells)
+int launch_pack_cells(hipStream_t s, int64_t n_field, const double* U, const double* alpha, const double* gradP, const double* divT, const double* vol,
+                      double nu, double rhoF, double* R);
+int launch_patch_rec_alpha(hipStream_t s, int64_t c0, int64_t n, const double* alpha, double* R);    // alpha slot of cells [c0, c0 + n)
+// scatters D[c] = sum -coeff w / rho_f into drag_acc and the Archimedes reaction into uSource; launch_fold_sources then adds D to
+// uSourceDrag and uParticle * D to uSource and clears D.  scr != nullptr (4 * p.cap doubles): gather and scatter as two kernels.
+int launch_force_gaussian(hipStream_t s, ParticleSoA p, int64_t n, ForceParams fp, CellWindow cw, const double* vol, const double* R,
+                          const double* vGrad, const double* ddtU, const double* rec, double* scr, double* drag_acc, double* uSource,
+                          double* force_out, TileBuckets tb = TileBuckets{});
+int launch_fold_sources(hipStream_t s, int64_t n_field, double* drag_acc, const double* uParticle, double* uSourceDrag, double* uSource);
 // z-slab migration: classify by owner slab and pack (11 doubles per particle: record + tag bits); counters = {stay, up, down}
 int launch_migrate_pack(hipStream_t s, const double* rec, const int64_t* tags, int64_t n, SlabOwn own, unsigned int* counters, double* stay, double* up, double* down);
 int launch_migrate_unpack(hipStream_t s, const double* packed, int64_t n, double* rec, int64_t* tags);
