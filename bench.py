@@ -1,6 +1,10 @@
 #!/usr/bin/env python3
 """Headline benchmark: coupled CFD-DEM steps/s at BASELINE.json configs[2] ("C3"):
 pimpleFoamYade 4-way coupling, 10 M particles, 160^3 = 4 096 000 cells, one MI355X.
+`--config c2` is BASELINE configs[1] at full size instead (icoFoamYade point force, 200 x 100 x 50 = 1 M-cell channel, 1 M particles).
+After the timed, HBM-resident region the same workload runs a few steps through the DROP-IN path (`--wire`, rank 0 of a single-GPU run):
+an in-process fake Yade (parallel-Yade protocol, 4 workers) hands the records over as host buffers through the fy_transport callbacks
+and takes the forces back, so that the PCIe copies and the wire-side host time are measured beside the headline number (never in it).
 
 A "step" is one pass of pimpleFoamYade's time-loop body (pimpleFoamYade.C:60-114): Courant number, pre-coupling fields,
 FoamYade::setParticleAction (k-d locate, Gaussian weights, void-fraction deposit, drag + Archimedes, momentum-source
@@ -67,34 +71,170 @@ def c3_particles_strong(torch, n_part, n, device, rank, world):
     return rec.to(device).contiguous()
 
 
-def cpu_baseline(n_sample, ppc, dt, threads):
-    """the CPU oracle (a faithful port of the reference's path, kind = "port") on a bounded sample of the same workload"""
+def c2_case(prod, dt, p_solver):
+    """200 x 100 x 50 channel, L = (2, 1, 0.5), inlet fixedValue U = (1,0,0) at x-, outlet p = 0 at x+, no-slip walls,
+    nu = 1e-3, icoFoamYade (PISO nCorr 2), point force"""
+    U, ZG = prod.FY_BC_U_FIXED_VALUE, prod.FY_BC_U_ZERO_GRADIENT
+    PZ, PF = prod.FY_BC_P_ZERO_GRADIENT, prod.FY_BC_P_FIXED_VALUE
+    return prod.make_case(prod.FY_SOLVER_ICO, 200, 100, 50, 0.01, dt, 1e-3, rho_f=1000.0, rho_p=2650.0, g=(0.0, 0.0, 0.0),
+                          u_bc=[U, ZG, U, U, U, U], u_val=[(1, 0, 0), (0, 0, 0), (0, 0, 0), (0, 0, 0), (0, 0, 0), (0, 0, 0)],
+                          p_bc=[PZ, PF, PZ, PZ, PZ, PZ], n_correctors=2, p_solver=p_solver)
+
+
+def c2_particles(torch, n_part, device):
+    """1 M particles uniform in the channel, seed 2, r = 0.15 dx, at rest"""
+    g = torch.Generator(device="cpu").manual_seed(2)
+    rec = torch.zeros(n_part, 10, dtype=torch.float64)
+    rec[:, 0:3] = torch.rand(n_part, 3, dtype=torch.float64, generator=g)
+    rec[:, 0] *= 2.0
+    rec[:, 2] *= 0.5
+    rec[:, 9] = 0.15 * 0.01
+    return rec.to(device).contiguous()
+
+
+def cpu_info():
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:                                                   # a container's CPU quota (cgroup v2): more threads than that only queue up
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = max(1, min(n, int(float(q) / float(per) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return model, n
+
+
+class FakeYadePeer:
+    """In-process stand-in for Yade's FoamCoupling engine in PARALLEL-Yade mode (the only mode whose message count does not grow with
+    the particle count): a master (world rank 0) and W workers (ranks 1..W); this process is the single solver rank W + 1.
+    Every call the solver side issues (FoamYade.C:114-155, 239-243, 504-507, 537-553) is answered from host memory the way the MPI library
+    would answer it -- a copy into / out of the caller's buffer."""
+
+    def __init__(self, prod, records, workers):
+        import ctypes as C
+        self.C, self.rec, self.W = C, records, workers
+        n = records.shape[0]
+        self.bounds = [(w * n) // workers for w in range(workers + 1)]
+        self.bytes_recv = 0
+        self.force_checksum = 0.0
+        self.fbuf = None
+        T = prod.Transport()
+        T.world_size, T.world_rank, T.local_rank, T.local_size = workers + 2, workers + 1, 0, 1
+        self._cb = [prod._SEND(self.send), prod._RECV(self.recv), prod._BCAST(self.bcast), prod._BCAST(self.bcast), prod._ALLRED(self.allreduce)]
+        T.send, T.recv, T.bcast_world, T.bcast_local, T.allreduce_world = self._cb
+        self.T = T
+
+    def _view(self, ptr, count, dtype):
+        ct = self.C.c_int32 if dtype == 0 else self.C.c_double
+        return np.ctypeslib.as_array((ct * count).from_address(ptr))
+
+    def send(self, user, buf, count, dtype, dest, tag):
+        if tag == 1005 and count:                      # forces: the MPI library would copy them out of the caller's buffer
+            if self.fbuf is None or self.fbuf.size < count:
+                self.fbuf = np.empty(count)
+            self.fbuf[:count] = self._view(buf, count, dtype)
+            self.force_checksum += float(self.fbuf[:count:max(count // 4096, 1)].sum())
+            self.bytes_recv += 8 * count
+        elif tag == 1004:
+            self.bytes_recv += 4 * count
+        return 0
+
+    def recv(self, user, buf, count, dtype, src, tag):
+        out = self._view(buf, count, dtype)
+        if tag == 1003:
+            out[:] = self.bounds[src] - self.bounds[src - 1]
+        elif tag == 1002:
+            out[:] = self.rec[self.bounds[src - 1]:self.bounds[src]].reshape(-1)
+        elif tag == 1060:
+            out[:] = 1e-6
+        else:
+            return 1
+        return 0
+
+    def bcast(self, user, buf, count, dtype, root):
+        return 0
+
+    def allreduce(self, user, inp, out, count, dtype, op):
+        return 1                                       # serial-Yade only
+
+
+def wire_leg(prod, torch, case, rec_host, steps, workers, device):
+    """the drop-in path: same case, the particles arrive as host buffers from a fake Yade and the forces go back; returns per-step averages"""
+    yade = FakeYadePeer(prod, rec_host, workers)
+    solver = prod.Solver(case, transport=yade.T, device=device)
+    solver.enable_particle_timing(True)
+    acc = dict(step=0.0, copy_in=0.0, copy_out=0.0, wire_recv=0.0, wire_send=0.0, particle=0.0, bytes_in=0, bytes_out=0)
+    for s in range(steps + 1):                         # one warm-up step (first-touch of the pinned staging buffers, tile capacities)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        solver.step()
+        torch.cuda.synchronize()
+        dt_ = time.perf_counter() - t0
+        ct = solver.coupling_timings(); st = solver.stats()
+        if s == 0:
+            continue
+        acc["step"] += 1e3 * dt_
+        acc["particle"] += st["ms_particle"]
+        for k in ("copy_in", "copy_out", "wire_recv", "wire_send"):
+            acc[k] += ct[k]
+        acc["bytes_in"] += ct["bytes_in"]; acc["bytes_out"] += ct["bytes_out"]
+    solver.close()
+    K = float(steps)
+    gbps = lambda b, ms: round(b / (ms * 1e-3) / 1e9, 1) if ms > 0 else None
+    return {"what": f"drop-in path: in-process fake Yade, parallel-Yade protocol with {workers} workers; records and forces cross PCIe through pinned "
+                    "staging on a copy stream, pipelined with the batches' kernels; wire_* = host time inside the transport callbacks (a host copy per "
+                    "message here, where MPI would do its own)",
+            "steps": steps, "ms_per_step": round(acc["step"] / K, 3), "steps_per_sec": round(1e3 * K / acc["step"], 3),
+            "per_step_ms": {"h2d": round(acc["copy_in"] / K, 3), "d2h": round(acc["copy_out"] / K, 3), "wire_recv": round(acc["wire_recv"] / K, 3),
+                            "wire_send": round(acc["wire_send"] / K, 3), "particle_phase_incl_transfers": round(acc["particle"] / K, 3)},
+            "bytes_per_step": {"h2d": int(acc["bytes_in"] / K), "d2h": int(acc["bytes_out"] / K)},
+            "pcie_GBps": {"h2d": gbps(acc["bytes_in"], acc["copy_in"]), "d2h": gbps(acc["bytes_out"], acc["copy_out"])}}
+
+
+def cpu_baseline(config, n_sample, n_part, dt, threads, full):
+    """the CPU oracle (a faithful port of the reference's path, kind = "port") on the GPU box's host cores: the bench's own workload at its own
+    size (full: one warm-up + two timed steps on all cores, one warm-up + one timed step on one core), or an n_sample^3 sample of C3"""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as orc
     orc.build()
-    dx = 1.0 / n_sample
-    case = orc.fv_case(1, n_sample, n_sample, n_sample, dx, dt, 1e-6, g=(0, 0, -9.81), p_bc=[orc.P_FIXEDFLUX] * 6, n_outer=1, n_corr=2, p_solver=1)
-    nc = n_sample ** 3
-    n_part = int(round(ppc * nc))
     rs = np.random.RandomState(3)
     rec = np.zeros((n_part, 10))
     rec[:, 0:3] = rs.random_sample((n_part, 3))
-    rec[:, 2] *= 0.6
-    rec[:, 9] = 0.2 * dx
+    if config == "c2":
+        nx, ny, nz, dx = 200, 100, 50, 0.01
+        case = orc.fv_case(0, nx, ny, nz, dx, dt, 1e-3, u_bc=[0, 1, 0, 0, 0, 0], u_val=[(1.0, 0, 0)] + [(0, 0, 0)] * 5, p_bc=[0, 1, 0, 0, 0, 0],
+                           p_val=[0.0] * 6, n_corr=2, p_solver=1)
+        rec[:, 0] *= 2.0; rec[:, 2] *= 0.5
+        rec[:, 9] = 0.15 * dx
+    else:
+        nx = ny = nz = n_sample
+        dx = 1.0 / n_sample
+        case = orc.fv_case(1, nx, ny, nz, dx, dt, 1e-6, g=(0, 0, -9.81), p_bc=[orc.P_FIXEDFLUX] * 6, n_outer=1, n_corr=2, p_solver=1)
+        rec[:, 2] *= 0.6
+        rec[:, 9] = 0.2 * dx
+    mesh = orc.Mesh(nx, ny, nz, dx)                       # tree build is construction-time work, not timed (as on the GPU side)
     out = {}
-    # a 64^3 sample does not feed a hundred threads: time 1 thread and a few team sizes up to the core count, report the best
-    for th in sorted(set([1] + [t for t in (8, 16, 32) if t <= threads] + ([threads] if threads <= 64 else []))):
+    teams = [threads, 1] if full else sorted(set([1] + [t for t in (8, 16, 32) if t <= threads] + ([threads] if threads <= 64 else [])))
+    for th in dict.fromkeys(teams):
         s = orc.FvSolver(case, threads=th)
-        s.mesh = orc.Mesh(n_sample, n_sample, n_sample, dx)     # tree build is construction-time work, not timed (as on the GPU side)
+        s.mesh = mesh
         s.step(rec)                                              # warm-up step
         t0 = time.time()
         k = 0
-        while k < 2 or (time.time() - t0 < 4.0 and k < 8):
+        n_min = (2 if th > 1 else 1) if full else 2
+        while k < n_min or (not full and time.time() - t0 < 4.0 and k < 8):
             s.step(rec)
             k += 1
         out[th] = (time.time() - t0) / k
         s.close()
-    return out, nc, n_part
+    return out, nx * ny * nz
 
 
 def cpu_reference_as_written(n_sample=32, n_part=80000):
@@ -206,7 +346,10 @@ def main():
     ap.add_argument("--dt", type=float, default=1e-4)
     ap.add_argument("--p-solver", type=int, default=1, help="0 PCG+Jacobi, 1 PCG+multigrid")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-n", type=int, default=64)
+    ap.add_argument("--cpu-sample-n", type=int, default=0, help="CPU baseline on an n^3 sample of the workload instead of the full size (0 = full size)")
+    ap.add_argument("--config", default="c3", choices=["c3", "c2"], help="c3: BASELINE configs[2] (the metric's configuration); c2: configs[1] at full size")
+    ap.add_argument("--wire", type=int, default=2, help="steps of the drop-in (host-buffer / fake-Yade) leg after the timed region, 0 = skip")
+    ap.add_argument("--wire-workers", type=int, default=4)
     ap.add_argument("--strong", action="store_true", help="N > 1: cut the ONE C3 box into N slabs (BASELINE configs[3]) instead of growing it (weak, the default)")
     ap.add_argument("--force-rccl", action="store_true", help="use the RCCL communicator even with one rank (smoke test of the RCCL path)")
     ap.add_argument("--rccl-selftest", default="", help=argparse.SUPPRESS)     # child mode: hex of the 128-byte RCCL id (see rccl_preflight)
@@ -232,7 +375,15 @@ def main():
 
     prod = ge.load_product()
     strong = bool(args.strong and world > 1)
-    case = c3_case(prod, args.n, args.dt, args.p_solver, world, strong)
+    c2 = args.config == "c2"
+    if c2:
+        if world > 1:
+            raise SystemExit("bench.py --config c2 is the single-GPU configuration (BASELINE configs[1])")
+        if args.particles == 10_000_000:
+            args.particles = 1_000_000
+        if args.dt == 1e-4:
+            args.dt = 2e-3
+    case = c2_case(prod, args.dt, args.p_solver) if c2 else c3_case(prod, args.n, args.dt, args.p_solver, world, strong)
     comm, solver, setup_err = None, None, ""
     try:
         if world > 1 and not os.environ.get("FOAMYADE_BENCH_NO_PREFLIGHT"):
@@ -277,14 +428,16 @@ def main():
         solver = prod.Solver(case, device=local_rank)
         parallelism = f"FALLBACK: {world} independent replicas of the single-GPU case, no exchange (z-slab/RCCL set-up failed: {setup_err or 'on another rank'})"
         slab_of_rank = 0
-    if strong and slabs_ok >= 1.0:
+    if c2:
+        rec = c2_particles(torch, args.particles, dev)
+    elif strong and slabs_ok >= 1.0:
         rec = c3_particles_strong(torch, args.particles, args.n, dev, rank, world)
     else:
         strong = False
         rec = c3_particles(torch, args.particles, args.n, 3 + rank, dev, slab=slab_of_rank)
     solver.set_particles_device(rec)
     solver.enable_particle_timing(True)
-    nc = args.n ** 3 // (world if strong else 1)      # cells per rank
+    nc = 200 * 100 * 50 if c2 else args.n ** 3 // (world if strong else 1)      # cells per rank
 
     def barrier():
         torch.cuda.synchronize()
@@ -295,14 +448,14 @@ def main():
     for _ in range(args.warmup):
         solver.step()
     solver.enable_kernel_timing(True)
-    acc = dict(particle=0.0, locate_deposit=0.0, force=0.0, bin=0.0, finalize=0.0, momentum=0.0, pressure=0.0, other=0.0, p_iters=0, u_iters=0)
+    acc = dict(particle=0.0, locate_deposit=0.0, force=0.0, bin=0.0, finalize=0.0, fold=0.0, momentum=0.0, pressure=0.0, other=0.0, p_iters=0, u_iters=0)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         solver.step()
         st = solver.stats(); ct = solver.coupling_timings()
         acc["particle"] += st["ms_particle"]; acc["momentum"] += st["ms_momentum"]; acc["pressure"] += st["ms_pressure"]; acc["other"] += st["ms_other"]
-        acc["locate_deposit"] += ct["locate_deposit"]; acc["force"] += ct["force"]; acc["bin"] += ct["bin"]; acc["finalize"] += ct["finalize"]
+        acc["locate_deposit"] += ct["locate_deposit"]; acc["force"] += ct["force"]; acc["bin"] += ct["bin"]; acc["finalize"] += ct["finalize"]; acc["fold"] += ct["fold"]
         acc["p_iters"] += st["p_iters_total"]; acc["u_iters"] += st["u_iters_total"]
     barrier()
     elapsed = time.perf_counter() - t0
@@ -319,21 +472,24 @@ def main():
     apply_ms, apply_n = solver.kernel_timing("p_apply_dot")
     mom_ms, mom_n = solver.kernel_timing("mom_pass")
     np_part = int(rec.shape[0]) if strong else args.particles      # particles of this rank
-    dep_ms = max(acc["finalize"], 0.0)
+    kbar = 5.46                  # stencil cells per particle at 160^3
     cand = {
-        # name: (total ms over the timed steps, launches, algorithmic bytes per launch, description) -- DESIGN.md section 3;
-        # kbar = 5.46 stencil cells per particle, 12 B per (id, weight) pair
-        # one pass since the candidate lists: positions 24 + velocity 24 + radius 8 + (cell, octant) list 2 B x 7.6 codes in,
-        # chain length 4 + 12 B/pair out, 65 B per touched cell (accumulators + alpha/uParticle in k_finalize_cells)
-        "k_locate_deposit+k_finalize_cells": (acc["locate_deposit"] + dep_ms, K, (24.0 + 24.0 + 8.0 + 15.2 + 4.0 + 12.0 * 5.46) * np_part + 65.0 * nc,
-                     "k-d 'range' locate through per-(cell, octant) candidate lists + Gaussian weights + void-fraction deposit (LDS-aggregated "
-                     "atomics) in one pass, then alpha/uParticle finalize"),
-        "k_force_gaussian": (acc["force"], K, (64.0 + 12.0 * 5.46 + 52.0) * np_part + 176.0 * nc,
-                             "drag + Archimedes + back-scatter: particle 64 B + stencil 12 B/pair in, force 52 B out, cell fields 112 B read + 64 B RMW"),
+        # name: (total ms over the timed steps, launches, algorithmic bytes per launch, description) -- DESIGN.md section 3.  The particle
+        # kernels' durations are those of the kernel ALONE, bracketed by HIP events on its stream (fy_particle_timings)
+        "k_locate_deposit": (acc["locate_deposit"], K, (24.0 + 24.0 + 8.0 + 15.2 + 4.0 + 12.0 * kbar) * np_part + 64.0 * nc,
+                             "k-d 'range' locate through per-(cell, octant) candidate lists + Gaussian weights + void-fraction deposit in one pass: "
+                             "position 24 + velocity 24 + radius 8 + list 15 B in, chain length 4 + 12 B/pair out per particle; 32 B of accumulators "
+                             "read-modify-written per cell"),
+        "k_force_gaussian": (acc["force"], K, (64.0 + 12.0 * kbar + 52.0) * np_part + 128.0 * nc,
+                             "drag + Archimedes + back-scatter: particle 64 B + stencil 12 B/pair in, force record 52 B out; per cell the 64-byte "
+                             "gather record read and 32 B of momentum-source accumulators read-modify-written"),
+        "k_point_force": (acc["force"], K, 128.0 * np_part, "findCell + Stokes drag / torque + uSource scatter: 80 B record in, 48 B force out per particle"),
         "k_mg_smooth(level 0)": (smooth_ms, smooth_n, 56.0 * nc, "pEqn Laplacian apply fused with the damped-Jacobi update: 48 B/cell (diag, 3 upper, x, y) + b 8"),
         "k_p_apply_dot": (apply_ms, apply_n, 48.0 * nc, "pEqn Laplacian apply y = A p (+ p.Ap) inside PCG: 48 B/cell"),
         "k_mom_pass": (mom_ms, mom_n, (7 * 8 + 24 * 3) * nc, "fused momentum Jacobi pass: 7 coeffs + b,x,xn (3 comps)"),
     }
+    for gone in (("k_locate_deposit", "k_force_gaussian") if c2 else ("k_point_force",)):
+        cand.pop(gone)
     # HBM traffic per launch from the committed PMC passes of this same command (tools/pmc_traffic.py; null if absent)
     traffic = {}
     for cand_file in sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1:]:
@@ -341,7 +497,7 @@ def main():
             traffic = {k: v.get("hbm_bytes_per_launch") for k, v in json.load(open(cand_file))["kernels"].items()}
         except Exception:
             traffic = {}
-    if not (args.n == 160 and args.particles == 10_000_000 and world == 1):
+    if c2 or not (args.n == 160 and args.particles == 10_000_000 and world == 1):
         traffic = {}            # the PMC passes were taken on the default single-GPU workload only
     for nm, (ms, nl, bytes_per, desc) in cand.items():
         if nl:
@@ -356,40 +512,74 @@ def main():
                 "frac": round(k["achieved_GBps"] / HBM_PEAK_GBPS, 4), "traffic": traffic.get(name.split("+")[0]), "avg_launch_ms": round(k["avg_ms"], 4),
                 "launches": k["launches"], "algorithmic_bytes_per_launch": k["alg_bytes"], "what": k["what"]}
 
+    default_c3 = (not c2) and args.n == 160 and args.particles == 10_000_000
+    p_iters, u_iters = acc["p_iters"] / K, acc["u_iters"] / K
+    n_corr = 2
+    # compulsory bytes of one coupled step -- particle phase 128 Np + 232 Nc; FV passes (280 + nCorr x 504) Nc; 128 Nc per
+    # Krylov iteration (pressure and momentum sweeps alike)
+    step_bytes = 128.0 * np_part + 232.0 * nc + (280.0 + n_corr * 504.0) * nc + 128.0 * nc * (p_iters + u_iters + 1)
+    ms_step = 1e3 * elapsed / K
+    if c2:
+        metric = "coupled_steps_per_sec (icoFoamYade point force, 1M particles / 1M cells)" if args.particles == 1_000_000 else f"coupled_steps_per_sec (icoFoamYade point force, {args.particles} particles / {nc} cells)"
+        workload = "C2: icoFoamYade point-force coupling, 200 x 100 x 50 = 1,000,000-cell channel (inlet U = (1,0,0), outlet p = 0, no-slip walls), " + f"{args.particles:,} particles uniform in the channel"
+    else:
+        metric = "coupled_steps_per_sec (pimpleFoamYade 4-way, 10M particles / 4M cells per GPU)" if default_c3 else f"coupled_steps_per_sec (pimpleFoamYade 4-way, {args.particles} particles / {nc} cells)"
+        workload = ("C3: pimpleFoamYade Gaussian 4-way coupling, 160^3 = 4,096,000-cell closed box, 10,000,000 particles in the lower 60 %" if default_c3
+                    else f"non-default C3-like case {args.n}^3 cells / {args.particles} particles")
     out = {
-        "metric": "coupled_steps_per_sec (pimpleFoamYade 4-way, 10M particles / 4M cells per GPU)" if (args.n == 160 and args.particles == 10_000_000)
-        else f"coupled_steps_per_sec (pimpleFoamYade 4-way, {args.particles} particles / {nc} cells)",
+        "metric": metric,
         "value": round(steps_per_s, 4), "unit": "steps/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
-        "ms_per_step": round(1e3 * elapsed / K, 3), "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
+        "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "particle_steps_per_sec": round(steps_per_s * (args.particles if strong else np_part), 1),
         "coupled_steps_per_sec_of_the_whole_box": round(steps_per_s if strong else steps_per_s / world, 4),
-        "config": {"workload": "C3: pimpleFoamYade Gaussian 4-way coupling, 160^3 = 4,096,000-cell closed box, 10,000,000 particles in the lower 60 %"
-                   if (args.n == 160 and args.particles == 10_000_000) else f"non-default C3-like case {args.n}^3 cells / {args.particles} particles",
-                   "cells": nc, "particles": np_part, "dt": args.dt, "pimple": {"nOuterCorrectors": 1, "nCorrectors": 2},
+        "config": {"workload": workload,
+                   "cells": nc, "particles": np_part, "dt": args.dt, ("piso" if c2 else "pimple"): ({"nCorrectors": 2} if c2 else {"nOuterCorrectors": 1, "nCorrectors": 2}),
                    "p_solver": "PCG+MG V(2,2) damped Jacobi" if args.p_solver == 1 else "PCG+Jacobi",
                    "p_tol": [case.p_tol, case.p_rel_tol, case.p_final_tol, case.p_final_rel_tol],
                    "parallelism": parallelism,
                    "global_cells": nc * world, "global_particles": args.particles if strong else np_part * world},
-        "per_step_ms": {k: round(acc[k] / K, 3) for k in ("particle", "bin", "locate_deposit", "finalize", "force", "momentum", "pressure", "other")},
-        "p_iters_per_step": acc["p_iters"] / K, "u_iters_per_step": acc["u_iters"] / K,
+        "per_step_ms": {k: round(acc[k] / K, 3) for k in ("particle", "bin", "locate_deposit", "finalize", "force", "fold", "momentum", "pressure", "other")},
+        "p_iters_per_step": p_iters, "u_iters_per_step": u_iters,
         "roofline": roof(dominant) if dominant else None,
         "roofline_pEqn_laplacian": roof(lap) if lap in kern else None,
+        "whole_step": {"compulsory_bytes": step_bytes, "achieved_GBps": round(step_bytes / (ms_step * 1e-3) / 1e9, 1),
+                       "frac_of_hbm_peak": round(step_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                       "what": "SURVEY.md 8(d) compulsory bytes of one coupled step (particle phase 128 Np + 232 Nc; FV passes (280 + nCorr 504) Nc; 128 Nc per "
+                               "Krylov iteration) / ms_per_step"},
         "kernels": {k: {"avg_ms": round(v["avg_ms"], 4), "launches": v["launches"], "GBps": round(v["achieved_GBps"], 1)} for k, v in kern.items()},
     }
+    if rank == 0 and world == 1 and args.wire > 0:
+        # the drop-in leg needs the device memory: the HBM-resident solver is done
+        rec_host = rec.cpu().numpy()
+        solver.close(); solver = None
+        del rec
+        torch.cuda.empty_cache()
+        try:
+            out["drop_in_path"] = wire_leg(prod, torch, case, rec_host, args.wire, args.wire_workers, local_rank)
+            out["per_step_ms"].update({"h2d": out["drop_in_path"]["per_step_ms"]["h2d"], "d2h": out["drop_in_path"]["per_step_ms"]["d2h"],
+                                       "wire": round(out["drop_in_path"]["per_step_ms"]["wire_recv"] + out["drop_in_path"]["per_step_ms"]["wire_send"], 3)})
+            out["per_step_ms_note"] = "h2d / d2h / wire are the drop-in leg's (host buffers through the transport), measured after the timed region; every other entry and `value` are the HBM-resident run"
+        except Exception as e:                                        # noqa: BLE001  (reported in the line, never fatal for the headline)
+            out["drop_in_path"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and not args.no_cpu_baseline and world == 1:
-        th = os.cpu_count() or 1
-        ppc = args.particles / nc
-        per, snc, snp = cpu_baseline(args.cpu_sample_n, ppc, args.dt, th)
+        model, ncores = cpu_info()
+        full = args.cpu_sample_n == 0 or c2
+        n_s = args.n if full else args.cpu_sample_n
+        n_part_cpu = args.particles if full else int(round(args.particles / nc * n_s ** 3))
+        per, snc = cpu_baseline(args.config, n_s, n_part_cpu, args.dt, ncores, full)
         best_th = min(per, key=lambda k: per[k])
-        scale = snc / nc                                   # linear-in-size extrapolation to the bench workload
+        scale = snc / nc                                   # 1 at full size; otherwise the linear-in-size extrapolation to the bench workload
         out["cpu_baseline"] = {
             "value": round((1.0 / per[best_th]) * scale, 6), "unit": "steps/s", "cores": int(best_th), "kind": "port",
-            "single_thread_value": round((1.0 / per[1]) * scale, 6),
-            "sample": f"same workload at {args.cpu_sample_n}^3 cells / {snp} particles ({snc / nc:.4f} of the bench size), CPU oracle (port of the "
-                      f"reference path, de-quadraticised deposit), measured {per[best_th]:.2f} s/step on {best_th} threads ({per[1]:.2f} s/step on 1); "
-                      f"value = measured steps/s x {scale:.5f} (linear-in-size extrapolation)"}
-        ref = cpu_reference_as_written()
+            "single_thread_value": round((1.0 / per[1]) * scale, 6), "cpu_model": model, "host_cores_usable": ncores, "host_cores_present": os.cpu_count(),
+            "sample": (f"the bench workload itself at full size ({snc} cells / {n_part_cpu} particles), CPU oracle (port of the reference path, de-quadraticised "
+                       f"deposit): one warm-up + 2 timed steps on {best_th} threads = {per[best_th]:.2f} s/step; one warm-up + 1 timed step on 1 thread = {per[1]:.2f} s/step"
+                       if full else
+                       f"same workload at {n_s}^3 cells / {n_part_cpu} particles ({scale:.4f} of the bench size), CPU oracle (port of the reference path, "
+                       f"de-quadraticised deposit), measured {per[best_th]:.2f} s/step on {best_th} threads ({per[1]:.2f} s/step on 1); value = measured steps/s x "
+                       f"{scale:.5f} (linear-in-size extrapolation)")}
+        ref = cpu_reference_as_written() if not c2 else None
         if ref is not None:
             out["cpu_reference_as_written"] = ref
             pp = args.particles * steps_per_s

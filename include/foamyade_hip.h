@@ -158,6 +158,10 @@ typedef struct fy_particle_timings {
     double copy_in, copy_out;         /* first H2D start .. last H2D end, first D2H start .. last D2H end (copy stream, ms) */
     double wire_recv, wire_send;      /* host wall time in the transport's record / result calls (ms) */
     int64_t bytes_in, bytes_out;      /* bytes that crossed PCIe in each direction (records; forces + found flags) */
+    /* Gaussian mode: locate_deposit and force above are the two big kernels ALONE (k_locate_deposit; k_force_gaussian), bracketed by HIP
+       events on their stream; finalize = cell-record pack + tile reduce + k_finalize_cells (+ slab halos); fold = tile reduce +
+       k_fold_sources (+ slab halos) */
+    double fold;
 } fy_particle_timings;
 int fy_get_particle_timings(fy_ctx*, fy_particle_timings* out);
 int fy_enable_timing(fy_ctx*, int on);

@@ -76,7 +76,7 @@ class ParticleTimings(C.Structure):
     _fields_ = [("h2d", C.c_double), ("bin", C.c_double), ("locate_deposit", C.c_double), ("finalize", C.c_double),
                 ("force", C.c_double), ("d2h", C.c_double), ("total", C.c_double), ("n_particles", C.c_int64),
                 ("n_pairs", C.c_int64), ("copy_in", C.c_double), ("copy_out", C.c_double), ("wire_recv", C.c_double),
-                ("wire_send", C.c_double), ("bytes_in", C.c_int64), ("bytes_out", C.c_int64)]
+                ("wire_send", C.c_double), ("bytes_in", C.c_int64), ("bytes_out", C.c_int64), ("fold", C.c_double)]
 
 
 class CaseDesc(C.Structure):

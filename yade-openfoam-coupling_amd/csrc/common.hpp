@@ -127,6 +127,25 @@ struct EventTimer {
     }
 };
 
+// consecutive phases on one stream share their boundary events: N + 1 records for N phases (an event record between two kernels idles
+// the stream for several microseconds, so every pair that can be saved is)
+struct PhaseMarks {
+    static constexpr int kMax = 8;
+    hipEvent_t ev[kMax] = {};
+    bool set_[kMax] = {};
+    int init() { for (auto& e : ev) FY_HIP(hipEventCreate(&e)); return FY_OK; }
+    void destroy() { for (auto& e : ev) { if (e) (void)hipEventDestroy(e); e = nullptr; } }
+    void clear() { for (auto& b : set_) b = false; }
+    void mark(int i, hipStream_t s) { (void)hipEventRecord(ev[i], s); set_[i] = true; }
+    double ms(int i, int j) {
+        if (!set_[i] || !set_[j]) return 0.0;
+        float t = 0.f;
+        (void)hipEventSynchronize(ev[j]);
+        (void)hipEventElapsedTime(&t, ev[i], ev[j]);
+        return (double)t;
+    }
+};
+
 // accumulating per-kernel clock: one HIP event pair per launch, recorded on the launch stream, harvested once per step
 struct KernelClock {
     std::vector<hipEvent_t> a, b;

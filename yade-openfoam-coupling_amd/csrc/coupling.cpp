@@ -227,6 +227,7 @@ int Coupling::create(const fy_mesh_desc* m, const fy_field_ptrs* f, int gaussian
         FY_TRY(d_tile_sums.alloc_exact((bins.nkeys + 2047u) / 2048u + 1));
     }
     for (auto& t : timers) FY_TRY(t.init());
+    FY_TRY(marks.init());
     if (const char* e = getenv("FOAMYADE_REBIN_INTERVAL")) rebin_interval = std::max(1, atoi(e));
     if (has_transport || fields_on_host) {
         FY_HIP(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
@@ -518,7 +519,7 @@ int Coupling::run_batch(Batch& b) {
     ForceParams fp{rhoF, nu, 1e-09, rhoP, delta_t, force_models, 0, vol_uniform ? v0 : 0.0};
     if (gaussian) {
         ParticleSoA p = soa_of(b);
-        if (timing) timers[T_BIN].start(stream);
+        if (timing) marks.mark(0, stream);
         // The binned order only buys locality -- every result is independent of it -- and particles move a fraction of a cell per
         // coupling step, so the placement of an earlier step stays nearly as good: the counting sort runs every rebin_interval
         // steps (or when the particle count changes), in between the records are just gathered through the old permutation.
@@ -532,7 +533,6 @@ int Coupling::run_batch(Batch& b) {
             FY_TRY(launch_bin_gather(stream, b.d_rec, b.n, p));
             ++b.bin_age;
         }
-        if (timing) { timers[T_BIN].stop(stream); timers[T_LOCATE].start(stream); }
         GaussParams gp;
         gp.maxdist = (interp_range * interp_range) + (0.25 * interp_range * interp_range);   // meshTree.C:155
         gp.two_sigma2 = 2 * std::pow(sigma_interp, 2);                                         // FoamYade.C:308
@@ -548,15 +548,16 @@ int Coupling::run_batch(Batch& b) {
         // the scatters' tables are flushed into per-tile buckets sized from the demand they counted in this batch's last step
         const TileBuckets tbD = buckets_of(b, 0), tbB = buckets_of(b, 1);
         FY_TRY(launch_tile_caps(stream, tbD, tbB));
+        if (timing) marks.mark(1, stream);
         if (unfused) {
             FY_TRY(launch_locate(stream, d_tree.p, use_implicit ? d_tree_packed.p : nullptr, implicit, n_cells, tree_levels, p, b.n, gp,
                                  use_implicit ? d_loc_start.p : nullptr, slab_own(), ll));
-            if (timing) { timers[T_LOCATE].stop(stream); timers[T_FINALIZE].start(stream); }
+            if (timing) marks.mark(2, stream);
             FY_TRY(launch_deposit(stream, p, b.n, gp, cw, d_pvol_acc.p, d_up_acc.p, d_touched.p, tbD));
         } else {
             FY_TRY(launch_locate_deposit(stream, d_tree.p, use_implicit ? d_tree_packed.p : nullptr, implicit, n_cells, tree_levels, p, b.n, gp,
                                          use_implicit ? d_loc_start.p : nullptr, slab_own(), ll, cw, d_pvol_acc.p, d_up_acc.p, d_touched.p, tbD, side));
-            if (timing) { timers[T_LOCATE].stop(stream); timers[T_FINALIZE].start(stream); }
+            if (timing) marks.mark(2, stream);
         }
         // The force pass gathers U, alpha and the Archimedes term from one packed record per cell.  U / gradP / divT do not change during the
         // call and the alpha slot follows k_finalize_cells, so the records are built once per call -- here, where the pack runs beside the
@@ -577,7 +578,6 @@ int Coupling::run_batch(Batch& b) {
             FY_TRY(launch_patch_rec_alpha(stream, 0, gcells, dAlpha, d_cellrec.p));
             FY_TRY(launch_patch_rec_alpha(stream, (int64_t)(slab.gz + slab.nz) * (int64_t)slab.plane, gcells, dAlpha, d_cellrec.p));
         }
-        if (timing) { timers[T_FINALIZE].stop(stream); timers[T_FORCE].start(stream); }
         // Gaussian torque is identically zero unless the opt-in model is on (FoamYade.C:618): zero the records once per buffer,
         // afterwards the kernel stores only the force half of each (permuted, 48-byte) record
         if (force_models & FY_FORCE_GAUSSIAN_TORQUE) {
@@ -589,8 +589,10 @@ int Coupling::run_batch(Batch& b) {
             }
             fp.torque_prezeroed = 1;
         }
+        if (timing) marks.mark(3, stream);
         FY_TRY(launch_force_gaussian(stream, p, b.n, fp, cw, d_vol.p, d_cellrec.p, dVGrad, dDdtU, b.d_rec, force_split ? b.fscr.p : nullptr,
                                      d_drag_acc.p, dUSource, b.force.p, tbB));
+        if (timing) marks.mark(4, stream);
         FY_TRY(launch_tile_reduce(stream, tbB, d_drag_acc.p, dUSource, nullptr));
         b.found_stale = true;
         if (slab.active) {
@@ -598,15 +600,15 @@ int Coupling::run_batch(Batch& b) {
         }
         // FoamYade.C:385-386 per cell: uSourceDrag += D, uSource += uParticle * D (this batch's uParticle: the owner's, after its finalize)
         FY_TRY(launch_fold_sources(stream, n_field, d_drag_acc.p, dUParticle, dUSourceDrag, dUSource));
-        if (timing) timers[T_FORCE].stop(stream);
+        if (timing) marks.mark(5, stream);
     } else {
         BlockGeom g;
         for (int a = 0; a < 3; ++a) { g.bbmin[a] = mesh.bbox_min[a]; g.bbmax[a] = mesh.bbox_max[a]; }
         g.dx = mesh.dx; g.nx = mesh.nx; g.ny = mesh.ny; g.nz = mesh.nz;
-        if (timing) timers[T_FORCE].start(stream);
+        if (timing) marks.mark(3, stream);
         const CellWindow cw{slab.active ? slab.base : 0, n_field};
         FY_TRY(launch_point_force(stream, b.d_rec, b.n, g, fp, cw, d_vol.p, dU, dVGrad, dUSource, b.force.p, b.found.p, b.incell.p, slab_own()));
-        if (timing) timers[T_FORCE].stop(stream);
+        if (timing) marks.mark(4, stream);
     }
     return FY_OK;
 }
@@ -656,8 +658,9 @@ int Coupling::collect_timings() {
     if (!timings_pending) return FY_OK;
     timings_pending = false;
     FY_HIP(hipStreamSynchronize(stream));
-    tm.bin = timers[T_BIN].ms(); tm.locate_deposit = timers[T_LOCATE].ms();
-    tm.finalize = timers[T_FINALIZE].ms(); tm.force = timers[T_FORCE].ms(); tm.total = timers[T_TOTAL].ms();
+    tm.bin = marks.ms(0, 1); tm.locate_deposit = marks.ms(1, 2); tm.finalize = marks.ms(2, 3); tm.force = marks.ms(3, 4); tm.fold = marks.ms(4, 5);
+    tm.total = timers[T_TOTAL].ms();
+    marks.clear();
     if (copy_stream) {
         FY_HIP(hipStreamSynchronize(copy_stream));
         for (auto* b : batches) if (b->events) { tm.copy_in += b->t_in.ms(); tm.copy_out += b->t_out.ms(); }
@@ -916,6 +919,7 @@ int Coupling::write_field_host(const char* name, const double* in) {
 Coupling::~Coupling() {
     if (device >= 0) (void)hipSetDevice(device);
     for (auto& t : timers) t.destroy();
+    marks.destroy();
     for (auto* b : batches) delete b;
     for (void* r : registered) (void)hipHostUnregister(r);
     if (side.fork) (void)hipEventDestroy(side.fork);

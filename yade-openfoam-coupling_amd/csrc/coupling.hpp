@@ -120,8 +120,9 @@ struct Coupling {
     int upload_batch(Batch& b, int64_t n);      // pinned h_rec -> rec_own on the copy stream; the compute stream waits for it
 
     // ---- timing
-    enum { T_H2D = 0, T_BIN, T_LOCATE, T_FINALIZE, T_FORCE, T_D2H, T_TOTAL, T_COUNT };
+    enum { T_TOTAL = 0, T_COUNT };
     EventTimer timers[T_COUNT];
+    PhaseMarks marks;                    // 0 | bin (+ tile capacities) | 1 | k_locate_deposit | 2 | pack, reduce, finalize | 3 | k_force_gaussian | 4 | reduce, fold | 5
     bool timing = false;
     fy_particle_timings tm{};
 

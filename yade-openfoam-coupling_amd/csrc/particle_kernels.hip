@@ -1110,7 +1110,11 @@ __global__ __launch_bounds__(MODE == 1 ? 256 : kForceThreads) void k_force_gauss
                     const size_t slot = (size_t)((chain - 1 - t) & (kMaxK - 1)) * p.cap + (size_t)i;
                     const int64_t cl = (int64_t)p.ids[slot] - cw.base;
                     if (cl < 0 || cl >= cw.n_field) continue;
+#if defined(FY_EXP_SAMECELL)
+                    interp_add(s, R, (int64_t)(threadIdx.x & 63), p.w[slot], volp);
+#else
                     interp_add(s, R, cl, p.w[slot], volp);
+#endif
                 }
                 if (fp.models)                              // uniform: off in the shipped reference
                     for (int t = 0; t < k; ++t) {
@@ -1119,7 +1123,15 @@ __global__ __launch_bounds__(MODE == 1 ? 256 : kForceThreads) void k_force_gauss
                         if (cl < 0 || cl >= cw.n_field) continue;
                         model_add(ms, fp, vGrad, ddtU, cl, p.w[slot], volp);
                     }
+#if defined(FY_EXP_NOLAW)          // timing-only experiments (never defined in the product build; tools/build_variant.sh)
+                pf.coeff = s.ufx + s.alpha_f; pf.bx = s.sax + s.pv; pf.by = s.say + s.ufy; pf.bz = s.saz + s.ufz;
+#elif defined(FY_EXP_NOFSTORE)
+                double Fl[6];
+                pf = force_law(fp, s, ms, k, dia, p.vx[i], p.vy[i], p.vz[i], rec + 10 * (size_t)orig, Fl);
+                if (Fl[0] == 1.2345e300) F[0] = Fl[1];
+#else
                 pf = force_law(fp, s, ms, k, dia, p.vx[i], p.vy[i], p.vz[i], rec + 10 * (size_t)orig, F);
+#endif
             }
             if constexpr (MODE == 1) {
                 scr[i] = pf.coeff; scr[p.cap + i] = pf.bx; scr[2 * p.cap + i] = pf.by; scr[3 * p.cap + i] = pf.bz;
@@ -1141,7 +1153,11 @@ __global__ __launch_bounds__(MODE == 1 ? 256 : kForceThreads) void k_force_gauss
                     const double ooCellVol = fp.uniform_vol > 0 ? ooUniform : 1. / (vol[c] * fp.rhoF);  // FoamYade.C:432
                     const double c0 = (-pf.coeff * w) * irho;                                      // FoamYade.C:385 (and, times uParticle[c], :386)
                     const double c1 = (-pf.bx * w) * ooCellVol, c2 = (-pf.by * w) * ooCellVol, c3 = (-pf.bz * w) * ooCellVol;   // FoamYade.C:433, 406-411
+#if defined(FY_EXP_NOHASH)
+                    const int h = (int)(((uint32_t)c * 2654435761u) >> (32 - kForceLog2)); keys[h] = (uint32_t)c;
+#else
                     const int h = agg_slot<kForceLog2>(keys, (uint32_t)c);
+#endif
                     if (h >= 0) {
                         lds_add_f64(&vals[4 * h], c0); lds_add_f64(&vals[4 * h + 1], c1);
                         lds_add_f64(&vals[4 * h + 2], c2); lds_add_f64(&vals[4 * h + 3], c3);
