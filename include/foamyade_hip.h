@@ -201,6 +201,13 @@ typedef struct fy_case_desc {
     double p_tol, p_rel_tol, p_final_tol, p_final_rel_tol; int32_t p_max_iter;
     double u_tol, u_rel_tol; int32_t u_max_iter;
     int32_t convection_scheme;             /* divSchemes for div(phi,U): FY_CONVECTION_LINEAR (Gauss linear, default) | _UPWIND (Gauss upwind) | _LINEAR_UPWIND (Gauss linearUpwind, unlimited) */
+    /* controlDict adjustTimeStep / maxCo / maxDeltaT: readTimeControls.H + CourantNo.H + setDeltaT.H at the top of the time loop
+       (pimpleFoamYade.C:62-64); dt above is then the initial deltaT and fy_step_stats.delta_t reports what each step used */
+    int32_t adjust_time_step; double max_co, max_delta_t;
+    /* fvSolution relaxationFactors: equations { Uc; UcFinal } for UcEqn.relax() (UcEqn.H:12), fields { p; pFinal } for p.relax()
+       (pEqn.H:41).  <= 0: no entry (the call does nothing); the *_final values apply on the last outer corrector, falling back to the
+       plain ones when absent.  fy_case_defaults: u_relax = 1 (the DPMFoam tutorials' `equations { ".*" 1; }`), no field relaxation */
+    double u_relax, u_relax_final, p_relax, p_relax_final;
 } fy_case_desc;
 
 typedef struct fy_solver fy_solver;
@@ -211,6 +218,7 @@ typedef struct fy_step_stats {
     int32_t p_iters_total, p_solves, u_iters_total;
     double p_initial_residual, p_final_residual;
     double ms_particle, ms_momentum, ms_pressure, ms_other, ms_total;
+    double delta_t;                                     /* the time step this pass used (setDeltaT.H when adjust_time_step) */
 } fy_step_stats;
 
 void fy_case_defaults(fy_case_desc* c, int solver);

@@ -43,11 +43,16 @@ struct orc_fv_case {
     double p_tol, p_rel_tol, p_final_tol, p_final_rel_tol; int p_max_iter;
     double u_tol, u_rel_tol; int u_max_iter;
     int convection_scheme;      // 0 Gauss linear, 1 Gauss upwind, 2 Gauss linearUpwind (unlimited, Gauss-linear gradient)
+    // controlDict adjustTimeStep / maxCo / maxDeltaT (readTimeControls.H + setDeltaT.H, pimpleFoamYade.C:62-64)
+    int adjust_time_step; double max_co, max_delta_t;
+    // fvSolution relaxationFactors: equations { Uc; UcFinal } (UcEqn.relax(), UcEqn.H:12), fields { p; pFinal } (p.relax(), pEqn.H:41); <= 0: no entry
+    double u_relax, u_relax_final, p_relax, p_relax_final;
 };
 struct orc_fv_stats {
     double courant_mean, courant_max, cont_sum_local, cont_global, cont_cumulative;
     int p_iters_total, p_solves, u_iters_total;
     double p_initial_residual, p_final_residual;
+    double delta_t;              // the time step this pass of the loop used (setDeltaT.H)
 };
 }
 
@@ -242,6 +247,8 @@ struct Fv {
     // pimple: fvm::ddt(a,Uc) + fvm::div(aPhi,Uc) - fvm::Sp(fvc::ddt(a)+fvc::div(aPhi),Uc) + divDevRhoReff(Uc) == fvm::Sp(uSourceDrag,Uc)
     //                                                                                              (UcEqn.H:3-10), then relax() (UcEqn.H:12)
     // an[2*d+s] = coefficient of the neighbour across face (d,s); src excludes any pressure term.
+    double u_relax_now = 1.0;      // the factor fvMatrix::relax() finds for this outer iteration (Uc / UcFinal)
+    vec pPrev;                     // p.prevIter(): stored by pimple.loop() at the start of every outer iteration when p has a relaxation factor
     void assemble_momentum() {
         const double nu = cs.nu, dt = cs.dt;
         if (pimple) {
@@ -318,10 +325,12 @@ struct Fv {
             } else {
                 for (int q = 0; q < 3; ++q) s3[q] += V * uSource[3 * (size_t)c + q];   // == uSource
             }
-            if (pimple) {
-                // fvMatrix::relax(1): enforce diagonal dominance, D = max(|D|, sum|offdiag|), source += (D_new - D_old) psi
+            if (pimple && u_relax_now > 0) {
+                // fvMatrix::relax(alpha) [OF-6 fvMatrix.C]: the boundary coefficients join the diagonal for the dominance test (they are
+                // part of dg here all along), D = max(|D|, sum|offdiag|) / alpha, source += (D_new - D_old) psi.  No relaxationFactors
+                // entry for the equation (alpha <= 0): relax() does nothing at all, not even the dominance step.
                 double so = 0.0; for (int q = 0; q < 6; ++q) so += std::fabs(an[q][c]);
-                const double dn = std::max(std::fabs(dg), so);
+                const double dn = std::max(std::fabs(dg), so) / u_relax_now;
                 for (int q = 0; q < 3; ++q) s3[q] += (dn - dg) * U[3 * (size_t)c + q];
                 dg = dn;
             }
@@ -656,6 +665,7 @@ struct Fv {
 
     // fvc::reconstruct(s_f) on the uniform block: per axis (s_{f+} + s_{f-}) / (2 |Sf|)
     // ---- one PISO/PIMPLE corrector (icoFoamYade.C:97-140 / pEqn.H) -------------------------------------------
+    double p_relax_now = 0.0;
     void corrector(bool final_inner) {
         compute_HbyA();
         if (!pimple) interp_rAU();
@@ -669,6 +679,8 @@ struct Fv {
                 pressure_flux(L);
                 for (int d = 0; d < 3; ++d) for (size_t f = 0; f < phi[d].size(); ++f)
                     phi[d][f] = phiHbyA[d][f] - pflux[d][f] / (pimple ? alphaf[d][f] : 1.0);      // icoFoamYade.C:129, pEqn.H:39
+                if (pimple && p_relax_now > 0 && p_relax_now < 1)                                     // p.relax(), pEqn.H:41 (after the flux: the flux keeps the unrelaxed solution)
+                    for (int c = 0; c < Nc; ++c) p[c] = pPrev[c] + p_relax_now * (p[c] - pPrev[c]);
             }
         }
         continuity_errors();                                                 // icoFoamYade.C:134, pEqn.H:50
@@ -693,6 +705,12 @@ struct Fv {
     void step_begin() {            // up to (excluding) yadeCoupling.setParticleAction
         st = orc_fv_stats{}; st.cont_cumulative = cumulativeContErr;
         courant();                                                           // icoFoamYade.C:68, pimpleFoamYade.C:63
+        if (cs.adjust_time_step) {                                           // setDeltaT.H [OF-6], pimpleFoamYade.C:64
+            const double maxDeltaTFact = cs.max_co / (st.courant_max + SMALL);
+            const double deltaTFact = std::min(std::min(maxDeltaTFact, 1.0 + 0.1 * maxDeltaTFact), 1.2);
+            cs.dt = std::min(deltaTFact * cs.dt, cs.max_delta_t);
+        }
+        st.delta_t = cs.dt;
         // runTime++ : old-time fields (U.oldTime(), phi.oldTime(), alphac.oldTime())
         Uold = U; for (int d = 0; d < 3; ++d) phiOld[d] = phi[d];
         pre_coupling_fields();                                               // icoFoamYade.C:71, pimpleFoamYade.C:73-76
@@ -707,6 +725,12 @@ struct Fv {
         if (pimple) interp_alpha();                                          // pimpleFoamYade.C:83-85 (alphaPhic is formed on the fly)
         const int nOuter = pimple ? std::max(cs.n_outer, 1) : 1;
         for (int outer = 0; outer < nOuter; ++outer) {
+            // pimple.loop(): "finalIteration" is set on the last outer corrector; fvMatrix::relax() / GeometricField::relax() then look
+            // for the <name>Final factor first [OF-6 solutionControl / fvMatrix.C / GeometricField.C]
+            const bool final_outer = outer == nOuter - 1;
+            u_relax_now = (final_outer && cs.u_relax_final > 0) ? cs.u_relax_final : cs.u_relax;
+            p_relax_now = (final_outer && cs.p_relax_final > 0) ? cs.p_relax_final : cs.p_relax;
+            if (pimple && p_relax_now > 0 && p_relax_now < 1) pPrev = p;          // storePrevIterFields()
             assemble_momentum();
             if (pimple) { interp_rAU(); compute_phi_forces(); }
             if (cs.momentum_predictor) {

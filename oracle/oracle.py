@@ -182,14 +182,16 @@ class FvCase(C.Structure):
                 ("n_outer", C.c_int), ("n_corr", C.c_int), ("n_non_orth", C.c_int), ("momentum_predictor", C.c_int),
                 ("p_ref_cell", C.c_int), ("p_ref_value", C.c_double), ("p_solver", C.c_int),
                 ("p_tol", C.c_double), ("p_rel_tol", C.c_double), ("p_final_tol", C.c_double), ("p_final_rel_tol", C.c_double),
-                ("p_max_iter", C.c_int), ("u_tol", C.c_double), ("u_rel_tol", C.c_double), ("u_max_iter", C.c_int), ("convection_scheme", C.c_int)]
+                ("p_max_iter", C.c_int), ("u_tol", C.c_double), ("u_rel_tol", C.c_double), ("u_max_iter", C.c_int), ("convection_scheme", C.c_int),
+                ("adjust_time_step", C.c_int), ("max_co", C.c_double), ("max_delta_t", C.c_double),
+                ("u_relax", C.c_double), ("u_relax_final", C.c_double), ("p_relax", C.c_double), ("p_relax_final", C.c_double)]
 
 
 class FvStats(C.Structure):
     _fields_ = [("courant_mean", C.c_double), ("courant_max", C.c_double), ("cont_sum_local", C.c_double),
                 ("cont_global", C.c_double), ("cont_cumulative", C.c_double), ("p_iters_total", C.c_int),
                 ("p_solves", C.c_int), ("u_iters_total", C.c_int), ("p_initial_residual", C.c_double),
-                ("p_final_residual", C.c_double)]
+                ("p_final_residual", C.c_double), ("delta_t", C.c_double)]
 
 
 U_FIXED, U_ZEROGRAD = 0, 1
@@ -200,7 +202,8 @@ XMIN, XMAX, YMIN, YMAX, ZMIN, ZMAX = range(6)
 def fv_case(solver, nx, ny, nz, dx, dt, nu, rho_f=1000.0, rho_p=2650.0, g=(0, 0, 0), u_bc=None, u_val=None, p_bc=None,
             p_val=None, n_outer=1, n_corr=2, p_solver=1, origin=(0, 0, 0), momentum_predictor=1, p_tol=1e-6, p_rel_tol=0.05,
             p_final_tol=1e-6, p_final_rel_tol=0.0, u_tol=1e-5, u_rel_tol=0.0, p_max_iter=1000, u_max_iter=1000, convection_scheme=0, p_ref_cell=0,
-            p_ref_value=0.0, n_non_orth=0):
+            p_ref_value=0.0, n_non_orth=0, adjust_time_step=0, max_co=1.0, max_delta_t=1e300, u_relax=1.0, u_relax_final=0.0, p_relax=0.0,
+            p_relax_final=0.0):
     """documented defaults = the icoFoam cavity / DPMFoam tutorial settings of SURVEY.md Appendix C"""
     c = FvCase()
     c.solver, c.nx, c.ny, c.nz, c.dx, c.dt, c.nu = solver, nx, ny, nz, dx, dt, nu
@@ -223,6 +226,8 @@ def fv_case(solver, nx, ny, nz, dx, dt, nu, rho_f=1000.0, rho_p=2650.0, g=(0, 0,
     c.p_tol, c.p_rel_tol, c.p_final_tol, c.p_final_rel_tol, c.p_max_iter = p_tol, p_rel_tol, p_final_tol, p_final_rel_tol, p_max_iter
     c.u_tol, c.u_rel_tol, c.u_max_iter = u_tol, u_rel_tol, u_max_iter
     c.convection_scheme = int(convection_scheme)
+    c.adjust_time_step, c.max_co, c.max_delta_t = int(adjust_time_step), max_co, max_delta_t
+    c.u_relax, c.u_relax_final, c.p_relax, c.p_relax_final = u_relax, u_relax_final, p_relax, p_relax_final
     return c
 
 
@@ -297,7 +302,7 @@ class FvSolver:
             n = records.shape[0]
             out = particle_action(self.mesh, fields, mut, records, np.array([0, n], np.int32), self.gaussian,
                                   c.rho_particle, c.rho_fluid, c.nu, threads=self.threads,
-                                  force_models=getattr(self, "force_models", 0), dt=c.dt)
+                                  force_models=getattr(self, "force_models", 0), dt=self.stats()["delta_t"])
         self.L.orc_fv_step_end(self.h)
         # yadeCoupling.setSourceZero() (icoFoamYade.C:147, pimpleFoamYade.C:109)
         self.L.orc_set_source_zero(self.Nc, int(self.gaussian), _d(self.view("uSourceDrag")), _d(self.view("alpha")),

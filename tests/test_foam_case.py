@@ -231,3 +231,38 @@ def test_upwind_convection_next_to_the_linear_stress_term_is_read(prod, tmp_path
     with pytest.raises(prod.FoamYadeError) as e:
         prod.FoamCase(dst, prod.FY_SOLVER_PIMPLE)
     assert "must be Gauss linear" in str(e.value)
+
+
+def test_time_step_control_and_relaxation_factors_are_read(prod, tmp_path):
+    """controlDict adjustTimeStep / maxCo / maxDeltaT (readTimeControls.H; only pimpleFoamYade's loop includes setDeltaT.H, pimpleFoamYade.C:62-64)
+    and fvSolution relaxationFactors (UcEqn.relax() UcEqn.H:12, p.relax() pEqn.H:41)"""
+    dst = tmp_path / "bed"
+    shutil.copytree(os.path.join(CASES, "bed_pimple"), dst)
+    base = prod.FoamCase(dst, prod.FY_SOLVER_PIMPLE)
+    assert base.case.adjust_time_step == 0 and base.case.u_relax == 0.0 and base.case.p_relax == 0.0      # no entries: relax() does nothing
+    base.close()
+    cd = dst / "system/controlDict"
+    cd.write_text(cd.read_text().rstrip() + "\nadjustTimeStep  yes;\nmaxCo           0.4;\nmaxDeltaT       0.001;\n")
+    with pytest.raises(prod.FoamYadeError) as e:          # output times that would cut the time step short are not implemented: said so
+        prod.FoamCase(dst, prod.FY_SOLVER_PIMPLE)
+    assert "writeControl" in str(e.value)
+    cd.write_text(cd.read_text().replace("adjustableRunTime", "timeStep").replace("writeInterval   0.001;", "writeInterval   5;"))
+    fs = dst / "system/fvSolution"
+    fs.write_text(fs.read_text().rstrip() + '\nrelaxationFactors\n{\n    equations { "U.water" 0.7; "U.waterFinal" 1; }\n    fields { p 0.3; pFinal 1; }\n}\n')
+    fc = prod.FoamCase(dst, prod.FY_SOLVER_PIMPLE)
+    c = fc.case
+    assert c.adjust_time_step == 1 and c.max_co == 0.4 and c.max_delta_t == 0.001
+    assert (c.u_relax, c.u_relax_final, c.p_relax, c.p_relax_final) == (0.7, 1.0, 0.3, 1.0)
+    fc.close()
+    fs.write_text(fs.read_text().replace('equations { "U.water" 0.7; "U.waterFinal" 1; }', 'equations { ".*" 1; }'))
+    fc = prod.FoamCase(dst, prod.FY_SOLVER_PIMPLE)
+    assert fc.case.u_relax == 1.0 and fc.case.u_relax_final == 1.0
+    fc.close()
+    # icoFoamYade's loop has no setDeltaT.H (icoFoamYade.C:65-70): the switch is ignored there, as the reference ignores it
+    dst2 = tmp_path / "cav"
+    shutil.copytree(os.path.join(CASES, "cavity_ico"), dst2)
+    cd2 = dst2 / "system/controlDict"
+    cd2.write_text(cd2.read_text().rstrip() + "\nadjustTimeStep  yes;\nmaxCo           0.4;\n")
+    fc = prod.FoamCase(dst2, prod.FY_SOLVER_ICO)
+    assert fc.case.adjust_time_step == 0
+    fc.close()

@@ -168,3 +168,57 @@ def test_two_slabs_at_weak_scaling_size(product, tmp_path, monkeypatch):
     so, sm = one.stats(), many.stats()[0]
     assert abs(sm["p_iters_total"] - so["p_iters_total"]) <= 2
     many.close(); one.close()
+
+
+def test_point_force_path_properties_at_c2_size(product):
+    """BASELINE configs[1] at FULL size (C2: icoFoamYade point force, 200 x 100 x 50 = 1 M-cell channel, 1 M particles),
+    through the solver's C-ABI, against closed forms on the host:
+      findCell                 found <=> inside the closed bounding box; the stencil's one cell is the containing cell     (FoamYade.C:248-253)
+      stokesDragForce/Torque   F = 3 pi d nu rho_f (U[cell] - v), T = pi d^3 nu rho_f (w_fluid[cell] - omega)              (FoamYade.C:437-453)
+      uSource                  the cell field equals -sum_p F_p / (V rho_f) accumulated independently (momentum exchanged exactly)
+      PISO                     the continuity error of the corrected flux is at solver tolerance with an inlet and a fixed-pressure outlet"""
+    nx, ny, nz, dx, nu, rho_f = 200, 100, 50, 0.01, 1e-3, 1000.0
+    U_, ZG = product.FY_BC_U_FIXED_VALUE, product.FY_BC_U_ZERO_GRADIENT
+    PZ, PF = product.FY_BC_P_ZERO_GRADIENT, product.FY_BC_P_FIXED_VALUE
+    case = product.make_case(product.FY_SOLVER_ICO, nx, ny, nz, dx, 2e-3, nu, rho_f=rho_f, rho_p=2650.0, g=(0.0, 0.0, 0.0),
+                             u_bc=[U_, ZG, U_, U_, U_, U_], u_val=[(1, 0, 0)] + [(0, 0, 0)] * 5, p_bc=[PZ, PF, PZ, PZ, PZ, PZ], n_correctors=2, p_solver=1)
+    npart = 1_000_000
+    rs = np.random.Generator(np.random.PCG64(2))
+    rec = np.zeros((npart, 10))
+    rec[:, 0:3] = rs.random((npart, 3)) * np.array([2.0, 1.0, 0.5])
+    rec[:2000, 0] += 2.0                                            # a few outside the box: not found, zero force
+    rec[:, 3:6] = rs.normal(0.0, 0.1, (npart, 3))
+    rec[:, 6:9] = rs.normal(0.0, 0.1, (npart, 3))
+    rec[:, 9] = 0.15 * dx
+    s = product.Solver(case)
+    s.hold_sources(True)                                            # keep this step's uSource readable after the step
+    Nc = nx * ny * nz
+    for step in range(3):
+        Ub = s.get("U").reshape(Nc, 3)                              # what the coupling call of this step reads (the solve comes after it)
+        s.set_particles(rec)
+        s.step()
+    F, found = s.forces(), s.found()
+    inside = (rec[:, 0] >= 0) & (rec[:, 0] <= 2.0) & (rec[:, 1] >= 0) & (rec[:, 1] <= 1.0) & (rec[:, 2] >= 0) & (rec[:, 2] <= 0.5)
+    assert np.array_equal(found == 1, inside) and inside.sum() == npart - 2000
+    cell = (np.minimum((rec[:, 0] / dx).astype(np.int64), nx - 1) + nx * (np.minimum((rec[:, 1] / dx).astype(np.int64), ny - 1)
+            + ny * np.minimum((rec[:, 2] / dx).astype(np.int64), nz - 1)))
+    d = 2 * rec[:, 9]
+    Fref = (3 * np.pi * d * nu * rho_f)[:, None] * (Ub[np.where(inside, cell, 0)] - rec[:, 3:6])
+    Fref[~inside] = 0.0
+    np.testing.assert_allclose(F[:, :3], Fref, rtol=1e-12, atol=1e-14 * np.abs(Fref).max())
+    G = s.get("vGrad").reshape(Nc, 9)[np.where(inside, cell, 0)]     # grad(U) of the step's start, row-major xx xy xz yx ...
+    wf = np.stack([G[:, 7] - G[:, 5], G[:, 6] - G[:, 2], G[:, 3] - G[:, 1]], axis=1)
+    Tref = (np.pi * d ** 3 * nu * rho_f)[:, None] * (wf - rec[:, 6:9])
+    Tref[~inside] = 0.0
+    np.testing.assert_allclose(F[:, 3:], Tref, rtol=1e-11, atol=1e-13 * np.abs(Tref).max())
+    assert np.abs(F[inside, :3]).max() > 0
+    uS = s.get("uSource").reshape(Nc, 3)
+    V = dx ** 3
+    for a in range(3):
+        ref = -np.bincount(cell[inside], weights=Fref[inside, a], minlength=Nc) / (V * rho_f)
+        np.testing.assert_allclose(uS[:, a], ref, rtol=1e-10, atol=1e-12 * np.abs(ref).max())
+    st = s.stats()
+    assert abs(st["cont_err_global"]) < 1e-8 and st["cont_err_sum_local"] < 1e-5 and st["courant_max"] < 1.0
+    U = s.get("U").reshape(nz, ny, nx, 3)
+    assert 0.5 < U[nz // 2, ny // 2, 2, 0] <= 1.5                    # the inlet drives the channel
+    s.close()

@@ -233,3 +233,65 @@ def test_linear_upwind_is_second_order_and_exact_on_a_linear_field(oracle):
         err[scheme] = np.abs(np.interp(GHIA_Y, yc, uc) - GHIA_U).max()
         s.close()
     assert err[2] < 0.02 and abs(err[2] - err[0]) < 0.01, err
+
+
+def test_adjustable_time_step_follows_setDeltaT(oracle):
+    """readTimeControls.H / CourantNo.H / setDeltaT.H at the top of pimpleFoamYade's loop (pimpleFoamYade.C:62-64): every step's deltaT is
+    min(min(maxCo / Co, 1 + 0.1 maxCo / Co, 1.2) deltaT_old, maxDeltaT) with Co the Courant number of the current flux at the OLD deltaT;
+    the run then settles at the requested maximum Courant number"""
+    n, max_co, max_dt = 16, 0.3, 0.2
+    dx = 1.0 / n
+    u_bc = [orc.U_FIXED] * 4 + [orc.U_ZEROGRAD] * 2
+    u_val = [(0, 0, 0)] * 6
+    u_val[orc.YMAX] = (1.0, 0, 0)
+    case = orc.fv_case(1, n, n, 1, dx, 1e-3, 0.01, u_bc=u_bc, u_val=u_val, adjust_time_step=1, max_co=max_co, max_delta_t=max_dt)
+    s = orc.FvSolver(case)
+    dt, seq = 1e-3, []
+    for step in range(60):
+        s.step()
+        st = s.stats()
+        co_at_old_dt = st["courant_max"]
+        f = max_co / (co_at_old_dt + 1e-15)
+        expect = min(min(min(f, 1.0 + 0.1 * f), 1.2) * dt, max_dt)
+        assert st["delta_t"] == pytest.approx(expect, rel=1e-14)
+        dt = st["delta_t"]
+        seq.append(dt)
+    assert seq[0] == pytest.approx(1.2e-3) and seq[5] > 2e-3                    # at rest the factor is the 1.2 cap
+    co_now = st["courant_max"] / seq[-2] * seq[-1] if len(seq) > 1 else 0.0    # the flux barely changes between the last two steps
+    assert 0.8 * max_co < co_now < 1.2 * max_co, co_now
+    # a fixed-deltaT case reports its deltaT unchanged
+    s2 = orc.FvSolver(cavity_case(1, n))
+    s2.step()
+    assert s2.stats()["delta_t"] == pytest.approx(0.4 * dx)
+    s.close(); s2.close()
+
+
+def test_relaxation_factors_change_the_iteration_not_the_converged_step(oracle):
+    """UcEqn.relax() (UcEqn.H:12) and p.relax() (pEqn.H:41) with factors < 1 slow the PIMPLE outer iteration down; its limit moves only by
+    the PISO splitting error of the two inner correctors (the relaxed diagonal weights the inner iterates differently): with many outer
+    correctors the relaxed and the unrelaxed step agree to that level, with two they are far apart; the *Final factors act on the last outer
+    corrector only; u_relax = 0 (no relaxationFactors entry) equals u_relax = 1 on a diagonally dominant matrix"""
+    n = 12
+
+    def run(n_outer, **kw):
+        dx = 1.0 / n
+        u_val = [(0, 0, 0)] * 6
+        u_val[orc.YMAX] = (1.0, 0, 0)
+        s = orc.FvSolver(orc.fv_case(1, n, n, n, dx, 0.5 * dx, 0.01, u_val=u_val, n_outer=n_outer, p_tol=1e-10, p_rel_tol=0.0, p_final_tol=1e-10,
+                                     u_tol=1e-10, **kw))
+        s.step()
+        U, p = s.get("U"), s.get("p")
+        s.close()
+        return U, p
+
+    relaxed = dict(u_relax=0.6, u_relax_final=1.0, p_relax=0.3, p_relax_final=1.0)
+    U2, p2 = run(2)
+    U2r, p2r = run(2, **relaxed)
+    U20, p20 = run(30)
+    U20r, p20r = run(30, **relaxed)
+    sc = np.abs(U20).max()
+    assert np.abs(U2r - U2).max() > 1e-3 * sc                                   # relaxation is really applied ...
+    assert np.abs(U20r - U20).max() < 0.25 * np.abs(U2r - U2).max() and np.abs(U20r - U20).max() < 2e-3 * sc     # ... and the converged step stays put
+    assert np.abs(p20r - p20).max() < 0.25 * np.abs(p2r - p2).max() + 1e-6 * np.abs(p20).max()
+    U0, p0 = run(2, u_relax=0.0)
+    np.testing.assert_allclose(U0, U2, rtol=0, atol=1e-12 * sc)

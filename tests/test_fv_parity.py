@@ -231,3 +231,46 @@ def test_corrector_counts_match_oracle(product, oracle, solver, n_outer, n_corr,
         so, ss = o.stats(), s.stats()
         assert so["p_solves"] == ss["p_solves"] == n_outer * n_corr * (n_non_orth + 1)
     compare(o, s, rtol=1e-5)
+
+
+def test_adjustable_time_step_and_relaxation_match_oracle(product, oracle):
+    """pimpleFoamYade with controlDict adjustTimeStep (readTimeControls.H / setDeltaT.H, pimpleFoamYade.C:62-64) and fvSolution
+    relaxationFactors for UcEqn.relax() / p.relax() (UcEqn.H:12, pEqn.H:41), three outer correctors: same deltaT sequence, same fields"""
+    n = 14
+    kw = dict(n_outer=3, adjust_time_step=1, max_co=0.35, max_delta_t=0.1, u_relax=0.7, u_relax_final=1.0, p_relax=0.3, p_relax_final=1.0)
+    o, s = both(product, oracle, 1, n, n, n, 1.0 / n, 2e-3, 0.01, **kw, **cavity_bcs())
+    dts = []
+    for step in range(25):
+        o.step(); s.step()
+        so, ss = o.stats(), s.stats()
+        assert np.isclose(so["delta_t"], ss["delta_t"], rtol=1e-7), (step, so["delta_t"], ss["delta_t"])
+        dts.append(ss["delta_t"])
+    assert dts[0] == pytest.approx(2.4e-3) and max(dts) > 5 * dts[0]          # the step grows from rest until the Courant limit binds
+    assert 0.2 < ss["courant_max"] * dts[-1] / dts[-2] < 0.45
+    compare(o, s, rtol=1e-5)
+    # relaxation really took part: the same run without it ends elsewhere
+    o2, s2 = both(product, oracle, 1, n, n, n, 1.0 / n, 2e-3, 0.01, n_outer=3, adjust_time_step=1, max_co=0.35, max_delta_t=0.1, **cavity_bcs())
+    for step in range(25):
+        s2.step()
+    assert np.abs(s2.get("p") - s.get("p")).max() > 1e-4 * np.abs(s.get("p")).max()
+    for x in (o, s, o2, s2):
+        x.close()
+
+
+def test_cases_where_adjustPhi_would_act_are_refused(product):
+    """adjustPhi (icoFoamYade.C:108, pEqn.H:13-16) rescales the outflow when no patch fixes the pressure; this library implements it only
+    where it is the identity and refuses the rest by name instead of solving an inconsistent pressure equation"""
+    U, ZG = product.FY_BC_U_FIXED_VALUE, product.FY_BC_U_ZERO_GRADIENT
+    PZ = product.FY_BC_P_ZERO_GRADIENT
+    inflow = [(1, 0, 0)] + [(0, 0, 0)] * 5
+    with pytest.raises(product.FoamYadeError) as e:           # inlet, free outlet, pressure fixed nowhere: adjustPhi scales the outflow
+        product.Solver(product.make_case(product.FY_SOLVER_ICO, 8, 8, 8, 0.1, 0.01, 0.01, u_bc=[U, ZG, U, U, U, U], u_val=inflow, p_bc=[PZ] * 6))
+    assert "adjustPhi" in str(e.value)
+    with pytest.raises(product.FoamYadeError) as e:           # inflow through fixed-value patches that nothing can balance: fatal in OpenFOAM too
+        product.Solver(product.make_case(product.FY_SOLVER_PIMPLE, 8, 8, 8, 0.1, 0.01, 0.01, u_bc=[U] * 6, u_val=inflow, p_bc=[PZ] * 6))
+    assert "do not balance" in str(e.value)
+    through = [(1, 0, 0), (1, 0, 0)] + [(0, 0, 0)] * 4        # what goes in comes out through fixed-value patches: adjustPhi is the identity
+    s = product.Solver(product.make_case(product.FY_SOLVER_ICO, 8, 8, 8, 0.1, 0.01, 0.01, u_bc=[U] * 6, u_val=through, p_bc=[PZ] * 6))
+    s.step()
+    assert abs(s.stats()["cont_err_global"]) < 1e-10
+    s.close()

@@ -89,7 +89,9 @@ class CaseDesc(C.Structure):
                 ("momentum_predictor", C.c_int32), ("p_ref_cell", C.c_int32), ("p_ref_value", C.c_double),
                 ("p_solver", C.c_int32), ("p_tol", C.c_double), ("p_rel_tol", C.c_double), ("p_final_tol", C.c_double),
                 ("p_final_rel_tol", C.c_double), ("p_max_iter", C.c_int32),
-                ("u_tol", C.c_double), ("u_rel_tol", C.c_double), ("u_max_iter", C.c_int32), ("convection_scheme", C.c_int32)]
+                ("u_tol", C.c_double), ("u_rel_tol", C.c_double), ("u_max_iter", C.c_int32), ("convection_scheme", C.c_int32),
+                ("adjust_time_step", C.c_int32), ("max_co", C.c_double), ("max_delta_t", C.c_double),
+                ("u_relax", C.c_double), ("u_relax_final", C.c_double), ("p_relax", C.c_double), ("p_relax_final", C.c_double)]
 
 
 class FoamCaseInfo(C.Structure):
@@ -104,7 +106,7 @@ class StepStats(C.Structure):
                 ("p_iters_total", C.c_int32), ("p_solves", C.c_int32), ("u_iters_total", C.c_int32),
                 ("p_initial_residual", C.c_double), ("p_final_residual", C.c_double),
                 ("ms_particle", C.c_double), ("ms_momentum", C.c_double), ("ms_pressure", C.c_double),
-                ("ms_other", C.c_double), ("ms_total", C.c_double)]
+                ("ms_other", C.c_double), ("ms_total", C.c_double), ("delta_t", C.c_double)]
 
 
 _lib = None

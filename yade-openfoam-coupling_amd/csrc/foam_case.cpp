@@ -261,8 +261,17 @@ int read_controls(fy_foam_case* c) {
         if (wc == "timeStep") c->write_interval_steps = (int)wi;
         else if (wc == "runTime" || wc == "adjustableRunTime") c->write_interval_steps = (int)std::llround(wi / c->desc.dt);
         else return fail(FY_ERR_UNSUPPORTED, "%s: writeControl %s is not supported", path.c_str(), wc.c_str());
+        // readTimeControls.H [OF-6]: adjustTimeStep (default no), maxCo (default 1), maxDeltaT (default great).  Only pimpleFoamYade
+        // includes setDeltaT.H (pimpleFoamYade.C:62-64); icoFoamYade's loop (icoFoamYade.C:65-70) never reads the switch, so there it is
+        // ignored exactly as the reference ignores it
         bool adj = false;
-        if (d.boolean("adjustTimeStep", &adj) && adj) return fail(FY_ERR_UNSUPPORTED, "%s: adjustTimeStep is not supported (the reference solvers run at fixed deltaT)", path.c_str());
+        if (d.boolean("adjustTimeStep", &adj) && adj && c->solver == FY_SOLVER_PIMPLE) {
+            if (wc != "timeStep") return fail(FY_ERR_UNSUPPORTED, "%s: adjustTimeStep with writeControl %s (output times that cut the time step) is not supported; use writeControl timeStep", path.c_str(), wc.c_str());
+            c->desc.adjust_time_step = 1;
+            c->desc.max_co = 1.0; c->desc.max_delta_t = 1e300;
+            d.scalar("maxCo", &c->desc.max_co);
+            d.scalar("maxDeltaT", &c->desc.max_delta_t);
+        }
     }
     {
         const std::string path = join(c->dir, "constant/transportProperties");
@@ -359,6 +368,30 @@ int read_controls(fy_foam_case* c) {
             for (const std::string& k : sv->order)
                 if (k.find(c->u_name) != std::string::npos || (k.find("U") != std::string::npos && k.find("Final") == std::string::npos)) { us = sv->subdict(k); if (us) break; }
         if (us) { us->scalar("tolerance", &c->desc.u_tol); us->scalar("relTol", &c->desc.u_rel_tol); us->integer("maxIter", &c->desc.u_max_iter); }
+        // relaxationFactors: equations { <U>; <U>Final; ".*" } for UcEqn.relax() (UcEqn.H:12), fields { p; pFinal } for p.relax() (pEqn.H:41).
+        // No entry = the call does nothing [OF-6 fvMatrix::relax(), GeometricField::relax()]; icoFoamYade relaxes nothing.
+        c->desc.u_relax = c->desc.u_relax_final = c->desc.p_relax = c->desc.p_relax_final = 0.0;
+        if (const FoamDict* rf = d.subdict("relaxationFactors")) {
+            if (c->solver == FY_SOLVER_PIMPLE) {
+                auto lookup = [&](const FoamDict* sd, const std::string& name, double* out) {
+                    if (!sd) return;
+                    double v = 0;
+                    if (sd->scalar(name, &v) || sd->scalar("\"" + name + "\"", &v)) { *out = v; return; }
+                    for (const std::string& k : sd->order) {            // the catch-all patterns the tutorials use
+                        const bool any = k == "\".*\"" || k == ".*" || k == "\"(.*)\"";
+                        const bool fin = k == "\".*Final\"" || k == "\"(.*)Final\"";
+                        const bool is_final = name.size() > 5 && name.compare(name.size() - 5, 5, "Final") == 0;
+                        if ((fin && is_final) || (any && sd->scalar(k, &v))) { if (sd->scalar(k, &v)) *out = v; }
+                    }
+                };
+                lookup(rf->subdict("equations"), c->u_name, &c->desc.u_relax);
+                lookup(rf->subdict("equations"), c->u_name + "Final", &c->desc.u_relax_final);
+                lookup(rf->subdict("fields"), "p", &c->desc.p_relax);
+                lookup(rf->subdict("fields"), "pFinal", &c->desc.p_relax_final);
+                for (double v : {c->desc.u_relax, c->desc.u_relax_final, c->desc.p_relax, c->desc.p_relax_final})
+                    if (v > 1.0) return fail(FY_ERR_INVALID, "%s: relaxationFactors above 1", path.c_str());
+            }
+        }
     }
     return FY_OK;
 }

@@ -485,9 +485,13 @@ __global__ __launch_bounds__(256) void k_assemble_momentum(FvGeo g, const double
         for (int q = 0; q < 3; ++q) s3[q] += V * divG[3 * (size_t)c + q];
         double so = 0.0;
         for (int q = 0; q < 6; ++q) so += fabs(an[q]);
-        const double dn = fmax(fabs(dg), so);                 // fvMatrix::relax(1): diagonal dominance
-        for (int q = 0; q < 3; ++q) s3[q] += (dn - dg) * U[3 * (size_t)c + q];
-        dg = dn;
+        if (g.u_relax > 0) {
+            // fvMatrix::relax(alpha) [OF-6 fvMatrix.C]: D = max(|D|, sum|offdiag|) / alpha (the boundary coefficients, part of dg here all
+            // along, take part in the dominance test), source += (D_new - D_old) psi; no factor for the equation: relax() does nothing
+            const double dn = fmax(fabs(dg), so) / g.u_relax;
+            for (int q = 0; q < 3; ++q) s3[q] += (dn - dg) * U[3 * (size_t)c + q];
+            dg = dn;
+        }
     } else {
         for (int q = 0; q < 3; ++q) s3[q] += V * uSource[3 * (size_t)c + q];
     }
@@ -1103,6 +1107,12 @@ __global__ __launch_bounds__(1024) void k_mg_coarse_solve(PMat A, const double* 
     if (cur != x) { if (act) x[c] = cur[c]; }
 }
 
+// GeometricField::relax(alpha), pEqn.H:41: p = prevIter + alpha (p - prevIter)
+__global__ __launch_bounds__(256) void k_relax_field(double* __restrict__ x, const double* __restrict__ prev, double alpha, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) x[i] = prev[i] + alpha * (x[i] - prev[i]);
+}
+
 __global__ __launch_bounds__(256) void k_copy(double* __restrict__ dst, const double* __restrict__ src, size_t n) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) dst[i] = src[i];
@@ -1350,6 +1360,13 @@ int launch_mg_coarse_solve(hipStream_t s, PMat A, const double* b, double* x, do
     if (A.c0 != 0) return fail(FY_ERR_INVALID, "the coarsest multigrid level must be replicated (no ghost planes)");
     if (A.N > 1024) return fail(FY_ERR_INVALID, "coarsest multigrid level too large (%d cells)", A.N);
     hipLaunchKernelGGL(k_mg_coarse_solve, dim3(1), dim3(1024), 0, s, A, b, x, tmp, sweeps, w);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+
+int launch_relax_field(hipStream_t s, double* x, const double* prev, double alpha, size_t n) {
+    if (n == 0) return FY_OK;
+    hipLaunchKernelGGL(k_relax_field, dim3(div_up(n, 256)), dim3(256), 0, s, x, prev, alpha, n);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }

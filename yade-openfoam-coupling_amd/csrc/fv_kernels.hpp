@@ -26,6 +26,7 @@ struct FvGeo {
     int pimple;
     int upwind;             // div(phi,U): 0 Gauss linear, 1 Gauss upwind (first order, bounded), 2 Gauss linearUpwind (upwind + explicit gradient correction)
     double dt, nu;
+    double u_relax;         // fvMatrix::relax factor of UcEqn for the current outer iteration (<= 0: no relaxationFactors entry, relax() is a no-op)
     double g[3];
     int need_ref, p_ref_cell;
     double p_ref_value;
@@ -110,6 +111,7 @@ constexpr int kMgTailCells = 1024;   // measured: at 8000 cells one workgroup (1
 int launch_mg_tail(hipStream_t s, const PMat* A, double* const* x0, double* const* x1, double* const* b, int n, double w, int coarse_sweeps);
 
 int launch_copy_f64(hipStream_t s, double* dst, const double* src, size_t n);
+int launch_relax_field(hipStream_t s, double* x, const double* prev, double alpha, size_t n);   // x = prev + alpha (x - prev)
 // slab interfaces: coefficient of the z-face below the first owned plane, stored at the ghost cell under it (what p_row reads as uz[c - sz])
 int launch_p_ghost_uz(hipStream_t s, FvGeo g, CFace3 rAUf, CFace3 alphaf, PMat A);
 int launch_mg_coarsen_ghost(hipStream_t s, PMat F, PMat C);

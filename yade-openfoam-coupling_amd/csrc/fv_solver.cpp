@@ -61,6 +61,8 @@ struct Solver {
     size_t mg_rep = 0;            // first replicated level (== mg.size() when nothing is replicated)
     DevBuf<double> rep_stage;     // local slice of the first replicated level before the all-gather (rhs / operator arrays)
     DevBuf<double> prhs, pr, pw, pp, pzj;
+    DevBuf<double> pPrev;        // p.prevIter() (only with a field relaxation factor for p)
+    double p_relax_now = 0.0;
     DevBuf<double> partials, red_out, sc, xbar3;
     bool hold_sources = false, sources_pending = false;
     bool overlap_halos = true;            // FOAMYADE_NO_HALO_OVERLAP=1: serial schedule (A/B switch, same results)
@@ -152,6 +154,27 @@ struct Solver {
         }
         for (int a = 0; a < 3; ++a) g.g[a] = c->g[a];
         g.need_ref = need_ref ? 1 : 0; g.p_ref_cell = c->p_ref_cell; g.p_ref_value = c->p_ref_value;
+        g.u_relax = c->u_relax;
+        if (c->adjust_time_step && !(c->max_co > 0 && c->max_delta_t > 0)) return fail(FY_ERR_INVALID, "adjustTimeStep needs maxCo > 0 and maxDeltaT > 0");
+        if (c->u_relax > 1 || c->u_relax_final > 1 || c->p_relax > 1 || c->p_relax_final > 1) return fail(FY_ERR_INVALID, "relaxation factors lie in (0, 1]");
+        if (need_ref) {
+            // adjustPhi (icoFoamYade.C:108, pEqn.H:13-16) acts when no patch fixes the pressure: it scales the outflow through the patches
+            // that do not fix U so that it balances the inflow, and is fatal when the fixed-value patches alone do not balance.  This
+            // library implements it only where it is the identity -- no adjustable patch, fixed-value patches with zero net flux (closed
+            // boxes, cavities) -- and says so for anything else instead of solving an inconsistent pressure equation.
+            double net = 0.0, mag = 0.0;
+            const double area[3] = {(double)c->ny * c->nz, (double)c->nx * c->nz, (double)c->nx * c->ny};
+            for (int q = 0; q < 6; ++q) {
+                if (c->u_bc[q] != FY_BC_U_FIXED_VALUE)
+                    return fail(FY_ERR_UNSUPPORTED, "no patch fixes the pressure and patch %d lets U float: adjustPhi (icoFoamYade.C:108, pEqn.H:13-16) would rescale its outflow, "
+                                                    "which this library does not implement; give the outlet a fixedValue pressure", q);
+                const double un = c->u_value[q][q / 2] * ((q & 1) ? 1.0 : -1.0) * area[q / 2];
+                net += un; mag += std::fabs(un);
+            }
+            if (std::fabs(net) > 1e-8 * (mag + 1e-300))
+                return fail(FY_ERR_UNSUPPORTED, "no patch fixes the pressure and the fixed-value velocity patches do not balance (net flux %g of %g): OpenFOAM's adjustPhi "
+                                                "ends such a run with 'Continuity error cannot be removed by adjusting the outflow'", net, mag);
+        }
         if (c->p_ref_cell < 0 || c->p_ref_cell >= Nglob) return fail(FY_ERR_INVALID, "pRefCell out of range");
 
         const size_t n = nstore;
@@ -542,6 +565,9 @@ struct Solver {
                 FY_TRY(halo_cells(p, 1, 1));
                 FY_TRY(launch_flux_correct(stream, g, p.p, C3(phiHbyA), C3(rAUf), C3(alphaf), C3(psn), F3(pflux), F3(phi)));
                 phi_fresh = true;
+                // p.relax() (pEqn.H:41): after the flux, which keeps the unrelaxed solution; the velocity correction below works with
+                // pEqn.flux() (pflux), not with grad(p), so only the carried pressure field is relaxed
+                if (pimple && p_relax_now > 0 && p_relax_now < 1) FY_TRY(launch_relax_field(stream, p.p, pPrev.p, p_relax_now, nstore));
             }
         }
         clk_pres.end(stream);
@@ -573,11 +599,20 @@ struct Solver {
         double h[2];
         FY_TRY(launch_courant(stream, g, C3(phi), partials.p));                               // icoFoamYade.C:68, pimpleFoamYade.C:63
         n_deferred = 0; cont_slots.clear(); courant_slot = -1;
-        {
+        if (cs.adjust_time_step) {
+            // readTimeControls.H + CourantNo.H + setDeltaT.H (pimpleFoamYade.C:62-64) [OF-6 setDeltaT.H]: the step's deltaT follows from the
+            // Courant number of the current flux at the OLD deltaT, so the host needs that number now
+            FY_TRY(reduce_read(2, true, h)); note_courant(h);
+            const double maxDeltaTFact = cs.max_co / (st.courant_max + 1e-15);
+            const double deltaTFact = std::min(std::min(maxDeltaTFact, 1.0 + 0.1 * maxDeltaTFact), 1.2);
+            cs.dt = std::min(deltaTFact * cs.dt, cs.max_delta_t);
+            g.dt = cs.dt;
+        } else {
             int slot = 0, rc = FY_OK;
             if (reduce_deferred(2, true, &slot, &rc)) { FY_TRY(rc); courant_slot = slot; }
             else { FY_TRY(reduce_read(2, true, h)); note_courant(h); }
         }
+        st.delta_t = cs.dt;
         // runTime++ : store old-time fields (whole storage, ghost planes included)
         comm->group_begin();                    // one exchange: U goes with the full particle-halo width straight away
         FY_TRY(halo_cells(U, 3, g.gz > 1 ? g.gz : 1));
@@ -619,6 +654,15 @@ struct Solver {
         if (pimple) FY_TRY(launch_interp_alpha(stream, g, alpha.p, F3(alphaf)));              // pimpleFoamYade.C:83-85 (alpha ghosts refreshed by the coupling)
         const int nOuter = pimple ? std::max(cs.n_outer_correctors, 1) : 1;
         for (int outer = 0; outer < nOuter; ++outer) {
+            // pimple.loop() marks the last outer corrector "finalIteration": relax() then prefers the <name>Final factors [OF-6], and
+            // stores p.prevIter() at the start of every outer iteration when p carries a relaxation factor (storePrevIterFields)
+            const bool final_outer = outer == nOuter - 1;
+            g.u_relax = (final_outer && cs.u_relax_final > 0) ? cs.u_relax_final : cs.u_relax;
+            p_relax_now = (final_outer && cs.p_relax_final > 0) ? cs.p_relax_final : cs.p_relax;
+            if (pimple && p_relax_now > 0 && p_relax_now < 1) {
+                if (!pPrev.p) FY_TRY(pPrev.alloc_exact(nstore));
+                FY_TRY(launch_copy_f64(stream, pPrev.p, p.p, nstore));
+            }
             clk_mom.begin(stream);
             if (pimple) {
                 // explicit stress term of divDevRhoReff from the CURRENT U and this step's alpha (one fused stencil pass)
@@ -700,6 +744,8 @@ void fy_case_defaults(fy_case_desc* c, int solver) {
     c->p_solver = FY_PSOLVER_PCG_MG;
     c->p_tol = 1e-6; c->p_rel_tol = 0.05; c->p_final_tol = 1e-6; c->p_final_rel_tol = 0.0; c->p_max_iter = 1000;
     c->u_tol = 1e-5; c->u_rel_tol = 0.0; c->u_max_iter = 1000;
+    c->adjust_time_step = 0; c->max_co = 1.0; c->max_delta_t = 1e300;
+    c->u_relax = 1.0; c->u_relax_final = 0.0; c->p_relax = 0.0; c->p_relax_final = 0.0;
 }
 
 static int solver_create_impl(const fy_case_desc* c, const fy_transport* tr, int device_ordinal, fy::Comm* cm, fy_solver** out) {
