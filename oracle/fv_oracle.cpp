@@ -439,6 +439,7 @@ struct Fv {
     }
 
     // phiHbyA = fvc::flux(HbyA) + [alphacf*]rAUf*fvc::ddtCorr(U, phi) [+ phicForces]   (icoFoamYade.C:101-106, pEqn.H:4-18)
+    bool adjust_phi_failed = false;
     void compute_phiHbyA() {
         flux_of(HbyA, phiHbyA);
         const double rDt = 1.0 / cs.dt;
@@ -459,7 +460,43 @@ struct Fv {
                 phiHbyA[d][f] += add;
                 if (pimple) phiHbyA[d][f] += phiForces[d][f];
             }
-        // adjustPhi(phiHbyA, U, p): only the closed-domain / fixed-pressure-outlet cases are supported, where it is a no-op.
+        // adjustPhi(phiHbyA, U, p) (icoFoamYade.C:108, pEqn.H:13-16) [OF-6 adjustPhi.C]: with no fixed-value pressure patch the outflow through
+        // the patches that do not fix U is scaled to balance the inflow.  pimpleFoamYade applies it before phicForces are added.
+        bool need_ref = true;
+        for (int q = 0; q < 6; ++q) if (cs.p_bc[q] == 1) need_ref = false;
+        if (need_ref) {
+            double massIn = 0, fixedOut = 0, adjOut = 0, total = VSMALL;
+            for (int d = 0; d < 3; ++d)
+                for (int k = 0; k < nz + (d == 2); ++k) for (int j = 0; j < ny + (d == 1); ++j) for (int i = 0; i < nx + (d == 0); ++i) {
+                    const int q = d == 0 ? i : d == 1 ? j : k;
+                    const int f = fid(d, i, j, k);
+                    const double fl = phiHbyA[d][f] - (pimple ? phiForces[d][f] : 0.0);
+                    if (q == 0 || q == n[d]) {
+                        const int s = q == 0 ? 0 : 1;
+                        const double outw = s ? fl : -fl;
+                        if (outw < 0.0) massIn -= outw;
+                        else if (cs.u_bc[2 * d + s] == 0) fixedOut += outw;
+                        else adjOut += outw;
+                    } else total += std::fabs(fl);
+                }
+            double massCorr = 1.0;
+            if (std::fabs(adjOut) > VSMALL && std::fabs(adjOut) / total > SMALL) massCorr = (massIn - fixedOut) / adjOut;
+            else if (std::fabs(fixedOut - massIn) / total > 1e-8) adjust_phi_failed = true;
+            if (massCorr != 1.0)
+                for (int d = 0; d < 3; ++d) for (int s = 0; s < 2; ++s) {
+                    if (cs.u_bc[2 * d + s] == 0) continue;
+                    const int q = s ? n[d] : 0;
+                    const int e1 = d == 0 ? ny : nx, e2 = d == 2 ? ny : nz;
+                    for (int b2 = 0; b2 < e2; ++b2) for (int b1 = 0; b1 < e1; ++b1) {
+                        int i, j, k;
+                        if (d == 0) { i = q; j = b1; k = b2; } else if (d == 1) { i = b1; j = q; k = b2; } else { i = b1; j = b2; k = q; }
+                        const int f = fid(d, i, j, k);
+                        const double pf = pimple ? phiForces[d][f] : 0.0;
+                        const double fl = phiHbyA[d][f] - pf;
+                        if ((s ? fl : -fl) > 0.0) phiHbyA[d][f] = fl * massCorr + pf;
+                    }
+                }
+        }
         // constrainPressure for fixedFluxPressure patches: snGrad(p) = (phiHbyA - (Sf & U_b)) / (magSf * rAUf), so that the
         // corrected boundary flux phiHbyA - rAUf |Sf| snGrad(p) equals Sf & U_b.
         for (int d = 0; d < 3; ++d) for (int s = 0; s < 2; ++s) {

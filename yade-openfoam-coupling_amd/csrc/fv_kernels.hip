@@ -277,6 +277,74 @@ __global__ __launch_bounds__(256) void k_phiHbyA_cells(FvGeo g, const double* __
 #undef FY_CALL
 }
 
+// ---- adjustPhi(phiHbyA, U, p) (icoFoamYade.C:108, pEqn.H:13-16) [OF-6 cfdTools/general/adjustPhi/adjustPhi.C].  Acts when no patch
+// fixes the pressure: the outflow through the patches that do not fix U is scaled by massCorr = (massIn - fixedMassOut) / adjustableMassOut
+// so that the pressure equation is solvable.  In pimpleFoamYade it is applied BEFORE phicForces are added (pEqn.H:13-18); phiHbyA here
+// already carries them, so the flux it works on is phiHbyA - phicForces.  slots: 0 massIn, 1 fixedMassOut, 2 adjustableMassOut,
+// 3 sum |flux| over the internal faces (the normalisation of the two tests)
+template <int D>
+__device__ __forceinline__ void adjust_phi_face(const FvGeo& g, size_t f, int i, int j, int k, const double* __restrict__ phiHbyA,
+                                                const double* __restrict__ phiForces, double* v) {
+    const int q = D == 0 ? i : D == 1 ? j : k;
+    const double fl = phiHbyA[f] - (g.pimple ? phiForces[f] : 0.0);
+    const bool lo = face_low_b(g, D, q), hi = face_high_b(g, D, q);
+    if (lo || hi) {
+        const double outw = lo ? -fl : fl;
+        const bool fixes = g.u_bc[2 * D + (hi ? 1 : 0)] == 0;
+        if (outw < 0.0) v[0] -= outw;
+        else if (fixes) v[1] += outw;
+        else v[2] += outw;
+    } else if (!(D == 2 && k == g.nz)) {                    // a slab's top interface face belongs to the slab above (counted there)
+        v[3] += fabs(fl);
+    }
+}
+__global__ __launch_bounds__(256) void k_adjust_phi_sums(FvGeo g, CFace3 phiHbyA, CFace3 phiForces, double* __restrict__ partials) {
+    double v[4] = {0.0, 0.0, 0.0, 0.0};
+    FY_RED_LOOP(t, g.Nc) {
+        int i, j, k; ijk_of(g, t, i, j, k);
+#define FY_CALL(D, fi, fj, fk) { const size_t f = (size_t)fid(g, D, fi, fj, fk); adjust_phi_face<D>(g, f, fi, fj, fk, phiHbyA.a[D], phiForces.a[D], v); }
+        FY_CELL_FACES(g, i, j, k, FY_CALL);
+#undef FY_CALL
+    }
+    const int mx[4] = {0, 0, 0, 0};
+    block_reduce_store<4>(v, mx, partials);
+}
+// one thread per boundary face of the block (both sides of the three directions); err: set when OpenFOAM would stop with
+// "Continuity error cannot be removed by adjusting the outflow"
+__global__ __launch_bounds__(256) void k_adjust_phi_apply(FvGeo g, const double* __restrict__ sums, Face3 phiHbyA, CFace3 phiForces, CFace3 rAUf,
+                                                          const double* __restrict__ U, Face3 psn, int* __restrict__ err) {
+    const double massIn = sums[0], fixedOut = sums[1], adjOut = sums[2], total = 1e-300 + sums[3];
+    double massCorr = 1.0;
+    if (fabs(adjOut) > 1e-300 && fabs(adjOut) / total > kSmall) massCorr = (massIn - fixedOut) / adjOut;
+    else if (fabs(fixedOut - massIn) / total > 1e-8) { if (blockIdx.x == 0 && threadIdx.x == 0) *err = 1; return; }
+    if (massCorr == 1.0) return;
+    const int nb[3] = {g.ny * g.nz, g.nx * g.nz, g.nx * g.ny};
+    int t = blockIdx.x * 256 + threadIdx.x;
+    int d = 0, s = 0;
+    for (; d < 3; ++d) { if (t < 2 * nb[d]) { s = t >= nb[d]; t -= s * nb[d]; break; } t -= 2 * nb[d]; }
+    if (d == 3) return;
+    int i, j, k;
+    if (d == 0) { j = t % g.ny; k = t / g.ny; i = s ? g.nx : 0; }
+    else if (d == 1) { i = t % g.nx; k = t / g.nx; j = s ? g.ny : 0; }
+    else { i = t % g.nx; j = t / g.nx; k = s ? g.nz : 0; }
+    const int q = d == 0 ? i : d == 1 ? j : k;
+    if (!(s ? face_high_b(g, d, q) : face_low_b(g, d, q))) return;        // (a slab's interface plane is not a patch)
+    const int patch = 2 * d + s;
+    if (g.u_bc[patch] == 0) return;                                        // fixes the value: not adjustable
+    const size_t f = (size_t)fid(g, d, i, j, k);
+    const double pf = g.pimple ? phiForces.a[d][f] : 0.0;
+    const double fl = phiHbyA.a[d][f] - pf;
+    const double outw = s ? fl : -fl;
+    if (!(outw > 0.0)) return;
+    const double v = fl * massCorr + pf;
+    phiHbyA.a[d][f] = v;
+    if (g.p_bc[patch] == 2) {                                              // constrainPressure sees the adjusted flux (pEqn.H:21)
+        const int c = cidx(g, i - (d == 0 && s), j - (d == 1 && s), k - (d == 2 && s));
+        double ub[3]; Ub(g, U, c, patch, ub);
+        psn.a[d][f] = (v - ub[d] * g.Af) / (rAUf.a[d][f] * g.Af);
+    }
+}
+
 // pEqn.flux() and phi = phiHbyA - pEqn.flux()[/alphacf]   (icoFoamYade.C:129, pEqn.H:39)
 template <int D>
 __global__ __launch_bounds__(256) void k_flux_correct(FvGeo g, const double* __restrict__ p, const double* __restrict__ phiHbyA,
@@ -1216,6 +1284,19 @@ int launch_HbyA(hipStream_t s, FvGeo g, Mom7 M, const double* src, const double*
 int launch_phiHbyA(hipStream_t s, FvGeo g, const double* HbyA, const double* U, const double* Uold, CFace3 phiOld, CFace3 rAUf,
                    CFace3 alphaf, CFace3 phiForces, Face3 out, Face3 psn) {
     hipLaunchKernelGGL(k_phiHbyA_cells, dim3(div_up(g.Nc, 256)), dim3(256), 0, s, g, HbyA, U, Uold, phiOld, rAUf, alphaf, phiForces, out, psn);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+
+int launch_adjust_phi_sums(hipStream_t s, FvGeo g, CFace3 phiHbyA, CFace3 phiForces, double* partials) {
+    hipLaunchKernelGGL(k_adjust_phi_sums, dim3(red_blocks(g.Nc)), dim3(256), 0, s, g, phiHbyA, phiForces, partials);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+
+int launch_adjust_phi_apply(hipStream_t s, FvGeo g, const double* sums, Face3 phiHbyA, CFace3 phiForces, CFace3 rAUf, const double* U, Face3 psn, int* err) {
+    const size_t nbf = 2 * ((size_t)g.ny * g.nz + (size_t)g.nx * g.nz + (size_t)g.nx * g.ny);
+    hipLaunchKernelGGL(k_adjust_phi_apply, dim3(div_up(nbf, 256)), dim3(256), 0, s, g, sums, phiHbyA, phiForces, rAUf, U, psn, err);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }

@@ -71,6 +71,10 @@ int launch_assemble_momentum(hipStream_t s, FvGeo g, const double* U, const doub
                              const double* vGrad /* grad(U) of the current iterate: linearUpwind only */, Mom7 M, double* src, double* rAU);
 int launch_interp_rAU(hipStream_t s, FvGeo g, const double* rAU, Face3 rAUf);
 // rAUf = interpolate(rAU) and phiForces (UcEqn.H:15-20) as one cell-centred sweep
+// adjustPhi (icoFoamYade.C:108, pEqn.H:13-16): partial sums {massIn, fixedMassOut, adjustableMassOut, sum |internal flux|}; apply scales the
+// outflow of the patches that do not fix U (and refreshes snGrad(p) of fixedFluxPressure patches); *err = 1 where OpenFOAM would stop
+int launch_adjust_phi_sums(hipStream_t s, FvGeo g, CFace3 phiHbyA, CFace3 phiForces, double* partials);
+int launch_adjust_phi_apply(hipStream_t s, FvGeo g, const double* sums, Face3 phiHbyA, CFace3 phiForces, CFace3 rAUf, const double* U, Face3 psn, int* err);
 int launch_rAUf_phi_forces(hipStream_t s, FvGeo g, const double* rAU, const double* uSource, Face3 rf, Face3 out);
 int launch_bmom(hipStream_t s, FvGeo g, const double* src, const double* p, CFace3 psn, CFace3 phiForces, CFace3 rAUf, double* bmom);
 // one fused Jacobi pass: residual sums of x (slots 0..2), norm-factor sums (slots 3..5, uses xbar[3]) and xn = next iterate

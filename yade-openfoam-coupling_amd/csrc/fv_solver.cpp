@@ -63,6 +63,9 @@ struct Solver {
     DevBuf<double> prhs, pr, pw, pp, pzj;
     DevBuf<double> pPrev;        // p.prevIter() (only with a field relaxation factor for p)
     double p_relax_now = 0.0;
+    bool adjust_phi = false;     // adjustPhi can act (no fixed-pressure patch, and a patch that lets U float or prescribed through-flow)
+    DevBuf<double> adj_sums;     // {massIn, fixedMassOut, adjustableMassOut, sum |internal flux|}
+    DevBuf<int> adj_err;
     DevBuf<double> partials, red_out, sc, xbar3;
     bool hold_sources = false, sources_pending = false;
     bool overlap_halos = true;            // FOAMYADE_NO_HALO_OVERLAP=1: serial schedule (A/B switch, same results)
@@ -158,24 +161,22 @@ struct Solver {
         if (c->adjust_time_step && !(c->max_co > 0 && c->max_delta_t > 0)) return fail(FY_ERR_INVALID, "adjustTimeStep needs maxCo > 0 and maxDeltaT > 0");
         if (c->u_relax > 1 || c->u_relax_final > 1 || c->p_relax > 1 || c->p_relax_final > 1) return fail(FY_ERR_INVALID, "relaxation factors lie in (0, 1]");
         if (need_ref) {
-            // adjustPhi (icoFoamYade.C:108, pEqn.H:13-16) acts when no patch fixes the pressure: it scales the outflow through the patches
-            // that do not fix U so that it balances the inflow, and is fatal when the fixed-value patches alone do not balance.  This
-            // library implements it only where it is the identity -- no adjustable patch, fixed-value patches with zero net flux (closed
-            // boxes, cavities) -- and says so for anything else instead of solving an inconsistent pressure equation.
+            // adjustPhi (icoFoamYade.C:108, pEqn.H:13-16) acts when no patch fixes the pressure.  It is the identity when every patch fixes U
+            // and the prescribed normal velocities balance (closed boxes, cavities): nothing is launched then.  With fixed-value patches
+            // that do NOT balance and no patch to adjust, OpenFOAM stops at the first corrector; say so here.
             double net = 0.0, mag = 0.0;
+            bool adjustable = false;
             const double area[3] = {(double)c->ny * c->nz, (double)c->nx * c->nz, (double)c->nx * c->ny};
             for (int q = 0; q < 6; ++q) {
-                if (c->u_bc[q] != FY_BC_U_FIXED_VALUE)
-                    return fail(FY_ERR_UNSUPPORTED, "no patch fixes the pressure and patch %d lets U float: adjustPhi (icoFoamYade.C:108, pEqn.H:13-16) would rescale its outflow, "
-                                                    "which this library does not implement; give the outlet a fixedValue pressure", q);
+                if (c->u_bc[q] != FY_BC_U_FIXED_VALUE) { adjustable = true; continue; }
                 const double un = c->u_value[q][q / 2] * ((q & 1) ? 1.0 : -1.0) * area[q / 2];
                 net += un; mag += std::fabs(un);
             }
-            if (std::fabs(net) > 1e-8 * (mag + 1e-300))
+            if (!adjustable && std::fabs(net) > 1e-8 * (mag + 1e-300))
                 return fail(FY_ERR_UNSUPPORTED, "no patch fixes the pressure and the fixed-value velocity patches do not balance (net flux %g of %g): OpenFOAM's adjustPhi "
                                                 "ends such a run with 'Continuity error cannot be removed by adjusting the outflow'", net, mag);
+            adjust_phi = adjustable || mag > 0.0;
         }
-        if (c->p_ref_cell < 0 || c->p_ref_cell >= Nglob) return fail(FY_ERR_INVALID, "pRefCell out of range");
 
         const size_t n = nstore;
         DevBuf<double>* v3[] = {&U, &Uold, &uSource, &uParticle, &gradP, &divT, &ddtU, &src, &HbyA, &bmom, &divG, &xscr};
@@ -194,6 +195,7 @@ struct Solver {
         FY_TRY(launch_fill_f64(stream, rAU.p, n, 1.0));            // ghost planes must hold finite values before the first exchange
         FY_TRY(partials.alloc_exact(8 * (size_t)red_blocks(Nc))); FY_TRY(red_out.alloc_exact(8)); FY_TRY(sc.alloc_exact(4)); FY_TRY(xbar3.alloc_exact(3));
         FY_TRY(zero(partials)); FY_TRY(zero(sc)); FY_TRY(zero(red_out));
+        if (adjust_phi) { FY_TRY(adj_sums.alloc_exact(4)); FY_TRY(adj_err.alloc_exact(1)); FY_HIP(hipMemsetAsync(adj_err.p, 0, sizeof(int), stream)); }
         if (hipHostMalloc((void**)&red_host, (kDeferBase + kDeferMax) * sizeof(double), hipHostMallocMapped) == hipSuccess) {
             if (hipHostGetDevicePointer((void**)&red_host_dev, red_host, 0) != hipSuccess) { (void)hipHostFree(red_host); red_host = nullptr; }
         } else {
@@ -553,6 +555,12 @@ struct Solver {
         if (!pimple && rAU_new) { FY_TRY(halo_cells(rAU, 1, 1)); FY_TRY(launch_interp_rAU(stream, g, rAU.p, F3(rAUf))); }
         FY_TRY(halo_cells(HbyA, 3, 1));
         FY_TRY(launch_phiHbyA(stream, g, HbyA.p, U.p, Uold.p, C3(phiOld), C3(rAUf), C3(alphaf), C3(phiForces), F3(phiHbyA), F3(psn)));
+        if (adjust_phi) {                                       // icoFoamYade.C:108, pEqn.H:13-16
+            FY_TRY(launch_adjust_phi_sums(stream, g, C3(phiHbyA), C3(phiForces), partials.p));
+            FY_TRY(launch_reduce_finalize(stream, partials.p, Nc, 4, nullptr, adj_sums.p));
+            FY_TRY(comm->allreduce(stream, adj_sums.p, 4, false));
+            FY_TRY(launch_adjust_phi_apply(stream, g, adj_sums.p, F3(phiHbyA), C3(phiForces), C3(rAUf), U.p, F3(psn), adj_err.p));
+        }
         MgLev& L = *mg[0];
         clk_pres.begin(stream);
         for (int no = 0; no <= cs.n_non_orth_correctors; ++no) {
@@ -692,6 +700,12 @@ struct Solver {
         else FY_TRY(cpl->c.set_source_zero());                                                // icoFoamYade.C:147, pimpleFoamYade.C:109
         if (timing) tim[3].stop(stream);
         FY_HIP(hipStreamSynchronize(stream));
+        if (adjust_phi) {
+            int e = 0;
+            FY_HIP(hipMemcpy(&e, adj_err.p, sizeof(int), hipMemcpyDeviceToHost));
+            if (e) return fail(FY_ERR_UNSUPPORTED, "adjustPhi: continuity error cannot be removed by adjusting the outflow (the in- and outflow through the "
+                                                   "fixed-value patches do not balance and no adjustable outflow is left) -- OpenFOAM stops here too");
+        }
         if (courant_slot >= 0) note_courant(red_host + courant_slot);                         // the deferred diagnostics have landed
         for (int sl : cont_slots) note_cont_err(red_host + sl);
         if (timing) {
