@@ -24,6 +24,9 @@ def classify(name, grid, nc):
     if "k_p_apply_dot" in name: return "k_p_apply_dot"
     if "k_mom_pass" in name: return "k_mom_pass"
     if "k_mg_smooth(" in name and grid >= nc: return "k_mg_smooth(level 0)"
+    if "k_tile_reduce" in name: return "k_tile_reduce"
+    if "k_point_force" in name: return "k_point_force"
+    if "k_bin_gather" in name: return "k_bin_gather"
     return None
 
 
@@ -36,7 +39,7 @@ def main():
         for r in csv.DictReader(open(path)):
             if r["Counter_Name"] != tag:
                 continue
-            k = classify(r["Kernel_Name"], int(r["Grid_Size"]), nc)
+            k = classify(r["Kernel_Name"], int(r.get("Grid_Size", r.get("Grid_Size_X", 0))), nc)
             if k:
                 agg[k].append(float(r["Counter_Value"]))
         for k, v in agg.items():
