@@ -270,6 +270,9 @@ int fy_foam_case_close(fy_foam_case*);
 /* ---- kernel-level entry points used by the roofline bench and the operator parity tests ------------------ */
 /* y = A x for the symmetric 7-point pressure matrix (diag, ux, uy, uz) currently held by the solver; x,y host arrays */
 int fy_solver_apply_p_matrix_host(fy_solver*, const double* x, double* y);
+/* solve  A x = rhs  with the pressure solver of the case (PCG + multigrid / Jacobi, pFinal tolerances) and the pressure matrix the last
+   step assembled; x holds the start vector on entry.  For known-answer tests of the solver itself (manufactured Poisson problems). */
+int fy_solver_solve_p_host(fy_solver*, const double* rhs, double* x, int* iterations);
 /* time `reps` launches of the pEqn Laplacian apply (the roofline kernel) with HIP events on the solver stream; returns avg ms */
 int fy_solver_time_p_apply(fy_solver*, int reps, double* avg_ms);
 

@@ -846,6 +846,15 @@ double* orc_fv_ptr(void* h, const char* name) { vec* v = fv_field((Fv*)h, name);
 void orc_fv_step_begin(void* h) { ((Fv*)h)->step_begin(); }
 void orc_fv_step_end(void* h) { ((Fv*)h)->step_end(); }
 void orc_fv_get_stats(void* h, orc_fv_stats* out) { *out = ((Fv*)h)->st; }
+// A x = rhs with the oracle's pressure solver (pFinal tolerances) and the matrix of the last step; returns the iteration count
+int orc_fv_solve_p(void* h, const double* rhs, double* x) {
+    Fv* f = (Fv*)h;
+    std::memcpy(f->pb.data(), rhs, (size_t)f->Nc * sizeof(double));
+    std::memcpy(f->p.data(), x, (size_t)f->Nc * sizeof(double));
+    const int it = f->solve_pressure(true);
+    std::memcpy(x, f->p.data(), (size_t)f->Nc * sizeof(double));
+    return it;
+}
 // y = A x with the current pressure matrix (level 0)
 void orc_fv_apply_p(void* h, const double* x, double* y) {
     Fv* f = (Fv*)h; vec xv(x, x + f->Nc), yv(f->Nc);

@@ -251,6 +251,8 @@ def _fv_lib():
         L.orc_fv_step_end.argtypes = [C.c_void_p]
         L.orc_fv_get_stats.argtypes = [C.c_void_p, C.POINTER(FvStats)]
         L.orc_fv_apply_p.argtypes = [C.c_void_p, _dp, _dp]
+        L.orc_fv_solve_p.argtypes = [C.c_void_p, _dp, _dp]
+        L.orc_fv_solve_p.restype = C.c_int
         _fv_ready = True
     return L
 
@@ -314,6 +316,12 @@ class FvSolver:
         y = np.empty_like(x)
         self.L.orc_fv_apply_p(self.h, _d(x), _d(y))
         return y
+
+    def solve_p(self, rhs, x0=None):
+        rhs = np.ascontiguousarray(rhs, dtype=np.float64)
+        x = np.zeros_like(rhs) if x0 is None else np.ascontiguousarray(x0, dtype=np.float64).copy()
+        it = self.L.orc_fv_solve_p(self.h, _d(rhs), _d(x))
+        return x, it
 
     def close(self):
         if self.h:

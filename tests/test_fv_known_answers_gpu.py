@@ -71,3 +71,46 @@ def test_poiseuille_profile_and_second_order_convergence(product, solver):
     e1, e2 = poiseuille_error(product, solver, 16), poiseuille_error(product, solver, 32)
     assert e2 < 2e-3
     assert 3.0 < e1 / e2 < 5.0, (e1, e2)            # halving dx divides the error by ~4
+
+
+# ---- closed-form checks shared with the CPU oracle's own known-answer tests (tests/test_fv_oracle.py holds the functions) ------------
+def test_manufactured_poisson_solution_converges_at_second_order_hip(product):
+    """PCG + multigrid on the device against -lap(p) = f with p* = cos cos cos and Neumann walls, up to 128^3: error falls 4x per halving of
+    dx, the iteration count barely moves"""
+    from test_fv_oracle import manufactured_poisson_errors
+    mk = lambda n: product.Solver(product.make_case(product.FY_SOLVER_ICO, n, n, n, 1.0 / n, 0.01, 1e-14, p_solver=1, p_tol=1e-10, p_final_tol=1e-10, p_rel_tol=0.0))
+    res = manufactured_poisson_errors(mk, (32, 64, 128))
+    errs = [e for _, e, _ in res]
+    its = [it for _, _, it in res]
+    assert 3.8 < errs[0] / errs[1] < 4.2 and 3.8 < errs[1] / errs[2] < 4.2, errs
+    assert its[2] <= 30 and its[2] - its[0] <= 8, res
+    jac = manufactured_poisson_errors(lambda n: product.Solver(product.make_case(product.FY_SOLVER_ICO, n, n, n, 1.0 / n, 0.01, 1e-14, p_solver=0, p_tol=1e-10,
+                                                                                 p_final_tol=1e-10, p_rel_tol=0.0)), (64,))
+    assert jac[0][1] == pytest.approx(errs[1], rel=1e-3) and jac[0][2] > 4 * its[1]       # same answer, many more iterations without the multigrid
+
+
+def test_decaying_shear_mode_has_the_discrete_and_the_continuum_rate_hip(product):
+    from test_fv_oracle import decaying_shear_mode
+    ZG, FV = product.FY_BC_U_ZERO_GRADIENT, product.FY_BC_U_FIXED_VALUE
+    PZ, PF = product.FY_BC_P_ZERO_GRADIENT, product.FY_BC_P_FIXED_VALUE
+    mk = lambda ny, dt, nu: product.Solver(product.make_case(product.FY_SOLVER_ICO, 4, ny, 1, 1.0 / ny, dt, nu, u_bc=[ZG, ZG, FV, FV, ZG, ZG],
+                                                             p_bc=[PZ, PF, PZ, PZ, PZ, PZ], u_tol=1e-12, p_tol=1e-12, p_final_tol=1e-12, p_rel_tol=0.0))
+    amp, disc, cont = decaying_shear_mode(mk, 64, 0.01, 0.05, 40)
+    assert amp == pytest.approx(disc, rel=1e-7)
+    e = []
+    for ny, dt in ((16, 0.01), (32, 0.0025), (64, 0.000625)):
+        amp, disc, cont = decaying_shear_mode(mk, ny, dt, 0.05, int(round(0.2 / dt)))
+        e.append(abs(amp - cont))
+    assert 3.3 < e[0] / e[1] < 4.7 and 3.3 < e[1] / e[2] < 4.7, e
+
+
+def test_corrected_flux_is_divergence_free_to_solver_tolerance_hip(product):
+    from test_fv_oracle import flux_identity
+    n = 48
+    u_val = [(0, 0, 0)] * 6
+    u_val[YMAX] = (1.0, 0, 0)
+    s = product.Solver(product.make_case(product.FY_SOLVER_ICO, n, n, n, 1.0 / n, 0.4 / n, 0.01, u_val=u_val))
+    for _ in range(5):
+        s.step()
+    flux_identity(s, n, 0.4 / n)
+    s.close()

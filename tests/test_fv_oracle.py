@@ -295,3 +295,111 @@ def test_relaxation_factors_change_the_iteration_not_the_converged_step(oracle):
     assert np.abs(p20r - p20).max() < 0.25 * np.abs(p2r - p2).max() + 1e-6 * np.abs(p20).max()
     U0, p0 = run(2, u_relax=0.0)
     np.testing.assert_allclose(U0, U2, rtol=0, atol=1e-12 * sc)
+
+
+# ---- known answers shared with tests/test_fv_known_answers_gpu.py (the same functions run on the HIP solver there) ------------------
+def manufactured_poisson_errors(make_solver, sizes):
+    """-lap(p) = f on the unit cube with homogeneous Neumann walls, p* = cos(pi x) cos(pi y) cos(pi z): the pressure matrix of a quiescent
+    closed box is rAU dx times the 7-point Laplacian (icoFoamYade.C:118-123 with uniform rAU = dt), so A p = rAU V f; the reference cell
+    pins the constant.  Returns [(n, max error of the mean-free solution, iterations)]"""
+    out = []
+    for n in sizes:
+        s = make_solver(n)
+        s.step()                                              # assembles the pressure matrix (U = 0: rAU = dt everywhere)
+        rAU = s.get("rAU")
+        assert np.allclose(rAU, rAU[0], rtol=1e-9)
+        dx = 1.0 / n
+        c = (np.arange(n) + 0.5) * dx
+        Z, Y, X = np.meshgrid(c, c, c, indexing="ij")
+        ps = (np.cos(np.pi * X) * np.cos(np.pi * Y) * np.cos(np.pi * Z)).ravel()
+        b = rAU[0] * dx ** 3 * 3 * np.pi ** 2 * ps
+        x, it = s.solve_p(b)
+        err = np.abs((x - x.mean()) - (ps - ps.mean())).max()
+        # the discrete problem itself is solved to the solver tolerance: A x = b
+        r = s.apply_p(x) - b
+        ref = np.abs(b).sum()
+        assert np.abs(r).sum() < 1e-4 * ref, (n, np.abs(r).sum() / ref)
+        out.append((n, err, it))
+        s.close()
+    return out
+
+
+def decaying_shear_mode(make_solver, ny, dt, nu, steps):
+    """u = sin(pi y) between two walls, v = w = 0, uniform in x: the one-Fourier-mode analogue of the Taylor-Green decay (the library has no
+    periodic patches).  sin(pi y_c) is an exact eigenvector of the cell-centred Laplacian with fixedValue walls, eigenvalue
+    lam_h = 2 (1 - cos(pi dx)) / dx^2, so implicit Euler multiplies the amplitude by 1 / (1 + nu lam_h dt) per step -- and that tends to
+    exp(-nu pi^2 t).  Returns (measured amplitude ratio over `steps`, the discrete prediction, the continuum one)"""
+    s = make_solver(ny, dt, nu)
+    dx = 1.0 / ny
+    nx = 4
+    yc = (np.arange(ny) + 0.5) * dx
+    U0 = np.zeros((1, ny, nx, 3))
+    U0[0, :, :, 0] = np.sin(np.pi * yc)[:, None]
+    s.set("U", U0)
+    for _ in range(steps):
+        s.step()
+    U = s.get("U").reshape(1, ny, nx, 3)
+    amp = (U[0, :, :, 0] * np.sin(np.pi * yc)[:, None]).sum() / (np.sin(np.pi * yc) ** 2).sum() / nx
+    assert np.abs(U[..., 1]).max() < 1e-8 and np.abs(U[..., 2]).max() < 1e-8           # the flow stays parallel
+    assert np.abs(U[0, :, :, 0] - amp * np.sin(np.pi * yc)[:, None]).max() < 1e-6     # and stays in the mode
+    lam_h = 2 * (1 - np.cos(np.pi * dx)) / dx ** 2
+    s.close()
+    return amp, (1.0 / (1.0 + nu * lam_h * dt)) ** steps, np.exp(-nu * np.pi ** 2 * dt * steps)
+
+
+def flux_identity(s, n, dt):
+    """after a corrector the flux is phiHbyA - pEqn.flux() (icoFoamYade.C:129): its divergence is the residual of the pressure equation, so
+    it vanishes to the solver tolerance in every cell, and continuityErrs.H's sums follow from it to rounding"""
+    phix, phiy, phiz = s.get("phi_x").reshape(n, n, n + 1), s.get("phi_y").reshape(n, n + 1, n), s.get("phi_z").reshape(n + 1, n, n)
+    div = (phix[:, :, 1:] - phix[:, :, :-1]) + (phiy[:, 1:, :] - phiy[:, :-1, :]) + (phiz[1:] - phiz[:-1])
+    scale = np.abs(phix).sum() + np.abs(phiy).sum() + np.abs(phiz).sum()
+    st = s.stats()
+    V = (1.0 / n) ** 3
+    assert np.abs(div).sum() < 2e-5 * scale
+    assert st["cont_sum_local" if "cont_sum_local" in st else "cont_err_sum_local"] == pytest.approx(dt * np.abs(div).sum() / (V * n ** 3), rel=1e-9, abs=1e-300)
+    assert st["cont_global" if "cont_global" in st else "cont_err_global"] == pytest.approx(dt * div.sum() / (V * n ** 3), rel=1e-6, abs=1e-14 * scale)
+
+
+def closed_box(n, p_solver=1):
+    return orc.fv_case(0, n, n, n, 1.0 / n, 0.01, 1e-14, p_solver=p_solver, p_final_tol=1e-10, p_tol=1e-10, p_rel_tol=0.0)     # (inviscid: rAU = dt in every cell)
+
+
+@pytest.mark.parametrize("p_solver", [0, 1])
+def test_manufactured_poisson_solution_converges_at_second_order(oracle, p_solver):
+    res = manufactured_poisson_errors(lambda n: orc.FvSolver(closed_box(n, p_solver)), (8, 16, 32))
+    errs = [e for _, e, _ in res]
+    assert 3.5 < errs[0] / errs[1] < 4.5 and 3.7 < errs[1] / errs[2] < 4.3, errs
+    its = [it for _, _, it in res]
+    if p_solver == 1:
+        assert its[2] <= 24 and its[2] - its[0] <= 8, res               # multigrid-preconditioned CG (1e-10): a few iterations more per doubling of n ...
+    else:
+        assert its[2] >= 1.7 * its[1] - 2, res                          # ... where Jacobi-preconditioned CG doubles
+
+
+def shear_case(ny, dt, nu):
+    u_bc = [orc.U_ZEROGRAD, orc.U_ZEROGRAD, orc.U_FIXED, orc.U_FIXED, orc.U_ZEROGRAD, orc.U_ZEROGRAD]
+    p_bc = [orc.P_ZEROGRAD, orc.P_FIXED] + [orc.P_ZEROGRAD] * 4
+    return orc.fv_case(0, 4, ny, 1, 1.0 / ny, dt, nu, u_bc=u_bc, p_bc=p_bc, u_tol=1e-12, p_tol=1e-12, p_final_tol=1e-12, p_rel_tol=0.0)
+
+
+def test_decaying_shear_mode_has_the_discrete_and_the_continuum_rate(oracle):
+    mk = lambda ny, dt, nu: orc.FvSolver(shear_case(ny, dt, nu))
+    amp, disc, cont = decaying_shear_mode(mk, 32, 0.01, 0.05, 40)
+    assert amp == pytest.approx(disc, rel=1e-7)
+    e = []
+    for ny, dt in ((8, 0.04), (16, 0.01), (32, 0.0025)):                   # dx halves, dt quarters: the error falls 4x per level
+        steps = int(round(0.4 / dt))
+        amp, disc, cont = decaying_shear_mode(mk, ny, dt, 0.05, steps)
+        e.append(abs(amp - cont))
+    assert 3.3 < e[0] / e[1] < 4.7 and 3.3 < e[1] / e[2] < 4.7, e
+
+
+def test_corrected_flux_is_divergence_free_to_solver_tolerance(oracle):
+    n = 12
+    u_val = [(0, 0, 0)] * 6
+    u_val[orc.YMAX] = (1.0, 0, 0)
+    s = orc.FvSolver(orc.fv_case(0, n, n, n, 1.0 / n, 0.4 / n, 0.01, u_val=u_val))
+    for _ in range(5):
+        s.step()
+    flux_identity(s, n, 0.4 / n)
+    s.close()

@@ -169,6 +169,7 @@ def lib():
     L.fy_solver_destroy.argtypes = [vp]
     L.fy_solver_apply_p_matrix_host.argtypes = [vp, _dp, _dp]
     L.fy_solver_time_p_apply.argtypes = [vp, C.c_int, _dp]
+    L.fy_solver_solve_p_host.argtypes = [vp, _dp, _dp, C.POINTER(C.c_int)]
     L.fy_rccl_unique_id.argtypes = [C.c_void_p]
     L.fy_comm_create_rccl.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(vp)]
     L.fy_comm_create_local_group.argtypes = [C.c_int, C.POINTER(vp)]
@@ -525,6 +526,14 @@ class Solver:
         y = np.empty_like(x)
         _check(lib().fy_solver_apply_p_matrix_host(self._h, _d(x), _d(y)))
         return y
+
+    def solve_p(self, rhs, x0=None):
+        """A x = rhs with the case's pressure solver and the matrix of the last step; returns (x, iterations)"""
+        rhs = np.ascontiguousarray(rhs, dtype=np.float64)
+        x = np.zeros_like(rhs) if x0 is None else np.ascontiguousarray(x0, dtype=np.float64).copy()
+        it = C.c_int(0)
+        _check(lib().fy_solver_solve_p_host(self._h, _d(rhs), _d(x), C.byref(it)))
+        return x, it.value
 
     def time_p_apply(self, reps=50):
         ms = C.c_double()

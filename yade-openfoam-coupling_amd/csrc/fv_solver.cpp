@@ -868,6 +868,21 @@ int fy_solver_apply_p_matrix_host(fy_solver* s, const double* x, double* y) {
     return FY_OK;
 }
 
+int fy_solver_solve_p_host(fy_solver* s, const double* rhs, double* x, int* iterations) {
+    FY_S(s);
+    if (!rhs || !x) return fy::fail(FY_ERR_INVALID, "fy_solver_solve_p_host: null argument");
+    fy::Solver& S = s->s;
+    FY_HIP(hipSetDevice(S.device));
+    FY_HIP(hipMemcpyAsync(S.prhs.p + S.g.c0, rhs, (size_t)S.Nc * sizeof(double), hipMemcpyHostToDevice, S.stream));
+    FY_HIP(hipMemcpyAsync(S.p.p + S.g.c0, x, (size_t)S.Nc * sizeof(double), hipMemcpyHostToDevice, S.stream));
+    const int before = S.st.p_iters_total;
+    FY_TRY(S.solve_pressure(true));
+    FY_HIP(hipMemcpyAsync(x, S.p.p + S.g.c0, (size_t)S.Nc * sizeof(double), hipMemcpyDeviceToHost, S.stream));
+    FY_HIP(hipStreamSynchronize(S.stream));
+    if (iterations) *iterations = S.st.p_iters_total - before;
+    return FY_OK;
+}
+
 int fy_solver_time_p_apply(fy_solver* s, int reps, double* avg_ms) {
     FY_S(s);
     if (reps < 1 || !avg_ms) return fy::fail(FY_ERR_INVALID, "bad arguments");
