@@ -290,6 +290,19 @@ typedef struct fy_comm fy_comm;
 int fy_rccl_unique_id(void* out128);
 int fy_comm_create_rccl(int rank, int size, const void* id128, int device_ordinal, fy_comm** out);
 int fy_comm_create_local_group(int n, fy_comm** out /* [n] */);
+/* host-staged communicator: the library moves the planes device -> pinned host -> callback -> device and leaves the transport between the
+   processes to the caller (MPI, gloo, pipes ...).  One process per slab like RCCL, so the ORDER in which separate processes reach the
+   collectives is real -- what the in-process group cannot show -- on machines where RCCL cannot run (one GPU shared by the ranks).
+   Callbacks return 0 on success; all buffers are host memory; a missing neighbour's buffers are NULL with count 0. */
+typedef struct fy_comm_callbacks {
+    void* user;
+    /* send n_up doubles to rank+1 and n_down to rank-1; receive m_down from rank-1 and m_up from rank+1 (any of them may be 0) */
+    int (*sendrecv)(void* user, const double* send_up, size_t n_up, double* recv_from_down, size_t m_down, const double* send_down, size_t n_down,
+                    double* recv_from_up, size_t m_up);
+    int (*allreduce)(void* user, double* buf, int n, int is_max);                       /* in place, identical result on every rank */
+    int (*allgather)(void* user, const double* send, double* recv, size_t count_per_rank);
+} fy_comm_callbacks;
+int fy_comm_create_host(int rank, int size, const fy_comm_callbacks* cb, fy_comm** out);
 /* diagnostic: calls made through this communicator so far: {neighbour exchanges, all-reduces, all-gathers, bytes sent to neighbours} */
 int fy_comm_stats(fy_comm*, uint64_t* out4);
 /* collective known-answer run of every operation the slab solver uses on this communicator (a grouped two-field neighbour exchange, sum and

@@ -1,5 +1,5 @@
-"""N > 1 path of bench.py on CPU: two gloo ranks, the timing rule (max over ranks) and the whole-job aggregate.
-(Round 1 shards nothing across GPUs: ranks are replicas, so this is all the cross-rank logic there is.)"""
+"""N > 1 path of bench.py on CPU: two gloo ranks, the contract's timing rule (max over ranks) and the whole-job aggregate.  (The sharded
+solver itself -- N z-slabs, one process each -- needs a GPU: tests/test_slabs.py and tests/test_slabs_multiprocess.py.)"""
 import os
 import subprocess
 import sys

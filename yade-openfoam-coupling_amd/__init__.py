@@ -12,6 +12,7 @@ There is no CPU fallback: if the library is missing or no HIP device is visible,
 """
 import ctypes as C
 import os
+import sys
 import subprocess
 
 import numpy as np
@@ -172,6 +173,7 @@ def lib():
     L.fy_solver_solve_p_host.argtypes = [vp, _dp, _dp, C.POINTER(C.c_int)]
     L.fy_rccl_unique_id.argtypes = [C.c_void_p]
     L.fy_comm_create_rccl.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(vp)]
+    L.fy_comm_create_host.argtypes = [C.c_int, C.c_int, C.c_void_p, C.POINTER(vp)]
     L.fy_comm_create_local_group.argtypes = [C.c_int, C.POINTER(vp)]
     L.fy_comm_destroy.argtypes = [vp]
     L.fy_comm_stats.argtypes = [vp, C.POINTER(C.c_uint64)]
@@ -585,6 +587,74 @@ def rccl_comm(rank, size, id128, device):
     buf = (C.c_char * 128).from_buffer_copy(id128)
     _check(lib().fy_comm_create_rccl(int(rank), int(size), buf, int(device), C.byref(h)))
     return h
+
+
+_CB_SENDRECV = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t)
+_CB_ALLREDUCE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int)
+_CB_ALLGATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
+
+
+class CommCallbacks(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("sendrecv", _CB_SENDRECV), ("allreduce", _CB_ALLREDUCE), ("allgather", _CB_ALLGATHER)]
+
+
+class GlooHostComm:
+    """fy_comm_create_host over torch.distributed (gloo, CPU tensors): one process per slab with the planes staged through host memory --
+    the deployment shape of the RCCL back-end on a machine where RCCL cannot run (all ranks on one GPU).  .handle goes to Solver(comm=)."""
+
+    def __init__(self, dist):
+        import torch
+        self.dist, self.torch = dist, torch
+        self.rank, self.size = dist.get_rank(), dist.get_world_size()
+
+        def view(ptr, n):
+            return torch.frombuffer((C.c_double * n).from_address(ptr), dtype=torch.float64)
+
+        def sendrecv(user, su, n_su, rd, n_rd, sd, n_sd, ru, n_ru):
+            try:
+                ops = []
+                if n_su: ops.append(dist.isend(view(su, n_su), self.rank + 1, tag=1))
+                if n_sd: ops.append(dist.isend(view(sd, n_sd), self.rank - 1, tag=2))
+                if n_rd: ops.append(dist.irecv(view(rd, n_rd), self.rank - 1, tag=1))
+                if n_ru: ops.append(dist.irecv(view(ru, n_ru), self.rank + 1, tag=2))
+                for o in ops:
+                    o.wait()
+                return 0
+            except Exception as e:                       # noqa: BLE001  (an exception must not cross the C frame)
+                print(f"[GlooHostComm rank {self.rank}] sendrecv: {e}", file=sys.stderr, flush=True)
+                return 1
+
+        def allreduce(user, buf, n, is_max):
+            try:
+                dist.all_reduce(view(buf, n), op=dist.ReduceOp.MAX if is_max else dist.ReduceOp.SUM)
+                return 0
+            except Exception as e:                       # noqa: BLE001
+                print(f"[GlooHostComm rank {self.rank}] allreduce: {e}", file=sys.stderr, flush=True)
+                return 1
+
+        def allgather(user, send, recv, n):
+            try:
+                out = view(recv, n * self.size)
+                dist.all_gather_into_tensor(out, view(send, n).clone())
+                return 0
+            except Exception as e:                       # noqa: BLE001
+                print(f"[GlooHostComm rank {self.rank}] allgather: {e}", file=sys.stderr, flush=True)
+                return 1
+
+        self._keep = (_CB_SENDRECV(sendrecv), _CB_ALLREDUCE(allreduce), _CB_ALLGATHER(allgather))
+        self._cb = CommCallbacks(None, *self._keep)
+        self.handle = C.c_void_p()
+        _check(lib().fy_comm_create_host(self.rank, self.size, C.byref(self._cb), C.byref(self.handle)))
+
+    def stats(self):
+        out = (C.c_uint64 * 4)()
+        _check(lib().fy_comm_stats(self.handle, out))
+        return dict(exchanges=out[0], allreduces=out[1], allgathers=out[2], bytes=out[3])
+
+    def close(self):
+        if self.handle:
+            lib().fy_comm_destroy(self.handle)
+            self.handle = C.c_void_p()
 
 
 def comm_selftest(comm, device=0):

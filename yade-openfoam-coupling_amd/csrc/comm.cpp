@@ -113,6 +113,68 @@ int local_comm_group_create(int n, Comm** out) {
     return FY_OK;
 }
 
+// ================================================================================================ HostComm
+namespace {
+
+struct HostComm : Comm {
+    fy_comm_callbacks cb{};
+    HostBuf<double> h_su, h_sd, h_rd, h_ru, h_small, h_gather;
+    int exchange_many(hipStream_t s, const Xchg* x, size_t n) override {
+        ++n_exchange;
+        // every item of a group in the order it was posted: all ranks post the same items in the same order
+        for (size_t q = 0; q < n; ++q) {
+            const size_t su = has_up() && x[q].send_up ? x[q].su() : 0, sd = has_down() && x[q].send_down ? x[q].sd() : 0;
+            const size_t rd = has_down() && x[q].recv_from_down ? x[q].rd() : 0, ru = has_up() && x[q].recv_from_up ? x[q].ru() : 0;
+            exchange_bytes += sizeof(double) * (su + sd);
+            FY_TRY(h_su.reserve(su + 1)); FY_TRY(h_sd.reserve(sd + 1)); FY_TRY(h_rd.reserve(rd + 1)); FY_TRY(h_ru.reserve(ru + 1));
+            if (su) FY_HIP(hipMemcpyAsync(h_su.p, x[q].send_up, su * sizeof(double), hipMemcpyDeviceToHost, s));
+            if (sd) FY_HIP(hipMemcpyAsync(h_sd.p, x[q].send_down, sd * sizeof(double), hipMemcpyDeviceToHost, s));
+            FY_HIP(hipStreamSynchronize(s));
+            if (cb.sendrecv(cb.user, su ? h_su.p : nullptr, su, rd ? h_rd.p : nullptr, rd, sd ? h_sd.p : nullptr, sd, ru ? h_ru.p : nullptr, ru) != 0)
+                return fail(FY_ERR_TRANSPORT, "host communicator: sendrecv callback failed");
+            if (rd) FY_HIP(hipMemcpyAsync(x[q].recv_from_down, h_rd.p, rd * sizeof(double), hipMemcpyHostToDevice, s));
+            if (ru) FY_HIP(hipMemcpyAsync(x[q].recv_from_up, h_ru.p, ru * sizeof(double), hipMemcpyHostToDevice, s));
+            FY_HIP(hipStreamSynchronize(s));             // the staging buffers are reused by the next item
+        }
+        return FY_OK;
+    }
+    int allreduce(hipStream_t s, double* dev, int n, bool is_max) override {
+        ++n_allreduce;
+        FY_TRY(h_small.reserve((size_t)n + 1));
+        FY_HIP(hipMemcpyAsync(h_small.p, dev, n * sizeof(double), hipMemcpyDeviceToHost, s));
+        FY_HIP(hipStreamSynchronize(s));
+        if (cb.allreduce(cb.user, h_small.p, n, is_max ? 1 : 0) != 0) return fail(FY_ERR_TRANSPORT, "host communicator: allreduce callback failed");
+        FY_HIP(hipMemcpyAsync(dev, h_small.p, n * sizeof(double), hipMemcpyHostToDevice, s));
+        FY_HIP(hipStreamSynchronize(s));
+        return FY_OK;
+    }
+    int allgather(hipStream_t s, const double* send, double* recv, size_t cnt) override {
+        ++n_allgather;
+        FY_TRY(h_su.reserve(cnt + 1)); FY_TRY(h_gather.reserve(cnt * (size_t)size + 1));
+        FY_HIP(hipMemcpyAsync(h_su.p, send, cnt * sizeof(double), hipMemcpyDeviceToHost, s));
+        FY_HIP(hipStreamSynchronize(s));
+        if (cb.allgather(cb.user, h_su.p, h_gather.p, cnt) != 0) return fail(FY_ERR_TRANSPORT, "host communicator: allgather callback failed");
+        FY_HIP(hipMemcpyAsync(recv, h_gather.p, cnt * (size_t)size * sizeof(double), hipMemcpyHostToDevice, s));
+        FY_HIP(hipStreamSynchronize(s));
+        return FY_OK;
+    }
+    int barrier(hipStream_t s) override {
+        double z = 0.0;
+        FY_HIP(hipStreamSynchronize(s));
+        return cb.allreduce(cb.user, &z, 1, 0) == 0 ? FY_OK : fail(FY_ERR_TRANSPORT, "host communicator: barrier failed");
+    }
+};
+
+}  // namespace
+
+int host_comm_create(int rank, int size, const fy_comm_callbacks* cb, Comm** out) {
+    if (!out || !cb || !cb->sendrecv || !cb->allreduce || !cb->allgather || size < 1 || rank < 0 || rank >= size) return fail(FY_ERR_INVALID, "bad host communicator arguments");
+    HostComm* c = new HostComm();
+    c->rank = rank; c->size = size; c->cb = *cb;
+    *out = c;
+    return FY_OK;
+}
+
 // ================================================================================================ RcclComm
 namespace {
 

@@ -14,6 +14,8 @@
 #include <cstdint>
 #include <vector>
 
+#include "../../include/foamyade_hip.h"
+
 namespace fy {
 
 struct Comm {
@@ -74,6 +76,8 @@ struct SelfComm : Comm {                                   // size 1: every call
     int barrier(hipStream_t) override { return 0; }
 };
 
+// HostComm: one process per slab, planes staged through pinned host memory, the inter-process transport is the caller's (callbacks)
+int host_comm_create(int rank, int size, const fy_comm_callbacks* cb, Comm** out);
 // LocalComm group: create `n` communicators that talk to each other inside this process
 int local_comm_group_create(int n, Comm** out /* [n] */);
 // RCCL: unique id = 128 opaque bytes produced on rank 0 (fy_rccl_unique_id) and broadcast by the launcher
