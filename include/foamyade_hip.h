@@ -139,6 +139,10 @@ const double* fy_forces_device(fy_ctx*, int batch);
 int fy_get_stencils_host(fy_ctx*, int batch, int32_t* k, int32_t* ids, double* weights, int32_t* chain_len);
 /* k-d tree in preorder (node, left subtree, right subtree): cell ids, for parity with meshTree.C:19-37 */
 int fy_get_tree_preorder(fy_ctx*, int32_t* out_ids /* [n_cells] */);
+/* meshTree::nearestCell (meshTree.C:66-135) for n points, pos[n][3] on the host: out[q] = id of the nearest cell centre (among equidistant
+   ones the first the reference's depth-first descent meets).  FoamYade itself never calls it (its Gaussian locate is the range search, its
+   point locate mesh.findCell); exposed because it is the tree's public API and the findCell stand-in on general meshes. */
+int fy_nearest_cells_host(fy_ctx*, const double* pos, int64_t n, int32_t* out);
 /* read / write any of the ctx's cell fields by name ("alpha","uParticle","uSourceDrag","uSource","U","gradP","vGrad","divT") */
 int fy_read_field_host(fy_ctx*, const char* name, double* out);
 int fy_write_field_host(fy_ctx*, const char* name, const double* in);

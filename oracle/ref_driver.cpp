@@ -222,6 +222,11 @@ void foam_rank(const std::string& dir, const Meta& m) {
                 FT[6 * (size_t)gi + 3] = prt->hydroTorque.x(); FT[6 * (size_t)gi + 4] = prt->hydroTorque.y(); FT[6 * (size_t)gi + 5] = prt->hydroTorque.z();
             }
         }
+        {   // meshTree::nearestCell (meshTree.C:66-135; no call site in FoamYade) on every record's position, for the NN locate of row A6
+            std::vector<int> nn(Np, -1);
+            for (int q = 0; q < Np; ++q) nn[q] = fy.mshTree.nearestCell(Foam::vector(rec[10 * (size_t)q], rec[10 * (size_t)q + 1], rec[10 * (size_t)q + 2]));
+            write_bin(dir + "/" + sfx("part_nn", s), nn.data(), nn.size());
+        }
         write_bin(dir + "/" + sfx("part_k", s), k.data(), k.size());
         write_bin(dir + "/" + sfx("part_incell", s), incell.data(), incell.size());
         write_bin(dir + "/" + sfx("part_ids", s), ids.data(), ids.size());

@@ -75,6 +75,7 @@ def build_case(c: gc.Case):
         for s in range(c.nsteps):
             Np = records[s].shape[0]
             out[f"records_s{s}"] = records[s]
+            out[f"nn_s{s}"] = rd(wd, f"part_nn_s{s}.bin", np.int32)          # meshTree::nearestCell of every record (kept in nn_<case>.npz)
             out[f"k_s{s}"] = rd(wd, f"part_k_s{s}.bin", np.int32).astype(np.int8)
             out[f"incell_s{s}"] = rd(wd, f"part_incell_s{s}.bin", np.int32)
             out[f"ids_s{s}"] = rd(wd, f"part_ids_s{s}.bin", np.int32, (Np, MAXK))
@@ -127,10 +128,17 @@ def build_case(c: gc.Case):
 def main():
     if not os.path.exists(DRIVER):
         sys.exit("build the reference driver first: make -C oracle ref")
-    names = sys.argv[1:] or [c.name for c in gc.CASES]
+    nn_only = "--nn-only" in sys.argv          # only the nearestCell fixtures (added in round 2; the other files stay as committed)
+    names = [a for a in sys.argv[1:] if not a.startswith("--")] or [c.name for c in gc.CASES]
     for name in names:
         c = gc.CASES_BY_NAME[name]
         out = build_case(c)
+        nn = {k: out.pop(k) for k in [k for k in out if k.startswith("nn_s")]}
+        nn["records_sha"] = np.array([gc.sha(out[f"records_s{s}"]) for s in range(c.nsteps)])
+        np.savez_compressed(os.path.join(HERE, "nn_" + name + ".npz"), **nn)
+        if nn_only:
+            print(f"{name}: nearestCell of {sum(v.size for k, v in nn.items() if k.startswith('nn_s'))} points")
+            continue
         path = os.path.join(HERE, name + ".npz")
         np.savez_compressed(path, **out)
         k = out["k_s0"].astype(int)

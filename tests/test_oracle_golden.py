@@ -105,3 +105,20 @@ def test_golden_covers_the_branches():
     o = np.array(c.origin); ext = np.array([c.nx, c.ny, c.nz]) * c.dx
     outside = np.any((rec[:, :3] < o) | (rec[:, :3] > o + ext), axis=1)
     assert (outside & (k > 0)).any() and (outside & (k == 0)).any()
+
+
+@pytest.mark.parametrize("name", [c.name for c in gc.CASES])
+def test_nearest_cell_matches_reference(oracle, name):
+    """meshTree::nearestCell (meshTree.C:66-135) of every record position, as the reference's own method returned it (nn_<case>.npz,
+    written by gen_golden.py --nn-only through oracle/ref_driver.cpp); bit exact, probes outside the block and on cell faces included"""
+    c = gc.CASES_BY_NAME[name]
+    g = gu.load(name)
+    import os
+    nn = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "nn_" + name + ".npz"))
+    C = gc.cell_centres(c)
+    pre = oracle.build_tree(C)
+    for s in range(c.nsteps):
+        rec = g[f"records_s{s}"]
+        assert gc.sha(rec) == str(nn["records_sha"][s])
+        got = oracle.nearest_cell(C, pre, rec[:, 0:3])
+        assert np.array_equal(got, nn[f"nn_s{s}"])

@@ -240,3 +240,28 @@ def test_locate_lists_equal_the_walk(product, oracle, dims, origin):
     walked = fy.locate_walk_count
     assert 0.05 * n < walked < 0.6 * n or walked == -1, walked            # both kernels took a share
     fy.close()
+
+
+@pytest.mark.parametrize("name", [c.name for c in gc.CASES])
+def test_nearest_cell_matches_reference(product, oracle, name):
+    """fy_nearest_cells_host = meshTree::nearestCell (meshTree.C:66-135): bit exact against what the reference's own method returned for every
+    record position of the golden cases (nn_<case>.npz), and against the oracle on lattice-aligned and far-outside queries"""
+    import os
+    c = gc.CASES_BY_NAME[name]
+    g = gu.load(name)
+    nn = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "nn_" + name + ".npz"))
+    mesh, fy = make_engine(product, c, gc.fluid_fields(c), seeded_mutable(c.ncells))
+    for s in range(c.nsteps):
+        rec = g[f"records_s{s}"]
+        assert np.array_equal(fy.nearest_cells(rec[:, 0:3]), nn[f"nn_s{s}"])
+    # adversarial queries: cell centres, face / edge / corner points (exact ties), points far outside the block
+    C = gc.cell_centres(c)
+    rs = np.random.RandomState(4)
+    pick = C[rs.randint(0, c.ncells, 400)]
+    q = np.concatenate([pick, pick + 0.5 * c.dx * rs.randint(-1, 2, (400, 3)), pick + c.dx * rs.uniform(-9, 9, (400, 3))])
+    np.testing.assert_array_equal(fy.nearest_cells(q), oracle.nearest_cell(C, fy.tree_preorder(), q))
+    # inside the block the nearest centre is the containing cell (uniform hex): the findCell stand-in of SURVEY.md 8a A6
+    inner = np.asarray(c.origin) + rs.uniform(0.001, 0.999, (500, 3)) * np.array([c.nx, c.ny, c.nz]) * c.dx
+    ijk = np.floor((inner - np.asarray(c.origin)) / c.dx).astype(int)
+    np.testing.assert_array_equal(fy.nearest_cells(inner), ijk[:, 0] + c.nx * (ijk[:, 1] + c.ny * ijk[:, 2]))
+    fy.close()

@@ -139,6 +139,7 @@ def lib():
     L.fy_forces_device.argtypes = [vp, C.c_int]
     L.fy_forces_device.restype = vp
     L.fy_get_stencils_host.argtypes = [vp, C.c_int, _ip, _ip, _dp, _ip]
+    L.fy_nearest_cells_host.argtypes = [vp, _dp, C.c_int64, _ip]
     L.fy_get_tree_preorder.argtypes = [vp, _ip]
     L.fy_read_field_host.argtypes = [vp, C.c_char_p, _dp]
     L.fy_write_field_host.argtypes = [vp, C.c_char_p, _dp]
@@ -337,6 +338,13 @@ class FoamYade:
         k = np.zeros(n, np.int32); ids = np.full((n, MAXK), -1, np.int32); w = np.zeros((n, MAXK)); chain = np.zeros(n, np.int32)
         _check(lib().fy_get_stencils_host(self._h, batch, _i(k), _i(ids), _d(w), _i(chain)))
         return k, ids, w, chain
+
+    def nearest_cells(self, pos):
+        """meshTree::nearestCell (meshTree.C:66-135) of every row of pos (n,3)"""
+        pos = np.ascontiguousarray(pos, dtype=np.float64).reshape(-1, 3)
+        out = np.zeros(pos.shape[0], dtype=np.int32)
+        _check(lib().fy_nearest_cells_host(self._h, _d(pos), pos.shape[0], _i(out)))
+        return out
 
     def tree_preorder(self):
         out = np.zeros(self.mesh.n_cells, dtype=np.int32)

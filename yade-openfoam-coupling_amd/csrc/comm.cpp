@@ -5,6 +5,7 @@
 #include <dlfcn.h>
 
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -186,6 +187,7 @@ struct RcclApi {
     int (*GetUniqueId)(UniqueId*) = nullptr;
     int (*CommInitRank)(NcclComm*, int, UniqueId, int) = nullptr;
     int (*CommDestroy)(NcclComm) = nullptr;
+    int (*CommSplit)(NcclComm, int, int, NcclComm*, void*) = nullptr;     // optional (RCCL >= 2.18)
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     int (*Send)(const void*, size_t, int, int, NcclComm, hipStream_t) = nullptr;
@@ -208,6 +210,7 @@ RcclApi* rccl_api() {
     api.GetUniqueId = (int (*)(UniqueId*))dlsym(h, "ncclGetUniqueId");
     api.CommInitRank = (int (*)(NcclComm*, int, UniqueId, int))dlsym(h, "ncclCommInitRank");
     api.CommDestroy = (int (*)(NcclComm))dlsym(h, "ncclCommDestroy");
+    api.CommSplit = (int (*)(NcclComm, int, int, NcclComm*, void*))dlsym(h, "ncclCommSplit");
     api.GroupStart = (int (*)())dlsym(h, "ncclGroupStart");
     api.GroupEnd = (int (*)())dlsym(h, "ncclGroupEnd");
     api.Send = (int (*)(const void*, size_t, int, int, NcclComm, hipStream_t))dlsym(h, "ncclSend");
@@ -230,18 +233,28 @@ RcclApi* rccl_api() {
 struct RcclComm : Comm {
     RcclApi* A = nullptr;
     NcclComm comm = nullptr;
-    ~RcclComm() override { if (A && comm && A->CommDestroy) A->CommDestroy(comm); }
+    // a second communicator of the same ranks (ncclCommSplit, colour 0) for the exchanges that overlap interior work on another stream:
+    // operations on ONE ncclComm are meant to be issued from one stream at a time, two communicators may progress independently
+    NcclComm comm_aux = nullptr;
+    hipStream_t aux_stream = nullptr;
+    ~RcclComm() override {
+        if (A && comm_aux && A->CommDestroy) A->CommDestroy(comm_aux);
+        if (A && comm && A->CommDestroy) A->CommDestroy(comm);
+    }
+    void set_aux_stream(hipStream_t s) override { aux_stream = s; }
+    NcclComm comm_for(hipStream_t s) const { return (comm_aux && aux_stream && s == aux_stream) ? comm_aux : comm; }
     // Both directions in ONE group: every rank posts all its sends and receives before any of them has to complete, so the
     // pairing cannot deadlock whatever order the ranks reach this call in.
     int exchange_many(hipStream_t s, const Xchg* x, size_t n) override {
         ++n_exchange;
+        const NcclComm cm = comm_for(s);
         FY_NCCL(A->GroupStart());
         for (size_t q = 0; q < n; ++q) {
             exchange_bytes += sizeof(double) * ((has_up() ? x[q].su() : 0) + (has_down() ? x[q].sd() : 0));
-            if (has_up() && x[q].send_up && x[q].su()) FY_NCCL(A->Send(x[q].send_up, x[q].su(), kNcclDouble, rank + 1, comm, s));
-            if (has_down() && x[q].recv_from_down && x[q].rd()) FY_NCCL(A->Recv(x[q].recv_from_down, x[q].rd(), kNcclDouble, rank - 1, comm, s));
-            if (has_down() && x[q].send_down && x[q].sd()) FY_NCCL(A->Send(x[q].send_down, x[q].sd(), kNcclDouble, rank - 1, comm, s));
-            if (has_up() && x[q].recv_from_up && x[q].ru()) FY_NCCL(A->Recv(x[q].recv_from_up, x[q].ru(), kNcclDouble, rank + 1, comm, s));
+            if (has_up() && x[q].send_up && x[q].su()) FY_NCCL(A->Send(x[q].send_up, x[q].su(), kNcclDouble, rank + 1, cm, s));
+            if (has_down() && x[q].recv_from_down && x[q].rd()) FY_NCCL(A->Recv(x[q].recv_from_down, x[q].rd(), kNcclDouble, rank - 1, cm, s));
+            if (has_down() && x[q].send_down && x[q].sd()) FY_NCCL(A->Send(x[q].send_down, x[q].sd(), kNcclDouble, rank - 1, cm, s));
+            if (has_up() && x[q].recv_from_up && x[q].ru()) FY_NCCL(A->Recv(x[q].recv_from_up, x[q].ru(), kNcclDouble, rank + 1, cm, s));
         }
         FY_NCCL(A->GroupEnd());
         return FY_OK;
@@ -284,6 +297,11 @@ int rccl_comm_create(int rank, int size, const void* id128, int device, Comm** o
     c->A = A; c->rank = rank; c->size = size;
     int r = A->CommInitRank(&c->comm, size, id, rank);
     if (r != 0) { delete c; return fail(FY_ERR_TRANSPORT, "ncclCommInitRank failed: %s", A->GetErrorString ? A->GetErrorString(r) : "?"); }
+    // the second communicator (collective over the same ranks); without ncclCommSplit, or if it fails, the overlapped exchanges share
+    // the first one as in round 1
+    if (A->CommSplit && getenv("FOAMYADE_NO_AUX_COMM") == nullptr) {
+        if (A->CommSplit(c->comm, 0, rank, &c->comm_aux, nullptr) != 0) c->comm_aux = nullptr;
+    }
     *out = c;
     return FY_OK;
 }

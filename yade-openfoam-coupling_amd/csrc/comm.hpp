@@ -61,6 +61,9 @@ struct Comm {
         pending.clear();
         return rc;
     }
+    // exchanges enqueued on `aux` run beside the ones on the main stream (the smoother's overlapped halo): a back-end whose handle may
+    // not be driven from two streams at once (RCCL: one ncclComm per stream in flight) routes them over a second communicator
+    virtual void set_aux_stream(hipStream_t) {}
     virtual int exchange_many(hipStream_t s, const Xchg* x, size_t n) = 0;
     std::vector<Xchg> pending;
     bool grouping = false;

@@ -991,6 +991,20 @@ const double* fy_forces_device(fy_ctx* c, int batch) {
     return c->c.batches[(size_t)batch]->force.p;
 }
 int fy_get_stencils_host(fy_ctx* c, int batch, int32_t* k, int32_t* ids, double* w, int32_t* chain) { FY_CTX(c); return c->c.get_stencils_host(batch, k, ids, w, chain); }
+int fy_nearest_cells_host(fy_ctx* c, const double* pos, int64_t n, int32_t* out) {
+    FY_CTX(c);
+    if (n < 0 || (n > 0 && (!pos || !out))) return fy::fail(FY_ERR_INVALID, "fy_nearest_cells_host: bad arguments");
+    if (n == 0) return FY_OK;
+    Coupling& C = c->c;
+    FY_HIP(hipSetDevice(C.device));
+    fy::DevBuf<double> dp; fy::DevBuf<int32_t> dout;
+    FY_TRY(dp.alloc_exact(3 * (size_t)n)); FY_TRY(dout.alloc_exact((size_t)n));
+    FY_HIP(hipMemcpyAsync(dp.p, pos, 3 * (size_t)n * sizeof(double), hipMemcpyHostToDevice, C.stream));
+    FY_TRY(fy::launch_nearest_cell(C.stream, C.d_tree.p, C.use_implicit ? C.d_tree_packed.p : nullptr, C.implicit, C.n_cells, dp.p, n, dout.p));
+    FY_HIP(hipMemcpyAsync(out, dout.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, C.stream));
+    FY_HIP(hipStreamSynchronize(C.stream));
+    return FY_OK;
+}
 int fy_get_tree_preorder(fy_ctx* c, int32_t* out) { FY_CTX(c); return c->c.get_tree_preorder(out); }
 int fy_read_field_host(fy_ctx* c, const char* name, double* out) { FY_CTX(c); return c->c.read_field_host(name, out); }
 int fy_write_field_host(fy_ctx* c, const char* name, const double* in) { FY_CTX(c); return c->c.write_field_host(name, in); }

@@ -132,6 +132,7 @@ struct Solver {
         FY_HIP(hipEventCreateWithFlags(&ev_ready, hipEventDisableTiming));
         FY_HIP(hipEventCreateWithFlags(&ev_halo, hipEventDisableTiming));
         overlap_halos = getenv("FOAMYADE_NO_HALO_OVERLAP") == nullptr;
+        comm->set_aux_stream(comm_stream);
         // ---- slab extents: the case describes the GLOBAL block; rank r owns planes [r*nz, (r+1)*nz)
         const int S = comm->size;
         if (c->nz % S != 0) return fail(FY_ERR_INVALID, "nz (%d) must be divisible by the number of slabs (%d)", c->nz, S);

@@ -541,6 +541,55 @@ __global__ __launch_bounds__(kWave) void k_locate(const KdNode* __restrict__ tre
 #undef STK
 }
 
+// ------------------------------------------------------------------------------------------------ nearest cell
+// meshTree::nearestCell (meshTree.C:66-135): plain nearest-neighbour descent of the same tree -- near side first, far side iff
+// df^2 < best, strict improvements only, so among equidistant centres the first one in depth-first order wins.  The reference never calls
+// it; it is the natural findCell stand-in on meshes where the nearest centre is the containing cell.  One lane per
+// query, explicit stack in scratch (tree depth <= 25); far sides that cannot pass `df2 < best` any more are dropped at push time.
+template <bool IMPLICIT>
+__global__ __launch_bounds__(256) void k_nearest_cell(const KdNode* __restrict__ tree, const uint32_t* __restrict__ packed, ImplicitGeom ig, int32_t n_cells,
+                                                      const double* __restrict__ pos, int64_t n, int32_t* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double qx = pos[3 * i], qy = pos[3 * i + 1], qz = pos[3 * i + 2];
+    uint32_t st_o[28], st_n[28];
+    double st_d[28];
+    unsigned char st_a[28];
+    int sp = 0;
+    const NodeVal root = fetch_node<IMPLICIT>(tree, packed, ig, 0u);
+    double best;
+    {
+        const double a = qx - root.x, b = qy - root.y, c = qz - root.z;
+        best = a * a; best += b * b; best += c * c;                 // meshTree.C:71: dist = distance(root->p, v)
+    }
+    int32_t best_id = root.id;
+    uint32_t o = 0, nn = (uint32_t)n_cells, axis = 0;
+    for (;;) {
+        if (nn == 0) {
+            if (sp == 0) break;
+            --sp;
+            if (!(st_d[sp] < best)) continue;                       // meshTree.C:121, evaluated when the near subtree has returned
+            o = st_o[sp]; nn = st_n[sp]; axis = st_a[sp];
+        }
+        const NodeVal nd = fetch_node<IMPLICIT>(tree, packed, ig, o);
+        const double a = qx - nd.x, b = qy - nd.y, c = qz - nd.z;
+        double d = a * a;                                           // meshTree.C:54-64
+        d += b * b;
+        d += c * c;
+        if (d < best) { best = d; best_id = nd.id; }                // meshTree.C:90-93 (and the comparisons on return: same node, same distance)
+        const double mdf = axis == 0 ? a : (axis == 1 ? b : c);     // -(node[axis] - q[axis])
+        const double df2 = mdf * mdf;
+        const uint32_t nl = nn >> 1, nr = nn - nl - 1;
+        uint32_t near_o, near_n, far_o, far_n;
+        if (mdf < 0.0) { near_o = o + 1; near_n = nl; far_o = o + 1 + nl; far_n = nr; }     // df > 0: left first (meshTree.C:104-110)
+        else          { near_o = o + 1 + nl; near_n = nr; far_o = o + 1; far_n = nl; }
+        axis = (axis == 2 ? 0 : axis + 1);
+        if (far_n > 0 && df2 < best && sp < 28) { st_o[sp] = far_o; st_n[sp] = far_n; st_d[sp] = df2; st_a[sp] = (unsigned char)axis; ++sp; }
+        o = near_o; nn = near_n;
+    }
+    out[i] = best_id;
+}
+
 // ------------------------------------------------------------------------------------------------ LDS aggregation of scatters
 // Binned particles that share a workgroup also share most of their stencil cells (measured on the C3 cloud: 8.4 (particle, cell)
 // pairs per distinct cell in a 256-particle block, 12 in a 1024-particle block).  FP64 global atomics are what bounds the scatter
@@ -1386,6 +1435,14 @@ int launch_locate(hipStream_t s, const KdNode* tree, const uint32_t* packed, Imp
     } else {
         hipLaunchKernelGGL(k_locate<false>, grid, dim3(kWave), lds, s, tree, packed, ig, n_cells, p, n, gp.maxdist, nullptr, own, nullptr, nullptr);
     }
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+
+int launch_nearest_cell(hipStream_t s, const KdNode* tree, const uint32_t* packed, ImplicitGeom ig, int32_t n_cells, const double* pos, int64_t n, int32_t* out) {
+    if (n <= 0) return FY_OK;
+    if (packed) hipLaunchKernelGGL(k_nearest_cell<true>, dim3(div_up(n, 256)), dim3(256), 0, s, tree, packed, ig, n_cells, pos, n, out);
+    else hipLaunchKernelGGL(k_nearest_cell<false>, dim3(div_up(n, 256)), dim3(256), 0, s, tree, packed, ig, n_cells, pos, n, out);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }

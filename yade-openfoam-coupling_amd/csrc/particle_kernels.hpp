@@ -79,6 +79,8 @@ constexpr int kLocateListLen = 24;       // codes (2 B) per (cell, octant)
 int launch_locate(hipStream_t s, const KdNode* tree, const uint32_t* packed, ImplicitGeom ig, int32_t n_cells, int levels,
                   ParticleSoA p, int64_t n, GaussParams gp, const unsigned long long* start = nullptr, SlabOwn own = SlabOwn{},
                   LocateLists ll = LocateLists{});
+// meshTree::nearestCell (meshTree.C:66-135) for n query points [n][3]: the id of the nearest cell centre, ties to the first in DFS order
+int launch_nearest_cell(hipStream_t s, const KdNode* tree, const uint32_t* packed, ImplicitGeom ig, int32_t n_cells, const double* pos, int64_t n, int32_t* out);
 // lists: n_listed * 8 * kLocateListLen codes, for the cells [cell0, cell0 + n_listed).  See k_build_locate_lists for what a list is and why scanning it reproduces the walk.
 int launch_build_locate_lists(hipStream_t s, const uint32_t* packed, ImplicitGeom ig, int32_t n_cells, double maxdist, unsigned short* lists,
                               int32_t cell0, int32_t n_listed);
