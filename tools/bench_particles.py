@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--gaussian", type=int, default=1)
     ap.add_argument("--fill", type=float, default=0.6)
+    ap.add_argument("--vel", type=float, default=0.0, help="particle velocity scale (0: at rest, the C3 cloud)")
     a = ap.parse_args()
     import torch
     prod = ge.load_product()
@@ -41,6 +42,8 @@ def main():
     rec = torch.rand(a.np, 10, dtype=torch.float64, generator=g)
     rec[:, 2] *= a.fill
     rec[:, 3:9] = 0.0
+    if a.vel:
+        rec[:, 3:6] = (torch.rand(a.np, 3, dtype=torch.float64, generator=g) - 0.5) * 2 * a.vel
     rec[:, 9] = 0.2 * dx
     rec = rec.to(dev).contiguous()
     print(f"inputs ready {time.time() - t0:.1f}s", flush=True)

@@ -393,11 +393,44 @@ __global__ __launch_bounds__(256) void k_locate_lists(LocateLists ll, ImplicitGe
     p.chain_len[i] = chain;
 }
 
+// What k_deposit does for one particle, straight after its walk and with plain global atomics: the candidate lists' leftovers are a few
+// hundred particles (within 8e-6 dx of a cell face), for which a second, latency-bound launch with its own aggregation table cost more
+// than the walk itself.  pvol_acc == nullptr: the walk only parks the squared distances (k_deposit follows).
+struct WalkDeposit { GaussParams gp; CellWindow cw; double* pvol_acc; double* up_acc; unsigned char* touched; };
+__device__ __attribute__((noinline)) void walk_deposit(const ParticleSoA& p, int64_t i, int chain, const WalkDeposit& wd) {
+    const int k = chain < kMaxK ? chain : kMaxK;
+    if (k <= 0) return;
+    const double dia = 2 * p.rad[i];                                  // FoamYade.C:219
+    const double pVol = M_PI * pow(dia, 3.0) / 6.0;                   // FoamYade.H:36
+    const double vx = p.vx[i], vy = p.vy[i], vz = p.vz[i];
+    double allwt = 0.0;                                               // calcInterpWeightGaussian FoamYade.C:301-314, ascending-d2 order
+#pragma unroll 1
+    for (int t = 0; t < k; ++t) {
+        const size_t slot = (size_t)((chain - 1 - t) & (kMaxK - 1)) * p.cap + (size_t)i;
+        const double wt = exp(-p.w[slot] / wd.gp.two_sigma2) * wd.gp.range_cu * wd.gp.sigma_pi;
+        p.w[slot] = wt;
+        allwt += wt;
+    }
+#pragma unroll 1
+    for (int t = 0; t < k; ++t) {
+        const size_t slot = (size_t)((chain - 1 - t) & (kMaxK - 1)) * p.cap + (size_t)i;
+        const double weight = p.w[slot] / allwt;                      // FoamYade.C:312-314
+        p.w[slot] = weight;
+        const int64_t cl = (int64_t)p.ids[slot] - wd.cw.base;         // storage index (slab window)
+        if (cl < 0 || cl >= wd.cw.n_field) continue;
+        atomic_add_f64(&wd.pvol_acc[cl], pVol * weight);              // buildCellPartList FoamYade.C:265-288
+        atomic_add_f64(&wd.up_acc[3 * (size_t)cl + 0], (weight * vx) * pVol);
+        atomic_add_f64(&wd.up_acc[3 * (size_t)cl + 1], (weight * vy) * pVol);
+        atomic_add_f64(&wd.up_acc[3 * (size_t)cl + 2], (weight * vz) * pVol);
+        wd.touched[cl] = 1;
+    }
+}
+
 template <bool IMPLICIT>
 __global__ __launch_bounds__(kWave) void k_locate(const KdNode* __restrict__ tree, const uint32_t* __restrict__ packed, ImplicitGeom ig,
                                                   int32_t n_cells, ParticleSoA p, int64_t n, double maxdist,
                                                   const unsigned long long* __restrict__ start, SlabOwn own,
-                                                  const int32_t* __restrict__ work, const unsigned int* __restrict__ work_n) {
+                                                  const int32_t* __restrict__ work, const unsigned int* __restrict__ work_n, WalkDeposit wd) {
     typedef typename StackEntry<IMPLICIT>::type entry_t;
     extern __shared__ __attribute__((aligned(16))) unsigned char stack_raw[];
     entry_t* stack = reinterpret_cast<entry_t*>(stack_raw);
@@ -460,7 +493,7 @@ __global__ __launch_bounds__(kWave) void k_locate(const KdNode* __restrict__ tre
                 for (int attempt = 0; attempt < 2; ++attempt) {
                     if (nn != 0) break;
                     if (sp == 0) {
-                        if (active) { p.chain_len[i] = chain; active = false; }    // walk finished; k = min(chain, 16)
+                        if (active) { p.chain_len[i] = chain; active = false; if (wd.pvol_acc) walk_deposit(p, i, chain, wd); }    // walk finished; k = min(chain, 16)
                         break;
                     }
                     --sp;
@@ -788,8 +821,12 @@ __device__ __forceinline__ void deposit_pair(uint32_t* keys, double* vals, int32
                                              double* __restrict__ pvol_acc, double* __restrict__ up_acc, unsigned char* __restrict__ touched) {
     const int h = agg_slot<kDepLog2>(keys, (uint32_t)cid);
     if (h >= 0) {
-        lds_add_f64(&vals[4 * h], c0); lds_add_f64(&vals[4 * h + 1], c1);
-        lds_add_f64(&vals[4 * h + 2], c2); lds_add_f64(&vals[4 * h + 3], c3);
+        // the LDS atomic unit (~1.4 ds_add_f64 lanes per clock per CU, tools/micro/lds_atomic_rate.hip) is what bounds this half of the
+        // kernel: adding an exact zero is the identity, so the momentum terms of a particle at rest are not issued at all
+        lds_add_f64(&vals[4 * h], c0);
+        if (c1 != 0.0) lds_add_f64(&vals[4 * h + 1], c1);
+        if (c2 != 0.0) lds_add_f64(&vals[4 * h + 2], c2);
+        if (c3 != 0.0) lds_add_f64(&vals[4 * h + 3], c3);
     } else {
         deposit_direct(cid, c0, c1, c2, c3, pvol_acc, up_acc, touched);
     }
@@ -927,7 +964,11 @@ __global__ __launch_bounds__(kDepThreads) void k_locate_deposit(LocateLists ll, 
                         if (d < best) {                      // meshTree.C:192
                             best = d;
                             if (d < gp.maxdist && !(code & kListNoEmit)) {       // meshTree.C:195; the root is never pushed
+#if defined(FY_EXP_LD_NOEXP)
+                                wt[h] = (1.0 - d / gp.two_sigma2) * gp.range_cu * gp.sigma_pi;
+#else
                                 wt[h] = exp(-d / gp.two_sigma2) * gp.range_cu * gp.sigma_pi;     // FoamYade.C:308
+#endif
                                 emitted |= 1u << h;
                             }
                         }
@@ -953,11 +994,19 @@ __global__ __launch_bounds__(kDepThreads) void k_locate_deposit(LocateLists ll, 
                             const int32_t id = ni + ig.nx * (nj + ig.ny * nk);
                             const double weight = wt[h] / allwt;                      // FoamYade.C:312-314
                             const size_t slot = (size_t)(pos & (kMaxK - 1)) * p.cap + (size_t)i;
+#if !defined(FY_EXP_LD_NOSTORE)
                             p.ids[slot] = id;
                             p.w[slot] = weight;
+#else
+                            if (weight == 1.2345e300) p.w[slot] = weight;
+#endif
                             ++pos;
                             const int64_t cl = (int64_t)id - cw.base;                 // storage index (slab window)
+#if defined(FY_EXP_LD_NODEPOSIT)
+                            if (cl == -12345) {
+#else
                             if (cl >= 0 && cl < cw.n_field) {
+#endif
                                 const double c0 = pVol * weight, c1 = (weight * vx) * pVol, c2 = (weight * vy) * pVol, c3 = (weight * vz) * pVol;
                                 deposit_pair(keys, vals, (int32_t)cl, c0, c1, c2, c3, pvol_acc, up_acc, touched);
                             }
@@ -1429,11 +1478,11 @@ int launch_locate(hipStream_t s, const KdNode* tree, const uint32_t* packed, Imp
         hipLaunchKernelGGL(k_locate_lists, dim3(div_up(n, 256)), dim3(256), 0, s, ll, ig, p, n, gp.maxdist, own);
         FY_LAUNCH_CHECK();
         const dim3 wgrid((unsigned)std::min<int64_t>(div_up(n, kLocPPB), 2048));
-        hipLaunchKernelGGL(k_locate<true>, wgrid, dim3(kWave), lds, s, tree, packed, ig, n_cells, p, n, gp.maxdist, start, SlabOwn{}, ll.fb_list, ll.fb_count);
+        hipLaunchKernelGGL(k_locate<true>, wgrid, dim3(kWave), lds, s, tree, packed, ig, n_cells, p, n, gp.maxdist, start, SlabOwn{}, ll.fb_list, ll.fb_count, WalkDeposit{});
     } else if (packed) {
-        hipLaunchKernelGGL(k_locate<true>, grid, dim3(kWave), lds, s, tree, packed, ig, n_cells, p, n, gp.maxdist, start, own, nullptr, nullptr);
+        hipLaunchKernelGGL(k_locate<true>, grid, dim3(kWave), lds, s, tree, packed, ig, n_cells, p, n, gp.maxdist, start, own, nullptr, nullptr, WalkDeposit{});
     } else {
-        hipLaunchKernelGGL(k_locate<false>, grid, dim3(kWave), lds, s, tree, packed, ig, n_cells, p, n, gp.maxdist, nullptr, own, nullptr, nullptr);
+        hipLaunchKernelGGL(k_locate<false>, grid, dim3(kWave), lds, s, tree, packed, ig, n_cells, p, n, gp.maxdist, nullptr, own, nullptr, nullptr, WalkDeposit{});
     }
     FY_LAUNCH_CHECK();
     return FY_OK;
@@ -1468,8 +1517,7 @@ int launch_locate_deposit(hipStream_t s, const KdNode* tree, const uint32_t* pac
     FY_HIP(hipMemsetAsync(ll.fb_count, 0, sizeof(unsigned int), s));
     hipLaunchKernelGGL(k_locate_deposit, dim3(div_up(n, kDepThreads)), dim3(kDepThreads), 0, s, ll, ig, p, n, gp, own, cw, pvol_acc, up_acc, touched, tb);
     FY_LAUNCH_CHECK();
-    // The leftovers (~5e-5 of the particles: within 8e-6 dx of a cell face) are two latency-bound launches, ~0.2 ms for a few hundred
-    // particles.  With a side stream they run beside whatever the caller enqueues next on `s` (the cell-record pack); the caller waits
+    // The leftovers (~5e-5 of the particles: within 8e-6 dx of a cell face) are one latency-bound launch (the walk, which also deposits for them).  With a side stream they run beside whatever the caller enqueues next on `s` (the cell-record pack); the caller waits
     // for side.join before anything reads the deposit.  Their few thousand contributions go out as plain atomics (no tile buckets).
     hipStream_t w = s;
     if (side.stream) {
@@ -1479,10 +1527,8 @@ int launch_locate_deposit(hipStream_t s, const KdNode* tree, const uint32_t* pac
     }
     const size_t lds = (size_t)(levels + 1) * kWave * sizeof(unsigned long long);
     const dim3 wgrid((unsigned)std::min<int64_t>(div_up(n, kLocPPB), 2048));
-    hipLaunchKernelGGL(k_locate<true>, wgrid, dim3(kWave), lds, w, tree, packed, ig, n_cells, p, n, gp.maxdist, start, SlabOwn{}, ll.fb_list, ll.fb_count);
-    FY_LAUNCH_CHECK();
-    const dim3 dgrid((unsigned)std::min<int64_t>(div_up(n, kDepThreads), 64));
-    hipLaunchKernelGGL(k_deposit, dgrid, dim3(kDepThreads), 0, w, p, n, gp, cw, pvol_acc, up_acc, touched, ll.fb_list, ll.fb_count, TileBuckets{});
+    hipLaunchKernelGGL(k_locate<true>, wgrid, dim3(kWave), lds, w, tree, packed, ig, n_cells, p, n, gp.maxdist, start, SlabOwn{}, ll.fb_list, ll.fb_count,
+                       WalkDeposit{gp, cw, pvol_acc, up_acc, touched});
     FY_LAUNCH_CHECK();
     if (side.stream) FY_HIP(hipEventRecord(side.join, side.stream));
     return FY_OK;
