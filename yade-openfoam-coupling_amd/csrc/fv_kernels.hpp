@@ -62,7 +62,7 @@ int launch_courant(hipStream_t s, FvGeo g, CFace3 phi, double* partials);       
 // write_pfields = 0 skips gradP / divT (pimple only); ddtU != nullptr: also ddtU_f = fvc::div(phi, U) (pimpleFoamYade.C:73)
 int launch_pre_coupling(hipStream_t s, FvGeo g, const double* U, const double* p, const double* alpha, CFace3 psn,
                         double* vGrad, double* gradP, double* divT, double* Gout, int write_vgrad, int write_pfields,
-                        CFace3 phi = CFace3{}, double* ddtU = nullptr);
+                        CFace3 phi = CFace3{}, double* ddtU = nullptr, double* Uold_out = nullptr);
 int launch_interp_alpha(hipStream_t s, FvGeo g, const double* alpha, Face3 alphaf);
 // G: three vec3 fields (rows of the tensor) over the whole storage, as k_pre_coupling writes them
 int launch_div_G(hipStream_t s, FvGeo g, const double* G, double* divG);

@@ -628,7 +628,8 @@ struct Solver {
         FY_TRY(halo_cells(p, 1, 1));
         FY_TRY(halo_cells(alpha, 1, 1));
         FY_TRY(comm->group_end(stream));
-        FY_TRY(launch_copy_f64(stream, Uold.p, U.p, 3 * nstore));
+        const bool fuse_uold = comm->size == 1;        // single domain: U.oldTime() is written by the pre-coupling sweep that reads U anyway
+        if (!fuse_uold) FY_TRY(launch_copy_f64(stream, Uold.p, U.p, 3 * nstore));
         // phi.oldTime(): the flux arrays trade places instead of being copied -- what was phi is phiOld now, and until the first
         // flux correction of this step rewrites phi (every face of it) the current flux is read from phiOld (phi_now())
         if (cs.n_correctors > 0) {
@@ -643,7 +644,7 @@ struct Solver {
         const unsigned fm = cpl->c.force_models;
         const bool want_vgrad = !pimple || (fm & FY_FORCE_GAUSSIAN_TORQUE), want_ddtU = pimple && (fm & FY_FORCE_ADDED_MASS);
         FY_TRY(launch_pre_coupling(stream, g, U.p, p.p, alpha.p, C3(psn), vGrad.p, gradP.p, divT.p, nullptr, want_vgrad ? 1 : 0, 1, phi_now(),
-                                   want_ddtU ? ddtU.p : nullptr));
+                                   want_ddtU ? ddtU.p : nullptr, fuse_uold ? Uold.p : nullptr));
 
         if (timing) tim[0].start(stream);
         if (g.gz > 1) {                      // the particle gathers reach gz planes into the neighbours
