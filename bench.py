@@ -350,6 +350,9 @@ def main():
     ap.add_argument("--config", default="c3", choices=["c3", "c2"], help="c3: BASELINE configs[2] (the metric's configuration); c2: configs[1] at full size")
     ap.add_argument("--wire", type=int, default=2, help="steps of the drop-in (host-buffer / fake-Yade) leg after the timed region, 0 = skip")
     ap.add_argument("--wire-workers", type=int, default=4)
+    ap.add_argument("--moving", action="store_true", help="not the BASELINE configuration: particles carry random velocities (+-0.05 m/s) and are displaced by "
+                    "~0.1 dx per step (alternating random offsets, applied between the steps inside the timed region), so that the momentum deposit, "
+                    "the re-bin amortisation and the pressure solver see a cloud that changes from step to step")
     ap.add_argument("--strong", action="store_true", help="N > 1: cut the ONE C3 box into N slabs (BASELINE configs[3]) instead of growing it (weak, the default)")
     ap.add_argument("--force-rccl", action="store_true", help="use the RCCL communicator even with one rank (smoke test of the RCCL path)")
     ap.add_argument("--rccl-selftest", default="", help=argparse.SUPPRESS)     # child mode: hex of the 128-byte RCCL id (see rccl_preflight)
@@ -448,10 +451,23 @@ def main():
     for _ in range(args.warmup):
         solver.step()
     solver.enable_kernel_timing(True)
+    warm_moving = args.moving
     acc = dict(particle=0.0, locate_deposit=0.0, force=0.0, bin=0.0, finalize=0.0, fold=0.0, momentum=0.0, pressure=0.0, other=0.0, p_iters=0, u_iters=0)
+    jitter = None
+    if args.moving:
+        gj = torch.Generator(device="cpu").manual_seed(77)
+        dxm = 0.01 if c2 else 1.0 / args.n
+        jitter = ((torch.rand(rec.shape[0], 3, dtype=torch.float64, generator=gj) - 0.5) * 0.2 * dxm).to(dev)
+        rec[:, 3:6] = ((torch.rand(rec.shape[0], 3, dtype=torch.float64, generator=gj) - 0.5) * 0.1).to(dev)
+    if warm_moving:                                         # the displacement kernels load on first use: not in the timed region
+        for it_ in range(2):
+            rec[:, 0:3] += jitter if it_ % 2 == 0 else -jitter
+            solver.step()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for it_ in range(args.steps):
+        if jitter is not None:
+            rec[:, 0:3] += jitter if it_ % 2 == 0 else -jitter
         solver.step()
         st = solver.stats(); ct = solver.coupling_timings()
         acc["particle"] += st["ms_particle"]; acc["momentum"] += st["ms_momentum"]; acc["pressure"] += st["ms_pressure"]; acc["other"] += st["ms_other"]
@@ -530,7 +546,7 @@ def main():
         "metric": metric,
         "value": round(steps_per_s, 4), "unit": "steps/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
         "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
-        "dtype": "f64", "data": "synthetic",
+        "dtype": "f64", "data": "synthetic" + (" (MOVING cloud: not the BASELINE configuration, see --moving)" if args.moving else ""),
         "particle_steps_per_sec": round(steps_per_s * (args.particles if strong else np_part), 1),
         "coupled_steps_per_sec_of_the_whole_box": round(steps_per_s if strong else steps_per_s / world, 4),
         "config": {"workload": workload,

@@ -596,9 +596,16 @@ struct Fv {
         }
     }
 
+    // The smoother.  Two sweeps as a pair are the degree-2 Chebyshev polynomial of D^-1 A on [1/3, 2] -- the high-frequency band of the
+    // 7-point operator under 2 x 2 x 2 coarsening, 2 bounding every diagonally dominant level -- i.e. Jacobi with the weights
+    // 1 / (7/6 -+ (5/6) cos(pi/4)): the pair damps that band by 0.34 where two sweeps at the fixed weight 0.8 reach 0.54, for the same
+    // work.  Pre-smoothing applies (kMgWa, kMgWb), post-smoothing the reverse order (the adjoint; the V-cycle stays a symmetric
+    // positive definite preconditioner).  The 40 sweeps of the coarsest level keep the fixed weight.  Same constants as the product.
+    static constexpr double kMgWa = 1.7318685872766142, kMgWb = 0.5695012757370842;
     static void jacobi(const MgLevel& L, vec& x, const vec& b, vec& tmp, int sweeps, bool zero_guess, int threads) {
-        const double w = 0.8;
         for (int s = 0; s < sweeps; ++s) {
+            double w = 0.8;
+            if (sweeps == 2) w = zero_guess ? (s == 0 ? kMgWa : kMgWb) : (s == 0 ? kMgWb : kMgWa);
             if (s == 0 && zero_guess) { for (int c = 0; c < L.N; ++c) x[c] = w * b[c] / L.diag[c]; continue; }
             apply(L, x, tmp, threads);
             for (int c = 0; c < L.N; ++c) x[c] += w * (b[c] - tmp[c]) / L.diag[c];

@@ -937,7 +937,7 @@ __global__ __launch_bounds__(256) void k_mg_smooth_first(PMat A, const double* _
 
 // smooth_first + one smooth in a single pass (non-distributed levels >= 1, which are launch-latency bound): the neighbours' first iterate
 // x1 = w b / diag is recomputed inline instead of being stored and re-read -- the same operations on the same operands, so x2 is bit-identical
-__global__ __launch_bounds__(256) void k_mg_smooth_two_from_zero(PMat A, const double* __restrict__ b, double* __restrict__ xn, double w) {
+__global__ __launch_bounds__(256) void k_mg_smooth_two_from_zero(PMat A, const double* __restrict__ b, double* __restrict__ xn, double w, double w2) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= A.N) return;
     const int c = t + A.c0;
@@ -955,7 +955,7 @@ __global__ __launch_bounds__(256) void k_mg_smooth_two_from_zero(PMat A, const d
     a = (c + sy < A.ntot) ? a - t3 : a;
     a = (c >= sz) ? a - t4 : a;
     a = (c + sz < A.ntot) ? a - t5 : a;
-    xn[c] = x1c + w * (bc - a) / dc;
+    xn[c] = x1c + w2 * (bc - a) / dc;
 }
 
 // the last level-0 sweep of a V-cycle used as PCG preconditioner: z = xn, and PCG wants z.r next -- r is this level's b, already in a
@@ -1039,7 +1039,7 @@ struct MgTail {
     double* b[kMgTailMax];
 };
 
-__global__ __launch_bounds__(1024) void k_mg_tail(MgTail T, double w, int coarse_sweeps) {
+__global__ __launch_bounds__(1024) void k_mg_tail(MgTail T, double w, int coarse_sweeps, double wa, double wb) {
     const int tid = threadIdx.x;
     // ---- down: smooth_first, smooth, residual -> restricted rhs of the next level
     for (int l = 0; l + 1 < T.n; ++l) {
@@ -1047,9 +1047,9 @@ __global__ __launch_bounds__(1024) void k_mg_tail(MgTail T, double w, int coarse
         const double* b = T.b[l];
         double* xa = T.x0[l];
         double* xb = T.x1[l];
-        for (int c = tid; c < A.N; c += 1024) xa[c] = w * b[c] / A.diag[c];
+        for (int c = tid; c < A.N; c += 1024) xa[c] = wa * b[c] / A.diag[c];
         __syncthreads();
-        for (int c = tid; c < A.N; c += 1024) xb[c] = xa[c] + w * (b[c] - p_row(A, xa, c)) / A.diag[c];
+        for (int c = tid; c < A.N; c += 1024) xb[c] = xa[c] + wb * (b[c] - p_row(A, xa, c)) / A.diag[c];
         __syncthreads();
         const PMat Cc = T.A[l + 1];
         double* bc = T.b[l + 1];
@@ -1153,9 +1153,9 @@ __global__ __launch_bounds__(1024) void k_mg_tail(MgTail T, double w, int coarse
             xb[c] += xc[(i >> 1) + Cc.nx * ((j >> 1) + Cc.ny * (k >> 1))];
         }
         __syncthreads();
-        for (int c = tid; c < A.N; c += 1024) xa[c] = xb[c] + w * (b[c] - p_row(A, xb, c)) / A.diag[c];
+        for (int c = tid; c < A.N; c += 1024) xa[c] = xb[c] + wb * (b[c] - p_row(A, xb, c)) / A.diag[c];
         __syncthreads();
-        for (int c = tid; c < A.N; c += 1024) xb[c] = xa[c] + w * (b[c] - p_row(A, xa, c)) / A.diag[c];
+        for (int c = tid; c < A.N; c += 1024) xb[c] = xa[c] + wa * (b[c] - p_row(A, xa, c)) / A.diag[c];
         __syncthreads();
     }
 }
@@ -1396,8 +1396,8 @@ int launch_mg_smooth_first(hipStream_t s, PMat A, const double* b, double* x, do
     return FY_OK;
 }
 
-int launch_mg_smooth_two_from_zero(hipStream_t s, PMat A, const double* b, double* xn, double w) {
-    hipLaunchKernelGGL(k_mg_smooth_two_from_zero, dim3(div_up(A.N, 256)), dim3(256), 0, s, A, b, xn, w);
+int launch_mg_smooth_two_from_zero(hipStream_t s, PMat A, const double* b, double* xn, double w, double w2) {
+    hipLaunchKernelGGL(k_mg_smooth_two_from_zero, dim3(div_up(A.N, 256)), dim3(256), 0, s, A, b, xn, w, w2);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }
@@ -1414,7 +1414,7 @@ int launch_mg_smooth(hipStream_t s, PMat A, const double* b, const double* x, do
     return FY_OK;
 }
 
-int launch_mg_tail(hipStream_t s, const PMat* A, double* const* x0, double* const* x1, double* const* b, int n, double w, int coarse_sweeps) {
+int launch_mg_tail(hipStream_t s, const PMat* A, double* const* x0, double* const* x1, double* const* b, int n, double w, int coarse_sweeps, double wa, double wb) {
     if (n < 1 || n > kMgTailMax) return fail(FY_ERR_INVALID, "bad multigrid tail depth %d", n);
     MgTail T;
     T.n = n;
@@ -1422,7 +1422,7 @@ int launch_mg_tail(hipStream_t s, const PMat* A, double* const* x0, double* cons
         if (A[l].c0 != 0) return fail(FY_ERR_INVALID, "multigrid tail levels must not carry ghost planes");
         T.A[l] = A[l]; T.x0[l] = x0[l]; T.x1[l] = x1[l]; T.b[l] = b[l];
     }
-    hipLaunchKernelGGL(k_mg_tail, dim3(1), dim3(1024), 0, s, T, w, coarse_sweeps);
+    hipLaunchKernelGGL(k_mg_tail, dim3(1), dim3(1024), 0, s, T, w, coarse_sweeps, wa, wb);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }

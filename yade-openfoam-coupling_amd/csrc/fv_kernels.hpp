@@ -102,7 +102,7 @@ int launch_pcg_update_xr(hipStream_t s, int n, int c0, double* x, double* r, con
 int launch_jacobi_precond(hipStream_t s, PMat A, const double* r, double* z);
 int launch_mg_coarsen(hipStream_t s, PMat F, PMat C);
 int launch_mg_smooth_first(hipStream_t s, PMat A, const double* b, double* x, double w);                   // x = w b / diag
-int launch_mg_smooth_two_from_zero(hipStream_t s, PMat A, const double* b, double* xn, double w);      // smooth_first + smooth fused (bit-identical)
+int launch_mg_smooth_two_from_zero(hipStream_t s, PMat A, const double* b, double* xn, double w, double w2);      // smooth_first(w) + smooth(w2) fused (bit-identical)
 int launch_mg_smooth(hipStream_t s, PMat A, const double* b, const double* x, double* xn, double w);
 // the same sweep + the block partials of xn . b (slot 0), what launch_dot(xn, b) would leave there
 int launch_mg_smooth_dot(hipStream_t s, PMat A, const double* b, const double* x, double* xn, double w, double* partials);      // xn = x + w (b - A x)/diag
@@ -112,7 +112,7 @@ int launch_mg_coarse_solve(hipStream_t s, PMat A, const double* b, double* x, do
 // the whole V-cycle below a size threshold in one workgroup; level l result: x1[l] (x0 for the coarsest / a single-level tail)
 constexpr int kMgTailMax = 6;
 constexpr int kMgTailCells = 1024;   // measured: at 8000 cells one workgroup (137 us) is SLOWER than the ~20 separate launches it replaces
-int launch_mg_tail(hipStream_t s, const PMat* A, double* const* x0, double* const* x1, double* const* b, int n, double w, int coarse_sweeps);
+int launch_mg_tail(hipStream_t s, const PMat* A, double* const* x0, double* const* x1, double* const* b, int n, double w, int coarse_sweeps, double wa, double wb);
 
 int launch_copy_f64(hipStream_t s, double* dst, const double* src, size_t n);
 int launch_relax_field(hipStream_t s, double* x, const double* prev, double alpha, size_t n);   // x = prev + alpha (x - prev)
