@@ -1039,7 +1039,7 @@ struct MgTail {
     double* b[kMgTailMax];
 };
 
-__global__ __launch_bounds__(1024) void k_mg_tail(MgTail T, double w, int coarse_sweeps, double wa, double wb) {
+__global__ __launch_bounds__(1024) void k_mg_tail(MgTail T, double w, int coarse_sweeps, MgWeights W) {
     const int tid = threadIdx.x;
     // ---- down: smooth_first, smooth, residual -> restricted rhs of the next level
     for (int l = 0; l + 1 < T.n; ++l) {
@@ -1047,10 +1047,14 @@ __global__ __launch_bounds__(1024) void k_mg_tail(MgTail T, double w, int coarse
         const double* b = T.b[l];
         double* xa = T.x0[l];
         double* xb = T.x1[l];
-        for (int c = tid; c < A.N; c += 1024) xa[c] = wa * b[c] / A.diag[c];
+        for (int c = tid; c < A.N; c += 1024) xa[c] = W.w[0] * b[c] / A.diag[c];
         __syncthreads();
-        for (int c = tid; c < A.N; c += 1024) xb[c] = xa[c] + wb * (b[c] - p_row(A, xa, c)) / A.diag[c];
-        __syncthreads();
+        for (int s = 1; s < W.n; ++s) {                       // the iterate alternates between x0 and x1; W.n is even, so it ends in x1
+            for (int c = tid; c < A.N; c += 1024) xb[c] = xa[c] + W.w[s] * (b[c] - p_row(A, xa, c)) / A.diag[c];
+            __syncthreads();
+            double* t = xa; xa = xb; xb = t;
+        }
+        { double* t = xa; xa = xb; xb = t; }                  // xb = the level's iterate (x1), xa the scratch (x0)
         const PMat Cc = T.A[l + 1];
         double* bc = T.b[l + 1];
         for (int cc = tid; cc < Cc.N; cc += 1024) {
@@ -1153,10 +1157,11 @@ __global__ __launch_bounds__(1024) void k_mg_tail(MgTail T, double w, int coarse
             xb[c] += xc[(i >> 1) + Cc.nx * ((j >> 1) + Cc.ny * (k >> 1))];
         }
         __syncthreads();
-        for (int c = tid; c < A.N; c += 1024) xa[c] = xb[c] + wb * (b[c] - p_row(A, xb, c)) / A.diag[c];
-        __syncthreads();
-        for (int c = tid; c < A.N; c += 1024) xb[c] = xa[c] + wa * (b[c] - p_row(A, xa, c)) / A.diag[c];
-        __syncthreads();
+        for (int s = W.n - 1; s >= 0; --s) {                  // post-smoothing: the weights in reverse; W.n even: the result is back in x1
+            for (int c = tid; c < A.N; c += 1024) xa[c] = xb[c] + W.w[s] * (b[c] - p_row(A, xb, c)) / A.diag[c];
+            __syncthreads();
+            double* t = xa; xa = xb; xb = t;
+        }
     }
 }
 
@@ -1414,7 +1419,7 @@ int launch_mg_smooth(hipStream_t s, PMat A, const double* b, const double* x, do
     return FY_OK;
 }
 
-int launch_mg_tail(hipStream_t s, const PMat* A, double* const* x0, double* const* x1, double* const* b, int n, double w, int coarse_sweeps, double wa, double wb) {
+int launch_mg_tail(hipStream_t s, const PMat* A, double* const* x0, double* const* x1, double* const* b, int n, double w, int coarse_sweeps, MgWeights W) {
     if (n < 1 || n > kMgTailMax) return fail(FY_ERR_INVALID, "bad multigrid tail depth %d", n);
     MgTail T;
     T.n = n;
@@ -1422,7 +1427,8 @@ int launch_mg_tail(hipStream_t s, const PMat* A, double* const* x0, double* cons
         if (A[l].c0 != 0) return fail(FY_ERR_INVALID, "multigrid tail levels must not carry ghost planes");
         T.A[l] = A[l]; T.x0[l] = x0[l]; T.x1[l] = x1[l]; T.b[l] = b[l];
     }
-    hipLaunchKernelGGL(k_mg_tail, dim3(1), dim3(1024), 0, s, T, w, coarse_sweeps, wa, wb);
+    if (W.n < 2 || (W.n & 1)) return fail(FY_ERR_INVALID, "the multigrid tail needs an even number of smoothing sweeps");
+    hipLaunchKernelGGL(k_mg_tail, dim3(1), dim3(1024), 0, s, T, w, coarse_sweeps, W);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }

@@ -112,7 +112,8 @@ int launch_mg_coarse_solve(hipStream_t s, PMat A, const double* b, double* x, do
 // the whole V-cycle below a size threshold in one workgroup; level l result: x1[l] (x0 for the coarsest / a single-level tail)
 constexpr int kMgTailMax = 6;
 constexpr int kMgTailCells = 1024;   // measured: at 8000 cells one workgroup (137 us) is SLOWER than the ~20 separate launches it replaces
-int launch_mg_tail(hipStream_t s, const PMat* A, double* const* x0, double* const* x1, double* const* b, int n, double w, int coarse_sweeps, double wa, double wb);
+struct MgWeights { int n; double w[4]; };      // the smoother's Jacobi weights per sweep (pre-smoothing order; post-smoothing runs them backwards)
+int launch_mg_tail(hipStream_t s, const PMat* A, double* const* x0, double* const* x1, double* const* b, int n, double w, int coarse_sweeps, MgWeights W);
 
 int launch_copy_f64(hipStream_t s, double* dst, const double* src, size_t n);
 int launch_relax_field(hipStream_t s, double* x, const double* prev, double alpha, size_t n);   // x = prev + alpha (x - prev)

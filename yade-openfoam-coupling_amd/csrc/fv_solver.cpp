@@ -434,10 +434,15 @@ struct Solver {
     // weights 1 / (7/6 -+ (5/6) cos(pi/4)).  The pair damps that band by 0.34 where two sweeps at the fixed weight 0.8 reach 0.54, for
     // the same memory traffic: PCG iterations 66 -> 48 on a moving 48^3 bed, 19 -> 14 on the manufactured Poisson problem (CPU oracle).
     // Pre-smoothing applies (wa, wb), post-smoothing the reverse order (its adjoint: the V-cycle stays a symmetric positive definite
-    // preconditioner).  The 40 sweeps of the coarsest level keep the fixed weight.
+    // preconditioner).  The 40 sweeps of the coarsest level keep the fixed weight.  Degree 4 (four sweeps each way, weights 2.520 /
+    // 1.180 / 0.673 / 0.516) was measured too: fewer iterations (C3 2.6 -> 2.1 per step, moving bed 5.75 -> 4.2, C2 7.5 -> 5.3) but every
+    // one of the three cases slower in time (7.40 -> 7.56, 9.55 -> 9.73, 2.35 -> 2.51 ms per step): the four extra sweeps cost more
+    // than the iterations they save.
     static constexpr double kMgWa = 1.7318685872766142, kMgWb = 0.5695012757370842;
+    MgWeights mgw{2, {kMgWa, kMgWb, 0, 0}};
     int vcycle(size_t l) {
-        const double w = 0.8, wa = kMgWa, wb = kMgWb;
+        const double w = 0.8;
+        const MgWeights& W = mgw;
         MgLev& L = *mg[l];
         if (!L.distributed && L.A.N <= kMgTailCells && mg.size() - l <= (size_t)kMgTailMax) {
             // the rest of the hierarchy fits one workgroup: one launch instead of ~8 per level (b of this level is already in place)
@@ -447,7 +452,7 @@ struct Solver {
                 MgLev& M = *mg[l + (size_t)q];
                 A[q] = M.A; x0[q] = M.x0.p; x1[q] = M.x1.p; b[q] = q == 0 ? const_cast<double*>(L.bptr) : M.b.p;
             }
-            FY_TRY(launch_mg_tail(stream, A, x0, x1, b, n, w, 40, wa, wb));
+            FY_TRY(launch_mg_tail(stream, A, x0, x1, b, n, w, 40, W));
             L.xcur = n > 1 ? L.x1.p : L.x0.p; L.xalt = n > 1 ? L.x0.p : L.x1.p;
             return FY_OK;
         }
@@ -460,11 +465,12 @@ struct Solver {
         if (!L.distributed) {
             // first iterate and first sweep in one pass (bit-identical, see the kernel): one launch fewer on the latency-bound small
             // levels, and on level 0 the first iterate never travels through memory (pressure 2.25 -> 2.21 ms)
-            FY_TRY(launch_mg_smooth_two_from_zero(stream, L.A, L.bptr, L.xcur, wa, wb));
+            FY_TRY(launch_mg_smooth_two_from_zero(stream, L.A, L.bptr, L.xcur, W.w[0], W.w[1]));
         } else {
-            FY_TRY(launch_mg_smooth_first(stream, L.A, L.bptr, L.xcur, wa));
-            FY_TRY(smooth(l, L, wb));
+            FY_TRY(launch_mg_smooth_first(stream, L.A, L.bptr, L.xcur, W.w[0]));
+            FY_TRY(smooth(l, L, W.w[1]));
         }
+        for (int s = 2; s < W.n; ++s) FY_TRY(smooth(l, L, W.w[s]));
         FY_TRY(halo_level(L, L.xcur));
         const bool handover = L.distributed && !Cc.distributed;
         if (handover) {
@@ -484,10 +490,10 @@ struct Solver {
         } else {
             FY_TRY(launch_mg_prolong_add(stream, L.A, L.xcur, Cc.A, Cc.xcur));
         }
-        FY_TRY(smooth(l, L, wb));
+        for (int s = W.n - 1; s >= 1; --s) FY_TRY(smooth(l, L, W.w[s]));
         // the last sweep of the whole cycle also leaves the partials of z.r where PCG's launch_dot would (vcycle_dot_done)
         vcycle_dot_done = l == 0 && want_vcycle_dot && !L.distributed && L.A.N == Nc && L.A.c0 == g.c0;
-        FY_TRY(smooth(l, L, wa, vcycle_dot_done));
+        FY_TRY(smooth(l, L, W.w[0], vcycle_dot_done));
         return FY_OK;
     }
     bool want_vcycle_dot = false, vcycle_dot_done = false;
