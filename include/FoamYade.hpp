@@ -45,6 +45,7 @@ public:
 
     void setScalarProperties(double rhoP, double rhoF, double nu) { check(fy_set_scalar_properties(ctx_, rhoP, rhoF, nu)); }   // FoamYade.C:9-11
     void setParticleAction(double dt) { check(fy_set_particle_action(ctx_, dt)); }                                               // FoamYade.C:605-632
+    int finalizeRun() { int v = -1; check(fy_finalize_run(ctx_, &v)); return v; }     // FoamYade.C:595-599: 10 = the caller finalizes MPI
     void setSourceZero() { check(fy_set_source_zero(ctx_)); }                                                                    // FoamYade.C:556-566
     // opt-in: the two force models the reference carries without a call site (FoamYade.C:392-413, 465-479); default off = shipped behaviour
     void setForceModels(unsigned flags) { check(fy_set_force_models(ctx_, flags)); }

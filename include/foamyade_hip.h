@@ -115,6 +115,9 @@ int fy_set_force_models(fy_ctx*, unsigned flags);
 int fy_set_particle_action(fy_ctx*, double dt);
 /* FoamYade::setSourceZero FoamYade.C:556-566 */
 int fy_set_source_zero(fy_ctx*);
+/* FoamYade::finalizeRun (FoamYade.C:595-599; declared FoamYade.H:159, never called by the two solvers): the value Yade's rank 0 broadcasts over
+   the world communicator; 10 means "finalize MPI now" -- which the caller does, the library does not own the MPI session */
+int fy_finalize_run(fy_ctx*, int* value_out);
 /* FoamYade::~FoamYade FoamYade.H:160 */
 int fy_destroy(fy_ctx*);
 

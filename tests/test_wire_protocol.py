@@ -76,6 +76,8 @@ class FakeYade:
             out[:] = self.records[self.step].shape[0]
         elif self.bcast_stage == 1:
             out[:] = self.records[self.step].ravel()
+        elif self.bcast_stage >= 99:
+            out[:] = self.finalize_value               # finalizeRun
         else:
             out[:] = 1.25e-5 * (self.step + 1)          # yadeDT
         self.bcast_stage += 1
@@ -171,6 +173,10 @@ def test_wire_protocol_matches_reference(product, name):
             np.testing.assert_allclose(mut[nm], ref, rtol=gu.RTOL_GPU, atol=gu.RTOL_GPU * 1e-3 * sc)
         fy.setSourceZero()
         yade.next_step()
+    # FoamYade::finalizeRun (FoamYade.C:595-599): one int broadcast from Yade's rank 0 over the world communicator; 10 = finalize
+    yade.log.clear(); yade.bcast_stage = 99; yade.finalize_value = 10
+    assert fy.finalizeRun() == 10
+    assert yade.log == [("bcast_world", 1, 0, 0, -1)]
     fy.close()
 
 

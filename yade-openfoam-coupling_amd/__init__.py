@@ -128,6 +128,7 @@ def lib():
     L.fy_set_particle_action.argtypes = [vp, C.c_double]
     L.fy_set_force_models.argtypes = [vp, C.c_uint]
     L.fy_set_source_zero.argtypes = [vp]
+    L.fy_finalize_run.argtypes = [vp, C.POINTER(C.c_int)]
     L.fy_destroy.argtypes = [vp]
     L.fy_set_num_batches.argtypes = [vp, C.c_int]
     L.fy_set_particles_host.argtypes = [vp, C.c_int, _dp, C.c_int64]
@@ -297,6 +298,12 @@ class FoamYade:
 
     def setSourceZero(self):
         _check(lib().fy_set_source_zero(self._h))
+
+    def finalizeRun(self):
+        """FoamYade::finalizeRun (FoamYade.C:595-599): the value Yade's rank 0 broadcasts (10: finalize MPI)"""
+        v = C.c_int(-1)
+        _check(lib().fy_finalize_run(self._h, C.byref(v)))
+        return v.value
 
     # ---- direct mode (no Yade peer)
     def setParticles(self, batches):

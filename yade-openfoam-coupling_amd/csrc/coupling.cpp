@@ -962,6 +962,14 @@ int fy_set_scalar_properties(fy_ctx* c, double rhoP, double rhoF, double nu) { F
 int fy_set_force_models(fy_ctx* c, unsigned flags) { FY_CTX(c); return c->c.set_force_models(flags); }
 int fy_set_particle_action(fy_ctx* c, double dt) { FY_CTX(c); return c->c.set_particle_action(dt); }
 int fy_set_source_zero(fy_ctx* c) { FY_CTX(c); return c->c.set_source_zero(); }
+int fy_finalize_run(fy_ctx* c, int* value_out) {
+    FY_CTX(c);
+    int value = -1;                                                         // FoamYade.C:596
+    if (c->c.has_transport && c->c.transport.bcast_world(c->c.transport.user, &value, 1, FY_T_INT, 0) != 0)
+        return fy::fail(FY_ERR_TRANSPORT, "fy_finalize_run: broadcast failed");
+    if (value_out) *value_out = value;
+    return FY_OK;
+}
 int fy_destroy(fy_ctx* c) { delete c; return FY_OK; }
 int fy_set_num_batches(fy_ctx* c, int nb) {
     FY_CTX(c);
