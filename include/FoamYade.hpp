@@ -49,6 +49,11 @@ public:
     void setSourceZero() { check(fy_set_source_zero(ctx_)); }                                                                    // FoamYade.C:556-566
     // opt-in: the two force models the reference carries without a call site (FoamYade.C:392-413, 465-479); default off = shipped behaviour
     void setForceModels(unsigned flags) { check(fy_set_force_models(ctx_, flags)); }
+    void setFibreCoupling(bool on) { check(fy_set_fibre_coupling(ctx_, on ? 1 : 0)); fibreCpl = on; }   // FoamYade.H:102
+    bool fibreCpl = false;
+    // FoamYade.C:582-590: both are empty in the reference ("TODO", immediate return); kept so that callers compile unchanged
+    void calcHydroTimeScale() {}
+    void sendHydroTimeScale(void* /*yProc*/) {}
     double yadeDT() const { return fy_yade_dt(ctx_); }                                                                           // FoamYade.H:94
     fy_ctx* handle() { return ctx_; }
 

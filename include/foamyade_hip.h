@@ -110,6 +110,11 @@ int fy_set_scalar_properties(fy_ctx*, double rhoP, double rhoF, double nu);
 #define FY_FORCE_ADDED_MASS 1u
 #define FY_FORCE_GAUSSIAN_TORQUE 2u
 int fy_set_force_models(fy_ctx*, unsigned flags);
+/* FoamYade::fibreCpl (public flag, FoamYade.H:102; off by default and never set by the two solvers).  When on, Yade sends 15 doubles per
+ * particle instead of 10 (FoamYade.C:131-136 parallel, :161-165 serial) and the position is read with that stride (:194-198) while
+ * velocity, spin and radius are still read from buf[np*10+3..9] of the same buffer (:211-221) -- mirrored literally.  After this call
+ * fy_set_particles_host/_device take [n][15] records and the transport receives 15 n doubles.  Not available with z-slabs. */
+int fy_set_fibre_coupling(fy_ctx*, int on);
 /* FoamYade::setParticleAction FoamYade.C:605-632 (blocking).  On return alpha, uParticle, uSourceDrag, uSource hold
  * this step's values and (with a transport) found flags / forces / dt have been exchanged with Yade. */
 int fy_set_particle_action(fy_ctx*, double dt);

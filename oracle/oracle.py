@@ -124,12 +124,30 @@ class Mesh:
 FORCE_ADDED_MASS, FORCE_GAUSSIAN_TORQUE = 1, 2
 
 
+def fibre_narrow(records15, batch_off):
+    """The (n,10) records the reference actually uses when fibreCpl is set (FoamYade.H:102): every Yade proc's buffer holds 15
+    doubles per particle (FoamYade.C:131-136,161-165); the position is buf[np*15 + 0..2] (FoamYade.C:194-198) while velocity, spin
+    and radius stay buf[np*10 + 3..9] (FoamYade.C:211-221) -- indices into the same buffer, restated literally."""
+    wide = np.ascontiguousarray(records15, dtype=np.float64).reshape(-1, 15)
+    off = np.asarray(batch_off, dtype=np.int64)
+    out = np.empty((wide.shape[0], 10))
+    for b in range(len(off) - 1):
+        lo, hi = int(off[b]), int(off[b + 1])
+        buf = wide[lo:hi].reshape(-1)
+        for np_ in range(hi - lo):
+            out[lo + np_, 0:3] = buf[np_ * 15:np_ * 15 + 3]
+            out[lo + np_, 3:10] = buf[np_ * 10 + 3:np_ * 10 + 10]
+    return out
+
+
 def particle_action(mesh: Mesh, fields: dict, mutable: dict, records, batch_off, gaussian, rhoP, rhoF, nu, threads=1,
-                    force_models=0, dt=None):
+                    force_models=0, dt=None, fibre=False):
     """FoamYade::setParticleAction without MPI.  `mutable` arrays (alpha, uParticle, uSourceDrag, uSource) are
     updated in place.  returns dict(k, ids, w, chain_len, force, found).
     force_models != 0 additionally applies the reference's call-site-less models (FoamYade.C:392-413, 465-479) on top
     (needs fields["ddtU"] and dt for the added mass)."""
+    if fibre:
+        records = fibre_narrow(records, batch_off)
     records = np.ascontiguousarray(records, dtype=np.float64).reshape(-1, 10)
     n = records.shape[0]
     off = np.ascontiguousarray(batch_off, dtype=np.int32)

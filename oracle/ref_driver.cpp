@@ -12,7 +12,8 @@
 // World rank layout follows README.md:29 / FoamYade.C:28-43: Yade ranks first
 // (0 = Yade master, 1..W = workers), the single Foam rank last.
 //
-// DIR/meta.txt:  nx ny nz dx ox oy oz gaussian nYade nsteps rhoP rhoF nu dt gx gy gz
+// DIR/meta.txt:  nx ny nz dx ox oy oz gaussian nYade nsteps rhoP rhoF nu dt gx gy gz [fibre]
+//   fibre = 1 sets the public flag FoamYade::fibreCpl (FoamYade.H:102); the records files then hold Np*15 doubles (FoamYade.C:131-136)
 // DIR/records_s<step>.bin : Np*10 doubles  [x y z vx vy vz wx wy wz radius]  (FoamYade.C:190-219)
 // DIR/{U,gradP,divT,ddtU}.bin : Nc*3 doubles ; DIR/vGrad.bin : Nc*9 doubles
 #include "FoamYade.H"
@@ -32,6 +33,8 @@ namespace {
 struct Meta {
     int nx, ny, nz; double dx, ox, oy, oz; int gaussian, nYade, nsteps;
     double rhoP, rhoF, nu, dt, gx, gy, gz;
+    int fibre = 0;
+    int stride() const { return fibre ? 15 : 10; }
 };
 
 Meta read_meta(const std::string& dir) {
@@ -40,6 +43,7 @@ Meta read_meta(const std::string& dir) {
     Meta m;
     f >> m.nx >> m.ny >> m.nz >> m.dx >> m.ox >> m.oy >> m.oz >> m.gaussian >> m.nYade >> m.nsteps
       >> m.rhoP >> m.rhoF >> m.nu >> m.dt >> m.gx >> m.gy >> m.gz;
+    if (!(f >> m.fibre)) m.fibre = 0;
     return m;
 }
 
@@ -86,9 +90,10 @@ const int MAXK = 16;  // dump width; reference bound is 12 (+ UB growth, meshTre
 void fake_yade_serial(const std::string& dir, const Meta& m, int foamRank) {
     for (int s = 0; s < m.nsteps; ++s) {
         std::vector<double> rec = read_bin<double>(dir + "/" + sfx("records", s));
-        int N = (int)(rec.size() / 10);
+        const int L = m.stride();
+        int N = (int)(rec.size() / L);
         MPI_Bcast(&N, 1, MPI_INT, 0, MPI_COMM_WORLD);
-        MPI_Bcast(rec.data(), 10 * N, MPI_DOUBLE, 0, MPI_COMM_WORLD);
+        MPI_Bcast(rec.data(), L * N, MPI_DOUBLE, 0, MPI_COMM_WORLD);
         std::vector<int> owner(N, -7);
         for (int i = 0; i < N; ++i) { int d = -5; MPI_Allreduce(&d, &owner[i], 1, MPI_INT, MPI_MAX, MPI_COMM_WORLD); }
         std::vector<double> F(6 * (size_t)N, 0.0);
@@ -125,12 +130,13 @@ void fake_yade_parallel(const std::string& dir, const Meta& m, int rank, int foa
             write_bin(dir + "/" + sfx("wire_fluiddt", s), &fluidDt, 1);
         } else {
             std::vector<double> rec = read_bin<double>(dir + "/" + sfx("records", s));
-            int N = (int)(rec.size() / 10), lo, hi;
+            const int L = m.stride();
+            int N = (int)(rec.size() / L), lo, hi;
             split(N, W, rank - 1, lo, hi);
             int cnt = hi - lo;                                   // one Foam rank => localCommSize == 1
             MPI_Send(&cnt, 1, MPI_INT, foamRank, 1003, MPI_COMM_WORLD);                 // FoamYade.C:122-125
             if (cnt > 0) {
-                MPI_Send(&rec[10 * (size_t)lo], 10 * cnt, MPI_DOUBLE, foamRank, 1002, MPI_COMM_WORLD);  // :149-153
+                MPI_Send(&rec[L * (size_t)lo], L * cnt, MPI_DOUBLE, foamRank, 1002, MPI_COMM_WORLD);  // :149-153
                 std::vector<int> found(cnt, 0);
                 MPI_Recv(found.data(), cnt, MPI_INT, foamRank, 1004, MPI_COMM_WORLD, &st);               // :239-243
                 std::vector<double> F(6 * (size_t)cnt, -9.0);
@@ -187,6 +193,7 @@ void foam_rank(const std::string& dir, const Meta& m) {
     Foam::FoamYade& fy = *new (&fyStorage) Foam::FoamYade(mesh, U, gradP, vGrad, divT, ddtU, g, uSourceDrag, alpha, uSource,
                                                          uParticle, m.gaussian != 0);
     fy.setScalarProperties(m.rhoP, m.rhoF, m.nu);
+    fy.fibreCpl = m.fibre != 0;                                // public member, FoamYade.H:102
 
     {   // tree, preorder (meshTree.C:19-37)
         std::vector<int> pre; pre.reserve(Nc);
@@ -205,7 +212,8 @@ void foam_rank(const std::string& dir, const Meta& m) {
 
         // per-particle dump in GLOBAL particle numbering
         std::vector<double> rec = read_bin<double>(dir + "/" + sfx("records", s));
-        const int Np = (int)(rec.size() / 10);
+        const int L = m.stride();
+        const int Np = (int)(rec.size() / L);
         std::vector<int> k(Np, 0), ids((size_t)Np * MAXK, -1), incell(Np, -1);
         std::vector<double> w((size_t)Np * MAXK, 0.0), FT((size_t)Np * 6, 0.0);
         for (const auto& yp : fy.inCommProcs) {
@@ -224,7 +232,7 @@ void foam_rank(const std::string& dir, const Meta& m) {
         }
         {   // meshTree::nearestCell (meshTree.C:66-135; no call site in FoamYade) on every record's position, for the NN locate of row A6
             std::vector<int> nn(Np, -1);
-            for (int q = 0; q < Np; ++q) nn[q] = fy.mshTree.nearestCell(Foam::vector(rec[10 * (size_t)q], rec[10 * (size_t)q + 1], rec[10 * (size_t)q + 2]));
+            for (int q = 0; q < Np; ++q) nn[q] = fy.mshTree.nearestCell(Foam::vector(rec[L * (size_t)q], rec[L * (size_t)q + 1], rec[L * (size_t)q + 2]));
             write_bin(dir + "/" + sfx("part_nn", s), nn.data(), nn.size());
         }
         write_bin(dir + "/" + sfx("part_k", s), k.data(), k.size());

@@ -29,7 +29,7 @@ MAXK = 16
 def run_reference(c: gc.Case, records, workdir):
     fields = gc.fluid_fields(c)
     meta = [c.nx, c.ny, c.nz, repr(c.dx), repr(c.origin[0]), repr(c.origin[1]), repr(c.origin[2]), c.gaussian,
-            c.n_yade, c.nsteps, repr(c.rhoP), repr(c.rhoF), repr(c.nu), repr(c.dt), repr(c.g[0]), repr(c.g[1]), repr(c.g[2])]
+            c.n_yade, c.nsteps, repr(c.rhoP), repr(c.rhoF), repr(c.nu), repr(c.dt), repr(c.g[0]), repr(c.g[1]), repr(c.g[2]), c.fibre]
     with open(os.path.join(workdir, "meta.txt"), "w") as f:
         f.write(" ".join(str(m) for m in meta) + "\n")
     for name, arr in fields.items():
@@ -129,7 +129,7 @@ def main():
     if not os.path.exists(DRIVER):
         sys.exit("build the reference driver first: make -C oracle ref")
     nn_only = "--nn-only" in sys.argv          # only the nearestCell fixtures (added in round 2; the other files stay as committed)
-    names = [a for a in sys.argv[1:] if not a.startswith("--")] or [c.name for c in gc.CASES]
+    names = [a for a in sys.argv[1:] if not a.startswith("--")] or [c.name for c in gc.CASES + gc.FIBRE_CASES]
     for name in names:
         c = gc.CASES_BY_NAME[name]
         out = build_case(c)

@@ -38,6 +38,7 @@ class Case:
     cluster: int = 0              # extra particles packed into a 2dx cube (alpha floor / Ergun branch)
     fast: int = 0                 # extra particles with |v| ~ 2 m/s (Re > 1000 branch)
     outside: int = 0              # extra particles placed just outside the block (Q8) and far outside
+    fibre: int = 0                # FoamYade::fibreCpl (FoamYade.H:102): 15 doubles per particle on the wire (FoamYade.C:131-136)
     extra: dict = field(default_factory=dict)
 
     @property
@@ -66,7 +67,12 @@ CASES = [
     Case("g9x7x5_odd", 9, 7, 5, 0.09, origin=(0.5, -0.5, 0.0), np_=300, seed=23, cluster=40, fast=5, outside=10),   # odd extents: median ties everywhere
     Case("p20x12x8_parallel4", 20, 12, 8, 0.2, origin=(0.0, 0.1, -0.3), gaussian=0, np_=700, seed=24, n_yade=5, nsteps=2, nu=0.005, outside=12),
 ]
-CASES_BY_NAME = {c.name: c for c in CASES}
+# fibre coupling (public flag, never set by the shipped solvers): own list, own tests (tests/test_fibre_coupling.py)
+FIBRE_CASES = [
+    Case("g8_fibre_serial", 8, 8, 8, 0.1, np_=200, seed=31, cluster=30, fast=6, outside=6, fibre=1),
+    Case("p16_fibre_parallel2", 16, 16, 16, 0.1, gaussian=0, np_=300, seed=32, n_yade=3, nu=0.01, outside=8, fibre=1),
+]
+CASES_BY_NAME = {c.name: c for c in CASES + FIBRE_CASES}
 
 
 def cell_centres(c: Case):
@@ -157,7 +163,36 @@ def particle_records(c: Case, step: int = 0):
         R[1, 0:3] = o + np.array([1.0, 1.0, 1.0]) * dx            # a mesh vertex
         R[2, 0:3] = o                                             # block corner
         R[3, 0:3] = o + ext                                       # opposite corner (on bbox max)
-    return R
+    return fibre_wide(c, R, step) if c.fibre else R
+
+
+def batch_ranges(c: Case, n):
+    if c.n_yade == 1:
+        return [(0, n)]
+    W = c.n_yade - 1
+    return [split_range(n, W, w) for w in range(W)]
+
+
+def fibre_wide(c: Case, R, step):
+    """(n,15) records for a fibreCpl run whose fields, AS THE REFERENCE READS THEM, are those of R (n,10).
+
+    With fibreCpl the reference takes the position from buf[np*15 + 0..2] (FoamYade.C:194-198) but velocity, spin and radius from
+    buf[np*10 + 3..9] of the same per-Yade-proc buffer (FoamYade.C:211-221).  Positions sit at residues {0,1,2,5,6,7} mod 10, the
+    radius at residue 9, so a buffer exists in which every radius the reference reads is a real radius: fill the stride-10 view first,
+    then the stride-15 positions (an odd particle's position overwrites some other particle's vz / wx / wy: still velocity-sized
+    numbers).  What lies beyond 10 m doubles of a buffer and is not a position is fibre payload nobody reads."""
+    rs = np.random.RandomState(c.seed + 1000 * step + 77)
+    n = R.shape[0]
+    out = np.empty((n, 15))
+    for lo, hi in batch_ranges(c, n):
+        m = hi - lo
+        B = (rs.random_sample(15 * m) * 2.0 - 1.0) * 0.1
+        for i in range(m):
+            B[10 * i + 3:10 * i + 10] = R[lo + i, 3:10]
+        for i in range(m):
+            B[15 * i:15 * i + 3] = R[lo + i, 0:3]
+        out[lo:hi] = B.reshape(m, 15)
+    return out
 
 
 def split_range(n, w_count, w):

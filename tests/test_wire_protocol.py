@@ -105,7 +105,7 @@ class FakeYade:
         self.log.clear(); self.sent.clear(); self.allred_int.clear(); self.allred_dbl.clear()
 
 
-@pytest.mark.parametrize("name", ["g16_serial_2step", "p32_serial_c1", "g16_parallel3", "p16_parallel2"])
+@pytest.mark.parametrize("name", ["g16_serial_2step", "p32_serial_c1", "g16_parallel3", "p16_parallel2", "g8_fibre_serial", "p16_fibre_parallel2"])
 def test_wire_protocol_matches_reference(product, name):
     prod = product
     c = gc.CASES_BY_NAME[name]
@@ -119,6 +119,10 @@ def test_wire_protocol_matches_reference(product, name):
     fy = prod.FoamYade(mesh, fields["U"], fields["gradP"], fields["vGrad"], fields["divT"], fields["ddtU"], c.g, mut["uSourceDrag"],
                        mut["alpha"], mut["uSource"], mut["uParticle"], bool(c.gaussian), transport=yade.T)
     fy.setScalarProperties(c.rhoP, c.rhoF, c.nu)
+    L = 10
+    if c.fibre:
+        fy.setFibreCoupling(True)            # FoamYade::fibreCpl: 15 doubles per particle on the wire (FoamYade.C:131-136,161-165)
+        L = 15
     foam = c.n_yade
     if not yade.serial:
         # sendMeshBbox: 6 doubles to every Yade rank including the master, tag 1001 (FoamYade.C:96-108)
@@ -135,7 +139,7 @@ def test_wire_protocol_matches_reference(product, name):
         fref = g[f"wire_force_s{s}"]
         scale = np.abs(fref).max() + 1e-300
         if yade.serial:
-            exp = [("bcast_world", 1, 0, 0, -1), ("bcast_world", 10 * n, 1, 0, -1)] + [("allreduce", 1, 0, 0, -1)] * n     # FoamYade.C:176,181,228
+            exp = [("bcast_world", 1, 0, 0, -1), ("bcast_world", L * n, 1, 0, -1)] + [("allreduce", 1, 0, 0, -1)] * n     # FoamYade.C:176,181,228
             owner = np.array(yade.allred_int)
             np.testing.assert_array_equal(np.maximum(owner, -5), g[f"wire_owner_s{s}"] * foam)     # found ? worldRank : 0
             if c.gaussian:
@@ -154,7 +158,7 @@ def test_wire_protocol_matches_reference(product, name):
             exp = [("recv", 1, 0, w + 1, TAG_SZ) for w in range(W)]                                 # FoamYade.C:122-125
             sl = [gc.split_range(n, W, w) for w in range(W)]
             live = [w for w in range(W) if sl[w][1] > sl[w][0]]
-            exp += [("recv", 10 * (sl[w][1] - sl[w][0]), 1, w + 1, TAG_DATA) for w in live]         # FoamYade.C:149-153
+            exp += [("recv", L * (sl[w][1] - sl[w][0]), 1, w + 1, TAG_DATA) for w in live]         # FoamYade.C:149-153
             exp += [("send", sl[w][1] - sl[w][0], 0, w + 1, TAG_RES) for w in live]                 # FoamYade.C:239-243
             exp += [("send", 6 * (sl[w][1] - sl[w][0]), 1, w + 1, TAG_FORCE) for w in live]         # FoamYade.C:504-507
             exp += [("send", 1, 1, 0, TAG_FDT), ("recv", 1, 1, 0, TAG_YDT), ("bcast_local", 1, 1, 0, -1)]   # FoamYade.C:538-547

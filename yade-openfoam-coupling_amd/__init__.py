@@ -127,6 +127,7 @@ def lib():
     L.fy_set_scalar_properties.argtypes = [vp, C.c_double, C.c_double, C.c_double]
     L.fy_set_particle_action.argtypes = [vp, C.c_double]
     L.fy_set_force_models.argtypes = [vp, C.c_uint]
+    L.fy_set_fibre_coupling.argtypes = [vp, C.c_int]
     L.fy_set_source_zero.argtypes = [vp]
     L.fy_finalize_run.argtypes = [vp, C.POINTER(C.c_int)]
     L.fy_destroy.argtypes = [vp]
@@ -296,6 +297,17 @@ class FoamYade:
         (FoamYade.C:465-479, commented out at :618)"""
         _check(lib().fy_set_force_models(self._h, int(flags)))
 
+    def setFibreCoupling(self, on):
+        """FoamYade::fibreCpl (FoamYade.H:102): records become 15 doubles per particle (FoamYade.C:131-136,161-165,189-198)"""
+        _check(lib().fy_set_fibre_coupling(self._h, 1 if on else 0))
+        self.fibreCpl = bool(on)
+
+    def calcHydroTimeScale(self):
+        """FoamYade.C:582-585: empty in the reference (TODO + return)"""
+
+    def sendHydroTimeScale(self, yProc=None):
+        """FoamYade.C:587-590: empty in the reference"""
+
     def setSourceZero(self):
         _check(lib().fy_set_source_zero(self._h))
 
@@ -307,12 +319,12 @@ class FoamYade:
 
     # ---- direct mode (no Yade peer)
     def setParticles(self, batches):
-        """batches: list of (n,10) float64 record arrays, one per Yade proc, processed in order."""
+        """batches: list of (n,10) float64 record arrays ((n,15) with fibre coupling), one per Yade proc, processed in order."""
         L = lib()
         _check(L.fy_set_num_batches(self._h, len(batches)))
         self._batch_n = []
         for b, rec in enumerate(batches):
-            rec = np.ascontiguousarray(rec, dtype=np.float64).reshape(-1, 10)
+            rec = np.ascontiguousarray(rec, dtype=np.float64).reshape(-1, 15 if getattr(self, "fibreCpl", False) else 10)
             _check(L.fy_set_particles_host(self._h, b, _d(rec), rec.shape[0]))
             self._batch_n.append(rec.shape[0])
 
@@ -324,7 +336,7 @@ class FoamYade:
         self._keep_rec = list(batches)
         for b, rec in enumerate(batches):
             assert rec.is_cuda and rec.is_contiguous() and rec.element_size() == 8
-            n = rec.numel() // 10
+            n = rec.numel() // (15 if getattr(self, "fibreCpl", False) else 10)
             _check(L.fy_set_particles_device(self._h, b, C.c_void_p(rec.data_ptr()), n))
             self._batch_n.append(n)
 

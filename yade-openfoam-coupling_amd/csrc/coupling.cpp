@@ -347,6 +347,14 @@ int Coupling::set_force_models(unsigned flags) {
     return FY_OK;
 }
 
+// fibreCpl (FoamYade.H:102; FoamYade.C:131-136,161-165,189-198): 15 doubles per particle from Yade
+int Coupling::set_fibre_coupling(int on) {
+    if (!created) return fail(FY_ERR_INVALID, "fy_set_fibre_coupling before fy_create");
+    if (slab.active) return fail(FY_ERR_INVALID, "fy_set_fibre_coupling: not with z-slabs (migration carries 10-double records)");
+    fibre = on != 0;
+    return FY_OK;
+}
+
 void Coupling::set_num_batches(int nb) {
     while ((int)batches.size() < nb) batches.emplace_back(new Batch());
     n_batches = nb;
@@ -418,7 +426,13 @@ int Coupling::set_particles_host(int bi, const double* rec, int64_t n) {
     if (bi < 0 || bi >= n_batches || n < 0 || (n > 0 && !rec)) return fail(FY_ERR_INVALID, "fy_set_particles_host: bad batch/arguments");
     Batch& b = *batches[bi];
     FY_TRY(b.rec_own.reserve(10 * (size_t)std::max<int64_t>(n, 1)));
-    if (n) FY_HIP(hipMemcpyAsync(b.rec_own.p, rec, 10 * (size_t)n * sizeof(double), hipMemcpyHostToDevice, stream));
+    if (fibre) {
+        FY_TRY(b.rec_wide.reserve(15 * (size_t)std::max<int64_t>(n, 1)));
+        if (n) FY_HIP(hipMemcpyAsync(b.rec_wide.p, rec, 15 * (size_t)n * sizeof(double), hipMemcpyHostToDevice, stream));
+        FY_TRY(launch_fibre_repack(stream, b.rec_wide.p, b.rec_own.p, n));
+    } else if (n) {
+        FY_HIP(hipMemcpyAsync(b.rec_own.p, rec, 10 * (size_t)n * sizeof(double), hipMemcpyHostToDevice, stream));
+    }
     b.d_rec = b.rec_own.p;
     return ensure_batch(b, n);
 }
@@ -438,8 +452,12 @@ int Coupling::upload_batch(Batch& b, int64_t n) {
     FY_TRY(b.rec_own.reserve(10 * (size_t)std::max<int64_t>(n, 1)));
     b.t_in.start(copy_stream);
     if (n) {
-        FY_HIP(hipMemcpyAsync(b.rec_own.p, b.h_rec.p, 10 * (size_t)n * sizeof(double), hipMemcpyHostToDevice, copy_stream));
-        tm.bytes_in += 10 * n * (int64_t)sizeof(double);
+        const size_t len = (size_t)rec_len();
+        double* dst = b.rec_own.p;
+        if (fibre) { FY_TRY(b.rec_wide.reserve(len * (size_t)n)); dst = b.rec_wide.p; }
+        FY_HIP(hipMemcpyAsync(dst, b.h_rec.p, len * (size_t)n * sizeof(double), hipMemcpyHostToDevice, copy_stream));
+        if (fibre) FY_TRY(launch_fibre_repack(copy_stream, b.rec_wide.p, b.rec_own.p, n));
+        tm.bytes_in += (int64_t)len * n * (int64_t)sizeof(double);
     }
     b.t_in.stop(copy_stream);
     FY_HIP(hipStreamWaitEvent(stream, b.t_in.b, 0));
@@ -450,7 +468,13 @@ int Coupling::upload_batch(Batch& b, int64_t n) {
 int Coupling::set_particles_device(int bi, const double* d_rec, int64_t n) {
     if (bi < 0 || bi >= n_batches || n < 0 || (n > 0 && !d_rec)) return fail(FY_ERR_INVALID, "fy_set_particles_device: bad batch/arguments");
     Batch& b = *batches[bi];
-    b.d_rec = d_rec;
+    if (fibre) {                                  // [n][15] in, the kernels' [n][10] gathered from it (k_fibre_repack)
+        FY_TRY(b.rec_own.reserve(10 * (size_t)std::max<int64_t>(n, 1)));
+        FY_TRY(launch_fibre_repack(stream, d_rec, b.rec_own.p, n));
+        b.d_rec = b.rec_own.p;
+    } else {
+        b.d_rec = d_rec;
+    }
     return ensure_batch(b, n);
 }
 
@@ -684,12 +708,12 @@ int Coupling::recv_serial() {
     if (N < 0) return fail(FY_ERR_TRANSPORT, "negative particle count from Yade");
     Batch& b = *batches[0];
     b.yrank = 0;
-    FY_TRY(b.h_rec.reserve(10 * (size_t)std::max(N, 1)));
+    FY_TRY(b.h_rec.reserve((size_t)rec_len() * (size_t)std::max(N, 1)));
     // the reference broadcasts the record buffer unconditionally (FoamYade.C:181), also when it is empty: a collective has to be
     // matched by every rank, so the zero-count call is issued too
     double none = 0.0;
     const WallClock wc;
-    FY_TR(transport.bcast_world(transport.user, N ? b.h_rec.data() : &none, 10 * N, FY_T_DOUBLE, 0));
+    FY_TR(transport.bcast_world(transport.user, N ? b.h_rec.data() : &none, rec_len() * N, FY_T_DOUBLE, 0));
     wire_recv_ms += wc.ms();
     return upload_batch(b, N);
 }
@@ -710,9 +734,9 @@ int Coupling::recv_yade_intrs() {
         Batch& b = *batches[q];
         b.yrank = in_comm[q].first;
         const int n = in_comm[q].second;
-        FY_TRY(b.h_rec.reserve(10 * (size_t)n));
+        FY_TRY(b.h_rec.reserve((size_t)rec_len() * (size_t)n));
         const WallClock wc;
-        FY_TR(transport.recv(transport.user, b.h_rec.data(), 10 * n, FY_T_DOUBLE, b.yrank, TAG_YADE_DATA));
+        FY_TR(transport.recv(transport.user, b.h_rec.data(), rec_len() * n, FY_T_DOUBLE, b.yrank, TAG_YADE_DATA));
         wire_recv_ms += wc.ms();
         FY_TRY(upload_batch(b, n));
         FY_TRY(run_batch(b));
@@ -960,6 +984,7 @@ int fy_create(const fy_mesh_desc* mesh, const fy_field_ptrs* fields, int gaussia
 
 int fy_set_scalar_properties(fy_ctx* c, double rhoP, double rhoF, double nu) { FY_CTX(c); c->c.rhoP = rhoP; c->c.rhoF = rhoF; c->c.nu = nu; return FY_OK; }
 int fy_set_force_models(fy_ctx* c, unsigned flags) { FY_CTX(c); return c->c.set_force_models(flags); }
+int fy_set_fibre_coupling(fy_ctx* c, int on) { FY_CTX(c); return c->c.set_fibre_coupling(on); }
 int fy_set_particle_action(fy_ctx* c, double dt) { FY_CTX(c); return c->c.set_particle_action(dt); }
 int fy_set_source_zero(fy_ctx* c) { FY_CTX(c); return c->c.set_source_zero(); }
 int fy_finalize_run(fy_ctx* c, int* value_out) {

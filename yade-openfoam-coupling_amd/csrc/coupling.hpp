@@ -17,6 +17,7 @@ struct Batch {
     int yrank = 0;                       // world rank of the Yade proc
     const double* d_rec = nullptr;       // device records [n][10] (borrowed, or rec_own)
     DevBuf<double> rec_own;
+    DevBuf<double> rec_wide;             // fibre coupling: the 15-double records as they arrived (repacked into rec_own)
     size_t cap = 0;                      // leading dimension of the SoA / stencil arrays
     DevBuf<double> soa;                  // 7 * cap : px py pz vx vy vz rad (binned order)
     DevBuf<int32_t> orig, chain, ids, found, incell;
@@ -98,6 +99,7 @@ struct Coupling {
     bool fields_on_host = false;
     DevBuf<double> own_U, own_gradP, own_vGrad, own_divT, own_ddtU, own_uSourceDrag, own_alpha, own_uSource, own_uParticle;
     const double *dU = nullptr, *dGradP = nullptr, *dVGrad = nullptr, *dDivT = nullptr, *dDdtU = nullptr;
+    bool fibre = false;                  // fibreCpl (FoamYade.H:102)
     unsigned force_models = 0;           // FY_FORCE_*: the reference's call-site-less models (off = shipped behaviour)
     double *dUSourceDrag = nullptr, *dAlpha = nullptr, *dUSource = nullptr, *dUParticle = nullptr;
     DevBuf<double> d_pvol_acc, d_up_acc;           // per-batch deposit accumulators (pVolContrib / uParticleContrib)
@@ -144,6 +146,8 @@ struct Coupling {
     int ensure_found(Batch& b);
     int run_batch(Batch& b);
     int set_force_models(unsigned flags);
+    int set_fibre_coupling(int on);
+    int rec_len() const { return fibre ? 15 : 10; }   // doubles per particle on the wire (FoamYade.C:131-136)
     int set_particle_action(double dt);
     bool timings_pending = false;        // the last call's phase events have not been read yet
     int collect_timings();

@@ -1599,6 +1599,25 @@ int launch_tile_reduce(hipStream_t s, TileBuckets tb, double* dst0, double* dst3
     return FY_OK;
 }
 
+// Fibre coupling (`fibreCpl`, FoamYade.H:102): Yade sends 15 doubles per particle (FoamYade.C:131-136,161-165) and the position is read
+// with that stride (FoamYade.C:194-198), but velocity, spin and radius are still taken from `buf[np*10 + 3..9]` of the SAME buffer
+// (FoamYade.C:211-221).  The reference ships it that way; the narrow records the kernels consume are gathered with exactly that indexing.
+__global__ void k_fibre_repack(const double* __restrict__ wide, double* __restrict__ rec, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) rec[10 * i + q] = wide[15 * i + q];
+#pragma unroll
+    for (int q = 3; q < 10; ++q) rec[10 * i + q] = wide[10 * i + q];
+}
+
+int launch_fibre_repack(hipStream_t s, const double* wide, double* rec, int64_t n) {
+    if (n <= 0) return FY_OK;
+    hipLaunchKernelGGL(k_fibre_repack, dim3(div_up(n, 256)), dim3(256), 0, s, wide, rec, n);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+
 int launch_migrate_pack(hipStream_t s, const double* rec, const int64_t* tags, int64_t n, SlabOwn own, unsigned int* counters, double* stay, double* up, double* down) {
     if (n <= 0) return FY_OK;
     hipLaunchKernelGGL(k_migrate_pack, dim3(div_up(n, 256)), dim3(256), 0, s, rec, tags, n, own, counters, stay, up, down);

@@ -139,6 +139,7 @@ int launch_force_gaussian(hipStream_t s, ParticleSoA p, int64_t n, ForceParams f
                           double* force_out, TileBuckets tb = TileBuckets{});
 int launch_fold_sources(hipStream_t s, int64_t n_field, double* drag_acc, const double* uParticle, double* uSourceDrag, double* uSource);
 // z-slab migration: classify by owner slab and pack (11 doubles per particle: record + tag bits); counters = {stay, up, down}
+int launch_fibre_repack(hipStream_t s, const double* wide, double* rec, int64_t n);   // 15-double fibre records -> [n][10]
 int launch_migrate_pack(hipStream_t s, const double* rec, const int64_t* tags, int64_t n, SlabOwn own, unsigned int* counters, double* stay, double* up, double* down);
 int launch_migrate_unpack(hipStream_t s, const double* packed, int64_t n, double* rec, int64_t* tags);
 // Gaussian mode: found flags in wire order from the chain lengths (launch_force_gaussian no longer writes found_out)
