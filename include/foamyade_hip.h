@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define FY_ABI_VERSION 3
+#define FY_ABI_VERSION 4
 
 /* ---- status codes ------------------------------------------------------------------------------------ */
 enum {
@@ -191,6 +191,11 @@ enum { FY_PSOLVER_PCG_JACOBI = 0, FY_PSOLVER_PCG_MG = 1 };
 #define FY_CONVECTION_LINEAR 0
 #define FY_CONVECTION_UPWIND 1
 #define FY_CONVECTION_LINEAR_UPWIND 2
+/* continuousPhaseTurbulence (pimpleFoamYade/createFields.H, DPMTurbulenceModels.C:67-77; icoFoamYade has no turbulence model) */
+#define FY_TURBULENCE_LAMINAR 0        /* simulationType laminar / laminarModel Stokes (DPMTurbulenceModels.C:67-68) */
+#define FY_TURBULENCE_SMAGORINSKY 1    /* simulationType LES, LESModel Smagorinsky (DPMTurbulenceModels.C:73-74), delta cubeRootVol */
+#define FY_BC_NUT_ZERO_GRADIENT 0
+#define FY_BC_NUT_FIXED_VALUE 1
 typedef struct fy_case_desc {
     int32_t solver;                 /* FY_SOLVER_ICO | FY_SOLVER_PIMPLE */
     int32_t nx, ny, nz;
@@ -220,6 +225,15 @@ typedef struct fy_case_desc {
        (pEqn.H:41).  <= 0: no entry (the call does nothing); the *_final values apply on the last outer corrector, falling back to the
        plain ones when absent.  fy_case_defaults: u_relax = 1 (the DPMFoam tutorials' `equations { ".*" 1; }`), no field relaxation */
     double u_relax, u_relax_final, p_relax, p_relax_final;
+    /* constant/turbulenceProperties (pimpleFoamYade only): FY_TURBULENCE_*.  Smagorinsky [OF-6 Smagorinsky.C]: k from
+       a = Ce/delta, b = 2/3 tr(D), c = 2 Ck delta (dev(D) && D), k = ((-b + sqrt(b^2 + 4ac)) / 2a)^2, nut = Ck delta sqrt(k), evaluated by
+       continuousPhaseTurbulence->correct() after the last corrector of the final outer iteration (pimpleFoamYade.C:101-104);
+       delta = les_delta_coeff * cbrt(V) (LESdelta cubeRootVol); nuEff = nu + nut enters divDevRhoReff (UcEqn.H:7) as
+       -fvm::laplacian(alpha nuEff, U) - fvc::div(alpha nuEff dev2(T(grad U))).  nut_initial / nut_bc / nut_value: the 0/nut file */
+    int32_t turbulence_model;
+    double les_ck, les_ce, les_delta_coeff;      /* fy_case_defaults: 0.094, 1.048, 1 */
+    int32_t nut_bc[6]; double nut_value[6];      /* FY_BC_NUT_* per side */
+    double nut_initial;                          /* uniform internalField of 0/nut (fy_solver_write_field_host("nut") for a non-uniform one) */
 } fy_case_desc;
 
 typedef struct fy_solver fy_solver;
@@ -238,7 +252,7 @@ int fy_solver_create(const fy_case_desc* c, const fy_transport* transport, int d
 fy_ctx* fy_solver_coupling(fy_solver*);                 /* the yadeCoupling object (icoFoamYade.C:54, pimpleFoamYade.C:54) */
 int fy_solver_step(fy_solver*);                         /* one pass of the while(runTime.loop()) body */
 int fy_solver_get_stats(fy_solver*, fy_step_stats* out);
-/* names: "U" [n][3], "p" [n], "phi_x" [(nx+1)*ny*nz], "phi_y", "phi_z", plus every fy_ctx field name */
+/* names: "U" [n][3], "p" [n], "phi_x" [(nx+1)*ny*nz], "phi_y", "phi_z", "nut" [n] (with a turbulence model), plus every fy_ctx field name */
 int fy_solver_read_field_host(fy_solver*, const char* name, double* out);
 int fy_solver_write_field_host(fy_solver*, const char* name, const double* in);
 /* number of doubles fy_solver_read/write_field_host move for `name` on this rank (owned cells / local faces) */
@@ -275,6 +289,8 @@ int fy_foam_case_open(const char* case_dir, int solver /* FY_SOLVER_ICO | FY_SOL
 int fy_foam_case_desc(const fy_foam_case*, fy_case_desc* out);                   /* ready for fy_solver_create */
 int fy_foam_case_info_get(const fy_foam_case*, fy_foam_case_info* out);
 int fy_foam_case_initial_fields(const fy_foam_case*, double* U /* [n][3] or NULL */, double* p /* [n] or NULL */);
+/* start-time nut.<phase> of a case with a turbulence model (hand it to fy_solver_write_field_host(s, "nut", ...) when it is not uniform) */
+int fy_foam_case_initial_nut(const fy_foam_case*, double* nut /* [n] */);
 /* runTime.write(): <case>/<time_name>/{U | U.<phase>, p [, alpha.<phase>]} as ASCII volFields with the case's own patch entries */
 int fy_foam_case_write_time(const fy_foam_case*, fy_solver*, const char* time_name);
 int fy_foam_case_close(fy_foam_case*);

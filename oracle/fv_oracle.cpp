@@ -47,6 +47,10 @@ struct orc_fv_case {
     int adjust_time_step; double max_co, max_delta_t;
     // fvSolution relaxationFactors: equations { Uc; UcFinal } (UcEqn.relax(), UcEqn.H:12), fields { p; pFinal } (p.relax(), pEqn.H:41); <= 0: no entry
     double u_relax, u_relax_final, p_relax, p_relax_final;
+    // constant/turbulenceProperties of pimpleFoamYade: 0 laminar (Stokes), 1 LES Smagorinsky (DPMTurbulenceModels.C:67-74), delta cubeRootVol;
+    // 0/nut: per-side boundary type (0 zeroGradient, 1 fixedValue) and value, uniform initial value
+    int turbulence_model; double les_ck, les_ce, les_delta_coeff;
+    int nut_bc[6]; double nut_value[6]; double nut_initial;
 };
 struct orc_fv_stats {
     double courant_mean, courant_max, cont_sum_local, cont_global, cont_cumulative;
@@ -77,6 +81,7 @@ struct Fv {
     int threads = 1;
     // state
     vec U, Uold, p, alpha, alphaOld, uSource, uSourceDrag, uParticle, gradP, divT, vGrad, ddtU;
+    vec nut;                                 // eddy viscosity (Smagorinsky); empty = laminar
     vec phi[3], phiOld[3], psn[3];           // psn: d p / d axis on fixedFluxPressure boundary faces
     // work
     vec diag, an[6], src, rAU, HbyA, alphaf[3], phiHbyA[3], phiForces[3], rAUf[3], pflux[3], bmom, Sc, divG;
@@ -115,6 +120,7 @@ struct Fv {
         src.assign(3 * (size_t)Nc, 0.0); rAU.assign(Nc, 0.0); HbyA.assign(3 * (size_t)Nc, 0.0); bmom.assign(3 * (size_t)Nc, 0.0);
         Sc.assign(Nc, 0.0); divG.assign(3 * (size_t)Nc, 0.0);
         pb.assign(Nc, 0.0); pr = pb; pw = pb; pp = pb; pz = pb;
+        if (pimple && c.turbulence_model == 1) nut.assign(Nc, c.nut_initial);      // the 0/nut file (eddyViscosity: MUST_READ)
         build_mg_shapes();
         // createPhi: phi = linearInterpolate(U) & Sf (icoFoamYade/createFields.H:151, pimpleFoamYade/createFields.H:70-81)
         flux_of(U, phi);
@@ -259,7 +265,7 @@ struct Fv {
                 const double* T = &vGrad[9 * (size_t)c];
                 const double tr = T[0] + T[4] + T[8];
                 for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b)
-                    G[9 * (size_t)c + 3 * a + b] = alpha[c] * nu * (T[3 * b + a] - (a == b ? (2.0 / 3.0) * tr : 0.0));
+                    G[9 * (size_t)c + 3 * a + b] = (nut.empty() ? alpha[c] * nu : alpha[c] * (nu + nut[c])) * (T[3 * b + a] - (a == b ? (2.0 / 3.0) * tr : 0.0));   // alpha nuEff dev2(T(grad U)) [OF-6 linearViscousStress::divDevRhoReff]
             }
 #pragma omp parallel for num_threads(threads) collapse(2)
             for (int k = 0; k < nz; ++k) for (int j = 0; j < ny; ++j) for (int i = 0; i < nx; ++i) {
@@ -289,7 +295,18 @@ struct Fv {
                 const double af = pimple ? alphaf[d][f] : 1.0;
                 const double phio = (s ? 1.0 : -1.0) * af * phi[d][f];       // outward (alpha-weighted) flux
                 divAPhi += phio;
-                const double gam = nu * af * dx;                             // (alpha nu)_f |Sf| / |d|
+                double gam = nu * af * dx;                                   // (alpha nu)_f |Sf| / |d|
+                if (!nut.empty()) {
+                    // - fvm::laplacian(alpha nuEff, U) [OF-6 linearViscousStress::divDevRhoReff]: the cell field alpha (nu + nut) is interpolated
+                    // linearly to the faces (gaussLaplacianScheme::fvmLaplacian(vol gamma)); boundary value alpha_b (nu + nut_b) with nut_b by 0/nut
+                    if (onb(d, s, i, j, k)) {
+                        const double nb = cs.nut_bc[2 * d + s] == 1 ? cs.nut_value[2 * d + s] : nut[c];
+                        gam = (af * (nu + nb)) * dx;
+                    } else {
+                        const int nbc = c + (s ? stride[d] : -stride[d]);
+                        gam = (0.5 * ((aP * (nu + nut[c])) + (alpha[nbc] * (nu + nut[nbc])))) * dx;
+                    }
+                }
                 if (onb(d, s, i, j, k)) {
                     an[2 * d + s][c] = 0.0;
                     const int patch = 2 * d + s;
@@ -800,6 +817,27 @@ struct Fv {
                 st.u_iters_total += solve_momentum(bmom);
             }
             for (int corr = 0; corr < cs.n_corr; ++corr) corrector(outer == nOuter - 1 && corr == cs.n_corr - 1);
+            if (!nut.empty() && final_outer) turbulence_correct();             // pimple.turbCorr() (final outer iteration), pimpleFoamYade.C:101-104
+        }
+    }
+    // continuousPhaseTurbulence->correct() for LESModel Smagorinsky [OF-6 LES/Smagorinsky/Smagorinsky.C: correct() -> correctNut();
+    // k(gradU): D = symm(gradU), a = Ce/delta, b = (2/3) tr(D), c = 2 Ck delta (dev(D) && D), k = sqr((-b + sqrt(sqr(b) + 4 a c))/(2 a));
+    // nut = Ck delta sqrt(k)]; delta = deltaCoeff * cbrt(V) [OF-6 LES/LESdeltas/cubeRootVolDelta]; gradU = fvc::grad(U) (Gauss linear)
+    void turbulence_correct() {
+        grad_U(U, vGrad);
+        const double delta = cs.les_delta_coeff * std::pow(V, 1.0 / 3.0), Ck = cs.les_ck, Ce = cs.les_ce;
+        for (int c = 0; c < Nc; ++c) {
+            const double* T = &vGrad[9 * (size_t)c];
+            double D[3][3];
+            for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) D[a][b] = 0.5 * (T[3 * a + b] + T[3 * b + a]);
+            const double trD = D[0][0] + D[1][1] + D[2][2];
+            const double a = Ce / delta, b = (2.0 / 3.0) * trD;
+            const double third = (1.0 / 3.0) * trD;
+            const double dd = (D[0][0] - third) * D[0][0] + (D[1][1] - third) * D[1][1] + (D[2][2] - third) * D[2][2]
+                            + 2.0 * (D[0][1] * D[0][1]) + 2.0 * (D[0][2] * D[0][2]) + 2.0 * (D[1][2] * D[1][2]);
+            const double cc = 2.0 * Ck * delta * dd;
+            const double r = (-b + std::sqrt(b * b + 4.0 * a * cc)) / (2.0 * a);
+            nut[c] = Ck * delta * std::sqrt(r * r);
         }
     }
 };
@@ -810,6 +848,7 @@ extern "C" {
 
 void* orc_fv_create(const orc_fv_case* c) { Fv* f = new Fv(); f->init(*c); return f; }
 void orc_fv_destroy(void* h) { delete (Fv*)h; }
+void orc_fv_turbulence_correct(void* h) { Fv* f = (Fv*)h; if (!f->nut.empty()) f->turbulence_correct(); }
 void orc_fv_set_threads(void* h, int t) { ((Fv*)h)->threads = t < 1 ? 1 : t; }
 
 static vec* fv_field(Fv* f, const char* name) {
@@ -824,6 +863,7 @@ static vec* fv_field(Fv* f, const char* name) {
         {"gradP", &f->gradP},
         {"divT", &f->divT},
         {"vGrad", &f->vGrad},
+        {"nut", &f->nut},
         {"ddtU", &f->ddtU},
         {"phi_x", &f->phi[0]},
         {"phi_y", &f->phi[1]},

@@ -202,7 +202,9 @@ class FvCase(C.Structure):
                 ("p_tol", C.c_double), ("p_rel_tol", C.c_double), ("p_final_tol", C.c_double), ("p_final_rel_tol", C.c_double),
                 ("p_max_iter", C.c_int), ("u_tol", C.c_double), ("u_rel_tol", C.c_double), ("u_max_iter", C.c_int), ("convection_scheme", C.c_int),
                 ("adjust_time_step", C.c_int), ("max_co", C.c_double), ("max_delta_t", C.c_double),
-                ("u_relax", C.c_double), ("u_relax_final", C.c_double), ("p_relax", C.c_double), ("p_relax_final", C.c_double)]
+                ("u_relax", C.c_double), ("u_relax_final", C.c_double), ("p_relax", C.c_double), ("p_relax_final", C.c_double),
+                ("turbulence_model", C.c_int), ("les_ck", C.c_double), ("les_ce", C.c_double), ("les_delta_coeff", C.c_double),
+                ("nut_bc", C.c_int * 6), ("nut_value", C.c_double * 6), ("nut_initial", C.c_double)]
 
 
 class FvStats(C.Structure):
@@ -221,7 +223,7 @@ def fv_case(solver, nx, ny, nz, dx, dt, nu, rho_f=1000.0, rho_p=2650.0, g=(0, 0,
             p_val=None, n_outer=1, n_corr=2, p_solver=1, origin=(0, 0, 0), momentum_predictor=1, p_tol=1e-6, p_rel_tol=0.05,
             p_final_tol=1e-6, p_final_rel_tol=0.0, u_tol=1e-5, u_rel_tol=0.0, p_max_iter=1000, u_max_iter=1000, convection_scheme=0, p_ref_cell=0,
             p_ref_value=0.0, n_non_orth=0, adjust_time_step=0, max_co=1.0, max_delta_t=1e300, u_relax=1.0, u_relax_final=0.0, p_relax=0.0,
-            p_relax_final=0.0):
+            p_relax_final=0.0, turbulence_model=0, les_ck=0.094, les_ce=1.048, les_delta_coeff=1.0, nut_bc=None, nut_value=None, nut_initial=0.0):
     """documented defaults = the icoFoam cavity / DPMFoam tutorial settings of SURVEY.md Appendix C"""
     c = FvCase()
     c.solver, c.nx, c.ny, c.nz, c.dx, c.dt, c.nu = solver, nx, ny, nz, dx, dt, nu
@@ -246,6 +248,10 @@ def fv_case(solver, nx, ny, nz, dx, dt, nu, rho_f=1000.0, rho_p=2650.0, g=(0, 0,
     c.convection_scheme = int(convection_scheme)
     c.adjust_time_step, c.max_co, c.max_delta_t = int(adjust_time_step), max_co, max_delta_t
     c.u_relax, c.u_relax_final, c.p_relax, c.p_relax_final = u_relax, u_relax_final, p_relax, p_relax_final
+    c.turbulence_model, c.les_ck, c.les_ce, c.les_delta_coeff, c.nut_initial = int(turbulence_model), les_ck, les_ce, les_delta_coeff, nut_initial
+    for q in range(6):
+        c.nut_bc[q] = (nut_bc or [0] * 6)[q]
+        c.nut_value[q] = (nut_value or [0.0] * 6)[q]
     return c
 
 
@@ -260,6 +266,7 @@ def _fv_lib():
         L.orc_fv_create.restype = C.c_void_p
         L.orc_fv_destroy.argtypes = [C.c_void_p]
         L.orc_fv_set_threads.argtypes = [C.c_void_p, C.c_int]
+        L.orc_fv_turbulence_correct.argtypes = [C.c_void_p]
         L.orc_fv_field_size.argtypes = [C.c_void_p, C.c_char_p]
         L.orc_fv_get.argtypes = [C.c_void_p, C.c_char_p, _dp]
         L.orc_fv_set.argtypes = [C.c_void_p, C.c_char_p, _dp]
@@ -288,10 +295,16 @@ class FvSolver:
         self.mesh = None
         self.threads = threads
 
+    def turbulence_correct(self):
+        """continuousPhaseTurbulence->correct() on the current U (Smagorinsky cases)"""
+        self.L.orc_fv_turbulence_correct(self.h)
+
     def view(self, name):
         """numpy view of the oracle's own storage (no copy)"""
         n = self.L.orc_fv_field_size(self.h, name.encode())
         assert n >= 0, name
+        if n == 0:
+            return np.zeros(0)
         return np.ctypeslib.as_array(self.L.orc_fv_ptr(self.h, name.encode()), shape=(n,))
 
     def get(self, name):

@@ -266,3 +266,92 @@ def test_time_step_control_and_relaxation_factors_are_read(prod, tmp_path):
     fc = prod.FoamCase(dst2, prod.FY_SOLVER_ICO)
     assert fc.case.adjust_time_step == 0
     fc.close()
+
+
+LES_PROPS = """FoamFile { version 2.0; format ascii; class dictionary; object turbulenceProperties.water; }
+simulationType  LES;
+LES
+{
+    LESModel        Smagorinsky;
+    turbulence      on;
+    printCoeffs     on;
+    delta           cubeRootVol;
+    SmagorinskyCoeffs { Ck 0.1; Ce 1.0; }
+    cubeRootVolCoeffs { deltaCoeff 1.5; }
+}
+"""
+NUT_FILE = """FoamFile { version 2.0; format ascii; class volScalarField; object nut.water; }
+dimensions      [0 2 -1 0 0 0 0];
+internalField   uniform 2e-6;
+boundaryField
+{
+    bottom { type fixedValue; value uniform 1e-6; }
+    top    { type zeroGradient; }
+    walls  { type zeroGradient; }
+}
+"""
+
+
+def les_case(tmp_path):
+    dst = tmp_path / "bed_les"
+    shutil.copytree(os.path.join(CASES, "bed_pimple"), dst)
+    (dst / "constant/turbulenceProperties.water").write_text(LES_PROPS)
+    (dst / "0/nut.water").write_text(NUT_FILE)
+    return dst
+
+
+def test_les_smagorinsky_case_is_read(prod, tmp_path):
+    """constant/turbulenceProperties.<phase> + <start>/nut.<phase> (continuousPhaseTurbulence, pimpleFoamYade/createFields.H;
+    DPMTurbulenceModels.C:67-77): laminar and LES Smagorinsky are read, the other two models are refused by name"""
+    lam = prod.FoamCase(os.path.join(CASES, "bed_pimple"), prod.FY_SOLVER_PIMPLE)
+    assert lam.case.turbulence_model == prod.TURBULENCE_LAMINAR            # no file: the laminar model
+    lam.close()
+    dst = les_case(tmp_path)
+    fc = prod.FoamCase(dst, prod.FY_SOLVER_PIMPLE)
+    c = fc.case
+    assert c.turbulence_model == prod.TURBULENCE_SMAGORINSKY and (c.les_ck, c.les_ce, c.les_delta_coeff) == (0.1, 1.0, 1.5)
+    assert c.nut_initial == 2e-6 and np.all(fc.initial_nut() == 2e-6)
+    assert list(c.nut_bc) == [0, 0, 0, 0, 1, 0] and c.nut_value[ZMIN] == 1e-6
+    fc.close()
+    for old, new, needle in (("LESModel        Smagorinsky;", "LESModel        kEqn;", "kEqn"),
+                             ("simulationType  LES;", "simulationType  RAS;", "RAS"),
+                             ("delta           cubeRootVol;", "delta           vanDriest;", "cubeRootVol"),
+                             ("turbulence      on;", "turbulence      off;", "turbulence off")):
+        (dst / "constant/turbulenceProperties.water").write_text(LES_PROPS.replace(old, new))
+        with pytest.raises(prod.FoamYadeError) as e:
+            prod.FoamCase(dst, prod.FY_SOLVER_PIMPLE)
+        assert needle in str(e.value) and "turbulenceProperties" in str(e.value)
+    (dst / "constant/turbulenceProperties.water").write_text(LES_PROPS)
+    (dst / "0/nut.water").write_text(NUT_FILE.replace("top    { type zeroGradient; }", "top    { type nutkWallFunction; value uniform 0; }"))
+    with pytest.raises(prod.FoamYadeError) as e:
+        prod.FoamCase(dst, prod.FY_SOLVER_PIMPLE)
+    assert "nutkWallFunction" in str(e.value) and "nut.water" in str(e.value)
+    os.remove(dst / "0/nut.water")
+    with pytest.raises(prod.FoamYadeError) as e:
+        prod.FoamCase(dst, prod.FY_SOLVER_PIMPLE)
+    assert "nut.water" in str(e.value)
+    # a laminar file says what the missing file means
+    (dst / "constant/turbulenceProperties.water").write_text("simulationType laminar;\n")
+    fc = prod.FoamCase(dst, prod.FY_SOLVER_PIMPLE)
+    assert fc.case.turbulence_model == prod.TURBULENCE_LAMINAR
+    fc.close()
+
+
+@pytest.mark.gpu
+def test_les_case_runs_and_writes_nut(prod, tmp_path):
+    dst = les_case(tmp_path)
+    fc = prod.FoamCase(dst, prod.FY_SOLVER_PIMPLE)
+    s = prod.Solver(fc.case)
+    U0, p0 = fc.initial_fields()
+    s.set("U", U0); s.set("p", p0); s.set("nut", fc.initial_nut())
+    for _ in range(3):
+        s.step()
+    nut = s.get("nut")
+    assert nut.max() > 0 and not np.all(nut == 2e-6)                         # correct() replaced the file's values
+    fc.write(s, "0.0006")
+    text = (dst / "system/controlDict").read_text().replace("startTime       0;", "startTime       0.0006;")
+    (dst / "system/controlDict").write_text(text)
+    fc2 = prod.FoamCase(dst, prod.FY_SOLVER_PIMPLE)
+    np.testing.assert_array_equal(fc2.initial_nut(), nut)
+    assert list(fc2.case.nut_bc) == list(fc.case.nut_bc) and fc2.case.nut_value[ZMIN] == 1e-6
+    fc.close(); fc2.close(); s.close()

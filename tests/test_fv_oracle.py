@@ -403,3 +403,50 @@ def test_corrected_flux_is_divergence_free_to_solver_tolerance(oracle):
         s.step()
     flux_identity(s, n, 0.4 / n)
     s.close()
+
+
+def test_smagorinsky_nut_of_a_linear_shear_flow(oracle):
+    """LES Smagorinsky (DPMTurbulenceModels.C:73-74) on U = (gamma y, 0, 0): D_xy = gamma/2, tr D = 0, so k = Ck delta^2 gamma^2 / Ce and
+    nut = Ck sqrt(Ck/Ce) delta^2 gamma -- the classic (Cs delta)^2 |S| with Cs = 0.168 for the OpenFOAM defaults Ck = 0.094, Ce = 1.048."""
+    n, dx, gamma = 10, 0.05, 3.0
+    c = oracle.fv_case(1, n, n, n, dx, 1e-3, 1e-3, u_bc=[1] * 6, turbulence_model=1)
+    o = oracle.FvSolver(c)
+    y = (np.arange(n) + 0.5) * dx
+    U = np.zeros((n, n, n, 3))
+    U[..., 0] = gamma * y[None, :, None]
+    o.set("U", U.reshape(-1, 3))
+    o.turbulence_correct()
+    nut = o.get("nut").reshape(n, n, n)
+    delta = (dx ** 3) ** (1.0 / 3.0)
+    expect = 0.094 * np.sqrt(0.094 / 1.048) * delta ** 2 * gamma
+    np.testing.assert_allclose(nut[:, 1:-1, :], expect, rtol=1e-12)
+    assert abs(np.sqrt(0.094 * np.sqrt(0.094 / 1.048)) - 0.168) < 1e-3
+    # zeroGradient walls halve the one-sided gradient of the wall cells
+    np.testing.assert_allclose(nut[:, 0, :], 0.5 * expect, rtol=1e-12)
+
+
+def test_smagorinsky_adds_eddy_viscosity_to_a_cavity(oracle):
+    """the lid-driven cavity with the LES model: nut > 0 where the flow shears, momentum diffuses faster than in the laminar run, and a
+    vanishing model constant gives the laminar run back"""
+    n = 12
+    u_val = [(0, 0, 0)] * 6
+    u_val[3] = (1.0, 0, 0)
+
+    def run(**kw):
+        o = oracle.FvSolver(oracle.fv_case(1, n, n, n, 1.0 / n, 0.02, 1e-3, u_bc=[0] * 6, u_val=u_val, **kw))
+        for _ in range(10):
+            o.step()
+        return o
+
+    lam = run()
+    les = run(turbulence_model=1, les_ck=0.3)
+    tiny = run(turbulence_model=1, les_ck=1e-9)
+    nut = les.get("nut")
+    assert nut.min() >= 0 and nut.max() > 5e-3
+    assert lam.get("nut").size == 0
+    dU = np.abs(les.get("U") - lam.get("U")).max()
+    assert dU > 1e-3
+    np.testing.assert_allclose(tiny.get("U"), lam.get("U"), atol=1e-9)
+    # more diffusion: the shear layer under the lid is thicker, so the lid drags less steeply -- the wall cells' velocity gradient drops
+    top = lambda o: o.get("U").reshape(n, n, n, 3)[:, n - 1, :, 0].mean()       # noqa: E731   (k, j, i) order: the cell layer under the lid
+    assert top(les) > top(lam)

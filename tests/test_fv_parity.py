@@ -293,3 +293,42 @@ def test_cases_adjustPhi_cannot_balance_are_refused(product):
     s.step()
     assert abs(s.stats()["cont_err_global"]) < 1e-10
     s.close()
+
+
+def test_smagorinsky_matches_oracle(product, oracle):
+    """pimpleFoamYade with LESModel Smagorinsky (DPMTurbulenceModels.C:73-74): nut from continuousPhaseTurbulence->correct() after the last
+    corrector (pimpleFoamYade.C:101-104), nuEff = nu + nut in both parts of divDevRhoReff (UcEqn.H:7); coupled, so alpha nuEff varies too"""
+    n = 16
+    dx = 0.1 / n
+    u_val = [(0, 0, 0)] * 6
+    u_val[YMAX] = (0.5, 0, 0)
+    nut_bc = [0, 0, 1, 0, 1, 1]
+    nut_value = [0, 0, 0.0, 0, 2e-5, 0.0]
+    o, s = both(product, oracle, 1, n, n, n, dx, 2e-4, 1e-5, g=(0, 0, -9.81), u_bc=[0] * 6, u_val=u_val, p_bc=[2] * 6,
+                turbulence_model=1, les_ck=0.2, nut_bc=nut_bc, nut_value=nut_value, nut_initial=3e-5)
+    np.testing.assert_array_equal(s.get("nut"), 3e-5)
+    case = gc.Case("cpl", n, n, n, 0.1, gaussian=1, np_=2000, seed=5, cluster=100, fast=10, outside=10, vel_scale=0.05)
+    for step in range(4):
+        rec = gc.particle_records(case, step)
+        o.step(rec)
+        s.set_particles(rec)
+        s.step()
+        a, b = s.get("nut"), o.get("nut")
+        assert b.max() > 1e-7
+        np.testing.assert_allclose(a, b, rtol=2e-5, atol=1e-9 * b.max())
+    compare(o, s, rtol=1e-5)
+    # and it is not the laminar answer
+    ol, sl = both(product, oracle, 1, n, n, n, dx, 2e-4, 1e-5, g=(0, 0, -9.81), u_bc=[0] * 6, u_val=u_val, p_bc=[2] * 6)
+    for step in range(4):
+        rec = gc.particle_records(case, step)
+        sl.set_particles(rec)
+        sl.step()
+    assert np.abs(sl.get("U") - s.get("U")).max() > 1e-4 * np.abs(sl.get("U")).max()
+
+
+def test_turbulence_model_refused_where_the_reference_has_none(product):
+    from importlib import import_module  # noqa: F401
+    with pytest.raises(product.FoamYadeError):
+        product.Solver(product.make_case(0, 8, 8, 8, 0.1, 0.01, 0.01, turbulence_model=1))           # icoFoamYade: laplacian(nu, U)
+    with pytest.raises(product.FoamYadeError):
+        product.Solver(product.make_case(1, 8, 8, 8, 0.1, 0.01, 0.01, turbulence_model=7))           # kEpsilon / kEqn: not built

@@ -61,10 +61,11 @@ def test_first_step_operators_are_identical(product):
     many.close(); one.close()
 
 
-@pytest.mark.parametrize("solver,n_slabs,models", [(1, 2, 0), (1, 3, 0), (0, 2, 0), (1, 2, 3)])
+@pytest.mark.parametrize("solver,n_slabs,models", [(1, 2, 0), (1, 3, 0), (0, 2, 0), (1, 2, 3), (1, 2, -1)])
 def test_coupled_slabs_match_single_domain(product, solver, n_slabs, models):
     """particles near slab interfaces: deposits/gathers reach up to 5 planes into the neighbours
-    (models = 3: with the opt-in added-mass / Gaussian-torque models, whose vGrad / ddtU gathers need the same halos)"""
+    (models = 3: with the opt-in added-mass / Gaussian-torque models, whose vGrad / ddtU gathers need the same halos;
+    models = -1: LES Smagorinsky, whose eddy viscosity is interpolated across the slab faces -- a moving lid on y+ makes it matter)"""
     n = 12
     nz = 12 * n_slabs
     dx = 0.1 / n
@@ -72,8 +73,14 @@ def test_coupled_slabs_match_single_domain(product, solver, n_slabs, models):
     u_val = [(0, 0, 0)] * 6
     if solver == 0:
         u_val[3] = (1.0, 0, 0)
+    if models < 0:
+        kw.update(turbulence_model=1, les_ck=0.3, nut_initial=1e-5, nut_bc=[0, 0, 1, 0, 0, 1], nut_value=[0, 0, 0.0, 0, 0, 2e-5])
+        u_val[3] = (0.5, 0, 0)
+        models = 0
     case = product.make_case(solver, n, n, nz, dx, 2e-4, 1e-5 if solver else 0.01, u_bc=[0] * 6, u_val=u_val, **kw)
     one = product.Solver(case); many = product.VirtualSlabs(case, n_slabs)
+    if case.turbulence_model:
+        assert np.all(many.get("nut") == 1e-5)
     if models:
         one.set_force_models(models)
         for sl in many.solvers:
@@ -89,6 +96,9 @@ def test_coupled_slabs_match_single_domain(product, solver, n_slabs, models):
             sc = np.abs(fo[:, cols]).max()
             assert sc > 0 and np.abs(fm[:, cols] - fo[:, cols]).max() <= 1e-6 * sc, (cols, np.abs(fm[:, cols] - fo[:, cols]).max() / sc)
     compare(many, one, ("U", "p", "alpha", "uSource") if solver else ("U", "p"), 1e-5)
+    if case.turbulence_model:
+        assert one.get("nut").max() > 1e-6
+        compare(many, one, ("nut",), 2e-5)
     many.close(); one.close()
 
 

@@ -92,7 +92,13 @@ class CaseDesc(C.Structure):
                 ("p_final_rel_tol", C.c_double), ("p_max_iter", C.c_int32),
                 ("u_tol", C.c_double), ("u_rel_tol", C.c_double), ("u_max_iter", C.c_int32), ("convection_scheme", C.c_int32),
                 ("adjust_time_step", C.c_int32), ("max_co", C.c_double), ("max_delta_t", C.c_double),
-                ("u_relax", C.c_double), ("u_relax_final", C.c_double), ("p_relax", C.c_double), ("p_relax_final", C.c_double)]
+                ("u_relax", C.c_double), ("u_relax_final", C.c_double), ("p_relax", C.c_double), ("p_relax_final", C.c_double),
+                ("turbulence_model", C.c_int32), ("les_ck", C.c_double), ("les_ce", C.c_double), ("les_delta_coeff", C.c_double),
+                ("nut_bc", C.c_int32 * 6), ("nut_value", C.c_double * 6), ("nut_initial", C.c_double)]
+
+
+TURBULENCE_LAMINAR, TURBULENCE_SMAGORINSKY = 0, 1
+NUT_ZERO_GRADIENT, NUT_FIXED_VALUE = 0, 1
 
 
 class FoamCaseInfo(C.Structure):
@@ -167,6 +173,7 @@ def lib():
     L.fy_foam_case_desc.argtypes = [vp, C.POINTER(CaseDesc)]
     L.fy_foam_case_info_get.argtypes = [vp, C.POINTER(FoamCaseInfo)]
     L.fy_foam_case_initial_fields.argtypes = [vp, _dp, _dp]
+    L.fy_foam_case_initial_nut.argtypes = [vp, _dp]
     L.fy_foam_case_write_time.argtypes = [vp, vp, C.c_char_p]
     L.fy_foam_case_close.argtypes = [vp]
     L.fy_solver_write_field_host.argtypes = [vp, C.c_char_p, _dp]
@@ -429,7 +436,12 @@ def make_case(solver, nx, ny, nz, dx, dt, nu, rho_f=1000.0, rho_p=2650.0, g=(0, 
                 c.u_value[q][a] = u_val[q][a]
     for k, v in kw.items():
         assert hasattr(c, k), k
-        setattr(c, k, v)
+        if isinstance(v, (list, tuple)):
+            arr = getattr(c, k)
+            for q, x in enumerate(v):
+                arr[q] = x
+        else:
+            setattr(c, k, v)
     return c
 
 
@@ -717,6 +729,11 @@ class FoamCase:
         U = np.zeros((self.n_cells, 3)); p = np.zeros(self.n_cells)
         _check(lib().fy_foam_case_initial_fields(self._h, _d(U), _d(p)))
         return U, p
+
+    def initial_nut(self):
+        nut = np.zeros(self.n_cells)
+        _check(lib().fy_foam_case_initial_nut(self._h, _d(nut)))
+        return nut
 
     def write(self, solver, time_name):
         _check(lib().fy_foam_case_write_time(self._h, solver._h, str(time_name).encode()))

@@ -30,7 +30,8 @@ struct fy_foam_case {
     std::string patch_of_side[6];               // blockMesh patch name covering XMIN, XMAX, YMIN, YMAX, ZMIN, ZMAX
     std::vector<std::string> patch_order;       // patch names in blockMeshDict order (one side each here)
     std::string u_bc_text[6], p_bc_text[6];     // the boundaryField entries as read, re-emitted on write
-    std::vector<double> U0, p0;                 // internalField of the start time
+    std::vector<double> U0, p0, nut0;           // internalField of the start time (nut0: turbulence cases only)
+    std::string nut_bc_text[6];
 };
 
 namespace {
@@ -39,6 +40,8 @@ using fy::fail;
 using fy::FoamDict;
 
 std::string join(const std::string& a, const std::string& b) { return a + "/" + b; }
+
+bool file_exists(const std::string& path) { struct stat st; return stat(path.c_str(), &st) == 0 && S_ISREG(st.st_mode); }
 
 int need_file(const std::string& path, FoamDict* d) {
     std::string err;
@@ -240,6 +243,34 @@ int read_fields(fy_foam_case* c) {
             }
         }
     }
+    if (c->desc.turbulence_model != FY_TURBULENCE_LAMINAR) {
+        // nut.<phase> [OF-6 eddyViscosity: nut_ is MUST_READ, named with the velocity's group]; uniform or nonuniform, patches zeroGradient |
+        // fixedValue (uniform) | calculated with a uniform value -- the latter only keeps its value, which is what fixedValue does here
+        const std::string path = join(c->dir, c->start_name + "/nut." + c->phase);
+        FoamDict f;
+        FY_TRY(need_file(path, &f));
+        FY_TRY(read_internal(f, path, 1, ncell, &c->nut0));
+        c->desc.nut_initial = c->nut0.empty() ? 0.0 : c->nut0[0];
+        const FoamDict* bf = f.subdict("boundaryField");
+        if (!bf) return fail(FY_ERR_INVALID, "%s: no boundaryField", path.c_str());
+        for (int s = 0; s < 6; ++s) {
+            const FoamDict* pd = bf->subdict(c->patch_of_side[s]);
+            std::string ty;
+            if (!pd || !pd->word("type", &ty)) return fail(FY_ERR_INVALID, "%s: boundaryField has no (typed) entry for patch '%s'", path.c_str(), c->patch_of_side[s].c_str());
+            c->nut_bc_text[s] = entry_text(*pd);
+            c->desc.nut_value[s] = 0.0;
+            if (ty == "zeroGradient") c->desc.nut_bc[s] = FY_BC_NUT_ZERO_GRADIENT;
+            else if (ty == "fixedValue") {
+                c->desc.nut_bc[s] = FY_BC_NUT_FIXED_VALUE;
+                const auto* vt = pd->tokens("value");
+                if (!vt || vt->size() < 2 || (*vt)[0] != "uniform" || !fy::foam_tok_is_number((*vt)[1], &c->desc.nut_value[s]))
+                    return fail(FY_ERR_UNSUPPORTED, "%s: patch '%s': fixedValue needs 'value uniform <nut>'", path.c_str(), c->patch_of_side[s].c_str());
+            } else {
+                return fail(FY_ERR_UNSUPPORTED, "%s: patch '%s': nut boundary type '%s' is not supported (zeroGradient, fixedValue; wall functions are not built)", path.c_str(),
+                            c->patch_of_side[s].c_str(), ty.c_str());
+            }
+        }
+    }
     return FY_OK;
 }
 
@@ -295,6 +326,39 @@ int read_controls(fy_foam_case* c) {
         FoamDict d;
         FY_TRY(need_file(path, &d));          // readGravitationalAcceleration.H (createFields.H:1 of both solvers)
         if (!d.vector3("value", c->desc.g)) return fail(FY_ERR_INVALID, "%s: 'value (gx gy gz)' missing", path.c_str());
+    }
+    if (c->solver == FY_SOLVER_PIMPLE) {
+        // continuousPhaseTurbulence (pimpleFoamYade/createFields.H): PhaseIncompressibleTurbulenceModel::New reads
+        // constant/turbulenceProperties.<phase> [OF-6: IOobject::groupName(turbulenceModel::propertiesName, U.group())]; the plain name is
+        // accepted too, and a case without the file runs the laminar model (the reference would stop).  DPMTurbulenceModels.C:67-77
+        // instantiates laminar Stokes, RAS kEpsilon, LES Smagorinsky and LES kEqn; Stokes and Smagorinsky are implemented.
+        std::string path = join(c->dir, "constant/turbulenceProperties." + c->phase);
+        FoamDict d;
+        bool have = file_exists(path);
+        if (!have) { path = join(c->dir, "constant/turbulenceProperties"); have = file_exists(path); }
+        if (have) {
+            FY_TRY(need_file(path, &d));
+            std::string sim;
+            if (!d.word("simulationType", &sim)) return fail(FY_ERR_INVALID, "%s: simulationType missing", path.c_str());
+            if (sim == "laminar") {
+                std::string lm;
+                const FoamDict* ld = d.subdict("laminar");
+                if (ld && ld->word("laminarModel", &lm) && lm != "Stokes") return fail(FY_ERR_UNSUPPORTED, "%s: laminarModel %s (DPMTurbulenceModels.C:67-68 instantiates Stokes only)", path.c_str(), lm.c_str());
+            } else if (sim == "LES") {
+                const FoamDict* ld = d.subdict("LES");
+                std::string model, delta;
+                if (!ld || !ld->word("LESModel", &model)) return fail(FY_ERR_INVALID, "%s: LES { LESModel ...; } missing", path.c_str());
+                if (model != "Smagorinsky") return fail(FY_ERR_UNSUPPORTED, "%s: LESModel %s is not implemented (Smagorinsky is; kEqn of DPMTurbulenceModels.C:76-77 is not)", path.c_str(), model.c_str());
+                bool on = true;
+                if (ld->boolean("turbulence", &on) && !on) return fail(FY_ERR_UNSUPPORTED, "%s: 'turbulence off' (frozen nut) is not supported: use simulationType laminar", path.c_str());
+                if (!ld->word("delta", &delta) || delta != "cubeRootVol") return fail(FY_ERR_UNSUPPORTED, "%s: LES delta must be cubeRootVol (got '%s')", path.c_str(), delta.c_str());
+                c->desc.turbulence_model = FY_TURBULENCE_SMAGORINSKY;
+                if (const FoamDict* sc = ld->subdict("SmagorinskyCoeffs")) { sc->scalar("Ck", &c->desc.les_ck); sc->scalar("Ce", &c->desc.les_ce); }
+                if (const FoamDict* dc = ld->subdict("cubeRootVolCoeffs")) dc->scalar("deltaCoeff", &c->desc.les_delta_coeff);
+            } else {
+                return fail(FY_ERR_UNSUPPORTED, "%s: simulationType %s is not implemented (laminar and LES Smagorinsky are; RAS kEpsilon of DPMTurbulenceModels.C:70-71 is not)", path.c_str(), sim.c_str());
+            }
+        }
     }
     {
         // the discretisation is fixed in this library (Euler ddt, Gauss linear grad / div / laplacian, linear
@@ -466,6 +530,13 @@ int fy_foam_case_initial_fields(const fy_foam_case* c, double* U, double* p) {
     return FY_OK;
 }
 
+int fy_foam_case_initial_nut(const fy_foam_case* c, double* nut) {
+    if (!c || !nut) return fail(FY_ERR_INVALID, "fy_foam_case_initial_nut: null argument");
+    if (c->nut0.empty()) return fail(FY_ERR_INVALID, "fy_foam_case_initial_nut: the case has no turbulence model");
+    std::memcpy(nut, c->nut0.data(), c->nut0.size() * sizeof(double));
+    return FY_OK;
+}
+
 int fy_foam_case_write_time(const fy_foam_case* c, fy_solver* s, const char* time_name) {
     if (!c || !s || !time_name || !*time_name) return fail(FY_ERR_INVALID, "fy_foam_case_write_time: null argument");
     const std::string tdir = join(c->dir, time_name);
@@ -488,6 +559,11 @@ int fy_foam_case_write_time(const fy_foam_case* c, fy_solver* s, const char* tim
         std::vector<double> a(n);
         FY_TRY(fy_solver_read_field_host(s, "alpha", a.data()));
         FY_TRY(write_field(c, tdir, time_name, "alpha." + c->phase, "volScalarField", "[0 0 0 0 0 0 0]", 1, a, nullptr, "        type            zeroGradient;\n"));
+    }
+    if (c->desc.turbulence_model != FY_TURBULENCE_LAMINAR) {
+        std::vector<double> nt(n);                                           // eddyViscosity::nut_ is AUTO_WRITE
+        FY_TRY(fy_solver_read_field_host(s, "nut", nt.data()));
+        FY_TRY(write_field(c, tdir, time_name, "nut." + c->phase, "volScalarField", "[0 2 -1 0 0 0 0]", 1, nt, c->nut_bc_text, "        type            zeroGradient;\n"));
     }
     return FY_OK;
 }

@@ -70,6 +70,10 @@ int main(int argc, char** argv) {
         std::vector<double> U(3 * (size_t)info.n_cells), p((size_t)info.n_cells);
         fy_foam_case_initial_fields(fc, U.data(), p.data());
         if (fy_solver_write_field_host(s, "p", p.data()) != FY_OK || fy_solver_write_field_host(s, "U", U.data()) != FY_OK) return die("initial fields");
+        if (cd.turbulence_model != FY_TURBULENCE_LAMINAR) {              // nut.<phase> of the start time (eddyViscosity: MUST_READ)
+            std::vector<double> nut((size_t)info.n_cells);
+            if (fy_foam_case_initial_nut(fc, nut.data()) != FY_OK || fy_solver_write_field_host(s, "nut", nut.data()) != FY_OK) return die("initial nut");
+        }
     }
     fy_solver_hold_sources(s, 1);                       // runTime.write() comes before setSourceZero (icoFoamYade.C:142-147)
 

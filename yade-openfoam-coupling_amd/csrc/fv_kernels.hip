@@ -468,7 +468,7 @@ __global__ __launch_bounds__(256) void k_pre_coupling(FvGeo g, const double* __r
         for (int q = 0; q < 3; ++q) divT[3 * (size_t)c + q] = 2 * g.nu * (lap[q] * g.rV);
     if (Gout) {
         const double tr = T[0] + T[4] + T[8];
-        const double an = alpha[c] * g.nu;
+        const double an = g.nut ? alpha[c] * (g.nu + g.nut[c]) : alpha[c] * g.nu;      // alpha nuEff (nuEff = nut + nu [OF-6 eddyViscosity/linearViscousStress])
         // stored BY ROWS (three vec3 arrays): k_div_G takes row d from the +-d neighbours only, so it streams 24-byte records
         // instead of picking 24 bytes out of 72-byte ones (fewer lines per load instruction, and the z-planes it re-reads fit L2)
         const size_t rs = g_row_stride(g);
@@ -504,6 +504,30 @@ __global__ __launch_bounds__(256) void k_div_G(FvGeo g, const double* __restrict
     for (int q = 0; q < 3; ++q) divG[3 * (size_t)c + q] = acc[q];
 }
 
+// continuousPhaseTurbulence->correct() (pimpleFoamYade.C:101-104) for LESModel Smagorinsky (DPMTurbulenceModels.C:73-74) [OF-6
+// Smagorinsky.C: k(gradU), correctNut()]: D = symm(grad U); a = Ce/delta; b = (2/3) tr(D); c = 2 Ck delta (dev(D) && D);
+// k = sqr((-b + sqrt(sqr(b) + 4 a c)) / (2 a)); nut = Ck delta sqrt(k).  grad U is the Gauss-linear gradient k_pre_coupling just wrote.
+__global__ __launch_bounds__(256) void k_smagorinsky_nut(FvGeo g, const double* __restrict__ vGrad, double ck, double ce, double delta, double* __restrict__ nut) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= g.Nc) return;
+    const int c = t + g.c0;
+    double T[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) T[q] = vGrad[9 * (size_t)c + q];
+    const double Dxx = T[0], Dyy = T[4], Dzz = T[8];
+    const double Dxy = 0.5 * (T[1] + T[3]), Dxz = 0.5 * (T[2] + T[6]), Dyz = 0.5 * (T[5] + T[7]);
+    const double trD = Dxx + Dyy + Dzz;
+    const double a = ce / delta;
+    const double b = (2.0 / 3.0) * trD;
+    const double third = (1.0 / 3.0) * trD;
+    // dev(D) && D over the nine components of the symmetric tensors
+    const double dd = (Dxx - third) * Dxx + (Dyy - third) * Dyy + (Dzz - third) * Dzz + 2.0 * (Dxy * Dxy) + 2.0 * (Dxz * Dxz) + 2.0 * (Dyz * Dyz);
+    const double cc = 2.0 * ck * delta * dd;
+    const double r = (-b + sqrt(b * b + 4.0 * a * cc)) / (2.0 * a);
+    const double kk = r * r;
+    nut[c] = ck * delta * sqrt(kk);
+}
+
 // UEqn (icoFoamYade.C:79-85) / UcEqn + relax (UcEqn.H:3-12): diag, 6 neighbour coefficients, source (no pressure term), rAU = 1/A
 __global__ __launch_bounds__(256) void k_assemble_momentum(FvGeo g, const double* __restrict__ U, const double* __restrict__ Uold,
                                                            const double* __restrict__ alpha, const double* __restrict__ alphaOld, CFace3 alphaf,
@@ -529,7 +553,18 @@ __global__ __launch_bounds__(256) void k_assemble_momentum(FvGeo g, const double
             const double af = pim ? alphaf.a[d][f] : 1.0;
             const double phio = (s ? 1.0 : -1.0) * af * phi.a[d][f];
             divAPhi += phio;
-            const double gam = nu * af * g.dx;
+            // fvm::laplacian(alpha nuEff, U): the face diffusivity is the linear interpolate of the cell field alpha (nu + nut) [OF-6
+            // linearViscousStress::divDevRhoReff, gaussLaplacianScheme]; its boundary value is alpha_b (nu + nut_b).  Laminar: nu alphaf
+            double gam = nu * af * g.dx;
+            if (g.nut) {
+                if (onb(g, d, s, i, j, k)) {
+                    const double nb = g.nut_bc[2 * d + s] == 1 ? g.nut_val[2 * d + s] : g.nut[c];
+                    gam = (af * (nu + nb)) * g.dx;
+                } else {
+                    const int nbc = c + (s ? stride_of(g, d) : -stride_of(g, d));
+                    gam = (0.5 * ((aP * (nu + g.nut[c])) + (alpha[nbc] * (nu + g.nut[nbc])))) * g.dx;
+                }
+            }
             if (onb(g, d, s, i, j, k)) {
                 an[2 * d + s] = 0.0;
                 const int patch = 2 * d + s;
@@ -1250,6 +1285,12 @@ int launch_interp_alpha(hipStream_t s, FvGeo g, const double* alpha, Face3 af) {
 
 int launch_div_G(hipStream_t s, FvGeo g, const double* G, double* divG) {
     hipLaunchKernelGGL(k_div_G, dim3(div_up(g.Nc, 256)), dim3(256), 0, s, g, G, divG);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+
+int launch_smagorinsky_nut(hipStream_t s, FvGeo g, const double* vGrad, double ck, double ce, double delta, double* nut) {
+    hipLaunchKernelGGL(k_smagorinsky_nut, dim3(div_up(g.Nc, 256)), dim3(256), 0, s, g, vGrad, ck, ce, delta, nut);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }

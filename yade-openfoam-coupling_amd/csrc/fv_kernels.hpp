@@ -26,6 +26,10 @@ struct FvGeo {
     int pimple;
     int upwind;             // div(phi,U): 0 Gauss linear, 1 Gauss upwind (first order, bounded), 2 Gauss linearUpwind (upwind + explicit gradient correction)
     double dt, nu;
+    // continuousPhaseTurbulence: nut = nullptr is the laminar (Stokes) model -- every kernel then computes exactly what it did without one
+    const double* nut;      // [storage cells] eddy viscosity of the Smagorinsky model (k_smagorinsky_nut), ghost planes refreshed by the solver
+    int nut_bc[6];          // FY_BC_NUT_*
+    double nut_val[6];
     double u_relax;         // fvMatrix::relax factor of UcEqn for the current outer iteration (<= 0: no relaxationFactors entry, relax() is a no-op)
     double g[3];
     int need_ref, p_ref_cell;
@@ -66,6 +70,7 @@ int launch_pre_coupling(hipStream_t s, FvGeo g, const double* U, const double* p
 int launch_interp_alpha(hipStream_t s, FvGeo g, const double* alpha, Face3 alphaf);
 // G: three vec3 fields (rows of the tensor) over the whole storage, as k_pre_coupling writes them
 int launch_div_G(hipStream_t s, FvGeo g, const double* G, double* divG);
+int launch_smagorinsky_nut(hipStream_t s, FvGeo g, const double* vGrad, double ck, double ce, double delta, double* nut);
 int launch_assemble_momentum(hipStream_t s, FvGeo g, const double* U, const double* Uold, const double* alpha, const double* alphaOld,
                              CFace3 alphaf, CFace3 phi, const double* uSource, const double* uSourceDrag, const double* divG,
                              const double* vGrad /* grad(U) of the current iterate: linearUpwind only */, Mom7 M, double* src, double* rAU);

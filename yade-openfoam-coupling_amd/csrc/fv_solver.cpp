@@ -52,6 +52,8 @@ struct Solver {
     SelfComm self_comm;
 
     DevBuf<double> U, Uold, p, alpha, uSource, uSourceDrag, uParticle, gradP, divT, vGrad, ddtU;
+    DevBuf<double> nut;                  // eddy viscosity (FY_TURBULENCE_SMAGORINSKY), storage cells; empty = laminar
+    double les_delta = 0.0;              // LESdelta cubeRootVol: deltaCoeff * cbrt(V) [OF-6 cubeRootVolDelta.C]
     bool phi_fresh = true;      // phi holds the current flux (false between the start-of-step exchange with phiOld and the first flux correction)
     CFace3 phi_now() const { return phi_fresh ? CFace3{{phi[0].p, phi[1].p, phi[2].p}} : CFace3{{phiOld[0].p, phiOld[1].p, phiOld[2].p}}; }
     bool rAU_new = true;        // rAU was (re)assembled since the last corrector: rAUf and the coarse pressure operators are stale
@@ -159,6 +161,16 @@ struct Solver {
         for (int a = 0; a < 3; ++a) g.g[a] = c->g[a];
         g.need_ref = need_ref ? 1 : 0; g.p_ref_cell = c->p_ref_cell; g.p_ref_value = c->p_ref_value;
         g.u_relax = c->u_relax;
+        if (c->turbulence_model != FY_TURBULENCE_LAMINAR && c->turbulence_model != FY_TURBULENCE_SMAGORINSKY) return fail(FY_ERR_UNSUPPORTED, "fy_solver_create: unknown turbulence_model %d (laminar and LES Smagorinsky are implemented; kEpsilon and kEqn of DPMTurbulenceModels.C:70-77 are not)", c->turbulence_model);
+        if (c->turbulence_model != FY_TURBULENCE_LAMINAR) {
+            if (!pimple) return fail(FY_ERR_INVALID, "fy_solver_create: icoFoamYade has no turbulence model (icoFoamYade.C:79-85 is laplacian(nu, U))");
+            if (!(c->les_ck > 0 && c->les_ce > 0 && c->les_delta_coeff > 0) || c->nut_initial < 0) return fail(FY_ERR_INVALID, "fy_solver_create: Smagorinsky needs Ck, Ce, deltaCoeff > 0 and nut >= 0");
+            for (int q = 0; q < 6; ++q) {
+                if (c->nut_bc[q] != FY_BC_NUT_ZERO_GRADIENT && c->nut_bc[q] != FY_BC_NUT_FIXED_VALUE) return fail(FY_ERR_INVALID, "fy_solver_create: unknown nut boundary type");
+                g.nut_bc[q] = c->nut_bc[q]; g.nut_val[q] = c->nut_value[q];
+            }
+            les_delta = c->les_delta_coeff * std::pow(g.V, 1.0 / 3.0);
+        }
         if (c->adjust_time_step && !(c->max_co > 0 && c->max_delta_t > 0)) return fail(FY_ERR_INVALID, "adjustTimeStep needs maxCo > 0 and maxDeltaT > 0");
         if (c->u_relax > 1 || c->u_relax_final > 1 || c->p_relax > 1 || c->p_relax_final > 1) return fail(FY_ERR_INVALID, "relaxation factors lie in (0, 1]");
         if (need_ref) {
@@ -186,6 +198,7 @@ struct Solver {
         for (auto* b : v1) { FY_TRY(b->alloc_exact(n)); FY_TRY(zero(*b)); }
         for (auto& b : man) { FY_TRY(b.alloc_exact(n)); FY_TRY(zero(b)); }
         FY_TRY(vGrad.alloc_exact(9 * n)); FY_TRY(zero(vGrad));
+        if (c->turbulence_model != FY_TURBULENCE_LAMINAR) { FY_TRY(nut.alloc_exact(n)); FY_TRY(launch_fill_f64(stream, nut.p, n, c->nut_initial)); g.nut = nut.p; }
         FY_TRY(Gt.alloc_exact(9 * n)); FY_TRY(zero(Gt));
         for (int d = 0; d < 3; ++d) {
             DevBuf<double>* fs[] = {&phi[d], &phiOld[d], &psn[d], &alphaf[d], &phiHbyA[d], &phiForces[d], &rAUf[d], &pflux[d]};
@@ -611,6 +624,14 @@ struct Solver {
     }
     void note_courant(const double* h) { st.courant_max = 0.5 * h[0] * cs.dt; st.courant_mean = 0.5 * (h[1] / (g.V * (double)Nglob)) * cs.dt; }
 
+    // continuousPhaseTurbulence->correct() for LES Smagorinsky: nut from the Gauss-linear gradient of the corrected velocity
+    int turbulence_correct() {
+        FY_TRY(halo_cells(U, 3, 1));
+        FY_TRY(launch_pre_coupling(stream, g, U.p, p.p, alpha.p, C3(psn), vGrad.p, gradP.p, divT.p, nullptr, 1, 0));
+        FY_TRY(launch_smagorinsky_nut(stream, g, vGrad.p, cs.les_ck, cs.les_ce, les_delta, nut.p));
+        return halo_cells(nut, 1, 1);
+    }
+
     // ---- one pass of the while (runTime.loop()) body ---------------------------------------------------------------------
     int step() {
         FY_HIP(hipSetDevice(device));
@@ -710,6 +731,7 @@ struct Solver {
             }
             clk_mom.end(stream);
             for (int corr = 0; corr < cs.n_correctors; ++corr) FY_TRY(corrector(outer == nOuter - 1 && corr == cs.n_correctors - 1));
+            if (g.nut && final_outer) FY_TRY(turbulence_correct());        // pimple.turbCorr(): on the final outer iteration only (the default) -- pimpleFoamYade.C:101-104
         }
         if (hold_sources) sources_pending = true;                                              // reset deferred to the next step (fy_solver_hold_sources)
         else FY_TRY(cpl->c.set_source_zero());                                                // icoFoamYade.C:147, pimpleFoamYade.C:109
@@ -742,8 +764,9 @@ struct Solver {
         const E tab[] = {{"U", U.p, 3 * n, 3}, {"p", p.p, n, 1}, {"phi_x", phi[0].p, phi[0].n, 0}, {"phi_y", phi[1].p, phi[1].n, 0}, {"phi_z", phi[2].p, phi[2].n, 0},
                          {"rAU", rAU.p, n, 1}, {"HbyA", HbyA.p, 3 * n, 3}, {"p_rhs", prhs.p, n, 1}, {"mom_diag", mdiag.p, n, 1}, {"mom_src", src.p, 3 * n, 3},
                          {"alpha", alpha.p, n, 1}, {"uSource", uSource.p, 3 * n, 3}, {"uSourceDrag", uSourceDrag.p, n, 1}, {"uParticle", uParticle.p, 3 * n, 3},
-                         {"gradP", gradP.p, 3 * n, 3}, {"divT", divT.p, 3 * n, 3}, {"vGrad", vGrad.p, 9 * n, 9}, {"ddtU", ddtU.p, 3 * n, 3}};
+                         {"gradP", gradP.p, 3 * n, 3}, {"divT", divT.p, 3 * n, 3}, {"vGrad", vGrad.p, 9 * n, 9}, {"ddtU", ddtU.p, 3 * n, 3}, {"nut", nut.p, n, 1}};
         for (const E& e : tab) if (s == e.nm) {
+            if (!e.p) return fail(FY_ERR_INVALID, "solver field '%s' does not exist in this case (no turbulence model)", s.c_str());
             *ptr = e.p + (size_t)e.comp * g.c0;          // skip the ghost planes below the owned range (comp = 0: face array)
             *count = e.c;
             return FY_OK;
@@ -775,6 +798,7 @@ void fy_case_defaults(fy_case_desc* c, int solver) {
     c->u_tol = 1e-5; c->u_rel_tol = 0.0; c->u_max_iter = 1000;
     c->adjust_time_step = 0; c->max_co = 1.0; c->max_delta_t = 1e300;
     c->u_relax = 1.0; c->u_relax_final = 0.0; c->p_relax = 0.0; c->p_relax_final = 0.0;
+    c->turbulence_model = FY_TURBULENCE_LAMINAR; c->les_ck = 0.094; c->les_ce = 1.048; c->les_delta_coeff = 1.0;     // [OF-6 Smagorinsky.C, cubeRootVolDelta.C defaults]
 }
 
 static int solver_create_impl(const fy_case_desc* c, const fy_transport* tr, int device_ordinal, fy::Comm* cm, fy_solver** out) {
@@ -872,6 +896,7 @@ int fy_solver_write_field_host(fy_solver* s, const char* name, const double* in)
         FY_TRY(s->s.halo_cells(s->s.U, 3, 1));
         FY_TRY(fy::launch_flux_of(s->s.stream, s->s.g, s->s.U.p, s->s.F3(s->s.phi)));
     }
+    if (std::string(name) == "nut") FY_TRY(s->s.halo_cells(s->s.nut, 1, 1));
     FY_HIP(hipStreamSynchronize(s->s.stream));
     return FY_OK;
 }
