@@ -11,10 +11,14 @@ for f in glob.glob(root + "/s*/*/*counter_collection.csv"):
             data[m.group(1)][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in data.items():
     av = {n: sum(v) / len(v) for n, v in d.items()}
-    g = av.get("GRBM_GUI_ACTIVE", float("nan"))
+    # GRBM_GUI_ACTIVE comes back summed over the 8 XCDs (2.7e7 "cycles" for a 1.3 ms kernel): per-unit shares are taken against one XCD's count
+    g = av.get("GRBM_GUI_ACTIVE", float("nan")) / 8.0
     print(k)
     def pct(a, b): return f"{100 * av[a] / av[b]:.1f} %" if a in av and b in av and av[b] else "n/a"
-    print("   TA busy / GUI active (per TA, 256 of them):", f"{100 * av.get('TA_TA_BUSY_sum', float('nan')) / 256 / g:.1f} %" if g == g else "n/a")
+    print("   TA busy / GUI active (per TA, 256 of them):", f"{100 * av.get('TA_TA_BUSY_sum', float('nan')) / 256 / g:.1f} %" if g == g else "n/a",
+          "| TD busy:", f"{100 * av.get('TD_TD_BUSY_sum', float('nan')) / 256 / g:.1f} %" if g == g else "n/a",
+          "| L1 line accesses per clock per CU:", f"{av.get('TCP_TOTAL_CACHE_ACCESSES_sum', float('nan')) / 256 / g:.2f}" if g == g else "n/a",
+          "| LDS index pipe busy:", f"{100 * av.get('SQ_LDS_IDX_ACTIVE', float('nan')) / 256 / g:.1f} %" if g == g else "n/a")
     print("   VALU active / busy cycles:", pct("SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES"), "| VMEM:", pct("SQ_ACTIVE_INST_VMEM", "SQ_BUSY_CYCLES"), "| LDS:", pct("SQ_ACTIVE_INST_LDS", "SQ_BUSY_CYCLES"))
     print("   wave cycles waiting:", pct("SQ_WAIT_ANY", "SQ_WAVE_CYCLES"), "| LDS bank conflict share of LDS cycles:", pct("SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"))
     print("   VALU / VMEM-read / VMEM-write / SALU instructions:", *(f"{av.get(n, float('nan')):.3g}" for n in ("SQ_INSTS_VALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_SALU")))

@@ -119,6 +119,26 @@ class StepStats(C.Structure):
 _lib = None
 
 
+def _share_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch's ROCm wheel bundles its own libamdhip64 (soname libamdhip64.so.7, file name libamdhip64.so)
+    and libtorch_hip asks for it by FILE name, so a process that loads this library first (resolved to /opt/rocm's copy) and initialises
+    torch.cuda later ends up with two HIP/ROCr runtimes side by side -- which works for a while and then fails in torch
+    ("No HIP GPUs are available" after a few dozen contexts).  Loading the wheel's copy first makes both resolve to the same object.
+    torch itself is not imported."""
+    if "torch" in sys.modules:
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.origin:
+            return
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except (OSError, ImportError, ValueError):
+        pass
+
+
 def lib():
     """load the product library; raises if it has not been built (no silent fallback)."""
     global _lib
@@ -126,6 +146,7 @@ def lib():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise FoamYadeError(f"{LIB_PATH} is missing: run __graft_entry__.build() (there is no CPU fallback)")
+    _share_torch_hip_runtime()
     L = C.CDLL(LIB_PATH)
     vp = C.c_void_p
     L.fy_last_error.restype = C.c_char_p

@@ -1191,6 +1191,13 @@ __global__ __launch_bounds__(MODE == 1 ? 256 : kForceThreads) void k_force_gauss
     if (i < n) {
         const int chain = p.chain_len[i];
         const int k = chain < kMaxK ? chain : kMaxK;
+        // The stencil rows are a ring indexed by push order (slot = push index & 15).  The loops below walk the k newest entries OLDEST
+        // FIRST: row (chain - k + t) & 15, which is row t for every chain that never wrapped (chain <= 12: all of them in practice) -- so
+        // in iteration t all lanes of a wave read the same row, whatever their chain lengths, and the id / weight loads are coalesced
+        // (walking newest first, row (chain - 1 - t) & 15, spread each load over as many rows as the wave has chain lengths: ~8).
+        // The sums are the reference's sums taken in the opposite order (FoamYade.C:358-365 runs over the container newest first);
+        // the difference is rounding in the last bits (covered by the 1e-10 bar of the golden tests).
+        const int first = chain - k;
         ParticleForce pf{0.0, 0.0, 0.0, 0.0};
         if constexpr (MODE != 2) {
             const int32_t orig = p.orig[i];
@@ -1205,7 +1212,7 @@ __global__ __launch_bounds__(MODE == 1 ? 256 : kForceThreads) void k_force_gauss
                 Interp s{0, 0, 0, 0, 0, 0, 0, 0};
                 ModelSums ms{0, 0, 0, 0, 0, 0, 0};
                 for (int t = 0; t < k; ++t) {
-                    const size_t slot = (size_t)((chain - 1 - t) & (kMaxK - 1)) * p.cap + (size_t)i;
+                    const size_t slot = (size_t)((first + t) & (kMaxK - 1)) * p.cap + (size_t)i;
                     const int64_t cl = (int64_t)p.ids[slot] - cw.base;
                     if (cl < 0 || cl >= cw.n_field) continue;
 #if defined(FY_EXP_SAMECELL)
@@ -1216,7 +1223,7 @@ __global__ __launch_bounds__(MODE == 1 ? 256 : kForceThreads) void k_force_gauss
                 }
                 if (fp.models)                              // uniform: off in the shipped reference
                     for (int t = 0; t < k; ++t) {
-                        const size_t slot = (size_t)((chain - 1 - t) & (kMaxK - 1)) * p.cap + (size_t)i;
+                        const size_t slot = (size_t)((first + t) & (kMaxK - 1)) * p.cap + (size_t)i;
                         const int64_t cl = (int64_t)p.ids[slot] - cw.base;
                         if (cl < 0 || cl >= cw.n_field) continue;
                         model_add(ms, fp, vGrad, ddtU, cl, p.w[slot], volp);
@@ -1243,7 +1250,7 @@ __global__ __launch_bounds__(MODE == 1 ? 256 : kForceThreads) void k_force_gauss
                 // a uniform block's cell volume is a constant, not a gather
                 const double ooUniform = fp.uniform_vol > 0 ? 1. / (fp.uniform_vol * fp.rhoF) : 0.0;
                 for (int t = 0; t < k; ++t) {
-                    const size_t slot = (size_t)((chain - 1 - t) & (kMaxK - 1)) * p.cap + (size_t)i;
+                    const size_t slot = (size_t)((first + t) & (kMaxK - 1)) * p.cap + (size_t)i;
                     const int64_t cl = (int64_t)p.ids[slot] - cw.base;
                     if (cl < 0 || cl >= cw.n_field) continue;
                     const int32_t c = (int32_t)cl;
