@@ -500,7 +500,7 @@ def main():
                              "drag + Archimedes + back-scatter: particle 64 B + stencil 12 B/pair in, force record 52 B out; per cell the 64-byte "
                              "gather record read and 32 B of momentum-source accumulators read-modify-written"),
         "k_point_force": (acc["force"], K, 128.0 * np_part, "findCell + Stokes drag / torque + uSource scatter: 80 B record in, 48 B force out per particle"),
-        "k_mg_smooth(level 0)": (smooth_ms, smooth_n, 56.0 * nc, "pEqn Laplacian apply fused with the damped-Jacobi update: 48 B/cell (diag, 3 upper, x, y) + b 8"),
+        "k_mg_smooth(level 0)": (smooth_ms, smooth_n, 56.0 * nc, "k_mg_smooth / k_mg_smooth_dot at level 0: pEqn Laplacian apply fused with the Jacobi update (and the z.r partials): 48 B/cell (diag, 3 upper, x, y) + b 8"),
         "k_p_apply_dot": (apply_ms, apply_n, 48.0 * nc, "pEqn Laplacian apply y = A p (+ p.Ap) inside PCG: 48 B/cell"),
         "k_mom_pass": (mom_ms, mom_n, (7 * 8 + 24 * 3) * nc, "fused momentum Jacobi pass: 7 coeffs + b,x,xn (3 comps)"),
     }
@@ -551,7 +551,7 @@ def main():
         "coupled_steps_per_sec_of_the_whole_box": round(steps_per_s if strong else steps_per_s / world, 4),
         "config": {"workload": workload,
                    "cells": nc, "particles": np_part, "dt": args.dt, ("piso" if c2 else "pimple"): ({"nCorrectors": 2} if c2 else {"nOuterCorrectors": 1, "nCorrectors": 2}),
-                   "p_solver": "PCG+MG V(2,2) damped Jacobi" if args.p_solver == 1 else "PCG+Jacobi",
+                   "p_solver": "PCG+MG V(2,2), Chebyshev-weighted Jacobi pairs" if args.p_solver == 1 else "PCG+Jacobi",
                    "p_tol": [case.p_tol, case.p_rel_tol, case.p_final_tol, case.p_final_rel_tol],
                    "parallelism": parallelism,
                    "global_cells": nc * world, "global_particles": args.particles if strong else np_part * world},

@@ -1,11 +1,10 @@
 #!/bin/bash
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
-true
-V=$R/yade-openfoam-coupling_amd/lib/variants/libfoamyade_hip_prev.so
+python -m pytest tests/test_fv_parity.py tests/test_fv_known_answers_gpu.py tests/test_slabs.py -x -q -m gpu 2>&1 | tail -2
 for rep in 1 2; do
-for lib in "" $V $R/yade-openfoam-coupling_amd/lib/variants/libfoamyade_hip_cache.so; do
-  echo "== lib=$lib"
-  FOAMYADE_HIP_LIB=$lib python bench.py --steps 20 --warmup 3 --no-cpu-baseline --wire 0 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['per_step_ms'])"
+for e in "" FOAMYADE_NO_PROLONG_FUSION=1; do
+  echo "== $e"
+  env $e python bench.py --steps 20 --warmup 3 --no-cpu-baseline --wire 0 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['per_step_ms'], d.get('p_iters_per_step'), d.get('roofline_pEqn_laplacian'))"
 done
 done

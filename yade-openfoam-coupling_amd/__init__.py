@@ -226,7 +226,7 @@ def _hip():
     """the HIP runtime through ctypes (the stub needs a few bytes of device scratch for particle tags; no torch involved)"""
     global _hip_rt
     if _hip_rt is None:
-        _hip_rt = C.CDLL("libamdhip64.so")
+        _hip_rt = C.CDLL("libamdhip64.so.7")       # by SONAME: resolves to the runtime this process already has (see _share_torch_hip_runtime)
         _hip_rt.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
         _hip_rt.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
         _hip_rt.hipFree.argtypes = [C.c_void_p]

@@ -113,6 +113,7 @@ int launch_mg_smooth(hipStream_t s, PMat A, const double* b, const double* x, do
 int launch_mg_smooth_dot(hipStream_t s, PMat A, const double* b, const double* x, double* xn, double w, double* partials);      // xn = x + w (b - A x)/diag
 int launch_mg_residual_restrict(hipStream_t s, PMat A, const double* b, const double* x, PMat C, double* bc);   // bc = P^T (b - A x)
 int launch_mg_prolong_add(hipStream_t s, PMat A, double* x, PMat C, const double* xc);
+int launch_mg_smooth_prolong(hipStream_t s, PMat A, const double* b, const double* x, PMat C, const double* xc, double* xn, double w);   // x += P xc, then one sweep (fused)
 int launch_mg_coarse_solve(hipStream_t s, PMat A, const double* b, double* x, double* tmp, int sweeps, double w);
 // the whole V-cycle below a size threshold in one workgroup; level l result: x1[l] (x0 for the coarsest / a single-level tail)
 constexpr int kMgTailMax = 6;

@@ -424,7 +424,9 @@ struct Solver {
         }
         FY_TRY(halo_level(L, L.xcur));
         if (with_dot) {                                    // (single domain only: the caller checks)
+            if (l == 0) kc[KC_MG_SMOOTH0].begin(stream);
             FY_TRY(launch_mg_smooth_dot(stream, L.A, L.bptr, L.xcur, L.xalt, w, partials.p));
+            if (l == 0) kc[KC_MG_SMOOTH0].end(stream);
             std::swap(L.xcur, L.xalt);
             return FY_OK;
         }
@@ -500,16 +502,23 @@ struct Solver {
             PMat loc = Cc.A;                      // this rank's slice of the replicated coarse solution
             loc.c0 = (int)(Cc.plane * (size_t)(L.A.nz / 2) * (size_t)comm->rank);
             FY_TRY(launch_mg_prolong_add(stream, L.A, L.xcur, loc, Cc.xcur));
+            for (int s = W.n - 1; s >= 1; --s) FY_TRY(smooth(l, L, W.w[s]));
+        } else if (!L.distributed && W.n >= 2 && fuse_prolong) {
+            // prolongation fused into the first post-smoothing sweep (bit-identical; one launch and one pass over the level fewer)
+            FY_TRY(launch_mg_smooth_prolong(stream, L.A, L.bptr, L.xcur, Cc.A, Cc.xcur, L.xalt, W.w[W.n - 1]));
+            std::swap(L.xcur, L.xalt);
+            for (int s = W.n - 2; s >= 1; --s) FY_TRY(smooth(l, L, W.w[s]));
         } else {
             FY_TRY(launch_mg_prolong_add(stream, L.A, L.xcur, Cc.A, Cc.xcur));
+            for (int s = W.n - 1; s >= 1; --s) FY_TRY(smooth(l, L, W.w[s]));
         }
-        for (int s = W.n - 1; s >= 1; --s) FY_TRY(smooth(l, L, W.w[s]));
         // the last sweep of the whole cycle also leaves the partials of z.r where PCG's launch_dot would (vcycle_dot_done)
         vcycle_dot_done = l == 0 && want_vcycle_dot && !L.distributed && L.A.N == Nc && L.A.c0 == g.c0;
         FY_TRY(smooth(l, L, W.w[0], vcycle_dot_done));
         return FY_OK;
     }
     bool want_vcycle_dot = false, vcycle_dot_done = false;
+    bool fuse_prolong = getenv("FOAMYADE_NO_PROLONG_FUSION") == nullptr;     // A/B switch (identical results)
 
     // coarse operators: A_{l+1} = 1/2 P^T A_l P level by level; the first replicated level is all-gathered from the slabs' slices
     int build_coarse_operators() {
