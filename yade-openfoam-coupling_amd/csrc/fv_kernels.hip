@@ -785,33 +785,62 @@ __global__ __launch_bounds__(256) void k_cont_err(FvGeo g, CFace3 phi, CFace3 al
 
 // ico:    U = HbyA - rAU*fvc::grad(p)                                                         icoFoamYade.C:136
 // pimple: Uc = HbyA + rAUc*fvc::reconstruct((phicForces - pEqn.flux()/alphacf)/rAUcf)         pEqn.H:43-45
+// DIAG: the same pass also forms the two per-cell diagnostics of the corrected flux that used to be sweeps of their own -- the continuity
+// errors (continuityErrs.H:32-46, k_cont_err; slots 0, 1) and the Courant sums of the NEXT pass of the time loop (CourantNo.H:32-49,
+// k_courant; slots 2 = max, 3 = sum: phi does not change between the last corrector and the next runTime++).  Same per-cell expressions
+// and the same block partition as the stand-alone kernels, so the folded values are the same bits.
+template <bool DIAG>
 __global__ __launch_bounds__(256) void k_U_correct(FvGeo g, const double* __restrict__ HbyA, const double* __restrict__ rAU,
                                                    const double* __restrict__ p, CFace3 psn, CFace3 phiForces, CFace3 pflux, CFace3 alphaf,
-                                                   CFace3 rAUf, double* __restrict__ U) {
-    const int t = swz_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
-    if (t >= g.Nc) return;
-    int i, j, k; ijk_of(g, t, i, j, k);
-    const int c = t + g.c0;
-    const double r = rAU[c];
-    double out[3];      // see k_bmom
+                                                   CFace3 rAUf, double* __restrict__ U, CFace3 phi, const double* __restrict__ alpha,
+                                                   const double* __restrict__ alphaOld, double* __restrict__ partials) {
+    double v[4] = {0, 0, 0, 0};
+    FY_RED_LOOP(t, g.Nc) {
+        int i, j, k; ijk_of(g, t, i, j, k);
+        const int c = t + g.c0;
+        const double r = rAU[c];
+        double out[3];      // see k_bmom
+        double dv = 0.0, sp = 0.0;
 #pragma unroll
-    for (int d = 0; d < 3; ++d) {
-        if (!g.pimple) {
-            double fv[2];
+        for (int d = 0; d < 3; ++d) {
+            if (!g.pimple) {
+                double fv[2];
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                if (onb(g, d, s, i, j, k)) fv[s] = pbv(g, p, psn, c, d, s, cface(g, d, s, i, j, k));
-                else fv[s] = 0.5 * (p[c] + p[c + (s ? stride_of(g, d) : -stride_of(g, d))]);
+                for (int s = 0; s < 2; ++s) {
+                    if (onb(g, d, s, i, j, k)) fv[s] = pbv(g, p, psn, c, d, s, cface(g, d, s, i, j, k));
+                    else fv[s] = 0.5 * (p[c] + p[c + (s ? stride_of(g, d) : -stride_of(g, d))]);
+                }
+                out[d] = HbyA[3 * (size_t)c + d] - r * ((fv[1] - fv[0]) * g.rdx);
+            } else {
+                double sm = 0;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) { const int f = cface(g, d, s, i, j, k); sm += (phiForces.a[d][f] - pflux.a[d][f] / alphaf.a[d][f]) / rAUf.a[d][f]; }
+                out[d] = HbyA[3 * (size_t)c + d] + r * (sm / (2.0 * g.Af));
             }
-            out[d] = HbyA[3 * (size_t)c + d] - r * ((fv[1] - fv[0]) * g.rdx);
-        } else {
-            double sm = 0;
+            if (DIAG) {
 #pragma unroll
-            for (int s = 0; s < 2; ++s) { const int f = cface(g, d, s, i, j, k); sm += (phiForces.a[d][f] - pflux.a[d][f] / alphaf.a[d][f]) / rAUf.a[d][f]; }
-            out[d] = HbyA[3 * (size_t)c + d] + r * (sm / (2.0 * g.Af));
+                for (int s = 0; s < 2; ++s) {
+                    const int f = cface(g, d, s, i, j, k);
+                    const double ph = phi.a[d][f];
+                    dv += (s ? 1.0 : -1.0) * (g.pimple ? alphaf.a[d][f] : 1.0) * ph;
+                    sp += fabs(ph);
+                }
+            }
+        }
+        for (int d = 0; d < 3; ++d) U[3 * (size_t)c + d] = out[d];
+        if (DIAG) {
+            double ce = dv * g.rV;
+            if (g.pimple) ce += (alpha[c] - alphaOld[c]) / g.dt;
+            v[0] += fabs(ce) * g.V;
+            v[1] += ce * g.V;
+            v[2] = fmax(v[2], sp * g.rV);
+            v[3] += sp;
         }
     }
-    for (int d = 0; d < 3; ++d) U[3 * (size_t)c + d] = out[d];
+    if (DIAG) {
+        const int mx[4] = {0, 0, 1, 0};
+        block_reduce_store<4>(v, mx, partials);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ pressure solver
@@ -1417,7 +1446,14 @@ int launch_cont_err(hipStream_t s, FvGeo g, CFace3 phi, CFace3 alphaf, const dou
 
 int launch_U_correct(hipStream_t s, FvGeo g, const double* HbyA, const double* rAU, const double* p, CFace3 psn, CFace3 phiForces,
                      CFace3 pflux, CFace3 alphaf, CFace3 rAUf, double* U) {
-    hipLaunchKernelGGL(k_U_correct, dim3(div_up(g.Nc, 256)), dim3(256), 0, s, g, HbyA, rAU, p, psn, phiForces, pflux, alphaf, rAUf, U);
+    hipLaunchKernelGGL(k_U_correct<false>, dim3(red_blocks(g.Nc)), dim3(256), 0, s, g, HbyA, rAU, p, psn, phiForces, pflux, alphaf, rAUf, U, CFace3{}, nullptr, nullptr, nullptr);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+
+int launch_U_correct_diag(hipStream_t s, FvGeo g, const double* HbyA, const double* rAU, const double* p, CFace3 psn, CFace3 phiForces,
+                          CFace3 pflux, CFace3 alphaf, CFace3 rAUf, double* U, CFace3 phi, const double* alpha, const double* alphaOld, double* partials) {
+    hipLaunchKernelGGL(k_U_correct<true>, dim3(red_blocks(g.Nc)), dim3(256), 0, s, g, HbyA, rAU, p, psn, phiForces, pflux, alphaf, rAUf, U, phi, alpha, alphaOld, partials);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }

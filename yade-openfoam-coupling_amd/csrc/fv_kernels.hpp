@@ -95,6 +95,9 @@ int launch_flux_correct(hipStream_t s, FvGeo g, const double* p, CFace3 phiHbyA,
 int launch_cont_err(hipStream_t s, FvGeo g, CFace3 phi, CFace3 alphaf, const double* alpha, const double* alphaOld, double* partials);   // slots 0,1
 int launch_U_correct(hipStream_t s, FvGeo g, const double* HbyA, const double* rAU, const double* p, CFace3 psn, CFace3 phiForces,
                      CFace3 pflux, CFace3 alphaf, CFace3 rAUf, double* U);
+// the same sweep + continuity errors (slots 0, 1) + next step's Courant sums (slots 2 max, 3 sum) of `phi`
+int launch_U_correct_diag(hipStream_t s, FvGeo g, const double* HbyA, const double* rAU, const double* p, CFace3 psn, CFace3 phiForces,
+                          CFace3 pflux, CFace3 alphaf, CFace3 rAUf, double* U, CFace3 phi, const double* alpha, const double* alphaOld, double* partials);
 
 // ---- pressure solver building blocks
 int launch_p_apply(hipStream_t s, PMat A, const double* x, double* y);                                     // y = A x (the roofline kernel)

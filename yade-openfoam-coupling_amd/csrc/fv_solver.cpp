@@ -76,7 +76,7 @@ struct Solver {
     unsigned long long* red_flag = nullptr;      // 8 arrival flags (mapped pinned) the host spins on, and their device alias
     unsigned long long* red_flag_dev = nullptr;
     unsigned long long red_seq = 0;
-    DevBuf<int> ops_courant;
+    DevBuf<int> ops_courant, ops_diag;   // per-slot fold operations (0 sum, 1 max) of the Courant pair and of k_U_correct<true>'s four diagnostics
     fy_step_stats st{};
     double cumulative_cont_err = 0.0;
     EventTimer tim[4];      // particle, (unused), (unused), total
@@ -224,6 +224,8 @@ struct Solver {
             red_flag = nullptr;
         }
         FY_TRY(ops_courant.alloc_exact(2));
+        FY_TRY(ops_diag.alloc_exact(4));
+        { const int h4[4] = {0, 0, 1, 0}; FY_HIP(hipMemcpyAsync(ops_diag.p, h4, sizeof(h4), hipMemcpyHostToDevice, stream)); }
         { const int h[2] = {1, 0}; FY_HIP(hipMemcpyAsync(ops_courant.p, h, sizeof(h), hipMemcpyHostToDevice, stream)); FY_HIP(hipStreamSynchronize(stream)); }
 
         // ---- multigrid hierarchy: 2x2x2 aggregation down to <= kMgCoarsest cells.  With several slabs the levels whose aggregates
@@ -345,15 +347,15 @@ struct Solver {
     // Diagnostics nobody branches on (Courant number, continuity errors): same fold [+ all-reduce], but the values land in their own
     // slots of the pinned buffer and are read after the step's final synchronisation instead of stalling the stream here.
     // Returns false when there is no slot left (the caller then reads at once).
-    static constexpr int kDeferBase = 8, kDeferMax = 2 + 2 * 255; // red_host: 8 immediate doubles + Courant + 255 correctors' continuity errors
+    static constexpr int kDeferBase = 8, kDeferMax = 2 + 4 * 255; // red_host: 8 immediate doubles + Courant + 255 correctors' continuity errors
     int n_deferred = 0;
-    bool reduce_deferred(int nslots, bool courant, int* slot, int* rc) {
+    bool reduce_deferred(int nslots, bool courant, int* slot, int* rc, const int* ops = nullptr) {      // ops (device, per slot 0 sum / 1 max): single domain only
         *rc = FY_OK;
         if (!red_host || n_deferred + nslots > kDeferMax) return false;
         *slot = kDeferBase + n_deferred;
         n_deferred += nslots;
         if (comm->size == 1) {
-            *rc = launch_reduce_finalize(stream, partials.p, Nc, nslots, courant ? ops_courant.p : nullptr, red_host_dev + *slot);
+            *rc = launch_reduce_finalize(stream, partials.p, Nc, nslots, ops ? ops : (courant ? ops_courant.p : nullptr), red_host_dev + *slot);
             return true;
         }
         *rc = launch_reduce_finalize(stream, partials.p, Nc, nslots, courant ? ops_courant.p : nullptr, red_out.p);
@@ -616,13 +618,31 @@ struct Solver {
         }
         clk_pres.end(stream);
         double h[2];
-        FY_TRY(launch_cont_err(stream, g, C3(phi), C3(alphaf), alpha.p, /* alphaOld */ alpha.p, partials.p));
         int slot = 0, rc = FY_OK;
+        if (fuse_diag && comm->size == 1 && red_host && n_deferred + 4 <= kDeferMax) {
+            // single domain: the continuity errors and the NEXT step's Courant sums ride on the velocity correction's sweep
+            // (k_U_correct<true>; same values as k_cont_err / k_courant) instead of being two sweeps of their own
+            FY_TRY(launch_U_correct_diag(stream, g, HbyA.p, rAU.p, p.p, C3(psn), C3(phiForces), C3(pflux), C3(alphaf), C3(rAUf), U.p, C3(phi), alpha.p,
+                                         /* alphaOld */ alpha.p, partials.p));
+            if (!reduce_deferred(4, false, &slot, &rc, ops_diag.p)) return fail(FY_ERR_INVALID, "no room for the deferred diagnostics");
+            FY_TRY(rc);
+            cont_slots.push_back(slot);
+            carry_slot = slot + 2;
+            return FY_OK;
+        }
+        carry_slot = -1;
+        FY_TRY(launch_cont_err(stream, g, C3(phi), C3(alphaf), alpha.p, /* alphaOld */ alpha.p, partials.p));
         if (reduce_deferred(2, false, &slot, &rc)) { FY_TRY(rc); cont_slots.push_back(slot); }
         else { FY_TRY(reduce_read(2, false, h)); note_cont_err(h); }
         FY_TRY(launch_U_correct(stream, g, HbyA.p, rAU.p, p.p, C3(psn), C3(phiForces), C3(pflux), C3(alphaf), C3(rAUf), U.p));
         return FY_OK;
     }
+    // Courant sums of the flux the last corrector left (max sumPhi/V, sum sumPhi), formed by k_U_correct<true>: what CourantNo.H at the top
+    // of the next pass would compute from the same phi.  Dropped whenever a field is written from outside (fy_solver_write_field_host).
+    bool fuse_diag = getenv("FOAMYADE_NO_DIAG_FUSION") == nullptr;
+    int carry_slot = -1;
+    bool carry_valid = false;
+    double carry_h[2] = {0, 0};
 
     std::vector<int> cont_slots;     // deferred continuity-error read-backs of this step, in corrector order
     int courant_slot = -1;
@@ -649,17 +669,20 @@ struct Solver {
         if (timing) tim[3].start(stream);
         if (sources_pending) { FY_TRY(cpl->c.set_source_zero()); sources_pending = false; }   // the previous step's deferred setSourceZero
         double h[2];
-        FY_TRY(launch_courant(stream, g, C3(phi), partials.p));                               // icoFoamYade.C:68, pimpleFoamYade.C:63
+        const bool carried = carry_valid;                                                      // the previous pass's last corrector already summed |phi|
+        carry_valid = false; carry_slot = -1;
+        if (!carried) FY_TRY(launch_courant(stream, g, C3(phi), partials.p));                 // icoFoamYade.C:68, pimpleFoamYade.C:63
         n_deferred = 0; cont_slots.clear(); courant_slot = -1;
+        if (carried) note_courant(carry_h);
         if (cs.adjust_time_step) {
             // readTimeControls.H + CourantNo.H + setDeltaT.H (pimpleFoamYade.C:62-64) [OF-6 setDeltaT.H]: the step's deltaT follows from the
             // Courant number of the current flux at the OLD deltaT, so the host needs that number now
-            FY_TRY(reduce_read(2, true, h)); note_courant(h);
+            if (!carried) { FY_TRY(reduce_read(2, true, h)); note_courant(h); }
             const double maxDeltaTFact = cs.max_co / (st.courant_max + 1e-15);
             const double deltaTFact = std::min(std::min(maxDeltaTFact, 1.0 + 0.1 * maxDeltaTFact), 1.2);
             cs.dt = std::min(deltaTFact * cs.dt, cs.max_delta_t);
             g.dt = cs.dt;
-        } else {
+        } else if (!carried) {
             int slot = 0, rc = FY_OK;
             if (reduce_deferred(2, true, &slot, &rc)) { FY_TRY(rc); courant_slot = slot; }
             else { FY_TRY(reduce_read(2, true, h)); note_courant(h); }
@@ -754,6 +777,7 @@ struct Solver {
         }
         if (courant_slot >= 0) note_courant(red_host + courant_slot);                         // the deferred diagnostics have landed
         for (int sl : cont_slots) note_cont_err(red_host + sl);
+        if (carry_slot >= 0) { carry_h[0] = red_host[carry_slot]; carry_h[1] = red_host[carry_slot + 1]; carry_valid = true; }
         if (timing) {
             clk_mom.collect(); clk_pres.collect();
             st.ms_momentum = clk_mom.total_ms; st.ms_pressure = clk_pres.total_ms;
@@ -901,6 +925,7 @@ int fy_solver_write_field_host(fy_solver* s, const char* name, const double* in)
     FY_TRY(s->s.field(name, &p, &n));
     FY_HIP(hipSetDevice(s->s.device));
     FY_HIP(hipMemcpyAsync(p, in, n * sizeof(double), hipMemcpyHostToDevice, s->s.stream));
+    s->s.carry_valid = false;                 // whatever was written, the carried Courant sums may no longer describe phi
     if (std::string(name) == "U") {           // createPhi (collective when there are several slabs)
         FY_TRY(s->s.halo_cells(s->s.U, 3, 1));
         FY_TRY(fy::launch_flux_of(s->s.stream, s->s.g, s->s.U.p, s->s.F3(s->s.phi)));
