@@ -103,7 +103,9 @@ def nearest_cell(centres, pre, pos):
 class Mesh:
     """uniform hex block, blockMesh order (same convention as tests/golden_cases.py)"""
 
-    def __init__(self, nx, ny, nz, dx, origin=(0.0, 0.0, 0.0), centres=None, pre=None):
+    def __init__(self, nx, ny, nz, dx, origin=(0.0, 0.0, 0.0), centres=None, pre=None, volumes=None, bbmin=None, bbmax=None):
+        """centres / volumes / bbmin / bbmax: a non-uniform mesh (mesh.C(), mesh.V(), bounding box of mesh.points()); nx, ny, nz, dx then
+        only serve the uniform-block findCell stand-in of the point-force mode, which such a mesh cannot use"""
         self.nx, self.ny, self.nz, self.dx = nx, ny, nz, float(dx)
         self.origin = tuple(float(o) for o in origin)
         self.Nc = nx * ny * nz
@@ -115,9 +117,9 @@ class Mesh:
             Cc[..., 2] = (self.origin[2] + (k + 0.5) * dx)[:, None, None]
             centres = Cc.reshape(-1, 3)
         self.C = np.ascontiguousarray(centres, dtype=np.float64)
-        self.V = np.full(self.Nc, dx * dx * dx, dtype=np.float64)
-        self.bbmin = np.array(self.origin, dtype=np.float64)
-        self.bbmax = np.array([self.origin[0] + nx * dx, self.origin[1] + ny * dx, self.origin[2] + nz * dx])
+        self.V = np.full(self.Nc, dx * dx * dx, dtype=np.float64) if volumes is None else np.ascontiguousarray(volumes, dtype=np.float64)
+        self.bbmin = np.array(self.origin, dtype=np.float64) if bbmin is None else np.array(bbmin, dtype=np.float64)
+        self.bbmax = np.array([self.origin[0] + nx * dx, self.origin[1] + ny * dx, self.origin[2] + nz * dx]) if bbmax is None else np.array(bbmax, dtype=np.float64)
         self.pre = build_tree(self.C) if pre is None else np.ascontiguousarray(pre, dtype=np.int32)
 
 

@@ -166,6 +166,18 @@ void foam_rank(const std::string& dir, const Meta& m) {
     mesh.bbmin = Foam::vector(m.ox, m.oy, m.oz);
     mesh.bbmax = Foam::vector(m.ox + nx * m.dx, m.oy + ny * m.dx, m.oz + nz * m.dx);
 
+    {   // a non-uniform mesh: mesh.C(), mesh.V(), mesh.points() as handed over (Gaussian mode only: findCell above is a uniform-block stand-in)
+        std::ifstream probe(dir + "/mesh_centres.bin", std::ios::binary);
+        if (probe.good()) {
+            std::vector<double> cc = read_bin<double>(dir + "/mesh_centres.bin"), vv = read_bin<double>(dir + "/mesh_volumes.bin"),
+                                pp = read_bin<double>(dir + "/mesh_points.bin");
+            if ((int)vv.size() != Nc || (int)cc.size() != 3 * Nc || !m.gaussian) throw std::runtime_error("bad non-uniform mesh files");
+            for (int c = 0; c < Nc; ++c) { mesh.Cc.f[c] = Foam::vector(cc[3 * (size_t)c], cc[3 * (size_t)c + 1], cc[3 * (size_t)c + 2]); mesh.Vv.f[c] = vv[c]; }
+            mesh.pts.f.clear();
+            for (size_t q = 0; q + 2 < pp.size(); q += 3) mesh.pts.f.push_back(Foam::vector(pp[q], pp[q + 1], pp[q + 2]));
+        }
+    }
+
     Foam::volVectorField U, gradP, divT, ddtU, uSource, uParticle;
     Foam::volTensorField vGrad;
     Foam::volScalarField uSourceDrag, alpha;

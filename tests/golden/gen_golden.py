@@ -34,6 +34,10 @@ def run_reference(c: gc.Case, records, workdir):
         f.write(" ".join(str(m) for m in meta) + "\n")
     for name, arr in fields.items():
         np.ascontiguousarray(arr, dtype=np.float64).tofile(os.path.join(workdir, name + ".bin"))
+    if gc.is_graded(c):          # non-uniform mesh: the driver takes mesh.C(), mesh.V(), mesh.points() from these instead of building a uniform block
+        gc.cell_centres(c).tofile(os.path.join(workdir, "mesh_centres.bin"))
+        gc.cell_volumes(c).tofile(os.path.join(workdir, "mesh_volumes.bin"))
+        gc.mesh_points(c).tofile(os.path.join(workdir, "mesh_points.bin"))
     for s, R in enumerate(records):
         np.ascontiguousarray(R, dtype=np.float64).tofile(os.path.join(workdir, f"records_s{s}.bin"))
     cmd = [MPIEXEC, "-n", str(c.n_yade), DRIVER, workdir, ":", "-n", "1", DRIVER, workdir]
@@ -122,6 +126,8 @@ def build_case(c: gc.Case):
     fields = gc.fluid_fields(c)
     out["field_sha"] = np.array([gc.sha(fields[n]) for n in ("U", "gradP", "divT", "ddtU", "vGrad")])
     out["centres_sha"] = np.array([gc.sha(gc.cell_centres(c))])
+    if gc.is_graded(c):
+        out["volumes_sha"] = np.array([gc.sha(gc.cell_volumes(c))])
     return out
 
 
@@ -129,7 +135,7 @@ def main():
     if not os.path.exists(DRIVER):
         sys.exit("build the reference driver first: make -C oracle ref")
     nn_only = "--nn-only" in sys.argv          # only the nearestCell fixtures (added in round 2; the other files stay as committed)
-    names = [a for a in sys.argv[1:] if not a.startswith("--")] or [c.name for c in gc.CASES + gc.FIBRE_CASES]
+    names = [a for a in sys.argv[1:] if not a.startswith("--")] or [c.name for c in gc.CASES + gc.FIBRE_CASES + gc.GRADED_CASES]
     for name in names:
         c = gc.CASES_BY_NAME[name]
         out = build_case(c)

@@ -38,6 +38,7 @@ class Case:
     cluster: int = 0              # extra particles packed into a 2dx cube (alpha floor / Ergun branch)
     fast: int = 0                 # extra particles with |v| ~ 2 m/s (Re > 1000 branch)
     outside: int = 0              # extra particles placed just outside the block (Q8) and far outside
+    grading: tuple = (1.0, 1.0, 1.0)   # blockMesh simpleGrading (last / first cell size per axis); anything but ones = a non-uniform mesh (explicit k-d nodes)
     fibre: int = 0                # FoamYade::fibreCpl (FoamYade.H:102): 15 doubles per particle on the wire (FoamYade.C:131-136)
     extra: dict = field(default_factory=dict)
 
@@ -72,11 +73,57 @@ FIBRE_CASES = [
     Case("g8_fibre_serial", 8, 8, 8, 0.1, np_=200, seed=31, cluster=30, fast=6, outside=6, fibre=1),
     Case("p16_fibre_parallel2", 16, 16, 16, 0.1, gaussian=0, np_=300, seed=32, n_yade=3, nu=0.01, outside=8, fibre=1),
 ]
-CASES_BY_NAME = {c.name: c for c in CASES + FIBRE_CASES}
+# a non-uniform mesh (graded block): the particle half on explicit k-d nodes, Gaussian mode (the point-force findCell stand-in of the
+# reference driver is a uniform-block one).  Own list, own tests (tests/test_graded_mesh.py)
+GRADED_CASES = [
+    Case("g16x12x10_graded", 16, 12, 10, 0.16, origin=(0.1, -0.05, 0.0), np_=700, seed=41, cluster=60, fast=10, outside=10, grading=(3.0, 1.0, 0.4)),
+    Case("g10_graded_parallel2", 10, 10, 10, 0.1, np_=400, seed=42, n_yade=3, cluster=40, fast=6, outside=8, grading=(0.5, 2.0, 2.5)),
+]
+CASES_BY_NAME = {c.name: c for c in CASES + FIBRE_CASES + GRADED_CASES}
+
+
+def is_graded(c: Case):
+    return tuple(c.grading) != (1.0, 1.0, 1.0)
+
+
+def axis_nodes(n, length, o, ratio):
+    """node coordinates of one block edge, blockMesh simpleGrading: geometric cell sizes with last / first = ratio"""
+    if ratio == 1.0:
+        return o + np.arange(n + 1, dtype=np.float64) * (length / n)
+    r = ratio ** (1.0 / (n - 1))
+    i = np.arange(n + 1, dtype=np.float64)
+    return o + length * ((r ** i - 1.0) / (r ** n - 1.0))
+
+
+def mesh_nodes(c: Case):
+    return [axis_nodes(n, n * c.dx, c.origin[a], c.grading[a]) for a, n in enumerate((c.nx, c.ny, c.nz))]
+
+
+def cell_volumes(c: Case):
+    if not is_graded(c):
+        return np.full(c.ncells, c.dx * c.dx * c.dx)
+    X, Y, Z = mesh_nodes(c)
+    V = np.diff(Z)[:, None, None] * (np.diff(Y)[None, :, None] * np.diff(X)[None, None, :])
+    return np.ascontiguousarray(V.reshape(-1))
+
+
+def mesh_points(c: Case):
+    """(Np,3) mesh.points() in blockMesh order (what sendMeshBbox scans, FoamYade.C:82-94)"""
+    X, Y, Z = mesh_nodes(c)
+    P = np.empty((c.nz + 1, c.ny + 1, c.nx + 1, 3))
+    P[..., 0] = X[None, None, :]; P[..., 1] = Y[None, :, None]; P[..., 2] = Z[:, None, None]
+    return np.ascontiguousarray(P.reshape(-1, 3))
 
 
 def cell_centres(c: Case):
-    """(Nc,3) float64, bit-identical to the C++ sides: o + (i + 0.5) * dx."""
+    """(Nc,3) float64, bit-identical to the C++ sides: o + (i + 0.5) * dx (graded blocks: midpoints of the node coordinates)."""
+    if is_graded(c):
+        X, Y, Z = mesh_nodes(c)
+        C = np.empty((c.nz, c.ny, c.nx, 3), dtype=np.float64)
+        C[..., 0] = (0.5 * (X[:-1] + X[1:]))[None, None, :]
+        C[..., 1] = (0.5 * (Y[:-1] + Y[1:]))[None, :, None]
+        C[..., 2] = (0.5 * (Z[:-1] + Z[1:]))[:, None, None]
+        return np.ascontiguousarray(C.reshape(-1, 3))
     dx = c.dx
     i = np.arange(c.nx, dtype=np.float64)
     j = np.arange(c.ny, dtype=np.float64)

@@ -290,6 +290,28 @@ class BlockMesh:
         return m
 
 
+class GeneralMesh:
+    """what FoamYade reads from fvMesh for ANY mesh: mesh.C(), mesh.V() and the bounding box of mesh.points() (fy_mesh_desc with nx = 0).
+    Gaussian mode only -- the point-force mode needs polyMesh::findCell, for which the library has a uniform-block stand-in (BlockMesh)."""
+
+    def __init__(self, centres, volumes, bbox_min, bbox_max):
+        self.C = np.ascontiguousarray(centres, dtype=np.float64).reshape(-1, 3)
+        self.V = np.ascontiguousarray(volumes, dtype=np.float64).reshape(-1)
+        assert self.C.shape[0] == self.V.shape[0]
+        self.n_cells = self.V.shape[0]
+        self.bbox_min = np.array(bbox_min, dtype=np.float64); self.bbox_max = np.array(bbox_max, dtype=np.float64)
+
+    def desc(self):
+        m = MeshDesc()
+        m.n_cells = self.n_cells
+        m.centres, m.volumes = _d(self.C), _d(self.V)
+        for q in range(3):
+            m.bbox_min[q], m.bbox_max[q], m.origin[q] = self.bbox_min[q], self.bbox_max[q], 0.0
+        m.nx = m.ny = m.nz = 0
+        m.dx = 0.0
+        return m
+
+
 class FoamYade:
     """Foam::FoamYade (FoamYade.H:57-161) over the C-ABI.  Field arguments are numpy arrays (host; staged per step) that
     stay owned by the caller, exactly like the reference's field references."""
