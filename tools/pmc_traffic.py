@@ -49,7 +49,7 @@ def main():
         f, w = v.get("FETCH_SIZE_KiB_per_launch", 0.0), v.get("WRITE_SIZE_KiB_per_launch", 0.0)
         v["hbm_bytes_per_launch"] = (2.0 * f + w) * 1024.0
         v["read_correction"] = "x2 (gfx950 wide-coalesced rule)" + ("; upper bound: gather-dominated" if k in ("k_force_gaussian", "k_deposit", "k_locate_deposit", "k_locate_lists", "k_locate(walk)") else "")
-    json.dump({"unit": "bytes", "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes of bench.py --steps 3 --warmup 1", "kernels": res},
+    json.dump({"unit": "bytes", "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes of bench.py --steps 10 --warmup 2 (12 launches per kernel and step; the first step of a particle population flushes its tables with global atomics and is in the averages)", "kernels": res},
               open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))
 
