@@ -353,6 +353,33 @@ int comm_selftest(Comm* c, int device) {
     if (ro[0] != s0 || ro[1] != s1 || ro[2] != -3.0 * S || ro[3] != mx) return fail(FY_ERR_TRANSPORT, "comm self-test: all-reduce wrong on rank %d", R);
     for (int r = 0; r < S; ++r) for (int q = 0; q < 8; ++q)
         if (out[8 * n + 64 + 8 * (size_t)r + q] != (double)(q + 1) * r) return fail(FY_ERR_TRANSPORT, "comm self-test: all-gather wrong on rank %d", R);
+    // the overlapped halo of the smoother goes over the communicator's second channel (RcclComm: the ncclCommSplit communicator) on
+    // another stream while the first stream keeps working: one plane each way on an auxiliary stream, an all-reduce on a main stream
+    {
+        hipStream_t s1 = nullptr, s2 = nullptr;
+        FY_HIP(hipStreamCreate(&s1));
+        FY_HIP(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+        c->set_aux_stream(s2);
+        FY_HIP(hipMemsetAsync(d.p + 4 * n, 0, 2 * n * sizeof(double), s2));
+        FY_TRY(c->neighbour_exchange(s2, d.p, d.p + 4 * n, d.p + n, d.p + 5 * n, n));
+        const double one = 1.0;
+        FY_HIP(hipMemcpyAsync(red.p + 4, &one, sizeof(one), hipMemcpyHostToDevice, s1));
+        FY_TRY(c->allreduce(s1, red.p + 4, 1, false));
+        double cnt = 0.0;
+        FY_HIP(hipMemcpyAsync(&cnt, red.p + 4, sizeof(cnt), hipMemcpyDeviceToHost, s1));
+        FY_HIP(hipMemcpyAsync(out.data(), d.p + 4 * n, 2 * n * sizeof(double), hipMemcpyDeviceToHost, s2));
+        FY_HIP(hipStreamSynchronize(s2));
+        FY_HIP(hipStreamSynchronize(s1));
+        c->set_aux_stream(nullptr);
+        (void)hipStreamDestroy(s1); (void)hipStreamDestroy(s2);
+        if (cnt != (double)S) return fail(FY_ERR_TRANSPORT, "comm self-test: all-reduce beside the auxiliary exchange wrong on rank %d", R);
+        for (size_t q = 0; q < n; q += 997) {
+            const double want_dn = c->has_down() ? 1000.0 * (R - 1) + 1.0 + 1e-3 * (double)q : 0.0;
+            const double want_up = c->has_up() ? 1000.0 * (R + 1) + 2.0 + 1e-3 * (double)q : 0.0;
+            if (out[q] != want_dn || out[n + q] != want_up)
+                return fail(FY_ERR_TRANSPORT, "comm self-test: exchange on the auxiliary stream delivered wrong data on rank %d (element %zu)", R, q);
+        }
+    }
     return FY_OK;
 }
 
