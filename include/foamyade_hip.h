@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define FY_ABI_VERSION 4
+#define FY_ABI_VERSION 5
 
 /* ---- status codes ------------------------------------------------------------------------------------ */
 enum {
@@ -194,6 +194,7 @@ enum { FY_PSOLVER_PCG_JACOBI = 0, FY_PSOLVER_PCG_MG = 1 };
 /* continuousPhaseTurbulence (pimpleFoamYade/createFields.H, DPMTurbulenceModels.C:67-77; icoFoamYade has no turbulence model) */
 #define FY_TURBULENCE_LAMINAR 0        /* simulationType laminar / laminarModel Stokes (DPMTurbulenceModels.C:67-68) */
 #define FY_TURBULENCE_SMAGORINSKY 1    /* simulationType LES, LESModel Smagorinsky (DPMTurbulenceModels.C:73-74), delta cubeRootVol */
+#define FY_TURBULENCE_KEQN 2           /* simulationType LES, LESModel kEqn (DPMTurbulenceModels.C:76-77), delta cubeRootVol */
 #define FY_BC_NUT_ZERO_GRADIENT 0
 #define FY_BC_NUT_FIXED_VALUE 1
 typedef struct fy_case_desc {
@@ -234,6 +235,15 @@ typedef struct fy_case_desc {
     double les_ck, les_ce, les_delta_coeff;      /* fy_case_defaults: 0.094, 1.048, 1 */
     int32_t nut_bc[6]; double nut_value[6];      /* FY_BC_NUT_* per side */
     double nut_initial;                          /* uniform internalField of 0/nut (fy_solver_write_field_host("nut") for a non-uniform one) */
+    /* kEqn [OF-6 LES/kEqn/kEqn.C]: fvm::ddt(alpha,k) + fvm::div(alphaPhic,k) - fvm::laplacian(alpha (nut + nu), k) == alpha G
+       - fvm::SuSp(2/3 alpha div(phic), k) - fvm::Sp(Ce alpha sqrt(k)/delta, k), G = nut (gradU && dev(twoSymm(gradU))); relax; solve; bound(k, kMin);
+       nut = Ck sqrt(k) delta.  The 0/k file: k_initial (uniform), k_bc / k_value per side (FY_BC_NUT_* values: zeroGradient | fixedValue);
+       divSchemes div(alphaPhic,k): k_convection_scheme FY_CONVECTION_LINEAR | _UPWIND; solvers.k: k_tol / k_rel_tol / k_max_iter;
+       relaxationFactors equations k: k_relax (<= 0: none) */
+    int32_t k_bc[6]; double k_value[6]; double k_initial;
+    int32_t k_convection_scheme;
+    double k_tol, k_rel_tol; int32_t k_max_iter;
+    double k_relax;
 } fy_case_desc;
 
 typedef struct fy_solver fy_solver;
@@ -252,7 +262,7 @@ int fy_solver_create(const fy_case_desc* c, const fy_transport* transport, int d
 fy_ctx* fy_solver_coupling(fy_solver*);                 /* the yadeCoupling object (icoFoamYade.C:54, pimpleFoamYade.C:54) */
 int fy_solver_step(fy_solver*);                         /* one pass of the while(runTime.loop()) body */
 int fy_solver_get_stats(fy_solver*, fy_step_stats* out);
-/* names: "U" [n][3], "p" [n], "phi_x" [(nx+1)*ny*nz], "phi_y", "phi_z", "nut" [n] (with a turbulence model), plus every fy_ctx field name */
+/* names: "U" [n][3], "p" [n], "phi_x" [(nx+1)*ny*nz], "phi_y", "phi_z", "nut" [n] (with a turbulence model), "k" [n] (kEqn), plus every fy_ctx field name */
 int fy_solver_read_field_host(fy_solver*, const char* name, double* out);
 int fy_solver_write_field_host(fy_solver*, const char* name, const double* in);
 /* number of doubles fy_solver_read/write_field_host move for `name` on this rank (owned cells / local faces) */
@@ -291,6 +301,7 @@ int fy_foam_case_info_get(const fy_foam_case*, fy_foam_case_info* out);
 int fy_foam_case_initial_fields(const fy_foam_case*, double* U /* [n][3] or NULL */, double* p /* [n] or NULL */);
 /* start-time nut.<phase> of a case with a turbulence model (hand it to fy_solver_write_field_host(s, "nut", ...) when it is not uniform) */
 int fy_foam_case_initial_nut(const fy_foam_case*, double* nut /* [n] */);
+int fy_foam_case_initial_k(const fy_foam_case*, double* k /* [n] */);          /* start-time k.<phase> of a kEqn case */
 /* runTime.write(): <case>/<time_name>/{U | U.<phase>, p [, alpha.<phase>]} as ASCII volFields with the case's own patch entries */
 int fy_foam_case_write_time(const fy_foam_case*, fy_solver*, const char* time_name);
 int fy_foam_case_close(fy_foam_case*);

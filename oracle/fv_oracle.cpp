@@ -51,6 +51,8 @@ struct orc_fv_case {
     // 0/nut: per-side boundary type (0 zeroGradient, 1 fixedValue) and value, uniform initial value
     int turbulence_model; double les_ck, les_ce, les_delta_coeff;
     int nut_bc[6]; double nut_value[6]; double nut_initial;
+    // LES kEqn (turbulence_model 2): the 0/k file, div(alphaPhic,k) scheme (0 linear, 1 upwind), solvers.k, relaxationFactors equations k
+    int k_bc[6]; double k_value[6]; double k_initial; int k_convection_scheme; double k_tol, k_rel_tol; int k_max_iter; double k_relax;
 };
 struct orc_fv_stats {
     double courant_mean, courant_max, cont_sum_local, cont_global, cont_cumulative;
@@ -81,7 +83,9 @@ struct Fv {
     int threads = 1;
     // state
     vec U, Uold, p, alpha, alphaOld, uSource, uSourceDrag, uParticle, gradP, divT, vGrad, ddtU;
-    vec nut;                                 // eddy viscosity (Smagorinsky); empty = laminar
+    vec nut;                                 // eddy viscosity (Smagorinsky, kEqn); empty = laminar
+    vec kturb;                               // sub-grid kinetic energy (kEqn)
+    int k_iters = 0;
     vec phi[3], phiOld[3], psn[3];           // psn: d p / d axis on fixedFluxPressure boundary faces
     // work
     vec diag, an[6], src, rAU, HbyA, alphaf[3], phiHbyA[3], phiForces[3], rAUf[3], pflux[3], bmom, Sc, divG;
@@ -120,7 +124,8 @@ struct Fv {
         src.assign(3 * (size_t)Nc, 0.0); rAU.assign(Nc, 0.0); HbyA.assign(3 * (size_t)Nc, 0.0); bmom.assign(3 * (size_t)Nc, 0.0);
         Sc.assign(Nc, 0.0); divG.assign(3 * (size_t)Nc, 0.0);
         pb.assign(Nc, 0.0); pr = pb; pw = pb; pp = pb; pz = pb;
-        if (pimple && c.turbulence_model == 1) nut.assign(Nc, c.nut_initial);      // the 0/nut file (eddyViscosity: MUST_READ)
+        if (pimple && c.turbulence_model >= 1) nut.assign(Nc, c.nut_initial);      // the 0/nut file (eddyViscosity: MUST_READ)
+        if (pimple && c.turbulence_model == 2) kturb.assign(Nc, c.k_initial);      // the 0/k file
         build_mg_shapes();
         // createPhi: phi = linearInterpolate(U) & Sf (icoFoamYade/createFields.H:151, pimpleFoamYade/createFields.H:70-81)
         flux_of(U, phi);
@@ -359,8 +364,10 @@ struct Fv {
 
     // lduMatrix residual normalisation: sum(|A psi - A xbar| + |b - A xbar|) + 1e-20
     // Jacobi solve of diag*x + sum an*x_nb = b for the 3 components (stand-in for smoothSolver symGaussSeidel)
-    int solve_momentum(const vec& b) {
-        vec x = U, xn(3 * (size_t)Nc), Ax(3 * (size_t)Nc);
+    int solve_momentum(const vec& b) { return solve_vec3(U, b, cs.u_tol, cs.u_rel_tol, cs.u_max_iter); }
+    // Jacobi sweeps on (diag, an) for a 3-component field X (updated in place), lduMatrix-style L1 residual control per component
+    int solve_vec3(vec& X, const vec& b, double tol, double rel_tol, int max_iter) {
+        vec x = X, xn(3 * (size_t)Nc), Ax(3 * (size_t)Nc);
         auto apply = [&](const vec& v, vec& out) {
 #pragma omp parallel for num_threads(threads) collapse(2)
             for (int k = 0; k < nz; ++k) for (int j = 0; j < ny; ++j) for (int i = 0; i < nx; ++i) {
@@ -390,12 +397,12 @@ struct Fv {
             for (int q = 0; q < 3; ++q) { norm[q] += 1e-20; res0[q] /= norm[q]; }
         }
         auto conv = [&](const double* r) {
-            for (int q = 0; q < 3; ++q) if (!(r[q] < cs.u_tol || (cs.u_rel_tol > 0 && r[q] < cs.u_rel_tol * res0[q]))) return false;
+            for (int q = 0; q < 3; ++q) if (!(r[q] < tol || (rel_tol > 0 && r[q] < rel_tol * res0[q]))) return false;
             return true;
         };
         int it = 0;
         double res[3] = {res0[0], res0[1], res0[2]};
-        while (!conv(res) && it < cs.u_max_iter) {
+        while (!conv(res) && it < max_iter) {
 #pragma omp parallel for num_threads(threads) collapse(2)
             for (int k = 0; k < nz; ++k) for (int j = 0; j < ny; ++j) for (int i = 0; i < nx; ++i) {
                 const int c = cid(i, j, k);
@@ -413,7 +420,7 @@ struct Fv {
             for (int c = 0; c < Nc; ++c) for (int q = 0; q < 3; ++q) res[q] += std::fabs(b[3 * (size_t)c + q] - Ax[3 * (size_t)c + q]);
             for (int q = 0; q < 3; ++q) res[q] /= norm[q];
         }
-        U = x;
+        X = x;
         return it;
     }
 
@@ -820,11 +827,88 @@ struct Fv {
             if (!nut.empty() && final_outer) turbulence_correct();             // pimple.turbCorr() (final outer iteration), pimpleFoamYade.C:101-104
         }
     }
+    // continuousPhaseTurbulence->correct() for LESModel kEqn (DPMTurbulenceModels.C:76-77) [OF-6 LES/kEqn/kEqn.C]:
+    //   divU = fvc::div(fvc::absolute(phi, U)); G = nut (gradU && dev(twoSymm(gradU)));
+    //   fvm::ddt(alpha, rho, k) + fvm::div(alphaRhoPhi, k) - fvm::laplacian(alpha rho DkEff(), k)
+    //     == alpha rho G - fvm::SuSp((2/3) alpha rho divU, k) - fvm::Sp(Ce alpha rho sqrt(k)/delta, k);   DkEff = nut + nu
+    //   kEqn.relax(); solve(kEqn); bound(k, kMin); correctNut(): nut = Ck sqrt(k) delta
+    // [OF-6 fvm::SuSp: diag += V max(susp, 0), source -= V min(susp, 0) psi; fvMatrix == volField: source += V field;
+    //  bound.C: k = max(max(k, fvc::average(max(k, kMin)) pos0(-k)), kMin)].  alpha.oldTime() == alpha (quirk F-Q1).
+    void keqn_correct() {
+        const double nu = cs.nu, dt = cs.dt, delta = cs.les_delta_coeff * std::pow(V, 1.0 / 3.0), Ck = cs.les_ck, Ce = cs.les_ce, kMin = 1e-15;
+        vec b3(3 * (size_t)Nc, 0.0), x3(3 * (size_t)Nc, 0.0);
+        for (int k = 0; k < nz; ++k) for (int j = 0; j < ny; ++j) for (int i = 0; i < nx; ++i) {
+            const int c = cid(i, j, k);
+            const double aP = alpha[c], kc = kturb[c], nutc = nut[c];
+            double dg = aP * V / dt, s = aP * V * kc / dt, sumPhi = 0.0;
+            for (int d = 0; d < 3; ++d) for (int sd = 0; sd < 2; ++sd) {
+                const int f = cface(d, sd, i, j, k);
+                const double af = alphaf[d][f];
+                const double pv = (sd ? 1.0 : -1.0) * phi[d][f];
+                const double phio = af * pv;
+                sumPhi += pv;
+                if (onb(d, sd, i, j, k)) {
+                    an[2 * d + sd][c] = 0.0;
+                    const int patch = 2 * d + sd;
+                    const double nb = cs.nut_bc[patch] == 1 ? cs.nut_value[patch] : nutc;
+                    const double gam = (af * (nu + nb)) * dx;
+                    if (cs.k_bc[patch] == 1) { const double gb = 2.0 * gam; dg += gb; s += (-phio + gb) * cs.k_value[patch]; }
+                    else dg += phio;
+                } else {
+                    const int nbc = c + (sd ? stride[d] : -stride[d]);
+                    const double gam = (0.5 * ((aP * (nu + nutc)) + (alpha[nbc] * (nu + nut[nbc])))) * dx;
+                    const bool up = cs.k_convection_scheme != 0;
+                    const double cP = up ? std::max(phio, 0.0) : 0.5 * phio, cN = up ? std::min(phio, 0.0) : 0.5 * phio;
+                    dg += cP + gam;
+                    an[2 * d + sd][c] = cN - gam;
+                }
+            }
+            const double* T = &vGrad[9 * (size_t)c];
+            const double tr2 = 2.0 * (T[0] + T[4] + T[8]);
+            double GG = 0.0;
+            for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) GG += T[3 * a + b] * ((T[3 * a + b] + T[3 * b + a]) - (a == b ? (1.0 / 3.0) * tr2 : 0.0));
+            const double G = nutc * GG;
+            const double divU = sumPhi / V;
+            const double c1 = (2.0 / 3.0) * aP * divU, c2 = Ce * aP * std::sqrt(kc) / delta;
+            dg += V * (std::max(c1, 0.0) + c2);
+            s += V * (aP * G) - V * std::min(c1, 0.0) * kc;
+            if (cs.k_relax > 0) {
+                double so = 0.0;
+                for (int q = 0; q < 6; ++q) so += std::fabs(an[q][c]);
+                const double dn = std::max(std::fabs(dg), so) / cs.k_relax;
+                s += (dn - dg) * kc;
+                dg = dn;
+            }
+            diag[c] = dg;
+            b3[3 * (size_t)c] = s;
+            x3[3 * (size_t)c] = kc;
+        }
+        k_iters += solve_vec3(x3, b3, cs.k_tol, cs.k_rel_tol, cs.k_max_iter);
+        vec kn(Nc);
+        for (int k = 0; k < nz; ++k) for (int j = 0; j < ny; ++j) for (int i = 0; i < nx; ++i) {
+            const int c = cid(i, j, k);
+            const double kc = x3[3 * (size_t)c];
+            double kb = kc;
+            if (!(kc > 0.0)) {
+                const double mP = std::max(kc, kMin);
+                double av = 0.0;
+                for (int d = 0; d < 3; ++d) for (int sd = 0; sd < 2; ++sd) {
+                    if (onb(d, sd, i, j, k)) { const int patch = 2 * d + sd; av += std::max(cs.k_bc[patch] == 1 ? cs.k_value[patch] : kc, kMin); }
+                    else { const int nbc = c + (sd ? stride[d] : -stride[d]); av += 0.5 * (mP + std::max(x3[3 * (size_t)nbc], kMin)); }
+                }
+                kb = std::max(kc, av / 6.0);
+            }
+            kn[c] = std::max(kb, kMin);
+        }
+        kturb = kn;
+        for (int c = 0; c < Nc; ++c) nut[c] = Ck * std::sqrt(kturb[c]) * delta;
+    }
     // continuousPhaseTurbulence->correct() for LESModel Smagorinsky [OF-6 LES/Smagorinsky/Smagorinsky.C: correct() -> correctNut();
     // k(gradU): D = symm(gradU), a = Ce/delta, b = (2/3) tr(D), c = 2 Ck delta (dev(D) && D), k = sqr((-b + sqrt(sqr(b) + 4 a c))/(2 a));
     // nut = Ck delta sqrt(k)]; delta = deltaCoeff * cbrt(V) [OF-6 LES/LESdeltas/cubeRootVolDelta]; gradU = fvc::grad(U) (Gauss linear)
     void turbulence_correct() {
         grad_U(U, vGrad);
+        if (cs.turbulence_model == 2) { keqn_correct(); return; }
         const double delta = cs.les_delta_coeff * std::pow(V, 1.0 / 3.0), Ck = cs.les_ck, Ce = cs.les_ce;
         for (int c = 0; c < Nc; ++c) {
             const double* T = &vGrad[9 * (size_t)c];
@@ -864,6 +948,7 @@ static vec* fv_field(Fv* f, const char* name) {
         {"divT", &f->divT},
         {"vGrad", &f->vGrad},
         {"nut", &f->nut},
+        {"k", &f->kturb},
         {"ddtU", &f->ddtU},
         {"phi_x", &f->phi[0]},
         {"phi_y", &f->phi[1]},

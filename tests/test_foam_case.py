@@ -313,7 +313,7 @@ def test_les_smagorinsky_case_is_read(prod, tmp_path):
     assert c.nut_initial == 2e-6 and np.all(fc.initial_nut() == 2e-6)
     assert list(c.nut_bc) == [0, 0, 0, 0, 1, 0] and c.nut_value[ZMIN] == 1e-6
     fc.close()
-    for old, new, needle in (("LESModel        Smagorinsky;", "LESModel        kEqn;", "kEqn"),
+    for old, new, needle in (("LESModel        Smagorinsky;", "LESModel        dynamicKEqn;", "dynamicKEqn"),
                              ("simulationType  LES;", "simulationType  RAS;", "RAS"),
                              ("delta           cubeRootVol;", "delta           vanDriest;", "cubeRootVol"),
                              ("turbulence      on;", "turbulence      off;", "turbulence off")):
@@ -355,3 +355,33 @@ def test_les_case_runs_and_writes_nut(prod, tmp_path):
     np.testing.assert_array_equal(fc2.initial_nut(), nut)
     assert list(fc2.case.nut_bc) == list(fc.case.nut_bc) and fc2.case.nut_value[ZMIN] == 1e-6
     fc.close(); fc2.close(); s.close()
+
+
+def test_les_keqn_case_is_read(prod, tmp_path):
+    """LESModel kEqn: kEqnCoeffs, <start>/k.<phase>, the k convection scheme, solvers.k.<phase>, relaxationFactors equations k.<phase>"""
+    dst = les_case(tmp_path)
+    (dst / "constant/turbulenceProperties.water").write_text(LES_PROPS.replace("LESModel        Smagorinsky;", "LESModel        kEqn;").replace("SmagorinskyCoeffs", "kEqnCoeffs"))
+    (dst / "0/k.water").write_text(NUT_FILE.replace("object nut.water", "object k.water").replace("[0 2 -1 0 0 0 0]", "[0 2 -2 0 0 0 0]")
+                                   .replace("uniform 2e-6", "uniform 3e-4").replace("top    { type zeroGradient; }", "top    { type kqRWallFunction; value uniform 0; }"))
+    fc = prod.FoamCase(dst, prod.FY_SOLVER_PIMPLE)                         # the case's "(U.water|k|epsilon)" pattern names k
+    assert (fc.case.k_tol, fc.case.k_rel_tol) == (1e-5, 0.1) and fc.case.k_convection_scheme == 1      # no div entry for k: `default` is none -> upwind
+    fc.close()
+    sol = (dst / "system/fvSolution").read_text()
+    (dst / "system/fvSolution").write_text(sol.replace('"(U.water|k|epsilon)"', "U.water"))
+    with pytest.raises(prod.FoamYadeError) as e:                           # now nothing names k
+        prod.FoamCase(dst, prod.FY_SOLVER_PIMPLE)
+    assert "k.water" in str(e.value) and "fvSolution" in str(e.value)
+    sol = (dst / "system/fvSolution").read_text()
+    assert "solvers" in sol
+    sol = sol.replace("solvers\n{", "solvers\n{\n    k.water { solver smoothSolver; smoother symGaussSeidel; tolerance 1e-7; relTol 0.01; maxIter 50; }", 1)
+    assert "k.water {" in sol
+    (dst / "system/fvSolution").write_text(sol)
+    sch = (dst / "system/fvSchemes").read_text().replace("div(alphaPhic,Uc) Gauss linear;", "div(alphaPhic,Uc) Gauss linear;\n    div(alphaPhi.water,k.water) Gauss upwind;")
+    (dst / "system/fvSchemes").write_text(sch)
+    fc = prod.FoamCase(dst, prod.FY_SOLVER_PIMPLE)
+    c = fc.case
+    assert c.turbulence_model == prod.TURBULENCE_KEQN and (c.les_ck, c.les_ce) == (0.1, 1.0)
+    assert c.k_initial == 3e-4 and np.all(fc.initial_k() == 3e-4) and list(c.k_bc) == [0, 0, 0, 0, 1, 0] and c.k_value[ZMIN] == 1e-6
+    assert c.k_convection_scheme == 1 and (c.k_tol, c.k_rel_tol, c.k_max_iter) == (1e-7, 0.01, 50)
+    assert c.convection_scheme == 0                                        # the momentum convection stays Gauss linear
+    fc.close()

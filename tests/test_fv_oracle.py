@@ -450,3 +450,55 @@ def test_smagorinsky_adds_eddy_viscosity_to_a_cavity(oracle):
     # more diffusion: the shear layer under the lid is thicker, so the lid drags less steeply -- the wall cells' velocity gradient drops
     top = lambda o: o.get("U").reshape(n, n, n, 3)[:, n - 1, :, 0].mean()       # noqa: E731   (k, j, i) order: the cell layer under the lid
     assert top(les) > top(lam)
+
+
+def test_keqn_decay_of_homogeneous_turbulence(oracle):
+    """LES kEqn (DPMTurbulenceModels.C:76-77) with the fluid at rest: no production, no convection, uniform k => the k equation is
+    alpha V/dt (k_new - k_old) = -Ce alpha V sqrt(k_old)/delta k_new, i.e. k_new = k_old / (1 + dt Ce sqrt(k_old)/delta) -- the implicit-Euler
+    form of dk/dt = -Ce k^1.5 / delta, whose exact solution is k(t) = (k0^-0.5 + Ce t / (2 delta))^-2"""
+    n, dx, dt, k0 = 8, 0.02, 1e-3, 0.05
+    c = oracle.fv_case(1, n, n, n, dx, dt, 1e-5, u_bc=[0] * 6, turbulence_model=2, k_initial=k0, nut_initial=1e-4, k_tol=1e-14)
+    o = oracle.FvSolver(c)
+    delta = (dx ** 3) ** (1.0 / 3.0)
+    k = k0
+    for step in range(50):
+        o.turbulence_correct()
+        k = k / (1.0 + dt * 1.048 * np.sqrt(k) / delta)
+        np.testing.assert_allclose(o.get("k"), k, rtol=1e-12)
+        np.testing.assert_allclose(o.get("nut"), 0.094 * np.sqrt(k) * delta, rtol=1e-12)
+    exact = (k0 ** -0.5 + 1.048 * 50 * dt / (2 * delta)) ** -2
+    assert abs(k - exact) / exact < 0.05                                  # first-order in dt
+
+
+def test_keqn_equilibrium_is_the_smagorinsky_value(oracle):
+    """under a uniform shear production balances dissipation at k = Ck delta^2 gamma^2 / Ce, where nut = Ck sqrt(k) delta equals the
+    Smagorinsky value Ck sqrt(Ck/Ce) delta^2 gamma (the algebraic model is the local-equilibrium limit of the k equation)"""
+    n, dx, gamma = 12, 0.05, 3.0
+    c = oracle.fv_case(1, n, n, n, dx, 0.05, 1e-6, u_bc=[1] * 6, turbulence_model=2, k_initial=1e-4, nut_initial=1e-5, k_tol=1e-13)
+    o = oracle.FvSolver(c)
+    y = (np.arange(n) + 0.5) * dx
+    U = np.zeros((n, n, n, 3))
+    U[..., 0] = gamma * y[None, :, None]
+    o.set("U", U.reshape(-1, 3))
+    for _ in range(400):
+        o.turbulence_correct()
+    delta = (dx ** 3) ** (1.0 / 3.0)
+    k = o.get("k").reshape(n, n, n)
+    nut = o.get("nut").reshape(n, n, n)
+    mid = slice(n // 2 - 1, n // 2 + 1)
+    np.testing.assert_allclose(k[:, mid, :], 0.094 * delta ** 2 * gamma ** 2 / 1.048, rtol=1e-4)
+    np.testing.assert_allclose(nut[:, mid, :], 0.094 * np.sqrt(0.094 / 1.048) * delta ** 2 * gamma, rtol=1e-4)
+    assert k[n // 2, 0, n // 2] < 0.5 * k[n // 2, n // 2, n // 2]         # the wall cells see half the gradient: a quarter of the production
+
+
+def test_keqn_cavity_runs_and_stays_bounded(oracle):
+    n = 12
+    u_val = [(0, 0, 0)] * 6
+    u_val[3] = (1.0, 0, 0)
+    o = oracle.FvSolver(oracle.fv_case(1, n, n, n, 1.0 / n, 0.02, 1e-3, u_bc=[0] * 6, u_val=u_val, turbulence_model=2, k_initial=1e-3,
+                                       nut_initial=1e-4, k_bc=[1] * 6, k_value=[0.0] * 6, k_convection_scheme=0))
+    for _ in range(10):
+        o.step()
+    k = o.get("k")
+    assert k.min() >= 1e-15 and np.isfinite(k).all() and k.max() > 1e-4
+    np.testing.assert_allclose(o.get("nut"), 0.094 * np.sqrt(k) * (1.0 / n), rtol=1e-13)

@@ -332,3 +332,28 @@ def test_turbulence_model_refused_where_the_reference_has_none(product):
         product.Solver(product.make_case(0, 8, 8, 8, 0.1, 0.01, 0.01, turbulence_model=1))           # icoFoamYade: laplacian(nu, U)
     with pytest.raises(product.FoamYadeError):
         product.Solver(product.make_case(1, 8, 8, 8, 0.1, 0.01, 0.01, turbulence_model=7))           # kEpsilon / kEqn: not built
+
+
+@pytest.mark.parametrize("k_scheme", [0, 1])
+def test_keqn_matches_oracle(product, oracle, k_scheme):
+    """pimpleFoamYade with LESModel kEqn (DPMTurbulenceModels.C:76-77): a transport equation for the sub-grid kinetic energy, solved after
+    the last corrector (pimpleFoamYade.C:101-104), nut = Ck sqrt(k) delta; coupled, so alpha weighs every term"""
+    n = 16
+    dx = 0.1 / n
+    u_val = [(0, 0, 0)] * 6
+    u_val[YMAX] = (0.5, 0, 0)
+    kw = dict(turbulence_model=2, les_ck=0.2, nut_bc=[0, 0, 1, 0, 1, 1], nut_value=[0, 0, 0.0, 0, 2e-5, 0.0], nut_initial=3e-5,
+              k_bc=[0, 1, 1, 1, 0, 1], k_value=[0, 1e-4, 0.0, 2e-4, 0, 0.0], k_initial=5e-4, k_convection_scheme=k_scheme, k_tol=1e-9, k_relax=0.9)
+    o, s = both(product, oracle, 1, n, n, n, dx, 2e-4, 1e-5, g=(0, 0, -9.81), u_bc=[0] * 6, u_val=u_val, p_bc=[2] * 6, **kw)
+    np.testing.assert_array_equal(s.get("k"), 5e-4)
+    case = gc.Case("cpl", n, n, n, 0.1, gaussian=1, np_=2000, seed=5, cluster=100, fast=10, outside=10, vel_scale=0.05)
+    for step in range(4):
+        rec = gc.particle_records(case, step)
+        o.step(rec)
+        s.set_particles(rec)
+        s.step()
+        for nm in ("k", "nut"):
+            a, b = s.get(nm), o.get(nm)
+            np.testing.assert_allclose(a, b, rtol=2e-5, atol=1e-9 * b.max(), err_msg=nm)
+    assert not np.allclose(o.get("k"), 5e-4)
+    compare(o, s, rtol=1e-5)

@@ -94,10 +94,12 @@ class CaseDesc(C.Structure):
                 ("adjust_time_step", C.c_int32), ("max_co", C.c_double), ("max_delta_t", C.c_double),
                 ("u_relax", C.c_double), ("u_relax_final", C.c_double), ("p_relax", C.c_double), ("p_relax_final", C.c_double),
                 ("turbulence_model", C.c_int32), ("les_ck", C.c_double), ("les_ce", C.c_double), ("les_delta_coeff", C.c_double),
-                ("nut_bc", C.c_int32 * 6), ("nut_value", C.c_double * 6), ("nut_initial", C.c_double)]
+                ("nut_bc", C.c_int32 * 6), ("nut_value", C.c_double * 6), ("nut_initial", C.c_double),
+                ("k_bc", C.c_int32 * 6), ("k_value", C.c_double * 6), ("k_initial", C.c_double), ("k_convection_scheme", C.c_int32),
+                ("k_tol", C.c_double), ("k_rel_tol", C.c_double), ("k_max_iter", C.c_int32), ("k_relax", C.c_double)]
 
 
-TURBULENCE_LAMINAR, TURBULENCE_SMAGORINSKY = 0, 1
+TURBULENCE_LAMINAR, TURBULENCE_SMAGORINSKY, TURBULENCE_KEQN = 0, 1, 2
 NUT_ZERO_GRADIENT, NUT_FIXED_VALUE = 0, 1
 
 
@@ -195,6 +197,7 @@ def lib():
     L.fy_foam_case_info_get.argtypes = [vp, C.POINTER(FoamCaseInfo)]
     L.fy_foam_case_initial_fields.argtypes = [vp, _dp, _dp]
     L.fy_foam_case_initial_nut.argtypes = [vp, _dp]
+    L.fy_foam_case_initial_k.argtypes = [vp, _dp]
     L.fy_foam_case_write_time.argtypes = [vp, vp, C.c_char_p]
     L.fy_foam_case_close.argtypes = [vp]
     L.fy_solver_write_field_host.argtypes = [vp, C.c_char_p, _dp]
@@ -777,6 +780,11 @@ class FoamCase:
         nut = np.zeros(self.n_cells)
         _check(lib().fy_foam_case_initial_nut(self._h, _d(nut)))
         return nut
+
+    def initial_k(self):
+        k = np.zeros(self.n_cells)
+        _check(lib().fy_foam_case_initial_k(self._h, _d(k)))
+        return k
 
     def write(self, solver, time_name):
         _check(lib().fy_foam_case_write_time(self._h, solver._h, str(time_name).encode()))

@@ -30,8 +30,8 @@ struct fy_foam_case {
     std::string patch_of_side[6];               // blockMesh patch name covering XMIN, XMAX, YMIN, YMAX, ZMIN, ZMAX
     std::vector<std::string> patch_order;       // patch names in blockMeshDict order (one side each here)
     std::string u_bc_text[6], p_bc_text[6];     // the boundaryField entries as read, re-emitted on write
-    std::vector<double> U0, p0, nut0;           // internalField of the start time (nut0: turbulence cases only)
-    std::string nut_bc_text[6];
+    std::vector<double> U0, p0, nut0, k0;       // internalField of the start time (nut0, k0: turbulence cases only)
+    std::string nut_bc_text[6], k_bc_text[6];
 };
 
 namespace {
@@ -271,6 +271,33 @@ int read_fields(fy_foam_case* c) {
             }
         }
     }
+    if (c->desc.turbulence_model == FY_TURBULENCE_KEQN) {
+        // k.<phase> [OF-6 kEqn: k_ is MUST_READ]; patches zeroGradient | fixedValue (uniform); kqRWallFunction is a zeroGradient condition
+        const std::string path = join(c->dir, c->start_name + "/k." + c->phase);
+        FoamDict f;
+        FY_TRY(need_file(path, &f));
+        FY_TRY(read_internal(f, path, 1, ncell, &c->k0));
+        c->desc.k_initial = c->k0.empty() ? 0.0 : c->k0[0];
+        const FoamDict* bf = f.subdict("boundaryField");
+        if (!bf) return fail(FY_ERR_INVALID, "%s: no boundaryField", path.c_str());
+        for (int s = 0; s < 6; ++s) {
+            const FoamDict* pd = bf->subdict(c->patch_of_side[s]);
+            std::string ty;
+            if (!pd || !pd->word("type", &ty)) return fail(FY_ERR_INVALID, "%s: boundaryField has no (typed) entry for patch '%s'", path.c_str(), c->patch_of_side[s].c_str());
+            c->k_bc_text[s] = entry_text(*pd);
+            c->desc.k_value[s] = 0.0;
+            if (ty == "zeroGradient" || ty == "kqRWallFunction") c->desc.k_bc[s] = FY_BC_NUT_ZERO_GRADIENT;
+            else if (ty == "fixedValue") {
+                c->desc.k_bc[s] = FY_BC_NUT_FIXED_VALUE;
+                const auto* vt = pd->tokens("value");
+                if (!vt || vt->size() < 2 || (*vt)[0] != "uniform" || !fy::foam_tok_is_number((*vt)[1], &c->desc.k_value[s]))
+                    return fail(FY_ERR_UNSUPPORTED, "%s: patch '%s': fixedValue needs 'value uniform <k>'", path.c_str(), c->patch_of_side[s].c_str());
+            } else {
+                return fail(FY_ERR_UNSUPPORTED, "%s: patch '%s': k boundary type '%s' is not supported (zeroGradient, kqRWallFunction, fixedValue)", path.c_str(),
+                            c->patch_of_side[s].c_str(), ty.c_str());
+            }
+        }
+    }
     return FY_OK;
 }
 
@@ -348,15 +375,15 @@ int read_controls(fy_foam_case* c) {
                 const FoamDict* ld = d.subdict("LES");
                 std::string model, delta;
                 if (!ld || !ld->word("LESModel", &model)) return fail(FY_ERR_INVALID, "%s: LES { LESModel ...; } missing", path.c_str());
-                if (model != "Smagorinsky") return fail(FY_ERR_UNSUPPORTED, "%s: LESModel %s is not implemented (Smagorinsky is; kEqn of DPMTurbulenceModels.C:76-77 is not)", path.c_str(), model.c_str());
+                if (model != "Smagorinsky" && model != "kEqn") return fail(FY_ERR_UNSUPPORTED, "%s: LESModel %s is not implemented (DPMTurbulenceModels.C:73-77 instantiates Smagorinsky and kEqn; both are)", path.c_str(), model.c_str());
                 bool on = true;
                 if (ld->boolean("turbulence", &on) && !on) return fail(FY_ERR_UNSUPPORTED, "%s: 'turbulence off' (frozen nut) is not supported: use simulationType laminar", path.c_str());
                 if (!ld->word("delta", &delta) || delta != "cubeRootVol") return fail(FY_ERR_UNSUPPORTED, "%s: LES delta must be cubeRootVol (got '%s')", path.c_str(), delta.c_str());
-                c->desc.turbulence_model = FY_TURBULENCE_SMAGORINSKY;
-                if (const FoamDict* sc = ld->subdict("SmagorinskyCoeffs")) { sc->scalar("Ck", &c->desc.les_ck); sc->scalar("Ce", &c->desc.les_ce); }
+                c->desc.turbulence_model = model == "kEqn" ? FY_TURBULENCE_KEQN : FY_TURBULENCE_SMAGORINSKY;
+                if (const FoamDict* sc = ld->subdict(model + "Coeffs")) { sc->scalar("Ck", &c->desc.les_ck); sc->scalar("Ce", &c->desc.les_ce); }
                 if (const FoamDict* dc = ld->subdict("cubeRootVolCoeffs")) dc->scalar("deltaCoeff", &c->desc.les_delta_coeff);
             } else {
-                return fail(FY_ERR_UNSUPPORTED, "%s: simulationType %s is not implemented (laminar and LES Smagorinsky are; RAS kEpsilon of DPMTurbulenceModels.C:70-71 is not)", path.c_str(), sim.c_str());
+                return fail(FY_ERR_UNSUPPORTED, "%s: simulationType %s is not implemented (laminar and LES Smagorinsky / kEqn are; RAS kEpsilon of DPMTurbulenceModels.C:70-71 is not)", path.c_str(), sim.c_str());
             }
         }
     }
@@ -391,12 +418,20 @@ int read_controls(fy_foam_case* c) {
                                   : joined.find("upwind") != std::string::npos ? FY_CONVECTION_UPWIND : FY_CONVECTION_LINEAR;
                     // only the convection terms select the scheme (icoFoamYade.C:82 div(phi,U), UcEqn.H:5-6 div(alphaPhic,Uc), or `default`);
                     // every other entry (the explicit stress term div(((alpha*nuEff)*dev2(T(grad(U))))) ...) must be plain Gauss linear
-                    const bool convection = k == "default" || k == "div(phi,U)" || k == "div(alphaPhic,Uc)" || k == "div(phic,Uc)";
+                    // (the fields' registered names are alphaPhi.<phase>, U.<phase>, k.<phase>: pimpleFoamYade/createFields.H:35-45,238-246)
+                    const bool convection = k == "default" || k == "div(phi,U)" || k == "div(alphaPhic,Uc)" || k == "div(phic,Uc)" ||
+                                            k == "div(alphaPhi." + c->phase + ",U." + c->phase + ")";
+                    const bool k_convection = k == "div(alphaPhic,k)" || k == "div(alphaPhi." + c->phase + ",k." + c->phase + ")";
+                    if (k_convection) {                                  // fvm::div(alphaRhoPhi, k) of the kEqn model
+                        if (sch == FY_CONVECTION_LINEAR_UPWIND) return fail(FY_ERR_UNSUPPORTED, "%s: divSchemes.%s = '%s': Gauss linear or Gauss upwind for k", path.c_str(), k.c_str(), joined.c_str());
+                        c->desc.k_convection_scheme = sch;
+                        continue;
+                    }
                     if (!convection) {
                         if (sch != FY_CONVECTION_LINEAR) return fail(FY_ERR_UNSUPPORTED, "%s: divSchemes.%s = '%s': only the convection terms may be upwinded, this one must be Gauss linear", path.c_str(), k.c_str(), joined.c_str());
                         continue;
                     }
-                    if (k == "default") { if (!n_div) c->desc.convection_scheme = sch; continue; }      // a named convection entry overrides it
+                    if (k == "default") { if (!n_div) c->desc.convection_scheme = sch; c->desc.k_convection_scheme = sch == FY_CONVECTION_LINEAR ? sch : FY_CONVECTION_UPWIND; continue; }      // a named convection entry overrides it
                     if (n_div++ && sch != c->desc.convection_scheme) return fail(FY_ERR_UNSUPPORTED, "%s: divSchemes mixes different convection schemes", path.c_str());
                     c->desc.convection_scheme = sch;
                 }
@@ -432,6 +467,16 @@ int read_controls(fy_foam_case* c) {
             for (const std::string& k : sv->order)
                 if (k.find(c->u_name) != std::string::npos || (k.find("U") != std::string::npos && k.find("Final") == std::string::npos)) { us = sv->subdict(k); if (us) break; }
         if (us) { us->scalar("tolerance", &c->desc.u_tol); us->scalar("relTol", &c->desc.u_rel_tol); us->integer("maxIter", &c->desc.u_max_iter); }
+        if (c->desc.turbulence_model == FY_TURBULENCE_KEQN) {          // solvers.k.<phase> (or a pattern naming k, e.g. "(U.water|k.water)")
+            c->desc.k_tol = c->desc.u_tol; c->desc.k_rel_tol = c->desc.u_rel_tol; c->desc.k_max_iter = c->desc.u_max_iter;
+            const std::string kn = "k." + c->phase;
+            const FoamDict* ks = sv->subdict(kn);
+            if (!ks)
+                for (const std::string& key : sv->order)
+                    if (key.find(kn) != std::string::npos || key.find("|k|") != std::string::npos || key.find("|k)") != std::string::npos) { ks = sv->subdict(key); if (ks) break; }
+            if (!ks) return fail(FY_ERR_INVALID, "%s: solvers has no entry for %s (kEqn solves a transport equation for it)", path.c_str(), kn.c_str());
+            ks->scalar("tolerance", &c->desc.k_tol); ks->scalar("relTol", &c->desc.k_rel_tol); ks->integer("maxIter", &c->desc.k_max_iter);
+        }
         // relaxationFactors: equations { <U>; <U>Final; ".*" } for UcEqn.relax() (UcEqn.H:12), fields { p; pFinal } for p.relax() (pEqn.H:41).
         // No entry = the call does nothing [OF-6 fvMatrix::relax(), GeometricField::relax()]; icoFoamYade relaxes nothing.
         c->desc.u_relax = c->desc.u_relax_final = c->desc.p_relax = c->desc.p_relax_final = 0.0;
@@ -450,6 +495,7 @@ int read_controls(fy_foam_case* c) {
                 };
                 lookup(rf->subdict("equations"), c->u_name, &c->desc.u_relax);
                 lookup(rf->subdict("equations"), c->u_name + "Final", &c->desc.u_relax_final);
+                if (c->desc.turbulence_model == FY_TURBULENCE_KEQN) lookup(rf->subdict("equations"), "k." + c->phase, &c->desc.k_relax);
                 lookup(rf->subdict("fields"), "p", &c->desc.p_relax);
                 lookup(rf->subdict("fields"), "pFinal", &c->desc.p_relax_final);
                 for (double v : {c->desc.u_relax, c->desc.u_relax_final, c->desc.p_relax, c->desc.p_relax_final})
@@ -537,6 +583,13 @@ int fy_foam_case_initial_nut(const fy_foam_case* c, double* nut) {
     return FY_OK;
 }
 
+int fy_foam_case_initial_k(const fy_foam_case* c, double* k) {
+    if (!c || !k) return fail(FY_ERR_INVALID, "fy_foam_case_initial_k: null argument");
+    if (c->k0.empty()) return fail(FY_ERR_INVALID, "fy_foam_case_initial_k: the case has no k equation");
+    std::memcpy(k, c->k0.data(), c->k0.size() * sizeof(double));
+    return FY_OK;
+}
+
 int fy_foam_case_write_time(const fy_foam_case* c, fy_solver* s, const char* time_name) {
     if (!c || !s || !time_name || !*time_name) return fail(FY_ERR_INVALID, "fy_foam_case_write_time: null argument");
     const std::string tdir = join(c->dir, time_name);
@@ -564,6 +617,11 @@ int fy_foam_case_write_time(const fy_foam_case* c, fy_solver* s, const char* tim
         std::vector<double> nt(n);                                           // eddyViscosity::nut_ is AUTO_WRITE
         FY_TRY(fy_solver_read_field_host(s, "nut", nt.data()));
         FY_TRY(write_field(c, tdir, time_name, "nut." + c->phase, "volScalarField", "[0 2 -1 0 0 0 0]", 1, nt, c->nut_bc_text, "        type            zeroGradient;\n"));
+    }
+    if (c->desc.turbulence_model == FY_TURBULENCE_KEQN) {
+        std::vector<double> kk(n);
+        FY_TRY(fy_solver_read_field_host(s, "k", kk.data()));
+        FY_TRY(write_field(c, tdir, time_name, "k." + c->phase, "volScalarField", "[0 2 -2 0 0 0 0]", 1, kk, c->k_bc_text, "        type            zeroGradient;\n"));
     }
     return FY_OK;
 }

@@ -70,6 +70,15 @@ int launch_pre_coupling(hipStream_t s, FvGeo g, const double* U, const double* p
 int launch_interp_alpha(hipStream_t s, FvGeo g, const double* alpha, Face3 alphaf);
 // G: three vec3 fields (rows of the tensor) over the whole storage, as k_pre_coupling writes them
 int launch_div_G(hipStream_t s, FvGeo g, const double* G, double* divG);
+// LES kEqn (DPMTurbulenceModels.C:76-77) [OF-6 LES/kEqn/kEqn.C]: boundary conditions of k (0 zeroGradient, 1 fixedValue), model constants,
+// convection scheme of div(alphaRhoPhi,k) (0 Gauss linear, 1 Gauss upwind), relaxation factor of the k equation (<= 0: none)
+struct KEqnParams { double ck, ce, delta, kmin, relax; int upwind; int k_bc[6]; double k_val[6]; };
+// assembles the k equation into the momentum matrix's storage (free after the correctors) as a 3-component system whose components 1, 2 are
+// identically zero, so that the momentum solver's Jacobi pass solves it: x3 = {k, 0, 0}, b3 = {source, 0, 0}
+int launch_assemble_k(hipStream_t s, FvGeo g, KEqnParams kp, const double* k, const double* alpha, CFace3 alphaf, CFace3 phi, const double* vGrad,
+                      Mom7 M, double* b3, double* x3);
+// bound(k, kMin) [OF-6 bound.C] on the solved component 0 of x3, then nut = Ck sqrt(k) delta (kEqn::correctNut)
+int launch_k_finish(hipStream_t s, FvGeo g, KEqnParams kp, const double* x3, double* k, double* nut);
 int launch_smagorinsky_nut(hipStream_t s, FvGeo g, const double* vGrad, double ck, double ce, double delta, double* nut);
 int launch_assemble_momentum(hipStream_t s, FvGeo g, const double* U, const double* Uold, const double* alpha, const double* alphaOld,
                              CFace3 alphaf, CFace3 phi, const double* uSource, const double* uSourceDrag, const double* divG,

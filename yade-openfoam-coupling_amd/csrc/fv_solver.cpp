@@ -52,7 +52,9 @@ struct Solver {
     SelfComm self_comm;
 
     DevBuf<double> U, Uold, p, alpha, uSource, uSourceDrag, uParticle, gradP, divT, vGrad, ddtU;
-    DevBuf<double> nut;                  // eddy viscosity (FY_TURBULENCE_SMAGORINSKY), storage cells; empty = laminar
+    DevBuf<double> nut;                  // eddy viscosity (FY_TURBULENCE_SMAGORINSKY / _KEQN), storage cells; empty = laminar
+    DevBuf<double> kturb;                // sub-grid kinetic energy k (FY_TURBULENCE_KEQN)
+    KEqnParams kp{};
     double les_delta = 0.0;              // LESdelta cubeRootVol: deltaCoeff * cbrt(V) [OF-6 cubeRootVolDelta.C]
     bool phi_fresh = true;      // phi holds the current flux (false between the start-of-step exchange with phiOld and the first flux correction)
     CFace3 phi_now() const { return phi_fresh ? CFace3{{phi[0].p, phi[1].p, phi[2].p}} : CFace3{{phiOld[0].p, phiOld[1].p, phiOld[2].p}}; }
@@ -161,7 +163,7 @@ struct Solver {
         for (int a = 0; a < 3; ++a) g.g[a] = c->g[a];
         g.need_ref = need_ref ? 1 : 0; g.p_ref_cell = c->p_ref_cell; g.p_ref_value = c->p_ref_value;
         g.u_relax = c->u_relax;
-        if (c->turbulence_model != FY_TURBULENCE_LAMINAR && c->turbulence_model != FY_TURBULENCE_SMAGORINSKY) return fail(FY_ERR_UNSUPPORTED, "fy_solver_create: unknown turbulence_model %d (laminar and LES Smagorinsky are implemented; kEpsilon and kEqn of DPMTurbulenceModels.C:70-77 are not)", c->turbulence_model);
+        if (c->turbulence_model != FY_TURBULENCE_LAMINAR && c->turbulence_model != FY_TURBULENCE_SMAGORINSKY && c->turbulence_model != FY_TURBULENCE_KEQN) return fail(FY_ERR_UNSUPPORTED, "fy_solver_create: unknown turbulence_model %d (laminar, LES Smagorinsky and LES kEqn are implemented; RAS kEpsilon of DPMTurbulenceModels.C:70-71 is not)", c->turbulence_model);
         if (c->turbulence_model != FY_TURBULENCE_LAMINAR) {
             if (!pimple) return fail(FY_ERR_INVALID, "fy_solver_create: icoFoamYade has no turbulence model (icoFoamYade.C:79-85 is laplacian(nu, U))");
             if (!(c->les_ck > 0 && c->les_ce > 0 && c->les_delta_coeff > 0) || c->nut_initial < 0) return fail(FY_ERR_INVALID, "fy_solver_create: Smagorinsky needs Ck, Ce, deltaCoeff > 0 and nut >= 0");
@@ -170,6 +172,16 @@ struct Solver {
                 g.nut_bc[q] = c->nut_bc[q]; g.nut_val[q] = c->nut_value[q];
             }
             les_delta = c->les_delta_coeff * std::pow(g.V, 1.0 / 3.0);
+            if (c->turbulence_model == FY_TURBULENCE_KEQN) {
+                if (c->k_initial < 0 || !(c->k_tol >= 0) || c->k_max_iter < 0 || c->k_relax > 1) return fail(FY_ERR_INVALID, "fy_solver_create: kEqn needs k >= 0, a solver tolerance and a relaxation factor in (0, 1]");
+                if (c->k_convection_scheme != FY_CONVECTION_LINEAR && c->k_convection_scheme != FY_CONVECTION_UPWIND) return fail(FY_ERR_UNSUPPORTED, "fy_solver_create: div(alphaPhic,k) must be Gauss linear or Gauss upwind");
+                kp.ck = c->les_ck; kp.ce = c->les_ce; kp.delta = les_delta; kp.kmin = 1e-15;        // kMin_ = small [OF-6 LESModel.C]
+                kp.relax = c->k_relax; kp.upwind = c->k_convection_scheme == FY_CONVECTION_UPWIND ? 1 : 0;
+                for (int q = 0; q < 6; ++q) {
+                    if (c->k_bc[q] != FY_BC_NUT_ZERO_GRADIENT && c->k_bc[q] != FY_BC_NUT_FIXED_VALUE) return fail(FY_ERR_INVALID, "fy_solver_create: unknown k boundary type");
+                    kp.k_bc[q] = c->k_bc[q]; kp.k_val[q] = c->k_value[q];
+                }
+            }
         }
         if (c->adjust_time_step && !(c->max_co > 0 && c->max_delta_t > 0)) return fail(FY_ERR_INVALID, "adjustTimeStep needs maxCo > 0 and maxDeltaT > 0");
         if (c->u_relax > 1 || c->u_relax_final > 1 || c->p_relax > 1 || c->p_relax_final > 1) return fail(FY_ERR_INVALID, "relaxation factors lie in (0, 1]");
@@ -199,6 +211,7 @@ struct Solver {
         for (auto& b : man) { FY_TRY(b.alloc_exact(n)); FY_TRY(zero(b)); }
         FY_TRY(vGrad.alloc_exact(9 * n)); FY_TRY(zero(vGrad));
         if (c->turbulence_model != FY_TURBULENCE_LAMINAR) { FY_TRY(nut.alloc_exact(n)); FY_TRY(launch_fill_f64(stream, nut.p, n, c->nut_initial)); g.nut = nut.p; }
+        if (c->turbulence_model == FY_TURBULENCE_KEQN) { FY_TRY(kturb.alloc_exact(n)); FY_TRY(launch_fill_f64(stream, kturb.p, n, c->k_initial)); }
         FY_TRY(Gt.alloc_exact(9 * n)); FY_TRY(zero(Gt));
         for (int d = 0; d < 3; ++d) {
             DevBuf<double>* fs[] = {&phi[d], &phiOld[d], &psn[d], &alphaf[d], &phiHbyA[d], &phiForces[d], &rAUf[d], &pflux[d]};
@@ -373,32 +386,35 @@ struct Solver {
     }
 
     // ---- momentum predictor: Jacobi sweeps with lduMatrix-style L1 residual control (stand-in for smoothSolver) ----------
-    int solve_momentum(int* iters) {
+    int solve_momentum(int* iters) { return solve_vec3(U, bmom.p, cs.u_tol, cs.u_rel_tol, cs.u_max_iter, iters); }
+    // Jacobi sweeps on the 7-point matrix in M7() for a 3-component field X (in place; xscr is the other buffer), lduMatrix-style L1
+    // residual control per component
+    int solve_vec3(DevBuf<double>& X, const double* rhs, double tol, double rel_tol, int max_iter, int* iters) {
         double h[6];
-        // sum(U) per component for xbar = average(U): folded (and all-reduced) on the device, divided where it is used
-        FY_TRY(launch_sum3(stream, U.p + 3 * (size_t)g.c0, Nc, partials.p));
+        // sum(X) per component for xbar = average(X): folded (and all-reduced) on the device, divided where it is used
+        FY_TRY(launch_sum3(stream, X.p + 3 * (size_t)g.c0, Nc, partials.p));
         FY_TRY(launch_reduce_finalize(stream, partials.p, Nc, 3, nullptr, xbar3.p));
         FY_TRY(comm->allreduce(stream, xbar3.p, 3, false));
-        double* xc = U.p; double* xn = xscr.p;
+        double* xc = X.p; double* xn = xscr.p;
         double norm[3] = {1, 1, 1}, res0[3] = {0, 0, 0}, res[3];
         int it = 0;
         for (;;) {
             FY_TRY(halo(xc, 3, plane, g.nz, g.gz, 1));
             kc[KC_MOM_PASS].begin(stream);
-            FY_TRY(launch_mom_pass(stream, g, M7(), bmom.p, xc, xn, xbar3.p, (double)Nglob, partials.p));
+            FY_TRY(launch_mom_pass(stream, g, M7(), rhs, xc, xn, xbar3.p, (double)Nglob, partials.p));
             kc[KC_MOM_PASS].end(stream);
             FY_TRY(reduce_read(6, false, h));
             if (it == 0) for (int q = 0; q < 3; ++q) { norm[q] = h[3 + q] + 1e-20; res0[q] = h[q] / norm[q]; }
             bool conv = true;
             for (int q = 0; q < 3; ++q) {
                 res[q] = h[q] / norm[q];
-                if (!(res[q] < cs.u_tol || (cs.u_rel_tol > 0 && res[q] < cs.u_rel_tol * res0[q]))) conv = false;
+                if (!(res[q] < tol || (rel_tol > 0 && res[q] < rel_tol * res0[q]))) conv = false;
             }
-            if (conv || it >= cs.u_max_iter) break;
+            if (conv || it >= max_iter) break;
             std::swap(xc, xn);
             ++it;
         }
-        if (xc != U.p) FY_TRY(launch_copy_f64(stream, U.p + 3 * (size_t)g.c0, xc + 3 * (size_t)g.c0, 3 * (size_t)Nc));
+        if (xc != X.p) FY_TRY(launch_copy_f64(stream, X.p + 3 * (size_t)g.c0, xc + 3 * (size_t)g.c0, 3 * (size_t)Nc));
         *iters = it;
         return FY_OK;
     }
@@ -657,9 +673,22 @@ struct Solver {
     int turbulence_correct() {
         FY_TRY(halo_cells(U, 3, 1));
         FY_TRY(launch_pre_coupling(stream, g, U.p, p.p, alpha.p, C3(psn), vGrad.p, gradP.p, divT.p, nullptr, 1, 0));
+        if (cs.turbulence_model == FY_TURBULENCE_KEQN) {
+            // kEqn::correct(): the k equation is assembled into the momentum matrix's storage and solved by the momentum solver's pass as a
+            // 3-component system whose last two components are identically zero (HbyA / bmom / xscr are free after the correctors)
+            FY_TRY(halo_cells(kturb, 1, 1));
+            FY_TRY(launch_assemble_k(stream, g, kp, kturb.p, alpha.p, C3(alphaf), C3(phi), vGrad.p, M7(), bmom.p, HbyA.p));
+            int it = 0;
+            FY_TRY(solve_vec3(HbyA, bmom.p, cs.k_tol, cs.k_rel_tol, cs.k_max_iter, &it));
+            st_k_iters += it;
+            FY_TRY(halo_cells(HbyA, 3, 1));
+            FY_TRY(launch_k_finish(stream, g, kp, HbyA.p, kturb.p, nut.p));
+            return halo_cells(nut, 1, 1);
+        }
         FY_TRY(launch_smagorinsky_nut(stream, g, vGrad.p, cs.les_ck, cs.les_ce, les_delta, nut.p));
         return halo_cells(nut, 1, 1);
     }
+    int st_k_iters = 0;
 
     // ---- one pass of the while (runTime.loop()) body ---------------------------------------------------------------------
     int step() {
@@ -797,7 +826,7 @@ struct Solver {
         const E tab[] = {{"U", U.p, 3 * n, 3}, {"p", p.p, n, 1}, {"phi_x", phi[0].p, phi[0].n, 0}, {"phi_y", phi[1].p, phi[1].n, 0}, {"phi_z", phi[2].p, phi[2].n, 0},
                          {"rAU", rAU.p, n, 1}, {"HbyA", HbyA.p, 3 * n, 3}, {"p_rhs", prhs.p, n, 1}, {"mom_diag", mdiag.p, n, 1}, {"mom_src", src.p, 3 * n, 3},
                          {"alpha", alpha.p, n, 1}, {"uSource", uSource.p, 3 * n, 3}, {"uSourceDrag", uSourceDrag.p, n, 1}, {"uParticle", uParticle.p, 3 * n, 3},
-                         {"gradP", gradP.p, 3 * n, 3}, {"divT", divT.p, 3 * n, 3}, {"vGrad", vGrad.p, 9 * n, 9}, {"ddtU", ddtU.p, 3 * n, 3}, {"nut", nut.p, n, 1}};
+                         {"gradP", gradP.p, 3 * n, 3}, {"divT", divT.p, 3 * n, 3}, {"vGrad", vGrad.p, 9 * n, 9}, {"ddtU", ddtU.p, 3 * n, 3}, {"nut", nut.p, n, 1}, {"k", kturb.p, n, 1}};
         for (const E& e : tab) if (s == e.nm) {
             if (!e.p) return fail(FY_ERR_INVALID, "solver field '%s' does not exist in this case (no turbulence model)", s.c_str());
             *ptr = e.p + (size_t)e.comp * g.c0;          // skip the ghost planes below the owned range (comp = 0: face array)
@@ -831,6 +860,7 @@ void fy_case_defaults(fy_case_desc* c, int solver) {
     c->u_tol = 1e-5; c->u_rel_tol = 0.0; c->u_max_iter = 1000;
     c->adjust_time_step = 0; c->max_co = 1.0; c->max_delta_t = 1e300;
     c->u_relax = 1.0; c->u_relax_final = 0.0; c->p_relax = 0.0; c->p_relax_final = 0.0;
+    c->k_tol = 1e-6; c->k_rel_tol = 0.0; c->k_max_iter = 1000; c->k_relax = 0.0; c->k_convection_scheme = FY_CONVECTION_UPWIND;
     c->turbulence_model = FY_TURBULENCE_LAMINAR; c->les_ck = 0.094; c->les_ce = 1.048; c->les_delta_coeff = 1.0;     // [OF-6 Smagorinsky.C, cubeRootVolDelta.C defaults]
 }
 
@@ -931,6 +961,7 @@ int fy_solver_write_field_host(fy_solver* s, const char* name, const double* in)
         FY_TRY(fy::launch_flux_of(s->s.stream, s->s.g, s->s.U.p, s->s.F3(s->s.phi)));
     }
     if (std::string(name) == "nut") FY_TRY(s->s.halo_cells(s->s.nut, 1, 1));
+    if (std::string(name) == "k") FY_TRY(s->s.halo_cells(s->s.kturb, 1, 1));
     FY_HIP(hipStreamSynchronize(s->s.stream));
     return FY_OK;
 }
