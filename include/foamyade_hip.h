@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define FY_ABI_VERSION 5
+#define FY_ABI_VERSION 6
 
 /* ---- status codes ------------------------------------------------------------------------------------ */
 enum {
@@ -195,6 +195,7 @@ enum { FY_PSOLVER_PCG_JACOBI = 0, FY_PSOLVER_PCG_MG = 1 };
 #define FY_TURBULENCE_LAMINAR 0        /* simulationType laminar / laminarModel Stokes (DPMTurbulenceModels.C:67-68) */
 #define FY_TURBULENCE_SMAGORINSKY 1    /* simulationType LES, LESModel Smagorinsky (DPMTurbulenceModels.C:73-74), delta cubeRootVol */
 #define FY_TURBULENCE_KEQN 2           /* simulationType LES, LESModel kEqn (DPMTurbulenceModels.C:76-77), delta cubeRootVol */
+#define FY_TURBULENCE_KEPSILON 3       /* simulationType RAS, RASModel kEpsilon (DPMTurbulenceModels.C:70-71); no wall functions */
 #define FY_BC_NUT_ZERO_GRADIENT 0
 #define FY_BC_NUT_FIXED_VALUE 1
 typedef struct fy_case_desc {
@@ -244,6 +245,17 @@ typedef struct fy_case_desc {
     int32_t k_convection_scheme;
     double k_tol, k_rel_tol; int32_t k_max_iter;
     double k_relax;
+    /* kEpsilon [OF-6 RAS/kEpsilon/kEpsilon.C]: first the dissipation equation, fvm::ddt(alpha,eps) + fvm::div(alphaPhic,eps)
+       - fvm::laplacian(alpha (nut/sigmaEps + nu), eps) == C1 alpha G eps/k - fvm::SuSp((2/3 C1 - C3) alpha div(phic), eps) - fvm::Sp(C2 alpha eps/k, eps),
+       bound(eps, epsilonMin); then fvm::ddt(alpha,k) + fvm::div(alphaPhic,k) - fvm::laplacian(alpha (nut/sigmak + nu), k) == alpha G
+       - fvm::SuSp(2/3 alpha div(phic), k) - fvm::Sp(alpha eps/k, k) with the NEW eps, bound(k, kMin); nut = Cmu k^2/eps.
+       k uses the k_* fields above; epsilon its own.  Boundary types zeroGradient | fixedValue only: the wall functions a RAS case normally
+       puts on its walls (epsilonWallFunction, nutkWallFunction) are not implemented and are refused by the case reader */
+    double ras_cmu, ras_c1, ras_c2, ras_c3, ras_sigmak, ras_sigmaeps;   /* fy_case_defaults: 0.09, 1.44, 1.92, 0, 1, 1.3 */
+    int32_t eps_bc[6]; double eps_value[6]; double eps_initial;
+    int32_t eps_convection_scheme;
+    double eps_tol, eps_rel_tol; int32_t eps_max_iter;
+    double eps_relax;
 } fy_case_desc;
 
 typedef struct fy_solver fy_solver;
@@ -262,7 +274,7 @@ int fy_solver_create(const fy_case_desc* c, const fy_transport* transport, int d
 fy_ctx* fy_solver_coupling(fy_solver*);                 /* the yadeCoupling object (icoFoamYade.C:54, pimpleFoamYade.C:54) */
 int fy_solver_step(fy_solver*);                         /* one pass of the while(runTime.loop()) body */
 int fy_solver_get_stats(fy_solver*, fy_step_stats* out);
-/* names: "U" [n][3], "p" [n], "phi_x" [(nx+1)*ny*nz], "phi_y", "phi_z", "nut" [n] (with a turbulence model), "k" [n] (kEqn), plus every fy_ctx field name */
+/* names: "U" [n][3], "p" [n], "phi_x" [(nx+1)*ny*nz], "phi_y", "phi_z", "nut" [n] (with a turbulence model), "k" [n] (kEqn, kEpsilon), "epsilon" [n] (kEpsilon), plus every fy_ctx field name */
 int fy_solver_read_field_host(fy_solver*, const char* name, double* out);
 int fy_solver_write_field_host(fy_solver*, const char* name, const double* in);
 /* number of doubles fy_solver_read/write_field_host move for `name` on this rank (owned cells / local faces) */
@@ -301,7 +313,8 @@ int fy_foam_case_info_get(const fy_foam_case*, fy_foam_case_info* out);
 int fy_foam_case_initial_fields(const fy_foam_case*, double* U /* [n][3] or NULL */, double* p /* [n] or NULL */);
 /* start-time nut.<phase> of a case with a turbulence model (hand it to fy_solver_write_field_host(s, "nut", ...) when it is not uniform) */
 int fy_foam_case_initial_nut(const fy_foam_case*, double* nut /* [n] */);
-int fy_foam_case_initial_k(const fy_foam_case*, double* k /* [n] */);          /* start-time k.<phase> of a kEqn case */
+int fy_foam_case_initial_k(const fy_foam_case*, double* k /* [n] */);          /* start-time k.<phase> of a kEqn / kEpsilon case */
+int fy_foam_case_initial_epsilon(const fy_foam_case*, double* eps /* [n] */);  /* start-time epsilon.<phase> of a kEpsilon case */
 /* runTime.write(): <case>/<time_name>/{U | U.<phase>, p [, alpha.<phase>]} as ASCII volFields with the case's own patch entries */
 int fy_foam_case_write_time(const fy_foam_case*, fy_solver*, const char* time_name);
 int fy_foam_case_close(fy_foam_case*);

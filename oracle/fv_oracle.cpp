@@ -53,6 +53,9 @@ struct orc_fv_case {
     int nut_bc[6]; double nut_value[6]; double nut_initial;
     // LES kEqn (turbulence_model 2): the 0/k file, div(alphaPhic,k) scheme (0 linear, 1 upwind), solvers.k, relaxationFactors equations k
     int k_bc[6]; double k_value[6]; double k_initial; int k_convection_scheme; double k_tol, k_rel_tol; int k_max_iter; double k_relax;
+    // RAS kEpsilon (turbulence_model 3): model constants, the 0/epsilon file, div(alphaPhic,epsilon) scheme, solvers.epsilon, relaxation
+    double ras_cmu, ras_c1, ras_c2, ras_c3, ras_sigmak, ras_sigmaeps;
+    int eps_bc[6]; double eps_value[6]; double eps_initial; int eps_convection_scheme; double eps_tol, eps_rel_tol; int eps_max_iter; double eps_relax;
 };
 struct orc_fv_stats {
     double courant_mean, courant_max, cont_sum_local, cont_global, cont_cumulative;
@@ -84,7 +87,7 @@ struct Fv {
     // state
     vec U, Uold, p, alpha, alphaOld, uSource, uSourceDrag, uParticle, gradP, divT, vGrad, ddtU;
     vec nut;                                 // eddy viscosity (Smagorinsky, kEqn); empty = laminar
-    vec kturb;                               // sub-grid kinetic energy (kEqn)
+    vec kturb, epsturb;                      // turbulent kinetic energy (kEqn, kEpsilon), dissipation rate (kEpsilon)
     int k_iters = 0;
     vec phi[3], phiOld[3], psn[3];           // psn: d p / d axis on fixedFluxPressure boundary faces
     // work
@@ -125,7 +128,8 @@ struct Fv {
         Sc.assign(Nc, 0.0); divG.assign(3 * (size_t)Nc, 0.0);
         pb.assign(Nc, 0.0); pr = pb; pw = pb; pp = pb; pz = pb;
         if (pimple && c.turbulence_model >= 1) nut.assign(Nc, c.nut_initial);      // the 0/nut file (eddyViscosity: MUST_READ)
-        if (pimple && c.turbulence_model == 2) kturb.assign(Nc, c.k_initial);      // the 0/k file
+        if (pimple && c.turbulence_model >= 2) kturb.assign(Nc, c.k_initial);      // the 0/k file
+        if (pimple && c.turbulence_model == 3) epsturb.assign(Nc, c.eps_initial);  // the 0/epsilon file
         build_mg_shapes();
         // createPhi: phi = linearInterpolate(U) & Sf (icoFoamYade/createFields.H:151, pimpleFoamYade/createFields.H:70-81)
         flux_of(U, phi);
@@ -827,20 +831,29 @@ struct Fv {
             if (!nut.empty() && final_outer) turbulence_correct();             // pimple.turbCorr() (final outer iteration), pimpleFoamYade.C:101-104
         }
     }
-    // continuousPhaseTurbulence->correct() for LESModel kEqn (DPMTurbulenceModels.C:76-77) [OF-6 LES/kEqn/kEqn.C]:
+    // The transport equations of LESModel kEqn (DPMTurbulenceModels.C:76-77) [OF-6 LES/kEqn/kEqn.C] and RASModel kEpsilon
+    // (DPMTurbulenceModels.C:70-71) [OF-6 RAS/kEpsilon/kEpsilon.C]:
     //   divU = fvc::div(fvc::absolute(phi, U)); G = nut (gradU && dev(twoSymm(gradU)));
-    //   fvm::ddt(alpha, rho, k) + fvm::div(alphaRhoPhi, k) - fvm::laplacian(alpha rho DkEff(), k)
-    //     == alpha rho G - fvm::SuSp((2/3) alpha rho divU, k) - fvm::Sp(Ce alpha rho sqrt(k)/delta, k);   DkEff = nut + nu
-    //   kEqn.relax(); solve(kEqn); bound(k, kMin); correctNut(): nut = Ck sqrt(k) delta
+    //   fvm::ddt(alpha, rho, X) + fvm::div(alphaRhoPhi, X) - fvm::laplacian(alpha rho DXEff(), X) == Su - fvm::SuSp(c1, X) - fvm::Sp(c2, X)
+    //   mode 0 (kEqn, X = k):       Su = alpha G,           c1 = 2/3 alpha divU,           c2 = Ce alpha sqrt(k)/delta, DkEff = nut + nu
+    //   mode 1 (kEpsilon, X = eps): Su = C1 alpha G eps/k,  c1 = (2/3 C1 - C3) alpha divU, c2 = C2 alpha eps/k,         DepsilonEff = nut/sigmaEps + nu
+    //   mode 2 (kEpsilon, X = k):   Su = alpha G,           c1 = 2/3 alpha divU,           c2 = alpha eps/k,            DkEff = nut/sigmak + nu
+    //   X.relax(); solve; bound(X, XMin); correctNut(): kEqn nut = Ck sqrt(k) delta, kEpsilon (after the k equation) nut = Cmu k^2/eps
     // [OF-6 fvm::SuSp: diag += V max(susp, 0), source -= V min(susp, 0) psi; fvMatrix == volField: source += V field;
-    //  bound.C: k = max(max(k, fvc::average(max(k, kMin)) pos0(-k)), kMin)].  alpha.oldTime() == alpha (quirk F-Q1).
-    void keqn_correct() {
-        const double nu = cs.nu, dt = cs.dt, delta = cs.les_delta_coeff * std::pow(V, 1.0 / 3.0), Ck = cs.les_ck, Ce = cs.les_ce, kMin = 1e-15;
+    //  bound.C: X = max(max(X, fvc::average(max(X, XMin)) pos0(-X)), XMin)].  alpha.oldTime() == alpha (quirk F-Q1).
+    void turb_eqn(int mode) {
+        const double nu = cs.nu, dt = cs.dt, delta = cs.les_delta_coeff * std::pow(V, 1.0 / 3.0), xMin = 1e-15;
+        const double sigma = mode == 0 ? 1.0 : mode == 1 ? cs.ras_sigmaeps : cs.ras_sigmak;
+        const int* bc = mode == 1 ? cs.eps_bc : cs.k_bc;
+        const double* bval = mode == 1 ? cs.eps_value : cs.k_value;
+        const int scheme = mode == 1 ? cs.eps_convection_scheme : cs.k_convection_scheme;
+        const double relax = mode == 1 ? cs.eps_relax : cs.k_relax;
+        vec& Xf = mode == 1 ? epsturb : kturb;
         vec b3(3 * (size_t)Nc, 0.0), x3(3 * (size_t)Nc, 0.0);
         for (int k = 0; k < nz; ++k) for (int j = 0; j < ny; ++j) for (int i = 0; i < nx; ++i) {
             const int c = cid(i, j, k);
-            const double aP = alpha[c], kc = kturb[c], nutc = nut[c];
-            double dg = aP * V / dt, s = aP * V * kc / dt, sumPhi = 0.0;
+            const double aP = alpha[c], xc = Xf[c], nutc = nut[c];
+            double dg = aP * V / dt, s = aP * V * xc / dt, sumPhi = 0.0;
             for (int d = 0; d < 3; ++d) for (int sd = 0; sd < 2; ++sd) {
                 const int f = cface(d, sd, i, j, k);
                 const double af = alphaf[d][f];
@@ -851,13 +864,13 @@ struct Fv {
                     an[2 * d + sd][c] = 0.0;
                     const int patch = 2 * d + sd;
                     const double nb = cs.nut_bc[patch] == 1 ? cs.nut_value[patch] : nutc;
-                    const double gam = (af * (nu + nb)) * dx;
-                    if (cs.k_bc[patch] == 1) { const double gb = 2.0 * gam; dg += gb; s += (-phio + gb) * cs.k_value[patch]; }
+                    const double gam = (af * (nu + nb / sigma)) * dx;
+                    if (bc[patch] == 1) { const double gb = 2.0 * gam; dg += gb; s += (-phio + gb) * bval[patch]; }
                     else dg += phio;
                 } else {
                     const int nbc = c + (sd ? stride[d] : -stride[d]);
-                    const double gam = (0.5 * ((aP * (nu + nutc)) + (alpha[nbc] * (nu + nut[nbc])))) * dx;
-                    const bool up = cs.k_convection_scheme != 0;
+                    const double gam = (0.5 * ((aP * (nu + nutc / sigma)) + (alpha[nbc] * (nu + nut[nbc] / sigma)))) * dx;
+                    const bool up = scheme != 0;
                     const double cP = up ? std::max(phio, 0.0) : 0.5 * phio, cN = up ? std::min(phio, 0.0) : 0.5 * phio;
                     dg += cP + gam;
                     an[2 * d + sd][c] = cN - gam;
@@ -869,46 +882,51 @@ struct Fv {
             for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) GG += T[3 * a + b] * ((T[3 * a + b] + T[3 * b + a]) - (a == b ? (1.0 / 3.0) * tr2 : 0.0));
             const double G = nutc * GG;
             const double divU = sumPhi / V;
-            const double c1 = (2.0 / 3.0) * aP * divU, c2 = Ce * aP * std::sqrt(kc) / delta;
+            double Su, c1, c2;
+            if (mode == 0) { Su = aP * G; c1 = (2.0 / 3.0) * aP * divU; c2 = cs.les_ce * aP * std::sqrt(xc) / delta; }
+            else if (mode == 1) { const double kc = kturb[c]; Su = cs.ras_c1 * aP * G * xc / kc; c1 = ((2.0 / 3.0) * cs.ras_c1 - cs.ras_c3) * aP * divU; c2 = cs.ras_c2 * aP * xc / kc; }
+            else { Su = aP * G; c1 = (2.0 / 3.0) * aP * divU; c2 = aP * epsturb[c] / xc; }
             dg += V * (std::max(c1, 0.0) + c2);
-            s += V * (aP * G) - V * std::min(c1, 0.0) * kc;
-            if (cs.k_relax > 0) {
+            s += V * Su - V * std::min(c1, 0.0) * xc;
+            if (relax > 0) {
                 double so = 0.0;
                 for (int q = 0; q < 6; ++q) so += std::fabs(an[q][c]);
-                const double dn = std::max(std::fabs(dg), so) / cs.k_relax;
-                s += (dn - dg) * kc;
+                const double dn = std::max(std::fabs(dg), so) / relax;
+                s += (dn - dg) * xc;
                 dg = dn;
             }
             diag[c] = dg;
             b3[3 * (size_t)c] = s;
-            x3[3 * (size_t)c] = kc;
+            x3[3 * (size_t)c] = xc;
         }
-        k_iters += solve_vec3(x3, b3, cs.k_tol, cs.k_rel_tol, cs.k_max_iter);
-        vec kn(Nc);
+        k_iters += mode == 1 ? solve_vec3(x3, b3, cs.eps_tol, cs.eps_rel_tol, cs.eps_max_iter) : solve_vec3(x3, b3, cs.k_tol, cs.k_rel_tol, cs.k_max_iter);
+        vec xn(Nc);
         for (int k = 0; k < nz; ++k) for (int j = 0; j < ny; ++j) for (int i = 0; i < nx; ++i) {
             const int c = cid(i, j, k);
-            const double kc = x3[3 * (size_t)c];
-            double kb = kc;
-            if (!(kc > 0.0)) {
-                const double mP = std::max(kc, kMin);
+            const double xc = x3[3 * (size_t)c];
+            double xb = xc;
+            if (!(xc > 0.0)) {
+                const double mP = std::max(xc, xMin);
                 double av = 0.0;
                 for (int d = 0; d < 3; ++d) for (int sd = 0; sd < 2; ++sd) {
-                    if (onb(d, sd, i, j, k)) { const int patch = 2 * d + sd; av += std::max(cs.k_bc[patch] == 1 ? cs.k_value[patch] : kc, kMin); }
-                    else { const int nbc = c + (sd ? stride[d] : -stride[d]); av += 0.5 * (mP + std::max(x3[3 * (size_t)nbc], kMin)); }
+                    if (onb(d, sd, i, j, k)) { const int patch = 2 * d + sd; av += std::max(bc[patch] == 1 ? bval[patch] : xc, xMin); }
+                    else { const int nbc = c + (sd ? stride[d] : -stride[d]); av += 0.5 * (mP + std::max(x3[3 * (size_t)nbc], xMin)); }
                 }
-                kb = std::max(kc, av / 6.0);
+                xb = std::max(xc, av / 6.0);
             }
-            kn[c] = std::max(kb, kMin);
+            xn[c] = std::max(xb, xMin);
         }
-        kturb = kn;
-        for (int c = 0; c < Nc; ++c) nut[c] = Ck * std::sqrt(kturb[c]) * delta;
+        Xf = xn;
+        if (mode == 0) for (int c = 0; c < Nc; ++c) nut[c] = cs.les_ck * std::sqrt(kturb[c]) * delta;
+        else if (mode == 2) for (int c = 0; c < Nc; ++c) nut[c] = cs.ras_cmu * (kturb[c] * kturb[c]) / epsturb[c];
     }
     // continuousPhaseTurbulence->correct() for LESModel Smagorinsky [OF-6 LES/Smagorinsky/Smagorinsky.C: correct() -> correctNut();
     // k(gradU): D = symm(gradU), a = Ce/delta, b = (2/3) tr(D), c = 2 Ck delta (dev(D) && D), k = sqr((-b + sqrt(sqr(b) + 4 a c))/(2 a));
     // nut = Ck delta sqrt(k)]; delta = deltaCoeff * cbrt(V) [OF-6 LES/LESdeltas/cubeRootVolDelta]; gradU = fvc::grad(U) (Gauss linear)
     void turbulence_correct() {
         grad_U(U, vGrad);
-        if (cs.turbulence_model == 2) { keqn_correct(); return; }
+        if (cs.turbulence_model == 2) { turb_eqn(0); return; }
+        if (cs.turbulence_model == 3) { turb_eqn(1); turb_eqn(2); return; }      // kEpsilon::correct(): epsilon first, then k with the new epsilon
         const double delta = cs.les_delta_coeff * std::pow(V, 1.0 / 3.0), Ck = cs.les_ck, Ce = cs.les_ce;
         for (int c = 0; c < Nc; ++c) {
             const double* T = &vGrad[9 * (size_t)c];
@@ -949,6 +967,7 @@ static vec* fv_field(Fv* f, const char* name) {
         {"vGrad", &f->vGrad},
         {"nut", &f->nut},
         {"k", &f->kturb},
+        {"epsilon", &f->epsturb},
         {"ddtU", &f->ddtU},
         {"phi_x", &f->phi[0]},
         {"phi_y", &f->phi[1]},

@@ -208,7 +208,11 @@ class FvCase(C.Structure):
                 ("turbulence_model", C.c_int), ("les_ck", C.c_double), ("les_ce", C.c_double), ("les_delta_coeff", C.c_double),
                 ("nut_bc", C.c_int * 6), ("nut_value", C.c_double * 6), ("nut_initial", C.c_double),
                 ("k_bc", C.c_int * 6), ("k_value", C.c_double * 6), ("k_initial", C.c_double), ("k_convection_scheme", C.c_int),
-                ("k_tol", C.c_double), ("k_rel_tol", C.c_double), ("k_max_iter", C.c_int), ("k_relax", C.c_double)]
+                ("k_tol", C.c_double), ("k_rel_tol", C.c_double), ("k_max_iter", C.c_int), ("k_relax", C.c_double),
+                ("ras_cmu", C.c_double), ("ras_c1", C.c_double), ("ras_c2", C.c_double), ("ras_c3", C.c_double), ("ras_sigmak", C.c_double),
+                ("ras_sigmaeps", C.c_double), ("eps_bc", C.c_int * 6), ("eps_value", C.c_double * 6), ("eps_initial", C.c_double),
+                ("eps_convection_scheme", C.c_int), ("eps_tol", C.c_double), ("eps_rel_tol", C.c_double), ("eps_max_iter", C.c_int),
+                ("eps_relax", C.c_double)]
 
 
 class FvStats(C.Structure):
@@ -228,7 +232,9 @@ def fv_case(solver, nx, ny, nz, dx, dt, nu, rho_f=1000.0, rho_p=2650.0, g=(0, 0,
             p_final_tol=1e-6, p_final_rel_tol=0.0, u_tol=1e-5, u_rel_tol=0.0, p_max_iter=1000, u_max_iter=1000, convection_scheme=0, p_ref_cell=0,
             p_ref_value=0.0, n_non_orth=0, adjust_time_step=0, max_co=1.0, max_delta_t=1e300, u_relax=1.0, u_relax_final=0.0, p_relax=0.0,
             p_relax_final=0.0, turbulence_model=0, les_ck=0.094, les_ce=1.048, les_delta_coeff=1.0, nut_bc=None, nut_value=None, nut_initial=0.0,
-            k_bc=None, k_value=None, k_initial=0.0, k_convection_scheme=1, k_tol=1e-6, k_rel_tol=0.0, k_max_iter=1000, k_relax=0.0):
+            k_bc=None, k_value=None, k_initial=0.0, k_convection_scheme=1, k_tol=1e-6, k_rel_tol=0.0, k_max_iter=1000, k_relax=0.0,
+            ras_cmu=0.09, ras_c1=1.44, ras_c2=1.92, ras_c3=0.0, ras_sigmak=1.0, ras_sigmaeps=1.3, eps_bc=None, eps_value=None, eps_initial=0.0,
+            eps_convection_scheme=1, eps_tol=1e-6, eps_rel_tol=0.0, eps_max_iter=1000, eps_relax=0.0):
     """documented defaults = the icoFoam cavity / DPMFoam tutorial settings of SURVEY.md Appendix C"""
     c = FvCase()
     c.solver, c.nx, c.ny, c.nz, c.dx, c.dt, c.nu = solver, nx, ny, nz, dx, dt, nu
@@ -260,6 +266,11 @@ def fv_case(solver, nx, ny, nz, dx, dt, nu, rho_f=1000.0, rho_p=2650.0, g=(0, 0,
         c.k_bc[q] = (k_bc or [0] * 6)[q]
         c.k_value[q] = (k_value or [0.0] * 6)[q]
     c.k_initial, c.k_convection_scheme, c.k_tol, c.k_rel_tol, c.k_max_iter, c.k_relax = k_initial, int(k_convection_scheme), k_tol, k_rel_tol, int(k_max_iter), k_relax
+    c.ras_cmu, c.ras_c1, c.ras_c2, c.ras_c3, c.ras_sigmak, c.ras_sigmaeps = ras_cmu, ras_c1, ras_c2, ras_c3, ras_sigmak, ras_sigmaeps
+    for q in range(6):
+        c.eps_bc[q] = (eps_bc or [0] * 6)[q]
+        c.eps_value[q] = (eps_value or [0.0] * 6)[q]
+    c.eps_initial, c.eps_convection_scheme, c.eps_tol, c.eps_rel_tol, c.eps_max_iter, c.eps_relax = eps_initial, int(eps_convection_scheme), eps_tol, eps_rel_tol, int(eps_max_iter), eps_relax
     return c
 
 

@@ -314,7 +314,7 @@ def test_les_smagorinsky_case_is_read(prod, tmp_path):
     assert list(c.nut_bc) == [0, 0, 0, 0, 1, 0] and c.nut_value[ZMIN] == 1e-6
     fc.close()
     for old, new, needle in (("LESModel        Smagorinsky;", "LESModel        dynamicKEqn;", "dynamicKEqn"),
-                             ("simulationType  LES;", "simulationType  RAS;", "RAS"),
+                             ("simulationType  LES;", "simulationType  DES;", "DES"),
                              ("delta           cubeRootVol;", "delta           vanDriest;", "cubeRootVol"),
                              ("turbulence      on;", "turbulence      off;", "turbulence off")):
         (dst / "constant/turbulenceProperties.water").write_text(LES_PROPS.replace(old, new))
@@ -385,3 +385,29 @@ def test_les_keqn_case_is_read(prod, tmp_path):
     assert c.k_convection_scheme == 1 and (c.k_tol, c.k_rel_tol, c.k_max_iter) == (1e-7, 0.01, 50)
     assert c.convection_scheme == 0                                        # the momentum convection stays Gauss linear
     fc.close()
+
+
+def test_ras_kepsilon_case_is_read(prod, tmp_path):
+    """simulationType RAS, RASModel kEpsilon (DPMTurbulenceModels.C:70-71): coefficients, k / epsilon / nut files, schemes, solver entries;
+    wall functions are refused by name"""
+    dst = les_case(tmp_path)
+    (dst / "constant/turbulenceProperties.water").write_text(
+        "simulationType RAS;\nRAS { RASModel kEpsilon; turbulence on; kEpsilonCoeffs { Cmu 0.085; C1 1.4; C2 1.9; C3 -0.33; sigmak 1.1; sigmaEps 1.25; } }\n")
+    kfile = NUT_FILE.replace("object nut.water", "object k.water").replace("[0 2 -1 0 0 0 0]", "[0 2 -2 0 0 0 0]").replace("uniform 2e-6", "uniform 3e-4")
+    (dst / "0/k.water").write_text(kfile)
+    efile = NUT_FILE.replace("object nut.water", "object epsilon.water").replace("[0 2 -1 0 0 0 0]", "[0 2 -3 0 0 0 0]").replace("uniform 2e-6", "uniform 5e-3").replace("uniform 1e-6", "uniform 4e-3")
+    (dst / "0/epsilon.water").write_text(efile)
+    sch = (dst / "system/fvSchemes").read_text().replace("div(alphaPhic,Uc) Gauss linear;", "div(alphaPhic,Uc) Gauss linear;\n    div(alphaPhi.water,k.water) Gauss upwind;\n    div(alphaPhi.water,epsilon.water) Gauss linear;")
+    (dst / "system/fvSchemes").write_text(sch)
+    fc = prod.FoamCase(dst, prod.FY_SOLVER_PIMPLE)
+    c = fc.case
+    assert c.turbulence_model == prod.TURBULENCE_KEPSILON
+    assert (c.ras_cmu, c.ras_c1, c.ras_c2, c.ras_c3, c.ras_sigmak, c.ras_sigmaeps) == (0.085, 1.4, 1.9, -0.33, 1.1, 1.25)
+    assert c.k_initial == 3e-4 and c.eps_initial == 5e-3 and np.all(fc.initial_epsilon() == 5e-3) and c.eps_value[ZMIN] == 4e-3 and list(c.eps_bc) == [0, 0, 0, 0, 1, 0]
+    assert c.k_convection_scheme == 1 and c.eps_convection_scheme == 0
+    assert (c.eps_tol, c.eps_rel_tol) == (1e-5, 0.1)                       # the "(U.water|k|epsilon)" entry
+    fc.close()
+    (dst / "0/epsilon.water").write_text(efile.replace("walls  { type zeroGradient; }", "walls  { type epsilonWallFunction; value uniform 5e-3; }"))
+    with pytest.raises(prod.FoamYadeError) as e:
+        prod.FoamCase(dst, prod.FY_SOLVER_PIMPLE)
+    assert "epsilonWallFunction" in str(e.value) and "epsilon.water" in str(e.value)

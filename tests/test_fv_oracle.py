@@ -502,3 +502,29 @@ def test_keqn_cavity_runs_and_stays_bounded(oracle):
     k = o.get("k")
     assert k.min() >= 1e-15 and np.isfinite(k).all() and k.max() > 1e-4
     np.testing.assert_allclose(o.get("nut"), 0.094 * np.sqrt(k) * (1.0 / n), rtol=1e-13)
+
+
+def test_kepsilon_decay_of_homogeneous_turbulence(oracle):
+    """RAS kEpsilon (DPMTurbulenceModels.C:70-71) with the fluid at rest: G = 0, uniform fields => per step
+    eps_new = eps / (1 + dt C2 eps/k), then k_new = k / (1 + dt eps_new/k) (kEpsilon::correct solves epsilon first and the k equation sees
+    the new value), nut = Cmu k^2/eps -- the implicit-Euler form of dk/dt = -eps, deps/dt = -C2 eps^2/k, whose solution decays as
+    k ~ t^(-1/(C2 - 1))"""
+    n, dx, dt, k0, e0 = 6, 0.02, 2e-3, 0.05, 0.4
+    c = oracle.fv_case(1, n, n, n, dx, dt, 1e-5, u_bc=[0] * 6, turbulence_model=3, k_initial=k0, eps_initial=e0, nut_initial=1e-4, k_tol=1e-14, eps_tol=1e-14)
+    o = oracle.FvSolver(c)
+    k, e = k0, e0
+    hist = []
+    for step in range(2000):
+        o.turbulence_correct()
+        e = e / (1.0 + dt * 1.92 * e / k)
+        k = k / (1.0 + dt * e / k)
+        if step < 50 or step % 100 == 0:
+            np.testing.assert_allclose(o.get("epsilon"), e, rtol=1e-11)
+            np.testing.assert_allclose(o.get("k"), k, rtol=1e-11)
+            np.testing.assert_allclose(o.get("nut"), 0.09 * k * k / e, rtol=1e-11)
+        hist.append(k)
+    # late-time decay exponent d ln k / d ln t -> -1/(C2 - 1) = -1.087 (virtual origin t0 = k0 / ((C2 - 1) e0))
+    t0 = k0 / (0.92 * e0)
+    t = dt * (np.arange(2000) + 1) + t0
+    slope = np.polyfit(np.log(t[1000:]), np.log(np.array(hist)[1000:]), 1)[0]
+    assert abs(slope + 1.0 / 0.92) < 0.02

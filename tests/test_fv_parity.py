@@ -357,3 +357,29 @@ def test_keqn_matches_oracle(product, oracle, k_scheme):
             np.testing.assert_allclose(a, b, rtol=2e-5, atol=1e-9 * b.max(), err_msg=nm)
     assert not np.allclose(o.get("k"), 5e-4)
     compare(o, s, rtol=1e-5)
+
+
+def test_kepsilon_matches_oracle(product, oracle):
+    """pimpleFoamYade with RASModel kEpsilon (DPMTurbulenceModels.C:70-71), boundary types zeroGradient / fixedValue (no wall functions):
+    epsilon equation, then k with the new epsilon, nut = Cmu k^2/eps; coupled"""
+    n = 16
+    dx = 0.1 / n
+    u_val = [(0, 0, 0)] * 6
+    u_val[YMAX] = (0.5, 0, 0)
+    kw = dict(turbulence_model=3, nut_bc=[0, 0, 1, 0, 0, 1], nut_value=[0, 0, 0.0, 0, 0, 1e-5], nut_initial=2e-5,
+              k_bc=[0, 1, 1, 1, 0, 1], k_value=[0, 1e-4, 2e-4, 2e-4, 0, 1e-4], k_initial=5e-4, k_convection_scheme=1, k_tol=1e-9, k_relax=0.9,
+              eps_bc=[0, 1, 0, 1, 0, 0], eps_value=[0, 2e-3, 0, 3e-3, 0, 0], eps_initial=2e-3, eps_convection_scheme=0, eps_tol=1e-9, eps_relax=0.8,
+              ras_c3=-0.33)
+    o, s = both(product, oracle, 1, n, n, n, dx, 2e-4, 1e-5, g=(0, 0, -9.81), u_bc=[0] * 6, u_val=u_val, p_bc=[2] * 6, **kw)
+    np.testing.assert_array_equal(s.get("epsilon"), 2e-3)
+    case = gc.Case("cpl", n, n, n, 0.1, gaussian=1, np_=2000, seed=5, cluster=100, fast=10, outside=10, vel_scale=0.05)
+    for step in range(4):
+        rec = gc.particle_records(case, step)
+        o.step(rec)
+        s.set_particles(rec)
+        s.step()
+        for nm in ("epsilon", "k", "nut"):
+            a, b = s.get(nm), o.get(nm)
+            np.testing.assert_allclose(a, b, rtol=2e-5, atol=1e-9 * b.max(), err_msg=nm)
+    assert not np.allclose(o.get("k"), 5e-4) and not np.allclose(o.get("epsilon"), 2e-3)
+    compare(o, s, rtol=1e-5)

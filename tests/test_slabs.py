@@ -61,10 +61,10 @@ def test_first_step_operators_are_identical(product):
     many.close(); one.close()
 
 
-@pytest.mark.parametrize("solver,n_slabs,models", [(1, 2, 0), (1, 3, 0), (0, 2, 0), (1, 2, 3), (1, 2, -1), (1, 2, -2)])
+@pytest.mark.parametrize("solver,n_slabs,models", [(1, 2, 0), (1, 3, 0), (0, 2, 0), (1, 2, 3), (1, 2, -1), (1, 2, -2), (1, 2, -3)])
 def test_coupled_slabs_match_single_domain(product, solver, n_slabs, models):
     """particles near slab interfaces: deposits/gathers reach up to 5 planes into the neighbours
-    (models = 3: with the opt-in added-mass / Gaussian-torque models, whose vGrad / ddtU gathers need the same halos;
+    (models = 3: with the opt-in added-mass / Gaussian-torque models, whose vGrad / ddtU gathers need the same halos; -2 / -3: LES kEqn / RAS kEpsilon;
     models = -1: LES Smagorinsky, whose eddy viscosity is interpolated across the slab faces -- a moving lid on y+ makes it matter)"""
     n = 12
     nz = 12 * n_slabs
@@ -75,8 +75,10 @@ def test_coupled_slabs_match_single_domain(product, solver, n_slabs, models):
         u_val[3] = (1.0, 0, 0)
     if models < 0:                                   # -1 LES Smagorinsky, -2 LES kEqn (its k equation is solved across the slab faces)
         kw.update(turbulence_model=-models, les_ck=0.3, nut_initial=1e-5, nut_bc=[0, 0, 1, 0, 0, 1], nut_value=[0, 0, 0.0, 0, 0, 2e-5])
-        if models == -2:
-            kw.update(k_initial=4e-4, k_bc=[0, 0, 1, 0, 1, 0], k_value=[0, 0, 0.0, 0, 1e-4, 0], k_convection_scheme=0, k_tol=1e-10)
+        if models <= -2:                             # (-3: RAS kEpsilon, two equations)
+            kw.update(k_initial=4e-4, k_bc=[0, 0, 1, 0, 1, 0], k_value=[0, 0, 1e-4, 0, 1e-4, 0], k_convection_scheme=0, k_tol=1e-10)
+        if models == -3:
+            kw.update(eps_initial=3e-3, eps_bc=[0, 0, 0, 1, 0, 1], eps_value=[0, 0, 0, 2e-3, 0, 4e-3], eps_tol=1e-10)
         u_val[3] = (0.5, 0, 0)
         models = 0
     case = product.make_case(solver, n, n, nz, dx, 2e-4, 1e-5 if solver else 0.01, u_bc=[0] * 6, u_val=u_val, **kw)
@@ -100,7 +102,7 @@ def test_coupled_slabs_match_single_domain(product, solver, n_slabs, models):
     compare(many, one, ("U", "p", "alpha", "uSource") if solver else ("U", "p"), 1e-5)
     if case.turbulence_model:
         assert one.get("nut").max() > 1e-6
-        compare(many, one, ("nut", "k") if case.turbulence_model == 2 else ("nut",), 2e-5)
+        compare(many, one, {1: ("nut",), 2: ("nut", "k"), 3: ("nut", "k", "epsilon")}[case.turbulence_model], 2e-5)
     many.close(); one.close()
 
 

@@ -96,10 +96,14 @@ class CaseDesc(C.Structure):
                 ("turbulence_model", C.c_int32), ("les_ck", C.c_double), ("les_ce", C.c_double), ("les_delta_coeff", C.c_double),
                 ("nut_bc", C.c_int32 * 6), ("nut_value", C.c_double * 6), ("nut_initial", C.c_double),
                 ("k_bc", C.c_int32 * 6), ("k_value", C.c_double * 6), ("k_initial", C.c_double), ("k_convection_scheme", C.c_int32),
-                ("k_tol", C.c_double), ("k_rel_tol", C.c_double), ("k_max_iter", C.c_int32), ("k_relax", C.c_double)]
+                ("k_tol", C.c_double), ("k_rel_tol", C.c_double), ("k_max_iter", C.c_int32), ("k_relax", C.c_double),
+                ("ras_cmu", C.c_double), ("ras_c1", C.c_double), ("ras_c2", C.c_double), ("ras_c3", C.c_double), ("ras_sigmak", C.c_double),
+                ("ras_sigmaeps", C.c_double), ("eps_bc", C.c_int32 * 6), ("eps_value", C.c_double * 6), ("eps_initial", C.c_double),
+                ("eps_convection_scheme", C.c_int32), ("eps_tol", C.c_double), ("eps_rel_tol", C.c_double), ("eps_max_iter", C.c_int32),
+                ("eps_relax", C.c_double)]
 
 
-TURBULENCE_LAMINAR, TURBULENCE_SMAGORINSKY, TURBULENCE_KEQN = 0, 1, 2
+TURBULENCE_LAMINAR, TURBULENCE_SMAGORINSKY, TURBULENCE_KEQN, TURBULENCE_KEPSILON = 0, 1, 2, 3
 NUT_ZERO_GRADIENT, NUT_FIXED_VALUE = 0, 1
 
 
@@ -198,6 +202,7 @@ def lib():
     L.fy_foam_case_initial_fields.argtypes = [vp, _dp, _dp]
     L.fy_foam_case_initial_nut.argtypes = [vp, _dp]
     L.fy_foam_case_initial_k.argtypes = [vp, _dp]
+    L.fy_foam_case_initial_epsilon.argtypes = [vp, _dp]
     L.fy_foam_case_write_time.argtypes = [vp, vp, C.c_char_p]
     L.fy_foam_case_close.argtypes = [vp]
     L.fy_solver_write_field_host.argtypes = [vp, C.c_char_p, _dp]
@@ -785,6 +790,11 @@ class FoamCase:
         k = np.zeros(self.n_cells)
         _check(lib().fy_foam_case_initial_k(self._h, _d(k)))
         return k
+
+    def initial_epsilon(self):
+        e = np.zeros(self.n_cells)
+        _check(lib().fy_foam_case_initial_epsilon(self._h, _d(e)))
+        return e
 
     def write(self, solver, time_name):
         _check(lib().fy_foam_case_write_time(self._h, solver._h, str(time_name).encode()))

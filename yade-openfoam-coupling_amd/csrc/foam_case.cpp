@@ -30,8 +30,8 @@ struct fy_foam_case {
     std::string patch_of_side[6];               // blockMesh patch name covering XMIN, XMAX, YMIN, YMAX, ZMIN, ZMAX
     std::vector<std::string> patch_order;       // patch names in blockMeshDict order (one side each here)
     std::string u_bc_text[6], p_bc_text[6];     // the boundaryField entries as read, re-emitted on write
-    std::vector<double> U0, p0, nut0, k0;       // internalField of the start time (nut0, k0: turbulence cases only)
-    std::string nut_bc_text[6], k_bc_text[6];
+    std::vector<double> U0, p0, nut0, k0, eps0; // internalField of the start time (nut0, k0, eps0: turbulence cases only)
+    std::string nut_bc_text[6], k_bc_text[6], eps_bc_text[6];
 };
 
 namespace {
@@ -271,8 +271,8 @@ int read_fields(fy_foam_case* c) {
             }
         }
     }
-    if (c->desc.turbulence_model == FY_TURBULENCE_KEQN) {
-        // k.<phase> [OF-6 kEqn: k_ is MUST_READ]; patches zeroGradient | fixedValue (uniform); kqRWallFunction is a zeroGradient condition
+    if (c->desc.turbulence_model == FY_TURBULENCE_KEQN || c->desc.turbulence_model == FY_TURBULENCE_KEPSILON) {
+        // k.<phase> [OF-6 kEqn / kEpsilon: k_ is MUST_READ]; patches zeroGradient | fixedValue (uniform); kqRWallFunction is a zeroGradient condition
         const std::string path = join(c->dir, c->start_name + "/k." + c->phase);
         FoamDict f;
         FY_TRY(need_file(path, &f));
@@ -294,6 +294,34 @@ int read_fields(fy_foam_case* c) {
                     return fail(FY_ERR_UNSUPPORTED, "%s: patch '%s': fixedValue needs 'value uniform <k>'", path.c_str(), c->patch_of_side[s].c_str());
             } else {
                 return fail(FY_ERR_UNSUPPORTED, "%s: patch '%s': k boundary type '%s' is not supported (zeroGradient, kqRWallFunction, fixedValue)", path.c_str(),
+                            c->patch_of_side[s].c_str(), ty.c_str());
+            }
+        }
+    }
+    if (c->desc.turbulence_model == FY_TURBULENCE_KEPSILON) {
+        // epsilon.<phase> [OF-6 kEpsilon: epsilon_ is MUST_READ]; zeroGradient | fixedValue (uniform).  epsilonWallFunction is NOT implemented
+        // (it rewrites the matrix rows of the wall cells, epsEqn.boundaryManipulate): such a case is refused
+        const std::string path = join(c->dir, c->start_name + "/epsilon." + c->phase);
+        FoamDict f;
+        FY_TRY(need_file(path, &f));
+        FY_TRY(read_internal(f, path, 1, ncell, &c->eps0));
+        c->desc.eps_initial = c->eps0.empty() ? 0.0 : c->eps0[0];
+        const FoamDict* bf = f.subdict("boundaryField");
+        if (!bf) return fail(FY_ERR_INVALID, "%s: no boundaryField", path.c_str());
+        for (int s = 0; s < 6; ++s) {
+            const FoamDict* pd = bf->subdict(c->patch_of_side[s]);
+            std::string ty;
+            if (!pd || !pd->word("type", &ty)) return fail(FY_ERR_INVALID, "%s: boundaryField has no (typed) entry for patch '%s'", path.c_str(), c->patch_of_side[s].c_str());
+            c->eps_bc_text[s] = entry_text(*pd);
+            c->desc.eps_value[s] = 0.0;
+            if (ty == "zeroGradient") c->desc.eps_bc[s] = FY_BC_NUT_ZERO_GRADIENT;
+            else if (ty == "fixedValue") {
+                c->desc.eps_bc[s] = FY_BC_NUT_FIXED_VALUE;
+                const auto* vt = pd->tokens("value");
+                if (!vt || vt->size() < 2 || (*vt)[0] != "uniform" || !fy::foam_tok_is_number((*vt)[1], &c->desc.eps_value[s]))
+                    return fail(FY_ERR_UNSUPPORTED, "%s: patch '%s': fixedValue needs 'value uniform <epsilon>'", path.c_str(), c->patch_of_side[s].c_str());
+            } else {
+                return fail(FY_ERR_UNSUPPORTED, "%s: patch '%s': epsilon boundary type '%s' is not supported (zeroGradient, fixedValue; epsilonWallFunction is not built)", path.c_str(),
                             c->patch_of_side[s].c_str(), ty.c_str());
             }
         }
@@ -382,8 +410,20 @@ int read_controls(fy_foam_case* c) {
                 c->desc.turbulence_model = model == "kEqn" ? FY_TURBULENCE_KEQN : FY_TURBULENCE_SMAGORINSKY;
                 if (const FoamDict* sc = ld->subdict(model + "Coeffs")) { sc->scalar("Ck", &c->desc.les_ck); sc->scalar("Ce", &c->desc.les_ce); }
                 if (const FoamDict* dc = ld->subdict("cubeRootVolCoeffs")) dc->scalar("deltaCoeff", &c->desc.les_delta_coeff);
+            } else if (sim == "RAS") {
+                const FoamDict* rd = d.subdict("RAS");
+                std::string model;
+                if (!rd || !rd->word("RASModel", &model)) return fail(FY_ERR_INVALID, "%s: RAS { RASModel ...; } missing", path.c_str());
+                if (model != "kEpsilon") return fail(FY_ERR_UNSUPPORTED, "%s: RASModel %s is not implemented (DPMTurbulenceModels.C:70-71 instantiates kEpsilon only)", path.c_str(), model.c_str());
+                bool on = true;
+                if (rd->boolean("turbulence", &on) && !on) return fail(FY_ERR_UNSUPPORTED, "%s: 'turbulence off' (frozen nut) is not supported: use simulationType laminar", path.c_str());
+                c->desc.turbulence_model = FY_TURBULENCE_KEPSILON;
+                if (const FoamDict* kc = rd->subdict("kEpsilonCoeffs")) {
+                    kc->scalar("Cmu", &c->desc.ras_cmu); kc->scalar("C1", &c->desc.ras_c1); kc->scalar("C2", &c->desc.ras_c2); kc->scalar("C3", &c->desc.ras_c3);
+                    kc->scalar("sigmak", &c->desc.ras_sigmak); kc->scalar("sigmaEps", &c->desc.ras_sigmaeps);
+                }
             } else {
-                return fail(FY_ERR_UNSUPPORTED, "%s: simulationType %s is not implemented (laminar and LES Smagorinsky / kEqn are; RAS kEpsilon of DPMTurbulenceModels.C:70-71 is not)", path.c_str(), sim.c_str());
+                return fail(FY_ERR_UNSUPPORTED, "%s: simulationType %s is not one of laminar, RAS, LES", path.c_str(), sim.c_str());
             }
         }
     }
@@ -422,7 +462,12 @@ int read_controls(fy_foam_case* c) {
                     const bool convection = k == "default" || k == "div(phi,U)" || k == "div(alphaPhic,Uc)" || k == "div(phic,Uc)" ||
                                             k == "div(alphaPhi." + c->phase + ",U." + c->phase + ")";
                     const bool k_convection = k == "div(alphaPhic,k)" || k == "div(alphaPhi." + c->phase + ",k." + c->phase + ")";
-                    if (k_convection) {                                  // fvm::div(alphaRhoPhi, k) of the kEqn model
+                    if (k == "div(alphaPhic,epsilon)" || k == "div(alphaPhi." + c->phase + ",epsilon." + c->phase + ")") {     // fvm::div(alphaRhoPhi, epsilon)
+                        if (sch == FY_CONVECTION_LINEAR_UPWIND) return fail(FY_ERR_UNSUPPORTED, "%s: divSchemes.%s = '%s': Gauss linear or Gauss upwind for epsilon", path.c_str(), k.c_str(), joined.c_str());
+                        c->desc.eps_convection_scheme = sch;
+                        continue;
+                    }
+                    if (k_convection) {                                  // fvm::div(alphaRhoPhi, k) of the kEqn / kEpsilon models
                         if (sch == FY_CONVECTION_LINEAR_UPWIND) return fail(FY_ERR_UNSUPPORTED, "%s: divSchemes.%s = '%s': Gauss linear or Gauss upwind for k", path.c_str(), k.c_str(), joined.c_str());
                         c->desc.k_convection_scheme = sch;
                         continue;
@@ -431,7 +476,7 @@ int read_controls(fy_foam_case* c) {
                         if (sch != FY_CONVECTION_LINEAR) return fail(FY_ERR_UNSUPPORTED, "%s: divSchemes.%s = '%s': only the convection terms may be upwinded, this one must be Gauss linear", path.c_str(), k.c_str(), joined.c_str());
                         continue;
                     }
-                    if (k == "default") { if (!n_div) c->desc.convection_scheme = sch; c->desc.k_convection_scheme = sch == FY_CONVECTION_LINEAR ? sch : FY_CONVECTION_UPWIND; continue; }      // a named convection entry overrides it
+                    if (k == "default") { if (!n_div) c->desc.convection_scheme = sch; c->desc.k_convection_scheme = c->desc.eps_convection_scheme = sch == FY_CONVECTION_LINEAR ? sch : FY_CONVECTION_UPWIND; continue; }      // a named convection entry overrides it
                     if (n_div++ && sch != c->desc.convection_scheme) return fail(FY_ERR_UNSUPPORTED, "%s: divSchemes mixes different convection schemes", path.c_str());
                     c->desc.convection_scheme = sch;
                 }
@@ -467,7 +512,17 @@ int read_controls(fy_foam_case* c) {
             for (const std::string& k : sv->order)
                 if (k.find(c->u_name) != std::string::npos || (k.find("U") != std::string::npos && k.find("Final") == std::string::npos)) { us = sv->subdict(k); if (us) break; }
         if (us) { us->scalar("tolerance", &c->desc.u_tol); us->scalar("relTol", &c->desc.u_rel_tol); us->integer("maxIter", &c->desc.u_max_iter); }
-        if (c->desc.turbulence_model == FY_TURBULENCE_KEQN) {          // solvers.k.<phase> (or a pattern naming k, e.g. "(U.water|k.water)")
+        if (c->desc.turbulence_model == FY_TURBULENCE_KEPSILON) {      // solvers.epsilon.<phase> (or a pattern naming epsilon)
+            c->desc.eps_tol = c->desc.u_tol; c->desc.eps_rel_tol = c->desc.u_rel_tol; c->desc.eps_max_iter = c->desc.u_max_iter;
+            const std::string en = "epsilon." + c->phase;
+            const FoamDict* es = sv->subdict(en);
+            if (!es)
+                for (const std::string& key : sv->order)
+                    if (key.find("epsilon") != std::string::npos) { es = sv->subdict(key); if (es) break; }
+            if (!es) return fail(FY_ERR_INVALID, "%s: solvers has no entry for %s (kEpsilon solves a transport equation for it)", path.c_str(), en.c_str());
+            es->scalar("tolerance", &c->desc.eps_tol); es->scalar("relTol", &c->desc.eps_rel_tol); es->integer("maxIter", &c->desc.eps_max_iter);
+        }
+        if (c->desc.turbulence_model == FY_TURBULENCE_KEQN || c->desc.turbulence_model == FY_TURBULENCE_KEPSILON) {          // solvers.k.<phase> (or a pattern naming k, e.g. "(U.water|k.water)")
             c->desc.k_tol = c->desc.u_tol; c->desc.k_rel_tol = c->desc.u_rel_tol; c->desc.k_max_iter = c->desc.u_max_iter;
             const std::string kn = "k." + c->phase;
             const FoamDict* ks = sv->subdict(kn);
@@ -495,7 +550,8 @@ int read_controls(fy_foam_case* c) {
                 };
                 lookup(rf->subdict("equations"), c->u_name, &c->desc.u_relax);
                 lookup(rf->subdict("equations"), c->u_name + "Final", &c->desc.u_relax_final);
-                if (c->desc.turbulence_model == FY_TURBULENCE_KEQN) lookup(rf->subdict("equations"), "k." + c->phase, &c->desc.k_relax);
+                if (c->desc.turbulence_model == FY_TURBULENCE_KEQN || c->desc.turbulence_model == FY_TURBULENCE_KEPSILON) lookup(rf->subdict("equations"), "k." + c->phase, &c->desc.k_relax);
+                if (c->desc.turbulence_model == FY_TURBULENCE_KEPSILON) lookup(rf->subdict("equations"), "epsilon." + c->phase, &c->desc.eps_relax);
                 lookup(rf->subdict("fields"), "p", &c->desc.p_relax);
                 lookup(rf->subdict("fields"), "pFinal", &c->desc.p_relax_final);
                 for (double v : {c->desc.u_relax, c->desc.u_relax_final, c->desc.p_relax, c->desc.p_relax_final})
@@ -590,6 +646,13 @@ int fy_foam_case_initial_k(const fy_foam_case* c, double* k) {
     return FY_OK;
 }
 
+int fy_foam_case_initial_epsilon(const fy_foam_case* c, double* eps) {
+    if (!c || !eps) return fail(FY_ERR_INVALID, "fy_foam_case_initial_epsilon: null argument");
+    if (c->eps0.empty()) return fail(FY_ERR_INVALID, "fy_foam_case_initial_epsilon: the case has no epsilon equation");
+    std::memcpy(eps, c->eps0.data(), c->eps0.size() * sizeof(double));
+    return FY_OK;
+}
+
 int fy_foam_case_write_time(const fy_foam_case* c, fy_solver* s, const char* time_name) {
     if (!c || !s || !time_name || !*time_name) return fail(FY_ERR_INVALID, "fy_foam_case_write_time: null argument");
     const std::string tdir = join(c->dir, time_name);
@@ -618,7 +681,12 @@ int fy_foam_case_write_time(const fy_foam_case* c, fy_solver* s, const char* tim
         FY_TRY(fy_solver_read_field_host(s, "nut", nt.data()));
         FY_TRY(write_field(c, tdir, time_name, "nut." + c->phase, "volScalarField", "[0 2 -1 0 0 0 0]", 1, nt, c->nut_bc_text, "        type            zeroGradient;\n"));
     }
-    if (c->desc.turbulence_model == FY_TURBULENCE_KEQN) {
+    if (c->desc.turbulence_model == FY_TURBULENCE_KEPSILON) {
+        std::vector<double> ee(n);
+        FY_TRY(fy_solver_read_field_host(s, "epsilon", ee.data()));
+        FY_TRY(write_field(c, tdir, time_name, "epsilon." + c->phase, "volScalarField", "[0 2 -3 0 0 0 0]", 1, ee, c->eps_bc_text, "        type            zeroGradient;\n"));
+    }
+    if (c->desc.turbulence_model == FY_TURBULENCE_KEQN || c->desc.turbulence_model == FY_TURBULENCE_KEPSILON) {
         std::vector<double> kk(n);
         FY_TRY(fy_solver_read_field_host(s, "k", kk.data()));
         FY_TRY(write_field(c, tdir, time_name, "k." + c->phase, "volScalarField", "[0 2 -2 0 0 0 0]", 1, kk, c->k_bc_text, "        type            zeroGradient;\n"));

@@ -73,8 +73,10 @@ int main(int argc, char** argv) {
         if (cd.turbulence_model != FY_TURBULENCE_LAMINAR) {              // nut.<phase> of the start time (eddyViscosity: MUST_READ)
             std::vector<double> nut((size_t)info.n_cells);
             if (fy_foam_case_initial_nut(fc, nut.data()) != FY_OK || fy_solver_write_field_host(s, "nut", nut.data()) != FY_OK) return die("initial nut");
-            if (cd.turbulence_model == FY_TURBULENCE_KEQN &&
+            if ((cd.turbulence_model == FY_TURBULENCE_KEQN || cd.turbulence_model == FY_TURBULENCE_KEPSILON) &&
                 (fy_foam_case_initial_k(fc, nut.data()) != FY_OK || fy_solver_write_field_host(s, "k", nut.data()) != FY_OK)) return die("initial k");
+            if (cd.turbulence_model == FY_TURBULENCE_KEPSILON &&
+                (fy_foam_case_initial_epsilon(fc, nut.data()) != FY_OK || fy_solver_write_field_host(s, "epsilon", nut.data()) != FY_OK)) return die("initial epsilon");
         }
     }
     fy_solver_hold_sources(s, 1);                       // runTime.write() comes before setSourceZero (icoFoamYade.C:142-147)

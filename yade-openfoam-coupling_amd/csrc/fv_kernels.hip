@@ -528,22 +528,25 @@ __global__ __launch_bounds__(256) void k_smagorinsky_nut(FvGeo g, const double* 
     nut[c] = ck * delta * sqrt(kk);
 }
 
-// LESModel kEqn (DPMTurbulenceModels.C:76-77) [OF-6 LES/kEqn/kEqn.C correct()]:
-//   fvm::ddt(alpha, rho, k) + fvm::div(alphaRhoPhi, k) - fvm::laplacian(alpha rho DkEff, k)
-//     == alpha rho G - fvm::SuSp((2/3) alpha rho divU, k) - fvm::Sp(Ce alpha rho sqrt(k)/delta, k)
-// with G = nut (gradU && dev(twoSymm(gradU))), divU = fvc::div(phi) (the phase's volumetric flux), DkEff = nut + nu; then relax(), solve,
-// bound(k, kMin), nut = Ck sqrt(k) delta.  alpha.oldTime() == alpha (quirk F-Q1, as in UcEqn).  Face diffusivity: linear interpolate of the
-// cell field alpha (nu + nut), boundary alpha_b (nu + nut_b), as in the momentum equation.
-__global__ __launch_bounds__(256) void k_assemble_k(FvGeo g, KEqnParams kp, const double* __restrict__ kf, const double* __restrict__ alpha, CFace3 alphaf,
-                                                    CFace3 phi, const double* __restrict__ vGrad, Mom7 M, double* __restrict__ b3, double* __restrict__ x3) {
+// Transport equations of LESModel kEqn (DPMTurbulenceModels.C:76-77) [OF-6 LES/kEqn/kEqn.C correct()] and RASModel kEpsilon
+// (DPMTurbulenceModels.C:70-71) [OF-6 RAS/kEpsilon/kEpsilon.C correct()], see TurbEqn in fv_kernels.hpp:
+//   fvm::ddt(alpha, rho, X) + fvm::div(alphaRhoPhi, X) - fvm::laplacian(alpha rho DXEff, X) == Su - fvm::SuSp(c1, X) - fvm::Sp(c2, X)
+// then relax(), solve, bound(X, XMin), correctNut().  alpha.oldTime() == alpha (quirk F-Q1, as in UcEqn).  Face diffusivity: linear
+// interpolate of the cell field alpha (nu + nut / sigma), boundary alpha_b (nu + nut_b / sigma), as in the momentum equation.
+// [OF-6 fvm::SuSp: diag += V max(susp, 0), source -= V min(susp, 0) psi; fvm::Sp: diag += V sp; fvMatrix == volField: source += V field]
+__global__ __launch_bounds__(256) void k_assemble_turb(FvGeo g, TurbEqn e, const double* __restrict__ kf, const double* __restrict__ ef,
+                                                       const double* __restrict__ alpha, CFace3 alphaf, CFace3 phi, const double* __restrict__ vGrad,
+                                                       Mom7 M, double* __restrict__ b3, double* __restrict__ x3) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= g.Nc) return;
     int i, j, k; ijk_of(g, t, i, j, k);
     const int c = t + g.c0;
     const double nu = g.nu, dt = g.dt, V = g.V;
-    const double aP = alpha[c], kc = kf[c], nutc = g.nut[c];
-    double dg = aP * V / dt;                                    // fvm::ddt(alpha, k)
-    double src = aP * V * kc / dt;
+    const double aP = alpha[c], nutc = g.nut[c];
+    const double* X = e.mode == 1 ? ef : kf;
+    const double xc = X[c];
+    double dg = aP * V / dt;                                    // fvm::ddt(alpha, X)
+    double src = aP * V * xc / dt;
     double sumPhi = 0.0, an[6];
 #pragma unroll
     for (int d = 0; d < 3; ++d)
@@ -558,18 +561,18 @@ __global__ __launch_bounds__(256) void k_assemble_k(FvGeo g, KEqnParams kp, cons
                 an[2 * d + s] = 0.0;
                 const int patch = 2 * d + s;
                 const double nb = g.nut_bc[patch] == 1 ? g.nut_val[patch] : nutc;
-                const double gam = (af * (nu + nb)) * g.dx;
-                if (kp.k_bc[patch] == 1) {
+                const double gam = (af * (nu + nb / e.sigma)) * g.dx;
+                if (e.bc[patch] == 1) {
                     const double gb = 2.0 * gam;
                     dg += gb;
-                    src += (-phio + gb) * kp.k_val[patch];
+                    src += (-phio + gb) * e.val[patch];
                 } else {
                     dg += phio;
                 }
             } else {
                 const int nbc = c + (s ? stride_of(g, d) : -stride_of(g, d));
-                const double gam = (0.5 * ((aP * (nu + nutc)) + (alpha[nbc] * (nu + g.nut[nbc])))) * g.dx;
-                const double cP = kp.upwind ? fmax(phio, 0.0) : 0.5 * phio, cN = kp.upwind ? fmin(phio, 0.0) : 0.5 * phio;
+                const double gam = (0.5 * ((aP * (nu + nutc / e.sigma)) + (alpha[nbc] * (nu + g.nut[nbc] / e.sigma)))) * g.dx;
+                const double cP = e.upwind ? fmax(phio, 0.0) : 0.5 * phio, cN = e.upwind ? fmin(phio, 0.0) : 0.5 * phio;
                 dg += cP + gam;
                 an[2 * d + s] = cN - gam;
             }
@@ -586,33 +589,37 @@ __global__ __launch_bounds__(256) void k_assemble_k(FvGeo g, KEqnParams kp, cons
         for (int b = 0; b < 3; ++b) GG += T[3 * a + b] * ((T[3 * a + b] + T[3 * b + a]) - (a == b ? (1.0 / 3.0) * tr2 : 0.0));
     const double G = nutc * GG;
     const double divU = sumPhi * g.rV;
-    const double c1 = (2.0 / 3.0) * aP * divU, c2 = kp.ce * aP * sqrt(kc) / kp.delta;
+    double Su, c1, c2;
+    if (e.mode == 0) { Su = aP * G; c1 = (2.0 / 3.0) * aP * divU; c2 = e.ce * aP * sqrt(xc) / e.delta; }
+    else if (e.mode == 1) { const double kc = kf[c]; Su = e.c1 * aP * G * xc / kc; c1 = ((2.0 / 3.0) * e.c1 - e.c3) * aP * divU; c2 = e.c2 * aP * xc / kc; }
+    else { Su = aP * G; c1 = (2.0 / 3.0) * aP * divU; c2 = aP * ef[c] / xc; }
     dg += V * (fmax(c1, 0.0) + c2);                             // fvm::SuSp (implicit where it stabilises) + fvm::Sp
-    src += V * (aP * G) - V * fmin(c1, 0.0) * kc;
-    if (kp.relax > 0) {                                         // kEqn.relax(): fvMatrix::relax as in UcEqn
+    src += V * Su - V * fmin(c1, 0.0) * xc;
+    if (e.relax > 0) {                                          // fvMatrix::relax as in UcEqn
         double so = 0.0;
         for (int q = 0; q < 6; ++q) so += fabs(an[q]);
-        const double dn = fmax(fabs(dg), so) / kp.relax;
-        src += (dn - dg) * kc;
+        const double dn = fmax(fabs(dg), so) / e.relax;
+        src += (dn - dg) * xc;
         dg = dn;
     }
     M.diag[c] = dg;
     for (int q = 0; q < 6; ++q) M.an[q][c] = an[q];
     b3[3 * (size_t)c] = src; b3[3 * (size_t)c + 1] = 0.0; b3[3 * (size_t)c + 2] = 0.0;
-    x3[3 * (size_t)c] = kc; x3[3 * (size_t)c + 1] = 0.0; x3[3 * (size_t)c + 2] = 0.0;
+    x3[3 * (size_t)c] = xc; x3[3 * (size_t)c + 1] = 0.0; x3[3 * (size_t)c + 2] = 0.0;
 }
 
-// bound(k, kMin) [OF-6 finiteVolume/cfdTools/general/bound/bound.C]: k = max(max(k, fvc::average(max(k, kMin)) pos0(-k)), kMin) -- the
-// identity where k >= kMin, so it is applied without the global min test OpenFOAM guards it with -- then kEqn::correctNut
-__global__ __launch_bounds__(256) void k_k_finish(FvGeo g, KEqnParams kp, const double* __restrict__ x3, double* __restrict__ kf, double* __restrict__ nut) {
+// bound(X, XMin) [OF-6 finiteVolume/cfdTools/general/bound/bound.C]: X = max(max(X, fvc::average(max(X, XMin)) pos0(-X)), XMin) -- the
+// identity where X >= XMin, so it is applied without the global min test OpenFOAM guards it with -- then correctNut (see launch_turb_finish)
+__global__ __launch_bounds__(256) void k_turb_finish(FvGeo g, TurbEqn e, const double* __restrict__ x3, double* __restrict__ Xf, int nut_mode, double cmu,
+                                                     const double* __restrict__ ef, double* __restrict__ nut) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= g.Nc) return;
     int i, j, k; ijk_of(g, t, i, j, k);
     const int c = t + g.c0;
-    const double kc = x3[3 * (size_t)c];
-    double kb = kc;
-    if (!(kc > 0.0)) {                                          // pos0(-k) = 1: the face-area average of the bounded neighbourhood
-        const double mP = fmax(kc, kp.kmin);
+    const double xc = x3[3 * (size_t)c];
+    double xb = xc;
+    if (!(xc > 0.0)) {                                          // pos0(-X) = 1: the face-area average of the bounded neighbourhood
+        const double mP = fmax(xc, e.xmin);
         double av = 0.0;
 #pragma unroll
         for (int d = 0; d < 3; ++d)
@@ -620,17 +627,18 @@ __global__ __launch_bounds__(256) void k_k_finish(FvGeo g, KEqnParams kp, const 
             for (int s = 0; s < 2; ++s) {
                 if (onb(g, d, s, i, j, k)) {
                     const int patch = 2 * d + s;
-                    av += fmax(kp.k_bc[patch] == 1 ? kp.k_val[patch] : kc, kp.kmin);
+                    av += fmax(e.bc[patch] == 1 ? e.val[patch] : xc, e.xmin);
                 } else {
                     const int nbc = c + (s ? stride_of(g, d) : -stride_of(g, d));
-                    av += 0.5 * (mP + fmax(x3[3 * (size_t)nbc], kp.kmin));
+                    av += 0.5 * (mP + fmax(x3[3 * (size_t)nbc], e.xmin));
                 }
             }
-        kb = fmax(kc, av / 6.0);
+        xb = fmax(xc, av / 6.0);
     }
-    kb = fmax(kb, kp.kmin);
-    kf[c] = kb;
-    nut[c] = kp.ck * sqrt(kb) * kp.delta;
+    xb = fmax(xb, e.xmin);
+    Xf[c] = xb;
+    if (nut_mode == 1) nut[c] = e.ck * sqrt(xb) * e.delta;
+    else if (nut_mode == 2) nut[c] = cmu * (xb * xb) / ef[c];
 }
 
 // UEqn (icoFoamYade.C:79-85) / UcEqn + relax (UcEqn.H:3-12): diag, 6 neighbour coefficients, source (no pressure term), rAU = 1/A
@@ -1457,15 +1465,15 @@ int launch_div_G(hipStream_t s, FvGeo g, const double* G, double* divG) {
     return FY_OK;
 }
 
-int launch_assemble_k(hipStream_t s, FvGeo g, KEqnParams kp, const double* k, const double* alpha, CFace3 alphaf, CFace3 phi, const double* vGrad,
-                      Mom7 M, double* b3, double* x3) {
-    hipLaunchKernelGGL(k_assemble_k, dim3(div_up(g.Nc, 256)), dim3(256), 0, s, g, kp, k, alpha, alphaf, phi, vGrad, M, b3, x3);
+int launch_assemble_turb(hipStream_t s, FvGeo g, TurbEqn e, const double* k, const double* eps, const double* alpha, CFace3 alphaf, CFace3 phi,
+                         const double* vGrad, Mom7 M, double* b3, double* x3) {
+    hipLaunchKernelGGL(k_assemble_turb, dim3(div_up(g.Nc, 256)), dim3(256), 0, s, g, e, k, eps, alpha, alphaf, phi, vGrad, M, b3, x3);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }
 
-int launch_k_finish(hipStream_t s, FvGeo g, KEqnParams kp, const double* x3, double* k, double* nut) {
-    hipLaunchKernelGGL(k_k_finish, dim3(div_up(g.Nc, 256)), dim3(256), 0, s, g, kp, x3, k, nut);
+int launch_turb_finish(hipStream_t s, FvGeo g, TurbEqn e, const double* x3, double* X, int nut_mode, double cmu, const double* eps, double* nut) {
+    hipLaunchKernelGGL(k_turb_finish, dim3(div_up(g.Nc, 256)), dim3(256), 0, s, g, e, x3, X, nut_mode, cmu, eps, nut);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }

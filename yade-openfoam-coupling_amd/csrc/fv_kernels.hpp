@@ -70,15 +70,21 @@ int launch_pre_coupling(hipStream_t s, FvGeo g, const double* U, const double* p
 int launch_interp_alpha(hipStream_t s, FvGeo g, const double* alpha, Face3 alphaf);
 // G: three vec3 fields (rows of the tensor) over the whole storage, as k_pre_coupling writes them
 int launch_div_G(hipStream_t s, FvGeo g, const double* G, double* divG);
-// LES kEqn (DPMTurbulenceModels.C:76-77) [OF-6 LES/kEqn/kEqn.C]: boundary conditions of k (0 zeroGradient, 1 fixedValue), model constants,
-// convection scheme of div(alphaRhoPhi,k) (0 Gauss linear, 1 Gauss upwind), relaxation factor of the k equation (<= 0: none)
-struct KEqnParams { double ck, ce, delta, kmin, relax; int upwind; int k_bc[6]; double k_val[6]; };
-// assembles the k equation into the momentum matrix's storage (free after the correctors) as a 3-component system whose components 1, 2 are
-// identically zero, so that the momentum solver's Jacobi pass solves it: x3 = {k, 0, 0}, b3 = {source, 0, 0}
-int launch_assemble_k(hipStream_t s, FvGeo g, KEqnParams kp, const double* k, const double* alpha, CFace3 alphaf, CFace3 phi, const double* vGrad,
-                      Mom7 M, double* b3, double* x3);
-// bound(k, kMin) [OF-6 bound.C] on the solved component 0 of x3, then nut = Ck sqrt(k) delta (kEqn::correctNut)
-int launch_k_finish(hipStream_t s, FvGeo g, KEqnParams kp, const double* x3, double* k, double* nut);
+// The transport equations of the two-equation / one-equation closures (DPMTurbulenceModels.C:70-71 RAS kEpsilon, :76-77 LES kEqn):
+//   fvm::ddt(alpha, X) + fvm::div(alphaPhi, X) - fvm::laplacian(alpha (nut / sigma + nu), X) == Su - fvm::SuSp(c1, X) - fvm::Sp(c2, X)
+// mode 0  kEqn      X = k:    Su = alpha G,            c1 = 2/3 alpha divU,            c2 = Ce alpha sqrt(k) / delta          (sigma = 1)
+// mode 1  kEpsilon  X = eps:  Su = C1 alpha G eps / k,  c1 = (2/3 C1 - C3) alpha divU,  c2 = C2 alpha eps / k                  (sigma = sigmaEps)
+// mode 2  kEpsilon  X = k:    Su = alpha G,            c1 = 2/3 alpha divU,            c2 = alpha eps / k  (eps already new)  (sigma = sigmak)
+// with G = nut (gradU && dev(twoSymm(gradU))), divU = fvc::div(phi).  bc / val: boundary conditions of X (0 zeroGradient, 1 fixedValue);
+// upwind: convection scheme of X (0 Gauss linear, 1 Gauss upwind); relax: relaxation factor of the equation (<= 0: none); xmin: bound()
+struct TurbEqn { int mode; double ck, ce, delta, c1, c2, c3, sigma, xmin, relax; int upwind; int bc[6]; double val[6]; };
+// assembles the equation into the momentum matrix's storage (free after the correctors) as a 3-component system whose components 1, 2 are
+// identically zero, so that the momentum solver's Jacobi pass solves it: x3 = {X, 0, 0}, b3 = {source, 0, 0}
+int launch_assemble_turb(hipStream_t s, FvGeo g, TurbEqn e, const double* k, const double* eps, const double* alpha, CFace3 alphaf, CFace3 phi,
+                         const double* vGrad, Mom7 M, double* b3, double* x3);
+// bound(X, xmin) [OF-6 bound.C] on the solved component 0 of x3 -> X; nut_mode 1: nut = Ck sqrt(k) delta (kEqn::correctNut, X = k),
+// 2: nut = Cmu k^2 / eps (kEpsilon::correctNut, X = k, eps given), 0: leave nut alone (the epsilon equation)
+int launch_turb_finish(hipStream_t s, FvGeo g, TurbEqn e, const double* x3, double* X, int nut_mode, double cmu, const double* eps, double* nut);
 int launch_smagorinsky_nut(hipStream_t s, FvGeo g, const double* vGrad, double ck, double ce, double delta, double* nut);
 int launch_assemble_momentum(hipStream_t s, FvGeo g, const double* U, const double* Uold, const double* alpha, const double* alphaOld,
                              CFace3 alphaf, CFace3 phi, const double* uSource, const double* uSourceDrag, const double* divG,

@@ -53,8 +53,8 @@ struct Solver {
 
     DevBuf<double> U, Uold, p, alpha, uSource, uSourceDrag, uParticle, gradP, divT, vGrad, ddtU;
     DevBuf<double> nut;                  // eddy viscosity (FY_TURBULENCE_SMAGORINSKY / _KEQN), storage cells; empty = laminar
-    DevBuf<double> kturb;                // sub-grid kinetic energy k (FY_TURBULENCE_KEQN)
-    KEqnParams kp{};
+    DevBuf<double> kturb, epsturb;       // turbulent kinetic energy k (FY_TURBULENCE_KEQN, _KEPSILON), dissipation rate epsilon (_KEPSILON)
+    TurbEqn eq_k{}, eq_eps{};
     double les_delta = 0.0;              // LESdelta cubeRootVol: deltaCoeff * cbrt(V) [OF-6 cubeRootVolDelta.C]
     bool phi_fresh = true;      // phi holds the current flux (false between the start-of-step exchange with phiOld and the first flux correction)
     CFace3 phi_now() const { return phi_fresh ? CFace3{{phi[0].p, phi[1].p, phi[2].p}} : CFace3{{phiOld[0].p, phiOld[1].p, phiOld[2].p}}; }
@@ -163,7 +163,7 @@ struct Solver {
         for (int a = 0; a < 3; ++a) g.g[a] = c->g[a];
         g.need_ref = need_ref ? 1 : 0; g.p_ref_cell = c->p_ref_cell; g.p_ref_value = c->p_ref_value;
         g.u_relax = c->u_relax;
-        if (c->turbulence_model != FY_TURBULENCE_LAMINAR && c->turbulence_model != FY_TURBULENCE_SMAGORINSKY && c->turbulence_model != FY_TURBULENCE_KEQN) return fail(FY_ERR_UNSUPPORTED, "fy_solver_create: unknown turbulence_model %d (laminar, LES Smagorinsky and LES kEqn are implemented; RAS kEpsilon of DPMTurbulenceModels.C:70-71 is not)", c->turbulence_model);
+        if (c->turbulence_model != FY_TURBULENCE_LAMINAR && c->turbulence_model != FY_TURBULENCE_SMAGORINSKY && c->turbulence_model != FY_TURBULENCE_KEQN && c->turbulence_model != FY_TURBULENCE_KEPSILON) return fail(FY_ERR_UNSUPPORTED, "fy_solver_create: unknown turbulence_model %d (DPMTurbulenceModels.C:67-77: laminar Stokes, RAS kEpsilon, LES Smagorinsky, LES kEqn)", c->turbulence_model);
         if (c->turbulence_model != FY_TURBULENCE_LAMINAR) {
             if (!pimple) return fail(FY_ERR_INVALID, "fy_solver_create: icoFoamYade has no turbulence model (icoFoamYade.C:79-85 is laplacian(nu, U))");
             if (!(c->les_ck > 0 && c->les_ce > 0 && c->les_delta_coeff > 0) || c->nut_initial < 0) return fail(FY_ERR_INVALID, "fy_solver_create: Smagorinsky needs Ck, Ce, deltaCoeff > 0 and nut >= 0");
@@ -172,14 +172,29 @@ struct Solver {
                 g.nut_bc[q] = c->nut_bc[q]; g.nut_val[q] = c->nut_value[q];
             }
             les_delta = c->les_delta_coeff * std::pow(g.V, 1.0 / 3.0);
-            if (c->turbulence_model == FY_TURBULENCE_KEQN) {
-                if (c->k_initial < 0 || !(c->k_tol >= 0) || c->k_max_iter < 0 || c->k_relax > 1) return fail(FY_ERR_INVALID, "fy_solver_create: kEqn needs k >= 0, a solver tolerance and a relaxation factor in (0, 1]");
+            const bool keqn = c->turbulence_model == FY_TURBULENCE_KEQN, keps = c->turbulence_model == FY_TURBULENCE_KEPSILON;
+            if (keqn || keps) {
+                if (!(c->k_initial >= 0) || (keps && !(c->k_initial > 0)) || !(c->k_tol >= 0) || c->k_max_iter < 0 || c->k_relax > 1) return fail(FY_ERR_INVALID, "fy_solver_create: the k equation needs k >= 0 (> 0 for kEpsilon), a solver tolerance and a relaxation factor in (0, 1]");
                 if (c->k_convection_scheme != FY_CONVECTION_LINEAR && c->k_convection_scheme != FY_CONVECTION_UPWIND) return fail(FY_ERR_UNSUPPORTED, "fy_solver_create: div(alphaPhic,k) must be Gauss linear or Gauss upwind");
-                kp.ck = c->les_ck; kp.ce = c->les_ce; kp.delta = les_delta; kp.kmin = 1e-15;        // kMin_ = small [OF-6 LESModel.C]
-                kp.relax = c->k_relax; kp.upwind = c->k_convection_scheme == FY_CONVECTION_UPWIND ? 1 : 0;
+                eq_k.mode = keqn ? 0 : 2;
+                eq_k.ck = c->les_ck; eq_k.ce = c->les_ce; eq_k.delta = les_delta; eq_k.xmin = 1e-15;        // kMin_ = small [OF-6 LESModel.C, RASModel.C]
+                eq_k.c1 = c->ras_c1; eq_k.c2 = c->ras_c2; eq_k.c3 = c->ras_c3; eq_k.sigma = keqn ? 1.0 : c->ras_sigmak;
+                eq_k.relax = c->k_relax; eq_k.upwind = c->k_convection_scheme == FY_CONVECTION_UPWIND ? 1 : 0;
                 for (int q = 0; q < 6; ++q) {
                     if (c->k_bc[q] != FY_BC_NUT_ZERO_GRADIENT && c->k_bc[q] != FY_BC_NUT_FIXED_VALUE) return fail(FY_ERR_INVALID, "fy_solver_create: unknown k boundary type");
-                    kp.k_bc[q] = c->k_bc[q]; kp.k_val[q] = c->k_value[q];
+                    eq_k.bc[q] = c->k_bc[q]; eq_k.val[q] = c->k_value[q];
+                }
+            }
+            if (keps) {
+                if (!(c->eps_initial > 0) || !(c->eps_tol >= 0) || c->eps_max_iter < 0 || c->eps_relax > 1 || !(c->ras_cmu > 0 && c->ras_sigmak > 0 && c->ras_sigmaeps > 0))
+                    return fail(FY_ERR_INVALID, "fy_solver_create: kEpsilon needs epsilon > 0, Cmu / sigmak / sigmaEps > 0, a solver tolerance and a relaxation factor in (0, 1]");
+                if (c->eps_convection_scheme != FY_CONVECTION_LINEAR && c->eps_convection_scheme != FY_CONVECTION_UPWIND) return fail(FY_ERR_UNSUPPORTED, "fy_solver_create: div(alphaPhic,epsilon) must be Gauss linear or Gauss upwind");
+                eq_eps = eq_k;
+                eq_eps.mode = 1; eq_eps.sigma = c->ras_sigmaeps; eq_eps.xmin = 1e-15;                        // epsilonMin_ = small [OF-6 RASModel.C]
+                eq_eps.relax = c->eps_relax; eq_eps.upwind = c->eps_convection_scheme == FY_CONVECTION_UPWIND ? 1 : 0;
+                for (int q = 0; q < 6; ++q) {
+                    if (c->eps_bc[q] != FY_BC_NUT_ZERO_GRADIENT && c->eps_bc[q] != FY_BC_NUT_FIXED_VALUE) return fail(FY_ERR_INVALID, "fy_solver_create: unknown epsilon boundary type");
+                    eq_eps.bc[q] = c->eps_bc[q]; eq_eps.val[q] = c->eps_value[q];
                 }
             }
         }
@@ -211,7 +226,8 @@ struct Solver {
         for (auto& b : man) { FY_TRY(b.alloc_exact(n)); FY_TRY(zero(b)); }
         FY_TRY(vGrad.alloc_exact(9 * n)); FY_TRY(zero(vGrad));
         if (c->turbulence_model != FY_TURBULENCE_LAMINAR) { FY_TRY(nut.alloc_exact(n)); FY_TRY(launch_fill_f64(stream, nut.p, n, c->nut_initial)); g.nut = nut.p; }
-        if (c->turbulence_model == FY_TURBULENCE_KEQN) { FY_TRY(kturb.alloc_exact(n)); FY_TRY(launch_fill_f64(stream, kturb.p, n, c->k_initial)); }
+        if (c->turbulence_model == FY_TURBULENCE_KEQN || c->turbulence_model == FY_TURBULENCE_KEPSILON) { FY_TRY(kturb.alloc_exact(n)); FY_TRY(launch_fill_f64(stream, kturb.p, n, c->k_initial)); }
+        if (c->turbulence_model == FY_TURBULENCE_KEPSILON) { FY_TRY(epsturb.alloc_exact(n)); FY_TRY(launch_fill_f64(stream, epsturb.p, n, c->eps_initial)); }
         FY_TRY(Gt.alloc_exact(9 * n)); FY_TRY(zero(Gt));
         for (int d = 0; d < 3; ++d) {
             DevBuf<double>* fs[] = {&phi[d], &phiOld[d], &psn[d], &alphaf[d], &phiHbyA[d], &phiForces[d], &rAUf[d], &pflux[d]};
@@ -673,16 +689,26 @@ struct Solver {
     int turbulence_correct() {
         FY_TRY(halo_cells(U, 3, 1));
         FY_TRY(launch_pre_coupling(stream, g, U.p, p.p, alpha.p, C3(psn), vGrad.p, gradP.p, divT.p, nullptr, 1, 0));
-        if (cs.turbulence_model == FY_TURBULENCE_KEQN) {
-            // kEqn::correct(): the k equation is assembled into the momentum matrix's storage and solved by the momentum solver's pass as a
-            // 3-component system whose last two components are identically zero (HbyA / bmom / xscr are free after the correctors)
-            FY_TRY(halo_cells(kturb, 1, 1));
-            FY_TRY(launch_assemble_k(stream, g, kp, kturb.p, alpha.p, C3(alphaf), C3(phi), vGrad.p, M7(), bmom.p, HbyA.p));
+        if (cs.turbulence_model == FY_TURBULENCE_KEQN || cs.turbulence_model == FY_TURBULENCE_KEPSILON) {
+            // kEqn::correct() / kEpsilon::correct(): each transport equation is assembled into the momentum matrix's storage and solved by the
+            // momentum solver's pass as a 3-component system whose last two components are identically zero (HbyA / bmom / xscr are free
+            // after the correctors).  kEpsilon: the dissipation equation first, then k with the new epsilon, then nut = Cmu k^2 / epsilon
+            const bool keps = cs.turbulence_model == FY_TURBULENCE_KEPSILON;
             int it = 0;
+            FY_TRY(halo_cells(kturb, 1, 1));
+            if (keps) {
+                FY_TRY(halo_cells(epsturb, 1, 1));
+                FY_TRY(launch_assemble_turb(stream, g, eq_eps, kturb.p, epsturb.p, alpha.p, C3(alphaf), C3(phi), vGrad.p, M7(), bmom.p, HbyA.p));
+                FY_TRY(solve_vec3(HbyA, bmom.p, cs.eps_tol, cs.eps_rel_tol, cs.eps_max_iter, &it));
+                st_k_iters += it;
+                FY_TRY(halo_cells(HbyA, 3, 1));
+                FY_TRY(launch_turb_finish(stream, g, eq_eps, HbyA.p, epsturb.p, 0, 0.0, nullptr, nullptr));
+            }
+            FY_TRY(launch_assemble_turb(stream, g, eq_k, kturb.p, epsturb.p, alpha.p, C3(alphaf), C3(phi), vGrad.p, M7(), bmom.p, HbyA.p));
             FY_TRY(solve_vec3(HbyA, bmom.p, cs.k_tol, cs.k_rel_tol, cs.k_max_iter, &it));
             st_k_iters += it;
             FY_TRY(halo_cells(HbyA, 3, 1));
-            FY_TRY(launch_k_finish(stream, g, kp, HbyA.p, kturb.p, nut.p));
+            FY_TRY(launch_turb_finish(stream, g, eq_k, HbyA.p, kturb.p, keps ? 2 : 1, cs.ras_cmu, epsturb.p, nut.p));
             return halo_cells(nut, 1, 1);
         }
         FY_TRY(launch_smagorinsky_nut(stream, g, vGrad.p, cs.les_ck, cs.les_ce, les_delta, nut.p));
@@ -826,7 +852,7 @@ struct Solver {
         const E tab[] = {{"U", U.p, 3 * n, 3}, {"p", p.p, n, 1}, {"phi_x", phi[0].p, phi[0].n, 0}, {"phi_y", phi[1].p, phi[1].n, 0}, {"phi_z", phi[2].p, phi[2].n, 0},
                          {"rAU", rAU.p, n, 1}, {"HbyA", HbyA.p, 3 * n, 3}, {"p_rhs", prhs.p, n, 1}, {"mom_diag", mdiag.p, n, 1}, {"mom_src", src.p, 3 * n, 3},
                          {"alpha", alpha.p, n, 1}, {"uSource", uSource.p, 3 * n, 3}, {"uSourceDrag", uSourceDrag.p, n, 1}, {"uParticle", uParticle.p, 3 * n, 3},
-                         {"gradP", gradP.p, 3 * n, 3}, {"divT", divT.p, 3 * n, 3}, {"vGrad", vGrad.p, 9 * n, 9}, {"ddtU", ddtU.p, 3 * n, 3}, {"nut", nut.p, n, 1}, {"k", kturb.p, n, 1}};
+                         {"gradP", gradP.p, 3 * n, 3}, {"divT", divT.p, 3 * n, 3}, {"vGrad", vGrad.p, 9 * n, 9}, {"ddtU", ddtU.p, 3 * n, 3}, {"nut", nut.p, n, 1}, {"k", kturb.p, n, 1}, {"epsilon", epsturb.p, n, 1}};
         for (const E& e : tab) if (s == e.nm) {
             if (!e.p) return fail(FY_ERR_INVALID, "solver field '%s' does not exist in this case (no turbulence model)", s.c_str());
             *ptr = e.p + (size_t)e.comp * g.c0;          // skip the ghost planes below the owned range (comp = 0: face array)
@@ -861,6 +887,8 @@ void fy_case_defaults(fy_case_desc* c, int solver) {
     c->adjust_time_step = 0; c->max_co = 1.0; c->max_delta_t = 1e300;
     c->u_relax = 1.0; c->u_relax_final = 0.0; c->p_relax = 0.0; c->p_relax_final = 0.0;
     c->k_tol = 1e-6; c->k_rel_tol = 0.0; c->k_max_iter = 1000; c->k_relax = 0.0; c->k_convection_scheme = FY_CONVECTION_UPWIND;
+    c->eps_tol = 1e-6; c->eps_rel_tol = 0.0; c->eps_max_iter = 1000; c->eps_relax = 0.0; c->eps_convection_scheme = FY_CONVECTION_UPWIND;
+    c->ras_cmu = 0.09; c->ras_c1 = 1.44; c->ras_c2 = 1.92; c->ras_c3 = 0.0; c->ras_sigmak = 1.0; c->ras_sigmaeps = 1.3;      // [OF-6 kEpsilon.C defaults]
     c->turbulence_model = FY_TURBULENCE_LAMINAR; c->les_ck = 0.094; c->les_ce = 1.048; c->les_delta_coeff = 1.0;     // [OF-6 Smagorinsky.C, cubeRootVolDelta.C defaults]
 }
 
@@ -962,6 +990,7 @@ int fy_solver_write_field_host(fy_solver* s, const char* name, const double* in)
     }
     if (std::string(name) == "nut") FY_TRY(s->s.halo_cells(s->s.nut, 1, 1));
     if (std::string(name) == "k") FY_TRY(s->s.halo_cells(s->s.kturb, 1, 1));
+    if (std::string(name) == "epsilon") FY_TRY(s->s.halo_cells(s->s.epsturb, 1, 1));
     FY_HIP(hipStreamSynchronize(s->s.stream));
     return FY_OK;
 }
