@@ -70,7 +70,7 @@ namespace {
 typedef std::vector<double> vec;
 const double SMALL = 1e-15;      // OpenFOAM `small` for double
 const double VSMALL = 1e-300;
-const int kMgCoarsest = 256;    // coarsest multigrid level (same rule as the product so iteration counts are comparable)
+const int kMgCoarsest = 256, kMgCoarsestEdge = 8;    // coarsest multigrid level (same rule as the product so iteration counts are comparable)
 
 struct MgLevel {
     int nx, ny, nz, N;
@@ -601,7 +601,7 @@ struct Fv {
             L.diag.assign(L.N, 0.0); L.ux = L.diag; L.uy = L.diag; L.uz = L.diag; L.x = L.diag; L.b = L.diag; L.r = L.diag;
             mg.push_back(L);
             if (cs.p_solver != 1) break;
-            if (L.N <= kMgCoarsest || (ax <= 2 && ay <= 2 && az <= 2)) break;
+            if ((L.N <= kMgCoarsest && std::max(std::max(ax, ay), az) <= kMgCoarsestEdge) || (ax <= 2 && ay <= 2 && az <= 2)) break;   // (no elongated coarsest grid: 40 Jacobi sweeps must solve it)
             ax = (ax + 1) / 2; ay = (ay + 1) / 2; az = (az + 1) / 2;
         }
     }

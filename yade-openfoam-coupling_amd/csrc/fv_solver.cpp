@@ -21,7 +21,7 @@ namespace fy {
 
 // coarsest multigrid level: solved by damped-Jacobi sweeps inside one 1024-thread workgroup (every level below ~20^3 is
 // launch-bound on the GPU; stopping at <= 1024 cells was tried and LOST: 40 sweeps no longer solve that level, +20 % PCG iterations)
-constexpr int kMgCoarsest = 256;
+constexpr int kMgCoarsest = 256, kMgCoarsestEdge = 8;
 constexpr int kMgReplicateBelow = 1 << 20;    // a distributed hierarchy hands over to the replicated one at <= this many GLOBAL cells: every
                                               // distributed level costs 4 neighbour exchanges per V-cycle, a replicated 1 M-cell level ~15 us per kernel
 
@@ -283,7 +283,11 @@ struct Solver {
                 if (!dist && mg_rep == (size_t)-1 && S > 1) mg_rep = lvl;
                 mg.push_back(std::move(L));
                 if (cs.p_solver != FY_PSOLVER_PCG_MG) break;
-                if (Ng <= kMgCoarsest || (ax <= 2 && ay <= 2 && az_glob <= 2)) break;
+                // the coarsest level is "solved" by 40 damped-Jacobi sweeps, which settles modes up to a few cells long: an elongated coarse grid
+                // (3 x 3 x 20 under a 160 x 160 x 1280 column) would keep its longest modes and the V-cycle would lose its grip on tall
+                // domains (PCG iterations per step 2.6 / 4.4 / 4.6 / 6.4 for 1 / 2 / 4 / 8 stacked C3 boxes) -- so coarsening also goes on
+                // while any edge is longer than kMgCoarsestEdge cells
+                if ((Ng <= kMgCoarsest && std::max(std::max(ax, ay), az_glob) <= kMgCoarsestEdge) || (ax <= 2 && ay <= 2 && az_glob <= 2)) break;
                 // next level
                 const int nax = (ax + 1) / 2, nay = (ay + 1) / 2, naz_glob = (az_glob + 1) / 2;
                 if (dist) {
