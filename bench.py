@@ -306,6 +306,7 @@ def aggregate_value(world, steps, elapsed):
 def rccl_selftest_child(args):
     """child of rccl_preflight: join the throw-away communicator, run the library's known-answer pattern, exit 0 / 3"""
     rank, world, local_rank = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+    import torch  # noqa: F401  -- first, as in the parent: the library then dlopens the SAME librccl (the wheel's) that produced the unique id
     prod = ge.load_product()
     try:
         comm = prod.rccl_comm(rank, world, bytes.fromhex(args.rccl_selftest), local_rank)
