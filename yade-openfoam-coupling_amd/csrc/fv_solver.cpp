@@ -382,7 +382,7 @@ struct Solver {
     // Returns false when there is no slot left (the caller then reads at once).
     static constexpr int kDeferBase = 8, kDeferMax = 2 + 4 * 255; // red_host: 8 immediate doubles + Courant + 255 correctors' continuity errors
     int n_deferred = 0;
-    bool reduce_deferred(int nslots, bool courant, int* slot, int* rc, const int* ops = nullptr) {      // ops (device, per slot 0 sum / 1 max): single domain only
+    bool reduce_deferred(int nslots, bool courant, int* slot, int* rc, const int* ops = nullptr) {      // ops: ops_diag.p (sum, sum, max, sum) or none
         *rc = FY_OK;
         if (!red_host || n_deferred + nslots > kDeferMax) return false;
         *slot = kDeferBase + n_deferred;
@@ -391,9 +391,14 @@ struct Solver {
             *rc = launch_reduce_finalize(stream, partials.p, Nc, nslots, ops ? ops : (courant ? ops_courant.p : nullptr), red_host_dev + *slot);
             return true;
         }
-        *rc = launch_reduce_finalize(stream, partials.p, Nc, nslots, courant ? ops_courant.p : nullptr, red_out.p);
+        *rc = launch_reduce_finalize(stream, partials.p, Nc, nslots, ops ? ops : (courant ? ops_courant.p : nullptr), red_out.p);
         if (*rc == FY_OK) {
-            if (courant) { *rc = comm->allreduce(stream, red_out.p, 1, true); if (*rc == FY_OK) *rc = comm->allreduce(stream, red_out.p + 1, 1, false); }
+            if (ops) {                       // the four diagnostics of k_U_correct<true>: sum, sum, max, sum
+                *rc = comm->allreduce(stream, red_out.p, 2, false);
+                if (*rc == FY_OK) *rc = comm->allreduce(stream, red_out.p + 2, 1, true);
+                if (*rc == FY_OK) *rc = comm->allreduce(stream, red_out.p + 3, 1, false);
+            }
+            else if (courant) { *rc = comm->allreduce(stream, red_out.p, 1, true); if (*rc == FY_OK) *rc = comm->allreduce(stream, red_out.p + 1, 1, false); }
             else *rc = comm->allreduce(stream, red_out.p, nslots, false);
         }
         if (*rc == FY_OK && hipMemcpyAsync(red_host + *slot, red_out.p, nslots * sizeof(double), hipMemcpyDeviceToHost, stream) != hipSuccess)
@@ -655,8 +660,8 @@ struct Solver {
         clk_pres.end(stream);
         double h[2];
         int slot = 0, rc = FY_OK;
-        if (fuse_diag && comm->size == 1 && red_host && n_deferred + 4 <= kDeferMax) {
-            // single domain: the continuity errors and the NEXT step's Courant sums ride on the velocity correction's sweep
+        if (fuse_diag && red_host && n_deferred + 4 <= kDeferMax) {
+            // the continuity errors and the NEXT step's Courant sums ride on the velocity correction's sweep
             // (k_U_correct<true>; same values as k_cont_err / k_courant) instead of being two sweeps of their own
             FY_TRY(launch_U_correct_diag(stream, g, HbyA.p, rAU.p, p.p, C3(psn), C3(phiForces), C3(pflux), C3(alphaf), C3(rAUf), U.p, C3(phi), alpha.p,
                                          /* alphaOld */ alpha.p, partials.p));
