@@ -758,8 +758,14 @@ struct Solver {
         FY_TRY(halo_cells(p, 1, 1));
         FY_TRY(halo_cells(alpha, 1, 1));
         FY_TRY(comm->group_end(stream));
-        const bool fuse_uold = comm->size == 1;        // single domain: U.oldTime() is written by the pre-coupling sweep that reads U anyway
-        if (!fuse_uold) FY_TRY(launch_copy_f64(stream, Uold.p, U.p, 3 * nstore));
+        // U.oldTime() of the owned cells is written by the pre-coupling sweep that reads U anyway; a slab copies only its ghost planes
+        // (phiHbyA's ddtCorr reads Uold across the slab faces), which the exchange above has just refreshed in U
+        const bool fuse_uold = true;
+        if (comm->size > 1 && g.gz > 0) {
+            const size_t gh = 3 * plane * (size_t)g.gz;
+            FY_TRY(launch_copy_f64(stream, Uold.p, U.p, gh));
+            FY_TRY(launch_copy_f64(stream, Uold.p + 3 * plane * (size_t)(g.gz + g.nz), U.p + 3 * plane * (size_t)(g.gz + g.nz), gh));
+        }
         // phi.oldTime(): the flux arrays trade places instead of being copied -- what was phi is phiOld now, and until the first
         // flux correction of this step rewrites phi (every face of it) the current flux is read from phiOld (phi_now())
         if (cs.n_correctors > 0) {
