@@ -232,9 +232,12 @@ int Coupling::create(const fy_mesh_desc* m, const fy_field_ptrs* f, int gaussian
     if (has_transport || fields_on_host) {
         FY_HIP(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
     }
-    if (fields_on_host && getenv("FOAMYADE_NO_HOST_REGISTER") == nullptr) {
-        // the caller's field arrays live as long as this object (FoamYade.H:76-90 holds references to them): pin them in place so that the
-        // per-step staging copies run at PCIe rate.  Best effort -- an array that cannot be registered is simply copied as pageable.
+    if (fields_on_host && getenv("FOAMYADE_HOST_REGISTER") != nullptr) {
+        // OPT-IN (FOAMYADE_HOST_REGISTER=1): the caller's field arrays live as long as this object (FoamYade.H:76-90 holds references to them),
+        // so they can be pinned in place and the per-step staging copies run at PCIe rate (56 GB/s instead of ~20).  Off by default: page-locking
+        // memory that somebody else's allocator owns (and shares pages of with its other objects) is only safe when the caller knows how those
+        // arrays were allocated -- an OpenFOAM field store is fine, a test process that allocates and frees numpy arrays around them is not
+        // (rare aborts inside later pageable copies were traced to this).  Best effort -- an array that cannot be registered is copied as pageable.
         const size_t nb = (size_t)n_cells * sizeof(double);
         struct { const void* p; size_t bytes; } arr[] = {{f->U, 3 * nb}, {f->gradP, 3 * nb}, {f->vGrad, 9 * nb}, {f->divT, 3 * nb}, {f->ddtU, 3 * nb},
                                                          {f->uSourceDrag, nb}, {f->alpha, nb}, {f->uSource, 3 * nb}, {f->uParticle, 3 * nb}};
