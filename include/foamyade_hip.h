@@ -129,7 +129,7 @@ int fy_destroy(fy_ctx*);
 /* ---- direct mode (no Yade peer): one call per "Yade proc" batch, batches are processed in index order exactly
  *      like the loop over inCommProcs (FoamYade.C:612-628) ------------------------------------------------- */
 int fy_set_num_batches(fy_ctx*, int nbatch);
-int fy_set_particles_host(fy_ctx*, int batch, const double* records, int64_t n);     /* copies (H2D) */
+int fy_set_particles_host(fy_ctx*, int batch, const double* records, int64_t n);     /* copies (H2D); `records` may be reused or freed on return */
 int fy_set_particles_device(fy_ctx*, int batch, const double* d_records, int64_t n); /* borrows the device pointer */
 int fy_get_forces_host(fy_ctx*, int batch, double* out_forces /* [n][6] */);
 /* z-slab mode (fy_solver_create_slab): hand the particles of batch 0 whose containing cell now lies in a neighbour's planes to that

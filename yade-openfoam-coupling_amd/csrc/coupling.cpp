@@ -437,6 +437,9 @@ int Coupling::set_particles_host(int bi, const double* rec, int64_t n) {
         FY_HIP(hipMemcpyAsync(b.rec_own.p, rec, 10 * (size_t)n * sizeof(double), hipMemcpyHostToDevice, stream));
     }
     b.d_rec = b.rec_own.p;
+    // the caller owns `rec` and may free it as soon as this returns: an asynchronous copy out of pageable memory is only staged, not
+    // necessarily finished, when hipMemcpyAsync comes back
+    if (n) FY_HIP(hipStreamSynchronize(stream));
     return ensure_batch(b, n);
 }
 
