@@ -29,6 +29,12 @@ constexpr int kWave = 64;
 // binned particle order) was measured on MI355X and LOSES for the particle kernels: locate+deposit 14.5 -> 16.1 ms, force 10.0 ->
 // 10.8 ms at 10 M particles, because the FP64 atomics of a spatially compact run pile onto few memory channels.
 
+// pow(dia, 3.0) of FoamYade.H:36 as two multiplications in the two hot kernels (k_locate_deposit, k_force_gaussian): the library pow is ~200 FP64
+// instructions per call, which showed in the VALU-bound list scan (1.02 -> 0.98 ms); x*x*x is within one ulp of the correctly rounded cube, the
+// same order as the difference between the device's and glibc's pow that the golden tolerances already carry.  The cold sites keep pow: with
+// the cheap form the compiler if-converts the opt-in torque branch of force_law and the force kernel loses 0.2 ms to register pressure
+__device__ __forceinline__ double cube3(double x) { return (x * x) * x; }
+
 __device__ __forceinline__ void atomic_add_f64(double* p, double v) {
     // global_atomic_add_f64, no return value, device (agent) scope.  (Workgroup-scope atomics were measured: no faster.)
     unsafeAtomicAdd(p, v);
@@ -981,7 +987,7 @@ __global__ __launch_bounds__(kDepThreads) void k_locate_deposit(LocateLists ll, 
 #pragma unroll
                     for (int h = kListLen - 1; h >= 0; --h) allwt += wt[h];       // last push first (FoamYade.C:301-311)
                     const double dia = 2 * p.rad[i];                                  // FoamYade.C:219
-                    const double pVol = M_PI * pow(dia, 3.0) / 6.0;                   // FoamYade.H:36
+                    const double pVol = M_PI * cube3(dia) / 6.0;                      // FoamYade.H:36
                     const double vx = p.vx[i], vy = p.vy[i], vz = p.vz[i];
                     int pos = 0;
 #pragma unroll
@@ -1207,7 +1213,7 @@ __global__ __launch_bounds__(MODE == 1 ? 256 : kForceThreads) void k_force_gauss
                 if (!fp.torque_prezeroed) { F[3] = F[4] = F[5] = 0.0; }
             } else {
                 const double dia = 2 * p.rad[i];
-                const double volp = M_PI * pow(dia, 3.0) / 6.0;
+                const double volp = M_PI * cube3(dia) / 6.0;
                 // hydroDragForce FoamYade.C:358-365 and archimedesForce FoamYade.C:416-424 share one gather pass over the cell records
                 Interp s{0, 0, 0, 0, 0, 0, 0, 0};
                 ModelSums ms{0, 0, 0, 0, 0, 0, 0};
