@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define FY_ABI_VERSION 6
+#define FY_ABI_VERSION 7
 
 /* ---- status codes ------------------------------------------------------------------------------------ */
 enum {
@@ -198,6 +198,7 @@ enum { FY_PSOLVER_PCG_JACOBI = 0, FY_PSOLVER_PCG_MG = 1 };
 #define FY_TURBULENCE_KEPSILON 3       /* simulationType RAS, RASModel kEpsilon (DPMTurbulenceModels.C:70-71); no wall functions */
 #define FY_BC_NUT_ZERO_GRADIENT 0
 #define FY_BC_NUT_FIXED_VALUE 1
+#define FY_BC_WALL_FUNCTION 2           /* nut_bc: nutkWallFunction (needs a model with k); eps_bc: epsilonWallFunction; k takes zeroGradient (kqRWallFunction) */
 typedef struct fy_case_desc {
     int32_t solver;                 /* FY_SOLVER_ICO | FY_SOLVER_PIMPLE */
     int32_t nx, ny, nz;
@@ -249,13 +250,16 @@ typedef struct fy_case_desc {
        - fvm::laplacian(alpha (nut/sigmaEps + nu), eps) == C1 alpha G eps/k - fvm::SuSp((2/3 C1 - C3) alpha div(phic), eps) - fvm::Sp(C2 alpha eps/k, eps),
        bound(eps, epsilonMin); then fvm::ddt(alpha,k) + fvm::div(alphaPhic,k) - fvm::laplacian(alpha (nut/sigmak + nu), k) == alpha G
        - fvm::SuSp(2/3 alpha div(phic), k) - fvm::Sp(alpha eps/k, k) with the NEW eps, bound(k, kMin); nut = Cmu k^2/eps.
-       k uses the k_* fields above; epsilon its own.  Boundary types zeroGradient | fixedValue only: the wall functions a RAS case normally
-       puts on its walls (epsilonWallFunction, nutkWallFunction) are not implemented and are refused by the case reader */
+       k uses the k_* fields above; epsilon its own.  Boundary types zeroGradient | fixedValue | FY_BC_WALL_FUNCTION (below) */
     double ras_cmu, ras_c1, ras_c2, ras_c3, ras_sigmak, ras_sigmaeps;   /* fy_case_defaults: 0.09, 1.44, 1.92, 0, 1, 1.3 */
     int32_t eps_bc[6]; double eps_value[6]; double eps_initial;
     int32_t eps_convection_scheme;
     double eps_tol, eps_rel_tol; int32_t eps_max_iter;
     double eps_relax;
+    /* wall functions [OF-6 nutkWallFunction / epsilonWallFunction]: nut_w = nu (y+ kappa / ln(E y+) - 1) above yPlusLam, else 0, with
+       y+ = Cmu^1/4 y sqrt(k)/nu; in the wall cells eps = Cmu^3/4 k^3/2/(kappa y) is imposed on the epsilon equation and the production G is
+       replaced by (1/W) sum (nut_w + nu) |snGrad U| Cmu^1/4 sqrt(k)/(kappa y).  Cmu is ras_cmu */
+    double wf_kappa, wf_E;                       /* fy_case_defaults: 0.41, 9.8 */
 } fy_case_desc;
 
 typedef struct fy_solver fy_solver;

@@ -56,6 +56,8 @@ struct orc_fv_case {
     // RAS kEpsilon (turbulence_model 3): model constants, the 0/epsilon file, div(alphaPhic,epsilon) scheme, solvers.epsilon, relaxation
     double ras_cmu, ras_c1, ras_c2, ras_c3, ras_sigmak, ras_sigmaeps;
     int eps_bc[6]; double eps_value[6]; double eps_initial; int eps_convection_scheme; double eps_tol, eps_rel_tol; int eps_max_iter; double eps_relax;
+    // wall functions: nut_bc == 2 nutkWallFunction, eps_bc == 2 epsilonWallFunction [OF-6]; kappa, E (Cmu = ras_cmu)
+    double wf_kappa, wf_E;
 };
 struct orc_fv_stats {
     double courant_mean, courant_max, cont_sum_local, cont_global, cont_cumulative;
@@ -264,6 +266,22 @@ struct Fv {
     // an[2*d+s] = coefficient of the neighbour across face (d,s); src excludes any pressure term.
     double u_relax_now = 1.0;      // the factor fvMatrix::relax() finds for this outer iteration (Uc / UcFinal)
     vec pPrev;                     // p.prevIter(): stored by pimple.loop() at the start of every outer iteration when p has a relaxation factor
+    // boundary value of nut on `patch` next to cell c: 0 zeroGradient, 1 fixedValue, 2 nutkWallFunction [OF-6 nutkWallFunctionFvPatchScalarField::nut():
+    // yPlus = Cmu^0.25 y sqrt(k_P)/nu_w; nut_w = nu_w (yPlus kappa/log(E yPlus) - 1) if yPlus > yPlusLam else 0; yPlusLam by ten fixed-point sweeps of
+    // ypl = log(max(E ypl, 1))/kappa from 11].  OpenFOAM keeps the values of the last correctNut(); before the first correct() the file's value stands
+    bool nut_wall_live = false;
+    double nut_boundary(int patch, int c) const {
+        const int t = cs.nut_bc[patch];
+        if (t == 1 || (t == 2 && !nut_wall_live)) return cs.nut_value[patch];
+        if (t == 2) {
+            double ypl = 11.0;
+            for (int it = 0; it < 10; ++it) ypl = std::log(std::max(cs.wf_E * ypl, 1.0)) / cs.wf_kappa;
+            const double y = 0.5 * dx;
+            const double yPlus = std::pow(cs.ras_cmu, 0.25) * y * std::sqrt(kturb[c]) / cs.nu;
+            return yPlus > ypl ? cs.nu * (yPlus * cs.wf_kappa / std::log(cs.wf_E * yPlus) - 1.0) : 0.0;
+        }
+        return nut[c];
+    }
     void assemble_momentum() {
         const double nu = cs.nu, dt = cs.dt;
         if (pimple) {
@@ -309,7 +327,7 @@ struct Fv {
                     // - fvm::laplacian(alpha nuEff, U) [OF-6 linearViscousStress::divDevRhoReff]: the cell field alpha (nu + nut) is interpolated
                     // linearly to the faces (gaussLaplacianScheme::fvmLaplacian(vol gamma)); boundary value alpha_b (nu + nut_b) with nut_b by 0/nut
                     if (onb(d, s, i, j, k)) {
-                        const double nb = cs.nut_bc[2 * d + s] == 1 ? cs.nut_value[2 * d + s] : nut[c];
+                        const double nb = nut_boundary(2 * d + s, c);
                         gam = (af * (nu + nb)) * dx;
                     } else {
                         const int nbc = c + (s ? stride[d] : -stride[d]);
@@ -844,7 +862,12 @@ struct Fv {
     void turb_eqn(int mode) {
         const double nu = cs.nu, dt = cs.dt, delta = cs.les_delta_coeff * std::pow(V, 1.0 / 3.0), xMin = 1e-15;
         const double sigma = mode == 0 ? 1.0 : mode == 1 ? cs.ras_sigmaeps : cs.ras_sigmak;
-        const int* bc = mode == 1 ? cs.eps_bc : cs.k_bc;
+        int bcv[6];
+        for (int q = 0; q < 6; ++q) bcv[q] = mode == 1 ? (cs.eps_bc[q] == 2 ? 0 : cs.eps_bc[q]) : cs.k_bc[q];      // an epsilonWallFunction patch is never asked for a face value: the wall cells are imposed
+        const int* bc = bcv;
+        auto wallp = [&](int patch) { return mode != 0 && cs.eps_bc[patch] == 2; };
+        auto wall_count = [&](int i, int j, int k) { int w = 0; for (int d = 0; d < 3; ++d) for (int sd = 0; sd < 2; ++sd) if (wallp(2 * d + sd) && onb(d, sd, i, j, k)) ++w; return w; };
+        const double ywall = 0.5 * dx, cmu75 = std::pow(cs.ras_cmu, 0.75), cmu25 = std::pow(cs.ras_cmu, 0.25);
         const double* bval = mode == 1 ? cs.eps_value : cs.k_value;
         const int scheme = mode == 1 ? cs.eps_convection_scheme : cs.k_convection_scheme;
         const double relax = mode == 1 ? cs.eps_relax : cs.k_relax;
@@ -863,7 +886,7 @@ struct Fv {
                 if (onb(d, sd, i, j, k)) {
                     an[2 * d + sd][c] = 0.0;
                     const int patch = 2 * d + sd;
-                    const double nb = cs.nut_bc[patch] == 1 ? cs.nut_value[patch] : nutc;
+                    const double nb = nut_boundary(patch, c);
                     const double gam = (af * (nu + nb / sigma)) * dx;
                     if (bc[patch] == 1) { const double gb = 2.0 * gam; dg += gb; s += (-phio + gb) * bval[patch]; }
                     else dg += phio;
@@ -880,7 +903,20 @@ struct Fv {
             const double tr2 = 2.0 * (T[0] + T[4] + T[8]);
             double GG = 0.0;
             for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) GG += T[3 * a + b] * ((T[3 * a + b] + T[3 * b + a]) - (a == b ? (1.0 / 3.0) * tr2 : 0.0));
-            const double G = nutc * GG;
+            double G = nutc * GG;
+            // epsilonWallFunction [OF-6 epsilonWallFunctionFvPatchScalarField::calculate / updateCoeffs]: in the wall cells
+            //   G = sum_f w (nut_w + nu_w) |snGrad U_w| Cmu^0.25 sqrt(k)/(kappa y),  eps = sum_f w Cmu^0.75 k^1.5/(kappa y),  w = 1/(wall faces of the cell)
+            const int Wc = wall_count(i, j, k);
+            if (Wc) {
+                double Gw = 0.0;
+                for (int d = 0; d < 3; ++d) for (int sd = 0; sd < 2; ++sd) if (wallp(2 * d + sd) && onb(d, sd, i, j, k)) {
+                    const int patch = 2 * d + sd;
+                    double ub[3]; Ub(U, c, patch, ub);
+                    const double d0 = (ub[0] - U[3 * (size_t)c]) / ywall, d1 = (ub[1] - U[3 * (size_t)c + 1]) / ywall, d2 = (ub[2] - U[3 * (size_t)c + 2]) / ywall;
+                    Gw += (nut_boundary(patch, c) + nu) * std::sqrt(d0 * d0 + d1 * d1 + d2 * d2) * cmu25 * std::sqrt(kturb[c]) / (cs.wf_kappa * ywall);
+                }
+                G = Gw / (double)Wc;
+            }
             const double divU = sumPhi / V;
             double Su, c1, c2;
             if (mode == 0) { Su = aP * G; c1 = (2.0 / 3.0) * aP * divU; c2 = cs.les_ce * aP * std::sqrt(xc) / delta; }
@@ -895,9 +931,28 @@ struct Fv {
                 s += (dn - dg) * xc;
                 dg = dn;
             }
+            double x0 = xc;
+            if (mode == 1) {
+                // epsEqn.boundaryManipulate -> fvMatrix::setValues(faceCells, value) [OF-6 fvMatrix.C setValuesFromList]: the wall cell's row becomes
+                // diag x = diag value, its neighbours' coefficients towards it move to their sources
+                if (Wc) {
+                    const double v = cmu75 * std::pow(kturb[c], 1.5) / (cs.wf_kappa * ywall);
+                    for (int q = 0; q < 6; ++q) an[q][c] = 0.0;
+                    s = dg * v; x0 = v;
+                } else {
+                    for (int d = 0; d < 3; ++d) for (int sd = 0; sd < 2; ++sd) if (!onb(d, sd, i, j, k)) {
+                        const int ni = i + (d == 0 ? (sd ? 1 : -1) : 0), nj = j + (d == 1 ? (sd ? 1 : -1) : 0), nk = k + (d == 2 ? (sd ? 1 : -1) : 0);
+                        if (wall_count(ni, nj, nk)) {
+                            const int nbc = c + (sd ? stride[d] : -stride[d]);
+                            s -= an[2 * d + sd][c] * (cmu75 * std::pow(kturb[nbc], 1.5) / (cs.wf_kappa * ywall));
+                            an[2 * d + sd][c] = 0.0;
+                        }
+                    }
+                }
+            }
             diag[c] = dg;
             b3[3 * (size_t)c] = s;
-            x3[3 * (size_t)c] = xc;
+            x3[3 * (size_t)c] = x0;
         }
         k_iters += mode == 1 ? solve_vec3(x3, b3, cs.eps_tol, cs.eps_rel_tol, cs.eps_max_iter) : solve_vec3(x3, b3, cs.k_tol, cs.k_rel_tol, cs.k_max_iter);
         vec xn(Nc);
@@ -919,6 +974,7 @@ struct Fv {
         Xf = xn;
         if (mode == 0) for (int c = 0; c < Nc; ++c) nut[c] = cs.les_ck * std::sqrt(kturb[c]) * delta;
         else if (mode == 2) for (int c = 0; c < Nc; ++c) nut[c] = cs.ras_cmu * (kturb[c] * kturb[c]) / epsturb[c];
+        if (mode != 1) nut_wall_live = true;          // correctNut(): the wall-function patches now carry nut_w(k)
     }
     // continuousPhaseTurbulence->correct() for LESModel Smagorinsky [OF-6 LES/Smagorinsky/Smagorinsky.C: correct() -> correctNut();
     // k(gradU): D = symm(gradU), a = Ce/delta, b = (2/3) tr(D), c = 2 Ck delta (dev(D) && D), k = sqr((-b + sqrt(sqr(b) + 4 a c))/(2 a));

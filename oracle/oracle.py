@@ -212,7 +212,7 @@ class FvCase(C.Structure):
                 ("ras_cmu", C.c_double), ("ras_c1", C.c_double), ("ras_c2", C.c_double), ("ras_c3", C.c_double), ("ras_sigmak", C.c_double),
                 ("ras_sigmaeps", C.c_double), ("eps_bc", C.c_int * 6), ("eps_value", C.c_double * 6), ("eps_initial", C.c_double),
                 ("eps_convection_scheme", C.c_int), ("eps_tol", C.c_double), ("eps_rel_tol", C.c_double), ("eps_max_iter", C.c_int),
-                ("eps_relax", C.c_double)]
+                ("eps_relax", C.c_double), ("wf_kappa", C.c_double), ("wf_E", C.c_double)]
 
 
 class FvStats(C.Structure):
@@ -234,7 +234,7 @@ def fv_case(solver, nx, ny, nz, dx, dt, nu, rho_f=1000.0, rho_p=2650.0, g=(0, 0,
             p_relax_final=0.0, turbulence_model=0, les_ck=0.094, les_ce=1.048, les_delta_coeff=1.0, nut_bc=None, nut_value=None, nut_initial=0.0,
             k_bc=None, k_value=None, k_initial=0.0, k_convection_scheme=1, k_tol=1e-6, k_rel_tol=0.0, k_max_iter=1000, k_relax=0.0,
             ras_cmu=0.09, ras_c1=1.44, ras_c2=1.92, ras_c3=0.0, ras_sigmak=1.0, ras_sigmaeps=1.3, eps_bc=None, eps_value=None, eps_initial=0.0,
-            eps_convection_scheme=1, eps_tol=1e-6, eps_rel_tol=0.0, eps_max_iter=1000, eps_relax=0.0):
+            eps_convection_scheme=1, eps_tol=1e-6, eps_rel_tol=0.0, eps_max_iter=1000, eps_relax=0.0, wf_kappa=0.41, wf_E=9.8):
     """documented defaults = the icoFoam cavity / DPMFoam tutorial settings of SURVEY.md Appendix C"""
     c = FvCase()
     c.solver, c.nx, c.ny, c.nz, c.dx, c.dt, c.nu = solver, nx, ny, nz, dx, dt, nu
@@ -271,6 +271,7 @@ def fv_case(solver, nx, ny, nz, dx, dt, nu, rho_f=1000.0, rho_p=2650.0, g=(0, 0,
         c.eps_bc[q] = (eps_bc or [0] * 6)[q]
         c.eps_value[q] = (eps_value or [0.0] * 6)[q]
     c.eps_initial, c.eps_convection_scheme, c.eps_tol, c.eps_rel_tol, c.eps_max_iter, c.eps_relax = eps_initial, int(eps_convection_scheme), eps_tol, eps_rel_tol, int(eps_max_iter), eps_relax
+    c.wf_kappa, c.wf_E = wf_kappa, wf_E
     return c
 
 

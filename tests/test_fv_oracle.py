@@ -528,3 +528,22 @@ def test_kepsilon_decay_of_homogeneous_turbulence(oracle):
     t = dt * (np.arange(2000) + 1) + t0
     slope = np.polyfit(np.log(t[1000:]), np.log(np.array(hist)[1000:]), 1)[0]
     assert abs(slope + 1.0 / 0.92) < 0.02
+
+
+def test_epsilon_wall_function_imposes_the_log_law_value(oracle):
+    """epsilonWallFunction [OF-6]: in the cells next to such a patch the epsilon equation's row is replaced by eps = Cmu^3/4 k^3/2 / (kappa y)
+    (y = dx/2, k of the cell before the update), whatever the other terms say; cells away from the wall solve their equation"""
+    n, dx, k0, e0 = 10, 0.02, 0.04, 0.05
+    bc = [0, 0, 2, 0, 0, 2]                                               # y- and z+ carry the wall function
+    c = oracle.fv_case(1, n, n, n, dx, 1e-3, 1e-5, u_bc=[0] * 6, turbulence_model=3, k_initial=k0, eps_initial=e0, nut_initial=1e-4,
+                       eps_bc=bc, nut_bc=[0, 0, 2, 0, 0, 2], k_tol=1e-13, eps_tol=1e-13)
+    o = oracle.FvSolver(c)
+    o.turbulence_correct()
+    eps = o.get("epsilon").reshape(n, n, n)                               # (k, j, i)
+    wall_value = 0.09 ** 0.75 * k0 ** 1.5 / (0.41 * 0.5 * dx)
+    np.testing.assert_allclose(eps[:, 0, :], wall_value, rtol=1e-13)
+    np.testing.assert_allclose(eps[n - 1, :, :], wall_value, rtol=1e-13)
+    interior = eps[0:n - 4, 4:n, :]
+    assert np.all(np.abs(interior - e0 / (1 + 1e-3 * 1.92 * e0 / k0)) < 1e-6 * e0)      # far from the walls: the homogeneous decay step
+    assert wall_value > 5 * e0                                            # and next to the wall cells diffusion feeds it inwards
+    assert eps[2, 1, 3] > eps[2, 3, 3]

@@ -100,9 +100,10 @@ class CaseDesc(C.Structure):
                 ("ras_cmu", C.c_double), ("ras_c1", C.c_double), ("ras_c2", C.c_double), ("ras_c3", C.c_double), ("ras_sigmak", C.c_double),
                 ("ras_sigmaeps", C.c_double), ("eps_bc", C.c_int32 * 6), ("eps_value", C.c_double * 6), ("eps_initial", C.c_double),
                 ("eps_convection_scheme", C.c_int32), ("eps_tol", C.c_double), ("eps_rel_tol", C.c_double), ("eps_max_iter", C.c_int32),
-                ("eps_relax", C.c_double)]
+                ("eps_relax", C.c_double), ("wf_kappa", C.c_double), ("wf_E", C.c_double)]
 
 
+BC_WALL_FUNCTION = 2
 TURBULENCE_LAMINAR, TURBULENCE_SMAGORINSKY, TURBULENCE_KEQN, TURBULENCE_KEPSILON = 0, 1, 2, 3
 NUT_ZERO_GRADIENT, NUT_FIXED_VALUE = 0, 1
 

@@ -265,8 +265,16 @@ int read_fields(fy_foam_case* c) {
                 const auto* vt = pd->tokens("value");
                 if (!vt || vt->size() < 2 || (*vt)[0] != "uniform" || !fy::foam_tok_is_number((*vt)[1], &c->desc.nut_value[s]))
                     return fail(FY_ERR_UNSUPPORTED, "%s: patch '%s': fixedValue needs 'value uniform <nut>'", path.c_str(), c->patch_of_side[s].c_str());
+            } else if (ty == "nutkWallFunction" && (c->desc.turbulence_model == FY_TURBULENCE_KEQN || c->desc.turbulence_model == FY_TURBULENCE_KEPSILON)) {
+                // [OF-6 nutkWallFunctionFvPatchScalarField]: Cmu / kappa / E may be given per patch; one set serves the case here
+                c->desc.nut_bc[s] = FY_BC_WALL_FUNCTION;
+                const auto* vt = pd->tokens("value");
+                if (vt && vt->size() >= 2 && (*vt)[0] == "uniform") fy::foam_tok_is_number((*vt)[1], &c->desc.nut_value[s]);
+                double cmu = c->desc.ras_cmu;
+                pd->scalar("kappa", &c->desc.wf_kappa); pd->scalar("E", &c->desc.wf_E);
+                if (pd->scalar("Cmu", &cmu) && cmu != c->desc.ras_cmu) return fail(FY_ERR_UNSUPPORTED, "%s: patch '%s': a wall-function Cmu other than the model's is not supported", path.c_str(), c->patch_of_side[s].c_str());
             } else {
-                return fail(FY_ERR_UNSUPPORTED, "%s: patch '%s': nut boundary type '%s' is not supported (zeroGradient, fixedValue; wall functions are not built)", path.c_str(),
+                return fail(FY_ERR_UNSUPPORTED, "%s: patch '%s': nut boundary type '%s' is not supported (zeroGradient, fixedValue, nutkWallFunction with kEqn / kEpsilon)", path.c_str(),
                             c->patch_of_side[s].c_str(), ty.c_str());
             }
         }
@@ -299,8 +307,7 @@ int read_fields(fy_foam_case* c) {
         }
     }
     if (c->desc.turbulence_model == FY_TURBULENCE_KEPSILON) {
-        // epsilon.<phase> [OF-6 kEpsilon: epsilon_ is MUST_READ]; zeroGradient | fixedValue (uniform).  epsilonWallFunction is NOT implemented
-        // (it rewrites the matrix rows of the wall cells, epsEqn.boundaryManipulate): such a case is refused
+        // epsilon.<phase> [OF-6 kEpsilon: epsilon_ is MUST_READ]; zeroGradient | fixedValue (uniform) | epsilonWallFunction
         const std::string path = join(c->dir, c->start_name + "/epsilon." + c->phase);
         FoamDict f;
         FY_TRY(need_file(path, &f));
@@ -320,8 +327,10 @@ int read_fields(fy_foam_case* c) {
                 const auto* vt = pd->tokens("value");
                 if (!vt || vt->size() < 2 || (*vt)[0] != "uniform" || !fy::foam_tok_is_number((*vt)[1], &c->desc.eps_value[s]))
                     return fail(FY_ERR_UNSUPPORTED, "%s: patch '%s': fixedValue needs 'value uniform <epsilon>'", path.c_str(), c->patch_of_side[s].c_str());
+            } else if (ty == "epsilonWallFunction") {
+                c->desc.eps_bc[s] = FY_BC_WALL_FUNCTION;
             } else {
-                return fail(FY_ERR_UNSUPPORTED, "%s: patch '%s': epsilon boundary type '%s' is not supported (zeroGradient, fixedValue; epsilonWallFunction is not built)", path.c_str(),
+                return fail(FY_ERR_UNSUPPORTED, "%s: patch '%s': epsilon boundary type '%s' is not supported (zeroGradient, fixedValue, epsilonWallFunction)", path.c_str(),
                             c->patch_of_side[s].c_str(), ty.c_str());
             }
         }

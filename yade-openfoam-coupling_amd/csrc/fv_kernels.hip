@@ -49,6 +49,17 @@ __device__ __forceinline__ double pbv(const FvGeo& g, const double* p, const CFa
     if (g.p_bc[patch] == 2) return p[c] + (s ? 0.5 : -0.5) * g.dx * psn.a[d][face];
     return p[c];
 }
+// boundary value of nut on patch `patch` next to cell c (FvGeo: nut_bc 0 zeroGradient, 1 fixedValue, 2 nutkWallFunction)
+__device__ __forceinline__ double nut_boundary(const FvGeo& g, int patch, int c) {
+    const int t = g.nut_bc[patch];
+    if (t == 1 || (t == 2 && !g.nut_wall_live)) return g.nut_val[patch];
+    if (t == 2) {
+        const double y = 0.5 * g.dx;
+        const double yPlus = g.wf_cmu25 * y * sqrt(g.kturb[c]) / g.nu;
+        return yPlus > g.wf_yPlusLam ? g.nu * (yPlus * g.wf_kappa / log(g.wf_E * yPlus) - 1.0) : 0.0;
+    }
+    return g.nut[c];
+}
 // Value held by the previous / next lane of the wave (undefined in lane 0 / 63): one DPP move per dword.  A wave's lanes are consecutive
 // x-cells, so the x-neighbours of a stencil are already in registers next door -- two more full-wave loads of an AoS vector field
 // (24 cache lines each way for the address unit) become two single-lane loads at the wave's ends.
@@ -536,7 +547,7 @@ __global__ __launch_bounds__(256) void k_smagorinsky_nut(FvGeo g, const double* 
 // [OF-6 fvm::SuSp: diag += V max(susp, 0), source -= V min(susp, 0) psi; fvm::Sp: diag += V sp; fvMatrix == volField: source += V field]
 __global__ __launch_bounds__(256) void k_assemble_turb(FvGeo g, TurbEqn e, const double* __restrict__ kf, const double* __restrict__ ef,
                                                        const double* __restrict__ alpha, CFace3 alphaf, CFace3 phi, const double* __restrict__ vGrad,
-                                                       Mom7 M, double* __restrict__ b3, double* __restrict__ x3) {
+                                                       const double* __restrict__ U, Mom7 M, double* __restrict__ b3, double* __restrict__ x3) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= g.Nc) return;
     int i, j, k; ijk_of(g, t, i, j, k);
@@ -560,7 +571,7 @@ __global__ __launch_bounds__(256) void k_assemble_turb(FvGeo g, TurbEqn e, const
             if (onb(g, d, s, i, j, k)) {
                 an[2 * d + s] = 0.0;
                 const int patch = 2 * d + s;
-                const double nb = g.nut_bc[patch] == 1 ? g.nut_val[patch] : nutc;
+                const double nb = nut_boundary(g, patch, c);
                 const double gam = (af * (nu + nb / e.sigma)) * g.dx;
                 if (e.bc[patch] == 1) {
                     const double gb = 2.0 * gam;
@@ -587,7 +598,27 @@ __global__ __launch_bounds__(256) void k_assemble_turb(FvGeo g, TurbEqn e, const
     for (int a = 0; a < 3; ++a)
 #pragma unroll
         for (int b = 0; b < 3; ++b) GG += T[3 * a + b] * ((T[3 * a + b] + T[3 * b + a]) - (a == b ? (1.0 / 3.0) * tr2 : 0.0));
-    const double G = nutc * GG;
+    double G = nutc * GG;
+    // epsilonWallFunction: wall value of G, and (in the epsilon equation) the imposed cell value
+    const double ywall = 0.5 * g.dx;
+    int Wc = 0;
+    double Gw = 0.0;
+    if (e.mode != 0) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+                if (e.wall[2 * d + s] && onb(g, d, s, i, j, k)) {
+                    const int patch = 2 * d + s;
+                    double ub[3];
+                    Ub(g, U, c, patch, ub);
+                    const double d0 = (ub[0] - U[3 * (size_t)c]) / ywall, d1 = (ub[1] - U[3 * (size_t)c + 1]) / ywall, d2 = (ub[2] - U[3 * (size_t)c + 2]) / ywall;
+                    const double magGradUw = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
+                    Gw += (nut_boundary(g, patch, c) + nu) * magGradUw * e.cmu25 * sqrt(kf[c]) / (e.kappa * ywall);
+                    ++Wc;
+                }
+        if (Wc) G = Gw / (double)Wc;
+    }
     const double divU = sumPhi * g.rV;
     double Su, c1, c2;
     if (e.mode == 0) { Su = aP * G; c1 = (2.0 / 3.0) * aP * divU; c2 = e.ce * aP * sqrt(xc) / e.delta; }
@@ -602,10 +633,38 @@ __global__ __launch_bounds__(256) void k_assemble_turb(FvGeo g, TurbEqn e, const
         src += (dn - dg) * xc;
         dg = dn;
     }
+    double x0 = xc;
+    if (e.mode == 1) {
+        // epsEqn.boundaryManipulate -> fvMatrix::setValues(faceCells, value) [OF-6 fvMatrix.C setValuesFromList]
+        if (Wc) {
+            const double v = e.cmu75 * pow(kf[c], 1.5) / (e.kappa * ywall);
+            for (int q = 0; q < 6; ++q) an[q] = 0.0;
+            src = dg * v;
+            x0 = v;
+        } else {
+#pragma unroll
+            for (int d = 0; d < 3; ++d)
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+                    if (!onb(g, d, s, i, j, k)) {
+                        const int ni = i + (d == 0 ? (s ? 1 : -1) : 0), nj = j + (d == 1 ? (s ? 1 : -1) : 0), nk = k + (d == 2 ? (s ? 1 : -1) : 0);
+                        bool nwall = false;
+#pragma unroll
+                        for (int d2 = 0; d2 < 3; ++d2)
+#pragma unroll
+                            for (int s2 = 0; s2 < 2; ++s2) nwall = nwall || (e.wall[2 * d2 + s2] && onb(g, d2, s2, ni, nj, nk));
+                        if (nwall) {
+                            const int nbc = c + (s ? stride_of(g, d) : -stride_of(g, d));
+                            src -= an[2 * d + s] * (e.cmu75 * pow(kf[nbc], 1.5) / (e.kappa * ywall));
+                            an[2 * d + s] = 0.0;
+                        }
+                    }
+        }
+    }
     M.diag[c] = dg;
     for (int q = 0; q < 6; ++q) M.an[q][c] = an[q];
     b3[3 * (size_t)c] = src; b3[3 * (size_t)c + 1] = 0.0; b3[3 * (size_t)c + 2] = 0.0;
-    x3[3 * (size_t)c] = xc; x3[3 * (size_t)c + 1] = 0.0; x3[3 * (size_t)c + 2] = 0.0;
+    x3[3 * (size_t)c] = x0; x3[3 * (size_t)c + 1] = 0.0; x3[3 * (size_t)c + 2] = 0.0;
 }
 
 // bound(X, XMin) [OF-6 finiteVolume/cfdTools/general/bound/bound.C]: X = max(max(X, fvc::average(max(X, XMin)) pos0(-X)), XMin) -- the
@@ -671,7 +730,7 @@ __global__ __launch_bounds__(256) void k_assemble_momentum(FvGeo g, const double
             double gam = nu * af * g.dx;
             if (g.nut) {
                 if (onb(g, d, s, i, j, k)) {
-                    const double nb = g.nut_bc[2 * d + s] == 1 ? g.nut_val[2 * d + s] : g.nut[c];
+                    const double nb = nut_boundary(g, 2 * d + s, c);
                     gam = (af * (nu + nb)) * g.dx;
                 } else {
                     const int nbc = c + (s ? stride_of(g, d) : -stride_of(g, d));
@@ -1466,8 +1525,8 @@ int launch_div_G(hipStream_t s, FvGeo g, const double* G, double* divG) {
 }
 
 int launch_assemble_turb(hipStream_t s, FvGeo g, TurbEqn e, const double* k, const double* eps, const double* alpha, CFace3 alphaf, CFace3 phi,
-                         const double* vGrad, Mom7 M, double* b3, double* x3) {
-    hipLaunchKernelGGL(k_assemble_turb, dim3(div_up(g.Nc, 256)), dim3(256), 0, s, g, e, k, eps, alpha, alphaf, phi, vGrad, M, b3, x3);
+                         const double* vGrad, const double* U, Mom7 M, double* b3, double* x3) {
+    hipLaunchKernelGGL(k_assemble_turb, dim3(div_up(g.Nc, 256)), dim3(256), 0, s, g, e, k, eps, alpha, alphaf, phi, vGrad, U, M, b3, x3);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }

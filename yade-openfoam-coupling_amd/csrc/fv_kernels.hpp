@@ -30,6 +30,13 @@ struct FvGeo {
     const double* nut;      // [storage cells] eddy viscosity of the Smagorinsky model (k_smagorinsky_nut), ghost planes refreshed by the solver
     int nut_bc[6];          // FY_BC_NUT_*
     double nut_val[6];
+    // wall functions: nut_bc == 2 is nutkWallFunction [OF-6 nutkWallFunctionFvPatchScalarField.C]: nut_w = nu (y+ kappa / ln(E y+) - 1) where
+    // y+ = Cmu^1/4 y sqrt(k_P) / nu exceeds yPlusLam, else 0 (y = dx/2: the wall cell's centre distance).  The boundary values OpenFOAM keeps
+    // are those of the last correctNut(); k does not change in between, so they are evaluated where they are used -- except before the
+    // first correct(), when the 0/nut file's value stands (nut_wall_live = 0)
+    const double* kturb;    // [storage cells] k of the kEqn / kEpsilon models (nullptr: none)
+    int nut_wall_live;
+    double wf_cmu25, wf_kappa, wf_E, wf_yPlusLam;
     double u_relax;         // fvMatrix::relax factor of UcEqn for the current outer iteration (<= 0: no relaxationFactors entry, relax() is a no-op)
     double g[3];
     int need_ref, p_ref_cell;
@@ -77,11 +84,15 @@ int launch_div_G(hipStream_t s, FvGeo g, const double* G, double* divG);
 // mode 2  kEpsilon  X = k:    Su = alpha G,            c1 = 2/3 alpha divU,            c2 = alpha eps / k  (eps already new)  (sigma = sigmak)
 // with G = nut (gradU && dev(twoSymm(gradU))), divU = fvc::div(phi).  bc / val: boundary conditions of X (0 zeroGradient, 1 fixedValue);
 // upwind: convection scheme of X (0 Gauss linear, 1 Gauss upwind); relax: relaxation factor of the equation (<= 0: none); xmin: bound()
-struct TurbEqn { int mode; double ck, ce, delta, c1, c2, c3, sigma, xmin, relax; int upwind; int bc[6]; double val[6]; };
+// wall[p] = 1: patch p carries epsilonWallFunction [OF-6 epsilonWallFunctionFvPatchScalarField.C]: in the cells next to it
+//   eps = Cmu^3/4 k^3/2 / (kappa y) is IMPOSED (fvMatrix::setValues: the row becomes diag x = diag value, the neighbours' coefficients towards the
+//   cell move to their sources) and the production G of both equations is replaced by the corner-weighted wall value
+//   (1/W) sum_faces (nut_w + nu) |snGrad U| Cmu^1/4 sqrt(k) / (kappa y)
+struct TurbEqn { int mode; double ck, ce, delta, c1, c2, c3, sigma, xmin, relax; int upwind; int bc[6]; double val[6]; int wall[6]; double cmu75, cmu25, kappa; };
 // assembles the equation into the momentum matrix's storage (free after the correctors) as a 3-component system whose components 1, 2 are
 // identically zero, so that the momentum solver's Jacobi pass solves it: x3 = {X, 0, 0}, b3 = {source, 0, 0}
 int launch_assemble_turb(hipStream_t s, FvGeo g, TurbEqn e, const double* k, const double* eps, const double* alpha, CFace3 alphaf, CFace3 phi,
-                         const double* vGrad, Mom7 M, double* b3, double* x3);
+                         const double* vGrad, const double* U, Mom7 M, double* b3, double* x3);
 // bound(X, xmin) [OF-6 bound.C] on the solved component 0 of x3 -> X; nut_mode 1: nut = Ck sqrt(k) delta (kEqn::correctNut, X = k),
 // 2: nut = Cmu k^2 / eps (kEpsilon::correctNut, X = k, eps given), 0: leave nut alone (the epsilon equation)
 int launch_turb_finish(hipStream_t s, FvGeo g, TurbEqn e, const double* x3, double* X, int nut_mode, double cmu, const double* eps, double* nut);

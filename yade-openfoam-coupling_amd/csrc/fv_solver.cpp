@@ -168,10 +168,19 @@ struct Solver {
             if (!pimple) return fail(FY_ERR_INVALID, "fy_solver_create: icoFoamYade has no turbulence model (icoFoamYade.C:79-85 is laplacian(nu, U))");
             if (!(c->les_ck > 0 && c->les_ce > 0 && c->les_delta_coeff > 0) || c->nut_initial < 0) return fail(FY_ERR_INVALID, "fy_solver_create: Smagorinsky needs Ck, Ce, deltaCoeff > 0 and nut >= 0");
             for (int q = 0; q < 6; ++q) {
-                if (c->nut_bc[q] != FY_BC_NUT_ZERO_GRADIENT && c->nut_bc[q] != FY_BC_NUT_FIXED_VALUE) return fail(FY_ERR_INVALID, "fy_solver_create: unknown nut boundary type");
+                const bool has_k = c->turbulence_model == FY_TURBULENCE_KEQN || c->turbulence_model == FY_TURBULENCE_KEPSILON;
+                if (c->nut_bc[q] != FY_BC_NUT_ZERO_GRADIENT && c->nut_bc[q] != FY_BC_NUT_FIXED_VALUE && !(c->nut_bc[q] == FY_BC_WALL_FUNCTION && has_k))
+                    return fail(FY_ERR_INVALID, "fy_solver_create: unknown nut boundary type (nutkWallFunction needs a model with a k equation)");
                 g.nut_bc[q] = c->nut_bc[q]; g.nut_val[q] = c->nut_value[q];
             }
             les_delta = c->les_delta_coeff * std::pow(g.V, 1.0 / 3.0);
+            {   // nutWallFunction::yPlusLam [OF-6 nutWallFunctionFvPatchScalarField.C]
+                if (!(c->wf_kappa > 0 && c->wf_E > 0)) return fail(FY_ERR_INVALID, "fy_solver_create: wall-function constants kappa, E must be positive");
+                double ypl = 11.0;
+                for (int it = 0; it < 10; ++it) ypl = std::log(std::max(c->wf_E * ypl, 1.0)) / c->wf_kappa;
+                g.wf_yPlusLam = ypl; g.wf_kappa = c->wf_kappa; g.wf_E = c->wf_E; g.wf_cmu25 = std::pow(c->ras_cmu, 0.25);
+                g.nut_wall_live = 0;
+            }
             const bool keqn = c->turbulence_model == FY_TURBULENCE_KEQN, keps = c->turbulence_model == FY_TURBULENCE_KEPSILON;
             if (keqn || keps) {
                 if (!(c->k_initial >= 0) || (keps && !(c->k_initial > 0)) || !(c->k_tol >= 0) || c->k_max_iter < 0 || c->k_relax > 1) return fail(FY_ERR_INVALID, "fy_solver_create: the k equation needs k >= 0 (> 0 for kEpsilon), a solver tolerance and a relaxation factor in (0, 1]");
@@ -193,9 +202,12 @@ struct Solver {
                 eq_eps.mode = 1; eq_eps.sigma = c->ras_sigmaeps; eq_eps.xmin = 1e-15;                        // epsilonMin_ = small [OF-6 RASModel.C]
                 eq_eps.relax = c->eps_relax; eq_eps.upwind = c->eps_convection_scheme == FY_CONVECTION_UPWIND ? 1 : 0;
                 for (int q = 0; q < 6; ++q) {
-                    if (c->eps_bc[q] != FY_BC_NUT_ZERO_GRADIENT && c->eps_bc[q] != FY_BC_NUT_FIXED_VALUE) return fail(FY_ERR_INVALID, "fy_solver_create: unknown epsilon boundary type");
-                    eq_eps.bc[q] = c->eps_bc[q]; eq_eps.val[q] = c->eps_value[q];
+                    if (c->eps_bc[q] != FY_BC_NUT_ZERO_GRADIENT && c->eps_bc[q] != FY_BC_NUT_FIXED_VALUE && c->eps_bc[q] != FY_BC_WALL_FUNCTION) return fail(FY_ERR_INVALID, "fy_solver_create: unknown epsilon boundary type");
+                    // an epsilonWallFunction patch behaves like a zero-gradient one wherever its face value would be asked for: the wall cells' rows are imposed
+                    eq_eps.bc[q] = c->eps_bc[q] == FY_BC_WALL_FUNCTION ? 0 : c->eps_bc[q]; eq_eps.val[q] = c->eps_value[q];
+                    eq_eps.wall[q] = eq_k.wall[q] = c->eps_bc[q] == FY_BC_WALL_FUNCTION ? 1 : 0;
                 }
+                eq_eps.cmu75 = eq_k.cmu75 = std::pow(c->ras_cmu, 0.75); eq_eps.cmu25 = eq_k.cmu25 = std::pow(c->ras_cmu, 0.25); eq_eps.kappa = eq_k.kappa = c->wf_kappa;
             }
         }
         if (c->adjust_time_step && !(c->max_co > 0 && c->max_delta_t > 0)) return fail(FY_ERR_INVALID, "adjustTimeStep needs maxCo > 0 and maxDeltaT > 0");
@@ -226,7 +238,7 @@ struct Solver {
         for (auto& b : man) { FY_TRY(b.alloc_exact(n)); FY_TRY(zero(b)); }
         FY_TRY(vGrad.alloc_exact(9 * n)); FY_TRY(zero(vGrad));
         if (c->turbulence_model != FY_TURBULENCE_LAMINAR) { FY_TRY(nut.alloc_exact(n)); FY_TRY(launch_fill_f64(stream, nut.p, n, c->nut_initial)); g.nut = nut.p; }
-        if (c->turbulence_model == FY_TURBULENCE_KEQN || c->turbulence_model == FY_TURBULENCE_KEPSILON) { FY_TRY(kturb.alloc_exact(n)); FY_TRY(launch_fill_f64(stream, kturb.p, n, c->k_initial)); }
+        if (c->turbulence_model == FY_TURBULENCE_KEQN || c->turbulence_model == FY_TURBULENCE_KEPSILON) { FY_TRY(kturb.alloc_exact(n)); FY_TRY(launch_fill_f64(stream, kturb.p, n, c->k_initial)); g.kturb = kturb.p; }
         if (c->turbulence_model == FY_TURBULENCE_KEPSILON) { FY_TRY(epsturb.alloc_exact(n)); FY_TRY(launch_fill_f64(stream, epsturb.p, n, c->eps_initial)); }
         FY_TRY(Gt.alloc_exact(9 * n)); FY_TRY(zero(Gt));
         for (int d = 0; d < 3; ++d) {
@@ -707,17 +719,19 @@ struct Solver {
             FY_TRY(halo_cells(kturb, 1, 1));
             if (keps) {
                 FY_TRY(halo_cells(epsturb, 1, 1));
-                FY_TRY(launch_assemble_turb(stream, g, eq_eps, kturb.p, epsturb.p, alpha.p, C3(alphaf), C3(phi), vGrad.p, M7(), bmom.p, HbyA.p));
+                FY_TRY(launch_assemble_turb(stream, g, eq_eps, kturb.p, epsturb.p, alpha.p, C3(alphaf), C3(phi), vGrad.p, U.p, M7(), bmom.p, HbyA.p));
                 FY_TRY(solve_vec3(HbyA, bmom.p, cs.eps_tol, cs.eps_rel_tol, cs.eps_max_iter, &it));
                 st_k_iters += it;
                 FY_TRY(halo_cells(HbyA, 3, 1));
                 FY_TRY(launch_turb_finish(stream, g, eq_eps, HbyA.p, epsturb.p, 0, 0.0, nullptr, nullptr));
             }
-            FY_TRY(launch_assemble_turb(stream, g, eq_k, kturb.p, epsturb.p, alpha.p, C3(alphaf), C3(phi), vGrad.p, M7(), bmom.p, HbyA.p));
+            FY_TRY(launch_assemble_turb(stream, g, eq_k, kturb.p, epsturb.p, alpha.p, C3(alphaf), C3(phi), vGrad.p, U.p, M7(), bmom.p, HbyA.p));
             FY_TRY(solve_vec3(HbyA, bmom.p, cs.k_tol, cs.k_rel_tol, cs.k_max_iter, &it));
             st_k_iters += it;
             FY_TRY(halo_cells(HbyA, 3, 1));
             FY_TRY(launch_turb_finish(stream, g, eq_k, HbyA.p, kturb.p, keps ? 2 : 1, cs.ras_cmu, epsturb.p, nut.p));
+            FY_TRY(halo_cells(kturb, 1, 1));
+            g.nut_wall_live = 1;              // correctNut(): from now on the wall-function patches carry nut_w(k), not the file's value
             return halo_cells(nut, 1, 1);
         }
         FY_TRY(launch_smagorinsky_nut(stream, g, vGrad.p, cs.les_ck, cs.les_ce, les_delta, nut.p));
@@ -903,6 +917,7 @@ void fy_case_defaults(fy_case_desc* c, int solver) {
     c->u_relax = 1.0; c->u_relax_final = 0.0; c->p_relax = 0.0; c->p_relax_final = 0.0;
     c->k_tol = 1e-6; c->k_rel_tol = 0.0; c->k_max_iter = 1000; c->k_relax = 0.0; c->k_convection_scheme = FY_CONVECTION_UPWIND;
     c->eps_tol = 1e-6; c->eps_rel_tol = 0.0; c->eps_max_iter = 1000; c->eps_relax = 0.0; c->eps_convection_scheme = FY_CONVECTION_UPWIND;
+    c->wf_kappa = 0.41; c->wf_E = 9.8;                      // [OF-6 nutWallFunctionFvPatchScalarField defaults]
     c->ras_cmu = 0.09; c->ras_c1 = 1.44; c->ras_c2 = 1.92; c->ras_c3 = 0.0; c->ras_sigmak = 1.0; c->ras_sigmaeps = 1.3;      // [OF-6 kEpsilon.C defaults]
     c->turbulence_model = FY_TURBULENCE_LAMINAR; c->les_ck = 0.094; c->les_ce = 1.048; c->les_delta_coeff = 1.0;     // [OF-6 Smagorinsky.C, cubeRootVolDelta.C defaults]
 }
