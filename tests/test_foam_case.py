@@ -420,3 +420,44 @@ def test_ras_kepsilon_case_is_read(prod, tmp_path):
     with pytest.raises(prod.FoamYadeError) as e:
         prod.FoamCase(dst, prod.FY_SOLVER_PIMPLE)
     assert "epsilonLowReWallFunction" in str(e.value) and "epsilon.water" in str(e.value)
+
+
+@pytest.mark.gpu
+def test_foamYadeHip_executable_runs_a_kepsilon_case(prod, tmp_path):
+    """the executable on the bed case with RAS kEpsilon and wall functions on the walls: start-time nut / k / epsilon handed to the solver, the three
+    fields written with the time directories, same numbers as driving the library from Python"""
+    import subprocess
+    exe = os.path.join(os.path.dirname(HERE), "yade-openfoam-coupling_amd", "bin", "foamYadeHip")
+    if not os.path.exists(exe):
+        pytest.fail("foamYadeHip has not been built: run __graft_entry__.build()")
+    dst = les_case(tmp_path)
+    (dst / "constant/turbulenceProperties.water").write_text("simulationType RAS;\nRAS { RASModel kEpsilon; turbulence on; }\n")
+    base = NUT_FILE.replace("walls  { type zeroGradient; }", "walls  { type WALLTYPE; value uniform VAL; }")
+    (dst / "0/nut.water").write_text(base.replace("WALLTYPE", "nutkWallFunction").replace("VAL", "0"))
+    (dst / "0/k.water").write_text(base.replace("object nut.water", "object k.water").replace("[0 2 -1 0 0 0 0]", "[0 2 -2 0 0 0 0]").replace("uniform 2e-6", "uniform 3e-4")
+                                   .replace("uniform 1e-6", "uniform 2e-4").replace("WALLTYPE", "kqRWallFunction").replace("VAL", "3e-4"))
+    (dst / "0/epsilon.water").write_text(base.replace("object nut.water", "object epsilon.water").replace("[0 2 -1 0 0 0 0]", "[0 2 -3 0 0 0 0]").replace("uniform 2e-6", "uniform 5e-3")
+                                         .replace("uniform 1e-6", "uniform 4e-3").replace("WALLTYPE", "epsilonWallFunction").replace("VAL", "5e-3"))
+    out = subprocess.run([exe, "-solver", "pimple", "-case", str(dst)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    times = sorted((d for d in os.listdir(dst) if d[0].isdigit()), key=float)
+    assert len(times) >= 2
+    last = times[-1]
+    for f in ("U.water", "p", "alpha.water", "nut.water", "k.water", "epsilon.water"):
+        assert os.path.exists(dst / last / f), f
+    fc = prod.FoamCase(dst, prod.FY_SOLVER_PIMPLE)
+    s = prod.Solver(fc.case)
+    U0, p0 = fc.initial_fields()
+    s.set("U", U0); s.set("p", p0); s.set("nut", fc.initial_nut()); s.set("k", fc.initial_k()); s.set("epsilon", fc.initial_epsilon())
+    nsteps = int(round((float(last) - fc.start_time) / fc.delta_t))
+    for _ in range(nsteps):
+        s.step()
+    (dst / "system/controlDict").write_text((dst / "system/controlDict").read_text().replace("startTime       0;", "startTime       %s;" % last))
+    fc2 = prod.FoamCase(dst, prod.FY_SOLVER_PIMPLE)
+    np.testing.assert_array_equal(fc2.initial_k(), s.get("k"))
+    np.testing.assert_array_equal(fc2.initial_epsilon(), s.get("epsilon"))
+    np.testing.assert_array_equal(fc2.initial_nut(), s.get("nut"))
+    assert not np.all(s.get("k") == 3e-4)
+    for o in (fc, fc2):
+        o.close()
+    s.close()
