@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define FY_ABI_VERSION 7
+#define FY_ABI_VERSION 8
 
 /* ---- status codes ------------------------------------------------------------------------------------ */
 enum {
@@ -198,6 +198,7 @@ enum { FY_PSOLVER_PCG_JACOBI = 0, FY_PSOLVER_PCG_MG = 1 };
 #define FY_TURBULENCE_KEPSILON 3       /* simulationType RAS, RASModel kEpsilon (DPMTurbulenceModels.C:70-71); no wall functions */
 #define FY_BC_NUT_ZERO_GRADIENT 0
 #define FY_BC_NUT_FIXED_VALUE 1
+#define FY_BC_NUT_CALCULATED 3          /* nut_bc: `calculated` patch = the model's expression on the boundary values of k (and epsilon); kEqn / kEpsilon */
 #define FY_BC_WALL_FUNCTION 2           /* nut_bc: nutkWallFunction (needs a model with k); eps_bc: epsilonWallFunction; k takes zeroGradient (kqRWallFunction) */
 typedef struct fy_case_desc {
     int32_t solver;                 /* FY_SOLVER_ICO | FY_SOLVER_PIMPLE */

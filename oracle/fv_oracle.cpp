@@ -272,7 +272,13 @@ struct Fv {
     bool nut_wall_live = false;
     double nut_boundary(int patch, int c) const {
         const int t = cs.nut_bc[patch];
-        if (t == 1 || (t == 2 && !nut_wall_live)) return cs.nut_value[patch];
+        if (t == 1 || ((t == 2 || t == 3) && !nut_wall_live)) return cs.nut_value[patch];
+        if (t == 3) {       // calculated: nut_ = <model expression> assigns the boundary too [OF-6 GeometricField::operator=]: Ck sqrt(k_b) delta | Cmu k_b^2/eps_b
+            const double kb = cs.k_bc[patch] == 1 ? cs.k_value[patch] : kturb[c];
+            if (cs.turbulence_model == 2) return cs.les_ck * std::sqrt(kb) * (cs.les_delta_coeff * std::pow(V, 1.0 / 3.0));
+            const double eb = cs.eps_bc[patch] == 1 ? cs.eps_value[patch] : epsturb[c];
+            return cs.ras_cmu * (kb * kb) / eb;
+        }
         if (t == 2) {
             double ypl = 11.0;
             for (int it = 0; it < 10; ++it) ypl = std::log(std::max(cs.wf_E * ypl, 1.0)) / cs.wf_kappa;

@@ -409,11 +409,12 @@ def test_ras_kepsilon_case_is_read(prod, tmp_path):
     fc.close()
     # wall functions on the walls: epsilonWallFunction, nutkWallFunction (kappa / E from the patch), kqRWallFunction
     (dst / "0/epsilon.water").write_text(efile.replace("walls  { type zeroGradient; }", "walls  { type epsilonWallFunction; value uniform 5e-3; }"))
-    (dst / "0/nut.water").write_text(NUT_FILE.replace("walls  { type zeroGradient; }", "walls  { type nutkWallFunction; kappa 0.4; E 9.0; value uniform 0; }"))
+    (dst / "0/nut.water").write_text(NUT_FILE.replace("walls  { type zeroGradient; }", "walls  { type nutkWallFunction; kappa 0.4; E 9.0; value uniform 0; }")
+                                     .replace("top    { type zeroGradient; }", "top    { type calculated; value uniform 3e-6; }"))
     (dst / "0/k.water").write_text(kfile.replace("walls  { type zeroGradient; }", "walls  { type kqRWallFunction; value uniform 3e-4; }"))
     fc = prod.FoamCase(dst, prod.FY_SOLVER_PIMPLE)
     c = fc.case
-    assert list(c.eps_bc) == [2, 2, 2, 2, 1, 0] and list(c.nut_bc) == [2, 2, 2, 2, 1, 0] and list(c.k_bc) == [0, 0, 0, 0, 1, 0]
+    assert list(c.eps_bc) == [2, 2, 2, 2, 1, 0] and list(c.nut_bc) == [2, 2, 2, 2, 1, 3] and list(c.k_bc) == [0, 0, 0, 0, 1, 0] and c.nut_value[ZMAX] == 3e-6
     assert (c.wf_kappa, c.wf_E) == (0.4, 9.0)
     fc.close()
     (dst / "0/epsilon.water").write_text(efile.replace("walls  { type zeroGradient; }", "walls  { type epsilonLowReWallFunction; value uniform 5e-3; }"))

@@ -343,7 +343,7 @@ def test_keqn_matches_oracle(product, oracle, k_scheme):
     dx = 0.1 / n
     u_val = [(0, 0, 0)] * 6
     u_val[YMAX] = (0.5, 0, 0)
-    kw = dict(turbulence_model=2, les_ck=0.2, nut_bc=[0, 0, 1, 0, 1, 1], nut_value=[0, 0, 0.0, 0, 2e-5, 0.0], nut_initial=3e-5,
+    kw = dict(turbulence_model=2, les_ck=0.2, nut_bc=[0, 3, 1, 3, 1, 1], nut_value=[0, 1e-5, 0.0, 4e-5, 2e-5, 0.0], nut_initial=3e-5,
               k_bc=[0, 1, 1, 1, 0, 1], k_value=[0, 1e-4, 0.0, 2e-4, 0, 0.0], k_initial=5e-4, k_convection_scheme=k_scheme, k_tol=1e-9, k_relax=0.9)
     o, s = both(product, oracle, 1, n, n, n, dx, 2e-4, 1e-5, g=(0, 0, -9.81), u_bc=[0] * 6, u_val=u_val, p_bc=[2] * 6, **kw)
     np.testing.assert_array_equal(s.get("k"), 5e-4)
@@ -393,7 +393,7 @@ def test_kepsilon_with_wall_functions_matches_oracle(product, oracle):
     dx = 0.1 / n
     u_val = [(0, 0, 0)] * 6
     u_val[YMAX] = (2.0, 0, 0)
-    kw = dict(turbulence_model=3, nut_bc=[2, 0, 2, 2, 1, 0], nut_value=[0, 0, 0, 0, 1e-5, 0], nut_initial=2e-5,
+    kw = dict(turbulence_model=3, nut_bc=[2, 3, 2, 2, 1, 3], nut_value=[0, 3e-5, 0, 0, 1e-5, 1e-5], nut_initial=2e-5,      # (x+ and z+: `calculated` nut)
               k_bc=[0, 0, 0, 0, 1, 0], k_value=[0, 0, 0, 0, 2e-3, 0], k_initial=4e-3, k_convection_scheme=1, k_tol=1e-9,
               eps_bc=[2, 0, 2, 2, 1, 0], eps_value=[0, 0, 0, 0, 0.05, 0], eps_initial=0.02, eps_convection_scheme=1, eps_tol=1e-9)
     o, s = both(product, oracle, 1, n, n, n, dx, 2e-4, 1e-6, g=(0, 0, -9.81), u_bc=[0] * 6, u_val=u_val, p_bc=[2] * 6, **kw)
@@ -410,7 +410,7 @@ def test_kepsilon_with_wall_functions_matches_oracle(product, oracle):
     eps = s.get("epsilon").reshape(n, n, n)
     assert eps[:, 0, :].min() > 1.3 * eps[n // 2, n // 2, n // 2]          # the wall cells sit on the log-law value (exact check: test_fv_oracle.py), above the core's
     # y+ of the lid-side cells is beyond the laminar sub-layer, so nut_w is live there: the run differs from the same case without wall functions
-    kw2 = dict(kw, nut_bc=[0, 0, 0, 0, 1, 0], eps_bc=[0, 0, 0, 0, 1, 0])
+    kw2 = dict(kw, nut_bc=[0, 3, 0, 0, 1, 3], eps_bc=[0, 0, 0, 0, 1, 0])
     o2, s2 = both(product, oracle, 1, n, n, n, dx, 2e-4, 1e-6, g=(0, 0, -9.81), u_bc=[0] * 6, u_val=u_val, p_bc=[2] * 6, **kw2)
     for step in range(4):
         s2.set_particles(gc.particle_records(case, step))

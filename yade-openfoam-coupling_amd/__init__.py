@@ -103,7 +103,7 @@ class CaseDesc(C.Structure):
                 ("eps_relax", C.c_double), ("wf_kappa", C.c_double), ("wf_E", C.c_double)]
 
 
-BC_WALL_FUNCTION = 2
+BC_WALL_FUNCTION, BC_NUT_CALCULATED = 2, 3
 TURBULENCE_LAMINAR, TURBULENCE_SMAGORINSKY, TURBULENCE_KEQN, TURBULENCE_KEPSILON = 0, 1, 2, 3
 NUT_ZERO_GRADIENT, NUT_FIXED_VALUE = 0, 1
 

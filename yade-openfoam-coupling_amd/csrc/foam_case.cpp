@@ -265,6 +265,10 @@ int read_fields(fy_foam_case* c) {
                 const auto* vt = pd->tokens("value");
                 if (!vt || vt->size() < 2 || (*vt)[0] != "uniform" || !fy::foam_tok_is_number((*vt)[1], &c->desc.nut_value[s]))
                     return fail(FY_ERR_UNSUPPORTED, "%s: patch '%s': fixedValue needs 'value uniform <nut>'", path.c_str(), c->patch_of_side[s].c_str());
+            } else if (ty == "calculated" && (c->desc.turbulence_model == FY_TURBULENCE_KEQN || c->desc.turbulence_model == FY_TURBULENCE_KEPSILON)) {
+                c->desc.nut_bc[s] = FY_BC_NUT_CALCULATED;              // file value until the first correct(), the model's expression afterwards
+                const auto* vt = pd->tokens("value");
+                if (vt && vt->size() >= 2 && (*vt)[0] == "uniform") fy::foam_tok_is_number((*vt)[1], &c->desc.nut_value[s]);
             } else if (ty == "nutkWallFunction" && (c->desc.turbulence_model == FY_TURBULENCE_KEQN || c->desc.turbulence_model == FY_TURBULENCE_KEPSILON)) {
                 // [OF-6 nutkWallFunctionFvPatchScalarField]: Cmu / kappa / E may be given per patch; one set serves the case here
                 c->desc.nut_bc[s] = FY_BC_WALL_FUNCTION;
@@ -274,7 +278,7 @@ int read_fields(fy_foam_case* c) {
                 pd->scalar("kappa", &c->desc.wf_kappa); pd->scalar("E", &c->desc.wf_E);
                 if (pd->scalar("Cmu", &cmu) && cmu != c->desc.ras_cmu) return fail(FY_ERR_UNSUPPORTED, "%s: patch '%s': a wall-function Cmu other than the model's is not supported", path.c_str(), c->patch_of_side[s].c_str());
             } else {
-                return fail(FY_ERR_UNSUPPORTED, "%s: patch '%s': nut boundary type '%s' is not supported (zeroGradient, fixedValue, nutkWallFunction with kEqn / kEpsilon)", path.c_str(),
+                return fail(FY_ERR_UNSUPPORTED, "%s: patch '%s': nut boundary type '%s' is not supported (zeroGradient, fixedValue; calculated / nutkWallFunction with kEqn / kEpsilon)", path.c_str(),
                             c->patch_of_side[s].c_str(), ty.c_str());
             }
         }

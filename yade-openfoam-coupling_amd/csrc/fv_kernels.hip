@@ -52,7 +52,13 @@ __device__ __forceinline__ double pbv(const FvGeo& g, const double* p, const CFa
 // boundary value of nut on patch `patch` next to cell c (FvGeo: nut_bc 0 zeroGradient, 1 fixedValue, 2 nutkWallFunction)
 __device__ __forceinline__ double nut_boundary(const FvGeo& g, int patch, int c) {
     const int t = g.nut_bc[patch];
-    if (t == 1 || (t == 2 && !g.nut_wall_live)) return g.nut_val[patch];
+    if (t == 1 || ((t == 2 || t == 3) && !g.nut_wall_live)) return g.nut_val[patch];
+    if (t == 3) {                                       // calculated: the model's expression on the boundary values
+        const double kb = g.k_bc[patch] == 1 ? g.k_val[patch] : g.kturb[c];
+        if (g.turb_model == 2) return g.turb_ck * sqrt(kb) * g.turb_delta;
+        const double eb = g.eps_bc[patch] == 1 ? g.eps_val[patch] : g.epsturb[c];
+        return g.turb_cmu * (kb * kb) / eb;
+    }
     if (t == 2) {
         const double y = 0.5 * g.dx;
         const double yPlus = g.wf_cmu25 * y * sqrt(g.kturb[c]) / g.nu;

@@ -34,6 +34,11 @@ struct FvGeo {
     // y+ = Cmu^1/4 y sqrt(k_P) / nu exceeds yPlusLam, else 0 (y = dx/2: the wall cell's centre distance).  The boundary values OpenFOAM keeps
     // are those of the last correctNut(); k does not change in between, so they are evaluated where they are used -- except before the
     // first correct(), when the 0/nut file's value stands (nut_wall_live = 0)
+    // nut_bc == 3 is a `calculated` patch: after correctNut() it holds the model's expression evaluated with the boundary values of k (and epsilon):
+    // Ck sqrt(k_b) delta (turb_model 2, kEqn) or Cmu k_b^2 / eps_b (3, kEpsilon); k_b / eps_b = the patch value, or the cell's for zeroGradient
+    int turb_model; double turb_ck, turb_cmu, turb_delta;
+    const double* epsturb;  // [storage cells] epsilon (kEpsilon)
+    int k_bc[6], eps_bc[6]; double k_val[6], eps_val[6];
     const double* kturb;    // [storage cells] k of the kEqn / kEpsilon models (nullptr: none)
     int nut_wall_live;
     double wf_cmu25, wf_kappa, wf_E, wf_yPlusLam;

@@ -169,8 +169,8 @@ struct Solver {
             if (!(c->les_ck > 0 && c->les_ce > 0 && c->les_delta_coeff > 0) || c->nut_initial < 0) return fail(FY_ERR_INVALID, "fy_solver_create: Smagorinsky needs Ck, Ce, deltaCoeff > 0 and nut >= 0");
             for (int q = 0; q < 6; ++q) {
                 const bool has_k = c->turbulence_model == FY_TURBULENCE_KEQN || c->turbulence_model == FY_TURBULENCE_KEPSILON;
-                if (c->nut_bc[q] != FY_BC_NUT_ZERO_GRADIENT && c->nut_bc[q] != FY_BC_NUT_FIXED_VALUE && !(c->nut_bc[q] == FY_BC_WALL_FUNCTION && has_k))
-                    return fail(FY_ERR_INVALID, "fy_solver_create: unknown nut boundary type (nutkWallFunction needs a model with a k equation)");
+                if (c->nut_bc[q] != FY_BC_NUT_ZERO_GRADIENT && c->nut_bc[q] != FY_BC_NUT_FIXED_VALUE && !((c->nut_bc[q] == FY_BC_WALL_FUNCTION || c->nut_bc[q] == FY_BC_NUT_CALCULATED) && has_k))
+                    return fail(FY_ERR_INVALID, "fy_solver_create: unknown nut boundary type (nutkWallFunction / calculated need a model with a k equation)");
                 g.nut_bc[q] = c->nut_bc[q]; g.nut_val[q] = c->nut_value[q];
             }
             les_delta = c->les_delta_coeff * std::pow(g.V, 1.0 / 3.0);
@@ -180,6 +180,11 @@ struct Solver {
                 for (int it = 0; it < 10; ++it) ypl = std::log(std::max(c->wf_E * ypl, 1.0)) / c->wf_kappa;
                 g.wf_yPlusLam = ypl; g.wf_kappa = c->wf_kappa; g.wf_E = c->wf_E; g.wf_cmu25 = std::pow(c->ras_cmu, 0.25);
                 g.nut_wall_live = 0;
+                g.turb_model = c->turbulence_model; g.turb_ck = c->les_ck; g.turb_cmu = c->ras_cmu; g.turb_delta = les_delta;
+                for (int q = 0; q < 6; ++q) {
+                    g.k_bc[q] = c->k_bc[q]; g.k_val[q] = c->k_value[q];
+                    g.eps_bc[q] = c->eps_bc[q] == FY_BC_NUT_FIXED_VALUE ? 1 : 0; g.eps_val[q] = c->eps_value[q];
+                }
             }
             const bool keqn = c->turbulence_model == FY_TURBULENCE_KEQN, keps = c->turbulence_model == FY_TURBULENCE_KEPSILON;
             if (keqn || keps) {
@@ -239,7 +244,7 @@ struct Solver {
         FY_TRY(vGrad.alloc_exact(9 * n)); FY_TRY(zero(vGrad));
         if (c->turbulence_model != FY_TURBULENCE_LAMINAR) { FY_TRY(nut.alloc_exact(n)); FY_TRY(launch_fill_f64(stream, nut.p, n, c->nut_initial)); g.nut = nut.p; }
         if (c->turbulence_model == FY_TURBULENCE_KEQN || c->turbulence_model == FY_TURBULENCE_KEPSILON) { FY_TRY(kturb.alloc_exact(n)); FY_TRY(launch_fill_f64(stream, kturb.p, n, c->k_initial)); g.kturb = kturb.p; }
-        if (c->turbulence_model == FY_TURBULENCE_KEPSILON) { FY_TRY(epsturb.alloc_exact(n)); FY_TRY(launch_fill_f64(stream, epsturb.p, n, c->eps_initial)); }
+        if (c->turbulence_model == FY_TURBULENCE_KEPSILON) { FY_TRY(epsturb.alloc_exact(n)); FY_TRY(launch_fill_f64(stream, epsturb.p, n, c->eps_initial)); g.epsturb = epsturb.p; }
         FY_TRY(Gt.alloc_exact(9 * n)); FY_TRY(zero(Gt));
         for (int d = 0; d < 3; ++d) {
             DevBuf<double>* fs[] = {&phi[d], &phiOld[d], &psn[d], &alphaf[d], &phiHbyA[d], &phiForces[d], &rAUf[d], &pflux[d]};
