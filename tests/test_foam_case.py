@@ -63,7 +63,8 @@ def test_bed_case_is_read_like_pimpleFoamYade_would(prod):
     (("system/controlDict", "startFrom       startTime;", "startFrom       latestTime;"), "startFrom"),
     (("constant/transportProperties", "fluidDensity", "fluidDensityX"), "fluidDensity"),
     (("system/fvSolution", "PISO", "SIMPLE"), "PISO"),
-    (("0/U", "value           uniform (1 0 0);", "#include \"lid\""), "not supported"),
+    (("0/U", "value           uniform (1 0 0);", "#include \"lid\""), "lid"),
+    (("0/U", "value           uniform (1 0 0);", "#calc \"1+1\";"), "#calc"),
     (("system/fvSchemes", "div(phi,U)       Gauss linear;", "div(phi,U)       Gauss limitedLinear 1;"), "div(phi,U)"),
     (("system/fvSchemes", "default Euler;", "default CrankNicolson 0.9;"), "ddtSchemes"),
 ])
@@ -462,3 +463,30 @@ def test_foamYadeHip_executable_runs_a_kepsilon_case(prod, tmp_path):
     for o in (fc, fc2):
         o.close()
     s.close()
+
+
+def test_include_files_and_macros_are_expanded(prod, tmp_path):
+    """#include "file" (relative to the including file), $name / ${name} in value position, `$dict;` merged in keyword position
+    [OF-6 functionEntries::includeEntry, primitiveEntry::expandVariable] -- what the tutorial cases' 0/ files use"""
+    dst = tmp_path / "cavity"
+    shutil.copytree(os.path.join(CASES, "cavity_ico"), dst)
+    (dst / "0/include").mkdir()
+    (dst / "0/include/initialConditions").write_text("lidVelocity (0.75 0 0);\npressure 0;\nwall { type noSlip; }\n")
+    U = (dst / "0/U").read_text()
+    assert "internalField   uniform (0 0 0);" in U and "value           uniform (1 0 0);" in U
+    U = U.replace("internalField   uniform (0 0 0);", '#include "include/initialConditions"\ninternalField   uniform (0 0 0);')
+    U = U.replace("value           uniform (1 0 0);", "value           uniform $lidVelocity;")
+    U = U.replace("type            noSlip;", "$wall;")
+    (dst / "0/U").write_text(U)
+    p = (dst / "0/p").read_text().replace("internalField   uniform 0;", '#include "include/initialConditions"\ninternalField   uniform ${pressure};')
+    (dst / "0/p").write_text(p)
+    fc = prod.FoamCase(dst, prod.FY_SOLVER_ICO)
+    c = fc.case
+    assert list(c.u_value[YMAX]) == [0.75, 0.0, 0.0] and all(c.u_bc[s] == prod.FY_BC_U_FIXED_VALUE for s in range(6))
+    U0, p0 = fc.initial_fields()
+    assert not U0.any() and not p0.any()
+    fc.close()
+    (dst / "0/p").write_text(p.replace("${pressure}", "$nowhere"))
+    with pytest.raises(prod.FoamYadeError) as e:
+        prod.FoamCase(dst, prod.FY_SOLVER_ICO)
+    assert "$nowhere" in str(e.value)

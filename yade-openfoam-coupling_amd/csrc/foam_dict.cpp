@@ -12,7 +12,7 @@ namespace {
 
 struct Tok { std::string s; int line; };
 
-bool tokenize(const std::string& t, std::vector<Tok>* out, std::string* err) {
+bool tokenize(const std::string& t, std::vector<Tok>* out, std::string* err, const std::string& dir = std::string(), int depth_inc = 0) {
     size_t i = 0, n = t.size();
     int line = 1;
     while (i < n) {
@@ -36,7 +36,42 @@ bool tokenize(const std::string& t, std::vector<Tok>* out, std::string* err) {
             i = j + 1;
             continue;
         }
-        if (c == '#') { *err = "directive '#...' at line " + std::to_string(line) + " is not supported"; return false; }
+        if (c == '#') {
+            // #include "file" / #includeIfPresent "file" (relative to the including file's directory) [OF-6 functionEntries::includeEntry];
+            // #inputMode is accepted and ignored (merge is what this reader does); every other directive (#calc, #codeStream, #includeEtc ...) is refused
+            size_t j = i + 1;
+            while (j < n && std::isalpha((unsigned char)t[j])) ++j;
+            const std::string dname = t.substr(i + 1, j - i - 1);
+            if (dname == "inputMode") { while (j < n && t[j] != '\n') ++j; i = j; continue; }
+            if (dname != "include" && dname != "includeIfPresent") { *err = "directive '#" + dname + "' at line " + std::to_string(line) + " is not supported"; return false; }
+            while (j < n && (t[j] == ' ' || t[j] == '\t')) ++j;
+            if (j >= n || t[j] != '"') { *err = "#" + dname + " at line " + std::to_string(line) + " needs a quoted file name"; return false; }
+            const size_t q = t.find('"', j + 1);
+            if (q == std::string::npos) { *err = "unterminated string at line " + std::to_string(line); return false; }
+            std::string fname = t.substr(j + 1, q - j - 1);
+            if (!fname.empty() && fname[0] != '/' && !dir.empty()) fname = dir + "/" + fname;
+            if (depth_inc > 16) { *err = "#include nested too deeply at line " + std::to_string(line); return false; }
+            std::ifstream f(fname);
+            if (!f) {
+                if (dname == "includeIfPresent") { i = q + 1; continue; }
+                *err = "#include at line " + std::to_string(line) + ": cannot open " + fname;
+                return false;
+            }
+            std::stringstream ss;
+            ss << f.rdbuf();
+            const size_t slash = fname.find_last_of('/');
+            std::string e2;
+            if (!tokenize(ss.str(), out, &e2, slash == std::string::npos ? std::string() : fname.substr(0, slash), depth_inc + 1)) { *err = fname + ": " + e2; return false; }
+            i = q + 1;
+            continue;
+        }
+        if (c == '$' && i + 1 < n && t[i + 1] == '{') {                     // ${name}: one token
+            const size_t q = t.find('}', i);
+            if (q == std::string::npos) { *err = "unterminated ${...} at line " + std::to_string(line); return false; }
+            out->push_back({t.substr(i, q - i + 1), line});
+            i = q + 1;
+            continue;
+        }
         // a word; like OpenFOAM's, a word that starts with a letter may carry balanced parentheses: div(phi,U), grad(U), interpolate(HbyA)
         size_t j = i;
         int depth = 0;
@@ -52,7 +87,21 @@ bool tokenize(const std::string& t, std::vector<Tok>* out, std::string* err) {
     return true;
 }
 
-bool parse_dict(const std::vector<Tok>& tk, size_t* pos, bool top, FoamDict* d, std::string* err) {
+// $name / ${name}: the entry `name` of this dictionary or of an enclosing one, as read so far [OF-6 primitiveEntry::expandVariable]
+const FoamDict::Entry* lookup_macro(const std::string& ref, const FoamDict* d, const std::vector<const FoamDict*>& scopes) {
+    std::string name = ref.substr(1);
+    if (name.size() >= 2 && name.front() == '{' && name.back() == '}') name = name.substr(1, name.size() - 2);
+    if (name.empty() || name.find(':') != std::string::npos || name[0] == '.') return nullptr;      // scoped forms ($:a.b, $..x) are not supported
+    auto it = d->e.find(name);
+    if (it != d->e.end()) return &it->second;
+    for (size_t q = scopes.size(); q-- > 0;) {
+        auto jt = scopes[q]->e.find(name);
+        if (jt != scopes[q]->e.end()) return &jt->second;
+    }
+    return nullptr;
+}
+
+bool parse_dict(const std::vector<Tok>& tk, size_t* pos, bool top, FoamDict* d, std::string* err, std::vector<const FoamDict*>& scopes) {
     while (*pos < tk.size()) {
         const Tok& k = tk[*pos];
         if (k.s == "}") {
@@ -66,11 +115,25 @@ bool parse_dict(const std::vector<Tok>& tk, size_t* pos, bool top, FoamDict* d, 
         std::string key = k.s;
         ++*pos;
         if (*pos >= tk.size()) { *err = "keyword '" + key + "' at end of file (line " + std::to_string(k.line) + ")"; return false; }
+        if (key[0] == '$' && tk[*pos].s == ";") {
+            // `$other;` in keyword position: the entries of dictionary `other` are merged in here (later entries override)
+            const FoamDict::Entry* m = lookup_macro(key, d, scopes);
+            if (!m || !m->sub) { *err = "'" + key + "' at line " + std::to_string(k.line) + " does not name a dictionary read before it"; return false; }
+            for (const std::string& kk : m->sub->order) {
+                if (!d->e.count(kk)) d->order.push_back(kk);
+                d->e[kk] = m->sub->e.at(kk);
+            }
+            ++*pos;
+            continue;
+        }
         FoamDict::Entry en;
         if (tk[*pos].s == "{") {
             ++*pos;
             en.sub.reset(new FoamDict());
-            if (!parse_dict(tk, pos, false, en.sub.get(), err)) return false;
+            scopes.push_back(d);
+            const bool ok = parse_dict(tk, pos, false, en.sub.get(), err, scopes);
+            scopes.pop_back();
+            if (!ok) return false;
         } else {
             int depth = 0;
             for (;;) {
@@ -85,6 +148,19 @@ bool parse_dict(const std::vector<Tok>& tk, size_t* pos, bool top, FoamDict* d, 
                 }
                 if (s == ";" && depth == 0) { ++*pos; break; }
                 if ((s == "{" || s == "}") && depth == 0) { *err = "unexpected '" + s + "' in entry '" + key + "' at line " + std::to_string(tk[*pos].line); return false; }
+                if (s.size() > 1 && s[0] == '$') {                    // macro in value position: the referenced entry's tokens (or its dictionary)
+                    const FoamDict::Entry* m = lookup_macro(s, d, scopes);
+                    if (!m) { *err = "'" + s + "' at line " + std::to_string(tk[*pos].line) + " does not name an entry read before it"; return false; }
+                    if (m->sub) {
+                        if (!en.tok.empty() || *pos + 1 >= tk.size() || tk[*pos + 1].s != ";") { *err = "'" + s + "' at line " + std::to_string(tk[*pos].line) + " names a dictionary inside a token stream"; return false; }
+                        en.sub = m->sub;                                // `key $dict;` : a copy of the dictionary
+                        *pos += 2;
+                        break;
+                    }
+                    en.tok.insert(en.tok.end(), m->tok.begin(), m->tok.end());
+                    ++*pos;
+                    continue;
+                }
                 en.tok.push_back(s);
                 ++*pos;
             }
@@ -191,11 +267,12 @@ bool foam_read_list(const std::vector<std::string>& tok, size_t i, int ncomp, st
     return true;
 }
 
-bool foam_parse(const std::string& text, FoamDict* out, std::string* err) {
+bool foam_parse(const std::string& text, FoamDict* out, std::string* err, const std::string& dir) {
     std::vector<Tok> tk;
-    if (!tokenize(text, &tk, err)) return false;
+    if (!tokenize(text, &tk, err, dir)) return false;
     size_t pos = 0;
-    return parse_dict(tk, &pos, true, out, err);
+    std::vector<const FoamDict*> scopes;
+    return parse_dict(tk, &pos, true, out, err, scopes);
 }
 
 bool foam_parse_file(const std::string& path, FoamDict* out, std::string* err) {
@@ -204,7 +281,8 @@ bool foam_parse_file(const std::string& path, FoamDict* out, std::string* err) {
     std::stringstream ss;
     ss << f.rdbuf();
     std::string e2;
-    if (!foam_parse(ss.str(), out, &e2)) { *err = path + ": " + e2; return false; }
+    const size_t slash = path.find_last_of('/');
+    if (!foam_parse(ss.str(), out, &e2, slash == std::string::npos ? std::string() : path.substr(0, slash))) { *err = path + ": " + e2; return false; }
     return true;
 }
 

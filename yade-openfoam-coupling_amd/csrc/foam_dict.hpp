@@ -2,7 +2,9 @@
 // such files through OpenFOAM's IOdictionary / GeometricField constructors, icoFoamYade/createFields.H:3-58,
 // pimpleFoamYade/createFields.H:3-110].  Supported: // and /* */ comments, `key tokens...;`, `key { ... }` sub-dictionaries,
 // ( ... ) lists (nested, with or without a leading count), [ ... ] dimension sets, quoted strings, the FoamFile header (kept as an
-// ordinary sub-dictionary).  Not supported: #include / #calc / $macros, binary format, regular-expression keys.
+// ordinary sub-dictionary), #include / #includeIfPresent "file" (relative to the including file), $name / ${name} macros (the entry of this or an
+// enclosing dictionary as read so far; `$dict;` in keyword position merges a dictionary).  Not supported: #calc / #codeStream / #includeEtc,
+// scoped macros ($:a.b, $..x), binary format, regular-expression keys.
 #pragma once
 #include <cstddef>
 #include <map>
@@ -34,7 +36,7 @@ struct FoamDict {
 };
 
 // Parses `text`; on failure returns false and sets *err (with a line number).
-bool foam_parse(const std::string& text, FoamDict* out, std::string* err);
+bool foam_parse(const std::string& text, FoamDict* out, std::string* err, const std::string& dir = std::string());     // dir: where #include looks
 bool foam_parse_file(const std::string& path, FoamDict* out, std::string* err);
 
 // helpers on token streams
