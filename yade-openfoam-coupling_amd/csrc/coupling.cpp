@@ -234,7 +234,8 @@ int Coupling::create(const fy_mesh_desc* m, const fy_field_ptrs* f, int gaussian
     }
     if (fields_on_host && getenv("FOAMYADE_HOST_REGISTER") != nullptr) {
         // OPT-IN (FOAMYADE_HOST_REGISTER=1): the caller's field arrays live as long as this object (FoamYade.H:76-90 holds references to them),
-        // so they can be pinned in place and the per-step staging copies run at PCIe rate (56 GB/s instead of ~20).  Off by default: page-locking
+        // so they can be pinned in place for the per-step staging copies.  It buys nothing measurable on this runtime -- hipMemcpyAsync out of pageable
+        // memory already moves the 819 MB per call at 55 GB/s (it pins on the fly) -- and it is off by default: page-locking
         // memory that somebody else's allocator owns (and shares pages of with its other objects) is only safe when the caller knows how those
         // arrays were allocated -- an OpenFOAM field store is fine, a test process that allocates and frees numpy arrays around them is not
         // (rare aborts inside later pageable copies were traced to this).  Best effort -- an array that cannot be registered is copied as pageable.
