@@ -72,7 +72,7 @@ namespace {
 typedef std::vector<double> vec;
 const double SMALL = 1e-15;      // OpenFOAM `small` for double
 const double VSMALL = 1e-300;
-const int kMgCoarsest = 256, kMgCoarsestEdge = 8;    // coarsest multigrid level (same rule as the product so iteration counts are comparable)
+const int kMgCoarsest = 256, kMgCoarsestEdge = 8, kMgCoarseSweeps = 120;    // coarsest multigrid level (same rule as the product so iteration counts are comparable)
 
 struct MgLevel {
     int nx, ny, nz, N;
@@ -625,7 +625,7 @@ struct Fv {
             L.diag.assign(L.N, 0.0); L.ux = L.diag; L.uy = L.diag; L.uz = L.diag; L.x = L.diag; L.b = L.diag; L.r = L.diag;
             mg.push_back(L);
             if (cs.p_solver != 1) break;
-            if ((L.N <= kMgCoarsest && std::max(std::max(ax, ay), az) <= kMgCoarsestEdge) || (ax <= 2 && ay <= 2 && az <= 2)) break;   // (no elongated coarsest grid: 40 Jacobi sweeps must solve it)
+            if ((L.N <= kMgCoarsest && std::max(std::max(ax, ay), az) <= kMgCoarsestEdge) || (ax <= 2 && ay <= 2 && az <= 2)) break;   // (no elongated coarsest grid: kMgCoarseSweeps Jacobi sweeps must solve it)
             ax = (ax + 1) / 2; ay = (ay + 1) / 2; az = (az + 1) / 2;
         }
     }
@@ -652,7 +652,7 @@ struct Fv {
     // 7-point operator under 2 x 2 x 2 coarsening, 2 bounding every diagonally dominant level -- i.e. Jacobi with the weights
     // 1 / (7/6 -+ (5/6) cos(pi/4)): the pair damps that band by 0.34 where two sweeps at the fixed weight 0.8 reach 0.54, for the same
     // work.  Pre-smoothing applies (kMgWa, kMgWb), post-smoothing the reverse order (the adjoint; the V-cycle stays a symmetric
-    // positive definite preconditioner).  The 40 sweeps of the coarsest level keep the fixed weight.  Same constants as the product.
+    // positive definite preconditioner).  The kMgCoarseSweeps (120) sweeps of the coarsest level keep the fixed weight.  Same constants as the product.
     static constexpr double kMgWa = 1.7318685872766142, kMgWb = 0.5695012757370842;
     static void jacobi(const MgLevel& L, vec& x, const vec& b, vec& tmp, int sweeps, bool zero_guess, int threads) {
         for (int s = 0; s < sweeps; ++s) {
@@ -666,7 +666,7 @@ struct Fv {
 
     void vcycle(size_t l) {
         MgLevel& L = mg[l];
-        if (l + 1 == mg.size()) { jacobi(L, L.x, L.b, L.r, 40, true, 1); return; }
+        if (l + 1 == mg.size()) { jacobi(L, L.x, L.b, L.r, kMgCoarseSweeps, true, 1); return; }
         jacobi(L, L.x, L.b, L.r, 2, true, threads);
         vec& r = L.r;
         apply(L, L.x, r, threads);

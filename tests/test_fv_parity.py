@@ -83,7 +83,7 @@ def test_hydrostatic_fixed_flux(product, oracle):
     o, s = both(product, oracle, 1, n, n, n, 0.1 / n, 1e-3, 1e-6, g=(0, 0, -9.81), p_bc=[2] * 6)
     for _ in range(3):
         o.step(); s.step()
-    assert np.abs(s.get("U")).max() < 1e-8
+    assert np.abs(s.get("U")).max() < 1e-6          # at rest to what the pressure tolerance (1e-6, L1-normalised) leaves behind
     p = s.get("p").reshape(n, n, n)
     np.testing.assert_allclose((p[2:] - p[:-2]) / (2 * 0.1 / n), -9.81, rtol=1e-5)
     compare(o, s, names=("p",), rtol=1e-5)

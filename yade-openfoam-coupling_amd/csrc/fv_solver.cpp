@@ -509,7 +509,7 @@ struct Solver {
     // weights 1 / (7/6 -+ (5/6) cos(pi/4)).  The pair damps that band by 0.34 where two sweeps at the fixed weight 0.8 reach 0.54, for
     // the same memory traffic: PCG iterations 66 -> 48 on a moving 48^3 bed, 19 -> 14 on the manufactured Poisson problem (CPU oracle).
     // Pre-smoothing applies (wa, wb), post-smoothing the reverse order (its adjoint: the V-cycle stays a symmetric positive definite
-    // preconditioner).  The 40 sweeps of the coarsest level keep the fixed weight.  Degree 4 (four sweeps each way, weights 2.520 /
+    // preconditioner).  The sweeps of the coarsest level (kMgCoarseSweeps) keep the fixed weight.  Degree 4 (four sweeps each way, weights 2.520 /
     // 1.180 / 0.673 / 0.516) was measured too: fewer iterations (C3 2.6 -> 2.1 per step, moving bed 5.75 -> 4.2, C2 7.5 -> 5.3) but every
     // one of the three cases slower in time (7.40 -> 7.56, 9.55 -> 9.73, 2.35 -> 2.51 ms per step): the four extra sweeps cost more
     // than the iterations they save.
@@ -527,12 +527,12 @@ struct Solver {
                 MgLev& M = *mg[l + (size_t)q];
                 A[q] = M.A; x0[q] = M.x0.p; x1[q] = M.x1.p; b[q] = q == 0 ? const_cast<double*>(L.bptr) : M.b.p;
             }
-            FY_TRY(launch_mg_tail(stream, A, x0, x1, b, n, w, 40, W));
+            FY_TRY(launch_mg_tail(stream, A, x0, x1, b, n, w, coarse_sweeps, W));
             L.xcur = n > 1 ? L.x1.p : L.x0.p; L.xalt = n > 1 ? L.x0.p : L.x1.p;
             return FY_OK;
         }
         if (l + 1 == mg.size()) {
-            FY_TRY(launch_mg_coarse_solve(stream, L.A, L.bptr, L.x0.p, L.x1.p, 40, w));
+            FY_TRY(launch_mg_coarse_solve(stream, L.A, L.bptr, L.x0.p, L.x1.p, coarse_sweeps, w));
             L.xcur = L.x0.p; L.xalt = L.x1.p;
             return FY_OK;
         }
@@ -578,6 +578,11 @@ struct Solver {
         return FY_OK;
     }
     bool want_vcycle_dot = false, vcycle_dot_done = false;
+    // damped-Jacobi sweeps that stand for the solve of the coarsest level (<= 256 cells, no edge over 8): 40 left its smoothest modes in and cost
+    // PCG iterations -- C3 after 30 steps: 3.0 iterations per step with 40 or 80 sweeps, 2.17 with 120 / 160 / 240 (135 -> 140 / 139 / 137.6
+    // steps/s); moving bed and C2 +-1 %.  The sweeps run inside the one-workgroup tail kernel, ~0.1 us each
+    static constexpr int kMgCoarseSweeps = 120;
+    int coarse_sweeps = kMgCoarseSweeps;
     bool fuse_prolong = getenv("FOAMYADE_NO_PROLONG_FUSION") == nullptr;     // A/B switch (identical results)
 
     // coarse operators: A_{l+1} = 1/2 P^T A_l P level by level; the first replicated level is all-gathered from the slabs' slices
