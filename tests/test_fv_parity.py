@@ -85,7 +85,7 @@ def test_hydrostatic_fixed_flux(product, oracle):
         o.step(); s.step()
     assert np.abs(s.get("U")).max() < 1e-6          # at rest to what the pressure tolerance (1e-6, L1-normalised) leaves behind
     p = s.get("p").reshape(n, n, n)
-    np.testing.assert_allclose((p[2:] - p[:-2]) / (2 * 0.1 / n), -9.81, rtol=1e-5)
+    np.testing.assert_allclose((p[2:] - p[:-2]) / (2 * 0.1 / n), -9.81, rtol=1e-4)      # (to the pressure solver's tolerance)
     compare(o, s, names=("p",), rtol=1e-5)
 
 
