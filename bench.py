@@ -32,6 +32,14 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as ge  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s copy-achievable)
+KBAR = 5.46                     # stencil cells per particle at 160^3
+# algorithmic (compulsory) HBM bytes per particle of the two big particle kernels -- DESIGN.md section 3
+LOCATE_BYTES_PER_PARTICLE = 24.0 + 24.0 + 8.0 + 15.2 + 4.0 + 12.0 * KBAR
+LOCATE_WHAT = ("k-d 'range' locate through per-(cell, octant) candidate lists + Gaussian weights + void-fraction deposit in one pass: position 24 + velocity 24 "
+               "+ radius 8 + list 15 B in, chain length 4 + 12 B/pair out per particle; 32 B of accumulators read-modify-written per cell")
+FORCE_BYTES_PER_PARTICLE = 64.0 + 12.0 * KBAR + 52.0
+FORCE_WHAT = ("drag + Archimedes + back-scatter: particle 64 B + stencil 12 B/pair in, force record 52 B out; per cell the 64-byte gather record read and "
+              "32 B of momentum-source accumulators read-modify-written")
 
 
 def c3_case(prod, n, dt, p_solver, n_slabs=1, strong=False):
@@ -69,6 +77,38 @@ def c3_particles_strong(torch, n_part, n, device, rank, world):
     rec[:, 0:3] = pos[mine]
     rec[:, 9] = 0.2 * dx
     return rec.to(device).contiguous()
+
+
+def c5_case(prod, dt, p_solver, n=320, u_in=0.05):
+    """320^3 = 32 768 000-cell box, fluidized bed -- bottom (z-) inlet fixedValue U = (0,0,Uin), top (z+) outlet p = 0 with
+    zeroGradient U, no-slip side walls (fixedFluxPressure there and at the inlet), g = (0,0,-9.81), nu = 1e-6; PIMPLE nOuter 1 nCorr 2"""
+    U, ZG = prod.FY_BC_U_FIXED_VALUE, prod.FY_BC_U_ZERO_GRADIENT
+    PX, PF = prod.FY_BC_P_FIXED_FLUX, prod.FY_BC_P_FIXED_VALUE
+    return prod.make_case(prod.FY_SOLVER_PIMPLE, n, n, n, 1.0 / n, dt, 1e-6, rho_f=1000.0, rho_p=2650.0, g=(0.0, 0.0, -9.81),
+                          u_bc=[U, U, U, U, U, ZG], u_val=[(0, 0, 0)] * 4 + [(0, 0, u_in), (0, 0, 0)], p_bc=[PX, PX, PX, PX, PX, PF], p_val=[0.0] * 6,
+                          n_outer_correctors=1, n_correctors=2, p_solver=p_solver)
+
+
+def c5_particles(torch, n_part, n, device, rank, world):
+    """100 M particles uniform in the lower third of the unit box, seed 5, r = 0.2 dx, at rest; a rank keeps those inside its z-slab.  Generated
+    in chunks: the host never holds more than one chunk beside the kept records"""
+    g = torch.Generator(device="cpu").manual_seed(5)
+    dx = 1.0 / n
+    h = 1.0 / world
+    keep = []
+    left = n_part
+    while left > 0:
+        m = min(left, 20_000_000)
+        pos = torch.rand(m, 3, dtype=torch.float64, generator=g)
+        pos[:, 2] *= 1.0 / 3.0
+        if world > 1:
+            pos = pos[(pos[:, 2] >= rank * h) & (pos[:, 2] < (rank + 1) * h)]
+        rec = torch.zeros(pos.shape[0], 10, dtype=torch.float64)
+        rec[:, 0:3] = pos
+        rec[:, 9] = 0.2 * dx
+        keep.append(rec.to(device))
+        left -= m
+    return torch.cat(keep).contiguous()
 
 
 def c2_case(prod, dt, p_solver):
@@ -199,42 +239,49 @@ def wire_leg(prod, torch, case, rec_host, steps, workers, device):
 
 
 def cpu_baseline(config, n_sample, n_part, dt, threads, full):
-    """the CPU oracle (a faithful port of the reference's path, kind = "port") on the GPU box's host cores: the bench's own workload at its own
-    size (full: one warm-up + two timed steps on all cores, one warm-up + one timed step on one core), or an n_sample^3 sample of C3"""
+    """the CPU oracle (a faithful port of the reference's path, kind = "port") on the GPU box's host cores, bounded to some tens of seconds:
+    all usable threads on the bench's own workload (full: at its own size, one warm-up + one timed step; else an n_sample^3 sample with the
+    same particles per cell), and ONE thread on a half-edge sample of that (1/8 of the cells and particles).  Returns ({threads: (s/step, cells)}, cells)"""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as orc
     orc.build()
-    rs = np.random.RandomState(3)
-    rec = np.zeros((n_part, 10))
-    rec[:, 0:3] = rs.random_sample((n_part, 3))
-    if config == "c2":
-        nx, ny, nz, dx = 200, 100, 50, 0.01
-        case = orc.fv_case(0, nx, ny, nz, dx, dt, 1e-3, u_bc=[0, 1, 0, 0, 0, 0], u_val=[(1.0, 0, 0)] + [(0, 0, 0)] * 5, p_bc=[0, 1, 0, 0, 0, 0],
-                           p_val=[0.0] * 6, n_corr=2, p_solver=1)
-        rec[:, 0] *= 2.0; rec[:, 2] *= 0.5
-        rec[:, 9] = 0.15 * dx
-    else:
-        nx = ny = nz = n_sample
-        dx = 1.0 / n_sample
-        case = orc.fv_case(1, nx, ny, nz, dx, dt, 1e-6, g=(0, 0, -9.81), p_bc=[orc.P_FIXEDFLUX] * 6, n_outer=1, n_corr=2, p_solver=1)
-        rec[:, 2] *= 0.6
-        rec[:, 9] = 0.2 * dx
-    mesh = orc.Mesh(nx, ny, nz, dx)                       # tree build is construction-time work, not timed (as on the GPU side)
-    out = {}
-    teams = [threads, 1] if full else sorted(set([1] + [t for t in (8, 16, 32) if t <= threads] + ([threads] if threads <= 64 else [])))
-    for th in dict.fromkeys(teams):
-        s = orc.FvSolver(case, threads=th)
-        s.mesh = mesh
-        s.step(rec)                                              # warm-up step
+
+    def one(th, n_s, npart):
+        rs = np.random.RandomState(3)
+        rec = np.zeros((npart, 10))
+        rec[:, 0:3] = rs.random_sample((npart, 3))
+        if config == "c2":
+            scale = n_s / 100.0                                  # n_s = 100 is the full 200 x 100 x 50 channel
+            nx, ny, nz, dx = int(200 * scale), int(100 * scale), int(50 * scale), 0.01
+            case = orc.fv_case(0, nx, ny, nz, dx, dt, 1e-3, u_bc=[0, 1, 0, 0, 0, 0], u_val=[(1.0, 0, 0)] + [(0, 0, 0)] * 5, p_bc=[0, 1, 0, 0, 0, 0],
+                               p_val=[0.0] * 6, n_corr=2, p_solver=1)
+            rec[:, 0:3] *= np.array([nx * dx, ny * dx, nz * dx])
+            rec[:, 9] = 0.15 * dx
+        elif config == "c5":
+            nx = ny = nz = n_s
+            dx = 1.0 / n_s
+            case = orc.fv_case(1, nx, ny, nz, dx, dt, 1e-6, g=(0, 0, -9.81), u_bc=[0, 0, 0, 0, 0, 1], u_val=[(0, 0, 0)] * 4 + [(0, 0, 0.05), (0, 0, 0)],
+                               p_bc=[orc.P_FIXEDFLUX] * 5 + [1], p_val=[0.0] * 6, n_outer=1, n_corr=2, p_solver=1)
+            rec[:, 2] *= 1.0 / 3.0
+            rec[:, 9] = 0.2 * dx
+        else:
+            nx = ny = nz = n_s
+            dx = 1.0 / n_s
+            case = orc.fv_case(1, nx, ny, nz, dx, dt, 1e-6, g=(0, 0, -9.81), p_bc=[orc.P_FIXEDFLUX] * 6, n_outer=1, n_corr=2, p_solver=1)
+            rec[:, 2] *= 0.6
+            rec[:, 9] = 0.2 * dx
+        s = orc.FvSolver(case, threads=th)                       # tree build is construction-time work, not timed (as on the GPU side)
+        s.step(rec)                                              # warm-up step (first touch of every array)
         t0 = time.time()
-        k = 0
-        n_min = (2 if th > 1 else 1) if full else 2
-        while k < n_min or (not full and time.time() - t0 < 4.0 and k < 8):
-            s.step(rec)
-            k += 1
-        out[th] = (time.time() - t0) / k
+        s.step(rec)
+        el = time.time() - t0
         s.close()
-    return out, nx * ny * nz
+        return el, nx * ny * nz
+
+    out = {threads: one(threads, n_sample, n_part)}
+    if threads != 1:
+        out[1] = one(1, n_sample // 2, n_part // 8)
+    return out, out[threads][1]
 
 
 def cpu_reference_as_written(n_sample=32, n_part=80000):
@@ -288,6 +335,50 @@ def cpu_reference_as_written(n_sample=32, n_part=80000):
             "note": "not extrapolated to C3: the deposit is quadratic in the number of touched cells, so the as-written code does not reach that size"}
 
 
+def live_pmc_traffic(extra_args, nc, steps=5, warmup=2, timeout=420):
+    """HBM bytes per launch, measured NOW: two rocprofv3 child passes of this very command (--pmc FETCH_SIZE, then --pmc WRITE_SIZE, each with
+    --kernel-trace only: the guide's HBM recipe, separate passes), `steps` timed + `warmup` steps each; the launches of the warm-up steps (the first
+    step of a particle population still flushes its tables with global atomics) are dropped.  Both counters are KiB; reads = 2 x FETCH_SIZE on
+    gfx950 (wide coalesced streams are counted at half their size: an UPPER bound for gather-dominated kernels).  Returns ({kernel: bytes}, note)"""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from pmc_traffic import classify
+    rp = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rp):
+        return None, "rocprofv3 not found"
+    res = {}
+    d = tempfile.mkdtemp(prefix="fy_pmc_", dir="/tmp")
+    try:
+        for tag in ("FETCH_SIZE", "WRITE_SIZE"):
+            od = os.path.join(d, tag)
+            cmd = [rp, "--pmc", tag, "--kernel-trace", "--output-format", "csv", "-d", od, "--", sys.executable, os.path.abspath(__file__),
+                   "--steps", str(steps), "--warmup", str(warmup), "--no-cpu-baseline", "--wire", "0", "--no-moving", "--pmc", "0"] + extra_args
+            env = dict(os.environ, TMPDIR="/tmp")
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout)
+            files = glob.glob(os.path.join(od, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, f"rocprofv3 --pmc {tag} pass failed (rc {r.returncode}): {(r.stderr or '')[-200:]}"
+            rows = [q for q in csv.DictReader(open(files[0])) if q["Counter_Name"] == tag]
+            rows.sort(key=lambda q: int(q.get("Dispatch_Id", 0)))
+            per = {}
+            for q in rows:
+                k = classify(q["Kernel_Name"], int(q.get("Grid_Size", q.get("Grid_Size_X", 0))), nc)
+                if k:
+                    per.setdefault(k, []).append(float(q["Counter_Value"]))
+            for k, v in per.items():
+                v = v[(len(v) * warmup) // (steps + warmup):]
+                res.setdefault(k, {})[tag] = 1024.0 * sum(v) / max(len(v), 1)
+    except Exception as e:                                            # noqa: BLE001
+        return None, f"{type(e).__name__}: {e}"
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    return {k: 2.0 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0) for k, v in res.items()}, ""
+
+
 def max_over_ranks(elapsed, dist, device):
     """the contract's timing rule: the slowest rank defines the step time (works with nccl on GPUs and gloo on CPU)"""
     if dist is None:
@@ -337,6 +428,21 @@ def rccl_preflight(prod, torch, dist, dev, rank, world, timeout=180):
         return f"RCCL self-test did not finish within {timeout} s"          # a HANG is: the real run would hang the same way
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: re-run this very command under torch.distributed.run, one rank per GPU of this node
+    (what the contract's N > 1 command line does), and hand its exit code back"""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -348,7 +454,8 @@ def main():
     ap.add_argument("--p-solver", type=int, default=1, help="0 PCG+Jacobi, 1 PCG+multigrid")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-n", type=int, default=0, help="CPU baseline on an n^3 sample of the workload instead of the full size (0 = full size)")
-    ap.add_argument("--config", default="c3", choices=["c3", "c2"], help="c3: BASELINE configs[2] (the metric's configuration); c2: configs[1] at full size")
+    ap.add_argument("--config", default="c3", choices=["c3", "c2", "c5"], help="c3: BASELINE configs[2] (the metric's configuration); c2: configs[1] at full size; "
+                    "c5: configs[4] at full size (320^3 cells, 100 M particles, fluidized bed: bottom inlet, top outlet) -- on one GPU, or with --gpus N cut into N z-slabs")
     ap.add_argument("--wire", type=int, default=2, help="steps of the drop-in (host-buffer / fake-Yade) leg after the timed region, 0 = skip")
     ap.add_argument("--wire-workers", type=int, default=4)
     ap.add_argument("--moving", action="store_true", help="not the BASELINE configuration: particles carry random velocities (+-0.05 m/s) and are displaced by "
@@ -357,9 +464,17 @@ def main():
     ap.add_argument("--strong", action="store_true", help="N > 1: cut the ONE C3 box into N slabs (BASELINE configs[3]) instead of growing it (weak, the default)")
     ap.add_argument("--force-rccl", action="store_true", help="use the RCCL communicator even with one rank (smoke test of the RCCL path)")
     ap.add_argument("--rccl-selftest", default="", help=argparse.SUPPRESS)     # child mode: hex of the 128-byte RCCL id (see rccl_preflight)
+    ap.add_argument("--no-moving", action="store_true", help="skip the moving-bed sub-record that follows the timed region (N = 1, C3 only)")
+    ap.add_argument("--pmc", type=int, default=-1, help="1: measure roofline.traffic live (two rocprofv3 --pmc child passes of this command, FETCH_SIZE and "
+                    "WRITE_SIZE, after everything else); 0: print null + the committed profile's path; -1 (default): live when rocprofv3 is there, N = 1, default C3")
     args = ap.parse_args()
     if args.rccl_selftest:
         rccl_selftest_child(args)
+    if args.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))
+    if os.environ.get("FOAMYADE_BENCH_LAUNCH_PROBE"):             # tests/test_bench_multirank.py: what did the launcher hand this rank?
+        print(json.dumps({"rank": int(os.environ.get("RANK", "-1")), "world": int(os.environ.get("WORLD_SIZE", "-1")), "gpus": args.gpus, "steps": args.steps}), flush=True)
+        raise SystemExit(0)
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -378,8 +493,8 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     prod = ge.load_product()
-    strong = bool(args.strong and world > 1)
-    c2 = args.config == "c2"
+    c2, c5 = args.config == "c2", args.config == "c5"
+    strong = bool((args.strong or c5) and world > 1)           # C5 on N GPUs is the ONE 320^3 box cut into N slabs (BASELINE configs[4])
     if c2:
         if world > 1:
             raise SystemExit("bench.py --config c2 is the single-GPU configuration (BASELINE configs[1])")
@@ -387,7 +502,14 @@ def main():
             args.particles = 1_000_000
         if args.dt == 1e-4:
             args.dt = 2e-3
-    case = c2_case(prod, args.dt, args.p_solver) if c2 else c3_case(prod, args.n, args.dt, args.p_solver, world, strong)
+    if c5:
+        if args.n == 160:
+            args.n = 320
+        if args.particles == 10_000_000:
+            args.particles = 100_000_000
+        if args.n % world or (args.n // world) % 2 or args.n // world < 10:
+            raise SystemExit(f"bench.py --config c5: {args.n} planes do not cut into {world} slabs of an even number >= 10 of planes")
+    case = c2_case(prod, args.dt, args.p_solver) if c2 else c5_case(prod, args.dt, args.p_solver, args.n) if c5 else c3_case(prod, args.n, args.dt, args.p_solver, world, strong)
     comm, solver, setup_err = None, None, ""
     try:
         if world > 1 and not os.environ.get("FOAMYADE_BENCH_NO_PREFLIGHT"):
@@ -401,9 +523,6 @@ def main():
             os.environ.setdefault("FOAMYADE_TREE_CACHE_DIR", "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp")
             idt = torch.zeros(128, dtype=torch.uint8, device=dev)
             if rank == 0:
-                import glob
-                for f in glob.glob(os.path.join(os.environ["FOAMYADE_TREE_CACHE_DIR"], "fy_tree_*.lock")):      # stale locks of a crashed run
-                    os.remove(f)
                 idt = torch.tensor(list(prod.rccl_unique_id()), dtype=torch.uint8, device=dev)
             if dist is not None:
                 dist.broadcast(idt, 0)
@@ -428,12 +547,17 @@ def main():
               f"falling back to {world} independent single-GPU replicas", file=sys.stderr, flush=True)
         if solver is not None:
             solver.close()
+        c5 = False
+        if args.config == "c5":
+            args.n, args.particles = 160, 10_000_000
         case = c3_case(prod, args.n, args.dt, args.p_solver, 1)
         solver = prod.Solver(case, device=local_rank)
-        parallelism = f"FALLBACK: {world} independent replicas of the single-GPU case, no exchange (z-slab/RCCL set-up failed: {setup_err or 'on another rank'})"
+        parallelism = f"FALLBACK: {world} independent replicas of the single-GPU C3 case, no exchange (z-slab/RCCL set-up failed: {setup_err or 'on another rank'})"
         slab_of_rank = 0
     if c2:
         rec = c2_particles(torch, args.particles, dev)
+    elif c5:
+        rec = c5_particles(torch, args.particles, args.n, dev, rank, world)
     elif strong and slabs_ok >= 1.0:
         rec = c3_particles_strong(torch, args.particles, args.n, dev, rank, world)
     else:
@@ -452,31 +576,36 @@ def main():
     for _ in range(args.warmup):
         solver.step()
     solver.enable_kernel_timing(True)
-    warm_moving = args.moving
-    acc = dict(particle=0.0, locate_deposit=0.0, force=0.0, bin=0.0, finalize=0.0, fold=0.0, momentum=0.0, pressure=0.0, other=0.0, p_iters=0, u_iters=0)
-    jitter = None
-    if args.moving:
-        gj = torch.Generator(device="cpu").manual_seed(77)
-        dxm = 0.01 if c2 else 1.0 / args.n
-        jitter = ((torch.rand(rec.shape[0], 3, dtype=torch.float64, generator=gj) - 0.5) * 0.2 * dxm).to(dev)
-        rec[:, 3:6] = ((torch.rand(rec.shape[0], 3, dtype=torch.float64, generator=gj) - 0.5) * 0.1).to(dev)
-    if warm_moving:                                         # the displacement kernels load on first use: not in the timed region
-        for it_ in range(2):
-            rec[:, 0:3] += jitter if it_ % 2 == 0 else -jitter
+    dxm = 0.01 if c2 else 1.0 / args.n
+    phase_keys = ("particle", "locate_deposit", "force", "bin", "finalize", "fold", "momentum", "pressure", "other")
+
+    def timed_region(steps, moving):
+        """EXACTLY `steps` steps between two barriers (+ device synchronisations); moving: random velocities (+-0.05 m/s) and alternating random
+        offsets of ~0.1 dx per step applied between the steps, inside the region"""
+        acc = dict.fromkeys(phase_keys, 0.0)
+        acc.update(p_iters=0, u_iters=0)
+        jitter = None
+        if moving:
+            gj = torch.Generator(device="cpu").manual_seed(77)
+            jitter = ((torch.rand(rec.shape[0], 3, dtype=torch.float64, generator=gj) - 0.5) * 0.2 * dxm).to(dev)
+            rec[:, 3:6] = ((torch.rand(rec.shape[0], 3, dtype=torch.float64, generator=gj) - 0.5) * 0.1).to(dev)
+            for it_ in range(2):                            # the displacement kernels load on first use: not in the timed region
+                rec[:, 0:3] += jitter if it_ % 2 == 0 else -jitter
+                solver.step()
+        barrier()
+        t0 = time.perf_counter()
+        for it_ in range(steps):
+            if jitter is not None:
+                rec[:, 0:3] += jitter if it_ % 2 == 0 else -jitter
             solver.step()
-    barrier()
-    t0 = time.perf_counter()
-    for it_ in range(args.steps):
-        if jitter is not None:
-            rec[:, 0:3] += jitter if it_ % 2 == 0 else -jitter
-        solver.step()
-        st = solver.stats(); ct = solver.coupling_timings()
-        acc["particle"] += st["ms_particle"]; acc["momentum"] += st["ms_momentum"]; acc["pressure"] += st["ms_pressure"]; acc["other"] += st["ms_other"]
-        acc["locate_deposit"] += ct["locate_deposit"]; acc["force"] += ct["force"]; acc["bin"] += ct["bin"]; acc["finalize"] += ct["finalize"]; acc["fold"] += ct["fold"]
-        acc["p_iters"] += st["p_iters_total"]; acc["u_iters"] += st["u_iters_total"]
-    barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed = max_over_ranks(elapsed, dist, dev)
+            st = solver.stats(); ct = solver.coupling_timings()
+            acc["particle"] += st["ms_particle"]; acc["momentum"] += st["ms_momentum"]; acc["pressure"] += st["ms_pressure"]; acc["other"] += st["ms_other"]
+            acc["locate_deposit"] += ct["locate_deposit"]; acc["force"] += ct["force"]; acc["bin"] += ct["bin"]; acc["finalize"] += ct["finalize"]; acc["fold"] += ct["fold"]
+            acc["p_iters"] += st["p_iters_total"]; acc["u_iters"] += st["u_iters_total"]
+        barrier()
+        return acc, max_over_ranks(time.perf_counter() - t0, dist, dev)
+
+    acc, elapsed = timed_region(args.steps, args.moving)
 
     K = args.steps
     steps_per_s = K / elapsed if strong else aggregate_value(world, K, elapsed)      # strong: steps of the one box; weak: slab-steps
@@ -488,18 +617,13 @@ def main():
     smooth_ms, smooth_n = solver.kernel_timing("mg_smooth_l0")
     apply_ms, apply_n = solver.kernel_timing("p_apply_dot")
     mom_ms, mom_n = solver.kernel_timing("mom_pass")
-    np_part = int(rec.shape[0]) if strong else args.particles      # particles of this rank
-    kbar = 5.46                  # stencil cells per particle at 160^3
+    np_part = int(rec.shape[0])                                    # particles of this rank
+    np_global = args.particles if (strong or world == 1) else np_part * world
     cand = {
         # name: (total ms over the timed steps, launches, algorithmic bytes per launch, description) -- DESIGN.md section 3.  The particle
         # kernels' durations are those of the kernel ALONE, bracketed by HIP events on its stream (fy_particle_timings)
-        "k_locate_deposit": (acc["locate_deposit"], K, (24.0 + 24.0 + 8.0 + 15.2 + 4.0 + 12.0 * kbar) * np_part + 64.0 * nc,
-                             "k-d 'range' locate through per-(cell, octant) candidate lists + Gaussian weights + void-fraction deposit in one pass: "
-                             "position 24 + velocity 24 + radius 8 + list 15 B in, chain length 4 + 12 B/pair out per particle; 32 B of accumulators "
-                             "read-modify-written per cell"),
-        "k_force_gaussian": (acc["force"], K, (64.0 + 12.0 * kbar + 52.0) * np_part + 128.0 * nc,
-                             "drag + Archimedes + back-scatter: particle 64 B + stencil 12 B/pair in, force record 52 B out; per cell the 64-byte "
-                             "gather record read and 32 B of momentum-source accumulators read-modify-written"),
+        "k_locate_deposit": (acc["locate_deposit"], K, LOCATE_BYTES_PER_PARTICLE * np_part + 64.0 * nc, LOCATE_WHAT),
+        "k_force_gaussian": (acc["force"], K, FORCE_BYTES_PER_PARTICLE * np_part + 128.0 * nc, FORCE_WHAT),
         "k_point_force": (acc["force"], K, 128.0 * np_part, "findCell + Stokes drag / torque + uSource scatter: 80 B record in, 48 B force out per particle"),
         "k_mg_smooth(level 0)": (smooth_ms, smooth_n, 56.0 * nc, "k_mg_smooth / k_mg_smooth_dot at level 0: pEqn Laplacian apply fused with the Jacobi update (and the z.r partials): 48 B/cell (diag, 3 upper, x, y) + b 8"),
         "k_p_apply_dot": (apply_ms, apply_n, 48.0 * nc, "pEqn Laplacian apply y = A p (+ p.Ap) inside PCG: 48 B/cell"),
@@ -507,15 +631,6 @@ def main():
     }
     for gone in (("k_locate_deposit", "k_force_gaussian") if c2 else ("k_point_force",)):
         cand.pop(gone)
-    # HBM traffic per launch from the committed PMC passes of this same command (tools/pmc_traffic.py; null if absent)
-    traffic = {}
-    for cand_file in sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1:]:
-        try:
-            traffic = {k: v.get("hbm_bytes_per_launch") for k, v in json.load(open(cand_file))["kernels"].items()}
-        except Exception:
-            traffic = {}
-    if c2 or not (args.n == 160 and args.particles == 10_000_000 and world == 1):
-        traffic = {}            # the PMC passes were taken on the default single-GPU workload only
     for nm, (ms, nl, bytes_per, desc) in cand.items():
         if nl:
             avg = ms / nl
@@ -526,10 +641,11 @@ def main():
     def roof(name):
         k = kern[name]
         return {"kernel": name, "bound": "hbm", "achieved": round(k["achieved_GBps"], 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(k["achieved_GBps"] / HBM_PEAK_GBPS, 4), "traffic": traffic.get(name.split("+")[0]), "avg_launch_ms": round(k["avg_ms"], 4),
+                "frac": round(k["achieved_GBps"] / HBM_PEAK_GBPS, 4), "traffic": None, "avg_launch_ms": round(k["avg_ms"], 4),
                 "launches": k["launches"], "algorithmic_bytes_per_launch": k["alg_bytes"], "what": k["what"]}
 
-    default_c3 = (not c2) and args.n == 160 and args.particles == 10_000_000
+    default_c3 = (not c2) and (not c5) and args.n == 160 and args.particles == 10_000_000
+    default_c5 = c5 and args.n == 320 and args.particles == 100_000_000
     p_iters, u_iters = acc["p_iters"] / K, acc["u_iters"] / K
     n_corr = 2
     # compulsory bytes of one coupled step -- particle phase 128 Np + 232 Nc; FV passes (280 + nCorr x 504) Nc; 128 Nc per
@@ -539,24 +655,33 @@ def main():
     if c2:
         metric = "coupled_steps_per_sec (icoFoamYade point force, 1M particles / 1M cells)" if args.particles == 1_000_000 else f"coupled_steps_per_sec (icoFoamYade point force, {args.particles} particles / {nc} cells)"
         workload = "C2: icoFoamYade point-force coupling, 200 x 100 x 50 = 1,000,000-cell channel (inlet U = (1,0,0), outlet p = 0, no-slip walls), " + f"{args.particles:,} particles uniform in the channel"
+    elif c5:
+        metric = ("coupled_steps_per_sec (pimpleFoamYade 4-way dense fluidized bed, 100M particles / 32M cells)" if default_c5
+                  else f"coupled_steps_per_sec (pimpleFoamYade 4-way fluidized bed, {args.particles} particles / {args.n ** 3} cells)")
+        workload = (f"C5: pimpleFoamYade Gaussian 4-way coupling, {args.n}^3 = {args.n ** 3:,}-cell fluidized bed (bottom inlet U = (0,0,0.05), top outlet p = 0, "
+                    f"no-slip side walls), {args.particles:,} particles in the lower third" + (f", cut into {world} z-slabs" if world > 1 else ", on ONE GPU"))
     else:
         metric = "coupled_steps_per_sec (pimpleFoamYade 4-way, 10M particles / 4M cells per GPU)" if default_c3 else f"coupled_steps_per_sec (pimpleFoamYade 4-way, {args.particles} particles / {nc} cells)"
         workload = ("C3: pimpleFoamYade Gaussian 4-way coupling, 160^3 = 4,096,000-cell closed box, 10,000,000 particles in the lower 60 %" if default_c3
                     else f"non-default C3-like case {args.n}^3 cells / {args.particles} particles")
+
+    def per_step(a, k):
+        return {q: round(a[q] / k, 3) for q in ("particle", "bin", "locate_deposit", "finalize", "force", "fold", "momentum", "pressure", "other")}
+
     out = {
         "metric": metric,
         "value": round(steps_per_s, 4), "unit": "steps/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
         "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic" + (" (MOVING cloud: not the BASELINE configuration, see --moving)" if args.moving else ""),
-        "particle_steps_per_sec": round(steps_per_s * (args.particles if strong else np_part), 1),
+        "particle_steps_per_sec": round((K / elapsed) * np_global, 1),
         "coupled_steps_per_sec_of_the_whole_box": round(steps_per_s if strong else steps_per_s / world, 4),
         "config": {"workload": workload,
                    "cells": nc, "particles": np_part, "dt": args.dt, ("piso" if c2 else "pimple"): ({"nCorrectors": 2} if c2 else {"nOuterCorrectors": 1, "nCorrectors": 2}),
                    "p_solver": "PCG+MG V(2,2), Chebyshev-weighted Jacobi pairs" if args.p_solver == 1 else "PCG+Jacobi",
                    "p_tol": [case.p_tol, case.p_rel_tol, case.p_final_tol, case.p_final_rel_tol],
                    "parallelism": parallelism,
-                   "global_cells": nc * world, "global_particles": args.particles if strong else np_part * world},
-        "per_step_ms": {k: round(acc[k] / K, 3) for k in ("particle", "bin", "locate_deposit", "finalize", "force", "fold", "momentum", "pressure", "other")},
+                   "global_cells": nc * world, "global_particles": np_global},
+        "per_step_ms": per_step(acc, K),
         "p_iters_per_step": p_iters, "u_iters_per_step": u_iters,
         "roofline": roof(dominant) if dominant else None,
         "roofline_pEqn_laplacian": roof(lap) if lap in kern else None,
@@ -566,6 +691,17 @@ def main():
                                "Krylov iteration) / ms_per_step"},
         "kernels": {k: {"avg_ms": round(v["avg_ms"], 4), "launches": v["launches"], "GBps": round(v["achieved_GBps"], 1)} for k, v in kern.items()},
     }
+    if default_c3 and world == 1 and not args.moving and not args.no_moving:
+        # the BASELINE cloud is at rest and identical every step -- the workload's best case (1 PCG iteration per solve, zero momentum deposits
+        # skipped, re-bin amortised).  The same run with a cloud that MOVES, for the same number of steps, so that the spread is in this record
+        rec0 = rec.clone()
+        macc, mel = timed_region(K, True)
+        out["moving"] = {"what": "same case, same step count, particles with random velocities (+-0.05 m/s) displaced by ~0.1 dx per step between the steps "
+                                 "(inside its timed region); NOT the BASELINE configuration -- reported beside `value`, never as it",
+                         "value": round(K / mel, 4), "unit": "steps/s", "ms_per_step": round(1e3 * mel / K, 3), "p_iters_per_step": macc["p_iters"] / K,
+                         "per_step_ms": per_step(macc, K)}
+        rec.copy_(rec0)
+        del rec0
     if rank == 0 and world == 1 and args.wire > 0:
         # the drop-in leg needs the device memory: the HBM-resident solver is done
         rec_host = rec.cpu().numpy()
@@ -581,27 +717,48 @@ def main():
             out["drop_in_path"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         model, ncores = cpu_info()
-        full = args.cpu_sample_n == 0 or c2
-        n_s = args.n if full else args.cpu_sample_n
-        n_part_cpu = args.particles if full else int(round(args.particles / nc * n_s ** 3))
+        full = args.cpu_sample_n == 0 and not c5                  # C5 at full size would be minutes per CPU step: a 96^3 sample of it by default
+        n_s = (100 if c2 else args.n) if full else (args.cpu_sample_n or 96)
+        nc_s = (n_s ** 3 if not c2 else 1_000_000)
+        n_part_cpu = args.particles if full else int(round(args.particles / nc * nc_s))
         per, snc = cpu_baseline(args.config, n_s, n_part_cpu, args.dt, ncores, full)
-        best_th = min(per, key=lambda k: per[k])
-        scale = snc / nc                                   # 1 at full size; otherwise the linear-in-size extrapolation to the bench workload
+        (t_all, c_all), (t_one, c_one) = per[ncores], per[1]
+        v_all, v_one = (c_all / nc) / t_all, (c_one / nc) / t_one      # steps/s of the bench workload (linear-in-size scaling where a sample was timed)
+        best_th = ncores if v_all >= v_one else 1
         out["cpu_baseline"] = {
-            "value": round((1.0 / per[best_th]) * scale, 6), "unit": "steps/s", "cores": int(best_th), "kind": "port",
-            "single_thread_value": round((1.0 / per[1]) * scale, 6), "cpu_model": model, "host_cores_usable": ncores, "host_cores_present": os.cpu_count(),
-            "sample": (f"the bench workload itself at full size ({snc} cells / {n_part_cpu} particles), CPU oracle (port of the reference path, de-quadraticised "
-                       f"deposit): one warm-up + 2 timed steps on {best_th} threads = {per[best_th]:.2f} s/step; one warm-up + 1 timed step on 1 thread = {per[1]:.2f} s/step"
-                       if full else
-                       f"same workload at {n_s}^3 cells / {n_part_cpu} particles ({scale:.4f} of the bench size), CPU oracle (port of the reference path, "
-                       f"de-quadraticised deposit), measured {per[best_th]:.2f} s/step on {best_th} threads ({per[1]:.2f} s/step on 1); value = measured steps/s x "
-                       f"{scale:.5f} (linear-in-size extrapolation)")}
-        ref = cpu_reference_as_written() if not c2 else None
+            "value": round(max(v_all, v_one), 6), "unit": "steps/s", "cores": int(best_th), "kind": "port",
+            "single_thread_value": round(v_one, 6), "cpu_model": model, "host_cores_usable": ncores, "host_cores_present": os.cpu_count(),
+            "sample": (f"CPU oracle (port of the reference path, de-quadraticised deposit; g++ -O3, no FMA contraction): on {ncores} threads "
+                       + ("the bench workload itself at full size" if full else f"a {c_all / nc:.4f} sample of the bench workload with the same particles per cell")
+                       + f" ({c_all} cells / {n_part_cpu} particles), one warm-up + 1 timed step = {t_all:.2f} s/step; on 1 thread a half-edge sample of that "
+                       f"({c_one} cells / {n_part_cpu // 8} particles) = {t_one:.2f} s/step; samples scaled to the bench size linearly in the cell count")}
+        ref = cpu_reference_as_written() if not (c2 or c5) else None
         if ref is not None:
             out["cpu_reference_as_written"] = ref
             pp = args.particles * steps_per_s
             if "particle_steps_per_sec" in ref:
                 ref["gpu_particle_steps_per_sec_whole_coupled_step"] = round(pp, 1)
+    if rank == 0 and world == 1:
+        # roofline.traffic: measured live or null (never a committed figure passed off as this run's)
+        committed = sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+        note = "not measured in this run" + (f"; the builder's committed passes of the same command: {os.path.relpath(committed[-1], ROOT)}" if committed else "")
+        want = args.pmc == 1 or (args.pmc < 0 and default_c3 and not args.moving)
+        if want:
+            solver_closed = solver is None
+            if not solver_closed:
+                solver.close(); solver = None
+            torch.cuda.empty_cache()
+            tr, why = live_pmc_traffic((["--config", args.config] if args.config != "c3" else []), nc)
+            if tr:
+                note = ("live: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child passes of this command (5 timed steps each), bytes per launch = "
+                        "(2 x FETCH_SIZE + WRITE_SIZE) x 1024; the doubled reads are an upper bound for the gather-dominated particle kernels")
+                for rf in ("roofline", "roofline_pEqn_laplacian"):
+                    if out.get(rf):
+                        out[rf]["traffic"] = tr.get(out[rf]["kernel"])
+                out["traffic_per_launch"] = {k: round(v) for k, v in tr.items()}
+            else:
+                note = f"live PMC pass failed ({why}); " + note
+        out["traffic_note"] = note
     if dist is not None:
         dist.barrier()
     if rank == 0:

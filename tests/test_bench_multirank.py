@@ -37,3 +37,15 @@ def test_two_gloo_ranks_take_the_max(tmp_path):
     j = json.loads(line[0])
     assert j["elapsed"] == 1.5
     assert abs(j["value"] - 2 * 10 / 1.5) < 1e-12
+
+
+def test_plain_command_line_launches_its_own_ranks():
+    """`python bench.py --gpus N` without a launcher (the shape of the driver's N = 1 command) re-runs itself under torch.distributed.run,
+    one rank per GPU, with its own arguments -- instead of dying on WORLD_SIZE != --gpus"""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["FOAMYADE_BENCH_LAUNCH_PROBE"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "7"], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    got = sorted((json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")), key=lambda j: j["rank"])
+    assert [j["rank"] for j in got] == [0, 1] and all(j["world"] == 2 and j["gpus"] == 2 and j["steps"] == 7 for j in got)

@@ -222,3 +222,155 @@ def test_point_force_path_properties_at_c2_size(product):
     U = s.get("U").reshape(nz, ny, nx, 3)
     assert 0.5 < U[nz // 2, ny // 2, 2, 0] <= 1.5                    # the inlet drives the channel
     s.close()
+
+
+def test_particle_path_properties_at_c5_size(product):
+    """BASELINE configs[4] at FULL size on one GPU (C5: 320^3 = 32 768 000 cells, 100 M particles in the lower third, ~9.2 per cell there),
+    handed over as ten Yade-worker batches of 10 M, through the class C-ABI, against host-side closed forms:
+      locate        every particle is located (found = 1) unless it sits in the tree's root cell; mean chain length of a uniform block
+      weights       partition of unity, the Gaussian of the distances (two batches checked pair by pair)
+      deposit       FoamYade.C:605-632 runs buildCellPartList -> setCellVolFraction per Yade proc and setCellVolFraction ASSIGNS
+                    (FoamYade.C:318-328): alpha / uParticle of a cell are those of the LAST batch that touched it -- reproduced on the host
+                    from the stencils of all ten batches, 0.1 floor included (a dense bed: the floor is hit in earnest)
+      forces        finite, zero torque half, zero where nothing was located; the cloud is at rest in a uniform stream, so every located
+                    particle is dragged downstream (F_x > 0) and buoyed up (F_z > 0: gradP = -rho g)"""
+    n, nb, npb = 320, 10, 10_000_000
+    dx = 1.0 / n
+    Nc = n ** 3
+    fields = dict(U=np.zeros((Nc, 3)), gradP=np.zeros((Nc, 3)), vGrad=np.zeros((Nc, 9)), divT=np.zeros((Nc, 3)), ddtU=np.zeros((Nc, 3)))
+    fields["U"][:, 0] = 0.1
+    fields["gradP"][:, 2] = -9810.0
+    mut = dict(uSourceDrag=np.zeros(Nc), alpha=np.zeros(Nc), uSource=np.zeros((Nc, 3)), uParticle=np.zeros((Nc, 3)))
+    mesh = product.BlockMesh(n, n, n, dx, (0.0, 0.0, 0.0))
+    fy = product.FoamYade(mesh, fields["U"], fields["gradP"], fields["vGrad"], fields["divT"], fields["ddtU"], (0, 0, -9.81),
+                          mut["uSourceDrag"], mut["alpha"], mut["uSource"], mut["uParticle"], True)
+    fy.setScalarProperties(2650.0, 1000.0, 1e-6)
+    rs = np.random.Generator(np.random.PCG64(5))
+    batches = []
+    for b in range(nb):
+        rec = np.zeros((npb, 10))
+        rec[:, 0:3] = rs.random((npb, 3))
+        rec[:, 2] *= 1.0 / 3.0
+        rec[:, 3:6] = 0.0 if b % 2 == 0 else rs.normal(0.0, 0.02, (npb, 3))      # every other worker's particles move
+        rec[:, 9] = 0.2 * dx
+        batches.append(rec)
+    fy.setParticles(batches)
+    fy.setParticleAction(1e-4)
+    root = int(fy.tree_preorder()[0])
+    V = dx ** 3
+    alpha_ref = np.ones(Nc)
+    uP_ref = np.zeros((Nc, 3))
+    n_pairs = 0
+    maxdist = 1.25 * (4 * dx) ** 2
+    for b, rec in enumerate(batches):
+        k, ids, w, chain = fy.stencils(b)
+        F, found = fy.forces(b), fy.found(b)
+        cell_of = (np.minimum((rec[:, 0] / dx).astype(np.int64), n - 1) + n * (np.minimum((rec[:, 1] / dx).astype(np.int64), n - 1)
+                   + n * np.minimum((rec[:, 2] / dx).astype(np.int64), n - 1)))
+        assert np.array_equal(found == 1, k > 0) and np.array_equal(k == 0, cell_of == root)
+        ok = (k > 0) & (chain <= 12)
+        assert ok.sum() > 0.999 * npb and 5.3 < k[ok].mean() < 5.6
+        valid = np.arange(16)[None, :] < k[:, None]
+        np.testing.assert_allclose(np.where(valid, w, 0.0).sum(axis=1)[ok], 1.0, rtol=0, atol=1e-12)
+        assert np.array_equal(ids[ok, 0], cell_of[ok].astype(ids.dtype))
+        if b in (0, nb - 1):                                       # pair-by-pair structure on two of the ten batches (the host cost is in these)
+            sl = slice(0, 2_000_000)
+            idc = ids[sl].astype(np.int64)
+            v = valid[sl]
+            d2 = ((((idc % n) + 0.5) * dx - rec[sl, 0:1]) ** 2 + (((idc // n) % n + 0.5) * dx - rec[sl, 1:2]) ** 2) + ((idc // (n * n) + 0.5) * dx - rec[sl, 2:3]) ** 2
+            d2 = np.where(v, d2, np.inf)
+            o = ok[sl]
+            with np.errstate(invalid="ignore"):
+                assert np.all(np.diff(d2[o], axis=1)[v[o][:, 1:]] > 0)
+            assert np.all(d2[o][v[o]] < maxdist)
+            sig = 4 * dx * 0.42460
+            g = np.where(v, np.exp(-np.where(v, d2, 0.0) / (2 * sig * sig)), 0.0)
+            g /= np.maximum(g.sum(axis=1, keepdims=True), 1e-300)
+            np.testing.assert_allclose(np.where(v, w[sl], 0.0)[o], g[o], rtol=1e-9, atol=1e-15)
+        pvol = np.pi * (2 * rec[:, 9]) ** 3 / 6.0
+        flat = ids[valid].astype(np.int64)
+        n_pairs += flat.size
+        wp = (w * pvol[:, None])[valid]
+        acc = np.bincount(flat, weights=wp, minlength=Nc)
+        touched = np.bincount(flat, minlength=Nc) > 0
+        alpha_ref[touched] = np.maximum(1.0 - acc[touched] / V, 0.10)
+        for a in range(3):
+            if b % 2 == 0:
+                uP_ref[touched, a] = 0.0
+            else:
+                uP_ref[touched, a] = np.bincount(flat, weights=wp * np.repeat(rec[:, 3 + a], k), minlength=Nc)[touched] / V
+        loc = k > 0
+        assert np.all(np.isfinite(F)) and np.all(F[:, 3:] == 0.0) and np.all(F[~loc] == 0.0)
+        if b % 2 == 0:
+            assert np.all(F[loc, 0] > 0) and np.all(F[loc, 2] > 0)
+        del k, ids, w, chain, F, found, valid, flat, wp, acc, touched
+    assert 5.3e8 < n_pairs < 5.6e8                                 # ~5.46 pairs per particle
+    np.testing.assert_allclose(mut["alpha"], alpha_ref, rtol=1e-10, atol=1e-12)
+    assert (mut["alpha"] == 0.1).sum() > 100 and (mut["alpha"] == 1.0).sum() > 0.6 * Nc
+    sc = np.abs(uP_ref).max()
+    np.testing.assert_allclose(mut["uParticle"], uP_ref, rtol=1e-9, atol=1e-12 * sc)
+    assert np.all(np.isfinite(mut["uSource"])) and np.abs(mut["uSource"]).max() > 0 and np.all(mut["uSourceDrag"] <= 0.0)
+    fy.close()
+
+
+def test_c5_fluidized_bed_steps_at_full_size(product):
+    """BASELINE configs[4], the whole loop at full size on one GPU (what `bench.py --config c5` times): bottom inlet U = (0,0,Uin), top outlet p = 0,
+    no-slip side walls, 100 M particles at rest in the lower third.  Known answers: all located; the volume flux through the inlet plane, a plane
+    above the bed and the outlet plane are equal (continuity at solver tolerance; alpha = 1 on all three); buoyancy and the drag of the rising
+    fluid push the resting particles up (F_z > 0)"""
+    n, npart, u_in = 320, 100_000_000, 0.05
+    dx = 1.0 / n
+    U_, ZG = product.FY_BC_U_FIXED_VALUE, product.FY_BC_U_ZERO_GRADIENT
+    PX, PF = product.FY_BC_P_FIXED_FLUX, product.FY_BC_P_FIXED_VALUE
+    case = product.make_case(product.FY_SOLVER_PIMPLE, n, n, n, dx, 1e-4, 1e-6, rho_f=1000.0, rho_p=2650.0, g=(0.0, 0.0, -9.81),
+                             u_bc=[U_, U_, U_, U_, U_, ZG], u_val=[(0, 0, 0)] * 4 + [(0, 0, u_in), (0, 0, 0)], p_bc=[PX, PX, PX, PX, PX, PF], p_val=[0.0] * 6,
+                             n_outer_correctors=1, n_correctors=2, p_solver=1)
+    rs = np.random.Generator(np.random.PCG64(5))
+    rec = np.zeros((npart, 10))
+    for lo in range(0, npart, 20_000_000):
+        rec[lo:lo + 20_000_000, 0:3] = rs.random((20_000_000, 3))
+    rec[:, 2] *= 1.0 / 3.0
+    rec[:, 9] = 0.2 * dx
+    s = product.Solver(case)
+    s.set_particles(rec)
+    for _ in range(3):
+        s.step()
+    st = s.stats()
+    found = s.found()
+    assert (found == 1).sum() >= npart - 40                         # all but the few in the root cell
+    F = s.forces()
+    assert np.all(np.isfinite(F)) and (F[found == 1, 2] > 0).mean() > 0.999 and np.all(F[found != 1] == 0.0)
+    del F, rec
+    assert abs(st["cont_err_global"]) < 1e-7 and st["p_iters_total"] < 60, st
+    phiz = s.get("phi_z").reshape(n + 1, n, n)
+    q_in = u_in * n * n * dx * dx
+    for kz in (0, n // 2, n):                                       # inlet plane, a plane above the bed, outlet plane
+        assert abs(phiz[kz].sum() - q_in) < 1e-4 * q_in, (kz, phiz[kz].sum(), q_in)
+    s.close()
+
+
+def test_eight_slabs_of_the_c3_box(product, tmp_path, monkeypatch):
+    """BASELINE configs[3] at full size: the ONE C3 box (160^3 cells, 10 M particles in its lower 60 %) cut into EIGHT z-slabs of 20 planes --
+    virtual slabs on one GPU, the code each RCCL rank runs -- against the same box as a single domain: every slab's 5-plane particle halo reaches a
+    quarter into its neighbour, slabs 5-7 hold few or no particles, the replicated multigrid hierarchy starts at level 1"""
+    monkeypatch.setenv("FOAMYADE_TREE_CACHE_DIR", str(tmp_path))
+    n = N
+    dx = 1.0 / n
+    case = product.make_case(product.FY_SOLVER_PIMPLE, n, n, n, dx, 1e-4, 1e-6, rho_f=1000.0, rho_p=2650.0, g=(0.0, 0.0, -9.81),
+                             u_bc=[product.FY_BC_U_FIXED_VALUE] * 6, u_val=[(0, 0, 0)] * 6, p_bc=[product.FY_BC_P_FIXED_FLUX] * 6,
+                             n_outer_correctors=1, n_correctors=2, p_solver=1)
+    rec = c3_records()
+    one = product.Solver(case)
+    many = product.VirtualSlabs(case, 8)
+    for _ in range(2):
+        one.set_particles(rec); many.set_particles(rec)
+        one.step(); many.step()
+    fo, fm = one.forces(), many.forces()
+    sc = np.abs(fo).max()
+    assert np.abs(fm - fo).max() <= 1e-6 * sc, np.abs(fm - fo).max() / sc
+    for nm, tol in (("U", 1e-5), ("p", 1e-5), ("alpha", 1e-9)):
+        a, b = many.get(nm), one.get(nm)
+        assert np.abs(a - b).max() <= tol * np.abs(b).max(), (nm, np.abs(a - b).max() / np.abs(b).max())
+    so, sm = one.stats(), many.stats()
+    assert all(r["p_iters_total"] == sm[0]["p_iters_total"] for r in sm) and abs(sm[0]["p_iters_total"] - so["p_iters_total"]) <= 2
+    many.close(); one.close()

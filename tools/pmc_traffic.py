@@ -23,7 +23,7 @@ def classify(name, grid, nc):
     if "k_deposit" in name: return "k_deposit"
     if "k_p_apply_dot" in name: return "k_p_apply_dot"
     if "k_mom_pass" in name: return "k_mom_pass"
-    if "k_mg_smooth(" in name and grid >= nc: return "k_mg_smooth(level 0)"
+    if ("k_mg_smooth(" in name or "k_mg_smooth_dot(" in name) and grid >= nc: return "k_mg_smooth(level 0)"
     if "k_tile_reduce" in name: return "k_tile_reduce"
     if "k_point_force" in name: return "k_point_force"
     if "k_bin_gather" in name: return "k_bin_gather"
