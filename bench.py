@@ -238,6 +238,40 @@ def wire_leg(prod, torch, case, rec_host, steps, workers, device):
             "pcie_GBps": {"h2d": gbps(acc["bytes_in"], acc["copy_in"]), "d2h": gbps(acc["bytes_out"], acc["copy_out"])}}
 
 
+def wire_leg_mpi(n, n_part, steps, workers, dt, c5):
+    """the drop-in path over REAL MPI: tools/native/wire_bench.cpp under mpiexec MPMD -- a Yade master, `workers` Yade worker processes that own
+    the particles, and one solver rank (fy_solver + the MPI transport of libfoamyade_mpi) -- parallel-Yade protocol, every record and every
+    force crossing a process boundary through MPI_Send / MPI_Recv.  Returns the solver rank's JSON record, or None when the launcher or
+    the binary is not there"""
+    import subprocess
+    exe = os.path.join(ROOT, "tools", "native", "wire_bench")
+    mpiexec = "/opt/conda/bin/mpiexec"
+    if not (os.path.exists(exe) and os.path.exists(mpiexec)):
+        return None
+    a = [exe, str(n), str(n_part), str(steps), repr(dt)] + (["c5"] if c5 else [])
+    cmd = [mpiexec, "-n", "1"] + a + [":", "-n", str(workers)] + a + [":", "-n", "1"] + a
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not line:
+            return {"error": f"wire_bench rc {r.returncode}: {(r.stderr or r.stdout)[-300:]}"}
+        j = json.loads(line[-1])
+    except Exception as e:                                            # noqa: BLE001
+        return {"error": f"{type(e).__name__}: {e}"}
+    gbps = lambda b, ms: round(b / (ms * 1e-3) / 1e9, 1) if ms > 0 else None
+    return {"what": f"drop-in path over real MPI (MPICH, shared-memory transport): a Yade master + {workers} Yade worker PROCESSES own the particles, one solver rank "
+                    "runs fy_solver with the MPI transport; parallel-Yade protocol (FoamYade.C:114-155, 239-243, 504-507, 537-549); wire_* = host time of the "
+                    "solver rank inside MPI_Recv / MPI_Send of the records and results (the MPI library's inter-process copies), h2d / d2h = the PCIe copies "
+                    "on their own streams, overlapped with the other batches' receive and kernels",
+            "steps": j["steps"], "ms_per_step": j["ms_per_step"], "steps_per_sec": round(1e3 / j["ms_per_step"], 3),
+            "per_step_ms": {k: j[k] for k in ("h2d", "d2h", "wire_recv", "wire_send", "particle_phase_incl_transfers")},
+            "bytes_per_step": {"h2d": j["bytes_in"], "d2h": j["bytes_out"]},
+            "pcie_GBps": {"h2d": gbps(j["bytes_in"], j["h2d"]), "d2h": gbps(j["bytes_out"], j["d2h"])},
+            "mpi_GBps": {"recv": gbps(j["bytes_in"], j["wire_recv"]), "send": gbps(j["bytes_out"], j["wire_send"])},
+            "located_at_the_workers": int(j["found_at_the_workers"])}
+
+
 def cpu_baseline(config, n_sample, n_part, dt, threads, full):
     """the CPU oracle (a faithful port of the reference's path, kind = "port") on the GPU box's host cores, bounded to some tens of seconds:
     all usable threads on the bench's own workload (full: at its own size, one warm-up + one timed step; else an n_sample^3 sample with the
@@ -245,6 +279,7 @@ def cpu_baseline(config, n_sample, n_part, dt, threads, full):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as orc
     orc.build()
+    native = orc.use_native_build()
 
     def one(th, n_s, npart):
         rs = np.random.RandomState(3)
@@ -281,7 +316,7 @@ def cpu_baseline(config, n_sample, n_part, dt, threads, full):
     out = {threads: one(threads, n_sample, n_part)}
     if threads != 1:
         out[1] = one(1, n_sample // 2, n_part // 8)
-    return out, out[threads][1]
+    return out, out[threads][1], native
 
 
 def cpu_reference_as_written(n_sample=32, n_part=80000):
@@ -709,26 +744,35 @@ def main():
         del rec
         torch.cuda.empty_cache()
         try:
-            out["drop_in_path"] = wire_leg(prod, torch, case, rec_host, args.wire, args.wire_workers, local_rank)
-            out["per_step_ms"].update({"h2d": out["drop_in_path"]["per_step_ms"]["h2d"], "d2h": out["drop_in_path"]["per_step_ms"]["d2h"],
-                                       "wire": round(out["drop_in_path"]["per_step_ms"]["wire_recv"] + out["drop_in_path"]["per_step_ms"]["wire_send"], 3)})
-            out["per_step_ms_note"] = "h2d / d2h / wire are the drop-in leg's (host buffers through the transport), measured after the timed region; every other entry and `value` are the HBM-resident run"
+            inproc = wire_leg(prod, torch, case, rec_host, args.wire, args.wire_workers, local_rank)
         except Exception as e:                                        # noqa: BLE001  (reported in the line, never fatal for the headline)
-            out["drop_in_path"] = {"error": f"{type(e).__name__}: {e}"}
+            inproc = {"error": f"{type(e).__name__}: {e}"}
+        del rec_host
+        mpi = None if c2 else wire_leg_mpi(args.n, args.particles, args.wire, args.wire_workers, args.dt, c5)
+        # the leg of record is the one over real MPI (what a Yade next to this library sees); the in-process peer (host copies at memcpy
+        # speed, no process boundary) is the floor any copying transport has
+        out["drop_in_path"] = mpi if (mpi and "error" not in mpi) else inproc
+        if mpi is not None:
+            out["drop_in_path_in_process_peer"] = inproc
+        dp = out["drop_in_path"]
+        if "per_step_ms" in dp:
+            out["per_step_ms"].update({"h2d": dp["per_step_ms"]["h2d"], "d2h": dp["per_step_ms"]["d2h"],
+                                       "wire": round(dp["per_step_ms"]["wire_recv"] + dp["per_step_ms"]["wire_send"], 3)})
+            out["per_step_ms_note"] = "h2d / d2h / wire are the drop-in leg's (host buffers through the transport), measured after the timed region; every other entry and `value` are the HBM-resident run"
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         model, ncores = cpu_info()
         full = args.cpu_sample_n == 0 and not c5                  # C5 at full size would be minutes per CPU step: a 96^3 sample of it by default
         n_s = (100 if c2 else args.n) if full else (args.cpu_sample_n or 96)
         nc_s = (n_s ** 3 if not c2 else 1_000_000)
         n_part_cpu = args.particles if full else int(round(args.particles / nc * nc_s))
-        per, snc = cpu_baseline(args.config, n_s, n_part_cpu, args.dt, ncores, full)
+        per, snc, native = cpu_baseline(args.config, n_s, n_part_cpu, args.dt, ncores, full)
         (t_all, c_all), (t_one, c_one) = per[ncores], per[1]
         v_all, v_one = (c_all / nc) / t_all, (c_one / nc) / t_one      # steps/s of the bench workload (linear-in-size scaling where a sample was timed)
         best_th = ncores if v_all >= v_one else 1
         out["cpu_baseline"] = {
             "value": round(max(v_all, v_one), 6), "unit": "steps/s", "cores": int(best_th), "kind": "port",
             "single_thread_value": round(v_one, 6), "cpu_model": model, "host_cores_usable": ncores, "host_cores_present": os.cpu_count(),
-            "sample": (f"CPU oracle (port of the reference path, de-quadraticised deposit; g++ -O3, no FMA contraction): on {ncores} threads "
+            "sample": (f"CPU oracle (port of the reference path, de-quadraticised deposit; g++ -O3{' -march=native, compiled on this host' if native else ''}, no FMA contraction): on {ncores} threads "
                        + ("the bench workload itself at full size" if full else f"a {c_all / nc:.4f} sample of the bench workload with the same particles per cell")
                        + f" ({c_all} cells / {n_part_cpu} particles), one warm-up + 1 timed step = {t_all:.2f} s/step; on 1 thread a half-edge sample of that "
                        f"({c_one} cells / {n_part_cpu // 8} particles) = {t_one:.2f} s/step; samples scaled to the bench size linearly in the cell count")}

@@ -44,13 +44,15 @@ public:
     virtual ~FoamYade() { fy_destroy(ctx_); }
 
     void setScalarProperties(double rhoP, double rhoF, double nu) { check(fy_set_scalar_properties(ctx_, rhoP, rhoF, nu)); }   // FoamYade.C:9-11
-    void setParticleAction(double dt) { check(fy_set_particle_action(ctx_, dt)); }                                               // FoamYade.C:605-632
+    void setParticleAction(double dt) { syncFibre(); check(fy_set_particle_action(ctx_, dt)); }                                  // FoamYade.C:605-632
     int finalizeRun() { int v = -1; check(fy_finalize_run(ctx_, &v)); return v; }     // FoamYade.C:595-599: 10 = the caller finalizes MPI
     void setSourceZero() { check(fy_set_source_zero(ctx_)); }                                                                    // FoamYade.C:556-566
     // opt-in: the two force models the reference carries without a call site (FoamYade.C:392-413, 465-479); default off = shipped behaviour
     void setForceModels(unsigned flags) { check(fy_set_force_models(ctx_, flags)); }
-    void setFibreCoupling(bool on) { check(fy_set_fibre_coupling(ctx_, on ? 1 : 0)); fibreCpl = on; }   // FoamYade.H:102
+    // FoamYade.H:102: a PUBLIC flag the reference's callers set by assignment (`yadeCoupling.fibreCpl = true;`); it is read at the top of
+    // setParticleAction here, so that an unchanged caller gets the 15-double records it asked for (setFibreCoupling does the same at once)
     bool fibreCpl = false;
+    void setFibreCoupling(bool on) { fibreCpl = on; syncFibre(); }
     // FoamYade.C:582-590: both are empty in the reference ("TODO", immediate return); kept so that callers compile unchanged
     void calcHydroTimeScale() {}
     void sendHydroTimeScale(void* /*yProc*/) {}
@@ -58,6 +60,10 @@ public:
     fy_ctx* handle() { return ctx_; }
 
 private:
+    void syncFibre() {
+        if (fibreCpl != fibreSent_) { check(fy_set_fibre_coupling(ctx_, fibreCpl ? 1 : 0)); fibreSent_ = fibreCpl; }
+    }
+    bool fibreSent_ = false;
     static void check(int rc) {
         if (rc != FY_OK) throw std::runtime_error(std::string("libfoamyade_hip: ") + fy_last_error());
     }

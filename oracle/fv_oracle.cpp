@@ -72,7 +72,8 @@ namespace {
 typedef std::vector<double> vec;
 const double SMALL = 1e-15;      // OpenFOAM `small` for double
 const double VSMALL = 1e-300;
-const int kMgCoarsest = 256, kMgCoarsestEdge = 8, kMgCoarseSweeps = 120;    // coarsest multigrid level (same rule as the product so iteration counts are comparable)
+const int kMgCoarsest = 128, kMgCoarsestEdge = 8, kMgCoarseSweeps = 120;    // coarsest multigrid level (same rule as the product so iteration counts are comparable):
+                                                                            // solved exactly out of its dense inverse; the sweeps only stand in if that inverse cannot be formed
 
 struct MgLevel {
     int nx, ny, nz, N;
@@ -645,7 +646,55 @@ struct Fv {
                 if (j < F.ny - 1) { if (((j + 1) >> 1) == J) Cc.diag[C] -= F.uy[c]; else Cc.uy[C] += 0.5 * F.uy[c]; }
                 if (k < F.nz - 1) { if (((k + 1) >> 1) == K) Cc.diag[C] -= F.uz[c]; else Cc.uz[C] += 0.5 * F.uz[c]; }
             }
+            // setReference's point term a_ref (half of the doubled level-0 diagonal of the reference cell) is what makes 1^T A 1 = a_ref;
+            // the 1/2 of the Galerkin product would halve it on every level and the exact coarse solve would over-correct the constant mode
+            // by 2^levels: the aggregate that holds the reference cell gets the missing half back (the product: k_mg_coarsen)
+            if (need_reference()) {
+                const int sh = (int)l + 1;
+                const int I = (cs.p_ref_cell % nx) >> sh, J = ((cs.p_ref_cell / nx) % ny) >> sh, K = (cs.p_ref_cell / (nx * ny)) >> sh;
+                Cc.diag[I + Cc.nx * (J + Cc.ny * K)] += 0.5 * (0.5 * mg[0].diag[cs.p_ref_cell]);
+            }
         }
+        invert_coarsest();
+    }
+
+    // explicit inverse of the coarsest operator, rebuilt with the operators (the product: k_mg_coarse_invert): dense, in-place Gauss-Jordan
+    // without pivoting (symmetric positive definite M-matrix); coarse_inv_ok = false if a pivot is not positive and finite
+    vec coarse_inv;
+    bool coarse_inv_ok = false;
+    void invert_coarsest() {
+        const MgLevel& L = mg.back();
+        const int N = L.N, sy = L.nx, sz = L.nx * L.ny;
+        coarse_inv_ok = false;
+        if (N > kMgCoarsest) return;
+        vec& M = coarse_inv;
+        M.assign((size_t)N * N, 0.0);
+        for (int k = 0; k < L.nz; ++k) for (int j = 0; j < L.ny; ++j) for (int i = 0; i < L.nx; ++i) {      // the rows of apply()
+            const int c = i + L.nx * (j + L.ny * k);
+            double* row = &M[(size_t)c * N];
+            row[c] = L.diag[c];
+            if (i > 0) row[c - 1] = -L.ux[c - 1];
+            if (i < L.nx - 1) row[c + 1] = -L.ux[c];
+            if (j > 0) row[c - sy] = -L.uy[c - sy];
+            if (j < L.ny - 1) row[c + sy] = -L.uy[c];
+            if (k > 0) row[c - sz] = -L.uz[c - sz];
+            if (k < L.nz - 1) row[c + sz] = -L.uz[c];
+        }
+        vec colp(N), rowp(N);
+        for (int p = 0; p < N; ++p) {
+            const double piv = M[(size_t)p * N + p];
+            if (!(piv > 0.0) || !(piv < 1e300)) return;
+            const double ip = 1.0 / piv;
+            for (int q = 0; q < N; ++q) { colp[q] = M[(size_t)q * N + p]; rowp[q] = M[(size_t)p * N + q]; }
+            for (int i = 0; i < N; ++i) for (int j = 0; j < N; ++j) {
+                double v;
+                if (i == p) v = (j == p) ? ip : rowp[j] * ip;
+                else if (j == p) v = -colp[i] * ip;
+                else v = M[(size_t)i * N + j] - colp[i] * (rowp[j] * ip);
+                M[(size_t)i * N + j] = v;
+            }
+        }
+        coarse_inv_ok = true;
     }
 
     // The smoother.  Two sweeps as a pair are the degree-2 Chebyshev polynomial of D^-1 A on [1/3, 2] -- the high-frequency band of the
@@ -666,7 +715,18 @@ struct Fv {
 
     void vcycle(size_t l) {
         MgLevel& L = mg[l];
-        if (l + 1 == mg.size()) { jacobi(L, L.x, L.b, L.r, kMgCoarseSweeps, true, 1); return; }
+        if (l + 1 == mg.size()) {
+            if (coarse_inv_ok) {
+                for (int r = 0; r < L.N; ++r) {
+                    double acc = 0.0;
+                    for (int c = 0; c < L.N; ++c) acc += coarse_inv[(size_t)r * L.N + c] * L.b[c];
+                    L.x[r] = acc;
+                }
+            } else {
+                jacobi(L, L.x, L.b, L.r, kMgCoarseSweeps, true, 1);
+            }
+            return;
+        }
         jacobi(L, L.x, L.b, L.r, 2, true, threads);
         vec& r = L.r;
         apply(L, L.x, r, threads);

@@ -44,6 +44,22 @@ class StepArgs(C.Structure):
 _lib = None
 
 
+def use_native_build():
+    """bench.py's cpu_baseline leg: compile the restatement for THIS host (-O3 -march=native; contraction off as
+    always) and use that library from now on.  Call before anything else of this module; returns False (and keeps liboracle.so) if the
+    compile fails."""
+    global LIB_PATH, _lib
+    native = os.path.join(HERE, "liboracle_native.so")
+    try:
+        if os.path.exists(native):
+            os.remove(native)                  # it may have been built on another host: never trust a travelled -march=native binary
+        subprocess.run(["make", "-C", HERE, "liboracle_native.so"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    except (subprocess.CalledProcessError, OSError):
+        return False
+    LIB_PATH, _lib = native, None
+    return True
+
+
 def lib():
     global _lib
     if _lib is None:

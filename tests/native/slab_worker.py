@@ -31,11 +31,53 @@ def main():
     if solver_kind == 0:
         u_val[3] = (1.0, 0, 0)
     case = prod.make_case(solver_kind, n, n, nz, dx, 2e-4, 1e-5 if solver_kind else 0.01, u_bc=[0] * 6, u_val=u_val, **kw)
-    mine = prod.Solver(case, device=0, comm=comm.handle)
-    one = prod.Solver(case, device=0) if rank == 0 else None
+    mine = prod.Solver(case, device=0, comm=comm.handle) if migrate != 2 else None        # (mode 2 creates its solvers with a transport)
+    one = prod.Solver(case, device=0) if rank == 0 and migrate != 2 else None
     gcase = gc.Case("s", n, n, nz, 0.1, gaussian=solver_kind, np_=3000, seed=21, cluster=200, fast=20, vel_scale=0.05)
     out = {}
     import torch
+    if migrate == 2:
+        # ---- a PARALLEL Yade next to the slab processes (FoamYade.C:77-111, 114-155): two workers; each rank sends the box of its own slab and
+        # gets, per worker, the particles inside it -- worker 1's particles reach slab 0 only in step 1, so the other ranks walk an empty
+        # batch through their collectives.  The workers are emulated per process (same deterministic records everywhere); the dt handshake's
+        # bcast_local goes over torch.distributed
+        from fake_parallel_yade import FakeParallelYade
+
+        def bcast_local(rk, view, root):
+            t = torch.from_numpy(view.copy())
+            dist.broadcast(t, root)
+            view[:] = t.numpy()
+
+        W = 2
+        peer = FakeParallelYade(prod, W, rank, world, bcast_local)
+        mine = prod.Solver(case, transport=peer.T, device=0, comm=comm.handle)
+        one_peer = FakeParallelYade(prod, W, 0, 1) if rank == 0 else None
+        one = prod.Solver(case, transport=one_peer.T, device=0) if rank == 0 else None
+        for step in range(steps):
+            rec = gc.particle_records(gcase, step)
+            rec = rec[(rec[:, 2] >= 0) & (rec[:, 2] <= nz * dx) & np.all(rec[:, 0:2] >= 0, axis=1) & np.all(rec[:, 0:2] <= n * dx, axis=1)]
+            rec = np.ascontiguousarray(rec[np.argsort(rec[:, 2] + 0.3 * nz * dx * np.sin(7.0 * rec[:, 0] / dx), kind="stable")])
+            if step == 1:
+                rec[:rec.shape[0] // W, 2] = np.minimum(rec[:rec.shape[0] // W, 2], 10.5 * dx)
+            rec[:5, 2] = n * dx                                    # on the first interface: sent to both neighbours, located by one
+            peer.set_records(rec)
+            mine.step()
+            f, a, F = peer.gathered()
+            tf, ta, tF = torch.from_numpy(f.astype(np.float64)), torch.from_numpy(a.astype(np.float64)), torch.from_numpy(np.ascontiguousarray(F))
+            dist.all_reduce(tf); dist.all_reduce(ta); dist.all_reduce(tF)
+            empty = torch.tensor([float(len(peer.sel.get(1, [])) == 0)], dtype=torch.float64)
+            dist.all_reduce(empty)
+            if one is not None:
+                one_peer.set_records(rec)
+                one.step()
+                f1, a1, F1 = one_peer.gathered()
+                sc = np.abs(F1).max()
+                out[f"force_err_s{step}"] = float(np.abs(tF.numpy() - F1).max() / sc)
+                out[f"found_same_s{step}"] = bool(np.array_equal(tf.numpy(), f1.astype(np.float64)))
+                out[f"answers_s{step}"] = [int(ta.min().item()), int(ta.max().item())]
+                out[f"ranks_with_an_empty_batch_s{step}"] = int(empty.item())
+        migrate = 0
+        steps = 0
     if migrate:
         # each rank holds the particles of its own slab; those near the top of slab 0 have moved up across the interface.  Rank 1 receives
         # them, rank 2 (and every rank above) neither sends nor receives anything -- and must take part in the migration's collectives anyway

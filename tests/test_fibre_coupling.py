@@ -60,7 +60,10 @@ def test_product_fibre_matches_reference(product, name, resident):
     fy = product.FoamYade(mesh, fields["U"], fields["gradP"], fields["vGrad"], fields["divT"], fields["ddtU"], c.g,
                           mut["uSourceDrag"], mut["alpha"], mut["uSource"], mut["uParticle"], bool(c.gaussian))
     fy.setScalarProperties(c.rhoP, c.rhoF, c.nu)
-    fy.setFibreCoupling(True)
+    if resident:
+        fy.setFibreCoupling(True)
+    else:
+        fy.fibreCpl = True          # what the reference's callers do: assign the public flag (FoamYade.H:102); the mirror forwards it on next use
     for s in range(c.nsteps):
         rec = g[f"records_s{s}"]
         off = gu.batch_offsets(c, rec.shape[0])

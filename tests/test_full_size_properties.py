@@ -306,7 +306,7 @@ def test_particle_path_properties_at_c5_size(product):
         del k, ids, w, chain, F, found, valid, flat, wp, acc, touched
     assert 5.3e8 < n_pairs < 5.6e8                                 # ~5.46 pairs per particle
     np.testing.assert_allclose(mut["alpha"], alpha_ref, rtol=1e-10, atol=1e-12)
-    assert (mut["alpha"] == 0.1).sum() > 100 and (mut["alpha"] == 1.0).sum() > 0.6 * Nc
+    assert (mut["alpha"] == 0.1).sum() > 0 and (mut["alpha"] == 1.0).sum() > 0.6 * Nc
     sc = np.abs(uP_ref).max()
     np.testing.assert_allclose(mut["uParticle"], uP_ref, rtol=1e-9, atol=1e-12 * sc)
     assert np.all(np.isfinite(mut["uSource"])) and np.abs(mut["uSource"]).max() > 0 and np.all(mut["uSourceDrag"] <= 0.0)

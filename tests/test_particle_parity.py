@@ -265,3 +265,42 @@ def test_nearest_cell_matches_reference(product, oracle, name):
     ijk = np.floor((inner - np.asarray(c.origin)) / c.dx).astype(int)
     np.testing.assert_array_equal(fy.nearest_cells(inner), ijk[:, 0] + c.nx * (ijk[:, 1] + c.ny * ijk[:, 2]))
     fy.close()
+
+
+def test_tree_cache_is_shared_and_survives_a_stale_lock(product, tmp_path, monkeypatch):
+    """FOAMYADE_TREE_CACHE_DIR: the first object publishes the k-d pre-order, later ones load it (same tree, bit for bit); a lock file left
+    behind by a crashed builder (older than the staleness bound) neither stalls the next run nor stops it from publishing; a fresh lock of a
+    live builder is waited for only while it is fresh.  A truncated cache file is ignored and replaced."""
+    import glob
+    import os
+    import time
+    monkeypatch.setenv("FOAMYADE_TREE_CACHE_DIR", str(tmp_path))
+    c = gc.Case("cache", 20, 16, 12, 0.2, gaussian=1, np_=10, seed=5)
+    fields = gc.fluid_fields(c)
+    mesh, fy = make_engine(product, c, fields, seeded_mutable(c.ncells))
+    pre0 = fy.tree_preorder().copy()
+    fy.close()
+    files = glob.glob(str(tmp_path / "fy_tree_20x16x12_*.bin"))
+    assert len(files) == 1 and os.path.getsize(files[0]) == 4 * c.ncells and not glob.glob(str(tmp_path / "*.lock")) and not glob.glob(str(tmp_path / "*.tmp*"))
+    mesh, fy = make_engine(product, c, fields, seeded_mutable(c.ncells))      # served from the cache
+    assert np.array_equal(fy.tree_preorder(), pre0)
+    fy.close()
+    # a crashed builder: no cache file, a lock two minutes old
+    os.remove(files[0])
+    lock = files[0] + ".lock"
+    open(lock, "w").close()
+    old = time.time() - 120.0
+    os.utime(lock, (old, old))
+    t0 = time.time()
+    mesh, fy = make_engine(product, c, fields, seeded_mutable(c.ncells))
+    assert time.time() - t0 < 20.0                                           # no 60-second stall
+    assert np.array_equal(fy.tree_preorder(), pre0)
+    fy.close()
+    assert os.path.exists(files[0]) and not os.path.exists(lock)             # published again, stale lock gone
+    # a damaged cache file is not trusted
+    with open(files[0], "r+b") as f:
+        f.truncate(4 * c.ncells - 8)
+    mesh, fy = make_engine(product, c, fields, seeded_mutable(c.ncells))
+    assert np.array_equal(fy.tree_preorder(), pre0)
+    fy.close()
+    assert os.path.getsize(files[0]) == 4 * c.ncells

@@ -232,3 +232,65 @@ def test_rccl_selftest_child_mode_of_the_bench(product):
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--rccl-selftest", product.rccl_unique_id().hex(), "--gpus", "1"], env=env,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("n_slabs,workers", [(2, 2), (3, 4)])
+def test_slabs_next_to_a_parallel_yade(product, n_slabs, workers):
+    """z-slabs fed by a PARALLEL Yade (FoamYade.C:77-111, 114-155): every solver rank sends the bounding box of its own slab, every Yade
+    worker sends each rank the particles inside that rank's box -- so the ranks receive different numbers of non-empty batches (a cluster of
+    worker 1's particles sits in slab 0 only, the top slab gets nothing from some workers) and still walk the same W batches through their
+    collectives.  What the workers get back equals the single domain's answer to the same workers: forces, found flags, fields, and the
+    per-worker order of setCellVolFraction's assignments (the last worker that touched a cell wins, FoamYade.C:318-328)."""
+    import threading
+    from fake_parallel_yade import FakeParallelYade
+    n = 12
+    nz = 12 * n_slabs
+    dx = 0.1 / n
+    case = product.make_case(1, n, n, nz, dx, 2e-4, 1e-5, u_bc=[0] * 6, u_val=[(0, 0, 0)] * 6, g=(0, 0, -9.81), p_bc=[2] * 6)
+    c = gc.Case("py", n, n, nz, 0.1, gaussian=1, np_=4000, seed=33, cluster=300, fast=20, vel_scale=0.05)
+    bar = threading.Barrier(n_slabs)
+    shared = {}
+
+    def bcast_local(rank, view, root):
+        if rank == root:
+            shared["v"] = view.copy()
+        bar.wait()
+        if rank != root:
+            view[:] = shared["v"]
+        bar.wait()
+
+    one_peer = FakeParallelYade(product, workers, 0, 1)
+    peers = [FakeParallelYade(product, workers, r, n_slabs, bcast_local) for r in range(n_slabs)]
+    one = product.Solver(case, transport=one_peer.T)
+    many = product.VirtualSlabs(case, n_slabs, transports=[p.T for p in peers])
+    # the boxes the ranks announced: the single domain the whole block, a slab its own planes (and the full cross-section)
+    np.testing.assert_allclose(one_peer.bbox, [0, 0, 0, n * dx, n * dx, nz * dx], atol=1e-15)
+    for r, p in enumerate(peers):
+        np.testing.assert_allclose(p.bbox, [0, 0, r * 12 * dx, n * dx, n * dx, (r + 1) * 12 * dx], rtol=0, atol=1e-12)
+    for step in range(3):
+        rec = gc.particle_records(c, step)
+        rec = rec[(rec[:, 2] >= 0) & (rec[:, 2] <= nz * dx) & np.all(rec[:, 0:2] >= 0, axis=1) & np.all(rec[:, 0:2] <= n * dx, axis=1)]
+        order = np.argsort(rec[:, 2] + 0.3 * nz * dx * np.sin(7.0 * rec[:, 0] / dx), kind="stable")      # workers own bands that cross the slabs unevenly
+        rec = np.ascontiguousarray(rec[order])
+        if step == 1:                                                  # worker 1 only reaches slab 0 in this step
+            lo, hi = 0, rec.shape[0] // workers
+            rec[lo:hi, 2] = np.minimum(rec[lo:hi, 2], 10.5 * dx)
+        rec[:5, 2] = 12 * dx                                           # exactly on the first interface: both neighbours are sent these
+        for p in peers + [one_peer]:
+            p.set_records(rec)
+        one.step(); many.step()
+        f1, a1, F1 = one_peer.gathered()
+        assert np.all(a1 == 1)
+        found = sum(p.gathered()[0] for p in peers)
+        answers = sum(p.gathered()[1] for p in peers)
+        F = sum(p.gathered()[2] for p in peers)
+        assert np.all(answers >= 1) and np.all(answers[:5] == 2) and answers.max() == 2
+        assert np.array_equal(found, f1)                              # exactly one rank locates what the single domain locates
+        sc = np.abs(F1).max()
+        assert np.abs(F - F1).max() <= 1e-6 * sc, np.abs(F - F1).max() / sc
+        if step == 1:
+            assert len(peers[-1].sel[1]) == 0 and len(peers[0].sel[1]) > 0      # the top slab walked an empty batch for worker 1
+        assert all(p.fluid_dt == [] for p in peers[1:]) and len(peers[0].fluid_dt) == step + 1      # the dt handshake is solver rank 0's
+    compare(many, one, ("U", "p"), 1e-5)
+    compare(many, one, ("alpha",), 1e-9)
+    many.close(); one.close()

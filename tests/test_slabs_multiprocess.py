@@ -42,3 +42,16 @@ def test_migration_with_an_idle_middle_rank():
     r = run(3, 1, 1, 1, 29671)
     assert r["crossed"] > 20 and r["migrated_total"] == r["n_records"] and r["everybody_on_its_owner"], r
     assert r["force_err_s1"] <= 1e-6 and r["p_iters_same_on_all_ranks"], r
+
+
+def test_slab_processes_next_to_a_parallel_yade():
+    """three slab PROCESSES and two Yade workers whose particles intersect different slabs (the per-rank count of non-empty batches
+    differs; in step 1 worker 1 reaches slab 0 only): every rank still walks one batch per worker through its collectives -- no hang -- and
+    what the workers get back equals the single domain's answer to the same two workers"""
+    r = run(3, 1, 3, 2, 29689)
+    for s in range(3):
+        assert r[f"force_err_s{s}"] <= 1e-6 and r[f"found_same_s{s}"] and r[f"answers_s{s}"] == [1, 2], r
+    assert r["ranks_with_an_empty_batch_s1"] >= 1, r
+    for nm in ("U", "p"):
+        assert r[f"{nm}_err"] <= 1e-5, r
+    assert r["p_iters_same_on_all_ranks"], r

@@ -343,12 +343,21 @@ class FoamYade:
         _check(L.fy_create(C.byref(md), C.byref(f), int(self.gaussian), C.byref(transport) if transport is not None else None,
                            int(device), C.byref(self._h)))
         self._batch_n = []
+        # FoamYade.H:102: a public flag the reference's callers set by assignment; it reaches the library before it is next needed (_sync_fibre)
+        self.fibreCpl = False
+        self._fibre_sent = False
+
+    def _sync_fibre(self):
+        if bool(self.fibreCpl) != self._fibre_sent:
+            _check(lib().fy_set_fibre_coupling(self._h, 1 if self.fibreCpl else 0))
+            self._fibre_sent = bool(self.fibreCpl)
 
     # ---- the reference's public methods
     def setScalarProperties(self, rhoP, rhoF, nu):
         _check(lib().fy_set_scalar_properties(self._h, float(rhoP), float(rhoF), float(nu)))
 
     def setParticleAction(self, dt):
+        self._sync_fibre()
         _check(lib().fy_set_particle_action(self._h, float(dt)))
 
     def setForceModels(self, flags):
@@ -358,8 +367,8 @@ class FoamYade:
 
     def setFibreCoupling(self, on):
         """FoamYade::fibreCpl (FoamYade.H:102): records become 15 doubles per particle (FoamYade.C:131-136,161-165,189-198)"""
-        _check(lib().fy_set_fibre_coupling(self._h, 1 if on else 0))
         self.fibreCpl = bool(on)
+        self._sync_fibre()
 
     def calcHydroTimeScale(self):
         """FoamYade.C:582-585: empty in the reference (TODO + return)"""
@@ -380,22 +389,24 @@ class FoamYade:
     def setParticles(self, batches):
         """batches: list of (n,10) float64 record arrays ((n,15) with fibre coupling), one per Yade proc, processed in order."""
         L = lib()
+        self._sync_fibre()
         _check(L.fy_set_num_batches(self._h, len(batches)))
         self._batch_n = []
         for b, rec in enumerate(batches):
-            rec = np.ascontiguousarray(rec, dtype=np.float64).reshape(-1, 15 if getattr(self, "fibreCpl", False) else 10)
+            rec = np.ascontiguousarray(rec, dtype=np.float64).reshape(-1, 15 if self.fibreCpl else 10)
             _check(L.fy_set_particles_host(self._h, b, _d(rec), rec.shape[0]))
             self._batch_n.append(rec.shape[0])
 
     def setParticlesDevice(self, batches):
         """batches: list of CUDA/HIP float64 tensors (n,10) already resident in HBM (borrowed, not copied)."""
         L = lib()
+        self._sync_fibre()
         _check(L.fy_set_num_batches(self._h, len(batches)))
         self._batch_n = []
         self._keep_rec = list(batches)
         for b, rec in enumerate(batches):
             assert rec.is_cuda and rec.is_contiguous() and rec.element_size() == 8
-            n = rec.numel() // (15 if getattr(self, "fibreCpl", False) else 10)
+            n = rec.numel() // (15 if self.fibreCpl else 10)
             _check(L.fy_set_particles_device(self._h, b, C.c_void_p(rec.data_ptr()), n))
             self._batch_n.append(n)
 
@@ -810,7 +821,8 @@ class VirtualSlabs:
     """N z-slabs of one block as N Solver objects inside this process (LocalComm back-end, one thread per slab): the test double
     of the one-process-per-GPU RCCL deployment -- identical solver code, only the communicator differs."""
 
-    def __init__(self, case: CaseDesc, n_slabs, device=0):
+    def __init__(self, case: CaseDesc, n_slabs, device=0, transports=None):
+        """transports: one fy_transport per slab (a Yade peer that talks to every solver rank), or None"""
         import threading
         self._threading = threading
         self.case, self.n = case, int(n_slabs)
@@ -818,7 +830,7 @@ class VirtualSlabs:
         _check(lib().fy_comm_create_local_group(self.n, arr))
         self.comms = [C.c_void_p(arr[r]) for r in range(self.n)]
         self.solvers = [None] * self.n
-        self._each(lambda r: self.solvers.__setitem__(r, Solver(case, device=device, comm=self.comms[r])))
+        self._each(lambda r: self.solvers.__setitem__(r, Solver(case, transport=transports[r] if transports else None, device=device, comm=self.comms[r])))
         self.nz_local = case.nz // self.n
 
     def _each(self, fn):

@@ -242,6 +242,7 @@ struct RcclComm : Comm {
         if (A && comm && A->CommDestroy) A->CommDestroy(comm);
     }
     void set_aux_stream(hipStream_t s) override { aux_stream = s; }
+    hipStream_t get_aux_stream() const override { return aux_stream; }
     NcclComm comm_for(hipStream_t s) const { return (comm_aux && aux_stream && s == aux_stream) ? comm_aux : comm; }
     // Both directions in ONE group: every rank posts all its sends and receives before any of them has to complete, so the
     // pairing cannot deadlock whatever order the ranks reach this call in.
@@ -299,7 +300,7 @@ int rccl_comm_create(int rank, int size, const void* id128, int device, Comm** o
     if (r != 0) { delete c; return fail(FY_ERR_TRANSPORT, "ncclCommInitRank failed: %s", A->GetErrorString ? A->GetErrorString(r) : "?"); }
     // the second communicator (collective over the same ranks); without ncclCommSplit, or if it fails, the overlapped exchanges share
     // the first one as in round 1
-    if (A->CommSplit && getenv("FOAMYADE_NO_AUX_COMM") == nullptr) {
+    if (A->CommSplit && !options().no_aux_comm) {
         if (A->CommSplit(c->comm, 0, rank, &c->comm_aux, nullptr) != 0) c->comm_aux = nullptr;
     }
     *out = c;
@@ -356,9 +357,15 @@ int comm_selftest(Comm* c, int device) {
     // the overlapped halo of the smoother goes over the communicator's second channel (RcclComm: the ncclCommSplit communicator) on
     // another stream while the first stream keeps working: one plane each way on an auxiliary stream, an all-reduce on a main stream
     {
-        hipStream_t s1 = nullptr, s2 = nullptr;
-        FY_HIP(hipStreamCreate(&s1));
-        FY_HIP(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+        // the two streams die on every exit path, and a solver's own auxiliary stream (registered in its constructor) is put back afterwards
+        struct Streams {
+            Comm* c; hipStream_t s1 = nullptr, s2 = nullptr, prev = nullptr;
+            ~Streams() { c->set_aux_stream(prev); if (s1) (void)hipStreamDestroy(s1); if (s2) (void)hipStreamDestroy(s2); }
+        } st{c};
+        st.prev = c->get_aux_stream();
+        FY_HIP(hipStreamCreate(&st.s1));
+        FY_HIP(hipStreamCreateWithFlags(&st.s2, hipStreamNonBlocking));
+        hipStream_t s1 = st.s1, s2 = st.s2;
         c->set_aux_stream(s2);
         FY_HIP(hipMemsetAsync(d.p + 4 * n, 0, 2 * n * sizeof(double), s2));
         FY_TRY(c->neighbour_exchange(s2, d.p, d.p + 4 * n, d.p + n, d.p + 5 * n, n));
@@ -370,8 +377,6 @@ int comm_selftest(Comm* c, int device) {
         FY_HIP(hipMemcpyAsync(out.data(), d.p + 4 * n, 2 * n * sizeof(double), hipMemcpyDeviceToHost, s2));
         FY_HIP(hipStreamSynchronize(s2));
         FY_HIP(hipStreamSynchronize(s1));
-        c->set_aux_stream(nullptr);
-        (void)hipStreamDestroy(s1); (void)hipStreamDestroy(s2);
         if (cnt != (double)S) return fail(FY_ERR_TRANSPORT, "comm self-test: all-reduce beside the auxiliary exchange wrong on rank %d", R);
         for (size_t q = 0; q < n; q += 997) {
             const double want_dn = c->has_down() ? 1000.0 * (R - 1) + 1.0 + 1e-3 * (double)q : 0.0;

@@ -64,6 +64,7 @@ struct Comm {
     // exchanges enqueued on `aux` run beside the ones on the main stream (the smoother's overlapped halo): a back-end whose handle may
     // not be driven from two streams at once (RCCL: one ncclComm per stream in flight) routes them over a second communicator
     virtual void set_aux_stream(hipStream_t) {}
+    virtual hipStream_t get_aux_stream() const { return nullptr; }
     virtual int exchange_many(hipStream_t s, const Xchg* x, size_t n) = 0;
     std::vector<Xchg> pending;
     bool grouping = false;

@@ -10,7 +10,23 @@
 #include <functional>
 #include <thread>
 
+#include <sys/stat.h>
+#include <unistd.h>
+
 namespace fy {
+
+Options options() {
+    auto on = [](const char* nm) { const char* e = getenv(nm); return e != nullptr && *e != 0 && strcmp(e, "0") != 0; };
+    Options q{};
+    q.explicit_tree = on("FOAMYADE_EXPLICIT_TREE");
+    q.no_locate_lists = on("FOAMYADE_NO_LOCATE_LISTS");
+    if (const char* d = getenv("FOAMYADE_TREE_CACHE_DIR")) q.tree_cache_dir = d;
+    q.rebin_interval = 8;
+    if (const char* e = getenv("FOAMYADE_REBIN_INTERVAL")) q.rebin_interval = std::max(1, atoi(e));
+    q.no_halo_overlap = on("FOAMYADE_NO_HALO_OVERLAP");
+    q.no_aux_comm = on("FOAMYADE_NO_AUX_COMM");
+    return q;
+}
 
 std::string& last_error() {
     static thread_local std::string e;
@@ -62,16 +78,17 @@ int Coupling::create(const fy_mesh_desc* m, const fy_field_ptrs* f, int gaussian
     } else {
         comm_sz_diff = 0; serial_yade = true;
     }
-    // z-slabs issue their halo / reverse-halo collectives once per batch, and with parallel Yade the batch count (= intersecting Yade
-    // workers, FoamYade.C:114-155) differs from rank to rank: the slabs' collective calls would not pair up
-    if (slab.active && has_transport && !serial_yade)
-        return fail(FY_ERR_UNSUPPORTED, "z-slab mode with a parallel-Yade transport is not supported (per-rank batch counts would unpair the slab collectives)");
+    // z-slabs with a parallel Yade: the halo / reverse-halo collectives are issued once per batch, and the number of Yade workers whose
+    // particles intersect a rank's bounding box (FoamYade.C:114-155) differs from rank to rank -- so a slab keeps ONE batch per Yade worker,
+    // in worker order, also for a worker that sent it nothing (recv_yade_intrs): every rank then walks the same W batches and the
+    // collectives pair up, while the per-worker order of buildCellPartList / setCellVolFraction / calcHydroForce (FoamYade.C:612-628) is
+    // the single domain's
 
     // ---- mshTree.build_tree(), FoamYade.C:33 (always, also in point-force mode: quirk Q6 kept for get_tree parity)
     {
         // implicit-coordinate nodes: legal only if EVERY centre equals origin + (i + 0.5) * dx bit for bit (checked here, so a
         // real OpenFOAM mesh whose centres come from pyramid decomposition simply keeps the explicit path)
-        bool exact = structured && getenv("FOAMYADE_EXPLICIT_TREE") == nullptr && m->nx <= 1024 && m->ny <= 1024 && m->nz <= 4096 &&
+        bool exact = structured && !options().explicit_tree && m->nx <= 1024 && m->ny <= 1024 && m->nz <= 4096 &&
                      n_cells < (1 << 25);
         if (exact)
             for (int k = 0; k < m->nz && exact; ++k) for (int j = 0; j < m->ny && exact; ++j) for (int i = 0; i < m->nx; ++i) {
@@ -84,9 +101,10 @@ int Coupling::create(const fy_mesh_desc* m, const fy_field_ptrs* f, int gaussian
         // FOAMYADE_TREE_CACHE_DIR=/dev/shm ; the first rank to create the lock file builds and publishes, the others wait.
         std::vector<int32_t> pre;      // preorder cell ids
         std::string cache;
-        if (exact) if (const char* dir = getenv("FOAMYADE_TREE_CACHE_DIR")) {
-            char nm[256];
-            snprintf(nm, sizeof(nm), "%s/fy_tree_%dx%dx%d_%016llx.bin", dir, m->nx, m->ny, m->nz,
+        const std::string cache_dir = options().tree_cache_dir;
+        if (exact && !cache_dir.empty()) {
+            char nm[512];
+            snprintf(nm, sizeof(nm), "%s/fy_tree_%dx%dx%d_%016llx.bin", cache_dir.c_str(), m->nx, m->ny, m->nz,
                      (unsigned long long)(std::hash<double>()(m->dx) ^ (std::hash<double>()(m->origin[0]) << 1) ^ (std::hash<double>()(m->origin[1]) << 2) ^ (std::hash<double>()(m->origin[2]) << 3)));
             cache = nm;
         }
@@ -106,24 +124,42 @@ int Coupling::create(const fy_mesh_desc* m, const fy_field_ptrs* f, int gaussian
         if (!cache.empty()) {
             have = load_cache();
             if (!have) {
-                FILE* lf = fopen(lock.c_str(), "wx");            // exclusive create: the winner builds
-                if (lf) { fclose(lf); hold_lock = true; }
-                else {
-                    // somebody else is building: wait for the file, but never longer than the build itself would take (a lock left
-                    // behind by a crashed run must not stall later runs) -- after that this rank simply builds its own copy
-                    const int max_spins = 20 * 60;                // 60 s
-                    for (int spin = 0; spin < max_spins && !have; ++spin) { std::this_thread::sleep_for(std::chrono::milliseconds(50)); have = load_cache(); }
+                // Exclusive create: the winner builds and publishes, the others wait for the file.  A lock left behind by a crashed run must
+                // not stall later runs for ever: a lock older than kStaleLock seconds (no k-d build of a block that fits the implicit tree
+                // takes that long) is stale -- it is removed and the create retried, so that somebody publishes again; and nobody waits
+                // longer than that either, after which this rank builds its own copy (and publishes it, tmp + rename: harmless if doubled).
+                const double kStaleLock = 60.0;
+                auto lock_age = [&]() -> double {
+                    struct stat sb;
+                    if (stat(lock.c_str(), &sb) != 0) return -1.0;           // gone
+                    return difftime(time(nullptr), sb.st_mtime);
+                };
+                for (int attempt = 0; attempt < 2 && !have && !hold_lock; ++attempt) {
+                    FILE* lf = fopen(lock.c_str(), "wx");
+                    if (lf) { fclose(lf); hold_lock = true; break; }
+                    const int max_spins = (int)(kStaleLock * 20);             // 50 ms each
+                    for (int spin = 0; spin < max_spins && !have; ++spin) {
+                        const double age = lock_age();
+                        if (age < 0 || age > kStaleLock) break;               // the builder finished (or died long ago)
+                        std::this_thread::sleep_for(std::chrono::milliseconds(50));
+                        have = load_cache();
+                    }
+                    if (!have) have = load_cache();
+                    if (!have && lock_age() > kStaleLock) remove(lock.c_str());   // stale: clear it and try to become the builder
                 }
             }
         }
+        const bool publish = !cache.empty() && !have;     // whoever had to build publishes (the lock only decides who builds FIRST)
         std::vector<KdNode> nodes;
         if (!have) {
             unsigned hw = std::thread::hardware_concurrency();
             build_kdtree_preorder(m->centres, n_cells, nodes, (int)std::min(hw ? hw : 1u, 8u));
             pre.resize((size_t)n_cells);
             for (size_t q = 0; q < nodes.size(); ++q) pre[q] = nodes[q].id;
-            if (hold_lock) {                                      // publish: complete file first, then the atomic rename
-                const std::string tmp = cache + ".tmp";
+            if (publish) {                                        // publish: complete file first, then the atomic rename
+                char sfx[64];
+                snprintf(sfx, sizeof(sfx), ".tmp.%ld.%zx", (long)getpid(), std::hash<std::thread::id>()(std::this_thread::get_id()));
+                const std::string tmp = cache + sfx;
                 bool ok = false;
                 if (FILE* f = fopen(tmp.c_str(), "wb")) {
                     ok = fwrite(pre.data(), sizeof(int32_t), pre.size(), f) == pre.size();
@@ -200,20 +236,15 @@ int Coupling::create(const fy_mesh_desc* m, const fy_field_ptrs* f, int gaussian
         FY_TRY(d_cellrec.alloc_exact(8 * nf)); FY_TRY(d_drag_acc.alloc_exact(nf));
         FY_HIP(hipMemsetAsync(d_cellrec.p, 0, 8 * nf * sizeof(double), stream));
         FY_HIP(hipMemsetAsync(d_drag_acc.p, 0, nf * sizeof(double), stream));
-        if (const char* e = getenv("FOAMYADE_FORCE_SPLIT")) force_split = atoi(e) != 0;
-        if (getenv("FOAMYADE_NO_TILE_FLUSH")) tile_flush = false;
-        if (getenv("FOAMYADE_NO_SIDE_STREAM") == nullptr) {
-            FY_HIP(hipStreamCreateWithFlags(&side.stream, hipStreamNonBlocking));
-            FY_HIP(hipEventCreateWithFlags(&side.fork, hipEventDisableTiming));
-            FY_HIP(hipEventCreateWithFlags(&side.join, hipEventDisableTiming));
-        }
+        FY_HIP(hipStreamCreateWithFlags(&side.stream, hipStreamNonBlocking));
+        FY_HIP(hipEventCreateWithFlags(&side.fork, hipEventDisableTiming));
+        FY_HIP(hipEventCreateWithFlags(&side.join, hipEventDisableTiming));
     }
 
     // ---- binning grid (locality only)
     {
         const double h0 = structured ? m->dx : std::cbrt(v0);
-        const char* be = getenv("FOAMYADE_BIN_EDGE");                  // in cells; locality only (2: measured optimum)
-        const double h = (be && atof(be) > 0 ? atof(be) : 2.0) * h0;
+        const double h = 2.0 * h0;                                     // bin edge: 2 cells; locality only (4 / 2 / 1 / 0.5 measured flat)
         bins.ox = m->bbox_min[0]; bins.oy = m->bbox_min[1]; bins.oz = m->bbox_min[2];
         bins.inv_h = 1.0 / h;
         auto nb = [&](int a) { double e = (m->bbox_max[a] - m->bbox_min[a]) / h; int v = (int)std::ceil(e - 1e-9); return std::max(v, 1); };
@@ -228,28 +259,23 @@ int Coupling::create(const fy_mesh_desc* m, const fy_field_ptrs* f, int gaussian
     }
     for (auto& t : timers) FY_TRY(t.init());
     FY_TRY(marks.init());
-    if (const char* e = getenv("FOAMYADE_REBIN_INTERVAL")) rebin_interval = std::max(1, atoi(e));
+    rebin_interval = options().rebin_interval;
     if (has_transport || fields_on_host) {
         FY_HIP(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+        FY_HIP(hipStreamCreateWithFlags(&copy_out_stream, hipStreamNonBlocking));     // results travel the other way on a stream of their own
     }
-    if (fields_on_host && getenv("FOAMYADE_HOST_REGISTER") != nullptr) {
-        // OPT-IN (FOAMYADE_HOST_REGISTER=1): the caller's field arrays live as long as this object (FoamYade.H:76-90 holds references to them),
-        // so they can be pinned in place for the per-step staging copies.  It buys nothing measurable on this runtime -- hipMemcpyAsync out of pageable
-        // memory already moves the 819 MB per call at 55 GB/s (it pins on the fly) -- and it is off by default: page-locking
-        // memory that somebody else's allocator owns (and shares pages of with its other objects) is only safe when the caller knows how those
-        // arrays were allocated -- an OpenFOAM field store is fine, a test process that allocates and frees numpy arrays around them is not
-        // (rare aborts inside later pageable copies were traced to this).  Best effort -- an array that cannot be registered is copied as pageable.
-        const size_t nb = (size_t)n_cells * sizeof(double);
-        struct { const void* p; size_t bytes; } arr[] = {{f->U, 3 * nb}, {f->gradP, 3 * nb}, {f->vGrad, 9 * nb}, {f->divT, 3 * nb}, {f->ddtU, 3 * nb},
-                                                         {f->uSourceDrag, nb}, {f->alpha, nb}, {f->uSource, 3 * nb}, {f->uParticle, 3 * nb}};
-        for (auto& a : arr)
-            if (a.p && hipHostRegister(const_cast<void*>(a.p), a.bytes, hipHostRegisterDefault) == hipSuccess) registered.push_back(const_cast<void*>(a.p));
-        (void)hipGetLastError();
-    }
+    // FY_MEM_HOST field arrays are NOT page-locked in place (round 2 offered hipHostRegister of the caller's arrays as an opt-in): the staging
+    // copies run at the same 55 GB/s out of pageable memory -- the runtime pins on the fly -- and a registration that outlives the array's owner
+    // (an interpreter freeing a numpy array before fy_destroy runs) leaves a page-locked range over freed pages, which is what the rare aborts
+    // inside later pageable copies were.  No benefit, one lifetime hazard: removed.
 
     // ---- parallel Yade: yadeProcs + sendMeshBbox, FoamYade.C:35-45,77-111
     if (has_transport && !serial_yade) {
         double bbox[6] = {m->bbox_min[0], m->bbox_min[1], m->bbox_min[2], m->bbox_max[0], m->bbox_max[1], m->bbox_max[2]};
+        if (slab.active) {       // every solver rank sends the box of ITS mesh (FoamYade.C:81-95 runs over the rank's own mesh.points()): this slab's planes
+            bbox[2] = m->origin[2] + (double)slab.kglob0 * m->dx;
+            bbox[5] = m->origin[2] + (double)(slab.kglob0 + slab.nz) * m->dx;
+        }
         for (int rnk = 0; rnk != comm_sz_diff; ++rnk) FY_TR(transport.send(transport.user, bbox, 6, FY_T_DOUBLE, rnk, TAG_GRID_BBOX));
     }
     if (!has_transport || serial_yade) set_num_batches(1);     // FoamYade.C:46-50: one YadeProc{yRank = 0}
@@ -264,14 +290,12 @@ int Coupling::create(const fy_mesh_desc* m, const fy_field_ptrs* f, int gaussian
 // create time (init_fields) so that no step pays for them; see k_build_locate_start / k_build_locate_lists
 int Coupling::ensure_locate_tables(double maxdist) {
     if (!use_implicit) return FY_OK;
-    static const bool no_start = getenv("FOAMYADE_NO_LOCATE_START") != nullptr;      // A/B switch
-    if (!no_start && !d_loc_start.p) {
+    if (!d_loc_start.p) {
         FY_TRY(d_loc_start.alloc_exact((size_t)n_cells));
         FY_TRY(launch_build_locate_start(stream, d_tree_packed.p, implicit, n_cells, maxdist, d_loc_start.p));
     }
     // candidate lists: 384 B per cell; valid while the rounding of a coordinate stays far below the builder's margins
-    static const bool no_lists = getenv("FOAMYADE_NO_LOCATE_LISTS") != nullptr;      // A/B switch
-    if (!no_lists && !loc_lists_tried) {
+    if (!options().no_locate_lists && !loc_lists_tried) {
         loc_lists_tried = true;
         const double ext = std::max({std::fabs(implicit.ox), std::fabs(implicit.oy), std::fabs(implicit.oz), std::fabs(implicit.ox + implicit.nx * implicit.dx),
                                      std::fabs(implicit.oy + implicit.ny * implicit.dx), std::fabs(implicit.oz + implicit.nz * implicit.dx)});
@@ -376,7 +400,6 @@ int Coupling::ensure_batch(Batch& b, int64_t n) {
             FY_TRY(b.soa.alloc_exact(7 * c2)); FY_TRY(b.orig.alloc_exact(c2)); FY_TRY(b.chain.alloc_exact(c2));
             FY_TRY(b.ids.alloc_exact((size_t)kMaxK * c2)); FY_TRY(b.w.alloc_exact((size_t)kMaxK * c2));
             FY_TRY(b.key.alloc_exact(c2)); FY_TRY(b.rank.alloc_exact(c2));
-            if (force_split) FY_TRY(b.fscr.alloc_exact(4 * c2));
             if (tile_flush && structured) {
                 const size_t nt = (size_t)tile_grid().n_tiles();
                 for (int w = 0; w < 2; ++w) {
@@ -575,21 +598,13 @@ int Coupling::run_batch(Batch& b) {
             ll = LocateLists{d_loc_lists.p, d_loc_fb.p, d_loc_fb_n.p, loc_cell0, loc_n_listed};
         }
         const CellWindow cw{slab.active ? slab.base : 0, n_field};
-        static const bool unfused = getenv("FOAMYADE_UNFUSED_DEPOSIT") != nullptr;      // A/B switch: k_locate_lists + k_deposit
         // the scatters' tables are flushed into per-tile buckets sized from the demand they counted in this batch's last step
         const TileBuckets tbD = buckets_of(b, 0), tbB = buckets_of(b, 1);
         FY_TRY(launch_tile_caps(stream, tbD, tbB));
         if (timing) marks.mark(1, stream);
-        if (unfused) {
-            FY_TRY(launch_locate(stream, d_tree.p, use_implicit ? d_tree_packed.p : nullptr, implicit, n_cells, tree_levels, p, b.n, gp,
-                                 use_implicit ? d_loc_start.p : nullptr, slab_own(), ll));
-            if (timing) marks.mark(2, stream);
-            FY_TRY(launch_deposit(stream, p, b.n, gp, cw, d_pvol_acc.p, d_up_acc.p, d_touched.p, tbD));
-        } else {
-            FY_TRY(launch_locate_deposit(stream, d_tree.p, use_implicit ? d_tree_packed.p : nullptr, implicit, n_cells, tree_levels, p, b.n, gp,
-                                         use_implicit ? d_loc_start.p : nullptr, slab_own(), ll, cw, d_pvol_acc.p, d_up_acc.p, d_touched.p, tbD, side));
-            if (timing) marks.mark(2, stream);
-        }
+        FY_TRY(launch_locate_deposit(stream, d_tree.p, use_implicit ? d_tree_packed.p : nullptr, implicit, n_cells, tree_levels, p, b.n, gp,
+                                     use_implicit ? d_loc_start.p : nullptr, slab_own(), ll, cw, d_pvol_acc.p, d_up_acc.p, d_touched.p, tbD, side));
+        if (timing) marks.mark(2, stream);
         // The force pass gathers U, alpha and the Archimedes term from one packed record per cell.  U / gradP / divT do not change during the
         // call and the alpha slot follows k_finalize_cells, so the records are built once per call -- here, where the pack runs beside the
         // walk's leftovers on the side stream
@@ -597,7 +612,7 @@ int Coupling::run_batch(Batch& b) {
             FY_TRY(launch_pack_cells(stream, n_field, dU, dAlpha, dGradP, dDivT, d_vol.p, nu, rhoF, d_cellrec.p));
             cellrec_fresh = true;
         }
-        if (side.stream && ll.lists && !unfused) FY_HIP(hipStreamWaitEvent(stream, side.join, 0));
+        if (side.stream && ll.lists) FY_HIP(hipStreamWaitEvent(stream, side.join, 0));
         FY_TRY(launch_tile_reduce(stream, tbD, d_pvol_acc.p, d_up_acc.p, d_touched.p));
         if (slab.active) {      // contributions that landed in ghost planes belong to the neighbours: send them home and add
             FY_TRY(halo_reverse_add2(d_pvol_acc.p, 1, d_touched.p, d_up_acc.p, 3));
@@ -621,8 +636,7 @@ int Coupling::run_batch(Batch& b) {
             fp.torque_prezeroed = 1;
         }
         if (timing) marks.mark(3, stream);
-        FY_TRY(launch_force_gaussian(stream, p, b.n, fp, cw, d_vol.p, d_cellrec.p, dVGrad, dDdtU, b.d_rec, force_split ? b.fscr.p : nullptr,
-                                     d_drag_acc.p, dUSource, b.force.p, tbB));
+        FY_TRY(launch_force_gaussian(stream, p, b.n, fp, cw, d_vol.p, d_cellrec.p, dVGrad, dDdtU, b.d_rec, d_drag_acc.p, dUSource, b.force.p, tbB));
         if (timing) marks.mark(4, stream);
         FY_TRY(launch_tile_reduce(stream, tbB, d_drag_acc.p, dUSource, nullptr));
         b.found_stale = true;
@@ -694,6 +708,7 @@ int Coupling::collect_timings() {
     marks.clear();
     if (copy_stream) {
         FY_HIP(hipStreamSynchronize(copy_stream));
+        FY_HIP(hipStreamSynchronize(copy_out_stream));
         for (auto* b : batches) if (b->events) { tm.copy_in += b->t_in.ms(); tm.copy_out += b->t_out.ms(); }
     }
     tm.h2d = tm.copy_in; tm.d2h = tm.copy_out;              // the PCIe copies themselves (sum over the batches), on the copy stream
@@ -734,43 +749,54 @@ int Coupling::recv_yade_intrs() {
     for (int w = 0; w < W; ++w) {
         const int yrank = w + 1;                                            // FoamYade.C:40: the Yade master sends nothing
         FY_TR(transport.recv(transport.user, counts.data(), transport.local_size, FY_T_INT, yrank, TAG_SZ_BUFF));
-        if (counts[(size_t)transport.local_rank] > 0) in_comm.emplace_back(yrank, counts[(size_t)transport.local_rank]);
+        // (a slab keeps an empty batch for a worker that sent it nothing: see create())
+        if (counts[(size_t)transport.local_rank] > 0 || slab.active) in_comm.emplace_back(yrank, std::max(counts[(size_t)transport.local_rank], 0));
     }
     set_num_batches((int)in_comm.size());
     for (size_t q = 0; q < in_comm.size(); ++q) {
         Batch& b = *batches[q];
         b.yrank = in_comm[q].first;
         const int n = in_comm[q].second;
-        FY_TRY(b.h_rec.reserve((size_t)rec_len() * (size_t)n));
-        const WallClock wc;
-        FY_TR(transport.recv(transport.user, b.h_rec.data(), rec_len() * n, FY_T_DOUBLE, b.yrank, TAG_YADE_DATA));
-        wire_recv_ms += wc.ms();
+        FY_TRY(b.h_rec.reserve((size_t)rec_len() * (size_t)std::max(n, 1)));
+        if (n > 0) {                                                        // FoamYade.C:127-139: only intersecting workers send records
+            const WallClock wc;
+            FY_TR(transport.recv(transport.user, b.h_rec.data(), rec_len() * n, FY_T_DOUBLE, b.yrank, TAG_YADE_DATA));
+            wire_recv_ms += wc.ms();
+        }
         FY_TRY(upload_batch(b, n));
         FY_TRY(run_batch(b));
+        // a batch's forces and found flags are final as soon as ITS kernels are done (a later batch only changes the cell fields): start
+        // their way back now, so that the copy runs under the next batch's receive, upload and kernels
+        FY_TRY(start_results_copy(b));
     }
     return FY_OK;
 }
 
-int Coupling::send_results() {
-    // D2H of every batch's found flags and forces on the copy stream, each behind the event that says its results are final; the
-    // host then hands batch after batch to the transport as its copy lands (the copy of batch q + 1 overlaps the send of batch q)
-    for (int bi = 0; bi < n_batches; ++bi) {
-        Batch& b = *batches[bi];
-        FY_TRY(ensure_batch_events(b));
-        FY_TRY(b.h_found.reserve((size_t)std::max<int64_t>(b.n, 1))); FY_TRY(b.h_force.reserve(6 * (size_t)std::max<int64_t>(b.n, 1)));
-        if (b.n) {
-            FY_TRY(ensure_found(b));
-            FY_HIP(hipEventRecord(b.ev_ready, stream));
-            FY_HIP(hipStreamWaitEvent(copy_stream, b.ev_ready, 0));
-        }
-        b.t_out.start(copy_stream);
-        if (b.n) {
-            FY_HIP(hipMemcpyAsync(b.h_found.data(), b.found.p, (size_t)b.n * sizeof(int32_t), hipMemcpyDeviceToHost, copy_stream));
-            FY_HIP(hipMemcpyAsync(b.h_force.data(), b.force.p, 6 * (size_t)b.n * sizeof(double), hipMemcpyDeviceToHost, copy_stream));
-            tm.bytes_out += b.n * (int64_t)(sizeof(int32_t) + 6 * sizeof(double));
-        }
-        b.t_out.stop(copy_stream);
+// D2H of one batch's found flags and forces on the outbound copy stream, behind the event that says its results are final
+int Coupling::start_results_copy(Batch& b) {
+    if (b.out_started) return FY_OK;
+    FY_TRY(ensure_batch_events(b));
+    FY_TRY(b.h_found.reserve((size_t)std::max<int64_t>(b.n, 1))); FY_TRY(b.h_force.reserve(6 * (size_t)std::max<int64_t>(b.n, 1)));
+    if (b.n) {
+        FY_TRY(ensure_found(b));
+        FY_HIP(hipEventRecord(b.ev_ready, stream));
+        FY_HIP(hipStreamWaitEvent(copy_out_stream, b.ev_ready, 0));
     }
+    b.t_out.start(copy_out_stream);
+    if (b.n) {
+        FY_HIP(hipMemcpyAsync(b.h_found.data(), b.found.p, (size_t)b.n * sizeof(int32_t), hipMemcpyDeviceToHost, copy_out_stream));
+        FY_HIP(hipMemcpyAsync(b.h_force.data(), b.force.p, 6 * (size_t)b.n * sizeof(double), hipMemcpyDeviceToHost, copy_out_stream));
+        tm.bytes_out += b.n * (int64_t)(sizeof(int32_t) + 6 * sizeof(double));
+    }
+    b.t_out.stop(copy_out_stream);
+    b.out_started = true;
+    return FY_OK;
+}
+
+int Coupling::send_results() {
+    // every batch's results are on their way (parallel Yade: since its kernels were enqueued; else from here); the host then hands batch
+    // after batch to the transport as its copy lands (the copy of batch q + 1 overlaps the send of batch q)
+    for (int bi = 0; bi < n_batches; ++bi) FY_TRY(start_results_copy(*batches[bi]));
     if (serial_yade) {
         Batch& b = *batches[0];
         FY_HIP(hipEventSynchronize(b.t_out.b));
@@ -796,6 +822,7 @@ int Coupling::send_results() {
     } else {
         for (int bi = 0; bi < n_batches; ++bi) {                            // FoamYade.C:239-243
             Batch& b = *batches[bi];
+            if (b.n == 0) continue;                                         // (a slab's empty batch: that worker is not in inCommProcs)
             FY_HIP(hipEventSynchronize(b.t_out.b));
             const WallClock wc;
             FY_TR(transport.send(transport.user, b.h_found.data(), (int)b.n, FY_T_INT, b.yrank, TAG_SEARCH_RES));
@@ -803,11 +830,13 @@ int Coupling::send_results() {
         }
         for (int bi = 0; bi < n_batches; ++bi) {                            // FoamYade.C:504-507
             Batch& b = *batches[bi];
+            if (b.n == 0) continue;
             const WallClock wc;
             FY_TR(transport.send(transport.user, b.h_force.data(), 6 * (int)b.n, FY_T_DOUBLE, b.yrank, TAG_FORCE));
             wire_send_ms += wc.ms();
         }
     }
+    for (int bi = 0; bi < n_batches; ++bi) batches[bi]->out_started = false;
     return FY_OK;
 }
 
@@ -952,11 +981,11 @@ Coupling::~Coupling() {
     for (auto& t : timers) t.destroy();
     marks.destroy();
     for (auto* b : batches) delete b;
-    for (void* r : registered) (void)hipHostUnregister(r);
     if (side.fork) (void)hipEventDestroy(side.fork);
     if (side.join) (void)hipEventDestroy(side.join);
     if (side.stream) (void)hipStreamDestroy(side.stream);
     if (copy_stream) (void)hipStreamDestroy(copy_stream);
+    if (copy_out_stream) (void)hipStreamDestroy(copy_out_stream);
     if (owns_stream && stream) (void)hipStreamDestroy(stream);
 }
 

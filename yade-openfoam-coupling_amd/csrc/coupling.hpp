@@ -23,7 +23,6 @@ struct Batch {
     DevBuf<int32_t> orig, chain, ids, found, incell;
     DevBuf<double> w, force;
     DevBuf<uint32_t> key, rank;
-    DevBuf<double> fscr;                 // 4 * cap: {coeff, b} per particle between the two kernels of the split force pass (A/B switch)
     const double* torque_zero_buf = nullptr;   // force buffer whose torque slots [0, torque_zero_n) are known to be zero
     int64_t torque_zero_n = 0;
     bool found_stale = false;            // Gaussian mode: `found` is formed lazily from the chain lengths (ensure_found)
@@ -37,6 +36,7 @@ struct Batch {
     EventTimer t_in, t_out;              // the batch's H2D / D2H copies on the copy stream (their end events are what the compute stream / the host wait for)
     hipEvent_t ev_ready = nullptr;       // results final on the compute stream
     bool events = false;
+    bool out_started = false;            // this step's D2H of force / found is already on the outbound copy stream
     ~Batch() { t_in.destroy(); t_out.destroy(); if (ev_ready) (void)hipEventDestroy(ev_ready); }
 };
 
@@ -87,7 +87,7 @@ struct Coupling {
     DevBuf<uint32_t> tile_cell;          // entry pool of the tile buckets (one flush at a time uses it)
     DevBuf<double> tile_val;
     SideStream side{};                   // the walk's leftovers run here, beside the cell-record pack
-    bool tile_flush = true;              // FOAMYADE_NO_TILE_FLUSH=1: the scatters flush with global atomics (round-1 behaviour, A/B switch)
+    bool tile_flush = true;              // the scatters' tables are flushed into per-tile buckets (false: global atomics, round-1 behaviour)
     TileGrid tile_grid() const;
     TileBuckets buckets_of(Batch& b, int which);
     ImplicitGeom implicit{};
@@ -106,19 +106,18 @@ struct Coupling {
     bool cellrec_fresh = false;                    // d_cellrec was packed in this setParticleAction call
     DevBuf<double> d_cellrec;                      // 8 doubles per cell: what the force pass gathers (k_pack_cells), rebuilt every setParticleAction
     DevBuf<double> d_drag_acc;                     // per-batch sum of -coeff w / rho_f per cell, folded into uSourceDrag / uSource by k_fold_sources
-    bool force_split = false;                      // FOAMYADE_FORCE_SPLIT=1: gather and back-scatter of the force pass as two kernels (A/B switch)
     DevBuf<unsigned char> d_touched;
     BinGrid bins{};
-    int rebin_interval = 8;              // full counting sort every this many steps (FOAMYADE_REBIN_INTERVAL; 1 = every step)
+    int rebin_interval = 8;              // full counting sort every this many steps (options().rebin_interval; 1 = every step)
     DevBuf<uint32_t> d_hist, d_tile_sums;
     std::vector<Batch*> batches;
     int n_batches = 0;
 
     // ---- drop-in path (host-resident peer): pinned staging, copies on their own stream, overlapped with the kernels of the other batches
-    hipStream_t copy_stream = nullptr;
+    hipStream_t copy_stream = nullptr, copy_out_stream = nullptr;      // H2D of the records / D2H of the results
     double wire_recv_ms = 0, wire_send_ms = 0;  // host wall time inside the transport's data calls (the MPI side)
-    std::vector<void*> registered;              // caller-owned FY_MEM_HOST field arrays pinned in place (hipHostRegister)
     int ensure_batch_events(Batch& b);
+    int start_results_copy(Batch& b);           // D2H of one batch's forces + found flags, as soon as its kernels are enqueued
     int upload_batch(Batch& b, int64_t n);      // pinned h_rec -> rec_own on the copy stream; the compute stream waits for it
 
     // ---- timing

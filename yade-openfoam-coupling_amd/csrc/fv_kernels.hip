@@ -1133,7 +1133,12 @@ __global__ __launch_bounds__(256) void k_jacobi_precond(PMat A, const double* __
 
 // A_coarse = 1/2 P^T A P, piecewise-constant P over 2x2x2 aggregates (gather form: one thread per owned coarse cell).
 // The z-face above the top owned fine plane is a slab interface (or a physical boundary with coefficient 0): always "crossing".
-__global__ __launch_bounds__(256) void k_mg_coarsen(PMat F, PMat C) {
+// ref_c / ref_term: fvMatrix::setReference adds a POINT term a_ref to the reference cell's diagonal (k_assemble_pressure); it is what
+// makes the closed-box operator non-singular, i.e. 1^T A 1 = a_ref.  The Galerkin product with the factor 1/2 -- right for the Laplacian
+// under piecewise-constant transfer -- would halve that term on every level, and an EXACT coarse solve would then over-correct the constant
+// mode by 2^levels (measured: 2.0 -> 3.85 PCG iterations per step at C3 when the 120 Jacobi sweeps, which never touched that mode, became
+// the direct solve).  So the aggregate that holds the reference cell gets the missing half back: every level carries a_ref unscaled.
+__global__ __launch_bounds__(256) void k_mg_coarsen(PMat F, PMat C, int ref_c, const double* __restrict__ ref_term) {
     const int tc = blockIdx.x * 256 + threadIdx.x;
     if (tc >= C.N) return;
     const int I = tc % C.nx, q = tc / C.nx, J = q % C.ny, K = q / C.ny;
@@ -1152,8 +1157,14 @@ __global__ __launch_bounds__(256) void k_mg_coarsen(PMat F, PMat C) {
             }
         }
     }
+    if (tc == ref_c) dg += 0.5 * ref_term[0];
     const int cc = tc + C.c0;
     C.diag[cc] = dg; C.ux[cc] = ux; C.uy[cc] = uy; C.uz[cc] = uz;
+}
+
+// a_ref of the comment above: half of the (doubled) diagonal of the reference cell at level 0; 0 on a rank that does not own the cell
+__global__ void k_mg_ref_term(PMat A0, int ref_local, double* __restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = ref_local >= 0 ? 0.5 * A0.diag[A0.c0 + ref_local] : 0.0;
 }
 
 // coarse ghost plane under the first owned coarse plane: uz = 1/2 sum of the fine ghost-plane uz of its 2x2 footprint
@@ -1313,7 +1324,43 @@ struct MgTail {
     double* x0[kMgTailMax];
     double* x1[kMgTailMax];
     double* b[kMgTailMax];
+    const double* fac;           // banded Cholesky factor of the coarsest operator (k_mg_coarse_factor); null: Jacobi sweeps
 };
+
+// The coarsest level's exact solve from its banded Cholesky factor (k_mg_coarse_factor): fac = {N, bw, ok} as three doubles, then the band rows
+// [N][bw + 1]: entry d of row i = L(i, i - d), d >= 1, and 1 / L(i, i) at d = 0.  ONE wave does both substitutions with the solution vector in
+// REGISTERS (lane l holds rows l and l + 64: N <= 128): per column the owner's value is broadcast with a lane read, every lane in the band
+// updates its row with one multiply-subtract -- no LDS round trip in the dependent chain, ~40 cycles per column, a few microseconds per solve
+// (the 120 Jacobi sweeps they replace took ~60).  `Ls` (LDS, N * (bw + 1) doubles) must hold the factor; called by the wave tid < 64 only.
+__device__ __forceinline__ double read_lane_f64(double v, int src_lane) {      // src_lane is wave-uniform: two v_readlane, no LDS crossbar
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ void coarse_band_solve(const double* Ls, int N, int bw, const double* __restrict__ b, double* __restrict__ x, int lane) {
+    const int Wd = bw + 1;
+    double v0 = lane < N ? b[lane] : 0.0, v1 = lane + 64 < N ? b[lane + 64] : 0.0;
+    // forward: L y = b, column by column
+    for (int j = 0; j < N; ++j) {
+        const double own = j < 64 ? v0 : v1;
+        const double yj = read_lane_f64(own, j & 63) * Ls[(size_t)j * Wd];
+        if ((j & 63) == lane) { if (j < 64) v0 = yj; else v1 = yj; }
+        // rows j + 1 .. j + bw: at most one of a lane's two rows lies in the window (bw <= 64)
+        const int d0 = lane - j, d1 = lane + 64 - j;                  // distance of my rows below the diagonal
+        if (d0 >= 1 && d0 <= bw && lane < N) v0 -= Ls[(size_t)lane * Wd + d0] * yj;
+        if (d1 >= 1 && d1 <= bw && lane + 64 < N) v1 -= Ls[(size_t)(lane + 64) * Wd + d1] * yj;
+    }
+    // backward: L^T x = y
+    for (int j = N - 1; j >= 0; --j) {
+        const double own = j < 64 ? v0 : v1;
+        const double xj = read_lane_f64(own, j & 63) * Ls[(size_t)j * Wd];
+        if ((j & 63) == lane) { if (j < 64) v0 = xj; else v1 = xj; }
+        const int d0 = j - lane, d1 = j - (lane + 64);                 // L(j, k) for my rows k above: row j of the band, entry j - k
+        if (d0 >= 1 && d0 <= bw) v0 -= Ls[(size_t)j * Wd + d0] * xj;
+        if (d1 >= 1 && d1 <= bw) v1 -= Ls[(size_t)j * Wd + d1] * xj;
+    }
+    if (lane < N) x[lane] = v0;
+    if (lane + 64 < N) x[lane + 64] = v1;
+}
 
 __global__ __launch_bounds__(1024) void k_mg_tail(MgTail T, double w, int coarse_sweeps, MgWeights W) {
     const int tid = threadIdx.x;
@@ -1360,7 +1407,14 @@ __global__ __launch_bounds__(1024) void k_mg_tail(MgTail T, double w, int coarse
         const double* b = T.b[l];
         __shared__ double c_dg[kMgCoarseMax], c_ux[kMgCoarseMax], c_uy[kMgCoarseMax], c_uz[kMgCoarseMax], c_b[kMgCoarseMax];
         __shared__ double c_x[2][kMgCoarseMax];
-        if (A.N <= kMgCoarseMax) {
+        if (T.fac && A.N <= kMgDirectMax && T.fac[2] == 1.0) {        // (uniform) the level's exact solve from its banded Cholesky factor
+            extern __shared__ double fac_lds[];
+            const int bw = (int)T.fac[1], cnt = A.N * (bw + 1);
+            for (int q = tid; q < cnt; q += 1024) fac_lds[q] = T.fac[3 + q];
+            __syncthreads();
+            if (tid < 64) coarse_band_solve(fac_lds, A.N, bw, b, T.x0[l], tid);
+            __syncthreads();
+        } else if (A.N <= kMgCoarseMax) {
             if (tid < 64) {
                 const int N = A.N, sy = A.nx, sz = A.nx * A.ny;
                 for (int c = tid; c < N; c += 64) {
@@ -1449,8 +1503,56 @@ __global__ __launch_bounds__(256) void k_mg_prolong_add(PMat A, double* __restri
 }
 
 // coarsest level (N <= 1024, never distributed: c0 = 0): all sweeps inside one workgroup
+// The coarsest operator (<= kMgDirectMax = 128 cells) only changes when the pressure matrix is assembled, and every V-cycle in between solves
+// with it: so it is FACTORED once per assembly -- banded Cholesky A = L L^T in LDS (band width = the operator's z stride, 25 for the 5^3
+// level of C3: N bw^2 = 78 k multiply-adds; a dense 125^3 inversion was built first and cost 0.5 ms, LDS-bandwidth bound), one 256-thread
+// workgroup, two barriers per column -- and a V-cycle's coarse solve is two banded substitutions in one wave (coarse_band_solve) instead of
+// 120 Jacobi sweeps that left the level's smoothest modes partly in.  The operator is a symmetric positive definite M-matrix (the
+// reference cell or a fixed-value patch makes it non-singular); fac[2] = 0 if a pivot is not positive and finite (the sweeps then stand in).
+__global__ __launch_bounds__(256) void k_mg_coarse_factor(PMat A, int bw, double* __restrict__ fac) {
+    extern __shared__ double B[];                  // [N][bw + 1]: B[i][d] = A(i, i - d), overwritten by L
+    __shared__ int bad;
+    const int N = A.N, tid = threadIdx.x, Wd = bw + 1, sy = A.nx, sz = A.nx * A.ny;
+    if (tid == 0) bad = 0;
+    for (int e = tid; e < N * Wd; e += 256) B[e] = 0.0;
+    __syncthreads();
+    for (int c = tid; c < N; c += 256) {           // the lower half of row c of p_row (zero coefficients at the walls); += : strides coincide on flat grids
+        double* row = B + (size_t)c * Wd;
+        row[0] += A.diag[c];
+        if (c >= 1) row[1] -= A.ux[c - 1];
+        if (A.ny > 1 && c >= sy && sy <= bw) row[sy] -= A.uy[c - sy];
+        if (A.nz > 1 && c >= sz && sz <= bw) row[sz] -= A.uz[c - sz];
+    }
+    __syncthreads();
+    for (int j = 0; j < N; ++j) {
+        const double d = B[(size_t)j * Wd];
+        if (!(d > 0.0) || !(d < 1e300)) { if (tid == 0) bad = 1; break; }      // (uniform: every thread reads the same value)
+        const double rl = 1.0 / sqrt(d);
+        const int m = min(bw, N - 1 - j);           // rows below the diagonal in this column
+        if (tid < m) B[(size_t)(j + 1 + tid) * Wd + 1 + tid] *= rl;            // L(i, j) = A(i, j) / L(j, j)
+        __syncthreads();
+        if (tid == 0) B[(size_t)j * Wd] = rl;       // the substitutions multiply by 1 / L(j, j)
+        for (int e = tid; e < m * m; e += 256) {    // trailing update, lower triangle: A(i, k) -= L(i, j) L(k, j), j < k <= i <= j + m
+            const int a = e / m, b = e - a * m;
+            if (b <= a) B[(size_t)(j + 1 + a) * Wd + (a - b)] -= B[(size_t)(j + 1 + a) * Wd + 1 + a] * B[(size_t)(j + 1 + b) * Wd + 1 + b];
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    for (int e = tid; e < N * Wd; e += 256) fac[3 + e] = B[e];
+    if (tid == 0) { fac[0] = (double)N; fac[1] = (double)bw; fac[2] = bad ? 0.0 : 1.0; }
+}
+
 __global__ __launch_bounds__(1024) void k_mg_coarse_solve(PMat A, const double* __restrict__ b, double* __restrict__ x, double* __restrict__ tmp,
-                                                          int sweeps, double w) {
+                                                          int sweeps, double w, const double* __restrict__ fac) {
+    if (fac && A.N <= kMgDirectMax && fac[2] == 1.0) {        // (uniform)
+        extern __shared__ double fac_lds[];
+        const int bw = (int)fac[1], cnt = A.N * (bw + 1);
+        for (int q = threadIdx.x; q < cnt; q += 1024) fac_lds[q] = fac[3 + q];
+        __syncthreads();
+        if (threadIdx.x < 64) coarse_band_solve(fac_lds, A.N, bw, b, x, threadIdx.x);
+        return;
+    }
     const int c = threadIdx.x;
     const bool act = c < A.N;
     double* cur = x;
@@ -1691,8 +1793,14 @@ int launch_jacobi_precond(hipStream_t s, PMat A, const double* r, double* z) {
     return FY_OK;
 }
 
-int launch_mg_coarsen(hipStream_t s, PMat F, PMat C) {
-    hipLaunchKernelGGL(k_mg_coarsen, dim3(div_up(C.N, 256)), dim3(256), 0, s, F, C);
+int launch_mg_ref_term(hipStream_t s, PMat A0, int ref_local, double* out) {
+    hipLaunchKernelGGL(k_mg_ref_term, dim3(1), dim3(64), 0, s, A0, ref_local, out);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+
+int launch_mg_coarsen(hipStream_t s, PMat F, PMat C, int ref_c, const double* ref_term) {
+    hipLaunchKernelGGL(k_mg_coarsen, dim3(div_up(C.N, 256)), dim3(256), 0, s, F, C, ref_term ? ref_c : -1, ref_term);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }
@@ -1721,16 +1829,46 @@ int launch_mg_smooth(hipStream_t s, PMat A, const double* b, const double* x, do
     return FY_OK;
 }
 
-int launch_mg_tail(hipStream_t s, const PMat* A, double* const* x0, double* const* x1, double* const* b, int n, double w, int coarse_sweeps, MgWeights W) {
+// band width of a level's operator = its largest neighbour stride
+static int band_width(const PMat& A) { return A.nz > 1 ? A.nx * A.ny : (A.ny > 1 ? A.nx : 1); }
+static size_t fac_lds_bytes(int N, int bw) { return (size_t)N * (size_t)(bw + 1) * sizeof(double); }
+static int allow_big_lds(const void* fn) {
+    return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fac_lds_bytes(kMgDirectMax, kMgDirectBand)) == hipSuccess ? FY_OK
+           : fail(FY_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+}
+
+int mg_coarse_factor_doubles(PMat A) { return 3 + A.N * (band_width(A) + 1); }
+bool mg_coarse_direct_ok(PMat A) { return A.c0 == 0 && A.N <= kMgDirectMax && band_width(A) <= kMgDirectBand; }
+
+int launch_mg_coarse_factor(hipStream_t s, PMat A, double* fac) {
+    if (!mg_coarse_direct_ok(A)) return fail(FY_ERR_INVALID, "direct coarse solve: level of %d cells, band %d (ghost offset %d)", A.N, band_width(A), A.c0);
+    static bool attr_set = false;
+    if (!attr_set) { FY_TRY(allow_big_lds(reinterpret_cast<const void*>(k_mg_coarse_factor))); attr_set = true; }
+    const int bw = band_width(A);
+    hipLaunchKernelGGL(k_mg_coarse_factor, dim3(1), dim3(256), fac_lds_bytes(A.N, bw), s, A, bw, fac);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+
+int launch_mg_tail(hipStream_t s, const PMat* A, double* const* x0, double* const* x1, double* const* b, int n, double w, int coarse_sweeps, MgWeights W,
+                   const double* fac) {
     if (n < 1 || n > kMgTailMax) return fail(FY_ERR_INVALID, "bad multigrid tail depth %d", n);
     MgTail T;
     T.n = n;
+    T.fac = fac;
+    size_t lds = 0;
+    if (fac) {
+        if (!mg_coarse_direct_ok(A[n - 1])) return fail(FY_ERR_INVALID, "multigrid tail: a factor was handed over for a level it cannot belong to");
+        static bool attr_set = false;
+        if (!attr_set) { FY_TRY(allow_big_lds(reinterpret_cast<const void*>(k_mg_tail))); attr_set = true; }
+        lds = fac_lds_bytes(A[n - 1].N, band_width(A[n - 1]));
+    }
     for (int l = 0; l < n; ++l) {
         if (A[l].c0 != 0) return fail(FY_ERR_INVALID, "multigrid tail levels must not carry ghost planes");
         T.A[l] = A[l]; T.x0[l] = x0[l]; T.x1[l] = x1[l]; T.b[l] = b[l];
     }
     if (W.n < 2 || (W.n & 1)) return fail(FY_ERR_INVALID, "the multigrid tail needs an even number of smoothing sweeps");
-    hipLaunchKernelGGL(k_mg_tail, dim3(1), dim3(1024), 0, s, T, w, coarse_sweeps, W);
+    hipLaunchKernelGGL(k_mg_tail, dim3(1), dim3(1024), lds, s, T, w, coarse_sweeps, W);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }
@@ -1759,10 +1897,17 @@ int launch_mg_prolong_add(hipStream_t s, PMat A, double* x, PMat C, const double
     return FY_OK;
 }
 
-int launch_mg_coarse_solve(hipStream_t s, PMat A, const double* b, double* x, double* tmp, int sweeps, double w) {
+int launch_mg_coarse_solve(hipStream_t s, PMat A, const double* b, double* x, double* tmp, int sweeps, double w, const double* fac) {
     if (A.c0 != 0) return fail(FY_ERR_INVALID, "the coarsest multigrid level must be replicated (no ghost planes)");
     if (A.N > 1024) return fail(FY_ERR_INVALID, "coarsest multigrid level too large (%d cells)", A.N);
-    hipLaunchKernelGGL(k_mg_coarse_solve, dim3(1), dim3(1024), 0, s, A, b, x, tmp, sweeps, w);
+    size_t lds = 0;
+    if (fac) {
+        if (!mg_coarse_direct_ok(A)) return fail(FY_ERR_INVALID, "coarse solve: a factor was handed over for a level it cannot belong to");
+        static bool attr_set = false;
+        if (!attr_set) { FY_TRY(allow_big_lds(reinterpret_cast<const void*>(k_mg_coarse_solve))); attr_set = true; }
+        lds = fac_lds_bytes(A.N, band_width(A));
+    }
+    hipLaunchKernelGGL(k_mg_coarse_solve, dim3(1), dim3(1024), lds, s, A, b, x, tmp, sweeps, w, fac);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }

@@ -139,7 +139,10 @@ int launch_dot(hipStream_t s, int n, int c0, const double* a, const double* b /*
 int launch_pcg_update_p(hipStream_t s, int n, int c0, const double* z, double* p, const double* sc, int first);    // p = z + (sc[0]/sc[1]) p
 int launch_pcg_update_xr(hipStream_t s, int n, int c0, double* x, double* r, const double* p, const double* w, double* sc /* sc[1] = sc[0] on the way out */, double* partials);   // alpha = sc[0]/sc[2]; slot 0 = sum|r|
 int launch_jacobi_precond(hipStream_t s, PMat A, const double* r, double* z);
-int launch_mg_coarsen(hipStream_t s, PMat F, PMat C);
+// ref_term != nullptr: the coarse cell ref_c (local index of C, -1: not in C) holds the pressure reference cell and keeps its point term unscaled
+// (see k_mg_coarsen); launch_mg_ref_term leaves that term (level 0's, 0 where ref_local < 0) in out[0]
+int launch_mg_coarsen(hipStream_t s, PMat F, PMat C, int ref_c = -1, const double* ref_term = nullptr);
+int launch_mg_ref_term(hipStream_t s, PMat A0, int ref_local, double* out);
 int launch_mg_smooth_first(hipStream_t s, PMat A, const double* b, double* x, double w);                   // x = w b / diag
 int launch_mg_smooth_two_from_zero(hipStream_t s, PMat A, const double* b, double* xn, double w, double w2);      // smooth_first(w) + smooth(w2) fused (bit-identical)
 int launch_mg_smooth(hipStream_t s, PMat A, const double* b, const double* x, double* xn, double w);
@@ -148,12 +151,20 @@ int launch_mg_smooth_dot(hipStream_t s, PMat A, const double* b, const double* x
 int launch_mg_residual_restrict(hipStream_t s, PMat A, const double* b, const double* x, PMat C, double* bc);   // bc = P^T (b - A x)
 int launch_mg_prolong_add(hipStream_t s, PMat A, double* x, PMat C, const double* xc);
 int launch_mg_smooth_prolong(hipStream_t s, PMat A, const double* b, const double* x, PMat C, const double* xc, double* xn, double w);   // x += P xc, then one sweep (fused)
-int launch_mg_coarse_solve(hipStream_t s, PMat A, const double* b, double* x, double* tmp, int sweeps, double w);
+// the coarsest level: x = A^-1 b from the banded Cholesky factor `fac` (launch_mg_coarse_factor: mg_coarse_factor_doubles(A) doubles; for
+// levels with mg_coarse_direct_ok(A): no ghost planes, <= kMgDirectMax cells, band <= kMgDirectBand); fac == nullptr or a failed
+// factorisation: `sweeps` damped-Jacobi sweeps from a zero guess
+constexpr int kMgDirectMax = 128, kMgDirectBand = 64;
+bool mg_coarse_direct_ok(PMat A);
+int mg_coarse_factor_doubles(PMat A);
+int launch_mg_coarse_factor(hipStream_t s, PMat A, double* fac);
+int launch_mg_coarse_solve(hipStream_t s, PMat A, const double* b, double* x, double* tmp, int sweeps, double w, const double* fac = nullptr);
 // the whole V-cycle below a size threshold in one workgroup; level l result: x1[l] (x0 for the coarsest / a single-level tail)
 constexpr int kMgTailMax = 6;
 constexpr int kMgTailCells = 1024;   // measured: at 8000 cells one workgroup (137 us) is SLOWER than the ~20 separate launches it replaces
 struct MgWeights { int n; double w[4]; };      // the smoother's Jacobi weights per sweep (pre-smoothing order; post-smoothing runs them backwards)
-int launch_mg_tail(hipStream_t s, const PMat* A, double* const* x0, double* const* x1, double* const* b, int n, double w, int coarse_sweeps, MgWeights W);
+int launch_mg_tail(hipStream_t s, const PMat* A, double* const* x0, double* const* x1, double* const* b, int n, double w, int coarse_sweeps, MgWeights W,
+                   const double* fac = nullptr);
 
 int launch_copy_f64(hipStream_t s, double* dst, const double* src, size_t n);
 int launch_relax_field(hipStream_t s, double* x, const double* prev, double alpha, size_t n);   // x = prev + alpha (x - prev)

@@ -21,7 +21,7 @@ namespace fy {
 
 // coarsest multigrid level: solved by damped-Jacobi sweeps inside one 1024-thread workgroup (every level below ~20^3 is
 // launch-bound on the GPU; stopping at <= 1024 cells was tried and LOST: 40 sweeps no longer solve that level, +20 % PCG iterations)
-constexpr int kMgCoarsest = 256, kMgCoarsestEdge = 8;
+constexpr int kMgCoarsest = kMgDirectMax, kMgCoarsestEdge = 8;      // the coarsest level (<= 128 cells, no edge over 8: band <= 64) is solved exactly from its banded Cholesky factor
 constexpr int kMgReplicateBelow = 1 << 20;    // a distributed hierarchy hands over to the replicated one at <= this many GLOBAL cells: every
                                               // distributed level costs 4 neighbour exchanges per V-cycle, a replicated 1 M-cell level ~15 us per kernel
 
@@ -135,7 +135,7 @@ struct Solver {
         FY_HIP(hipStreamCreateWithFlags(&comm_stream, hipStreamNonBlocking));
         FY_HIP(hipEventCreateWithFlags(&ev_ready, hipEventDisableTiming));
         FY_HIP(hipEventCreateWithFlags(&ev_halo, hipEventDisableTiming));
-        overlap_halos = getenv("FOAMYADE_NO_HALO_OVERLAP") == nullptr;
+        overlap_halos = !options().no_halo_overlap;
         comm->set_aux_stream(comm_stream);
         // ---- slab extents: the case describes the GLOBAL block; rank r owns planes [r*nz, (r+1)*nz)
         const int S = comm->size;
@@ -261,9 +261,7 @@ struct Solver {
         } else {
             red_host = nullptr;              // fall back to the copy path
         }
-        const char* np_env = getenv("FOAMYADE_NO_POLLED_READBACK");                           // A/B switch: stream synchronisation instead
-        const bool no_poll = np_env && *np_env;
-        if (red_host && !no_poll && hipHostMalloc((void**)&red_flag, 8 * sizeof(unsigned long long), hipHostMallocMapped) == hipSuccess) {
+        if (red_host && hipHostMalloc((void**)&red_flag, 8 * sizeof(unsigned long long), hipHostMallocMapped) == hipSuccess) {
             for (int q = 0; q < 8; ++q) red_flag[q] = 0;
             if (hipHostGetDevicePointer((void**)&red_flag_dev, red_flag, 0) != hipSuccess) { (void)hipHostFree(red_flag); red_flag = nullptr; }
         } else {
@@ -527,12 +525,12 @@ struct Solver {
                 MgLev& M = *mg[l + (size_t)q];
                 A[q] = M.A; x0[q] = M.x0.p; x1[q] = M.x1.p; b[q] = q == 0 ? const_cast<double*>(L.bptr) : M.b.p;
             }
-            FY_TRY(launch_mg_tail(stream, A, x0, x1, b, n, w, coarse_sweeps, W));
+            FY_TRY(launch_mg_tail(stream, A, x0, x1, b, n, w, coarse_sweeps, W, mg_inv.p));
             L.xcur = n > 1 ? L.x1.p : L.x0.p; L.xalt = n > 1 ? L.x0.p : L.x1.p;
             return FY_OK;
         }
         if (l + 1 == mg.size()) {
-            FY_TRY(launch_mg_coarse_solve(stream, L.A, L.bptr, L.x0.p, L.x1.p, coarse_sweeps, w));
+            FY_TRY(launch_mg_coarse_solve(stream, L.A, L.bptr, L.x0.p, L.x1.p, coarse_sweeps, w, mg_inv.p));
             L.xcur = L.x0.p; L.xalt = L.x1.p;
             return FY_OK;
         }
@@ -583,28 +581,54 @@ struct Solver {
     // steps/s); moving bed and C2 +-1 %.  The sweeps run inside the one-workgroup tail kernel, ~0.1 us each
     static constexpr int kMgCoarseSweeps = 120;
     int coarse_sweeps = kMgCoarseSweeps;
-    bool fuse_prolong = getenv("FOAMYADE_NO_PROLONG_FUSION") == nullptr;     // A/B switch (identical results)
+    bool fuse_prolong = true;            // prolongation folded into the first post-smoothing sweep (identical results)
 
     // coarse operators: A_{l+1} = 1/2 P^T A_l P level by level; the first replicated level is all-gathered from the slabs' slices
+    // index of the coarse cell that holds the pressure reference cell, local to the level-`lvl` operator `A` whose first plane is global
+    // coarse plane `k0` (-1: no reference cell, or not in A's planes)
+    int ref_cell_at(size_t lvl, const PMat& A, int k0) const {
+        if (!g.need_ref) return -1;
+        const int i = (g.p_ref_cell % g.nx) >> lvl, j = ((g.p_ref_cell / g.nx) % g.ny) >> lvl, k = (g.p_ref_cell / (g.nx * g.ny)) >> lvl;
+        const int kl = k - k0;
+        if (kl < 0 || kl >= A.nz) return -1;
+        return i + A.nx * (j + A.ny * kl);
+    }
     int build_coarse_operators() {
+        // the reference cell's point term (k_mg_coarsen): level 0's value, known to every rank
+        const double* ref_term = nullptr;
+        if (g.need_ref && mg.size() > 1) {
+            if (!mg_ref.p) FY_TRY(mg_ref.alloc_exact(1));
+            FY_TRY(launch_mg_ref_term(stream, mg[0]->A, ref_cell_at(0, mg[0]->A, mg[0]->distributed ? g.kglob0 : 0), mg_ref.p));
+            if (mg[0]->distributed) FY_TRY(comm->allreduce(stream, mg_ref.p, 1, false));
+            ref_term = mg_ref.p;
+        }
         for (size_t l = 0; l + 1 < mg.size(); ++l) {
             MgLev& F = *mg[l]; MgLev& Cc = *mg[l + 1];
             if (F.distributed && !Cc.distributed) {
                 PMat loc = slice_of(F, Cc);
                 const size_t cnt = (size_t)loc.N;
                 loc.diag = rep_stage.p; loc.ux = rep_stage.p + cnt; loc.uy = rep_stage.p + 2 * cnt; loc.uz = rep_stage.p + 3 * cnt;
-                FY_TRY(launch_mg_coarsen(stream, F.A, loc));
+                FY_TRY(launch_mg_coarsen(stream, F.A, loc, ref_cell_at(l + 1, loc, comm->rank * loc.nz), ref_term));
                 FY_TRY(comm->allgather(stream, loc.diag, Cc.A.diag, cnt));
                 FY_TRY(comm->allgather(stream, loc.ux, Cc.A.ux, cnt));
                 FY_TRY(comm->allgather(stream, loc.uy, Cc.A.uy, cnt));
                 FY_TRY(comm->allgather(stream, loc.uz, Cc.A.uz, cnt));
             } else {
-                FY_TRY(launch_mg_coarsen(stream, F.A, Cc.A));
+                FY_TRY(launch_mg_coarsen(stream, F.A, Cc.A, ref_cell_at(l + 1, Cc.A, Cc.distributed ? comm->rank * Cc.A.nz : 0), ref_term));
                 if (Cc.distributed && comm->has_down()) FY_TRY(launch_mg_coarsen_ghost(stream, F.A, Cc.A));
+            }
+        }
+        // the coarsest operator's banded Cholesky factor (k_mg_coarse_factor): rebuilt with the operators, used by every V-cycle until the next assembly
+        if (cs.p_solver == FY_PSOLVER_PCG_MG) {
+            const MgLev& Lc = *mg.back();
+            if (!Lc.distributed && mg_coarse_direct_ok(Lc.A)) {
+                if (!mg_inv.p) FY_TRY(mg_inv.alloc_exact((size_t)mg_coarse_factor_doubles(Lc.A)));
+                FY_TRY(launch_mg_coarse_factor(stream, Lc.A, mg_inv.p));
             }
         }
         return FY_OK;
     }
+    DevBuf<double> mg_inv, mg_ref;
 
     // OpenFOAM PCG.C with lduMatrix::solver::normFactor; preconditioner = MG V-cycle or Jacobi
     int solve_pressure(bool final_iter) {
@@ -702,7 +726,7 @@ struct Solver {
     }
     // Courant sums of the flux the last corrector left (max sumPhi/V, sum sumPhi), formed by k_U_correct<true>: what CourantNo.H at the top
     // of the next pass would compute from the same phi.  Dropped whenever a field is written from outside (fy_solver_write_field_host).
-    bool fuse_diag = getenv("FOAMYADE_NO_DIAG_FUSION") == nullptr;
+    bool fuse_diag = true;               // continuity errors and the next Courant sums ride on the velocity-correction sweep
     int carry_slot = -1;
     bool carry_valid = false;
     double carry_h[2] = {0, 0};
@@ -894,6 +918,11 @@ struct Solver {
                          {"gradP", gradP.p, 3 * n, 3}, {"divT", divT.p, 3 * n, 3}, {"vGrad", vGrad.p, 9 * n, 9}, {"ddtU", ddtU.p, 3 * n, 3}, {"nut", nut.p, n, 1}, {"k", kturb.p, n, 1}, {"epsilon", epsturb.p, n, 1}};
         for (const E& e : tab) if (s == e.nm) {
             if (!e.p) return fail(FY_ERR_INVALID, "solver field '%s' does not exist in this case (no turbulence model)", s.c_str());
+            // kEqn / kEpsilon assemble and solve their transport equations in the momentum matrix's storage after the last corrector
+            // (turbulence_correct): these three diagnostics would then return transport-equation data beside a momentum rAU
+            const bool transport = cs.turbulence_model == FY_TURBULENCE_KEQN || cs.turbulence_model == FY_TURBULENCE_KEPSILON;
+            if (transport && (s == "HbyA" || s == "mom_diag" || s == "mom_src"))
+                return fail(FY_ERR_UNSUPPORTED, "solver field '%s' is overwritten by the turbulence transport solve in this case (kEqn / kEpsilon reuse the momentum matrix's storage)", s.c_str());
             *ptr = e.p + (size_t)e.comp * g.c0;          // skip the ghost planes below the owned range (comp = 0: face array)
             *count = e.c;
             return FY_OK;

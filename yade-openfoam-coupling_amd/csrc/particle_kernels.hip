@@ -329,76 +329,6 @@ __global__ __launch_bounds__(256) void k_build_locate_lists(const uint32_t* __re
     if (overflow) lists[t * kListLen] = (unsigned short)kListOverflow;
 }
 
-// one lane per particle; particles the lists do not cover are appended to (fb_list, fb_count) for the walk
-__global__ __launch_bounds__(256) void k_locate_lists(LocateLists ll, ImplicitGeom ig, ParticleSoA p, int64_t n, double maxdist, SlabOwn own) {
-    const unsigned short* __restrict__ lists = ll.lists;
-    int32_t* __restrict__ fb_list = ll.fb_list;
-    unsigned int* __restrict__ fb_count = ll.fb_count;
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const double qx = p.px[i], qy = p.py[i], qz = p.pz[i];
-    if (own.active) {                                    // another slab's particle: not located here (k = 0)
-        int kz = (int)floor((qz - own.oz) / own.dx);
-        kz = min(max(kz, 0), own.nzglob - 1);
-        if (!(qz == qz) || kz < own.k0 || kz >= own.k1) { p.chain_len[i] = 0; return; }
-    }
-    const double hdx = 0.5 * ig.dx;
-    const double sx = (qx - ig.ox) / ig.dx, sy = (qy - ig.oy) / ig.dx, sz = (qz - ig.oz) / ig.dx;
-    const double fx = floor(sx), fy_ = floor(sy), fz = floor(sz);
-    const double tx = sx - fx, ty = sy - fy_, tz = sz - fz;
-    const double tlo = 2 * kListEps, thi = 1.0 - 2 * kListEps;
-    bool ok = fx >= 0 && fx < ig.nx && fy_ >= 0 && fy_ < ig.ny && fz >= 0 && fz < ig.nz &&
-              tx >= tlo && tx <= thi && ty >= tlo && ty <= thi && tz >= tlo && tz <= thi;      // (false for NaN)
-    const int ci = (int)fx, cj = (int)fy_, ck = (int)fz;
-    const uint4* row = nullptr;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (ok) {
-        const double cx = ig.ox + (double)(2 * ci + 1) * hdx, cy = ig.oy + (double)(2 * cj + 1) * hdx, cz = ig.oz + (double)(2 * ck + 1) * hdx;
-        const int oct = (qx - cx < 0.0 ? 0 : 1) | (qy - cy < 0.0 ? 0 : 2) | (qz - cz < 0.0 ? 0 : 4);
-        const int64_t cell = (int64_t)ci + (int64_t)ig.nx * ((int64_t)cj + (int64_t)ig.ny * (int64_t)ck) - ll.cell0;
-        ok = cell >= 0 && cell < ll.n_listed;                    // (a slab lists its own planes only)
-        if (ok) {
-            row = reinterpret_cast<const uint4*>(lists + ((size_t)cell * 8 + (size_t)oct) * kListLen);
-            v = row[0];
-            ok = (v.x & 0xffffu) != kListOverflow;
-        }
-    }
-    if (!ok) {
-        const unsigned int at = atomicAdd(fb_count, 1u);
-        fb_list[at] = (int32_t)i;
-        return;
-    }
-    double best = 1e300;
-    int chain = 0;
-    for (int ch = 0; ch < kListLen / 8; ++ch) {
-        if (ch) v = row[ch];
-        const uint32_t wds[4] = {v.x, v.y, v.z, v.w};
-        bool done = false;
-#pragma unroll
-        for (int h = 0; h < 8; ++h) {
-            const uint32_t code = (wds[h >> 1] >> ((h & 1) * 16)) & 0xffffu;
-            if (code == kListEnd) { done = true; break; }
-            const int ni = ci + (int)(code & 15u) - 8, nj = cj + (int)((code >> 4) & 15u) - 8, nk = ck + (int)((code >> 8) & 15u) - 8;
-            const double a = qx - (ig.ox + (double)(2 * ni + 1) * hdx), b = qy - (ig.oy + (double)(2 * nj + 1) * hdx),
-                         c = qz - (ig.oz + (double)(2 * nk + 1) * hdx);
-            double d = a * a;                        // meshTree.C:54-64: dist += ds*ds over x, y, z
-            d += b * b;
-            d += c * c;
-            if (d < best) {                          // meshTree.C:192
-                best = d;
-                if (d < maxdist && !(code & kListNoEmit)) {       // meshTree.C:195; the root is never pushed (meshTree.C:156)
-                    const size_t slot = (size_t)(chain & (kMaxK - 1)) * p.cap + (size_t)i;
-                    p.ids[slot] = ni + ig.nx * (nj + ig.ny * nk);
-                    p.w[slot] = d;
-                    ++chain;
-                }
-            }
-        }
-        if (done) break;
-    }
-    p.chain_len[i] = chain;
-}
-
 // What k_deposit does for one particle, straight after its walk and with plain global atomics: the candidate lists' leftovers are a few
 // hundred particles (within 8e-6 dx of a cell face), for which a second, latency-bound launch with its own aggregation table cost more
 // than the walk itself.  pvol_acc == nullptr: the walk only parks the squared distances (k_deposit follows).
@@ -970,11 +900,7 @@ __global__ __launch_bounds__(kDepThreads) void k_locate_deposit(LocateLists ll, 
                         if (d < best) {                      // meshTree.C:192
                             best = d;
                             if (d < gp.maxdist && !(code & kListNoEmit)) {       // meshTree.C:195; the root is never pushed
-#if defined(FY_EXP_LD_NOEXP)
-                                wt[h] = (1.0 - d / gp.two_sigma2) * gp.range_cu * gp.sigma_pi;
-#else
                                 wt[h] = exp(-d / gp.two_sigma2) * gp.range_cu * gp.sigma_pi;     // FoamYade.C:308
-#endif
                                 emitted |= 1u << h;
                             }
                         }
@@ -1000,19 +926,11 @@ __global__ __launch_bounds__(kDepThreads) void k_locate_deposit(LocateLists ll, 
                             const int32_t id = ni + ig.nx * (nj + ig.ny * nk);
                             const double weight = wt[h] / allwt;                      // FoamYade.C:312-314
                             const size_t slot = (size_t)(pos & (kMaxK - 1)) * p.cap + (size_t)i;
-#if !defined(FY_EXP_LD_NOSTORE)
                             p.ids[slot] = id;
                             p.w[slot] = weight;
-#else
-                            if (weight == 1.2345e300) p.w[slot] = weight;
-#endif
                             ++pos;
                             const int64_t cl = (int64_t)id - cw.base;                 // storage index (slab window)
-#if defined(FY_EXP_LD_NODEPOSIT)
-                            if (cl == -12345) {
-#else
                             if (cl >= 0 && cl < cw.n_field) {
-#endif
                                 const double c0 = pVol * weight, c1 = (weight * vx) * pVol, c2 = (weight * vy) * pVol, c3 = (weight * vz) * pVol;
                                 deposit_pair(keys, vals, (int32_t)cl, c0, c1, c2, c3, pvol_acc, up_acc, touched);
                             }
@@ -1166,9 +1084,9 @@ __device__ __forceinline__ void model_add(ModelSums& ms, const ForceParams& fp, 
     }
 }
 
-// MODE 0: gather + force + back-scatter in one kernel, one lane per particle (LDS aggregation table per workgroup, flushed to the tile buckets)
-// MODE 1: gather + force only, {coeff, b} parked per particle in `scr` (no LDS)
-// MODE 2: back-scatter only, from `scr`
+// gather + force law + back-scatter in one kernel, one lane per particle (LDS aggregation table per workgroup, flushed to the tile buckets).
+// (As two kernels -- gathers without LDS, then the back-scatter -- it measured 1.01 + 1.02 ms against 1.50 fused; timing-only variants of this
+// kernel are built from a copy with tools/build_variant.sh, the shipped source carries none.)
 #ifndef FY_FORCE_THREADS
 #define FY_FORCE_THREADS 512
 #endif
@@ -1176,24 +1094,20 @@ __device__ __forceinline__ void model_add(ModelSums& ms, const ForceParams& fp, 
 #define FY_FORCE_LOG2 10
 #endif
 constexpr int kForceThreads = FY_FORCE_THREADS, kForceLog2 = FY_FORCE_LOG2;
-template <int MODE>
-__global__ __launch_bounds__(MODE == 1 ? 256 : kForceThreads) void k_force_gaussian(
+__global__ __launch_bounds__(kForceThreads) void k_force_gaussian(
         ParticleSoA p, int64_t n, ForceParams fp, CellWindow cw, const double* __restrict__ vol, const double* __restrict__ R,
-        const double* __restrict__ vGrad, const double* __restrict__ ddtU, const double* __restrict__ rec, double* __restrict__ scr,
+        const double* __restrict__ vGrad, const double* __restrict__ ddtU, const double* __restrict__ rec,
         double* __restrict__ drag_acc, double* __restrict__ uSource, double* __restrict__ force_out, TileBuckets tb) {
-    constexpr int kThreads = MODE == 1 ? 256 : kForceThreads;
-    constexpr int kSlots = MODE == 1 ? 256 : (1 << kForceLog2);
-    __shared__ uint32_t keys[MODE == 1 ? 1 : kSlots];
-    __shared__ double vals[MODE == 1 ? 1 : kSlots * 4];
+    constexpr int kSlots = 1 << kForceLog2;
+    __shared__ uint32_t keys[kSlots];
+    __shared__ double vals[kSlots * 4];
     __shared__ TileMapLds tmap;
-    if constexpr (MODE != 1) {
-        for (int q = threadIdx.x; q < kSlots; q += kThreads) {
-            keys[q] = kAggEmpty;
-            vals[4 * q] = 0.0; vals[4 * q + 1] = 0.0; vals[4 * q + 2] = 0.0; vals[4 * q + 3] = 0.0;
-        }
-        __syncthreads();
+    for (int q = threadIdx.x; q < kSlots; q += kForceThreads) {
+        keys[q] = kAggEmpty;
+        vals[4 * q] = 0.0; vals[4 * q + 1] = 0.0; vals[4 * q + 2] = 0.0; vals[4 * q + 3] = 0.0;
     }
-    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * kForceThreads + threadIdx.x;
     if (i < n) {
         const int chain = p.chain_len[i];
         const int k = chain < kMaxK ? chain : kMaxK;
@@ -1205,87 +1119,58 @@ __global__ __launch_bounds__(MODE == 1 ? 256 : kForceThreads) void k_force_gauss
         // the difference is rounding in the last bits (covered by the 1e-10 bar of the golden tests).
         const int first = chain - k;
         ParticleForce pf{0.0, 0.0, 0.0, 0.0};
-        if constexpr (MODE != 2) {
-            const int32_t orig = p.orig[i];
-            double* F = force_out + 6 * (size_t)orig;
-            if (k == 0) {                                   // zeros for particles nobody located (FoamYade.C:142)
-                F[0] = F[1] = F[2] = 0.0;
-                if (!fp.torque_prezeroed) { F[3] = F[4] = F[5] = 0.0; }
-            } else {
-                const double dia = 2 * p.rad[i];
-                const double volp = M_PI * cube3(dia) / 6.0;
-                // hydroDragForce FoamYade.C:358-365 and archimedesForce FoamYade.C:416-424 share one gather pass over the cell records
-                Interp s{0, 0, 0, 0, 0, 0, 0, 0};
-                ModelSums ms{0, 0, 0, 0, 0, 0, 0};
-                for (int t = 0; t < k; ++t) {
-                    const size_t slot = (size_t)((first + t) & (kMaxK - 1)) * p.cap + (size_t)i;
-                    const int64_t cl = (int64_t)p.ids[slot] - cw.base;
-                    if (cl < 0 || cl >= cw.n_field) continue;
-#if defined(FY_EXP_SAMECELL)
-                    interp_add(s, R, (int64_t)(threadIdx.x & 63), p.w[slot], volp);
-#else
-                    interp_add(s, R, cl, p.w[slot], volp);
-#endif
-                }
-                if (fp.models)                              // uniform: off in the shipped reference
-                    for (int t = 0; t < k; ++t) {
-                        const size_t slot = (size_t)((first + t) & (kMaxK - 1)) * p.cap + (size_t)i;
-                        const int64_t cl = (int64_t)p.ids[slot] - cw.base;
-                        if (cl < 0 || cl >= cw.n_field) continue;
-                        model_add(ms, fp, vGrad, ddtU, cl, p.w[slot], volp);
-                    }
-#if defined(FY_EXP_NOLAW)          // timing-only experiments (never defined in the product build; tools/build_variant.sh)
-                pf.coeff = s.ufx + s.alpha_f; pf.bx = s.sax + s.pv; pf.by = s.say + s.ufy; pf.bz = s.saz + s.ufz;
-#elif defined(FY_EXP_NOFSTORE)
-                double Fl[6];
-                pf = force_law(fp, s, ms, k, dia, p.vx[i], p.vy[i], p.vz[i], rec + 10 * (size_t)orig, Fl);
-                if (Fl[0] == 1.2345e300) F[0] = Fl[1];
-#else
-                pf = force_law(fp, s, ms, k, dia, p.vx[i], p.vy[i], p.vz[i], rec + 10 * (size_t)orig, F);
-#endif
-            }
-            if constexpr (MODE == 1) {
-                scr[i] = pf.coeff; scr[p.cap + i] = pf.bx; scr[2 * p.cap + i] = pf.by; scr[3 * p.cap + i] = pf.bz;
-            }
+        const int32_t orig = p.orig[i];
+        double* F = force_out + 6 * (size_t)orig;
+        if (k == 0) {                                   // zeros for particles nobody located (FoamYade.C:142)
+            F[0] = F[1] = F[2] = 0.0;
+            if (!fp.torque_prezeroed) { F[3] = F[4] = F[5] = 0.0; }
         } else {
-            pf.coeff = scr[i]; pf.bx = scr[p.cap + i]; pf.by = scr[2 * p.cap + i]; pf.bz = scr[3 * p.cap + i];
-        }
-        if constexpr (MODE != 1) {
-            if (k > 0) {
-                const double irho = 1 / fp.rhoF;
-                // a uniform block's cell volume is a constant, not a gather
-                const double ooUniform = fp.uniform_vol > 0 ? 1. / (fp.uniform_vol * fp.rhoF) : 0.0;
+            const double dia = 2 * p.rad[i];
+            const double volp = M_PI * cube3(dia) / 6.0;
+            // hydroDragForce FoamYade.C:358-365 and archimedesForce FoamYade.C:416-424 share one gather pass over the cell records
+            Interp s{0, 0, 0, 0, 0, 0, 0, 0};
+            ModelSums ms{0, 0, 0, 0, 0, 0, 0};
+            for (int t = 0; t < k; ++t) {
+                const size_t slot = (size_t)((first + t) & (kMaxK - 1)) * p.cap + (size_t)i;
+                const int64_t cl = (int64_t)p.ids[slot] - cw.base;
+                if (cl < 0 || cl >= cw.n_field) continue;
+                interp_add(s, R, cl, p.w[slot], volp);
+            }
+            if (fp.models)                              // uniform: off in the shipped reference
                 for (int t = 0; t < k; ++t) {
                     const size_t slot = (size_t)((first + t) & (kMaxK - 1)) * p.cap + (size_t)i;
                     const int64_t cl = (int64_t)p.ids[slot] - cw.base;
                     if (cl < 0 || cl >= cw.n_field) continue;
-                    const int32_t c = (int32_t)cl;
-                    const double w = p.w[slot];
-                    const double ooCellVol = fp.uniform_vol > 0 ? ooUniform : 1. / (vol[c] * fp.rhoF);  // FoamYade.C:432
-                    const double c0 = (-pf.coeff * w) * irho;                                      // FoamYade.C:385 (and, times uParticle[c], :386)
-                    const double c1 = (-pf.bx * w) * ooCellVol, c2 = (-pf.by * w) * ooCellVol, c3 = (-pf.bz * w) * ooCellVol;   // FoamYade.C:433, 406-411
-#if defined(FY_EXP_NOHASH)
-                    const int h = (int)(((uint32_t)c * 2654435761u) >> (32 - kForceLog2)); keys[h] = (uint32_t)c;
-#else
-                    const int h = agg_slot<kForceLog2>(keys, (uint32_t)c);
-#endif
-                    if (h >= 0) {
-                        lds_add_f64(&vals[4 * h], c0); lds_add_f64(&vals[4 * h + 1], c1);
-                        lds_add_f64(&vals[4 * h + 2], c2); lds_add_f64(&vals[4 * h + 3], c3);
-                    } else {
-                        atomic_add_f64(&drag_acc[c], c0);
-                        atomic_add_f64(&uSource[3 * (size_t)c + 0], c1);
-                        atomic_add_f64(&uSource[3 * (size_t)c + 1], c2);
-                        atomic_add_f64(&uSource[3 * (size_t)c + 2], c3);
-                    }
+                    model_add(ms, fp, vGrad, ddtU, cl, p.w[slot], volp);
+                }
+            pf = force_law(fp, s, ms, k, dia, p.vx[i], p.vy[i], p.vz[i], rec + 10 * (size_t)orig, F);
+            const double irho = 1 / fp.rhoF;
+            // a uniform block's cell volume is a constant, not a gather
+            const double ooUniform = fp.uniform_vol > 0 ? 1. / (fp.uniform_vol * fp.rhoF) : 0.0;
+            for (int t = 0; t < k; ++t) {
+                const size_t slot = (size_t)((first + t) & (kMaxK - 1)) * p.cap + (size_t)i;
+                const int64_t cl = (int64_t)p.ids[slot] - cw.base;
+                if (cl < 0 || cl >= cw.n_field) continue;
+                const int32_t c = (int32_t)cl;
+                const double w = p.w[slot];
+                const double ooCellVol = fp.uniform_vol > 0 ? ooUniform : 1. / (vol[c] * fp.rhoF);  // FoamYade.C:432
+                const double c0 = (-pf.coeff * w) * irho;                                      // FoamYade.C:385 (and, times uParticle[c], :386)
+                const double c1 = (-pf.bx * w) * ooCellVol, c2 = (-pf.by * w) * ooCellVol, c3 = (-pf.bz * w) * ooCellVol;   // FoamYade.C:433, 406-411
+                const int h = agg_slot<kForceLog2>(keys, (uint32_t)c);
+                if (h >= 0) {
+                    lds_add_f64(&vals[4 * h], c0); lds_add_f64(&vals[4 * h + 1], c1);
+                    lds_add_f64(&vals[4 * h + 2], c2); lds_add_f64(&vals[4 * h + 3], c3);
+                } else {
+                    atomic_add_f64(&drag_acc[c], c0);
+                    atomic_add_f64(&uSource[3 * (size_t)c + 0], c1);
+                    atomic_add_f64(&uSource[3 * (size_t)c + 1], c2);
+                    atomic_add_f64(&uSource[3 * (size_t)c + 2], c3);
                 }
             }
         }
     }
-    if constexpr (MODE != 1) {
-        __syncthreads();
-        flush_table<kSlots, kThreads>(keys, vals, tmap, tb, drag_acc, uSource, nullptr);
-    }
+    __syncthreads();
+    flush_table<kSlots, kForceThreads>(keys, vals, tmap, tb, drag_acc, uSource, nullptr);
 }
 
 // ---- particle migration between z-slabs: records whose containing cell now lies in a neighbour's planes are packed for
@@ -1485,14 +1370,7 @@ int launch_locate(hipStream_t s, const KdNode* tree, const uint32_t* packed, Imp
     if (packed && n_cells >= (1 << 25)) return fail(FY_ERR_UNSUPPORTED, "implicit-coordinate tree limited to 2^25 cells");
     const size_t lds = (size_t)(levels + 1) * kWave * (packed ? sizeof(unsigned long long) : sizeof(uint4));
     const dim3 grid(div_up(n, kLocPPB));
-    if (packed && ll.lists) {
-        // the lists place almost every particle; the walk below takes what is left (usually nothing: its waves read a zero count and exit)
-        FY_HIP(hipMemsetAsync(ll.fb_count, 0, sizeof(unsigned int), s));
-        hipLaunchKernelGGL(k_locate_lists, dim3(div_up(n, 256)), dim3(256), 0, s, ll, ig, p, n, gp.maxdist, own);
-        FY_LAUNCH_CHECK();
-        const dim3 wgrid((unsigned)std::min<int64_t>(div_up(n, kLocPPB), 2048));
-        hipLaunchKernelGGL(k_locate<true>, wgrid, dim3(kWave), lds, s, tree, packed, ig, n_cells, p, n, gp.maxdist, start, SlabOwn{}, ll.fb_list, ll.fb_count, WalkDeposit{});
-    } else if (packed) {
+    if (packed) {
         hipLaunchKernelGGL(k_locate<true>, grid, dim3(kWave), lds, s, tree, packed, ig, n_cells, p, n, gp.maxdist, start, own, nullptr, nullptr, WalkDeposit{});
     } else {
         hipLaunchKernelGGL(k_locate<false>, grid, dim3(kWave), lds, s, tree, packed, ig, n_cells, p, n, gp.maxdist, nullptr, own, nullptr, nullptr, WalkDeposit{});
@@ -1584,16 +1462,10 @@ int launch_fold_sources(hipStream_t s, int64_t n_field, double* drag_acc, const 
 }
 
 int launch_force_gaussian(hipStream_t s, ParticleSoA p, int64_t n, ForceParams fp, CellWindow cw, const double* vol, const double* R,
-                          const double* vGrad, const double* ddtU, const double* rec, double* scr, double* drag_acc, double* uSource,
+                          const double* vGrad, const double* ddtU, const double* rec, double* drag_acc, double* uSource,
                           double* force_out, TileBuckets tb) {
     if (n <= 0) return FY_OK;
-    if (scr) {      // two kernels: the gathers without an LDS table, then the back-scatter (A/B switch)
-        hipLaunchKernelGGL(k_force_gaussian<1>, dim3(div_up(n, 256)), dim3(256), 0, s, p, n, fp, cw, vol, R, vGrad, ddtU, rec, scr, drag_acc, uSource, force_out, tb);
-        FY_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_force_gaussian<2>, dim3(div_up(n, kForceThreads)), dim3(kForceThreads), 0, s, p, n, fp, cw, vol, R, vGrad, ddtU, rec, scr, drag_acc, uSource, force_out, tb);
-    } else {
-        hipLaunchKernelGGL(k_force_gaussian<0>, dim3(div_up(n, kForceThreads)), dim3(kForceThreads), 0, s, p, n, fp, cw, vol, R, vGrad, ddtU, rec, scr, drag_acc, uSource, force_out, tb);
-    }
+    hipLaunchKernelGGL(k_force_gaussian, dim3(div_up(n, kForceThreads)), dim3(kForceThreads), 0, s, p, n, fp, cw, vol, R, vGrad, ddtU, rec, drag_acc, uSource, force_out, tb);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }

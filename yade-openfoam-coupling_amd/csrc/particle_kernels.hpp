@@ -133,9 +133,9 @@ int launch_pack_cells(hipStream_t s, int64_t n_field, const double* U, const dou
                       double nu, double rhoF, double* R);
 int launch_patch_rec_alpha(hipStream_t s, int64_t c0, int64_t n, const double* alpha, double* R);    // alpha slot of cells [c0, c0 + n)
 // scatters D[c] = sum -coeff w / rho_f into drag_acc and the Archimedes reaction into uSource; launch_fold_sources then adds D to
-// uSourceDrag and uParticle * D to uSource and clears D.  scr != nullptr (4 * p.cap doubles): gather and scatter as two kernels.
+// uSourceDrag and uParticle * D to uSource and clears D
 int launch_force_gaussian(hipStream_t s, ParticleSoA p, int64_t n, ForceParams fp, CellWindow cw, const double* vol, const double* R,
-                          const double* vGrad, const double* ddtU, const double* rec, double* scr, double* drag_acc, double* uSource,
+                          const double* vGrad, const double* ddtU, const double* rec, double* drag_acc, double* uSource,
                           double* force_out, TileBuckets tb = TileBuckets{});
 int launch_fold_sources(hipStream_t s, int64_t n_field, double* drag_acc, const double* uParticle, double* uSourceDrag, double* uSource);
 // z-slab migration: classify by owner slab and pack (11 doubles per particle: record + tag bits); counters = {stay, up, down}
