@@ -59,7 +59,7 @@ def main():
             rec = np.ascontiguousarray(rec[np.argsort(rec[:, 2] + 0.3 * nz * dx * np.sin(7.0 * rec[:, 0] / dx), kind="stable")])
             if step == 1:
                 rec[:rec.shape[0] // W, 2] = np.minimum(rec[:rec.shape[0] // W, 2], 10.5 * dx)
-            rec[:5, 2] = n * dx                                    # on the first interface: sent to both neighbours, located by one
+            rec[-5:, 2] = n * dx                                   # on the first interface: sent to both neighbours, located by one
             peer.set_records(rec)
             mine.step()
             f, a, F = peer.gathered()

@@ -1505,18 +1505,17 @@ __global__ __launch_bounds__(256) void k_mg_prolong_add(PMat A, double* __restri
 // coarsest level (N <= 1024, never distributed: c0 = 0): all sweeps inside one workgroup
 // The coarsest operator (<= kMgDirectMax = 128 cells) only changes when the pressure matrix is assembled, and every V-cycle in between solves
 // with it: so it is FACTORED once per assembly -- banded Cholesky A = L L^T in LDS (band width = the operator's z stride, 25 for the 5^3
-// level of C3: N bw^2 = 78 k multiply-adds; a dense 125^3 inversion was built first and cost 0.5 ms, LDS-bandwidth bound), one 256-thread
-// workgroup, two barriers per column -- and a V-cycle's coarse solve is two banded substitutions in one wave (coarse_band_solve) instead of
+// level of C3: N bw^2 = 78 k multiply-adds; a dense 125^3 inversion was built first and cost 0.5 ms, LDS-bandwidth bound), one workgroup, one barrier per column -- and a V-cycle's coarse solve is two banded substitutions in one wave (coarse_band_solve) instead of
 // 120 Jacobi sweeps that left the level's smoothest modes partly in.  The operator is a symmetric positive definite M-matrix (the
 // reference cell or a fixed-value patch makes it non-singular); fac[2] = 0 if a pivot is not positive and finite (the sweeps then stand in).
-__global__ __launch_bounds__(256) void k_mg_coarse_factor(PMat A, int bw, double* __restrict__ fac) {
+__global__ __launch_bounds__(1024) void k_mg_coarse_factor(PMat A, int bw, double* __restrict__ fac) {
     extern __shared__ double B[];                  // [N][bw + 1]: B[i][d] = A(i, i - d), overwritten by L
     __shared__ int bad;
     const int N = A.N, tid = threadIdx.x, Wd = bw + 1, sy = A.nx, sz = A.nx * A.ny;
     if (tid == 0) bad = 0;
-    for (int e = tid; e < N * Wd; e += 256) B[e] = 0.0;
+    for (int e = tid; e < N * Wd; e += 1024) B[e] = 0.0;
     __syncthreads();
-    for (int c = tid; c < N; c += 256) {           // the lower half of row c of p_row (zero coefficients at the walls); += : strides coincide on flat grids
+    for (int c = tid; c < N; c += 1024) {          // the lower half of row c of p_row (zero coefficients at the walls); += : strides coincide on flat grids
         double* row = B + (size_t)c * Wd;
         row[0] += A.diag[c];
         if (c >= 1) row[1] -= A.ux[c - 1];
@@ -1524,22 +1523,33 @@ __global__ __launch_bounds__(256) void k_mg_coarse_factor(PMat A, int bw, double
         if (A.nz > 1 && c >= sz && sz <= bw) row[sz] -= A.uz[c - sz];
     }
     __syncthreads();
+    // Right-looking elimination with the column entries left UNSCALED (they hold L(i, j) L(j, j)): the trailing update of column j,
+    // A(i, k) -= A(i, j) A(k, j) / A(j, j) for j < k <= i <= j + m, reads column j and writes columns > j only -- ONE barrier per column --
+    // and the division by L(j, j) is applied to every entry at the end.  A thread owns fixed positions (a, b) of the bw x bw update window
+    // (bw <= 64: at most four), so there is no index arithmetic in the loop.
+    int ua[4], ub[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const int e = tid + 1024 * q; ua[q] = e / bw; ub[q] = e - ua[q] * bw; }
     for (int j = 0; j < N; ++j) {
         const double d = B[(size_t)j * Wd];
         if (!(d > 0.0) || !(d < 1e300)) { if (tid == 0) bad = 1; break; }      // (uniform: every thread reads the same value)
-        const double rl = 1.0 / sqrt(d);
+        const double id = 1.0 / d;
         const int m = min(bw, N - 1 - j);           // rows below the diagonal in this column
-        if (tid < m) B[(size_t)(j + 1 + tid) * Wd + 1 + tid] *= rl;            // L(i, j) = A(i, j) / L(j, j)
-        __syncthreads();
-        if (tid == 0) B[(size_t)j * Wd] = rl;       // the substitutions multiply by 1 / L(j, j)
-        for (int e = tid; e < m * m; e += 256) {    // trailing update, lower triangle: A(i, k) -= L(i, j) L(k, j), j < k <= i <= j + m
-            const int a = e / m, b = e - a * m;
-            if (b <= a) B[(size_t)(j + 1 + a) * Wd + (a - b)] -= B[(size_t)(j + 1 + a) * Wd + 1 + a] * B[(size_t)(j + 1 + b) * Wd + 1 + b];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int a = ua[q], b = ub[q];
+            if (a < m && b <= a) B[(size_t)(j + 1 + a) * Wd + (a - b)] -= (B[(size_t)(j + 1 + a) * Wd + 1 + a] * B[(size_t)(j + 1 + b) * Wd + 1 + b]) * id;
         }
         __syncthreads();
     }
     __syncthreads();
-    for (int e = tid; e < N * Wd; e += 256) fac[3 + e] = B[e];
+    if (!bad) {
+        for (int i = tid; i < N; i += 1024) fac[3 + (size_t)i * Wd] = 1.0 / sqrt(B[(size_t)i * Wd]);      // 1 / L(i, i): the substitutions multiply
+        for (int e = tid; e < N * Wd; e += 1024) {
+            const int i = e / Wd, dd = e - i * Wd;
+            if (dd >= 1) fac[3 + e] = dd <= i ? B[e] / sqrt(B[(size_t)(i - dd) * Wd]) : 0.0;                   // L(i, i - dd) = stored / L(i - dd, i - dd)
+        }
+    }
     if (tid == 0) { fac[0] = (double)N; fac[1] = (double)bw; fac[2] = bad ? 0.0 : 1.0; }
 }
 
@@ -1845,7 +1855,7 @@ int launch_mg_coarse_factor(hipStream_t s, PMat A, double* fac) {
     static bool attr_set = false;
     if (!attr_set) { FY_TRY(allow_big_lds(reinterpret_cast<const void*>(k_mg_coarse_factor))); attr_set = true; }
     const int bw = band_width(A);
-    hipLaunchKernelGGL(k_mg_coarse_factor, dim3(1), dim3(256), fac_lds_bytes(A.N, bw), s, A, bw, fac);
+    hipLaunchKernelGGL(k_mg_coarse_factor, dim3(1), dim3(1024), fac_lds_bytes(A.N, bw), s, A, bw, fac);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }
