@@ -58,6 +58,8 @@ struct orc_fv_case {
     int eps_bc[6]; double eps_value[6]; double eps_initial; int eps_convection_scheme; double eps_tol, eps_rel_tol; int eps_max_iter; double eps_relax;
     // wall functions: nut_bc == 2 nutkWallFunction, eps_bc == 2 epsilonWallFunction [OF-6]; kappa, E (Cmu = ras_cmu)
     double wf_kappa, wf_E;
+    // graded (rectilinear) block: cell sizes along x, y, z (nx, ny, nz doubles; blockMesh simpleGrading); all null = uniform cubes of edge dx
+    const double* hx; const double* hy; const double* hz;
 };
 struct orc_fv_stats {
     double courant_mean, courant_max, cont_sum_local, cont_global, cont_cumulative;
@@ -86,6 +88,33 @@ struct Fv {
     int nx, ny, nz, Nc, n[3], stride[3];
     double dx, Af, V;
     bool pimple;
+    // ---- geometry of a graded (rectilinear, orthogonal) block [OF-6 surfaceInterpolation::weights / deltaCoeffs on a hex mesh whose cell sizes
+    // vary along the axes]: the uniform block keeps its constants (dx, Af, V) and its original expressions, `graded` switches every operator to
+    // the general form -- linear-interpolation weight of the low-side cell at an internal face = distance from the face to the high-side
+    // centre over the centre distance; |Sf| / |d| from the face area and the centre distance (a boundary face: centre to face)
+    bool graded = false;
+    vec h[3];
+    double total_volume = 0.0;
+    inline int idx_of(int d, int c) const { return (c / stride[d]) % n[d]; }
+    inline double vol(int i, int j, int k) const { return graded ? (h[0][i] * h[1][j]) * h[2][k] : V; }
+    inline double volc(int c) const { return graded ? vol(c % nx, (c / nx) % ny, c / (nx * ny)) : V; }
+    // area of a face normal to d whose transverse indices are those of (i, j, k) (cell or face indices: the normal one is not used)
+    inline double area(int d, int i, int j, int k) const { return graded ? (d == 0 ? h[1][j] * h[2][k] : d == 1 ? h[0][i] * h[2][k] : h[0][i] * h[1][j]) : Af; }
+    inline double wlow(int d, int q) const { return graded ? h[d][q] / (h[d][q - 1] + h[d][q]) : 0.5; }
+    inline double lerp(int d, int q, double lo, double hi) const { if (!graded) return 0.5 * (lo + hi); const double w = wlow(d, q); return w * lo + (1.0 - w) * hi; }
+    // centre distance across face q of axis d (q = 0 or n[d]: cell centre to the boundary face)
+    inline double delta(int d, int q) const {
+        if (!graded) return (q == 0 || q == n[d]) ? 0.5 * dx : dx;
+        if (q == 0) return 0.5 * h[d][0];
+        if (q == n[d]) return 0.5 * h[d][n[d] - 1];
+        return 0.5 * (h[d][q - 1] + h[d][q]);
+    }
+    // face index along d of face (d, s) of cell (i, j, k)
+    inline int fq(int d, int s, int i, int j, int k) const { return (d == 0 ? i : d == 1 ? j : k) + s; }
+    // |Sf| / |d| of face (d, s) of cell (i, j, k).  Uniform block: dx for EVERY face -- the boundary factor 2 stays where the uniform code has it
+    inline double sfd(int d, int s, int i, int j, int k) const { return graded ? area(d, i, j, k) / delta(d, fq(d, s, i, j, k)) : dx; }
+    inline double bfac() const { return graded ? 1.0 : 2.0; }          // (gb = bfac * gamma: see sfd)
+    inline double hcell(int d, int c) const { return graded ? h[d][idx_of(d, c)] : dx; }
     int threads = 1;
     // state
     vec U, Uold, p, alpha, alphaOld, uSource, uSourceDrag, uParticle, gradP, divT, vGrad, ddtU;
@@ -118,6 +147,13 @@ struct Fv {
         cs = c; nx = c.nx; ny = c.ny; nz = c.nz; Nc = nx * ny * nz; dx = c.dx; Af = dx * dx; V = dx * dx * dx;
         n[0] = nx; n[1] = ny; n[2] = nz; stride[0] = 1; stride[1] = nx; stride[2] = nx * ny;
         pimple = c.solver == 1;
+        graded = c.hx != nullptr && c.hy != nullptr && c.hz != nullptr;
+        total_volume = V * Nc;
+        if (graded) {
+            h[0].assign(c.hx, c.hx + nx); h[1].assign(c.hy, c.hy + ny); h[2].assign(c.hz, c.hz + nz);
+            total_volume = 0.0;
+            for (int k = 0; k < nz; ++k) for (int j = 0; j < ny; ++j) for (int i = 0; i < nx; ++i) total_volume += vol(i, j, k);
+        }
         U.assign(3 * (size_t)Nc, 0.0); Uold = U; p.assign(Nc, 0.0); alpha.assign(Nc, 1.0); alphaOld = alpha;
         uSource.assign(3 * (size_t)Nc, 0.0); uSourceDrag.assign(Nc, 0.0); uParticle.assign(3 * (size_t)Nc, 0.0);
         gradP.assign(3 * (size_t)Nc, 0.0); divT.assign(3 * (size_t)Nc, 0.0); vGrad.assign(9 * (size_t)Nc, 0.0); ddtU.assign(3 * (size_t)Nc, 0.0);
@@ -146,7 +182,7 @@ struct Fv {
     inline double pbv(int c, int d, int s, int face) const {                     // boundary value of p
         const int patch = 2 * d + s;
         if (cs.p_bc[patch] == 1) return cs.p_value[patch];
-        if (cs.p_bc[patch] == 2) return p[c] + (s ? 0.5 : -0.5) * dx * psn[d][face];
+        if (cs.p_bc[patch] == 2) return p[c] + (s ? 0.5 : -0.5) * hcell(d, c) * psn[d][face];
         return p[c];
     }
     bool need_reference() const { for (int q = 0; q < 6; ++q) if (cs.p_bc[q] == 1) return false; return true; }
@@ -160,8 +196,8 @@ struct Fv {
                 double v;
                 if (q == 0) { double b[3]; Ub(F, cid(i, j, k), 2 * d, b); v = b[d]; }
                 else if (q == n[d]) { double b[3]; const int c = cid(i - (d == 0), j - (d == 1), k - (d == 2)); Ub(F, c, 2 * d + 1, b); v = b[d]; }
-                else { const int c = cid(i, j, k); v = 0.5 * (F[3 * (size_t)(c - stride[d]) + d] + F[3 * (size_t)c + d]); }
-                out[d][f] = v * Af;
+                else { const int c = cid(i, j, k); v = lerp(d, q, F[3 * (size_t)(c - stride[d]) + d], F[3 * (size_t)c + d]); }
+                out[d][f] = v * area(d, i, j, k);
             }
     }
 
@@ -174,9 +210,10 @@ struct Fv {
                 double fv[2];
                 for (int s = 0; s < 2; ++s) {
                     if (onb(d, s, i, j, k)) fv[s] = pbv(c, d, s, cface(d, s, i, j, k));
-                    else fv[s] = 0.5 * (p[c] + p[c + (s ? stride[d] : -stride[d])]);
+                    else if (!graded) fv[s] = 0.5 * (p[c] + p[c + (s ? stride[d] : -stride[d])]);
+                    else fv[s] = s ? lerp(d, fq(d, 1, i, j, k), p[c], p[c + stride[d]]) : lerp(d, fq(d, 0, i, j, k), p[c - stride[d]], p[c]);
                 }
-                G[3 * (size_t)c + d] = (fv[1] - fv[0]) / dx;
+                G[3 * (size_t)c + d] = (fv[1] - fv[0]) / hcell(d, c);
             }
         }
     }
@@ -190,9 +227,13 @@ struct Fv {
                 double fv[2][3];
                 for (int s = 0; s < 2; ++s) {
                     if (onb(d, s, i, j, k)) Ub(F, c, 2 * d + s, fv[s]);
-                    else { const int nb = c + (s ? stride[d] : -stride[d]); for (int q = 0; q < 3; ++q) fv[s][q] = 0.5 * (F[3 * (size_t)c + q] + F[3 * (size_t)nb + q]); }
+                    else {
+                        const int nb = c + (s ? stride[d] : -stride[d]);
+                        for (int q = 0; q < 3; ++q) fv[s][q] = !graded ? 0.5 * (F[3 * (size_t)c + q] + F[3 * (size_t)nb + q])
+                                                             : (s ? lerp(d, fq(d, 1, i, j, k), F[3 * (size_t)c + q], F[3 * (size_t)nb + q]) : lerp(d, fq(d, 0, i, j, k), F[3 * (size_t)nb + q], F[3 * (size_t)c + q]));
+                    }
                 }
-                for (int q = 0; q < 3; ++q) T[9 * (size_t)c + 3 * d + q] = (fv[1][q] - fv[0][q]) / dx;
+                for (int q = 0; q < 3; ++q) T[9 * (size_t)c + 3 * d + q] = (fv[1][q] - fv[0][q]) / hcell(d, c);
             }
         }
     }
@@ -204,7 +245,7 @@ struct Fv {
                 const int q = d == 0 ? i : d == 1 ? j : k;
                 const int f = fid(d, i, j, k);
                 if (q == 0 || q == n[d]) alphaf[d][f] = 1.0;
-                else { const int c = cid(i, j, k); alphaf[d][f] = 0.5 * (alpha[c - stride[d]] + alpha[c]); }
+                else { const int c = cid(i, j, k); alphaf[d][f] = lerp(d, q, alpha[c - stride[d]], alpha[c]); }
             }
     }
 
@@ -214,10 +255,10 @@ struct Fv {
         for (int k = 0; k < nz; ++k) for (int j = 0; j < ny; ++j) for (int i = 0; i < nx; ++i) {
             double s = 0.0;
             for (int d = 0; d < 3; ++d) for (int sd = 0; sd < 2; ++sd) s += std::fabs(phi[d][cface(d, sd, i, j, k)]);
-            mx = std::max(mx, s / V); sum += s;
+            mx = std::max(mx, s / vol(i, j, k)); sum += s;
         }
         st.courant_max = 0.5 * mx * cs.dt;
-        st.courant_mean = 0.5 * (sum / (V * Nc)) * cs.dt;
+        st.courant_mean = 0.5 * (sum / (graded ? total_volume : V * Nc)) * cs.dt;
     }
 
     // pre-coupling fields, pimpleFoamYade.C:73-76: gradP = grad(p); divT = 2 nu laplacian(alphac, Uc); vGrad = grad(Uc)
@@ -235,10 +276,14 @@ struct Fv {
                 const double flux = (s ? 1.0 : -1.0) * phi[d][cface(d, s, i, j, k)];
                 double uf[3];
                 if (onb(d, s, i, j, k)) Ub(U, c, 2 * d + s, uf);
-                else { const int nb = c + (s ? stride[d] : -stride[d]); for (int q = 0; q < 3; ++q) uf[q] = 0.5 * (U[3 * (size_t)c + q] + U[3 * (size_t)nb + q]); }
+                else {
+                    const int nb = c + (s ? stride[d] : -stride[d]);
+                    for (int q = 0; q < 3; ++q) uf[q] = !graded ? 0.5 * (U[3 * (size_t)c + q] + U[3 * (size_t)nb + q])
+                                                      : (s ? lerp(d, fq(d, 1, i, j, k), U[3 * (size_t)c + q], U[3 * (size_t)nb + q]) : lerp(d, fq(d, 0, i, j, k), U[3 * (size_t)nb + q], U[3 * (size_t)c + q]));
+                }
                 for (int q = 0; q < 3; ++q) acc[q] += flux * uf[q];
             }
-            for (int q = 0; q < 3; ++q) ddtU[3 * (size_t)c + q] = acc[q] / V;
+            for (int q = 0; q < 3; ++q) ddtU[3 * (size_t)c + q] = acc[q] / vol(i, j, k);
         }
         grad_p(gradP);
         interp_alpha();                                     // alphac is 1 here (reset by setSourceZero), kept general
@@ -250,13 +295,13 @@ struct Fv {
                 const double af = alphaf[d][cface(d, s, i, j, k)];
                 if (onb(d, s, i, j, k)) {
                     double b[3]; Ub(U, c, 2 * d + s, b);
-                    for (int q = 0; q < 3; ++q) acc[q] += af * Af * (b[q] - U[3 * (size_t)c + q]) / (0.5 * dx);
+                    for (int q = 0; q < 3; ++q) acc[q] += graded ? af * sfd(d, s, i, j, k) * (b[q] - U[3 * (size_t)c + q]) : af * Af * (b[q] - U[3 * (size_t)c + q]) / (0.5 * dx);
                 } else {
                     const int nb = c + (s ? stride[d] : -stride[d]);
-                    for (int q = 0; q < 3; ++q) acc[q] += af * Af * (U[3 * (size_t)nb + q] - U[3 * (size_t)c + q]) / dx;
+                    for (int q = 0; q < 3; ++q) acc[q] += graded ? af * sfd(d, s, i, j, k) * (U[3 * (size_t)nb + q] - U[3 * (size_t)c + q]) : af * Af * (U[3 * (size_t)nb + q] - U[3 * (size_t)c + q]) / dx;
                 }
             }
-            for (int q = 0; q < 3; ++q) divT[3 * (size_t)c + q] = 2 * cs.nu * (acc[q] / V);
+            for (int q = 0; q < 3; ++q) divT[3 * (size_t)c + q] = 2 * cs.nu * (acc[q] / vol(i, j, k));
         }
     }
 
@@ -309,9 +354,15 @@ struct Fv {
                     double fv[2][3];
                     for (int s = 0; s < 2; ++s) {
                         if (onb(d, s, i, j, k)) for (int q = 0; q < 3; ++q) fv[s][q] = G[9 * (size_t)c + 3 * d + q];
-                        else { const int nb = c + (s ? stride[d] : -stride[d]); for (int q = 0; q < 3; ++q) fv[s][q] = 0.5 * (G[9 * (size_t)c + 3 * d + q] + G[9 * (size_t)nb + 3 * d + q]); }
+                        else {
+                            const int nb = c + (s ? stride[d] : -stride[d]);
+                            for (int q = 0; q < 3; ++q) {
+                                const double gc = G[9 * (size_t)c + 3 * d + q], gn = G[9 * (size_t)nb + 3 * d + q];
+                                fv[s][q] = !graded ? 0.5 * (gc + gn) : (s ? lerp(d, fq(d, 1, i, j, k), gc, gn) : lerp(d, fq(d, 0, i, j, k), gn, gc));
+                            }
+                        }
                     }
-                    for (int q = 0; q < 3; ++q) acc[q] += (fv[1][q] - fv[0][q]) / dx;
+                    for (int q = 0; q < 3; ++q) acc[q] += (fv[1][q] - fv[0][q]) / hcell(d, c);
                 }
                 for (int q = 0; q < 3; ++q) divG[3 * (size_t)c + q] = acc[q];
             }
@@ -320,32 +371,34 @@ struct Fv {
         for (int k = 0; k < nz; ++k) for (int j = 0; j < ny; ++j) for (int i = 0; i < nx; ++i) {
             const int c = cid(i, j, k);
             const double aP = pimple ? alpha[c] : 1.0, aP0 = pimple ? alphaOld[c] : 1.0;
-            double dg = aP * V / dt;                                         // fvm::ddt
+            const double Vc = vol(i, j, k);
+            double dg = aP * Vc / dt;                                        // fvm::ddt
             double s3[3];
-            for (int q = 0; q < 3; ++q) s3[q] = aP0 * V * Uold[3 * (size_t)c + q] / dt;
+            for (int q = 0; q < 3; ++q) s3[q] = aP0 * Vc * Uold[3 * (size_t)c + q] / dt;
             double divAPhi = 0.0;
             for (int d = 0; d < 3; ++d) for (int s = 0; s < 2; ++s) {
                 const int f = cface(d, s, i, j, k);
                 const double af = pimple ? alphaf[d][f] : 1.0;
                 const double phio = (s ? 1.0 : -1.0) * af * phi[d][f];       // outward (alpha-weighted) flux
                 divAPhi += phio;
-                double gam = nu * af * dx;                                   // (alpha nu)_f |Sf| / |d|
+                const double geo = sfd(d, s, i, j, k);                       // |Sf| / |d| (uniform block: dx, the boundary's factor 2 is bfac())
+                double gam = nu * af * geo;                                  // (alpha nu)_f |Sf| / |d|
                 if (!nut.empty()) {
                     // - fvm::laplacian(alpha nuEff, U) [OF-6 linearViscousStress::divDevRhoReff]: the cell field alpha (nu + nut) is interpolated
                     // linearly to the faces (gaussLaplacianScheme::fvmLaplacian(vol gamma)); boundary value alpha_b (nu + nut_b) with nut_b by 0/nut
                     if (onb(d, s, i, j, k)) {
                         const double nb = nut_boundary(2 * d + s, c);
-                        gam = (af * (nu + nb)) * dx;
+                        gam = (af * (nu + nb)) * geo;
                     } else {
                         const int nbc = c + (s ? stride[d] : -stride[d]);
-                        gam = (0.5 * ((aP * (nu + nut[c])) + (alpha[nbc] * (nu + nut[nbc])))) * dx;
+                        gam = (0.5 * ((aP * (nu + nut[c])) + (alpha[nbc] * (nu + nut[nbc])))) * geo;
                     }
                 }
                 if (onb(d, s, i, j, k)) {
                     an[2 * d + s][c] = 0.0;
                     const int patch = 2 * d + s;
                     if (cs.u_bc[patch] == 0) {                               // fixedValue
-                        const double gb = 2.0 * gam;
+                        const double gb = bfac() * gam;
                         dg += gb;
                         for (int q = 0; q < 3; ++q) s3[q] += (-phio + gb) * cs.u_value[patch][q];
                     } else {                                                 // zeroGradient
@@ -353,8 +406,10 @@ struct Fv {
                     }
                 } else {
                     const bool up = cs.convection_scheme != 0;               // 1 upwind, 2 linearUpwind (implicit part = upwind)
-                    const double cP = up ? std::max(phio, 0.0) : 0.5 * phio;
-                    const double cN = up ? std::min(phio, 0.0) : 0.5 * phio;
+                    // Gauss linear: the face value is w_P U_P + (1 - w_P) U_N with the linear weights of the (graded) block
+                    const double wP = !graded ? 0.5 : (s ? wlow(d, fq(d, 1, i, j, k)) : 1.0 - wlow(d, fq(d, 0, i, j, k)));
+                    const double cP = up ? std::max(phio, 0.0) : wP * phio;
+                    const double cN = up ? std::min(phio, 0.0) : (!graded ? 0.5 * phio : (1.0 - wP) * phio);
                     dg += cP + gam;
                     an[2 * d + s][c] = cN - gam;
                     if (cs.convection_scheme == 2) {
@@ -368,13 +423,13 @@ struct Fv {
                 }
             }
             if (pimple) {
-                const double S = (alpha[c] - alphaOld[c]) / dt + divAPhi / V;   // fvc::ddt(alphac) + fvc::div(alphaPhic)
+                const double S = (alpha[c] - alphaOld[c]) / dt + divAPhi / Vc;  // fvc::ddt(alphac) + fvc::div(alphaPhic)
                 Sc[c] = S;
-                dg -= V * S;                                                 // - fvm::Sp(S, Uc)
-                dg -= V * uSourceDrag[c];                                    // == fvm::Sp(uSourceDrag, Uc)
-                for (int q = 0; q < 3; ++q) s3[q] += V * divG[3 * (size_t)c + q];
+                dg -= Vc * S;                                                // - fvm::Sp(S, Uc)
+                dg -= Vc * uSourceDrag[c];                                   // == fvm::Sp(uSourceDrag, Uc)
+                for (int q = 0; q < 3; ++q) s3[q] += Vc * divG[3 * (size_t)c + q];
             } else {
-                for (int q = 0; q < 3; ++q) s3[q] += V * uSource[3 * (size_t)c + q];   // == uSource
+                for (int q = 0; q < 3; ++q) s3[q] += Vc * uSource[3 * (size_t)c + q];  // == uSource
             }
             if (pimple && u_relax_now > 0) {
                 // fvMatrix::relax(alpha) [OF-6 fvMatrix.C]: the boundary coefficients join the diagonal for the dominance test (they are
@@ -387,7 +442,7 @@ struct Fv {
             }
             diag[c] = dg;
             for (int q = 0; q < 3; ++q) src[3 * (size_t)c + q] = s3[q];
-            rAU[c] = 1.0 / (dg / V);                                         // 1/UEqn.A()
+            rAU[c] = 1.0 / (dg / Vc);                                        // 1/UEqn.A()
         }
     }
 
@@ -463,7 +518,7 @@ struct Fv {
                 const int nb = c + (s ? stride[d] : -stride[d]); const double a = an[2 * d + s][c];
                 for (int q = 0; q < 3; ++q) acc[q] -= a * U[3 * (size_t)nb + q];
             }
-            for (int q = 0; q < 3; ++q) HbyA[3 * (size_t)c + q] = rAU[c] * (acc[q] / V);
+            for (int q = 0; q < 3; ++q) HbyA[3 * (size_t)c + q] = rAU[c] * (acc[q] / vol(i, j, k));
         }
     }
 
@@ -475,7 +530,7 @@ struct Fv {
                 const int f = fid(d, i, j, k);
                 if (q == 0) rAUf[d][f] = rAU[cid(i, j, k)];
                 else if (q == n[d]) rAUf[d][f] = rAU[cid(i - (d == 0), j - (d == 1), k - (d == 2))];
-                else { const int c = cid(i, j, k); rAUf[d][f] = 0.5 * (rAU[c - stride[d]] + rAU[c]); }
+                else { const int c = cid(i, j, k); rAUf[d][f] = lerp(d, q, rAU[c - stride[d]], rAU[c]); }
             }
     }
 
@@ -486,8 +541,9 @@ struct Fv {
                 const int q = d == 0 ? i : d == 1 ? j : k;
                 const int f = fid(d, i, j, k);
                 double fl = 0.0;
-                if (q != 0 && q != n[d]) { const int c = cid(i, j, k), cm = c - stride[d]; fl = 0.5 * (rAU[cm] * uSource[3 * (size_t)cm + d] + rAU[c] * uSource[3 * (size_t)c + d]) * Af; }
-                phiForces[d][f] = fl + rAUf[d][f] * (cs.g[d] * Af);
+                const double Afc = area(d, i, j, k);
+                if (q != 0 && q != n[d]) { const int c = cid(i, j, k), cm = c - stride[d]; fl = lerp(d, q, rAU[cm] * uSource[3 * (size_t)cm + d], rAU[c] * uSource[3 * (size_t)c + d]) * Afc; }
+                phiForces[d][f] = fl + rAUf[d][f] * (cs.g[d] * Afc);
             }
     }
 
@@ -502,9 +558,10 @@ struct Fv {
                 const int f = fid(d, i, j, k);
                 double uf;   // (Sf & U.oldTime()_f)
                 bool fixes = false;
-                if (q == 0) { const int patch = 2 * d; fixes = cs.u_bc[patch] == 0; double b[3]; Ub(Uold, cid(i, j, k), patch, b); uf = b[d] * Af; }
-                else if (q == n[d]) { const int patch = 2 * d + 1; fixes = cs.u_bc[patch] == 0; double b[3]; Ub(Uold, cid(i - (d == 0), j - (d == 1), k - (d == 2)), patch, b); uf = b[d] * Af; }
-                else { const int c = cid(i, j, k); uf = 0.5 * (Uold[3 * (size_t)(c - stride[d]) + d] + Uold[3 * (size_t)c + d]) * Af; }
+                const double Afc = area(d, i, j, k);
+                if (q == 0) { const int patch = 2 * d; fixes = cs.u_bc[patch] == 0; double b[3]; Ub(Uold, cid(i, j, k), patch, b); uf = b[d] * Afc; }
+                else if (q == n[d]) { const int patch = 2 * d + 1; fixes = cs.u_bc[patch] == 0; double b[3]; Ub(Uold, cid(i - (d == 0), j - (d == 1), k - (d == 2)), patch, b); uf = b[d] * Afc; }
+                else { const int c = cid(i, j, k); uf = lerp(d, q, Uold[3 * (size_t)(c - stride[d]) + d], Uold[3 * (size_t)c + d]) * Afc; }
                 const double phiCorr = phiOld[d][f] - uf;
                 // EulerDdtScheme::fvcDdtPhiCoeff: 1 - min(|phiCorr| / (|phi| + small), 1); 0 where U fixes the value
                 double coef = fixes ? 0.0 : 1.0 - std::min(std::fabs(phiCorr) / (std::fabs(phiOld[d][f]) + SMALL), 1.0);
@@ -563,8 +620,9 @@ struct Fv {
                 const int f = fid(d, i, j, k);
                 const int c = cid(i - (d == 0 && s), j - (d == 1 && s), k - (d == 2 && s));
                 double ub[3]; Ub(U, c, patch, ub);
-                const double target = ub[d] * Af;
-                psn[d][f] = (phiHbyA[d][f] - target) / (rAUf[d][f] * Af);     // d p / d axis at the face
+                const double Afc = area(d, i, j, k);
+                const double target = ub[d] * Afc;
+                psn[d][f] = (phiHbyA[d][f] - target) / (rAUf[d][f] * Afc);    // d p / d axis at the face
             }
         }
     }
@@ -580,19 +638,19 @@ struct Fv {
                 const double af = pimple ? alphaf[d][f] : 1.0;
                 double ph = (s ? 1.0 : -1.0) * af * phiHbyA[d][f];
                 if (onb(d, s, i, j, k) && cs.p_bc[2 * d + s] == 2)           // fixed-gradient source of the laplacian
-                    ph = (s ? 1.0 : -1.0) * af * (phiHbyA[d][f] - rAUf[d][f] * Af * psn[d][f]);
+                    ph = (s ? 1.0 : -1.0) * af * (phiHbyA[d][f] - rAUf[d][f] * area(d, i, j, k) * psn[d][f]);
                 rhs -= ph;
                 if (onb(d, s, i, j, k)) {
                     const int patch = 2 * d + s;
-                    if (cs.p_bc[patch] == 1) { const double gb = 2.0 * af * rAUf[d][f] * dx; dg += gb; rhs += gb * cs.p_value[patch]; }
+                    if (cs.p_bc[patch] == 1) { const double gb = bfac() * af * rAUf[d][f] * sfd(d, s, i, j, k); dg += gb; rhs += gb * cs.p_value[patch]; }
                     if (s) (d == 0 ? L.ux : d == 1 ? L.uy : L.uz)[c] = 0.0;
                 } else {
-                    const double g = af * rAUf[d][f] * dx;
+                    const double g = af * rAUf[d][f] * sfd(d, s, i, j, k);
                     dg += g;
                     if (s) (d == 0 ? L.ux : d == 1 ? L.uy : L.uz)[c] = g;
                 }
             }
-            if (pimple) rhs -= V * (alpha[c] - alphaOld[c]) / cs.dt;          // fvc::ddt(alphac), pEqn.H:30
+            if (pimple) rhs -= vol(i, j, k) * (alpha[c] - alphaOld[c]) / cs.dt;  // fvc::ddt(alphac), pEqn.H:30
             L.diag[c] = dg; pb[c] = rhs;
         }
         if (need_reference()) {                                              // fvMatrix::setReference
@@ -794,11 +852,13 @@ struct Fv {
                 if (q == 0 || q == n[d]) {
                     const int s = q == 0 ? 0 : 1, patch = 2 * d + s;
                     const int c = cid(i - (d == 0 && s), j - (d == 1 && s), k - (d == 2 && s));
-                    if (cs.p_bc[patch] == 1) { const double gb = 2.0 * af * rAUf[d][f] * dx; fl = s ? gb * (cs.p_value[patch] - p[c]) : gb * (p[c] - cs.p_value[patch]); }
-                    else if (cs.p_bc[patch] == 2) fl = af * rAUf[d][f] * Af * psn[d][f];
+                    const double geo = graded ? area(d, i, j, k) / delta(d, q) : dx;
+                    if (cs.p_bc[patch] == 1) { const double gb = bfac() * af * rAUf[d][f] * geo; fl = s ? gb * (cs.p_value[patch] - p[c]) : gb * (p[c] - cs.p_value[patch]); }
+                    else if (cs.p_bc[patch] == 2) fl = af * rAUf[d][f] * area(d, i, j, k) * psn[d][f];
                 } else {
                     const int c = cid(i, j, k);
-                    fl = af * rAUf[d][f] * dx * (p[c] - p[c - stride[d]]);
+                    const double geo = graded ? area(d, i, j, k) / delta(d, q) : dx;
+                    fl = af * rAUf[d][f] * geo * (p[c] - p[c - stride[d]]);
                 }
                 pflux[d][f] = fl;
             }
@@ -810,11 +870,12 @@ struct Fv {
             const int c = cid(i, j, k);
             double dv = 0;
             for (int d = 0; d < 3; ++d) for (int s = 0; s < 2; ++s) { const int f = cface(d, s, i, j, k); dv += (s ? 1.0 : -1.0) * (pimple ? alphaf[d][f] : 1.0) * phi[d][f]; }
-            double ce = dv / V;
+            const double Vc = vol(i, j, k);
+            double ce = dv / Vc;
             if (pimple) ce += (alpha[c] - alphaOld[c]) / cs.dt;
-            sl += std::fabs(ce) * V; gl += ce * V;
+            sl += std::fabs(ce) * Vc; gl += ce * Vc;
         }
-        const double tv = V * Nc;
+        const double tv = graded ? total_volume : V * Nc;
         st.cont_sum_local = cs.dt * sl / tv; st.cont_global = cs.dt * gl / tv;
         cumulativeContErr += st.cont_global; st.cont_cumulative = cumulativeContErr;
     }
@@ -851,7 +912,7 @@ struct Fv {
                 for (int d = 0; d < 3; ++d) {
                     double sm = 0;
                     for (int s = 0; s < 2; ++s) { const int f = cface(d, s, i, j, k); sm += (phiForces[d][f] - pflux[d][f] / alphaf[d][f]) / rAUf[d][f]; }
-                    U[3 * (size_t)c + d] = HbyA[3 * (size_t)c + d] + rAU[c] * (sm / (2.0 * Af));
+                    U[3 * (size_t)c + d] = HbyA[3 * (size_t)c + d] + rAU[c] * (sm / (2.0 * area(d, i, j, k)));
                 }
             }
         }
@@ -892,7 +953,7 @@ struct Fv {
             if (cs.momentum_predictor) {
                 if (!pimple) {                                               // solve(UEqn == -fvc::grad(p)), icoFoamYade.C:91-94
                     grad_p(gradP);
-                    for (int c = 0; c < Nc; ++c) for (int q = 0; q < 3; ++q) bmom[3 * (size_t)c + q] = src[3 * (size_t)c + q] - V * gradP[3 * (size_t)c + q];
+                    for (int c = 0; c < Nc; ++c) for (int q = 0; q < 3; ++q) bmom[3 * (size_t)c + q] = src[3 * (size_t)c + q] - volc(c) * gradP[3 * (size_t)c + q];
                 } else {                                                     // UcEqn.H:22-33
                     for (int k = 0; k < nz; ++k) for (int j = 0; j < ny; ++j) for (int i = 0; i < nx; ++i) {
                         const int c = cid(i, j, k);
@@ -901,11 +962,12 @@ struct Fv {
                             for (int s = 0; s < 2; ++s) {
                                 const int f = cface(d, s, i, j, k);
                                 double sng;   // snGrad(p) along +axis
-                                if (onb(d, s, i, j, k)) { const double pbd = pbv(c, d, s, f); sng = s ? (pbd - p[c]) / (0.5 * dx) : (p[c] - pbd) / (0.5 * dx); }
-                                else sng = s ? (p[c + stride[d]] - p[c]) / dx : (p[c] - p[c - stride[d]]) / dx;
-                                sm += phiForces[d][f] / rAUf[d][f] - sng * Af;
+                                const double dl = delta(d, fq(d, s, i, j, k));
+                                if (onb(d, s, i, j, k)) { const double pbd = pbv(c, d, s, f); sng = s ? (pbd - p[c]) / dl : (p[c] - pbd) / dl; }
+                                else sng = s ? (p[c + stride[d]] - p[c]) / dl : (p[c] - p[c - stride[d]]) / dl;
+                                sm += phiForces[d][f] / rAUf[d][f] - sng * area(d, i, j, k);
                             }
-                            bmom[3 * (size_t)c + d] = src[3 * (size_t)c + d] + V * (sm / (2.0 * Af));
+                            bmom[3 * (size_t)c + d] = src[3 * (size_t)c + d] + vol(i, j, k) * (sm / (2.0 * area(d, i, j, k)));
                         }
                     }
                 }
@@ -1070,7 +1132,12 @@ struct Fv {
 
 extern "C" {
 
-void* orc_fv_create(const orc_fv_case* c) { Fv* f = new Fv(); f->init(*c); return f; }
+void* orc_fv_create(const orc_fv_case* c) {
+    // a graded block carries the laminar operators with Gauss linear / upwind convection only (the closures' delta, wall distance and the
+    // linearUpwind correction assume uniform cubes)
+    if (c->hx && (c->turbulence_model != 0 || c->convection_scheme == 2)) return nullptr;
+    Fv* f = new Fv(); f->init(*c); return f;
+}
 void orc_fv_destroy(void* h) { delete (Fv*)h; }
 void orc_fv_turbulence_correct(void* h) { Fv* f = (Fv*)h; if (!f->nut.empty()) f->turbulence_correct(); }
 void orc_fv_set_threads(void* h, int t) { ((Fv*)h)->threads = t < 1 ? 1 : t; }

@@ -139,6 +139,26 @@ class Mesh:
         self.pre = build_tree(self.C) if pre is None else np.ascontiguousarray(pre, dtype=np.int32)
 
 
+def graded_block_geometry(grading, origin=(0.0, 0.0, 0.0)):
+    """cell centres, volumes, face coordinates of a rectilinear block whose cell sizes along x, y, z are `grading` = (hx, hy, hz), blockMesh order"""
+    hx, hy, hz = (np.asarray(a, dtype=np.float64) for a in grading)
+    xf, yf, zf = (o + np.concatenate([[0.0], np.cumsum(h)]) for o, h in zip(origin, (hx, hy, hz)))
+    xc, yc, zc = 0.5 * (xf[1:] + xf[:-1]), 0.5 * (yf[1:] + yf[:-1]), 0.5 * (zf[1:] + zf[:-1])
+    nx, ny, nz = hx.size, hy.size, hz.size
+    Cc = np.empty((nz, ny, nx, 3))
+    Cc[..., 0] = xc[None, None, :]; Cc[..., 1] = yc[None, :, None]; Cc[..., 2] = zc[:, None, None]
+    V = (hz[:, None, None] * hy[None, :, None]) * hx[None, None, :]
+    return Cc.reshape(-1, 3), V.reshape(-1), (xf, yf, zf)
+
+
+def graded_mesh(grading, origin=(0.0, 0.0, 0.0)):
+    Cc, V, (xf, yf, zf) = graded_block_geometry(grading, origin)
+    m = Mesh(len(grading[0]), len(grading[1]), len(grading[2]), float(np.cbrt(V[0])), origin, centres=Cc, volumes=V,
+             bbmin=(xf[0], yf[0], zf[0]), bbmax=(xf[-1], yf[-1], zf[-1]))
+    m.faces = (xf, yf, zf)
+    return m
+
+
 FORCE_ADDED_MASS, FORCE_GAUSSIAN_TORQUE = 1, 2
 
 
@@ -228,7 +248,8 @@ class FvCase(C.Structure):
                 ("ras_cmu", C.c_double), ("ras_c1", C.c_double), ("ras_c2", C.c_double), ("ras_c3", C.c_double), ("ras_sigmak", C.c_double),
                 ("ras_sigmaeps", C.c_double), ("eps_bc", C.c_int * 6), ("eps_value", C.c_double * 6), ("eps_initial", C.c_double),
                 ("eps_convection_scheme", C.c_int), ("eps_tol", C.c_double), ("eps_rel_tol", C.c_double), ("eps_max_iter", C.c_int),
-                ("eps_relax", C.c_double), ("wf_kappa", C.c_double), ("wf_E", C.c_double)]
+                ("eps_relax", C.c_double), ("wf_kappa", C.c_double), ("wf_E", C.c_double),
+                ("hx", _dp), ("hy", _dp), ("hz", _dp)]
 
 
 class FvStats(C.Structure):
@@ -250,7 +271,7 @@ def fv_case(solver, nx, ny, nz, dx, dt, nu, rho_f=1000.0, rho_p=2650.0, g=(0, 0,
             p_relax_final=0.0, turbulence_model=0, les_ck=0.094, les_ce=1.048, les_delta_coeff=1.0, nut_bc=None, nut_value=None, nut_initial=0.0,
             k_bc=None, k_value=None, k_initial=0.0, k_convection_scheme=1, k_tol=1e-6, k_rel_tol=0.0, k_max_iter=1000, k_relax=0.0,
             ras_cmu=0.09, ras_c1=1.44, ras_c2=1.92, ras_c3=0.0, ras_sigmak=1.0, ras_sigmaeps=1.3, eps_bc=None, eps_value=None, eps_initial=0.0,
-            eps_convection_scheme=1, eps_tol=1e-6, eps_rel_tol=0.0, eps_max_iter=1000, eps_relax=0.0, wf_kappa=0.41, wf_E=9.8):
+            eps_convection_scheme=1, eps_tol=1e-6, eps_rel_tol=0.0, eps_max_iter=1000, eps_relax=0.0, wf_kappa=0.41, wf_E=9.8, grading=None):
     """documented defaults = the icoFoam cavity / DPMFoam tutorial settings of SURVEY.md Appendix C"""
     c = FvCase()
     c.solver, c.nx, c.ny, c.nz, c.dx, c.dt, c.nu = solver, nx, ny, nz, dx, dt, nu
@@ -288,6 +309,10 @@ def fv_case(solver, nx, ny, nz, dx, dt, nu, rho_f=1000.0, rho_p=2650.0, g=(0, 0,
         c.eps_value[q] = (eps_value or [0.0] * 6)[q]
     c.eps_initial, c.eps_convection_scheme, c.eps_tol, c.eps_rel_tol, c.eps_max_iter, c.eps_relax = eps_initial, int(eps_convection_scheme), eps_tol, eps_rel_tol, int(eps_max_iter), eps_relax
     c.wf_kappa, c.wf_E = wf_kappa, wf_E
+    if grading is not None:                      # (hx, hy, hz): cell sizes along the axes of a graded block (kept alive on the case object)
+        c._grading = [np.ascontiguousarray(a, dtype=np.float64) for a in grading]
+        assert [a.size for a in c._grading] == [nx, ny, nz]
+        c.hx, c.hy, c.hz = (_d(a) for a in c._grading)
     return c
 
 
@@ -325,6 +350,8 @@ class FvSolver:
         self.case = case
         self.L = _fv_lib()
         self.h = self.L.orc_fv_create(C.byref(case))
+        if not self.h:
+            raise ValueError("oracle: this case is outside what the restatement carries (graded block with a turbulence model or linearUpwind)")
         self.L.orc_fv_set_threads(self.h, threads)
         self.Nc = case.nx * case.ny * case.nz
         self.gaussian = case.solver == 1
@@ -362,7 +389,11 @@ class FvSolver:
         if records is not None:
             c = self.case
             if self.mesh is None:
-                self.mesh = Mesh(c.nx, c.ny, c.nz, c.dx, tuple(c.origin))
+                g = getattr(c, "_grading", None)
+                if g is None:
+                    self.mesh = Mesh(c.nx, c.ny, c.nz, c.dx, tuple(c.origin))
+                else:
+                    self.mesh = graded_mesh(g, tuple(c.origin))
             fields = dict(U=self.view("U").reshape(-1, 3), gradP=self.view("gradP").reshape(-1, 3),
                           vGrad=self.view("vGrad").reshape(-1, 9), divT=self.view("divT").reshape(-1, 3),
                           ddtU=self.view("ddtU").reshape(-1, 3))

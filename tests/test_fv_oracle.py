@@ -547,3 +547,110 @@ def test_epsilon_wall_function_imposes_the_log_law_value(oracle):
     assert np.all(np.abs(interior - e0 / (1 + 1e-3 * 1.92 * e0 / k0)) < 1e-6 * e0)      # far from the walls: the homogeneous decay step
     assert wall_value > 5 * e0                                            # and next to the wall cells diffusion feeds it inwards
     assert eps[2, 1, 3] > eps[2, 3, 3]
+
+
+# ---- graded (rectilinear) single block: per-axis cell sizes, linear-interpolation weights != 1/2, |Sf|/|d| per face (blockMesh simpleGrading) ----
+def geometric_sizes(n, ratio, length=1.0):
+    """n cell sizes with the last/first ratio `ratio` (what simpleGrading's expansion ratio means), summing to `length`"""
+    r = ratio ** (1.0 / (n - 1)) if n > 1 else 1.0
+    h = r ** np.arange(n)
+    return h * (length / h.sum())
+
+
+def wall_refined_sizes(n, ratio, length=1.0):
+    """symmetric: fine at both walls, coarse in the middle (n even)"""
+    half = geometric_sizes(n // 2, ratio, 0.5 * length)
+    return np.concatenate([half, half[::-1]])
+
+
+def test_graded_path_with_uniform_sizes_equals_the_uniform_block(oracle):
+    """the general operators with every cell size equal to dx are the uniform block's operators: a cavity and a coupled pimple box agree to
+    rounding (the uniform path keeps its own expressions; this pins the two against each other)"""
+    n = 10
+    dx = 1.0 / n
+    h = np.full(n, dx)
+    for solver in (0, 1):
+        kw = dict(u_bc=[0] * 6, u_val=[(0, 0, 0)] * 3 + [(1.0, 0, 0)] + [(0, 0, 0)] * 2) if solver == 0 else dict(g=(0, 0, -9.81), p_bc=[orc.P_FIXEDFLUX] * 6)
+        a = orc.FvSolver(orc.fv_case(solver, n, n, n, dx, 0.02, 0.01, **kw))
+        b = orc.FvSolver(orc.fv_case(solver, n, n, n, dx, 0.02, 0.01, grading=(h, h, h), **kw))
+        rs = np.random.RandomState(4)
+        rec = np.zeros((300, 10)); rec[:, 0:3] = 0.1 + 0.8 * rs.random_sample((300, 3)); rec[:, 3:6] = 0.05 * rs.standard_normal((300, 3)); rec[:, 9] = 0.2 * dx
+        for _ in range(4):
+            fa = a.step(rec if solver else None); fb = b.step(rec if solver else None)
+        for nm in ("U", "p"):
+            x, y = a.get(nm), b.get(nm)
+            assert np.abs(x - y).max() <= 1e-9 * (np.abs(x).max() + 1e-300), nm
+        if solver:
+            assert np.abs(fa["force"] - fb["force"]).max() <= 1e-9 * np.abs(fa["force"]).max()
+        a.close(); b.close()
+
+
+def test_graded_couette_and_hydrostatics_are_exact(oracle):
+    """linear fields are reproduced exactly by linear interpolation on ANY rectilinear grading: Couette flow between graded walls, and a
+    quiescent box under gravity (fixedFluxPressure) stays at rest with a linear pressure"""
+    nx, ny = 5, 14
+    hy = wall_refined_sizes(ny, 6.0)
+    hx = geometric_sizes(nx, 2.5, 0.5)
+    hz = np.array([0.07])
+    u_bc = [orc.U_ZEROGRAD, orc.U_ZEROGRAD, orc.U_FIXED, orc.U_FIXED, orc.U_ZEROGRAD, orc.U_ZEROGRAD]
+    u_val = [(0, 0, 0)] * 6
+    u_val[orc.YMAX] = (1.0, 0, 0)
+    p_bc = [orc.P_FIXED, orc.P_FIXED, orc.P_ZEROGRAD, orc.P_ZEROGRAD, orc.P_ZEROGRAD, orc.P_ZEROGRAD]
+    s = orc.FvSolver(orc.fv_case(0, nx, ny, 1, 0.07, 0.05, 0.1, u_bc=u_bc, u_val=u_val, p_bc=p_bc, u_tol=1e-11, p_tol=1e-11, p_final_tol=1e-11, grading=(hx, hy, hz)))
+    for _ in range(400):
+        s.step()
+    yc = np.cumsum(hy) - 0.5 * hy
+    U = s.get("U").reshape(ny, nx, 3)
+    assert np.abs(U[:, :, 0] - yc[:, None]).max() < 1e-7 and np.abs(U[:, :, 1]).max() < 1e-8
+    s.close()
+    n = 8
+    hz3 = geometric_sizes(n, 4.0, 0.3)
+    hx3 = geometric_sizes(n, 0.5, 0.2)
+    hy3 = wall_refined_sizes(n, 3.0, 0.25)
+    s = orc.FvSolver(orc.fv_case(1, n, n, n, 0.03, 1e-3, 1e-6, g=(0, 0, -9.81), p_bc=[orc.P_FIXEDFLUX] * 6, p_tol=1e-11, p_final_tol=1e-11, p_rel_tol=0.0, grading=(hx3, hy3, hz3)))
+    for _ in range(3):
+        s.step()
+    assert np.abs(s.get("U")).max() < 1e-9
+    p = s.get("p").reshape(n, n, n)
+    zc = np.cumsum(hz3) - 0.5 * hz3
+    dpdz = np.diff(p, axis=0) / np.diff(zc)[:, None, None]
+    np.testing.assert_allclose(dpdz, -9.81, rtol=1e-7)
+    s.close()
+
+
+def test_graded_poiseuille_on_a_wall_refined_mesh(oracle):
+    """pressure-driven plane channel on meshes refined towards both walls (last/first size ratio 5): the parabola is approached at second
+    order in the mean cell size, and the discrete wall shear carries the driving force exactly"""
+    nu, G = 0.05, 0.4
+    errs, shear = {}, {}
+    u_bc = [orc.U_ZEROGRAD, orc.U_ZEROGRAD, orc.U_FIXED, orc.U_FIXED, orc.U_ZEROGRAD, orc.U_ZEROGRAD]
+    p_bc = [orc.P_FIXED, orc.P_FIXED, orc.P_ZEROGRAD, orc.P_ZEROGRAD, orc.P_ZEROGRAD, orc.P_ZEROGRAD]
+    for ny, ratio in ((12, 5.0), (24, 5.0), (24, 1.0)):
+        nx = 4
+        hy = wall_refined_sizes(ny, ratio)
+        hx = np.full(nx, 0.1)
+        L = hx.sum()
+        c = orc.fv_case(0, nx, ny, 1, 0.1, 0.02, nu, u_bc=u_bc, p_bc=p_bc, p_val=[G * L, 0.0, 0, 0, 0, 0], u_tol=1e-10, p_tol=1e-10, p_final_tol=1e-10, grading=(hx, hy, np.array([0.1])))
+        s = orc.FvSolver(c)
+        for _ in range(2500):
+            s.step()
+        U = s.get("U").reshape(ny, nx, 3)[:, nx // 2, 0]
+        yc = np.cumsum(hy) - 0.5 * hy
+        exact = G / (2 * nu) * yc * (1.0 - yc)
+        errs[(ny, ratio)] = np.abs(U - exact).max() / exact.max()
+        shear[(ny, ratio)] = abs(U[0] / yc[0] - G / (2 * nu)) / (G / (2 * nu))      # one-sided wall gradient vs du/dy(0) = G/(2 nu)
+        assert np.abs(s.get("U").reshape(ny, nx, 3)[:, :, 1]).max() < 1e-7
+        s.close()
+    assert errs[(24, 5.0)] < 0.35 * errs[(12, 5.0)], errs           # ~4x per halving
+    assert errs[(24, 5.0)] < 1e-2, errs                               # (coarser than the uniform mesh mid-channel, finer at the walls)
+    # the wall shear nu U_1 / (h_1 / 2) balances the pressure force on the half channel EXACTLY on every mesh (conservation: the finite
+    # volume statement of the momentum balance), whatever the interior error
+    assert max(shear.values()) < 1e-8, shear
+
+
+def test_graded_block_refuses_what_it_does_not_carry(oracle):
+    h = np.full(6, 1.0 / 6)
+    with pytest.raises(ValueError):
+        orc.FvSolver(orc.fv_case(1, 6, 6, 6, 1.0 / 6, 0.01, 0.01, turbulence_model=1, grading=(h, h, h)))
+    with pytest.raises(ValueError):
+        orc.FvSolver(orc.fv_case(0, 6, 6, 6, 1.0 / 6, 0.01, 0.01, convection_scheme=2, grading=(h, h, h)))
