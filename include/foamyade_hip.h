@@ -55,6 +55,10 @@ typedef struct fy_mesh_desc {
     int32_t nx, ny, nz;
     double dx;
     double origin[3];
+    /* A GRADED (rectilinear) block in the same cell order: coordinates of the nx + 1, ny + 1, nz + 1 face planes along the axes (HOST memory,
+     * copied at create); all NULL = the uniform block above.  With them findCell is a search along each axis, the k-d tree carries explicit
+     * node coordinates (the centres as given) and dx is unused. */
+    const double *xf, *yf, *zf;
 } fy_mesh_desc;
 
 /* ---- the twelve constructor arguments of Foam::FoamYade (FoamYade.H:106-117), minus mesh and the bool ---- */
@@ -261,6 +265,11 @@ typedef struct fy_case_desc {
        y+ = Cmu^1/4 y sqrt(k)/nu; in the wall cells eps = Cmu^3/4 k^3/2/(kappa y) is imposed on the epsilon equation and the production G is
        replaced by (1/W) sum (nut_w + nu) |snGrad U| Cmu^1/4 sqrt(k)/(kappa y).  Cmu is ras_cmu */
     double wf_kappa, wf_E;                       /* fy_case_defaults: 0.41, 9.8 */
+    /* A GRADED single block (blockMesh simpleGrading; icoFoamYade/createFields.H:15-162 and pimpleFoamYade/createFields.H:32-261 take any
+       fvMesh): cell sizes along x, y, z -- nx, ny, nz doubles each, copied at fy_solver_create; all three NULL (fy_case_defaults) = uniform
+       cubes of edge dx.  The block then starts at `origin`, dx is ignored.  Carried: the laminar operators with Gauss linear / upwind
+       convection, single domain; turbulence models, linearUpwind and z-slabs are refused on a graded block */
+    const double *hx, *hy, *hz;
 } fy_case_desc;
 
 typedef struct fy_solver fy_solver;

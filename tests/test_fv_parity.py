@@ -428,3 +428,104 @@ def test_kepsilon_with_wall_functions_matches_oracle(product, oracle):
         s2.set_particles(gc.particle_records(case, step))
         s2.step()
     assert np.abs(s2.get("k") - s.get("k")).max() > 1e-3 * np.abs(s.get("k")).max()
+
+
+# ---- graded (rectilinear) single block: the kernels of namespace fy::gr (fv_kernels.hip compiled with the general geometry) vs the oracle ----
+def geometric_sizes(n, ratio, length):
+    r = ratio ** (1.0 / (n - 1)) if n > 1 else 1.0
+    h = r ** np.arange(n)
+    return h * (length / h.sum())
+
+
+def wall_refined_sizes(n, ratio, length):
+    half = geometric_sizes(n // 2, ratio, 0.5 * length)
+    return np.concatenate([half, half[::-1]])
+
+
+@pytest.mark.parametrize("solver,p_solver,scheme", [(0, 1, 0), (0, 0, 1), (1, 1, 0)])
+def test_graded_cavity_steps_match_oracle(product, oracle, solver, p_solver, scheme):
+    """lid-driven cavity on a block refined towards all walls (size ratio 4 in x and y, 2.5 in z): matrices, fluxes and fields of the graded
+    kernels against the oracle's general operators, Gauss linear and Gauss upwind"""
+    n = 14
+    g = (wall_refined_sizes(n, 4.0, 1.0), wall_refined_sizes(n, 4.0, 1.0), wall_refined_sizes(n, 2.5, 0.8))
+    o, s = both(product, oracle, solver, n, n, n, 1.0 / n, 0.01, 0.01, p_solver=p_solver, convection_scheme=scheme, grading=g, **cavity_bcs())
+    for step in range(5):
+        o.step(); s.step()
+        so, ss = o.stats(), s.stats()
+        assert abs(so["p_iters_total"] - ss["p_iters_total"]) <= 2
+        assert np.isclose(so["courant_max"], ss["courant_max"], rtol=1e-6) and np.isclose(so["courant_mean"], ss["courant_mean"], rtol=1e-6)
+        if step == 0:
+            for nm in ("p_diag", "p_ux", "p_uy", "p_uz", "mom_diag", "rAU"):
+                np.testing.assert_allclose(s.get(nm), o.get(nm), rtol=1e-10, err_msg=nm)
+    compare(o, s)
+    assert ss["cont_err_sum_local"] < 1e-5 and np.abs(s.get("U")).max() > 0.05
+
+
+def test_graded_coupled_pimple_steps_match_oracle(product, oracle):
+    """pimpleFoamYade 4-way on a graded box under gravity: the particle half runs on the explicit k-d tree of the graded block's centres with
+    every cell's own volume, the FV half on the graded operators; forces and fields against the oracle over three coupled steps"""
+    n = 12
+    g = (geometric_sizes(n, 2.0, 0.1), wall_refined_sizes(n, 3.0, 0.1), geometric_sizes(n, 0.4, 0.12))
+    o, s = both(product, oracle, 1, n, n, n, 0.1 / n, 2e-4, 1e-5, g=(0, 0, -9.81), p_bc=[2] * 6, grading=g)
+    rs = np.random.RandomState(17)
+    npart = 2500
+    for step in range(3):
+        rec = np.zeros((npart, 10))
+        rec[:, 0:3] = rs.random_sample((npart, 3)) * np.array([0.1, 0.1, 0.07]) + np.array([0.0, 0.0, 0.005])
+        rec[:, 3:6] = 0.05 * rs.standard_normal((npart, 3))
+        rec[:, 9] = 0.2 * (0.1 / n)
+        fo = o.step(rec)["force"]
+        s.set_particles(rec); s.step()
+        sc = np.abs(fo).max()
+        assert sc > 0 and np.abs(s.forces() - fo).max() <= 1e-6 * sc, np.abs(s.forces() - fo).max() / sc
+    compare(o, s, rtol=1e-5)
+
+
+def test_graded_point_force_finds_cells_by_axis_search(product, oracle):
+    """icoFoamYade on a graded channel with particles: findCell on the graded block is a search along each axis (particles on face planes and on
+    the outer faces included); Stokes drag and the source field against closed forms on the host"""
+    nx, ny, nz = 16, 10, 6
+    g = (geometric_sizes(nx, 3.0, 0.4), wall_refined_sizes(ny, 4.0, 0.1), geometric_sizes(nz, 1.0, 0.06))
+    U_, ZG = product.FY_BC_U_FIXED_VALUE, product.FY_BC_U_ZERO_GRADIENT
+    PZ, PF = product.FY_BC_P_ZERO_GRADIENT, product.FY_BC_P_FIXED_VALUE
+    case = product.make_case(0, nx, ny, nz, 0.01, 1e-3, 1e-3, u_bc=[U_, ZG, U_, U_, U_, U_], u_val=[(0.5, 0, 0)] + [(0, 0, 0)] * 5, p_bc=[PZ, PF, PZ, PZ, PZ, PZ], grading=g)
+    s = product.Solver(case)
+    s.hold_sources(True)
+    faces = [np.concatenate([[0.0], np.cumsum(h)]) for h in g]
+    rs = np.random.RandomState(3)
+    npart = 4000
+    rec = np.zeros((npart, 10))
+    rec[:, 0:3] = rs.random_sample((npart, 3)) * np.array([0.4, 0.1, 0.06])
+    rec[:50, 0] = faces[0][rs.randint(0, nx + 1, 50)]                # exactly on x face planes (the outer ones too)
+    rec[50:100, 1] = faces[1][rs.randint(0, ny + 1, 50)]
+    rec[100:130, 2] = 0.0601                                         # outside: not found
+    rec[:, 3:6] = 0.1 * rs.standard_normal((npart, 3))
+    rec[:, 9] = 5e-4
+    for _ in range(2):
+        Ub = s.get("U").reshape(-1, 3)
+        s.set_particles(rec); s.step()
+    F, found = s.forces(), s.found()
+    hi = np.array([f[-1] for f in faces])                             # (the block ends where the summed sizes end, not at the nominal lengths)
+    inside = np.all((rec[:, 0:3] >= 0) & (rec[:, 0:3] <= hi), axis=1)
+    assert np.array_equal(found == 1, inside) and (~inside).sum() == 30
+    idx = [np.minimum(np.searchsorted(f, rec[:, a], side="right") - 1, n - 1) for a, (f, n) in enumerate(zip(faces, (nx, ny, nz)))]
+    cell = idx[0] + nx * (idx[1] + ny * idx[2])
+    Fref = (3 * np.pi * 2 * rec[:, 9] * 1e-3 * 1000.0)[:, None] * (Ub[np.where(inside, cell, 0)] - rec[:, 3:6])
+    Fref[~inside] = 0.0
+    np.testing.assert_allclose(F[:, :3], Fref, rtol=1e-12, atol=1e-14 * np.abs(Fref).max())
+    V = ((g[2][:, None, None] * g[1][None, :, None]) * g[0][None, None, :]).reshape(-1)
+    uS = s.get("uSource").reshape(-1, 3)
+    for a in range(3):
+        ref = -np.bincount(cell[inside], weights=Fref[inside, a], minlength=V.size) / (V * 1000.0)
+        np.testing.assert_allclose(uS[:, a], ref, rtol=1e-10, atol=1e-12 * np.abs(ref).max())
+    s.close()
+
+
+def test_graded_block_refusals(product):
+    h = np.full(8, 0.125)
+    for kw, msg in ((dict(turbulence_model=1, nut_initial=1e-5), "turbulence"), (dict(convection_scheme=2), "linearUpwind")):
+        c = product.make_case(1 if "turbulence_model" in kw else 0, 8, 8, 8, 0.125, 1e-3, 1e-3, grading=(h, h, h), **kw)
+        with pytest.raises(product.FoamYadeError, match=msg):
+            product.Solver(c)
+    with pytest.raises(product.FoamYadeError, match="z-slabs"):
+        product.VirtualSlabs(product.make_case(0, 8, 8, 8, 0.125, 1e-3, 1e-3, grading=(h, h, h)), 2)

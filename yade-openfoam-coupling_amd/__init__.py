@@ -53,7 +53,7 @@ def build(verbose=False):
 class MeshDesc(C.Structure):
     _fields_ = [("n_cells", C.c_int32), ("centres", _dp), ("volumes", _dp), ("bbox_min", C.c_double * 3),
                 ("bbox_max", C.c_double * 3), ("nx", C.c_int32), ("ny", C.c_int32), ("nz", C.c_int32), ("dx", C.c_double),
-                ("origin", C.c_double * 3)]
+                ("origin", C.c_double * 3), ("xf", _dp), ("yf", _dp), ("zf", _dp)]
 
 
 class FieldPtrs(C.Structure):
@@ -100,7 +100,8 @@ class CaseDesc(C.Structure):
                 ("ras_cmu", C.c_double), ("ras_c1", C.c_double), ("ras_c2", C.c_double), ("ras_c3", C.c_double), ("ras_sigmak", C.c_double),
                 ("ras_sigmaeps", C.c_double), ("eps_bc", C.c_int32 * 6), ("eps_value", C.c_double * 6), ("eps_initial", C.c_double),
                 ("eps_convection_scheme", C.c_int32), ("eps_tol", C.c_double), ("eps_rel_tol", C.c_double), ("eps_max_iter", C.c_int32),
-                ("eps_relax", C.c_double), ("wf_kappa", C.c_double), ("wf_E", C.c_double)]
+                ("eps_relax", C.c_double), ("wf_kappa", C.c_double), ("wf_E", C.c_double),
+                ("hx", C.POINTER(C.c_double)), ("hy", C.POINTER(C.c_double)), ("hz", C.POINTER(C.c_double))]
 
 
 BC_WALL_FUNCTION, BC_NUT_CALCULATED = 2, 3
@@ -321,6 +322,31 @@ class GeneralMesh:
         return m
 
 
+class GradedBlockMesh(GeneralMesh):
+    """a graded (rectilinear) block in blockMesh cell order: cell sizes hx, hy, hz along the axes (fy_mesh_desc with nx, ny, nz AND the face planes
+    xf, yf, zf): explicit k-d tree over the centres, findCell by a search along each axis -- so the point-force mode works on it too"""
+
+    def __init__(self, hx, hy, hz, origin=(0.0, 0.0, 0.0)):
+        h = [np.ascontiguousarray(a, dtype=np.float64) for a in (hx, hy, hz)]
+        self.faces = [np.ascontiguousarray(o + np.concatenate([[0.0], np.cumsum(a)])) for o, a in zip(origin, h)]
+        xc, yc, zc = (0.5 * (f[1:] + f[:-1]) for f in self.faces)
+        self.nx, self.ny, self.nz = (a.size for a in h)
+        Cc = np.empty((self.nz, self.ny, self.nx, 3))
+        Cc[..., 0] = xc[None, None, :]; Cc[..., 1] = yc[None, :, None]; Cc[..., 2] = zc[:, None, None]
+        V = (h[2][:, None, None] * h[1][None, :, None]) * h[0][None, None, :]
+        super().__init__(Cc.reshape(-1, 3), V.reshape(-1), [f[0] for f in self.faces], [f[-1] for f in self.faces])
+        self.origin = tuple(float(o) for o in origin)
+
+    def desc(self):
+        m = super().desc()
+        m.nx, m.ny, m.nz = self.nx, self.ny, self.nz
+        m.dx = float(np.cbrt(self.V[0]))
+        for q in range(3):
+            m.origin[q] = self.origin[q]
+        m.xf, m.yf, m.zf = (_d(f) for f in self.faces)
+        return m
+
+
 class FoamYade:
     """Foam::FoamYade (FoamYade.H:57-161) over the C-ABI.  Field arguments are numpy arrays (host; staged per step) that
     stay owned by the caller, exactly like the reference's field references."""
@@ -481,8 +507,13 @@ def case_defaults(solver):
 
 
 def make_case(solver, nx, ny, nz, dx, dt, nu, rho_f=1000.0, rho_p=2650.0, g=(0, 0, 0), u_bc=None, u_val=None, p_bc=None,
-              p_val=None, origin=(0, 0, 0), **kw):
+              p_val=None, origin=(0, 0, 0), grading=None, **kw):
+    """grading = (hx, hy, hz): cell sizes along the axes of a graded block (fy_case_desc.hx / hy / hz); dx is then ignored"""
     c = case_defaults(solver)
+    if grading is not None:
+        c._grading = [np.ascontiguousarray(a, dtype=np.float64) for a in grading]      # kept alive on the case object
+        assert [a.size for a in c._grading] == [nx, ny, nz]
+        c.hx, c.hy, c.hz = (a.ctypes.data_as(C.POINTER(C.c_double)) for a in c._grading)
     c.nx, c.ny, c.nz, c.dx, c.dt, c.nu, c.rho_fluid, c.rho_particle = nx, ny, nz, dx, dt, nu, rho_f, rho_p
     for q in range(3):
         c.g[q] = g[q]

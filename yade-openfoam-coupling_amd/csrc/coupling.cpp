@@ -63,10 +63,11 @@ int Coupling::create(const fy_mesh_desc* m, const fy_field_ptrs* f, int gaussian
     if (ext_stream) { stream = ext_stream; owns_stream = false; }
     else { FY_HIP(hipStreamCreate(&stream)); owns_stream = true; }
     mesh = *m;
-    mesh.centres = nullptr; mesh.volumes = nullptr;   // not retained
+    mesh.centres = nullptr; mesh.volumes = nullptr; mesh.xf = mesh.yf = mesh.zf = nullptr;   // not retained
     n_cells = m->n_cells;
     gaussian = gaussian_interp != 0;
     structured = m->nx > 0;
+    rectilinear = structured && m->xf && m->yf && m->zf;          // graded block: lattice INDEXING, but no lattice of centres
     if (!gaussian && !structured) return fail(FY_ERR_UNSUPPORTED, "point-force mode needs the structured block description (findCell stand-in)");
     if (structured && (int64_t)m->nx * m->ny * m->nz != m->n_cells) return fail(FY_ERR_INVALID, "nx*ny*nz != n_cells");
     if (tr) { transport = *tr; has_transport = true; }
@@ -88,7 +89,7 @@ int Coupling::create(const fy_mesh_desc* m, const fy_field_ptrs* f, int gaussian
     {
         // implicit-coordinate nodes: legal only if EVERY centre equals origin + (i + 0.5) * dx bit for bit (checked here, so a
         // real OpenFOAM mesh whose centres come from pyramid decomposition simply keeps the explicit path)
-        bool exact = structured && !options().explicit_tree && m->nx <= 1024 && m->ny <= 1024 && m->nz <= 4096 &&
+        bool exact = structured && !rectilinear && !options().explicit_tree && m->nx <= 1024 && m->ny <= 1024 && m->nz <= 4096 &&
                      n_cells < (1 << 25);
         if (exact)
             for (int k = 0; k < m->nz && exact; ++k) for (int j = 0; j < m->ny && exact; ++j) for (int i = 0; i < m->nx; ++i) {
@@ -199,7 +200,7 @@ int Coupling::create(const fy_mesh_desc* m, const fy_field_ptrs* f, int gaussian
     n_field = slab.active ? (int64_t)slab.n_store : (int64_t)n_cells;
     FY_TRY(d_vol.alloc_exact((size_t)n_field));
     if (slab.active) {
-        if (!structured) return fail(FY_ERR_UNSUPPORTED, "slab mode needs the structured block description");
+        if (!structured || rectilinear) return fail(FY_ERR_UNSUPPORTED, "slab mode needs the uniform structured block description");
         FY_TRY(launch_fill_f64(stream, d_vol.p, (size_t)n_field, v0));        // uniform block
         FY_TRY(halo_tmp.alloc_exact(2 * (size_t)slab.gz * slab.plane * 4));   // both directions x (1 + 3) components of a grouped reverse sum
     } else {
@@ -243,7 +244,7 @@ int Coupling::create(const fy_mesh_desc* m, const fy_field_ptrs* f, int gaussian
 
     // ---- binning grid (locality only)
     {
-        const double h0 = structured ? m->dx : std::cbrt(v0);
+        const double h0 = (structured && !rectilinear) ? m->dx : std::cbrt(v0);
         const double h = 2.0 * h0;                                     // bin edge: 2 cells; locality only (4 / 2 / 1 / 0.5 measured flat)
         bins.ox = m->bbox_min[0]; bins.oy = m->bbox_min[1]; bins.oz = m->bbox_min[2];
         bins.inv_h = 1.0 / h;
@@ -256,6 +257,15 @@ int Coupling::create(const fy_mesh_desc* m, const fy_field_ptrs* f, int gaussian
         bins.nkeys = (uint32_t)nk;
         FY_TRY(d_hist.alloc_exact(bins.nkeys));
         FY_TRY(d_tile_sums.alloc_exact((bins.nkeys + 2047u) / 2048u + 1));
+    }
+    if (rectilinear) {                                            // face planes for findCell (point-force mode)
+        const double* src[3] = {m->xf, m->yf, m->zf};
+        const int cnt[3] = {m->nx + 1, m->ny + 1, m->nz + 1};
+        for (int a = 0; a < 3; ++a) {
+            FY_TRY(d_faces[a].alloc_exact((size_t)cnt[a]));
+            FY_HIP(hipMemcpyAsync(d_faces[a].p, src[a], (size_t)cnt[a] * sizeof(double), hipMemcpyHostToDevice, stream));
+        }
+        FY_HIP(hipStreamSynchronize(stream));
     }
     for (auto& t : timers) FY_TRY(t.init());
     FY_TRY(marks.init());
@@ -650,6 +660,7 @@ int Coupling::run_batch(Batch& b) {
         BlockGeom g;
         for (int a = 0; a < 3; ++a) { g.bbmin[a] = mesh.bbox_min[a]; g.bbmax[a] = mesh.bbox_max[a]; }
         g.dx = mesh.dx; g.nx = mesh.nx; g.ny = mesh.ny; g.nz = mesh.nz;
+        for (int a = 0; a < 3; ++a) g.faces[a] = rectilinear ? d_faces[a].p : nullptr;
         if (timing) marks.mark(3, stream);
         const CellWindow cw{slab.active ? slab.base : 0, n_field};
         FY_TRY(launch_point_force(stream, b.d_rec, b.n, g, fp, cw, d_vol.p, dU, dVGrad, dUSource, b.force.p, b.found.p, b.incell.p, slab_own()));

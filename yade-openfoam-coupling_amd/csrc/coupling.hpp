@@ -90,6 +90,8 @@ struct Coupling {
     bool tile_flush = true;              // the scatters' tables are flushed into per-tile buckets (false: global atomics, round-1 behaviour)
     TileGrid tile_grid() const;
     TileBuckets buckets_of(Batch& b, int which);
+    bool rectilinear = false;            // graded block (fy_mesh_desc.xf / yf / zf): lattice indexing, explicit tree, findCell by search
+    DevBuf<double> d_faces[3];
     ImplicitGeom implicit{};
     bool use_implicit = false;
     int tree_levels = 0;

@@ -2,11 +2,22 @@
 // pimpleFoamYade.C:60-114 / UcEqn.H / pEqn.H on a uniform hex block.  One lane per cell (or per face), consecutive lanes on
 // consecutive x-cells => every array access is a coalesced stream; y/z neighbours are re-reads served by L2.  FP64, no MFMA.
 // Operator semantics follow OpenFOAM-6 (see DESIGN.md "FV discretisation"); parity for this half is UNPINNED (no OpenFOAM here).
+// This source is compiled TWICE: as it stands (FY_FVK_GRADED 0: the uniform block of cubes, every kernel works with the constants dx, Af, V --
+// namespace fy) and through fv_kernels_graded.hip (FY_FVK_GRADED 1: a graded, rectilinear block with per-axis cell sizes -- namespace fy::gr).
+// Every geometric quantity goes through the geo_* functions below; in the uniform build they ARE the constants, in the expressions the
+// kernels were written and measured with.
 #include "fv_kernels.hpp"
 
 #include "common.hpp"
 
+#ifndef FY_FVK_GRADED
+#define FY_FVK_GRADED 0
+#endif
+
 namespace fy {
+#if FY_FVK_GRADED
+namespace gr {
+#endif
 namespace {
 
 constexpr double kSmall = 1e-15;     // OpenFOAM `small`
@@ -30,6 +41,88 @@ __device__ __forceinline__ int fid(const FvGeo& g, int d, int i, int j, int k) {
 __device__ __forceinline__ int cface(const FvGeo& g, int d, int s, int i, int j, int k) {
     return fid(g, d, i + (d == 0 ? s : 0), j + (d == 1 ? s : 0), k + (d == 2 ? s : 0));
 }
+// ------------------------------------------------------------------------------------------------ geometry
+// q = index along axis d: of a cell (geo_h, geo_rh, geo_rhalf, geo_lerp_side's qc) or of a face (geo_lerp, geo_rdelta: face q lies between
+// cells q - 1 and q).  Linear-interpolation weight of the low-side cell at an internal face = distance from the face to the high-side
+// centre over the centre distance [OF-6 surfaceInterpolation::weights]; |Sf| / |d| from the face area and the centre distance, centre to
+// face at a boundary [OF-6 deltaCoeffs / fvPatch::deltaCoeffs].  kBfac: the uniform code writes a boundary coefficient as 2 x (gamma dx).
+#if FY_FVK_GRADED
+[[maybe_unused]] __device__ __forceinline__ double geo_h(const FvGeo& g, int d, int q) { return g.h[d][q]; }
+__device__ __forceinline__ double geo_rh(const FvGeo& g, int d, int q) { return 1.0 / g.h[d][q]; }
+__device__ __forceinline__ double geo_rhalf(const FvGeo& g, int d, int q) { return 2.0 / g.h[d][q]; }
+__device__ __forceinline__ double geo_rdelta(const FvGeo& g, int d, int q) { return 2.0 / (g.h[d][q - 1] + g.h[d][q]); }
+__device__ __forceinline__ double geo_V(const FvGeo& g, int i, int j, int k) { return (g.h[0][i] * g.h[1][j]) * g.h[2][k]; }
+__device__ __forceinline__ double geo_rV(const FvGeo& g, int i, int j, int k) { return 1.0 / geo_V(g, i, j, k); }
+// area of a face normal to d whose transverse indices are those of (i, j, k) (cell or face indices: the normal one is not used)
+__device__ __forceinline__ double geo_Af(const FvGeo& g, int d, int i, int j, int k) { return d == 0 ? g.h[1][j] * g.h[2][k] : d == 1 ? g.h[0][i] * g.h[2][k] : g.h[0][i] * g.h[1][j]; }
+__device__ __forceinline__ double geo_wlow(const FvGeo& g, int d, int q) { return g.h[d][q] / (g.h[d][q - 1] + g.h[d][q]); }
+__device__ __forceinline__ double geo_lerp(const FvGeo& g, int d, int q, double lo, double hi) { const double w = geo_wlow(g, d, q); return w * lo + (1.0 - w) * hi; }
+constexpr double kBfac = 1.0;
+#else
+[[maybe_unused]] __device__ __forceinline__ double geo_h(const FvGeo& g, int, int) { return g.dx; }
+__device__ __forceinline__ double geo_rh(const FvGeo& g, int, int) { return g.rdx; }
+__device__ __forceinline__ double geo_rhalf(const FvGeo& g, int, int) { return g.rhdx; }
+__device__ __forceinline__ double geo_rdelta(const FvGeo& g, int, int) { return g.rdx; }
+__device__ __forceinline__ double geo_V(const FvGeo& g, int, int, int) { return g.V; }
+__device__ __forceinline__ double geo_rV(const FvGeo& g, int, int, int) { return g.rV; }
+__device__ __forceinline__ double geo_Af(const FvGeo& g, int, int, int, int) { return g.Af; }
+[[maybe_unused]] __device__ __forceinline__ double geo_wlow(const FvGeo&, int, int) { return 0.5; }
+__device__ __forceinline__ double geo_lerp(const FvGeo&, int, int, double lo, double hi) { return 0.5 * (lo + hi); }
+constexpr double kBfac = 2.0;
+#endif
+// value at face (d, s) of the cell with index qc along d, from the cell's own value and its neighbour's across that face
+__device__ __forceinline__ double geo_lerp_side(const FvGeo& g, int d, int s, int qc, double own, double nb) {
+#if FY_FVK_GRADED
+    return s ? geo_lerp(g, d, qc + 1, own, nb) : geo_lerp(g, d, qc, nb, own);
+#else
+    return 0.5 * (own + nb);
+#endif
+}
+// weight of the cell's own value at its face (d, s)
+__device__ __forceinline__ double geo_wown(const FvGeo& g, int d, int s, int qc) {
+#if FY_FVK_GRADED
+    return s ? geo_wlow(g, d, qc + 1) : 1.0 - geo_wlow(g, d, qc);
+#else
+    return 0.5;
+#endif
+}
+// 1 / (centre distance) across face (d, s) of the cell (i, j, k): centre to face on a physical boundary
+__device__ __forceinline__ bool onb(const FvGeo& g, int d, int s, int i, int j, int k);
+__device__ __forceinline__ double geo_rdist(const FvGeo& g, int d, int s, int i, int j, int k) {
+#if FY_FVK_GRADED
+    const int qc = d == 0 ? i : d == 1 ? j : k;
+    return onb(g, d, s, i, j, k) ? geo_rhalf(g, d, qc) : geo_rdelta(g, d, qc + s);
+#else
+    return onb(g, d, s, i, j, k) ? g.rhdx : g.rdx;
+#endif
+}
+// |Sf| / |d| of face (d, s) of cell (i, j, k).  Uniform block: dx for EVERY face -- the boundary's factor 2 is kBfac, where the uniform code has it
+__device__ __forceinline__ double geo_sfd(const FvGeo& g, int d, int s, int i, int j, int k) {
+#if FY_FVK_GRADED
+    return geo_Af(g, d, i, j, k) * geo_rdist(g, d, s, i, j, k);
+#else
+    return g.dx;
+#endif
+}
+// the same for a FACE given by its own indices (fi, fj, fk) (q = its index along d): boundary faces have q = 0 or q = n
+__device__ __forceinline__ double geo_sfd_face(const FvGeo& g, int d, int q, int nq, int fi, int fj, int fk) {
+#if FY_FVK_GRADED
+    const double rd = q == 0 ? geo_rhalf(g, d, 0) : (q == nq ? geo_rhalf(g, d, nq - 1) : geo_rdelta(g, d, q));
+    return geo_Af(g, d, fi, fj, fk) * rd;
+#else
+    return g.dx;
+#endif
+}
+// cell size along d of the cell with STORAGE index c
+__device__ __forceinline__ double geo_hc(const FvGeo& g, int d, int c) {
+#if FY_FVK_GRADED
+    const int t = c - g.c0;
+    return g.h[d][d == 0 ? t % g.nx : d == 1 ? (t / g.nx) % g.ny : t / (g.nx * g.ny)];
+#else
+    return g.dx;
+#endif
+}
+
 // is face (d, s) of owned cell (i,j,k) on a PHYSICAL boundary?  (slab interfaces in z are interior faces)
 __device__ __forceinline__ bool onb(const FvGeo& g, int d, int s, int i, int j, int k) {
     if (d == 2) { const int kg = k + g.kglob0; return s ? kg == g.nzglob - 1 : kg == 0; }
@@ -46,7 +139,7 @@ __device__ __forceinline__ void Ub(const FvGeo& g, const double* F, int c, int p
 __device__ __forceinline__ double pbv(const FvGeo& g, const double* p, const CFace3& psn, int c, int d, int s, int face) {
     const int patch = 2 * d + s;
     if (g.p_bc[patch] == 1) return g.p_val[patch];
-    if (g.p_bc[patch] == 2) return p[c] + (s ? 0.5 : -0.5) * g.dx * psn.a[d][face];
+    if (g.p_bc[patch] == 2) return p[c] + (s ? 0.5 : -0.5) * geo_hc(g, d, c) * psn.a[d][face];
     return p[c];
 }
 // boundary value of nut on patch `patch` next to cell c (FvGeo: nut_bc 0 zeroGradient, 1 fixedValue, 2 nutkWallFunction)
@@ -176,8 +269,8 @@ __device__ __forceinline__ double face_flux_vec(const FvGeo& g, const double* F,
     double v;
     if (face_low_b(g, d, q)) { double b[3]; Ub(g, F, cidx(g, i, j, k), 2 * d, b); v = b[d]; }
     else if (face_high_b(g, d, q)) { double b[3]; Ub(g, F, cidx(g, i - (d == 0), j - (d == 1), k - (d == 2)), 2 * d + 1, b); v = b[d]; }
-    else { const int c = cidx(g, i, j, k); v = 0.5 * (F[3 * (size_t)(c - stride_of(g, d)) + d] + F[3 * (size_t)c + d]); }
-    return v * g.Af;
+    else { const int c = cidx(g, i, j, k); v = geo_lerp(g, d, q, F[3 * (size_t)(c - stride_of(g, d)) + d], F[3 * (size_t)c + d]); }
+    return v * geo_Af(g, d, i, j, k);
 }
 
 template <int D>
@@ -192,7 +285,7 @@ template <int D>
 __device__ __forceinline__ void interp_alpha_face(const FvGeo& g, size_t f, int i, int j, int k, const double* __restrict__ alpha, double* __restrict__ af) {
     const int q = D == 0 ? i : D == 1 ? j : k;
     if (face_low_b(g, D, q) || face_high_b(g, D, q)) af[f] = 1.0;     // calculated patch, value 1 (`alpha = 1.0`, FoamYade.C:68)
-    else { const int c = cidx(g, i, j, k); af[f] = 0.5 * (alpha[c - stride_of(g, D)] + alpha[c]); }
+    else { const int c = cidx(g, i, j, k); af[f] = geo_lerp(g, D, q, alpha[c - stride_of(g, D)], alpha[c]); }
 }
 
 template <int D>
@@ -203,7 +296,7 @@ __global__ __launch_bounds__(256) void k_interp_rAU(FvGeo g, const double* __res
     const int q = D == 0 ? i : D == 1 ? j : k;
     if (face_low_b(g, D, q)) rf[f] = rAU[cidx(g, i, j, k)];
     else if (face_high_b(g, D, q)) rf[f] = rAU[cidx(g, i - (D == 0), j - (D == 1), k - (D == 2))];
-    else { const int c = cidx(g, i, j, k); rf[f] = 0.5 * (rAU[c - stride_of(g, D)] + rAU[c]); }
+    else { const int c = cidx(g, i, j, k); rf[f] = geo_lerp(g, D, q, rAU[c - stride_of(g, D)], rAU[c]); }
 }
 
 // Every face of the block exactly once from a cell-centred sweep: an owned cell does its three low faces, and the high face where it
@@ -228,11 +321,11 @@ __device__ __forceinline__ void rAUf_phi_forces_face(const FvGeo& g, size_t f, i
     else {
         const int c = cidx(g, i, j, k), cm = c - stride_of(g, D);
         const double rm = rAU[cm], rc = rAU[c];
-        r = 0.5 * (rm + rc);
-        fl = 0.5 * (rm * uSource[3 * (size_t)cm + D] + rc * uSource[3 * (size_t)c + D]) * g.Af;
+        r = geo_lerp(g, D, q, rm, rc);
+        fl = geo_lerp(g, D, q, rm * uSource[3 * (size_t)cm + D], rc * uSource[3 * (size_t)c + D]) * geo_Af(g, D, i, j, k);
     }
     rf[f] = r;
-    out[f] = fl + r * (g.g[D] * g.Af);
+    out[f] = fl + r * (g.g[D] * geo_Af(g, D, i, j, k));
 }
 __global__ __launch_bounds__(256) void k_rAUf_phi_forces_cells(FvGeo g, const double* __restrict__ rAU, const double* __restrict__ uSource, Face3 rf, Face3 out) {
     const int t = swz_block(blockIdx.x, gridDim.x) * 256 + (int)threadIdx.x;
@@ -266,8 +359,9 @@ __device__ __forceinline__ void phiHbyA_face(const FvGeo& g, size_t f, int i, in
     int bpatch = -1, bc = -1;
     if (face_low_b(g, D, q)) { bpatch = 2 * D; bc = cidx(g, i, j, k); }
     else if (face_high_b(g, D, q)) { bpatch = 2 * D + 1; bc = cidx(g, i - (D == 0), j - (D == 1), k - (D == 2)); }
-    if (bpatch >= 0) { fixes = g.u_bc[bpatch] == 0; double b[3]; Ub(g, Uold, bc, bpatch, b); uf = b[D] * g.Af; }
-    else { const int c = cidx(g, i, j, k); uf = 0.5 * (Uold[3 * (size_t)(c - stride_of(g, D)) + D] + Uold[3 * (size_t)c + D]) * g.Af; }
+    const double Afc = geo_Af(g, D, i, j, k);
+    if (bpatch >= 0) { fixes = g.u_bc[bpatch] == 0; double b[3]; Ub(g, Uold, bc, bpatch, b); uf = b[D] * Afc; }
+    else { const int c = cidx(g, i, j, k); uf = geo_lerp(g, D, q, Uold[3 * (size_t)(c - stride_of(g, D)) + D], Uold[3 * (size_t)c + D]) * Afc; }
     const double po = phiOld[f];
     const double phiCorr = po - uf;
     const double coef = fixes ? 0.0 : 1.0 - fmin(fabs(phiCorr) / (fabs(po) + kSmall), 1.0);
@@ -278,7 +372,7 @@ __device__ __forceinline__ void phiHbyA_face(const FvGeo& g, size_t f, int i, in
     out[f] = v;
     if (bpatch >= 0 && g.p_bc[bpatch] == 2) {
         double ub[3]; Ub(g, U, bc, bpatch, ub);
-        psn[f] = (v - ub[D] * g.Af) / (rAUf[f] * g.Af);
+        psn[f] = (v - ub[D] * Afc) / (rAUf[f] * Afc);
     }
 }
 
@@ -358,7 +452,8 @@ __global__ __launch_bounds__(256) void k_adjust_phi_apply(FvGeo g, const double*
     if (g.p_bc[patch] == 2) {                                              // constrainPressure sees the adjusted flux (pEqn.H:21)
         const int c = cidx(g, i - (d == 0 && s), j - (d == 1 && s), k - (d == 2 && s));
         double ub[3]; Ub(g, U, c, patch, ub);
-        psn.a[d][f] = (v - ub[d] * g.Af) / (rAUf.a[d][f] * g.Af);
+        const double Afc = geo_Af(g, d, i, j, k);
+        psn.a[d][f] = (v - ub[d] * Afc) / (rAUf.a[d][f] * Afc);
     }
 }
 
@@ -375,11 +470,11 @@ __device__ __forceinline__ void flux_correct_face(const FvGeo& g, size_t f, int 
     if (lo || hi) {
         const int s = lo ? 0 : 1, patch = 2 * D + s;
         const int c = cidx(g, i - (D == 0 && s), j - (D == 1 && s), k - (D == 2 && s));
-        if (g.p_bc[patch] == 1) { const double gb = 2.0 * af * rAUf[f] * g.dx; fl = s ? gb * (g.p_val[patch] - p[c]) : gb * (p[c] - g.p_val[patch]); }
-        else if (g.p_bc[patch] == 2) fl = af * rAUf[f] * g.Af * psn[f];
+        if (g.p_bc[patch] == 1) { const double gb = kBfac * af * rAUf[f] * geo_sfd_face(g, D, q, ndim(g, D), i, j, k); fl = s ? gb * (g.p_val[patch] - p[c]) : gb * (p[c] - g.p_val[patch]); }
+        else if (g.p_bc[patch] == 2) fl = af * rAUf[f] * geo_Af(g, D, i, j, k) * psn[f];
     } else {
         const int c = cidx(g, i, j, k);
-        fl = af * rAUf[f] * g.dx * (p[c] - p[c - stride_of(g, D)]);
+        fl = af * rAUf[f] * geo_sfd_face(g, D, q, ndim(g, D), i, j, k) * (p[c] - p[c - stride_of(g, D)]);
     }
     pflux[f] = fl;
     phi[f] = phiHbyA[f] - fl / af;
@@ -406,7 +501,7 @@ __global__ __launch_bounds__(256) void k_courant(FvGeo g, CFace3 phi, double* __
         for (int d = 0; d < 3; ++d)
 #pragma unroll
             for (int sd = 0; sd < 2; ++sd) s += fabs(phi.a[d][cface(g, d, sd, i, j, k)]);
-        v[0] = fmax(v[0], s * g.rV);
+        v[0] = fmax(v[0], s * geo_rV(g, i, j, k));
         v[1] += s;
     }
     const int mx[2] = {1, 0};
@@ -448,23 +543,25 @@ __global__ __launch_bounds__(256) void k_pre_coupling(FvGeo g, const double* __r
                 Ub(g, U, c, 2 * d + s, fv[s]);
                 if (pf) {
                     fp[s] = pbv(g, p, psn, c, d, s, cface(g, d, s, i, j, k));
-                    for (int q = 0; q < 3; ++q) lap[q] += 1.0 * g.Af * (fv[s][q] - uc[q]) * g.rhdx;     // alphaf = 1 on the boundary
+                    for (int q = 0; q < 3; ++q) lap[q] += 1.0 * geo_Af(g, d, i, j, k) * (fv[s][q] - uc[q]) * geo_rhalf(g, d, d == 0 ? i : d == 1 ? j : k);     // alphaf = 1 on the boundary
                 }
             } else {
                 const int nb = c + (s ? stride_of(g, d) : -stride_of(g, d));
                 double un[3], pn = 0.0, an = 0.0;
                 if (d == 0) { un[0] = ux[s][0]; un[1] = ux[s][1]; un[2] = ux[s][2]; pn = px[s]; an = ax[s]; }
                 else { un[0] = U[3 * (size_t)nb]; un[1] = U[3 * (size_t)nb + 1]; un[2] = U[3 * (size_t)nb + 2]; if (pf) { pn = p[nb]; an = alpha[nb]; } }
-                for (int q = 0; q < 3; ++q) fv[s][q] = 0.5 * (uc[q] + un[q]);
+                const int qc = d == 0 ? i : d == 1 ? j : k;
+                for (int q = 0; q < 3; ++q) fv[s][q] = geo_lerp_side(g, d, s, qc, uc[q], un[q]);
                 if (pf) {
-                    fp[s] = 0.5 * (pc + pn);
-                    const double af = 0.5 * (ac + an);
-                    for (int q = 0; q < 3; ++q) lap[q] += af * g.Af * (un[q] - uc[q]) * g.rdx;
+                    fp[s] = geo_lerp_side(g, d, s, qc, pc, pn);
+                    const double af = geo_lerp_side(g, d, s, qc, ac, an);
+                    for (int q = 0; q < 3; ++q) lap[q] += af * geo_Af(g, d, i, j, k) * (un[q] - uc[q]) * geo_rdelta(g, d, qc + s);
                 }
             }
         }
-        for (int q = 0; q < 3; ++q) T[3 * d + q] = (fv[1][q] - fv[0][q]) * g.rdx;
-        if (pf) gp3[d] = (fp[1] - fp[0]) * g.rdx;
+        const double rhd = geo_rh(g, d, d == 0 ? i : d == 1 ? j : k);
+        for (int q = 0; q < 3; ++q) T[3 * d + q] = (fv[1][q] - fv[0][q]) * rhd;
+        if (pf) gp3[d] = (fp[1] - fp[0]) * rhd;
         if (ddtU) {     // fvc::div(phic, Uc), Gauss linear: the face values are the ones the gradient just used
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
@@ -476,13 +573,13 @@ __global__ __launch_bounds__(256) void k_pre_coupling(FvGeo g, const double* __r
     // pimpleFoamYade.C:73 ddtU_f = fvc::ddt(Uc) + fvc::div(phic, Uc); the ddt term is identically zero there (Uc.oldTime() is
     // stored on that access, before Uc is written in the new step), only consumer: addedMassForce (fy_set_force_models)
     if (ddtU)
-        for (int q = 0; q < 3; ++q) ddtU[3 * (size_t)c + q] = conv[q] * g.rV;
+        for (int q = 0; q < 3; ++q) ddtU[3 * (size_t)c + q] = conv[q] * geo_rV(g, i, j, k);
     if (write_vgrad)
         for (int q = 0; q < 9; ++q) vGrad[9 * (size_t)c + q] = T[q];
     if (pf)
         for (int q = 0; q < 3; ++q) gradP[3 * (size_t)c + q] = gp3[q];
     if (pf)
-        for (int q = 0; q < 3; ++q) divT[3 * (size_t)c + q] = 2 * g.nu * (lap[q] * g.rV);
+        for (int q = 0; q < 3; ++q) divT[3 * (size_t)c + q] = 2 * g.nu * (lap[q] * geo_rV(g, i, j, k));
     if (Gout) {
         const double tr = T[0] + T[4] + T[8];
         const double an = g.nut ? alpha[c] * (g.nu + g.nut[c]) : alpha[c] * g.nu;      // alpha nuEff (nuEff = nut + nu [OF-6 eddyViscosity/linearViscousStress])
@@ -512,11 +609,11 @@ __global__ __launch_bounds__(256) void k_div_G(FvGeo g, const double* __restrict
             const double* Gd = G + (size_t)d * g_row_stride(g);           // row d of the tensor field
             if (d == 0) {
                 if (onb(g, d, s, i, j, k)) for (int q = 0; q < 3; ++q) fv[s][q] = g0[q];
-                else for (int q = 0; q < 3; ++q) fv[s][q] = 0.5 * (g0[q] + gx[s][q]);
+                else for (int q = 0; q < 3; ++q) fv[s][q] = geo_lerp_side(g, d, s, i, g0[q], gx[s][q]);
             } else if (onb(g, d, s, i, j, k)) for (int q = 0; q < 3; ++q) fv[s][q] = Gd[3 * (size_t)c + q];
-            else { const int nb = c + (s ? stride_of(g, d) : -stride_of(g, d)); for (int q = 0; q < 3; ++q) fv[s][q] = 0.5 * (Gd[3 * (size_t)c + q] + Gd[3 * (size_t)nb + q]); }
+            else { const int nb = c + (s ? stride_of(g, d) : -stride_of(g, d)); for (int q = 0; q < 3; ++q) fv[s][q] = geo_lerp_side(g, d, s, d == 1 ? j : k, Gd[3 * (size_t)c + q], Gd[3 * (size_t)nb + q]); }
         }
-        for (int q = 0; q < 3; ++q) acc[q] += (fv[1][q] - fv[0][q]) * g.rdx;
+        for (int q = 0; q < 3; ++q) acc[q] += (fv[1][q] - fv[0][q]) * geo_rh(g, d, d == 0 ? i : d == 1 ? j : k);
     }
     for (int q = 0; q < 3; ++q) divG[3 * (size_t)c + q] = acc[q];
 }
@@ -716,7 +813,7 @@ __global__ __launch_bounds__(256) void k_assemble_momentum(FvGeo g, const double
     if (t >= g.Nc) return;
     int i, j, k; ijk_of(g, t, i, j, k);
     const int c = t + g.c0;
-    const double nu = g.nu, dt = g.dt, V = g.V;
+    const double nu = g.nu, dt = g.dt, V = geo_V(g, i, j, k);
     const bool pim = g.pimple != 0;
     const double aP = pim ? alpha[c] : 1.0, aP0 = pim ? alphaOld[c] : 1.0;
     double dg = aP * V / dt;
@@ -733,21 +830,22 @@ __global__ __launch_bounds__(256) void k_assemble_momentum(FvGeo g, const double
             divAPhi += phio;
             // fvm::laplacian(alpha nuEff, U): the face diffusivity is the linear interpolate of the cell field alpha (nu + nut) [OF-6
             // linearViscousStress::divDevRhoReff, gaussLaplacianScheme]; its boundary value is alpha_b (nu + nut_b).  Laminar: nu alphaf
-            double gam = nu * af * g.dx;
+            const double geo = geo_sfd(g, d, s, i, j, k);          // |Sf| / |d| (uniform block: dx; a boundary's factor 2 is kBfac)
+            double gam = nu * af * geo;
             if (g.nut) {
                 if (onb(g, d, s, i, j, k)) {
                     const double nb = nut_boundary(g, 2 * d + s, c);
-                    gam = (af * (nu + nb)) * g.dx;
+                    gam = (af * (nu + nb)) * geo;
                 } else {
                     const int nbc = c + (s ? stride_of(g, d) : -stride_of(g, d));
-                    gam = (0.5 * ((aP * (nu + g.nut[c])) + (alpha[nbc] * (nu + g.nut[nbc])))) * g.dx;
+                    gam = (0.5 * ((aP * (nu + g.nut[c])) + (alpha[nbc] * (nu + g.nut[nbc])))) * geo;
                 }
             }
             if (onb(g, d, s, i, j, k)) {
                 an[2 * d + s] = 0.0;
                 const int patch = 2 * d + s;
                 if (g.u_bc[patch] == 0) {
-                    const double gb = 2.0 * gam;
+                    const double gb = kBfac * gam;
                     dg += gb;
                     for (int q = 0; q < 3; ++q) s3[q] += (-phio + gb) * g.u_val[patch][q];
                 } else {
@@ -756,7 +854,12 @@ __global__ __launch_bounds__(256) void k_assemble_momentum(FvGeo g, const double
             } else {
                 // fvm::div(phi, U): Gauss linear puts half the face flux on either side; Gauss upwind takes the whole of an
                 // outgoing flux on the diagonal and the whole of an incoming one on the neighbour [OF-6 gaussConvectionScheme]
-                const double cP = g.upwind ? fmax(phio, 0.0) : 0.5 * phio, cN = g.upwind ? fmin(phio, 0.0) : 0.5 * phio;
+                const double wP = geo_wown(g, d, s, d == 0 ? i : d == 1 ? j : k);      // Gauss linear: w_P U_P + (1 - w_P) U_N at the face
+#if FY_FVK_GRADED
+                const double cP = g.upwind ? fmax(phio, 0.0) : wP * phio, cN = g.upwind ? fmin(phio, 0.0) : (1.0 - wP) * phio;
+#else
+                const double cP = g.upwind ? fmax(phio, 0.0) : wP * phio, cN = g.upwind ? fmin(phio, 0.0) : wP * phio;
+#endif
                 dg += cP + gam;
                 an[2 * d + s] = cN - gam;
                 if (g.upwind == 2) {
@@ -807,20 +910,21 @@ __global__ __launch_bounds__(256) void k_bmom(FvGeo g, const double* __restrict_
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 if (onb(g, d, s, i, j, k)) fv[s] = pbv(g, p, psn, c, d, s, cface(g, d, s, i, j, k));
-                else fv[s] = 0.5 * (p[c] + p[c + (s ? stride_of(g, d) : -stride_of(g, d))]);
+                else fv[s] = geo_lerp_side(g, d, s, d == 0 ? i : d == 1 ? j : k, p[c], p[c + (s ? stride_of(g, d) : -stride_of(g, d))]);
             }
-            out[d] = src[3 * (size_t)c + d] - g.V * ((fv[1] - fv[0]) * g.rdx);
+            out[d] = src[3 * (size_t)c + d] - geo_V(g, i, j, k) * ((fv[1] - fv[0]) * geo_rh(g, d, d == 0 ? i : d == 1 ? j : k));
         } else {
             double sm = 0;
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const int f = cface(g, d, s, i, j, k);
                 double sng;
-                if (onb(g, d, s, i, j, k)) { const double pbd = pbv(g, p, psn, c, d, s, f); sng = s ? (pbd - p[c]) * g.rhdx : (p[c] - pbd) * g.rhdx; }
-                else sng = s ? (p[c + stride_of(g, d)] - p[c]) * g.rdx : (p[c] - p[c - stride_of(g, d)]) * g.rdx;
-                sm += phiForces.a[d][f] / rAUf.a[d][f] - sng * g.Af;
+                const double rds = geo_rdist(g, d, s, i, j, k);
+                if (onb(g, d, s, i, j, k)) { const double pbd = pbv(g, p, psn, c, d, s, f); sng = s ? (pbd - p[c]) * rds : (p[c] - pbd) * rds; }
+                else sng = s ? (p[c + stride_of(g, d)] - p[c]) * rds : (p[c] - p[c - stride_of(g, d)]) * rds;
+                sm += phiForces.a[d][f] / rAUf.a[d][f] - sng * geo_Af(g, d, i, j, k);
             }
-            out[d] = src[3 * (size_t)c + d] + g.V * (sm / (2.0 * g.Af));
+            out[d] = src[3 * (size_t)c + d] + geo_V(g, i, j, k) * (sm / (2.0 * geo_Af(g, d, i, j, k)));
         }
     }
     for (int d = 0; d < 3; ++d) bmom[3 * (size_t)c + d] = out[d];
@@ -893,7 +997,7 @@ __global__ __launch_bounds__(256) void k_HbyA(FvGeo g, Mom7 M, const double* __r
                 for (int q = 0; q < 3; ++q) acc[q] -= a * U[3 * (size_t)nb + q];
             }
     const double r = rAU[c];
-    for (int q = 0; q < 3; ++q) HbyA[3 * (size_t)c + q] = r * (acc[q] * g.rV);
+    for (int q = 0; q < 3; ++q) HbyA[3 * (size_t)c + q] = r * (acc[q] * geo_rV(g, i, j, k));
 }
 
 // pEqn in SPD form: sum_f g_f (p_P - p_nb) [+ g_b (p_P - p_b)] = -(ddt(alpha) V + sum_out alphaf phiHbyA)   (icoFoamYade.C:118-123, pEqn.H:26-33)
@@ -914,18 +1018,18 @@ __global__ __launch_bounds__(256) void k_assemble_pressure(FvGeo g, CFace3 phiHb
             const double rf = rAUf.a[d][f];
             double ph = (s ? 1.0 : -1.0) * af * phiHbyA.a[d][f];
             const bool b = onb(g, d, s, i, j, k);
-            if (b && g.p_bc[2 * d + s] == 2) ph = (s ? 1.0 : -1.0) * af * (phiHbyA.a[d][f] - rf * g.Af * psn.a[d][f]);
+            if (b && g.p_bc[2 * d + s] == 2) ph = (s ? 1.0 : -1.0) * af * (phiHbyA.a[d][f] - rf * geo_Af(g, d, i, j, k) * psn.a[d][f]);
             r -= ph;
             if (b) {
                 const int patch = 2 * d + s;
-                if (g.p_bc[patch] == 1) { const double gb = 2.0 * af * rf * g.dx; dg += gb; r += gb * g.p_val[patch]; }
+                if (g.p_bc[patch] == 1) { const double gb = kBfac * af * rf * geo_sfd(g, d, s, i, j, k); dg += gb; r += gb * g.p_val[patch]; }
             } else {
-                const double gg = af * rf * g.dx;
+                const double gg = af * rf * geo_sfd(g, d, s, i, j, k);
                 dg += gg;
                 if (s) up[d] = gg;
             }
         }
-    if (g.pimple) r -= g.V * (alpha[c] - alphaOld[c]) / g.dt;
+    if (g.pimple) r -= geo_V(g, i, j, k) * (alpha[c] - alphaOld[c]) / g.dt;
     // fvMatrix::setReference: p_ref_cell is a GLOBAL cell number (i + nx*(j + ny*kglob))
     if (g.need_ref && (i + g.nx * (j + g.ny * (k + g.kglob0))) == g.p_ref_cell) { r += dg * g.p_ref_value; dg += dg; }
     A.diag[c] = dg; A.ux[c] = up[0]; A.uy[c] = up[1]; A.uz[c] = up[2];
@@ -952,10 +1056,10 @@ __global__ __launch_bounds__(256) void k_cont_err(FvGeo g, CFace3 phi, CFace3 al
         for (int d = 0; d < 3; ++d)
 #pragma unroll
             for (int s = 0; s < 2; ++s) { const int f = cface(g, d, s, i, j, k); dv += (s ? 1.0 : -1.0) * (g.pimple ? alphaf.a[d][f] : 1.0) * phi.a[d][f]; }
-        double ce = dv * g.rV;
+        double ce = dv * geo_rV(g, i, j, k);
         if (g.pimple) ce += (alpha[c] - alphaOld[c]) / g.dt;
-        v[0] += fabs(ce) * g.V;
-        v[1] += ce * g.V;
+        v[0] += fabs(ce) * geo_V(g, i, j, k);
+        v[1] += ce * geo_V(g, i, j, k);
     }
     const int mx[2] = {0, 0};
     block_reduce_store<2>(v, mx, partials);
@@ -986,14 +1090,14 @@ __global__ __launch_bounds__(256) void k_U_correct(FvGeo g, const double* __rest
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     if (onb(g, d, s, i, j, k)) fv[s] = pbv(g, p, psn, c, d, s, cface(g, d, s, i, j, k));
-                    else fv[s] = 0.5 * (p[c] + p[c + (s ? stride_of(g, d) : -stride_of(g, d))]);
+                    else fv[s] = geo_lerp_side(g, d, s, d == 0 ? i : d == 1 ? j : k, p[c], p[c + (s ? stride_of(g, d) : -stride_of(g, d))]);
                 }
-                out[d] = HbyA[3 * (size_t)c + d] - r * ((fv[1] - fv[0]) * g.rdx);
+                out[d] = HbyA[3 * (size_t)c + d] - r * ((fv[1] - fv[0]) * geo_rh(g, d, d == 0 ? i : d == 1 ? j : k));
             } else {
                 double sm = 0;
 #pragma unroll
                 for (int s = 0; s < 2; ++s) { const int f = cface(g, d, s, i, j, k); sm += (phiForces.a[d][f] - pflux.a[d][f] / alphaf.a[d][f]) / rAUf.a[d][f]; }
-                out[d] = HbyA[3 * (size_t)c + d] + r * (sm / (2.0 * g.Af));
+                out[d] = HbyA[3 * (size_t)c + d] + r * (sm / (2.0 * geo_Af(g, d, i, j, k)));
             }
             if (DIAG) {
 #pragma unroll
@@ -1007,11 +1111,11 @@ __global__ __launch_bounds__(256) void k_U_correct(FvGeo g, const double* __rest
         }
         for (int d = 0; d < 3; ++d) U[3 * (size_t)c + d] = out[d];
         if (DIAG) {
-            double ce = dv * g.rV;
+            double ce = dv * geo_rV(g, i, j, k);
             if (g.pimple) ce += (alpha[c] - alphaOld[c]) / g.dt;
-            v[0] += fabs(ce) * g.V;
-            v[1] += ce * g.V;
-            v[2] = fmax(v[2], sp * g.rV);
+            v[0] += fabs(ce) * geo_V(g, i, j, k);
+            v[1] += ce * geo_V(g, i, j, k);
+            v[2] = fmax(v[2], sp * geo_rV(g, i, j, k));
             v[3] += sp;
         }
     }
@@ -1851,7 +1955,7 @@ int mg_coarse_factor_doubles(PMat A) { return 3 + A.N * (band_width(A) + 1); }
 bool mg_coarse_direct_ok(PMat A) { return A.c0 == 0 && A.N <= kMgDirectMax && band_width(A) <= kMgDirectBand; }
 
 int launch_mg_coarse_factor(hipStream_t s, PMat A, double* fac) {
-    if (!mg_coarse_direct_ok(A)) return fail(FY_ERR_INVALID, "direct coarse solve: level of %d cells, band %d (ghost offset %d)", A.N, band_width(A), A.c0);
+    if (!(mg_coarse_direct_ok)(A)) return fail(FY_ERR_INVALID, "direct coarse solve: level of %d cells, band %d (ghost offset %d)", A.N, band_width(A), A.c0);
     static bool attr_set = false;
     if (!attr_set) { FY_TRY(allow_big_lds(reinterpret_cast<const void*>(k_mg_coarse_factor))); attr_set = true; }
     const int bw = band_width(A);
@@ -1868,7 +1972,7 @@ int launch_mg_tail(hipStream_t s, const PMat* A, double* const* x0, double* cons
     T.fac = fac;
     size_t lds = 0;
     if (fac) {
-        if (!mg_coarse_direct_ok(A[n - 1])) return fail(FY_ERR_INVALID, "multigrid tail: a factor was handed over for a level it cannot belong to");
+        if (!(mg_coarse_direct_ok)(A[n - 1])) return fail(FY_ERR_INVALID, "multigrid tail: a factor was handed over for a level it cannot belong to");
         static bool attr_set = false;
         if (!attr_set) { FY_TRY(allow_big_lds(reinterpret_cast<const void*>(k_mg_tail))); attr_set = true; }
         lds = fac_lds_bytes(A[n - 1].N, band_width(A[n - 1]));
@@ -1912,7 +2016,7 @@ int launch_mg_coarse_solve(hipStream_t s, PMat A, const double* b, double* x, do
     if (A.N > 1024) return fail(FY_ERR_INVALID, "coarsest multigrid level too large (%d cells)", A.N);
     size_t lds = 0;
     if (fac) {
-        if (!mg_coarse_direct_ok(A)) return fail(FY_ERR_INVALID, "coarse solve: a factor was handed over for a level it cannot belong to");
+        if (!(mg_coarse_direct_ok)(A)) return fail(FY_ERR_INVALID, "coarse solve: a factor was handed over for a level it cannot belong to");
         static bool attr_set = false;
         if (!attr_set) { FY_TRY(allow_big_lds(reinterpret_cast<const void*>(k_mg_coarse_solve))); attr_set = true; }
         lds = fac_lds_bytes(A.N, band_width(A));
@@ -1955,4 +2059,7 @@ int launch_add_f64(hipStream_t s, double* y, const double* x, size_t n) {
     return FY_OK;
 }
 
+#if FY_FVK_GRADED
+}  // namespace gr
+#endif
 }  // namespace fy

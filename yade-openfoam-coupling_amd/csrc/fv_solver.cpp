@@ -17,6 +17,9 @@
 #include "coupling.hpp"
 #include "fv_kernels.hpp"
 
+// geometry-dependent launchers exist per geometry model (fv_kernels.hpp): the uniform block's in fy, the graded block's in fy::gr
+#define FVK(fn, ...) (g.graded ? ::fy::gr::fn(__VA_ARGS__) : ::fy::fn(__VA_ARGS__))
+
 namespace fy {
 
 // coarsest multigrid level: solved by damped-Jacobi sweeps inside one 1024-thread workgroup (every level below ~20^3 is
@@ -38,6 +41,9 @@ struct MgLev {
 
 struct Solver {
     fy_case_desc cs{};
+    std::vector<double> h_host[3];       // graded block: cell sizes per axis (host copy) and their device arrays (FvGeo::h)
+    DevBuf<double> d_h[3];
+    double total_volume = 0.0;
     FvGeo g{};
     int device = 0;
     hipStream_t stream = nullptr;
@@ -124,11 +130,23 @@ struct Solver {
 
     int create(const fy_case_desc* c, const fy_transport* tr, int dev, Comm* cm) {
         if (c && (c->convection_scheme < FY_CONVECTION_LINEAR || c->convection_scheme > FY_CONVECTION_LINEAR_UPWIND)) return fail(FY_ERR_INVALID, "fy_solver_create: unknown convection_scheme");
-        if (!c || c->nx <= 0 || c->ny <= 0 || c->nz <= 0 || !(c->dx > 0) || !(c->dt > 0)) return fail(FY_ERR_INVALID, "fy_solver_create: bad case");
+        const bool gradedc = c && (c->hx || c->hy || c->hz);
+        if (!c || c->nx <= 0 || c->ny <= 0 || c->nz <= 0 || (!gradedc && !(c->dx > 0)) || !(c->dt > 0)) return fail(FY_ERR_INVALID, "fy_solver_create: bad case");
+        if (gradedc) {
+            // a graded (rectilinear) single block: the laminar operators, Gauss linear / upwind convection, one domain
+            if (!(c->hx && c->hy && c->hz)) return fail(FY_ERR_INVALID, "fy_solver_create: a graded block needs hx, hy AND hz");
+            if (cm && cm->size > 1) return fail(FY_ERR_UNSUPPORTED, "fy_solver_create: z-slabs need the uniform block (a graded block runs on one domain)");
+            if (c->turbulence_model != FY_TURBULENCE_LAMINAR) return fail(FY_ERR_UNSUPPORTED, "fy_solver_create: the turbulence closures (delta = cbrt(V), wall distance dx / 2) are built for the uniform block; a graded block is laminar");
+            if (c->convection_scheme == FY_CONVECTION_LINEAR_UPWIND) return fail(FY_ERR_UNSUPPORTED, "fy_solver_create: Gauss linearUpwind is built for the uniform block; a graded block takes Gauss linear or Gauss upwind");
+            const double* hh[3] = {c->hx, c->hy, c->hz};
+            const int nn[3] = {c->nx, c->ny, c->nz};
+            for (int a = 0; a < 3; ++a) for (int q = 0; q < nn[a]; ++q) if (!(hh[a][q] > 0)) return fail(FY_ERR_INVALID, "fy_solver_create: graded block with a non-positive cell size");
+        }
         int ndev = 0;
         if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(FY_ERR_NO_DEVICE, "no HIP device visible: libfoamyade_hip has no CPU path");
         if (dev < 0 || dev >= ndev) return fail(FY_ERR_INVALID, "device ordinal out of range");
         cs = *c; device = dev; pimple = c->solver == FY_SOLVER_PIMPLE;
+        cs.hx = cs.hy = cs.hz = nullptr;        // (the caller's arrays are copied below, not kept)
         comm = cm ? cm : &self_comm;
         FY_HIP(hipSetDevice(device));
         FY_HIP(hipStreamCreate(&stream));
@@ -151,6 +169,25 @@ struct Solver {
         Nglob = (int64_t)plane * c->nz;
         g.nx = c->nx; g.ny = c->ny; g.nz = nzl; g.Nc = Nc; g.gz = gz; g.c0 = (int)(plane * gz); g.kglob0 = comm->rank * nzl; g.nzglob = c->nz;
         g.dx = c->dx; g.Af = c->dx * c->dx; g.V = c->dx * c->dx * c->dx;
+        g.graded = 0; g.h[0] = g.h[1] = g.h[2] = nullptr;
+        total_volume = g.V * (double)Nglob;
+        if (gradedc) {
+            const double* hh[3] = {c->hx, c->hy, c->hz};
+            const int nn[3] = {c->nx, c->ny, c->nz};
+            double len[3] = {0, 0, 0};
+            for (int a = 0; a < 3; ++a) {
+                h_host[a].assign(hh[a], hh[a] + nn[a]);
+                for (double v : h_host[a]) len[a] += v;
+                FY_TRY(d_h[a].alloc_exact((size_t)nn[a]));
+                FY_HIP(hipMemcpyAsync(d_h[a].p, hh[a], (size_t)nn[a] * sizeof(double), hipMemcpyHostToDevice, stream));
+                g.h[a] = d_h[a].p;
+            }
+            FY_HIP(hipStreamSynchronize(stream));
+            g.graded = 1;
+            g.dx = std::cbrt((h_host[0][0] * h_host[1][0]) * h_host[2][0]);       // (only what still assumes cubes reads it: nothing on this path)
+            g.Af = g.dx * g.dx; g.V = g.dx * g.dx * g.dx;
+            total_volume = (len[0] * len[1]) * len[2];
+        }
         g.upwind = c->convection_scheme;          // 0 linear, 1 upwind, 2 linearUpwind
         g.rdx = 1.0 / g.dx; g.rhdx = 1.0 / (0.5 * g.dx); g.rV = 1.0 / g.V;
         g.pimple = pimple ? 1 : 0; g.dt = c->dt; g.nu = c->nu;
@@ -326,15 +363,31 @@ struct Solver {
         {
             const size_t ng = (size_t)Nglob;
             std::vector<double> C(3 * ng), V(ng, g.V);
-            for (int k = 0; k < c->nz; ++k) for (int j = 0; j < g.ny; ++j) for (int i = 0; i < g.nx; ++i) {
-                const size_t cc = (size_t)i + (size_t)g.nx * (j + (size_t)g.ny * k);
-                C[3 * cc] = c->origin[0] + (i + 0.5) * c->dx; C[3 * cc + 1] = c->origin[1] + (j + 0.5) * c->dx; C[3 * cc + 2] = c->origin[2] + (k + 0.5) * c->dx;
-            }
+            std::vector<double> fc[3];           // graded block: face planes per axis
             fy_mesh_desc md{};
+            if (!g.graded) {
+                for (int k = 0; k < c->nz; ++k) for (int j = 0; j < g.ny; ++j) for (int i = 0; i < g.nx; ++i) {
+                    const size_t cc = (size_t)i + (size_t)g.nx * (j + (size_t)g.ny * k);
+                    C[3 * cc] = c->origin[0] + (i + 0.5) * c->dx; C[3 * cc + 1] = c->origin[1] + (j + 0.5) * c->dx; C[3 * cc + 2] = c->origin[2] + (k + 0.5) * c->dx;
+                }
+                md.bbox_max[0] = c->origin[0] + g.nx * c->dx; md.bbox_max[1] = c->origin[1] + g.ny * c->dx; md.bbox_max[2] = c->origin[2] + c->nz * c->dx;
+            } else {
+                for (int a = 0; a < 3; ++a) {
+                    fc[a].resize(h_host[a].size() + 1);
+                    fc[a][0] = c->origin[a];
+                    for (size_t q = 0; q < h_host[a].size(); ++q) fc[a][q + 1] = fc[a][q] + h_host[a][q];
+                    md.bbox_max[a] = fc[a].back();
+                }
+                for (int k = 0; k < c->nz; ++k) for (int j = 0; j < g.ny; ++j) for (int i = 0; i < g.nx; ++i) {
+                    const size_t cc = (size_t)i + (size_t)g.nx * (j + (size_t)g.ny * k);
+                    C[3 * cc] = 0.5 * (fc[0][i] + fc[0][i + 1]); C[3 * cc + 1] = 0.5 * (fc[1][j] + fc[1][j + 1]); C[3 * cc + 2] = 0.5 * (fc[2][k] + fc[2][k + 1]);
+                    V[cc] = (h_host[0][i] * h_host[1][j]) * h_host[2][k];
+                }
+                md.xf = fc[0].data(); md.yf = fc[1].data(); md.zf = fc[2].data();
+            }
             md.n_cells = (int32_t)Nglob; md.centres = C.data(); md.volumes = V.data();
-            md.nx = g.nx; md.ny = g.ny; md.nz = c->nz; md.dx = c->dx;
+            md.nx = g.nx; md.ny = g.ny; md.nz = c->nz; md.dx = g.dx;
             for (int a = 0; a < 3; ++a) { md.origin[a] = c->origin[a]; md.bbox_min[a] = c->origin[a]; }
-            md.bbox_max[0] = c->origin[0] + g.nx * c->dx; md.bbox_max[1] = c->origin[1] + g.ny * c->dx; md.bbox_max[2] = c->origin[2] + c->nz * c->dx;
             fy_field_ptrs fp{};
             fp.location = FY_MEM_DEVICE;
             fp.U = U.p; fp.gradP = gradP.p; fp.vGrad = vGrad.p; fp.divT = divT.p; fp.ddtU = ddtU.p;
@@ -352,7 +405,7 @@ struct Solver {
             cpl->c.rhoP = c->rho_particle; cpl->c.rhoF = c->rho_fluid; cpl->c.nu = c->nu;   // setScalarProperties (icoFoamYade.C:55)
         }
         FY_TRY(halo_cells(U, 3, 1));
-        FY_TRY(launch_flux_of(stream, g, U.p, F3(phi)));                     // createPhi
+        FY_TRY(FVK(launch_flux_of, stream, g, U.p, F3(phi)));                     // createPhi
         FY_HIP(hipStreamSynchronize(stream));
         return FY_OK;
     }
@@ -441,7 +494,7 @@ struct Solver {
         for (;;) {
             FY_TRY(halo(xc, 3, plane, g.nz, g.gz, 1));
             kc[KC_MOM_PASS].begin(stream);
-            FY_TRY(launch_mom_pass(stream, g, M7(), rhs, xc, xn, xbar3.p, (double)Nglob, partials.p));
+            FY_TRY(FVK(launch_mom_pass, stream, g, M7(), rhs, xc, xn, xbar3.p, (double)Nglob, partials.p));
             kc[KC_MOM_PASS].end(stream);
             FY_TRY(reduce_read(6, false, h));
             if (it == 0) for (int q = 0; q < 3; ++q) { norm[q] = h[3 + q] + 1e-20; res0[q] = h[q] / norm[q]; }
@@ -674,29 +727,29 @@ struct Solver {
     // ---- one PISO / PIMPLE corrector (icoFoamYade.C:97-140, pEqn.H) ----------------------------------------------------
     int corrector(bool final_inner) {
         FY_TRY(halo_cells(U, 3, 1));
-        FY_TRY(launch_HbyA(stream, g, M7(), src.p, U.p, rAU.p, HbyA.p));
+        FY_TRY(FVK(launch_HbyA, stream, g, M7(), src.p, U.p, rAU.p, HbyA.p));
         // rAU (hence rAUf and the pressure matrix rAUf*alphaf) belongs to the momentum matrix: it only changes when that is assembled,
         // not between the PISO correctors of one assembly
-        if (!pimple && rAU_new) { FY_TRY(halo_cells(rAU, 1, 1)); FY_TRY(launch_interp_rAU(stream, g, rAU.p, F3(rAUf))); }
+        if (!pimple && rAU_new) { FY_TRY(halo_cells(rAU, 1, 1)); FY_TRY(FVK(launch_interp_rAU, stream, g, rAU.p, F3(rAUf))); }
         FY_TRY(halo_cells(HbyA, 3, 1));
-        FY_TRY(launch_phiHbyA(stream, g, HbyA.p, U.p, Uold.p, C3(phiOld), C3(rAUf), C3(alphaf), C3(phiForces), F3(phiHbyA), F3(psn)));
+        FY_TRY(FVK(launch_phiHbyA, stream, g, HbyA.p, U.p, Uold.p, C3(phiOld), C3(rAUf), C3(alphaf), C3(phiForces), F3(phiHbyA), F3(psn)));
         if (adjust_phi) {                                       // icoFoamYade.C:108, pEqn.H:13-16
-            FY_TRY(launch_adjust_phi_sums(stream, g, C3(phiHbyA), C3(phiForces), partials.p));
+            FY_TRY(FVK(launch_adjust_phi_sums, stream, g, C3(phiHbyA), C3(phiForces), partials.p));
             FY_TRY(launch_reduce_finalize(stream, partials.p, Nc, 4, nullptr, adj_sums.p));
             FY_TRY(comm->allreduce(stream, adj_sums.p, 4, false));
-            FY_TRY(launch_adjust_phi_apply(stream, g, adj_sums.p, F3(phiHbyA), C3(phiForces), C3(rAUf), U.p, F3(psn), adj_err.p));
+            FY_TRY(FVK(launch_adjust_phi_apply, stream, g, adj_sums.p, F3(phiHbyA), C3(phiForces), C3(rAUf), U.p, F3(psn), adj_err.p));
         }
         MgLev& L = *mg[0];
         clk_pres.begin(stream);
         for (int no = 0; no <= cs.n_non_orth_correctors; ++no) {
-            FY_TRY(launch_assemble_pressure(stream, g, C3(phiHbyA), C3(rAUf), C3(alphaf), C3(psn), alpha.p, /* alphaOld */ alpha.p, L.A, prhs.p));
-            if (L.distributed && comm->has_down()) FY_TRY(launch_p_ghost_uz(stream, g, C3(rAUf), C3(alphaf), L.A));
+            FY_TRY(FVK(launch_assemble_pressure, stream, g, C3(phiHbyA), C3(rAUf), C3(alphaf), C3(psn), alpha.p, /* alphaOld */ alpha.p, L.A, prhs.p));
+            if (L.distributed && comm->has_down()) FY_TRY(FVK(launch_p_ghost_uz, stream, g, C3(rAUf), C3(alphaf), L.A));
             if (rAU_new) FY_TRY(build_coarse_operators());        // same matrix as in the previous corrector otherwise: only the right-hand side moved
             rAU_new = false;
             FY_TRY(solve_pressure(final_inner && no == cs.n_non_orth_correctors));
             if (no == cs.n_non_orth_correctors) {
                 FY_TRY(halo_cells(p, 1, 1));
-                FY_TRY(launch_flux_correct(stream, g, p.p, C3(phiHbyA), C3(rAUf), C3(alphaf), C3(psn), F3(pflux), F3(phi)));
+                FY_TRY(FVK(launch_flux_correct, stream, g, p.p, C3(phiHbyA), C3(rAUf), C3(alphaf), C3(psn), F3(pflux), F3(phi)));
                 phi_fresh = true;
                 // p.relax() (pEqn.H:41): after the flux, which keeps the unrelaxed solution; the velocity correction below works with
                 // pEqn.flux() (pflux), not with grad(p), so only the carried pressure field is relaxed
@@ -709,7 +762,7 @@ struct Solver {
         if (fuse_diag && red_host && n_deferred + 4 <= kDeferMax) {
             // the continuity errors and the NEXT step's Courant sums ride on the velocity correction's sweep
             // (k_U_correct<true>; same values as k_cont_err / k_courant) instead of being two sweeps of their own
-            FY_TRY(launch_U_correct_diag(stream, g, HbyA.p, rAU.p, p.p, C3(psn), C3(phiForces), C3(pflux), C3(alphaf), C3(rAUf), U.p, C3(phi), alpha.p,
+            FY_TRY(FVK(launch_U_correct_diag, stream, g, HbyA.p, rAU.p, p.p, C3(psn), C3(phiForces), C3(pflux), C3(alphaf), C3(rAUf), U.p, C3(phi), alpha.p,
                                          /* alphaOld */ alpha.p, partials.p));
             if (!reduce_deferred(4, false, &slot, &rc, ops_diag.p)) return fail(FY_ERR_INVALID, "no room for the deferred diagnostics");
             FY_TRY(rc);
@@ -718,10 +771,10 @@ struct Solver {
             return FY_OK;
         }
         carry_slot = -1;
-        FY_TRY(launch_cont_err(stream, g, C3(phi), C3(alphaf), alpha.p, /* alphaOld */ alpha.p, partials.p));
+        FY_TRY(FVK(launch_cont_err, stream, g, C3(phi), C3(alphaf), alpha.p, /* alphaOld */ alpha.p, partials.p));
         if (reduce_deferred(2, false, &slot, &rc)) { FY_TRY(rc); cont_slots.push_back(slot); }
         else { FY_TRY(reduce_read(2, false, h)); note_cont_err(h); }
-        FY_TRY(launch_U_correct(stream, g, HbyA.p, rAU.p, p.p, C3(psn), C3(phiForces), C3(pflux), C3(alphaf), C3(rAUf), U.p));
+        FY_TRY(FVK(launch_U_correct, stream, g, HbyA.p, rAU.p, p.p, C3(psn), C3(phiForces), C3(pflux), C3(alphaf), C3(rAUf), U.p));
         return FY_OK;
     }
     // Courant sums of the flux the last corrector left (max sumPhi/V, sum sumPhi), formed by k_U_correct<true>: what CourantNo.H at the top
@@ -734,16 +787,16 @@ struct Solver {
     std::vector<int> cont_slots;     // deferred continuity-error read-backs of this step, in corrector order
     int courant_slot = -1;
     void note_cont_err(const double* h) {      // continuityErrs.H:36-46
-        const double tv = g.V * (double)Nglob;
+        const double tv = total_volume;
         st.cont_err_sum_local = cs.dt * h[0] / tv; st.cont_err_global = cs.dt * h[1] / tv;
         cumulative_cont_err += st.cont_err_global; st.cont_err_cumulative = cumulative_cont_err;
     }
-    void note_courant(const double* h) { st.courant_max = 0.5 * h[0] * cs.dt; st.courant_mean = 0.5 * (h[1] / (g.V * (double)Nglob)) * cs.dt; }
+    void note_courant(const double* h) { st.courant_max = 0.5 * h[0] * cs.dt; st.courant_mean = 0.5 * (h[1] / total_volume) * cs.dt; }
 
     // continuousPhaseTurbulence->correct() for LES Smagorinsky: nut from the Gauss-linear gradient of the corrected velocity
     int turbulence_correct() {
         FY_TRY(halo_cells(U, 3, 1));
-        FY_TRY(launch_pre_coupling(stream, g, U.p, p.p, alpha.p, C3(psn), vGrad.p, gradP.p, divT.p, nullptr, 1, 0));
+        FY_TRY(FVK(launch_pre_coupling, stream, g, U.p, p.p, alpha.p, C3(psn), vGrad.p, gradP.p, divT.p, nullptr, 1, 0));
         if (cs.turbulence_model == FY_TURBULENCE_KEQN || cs.turbulence_model == FY_TURBULENCE_KEPSILON) {
             // kEqn::correct() / kEpsilon::correct(): each transport equation is assembled into the momentum matrix's storage and solved by the
             // momentum solver's pass as a 3-component system whose last two components are identically zero (HbyA / bmom / xscr are free
@@ -753,22 +806,22 @@ struct Solver {
             FY_TRY(halo_cells(kturb, 1, 1));
             if (keps) {
                 FY_TRY(halo_cells(epsturb, 1, 1));
-                FY_TRY(launch_assemble_turb(stream, g, eq_eps, kturb.p, epsturb.p, alpha.p, C3(alphaf), C3(phi), vGrad.p, U.p, M7(), bmom.p, HbyA.p));
+                FY_TRY(FVK(launch_assemble_turb, stream, g, eq_eps, kturb.p, epsturb.p, alpha.p, C3(alphaf), C3(phi), vGrad.p, U.p, M7(), bmom.p, HbyA.p));
                 FY_TRY(solve_vec3(HbyA, bmom.p, cs.eps_tol, cs.eps_rel_tol, cs.eps_max_iter, &it));
                 st_k_iters += it;
                 FY_TRY(halo_cells(HbyA, 3, 1));
-                FY_TRY(launch_turb_finish(stream, g, eq_eps, HbyA.p, epsturb.p, 0, 0.0, nullptr, nullptr));
+                FY_TRY(FVK(launch_turb_finish, stream, g, eq_eps, HbyA.p, epsturb.p, 0, 0.0, nullptr, nullptr));
             }
-            FY_TRY(launch_assemble_turb(stream, g, eq_k, kturb.p, epsturb.p, alpha.p, C3(alphaf), C3(phi), vGrad.p, U.p, M7(), bmom.p, HbyA.p));
+            FY_TRY(FVK(launch_assemble_turb, stream, g, eq_k, kturb.p, epsturb.p, alpha.p, C3(alphaf), C3(phi), vGrad.p, U.p, M7(), bmom.p, HbyA.p));
             FY_TRY(solve_vec3(HbyA, bmom.p, cs.k_tol, cs.k_rel_tol, cs.k_max_iter, &it));
             st_k_iters += it;
             FY_TRY(halo_cells(HbyA, 3, 1));
-            FY_TRY(launch_turb_finish(stream, g, eq_k, HbyA.p, kturb.p, keps ? 2 : 1, cs.ras_cmu, epsturb.p, nut.p));
+            FY_TRY(FVK(launch_turb_finish, stream, g, eq_k, HbyA.p, kturb.p, keps ? 2 : 1, cs.ras_cmu, epsturb.p, nut.p));
             FY_TRY(halo_cells(kturb, 1, 1));
             g.nut_wall_live = 1;              // correctNut(): from now on the wall-function patches carry nut_w(k), not the file's value
             return halo_cells(nut, 1, 1);
         }
-        FY_TRY(launch_smagorinsky_nut(stream, g, vGrad.p, cs.les_ck, cs.les_ce, les_delta, nut.p));
+        FY_TRY(FVK(launch_smagorinsky_nut, stream, g, vGrad.p, cs.les_ck, cs.les_ce, les_delta, nut.p));
         return halo_cells(nut, 1, 1);
     }
     int st_k_iters = 0;
@@ -783,7 +836,7 @@ struct Solver {
         double h[2];
         const bool carried = carry_valid;                                                      // the previous pass's last corrector already summed |phi|
         carry_valid = false; carry_slot = -1;
-        if (!carried) FY_TRY(launch_courant(stream, g, C3(phi), partials.p));                 // icoFoamYade.C:68, pimpleFoamYade.C:63
+        if (!carried) FY_TRY(FVK(launch_courant, stream, g, C3(phi), partials.p));                 // icoFoamYade.C:68, pimpleFoamYade.C:63
         n_deferred = 0; cont_slots.clear(); courant_slot = -1;
         if (carried) note_courant(carry_h);
         if (cs.adjust_time_step) {
@@ -827,7 +880,7 @@ struct Solver {
         // the opt-in force models (fy_set_force_models on fy_solver_coupling()) read vGrad / ddtU_f, which the shipped path never does
         const unsigned fm = cpl->c.force_models;
         const bool want_vgrad = !pimple || (fm & FY_FORCE_GAUSSIAN_TORQUE), want_ddtU = pimple && (fm & FY_FORCE_ADDED_MASS);
-        FY_TRY(launch_pre_coupling(stream, g, U.p, p.p, alpha.p, C3(psn), vGrad.p, gradP.p, divT.p, nullptr, want_vgrad ? 1 : 0, 1, phi_now(),
+        FY_TRY(FVK(launch_pre_coupling, stream, g, U.p, p.p, alpha.p, C3(psn), vGrad.p, gradP.p, divT.p, nullptr, want_vgrad ? 1 : 0, 1, phi_now(),
                                    want_ddtU ? ddtU.p : nullptr, fuse_uold ? Uold.p : nullptr));
 
         if (timing) tim[0].start(stream);
@@ -845,7 +898,7 @@ struct Solver {
         // FoamYade wrote alpha through untracked operator[]: old == current, fvc::ddt(alphac) == 0.
         // The kernels keep their alphaOld argument (the term is written out as in UcEqn.H:5 / pEqn.H:30); it is handed the same array
         // -- what a copy taken here would hold, without the copy or a second stream of reads.
-        if (pimple) FY_TRY(launch_interp_alpha(stream, g, alpha.p, F3(alphaf)));              // pimpleFoamYade.C:83-85 (alpha ghosts refreshed by the coupling)
+        if (pimple) FY_TRY(FVK(launch_interp_alpha, stream, g, alpha.p, F3(alphaf)));              // pimpleFoamYade.C:83-85 (alpha ghosts refreshed by the coupling)
         const int nOuter = pimple ? std::max(cs.n_outer_correctors, 1) : 1;
         for (int outer = 0; outer < nOuter; ++outer) {
             // pimple.loop() marks the last outer corrector "finalIteration": relax() then prefers the <name>Final factors [OF-6], and
@@ -861,20 +914,20 @@ struct Solver {
             if (pimple) {
                 // explicit stress term of divDevRhoReff from the CURRENT U and this step's alpha (one fused stencil pass)
                 if (outer > 0) FY_TRY(halo_cells(U, 3, 1));
-                FY_TRY(launch_pre_coupling(stream, g, U.p, p.p, alpha.p, C3(psn), vGrad.p, gradP.p, divT.p, Gt.p, g.upwind == 2 ? 1 : 0, 0));
+                FY_TRY(FVK(launch_pre_coupling, stream, g, U.p, p.p, alpha.p, C3(psn), vGrad.p, gradP.p, divT.p, Gt.p, g.upwind == 2 ? 1 : 0, 0));
                 FY_TRY(halo(Gt.p + 2 * 3 * nstore, 3, plane, g.nz, g.gz, 1));     // G is stored by rows; only row z is read across the slab faces
-                FY_TRY(launch_div_G(stream, g, Gt.p, divG.p));
+                FY_TRY(FVK(launch_div_G, stream, g, Gt.p, divG.p));
             }
             if (g.upwind == 2) FY_TRY(halo_cells(vGrad, 9, 1));      // linearUpwind reads grad(U) of the upwind neighbour (ico: written at step start)
-            FY_TRY(launch_assemble_momentum(stream, g, U.p, Uold.p, alpha.p, /* alphaOld */ alpha.p, C3(alphaf), phi_now(), uSource.p, uSourceDrag.p,
+            FY_TRY(FVK(launch_assemble_momentum, stream, g, U.p, Uold.p, alpha.p, /* alphaOld */ alpha.p, C3(alphaf), phi_now(), uSource.p, uSourceDrag.p,
                                             divG.p, vGrad.p, M7(), src.p, rAU.p));
             rAU_new = true;
             if (pimple) {
                 FY_TRY(halo_cells(rAU, 1, 1));
-                FY_TRY(launch_rAUf_phi_forces(stream, g, rAU.p, uSource.p, F3(rAUf), F3(phiForces)));  // uSource ghosts refreshed by the coupling
+                FY_TRY(FVK(launch_rAUf_phi_forces, stream, g, rAU.p, uSource.p, F3(rAUf), F3(phiForces)));  // uSource ghosts refreshed by the coupling
             }
             if (cs.momentum_predictor) {
-                FY_TRY(launch_bmom(stream, g, src.p, p.p, C3(psn), C3(phiForces), C3(rAUf), bmom.p));
+                FY_TRY(FVK(launch_bmom, stream, g, src.p, p.p, C3(psn), C3(phiForces), C3(rAUf), bmom.p));
                 int it = 0;
                 FY_TRY(solve_momentum(&it));
                 st.u_iters_total += it;

@@ -1230,6 +1230,12 @@ __global__ __launch_bounds__(256) void k_unpack_stencils(ParticleSoA p, int64_t 
 }
 
 // ------------------------------------------------------------------------------------------------ point force
+// index q with f[q] <= x < f[q + 1] by bisection over the n + 1 face planes of one axis (x inside [f[0], f[n]] is the caller's business)
+__device__ __forceinline__ int axis_cell(const double* __restrict__ f, int n, double x) {
+    int lo = 0, hi = n;                        // invariant: f[lo] <= x, and x < f[hi] or hi == n
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (f[mid] <= x) lo = mid; else hi = mid; }
+    return lo;
+}
 __global__ __launch_bounds__(256) void k_point_force(const double* __restrict__ rec, int64_t n, BlockGeom g, ForceParams fp, CellWindow cw,
                                                      const double* __restrict__ vol, const double* __restrict__ U,
                                                      const double* __restrict__ vGrad, double* __restrict__ uSource,
@@ -1248,9 +1254,14 @@ __global__ __launch_bounds__(256) void k_point_force(const double* __restrict__ 
         incell_out[i] = -1;
         return;
     }
-    const int ci = min(g.nx - 1, (int)((x - g.bbmin[0]) / g.dx));
-    const int cj = min(g.ny - 1, (int)((y - g.bbmin[1]) / g.dx));
-    const int ck = min(g.nz - 1, (int)((z - g.bbmin[2]) / g.dx));
+    int ci, cj, ck;
+    if (g.faces[0]) {              // graded block: the cell whose [low, high) face planes hold the coordinate (the last cell takes its high plane too)
+        ci = axis_cell(g.faces[0], g.nx, x); cj = axis_cell(g.faces[1], g.ny, y); ck = axis_cell(g.faces[2], g.nz, z);
+    } else {
+        ci = min(g.nx - 1, (int)((x - g.bbmin[0]) / g.dx));
+        cj = min(g.ny - 1, (int)((y - g.bbmin[1]) / g.dx));
+        ck = min(g.nz - 1, (int)((z - g.bbmin[2]) / g.dx));
+    }
     if (own.active && (ck < own.k0 || ck >= own.k1)) {         // in another slab's planes: that rank owns it
         F[0] = F[1] = F[2] = F[3] = F[4] = F[5] = 0.0;
         found_out[i] = -1;

@@ -150,6 +150,7 @@ int launch_unpack_stencils(hipStream_t s, ParticleSoA p, int64_t n, int32_t* k, 
 struct BlockGeom {
     double bbmin[3], bbmax[3], dx;
     int nx, ny, nz;
+    const double* faces[3];        // graded block: coordinates of the n + 1 face planes per axis (device); null = uniform block
 };
 int launch_point_force(hipStream_t s, const double* rec, int64_t n, BlockGeom g, ForceParams fp, CellWindow cw, const double* vol,
                        const double* U, const double* vGrad, double* uSource, double* force_out, int32_t* found_out,
