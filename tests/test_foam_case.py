@@ -55,8 +55,8 @@ def test_bed_case_is_read_like_pimpleFoamYade_would(prod):
 
 
 @pytest.mark.parametrize("edit,needle", [
-    (("system/blockMeshDict", "simpleGrading (1 1 1)", "simpleGrading (2 1 1)"), "graded"),
-    (("system/blockMeshDict", "(16 16 16)", "(16 16 8)"), "cubes"),
+    (("system/blockMeshDict", "simpleGrading (1 1 1)", "simpleGrading (((0.5 0.5 4) (0.5 0.5 0.25)) 1 1)"), "multi-grading"),
+    (("system/blockMeshDict", "simpleGrading (1 1 1)", "edgeGrading (1 1 1 1 1 1 1 1 1 1 1 1)"), "edgeGrading"),
     (("system/blockMeshDict", "(3 7 6 2)", "(3 7 6 1)"), "not a side"),
     (("0/U", "noSlip", "slip"), "not supported"),
     (("0/p", "type            zeroGradient;", "type            totalPressure;"), "not supported"),
@@ -78,6 +78,51 @@ def test_what_is_outside_the_supported_subset_is_refused_by_name(prod, tmp_path,
     with pytest.raises(prod.FoamYadeError) as e:
         prod.FoamCase(dst, prod.FY_SOLVER_ICO)
     assert needle in str(e.value) and rel.split("/")[-1] in str(e.value)
+
+
+def test_simple_grading_is_read_as_a_geometric_progression(prod, tmp_path):
+    """blockMeshDict simpleGrading (ex ey ez): last / first cell size per direction, geometric in between [OF-6 blockMesh lineDivide]; cells that
+    are uniform but not cubes come out as a (trivially) graded block as well"""
+    dst = tmp_path / "case"
+    shutil.copytree(os.path.join(CASES, "cavity_ico"), dst)
+    text = (dst / "system/blockMeshDict").read_text()
+    (dst / "system/blockMeshDict").write_text(text.replace("simpleGrading (1 1 1)", "simpleGrading (4 0.25 1)", 1).replace("(16 16 16)", "(16 16 8)", 1))
+    fc = prod.FoamCase(dst, prod.FY_SOLVER_ICO)
+    c = fc.case
+    assert (c.nx, c.ny, c.nz) == (16, 16, 8) and bool(c.hx) and bool(c.hy) and bool(c.hz)
+    hx = np.array([c.hx[q] for q in range(16)]); hy = np.array([c.hy[q] for q in range(16)]); hz = np.array([c.hz[q] for q in range(8)])
+    L = 16 * 0.1 / 16                                                      # the cavity fixture's edge
+    np.testing.assert_allclose([hx.sum(), hy.sum(), hz.sum()], [L, L, L], rtol=1e-13)
+    np.testing.assert_allclose(hx[-1] / hx[0], 4.0, rtol=1e-12); np.testing.assert_allclose(hy[-1] / hy[0], 0.25, rtol=1e-12)
+    np.testing.assert_allclose(hx[1:] / hx[:-1], 4.0 ** (1 / 15), rtol=1e-12)
+    np.testing.assert_allclose(hz, L / 8, rtol=1e-13)                       # uniform, twice as thick as a cube would be
+    fc.close()
+
+
+@pytest.mark.gpu
+def test_graded_case_directory_runs_like_the_hand_built_graded_case(prod, tmp_path):
+    """a cavity case whose blockMeshDict grades the block towards two walls: the run started from the directory equals the run of the same
+    fy_case_desc built by hand with the same cell sizes"""
+    dst = tmp_path / "case"
+    shutil.copytree(os.path.join(CASES, "cavity_ico"), dst)
+    text = (dst / "system/blockMeshDict").read_text()
+    (dst / "system/blockMeshDict").write_text(text.replace("simpleGrading (1 1 1)", "simpleGrading (3 0.5 1)", 1))
+    fc = prod.FoamCase(dst, prod.FY_SOLVER_ICO)
+    c = fc.case
+    g = tuple(np.array([h[q] for q in range(n)]) for h, n in ((c.hx, c.nx), (c.hy, c.ny), (c.hz, c.nz)))
+    s = prod.Solver(c)
+    U0, p0 = fc.initial_fields()
+    s.set("U", U0); s.set("p", p0)
+    ref = prod.Solver(prod.make_case(0, c.nx, c.ny, c.nz, c.dx, c.dt, c.nu, rho_f=c.rho_fluid, rho_p=c.rho_particle, g=tuple(c.g),
+                                     u_bc=list(c.u_bc), u_val=[tuple(c.u_value[q]) for q in range(6)], p_bc=list(c.p_bc), p_val=list(c.p_value),
+                                     origin=tuple(c.origin), n_correctors=c.n_correctors, p_solver=c.p_solver, p_tol=c.p_tol, p_rel_tol=c.p_rel_tol,
+                                     p_final_tol=c.p_final_tol, p_final_rel_tol=c.p_final_rel_tol, u_tol=c.u_tol, u_rel_tol=c.u_rel_tol, grading=g))
+    for _ in range(5):
+        s.step(); ref.step()
+    for nm in ("U", "p"):
+        np.testing.assert_array_equal(s.get(nm), ref.get(nm))
+    assert np.abs(s.get("U")).max() > 0.05
+    s.close(); ref.close(); fc.close()
 
 
 @pytest.mark.gpu

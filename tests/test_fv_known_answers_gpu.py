@@ -114,3 +114,36 @@ def test_corrected_flux_is_divergence_free_to_solver_tolerance_hip(product):
         s.step()
     flux_identity(s, n, 0.4 / n)
     s.close()
+
+
+def test_graded_poiseuille_on_a_wall_refined_mesh_hip(product):
+    """the graded-block kernels held to physics on their own (no oracle in the loop): pressure-driven plane channel on meshes refined towards
+    both walls (last / first size ratio 5) -- second-order approach to the parabola, and the discrete wall shear carries the driving force
+    exactly (conservation)"""
+    def sizes(n, ratio, length):
+        r = ratio ** (1.0 / (n // 2 - 1))
+        h = r ** np.arange(n // 2)
+        h *= 0.5 * length / h.sum()
+        return np.concatenate([h, h[::-1]])
+    nu, G = 0.05, 0.4
+    U_, ZG = product.FY_BC_U_FIXED_VALUE, product.FY_BC_U_ZERO_GRADIENT
+    PZ, PF = product.FY_BC_P_ZERO_GRADIENT, product.FY_BC_P_FIXED_VALUE
+    errs = {}
+    for ny in (16, 32):
+        nx, nz = 4, 2
+        hy = sizes(ny, 5.0, 1.0)
+        hx, hz = np.full(nx, 0.1), np.full(nz, 0.1)
+        L = hx.sum()
+        c = product.make_case(0, nx, ny, nz, 0.1, 0.02, nu, u_bc=[ZG, ZG, U_, U_, ZG, ZG], p_bc=[PF, PF, PZ, PZ, PZ, PZ], p_val=[G * L, 0.0, 0, 0, 0, 0],
+                              u_tol=1e-10, p_tol=1e-10, p_final_tol=1e-10, grading=(hx, hy, hz))
+        s = product.Solver(c)
+        for _ in range(2500):
+            s.step()
+        U = s.get("U").reshape(nz, ny, nx, 3)
+        yc = np.cumsum(hy) - 0.5 * hy
+        exact = G / (2 * nu) * yc * (1.0 - yc)
+        errs[ny] = np.abs(U[0, :, nx // 2, 0] - exact).max() / exact.max()
+        assert np.abs(U[..., 1]).max() < 1e-7 and np.abs(U[..., 2]).max() < 1e-7
+        assert abs(U[0, 0, nx // 2, 0] / yc[0] - G / (2 * nu)) < 1e-7 * G / (2 * nu)
+        s.close()
+    assert errs[32] < 0.3 * errs[16] and errs[32] < 5e-3, errs

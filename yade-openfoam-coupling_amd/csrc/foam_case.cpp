@@ -28,6 +28,7 @@ struct fy_foam_case {
     double start_time = 0, end_time = 0;
     int write_interval_steps = 0;
     std::string patch_of_side[6];               // blockMesh patch name covering XMIN, XMAX, YMIN, YMAX, ZMIN, ZMAX
+    std::vector<double> grading[3];             // graded block: cell sizes per axis (fy_case_desc.hx / hy / hz point here)
     std::vector<std::string> patch_order;       // patch names in blockMeshDict order (one side each here)
     std::string u_bc_text[6], p_bc_text[6];     // the boundaryField entries as read, re-emitted on write
     std::vector<double> U0, p0, nut0, k0, eps0; // internalField of the start time (nut0, k0, eps0: turbulence cases only)
@@ -99,8 +100,15 @@ int read_block_mesh(fy_foam_case* c) {
     if ((*bt)[i++] != ")" || (*bt)[i++] != "(") return fail(FY_ERR_INVALID, "%s: malformed hex cell counts", path.c_str());
     for (int q = 0; q < 3; ++q) { double x; if (!fy::foam_tok_is_number((*bt)[i++], &x)) return fail(FY_ERR_INVALID, "%s: malformed hex cell counts", path.c_str()); nn[q] = (int)x; }
     if ((*bt)[i++] != ")") return fail(FY_ERR_INVALID, "%s: malformed hex cell counts", path.c_str());
-    if ((*bt)[i] != "simpleGrading") return fail(FY_ERR_UNSUPPORTED, "%s: only simpleGrading (1 1 1) is supported", path.c_str());
-    for (size_t q = i + 2; q < i + 5 && q < bt->size(); ++q) { double g; if (!fy::foam_tok_is_number((*bt)[q], &g) || g != 1.0) return fail(FY_ERR_UNSUPPORTED, "%s: graded blocks are not supported (uniform cubes only)", path.c_str()); }
+    // simpleGrading (ex ey ez): per direction the ratio of the LAST cell's size to the FIRST one's; the sizes in between form a geometric
+    // progression [OF-6 blockMesh lineDivide].  Multi-grading lists ((fraction cells ratio) ...) and edgeGrading are refused.
+    if ((*bt)[i] != "simpleGrading") return fail(FY_ERR_UNSUPPORTED, "%s: only simpleGrading (ex ey ez) is supported (no edgeGrading)", path.c_str());
+    double expan[3] = {1, 1, 1};
+    if (i + 1 >= bt->size() || (*bt)[i + 1] != "(") return fail(FY_ERR_INVALID, "%s: malformed simpleGrading", path.c_str());
+    for (size_t q = i + 2; q < i + 5 && q < bt->size(); ++q) {
+        if (!fy::foam_tok_is_number((*bt)[q], &expan[q - i - 2]) || !(expan[q - i - 2] > 0))
+            return fail(FY_ERR_UNSUPPORTED, "%s: simpleGrading takes one positive expansion ratio per direction (multi-grading lists are not supported)", path.c_str());
+    }
     size_t close = i + 6;
     if (close >= bt->size() || (*bt)[close] != ")") return fail(FY_ERR_UNSUPPORTED, "%s: exactly one block is supported", path.c_str());
     for (int q = 0; q < 8; ++q) if (hv[q] < 0 || hv[q] > 7) return fail(FY_ERR_INVALID, "%s: hex vertex label out of range", path.c_str());
@@ -114,8 +122,23 @@ int read_block_mesh(fy_foam_case* c) {
             if (!near(P(q, a), P(0, a) + bits[q][a] * L[a], scl)) return fail(FY_ERR_UNSUPPORTED, "%s: the block must be an axis-aligned box with the standard hex vertex order", path.c_str());
     if (!(L[0] > 0 && L[1] > 0 && L[2] > 0) || nn[0] < 1 || nn[1] < 1 || nn[2] < 1) return fail(FY_ERR_INVALID, "%s: degenerate block", path.c_str());
     const double dx = L[0] / nn[0];
-    if (!near(L[1] / nn[1], dx, dx) || !near(L[2] / nn[2], dx, dx)) return fail(FY_ERR_UNSUPPORTED, "%s: cells must be cubes (dx = %g, dy = %g, dz = %g)", path.c_str(), dx, L[1] / nn[1], L[2] / nn[2]);
+    const bool cubes = expan[0] == 1.0 && expan[1] == 1.0 && expan[2] == 1.0 && near(L[1] / nn[1], dx, dx) && near(L[2] / nn[2], dx, dx);
     c->desc.nx = nn[0]; c->desc.ny = nn[1]; c->desc.nz = nn[2]; c->desc.dx = dx;
+    c->desc.hx = c->desc.hy = c->desc.hz = nullptr;
+    if (!cubes) {
+        // a graded block (or uniform cells that are not cubes): per-axis cell sizes, h_q = h_0 r^q with r = expansion^(1 / (n - 1)) and sum = L
+        for (int a = 0; a < 3; ++a) {
+            std::vector<double>& h = c->grading[a];
+            h.assign((size_t)nn[a], L[a] / nn[a]);
+            if (expan[a] != 1.0 && nn[a] > 1) {
+                const double r = std::pow(expan[a], 1.0 / (nn[a] - 1));
+                double sum = 0.0, w = 1.0;
+                for (int q = 0; q < nn[a]; ++q) { h[(size_t)q] = w; sum += w; w *= r; }
+                for (double& x : h) x *= L[a] / sum;
+            }
+        }
+        c->desc.hx = c->grading[0].data(); c->desc.hy = c->grading[1].data(); c->desc.hz = c->grading[2].data();
+    }
     for (int a = 0; a < 3; ++a) c->desc.origin[a] = P(0, a);
 
     const auto* bd = d.tokens("boundary");
