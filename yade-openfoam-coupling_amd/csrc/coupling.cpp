@@ -587,14 +587,17 @@ int Coupling::run_batch(Batch& b) {
         // The binned order only buys locality -- every result is independent of it -- and particles move a fraction of a cell per
         // coupling step, so the placement of an earlier step stays nearly as good: the counting sort runs every rebin_interval
         // steps (or when the particle count changes), in between the records are just gathered through the old permutation.
+        // With the candidate lists k_locate_deposit fetches the records through the placement itself (and leaves the SoA copy behind for
+        // the force pass): no separate gather pass
+        const bool fused_gather = use_implicit && d_loc_lists.p != nullptr;
         if (b.binned_n != b.n || b.bin_age >= rebin_interval) {
             FY_HIP(hipMemsetAsync(d_hist.p, 0, (size_t)bins.nkeys * sizeof(uint32_t), stream));
             FY_TRY(launch_bin_count(stream, b.d_rec, b.n, bins, b.key.p, b.rank.p, d_hist.p));
             FY_TRY(launch_exclusive_scan_u32(stream, d_hist.p, bins.nkeys, d_tile_sums.p));
-            FY_TRY(launch_bin_scatter(stream, b.d_rec, b.n, b.key.p, b.rank.p, d_hist.p, d_tile_sums.p, p));
+            FY_TRY(launch_bin_scatter(stream, b.d_rec, b.n, b.key.p, b.rank.p, d_hist.p, d_tile_sums.p, p, !fused_gather));
             b.binned_n = b.n; b.bin_age = 1;
         } else {
-            FY_TRY(launch_bin_gather(stream, b.d_rec, b.n, p));
+            if (!fused_gather) FY_TRY(launch_bin_gather(stream, b.d_rec, b.n, p));
             ++b.bin_age;
         }
         GaussParams gp;
@@ -613,7 +616,8 @@ int Coupling::run_batch(Batch& b) {
         FY_TRY(launch_tile_caps(stream, tbD, tbB));
         if (timing) marks.mark(1, stream);
         FY_TRY(launch_locate_deposit(stream, d_tree.p, use_implicit ? d_tree_packed.p : nullptr, implicit, n_cells, tree_levels, p, b.n, gp,
-                                     use_implicit ? d_loc_start.p : nullptr, slab_own(), ll, cw, d_pvol_acc.p, d_up_acc.p, d_touched.p, tbD, side));
+                                     use_implicit ? d_loc_start.p : nullptr, slab_own(), ll, cw, d_pvol_acc.p, d_up_acc.p, d_touched.p, tbD, side,
+                                     fused_gather ? b.d_rec : nullptr));
         if (timing) marks.mark(2, stream);
         // The force pass gathers U, alpha and the Archimedes term from one packed record per cell.  U / gradP / divT do not change during the
         // call and the alpha slot follows k_finalize_cells, so the records are built once per call -- here, where the pack runs beside the
@@ -681,7 +685,8 @@ int Coupling::set_particle_action(double dt) {
     // the force pass gathers U, alpha and the Archimedes term from one packed record per cell; U / gradP / divT do not change during
     // the call and alpha follows k_finalize_cells, so the records are built once here
     if (fields_on_host) { FY_TRY(stage_readonly_in()); FY_TRY(stage_mutable_in()); }
-    cellrec_fresh = false;
+    cellrec_fresh = cellrec_external;       // (fy_solver's pre-coupling sweep may have written the records already)
+    cellrec_external = false;
 
     // ---- receive particles, and per Yade proc: locate + deposit + finalize + force (FoamYade.C:609, 612-628).  With a transport every
     // batch is processed as soon as its records have landed, so the kernels of batch q run while the host waits for batch q + 1 on the

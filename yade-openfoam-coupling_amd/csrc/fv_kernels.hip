@@ -516,7 +516,8 @@ __global__ __launch_bounds__(256) void k_courant(FvGeo g, CFace3 phi, double* __
 __global__ __launch_bounds__(256) void k_pre_coupling(FvGeo g, const double* __restrict__ U, const double* __restrict__ p,
                                                       const double* __restrict__ alpha, CFace3 psn, double* __restrict__ vGrad,
                                                       double* __restrict__ gradP, double* __restrict__ divT, double* __restrict__ Gout,
-                                                      int write_vgrad, int write_pfields, CFace3 phi, double* __restrict__ ddtU, double* __restrict__ Uold_out) {
+                                                      int write_vgrad, int write_pfields, CFace3 phi, double* __restrict__ ddtU, double* __restrict__ Uold_out,
+                                                      double* __restrict__ cellrec, double rec_two_nu, double rec_rhoF) {
     const int t = swz_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
     if (t >= g.Nc) return;
     int i, j, k; ijk_of(g, t, i, j, k);
@@ -578,8 +579,19 @@ __global__ __launch_bounds__(256) void k_pre_coupling(FvGeo g, const double* __r
         for (int q = 0; q < 9; ++q) vGrad[9 * (size_t)c + q] = T[q];
     if (pf)
         for (int q = 0; q < 3; ++q) gradP[3 * (size_t)c + q] = gp3[q];
-    if (pf)
-        for (int q = 0; q < 3; ++q) divT[3 * (size_t)c + q] = 2 * g.nu * (lap[q] * geo_rV(g, i, j, k));
+    if (pf) {
+        double dT[3];
+        for (int q = 0; q < 3; ++q) { dT[q] = 2 * g.nu * (lap[q] * geo_rV(g, i, j, k)); divT[3 * (size_t)c + q] = dT[q]; }
+        if (cellrec) {
+            // the 64-byte record the force pass gathers per stencil cell, {U, alpha, 2 nu rho_f divT - gradP, V}, written from here instead of by
+            // a pass of its own over U / gradP / divT (k_pack_cells: same operands, same operations, same bits; single domain only)
+            double2* r = reinterpret_cast<double2*>(cellrec + 8 * (size_t)c);
+            r[0] = make_double2(uc[0], uc[1]);
+            r[1] = make_double2(uc[2], ac);
+            r[2] = make_double2(((rec_two_nu * dT[0]) * rec_rhoF) - gp3[0], ((rec_two_nu * dT[1]) * rec_rhoF) - gp3[1]);
+            r[3] = make_double2(((rec_two_nu * dT[2]) * rec_rhoF) - gp3[2], geo_V(g, i, j, k));
+        }
+    }
     if (Gout) {
         const double tr = T[0] + T[4] + T[8];
         const double an = g.nut ? alpha[c] * (g.nu + g.nut[c]) : alpha[c] * g.nu;      // alpha nuEff (nuEff = nut + nu [OF-6 eddyViscosity/linearViscousStress])
@@ -1727,9 +1739,10 @@ int launch_courant(hipStream_t s, FvGeo g, CFace3 phi, double* partials) {
 }
 
 int launch_pre_coupling(hipStream_t s, FvGeo g, const double* U, const double* p, const double* alpha, CFace3 psn, double* vGrad,
-                        double* gradP, double* divT, double* Gout, int write_vgrad, int write_pfields, CFace3 phi, double* ddtU, double* Uold_out) {
+                        double* gradP, double* divT, double* Gout, int write_vgrad, int write_pfields, CFace3 phi, double* ddtU, double* Uold_out,
+                        double* cellrec, double rec_nu, double rec_rhoF) {
     hipLaunchKernelGGL(k_pre_coupling, dim3(div_up(g.Nc, 256)), dim3(256), 0, s, g, U, p, alpha, psn, vGrad, gradP, divT, Gout, write_vgrad, write_pfields,
-                       phi, ddtU, Uold_out);
+                       phi, ddtU, Uold_out, cellrec, 2.0 * rec_nu, rec_rhoF);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }

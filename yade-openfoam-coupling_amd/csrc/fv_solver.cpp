@@ -880,8 +880,11 @@ struct Solver {
         // the opt-in force models (fy_set_force_models on fy_solver_coupling()) read vGrad / ddtU_f, which the shipped path never does
         const unsigned fm = cpl->c.force_models;
         const bool want_vgrad = !pimple || (fm & FY_FORCE_GAUSSIAN_TORQUE), want_ddtU = pimple && (fm & FY_FORCE_ADDED_MASS);
+        // single domain, Gaussian mode: the sweep also leaves the force pass's packed cell records (the coupling then skips its own pack pass)
+        double* rec_out = (pimple && comm->size == 1) ? cpl->c.d_cellrec.p : nullptr;
         FY_TRY(FVK(launch_pre_coupling, stream, g, U.p, p.p, alpha.p, C3(psn), vGrad.p, gradP.p, divT.p, nullptr, want_vgrad ? 1 : 0, 1, phi_now(),
-                                   want_ddtU ? ddtU.p : nullptr, fuse_uold ? Uold.p : nullptr));
+                                   want_ddtU ? ddtU.p : nullptr, fuse_uold ? Uold.p : nullptr, rec_out, cpl->c.nu, cpl->c.rhoF));
+        cpl->c.cellrec_external = rec_out != nullptr;
 
         if (timing) tim[0].start(stream);
         if (g.gz > 1) {                      // the particle gathers reach gz planes into the neighbours

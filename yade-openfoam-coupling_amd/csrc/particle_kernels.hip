@@ -826,9 +826,13 @@ __global__ __launch_bounds__(kDepThreads) void k_deposit(ParticleSoA p, int64_t 
 // node in a register (zero where the node did not enter the chain; slots are static because the scan is unrolled), so the chain's
 // squared distances never travel through memory: ids and NORMALISED weights are stored once, for k_force_gaussian.  Same arithmetic
 // as the two kernels: allwt adds the weights from the last push to the first (adding the zeros in between is exact).
+// rec != nullptr: the binned SoA arrays are not filled yet -- the lane fetches its wire record through the placement (p.orig) itself and
+// leaves the SoA copy behind for the force pass (k_bin_gather folded into this kernel: one launch and one coalesced read of the SoA less;
+// the record fetch is the same random 80-byte read either way)
 __global__ __launch_bounds__(kDepThreads) void k_locate_deposit(LocateLists ll, ImplicitGeom ig, ParticleSoA p, int64_t n,
                                                                  GaussParams gp, SlabOwn own, CellWindow cw, double* __restrict__ pvol_acc,
-                                                                 double* __restrict__ up_acc, unsigned char* __restrict__ touched, TileBuckets tb) {
+                                                                 double* __restrict__ up_acc, unsigned char* __restrict__ touched, TileBuckets tb,
+                                                                 const double* __restrict__ rec) {
     const unsigned short* __restrict__ lists = ll.lists;
     int32_t* __restrict__ fb_list = ll.fb_list;
     unsigned int* __restrict__ fb_count = ll.fb_count;
@@ -842,7 +846,14 @@ __global__ __launch_bounds__(kDepThreads) void k_locate_deposit(LocateLists ll, 
     __syncthreads();
     const int64_t i = (int64_t)blockIdx.x * kDepThreads + threadIdx.x;
     if (i < n) {
-        const double qx = p.px[i], qy = p.py[i], qz = p.pz[i];
+        double qx, qy, qz, pvx, pvy, pvz, prad;
+        if (rec) {
+            const double* r = rec + 10 * (size_t)p.orig[i];
+            qx = r[0]; qy = r[1]; qz = r[2]; pvx = r[3]; pvy = r[4]; pvz = r[5]; prad = r[9];
+            p.px[i] = qx; p.py[i] = qy; p.pz[i] = qz; p.vx[i] = pvx; p.vy[i] = pvy; p.vz[i] = pvz; p.rad[i] = prad;
+        } else {
+            qx = p.px[i]; qy = p.py[i]; qz = p.pz[i]; pvx = p.vx[i]; pvy = p.vy[i]; pvz = p.vz[i]; prad = p.rad[i];
+        }
         bool mine = true;
         if (own.active) {                                    // another slab's particle: not located here (k = 0)
             int kz = (int)floor((qz - own.oz) / own.dx);
@@ -912,9 +923,9 @@ __global__ __launch_bounds__(kDepThreads) void k_locate_deposit(LocateLists ll, 
                     double allwt = 0.0;
 #pragma unroll
                     for (int h = kListLen - 1; h >= 0; --h) allwt += wt[h];       // last push first (FoamYade.C:301-311)
-                    const double dia = 2 * p.rad[i];                                  // FoamYade.C:219
+                    const double dia = 2 * prad;                                      // FoamYade.C:219
                     const double pVol = M_PI * cube3(dia) / 6.0;                      // FoamYade.H:36
-                    const double vx = p.vx[i], vy = p.vy[i], vz = p.vz[i];
+                    const double vx = pvx, vy = pvy, vz = pvz;
                     int pos = 0;
 #pragma unroll
                     for (int h = 0; h < kListLen; ++h) {
@@ -1351,12 +1362,14 @@ int launch_exclusive_scan_u32(hipStream_t s, uint32_t* data, uint32_t n, uint32_
 }
 
 int launch_bin_scatter(hipStream_t s, const double* rec, int64_t n, const uint32_t* key, const uint32_t* rank,
-                       const uint32_t* start, const uint32_t* tile_off, ParticleSoA p) {
+                       const uint32_t* start, const uint32_t* tile_off, ParticleSoA p, bool gather) {
     if (n <= 0) return FY_OK;
     hipLaunchKernelGGL(k_bin_scatter, dim3(div_up(n, 256)), dim3(256), 0, s, n, key, rank, start, tile_off, p.orig);
     FY_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_bin_gather, dim3(div_up(n, 256)), dim3(256), 0, s, rec, n, p);
-    FY_LAUNCH_CHECK();
+    if (gather) {
+        hipLaunchKernelGGL(k_bin_gather, dim3(div_up(n, 256)), dim3(256), 0, s, rec, n, p);
+        FY_LAUNCH_CHECK();
+    }
     return FY_OK;
 }
 
@@ -1408,8 +1421,9 @@ int launch_build_locate_lists(hipStream_t s, const uint32_t* packed, ImplicitGeo
 
 int launch_locate_deposit(hipStream_t s, const KdNode* tree, const uint32_t* packed, ImplicitGeom ig, int32_t n_cells, int levels, ParticleSoA p, int64_t n,
                           GaussParams gp, const unsigned long long* start, SlabOwn own, LocateLists ll, CellWindow cw, double* pvol_acc, double* up_acc,
-                          unsigned char* touched, TileBuckets tb, SideStream side) {
+                          unsigned char* touched, TileBuckets tb, SideStream side, const double* rec_gather) {
     if (n <= 0) return FY_OK;
+    if (rec_gather && !(packed && ll.lists)) return fail(FY_ERR_INVALID, "launch_locate_deposit: the fused record gather needs the candidate lists");
     if (!(packed && ll.lists)) {
         FY_TRY(launch_locate(s, tree, packed, ig, n_cells, levels, p, n, gp, start, own, LocateLists{}));
         return launch_deposit(s, p, n, gp, cw, pvol_acc, up_acc, touched, tb);
@@ -1417,7 +1431,7 @@ int launch_locate_deposit(hipStream_t s, const KdNode* tree, const uint32_t* pac
     if (n_cells >= (1 << 25)) return fail(FY_ERR_UNSUPPORTED, "implicit-coordinate tree limited to 2^25 cells");
     // the lists place and deposit almost every particle; the walk + k_deposit pair takes what is left (usually nothing: zero count, exit)
     FY_HIP(hipMemsetAsync(ll.fb_count, 0, sizeof(unsigned int), s));
-    hipLaunchKernelGGL(k_locate_deposit, dim3(div_up(n, kDepThreads)), dim3(kDepThreads), 0, s, ll, ig, p, n, gp, own, cw, pvol_acc, up_acc, touched, tb);
+    hipLaunchKernelGGL(k_locate_deposit, dim3(div_up(n, kDepThreads)), dim3(kDepThreads), 0, s, ll, ig, p, n, gp, own, cw, pvol_acc, up_acc, touched, tb, rec_gather);
     FY_LAUNCH_CHECK();
     // The leftovers (~5e-5 of the particles: within 8e-6 dx of a cell face) are one latency-bound launch (the walk, which also deposits for them).  With a side stream they run beside whatever the caller enqueues next on `s` (the cell-record pack); the caller waits
     // for side.join before anything reads the deposit.  Their few thousand contributions go out as plain atomics (no tile buckets).

@@ -47,8 +47,9 @@ int launch_bin_count(hipStream_t s, const double* rec, int64_t n, BinGrid g, uin
 int launch_exclusive_scan_u32(hipStream_t s, uint32_t* data, uint32_t n, uint32_t* block_sums /* >= ceil(n/2048)+1 */);
 // after the scan `data` holds tile-local exclusive offsets and `block_sums` the exclusive tile offsets:
 // start(key) = data[key] + block_sums[key >> 11]
+// gather = false: only the placement (p.orig) is formed; whoever runs next fills the SoA arrays (launch_locate_deposit with rec_gather)
 int launch_bin_scatter(hipStream_t s, const double* rec, int64_t n, const uint32_t* key, const uint32_t* rank,
-                       const uint32_t* start, const uint32_t* tile_off, ParticleSoA p);
+                       const uint32_t* start, const uint32_t* tile_off, ParticleSoA p, bool gather = true);
 
 // implicit-coordinate tree (uniform hex block verified at create time): node = packed (i | j << 10 | k << 20)
 // z-slab ownership: a rank that is handed particles of the whole block -- what the reference's serial-Yade broadcast
@@ -124,7 +125,8 @@ int launch_deposit(hipStream_t s, ParticleSoA p, int64_t n, GaussParams gp, Cell
 // distances never reach memory
 int launch_locate_deposit(hipStream_t s, const KdNode* tree, const uint32_t* packed, ImplicitGeom ig, int32_t n_cells, int levels, ParticleSoA p, int64_t n,
                           GaussParams gp, const unsigned long long* start, SlabOwn own, LocateLists ll, CellWindow cw, double* pvol_acc, double* up_acc,
-                          unsigned char* touched, TileBuckets tb = TileBuckets{}, SideStream side = SideStream{});
+                          unsigned char* touched, TileBuckets tb = TileBuckets{}, SideStream side = SideStream{},
+                          const double* rec_gather = nullptr /* wire records: k_locate_deposit fetches them through p.orig and fills the SoA arrays itself */);
 int launch_add_mark(hipStream_t s, double* y, const double* x, size_t n, unsigned char* mark /* nullable; set where x != 0 */);
 int launch_finalize_cells(hipStream_t s, int32_t n_cells, const double* vol, double* pvol_acc, double* up_acc,
                           unsigned char* touched, double* alpha, double* uParticle, double* R /* nullable: cell records whose alpha slot follows */);
