@@ -34,9 +34,10 @@ import __graft_entry__ as ge  # noqa: E402
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s copy-achievable)
 KBAR = 5.46                     # stencil cells per particle at 160^3
 # algorithmic (compulsory) HBM bytes per particle of the two big particle kernels -- DESIGN.md section 3
-LOCATE_BYTES_PER_PARTICLE = 24.0 + 24.0 + 8.0 + 15.2 + 4.0 + 12.0 * KBAR
-LOCATE_WHAT = ("k-d 'range' locate through per-(cell, octant) candidate lists + Gaussian weights + void-fraction deposit in one pass: position 24 + velocity 24 "
-               "+ radius 8 + list 15 B in, chain length 4 + 12 B/pair out per particle; 32 B of accumulators read-modify-written per cell")
+LOCATE_BYTES_PER_PARTICLE = 80.0 + 4.0 + 56.0 + 15.2 + 4.0 + 12.0 * KBAR
+LOCATE_WHAT = ("k-d 'range' locate through per-(cell, octant) candidate lists + Gaussian weights + void-fraction deposit in one pass, the wire record fetched "
+               "through the binned placement by the kernel itself (round 3: no separate gather pass): record 80 + placement 4 + list 15 B in, binned SoA copy 56 + "
+               "chain length 4 + 12 B/pair out per particle; 32 B of accumulators read-modify-written per cell")
 FORCE_BYTES_PER_PARTICLE = 64.0 + 12.0 * KBAR + 52.0
 FORCE_WHAT = ("drag + Archimedes + back-scatter: particle 64 B + stencil 12 B/pair in, force record 52 B out; per cell the 64-byte gather record read and "
               "32 B of momentum-source accumulators read-modify-written")

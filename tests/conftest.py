@@ -19,6 +19,10 @@ def load_product():
     name = "yade_openfoam_coupling_amd"
     if name in sys.modules:
         return sys.modules[name]
+    try:                                  # some tests hand torch tensors to the library: torch (its HIP runtime) first, see _share_torch_hip_runtime
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     pkg_dir = os.path.join(ROOT, "yade-openfoam-coupling_amd")
     spec = importlib.util.spec_from_file_location(name, os.path.join(pkg_dir, "__init__.py"),
                                                   submodule_search_locations=[pkg_dir])

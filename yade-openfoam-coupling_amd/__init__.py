@@ -132,7 +132,10 @@ def _share_torch_hip_runtime():
     and libtorch_hip asks for it by FILE name, so a process that loads this library first (resolved to /opt/rocm's copy) and initialises
     torch.cuda later ends up with two HIP/ROCr runtimes side by side -- which works for a while and then fails in torch
     ("No HIP GPUs are available" after a few dozen contexts).  Loading the wheel's copy first makes both resolve to the same object.
-    torch itself is not imported."""
+    torch itself is not imported.  This is NOT enough for a process that works this library hard and imports torch afterwards (measured: any
+    of the slab / particle test files followed by a test that does `import torch` ends in "double free or corruption" at interpreter exit, while
+    the same tests with torch imported first are clean): a process that is going to use torch should import it BEFORE loading this library --
+    tests/conftest.py and __graft_entry__.load_product() do."""
     if "torch" in sys.modules:
         return
     try:

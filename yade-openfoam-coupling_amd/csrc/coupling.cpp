@@ -627,11 +627,15 @@ int Coupling::run_batch(Batch& b) {
             cellrec_fresh = true;
         }
         if (side.stream && ll.lists) FY_HIP(hipStreamWaitEvent(stream, side.join, 0));
-        FY_TRY(launch_tile_reduce(stream, tbD, d_pvol_acc.p, d_up_acc.p, d_touched.p));
-        if (slab.active) {      // contributions that landed in ghost planes belong to the neighbours: send them home and add
-            FY_TRY(halo_reverse_add2(d_pvol_acc.p, 1, d_touched.p, d_up_acc.p, 3));
+        if (tbD.cell && !slab.active) {      // single domain: the tile's sums are complete, setCellVolFraction rides on the reduction
+            FY_TRY(launch_tile_reduce_finalize(stream, tbD, d_pvol_acc.p, d_up_acc.p, d_touched.p, d_vol.p, dAlpha, dUParticle, d_cellrec.p));
+        } else {
+            FY_TRY(launch_tile_reduce(stream, tbD, d_pvol_acc.p, d_up_acc.p, d_touched.p));
+            if (slab.active) {      // contributions that landed in ghost planes belong to the neighbours: send them home and add
+                FY_TRY(halo_reverse_add2(d_pvol_acc.p, 1, d_touched.p, d_up_acc.p, 3));
+            }
+            FY_TRY(launch_finalize_cells(stream, (int32_t)n_field, d_vol.p, d_pvol_acc.p, d_up_acc.p, d_touched.p, dAlpha, dUParticle, d_cellrec.p));
         }
-        FY_TRY(launch_finalize_cells(stream, (int32_t)n_field, d_vol.p, d_pvol_acc.p, d_up_acc.p, d_touched.p, dAlpha, dUParticle, d_cellrec.p));
         if (slab.active) {      // the gathers below reach gz planes into the neighbours (alpha only: uParticle is applied per cell by its owner, k_fold_sources)
             FY_TRY(halo_fwd(dAlpha, 1, slab.gz));
             const int64_t gcells = (int64_t)slab.gz * (int64_t)slab.plane;
@@ -652,13 +656,17 @@ int Coupling::run_batch(Batch& b) {
         if (timing) marks.mark(3, stream);
         FY_TRY(launch_force_gaussian(stream, p, b.n, fp, cw, d_vol.p, d_cellrec.p, dVGrad, dDdtU, b.d_rec, d_drag_acc.p, dUSource, b.force.p, tbB));
         if (timing) marks.mark(4, stream);
-        FY_TRY(launch_tile_reduce(stream, tbB, d_drag_acc.p, dUSource, nullptr));
         b.found_stale = true;
-        if (slab.active) {
-            FY_TRY(halo_reverse_add2(d_drag_acc.p, 1, nullptr, dUSource, 3));
+        if (tbB.cell && !slab.active) {      // single domain: the fold rides on the reduction
+            FY_TRY(launch_tile_reduce_fold(stream, tbB, d_drag_acc.p, dUSource, dUParticle, dUSourceDrag));
+        } else {
+            FY_TRY(launch_tile_reduce(stream, tbB, d_drag_acc.p, dUSource, nullptr));
+            if (slab.active) {
+                FY_TRY(halo_reverse_add2(d_drag_acc.p, 1, nullptr, dUSource, 3));
+            }
+            // FoamYade.C:385-386 per cell: uSourceDrag += D, uSource += uParticle * D (this batch's uParticle: the owner's, after its finalize)
+            FY_TRY(launch_fold_sources(stream, n_field, d_drag_acc.p, dUParticle, dUSourceDrag, dUSource));
         }
-        // FoamYade.C:385-386 per cell: uSourceDrag += D, uSource += uParticle * D (this batch's uParticle: the owner's, after its finalize)
-        FY_TRY(launch_fold_sources(stream, n_field, d_drag_acc.p, dUParticle, dUSourceDrag, dUSource));
         if (timing) marks.mark(5, stream);
     } else {
         BlockGeom g;

@@ -700,37 +700,84 @@ __device__ __forceinline__ void flush_table(const uint32_t* keys, const double* 
 
 // One workgroup per tile of 8 x 8 x 8 cells: the tile's bucket is summed into a dense LDS accumulator (ds_add_f64: ~37 x the global
 // atomics' rate), then the tile goes to the cell arrays with plain read-modify-writes -- this workgroup is the tile's only writer.
-__global__ __launch_bounds__(256) void k_tile_reduce(TileBuckets tb, double* __restrict__ dst0, double* __restrict__ dst3, unsigned char* __restrict__ touched) {
+// FINISH 0: that is all (z-slabs: the reverse-halo sums of the neighbours come in before the cells are finished).
+// FINISH 1 (single domain, void-fraction deposit): the cell's sums are complete here, so setCellVolFraction (k_finalize_cells) happens in the
+//          same pass -- no round trip of the accumulators through memory, no second sweep over the touched flags.
+// FINISH 2 (single domain, momentum-source back-scatter): likewise k_fold_sources (uSourceDrag += D, uSource += uParticle D).
+// Same operations on the same operands in the same order as the separate kernels: identical bits.  With FINISH != 0 every tile runs,
+// also one whose bucket is empty (its cells may have been reached by the fallback atomics).
+struct TileFinish { const double* vol; double* alpha; double* uParticle; double* R; const double* uParticleC; double* uSourceDrag; };
+template <int FINISH>
+__global__ __launch_bounds__(256) void k_tile_reduce(TileBuckets tb, double* __restrict__ dst0, double* __restrict__ dst3, unsigned char* __restrict__ touched, TileFinish fin) {
     __shared__ double acc[kTileCells * 4];
     const uint32_t tile = blockIdx.x;
     uint32_t cnt = tb.fill[tile];
     const uint32_t cap = tb.cap[tile];
     if (cnt > cap) cnt = cap;
-    if (cnt == 0) return;                                   // (block-uniform)
-    for (int q = threadIdx.x; q < kTileCells * 4; q += 256) acc[q] = 0.0;
-    __syncthreads();
-    const size_t off = tb.off[tile];
-    for (uint32_t j = threadIdx.x; j < cnt; j += 256) {
-        const uint32_t l = tb.cell[off + j];
-        const double2* v = reinterpret_cast<const double2*>(tb.val + 4 * (off + j));
-        const double2 v0 = v[0], v1 = v[1];
-        double* a = acc + 4 * l;
-        lds_add_f64(a, v0.x); lds_add_f64(a + 1, v0.y); lds_add_f64(a + 2, v1.x); lds_add_f64(a + 3, v1.y);
+    if (FINISH == 0 && cnt == 0) return;                    // (block-uniform)
+    if (cnt) {
+        for (int q = threadIdx.x; q < kTileCells * 4; q += 256) acc[q] = 0.0;
+        __syncthreads();
+        const size_t off = tb.off[tile];
+        for (uint32_t j = threadIdx.x; j < cnt; j += 256) {
+            const uint32_t l = tb.cell[off + j];
+            const double2* v = reinterpret_cast<const double2*>(tb.val + 4 * (off + j));
+            const double2 v0 = v[0], v1 = v[1];
+            double* a = acc + 4 * l;
+            lds_add_f64(a, v0.x); lds_add_f64(a + 1, v0.y); lds_add_f64(a + 2, v1.x); lds_add_f64(a + 3, v1.y);
+        }
+        __syncthreads();
     }
-    __syncthreads();
     const TileGrid& tg = tb.tg;
     const int ti = (int)(tile % (uint32_t)tg.ntx), tj = (int)((tile / (uint32_t)tg.ntx) % (uint32_t)tg.nty), tk = (int)(tile / (uint32_t)(tg.ntx * tg.nty));
     for (int l = threadIdx.x; l < kTileCells; l += 256) {
         const int i = ti * 8 + (l & 7), j = tj * 8 + ((l >> 3) & 7), k = tk * 8 + (l >> 6);
         if (i >= tg.nx || j >= tg.ny || k >= tg.nzs) continue;
-        const double a0 = acc[4 * l], a1 = acc[4 * l + 1], a2 = acc[4 * l + 2], a3 = acc[4 * l + 3];
-        if (a0 == 0.0 && a1 == 0.0 && a2 == 0.0 && a3 == 0.0) continue;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        if (cnt) { a0 = acc[4 * l]; a1 = acc[4 * l + 1]; a2 = acc[4 * l + 2]; a3 = acc[4 * l + 3]; }
+        const bool any = !(a0 == 0.0 && a1 == 0.0 && a2 == 0.0 && a3 == 0.0);
         const size_t c = (size_t)i + (size_t)tg.nx * ((size_t)j + (size_t)tg.ny * (size_t)k);
-        dst0[c] += a0;
-        double* d = dst3 + 3 * c;
-        const double d0 = d[0] + a1, d1 = d[1] + a2, d2 = d[2] + a3;
-        d[0] = d0; d[1] = d1; d[2] = d2;
-        if (touched) touched[c] = 1;
+        if (FINISH == 0) {
+            if (!any) continue;
+            dst0[c] += a0;
+            double* d = dst3 + 3 * c;
+            const double d0 = d[0] + a1, d1 = d[1] + a2, d2 = d[2] + a3;
+            d[0] = d0; d[1] = d1; d[2] = d2;
+            if (touched) touched[c] = 1;
+        } else if (FINISH == 1) {
+            // the accumulators hold what the fallback atomics left (touched says so); they go back to zero, the cell is finished
+            const bool t = touched[c] != 0;
+            if (!any && !t) continue;
+            double pv = a0, u0 = a1, u1 = a2, u2 = a3;
+            if (t) {
+                double* d = dst3 + 3 * c;
+                if (any) { pv = dst0[c] + a0; u0 = d[0] + a1; u1 = d[1] + a2; u2 = d[2] + a3; }
+                else { pv = dst0[c]; u0 = d[0]; u1 = d[1]; u2 = d[2]; }
+                dst0[c] = 0.0; d[0] = 0.0; d[1] = 0.0; d[2] = 0.0;
+                touched[c] = 0;
+            }
+            const double V = fin.vol[c];                      // setCellVolFraction FoamYade.C:318-328
+            const double pvolC = 1.0 - (pv / V);
+            const double al = ((pvolC > 0.10) ? pvolC : 0.10);
+            fin.alpha[c] = al;
+            if (fin.R) fin.R[8 * c + 3] = al;
+            double* o = fin.uParticle + 3 * c;
+            o[0] = u0 / V; o[1] = u1 / V; o[2] = u2 / V;
+        } else {
+            const double D0 = dst0[c];                        // what the fallback atomics added to the drag accumulator (usually nothing)
+            double D = D0;
+            double* sp = dst3 + 3 * c;
+            if (!any && D0 == 0.0) continue;
+            double s0 = sp[0], s1 = sp[1], s2 = sp[2];
+            if (any) { D += a0; s0 += a1; s1 += a2; s2 += a3; }
+            if (D0 != 0.0) dst0[c] = 0.0;                     // the accumulator is empty again either way
+            if (D != 0.0) {                                   // k_fold_sources, FoamYade.C:385-386
+                fin.uSourceDrag[c] += D;
+                const double* up = fin.uParticleC + 3 * c;
+                s0 = s0 + (up[0] * D); s1 = s1 + (up[1] * D); s2 = s2 + (up[2] * D);
+            }
+            sp[0] = s0; sp[1] = s1; sp[2] = s2;
+        }
     }
 }
 
@@ -1504,7 +1551,22 @@ int launch_tile_caps(hipStream_t s, TileBuckets a, TileBuckets b) {
 
 int launch_tile_reduce(hipStream_t s, TileBuckets tb, double* dst0, double* dst3, unsigned char* touched) {
     if (!tb.cell) return FY_OK;
-    hipLaunchKernelGGL(k_tile_reduce, dim3((unsigned)tb.tg.n_tiles()), dim3(256), 0, s, tb, dst0, dst3, touched);
+    hipLaunchKernelGGL(k_tile_reduce<0>, dim3((unsigned)tb.tg.n_tiles()), dim3(256), 0, s, tb, dst0, dst3, touched, TileFinish{});
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+
+int launch_tile_reduce_finalize(hipStream_t s, TileBuckets tb, double* pvol_acc, double* up_acc, unsigned char* touched, const double* vol, double* alpha,
+                                double* uParticle, double* R) {
+    if (!tb.cell) return fail(FY_ERR_INVALID, "launch_tile_reduce_finalize without tile buckets");
+    hipLaunchKernelGGL(k_tile_reduce<1>, dim3((unsigned)tb.tg.n_tiles()), dim3(256), 0, s, tb, pvol_acc, up_acc, touched, TileFinish{vol, alpha, uParticle, R, nullptr, nullptr});
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+
+int launch_tile_reduce_fold(hipStream_t s, TileBuckets tb, double* drag_acc, double* uSource, const double* uParticle, double* uSourceDrag) {
+    if (!tb.cell) return fail(FY_ERR_INVALID, "launch_tile_reduce_fold without tile buckets");
+    hipLaunchKernelGGL(k_tile_reduce<2>, dim3((unsigned)tb.tg.n_tiles()), dim3(256), 0, s, tb, drag_acc, uSource, nullptr, TileFinish{nullptr, nullptr, nullptr, nullptr, uParticle, uSourceDrag});
     FY_LAUNCH_CHECK();
     return FY_OK;
 }

@@ -116,6 +116,10 @@ struct TileBuckets {               // all null: flush with global atomics (round
 int launch_tile_caps(hipStream_t s, TileBuckets a, TileBuckets b);
 // dst0[c] += sum of the tile's entries' first value, dst3[c][0..2] += the other three; touched[c] = 1 where something arrived (nullable)
 int launch_tile_reduce(hipStream_t s, TileBuckets tb, double* dst0, double* dst3, unsigned char* touched);
+// single domain: the reduction and what follows it per cell in ONE pass over the tiles -- launch_finalize_cells, resp. launch_fold_sources
+int launch_tile_reduce_finalize(hipStream_t s, TileBuckets tb, double* pvol_acc, double* up_acc, unsigned char* touched, const double* vol, double* alpha,
+                                double* uParticle, double* R);
+int launch_tile_reduce_fold(hipStream_t s, TileBuckets tb, double* drag_acc, double* uSource, const double* uParticle, double* uSourceDrag);
 
 // a second stream for work that may run beside the caller's next launches: forked from the main stream at `fork`, done at `join`
 struct SideStream { hipStream_t stream; hipEvent_t fork, join; };
