@@ -1,7 +1,7 @@
 // OpenFOAM case directories for fy_solver: what icoFoamYade / pimpleFoamYade get from OpenFOAM's runTime / mesh / field
 // constructors (icoFoamYade.C:38-46, createFields.H of both solvers) and give back with runTime.write() (icoFoamYade.C:142,
-// pimpleFoamYade.C:107), for the one mesh class this library computes on: a single axis-aligned blockMesh hex block of uniform cubes.
-//   read   system/blockMeshDict  (vertices, one `hex` block, simpleGrading (1 1 1), `boundary` patches -> the 6 box sides)
+// pimpleFoamYade.C:107), for the one mesh class this library computes on: a single axis-aligned blockMesh hex block (uniform cubes, or graded: simpleGrading (ex ey ez)).
+//   read   system/blockMeshDict  (vertices, one `hex` block, simpleGrading (ex ey ez), `boundary` patches -> the 6 box sides)
 //          system/controlDict    (startTime, endTime, deltaT, writeControl, writeInterval)
 //          system/fvSolution     (PISO | PIMPLE controls, solvers.p / pFinal / U tolerances)
 //          constant/transportProperties (nu, partDensity, fluidDensity | continuousPhaseName + rho.<phase>), constant/g
