@@ -188,7 +188,8 @@ int fy_enable_timing(fy_ctx*, int on);
 enum { FY_SOLVER_ICO = 0, FY_SOLVER_PIMPLE = 1 };
 /* boundary patches of the block, in this order */
 enum { FY_XMIN = 0, FY_XMAX = 1, FY_YMIN = 2, FY_YMAX = 3, FY_ZMIN = 4, FY_ZMAX = 5 };
-enum { FY_BC_U_FIXED_VALUE = 0, FY_BC_U_ZERO_GRADIENT = 1 };
+enum { FY_BC_U_FIXED_VALUE = 0, FY_BC_U_ZERO_GRADIENT = 1,
+       FY_BC_U_SLIP = 2 /* symmetryPlane / symmetry / slip on the block's (planar) side: normal component 0, tangential components zeroGradient */ };
 enum { FY_BC_P_ZERO_GRADIENT = 0, FY_BC_P_FIXED_VALUE = 1, FY_BC_P_FIXED_FLUX = 2 };
 enum { FY_PSOLVER_PCG_JACOBI = 0, FY_PSOLVER_PCG_MG = 1 };
 

@@ -33,7 +33,7 @@ struct orc_fv_case {
     double origin[3];
     double dt, nu, rho_fluid, rho_particle;
     double g[3];
-    int u_bc[6];                 // 0 fixedValue, 1 zeroGradient
+    int u_bc[6];                 // 0 fixedValue, 1 zeroGradient, 2 slip / symmetryPlane (normal component 0, tangential zeroGradient)
     double u_value[6][3];
     int p_bc[6];                 // 0 zeroGradient, 1 fixedValue, 2 fixedFluxPressure
     double p_value[6];
@@ -123,6 +123,7 @@ struct Fv {
     int k_iters = 0;
     vec phi[3], phiOld[3], psn[3];           // psn: d p / d axis on fixedFluxPressure boundary faces
     // work
+    vec bdiag;                   // [3 Nc] per-component boundary diagonal of the momentum matrix (slip patches); empty without one
     vec diag, an[6], src, rAU, HbyA, alphaf[3], phiHbyA[3], phiForces[3], rAUf[3], pflux[3], bmom, Sc, divG;
     std::vector<MgLevel> mg;
     vec pb, pr, pw, pp, pz;
@@ -163,6 +164,7 @@ struct Fv {
             rAUf[d].assign(fsize(d), 0.0); pflux[d].assign(fsize(d), 0.0);
         }
         diag.assign(Nc, 0.0); for (auto& a : an) a.assign(Nc, 0.0);
+        for (int q = 0; q < 6; ++q) if (cs.u_bc[q] == 2) bdiag.assign(3 * (size_t)Nc, 0.0);
         src.assign(3 * (size_t)Nc, 0.0); rAU.assign(Nc, 0.0); HbyA.assign(3 * (size_t)Nc, 0.0); bmom.assign(3 * (size_t)Nc, 0.0);
         Sc.assign(Nc, 0.0); divG.assign(3 * (size_t)Nc, 0.0);
         pb.assign(Nc, 0.0); pr = pb; pw = pb; pp = pb; pz = pb;
@@ -178,6 +180,9 @@ struct Fv {
     inline void Ub(const vec& F, int c, int patch, double* out) const {          // velocity-like field with U's BCs
         if (cs.u_bc[patch] == 0) { out[0] = cs.u_value[patch][0]; out[1] = cs.u_value[patch][1]; out[2] = cs.u_value[patch][2]; }
         else { out[0] = F[3 * (size_t)c]; out[1] = F[3 * (size_t)c + 1]; out[2] = F[3 * (size_t)c + 2]; }
+        // symmetryPlane / slip on a planar, axis-aligned patch [OF-6 basicSymmetryFvPatchField::evaluate]: the cell value with its normal
+        // component removed, (pif + transform(I - 2 nn, pif)) / 2
+        if (cs.u_bc[patch] == 2) out[patch / 2] = 0.0;
     }
     inline double pbv(int c, int d, int s, int face) const {                     // boundary value of p
         const int patch = 2 * d + s;
@@ -373,6 +378,7 @@ struct Fv {
             const double aP = pimple ? alpha[c] : 1.0, aP0 = pimple ? alphaOld[c] : 1.0;
             const double Vc = vol(i, j, k);
             double dg = aP * Vc / dt;                                        // fvm::ddt
+            if (!bdiag.empty()) for (int q = 0; q < 3; ++q) bdiag[3 * (size_t)c + q] = 0.0;
             double s3[3];
             for (int q = 0; q < 3; ++q) s3[q] = aP0 * Vc * Uold[3 * (size_t)c + q] / dt;
             double divAPhi = 0.0;
@@ -401,6 +407,14 @@ struct Fv {
                         const double gb = bfac() * gam;
                         dg += gb;
                         for (int q = 0; q < 3; ++q) s3[q] += (-phio + gb) * cs.u_value[patch][q];
+                    } else if (cs.u_bc[patch] == 2) {
+                        // symmetryPlane / slip [OF-6 transformFvPatchField::gradientInternalCoeffs = -deltaCoeffs * snGradTransformDiag, with
+                        // basicSymmetry's snGradTransformDiag = the squared normal's components]: on an axis-aligned patch the NORMAL component
+                        // sees a fixed value 0 (implicit coefficient (alpha nu)_f |Sf| deltaCoeffs, boundary source 0), the tangential ones a
+                        // zero gradient; the flux through the patch is zero, so convection adds nothing.  A per-component boundary diagonal:
+                        // kept apart from the scalar diagonal, as fvMatrix keeps internalCoeffs apart from the lduMatrix
+                        bdiag[3 * (size_t)c + d] += bfac() * gam;
+                        dg += phio;
                     } else {                                                 // zeroGradient
                         dg += phio;
                     }
@@ -436,19 +450,33 @@ struct Fv {
                 // part of dg here all along), D = max(|D|, sum|offdiag|) / alpha, source += (D_new - D_old) psi.  No relaxationFactors
                 // entry for the equation (alpha <= 0): relax() does nothing at all, not even the dominance step.
                 double so = 0.0; for (int q = 0; q < 6; ++q) so += std::fabs(an[q][c]);
-                const double dn = std::max(std::fabs(dg), so) / u_relax_now;
+                // a slip patch's coefficient differs by component: relax() adds cmptMax(cmptMag(internalCoeffs)) before the test and
+                // takes cmptMin(internalCoeffs) (= 0 there) off afterwards, so the whole of it takes part in the dominance test and the
+                // scalar diagonal keeps what the test gave
+                const double bsum = bdiag.empty() ? 0.0 : bdiag[3 * (size_t)c] + bdiag[3 * (size_t)c + 1] + bdiag[3 * (size_t)c + 2];
+                const double dn = std::max(std::fabs(dg + bsum), so) / u_relax_now;
                 for (int q = 0; q < 3; ++q) s3[q] += (dn - dg) * U[3 * (size_t)c + q];
                 dg = dn;
             }
             diag[c] = dg;
             for (int q = 0; q < 3; ++q) src[3 * (size_t)c + q] = s3[q];
-            rAU[c] = 1.0 / (dg / Vc);                                        // 1/UEqn.A()
+            // 1/UEqn.A(): fvMatrix::A() adds the COMPONENT AVERAGE of the boundary diagonal (addCmptAvBoundaryDiag)
+            const double bav = bdiag.empty() ? 0.0 : (bdiag[3 * (size_t)c] + bdiag[3 * (size_t)c + 1] + bdiag[3 * (size_t)c + 2]) / 3.0;
+            rAU[c] = 1.0 / ((dg + bav) / Vc);
         }
     }
 
     // lduMatrix residual normalisation: sum(|A psi - A xbar| + |b - A xbar|) + 1e-20
     // Jacobi solve of diag*x + sum an*x_nb = b for the 3 components (stand-in for smoothSolver symGaussSeidel)
-    int solve_momentum(const vec& b) { return solve_vec3(U, b, cs.u_tol, cs.u_rel_tol, cs.u_max_iter); }
+    // diagonal of component q: the scalar one + that component's boundary diagonal (slip patches)
+    bool bdiag_on = false;       // (solve_vec3 also solves the k / epsilon equations, which have none)
+    inline double dgc(int c, int q) const { return bdiag_on ? diag[c] + bdiag[3 * (size_t)c + q] : diag[c]; }
+    int solve_momentum(const vec& b) {
+        bdiag_on = !bdiag.empty();
+        const int it = solve_vec3(U, b, cs.u_tol, cs.u_rel_tol, cs.u_max_iter);
+        bdiag_on = false;
+        return it;
+    }
     // Jacobi sweeps on (diag, an) for a 3-component field X (updated in place), lduMatrix-style L1 residual control per component
     int solve_vec3(vec& X, const vec& b, double tol, double rel_tol, int max_iter) {
         vec x = X, xn(3 * (size_t)Nc), Ax(3 * (size_t)Nc);
@@ -456,7 +484,8 @@ struct Fv {
 #pragma omp parallel for num_threads(threads) collapse(2)
             for (int k = 0; k < nz; ++k) for (int j = 0; j < ny; ++j) for (int i = 0; i < nx; ++i) {
                 const int c = cid(i, j, k);
-                double acc[3] = {diag[c] * v[3 * (size_t)c], diag[c] * v[3 * (size_t)c + 1], diag[c] * v[3 * (size_t)c + 2]};
+                double acc[3];
+                for (int q = 0; q < 3; ++q) acc[q] = dgc(c, q) * v[3 * (size_t)c + q];      // (fvMatrix::solveSegregated: addBoundaryDiag per component)
                 for (int d = 0; d < 3; ++d) for (int s = 0; s < 2; ++s) if (!onb(d, s, i, j, k)) {
                     const int nb = c + (s ? stride[d] : -stride[d]); const double a = an[2 * d + s][c];
                     for (int q = 0; q < 3; ++q) acc[q] += a * v[3 * (size_t)nb + q];
@@ -495,7 +524,7 @@ struct Fv {
                     const int nb = c + (s ? stride[d] : -stride[d]); const double a = an[2 * d + s][c];
                     for (int q = 0; q < 3; ++q) acc[q] -= a * x[3 * (size_t)nb + q];
                 }
-                for (int q = 0; q < 3; ++q) xn[3 * (size_t)c + q] = acc[q] / diag[c];
+                for (int q = 0; q < 3; ++q) xn[3 * (size_t)c + q] = acc[q] / dgc(c, q);
             }
             x.swap(xn);
             ++it;
@@ -517,6 +546,12 @@ struct Fv {
             for (int d = 0; d < 3; ++d) for (int s = 0; s < 2; ++s) if (!onb(d, s, i, j, k)) {
                 const int nb = c + (s ? stride[d] : -stride[d]); const double a = an[2 * d + s][c];
                 for (int q = 0; q < 3; ++q) acc[q] -= a * U[3 * (size_t)nb + q];
+            }
+            if (!bdiag.empty()) {
+                // fvMatrix::H(): per component (component-averaged boundary diagonal - that component's boundary diagonal) * psi -- what
+                // A() holds too much or too little of for this component goes to H
+                const double bav = (bdiag[3 * (size_t)c] + bdiag[3 * (size_t)c + 1] + bdiag[3 * (size_t)c + 2]) / 3.0;
+                for (int q = 0; q < 3; ++q) acc[q] += (bav - bdiag[3 * (size_t)c + q]) * U[3 * (size_t)c + q];
             }
             for (int q = 0; q < 3; ++q) HbyA[3 * (size_t)c + q] = rAU[c] * (acc[q] / vol(i, j, k));
         }

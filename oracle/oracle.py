@@ -259,7 +259,7 @@ class FvStats(C.Structure):
                 ("p_final_residual", C.c_double), ("delta_t", C.c_double)]
 
 
-U_FIXED, U_ZEROGRAD = 0, 1
+U_FIXED, U_ZEROGRAD, U_SLIP = 0, 1, 2         # U_SLIP: symmetryPlane / slip (normal component 0, tangential zeroGradient)
 P_ZEROGRAD, P_FIXED, P_FIXEDFLUX = 0, 1, 2
 XMIN, XMAX, YMIN, YMAX, ZMIN, ZMAX = range(6)
 

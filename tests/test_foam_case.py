@@ -54,11 +54,29 @@ def test_bed_case_is_read_like_pimpleFoamYade_would(prod):
     fc.close()
 
 
+@pytest.mark.parametrize("ty", ["slip", "symmetryPlane", "symmetry"])
+def test_symmetry_sides_are_read_as_slip(prod, tmp_path, ty):
+    dst = tmp_path / "case"
+    shutil.copytree(os.path.join(CASES, "cavity_ico"), dst)
+    text = (dst / "0/U").read_text()
+    assert "noSlip" in text
+    (dst / "0/U").write_text(text.replace("noSlip", ty, 1))
+    if ty != "slip":                                   # (a symmetry patch carries its type in every field file)
+        ptext = (dst / "0/p").read_text()
+        i = ptext.index("fixedWalls")
+        (dst / "0/p").write_text(ptext[:i] + ptext[i:].replace("zeroGradient", ty, 1))
+    fc = prod.FoamCase(dst, prod.FY_SOLVER_ICO)
+    c = fc.case
+    assert c.u_bc[YMAX] == prod.FY_BC_U_FIXED_VALUE and all(c.u_bc[s] == prod.FY_BC_U_SLIP for s in (XMIN, XMAX, YMIN, ZMIN, ZMAX))
+    assert all(c.p_bc[s] == prod.FY_BC_P_ZERO_GRADIENT for s in range(6))
+    fc.close()
+
+
 @pytest.mark.parametrize("edit,needle", [
     (("system/blockMeshDict", "simpleGrading (1 1 1)", "simpleGrading (((0.5 0.5 4) (0.5 0.5 0.25)) 1 1)"), "multi-grading"),
     (("system/blockMeshDict", "simpleGrading (1 1 1)", "edgeGrading (1 1 1 1 1 1 1 1 1 1 1 1)"), "edgeGrading"),
     (("system/blockMeshDict", "(3 7 6 2)", "(3 7 6 1)"), "not a side"),
-    (("0/U", "noSlip", "slip"), "not supported"),
+    (("0/U", "noSlip", "partialSlip"), "not supported"),
     (("0/p", "type            zeroGradient;", "type            totalPressure;"), "not supported"),
     (("system/controlDict", "startFrom       startTime;", "startFrom       latestTime;"), "startFrom"),
     (("constant/transportProperties", "fluidDensity", "fluidDensityX"), "fluidDensity"),

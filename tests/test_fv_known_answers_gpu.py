@@ -147,3 +147,74 @@ def test_graded_poiseuille_on_a_wall_refined_mesh_hip(product):
         assert abs(U[0, 0, nx // 2, 0] / yc[0] - G / (2 * nu)) < 1e-7 * G / (2 * nu)
         s.close()
     assert errs[32] < 0.3 * errs[16] and errs[32] < 5e-3, errs
+
+
+# ---- Taylor-Green vortices between symmetry planes (the functions are shared with the oracle's CPU test) ---------------------------------
+def _slip_solver(product, solver=0):
+    def mk(shape, dx, dt, nu):
+        return product.Solver(product.make_case(solver, shape[0], shape[1], shape[2], dx, dt, nu, u_bc=[product.FY_BC_U_SLIP] * 6, u_tol=1e-12, p_tol=1e-11,
+                                                p_final_tol=1e-11, p_rel_tol=0.0))
+    return mk
+
+
+@pytest.mark.parametrize("plane", ["xy", "yz", "xz"])
+def test_taylor_green_vortex_is_the_exact_navier_stokes_solution(product, plane):
+    """two-dimensional Taylor-Green in each coordinate plane, exact for the full equations (Re = 31 and the Stokes regime), up to 64 x 64"""
+    from test_fv_oracle import taylor_green_2d_checks
+    taylor_green_2d_checks(_slip_solver(product, 0), plane, sizes=(8, 16, 32, 64))
+
+
+def test_taylor_green_vortex_in_pimpleFoamYade_converges_at_first_order(product):
+    """the same vortex through pimpleFoamYade's UcEqn (no particles, alphac = 1): its explicit stress term div(nuEff dev2(T(grad(Uc))))
+    (divDevRhoReff; zero for a solenoidal field) is a Gauss gradient inside a Gauss divergence, one-sided in the cells along a boundary -- an
+    O(1) residue in a layer of thickness dx, so the amplitude converges at first order where icoFoamYade's laplacian(nu, U) converges at second.
+    (No relaxationFactors entry: relax(1) on a symmetry plane would lag the tangential components of the boundary cells by one iteration.)"""
+    from test_fv_oracle import taylor_green
+    nu, T = 0.1, 0.5
+    errs = []
+    for n in (16, 32, 64):
+        dt = 0.1 * (8.0 / n) ** 2
+        mk = lambda shape, dx, dt_, nu_: product.Solver(product.make_case(1, shape[0], shape[1], shape[2], dx, dt_, nu_, u_bc=[product.FY_BC_U_SLIP] * 6,
+                                                                           u_tol=1e-12, p_tol=1e-11, p_final_tol=1e-11, p_rel_tol=0.0, u_relax=0.0))
+        amp, dev = taylor_green(mk, (n, n, 1), nu, dt, int(round(T / dt)))
+        errs.append(abs(amp - np.exp(-2 * nu * T)))
+        assert dev < 0.01, (n, dev)
+    assert errs[2] < 2e-3 and 1.6 < errs[0] / errs[1] < 2.6 and 1.6 < errs[1] / errs[2] < 2.6, errs
+
+
+def test_three_dimensional_taylor_green_vortex(product):
+    """Taylor & Green's three-dimensional vortex in one cell of its array (symmetry planes on all six sides), 16^3 .. 64^3: at Re = 0.03 the
+    field decays in place at the Stokes rate exp(-3 nu t), second order in dx; at Re = 31 (no closed form) the run stays symmetric, loses
+    kinetic energy at least as fast as the Stokes rate at t = 0 predicts, and conserves mass to solver tolerance"""
+    from test_fv_oracle import taylor_green
+    nu, T, amp0 = 1.0, 0.1, 0.01
+    errs = []
+    for n in (16, 32, 64):
+        dt = 0.004 * (8.0 / n) ** 2
+        amp, dev = taylor_green(_slip_solver(product), (n, n, n), nu, dt, int(round(T / dt)), amp0=amp0, three_d=True)
+        errs.append(amp - np.exp(-3 * nu * T))
+        assert dev < 5e-4, (n, dev)                       # (the secondary flow the convective term drives: O(Re), not a discretisation error)
+    assert errs[0] > 0 and 3.7 < errs[0] / errs[1] < 4.3 and 3.7 < errs[1] / errs[2] < 4.3, errs
+    assert errs[2] < 1e-4
+    # Re = 31
+    n, nu, dt = 32, 0.1, 0.01
+    s = _slip_solver(product)((n, n, n), np.pi / n, dt, nu)
+    c = (np.arange(n) + 0.5) * np.pi / n
+    Z, Y, X = np.meshgrid(c, c, c, indexing="ij")
+    U0 = np.zeros((n, n, n, 3))
+    U0[..., 0] = np.sin(X) * np.cos(Y) * np.cos(Z)
+    U0[..., 1] = -np.cos(X) * np.sin(Y) * np.cos(Z)
+    s.set("U", U0.reshape(-1, 3))
+    E0 = (U0 ** 2).sum()
+    for _ in range(20):
+        s.step()
+    U = s.get("U").reshape(n, n, n, 3)
+    E = (U ** 2).sum()
+    t = 20 * dt
+    assert 0.5 * np.exp(-6 * nu * t) < E / E0 < np.exp(-6 * nu * t) * 1.01, (E / E0, np.exp(-6 * nu * t))
+    assert np.abs(U[..., 2]).max() > 1e-3                                  # the third component is born from the other two
+    # the vortex array's symmetry: a quarter turn about the box's z axis maps the flow onto itself, u(x, y, z) = -v(y, pi - x, z), w(x, y, z) = w(y, pi - x, z)
+    np.testing.assert_allclose(U[..., 0], -np.flip(np.swapaxes(U[..., 1], 1, 2), axis=2), atol=1e-8)
+    np.testing.assert_allclose(U[..., 2], np.flip(np.swapaxes(U[..., 2], 1, 2), axis=2), atol=1e-8)
+    assert s.stats()["cont_err_sum_local"] < 1e-8
+    s.close()

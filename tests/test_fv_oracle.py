@@ -360,6 +360,48 @@ def flux_identity(s, n, dt):
     assert st["cont_global" if "cont_global" in st else "cont_err_global"] == pytest.approx(dt * div.sum() / (V * n ** 3), rel=1e-6, abs=1e-14 * scale)
 
 
+def taylor_green(make_solver, shape, nu, dt, steps, amp0=1.0, three_d=False):
+    """Taylor-Green vortices in a box of symmetry planes (the classical reduction of the periodic problem to one cell of the vortex array).
+    shape = (nx, ny, nz) cells of edge dx = pi / n over [0, pi] along every axis with more than one cell.
+    Two-dimensional (one axis with a single cell; a, b = the other two): u_a = sin a cos b F, u_b = -cos a sin b F, F = exp(-2 nu t), is an EXACT
+    solution of the full Navier-Stokes equations (the convective term is the gradient of -(cos 2a + cos 2b) F^2 / 4), at any Reynolds number.
+    Three-dimensional (three_d): u = sin x cos y cos z, v = -cos x sin y cos z, w = 0 at t = 0 (Taylor & Green 1937): every component is an
+    eigenfunction of the Laplacian with eigenvalue -3, so in the Stokes limit the field decays as exp(-3 nu t) in place; the convective term
+    feeds other modes at second order in the Reynolds number only as far as the projection on the initial mode goes.
+    Returns (amplitude of the initial mode at the end / amp0, largest deviation of U from amplitude * mode, relative to amp0)"""
+    nx, ny, nz = shape
+    axes = [q for q, m in enumerate(shape) if m > 1]
+    n = shape[axes[0]]
+    dx = np.pi / n
+    s = make_solver(shape, dx, dt, nu)
+    cs = [(np.arange(m) + 0.5) * dx for m in shape]
+    Z, Y, X = np.meshgrid(cs[2], cs[1], cs[0], indexing="ij")
+    co = [X, Y, Z]
+    mode = np.zeros((nz, ny, nx, 3))
+    if three_d:
+        mode[..., 0] = np.sin(X) * np.cos(Y) * np.cos(Z)
+        mode[..., 1] = -np.cos(X) * np.sin(Y) * np.cos(Z)
+    else:
+        a, b = axes
+        mode[..., a] = np.sin(co[a]) * np.cos(co[b])
+        mode[..., b] = -np.cos(co[a]) * np.sin(co[b])
+    s.set("U", (amp0 * mode).reshape(-1, 3))
+    for _ in range(steps):
+        s.step()
+    U = s.get("U").reshape(nz, ny, nx, 3)
+    amp = (U * mode).sum() / (mode * mode).sum()
+    dev = np.abs(U - amp * mode).max() / amp0
+    s.close()
+    return amp / amp0, dev
+
+
+def slip_box(solver=0, **kw):
+    def mk(shape, dx, dt, nu):
+        return orc.fv_case(solver, shape[0], shape[1], shape[2], dx, dt, nu, u_bc=[orc.U_SLIP] * 6, u_tol=1e-12, p_tol=1e-11, p_final_tol=1e-11,
+                           p_rel_tol=0.0, **kw)
+    return mk
+
+
 def closed_box(n, p_solver=1):
     return orc.fv_case(0, n, n, n, 1.0 / n, 0.01, 1e-14, p_solver=p_solver, p_final_tol=1e-10, p_tol=1e-10, p_rel_tol=0.0)     # (inviscid: rAU = dt in every cell)
 
@@ -654,3 +696,58 @@ def test_graded_block_refuses_what_it_does_not_carry(oracle):
         orc.FvSolver(orc.fv_case(1, 6, 6, 6, 1.0 / 6, 0.01, 0.01, turbulence_model=1, grading=(h, h, h)))
     with pytest.raises(ValueError):
         orc.FvSolver(orc.fv_case(0, 6, 6, 6, 1.0 / 6, 0.01, 0.01, convection_scheme=2, grading=(h, h, h)))
+
+
+def taylor_green_2d_checks(mk, plane, sizes=(8, 16, 32)):
+    """(shared with the HIP solver's test) U: symmetryPlane / slip on every side.  amp0 = 1: Re = amp0 pi / nu = 31, the convective term is five
+    times the viscous one and balanced by the pressure gradient exactly -- the amplitude error is the sum of the diffusion operator's
+    (second order, positive: the discrete Laplacian and implicit Euler both decay too slowly) and the convection scheme's (negative, falling
+    faster), so it is held to bounds that fall with n, not to a ratio; amp0 = 0.01 leaves the diffusion error alone, which falls 4x per level"""
+    nu, T = 0.1, 0.5
+    bound = {8: 5e-3, 16: 6e-4, 32: 1.5e-4, 64: 5e-5}
+    shape_of = lambda n: {"xy": (n, n, 1), "yz": (1, n, n), "xz": (n, 1, n)}[plane]
+    lin = []
+    for n in sizes:
+        dt = 0.1 * (8.0 / n) ** 2                                 # dx halves, dt quarters
+        steps = int(round(T / dt))
+        amp, dev = taylor_green(mk, shape_of(n), nu, dt, steps)
+        assert abs(amp - np.exp(-2 * nu * T)) < bound[n], (n, amp - np.exp(-2 * nu * T))
+        assert dev < 0.02 * (8.0 / n) ** 3, (n, dev)              # the vortex keeps its shape (measured: 4th order)
+        amp, dev = taylor_green(mk, shape_of(n), nu, dt, steps, amp0=0.01)
+        lin.append(amp - np.exp(-2 * nu * T))
+        assert dev < 2e-4 * (8.0 / n) ** 2, (n, dev)
+    for a_, b_ in zip(lin, lin[1:]):
+        assert a_ > 0 and 3.7 < a_ / b_ < 4.3, lin
+
+
+@pytest.mark.parametrize("plane", ["xy", "yz", "xz"])
+def test_taylor_green_vortex_between_symmetry_planes_is_the_exact_navier_stokes_solution(oracle, plane):
+    taylor_green_2d_checks(lambda shape, dx, dt, nu_: orc.FvSolver(slip_box()(shape, dx, dt, nu_)), plane)
+
+
+def test_three_dimensional_taylor_green_vortex_decays_at_the_stokes_rate(oracle):
+    """the genuinely three-dimensional transient: at Re = amp pi / nu = 0.03 the initial Taylor-Green field decays in place as exp(-3 nu t)"""
+    nu, T, amp0 = 1.0, 0.1, 0.01
+    mk = lambda shape, dx, dt, nu_: orc.FvSolver(slip_box()(shape, dx, dt, nu_))
+    errs = []
+    for n in (8, 16):
+        dt = 0.004 * (8.0 / n) ** 2
+        amp, dev = taylor_green(mk, (n, n, n), nu, dt, int(round(T / dt)), amp0=amp0, three_d=True)
+        errs.append(abs(amp - np.exp(-3 * nu * T)))
+        assert dev < 1e-3, (n, dev)
+    assert errs[1] < 1.5e-3 and 3.3 < errs[0] / errs[1] < 4.7, errs
+
+
+def test_slip_walls_carry_no_flux_and_no_shear(oracle):
+    """a uniform stream along slip walls stays uniform (no boundary layer); the same box with no-slip walls slows down at the walls"""
+    n = 8
+    u_bc = [orc.U_ZEROGRAD, orc.U_ZEROGRAD, orc.U_SLIP, orc.U_SLIP, orc.U_SLIP, orc.U_SLIP]
+    p_bc = [orc.P_ZEROGRAD, orc.P_FIXED] + [orc.P_ZEROGRAD] * 4
+    s = orc.FvSolver(orc.fv_case(0, n, n, n, 1.0 / n, 0.01, 0.05, u_bc=u_bc, p_bc=p_bc, u_tol=1e-12, p_tol=1e-12, p_final_tol=1e-12, p_rel_tol=0.0))
+    U0 = np.zeros((n ** 3, 3)); U0[:, 0] = 1.0
+    s.set("U", U0)
+    for _ in range(5):
+        s.step()
+    np.testing.assert_allclose(s.get("U").reshape(-1, 3), U0, atol=1e-9)
+    assert np.abs(s.get("phi_y")).max() < 1e-12 and np.abs(s.get("phi_z")).max() < 1e-12
+    s.close()

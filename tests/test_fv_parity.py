@@ -529,3 +529,80 @@ def test_graded_block_refusals(product):
             product.Solver(c)
     with pytest.raises(product.FoamYadeError, match="z-slabs"):
         product.VirtualSlabs(product.make_case(0, 8, 8, 8, 0.125, 1e-3, 1e-3, grading=(h, h, h)), 2)
+
+
+# ---- symmetryPlane / slip sides ------------------------------------------------------------------------------------------------------
+def vortex_field(nx, ny, nz, dx):
+    """a swirling, divergence-free start that slides along every side of the box"""
+    cs = [(np.arange(m) + 0.5) * dx for m in (nx, ny, nz)]
+    L = [m * dx for m in (nx, ny, nz)]
+    Z, Y, X = np.meshgrid(cs[2], cs[1], cs[0], indexing="ij")
+    U = np.zeros((nz, ny, nx, 3))
+    kx, ky, kz = np.pi / L[0], np.pi / L[1], np.pi / L[2]
+    U[..., 0] = np.sin(kx * X) * np.cos(ky * Y) * np.cos(kz * Z) / kx
+    U[..., 1] = -0.4 * np.cos(kx * X) * np.sin(ky * Y) * np.cos(kz * Z) / ky
+    U[..., 2] = -0.6 * np.cos(kx * X) * np.cos(ky * Y) * np.sin(kz * Z) / kz
+    return U.reshape(-1, 3)
+
+
+@pytest.mark.parametrize("solver,kw", [(0, {}), (0, dict(convection_scheme=1)), (1, dict(u_relax=0.7, n_outer=2)), (1, dict(u_relax=0.0))])
+def test_slip_sides_match_oracle(product, oracle, solver, kw):
+    """four symmetry planes, a moving lid and a wall: the per-component boundary diagonal in the momentum solve, its component average in
+    A() and the remainder in H(), with relax() on top in pimple"""
+    nx, ny, nz = 14, 12, 10
+    dx = 1.0 / 14
+    u_bc = [2, 2, 0, 0, 2, 2]
+    u_val = [(0, 0, 0)] * 6
+    u_val[YMAX] = (0.5, 0, 0.2)
+    o, s = both(product, oracle, solver, nx, ny, nz, dx, 0.02, 0.01, u_bc=u_bc, u_val=u_val, **kw)
+    U0 = 0.3 * vortex_field(nx, ny, nz, dx)
+    o.set("U", U0); s.set("U", U0)
+    for step in range(5):
+        o.step(); s.step()
+        so, ss = o.stats(), s.stats()
+        assert abs(so["p_iters_total"] - ss["p_iters_total"]) <= 2 and abs(so["u_iters_total"] - ss["u_iters_total"]) <= 1
+        if step == 0:
+            for nm in ("mom_diag", "rAU", "HbyA"):
+                np.testing.assert_allclose(s.get(nm), o.get(nm), rtol=1e-9, atol=1e-12, err_msg=nm)
+    compare(o, s)
+    for side, nm in ((XMIN, "phi_x"), (ZMIN, "phi_z")):
+        assert np.abs(s.get(nm)).max() > 1e-4
+    px = s.get("phi_x").reshape(nz, ny, nx + 1)
+    pz = s.get("phi_z").reshape(nz + 1, ny, nx)
+    assert np.abs(px[:, :, 0]).max() == 0 and np.abs(px[:, :, -1]).max() == 0 and np.abs(pz[0]).max() == 0 and np.abs(pz[-1]).max() == 0
+    o.close(); s.close()
+
+
+def test_slip_sides_on_a_graded_block_match_oracle(product, oracle):
+    n = 12
+    g = (wall_refined_sizes(n, 3.0, 1.0), geometric_sizes(n, 2.0, 1.0), wall_refined_sizes(n, 2.0, 0.8))
+    u_val = [(0, 0, 0)] * 6
+    u_val[YMAX] = (0.5, 0, 0)
+    o, s = both(product, oracle, 0, n, n, n, 1.0 / n, 0.01, 0.01, u_bc=[2, 2, 0, 0, 2, 2], u_val=u_val, grading=g)
+    for step in range(5):
+        o.step(); s.step()
+    compare(o, s)
+    assert np.abs(s.get("U")).max() > 0.02
+    o.close(); s.close()
+
+
+def test_slip_sides_in_virtual_slabs_match_single_domain(product):
+    n, n_slabs = 12, 2
+    nz = n * n_slabs
+    dx = 1.0 / n
+    u_val = [(0, 0, 0)] * 6
+    u_val[YMAX] = (0.5, 0, 0.1)
+    case = product.make_case(0, n, n, nz, dx, 0.02, 0.01, u_bc=[2, 2, 0, 0, 2, 2], u_val=u_val)
+    one = product.Solver(case); many = product.VirtualSlabs(case, n_slabs)
+    U0 = 0.3 * vortex_field(n, n, nz, dx)
+    one.set("U", U0); many.set("U", U0)
+    for step in range(4):
+        one.step(); many.step()
+    compare(one, many, ("U", "p"), 1e-5)
+    one.close(); many.close()
+
+
+def test_unknown_boundary_types_are_refused(product):
+    case = product.make_case(0, 8, 8, 8, 0.125, 0.01, 0.01, u_bc=[0, 0, 0, 3, 0, 0])
+    with pytest.raises(product.FoamYadeError):
+        product.Solver(case)

@@ -30,7 +30,7 @@ FY_MEM_HOST, FY_MEM_DEVICE = 0, 1
 FY_T_INT, FY_T_DOUBLE = 0, 1
 FY_OP_MAX, FY_OP_SUM = 0, 1
 FY_SOLVER_ICO, FY_SOLVER_PIMPLE = 0, 1
-FY_BC_U_FIXED_VALUE, FY_BC_U_ZERO_GRADIENT = 0, 1
+FY_BC_U_FIXED_VALUE, FY_BC_U_ZERO_GRADIENT, FY_BC_U_SLIP = 0, 1, 2
 FY_BC_P_ZERO_GRADIENT, FY_BC_P_FIXED_VALUE, FY_BC_P_FIXED_FLUX = 0, 1, 2
 FY_PSOLVER_PCG_JACOBI, FY_PSOLVER_PCG_MG = 0, 1
 FY_CONVECTION_LINEAR, FY_CONVECTION_UPWIND, FY_CONVECTION_LINEAR_UPWIND = 0, 1, 2

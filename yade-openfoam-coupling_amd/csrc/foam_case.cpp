@@ -234,8 +234,10 @@ int read_fields(fy_foam_case* c) {
                 c->desc.u_bc[s] = FY_BC_U_FIXED_VALUE;
             } else if (ty == "zeroGradient") {
                 c->desc.u_bc[s] = FY_BC_U_ZERO_GRADIENT;
+            } else if (ty == "symmetryPlane" || ty == "symmetry" || ty == "slip") {       // (one and the same on a planar patch)
+                c->desc.u_bc[s] = FY_BC_U_SLIP;
             } else {
-                return fail(FY_ERR_UNSUPPORTED, "%s: patch '%s': velocity boundary type '%s' is not supported (fixedValue, noSlip, zeroGradient)", path.c_str(),
+                return fail(FY_ERR_UNSUPPORTED, "%s: patch '%s': velocity boundary type '%s' is not supported (fixedValue, noSlip, zeroGradient, symmetryPlane, symmetry, slip)", path.c_str(),
                             c->patch_of_side[s].c_str(), ty.c_str());
             }
         }
@@ -253,7 +255,7 @@ int read_fields(fy_foam_case* c) {
             if (!pd || !pd->word("type", &ty)) return fail(FY_ERR_INVALID, "%s: boundaryField has no (typed) entry for patch '%s'", path.c_str(), c->patch_of_side[s].c_str());
             c->p_bc_text[s] = entry_text(*pd);
             c->desc.p_value[s] = 0.0;
-            if (ty == "zeroGradient") c->desc.p_bc[s] = FY_BC_P_ZERO_GRADIENT;
+            if (ty == "zeroGradient" || ty == "symmetryPlane" || ty == "symmetry") c->desc.p_bc[s] = FY_BC_P_ZERO_GRADIENT;       // (a scalar on a symmetry plane: the cell value)
             else if (ty == "fixedFluxPressure") c->desc.p_bc[s] = FY_BC_P_FIXED_FLUX;
             else if (ty == "fixedValue") {
                 c->desc.p_bc[s] = FY_BC_P_FIXED_VALUE;
@@ -282,7 +284,7 @@ int read_fields(fy_foam_case* c) {
             if (!pd || !pd->word("type", &ty)) return fail(FY_ERR_INVALID, "%s: boundaryField has no (typed) entry for patch '%s'", path.c_str(), c->patch_of_side[s].c_str());
             c->nut_bc_text[s] = entry_text(*pd);
             c->desc.nut_value[s] = 0.0;
-            if (ty == "zeroGradient") c->desc.nut_bc[s] = FY_BC_NUT_ZERO_GRADIENT;
+            if (ty == "zeroGradient" || ty == "symmetryPlane" || ty == "symmetry") c->desc.nut_bc[s] = FY_BC_NUT_ZERO_GRADIENT;
             else if (ty == "fixedValue") {
                 c->desc.nut_bc[s] = FY_BC_NUT_FIXED_VALUE;
                 const auto* vt = pd->tokens("value");
@@ -321,7 +323,7 @@ int read_fields(fy_foam_case* c) {
             if (!pd || !pd->word("type", &ty)) return fail(FY_ERR_INVALID, "%s: boundaryField has no (typed) entry for patch '%s'", path.c_str(), c->patch_of_side[s].c_str());
             c->k_bc_text[s] = entry_text(*pd);
             c->desc.k_value[s] = 0.0;
-            if (ty == "zeroGradient" || ty == "kqRWallFunction") c->desc.k_bc[s] = FY_BC_NUT_ZERO_GRADIENT;
+            if ((ty == "zeroGradient" || ty == "symmetryPlane" || ty == "symmetry") || ty == "kqRWallFunction") c->desc.k_bc[s] = FY_BC_NUT_ZERO_GRADIENT;
             else if (ty == "fixedValue") {
                 c->desc.k_bc[s] = FY_BC_NUT_FIXED_VALUE;
                 const auto* vt = pd->tokens("value");
@@ -348,7 +350,7 @@ int read_fields(fy_foam_case* c) {
             if (!pd || !pd->word("type", &ty)) return fail(FY_ERR_INVALID, "%s: boundaryField has no (typed) entry for patch '%s'", path.c_str(), c->patch_of_side[s].c_str());
             c->eps_bc_text[s] = entry_text(*pd);
             c->desc.eps_value[s] = 0.0;
-            if (ty == "zeroGradient") c->desc.eps_bc[s] = FY_BC_NUT_ZERO_GRADIENT;
+            if (ty == "zeroGradient" || ty == "symmetryPlane" || ty == "symmetry") c->desc.eps_bc[s] = FY_BC_NUT_ZERO_GRADIENT;
             else if (ty == "fixedValue") {
                 c->desc.eps_bc[s] = FY_BC_NUT_FIXED_VALUE;
                 const auto* vt = pd->tokens("value");

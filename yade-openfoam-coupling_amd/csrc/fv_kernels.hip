@@ -135,6 +135,8 @@ __device__ __forceinline__ bool face_high_b(const FvGeo& g, int d, int q) { retu
 __device__ __forceinline__ void Ub(const FvGeo& g, const double* F, int c, int patch, double* out) {
     if (g.u_bc[patch] == 0) { out[0] = g.u_val[patch][0]; out[1] = g.u_val[patch][1]; out[2] = g.u_val[patch][2]; }
     else { out[0] = F[3 * (size_t)c]; out[1] = F[3 * (size_t)c + 1]; out[2] = F[3 * (size_t)c + 2]; }
+    // symmetryPlane / slip on a planar, axis-aligned patch [OF-6 basicSymmetryFvPatchField::evaluate]: the cell value without its normal component
+    if (g.u_bc[patch] == 2) out[patch >> 1] = 0.0;
 }
 __device__ __forceinline__ double pbv(const FvGeo& g, const double* p, const CFace3& psn, int c, int d, int s, int face) {
     const int patch = 2 * d + s;
@@ -832,6 +834,7 @@ __global__ __launch_bounds__(256) void k_assemble_momentum(FvGeo g, const double
     double s3[3];
     for (int q = 0; q < 3; ++q) s3[q] = aP0 * V * Uold[3 * (size_t)c + q] / dt;
     double divAPhi = 0.0, an[6];
+    double bd[3] = {0.0, 0.0, 0.0};               // per-component boundary diagonal (slip patches; M.bd)
 #pragma unroll
     for (int d = 0; d < 3; ++d)
 #pragma unroll
@@ -861,6 +864,9 @@ __global__ __launch_bounds__(256) void k_assemble_momentum(FvGeo g, const double
                     dg += gb;
                     for (int q = 0; q < 3; ++q) s3[q] += (-phio + gb) * g.u_val[patch][q];
                 } else {
+                    // symmetryPlane / slip [OF-6 transformFvPatchField::gradientInternalCoeffs with basicSymmetry's snGradTransformDiag]: the
+                    // NORMAL component sees a fixed value 0 (implicit coefficient only), the tangential ones a zero gradient
+                    if (g.u_bc[patch] == 2) bd[d] += kBfac * gam;
                     dg += phio;
                 }
             } else {
@@ -893,7 +899,9 @@ __global__ __launch_bounds__(256) void k_assemble_momentum(FvGeo g, const double
         if (g.u_relax > 0) {
             // fvMatrix::relax(alpha) [OF-6 fvMatrix.C]: D = max(|D|, sum|offdiag|) / alpha (the boundary coefficients, part of dg here all
             // along, take part in the dominance test), source += (D_new - D_old) psi; no factor for the equation: relax() does nothing
-            const double dn = fmax(fabs(dg), so) / g.u_relax;
+            // (a slip patch's coefficient differs by component: relax() adds cmptMax(cmptMag(internalCoeffs)) before the test and takes
+            // cmptMin (= 0) off afterwards -- all of it joins the test, the scalar diagonal keeps what the test gave)
+            const double dn = fmax(fabs(dg + ((bd[0] + bd[1]) + bd[2])), so) / g.u_relax;
             for (int q = 0; q < 3; ++q) s3[q] += (dn - dg) * U[3 * (size_t)c + q];
             dg = dn;
         }
@@ -903,7 +911,10 @@ __global__ __launch_bounds__(256) void k_assemble_momentum(FvGeo g, const double
     M.diag[c] = dg;
     for (int q = 0; q < 6; ++q) M.an[q][c] = an[q];
     for (int q = 0; q < 3; ++q) src[3 * (size_t)c + q] = s3[q];
-    rAU[c] = 1.0 / (dg / V);
+    // 1 / UEqn.A(): fvMatrix::A() adds the COMPONENT AVERAGE of the boundary diagonal
+    double bav = 0.0;
+    if (M.bd) { for (int q = 0; q < 3; ++q) M.bd[3 * (size_t)c + q] = bd[q]; bav = ((bd[0] + bd[1]) + bd[2]) / 3.0; }
+    rAU[c] = 1.0 / ((dg + bav) / V);
 }
 
 // RHS of the momentum predictor: ico  src - V grad(p)            (icoFoamYade.C:91-94)
@@ -954,6 +965,8 @@ __global__ __launch_bounds__(256) void k_mom_pass(FvGeo g, Mom7 M, const double*
         int i, j, k; ijk_of(g, t, i, j, k);
         const int c = t + g.c0;
         const double dg = M.diag[c];
+        double dq[3] = {dg, dg, dg};                      // (fvMatrix::solveSegregated: addBoundaryDiag per component)
+        if (M.bd) for (int q = 0; q < 3; ++q) dq[q] += M.bd[3 * (size_t)c + q];
         double off[3] = {0, 0, 0}, rowsum = dg;
         const double xc[3] = {x[3 * (size_t)c], x[3 * (size_t)c + 1], x[3 * (size_t)c + 2]};
         double xx[2][3];
@@ -971,11 +984,11 @@ __global__ __launch_bounds__(256) void k_mom_pass(FvGeo g, Mom7 M, const double*
                 }
         for (int q = 0; q < 3; ++q) {
             const double bq = b[3 * (size_t)c + q];
-            const double Ax = dg * xc[q] + off[q];
-            const double Aref = rowsum * xb[q];
+            const double Ax = dq[q] * xc[q] + off[q];
+            const double Aref = (rowsum + (dq[q] - dg)) * xb[q];
             v[q] += fabs(bq - Ax);
             v[3 + q] += fabs(Ax - Aref) + fabs(bq - Aref);
-            xn[3 * (size_t)c + q] = (bq - off[q]) / dg;
+            xn[3 * (size_t)c + q] = (bq - off[q]) / dq[q];
         }
     }
     const int mx[6] = {0, 0, 0, 0, 0, 0};
@@ -1008,6 +1021,12 @@ __global__ __launch_bounds__(256) void k_HbyA(FvGeo g, Mom7 M, const double* __r
                 const double a = M.an[2 * d + s][c];
                 for (int q = 0; q < 3; ++q) acc[q] -= a * U[3 * (size_t)nb + q];
             }
+    if (M.bd) {
+        // fvMatrix::H(): per component (component-averaged boundary diagonal - that component's) * psi
+        const double b0 = M.bd[3 * (size_t)c], b1 = M.bd[3 * (size_t)c + 1], b2 = M.bd[3 * (size_t)c + 2];
+        const double bav = ((b0 + b1) + b2) / 3.0;
+        acc[0] += (bav - b0) * U[3 * (size_t)c]; acc[1] += (bav - b1) * U[3 * (size_t)c + 1]; acc[2] += (bav - b2) * U[3 * (size_t)c + 2];
+    }
     const double r = rAU[c];
     for (int q = 0; q < 3; ++q) HbyA[3 * (size_t)c + q] = r * (acc[q] * geo_rV(g, i, j, k));
 }

@@ -55,7 +55,10 @@ struct FvGeo {
 
 struct Face3 { double* a[3]; };           // +axis oriented face arrays (x: (nx+1)*ny*nz, y: nx*(ny+1)*nz, z: nx*ny*(nz+1))
 struct CFace3 { const double* a[3]; };
-struct Mom7 { double* diag; double* an[6]; };   // momentum matrix: diag + neighbour coefficient across face 2*d+s
+// momentum matrix: diag + neighbour coefficient across face 2*d+s.  bd ([3 x storage cells], nullptr without a slip patch): the boundary
+// diagonal that differs by component -- a symmetryPlane / slip patch puts the wall coefficient on the NORMAL component only (fvMatrix keeps
+// such internalCoeffs apart from the scalar lduMatrix diagonal: solve adds them per component, A() their component average, H() the rest)
+struct Mom7 { double* diag; double* an[6]; double* bd; };
 
 // symmetric 7-point pressure matrix of one multigrid level: (A x)_c = diag_c x_c - sum u_f x_nb, u_* stored at the owner (low) cell
 struct PMat {

@@ -66,6 +66,7 @@ struct Solver {
     CFace3 phi_now() const { return phi_fresh ? CFace3{{phi[0].p, phi[1].p, phi[2].p}} : CFace3{{phiOld[0].p, phiOld[1].p, phiOld[2].p}}; }
     bool rAU_new = true;        // rAU was (re)assembled since the last corrector: rAUf and the coarse pressure operators are stale
     DevBuf<double> phi[3], phiOld[3], psn[3], alphaf[3], phiHbyA[3], phiForces[3], rAUf[3], pflux[3];
+    DevBuf<double> mbd;                  // [3 nstore] per-component boundary diagonal of the momentum matrix (Mom7::bd): only with a slip patch
     DevBuf<double> mdiag, man[6], src, rAU, HbyA, bmom, Gt, divG, xscr;
     std::vector<std::unique_ptr<MgLev> > mg;
     size_t mg_rep = 0;            // first replicated level (== mg.size() when nothing is replicated)
@@ -96,7 +97,8 @@ struct Solver {
 
     Face3 F3(DevBuf<double>* a) { Face3 f; for (int d = 0; d < 3; ++d) f.a[d] = a[d].p; return f; }
     CFace3 C3(DevBuf<double>* a) { CFace3 f; for (int d = 0; d < 3; ++d) f.a[d] = a[d].p; return f; }
-    Mom7 M7() { Mom7 m; m.diag = mdiag.p; for (int q = 0; q < 6; ++q) m.an[q] = man[q].p; return m; }
+    // with_bd: the momentum matrix (the k / epsilon equations re-use diag / an and have no per-component boundary diagonal)
+    Mom7 M7(bool with_bd = true) { Mom7 m; m.diag = mdiag.p; for (int q = 0; q < 6; ++q) m.an[q] = man[q].p; m.bd = with_bd ? mbd.p : nullptr; return m; }
 
     ~Solver() {
         if (cpl) fy_destroy(cpl);
@@ -193,6 +195,8 @@ struct Solver {
         g.pimple = pimple ? 1 : 0; g.dt = c->dt; g.nu = c->nu;
         bool need_ref = true;
         for (int q = 0; q < 6; ++q) {
+            if (c->u_bc[q] != FY_BC_U_FIXED_VALUE && c->u_bc[q] != FY_BC_U_ZERO_GRADIENT && c->u_bc[q] != FY_BC_U_SLIP) return fail(FY_ERR_INVALID, "fy_solver_create: unknown velocity boundary type %d on side %d", c->u_bc[q], q);
+            if (c->p_bc[q] != FY_BC_P_ZERO_GRADIENT && c->p_bc[q] != FY_BC_P_FIXED_VALUE && c->p_bc[q] != FY_BC_P_FIXED_FLUX) return fail(FY_ERR_INVALID, "fy_solver_create: unknown pressure boundary type %d on side %d", c->p_bc[q], q);
             g.u_bc[q] = c->u_bc[q]; g.p_bc[q] = c->p_bc[q]; g.p_val[q] = c->p_value[q];
             for (int a = 0; a < 3; ++a) g.u_val[q][a] = c->u_value[q][a];
             if (c->p_bc[q] == FY_BC_P_FIXED_VALUE) need_ref = false;
@@ -262,6 +266,7 @@ struct Solver {
             bool adjustable = false;
             const double area[3] = {(double)c->ny * c->nz, (double)c->nx * c->nz, (double)c->nx * c->ny};
             for (int q = 0; q < 6; ++q) {
+                if (c->u_bc[q] == FY_BC_U_SLIP) continue;                       // (carries no flux, and none to adjust)
                 if (c->u_bc[q] != FY_BC_U_FIXED_VALUE) { adjustable = true; continue; }
                 const double un = c->u_value[q][q / 2] * ((q & 1) ? 1.0 : -1.0) * area[q / 2];
                 net += un; mag += std::fabs(un);
@@ -278,6 +283,7 @@ struct Solver {
         DevBuf<double>* v1[] = {&p, &alpha, &uSourceDrag, &mdiag, &rAU, &prhs, &pr, &pw, &pp, &pzj};
         for (auto* b : v1) { FY_TRY(b->alloc_exact(n)); FY_TRY(zero(*b)); }
         for (auto& b : man) { FY_TRY(b.alloc_exact(n)); FY_TRY(zero(b)); }
+        for (int q = 0; q < 6; ++q) if (c->u_bc[q] == FY_BC_U_SLIP && !mbd.p) { FY_TRY(mbd.alloc_exact(3 * n)); FY_TRY(zero(mbd)); }
         FY_TRY(vGrad.alloc_exact(9 * n)); FY_TRY(zero(vGrad));
         if (c->turbulence_model != FY_TURBULENCE_LAMINAR) { FY_TRY(nut.alloc_exact(n)); FY_TRY(launch_fill_f64(stream, nut.p, n, c->nut_initial)); g.nut = nut.p; }
         if (c->turbulence_model == FY_TURBULENCE_KEQN || c->turbulence_model == FY_TURBULENCE_KEPSILON) { FY_TRY(kturb.alloc_exact(n)); FY_TRY(launch_fill_f64(stream, kturb.p, n, c->k_initial)); g.kturb = kturb.p; }
@@ -479,10 +485,10 @@ struct Solver {
     }
 
     // ---- momentum predictor: Jacobi sweeps with lduMatrix-style L1 residual control (stand-in for smoothSolver) ----------
-    int solve_momentum(int* iters) { return solve_vec3(U, bmom.p, cs.u_tol, cs.u_rel_tol, cs.u_max_iter, iters); }
+    int solve_momentum(int* iters) { return solve_vec3(U, bmom.p, cs.u_tol, cs.u_rel_tol, cs.u_max_iter, iters, true); }
     // Jacobi sweeps on the 7-point matrix in M7() for a 3-component field X (in place; xscr is the other buffer), lduMatrix-style L1
     // residual control per component
-    int solve_vec3(DevBuf<double>& X, const double* rhs, double tol, double rel_tol, int max_iter, int* iters) {
+    int solve_vec3(DevBuf<double>& X, const double* rhs, double tol, double rel_tol, int max_iter, int* iters, bool momentum = false) {
         double h[6];
         // sum(X) per component for xbar = average(X): folded (and all-reduced) on the device, divided where it is used
         FY_TRY(launch_sum3(stream, X.p + 3 * (size_t)g.c0, Nc, partials.p));
@@ -494,7 +500,7 @@ struct Solver {
         for (;;) {
             FY_TRY(halo(xc, 3, plane, g.nz, g.gz, 1));
             kc[KC_MOM_PASS].begin(stream);
-            FY_TRY(FVK(launch_mom_pass, stream, g, M7(), rhs, xc, xn, xbar3.p, (double)Nglob, partials.p));
+            FY_TRY(FVK(launch_mom_pass, stream, g, M7(momentum), rhs, xc, xn, xbar3.p, (double)Nglob, partials.p));
             kc[KC_MOM_PASS].end(stream);
             FY_TRY(reduce_read(6, false, h));
             if (it == 0) for (int q = 0; q < 3; ++q) { norm[q] = h[3 + q] + 1e-20; res0[q] = h[q] / norm[q]; }
