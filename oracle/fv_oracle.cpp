@@ -115,6 +115,11 @@ struct Fv {
     inline double sfd(int d, int s, int i, int j, int k) const { return graded ? area(d, i, j, k) / delta(d, fq(d, s, i, j, k)) : dx; }
     inline double bfac() const { return graded ? 1.0 : 2.0; }          // (gb = bfac * gamma: see sfd)
     inline double hcell(int d, int c) const { return graded ? h[d][idx_of(d, c)] : dx; }
+    // LESdelta cubeRootVol [OF-6 cubeRootVolDelta.C]: deltaCoeff * cbrt(V) of the cell; nearWallDist: half the cell's extent along the wall normal
+    inline double les_delta(int c) const { return graded ? cs.les_delta_coeff * std::cbrt(volc(c)) : cs.les_delta_coeff * std::pow(V, 1.0 / 3.0); }
+    inline double ywall_of(int d, int c) const { return 0.5 * hcell(d, c); }
+    // linear face interpolate of a cell pair across face (d, s) of the cell with index qc along d: own = this cell's value, nb = the neighbour's
+    inline double lerp_side(int d, int s, int qc, double own, double nb) const { return !graded ? 0.5 * (own + nb) : (s ? lerp(d, qc + 1, own, nb) : lerp(d, qc, nb, own)); }
     int threads = 1;
     // state
     vec U, Uold, p, alpha, alphaOld, uSource, uSourceDrag, uParticle, gradP, divT, vGrad, ddtU;
@@ -326,14 +331,14 @@ struct Fv {
         if (t == 1 || ((t == 2 || t == 3) && !nut_wall_live)) return cs.nut_value[patch];
         if (t == 3) {       // calculated: nut_ = <model expression> assigns the boundary too [OF-6 GeometricField::operator=]: Ck sqrt(k_b) delta | Cmu k_b^2/eps_b
             const double kb = cs.k_bc[patch] == 1 ? cs.k_value[patch] : kturb[c];
-            if (cs.turbulence_model == 2) return cs.les_ck * std::sqrt(kb) * (cs.les_delta_coeff * std::pow(V, 1.0 / 3.0));
+            if (cs.turbulence_model == 2) return cs.les_ck * std::sqrt(kb) * les_delta(c);
             const double eb = cs.eps_bc[patch] == 1 ? cs.eps_value[patch] : epsturb[c];
             return cs.ras_cmu * (kb * kb) / eb;
         }
         if (t == 2) {
             double ypl = 11.0;
             for (int it = 0; it < 10; ++it) ypl = std::log(std::max(cs.wf_E * ypl, 1.0)) / cs.wf_kappa;
-            const double y = 0.5 * dx;
+            const double y = ywall_of(patch / 2, c);
             const double yPlus = std::pow(cs.ras_cmu, 0.25) * y * std::sqrt(kturb[c]) / cs.nu;
             return yPlus > ypl ? cs.nu * (yPlus * cs.wf_kappa / std::log(cs.wf_E * yPlus) - 1.0) : 0.0;
         }
@@ -397,7 +402,7 @@ struct Fv {
                         gam = (af * (nu + nb)) * geo;
                     } else {
                         const int nbc = c + (s ? stride[d] : -stride[d]);
-                        gam = (0.5 * ((aP * (nu + nut[c])) + (alpha[nbc] * (nu + nut[nbc])))) * geo;
+                        gam = lerp_side(d, s, d == 0 ? i : d == 1 ? j : k, aP * (nu + nut[c]), alpha[nbc] * (nu + nut[nbc])) * geo;
                     }
                 }
                 if (onb(d, s, i, j, k)) {
@@ -431,7 +436,7 @@ struct Fv {
                         // the second term explicit (deferred correction) with the Gauss-linear gradient of the current U
                         const int nb = c + (s ? stride[d] : -stride[d]);
                         const int uw = phio > 0.0 ? c : nb;
-                        const double half = (phio > 0.0 ? (s ? 0.5 : -0.5) : (s ? -0.5 : 0.5)) * dx;
+                        const double half = (phio > 0.0 ? (s ? 0.5 : -0.5) : (s ? -0.5 : 0.5)) * hcell(d, uw);      // half the UPWIND cell's extent, towards the face
                         for (int q = 0; q < 3; ++q) s3[q] -= phio * (half * vGrad[9 * (size_t)uw + 3 * d + q]);
                     }
                 }
@@ -1023,14 +1028,21 @@ struct Fv {
     // [OF-6 fvm::SuSp: diag += V max(susp, 0), source -= V min(susp, 0) psi; fvMatrix == volField: source += V field;
     //  bound.C: X = max(max(X, fvc::average(max(X, XMin)) pos0(-X)), XMin)].  alpha.oldTime() == alpha (quirk F-Q1).
     void turb_eqn(int mode) {
-        const double nu = cs.nu, dt = cs.dt, delta = cs.les_delta_coeff * std::pow(V, 1.0 / 3.0), xMin = 1e-15;
+        const double nu = cs.nu, dt = cs.dt, xMin = 1e-15;
         const double sigma = mode == 0 ? 1.0 : mode == 1 ? cs.ras_sigmaeps : cs.ras_sigmak;
         int bcv[6];
         for (int q = 0; q < 6; ++q) bcv[q] = mode == 1 ? (cs.eps_bc[q] == 2 ? 0 : cs.eps_bc[q]) : cs.k_bc[q];      // an epsilonWallFunction patch is never asked for a face value: the wall cells are imposed
         const int* bc = bcv;
         auto wallp = [&](int patch) { return mode != 0 && cs.eps_bc[patch] == 2; };
         auto wall_count = [&](int i, int j, int k) { int w = 0; for (int d = 0; d < 3; ++d) for (int sd = 0; sd < 2; ++sd) if (wallp(2 * d + sd) && onb(d, sd, i, j, k)) ++w; return w; };
-        const double ywall = 0.5 * dx, cmu75 = std::pow(cs.ras_cmu, 0.75), cmu25 = std::pow(cs.ras_cmu, 0.25);
+        const double cmu75 = std::pow(cs.ras_cmu, 0.75), cmu25 = std::pow(cs.ras_cmu, 0.25);
+        // the value epsilonWallFunction imposes on a cell with wall faces: the average over them of Cmu^3/4 k^3/2 / (kappa y_w)
+        auto wall_eps = [&](int c, int i, int j, int k) {
+            if (!graded) return cmu75 * std::pow(kturb[c], 1.5) / (cs.wf_kappa * ywall_of(0, c));
+            double sum = 0.0; int W = 0;
+            for (int d = 0; d < 3; ++d) for (int sd = 0; sd < 2; ++sd) if (wallp(2 * d + sd) && onb(d, sd, i, j, k)) { sum += cmu75 * std::pow(kturb[c], 1.5) / (cs.wf_kappa * ywall_of(d, c)); ++W; }
+            return sum / (double)W;
+        };
         const double* bval = mode == 1 ? cs.eps_value : cs.k_value;
         const int scheme = mode == 1 ? cs.eps_convection_scheme : cs.k_convection_scheme;
         const double relax = mode == 1 ? cs.eps_relax : cs.k_relax;
@@ -1039,6 +1051,7 @@ struct Fv {
         for (int k = 0; k < nz; ++k) for (int j = 0; j < ny; ++j) for (int i = 0; i < nx; ++i) {
             const int c = cid(i, j, k);
             const double aP = alpha[c], xc = Xf[c], nutc = nut[c];
+            const double V = vol(i, j, k), delta = les_delta(c);
             double dg = aP * V / dt, s = aP * V * xc / dt, sumPhi = 0.0;
             for (int d = 0; d < 3; ++d) for (int sd = 0; sd < 2; ++sd) {
                 const int f = cface(d, sd, i, j, k);
@@ -1050,14 +1063,16 @@ struct Fv {
                     an[2 * d + sd][c] = 0.0;
                     const int patch = 2 * d + sd;
                     const double nb = nut_boundary(patch, c);
-                    const double gam = (af * (nu + nb / sigma)) * dx;
-                    if (bc[patch] == 1) { const double gb = 2.0 * gam; dg += gb; s += (-phio + gb) * bval[patch]; }
+                    const double gam = (af * (nu + nb / sigma)) * sfd(d, sd, i, j, k);
+                    if (bc[patch] == 1) { const double gb = bfac() * gam; dg += gb; s += (-phio + gb) * bval[patch]; }
                     else dg += phio;
                 } else {
                     const int nbc = c + (sd ? stride[d] : -stride[d]);
-                    const double gam = (0.5 * ((aP * (nu + nutc / sigma)) + (alpha[nbc] * (nu + nut[nbc] / sigma)))) * dx;
+                    const int qc = d == 0 ? i : d == 1 ? j : k;
+                    const double gam = lerp_side(d, sd, qc, aP * (nu + nutc / sigma), alpha[nbc] * (nu + nut[nbc] / sigma)) * sfd(d, sd, i, j, k);
                     const bool up = scheme != 0;
-                    const double cP = up ? std::max(phio, 0.0) : 0.5 * phio, cN = up ? std::min(phio, 0.0) : 0.5 * phio;
+                    const double wP = !graded ? 0.5 : (sd ? wlow(d, qc + 1) : 1.0 - wlow(d, qc));
+                    const double cP = up ? std::max(phio, 0.0) : wP * phio, cN = up ? std::min(phio, 0.0) : (!graded ? 0.5 * phio : (1.0 - wP) * phio);
                     dg += cP + gam;
                     an[2 * d + sd][c] = cN - gam;
                 }
@@ -1075,6 +1090,7 @@ struct Fv {
                 for (int d = 0; d < 3; ++d) for (int sd = 0; sd < 2; ++sd) if (wallp(2 * d + sd) && onb(d, sd, i, j, k)) {
                     const int patch = 2 * d + sd;
                     double ub[3]; Ub(U, c, patch, ub);
+                    const double ywall = ywall_of(d, c);
                     const double d0 = (ub[0] - U[3 * (size_t)c]) / ywall, d1 = (ub[1] - U[3 * (size_t)c + 1]) / ywall, d2 = (ub[2] - U[3 * (size_t)c + 2]) / ywall;
                     Gw += (nut_boundary(patch, c) + nu) * std::sqrt(d0 * d0 + d1 * d1 + d2 * d2) * cmu25 * std::sqrt(kturb[c]) / (cs.wf_kappa * ywall);
                 }
@@ -1099,7 +1115,7 @@ struct Fv {
                 // epsEqn.boundaryManipulate -> fvMatrix::setValues(faceCells, value) [OF-6 fvMatrix.C setValuesFromList]: the wall cell's row becomes
                 // diag x = diag value, its neighbours' coefficients towards it move to their sources
                 if (Wc) {
-                    const double v = cmu75 * std::pow(kturb[c], 1.5) / (cs.wf_kappa * ywall);
+                    const double v = wall_eps(c, i, j, k);
                     for (int q = 0; q < 6; ++q) an[q][c] = 0.0;
                     s = dg * v; x0 = v;
                 } else {
@@ -1107,7 +1123,7 @@ struct Fv {
                         const int ni = i + (d == 0 ? (sd ? 1 : -1) : 0), nj = j + (d == 1 ? (sd ? 1 : -1) : 0), nk = k + (d == 2 ? (sd ? 1 : -1) : 0);
                         if (wall_count(ni, nj, nk)) {
                             const int nbc = c + (sd ? stride[d] : -stride[d]);
-                            s -= an[2 * d + sd][c] * (cmu75 * std::pow(kturb[nbc], 1.5) / (cs.wf_kappa * ywall));
+                            s -= an[2 * d + sd][c] * wall_eps(nbc, ni, nj, nk);
                             an[2 * d + sd][c] = 0.0;
                         }
                     }
@@ -1125,17 +1141,19 @@ struct Fv {
             double xb = xc;
             if (!(xc > 0.0)) {
                 const double mP = std::max(xc, xMin);
-                double av = 0.0;
+                double av = 0.0, asum = 0.0;                      // fvc::average: sum |Sf| x_f / sum |Sf| (six equal faces on the uniform block)
                 for (int d = 0; d < 3; ++d) for (int sd = 0; sd < 2; ++sd) {
-                    if (onb(d, sd, i, j, k)) { const int patch = 2 * d + sd; av += std::max(bc[patch] == 1 ? bval[patch] : xc, xMin); }
-                    else { const int nbc = c + (sd ? stride[d] : -stride[d]); av += 0.5 * (mP + std::max(x3[3 * (size_t)nbc], xMin)); }
+                    double xf;
+                    if (onb(d, sd, i, j, k)) { const int patch = 2 * d + sd; xf = std::max(bc[patch] == 1 ? bval[patch] : xc, xMin); }
+                    else { const int nbc = c + (sd ? stride[d] : -stride[d]); xf = lerp_side(d, sd, d == 0 ? i : d == 1 ? j : k, mP, std::max(x3[3 * (size_t)nbc], xMin)); }
+                    if (graded) { av += area(d, i, j, k) * xf; asum += area(d, i, j, k); } else av += xf;
                 }
-                xb = std::max(xc, av / 6.0);
+                xb = std::max(xc, graded ? av / asum : av / 6.0);
             }
             xn[c] = std::max(xb, xMin);
         }
         Xf = xn;
-        if (mode == 0) for (int c = 0; c < Nc; ++c) nut[c] = cs.les_ck * std::sqrt(kturb[c]) * delta;
+        if (mode == 0) for (int c = 0; c < Nc; ++c) nut[c] = cs.les_ck * std::sqrt(kturb[c]) * les_delta(c);
         else if (mode == 2) for (int c = 0; c < Nc; ++c) nut[c] = cs.ras_cmu * (kturb[c] * kturb[c]) / epsturb[c];
         if (mode != 1) nut_wall_live = true;          // correctNut(): the wall-function patches now carry nut_w(k)
     }
@@ -1146,8 +1164,9 @@ struct Fv {
         grad_U(U, vGrad);
         if (cs.turbulence_model == 2) { turb_eqn(0); return; }
         if (cs.turbulence_model == 3) { turb_eqn(1); turb_eqn(2); return; }      // kEpsilon::correct(): epsilon first, then k with the new epsilon
-        const double delta = cs.les_delta_coeff * std::pow(V, 1.0 / 3.0), Ck = cs.les_ck, Ce = cs.les_ce;
+        const double Ck = cs.les_ck, Ce = cs.les_ce;
         for (int c = 0; c < Nc; ++c) {
+            const double delta = les_delta(c);
             const double* T = &vGrad[9 * (size_t)c];
             double D[3][3];
             for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) D[a][b] = 0.5 * (T[3 * a + b] + T[3 * b + a]);
@@ -1170,7 +1189,6 @@ extern "C" {
 void* orc_fv_create(const orc_fv_case* c) {
     // a graded block carries the laminar operators with Gauss linear / upwind convection only (the closures' delta, wall distance and the
     // linearUpwind correction assume uniform cubes)
-    if (c->hx && (c->turbulence_model != 0 || c->convection_scheme == 2)) return nullptr;
     Fv* f = new Fv(); f->init(*c); return f;
 }
 void orc_fv_destroy(void* h) { delete (Fv*)h; }

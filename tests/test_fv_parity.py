@@ -523,12 +523,38 @@ def test_graded_point_force_finds_cells_by_axis_search(product, oracle):
 
 def test_graded_block_refusals(product):
     h = np.full(8, 0.125)
-    for kw, msg in ((dict(turbulence_model=1, nut_initial=1e-5), "turbulence"), (dict(convection_scheme=2), "linearUpwind")):
-        c = product.make_case(1 if "turbulence_model" in kw else 0, 8, 8, 8, 0.125, 1e-3, 1e-3, grading=(h, h, h), **kw)
-        with pytest.raises(product.FoamYadeError, match=msg):
-            product.Solver(c)
     with pytest.raises(product.FoamYadeError, match="z-slabs"):
         product.VirtualSlabs(product.make_case(0, 8, 8, 8, 0.125, 1e-3, 1e-3, grading=(h, h, h)), 2)
+
+
+@pytest.mark.parametrize("what", ["smagorinsky", "kEqn", "kEpsilon_wall_functions", "linearUpwind"])
+def test_graded_turbulence_closures_and_linear_upwind_match_oracle(product, oracle, what):
+    """the closures of DPMTurbulenceModels.C:67-77 and Gauss linearUpwind on a block graded towards the walls, coupled with particles: per-cell
+    LES delta, per-wall distances in the wall functions, linear weights in every face interpolate, |Sf|-weighted average in bound()"""
+    from test_fv_oracle import TURB_CASES, TURB_FIELDS
+    n = 12
+    L = 0.1
+    g = (wall_refined_sizes(n, 3.0, L), wall_refined_sizes(n, 4.0, L), geometric_sizes(n, 2.0, L))
+    u_val = [(0, 0, 0)] * 6
+    u_val[YMAX] = (2.0, 0, 0)
+    o, s = both(product, oracle, 1, n, n, n, L / n, 2e-4, 1e-6, g=(0, 0, -9.81), u_bc=[0] * 6, u_val=u_val, p_bc=[2] * 6, grading=g, **TURB_CASES[what])
+    rs = np.random.RandomState(23)
+    npart = 1500
+    for step in range(4):
+        rec = np.zeros((npart, 10))
+        rec[:, 0:3] = L * (0.05 + 0.9 * rs.random_sample((npart, 3)))
+        rec[:, 3:6] = 0.05 * rs.standard_normal((npart, 3))
+        rec[:, 9] = 0.1 * (L / n)
+        fo = o.step(rec)["force"]
+        s.set_particles(rec); s.step()
+        sc = np.abs(fo).max()
+        assert sc > 0 and np.abs(s.forces() - fo).max() <= 1e-6 * sc
+        for nm in TURB_FIELDS[what]:
+            a, b = s.get(nm), o.get(nm)
+            np.testing.assert_allclose(a, b, rtol=2e-5, atol=1e-9 * b.max(), err_msg=nm)
+    compare(o, s, rtol=1e-5)
+    assert np.abs(s.get("U")).max() > 1e-6
+    o.close(); s.close()
 
 
 # ---- symmetryPlane / slip sides ------------------------------------------------------------------------------------------------------

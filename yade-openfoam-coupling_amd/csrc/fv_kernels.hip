@@ -122,6 +122,16 @@ __device__ __forceinline__ double geo_hc(const FvGeo& g, int d, int c) {
     return g.dx;
 #endif
 }
+// LESdelta cubeRootVol [OF-6 cubeRootVolDelta.C]: deltaCoeff * cbrt(V) of the cell (storage index c); the uniform block's is one number
+__device__ __forceinline__ double geo_delta(const FvGeo& g, double uniform_delta, int c) {
+#if FY_FVK_GRADED
+    return g.turb_dcoeff * cbrt((geo_hc(g, 0, c) * geo_hc(g, 1, c)) * geo_hc(g, 2, c));
+#else
+    return uniform_delta;
+#endif
+}
+// nearWallDist: distance of the cell centre from its face on side d (half the cell's extent along d)
+__device__ __forceinline__ double geo_ywall(const FvGeo& g, int d, int c) { return 0.5 * geo_hc(g, d, c); }
 
 // is face (d, s) of owned cell (i,j,k) on a PHYSICAL boundary?  (slab interfaces in z are interior faces)
 __device__ __forceinline__ bool onb(const FvGeo& g, int d, int s, int i, int j, int k) {
@@ -150,12 +160,12 @@ __device__ __forceinline__ double nut_boundary(const FvGeo& g, int patch, int c)
     if (t == 1 || ((t == 2 || t == 3) && !g.nut_wall_live)) return g.nut_val[patch];
     if (t == 3) {                                       // calculated: the model's expression on the boundary values
         const double kb = g.k_bc[patch] == 1 ? g.k_val[patch] : g.kturb[c];
-        if (g.turb_model == 2) return g.turb_ck * sqrt(kb) * g.turb_delta;
+        if (g.turb_model == 2) return g.turb_ck * sqrt(kb) * geo_delta(g, g.turb_delta, c);
         const double eb = g.eps_bc[patch] == 1 ? g.eps_val[patch] : g.epsturb[c];
         return g.turb_cmu * (kb * kb) / eb;
     }
     if (t == 2) {
-        const double y = 0.5 * g.dx;
+        const double y = geo_ywall(g, patch >> 1, c);
         const double yPlus = g.wf_cmu25 * y * sqrt(g.kturb[c]) / g.nu;
         return yPlus > g.wf_yPlusLam ? g.nu * (yPlus * g.wf_kappa / log(g.wf_E * yPlus) - 1.0) : 0.0;
     }
@@ -639,6 +649,7 @@ __global__ __launch_bounds__(256) void k_smagorinsky_nut(FvGeo g, const double* 
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= g.Nc) return;
     const int c = t + g.c0;
+    delta = geo_delta(g, delta, c);
     double T[9];
 #pragma unroll
     for (int q = 0; q < 9; ++q) T[q] = vGrad[9 * (size_t)c + q];
@@ -656,6 +667,23 @@ __global__ __launch_bounds__(256) void k_smagorinsky_nut(FvGeo g, const double* 
     nut[c] = ck * delta * sqrt(kk);
 }
 
+// epsilonWallFunction [OF-6 epsilonWallFunctionFvPatchScalarField::calculate]: the value imposed on a cell with wall faces is the average over
+// them of Cmu^3/4 k^3/2 / (kappa y_w) (cornerWeights = 1 / number of wall faces); on the uniform block every y_w is dx / 2
+__device__ __forceinline__ double wall_epsilon(const FvGeo& g, const TurbEqn& e, double kc, int c, int i, int j, int k) {
+#if FY_FVK_GRADED
+    double sum = 0.0;
+    int W = 0;
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+            if (e.wall[2 * d + s] && onb(g, d, s, i, j, k)) { sum += e.cmu75 * pow(kc, 1.5) / (e.kappa * geo_ywall(g, d, c)); ++W; }
+    return sum / (double)W;
+#else
+    return e.cmu75 * pow(kc, 1.5) / (e.kappa * geo_ywall(g, 0, c));
+#endif
+}
+
 // Transport equations of LESModel kEqn (DPMTurbulenceModels.C:76-77) [OF-6 LES/kEqn/kEqn.C correct()] and RASModel kEpsilon
 // (DPMTurbulenceModels.C:70-71) [OF-6 RAS/kEpsilon/kEpsilon.C correct()], see TurbEqn in fv_kernels.hpp:
 //   fvm::ddt(alpha, rho, X) + fvm::div(alphaRhoPhi, X) - fvm::laplacian(alpha rho DXEff, X) == Su - fvm::SuSp(c1, X) - fvm::Sp(c2, X)
@@ -669,7 +697,7 @@ __global__ __launch_bounds__(256) void k_assemble_turb(FvGeo g, TurbEqn e, const
     if (t >= g.Nc) return;
     int i, j, k; ijk_of(g, t, i, j, k);
     const int c = t + g.c0;
-    const double nu = g.nu, dt = g.dt, V = g.V;
+    const double nu = g.nu, dt = g.dt, V = geo_V(g, i, j, k);
     const double aP = alpha[c], nutc = g.nut[c];
     const double* X = e.mode == 1 ? ef : kf;
     const double xc = X[c];
@@ -689,9 +717,9 @@ __global__ __launch_bounds__(256) void k_assemble_turb(FvGeo g, TurbEqn e, const
                 an[2 * d + s] = 0.0;
                 const int patch = 2 * d + s;
                 const double nb = nut_boundary(g, patch, c);
-                const double gam = (af * (nu + nb / e.sigma)) * g.dx;
+                const double gam = (af * (nu + nb / e.sigma)) * geo_sfd(g, d, s, i, j, k);
                 if (e.bc[patch] == 1) {
-                    const double gb = 2.0 * gam;
+                    const double gb = kBfac * gam;
                     dg += gb;
                     src += (-phio + gb) * e.val[patch];
                 } else {
@@ -699,8 +727,14 @@ __global__ __launch_bounds__(256) void k_assemble_turb(FvGeo g, TurbEqn e, const
                 }
             } else {
                 const int nbc = c + (s ? stride_of(g, d) : -stride_of(g, d));
-                const double gam = (0.5 * ((aP * (nu + nutc / e.sigma)) + (alpha[nbc] * (nu + g.nut[nbc] / e.sigma)))) * g.dx;
-                const double cP = e.upwind ? fmax(phio, 0.0) : 0.5 * phio, cN = e.upwind ? fmin(phio, 0.0) : 0.5 * phio;
+                const int qc = d == 0 ? i : d == 1 ? j : k;
+                const double gam = geo_lerp_side(g, d, s, qc, aP * (nu + nutc / e.sigma), alpha[nbc] * (nu + g.nut[nbc] / e.sigma)) * geo_sfd(g, d, s, i, j, k);
+                const double wP = geo_wown(g, d, s, qc);
+#if FY_FVK_GRADED
+                const double cP = e.upwind ? fmax(phio, 0.0) : wP * phio, cN = e.upwind ? fmin(phio, 0.0) : (1.0 - wP) * phio;
+#else
+                const double cP = e.upwind ? fmax(phio, 0.0) : wP * phio, cN = e.upwind ? fmin(phio, 0.0) : wP * phio;
+#endif
                 dg += cP + gam;
                 an[2 * d + s] = cN - gam;
             }
@@ -717,7 +751,6 @@ __global__ __launch_bounds__(256) void k_assemble_turb(FvGeo g, TurbEqn e, const
         for (int b = 0; b < 3; ++b) GG += T[3 * a + b] * ((T[3 * a + b] + T[3 * b + a]) - (a == b ? (1.0 / 3.0) * tr2 : 0.0));
     double G = nutc * GG;
     // epsilonWallFunction: wall value of G, and (in the epsilon equation) the imposed cell value
-    const double ywall = 0.5 * g.dx;
     int Wc = 0;
     double Gw = 0.0;
     if (e.mode != 0) {
@@ -729,6 +762,7 @@ __global__ __launch_bounds__(256) void k_assemble_turb(FvGeo g, TurbEqn e, const
                     const int patch = 2 * d + s;
                     double ub[3];
                     Ub(g, U, c, patch, ub);
+                    const double ywall = geo_ywall(g, d, c);
                     const double d0 = (ub[0] - U[3 * (size_t)c]) / ywall, d1 = (ub[1] - U[3 * (size_t)c + 1]) / ywall, d2 = (ub[2] - U[3 * (size_t)c + 2]) / ywall;
                     const double magGradUw = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
                     Gw += (nut_boundary(g, patch, c) + nu) * magGradUw * e.cmu25 * sqrt(kf[c]) / (e.kappa * ywall);
@@ -736,9 +770,9 @@ __global__ __launch_bounds__(256) void k_assemble_turb(FvGeo g, TurbEqn e, const
                 }
         if (Wc) G = Gw / (double)Wc;
     }
-    const double divU = sumPhi * g.rV;
+    const double divU = sumPhi * geo_rV(g, i, j, k);
     double Su, c1, c2;
-    if (e.mode == 0) { Su = aP * G; c1 = (2.0 / 3.0) * aP * divU; c2 = e.ce * aP * sqrt(xc) / e.delta; }
+    if (e.mode == 0) { Su = aP * G; c1 = (2.0 / 3.0) * aP * divU; c2 = e.ce * aP * sqrt(xc) / geo_delta(g, e.delta, c); }
     else if (e.mode == 1) { const double kc = kf[c]; Su = e.c1 * aP * G * xc / kc; c1 = ((2.0 / 3.0) * e.c1 - e.c3) * aP * divU; c2 = e.c2 * aP * xc / kc; }
     else { Su = aP * G; c1 = (2.0 / 3.0) * aP * divU; c2 = aP * ef[c] / xc; }
     dg += V * (fmax(c1, 0.0) + c2);                             // fvm::SuSp (implicit where it stabilises) + fvm::Sp
@@ -754,7 +788,7 @@ __global__ __launch_bounds__(256) void k_assemble_turb(FvGeo g, TurbEqn e, const
     if (e.mode == 1) {
         // epsEqn.boundaryManipulate -> fvMatrix::setValues(faceCells, value) [OF-6 fvMatrix.C setValuesFromList]
         if (Wc) {
-            const double v = e.cmu75 * pow(kf[c], 1.5) / (e.kappa * ywall);
+            const double v = wall_epsilon(g, e, kf[c], c, i, j, k);
             for (int q = 0; q < 6; ++q) an[q] = 0.0;
             src = dg * v;
             x0 = v;
@@ -772,7 +806,7 @@ __global__ __launch_bounds__(256) void k_assemble_turb(FvGeo g, TurbEqn e, const
                             for (int s2 = 0; s2 < 2; ++s2) nwall = nwall || (e.wall[2 * d2 + s2] && onb(g, d2, s2, ni, nj, nk));
                         if (nwall) {
                             const int nbc = c + (s ? stride_of(g, d) : -stride_of(g, d));
-                            src -= an[2 * d + s] * (e.cmu75 * pow(kf[nbc], 1.5) / (e.kappa * ywall));
+                            src -= an[2 * d + s] * wall_epsilon(g, e, kf[nbc], nbc, ni, nj, nk);
                             an[2 * d + s] = 0.0;
                         }
                     }
@@ -797,23 +831,37 @@ __global__ __launch_bounds__(256) void k_turb_finish(FvGeo g, TurbEqn e, const d
     if (!(xc > 0.0)) {                                          // pos0(-X) = 1: the face-area average of the bounded neighbourhood
         const double mP = fmax(xc, e.xmin);
         double av = 0.0;
+#if FY_FVK_GRADED
+        double asum = 0.0;                                      // fvc::average: sum |Sf| x_f / sum |Sf|
+#endif
 #pragma unroll
         for (int d = 0; d < 3; ++d)
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
+                double xf;
                 if (onb(g, d, s, i, j, k)) {
                     const int patch = 2 * d + s;
-                    av += fmax(e.bc[patch] == 1 ? e.val[patch] : xc, e.xmin);
+                    xf = fmax(e.bc[patch] == 1 ? e.val[patch] : xc, e.xmin);
                 } else {
                     const int nbc = c + (s ? stride_of(g, d) : -stride_of(g, d));
-                    av += 0.5 * (mP + fmax(x3[3 * (size_t)nbc], e.xmin));
+                    xf = geo_lerp_side(g, d, s, d == 0 ? i : d == 1 ? j : k, mP, fmax(x3[3 * (size_t)nbc], e.xmin));
                 }
+#if FY_FVK_GRADED
+                const double Afc = geo_Af(g, d, i, j, k);
+                av += Afc * xf; asum += Afc;
+#else
+                av += xf;
+#endif
             }
+#if FY_FVK_GRADED
+        xb = fmax(xc, av / asum);
+#else
         xb = fmax(xc, av / 6.0);
+#endif
     }
     xb = fmax(xb, e.xmin);
     Xf[c] = xb;
-    if (nut_mode == 1) nut[c] = e.ck * sqrt(xb) * e.delta;
+    if (nut_mode == 1) nut[c] = e.ck * sqrt(xb) * geo_delta(g, e.delta, c);
     else if (nut_mode == 2) nut[c] = cmu * (xb * xb) / ef[c];
 }
 
@@ -853,7 +901,7 @@ __global__ __launch_bounds__(256) void k_assemble_momentum(FvGeo g, const double
                     gam = (af * (nu + nb)) * geo;
                 } else {
                     const int nbc = c + (s ? stride_of(g, d) : -stride_of(g, d));
-                    gam = (0.5 * ((aP * (nu + g.nut[c])) + (alpha[nbc] * (nu + g.nut[nbc])))) * geo;
+                    gam = geo_lerp_side(g, d, s, d == 0 ? i : d == 1 ? j : k, aP * (nu + g.nut[c]), alpha[nbc] * (nu + g.nut[nbc])) * geo;
                 }
             }
             if (onb(g, d, s, i, j, k)) {
@@ -884,7 +932,8 @@ __global__ __launch_bounds__(256) void k_assemble_momentum(FvGeo g, const double
                     // linearUpwind: implicit upwind + explicit (C_f - C_upwind) . grad(U)_upwind with the current Gauss-linear gradient
                     const int nb = c + (s ? stride_of(g, d) : -stride_of(g, d));
                     const int uw = phio > 0.0 ? c : nb;
-                    const double half = (phio > 0.0 ? (s ? 0.5 : -0.5) : (s ? -0.5 : 0.5)) * g.dx;
+                    // (C_f - C_upwind) along d: half the UPWIND cell's extent, towards the face
+                    const double half = (phio > 0.0 ? (s ? 0.5 : -0.5) : (s ? -0.5 : 0.5)) * geo_hc(g, d, uw);
                     for (int q = 0; q < 3; ++q) s3[q] -= phio * (half * vGrad[9 * (size_t)uw + 3 * d + q]);
                 }
             }

@@ -37,6 +37,7 @@ struct FvGeo {
     // nut_bc == 3 is a `calculated` patch: after correctNut() it holds the model's expression evaluated with the boundary values of k (and epsilon):
     // Ck sqrt(k_b) delta (turb_model 2, kEqn) or Cmu k_b^2 / eps_b (3, kEpsilon); k_b / eps_b = the patch value, or the cell's for zeroGradient
     int turb_model; double turb_ck, turb_cmu, turb_delta;
+    double turb_dcoeff;     // LESdelta deltaCoeff (the graded block's kernels form deltaCoeff * cbrt(V) per cell; turb_delta is the uniform block's)
     const double* epsturb;  // [storage cells] epsilon (kEpsilon)
     int k_bc[6], eps_bc[6]; double k_val[6], eps_val[6];
     const double* kturb;    // [storage cells] k of the kEqn / kEpsilon models (nullptr: none)

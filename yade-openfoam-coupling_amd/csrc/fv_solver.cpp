@@ -135,11 +135,9 @@ struct Solver {
         const bool gradedc = c && (c->hx || c->hy || c->hz);
         if (!c || c->nx <= 0 || c->ny <= 0 || c->nz <= 0 || (!gradedc && !(c->dx > 0)) || !(c->dt > 0)) return fail(FY_ERR_INVALID, "fy_solver_create: bad case");
         if (gradedc) {
-            // a graded (rectilinear) single block: the laminar operators, Gauss linear / upwind convection, one domain
+            // a graded (rectilinear) single block, one domain
             if (!(c->hx && c->hy && c->hz)) return fail(FY_ERR_INVALID, "fy_solver_create: a graded block needs hx, hy AND hz");
             if (cm && cm->size > 1) return fail(FY_ERR_UNSUPPORTED, "fy_solver_create: z-slabs need the uniform block (a graded block runs on one domain)");
-            if (c->turbulence_model != FY_TURBULENCE_LAMINAR) return fail(FY_ERR_UNSUPPORTED, "fy_solver_create: the turbulence closures (delta = cbrt(V), wall distance dx / 2) are built for the uniform block; a graded block is laminar");
-            if (c->convection_scheme == FY_CONVECTION_LINEAR_UPWIND) return fail(FY_ERR_UNSUPPORTED, "fy_solver_create: Gauss linearUpwind is built for the uniform block; a graded block takes Gauss linear or Gauss upwind");
             const double* hh[3] = {c->hx, c->hy, c->hz};
             const int nn[3] = {c->nx, c->ny, c->nz};
             for (int a = 0; a < 3; ++a) for (int q = 0; q < nn[a]; ++q) if (!(hh[a][q] > 0)) return fail(FY_ERR_INVALID, "fy_solver_create: graded block with a non-positive cell size");
@@ -221,7 +219,7 @@ struct Solver {
                 for (int it = 0; it < 10; ++it) ypl = std::log(std::max(c->wf_E * ypl, 1.0)) / c->wf_kappa;
                 g.wf_yPlusLam = ypl; g.wf_kappa = c->wf_kappa; g.wf_E = c->wf_E; g.wf_cmu25 = std::pow(c->ras_cmu, 0.25);
                 g.nut_wall_live = 0;
-                g.turb_model = c->turbulence_model; g.turb_ck = c->les_ck; g.turb_cmu = c->ras_cmu; g.turb_delta = les_delta;
+                g.turb_model = c->turbulence_model; g.turb_ck = c->les_ck; g.turb_cmu = c->ras_cmu; g.turb_delta = les_delta; g.turb_dcoeff = c->les_delta_coeff;
                 for (int q = 0; q < 6; ++q) {
                     g.k_bc[q] = c->k_bc[q]; g.k_val[q] = c->k_value[q];
                     g.eps_bc[q] = c->eps_bc[q] == FY_BC_NUT_FIXED_VALUE ? 1 : 0; g.eps_val[q] = c->eps_value[q];
