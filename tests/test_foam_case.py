@@ -73,12 +73,12 @@ def test_symmetry_sides_are_read_as_slip(prod, tmp_path, ty):
 
 
 @pytest.mark.parametrize("edit,needle", [
-    (("system/blockMeshDict", "simpleGrading (1 1 1)", "simpleGrading (((0.5 0.5 4) (0.5 0.5 0.25)) 1 1)"), "multi-grading"),
+    (("system/blockMeshDict", "edges ( );", "edges ( arc 0 1 (0.5 -0.1 0) );"), "edges"),
     (("system/blockMeshDict", "simpleGrading (1 1 1)", "edgeGrading (1 1 1 1 1 1 1 1 1 1 1 1)"), "edgeGrading"),
     (("system/blockMeshDict", "(3 7 6 2)", "(3 7 6 1)"), "not a side"),
     (("0/U", "noSlip", "partialSlip"), "not supported"),
     (("0/p", "type            zeroGradient;", "type            totalPressure;"), "not supported"),
-    (("system/controlDict", "startFrom       startTime;", "startFrom       latestTime;"), "startFrom"),
+    (("system/controlDict", "startFrom       startTime;", "startFrom       someTime;"), "startFrom"),
     (("constant/transportProperties", "fluidDensity", "fluidDensityX"), "fluidDensity"),
     (("system/fvSolution", "PISO", "SIMPLE"), "PISO"),
     (("0/U", "value           uniform (1 0 0);", "#include \"lid\""), "lid"),
@@ -553,3 +553,252 @@ def test_include_files_and_macros_are_expanded(prod, tmp_path):
     with pytest.raises(prod.FoamYadeError) as e:
         prod.FoamCase(dst, prod.FY_SOLVER_ICO)
     assert "$nowhere" in str(e.value)
+
+
+# ---- blockMeshDict beyond one simply graded block ---------------------------------------------------------------------------------------
+def _edit_block_mesh(tmp_path, old, new):
+    dst = tmp_path / "case"
+    shutil.copytree(os.path.join(CASES, "cavity_ico"), dst)
+    f = dst / "system/blockMeshDict"
+    text = f.read_text()
+    assert old in text
+    f.write_text(text.replace(old, new, 1))
+    return dst
+
+
+def test_multi_grading_sections_follow_lineDivide(prod, tmp_path):
+    """simpleGrading with a list of (length fraction, cell fraction, expansion ratio) sections per direction [OF-6 blockMesh lineDivide]:
+    x refined towards both walls, y towards the lid through unnormalised fractions and a negative ratio (= 1 / 3), z uniform"""
+    dst = _edit_block_mesh(tmp_path, "simpleGrading (1 1 1)", "simpleGrading ( ((0.5 0.5 4) (0.5 0.5 0.25))  ((2 3 1) (2 1 -3))  1 )")
+    fc = prod.FoamCase(dst, prod.FY_SOLVER_ICO)
+    c = fc.case
+    hx = np.ctypeslib.as_array(c.hx, (16,)).copy(); hy = np.ctypeslib.as_array(c.hy, (16,)).copy(); hz = np.ctypeslib.as_array(c.hz, (16,)).copy()
+    np.testing.assert_allclose([hx.sum(), hy.sum(), hz.sum()], 0.1, rtol=1e-13)
+    np.testing.assert_allclose(hx[:8].sum(), 0.05, rtol=1e-13)
+    np.testing.assert_allclose(hx[7] / hx[0], 4.0, rtol=1e-12); np.testing.assert_allclose(hx[15] / hx[8], 0.25, rtol=1e-12)
+    np.testing.assert_allclose(hx[1:8] / hx[:7], 4.0 ** (1 / 7), rtol=1e-12)
+    np.testing.assert_allclose(hx, hx[::-1], rtol=1e-12)
+    # y: half the length in 12 uniform cells, the other half in 4 cells shrinking by 3 overall
+    np.testing.assert_allclose(hy[:12], 0.05 / 12, rtol=1e-12)
+    np.testing.assert_allclose(hy[12:].sum(), 0.05, rtol=1e-13); np.testing.assert_allclose(hy[15] / hy[12], 1.0 / 3.0, rtol=1e-12)
+    np.testing.assert_allclose(hz, 0.1 / 16, rtol=1e-13)
+    fc.close()
+
+
+MULTI_BLOCK = """
+vertices
+(
+    (0 0 0) (0.4 0 0) (1 0 0)   (0 1 0) (0.4 1 0) (1 1 0)
+    (0 0 0.5) (0.4 0 0.5) (1 0 0.5)   (0 1 0.5) (0.4 1 0.5) (1 1 0.5)
+    (0 0 1) (0.4 0 1) (1 0 1)   (0 1 1) (0.4 1 1) (1 1 1)
+);
+
+blocks
+(
+    hex (0 1 4 3 6 7 10 9)     (6 16 8)  simpleGrading (2 1 1)
+    hex (1 2 5 4 7 8 11 10)    (10 16 8) simpleGrading (1 1 1)
+    hex (6 7 10 9 12 13 16 15) lower (6 16 8)  simpleGrading (2 1 0.5)
+    hex (7 8 11 10 13 14 17 16) (10 16 8) simpleGrading (1 1 0.5)
+);
+
+edges ( );
+
+boundary
+(
+    movingWall
+    {
+        type wall;
+        faces ( (3 9 10 4) (4 10 11 5) (9 15 16 10) (10 16 17 11) );
+    }
+    fixedWalls
+    {
+        type wall;
+        faces
+        (
+            (0 6 9 3) (6 12 15 9)
+            (2 5 11 8) (8 11 17 14)
+            (0 1 7 6) (1 2 8 7) (6 7 13 12) (7 8 14 13)
+            (0 3 4 1) (1 4 5 2)
+            (12 13 16 15) (13 14 17 16)
+        );
+    }
+);
+"""
+
+
+def _multi_block_case(tmp_path, text=MULTI_BLOCK):
+    dst = tmp_path / "case"
+    shutil.copytree(os.path.join(CASES, "cavity_ico"), dst)
+    f = dst / "system/blockMeshDict"
+    head = f.read_text()
+    f.write_text(head[:head.index("vertices")] + text + "\nmergePatchPairs ( );\n")
+    return dst
+
+
+def test_blocks_that_tile_a_box_are_merged_into_one_rectilinear_block(prod, tmp_path):
+    """2 x 1 x 2 hex blocks with different cell counts and gradings, conforming along the faces they share"""
+    fc = prod.FoamCase(_multi_block_case(tmp_path), prod.FY_SOLVER_ICO)
+    c = fc.case
+    assert (c.nx, c.ny, c.nz) == (16, 16, 16) and list(c.origin) == [0.0, 0.0, 0.0]
+    hx = np.ctypeslib.as_array(c.hx, (16,)).copy(); hy = np.ctypeslib.as_array(c.hy, (16,)).copy(); hz = np.ctypeslib.as_array(c.hz, (16,)).copy()
+    np.testing.assert_allclose(hx[:6].sum(), 0.04, rtol=1e-13); np.testing.assert_allclose(hx[5] / hx[0], 2.0, rtol=1e-12)
+    np.testing.assert_allclose(hx[6:], 0.06 / 10, rtol=1e-13)
+    np.testing.assert_allclose(hy, 0.1 / 16, rtol=1e-13)
+    np.testing.assert_allclose(hz[:8], 0.05 / 8, rtol=1e-13); np.testing.assert_allclose(hz[15] / hz[8], 0.5, rtol=1e-12)
+    assert fc.patch_of_side[YMAX] == "movingWall" and all(fc.patch_of_side[s] == "fixedWalls" for s in (XMIN, XMAX, YMIN, ZMIN, ZMAX))
+    fc.close()
+
+
+@pytest.mark.parametrize("old,new,needle", [
+    ("hex (7 8 11 10 13 14 17 16) (10 16 8) simpleGrading (1 1 0.5)", "", "tensor product"),
+    ("(10 16 8) simpleGrading (1 1 0.5)", "(10 16 8) simpleGrading (1 1 0.25)", "disagree"),
+    ("(10 16 8) simpleGrading (1 1 1)", "(12 16 8) simpleGrading (1 1 1)", "disagree"),
+    ("(10 16 17 11) );\n    }", ");\n    }\n    inlet { type patch; faces ( (10 16 17 11) ); }", "shared by the patches"),
+    ("(13 14 17 16)\n", "\n", "only in part"),
+    ("(12 13 16 15) (13 14 17 16)", "(12 13 16 15) (13 14 17 16) (13 14 17 16)", "more than once"),
+])
+def test_block_arrangements_outside_the_tensor_product_are_refused(prod, tmp_path, old, new, needle):
+    assert old in MULTI_BLOCK
+    with pytest.raises(prod.FoamYadeError, match=needle):
+        prod.FoamCase(_multi_block_case(tmp_path, MULTI_BLOCK.replace(old, new, 1)), prod.FY_SOLVER_ICO)
+
+
+@pytest.mark.gpu
+def test_a_box_cut_into_four_uniform_blocks_runs_like_the_one_block_cavity(prod, tmp_path):
+    """the same 16^3 cavity described as 2 x 1 x 2 hex blocks of equal cubes (one with a cellZone name): read as the uniform block, the run is
+    the one-block case's bit for bit; with graded blocks it is the hand-built graded case's"""
+    uni = MULTI_BLOCK.replace("0.4", "0.5").replace("(6 16 8)", "(8 16 8)").replace("(10 16 8)", "(8 16 8)").replace("simpleGrading (2 1 1)", "simpleGrading (1 1 1)")
+    uni = uni.replace("simpleGrading (2 1 0.5)", "simpleGrading (1 1 1)").replace("simpleGrading (1 1 0.5)", "simpleGrading (1 1 1)")
+    runs = []
+    for k, dst in enumerate((_multi_block_case(tmp_path / "a", uni), os.path.join(CASES, "cavity_ico"))):
+        fc = prod.FoamCase(dst, prod.FY_SOLVER_ICO)
+        assert not fc.case.hx and (fc.case.nx, fc.case.ny, fc.case.nz) == (16, 16, 16)
+        s = prod.Solver(fc.case)
+        U0, p0 = fc.initial_fields()
+        s.set("U", U0); s.set("p", p0)
+        for _ in range(5):
+            s.step()
+        runs.append((s.get("U"), s.get("p")))
+        s.close(); fc.close()
+    np.testing.assert_array_equal(runs[0][0], runs[1][0]); np.testing.assert_array_equal(runs[0][1], runs[1][1])
+    assert np.abs(runs[0][0]).max() > 0.05
+    # graded blocks
+    fc = prod.FoamCase(_multi_block_case(tmp_path / "b"), prod.FY_SOLVER_ICO)
+    c = fc.case
+    g = tuple(np.array([h[q] for q in range(n)]) for h, n in ((c.hx, c.nx), (c.hy, c.ny), (c.hz, c.nz)))
+    s = prod.Solver(c)
+    ref = prod.Solver(prod.make_case(0, c.nx, c.ny, c.nz, c.dx, c.dt, c.nu, rho_f=c.rho_fluid, rho_p=c.rho_particle, g=tuple(c.g),
+                                     u_bc=list(c.u_bc), u_val=[tuple(c.u_value[q]) for q in range(6)], p_bc=list(c.p_bc), p_val=list(c.p_value),
+                                     origin=tuple(c.origin), n_correctors=c.n_correctors, p_solver=c.p_solver, p_tol=c.p_tol, p_rel_tol=c.p_rel_tol,
+                                     p_final_tol=c.p_final_tol, p_final_rel_tol=c.p_final_rel_tol, u_tol=c.u_tol, u_rel_tol=c.u_rel_tol, grading=g))
+    for _ in range(5):
+        s.step(); ref.step()
+    np.testing.assert_array_equal(s.get("U"), ref.get("U"))
+    assert np.abs(s.get("U")).max() > 0.05
+    s.close(); ref.close(); fc.close()
+
+
+# ---- controlDict's input / output settings -----------------------------------------------------------------------------------------------
+def _binary_field_file(cls, obj, dims, values, patches):
+    """an OpenFOAM field file in the binary stream format (what `writeFormat binary` produces): the list's doubles between the parentheses"""
+    v = np.ascontiguousarray(values, dtype="<f8")
+    ty = "vector" if v.ndim == 2 else "scalar"
+    head = ("FoamFile\n{\n    version     2.0;\n    format      binary;\n    arch        \"LSB;label=32;scalar=64\";\n    class       %s;\n"
+            "    location    \"0\";\n    object      %s;\n}\n\ndimensions      %s;\n\ninternalField   nonuniform List<%s> %d\n(" % (cls, obj, dims, ty, v.shape[0]))
+    tail = ")\n;\n\nboundaryField\n{\n" + "".join("    %s\n    {\n%s    }\n" % (n, t) for n, t in patches) + "}\n"
+    return head.encode() + v.tobytes() + tail.encode()
+
+
+def test_binary_field_files_are_read(prod, tmp_path):
+    dst = tmp_path / "case"
+    shutil.copytree(os.path.join(CASES, "cavity_ico"), dst)
+    rs = np.random.RandomState(2)
+    U = rs.standard_normal((4096, 3)); p = rs.standard_normal(4096)
+    U[7] = (np.frombuffer(b");\n}\n()(", dtype="<f8")[0], 1e-300, -0.0)            # bytes that would end the list, were they read as text
+    (dst / "0/U").write_bytes(_binary_field_file("volVectorField", "U", "[0 1 -1 0 0 0 0]", U,
+                                                 [("movingWall", "        type            fixedValue;\n        value           uniform (1 0 0);\n"),
+                                                  ("fixedWalls", "        type            noSlip;\n")]))
+    (dst / "0/p").write_bytes(_binary_field_file("volScalarField", "p", "[0 2 -2 0 0 0 0]", p,
+                                                 [("movingWall", "        type            zeroGradient;\n"), ("fixedWalls", "        type            zeroGradient;\n")]))
+    fc = prod.FoamCase(dst, prod.FY_SOLVER_ICO)
+    U0, p0 = fc.initial_fields()
+    np.testing.assert_array_equal(U0, U); np.testing.assert_array_equal(p0, p)
+    assert list(fc.case.u_value[YMAX]) == [1.0, 0.0, 0.0]
+    fc.close()
+    # a list that is shorter than it says
+    data = (dst / "0/p").read_bytes()
+    (dst / "0/p").write_bytes(data[:600])
+    with pytest.raises(prod.FoamYadeError, match="past the end"):
+        prod.FoamCase(dst, prod.FY_SOLVER_ICO)
+
+
+@pytest.mark.parametrize("start_from,expect", [("latestTime", "0.02"), ("firstTime", "0"), ("startTime", "0")])
+def test_start_from_picks_the_time_directory(prod, tmp_path, start_from, expect):
+    dst = tmp_path / "case"
+    shutil.copytree(os.path.join(CASES, "cavity_ico"), dst)
+    for name, val in (("0.02", 0.25), ("0.01", 0.125)):
+        shutil.copytree(dst / "0", dst / name)
+        pf = dst / name / "p"
+        pf.write_text(pf.read_text().replace("internalField   uniform 0;", "internalField   uniform %g;" % val))
+    os.makedirs(dst / "postProcessing" / "7")                                           # (not a time directory of the case)
+    cd = dst / "system/controlDict"
+    cd.write_text(cd.read_text().replace("startFrom       startTime;", "startFrom       %s;" % start_from))
+    fc = prod.FoamCase(dst, prod.FY_SOLVER_ICO)
+    assert fc.start_name == expect
+    _, p0 = fc.initial_fields()
+    assert np.all(p0 == {"0.02": 0.25, "0": 0.0}[expect])
+    fc.close()
+
+
+@pytest.mark.parametrize("key,val,needle", [("writeFormat", "xml", "writeFormat"), ("writeCompression", "on", "writeCompression"), ("writePrecision", "0", "writePrecision"),
+                                            ("writeControl", "clockTime", "writeControl")])
+def test_output_settings_outside_the_subset_are_refused(prod, tmp_path, key, val, needle):
+    dst = tmp_path / "case"
+    shutil.copytree(os.path.join(CASES, "cavity_ico"), dst)
+    cd = dst / "system/controlDict"
+    text = cd.read_text()
+    import re
+    text, k = re.subn(r"(?m)^%s\s+[^;]*;" % key, "%s %s;" % (key, val), text)
+    if not k:
+        text += "\n%s %s;\n" % (key, val)
+    cd.write_text(text)
+    with pytest.raises(prod.FoamYadeError, match=needle):
+        prod.FoamCase(dst, prod.FY_SOLVER_ICO)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fmt", ["binary", "ascii6"])
+def test_write_format_precision_and_purge(prod, tmp_path, fmt):
+    """writeFormat binary: the time directory restarts the run exactly (startFrom latestTime reads it back); writePrecision 6: six digits in
+    the file; purgeWrite 2: only the two newest time directories this run wrote are kept"""
+    dst = tmp_path / "case"
+    shutil.copytree(os.path.join(CASES, "cavity_ico"), dst)
+    cd = dst / "system/controlDict"
+    extra = "\nwriteFormat binary;\npurgeWrite 2;\n" if fmt == "binary" else "\nwriteFormat ascii;\nwritePrecision 6;\npurgeWrite 2;\n"
+    import re
+    text = cd.read_text()
+    for key in ("writeFormat", "writePrecision", "purgeWrite"):
+        text = re.sub(r"(?m)^%s\s+[^;]*;\n" % key, "", text)
+    cd.write_text(text.replace("startFrom       startTime;", "startFrom       latestTime;") + extra)
+    fc = prod.FoamCase(dst, prod.FY_SOLVER_ICO)
+    assert fc.start_name == "0"
+    s = prod.Solver(fc.case)
+    U0, p0 = fc.initial_fields()
+    s.set("U", U0); s.set("p", p0)
+    for k in range(1, 5):
+        s.step()
+        fc.write(s, "%g" % (0.005 * k))
+    assert sorted(d for d in os.listdir(dst) if d[0].isdigit()) == ["0", "0.015", "0.02"]
+    U, p = s.get("U"), s.get("p")
+    raw = (dst / "0.02" / "U").read_bytes()
+    fc2 = prod.FoamCase(dst, prod.FY_SOLVER_ICO)
+    assert fc2.start_name == "0.02"
+    U2, p2 = fc2.initial_fields()
+    if fmt == "binary":
+        assert b"format      binary;" in raw and U.astype("<f8").tobytes() in raw
+        np.testing.assert_array_equal(U2.reshape(U.shape), U); np.testing.assert_array_equal(p2, p)
+    else:
+        assert b"format      ascii;" in raw
+        np.testing.assert_allclose(U2.reshape(U.shape), U, rtol=5e-6, atol=1e-300)
+        assert np.abs(U2.reshape(U.shape) - U).max() > 0 and max(len(w) for w in raw.split(b"boundaryField")[0].split()[-300:]) <= 14
+    s.close(); fc.close(); fc2.close()

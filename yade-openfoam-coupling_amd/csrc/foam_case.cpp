@@ -9,8 +9,11 @@
 //                                                    internalField uniform or nonuniform)
 //   write  <time>/U | U.<phase>, p, and in Gaussian mode alpha.<phase>: ASCII volFields with the case's own patch entries
 // Anything outside that subset is refused with FY_ERR_UNSUPPORTED and a message naming the file and keyword -- never guessed.
+#include <dirent.h>
 #include <sys/stat.h>
+#include <unistd.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -33,6 +36,12 @@ struct fy_foam_case {
     std::string u_bc_text[6], p_bc_text[6];     // the boundaryField entries as read, re-emitted on write
     std::vector<double> U0, p0, nut0, k0, eps0; // internalField of the start time (nut0, k0, eps0: turbulence cases only)
     std::string nut_bc_text[6], k_bc_text[6], eps_bc_text[6];
+    // controlDict's output settings [OF-6 Time::readDict]: writeFormat ascii | binary, writePrecision (ASCII digits; absent: 17, lossless --
+    // OpenFOAM's own default of 6 would not restart a run where it stopped), purgeWrite N (keep the N newest time directories this run wrote)
+    bool write_binary = false;
+    int write_precision = 17;
+    int purge_write = 0;
+    mutable std::vector<std::string> written;   // time directories written so far (purgeWrite's ring)
 };
 
 namespace {
@@ -79,6 +88,41 @@ int named_dicts(const std::vector<std::string>& tok, const std::string& what, st
 
 bool near(double a, double b, double scale) { return std::fabs(a - b) <= 1e-9 * scale; }
 
+// one direction of one hex block: its cell sizes from the grading [OF-6 blockMesh lineDivide.C, gradingDescriptor(s).C].  A grading is a list of
+// sections (fraction of the length, fraction of the cells, expansion ratio = last cell / first cell of the section); `simpleGrading (2 ...)` is the
+// one-section list ((1 1 2)).  Fractions are normalised to sum 1; a section holds label(nDivFrac * n + 0.5) cells, the last one what is left;
+// inside a section the sizes form a geometric progression with factor ratio^(1 / (cells - 1)); a negative ratio r means 1 / |r|
+struct GradSection { double len, cells, ratio; };
+int axis_sizes(const std::string& path, int n, double L, std::vector<GradSection> sec, std::vector<double>* h) {
+    double sl = 0.0, sc = 0.0;
+    for (GradSection& g : sec) {
+        if (!(g.len > 0) || !(g.cells > 0) || g.ratio == 0.0) return fail(FY_ERR_INVALID, "%s: grading section (%g %g %g): fractions must be positive, the ratio non-zero", path.c_str(), g.len, g.cells, g.ratio);
+        if (g.ratio < 0) g.ratio = 1.0 / -g.ratio;
+        sl += g.len; sc += g.cells;
+    }
+    h->clear();
+    int start = 0;
+    for (size_t q = 0; q < sec.size(); ++q) {
+        int m = (int)(sec[q].cells / sc * n + 0.5);
+        if (q + 1 == sec.size() || m > n - start) m = n - start;
+        if (m < 1) return fail(FY_ERR_INVALID, "%s: a grading section is left without cells (%d cells over %zu sections)", path.c_str(), n, sec.size());
+        const double len = sec[q].len / sl * L;
+        const double r = (sec[q].ratio != 1.0 && m > 1) ? std::pow(sec[q].ratio, 1.0 / (m - 1)) : 1.0;
+        double sum = 0.0, w = 1.0;
+        const size_t at = h->size();
+        for (int i = 0; i < m; ++i) { h->push_back(w); sum += w; w *= r; }
+        for (size_t i = at; i < h->size(); ++i) (*h)[i] *= len / sum;
+        start += m;
+    }
+    if (start != n) return fail(FY_ERR_INVALID, "%s: the grading sections hold %d of %d cells", path.c_str(), start, n);
+    return FY_OK;
+}
+
+struct HexBlock { int hv[8]; int nn[3]; double lo[3], hi[3]; std::vector<double> h[3]; };
+
+// system/blockMeshDict: one hex block, or several that tile a box as a tensor product (Bx x By x Bz blocks, every one present, neighbours
+// agreeing on the cell sizes along the faces they share -- what blockMesh merges into one rectilinear lattice); simpleGrading with one
+// expansion ratio or a multi-grading list per direction.  Curved edges, edgeGrading, mergePatchPairs and sides shared by two patches are refused.
 int read_block_mesh(fy_foam_case* c) {
     const std::string path = join(c->dir, "system/blockMeshDict");
     FoamDict d;
@@ -87,64 +131,121 @@ int read_block_mesh(fy_foam_case* c) {
     if (!d.scalar("convertToMeters", &scale)) d.scalar("scale", &scale);
     const auto* vt = d.tokens("vertices");
     std::vector<double> v;
-    if (!vt || !fy::foam_read_list(*vt, 0, 3, &v) || v.size() != 24)
-        return fail(FY_ERR_UNSUPPORTED, "%s: need exactly 8 vertices (one hex block)", path.c_str());
+    if (!vt || !fy::foam_read_list(*vt, 0, 3, &v) || v.size() < 24 || v.size() % 3 != 0)
+        return fail(FY_ERR_UNSUPPORTED, "%s: need at least 8 vertices (x y z)", path.c_str());
     for (double& x : v) x *= scale;
-    const auto* bt = d.tokens("blocks");
-    // ( hex ( 0 1 2 3 4 5 6 7 ) ( nx ny nz ) simpleGrading ( 1 1 1 ) )
-    if (!bt || bt->size() < 24 || (*bt)[0] != "(" || (*bt)[1] != "hex") return fail(FY_ERR_UNSUPPORTED, "%s: blocks must hold one 'hex' block", path.c_str());
-    int hv[8], nn[3];
-    size_t i = 2;
-    if ((*bt)[i++] != "(") return fail(FY_ERR_INVALID, "%s: malformed hex vertex list", path.c_str());
-    for (int q = 0; q < 8; ++q) { double x; if (!fy::foam_tok_is_number((*bt)[i++], &x)) return fail(FY_ERR_INVALID, "%s: malformed hex vertex list", path.c_str()); hv[q] = (int)x; }
-    if ((*bt)[i++] != ")" || (*bt)[i++] != "(") return fail(FY_ERR_INVALID, "%s: malformed hex cell counts", path.c_str());
-    for (int q = 0; q < 3; ++q) { double x; if (!fy::foam_tok_is_number((*bt)[i++], &x)) return fail(FY_ERR_INVALID, "%s: malformed hex cell counts", path.c_str()); nn[q] = (int)x; }
-    if ((*bt)[i++] != ")") return fail(FY_ERR_INVALID, "%s: malformed hex cell counts", path.c_str());
-    // simpleGrading (ex ey ez): per direction the ratio of the LAST cell's size to the FIRST one's; the sizes in between form a geometric
-    // progression [OF-6 blockMesh lineDivide].  Multi-grading lists ((fraction cells ratio) ...) and edgeGrading are refused.
-    if ((*bt)[i] != "simpleGrading") return fail(FY_ERR_UNSUPPORTED, "%s: only simpleGrading (ex ey ez) is supported (no edgeGrading)", path.c_str());
-    double expan[3] = {1, 1, 1};
-    if (i + 1 >= bt->size() || (*bt)[i + 1] != "(") return fail(FY_ERR_INVALID, "%s: malformed simpleGrading", path.c_str());
-    for (size_t q = i + 2; q < i + 5 && q < bt->size(); ++q) {
-        if (!fy::foam_tok_is_number((*bt)[q], &expan[q - i - 2]) || !(expan[q - i - 2] > 0))
-            return fail(FY_ERR_UNSUPPORTED, "%s: simpleGrading takes one positive expansion ratio per direction (multi-grading lists are not supported)", path.c_str());
+    const int nvert = (int)(v.size() / 3);
+    for (const char* key : {"edges", "mergePatchPairs"}) {
+        const auto* et = d.tokens(key);
+        if (et) for (const std::string& t : *et) if (t != "(" && t != ")") return fail(FY_ERR_UNSUPPORTED, "%s: a non-empty '%s' list is not supported (straight edges, conforming blocks)", path.c_str(), key);
     }
-    size_t close = i + 6;
-    if (close >= bt->size() || (*bt)[close] != ")") return fail(FY_ERR_UNSUPPORTED, "%s: exactly one block is supported", path.c_str());
-    for (int q = 0; q < 8; ++q) if (hv[q] < 0 || hv[q] > 7) return fail(FY_ERR_INVALID, "%s: hex vertex label out of range", path.c_str());
-    auto P = [&](int q, int a) { return v[3 * (size_t)hv[q] + a]; };
-    // blockMesh's hex: 0-1 = local x, 0-3 = local y, 0-4 = local z; require them to be +x, +y, +z of an axis-aligned box
-    const double L[3] = {P(1, 0) - P(0, 0), P(3, 1) - P(0, 1), P(4, 2) - P(0, 2)};
-    const double scl = std::fabs(L[0]) + std::fabs(L[1]) + std::fabs(L[2]);
-    const int bits[8][3] = {{0, 0, 0}, {1, 0, 0}, {1, 1, 0}, {0, 1, 0}, {0, 0, 1}, {1, 0, 1}, {1, 1, 1}, {0, 1, 1}};
-    for (int q = 0; q < 8; ++q)
-        for (int a = 0; a < 3; ++a)
-            if (!near(P(q, a), P(0, a) + bits[q][a] * L[a], scl)) return fail(FY_ERR_UNSUPPORTED, "%s: the block must be an axis-aligned box with the standard hex vertex order", path.c_str());
-    if (!(L[0] > 0 && L[1] > 0 && L[2] > 0) || nn[0] < 1 || nn[1] < 1 || nn[2] < 1) return fail(FY_ERR_INVALID, "%s: degenerate block", path.c_str());
-    const double dx = L[0] / nn[0];
-    const bool cubes = expan[0] == 1.0 && expan[1] == 1.0 && expan[2] == 1.0 && near(L[1] / nn[1], dx, dx) && near(L[2] / nn[2], dx, dx);
-    c->desc.nx = nn[0]; c->desc.ny = nn[1]; c->desc.nz = nn[2]; c->desc.dx = dx;
-    c->desc.hx = c->desc.hy = c->desc.hz = nullptr;
-    if (!cubes) {
-        // a graded block (or uniform cells that are not cubes): per-axis cell sizes, h_q = h_0 r^q with r = expansion^(1 / (n - 1)) and sum = L
+    const auto* bt = d.tokens("blocks");
+    if (!bt || bt->size() < 24 || (*bt)[0] != "(" || (*bt)[1] != "hex") return fail(FY_ERR_UNSUPPORTED, "%s: blocks must hold 'hex' blocks", path.c_str());
+    const std::vector<std::string>& T = *bt;
+    std::vector<HexBlock> blocks;
+    size_t i = 1;
+    auto num = [&](double* x) { return i < T.size() && fy::foam_tok_is_number(T[i], x) ? (++i, true) : false; };
+    auto tok = [&](const char* w) { return i < T.size() && T[i] == w ? (++i, true) : false; };
+    double scl = 0.0;
+    while (i < T.size() && T[i] != ")") {
+        HexBlock B;
+        if (!tok("hex") || !tok("(")) return fail(FY_ERR_UNSUPPORTED, "%s: blocks must hold 'hex' blocks", path.c_str());
+        for (int q = 0; q < 8; ++q) { double x; if (!num(&x)) return fail(FY_ERR_INVALID, "%s: malformed hex vertex list", path.c_str()); B.hv[q] = (int)x; }
+        if (!tok(")")) return fail(FY_ERR_INVALID, "%s: malformed hex vertex list", path.c_str());
+        if (i < T.size() && T[i] != "(") ++i;                                   // (an optional cellZone name)
+        if (!tok("(")) return fail(FY_ERR_INVALID, "%s: malformed hex cell counts", path.c_str());
+        for (int q = 0; q < 3; ++q) { double x; if (!num(&x)) return fail(FY_ERR_INVALID, "%s: malformed hex cell counts", path.c_str()); B.nn[q] = (int)x; }
+        if (!tok(")")) return fail(FY_ERR_INVALID, "%s: malformed hex cell counts", path.c_str());
+        if (!tok("simpleGrading")) return fail(FY_ERR_UNSUPPORTED, "%s: only simpleGrading is supported (no edgeGrading)", path.c_str());
+        if (!tok("(")) return fail(FY_ERR_INVALID, "%s: malformed simpleGrading", path.c_str());
+        std::vector<GradSection> grad[3];
         for (int a = 0; a < 3; ++a) {
-            std::vector<double>& h = c->grading[a];
-            h.assign((size_t)nn[a], L[a] / nn[a]);
-            if (expan[a] != 1.0 && nn[a] > 1) {
-                const double r = std::pow(expan[a], 1.0 / (nn[a] - 1));
-                double sum = 0.0, w = 1.0;
-                for (int q = 0; q < nn[a]; ++q) { h[(size_t)q] = w; sum += w; w *= r; }
-                for (double& x : h) x *= L[a] / sum;
+            double r;
+            if (num(&r)) { grad[a].push_back(GradSection{1.0, 1.0, r}); continue; }
+            if (!tok("(")) return fail(FY_ERR_INVALID, "%s: simpleGrading takes an expansion ratio or a list ((fraction cells ratio) ...) per direction", path.c_str());
+            while (tok("(")) {
+                GradSection g;
+                if (!num(&g.len) || !num(&g.cells) || !num(&g.ratio) || !tok(")")) return fail(FY_ERR_INVALID, "%s: malformed multi-grading section (fraction cells ratio)", path.c_str());
+                grad[a].push_back(g);
+            }
+            if (!tok(")") || grad[a].empty()) return fail(FY_ERR_INVALID, "%s: malformed multi-grading list", path.c_str());
+        }
+        if (!tok(")")) return fail(FY_ERR_INVALID, "%s: simpleGrading takes three entries", path.c_str());
+        for (int q = 0; q < 8; ++q) if (B.hv[q] < 0 || B.hv[q] >= nvert) return fail(FY_ERR_INVALID, "%s: hex vertex label out of range", path.c_str());
+        auto P = [&](int q, int a) { return v[3 * (size_t)B.hv[q] + a]; };
+        // blockMesh's hex: 0-1 = local x, 0-3 = local y, 0-4 = local z; require them to be +x, +y, +z of an axis-aligned box
+        const double L[3] = {P(1, 0) - P(0, 0), P(3, 1) - P(0, 1), P(4, 2) - P(0, 2)};
+        const double bs = std::fabs(L[0]) + std::fabs(L[1]) + std::fabs(L[2]);
+        scl = std::max(scl, bs);
+        const int bits[8][3] = {{0, 0, 0}, {1, 0, 0}, {1, 1, 0}, {0, 1, 0}, {0, 0, 1}, {1, 0, 1}, {1, 1, 1}, {0, 1, 1}};
+        for (int q = 0; q < 8; ++q)
+            for (int a = 0; a < 3; ++a)
+                if (!near(P(q, a), P(0, a) + bits[q][a] * L[a], bs)) return fail(FY_ERR_UNSUPPORTED, "%s: every block must be an axis-aligned box with the standard hex vertex order", path.c_str());
+        if (!(L[0] > 0 && L[1] > 0 && L[2] > 0) || B.nn[0] < 1 || B.nn[1] < 1 || B.nn[2] < 1) return fail(FY_ERR_INVALID, "%s: degenerate block", path.c_str());
+        for (int a = 0; a < 3; ++a) {
+            B.lo[a] = P(0, a); B.hi[a] = P(0, a) + L[a];
+            FY_TRY(axis_sizes(path, B.nn[a], L[a], grad[a], &B.h[a]));
+        }
+        blocks.push_back(B);
+    }
+    if (blocks.empty()) return fail(FY_ERR_UNSUPPORTED, "%s: blocks must hold 'hex' blocks", path.c_str());
+    // ---- the blocks as a tensor product: break points per axis, one block per slot, equal sizes along shared intervals
+    std::vector<double> brk[3];
+    for (int a = 0; a < 3; ++a) {
+        for (const HexBlock& B : blocks) { brk[a].push_back(B.lo[a]); brk[a].push_back(B.hi[a]); }
+        std::sort(brk[a].begin(), brk[a].end());
+        std::vector<double> u;
+        for (double x : brk[a]) if (u.empty() || !near(x, u.back(), scl)) u.push_back(x);
+        brk[a].swap(u);
+    }
+    const size_t nslot[3] = {brk[0].size() - 1, brk[1].size() - 1, brk[2].size() - 1};
+    if (nslot[0] * nslot[1] * nslot[2] != blocks.size())
+        return fail(FY_ERR_UNSUPPORTED, "%s: the %zu blocks do not tile a box as a %zu x %zu x %zu tensor product (L-shaped or partly refined arrangements are not supported)", path.c_str(),
+                    blocks.size(), nslot[0], nslot[1], nslot[2]);
+    std::vector<int> taken(blocks.size(), 0);
+    std::vector<const std::vector<double>*> hs[3];
+    for (int a = 0; a < 3; ++a) hs[a].assign(nslot[a], nullptr);
+    for (const HexBlock& B : blocks) {
+        size_t at[3];
+        for (int a = 0; a < 3; ++a) {
+            size_t q = 0;
+            while (q < nslot[a] && !near(brk[a][q], B.lo[a], scl)) ++q;
+            if (q == nslot[a] || !near(brk[a][q + 1], B.hi[a], scl)) return fail(FY_ERR_UNSUPPORTED, "%s: a block spans more than one interval of the block lattice (not a tensor-product arrangement)", path.c_str());
+            at[a] = q;
+            if (!hs[a][q]) hs[a][q] = &B.h[a];
+            else {
+                const std::vector<double>& o = *hs[a][q];
+                bool same = o.size() == B.h[a].size();
+                for (size_t m = 0; same && m < o.size(); ++m) same = near(o[m], B.h[a][m], o[m]);
+                if (!same) return fail(FY_ERR_UNSUPPORTED, "%s: neighbouring blocks disagree on the cell sizes along a shared direction (non-conforming blocks)", path.c_str());
             }
         }
+        int& t = taken[at[0] + nslot[0] * (at[1] + nslot[1] * at[2])];
+        if (t++) return fail(FY_ERR_INVALID, "%s: two blocks occupy the same place", path.c_str());
+    }
+    double L[3], lo[3];
+    int nn[3];
+    std::vector<double> h[3];
+    for (int a = 0; a < 3; ++a) {
+        for (size_t q = 0; q < nslot[a]; ++q) h[a].insert(h[a].end(), hs[a][q]->begin(), hs[a][q]->end());
+        nn[a] = (int)h[a].size(); lo[a] = brk[a].front(); L[a] = brk[a].back() - brk[a].front();
+    }
+    const double dx = L[0] / nn[0];
+    bool cubes = true;
+    for (int a = 0; a < 3; ++a) for (double x : h[a]) cubes = cubes && near(x, dx, dx);
+    c->desc.nx = nn[0]; c->desc.ny = nn[1]; c->desc.nz = nn[2]; c->desc.dx = dx;
+    c->desc.hx = c->desc.hy = c->desc.hz = nullptr;
+    if (!cubes) {       // a graded block (or uniform cells that are not cubes): per-axis cell sizes
+        for (int a = 0; a < 3; ++a) c->grading[a] = h[a];
         c->desc.hx = c->grading[0].data(); c->desc.hy = c->grading[1].data(); c->desc.hz = c->grading[2].data();
     }
-    for (int a = 0; a < 3; ++a) c->desc.origin[a] = P(0, a);
+    for (int a = 0; a < 3; ++a) c->desc.origin[a] = lo[a];
 
     const auto* bd = d.tokens("boundary");
     if (!bd) return fail(FY_ERR_UNSUPPORTED, "%s: no 'boundary' list (the old 'patches' syntax is not supported)", path.c_str());
     std::vector<std::pair<std::string, FoamDict> > patches;
     FY_TRY(named_dicts(*bd, path + ": boundary", &patches));
+    double covered[6] = {0, 0, 0, 0, 0, 0};
     for (auto& pd : patches) {
         const auto* ft = pd.second.tokens("faces");
         std::vector<double> f;
@@ -152,28 +253,34 @@ int read_block_mesh(fy_foam_case* c) {
         // ( (a b c d) (a b c d) ... ): read as 4-component tuples
         if (!fy::foam_read_list(*ft, 0, 4, &f) || f.empty()) return fail(FY_ERR_INVALID, "%s: patch '%s': malformed faces list", path.c_str(), pd.first.c_str());
         std::string ty;
-        if (pd.second.word("type", &ty) && (ty == "empty" || ty == "cyclic" || ty == "symmetryPlane" || ty == "symmetry" || ty == "wedge"))
-            return fail(FY_ERR_UNSUPPORTED, "%s: patch '%s' of type '%s' is not supported (3-D wall / patch sides only)", path.c_str(), pd.first.c_str(), ty.c_str());
+        if (pd.second.word("type", &ty) && (ty == "empty" || ty == "cyclic" || ty == "wedge"))
+            return fail(FY_ERR_UNSUPPORTED, "%s: patch '%s' of type '%s' is not supported (wall / patch / symmetryPlane sides of a 3-D box)", path.c_str(), pd.first.c_str(), ty.c_str());
         for (size_t q = 0; q + 3 < f.size(); q += 4) {
             int side = -1;
+            double flo[3] = {1e300, 1e300, 1e300}, fhi[3] = {-1e300, -1e300, -1e300};
+            for (int m = 0; m < 4; ++m) {
+                const int vi = (int)f[q + m];
+                if (vi < 0 || vi >= nvert) return fail(FY_ERR_INVALID, "%s: patch '%s': vertex label out of range", path.c_str(), pd.first.c_str());
+                for (int a = 0; a < 3; ++a) { flo[a] = std::min(flo[a], v[3 * (size_t)vi + a]); fhi[a] = std::max(fhi[a], v[3 * (size_t)vi + a]); }
+            }
             for (int a = 0; a < 3 && side < 0; ++a)
-                for (int s = 0; s < 2 && side < 0; ++s) {
-                    bool all = true;
-                    for (int m = 0; m < 4; ++m) {
-                        const int vi = (int)f[q + m];
-                        if (vi < 0 || vi > 7) return fail(FY_ERR_INVALID, "%s: patch '%s': vertex label out of range", path.c_str(), pd.first.c_str());
-                        all = all && near(v[3 * (size_t)vi + a], P(0, a) + s * L[a], scl);
-                    }
-                    if (all) side = 2 * a + s;
-                }
+                for (int s = 0; s < 2 && side < 0; ++s)
+                    if (near(flo[a], lo[a] + s * L[a], scl) && near(fhi[a], lo[a] + s * L[a], scl)) side = 2 * a + s;
             if (side < 0) return fail(FY_ERR_UNSUPPORTED, "%s: patch '%s' has a face that is not a side of the block", path.c_str(), pd.first.c_str());
-            if (!c->patch_of_side[side].empty()) return fail(FY_ERR_INVALID, "%s: block side %d is covered twice", path.c_str(), side);
+            if (!c->patch_of_side[side].empty() && c->patch_of_side[side] != pd.first)
+                return fail(FY_ERR_UNSUPPORTED, "%s: side %d of the box is shared by the patches '%s' and '%s' (one boundary condition per side)", path.c_str(), side, c->patch_of_side[side].c_str(), pd.first.c_str());
             c->patch_of_side[side] = pd.first;
+            const int a = side / 2, t1 = (a + 1) % 3, t2 = (a + 2) % 3;
+            covered[side] += (fhi[t1] - flo[t1]) * (fhi[t2] - flo[t2]);
         }
         c->patch_order.push_back(pd.first);
     }
-    for (int s = 0; s < 6; ++s)
+    for (int s = 0; s < 6; ++s) {
         if (c->patch_of_side[s].empty()) return fail(FY_ERR_INVALID, "%s: block side %d belongs to no patch", path.c_str(), s);
+        const int a = s / 2;
+        const double area = L[(a + 1) % 3] * L[(a + 2) % 3];
+        if (!near(covered[s], area, area)) return fail(FY_ERR_INVALID, "%s: block side %d is covered %s by its patch's faces (%g of %g)", path.c_str(), s, covered[s] > area ? "more than once" : "only in part", covered[s], area);
+    }
     return FY_OK;
 }
 
@@ -182,6 +289,9 @@ std::string entry_text(const FoamDict& d) {
     for (const std::string& k : d.order) {
         const auto* tk = d.tokens(k);
         if (!tk) continue;
+        bool blob = false;
+        for (const std::string& s : *tk) blob = blob || (!s.empty() && s[0] == '\x01');
+        if (blob) continue;                                // (a binary list: not text; the types that need a value here take `uniform`)
         t += "        " + k;
         for (const std::string& s : *tk) t += " " + s;
         t += ";\n";
@@ -376,15 +486,39 @@ int read_controls(fy_foam_case* c) {
         if (!d.scalar("endTime", &c->end_time)) return fail(FY_ERR_INVALID, "%s: endTime missing", path.c_str());
         c->start_time = 0.0; c->start_name = "0";
         std::string from;
-        if (d.word("startFrom", &from) && from != "startTime") return fail(FY_ERR_UNSUPPORTED, "%s: startFrom %s is not supported (startTime only)", path.c_str(), from.c_str());
-        if (d.word("startTime", &c->start_name)) d.scalar("startTime", &c->start_time);
+        if (d.word("startFrom", &from) && from != "startTime" && from != "latestTime" && from != "firstTime")
+            return fail(FY_ERR_UNSUPPORTED, "%s: startFrom %s is not supported (startTime, firstTime, latestTime)", path.c_str(), from.c_str());
+        if (from == "latestTime" || from == "firstTime") {
+            // the time directories of the case: the entries of the case directory whose names read as numbers [OF-6 Time::findTimes]
+            DIR* dd = opendir(c->dir.c_str());
+            if (!dd) return fail(FY_ERR_INVALID, "%s: cannot list %s", path.c_str(), c->dir.c_str());
+            bool any = false;
+            while (struct dirent* de = readdir(dd)) {
+                double t;
+                struct stat st;
+                if (!fy::foam_tok_is_number(de->d_name, &t) || stat(join(c->dir, de->d_name).c_str(), &st) != 0 || !S_ISDIR(st.st_mode)) continue;
+                if (!any || (from == "latestTime" ? t > c->start_time : t < c->start_time)) { c->start_time = t; c->start_name = de->d_name; }
+                any = true;
+            }
+            closedir(dd);
+            if (!any) return fail(FY_ERR_INVALID, "%s: startFrom %s: the case holds no time directory", path.c_str(), from.c_str());
+        } else if (d.word("startTime", &c->start_name)) d.scalar("startTime", &c->start_time);
         std::string wc = "timeStep";
         d.word("writeControl", &wc);
         double wi = 0;
         d.scalar("writeInterval", &wi);
         if (wc == "timeStep") c->write_interval_steps = (int)wi;
         else if (wc == "runTime" || wc == "adjustableRunTime") c->write_interval_steps = (int)std::llround(wi / c->desc.dt);
-        else return fail(FY_ERR_UNSUPPORTED, "%s: writeControl %s is not supported", path.c_str(), wc.c_str());
+        else return fail(FY_ERR_UNSUPPORTED, "%s: writeControl %s is not supported (timeStep, runTime, adjustableRunTime)", path.c_str(), wc.c_str());
+        std::string wf = "ascii";
+        if (d.word("writeFormat", &wf) && wf != "ascii" && wf != "binary") return fail(FY_ERR_INVALID, "%s: writeFormat %s (ascii or binary)", path.c_str(), wf.c_str());
+        c->write_binary = wf == "binary";
+        std::string comp;
+        if (d.word("writeCompression", &comp) && comp != "off" && comp != "no" && comp != "false" && comp != "none" && comp != "uncompressed")
+            return fail(FY_ERR_UNSUPPORTED, "%s: writeCompression %s is not supported (off)", path.c_str(), comp.c_str());
+        double wp = 0, pw = 0;
+        if (d.scalar("writePrecision", &wp)) { if (!(wp >= 1 && wp <= 17)) return fail(FY_ERR_INVALID, "%s: writePrecision %g", path.c_str(), wp); c->write_precision = (int)wp; }
+        if (d.scalar("purgeWrite", &pw)) { if (pw < 0) return fail(FY_ERR_INVALID, "%s: purgeWrite %g", path.c_str(), pw); c->purge_write = (int)pw; }
         // readTimeControls.H [OF-6]: adjustTimeStep (default no), maxCo (default 1), maxDeltaT (default great).  Only pimpleFoamYade
         // includes setDeltaT.H (pimpleFoamYade.C:62-64); icoFoamYade's loop (icoFoamYade.C:65-70) never reads the switch, so there it is
         // ignored exactly as the reference ignores it
@@ -603,14 +737,23 @@ int read_controls(fy_foam_case* c) {
 int write_field(const fy_foam_case* c, const std::string& tdir, const std::string& tname, const std::string& name, const char* cls, const char* dims, int ncomp,
                 const std::vector<double>& v, const std::string bc_text[6], const char* default_bc) {
     const std::string path = tdir + "/" + name;
-    FILE* f = std::fopen(path.c_str(), "w");
+    FILE* f = std::fopen(path.c_str(), "wb");
     if (!f) return fail(FY_ERR_INVALID, "cannot write %s", path.c_str());
     const size_t n = v.size() / (size_t)ncomp;
-    std::fprintf(f, "FoamFile\n{\n    version     2.0;\n    format      ascii;\n    class       %s;\n    location    \"%s\";\n    object      %s;\n}\n\n", cls, tname.c_str(), name.c_str());
-    std::fprintf(f, "dimensions      %s;\n\ninternalField   nonuniform List<%s> %zu\n(\n", dims, ncomp == 3 ? "vector" : "scalar", n);
-    for (size_t q = 0; q < n; ++q) {
-        if (ncomp == 3) std::fprintf(f, "(%.17g %.17g %.17g)\n", v[3 * q], v[3 * q + 1], v[3 * q + 2]);
-        else std::fprintf(f, "%.17g\n", v[q]);
+    std::fprintf(f, "FoamFile\n{\n    version     2.0;\n    format      %s;\n", c->write_binary ? "binary" : "ascii");
+    if (c->write_binary) std::fprintf(f, "    arch        \"LSB;label=32;scalar=64\";\n");
+    std::fprintf(f, "    class       %s;\n    location    \"%s\";\n    object      %s;\n}\n\n", cls, tname.c_str(), name.c_str());
+    std::fprintf(f, "dimensions      %s;\n\ninternalField   nonuniform List<%s> %zu\n(", dims, ncomp == 3 ? "vector" : "scalar", n);
+    if (c->write_binary) {
+        // the list's values as they lie in memory, between the parentheses [OF-6 UList<T>::writeEntry, binary stream]
+        if (std::fwrite(v.data(), sizeof(double), v.size(), f) != v.size()) { std::fclose(f); return fail(FY_ERR_INVALID, "cannot write %s", path.c_str()); }
+    } else {
+        const int pr = c->write_precision;
+        std::fputc('\n', f);
+        for (size_t q = 0; q < n; ++q) {
+            if (ncomp == 3) std::fprintf(f, "(%.*g %.*g %.*g)\n", pr, v[3 * q], pr, v[3 * q + 1], pr, v[3 * q + 2]);
+            else std::fprintf(f, "%.*g\n", pr, v[q]);
+        }
     }
     std::fprintf(f, ")\n;\n\nboundaryField\n{\n");
     for (const std::string& pn : c->patch_order) {
@@ -728,6 +871,24 @@ int fy_foam_case_write_time(const fy_foam_case* c, fy_solver* s, const char* tim
         std::vector<double> kk(n);
         FY_TRY(fy_solver_read_field_host(s, "k", kk.data()));
         FY_TRY(write_field(c, tdir, time_name, "k." + c->phase, "volScalarField", "[0 2 -2 0 0 0 0]", 1, kk, c->k_bc_text, "        type            zeroGradient;\n"));
+    }
+    if (c->purge_write > 0) {
+        // purgeWrite [OF-6 Time::writeObject]: once more than N time directories have been written, the oldest of them goes
+        bool known = false;
+        for (const std::string& w : c->written) known = known || w == time_name;
+        if (!known) c->written.push_back(time_name);
+        while ((int)c->written.size() > c->purge_write) {
+            const std::string old = join(c->dir, c->written.front());
+            c->written.erase(c->written.begin());
+            if (DIR* dd = opendir(old.c_str())) {
+                while (struct dirent* de = readdir(dd)) {
+                    const std::string nm = de->d_name;
+                    if (nm != "." && nm != "..") ::unlink(join(old, nm).c_str());
+                }
+                closedir(dd);
+                ::rmdir(old.c_str());
+            }
+        }
     }
     return FY_OK;
 }

@@ -3,6 +3,7 @@
 
 #include <cctype>
 #include <cstdlib>
+#include <cstring>
 #include <fstream>
 #include <sstream>
 
@@ -15,6 +16,7 @@ struct Tok { std::string s; int line; };
 bool tokenize(const std::string& t, std::vector<Tok>* out, std::string* err, const std::string& dir = std::string(), int depth_inc = 0) {
     size_t i = 0, n = t.size();
     int line = 1;
+    bool binary = false;
     while (i < n) {
         const char c = t[i];
         if (c == '\n') { ++line; ++i; continue; }
@@ -27,7 +29,28 @@ bool tokenize(const std::string& t, std::vector<Tok>* out, std::string* err, con
             i += 2;
             continue;
         }
-        if (c == '{' || c == '}' || c == '(' || c == ')' || c == '[' || c == ']' || c == ';') { out->push_back({std::string(1, c), line}); ++i; continue; }
+        if (c == '{' || c == '}' || c == '(' || c == ')' || c == '[' || c == ']' || c == ';') {
+            out->push_back({std::string(1, c), line});
+            ++i;
+            if (c == ';' && out->size() >= 3 && (*out)[out->size() - 3].s == "format" && (*out)[out->size() - 2].s == "binary") binary = true;      // FoamFile { format binary; }
+            if (c == '(' && binary && out->size() >= 3) {
+                // binary stream format [OF-6 UList<T>::writeEntry / Istream read of contiguous lists]: `List<scalar> N (` is followed by
+                // N * sizeof(T) raw bytes (native doubles: arch "LSB;label=32;scalar=64") and `)`.  The bytes become ONE token, marked
+                // by a leading 0x01, which foam_read_list unpacks
+                const std::string& ty = (*out)[out->size() - 3].s;
+                double cnt;
+                const int ncomp = ty == "List<scalar>" ? 1 : ty == "List<vector>" ? 3 : ty == "List<symmTensor>" ? 6 : ty == "List<tensor>" ? 9 : 0;
+                if (ncomp && foam_tok_is_number((*out)[out->size() - 2].s, &cnt) && cnt >= 0) {
+                    const size_t bytes = (size_t)cnt * (size_t)ncomp * sizeof(double);
+                    if (i + bytes > n) { *err = "binary list at line " + std::to_string(line) + " runs past the end of the file"; return false; }
+                    std::string blob(1, '\x01');
+                    blob.append(t, i, bytes);
+                    out->push_back({blob, line});
+                    i += bytes;
+                }
+            }
+            continue;
+        }
         if (c == '"') {
             size_t j = i + 1;
             while (j < n && t[j] != '"') { if (t[j] == '\n') ++line; ++j; }
@@ -244,6 +267,14 @@ bool foam_read_list(const std::vector<std::string>& tok, size_t i, int ncomp, st
     if (i >= tok.size() || tok[i] != "(") return false;
     ++i;
     out->clear();
+    if (i < tok.size() && !tok[i].empty() && tok[i][0] == '\x01') {       // a binary list's bytes (see tokenize)
+        const size_t bytes = tok[i].size() - 1;
+        if (bytes % sizeof(double) != 0 || i + 1 >= tok.size() || tok[i + 1] != ")") return false;
+        out->resize(bytes / sizeof(double));
+        if (bytes) std::memcpy(out->data(), tok[i].data() + 1, bytes);
+        if (cnt >= 0 && (size_t)cnt * (size_t)ncomp != out->size()) return false;
+        return true;
+    }
     while (i < tok.size() && tok[i] != ")") {
         if (ncomp == 1) {
             double v;
@@ -276,7 +307,7 @@ bool foam_parse(const std::string& text, FoamDict* out, std::string* err, const 
 }
 
 bool foam_parse_file(const std::string& path, FoamDict* out, std::string* err) {
-    std::ifstream f(path);
+    std::ifstream f(path, std::ios::binary);
     if (!f) { *err = "cannot open " + path; return false; }
     std::stringstream ss;
     ss << f.rdbuf();

@@ -82,14 +82,17 @@ int main(int argc, char** argv) {
     fy_solver_hold_sources(s, 1);                       // runTime.write() comes before setSourceZero (icoFoamYade.C:142-147)
 
     std::printf("\nStarting time loop\n\n");
+    // runTime.loop(): fixed deltaT -> endTime / deltaT steps named start + k deltaT; adjustTimeStep (pimpleFoamYade.C:62-64) -> the time
+    // advances by what setDeltaT.H chose for each step, until endTime is reached to within half a step
     const long n_steps = std::lround((info.end_time - info.start_time) / info.delta_t);
-    for (long k = 1; k <= n_steps; ++k) {
-        const double t = info.start_time + (double)k * info.delta_t;
-        char tname[64];
-        std::snprintf(tname, sizeof(tname), "%.12g", t);
+    double t = info.start_time;
+    for (long k = 1; cd.adjust_time_step ? t < info.end_time - 1e-9 * std::fabs(info.end_time) : k <= n_steps; ++k) {
         if (fy_solver_step(s) != FY_OK) return die("fy_solver_step");
         fy_step_stats st;
         fy_solver_get_stats(s, &st);
+        t = cd.adjust_time_step ? t + st.delta_t : info.start_time + (double)k * info.delta_t;
+        char tname[64];
+        std::snprintf(tname, sizeof(tname), "%.12g", t);
         std::printf("Time = %s\n\nCourant Number mean: %g max: %g\n", tname, st.courant_mean, st.courant_max);
         std::printf("pressure: %d solves, %d iterations, initial residual %g, final residual %g\n", st.p_solves, st.p_iters_total, st.p_initial_residual, st.p_final_residual);
         std::printf("time step continuity errors : sum local = %g, global = %g, cumulative = %g\n\n", st.cont_err_sum_local, st.cont_err_global, st.cont_err_cumulative);
