@@ -196,6 +196,14 @@ enum { FY_PSOLVER_PCG_JACOBI = 0, FY_PSOLVER_PCG_MG = 1 };
 #define FY_CONVECTION_LINEAR 0
 #define FY_CONVECTION_UPWIND 1
 #define FY_CONVECTION_LINEAR_UPWIND 2
+/* NVD / TVD limited schemes [OF-6 LimitedScheme, NVDTVD]: face value = w U_owner + (1 - w) U_neighbour, w = limiter(r) w_linear + (1 - limiter(r)) pos0(flux),
+   r = 2 (d . grad(magSqr(U))_upwind) / (magSqr(U)_N - magSqr(U)_P) - 1; one limiter for the three components, weights implicit */
+#define FY_CONVECTION_LIMITED_LINEAR 3   /* Gauss limitedLinear k: max(min(2 r / k, 1), 0), k = convection_limiter_k in [0, 1] */
+#define FY_CONVECTION_VAN_LEER 4         /* (r + |r|) / (1 + |r|) */
+#define FY_CONVECTION_MUSCL 5            /* max(min(2 r, r / 2 + 1 / 2, 2), 0) */
+#define FY_CONVECTION_MINMOD 6           /* max(min(r, 1), 0) */
+#define FY_CONVECTION_SUPERBEE 7         /* max(min(2 r, 1), min(r, 2), 0) */
+#define FY_CONVECTION_QUICK 8            /* max(min(2 r, (3 + r) / 4, 2), 0) */
 /* continuousPhaseTurbulence (pimpleFoamYade/createFields.H, DPMTurbulenceModels.C:67-77; icoFoamYade has no turbulence model) */
 #define FY_TURBULENCE_LAMINAR 0        /* simulationType laminar / laminarModel Stokes (DPMTurbulenceModels.C:67-68) */
 #define FY_TURBULENCE_SMAGORINSKY 1    /* simulationType LES, LESModel Smagorinsky (DPMTurbulenceModels.C:73-74), delta cubeRootVol */
@@ -226,7 +234,7 @@ typedef struct fy_case_desc {
     int32_t p_solver;               /* FY_PSOLVER_* */
     double p_tol, p_rel_tol, p_final_tol, p_final_rel_tol; int32_t p_max_iter;
     double u_tol, u_rel_tol; int32_t u_max_iter;
-    int32_t convection_scheme;             /* divSchemes for div(phi,U): FY_CONVECTION_LINEAR (Gauss linear, default) | _UPWIND (Gauss upwind) | _LINEAR_UPWIND (Gauss linearUpwind, unlimited) */
+    int32_t convection_scheme;             /* divSchemes for div(phi,U): FY_CONVECTION_LINEAR (Gauss linear, default) | _UPWIND (Gauss upwind) | _LINEAR_UPWIND (Gauss linearUpwind, unlimited) | the limited schemes _LIMITED_LINEAR .. _QUICK */
     /* controlDict adjustTimeStep / maxCo / maxDeltaT: readTimeControls.H + CourantNo.H + setDeltaT.H at the top of the time loop
        (pimpleFoamYade.C:62-64); dt above is then the initial deltaT and fy_step_stats.delta_t reports what each step used */
     int32_t adjust_time_step; double max_co, max_delta_t;
@@ -268,9 +276,10 @@ typedef struct fy_case_desc {
     double wf_kappa, wf_E;                       /* fy_case_defaults: 0.41, 9.8 */
     /* A GRADED single block (blockMesh simpleGrading; icoFoamYade/createFields.H:15-162 and pimpleFoamYade/createFields.H:32-261 take any
        fvMesh): cell sizes along x, y, z -- nx, ny, nz doubles each, copied at fy_solver_create; all three NULL (fy_case_defaults) = uniform
-       cubes of edge dx.  The block then starts at `origin`, dx is ignored.  Carried: the laminar operators with Gauss linear / upwind
-       convection, single domain; turbulence models, linearUpwind and z-slabs are refused on a graded block */
+       cubes of edge dx.  The block then starts at `origin`, dx is ignored.  Everything the uniform block carries except z-slabs (a graded
+       block runs on one domain) */
     const double *hx, *hy, *hz;
+    double convection_limiter_k;            /* FY_CONVECTION_LIMITED_LINEAR: the k of `Gauss limitedLinear k` (fy_case_defaults: 1) */
 } fy_case_desc;
 
 typedef struct fy_solver fy_solver;

@@ -42,7 +42,7 @@ struct orc_fv_case {
     int p_solver;                // 0 PCG+Jacobi, 1 PCG+MG
     double p_tol, p_rel_tol, p_final_tol, p_final_rel_tol; int p_max_iter;
     double u_tol, u_rel_tol; int u_max_iter;
-    int convection_scheme;      // 0 Gauss linear, 1 Gauss upwind, 2 Gauss linearUpwind (unlimited, Gauss-linear gradient)
+    int convection_scheme;      // 0 Gauss linear, 1 Gauss upwind, 2 Gauss linearUpwind (unlimited, Gauss-linear gradient), 3.. the NVD / TVD limited schemes (limited_weight)
     // controlDict adjustTimeStep / maxCo / maxDeltaT (readTimeControls.H + setDeltaT.H, pimpleFoamYade.C:62-64)
     int adjust_time_step; double max_co, max_delta_t;
     // fvSolution relaxationFactors: equations { Uc; UcFinal } (UcEqn.relax(), UcEqn.H:12), fields { p; pFinal } (p.relax(), pEqn.H:41); <= 0: no entry
@@ -60,6 +60,7 @@ struct orc_fv_case {
     double wf_kappa, wf_E;
     // graded (rectilinear) block: cell sizes along x, y, z (nx, ny, nz doubles; blockMesh simpleGrading); all null = uniform cubes of edge dx
     const double* hx; const double* hy; const double* hz;
+    double convection_limiter_k;     // limitedLinear's coefficient (Gauss limitedLinear k)
 };
 struct orc_fv_stats {
     double courant_mean, courant_max, cont_sum_local, cont_global, cont_cumulative;
@@ -228,6 +229,50 @@ struct Fv {
         }
     }
 
+    // ---- NVD / TVD limited convection schemes for div(phi,U) [OF-6 LimitedScheme<vector, Limiter<NVDTVD>, limitFuncs::magSqr>, NVDTVD.H] ----------
+    // One limiter per face from the scalar lPhi = magSqr(U): r = 2 (d . grad(lPhi)_C) / (lPhi_N - lPhi_P) - 1 with C the upwind cell of the face
+    // flux and the Gauss-linear gradient of lPhi (boundary value magSqr(U_b)); the face weight of the OWNER's value is
+    // limiter * w_linear + (1 - limiter) * pos0(faceFlux) [limitedSurfaceInterpolationScheme::weights], used implicitly.
+    vec lphi, gradL;
+    void limiter_gradient(const vec& F) {
+        lphi.assign(Nc, 0.0); gradL.assign(3 * (size_t)Nc, 0.0);
+        for (int c = 0; c < Nc; ++c) lphi[c] = (F[3 * (size_t)c] * F[3 * (size_t)c] + F[3 * (size_t)c + 1] * F[3 * (size_t)c + 1]) + F[3 * (size_t)c + 2] * F[3 * (size_t)c + 2];
+#pragma omp parallel for num_threads(threads) collapse(2)
+        for (int k = 0; k < nz; ++k) for (int j = 0; j < ny; ++j) for (int i = 0; i < nx; ++i) {
+            const int c = cid(i, j, k);
+            for (int d = 0; d < 3; ++d) {
+                double fv[2];
+                for (int s = 0; s < 2; ++s) {
+                    if (onb(d, s, i, j, k)) { double b[3]; Ub(F, c, 2 * d + s, b); fv[s] = (b[0] * b[0] + b[1] * b[1]) + b[2] * b[2]; }
+                    else fv[s] = lerp_side(d, s, d == 0 ? i : d == 1 ? j : k, lphi[c], lphi[c + (s ? stride[d] : -stride[d])]);
+                }
+                gradL[3 * (size_t)c + d] = (fv[1] - fv[0]) / hcell(d, c);
+            }
+        }
+    }
+    static double limiter_fn(int scheme, double twoByk, double r) {
+        switch (scheme) {
+            case 3: return std::max(std::min(twoByk * r, 1.0), 0.0);                                             // limitedLinear
+            case 4: return (r + std::fabs(r)) / (1.0 + std::fabs(r));                                            // vanLeer
+            case 5: return std::max(std::min(std::min(2.0 * r, 0.5 * r + 0.5), 2.0), 0.0);                       // MUSCL
+            case 6: return std::max(std::min(std::min(r, 1.0), 2.0), 0.0);                                       // Minmod
+            case 7: return std::max(std::max(std::min(2.0 * r, 1.0), std::min(r, 2.0)), 0.0);                    // SuperBee
+            default: return std::max(std::min(std::min(2.0 * r, (3.0 + r) / 4.0), 2.0), 0.0);                    // QUICK (8)
+        }
+    }
+    // weight of the owner's (low cell's) value on interior face q of axis d between cells own and nei, for the face flux `flux` (owner -> neighbour)
+    double limited_weight(int d, int q, int own, int nei, double flux) const {
+        const double gradf = lphi[nei] - lphi[own];
+        const double gradcf = delta(d, q) * gradL[3 * (size_t)(flux > 0 ? own : nei) + d];
+        double r;
+        if (std::fabs(gradcf) >= 1000.0 * std::fabs(gradf)) r = 2.0 * 1000.0 * (gradcf >= 0 ? 1.0 : -1.0) * (gradf >= 0 ? 1.0 : -1.0) - 1.0;
+        else r = 2.0 * (gradcf / gradf) - 1.0;
+        const double kk = std::max(cs.convection_limiter_k, SMALL);            // limitedLinearLimiter: twoByk_ = 2 / max(k, small) (k = 1: min(2 r, 1), TVD conforming)
+        const double lim = limiter_fn(cs.convection_scheme, 2.0 / kk, r);
+        const double wl = graded ? wlow(d, q) : 0.5;
+        return lim * wl + (1.0 - lim) * (flux >= 0 ? 1.0 : 0.0);
+    }
+
     // fvc::grad(U): T[3*i + j] = d_i U_j  (row-major xx xy xz ...), Gauss linear
     void grad_U(const vec& F, vec& T) const {
 #pragma omp parallel for num_threads(threads) collapse(2)
@@ -346,6 +391,7 @@ struct Fv {
     }
     void assemble_momentum() {
         const double nu = cs.nu, dt = cs.dt;
+        if (cs.convection_scheme >= 3) limiter_gradient(U);          // the limiter sees the CURRENT U (the scheme is built when UEqn is assembled)
         if (pimple) {
             // explicit part of divDevRhoReff: + fvc::div(alpha nu dev2(T(grad U))) on the RHS (laminar Stokes model)
             grad_U(U, vGrad);
@@ -424,11 +470,17 @@ struct Fv {
                         dg += phio;
                     }
                 } else {
-                    const bool up = cs.convection_scheme != 0;               // 1 upwind, 2 linearUpwind (implicit part = upwind)
+                    const bool up = cs.convection_scheme == 1 || cs.convection_scheme == 2;      // 1 upwind, 2 linearUpwind (implicit part = upwind)
                     // Gauss linear: the face value is w_P U_P + (1 - w_P) U_N with the linear weights of the (graded) block
                     const double wP = !graded ? 0.5 : (s ? wlow(d, fq(d, 1, i, j, k)) : 1.0 - wlow(d, fq(d, 0, i, j, k)));
-                    const double cP = up ? std::max(phio, 0.0) : wP * phio;
-                    const double cN = up ? std::min(phio, 0.0) : (!graded ? 0.5 * phio : (1.0 - wP) * phio);
+                    double cP = up ? std::max(phio, 0.0) : wP * phio;
+                    double cN = up ? std::min(phio, 0.0) : (!graded ? 0.5 * phio : (1.0 - wP) * phio);
+                    if (cs.convection_scheme >= 3) {
+                        const int nb = c + (s ? stride[d] : -stride[d]);
+                        const double w = limited_weight(d, fq(d, s, i, j, k), s ? c : nb, s ? nb : c, af * phi[d][f]);
+                        cP = s ? phio * w : phio * (1.0 - w);
+                        cN = s ? phio * (1.0 - w) : phio * w;
+                    }
                     dg += cP + gam;
                     an[2 * d + s][c] = cN - gam;
                     if (cs.convection_scheme == 2) {
@@ -1186,6 +1238,8 @@ struct Fv {
 
 extern "C" {
 
+// the limiter function of an NVD / TVD scheme at gradient ratio r (tests: Sweby's region)
+double orc_fv_limiter(int scheme, double k, double r) { return Fv::limiter_fn(scheme, 2.0 / std::max(k, SMALL), r); }
 void* orc_fv_create(const orc_fv_case* c) {
     // a graded block carries the laminar operators with Gauss linear / upwind convection only (the closures' delta, wall distance and the
     // linearUpwind correction assume uniform cubes)

@@ -249,7 +249,7 @@ class FvCase(C.Structure):
                 ("ras_sigmaeps", C.c_double), ("eps_bc", C.c_int * 6), ("eps_value", C.c_double * 6), ("eps_initial", C.c_double),
                 ("eps_convection_scheme", C.c_int), ("eps_tol", C.c_double), ("eps_rel_tol", C.c_double), ("eps_max_iter", C.c_int),
                 ("eps_relax", C.c_double), ("wf_kappa", C.c_double), ("wf_E", C.c_double),
-                ("hx", _dp), ("hy", _dp), ("hz", _dp)]
+                ("hx", _dp), ("hy", _dp), ("hz", _dp), ("convection_limiter_k", C.c_double)]
 
 
 class FvStats(C.Structure):
@@ -259,6 +259,8 @@ class FvStats(C.Structure):
                 ("p_final_residual", C.c_double), ("delta_t", C.c_double)]
 
 
+# div(phi,U): Gauss linear | upwind | linearUpwind | the NVD / TVD limited schemes
+LINEAR, UPWIND, LINEAR_UPWIND, LIMITED_LINEAR, VAN_LEER, MUSCL, MINMOD, SUPERBEE, QUICK = range(9)
 U_FIXED, U_ZEROGRAD, U_SLIP = 0, 1, 2         # U_SLIP: symmetryPlane / slip (normal component 0, tangential zeroGradient)
 P_ZEROGRAD, P_FIXED, P_FIXEDFLUX = 0, 1, 2
 XMIN, XMAX, YMIN, YMAX, ZMIN, ZMAX = range(6)
@@ -271,7 +273,7 @@ def fv_case(solver, nx, ny, nz, dx, dt, nu, rho_f=1000.0, rho_p=2650.0, g=(0, 0,
             p_relax_final=0.0, turbulence_model=0, les_ck=0.094, les_ce=1.048, les_delta_coeff=1.0, nut_bc=None, nut_value=None, nut_initial=0.0,
             k_bc=None, k_value=None, k_initial=0.0, k_convection_scheme=1, k_tol=1e-6, k_rel_tol=0.0, k_max_iter=1000, k_relax=0.0,
             ras_cmu=0.09, ras_c1=1.44, ras_c2=1.92, ras_c3=0.0, ras_sigmak=1.0, ras_sigmaeps=1.3, eps_bc=None, eps_value=None, eps_initial=0.0,
-            eps_convection_scheme=1, eps_tol=1e-6, eps_rel_tol=0.0, eps_max_iter=1000, eps_relax=0.0, wf_kappa=0.41, wf_E=9.8, grading=None):
+            eps_convection_scheme=1, eps_tol=1e-6, eps_rel_tol=0.0, eps_max_iter=1000, eps_relax=0.0, wf_kappa=0.41, wf_E=9.8, grading=None, limiter_k=1.0):
     """documented defaults = the icoFoam cavity / DPMFoam tutorial settings of SURVEY.md Appendix C"""
     c = FvCase()
     c.solver, c.nx, c.ny, c.nz, c.dx, c.dt, c.nu = solver, nx, ny, nz, dx, dt, nu
@@ -294,6 +296,7 @@ def fv_case(solver, nx, ny, nz, dx, dt, nu, rho_f=1000.0, rho_p=2650.0, g=(0, 0,
     c.p_tol, c.p_rel_tol, c.p_final_tol, c.p_final_rel_tol, c.p_max_iter = p_tol, p_rel_tol, p_final_tol, p_final_rel_tol, p_max_iter
     c.u_tol, c.u_rel_tol, c.u_max_iter = u_tol, u_rel_tol, u_max_iter
     c.convection_scheme = int(convection_scheme)
+    c.convection_limiter_k = float(limiter_k)
     c.adjust_time_step, c.max_co, c.max_delta_t = int(adjust_time_step), max_co, max_delta_t
     c.u_relax, c.u_relax_final, c.p_relax, c.p_relax_final = u_relax, u_relax_final, p_relax, p_relax_final
     c.turbulence_model, c.les_ck, c.les_ce, c.les_delta_coeff, c.nut_initial = int(turbulence_model), les_ck, les_ce, les_delta_coeff, nut_initial

@@ -83,7 +83,8 @@ def test_symmetry_sides_are_read_as_slip(prod, tmp_path, ty):
     (("system/fvSolution", "PISO", "SIMPLE"), "PISO"),
     (("0/U", "value           uniform (1 0 0);", "#include \"lid\""), "lid"),
     (("0/U", "value           uniform (1 0 0);", "#calc \"1+1\";"), "#calc"),
-    (("system/fvSchemes", "div(phi,U)       Gauss linear;", "div(phi,U)       Gauss limitedLinear 1;"), "div(phi,U)"),
+    (("system/fvSchemes", "div(phi,U)       Gauss linear;", "div(phi,U)       Gauss limitedLinearV 1;"), "div(phi,U)"),
+    (("system/fvSchemes", "div(phi,U)       Gauss linear;", "div(phi,U)       Gauss limitedLinear;"), "coefficient"),
     (("system/fvSchemes", "default Euler;", "default CrankNicolson 0.9;"), "ddtSchemes"),
 ])
 def test_what_is_outside_the_supported_subset_is_refused_by_name(prod, tmp_path, edit, needle):
@@ -265,10 +266,8 @@ def test_gauss_upwind_is_read_as_the_upwind_scheme(prod, tmp_path):
     fc = prod.FoamCase(dst, prod.FY_SOLVER_PIMPLE)
     assert fc.case.convection_scheme == prod.FY_CONVECTION_UPWIND
     fc.close()
-    f.write_text(f.read_text().replace("div(phi,U)       Gauss upwind;", "div(phi,U)       Gauss linear;"))        # one of each: refused
-    with pytest.raises(prod.FoamYadeError) as e:
-        prod.FoamCase(dst, prod.FY_SOLVER_PIMPLE)
-    assert "mixes" in str(e.value)
+    f.write_text(f.read_text().replace("div(phi,U)       Gauss upwind;", "div(phi,U)       Gauss linear;"))        # each executable reads its own term
+    assert prod.FoamCase(dst, prod.FY_SOLVER_PIMPLE).case.convection_scheme == prod.FY_CONVECTION_UPWIND
     assert prod.FoamCase(os.path.join(CASES, "bed_pimple"), prod.FY_SOLVER_PIMPLE).case.convection_scheme == prod.FY_CONVECTION_LINEAR
     f.write_text(f.read_text().replace("div(phi,U)       Gauss linear;", "div(phi,U)       Gauss linearUpwind grad(U);").replace("div(alphaPhic,Uc) Gauss upwind;", "div(alphaPhic,Uc) Gauss linearUpwind grad(Uc);"))
     assert prod.FoamCase(dst, prod.FY_SOLVER_PIMPLE).case.convection_scheme == prod.FY_CONVECTION_LINEAR_UPWIND
@@ -802,3 +801,17 @@ def test_write_format_precision_and_purge(prod, tmp_path, fmt):
         np.testing.assert_allclose(U2.reshape(U.shape), U, rtol=5e-6, atol=1e-300)
         assert np.abs(U2.reshape(U.shape) - U).max() > 0 and max(len(w) for w in raw.split(b"boundaryField")[0].split()[-300:]) <= 14
     s.close(); fc.close(); fc2.close()
+
+
+@pytest.mark.parametrize("text,scheme,k", [("Gauss limitedLinear 0.5", 3, 0.5), ("bounded Gauss vanLeer", 4, 1.0), ("Gauss MUSCL", 5, 1.0), ("Gauss Minmod", 6, 1.0),
+                                           ("Gauss SuperBee", 7, 1.0), ("Gauss QUICK", 8, 1.0), ("bounded Gauss upwind", 1, 1.0), ("Gauss linearUpwind grad(U)", 2, 1.0)])
+def test_convection_schemes_are_read_by_name(prod, tmp_path, text, scheme, k):
+    dst = tmp_path / "case"
+    shutil.copytree(os.path.join(CASES, "cavity_ico"), dst)
+    f = dst / "system/fvSchemes"
+    t = f.read_text()
+    assert "div(phi,U)       Gauss linear;" in t
+    f.write_text(t.replace("div(phi,U)       Gauss linear;", "div(phi,U)       %s;" % text))
+    fc = prod.FoamCase(dst, prod.FY_SOLVER_ICO)
+    assert fc.case.convection_scheme == scheme and fc.case.convection_limiter_k == k
+    fc.close()

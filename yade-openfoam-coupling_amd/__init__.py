@@ -34,6 +34,7 @@ FY_BC_U_FIXED_VALUE, FY_BC_U_ZERO_GRADIENT, FY_BC_U_SLIP = 0, 1, 2
 FY_BC_P_ZERO_GRADIENT, FY_BC_P_FIXED_VALUE, FY_BC_P_FIXED_FLUX = 0, 1, 2
 FY_PSOLVER_PCG_JACOBI, FY_PSOLVER_PCG_MG = 0, 1
 FY_CONVECTION_LINEAR, FY_CONVECTION_UPWIND, FY_CONVECTION_LINEAR_UPWIND = 0, 1, 2
+FY_CONVECTION_LIMITED_LINEAR, FY_CONVECTION_VAN_LEER, FY_CONVECTION_MUSCL, FY_CONVECTION_MINMOD, FY_CONVECTION_SUPERBEE, FY_CONVECTION_QUICK = 3, 4, 5, 6, 7, 8
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)
@@ -101,7 +102,7 @@ class CaseDesc(C.Structure):
                 ("ras_sigmaeps", C.c_double), ("eps_bc", C.c_int32 * 6), ("eps_value", C.c_double * 6), ("eps_initial", C.c_double),
                 ("eps_convection_scheme", C.c_int32), ("eps_tol", C.c_double), ("eps_rel_tol", C.c_double), ("eps_max_iter", C.c_int32),
                 ("eps_relax", C.c_double), ("wf_kappa", C.c_double), ("wf_E", C.c_double),
-                ("hx", C.POINTER(C.c_double)), ("hy", C.POINTER(C.c_double)), ("hz", C.POINTER(C.c_double))]
+                ("hx", C.POINTER(C.c_double)), ("hy", C.POINTER(C.c_double)), ("hz", C.POINTER(C.c_double)), ("convection_limiter_k", C.c_double)]
 
 
 BC_WALL_FUNCTION, BC_NUT_CALCULATED = 2, 3

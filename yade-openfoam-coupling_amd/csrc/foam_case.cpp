@@ -608,7 +608,7 @@ int read_controls(fy_foam_case* c) {
         struct Want { const char* dict; const char* must; const char* alt; const char* forbid; };
         const Want wants[] = {{"ddtSchemes", "Euler", nullptr, nullptr},
                               {"gradSchemes", "linear", nullptr, "Limited"},
-                              {"divSchemes", "linear", "upwind", "UpwindV"},         // Gauss linear | upwind | linearUpwind grad(U); not linearUpwindV, limitedLinear ...
+                              {"divSchemes", "linear", "upwind", "UpwindV"},         // parsed by name below: Gauss linear | upwind | linearUpwind grad(U) | the limited schemes; not the V variants
                               {"laplacianSchemes", "linear", nullptr, nullptr},
                               {"interpolationSchemes", "linear", nullptr, "pwind"},
                               {"snGradSchemes", "corrected", "orthogonal", nullptr}};   // corrected == uncorrected == orthogonal on this mesh
@@ -621,26 +621,45 @@ int read_controls(fy_foam_case* c) {
                 if (!tk) continue;
                 std::string joined;
                 for (const std::string& t : *tk) joined += t + " ";
-                const bool ok = (joined.find(w.must) != std::string::npos || (w.alt && joined.find(w.alt) != std::string::npos) || joined.find("none") == 0) &&
-                                !(w.forbid && joined.find(w.forbid) != std::string::npos) && joined.find("limited") == std::string::npos &&
-                                joined.find("vanLeer") == std::string::npos && joined.find("QUICK") == std::string::npos;
-                if (!ok) return fail(FY_ERR_UNSUPPORTED, "%s: %s.%s = '%s' is not supported (Euler; Gauss linear; div(phi,U) Gauss linear | upwind | linearUpwind)", path.c_str(), w.dict, k.c_str(), joined.c_str());
-                if (std::string(w.dict) == "divSchemes" && joined.find("none") != 0) {
-                    const int sch = joined.find("inearUpwind") != std::string::npos ? FY_CONVECTION_LINEAR_UPWIND
-                                  : joined.find("upwind") != std::string::npos ? FY_CONVECTION_UPWIND : FY_CONVECTION_LINEAR;
+                const bool is_div = std::string(w.dict) == "divSchemes";
+                // divSchemes: [bounded] Gauss <scheme> [args]; the scheme by name
+                int sch = -1;
+                double lim_k = 1.0;
+                if (is_div && joined.find("none") != 0) {
+                    size_t q = 0;
+                    if (q < tk->size() && (*tk)[q] == "bounded") ++q;
+                    if (q + 1 < tk->size() && (*tk)[q] == "Gauss") {
+                        const std::string& nm = (*tk)[q + 1];
+                        static const struct { const char* name; int id; } known[] = {
+                            {"linear", FY_CONVECTION_LINEAR}, {"upwind", FY_CONVECTION_UPWIND}, {"linearUpwind", FY_CONVECTION_LINEAR_UPWIND},
+                            {"limitedLinear", FY_CONVECTION_LIMITED_LINEAR}, {"vanLeer", FY_CONVECTION_VAN_LEER}, {"MUSCL", FY_CONVECTION_MUSCL},
+                            {"Minmod", FY_CONVECTION_MINMOD}, {"SuperBee", FY_CONVECTION_SUPERBEE}, {"QUICK", FY_CONVECTION_QUICK}};
+                        for (const auto& e : known) if (nm == e.name) sch = e.id;
+                        if (sch == FY_CONVECTION_LIMITED_LINEAR && !(q + 2 < tk->size() && fy::foam_tok_is_number((*tk)[q + 2], &lim_k) && lim_k >= 0 && lim_k <= 1))
+                            return fail(FY_ERR_INVALID, "%s: divSchemes.%s = '%s': limitedLinear takes a coefficient in [0, 1]", path.c_str(), k.c_str(), joined.c_str());
+                    }
+                }
+                const bool ok = is_div ? (sch >= 0 || joined.find("none") == 0)
+                              : ((joined.find(w.must) != std::string::npos || (w.alt && joined.find(w.alt) != std::string::npos) || joined.find("none") == 0) &&
+                                 !(w.forbid && joined.find(w.forbid) != std::string::npos) && joined.find("limited") == std::string::npos &&
+                                 joined.find("vanLeer") == std::string::npos && joined.find("QUICK") == std::string::npos);
+                if (!ok) return fail(FY_ERR_UNSUPPORTED, "%s: %s.%s = '%s' is not supported (Euler; Gauss linear; div(phi,U) Gauss linear | upwind | linearUpwind | limitedLinear k | vanLeer | MUSCL | Minmod | SuperBee | QUICK)", path.c_str(), w.dict, k.c_str(), joined.c_str());
+                if (is_div && joined.find("none") != 0) {
                     // only the convection terms select the scheme (icoFoamYade.C:82 div(phi,U), UcEqn.H:5-6 div(alphaPhic,Uc), or `default`);
                     // every other entry (the explicit stress term div(((alpha*nuEff)*dev2(T(grad(U))))) ...) must be plain Gauss linear
                     // (the fields' registered names are alphaPhi.<phase>, U.<phase>, k.<phase>: pimpleFoamYade/createFields.H:35-45,238-246)
-                    const bool convection = k == "default" || k == "div(phi,U)" || k == "div(alphaPhic,Uc)" || k == "div(phic,Uc)" ||
-                                            k == "div(alphaPhi." + c->phase + ",U." + c->phase + ")";
+                    const bool ico_term = k == "div(phi,U)";
+                    const bool pimple_term = k == "div(alphaPhic,Uc)" || k == "div(phic,Uc)" || k == "div(alphaPhi." + c->phase + ",U." + c->phase + ")";
+                    if ((ico_term && c->solver != FY_SOLVER_ICO) || (pimple_term && c->solver != FY_SOLVER_PIMPLE)) continue;      // (the other executable's term)
+                    const bool convection = k == "default" || ico_term || pimple_term;
                     const bool k_convection = k == "div(alphaPhic,k)" || k == "div(alphaPhi." + c->phase + ",k." + c->phase + ")";
                     if (k == "div(alphaPhic,epsilon)" || k == "div(alphaPhi." + c->phase + ",epsilon." + c->phase + ")") {     // fvm::div(alphaRhoPhi, epsilon)
-                        if (sch == FY_CONVECTION_LINEAR_UPWIND) return fail(FY_ERR_UNSUPPORTED, "%s: divSchemes.%s = '%s': Gauss linear or Gauss upwind for epsilon", path.c_str(), k.c_str(), joined.c_str());
+                        if (sch >= FY_CONVECTION_LINEAR_UPWIND) return fail(FY_ERR_UNSUPPORTED, "%s: divSchemes.%s = '%s': Gauss linear or Gauss upwind for epsilon", path.c_str(), k.c_str(), joined.c_str());
                         c->desc.eps_convection_scheme = sch;
                         continue;
                     }
                     if (k_convection) {                                  // fvm::div(alphaRhoPhi, k) of the kEqn / kEpsilon models
-                        if (sch == FY_CONVECTION_LINEAR_UPWIND) return fail(FY_ERR_UNSUPPORTED, "%s: divSchemes.%s = '%s': Gauss linear or Gauss upwind for k", path.c_str(), k.c_str(), joined.c_str());
+                        if (sch >= FY_CONVECTION_LINEAR_UPWIND) return fail(FY_ERR_UNSUPPORTED, "%s: divSchemes.%s = '%s': Gauss linear or Gauss upwind for k", path.c_str(), k.c_str(), joined.c_str());
                         c->desc.k_convection_scheme = sch;
                         continue;
                     }
@@ -648,9 +667,10 @@ int read_controls(fy_foam_case* c) {
                         if (sch != FY_CONVECTION_LINEAR) return fail(FY_ERR_UNSUPPORTED, "%s: divSchemes.%s = '%s': only the convection terms may be upwinded, this one must be Gauss linear", path.c_str(), k.c_str(), joined.c_str());
                         continue;
                     }
-                    if (k == "default") { if (!n_div) c->desc.convection_scheme = sch; c->desc.k_convection_scheme = c->desc.eps_convection_scheme = sch == FY_CONVECTION_LINEAR ? sch : FY_CONVECTION_UPWIND; continue; }      // a named convection entry overrides it
+                    if (k == "default") { if (!n_div) { c->desc.convection_scheme = sch; c->desc.convection_limiter_k = lim_k; } c->desc.k_convection_scheme = c->desc.eps_convection_scheme = sch == FY_CONVECTION_LINEAR ? sch : FY_CONVECTION_UPWIND; continue; }      // a named convection entry overrides it
                     if (n_div++ && sch != c->desc.convection_scheme) return fail(FY_ERR_UNSUPPORTED, "%s: divSchemes mixes different convection schemes", path.c_str());
                     c->desc.convection_scheme = sch;
+                    c->desc.convection_limiter_k = lim_k;
                 }
             }
         }

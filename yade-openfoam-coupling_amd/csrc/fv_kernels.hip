@@ -866,6 +866,59 @@ __global__ __launch_bounds__(256) void k_turb_finish(FvGeo g, TurbEqn e, const d
 }
 
 // UEqn (icoFoamYade.C:79-85) / UcEqn + relax (UcEqn.H:3-12): diag, 6 neighbour coefficients, source (no pressure term), rAU = 1/A
+// ---- NVD / TVD limited convection schemes for div(phi,U) [OF-6 LimitedScheme<vector, Limiter<NVDTVD>, limitFuncs::magSqr>, NVDTVD.H]: one
+// limiter per face from the scalar lPhi = magSqr(U): r = 2 (d . grad(lPhi)_C) / (lPhi_N - lPhi_P) - 1, C the upwind cell of the face flux, grad
+// the Gauss-linear gradient (boundary value magSqr(U_b)); the weight of the OWNER's value is limiter * w_linear + (1 - limiter) * pos0(faceFlux)
+// [limitedSurfaceInterpolationScheme::weights], used implicitly in the matrix.
+__device__ __forceinline__ double magsqr3(const double* __restrict__ F, int c) {
+    const double a = F[3 * (size_t)c], b = F[3 * (size_t)c + 1], e = F[3 * (size_t)c + 2];
+    return (a * a + b * b) + e * e;
+}
+__global__ __launch_bounds__(256) void k_grad_magsqr(FvGeo g, const double* __restrict__ U, double* __restrict__ gradL) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= g.Nc) return;
+    int i, j, k; ijk_of(g, t, i, j, k);
+    const int c = t + g.c0;
+    const double lc = magsqr3(U, c);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        double fv[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            if (onb(g, d, s, i, j, k)) { double b[3]; Ub(g, U, c, 2 * d + s, b); fv[s] = (b[0] * b[0] + b[1] * b[1]) + b[2] * b[2]; }
+            else fv[s] = geo_lerp_side(g, d, s, d == 0 ? i : d == 1 ? j : k, lc, magsqr3(U, c + (s ? stride_of(g, d) : -stride_of(g, d))));
+        }
+        gradL[3 * (size_t)c + d] = (fv[1] - fv[0]) * geo_rh(g, d, d == 0 ? i : d == 1 ? j : k);
+    }
+}
+__device__ __forceinline__ double limiter_fn(int scheme, double twoByk, double r) {
+    switch (scheme) {
+        case 3: return fmax(fmin(twoByk * r, 1.0), 0.0);                                   // limitedLinear k: twoByk = 2 / max(k, small)
+        case 4: return (r + fabs(r)) / (1.0 + fabs(r));                                    // vanLeer
+        case 5: return fmax(fmin(fmin(2.0 * r, 0.5 * r + 0.5), 2.0), 0.0);                 // MUSCL
+        case 6: return fmax(fmin(fmin(r, 1.0), 2.0), 0.0);                                 // Minmod
+        case 7: return fmax(fmax(fmin(2.0 * r, 1.0), fmin(r, 2.0)), 0.0);                  // SuperBee
+        default: return fmax(fmin(fmin(2.0 * r, (3.0 + r) / 4.0), 2.0), 0.0);              // QUICK (8)
+    }
+}
+// weight of the owner's (low cell's) value on the interior face between own and nei (axis d; qn = the neighbour's index along d); flux: owner -> neighbour
+__device__ __forceinline__ double limited_weight(const FvGeo& g, const double* __restrict__ U, const double* __restrict__ gradL, int d, int qn, int own,
+                                                 int nei, double flux) {
+    const double gradf = magsqr3(U, nei) - magsqr3(U, own);
+    const double gradcf = (1.0 / geo_rdelta(g, d, qn)) * gradL[3 * (size_t)(flux > 0 ? own : nei) + d];
+    double r;
+    if (fabs(gradcf) >= 1000.0 * fabs(gradf)) r = 2.0 * 1000.0 * (gradcf >= 0 ? 1.0 : -1.0) * (gradf >= 0 ? 1.0 : -1.0) - 1.0;
+    else r = 2.0 * (gradcf / gradf) - 1.0;
+    const double lim = limiter_fn(g.upwind, g.lim_twoByk, r);
+#if FY_FVK_GRADED
+    const double wl = geo_wlow(g, d, qn);
+#else
+    const double wl = 0.5;
+#endif
+    return lim * wl + (1.0 - lim) * (flux >= 0 ? 1.0 : 0.0);
+}
+
+template <bool LIMITED>
 __global__ __launch_bounds__(256) void k_assemble_momentum(FvGeo g, const double* __restrict__ U, const double* __restrict__ Uold,
                                                            const double* __restrict__ alpha, const double* __restrict__ alphaOld, CFace3 alphaf,
                                                            CFace3 phi, const double* __restrict__ uSource, const double* __restrict__ uSourceDrag,
@@ -922,10 +975,17 @@ __global__ __launch_bounds__(256) void k_assemble_momentum(FvGeo g, const double
                 // outgoing flux on the diagonal and the whole of an incoming one on the neighbour [OF-6 gaussConvectionScheme]
                 const double wP = geo_wown(g, d, s, d == 0 ? i : d == 1 ? j : k);      // Gauss linear: w_P U_P + (1 - w_P) U_N at the face
 #if FY_FVK_GRADED
-                const double cP = g.upwind ? fmax(phio, 0.0) : wP * phio, cN = g.upwind ? fmin(phio, 0.0) : (1.0 - wP) * phio;
+                double cP = g.upwind ? fmax(phio, 0.0) : wP * phio, cN = g.upwind ? fmin(phio, 0.0) : (1.0 - wP) * phio;
 #else
-                const double cP = g.upwind ? fmax(phio, 0.0) : wP * phio, cN = g.upwind ? fmin(phio, 0.0) : wP * phio;
+                double cP = g.upwind ? fmax(phio, 0.0) : wP * phio, cN = g.upwind ? fmin(phio, 0.0) : wP * phio;
 #endif
+                if (LIMITED) {                                 // (vGrad carries grad(magSqr(U)), three per cell)
+                    const int nb = c + (s ? stride_of(g, d) : -stride_of(g, d));
+                    const int qc = d == 0 ? i : d == 1 ? j : k;
+                    const double w = limited_weight(g, U, vGrad, d, qc + s, s ? c : nb, s ? nb : c, af * phi.a[d][f]);
+                    cP = s ? phio * w : phio * (1.0 - w);
+                    cN = s ? phio * (1.0 - w) : phio * w;
+                }
                 dg += cP + gam;
                 an[2 * d + s] = cN - gam;
                 if (g.upwind == 2) {
@@ -1849,8 +1909,15 @@ int launch_smagorinsky_nut(hipStream_t s, FvGeo g, const double* vGrad, double c
 int launch_assemble_momentum(hipStream_t s, FvGeo g, const double* U, const double* Uold, const double* alpha, const double* alphaOld,
                              CFace3 alphaf, CFace3 phi, const double* uSource, const double* uSourceDrag, const double* divG, const double* vGrad,
                              Mom7 M, double* src, double* rAU) {
-    hipLaunchKernelGGL(k_assemble_momentum, dim3(div_up(g.Nc, 256)), dim3(256), 0, s, g, U, Uold, alpha, alphaOld, alphaf, phi, uSource,
-                       uSourceDrag, divG, vGrad, M, src, rAU);
+    if (g.upwind >= 3) hipLaunchKernelGGL(k_assemble_momentum<true>, dim3(div_up(g.Nc, 256)), dim3(256), 0, s, g, U, Uold, alpha, alphaOld, alphaf, phi, uSource,
+                                          uSourceDrag, divG, vGrad, M, src, rAU);
+    else hipLaunchKernelGGL(k_assemble_momentum<false>, dim3(div_up(g.Nc, 256)), dim3(256), 0, s, g, U, Uold, alpha, alphaOld, alphaf, phi, uSource,
+                            uSourceDrag, divG, vGrad, M, src, rAU);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+int launch_grad_magsqr(hipStream_t s, FvGeo g, const double* U, double* gradL) {
+    hipLaunchKernelGGL(k_grad_magsqr, dim3(div_up(g.Nc, 256)), dim3(256), 0, s, g, U, gradL);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }

@@ -24,7 +24,9 @@ struct FvGeo {
     int p_bc[6];            // FY_BC_P_*
     double p_val[6];
     int pimple;
-    int upwind;             // div(phi,U): 0 Gauss linear, 1 Gauss upwind (first order, bounded), 2 Gauss linearUpwind (upwind + explicit gradient correction)
+    int upwind;             // div(phi,U): 0 Gauss linear, 1 Gauss upwind (first order, bounded), 2 Gauss linearUpwind (upwind + explicit gradient correction),
+                            // 3 .. 8 the NVD / TVD limited schemes limitedLinear k | vanLeer | MUSCL | Minmod | SuperBee | QUICK (FY_CONVECTION_*)
+    double lim_twoByk;      // limitedLinear: 2 / max(k, small)
     double dt, nu;
     // continuousPhaseTurbulence: nut = nullptr is the laminar (Stokes) model -- every kernel then computes exactly what it did without one
     const double* nut;      // [storage cells] eddy viscosity of the Smagorinsky model (k_smagorinsky_nut), ghost planes refreshed by the solver

@@ -66,6 +66,7 @@ struct Solver {
     CFace3 phi_now() const { return phi_fresh ? CFace3{{phi[0].p, phi[1].p, phi[2].p}} : CFace3{{phiOld[0].p, phiOld[1].p, phiOld[2].p}}; }
     bool rAU_new = true;        // rAU was (re)assembled since the last corrector: rAUf and the coarse pressure operators are stale
     DevBuf<double> phi[3], phiOld[3], psn[3], alphaf[3], phiHbyA[3], phiForces[3], rAUf[3], pflux[3];
+    DevBuf<double> gradL;                // [3 nstore] grad(magSqr(U)) for the limited convection schemes
     DevBuf<double> mbd;                  // [3 nstore] per-component boundary diagonal of the momentum matrix (Mom7::bd): only with a slip patch
     DevBuf<double> mdiag, man[6], src, rAU, HbyA, bmom, Gt, divG, xscr;
     std::vector<std::unique_ptr<MgLev> > mg;
@@ -131,7 +132,8 @@ struct Solver {
     int halo_level(MgLev& L, double* x) { return L.distributed ? halo(x, 1, L.plane, L.A.nz, L.gz, 1) : FY_OK; }
 
     int create(const fy_case_desc* c, const fy_transport* tr, int dev, Comm* cm) {
-        if (c && (c->convection_scheme < FY_CONVECTION_LINEAR || c->convection_scheme > FY_CONVECTION_LINEAR_UPWIND)) return fail(FY_ERR_INVALID, "fy_solver_create: unknown convection_scheme");
+        if (c && (c->convection_scheme < FY_CONVECTION_LINEAR || c->convection_scheme > FY_CONVECTION_QUICK)) return fail(FY_ERR_INVALID, "fy_solver_create: unknown convection_scheme");
+        if (c && c->convection_scheme == FY_CONVECTION_LIMITED_LINEAR && !(c->convection_limiter_k >= 0 && c->convection_limiter_k <= 1)) return fail(FY_ERR_INVALID, "fy_solver_create: limitedLinear's coefficient must lie in [0, 1]");
         const bool gradedc = c && (c->hx || c->hy || c->hz);
         if (!c || c->nx <= 0 || c->ny <= 0 || c->nz <= 0 || (!gradedc && !(c->dx > 0)) || !(c->dt > 0)) return fail(FY_ERR_INVALID, "fy_solver_create: bad case");
         if (gradedc) {
@@ -188,7 +190,8 @@ struct Solver {
             g.Af = g.dx * g.dx; g.V = g.dx * g.dx * g.dx;
             total_volume = (len[0] * len[1]) * len[2];
         }
-        g.upwind = c->convection_scheme;          // 0 linear, 1 upwind, 2 linearUpwind
+        g.upwind = c->convection_scheme;          // 0 linear, 1 upwind, 2 linearUpwind, 3 .. 8 limited
+        g.lim_twoByk = 2.0 / std::max(c->convection_limiter_k, 1e-15);
         g.rdx = 1.0 / g.dx; g.rhdx = 1.0 / (0.5 * g.dx); g.rV = 1.0 / g.V;
         g.pimple = pimple ? 1 : 0; g.dt = c->dt; g.nu = c->nu;
         bool need_ref = true;
@@ -283,6 +286,7 @@ struct Solver {
         for (auto& b : man) { FY_TRY(b.alloc_exact(n)); FY_TRY(zero(b)); }
         for (int q = 0; q < 6; ++q) if (c->u_bc[q] == FY_BC_U_SLIP && !mbd.p) { FY_TRY(mbd.alloc_exact(3 * n)); FY_TRY(zero(mbd)); }
         FY_TRY(vGrad.alloc_exact(9 * n)); FY_TRY(zero(vGrad));
+        if (c->convection_scheme >= FY_CONVECTION_LIMITED_LINEAR) { FY_TRY(gradL.alloc_exact(3 * n)); FY_TRY(zero(gradL)); }
         if (c->turbulence_model != FY_TURBULENCE_LAMINAR) { FY_TRY(nut.alloc_exact(n)); FY_TRY(launch_fill_f64(stream, nut.p, n, c->nut_initial)); g.nut = nut.p; }
         if (c->turbulence_model == FY_TURBULENCE_KEQN || c->turbulence_model == FY_TURBULENCE_KEPSILON) { FY_TRY(kturb.alloc_exact(n)); FY_TRY(launch_fill_f64(stream, kturb.p, n, c->k_initial)); g.kturb = kturb.p; }
         if (c->turbulence_model == FY_TURBULENCE_KEPSILON) { FY_TRY(epsturb.alloc_exact(n)); FY_TRY(launch_fill_f64(stream, epsturb.p, n, c->eps_initial)); g.epsturb = epsturb.p; }
@@ -926,8 +930,13 @@ struct Solver {
                 FY_TRY(FVK(launch_div_G, stream, g, Gt.p, divG.p));
             }
             if (g.upwind == 2) FY_TRY(halo_cells(vGrad, 9, 1));      // linearUpwind reads grad(U) of the upwind neighbour (ico: written at step start)
+            if (g.upwind >= 3) {                                     // the limited schemes: gradient ratio from grad(magSqr(U)) of the current U
+                FY_TRY(halo_cells(U, 3, 1));
+                FY_TRY(FVK(launch_grad_magsqr, stream, g, U.p, gradL.p));
+                FY_TRY(halo_cells(gradL, 3, 1));
+            }
             FY_TRY(FVK(launch_assemble_momentum, stream, g, U.p, Uold.p, alpha.p, /* alphaOld */ alpha.p, C3(alphaf), phi_now(), uSource.p, uSourceDrag.p,
-                                            divG.p, vGrad.p, M7(), src.p, rAU.p));
+                                            divG.p, g.upwind >= 3 ? gradL.p : vGrad.p, M7(), src.p, rAU.p));
             rAU_new = true;
             if (pimple) {
                 FY_TRY(halo_cells(rAU, 1, 1));
@@ -1014,6 +1023,7 @@ void fy_case_defaults(fy_case_desc* c, int solver) {
     c->u_tol = 1e-5; c->u_rel_tol = 0.0; c->u_max_iter = 1000;
     c->adjust_time_step = 0; c->max_co = 1.0; c->max_delta_t = 1e300;
     c->u_relax = 1.0; c->u_relax_final = 0.0; c->p_relax = 0.0; c->p_relax_final = 0.0;
+    c->convection_limiter_k = 1.0;
     c->k_tol = 1e-6; c->k_rel_tol = 0.0; c->k_max_iter = 1000; c->k_relax = 0.0; c->k_convection_scheme = FY_CONVECTION_UPWIND;
     c->eps_tol = 1e-6; c->eps_rel_tol = 0.0; c->eps_max_iter = 1000; c->eps_relax = 0.0; c->eps_convection_scheme = FY_CONVECTION_UPWIND;
     c->wf_kappa = 0.41; c->wf_E = 9.8;                      // [OF-6 nutWallFunctionFvPatchScalarField defaults]
