@@ -590,11 +590,19 @@ int Coupling::run_batch(Batch& b) {
         // With the candidate lists k_locate_deposit fetches the records through the placement itself (and leaves the SoA copy behind for
         // the force pass): no separate gather pass
         const bool fused_gather = use_implicit && d_loc_lists.p != nullptr;
-        if (b.binned_n != b.n || b.bin_age >= rebin_interval) {
+        const bool have_chains = b.chain_n == b.n && b.binned_n == b.n;       // last step's lengths, in the placement that is still there
+        if (b.binned_n != b.n || b.bin_age >= rebin_interval || (have_chains && !b.ordered_by_chain)) {
+            if (have_chains) {
+                if (b.kwire.n < (size_t)b.n) FY_TRY(b.kwire.alloc_exact((size_t)b.cap));
+                FY_TRY(launch_chain_by_wire(stream, b.orig.p, b.chain.p, b.n, b.kwire.p));
+            }
             FY_HIP(hipMemsetAsync(d_hist.p, 0, (size_t)bins.nkeys * sizeof(uint32_t), stream));
             FY_TRY(launch_bin_count(stream, b.d_rec, b.n, bins, b.key.p, b.rank.p, d_hist.p));
             FY_TRY(launch_exclusive_scan_u32(stream, d_hist.p, bins.nkeys, d_tile_sums.p));
-            FY_TRY(launch_bin_scatter(stream, b.d_rec, b.n, b.key.p, b.rank.p, d_hist.p, d_tile_sums.p, p, !fused_gather));
+            FY_TRY(launch_bin_scatter(stream, b.d_rec, b.n, b.key.p, b.rank.p, d_hist.p, d_tile_sums.p, p, false));
+            if (have_chains) FY_TRY(launch_order_blocks_by_chain(stream, b.orig.p, b.kwire.p, b.n));
+            if (!fused_gather) FY_TRY(launch_bin_gather(stream, b.d_rec, b.n, p));
+            b.ordered_by_chain = have_chains;
             b.binned_n = b.n; b.bin_age = 1;
         } else {
             if (!fused_gather) FY_TRY(launch_bin_gather(stream, b.d_rec, b.n, p));
@@ -618,6 +626,7 @@ int Coupling::run_batch(Batch& b) {
         FY_TRY(launch_locate_deposit(stream, d_tree.p, use_implicit ? d_tree_packed.p : nullptr, implicit, n_cells, tree_levels, p, b.n, gp,
                                      use_implicit ? d_loc_start.p : nullptr, slab_own(), ll, cw, d_pvol_acc.p, d_up_acc.p, d_touched.p, tbD, side,
                                      fused_gather ? b.d_rec : nullptr));
+        b.chain_n = b.n;                                   // (what the next placement's runs are ordered by)
         if (timing) marks.mark(2, stream);
         // The force pass gathers U, alpha and the Archimedes term from one packed record per cell.  U / gradP / divT do not change during the
         // call and the alpha slot follows k_finalize_cells, so the records are built once per call -- here, where the pack runs beside the

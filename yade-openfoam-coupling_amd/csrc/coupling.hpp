@@ -28,6 +28,9 @@ struct Batch {
     bool found_stale = false;            // Gaussian mode: `found` is formed lazily from the chain lengths (ensure_found)
     int64_t binned_n = -1;               // particle count the current placement (orig) was computed for
     int bin_age = 0;                     // steps since it was computed
+    DevBuf<unsigned char> kwire;         // chain length of the step before, by wire index (what the placement's runs are ordered by)
+    int64_t chain_n = -1;                // particle count chain_len holds last step's lengths for (-1: none)
+    bool ordered_by_chain = false;       // the current placement was ordered with them
     // tile buckets of the two scatters' flushes (TileBuckets): per-tile offsets / capacities / demand counters of this batch's population;
     // [0] void-fraction deposit, [1] momentum-source back-scatter.  The entry pool itself is shared (Coupling::tile_cell / tile_val).
     DevBuf<uint32_t> tb_off[2], tb_cap[2], tb_fill[2];

@@ -134,6 +134,40 @@ __global__ __launch_bounds__(256) void k_bin_scatter(int64_t n, const uint32_t* 
     orig[d] = (int32_t)i;
 }
 
+// The chain length of a particle barely changes from one coupling step to the next (at rest: not at all), and the force pass's three loops
+// over a stencil run to the LONGEST chain of a wave: with a wave's lanes holding a 0 .. 14 mix around the mean of 5.46 that is ~9.5
+// iterations, with chains of one length (two at a class boundary) ~5.6.  So when the placement is recomputed, every run of 512 slots (one
+// workgroup of the locate and of the force pass: the same particles, the same cells in reach) is put in order of the chain lengths of the
+// step before -- stable, so the cell order survives inside a class.  k_chain_by_wire files the lengths under the wire index first (the
+// placement they were computed in is about to be overwritten).  Costs two small launches per rebin_interval steps.
+__global__ __launch_bounds__(256) void k_chain_by_wire(const int32_t* __restrict__ orig, const int32_t* __restrict__ chain_len, int64_t n,
+                                                       unsigned char* __restrict__ kwire) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int c = chain_len[i];
+    kwire[orig[i]] = (unsigned char)(c < 0 ? 0 : (c > kMaxK ? kMaxK : c));
+}
+__global__ __launch_bounds__(512) void k_order_blocks_by_chain(int32_t* __restrict__ orig, const unsigned char* __restrict__ kwire, int64_t n) {
+    __shared__ uint32_t cnt[kMaxK + 1][8];                 // [class][wave]
+    const int64_t i = (int64_t)blockIdx.x * 512 + threadIdx.x;
+    const bool have = i < n;
+    const int32_t w = have ? orig[i] : 0;
+    const int k = have ? (int)kwire[w] : -1;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t rank = 0;
+    for (int c = 0; c <= kMaxK; ++c) {
+        const unsigned long long m = __ballot(k == c);
+        if (k == c) rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) cnt[c][wv] = (uint32_t)__popcll(m);
+    }
+    __syncthreads();
+    if (!have) return;
+    uint32_t before = 0;
+    for (int c = 0; c < k; ++c) for (int q = 0; q < 8; ++q) before += cnt[c][q];
+    for (int q = 0; q < wv; ++q) before += cnt[k][q];
+    orig[(int64_t)blockIdx.x * 512 + before + rank] = w;
+}
+
 __global__ __launch_bounds__(256) void k_bin_gather(const double* __restrict__ rec, int64_t n, ParticleSoA p) {
     const int64_t d = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (d >= n) return;
@@ -1417,6 +1451,20 @@ int launch_bin_scatter(hipStream_t s, const double* rec, int64_t n, const uint32
         hipLaunchKernelGGL(k_bin_gather, dim3(div_up(n, 256)), dim3(256), 0, s, rec, n, p);
         FY_LAUNCH_CHECK();
     }
+    return FY_OK;
+}
+
+int launch_chain_by_wire(hipStream_t s, const int32_t* orig, const int32_t* chain_len, int64_t n, unsigned char* kwire) {
+    if (n <= 0) return FY_OK;
+    hipLaunchKernelGGL(k_chain_by_wire, dim3(div_up(n, 256)), dim3(256), 0, s, orig, chain_len, n, kwire);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+int launch_order_blocks_by_chain(hipStream_t s, int32_t* orig, const unsigned char* kwire, int64_t n) {
+    if (n <= 0) return FY_OK;
+    static_assert(kDepThreads == 512, "the runs that are ordered are the locate's workgroups");
+    hipLaunchKernelGGL(k_order_blocks_by_chain, dim3(div_up(n, 512)), dim3(512), 0, s, orig, kwire, n);
+    FY_LAUNCH_CHECK();
     return FY_OK;
 }
 

@@ -64,6 +64,10 @@ struct ImplicitGeom {
     double ox, oy, oz, dx;
     int nx, ny, nz;
 };
+// the chain lengths of the step before, filed under the wire index (before the placement they belong to is overwritten), and the new placement's
+// runs of 512 slots put in order of them (stable): see k_order_blocks_by_chain
+int launch_chain_by_wire(hipStream_t s, const int32_t* orig, const int32_t* chain_len, int64_t n, unsigned char* kwire);
+int launch_order_blocks_by_chain(hipStream_t s, int32_t* orig, const unsigned char* kwire, int64_t n);
 // re-use the placement (p.orig) of an earlier step: only gather the records into the SoA arrays
 int launch_bin_gather(hipStream_t s, const double* rec, int64_t n, ParticleSoA p);
 // packed == nullptr selects the explicit 32-byte-node path.  Leaves chain ids and squared distances (in the weight slots).
