@@ -407,7 +407,7 @@ int Coupling::ensure_batch(Batch& b, int64_t n) {
     if (gaussian) {
         if (b.cap < cap) {
             const size_t c2 = cap + cap / 8 + 64;
-            FY_TRY(b.soa.alloc_exact(7 * c2)); FY_TRY(b.orig.alloc_exact(c2)); FY_TRY(b.chain.alloc_exact(c2));
+            FY_TRY(b.soa.alloc_exact(7 * c2)); FY_TRY(b.orig.alloc_exact(c2)); FY_TRY(b.chain.alloc_exact(c2)); FY_TRY(b.scan_class.alloc_exact(c2)); FY_HIP(hipMemset(b.scan_class.p, 0, c2));
             FY_TRY(b.ids.alloc_exact((size_t)kMaxK * c2)); FY_TRY(b.w.alloc_exact((size_t)kMaxK * c2));
             FY_TRY(b.key.alloc_exact(c2)); FY_TRY(b.rank.alloc_exact(c2));
             if (tile_flush && structured) {
@@ -436,7 +436,7 @@ ParticleSoA Coupling::soa_of(Batch& b) {
     ParticleSoA p;
     double* s = b.soa.p;
     p.px = s; p.py = s + b.cap; p.pz = s + 2 * b.cap; p.vx = s + 3 * b.cap; p.vy = s + 4 * b.cap; p.vz = s + 5 * b.cap; p.rad = s + 6 * b.cap;
-    p.orig = b.orig.p; p.chain_len = b.chain.p; p.ids = b.ids.p; p.w = b.w.p; p.cap = b.cap;
+    p.orig = b.orig.p; p.chain_len = b.chain.p; p.scan_class = b.scan_class.p; p.ids = b.ids.p; p.w = b.w.p; p.cap = b.cap;
     return p;
 }
 
@@ -594,7 +594,7 @@ int Coupling::run_batch(Batch& b) {
         if (b.binned_n != b.n || b.bin_age >= rebin_interval || (have_chains && !b.ordered_by_chain)) {
             if (have_chains) {
                 if (b.kwire.n < (size_t)b.n) FY_TRY(b.kwire.alloc_exact((size_t)b.cap));
-                FY_TRY(launch_chain_by_wire(stream, b.orig.p, b.chain.p, b.n, b.kwire.p));
+                FY_TRY(launch_chain_by_wire(stream, b.orig.p, b.chain.p, b.scan_class.p, b.n, b.kwire.p));
             }
             FY_HIP(hipMemsetAsync(d_hist.p, 0, (size_t)bins.nkeys * sizeof(uint32_t), stream));
             FY_TRY(launch_bin_count(stream, b.d_rec, b.n, bins, b.key.p, b.rank.p, d_hist.p));

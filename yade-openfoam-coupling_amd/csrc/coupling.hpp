@@ -28,6 +28,7 @@ struct Batch {
     bool found_stale = false;            // Gaussian mode: `found` is formed lazily from the chain lengths (ensure_found)
     int64_t binned_n = -1;               // particle count the current placement (orig) was computed for
     int bin_age = 0;                     // steps since it was computed
+    DevBuf<unsigned char> scan_class;    // per slot: how far the locate's list scan ran (ParticleSoA::scan_class)
     DevBuf<unsigned char> kwire;         // chain length of the step before, by wire index (what the placement's runs are ordered by)
     int64_t chain_n = -1;                // particle count chain_len holds last step's lengths for (-1: none)
     bool ordered_by_chain = false;       // the current placement was ordered with them

@@ -140,23 +140,26 @@ __global__ __launch_bounds__(256) void k_bin_scatter(int64_t n, const uint32_t* 
 // workgroup of the locate and of the force pass: the same particles, the same cells in reach) is put in order of the chain lengths of the
 // step before -- stable, so the cell order survives inside a class.  k_chain_by_wire files the lengths under the wire index first (the
 // placement they were computed in is about to be overwritten).  Costs two small launches per rebin_interval steps.
-__global__ __launch_bounds__(256) void k_chain_by_wire(const int32_t* __restrict__ orig, const int32_t* __restrict__ chain_len, int64_t n,
-                                                       unsigned char* __restrict__ kwire) {
+constexpr int kOrderClasses = 3 * (kMaxK + 1);
+__global__ __launch_bounds__(256) void k_chain_by_wire(const int32_t* __restrict__ orig, const int32_t* __restrict__ chain_len,
+                                                       const unsigned char* __restrict__ scan_class, int64_t n, unsigned char* __restrict__ kwire) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const int c = chain_len[i];
-    kwire[orig[i]] = (unsigned char)(c < 0 ? 0 : (c > kMaxK ? kMaxK : c));
+    const int k = c < 0 ? 0 : (c > kMaxK ? kMaxK : c);
+    const int sc = scan_class ? (int)scan_class[i] : 0;
+    kwire[orig[i]] = (unsigned char)(3 * k + sc);        // chain length first, then how far the list scan ran (measured: +0.5 - 1 % of the particle phase over the length alone; the other way round is no better)
 }
 constexpr int kRun = 512;      // = kDepThreads: the locate's workgroup (1024 loses 4 % of the step to locality, 256 is no better)
 __global__ __launch_bounds__(kRun) void k_order_blocks_by_chain(int32_t* __restrict__ orig, const unsigned char* __restrict__ kwire, int64_t n) {
-    __shared__ uint32_t cnt[kMaxK + 1][kRun / 64];                 // [class][wave]
+    __shared__ uint32_t cnt[kOrderClasses][kRun / 64];             // [class][wave]
     const int64_t i = (int64_t)blockIdx.x * kRun + threadIdx.x;
     const bool have = i < n;
     const int32_t w = have ? orig[i] : 0;
     const int k = have ? (int)kwire[w] : -1;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     uint32_t rank = 0;
-    for (int c = 0; c <= kMaxK; ++c) {
+    for (int c = 0; c < kOrderClasses; ++c) {
         const unsigned long long m = __ballot(k == c);
         if (k == c) rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
         if (lane == 0) cnt[c][wv] = (uint32_t)__popcll(m);
@@ -948,6 +951,7 @@ __global__ __launch_bounds__(kDepThreads) void k_locate_deposit(LocateLists ll, 
             const double fx = floor(sx), fy_ = floor(sy), fz = floor(sz);
             const double tx = sx - fx, ty = sy - fy_, tz = sz - fz;
             const double tlo = 2 * kListEps, thi = 1.0 - 2 * kListEps;
+            int sclass = 0;
             bool ok = fx >= 0 && fx < ig.nx && fy_ >= 0 && fy_ < ig.ny && fz >= 0 && fz < ig.nz &&
                       tx >= tlo && tx <= thi && ty >= tlo && ty <= thi && tz >= tlo && tz <= thi;      // (false for NaN)
             const int ci = (int)fx, cj = (int)fy_, ck = (int)fz;
@@ -966,9 +970,10 @@ __global__ __launch_bounds__(kDepThreads) void k_locate_deposit(LocateLists ll, 
                 }
                 if (ok) {
                     // the second and third chunk only where the list goes on (its last code is not the end mark)
-                    if ((v[0].w >> 16) != kListEnd) { v[1] = row[1]; if ((v[1].w >> 16) != kListEnd) v[2] = row[2]; }
+                    if ((v[0].w >> 16) != kListEnd) { v[1] = row[1]; sclass = 1; if ((v[1].w >> 16) != kListEnd) { v[2] = row[2]; sclass = 2; } }
                 }
             }
+            if (p.scan_class) p.scan_class[i] = (unsigned char)(ok ? sclass : 2);
             if (!ok) {
                 const unsigned int at = atomicAdd(fb_count, 1u);
                 fb_list[at] = (int32_t)i;
@@ -1455,9 +1460,9 @@ int launch_bin_scatter(hipStream_t s, const double* rec, int64_t n, const uint32
     return FY_OK;
 }
 
-int launch_chain_by_wire(hipStream_t s, const int32_t* orig, const int32_t* chain_len, int64_t n, unsigned char* kwire) {
+int launch_chain_by_wire(hipStream_t s, const int32_t* orig, const int32_t* chain_len, const unsigned char* scan_class, int64_t n, unsigned char* kwire) {
     if (n <= 0) return FY_OK;
-    hipLaunchKernelGGL(k_chain_by_wire, dim3(div_up(n, 256)), dim3(256), 0, s, orig, chain_len, n, kwire);
+    hipLaunchKernelGGL(k_chain_by_wire, dim3(div_up(n, 256)), dim3(256), 0, s, orig, chain_len, scan_class, n, kwire);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }

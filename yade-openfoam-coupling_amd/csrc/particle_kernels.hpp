@@ -38,6 +38,7 @@ struct ParticleSoA {
     double *px, *py, *pz, *vx, *vy, *vz, *rad;
     int32_t* orig;                 // original (wire) index
     int32_t* chain_len;            // pushes into the improvement chain (k = min(chain_len, 16))
+    unsigned char* scan_class;     // (nullable) how far the locate's list scan ran: 0 one chunk of 8 codes, 1 two, 2 three or the walk -- second ordering key of the placement's runs
     int32_t* ids;                  // [16][cap]  chain order, slot = push index & 15
     double* w;                     // [16][cap]  normalised weights, same slots
     size_t cap;                    // leading dimension
@@ -66,7 +67,7 @@ struct ImplicitGeom {
 };
 // the chain lengths of the step before, filed under the wire index (before the placement they belong to is overwritten), and the new placement's
 // runs of 512 slots put in order of them (stable): see k_order_blocks_by_chain
-int launch_chain_by_wire(hipStream_t s, const int32_t* orig, const int32_t* chain_len, int64_t n, unsigned char* kwire);
+int launch_chain_by_wire(hipStream_t s, const int32_t* orig, const int32_t* chain_len, const unsigned char* scan_class /* nullable */, int64_t n, unsigned char* kwire);
 int launch_order_blocks_by_chain(hipStream_t s, int32_t* orig, const unsigned char* kwire, int64_t n);
 // re-use the placement (p.orig) of an earlier step: only gather the records into the SoA arrays
 int launch_bin_gather(hipStream_t s, const double* rec, int64_t n, ParticleSoA p);
