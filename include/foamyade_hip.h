@@ -341,6 +341,10 @@ int fy_foam_case_initial_k(const fy_foam_case*, double* k /* [n] */);          /
 int fy_foam_case_initial_epsilon(const fy_foam_case*, double* eps /* [n] */);  /* start-time epsilon.<phase> of a kEpsilon case */
 /* runTime.write(): <case>/<time_name>/{U | U.<phase>, p [, alpha.<phase>]} as ASCII volFields with the case's own patch entries */
 int fy_foam_case_write_time(const fy_foam_case*, fy_solver*, const char* time_name);
+/* the same from host arrays over the WHOLE block (a slab run gathers its ranks' owned cells first: foamYadeHip_mpi -parallel); alpha / nut / k / epsilon
+   may be NULL where the case has no such field */
+int fy_foam_case_write_fields(const fy_foam_case*, const char* time_name, const double* U, const double* p, const double* alpha, const double* nut,
+                              const double* k, const double* epsilon);
 int fy_foam_case_close(fy_foam_case*);
 
 /* ---- kernel-level entry points used by the roofline bench and the operator parity tests ------------------ */

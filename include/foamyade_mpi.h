@@ -16,6 +16,12 @@ extern "C" {
  * they do for the reference.  Fills *out; returns FY_OK or FY_ERR_TRANSPORT. */
 int fy_mpi_transport_create(int n_yade_ranks, fy_transport* out);
 int fy_mpi_transport_destroy(fy_transport* t);
+/* the solver ranks' communicator the split produced (what OpenFOAM's -parallel run has as its world): *mpi_comm_out is an MPI_Comm */
+int fy_mpi_local_comm(const fy_transport* t, void* mpi_comm_out);
+/* a z-slab communicator (fy_solver_create_slab) over the ranks of *mpi_comm (an MPI_Comm; collective over it):
+ *   use_rccl != 0  one GPU per rank -- halos, reductions and the coarse-level gather run over RCCL / xGMI, MPI only distributes the communicator id;
+ *   use_rccl == 0  ranks that share a GPU (or no RCCL): the library stages the planes through pinned host memory and MPI moves them */
+int fy_mpi_comm_create(const void* mpi_comm, int use_rccl, int device_ordinal, fy_comm** out);
 #ifdef __cplusplus
 }
 #endif

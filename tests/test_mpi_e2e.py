@@ -80,3 +80,48 @@ def test_foamYadeHip_mpi_next_to_a_serial_yade(product, tmp_path):
     np.testing.assert_allclose(F, Fr, rtol=1e-8, atol=1e-10 * sc)
     assert sorted(d for d in os.listdir(dst) if d[0].isdigit()) == ["0", "0.001", "0.002"]
     s.close(); fc.close()
+
+
+@pytest.mark.skipif(not (os.path.exists(MPIEXEC) and os.path.exists(FAKE_YADE) and os.path.exists(RUNNER)), reason="no MPI launcher / binaries (run __graft_entry__.build())")
+@pytest.mark.parametrize("n_fluid", [2, 3])
+def test_foamYadeHip_mpi_parallel_next_to_a_serial_yade(product, tmp_path, n_fluid):
+    """the reference's `-parallel` launch (README.md:29): `mpiexec -n 1 <yade> : -n N <solver> -parallel` -- N solver PROCESSES, each with its
+    z-slab of the undecomposed case, halos / reductions / the coarse-level gather staged through the host and moved by MPI (the ranks share the
+    box's one GPU here; with a GPU per rank the same executable takes RCCL), every rank answering the serial-Yade protocol for the particles of
+    its slab; the forces Yade receives and the gathered, undecomposed time directory equal the one-rank run's"""
+    import shutil
+    case_src = os.path.join(ROOT, "tests", "golden", "cases", "bed_pimple")
+    rs = np.random.RandomState(8)
+    runs = {}
+    for tag, nf in (("one", 1), ("many", n_fluid)):
+        dst = tmp_path / tag / "bed"
+        shutil.copytree(case_src, dst)
+        fc = product.FoamCase(dst, 1)
+        c = fc.case
+        assert c.nz % (2 * n_fluid) == 0
+        if tag == "one":
+            rec = np.zeros((2500, 10))
+            rec[:, 0:2] = -0.03 + 0.06 * rs.random_sample((2500, 2)); rec[:, 2] = 0.11 * rs.random_sample(2500)       # (the cloud spans every slab)
+            rec[:, 3:6] = 0.01 * rs.standard_normal((2500, 3)); rec[:, 9] = 0.2 * c.dx
+        rec.tofile(tmp_path / tag / "records.bin")
+        nsteps = int(round((fc.end_time - fc.start_time) / fc.delta_t))
+        tlast = "%g" % fc.end_time
+        fc.close()
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        cmd = [MPIEXEC, "-n", "1", FAKE_YADE, str(tmp_path / tag / "records.bin"), "1", str(nsteps), str(tmp_path / tag / "force.bin"), ":",
+               "-n", str(nf), RUNNER, "-solver", "pimple", "-case", str(dst)] + (["-parallel", "-nYade", "1", "-hostComm"] if nf > 1 else [])
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+        assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-2000:])
+        assert out.stdout.count("End") == 1 and ("Decomposition: %d z-slabs" % nf in out.stdout) == (nf > 1)
+        (dst / "system/controlDict").write_text((dst / "system/controlDict").read_text().replace("startFrom       startTime;", "startFrom       latestTime;"))
+        fc2 = product.FoamCase(dst, 1)
+        assert fc2.start_name == tlast
+        U, p = fc2.initial_fields()
+        runs[tag] = (np.fromfile(tmp_path / tag / "force.bin").reshape(-1, 6), U, p, (dst / tlast / "alpha.water").read_text())
+        fc2.close()
+    Fo, Uo, po, ao = runs["one"]
+    Fm, Um, pm, am = runs["many"]
+    sc = np.abs(Fo).max()
+    assert sc > 0 and np.abs(Fm - Fo).max() <= 1e-6 * sc
+    assert np.abs(Um - Uo).max() <= 1e-5 * np.abs(Uo).max() and np.abs(pm - po).max() <= 1e-5 * np.abs(po).max()
+    assert np.abs(Uo).max() > 0 and "nonuniform List<scalar>" in am

@@ -854,44 +854,28 @@ int fy_foam_case_initial_epsilon(const fy_foam_case* c, double* eps) {
     return FY_OK;
 }
 
-int fy_foam_case_write_time(const fy_foam_case* c, fy_solver* s, const char* time_name) {
-    if (!c || !s || !time_name || !*time_name) return fail(FY_ERR_INVALID, "fy_foam_case_write_time: null argument");
+int fy_foam_case_write_fields(const fy_foam_case* c, const char* time_name, const double* U, const double* p, const double* alpha, const double* nut,
+                              const double* k, const double* epsilon) {
+    if (!c || !time_name || !*time_name || !U || !p) return fail(FY_ERR_INVALID, "fy_foam_case_write_fields: null argument");
     const std::string tdir = join(c->dir, time_name);
     if (mkdir(tdir.c_str(), 0777) != 0) {
         struct stat st;
         if (stat(tdir.c_str(), &st) != 0 || !S_ISDIR(st.st_mode)) return fail(FY_ERR_INVALID, "cannot create %s", tdir.c_str());
     }
     const size_t n = (size_t)c->desc.nx * c->desc.ny * c->desc.nz;
-    int64_t cnt = 0;
-    FY_TRY(fy_solver_field_count(s, "p", &cnt));
-    if ((size_t)cnt != n) return fail(FY_ERR_UNSUPPORTED, "fy_foam_case_write_time: the solver is one slab of a decomposed case; gather the slabs first");
-    std::vector<double> U(3 * n), p(n);
-    FY_TRY(fy_solver_read_field_host(s, "U", U.data()));
-    FY_TRY(fy_solver_read_field_host(s, "p", p.data()));
-    FY_TRY(write_field(c, tdir, time_name, c->u_name, "volVectorField", "[0 1 -1 0 0 0 0]", 3, U, c->u_bc_text, "        type            zeroGradient;\n"));
-    FY_TRY(write_field(c, tdir, time_name, "p", "volScalarField", "[0 2 -2 0 0 0 0]", 1, p, c->p_bc_text, "        type            zeroGradient;\n"));
-    if (c->solver == FY_SOLVER_PIMPLE) {
-        // alphac is AUTO_WRITE (pimpleFoamYade/createFields.H:139-150) and is written BEFORE setSourceZero resets it (pimpleFoamYade.C:106-108):
-        // run the solver with fy_solver_hold_sources(s, 1) to get that
-        std::vector<double> a(n);
-        FY_TRY(fy_solver_read_field_host(s, "alpha", a.data()));
-        FY_TRY(write_field(c, tdir, time_name, "alpha." + c->phase, "volScalarField", "[0 0 0 0 0 0 0]", 1, a, nullptr, "        type            zeroGradient;\n"));
-    }
-    if (c->desc.turbulence_model != FY_TURBULENCE_LAMINAR) {
-        std::vector<double> nt(n);                                           // eddyViscosity::nut_ is AUTO_WRITE
-        FY_TRY(fy_solver_read_field_host(s, "nut", nt.data()));
-        FY_TRY(write_field(c, tdir, time_name, "nut." + c->phase, "volScalarField", "[0 2 -1 0 0 0 0]", 1, nt, c->nut_bc_text, "        type            zeroGradient;\n"));
-    }
-    if (c->desc.turbulence_model == FY_TURBULENCE_KEPSILON) {
-        std::vector<double> ee(n);
-        FY_TRY(fy_solver_read_field_host(s, "epsilon", ee.data()));
-        FY_TRY(write_field(c, tdir, time_name, "epsilon." + c->phase, "volScalarField", "[0 2 -3 0 0 0 0]", 1, ee, c->eps_bc_text, "        type            zeroGradient;\n"));
-    }
-    if (c->desc.turbulence_model == FY_TURBULENCE_KEQN || c->desc.turbulence_model == FY_TURBULENCE_KEPSILON) {
-        std::vector<double> kk(n);
-        FY_TRY(fy_solver_read_field_host(s, "k", kk.data()));
-        FY_TRY(write_field(c, tdir, time_name, "k." + c->phase, "volScalarField", "[0 2 -2 0 0 0 0]", 1, kk, c->k_bc_text, "        type            zeroGradient;\n"));
-    }
+    const char* zg = "        type            zeroGradient;\n";
+    auto vec = [&](const double* src, int nc) { return std::vector<double>(src, src + n * (size_t)nc); };
+    FY_TRY(write_field(c, tdir, time_name, c->u_name, "volVectorField", "[0 1 -1 0 0 0 0]", 3, vec(U, 3), c->u_bc_text, zg));
+    FY_TRY(write_field(c, tdir, time_name, "p", "volScalarField", "[0 2 -2 0 0 0 0]", 1, vec(p, 1), c->p_bc_text, zg));
+    // alphac is AUTO_WRITE (pimpleFoamYade/createFields.H:139-150) and is written BEFORE setSourceZero resets it (pimpleFoamYade.C:106-108):
+    // run the solver with fy_solver_hold_sources(s, 1) to get that
+    if (c->solver == FY_SOLVER_PIMPLE && alpha) FY_TRY(write_field(c, tdir, time_name, "alpha." + c->phase, "volScalarField", "[0 0 0 0 0 0 0]", 1, vec(alpha, 1), nullptr, zg));
+    if (c->desc.turbulence_model != FY_TURBULENCE_LAMINAR && nut)          // eddyViscosity::nut_ is AUTO_WRITE
+        FY_TRY(write_field(c, tdir, time_name, "nut." + c->phase, "volScalarField", "[0 2 -1 0 0 0 0]", 1, vec(nut, 1), c->nut_bc_text, zg));
+    if (c->desc.turbulence_model == FY_TURBULENCE_KEPSILON && epsilon)
+        FY_TRY(write_field(c, tdir, time_name, "epsilon." + c->phase, "volScalarField", "[0 2 -3 0 0 0 0]", 1, vec(epsilon, 1), c->eps_bc_text, zg));
+    if ((c->desc.turbulence_model == FY_TURBULENCE_KEQN || c->desc.turbulence_model == FY_TURBULENCE_KEPSILON) && k)
+        FY_TRY(write_field(c, tdir, time_name, "k." + c->phase, "volScalarField", "[0 2 -2 0 0 0 0]", 1, vec(k, 1), c->k_bc_text, zg));
     if (c->purge_write > 0) {
         // purgeWrite [OF-6 Time::writeObject]: once more than N time directories have been written, the oldest of them goes
         bool known = false;
@@ -911,6 +895,23 @@ int fy_foam_case_write_time(const fy_foam_case* c, fy_solver* s, const char* tim
         }
     }
     return FY_OK;
+}
+
+int fy_foam_case_write_time(const fy_foam_case* c, fy_solver* s, const char* time_name) {
+    if (!c || !s || !time_name || !*time_name) return fail(FY_ERR_INVALID, "fy_foam_case_write_time: null argument");
+    const size_t n = (size_t)c->desc.nx * c->desc.ny * c->desc.nz;
+    int64_t cnt = 0;
+    FY_TRY(fy_solver_field_count(s, "p", &cnt));
+    if ((size_t)cnt != n) return fail(FY_ERR_UNSUPPORTED, "fy_foam_case_write_time: the solver is one slab of a decomposed case; gather the slabs and use fy_foam_case_write_fields");
+    std::vector<double> U(3 * n), p(n), a, nt, kk, ee;
+    FY_TRY(fy_solver_read_field_host(s, "U", U.data()));
+    FY_TRY(fy_solver_read_field_host(s, "p", p.data()));
+    if (c->solver == FY_SOLVER_PIMPLE) { a.resize(n); FY_TRY(fy_solver_read_field_host(s, "alpha", a.data())); }
+    if (c->desc.turbulence_model != FY_TURBULENCE_LAMINAR) { nt.resize(n); FY_TRY(fy_solver_read_field_host(s, "nut", nt.data())); }
+    if (c->desc.turbulence_model == FY_TURBULENCE_KEPSILON) { ee.resize(n); FY_TRY(fy_solver_read_field_host(s, "epsilon", ee.data())); }
+    if (c->desc.turbulence_model == FY_TURBULENCE_KEQN || c->desc.turbulence_model == FY_TURBULENCE_KEPSILON) { kk.resize(n); FY_TRY(fy_solver_read_field_host(s, "k", kk.data())); }
+    return fy_foam_case_write_fields(c, time_name, U.data(), p.data(), a.empty() ? nullptr : a.data(), nt.empty() ? nullptr : nt.data(), kk.empty() ? nullptr : kk.data(),
+                                     ee.empty() ? nullptr : ee.data());
 }
 
 int fy_foam_case_close(fy_foam_case* c) {

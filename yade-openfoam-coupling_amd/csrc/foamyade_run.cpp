@@ -2,11 +2,16 @@
 // over an OpenFOAM case directory, on the C-ABI of libfoamyade_hip.so:
 //
 //     foamYadeHip -solver ico|pimple [-case DIR] [-device N]
+//     mpiexec -n Y yade ... : -n N foamYadeHip_mpi -solver ... -case DIR -parallel [-nYade Y] [-hostComm]
 //
 // read the case (fy_foam_case_open), create the solver, then  while (runTime.loop()) { step; runTime.write(); setSourceZero }.
 // Built with -DFY_WITH_MPI (make mpi -> foamYadeHip_mpi) it is launched like the reference, MPMD next to Yade ("mpiexec -n 1 yade ... :
 // -n 1 foamYadeHip_mpi ...", README.md:29 of the reference) and talks to Yade's FoamCoupling engine through fy_mpi_transport_create;
 // without MPI it runs the fluid alone (no particles), which is what the reference does when Yade sends none.
+// -parallel: N solver ranks, the reference's `-parallel` run (README.md:29) without decomposePar -- every rank reads the undecomposed case and
+// takes its z-slab (fy_solver_create_slab), one GPU per rank over RCCL (or, with -hostComm / fewer GPUs than ranks, planes staged through the host
+// and moved by MPI); each rank receives the particles of its slab from Yade as the reference's ranks do (FoamYade.C:77-155); time directories
+// are gathered to the first solver rank and written undecomposed.
 // This file is host glue only: no arithmetic of the path lives here.
 #include <cmath>
 #include <cstdio>
@@ -29,32 +34,55 @@ static int die(const char* what) {
 
 int main(int argc, char** argv) {
     std::string dir = ".", solver_name;
-    int device = 0;
+    int device = -1, n_yade_arg = -1;
+    bool parallel = false, host_comm = false;
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
         if (a == "-case" && i + 1 < argc) dir = argv[++i];
         else if (a == "-solver" && i + 1 < argc) solver_name = argv[++i];
         else if (a == "-device" && i + 1 < argc) device = std::atoi(argv[++i]);
-        else { std::fprintf(stderr, "usage: foamYadeHip -solver ico|pimple [-case DIR] [-device N]\n"); return 2; }
+        else if (a == "-parallel") parallel = true;
+        else if (a == "-nYade" && i + 1 < argc) n_yade_arg = std::atoi(argv[++i]);
+        else if (a == "-hostComm") host_comm = true;
+        else { std::fprintf(stderr, "usage: foamYadeHip -solver ico|pimple [-case DIR] [-device N] [-parallel [-nYade Y] [-hostComm]]\n"); return 2; }
     }
     if (solver_name != "ico" && solver_name != "pimple") { std::fprintf(stderr, "foamYadeHip: -solver ico|pimple is required\n"); return 2; }
     const int solver = solver_name == "ico" ? FY_SOLVER_ICO : FY_SOLVER_PIMPLE;
 
     fy_transport tr{};
     const fy_transport* trp = nullptr;
+    fy_comm* comm = nullptr;
+    int srank = 0, ssize = 1;                       // this rank among the solver ranks
 #ifdef FY_WITH_MPI
     MPI_Init(&argc, &argv);
     int world = 1, wrank = 0;
     MPI_Comm_size(MPI_COMM_WORLD, &world);
     MPI_Comm_rank(MPI_COMM_WORLD, &wrank);
-    // Yade ranks come first in MPI_COMM_WORLD (README.md:29, FoamYade.C:28); this build runs ONE fluid rank, the rest is Yade
-    const int n_yade = world - 1;
-    if (wrank != world - 1) { std::fprintf(stderr, "foamYadeHip_mpi must be the last rank of the MPMD launch\n"); MPI_Abort(MPI_COMM_WORLD, 2); }
+    // Yade ranks come first in MPI_COMM_WORLD (README.md:29, FoamYade.C:28).  Without -parallel ONE fluid rank, the rest is Yade; with it the
+    // solver ranks are the world's last world - nYade ranks (-nYade defaults to 1: a serial Yade)
+    const int n_yade = parallel ? (n_yade_arg >= 0 ? n_yade_arg : 1) : world - 1;
+    if (n_yade < 0 || n_yade >= world || wrank < n_yade) { std::fprintf(stderr, "foamYadeHip_mpi: the solver ranks must come last in the MPMD launch (world %d, Yade ranks %d)\n", world, n_yade); MPI_Abort(MPI_COMM_WORLD, 2); }
+    MPI_Comm solver_comm = MPI_COMM_WORLD;
     if (n_yade > 0) {
         if (fy_mpi_transport_create(n_yade, &tr) != FY_OK) return die("fy_mpi_transport_create");
         trp = &tr;
+        fy_mpi_local_comm(&tr, &solver_comm);
     }
+    MPI_Comm_rank(solver_comm, &srank);
+    MPI_Comm_size(solver_comm, &ssize);
+    if (ssize > 1) {
+        const int ndev = fy_device_count();
+        if (ndev < 1) return die("no HIP device");
+        if (device < 0) device = srank % ndev;
+        const int use_rccl = (!host_comm && ndev >= ssize) ? 1 : 0;       // one GPU per rank, or the ranks share and MPI moves the planes
+        if (fy_mpi_comm_create(&solver_comm, use_rccl, device, &comm) != FY_OK) return die("fy_mpi_comm_create");
+        if (srank == 0) std::printf("Decomposition: %d z-slabs, %s\n", ssize, use_rccl ? "RCCL" : "planes staged through the host, moved by MPI");
+    }
+#else
+    if (parallel) { std::fprintf(stderr, "foamYadeHip: -parallel needs the MPI build (foamYadeHip_mpi)\n"); return 2; }
 #endif
+    if (device < 0) device = 0;
+    const bool master = srank == 0;
 
     fy_foam_case* fc = nullptr;
     if (fy_foam_case_open(dir.c_str(), solver, &fc) != FY_OK) return die("reading the case");
@@ -62,26 +90,53 @@ int main(int argc, char** argv) {
     fy_foam_case_info info;
     fy_foam_case_desc(fc, &cd);
     fy_foam_case_info_get(fc, &info);
-    std::printf("Create mesh: %d x %d x %d cells of %g m, %s on the six sides x- x+ y- y+ z- z+: %s %s %s %s %s %s\n", cd.nx, cd.ny, cd.nz, cd.dx,
-                "patches", info.patch_of_side[0], info.patch_of_side[1], info.patch_of_side[2], info.patch_of_side[3], info.patch_of_side[4], info.patch_of_side[5]);
+    if (master)
+        std::printf("Create mesh: %d x %d x %d cells of %g m, %s on the six sides x- x+ y- y+ z- z+: %s %s %s %s %s %s\n", cd.nx, cd.ny, cd.nz, cd.dx,
+                    "patches", info.patch_of_side[0], info.patch_of_side[1], info.patch_of_side[2], info.patch_of_side[3], info.patch_of_side[4], info.patch_of_side[5]);
     fy_solver* s = nullptr;
-    if (fy_solver_create(&cd, trp, device, &s) != FY_OK) return die("fy_solver_create");
+    if ((comm ? fy_solver_create_slab(&cd, trp, device, comm, &s) : fy_solver_create(&cd, trp, device, &s)) != FY_OK) return die("fy_solver_create");
+    // a slab owns the z-planes [srank nz / ssize, (srank + 1) nz / ssize): a contiguous run of the block's cells, `first` cells in
+    const size_t n_own = (size_t)fy_solver_local_cells(s), first = (size_t)srank * n_own;
     {
         std::vector<double> U(3 * (size_t)info.n_cells), p((size_t)info.n_cells);
         fy_foam_case_initial_fields(fc, U.data(), p.data());
-        if (fy_solver_write_field_host(s, "p", p.data()) != FY_OK || fy_solver_write_field_host(s, "U", U.data()) != FY_OK) return die("initial fields");
+        if (fy_solver_write_field_host(s, "p", p.data() + first) != FY_OK || fy_solver_write_field_host(s, "U", U.data() + 3 * first) != FY_OK) return die("initial fields");
         if (cd.turbulence_model != FY_TURBULENCE_LAMINAR) {              // nut.<phase> of the start time (eddyViscosity: MUST_READ)
             std::vector<double> nut((size_t)info.n_cells);
-            if (fy_foam_case_initial_nut(fc, nut.data()) != FY_OK || fy_solver_write_field_host(s, "nut", nut.data()) != FY_OK) return die("initial nut");
+            if (fy_foam_case_initial_nut(fc, nut.data()) != FY_OK || fy_solver_write_field_host(s, "nut", nut.data() + first) != FY_OK) return die("initial nut");
             if ((cd.turbulence_model == FY_TURBULENCE_KEQN || cd.turbulence_model == FY_TURBULENCE_KEPSILON) &&
-                (fy_foam_case_initial_k(fc, nut.data()) != FY_OK || fy_solver_write_field_host(s, "k", nut.data()) != FY_OK)) return die("initial k");
+                (fy_foam_case_initial_k(fc, nut.data()) != FY_OK || fy_solver_write_field_host(s, "k", nut.data() + first) != FY_OK)) return die("initial k");
             if (cd.turbulence_model == FY_TURBULENCE_KEPSILON &&
-                (fy_foam_case_initial_epsilon(fc, nut.data()) != FY_OK || fy_solver_write_field_host(s, "epsilon", nut.data()) != FY_OK)) return die("initial epsilon");
+                (fy_foam_case_initial_epsilon(fc, nut.data()) != FY_OK || fy_solver_write_field_host(s, "epsilon", nut.data() + first) != FY_OK)) return die("initial epsilon");
         }
     }
+    // runTime.write(): one rank writes its solver's fields; slabs are gathered to the first solver rank, which writes the whole block
+    auto write_time = [&](const char* tname) -> int {
+        if (!comm) return fy_foam_case_write_time(fc, s, tname);
+#ifdef FY_WITH_MPI
+        const size_t n = (size_t)info.n_cells;
+        const bool turb = cd.turbulence_model != FY_TURBULENCE_LAMINAR, has_k = cd.turbulence_model == FY_TURBULENCE_KEQN || cd.turbulence_model == FY_TURBULENCE_KEPSILON;
+        const bool has_eps = cd.turbulence_model == FY_TURBULENCE_KEPSILON, has_alpha = solver == FY_SOLVER_PIMPLE;
+        struct Fld { const char* name; int nc; bool on; std::vector<double> all; } f[6] = {{"U", 3, true, {}}, {"p", 1, true, {}}, {"alpha", 1, has_alpha, {}},
+                                                                                          {"nut", 1, turb, {}}, {"k", 1, has_k, {}}, {"epsilon", 1, has_eps, {}}};
+        std::vector<double> mine;
+        for (Fld& q : f) {
+            if (!q.on) continue;
+            mine.resize(n_own * (size_t)q.nc);
+            if (fy_solver_read_field_host(s, q.name, mine.data()) != FY_OK) return FY_ERR_INVALID;
+            if (master) q.all.resize(n * (size_t)q.nc);
+            if (MPI_Gather(mine.data(), (int)mine.size(), MPI_DOUBLE, master ? q.all.data() : nullptr, (int)mine.size(), MPI_DOUBLE, 0, solver_comm) != MPI_SUCCESS) return FY_ERR_TRANSPORT;
+        }
+        if (!master) return FY_OK;
+        auto ptr = [&](int i) { return f[i].on ? f[i].all.data() : nullptr; };
+        return fy_foam_case_write_fields(fc, tname, ptr(0), ptr(1), ptr(2), ptr(3), ptr(4), ptr(5));
+#else
+        return FY_ERR_UNSUPPORTED;
+#endif
+    };
     fy_solver_hold_sources(s, 1);                       // runTime.write() comes before setSourceZero (icoFoamYade.C:142-147)
 
-    std::printf("\nStarting time loop\n\n");
+    if (master) std::printf("\nStarting time loop\n\n");
     // runTime.loop(): fixed deltaT -> endTime / deltaT steps named start + k deltaT; adjustTimeStep (pimpleFoamYade.C:62-64) -> the time
     // advances by what setDeltaT.H chose for each step, until endTime is reached to within half a step
     const long n_steps = std::lround((info.end_time - info.start_time) / info.delta_t);
@@ -93,14 +148,17 @@ int main(int argc, char** argv) {
         t = cd.adjust_time_step ? t + st.delta_t : info.start_time + (double)k * info.delta_t;
         char tname[64];
         std::snprintf(tname, sizeof(tname), "%.12g", t);
-        std::printf("Time = %s\n\nCourant Number mean: %g max: %g\n", tname, st.courant_mean, st.courant_max);
-        std::printf("pressure: %d solves, %d iterations, initial residual %g, final residual %g\n", st.p_solves, st.p_iters_total, st.p_initial_residual, st.p_final_residual);
-        std::printf("time step continuity errors : sum local = %g, global = %g, cumulative = %g\n\n", st.cont_err_sum_local, st.cont_err_global, st.cont_err_cumulative);
+        if (master) {
+            std::printf("Time = %s\n\nCourant Number mean: %g max: %g\n", tname, st.courant_mean, st.courant_max);
+            std::printf("pressure: %d solves, %d iterations, initial residual %g, final residual %g\n", st.p_solves, st.p_iters_total, st.p_initial_residual, st.p_final_residual);
+            std::printf("time step continuity errors : sum local = %g, global = %g, cumulative = %g\n\n", st.cont_err_sum_local, st.cont_err_global, st.cont_err_cumulative);
+        }
         if (info.write_interval_steps > 0 && k % info.write_interval_steps == 0)
-            if (fy_foam_case_write_time(fc, s, tname) != FY_OK) return die("writing the time directory");
+            if (write_time(tname) != FY_OK) return die("writing the time directory");
     }
-    std::printf("End\n");
+    if (master) std::printf("End\n");
     fy_solver_destroy(s);
+    if (comm) fy_comm_destroy(comm);
     fy_foam_case_close(fc);
 #ifdef FY_WITH_MPI
     if (trp) fy_mpi_transport_destroy(&tr);

@@ -48,6 +48,57 @@ int fy_mpi_transport_create(int n_yade_ranks, fy_transport* out) {
     return FY_OK;
 }
 
+int fy_mpi_local_comm(const fy_transport* t, void* mpi_comm_out) {
+    if (!t || !t->user || !mpi_comm_out) return FY_ERR_INVALID;
+    *static_cast<MPI_Comm*>(mpi_comm_out) = static_cast<MpiState*>(t->user)->foam;
+    return FY_OK;
+}
+
+namespace {
+// fy_comm_callbacks over an MPI communicator of the solver ranks: the planes have been staged to host memory by the library
+struct CommState { MPI_Comm c; int rank, size; };
+int cb_sendrecv(void* u, const double* su, size_t nu, double* rd, size_t md, const double* sd, size_t nd, double* ru, size_t mu) {
+    CommState* st = static_cast<CommState*>(u);
+    MPI_Request rq[4];
+    int n = 0;
+    const int up = st->rank + 1, down = st->rank - 1;
+    if (md) MPI_Irecv(rd, (int)md, MPI_DOUBLE, down, 71, st->c, &rq[n++]);
+    if (mu) MPI_Irecv(ru, (int)mu, MPI_DOUBLE, up, 72, st->c, &rq[n++]);
+    if (nu) MPI_Isend(const_cast<double*>(su), (int)nu, MPI_DOUBLE, up, 71, st->c, &rq[n++]);
+    if (nd) MPI_Isend(const_cast<double*>(sd), (int)nd, MPI_DOUBLE, down, 72, st->c, &rq[n++]);
+    return MPI_Waitall(n, rq, MPI_STATUSES_IGNORE) == MPI_SUCCESS ? 0 : 1;
+}
+int cb_allreduce(void* u, double* buf, int n, int is_max) {
+    return MPI_Allreduce(MPI_IN_PLACE, buf, n, MPI_DOUBLE, is_max ? MPI_MAX : MPI_SUM, static_cast<CommState*>(u)->c) == MPI_SUCCESS ? 0 : 1;
+}
+int cb_allgather(void* u, const double* send, double* recv, size_t cnt) {
+    return MPI_Allgather(const_cast<double*>(send), (int)cnt, MPI_DOUBLE, recv, (int)cnt, MPI_DOUBLE, static_cast<CommState*>(u)->c) == MPI_SUCCESS ? 0 : 1;
+}
+}  // namespace
+
+int fy_mpi_comm_create(const void* mpi_comm, int use_rccl, int device_ordinal, fy_comm** out) {
+    if (!mpi_comm || !out) return FY_ERR_INVALID;
+    const MPI_Comm c = *static_cast<const MPI_Comm*>(mpi_comm);
+    int rank = 0, size = 1;
+    MPI_Comm_rank(c, &rank);
+    MPI_Comm_size(c, &size);
+    if (use_rccl) {
+        // one GPU per rank: the planes go over RCCL / xGMI; MPI only carries the communicator's 128-byte id
+        unsigned char id[128] = {0};
+        int rc = rank == 0 ? fy_rccl_unique_id(id) : FY_OK;
+        int ok = rc == FY_OK ? 1 : 0;
+        MPI_Bcast(&ok, 1, MPI_INT, 0, c);
+        if (!ok) return rc != FY_OK ? rc : FY_ERR_TRANSPORT;
+        MPI_Bcast(id, 128, MPI_BYTE, 0, c);
+        return fy_comm_create_rccl(rank, size, id, device_ordinal, out);
+    }
+    CommState* st = new (std::nothrow) CommState{c, rank, size};
+    if (!st) return FY_ERR_INVALID;
+    fy_comm_callbacks cb{};
+    cb.user = st; cb.sendrecv = cb_sendrecv; cb.allreduce = cb_allreduce; cb.allgather = cb_allgather;
+    return fy_comm_create_host(rank, size, &cb, out);      // (st lives as long as the process: the communicator keeps the pointer)
+}
+
 int fy_mpi_transport_destroy(fy_transport* t) {
     if (!t || !t->user) return FY_OK;
     MpiState* st = static_cast<MpiState*>(t->user);
