@@ -470,11 +470,14 @@ __global__ __launch_bounds__(256) void k_adjust_phi_apply(FvGeo g, const double*
 }
 
 // pEqn.flux() and phi = phiHbyA - pEqn.flux()[/alphacf]   (icoFoamYade.C:129, pEqn.H:39), all three directions in one cell-centred sweep
-// (three per-direction launches: 3 x 36 us at 160^3; the pressure field went through three times)
+// (three per-direction launches: 3 x 36 us at 160^3; the pressure field went through three times).
+// pimple: what is kept per face is not pEqn.flux() itself but the face term of the velocity reconstruction that follows (pEqn.H:43-45),
+// (phicForces - pEqn.flux() / alphacf) / rAUcf -- its only reader, k_U_correct, then streams ONE face field instead of four (the same
+// operations on the same operands in the same order, so the same bits; 48 B per cell and corrector less traffic)
 template <int D>
 __device__ __forceinline__ void flux_correct_face(const FvGeo& g, size_t f, int i, int j, int k, const double* __restrict__ p, const double* __restrict__ phiHbyA,
                                                   const double* __restrict__ rAUf, const double* __restrict__ alphaf, const double* __restrict__ psn,
-                                                  double* __restrict__ pflux, double* __restrict__ phi) {
+                                                  const double* __restrict__ phiForces, double* __restrict__ pflux, double* __restrict__ phi) {
     const int q = D == 0 ? i : D == 1 ? j : k;
     const double af = g.pimple ? alphaf[f] : 1.0;
     double fl = 0.0;
@@ -488,16 +491,17 @@ __device__ __forceinline__ void flux_correct_face(const FvGeo& g, size_t f, int 
         const int c = cidx(g, i, j, k);
         fl = af * rAUf[f] * geo_sfd_face(g, D, q, ndim(g, D), i, j, k) * (p[c] - p[c - stride_of(g, D)]);
     }
-    pflux[f] = fl;
-    phi[f] = phiHbyA[f] - fl / af;
+    const double fa = fl / af;
+    pflux[f] = g.pimple ? (phiForces[f] - fa) / rAUf[f] : fl;
+    phi[f] = phiHbyA[f] - fa;
 }
 __global__ __launch_bounds__(256) void k_flux_correct_cells(FvGeo g, const double* __restrict__ p, CFace3 phiHbyA, CFace3 rAUf, CFace3 alphaf, CFace3 psn,
-                                                            Face3 pflux, Face3 phi) {
+                                                            CFace3 phiForces, Face3 pflux, Face3 phi) {
     const int t = swz_block(blockIdx.x, gridDim.x) * 256 + (int)threadIdx.x;
     if (t >= g.Nc) return;
     int i, j, k; ijk_of(g, t, i, j, k);
 #define FY_CALL(D, fi, fj, fk) { const size_t f = (size_t)fid(g, D, fi, fj, fk); \
-        flux_correct_face<D>(g, f, fi, fj, fk, p, phiHbyA.a[D], rAUf.a[D], alphaf.a[D], psn.a[D], pflux.a[D], phi.a[D]); }
+        flux_correct_face<D>(g, f, fi, fj, fk, p, phiHbyA.a[D], rAUf.a[D], alphaf.a[D], psn.a[D], phiForces.a[D], pflux.a[D], phi.a[D]); }
     FY_CELL_FACES(g, i, j, k, FY_CALL);
 #undef FY_CALL
 }
@@ -1236,7 +1240,7 @@ __global__ __launch_bounds__(256) void k_U_correct(FvGeo g, const double* __rest
             } else {
                 double sm = 0;
 #pragma unroll
-                for (int s = 0; s < 2; ++s) { const int f = cface(g, d, s, i, j, k); sm += (phiForces.a[d][f] - pflux.a[d][f] / alphaf.a[d][f]) / rAUf.a[d][f]; }
+                for (int s = 0; s < 2; ++s) sm += pflux.a[d][cface(g, d, s, i, j, k)];          // (phicForces - pEqn.flux() / alphacf) / rAUcf, formed by flux_correct_face
                 out[d] = HbyA[3 * (size_t)c + d] + r * (sm / (2.0 * geo_Af(g, d, i, j, k)));
             }
             if (DIAG) {
@@ -1987,8 +1991,8 @@ int launch_assemble_pressure(hipStream_t s, FvGeo g, CFace3 phiHbyA, CFace3 rAUf
     return FY_OK;
 }
 
-int launch_flux_correct(hipStream_t s, FvGeo g, const double* p, CFace3 phiHbyA, CFace3 rAUf, CFace3 alphaf, CFace3 psn, Face3 pflux, Face3 phi) {
-    hipLaunchKernelGGL(k_flux_correct_cells, dim3(div_up(g.Nc, 256)), dim3(256), 0, s, g, p, phiHbyA, rAUf, alphaf, psn, pflux, phi);
+int launch_flux_correct(hipStream_t s, FvGeo g, const double* p, CFace3 phiHbyA, CFace3 rAUf, CFace3 alphaf, CFace3 psn, CFace3 phiForces, Face3 pflux, Face3 phi) {
+    hipLaunchKernelGGL(k_flux_correct_cells, dim3(div_up(g.Nc, 256)), dim3(256), 0, s, g, p, phiHbyA, rAUf, alphaf, psn, phiForces, pflux, phi);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }

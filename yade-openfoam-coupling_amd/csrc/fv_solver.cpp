@@ -757,7 +757,7 @@ struct Solver {
             FY_TRY(solve_pressure(final_inner && no == cs.n_non_orth_correctors));
             if (no == cs.n_non_orth_correctors) {
                 FY_TRY(halo_cells(p, 1, 1));
-                FY_TRY(FVK(launch_flux_correct, stream, g, p.p, C3(phiHbyA), C3(rAUf), C3(alphaf), C3(psn), F3(pflux), F3(phi)));
+                FY_TRY(FVK(launch_flux_correct, stream, g, p.p, C3(phiHbyA), C3(rAUf), C3(alphaf), C3(psn), C3(phiForces), F3(pflux), F3(phi)));
                 phi_fresh = true;
                 // p.relax() (pEqn.H:41): after the flux, which keeps the unrelaxed solution; the velocity correction below works with
                 // pEqn.flux() (pflux), not with grad(p), so only the carried pressure field is relaxed
