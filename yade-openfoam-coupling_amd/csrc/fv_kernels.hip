@@ -1145,6 +1145,10 @@ __global__ __launch_bounds__(256) void k_HbyA(FvGeo g, Mom7 M, const double* __r
 }
 
 // pEqn in SPD form: sum_f g_f (p_P - p_nb) [+ g_b (p_P - p_b)] = -(ddt(alpha) V + sum_out alphaf phiHbyA)   (icoFoamYade.C:118-123, pEqn.H:26-33)
+// MATRIX = false: the right-hand side alone -- the second PISO corrector (and the non-orthogonal correctors) solve with the SAME matrix
+// (rAU, alphacf have not changed), so the four coefficient arrays are neither recomputed nor rewritten and rAUf is read only where the
+// right-hand side itself needs it (fixedFluxPressure / fixedValue boundary faces, the reference cell).  Same expressions, same bits.
+template <bool MATRIX>
 __global__ __launch_bounds__(256) void k_assemble_pressure(FvGeo g, CFace3 phiHbyA, CFace3 rAUf, CFace3 alphaf, CFace3 psn,
                                                            const double* __restrict__ alpha, const double* __restrict__ alphaOld, PMat A,
                                                            double* __restrict__ rhs) {
@@ -1152,6 +1156,8 @@ __global__ __launch_bounds__(256) void k_assemble_pressure(FvGeo g, CFace3 phiHb
     if (t >= g.Nc) return;
     int i, j, k; ijk_of(g, t, i, j, k);
     const int c = t + g.c0;
+    // fvMatrix::setReference: p_ref_cell is a GLOBAL cell number (i + nx*(j + ny*kglob))
+    const bool refc = g.need_ref && (i + g.nx * (j + g.ny * (k + g.kglob0))) == g.p_ref_cell;
     double dg = 0.0, r = 0.0, up[3] = {0, 0, 0};
 #pragma unroll
     for (int d = 0; d < 3; ++d)
@@ -1159,24 +1165,22 @@ __global__ __launch_bounds__(256) void k_assemble_pressure(FvGeo g, CFace3 phiHb
         for (int s = 0; s < 2; ++s) {
             const int f = cface(g, d, s, i, j, k);
             const double af = g.pimple ? alphaf.a[d][f] : 1.0;
-            const double rf = rAUf.a[d][f];
             double ph = (s ? 1.0 : -1.0) * af * phiHbyA.a[d][f];
             const bool b = onb(g, d, s, i, j, k);
-            if (b && g.p_bc[2 * d + s] == 2) ph = (s ? 1.0 : -1.0) * af * (phiHbyA.a[d][f] - rf * geo_Af(g, d, i, j, k) * psn.a[d][f]);
+            if (b && g.p_bc[2 * d + s] == 2) ph = (s ? 1.0 : -1.0) * af * (phiHbyA.a[d][f] - rAUf.a[d][f] * geo_Af(g, d, i, j, k) * psn.a[d][f]);
             r -= ph;
             if (b) {
                 const int patch = 2 * d + s;
-                if (g.p_bc[patch] == 1) { const double gb = kBfac * af * rf * geo_sfd(g, d, s, i, j, k); dg += gb; r += gb * g.p_val[patch]; }
-            } else {
-                const double gg = af * rf * geo_sfd(g, d, s, i, j, k);
+                if (g.p_bc[patch] == 1) { const double gb = kBfac * af * rAUf.a[d][f] * geo_sfd(g, d, s, i, j, k); dg += gb; r += gb * g.p_val[patch]; }
+            } else if (MATRIX || refc) {
+                const double gg = af * rAUf.a[d][f] * geo_sfd(g, d, s, i, j, k);
                 dg += gg;
                 if (s) up[d] = gg;
             }
         }
     if (g.pimple) r -= geo_V(g, i, j, k) * (alpha[c] - alphaOld[c]) / g.dt;
-    // fvMatrix::setReference: p_ref_cell is a GLOBAL cell number (i + nx*(j + ny*kglob))
-    if (g.need_ref && (i + g.nx * (j + g.ny * (k + g.kglob0))) == g.p_ref_cell) { r += dg * g.p_ref_value; dg += dg; }
-    A.diag[c] = dg; A.ux[c] = up[0]; A.uy[c] = up[1]; A.uz[c] = up[2];
+    if (refc) { r += dg * g.p_ref_value; dg += dg; }
+    if (MATRIX) { A.diag[c] = dg; A.ux[c] = up[0]; A.uy[c] = up[1]; A.uz[c] = up[2]; }
     rhs[c] = r;
 }
 
@@ -1985,8 +1989,9 @@ int launch_rAUf_phi_forces(hipStream_t s, FvGeo g, const double* rAU, const doub
 }
 
 int launch_assemble_pressure(hipStream_t s, FvGeo g, CFace3 phiHbyA, CFace3 rAUf, CFace3 alphaf, CFace3 psn, const double* alpha,
-                             const double* alphaOld, PMat A, double* rhs) {
-    hipLaunchKernelGGL(k_assemble_pressure, dim3(div_up(g.Nc, 256)), dim3(256), 0, s, g, phiHbyA, rAUf, alphaf, psn, alpha, alphaOld, A, rhs);
+                             const double* alphaOld, PMat A, double* rhs, bool matrix) {
+    if (matrix) hipLaunchKernelGGL(k_assemble_pressure<true>, dim3(div_up(g.Nc, 256)), dim3(256), 0, s, g, phiHbyA, rAUf, alphaf, psn, alpha, alphaOld, A, rhs);
+    else hipLaunchKernelGGL(k_assemble_pressure<false>, dim3(div_up(g.Nc, 256)), dim3(256), 0, s, g, phiHbyA, rAUf, alphaf, psn, alpha, alphaOld, A, rhs);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }

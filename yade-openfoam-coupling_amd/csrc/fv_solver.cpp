@@ -750,8 +750,8 @@ struct Solver {
         MgLev& L = *mg[0];
         clk_pres.begin(stream);
         for (int no = 0; no <= cs.n_non_orth_correctors; ++no) {
-            FY_TRY(FVK(launch_assemble_pressure, stream, g, C3(phiHbyA), C3(rAUf), C3(alphaf), C3(psn), alpha.p, /* alphaOld */ alpha.p, L.A, prhs.p));
-            if (L.distributed && comm->has_down()) FY_TRY(FVK(launch_p_ghost_uz, stream, g, C3(rAUf), C3(alphaf), L.A));
+            FY_TRY(FVK(launch_assemble_pressure, stream, g, C3(phiHbyA), C3(rAUf), C3(alphaf), C3(psn), alpha.p, /* alphaOld */ alpha.p, L.A, prhs.p, rAU_new));
+            if (rAU_new && L.distributed && comm->has_down()) FY_TRY(FVK(launch_p_ghost_uz, stream, g, C3(rAUf), C3(alphaf), L.A));
             if (rAU_new) FY_TRY(build_coarse_operators());        // same matrix as in the previous corrector otherwise: only the right-hand side moved
             rAU_new = false;
             FY_TRY(solve_pressure(final_inner && no == cs.n_non_orth_correctors));
