@@ -140,10 +140,12 @@ int read_block_mesh(fy_foam_case* c) {
         if (et) for (const std::string& t : *et) if (t != "(" && t != ")") return fail(FY_ERR_UNSUPPORTED, "%s: a non-empty '%s' list is not supported (straight edges, conforming blocks)", path.c_str(), key);
     }
     const auto* bt = d.tokens("blocks");
-    if (!bt || bt->size() < 24 || (*bt)[0] != "(" || (*bt)[1] != "hex") return fail(FY_ERR_UNSUPPORTED, "%s: blocks must hold 'hex' blocks", path.c_str());
+    double lead;
+    const size_t t0 = (bt && !bt->empty() && fy::foam_tok_is_number((*bt)[0], &lead)) ? 1 : 0;      // (an optional element count before the list)
+    if (!bt || bt->size() < 24 + t0 || (*bt)[t0] != "(" || (*bt)[t0 + 1] != "hex") return fail(FY_ERR_UNSUPPORTED, "%s: blocks must hold 'hex' blocks", path.c_str());
     const std::vector<std::string>& T = *bt;
     std::vector<HexBlock> blocks;
-    size_t i = 1;
+    size_t i = t0 + 1;
     auto num = [&](double* x) { return i < T.size() && fy::foam_tok_is_number(T[i], x) ? (++i, true) : false; };
     auto tok = [&](const char* w) { return i < T.size() && T[i] == w ? (++i, true) : false; };
     double scl = 0.0;
