@@ -19,7 +19,7 @@ struct Options {
     bool explicit_tree;          // FOAMYADE_EXPLICIT_TREE=1     32-byte explicit tree nodes even on a lattice block (what a general mesh gets)
     bool no_locate_lists;        // FOAMYADE_NO_LOCATE_LISTS=1   the plain tree walk places every particle (what a general mesh gets); tests/test_locate_paths.py
     std::string tree_cache_dir;  // FOAMYADE_TREE_CACHE_DIR      ranks of one node share the k-d build through this directory ("" = off)
-    int rebin_interval;          // FOAMYADE_REBIN_INTERVAL      counting sort of the particles every this many steps (default 8; locality only)
+    int rebin_interval;          // FOAMYADE_REBIN_INTERVAL      counting sort of the particles every this many steps (default 32; locality only)
     bool no_halo_overlap;        // FOAMYADE_NO_HALO_OVERLAP=1   slab smoother: exchange, then sweep (serial schedule; identical results)
     bool no_aux_comm;            // FOAMYADE_NO_AUX_COMM=1       slab mode: no second RCCL communicator for the overlapped halo
 };

@@ -21,7 +21,7 @@ Options options() {
     q.explicit_tree = on("FOAMYADE_EXPLICIT_TREE");
     q.no_locate_lists = on("FOAMYADE_NO_LOCATE_LISTS");
     if (const char* d = getenv("FOAMYADE_TREE_CACHE_DIR")) q.tree_cache_dir = d;
-    q.rebin_interval = 8;
+    q.rebin_interval = 32;
     if (const char* e = getenv("FOAMYADE_REBIN_INTERVAL")) q.rebin_interval = std::max(1, atoi(e));
     q.no_halo_overlap = on("FOAMYADE_NO_HALO_OVERLAP");
     q.no_aux_comm = on("FOAMYADE_NO_AUX_COMM");

@@ -115,7 +115,7 @@ struct Coupling {
     DevBuf<double> d_drag_acc;                     // per-batch sum of -coeff w / rho_f per cell, folded into uSourceDrag / uSource by k_fold_sources
     DevBuf<unsigned char> d_touched;
     BinGrid bins{};
-    int rebin_interval = 8;              // full counting sort every this many steps (options().rebin_interval; 1 = every step)
+    int rebin_interval = 32;             // full counting sort every this many steps (options().rebin_interval; 1 = every step)
     DevBuf<uint32_t> d_hist, d_tile_sums;
     std::vector<Batch*> batches;
     int n_batches = 0;
