@@ -609,8 +609,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    rebuild_ms = 0.0                        # the placement is rebuilt in the first two steps (binning; then once more, ordered by the chain lengths)
     for _ in range(args.warmup):
         solver.step()
+        rebuild_ms = max(rebuild_ms, solver.coupling_timings()["bin"])
     solver.enable_kernel_timing(True)
     dxm = 0.01 if c2 else 1.0 / args.n
     phase_keys = ("particle", "locate_deposit", "force", "bin", "finalize", "fold", "momentum", "pressure", "other")
@@ -718,6 +720,10 @@ def main():
                    "parallelism": parallelism,
                    "global_cells": nc * world, "global_particles": np_global},
         "per_step_ms": per_step(acc, K),
+        "placement_rebuild": {"every_n_steps": int(os.environ.get("FOAMYADE_REBIN_INTERVAL", "32")), "ms": round(rebuild_ms, 3),
+                              "what": "the binned placement of the particles (counting sort + chain-length ordering) is rebuilt every n-th coupling step; a timed region "
+                                      "shorter than n steps may hold none: `ms` is the rebuild measured in the warm-up, ms / n its share of a step "
+                                      "(per_step_ms.bin holds what fell inside the region)"},
         "p_iters_per_step": p_iters, "u_iters_per_step": u_iters,
         "roofline": roof(dominant) if dominant else None,
         "roofline_pEqn_laplacian": roof(lap) if lap in kern else None,
