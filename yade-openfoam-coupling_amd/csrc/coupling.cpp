@@ -627,6 +627,7 @@ int Coupling::run_batch(Batch& b) {
                                      use_implicit ? d_loc_start.p : nullptr, slab_own(), ll, cw, d_pvol_acc.p, d_up_acc.p, d_touched.p, tbD, side,
                                      fused_gather ? b.d_rec : nullptr));
         b.chain_n = b.n;                                   // (what the next placement's runs are ordered by)
+        FY_TRY(run_mid_hook());                            // (the solver's field sweep: beside the side stream's walk)
         if (timing) marks.mark(2, stream);
         // The force pass gathers U, alpha and the Archimedes term from one packed record per cell.  U / gradP / divT do not change during the
         // call and the alpha slot follows k_finalize_cells, so the records are built once per call -- here, where the pack runs beside the
@@ -702,6 +703,8 @@ int Coupling::set_particle_action(double dt) {
     // the force pass gathers U, alpha and the Archimedes term from one packed record per cell; U / gradP / divT do not change during
     // the call and alpha follows k_finalize_cells, so the records are built once here
     if (fields_on_host) { FY_TRY(stage_readonly_in()); FY_TRY(stage_mutable_in()); }
+    mid_hook_done = false;
+    if (!gaussian || n_batches == 0 || fields_on_host) FY_TRY(run_mid_hook());      // (nobody further down would, or the sweep's output is needed at once)
     cellrec_fresh = cellrec_external;       // (fy_solver's pre-coupling sweep may have written the records already)
     cellrec_external = false;
 
@@ -715,6 +718,7 @@ int Coupling::set_particle_action(double dt) {
     } else {
         for (int bi = 0; bi < n_batches; ++bi) FY_TRY(run_batch(*batches[bi]));
     }
+    FY_TRY(run_mid_hook());                                                // (every batch was empty)
     if (slab.active && gaussian) FY_TRY(halo_fwd(dUSource, 3, 1));       // UcEqn.H:17-20 interpolates rAUc*uSource across the interface
 
     if (fields_on_host) FY_TRY(stage_mutable_out());

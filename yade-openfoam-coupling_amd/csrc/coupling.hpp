@@ -69,6 +69,14 @@ struct Coupling {
     int32_t n_cells = 0;
     bool gaussian = false, structured = false;
     bool has_transport = false;
+    // fy_solver's field sweep that feeds the force pass (gradP, divT, cell records) reads nothing the locate writes and vice versa: handed over as a
+    // hook, it is launched right AFTER the locate + deposit of the first batch, so that it runs while the few particles the candidate lists hand to the
+    // tree walk are walked on the side stream (a latency-bound ~90 us that otherwise sits alone between the locate and the cells' finalisation).
+    // Called at the top of set_particle_action instead when nothing would call it later (point-force mode, no batch)
+    int (*mid_hook)(void*) = nullptr;
+    void* mid_hook_user = nullptr;
+    bool mid_hook_done = true;
+    int run_mid_hook() { if (mid_hook && !mid_hook_done) { mid_hook_done = true; return mid_hook(mid_hook_user); } return 0; }
     fy_transport transport{};
     int comm_sz_diff = 0;                // FoamYade.H:74
     bool serial_yade = true;             // FoamYade.H:91

@@ -11,6 +11,7 @@
 #include <cmath>
 #include <memory>
 #include <string>
+#include <functional>
 #include <vector>
 
 #include "comm.hpp"
@@ -890,8 +891,21 @@ struct Solver {
         const bool want_vgrad = !pimple || (fm & FY_FORCE_GAUSSIAN_TORQUE), want_ddtU = pimple && (fm & FY_FORCE_ADDED_MASS);
         // single domain, Gaussian mode: the sweep also leaves the force pass's packed cell records (the coupling then skips its own pack pass)
         double* rec_out = (pimple && comm->size == 1) ? cpl->c.d_cellrec.p : nullptr;
-        FY_TRY(FVK(launch_pre_coupling, stream, g, U.p, p.p, alpha.p, C3(psn), vGrad.p, gradP.p, divT.p, nullptr, want_vgrad ? 1 : 0, 1, phi_now(),
-                                   want_ddtU ? ddtU.p : nullptr, fuse_uold ? Uold.p : nullptr, rec_out, cpl->c.nu, cpl->c.rhoF));
+        // On a single domain in Gaussian mode the sweep is handed to the coupling as a hook and launched right after the locate + deposit (which
+        // read no fluid field): it then runs beside the side stream's tree walk of the few particles the candidate lists hand over -- ~90 us of
+        // memory latency that would otherwise sit alone between the locate and the cells' finalisation (Coupling::mid_hook)
+        std::function<int()> pre_sweep = [&]() -> int {
+            return FVK(launch_pre_coupling, stream, g, U.p, p.p, alpha.p, C3(psn), vGrad.p, gradP.p, divT.p, nullptr, want_vgrad ? 1 : 0, 1, phi_now(),
+                       want_ddtU ? ddtU.p : nullptr, fuse_uold ? Uold.p : nullptr, rec_out, cpl->c.nu, cpl->c.rhoF);
+        };
+        const bool defer_sweep = comm->size == 1 && cpl->c.gaussian;
+        if (defer_sweep) {
+            cpl->c.mid_hook = [](void* u) -> int { return (*static_cast<std::function<int()>*>(u))(); };
+            cpl->c.mid_hook_user = &pre_sweep;
+        } else {
+            cpl->c.mid_hook = nullptr;
+            FY_TRY(pre_sweep());
+        }
         cpl->c.cellrec_external = rec_out != nullptr;
 
         if (timing) tim[0].start(stream);
@@ -902,7 +916,11 @@ struct Solver {
             if (want_ddtU) FY_TRY(halo_cells(ddtU, 3, g.gz));
             FY_TRY(comm->group_end(stream));
         }
-        FY_TRY(cpl->c.set_particle_action(cs.dt));                                            // icoFoamYade.C:74, pimpleFoamYade.C:78
+        {
+            const int rc = cpl->c.set_particle_action(cs.dt);                                 // icoFoamYade.C:74, pimpleFoamYade.C:78
+            cpl->c.mid_hook = nullptr; cpl->c.mid_hook_user = nullptr;                        // (pre_sweep lives in this frame only)
+            FY_TRY(rc);
+        }
         if (timing) { tim[0].stop(stream); }
 
         // alphac.oldTime() is captured lazily by OpenFOAM at alphac.correctBoundaryConditions() (pimpleFoamYade.C:83), i.e. after
