@@ -138,7 +138,7 @@ struct Coupling {
     // ---- timing
     enum { T_TOTAL = 0, T_COUNT };
     EventTimer timers[T_COUNT];
-    PhaseMarks marks;                    // 0 | bin (+ tile capacities) | 1 | k_locate_deposit | 2 | pack, reduce, finalize | 3 | k_force_gaussian | 4 | reduce, fold | 5
+    PhaseMarks marks;                    // 0 | bin (+ tile capacities) | 1 | k_locate_deposit | 2 | pack, reduce, finalize | 3 | k_force_gaussian | 4 | reduce, fold | 5;  6 | the hook (mid_hook) | 7 lies inside 2 .. 3 and is taken off it
     bool timing = false;
     fy_particle_timings tm{};
 

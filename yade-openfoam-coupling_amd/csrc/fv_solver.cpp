@@ -894,11 +894,11 @@ struct Solver {
         // On a single domain in Gaussian mode the sweep is handed to the coupling as a hook and launched right after the locate + deposit (which
         // read no fluid field): it then runs beside the side stream's tree walk of the few particles the candidate lists hand over -- ~90 us of
         // memory latency that would otherwise sit alone between the locate and the cells' finalisation (Coupling::mid_hook)
+        const bool defer_sweep = comm->size == 1 && cpl->c.gaussian;
         std::function<int()> pre_sweep = [&]() -> int {
             return FVK(launch_pre_coupling, stream, g, U.p, p.p, alpha.p, C3(psn), vGrad.p, gradP.p, divT.p, nullptr, want_vgrad ? 1 : 0, 1, phi_now(),
                        want_ddtU ? ddtU.p : nullptr, fuse_uold ? Uold.p : nullptr, rec_out, cpl->c.nu, cpl->c.rhoF);
         };
-        const bool defer_sweep = comm->size == 1 && cpl->c.gaussian;
         if (defer_sweep) {
             cpl->c.mid_hook = [](void* u) -> int { return (*static_cast<std::function<int()>*>(u))(); };
             cpl->c.mid_hook_user = &pre_sweep;
@@ -986,7 +986,7 @@ struct Solver {
         if (timing) {
             clk_mom.collect(); clk_pres.collect();
             st.ms_momentum = clk_mom.total_ms; st.ms_pressure = clk_pres.total_ms;
-            st.ms_particle = tim[0].ms();
+            st.ms_particle = tim[0].ms() - cpl->c.marks.ms(6, 7);      // (the sweep that ran as the coupling's hook is the solver's, not FoamYade's: it counts as "other")
             st.ms_total = tim[3].ms();
             st.ms_other = st.ms_total - st.ms_particle - st.ms_momentum - st.ms_pressure;
             for (auto& k : kc) k.collect();
