@@ -50,6 +50,12 @@ struct Solver {
     hipStream_t stream = nullptr;
     hipStream_t comm_stream = nullptr;     // halo exchanges that overlap interior stencil work run here (slab mode)
     hipEvent_t ev_ready = nullptr, ev_halo = nullptr;
+    // single domain: the coarse operators (k_mg_coarsen per level, the reference term, the coarsest level's Cholesky factor -- small, launch- and
+    // latency-bound kernels, ~110 us in a row) are built on comm_stream while the main stream starts the solve on level 0, which needs none of them
+    // (initial residual, pre-smoothing, restriction); the first touch of a coarse level waits for ev_coarse
+    hipEvent_t ev_assembled = nullptr, ev_coarse = nullptr;
+    bool coarse_pending = false;
+    int wait_coarse() { if (coarse_pending) { coarse_pending = false; FY_HIP(hipStreamWaitEvent(stream, ev_coarse, 0)); } return FY_OK; }
     fy_ctx* cpl = nullptr;
     bool pimple = false;
     int Nc = 0;                   // owned cells
@@ -109,6 +115,8 @@ struct Solver {
         clk_mom.destroy(); clk_pres.destroy();
         if (ev_ready) (void)hipEventDestroy(ev_ready);
         if (ev_halo) (void)hipEventDestroy(ev_halo);
+        if (ev_assembled) (void)hipEventDestroy(ev_assembled);
+        if (ev_coarse) (void)hipEventDestroy(ev_coarse);
         if (comm_stream) (void)hipStreamDestroy(comm_stream);
         if (red_host) (void)hipHostFree(red_host);
         if (red_flag) (void)hipHostFree(red_flag);
@@ -156,6 +164,8 @@ struct Solver {
         FY_HIP(hipStreamCreateWithFlags(&comm_stream, hipStreamNonBlocking));
         FY_HIP(hipEventCreateWithFlags(&ev_ready, hipEventDisableTiming));
         FY_HIP(hipEventCreateWithFlags(&ev_halo, hipEventDisableTiming));
+        FY_HIP(hipEventCreateWithFlags(&ev_assembled, hipEventDisableTiming));
+        FY_HIP(hipEventCreateWithFlags(&ev_coarse, hipEventDisableTiming));
         overlap_halos = !options().no_halo_overlap;
         comm->set_aux_stream(comm_stream);
         // ---- slab extents: the case describes the GLOBAL block; rank r owns planes [r*nz, (r+1)*nz)
@@ -578,9 +588,11 @@ struct Solver {
     int vcycle(size_t l) {
         const double w = 0.8;
         const MgWeights& W = mgw;
+        if (l >= 1) FY_TRY(wait_coarse());                        // (level 0's operator is the assembled one; everything below comes from build_coarse_operators)
         MgLev& L = *mg[l];
         if (!L.distributed && L.A.N <= kMgTailCells && mg.size() - l <= (size_t)kMgTailMax) {
             // the rest of the hierarchy fits one workgroup: one launch instead of ~8 per level (b of this level is already in place)
+            FY_TRY(wait_coarse());
             PMat A[kMgTailMax]; double* x0[kMgTailMax]; double* x1[kMgTailMax]; double* b[kMgTailMax];
             const int n = (int)(mg.size() - l);
             for (int q = 0; q < n; ++q) {
@@ -592,6 +604,7 @@ struct Solver {
             return FY_OK;
         }
         if (l + 1 == mg.size()) {
+            FY_TRY(wait_coarse());
             FY_TRY(launch_mg_coarse_solve(stream, L.A, L.bptr, L.x0.p, L.x1.p, coarse_sweeps, w, mg_inv.p));
             L.xcur = L.x0.p; L.xalt = L.x1.p;
             return FY_OK;
@@ -753,9 +766,23 @@ struct Solver {
         for (int no = 0; no <= cs.n_non_orth_correctors; ++no) {
             FY_TRY(FVK(launch_assemble_pressure, stream, g, C3(phiHbyA), C3(rAUf), C3(alphaf), C3(psn), alpha.p, /* alphaOld */ alpha.p, L.A, prhs.p, rAU_new));
             if (rAU_new && L.distributed && comm->has_down()) FY_TRY(FVK(launch_p_ghost_uz, stream, g, C3(rAUf), C3(alphaf), L.A));
-            if (rAU_new) FY_TRY(build_coarse_operators());        // same matrix as in the previous corrector otherwise: only the right-hand side moved
+            if (rAU_new) {                                        // same matrix as in the previous corrector otherwise: only the right-hand side moved
+                if (comm->size == 1 && cs.p_solver == FY_PSOLVER_PCG_MG && mg.size() > 1) {
+                    FY_HIP(hipEventRecord(ev_assembled, stream));
+                    FY_HIP(hipStreamWaitEvent(comm_stream, ev_assembled, 0));
+                    std::swap(stream, comm_stream);               // (build_coarse_operators launches on `stream`)
+                    const int rc = build_coarse_operators();
+                    std::swap(stream, comm_stream);
+                    FY_TRY(rc);
+                    FY_HIP(hipEventRecord(ev_coarse, comm_stream));
+                    coarse_pending = true;
+                } else {
+                    FY_TRY(build_coarse_operators());
+                }
+            }
             rAU_new = false;
             FY_TRY(solve_pressure(final_inner && no == cs.n_non_orth_correctors));
+            FY_TRY(wait_coarse());                                // (a solve that never left level 0)
             if (no == cs.n_non_orth_correctors) {
                 FY_TRY(halo_cells(p, 1, 1));
                 FY_TRY(FVK(launch_flux_correct, stream, g, p.p, C3(phiHbyA), C3(rAUf), C3(alphaf), C3(psn), C3(phiForces), F3(pflux), F3(phi)));
