@@ -5,8 +5,8 @@ import csv, re, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 names = [r["Kernel_Name"] for r in rows]
-# a step starts at k_courant
-starts = [i for i, n in enumerate(names) if "k_courant" in n]
+# a step starts at the particle phase's first kernel (k_tile_caps; k_courant has been folded into the velocity correction)
+starts = [i for i, n in enumerate(names) if "k_tile_caps" in n]
 which = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 a, b = starts[-which - 1], starts[-which]
 prev_end = None
