@@ -1328,9 +1328,9 @@ __global__ __launch_bounds__(256) void k_p_apply_dot(PMat A, const double* __res
 
 // r = b - A x ; slot 0 = sum|r| ; slot 1 = sum(|A x - A xbar| + |b - A xbar|)   (lduMatrix::solver::normFactor)
 __global__ __launch_bounds__(256) void k_p_init(PMat A, const double* __restrict__ b, const double* __restrict__ x, const double* __restrict__ xbar_dev,
-                                                double inv_n, double* __restrict__ r, double* __restrict__ partials) {
+                                                double xsum_val, double inv_n, double* __restrict__ r, double* __restrict__ partials) {
     double v[2] = {0, 0};
-    const double xbar = xbar_dev[0] * inv_n;
+    const double xbar = (xbar_dev ? xbar_dev[0] : xsum_val) * inv_n;      // sum(x) from the device, or the value the last update of x left with the host
     FY_RED_LOOP(t, A.N) {
         const int c = t + A.c0;
         const double Ax = p_row(A, x, c);
@@ -1363,19 +1363,21 @@ __global__ __launch_bounds__(256) void k_pcg_update_p(int n, int c0, const doubl
 
 __global__ __launch_bounds__(256) void k_pcg_update_xr(int n, int c0, double* __restrict__ x, double* __restrict__ r, const double* __restrict__ p,
                                                        const double* __restrict__ w, double* __restrict__ sc, double* __restrict__ partials) {
-    double v[1] = {0};
+    double v[2] = {0, 0};
     const double al = sc[0] / sc[2];
     // wArAold = wArA for the next iteration's beta (PCG.C): nothing in this kernel reads sc[1], and k_pcg_update_p runs after it
     if (blockIdx.x == 0 && threadIdx.x == 0) sc[1] = sc[0];
     FY_RED_LOOP(t, n) {
         const int c = t + c0;
-        x[c] += al * p[c];
+        const double xn = x[c] + al * p[c];
+        x[c] = xn;
         const double rr = r[c] - al * w[c];
         r[c] = rr;
         v[0] += fabs(rr);
+        v[1] += xn;          // sum(x): the next solve's xbar (normFactor) -- k_dot's partition and order, so k_dot's bits, without k_dot's pass
     }
-    const int mx[1] = {0};
-    block_reduce_store<1>(v, mx, partials);
+    const int mx[2] = {0, 0};
+    block_reduce_store<2>(v, mx, partials);
 }
 
 __global__ __launch_bounds__(256) void k_jacobi_precond(PMat A, const double* __restrict__ r, double* __restrict__ z) {
@@ -2034,8 +2036,8 @@ int launch_p_apply_dot(hipStream_t s, PMat A, const double* x, double* y, double
     return FY_OK;
 }
 
-int launch_p_init(hipStream_t s, PMat A, const double* b, const double* x, const double* xsum_dev, double inv_n, double* r, double* partials) {
-    hipLaunchKernelGGL(k_p_init, dim3(red_blocks(A.N)), dim3(256), 0, s, A, b, x, xsum_dev, inv_n, r, partials);
+int launch_p_init(hipStream_t s, PMat A, const double* b, const double* x, const double* xsum_dev, double xsum_val, double inv_n, double* r, double* partials) {
+    hipLaunchKernelGGL(k_p_init, dim3(red_blocks(A.N)), dim3(256), 0, s, A, b, x, xsum_dev, xsum_val, inv_n, r, partials);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }

@@ -704,17 +704,22 @@ struct Solver {
         return FY_OK;
     }
     DevBuf<double> mg_inv, mg_ref;
+    double p_sum = 0.0;            // sum(p) over all cells as the last PCG update left it (solve_pressure)
+    bool p_sum_valid = false;
 
     // OpenFOAM PCG.C with lduMatrix::solver::normFactor; preconditioner = MG V-cycle or Jacobi
     int solve_pressure(bool final_iter) {
         MgLev& L = *mg[0];
         const double tol = final_iter ? cs.p_final_tol : cs.p_tol, rel = final_iter ? cs.p_final_rel_tol : cs.p_rel_tol;
         double h[2];
-        // xbar = average(p) for lduMatrix::solver::normFactor: sum(p) over the owned cells, all-reduced, kept on the device
-        FY_TRY(launch_dot(stream, Nc, g.c0, p.p, nullptr, partials.p));
-        FY_TRY(reduce_to_device(sc.p + 3));
+        // xbar = average(p) for lduMatrix::solver::normFactor: sum(p) over the owned cells, all-reduced.  The last PCG update of p left it with the
+        // host (k_pcg_update_xr's second slot: the same partition and order as the sum below, the same bits); p_sum_valid falls when anything else writes p
+        if (!p_sum_valid) {
+            FY_TRY(launch_dot(stream, Nc, g.c0, p.p, nullptr, partials.p));
+            FY_TRY(reduce_to_device(sc.p + 3));
+        }
         FY_TRY(halo_cells(p, 1, 1));
-        FY_TRY(launch_p_init(stream, L.A, prhs.p, p.p, sc.p + 3, 1.0 / (double)Nglob, pr.p, partials.p));
+        FY_TRY(launch_p_init(stream, L.A, prhs.p, p.p, p_sum_valid ? nullptr : sc.p + 3, p_sum, 1.0 / (double)Nglob, pr.p, partials.p));
         FY_TRY(reduce_read(2, false, h));
         const double norm = h[1] + 1e-20;
         double res = h[0] / norm;
@@ -737,8 +742,9 @@ struct Solver {
                 kc[KC_P_APPLY_DOT].end(stream);
                 FY_TRY(reduce_to_device(sc.p + 2));                                                   // wApA
                 FY_TRY(launch_pcg_update_xr(stream, Nc, g.c0, p.p, pr.p, pp.p, pw.p, sc.p, partials.p));
-                FY_TRY(reduce_read(1, false, h));
+                FY_TRY(reduce_read(2, false, h));
                 res = h[0] / norm;
+                p_sum = h[1]; p_sum_valid = true;
             } while (++it < cs.p_max_iter && !converged(res));
         }
         st.p_final_residual = res;
@@ -789,7 +795,7 @@ struct Solver {
                 phi_fresh = true;
                 // p.relax() (pEqn.H:41): after the flux, which keeps the unrelaxed solution; the velocity correction below works with
                 // pEqn.flux() (pflux), not with grad(p), so only the carried pressure field is relaxed
-                if (pimple && p_relax_now > 0 && p_relax_now < 1) FY_TRY(launch_relax_field(stream, p.p, pPrev.p, p_relax_now, nstore));
+                if (pimple && p_relax_now > 0 && p_relax_now < 1) { FY_TRY(launch_relax_field(stream, p.p, pPrev.p, p_relax_now, nstore)); p_sum_valid = false; }
             }
         }
         clk_pres.end(stream);
@@ -1168,6 +1174,7 @@ int fy_solver_write_field_host(fy_solver* s, const char* name, const double* in)
     FY_HIP(hipSetDevice(s->s.device));
     FY_HIP(hipMemcpyAsync(p, in, n * sizeof(double), hipMemcpyHostToDevice, s->s.stream));
     s->s.carry_valid = false;                 // whatever was written, the carried Courant sums may no longer describe phi
+    s->s.p_sum_valid = false;
     if (std::string(name) == "U") {           // createPhi (collective when there are several slabs)
         FY_TRY(s->s.halo_cells(s->s.U, 3, 1));
         FY_TRY(fy::launch_flux_of(s->s.stream, s->s.g, s->s.U.p, s->s.F3(s->s.phi)));
@@ -1200,6 +1207,7 @@ int fy_solver_solve_p_host(fy_solver* s, const double* rhs, double* x, int* iter
     FY_HIP(hipSetDevice(S.device));
     FY_HIP(hipMemcpyAsync(S.prhs.p + S.g.c0, rhs, (size_t)S.Nc * sizeof(double), hipMemcpyHostToDevice, S.stream));
     FY_HIP(hipMemcpyAsync(S.p.p + S.g.c0, x, (size_t)S.Nc * sizeof(double), hipMemcpyHostToDevice, S.stream));
+    S.p_sum_valid = false;
     const int before = S.st.p_iters_total;
     FY_TRY(S.solve_pressure(true));
     FY_HIP(hipMemcpyAsync(x, S.p.p + S.g.c0, (size_t)S.Nc * sizeof(double), hipMemcpyDeviceToHost, S.stream));
