@@ -526,7 +526,12 @@ struct Solver {
             std::swap(xc, xn);
             ++it;
         }
-        if (xc != X.p) FY_TRY(launch_copy_f64(stream, X.p + 3 * (size_t)g.c0, xc + 3 * (size_t)g.c0, 3 * (size_t)Nc));
+        // the converged iterate may sit in the scratch buffer: the two arrays (same size, both whole-storage) trade places instead of 3 Nc doubles being
+        // copied (36 us at 160^3).  Ghost planes of the new X are whatever the scratch held: every reader across a slab face exchanges first.
+        if (xc != X.p) {
+            std::swap(X.p, xscr.p);
+            if (&X == &U && cpl) cpl->c.dU = U.p;             // (the coupling gathers U through its own pointer)
+        }
         *iters = it;
         return FY_OK;
     }
