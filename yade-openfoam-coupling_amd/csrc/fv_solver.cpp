@@ -54,6 +54,11 @@ struct Solver {
     // latency-bound kernels, ~110 us in a row) are built on comm_stream while the main stream starts the solve on level 0, which needs none of them
     // (initial residual, pre-smoothing, restriction); the first touch of a coarse level waits for ev_coarse
     hipEvent_t ev_assembled = nullptr, ev_coarse = nullptr;
+    // single domain: the component sums of U that the momentum predictor's normFactor needs (k_sum3 + fold, 35 us) are formed on comm_stream at the top
+    // of the step, beside the particle phase -- U does not change between there and the predictor -- into a partials buffer of their own
+    hipEvent_t ev_usum0 = nullptr, ev_usum1 = nullptr;
+    DevBuf<double> usum_partials;
+    bool usum_pending = false;
     bool coarse_pending = false;
     int wait_coarse() { if (coarse_pending) { coarse_pending = false; FY_HIP(hipStreamWaitEvent(stream, ev_coarse, 0)); } return FY_OK; }
     fy_ctx* cpl = nullptr;
@@ -116,6 +121,8 @@ struct Solver {
         if (ev_ready) (void)hipEventDestroy(ev_ready);
         if (ev_halo) (void)hipEventDestroy(ev_halo);
         if (ev_assembled) (void)hipEventDestroy(ev_assembled);
+        if (ev_usum0) (void)hipEventDestroy(ev_usum0);
+        if (ev_usum1) (void)hipEventDestroy(ev_usum1);
         if (ev_coarse) (void)hipEventDestroy(ev_coarse);
         if (comm_stream) (void)hipStreamDestroy(comm_stream);
         if (red_host) (void)hipHostFree(red_host);
@@ -165,6 +172,8 @@ struct Solver {
         FY_HIP(hipEventCreateWithFlags(&ev_ready, hipEventDisableTiming));
         FY_HIP(hipEventCreateWithFlags(&ev_halo, hipEventDisableTiming));
         FY_HIP(hipEventCreateWithFlags(&ev_assembled, hipEventDisableTiming));
+        FY_HIP(hipEventCreateWithFlags(&ev_usum0, hipEventDisableTiming));
+        FY_HIP(hipEventCreateWithFlags(&ev_usum1, hipEventDisableTiming));
         FY_HIP(hipEventCreateWithFlags(&ev_coarse, hipEventDisableTiming));
         overlap_halos = !options().no_halo_overlap;
         comm->set_aux_stream(comm_stream);
@@ -504,9 +513,14 @@ struct Solver {
     int solve_vec3(DevBuf<double>& X, const double* rhs, double tol, double rel_tol, int max_iter, int* iters, bool momentum = false) {
         double h[6];
         // sum(X) per component for xbar = average(X): folded (and all-reduced) on the device, divided where it is used
-        FY_TRY(launch_sum3(stream, X.p + 3 * (size_t)g.c0, Nc, partials.p));
-        FY_TRY(launch_reduce_finalize(stream, partials.p, Nc, 3, nullptr, xbar3.p));
-        FY_TRY(comm->allreduce(stream, xbar3.p, 3, false));
+        if (momentum && usum_pending) {                          // (formed beside the particle phase: step())
+            usum_pending = false;
+            FY_HIP(hipStreamWaitEvent(stream, ev_usum1, 0));
+        } else {
+            FY_TRY(launch_sum3(stream, X.p + 3 * (size_t)g.c0, Nc, partials.p));
+            FY_TRY(launch_reduce_finalize(stream, partials.p, Nc, 3, nullptr, xbar3.p));
+            FY_TRY(comm->allreduce(stream, xbar3.p, 3, false));
+        }
         double* xc = X.p; double* xn = xscr.p;
         double norm[3] = {1, 1, 1}, res0[3] = {0, 0, 0}, res[3];
         int it = 0;
@@ -953,6 +967,16 @@ struct Solver {
             if (fm & FY_FORCE_GAUSSIAN_TORQUE) FY_TRY(halo_cells(vGrad, 9, g.gz));
             if (want_ddtU) FY_TRY(halo_cells(ddtU, 3, g.gz));
             FY_TRY(comm->group_end(stream));
+        }
+        usum_pending = false;
+        if (comm->size == 1 && cs.momentum_predictor) {
+            if (!usum_partials.p) FY_TRY(usum_partials.alloc_exact(3 * (size_t)red_blocks(Nc)));
+            FY_HIP(hipEventRecord(ev_usum0, stream));
+            FY_HIP(hipStreamWaitEvent(comm_stream, ev_usum0, 0));
+            FY_TRY(launch_sum3(comm_stream, U.p + 3 * (size_t)g.c0, Nc, usum_partials.p));
+            FY_TRY(launch_reduce_finalize(comm_stream, usum_partials.p, Nc, 3, nullptr, xbar3.p));
+            FY_HIP(hipEventRecord(ev_usum1, comm_stream));
+            usum_pending = true;
         }
         {
             const int rc = cpl->c.set_particle_action(cs.dt);                                 // icoFoamYade.C:74, pimpleFoamYade.C:78
