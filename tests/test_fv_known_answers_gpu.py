@@ -218,3 +218,23 @@ def test_three_dimensional_taylor_green_vortex(product):
     np.testing.assert_allclose(U[..., 2], np.flip(np.swapaxes(U[..., 2], 1, 2), axis=2), atol=1e-8)
     assert s.stats()["cont_err_sum_local"] < 1e-8
     s.close()
+
+
+def test_rayleigh_layer_over_an_impulsively_started_plate(product):
+    """Stokes' first problem on the HIP solver, up to 512 cells across the layer and on a block graded towards the plate (shared with the oracle's test)"""
+    from test_fv_oracle import rayleigh_layer, rayleigh_case, geometric_sizes
+
+    def mk(ny, h, dt, nu, U0, solver):
+        a, kw = rayleigh_case(ny, h, dt, nu, U0, solver)
+        return product.Solver(product.make_case(*a, **kw))
+    nu, U0, T = 0.01, 1.0, 0.5
+    errs = []
+    for ny, dt in ((64, 0.005), (128, 0.00125), (256, 0.0003125), (512, 0.000078125)):
+        e, cross = rayleigh_layer(mk, np.full(ny, 1.0 / ny), nu, U0, dt, int(round(T / dt)))
+        assert cross < 1e-9
+        errs.append(e)
+    assert errs[3] < 1.5e-4 and all(2.5 < a / b < 5.0 for a, b in zip(errs, errs[1:])), errs
+    ep, cross = rayleigh_layer(mk, np.full(128, 1.0 / 128), nu, U0, 0.00125, 400, solver=1)
+    assert abs(ep - errs[1]) < 3e-4 and cross < 1e-9
+    eg, cross = rayleigh_layer(mk, geometric_sizes(48, 8.0, 1.0), nu, U0, 0.00125, 400)
+    assert eg < 1.5 * errs[1] and cross < 1e-9, (eg, errs[1])

@@ -888,3 +888,56 @@ def test_limited_schemes_between_upwind_and_central(oracle, name):
     e = np.abs(np.interp(GHIA_Y, yc, uc) - GHIA_U).max()
     assert e < 0.03, e
     s.close()
+
+
+# ---- Stokes' first problem (the impulsively started plate): a transient with a closed form that the existing patches carry ------------------
+def rayleigh_layer(make_solver, sizes_y, nu, U0, dt, steps, solver=0):
+    """The wall y = 0 starts to move at t = 0 with U0 along x under a fluid at rest: u(y, t) = U0 erfc(y / (2 sqrt(nu t))), v = w = 0, p = const
+    (exact for the full equations: the flow is parallel).  sizes_y = the cell sizes along y (uniform or graded towards the plate); the far wall
+    at y = sum(sizes_y) is zeroGradient and far enough (erfc < 1e-9 there); x and z sides zeroGradient, pressure fixed on one x side.
+    Returns (max error of u over the cells / U0, max |v| + |w|)"""
+    from math import erfc, sqrt
+    ny = len(sizes_y)
+    s = make_solver(ny, sizes_y, dt, nu, U0, solver)
+    for _ in range(steps):
+        s.step()
+    U = s.get("U").reshape(1, ny, 4, 3)
+    yc = np.cumsum(sizes_y) - 0.5 * np.asarray(sizes_y)
+    t = dt * steps
+    exact = np.array([U0 * erfc(y / (2 * sqrt(nu * t))) for y in yc])
+    err = np.abs(U[0, :, :, 0] - exact[:, None]).max() / U0
+    cross = np.abs(U[..., 1]).max() + np.abs(U[..., 2]).max()
+    s.close()
+    return err, cross
+
+
+def rayleigh_case(ny, sizes_y, dt, nu, U0, solver, mod=orc):
+    u_bc = [1, 1, 0, 1, 1, 1]
+    u_val = [(0, 0, 0)] * 6
+    u_val[2] = (U0, 0, 0)                                # YMIN: the plate
+    p_bc = [0, 1, 0, 0, 0, 0]
+    h = np.asarray(sizes_y, dtype=float)
+    uniform = np.allclose(h, h[0])
+    dx = float(h[0])
+    kw = dict(u_bc=u_bc, u_val=u_val, p_bc=p_bc, u_tol=1e-12, p_tol=1e-12, p_final_tol=1e-12, p_rel_tol=0.0)
+    if not uniform:
+        kw["grading"] = (np.full(4, dx), h, np.full(1, dx))
+    return (solver, 4, ny, 1, dx, dt, nu), kw
+
+
+def test_rayleigh_layer_over_an_impulsively_started_plate(oracle):
+    """icoFoamYade and pimpleFoamYade, uniform cells: the error of the erfc profile falls with dt and dy (first order in time: the impulsive start
+    is the worst case for implicit Euler); a block graded towards the plate (cell ratio 8) resolves the young layer with a third of the cells"""
+    nu, U0, T = 0.01, 1.0, 0.5
+    mk = lambda ny, h, dt, nu_, U0_, solver: orc.FvSolver((lambda a, kw: orc.fv_case(*a, **kw))(*rayleigh_case(ny, h, dt, nu_, U0_, solver)))
+    errs = []
+    for ny, dt in ((32, 0.02), (64, 0.005), (128, 0.00125)):
+        e, cross = rayleigh_layer(mk, np.full(ny, 1.0 / ny), nu, U0, dt, int(round(T / dt)))
+        assert cross < 1e-9
+        errs.append(e)
+    assert errs[0] < 0.02 and errs[2] < 2e-3 and 2.5 < errs[0] / errs[1] < 5.0 and 2.5 < errs[1] / errs[2] < 5.0, errs
+    ep, cross = rayleigh_layer(mk, np.full(64, 1.0 / 64), nu, U0, 0.005, 100, solver=1)
+    assert abs(ep - errs[1]) < 1e-3 and cross < 1e-9, (ep, errs[1])          # (pimpleFoamYade without particles: the same parallel flow)
+    hg = geometric_sizes(24, 8.0, 1.0)
+    eg, cross = rayleigh_layer(mk, hg, nu, U0, 0.005, 100)
+    assert eg < 1.5 * errs[1] and cross < 1e-9, (eg, errs[1])
