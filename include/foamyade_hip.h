@@ -330,8 +330,14 @@ typedef struct fy_foam_case_info {
     char phase[32];
     char start_name[32];                   /* name of the start time directory as written in controlDict */
     char patch_of_side[6][64];             /* blockMesh patch on the XMIN, XMAX, YMIN, YMAX, ZMIN, ZMAX side */
+    int64_t field_cells, field_offset;     /* cells the field files (and fy_foam_case_initial_*, fy_foam_case_write_fields) hold, global number of the first:
+                                              n_cells and 0, or one processor directory's slab (fy_foam_case_open_processor) */
 } fy_foam_case_info;
 int fy_foam_case_open(const char* case_dir, int solver /* FY_SOLVER_ICO | FY_SOLVER_PIMPLE */, fy_foam_case** out);
+/* a DECOMPOSED case (decomposePar, simple (1 1 nranks); the reference's -parallel run, README.md:29): mesh, controls and schemes from the case, the
+   field files of <case>/processor<rank> -- its z-slab's cells in the global order, the processor patches kept as read and written back --; time
+   directories go to the processor directory (reconstructPar's input).  fy_case_desc still describes the WHOLE block (fy_solver_create_slab) */
+int fy_foam_case_open_processor(const char* case_dir, int solver, int rank, int nranks, fy_foam_case** out);
 int fy_foam_case_desc(const fy_foam_case*, fy_case_desc* out);                   /* ready for fy_solver_create */
 int fy_foam_case_info_get(const fy_foam_case*, fy_foam_case_info* out);
 int fy_foam_case_initial_fields(const fy_foam_case*, double* U /* [n][3] or NULL */, double* p /* [n] or NULL */);

@@ -815,3 +815,58 @@ def test_convection_schemes_are_read_by_name(prod, tmp_path, text, scheme, k):
     fc = prod.FoamCase(dst, prod.FY_SOLVER_ICO)
     assert fc.case.convection_scheme == scheme and fc.case.convection_limiter_k == k
     fc.close()
+
+
+# ---- decomposed cases (processorN directories) ---------------------------------------------------------------------------------------------
+def decompose_case(dst, n_proc, fields=("U.water", "p")):
+    """what `decomposePar` with simpleCoeffs (1 1 n) leaves for a one-block case, as far as the field files go: processorR/<start>/<field> with the
+    R-th z-slab's cells (global order) and the processor patches next to the case's own.  Test infrastructure (no OpenFOAM here to run the tool)"""
+    import re
+    for r in range(n_proc):
+        pdir = dst / ("processor%d" % r) / "0"
+        os.makedirs(pdir)
+        for fname in os.listdir(dst / "0"):
+            text = (dst / "0" / fname).read_text()
+            m = re.search(r"internalField\s+nonuniform\s+List<(\w+)>\s+(\d+)\s*\(", text)
+            if m:
+                n = int(m.group(2)); per = n // n_proc
+                body_start = m.end()
+                body_end = text.index("\n)", body_start)
+                rows = [ln for ln in text[body_start:body_end].split("\n") if ln.strip()]
+                assert len(rows) == n
+                text = text[:m.start()] + "internalField   nonuniform List<%s> %d\n(\n" % (m.group(1), per) + "\n".join(rows[r * per:(r + 1) * per]) + text[body_end:]
+            procs = ""
+            for nb in (r - 1, r + 1):
+                if 0 <= nb < n_proc:
+                    procs += "    procBoundary%dto%d\n    {\n        type            processor;\n        value           uniform %s;\n    }\n" % (
+                        r, nb, "(0 0 0)" if "Vector" in text.split("class", 1)[1].split(";", 1)[0] else "0")
+            k = text.rindex("}")
+            (pdir / fname).write_text(text[:k] + procs + text[k:])
+
+
+def test_processor_directories_are_read_and_written(prod, tmp_path):
+    """fy_foam_case_open_processor: mesh, controls and schemes from the case, the fields of processorR (its slab's cells; uniform or a nonuniform
+    list of the slab's length), the processor patches kept and written back; a processor directory of the wrong size is refused"""
+    dst = tmp_path / "bed"
+    shutil.copytree(os.path.join(CASES, "bed_pimple"), dst)
+    whole = prod.FoamCase(dst, prod.FY_SOLVER_PIMPLE)
+    n = whole.n_cells
+    rs = np.random.RandomState(5)
+    p_all = rs.standard_normal(n)
+    ptext = (dst / "0/p").read_text()
+    import re
+    ptext = re.sub(r"internalField\s+uniform\s+[^;]+;", "internalField   nonuniform List<scalar> %d\n(\n%s\n)\n;" % (n, "\n".join(repr(float(v)) for v in p_all)), ptext)
+    (dst / "0/p").write_text(ptext)
+    decompose_case(dst, 3)
+    for r in range(3):
+        fc = prod.FoamCase(dst, prod.FY_SOLVER_PIMPLE, processor=(r, 3))
+        assert fc.n_cells == n and fc.field_cells == n // 3 and fc.field_offset == r * (n // 3)
+        assert list(fc.case.u_bc) == list(whole.case.u_bc) and fc.case.nz == whole.case.nz
+        U, p = fc.initial_fields()
+        np.testing.assert_array_equal(p, p_all[r * (n // 3):(r + 1) * (n // 3)])
+        fc.close()
+    with pytest.raises(prod.FoamYadeError, match="more than 2 parts"):
+        prod.FoamCase(dst, prod.FY_SOLVER_PIMPLE, processor=(0, 2))
+    with pytest.raises(prod.FoamYadeError, match="internalField"):
+        prod.FoamCase(dst, prod.FY_SOLVER_PIMPLE, processor=(0, 6))      # (processor3 .. 5 are missing too, but rank 0's list has the wrong length first)
+    whole.close()

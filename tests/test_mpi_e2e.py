@@ -125,3 +125,64 @@ def test_foamYadeHip_mpi_parallel_next_to_a_serial_yade(product, tmp_path, n_flu
     assert sc > 0 and np.abs(Fm - Fo).max() <= 1e-6 * sc
     assert np.abs(Um - Uo).max() <= 1e-5 * np.abs(Uo).max() and np.abs(pm - po).max() <= 1e-5 * np.abs(po).max()
     assert np.abs(Uo).max() > 0 and "nonuniform List<scalar>" in am
+
+
+@pytest.mark.skipif(not (os.path.exists(MPIEXEC) and os.path.exists(FAKE_YADE) and os.path.exists(RUNNER)), reason="no MPI launcher / binaries (run __graft_entry__.build())")
+def test_foamYadeHip_mpi_parallel_on_a_decomposed_case(product, tmp_path):
+    """the reference's workflow to the letter: decomposePar, then `mpiexec -n 1 <yade> : -n N <solver> -parallel` -- every solver rank reads the fields
+    of its processor directory and writes its time directories there (with the processor patches), nobody gathers; put together, the processors'
+    fields are the one-rank run's"""
+    import shutil
+    from test_foam_case import decompose_case
+    case_src = os.path.join(ROOT, "tests", "golden", "cases", "bed_pimple")
+    rs = np.random.RandomState(8)
+    rec = None
+    out_fields = {}
+    for tag, nf in (("one", 1), ("many", 2)):
+        dst = tmp_path / tag / "bed"
+        shutil.copytree(case_src, dst)
+        fc = product.FoamCase(dst, 1)
+        c = fc.case
+        if rec is None:
+            rec = np.zeros((2000, 10))
+            rec[:, 0:2] = -0.03 + 0.06 * rs.random_sample((2000, 2)); rec[:, 2] = 0.11 * rs.random_sample(2000)
+            rec[:, 3:6] = 0.01 * rs.standard_normal((2000, 3)); rec[:, 9] = 0.2 * c.dx
+        rec.tofile(tmp_path / tag / "records.bin")
+        nsteps = int(round((fc.end_time - fc.start_time) / fc.delta_t))
+        tlast = "%g" % fc.end_time
+        n = fc.n_cells
+        fc.close()
+        if nf > 1:
+            decompose_case(dst, nf)
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        cmd = [MPIEXEC, "-n", "1", FAKE_YADE, str(tmp_path / tag / "records.bin"), "1", str(nsteps), str(tmp_path / tag / "force.bin"), ":",
+               "-n", str(nf), RUNNER, "-solver", "pimple", "-case", str(dst)] + (["-parallel", "-nYade", "1", "-hostComm"] if nf > 1 else [])
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+        assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-2000:])
+        if nf == 1:
+            (dst / "system/controlDict").write_text((dst / "system/controlDict").read_text().replace("startFrom       startTime;", "startFrom       latestTime;"))
+            f2 = product.FoamCase(dst, 1)
+            out_fields[tag] = f2.initial_fields()
+            f2.close()
+        else:
+            assert "decomposed (processor directories)" in out.stdout
+            assert not os.path.exists(dst / tlast)                                  # nothing gathered into the case root
+            (dst / "system/controlDict").write_text((dst / "system/controlDict").read_text().replace("startFrom       startTime;", "startFrom       latestTime;"))
+            Us, ps = [], []
+            for r in range(nf):
+                text = (dst / ("processor%d" % r) / tlast / "U.water").read_text()
+                import re
+                assert re.search(r"procBoundary%dto%d\s*\{\s*type\s+processor;" % (r, 1 - r), text)
+                assert "procBoundary%dto%d" % (r, 1 - r) in (dst / ("processor%d" % r) / tlast / "alpha.water").read_text()
+                f2 = product.FoamCase(dst, 1, processor=(r, nf))
+                assert f2.start_name == tlast and f2.field_cells == n // nf
+                U, p = f2.initial_fields()
+                Us.append(U); ps.append(p)
+                f2.close()
+            out_fields[tag] = (np.vstack(Us), np.concatenate(ps))
+    Uo, po = out_fields["one"]
+    Um, pm = out_fields["many"]
+    assert np.abs(Uo).max() > 0
+    assert np.abs(Um - Uo).max() <= 1e-5 * np.abs(Uo).max() and np.abs(pm - po).max() <= 1e-5 * np.abs(po).max()
+    Fo = np.fromfile(tmp_path / "one" / "force.bin"); Fm = np.fromfile(tmp_path / "many" / "force.bin")
+    assert np.abs(Fm - Fo).max() <= 1e-6 * np.abs(Fo).max()

@@ -113,7 +113,7 @@ NUT_ZERO_GRADIENT, NUT_FIXED_VALUE = 0, 1
 class FoamCaseInfo(C.Structure):
     _fields_ = [("start_time", C.c_double), ("end_time", C.c_double), ("delta_t", C.c_double), ("write_interval_steps", C.c_int32),
                 ("n_cells", C.c_int64), ("u_name", C.c_char * 64), ("phase", C.c_char * 32), ("start_name", C.c_char * 32),
-                ("patch_of_side", (C.c_char * 64) * 6)]
+                ("patch_of_side", (C.c_char * 64) * 6), ("field_cells", C.c_int64), ("field_offset", C.c_int64)]
 
 
 class StepStats(C.Structure):
@@ -810,9 +810,13 @@ class FoamCase:
     """an OpenFOAM case directory as icoFoamYade / pimpleFoamYade would open it (fy_foam_case_*): .case is the CaseDesc for Solver(),
     .initial_fields() the start-time U and p, .write(solver, time_name) = runTime.write()"""
 
-    def __init__(self, case_dir, solver):
+    def __init__(self, case_dir, solver, processor=None):
+        """processor = (rank, nranks): the field files of <case>/processor<rank> of a decomposed case (fy_foam_case_open_processor)"""
         h = C.c_void_p()
-        _check(lib().fy_foam_case_open(str(case_dir).encode(), int(solver), C.byref(h)))
+        if processor is None:
+            _check(lib().fy_foam_case_open(str(case_dir).encode(), int(solver), C.byref(h)))
+        else:
+            _check(lib().fy_foam_case_open_processor(str(case_dir).encode(), int(solver), int(processor[0]), int(processor[1]), C.byref(h)))
         self._h = h
         self.case = CaseDesc()
         _check(lib().fy_foam_case_desc(self._h, C.byref(self.case)))
@@ -820,26 +824,27 @@ class FoamCase:
         _check(lib().fy_foam_case_info_get(self._h, C.byref(info)))
         self.start_time, self.end_time, self.delta_t = info.start_time, info.end_time, info.delta_t
         self.write_interval_steps, self.n_cells = info.write_interval_steps, info.n_cells
+        self.field_cells, self.field_offset = info.field_cells, info.field_offset
         self.u_name, self.phase, self.start_name = info.u_name.decode(), info.phase.decode(), info.start_name.decode()
         self.patch_of_side = [bytes(info.patch_of_side[s]).split(b"\0", 1)[0].decode() for s in range(6)]
 
     def initial_fields(self):
-        U = np.zeros((self.n_cells, 3)); p = np.zeros(self.n_cells)
+        U = np.zeros((self.field_cells, 3)); p = np.zeros(self.field_cells)
         _check(lib().fy_foam_case_initial_fields(self._h, _d(U), _d(p)))
         return U, p
 
     def initial_nut(self):
-        nut = np.zeros(self.n_cells)
+        nut = np.zeros(self.field_cells)
         _check(lib().fy_foam_case_initial_nut(self._h, _d(nut)))
         return nut
 
     def initial_k(self):
-        k = np.zeros(self.n_cells)
+        k = np.zeros(self.field_cells)
         _check(lib().fy_foam_case_initial_k(self._h, _d(k)))
         return k
 
     def initial_epsilon(self):
-        e = np.zeros(self.n_cells)
+        e = np.zeros(self.field_cells)
         _check(lib().fy_foam_case_initial_epsilon(self._h, _d(e)))
         return e
 

@@ -42,6 +42,12 @@ struct fy_foam_case {
     int write_precision = 17;
     int purge_write = 0;
     mutable std::vector<std::string> written;   // time directories written so far (purgeWrite's ring)
+    // A DECOMPOSED case (decomposePar, simple (1 1 N): processorR = the R-th z-slab, its cells in the global order): the field files are read
+    // from and written to <case>/processorR, hold the slab's cells only, and carry the processor patches (procBoundaryRtoS) next to the case's own
+    std::string fdir;                           // where the time directories are: dir, or dir/processorR
+    size_t fcells = 0, foffset = 0;             // cells per field file, global number of the first one
+    int proc_rank = -1, proc_count = 0;
+    std::vector<std::pair<std::string, std::string> > extra_patches[5];   // per field (U, p, nut, k, epsilon): boundaryField entries of other patches, as read
 };
 
 namespace {
@@ -322,15 +328,27 @@ int read_internal(const FoamDict& f, const std::string& path, int ncomp, size_t 
     return fail(FY_ERR_UNSUPPORTED, "%s: internalField must be 'uniform' or 'nonuniform List<...>'", path.c_str());
 }
 
+// boundaryField entries that belong to none of the six sides (a decomposed case's processor patches): kept as text, written back as they are
+void keep_extra_patches(const fy_foam_case* c, const FoamDict& bf, std::vector<std::pair<std::string, std::string> >* out) {
+    out->clear();
+    for (const std::string& name : bf.order) {
+        bool side = false;
+        for (int s = 0; s < 6; ++s) side = side || c->patch_of_side[s] == name;
+        const FoamDict* pd = bf.subdict(name);
+        if (!side && pd) out->emplace_back(name, entry_text(*pd));
+    }
+}
+
 int read_fields(fy_foam_case* c) {
-    const size_t ncell = (size_t)c->desc.nx * c->desc.ny * c->desc.nz;
+    const size_t ncell = c->fcells;
     {
-        const std::string path = join(c->dir, c->start_name + "/" + c->u_name);
+        const std::string path = join(c->fdir, c->start_name + "/" + c->u_name);
         FoamDict f;
         FY_TRY(need_file(path, &f));
         FY_TRY(read_internal(f, path, 3, ncell, &c->U0));
         const FoamDict* bf = f.subdict("boundaryField");
         if (!bf) return fail(FY_ERR_INVALID, "%s: no boundaryField", path.c_str());
+        keep_extra_patches(c, *bf, &c->extra_patches[0]);
         for (int s = 0; s < 6; ++s) {
             const FoamDict* pd = bf->subdict(c->patch_of_side[s]);
             std::string ty;
@@ -355,12 +373,13 @@ int read_fields(fy_foam_case* c) {
         }
     }
     {
-        const std::string path = join(c->dir, c->start_name + "/p");
+        const std::string path = join(c->fdir, c->start_name + "/p");
         FoamDict f;
         FY_TRY(need_file(path, &f));
         FY_TRY(read_internal(f, path, 1, ncell, &c->p0));
         const FoamDict* bf = f.subdict("boundaryField");
         if (!bf) return fail(FY_ERR_INVALID, "%s: no boundaryField", path.c_str());
+        keep_extra_patches(c, *bf, &c->extra_patches[1]);
         for (int s = 0; s < 6; ++s) {
             const FoamDict* pd = bf->subdict(c->patch_of_side[s]);
             std::string ty;
@@ -383,13 +402,14 @@ int read_fields(fy_foam_case* c) {
     if (c->desc.turbulence_model != FY_TURBULENCE_LAMINAR) {
         // nut.<phase> [OF-6 eddyViscosity: nut_ is MUST_READ, named with the velocity's group]; uniform or nonuniform, patches zeroGradient |
         // fixedValue (uniform) | calculated with a uniform value -- the latter only keeps its value, which is what fixedValue does here
-        const std::string path = join(c->dir, c->start_name + "/nut." + c->phase);
+        const std::string path = join(c->fdir, c->start_name + "/nut." + c->phase);
         FoamDict f;
         FY_TRY(need_file(path, &f));
         FY_TRY(read_internal(f, path, 1, ncell, &c->nut0));
         c->desc.nut_initial = c->nut0.empty() ? 0.0 : c->nut0[0];
         const FoamDict* bf = f.subdict("boundaryField");
         if (!bf) return fail(FY_ERR_INVALID, "%s: no boundaryField", path.c_str());
+        keep_extra_patches(c, *bf, &c->extra_patches[2]);
         for (int s = 0; s < 6; ++s) {
             const FoamDict* pd = bf->subdict(c->patch_of_side[s]);
             std::string ty;
@@ -422,13 +442,14 @@ int read_fields(fy_foam_case* c) {
     }
     if (c->desc.turbulence_model == FY_TURBULENCE_KEQN || c->desc.turbulence_model == FY_TURBULENCE_KEPSILON) {
         // k.<phase> [OF-6 kEqn / kEpsilon: k_ is MUST_READ]; patches zeroGradient | fixedValue (uniform); kqRWallFunction is a zeroGradient condition
-        const std::string path = join(c->dir, c->start_name + "/k." + c->phase);
+        const std::string path = join(c->fdir, c->start_name + "/k." + c->phase);
         FoamDict f;
         FY_TRY(need_file(path, &f));
         FY_TRY(read_internal(f, path, 1, ncell, &c->k0));
         c->desc.k_initial = c->k0.empty() ? 0.0 : c->k0[0];
         const FoamDict* bf = f.subdict("boundaryField");
         if (!bf) return fail(FY_ERR_INVALID, "%s: no boundaryField", path.c_str());
+        keep_extra_patches(c, *bf, &c->extra_patches[3]);
         for (int s = 0; s < 6; ++s) {
             const FoamDict* pd = bf->subdict(c->patch_of_side[s]);
             std::string ty;
@@ -449,13 +470,14 @@ int read_fields(fy_foam_case* c) {
     }
     if (c->desc.turbulence_model == FY_TURBULENCE_KEPSILON) {
         // epsilon.<phase> [OF-6 kEpsilon: epsilon_ is MUST_READ]; zeroGradient | fixedValue (uniform) | epsilonWallFunction
-        const std::string path = join(c->dir, c->start_name + "/epsilon." + c->phase);
+        const std::string path = join(c->fdir, c->start_name + "/epsilon." + c->phase);
         FoamDict f;
         FY_TRY(need_file(path, &f));
         FY_TRY(read_internal(f, path, 1, ncell, &c->eps0));
         c->desc.eps_initial = c->eps0.empty() ? 0.0 : c->eps0[0];
         const FoamDict* bf = f.subdict("boundaryField");
         if (!bf) return fail(FY_ERR_INVALID, "%s: no boundaryField", path.c_str());
+        keep_extra_patches(c, *bf, &c->extra_patches[4]);
         for (int s = 0; s < 6; ++s) {
             const FoamDict* pd = bf->subdict(c->patch_of_side[s]);
             std::string ty;
@@ -492,13 +514,13 @@ int read_controls(fy_foam_case* c) {
             return fail(FY_ERR_UNSUPPORTED, "%s: startFrom %s is not supported (startTime, firstTime, latestTime)", path.c_str(), from.c_str());
         if (from == "latestTime" || from == "firstTime") {
             // the time directories of the case: the entries of the case directory whose names read as numbers [OF-6 Time::findTimes]
-            DIR* dd = opendir(c->dir.c_str());
-            if (!dd) return fail(FY_ERR_INVALID, "%s: cannot list %s", path.c_str(), c->dir.c_str());
+            DIR* dd = opendir(c->fdir.c_str());
+            if (!dd) return fail(FY_ERR_INVALID, "%s: cannot list %s", path.c_str(), c->fdir.c_str());
             bool any = false;
             while (struct dirent* de = readdir(dd)) {
                 double t;
                 struct stat st;
-                if (!fy::foam_tok_is_number(de->d_name, &t) || stat(join(c->dir, de->d_name).c_str(), &st) != 0 || !S_ISDIR(st.st_mode)) continue;
+                if (!fy::foam_tok_is_number(de->d_name, &t) || stat(join(c->fdir, de->d_name).c_str(), &st) != 0 || !S_ISDIR(st.st_mode)) continue;
                 if (!any || (from == "latestTime" ? t > c->start_time : t < c->start_time)) { c->start_time = t; c->start_name = de->d_name; }
                 any = true;
             }
@@ -757,7 +779,8 @@ int read_controls(fy_foam_case* c) {
 }
 
 int write_field(const fy_foam_case* c, const std::string& tdir, const std::string& tname, const std::string& name, const char* cls, const char* dims, int ncomp,
-                const std::vector<double>& v, const std::string bc_text[6], const char* default_bc) {
+                const std::vector<double>& v, const std::string bc_text[6], const char* default_bc,
+                const std::vector<std::pair<std::string, std::string> >* extras = nullptr) {
     const std::string path = tdir + "/" + name;
     FILE* f = std::fopen(path.c_str(), "wb");
     if (!f) return fail(FY_ERR_INVALID, "cannot write %s", path.c_str());
@@ -783,6 +806,8 @@ int write_field(const fy_foam_case* c, const std::string& tdir, const std::strin
         for (int s = 0; s < 6; ++s) if (c->patch_of_side[s] == pn) side = s;
         std::fprintf(f, "    %s\n    {\n%s    }\n", pn.c_str(), (bc_text && side >= 0 && !bc_text[side].empty()) ? bc_text[side].c_str() : default_bc);
     }
+    // a decomposed case's processor patches, as the start time's file had them (fields without a start-time file: those of U, type only)
+    if (extras) for (const auto& e : *extras) std::fprintf(f, "    %s\n    {\n%s    }\n", e.first.c_str(), e.second.c_str());
     std::fprintf(f, "}\n");
     std::fclose(f);
     return FY_OK;
@@ -792,21 +817,44 @@ int write_field(const fy_foam_case* c, const std::string& tdir, const std::strin
 
 extern "C" {
 
-int fy_foam_case_open(const char* case_dir, int solver, fy_foam_case** out) {
+static int open_case(const char* case_dir, int solver, int rank, int nranks, fy_foam_case** out) {
     if (!case_dir || !out) return fail(FY_ERR_INVALID, "fy_foam_case_open: null argument");
     if (solver != FY_SOLVER_ICO && solver != FY_SOLVER_PIMPLE) return fail(FY_ERR_INVALID, "fy_foam_case_open: solver must be FY_SOLVER_ICO or FY_SOLVER_PIMPLE");
     *out = nullptr;
     fy_foam_case* c = new (std::nothrow) fy_foam_case();
     if (!c) return fail(FY_ERR_INVALID, "out of host memory");
     c->dir = case_dir;
+    c->fdir = c->dir;
     c->solver = solver;
     fy_case_defaults(&c->desc, solver);
     int rc = read_block_mesh(c);
+    if (rc == FY_OK) {
+        c->fcells = (size_t)c->desc.nx * c->desc.ny * c->desc.nz;
+        if (nranks > 0) {
+            // processorR of a decomposed case = the R-th of nranks equal z-slabs (decomposePar, simple (1 1 N)), cells in the global order
+            struct stat st;
+            const std::string pd = join(c->dir, "processor" + std::to_string(rank));
+            if (rank < 0 || rank >= nranks) rc = fail(FY_ERR_INVALID, "fy_foam_case_open_processor: rank %d of %d", rank, nranks);
+            else if (stat(pd.c_str(), &st) != 0 || !S_ISDIR(st.st_mode)) rc = fail(FY_ERR_INVALID, "%s: no such processor directory (decomposePar first, or open the undecomposed case)", pd.c_str());
+            else if (stat(join(c->dir, "processor" + std::to_string(nranks)).c_str(), &st) == 0) rc = fail(FY_ERR_INVALID, "%s is decomposed into more than %d parts", c->dir.c_str(), nranks);
+            else if (c->desc.nz % nranks != 0) rc = fail(FY_ERR_UNSUPPORTED, "%s: %d planes do not split into %d equal z-slabs", c->dir.c_str(), c->desc.nz, nranks);
+            else {
+                c->fdir = pd; c->proc_rank = rank; c->proc_count = nranks;
+                c->fcells /= (size_t)nranks; c->foffset = c->fcells * (size_t)rank;
+            }
+        }
+    }
     if (rc == FY_OK) rc = read_controls(c);
     if (rc == FY_OK) rc = read_fields(c);
     if (rc != FY_OK) { delete c; return rc; }
     *out = c;
     return FY_OK;
+}
+
+int fy_foam_case_open(const char* case_dir, int solver, fy_foam_case** out) { return open_case(case_dir, solver, 0, 0, out); }
+int fy_foam_case_open_processor(const char* case_dir, int solver, int rank, int nranks, fy_foam_case** out) {
+    if (nranks < 1) return fail(FY_ERR_INVALID, "fy_foam_case_open_processor: nranks must be positive");
+    return open_case(case_dir, solver, rank, nranks, out);
 }
 
 int fy_foam_case_desc(const fy_foam_case* c, fy_case_desc* out) {
@@ -821,6 +869,7 @@ int fy_foam_case_info_get(const fy_foam_case* c, fy_foam_case_info* out) {
     out->start_time = c->start_time; out->end_time = c->end_time; out->delta_t = c->desc.dt;
     out->write_interval_steps = c->write_interval_steps;
     out->n_cells = (int64_t)c->desc.nx * c->desc.ny * c->desc.nz;
+    out->field_cells = (int64_t)c->fcells; out->field_offset = (int64_t)c->foffset;
     std::snprintf(out->u_name, sizeof(out->u_name), "%s", c->u_name.c_str());
     std::snprintf(out->phase, sizeof(out->phase), "%s", c->phase.c_str());
     std::snprintf(out->start_name, sizeof(out->start_name), "%s", c->start_name.c_str());
@@ -859,32 +908,39 @@ int fy_foam_case_initial_epsilon(const fy_foam_case* c, double* eps) {
 int fy_foam_case_write_fields(const fy_foam_case* c, const char* time_name, const double* U, const double* p, const double* alpha, const double* nut,
                               const double* k, const double* epsilon) {
     if (!c || !time_name || !*time_name || !U || !p) return fail(FY_ERR_INVALID, "fy_foam_case_write_fields: null argument");
-    const std::string tdir = join(c->dir, time_name);
+    const std::string tdir = join(c->fdir, time_name);
     if (mkdir(tdir.c_str(), 0777) != 0) {
         struct stat st;
         if (stat(tdir.c_str(), &st) != 0 || !S_ISDIR(st.st_mode)) return fail(FY_ERR_INVALID, "cannot create %s", tdir.c_str());
     }
-    const size_t n = (size_t)c->desc.nx * c->desc.ny * c->desc.nz;
+    const size_t n = c->fcells;
+    // (a field the start time had no file for -- alpha -- takes the processor patches of U with their type alone)
+    std::vector<std::pair<std::string, std::string> > bare;
+    for (const auto& e : c->extra_patches[0]) {
+        const size_t a = e.second.find("type");
+        const size_t b = a == std::string::npos ? a : e.second.find('\n', a);
+        bare.emplace_back(e.first, a == std::string::npos ? e.second : e.second.substr(0, b + 1));
+    }
     const char* zg = "        type            zeroGradient;\n";
     auto vec = [&](const double* src, int nc) { return std::vector<double>(src, src + n * (size_t)nc); };
-    FY_TRY(write_field(c, tdir, time_name, c->u_name, "volVectorField", "[0 1 -1 0 0 0 0]", 3, vec(U, 3), c->u_bc_text, zg));
-    FY_TRY(write_field(c, tdir, time_name, "p", "volScalarField", "[0 2 -2 0 0 0 0]", 1, vec(p, 1), c->p_bc_text, zg));
+    FY_TRY(write_field(c, tdir, time_name, c->u_name, "volVectorField", "[0 1 -1 0 0 0 0]", 3, vec(U, 3), c->u_bc_text, zg, &c->extra_patches[0]));
+    FY_TRY(write_field(c, tdir, time_name, "p", "volScalarField", "[0 2 -2 0 0 0 0]", 1, vec(p, 1), c->p_bc_text, zg, &c->extra_patches[1]));
     // alphac is AUTO_WRITE (pimpleFoamYade/createFields.H:139-150) and is written BEFORE setSourceZero resets it (pimpleFoamYade.C:106-108):
     // run the solver with fy_solver_hold_sources(s, 1) to get that
-    if (c->solver == FY_SOLVER_PIMPLE && alpha) FY_TRY(write_field(c, tdir, time_name, "alpha." + c->phase, "volScalarField", "[0 0 0 0 0 0 0]", 1, vec(alpha, 1), nullptr, zg));
+    if (c->solver == FY_SOLVER_PIMPLE && alpha) FY_TRY(write_field(c, tdir, time_name, "alpha." + c->phase, "volScalarField", "[0 0 0 0 0 0 0]", 1, vec(alpha, 1), nullptr, zg, &bare));
     if (c->desc.turbulence_model != FY_TURBULENCE_LAMINAR && nut)          // eddyViscosity::nut_ is AUTO_WRITE
-        FY_TRY(write_field(c, tdir, time_name, "nut." + c->phase, "volScalarField", "[0 2 -1 0 0 0 0]", 1, vec(nut, 1), c->nut_bc_text, zg));
+        FY_TRY(write_field(c, tdir, time_name, "nut." + c->phase, "volScalarField", "[0 2 -1 0 0 0 0]", 1, vec(nut, 1), c->nut_bc_text, zg, &c->extra_patches[2]));
     if (c->desc.turbulence_model == FY_TURBULENCE_KEPSILON && epsilon)
-        FY_TRY(write_field(c, tdir, time_name, "epsilon." + c->phase, "volScalarField", "[0 2 -3 0 0 0 0]", 1, vec(epsilon, 1), c->eps_bc_text, zg));
+        FY_TRY(write_field(c, tdir, time_name, "epsilon." + c->phase, "volScalarField", "[0 2 -3 0 0 0 0]", 1, vec(epsilon, 1), c->eps_bc_text, zg, &c->extra_patches[4]));
     if ((c->desc.turbulence_model == FY_TURBULENCE_KEQN || c->desc.turbulence_model == FY_TURBULENCE_KEPSILON) && k)
-        FY_TRY(write_field(c, tdir, time_name, "k." + c->phase, "volScalarField", "[0 2 -2 0 0 0 0]", 1, vec(k, 1), c->k_bc_text, zg));
+        FY_TRY(write_field(c, tdir, time_name, "k." + c->phase, "volScalarField", "[0 2 -2 0 0 0 0]", 1, vec(k, 1), c->k_bc_text, zg, &c->extra_patches[3]));
     if (c->purge_write > 0) {
         // purgeWrite [OF-6 Time::writeObject]: once more than N time directories have been written, the oldest of them goes
         bool known = false;
         for (const std::string& w : c->written) known = known || w == time_name;
         if (!known) c->written.push_back(time_name);
         while ((int)c->written.size() > c->purge_write) {
-            const std::string old = join(c->dir, c->written.front());
+            const std::string old = join(c->fdir, c->written.front());
             c->written.erase(c->written.begin());
             if (DIR* dd = opendir(old.c_str())) {
                 while (struct dirent* de = readdir(dd)) {
@@ -901,10 +957,10 @@ int fy_foam_case_write_fields(const fy_foam_case* c, const char* time_name, cons
 
 int fy_foam_case_write_time(const fy_foam_case* c, fy_solver* s, const char* time_name) {
     if (!c || !s || !time_name || !*time_name) return fail(FY_ERR_INVALID, "fy_foam_case_write_time: null argument");
-    const size_t n = (size_t)c->desc.nx * c->desc.ny * c->desc.nz;
+    const size_t n = c->fcells;
     int64_t cnt = 0;
     FY_TRY(fy_solver_field_count(s, "p", &cnt));
-    if ((size_t)cnt != n) return fail(FY_ERR_UNSUPPORTED, "fy_foam_case_write_time: the solver is one slab of a decomposed case; gather the slabs and use fy_foam_case_write_fields");
+    if ((size_t)cnt != n) return fail(FY_ERR_UNSUPPORTED, "fy_foam_case_write_time: the solver holds %lld cells, the case's field files %zu (a slab of an undecomposed case: gather the slabs and use fy_foam_case_write_fields)", (long long)cnt, n);
     std::vector<double> U(3 * n), p(n), a, nt, kk, ee;
     FY_TRY(fy_solver_read_field_host(s, "U", U.data()));
     FY_TRY(fy_solver_read_field_host(s, "p", p.data()));

@@ -13,6 +13,8 @@
 // and moved by MPI); each rank receives the particles of its slab from Yade as the reference's ranks do (FoamYade.C:77-155); time directories
 // are gathered to the first solver rank and written undecomposed.
 // This file is host glue only: no arithmetic of the path lives here.
+#include <sys/stat.h>
+
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -84,8 +86,13 @@ int main(int argc, char** argv) {
     if (device < 0) device = 0;
     const bool master = srank == 0;
 
+    // -parallel on a DECOMPOSED case (<case>/processor0 exists: decomposePar, simple (1 1 N)): every rank reads and writes the field files of its own
+    // processor directory, as the reference's ranks do; otherwise every rank reads the undecomposed case and the first solver rank writes it
     fy_foam_case* fc = nullptr;
-    if (fy_foam_case_open(dir.c_str(), solver, &fc) != FY_OK) return die("reading the case");
+    bool decomposed = false;
+    if (ssize > 1) { struct stat sb; decomposed = stat((dir + "/processor0").c_str(), &sb) == 0 && S_ISDIR(sb.st_mode); }
+    if ((decomposed ? fy_foam_case_open_processor(dir.c_str(), solver, srank, ssize, &fc) : fy_foam_case_open(dir.c_str(), solver, &fc)) != FY_OK) return die("reading the case");
+    if (master && ssize > 1) std::printf("Case: %s\n", decomposed ? "decomposed (processor directories)" : "undecomposed (gathered on write)");
     fy_case_desc cd;
     fy_foam_case_info info;
     fy_foam_case_desc(fc, &cd);
@@ -96,13 +103,15 @@ int main(int argc, char** argv) {
     fy_solver* s = nullptr;
     if ((comm ? fy_solver_create_slab(&cd, trp, device, comm, &s) : fy_solver_create(&cd, trp, device, &s)) != FY_OK) return die("fy_solver_create");
     // a slab owns the z-planes [srank nz / ssize, (srank + 1) nz / ssize): a contiguous run of the block's cells, `first` cells in
-    const size_t n_own = (size_t)fy_solver_local_cells(s), first = (size_t)srank * n_own;
+    // (the field files hold the whole block, or -- processor directories -- exactly this rank's cells)
+    const size_t n_own = (size_t)fy_solver_local_cells(s), first = info.field_cells == (int64_t)n_own ? 0 : (size_t)srank * n_own;
+    if (decomposed && info.field_cells != (int64_t)n_own) return die("the processor directory does not hold this rank's slab");
     {
-        std::vector<double> U(3 * (size_t)info.n_cells), p((size_t)info.n_cells);
+        std::vector<double> U(3 * (size_t)info.field_cells), p((size_t)info.field_cells);
         fy_foam_case_initial_fields(fc, U.data(), p.data());
         if (fy_solver_write_field_host(s, "p", p.data() + first) != FY_OK || fy_solver_write_field_host(s, "U", U.data() + 3 * first) != FY_OK) return die("initial fields");
         if (cd.turbulence_model != FY_TURBULENCE_LAMINAR) {              // nut.<phase> of the start time (eddyViscosity: MUST_READ)
-            std::vector<double> nut((size_t)info.n_cells);
+            std::vector<double> nut((size_t)info.field_cells);
             if (fy_foam_case_initial_nut(fc, nut.data()) != FY_OK || fy_solver_write_field_host(s, "nut", nut.data() + first) != FY_OK) return die("initial nut");
             if ((cd.turbulence_model == FY_TURBULENCE_KEQN || cd.turbulence_model == FY_TURBULENCE_KEPSILON) &&
                 (fy_foam_case_initial_k(fc, nut.data()) != FY_OK || fy_solver_write_field_host(s, "k", nut.data() + first) != FY_OK)) return die("initial k");
@@ -112,7 +121,7 @@ int main(int argc, char** argv) {
     }
     // runTime.write(): one rank writes its solver's fields; slabs are gathered to the first solver rank, which writes the whole block
     auto write_time = [&](const char* tname) -> int {
-        if (!comm) return fy_foam_case_write_time(fc, s, tname);
+        if (!comm || decomposed) return fy_foam_case_write_time(fc, s, tname);       // one domain, or every rank into its own processor directory
 #ifdef FY_WITH_MPI
         const size_t n = (size_t)info.n_cells;
         const bool turb = cd.turbulence_model != FY_TURBULENCE_LAMINAR, has_k = cd.turbulence_model == FY_TURBULENCE_KEQN || cd.turbulence_model == FY_TURBULENCE_KEPSILON;
