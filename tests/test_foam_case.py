@@ -870,3 +870,141 @@ def test_processor_directories_are_read_and_written(prod, tmp_path):
     with pytest.raises(prod.FoamYadeError, match="internalField"):
         prod.FoamCase(dst, prod.FY_SOLVER_PIMPLE, processor=(0, 6))      # (processor3 .. 5 are missing too, but rank 0's list has the wrong length first)
     whole.close()
+
+
+# ---- constant/polyMesh (what the reference's solvers read; written here the way blockMesh numbers things) --------------------------------------
+def write_poly_mesh(dst, xs, ys, zs, patches, split_x=None):
+    """points / faces / owner / neighbour / boundary of a rectilinear box with node coordinates xs, ys, zs.  patches = [(name, type, [sides])], sides
+    0..5 = x- x+ y- y+ z- z+.  split_x = m: the cells are numbered as blockMesh numbers TWO blocks joined at x index m (block by block), otherwise as
+    one block (i fastest).  Test infrastructure: there is no blockMesh here to write the files"""
+    nx, ny, nz = len(xs) - 1, len(ys) - 1, len(zs) - 1
+    pid = lambda i, j, k: i + (nx + 1) * (j + (ny + 1) * k)
+
+    def cid(i, j, k):
+        if split_x is None:
+            return i + nx * (j + ny * k)
+        m = split_x
+        return i + m * (j + ny * k) if i < m else m * ny * nz + (i - m) + (nx - m) * (j + ny * k)
+    quad = {0: lambda i, j, k: (pid(i, j, k), pid(i, j, k + 1), pid(i, j + 1, k + 1), pid(i, j + 1, k)),
+            1: lambda i, j, k: (pid(i, j, k), pid(i + 1, j, k), pid(i + 1, j, k + 1), pid(i, j, k + 1)),
+            2: lambda i, j, k: (pid(i, j, k), pid(i, j + 1, k), pid(i + 1, j + 1, k), pid(i + 1, j, k))}
+    internal = []
+    for k in range(nz):
+        for j in range(ny):
+            for i in range(nx):
+                c = cid(i, j, k)
+                if i + 1 < nx: internal.append((min(c, cid(i + 1, j, k)), max(c, cid(i + 1, j, k)), quad[0](i + 1, j, k)))
+                if j + 1 < ny: internal.append((min(c, cid(i, j + 1, k)), max(c, cid(i, j + 1, k)), quad[1](i, j + 1, k)))
+                if k + 1 < nz: internal.append((min(c, cid(i, j, k + 1)), max(c, cid(i, j, k + 1)), quad[2](i, j, k + 1)))
+    internal.sort(key=lambda t: (t[0], t[1]))
+    faces = [t[2] for t in internal]; owner = [t[0] for t in internal]; neigh = [t[1] for t in internal]
+    btext = []
+    for name, ty, sides in patches:
+        start = len(faces)
+        for sd in sides:
+            a, hi = sd // 2, sd % 2
+            rng = [range(nx), range(ny), range(nz)]
+            rng[a] = [([nx, ny, nz][a] if hi else 0)]
+            for k in rng[2]:
+                for j in rng[1]:
+                    for i in rng[0]:
+                        faces.append(quad[a](i, j, k))
+                        ci, cj, ck = (i - (a == 0 and hi), j - (a == 1 and hi), k - (a == 2 and hi))
+                        owner.append(cid(ci, cj, ck))
+        btext.append("    %s\n    {\n        type            %s;\n        nFaces          %d;\n        startFace       %d;\n    }\n" % (name, ty, len(faces) - start, start))
+    pm = dst / "constant" / "polyMesh"
+    os.makedirs(pm, exist_ok=True)
+    head = lambda cls, obj: "FoamFile\n{\n    version     2.0;\n    format      ascii;\n    class       %s;\n    location    \"constant/polyMesh\";\n    object      %s;\n}\n\n" % (cls, obj)
+    (pm / "points").write_text(head("vectorField", "points") + "%d\n(\n" % ((nx + 1) * (ny + 1) * (nz + 1)) +
+                               "".join("(%r %r %r)\n" % (float(xs[i]), float(ys[j]), float(zs[k])) for k in range(nz + 1) for j in range(ny + 1) for i in range(nx + 1)) + ")\n")
+    (pm / "faces").write_text(head("faceList", "faces") + "%d\n(\n" % len(faces) + "".join("4(%d %d %d %d)\n" % f for f in faces) + ")\n")
+    (pm / "owner").write_text(head("labelList", "owner") + "%d\n(\n" % len(owner) + "".join("%d\n" % o for o in owner) + ")\n")
+    (pm / "neighbour").write_text(head("labelList", "neighbour") + "%d\n(\n" % len(neigh) + "".join("%d\n" % o for o in neigh) + ")\n")
+    (pm / "boundary").write_text(head("polyBoundaryMesh", "boundary") + "%d\n(\n" % len(patches) + "".join(btext) + ")\n")
+    return cid
+
+
+CAVITY_PATCHES = [("movingWall", "wall", [3]), ("fixedWalls", "wall", [0, 1, 2, 4, 5])]
+
+
+def test_polyMesh_is_read_where_the_case_has_one(prod, tmp_path):
+    """constant/polyMesh takes precedence over blockMeshDict (it is what icoFoamYade's createMesh.H reads): a graded one-block mesh gives the block the
+    dictionary gives; with blockMeshDict removed the case still opens; a mesh that is no lattice is refused"""
+    dst = _edit_block_mesh(tmp_path, "simpleGrading (1 1 1)", "simpleGrading (3 0.5 1)")
+    ref = prod.FoamCase(dst, prod.FY_SOLVER_ICO)
+    c = ref.case
+    g = [np.array([h[q] for q in range(n)]) for h, n in ((c.hx, c.nx), (c.hy, c.ny), (c.hz, c.nz))]
+    nodes = [np.concatenate([[0.0], np.cumsum(h)]) for h in g]
+    write_poly_mesh(dst, nodes[0], nodes[1], nodes[2], CAVITY_PATCHES)
+    os.remove(dst / "system/blockMeshDict")
+    fc = prod.FoamCase(dst, prod.FY_SOLVER_ICO)
+    d = fc.case
+    assert (d.nx, d.ny, d.nz) == (c.nx, c.ny, c.nz) and fc.patch_of_side == ref.patch_of_side
+    for a, hn in enumerate(("hx", "hy", "hz")):
+        np.testing.assert_allclose([getattr(d, hn)[q] for q in range(16)], g[a], rtol=1e-12)
+    assert list(d.u_bc) == list(c.u_bc) and list(d.u_value[YMAX]) == [1.0, 0.0, 0.0]
+    fc.close(); ref.close()
+    # one point moved off the lattice
+    ptxt = (dst / "constant/polyMesh/points").read_text().split("\n")
+    k = next(i for i, ln in enumerate(ptxt) if ln.startswith("(") and len(ln) > 2) + 40
+    ptxt[k] = "(0.0123 0.0456 0.0789)"
+    (dst / "constant/polyMesh/points").write_text("\n".join(ptxt))
+    with pytest.raises(prod.FoamYadeError, match="not a rectilinear lattice"):
+        prod.FoamCase(dst, prod.FY_SOLVER_ICO)
+
+
+def test_polyMesh_numbered_block_by_block_is_mapped_to_the_lattice(prod, tmp_path):
+    """two blocks joined in x: blockMesh numbers the cells of the first block, then those of the second; the field files follow the MESH's numbers and are
+    read (and written) through the map"""
+    dst = tmp_path / "case"
+    shutil.copytree(os.path.join(CASES, "cavity_ico"), dst)
+    n = 16
+    nodes = np.linspace(0.0, 0.1, n + 1)
+    cid = write_poly_mesh(dst, nodes, nodes, nodes, CAVITY_PATCHES, split_x=6)
+    vals = np.zeros(n ** 3)
+    lattice = np.zeros(n ** 3)
+    for k in range(n):
+        for j in range(n):
+            for i in range(n):
+                vals[cid(i, j, k)] = 1000.0 * i + 10.0 * j + 0.1 * k           # (the value names the cell's place)
+                lattice[i + n * (j + n * k)] = 1000.0 * i + 10.0 * j + 0.1 * k
+    ptext = (dst / "0/p").read_text().replace("internalField   uniform 0;", "internalField   nonuniform List<scalar> %d\n(\n%s\n)\n;" % (n ** 3, "\n".join(repr(float(v)) for v in vals)))
+    (dst / "0/p").write_text(ptext)
+    fc = prod.FoamCase(dst, prod.FY_SOLVER_ICO)
+    assert (fc.case.nx, fc.case.ny, fc.case.nz) == (n, n, n) and not fc.case.hx
+    U, p = fc.initial_fields()
+    np.testing.assert_array_equal(p, lattice)
+    fc.close()
+
+
+@pytest.mark.gpu
+def test_case_with_a_block_by_block_polyMesh_runs_and_writes_in_the_meshs_numbering(prod, tmp_path):
+    dst = tmp_path / "case"
+    shutil.copytree(os.path.join(CASES, "cavity_ico"), dst)
+    n = 16
+    nodes = np.linspace(0.0, 0.1, n + 1)
+    cid = write_poly_mesh(dst, nodes, nodes, nodes, CAVITY_PATCHES, split_x=6)
+    perm = np.array([cid(i, j, k) for k in range(n) for j in range(n) for i in range(n)])      # lattice index -> the mesh's cell number
+    runs = []
+    for d in (dst, os.path.join(CASES, "cavity_ico")):
+        fc = prod.FoamCase(d, prod.FY_SOLVER_ICO)
+        s = prod.Solver(fc.case)
+        U0, p0 = fc.initial_fields()
+        s.set("U", U0); s.set("p", p0)
+        for _ in range(5):
+            s.step()
+        runs.append((s.get("U").reshape(-1, 3), s.get("p")))
+        if d is dst:
+            fc.write(s, "0.025")
+        s.close(); fc.close()
+    np.testing.assert_array_equal(runs[0][0], runs[1][0])
+    # the written file lists the cells in the mesh's order
+    cd = dst / "system/controlDict"
+    cd.write_text(cd.read_text().replace("startFrom       startTime;", "startFrom       latestTime;"))
+    import re
+    rows = re.search(r"internalField\s+nonuniform List<scalar> \d+\s*\(([^)]*)\)", (dst / "0.025" / "p").read_text()).group(1).split()
+    np.testing.assert_array_equal(np.array([float(r) for r in rows])[perm], runs[0][1])
+    fc2 = prod.FoamCase(dst, prod.FY_SOLVER_ICO)
+    U2, p2 = fc2.initial_fields()
+    np.testing.assert_array_equal(U2, runs[0][0]); np.testing.assert_array_equal(p2, runs[0][1])
+    fc2.close()

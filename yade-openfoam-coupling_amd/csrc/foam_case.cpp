@@ -14,7 +14,9 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <climits>
 #include <cmath>
+#include <cstdint>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -48,6 +50,9 @@ struct fy_foam_case {
     size_t fcells = 0, foffset = 0;             // cells per field file, global number of the first one
     int proc_rank = -1, proc_count = 0;
     std::vector<std::pair<std::string, std::string> > extra_patches[5];   // per field (U, p, nut, k, epsilon): boundaryField entries of other patches, as read
+    // constant/polyMesh read instead of blockMeshDict: the mesh's cell numbers may differ from the lattice's (several blocks): file_cell[L] = the mesh's
+    // cell at lattice index L = i + nx (j + ny k); empty = the same numbering (one block)
+    std::vector<int32_t> file_cell;
 };
 
 namespace {
@@ -292,6 +297,148 @@ int read_block_mesh(fy_foam_case* c) {
     return FY_OK;
 }
 
+// constant/polyMesh (points, faces, owner, neighbour, boundary: what the reference's solvers read -- createMesh.H -- and blockMesh wrote): accepted
+// when it is a rectilinear lattice of hexahedra filling an axis-aligned box, i.e. what blockMesh makes of the block arrangements read_block_mesh
+// takes.  The lattice comes from the distinct point coordinates; a cell's place in it from the smallest corner of its faces' points; its number in the
+// mesh need not be the lattice's (blocks are numbered one after the other): file_cell keeps the map, and the field files are read and written through it.
+int read_poly_mesh(fy_foam_case* c) {
+    const std::string base = join(c->dir, "constant/polyMesh");
+    std::vector<std::string> tk;
+    std::string err;
+    auto list_of = [&](const char* name) -> int { return fy::foam_list_file_tokens(join(base, name), &tk, &err) ? FY_OK : fail(FY_ERR_INVALID, "%s", err.c_str()); };
+    // ---- points
+    FY_TRY(list_of("points"));
+    for (const std::string& t : tk) if (!t.empty() && t[0] == '\x01') return fail(FY_ERR_UNSUPPORTED, "%s/points: binary mesh files are not supported (the field files are)", base.c_str());
+    std::vector<double> pts;
+    if (!fy::foam_read_list(tk, 0, 3, &pts) || pts.size() < 24) return fail(FY_ERR_INVALID, "%s/points: malformed point list", base.c_str());
+    const size_t npts = pts.size() / 3;
+    std::vector<double> ax[3];
+    double span = 0.0;
+    for (int a = 0; a < 3; ++a) {
+        std::vector<double> v(npts);
+        for (size_t q = 0; q < npts; ++q) v[q] = pts[3 * q + a];
+        std::sort(v.begin(), v.end());
+        span = std::max(span, v.back() - v.front());
+        ax[a].swap(v);
+    }
+    for (int a = 0; a < 3; ++a) {
+        std::vector<double> u;
+        for (double x : ax[a]) if (u.empty() || !(std::fabs(x - u.back()) <= 1e-9 * span)) u.push_back(x);
+        ax[a].swap(u);
+        if (ax[a].size() < 2) return fail(FY_ERR_INVALID, "%s/points: the mesh is flat along axis %d", base.c_str(), a);
+    }
+    const size_t np1[3] = {ax[0].size(), ax[1].size(), ax[2].size()};
+    if (np1[0] * np1[1] * np1[2] != npts)
+        return fail(FY_ERR_UNSUPPORTED, "%s/points: %zu points on %zu x %zu x %zu distinct coordinates -- not a rectilinear lattice (only axis-aligned boxes of hexahedra are supported)", base.c_str(),
+                    npts, np1[0], np1[1], np1[2]);
+    const int nn[3] = {(int)np1[0] - 1, (int)np1[1] - 1, (int)np1[2] - 1};
+    const size_t ncell = (size_t)nn[0] * nn[1] * nn[2];
+    auto index_of = [&](int a, double x) { return (int)(std::lower_bound(ax[a].begin(), ax[a].end(), x - 1e-9 * span) - ax[a].begin()); };
+    std::vector<int32_t> pidx(3 * npts);
+    for (size_t q = 0; q < npts; ++q) for (int a = 0; a < 3; ++a) pidx[3 * q + a] = index_of(a, pts[3 * q + a]);
+    // ---- faces: N ( 4(a b c d) ... )
+    FY_TRY(list_of("faces"));
+    std::vector<int32_t> fpt;
+    {
+        size_t i = 0;
+        double cnt;
+        if (i < tk.size() && fy::foam_tok_is_number(tk[i], &cnt)) ++i;
+        if (i >= tk.size() || tk[i] != "(") return fail(FY_ERR_INVALID, "%s/faces: malformed face list", base.c_str());
+        ++i;
+        while (i < tk.size() && tk[i] != ")") {
+            double nv;
+            if (!fy::foam_tok_is_number(tk[i], &nv) || nv != 4.0 || i + 6 >= tk.size() || tk[i + 1] != "(" || tk[i + 6] != ")")
+                return fail(FY_ERR_UNSUPPORTED, "%s/faces: only quadrilateral faces (hexahedral cells) are supported", base.c_str());
+            for (int m = 0; m < 4; ++m) {
+                double l;
+                if (!fy::foam_tok_is_number(tk[i + 2 + m], &l) || l < 0 || (size_t)l >= npts) return fail(FY_ERR_INVALID, "%s/faces: point label out of range", base.c_str());
+                fpt.push_back((int32_t)l);
+            }
+            i += 7;
+        }
+    }
+    const size_t nfaces = fpt.size() / 4;
+    std::vector<double> own, nei;
+    FY_TRY(list_of("owner"));
+    if (!fy::foam_read_list(tk, 0, 1, &own) || own.size() != nfaces) return fail(FY_ERR_INVALID, "%s/owner: %zu entries for %zu faces", base.c_str(), own.size(), nfaces);
+    FY_TRY(list_of("neighbour"));
+    if (!fy::foam_read_list(tk, 0, 1, &nei) || nei.size() > nfaces) return fail(FY_ERR_INVALID, "%s/neighbour: malformed", base.c_str());
+    // ---- every cell's smallest corner -> its place in the lattice
+    std::vector<int32_t> cmin(3 * ncell, INT32_MAX);
+    auto touch = [&](double cell, size_t f) -> bool {
+        if (cell < 0 || (size_t)cell >= ncell) return false;
+        for (int m = 0; m < 4; ++m) for (int a = 0; a < 3; ++a) {
+            int32_t& v = cmin[3 * (size_t)cell + a];
+            v = std::min(v, pidx[3 * (size_t)fpt[4 * f + m] + a]);
+        }
+        return true;
+    };
+    for (size_t f = 0; f < nfaces; ++f) {
+        if (!touch(own[f], f) || (f < nei.size() && !touch(nei[f], f)))
+            return fail(FY_ERR_UNSUPPORTED, "%s: cell labels beyond %zu = the lattice's cell count (not a box filled with hexahedra)", base.c_str(), ncell);
+    }
+    c->file_cell.assign(ncell, -1);
+    bool identity = true;
+    for (size_t q = 0; q < ncell; ++q) {
+        const int i = cmin[3 * q], j = cmin[3 * q + 1], k = cmin[3 * q + 2];
+        if (i < 0 || i >= nn[0] || j < 0 || j >= nn[1] || k < 0 || k >= nn[2]) return fail(FY_ERR_UNSUPPORTED, "%s: cell %zu does not sit in the lattice", base.c_str(), q);
+        const size_t L = (size_t)i + (size_t)nn[0] * ((size_t)j + (size_t)nn[1] * (size_t)k);
+        if (c->file_cell[L] != -1) return fail(FY_ERR_UNSUPPORTED, "%s: two cells share the lattice place (%d %d %d)", base.c_str(), i, j, k);
+        c->file_cell[L] = (int32_t)q;
+        identity = identity && L == q;
+    }
+    if (identity) c->file_cell.clear();
+    // ---- boundary: N ( name { type ...; nFaces n; startFace s; } ... ): every patch's faces lie on sides of the box, every side belongs to one patch
+    FY_TRY(list_of("boundary"));
+    std::vector<std::pair<std::string, FoamDict> > patches;
+    FY_TRY(named_dicts(tk, base + "/boundary", &patches));
+    std::vector<size_t> side_faces(6, 0);
+    for (auto& pd : patches) {
+        int nf = 0, sf = 0;
+        std::string ty;
+        pd.second.word("type", &ty);
+        if (!pd.second.integer("nFaces", &nf) || !pd.second.integer("startFace", &sf) || nf < 0 || sf < 0 || (size_t)sf + (size_t)nf > nfaces)
+            return fail(FY_ERR_INVALID, "%s/boundary: patch '%s' needs nFaces and startFace inside the face list", base.c_str(), pd.first.c_str());
+        if (ty == "empty" || ty == "cyclic" || ty == "wedge" || ty == "processor")
+            return fail(FY_ERR_UNSUPPORTED, "%s/boundary: patch '%s' of type '%s' is not supported (wall / patch / symmetryPlane sides of a 3-D box)", base.c_str(), pd.first.c_str(), ty.c_str());
+        for (int q = 0; q < nf; ++q) {
+            const size_t f = (size_t)sf + (size_t)q;
+            int side = -1;
+            for (int a = 0; a < 3 && side < 0; ++a)
+                for (int sd = 0; sd < 2 && side < 0; ++sd) {
+                    bool all = true;
+                    for (int m = 0; m < 4; ++m) all = all && pidx[3 * (size_t)fpt[4 * f + m] + a] == (sd ? nn[a] : 0);
+                    if (all) side = 2 * a + sd;
+                }
+            if (side < 0) return fail(FY_ERR_UNSUPPORTED, "%s/boundary: patch '%s' has a face that is not on a side of the box", base.c_str(), pd.first.c_str());
+            if (!c->patch_of_side[side].empty() && c->patch_of_side[side] != pd.first)
+                return fail(FY_ERR_UNSUPPORTED, "%s/boundary: side %d of the box is shared by the patches '%s' and '%s' (one boundary condition per side)", base.c_str(), side, c->patch_of_side[side].c_str(), pd.first.c_str());
+            c->patch_of_side[side] = pd.first;
+            ++side_faces[(size_t)side];
+        }
+        if (nf > 0) c->patch_order.push_back(pd.first);
+    }
+    for (int sd = 0; sd < 6; ++sd) {
+        const int a = sd / 2;
+        const size_t want = (size_t)nn[(a + 1) % 3] * (size_t)nn[(a + 2) % 3];
+        if (side_faces[(size_t)sd] != want) return fail(FY_ERR_INVALID, "%s/boundary: side %d of the box has %zu of its %zu faces in patches", base.c_str(), sd, side_faces[(size_t)sd], want);
+    }
+    // ---- the block: cell sizes per axis, cubes or graded
+    std::vector<double> h[3];
+    for (int a = 0; a < 3; ++a) for (int q = 0; q < nn[a]; ++q) h[a].push_back(ax[a][(size_t)q + 1] - ax[a][(size_t)q]);
+    const double dx = (ax[0].back() - ax[0].front()) / nn[0];
+    bool cubes = true;
+    for (int a = 0; a < 3; ++a) for (double x : h[a]) cubes = cubes && near(x, dx, dx);
+    c->desc.nx = nn[0]; c->desc.ny = nn[1]; c->desc.nz = nn[2]; c->desc.dx = dx;
+    c->desc.hx = c->desc.hy = c->desc.hz = nullptr;
+    if (!cubes) {
+        for (int a = 0; a < 3; ++a) c->grading[a] = h[a];
+        c->desc.hx = c->grading[0].data(); c->desc.hy = c->grading[1].data(); c->desc.hz = c->grading[2].data();
+    }
+    for (int a = 0; a < 3; ++a) c->desc.origin[a] = ax[a].front();
+    return FY_OK;
+}
+
 std::string entry_text(const FoamDict& d) {
     std::string t;
     for (const std::string& k : d.order) {
@@ -307,7 +454,7 @@ std::string entry_text(const FoamDict& d) {
     return t;
 }
 
-int read_internal(const FoamDict& f, const std::string& path, int ncomp, size_t ncell, std::vector<double>* out) {
+int read_internal(const FoamDict& f, const std::string& path, int ncomp, size_t ncell, std::vector<double>* out, const std::vector<int32_t>* file_cell = nullptr) {
     const auto* t = f.tokens("internalField");
     if (!t || t->empty()) return fail(FY_ERR_INVALID, "%s: no internalField", path.c_str());
     out->assign(ncell * (size_t)ncomp, 0.0);
@@ -322,7 +469,11 @@ int read_internal(const FoamDict& f, const std::string& path, int ncomp, size_t 
         std::vector<double> v;
         if (!fy::foam_read_list(*t, 2, ncomp, &v) || v.size() != ncell * (size_t)ncomp)
             return fail(FY_ERR_INVALID, "%s: nonuniform internalField does not hold %zu values", path.c_str(), ncell);
-        out->swap(v);
+        if (file_cell && !file_cell->empty()) {           // the mesh's cell numbers -> lattice order
+            for (size_t L = 0; L < ncell; ++L) for (int q = 0; q < ncomp; ++q) (*out)[L * ncomp + q] = v[(size_t)(*file_cell)[L] * ncomp + q];
+        } else {
+            out->swap(v);
+        }
         return FY_OK;
     }
     return fail(FY_ERR_UNSUPPORTED, "%s: internalField must be 'uniform' or 'nonuniform List<...>'", path.c_str());
@@ -345,7 +496,7 @@ int read_fields(fy_foam_case* c) {
         const std::string path = join(c->fdir, c->start_name + "/" + c->u_name);
         FoamDict f;
         FY_TRY(need_file(path, &f));
-        FY_TRY(read_internal(f, path, 3, ncell, &c->U0));
+        FY_TRY(read_internal(f, path, 3, ncell, &c->U0, &c->file_cell));
         const FoamDict* bf = f.subdict("boundaryField");
         if (!bf) return fail(FY_ERR_INVALID, "%s: no boundaryField", path.c_str());
         keep_extra_patches(c, *bf, &c->extra_patches[0]);
@@ -376,7 +527,7 @@ int read_fields(fy_foam_case* c) {
         const std::string path = join(c->fdir, c->start_name + "/p");
         FoamDict f;
         FY_TRY(need_file(path, &f));
-        FY_TRY(read_internal(f, path, 1, ncell, &c->p0));
+        FY_TRY(read_internal(f, path, 1, ncell, &c->p0, &c->file_cell));
         const FoamDict* bf = f.subdict("boundaryField");
         if (!bf) return fail(FY_ERR_INVALID, "%s: no boundaryField", path.c_str());
         keep_extra_patches(c, *bf, &c->extra_patches[1]);
@@ -405,7 +556,7 @@ int read_fields(fy_foam_case* c) {
         const std::string path = join(c->fdir, c->start_name + "/nut." + c->phase);
         FoamDict f;
         FY_TRY(need_file(path, &f));
-        FY_TRY(read_internal(f, path, 1, ncell, &c->nut0));
+        FY_TRY(read_internal(f, path, 1, ncell, &c->nut0, &c->file_cell));
         c->desc.nut_initial = c->nut0.empty() ? 0.0 : c->nut0[0];
         const FoamDict* bf = f.subdict("boundaryField");
         if (!bf) return fail(FY_ERR_INVALID, "%s: no boundaryField", path.c_str());
@@ -445,7 +596,7 @@ int read_fields(fy_foam_case* c) {
         const std::string path = join(c->fdir, c->start_name + "/k." + c->phase);
         FoamDict f;
         FY_TRY(need_file(path, &f));
-        FY_TRY(read_internal(f, path, 1, ncell, &c->k0));
+        FY_TRY(read_internal(f, path, 1, ncell, &c->k0, &c->file_cell));
         c->desc.k_initial = c->k0.empty() ? 0.0 : c->k0[0];
         const FoamDict* bf = f.subdict("boundaryField");
         if (!bf) return fail(FY_ERR_INVALID, "%s: no boundaryField", path.c_str());
@@ -473,7 +624,7 @@ int read_fields(fy_foam_case* c) {
         const std::string path = join(c->fdir, c->start_name + "/epsilon." + c->phase);
         FoamDict f;
         FY_TRY(need_file(path, &f));
-        FY_TRY(read_internal(f, path, 1, ncell, &c->eps0));
+        FY_TRY(read_internal(f, path, 1, ncell, &c->eps0, &c->file_cell));
         c->desc.eps_initial = c->eps0.empty() ? 0.0 : c->eps0[0];
         const FoamDict* bf = f.subdict("boundaryField");
         if (!bf) return fail(FY_ERR_INVALID, "%s: no boundaryField", path.c_str());
@@ -789,15 +940,21 @@ int write_field(const fy_foam_case* c, const std::string& tdir, const std::strin
     if (c->write_binary) std::fprintf(f, "    arch        \"LSB;label=32;scalar=64\";\n");
     std::fprintf(f, "    class       %s;\n    location    \"%s\";\n    object      %s;\n}\n\n", cls, tname.c_str(), name.c_str());
     std::fprintf(f, "dimensions      %s;\n\ninternalField   nonuniform List<%s> %zu\n(", dims, ncomp == 3 ? "vector" : "scalar", n);
+    std::vector<double> vf;                                // lattice order -> the mesh's cell numbers
+    if (!c->file_cell.empty() && n == c->file_cell.size()) {
+        vf.resize(v.size());
+        for (size_t L = 0; L < n; ++L) for (int q = 0; q < ncomp; ++q) vf[(size_t)c->file_cell[L] * ncomp + q] = v[L * ncomp + q];
+    }
+    const std::vector<double>& v_out = vf.empty() ? v : vf;
     if (c->write_binary) {
         // the list's values as they lie in memory, between the parentheses [OF-6 UList<T>::writeEntry, binary stream]
-        if (std::fwrite(v.data(), sizeof(double), v.size(), f) != v.size()) { std::fclose(f); return fail(FY_ERR_INVALID, "cannot write %s", path.c_str()); }
+        if (std::fwrite(v_out.data(), sizeof(double), v_out.size(), f) != v_out.size()) { std::fclose(f); return fail(FY_ERR_INVALID, "cannot write %s", path.c_str()); }
     } else {
         const int pr = c->write_precision;
         std::fputc('\n', f);
         for (size_t q = 0; q < n; ++q) {
-            if (ncomp == 3) std::fprintf(f, "(%.*g %.*g %.*g)\n", pr, v[3 * q], pr, v[3 * q + 1], pr, v[3 * q + 2]);
-            else std::fprintf(f, "%.*g\n", pr, v[q]);
+            if (ncomp == 3) std::fprintf(f, "(%.*g %.*g %.*g)\n", pr, v_out[3 * q], pr, v_out[3 * q + 1], pr, v_out[3 * q + 2]);
+            else std::fprintf(f, "%.*g\n", pr, v_out[q]);
         }
     }
     std::fprintf(f, ")\n;\n\nboundaryField\n{\n");
@@ -827,7 +984,8 @@ static int open_case(const char* case_dir, int solver, int rank, int nranks, fy_
     c->fdir = c->dir;
     c->solver = solver;
     fy_case_defaults(&c->desc, solver);
-    int rc = read_block_mesh(c);
+    // the mesh: constant/polyMesh when the case has one (what the reference's solvers read), else system/blockMeshDict (what blockMesh would make of it)
+    int rc = file_exists(join(c->dir, "constant/polyMesh/points")) ? read_poly_mesh(c) : read_block_mesh(c);
     if (rc == FY_OK) {
         c->fcells = (size_t)c->desc.nx * c->desc.ny * c->desc.nz;
         if (nranks > 0) {
@@ -838,6 +996,7 @@ static int open_case(const char* case_dir, int solver, int rank, int nranks, fy_
             else if (stat(pd.c_str(), &st) != 0 || !S_ISDIR(st.st_mode)) rc = fail(FY_ERR_INVALID, "%s: no such processor directory (decomposePar first, or open the undecomposed case)", pd.c_str());
             else if (stat(join(c->dir, "processor" + std::to_string(nranks)).c_str(), &st) == 0) rc = fail(FY_ERR_INVALID, "%s is decomposed into more than %d parts", c->dir.c_str(), nranks);
             else if (c->desc.nz % nranks != 0) rc = fail(FY_ERR_UNSUPPORTED, "%s: %d planes do not split into %d equal z-slabs", c->dir.c_str(), c->desc.nz, nranks);
+            else if (!c->file_cell.empty()) rc = fail(FY_ERR_UNSUPPORTED, "%s: a decomposed case whose mesh numbers its cells block by block is not supported", c->dir.c_str());
             else {
                 c->fdir = pd; c->proc_rank = rank; c->proc_count = nranks;
                 c->fcells /= (size_t)nranks; c->foffset = c->fcells * (size_t)rank;

@@ -306,6 +306,30 @@ bool foam_parse(const std::string& text, FoamDict* out, std::string* err, const 
     return parse_dict(tk, &pos, true, out, err, scopes);
 }
 
+// a file that is a FoamFile header followed by ONE bare list (constant/polyMesh/points, faces, owner, neighbour, boundary): the tokens of the list,
+// header skipped
+bool foam_list_file_tokens(const std::string& path, std::vector<std::string>* out, std::string* err) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) { *err = "cannot open " + path; return false; }
+    std::stringstream ss;
+    ss << f.rdbuf();
+    std::vector<Tok> tk;
+    std::string e2;
+    if (!tokenize(ss.str(), &tk, &e2)) { *err = path + ": " + e2; return false; }
+    size_t i = 0;
+    if (i + 1 < tk.size() && tk[i].s == "FoamFile" && tk[i + 1].s == "{") {
+        int depth = 0;
+        for (; i < tk.size(); ++i) {
+            if (tk[i].s == "{") ++depth;
+            if (tk[i].s == "}" && --depth == 0) { ++i; break; }
+        }
+    }
+    out->clear();
+    out->reserve(tk.size() - i);
+    for (; i < tk.size(); ++i) out->push_back(std::move(tk[i].s));
+    return true;
+}
+
 bool foam_parse_file(const std::string& path, FoamDict* out, std::string* err) {
     std::ifstream f(path, std::ios::binary);
     if (!f) { *err = "cannot open " + path; return false; }

@@ -38,6 +38,7 @@ struct FoamDict {
 // Parses `text`; on failure returns false and sets *err (with a line number).
 bool foam_parse(const std::string& text, FoamDict* out, std::string* err, const std::string& dir = std::string());     // dir: where #include looks
 bool foam_parse_file(const std::string& path, FoamDict* out, std::string* err);
+bool foam_list_file_tokens(const std::string& path, std::vector<std::string>* out, std::string* err);      // FoamFile header + one bare list: the list's tokens
 
 // helpers on token streams
 bool foam_tok_is_number(const std::string& t, double* v);
