@@ -306,11 +306,11 @@ int read_poly_mesh(fy_foam_case* c) {
     std::vector<std::string> tk;
     std::string err;
     auto list_of = [&](const char* name) -> int { return fy::foam_list_file_tokens(join(base, name), &tk, &err) ? FY_OK : fail(FY_ERR_INVALID, "%s", err.c_str()); };
-    // ---- points
-    FY_TRY(list_of("points"));
-    for (const std::string& t : tk) if (!t.empty() && t[0] == '\x01') return fail(FY_ERR_UNSUPPORTED, "%s/points: binary mesh files are not supported (the field files are)", base.c_str());
+    // ---- points: N (x y z) ...
     std::vector<double> pts;
-    if (!fy::foam_read_list(tk, 0, 3, &pts) || pts.size() < 24) return fail(FY_ERR_INVALID, "%s/points: malformed point list", base.c_str());
+    if (!fy::foam_numeric_list_file(join(base, "points"), &pts, &err)) return fail(FY_ERR_INVALID, "%s", err.c_str());
+    if (pts.size() < 25 || (pts.size() - 1) % 3 != 0 || (double)((pts.size() - 1) / 3) != pts[0]) return fail(FY_ERR_INVALID, "%s/points: malformed point list", base.c_str());
+    pts.erase(pts.begin());
     const size_t npts = pts.size() / 3;
     std::vector<double> ax[3];
     double span = 0.0;
@@ -336,36 +336,32 @@ int read_poly_mesh(fy_foam_case* c) {
     auto index_of = [&](int a, double x) { return (int)(std::lower_bound(ax[a].begin(), ax[a].end(), x - 1e-9 * span) - ax[a].begin()); };
     std::vector<int32_t> pidx(3 * npts);
     for (size_t q = 0; q < npts; ++q) for (int a = 0; a < 3; ++a) pidx[3 * q + a] = index_of(a, pts[3 * q + a]);
-    // ---- faces: N ( 4(a b c d) ... )
-    FY_TRY(list_of("faces"));
-    std::vector<int32_t> fpt;
-    {
-        size_t i = 0;
-        double cnt;
-        if (i < tk.size() && fy::foam_tok_is_number(tk[i], &cnt)) ++i;
-        if (i >= tk.size() || tk[i] != "(") return fail(FY_ERR_INVALID, "%s/faces: malformed face list", base.c_str());
-        ++i;
-        while (i < tk.size() && tk[i] != ")") {
-            double nv;
-            if (!fy::foam_tok_is_number(tk[i], &nv) || nv != 4.0 || i + 6 >= tk.size() || tk[i + 1] != "(" || tk[i + 6] != ")")
-                return fail(FY_ERR_UNSUPPORTED, "%s/faces: only quadrilateral faces (hexahedral cells) are supported", base.c_str());
-            for (int m = 0; m < 4; ++m) {
-                double l;
-                if (!fy::foam_tok_is_number(tk[i + 2 + m], &l) || l < 0 || (size_t)l >= npts) return fail(FY_ERR_INVALID, "%s/faces: point label out of range", base.c_str());
-                fpt.push_back((int32_t)l);
-            }
-            i += 7;
+    { std::vector<double>().swap(pts); }
+    // ---- faces: N 4(a b c d) ...
+    std::vector<int32_t> fl;
+    if (!fy::foam_label_list_file(join(base, "faces"), &fl, &err)) return fail(FY_ERR_INVALID, "%s", err.c_str());
+    if (fl.empty() || (fl.size() - 1) % 5 != 0 || (size_t)fl[0] != (fl.size() - 1) / 5) return fail(FY_ERR_UNSUPPORTED, "%s/faces: only quadrilateral faces (hexahedral cells) are supported", base.c_str());
+    const size_t nfaces = (fl.size() - 1) / 5;
+    std::vector<int32_t> fpt(4 * nfaces);
+    for (size_t f = 0; f < nfaces; ++f) {
+        if (fl[1 + 5 * f] != 4) return fail(FY_ERR_UNSUPPORTED, "%s/faces: only quadrilateral faces (hexahedral cells) are supported", base.c_str());
+        for (int m = 0; m < 4; ++m) {
+            const int32_t l = fl[2 + 5 * f + m];
+            if (l < 0 || (size_t)l >= npts) return fail(FY_ERR_INVALID, "%s/faces: point label out of range", base.c_str());
+            fpt[4 * f + m] = l;
         }
     }
-    const size_t nfaces = fpt.size() / 4;
-    std::vector<double> own, nei;
-    FY_TRY(list_of("owner"));
-    if (!fy::foam_read_list(tk, 0, 1, &own) || own.size() != nfaces) return fail(FY_ERR_INVALID, "%s/owner: %zu entries for %zu faces", base.c_str(), own.size(), nfaces);
-    FY_TRY(list_of("neighbour"));
-    if (!fy::foam_read_list(tk, 0, 1, &nei) || nei.size() > nfaces) return fail(FY_ERR_INVALID, "%s/neighbour: malformed", base.c_str());
+    { std::vector<int32_t>().swap(fl); }
+    std::vector<int32_t> own, nei;
+    if (!fy::foam_label_list_file(join(base, "owner"), &own, &err)) return fail(FY_ERR_INVALID, "%s", err.c_str());
+    if (own.empty() || (size_t)own[0] != own.size() - 1 || own.size() - 1 != nfaces) return fail(FY_ERR_INVALID, "%s/owner: %zu entries for %zu faces", base.c_str(), own.size() - 1, nfaces);
+    own.erase(own.begin());
+    if (!fy::foam_label_list_file(join(base, "neighbour"), &nei, &err)) return fail(FY_ERR_INVALID, "%s", err.c_str());
+    if (nei.empty() || (size_t)nei[0] != nei.size() - 1 || nei.size() - 1 > nfaces) return fail(FY_ERR_INVALID, "%s/neighbour: malformed", base.c_str());
+    nei.erase(nei.begin());
     // ---- every cell's smallest corner -> its place in the lattice
     std::vector<int32_t> cmin(3 * ncell, INT32_MAX);
-    auto touch = [&](double cell, size_t f) -> bool {
+    auto touch = [&](int32_t cell, size_t f) -> bool {
         if (cell < 0 || (size_t)cell >= ncell) return false;
         for (int m = 0; m < 4; ++m) for (int a = 0; a < 3; ++a) {
             int32_t& v = cmin[3 * (size_t)cell + a];

@@ -330,6 +330,50 @@ bool foam_list_file_tokens(const std::string& path, std::vector<std::string>* ou
     return true;
 }
 
+// The numbers of a file that is a FoamFile header followed by ONE bare list of numbers (constant/polyMesh/points, faces, owner, neighbour), in file
+// order, parentheses dropped: points -> N x y z x y z ..., faces -> N 4 a b c d 4 a b c d ..., owner -> N l l l ...  A scanner of its own: these lists have
+// tens of millions of entries, and the dictionary lexer above makes a std::string of every token.
+template <typename T>
+static bool numeric_list_file(const std::string& path, std::vector<T>* out, std::string* err) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) { *err = "cannot open " + path; return false; }
+    std::stringstream ss;
+    ss << f.rdbuf();
+    const std::string t = ss.str();
+    size_t i = 0;
+    const size_t n = t.size();
+    auto skip = [&]() {
+        for (;;) {
+            while (i < n && std::isspace((unsigned char)t[i])) ++i;
+            if (i + 1 < n && t[i] == '/' && t[i + 1] == '/') { while (i < n && t[i] != '\n') ++i; continue; }
+            if (i + 1 < n && t[i] == '/' && t[i + 1] == '*') { const size_t q = t.find("*/", i + 2); i = q == std::string::npos ? n : q + 2; continue; }
+            break;
+        }
+    };
+    skip();
+    if (t.compare(i, 8, "FoamFile") == 0) {
+        const size_t q = t.find('}', i);
+        if (q == std::string::npos) { *err = path + ": unterminated FoamFile header"; return false; }
+        if (t.find("binary", i) < q) { *err = path + ": binary mesh files are not supported (the field files are)"; return false; }
+        i = q + 1;
+    }
+    out->clear();
+    for (;;) {
+        skip();
+        if (i >= n) break;
+        const char c = t[i];
+        if (c == '(' || c == ')') { ++i; continue; }
+        char* end = nullptr;
+        const double v = std::strtod(t.c_str() + i, &end);
+        if (end == t.c_str() + i) { *err = path + ": unexpected '" + std::string(1, c) + "' in a list of numbers"; return false; }
+        out->push_back((T)v);
+        i = (size_t)(end - t.c_str());
+    }
+    return true;
+}
+bool foam_numeric_list_file(const std::string& path, std::vector<double>* out, std::string* err) { return numeric_list_file(path, out, err); }
+bool foam_label_list_file(const std::string& path, std::vector<int32_t>* out, std::string* err) { return numeric_list_file(path, out, err); }
+
 bool foam_parse_file(const std::string& path, FoamDict* out, std::string* err) {
     std::ifstream f(path, std::ios::binary);
     if (!f) { *err = "cannot open " + path; return false; }

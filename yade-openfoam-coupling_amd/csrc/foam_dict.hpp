@@ -9,6 +9,7 @@
 #include <cstddef>
 #include <map>
 #include <memory>
+#include <cstdint>
 #include <string>
 #include <vector>
 
@@ -39,6 +40,9 @@ struct FoamDict {
 bool foam_parse(const std::string& text, FoamDict* out, std::string* err, const std::string& dir = std::string());     // dir: where #include looks
 bool foam_parse_file(const std::string& path, FoamDict* out, std::string* err);
 bool foam_list_file_tokens(const std::string& path, std::vector<std::string>* out, std::string* err);      // FoamFile header + one bare list: the list's tokens
+// FoamFile header + one bare list of numbers, parentheses dropped (polyMesh points / faces / owner / neighbour: tens of millions of entries)
+bool foam_numeric_list_file(const std::string& path, std::vector<double>* out, std::string* err);
+bool foam_label_list_file(const std::string& path, std::vector<int32_t>* out, std::string* err);
 
 // helpers on token streams
 bool foam_tok_is_number(const std::string& t, double* v);
