@@ -77,7 +77,7 @@ struct Solver {
     bool phi_fresh = true;      // phi holds the current flux (false between the start-of-step exchange with phiOld and the first flux correction)
     CFace3 phi_now() const { return phi_fresh ? CFace3{{phi[0].p, phi[1].p, phi[2].p}} : CFace3{{phiOld[0].p, phiOld[1].p, phiOld[2].p}}; }
     bool rAU_new = true;        // rAU was (re)assembled since the last corrector: rAUf and the coarse pressure operators are stale
-    DevBuf<double> phi[3], phiOld[3], psn[3], alphaf[3], phiHbyA[3], phiForces[3], rAUf[3], pflux[3];
+    DevBuf<double> phi[3], phiOld[3], psn[3], alphaf[3], phiHbyA[3], phiForces[3], rAUf[3], pflux[3], ddtc[3];
     DevBuf<double> gradL;                // [3 nstore] grad(magSqr(U)) for the limited convection schemes
     DevBuf<double> mbd;                  // [3 nstore] per-component boundary diagonal of the momentum matrix (Mom7::bd): only with a slip patch
     DevBuf<double> mdiag, man[6], src, rAU, HbyA, bmom, Gt, divG, xscr;
@@ -312,7 +312,7 @@ struct Solver {
         if (c->turbulence_model == FY_TURBULENCE_KEPSILON) { FY_TRY(epsturb.alloc_exact(n)); FY_TRY(launch_fill_f64(stream, epsturb.p, n, c->eps_initial)); g.epsturb = epsturb.p; }
         FY_TRY(Gt.alloc_exact(9 * n)); FY_TRY(zero(Gt));
         for (int d = 0; d < 3; ++d) {
-            DevBuf<double>* fs[] = {&phi[d], &phiOld[d], &psn[d], &alphaf[d], &phiHbyA[d], &phiForces[d], &rAUf[d], &pflux[d]};
+            DevBuf<double>* fs[] = {&phi[d], &phiOld[d], &psn[d], &alphaf[d], &phiHbyA[d], &phiForces[d], &rAUf[d], &pflux[d], &ddtc[d]};
             for (auto* b : fs) { FY_TRY(b->alloc_exact(fv_fsize(g, d))); FY_TRY(zero(*b)); }
             FY_TRY(launch_fill_f64(stream, alphaf[d].p, alphaf[d].n, 1.0));
         }
@@ -779,7 +779,8 @@ struct Solver {
         // not between the PISO correctors of one assembly
         if (!pimple && rAU_new) { FY_TRY(halo_cells(rAU, 1, 1)); FY_TRY(FVK(launch_interp_rAU, stream, g, rAU.p, F3(rAUf))); }
         FY_TRY(halo_cells(HbyA, 3, 1));
-        FY_TRY(FVK(launch_phiHbyA, stream, g, HbyA.p, U.p, Uold.p, C3(phiOld), C3(rAUf), C3(alphaf), C3(phiForces), F3(phiHbyA), F3(psn)));
+        // the ddtCorr term is the same in every corrector of one momentum assembly: stored by the first, read back by the others
+        FY_TRY(FVK(launch_phiHbyA, stream, g, HbyA.p, U.p, Uold.p, C3(phiOld), C3(rAUf), C3(alphaf), C3(phiForces), F3(phiHbyA), F3(psn), F3(ddtc), rAU_new ? 1 : 2));
         if (adjust_phi) {                                       // icoFoamYade.C:108, pEqn.H:13-16
             FY_TRY(FVK(launch_adjust_phi_sums, stream, g, C3(phiHbyA), C3(phiForces), partials.p));
             FY_TRY(launch_reduce_finalize(stream, partials.p, Nc, 4, nullptr, adj_sums.p));
