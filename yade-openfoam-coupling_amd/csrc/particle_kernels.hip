@@ -618,6 +618,14 @@ __device__ __forceinline__ int agg_slot(uint32_t* keys, uint32_t cell) {
 
 __device__ __forceinline__ void lds_add_f64(double* p, double v) { unsafeAtomicAdd(p, v); }   // ds_add_f64
 
+// Where component j of table slot h lives.  Component-major (round 4): an 8-byte LDS access is banked by (byte address / 4) mod 32 within
+// groups of 16 lanes, so slot-major storage (4 h + j: a 32-byte stride) lets the random slots of a group reach only 4 of the 16 bank pairs
+// for a given j -- at least 4-way conflicts by construction; component-major (j N + h) spreads them over all 16.
+// Measured (profiles/r04_lds_table_layout.txt): the micro-benchmark's random-slot ds_add_f64 rate doubles (1.4 -> 2.9 lanes per clock per CU),
+// k_force_gaussian loses a quarter of its conflict cycles and a third of its LDS wait cycles but only 0.03 ms -- what is left are the
+// 16 random slots of a lane group on 16 bank pairs (~3 deep), same-cell adds (an atomic cannot broadcast) and the 4-byte CAS probes.
+template <int NSLOTS> __device__ __forceinline__ int agg_at(int h, int j) { return j * NSLOTS + h; }
+
 // ------------------------------------------------------------------------------------------------ tile buckets (see particle_kernels.hpp)
 // storage cell index -> (tile, cell inside the tile)
 __device__ __forceinline__ void tile_of(const TileGrid& tg, uint32_t cl, uint32_t* tile, uint32_t* local) {
@@ -710,7 +718,7 @@ __device__ __forceinline__ void flush_table(const uint32_t* keys, const double* 
         if (pr[r] == 0xffffffffu) continue;
         const int q = threadIdx.x + r * NTHREADS;
         const uint32_t c = keys[q];
-        const double v0 = vals[4 * q], v1 = vals[4 * q + 1], v2 = vals[4 * q + 2], v3 = vals[4 * q + 3];
+        const double v0 = vals[agg_at<NSLOTS>(q, 0)], v1 = vals[agg_at<NSLOTS>(q, 1)], v2 = vals[agg_at<NSLOTS>(q, 2)], v3 = vals[agg_at<NSLOTS>(q, 3)];
         bool placed = false;
         if (pr[r] != 0xfffffffeu) {
             const uint32_t slot = pr[r] >> 16, rank = pr[r] & 0xffffu;
@@ -761,8 +769,8 @@ __global__ __launch_bounds__(256) void k_tile_reduce(TileBuckets tb, double* __r
             const uint32_t l = tb.cell[off + j];
             const double2* v = reinterpret_cast<const double2*>(tb.val + 4 * (off + j));
             const double2 v0 = v[0], v1 = v[1];
-            double* a = acc + 4 * l;
-            lds_add_f64(a, v0.x); lds_add_f64(a + 1, v0.y); lds_add_f64(a + 2, v1.x); lds_add_f64(a + 3, v1.y);
+            lds_add_f64(&acc[agg_at<kTileCells>(l, 0)], v0.x); lds_add_f64(&acc[agg_at<kTileCells>(l, 1)], v0.y);
+            lds_add_f64(&acc[agg_at<kTileCells>(l, 2)], v1.x); lds_add_f64(&acc[agg_at<kTileCells>(l, 3)], v1.y);
         }
         __syncthreads();
     }
@@ -772,7 +780,7 @@ __global__ __launch_bounds__(256) void k_tile_reduce(TileBuckets tb, double* __r
         const int i = ti * 8 + (l & 7), j = tj * 8 + ((l >> 3) & 7), k = tk * 8 + (l >> 6);
         if (i >= tg.nx || j >= tg.ny || k >= tg.nzs) continue;
         double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-        if (cnt) { a0 = acc[4 * l]; a1 = acc[4 * l + 1]; a2 = acc[4 * l + 2]; a3 = acc[4 * l + 3]; }
+        if (cnt) { a0 = acc[agg_at<kTileCells>(l, 0)]; a1 = acc[agg_at<kTileCells>(l, 1)]; a2 = acc[agg_at<kTileCells>(l, 2)]; a3 = acc[agg_at<kTileCells>(l, 3)]; }
         const bool any = !(a0 == 0.0 && a1 == 0.0 && a2 == 0.0 && a3 == 0.0);
         const size_t c = (size_t)i + (size_t)tg.nx * ((size_t)j + (size_t)tg.ny * (size_t)k);
         if (FINISH == 0) {
@@ -844,10 +852,11 @@ __device__ __forceinline__ void deposit_pair(uint32_t* keys, double* vals, int32
     if (h >= 0) {
         // the LDS atomic unit (~1.4 ds_add_f64 lanes per clock per CU, tools/micro/lds_atomic_rate.hip) is what bounds this half of the
         // kernel: adding an exact zero is the identity, so the momentum terms of a particle at rest are not issued at all
-        lds_add_f64(&vals[4 * h], c0);
-        if (c1 != 0.0) lds_add_f64(&vals[4 * h + 1], c1);
-        if (c2 != 0.0) lds_add_f64(&vals[4 * h + 2], c2);
-        if (c3 != 0.0) lds_add_f64(&vals[4 * h + 3], c3);
+        constexpr int N = 1 << kDepLog2;
+        lds_add_f64(&vals[agg_at<N>(h, 0)], c0);
+        if (c1 != 0.0) lds_add_f64(&vals[agg_at<N>(h, 1)], c1);
+        if (c2 != 0.0) lds_add_f64(&vals[agg_at<N>(h, 2)], c2);
+        if (c3 != 0.0) lds_add_f64(&vals[agg_at<N>(h, 3)], c3);
     } else {
         deposit_direct(cid, c0, c1, c2, c3, pvol_acc, up_acc, touched);
     }
@@ -862,7 +871,7 @@ __global__ __launch_bounds__(kDepThreads) void k_deposit(ParticleSoA p, int64_t 
     if (work) { n = (int64_t)*work_n; if ((int64_t)blockIdx.x * kDepThreads >= n) return; }      // (block-uniform)
     for (int q = threadIdx.x; q < (1 << kDepLog2); q += kDepThreads) {
         keys[q] = kAggEmpty;
-        vals[4 * q] = 0.0; vals[4 * q + 1] = 0.0; vals[4 * q + 2] = 0.0; vals[4 * q + 3] = 0.0;
+        vals[q] = 0.0; vals[q + (1 << kDepLog2)] = 0.0; vals[q + 2 * (1 << kDepLog2)] = 0.0; vals[q + 3 * (1 << kDepLog2)] = 0.0;
     }
     __syncthreads();
     for (int64_t idx = (int64_t)blockIdx.x * kDepThreads + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * kDepThreads) {
@@ -926,7 +935,7 @@ __global__ __launch_bounds__(kDepThreads) void k_locate_deposit(LocateLists ll, 
     __shared__ TileMapLds tmap;
     for (int q = threadIdx.x; q < (1 << kDepLog2); q += kDepThreads) {
         keys[q] = kAggEmpty;
-        vals[4 * q] = 0.0; vals[4 * q + 1] = 0.0; vals[4 * q + 2] = 0.0; vals[4 * q + 3] = 0.0;
+        vals[q] = 0.0; vals[q + (1 << kDepLog2)] = 0.0; vals[q + 2 * (1 << kDepLog2)] = 0.0; vals[q + 3 * (1 << kDepLog2)] = 0.0;
     }
     __syncthreads();
     const int64_t i = (int64_t)blockIdx.x * kDepThreads + threadIdx.x;
@@ -1202,7 +1211,7 @@ __global__ __launch_bounds__(kForceThreads) void k_force_gaussian(
     __shared__ TileMapLds tmap;
     for (int q = threadIdx.x; q < kSlots; q += kForceThreads) {
         keys[q] = kAggEmpty;
-        vals[4 * q] = 0.0; vals[4 * q + 1] = 0.0; vals[4 * q + 2] = 0.0; vals[4 * q + 3] = 0.0;
+        vals[q] = 0.0; vals[q + kSlots] = 0.0; vals[q + 2 * kSlots] = 0.0; vals[q + 3 * kSlots] = 0.0;
     }
     __syncthreads();
     const int64_t i = (int64_t)blockIdx.x * kForceThreads + threadIdx.x;
@@ -1256,8 +1265,8 @@ __global__ __launch_bounds__(kForceThreads) void k_force_gaussian(
                 const double c1 = (-pf.bx * w) * ooCellVol, c2 = (-pf.by * w) * ooCellVol, c3 = (-pf.bz * w) * ooCellVol;   // FoamYade.C:433, 406-411
                 const int h = agg_slot<kForceLog2>(keys, (uint32_t)c);
                 if (h >= 0) {
-                    lds_add_f64(&vals[4 * h], c0); lds_add_f64(&vals[4 * h + 1], c1);
-                    lds_add_f64(&vals[4 * h + 2], c2); lds_add_f64(&vals[4 * h + 3], c3);
+                    lds_add_f64(&vals[agg_at<kSlots>(h, 0)], c0); lds_add_f64(&vals[agg_at<kSlots>(h, 1)], c1);
+                    lds_add_f64(&vals[agg_at<kSlots>(h, 2)], c2); lds_add_f64(&vals[agg_at<kSlots>(h, 3)], c3);
                 } else {
                     atomic_add_f64(&drag_acc[c], c0);
                     atomic_add_f64(&uSource[3 * (size_t)c + 0], c1);
