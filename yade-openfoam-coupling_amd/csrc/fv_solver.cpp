@@ -7,1273 +7,700 @@
 // halo exchange precedes every kernel that reads a z-neighbour of a field that changed; reductions are all-reduced on the device;
 // multigrid levels whose 2x2x2 aggregates stay inside a slab are distributed, the coarse remainder is all-gathered and solved
 // redundantly (bit-identically) on every rank.  With one rank every communication call is a no-op and gz = 0.
-#include <algorithm>
-#include <cmath>
-#include <memory>
-#include <string>
-#include <functional>
-#include <vector>
-
-#include "comm.hpp"
-#include "coupling.hpp"
-#include "fv_kernels.hpp"
-
-// geometry-dependent launchers exist per geometry model (fv_kernels.hpp): the uniform block's in fy, the graded block's in fy::gr
-#define FVK(fn, ...) (g.graded ? ::fy::gr::fn(__VA_ARGS__) : ::fy::fn(__VA_ARGS__))
+#include "fv_solver.hpp"
 
 namespace fy {
 
-// coarsest multigrid level: solved by damped-Jacobi sweeps inside one 1024-thread workgroup (every level below ~20^3 is
-// launch-bound on the GPU; stopping at <= 1024 cells was tried and LOST: 40 sweeps no longer solve that level, +20 % PCG iterations)
-constexpr int kMgCoarsest = kMgDirectMax, kMgCoarsestEdge = 8;      // the coarsest level (<= 128 cells, no edge over 8: band <= 64) is solved exactly from its banded Cholesky factor
-constexpr int kMgReplicateBelow = 1 << 20;    // a distributed hierarchy hands over to the replicated one at <= this many GLOBAL cells: every
-                                              // distributed level costs 4 neighbour exchanges per V-cycle, a replicated 1 M-cell level ~15 us per kernel
-
-struct MgLev {
-    PMat A{};
-    bool distributed = false;     // owned z-slab + 1 ghost plane per side (only when comm->size > 1)
-    int gz = 0;
-    size_t plane = 0;
-    DevBuf<double> diag, ux, uy, uz, x0, x1, b;
-    double* xcur = nullptr;       // holds the level's current iterate
-    double* xalt = nullptr;
-    const double* bptr = nullptr;
-};
-
-struct Solver {
-    fy_case_desc cs{};
-    std::vector<double> h_host[3];       // graded block: cell sizes per axis (host copy) and their device arrays (FvGeo::h)
-    DevBuf<double> d_h[3];
-    double total_volume = 0.0;
-    FvGeo g{};
-    int device = 0;
-    hipStream_t stream = nullptr;
-    hipStream_t comm_stream = nullptr;     // halo exchanges that overlap interior stencil work run here (slab mode)
-    hipEvent_t ev_ready = nullptr, ev_halo = nullptr;
-    // single domain: the coarse operators (k_mg_coarsen per level, the reference term, the coarsest level's Cholesky factor -- small, launch- and
-    // latency-bound kernels, ~110 us in a row) are built on comm_stream while the main stream starts the solve on level 0, which needs none of them
-    // (initial residual, pre-smoothing, restriction); the first touch of a coarse level waits for ev_coarse
-    hipEvent_t ev_assembled = nullptr, ev_coarse = nullptr;
-    // single domain: the component sums of U that the momentum predictor's normFactor needs (k_sum3 + fold, 35 us) are formed on comm_stream at the top
-    // of the step, beside the particle phase -- U does not change between there and the predictor -- into a partials buffer of their own
-    hipEvent_t ev_usum0 = nullptr, ev_usum1 = nullptr;
-    DevBuf<double> usum_partials;
-    bool usum_pending = false;
-    bool coarse_pending = false;
-    int wait_coarse() { if (coarse_pending) { coarse_pending = false; FY_HIP(hipStreamWaitEvent(stream, ev_coarse, 0)); } return FY_OK; }
-    fy_ctx* cpl = nullptr;
-    bool pimple = false;
-    int Nc = 0;                   // owned cells
-    size_t nstore = 0, plane = 0; // storage cells (owned + ghost planes), cells per z-plane
-    int64_t Nglob = 0;
-    Comm* comm = nullptr;
-    SelfComm self_comm;
-
-    DevBuf<double> U, Uold, p, alpha, uSource, uSourceDrag, uParticle, gradP, divT, vGrad, ddtU;
-    DevBuf<double> nut;                  // eddy viscosity (FY_TURBULENCE_SMAGORINSKY / _KEQN), storage cells; empty = laminar
-    DevBuf<double> kturb, epsturb;       // turbulent kinetic energy k (FY_TURBULENCE_KEQN, _KEPSILON), dissipation rate epsilon (_KEPSILON)
-    TurbEqn eq_k{}, eq_eps{};
-    double les_delta = 0.0;              // LESdelta cubeRootVol: deltaCoeff * cbrt(V) [OF-6 cubeRootVolDelta.C]
-    bool phi_fresh = true;      // phi holds the current flux (false between the start-of-step exchange with phiOld and the first flux correction)
-    CFace3 phi_now() const { return phi_fresh ? CFace3{{phi[0].p, phi[1].p, phi[2].p}} : CFace3{{phiOld[0].p, phiOld[1].p, phiOld[2].p}}; }
-    bool rAU_new = true;        // rAU was (re)assembled since the last corrector: rAUf and the coarse pressure operators are stale
-    DevBuf<double> phi[3], phiOld[3], psn[3], alphaf[3], phiHbyA[3], phiForces[3], rAUf[3], pflux[3], ddtc[3];
-    DevBuf<double> gradL;                // [3 nstore] grad(magSqr(U)) for the limited convection schemes
-    DevBuf<double> mbd;                  // [3 nstore] per-component boundary diagonal of the momentum matrix (Mom7::bd): only with a slip patch
-    DevBuf<double> mdiag, man[6], src, rAU, HbyA, bmom, Gt, divG, xscr;
-    std::vector<std::unique_ptr<MgLev> > mg;
-    size_t mg_rep = 0;            // first replicated level (== mg.size() when nothing is replicated)
-    DevBuf<double> rep_stage;     // local slice of the first replicated level before the all-gather (rhs / operator arrays)
-    DevBuf<double> prhs, pr, pw, pp, pzj;
-    DevBuf<double> pPrev;        // p.prevIter() (only with a field relaxation factor for p)
-    double p_relax_now = 0.0;
-    bool adjust_phi = false;     // adjustPhi can act (no fixed-pressure patch, and a patch that lets U float or prescribed through-flow)
-    DevBuf<double> adj_sums;     // {massIn, fixedMassOut, adjustableMassOut, sum |internal flux|}
-    DevBuf<int> adj_err;
-    DevBuf<double> partials, red_out, sc, xbar3;
-    bool hold_sources = false, sources_pending = false;
-    bool overlap_halos = true;            // FOAMYADE_NO_HALO_OVERLAP=1: serial schedule (A/B switch, same results)
-    double* red_host = nullptr;           // mapped pinned host memory (+ its device alias): reduce_read's landing zone (8 doubles) + deferred slots
-    double* red_host_dev = nullptr;
-    unsigned long long* red_flag = nullptr;      // 8 arrival flags (mapped pinned) the host spins on, and their device alias
-    unsigned long long* red_flag_dev = nullptr;
-    unsigned long long red_seq = 0;
-    DevBuf<int> ops_courant, ops_diag;   // per-slot fold operations (0 sum, 1 max) of the Courant pair and of k_U_correct<true>'s four diagnostics
-    fy_step_stats st{};
-    double cumulative_cont_err = 0.0;
-    EventTimer tim[4];      // particle, (unused), (unused), total
-    KernelClock clk_mom, clk_pres;   // momentum / pressure phases: one event pair per outer iteration / corrector, read after the step's final
-                                     // synchronisation (reading a phase time on the spot stalls the host until the phase has drained)
-    bool timing = true;
-    enum { KC_MG_SMOOTH0 = 0, KC_P_APPLY_DOT, KC_MOM_PASS, KC_COUNT };
-    KernelClock kc[KC_COUNT];
-
-    Face3 F3(DevBuf<double>* a) { Face3 f; for (int d = 0; d < 3; ++d) f.a[d] = a[d].p; return f; }
-    CFace3 C3(DevBuf<double>* a) { CFace3 f; for (int d = 0; d < 3; ++d) f.a[d] = a[d].p; return f; }
-    // with_bd: the momentum matrix (the k / epsilon equations re-use diag / an and have no per-component boundary diagonal)
-    Mom7 M7(bool with_bd = true) { Mom7 m; m.diag = mdiag.p; for (int q = 0; q < 6; ++q) m.an[q] = man[q].p; m.bd = with_bd ? mbd.p : nullptr; return m; }
-
-    ~Solver() {
-        if (cpl) fy_destroy(cpl);
-        for (auto& t : tim) t.destroy();
-        for (auto& k : kc) k.destroy();
-        clk_mom.destroy(); clk_pres.destroy();
-        if (ev_ready) (void)hipEventDestroy(ev_ready);
-        if (ev_halo) (void)hipEventDestroy(ev_halo);
-        if (ev_assembled) (void)hipEventDestroy(ev_assembled);
-        if (ev_usum0) (void)hipEventDestroy(ev_usum0);
-        if (ev_usum1) (void)hipEventDestroy(ev_usum1);
-        if (ev_coarse) (void)hipEventDestroy(ev_coarse);
-        if (comm_stream) (void)hipStreamDestroy(comm_stream);
-        if (red_host) (void)hipHostFree(red_host);
-        if (red_flag) (void)hipHostFree(red_flag);
-        if (stream) (void)hipStreamDestroy(stream);
+int Solver::create(const fy_case_desc* c, const fy_transport* tr, int dev, Comm* cm) {
+    if (c && (c->convection_scheme < FY_CONVECTION_LINEAR || c->convection_scheme > FY_CONVECTION_QUICK)) return fail(FY_ERR_INVALID, "fy_solver_create: unknown convection_scheme");
+    if (c && c->convection_scheme == FY_CONVECTION_LIMITED_LINEAR && !(c->convection_limiter_k >= 0 && c->convection_limiter_k <= 1)) return fail(FY_ERR_INVALID, "fy_solver_create: limitedLinear's coefficient must lie in [0, 1]");
+    const bool gradedc = c && (c->hx || c->hy || c->hz);
+    if (!c || c->nx <= 0 || c->ny <= 0 || c->nz <= 0 || (!gradedc && !(c->dx > 0)) || !(c->dt > 0)) return fail(FY_ERR_INVALID, "fy_solver_create: bad case");
+    if (gradedc) {
+        // a graded (rectilinear) single block, one domain
+        if (!(c->hx && c->hy && c->hz)) return fail(FY_ERR_INVALID, "fy_solver_create: a graded block needs hx, hy AND hz");
+        if (cm && cm->size > 1) return fail(FY_ERR_UNSUPPORTED, "fy_solver_create: z-slabs need the uniform block (a graded block runs on one domain)");
+        const double* hh[3] = {c->hx, c->hy, c->hz};
+        const int nn[3] = {c->nx, c->ny, c->nz};
+        for (int a = 0; a < 3; ++a) for (int q = 0; q < nn[a]; ++q) if (!(hh[a][q] > 0)) return fail(FY_ERR_INVALID, "fy_solver_create: graded block with a non-positive cell size");
     }
-
-    int zero(DevBuf<double>& b) { if (b.n) FY_HIP(hipMemsetAsync(b.p, 0, b.n * sizeof(double), stream)); return FY_OK; }
-
-    // ---- slab halos -----------------------------------------------------------------------------------------------------
-    // refresh w ghost planes per side of a cell array with `ncomp` interleaved components (planes are contiguous in memory)
-    int halo(double* f, int ncomp, size_t pl, int nzl, int gzl, int w, hipStream_t on = nullptr) {
-        if (comm->size == 1) return FY_OK;
-        if (!on) on = stream;
-        const size_t P = pl * (size_t)ncomp;
-        double* own_lo = f + (size_t)gzl * P;
-        double* own_hi = f + (size_t)(gzl + nzl - w) * P;
-        double* gh_lo = f + (size_t)(gzl - w) * P;
-        double* gh_hi = f + (size_t)(gzl + nzl) * P;
-        return comm->neighbour_exchange(on, own_hi, gh_lo, own_lo, gh_hi, (size_t)w * P);
-    }
-    int halo_cells(DevBuf<double>& f, int ncomp, int w) { return halo(f.p, ncomp, plane, g.nz, g.gz, w); }
-    int halo_level(MgLev& L, double* x) { return L.distributed ? halo(x, 1, L.plane, L.A.nz, L.gz, 1) : FY_OK; }
-
-    int create(const fy_case_desc* c, const fy_transport* tr, int dev, Comm* cm) {
-        if (c && (c->convection_scheme < FY_CONVECTION_LINEAR || c->convection_scheme > FY_CONVECTION_QUICK)) return fail(FY_ERR_INVALID, "fy_solver_create: unknown convection_scheme");
-        if (c && c->convection_scheme == FY_CONVECTION_LIMITED_LINEAR && !(c->convection_limiter_k >= 0 && c->convection_limiter_k <= 1)) return fail(FY_ERR_INVALID, "fy_solver_create: limitedLinear's coefficient must lie in [0, 1]");
-        const bool gradedc = c && (c->hx || c->hy || c->hz);
-        if (!c || c->nx <= 0 || c->ny <= 0 || c->nz <= 0 || (!gradedc && !(c->dx > 0)) || !(c->dt > 0)) return fail(FY_ERR_INVALID, "fy_solver_create: bad case");
-        if (gradedc) {
-            // a graded (rectilinear) single block, one domain
-            if (!(c->hx && c->hy && c->hz)) return fail(FY_ERR_INVALID, "fy_solver_create: a graded block needs hx, hy AND hz");
-            if (cm && cm->size > 1) return fail(FY_ERR_UNSUPPORTED, "fy_solver_create: z-slabs need the uniform block (a graded block runs on one domain)");
-            const double* hh[3] = {c->hx, c->hy, c->hz};
-            const int nn[3] = {c->nx, c->ny, c->nz};
-            for (int a = 0; a < 3; ++a) for (int q = 0; q < nn[a]; ++q) if (!(hh[a][q] > 0)) return fail(FY_ERR_INVALID, "fy_solver_create: graded block with a non-positive cell size");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(FY_ERR_NO_DEVICE, "no HIP device visible: libfoamyade_hip has no CPU path");
+    if (dev < 0 || dev >= ndev) return fail(FY_ERR_INVALID, "device ordinal out of range");
+    cs = *c; device = dev; pimple = c->solver == FY_SOLVER_PIMPLE;
+    cs.hx = cs.hy = cs.hz = nullptr;        // (the caller's arrays are copied below, not kept)
+    comm = cm ? cm : &self_comm;
+    FY_HIP(hipSetDevice(device));
+    FY_HIP(hipStreamCreate(&stream));
+    FY_HIP(hipStreamCreateWithFlags(&comm_stream, hipStreamNonBlocking));
+    FY_HIP(hipEventCreateWithFlags(&ev_ready, hipEventDisableTiming));
+    FY_HIP(hipEventCreateWithFlags(&ev_halo, hipEventDisableTiming));
+    FY_HIP(hipEventCreateWithFlags(&ev_assembled, hipEventDisableTiming));
+    FY_HIP(hipEventCreateWithFlags(&ev_usum0, hipEventDisableTiming));
+    FY_HIP(hipEventCreateWithFlags(&ev_usum1, hipEventDisableTiming));
+    FY_HIP(hipEventCreateWithFlags(&ev_coarse, hipEventDisableTiming));
+    overlap_halos = !options().no_halo_overlap;
+    comm->set_aux_stream(comm_stream);
+    // ---- slab extents: the case describes the GLOBAL block; rank r owns planes [r*nz, (r+1)*nz)
+    const int S = comm->size;
+    if (c->nz % S != 0) return fail(FY_ERR_INVALID, "nz (%d) must be divisible by the number of slabs (%d)", c->nz, S);
+    const int nzl = c->nz / S;
+    if (S > 1 && (nzl % 2 != 0 || nzl < 2)) return fail(FY_ERR_INVALID, "each slab needs an even number (>= 2) of z-planes, got %d", nzl);
+    // ghost width: 1 plane for the FV stencils; the Gaussian stencil reaches sqrt(1.25)*4 dx = 4.47 dx => 5 planes
+    const int gz = S == 1 ? 0 : (pimple ? 5 : 1);
+    if (S > 1 && nzl < gz) return fail(FY_ERR_INVALID, "slab thinner (%d planes) than the particle halo (%d)", nzl, gz);
+    plane = (size_t)c->nx * c->ny;
+    Nc = (int)(plane * nzl);
+    nstore = plane * (size_t)(nzl + 2 * gz);
+    Nglob = (int64_t)plane * c->nz;
+    g.nx = c->nx; g.ny = c->ny; g.nz = nzl; g.Nc = Nc; g.gz = gz; g.c0 = (int)(plane * gz); g.kglob0 = comm->rank * nzl; g.nzglob = c->nz;
+    g.dx = c->dx; g.Af = c->dx * c->dx; g.V = c->dx * c->dx * c->dx;
+    g.graded = 0; g.h[0] = g.h[1] = g.h[2] = nullptr;
+    total_volume = g.V * (double)Nglob;
+    if (gradedc) {
+        const double* hh[3] = {c->hx, c->hy, c->hz};
+        const int nn[3] = {c->nx, c->ny, c->nz};
+        double len[3] = {0, 0, 0};
+        for (int a = 0; a < 3; ++a) {
+            h_host[a].assign(hh[a], hh[a] + nn[a]);
+            for (double v : h_host[a]) len[a] += v;
+            FY_TRY(d_h[a].alloc_exact((size_t)nn[a]));
+            FY_HIP(hipMemcpyAsync(d_h[a].p, hh[a], (size_t)nn[a] * sizeof(double), hipMemcpyHostToDevice, stream));
+            g.h[a] = d_h[a].p;
         }
-        int ndev = 0;
-        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(FY_ERR_NO_DEVICE, "no HIP device visible: libfoamyade_hip has no CPU path");
-        if (dev < 0 || dev >= ndev) return fail(FY_ERR_INVALID, "device ordinal out of range");
-        cs = *c; device = dev; pimple = c->solver == FY_SOLVER_PIMPLE;
-        cs.hx = cs.hy = cs.hz = nullptr;        // (the caller's arrays are copied below, not kept)
-        comm = cm ? cm : &self_comm;
-        FY_HIP(hipSetDevice(device));
-        FY_HIP(hipStreamCreate(&stream));
-        FY_HIP(hipStreamCreateWithFlags(&comm_stream, hipStreamNonBlocking));
-        FY_HIP(hipEventCreateWithFlags(&ev_ready, hipEventDisableTiming));
-        FY_HIP(hipEventCreateWithFlags(&ev_halo, hipEventDisableTiming));
-        FY_HIP(hipEventCreateWithFlags(&ev_assembled, hipEventDisableTiming));
-        FY_HIP(hipEventCreateWithFlags(&ev_usum0, hipEventDisableTiming));
-        FY_HIP(hipEventCreateWithFlags(&ev_usum1, hipEventDisableTiming));
-        FY_HIP(hipEventCreateWithFlags(&ev_coarse, hipEventDisableTiming));
-        overlap_halos = !options().no_halo_overlap;
-        comm->set_aux_stream(comm_stream);
-        // ---- slab extents: the case describes the GLOBAL block; rank r owns planes [r*nz, (r+1)*nz)
-        const int S = comm->size;
-        if (c->nz % S != 0) return fail(FY_ERR_INVALID, "nz (%d) must be divisible by the number of slabs (%d)", c->nz, S);
-        const int nzl = c->nz / S;
-        if (S > 1 && (nzl % 2 != 0 || nzl < 2)) return fail(FY_ERR_INVALID, "each slab needs an even number (>= 2) of z-planes, got %d", nzl);
-        // ghost width: 1 plane for the FV stencils; the Gaussian stencil reaches sqrt(1.25)*4 dx = 4.47 dx => 5 planes
-        const int gz = S == 1 ? 0 : (pimple ? 5 : 1);
-        if (S > 1 && nzl < gz) return fail(FY_ERR_INVALID, "slab thinner (%d planes) than the particle halo (%d)", nzl, gz);
-        plane = (size_t)c->nx * c->ny;
-        Nc = (int)(plane * nzl);
-        nstore = plane * (size_t)(nzl + 2 * gz);
-        Nglob = (int64_t)plane * c->nz;
-        g.nx = c->nx; g.ny = c->ny; g.nz = nzl; g.Nc = Nc; g.gz = gz; g.c0 = (int)(plane * gz); g.kglob0 = comm->rank * nzl; g.nzglob = c->nz;
-        g.dx = c->dx; g.Af = c->dx * c->dx; g.V = c->dx * c->dx * c->dx;
-        g.graded = 0; g.h[0] = g.h[1] = g.h[2] = nullptr;
-        total_volume = g.V * (double)Nglob;
-        if (gradedc) {
-            const double* hh[3] = {c->hx, c->hy, c->hz};
-            const int nn[3] = {c->nx, c->ny, c->nz};
-            double len[3] = {0, 0, 0};
-            for (int a = 0; a < 3; ++a) {
-                h_host[a].assign(hh[a], hh[a] + nn[a]);
-                for (double v : h_host[a]) len[a] += v;
-                FY_TRY(d_h[a].alloc_exact((size_t)nn[a]));
-                FY_HIP(hipMemcpyAsync(d_h[a].p, hh[a], (size_t)nn[a] * sizeof(double), hipMemcpyHostToDevice, stream));
-                g.h[a] = d_h[a].p;
-            }
-            FY_HIP(hipStreamSynchronize(stream));
-            g.graded = 1;
-            g.dx = std::cbrt((h_host[0][0] * h_host[1][0]) * h_host[2][0]);       // (only what still assumes cubes reads it: nothing on this path)
-            g.Af = g.dx * g.dx; g.V = g.dx * g.dx * g.dx;
-            total_volume = (len[0] * len[1]) * len[2];
-        }
-        g.upwind = c->convection_scheme;          // 0 linear, 1 upwind, 2 linearUpwind, 3 .. 8 limited
-        g.lim_twoByk = 2.0 / std::max(c->convection_limiter_k, 1e-15);
-        g.rdx = 1.0 / g.dx; g.rhdx = 1.0 / (0.5 * g.dx); g.rV = 1.0 / g.V;
-        g.pimple = pimple ? 1 : 0; g.dt = c->dt; g.nu = c->nu;
-        bool need_ref = true;
-        for (int q = 0; q < 6; ++q) {
-            if (c->u_bc[q] != FY_BC_U_FIXED_VALUE && c->u_bc[q] != FY_BC_U_ZERO_GRADIENT && c->u_bc[q] != FY_BC_U_SLIP) return fail(FY_ERR_INVALID, "fy_solver_create: unknown velocity boundary type %d on side %d", c->u_bc[q], q);
-            if (c->p_bc[q] != FY_BC_P_ZERO_GRADIENT && c->p_bc[q] != FY_BC_P_FIXED_VALUE && c->p_bc[q] != FY_BC_P_FIXED_FLUX) return fail(FY_ERR_INVALID, "fy_solver_create: unknown pressure boundary type %d on side %d", c->p_bc[q], q);
-            g.u_bc[q] = c->u_bc[q]; g.p_bc[q] = c->p_bc[q]; g.p_val[q] = c->p_value[q];
-            for (int a = 0; a < 3; ++a) g.u_val[q][a] = c->u_value[q][a];
-            if (c->p_bc[q] == FY_BC_P_FIXED_VALUE) need_ref = false;
-        }
-        for (int a = 0; a < 3; ++a) g.g[a] = c->g[a];
-        g.need_ref = need_ref ? 1 : 0; g.p_ref_cell = c->p_ref_cell; g.p_ref_value = c->p_ref_value;
-        g.u_relax = c->u_relax;
-        if (c->turbulence_model != FY_TURBULENCE_LAMINAR && c->turbulence_model != FY_TURBULENCE_SMAGORINSKY && c->turbulence_model != FY_TURBULENCE_KEQN && c->turbulence_model != FY_TURBULENCE_KEPSILON) return fail(FY_ERR_UNSUPPORTED, "fy_solver_create: unknown turbulence_model %d (DPMTurbulenceModels.C:67-77: laminar Stokes, RAS kEpsilon, LES Smagorinsky, LES kEqn)", c->turbulence_model);
-        if (c->turbulence_model != FY_TURBULENCE_LAMINAR) {
-            if (!pimple) return fail(FY_ERR_INVALID, "fy_solver_create: icoFoamYade has no turbulence model (icoFoamYade.C:79-85 is laplacian(nu, U))");
-            if (!(c->les_ck > 0 && c->les_ce > 0 && c->les_delta_coeff > 0) || c->nut_initial < 0) return fail(FY_ERR_INVALID, "fy_solver_create: Smagorinsky needs Ck, Ce, deltaCoeff > 0 and nut >= 0");
-            for (int q = 0; q < 6; ++q) {
-                const bool has_k = c->turbulence_model == FY_TURBULENCE_KEQN || c->turbulence_model == FY_TURBULENCE_KEPSILON;
-                if (c->nut_bc[q] != FY_BC_NUT_ZERO_GRADIENT && c->nut_bc[q] != FY_BC_NUT_FIXED_VALUE && !((c->nut_bc[q] == FY_BC_WALL_FUNCTION || c->nut_bc[q] == FY_BC_NUT_CALCULATED) && has_k))
-                    return fail(FY_ERR_INVALID, "fy_solver_create: unknown nut boundary type (nutkWallFunction / calculated need a model with a k equation)");
-                g.nut_bc[q] = c->nut_bc[q]; g.nut_val[q] = c->nut_value[q];
-            }
-            les_delta = c->les_delta_coeff * std::pow(g.V, 1.0 / 3.0);
-            {   // nutWallFunction::yPlusLam [OF-6 nutWallFunctionFvPatchScalarField.C]
-                if (!(c->wf_kappa > 0 && c->wf_E > 0)) return fail(FY_ERR_INVALID, "fy_solver_create: wall-function constants kappa, E must be positive");
-                double ypl = 11.0;
-                for (int it = 0; it < 10; ++it) ypl = std::log(std::max(c->wf_E * ypl, 1.0)) / c->wf_kappa;
-                g.wf_yPlusLam = ypl; g.wf_kappa = c->wf_kappa; g.wf_E = c->wf_E; g.wf_cmu25 = std::pow(c->ras_cmu, 0.25);
-                g.nut_wall_live = 0;
-                g.turb_model = c->turbulence_model; g.turb_ck = c->les_ck; g.turb_cmu = c->ras_cmu; g.turb_delta = les_delta; g.turb_dcoeff = c->les_delta_coeff;
-                for (int q = 0; q < 6; ++q) {
-                    g.k_bc[q] = c->k_bc[q]; g.k_val[q] = c->k_value[q];
-                    g.eps_bc[q] = c->eps_bc[q] == FY_BC_NUT_FIXED_VALUE ? 1 : 0; g.eps_val[q] = c->eps_value[q];
-                }
-            }
-            const bool keqn = c->turbulence_model == FY_TURBULENCE_KEQN, keps = c->turbulence_model == FY_TURBULENCE_KEPSILON;
-            if (keqn || keps) {
-                if (!(c->k_initial >= 0) || (keps && !(c->k_initial > 0)) || !(c->k_tol >= 0) || c->k_max_iter < 0 || c->k_relax > 1) return fail(FY_ERR_INVALID, "fy_solver_create: the k equation needs k >= 0 (> 0 for kEpsilon), a solver tolerance and a relaxation factor in (0, 1]");
-                if (c->k_convection_scheme != FY_CONVECTION_LINEAR && c->k_convection_scheme != FY_CONVECTION_UPWIND) return fail(FY_ERR_UNSUPPORTED, "fy_solver_create: div(alphaPhic,k) must be Gauss linear or Gauss upwind");
-                eq_k.mode = keqn ? 0 : 2;
-                eq_k.ck = c->les_ck; eq_k.ce = c->les_ce; eq_k.delta = les_delta; eq_k.xmin = 1e-15;        // kMin_ = small [OF-6 LESModel.C, RASModel.C]
-                eq_k.c1 = c->ras_c1; eq_k.c2 = c->ras_c2; eq_k.c3 = c->ras_c3; eq_k.sigma = keqn ? 1.0 : c->ras_sigmak;
-                eq_k.relax = c->k_relax; eq_k.upwind = c->k_convection_scheme == FY_CONVECTION_UPWIND ? 1 : 0;
-                for (int q = 0; q < 6; ++q) {
-                    if (c->k_bc[q] != FY_BC_NUT_ZERO_GRADIENT && c->k_bc[q] != FY_BC_NUT_FIXED_VALUE) return fail(FY_ERR_INVALID, "fy_solver_create: unknown k boundary type");
-                    eq_k.bc[q] = c->k_bc[q]; eq_k.val[q] = c->k_value[q];
-                }
-            }
-            if (keps) {
-                if (!(c->eps_initial > 0) || !(c->eps_tol >= 0) || c->eps_max_iter < 0 || c->eps_relax > 1 || !(c->ras_cmu > 0 && c->ras_sigmak > 0 && c->ras_sigmaeps > 0))
-                    return fail(FY_ERR_INVALID, "fy_solver_create: kEpsilon needs epsilon > 0, Cmu / sigmak / sigmaEps > 0, a solver tolerance and a relaxation factor in (0, 1]");
-                if (c->eps_convection_scheme != FY_CONVECTION_LINEAR && c->eps_convection_scheme != FY_CONVECTION_UPWIND) return fail(FY_ERR_UNSUPPORTED, "fy_solver_create: div(alphaPhic,epsilon) must be Gauss linear or Gauss upwind");
-                eq_eps = eq_k;
-                eq_eps.mode = 1; eq_eps.sigma = c->ras_sigmaeps; eq_eps.xmin = 1e-15;                        // epsilonMin_ = small [OF-6 RASModel.C]
-                eq_eps.relax = c->eps_relax; eq_eps.upwind = c->eps_convection_scheme == FY_CONVECTION_UPWIND ? 1 : 0;
-                for (int q = 0; q < 6; ++q) {
-                    if (c->eps_bc[q] != FY_BC_NUT_ZERO_GRADIENT && c->eps_bc[q] != FY_BC_NUT_FIXED_VALUE && c->eps_bc[q] != FY_BC_WALL_FUNCTION) return fail(FY_ERR_INVALID, "fy_solver_create: unknown epsilon boundary type");
-                    // an epsilonWallFunction patch behaves like a zero-gradient one wherever its face value would be asked for: the wall cells' rows are imposed
-                    eq_eps.bc[q] = c->eps_bc[q] == FY_BC_WALL_FUNCTION ? 0 : c->eps_bc[q]; eq_eps.val[q] = c->eps_value[q];
-                    eq_eps.wall[q] = eq_k.wall[q] = c->eps_bc[q] == FY_BC_WALL_FUNCTION ? 1 : 0;
-                }
-                eq_eps.cmu75 = eq_k.cmu75 = std::pow(c->ras_cmu, 0.75); eq_eps.cmu25 = eq_k.cmu25 = std::pow(c->ras_cmu, 0.25); eq_eps.kappa = eq_k.kappa = c->wf_kappa;
-            }
-        }
-        if (c->adjust_time_step && !(c->max_co > 0 && c->max_delta_t > 0)) return fail(FY_ERR_INVALID, "adjustTimeStep needs maxCo > 0 and maxDeltaT > 0");
-        if (c->u_relax > 1 || c->u_relax_final > 1 || c->p_relax > 1 || c->p_relax_final > 1) return fail(FY_ERR_INVALID, "relaxation factors lie in (0, 1]");
-        if (need_ref) {
-            // adjustPhi (icoFoamYade.C:108, pEqn.H:13-16) acts when no patch fixes the pressure.  It is the identity when every patch fixes U
-            // and the prescribed normal velocities balance (closed boxes, cavities): nothing is launched then.  With fixed-value patches
-            // that do NOT balance and no patch to adjust, OpenFOAM stops at the first corrector; say so here.
-            double net = 0.0, mag = 0.0;
-            bool adjustable = false;
-            const double area[3] = {(double)c->ny * c->nz, (double)c->nx * c->nz, (double)c->nx * c->ny};
-            for (int q = 0; q < 6; ++q) {
-                if (c->u_bc[q] == FY_BC_U_SLIP) continue;                       // (carries no flux, and none to adjust)
-                if (c->u_bc[q] != FY_BC_U_FIXED_VALUE) { adjustable = true; continue; }
-                const double un = c->u_value[q][q / 2] * ((q & 1) ? 1.0 : -1.0) * area[q / 2];
-                net += un; mag += std::fabs(un);
-            }
-            if (!adjustable && std::fabs(net) > 1e-8 * (mag + 1e-300))
-                return fail(FY_ERR_UNSUPPORTED, "no patch fixes the pressure and the fixed-value velocity patches do not balance (net flux %g of %g): OpenFOAM's adjustPhi "
-                                                "ends such a run with 'Continuity error cannot be removed by adjusting the outflow'", net, mag);
-            adjust_phi = adjustable || mag > 0.0;
-        }
-
-        const size_t n = nstore;
-        DevBuf<double>* v3[] = {&U, &Uold, &uSource, &uParticle, &gradP, &divT, &ddtU, &src, &HbyA, &bmom, &divG, &xscr};
-        for (auto* b : v3) { FY_TRY(b->alloc_exact(3 * n)); FY_TRY(zero(*b)); }
-        DevBuf<double>* v1[] = {&p, &alpha, &uSourceDrag, &mdiag, &rAU, &prhs, &pr, &pw, &pp, &pzj};
-        for (auto* b : v1) { FY_TRY(b->alloc_exact(n)); FY_TRY(zero(*b)); }
-        for (auto& b : man) { FY_TRY(b.alloc_exact(n)); FY_TRY(zero(b)); }
-        for (int q = 0; q < 6; ++q) if (c->u_bc[q] == FY_BC_U_SLIP && !mbd.p) { FY_TRY(mbd.alloc_exact(3 * n)); FY_TRY(zero(mbd)); }
-        FY_TRY(vGrad.alloc_exact(9 * n)); FY_TRY(zero(vGrad));
-        if (c->convection_scheme >= FY_CONVECTION_LIMITED_LINEAR) { FY_TRY(gradL.alloc_exact(3 * n)); FY_TRY(zero(gradL)); }
-        if (c->turbulence_model != FY_TURBULENCE_LAMINAR) { FY_TRY(nut.alloc_exact(n)); FY_TRY(launch_fill_f64(stream, nut.p, n, c->nut_initial)); g.nut = nut.p; }
-        if (c->turbulence_model == FY_TURBULENCE_KEQN || c->turbulence_model == FY_TURBULENCE_KEPSILON) { FY_TRY(kturb.alloc_exact(n)); FY_TRY(launch_fill_f64(stream, kturb.p, n, c->k_initial)); g.kturb = kturb.p; }
-        if (c->turbulence_model == FY_TURBULENCE_KEPSILON) { FY_TRY(epsturb.alloc_exact(n)); FY_TRY(launch_fill_f64(stream, epsturb.p, n, c->eps_initial)); g.epsturb = epsturb.p; }
-        FY_TRY(Gt.alloc_exact(9 * n)); FY_TRY(zero(Gt));
-        for (int d = 0; d < 3; ++d) {
-            DevBuf<double>* fs[] = {&phi[d], &phiOld[d], &psn[d], &alphaf[d], &phiHbyA[d], &phiForces[d], &rAUf[d], &pflux[d], &ddtc[d]};
-            for (auto* b : fs) { FY_TRY(b->alloc_exact(fv_fsize(g, d))); FY_TRY(zero(*b)); }
-            FY_TRY(launch_fill_f64(stream, alphaf[d].p, alphaf[d].n, 1.0));
-        }
-        FY_TRY(launch_fill_f64(stream, alpha.p, n, 1.0));
-        FY_TRY(launch_fill_f64(stream, rAU.p, n, 1.0));            // ghost planes must hold finite values before the first exchange
-        FY_TRY(partials.alloc_exact(8 * (size_t)red_blocks(Nc))); FY_TRY(red_out.alloc_exact(8)); FY_TRY(sc.alloc_exact(4)); FY_TRY(xbar3.alloc_exact(3));
-        FY_TRY(zero(partials)); FY_TRY(zero(sc)); FY_TRY(zero(red_out));
-        if (adjust_phi) { FY_TRY(adj_sums.alloc_exact(4)); FY_TRY(adj_err.alloc_exact(1)); FY_HIP(hipMemsetAsync(adj_err.p, 0, sizeof(int), stream)); }
-        if (hipHostMalloc((void**)&red_host, (kDeferBase + kDeferMax) * sizeof(double), hipHostMallocMapped) == hipSuccess) {
-            if (hipHostGetDevicePointer((void**)&red_host_dev, red_host, 0) != hipSuccess) { (void)hipHostFree(red_host); red_host = nullptr; }
-        } else {
-            red_host = nullptr;              // fall back to the copy path
-        }
-        if (red_host && hipHostMalloc((void**)&red_flag, 8 * sizeof(unsigned long long), hipHostMallocMapped) == hipSuccess) {
-            for (int q = 0; q < 8; ++q) red_flag[q] = 0;
-            if (hipHostGetDevicePointer((void**)&red_flag_dev, red_flag, 0) != hipSuccess) { (void)hipHostFree(red_flag); red_flag = nullptr; }
-        } else {
-            red_flag = nullptr;
-        }
-        FY_TRY(ops_courant.alloc_exact(2));
-        FY_TRY(ops_diag.alloc_exact(4));
-        { const int h4[4] = {0, 0, 1, 0}; FY_HIP(hipMemcpyAsync(ops_diag.p, h4, sizeof(h4), hipMemcpyHostToDevice, stream)); }
-        { const int h[2] = {1, 0}; FY_HIP(hipMemcpyAsync(ops_courant.p, h, sizeof(h), hipMemcpyHostToDevice, stream)); FY_HIP(hipStreamSynchronize(stream)); }
-
-        // ---- multigrid hierarchy: 2x2x2 aggregation down to <= kMgCoarsest cells.  With several slabs the levels whose aggregates
-        // stay inside a slab keep the slab layout (+1 ghost plane); from the first level with <= kMgReplicateBelow global cells (or
-        // whose parent has an odd plane count) on, the hierarchy is replicated on every rank.
-        {
-            int ax = g.nx, ay = g.ny, az_loc = g.nz, az_glob = c->nz;
-            bool dist = S > 1;
-            size_t lvl = 0;
-            mg_rep = (size_t)-1;
-            for (;;) {
-                std::unique_ptr<MgLev> L(new MgLev());
-                L->distributed = dist;
-                L->gz = dist ? (lvl == 0 ? g.gz : 1) : 0;       // level 0 shares the layout of the solver's cell vectors (p, r, ...)
-                L->plane = (size_t)ax * ay;
-                const int nzv = dist ? az_loc : az_glob;
-                L->A.nx = ax; L->A.ny = ay; L->A.nz = nzv; L->A.N = (int)(L->plane * nzv);
-                L->A.c0 = (int)(L->plane * L->gz); L->A.ntot = (int)(L->plane * (nzv + 2 * L->gz));
-                const size_t m = (size_t)L->A.ntot;
-                DevBuf<double>* bs[] = {&L->diag, &L->ux, &L->uy, &L->uz, &L->x0, &L->x1, &L->b};
-                for (auto* b : bs) { FY_TRY(b->alloc_exact(m)); FY_TRY(zero(*b)); }
-                FY_TRY(launch_fill_f64(stream, L->diag.p, m, 1.0));          // never divide by an unset ghost diagonal
-                L->A.diag = L->diag.p; L->A.ux = L->ux.p; L->A.uy = L->uy.p; L->A.uz = L->uz.p;
-                L->xcur = L->x0.p; L->xalt = L->x1.p; L->bptr = L->b.p;
-                const int64_t Ng = (int64_t)L->plane * az_glob;
-                if (!dist && mg_rep == (size_t)-1 && S > 1) mg_rep = lvl;
-                mg.push_back(std::move(L));
-                if (cs.p_solver != FY_PSOLVER_PCG_MG) break;
-                // the coarsest level is "solved" by 40 damped-Jacobi sweeps, which settles modes up to a few cells long: an elongated coarse grid
-                // (3 x 3 x 20 under a 160 x 160 x 1280 column) would keep its longest modes and the V-cycle would lose its grip on tall
-                // domains (PCG iterations per step 2.6 / 4.4 / 4.6 / 6.4 for 1 / 2 / 4 / 8 stacked C3 boxes) -- so coarsening also goes on
-                // while any edge is longer than kMgCoarsestEdge cells
-                if ((Ng <= kMgCoarsest && std::max(std::max(ax, ay), az_glob) <= kMgCoarsestEdge) || (ax <= 2 && ay <= 2 && az_glob <= 2)) break;
-                // next level
-                const int nax = (ax + 1) / 2, nay = (ay + 1) / 2, naz_glob = (az_glob + 1) / 2;
-                if (dist) {
-                    const int64_t nNg = (int64_t)nax * nay * naz_glob;
-                    if (az_loc % 2 != 0) return fail(FY_ERR_UNSUPPORTED, "slab plane count %d cannot be aggregated", az_loc);
-                    az_loc /= 2;                                         // the slice of the next level this rank's cells aggregate to
-                    if (az_loc % 2 != 0 || az_loc < 2 || nNg <= kMgReplicateBelow) dist = false;   // next level: replicated
-                }
-                ax = nax; ay = nay; az_glob = naz_glob;
-                ++lvl;
-            }
-            if (mg_rep == (size_t)-1) mg_rep = mg.size();
-            if (S > 1 && cs.p_solver == FY_PSOLVER_PCG_MG && mg_rep >= mg.size()) return fail(FY_ERR_UNSUPPORTED, "multigrid hierarchy never became replicable");
-            if (mg.back()->A.N > 1024 && cs.p_solver == FY_PSOLVER_PCG_MG) return fail(FY_ERR_UNSUPPORTED, "coarsest multigrid level too large");
-            if (mg_rep < mg.size()) FY_TRY(rep_stage.alloc_exact(4 * ((size_t)mg[mg_rep]->A.N / S + 8)));
-        }
-        for (auto& t : tim) FY_TRY(t.init());
-
-        // the coupling object shares the solver's device fields and stream (icoFoamYade.C:54, pimpleFoamYade.C:54); its tree spans
-        // the GLOBAL block (the improvement chain depends on the whole tree), its cell arrays are this slab's storage
-        {
-            const size_t ng = (size_t)Nglob;
-            std::vector<double> C(3 * ng), V(ng, g.V);
-            std::vector<double> fc[3];           // graded block: face planes per axis
-            fy_mesh_desc md{};
-            if (!g.graded) {
-                for (int k = 0; k < c->nz; ++k) for (int j = 0; j < g.ny; ++j) for (int i = 0; i < g.nx; ++i) {
-                    const size_t cc = (size_t)i + (size_t)g.nx * (j + (size_t)g.ny * k);
-                    C[3 * cc] = c->origin[0] + (i + 0.5) * c->dx; C[3 * cc + 1] = c->origin[1] + (j + 0.5) * c->dx; C[3 * cc + 2] = c->origin[2] + (k + 0.5) * c->dx;
-                }
-                md.bbox_max[0] = c->origin[0] + g.nx * c->dx; md.bbox_max[1] = c->origin[1] + g.ny * c->dx; md.bbox_max[2] = c->origin[2] + c->nz * c->dx;
-            } else {
-                for (int a = 0; a < 3; ++a) {
-                    fc[a].resize(h_host[a].size() + 1);
-                    fc[a][0] = c->origin[a];
-                    for (size_t q = 0; q < h_host[a].size(); ++q) fc[a][q + 1] = fc[a][q] + h_host[a][q];
-                    md.bbox_max[a] = fc[a].back();
-                }
-                for (int k = 0; k < c->nz; ++k) for (int j = 0; j < g.ny; ++j) for (int i = 0; i < g.nx; ++i) {
-                    const size_t cc = (size_t)i + (size_t)g.nx * (j + (size_t)g.ny * k);
-                    C[3 * cc] = 0.5 * (fc[0][i] + fc[0][i + 1]); C[3 * cc + 1] = 0.5 * (fc[1][j] + fc[1][j + 1]); C[3 * cc + 2] = 0.5 * (fc[2][k] + fc[2][k + 1]);
-                    V[cc] = (h_host[0][i] * h_host[1][j]) * h_host[2][k];
-                }
-                md.xf = fc[0].data(); md.yf = fc[1].data(); md.zf = fc[2].data();
-            }
-            md.n_cells = (int32_t)Nglob; md.centres = C.data(); md.volumes = V.data();
-            md.nx = g.nx; md.ny = g.ny; md.nz = c->nz; md.dx = g.dx;
-            for (int a = 0; a < 3; ++a) { md.origin[a] = c->origin[a]; md.bbox_min[a] = c->origin[a]; }
-            fy_field_ptrs fp{};
-            fp.location = FY_MEM_DEVICE;
-            fp.U = U.p; fp.gradP = gradP.p; fp.vGrad = vGrad.p; fp.divT = divT.p; fp.ddtU = ddtU.p;
-            for (int a = 0; a < 3; ++a) fp.g[a] = c->g[a];
-            fp.uSourceDrag = uSourceDrag.p; fp.alpha = alpha.p; fp.uSource = uSource.p; fp.uParticle = uParticle.p;
-            cpl = new (std::nothrow) fy_ctx();
-            if (!cpl) return fail(FY_ERR_INVALID, "out of host memory");
-            cpl->c.ext_stream = stream;
-            if (S > 1) {
-                cpl->c.slab.active = true; cpl->c.slab.comm = comm; cpl->c.slab.gz = gz; cpl->c.slab.nz = nzl; cpl->c.slab.plane = plane;
-                cpl->c.slab.n_store = nstore; cpl->c.slab.base = ((int64_t)g.kglob0 - gz) * (int64_t)plane;
-                cpl->c.slab.kglob0 = g.kglob0; cpl->c.slab.nzglob = g.nzglob;
-            }
-            FY_TRY(cpl->c.create(&md, &fp, pimple ? 1 : 0, tr, device));      // gaussianInterp: false for ico, true for pimple (icoFoamYade.C:53, pimpleFoamYade.C:53)
-            cpl->c.rhoP = c->rho_particle; cpl->c.rhoF = c->rho_fluid; cpl->c.nu = c->nu;   // setScalarProperties (icoFoamYade.C:55)
-        }
-        FY_TRY(halo_cells(U, 3, 1));
-        FY_TRY(FVK(launch_flux_of, stream, g, U.p, F3(phi)));                     // createPhi
         FY_HIP(hipStreamSynchronize(stream));
-        return FY_OK;
+        g.graded = 1;
+        g.dx = std::cbrt((h_host[0][0] * h_host[1][0]) * h_host[2][0]);       // (only what still assumes cubes reads it: nothing on this path)
+        g.Af = g.dx * g.dx; g.V = g.dx * g.dx * g.dx;
+        total_volume = (len[0] * len[1]) * len[2];
+    }
+    g.upwind = c->convection_scheme;          // 0 linear, 1 upwind, 2 linearUpwind, 3 .. 8 limited
+    g.lim_twoByk = 2.0 / std::max(c->convection_limiter_k, 1e-15);
+    g.rdx = 1.0 / g.dx; g.rhdx = 1.0 / (0.5 * g.dx); g.rV = 1.0 / g.V;
+    g.pimple = pimple ? 1 : 0; g.dt = c->dt; g.nu = c->nu;
+    bool need_ref = true;
+    for (int q = 0; q < 6; ++q) {
+        if (c->u_bc[q] != FY_BC_U_FIXED_VALUE && c->u_bc[q] != FY_BC_U_ZERO_GRADIENT && c->u_bc[q] != FY_BC_U_SLIP) return fail(FY_ERR_INVALID, "fy_solver_create: unknown velocity boundary type %d on side %d", c->u_bc[q], q);
+        if (c->p_bc[q] != FY_BC_P_ZERO_GRADIENT && c->p_bc[q] != FY_BC_P_FIXED_VALUE && c->p_bc[q] != FY_BC_P_FIXED_FLUX) return fail(FY_ERR_INVALID, "fy_solver_create: unknown pressure boundary type %d on side %d", c->p_bc[q], q);
+        g.u_bc[q] = c->u_bc[q]; g.p_bc[q] = c->p_bc[q]; g.p_val[q] = c->p_value[q];
+        for (int a = 0; a < 3; ++a) g.u_val[q][a] = c->u_value[q][a];
+        if (c->p_bc[q] == FY_BC_P_FIXED_VALUE) need_ref = false;
+    }
+    for (int a = 0; a < 3; ++a) g.g[a] = c->g[a];
+    g.need_ref = need_ref ? 1 : 0; g.p_ref_cell = c->p_ref_cell; g.p_ref_value = c->p_ref_value;
+    g.u_relax = c->u_relax;
+    if (c->turbulence_model != FY_TURBULENCE_LAMINAR && c->turbulence_model != FY_TURBULENCE_SMAGORINSKY && c->turbulence_model != FY_TURBULENCE_KEQN && c->turbulence_model != FY_TURBULENCE_KEPSILON) return fail(FY_ERR_UNSUPPORTED, "fy_solver_create: unknown turbulence_model %d (DPMTurbulenceModels.C:67-77: laminar Stokes, RAS kEpsilon, LES Smagorinsky, LES kEqn)", c->turbulence_model);
+    if (c->turbulence_model != FY_TURBULENCE_LAMINAR) {
+        if (!pimple) return fail(FY_ERR_INVALID, "fy_solver_create: icoFoamYade has no turbulence model (icoFoamYade.C:79-85 is laplacian(nu, U))");
+        if (!(c->les_ck > 0 && c->les_ce > 0 && c->les_delta_coeff > 0) || c->nut_initial < 0) return fail(FY_ERR_INVALID, "fy_solver_create: Smagorinsky needs Ck, Ce, deltaCoeff > 0 and nut >= 0");
+        for (int q = 0; q < 6; ++q) {
+            const bool has_k = c->turbulence_model == FY_TURBULENCE_KEQN || c->turbulence_model == FY_TURBULENCE_KEPSILON;
+            if (c->nut_bc[q] != FY_BC_NUT_ZERO_GRADIENT && c->nut_bc[q] != FY_BC_NUT_FIXED_VALUE && !((c->nut_bc[q] == FY_BC_WALL_FUNCTION || c->nut_bc[q] == FY_BC_NUT_CALCULATED) && has_k))
+                return fail(FY_ERR_INVALID, "fy_solver_create: unknown nut boundary type (nutkWallFunction / calculated need a model with a k equation)");
+            g.nut_bc[q] = c->nut_bc[q]; g.nut_val[q] = c->nut_value[q];
+        }
+        les_delta = c->les_delta_coeff * std::pow(g.V, 1.0 / 3.0);
+        {   // nutWallFunction::yPlusLam [OF-6 nutWallFunctionFvPatchScalarField.C]
+            if (!(c->wf_kappa > 0 && c->wf_E > 0)) return fail(FY_ERR_INVALID, "fy_solver_create: wall-function constants kappa, E must be positive");
+            double ypl = 11.0;
+            for (int it = 0; it < 10; ++it) ypl = std::log(std::max(c->wf_E * ypl, 1.0)) / c->wf_kappa;
+            g.wf_yPlusLam = ypl; g.wf_kappa = c->wf_kappa; g.wf_E = c->wf_E; g.wf_cmu25 = std::pow(c->ras_cmu, 0.25);
+            g.nut_wall_live = 0;
+            g.turb_model = c->turbulence_model; g.turb_ck = c->les_ck; g.turb_cmu = c->ras_cmu; g.turb_delta = les_delta; g.turb_dcoeff = c->les_delta_coeff;
+            for (int q = 0; q < 6; ++q) {
+                g.k_bc[q] = c->k_bc[q]; g.k_val[q] = c->k_value[q];
+                g.eps_bc[q] = c->eps_bc[q] == FY_BC_NUT_FIXED_VALUE ? 1 : 0; g.eps_val[q] = c->eps_value[q];
+            }
+        }
+        const bool keqn = c->turbulence_model == FY_TURBULENCE_KEQN, keps = c->turbulence_model == FY_TURBULENCE_KEPSILON;
+        if (keqn || keps) {
+            if (!(c->k_initial >= 0) || (keps && !(c->k_initial > 0)) || !(c->k_tol >= 0) || c->k_max_iter < 0 || c->k_relax > 1) return fail(FY_ERR_INVALID, "fy_solver_create: the k equation needs k >= 0 (> 0 for kEpsilon), a solver tolerance and a relaxation factor in (0, 1]");
+            if (c->k_convection_scheme != FY_CONVECTION_LINEAR && c->k_convection_scheme != FY_CONVECTION_UPWIND) return fail(FY_ERR_UNSUPPORTED, "fy_solver_create: div(alphaPhic,k) must be Gauss linear or Gauss upwind");
+            eq_k.mode = keqn ? 0 : 2;
+            eq_k.ck = c->les_ck; eq_k.ce = c->les_ce; eq_k.delta = les_delta; eq_k.xmin = 1e-15;        // kMin_ = small [OF-6 LESModel.C, RASModel.C]
+            eq_k.c1 = c->ras_c1; eq_k.c2 = c->ras_c2; eq_k.c3 = c->ras_c3; eq_k.sigma = keqn ? 1.0 : c->ras_sigmak;
+            eq_k.relax = c->k_relax; eq_k.upwind = c->k_convection_scheme == FY_CONVECTION_UPWIND ? 1 : 0;
+            for (int q = 0; q < 6; ++q) {
+                if (c->k_bc[q] != FY_BC_NUT_ZERO_GRADIENT && c->k_bc[q] != FY_BC_NUT_FIXED_VALUE) return fail(FY_ERR_INVALID, "fy_solver_create: unknown k boundary type");
+                eq_k.bc[q] = c->k_bc[q]; eq_k.val[q] = c->k_value[q];
+            }
+        }
+        if (keps) {
+            if (!(c->eps_initial > 0) || !(c->eps_tol >= 0) || c->eps_max_iter < 0 || c->eps_relax > 1 || !(c->ras_cmu > 0 && c->ras_sigmak > 0 && c->ras_sigmaeps > 0))
+                return fail(FY_ERR_INVALID, "fy_solver_create: kEpsilon needs epsilon > 0, Cmu / sigmak / sigmaEps > 0, a solver tolerance and a relaxation factor in (0, 1]");
+            if (c->eps_convection_scheme != FY_CONVECTION_LINEAR && c->eps_convection_scheme != FY_CONVECTION_UPWIND) return fail(FY_ERR_UNSUPPORTED, "fy_solver_create: div(alphaPhic,epsilon) must be Gauss linear or Gauss upwind");
+            eq_eps = eq_k;
+            eq_eps.mode = 1; eq_eps.sigma = c->ras_sigmaeps; eq_eps.xmin = 1e-15;                        // epsilonMin_ = small [OF-6 RASModel.C]
+            eq_eps.relax = c->eps_relax; eq_eps.upwind = c->eps_convection_scheme == FY_CONVECTION_UPWIND ? 1 : 0;
+            for (int q = 0; q < 6; ++q) {
+                if (c->eps_bc[q] != FY_BC_NUT_ZERO_GRADIENT && c->eps_bc[q] != FY_BC_NUT_FIXED_VALUE && c->eps_bc[q] != FY_BC_WALL_FUNCTION) return fail(FY_ERR_INVALID, "fy_solver_create: unknown epsilon boundary type");
+                // an epsilonWallFunction patch behaves like a zero-gradient one wherever its face value would be asked for: the wall cells' rows are imposed
+                eq_eps.bc[q] = c->eps_bc[q] == FY_BC_WALL_FUNCTION ? 0 : c->eps_bc[q]; eq_eps.val[q] = c->eps_value[q];
+                eq_eps.wall[q] = eq_k.wall[q] = c->eps_bc[q] == FY_BC_WALL_FUNCTION ? 1 : 0;
+            }
+            eq_eps.cmu75 = eq_k.cmu75 = std::pow(c->ras_cmu, 0.75); eq_eps.cmu25 = eq_k.cmu25 = std::pow(c->ras_cmu, 0.25); eq_eps.kappa = eq_k.kappa = c->wf_kappa;
+        }
+    }
+    if (c->adjust_time_step && !(c->max_co > 0 && c->max_delta_t > 0)) return fail(FY_ERR_INVALID, "adjustTimeStep needs maxCo > 0 and maxDeltaT > 0");
+    if (c->u_relax > 1 || c->u_relax_final > 1 || c->p_relax > 1 || c->p_relax_final > 1) return fail(FY_ERR_INVALID, "relaxation factors lie in (0, 1]");
+    if (need_ref) {
+        // adjustPhi (icoFoamYade.C:108, pEqn.H:13-16) acts when no patch fixes the pressure.  It is the identity when every patch fixes U
+        // and the prescribed normal velocities balance (closed boxes, cavities): nothing is launched then.  With fixed-value patches
+        // that do NOT balance and no patch to adjust, OpenFOAM stops at the first corrector; say so here.
+        double net = 0.0, mag = 0.0;
+        bool adjustable = false;
+        const double area[3] = {(double)c->ny * c->nz, (double)c->nx * c->nz, (double)c->nx * c->ny};
+        for (int q = 0; q < 6; ++q) {
+            if (c->u_bc[q] == FY_BC_U_SLIP) continue;                       // (carries no flux, and none to adjust)
+            if (c->u_bc[q] != FY_BC_U_FIXED_VALUE) { adjustable = true; continue; }
+            const double un = c->u_value[q][q / 2] * ((q & 1) ? 1.0 : -1.0) * area[q / 2];
+            net += un; mag += std::fabs(un);
+        }
+        if (!adjustable && std::fabs(net) > 1e-8 * (mag + 1e-300))
+            return fail(FY_ERR_UNSUPPORTED, "no patch fixes the pressure and the fixed-value velocity patches do not balance (net flux %g of %g): OpenFOAM's adjustPhi "
+                                            "ends such a run with 'Continuity error cannot be removed by adjusting the outflow'", net, mag);
+        adjust_phi = adjustable || mag > 0.0;
     }
 
-    // fold the block partials, all-reduce over the slabs, read back
-    int reduce_read(int nslots, bool courant, double* h) {
-        if (comm->size == 1 && red_host) {
-            // single domain: the fold writes straight into mapped pinned host memory -- no device-to-host blit per read-back
-            if (red_flag && nslots <= 8) {
-                // spin on the flags the fold stores behind its results; everything enqueued before it has completed by then (in-order stream)
-                const unsigned long long seq = ++red_seq;
-                FY_TRY(launch_reduce_finalize(stream, partials.p, Nc, nslots, courant ? ops_courant.p : nullptr, red_host_dev, red_flag_dev, seq));
-                for (int q = 0; q < nslots; ++q) {
-                    unsigned long spins = 0;
-                    while (__atomic_load_n(&red_flag[q], __ATOMIC_ACQUIRE) != seq) {
-                        if ((++spins & 0xfffu) == 0) {                      // every 4096 polls: is the stream still alive?
-                            const hipError_t e = hipStreamQuery(stream);
-                            if (e == hipSuccess) { if (__atomic_load_n(&red_flag[q], __ATOMIC_ACQUIRE) == seq) break; return fail(FY_ERR_HIP, "reduction flag never arrived"); }
-                            if (e != hipErrorNotReady) return fail(FY_ERR_HIP, "stream failed while waiting for a reduction: %s", hipGetErrorString(e));
-                        }
-                    }
-                    h[q] = red_host[q];
-                }
-                return FY_OK;
+    const size_t n = nstore;
+    DevBuf<double>* v3[] = {&U, &Uold, &uSource, &uParticle, &gradP, &divT, &ddtU, &src, &HbyA, &bmom, &divG, &xscr};
+    for (auto* b : v3) { FY_TRY(b->alloc_exact(3 * n)); FY_TRY(zero(*b)); }
+    DevBuf<double>* v1[] = {&p, &alpha, &uSourceDrag, &mdiag, &rAU, &prhs, &pr, &pw, &pp, &pzj};
+    for (auto* b : v1) { FY_TRY(b->alloc_exact(n)); FY_TRY(zero(*b)); }
+    for (auto& b : man) { FY_TRY(b.alloc_exact(n)); FY_TRY(zero(b)); }
+    for (int q = 0; q < 6; ++q) if (c->u_bc[q] == FY_BC_U_SLIP && !mbd.p) { FY_TRY(mbd.alloc_exact(3 * n)); FY_TRY(zero(mbd)); }
+    FY_TRY(vGrad.alloc_exact(9 * n)); FY_TRY(zero(vGrad));
+    if (c->convection_scheme >= FY_CONVECTION_LIMITED_LINEAR) { FY_TRY(gradL.alloc_exact(3 * n)); FY_TRY(zero(gradL)); }
+    if (c->turbulence_model != FY_TURBULENCE_LAMINAR) { FY_TRY(nut.alloc_exact(n)); FY_TRY(launch_fill_f64(stream, nut.p, n, c->nut_initial)); g.nut = nut.p; }
+    if (c->turbulence_model == FY_TURBULENCE_KEQN || c->turbulence_model == FY_TURBULENCE_KEPSILON) { FY_TRY(kturb.alloc_exact(n)); FY_TRY(launch_fill_f64(stream, kturb.p, n, c->k_initial)); g.kturb = kturb.p; }
+    if (c->turbulence_model == FY_TURBULENCE_KEPSILON) { FY_TRY(epsturb.alloc_exact(n)); FY_TRY(launch_fill_f64(stream, epsturb.p, n, c->eps_initial)); g.epsturb = epsturb.p; }
+    FY_TRY(Gt.alloc_exact(9 * n)); FY_TRY(zero(Gt));
+    for (int d = 0; d < 3; ++d) {
+        DevBuf<double>* fs[] = {&phi[d], &phiOld[d], &psn[d], &alphaf[d], &phiHbyA[d], &phiForces[d], &rAUf[d], &pflux[d], &ddtc[d]};
+        for (auto* b : fs) { FY_TRY(b->alloc_exact(fv_fsize(g, d))); FY_TRY(zero(*b)); }
+        FY_TRY(launch_fill_f64(stream, alphaf[d].p, alphaf[d].n, 1.0));
+    }
+    FY_TRY(launch_fill_f64(stream, alpha.p, n, 1.0));
+    FY_TRY(launch_fill_f64(stream, rAU.p, n, 1.0));            // ghost planes must hold finite values before the first exchange
+    FY_TRY(partials.alloc_exact(8 * (size_t)red_blocks(Nc))); FY_TRY(red_out.alloc_exact(8)); FY_TRY(sc.alloc_exact(4)); FY_TRY(xbar3.alloc_exact(3));
+    FY_TRY(zero(partials)); FY_TRY(zero(sc)); FY_TRY(zero(red_out));
+    if (adjust_phi) { FY_TRY(adj_sums.alloc_exact(4)); FY_TRY(adj_err.alloc_exact(1)); FY_HIP(hipMemsetAsync(adj_err.p, 0, sizeof(int), stream)); }
+    if (hipHostMalloc((void**)&red_host, (kDeferBase + kDeferMax) * sizeof(double), hipHostMallocMapped) == hipSuccess) {
+        if (hipHostGetDevicePointer((void**)&red_host_dev, red_host, 0) != hipSuccess) { (void)hipHostFree(red_host); red_host = nullptr; }
+    } else {
+        red_host = nullptr;              // fall back to the copy path
+    }
+    if (red_host && hipHostMalloc((void**)&red_flag, 8 * sizeof(unsigned long long), hipHostMallocMapped) == hipSuccess) {
+        for (int q = 0; q < 8; ++q) red_flag[q] = 0;
+        if (hipHostGetDevicePointer((void**)&red_flag_dev, red_flag, 0) != hipSuccess) { (void)hipHostFree(red_flag); red_flag = nullptr; }
+    } else {
+        red_flag = nullptr;
+    }
+    FY_TRY(ops_courant.alloc_exact(2));
+    FY_TRY(ops_diag.alloc_exact(4));
+    { const int h4[4] = {0, 0, 1, 0}; FY_HIP(hipMemcpyAsync(ops_diag.p, h4, sizeof(h4), hipMemcpyHostToDevice, stream)); }
+    { const int h[2] = {1, 0}; FY_HIP(hipMemcpyAsync(ops_courant.p, h, sizeof(h), hipMemcpyHostToDevice, stream)); FY_HIP(hipStreamSynchronize(stream)); }
+
+    // ---- multigrid hierarchy: 2x2x2 aggregation down to <= kMgCoarsest cells.  With several slabs the levels whose aggregates
+    // stay inside a slab keep the slab layout (+1 ghost plane); from the first level with <= kMgReplicateBelow global cells (or
+    // whose parent has an odd plane count) on, the hierarchy is replicated on every rank.
+    {
+        int ax = g.nx, ay = g.ny, az_loc = g.nz, az_glob = c->nz;
+        bool dist = S > 1;
+        size_t lvl = 0;
+        mg_rep = (size_t)-1;
+        for (;;) {
+            std::unique_ptr<MgLev> L(new MgLev());
+            L->distributed = dist;
+            L->gz = dist ? (lvl == 0 ? g.gz : 1) : 0;       // level 0 shares the layout of the solver's cell vectors (p, r, ...)
+            L->plane = (size_t)ax * ay;
+            const int nzv = dist ? az_loc : az_glob;
+            L->A.nx = ax; L->A.ny = ay; L->A.nz = nzv; L->A.N = (int)(L->plane * nzv);
+            L->A.c0 = (int)(L->plane * L->gz); L->A.ntot = (int)(L->plane * (nzv + 2 * L->gz));
+            const size_t m = (size_t)L->A.ntot;
+            DevBuf<double>* bs[] = {&L->diag, &L->ux, &L->uy, &L->uz, &L->x0, &L->x1, &L->b};
+            for (auto* b : bs) { FY_TRY(b->alloc_exact(m)); FY_TRY(zero(*b)); }
+            FY_TRY(launch_fill_f64(stream, L->diag.p, m, 1.0));          // never divide by an unset ghost diagonal
+            L->A.diag = L->diag.p; L->A.ux = L->ux.p; L->A.uy = L->uy.p; L->A.uz = L->uz.p;
+            L->xcur = L->x0.p; L->xalt = L->x1.p; L->bptr = L->b.p;
+            const int64_t Ng = (int64_t)L->plane * az_glob;
+            if (!dist && mg_rep == (size_t)-1 && S > 1) mg_rep = lvl;
+            mg.push_back(std::move(L));
+            if (cs.p_solver != FY_PSOLVER_PCG_MG) break;
+            // the coarsest level is "solved" by 40 damped-Jacobi sweeps, which settles modes up to a few cells long: an elongated coarse grid
+            // (3 x 3 x 20 under a 160 x 160 x 1280 column) would keep its longest modes and the V-cycle would lose its grip on tall
+            // domains (PCG iterations per step 2.6 / 4.4 / 4.6 / 6.4 for 1 / 2 / 4 / 8 stacked C3 boxes) -- so coarsening also goes on
+            // while any edge is longer than kMgCoarsestEdge cells
+            if ((Ng <= kMgCoarsest && std::max(std::max(ax, ay), az_glob) <= kMgCoarsestEdge) || (ax <= 2 && ay <= 2 && az_glob <= 2)) break;
+            // next level
+            const int nax = (ax + 1) / 2, nay = (ay + 1) / 2, naz_glob = (az_glob + 1) / 2;
+            if (dist) {
+                const int64_t nNg = (int64_t)nax * nay * naz_glob;
+                if (az_loc % 2 != 0) return fail(FY_ERR_UNSUPPORTED, "slab plane count %d cannot be aggregated", az_loc);
+                az_loc /= 2;                                         // the slice of the next level this rank's cells aggregate to
+                if (az_loc % 2 != 0 || az_loc < 2 || nNg <= kMgReplicateBelow) dist = false;   // next level: replicated
             }
-            FY_TRY(launch_reduce_finalize(stream, partials.p, Nc, nslots, courant ? ops_courant.p : nullptr, red_host_dev));
-            FY_HIP(hipStreamSynchronize(stream));
-            for (int q = 0; q < nslots; ++q) h[q] = red_host[q];
+            ax = nax; ay = nay; az_glob = naz_glob;
+            ++lvl;
+        }
+        if (mg_rep == (size_t)-1) mg_rep = mg.size();
+        if (S > 1 && cs.p_solver == FY_PSOLVER_PCG_MG && mg_rep >= mg.size()) return fail(FY_ERR_UNSUPPORTED, "multigrid hierarchy never became replicable");
+        if (mg.back()->A.N > 1024 && cs.p_solver == FY_PSOLVER_PCG_MG) return fail(FY_ERR_UNSUPPORTED, "coarsest multigrid level too large");
+        if (mg_rep < mg.size()) FY_TRY(rep_stage.alloc_exact(4 * ((size_t)mg[mg_rep]->A.N / S + 8)));
+    }
+    for (auto& t : tim) FY_TRY(t.init());
+
+    // the coupling object shares the solver's device fields and stream (icoFoamYade.C:54, pimpleFoamYade.C:54); its tree spans
+    // the GLOBAL block (the improvement chain depends on the whole tree), its cell arrays are this slab's storage
+    {
+        const size_t ng = (size_t)Nglob;
+        std::vector<double> C(3 * ng), V(ng, g.V);
+        std::vector<double> fc[3];           // graded block: face planes per axis
+        fy_mesh_desc md{};
+        if (!g.graded) {
+            for (int k = 0; k < c->nz; ++k) for (int j = 0; j < g.ny; ++j) for (int i = 0; i < g.nx; ++i) {
+                const size_t cc = (size_t)i + (size_t)g.nx * (j + (size_t)g.ny * k);
+                C[3 * cc] = c->origin[0] + (i + 0.5) * c->dx; C[3 * cc + 1] = c->origin[1] + (j + 0.5) * c->dx; C[3 * cc + 2] = c->origin[2] + (k + 0.5) * c->dx;
+            }
+            md.bbox_max[0] = c->origin[0] + g.nx * c->dx; md.bbox_max[1] = c->origin[1] + g.ny * c->dx; md.bbox_max[2] = c->origin[2] + c->nz * c->dx;
+        } else {
+            for (int a = 0; a < 3; ++a) {
+                fc[a].resize(h_host[a].size() + 1);
+                fc[a][0] = c->origin[a];
+                for (size_t q = 0; q < h_host[a].size(); ++q) fc[a][q + 1] = fc[a][q] + h_host[a][q];
+                md.bbox_max[a] = fc[a].back();
+            }
+            for (int k = 0; k < c->nz; ++k) for (int j = 0; j < g.ny; ++j) for (int i = 0; i < g.nx; ++i) {
+                const size_t cc = (size_t)i + (size_t)g.nx * (j + (size_t)g.ny * k);
+                C[3 * cc] = 0.5 * (fc[0][i] + fc[0][i + 1]); C[3 * cc + 1] = 0.5 * (fc[1][j] + fc[1][j + 1]); C[3 * cc + 2] = 0.5 * (fc[2][k] + fc[2][k + 1]);
+                V[cc] = (h_host[0][i] * h_host[1][j]) * h_host[2][k];
+            }
+            md.xf = fc[0].data(); md.yf = fc[1].data(); md.zf = fc[2].data();
+        }
+        md.n_cells = (int32_t)Nglob; md.centres = C.data(); md.volumes = V.data();
+        md.nx = g.nx; md.ny = g.ny; md.nz = c->nz; md.dx = g.dx;
+        for (int a = 0; a < 3; ++a) { md.origin[a] = c->origin[a]; md.bbox_min[a] = c->origin[a]; }
+        fy_field_ptrs fp{};
+        fp.location = FY_MEM_DEVICE;
+        fp.U = U.p; fp.gradP = gradP.p; fp.vGrad = vGrad.p; fp.divT = divT.p; fp.ddtU = ddtU.p;
+        for (int a = 0; a < 3; ++a) fp.g[a] = c->g[a];
+        fp.uSourceDrag = uSourceDrag.p; fp.alpha = alpha.p; fp.uSource = uSource.p; fp.uParticle = uParticle.p;
+        cpl = new (std::nothrow) fy_ctx();
+        if (!cpl) return fail(FY_ERR_INVALID, "out of host memory");
+        cpl->c.ext_stream = stream;
+        if (S > 1) {
+            cpl->c.slab.active = true; cpl->c.slab.comm = comm; cpl->c.slab.gz = gz; cpl->c.slab.nz = nzl; cpl->c.slab.plane = plane;
+            cpl->c.slab.n_store = nstore; cpl->c.slab.base = ((int64_t)g.kglob0 - gz) * (int64_t)plane;
+            cpl->c.slab.kglob0 = g.kglob0; cpl->c.slab.nzglob = g.nzglob;
+        }
+        FY_TRY(cpl->c.create(&md, &fp, pimple ? 1 : 0, tr, device));      // gaussianInterp: false for ico, true for pimple (icoFoamYade.C:53, pimpleFoamYade.C:53)
+        cpl->c.rhoP = c->rho_particle; cpl->c.rhoF = c->rho_fluid; cpl->c.nu = c->nu;   // setScalarProperties (icoFoamYade.C:55)
+    }
+    FY_TRY(halo_cells(U, 3, 1));
+    FY_TRY(FVK(launch_flux_of, stream, g, U.p, F3(phi)));                     // createPhi
+    FY_HIP(hipStreamSynchronize(stream));
+    return FY_OK;
+}
+
+// fold the block partials, all-reduce over the slabs, read back
+int Solver::reduce_read(int nslots, bool courant, double* h) {
+    if (comm->size == 1 && red_host) {
+        // single domain: the fold writes straight into mapped pinned host memory -- no device-to-host blit per read-back
+        if (red_flag && nslots <= 8) {
+            // spin on the flags the fold stores behind its results; everything enqueued before it has completed by then (in-order stream)
+            const unsigned long long seq = ++red_seq;
+            FY_TRY(launch_reduce_finalize(stream, partials.p, Nc, nslots, courant ? ops_courant.p : nullptr, red_host_dev, red_flag_dev, seq));
+            for (int q = 0; q < nslots; ++q) {
+                unsigned long spins = 0;
+                while (__atomic_load_n(&red_flag[q], __ATOMIC_ACQUIRE) != seq) {
+                    if ((++spins & 0xfffu) == 0) {                      // every 4096 polls: is the stream still alive?
+                        const hipError_t e = hipStreamQuery(stream);
+                        if (e == hipSuccess) { if (__atomic_load_n(&red_flag[q], __ATOMIC_ACQUIRE) == seq) break; return fail(FY_ERR_HIP, "reduction flag never arrived"); }
+                        if (e != hipErrorNotReady) return fail(FY_ERR_HIP, "stream failed while waiting for a reduction: %s", hipGetErrorString(e));
+                    }
+                }
+                h[q] = red_host[q];
+            }
             return FY_OK;
         }
-        FY_TRY(launch_reduce_finalize(stream, partials.p, Nc, nslots, courant ? ops_courant.p : nullptr, red_out.p));
-        if (courant) { FY_TRY(comm->allreduce(stream, red_out.p, 1, true)); FY_TRY(comm->allreduce(stream, red_out.p + 1, 1, false)); }
-        else FY_TRY(comm->allreduce(stream, red_out.p, nslots, false));
-        double* land = (red_host && nslots <= 8) ? red_host : h;          // pinned landing zone: a pageable destination makes the copy a staged, blocking one
-        FY_HIP(hipMemcpyAsync(land, red_out.p, nslots * sizeof(double), hipMemcpyDeviceToHost, stream));
+        FY_TRY(launch_reduce_finalize(stream, partials.p, Nc, nslots, courant ? ops_courant.p : nullptr, red_host_dev));
         FY_HIP(hipStreamSynchronize(stream));
-        if (land != h) for (int q = 0; q < nslots; ++q) h[q] = land[q];
+        for (int q = 0; q < nslots; ++q) h[q] = red_host[q];
         return FY_OK;
     }
-    // Diagnostics nobody branches on (Courant number, continuity errors): same fold [+ all-reduce], but the values land in their own
-    // slots of the pinned buffer and are read after the step's final synchronisation instead of stalling the stream here.
-    // Returns false when there is no slot left (the caller then reads at once).
-    static constexpr int kDeferBase = 8, kDeferMax = 2 + 4 * 255; // red_host: 8 immediate doubles + Courant + 255 correctors' continuity errors
-    int n_deferred = 0;
-    bool reduce_deferred(int nslots, bool courant, int* slot, int* rc, const int* ops = nullptr) {      // ops: ops_diag.p (sum, sum, max, sum) or none
-        *rc = FY_OK;
-        if (!red_host || n_deferred + nslots > kDeferMax) return false;
-        *slot = kDeferBase + n_deferred;
-        n_deferred += nslots;
-        if (comm->size == 1) {
-            *rc = launch_reduce_finalize(stream, partials.p, Nc, nslots, ops ? ops : (courant ? ops_courant.p : nullptr), red_host_dev + *slot);
-            return true;
-        }
-        *rc = launch_reduce_finalize(stream, partials.p, Nc, nslots, ops ? ops : (courant ? ops_courant.p : nullptr), red_out.p);
-        if (*rc == FY_OK) {
-            if (ops) {                       // the four diagnostics of k_U_correct<true>: sum, sum, max, sum
-                *rc = comm->allreduce(stream, red_out.p, 2, false);
-                if (*rc == FY_OK) *rc = comm->allreduce(stream, red_out.p + 2, 1, true);
-                if (*rc == FY_OK) *rc = comm->allreduce(stream, red_out.p + 3, 1, false);
-            }
-            else if (courant) { *rc = comm->allreduce(stream, red_out.p, 1, true); if (*rc == FY_OK) *rc = comm->allreduce(stream, red_out.p + 1, 1, false); }
-            else *rc = comm->allreduce(stream, red_out.p, nslots, false);
-        }
-        if (*rc == FY_OK && hipMemcpyAsync(red_host + *slot, red_out.p, nslots * sizeof(double), hipMemcpyDeviceToHost, stream) != hipSuccess)
-            *rc = fail(FY_ERR_HIP, "deferred read-back failed");
+    FY_TRY(launch_reduce_finalize(stream, partials.p, Nc, nslots, courant ? ops_courant.p : nullptr, red_out.p));
+    if (courant) { FY_TRY(comm->allreduce(stream, red_out.p, 1, true)); FY_TRY(comm->allreduce(stream, red_out.p + 1, 1, false)); }
+    else FY_TRY(comm->allreduce(stream, red_out.p, nslots, false));
+    double* land = (red_host && nslots <= 8) ? red_host : h;          // pinned landing zone: a pageable destination makes the copy a staged, blocking one
+    FY_HIP(hipMemcpyAsync(land, red_out.p, nslots * sizeof(double), hipMemcpyDeviceToHost, stream));
+    FY_HIP(hipStreamSynchronize(stream));
+    if (land != h) for (int q = 0; q < nslots; ++q) h[q] = land[q];
+    return FY_OK;
+}
+bool Solver::reduce_deferred(int nslots, bool courant, int* slot, int* rc, const int* ops) {      // ops: ops_diag.p (sum, sum, max, sum) or none
+    *rc = FY_OK;
+    if (!red_host || n_deferred + nslots > kDeferMax) return false;
+    *slot = kDeferBase + n_deferred;
+    n_deferred += nslots;
+    if (comm->size == 1) {
+        *rc = launch_reduce_finalize(stream, partials.p, Nc, nslots, ops ? ops : (courant ? ops_courant.p : nullptr), red_host_dev + *slot);
         return true;
     }
-    int reduce_to_device(double* dst) {          // one slot, stays on the device (PCG scalars)
-        FY_TRY(launch_reduce_finalize(stream, partials.p, Nc, 1, nullptr, dst));
-        return comm->allreduce(stream, dst, 1, false);
+    *rc = launch_reduce_finalize(stream, partials.p, Nc, nslots, ops ? ops : (courant ? ops_courant.p : nullptr), red_out.p);
+    if (*rc == FY_OK) {
+        if (ops) {                       // the four diagnostics of k_U_correct<true>: sum, sum, max, sum
+            *rc = comm->allreduce(stream, red_out.p, 2, false);
+            if (*rc == FY_OK) *rc = comm->allreduce(stream, red_out.p + 2, 1, true);
+            if (*rc == FY_OK) *rc = comm->allreduce(stream, red_out.p + 3, 1, false);
+        }
+        else if (courant) { *rc = comm->allreduce(stream, red_out.p, 1, true); if (*rc == FY_OK) *rc = comm->allreduce(stream, red_out.p + 1, 1, false); }
+        else *rc = comm->allreduce(stream, red_out.p, nslots, false);
     }
+    if (*rc == FY_OK && hipMemcpyAsync(red_host + *slot, red_out.p, nslots * sizeof(double), hipMemcpyDeviceToHost, stream) != hipSuccess)
+        *rc = fail(FY_ERR_HIP, "deferred read-back failed");
+    return true;
+}
+int Solver::reduce_to_device(double* dst) {          // one slot, stays on the device (PCG scalars)
+    FY_TRY(launch_reduce_finalize(stream, partials.p, Nc, 1, nullptr, dst));
+    return comm->allreduce(stream, dst, 1, false);
+}
 
-    // ---- momentum predictor: Jacobi sweeps with lduMatrix-style L1 residual control (stand-in for smoothSolver) ----------
-    int solve_momentum(int* iters) { return solve_vec3(U, bmom.p, cs.u_tol, cs.u_rel_tol, cs.u_max_iter, iters, true); }
-    // Jacobi sweeps on the 7-point matrix in M7() for a 3-component field X (in place; xscr is the other buffer), lduMatrix-style L1
-    // residual control per component
-    int solve_vec3(DevBuf<double>& X, const double* rhs, double tol, double rel_tol, int max_iter, int* iters, bool momentum = false) {
-        double h[6];
-        // sum(X) per component for xbar = average(X): folded (and all-reduced) on the device, divided where it is used
-        if (momentum && usum_pending) {                          // (formed beside the particle phase: step())
-            usum_pending = false;
-            FY_HIP(hipStreamWaitEvent(stream, ev_usum1, 0));
-        } else {
-            FY_TRY(launch_sum3(stream, X.p + 3 * (size_t)g.c0, Nc, partials.p));
-            FY_TRY(launch_reduce_finalize(stream, partials.p, Nc, 3, nullptr, xbar3.p));
-            FY_TRY(comm->allreduce(stream, xbar3.p, 3, false));
-        }
-        double* xc = X.p; double* xn = xscr.p;
-        double norm[3] = {1, 1, 1}, res0[3] = {0, 0, 0}, res[3];
-        int it = 0;
-        for (;;) {
-            FY_TRY(halo(xc, 3, plane, g.nz, g.gz, 1));
-            kc[KC_MOM_PASS].begin(stream);
-            FY_TRY(FVK(launch_mom_pass, stream, g, M7(momentum), rhs, xc, xn, xbar3.p, (double)Nglob, partials.p));
-            kc[KC_MOM_PASS].end(stream);
-            FY_TRY(reduce_read(6, false, h));
-            if (it == 0) for (int q = 0; q < 3; ++q) { norm[q] = h[3 + q] + 1e-20; res0[q] = h[q] / norm[q]; }
-            bool conv = true;
-            for (int q = 0; q < 3; ++q) {
-                res[q] = h[q] / norm[q];
-                if (!(res[q] < tol || (rel_tol > 0 && res[q] < rel_tol * res0[q]))) conv = false;
-            }
-            if (conv || it >= max_iter) break;
-            std::swap(xc, xn);
-            ++it;
-        }
-        // the converged iterate may sit in the scratch buffer: the two arrays (same size, both whole-storage) trade places instead of 3 Nc doubles being
-        // copied (36 us at 160^3).  Ghost planes of the new X are whatever the scratch held: every reader across a slab face exchanges first.
-        if (xc != X.p) {
-            std::swap(X.p, xscr.p);
-            if (&X == &U && cpl) cpl->c.dU = U.p;             // (the coupling gathers U through its own pointer)
-        }
-        *iters = it;
-        return FY_OK;
+// Jacobi sweeps on the 7-point matrix in M7() for a 3-component field X (in place; xscr is the other buffer), lduMatrix-style L1
+// residual control per component
+int Solver::solve_vec3(DevBuf<double>& X, const double* rhs, double tol, double rel_tol, int max_iter, int* iters, bool momentum) {
+    double h[6];
+    // sum(X) per component for xbar = average(X): folded (and all-reduced) on the device, divided where it is used
+    if (momentum && usum_pending) {                          // (formed beside the particle phase: step())
+        usum_pending = false;
+        FY_HIP(hipStreamWaitEvent(stream, ev_usum1, 0));
+    } else {
+        FY_TRY(launch_sum3(stream, X.p + 3 * (size_t)g.c0, Nc, partials.p));
+        FY_TRY(launch_reduce_finalize(stream, partials.p, Nc, 3, nullptr, xbar3.p));
+        FY_TRY(comm->allreduce(stream, xbar3.p, 3, false));
     }
+    double* xc = X.p; double* xn = xscr.p;
+    double norm[3] = {1, 1, 1}, res0[3] = {0, 0, 0}, res[3];
+    int it = 0;
+    for (;;) {
+        FY_TRY(halo(xc, 3, plane, g.nz, g.gz, 1));
+        kc[KC_MOM_PASS].begin(stream);
+        FY_TRY(FVK(launch_mom_pass, stream, g, M7(momentum), rhs, xc, xn, xbar3.p, (double)Nglob, partials.p));
+        kc[KC_MOM_PASS].end(stream);
+        FY_TRY(reduce_read(6, false, h));
+        if (it == 0) for (int q = 0; q < 3; ++q) { norm[q] = h[3 + q] + 1e-20; res0[q] = h[q] / norm[q]; }
+        bool conv = true;
+        for (int q = 0; q < 3; ++q) {
+            res[q] = h[q] / norm[q];
+            if (!(res[q] < tol || (rel_tol > 0 && res[q] < rel_tol * res0[q]))) conv = false;
+        }
+        if (conv || it >= max_iter) break;
+        std::swap(xc, xn);
+        ++it;
+    }
+    // the converged iterate may sit in the scratch buffer: the two arrays (same size, both whole-storage) trade places instead of 3 Nc doubles being
+    // copied (36 us at 160^3).  Ghost planes of the new X are whatever the scratch held: every reader across a slab face exchanges first.
+    if (xc != X.p) {
+        std::swap(X.p, xscr.p);
+        if (&X == &U && cpl) cpl->c.dU = U.p;             // (the coupling gathers U through its own pointer)
+    }
+    *iters = it;
+    return FY_OK;
+}
 
-    // ---- multigrid V(2,2) with damped Jacobi, used as the PCG preconditioner ------------------------------------------
-    int smooth(size_t l, MgLev& L, double w, bool with_dot = false) {
-        if (L.distributed && overlap_halos && L.A.nz >= 4) {
-            // Halo exchange overlapped with interior stencil work: the sweep over the planes that need no ghost values starts at
-            // once on `stream`, the one-plane exchange of x runs meanwhile on comm_stream, and the two boundary planes are swept
-            // when it has landed.  Same arithmetic per cell, so the result is the serial schedule's bit for bit.
-            const int pl = (int)L.plane;
-            FY_HIP(hipEventRecord(ev_ready, stream));                      // x is final
-            FY_HIP(hipStreamWaitEvent(comm_stream, ev_ready, 0));
-            PMat in = L.A; in.c0 += pl; in.N -= 2 * pl;
-            FY_TRY(launch_mg_smooth(stream, in, L.bptr, L.xcur, L.xalt, w));
-            FY_TRY(halo(L.xcur, 1, L.plane, L.A.nz, L.gz, 1, comm_stream));
-            FY_HIP(hipEventRecord(ev_halo, comm_stream));
-            FY_HIP(hipStreamWaitEvent(stream, ev_halo, 0));
-            PMat lo = L.A; lo.N = pl;
-            PMat hi = L.A; hi.c0 += (L.A.nz - 1) * pl; hi.N = pl;
-            FY_TRY(launch_mg_smooth(stream, lo, L.bptr, L.xcur, L.xalt, w));
-            FY_TRY(launch_mg_smooth(stream, hi, L.bptr, L.xcur, L.xalt, w));
-            std::swap(L.xcur, L.xalt);
-            return FY_OK;
-        }
-        FY_TRY(halo_level(L, L.xcur));
-        if (with_dot) {                                    // (single domain only: the caller checks)
-            if (l == 0) kc[KC_MG_SMOOTH0].begin(stream);
-            FY_TRY(launch_mg_smooth_dot(stream, L.A, L.bptr, L.xcur, L.xalt, w, partials.p));
-            if (l == 0) kc[KC_MG_SMOOTH0].end(stream);
-            std::swap(L.xcur, L.xalt);
-            return FY_OK;
-        }
-        if (l == 0) kc[KC_MG_SMOOTH0].begin(stream);
-        FY_TRY(launch_mg_smooth(stream, L.A, L.bptr, L.xcur, L.xalt, w));
-        if (l == 0) kc[KC_MG_SMOOTH0].end(stream);
-        std::swap(L.xcur, L.xalt);
-        return FY_OK;
+// ---- one PISO / PIMPLE corrector (icoFoamYade.C:97-140, pEqn.H) ----------------------------------------------------
+int Solver::corrector(bool final_inner) {
+    FY_TRY(halo_cells(U, 3, 1));
+    FY_TRY(FVK(launch_HbyA, stream, g, M7(), src.p, U.p, rAU.p, HbyA.p));
+    // rAU (hence rAUf and the pressure matrix rAUf*alphaf) belongs to the momentum matrix: it only changes when that is assembled,
+    // not between the PISO correctors of one assembly
+    if (!pimple && rAU_new) { FY_TRY(halo_cells(rAU, 1, 1)); FY_TRY(FVK(launch_interp_rAU, stream, g, rAU.p, F3(rAUf))); }
+    FY_TRY(halo_cells(HbyA, 3, 1));
+    // the ddtCorr term is the same in every corrector of one momentum assembly: stored by the first, read back by the others
+    FY_TRY(FVK(launch_phiHbyA, stream, g, HbyA.p, U.p, Uold.p, C3(phiOld), C3(rAUf), C3(alphaf), C3(phiForces), F3(phiHbyA), F3(psn), F3(ddtc), rAU_new ? 1 : 2));
+    if (adjust_phi) {                                       // icoFoamYade.C:108, pEqn.H:13-16
+        FY_TRY(FVK(launch_adjust_phi_sums, stream, g, C3(phiHbyA), C3(phiForces), partials.p));
+        FY_TRY(launch_reduce_finalize(stream, partials.p, Nc, 4, nullptr, adj_sums.p));
+        FY_TRY(comm->allreduce(stream, adj_sums.p, 4, false));
+        FY_TRY(FVK(launch_adjust_phi_apply, stream, g, adj_sums.p, F3(phiHbyA), C3(phiForces), C3(rAUf), U.p, F3(psn), adj_err.p));
     }
-
-    // the slice of the (replicated) level `Cc` that this rank's distributed parent `L` aggregates to, as a stand-alone PMat
-    PMat slice_of(const MgLev& L, const MgLev& Cc) const {
-        PMat loc = Cc.A;
-        loc.nz = L.A.nz / 2; loc.N = (int)(Cc.plane * (size_t)loc.nz); loc.c0 = 0; loc.ntot = loc.N;
-        return loc;
-    }
-
-    // The smoother: two sweeps as a pair are the degree-2 Chebyshev polynomial of D^-1 A on [1/3, 2] -- the high-frequency band of the
-    // 7-point operator under 2 x 2 x 2 coarsening; 2 bounds the spectrum of every diagonally dominant level -- i.e. Jacobi with the
-    // weights 1 / (7/6 -+ (5/6) cos(pi/4)).  The pair damps that band by 0.34 where two sweeps at the fixed weight 0.8 reach 0.54, for
-    // the same memory traffic: PCG iterations 66 -> 48 on a moving 48^3 bed, 19 -> 14 on the manufactured Poisson problem (CPU oracle).
-    // Pre-smoothing applies (wa, wb), post-smoothing the reverse order (its adjoint: the V-cycle stays a symmetric positive definite
-    // preconditioner).  The sweeps of the coarsest level (kMgCoarseSweeps) keep the fixed weight.  Degree 4 (four sweeps each way, weights 2.520 /
-    // 1.180 / 0.673 / 0.516) was measured too: fewer iterations (C3 2.6 -> 2.1 per step, moving bed 5.75 -> 4.2, C2 7.5 -> 5.3) but every
-    // one of the three cases slower in time (7.40 -> 7.56, 9.55 -> 9.73, 2.35 -> 2.51 ms per step): the four extra sweeps cost more
-    // than the iterations they save.
-    static constexpr double kMgWa = 1.7318685872766142, kMgWb = 0.5695012757370842;
-    MgWeights mgw{2, {kMgWa, kMgWb, 0, 0}};
-    int vcycle(size_t l) {
-        const double w = 0.8;
-        const MgWeights& W = mgw;
-        if (l >= 1) FY_TRY(wait_coarse());                        // (level 0's operator is the assembled one; everything below comes from build_coarse_operators)
-        MgLev& L = *mg[l];
-        if (!L.distributed && L.A.N <= kMgTailCells && mg.size() - l <= (size_t)kMgTailMax) {
-            // the rest of the hierarchy fits one workgroup: one launch instead of ~8 per level (b of this level is already in place)
-            FY_TRY(wait_coarse());
-            PMat A[kMgTailMax]; double* x0[kMgTailMax]; double* x1[kMgTailMax]; double* b[kMgTailMax];
-            const int n = (int)(mg.size() - l);
-            for (int q = 0; q < n; ++q) {
-                MgLev& M = *mg[l + (size_t)q];
-                A[q] = M.A; x0[q] = M.x0.p; x1[q] = M.x1.p; b[q] = q == 0 ? const_cast<double*>(L.bptr) : M.b.p;
-            }
-            FY_TRY(launch_mg_tail(stream, A, x0, x1, b, n, w, coarse_sweeps, W, mg_inv.p));
-            L.xcur = n > 1 ? L.x1.p : L.x0.p; L.xalt = n > 1 ? L.x0.p : L.x1.p;
-            return FY_OK;
-        }
-        if (l + 1 == mg.size()) {
-            FY_TRY(wait_coarse());
-            FY_TRY(launch_mg_coarse_solve(stream, L.A, L.bptr, L.x0.p, L.x1.p, coarse_sweeps, w, mg_inv.p));
-            L.xcur = L.x0.p; L.xalt = L.x1.p;
-            return FY_OK;
-        }
-        MgLev& Cc = *mg[l + 1];
-        if (!L.distributed) {
-            // first iterate and first sweep in one pass (bit-identical, see the kernel): one launch fewer on the latency-bound small
-            // levels, and on level 0 the first iterate never travels through memory (pressure 2.25 -> 2.21 ms)
-            FY_TRY(launch_mg_smooth_two_from_zero(stream, L.A, L.bptr, L.xcur, W.w[0], W.w[1]));
-        } else {
-            FY_TRY(launch_mg_smooth_first(stream, L.A, L.bptr, L.xcur, W.w[0]));
-            FY_TRY(smooth(l, L, W.w[1]));
-        }
-        for (int s = 2; s < W.n; ++s) FY_TRY(smooth(l, L, W.w[s]));
-        FY_TRY(halo_level(L, L.xcur));
-        const bool handover = L.distributed && !Cc.distributed;
-        if (handover) {
-            // hand-over to the replicated hierarchy: restrict into the local slice, all-gather the coarse right-hand side
-            PMat loc = slice_of(L, Cc);
-            FY_TRY(launch_mg_residual_restrict(stream, L.A, L.bptr, L.xcur, loc, rep_stage.p));
-            FY_TRY(comm->allgather(stream, rep_stage.p, Cc.b.p, (size_t)loc.N));
-        } else {
-            FY_TRY(launch_mg_residual_restrict(stream, L.A, L.bptr, L.xcur, Cc.A, Cc.b.p));
-        }
-        Cc.bptr = Cc.b.p;
-        FY_TRY(vcycle(l + 1));
-        if (handover) {
-            PMat loc = Cc.A;                      // this rank's slice of the replicated coarse solution
-            loc.c0 = (int)(Cc.plane * (size_t)(L.A.nz / 2) * (size_t)comm->rank);
-            FY_TRY(launch_mg_prolong_add(stream, L.A, L.xcur, loc, Cc.xcur));
-            for (int s = W.n - 1; s >= 1; --s) FY_TRY(smooth(l, L, W.w[s]));
-        } else if (!L.distributed && W.n >= 2 && fuse_prolong) {
-            // prolongation fused into the first post-smoothing sweep (bit-identical; one launch and one pass over the level fewer)
-            FY_TRY(launch_mg_smooth_prolong(stream, L.A, L.bptr, L.xcur, Cc.A, Cc.xcur, L.xalt, W.w[W.n - 1]));
-            std::swap(L.xcur, L.xalt);
-            for (int s = W.n - 2; s >= 1; --s) FY_TRY(smooth(l, L, W.w[s]));
-        } else {
-            FY_TRY(launch_mg_prolong_add(stream, L.A, L.xcur, Cc.A, Cc.xcur));
-            for (int s = W.n - 1; s >= 1; --s) FY_TRY(smooth(l, L, W.w[s]));
-        }
-        // the last sweep of the whole cycle also leaves the partials of z.r where PCG's launch_dot would (vcycle_dot_done)
-        vcycle_dot_done = l == 0 && want_vcycle_dot && !L.distributed && L.A.N == Nc && L.A.c0 == g.c0;
-        FY_TRY(smooth(l, L, W.w[0], vcycle_dot_done));
-        return FY_OK;
-    }
-    bool want_vcycle_dot = false, vcycle_dot_done = false;
-    // damped-Jacobi sweeps that stand for the solve of the coarsest level (<= 256 cells, no edge over 8): 40 left its smoothest modes in and cost
-    // PCG iterations -- C3 after 30 steps: 3.0 iterations per step with 40 or 80 sweeps, 2.17 with 120 / 160 / 240 (135 -> 140 / 139 / 137.6
-    // steps/s); moving bed and C2 +-1 %.  The sweeps run inside the one-workgroup tail kernel, ~0.1 us each
-    static constexpr int kMgCoarseSweeps = 120;
-    int coarse_sweeps = kMgCoarseSweeps;
-    bool fuse_prolong = true;            // prolongation folded into the first post-smoothing sweep (identical results)
-
-    // coarse operators: A_{l+1} = 1/2 P^T A_l P level by level; the first replicated level is all-gathered from the slabs' slices
-    // index of the coarse cell that holds the pressure reference cell, local to the level-`lvl` operator `A` whose first plane is global
-    // coarse plane `k0` (-1: no reference cell, or not in A's planes)
-    int ref_cell_at(size_t lvl, const PMat& A, int k0) const {
-        if (!g.need_ref) return -1;
-        const int i = (g.p_ref_cell % g.nx) >> lvl, j = ((g.p_ref_cell / g.nx) % g.ny) >> lvl, k = (g.p_ref_cell / (g.nx * g.ny)) >> lvl;
-        const int kl = k - k0;
-        if (kl < 0 || kl >= A.nz) return -1;
-        return i + A.nx * (j + A.ny * kl);
-    }
-    int build_coarse_operators() {
-        // the reference cell's point term (k_mg_coarsen): level 0's value, known to every rank
-        const double* ref_term = nullptr;
-        if (g.need_ref && mg.size() > 1) {
-            if (!mg_ref.p) FY_TRY(mg_ref.alloc_exact(1));
-            FY_TRY(launch_mg_ref_term(stream, mg[0]->A, ref_cell_at(0, mg[0]->A, mg[0]->distributed ? g.kglob0 : 0), mg_ref.p));
-            if (mg[0]->distributed) FY_TRY(comm->allreduce(stream, mg_ref.p, 1, false));
-            ref_term = mg_ref.p;
-        }
-        for (size_t l = 0; l + 1 < mg.size(); ++l) {
-            MgLev& F = *mg[l]; MgLev& Cc = *mg[l + 1];
-            if (F.distributed && !Cc.distributed) {
-                PMat loc = slice_of(F, Cc);
-                const size_t cnt = (size_t)loc.N;
-                loc.diag = rep_stage.p; loc.ux = rep_stage.p + cnt; loc.uy = rep_stage.p + 2 * cnt; loc.uz = rep_stage.p + 3 * cnt;
-                FY_TRY(launch_mg_coarsen(stream, F.A, loc, ref_cell_at(l + 1, loc, comm->rank * loc.nz), ref_term));
-                FY_TRY(comm->allgather(stream, loc.diag, Cc.A.diag, cnt));
-                FY_TRY(comm->allgather(stream, loc.ux, Cc.A.ux, cnt));
-                FY_TRY(comm->allgather(stream, loc.uy, Cc.A.uy, cnt));
-                FY_TRY(comm->allgather(stream, loc.uz, Cc.A.uz, cnt));
+    MgLev& L = *mg[0];
+    clk_pres.begin(stream);
+    for (int no = 0; no <= cs.n_non_orth_correctors; ++no) {
+        FY_TRY(FVK(launch_assemble_pressure, stream, g, C3(phiHbyA), C3(rAUf), C3(alphaf), C3(psn), alpha.p, /* alphaOld */ alpha.p, L.A, prhs.p, rAU_new));
+        if (rAU_new && L.distributed && comm->has_down()) FY_TRY(FVK(launch_p_ghost_uz, stream, g, C3(rAUf), C3(alphaf), L.A));
+        if (rAU_new) {                                        // same matrix as in the previous corrector otherwise: only the right-hand side moved
+            if (comm->size == 1 && cs.p_solver == FY_PSOLVER_PCG_MG && mg.size() > 1) {
+                FY_HIP(hipEventRecord(ev_assembled, stream));
+                FY_HIP(hipStreamWaitEvent(comm_stream, ev_assembled, 0));
+                std::swap(stream, comm_stream);               // (build_coarse_operators launches on `stream`)
+                const int rc = build_coarse_operators();
+                std::swap(stream, comm_stream);
+                FY_TRY(rc);
+                FY_HIP(hipEventRecord(ev_coarse, comm_stream));
+                coarse_pending = true;
             } else {
-                FY_TRY(launch_mg_coarsen(stream, F.A, Cc.A, ref_cell_at(l + 1, Cc.A, Cc.distributed ? comm->rank * Cc.A.nz : 0), ref_term));
-                if (Cc.distributed && comm->has_down()) FY_TRY(launch_mg_coarsen_ghost(stream, F.A, Cc.A));
+                FY_TRY(build_coarse_operators());
             }
         }
-        // the coarsest operator's banded Cholesky factor (k_mg_coarse_factor): rebuilt with the operators, used by every V-cycle until the next assembly
-        if (cs.p_solver == FY_PSOLVER_PCG_MG) {
-            const MgLev& Lc = *mg.back();
-            if (!Lc.distributed && mg_coarse_direct_ok(Lc.A)) {
-                if (!mg_inv.p) FY_TRY(mg_inv.alloc_exact((size_t)mg_coarse_factor_doubles(Lc.A)));
-                FY_TRY(launch_mg_coarse_factor(stream, Lc.A, mg_inv.p));
-            }
+        rAU_new = false;
+        FY_TRY(solve_pressure(final_inner && no == cs.n_non_orth_correctors));
+        FY_TRY(wait_coarse());                                // (a solve that never left level 0)
+        if (no == cs.n_non_orth_correctors) {
+            FY_TRY(halo_cells(p, 1, 1));
+            FY_TRY(FVK(launch_flux_correct, stream, g, p.p, C3(phiHbyA), C3(rAUf), C3(alphaf), C3(psn), C3(phiForces), F3(pflux), F3(phi)));
+            phi_fresh = true;
+            // p.relax() (pEqn.H:41): after the flux, which keeps the unrelaxed solution; the velocity correction below works with
+            // pEqn.flux() (pflux), not with grad(p), so only the carried pressure field is relaxed
+            if (pimple && p_relax_now > 0 && p_relax_now < 1) { FY_TRY(launch_relax_field(stream, p.p, pPrev.p, p_relax_now, nstore)); p_sum_valid = false; }
         }
+    }
+    clk_pres.end(stream);
+    double h[2];
+    int slot = 0, rc = FY_OK;
+    if (fuse_diag && red_host && n_deferred + 4 <= kDeferMax) {
+        // the continuity errors and the NEXT step's Courant sums ride on the velocity correction's sweep
+        // (k_U_correct<true>; same values as k_cont_err / k_courant) instead of being two sweeps of their own
+        FY_TRY(FVK(launch_U_correct_diag, stream, g, HbyA.p, rAU.p, p.p, C3(psn), C3(phiForces), C3(pflux), C3(alphaf), C3(rAUf), U.p, C3(phi), alpha.p,
+                                     /* alphaOld */ alpha.p, partials.p));
+        if (!reduce_deferred(4, false, &slot, &rc, ops_diag.p)) return fail(FY_ERR_INVALID, "no room for the deferred diagnostics");
+        FY_TRY(rc);
+        cont_slots.push_back(slot);
+        carry_slot = slot + 2;
         return FY_OK;
     }
-    DevBuf<double> mg_inv, mg_ref;
-    double p_sum = 0.0;            // sum(p) over all cells as the last PCG update left it (solve_pressure)
-    bool p_sum_valid = false;
+    carry_slot = -1;
+    FY_TRY(FVK(launch_cont_err, stream, g, C3(phi), C3(alphaf), alpha.p, /* alphaOld */ alpha.p, partials.p));
+    if (reduce_deferred(2, false, &slot, &rc)) { FY_TRY(rc); cont_slots.push_back(slot); }
+    else { FY_TRY(reduce_read(2, false, h)); note_cont_err(h); }
+    FY_TRY(FVK(launch_U_correct, stream, g, HbyA.p, rAU.p, p.p, C3(psn), C3(phiForces), C3(pflux), C3(alphaf), C3(rAUf), U.p));
+    return FY_OK;
+}
 
-    // OpenFOAM PCG.C with lduMatrix::solver::normFactor; preconditioner = MG V-cycle or Jacobi
-    int solve_pressure(bool final_iter) {
-        MgLev& L = *mg[0];
-        const double tol = final_iter ? cs.p_final_tol : cs.p_tol, rel = final_iter ? cs.p_final_rel_tol : cs.p_rel_tol;
-        double h[2];
-        // xbar = average(p) for lduMatrix::solver::normFactor: sum(p) over the owned cells, all-reduced.  The last PCG update of p left it with the
-        // host (k_pcg_update_xr's second slot: the same partition and order as the sum below, the same bits); p_sum_valid falls when anything else writes p
-        if (!p_sum_valid) {
-            FY_TRY(launch_dot(stream, Nc, g.c0, p.p, nullptr, partials.p));
-            FY_TRY(reduce_to_device(sc.p + 3));
-        }
-        FY_TRY(halo_cells(p, 1, 1));
-        FY_TRY(launch_p_init(stream, L.A, prhs.p, p.p, p_sum_valid ? nullptr : sc.p + 3, p_sum, 1.0 / (double)Nglob, pr.p, partials.p));
-        FY_TRY(reduce_read(2, false, h));
-        const double norm = h[1] + 1e-20;
-        double res = h[0] / norm;
-        const double res0 = res;
-        st.p_initial_residual = res0;
-        auto converged = [&](double r) { return r < tol || (rel > 0 && r < rel * res0); };
+// continuousPhaseTurbulence->correct() for LES Smagorinsky: nut from the Gauss-linear gradient of the corrected velocity
+int Solver::turbulence_correct() {
+    FY_TRY(halo_cells(U, 3, 1));
+    FY_TRY(FVK(launch_pre_coupling, stream, g, U.p, p.p, alpha.p, C3(psn), vGrad.p, gradP.p, divT.p, nullptr, 1, 0));
+    if (cs.turbulence_model == FY_TURBULENCE_KEQN || cs.turbulence_model == FY_TURBULENCE_KEPSILON) {
+        // kEqn::correct() / kEpsilon::correct(): each transport equation is assembled into the momentum matrix's storage and solved by the
+        // momentum solver's pass as a 3-component system whose last two components are identically zero (HbyA / bmom / xscr are free
+        // after the correctors).  kEpsilon: the dissipation equation first, then k with the new epsilon, then nut = Cmu k^2 / epsilon
+        const bool keps = cs.turbulence_model == FY_TURBULENCE_KEPSILON;
         int it = 0;
-        if (!converged(res)) {
-            do {
-                const double* z;
-                vcycle_dot_done = false;
-                if (cs.p_solver == FY_PSOLVER_PCG_MG) { L.bptr = pr.p; want_vcycle_dot = true; FY_TRY(vcycle(0)); want_vcycle_dot = false; z = L.xcur; }
-                else { FY_TRY(launch_jacobi_precond(stream, L.A, pr.p, pzj.p)); z = pzj.p; }
-                if (!vcycle_dot_done) FY_TRY(launch_dot(stream, Nc, g.c0, z, pr.p, partials.p));
-                FY_TRY(reduce_to_device(sc.p + 0));                                                   // wArA
-                FY_TRY(launch_pcg_update_p(stream, Nc, g.c0, z, pp.p, sc.p, it == 0 ? 1 : 0));
-                FY_TRY(halo_cells(pp, 1, 1));
-                kc[KC_P_APPLY_DOT].begin(stream);
-                FY_TRY(launch_p_apply_dot(stream, L.A, pp.p, pw.p, partials.p));
-                kc[KC_P_APPLY_DOT].end(stream);
-                FY_TRY(reduce_to_device(sc.p + 2));                                                   // wApA
-                FY_TRY(launch_pcg_update_xr(stream, Nc, g.c0, p.p, pr.p, pp.p, pw.p, sc.p, partials.p));
-                FY_TRY(reduce_read(2, false, h));
-                res = h[0] / norm;
-                p_sum = h[1]; p_sum_valid = true;
-            } while (++it < cs.p_max_iter && !converged(res));
-        }
-        st.p_final_residual = res;
-        st.p_iters_total += it; st.p_solves += 1;
-        return FY_OK;
-    }
-
-    // ---- one PISO / PIMPLE corrector (icoFoamYade.C:97-140, pEqn.H) ----------------------------------------------------
-    int corrector(bool final_inner) {
-        FY_TRY(halo_cells(U, 3, 1));
-        FY_TRY(FVK(launch_HbyA, stream, g, M7(), src.p, U.p, rAU.p, HbyA.p));
-        // rAU (hence rAUf and the pressure matrix rAUf*alphaf) belongs to the momentum matrix: it only changes when that is assembled,
-        // not between the PISO correctors of one assembly
-        if (!pimple && rAU_new) { FY_TRY(halo_cells(rAU, 1, 1)); FY_TRY(FVK(launch_interp_rAU, stream, g, rAU.p, F3(rAUf))); }
-        FY_TRY(halo_cells(HbyA, 3, 1));
-        // the ddtCorr term is the same in every corrector of one momentum assembly: stored by the first, read back by the others
-        FY_TRY(FVK(launch_phiHbyA, stream, g, HbyA.p, U.p, Uold.p, C3(phiOld), C3(rAUf), C3(alphaf), C3(phiForces), F3(phiHbyA), F3(psn), F3(ddtc), rAU_new ? 1 : 2));
-        if (adjust_phi) {                                       // icoFoamYade.C:108, pEqn.H:13-16
-            FY_TRY(FVK(launch_adjust_phi_sums, stream, g, C3(phiHbyA), C3(phiForces), partials.p));
-            FY_TRY(launch_reduce_finalize(stream, partials.p, Nc, 4, nullptr, adj_sums.p));
-            FY_TRY(comm->allreduce(stream, adj_sums.p, 4, false));
-            FY_TRY(FVK(launch_adjust_phi_apply, stream, g, adj_sums.p, F3(phiHbyA), C3(phiForces), C3(rAUf), U.p, F3(psn), adj_err.p));
-        }
-        MgLev& L = *mg[0];
-        clk_pres.begin(stream);
-        for (int no = 0; no <= cs.n_non_orth_correctors; ++no) {
-            FY_TRY(FVK(launch_assemble_pressure, stream, g, C3(phiHbyA), C3(rAUf), C3(alphaf), C3(psn), alpha.p, /* alphaOld */ alpha.p, L.A, prhs.p, rAU_new));
-            if (rAU_new && L.distributed && comm->has_down()) FY_TRY(FVK(launch_p_ghost_uz, stream, g, C3(rAUf), C3(alphaf), L.A));
-            if (rAU_new) {                                        // same matrix as in the previous corrector otherwise: only the right-hand side moved
-                if (comm->size == 1 && cs.p_solver == FY_PSOLVER_PCG_MG && mg.size() > 1) {
-                    FY_HIP(hipEventRecord(ev_assembled, stream));
-                    FY_HIP(hipStreamWaitEvent(comm_stream, ev_assembled, 0));
-                    std::swap(stream, comm_stream);               // (build_coarse_operators launches on `stream`)
-                    const int rc = build_coarse_operators();
-                    std::swap(stream, comm_stream);
-                    FY_TRY(rc);
-                    FY_HIP(hipEventRecord(ev_coarse, comm_stream));
-                    coarse_pending = true;
-                } else {
-                    FY_TRY(build_coarse_operators());
-                }
-            }
-            rAU_new = false;
-            FY_TRY(solve_pressure(final_inner && no == cs.n_non_orth_correctors));
-            FY_TRY(wait_coarse());                                // (a solve that never left level 0)
-            if (no == cs.n_non_orth_correctors) {
-                FY_TRY(halo_cells(p, 1, 1));
-                FY_TRY(FVK(launch_flux_correct, stream, g, p.p, C3(phiHbyA), C3(rAUf), C3(alphaf), C3(psn), C3(phiForces), F3(pflux), F3(phi)));
-                phi_fresh = true;
-                // p.relax() (pEqn.H:41): after the flux, which keeps the unrelaxed solution; the velocity correction below works with
-                // pEqn.flux() (pflux), not with grad(p), so only the carried pressure field is relaxed
-                if (pimple && p_relax_now > 0 && p_relax_now < 1) { FY_TRY(launch_relax_field(stream, p.p, pPrev.p, p_relax_now, nstore)); p_sum_valid = false; }
-            }
-        }
-        clk_pres.end(stream);
-        double h[2];
-        int slot = 0, rc = FY_OK;
-        if (fuse_diag && red_host && n_deferred + 4 <= kDeferMax) {
-            // the continuity errors and the NEXT step's Courant sums ride on the velocity correction's sweep
-            // (k_U_correct<true>; same values as k_cont_err / k_courant) instead of being two sweeps of their own
-            FY_TRY(FVK(launch_U_correct_diag, stream, g, HbyA.p, rAU.p, p.p, C3(psn), C3(phiForces), C3(pflux), C3(alphaf), C3(rAUf), U.p, C3(phi), alpha.p,
-                                         /* alphaOld */ alpha.p, partials.p));
-            if (!reduce_deferred(4, false, &slot, &rc, ops_diag.p)) return fail(FY_ERR_INVALID, "no room for the deferred diagnostics");
-            FY_TRY(rc);
-            cont_slots.push_back(slot);
-            carry_slot = slot + 2;
-            return FY_OK;
-        }
-        carry_slot = -1;
-        FY_TRY(FVK(launch_cont_err, stream, g, C3(phi), C3(alphaf), alpha.p, /* alphaOld */ alpha.p, partials.p));
-        if (reduce_deferred(2, false, &slot, &rc)) { FY_TRY(rc); cont_slots.push_back(slot); }
-        else { FY_TRY(reduce_read(2, false, h)); note_cont_err(h); }
-        FY_TRY(FVK(launch_U_correct, stream, g, HbyA.p, rAU.p, p.p, C3(psn), C3(phiForces), C3(pflux), C3(alphaf), C3(rAUf), U.p));
-        return FY_OK;
-    }
-    // Courant sums of the flux the last corrector left (max sumPhi/V, sum sumPhi), formed by k_U_correct<true>: what CourantNo.H at the top
-    // of the next pass would compute from the same phi.  Dropped whenever a field is written from outside (fy_solver_write_field_host).
-    bool fuse_diag = true;               // continuity errors and the next Courant sums ride on the velocity-correction sweep
-    int carry_slot = -1;
-    bool carry_valid = false;
-    double carry_h[2] = {0, 0};
-
-    std::vector<int> cont_slots;     // deferred continuity-error read-backs of this step, in corrector order
-    int courant_slot = -1;
-    void note_cont_err(const double* h) {      // continuityErrs.H:36-46
-        const double tv = total_volume;
-        st.cont_err_sum_local = cs.dt * h[0] / tv; st.cont_err_global = cs.dt * h[1] / tv;
-        cumulative_cont_err += st.cont_err_global; st.cont_err_cumulative = cumulative_cont_err;
-    }
-    void note_courant(const double* h) { st.courant_max = 0.5 * h[0] * cs.dt; st.courant_mean = 0.5 * (h[1] / total_volume) * cs.dt; }
-
-    // continuousPhaseTurbulence->correct() for LES Smagorinsky: nut from the Gauss-linear gradient of the corrected velocity
-    int turbulence_correct() {
-        FY_TRY(halo_cells(U, 3, 1));
-        FY_TRY(FVK(launch_pre_coupling, stream, g, U.p, p.p, alpha.p, C3(psn), vGrad.p, gradP.p, divT.p, nullptr, 1, 0));
-        if (cs.turbulence_model == FY_TURBULENCE_KEQN || cs.turbulence_model == FY_TURBULENCE_KEPSILON) {
-            // kEqn::correct() / kEpsilon::correct(): each transport equation is assembled into the momentum matrix's storage and solved by the
-            // momentum solver's pass as a 3-component system whose last two components are identically zero (HbyA / bmom / xscr are free
-            // after the correctors).  kEpsilon: the dissipation equation first, then k with the new epsilon, then nut = Cmu k^2 / epsilon
-            const bool keps = cs.turbulence_model == FY_TURBULENCE_KEPSILON;
-            int it = 0;
-            FY_TRY(halo_cells(kturb, 1, 1));
-            if (keps) {
-                FY_TRY(halo_cells(epsturb, 1, 1));
-                FY_TRY(FVK(launch_assemble_turb, stream, g, eq_eps, kturb.p, epsturb.p, alpha.p, C3(alphaf), C3(phi), vGrad.p, U.p, M7(), bmom.p, HbyA.p));
-                FY_TRY(solve_vec3(HbyA, bmom.p, cs.eps_tol, cs.eps_rel_tol, cs.eps_max_iter, &it));
-                st_k_iters += it;
-                FY_TRY(halo_cells(HbyA, 3, 1));
-                FY_TRY(FVK(launch_turb_finish, stream, g, eq_eps, HbyA.p, epsturb.p, 0, 0.0, nullptr, nullptr));
-            }
-            FY_TRY(FVK(launch_assemble_turb, stream, g, eq_k, kturb.p, epsturb.p, alpha.p, C3(alphaf), C3(phi), vGrad.p, U.p, M7(), bmom.p, HbyA.p));
-            FY_TRY(solve_vec3(HbyA, bmom.p, cs.k_tol, cs.k_rel_tol, cs.k_max_iter, &it));
+        FY_TRY(halo_cells(kturb, 1, 1));
+        if (keps) {
+            FY_TRY(halo_cells(epsturb, 1, 1));
+            FY_TRY(FVK(launch_assemble_turb, stream, g, eq_eps, kturb.p, epsturb.p, alpha.p, C3(alphaf), C3(phi), vGrad.p, U.p, M7(), bmom.p, HbyA.p));
+            FY_TRY(solve_vec3(HbyA, bmom.p, cs.eps_tol, cs.eps_rel_tol, cs.eps_max_iter, &it));
             st_k_iters += it;
             FY_TRY(halo_cells(HbyA, 3, 1));
-            FY_TRY(FVK(launch_turb_finish, stream, g, eq_k, HbyA.p, kturb.p, keps ? 2 : 1, cs.ras_cmu, epsturb.p, nut.p));
-            FY_TRY(halo_cells(kturb, 1, 1));
-            g.nut_wall_live = 1;              // correctNut(): from now on the wall-function patches carry nut_w(k), not the file's value
-            return halo_cells(nut, 1, 1);
+            FY_TRY(FVK(launch_turb_finish, stream, g, eq_eps, HbyA.p, epsturb.p, 0, 0.0, nullptr, nullptr));
         }
-        FY_TRY(FVK(launch_smagorinsky_nut, stream, g, vGrad.p, cs.les_ck, cs.les_ce, les_delta, nut.p));
+        FY_TRY(FVK(launch_assemble_turb, stream, g, eq_k, kturb.p, epsturb.p, alpha.p, C3(alphaf), C3(phi), vGrad.p, U.p, M7(), bmom.p, HbyA.p));
+        FY_TRY(solve_vec3(HbyA, bmom.p, cs.k_tol, cs.k_rel_tol, cs.k_max_iter, &it));
+        st_k_iters += it;
+        FY_TRY(halo_cells(HbyA, 3, 1));
+        FY_TRY(FVK(launch_turb_finish, stream, g, eq_k, HbyA.p, kturb.p, keps ? 2 : 1, cs.ras_cmu, epsturb.p, nut.p));
+        FY_TRY(halo_cells(kturb, 1, 1));
+        g.nut_wall_live = 1;              // correctNut(): from now on the wall-function patches carry nut_w(k), not the file's value
         return halo_cells(nut, 1, 1);
     }
-    int st_k_iters = 0;
+    FY_TRY(FVK(launch_smagorinsky_nut, stream, g, vGrad.p, cs.les_ck, cs.les_ce, les_delta, nut.p));
+    return halo_cells(nut, 1, 1);
+}
 
-    // ---- one pass of the while (runTime.loop()) body ---------------------------------------------------------------------
-    int step() {
-        FY_HIP(hipSetDevice(device));
-        st = fy_step_stats{}; st.cont_err_cumulative = cumulative_cont_err;
-        clk_mom.on = clk_pres.on = timing; clk_mom.per_collect = clk_pres.per_collect = 1024; clk_mom.reset(); clk_pres.reset();
-        if (timing) tim[3].start(stream);
-        if (sources_pending) { FY_TRY(cpl->c.set_source_zero()); sources_pending = false; }   // the previous step's deferred setSourceZero
-        double h[2];
-        const bool carried = carry_valid;                                                      // the previous pass's last corrector already summed |phi|
-        carry_valid = false; carry_slot = -1;
-        if (!carried) FY_TRY(FVK(launch_courant, stream, g, C3(phi), partials.p));                 // icoFoamYade.C:68, pimpleFoamYade.C:63
-        n_deferred = 0; cont_slots.clear(); courant_slot = -1;
-        if (carried) note_courant(carry_h);
-        if (cs.adjust_time_step) {
-            // readTimeControls.H + CourantNo.H + setDeltaT.H (pimpleFoamYade.C:62-64) [OF-6 setDeltaT.H]: the step's deltaT follows from the
-            // Courant number of the current flux at the OLD deltaT, so the host needs that number now
-            if (!carried) { FY_TRY(reduce_read(2, true, h)); note_courant(h); }
-            const double maxDeltaTFact = cs.max_co / (st.courant_max + 1e-15);
-            const double deltaTFact = std::min(std::min(maxDeltaTFact, 1.0 + 0.1 * maxDeltaTFact), 1.2);
-            cs.dt = std::min(deltaTFact * cs.dt, cs.max_delta_t);
-            g.dt = cs.dt;
-        } else if (!carried) {
-            int slot = 0, rc = FY_OK;
-            if (reduce_deferred(2, true, &slot, &rc)) { FY_TRY(rc); courant_slot = slot; }
-            else { FY_TRY(reduce_read(2, true, h)); note_courant(h); }
-        }
-        st.delta_t = cs.dt;
-        // runTime++ : store old-time fields (whole storage, ghost planes included)
-        comm->group_begin();                    // one exchange: U goes with the full particle-halo width straight away
-        FY_TRY(halo_cells(U, 3, g.gz > 1 ? g.gz : 1));
-        FY_TRY(halo_cells(p, 1, 1));
-        FY_TRY(halo_cells(alpha, 1, 1));
+// ---- one pass of the while (runTime.loop()) body ---------------------------------------------------------------------
+int Solver::step() {
+    FY_HIP(hipSetDevice(device));
+    st = fy_step_stats{}; st.cont_err_cumulative = cumulative_cont_err;
+    clk_mom.on = clk_pres.on = timing; clk_mom.per_collect = clk_pres.per_collect = 1024; clk_mom.reset(); clk_pres.reset();
+    if (timing) tim[3].start(stream);
+    if (sources_pending) { FY_TRY(cpl->c.set_source_zero()); sources_pending = false; }   // the previous step's deferred setSourceZero
+    double h[2];
+    const bool carried = carry_valid;                                                      // the previous pass's last corrector already summed |phi|
+    carry_valid = false; carry_slot = -1;
+    if (!carried) FY_TRY(FVK(launch_courant, stream, g, C3(phi), partials.p));                 // icoFoamYade.C:68, pimpleFoamYade.C:63
+    n_deferred = 0; cont_slots.clear(); courant_slot = -1;
+    if (carried) note_courant(carry_h);
+    if (cs.adjust_time_step) {
+        // readTimeControls.H + CourantNo.H + setDeltaT.H (pimpleFoamYade.C:62-64) [OF-6 setDeltaT.H]: the step's deltaT follows from the
+        // Courant number of the current flux at the OLD deltaT, so the host needs that number now
+        if (!carried) { FY_TRY(reduce_read(2, true, h)); note_courant(h); }
+        const double maxDeltaTFact = cs.max_co / (st.courant_max + 1e-15);
+        const double deltaTFact = std::min(std::min(maxDeltaTFact, 1.0 + 0.1 * maxDeltaTFact), 1.2);
+        cs.dt = std::min(deltaTFact * cs.dt, cs.max_delta_t);
+        g.dt = cs.dt;
+    } else if (!carried) {
+        int slot = 0, rc = FY_OK;
+        if (reduce_deferred(2, true, &slot, &rc)) { FY_TRY(rc); courant_slot = slot; }
+        else { FY_TRY(reduce_read(2, true, h)); note_courant(h); }
+    }
+    st.delta_t = cs.dt;
+    // runTime++ : store old-time fields (whole storage, ghost planes included)
+    comm->group_begin();                    // one exchange: U goes with the full particle-halo width straight away
+    FY_TRY(halo_cells(U, 3, g.gz > 1 ? g.gz : 1));
+    FY_TRY(halo_cells(p, 1, 1));
+    FY_TRY(halo_cells(alpha, 1, 1));
+    FY_TRY(comm->group_end(stream));
+    // U.oldTime() of the owned cells is written by the pre-coupling sweep that reads U anyway; a slab copies only its ghost planes
+    // (phiHbyA's ddtCorr reads Uold across the slab faces), which the exchange above has just refreshed in U
+    const bool fuse_uold = true;
+    if (comm->size > 1 && g.gz > 0) {
+        const size_t gh = 3 * plane * (size_t)g.gz;
+        FY_TRY(launch_copy_f64(stream, Uold.p, U.p, gh));
+        FY_TRY(launch_copy_f64(stream, Uold.p + 3 * plane * (size_t)(g.gz + g.nz), U.p + 3 * plane * (size_t)(g.gz + g.nz), gh));
+    }
+    // phi.oldTime(): the flux arrays trade places instead of being copied -- what was phi is phiOld now, and until the first
+    // flux correction of this step rewrites phi (every face of it) the current flux is read from phiOld (phi_now())
+    if (cs.n_correctors > 0) {
+        for (int d = 0; d < 3; ++d) { std::swap(phi[d].p, phiOld[d].p); std::swap(phi[d].n, phiOld[d].n); }
+        phi_fresh = false;
+    } else {
+        for (int d = 0; d < 3; ++d) FY_TRY(launch_copy_f64(stream, phiOld[d].p, phi[d].p, phi[d].n));
+    }
+    // icoFoamYade.C:71, pimpleFoamYade.C:73-76.  pimple: alpha is 1 here (reset by setSourceZero), so G is re-formed after the
+    // coupling call with this step's alpha; only gradP / divT are needed now.
+    // the opt-in force models (fy_set_force_models on fy_solver_coupling()) read vGrad / ddtU_f, which the shipped path never does
+    const unsigned fm = cpl->c.force_models;
+    const bool want_vgrad = !pimple || (fm & FY_FORCE_GAUSSIAN_TORQUE), want_ddtU = pimple && (fm & FY_FORCE_ADDED_MASS);
+    // single domain, Gaussian mode: the sweep also leaves the force pass's packed cell records (the coupling then skips its own pack pass)
+    double* rec_out = (pimple && comm->size == 1) ? cpl->c.d_cellrec.p : nullptr;
+    // On a single domain in Gaussian mode the sweep is handed to the coupling as a hook and launched right after the locate + deposit (which
+    // read no fluid field): it then runs beside the side stream's tree walk of the few particles the candidate lists hand over -- ~90 us of
+    // memory latency that would otherwise sit alone between the locate and the cells' finalisation (Coupling::mid_hook)
+    const bool defer_sweep = comm->size == 1 && cpl->c.gaussian;
+    std::function<int()> pre_sweep = [&]() -> int {
+        return FVK(launch_pre_coupling, stream, g, U.p, p.p, alpha.p, C3(psn), vGrad.p, gradP.p, divT.p, nullptr, want_vgrad ? 1 : 0, 1, phi_now(),
+                   want_ddtU ? ddtU.p : nullptr, fuse_uold ? Uold.p : nullptr, rec_out, cpl->c.nu, cpl->c.rhoF);
+    };
+    if (defer_sweep) {
+        cpl->c.mid_hook = [](void* u) -> int { return (*static_cast<std::function<int()>*>(u))(); };
+        cpl->c.mid_hook_user = &pre_sweep;
+    } else {
+        cpl->c.mid_hook = nullptr;
+        FY_TRY(pre_sweep());
+    }
+    cpl->c.cellrec_external = rec_out != nullptr;
+
+    if (timing) tim[0].start(stream);
+    if (g.gz > 1) {                      // the particle gathers reach gz planes into the neighbours
+        comm->group_begin();
+        FY_TRY(halo_cells(gradP, 3, g.gz)); FY_TRY(halo_cells(divT, 3, g.gz));
+        if (fm & FY_FORCE_GAUSSIAN_TORQUE) FY_TRY(halo_cells(vGrad, 9, g.gz));
+        if (want_ddtU) FY_TRY(halo_cells(ddtU, 3, g.gz));
         FY_TRY(comm->group_end(stream));
-        // U.oldTime() of the owned cells is written by the pre-coupling sweep that reads U anyway; a slab copies only its ghost planes
-        // (phiHbyA's ddtCorr reads Uold across the slab faces), which the exchange above has just refreshed in U
-        const bool fuse_uold = true;
-        if (comm->size > 1 && g.gz > 0) {
-            const size_t gh = 3 * plane * (size_t)g.gz;
-            FY_TRY(launch_copy_f64(stream, Uold.p, U.p, gh));
-            FY_TRY(launch_copy_f64(stream, Uold.p + 3 * plane * (size_t)(g.gz + g.nz), U.p + 3 * plane * (size_t)(g.gz + g.nz), gh));
-        }
-        // phi.oldTime(): the flux arrays trade places instead of being copied -- what was phi is phiOld now, and until the first
-        // flux correction of this step rewrites phi (every face of it) the current flux is read from phiOld (phi_now())
-        if (cs.n_correctors > 0) {
-            for (int d = 0; d < 3; ++d) { std::swap(phi[d].p, phiOld[d].p); std::swap(phi[d].n, phiOld[d].n); }
-            phi_fresh = false;
-        } else {
-            for (int d = 0; d < 3; ++d) FY_TRY(launch_copy_f64(stream, phiOld[d].p, phi[d].p, phi[d].n));
-        }
-        // icoFoamYade.C:71, pimpleFoamYade.C:73-76.  pimple: alpha is 1 here (reset by setSourceZero), so G is re-formed after the
-        // coupling call with this step's alpha; only gradP / divT are needed now.
-        // the opt-in force models (fy_set_force_models on fy_solver_coupling()) read vGrad / ddtU_f, which the shipped path never does
-        const unsigned fm = cpl->c.force_models;
-        const bool want_vgrad = !pimple || (fm & FY_FORCE_GAUSSIAN_TORQUE), want_ddtU = pimple && (fm & FY_FORCE_ADDED_MASS);
-        // single domain, Gaussian mode: the sweep also leaves the force pass's packed cell records (the coupling then skips its own pack pass)
-        double* rec_out = (pimple && comm->size == 1) ? cpl->c.d_cellrec.p : nullptr;
-        // On a single domain in Gaussian mode the sweep is handed to the coupling as a hook and launched right after the locate + deposit (which
-        // read no fluid field): it then runs beside the side stream's tree walk of the few particles the candidate lists hand over -- ~90 us of
-        // memory latency that would otherwise sit alone between the locate and the cells' finalisation (Coupling::mid_hook)
-        const bool defer_sweep = comm->size == 1 && cpl->c.gaussian;
-        std::function<int()> pre_sweep = [&]() -> int {
-            return FVK(launch_pre_coupling, stream, g, U.p, p.p, alpha.p, C3(psn), vGrad.p, gradP.p, divT.p, nullptr, want_vgrad ? 1 : 0, 1, phi_now(),
-                       want_ddtU ? ddtU.p : nullptr, fuse_uold ? Uold.p : nullptr, rec_out, cpl->c.nu, cpl->c.rhoF);
-        };
-        if (defer_sweep) {
-            cpl->c.mid_hook = [](void* u) -> int { return (*static_cast<std::function<int()>*>(u))(); };
-            cpl->c.mid_hook_user = &pre_sweep;
-        } else {
-            cpl->c.mid_hook = nullptr;
-            FY_TRY(pre_sweep());
-        }
-        cpl->c.cellrec_external = rec_out != nullptr;
+    }
+    usum_pending = false;
+    if (comm->size == 1 && cs.momentum_predictor) {
+        if (!usum_partials.p) FY_TRY(usum_partials.alloc_exact(3 * (size_t)red_blocks(Nc)));
+        FY_HIP(hipEventRecord(ev_usum0, stream));
+        FY_HIP(hipStreamWaitEvent(comm_stream, ev_usum0, 0));
+        FY_TRY(launch_sum3(comm_stream, U.p + 3 * (size_t)g.c0, Nc, usum_partials.p));
+        FY_TRY(launch_reduce_finalize(comm_stream, usum_partials.p, Nc, 3, nullptr, xbar3.p));
+        FY_HIP(hipEventRecord(ev_usum1, comm_stream));
+        usum_pending = true;
+    }
+    {
+        const int rc = cpl->c.set_particle_action(cs.dt);                                 // icoFoamYade.C:74, pimpleFoamYade.C:78
+        cpl->c.mid_hook = nullptr; cpl->c.mid_hook_user = nullptr;                        // (pre_sweep lives in this frame only)
+        FY_TRY(rc);
+    }
+    if (timing) { tim[0].stop(stream); }
 
-        if (timing) tim[0].start(stream);
-        if (g.gz > 1) {                      // the particle gathers reach gz planes into the neighbours
-            comm->group_begin();
-            FY_TRY(halo_cells(gradP, 3, g.gz)); FY_TRY(halo_cells(divT, 3, g.gz));
-            if (fm & FY_FORCE_GAUSSIAN_TORQUE) FY_TRY(halo_cells(vGrad, 9, g.gz));
-            if (want_ddtU) FY_TRY(halo_cells(ddtU, 3, g.gz));
-            FY_TRY(comm->group_end(stream));
+    // alphac.oldTime() is captured lazily by OpenFOAM at alphac.correctBoundaryConditions() (pimpleFoamYade.C:83), i.e. after
+    // FoamYade wrote alpha through untracked operator[]: old == current, fvc::ddt(alphac) == 0.
+    // The kernels keep their alphaOld argument (the term is written out as in UcEqn.H:5 / pEqn.H:30); it is handed the same array
+    // -- what a copy taken here would hold, without the copy or a second stream of reads.
+    if (pimple) FY_TRY(FVK(launch_interp_alpha, stream, g, alpha.p, F3(alphaf)));              // pimpleFoamYade.C:83-85 (alpha ghosts refreshed by the coupling)
+    const int nOuter = pimple ? std::max(cs.n_outer_correctors, 1) : 1;
+    for (int outer = 0; outer < nOuter; ++outer) {
+        // pimple.loop() marks the last outer corrector "finalIteration": relax() then prefers the <name>Final factors [OF-6], and
+        // stores p.prevIter() at the start of every outer iteration when p carries a relaxation factor (storePrevIterFields)
+        const bool final_outer = outer == nOuter - 1;
+        g.u_relax = (final_outer && cs.u_relax_final > 0) ? cs.u_relax_final : cs.u_relax;
+        p_relax_now = (final_outer && cs.p_relax_final > 0) ? cs.p_relax_final : cs.p_relax;
+        if (pimple && p_relax_now > 0 && p_relax_now < 1) {
+            if (!pPrev.p) FY_TRY(pPrev.alloc_exact(nstore));
+            FY_TRY(launch_copy_f64(stream, pPrev.p, p.p, nstore));
         }
-        usum_pending = false;
-        if (comm->size == 1 && cs.momentum_predictor) {
-            if (!usum_partials.p) FY_TRY(usum_partials.alloc_exact(3 * (size_t)red_blocks(Nc)));
-            FY_HIP(hipEventRecord(ev_usum0, stream));
-            FY_HIP(hipStreamWaitEvent(comm_stream, ev_usum0, 0));
-            FY_TRY(launch_sum3(comm_stream, U.p + 3 * (size_t)g.c0, Nc, usum_partials.p));
-            FY_TRY(launch_reduce_finalize(comm_stream, usum_partials.p, Nc, 3, nullptr, xbar3.p));
-            FY_HIP(hipEventRecord(ev_usum1, comm_stream));
-            usum_pending = true;
+        clk_mom.begin(stream);
+        if (pimple) {
+            // explicit stress term of divDevRhoReff from the CURRENT U and this step's alpha (one fused stencil pass)
+            if (outer > 0) FY_TRY(halo_cells(U, 3, 1));
+            FY_TRY(FVK(launch_pre_coupling, stream, g, U.p, p.p, alpha.p, C3(psn), vGrad.p, gradP.p, divT.p, Gt.p, g.upwind == 2 ? 1 : 0, 0));
+            FY_TRY(halo(Gt.p + 2 * 3 * nstore, 3, plane, g.nz, g.gz, 1));     // G is stored by rows; only row z is read across the slab faces
+            FY_TRY(FVK(launch_div_G, stream, g, Gt.p, divG.p));
         }
-        {
-            const int rc = cpl->c.set_particle_action(cs.dt);                                 // icoFoamYade.C:74, pimpleFoamYade.C:78
-            cpl->c.mid_hook = nullptr; cpl->c.mid_hook_user = nullptr;                        // (pre_sweep lives in this frame only)
-            FY_TRY(rc);
+        if (g.upwind == 2) FY_TRY(halo_cells(vGrad, 9, 1));      // linearUpwind reads grad(U) of the upwind neighbour (ico: written at step start)
+        if (g.upwind >= 3) {                                     // the limited schemes: gradient ratio from grad(magSqr(U)) of the current U
+            FY_TRY(halo_cells(U, 3, 1));
+            FY_TRY(FVK(launch_grad_magsqr, stream, g, U.p, gradL.p));
+            FY_TRY(halo_cells(gradL, 3, 1));
         }
-        if (timing) { tim[0].stop(stream); }
+        FY_TRY(FVK(launch_assemble_momentum, stream, g, U.p, Uold.p, alpha.p, /* alphaOld */ alpha.p, C3(alphaf), phi_now(), uSource.p, uSourceDrag.p,
+                                        divG.p, g.upwind >= 3 ? gradL.p : vGrad.p, M7(), src.p, rAU.p));
+        rAU_new = true;
+        if (pimple) {
+            FY_TRY(halo_cells(rAU, 1, 1));
+            FY_TRY(FVK(launch_rAUf_phi_forces, stream, g, rAU.p, uSource.p, F3(rAUf), F3(phiForces)));  // uSource ghosts refreshed by the coupling
+        }
+        if (cs.momentum_predictor) {
+            FY_TRY(FVK(launch_bmom, stream, g, src.p, p.p, C3(psn), C3(phiForces), C3(rAUf), bmom.p));
+            int it = 0;
+            FY_TRY(solve_momentum(&it));
+            st.u_iters_total += it;
+        }
+        clk_mom.end(stream);
+        for (int corr = 0; corr < cs.n_correctors; ++corr) FY_TRY(corrector(outer == nOuter - 1 && corr == cs.n_correctors - 1));
+        if (g.nut && final_outer) FY_TRY(turbulence_correct());        // pimple.turbCorr(): on the final outer iteration only (the default) -- pimpleFoamYade.C:101-104
+    }
+    if (hold_sources) sources_pending = true;                                              // reset deferred to the next step (fy_solver_hold_sources)
+    else FY_TRY(cpl->c.set_source_zero());                                                // icoFoamYade.C:147, pimpleFoamYade.C:109
+    if (timing) tim[3].stop(stream);
+    FY_HIP(hipStreamSynchronize(stream));
+    if (adjust_phi) {
+        int e = 0;
+        FY_HIP(hipMemcpy(&e, adj_err.p, sizeof(int), hipMemcpyDeviceToHost));
+        if (e) return fail(FY_ERR_UNSUPPORTED, "adjustPhi: continuity error cannot be removed by adjusting the outflow (the in- and outflow through the "
+                                               "fixed-value patches do not balance and no adjustable outflow is left) -- OpenFOAM stops here too");
+    }
+    if (courant_slot >= 0) note_courant(red_host + courant_slot);                         // the deferred diagnostics have landed
+    for (int sl : cont_slots) note_cont_err(red_host + sl);
+    if (carry_slot >= 0) { carry_h[0] = red_host[carry_slot]; carry_h[1] = red_host[carry_slot + 1]; carry_valid = true; }
+    if (timing) {
+        clk_mom.collect(); clk_pres.collect();
+        st.ms_momentum = clk_mom.total_ms; st.ms_pressure = clk_pres.total_ms;
+        st.ms_particle = tim[0].ms() - cpl->c.marks.ms(6, 7);      // (the sweep that ran as the coupling's hook is the solver's, not FoamYade's: it counts as "other")
+        st.ms_total = tim[3].ms();
+        st.ms_other = st.ms_total - st.ms_particle - st.ms_momentum - st.ms_pressure;
+        for (auto& k : kc) k.collect();
+    }
+    return FY_OK;
+}
 
-        // alphac.oldTime() is captured lazily by OpenFOAM at alphac.correctBoundaryConditions() (pimpleFoamYade.C:83), i.e. after
-        // FoamYade wrote alpha through untracked operator[]: old == current, fvc::ddt(alphac) == 0.
-        // The kernels keep their alphaOld argument (the term is written out as in UcEqn.H:5 / pEqn.H:30); it is handed the same array
-        // -- what a copy taken here would hold, without the copy or a second stream of reads.
-        if (pimple) FY_TRY(FVK(launch_interp_alpha, stream, g, alpha.p, F3(alphaf)));              // pimpleFoamYade.C:83-85 (alpha ghosts refreshed by the coupling)
-        const int nOuter = pimple ? std::max(cs.n_outer_correctors, 1) : 1;
-        for (int outer = 0; outer < nOuter; ++outer) {
-            // pimple.loop() marks the last outer corrector "finalIteration": relax() then prefers the <name>Final factors [OF-6], and
-            // stores p.prevIter() at the start of every outer iteration when p carries a relaxation factor (storePrevIterFields)
-            const bool final_outer = outer == nOuter - 1;
-            g.u_relax = (final_outer && cs.u_relax_final > 0) ? cs.u_relax_final : cs.u_relax;
-            p_relax_now = (final_outer && cs.p_relax_final > 0) ? cs.p_relax_final : cs.p_relax;
-            if (pimple && p_relax_now > 0 && p_relax_now < 1) {
-                if (!pPrev.p) FY_TRY(pPrev.alloc_exact(nstore));
-                FY_TRY(launch_copy_f64(stream, pPrev.p, p.p, nstore));
-            }
-            clk_mom.begin(stream);
-            if (pimple) {
-                // explicit stress term of divDevRhoReff from the CURRENT U and this step's alpha (one fused stencil pass)
-                if (outer > 0) FY_TRY(halo_cells(U, 3, 1));
-                FY_TRY(FVK(launch_pre_coupling, stream, g, U.p, p.p, alpha.p, C3(psn), vGrad.p, gradP.p, divT.p, Gt.p, g.upwind == 2 ? 1 : 0, 0));
-                FY_TRY(halo(Gt.p + 2 * 3 * nstore, 3, plane, g.nz, g.gz, 1));     // G is stored by rows; only row z is read across the slab faces
-                FY_TRY(FVK(launch_div_G, stream, g, Gt.p, divG.p));
-            }
-            if (g.upwind == 2) FY_TRY(halo_cells(vGrad, 9, 1));      // linearUpwind reads grad(U) of the upwind neighbour (ico: written at step start)
-            if (g.upwind >= 3) {                                     // the limited schemes: gradient ratio from grad(magSqr(U)) of the current U
-                FY_TRY(halo_cells(U, 3, 1));
-                FY_TRY(FVK(launch_grad_magsqr, stream, g, U.p, gradL.p));
-                FY_TRY(halo_cells(gradL, 3, 1));
-            }
-            FY_TRY(FVK(launch_assemble_momentum, stream, g, U.p, Uold.p, alpha.p, /* alphaOld */ alpha.p, C3(alphaf), phi_now(), uSource.p, uSourceDrag.p,
-                                            divG.p, g.upwind >= 3 ? gradL.p : vGrad.p, M7(), src.p, rAU.p));
-            rAU_new = true;
-            if (pimple) {
-                FY_TRY(halo_cells(rAU, 1, 1));
-                FY_TRY(FVK(launch_rAUf_phi_forces, stream, g, rAU.p, uSource.p, F3(rAUf), F3(phiForces)));  // uSource ghosts refreshed by the coupling
-            }
-            if (cs.momentum_predictor) {
-                FY_TRY(FVK(launch_bmom, stream, g, src.p, p.p, C3(psn), C3(phiForces), C3(rAUf), bmom.p));
-                int it = 0;
-                FY_TRY(solve_momentum(&it));
-                st.u_iters_total += it;
-            }
-            clk_mom.end(stream);
-            for (int corr = 0; corr < cs.n_correctors; ++corr) FY_TRY(corrector(outer == nOuter - 1 && corr == cs.n_correctors - 1));
-            if (g.nut && final_outer) FY_TRY(turbulence_correct());        // pimple.turbCorr(): on the final outer iteration only (the default) -- pimpleFoamYade.C:101-104
-        }
-        if (hold_sources) sources_pending = true;                                              // reset deferred to the next step (fy_solver_hold_sources)
-        else FY_TRY(cpl->c.set_source_zero());                                                // icoFoamYade.C:147, pimpleFoamYade.C:109
-        if (timing) tim[3].stop(stream);
-        FY_HIP(hipStreamSynchronize(stream));
-        if (adjust_phi) {
-            int e = 0;
-            FY_HIP(hipMemcpy(&e, adj_err.p, sizeof(int), hipMemcpyDeviceToHost));
-            if (e) return fail(FY_ERR_UNSUPPORTED, "adjustPhi: continuity error cannot be removed by adjusting the outflow (the in- and outflow through the "
-                                                   "fixed-value patches do not balance and no adjustable outflow is left) -- OpenFOAM stops here too");
-        }
-        if (courant_slot >= 0) note_courant(red_host + courant_slot);                         // the deferred diagnostics have landed
-        for (int sl : cont_slots) note_cont_err(red_host + sl);
-        if (carry_slot >= 0) { carry_h[0] = red_host[carry_slot]; carry_h[1] = red_host[carry_slot + 1]; carry_valid = true; }
-        if (timing) {
-            clk_mom.collect(); clk_pres.collect();
-            st.ms_momentum = clk_mom.total_ms; st.ms_pressure = clk_pres.total_ms;
-            st.ms_particle = tim[0].ms() - cpl->c.marks.ms(6, 7);      // (the sweep that ran as the coupling's hook is the solver's, not FoamYade's: it counts as "other")
-            st.ms_total = tim[3].ms();
-            st.ms_other = st.ms_total - st.ms_particle - st.ms_momentum - st.ms_pressure;
-            for (auto& k : kc) k.collect();
-        }
+// field lookup; cell fields are returned/accepted as the OWNED part only (ghost planes are an implementation detail)
+int Solver::field(const char* name, double** ptr, size_t* count) {
+    const std::string s = name ? name : "";
+    const size_t n = (size_t)Nc;
+    struct E { const char* nm; double* p; size_t c; int comp; };
+    const E tab[] = {{"U", U.p, 3 * n, 3}, {"p", p.p, n, 1}, {"phi_x", phi[0].p, phi[0].n, 0}, {"phi_y", phi[1].p, phi[1].n, 0}, {"phi_z", phi[2].p, phi[2].n, 0},
+                     {"rAU", rAU.p, n, 1}, {"HbyA", HbyA.p, 3 * n, 3}, {"p_rhs", prhs.p, n, 1}, {"mom_diag", mdiag.p, n, 1}, {"mom_src", src.p, 3 * n, 3},
+                     {"alpha", alpha.p, n, 1}, {"uSource", uSource.p, 3 * n, 3}, {"uSourceDrag", uSourceDrag.p, n, 1}, {"uParticle", uParticle.p, 3 * n, 3},
+                     {"gradP", gradP.p, 3 * n, 3}, {"divT", divT.p, 3 * n, 3}, {"vGrad", vGrad.p, 9 * n, 9}, {"ddtU", ddtU.p, 3 * n, 3}, {"nut", nut.p, n, 1}, {"k", kturb.p, n, 1}, {"epsilon", epsturb.p, n, 1}};
+    for (const E& e : tab) if (s == e.nm) {
+        if (!e.p) return fail(FY_ERR_INVALID, "solver field '%s' does not exist in this case (no turbulence model)", s.c_str());
+        // kEqn / kEpsilon assemble and solve their transport equations in the momentum matrix's storage after the last corrector
+        // (turbulence_correct): these three diagnostics would then return transport-equation data beside a momentum rAU
+        const bool transport = cs.turbulence_model == FY_TURBULENCE_KEQN || cs.turbulence_model == FY_TURBULENCE_KEPSILON;
+        if (transport && (s == "HbyA" || s == "mom_diag" || s == "mom_src"))
+            return fail(FY_ERR_UNSUPPORTED, "solver field '%s' is overwritten by the turbulence transport solve in this case (kEqn / kEpsilon reuse the momentum matrix's storage)", s.c_str());
+        *ptr = e.p + (size_t)e.comp * g.c0;          // skip the ghost planes below the owned range (comp = 0: face array)
+        *count = e.c;
         return FY_OK;
     }
-
-    // field lookup; cell fields are returned/accepted as the OWNED part only (ghost planes are an implementation detail)
-    int field(const char* name, double** ptr, size_t* count) {
-        const std::string s = name ? name : "";
-        const size_t n = (size_t)Nc;
-        struct E { const char* nm; double* p; size_t c; int comp; };
-        const E tab[] = {{"U", U.p, 3 * n, 3}, {"p", p.p, n, 1}, {"phi_x", phi[0].p, phi[0].n, 0}, {"phi_y", phi[1].p, phi[1].n, 0}, {"phi_z", phi[2].p, phi[2].n, 0},
-                         {"rAU", rAU.p, n, 1}, {"HbyA", HbyA.p, 3 * n, 3}, {"p_rhs", prhs.p, n, 1}, {"mom_diag", mdiag.p, n, 1}, {"mom_src", src.p, 3 * n, 3},
-                         {"alpha", alpha.p, n, 1}, {"uSource", uSource.p, 3 * n, 3}, {"uSourceDrag", uSourceDrag.p, n, 1}, {"uParticle", uParticle.p, 3 * n, 3},
-                         {"gradP", gradP.p, 3 * n, 3}, {"divT", divT.p, 3 * n, 3}, {"vGrad", vGrad.p, 9 * n, 9}, {"ddtU", ddtU.p, 3 * n, 3}, {"nut", nut.p, n, 1}, {"k", kturb.p, n, 1}, {"epsilon", epsturb.p, n, 1}};
-        for (const E& e : tab) if (s == e.nm) {
-            if (!e.p) return fail(FY_ERR_INVALID, "solver field '%s' does not exist in this case (no turbulence model)", s.c_str());
-            // kEqn / kEpsilon assemble and solve their transport equations in the momentum matrix's storage after the last corrector
-            // (turbulence_correct): these three diagnostics would then return transport-equation data beside a momentum rAU
-            const bool transport = cs.turbulence_model == FY_TURBULENCE_KEQN || cs.turbulence_model == FY_TURBULENCE_KEPSILON;
-            if (transport && (s == "HbyA" || s == "mom_diag" || s == "mom_src"))
-                return fail(FY_ERR_UNSUPPORTED, "solver field '%s' is overwritten by the turbulence transport solve in this case (kEqn / kEpsilon reuse the momentum matrix's storage)", s.c_str());
-            *ptr = e.p + (size_t)e.comp * g.c0;          // skip the ghost planes below the owned range (comp = 0: face array)
-            *count = e.c;
-            return FY_OK;
-        }
-        MgLev& L = *mg[0];
-        const struct { const char* nm; double* p; } pm[] = {{"p_diag", L.diag.p}, {"p_ux", L.ux.p}, {"p_uy", L.uy.p}, {"p_uz", L.uz.p}};
-        for (auto& e : pm) if (s == e.nm) { *ptr = e.p + L.A.c0; *count = n; return FY_OK; }
-        return fail(FY_ERR_INVALID, "unknown solver field '%s'", s.c_str());
-    }
-};
+    MgLev& L = *mg[0];
+    const struct { const char* nm; double* p; } pm[] = {{"p_diag", L.diag.p}, {"p_ux", L.ux.p}, {"p_uy", L.uy.p}, {"p_uz", L.uz.p}};
+    for (auto& e : pm) if (s == e.nm) { *ptr = e.p + L.A.c0; *count = n; return FY_OK; }
+    return fail(FY_ERR_INVALID, "unknown solver field '%s'", s.c_str());
+}
 
 }  // namespace fy
-
-struct fy_solver { fy::Solver s; };
-
-extern "C" {
-
-// documented defaults: icoFoam cavity / DPMFoam tutorial settings (the reference ships no case)
-void fy_case_defaults(fy_case_desc* c, int solver) {
-    if (!c) return;
-    std::memset(c, 0, sizeof(*c));
-    c->solver = solver;
-    c->nx = c->ny = c->nz = 32; c->dx = 0.1 / 32; c->dt = 0.005; c->nu = 0.01; c->rho_fluid = 1000.0; c->rho_particle = 2650.0;
-    for (int q = 0; q < 6; ++q) { c->u_bc[q] = FY_BC_U_FIXED_VALUE; c->p_bc[q] = FY_BC_P_ZERO_GRADIENT; }
-    c->n_outer_correctors = 1; c->n_correctors = 2; c->n_non_orth_correctors = 0; c->momentum_predictor = 1;
-    c->p_ref_cell = 0; c->p_ref_value = 0.0;
-    c->p_solver = FY_PSOLVER_PCG_MG;
-    c->p_tol = 1e-6; c->p_rel_tol = 0.05; c->p_final_tol = 1e-6; c->p_final_rel_tol = 0.0; c->p_max_iter = 1000;
-    c->u_tol = 1e-5; c->u_rel_tol = 0.0; c->u_max_iter = 1000;
-    c->adjust_time_step = 0; c->max_co = 1.0; c->max_delta_t = 1e300;
-    c->u_relax = 1.0; c->u_relax_final = 0.0; c->p_relax = 0.0; c->p_relax_final = 0.0;
-    c->convection_limiter_k = 1.0;
-    c->k_tol = 1e-6; c->k_rel_tol = 0.0; c->k_max_iter = 1000; c->k_relax = 0.0; c->k_convection_scheme = FY_CONVECTION_UPWIND;
-    c->eps_tol = 1e-6; c->eps_rel_tol = 0.0; c->eps_max_iter = 1000; c->eps_relax = 0.0; c->eps_convection_scheme = FY_CONVECTION_UPWIND;
-    c->wf_kappa = 0.41; c->wf_E = 9.8;                      // [OF-6 nutWallFunctionFvPatchScalarField defaults]
-    c->ras_cmu = 0.09; c->ras_c1 = 1.44; c->ras_c2 = 1.92; c->ras_c3 = 0.0; c->ras_sigmak = 1.0; c->ras_sigmaeps = 1.3;      // [OF-6 kEpsilon.C defaults]
-    c->turbulence_model = FY_TURBULENCE_LAMINAR; c->les_ck = 0.094; c->les_ce = 1.048; c->les_delta_coeff = 1.0;     // [OF-6 Smagorinsky.C, cubeRootVolDelta.C defaults]
-}
-
-static int solver_create_impl(const fy_case_desc* c, const fy_transport* tr, int device_ordinal, fy::Comm* cm, fy_solver** out) {
-    if (!out) return fy::fail(FY_ERR_INVALID, "null out");
-    *out = nullptr;
-    fy_solver* s = new (std::nothrow) fy_solver();
-    if (!s) return fy::fail(FY_ERR_INVALID, "out of host memory");
-    int rc = s->s.create(c, tr, device_ordinal, cm);
-    if (rc != FY_OK) { delete s; return rc; }
-    *out = s;
-    return FY_OK;
-}
-
-int fy_solver_create(const fy_case_desc* c, const fy_transport* tr, int device_ordinal, fy_solver** out) {
-    return solver_create_impl(c, tr, device_ordinal, nullptr, out);
-}
-
-int fy_solver_create_slab(const fy_case_desc* c, const fy_transport* tr, int device_ordinal, fy_comm* comm, fy_solver** out) {
-    if (!comm || !comm->c) return fy::fail(FY_ERR_INVALID, "null communicator");
-    return solver_create_impl(c, tr, device_ordinal, comm->c, out);
-}
-
-int fy_comm_create_local_group(int n, fy_comm** out) {
-    if (n < 1 || !out) return fy::fail(FY_ERR_INVALID, "bad arguments");
-    std::vector<fy::Comm*> cs((size_t)n);
-    FY_TRY(fy::local_comm_group_create(n, cs.data()));
-    for (int r = 0; r < n; ++r) { out[r] = new fy_comm(); out[r]->c = cs[(size_t)r]; }
-    return FY_OK;
-}
-int fy_comm_create_host(int rank, int size, const fy_comm_callbacks* cb, fy_comm** out) {
-    if (!out) return fy::fail(FY_ERR_INVALID, "null out");
-    fy::Comm* c = nullptr;
-    FY_TRY(fy::host_comm_create(rank, size, cb, &c));
-    *out = new fy_comm(); (*out)->c = c;
-    return FY_OK;
-}
-int fy_rccl_unique_id(void* out128) { return fy::rccl_unique_id(out128); }
-int fy_comm_create_rccl(int rank, int size, const void* id128, int device, fy_comm** out) {
-    if (!out) return fy::fail(FY_ERR_INVALID, "null out");
-    fy::Comm* c = nullptr;
-    FY_TRY(fy::rccl_comm_create(rank, size, id128, device, &c));
-    *out = new fy_comm(); (*out)->c = c;
-    return FY_OK;
-}
-int fy_comm_destroy(fy_comm* c) { if (c) { delete c->c; delete c; } return FY_OK; }
-int fy_comm_stats(fy_comm* c, uint64_t* out4) {
-    if (!c || !c->c || !out4) return fy::fail(FY_ERR_INVALID, "fy_comm_stats: null argument");
-    out4[0] = c->c->n_exchange; out4[1] = c->c->n_allreduce; out4[2] = c->c->n_allgather; out4[3] = c->c->exchange_bytes;
-    return FY_OK;
-}
-int fy_comm_selftest(fy_comm* c, int device_ordinal) { if (!c || !c->c) return fy::fail(FY_ERR_INVALID, "null communicator"); return fy::comm_selftest(c->c, device_ordinal); }
-int fy_comm_rank(fy_comm* c) { return c && c->c ? c->c->rank : -1; }
-int fy_comm_size(fy_comm* c) { return c && c->c ? c->c->size : -1; }
-
-#define FY_S(s) if (!(s)) return fy::fail(FY_ERR_INVALID, "null fy_solver")
-
-fy_ctx* fy_solver_coupling(fy_solver* s) { return s ? s->s.cpl : nullptr; }
-int fy_solver_step(fy_solver* s) { FY_S(s); return s->s.step(); }
-int fy_solver_get_stats(fy_solver* s, fy_step_stats* out) { FY_S(s); if (!out) return fy::fail(FY_ERR_INVALID, "null out"); *out = s->s.st; return FY_OK; }
-int fy_solver_local_cells(fy_solver* s) { return s ? s->s.Nc : -1; }
-
-int fy_solver_hold_sources(fy_solver* s, int hold) {
-    FY_S(s);
-    s->s.hold_sources = hold != 0;
-    if (!hold && s->s.sources_pending) { FY_HIP(hipSetDevice(s->s.device)); FY_TRY(s->s.cpl->c.set_source_zero()); s->s.sources_pending = false; }
-    return FY_OK;
-}
-
-int fy_solver_field_count(fy_solver* s, const char* name, int64_t* count) {
-    FY_S(s);
-    if (!count) return fy::fail(FY_ERR_INVALID, "null count");
-    double* p; size_t n;
-    FY_TRY(s->s.field(name, &p, &n));
-    *count = (int64_t)n;
-    return FY_OK;
-}
-
-int fy_solver_read_field_host(fy_solver* s, const char* name, double* out) {
-    FY_S(s);
-    double* p; size_t n;
-    FY_TRY(s->s.field(name, &p, &n));
-    FY_HIP(hipSetDevice(s->s.device));
-    FY_HIP(hipMemcpyAsync(out, p, n * sizeof(double), hipMemcpyDeviceToHost, s->s.stream));
-    FY_HIP(hipStreamSynchronize(s->s.stream));
-    return FY_OK;
-}
-
-int fy_solver_write_field_host(fy_solver* s, const char* name, const double* in) {
-    FY_S(s);
-    double* p; size_t n;
-    FY_TRY(s->s.field(name, &p, &n));
-    FY_HIP(hipSetDevice(s->s.device));
-    FY_HIP(hipMemcpyAsync(p, in, n * sizeof(double), hipMemcpyHostToDevice, s->s.stream));
-    s->s.carry_valid = false;                 // whatever was written, the carried Courant sums may no longer describe phi
-    s->s.p_sum_valid = false;
-    if (std::string(name) == "U") {           // createPhi (collective when there are several slabs)
-        FY_TRY(s->s.halo_cells(s->s.U, 3, 1));
-        FY_TRY(fy::launch_flux_of(s->s.stream, s->s.g, s->s.U.p, s->s.F3(s->s.phi)));
-    }
-    if (std::string(name) == "nut") FY_TRY(s->s.halo_cells(s->s.nut, 1, 1));
-    if (std::string(name) == "k") FY_TRY(s->s.halo_cells(s->s.kturb, 1, 1));
-    if (std::string(name) == "epsilon") FY_TRY(s->s.halo_cells(s->s.epsturb, 1, 1));
-    FY_HIP(hipStreamSynchronize(s->s.stream));
-    return FY_OK;
-}
-
-int fy_solver_destroy(fy_solver* s) { delete s; return FY_OK; }
-
-int fy_solver_apply_p_matrix_host(fy_solver* s, const double* x, double* y) {
-    FY_S(s);
-    fy::Solver& S = s->s;
-    FY_HIP(hipSetDevice(S.device));
-    FY_HIP(hipMemcpyAsync(S.pp.p + S.g.c0, x, (size_t)S.Nc * sizeof(double), hipMemcpyHostToDevice, S.stream));
-    FY_TRY(S.halo_cells(S.pp, 1, 1));
-    FY_TRY(fy::launch_p_apply(S.stream, S.mg[0]->A, S.pp.p, S.pw.p));
-    FY_HIP(hipMemcpyAsync(y, S.pw.p + S.g.c0, (size_t)S.Nc * sizeof(double), hipMemcpyDeviceToHost, S.stream));
-    FY_HIP(hipStreamSynchronize(S.stream));
-    return FY_OK;
-}
-
-int fy_solver_solve_p_host(fy_solver* s, const double* rhs, double* x, int* iterations) {
-    FY_S(s);
-    if (!rhs || !x) return fy::fail(FY_ERR_INVALID, "fy_solver_solve_p_host: null argument");
-    fy::Solver& S = s->s;
-    FY_HIP(hipSetDevice(S.device));
-    FY_HIP(hipMemcpyAsync(S.prhs.p + S.g.c0, rhs, (size_t)S.Nc * sizeof(double), hipMemcpyHostToDevice, S.stream));
-    FY_HIP(hipMemcpyAsync(S.p.p + S.g.c0, x, (size_t)S.Nc * sizeof(double), hipMemcpyHostToDevice, S.stream));
-    S.p_sum_valid = false;
-    const int before = S.st.p_iters_total;
-    FY_TRY(S.solve_pressure(true));
-    FY_HIP(hipMemcpyAsync(x, S.p.p + S.g.c0, (size_t)S.Nc * sizeof(double), hipMemcpyDeviceToHost, S.stream));
-    FY_HIP(hipStreamSynchronize(S.stream));
-    if (iterations) *iterations = S.st.p_iters_total - before;
-    return FY_OK;
-}
-
-int fy_solver_time_p_apply(fy_solver* s, int reps, double* avg_ms) {
-    FY_S(s);
-    if (reps < 1 || !avg_ms) return fy::fail(FY_ERR_INVALID, "bad arguments");
-    fy::Solver& S = s->s;
-    fy::EventTimer t;
-    FY_TRY(t.init());
-    for (int i = 0; i < 3; ++i) FY_TRY(fy::launch_p_apply(S.stream, S.mg[0]->A, S.pp.p, S.pw.p));
-    t.start(S.stream);
-    for (int i = 0; i < reps; ++i) FY_TRY(fy::launch_p_apply(S.stream, S.mg[0]->A, S.pp.p, S.pw.p));
-    t.stop(S.stream);
-    *avg_ms = t.ms() / reps;
-    t.destroy();
-    return FY_OK;
-}
-
-int fy_solver_enable_kernel_timing(fy_solver* s, int on) {
-    FY_S(s);
-    for (auto& k : s->s.kc) { k.reset(); k.on = on != 0; }
-    return FY_OK;
-}
-
-int fy_solver_get_kernel_timing(fy_solver* s, const char* kernel, double* total_ms, int64_t* launches) {
-    FY_S(s);
-    const std::string k = kernel ? kernel : "";
-    int idx = k == "mg_smooth_l0" ? fy::Solver::KC_MG_SMOOTH0 : k == "p_apply_dot" ? fy::Solver::KC_P_APPLY_DOT : k == "mom_pass" ? fy::Solver::KC_MOM_PASS : -1;
-    if (idx < 0 || !total_ms || !launches) return fy::fail(FY_ERR_INVALID, "unknown kernel clock '%s'", k.c_str());
-    *total_ms = s->s.kc[idx].total_ms; *launches = s->s.kc[idx].launches;
-    return FY_OK;
-}
-
-}  // extern "C"
