@@ -391,6 +391,10 @@ typedef struct fy_comm_callbacks {
 int fy_comm_create_host(int rank, int size, const fy_comm_callbacks* cb, fy_comm** out);
 /* diagnostic: calls made through this communicator so far: {neighbour exchanges, all-reduces, all-gathers, bytes sent to neighbours} */
 int fy_comm_stats(fy_comm*, uint64_t* out4);
+/* the same call counts by the solver phase that issued them, as text: one line "<phase> <exchanges> <all-reduces> <all-gathers>" per phase
+ * (step_start, particle, momentum, momentum_solve, corrector, p_operators, pcg, vcycle, turbulence ...); the per-step collective budget
+ * of the slab solver is asserted on these (tests/test_slabs.py) */
+int fy_comm_stats_by_tag(fy_comm*, char* buf, size_t cap);
 /* collective known-answer run of every operation the slab solver uses on this communicator (a grouped two-field neighbour exchange, sum and
  * max all-reduce, all-gather); bench.py runs it in throw-away processes before it commits a multi-GPU run to the communicator */
 int fy_comm_selftest(fy_comm*, int device_ordinal);

@@ -294,3 +294,70 @@ def test_slabs_next_to_a_parallel_yade(product, n_slabs, workers):
     compare(many, one, ("U", "p"), 1e-5)
     compare(many, one, ("alpha",), 1e-9)
     many.close(); one.close()
+
+
+def _coupled_pimple_run(product, n_slabs, steps=3, n=12):
+    nz = 12 * n_slabs
+    dx = 0.1 / n
+    case = product.make_case(1, n, n, nz, dx, 2e-4, 1e-5, u_bc=[0] * 6, u_val=[(0, 0, 0)] * 6, g=(0, 0, -9.81), p_bc=[2] * 6)
+    many = product.VirtualSlabs(case, n_slabs)
+    gcase = gc.Case("s", n, n, nz, 0.1, gaussian=1, np_=4000, seed=21, cluster=200, fast=20, vel_scale=0.05)
+    per_step = []
+    for step in range(steps):
+        rec = gc.particle_records(gcase, step)
+        rec = rec[(rec[:, 2] > 0) & (rec[:, 2] < nz * dx)]
+        many.set_particles(rec)
+        before = many.comm_stats_by_tag(0)
+        many.step()
+        after = many.comm_stats_by_tag(0)
+        tot = [sum(after[k][q] - before.get(k, (0, 0, 0))[q] for k in after) for q in range(3)]
+        per_step.append((tot, many.stats()[0]))
+    return many, per_step
+
+
+def test_collective_budget_per_step(product):
+    """The slab solver's collectives are latency-bound RCCL calls on real hardware: their number per coupled step is a budget,
+    asserted here so that it cannot creep back (round 3: ~112 per step at two slabs; round 4: 1 exchange + 1 all-gather + 2 all-reduces per
+    PCG iteration, one collective per diagnostics group, no exchange for ghost planes that are still valid).
+    pimpleFoamYade, nOuter 1, nCorr 2, momentum predictor with m Jacobi passes, I PCG iterations in the step's two solves:
+      exchanges   <= 1 (step start) + 5 (particle phase) + 2 (stress row, rAU) + (m - 1) + 2 x 2 (HbyA, p per corrector) + 1 (U, second corrector)
+                     + 1 (operator ghosts) + I
+      all-reduces <= 1 (sum U) + m + 1 (reference term) + 2 (initial residuals) + 2 I + 2 (diagnostics groups)
+      all-gathers <= 1 (coarse operators) + I"""
+    many, per_step = _coupled_pimple_run(product, 2)
+    for (ex, ar, ag), st in per_step[1:]:             # (the first step also carries one-off set-up exchanges)
+        m, I = st["u_iters_total"] + 1, st["p_iters_total"]
+        assert ex <= 14 + (m - 1) + I, (ex, m, I)
+        assert ar <= 6 + m + 2 * I, (ar, m, I)
+        assert ag <= 1 + I, (ag, I)
+        if I <= 4 and m <= 3:
+            assert ex + ar + ag <= 60
+    many.close()
+
+
+def test_deep_vcycle_equals_the_exchange_per_sweep_schedule(product, monkeypatch):
+    """the communication-avoiding V-cycle recomputes the ghost rows the per-sweep schedule exchanges: same operands, same operations ->
+    the pressure solver's iterates, and with them every field, are the same BITS (FOAMYADE_NO_DEEP_VCYCLE=1 is round 3's schedule).
+    Fluid only: the particle phase's scatters are summed in an order that changes from run to run."""
+    n, nz, n_slabs = 16, 36, 3
+
+    def run():
+        case = cavity(product, 1, n, nz, p_solver=1)
+        vs = product.VirtualSlabs(case, n_slabs)
+        vs.set("U", np.random.RandomState(5).rand(n * n * nz, 3) * 0.1)
+        ex0 = vs.comm_stats(0)[0]
+        its = []
+        for _ in range(4):
+            vs.step()
+            its.append(vs.stats()[0]["p_iters_total"])
+        return vs, vs.comm_stats(0)[0] - ex0, its
+
+    deep, ex_deep, its_deep = run()
+    monkeypatch.setenv("FOAMYADE_NO_DEEP_VCYCLE", "1")
+    old, ex_old, its_old = run()
+    monkeypatch.delenv("FOAMYADE_NO_DEEP_VCYCLE")
+    assert ex_deep < ex_old and sum(its_deep) > 0                                     # fewer exchanges ...
+    assert its_deep == its_old
+    for nm in ("p", "U", "phi_z"):
+        np.testing.assert_array_equal(deep.get(nm), old.get(nm), err_msg=nm)            # ... for the same answer
+    deep.close(); old.close()

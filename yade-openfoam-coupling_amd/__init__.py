@@ -222,6 +222,7 @@ def lib():
     L.fy_comm_create_local_group.argtypes = [C.c_int, C.POINTER(vp)]
     L.fy_comm_destroy.argtypes = [vp]
     L.fy_comm_stats.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.fy_comm_stats_by_tag.argtypes = [vp, C.c_char_p, C.c_size_t]
     L.fy_comm_selftest.argtypes = [vp, C.c_int]
     L.fy_comm_rank.argtypes = [vp]
     L.fy_comm_size.argtypes = [vp]
@@ -951,6 +952,16 @@ class VirtualSlabs:
         out = (C.c_uint64 * 4)()
         _check(lib().fy_comm_stats(self.comms[rank], out))
         return tuple(int(v) for v in out)
+
+    def comm_stats_by_tag(self, rank=0):
+        """{phase: (exchanges, all-reduces, all-gathers)} issued so far by one slab's communicator"""
+        buf = C.create_string_buffer(1 << 14)
+        _check(lib().fy_comm_stats_by_tag(self.comms[rank], buf, len(buf)))
+        out = {}
+        for line in buf.value.decode().splitlines():
+            nm, a, b, c = line.split()
+            out[nm] = (int(a), int(b), int(c))
+        return out
 
     def close(self):
         for s in self.solvers:

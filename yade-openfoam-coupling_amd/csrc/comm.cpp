@@ -15,6 +15,43 @@
 
 namespace fy {
 
+namespace {
+__global__ void k_fold_gathered(const double* __restrict__ g, int size, int n, unsigned max_mask, double* __restrict__ out) {
+    const int q = threadIdx.x;
+    if (q >= n) return;
+    const bool mx = (max_mask >> q) & 1u;
+    double x = g[q];
+    for (int r = 1; r < size; ++r) { const double y = g[(size_t)r * n + q]; x = mx ? (x > y ? x : y) : x + y; }
+    out[q] = x;
+}
+}  // namespace
+
+int Comm::allreduce_ops(hipStream_t s, double* dev, int n, unsigned max_mask) {
+    if (size == 1 || n <= 0) return FY_OK;
+    if (n > 32) return fail(FY_ERR_INVALID, "allreduce_ops: at most 32 slots");
+    const unsigned all = n == 32 ? 0xffffffffu : ((1u << n) - 1u);
+    if ((max_mask & all) == 0) return allreduce(s, dev, n, false);
+    if ((max_mask & all) == all) return allreduce(s, dev, n, true);
+    const size_t need = (size_t)size * (size_t)n;
+    if (ops_scratch_n < need) {
+        if (ops_scratch) (void)hipFree(ops_scratch);
+        ops_scratch = nullptr; ops_scratch_n = 0;
+        FY_HIP(hipMalloc((void**)&ops_scratch, std::max(need, (size_t)size * 32) * sizeof(double)));
+        ops_scratch_n = std::max(need, (size_t)size * 32);
+    }
+    const uint64_t g0 = n_allgather;
+    auto it = by_tag.find(tag);
+    const uint64_t t0 = it == by_tag.end() ? 0 : it->second[2];
+    FY_TRY(allgather(s, dev, ops_scratch, (size_t)n));
+    // (counted as what it stands for: one all-reduce)
+    n_allreduce += n_allgather - g0; n_allgather = g0;
+    auto& bt = by_tag[tag];
+    bt[1] += bt[2] - t0; bt[2] = t0;
+    hipLaunchKernelGGL(k_fold_gathered, dim3(1), dim3(32), 0, s, ops_scratch, size, n, max_mask, dev);
+    if (hipGetLastError() != hipSuccess) return fail(FY_ERR_HIP, "allreduce_ops: fold launch failed");
+    return FY_OK;
+}
+
 int SelfComm::allgather(hipStream_t s, const double* send, double* recv, size_t n) {
     if (send != recv) FY_HIP(hipMemcpyAsync(recv, send, n * sizeof(double), hipMemcpyDeviceToDevice, s));
     return FY_OK;
@@ -49,7 +86,7 @@ struct LocalShared {
 struct LocalComm : Comm {
     std::shared_ptr<LocalShared> sh;
     int exchange_many(hipStream_t s, const Xchg* x, size_t n) override {
-        ++n_exchange;
+        count(0);
         for (size_t q = 0; q < n; ++q) exchange_bytes += sizeof(double) * ((has_up() ? x[q].su() : 0) + (has_down() ? x[q].sd() : 0));
         FY_HIP(hipStreamSynchronize(s));                       // my planes are final
         sh->lists[rank] = x;                                   // every rank posts the same number of items in the same order
@@ -69,7 +106,7 @@ struct LocalComm : Comm {
         return FY_OK;
     }
     int allreduce(hipStream_t s, double* dev, int n, bool is_max) override {
-        ++n_allreduce;
+        count(1);
         std::vector<double>& mine = sh->red[rank];
         mine.resize((size_t)n);
         FY_HIP(hipMemcpyAsync(mine.data(), dev, n * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -84,7 +121,7 @@ struct LocalComm : Comm {
         return FY_OK;
     }
     int allgather(hipStream_t s, const double* send, double* recv, size_t cnt) override {
-        ++n_allgather;
+        count(2);
         FY_HIP(hipStreamSynchronize(s));
         sh->gather_src[rank] = send;
         sh->bar.wait();
@@ -121,7 +158,7 @@ struct HostComm : Comm {
     fy_comm_callbacks cb{};
     HostBuf<double> h_su, h_sd, h_rd, h_ru, h_small, h_gather;
     int exchange_many(hipStream_t s, const Xchg* x, size_t n) override {
-        ++n_exchange;
+        count(0);
         // every item of a group in the order it was posted: all ranks post the same items in the same order
         for (size_t q = 0; q < n; ++q) {
             const size_t su = has_up() && x[q].send_up ? x[q].su() : 0, sd = has_down() && x[q].send_down ? x[q].sd() : 0;
@@ -140,7 +177,7 @@ struct HostComm : Comm {
         return FY_OK;
     }
     int allreduce(hipStream_t s, double* dev, int n, bool is_max) override {
-        ++n_allreduce;
+        count(1);
         FY_TRY(h_small.reserve((size_t)n + 1));
         FY_HIP(hipMemcpyAsync(h_small.p, dev, n * sizeof(double), hipMemcpyDeviceToHost, s));
         FY_HIP(hipStreamSynchronize(s));
@@ -150,7 +187,7 @@ struct HostComm : Comm {
         return FY_OK;
     }
     int allgather(hipStream_t s, const double* send, double* recv, size_t cnt) override {
-        ++n_allgather;
+        count(2);
         FY_TRY(h_su.reserve(cnt + 1)); FY_TRY(h_gather.reserve(cnt * (size_t)size + 1));
         FY_HIP(hipMemcpyAsync(h_su.p, send, cnt * sizeof(double), hipMemcpyDeviceToHost, s));
         FY_HIP(hipStreamSynchronize(s));
@@ -247,7 +284,7 @@ struct RcclComm : Comm {
     // Both directions in ONE group: every rank posts all its sends and receives before any of them has to complete, so the
     // pairing cannot deadlock whatever order the ranks reach this call in.
     int exchange_many(hipStream_t s, const Xchg* x, size_t n) override {
-        ++n_exchange;
+        count(0);
         const NcclComm cm = comm_for(s);
         FY_NCCL(A->GroupStart());
         for (size_t q = 0; q < n; ++q) {
@@ -261,12 +298,12 @@ struct RcclComm : Comm {
         return FY_OK;
     }
     int allreduce(hipStream_t s, double* dev, int n, bool is_max) override {
-        ++n_allreduce;
+        count(1);
         FY_NCCL(A->AllReduce(dev, dev, (size_t)n, kNcclDouble, is_max ? kNcclMax : kNcclSum, comm, s));
         return FY_OK;
     }
     int allgather(hipStream_t s, const double* send, double* recv, size_t cnt) override {
-        ++n_allgather;
+        count(2);
         FY_NCCL(A->AllGather(send, recv, cnt, kNcclDouble, comm, s));
         return FY_OK;
     }
@@ -333,6 +370,17 @@ int comm_selftest(Comm* c, int device) {
     FY_HIP(hipMemcpyAsync(red.p, r0, sizeof(r0), hipMemcpyHostToDevice, s));
     FY_TRY(c->allreduce(s, red.p, 3, false));
     FY_TRY(c->allreduce(s, red.p + 3, 1, true));
+    {   // a diagnostics group in one collective: {sum, sum, max, sum}
+        const double m0[4] = {(double)(R + 1), 0.25 * (double)R, (double)((R * 5) % S), -1.0};
+        FY_HIP(hipMemcpyAsync(red.p + 4, m0, sizeof(m0), hipMemcpyHostToDevice, s));
+        FY_TRY(c->allreduce_ops(s, red.p + 4, 4, 4u));
+        double mo[4];
+        FY_HIP(hipMemcpyAsync(mo, red.p + 4, sizeof(mo), hipMemcpyDeviceToHost, s));
+        FY_HIP(hipStreamSynchronize(s));
+        double a0 = 0, a1 = 0, mxv = -1;
+        for (int r = 0; r < S; ++r) { a0 += r + 1; a1 += 0.25 * r; mxv = std::max(mxv, (double)((r * 5) % S)); }
+        if (mo[0] != a0 || mo[1] != a1 || mo[2] != mxv || mo[3] != -1.0 * S) return fail(FY_ERR_TRANSPORT, "comm self-test: mixed sum / max all-reduce wrong on rank %d", R);
+    }
     const double g0[8] = {1.0 * R, 2.0 * R, 3.0 * R, 4.0 * R, 5.0 * R, 6.0 * R, 7.0 * R, 8.0 * R};
     FY_HIP(hipMemcpyAsync(gat.p + 8 * (size_t)S, g0, sizeof(g0), hipMemcpyHostToDevice, s));
     FY_TRY(c->allgather(s, gat.p + 8 * (size_t)S, gat.p, 8));

@@ -10,8 +10,11 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <array>
 #include <cstddef>
 #include <cstdint>
+#include <map>
+#include <string>
 #include <vector>
 
 #include "../../include/foamyade_hip.h"
@@ -21,7 +24,18 @@ namespace fy {
 struct Comm {
     int rank = 0, size = 1;
     uint64_t n_exchange = 0, n_allreduce = 0, n_allgather = 0, exchange_bytes = 0;   // call counters (fy_comm_stats)
-    virtual ~Comm() {}
+    // the same counters by the phase that issued the call (the solver names the phase it is in: fy_comm_stats_by_tag, tools/comm_count.py)
+    const char* tag = "";
+    std::map<std::string, std::array<uint64_t, 3> > by_tag;
+    void count(int kind) { ++(kind == 0 ? n_exchange : kind == 1 ? n_allreduce : n_allgather); ++by_tag[tag][(size_t)kind]; }
+    struct Tag {                                         // scoped phase name
+        Comm* c; const char* prev;
+        Tag(Comm* c_, const char* t) : c(c_), prev(c_->tag) { c->tag = t; }
+        ~Tag() { c->tag = prev; }
+    };
+    double* ops_scratch = nullptr;                       // [size x n] landing zone of allreduce_ops
+    size_t ops_scratch_n = 0;
+    virtual ~Comm() { if (ops_scratch) (void)hipFree(ops_scratch); }
     bool has_down() const { return rank > 0; }           // neighbour owning the planes below mine
     bool has_up() const { return rank + 1 < size; }
     // send `count` doubles starting at send_up to the upper neighbour (it receives them at ITS recv_from_down), and so on.
@@ -69,6 +83,9 @@ struct Comm {
     std::vector<Xchg> pending;
     bool grouping = false;
     virtual int allreduce(hipStream_t s, double* dev, int n, bool is_max) = 0;   // in place; identical result on every rank
+    // n <= 32 scalars of which the slots in `max_mask` are maxima and the others sums, in ONE collective: the ranks' values are all-gathered and
+    // folded locally in rank order (a diagnostics group such as {sum, sum, max, sum} cost three latency-bound all-reduces before)
+    int allreduce_ops(hipStream_t s, double* dev, int n, unsigned max_mask);
     virtual int allgather(hipStream_t s, const double* send, double* recv, size_t count_per_rank) = 0;
     virtual int barrier(hipStream_t s) = 0;
 };

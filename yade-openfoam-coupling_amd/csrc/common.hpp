@@ -22,6 +22,7 @@ struct Options {
     int rebin_interval;          // FOAMYADE_REBIN_INTERVAL      counting sort of the particles every this many steps (default 32; locality only)
     bool no_halo_overlap;        // FOAMYADE_NO_HALO_OVERLAP=1   slab smoother: exchange, then sweep (serial schedule; identical results)
     bool no_aux_comm;            // FOAMYADE_NO_AUX_COMM=1       slab mode: no second RCCL communicator for the overlapped halo
+    bool no_deep_vcycle;         // FOAMYADE_NO_DEEP_VCYCLE=1    slab multigrid: one exchange per sweep (round 3's schedule) instead of one per level and cycle
 };
 Options options();
 

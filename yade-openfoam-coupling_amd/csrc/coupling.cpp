@@ -25,6 +25,7 @@ Options options() {
     if (const char* e = getenv("FOAMYADE_REBIN_INTERVAL")) q.rebin_interval = std::max(1, atoi(e));
     q.no_halo_overlap = on("FOAMYADE_NO_HALO_OVERLAP");
     q.no_aux_comm = on("FOAMYADE_NO_AUX_COMM");
+    q.no_deep_vcycle = on("FOAMYADE_NO_DEEP_VCYCLE");
     return q;
 }
 

@@ -1324,16 +1324,27 @@ __global__ __launch_bounds__(256) void k_p_apply(PMat A, const double* __restric
     y[c] = p_row(A, x, c);
 }
 
-__global__ __launch_bounds__(256) void k_p_apply_dot(PMat A, const double* __restrict__ x, double* __restrict__ y, double* __restrict__ partials) {
-    double v[1] = {0};
+// w = A u inside the single-reduction PCG (fv_pressure.cpp): slot 1 = u.w (delta); WITH_R: also slot 0 = u.r (gamma) -- on a single domain
+// the V-cycle's last sweep has left gamma's partials in slot 0 already (k_mg_smooth_dot: same blocks, same order) and only delta is formed here
+template <bool WITH_R>
+__global__ __launch_bounds__(256) void k_p_apply_dot(PMat A, const double* __restrict__ x, const double* __restrict__ r, double* __restrict__ y, double* __restrict__ partials) {
+    double v[2] = {0, 0};
     FY_RED_LOOP(t, A.N) {
         const int c = t + A.c0;
         const double a = p_row(A, x, c);
         y[c] = a;
-        v[0] += a * x[c];
+        const double xc = x[c];
+        if (WITH_R) v[0] += xc * r[c];
+        v[1] += a * xc;
     }
-    const int mx[1] = {0};
-    block_reduce_store<1>(v, mx, partials);
+    if (WITH_R) {
+        const int mx[2] = {0, 0};
+        block_reduce_store<2>(v, mx, partials);
+    } else {
+        double v1[1] = {v[1]};
+        const int mx[1] = {0};
+        block_reduce_store<1>(v1, mx, partials + gridDim.x);
+    }
 }
 
 // r = b - A x ; slot 0 = sum|r| ; slot 1 = sum(|A x - A xbar| + |b - A xbar|)   (lduMatrix::solver::normFactor)
@@ -1362,29 +1373,41 @@ __global__ __launch_bounds__(256) void k_dot(int n, int c0, const double* __rest
     block_reduce_store<1>(v, mx, partials);
 }
 
-// sc[0] = wArA, sc[1] = wArAold, sc[2] = wApA
-__global__ __launch_bounds__(256) void k_pcg_update_p(int n, int c0, const double* __restrict__ z, double* __restrict__ p, const double* __restrict__ sc, int first) {
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= n) return;
-    const int c = t + c0;
-    if (first) p[c] = z[c];
-    else { const double beta = sc[0] / sc[1]; p[c] = z[c] + beta * p[c]; }
-}
-
-__global__ __launch_bounds__(256) void k_pcg_update_xr(int n, int c0, double* __restrict__ x, double* __restrict__ r, const double* __restrict__ p,
-                                                       const double* __restrict__ w, double* __restrict__ sc, double* __restrict__ partials) {
+// The vector update of the single-reduction (Chronopoulos-Gear) form of PCG.C's loop [OF-6]: with u = M^-1 r, w = A u and the ONE reduction
+// gamma = u.r, delta = u.w per iteration,
+//     beta = gamma / gamma_old,  alpha = gamma / (delta - beta gamma / alpha_old)      (beta = 0, alpha = gamma / delta in the first iteration)
+//     p = u + beta p,  s = w + beta s  (= A p),  x += alpha p,  r -= alpha s
+// -- the iterates of the textbook loop in exact arithmetic, with the search direction's image s carried by recurrence instead of a second dot
+// product + all-reduce after the matrix-vector product.  sc[0] = gamma, sc[1] = delta (this iteration's fold); {gamma_old, alpha_old} live in
+// sc[2 + 2 q], sc[3 + 2 q] with q = it & 1: an iteration reads set q and leaves set 1 - q, so no block reads what another one has rewritten.
+// slot 0 = sum|r|, slot 1 = sum(x): the next solve's xbar (normFactor) -- k_dot's partition and order, so k_dot's bits, without k_dot's pass.
+// FIRST: p = u and s = w need no pass of their own -- the host lets the two pairs of buffers trade places afterwards (fv_pressure.cpp)
+template <bool FIRST>
+__global__ __launch_bounds__(256) void k_pcg_cg_update(int n, int c0, const double* __restrict__ u, const double* __restrict__ w, double* __restrict__ p,
+                                                       double* __restrict__ sv, double* __restrict__ x, double* __restrict__ r, double* __restrict__ sc, int it,
+                                                       double* __restrict__ partials) {
     double v[2] = {0, 0};
-    const double al = sc[0] / sc[2];
-    // wArAold = wArA for the next iteration's beta (PCG.C): nothing in this kernel reads sc[1], and k_pcg_update_p runs after it
-    if (blockIdx.x == 0 && threadIdx.x == 0) sc[1] = sc[0];
+    const double gamma = sc[0], delta = sc[1];
+    double beta = 0.0, al = gamma / delta;
+    if (!FIRST) {
+        const double gold = sc[2 + 2 * (it & 1)], aold = sc[3 + 2 * (it & 1)];
+        beta = gamma / gold;
+        al = gamma / (delta - beta * gamma / aold);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { sc[2 + 2 * ((it + 1) & 1)] = gamma; sc[3 + 2 * ((it + 1) & 1)] = al; }
     FY_RED_LOOP(t, n) {
         const int c = t + c0;
-        const double xn = x[c] + al * p[c];
+        double pn = u[c], sn = w[c];
+        if (!FIRST) {
+            pn = pn + beta * p[c]; sn = sn + beta * sv[c];
+            p[c] = pn; sv[c] = sn;
+        }
+        const double xn = x[c] + al * pn;
         x[c] = xn;
-        const double rr = r[c] - al * w[c];
+        const double rr = r[c] - al * sn;
         r[c] = rr;
         v[0] += fabs(rr);
-        v[1] += xn;          // sum(x): the next solve's xbar (normFactor) -- k_dot's partition and order, so k_dot's bits, without k_dot's pass
+        v[1] += xn;
     }
     const int mx[2] = {0, 0};
     block_reduce_store<2>(v, mx, partials);
@@ -1766,6 +1789,16 @@ __global__ __launch_bounds__(256) void k_mg_prolong_add(PMat A, double* __restri
     x[t + A.c0] += xc[C.c0 + (i >> 1) + C.nx * ((j >> 1) + C.ny * (k >> 1))];
 }
 
+// the same over a range of z-planes that starts `kofs` planes away from the level's first owned plane (negative: ghost planes below it; the
+// communication-avoiding V-cycle of a z-slab, fv_pressure.cpp): C.c0 is the coarse cell under the fine level's first OWNED cell
+__global__ __launch_bounds__(256) void k_mg_prolong_add_planes(PMat A, int kofs, double* __restrict__ x, PMat C, const double* __restrict__ xc) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= A.N) return;
+    const int i = t % A.nx, q = t / A.nx, j = q % A.ny, k = q / A.ny + kofs;
+    const int K = k >= 0 ? (k >> 1) : -((1 - k) >> 1);                  // floor(k / 2)
+    x[t + A.c0] += xc[C.c0 + (i >> 1) + C.nx * ((j >> 1) + C.ny * K)];
+}
+
 // coarsest level (N <= 1024, never distributed: c0 = 0): all sweeps inside one workgroup
 // The coarsest operator (<= kMgDirectMax = 128 cells) only changes when the pressure matrix is assembled, and every V-cycle in between solves
 // with it: so it is FACTORED once per assembly -- banded Cholesky A = L L^T in LDS (band width = the operator's z stride, 25 for the 5^3
@@ -2042,8 +2075,9 @@ int launch_p_apply(hipStream_t s, PMat A, const double* x, double* y) {
     return FY_OK;
 }
 
-int launch_p_apply_dot(hipStream_t s, PMat A, const double* x, double* y, double* partials) {
-    hipLaunchKernelGGL(k_p_apply_dot, dim3(red_blocks(A.N)), dim3(256), 0, s, A, x, y, partials);
+int launch_p_apply_dot(hipStream_t s, PMat A, const double* x, const double* r, double* y, double* partials) {
+    if (r) hipLaunchKernelGGL(k_p_apply_dot<true>, dim3(red_blocks(A.N)), dim3(256), 0, s, A, x, r, y, partials);
+    else hipLaunchKernelGGL(k_p_apply_dot<false>, dim3(red_blocks(A.N)), dim3(256), 0, s, A, x, r, y, partials);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }
@@ -2060,14 +2094,9 @@ int launch_dot(hipStream_t s, int n, int c0, const double* a, const double* b, d
     return FY_OK;
 }
 
-int launch_pcg_update_p(hipStream_t s, int n, int c0, const double* z, double* p, const double* sc, int first) {
-    hipLaunchKernelGGL(k_pcg_update_p, dim3(div_up(n, 256)), dim3(256), 0, s, n, c0, z, p, sc, first);
-    FY_LAUNCH_CHECK();
-    return FY_OK;
-}
-
-int launch_pcg_update_xr(hipStream_t s, int n, int c0, double* x, double* r, const double* p, const double* w, double* sc, double* partials) {
-    hipLaunchKernelGGL(k_pcg_update_xr, dim3(red_blocks(n)), dim3(256), 0, s, n, c0, x, r, p, w, sc, partials);
+int launch_pcg_cg_update(hipStream_t s, int n, int c0, const double* u, const double* w, double* p, double* sv, double* x, double* r, double* sc, int it, double* partials) {
+    if (it == 0) hipLaunchKernelGGL(k_pcg_cg_update<true>, dim3(red_blocks(n)), dim3(256), 0, s, n, c0, u, w, p, sv, x, r, sc, it, partials);
+    else hipLaunchKernelGGL(k_pcg_cg_update<false>, dim3(red_blocks(n)), dim3(256), 0, s, n, c0, u, w, p, sv, x, r, sc, it, partials);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }
@@ -2178,6 +2207,12 @@ int launch_mg_smooth_prolong(hipStream_t s, PMat A, const double* b, const doubl
 
 int launch_mg_prolong_add(hipStream_t s, PMat A, double* x, PMat C, const double* xc) {
     hipLaunchKernelGGL(k_mg_prolong_add, dim3(div_up(A.N, 256)), dim3(256), 0, s, A, x, C, xc);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+
+int launch_mg_prolong_add_planes(hipStream_t s, PMat A, int kofs, double* x, PMat C, const double* xc) {
+    hipLaunchKernelGGL(k_mg_prolong_add_planes, dim3(div_up(A.N, 256)), dim3(256), 0, s, A, kofs, x, C, xc);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }

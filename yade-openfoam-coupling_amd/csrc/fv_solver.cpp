@@ -165,7 +165,7 @@ int Solver::create(const fy_case_desc* c, const fy_transport* tr, int dev, Comm*
     const size_t n = nstore;
     DevBuf<double>* v3[] = {&U, &Uold, &uSource, &uParticle, &gradP, &divT, &ddtU, &src, &HbyA, &bmom, &divG, &xscr};
     for (auto* b : v3) { FY_TRY(b->alloc_exact(3 * n)); FY_TRY(zero(*b)); }
-    DevBuf<double>* v1[] = {&p, &alpha, &uSourceDrag, &mdiag, &rAU, &prhs, &pr, &pw, &pp, &pzj};
+    DevBuf<double>* v1[] = {&p, &alpha, &uSourceDrag, &mdiag, &rAU, &prhs, &pr, &pw, &pp, &ps, &pzj};
     for (auto* b : v1) { FY_TRY(b->alloc_exact(n)); FY_TRY(zero(*b)); }
     for (auto& b : man) { FY_TRY(b.alloc_exact(n)); FY_TRY(zero(b)); }
     for (int q = 0; q < 6; ++q) if (c->u_bc[q] == FY_BC_U_SLIP && !mbd.p) { FY_TRY(mbd.alloc_exact(3 * n)); FY_TRY(zero(mbd)); }
@@ -182,7 +182,7 @@ int Solver::create(const fy_case_desc* c, const fy_transport* tr, int dev, Comm*
     }
     FY_TRY(launch_fill_f64(stream, alpha.p, n, 1.0));
     FY_TRY(launch_fill_f64(stream, rAU.p, n, 1.0));            // ghost planes must hold finite values before the first exchange
-    FY_TRY(partials.alloc_exact(8 * (size_t)red_blocks(Nc))); FY_TRY(red_out.alloc_exact(8)); FY_TRY(sc.alloc_exact(4)); FY_TRY(xbar3.alloc_exact(3));
+    FY_TRY(partials.alloc_exact(8 * (size_t)red_blocks(Nc))); FY_TRY(red_out.alloc_exact(8)); FY_TRY(sc.alloc_exact(8)); FY_TRY(xbar3.alloc_exact(3));
     FY_TRY(zero(partials)); FY_TRY(zero(sc)); FY_TRY(zero(red_out));
     if (adjust_phi) { FY_TRY(adj_sums.alloc_exact(4)); FY_TRY(adj_err.alloc_exact(1)); FY_HIP(hipMemsetAsync(adj_err.p, 0, sizeof(int), stream)); }
     if (hipHostMalloc((void**)&red_host, (kDeferBase + kDeferMax) * sizeof(double), hipHostMallocMapped) == hipSuccess) {
@@ -212,7 +212,9 @@ int Solver::create(const fy_case_desc* c, const fy_transport* tr, int dev, Comm*
         for (;;) {
             std::unique_ptr<MgLev> L(new MgLev());
             L->distributed = dist;
-            L->gz = dist ? (lvl == 0 ? g.gz : 1) : 0;       // level 0 shares the layout of the solver's cell vectors (p, r, ...)
+            // level 0 shares the layout of the solver's cell vectors (p, r, ...); the distributed levels under it carry the ghost depth of the
+            // communication-avoiding V-cycle where their slabs are thick enough for it
+            L->gz = dist ? (lvl == 0 ? g.gz : (az_loc >= kMgDeepGhost ? kMgDeepGhost : 1)) : 0;
             L->plane = (size_t)ax * ay;
             const int nzv = dist ? az_loc : az_glob;
             L->A.nx = ax; L->A.ny = ay; L->A.nz = nzv; L->A.N = (int)(L->plane * nzv);
@@ -247,6 +249,8 @@ int Solver::create(const fy_case_desc* c, const fy_transport* tr, int dev, Comm*
         if (S > 1 && cs.p_solver == FY_PSOLVER_PCG_MG && mg_rep >= mg.size()) return fail(FY_ERR_UNSUPPORTED, "multigrid hierarchy never became replicable");
         if (mg.back()->A.N > 1024 && cs.p_solver == FY_PSOLVER_PCG_MG) return fail(FY_ERR_UNSUPPORTED, "coarsest multigrid level too large");
         if (mg_rep < mg.size()) FY_TRY(rep_stage.alloc_exact(4 * ((size_t)mg[mg_rep]->A.N / S + 8)));
+        mg_deep = S > 1 && cs.p_solver == FY_PSOLVER_PCG_MG && mgw.n == 2 && !options().no_deep_vcycle && mg_rep < mg.size();
+        for (auto& L : mg) if (L->distributed && (L->gz < kMgDeepGhost || L->A.nz < kMgDeepGhost)) mg_deep = false;
     }
     for (auto& t : tim) FY_TRY(t.init());
 
@@ -296,7 +300,7 @@ int Solver::create(const fy_case_desc* c, const fy_transport* tr, int dev, Comm*
         FY_TRY(cpl->c.create(&md, &fp, pimple ? 1 : 0, tr, device));      // gaussianInterp: false for ico, true for pimple (icoFoamYade.C:53, pimpleFoamYade.C:53)
         cpl->c.rhoP = c->rho_particle; cpl->c.rhoF = c->rho_fluid; cpl->c.nu = c->nu;   // setScalarProperties (icoFoamYade.C:55)
     }
-    FY_TRY(halo_cells(U, 3, 1));
+    FY_TRY(halo_U());
     FY_TRY(FVK(launch_flux_of, stream, g, U.p, F3(phi)));                     // createPhi
     FY_HIP(hipStreamSynchronize(stream));
     return FY_OK;
@@ -329,8 +333,7 @@ int Solver::reduce_read(int nslots, bool courant, double* h) {
         return FY_OK;
     }
     FY_TRY(launch_reduce_finalize(stream, partials.p, Nc, nslots, courant ? ops_courant.p : nullptr, red_out.p));
-    if (courant) { FY_TRY(comm->allreduce(stream, red_out.p, 1, true)); FY_TRY(comm->allreduce(stream, red_out.p + 1, 1, false)); }
-    else FY_TRY(comm->allreduce(stream, red_out.p, nslots, false));
+    FY_TRY(comm->allreduce_ops(stream, red_out.p, nslots, courant ? 1u : 0u));         // Courant pair: {max, sum} in one collective
     double* land = (red_host && nslots <= 8) ? red_host : h;          // pinned landing zone: a pageable destination makes the copy a staged, blocking one
     FY_HIP(hipMemcpyAsync(land, red_out.p, nslots * sizeof(double), hipMemcpyDeviceToHost, stream));
     FY_HIP(hipStreamSynchronize(stream));
@@ -348,13 +351,8 @@ bool Solver::reduce_deferred(int nslots, bool courant, int* slot, int* rc, const
     }
     *rc = launch_reduce_finalize(stream, partials.p, Nc, nslots, ops ? ops : (courant ? ops_courant.p : nullptr), red_out.p);
     if (*rc == FY_OK) {
-        if (ops) {                       // the four diagnostics of k_U_correct<true>: sum, sum, max, sum
-            *rc = comm->allreduce(stream, red_out.p, 2, false);
-            if (*rc == FY_OK) *rc = comm->allreduce(stream, red_out.p + 2, 1, true);
-            if (*rc == FY_OK) *rc = comm->allreduce(stream, red_out.p + 3, 1, false);
-        }
-        else if (courant) { *rc = comm->allreduce(stream, red_out.p, 1, true); if (*rc == FY_OK) *rc = comm->allreduce(stream, red_out.p + 1, 1, false); }
-        else *rc = comm->allreduce(stream, red_out.p, nslots, false);
+        // one collective per group: the four diagnostics of k_U_correct<true> are {sum, sum, max, sum}, the Courant pair {max, sum}
+        *rc = comm->allreduce_ops(stream, red_out.p, nslots, ops ? 4u : (courant ? 1u : 0u));
     }
     if (*rc == FY_OK && hipMemcpyAsync(red_host + *slot, red_out.p, nslots * sizeof(double), hipMemcpyDeviceToHost, stream) != hipSuccess)
         *rc = fail(FY_ERR_HIP, "deferred read-back failed");
@@ -368,6 +366,7 @@ int Solver::reduce_to_device(double* dst) {          // one slot, stays on the d
 // Jacobi sweeps on the 7-point matrix in M7() for a 3-component field X (in place; xscr is the other buffer), lduMatrix-style L1
 // residual control per component
 int Solver::solve_vec3(DevBuf<double>& X, const double* rhs, double tol, double rel_tol, int max_iter, int* iters, bool momentum) {
+    Comm::Tag tag(comm, momentum ? "momentum_solve" : "turbulence_solve");
     double h[6];
     // sum(X) per component for xbar = average(X): folded (and all-reduced) on the device, divided where it is used
     if (momentum && usum_pending) {                          // (formed beside the particle phase: step())
@@ -382,7 +381,8 @@ int Solver::solve_vec3(DevBuf<double>& X, const double* rhs, double tol, double 
     double norm[3] = {1, 1, 1}, res0[3] = {0, 0, 0}, res[3];
     int it = 0;
     for (;;) {
-        FY_TRY(halo(xc, 3, plane, g.nz, g.gz, 1));
+        // (the predictor's first pass reads the ghost planes the step's opening exchange left in U)
+        if (!(it == 0 && &X == &U && U_ghosts_fresh)) FY_TRY(halo(xc, 3, plane, g.nz, g.gz, 1));
         kc[KC_MOM_PASS].begin(stream);
         FY_TRY(FVK(launch_mom_pass, stream, g, M7(momentum), rhs, xc, xn, xbar3.p, (double)Nglob, partials.p));
         kc[KC_MOM_PASS].end(stream);
@@ -403,13 +403,16 @@ int Solver::solve_vec3(DevBuf<double>& X, const double* rhs, double tol, double 
         std::swap(X.p, xscr.p);
         if (&X == &U && cpl) cpl->c.dU = U.p;             // (the coupling gathers U through its own pointer)
     }
+    // the pass that found the iterate converged had just exchanged that iterate's ghost planes (or they were fresh): they still are
+    if (&X == &U) U_ghosts_fresh = true;
     *iters = it;
     return FY_OK;
 }
 
 // ---- one PISO / PIMPLE corrector (icoFoamYade.C:97-140, pEqn.H) ----------------------------------------------------
 int Solver::corrector(bool final_inner) {
-    FY_TRY(halo_cells(U, 3, 1));
+    Comm::Tag tag(comm, "corrector");
+    FY_TRY(halo_U());
     FY_TRY(FVK(launch_HbyA, stream, g, M7(), src.p, U.p, rAU.p, HbyA.p));
     // rAU (hence rAUf and the pressure matrix rAUf*alphaf) belongs to the momentum matrix: it only changes when that is assembled,
     // not between the PISO correctors of one assembly
@@ -427,7 +430,7 @@ int Solver::corrector(bool final_inner) {
     clk_pres.begin(stream);
     for (int no = 0; no <= cs.n_non_orth_correctors; ++no) {
         FY_TRY(FVK(launch_assemble_pressure, stream, g, C3(phiHbyA), C3(rAUf), C3(alphaf), C3(psn), alpha.p, /* alphaOld */ alpha.p, L.A, prhs.p, rAU_new));
-        if (rAU_new && L.distributed && comm->has_down()) FY_TRY(FVK(launch_p_ghost_uz, stream, g, C3(rAUf), C3(alphaf), L.A));
+        if (rAU_new && L.distributed && comm->has_down() && !mg_deep) FY_TRY(FVK(launch_p_ghost_uz, stream, g, C3(rAUf), C3(alphaf), L.A));
         if (rAU_new) {                                        // same matrix as in the previous corrector otherwise: only the right-hand side moved
             if (comm->size == 1 && cs.p_solver == FY_PSOLVER_PCG_MG && mg.size() > 1) {
                 FY_HIP(hipEventRecord(ev_assembled, stream));
@@ -446,12 +449,12 @@ int Solver::corrector(bool final_inner) {
         FY_TRY(solve_pressure(final_inner && no == cs.n_non_orth_correctors));
         FY_TRY(wait_coarse());                                // (a solve that never left level 0)
         if (no == cs.n_non_orth_correctors) {
-            FY_TRY(halo_cells(p, 1, 1));
+            FY_TRY(halo_p());
             FY_TRY(FVK(launch_flux_correct, stream, g, p.p, C3(phiHbyA), C3(rAUf), C3(alphaf), C3(psn), C3(phiForces), F3(pflux), F3(phi)));
             phi_fresh = true;
             // p.relax() (pEqn.H:41): after the flux, which keeps the unrelaxed solution; the velocity correction below works with
             // pEqn.flux() (pflux), not with grad(p), so only the carried pressure field is relaxed
-            if (pimple && p_relax_now > 0 && p_relax_now < 1) { FY_TRY(launch_relax_field(stream, p.p, pPrev.p, p_relax_now, nstore)); p_sum_valid = false; }
+            if (pimple && p_relax_now > 0 && p_relax_now < 1) { FY_TRY(launch_relax_field(stream, p.p, pPrev.p, p_relax_now, nstore)); p_sum_valid = false; p_ghosts_fresh = false; }
         }
     }
     clk_pres.end(stream);
@@ -462,6 +465,7 @@ int Solver::corrector(bool final_inner) {
         // (k_U_correct<true>; same values as k_cont_err / k_courant) instead of being two sweeps of their own
         FY_TRY(FVK(launch_U_correct_diag, stream, g, HbyA.p, rAU.p, p.p, C3(psn), C3(phiForces), C3(pflux), C3(alphaf), C3(rAUf), U.p, C3(phi), alpha.p,
                                      /* alphaOld */ alpha.p, partials.p));
+        U_ghosts_fresh = false;
         if (!reduce_deferred(4, false, &slot, &rc, ops_diag.p)) return fail(FY_ERR_INVALID, "no room for the deferred diagnostics");
         FY_TRY(rc);
         cont_slots.push_back(slot);
@@ -473,12 +477,14 @@ int Solver::corrector(bool final_inner) {
     if (reduce_deferred(2, false, &slot, &rc)) { FY_TRY(rc); cont_slots.push_back(slot); }
     else { FY_TRY(reduce_read(2, false, h)); note_cont_err(h); }
     FY_TRY(FVK(launch_U_correct, stream, g, HbyA.p, rAU.p, p.p, C3(psn), C3(phiForces), C3(pflux), C3(alphaf), C3(rAUf), U.p));
+    U_ghosts_fresh = false;
     return FY_OK;
 }
 
 // continuousPhaseTurbulence->correct() for LES Smagorinsky: nut from the Gauss-linear gradient of the corrected velocity
 int Solver::turbulence_correct() {
-    FY_TRY(halo_cells(U, 3, 1));
+    Comm::Tag tag(comm, "turbulence");
+    FY_TRY(halo_U());
     FY_TRY(FVK(launch_pre_coupling, stream, g, U.p, p.p, alpha.p, C3(psn), vGrad.p, gradP.p, divT.p, nullptr, 1, 0));
     if (cs.turbulence_model == FY_TURBULENCE_KEQN || cs.turbulence_model == FY_TURBULENCE_KEPSILON) {
         // kEqn::correct() / kEpsilon::correct(): each transport equation is assembled into the momentum matrix's storage and solved by the
@@ -510,6 +516,7 @@ int Solver::turbulence_correct() {
 
 // ---- one pass of the while (runTime.loop()) body ---------------------------------------------------------------------
 int Solver::step() {
+    Comm::Tag tag(comm, "step_start");
     FY_HIP(hipSetDevice(device));
     st = fy_step_stats{}; st.cont_err_cumulative = cumulative_cont_err;
     clk_mom.on = clk_pres.on = timing; clk_mom.per_collect = clk_pres.per_collect = 1024; clk_mom.reset(); clk_pres.reset();
@@ -538,9 +545,10 @@ int Solver::step() {
     // runTime++ : store old-time fields (whole storage, ghost planes included)
     comm->group_begin();                    // one exchange: U goes with the full particle-halo width straight away
     FY_TRY(halo_cells(U, 3, g.gz > 1 ? g.gz : 1));
-    FY_TRY(halo_cells(p, 1, 1));
+    if (!p_ghosts_fresh) FY_TRY(halo_cells(p, 1, 1));        // (the last corrector's exchange still stands unless p was written since)
     FY_TRY(halo_cells(alpha, 1, 1));
     FY_TRY(comm->group_end(stream));
+    p_ghosts_fresh = true; U_ghosts_fresh = true;
     // U.oldTime() of the owned cells is written by the pre-coupling sweep that reads U anyway; a slab copies only its ghost planes
     // (phiHbyA's ddtCorr reads Uold across the slab faces), which the exchange above has just refreshed in U
     const bool fuse_uold = true;
@@ -582,6 +590,7 @@ int Solver::step() {
     cpl->c.cellrec_external = rec_out != nullptr;
 
     if (timing) tim[0].start(stream);
+    comm->tag = "particle";
     if (g.gz > 1) {                      // the particle gathers reach gz planes into the neighbours
         comm->group_begin();
         FY_TRY(halo_cells(gradP, 3, g.gz)); FY_TRY(halo_cells(divT, 3, g.gz));
@@ -605,6 +614,7 @@ int Solver::step() {
         FY_TRY(rc);
     }
     if (timing) { tim[0].stop(stream); }
+    comm->tag = "momentum";
 
     // alphac.oldTime() is captured lazily by OpenFOAM at alphac.correctBoundaryConditions() (pimpleFoamYade.C:83), i.e. after
     // FoamYade wrote alpha through untracked operator[]: old == current, fvc::ddt(alphac) == 0.
@@ -625,14 +635,14 @@ int Solver::step() {
         clk_mom.begin(stream);
         if (pimple) {
             // explicit stress term of divDevRhoReff from the CURRENT U and this step's alpha (one fused stencil pass)
-            if (outer > 0) FY_TRY(halo_cells(U, 3, 1));
+            if (outer > 0) FY_TRY(halo_U());
             FY_TRY(FVK(launch_pre_coupling, stream, g, U.p, p.p, alpha.p, C3(psn), vGrad.p, gradP.p, divT.p, Gt.p, g.upwind == 2 ? 1 : 0, 0));
             FY_TRY(halo(Gt.p + 2 * 3 * nstore, 3, plane, g.nz, g.gz, 1));     // G is stored by rows; only row z is read across the slab faces
             FY_TRY(FVK(launch_div_G, stream, g, Gt.p, divG.p));
         }
         if (g.upwind == 2) FY_TRY(halo_cells(vGrad, 9, 1));      // linearUpwind reads grad(U) of the upwind neighbour (ico: written at step start)
         if (g.upwind >= 3) {                                     // the limited schemes: gradient ratio from grad(magSqr(U)) of the current U
-            FY_TRY(halo_cells(U, 3, 1));
+            FY_TRY(halo_U());
             FY_TRY(FVK(launch_grad_magsqr, stream, g, U.p, gradL.p));
             FY_TRY(halo_cells(gradL, 3, 1));
         }

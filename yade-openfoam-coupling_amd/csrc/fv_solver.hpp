@@ -22,12 +22,13 @@ namespace fy {
 // coarsest multigrid level: solved by damped-Jacobi sweeps inside one 1024-thread workgroup (every level below ~20^3 is
 // launch-bound on the GPU; stopping at <= 1024 cells was tried and LOST: 40 sweeps no longer solve that level, +20 % PCG iterations)
 constexpr int kMgCoarsest = kMgDirectMax, kMgCoarsestEdge = 8;      // the coarsest level (<= 128 cells, no edge over 8: band <= 64) is solved exactly from its banded Cholesky factor
+constexpr int kMgDeepGhost = 5;               // ghost planes of a distributed level that runs the communication-avoiding V-cycle (fv_pressure.cpp: E + 3 <= 5)
 constexpr int kMgReplicateBelow = 1 << 20;    // a distributed hierarchy hands over to the replicated one at <= this many GLOBAL cells: every
                                               // distributed level costs 4 neighbour exchanges per V-cycle, a replicated 1 M-cell level ~15 us per kernel
 
 struct MgLev {
     PMat A{};
-    bool distributed = false;     // owned z-slab + 1 ghost plane per side (only when comm->size > 1)
+    bool distributed = false;     // owned z-slab + gz ghost planes per side (only when comm->size > 1)
     int gz = 0;
     size_t plane = 0;
     DevBuf<double> diag, ux, uy, uz, x0, x1, b;
@@ -80,7 +81,14 @@ struct Solver {
     std::vector<std::unique_ptr<MgLev> > mg;
     size_t mg_rep = 0;            // first replicated level (== mg.size() when nothing is replicated)
     DevBuf<double> rep_stage;     // local slice of the first replicated level before the all-gather (rhs / operator arrays)
-    DevBuf<double> prhs, pr, pw, pp, pzj;
+    DevBuf<double> prhs, pr, pw, pp, ps, pzj;      // PCG: right-hand side, residual, w = A u, search direction p, its image s = A p, Jacobi-preconditioned residual
+    DevBuf<double> rep_gather;   // landing zone of the coarse operators' all-gather (build_coarse_operators)
+    bool mg_deep = false;        // every distributed level carries kMgDeepGhost ghost planes: one exchange per level and V-cycle (vcycle_deep)
+    // p's ghost planes equal the neighbours' owned planes until somebody writes p: the exchanges in between are skipped
+    bool p_ghosts_fresh = false;
+    bool U_ghosts_fresh = false; // the same for U (one plane)
+    int halo_U() { if (comm->size > 1 && !U_ghosts_fresh) { FY_TRY(halo_cells(U, 3, 1)); U_ghosts_fresh = true; } return FY_OK; }
+    int halo_p() { if (comm->size > 1 && !p_ghosts_fresh) { FY_TRY(halo_cells(p, 1, 1)); p_ghosts_fresh = true; } return FY_OK; }
     DevBuf<double> pPrev;        // p.prevIter() (only with a field relaxation factor for p)
     double p_relax_now = 0.0;
     bool adjust_phi = false;     // adjustPhi can act (no fixed-pressure patch, and a patch that lets U float or prescribed through-flow)
@@ -174,6 +182,9 @@ struct Solver {
     static constexpr double kMgWa = 1.7318685872766142, kMgWb = 0.5695012757370842;
     MgWeights mgw{2, {kMgWa, kMgWb, 0, 0}};
     int vcycle(size_t l);
+    PMat planes_of(const MgLev& L, int ext, int* kofs = nullptr) const;
+    int vcycle_deep(size_t l, int E);
+    int exchange_operator_ghosts(MgLev& L);
     bool want_vcycle_dot = false, vcycle_dot_done = false;
     // damped-Jacobi sweeps that stand for the solve of the coarsest level (<= 256 cells, no edge over 8): 40 left its smoothest modes in and cost
     // PCG iterations -- C3 after 30 steps: 3.0 iterations per step with 40 or 80 sweeps, 2.17 with 120 / 160 / 240 (135 -> 140 / 139 / 137.6

@@ -73,6 +73,15 @@ int fy_comm_stats(fy_comm* c, uint64_t* out4) {
     out4[0] = c->c->n_exchange; out4[1] = c->c->n_allreduce; out4[2] = c->c->n_allgather; out4[3] = c->c->exchange_bytes;
     return FY_OK;
 }
+int fy_comm_stats_by_tag(fy_comm* c, char* buf, size_t cap) {
+    if (!c || !c->c || !buf || cap == 0) return fy::fail(FY_ERR_INVALID, "fy_comm_stats_by_tag: null argument");
+    std::string out;
+    for (const auto& kv : c->c->by_tag)
+        out += (kv.first.empty() ? std::string("-") : kv.first) + " " + std::to_string(kv.second[0]) + " " + std::to_string(kv.second[1]) + " " + std::to_string(kv.second[2]) + "\n";
+    if (out.size() + 1 > cap) return fy::fail(FY_ERR_INVALID, "fy_comm_stats_by_tag: buffer too small (%zu needed)", out.size() + 1);
+    std::memcpy(buf, out.c_str(), out.size() + 1);
+    return FY_OK;
+}
 int fy_comm_selftest(fy_comm* c, int device_ordinal) { if (!c || !c->c) return fy::fail(FY_ERR_INVALID, "null communicator"); return fy::comm_selftest(c->c, device_ordinal); }
 int fy_comm_rank(fy_comm* c) { return c && c->c ? c->c->rank : -1; }
 int fy_comm_size(fy_comm* c) { return c && c->c ? c->c->size : -1; }
@@ -117,9 +126,10 @@ int fy_solver_write_field_host(fy_solver* s, const char* name, const double* in)
     FY_HIP(hipSetDevice(s->s.device));
     FY_HIP(hipMemcpyAsync(p, in, n * sizeof(double), hipMemcpyHostToDevice, s->s.stream));
     s->s.carry_valid = false;                 // whatever was written, the carried Courant sums may no longer describe phi
-    s->s.p_sum_valid = false;
+    s->s.p_sum_valid = false; s->s.p_ghosts_fresh = false;
     if (std::string(name) == "U") {           // createPhi (collective when there are several slabs)
-        FY_TRY(s->s.halo_cells(s->s.U, 3, 1));
+        s->s.U_ghosts_fresh = false;
+        FY_TRY(s->s.halo_U());
         FY_TRY(fy::launch_flux_of(s->s.stream, s->s.g, s->s.U.p, s->s.F3(s->s.phi)));
     }
     if (std::string(name) == "nut") FY_TRY(s->s.halo_cells(s->s.nut, 1, 1));
@@ -150,7 +160,7 @@ int fy_solver_solve_p_host(fy_solver* s, const double* rhs, double* x, int* iter
     FY_HIP(hipSetDevice(S.device));
     FY_HIP(hipMemcpyAsync(S.prhs.p + S.g.c0, rhs, (size_t)S.Nc * sizeof(double), hipMemcpyHostToDevice, S.stream));
     FY_HIP(hipMemcpyAsync(S.p.p + S.g.c0, x, (size_t)S.Nc * sizeof(double), hipMemcpyHostToDevice, S.stream));
-    S.p_sum_valid = false;
+    S.p_sum_valid = false; S.p_ghosts_fresh = false;
     const int before = S.st.p_iters_total;
     FY_TRY(S.solve_pressure(true));
     FY_HIP(hipMemcpyAsync(x, S.p.p + S.g.c0, (size_t)S.Nc * sizeof(double), hipMemcpyDeviceToHost, S.stream));
