@@ -239,18 +239,18 @@ def wire_leg(prod, torch, case, rec_host, steps, workers, device):
             "pcie_GBps": {"h2d": gbps(acc["bytes_in"], acc["copy_in"]), "d2h": gbps(acc["bytes_out"], acc["copy_out"])}}
 
 
-def wire_leg_mpi(n, n_part, steps, workers, dt, c5):
+def wire_leg_mpi(n, n_part, steps, workers, dt, c5, solver_ranks=1):
     """the drop-in path over REAL MPI: tools/native/wire_bench.cpp under mpiexec MPMD -- a Yade master, `workers` Yade worker processes that own
-    the particles, and one solver rank (fy_solver + the MPI transport of libfoamyade_mpi) -- parallel-Yade protocol, every record and every
-    force crossing a process boundary through MPI_Send / MPI_Recv.  Returns the solver rank's JSON record, or None when the launcher or
-    the binary is not there"""
+    the particles, and the solver side (fy_solver + the MPI transport of libfoamyade_mpi): ONE rank (solver_ranks = 1), or a computing rank and
+    solver_ranks - 1 wire helpers (include/foamyade_mpi.h) -- parallel-Yade protocol, every record and every force crossing a process boundary
+    through MPI_Send / MPI_Recv.  Returns the computing rank's JSON record, or None when the launcher or the binary is not there"""
     import subprocess
     exe = os.path.join(ROOT, "tools", "native", "wire_bench")
     mpiexec = "/opt/conda/bin/mpiexec"
     if not (os.path.exists(exe) and os.path.exists(mpiexec)):
         return None
-    a = [exe, str(n), str(n_part), str(steps), repr(dt)] + (["c5"] if c5 else [])
-    cmd = [mpiexec, "-n", "1"] + a + [":", "-n", str(workers)] + a + [":", "-n", "1"] + a
+    a = [exe, str(n), str(n_part), str(steps), repr(dt), "c5" if c5 else "-", str(solver_ranks)]
+    cmd = [mpiexec, "-n", "1"] + a + [":", "-n", str(workers)] + a + [":", "-n", str(solver_ranks)] + a
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     try:
         r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
@@ -261,16 +261,20 @@ def wire_leg_mpi(n, n_part, steps, workers, dt, c5):
     except Exception as e:                                            # noqa: BLE001
         return {"error": f"{type(e).__name__}: {e}"}
     gbps = lambda b, ms: round(b / (ms * 1e-3) / 1e9, 1) if ms > 0 else None
-    return {"what": f"drop-in path over real MPI (MPICH, shared-memory transport): a Yade master + {workers} Yade worker PROCESSES own the particles, one solver rank "
-                    "runs fy_solver with the MPI transport; parallel-Yade protocol (FoamYade.C:114-155, 239-243, 504-507, 537-549); wire_* = host time of the "
-                    "solver rank inside MPI_Recv / MPI_Send of the records and results (the MPI library's inter-process copies), h2d / d2h = the PCIe copies "
-                    "on their own streams, overlapped with the other batches' receive and kernels",
+    side = ("one solver rank runs fy_solver with the MPI transport" if solver_ranks == 1 else
+            f"the solver side is a computing rank (fy_solver) + {solver_ranks - 1} wire helpers that receive the records into a shared-memory arena and send the "
+            "answers out of it in parallel (to Yade a {0}-rank solver; the library sees views of the arena, fy_transport::recv_view / send_reserve)".format(solver_ranks))
+    return {"what": f"drop-in path over real MPI (MPICH, shared-memory transport): a Yade master + {workers} Yade worker PROCESSES own the particles, {side}; "
+                    "parallel-Yade protocol (FoamYade.C:114-155, 239-243, 504-507, 537-549); wire_* = host time of the computing rank inside the transport's "
+                    "data calls (one rank: MPI_Recv / MPI_Send of the records and results; helpers: waiting for their reports), h2d / d2h = the PCIe copies "
+                    "on their own streams, overlapped with the other batches' receive and kernels; pcie floor = bytes / 56 GB/s",
+            "solver_side_ranks": solver_ranks,
             "steps": j["steps"], "ms_per_step": j["ms_per_step"], "steps_per_sec": round(1e3 / j["ms_per_step"], 3),
             "per_step_ms": {k: j[k] for k in ("h2d", "d2h", "wire_recv", "wire_send", "particle_phase_incl_transfers")},
             "bytes_per_step": {"h2d": j["bytes_in"], "d2h": j["bytes_out"]},
             "pcie_GBps": {"h2d": gbps(j["bytes_in"], j["h2d"]), "d2h": gbps(j["bytes_out"], j["d2h"])},
             "mpi_GBps": {"recv": gbps(j["bytes_in"], j["wire_recv"]), "send": gbps(j["bytes_out"], j["wire_send"])},
-            "located_at_the_workers": int(j["found_at_the_workers"])}
+            "located_at_the_workers": int(j["found_at_the_workers"]), "located_by_two_solver_ranks": int(j.get("found_by_two_ranks", 0))}
 
 
 def cpu_baseline(config, n_sample, n_part, dt, threads, full):
@@ -494,6 +498,7 @@ def main():
                     "c5: configs[4] at full size (320^3 cells, 100 M particles, fluidized bed: bottom inlet, top outlet) -- on one GPU, or with --gpus N cut into N z-slabs")
     ap.add_argument("--wire", type=int, default=2, help="steps of the drop-in (host-buffer / fake-Yade) leg after the timed region, 0 = skip")
     ap.add_argument("--wire-workers", type=int, default=4)
+    ap.add_argument("--wire-helpers", type=int, default=4, help="wire-helper ranks beside the computing rank in the drop-in leg over MPI (0: one solver rank receives everything)")
     ap.add_argument("--moving", action="store_true", help="not the BASELINE configuration: particles carry random velocities (+-0.05 m/s) and are displaced by "
                     "~0.1 dx per step (alternating random offsets, applied between the steps inside the timed region), so that the momentum deposit, "
                     "the re-bin amortisation and the pressure solver see a cloud that changes from step to step")
@@ -755,12 +760,15 @@ def main():
         except Exception as e:                                        # noqa: BLE001  (reported in the line, never fatal for the headline)
             inproc = {"error": f"{type(e).__name__}: {e}"}
         del rec_host
-        mpi = None if c2 else wire_leg_mpi(args.n, args.particles, args.wire, args.wire_workers, args.dt, c5)
+        mpi = None if c2 else wire_leg_mpi(args.n, args.particles, args.wire, args.wire_workers, args.dt, c5, args.wire_helpers + 1)
+        mpi1 = None if (c2 or args.wire_helpers == 0) else wire_leg_mpi(args.n, args.particles, args.wire, args.wire_workers, args.dt, c5, 1)
         # the leg of record is the one over real MPI (what a Yade next to this library sees); the in-process peer (host copies at memcpy
         # speed, no process boundary) is the floor any copying transport has
         out["drop_in_path"] = mpi if (mpi and "error" not in mpi) else inproc
         if mpi is not None:
             out["drop_in_path_in_process_peer"] = inproc
+        if mpi1 is not None:
+            out["drop_in_path_one_receiving_rank"] = mpi1
         dp = out["drop_in_path"]
         if "per_step_ms" in dp:
             out["per_step_ms"].update({"h2d": dp["per_step_ms"]["h2d"], "d2h": dp["per_step_ms"]["d2h"],

@@ -82,6 +82,7 @@ enum { FY_T_INT = 0, FY_T_DOUBLE = 1 };
 enum { FY_OP_MAX = 0, FY_OP_SUM = 1 };
 /* All callbacks return 0 on success.  "world" = MPI_COMM_WORLD (Yade ranks first, README.md:29, FoamYade.C:28-43),
  * "local" = PstreamGlobals::MPI_COMM_FOAM (FoamYade.C:21-22). */
+struct fy_wire_pieces;
 typedef struct fy_transport {
     void* user;
     int32_t world_rank, world_size;     /* FoamYade.C:24-25 */
@@ -91,7 +92,36 @@ typedef struct fy_transport {
     int (*bcast_world)(void* user, void* buf, int count, int dtype, int root);                      /* MPI_Bcast(WORLD) */
     int (*bcast_local)(void* user, void* buf, int count, int dtype, int root);                      /* MPI_Bcast(MPI_COMM_FOAM) */
     int (*allreduce_world)(void* user, const void* in, void* out, int count, int dtype, int op);    /* MPI_Allreduce(WORLD) */
+    /* ---- optional zero-copy wire (round 4; every pointer may be NULL: a zero-initialised struct is the round-3 transport) ----
+     * A transport that owns staging memory -- the shared-memory arena that wire-helper ranks fill in parallel (include/foamyade_mpi.h:
+     * one receiving core copies ~9 GB/s out of the MPI library whatever it posts, so the 800 MB of a 10 M-particle step need SEVERAL
+     * receiving processes; measured: tools/native/mpi_recv_rate.cpp) -- hands the library VIEWS of the messages instead of copying them
+     * into buffers of the library: the PCIe copies then start from / end in that memory.  Parallel-Yade protocol only. */
+    /* called once from fy_create, before the bounding box goes out (FoamYade.C:77-111): the uniform block this rank computes on */
+    int (*describe_block)(void* user, const double origin[3], double dx, const int32_t n[3]);
+    /* recv(..., src, FY_TAG 1002) without the copy: *buf = the message where the transport keeps it (valid until the step's last send_commit).
+     * The message may be the concatenation of several PIECES, each received by another helper for its own cell layers [k0, k1) across one axis: a record is
+     * located only within its piece's layers (a particle near a cut arrives in both pieces and is found in exactly one). */
+    int (*recv_view)(void* user, const void** buf, int count, int dtype, int src, int tag, struct fy_wire_pieces* pieces);
+    /* the same in two halves (both or neither): recv_view_layout returns at once -- where the message WILL lie and how it is cut -- and
+     * recv_view_next blocks until one more piece of this step's messages has landed and says which (src = the worker, piece = index into that
+     * message's fy_wire_pieces; a message without cuts is its own piece 0).  The library then starts each piece's PCIe copy when it lands, in
+     * whatever order the workers deliver, instead of each message's when it is complete. */
+    int (*recv_view_layout)(void* user, const void** buf, int count, int dtype, int src, int tag, struct fy_wire_pieces* pieces);
+    int (*recv_view_next)(void* user, int* src, int* piece);
+    /* where the library should write a message it is about to send (count elements), then the hand-over: replaces send(...) */
+    int (*send_reserve)(void* user, void** buf, int count, int dtype, int dest, int tag);
+    int (*send_commit)(void* user, const void* buf, int count, int dtype, int dest, int tag);
+    /* the memory the views point into, for page-locking (hipHostRegister) while `generation` stays the same; bytes = 0: nothing to lock */
+    int (*view_region)(void* user, void** base, size_t* bytes, uint64_t* generation);
 } fy_transport;
+#define FY_WIRE_MAX_PIECES 8
+typedef struct fy_wire_pieces {
+    int32_t n;                                  /* 0: one message, no cuts */
+    int32_t axis;                               /* the block is cut across this axis (0 x, 1 y, 2 z) */
+    int32_t start[FY_WIRE_MAX_PIECES];          /* first record of piece q within the message */
+    int32_t k0[FY_WIRE_MAX_PIECES], k1[FY_WIRE_MAX_PIECES];      /* cell layers [k0, k1) along `axis` piece q's records may be located in */
+} fy_wire_pieces;
 
 typedef struct fy_ctx fy_ctx;
 

@@ -186,3 +186,31 @@ def test_foamYadeHip_mpi_parallel_on_a_decomposed_case(product, tmp_path):
     assert np.abs(Um - Uo).max() <= 1e-5 * np.abs(Uo).max() and np.abs(pm - po).max() <= 1e-5 * np.abs(po).max()
     Fo = np.fromfile(tmp_path / "one" / "force.bin"); Fm = np.fromfile(tmp_path / "many" / "force.bin")
     assert np.abs(Fm - Fo).max() <= 1e-6 * np.abs(Fo).max()
+
+
+WIRE_BENCH = os.path.join(ROOT, "tools", "native", "wire_bench")
+
+
+@pytest.mark.skipif(not (os.path.exists(MPIEXEC) and os.path.exists(WIRE_BENCH)), reason="no MPI launcher / binary (run __graft_entry__.build())")
+@pytest.mark.parametrize("solver_ranks,axis", [(3, None), (5, None), (4, "2")])
+def test_wire_helpers_answer_like_one_solver_rank(solver_ranks, axis):
+    """K solver-side ranks in front of the one GPU -- a computing rank and K - 1 wire helpers that receive a parallel Yade's records into a
+    shared-memory arena and send the answers out of it (include/foamyade_mpi.h; FoamYade.C:77-155, 239-243, 504-507 with K solver ranks) -- give
+    every Yade worker what ONE solver rank gives it: the same particles located, none by two ranks (a particle whose sphere reaches two helpers'
+    boxes is sent to both and found by exactly one), the same forces.  tools/native/wire_bench.cpp is the peer: a master and three workers."""
+    import json
+
+    def run(k, env_extra):
+        a = [WIRE_BENCH, "24", "30000", "2", "1e-4", "-", str(k)]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
+        out = subprocess.run([MPIEXEC, "-n", "1"] + a + [":", "-n", "3"] + a + [":", "-n", str(k)] + a, capture_output=True, text=True, timeout=300, env=env)
+        assert out.returncode == 0, (out.stderr or out.stdout)[-1500:]
+        return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+
+    one = run(1, {})
+    many = run(solver_ranks, {"FOAMYADE_WIRE_CUT_AXIS": axis} if axis else {})
+    assert many["solver_side_ranks"] == solver_ranks and one["solver_side_ranks"] == 1
+    assert many["found_by_two_ranks"] == 0
+    assert many["found_at_the_workers"] == one["found_at_the_workers"] > 29000
+    assert many["bytes_in"] > one["bytes_in"]                       # (the particles at the cuts travel twice)
+    assert abs(many["sum_fz_at_the_workers"] - one["sum_fz_at_the_workers"]) <= 1e-9 * abs(one["sum_fz_at_the_workers"])

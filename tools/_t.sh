@@ -1,4 +1,4 @@
 #!/bin/bash
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r4c; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r4f; mkdir -p $O
 cd $R
-timeout 1500 python -m pytest tests/test_slabs.py -x -q -m gpu -k "deep or budget" > $O/tests.txt 2>&1; tail -15 $O/tests.txt
+timeout 3000 python -m pytest tests -x -q -m gpu > $O/tests.txt 2>&1; tail -6 $O/tests.txt

@@ -71,7 +71,10 @@ _ALLRED = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_
 class Transport(C.Structure):
     _fields_ = [("user", C.c_void_p), ("world_rank", C.c_int32), ("world_size", C.c_int32), ("local_rank", C.c_int32),
                 ("local_size", C.c_int32), ("send", _SEND), ("recv", _RECV), ("bcast_world", _BCAST),
-                ("bcast_local", _BCAST), ("allreduce_world", _ALLRED)]
+                ("bcast_local", _BCAST), ("allreduce_world", _ALLRED),
+                # the optional zero-copy wire of round 4 (include/foamyade_hip.h): absent (NULL) in the Python transports
+                ("describe_block", C.c_void_p), ("recv_view", C.c_void_p), ("recv_view_layout", C.c_void_p), ("recv_view_next", C.c_void_p),
+                ("send_reserve", C.c_void_p), ("send_commit", C.c_void_p), ("view_region", C.c_void_p)]
 
 
 class ParticleTimings(C.Structure):

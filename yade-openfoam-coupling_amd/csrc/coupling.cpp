@@ -282,6 +282,11 @@ int Coupling::create(const fy_mesh_desc* m, const fy_field_ptrs* f, int gaussian
 
     // ---- parallel Yade: yadeProcs + sendMeshBbox, FoamYade.C:35-45,77-111
     if (has_transport && !serial_yade) {
+        if (transport.describe_block) {                 // a transport with wire helpers cuts the block among them before any box goes out
+            if (slab.active || !(m->nx > 0 && m->dx > 0) || m->xf) return fail(FY_ERR_UNSUPPORTED, "a zero-copy wire transport needs the uniform block on one domain");
+            const int32_t nn[3] = {m->nx, m->ny, m->nz};
+            FY_TR(transport.describe_block(transport.user, m->origin, m->dx, nn));
+        }
         double bbox[6] = {m->bbox_min[0], m->bbox_min[1], m->bbox_min[2], m->bbox_max[0], m->bbox_max[1], m->bbox_max[2]};
         if (slab.active) {       // every solver rank sends the box of ITS mesh (FoamYade.C:81-95 runs over the rank's own mesh.points()): this slab's planes
             bbox[2] = m->origin[2] + (double)slab.kglob0 * m->dx;
@@ -488,7 +493,7 @@ int Coupling::ensure_batch_events(Batch& b) {
 
 // records that the transport has just delivered into the batch's pinned staging buffer: H2D on the copy stream (so that it overlaps the
 // kernels of the batches received before, which are already running on the compute stream); the compute stream waits for the event
-int Coupling::upload_batch(Batch& b, int64_t n) {
+int Coupling::upload_batch(Batch& b, int64_t n, const double* src) {
     FY_TRY(ensure_batch_events(b));
     FY_TRY(b.rec_own.reserve(10 * (size_t)std::max<int64_t>(n, 1)));
     b.t_in.start(copy_stream);
@@ -496,7 +501,7 @@ int Coupling::upload_batch(Batch& b, int64_t n) {
         const size_t len = (size_t)rec_len();
         double* dst = b.rec_own.p;
         if (fibre) { FY_TRY(b.rec_wide.reserve(len * (size_t)n)); dst = b.rec_wide.p; }
-        FY_HIP(hipMemcpyAsync(dst, b.h_rec.p, len * (size_t)n * sizeof(double), hipMemcpyHostToDevice, copy_stream));
+        FY_HIP(hipMemcpyAsync(dst, src ? src : b.h_rec.p, len * (size_t)n * sizeof(double), hipMemcpyHostToDevice, copy_stream));
         if (fibre) FY_TRY(launch_fibre_repack(copy_stream, b.rec_wide.p, b.rec_own.p, n));
         tm.bytes_in += (int64_t)len * n * (int64_t)sizeof(double);
     }
@@ -625,7 +630,7 @@ int Coupling::run_batch(Batch& b) {
         FY_TRY(launch_tile_caps(stream, tbD, tbB));
         if (timing) marks.mark(1, stream);
         FY_TRY(launch_locate_deposit(stream, d_tree.p, use_implicit ? d_tree_packed.p : nullptr, implicit, n_cells, tree_levels, p, b.n, gp,
-                                     use_implicit ? d_loc_start.p : nullptr, slab_own(), ll, cw, d_pvol_acc.p, d_up_acc.p, d_touched.p, tbD, side,
+                                     use_implicit ? d_loc_start.p : nullptr, own_of(b), ll, cw, d_pvol_acc.p, d_up_acc.p, d_touched.p, tbD, side,
                                      fused_gather ? b.d_rec : nullptr));
         b.chain_n = b.n;                                   // (what the next placement's runs are ordered by)
         if (timing) marks.mark(2, stream);
@@ -690,7 +695,7 @@ int Coupling::run_batch(Batch& b) {
         for (int a = 0; a < 3; ++a) g.faces[a] = rectilinear ? d_faces[a].p : nullptr;
         if (timing) marks.mark(3, stream);
         const CellWindow cw{slab.active ? slab.base : 0, n_field};
-        FY_TRY(launch_point_force(stream, b.d_rec, b.n, g, fp, cw, d_vol.p, dU, dVGrad, dUSource, b.force.p, b.found.p, b.incell.p, slab_own()));
+        FY_TRY(launch_point_force(stream, b.d_rec, b.n, g, fp, cw, d_vol.p, dU, dVGrad, dUSource, b.force.p, b.found.p, b.incell.p, own_of(b)));
         if (timing) marks.mark(4, stream);
     }
     return FY_OK;
@@ -752,6 +757,7 @@ int Coupling::collect_timings() {
         FY_HIP(hipStreamSynchronize(copy_stream));
         FY_HIP(hipStreamSynchronize(copy_out_stream));
         for (auto* b : batches) if (b->events) { tm.copy_in += b->t_in.ms(); tm.copy_out += b->t_out.ms(); }
+        for (auto& ck : piece_clocks) tm.copy_in += ck.ms();
     }
     tm.h2d = tm.copy_in; tm.d2h = tm.copy_out;              // the PCIe copies themselves (sum over the batches), on the copy stream
     tm.wire_recv = wire_recv_ms; tm.wire_send = wire_send_ms;
@@ -795,22 +801,142 @@ int Coupling::recv_yade_intrs() {
         if (counts[(size_t)transport.local_rank] > 0 || slab.active) in_comm.emplace_back(yrank, std::max(counts[(size_t)transport.local_rank], 0));
     }
     set_num_batches((int)in_comm.size());
+    const bool views = transport.recv_view != nullptr && transport.send_reserve != nullptr && transport.send_commit != nullptr;
+    wire_views = views;
+    if (views) FY_TRY(lock_view_region());
+    if (views && transport.recv_view_layout && transport.recv_view_next && !fibre) return recv_yade_pieces(in_comm);
     for (size_t q = 0; q < in_comm.size(); ++q) {
         Batch& b = *batches[q];
         b.yrank = in_comm[q].first;
+        b.committed = false; b.out_found = nullptr; b.out_force = nullptr; b.pieces.n = 0; b.pieces.axis = 2;
         const int n = in_comm[q].second;
-        FY_TRY(b.h_rec.reserve((size_t)rec_len() * (size_t)std::max(n, 1)));
-        if (n > 0) {                                                        // FoamYade.C:127-139: only intersecting workers send records
+        const double* view = nullptr;
+        if (n > 0 && views) {
+            // the records stay where the transport (its wire helpers) put them: the PCIe copy starts from there
             const WallClock wc;
-            FY_TR(transport.recv(transport.user, b.h_rec.data(), rec_len() * n, FY_T_DOUBLE, b.yrank, TAG_YADE_DATA));
+            const void* vp = nullptr;
+            FY_TR(transport.recv_view(transport.user, &vp, rec_len() * n, FY_T_DOUBLE, b.yrank, TAG_YADE_DATA, &b.pieces));
             wire_recv_ms += wc.ms();
+            view = static_cast<const double*>(vp);
+            if (b.pieces.n < 0 || b.pieces.n > FY_WIRE_MAX_PIECES || b.pieces.axis < 0 || b.pieces.axis > 2) return fail(FY_ERR_TRANSPORT, "recv_view: bad pieces (%d across axis %d)", b.pieces.n, b.pieces.axis);
+        } else {
+            FY_TRY(b.h_rec.reserve((size_t)rec_len() * (size_t)std::max(n, 1)));
+            if (n > 0) {                                                    // FoamYade.C:127-139: only intersecting workers send records
+                const WallClock wc;
+                FY_TR(transport.recv(transport.user, b.h_rec.data(), rec_len() * n, FY_T_DOUBLE, b.yrank, TAG_YADE_DATA));
+                wire_recv_ms += wc.ms();
+            }
         }
-        FY_TRY(upload_batch(b, n));
+        FY_TRY(upload_batch(b, n, view));
         FY_TRY(run_batch(b));
         // a batch's forces and found flags are final as soon as ITS kernels are done (a later batch only changes the cell fields): start
         // their way back now, so that the copy runs under the next batch's receive, upload and kernels
         FY_TRY(start_results_copy(b));
+        // ... and with a zero-copy wire the results of the batches before it go out as soon as they have landed (FoamYade.C:239-243, 504-507
+        // send per Yade proc: nothing orders one proc's answers after another's): the helpers send them while the next records come in
+        if (views) for (size_t e = 0; e < q; ++e) FY_TRY(commit_results(*batches[e], false));
     }
+    return FY_OK;
+}
+
+// The same with a transport that reports the record messages piece by piece (fy_transport::recv_view_layout / recv_view_next: wire helpers take the
+// workers' pieces in whatever order they are delivered -- taking them worker by worker makes the helpers queue behind one sending core): every
+// piece's PCIe copy starts when it lands, so the copies hide under the receive; a worker's kernels start when its last piece is on its way to the
+// device and every earlier worker's kernels are enqueued -- the reference's order of Yade procs (FoamYade.C:612-628), whatever order the wire kept.
+int Coupling::recv_yade_pieces(const std::vector<std::pair<int, int> >& in_comm) {
+    const size_t nb = in_comm.size();
+    std::vector<const double*> view(nb, nullptr);
+    std::vector<int> left(nb, 0);
+    for (size_t q = 0; q < nb; ++q) {
+        Batch& b = *batches[q];
+        b.yrank = in_comm[q].first;
+        b.committed = false; b.out_found = nullptr; b.out_force = nullptr; b.pieces.n = 0; b.pieces.axis = 2;
+        const int n = in_comm[q].second;
+        const void* vp = nullptr;
+        FY_TR(transport.recv_view_layout(transport.user, &vp, rec_len() * n, FY_T_DOUBLE, b.yrank, TAG_YADE_DATA, &b.pieces));
+        if (b.pieces.n < 0 || b.pieces.n > FY_WIRE_MAX_PIECES || b.pieces.axis < 0 || b.pieces.axis > 2) return fail(FY_ERR_TRANSPORT, "recv_view_layout: bad pieces");
+        view[q] = static_cast<const double*>(vp);
+        left[q] = std::max(b.pieces.n, 1);
+        FY_TRY(ensure_batch_events(b));
+        FY_TRY(b.rec_own.reserve(10 * (size_t)std::max(n, 1)));
+    }
+    // the pieces of different workers interleave on the copy stream: each copy gets an event pair of its own (tm.copy_in is their sum), and a
+    // batch's end event b.t_in.b -- what its kernels wait for -- is recorded when its last piece is enqueued
+    size_t pc_used = 0;
+    size_t next = 0;
+    auto run_ready = [&]() -> int {
+        while (next < nb && left[next] == 0) {
+            Batch& b = *batches[next];
+            const int n = in_comm[next].second;
+            b.t_in.armed = false;
+            b.t_in.stop(copy_stream);                    // every copy enqueued so far, this batch's last piece among them, lies before this event
+            FY_HIP(hipStreamWaitEvent(stream, b.t_in.b, 0));
+            b.d_rec = b.rec_own.p;
+            FY_TRY(ensure_batch(b, n));
+            FY_TRY(run_batch(b));
+            FY_TRY(start_results_copy(b));
+            for (size_t e = 0; e < next; ++e) FY_TRY(commit_results(*batches[e], false));
+            ++next;
+        }
+        return FY_OK;
+    };
+    size_t outstanding = 0;
+    for (size_t q = 0; q < nb; ++q) outstanding += (size_t)left[q];
+    while (outstanding > 0) {
+        int src = -1, pc = -1;
+        const WallClock wc;
+        FY_TR(transport.recv_view_next(transport.user, &src, &pc));
+        wire_recv_ms += wc.ms();
+        size_t q = 0;
+        while (q < nb && in_comm[q].first != src) ++q;
+        if (q == nb || pc < 0 || pc >= std::max(batches[q]->pieces.n, 1) || left[q] <= 0) return fail(FY_ERR_TRANSPORT, "recv_view_next: unexpected piece %d of worker %d", pc, src);
+        Batch& b = *batches[q];
+        const int64_t n = in_comm[q].second;
+        const int64_t lo = b.pieces.n > 0 ? b.pieces.start[pc] : 0, hi = (b.pieces.n > 0 && pc + 1 < b.pieces.n) ? b.pieces.start[pc + 1] : n;
+        if (hi > lo) {
+            if (pc_used == piece_clocks.size()) { piece_clocks.emplace_back(); FY_TRY(piece_clocks.back().init()); }
+            EventTimer& ck = piece_clocks[pc_used++];
+            ck.start(copy_stream);
+            FY_HIP(hipMemcpyAsync(b.rec_own.p + 10 * lo, view[q] + 10 * lo, 10 * (size_t)(hi - lo) * sizeof(double), hipMemcpyHostToDevice, copy_stream));
+            ck.stop(copy_stream);
+            tm.bytes_in += 10 * (hi - lo) * (int64_t)sizeof(double);
+        }
+        --left[q]; --outstanding;
+        FY_TRY(run_ready());
+    }
+    return run_ready();
+}
+
+// page-lock the memory the transport's views point into (once per generation; a failed registration leaves the copies pageable, which the
+// runtime stages at the same rate but synchronously)
+int Coupling::lock_view_region() {
+    if (!transport.view_region) return FY_OK;
+    void* base = nullptr; size_t bytes = 0; uint64_t gen = 0;
+    FY_TR(transport.view_region(transport.user, &base, &bytes, &gen));
+    if (base == view_base && bytes == view_bytes && gen == view_generation) return FY_OK;
+    if (view_locked) { (void)hipHostUnregister(view_base); view_locked = false; }
+    view_base = base; view_bytes = bytes; view_generation = gen;
+    if (base && bytes) {
+        if (hipHostRegister(base, bytes, hipHostRegisterDefault) == hipSuccess) view_locked = true;
+        else (void)hipGetLastError();
+    }
+    return FY_OK;
+}
+
+// hand one batch's results to the transport: found flags (FoamYade.C:239-243), then forces (FoamYade.C:504-507)
+int Coupling::commit_results(Batch& b, bool wait) {
+    if (b.committed || b.n == 0 || !b.out_started) return FY_OK;
+    if (wait) FY_HIP(hipEventSynchronize(b.t_out.b));
+    else {
+        const hipError_t e = hipEventQuery(b.t_out.b);
+        if (e == hipErrorNotReady) return FY_OK;
+        if (e != hipSuccess) return fail(FY_ERR_HIP, "results copy failed: %s", hipGetErrorString(e));
+    }
+    const WallClock wc;
+    FY_TR(transport.send_commit(transport.user, b.out_found, (int)b.n, FY_T_INT, b.yrank, TAG_SEARCH_RES));
+    FY_TR(transport.send_commit(transport.user, b.out_force, 6 * (int)b.n, FY_T_DOUBLE, b.yrank, TAG_FORCE));
+    wire_send_ms += wc.ms();
+    b.committed = true;
     return FY_OK;
 }
 
@@ -818,7 +944,18 @@ int Coupling::recv_yade_intrs() {
 int Coupling::start_results_copy(Batch& b) {
     if (b.out_started) return FY_OK;
     FY_TRY(ensure_batch_events(b));
-    FY_TRY(b.h_found.reserve((size_t)std::max<int64_t>(b.n, 1))); FY_TRY(b.h_force.reserve(6 * (size_t)std::max<int64_t>(b.n, 1)));
+    int32_t* hf = nullptr; double* hF = nullptr;
+    if (b.n && !serial_yade && wire_views) {
+        void* v = nullptr;
+        FY_TR(transport.send_reserve(transport.user, &v, (int)b.n, FY_T_INT, b.yrank, TAG_SEARCH_RES));
+        hf = b.out_found = static_cast<int32_t*>(v);
+        FY_TR(transport.send_reserve(transport.user, &v, 6 * (int)b.n, FY_T_DOUBLE, b.yrank, TAG_FORCE));
+        hF = b.out_force = static_cast<double*>(v);
+    } else {
+        FY_TRY(b.h_found.reserve((size_t)std::max<int64_t>(b.n, 1))); FY_TRY(b.h_force.reserve(6 * (size_t)std::max<int64_t>(b.n, 1)));
+        hf = b.h_found.data(); hF = b.h_force.data();
+        b.out_found = nullptr; b.out_force = nullptr;
+    }
     if (b.n) {
         FY_TRY(ensure_found(b));
         FY_HIP(hipEventRecord(b.ev_ready, stream));
@@ -826,8 +963,8 @@ int Coupling::start_results_copy(Batch& b) {
     }
     b.t_out.start(copy_out_stream);
     if (b.n) {
-        FY_HIP(hipMemcpyAsync(b.h_found.data(), b.found.p, (size_t)b.n * sizeof(int32_t), hipMemcpyDeviceToHost, copy_out_stream));
-        FY_HIP(hipMemcpyAsync(b.h_force.data(), b.force.p, 6 * (size_t)b.n * sizeof(double), hipMemcpyDeviceToHost, copy_out_stream));
+        FY_HIP(hipMemcpyAsync(hf, b.found.p, (size_t)b.n * sizeof(int32_t), hipMemcpyDeviceToHost, copy_out_stream));
+        FY_HIP(hipMemcpyAsync(hF, b.force.p, 6 * (size_t)b.n * sizeof(double), hipMemcpyDeviceToHost, copy_out_stream));
         tm.bytes_out += b.n * (int64_t)(sizeof(int32_t) + 6 * sizeof(double));
     }
     b.t_out.stop(copy_out_stream);
@@ -861,6 +998,8 @@ int Coupling::send_results() {
                     FY_TR(transport.send(transport.user, &b.h_force[6 * (size_t)np], 6, FY_T_DOUBLE, 0, TAG_FORCE));
         }
         wire_send_ms += wc.ms();
+    } else if (wire_views) {                                                // zero-copy wire: whatever has not gone out yet, in worker order
+        for (int bi = 0; bi < n_batches; ++bi) FY_TRY(commit_results(*batches[bi], true));
     } else {
         for (int bi = 0; bi < n_batches; ++bi) {                            // FoamYade.C:239-243
             Batch& b = *batches[bi];
@@ -1020,6 +1159,8 @@ int Coupling::write_field_host(const char* name, const double* in) {
 
 Coupling::~Coupling() {
     if (device >= 0) (void)hipSetDevice(device);
+    if (view_locked) (void)hipHostUnregister(view_base);
+    for (auto& ck : piece_clocks) ck.destroy();
     for (auto& t : timers) t.destroy();
     marks.destroy();
     for (auto* b : batches) delete b;

@@ -41,6 +41,12 @@ struct Batch {
     hipEvent_t ev_ready = nullptr;       // results final on the compute stream
     bool events = false;
     bool out_started = false;            // this step's D2H of force / found is already on the outbound copy stream
+    // zero-copy wire (fy_transport::recv_view / send_reserve): the records stay where the transport keeps them and the results are copied
+    // straight into the memory the transport sends from
+    fy_wire_pieces pieces{};             // cuts of the record message (wire helpers), for the ownership test
+    int32_t* out_found = nullptr;        // reserved send buffers of this step (nullptr: the pinned h_found / h_force above)
+    double* out_force = nullptr;
+    bool committed = false;              // this step's results were handed to the transport already
     ~Batch() { t_in.destroy(); t_out.destroy(); if (ev_ready) (void)hipEventDestroy(ev_ready); }
 };
 
@@ -133,7 +139,13 @@ struct Coupling {
     double wire_recv_ms = 0, wire_send_ms = 0;  // host wall time inside the transport's data calls (the MPI side)
     int ensure_batch_events(Batch& b);
     int start_results_copy(Batch& b);           // D2H of one batch's forces + found flags, as soon as its kernels are enqueued
-    int upload_batch(Batch& b, int64_t n);      // pinned h_rec -> rec_own on the copy stream; the compute stream waits for it
+    int upload_batch(Batch& b, int64_t n, const double* src = nullptr);      // pinned h_rec (or the transport's view) -> rec_own on the copy stream; the compute stream waits for it
+    int recv_yade_pieces(const std::vector<std::pair<int, int> >& in_comm);      // recv_yade_intrs with a transport that reports the record messages piece by piece
+    int commit_results(Batch& b, bool wait);    // hand a batch's found flags and forces to the transport once their D2H has landed (wait = false: only if it has)
+    int lock_view_region();                     // page-lock the memory the transport's views point into (fy_transport::view_region)
+    void* view_base = nullptr; size_t view_bytes = 0; uint64_t view_generation = 0; bool view_locked = false;
+    std::vector<EventTimer> piece_clocks;       // one event pair per piece copy of the piece-wise receive (recv_yade_pieces)
+    bool wire_views = false;                    // this step's records came as views and its results go out through send_reserve / send_commit
 
     // ---- timing
     enum { T_TOTAL = 0, T_COUNT };
@@ -153,7 +165,18 @@ struct Coupling {
     ParticleSoA soa_of(Batch& b);
     int set_particles_host(int bi, const double* rec, int64_t n);
     int set_particles_device(int bi, const double* d_rec, int64_t n);
-    SlabOwn slab_own() const { return SlabOwn{slab.active ? 1 : 0, slab.kglob0, slab.kglob0 + slab.nz, slab.nzglob, mesh.origin[2], mesh.dx}; }
+    SlabOwn slab_own() const { return SlabOwn{slab.active ? 1 : 0, slab.kglob0, slab.kglob0 + slab.nz, slab.nzglob, mesh.origin[2], mesh.dx, 0, 0, 0, 0.0, {0}, {0}, {0}}; }
+    // ... of one batch: its slab's planes, cut further by the wire pieces its records arrived in
+    SlabOwn own_of(const Batch& b) const {
+        SlabOwn o = slab_own();
+        if (b.pieces.n > 0) {
+            if (!o.active) { o.active = 1; o.k0 = 0; o.k1 = mesh.nz; o.nzglob = mesh.nz; }
+            o.npieces = b.pieces.n;
+            o.paxis = b.pieces.axis; o.po = mesh.origin[b.pieces.axis]; o.pn = b.pieces.axis == 0 ? mesh.nx : (b.pieces.axis == 1 ? mesh.ny : mesh.nz);
+            for (int q = 0; q < b.pieces.n; ++q) { o.pstart[q] = b.pieces.start[q]; o.pk0[q] = b.pieces.k0[q]; o.pk1[q] = b.pieces.k1[q]; }
+        }
+        return o;
+    }
     int migrate(int64_t* d_tags, int64_t tag_capacity, int64_t* n_out);
     DevBuf<double> mig_stay, mig_up, mig_down, mig_cnt;
     DevBuf<unsigned int> mig_counters;

@@ -3,6 +3,7 @@
 //
 //     foamYadeHip -solver ico|pimple [-case DIR] [-device N]
 //     mpiexec -n Y yade ... : -n N foamYadeHip_mpi -solver ... -case DIR -parallel [-nYade Y] [-hostComm]
+//     mpiexec -n Y yade ... : -n K foamYadeHip_mpi -solver ... -case DIR -wireHelpers [-nYade Y]
 //
 // read the case (fy_foam_case_open), create the solver, then  while (runTime.loop()) { step; runTime.write(); setSourceZero }.
 // Built with -DFY_WITH_MPI (make mpi -> foamYadeHip_mpi) it is launched like the reference, MPMD next to Yade ("mpiexec -n 1 yade ... :
@@ -12,6 +13,8 @@
 // takes its z-slab (fy_solver_create_slab), one GPU per rank over RCCL (or, with -hostComm / fewer GPUs than ranks, planes staged through the host
 // and moved by MPI); each rank receives the particles of its slab from Yade as the reference's ranks do (FoamYade.C:77-155); time directories
 // are gathered to the first solver rank and written undecomposed.
+// -wireHelpers: K solver-side ranks in front of ONE GPU (include/foamyade_mpi.h): the first computes, the others receive the particles from a parallel
+// Yade and send the answers back, in parallel -- one receiving process cannot take a 10 M-particle step off the wire faster than ~9 GB/s.
 // This file is host glue only: no arithmetic of the path lives here.
 #include <sys/stat.h>
 
@@ -37,7 +40,7 @@ static int die(const char* what) {
 int main(int argc, char** argv) {
     std::string dir = ".", solver_name;
     int device = -1, n_yade_arg = -1;
-    bool parallel = false, host_comm = false;
+    bool parallel = false, host_comm = false, wire_helpers = false;
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
         if (a == "-case" && i + 1 < argc) dir = argv[++i];
@@ -46,7 +49,8 @@ int main(int argc, char** argv) {
         else if (a == "-parallel") parallel = true;
         else if (a == "-nYade" && i + 1 < argc) n_yade_arg = std::atoi(argv[++i]);
         else if (a == "-hostComm") host_comm = true;
-        else { std::fprintf(stderr, "usage: foamYadeHip -solver ico|pimple [-case DIR] [-device N] [-parallel [-nYade Y] [-hostComm]]\n"); return 2; }
+        else if (a == "-wireHelpers") wire_helpers = true;
+        else { std::fprintf(stderr, "usage: foamYadeHip -solver ico|pimple [-case DIR] [-device N] [-parallel [-nYade Y] [-hostComm]] | [-wireHelpers [-nYade Y]]\n"); return 2; }
     }
     if (solver_name != "ico" && solver_name != "pimple") { std::fprintf(stderr, "foamYadeHip: -solver ico|pimple is required\n"); return 2; }
     const int solver = solver_name == "ico" ? FY_SOLVER_ICO : FY_SOLVER_PIMPLE;
@@ -62,10 +66,27 @@ int main(int argc, char** argv) {
     MPI_Comm_rank(MPI_COMM_WORLD, &wrank);
     // Yade ranks come first in MPI_COMM_WORLD (README.md:29, FoamYade.C:28).  Without -parallel ONE fluid rank, the rest is Yade; with it the
     // solver ranks are the world's last world - nYade ranks (-nYade defaults to 1: a serial Yade)
-    const int n_yade = parallel ? (n_yade_arg >= 0 ? n_yade_arg : 1) : world - 1;
-    if (n_yade < 0 || n_yade >= world || wrank < n_yade) { std::fprintf(stderr, "foamYadeHip_mpi: the solver ranks must come last in the MPMD launch (world %d, Yade ranks %d)\n", world, n_yade); MPI_Abort(MPI_COMM_WORLD, 2); }
+    // -nYade absent: the transport derives it as the reference does (commSzDff = world size - solver communicator size, FoamYade.C:28): every rank
+    // running this executable is a solver rank, the Yade ranks are the ones in front of them (README.md:29)
+    int n_yade = (parallel || wire_helpers) ? (n_yade_arg >= 0 ? n_yade_arg : -1) : world - 1;
+    if (n_yade < 0) {                                  // (the launch's FIRST executable has nobody in front of it: the fluid alone, in parallel)
+        int* appnum = nullptr; int flag = 0;
+        MPI_Comm_get_attr(MPI_COMM_WORLD, MPI_APPNUM, &appnum, &flag);
+        if (flag && appnum && *appnum == 0) n_yade = 0;
+    }
+    if (n_yade >= world || (n_yade >= 0 && wrank < n_yade)) { std::fprintf(stderr, "foamYadeHip_mpi: the solver ranks must come last in the MPMD launch (world %d, Yade ranks %d)\n", world, n_yade); MPI_Abort(MPI_COMM_WORLD, 2); }
     MPI_Comm solver_comm = MPI_COMM_WORLD;
-    if (n_yade > 0) {
+    if (wire_helpers) {
+        int is_helper = 0;
+        if (fy_mpi_transport_create_wire_helpers(n_yade, &tr, &is_helper) != FY_OK) return die("fy_mpi_transport_create_wire_helpers");
+        if (is_helper) {                                  // receive and answer for my slab of the block until the computing rank is done
+            const int rc = fy_mpi_wire_helper_serve(&tr);
+            MPI_Finalize();
+            return rc == FY_OK ? 0 : 1;
+        }
+        trp = &tr;
+        solver_comm = MPI_COMM_SELF;
+    } else if (n_yade != 0) {
         if (fy_mpi_transport_create(n_yade, &tr) != FY_OK) return die("fy_mpi_transport_create");
         trp = &tr;
         fy_mpi_local_comm(&tr, &solver_comm);
@@ -75,8 +96,15 @@ int main(int argc, char** argv) {
     if (ssize > 1) {
         const int ndev = fy_device_count();
         if (ndev < 1) return die("no HIP device");
-        if (device < 0) device = srank % ndev;
-        const int use_rccl = (!host_comm && ndev >= ssize) ? 1 : 0;       // one GPU per rank, or the ranks share and MPI moves the planes
+        // a GPU per rank is a question of THIS node's ranks and GPUs (two nodes of 8 GPUs run 16 ranks over RCCL)
+        MPI_Comm node;
+        MPI_Comm_split_type(solver_comm, MPI_COMM_TYPE_SHARED, srank, MPI_INFO_NULL, &node);
+        int nrank = 0, nsize = 1;
+        MPI_Comm_rank(node, &nrank); MPI_Comm_size(node, &nsize);
+        MPI_Comm_free(&node);
+        if (device < 0) device = nrank % ndev;
+        int mine_ok = (!host_comm && ndev >= nsize) ? 1 : 0, use_rccl = 0;
+        MPI_Allreduce(&mine_ok, &use_rccl, 1, MPI_INT, MPI_MIN, solver_comm);      // one GPU per rank everywhere, or the ranks share and MPI moves the planes
         if (fy_mpi_comm_create(&solver_comm, use_rccl, device, &comm) != FY_OK) return die("fy_mpi_comm_create");
         if (srank == 0) std::printf("Decomposition: %d z-slabs, %s\n", ssize, use_rccl ? "RCCL" : "planes staged through the host, moved by MPI");
     }
@@ -150,11 +178,13 @@ int main(int argc, char** argv) {
     // advances by what setDeltaT.H chose for each step, until endTime is reached to within half a step
     const long n_steps = std::lround((info.end_time - info.start_time) / info.delta_t);
     double t = info.start_time;
-    for (long k = 1; cd.adjust_time_step ? t < info.end_time - 1e-9 * std::fabs(info.end_time) : k <= n_steps; ++k) {
+    double dt_now = info.delta_t;                      // Time::run(): value() < endTime - 0.5 deltaT [OF-6 Time.C], with the deltaT setDeltaT.H left
+    for (long k = 1; cd.adjust_time_step ? t < info.end_time - 0.5 * dt_now : k <= n_steps; ++k) {
         if (fy_solver_step(s) != FY_OK) return die("fy_solver_step");
         fy_step_stats st;
         fy_solver_get_stats(s, &st);
         t = cd.adjust_time_step ? t + st.delta_t : info.start_time + (double)k * info.delta_t;
+        dt_now = st.delta_t;
         char tname[64];
         std::snprintf(tname, sizeof(tname), "%.12g", t);
         if (master) {

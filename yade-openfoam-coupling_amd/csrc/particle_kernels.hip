@@ -192,6 +192,19 @@ __global__ __launch_bounds__(256) void k_bin_gather(const double* __restrict__ r
 // trading ~12 FP64 ALU ops for 8x fewer lines is the MI355X-shaped choice.
 struct NodeVal { double x, y, z; int32_t id; };
 
+// may this record be located here: its containing cell lies in the slab's planes and -- records that came in wire pieces -- in its piece's layers
+__device__ __forceinline__ bool own_planes(const SlabOwn& own, int wire_index, int kz, double qx, double qy, double qz) {
+    if (kz < own.k0 || kz >= own.k1) return false;
+    if (own.npieces == 0) return true;
+    const double qa = own.paxis == 0 ? qx : (own.paxis == 1 ? qy : qz);
+    int ka = (int)floor((qa - own.po) / own.dx);
+    ka = min(max(ka, 0), own.pn - 1);
+    int a0 = 0, a1 = 0;
+    for (int q = 0; q < own.npieces; ++q)
+        if (wire_index >= own.pstart[q]) { a0 = own.pk0[q]; a1 = own.pk1[q]; }
+    return ka >= a0 && ka < a1;
+}
+
 template <bool IMPLICIT>
 __device__ __forceinline__ NodeVal fetch_node(const KdNode* __restrict__ tree, const uint32_t* __restrict__ packed, const ImplicitGeom& ig, uint32_t o) {
     NodeVal v;
@@ -453,7 +466,7 @@ __global__ __launch_bounds__(kWave) void k_locate(const KdNode* __restrict__ tre
                 if (own.active) {                                // another slab's particle: not located here (k = 0)
                     int kz = (int)floor((qz - own.oz) / own.dx);
                     kz = min(max(kz, 0), own.nzglob - 1);
-                    if (!(qz == qz) || kz < own.k0 || kz >= own.k1) { p.chain_len[i] = 0; active = false; }
+                    if (!(qz == qz) || !own_planes(own, p.orig[i], kz, qx, qy, qz)) { p.chain_len[i] = 0; active = false; }
                 }
             }
             next += n_idle;
@@ -952,7 +965,7 @@ __global__ __launch_bounds__(kDepThreads) void k_locate_deposit(LocateLists ll, 
         if (own.active) {                                    // another slab's particle: not located here (k = 0)
             int kz = (int)floor((qz - own.oz) / own.dx);
             kz = min(max(kz, 0), own.nzglob - 1);
-            if (!(qz == qz) || kz < own.k0 || kz >= own.k1) { p.chain_len[i] = 0; mine = false; }
+            if (!(qz == qz) || !own_planes(own, p.orig[i], kz, qx, qy, qz)) { p.chain_len[i] = 0; mine = false; }
         }
         if (mine) {
             const double hdx = 0.5 * ig.dx;
@@ -1369,7 +1382,7 @@ __global__ __launch_bounds__(256) void k_point_force(const double* __restrict__ 
         cj = min(g.ny - 1, (int)((y - g.bbmin[1]) / g.dx));
         ck = min(g.nz - 1, (int)((z - g.bbmin[2]) / g.dx));
     }
-    if (own.active && (ck < own.k0 || ck >= own.k1)) {         // in another slab's planes: that rank owns it
+    if (own.active && !own_planes(own, (int)i, ck, x, y, z)) {           // in another slab's (or wire piece's) planes: that one owns it
         F[0] = F[1] = F[2] = F[3] = F[4] = F[5] = 0.0;
         found_out[i] = -1;
         incell_out[i] = -1;

@@ -56,9 +56,14 @@ int launch_bin_scatter(hipStream_t s, const double* rec, int64_t n, const uint32
 // z-slab ownership: a rank that is handed particles of the whole block -- what the reference's serial-Yade broadcast
 // does (FoamYade.C:176-183) -- locates only those whose containing (nearest) cell lies in its own planes [k0, k1); every other
 // particle is "not found" here (found = -1, zero force), exactly one rank owns each particle.  active = 0: single domain.
+// npieces > 0 (records that came in as several wire pieces, fy_transport::recv_view): record `w` (wire index) belongs to the last piece
+// whose pstart <= w and is located only within that piece's cell layers [pk0, pk1) across paxis -- a particle near a cut arrives in both pieces, one finds it.
 struct SlabOwn {
     int active, k0, k1, nzglob;
     double oz, dx;
+    int npieces, paxis, pn;        // pieces cut the block across axis paxis (pn cell layers, first one at po)
+    double po;
+    int pstart[8], pk0[8], pk1[8];
 };
 
 struct ImplicitGeom {
