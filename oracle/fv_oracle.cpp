@@ -257,7 +257,7 @@ struct Fv {
             case 5: return std::max(std::min(std::min(2.0 * r, 0.5 * r + 0.5), 2.0), 0.0);                       // MUSCL
             case 6: return std::max(std::min(std::min(r, 1.0), 2.0), 0.0);                                       // Minmod
             case 7: return std::max(std::max(std::min(2.0 * r, 1.0), std::min(r, 2.0)), 0.0);                    // SuperBee
-            default: return std::max(std::min(std::min(2.0 * r, (3.0 + r) / 4.0), 2.0), 0.0);                    // QUICK (8)
+            default: return std::max(std::min((3.0 + r) / 4.0, 2.0), 0.0);        // QUICK (8) [OF-6 QUICK.H]: (phif - phiU) / (phiCD - phiU) = (3 + r) / 4, limited to [0, 2] only
         }
     }
     // weight of the owner's (low cell's) value on interior face q of axis d between cells own and nei, for the face flux `flux` (owner -> neighbour)

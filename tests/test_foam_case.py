@@ -818,7 +818,7 @@ def test_convection_schemes_are_read_by_name(prod, tmp_path, text, scheme, k):
 
 
 # ---- decomposed cases (processorN directories) ---------------------------------------------------------------------------------------------
-def decompose_case(dst, n_proc, fields=("U.water", "p")):
+def decompose_case(dst, n_proc, fields=("U.water", "p"), real_output=False):
     """what `decomposePar` with simpleCoeffs (1 1 n) leaves for a one-block case, as far as the field files go: processorR/<start>/<field> with the
     R-th z-slab's cells (global order) and the processor patches next to the case's own.  Test infrastructure (no OpenFOAM here to run the tool)"""
     import re
@@ -835,6 +835,13 @@ def decompose_case(dst, n_proc, fields=("U.water", "p")):
                 rows = [ln for ln in text[body_start:body_end].split("\n") if ln.strip()]
                 assert len(rows) == n
                 text = text[:m.start()] + "internalField   nonuniform List<%s> %d\n(\n" % (m.group(1), per) + "\n".join(rows[r * per:(r + 1) * per]) + text[body_end:]
+            # decomposePar keeps a patch that has no face on this processor -- the block's z sides on the ranks that do not touch them -- and writes
+            # its `value` as an empty list [OF-6 behaviour, recalled]
+            if real_output:
+                for patch, touches in (("bottom", r == 0), ("top", r == n_proc - 1)):
+                    if not touches:
+                        text = re.sub(r"(%s\s*\{[^}]*?)value\s+uniform\s+(\([^)]*\)|[^;]+);" % patch,
+                                      lambda mm: mm.group(1) + "value nonuniform List<%s> 0();" % ("vector" if mm.group(2).startswith("(") else "scalar"), text)
             procs = ""
             for nb in (r - 1, r + 1):
                 if 0 <= nb < n_proc:
@@ -869,6 +876,32 @@ def test_processor_directories_are_read_and_written(prod, tmp_path):
         prod.FoamCase(dst, prod.FY_SOLVER_PIMPLE, processor=(0, 2))
     with pytest.raises(prod.FoamYadeError, match="internalField"):
         prod.FoamCase(dst, prod.FY_SOLVER_PIMPLE, processor=(0, 6))      # (processor3 .. 5 are missing too, but rank 0's list has the wrong length first)
+    whole.close()
+
+
+def test_processor_directories_shaped_like_decomposePar_output(prod, tmp_path):
+    """(advisor, round 3) a patch without faces on a processor carries `value nonuniform List<vector> 0()`: the ranks that do not touch the inlet read
+    their directory all the same; and every processor patch this library writes has a `value` entry (processorFvPatchField reads one: a file
+    without it would be refused by reconstructPar) -- also alpha's, whose start time had no file"""
+    dst = tmp_path / "bed"
+    shutil.copytree(os.path.join(CASES, "bed_pimple"), dst)
+    decompose_case(dst, 3, real_output=True)
+    assert "nonuniform List<vector> 0()" in (dst / "processor1/0/U.water").read_text()
+    whole = prod.FoamCase(dst, prod.FY_SOLVER_PIMPLE)
+    for r in range(3):
+        fc = prod.FoamCase(dst, prod.FY_SOLVER_PIMPLE, processor=(r, 3))
+        assert list(fc.case.u_bc) == list(whole.case.u_bc) and list(fc.case.p_bc) == list(whole.case.p_bc)
+        if r == 0:
+            assert tuple(fc.case.u_value[4]) == tuple(whole.case.u_value[4])          # (the rank that holds the inlet's faces knows its value)
+        nloc = fc.field_cells
+        fc.write_fields("0.5", np.zeros((nloc, 3)), np.zeros(nloc), alpha=np.ones(nloc))
+        for fname in ("U.water", "p", "alpha.water"):
+            text = (dst / ("processor%d" % r) / "0.5" / fname).read_text()
+            import re
+            for m in re.finditer(r"procBoundary\w+\s*\{([^}]*)\}", text):
+                assert "type" in m.group(1) and "processor" in m.group(1) and "value" in m.group(1), (fname, m.group(0))
+            assert text.count("procBoundary") == (1 if r in (0, 2) else 2), fname
+        fc.close()
     whole.close()
 
 

@@ -855,6 +855,14 @@ class FoamCase:
     def write(self, solver, time_name):
         _check(lib().fy_foam_case_write_time(self._h, solver._h, str(time_name).encode()))
 
+    def write_fields(self, time_name, U, p, alpha=None, nut=None, k=None, epsilon=None):
+        """runTime.write() from host arrays holding this case's (or processor directory's) cells: fy_foam_case_write_fields"""
+        arrs = [None if a is None else np.ascontiguousarray(a, dtype=np.float64) for a in (U, p, alpha, nut, k, epsilon)]
+        ptr = [None if a is None else a.ctypes.data_as(_dp) for a in arrs]
+        L = lib()
+        L.fy_foam_case_write_fields.argtypes = [C.c_void_p, C.c_char_p] + [_dp] * 6
+        _check(L.fy_foam_case_write_fields(self._h, str(time_name).encode(), *ptr))
+
     def close(self):
         if self._h:
             lib().fy_foam_case_close(self._h)

@@ -305,10 +305,11 @@ int read_poly_mesh(fy_foam_case* c) {
     const std::string base = join(c->dir, "constant/polyMesh");
     std::vector<std::string> tk;
     std::string err;
-    auto list_of = [&](const char* name) -> int { return fy::foam_list_file_tokens(join(base, name), &tk, &err) ? FY_OK : fail(FY_ERR_INVALID, "%s", err.c_str()); };
+    auto code_of = [&]() { return err.find("not supported") != std::string::npos ? FY_ERR_UNSUPPORTED : FY_ERR_INVALID; };      // (an unsupported file format falls back to blockMeshDict)
+    auto list_of = [&](const char* name) -> int { return fy::foam_list_file_tokens(join(base, name), &tk, &err) ? FY_OK : fail(code_of(), "%s", err.c_str()); };
     // ---- points: N (x y z) ...
     std::vector<double> pts;
-    if (!fy::foam_numeric_list_file(join(base, "points"), &pts, &err)) return fail(FY_ERR_INVALID, "%s", err.c_str());
+    if (!fy::foam_numeric_list_file(join(base, "points"), &pts, &err)) return fail(code_of(), "%s", err.c_str());
     if (pts.size() < 25 || (pts.size() - 1) % 3 != 0 || (double)((pts.size() - 1) / 3) != pts[0]) return fail(FY_ERR_INVALID, "%s/points: malformed point list", base.c_str());
     pts.erase(pts.begin());
     const size_t npts = pts.size() / 3;
@@ -395,6 +396,7 @@ int read_poly_mesh(fy_foam_case* c) {
         pd.second.word("type", &ty);
         if (!pd.second.integer("nFaces", &nf) || !pd.second.integer("startFace", &sf) || nf < 0 || sf < 0 || (size_t)sf + (size_t)nf > nfaces)
             return fail(FY_ERR_INVALID, "%s/boundary: patch '%s' needs nFaces and startFace inside the face list", base.c_str(), pd.first.c_str());
+        if (nf == 0) continue;                               // (a patch without faces -- blockMesh's empty `defaultFaces` -- constrains nothing, whatever its type)
         if (ty == "empty" || ty == "cyclic" || ty == "wedge" || ty == "processor")
             return fail(FY_ERR_UNSUPPORTED, "%s/boundary: patch '%s' of type '%s' is not supported (wall / patch / symmetryPlane sides of a 3-D box)", base.c_str(), pd.first.c_str(), ty.c_str());
         for (int q = 0; q < nf; ++q) {
@@ -476,14 +478,27 @@ int read_internal(const FoamDict& f, const std::string& path, int ncomp, size_t 
 }
 
 // boundaryField entries that belong to none of the six sides (a decomposed case's processor patches): kept as text, written back as they are
-void keep_extra_patches(const fy_foam_case* c, const FoamDict& bf, std::vector<std::pair<std::string, std::string> >* out) {
+// A processor patch is written back with a `value` entry in any case: processorFvPatchField's dictionary constructor reads one [OF-6
+// processorFvPatchField.C], so reconstructPar would refuse a file without it -- where the file's value was a binary list (not kept as text) or
+// absent, `uniform 0` stands in (the patch's values are re-evaluated from the neighbour's cells on the first use)
+void keep_extra_patches(const fy_foam_case* c, const FoamDict& bf, int ncomp, std::vector<std::pair<std::string, std::string> >* out) {
     out->clear();
     for (const std::string& name : bf.order) {
         bool side = false;
         for (int s = 0; s < 6; ++s) side = side || c->patch_of_side[s] == name;
         const FoamDict* pd = bf.subdict(name);
-        if (!side && pd) out->emplace_back(name, entry_text(*pd));
+        if (side || !pd) continue;
+        std::string text = entry_text(*pd);
+        if (text.find("        value ") == std::string::npos) text += ncomp == 3 ? "        value uniform (0 0 0);\n" : "        value uniform 0;\n";
+        out->emplace_back(name, text);
     }
+}
+// `value nonuniform List<...> 0()`: what decomposePar writes for a patch that has no face on this processor (every z side of the block on the ranks
+// that do not touch it): the patch's value is then nobody's business here
+bool empty_patch_value(const std::vector<std::string>* vt, int ncomp) {
+    if (!vt || vt->size() < 3 || (*vt)[0] != "nonuniform") return false;
+    std::vector<double> v;
+    return fy::foam_read_list(*vt, 2, ncomp, &v) && v.empty();
 }
 
 int read_fields(fy_foam_case* c) {
@@ -495,7 +510,7 @@ int read_fields(fy_foam_case* c) {
         FY_TRY(read_internal(f, path, 3, ncell, &c->U0, &c->file_cell));
         const FoamDict* bf = f.subdict("boundaryField");
         if (!bf) return fail(FY_ERR_INVALID, "%s: no boundaryField", path.c_str());
-        keep_extra_patches(c, *bf, &c->extra_patches[0]);
+        keep_extra_patches(c, *bf, 3, &c->extra_patches[0]);
         for (int s = 0; s < 6; ++s) {
             const FoamDict* pd = bf->subdict(c->patch_of_side[s]);
             std::string ty;
@@ -505,7 +520,8 @@ int read_fields(fy_foam_case* c) {
             if (ty == "fixedValue") {
                 c->desc.u_bc[s] = FY_BC_U_FIXED_VALUE;
                 const auto* vt = pd->tokens("value");
-                if (!vt || vt->empty() || (*vt)[0] != "uniform" || !pd->vector3("value", c->desc.u_value[s]))
+                if (empty_patch_value(vt, 3)) { /* no face of this patch on this processor */ }
+                else if (!vt || vt->empty() || (*vt)[0] != "uniform" || !pd->vector3("value", c->desc.u_value[s]))
                     return fail(FY_ERR_UNSUPPORTED, "%s: patch '%s': fixedValue needs 'value uniform (x y z)'", path.c_str(), c->patch_of_side[s].c_str());
             } else if (ty == "noSlip") {
                 c->desc.u_bc[s] = FY_BC_U_FIXED_VALUE;
@@ -526,7 +542,7 @@ int read_fields(fy_foam_case* c) {
         FY_TRY(read_internal(f, path, 1, ncell, &c->p0, &c->file_cell));
         const FoamDict* bf = f.subdict("boundaryField");
         if (!bf) return fail(FY_ERR_INVALID, "%s: no boundaryField", path.c_str());
-        keep_extra_patches(c, *bf, &c->extra_patches[1]);
+        keep_extra_patches(c, *bf, 1, &c->extra_patches[1]);
         for (int s = 0; s < 6; ++s) {
             const FoamDict* pd = bf->subdict(c->patch_of_side[s]);
             std::string ty;
@@ -538,7 +554,8 @@ int read_fields(fy_foam_case* c) {
             else if (ty == "fixedValue") {
                 c->desc.p_bc[s] = FY_BC_P_FIXED_VALUE;
                 const auto* vt = pd->tokens("value");
-                if (!vt || vt->size() < 2 || (*vt)[0] != "uniform" || !fy::foam_tok_is_number((*vt)[1], &c->desc.p_value[s]))
+                if (empty_patch_value(vt, 1)) { /* no face of this patch on this processor */ }
+                else if (!vt || vt->size() < 2 || (*vt)[0] != "uniform" || !fy::foam_tok_is_number((*vt)[1], &c->desc.p_value[s]))
                     return fail(FY_ERR_UNSUPPORTED, "%s: patch '%s': fixedValue needs 'value uniform <p>'", path.c_str(), c->patch_of_side[s].c_str());
             } else {
                 return fail(FY_ERR_UNSUPPORTED, "%s: patch '%s': pressure boundary type '%s' is not supported (zeroGradient, fixedValue, fixedFluxPressure)", path.c_str(),
@@ -556,7 +573,7 @@ int read_fields(fy_foam_case* c) {
         c->desc.nut_initial = c->nut0.empty() ? 0.0 : c->nut0[0];
         const FoamDict* bf = f.subdict("boundaryField");
         if (!bf) return fail(FY_ERR_INVALID, "%s: no boundaryField", path.c_str());
-        keep_extra_patches(c, *bf, &c->extra_patches[2]);
+        keep_extra_patches(c, *bf, 1, &c->extra_patches[2]);
         for (int s = 0; s < 6; ++s) {
             const FoamDict* pd = bf->subdict(c->patch_of_side[s]);
             std::string ty;
@@ -596,7 +613,7 @@ int read_fields(fy_foam_case* c) {
         c->desc.k_initial = c->k0.empty() ? 0.0 : c->k0[0];
         const FoamDict* bf = f.subdict("boundaryField");
         if (!bf) return fail(FY_ERR_INVALID, "%s: no boundaryField", path.c_str());
-        keep_extra_patches(c, *bf, &c->extra_patches[3]);
+        keep_extra_patches(c, *bf, 1, &c->extra_patches[3]);
         for (int s = 0; s < 6; ++s) {
             const FoamDict* pd = bf->subdict(c->patch_of_side[s]);
             std::string ty;
@@ -624,7 +641,7 @@ int read_fields(fy_foam_case* c) {
         c->desc.eps_initial = c->eps0.empty() ? 0.0 : c->eps0[0];
         const FoamDict* bf = f.subdict("boundaryField");
         if (!bf) return fail(FY_ERR_INVALID, "%s: no boundaryField", path.c_str());
-        keep_extra_patches(c, *bf, &c->extra_patches[4]);
+        keep_extra_patches(c, *bf, 1, &c->extra_patches[4]);
         for (int s = 0; s < 6; ++s) {
             const FoamDict* pd = bf->subdict(c->patch_of_side[s]);
             std::string ty;
@@ -982,6 +999,15 @@ static int open_case(const char* case_dir, int solver, int rank, int nranks, fy_
     fy_case_defaults(&c->desc, solver);
     // the mesh: constant/polyMesh when the case has one (what the reference's solvers read), else system/blockMeshDict (what blockMesh would make of it)
     int rc = file_exists(join(c->dir, "constant/polyMesh/points")) ? read_poly_mesh(c) : read_block_mesh(c);
+    if (rc == FY_ERR_UNSUPPORTED && file_exists(join(c->dir, "constant/polyMesh/points")) && file_exists(join(c->dir, "system/blockMeshDict"))) {
+        // a polyMesh this reader does not take (binary, or not a lattice of hexahedra): the dictionary it was made from may still describe the block
+        const std::string why = fy_last_error();
+        *c = fy_foam_case();
+        c->dir = case_dir; c->fdir = c->dir; c->solver = solver;
+        fy_case_defaults(&c->desc, solver);
+        rc = read_block_mesh(c);
+        if (rc != FY_OK) rc = fail(rc, "%s (constant/polyMesh was refused first: %s)", std::string(fy_last_error()).c_str(), why.c_str());
+    }
     if (rc == FY_OK) {
         c->fcells = (size_t)c->desc.nx * c->desc.ny * c->desc.nz;
         if (nranks > 0) {
@@ -1074,7 +1100,7 @@ int fy_foam_case_write_fields(const fy_foam_case* c, const char* time_name, cons
     for (const auto& e : c->extra_patches[0]) {
         const size_t a = e.second.find("type");
         const size_t b = a == std::string::npos ? a : e.second.find('\n', a);
-        bare.emplace_back(e.first, a == std::string::npos ? e.second : e.second.substr(0, b + 1));
+        bare.emplace_back(e.first, (a == std::string::npos ? e.second : e.second.substr(0, b + 1)) + "        value uniform 1;\n");      // (alphac = 1 where nothing was deposited)
     }
     const char* zg = "        type            zeroGradient;\n";
     auto vec = [&](const double* src, int nc) { return std::vector<double>(src, src + n * (size_t)nc); };

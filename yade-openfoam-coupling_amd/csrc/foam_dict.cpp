@@ -354,7 +354,18 @@ static bool numeric_list_file(const std::string& path, std::vector<T>* out, std:
     if (t.compare(i, 8, "FoamFile") == 0) {
         const size_t q = t.find('}', i);
         if (q == std::string::npos) { *err = path + ": unterminated FoamFile header"; return false; }
-        if (t.find("binary", i) < q) { *err = path + ": binary mesh files are not supported (the field files are)"; return false; }
+        {   // the header's `format` ENTRY says so, not the word somewhere in it (a `note "... binary ..."` is text)
+            size_t f = i;
+            bool is_binary = false;
+            while ((f = t.find("format", f)) != std::string::npos && f < q) {
+                const bool word = (f == 0 || !(std::isalnum((unsigned char)t[f - 1]) || t[f - 1] == '_')) && f + 6 < n && std::isspace((unsigned char)t[f + 6]);
+                size_t v = f + 6;
+                while (v < q && std::isspace((unsigned char)t[v])) ++v;
+                if (word && t.compare(v, 6, "binary") == 0 && v + 6 < n && (t[v + 6] == ';' || std::isspace((unsigned char)t[v + 6]))) is_binary = true;
+                f += 6;
+            }
+            if (is_binary) { *err = path + ": binary mesh files are not supported (the field files are)"; return false; }
+        }
         i = q + 1;
     }
     out->clear();

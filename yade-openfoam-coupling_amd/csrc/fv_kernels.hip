@@ -912,7 +912,10 @@ __device__ __forceinline__ double limiter_fn(int scheme, double twoByk, double r
         case 5: return fmax(fmin(fmin(2.0 * r, 0.5 * r + 0.5), 2.0), 0.0);                 // MUSCL
         case 6: return fmax(fmin(fmin(r, 1.0), 2.0), 0.0);                                 // Minmod
         case 7: return fmax(fmax(fmin(2.0 * r, 1.0), fmin(r, 2.0)), 0.0);                  // SuperBee
-        default: return fmax(fmin(fmin(2.0 * r, (3.0 + r) / 4.0), 2.0), 0.0);              // QUICK (8)
+        // QUICK (8) [OF-6 QUICK.H]: QLimiter = (phif - phiU) / (phiCD - phiU) with phif = (phiCD + phiU + (1 - w) d.grad(phi)_U) / 2, which is
+        // (3 + r) / 4 whatever the linear weight w; limited "between upwind and downwind" only -- max(min(., 2), 0) -- so NOT a TVD limiter: it stays
+        // positive down to r = -3 and has no 2 r bound (rounds 2 - 3 had min(2 r, .) here: another scheme under QUICK's name)
+        default: return fmax(fmin((3.0 + r) / 4.0, 2.0), 0.0);
     }
 }
 // weight of the owner's (low cell's) value on the interior face between own and nei (axis d; qn = the neighbour's index along d); flux: owner -> neighbour
