@@ -39,6 +39,12 @@ LOCATE_WHAT = ("k-d 'range' locate through per-(cell, octant) candidate lists + 
                "through the binned placement by the kernel itself (round 3: no separate gather pass): record 80 + placement 4 + list 15 B in, binned SoA copy 56 + "
                "chain length 4 + 12 B/pair out per particle; 32 B of accumulators read-modify-written per cell")
 FORCE_BYTES_PER_PARTICLE = 64.0 + 12.0 * KBAR + 52.0
+# SURVEY.md 8(d) COMPULSORY bytes (every array once) of the same two kernels: the locate + deposit reads the 80-byte wire record and read-modify-writes
+# the deposit accumulators (alpha 8 + uParticle 24 = 32 B per cell, twice); the force pass writes 48 B of force per particle, reads U, gradP, divT, C, V
+# (104 B per cell) and read-modify-writes uSourceDrag + uSource (32 B per cell, twice).  Everything else in *_BYTES_PER_PARTICLE is traffic the
+# design chose (binned SoA copy, stencil rows, placement)
+LOCATE_COMPULSORY = (80.0, 64.0)            # per particle, per cell
+FORCE_COMPULSORY = (48.0, 168.0)
 FORCE_WHAT = ("drag + Archimedes + back-scatter: particle 64 B + stencil 12 B/pair in, force record 52 B out; per cell the 64-byte gather record read and "
               "32 B of momentum-source accumulators read-modify-written")
 
@@ -375,6 +381,99 @@ def cpu_reference_as_written(n_sample=32, n_part=80000):
             "note": "not extrapolated to C3: the deposit is quadratic in the number of touched cells, so the as-written code does not reach that size"}
 
 
+def c2_subrecord(prod, torch, dev, device_index, steps=20, warmup=5):
+    """BASELINE configs[1] at full size beside the headline (driver-observed since round 4): icoFoamYade point force, 200 x 100 x 50 cells, 1 M
+    particles, dt = 2e-3 -- `steps` timed steps after `warmup`, same barriers as the headline's region"""
+    case = c2_case(prod, 2e-3, 1)
+    s = prod.Solver(case, device=device_index)
+    rec = c2_particles(torch, 1_000_000, dev)
+    s.set_particles_device(rec)
+    s.enable_particle_timing(True)
+    for _ in range(warmup):
+        s.step()
+    acc = dict(particle=0.0, momentum=0.0, pressure=0.0, other=0.0, force=0.0, p_iters=0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        s.step()
+        st = s.stats(); ct = s.coupling_timings()
+        for k in ("particle", "momentum", "pressure", "other"):
+            acc[k] += st["ms_" + k]
+        acc["force"] += ct["force"]; acc["p_iters"] += st["p_iters_total"]
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    s.close()
+    f_ms = acc["force"] / steps
+    return {"what": "BASELINE configs[1] at full size in the same run: icoFoamYade point-force coupling, 200 x 100 x 50 = 1,000,000-cell channel (inlet U = (1,0,0), "
+                    "outlet p = 0, no-slip walls), 1,000,000 particles, dt = 2e-3, PISO nCorr 2; NOT the configuration `value` is quoted on",
+            "value": round(steps / el, 3), "unit": "steps/s", "steps": steps, "warmup": warmup, "ms_per_step": round(1e3 * el / steps, 3),
+            "particle_steps_per_sec": round(steps / el * 1_000_000, 1), "p_iters_per_step": acc["p_iters"] / steps,
+            "per_step_ms": {k: round(acc[k] / steps, 3) for k in ("particle", "force", "momentum", "pressure", "other")},
+            "k_point_force": {"avg_ms": round(f_ms, 4), "GBps": round(128.0e6 / (f_ms * 1e-3) / 1e9, 1) if f_ms > 0 else None,
+                              "what": "128 B per particle (80 B record in, 48 B force out); bound by its three global FP64 atomics per particle"}}
+
+
+def laplacian_probe_child(n, reps):
+    """child of laplacian_past_cache (also run under rocprofv3 --pmc): the pEqn Laplacian apply y = A p (k_p_apply, 48 B per cell: diag, three upper
+    coefficients, x, y) on an n^3 operator -- 1.57 GB per launch at 320^3, six times the 256 MiB Infinity Cache -- timed by HIP events on its stream"""
+    import torch  # noqa: F401
+    prod = ge.load_product()
+    case = prod.make_case(prod.FY_SOLVER_ICO, n, n, n, 1.0 / n, 1e-3, 1e-2, u_bc=[prod.FY_BC_U_FIXED_VALUE] * 6, u_val=[(0, 0, 0)] * 6, p_solver=1)
+    s = prod.Solver(case)
+    s.step()                                   # assembles the pressure matrix
+    ms = s.time_p_apply(reps)
+    s.close()
+    print(json.dumps({"n": n, "reps": reps, "avg_ms": ms}), flush=True)
+
+
+def laplacian_past_cache(n=320, reps=40, timeout=300):
+    """roofline of the pEqn Laplacian where the Infinity Cache cannot hold it: two child passes of `bench.py --laplacian-probe n` under rocprofv3
+    (--pmc FETCH_SIZE, then --pmc WRITE_SIZE; --kernel-trace only), each timing k_p_apply itself with HIP events; bytes from the counters as in
+    live_pmc_traffic"""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    rp = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    nc = n ** 3
+    out = {"kernel": "k_p_apply", "what": f"pEqn Laplacian apply y = A p on a {n}^3 operator: 48 B/cell (diag, 3 upper, x, y) = {48.0 * nc / 1e9:.2f} GB per launch, "
+                                          "several times the 256 MiB Infinity Cache; HIP-event average over the launches of a child process, bytes from its rocprofv3 counters",
+           "bound": "hbm", "peak": HBM_PEAK_GBPS, "unit": "GB/s", "algorithmic_bytes_per_launch": 48.0 * nc, "cells": nc}
+    d = tempfile.mkdtemp(prefix="fy_lap_", dir="/tmp")
+    try:
+        cnt, times = {}, []
+        for tag in ("FETCH_SIZE", "WRITE_SIZE"):
+            od = os.path.join(d, tag)
+            base = [sys.executable, os.path.abspath(__file__), "--laplacian-probe", str(n), "--laplacian-reps", str(reps)]
+            cmd = ([rp, "--pmc", tag, "--kernel-trace", "--output-format", "csv", "-d", od, "--"] if os.path.exists(rp) else []) + base
+            env = dict(os.environ, TMPDIR="/tmp", FOAMYADE_TREE_CACHE_DIR="/dev/shm" if os.path.isdir("/dev/shm") else "/tmp")
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout)
+            line = [q for q in r.stdout.splitlines() if q.startswith("{")]
+            if r.returncode != 0 or not line:
+                out["error"] = f"probe failed (rc {r.returncode}): {(r.stderr or r.stdout)[-200:]}"
+                return out
+            times.append(json.loads(line[-1])["avg_ms"])
+            files = glob.glob(os.path.join(od, "**", "*counter_collection.csv"), recursive=True)
+            if files:
+                v = [float(q["Counter_Value"]) for q in csv.DictReader(open(files[0])) if q["Counter_Name"] == tag and "k_p_apply" in q["Kernel_Name"] and "dot" not in q["Kernel_Name"]]
+                if v:
+                    cnt[tag] = 1024.0 * sum(v) / len(v)
+        avg = min(times)
+        out.update({"avg_launch_ms": round(avg, 4), "launches": reps, "achieved": round(48.0 * nc / (avg * 1e-3) / 1e9, 1),
+                    "frac": round(48.0 * nc / (avg * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)})
+        if len(cnt) == 2:
+            t2, t1 = traffic_of(cnt)
+            out.update({"traffic": round(t2), "traffic_reads_undoubled": round(t1), "traffic_GBps": round(t2 / (avg * 1e-3) / 1e9, 1)})
+        else:
+            out["traffic"] = None
+    except Exception as e:                                            # noqa: BLE001
+        out["error"] = f"{type(e).__name__}: {e}"
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    return out
+
+
 def live_pmc_traffic(extra_args, nc, steps=5, warmup=2, timeout=420):
     """HBM bytes per launch, measured NOW: two rocprofv3 child passes of this very command (--pmc FETCH_SIZE, then --pmc WRITE_SIZE, each with
     --kernel-trace only: the guide's HBM recipe, separate passes), `steps` timed + `warmup` steps each; the launches of the warm-up steps (the first
@@ -396,7 +495,7 @@ def live_pmc_traffic(extra_args, nc, steps=5, warmup=2, timeout=420):
         for tag in ("FETCH_SIZE", "WRITE_SIZE"):
             od = os.path.join(d, tag)
             cmd = [rp, "--pmc", tag, "--kernel-trace", "--output-format", "csv", "-d", od, "--", sys.executable, os.path.abspath(__file__),
-                   "--steps", str(steps), "--warmup", str(warmup), "--no-cpu-baseline", "--wire", "0", "--no-moving", "--pmc", "0"] + extra_args
+                   "--steps", str(steps), "--warmup", str(warmup), "--no-cpu-baseline", "--wire", "0", "--no-moving", "--no-extras", "--pmc", "0"] + extra_args
             env = dict(os.environ, TMPDIR="/tmp")
             r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout)
             files = glob.glob(os.path.join(od, "**", "*counter_collection.csv"), recursive=True)
@@ -416,7 +515,14 @@ def live_pmc_traffic(extra_args, nc, steps=5, warmup=2, timeout=420):
         return None, f"{type(e).__name__}: {e}"
     finally:
         shutil.rmtree(d, ignore_errors=True)
-    return {k: 2.0 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0) for k, v in res.items()}, ""
+    return res, ""
+
+
+def traffic_of(v):
+    """HBM bytes per launch from the two counters: reads doubled as the guide's gfx950 correction prescribes (calibrated on wide coalesced streams;
+    an UPPER bound for gather-dominated kernels), and as counted (a LOWER bound there)"""
+    f, w = v.get("FETCH_SIZE", 0.0), v.get("WRITE_SIZE", 0.0)
+    return 2.0 * f + w, f + w
 
 
 def max_over_ranks(elapsed, dist, device):
@@ -498,6 +604,9 @@ def main():
                     "c5: configs[4] at full size (320^3 cells, 100 M particles, fluidized bed: bottom inlet, top outlet) -- on one GPU, or with --gpus N cut into N z-slabs")
     ap.add_argument("--wire", type=int, default=2, help="steps of the drop-in (host-buffer / fake-Yade) leg after the timed region, 0 = skip")
     ap.add_argument("--wire-workers", type=int, default=4)
+    ap.add_argument("--laplacian-probe", type=int, default=0, help=argparse.SUPPRESS)       # child mode of laplacian_past_cache
+    ap.add_argument("--laplacian-reps", type=int, default=40, help=argparse.SUPPRESS)
+    ap.add_argument("--no-extras", action="store_true", help="skip the C2 sub-record and the past-the-Infinity-Cache Laplacian probe of the default run")
     ap.add_argument("--wire-helpers", type=int, default=4, help="wire-helper ranks beside the computing rank in the drop-in leg over MPI (0: one solver rank receives everything)")
     ap.add_argument("--moving", action="store_true", help="not the BASELINE configuration: particles carry random velocities (+-0.05 m/s) and are displaced by "
                     "~0.1 dx per step (alternating random offsets, applied between the steps inside the timed region), so that the momentum deposit, "
@@ -511,6 +620,9 @@ def main():
     args = ap.parse_args()
     if args.rccl_selftest:
         rccl_selftest_child(args)
+    if args.laplacian_probe:
+        laplacian_probe_child(args.laplacian_probe, args.laplacian_reps)
+        raise SystemExit(0)
     if args.gpus > 1 and "RANK" not in os.environ:
         raise SystemExit(self_launch(args.gpus))
     if os.environ.get("FOAMYADE_BENCH_LAUNCH_PROBE"):             # tests/test_bench_multirank.py: what did the launcher hand this rank?
@@ -674,10 +786,12 @@ def main():
     }
     for gone in (("k_locate_deposit", "k_force_gaussian") if c2 else ("k_point_force",)):
         cand.pop(gone)
+    compulsory = {"k_locate_deposit": LOCATE_COMPULSORY[0] * np_part + LOCATE_COMPULSORY[1] * nc, "k_force_gaussian": FORCE_COMPULSORY[0] * np_part + FORCE_COMPULSORY[1] * nc}
     for nm, (ms, nl, bytes_per, desc) in cand.items():
         if nl:
             avg = ms / nl
-            kern[nm] = dict(total_ms=ms, launches=int(nl), avg_ms=avg, achieved_GBps=bytes_per / (avg * 1e-3) / 1e9, alg_bytes=bytes_per, what=desc)
+            kern[nm] = dict(total_ms=ms, launches=int(nl), avg_ms=avg, achieved_GBps=bytes_per / (avg * 1e-3) / 1e9, alg_bytes=bytes_per, what=desc,
+                            compulsory=compulsory.get(nm, bytes_per))
     dominant = max(kern, key=lambda k: kern[k]["total_ms"]) if kern else None
     lap = "k_mg_smooth(level 0)" if "k_mg_smooth(level 0)" in kern else "k_p_apply_dot"
 
@@ -685,7 +799,10 @@ def main():
         k = kern[name]
         return {"kernel": name, "bound": "hbm", "achieved": round(k["achieved_GBps"], 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(k["achieved_GBps"] / HBM_PEAK_GBPS, 4), "traffic": None, "avg_launch_ms": round(k["avg_ms"], 4),
-                "launches": k["launches"], "algorithmic_bytes_per_launch": k["alg_bytes"], "what": k["what"]}
+                "launches": k["launches"], "algorithmic_bytes_per_launch": k["alg_bytes"], "what": k["what"],
+                # `frac` counts the DESIGN's bytes (what this kernel must move given the layout chosen); compulsory_frac counts SURVEY.md 8(d)'s --
+                # every array of the path once -- so traffic the design added (SoA copy, stencil rows, placement) does not flatter it
+                "compulsory_bytes_per_launch": k["compulsory"], "compulsory_frac": round(k["compulsory"] / (k["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
 
     default_c3 = (not c2) and (not c5) and args.n == 160 and args.particles == 10_000_000
     default_c5 = c5 and args.n == 320 and args.particles == 100_000_000
@@ -749,6 +866,12 @@ def main():
                          "per_step_ms": per_step(macc, K)}
         rec.copy_(rec0)
         del rec0
+    if rank == 0 and world == 1 and default_c3 and not args.moving and not args.no_extras:
+        # driver-observed since round 4: BASELINE configs[1] at full size, and the pEqn Laplacian where no cache holds it
+        try:
+            out["c2"] = c2_subrecord(prod, torch, dev, local_rank)
+        except Exception as e:                                        # noqa: BLE001  (reported in the line, never fatal for the headline)
+            out["c2"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and world == 1 and args.wire > 0:
         # the drop-in leg needs the device memory: the HBM-resident solver is done
         rec_host = rec.cpu().numpy()
@@ -810,14 +933,25 @@ def main():
             tr, why = live_pmc_traffic((["--config", args.config] if args.config != "c3" else []), nc)
             if tr:
                 note = ("live: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child passes of this command (5 timed steps each), bytes per launch = "
-                        "(2 x FETCH_SIZE + WRITE_SIZE) x 1024; the doubled reads are an upper bound for the gather-dominated particle kernels")
+                        "(2 x FETCH_SIZE + WRITE_SIZE) x 1024 (`traffic`; the doubled reads are an upper bound for the gather-dominated particle kernels) and "
+                        "(FETCH_SIZE + WRITE_SIZE) x 1024 (`traffic_reads_undoubled`: the lower bound)")
                 for rf in ("roofline", "roofline_pEqn_laplacian"):
-                    if out.get(rf):
-                        out[rf]["traffic"] = tr.get(out[rf]["kernel"])
-                out["traffic_per_launch"] = {k: round(v) for k, v in tr.items()}
+                    if out.get(rf) and out[rf]["kernel"] in tr:
+                        out[rf]["traffic"], out[rf]["traffic_reads_undoubled"] = (round(x) for x in traffic_of(tr[out[rf]["kernel"]]))
+                out["traffic_per_launch"] = {k: round(traffic_of(v)[0]) for k, v in tr.items()}
+                out["traffic_per_launch_reads_undoubled"] = {k: round(traffic_of(v)[1]) for k, v in tr.items()}
             else:
                 note = f"live PMC pass failed ({why}); " + note
         out["traffic_note"] = note
+        if default_c3 and not args.moving and not args.no_extras and args.pmc != 0:
+            if solver is not None:
+                solver.close(); solver = None
+            torch.cuda.empty_cache()
+            past = laplacian_past_cache()
+            if out.get("roofline_pEqn_laplacian") is not None:
+                out["roofline_pEqn_laplacian"]["past_infinity_cache"] = past
+            else:
+                out["roofline_pEqn_laplacian_past_infinity_cache"] = past
     if dist is not None:
         dist.barrier()
     if rank == 0:
