@@ -1,17 +1,12 @@
 #!/bin/bash
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r4g; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r4h; mkdir -p $O
 cd $R
-( time timeout 900 python bench.py ) > $O/bench.txt 2> $O/bench.err; tail -1 $O/bench.txt > $O/bench_line.json; tail -5 $O/bench.err
-python - <<'PY'
-import json
-j=json.load(open("gpurun_out/r4g/bench_line.json"))
-print("value", j["value"], "ms", j["ms_per_step"], j["per_step_ms"])
-print("roofline", {k:j["roofline"][k] for k in ("kernel","frac","compulsory_frac","traffic","traffic_reads_undoubled","avg_launch_ms")})
-print("lap", {k:j["roofline_pEqn_laplacian"].get(k) for k in ("kernel","frac","traffic","avg_launch_ms")})
-print("past", j["roofline_pEqn_laplacian"].get("past_infinity_cache"))
-print("c2", j.get("c2"))
-print("moving", j.get("moving",{}).get("value"), j.get("moving",{}).get("per_step_ms"))
-for k in ("drop_in_path","drop_in_path_one_receiving_rank","drop_in_path_in_process_peer"):
-    d=j.get(k,{}); print(k, d.get("ms_per_step"), d.get("per_step_ms"), d.get("error"))
-print("cpu", j.get("cpu_baseline",{}).get("value"))
-PY
+export FOAMYADE_TREE_CACHE_DIR=/dev/shm
+V=$R/yade-openfoam-coupling_amd/lib/variants
+for rep in 1 2; do
+for v in cells base zm_u4 zm_u8 zm_p32u4 zm_p8u4; do
+  if [ $v == cells ]; then export FOAMYADE_ZMARCH_MIN_CELLS=100000000000; unset FOAMYADE_HIP_LIB;
+  elif [ $v == base ]; then export FOAMYADE_ZMARCH_MIN_CELLS=1; unset FOAMYADE_HIP_LIB;
+  else export FOAMYADE_ZMARCH_MIN_CELLS=1; export FOAMYADE_HIP_LIB=$V/libfoamyade_hip_$v.so; fi
+  echo -n "$v: "; timeout 300 python bench.py --laplacian-probe 320 --laplacian-reps 40 2>/dev/null | tail -1
+done; done
