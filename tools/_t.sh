@@ -1,12 +1,8 @@
 #!/bin/bash
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r4h; mkdir -p $O
-cd $R
-export FOAMYADE_TREE_CACHE_DIR=/dev/shm
-V=$R/yade-openfoam-coupling_amd/lib/variants
-for rep in 1 2; do
-for v in cells base zm_u4 zm_u8 zm_p32u4 zm_p8u4; do
-  if [ $v == cells ]; then export FOAMYADE_ZMARCH_MIN_CELLS=100000000000; unset FOAMYADE_HIP_LIB;
-  elif [ $v == base ]; then export FOAMYADE_ZMARCH_MIN_CELLS=1; unset FOAMYADE_HIP_LIB;
-  else export FOAMYADE_ZMARCH_MIN_CELLS=1; export FOAMYADE_HIP_LIB=$V/libfoamyade_hip_$v.so; fi
-  echo -n "$v: "; timeout 300 python bench.py --laplacian-probe 320 --laplacian-reps 40 2>/dev/null | tail -1
-done; done
+export RND=r04
+bash $GRAFT_REPO_ROOT/tools/profile_round.sh > /dev/null 2>&1
+cd $GRAFT_REPO_ROOT
+timeout 600 python tools/comm_count.py 160 2 10000000 4 > gpurun_out/r04/collectives_2x160.txt 2>&1
+timeout 600 python tools/comm_count.py 160 2 10000000 4 0.05 > gpurun_out/r04/collectives_2x160_moving.txt 2>&1
+timeout 900 python tools/virtual_slab_bench.py 2 6 > gpurun_out/r04/virtual_slabs_2.txt 2>&1
+ls -la gpurun_out/r04; tail -c 400 gpurun_out/r04/bench_line.json
