@@ -434,3 +434,112 @@ class FvSolver:
             self.close()
         except Exception:
             pass
+
+
+# ---- icoFoamYade on a general polyhedral mesh in OpenFOAM's addressing (oracle/ldu_oracle.cpp) -------------------------------------------------
+class LduCase(C.Structure):
+    _fields_ = [("solver", C.c_int), ("dt", C.c_double), ("nu", C.c_double), ("rho_fluid", C.c_double), ("rho_particle", C.c_double),
+                ("n_correctors", C.c_int), ("n_non_orth_correctors", C.c_int), ("momentum_predictor", C.c_int), ("p_ref_cell", C.c_int),
+                ("p_ref_value", C.c_double), ("p_tol", C.c_double), ("p_rel_tol", C.c_double), ("p_final_tol", C.c_double),
+                ("p_final_rel_tol", C.c_double), ("p_max_iter", C.c_int), ("u_tol", C.c_double), ("u_rel_tol", C.c_double), ("u_max_iter", C.c_int),
+                ("u_bc", _ip), ("u_value", _dp), ("p_bc", _ip), ("p_value", _dp)]
+
+
+class LduStats(C.Structure):
+    _fields_ = [("courant_mean", C.c_double), ("courant_max", C.c_double), ("cont_sum_local", C.c_double), ("cont_global", C.c_double),
+                ("cont_cumulative", C.c_double), ("p_iters_total", C.c_int), ("p_solves", C.c_int), ("u_iters_total", C.c_int),
+                ("p_initial_residual", C.c_double), ("p_final_residual", C.c_double)]
+
+
+_ldu_ready = False
+
+
+def _ldu_lib():
+    global _ldu_ready
+    L = lib()
+    if not _ldu_ready:
+        L.orc_ldu_create.argtypes = [C.c_int, _dp, C.c_int, C.c_int, _ip, _ip, _ip, _ip, C.c_int, C.c_int, _ip, _ip, C.POINTER(LduCase)]
+        L.orc_ldu_create.restype = C.c_void_p
+        L.orc_ldu_destroy.argtypes = [C.c_void_p]
+        L.orc_ldu_geometry.argtypes = [C.c_void_p, C.c_char_p, _dp]
+        L.orc_ldu_ptr.argtypes = [C.c_void_p, C.c_char_p, _ip]
+        L.orc_ldu_ptr.restype = C.POINTER(C.c_double)
+        for f in ("orc_ldu_step_begin", "orc_ldu_step_end", "orc_ldu_refresh_phi"):
+            getattr(L, f).argtypes = [C.c_void_p]
+        L.orc_ldu_get_stats.argtypes = [C.c_void_p, C.POINTER(LduStats)]
+        L.orc_ldu_adjust_phi_failed.argtypes = [C.c_void_p]
+        L.orc_ldu_sngrad.argtypes = [C.c_void_p, _dp, _dp, C.c_int, _dp]
+        _ldu_ready = True
+    return L
+
+
+class LduSolver:
+    """mesh: dict with points (n,3), face_offsets, face_points, owner, neighbour (internal faces first), n_cells, patch_start, patch_size
+    (tests/poly_meshes.py builds them); u_bc / p_bc / values per patch"""
+
+    def __init__(self, mesh, dt, nu, u_bc, u_val, p_bc, p_val=None, n_correctors=2, n_non_orth=0, momentum_predictor=1, p_ref_cell=0, p_ref_value=0.0,
+                 p_tol=1e-6, p_rel_tol=0.05, p_final_tol=1e-6, p_final_rel_tol=0.0, p_max_iter=5000, u_tol=1e-5, u_rel_tol=0.0, u_max_iter=1000,
+                 rho_f=1000.0, rho_p=2650.0):
+        self.L = _ldu_lib()
+        self.mesh = mesh
+        npatch = len(mesh["patch_start"])
+        self._keep = dict(points=np.ascontiguousarray(mesh["points"], np.float64), foff=np.ascontiguousarray(mesh["face_offsets"], np.int32),
+                          fpts=np.ascontiguousarray(mesh["face_points"], np.int32), own=np.ascontiguousarray(mesh["owner"], np.int32),
+                          nei=np.ascontiguousarray(mesh["neighbour"], np.int32), ps=np.ascontiguousarray(mesh["patch_start"], np.int32),
+                          pz=np.ascontiguousarray(mesh["patch_size"], np.int32), ub=np.ascontiguousarray(u_bc, np.int32),
+                          uv=np.ascontiguousarray(u_val, np.float64).reshape(npatch, 3), pb=np.ascontiguousarray(p_bc, np.int32),
+                          pv=np.ascontiguousarray(p_val if p_val is not None else np.zeros(npatch), np.float64))
+        k = self._keep
+        self.case = LduCase(0, dt, nu, rho_f, rho_p, n_correctors, n_non_orth, momentum_predictor, p_ref_cell, p_ref_value, p_tol, p_rel_tol, p_final_tol,
+                            p_final_rel_tol, p_max_iter, u_tol, u_rel_tol, u_max_iter, _i(k["ub"]), _d(k["uv"]), _i(k["pb"]), _d(k["pv"]))
+        self.nc, self.nf, self.ni = int(mesh["n_cells"]), len(k["own"]), len(k["nei"])
+        self.h = self.L.orc_ldu_create(k["points"].shape[0], _d(k["points"]), self.nf, self.ni, _i(k["foff"]), _i(k["fpts"]), _i(k["own"]), _i(k["nei"]),
+                                       self.nc, npatch, _i(k["ps"]), _i(k["pz"]), C.byref(self.case))
+        if not self.h:
+            raise ValueError("oracle: malformed polyhedral mesh (a boundary face outside every patch)")
+
+    def geometry(self, name):
+        size = {"C": 3 * self.nc, "V": self.nc, "Cf": 3 * self.nf, "Sf": 3 * self.nf, "magSf": self.nf, "w": self.ni, "dcNO": self.nf, "kvec": 3 * self.ni}[name]
+        out = np.empty(size)
+        assert self.L.orc_ldu_geometry(self.h, name.encode(), _d(out)) == size
+        return out.reshape(-1, 3) if name in ("C", "Cf", "Sf", "kvec") else out
+
+    def sngrad(self, cell_values, boundary_values, corrected=True):
+        """corrected surface-normal gradient on the internal faces (correctedSnGrad [OF-6])"""
+        out = np.empty(self.ni)
+        self.L.orc_ldu_sngrad(self.h, _d(np.ascontiguousarray(cell_values, np.float64)), _d(np.ascontiguousarray(boundary_values, np.float64)), 0 if corrected else 1, _d(out))
+        return out
+
+    def view(self, name):
+        n = C.c_int(0)
+        ptr = self.L.orc_ldu_ptr(self.h, name.encode(), C.byref(n))
+        if not ptr:
+            raise KeyError(name)
+        return np.ctypeslib.as_array(ptr, shape=(n.value,))
+
+    def get(self, name):
+        return self.view(name).copy()
+
+    def set(self, name, arr):
+        self.view(name)[:] = np.ascontiguousarray(arr, np.float64).ravel()
+        if name == "U":
+            self.L.orc_ldu_refresh_phi(self.h)
+
+    def step(self, source=None):
+        """source: (nc,3) explicit momentum source uSource for this step (what the coupling would leave), or None"""
+        self.L.orc_ldu_step_begin(self.h)
+        self.view("uSource")[:] = 0.0 if source is None else np.ascontiguousarray(source, np.float64).ravel()
+        self.L.orc_ldu_step_end(self.h)
+
+    def stats(self):
+        s = LduStats()
+        self.L.orc_ldu_get_stats(self.h, C.byref(s))
+        return {n: getattr(s, n) for n, _ in LduStats._fields_}
+
+    def close(self):
+        if self.h:
+            self.L.orc_ldu_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()

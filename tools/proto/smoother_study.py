@@ -12,8 +12,8 @@ import time
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-from oracle import oracle as orc  # noqa: E402
+sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle as orc  # noqa: E402
 import golden_cases as gc  # noqa: E402
 
 mode = os.environ.get("ORACLE_MG_SMOOTHER", "0")
