@@ -443,6 +443,54 @@ int fy_solver_local_cells(fy_solver*);
 int fy_solver_enable_kernel_timing(fy_solver*, int on);
 int fy_solver_get_kernel_timing(fy_solver*, const char* kernel, double* total_ms, int64_t* launches);
 
+
+/* ------------------------------------------------------------------------------------------------------------------------------------
+ * icoFoamYade on a GENERAL polyhedral mesh (round 4).  The reference's solvers run on whatever createMesh.H hands them
+ * (icoFoamYade/icoFoamYade.C:42) and carry a non-orthogonal corrector loop (icoFoamYade.C:114-131); fy_solver above is the structured block.
+ * fy_ldu_solver takes the mesh in OpenFOAM's own addressing -- constant/polyMesh: points, faces, owner, neighbour, boundary -- builds
+ * OpenFOAM's geometry from it (face triangle / cell pyramid decomposition, linear weights, nonOrthDeltaCoeffs, nonOrthCorrectionVectors
+ * [OF-6]) and runs the same loop body with owner / neighbour (LDU) addressing: Euler ddt, Gauss linear div / grad, Gauss linear CORRECTED
+ * laplacian (the explicit non-orthogonal part is what the correctNonOrthogonal loop iterates on), PCG with the diagonal preconditioner in
+ * its single-reduction form, Jacobi sweeps for U.  Patches: fixedValue / zeroGradient for U (noSlip = fixedValue 0), zeroGradient /
+ * fixedValue for p.  The coupling object (fy_ldu_solver_coupling) works on the mesh's own cell centres and volumes: explicit k-d tree, and
+ * for the point-force locate (mesh.findCell, FoamYade.C:251) the nearest centre followed by a walk across the faces the point lies outside of. */
+typedef struct fy_poly_mesh {
+    int32_t n_points;
+    const double* points;            /* [n_points][3] */
+    int32_t n_faces, n_internal_faces;
+    const int32_t* face_offsets;     /* [n_faces + 1] into face_points */
+    const int32_t* face_points;      /* a face's points turn counter-clockwise seen from outside its owner */
+    const int32_t* owner;            /* [n_faces] */
+    const int32_t* neighbour;        /* [n_internal_faces]: internal faces first, owner < neighbour */
+    int32_t n_cells;
+    int32_t n_patches;
+    const int32_t* patch_start;      /* [n_patches] first face of the patch (>= n_internal_faces) */
+    const int32_t* patch_size;
+} fy_poly_mesh;
+typedef struct fy_ldu_case {
+    double dt, nu, rho_fluid, rho_particle;
+    int32_t n_correctors, n_non_orth_correctors, momentum_predictor, p_ref_cell;
+    double p_ref_value;
+    double p_tol, p_rel_tol, p_final_tol, p_final_rel_tol; int32_t p_max_iter;
+    double u_tol, u_rel_tol; int32_t u_max_iter;
+    const int32_t* u_bc;             /* per patch: FY_BC_U_FIXED_VALUE | FY_BC_U_ZERO_GRADIENT */
+    const double* u_value;           /* [n_patches][3] */
+    const int32_t* p_bc;             /* per patch: FY_BC_P_ZERO_GRADIENT | FY_BC_P_FIXED_VALUE */
+    const double* p_value;           /* [n_patches] */
+} fy_ldu_case;
+typedef struct fy_ldu_solver fy_ldu_solver;
+void fy_ldu_case_defaults(fy_ldu_case*);        /* the icoFoam cavity tutorial's controls (as fy_case_defaults); the patch arrays stay NULL */
+int fy_ldu_solver_create(const fy_poly_mesh*, const fy_ldu_case*, const fy_transport* transport /* or NULL */, int device_ordinal, fy_ldu_solver** out);
+int fy_ldu_solver_step(fy_ldu_solver*);                                     /* one pass of icoFoamYade.C:65-149 */
+int fy_ldu_solver_get_stats(fy_ldu_solver*, fy_step_stats* out);
+fy_ctx* fy_ldu_solver_coupling(fy_ldu_solver*);                              /* FoamYade on this mesh (point force); fy_set_particles_* as usual */
+/* fields by name, host copies: "U" [nc][3], "p", "phi" [n_faces], "uSource" [nc][3] (added to what the coupling leaves: an external momentum source),
+ * "rAU", "HbyA", "phiHbyA", "p_diag", "p_coef" [n_faces], "p_rhs", "vGrad" [nc][9]; geometry: "C" "V" "Cf" "Sf" "magSf" "w" "dcNO" "kvec" */
+int fy_ldu_solver_field_count(fy_ldu_solver*, const char* name, int64_t* count);
+int fy_ldu_solver_read_field_host(fy_ldu_solver*, const char* name, double* out);
+int fy_ldu_solver_write_field_host(fy_ldu_solver*, const char* name, const double* in);
+int fy_ldu_solver_destroy(fy_ldu_solver*);
+
 #ifdef __cplusplus
 }
 #endif

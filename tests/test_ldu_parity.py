@@ -1,0 +1,135 @@
+"""fy_ldu_solver (icoFoamYade's loop body on a general polyhedral mesh, HIP: csrc/ldu_*.{cpp,hip}) against oracle/ldu_oracle.cpp, the CPU restatement, and
+against the structured HIP solver on a lattice.  FV parity is unpinned (OpenFOAM-6 is not here): what the restatement itself is held to is in
+tests/test_ldu_oracle.py.  Tolerances: geometry 1e-13; matrices of the first step 1e-10; fields after a few steps 2e-6 (both sides converge the same
+linear systems to their tolerances with the same algorithms, summed in another order)."""
+import numpy as np
+import pytest
+
+import poly_meshes as pm
+
+pytestmark = pytest.mark.gpu
+
+
+def pair(product, oracle, mesh, dt, nu, u_bc, u_val, p_bc, p_val=None, **kw):
+    okw = dict(kw)
+    h = product.LduSolver(mesh, dt, nu, u_bc, u_val, p_bc, p_val, **kw)
+    o = oracle.LduSolver(mesh, dt, nu, u_bc, u_val, p_bc, p_val, **okw)
+    return h, o
+
+
+def close(a, b, rtol, what):
+    sc = np.abs(b).max() + 1e-300
+    assert np.abs(a - b).max() <= rtol * sc, (what, np.abs(a - b).max() / sc)
+
+
+def lid(n_patches=6, lid_patch=3):
+    v = [(0, 0, 0)] * n_patches
+    v[lid_patch] = (1.0, 0, 0)
+    return v
+
+
+def test_geometry_equals_the_restatement(product, oracle):
+    mesh = pm.hex_block(5, 4, 6, (1.0, 0.8, 1.2), pm.wavy(0.04, (1.0, 0.8, 1.2)), renumber_seed=4)
+    h, o = pair(product, oracle, mesh, 1e-3, 0.01, [0] * 6, lid(), [0] * 6)
+    for nm in ("C", "V", "Cf", "Sf", "magSf", "w", "dcNO", "kvec"):
+        np.testing.assert_allclose(h.geometry(nm), o.geometry(nm), rtol=0, atol=1e-13, err_msg=nm)
+    h.close(); o.close()
+
+
+@pytest.mark.parametrize("kind", ["lattice", "sheared", "wavy_renumbered"])
+def test_cavity_matches_the_restatement(product, oracle, kind):
+    """lid-driven cavity, four steps, two non-orthogonal correctors: first-step matrices, then fields and counters"""
+    n = 10
+    vm, seed = {"lattice": (None, None), "sheared": (pm.shear(0.3, 0.0, 0.2), None), "wavy_renumbered": (pm.wavy(0.03), 9)}[kind]
+    mesh = pm.hex_block(n, n, n, vertex_map=vm, renumber_seed=seed)
+    kw = dict(n_non_orth=2, p_tol=1e-9, p_rel_tol=0.0, p_final_tol=1e-9, u_tol=1e-9, p_max_iter=5000)
+    h, o = pair(product, oracle, mesh, 0.4 / n, 0.01, [0] * 6, lid(), [0] * 6, **kw)
+    U0 = np.random.RandomState(3).rand(n ** 3, 3) * 0.05
+    h.set("U", U0); o.set("U", U0)
+    h.step(); o.step()
+    ni = len(mesh["neighbour"])
+    close(h.get("mom_lower"), o.get("mom_lower"), 1e-10, "lower"); close(h.get("mom_upper"), o.get("mom_upper"), 1e-10, "upper")
+    close(h.get("p_coef")[:ni], o.get("p_coef")[:ni], 1e-8, "p_coef")
+    for _ in range(3):
+        h.step(); o.step()
+    sh, so = h.stats(), o.stats()
+    assert abs(sh["p_iters_total"] - so["p_iters_total"]) <= max(3, so["p_iters_total"] // 20) and abs(sh["u_iters_total"] - so["u_iters_total"]) <= 1
+    assert sh["courant_max"] == pytest.approx(so["courant_max"], rel=1e-6)
+    close(h.get("U"), o.get("U"), 2e-6, "U")
+    ph, po = h.get("p"), o.get("p")
+    close(ph - ph.mean(), po - po.mean(), 1e-5, "p")
+    close(h.get("phi"), o.get("phi"), 5e-6, "phi")
+    h.close(); o.close()
+
+
+def test_through_flow_with_fixed_pressure_and_a_momentum_source(product, oracle):
+    """inlet fixedValue U, outlet fixedValue p, zeroGradient elsewhere on the in/outlet pair, walls, and an external momentum source: every boundary branch"""
+    mesh = pm.hex_block(8, 6, 4, (2.0, 1.0, 0.5), pm.wavy(0.03, (2.0, 1.0, 0.5)), patches=[("inlet", [0]), ("outlet", [1]), ("walls", [2, 3]), ("sides", [4, 5])], renumber_seed=1)
+    kw = dict(n_non_orth=1, p_tol=1e-10, p_rel_tol=0.0, p_final_tol=1e-10, u_tol=1e-10, p_max_iter=5000)
+    h, o = pair(product, oracle, mesh, 0.05, 0.02, [0, 1, 0, 1], [(0.5, 0, 0), (0, 0, 0), (0, 0, 0), (0, 0, 0)], [0, 1, 0, 0], [0, 0.0, 0, 0], **kw)
+    src = np.random.RandomState(8).standard_normal((mesh["n_cells"], 3)) * 0.3
+    for _ in range(5):
+        h.step(src); o.step(src)
+    close(h.get("U"), o.get("U"), 2e-6, "U"); close(h.get("p"), o.get("p"), 1e-5, "p"); close(h.get("phi"), o.get("phi"), 5e-6, "phi")
+    assert h.stats()["cont_err_sum_local"] < 1e-10
+    h.close(); o.close()
+
+
+def test_lattice_block_equals_the_structured_hip_solver(product):
+    """the same cavity through both HIP solvers: fy_solver on the block (Jacobi-preconditioned PCG) and fy_ldu_solver on the block written as a polyhedral mesh"""
+    n = 12
+    mesh = pm.hex_block(n, n, n, renumber_seed=6)
+    g = product.LduSolver(mesh, 0.4 / n, 0.01, [0] * 6, lid(), [0] * 6, p_tol=1e-10, p_rel_tol=0.0, p_final_tol=1e-10, u_tol=1e-10, p_max_iter=5000)
+    case = product.make_case(0, n, n, n, 1.0 / n, 0.4 / n, 0.01, u_bc=[0] * 6, u_val=lid(), p_solver=0, p_tol=1e-10, p_rel_tol=0.0, p_final_tol=1e-10, u_tol=1e-10)
+    f = product.Solver(case)
+    U0 = np.random.RandomState(2).rand(n ** 3, 3) * 0.05
+    f.set("U", U0)
+    Ug = np.zeros_like(U0); Ug[mesh["perm"]] = U0
+    g.set("U", Ug)
+    for _ in range(4):
+        f.step(); g.step()
+    Uf = f.get("U").reshape(-1, 3)
+    close(pm.to_lattice(mesh, g.get("U").reshape(-1, 3)), Uf, 1e-7, "U")
+    pf, pg = f.get("p"), pm.to_lattice(mesh, g.get("p"))
+    close(pg - pg.mean(), pf - pf.mean(), 1e-6, "p")
+    f.close(); g.close()
+
+
+def test_point_force_coupling_on_a_general_mesh(product):
+    """mesh.findCell (FoamYade.C:251) on a non-lattice mesh = nearest centre + a walk across faces: every particle lands in the cell whose face planes
+    contain it (checked by brute force from the solver's own geometry), particles outside the mesh are not found, and the Stokes drag / torque and the
+    momentum source follow FoamYade.C:437-453 from that cell's U and grad U"""
+    n = 8
+    mesh = pm.hex_block(n, n, n, vertex_map=pm.wavy(0.04), renumber_seed=12)
+    nu, rho = 0.01, 1000.0
+    s = product.LduSolver(mesh, 1e-3, nu, [0] * 6, lid(), [0] * 6, rho_f=rho)
+    U0 = np.random.RandomState(4).rand(n ** 3, 3) * 0.2
+    s.set("U", U0)
+    rs = np.random.RandomState(5)
+    npart = 3000
+    rec = np.zeros((npart, 10))
+    rec[:, 0:3] = rs.random_sample((npart, 3)) * 1.1 - 0.05          # some of them outside the unit box
+    rec[:, 3:9] = rs.standard_normal((npart, 6)) * 0.1
+    rec[:, 9] = 0.01
+    s.set_particles(rec)
+    # the step's grad U is that of U0; the source is consumed by the step, so look at the forces
+    s.step()
+    F, found = s.forces(), s.found()
+    C_, Cf, Sf, V = s.geometry("C"), s.geometry("Cf"), s.geometry("Sf"), s.geometry("V")
+    own, nei, ni = mesh["owner"], mesh["neighbour"], len(mesh["neighbour"])
+    inside_box = np.all((rec[:, 0:3] > 1e-9) & (rec[:, 0:3] < 1 - 1e-9), axis=1)
+    assert np.all(found[inside_box] == 1) and np.all(found[~inside_box & np.any((rec[:, 0:3] < -1e-9) | (rec[:, 0:3] > 1 + 1e-9), axis=1)] == -1)
+    # brute force: the cell all of whose faces have the point on the inner side
+    cells_of_face = [(own[f], +1.0) for f in range(len(own))] + [(nei[f], -1.0) for f in range(ni)]
+    face_id = list(range(len(own))) + list(range(ni))
+    for i in np.where(inside_box)[0][:400]:
+        x = rec[i, 0:3]
+        s_out = np.einsum("fk,fk->f", x[None, :] - Cf[face_id], Sf[face_id]) * np.array([sg for _, sg in cells_of_face])
+        worst = np.full(mesh["n_cells"], -np.inf)
+        np.maximum.at(worst, np.array([c for c, _ in cells_of_face]), s_out)
+        c = int(np.argmin(worst))
+        assert worst[c] <= 1e-12
+        dia = 2 * rec[i, 9]
+        drag = 3 * np.pi * dia * nu * rho * (U0[c] - rec[i, 3:6])
+        np.testing.assert_allclose(F[i, 0:3], drag, rtol=1e-10, atol=1e-16)
+    s.close()

@@ -77,6 +77,18 @@ class Transport(C.Structure):
                 ("send_reserve", C.c_void_p), ("send_commit", C.c_void_p), ("view_region", C.c_void_p)]
 
 
+class PolyMesh(C.Structure):
+    _fields_ = [("n_points", C.c_int32), ("points", _dp), ("n_faces", C.c_int32), ("n_internal_faces", C.c_int32), ("face_offsets", _ip), ("face_points", _ip),
+                ("owner", _ip), ("neighbour", _ip), ("n_cells", C.c_int32), ("n_patches", C.c_int32), ("patch_start", _ip), ("patch_size", _ip)]
+
+
+class LduCase(C.Structure):
+    _fields_ = [("dt", C.c_double), ("nu", C.c_double), ("rho_fluid", C.c_double), ("rho_particle", C.c_double), ("n_correctors", C.c_int32),
+                ("n_non_orth_correctors", C.c_int32), ("momentum_predictor", C.c_int32), ("p_ref_cell", C.c_int32), ("p_ref_value", C.c_double),
+                ("p_tol", C.c_double), ("p_rel_tol", C.c_double), ("p_final_tol", C.c_double), ("p_final_rel_tol", C.c_double), ("p_max_iter", C.c_int32),
+                ("u_tol", C.c_double), ("u_rel_tol", C.c_double), ("u_max_iter", C.c_int32), ("u_bc", _ip), ("u_value", _dp), ("p_bc", _ip), ("p_value", _dp)]
+
+
 class ParticleTimings(C.Structure):
     _fields_ = [("h2d", C.c_double), ("bin", C.c_double), ("locate_deposit", C.c_double), ("finalize", C.c_double),
                 ("force", C.c_double), ("d2h", C.c_double), ("total", C.c_double), ("n_particles", C.c_int64),
@@ -981,3 +993,98 @@ class VirtualSlabs:
         for cm in self.comms:
             lib().fy_comm_destroy(cm)
         self.solvers, self.comms = [], []
+
+
+class LduSolver:
+    """icoFoamYade's loop body on a general polyhedral mesh in OpenFOAM's addressing (fy_ldu_solver, include/foamyade_hip.h).  mesh: dict with points (n,3),
+    face_offsets, face_points, owner, neighbour, n_cells, patch_start, patch_size (tests/poly_meshes.py builds them); u_bc / p_bc / values per patch; the
+    controls are fy_ldu_case's (defaults: the icoFoam cavity tutorial's)"""
+
+    def __init__(self, mesh, dt, nu, u_bc, u_val, p_bc, p_val=None, device=0, transport=None, **controls):
+        L = lib()
+        L.fy_ldu_case_defaults.argtypes = [C.POINTER(LduCase)]; L.fy_ldu_case_defaults.restype = None
+        L.fy_ldu_solver_create.argtypes = [C.POINTER(PolyMesh), C.POINTER(LduCase), C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+        for f in ("fy_ldu_solver_step", "fy_ldu_solver_destroy"):
+            getattr(L, f).argtypes = [C.c_void_p]
+        L.fy_ldu_solver_get_stats.argtypes = [C.c_void_p, C.POINTER(StepStats)]
+        L.fy_ldu_solver_coupling.argtypes = [C.c_void_p]; L.fy_ldu_solver_coupling.restype = C.c_void_p
+        L.fy_ldu_solver_field_count.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64)]
+        L.fy_ldu_solver_read_field_host.argtypes = [C.c_void_p, C.c_char_p, _dp]
+        L.fy_ldu_solver_write_field_host.argtypes = [C.c_void_p, C.c_char_p, _dp]
+        npatch = len(mesh["patch_start"])
+        i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+        k = self._keep = dict(points=np.ascontiguousarray(mesh["points"], np.float64), foff=i32(mesh["face_offsets"]), fpts=i32(mesh["face_points"]), own=i32(mesh["owner"]),
+                              nei=i32(mesh["neighbour"]), ps=i32(mesh["patch_start"]), pz=i32(mesh["patch_size"]), ub=i32(u_bc),
+                              uv=np.ascontiguousarray(u_val, np.float64).reshape(npatch, 3), pb=i32(p_bc),
+                              pv=np.ascontiguousarray(p_val if p_val is not None else np.zeros(npatch), np.float64))
+        self.pm = PolyMesh(k["points"].shape[0], _d(k["points"]), len(k["own"]), len(k["nei"]), _i(k["foff"]), _i(k["fpts"]), _i(k["own"]), _i(k["nei"]), int(mesh["n_cells"]),
+                           npatch, _i(k["ps"]), _i(k["pz"]))
+        self.case = LduCase()
+        L.fy_ldu_case_defaults(C.byref(self.case))
+        self.case.dt, self.case.nu = dt, nu
+        names = dict(n_non_orth="n_non_orth_correctors", rho_f="rho_fluid", rho_p="rho_particle")
+        for key, v in controls.items():
+            setattr(self.case, names.get(key, key), v)
+        self.case.u_bc, self.case.u_value, self.case.p_bc, self.case.p_value = _i(k["ub"]), _d(k["uv"]), _i(k["pb"]), _d(k["pv"])
+        self._h = C.c_void_p()
+        self._tr = transport
+        _check(L.fy_ldu_solver_create(C.byref(self.pm), C.byref(self.case), C.byref(transport) if transport is not None else None, int(device), C.byref(self._h)))
+        self._cpl = C.c_void_p(L.fy_ldu_solver_coupling(self._h))
+        self.n_cells = int(mesh["n_cells"])
+        self._batch_n = [0]
+
+    def _size(self, name):
+        cnt = C.c_int64(0)
+        _check(lib().fy_ldu_solver_field_count(self._h, name.encode(), C.byref(cnt)))
+        return cnt.value
+
+    def get(self, name):
+        out = np.zeros(self._size(name))
+        _check(lib().fy_ldu_solver_read_field_host(self._h, name.encode(), _d(out)))
+        return out.reshape(-1, 3) if name in ("C", "Cf", "Sf", "kvec") else out
+
+    geometry = get
+
+    def set(self, name, arr):
+        arr = np.ascontiguousarray(arr, dtype=np.float64).ravel()
+        assert arr.size == self._size(name)
+        _check(lib().fy_ldu_solver_write_field_host(self._h, name.encode(), _d(arr)))
+
+    def set_particles(self, records):
+        L = lib()
+        _check(L.fy_set_num_batches(self._cpl, 1))
+        rec = np.zeros((0, 10)) if records is None else np.ascontiguousarray(records, dtype=np.float64).reshape(-1, 10)
+        _check(L.fy_set_particles_host(self._cpl, 0, _d(rec) if rec.size else None, rec.shape[0]))
+        self._batch_n = [rec.shape[0]]
+
+    def forces(self):
+        out = np.zeros((self._batch_n[0], 6))
+        _check(lib().fy_get_forces_host(self._cpl, 0, _d(out)))
+        return out
+
+    def found(self):
+        out = np.zeros(self._batch_n[0], dtype=np.int32)
+        _check(lib().fy_get_found_host(self._cpl, 0, _i(out)))
+        return out
+
+    def step(self, source=None):
+        """source: an external momentum source [nc][3] added to what the coupling leaves (kept until set again)"""
+        if source is not None:
+            self.set("uSource", source)
+        _check(lib().fy_ldu_solver_step(self._h))
+
+    def stats(self):
+        s = StepStats()
+        _check(lib().fy_ldu_solver_get_stats(self._h, C.byref(s)))
+        return {n: getattr(s, n) for n, _ in StepStats._fields_}
+
+    def close(self):
+        if self._h:
+            lib().fy_ldu_solver_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:            # noqa: BLE001
+            pass

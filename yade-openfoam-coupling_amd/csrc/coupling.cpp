@@ -2,6 +2,7 @@
 // all arithmetic runs in the HIP kernels of particle_kernels.hip.  There is no CPU compute path: without a HIP
 // device fy_create fails with FY_ERR_NO_DEVICE.
 #include "coupling.hpp"
+#include "ldu.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -69,7 +70,7 @@ int Coupling::create(const fy_mesh_desc* m, const fy_field_ptrs* f, int gaussian
     gaussian = gaussian_interp != 0;
     structured = m->nx > 0;
     rectilinear = structured && m->xf && m->yf && m->zf;          // graded block: lattice INDEXING, but no lattice of centres
-    if (!gaussian && !structured) return fail(FY_ERR_UNSUPPORTED, "point-force mode needs the structured block description (findCell stand-in)");
+    if (!gaussian && !structured && !ldu_geo) return fail(FY_ERR_UNSUPPORTED, "point-force mode needs the structured block description, or a general mesh's face addressing (fy_ldu_solver): the findCell stand-ins");
     if (structured && (int64_t)m->nx * m->ny * m->nz != m->n_cells) return fail(FY_ERR_INVALID, "nx*ny*nz != n_cells");
     if (tr) { transport = *tr; has_transport = true; }
 
@@ -693,6 +694,16 @@ int Coupling::run_batch(Batch& b) {
         for (int a = 0; a < 3; ++a) { g.bbmin[a] = mesh.bbox_min[a]; g.bbmax[a] = mesh.bbox_max[a]; }
         g.dx = mesh.dx; g.nx = mesh.nx; g.ny = mesh.ny; g.nz = mesh.nz;
         for (int a = 0; a < 3; ++a) g.faces[a] = rectilinear ? d_faces[a].p : nullptr;
+        g.cell_of = nullptr;
+        if (!structured) {
+            // a general mesh (fy_ldu_solver): mesh.findCell (FoamYade.C:251) = the cell whose centre is nearest (the k-d tree), then a walk across
+            // the faces the point lies outside of until it is inside every face of a cell (k_ldu_find_cell)
+            FY_TRY(b.pos3.reserve(3 * (size_t)std::max<int64_t>(b.n, 1))); FY_TRY(b.cell_hint.reserve((size_t)std::max<int64_t>(b.n, 1)));
+            FY_TRY(launch_ldu_positions(stream, b.d_rec, 10, b.n, b.pos3.p));
+            FY_TRY(launch_nearest_cell(stream, d_tree.p, nullptr, implicit, n_cells, b.pos3.p, b.n, b.cell_hint.p));
+            FY_TRY(launch_ldu_find_cell(stream, *ldu_geo, b.d_rec, 10, b.n, b.cell_hint.p, b.cell_hint.p));
+            g.cell_of = b.cell_hint.p;
+        }
         if (timing) marks.mark(3, stream);
         const CellWindow cw{slab.active ? slab.base : 0, n_field};
         FY_TRY(launch_point_force(stream, b.d_rec, b.n, g, fp, cw, d_vol.p, dU, dVGrad, dUSource, b.force.p, b.found.p, b.incell.p, own_of(b)));

@@ -40,6 +40,8 @@ struct Batch {
     EventTimer t_in, t_out;              // the batch's H2D / D2H copies on the copy stream (their end events are what the compute stream / the host wait for)
     hipEvent_t ev_ready = nullptr;       // results final on the compute stream
     bool events = false;
+    DevBuf<double> pos3;                 // general mesh, point force: the records' positions [n][3] and the located cells
+    DevBuf<int32_t> cell_hint;
     bool out_started = false;            // this step's D2H of force / found is already on the outbound copy stream
     // zero-copy wire (fy_transport::recv_view / send_reserve): the records stay where the transport keeps them and the results are copied
     // straight into the memory the transport sends from
@@ -84,6 +86,7 @@ struct Coupling {
     bool mid_hook_done = true;
     int run_mid_hook() { if (mid_hook && !mid_hook_done) { mid_hook_done = true; return mid_hook(mid_hook_user); } return 0; }
     fy_transport transport{};
+    const struct LduGeo* ldu_geo = nullptr;   // set before create() by fy_ldu_solver: the general mesh's face addressing on the device (point-force locate)
     int comm_sz_diff = 0;                // FoamYade.H:74
     bool serial_yade = true;             // FoamYade.H:91
     double rhoP = 0, rhoF = 0, nu = 0;   // FoamYade.H:83-85

@@ -1,0 +1,70 @@
+// fy_ldu_solver: icoFoamYade's loop body (icoFoamYade/icoFoamYade.C:65-149, with the correctNonOrthogonal loop of :114-131) on a general
+// polyhedral mesh in OpenFOAM's addressing (constant/polyMesh, what createMesh.H hands the solver: icoFoamYade.C:42).  See include/foamyade_hip.h.
+//   ldu_mesh.cpp     host: OpenFOAM's geometry from points / faces / owner / neighbour [OF-6 primitiveMesh*, surfaceInterpolation], cell -> face lists
+//   ldu_kernels.hip  the operators as HIP kernels: one lane per cell GATHERING over the cell's faces, or one lane per face (no scatter, no atomics)
+//   ldu_solver.cpp   sequencing + the C entry points
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <vector>
+
+#include "../../include/foamyade_hip.h"
+#include "common.hpp"
+
+namespace fy {
+
+// host-side geometry in OpenFOAM's conventions (face area vectors point owner -> neighbour / outwards)
+struct LduHostMesh {
+    int nPoints = 0, nFaces = 0, nInt = 0, nCells = 0, nPatches = 0;
+    std::vector<int32_t> own, nei, patch_of;            // patch_of[f - nInt]
+    std::vector<int32_t> cf_off, cf_face;               // per cell: its faces (ascending face number)
+    std::vector<double> Cf, Sf, magSf, C, V, w, dcNO, kvec;      // [3 nF] [3 nF] [nF] [3 nc] [nc] [nInt] [nF] [3 nInt]
+    double bbox_min[3], bbox_max[3];
+    int build(const fy_poly_mesh* m);                   // FY_OK or an error (malformed addressing)
+};
+
+// what the kernels see (device pointers), passed by value
+struct LduGeo {
+    int nCells, nFaces, nInt, nPatches;
+    const int32_t *own, *nei, *patch_of, *cf_off, *cf_face;
+    const double *Cf, *Sf, *magSf, *C, *V, *w, *dcNO, *kvec;
+    const int32_t *u_bc, *p_bc;                          // per patch
+    const double *u_val, *p_val;
+    double dt, nu;
+    int need_ref, p_ref_cell;
+    double p_ref_value;
+};
+
+// momentum matrix in LDU form: diag [nc] (boundary diagonal included), lower / upper per internal face, b [3 nc] (boundary sources included)
+struct LduMom { double *diag, *lower, *upper, *b; };
+
+int ldu_red_blocks(int n);      // partials per slot of the reducing kernels (= red_blocks(n) of fv_kernels.hpp: the folds are shared)
+
+int launch_ldu_flux_of(hipStream_t s, LduGeo g, const double* F, double* phi);
+int launch_ldu_courant(hipStream_t s, LduGeo g, const double* phi, double* partials);                    // slot 0 = max sumPhi / V, slot 1 = sum sumPhi
+int launch_ldu_grad_vec(hipStream_t s, LduGeo g, const double* F, double* T);                           // T[9 c + 3 i + j] = d_i F_j
+int launch_ldu_grad_scalar(hipStream_t s, LduGeo g, const double* p, double* gp);
+// UEqn (icoFoamYade.C:79-85): face part (lower / upper, the explicit non-orthogonal flux of the laplacian), then the cell part (diag, b)
+int launch_ldu_assemble_momentum(hipStream_t s, LduGeo g, const double* phi, const double* Uold, const double* uSource, const double* gradU, LduMom M,
+                                 double* face_corr /* [3 nInt] scratch */);
+// one Jacobi pass: xn = (b - V gradp - offdiag x) / diag and the L1 residual / normFactor sums of x (slots 0-2 |b - A x|, 3-5 normFactor terms)
+int launch_ldu_mom_pass(hipStream_t s, LduGeo g, LduMom M, const double* gradp, const double* x, double* xn, const double* xsum3, double* partials);
+int launch_ldu_HbyA(hipStream_t s, LduGeo g, LduMom M, const double* U, double* rAU, double* HbyA);
+int launch_ldu_phiHbyA(hipStream_t s, LduGeo g, const double* HbyA, const double* rAU, const double* Uold, const double* phiOld, double* rAUf, double* phiHbyA);
+int launch_ldu_adjust_phi(hipStream_t s, LduGeo g, double* phiHbyA, double* sums4 /* device scratch */, int* err);
+// pEqn (icoFoamYade.C:118-123): face part (coefficients, the explicit non-orthogonal flux from grad p), cell part (diag, right-hand side, setReference)
+int launch_ldu_assemble_pressure(hipStream_t s, LduGeo g, const double* rAUf, const double* phiHbyA, const double* gradp, double* pcoef, double* pcorr, double* pdiag, double* prhs);
+// r = b - A x with slot 0 = sum |r|, slot 1 = normFactor terms (xbar from xsum); w = A u with slot 0 = u.r, slot 1 = u.w where u = r / diag is formed inline
+int launch_ldu_p_init(hipStream_t s, LduGeo g, const double* pdiag, const double* pcoef, const double* b, const double* x, const double* xsum, double inv_n, double* r, double* partials);
+int launch_ldu_p_apply_dot(hipStream_t s, LduGeo g, const double* pdiag, const double* pcoef, const double* r, double* u, double* w, double* partials);
+int launch_ldu_flux_correct(hipStream_t s, LduGeo g, const double* p, const double* phiHbyA, const double* pcoef, const double* pcorr, double* phi);
+// U = HbyA - rAU grad(p) (gradient formed inline) + continuity sums (slot 0 sum |div phi|, slot 1 sum div phi)
+int launch_ldu_U_correct(hipStream_t s, LduGeo g, const double* HbyA, const double* rAU, const double* p, const double* phi, double* U, double* partials);
+int launch_ldu_sum(hipStream_t s, const double* x, int n, int ncomp, double* partials);                  // slot q = sum of component q
+// mesh.findCell stand-in for the point-force locate: from the nearest centre (hint[i], or -1: not located) walk across the face the point lies
+// furthest outside of until it lies inside every face of a cell; cell_out[i] = that cell or -1 (outside the mesh)
+int launch_ldu_find_cell(hipStream_t s, LduGeo g, const double* rec, int rec_len, int64_t n, const int32_t* hint, int32_t* cell_out);
+int launch_ldu_positions(hipStream_t s, const double* rec, int rec_len, int64_t n, double* pos3);      // pos3[i] = rec[i][0..2]
+
+}  // namespace fy

@@ -1,0 +1,538 @@
+// HIP kernels of fy_ldu_solver (ldu.hpp): icoFoamYade's operators (icoFoamYade.C:65-149) on a general polyhedral mesh with owner / neighbour
+// addressing.  Two shapes only: one lane per FACE (coefficients, fluxes) and one lane per CELL gathering over the cell's faces through the
+// cell -> face lists (sums, gradients, matrix rows) -- no scatter, hence no atomics, and every sum has a fixed order.  FP64, bandwidth / latency
+// bound like the structured kernels (no MFMA: nothing here is a dense contraction); the indirection through own / nei / cf_face costs what a
+// general mesh costs.  The arithmetic is OpenFOAM-6's, restated [OF-6]; oracle/ldu_oracle.cpp is the CPU restatement the tests compare with.
+#include <hip/hip_runtime.h>
+
+#include "fv_kernels.hpp"
+#include "ldu.hpp"
+
+namespace fy {
+namespace {
+
+struct D3 { double x, y, z; };
+__device__ __forceinline__ D3 ld3(const double* p, int q) { return D3{p[3 * (size_t)q], p[3 * (size_t)q + 1], p[3 * (size_t)q + 2]}; }
+__device__ __forceinline__ void st3(double* p, int q, D3 a) { p[3 * (size_t)q] = a.x; p[3 * (size_t)q + 1] = a.y; p[3 * (size_t)q + 2] = a.z; }
+__device__ __forceinline__ double dot3(D3 a, D3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+__device__ __forceinline__ D3 lerp3(double w, D3 a, D3 b) { return D3{w * a.x + (1.0 - w) * b.x, w * a.y + (1.0 - w) * b.y, w * a.z + (1.0 - w) * b.z}; }
+
+// boundary value of a velocity-like field on boundary face f: the patch's value (fixedValue) or the cell's (zeroGradient)
+__device__ __forceinline__ D3 Ub(const LduGeo& g, const double* F, int f) {
+    const int pa = g.patch_of[f - g.nInt];
+    if (g.u_bc[pa] == FY_BC_U_FIXED_VALUE) return ld3(g.u_val, pa);
+    return ld3(F, g.own[f]);
+}
+__device__ __forceinline__ double pbv(const LduGeo& g, const double* p, int f) {
+    const int pa = g.patch_of[f - g.nInt];
+    return g.p_bc[pa] == FY_BC_P_FIXED_VALUE ? g.p_val[pa] : p[g.own[f]];
+}
+
+template <int N>
+__device__ __forceinline__ void block_reduce_store(double (&v)[N], const int (&is_max)[N], double* partials) {
+    __shared__ double sh[4][N];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+        double x = v[q];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double y = __shfl_down(x, o, 64);
+            x = is_max[q] ? fmax(x, y) : x + y;
+        }
+        if (lane == 0) sh[wv][q] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x < N) {
+        const int q = threadIdx.x;
+        double x = sh[0][q];
+        for (int w = 1; w < 4; ++w) x = is_max[q] ? fmax(x, sh[w][q]) : x + sh[w][q];
+        partials[(size_t)q * gridDim.x + blockIdx.x] = x;
+    }
+}
+
+// fvc::flux(F) = linearInterpolate(F) & Sf (createPhi; boundary: the patch value)
+__global__ __launch_bounds__(256) void k_ldu_flux_of(LduGeo g, const double* __restrict__ F, double* __restrict__ phi) {
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= g.nFaces) return;
+    const D3 uf = f < g.nInt ? lerp3(g.w[f], ld3(F, g.own[f]), ld3(F, g.nei[f])) : Ub(g, F, f);
+    phi[f] = dot3(uf, ld3(g.Sf, f));
+}
+
+// CourantNo.H [OF-6] (icoFoamYade.C:68): sumPhi = fvc::surfaceSum(mag(phi)); slot 0 = max sumPhi / V, slot 1 = sum sumPhi
+__global__ __launch_bounds__(256) void k_ldu_courant(LduGeo g, const double* __restrict__ phi, double* __restrict__ partials) {
+    double v[2] = {0, 0};
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < g.nCells) {
+        double s = 0.0;
+        for (int q = g.cf_off[c]; q < g.cf_off[c + 1]; ++q) s += fabs(phi[g.cf_face[q]]);
+        v[0] = s / g.V[c]; v[1] = s;
+    }
+    const int mx[2] = {1, 0};
+    block_reduce_store<2>(v, mx, partials);
+}
+
+// fvc::grad(F), Gauss linear: T[3 i + j] = (1/V) sum_f (+-Sf_i) F_f,j
+__global__ __launch_bounds__(256) void k_ldu_grad_vec(LduGeo g, const double* __restrict__ F, double* __restrict__ T) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= g.nCells) return;
+    double t[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int q = g.cf_off[c]; q < g.cf_off[c + 1]; ++q) {
+        const int f = g.cf_face[q];
+        D3 uf; double sg = 1.0;
+        if (f < g.nInt) { uf = lerp3(g.w[f], ld3(F, g.own[f]), ld3(F, g.nei[f])); sg = g.own[f] == c ? 1.0 : -1.0; }
+        else uf = Ub(g, F, f);
+        const D3 S = ld3(g.Sf, f);
+        const double s[3] = {sg * S.x, sg * S.y, sg * S.z}, u[3] = {uf.x, uf.y, uf.z};
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) t[3 * i + j] += s[i] * u[j];
+    }
+    const double rV = 1.0 / g.V[c];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) T[9 * (size_t)c + e] = t[e] * rV;
+}
+
+__device__ __forceinline__ D3 grad_scalar_at(const LduGeo& g, const double* __restrict__ p, int c) {
+    D3 a{0, 0, 0};
+    for (int q = g.cf_off[c]; q < g.cf_off[c + 1]; ++q) {
+        const int f = g.cf_face[q];
+        double pf, sg = 1.0;
+        if (f < g.nInt) { pf = g.w[f] * p[g.own[f]] + (1.0 - g.w[f]) * p[g.nei[f]]; sg = g.own[f] == c ? 1.0 : -1.0; }
+        else pf = pbv(g, p, f);
+        const D3 S = ld3(g.Sf, f);
+        a.x += sg * S.x * pf; a.y += sg * S.y * pf; a.z += sg * S.z * pf;
+    }
+    const double rV = 1.0 / g.V[c];
+    return D3{a.x * rV, a.y * rV, a.z * rV};
+}
+__global__ __launch_bounds__(256) void k_ldu_grad_scalar(LduGeo g, const double* __restrict__ p, double* __restrict__ gp) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < g.nCells) st3(gp, c, grad_scalar_at(g, p, c));
+}
+
+// UEqn, face part: gaussConvectionScheme<linear>::fvmDiv (lower = -w phi, upper = lower + phi) minus gaussLaplacianScheme::fvmLaplacianUncorrected
+// (gamma |Sf| nonOrthDeltaCoeffs on both), and the corrected scheme's explicit flux nu |Sf| (k & linearInterpolate(grad U)) per internal face
+__global__ __launch_bounds__(256) void k_ldu_mom_faces(LduGeo g, const double* __restrict__ phi, const double* __restrict__ gradU, LduMom M, double* __restrict__ corr) {
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= g.nInt) return;
+    const double gm = g.nu * g.magSf[f];
+    double lo = -g.w[f] * phi[f];
+    double up = lo + phi[f];
+    lo -= gm * g.dcNO[f]; up -= gm * g.dcNO[f];
+    M.lower[f] = lo; M.upper[f] = up;
+    const D3 k = ld3(g.kvec, f);
+    const double kk[3] = {k.x, k.y, k.z};
+    const double* To = gradU + 9 * (size_t)g.own[f];
+    const double* Tn = gradU + 9 * (size_t)g.nei[f];
+    const double w = g.w[f];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        double cj = 0.0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) cj += kk[i] * (w * To[3 * i + j] + (1.0 - w) * Tn[3 * i + j]);
+        corr[3 * (size_t)f + j] = gm * cj;
+    }
+}
+// ... cell part: EulerDdtScheme::fvmDdt, negSumDiag, the patches' coefficients (fixedValue: value* 0 / U_b, gradient* -+ deltaCoeffs; zeroGradient: value* 1),
+// == uSource, and the divergence of the explicit flux on the right-hand side
+__global__ __launch_bounds__(256) void k_ldu_mom_cells(LduGeo g, const double* __restrict__ phi, const double* __restrict__ Uold, const double* __restrict__ uSource, LduMom M,
+                                                       const double* __restrict__ corr) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= g.nCells) return;
+    const double Vc = g.V[c], rdt = Vc / g.dt;
+    double dg = rdt;
+    const D3 uo = ld3(Uold, c), us = ld3(uSource, c);
+    double b[3] = {rdt * uo.x + Vc * us.x, rdt * uo.y + Vc * us.y, rdt * uo.z + Vc * us.z};
+    for (int q = g.cf_off[c]; q < g.cf_off[c + 1]; ++q) {
+        const int f = g.cf_face[q];
+        if (f < g.nInt) {
+            const D3 cr = ld3(corr, f);
+            if (g.own[f] == c) { dg -= M.lower[f]; b[0] += cr.x; b[1] += cr.y; b[2] += cr.z; }
+            else { dg -= M.upper[f]; b[0] -= cr.x; b[1] -= cr.y; b[2] -= cr.z; }
+        } else {
+            const int pa = g.patch_of[f - g.nInt];
+            if (g.u_bc[pa] == FY_BC_U_FIXED_VALUE) {
+                const double gm = g.nu * g.magSf[f] * g.dcNO[f];
+                const D3 ub = ld3(g.u_val, pa);
+                dg += gm;
+                b[0] += (-phi[f] + gm) * ub.x; b[1] += (-phi[f] + gm) * ub.y; b[2] += (-phi[f] + gm) * ub.z;
+            } else {
+                dg += phi[f];
+            }
+        }
+    }
+    M.diag[c] = dg;
+    st3(M.b, c, D3{b[0], b[1], b[2]});
+}
+
+// row of the momentum matrix applied to x without its diagonal: sum offdiag x_nb; also the row's off-diagonal sum (for A xbar)
+__device__ __forceinline__ void mom_offdiag(const LduGeo& g, const LduMom& M, const double* __restrict__ x, int c, double (&s)[3], double* offsum) {
+    s[0] = s[1] = s[2] = 0.0;
+    double os = 0.0;
+    for (int q = g.cf_off[c]; q < g.cf_off[c + 1]; ++q) {
+        const int f = g.cf_face[q];
+        if (f >= g.nInt) continue;
+        const bool o = g.own[f] == c;
+        const double a = o ? M.upper[f] : M.lower[f];
+        const D3 xn = ld3(x, o ? g.nei[f] : g.own[f]);
+        s[0] += a * xn.x; s[1] += a * xn.y; s[2] += a * xn.z;
+        os += a;
+    }
+    if (offsum) *offsum = os;
+}
+// the momentum predictor's Jacobi pass (solve(UEqn == -fvc::grad(p)), icoFoamYade.C:91-94): residual sums of x and the next iterate in one pass
+__global__ __launch_bounds__(256) void k_ldu_mom_pass(LduGeo g, LduMom M, const double* __restrict__ gradp, const double* __restrict__ x, double* __restrict__ xn,
+                                                      const double* __restrict__ xsum3, double* __restrict__ partials) {
+    double v[6] = {0, 0, 0, 0, 0, 0};
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < g.nCells) {
+        double s[3], os;
+        mom_offdiag(g, M, x, c, s, &os);
+        const double dg = M.diag[c], Vc = g.V[c];
+        const D3 b0 = ld3(M.b, c), gp = ld3(gradp, c), xc = ld3(x, c);
+        const double b[3] = {b0.x - Vc * gp.x, b0.y - Vc * gp.y, b0.z - Vc * gp.z}, xx[3] = {xc.x, xc.y, xc.z};
+        double o[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const double Ax = dg * xx[q] + s[q];
+            const double Aref = (dg + os) * (xsum3[q] / (double)g.nCells);
+            v[q] = fabs(b[q] - Ax);
+            v[3 + q] = fabs(Ax - Aref) + fabs(b[q] - Aref);
+            o[q] = (b[q] - s[q]) / dg;
+        }
+        st3(xn, c, D3{o[0], o[1], o[2]});
+    }
+    const int mx[6] = {0, 0, 0, 0, 0, 0};
+    block_reduce_store<6>(v, mx, partials);
+}
+
+// rAU = 1 / A, HbyA = rAU H (icoFoamYade.C:99-100; constrainHbyA acts on the boundary values, formed where they are used)
+__global__ __launch_bounds__(256) void k_ldu_HbyA(LduGeo g, LduMom M, const double* __restrict__ U, double* __restrict__ rAU, double* __restrict__ HbyA) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= g.nCells) return;
+    double s[3];
+    mom_offdiag(g, M, U, c, s, nullptr);
+    const double Vc = g.V[c];
+    const double r = 1.0 / (M.diag[c] / Vc);
+    const D3 b = ld3(M.b, c);
+    rAU[c] = r;
+    st3(HbyA, c, D3{r * ((b.x - s[0]) / Vc), r * ((b.y - s[1]) / Vc), r * ((b.z - s[2]) / Vc)});
+}
+
+// phiHbyA = fvc::flux(HbyA) + fvc::interpolate(rAU) fvc::ddtCorr(U, phi) (icoFoamYade.C:101-106) [OF-6 EulerDdtScheme::fvcDdtPhiCorr / fvcDdtPhiCoeff]
+__global__ __launch_bounds__(256) void k_ldu_phiHbyA(LduGeo g, const double* __restrict__ HbyA, const double* __restrict__ rAU, const double* __restrict__ Uold,
+                                                     const double* __restrict__ phiOld, double* __restrict__ rAUf, double* __restrict__ phiHbyA) {
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= g.nFaces) return;
+    const D3 S = ld3(g.Sf, f);
+    double rf, fl, uf;
+    bool fixes = false;
+    if (f < g.nInt) {
+        const int o = g.own[f], n = g.nei[f];
+        const double w = g.w[f];
+        rf = w * rAU[o] + (1.0 - w) * rAU[n];
+        fl = dot3(lerp3(w, ld3(HbyA, o), ld3(HbyA, n)), S);
+        uf = dot3(lerp3(w, ld3(Uold, o), ld3(Uold, n)), S);
+    } else {
+        const int pa = g.patch_of[f - g.nInt];
+        fixes = g.u_bc[pa] == FY_BC_U_FIXED_VALUE;
+        rf = rAU[g.own[f]];
+        fl = dot3(fixes ? ld3(g.u_val, pa) : ld3(HbyA, g.own[f]), S);       // constrainHbyA
+        uf = dot3(Ub(g, Uold, f), S);
+    }
+    const double phiCorr = phiOld[f] - uf;
+    const double coef = fixes ? 0.0 : 1.0 - fmin(fabs(phiCorr) / (fabs(phiOld[f]) + 1e-15), 1.0);
+    rAUf[f] = rf;
+    phiHbyA[f] = fl + rf * (coef * (1.0 / g.dt) * phiCorr);
+}
+
+// adjustPhi [OF-6 adjustPhi.C] (icoFoamYade.C:108), only when no patch fixes the pressure: one workgroup sums, the boundary faces are scaled
+__global__ __launch_bounds__(1024) void k_ldu_adjust_sums(LduGeo g, const double* __restrict__ phiHbyA, double* __restrict__ sums) {
+    __shared__ double sh[4][16];
+    double v[4] = {0, 0, 0, 0};              // massIn, fixedMassOut, adjustableMassOut, sum |internal flux|
+    for (int f = threadIdx.x; f < g.nFaces; f += 1024) {
+        const double fl = phiHbyA[f];
+        if (f < g.nInt) v[3] += fabs(fl);
+        else if (fl < 0.0) v[0] -= fl;
+        else if (g.u_bc[g.patch_of[f - g.nInt]] == FY_BC_U_FIXED_VALUE) v[1] += fl;
+        else v[2] += fl;
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int q = 0; q < 4; ++q) {
+        double x = v[q];
+        for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o, 64);
+        if (lane == 0) sh[q][wv] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) { double x = 0; for (int w = 0; w < 16; ++w) x += sh[threadIdx.x][w]; sums[threadIdx.x] = x; }
+}
+__global__ __launch_bounds__(256) void k_ldu_adjust_apply(LduGeo g, const double* __restrict__ sums, double* __restrict__ phiHbyA, int* __restrict__ err) {
+    const int f = g.nInt + blockIdx.x * 256 + threadIdx.x;
+    const double massIn = sums[0], fixedOut = sums[1], adjOut = sums[2], total = sums[3] + 1e-300;
+    double massCorr = 1.0;
+    if (fabs(adjOut) > 1e-300 && fabs(adjOut) / total > 1e-15) massCorr = (massIn - fixedOut) / adjOut;
+    else if (fabs(fixedOut - massIn) / total > 1e-8) { if (f == g.nInt) *err = 1; }
+    if (f >= g.nFaces || massCorr == 1.0) return;
+    if (g.u_bc[g.patch_of[f - g.nInt]] != FY_BC_U_FIXED_VALUE && phiHbyA[f] > 0.0) phiHbyA[f] *= massCorr;
+}
+
+// pEqn, face part (icoFoamYade.C:118-121): c_f = rAUf |Sf| nonOrthDeltaCoeffs, and the corrected scheme's explicit flux rAUf |Sf| (k & interpolate(grad p))
+// from the pressure as it stands -- what each pass of the correctNonOrthogonal loop (icoFoamYade.C:114-131) renews
+__global__ __launch_bounds__(256) void k_ldu_p_faces(LduGeo g, const double* __restrict__ rAUf, const double* __restrict__ gradp, double* __restrict__ pcoef, double* __restrict__ pcorr) {
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= g.nFaces) return;
+    const double gm = rAUf[f] * g.magSf[f];
+    pcoef[f] = gm * g.dcNO[f];
+    if (f < g.nInt) pcorr[f] = gm * dot3(ld3(g.kvec, f), lerp3(g.w[f], ld3(gradp, g.own[f]), ld3(gradp, g.nei[f])));
+}
+// ... cell part, in the positive form  sum_f c_f (p_P - p_N) + sum_b c_b (p_P - p_b) = -div(phiHbyA) + div(explicit flux);  fvMatrix::setReference
+__global__ __launch_bounds__(256) void k_ldu_p_cells(LduGeo g, const double* __restrict__ phiHbyA, const double* __restrict__ pcoef, const double* __restrict__ pcorr,
+                                                     double* __restrict__ pdiag, double* __restrict__ prhs) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= g.nCells) return;
+    double dg = 0.0, b = 0.0;
+    for (int q = g.cf_off[c]; q < g.cf_off[c + 1]; ++q) {
+        const int f = g.cf_face[q];
+        if (f < g.nInt) {
+            dg += pcoef[f];
+            const double t = -phiHbyA[f] + pcorr[f];
+            b += g.own[f] == c ? t : -t;
+        } else {
+            const int pa = g.patch_of[f - g.nInt];
+            b -= phiHbyA[f];
+            if (g.p_bc[pa] == FY_BC_P_FIXED_VALUE) { dg += pcoef[f]; b += pcoef[f] * g.p_val[pa]; }
+        }
+    }
+    if (g.need_ref && c == g.p_ref_cell) { b += dg * g.p_ref_value; dg += dg; }
+    pdiag[c] = dg; prhs[c] = b;
+}
+
+__device__ __forceinline__ double p_offdiag(const LduGeo& g, const double* __restrict__ pcoef, const double* __restrict__ x, int c, double* coefsum) {
+    double s = 0.0, cs = 0.0;
+    for (int q = g.cf_off[c]; q < g.cf_off[c + 1]; ++q) {
+        const int f = g.cf_face[q];
+        if (f >= g.nInt) continue;
+        const double a = pcoef[f];
+        s += a * x[g.own[f] == c ? g.nei[f] : g.own[f]];
+        cs += a;
+    }
+    if (coefsum) *coefsum = cs;
+    return s;
+}
+// r = b - A x; slot 0 = sum |r|, slot 1 = sum (|A x - A xbar| + |b - A xbar|)  [OF-6 lduMatrix::solver::normFactor]
+__global__ __launch_bounds__(256) void k_ldu_p_init(LduGeo g, const double* __restrict__ pdiag, const double* __restrict__ pcoef, const double* __restrict__ b,
+                                                    const double* __restrict__ x, const double* __restrict__ xsum, double inv_n, double* __restrict__ r, double* __restrict__ partials) {
+    double v[2] = {0, 0};
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < g.nCells) {
+        double cs;
+        const double off = p_offdiag(g, pcoef, x, c, &cs);
+        const double Ax = pdiag[c] * x[c] - off, Aref = (pdiag[c] - cs) * (xsum[0] * inv_n);
+        const double rr = b[c] - Ax;
+        r[c] = rr;
+        v[0] = fabs(rr); v[1] = fabs(Ax - Aref) + fabs(b[c] - Aref);
+    }
+    const int mx[2] = {0, 0};
+    block_reduce_store<2>(v, mx, partials);
+}
+// the diagonal preconditioner and the matrix-vector product of the single-reduction PCG in one gather: u = r / diag (the neighbours' u formed
+// inline from the same operands), w = A u; slot 0 = u.r, slot 1 = u.w
+__global__ __launch_bounds__(256) void k_ldu_p_apply_dot(LduGeo g, const double* __restrict__ pdiag, const double* __restrict__ pcoef, const double* __restrict__ r,
+                                                         double* __restrict__ u, double* __restrict__ w, double* __restrict__ partials) {
+    double v[2] = {0, 0};
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < g.nCells) {
+        const double uc = r[c] / pdiag[c];
+        double s = 0.0;
+        for (int q = g.cf_off[c]; q < g.cf_off[c + 1]; ++q) {
+            const int f = g.cf_face[q];
+            if (f >= g.nInt) continue;
+            const int nb = g.own[f] == c ? g.nei[f] : g.own[f];
+            s += pcoef[f] * (r[nb] / pdiag[nb]);
+        }
+        const double wc = pdiag[c] * uc - s;
+        u[c] = uc; w[c] = wc;
+        v[0] = uc * r[c]; v[1] = uc * wc;
+    }
+    const int mx[2] = {0, 0};
+    block_reduce_store<2>(v, mx, partials);
+}
+
+// phi = phiHbyA - pEqn.flux() (icoFoamYade.C:127-130): the matrix's flux c_f (p_N - p_P) and the explicit non-orthogonal flux it was assembled with
+__global__ __launch_bounds__(256) void k_ldu_flux_correct(LduGeo g, const double* __restrict__ p, const double* __restrict__ phiHbyA, const double* __restrict__ pcoef,
+                                                          const double* __restrict__ pcorr, double* __restrict__ phi) {
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= g.nFaces) return;
+    if (f < g.nInt) phi[f] = phiHbyA[f] - (pcoef[f] * (p[g.nei[f]] - p[g.own[f]]) + pcorr[f]);
+    else {
+        const int pa = g.patch_of[f - g.nInt];
+        phi[f] = phiHbyA[f] - (g.p_bc[pa] == FY_BC_P_FIXED_VALUE ? pcoef[f] * (g.p_val[pa] - p[g.own[f]]) : 0.0);
+    }
+}
+
+// U = HbyA - rAU fvc::grad(p) (icoFoamYade.C:136-137) and continuityErrs.H (:134): slot 0 = sum |div phi|, slot 1 = sum div phi
+__global__ __launch_bounds__(256) void k_ldu_U_correct(LduGeo g, const double* __restrict__ HbyA, const double* __restrict__ rAU, const double* __restrict__ p,
+                                                       const double* __restrict__ phi, double* __restrict__ U, double* __restrict__ partials) {
+    double v[2] = {0, 0};
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < g.nCells) {
+        const D3 gp = grad_scalar_at(g, p, c), h = ld3(HbyA, c);
+        const double r = rAU[c];
+        st3(U, c, D3{h.x - r * gp.x, h.y - r * gp.y, h.z - r * gp.z});
+        double dv = 0.0;
+        for (int q = g.cf_off[c]; q < g.cf_off[c + 1]; ++q) {
+            const int f = g.cf_face[q];
+            dv += (f >= g.nInt || g.own[f] == c) ? phi[f] : -phi[f];
+        }
+        v[0] = fabs(dv); v[1] = dv;
+    }
+    const int mx[2] = {0, 0};
+    block_reduce_store<2>(v, mx, partials);
+}
+
+__global__ __launch_bounds__(256) void k_ldu_sum(const double* __restrict__ x, int n, int ncomp, double* __restrict__ partials) {
+    double v[3] = {0, 0, 0};
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < n) for (int q = 0; q < ncomp; ++q) v[q] = x[(size_t)ncomp * c + q];
+    const int mx[3] = {0, 0, 0};
+    block_reduce_store<3>(v, mx, partials);
+}
+
+// mesh.findCell (FoamYade.C:251) on a general mesh of convex cells: from the cell whose centre is nearest, step across the face the point lies
+// furthest outside of until no face has it outside (tolerance 1e-10 of the cell's size); a boundary face on the way = outside the mesh
+__global__ __launch_bounds__(256) void k_ldu_find_cell(LduGeo g, const double* __restrict__ rec, int rec_len, int64_t n, const int32_t* __restrict__ hint, int32_t* __restrict__ cell_out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double* r = rec + (size_t)rec_len * (size_t)i;
+    const D3 x{r[0], r[1], r[2]};
+    int c = hint[i];
+    if (!(x.x == x.x) || !(x.y == x.y) || !(x.z == x.z)) c = -1;
+    for (int hop = 0; c >= 0 && hop < 64; ++hop) {
+        double worst = 0.0;
+        int wf = -1;
+        const double tol = 1e-10 * cbrt(g.V[c]);
+        for (int q = g.cf_off[c]; q < g.cf_off[c + 1]; ++q) {
+            const int f = g.cf_face[q];
+            const D3 S = ld3(g.Sf, f), cf = ld3(g.Cf, f);
+            const double sg = (f >= g.nInt || g.own[f] == c) ? 1.0 : -1.0;
+            const double s = sg * dot3(D3{x.x - cf.x, x.y - cf.y, x.z - cf.z}, S) / g.magSf[f];
+            if (s > worst) { worst = s; wf = f; }
+        }
+        if (wf < 0 || worst <= tol) break;
+        c = wf >= g.nInt ? -1 : (g.own[wf] == c ? g.nei[wf] : g.own[wf]);
+        if (hop == 63) c = -1;
+    }
+    cell_out[i] = c;
+}
+
+__global__ __launch_bounds__(256) void k_ldu_positions(const double* __restrict__ rec, int rec_len, int64_t n, double* __restrict__ pos3) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double* r = rec + (size_t)rec_len * (size_t)i;
+    pos3[3 * (size_t)i] = r[0]; pos3[3 * (size_t)i + 1] = r[1]; pos3[3 * (size_t)i + 2] = r[2];
+}
+
+#define FY_LAUNCH_CHECK()                                                                                     \
+    do {                                                                                                      \
+        hipError_t _e = hipGetLastError();                                                                    \
+        if (_e != hipSuccess) return fail(FY_ERR_HIP, "kernel launch failed: %s (%s:%d)", hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+inline int div_up(long long a, int b) { return (int)((a + b - 1) / b); }
+
+}  // namespace
+
+int ldu_red_blocks(int n) { return red_blocks(n); }
+
+int launch_ldu_flux_of(hipStream_t s, LduGeo g, const double* F, double* phi) {
+    hipLaunchKernelGGL(k_ldu_flux_of, dim3(div_up(g.nFaces, 256)), dim3(256), 0, s, g, F, phi);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+int launch_ldu_courant(hipStream_t s, LduGeo g, const double* phi, double* partials) {
+    hipLaunchKernelGGL(k_ldu_courant, dim3(red_blocks(g.nCells)), dim3(256), 0, s, g, phi, partials);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+int launch_ldu_grad_vec(hipStream_t s, LduGeo g, const double* F, double* T) {
+    hipLaunchKernelGGL(k_ldu_grad_vec, dim3(div_up(g.nCells, 256)), dim3(256), 0, s, g, F, T);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+int launch_ldu_grad_scalar(hipStream_t s, LduGeo g, const double* p, double* gp) {
+    hipLaunchKernelGGL(k_ldu_grad_scalar, dim3(div_up(g.nCells, 256)), dim3(256), 0, s, g, p, gp);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+int launch_ldu_assemble_momentum(hipStream_t s, LduGeo g, const double* phi, const double* Uold, const double* uSource, const double* gradU, LduMom M, double* face_corr) {
+    if (g.nInt > 0) hipLaunchKernelGGL(k_ldu_mom_faces, dim3(div_up(g.nInt, 256)), dim3(256), 0, s, g, phi, gradU, M, face_corr);
+    hipLaunchKernelGGL(k_ldu_mom_cells, dim3(div_up(g.nCells, 256)), dim3(256), 0, s, g, phi, Uold, uSource, M, face_corr);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+int launch_ldu_mom_pass(hipStream_t s, LduGeo g, LduMom M, const double* gradp, const double* x, double* xn, const double* xsum3, double* partials) {
+    hipLaunchKernelGGL(k_ldu_mom_pass, dim3(red_blocks(g.nCells)), dim3(256), 0, s, g, M, gradp, x, xn, xsum3, partials);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+int launch_ldu_HbyA(hipStream_t s, LduGeo g, LduMom M, const double* U, double* rAU, double* HbyA) {
+    hipLaunchKernelGGL(k_ldu_HbyA, dim3(div_up(g.nCells, 256)), dim3(256), 0, s, g, M, U, rAU, HbyA);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+int launch_ldu_phiHbyA(hipStream_t s, LduGeo g, const double* HbyA, const double* rAU, const double* Uold, const double* phiOld, double* rAUf, double* phiHbyA) {
+    hipLaunchKernelGGL(k_ldu_phiHbyA, dim3(div_up(g.nFaces, 256)), dim3(256), 0, s, g, HbyA, rAU, Uold, phiOld, rAUf, phiHbyA);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+int launch_ldu_adjust_phi(hipStream_t s, LduGeo g, double* phiHbyA, double* sums4, int* err) {
+    hipLaunchKernelGGL(k_ldu_adjust_sums, dim3(1), dim3(1024), 0, s, g, phiHbyA, sums4);
+    hipLaunchKernelGGL(k_ldu_adjust_apply, dim3(div_up(g.nFaces - g.nInt, 256)), dim3(256), 0, s, g, sums4, phiHbyA, err);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+int launch_ldu_assemble_pressure(hipStream_t s, LduGeo g, const double* rAUf, const double* phiHbyA, const double* gradp, double* pcoef, double* pcorr, double* pdiag, double* prhs) {
+    hipLaunchKernelGGL(k_ldu_p_faces, dim3(div_up(g.nFaces, 256)), dim3(256), 0, s, g, rAUf, gradp, pcoef, pcorr);
+    hipLaunchKernelGGL(k_ldu_p_cells, dim3(div_up(g.nCells, 256)), dim3(256), 0, s, g, phiHbyA, pcoef, pcorr, pdiag, prhs);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+int launch_ldu_p_init(hipStream_t s, LduGeo g, const double* pdiag, const double* pcoef, const double* b, const double* x, const double* xsum, double inv_n, double* r, double* partials) {
+    hipLaunchKernelGGL(k_ldu_p_init, dim3(red_blocks(g.nCells)), dim3(256), 0, s, g, pdiag, pcoef, b, x, xsum, inv_n, r, partials);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+int launch_ldu_p_apply_dot(hipStream_t s, LduGeo g, const double* pdiag, const double* pcoef, const double* r, double* u, double* w, double* partials) {
+    hipLaunchKernelGGL(k_ldu_p_apply_dot, dim3(red_blocks(g.nCells)), dim3(256), 0, s, g, pdiag, pcoef, r, u, w, partials);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+int launch_ldu_flux_correct(hipStream_t s, LduGeo g, const double* p, const double* phiHbyA, const double* pcoef, const double* pcorr, double* phi) {
+    hipLaunchKernelGGL(k_ldu_flux_correct, dim3(div_up(g.nFaces, 256)), dim3(256), 0, s, g, p, phiHbyA, pcoef, pcorr, phi);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+int launch_ldu_U_correct(hipStream_t s, LduGeo g, const double* HbyA, const double* rAU, const double* p, const double* phi, double* U, double* partials) {
+    hipLaunchKernelGGL(k_ldu_U_correct, dim3(red_blocks(g.nCells)), dim3(256), 0, s, g, HbyA, rAU, p, phi, U, partials);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+int launch_ldu_sum(hipStream_t s, const double* x, int n, int ncomp, double* partials) {
+    if (ncomp < 1 || ncomp > 3) return fail(FY_ERR_INVALID, "launch_ldu_sum: 1 .. 3 components");
+    hipLaunchKernelGGL(k_ldu_sum, dim3(red_blocks(n)), dim3(256), 0, s, x, n, ncomp, partials);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+int launch_ldu_positions(hipStream_t s, const double* rec, int rec_len, int64_t n, double* pos3) {
+    if (n > 0) hipLaunchKernelGGL(k_ldu_positions, dim3(div_up(n, 256)), dim3(256), 0, s, rec, rec_len, n, pos3);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+int launch_ldu_find_cell(hipStream_t s, LduGeo g, const double* rec, int rec_len, int64_t n, const int32_t* hint, int32_t* cell_out) {
+    if (n > 0) hipLaunchKernelGGL(k_ldu_find_cell, dim3(div_up(n, 256)), dim3(256), 0, s, g, rec, rec_len, n, hint, cell_out);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+
+}  // namespace fy

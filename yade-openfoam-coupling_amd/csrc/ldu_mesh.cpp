@@ -1,0 +1,128 @@
+// Host side of fy_ldu_solver: OpenFOAM's mesh geometry from constant/polyMesh's arrays (what createMesh.H builds before icoFoamYade.C:42 hands
+// the mesh to everything else) [OF-6, restated: primitiveMeshFaceCentresAndAreas.C, primitiveMeshCellCentresAndVols.C, surfaceInterpolation.C]:
+//   face centre / area vector   triangle decomposition about the face's point average (a triangle: its own centroid and half cross product)
+//   cell centre / volume        pyramid decomposition about the average of the cell's face centres
+//   linear weights              w = |Sf.(C_N - Cf)| / (|Sf.(Cf - C_P)| + |Sf.(C_N - Cf)|)
+//   nonOrthDeltaCoeffs          1 / max(n.d, 0.05 |d|), d = C_N - C_P; boundary faces: 1 / (n.(Cf - C_P))
+//   nonOrthCorrectionVectors    n - d nonOrthDeltaCoeffs (internal faces; none on non-coupled boundary faces)
+#include <algorithm>
+#include <cmath>
+
+#include "ldu.hpp"
+
+namespace fy {
+
+namespace {
+struct V3 { double x, y, z; };
+inline V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline V3 operator*(double s, V3 a) { return {s * a.x, s * a.y, s * a.z}; }
+inline double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+inline double mag(V3 a) { return std::sqrt(dot(a, a)); }
+inline V3 at(const double* p, int q) { return {p[3 * (size_t)q], p[3 * (size_t)q + 1], p[3 * (size_t)q + 2]}; }
+inline void put(std::vector<double>& v, int q, V3 a) { v[3 * (size_t)q] = a.x; v[3 * (size_t)q + 1] = a.y; v[3 * (size_t)q + 2] = a.z; }
+const double VSMALL = 1e-300;
+}  // namespace
+
+int LduHostMesh::build(const fy_poly_mesh* m) {
+    if (!m || m->n_points < 4 || m->n_faces < 4 || m->n_cells < 1 || m->n_internal_faces < 0 || m->n_internal_faces > m->n_faces || !m->points || !m->face_offsets ||
+        !m->face_points || !m->owner || (m->n_internal_faces > 0 && !m->neighbour) || m->n_patches < 1 || !m->patch_start || !m->patch_size)
+        return fail(FY_ERR_INVALID, "fy_poly_mesh: missing arrays or empty mesh");
+    nPoints = m->n_points; nFaces = m->n_faces; nInt = m->n_internal_faces; nCells = m->n_cells; nPatches = m->n_patches;
+    own.assign(m->owner, m->owner + nFaces);
+    nei.assign(m->neighbour, m->neighbour + nInt);
+    for (int f = 0; f < nFaces; ++f) {
+        if (own[f] < 0 || own[f] >= nCells) return fail(FY_ERR_INVALID, "fy_poly_mesh: owner of face %d out of range", f);
+        if (f < nInt && (nei[f] <= own[f] || nei[f] >= nCells)) return fail(FY_ERR_INVALID, "fy_poly_mesh: internal face %d needs owner < neighbour < n_cells", f);
+        const int n = m->face_offsets[f + 1] - m->face_offsets[f];
+        if (n < 3) return fail(FY_ERR_INVALID, "fy_poly_mesh: face %d has fewer than three points", f);
+        for (int a = 0; a < n; ++a) { const int q = m->face_points[m->face_offsets[f] + a]; if (q < 0 || q >= nPoints) return fail(FY_ERR_INVALID, "fy_poly_mesh: face %d names point %d", f, q); }
+    }
+    patch_of.assign((size_t)(nFaces - nInt), -1);
+    for (int pa = 0; pa < nPatches; ++pa)
+        for (int q = 0; q < m->patch_size[pa]; ++q) {
+            const int f = m->patch_start[pa] + q;
+            if (f < nInt || f >= nFaces || patch_of[(size_t)(f - nInt)] >= 0) return fail(FY_ERR_INVALID, "fy_poly_mesh: patch %d does not hold boundary faces of its own", pa);
+            patch_of[(size_t)(f - nInt)] = pa;
+        }
+    for (int32_t v : patch_of) if (v < 0) return fail(FY_ERR_INVALID, "fy_poly_mesh: a boundary face belongs to no patch");
+    // ---- faces
+    Cf.assign(3 * (size_t)nFaces, 0.0); Sf = Cf; magSf.assign((size_t)nFaces, 0.0);
+    for (int f = 0; f < nFaces; ++f) {
+        const int n = m->face_offsets[f + 1] - m->face_offsets[f];
+        const int32_t* q = m->face_points + m->face_offsets[f];
+        V3 c, S;
+        if (n == 3) {
+            c = (1.0 / 3.0) * (at(m->points, q[0]) + at(m->points, q[1]) + at(m->points, q[2]));
+            S = 0.5 * cross(at(m->points, q[1]) - at(m->points, q[0]), at(m->points, q[2]) - at(m->points, q[0]));
+        } else {
+            V3 fc{0, 0, 0};
+            for (int a = 0; a < n; ++a) fc = fc + at(m->points, q[a]);
+            fc = (1.0 / n) * fc;
+            V3 sumN{0, 0, 0}, sumAc{0, 0, 0};
+            double sumA = 0.0;
+            for (int a = 0; a < n; ++a) {
+                const V3 p0 = at(m->points, q[a]), p1 = at(m->points, q[(a + 1) % n]);
+                const V3 nn = cross(p1 - p0, fc - p0);
+                const double aa = mag(nn);
+                sumN = sumN + nn; sumA += aa; sumAc = sumAc + aa * (p0 + p1 + fc);
+            }
+            c = sumA < VSMALL ? fc : (1.0 / 3.0) * ((1.0 / sumA) * sumAc);
+            S = 0.5 * sumN;
+        }
+        put(Cf, f, c); put(Sf, f, S); magSf[(size_t)f] = mag(S);
+        if (!(magSf[(size_t)f] > 0)) return fail(FY_ERR_INVALID, "fy_poly_mesh: face %d has no area", f);
+    }
+    // ---- cell -> faces
+    cf_off.assign((size_t)nCells + 1, 0);
+    for (int f = 0; f < nFaces; ++f) { ++cf_off[(size_t)own[f] + 1]; if (f < nInt) ++cf_off[(size_t)nei[f] + 1]; }
+    for (int c = 0; c < nCells; ++c) { if (cf_off[(size_t)c + 1] < 4) return fail(FY_ERR_INVALID, "fy_poly_mesh: cell %d has fewer than four faces", c); cf_off[(size_t)c + 1] += cf_off[(size_t)c]; }
+    cf_face.assign((size_t)cf_off[(size_t)nCells], 0);
+    {
+        std::vector<int32_t> fill(cf_off.begin(), cf_off.end() - 1);
+        for (int f = 0; f < nFaces; ++f) { cf_face[(size_t)fill[(size_t)own[f]]++] = f; if (f < nInt) cf_face[(size_t)fill[(size_t)nei[f]]++] = f; }
+    }
+    // ---- cells
+    std::vector<double> cEst(3 * (size_t)nCells, 0.0);
+    for (int c = 0; c < nCells; ++c) {
+        V3 e{0, 0, 0};
+        for (int32_t q = cf_off[(size_t)c]; q < cf_off[(size_t)c + 1]; ++q) e = e + at(Cf.data(), cf_face[(size_t)q]);
+        put(cEst, c, (1.0 / (cf_off[(size_t)c + 1] - cf_off[(size_t)c])) * e);
+    }
+    C.assign(3 * (size_t)nCells, 0.0); V.assign((size_t)nCells, 0.0);
+    auto pyramid = [&](int c, int f, double sgn) {
+        const V3 fc = at(Cf.data(), f), ce = at(cEst.data(), c);
+        const double pyr3 = std::max(sgn * dot(at(Sf.data(), f), fc - ce), VSMALL);
+        const V3 pc = 0.75 * fc + 0.25 * ce;
+        put(C, c, at(C.data(), c) + pyr3 * pc);
+        V[(size_t)c] += pyr3;
+    };
+    for (int f = 0; f < nFaces; ++f) { pyramid(own[f], f, 1.0); if (f < nInt) pyramid(nei[f], f, -1.0); }
+    for (int a = 0; a < 3; ++a) { bbox_min[a] = 1e300; bbox_max[a] = -1e300; }
+    for (int q = 0; q < nPoints; ++q) for (int a = 0; a < 3; ++a) { bbox_min[a] = std::min(bbox_min[a], m->points[3 * (size_t)q + a]); bbox_max[a] = std::max(bbox_max[a], m->points[3 * (size_t)q + a]); }
+    for (int c = 0; c < nCells; ++c) {
+        if (!(V[(size_t)c] > 0)) return fail(FY_ERR_INVALID, "fy_poly_mesh: cell %d has no volume (are the faces' points ordered outwards of their owners?)", c);
+        put(C, c, (1.0 / V[(size_t)c]) * at(C.data(), c));
+        V[(size_t)c] *= (1.0 / 3.0);
+    }
+    // ---- interpolation / gradient coefficients
+    w.assign((size_t)nInt, 0.5); dcNO.assign((size_t)nFaces, 0.0); kvec.assign(3 * (size_t)nInt, 0.0);
+    for (int f = 0; f < nInt; ++f) {
+        const V3 S = at(Sf.data(), f), cf = at(Cf.data(), f), cp = at(C.data(), own[f]), cn = at(C.data(), nei[f]);
+        const double sOwn = std::fabs(dot(S, cf - cp)), sNei = std::fabs(dot(S, cn - cf));
+        w[(size_t)f] = sNei / (sOwn + sNei);
+        const V3 d = cn - cp, n = (1.0 / magSf[(size_t)f]) * S;
+        dcNO[(size_t)f] = 1.0 / std::max(dot(n, d), 0.05 * mag(d));
+        put(kvec, f, n - dcNO[(size_t)f] * d);
+    }
+    for (int f = nInt; f < nFaces; ++f) {
+        const V3 n = (1.0 / magSf[(size_t)f]) * at(Sf.data(), f);
+        const double nd = dot(n, at(Cf.data(), f) - at(C.data(), own[f]));
+        if (!(nd > 0)) return fail(FY_ERR_INVALID, "fy_poly_mesh: boundary face %d does not point out of its cell", f);
+        dcNO[(size_t)f] = 1.0 / nd;
+    }
+    return FY_OK;
+}
+
+}  // namespace fy

@@ -1,0 +1,317 @@
+// fy_ldu_solver: the time-loop body of icoFoamYade (icoFoamYade/icoFoamYade.C:65-149) on a general polyhedral mesh (ldu.hpp), sequencing the
+// kernels of ldu_kernels.hip, with the coupling engine (fy_ctx, point force) sharing the device fields and the stream.  Control flow follows the
+// reference line by line; the pressure solver is PCG.C's loop [OF-6] in the single-reduction form of fv_pressure.cpp with the diagonal
+// preconditioner, the momentum predictor Jacobi sweeps with lduMatrix::solver's residual control (the stand-in for smoothSolver, as in fv_solver.cpp).
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "coupling.hpp"
+#include "fv_kernels.hpp"
+#include "ldu.hpp"
+
+namespace fy {
+
+struct LduSolver {
+    LduHostMesh hm;
+    fy_ldu_case cs{};
+    LduGeo g{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    fy_ctx* cpl = nullptr;
+    int nc = 0, nf = 0, ni = 0;
+    // geometry + addressing on the device
+    DevBuf<int32_t> d_own, d_nei, d_patch_of, d_cf_off, d_cf_face, d_ubc, d_pbc;
+    DevBuf<double> d_Cf, d_Sf, d_magSf, d_C, d_V, d_w, d_dcNO, d_kvec, d_uval, d_pval;
+    // fields
+    DevBuf<double> U, Uold, p, phi, phiOld, uSource, uSourceExt, uSourceSum, vGrad, gradp, dummy3, dummy1;
+    DevBuf<double> mdiag, mlower, mupper, mb, fcorr, xscr, rAU, HbyA, rAUf, phiHbyA, pcoef, pcorr, pdiag, prhs, pr, pu, pw, pp, ps;
+    DevBuf<double> partials, sc, xsum, adj;
+    DevBuf<int> adj_err;
+    bool need_ref = true, ext_source = false;
+    fy_step_stats st{};
+    double cumulative = 0.0, total_volume = 0.0;
+    EventTimer tim[2];
+
+    ~LduSolver() {
+        if (cpl) fy_destroy(cpl);
+        for (auto& t : tim) t.destroy();
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+    template <class T> int up(DevBuf<T>& d, const std::vector<T>& h) {
+        FY_TRY(d.alloc_exact(std::max<size_t>(h.size(), 1)));
+        if (!h.empty()) FY_HIP(hipMemcpyAsync(d.p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, stream));
+        return FY_OK;
+    }
+    int zero(DevBuf<double>& b) { if (b.n) FY_HIP(hipMemsetAsync(b.p, 0, b.n * sizeof(double), stream)); return FY_OK; }
+    LduMom M() { return LduMom{mdiag.p, mlower.p, mupper.p, mb.p}; }
+
+    int create(const fy_poly_mesh* m, const fy_ldu_case* c, const fy_transport* tr, int dev) {
+        if (!c || !(c->dt > 0) || !(c->nu >= 0) || !c->u_bc || !c->u_value || !c->p_bc || !c->p_value) return fail(FY_ERR_INVALID, "fy_ldu_solver_create: bad case (dt, nu, the per-patch arrays)");
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(FY_ERR_NO_DEVICE, "no HIP device visible: libfoamyade_hip has no CPU path");
+        if (dev < 0 || dev >= ndev) return fail(FY_ERR_INVALID, "device ordinal out of range");
+        FY_TRY(hm.build(m));
+        cs = *c; device = dev;
+        nc = hm.nCells; nf = hm.nFaces; ni = hm.nInt;
+        std::vector<int32_t> ubc(c->u_bc, c->u_bc + hm.nPatches), pbc(c->p_bc, c->p_bc + hm.nPatches);
+        std::vector<double> uval(c->u_value, c->u_value + 3 * (size_t)hm.nPatches), pval(c->p_value, c->p_value + hm.nPatches);
+        need_ref = true;
+        for (int pa = 0; pa < hm.nPatches; ++pa) {
+            if (ubc[(size_t)pa] != FY_BC_U_FIXED_VALUE && ubc[(size_t)pa] != FY_BC_U_ZERO_GRADIENT) return fail(FY_ERR_UNSUPPORTED, "fy_ldu_solver: velocity patch type %d (fixedValue, zeroGradient)", ubc[(size_t)pa]);
+            if (pbc[(size_t)pa] != FY_BC_P_ZERO_GRADIENT && pbc[(size_t)pa] != FY_BC_P_FIXED_VALUE) return fail(FY_ERR_UNSUPPORTED, "fy_ldu_solver: pressure patch type %d (zeroGradient, fixedValue)", pbc[(size_t)pa]);
+            if (pbc[(size_t)pa] == FY_BC_P_FIXED_VALUE) need_ref = false;
+        }
+        if (need_ref && (c->p_ref_cell < 0 || c->p_ref_cell >= nc)) return fail(FY_ERR_INVALID, "fy_ldu_solver: pRefCell out of range");
+        cs.u_bc = nullptr; cs.u_value = nullptr; cs.p_bc = nullptr; cs.p_value = nullptr;      // (copied; the caller's arrays are not kept)
+        FY_HIP(hipSetDevice(device));
+        FY_HIP(hipStreamCreate(&stream));
+        FY_TRY(up(d_own, hm.own)); FY_TRY(up(d_nei, hm.nei)); FY_TRY(up(d_patch_of, hm.patch_of)); FY_TRY(up(d_cf_off, hm.cf_off)); FY_TRY(up(d_cf_face, hm.cf_face));
+        FY_TRY(up(d_Cf, hm.Cf)); FY_TRY(up(d_Sf, hm.Sf)); FY_TRY(up(d_magSf, hm.magSf)); FY_TRY(up(d_C, hm.C)); FY_TRY(up(d_V, hm.V)); FY_TRY(up(d_w, hm.w));
+        FY_TRY(up(d_dcNO, hm.dcNO)); FY_TRY(up(d_kvec, hm.kvec)); FY_TRY(up(d_ubc, ubc)); FY_TRY(up(d_pbc, pbc)); FY_TRY(up(d_uval, uval)); FY_TRY(up(d_pval, pval));
+        g = LduGeo{nc, nf, ni, hm.nPatches, d_own.p, d_nei.p, d_patch_of.p, d_cf_off.p, d_cf_face.p, d_Cf.p, d_Sf.p, d_magSf.p, d_C.p, d_V.p, d_w.p, d_dcNO.p, d_kvec.p,
+                   d_ubc.p, d_pbc.p, d_uval.p, d_pval.p, cs.dt, cs.nu, need_ref ? 1 : 0, cs.p_ref_cell, cs.p_ref_value};
+        total_volume = 0.0;
+        for (double v : hm.V) total_volume += v;
+        const size_t n = (size_t)nc;
+        DevBuf<double>* v3[] = {&U, &Uold, &uSource, &uSourceExt, &uSourceSum, &gradp, &mb, &xscr, &HbyA, &dummy3};
+        for (auto* b : v3) { FY_TRY(b->alloc_exact(3 * n)); FY_TRY(zero(*b)); }
+        DevBuf<double>* v1[] = {&p, &mdiag, &rAU, &pdiag, &prhs, &pr, &pu, &pw, &pp, &ps, &dummy1};
+        for (auto* b : v1) { FY_TRY(b->alloc_exact(n)); FY_TRY(zero(*b)); }
+        FY_TRY(vGrad.alloc_exact(9 * n)); FY_TRY(zero(vGrad));
+        DevBuf<double>* vf[] = {&phi, &phiOld, &rAUf, &phiHbyA, &pcoef};
+        for (auto* b : vf) { FY_TRY(b->alloc_exact((size_t)nf)); FY_TRY(zero(*b)); }
+        DevBuf<double>* vi[] = {&mlower, &mupper, &pcorr};
+        for (auto* b : vi) { FY_TRY(b->alloc_exact(std::max<size_t>((size_t)ni, 1))); FY_TRY(zero(*b)); }
+        FY_TRY(fcorr.alloc_exact(3 * std::max<size_t>((size_t)ni, 1))); FY_TRY(zero(fcorr));
+        FY_TRY(partials.alloc_exact(8 * (size_t)ldu_red_blocks(std::max(nc, nf)))); FY_TRY(zero(partials));
+        FY_TRY(sc.alloc_exact(8)); FY_TRY(zero(sc)); FY_TRY(xsum.alloc_exact(4)); FY_TRY(zero(xsum)); FY_TRY(adj.alloc_exact(4)); FY_TRY(zero(adj));
+        FY_TRY(adj_err.alloc_exact(1)); FY_HIP(hipMemsetAsync(adj_err.p, 0, sizeof(int), stream));
+        for (auto& t : tim) FY_TRY(t.init());
+        // the coupling object on this mesh (icoFoamYade.C:54: point force): its tree over the cell centres, its fields the solver's device arrays
+        {
+            fy_mesh_desc md{};
+            md.n_cells = nc; md.centres = hm.C.data(); md.volumes = hm.V.data();
+            md.nx = md.ny = md.nz = 0; md.dx = 0.0;
+            for (int a = 0; a < 3; ++a) { md.bbox_min[a] = hm.bbox_min[a]; md.bbox_max[a] = hm.bbox_max[a]; md.origin[a] = hm.bbox_min[a]; }
+            fy_field_ptrs fp{};
+            fp.location = FY_MEM_DEVICE;
+            fp.U = U.p; fp.gradP = dummy3.p; fp.vGrad = vGrad.p; fp.divT = dummy3.p; fp.ddtU = dummy3.p;
+            fp.uSourceDrag = dummy1.p; fp.alpha = dummy1.p; fp.uSource = uSource.p; fp.uParticle = dummy3.p;
+            cpl = new (std::nothrow) fy_ctx();
+            if (!cpl) return fail(FY_ERR_INVALID, "out of host memory");
+            cpl->c.ext_stream = stream;
+            cpl->c.ldu_geo = &g;
+            FY_TRY(cpl->c.create(&md, &fp, 0, tr, device));                 // gaussianInterp = false (icoFoamYade.C:53)
+            cpl->c.rhoP = c->rho_particle; cpl->c.rhoF = c->rho_fluid; cpl->c.nu = c->nu;      // setScalarProperties (icoFoamYade.C:55)
+        }
+        FY_TRY(launch_ldu_flux_of(stream, g, U.p, phi.p));                    // createPhi
+        FY_HIP(hipStreamSynchronize(stream));
+        return FY_OK;
+    }
+
+    // fold `nslots` of the block partials of an n-cell reduction and read them back
+    int reduce_read(int n, int nslots, const int* ops_dev, double* h) {
+        FY_TRY(launch_reduce_finalize(stream, partials.p, n, nslots, ops_dev, sc.p, nullptr, 0));
+        FY_HIP(hipMemcpyAsync(h, sc.p, nslots * sizeof(double), hipMemcpyDeviceToHost, stream));
+        FY_HIP(hipStreamSynchronize(stream));
+        return FY_OK;
+    }
+    DevBuf<int> ops_courant;
+
+    int solve_momentum(int* iters) {
+        FY_TRY(launch_ldu_sum(stream, U.p, nc, 3, partials.p));
+        FY_TRY(launch_reduce_finalize(stream, partials.p, nc, 3, nullptr, xsum.p, nullptr, 0));
+        double* xc = U.p; double* xn = xscr.p;
+        double norm[3] = {1, 1, 1}, res0[3] = {0, 0, 0}, res[3], h[6];
+        int it = 0;
+        for (;;) {
+            FY_TRY(launch_ldu_mom_pass(stream, g, M(), gradp.p, xc, xn, xsum.p, partials.p));
+            FY_TRY(reduce_read(nc, 6, nullptr, h));
+            if (it == 0) for (int q = 0; q < 3; ++q) { norm[q] = h[3 + q] + 1e-20; res0[q] = h[q] / norm[q]; }
+            bool conv = true;
+            for (int q = 0; q < 3; ++q) {
+                res[q] = h[q] / norm[q];
+                if (!(res[q] < cs.u_tol || (cs.u_rel_tol > 0 && res[q] < cs.u_rel_tol * res0[q]))) conv = false;
+            }
+            if (conv || it >= cs.u_max_iter) break;
+            std::swap(xc, xn);
+            ++it;
+        }
+        if (xc != U.p) {                                   // the converged iterate sits in the scratch buffer: the two trade places
+            std::swap(U.p, xscr.p);
+            if (cpl) cpl->c.dU = U.p;
+        }
+        *iters = it;
+        return FY_OK;
+    }
+
+    // OpenFOAM PCG.C with the diagonal preconditioner and lduMatrix::solver::normFactor, in the single-reduction form (fv_pressure.cpp, k_pcg_cg_update)
+    int solve_pressure(bool final_iter) {
+        const double tol = final_iter ? cs.p_final_tol : cs.p_tol, rel = final_iter ? cs.p_final_rel_tol : cs.p_rel_tol;
+        double h[2];
+        FY_TRY(launch_ldu_sum(stream, p.p, nc, 1, partials.p));
+        FY_TRY(launch_reduce_finalize(stream, partials.p, nc, 1, nullptr, xsum.p, nullptr, 0));
+        FY_TRY(launch_ldu_p_init(stream, g, pdiag.p, pcoef.p, prhs.p, p.p, xsum.p, 1.0 / (double)nc, pr.p, partials.p));
+        FY_TRY(reduce_read(nc, 2, nullptr, h));
+        const double norm = h[1] + 1e-20;
+        double res = h[0] / norm;
+        const double res0 = res;
+        st.p_initial_residual = res0;
+        auto converged = [&](double r) { return r < tol || (rel > 0 && r < rel * res0); };
+        int it = 0;
+        if (!converged(res)) {
+            do {
+                FY_TRY(launch_ldu_p_apply_dot(stream, g, pdiag.p, pcoef.p, pr.p, pu.p, pw.p, partials.p));       // u = r / diag, w = A u; gamma, delta
+                FY_TRY(launch_reduce_finalize(stream, partials.p, nc, 2, nullptr, sc.p, nullptr, 0));
+                FY_TRY(launch_pcg_cg_update(stream, nc, 0, pu.p, pw.p, pp.p, ps.p, p.p, pr.p, sc.p, it, partials.p));
+                if (it == 0) { std::swap(pp.p, pu.p); std::swap(ps.p, pw.p); }      // p = u, s = w without a pass
+                FY_TRY(launch_reduce_finalize(stream, partials.p, nc, 2, nullptr, sc.p + 6, nullptr, 0));
+                FY_HIP(hipMemcpyAsync(h, sc.p + 6, 2 * sizeof(double), hipMemcpyDeviceToHost, stream));
+                FY_HIP(hipStreamSynchronize(stream));
+                res = h[0] / norm;
+            } while (++it < cs.p_max_iter && !converged(res));
+        }
+        st.p_final_residual = res;
+        st.p_iters_total += it; st.p_solves += 1;
+        return FY_OK;
+    }
+
+    int corrector(bool final_corr) {
+        FY_TRY(launch_ldu_HbyA(stream, g, M(), U.p, rAU.p, HbyA.p));                                              // icoFoamYade.C:99-100
+        FY_TRY(launch_ldu_phiHbyA(stream, g, HbyA.p, rAU.p, Uold.p, phiOld.p, rAUf.p, phiHbyA.p));               // :101-106
+        if (need_ref) FY_TRY(launch_ldu_adjust_phi(stream, g, phiHbyA.p, adj.p, adj_err.p));                      // :108
+        for (int no = 0; no <= cs.n_non_orth_correctors; ++no) {                                                   // :114-131
+            FY_TRY(launch_ldu_grad_scalar(stream, g, p.p, gradp.p));
+            FY_TRY(launch_ldu_assemble_pressure(stream, g, rAUf.p, phiHbyA.p, gradp.p, pcoef.p, pcorr.p, pdiag.p, prhs.p));
+            FY_TRY(solve_pressure(final_corr && no == cs.n_non_orth_correctors));
+            if (no == cs.n_non_orth_correctors) FY_TRY(launch_ldu_flux_correct(stream, g, p.p, phiHbyA.p, pcoef.p, pcorr.p, phi.p));
+        }
+        FY_TRY(launch_ldu_U_correct(stream, g, HbyA.p, rAU.p, p.p, phi.p, U.p, partials.p));                     // :134-137
+        double h[2];
+        FY_TRY(reduce_read(nc, 2, nullptr, h));
+        st.cont_err_sum_local = cs.dt * h[0] / total_volume; st.cont_err_global = cs.dt * h[1] / total_volume;
+        cumulative += st.cont_err_global; st.cont_err_cumulative = cumulative;
+        return FY_OK;
+    }
+
+    int step() {
+        FY_HIP(hipSetDevice(device));
+        st = fy_step_stats{}; st.cont_err_cumulative = cumulative; st.delta_t = cs.dt;
+        tim[1].start(stream);
+        if (!ops_courant.p) { FY_TRY(ops_courant.alloc_exact(2)); const int o[2] = {1, 0}; FY_HIP(hipMemcpyAsync(ops_courant.p, o, sizeof(o), hipMemcpyHostToDevice, stream)); FY_HIP(hipStreamSynchronize(stream)); }
+        double h[2];
+        FY_TRY(launch_ldu_courant(stream, g, phi.p, partials.p));                                                   // icoFoamYade.C:68
+        FY_TRY(reduce_read(nc, 2, ops_courant.p, h));
+        st.courant_max = 0.5 * h[0] * cs.dt; st.courant_mean = 0.5 * (h[1] / total_volume) * cs.dt;
+        FY_HIP(hipMemcpyAsync(Uold.p, U.p, 3 * (size_t)nc * sizeof(double), hipMemcpyDeviceToDevice, stream));    // runTime++: old-time fields
+        FY_HIP(hipMemcpyAsync(phiOld.p, phi.p, (size_t)nf * sizeof(double), hipMemcpyDeviceToDevice, stream));
+        FY_TRY(launch_ldu_grad_vec(stream, g, U.p, vGrad.p));                                                      // :71
+        tim[0].start(stream);
+        FY_TRY(cpl->c.set_particle_action(cs.dt));                                                                // :74
+        tim[0].stop(stream);
+        // the momentum source: what the coupling left (+ an external one, fy_ldu_solver_write_field_host("uSource", ...))
+        const double* src = uSource.p;
+        if (ext_source) { FY_TRY(launch_copy_f64(stream, uSourceSum.p, uSource.p, 3 * (size_t)nc)); FY_TRY(launch_add_f64(stream, uSourceSum.p, uSourceExt.p, 3 * (size_t)nc)); src = uSourceSum.p; }
+        FY_TRY(launch_ldu_assemble_momentum(stream, g, phi.p, Uold.p, src, vGrad.p, M(), fcorr.p));                // :79-85 (grad U of the iterate it is assembled from = vGrad)
+        if (cs.momentum_predictor) {
+            FY_TRY(launch_ldu_grad_scalar(stream, g, p.p, gradp.p));
+            int it = 0;
+            FY_TRY(solve_momentum(&it));                                                                          // :91-94
+            st.u_iters_total += it;
+        }
+        for (int corr = 0; corr < cs.n_correctors; ++corr) FY_TRY(corrector(corr == cs.n_correctors - 1));         // :97-140
+        FY_TRY(cpl->c.set_source_zero());                                                                         // :147
+        tim[1].stop(stream);
+        FY_HIP(hipStreamSynchronize(stream));
+        if (need_ref) {
+            int e = 0;
+            FY_HIP(hipMemcpy(&e, adj_err.p, sizeof(int), hipMemcpyDeviceToHost));
+            if (e) return fail(FY_ERR_UNSUPPORTED, "adjustPhi: continuity error cannot be removed by adjusting the outflow -- OpenFOAM stops here too");
+        }
+        st.ms_particle = tim[0].ms(); st.ms_total = tim[1].ms();
+        return FY_OK;
+    }
+
+    int field(const char* name, double** ptr, size_t* count, const std::vector<double>** host) {
+        const std::string s = name ? name : "";
+        *host = nullptr;
+        const size_t n = (size_t)nc;
+        struct E { const char* nm; double* p; size_t c; };
+        const E tab[] = {{"U", U.p, 3 * n}, {"p", p.p, n}, {"phi", phi.p, (size_t)nf}, {"uSource", uSourceExt.p, 3 * n}, {"rAU", rAU.p, n}, {"HbyA", HbyA.p, 3 * n},
+                         {"phiHbyA", phiHbyA.p, (size_t)nf}, {"p_diag", pdiag.p, n}, {"p_coef", pcoef.p, (size_t)nf}, {"p_rhs", prhs.p, n}, {"vGrad", vGrad.p, 9 * n},
+                         {"mom_diag", mdiag.p, n}, {"mom_lower", mlower.p, (size_t)ni}, {"mom_upper", mupper.p, (size_t)ni}, {"mom_b", mb.p, 3 * n}};
+        for (const E& e : tab) if (s == e.nm) { *ptr = e.p; *count = e.c; return FY_OK; }
+        const struct { const char* nm; const std::vector<double>* v; } geo[] = {{"C", &hm.C}, {"V", &hm.V}, {"Cf", &hm.Cf}, {"Sf", &hm.Sf}, {"magSf", &hm.magSf}, {"w", &hm.w},
+                                                                                  {"dcNO", &hm.dcNO}, {"kvec", &hm.kvec}};
+        for (const auto& e : geo) if (s == e.nm) { *host = e.v; *count = e.v->size(); *ptr = nullptr; return FY_OK; }
+        return fail(FY_ERR_INVALID, "unknown fy_ldu_solver field '%s'", s.c_str());
+    }
+};
+
+}  // namespace fy
+
+struct fy_ldu_solver { fy::LduSolver s; };
+
+extern "C" {
+
+void fy_ldu_case_defaults(fy_ldu_case* c) {
+    if (!c) return;
+    std::memset(c, 0, sizeof(*c));
+    c->dt = 0.005; c->nu = 0.01; c->rho_fluid = 1000.0; c->rho_particle = 2650.0;
+    c->n_correctors = 2; c->n_non_orth_correctors = 0; c->momentum_predictor = 1; c->p_ref_cell = 0; c->p_ref_value = 0.0;
+    c->p_tol = 1e-6; c->p_rel_tol = 0.05; c->p_final_tol = 1e-6; c->p_final_rel_tol = 0.0; c->p_max_iter = 1000;
+    c->u_tol = 1e-5; c->u_rel_tol = 0.0; c->u_max_iter = 1000;
+}
+
+int fy_ldu_solver_create(const fy_poly_mesh* m, const fy_ldu_case* c, const fy_transport* tr, int device_ordinal, fy_ldu_solver** out) {
+    if (!out) return fy::fail(FY_ERR_INVALID, "null out");
+    *out = nullptr;
+    fy_ldu_solver* s = new (std::nothrow) fy_ldu_solver();
+    if (!s) return fy::fail(FY_ERR_INVALID, "out of host memory");
+    const int rc = s->s.create(m, c, tr, device_ordinal);
+    if (rc != FY_OK) { delete s; return rc; }
+    *out = s;
+    return FY_OK;
+}
+#define FY_LS(s) if (!(s)) return fy::fail(FY_ERR_INVALID, "null fy_ldu_solver")
+int fy_ldu_solver_step(fy_ldu_solver* s) { FY_LS(s); return s->s.step(); }
+int fy_ldu_solver_get_stats(fy_ldu_solver* s, fy_step_stats* out) { FY_LS(s); if (!out) return fy::fail(FY_ERR_INVALID, "null out"); *out = s->s.st; return FY_OK; }
+fy_ctx* fy_ldu_solver_coupling(fy_ldu_solver* s) { return s ? s->s.cpl : nullptr; }
+int fy_ldu_solver_field_count(fy_ldu_solver* s, const char* name, int64_t* count) {
+    FY_LS(s);
+    if (!count) return fy::fail(FY_ERR_INVALID, "null count");
+    double* p; size_t n; const std::vector<double>* h;
+    FY_TRY(s->s.field(name, &p, &n, &h));
+    *count = (int64_t)n;
+    return FY_OK;
+}
+int fy_ldu_solver_read_field_host(fy_ldu_solver* s, const char* name, double* out) {
+    FY_LS(s);
+    double* p; size_t n; const std::vector<double>* h;
+    FY_TRY(s->s.field(name, &p, &n, &h));
+    if (h) { std::memcpy(out, h->data(), n * sizeof(double)); return FY_OK; }
+    FY_HIP(hipSetDevice(s->s.device));
+    FY_HIP(hipMemcpyAsync(out, p, n * sizeof(double), hipMemcpyDeviceToHost, s->s.stream));
+    FY_HIP(hipStreamSynchronize(s->s.stream));
+    return FY_OK;
+}
+int fy_ldu_solver_write_field_host(fy_ldu_solver* s, const char* name, const double* in) {
+    FY_LS(s);
+    double* p; size_t n; const std::vector<double>* h;
+    FY_TRY(s->s.field(name, &p, &n, &h));
+    const std::string nm = name;
+    if (h || (nm != "U" && nm != "p" && nm != "uSource")) return fy::fail(FY_ERR_INVALID, "fy_ldu_solver_write_field_host: '%s' cannot be written (U, p, uSource)", nm.c_str());
+    FY_HIP(hipSetDevice(s->s.device));
+    FY_HIP(hipMemcpyAsync(p, in, n * sizeof(double), hipMemcpyHostToDevice, s->s.stream));
+    if (nm == "uSource") s->s.ext_source = true;
+    if (nm == "U") FY_TRY(fy::launch_ldu_flux_of(s->s.stream, s->s.g, s->s.U.p, s->s.phi.p));      // createPhi
+    FY_HIP(hipStreamSynchronize(s->s.stream));
+    return FY_OK;
+}
+int fy_ldu_solver_destroy(fy_ldu_solver* s) { delete s; return FY_OK; }
+
+}  // extern "C"

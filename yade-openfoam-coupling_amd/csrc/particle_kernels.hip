@@ -1366,29 +1366,41 @@ __global__ __launch_bounds__(256) void k_point_force(const double* __restrict__ 
     const double* r = rec + 10 * i;
     const double x = r[0], y = r[1], z = r[2];
     double* F = force_out + 6 * (size_t)i;
-    // uniform-block stand-in for mesh.findCell (FoamYade.C:251): inside the closed bounding box, floor((p-min)/dx) clamped
-    const bool outside = (x < g.bbmin[0] || y < g.bbmin[1] || z < g.bbmin[2] || x > g.bbmax[0] || y > g.bbmax[1] || z > g.bbmax[2]);
-    if (outside || !(x == x) || !(y == y) || !(z == z)) {
-        F[0] = F[1] = F[2] = F[3] = F[4] = F[5] = 0.0;
-        found_out[i] = -1;
-        incell_out[i] = -1;
-        return;
-    }
-    int ci, cj, ck;
-    if (g.faces[0]) {              // graded block: the cell whose [low, high) face planes hold the coordinate (the last cell takes its high plane too)
-        ci = axis_cell(g.faces[0], g.nx, x); cj = axis_cell(g.faces[1], g.ny, y); ck = axis_cell(g.faces[2], g.nz, z);
+    int cglob;
+    if (g.cell_of) {
+        // general mesh: mesh.findCell (FoamYade.C:251) was stood in for by the nearest centre + a walk across faces (k_ldu_find_cell)
+        cglob = g.cell_of[i];
+        if (cglob < 0) {
+            F[0] = F[1] = F[2] = F[3] = F[4] = F[5] = 0.0;
+            found_out[i] = -1;
+            incell_out[i] = -1;
+            return;
+        }
     } else {
-        ci = min(g.nx - 1, (int)((x - g.bbmin[0]) / g.dx));
-        cj = min(g.ny - 1, (int)((y - g.bbmin[1]) / g.dx));
-        ck = min(g.nz - 1, (int)((z - g.bbmin[2]) / g.dx));
+        // uniform-block stand-in for mesh.findCell (FoamYade.C:251): inside the closed bounding box, floor((p-min)/dx) clamped
+        const bool outside = (x < g.bbmin[0] || y < g.bbmin[1] || z < g.bbmin[2] || x > g.bbmax[0] || y > g.bbmax[1] || z > g.bbmax[2]);
+        if (outside || !(x == x) || !(y == y) || !(z == z)) {
+            F[0] = F[1] = F[2] = F[3] = F[4] = F[5] = 0.0;
+            found_out[i] = -1;
+            incell_out[i] = -1;
+            return;
+        }
+        int ci, cj, ck;
+        if (g.faces[0]) {              // graded block: the cell whose [low, high) face planes hold the coordinate (the last cell takes its high plane too)
+            ci = axis_cell(g.faces[0], g.nx, x); cj = axis_cell(g.faces[1], g.ny, y); ck = axis_cell(g.faces[2], g.nz, z);
+        } else {
+            ci = min(g.nx - 1, (int)((x - g.bbmin[0]) / g.dx));
+            cj = min(g.ny - 1, (int)((y - g.bbmin[1]) / g.dx));
+            ck = min(g.nz - 1, (int)((z - g.bbmin[2]) / g.dx));
+        }
+        if (own.active && !own_planes(own, (int)i, ck, x, y, z)) {           // in another slab's (or wire piece's) planes: that one owns it
+            F[0] = F[1] = F[2] = F[3] = F[4] = F[5] = 0.0;
+            found_out[i] = -1;
+            incell_out[i] = -1;
+            return;
+        }
+        cglob = ci + g.nx * (cj + g.ny * ck);
     }
-    if (own.active && !own_planes(own, (int)i, ck, x, y, z)) {           // in another slab's (or wire piece's) planes: that one owns it
-        F[0] = F[1] = F[2] = F[3] = F[4] = F[5] = 0.0;
-        found_out[i] = -1;
-        incell_out[i] = -1;
-        return;
-    }
-    const int cglob = ci + g.nx * (cj + g.ny * ck);
     found_out[i] = 1;
     incell_out[i] = cglob;
     const int64_t cl = (int64_t)cglob - cw.base;

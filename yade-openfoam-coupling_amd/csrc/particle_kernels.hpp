@@ -167,6 +167,7 @@ struct BlockGeom {
     double bbmin[3], bbmax[3], dx;
     int nx, ny, nz;
     const double* faces[3];        // graded block: coordinates of the n + 1 face planes per axis (device); null = uniform block
+    const int32_t* cell_of;        // general mesh (fy_ldu_solver): the containing cell of every record, located beforehand (-1: outside); null = block arithmetic
 };
 int launch_point_force(hipStream_t s, const double* rec, int64_t n, BlockGeom g, ForceParams fp, CellWindow cw, const double* vol,
                        const double* U, const double* vGrad, double* uSource, double* force_out, int32_t* found_out,
