@@ -82,3 +82,140 @@ def wavy(amp, lengths=(1.0, 1.0, 1.0)):
 def to_lattice(mesh, field):
     """a cell field of a (renumbered) block back in lattice order i + nx (j + ny k)"""
     return np.asarray(field)[mesh["perm"]]
+
+
+def from_cells(points, cells, patch_of_face, patch_names, shape=None):
+    """a mesh in OpenFOAM's addressing from cells given as lists of faces (point tuples turning counter-clockwise seen from OUTSIDE the cell).  A face two
+    cells share becomes an internal face (owner = the lower cell, point order = the owner's); the others go to the patch patch_of_face(face centre) names.
+    Internal faces in upper-triangular order, boundary faces patch by patch sorted by owner [OF-6 polyMesh ordering]."""
+    seen = {}
+    for c, faces in enumerate(cells):
+        for f in faces:
+            key = tuple(sorted(f))
+            if key in seen:
+                seen[key].append((c, tuple(f)))
+            else:
+                seen[key] = [(c, tuple(f))]
+    internal, boundary = [], [[] for _ in patch_names]
+    P = np.asarray(points, np.float64)
+    for key, users in seen.items():
+        if len(users) == 2:
+            (c0, f0), (c1, f1) = sorted(users)
+            internal.append((c0, c1, f0))
+        else:
+            c0, f0 = users[0]
+            boundary[patch_names.index(patch_of_face(P[list(f0)].mean(axis=0)))].append((c0, f0))
+    internal.sort(key=lambda t: (t[0], t[1]))
+    faces = [t[2] for t in internal]; owner = [t[0] for t in internal]; neigh = [t[1] for t in internal]
+    pstart, psize = [], []
+    for bf in boundary:
+        pstart.append(len(faces)); psize.append(len(bf))
+        for c, f in sorted(bf, key=lambda t: t[0]):
+            faces.append(f); owner.append(c)
+    off = np.concatenate([[0], np.cumsum([len(f) for f in faces])]).astype(np.int32)
+    return dict(points=P, face_offsets=off, face_points=np.asarray([q for f in faces for q in f], np.int32), owner=np.asarray(owner, np.int32),
+                neighbour=np.asarray(neigh, np.int32), n_cells=len(cells), patch_start=np.asarray(pstart, np.int32), patch_size=np.asarray(psize, np.int32),
+                patch_names=list(patch_names), perm=np.arange(len(cells)), shape=shape)
+
+
+def prism_block(nx, ny, nz, lengths=(1.0, 1.0, 1.0), vertex_map=None):
+    """the box cut into triangular prisms: every hexahedron of the nx x ny x nz lattice split along the diagonal of its z faces (alternating direction from
+    cell to cell), so the mesh has triangular AND quadrilateral faces and cells with five faces.  Patches: one per side of the box (SIDES)."""
+    lx, ly, lz = lengths
+    pid = lambda i, j, k: i + (nx + 1) * (j + (ny + 1) * k)
+    ii, jj, kk = np.meshgrid(np.arange(nx + 1), np.arange(ny + 1), np.arange(nz + 1), indexing="ij")
+    P0 = np.zeros(((nx + 1) * (ny + 1) * (nz + 1), 3))
+    P0[pid(ii, jj, kk).ravel()] = np.stack([ii.ravel() * lx / nx, jj.ravel() * ly / ny, kk.ravel() * lz / nz], axis=1)
+    P = P0 if vertex_map is None else np.asarray(vertex_map(P0), np.float64)
+
+    def prism(a, b, c, k):          # triangle a b c (counter-clockwise seen from +z) extruded from plane k to k + 1
+        lo = [pid(i, j, k) for i, j in (a, b, c)]; hi = [pid(i, j, k + 1) for i, j in (a, b, c)]
+        return [(lo[0], lo[2], lo[1]), (hi[0], hi[1], hi[2]), (lo[0], lo[1], hi[1], hi[0]), (lo[1], lo[2], hi[2], hi[1]), (lo[2], lo[0], hi[0], hi[2])]
+    cells = []
+    for k in range(nz):
+        for j in range(ny):
+            for i in range(nx):
+                a, b, c, d = (i, j), (i + 1, j), (i + 1, j + 1), (i, j + 1)
+                if (i + j) % 2 == 0:
+                    cells += [prism(a, b, c, k), prism(a, c, d, k)]
+                else:
+                    cells += [prism(a, b, d, k), prism(b, c, d, k)]
+    # the side of the box a boundary face lies on comes from the UNMAPPED lattice (the map may move the sides)
+    eps = 1e-9
+
+    def patch_of_face_pts(f):
+        c = P0[list(f)].mean(axis=0)
+        for a, L in enumerate((lx, ly, lz)):
+            if abs(c[a]) < eps: return SIDES[2 * a]
+            if abs(c[a] - L) < eps: return SIDES[2 * a + 1]
+        raise ValueError("face not on the box")
+    # from_cells looks a patch up by the (mapped) face centre: hand it a lookup keyed on that centre
+    table = {}
+    for faces in cells:
+        for f in faces:
+            c0 = P0[list(f)].mean(axis=0)
+            on_side = any(abs(c0[a]) < eps or abs(c0[a] - L) < eps for a, L in enumerate((lx, ly, lz)))
+            if on_side:
+                table[tuple(np.round(P[list(f)].mean(axis=0), 12))] = patch_of_face_pts(f)
+    return from_cells(P, cells, lambda ctr: table[tuple(np.round(ctr, 12))], list(SIDES), shape=(nx, ny, nz))
+
+
+def write_poly_mesh_files(case_dir, mesh, patch_types=None):
+    """constant/polyMesh of `mesh` (ASCII, the layout OpenFOAM writes).  Test infrastructure: there is no blockMesh / snappyHexMesh here"""
+    import os
+    pm = os.path.join(str(case_dir), "constant", "polyMesh")
+    os.makedirs(pm, exist_ok=True)
+    head = lambda cls, obj: "FoamFile\n{\n    version     2.0;\n    format      ascii;\n    class       %s;\n    location    \"constant/polyMesh\";\n    object      %s;\n}\n\n" % (cls, obj)
+    P, off, fp = mesh["points"], mesh["face_offsets"], mesh["face_points"]
+    with open(os.path.join(pm, "points"), "w") as f:
+        f.write(head("vectorField", "points") + "%d\n(\n" % len(P) + "".join("(%r %r %r)\n" % (float(x), float(y), float(z)) for x, y, z in P) + ")\n")
+    with open(os.path.join(pm, "faces"), "w") as f:
+        f.write(head("faceList", "faces") + "%d\n(\n" % (len(off) - 1) +
+                "".join("%d(%s)\n" % (off[q + 1] - off[q], " ".join(str(int(v)) for v in fp[off[q]:off[q + 1]])) for q in range(len(off) - 1)) + ")\n")
+    for name in ("owner", "neighbour"):
+        with open(os.path.join(pm, name), "w") as f:
+            f.write(head("labelList", name) + "%d\n(\n" % len(mesh[name]) + "".join("%d\n" % int(v) for v in mesh[name]) + ")\n")
+    with open(os.path.join(pm, "boundary"), "w") as f:
+        f.write(head("polyBoundaryMesh", "boundary") + "%d\n(\n" % len(mesh["patch_names"]))
+        for q, name in enumerate(mesh["patch_names"]):
+            ty = (patch_types or {}).get(name, "wall")
+            f.write("    %s\n    {\n        type            %s;\n        nFaces          %d;\n        startFace       %d;\n    }\n" % (name, ty, int(mesh["patch_size"][q]), int(mesh["patch_start"][q])))
+        f.write(")\n")
+
+
+def hex_block_fast(nx, ny, nz, lengths=(1.0, 1.0, 1.0), vertex_map=None):
+    """hex_block(nx, ny, nz, lengths, vertex_map) with one patch per side and the lattice numbering, built with array operations (millions of cells)"""
+    lx, ly, lz = lengths
+    I, J, K = np.meshgrid(np.arange(nx + 1), np.arange(ny + 1), np.arange(nz + 1), indexing="ij")
+    pid = lambda i, j, k: i + (nx + 1) * (j + (ny + 1) * k)
+    P = np.zeros(((nx + 1) * (ny + 1) * (nz + 1), 3))
+    P[pid(I, J, K).ravel()] = np.stack([I.ravel() * lx / nx, J.ravel() * ly / ny, K.ravel() * lz / nz], axis=1)
+    if vertex_map is not None:
+        P = np.asarray(vertex_map(P), np.float64)
+    ci, cj, ck = [a.ravel(order="F") for a in np.meshgrid(np.arange(nx), np.arange(ny), np.arange(nz), indexing="ij")]      # i fastest
+    cid = ci + nx * (cj + ny * ck)
+
+    def quad(d, i, j, k):
+        if d == 0: return np.stack([pid(i, j, k), pid(i, j + 1, k), pid(i, j + 1, k + 1), pid(i, j, k + 1)], axis=1)
+        if d == 1: return np.stack([pid(i, j, k), pid(i, j, k + 1), pid(i + 1, j, k + 1), pid(i + 1, j, k)], axis=1)
+        return np.stack([pid(i, j, k), pid(i + 1, j, k), pid(i + 1, j + 1, k), pid(i, j + 1, k)], axis=1)
+    own_l, nei_l, f_l, key_l = [], [], [], []
+    for d, (di, dj, dk) in enumerate(((1, 0, 0), (0, 1, 0), (0, 0, 1))):
+        ok = (ci + di < nx) & (cj + dj < ny) & (ck + dk < nz)
+        o = cid[ok]
+        own_l.append(o); nei_l.append(o + (1, nx, nx * ny)[d]); f_l.append(quad(d, ci[ok] + di, cj[ok] + dj, ck[ok] + dk)); key_l.append(3 * o.astype(np.int64) + d)
+    order = np.argsort(np.concatenate(key_l), kind="stable")
+    faces = [np.concatenate(f_l)[order]]; owner = [np.concatenate(own_l)[order]]; neigh = np.concatenate(nei_l)[order]
+    pstart, psize = [], []
+    nfaces = len(neigh)
+    for s in range(6):
+        d, hi = s // 2, s % 2
+        on = (ci, cj, ck)[d] == (((nx, ny, nz)[d] - 1) if hi else 0)
+        i, j, k = ci[on], cj[on], ck[on]
+        q = quad(d, i + (d == 0 and hi), j + (d == 1 and hi), k + (d == 2 and hi))
+        faces.append(q if hi else q[:, ::-1]); owner.append(cid[on])
+        pstart.append(nfaces); psize.append(int(on.sum())); nfaces += int(on.sum())
+    F = np.concatenate(faces)
+    return dict(points=P, face_offsets=np.arange(0, 4 * len(F) + 1, 4, dtype=np.int32), face_points=F.astype(np.int32).ravel(), owner=np.concatenate(owner).astype(np.int32),
+                neighbour=neigh.astype(np.int32), n_cells=nx * ny * nz, patch_start=np.asarray(pstart, np.int32), patch_size=np.asarray(psize, np.int32),
+                patch_names=list(SIDES), perm=np.arange(nx * ny * nz), shape=(nx, ny, nz))

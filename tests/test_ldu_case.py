@@ -1,0 +1,161 @@
+"""An icoFoamYade case directory whose constant/polyMesh is NOT a block (fy_foam_case_open_general -> fy_ldu_solver): what createMesh.H / createFields.H read
+(icoFoamYade.C:42-44) and runTime.write() writes back (icoFoamYade.C:142).  The meshes are written by tests/poly_meshes.py (there is no blockMesh here)."""
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+import poly_meshes as pm
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CASES = os.path.join(HERE, "golden", "cases")
+CAVITY = [("movingWall", [3]), ("fixedWalls", [0, 1, 2, 4, 5])]
+
+
+@pytest.fixture
+def prod():
+    from conftest import load_product
+    return load_product()
+
+
+def general_cavity(tmp_path, mesh, p_file=None):
+    dst = tmp_path / "case"
+    shutil.copytree(os.path.join(CASES, "cavity_ico"), dst)
+    os.remove(dst / "system/blockMeshDict")
+    pm.write_poly_mesh_files(dst, mesh)
+    return dst
+
+
+def test_general_polyMesh_case_is_read(prod, tmp_path):
+    """a sheared, randomly renumbered block: the block reader refuses it by name, the general reader returns the files' arrays, the patches in the boundary
+    file's order with their conditions, and the controls of the dictionaries"""
+    mesh = pm.hex_block(6, 5, 4, (0.1, 0.1, 0.1), pm.shear(0.3, 0.1, 0.2), patches=CAVITY, renumber_seed=3)
+    dst = general_cavity(tmp_path, mesh)
+    with pytest.raises(prod.FoamYadeError, match="not a rectilinear lattice"):
+        prod.FoamCase(dst, prod.FY_SOLVER_ICO)
+    fc = prod.GeneralFoamCase(dst)
+    for k in ("face_offsets", "face_points", "owner", "neighbour", "patch_start", "patch_size"):
+        np.testing.assert_array_equal(fc.mesh[k], mesh[k], err_msg=k)
+    np.testing.assert_array_equal(fc.mesh["points"], mesh["points"])                 # (%r round-trips doubles)
+    assert fc.mesh["n_cells"] == 120 and fc.n_cells == 120 and fc.patch_names == ["movingWall", "fixedWalls"]
+    assert fc.u_bc == [prod.FY_BC_U_FIXED_VALUE] * 2 and fc.p_bc == [prod.FY_BC_P_ZERO_GRADIENT] * 2
+    np.testing.assert_array_equal(fc.u_value, [[1, 0, 0], [0, 0, 0]])
+    ref = prod.FoamCase(os.path.join(CASES, "cavity_ico"), prod.FY_SOLVER_ICO)
+    lc, d = fc.ldu_case, ref.case
+    assert (lc.dt, lc.nu, lc.rho_fluid, lc.rho_particle) == (d.dt, d.nu, d.rho_fluid, d.rho_particle)
+    assert (lc.n_correctors, lc.n_non_orth_correctors, lc.p_ref_cell, lc.p_ref_value) == (d.n_correctors, d.n_non_orth_correctors, d.p_ref_cell, d.p_ref_value)
+    assert (lc.p_tol, lc.p_rel_tol, lc.p_final_tol, lc.u_tol) == (d.p_tol, d.p_rel_tol, d.p_final_tol, d.u_tol)
+    assert (fc.start_time, fc.end_time, fc.delta_t, fc.write_interval_steps) == (ref.start_time, ref.end_time, ref.delta_t, ref.write_interval_steps)
+    U, p = fc.initial_fields()
+    assert U.shape == (120, 3) and not U.any() and not p.any()
+    ref.close()
+    # runTime.write() from host arrays: the case's own patch entries come back, the values in the mesh's numbering
+    Uw = np.arange(360.0).reshape(120, 3); pw = np.arange(120.0) * 0.5
+    fc.write_fields("0.5", Uw, pw)
+    text = (dst / "0.5/U").read_text()
+    assert "movingWall" in text and "fixedWalls" in text and "uniform ( 1 0 0 )" in text and "noSlip" in text
+    (dst / "system/controlDict").write_text((dst / "system/controlDict").read_text().replace("startFrom       startTime;", "startFrom       latestTime;"))
+    fc.close()
+    fc = prod.GeneralFoamCase(dst)
+    U, p = fc.initial_fields()
+    np.testing.assert_array_equal(U, Uw); np.testing.assert_array_equal(p, pw)
+    assert fc.start_name == "0.5"
+    fc.close()
+
+
+def test_prism_polyMesh_case_is_read(prod, tmp_path):
+    """triangular and quadrilateral faces in one faces file"""
+    mesh = pm.prism_block(3, 3, 2, (0.1, 0.1, 0.1), pm.wavy(0.004, (0.1, 0.1, 0.1)))
+    dst = general_cavity(tmp_path, mesh)
+    for nm in ("U", "p"):       # six patches, one per side: the cavity's two entries are replaced
+        t = (dst / "0" / nm).read_text()
+        head = t[:t.index("boundaryField")]
+        body = "".join("    %s { type %s; }\n" % (s, ("noSlip" if nm == "U" else "zeroGradient")) for s in pm.SIDES)
+        if nm == "U":
+            body = body.replace("ymax { type noSlip; }", "ymax { type fixedValue; value uniform (1 0 0); }")
+        (dst / "0" / nm).write_text(head + "boundaryField\n{\n" + body + "}\n")
+    fc = prod.GeneralFoamCase(dst)
+    for k in ("face_offsets", "face_points", "owner", "neighbour", "patch_start", "patch_size"):
+        np.testing.assert_array_equal(fc.mesh[k], mesh[k], err_msg=k)
+    assert fc.patch_names == list(pm.SIDES) and fc.mesh["n_cells"] == 36
+    np.testing.assert_array_equal(fc.u_value[3], [1, 0, 0])
+    fc.close()
+
+
+@pytest.mark.parametrize("edit,needle", [
+    (("system/fvSchemes", "Gauss linear corrected", "Gauss linear uncorrected"), "must be 'corrected'"),
+    (("system/fvSchemes", "default corrected", "default orthogonal"), "must be 'corrected'"),
+    (("system/fvSchemes", "div(phi,U)       Gauss linear", "div(phi,U)       Gauss upwind"), "must be Gauss linear"),
+    (("constant/polyMesh/boundary", "type            wall;", "type            symmetryPlane;"), "symmetryPlane"),
+    (("0/U", "noSlip", "slip"), "slip"),
+    (("0/p", "zeroGradient", "fixedFluxPressure"), "fixedFluxPressure"),
+])
+def test_what_the_general_solver_cannot_do_is_refused_by_name(prod, tmp_path, edit, needle):
+    mesh = pm.hex_block(4, 4, 4, (0.1, 0.1, 0.1), pm.shear(0.2), patches=CAVITY)
+    dst = general_cavity(tmp_path, mesh)
+    f, old, new = edit
+    t = (dst / f).read_text()
+    assert old in t
+    (dst / f).write_text(t.replace(old, new))
+    with pytest.raises(prod.FoamYadeError, match=needle):
+        prod.GeneralFoamCase(dst)
+
+
+@pytest.mark.gpu
+def test_run_from_a_general_case_directory_equals_the_hand_built_solver(prod, tmp_path):
+    """LduSolver.from_foam_case on a wavy renumbered block = the solver built from the same arrays by hand, bit for bit; write, reopen from latestTime"""
+    n = 8
+    mesh = pm.hex_block(n, n, n, (0.1, 0.1, 0.1), pm.wavy(0.003, (0.1, 0.1, 0.1)), patches=CAVITY, renumber_seed=7)
+    dst = general_cavity(tmp_path, mesh)
+    fc = prod.GeneralFoamCase(dst)
+    s = prod.LduSolver.from_foam_case(fc)
+    lc = fc.ldu_case
+    h = prod.LduSolver(mesh, lc.dt, lc.nu, [0, 0], [(1, 0, 0), (0, 0, 0)], [0, 0], n_correctors=lc.n_correctors, n_non_orth_correctors=lc.n_non_orth_correctors,
+                       p_tol=lc.p_tol, p_rel_tol=lc.p_rel_tol, p_final_tol=lc.p_final_tol, p_final_rel_tol=lc.p_final_rel_tol, p_max_iter=lc.p_max_iter,
+                       u_tol=lc.u_tol, u_rel_tol=lc.u_rel_tol, u_max_iter=lc.u_max_iter, p_ref_cell=lc.p_ref_cell, p_ref_value=lc.p_ref_value,
+                       rho_fluid=lc.rho_fluid, rho_particle=lc.rho_particle, momentum_predictor=lc.momentum_predictor)
+    for _ in range(3):
+        s.step(); h.step()
+    np.testing.assert_array_equal(s.get("U"), h.get("U")); np.testing.assert_array_equal(s.get("p"), h.get("p"))
+    assert np.abs(s.get("U")).max() > 0.05
+    fc.write(s, "0.015")
+    U, p = s.get("U").reshape(-1, 3), s.get("p")
+    s.close(); h.close(); fc.close()
+    (dst / "system/controlDict").write_text((dst / "system/controlDict").read_text().replace("startFrom       startTime;", "startFrom       latestTime;"))
+    fc = prod.GeneralFoamCase(dst)
+    U1, p1 = fc.initial_fields()
+    np.testing.assert_array_equal(U1, U); np.testing.assert_array_equal(p1, p)
+    fc.close()
+
+
+@pytest.mark.gpu
+def test_foamYadeHip_executable_runs_a_general_mesh_case(prod, tmp_path):
+    """foamYadeHip -solver ico on a case the block reader refuses: it falls through to the general solver, prints icoFoamYade's log lines and writes the
+    time directories of controlDict"""
+    n = 8
+    mesh = pm.prism_block(n, n, 4, (0.1, 0.1, 0.1), pm.wavy(0.002, (0.1, 0.1, 0.1)))
+    dst = general_cavity(tmp_path, mesh)
+    for nm in ("U", "p"):
+        t = (dst / "0" / nm).read_text()
+        head = t[:t.index("boundaryField")]
+        body = "".join("    %s { type %s; }\n" % (s, ("noSlip" if nm == "U" else "zeroGradient")) for s in pm.SIDES)
+        if nm == "U":
+            body = body.replace("ymax { type noSlip; }", "ymax { type fixedValue; value uniform (1 0 0); }")
+        (dst / "0" / nm).write_text(head + "boundaryField\n{\n" + body + "}\n")
+    cd = (dst / "system/controlDict").read_text()
+    import re
+    cd = re.sub(r"endTime\s+[0-9.eE+-]+;", "endTime         0.02;", cd)
+    cd = re.sub(r"writeInterval\s+[0-9.eE+-]+;", "writeInterval   2;", cd)
+    (dst / "system/controlDict").write_text(cd)
+    exe = os.path.join(os.path.dirname(prod.__file__), "bin", "foamYadeHip")
+    out = subprocess.run([exe, "-solver", "ico", "-case", str(dst)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "general polyhedral mesh" in out.stdout and "Courant Number mean" in out.stdout and out.stdout.rstrip().endswith("End")
+    fc = prod.GeneralFoamCase(dst)
+    written = sorted(d for d in os.listdir(dst) if d[0].isdigit() and d != "0")
+    assert written, os.listdir(dst)
+    t = (dst / written[-1] / "U").read_text()
+    assert "nonuniform List<vector>" in t and "ymax" in t
+    fc.close()

@@ -158,3 +158,26 @@ def test_poiseuille_converges_at_second_order_on_wavy_meshes(oracle):
         assert np.abs(U[:, 1:]).max() < 0.02 * umax
         s.close()
     assert errs[0] < 0.08 and errs[1] < errs[0] / 2.8, errs
+
+
+def test_prisms_geometry(oracle):
+    """triangular prisms (triangular + quadrilateral faces, five-faced cells) under a shear: closed cells, equal volumes adding up to the box's, centres =
+    the prisms' centroids (the triangle branch of the face decomposition, the pyramid sums over five faces)"""
+    mesh = pm.prism_block(4, 4, 3, (1.0, 1.0, 0.9), pm.shear(0.3, 0.2, -0.1))
+    assert sorted(set(np.diff(mesh["face_offsets"]))) == [3, 4]
+    s = make(mesh, 1e-3, 0.01)
+    Sf, V, C, Cf = (s.geometry(n) for n in ("Sf", "V", "C", "Cf"))
+    own, nei, ni = mesh["owner"], mesh["neighbour"], len(mesh["neighbour"])
+    tot = np.zeros((mesh["n_cells"], 3))
+    np.add.at(tot, own, Sf); np.subtract.at(tot, nei, Sf[:ni])
+    assert np.abs(tot).max() < 1e-15
+    assert V.sum() == pytest.approx(0.9, rel=1e-13) and np.allclose(V, V[0], rtol=1e-12)
+    # a prism's centroid = the mean of its six vertices (it is the affine image of a right prism)
+    P, off, fp = mesh["points"], mesh["face_offsets"], mesh["face_points"]
+    verts = [set() for _ in range(mesh["n_cells"])]
+    for f in range(len(own)):
+        verts[own[f]].update(fp[off[f]:off[f + 1]])
+        if f < ni: verts[nei[f]].update(fp[off[f]:off[f + 1]])
+    want = np.array([P[sorted(v)].mean(axis=0) for v in verts])
+    np.testing.assert_allclose(C, want, atol=1e-14)
+    s.close()

@@ -36,15 +36,16 @@ def test_geometry_equals_the_restatement(product, oracle):
     h.close(); o.close()
 
 
-@pytest.mark.parametrize("kind", ["lattice", "sheared", "wavy_renumbered"])
+@pytest.mark.parametrize("kind", ["lattice", "sheared", "wavy_renumbered", "prisms"])
 def test_cavity_matches_the_restatement(product, oracle, kind):
-    """lid-driven cavity, four steps, two non-orthogonal correctors: first-step matrices, then fields and counters"""
+    """lid-driven cavity, four steps, two non-orthogonal correctors: first-step matrices, then fields and counters.  prisms: triangular prisms on a wavy
+    lattice (triangular and quadrilateral faces, five-faced cells)"""
     n = 10
-    vm, seed = {"lattice": (None, None), "sheared": (pm.shear(0.3, 0.0, 0.2), None), "wavy_renumbered": (pm.wavy(0.03), 9)}[kind]
-    mesh = pm.hex_block(n, n, n, vertex_map=vm, renumber_seed=seed)
+    vm, seed = {"lattice": (None, None), "sheared": (pm.shear(0.3, 0.0, 0.2), None), "wavy_renumbered": (pm.wavy(0.03), 9), "prisms": (pm.wavy(0.02), None)}[kind]
+    mesh = pm.prism_block(n, n, 6, vertex_map=vm) if kind == "prisms" else pm.hex_block(n, n, n, vertex_map=vm, renumber_seed=seed)
     kw = dict(n_non_orth=2, p_tol=1e-9, p_rel_tol=0.0, p_final_tol=1e-9, u_tol=1e-9, p_max_iter=5000)
     h, o = pair(product, oracle, mesh, 0.4 / n, 0.01, [0] * 6, lid(), [0] * 6, **kw)
-    U0 = np.random.RandomState(3).rand(n ** 3, 3) * 0.05
+    U0 = np.random.RandomState(3).rand(mesh["n_cells"], 3) * 0.05
     h.set("U", U0); o.set("U", U0)
     h.step(); o.step()
     ni = len(mesh["neighbour"])

@@ -881,6 +881,49 @@ class FoamCase:
             self._h = None
 
 
+class GeneralFoamCase(FoamCase):
+    """an icoFoamYade case directory whose constant/polyMesh is any mesh of wall / patch boundaries (fy_foam_case_open_general): .pm / .ldu_case are the
+    structs for fy_ldu_solver_create (LduSolver.from_foam_case), .mesh the arrays as numpy copies, .patch_names the boundary file's order"""
+
+    def __init__(self, case_dir):
+        L = lib()
+        L.fy_foam_case_open_general.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
+        L.fy_foam_case_poly_mesh.argtypes = [C.c_void_p, C.POINTER(PolyMesh)]
+        L.fy_foam_case_ldu_desc.argtypes = [C.c_void_p, C.POINTER(LduCase)]
+        L.fy_foam_case_patch_name.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int]
+        L.fy_foam_case_write_time_ldu.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p]
+        h = C.c_void_p()
+        _check(L.fy_foam_case_open_general(str(case_dir).encode(), C.byref(h)))
+        self._h = h
+        self.pm, self.ldu_case = PolyMesh(), LduCase()
+        _check(L.fy_foam_case_poly_mesh(self._h, C.byref(self.pm)))
+        _check(L.fy_foam_case_ldu_desc(self._h, C.byref(self.ldu_case)))
+        info = FoamCaseInfo()
+        _check(L.fy_foam_case_info_get(self._h, C.byref(info)))
+        self.start_time, self.end_time, self.delta_t = info.start_time, info.end_time, info.delta_t
+        self.write_interval_steps, self.n_cells = info.write_interval_steps, info.n_cells
+        self.field_cells, self.field_offset = info.field_cells, info.field_offset
+        self.u_name, self.start_name = info.u_name.decode(), info.start_name.decode()
+        m = self.pm
+        arr = lambda ptr, n, dt: np.ctypeslib.as_array(ptr, shape=(n,)).astype(dt) if n else np.zeros(0, dt)
+        nfp = int(m.face_offsets[m.n_faces])
+        self.mesh = dict(points=arr(m.points, 3 * m.n_points, np.float64).reshape(-1, 3), face_offsets=arr(m.face_offsets, m.n_faces + 1, np.int32),
+                         face_points=arr(m.face_points, nfp, np.int32), owner=arr(m.owner, m.n_faces, np.int32), neighbour=arr(m.neighbour, m.n_internal_faces, np.int32),
+                         n_cells=int(m.n_cells), patch_start=arr(m.patch_start, m.n_patches, np.int32), patch_size=arr(m.patch_size, m.n_patches, np.int32))
+        self.patch_names = []
+        for pa in range(m.n_patches):
+            buf = C.create_string_buffer(128)
+            _check(L.fy_foam_case_patch_name(self._h, pa, buf, 128))
+            self.patch_names.append(buf.value.decode())
+        self.u_bc = [int(self.ldu_case.u_bc[q]) for q in range(m.n_patches)]
+        self.p_bc = [int(self.ldu_case.p_bc[q]) for q in range(m.n_patches)]
+        self.u_value = np.array([[self.ldu_case.u_value[3 * q + a] for a in range(3)] for q in range(m.n_patches)])
+        self.p_value = np.array([self.ldu_case.p_value[q] for q in range(m.n_patches)])
+
+    def write(self, solver, time_name):
+        _check(lib().fy_foam_case_write_time_ldu(self._h, solver._h, str(time_name).encode()))
+
+
 class VirtualSlabs:
     """N z-slabs of one block as N Solver objects inside this process (LocalComm back-end, one thread per slab): the test double
     of the one-process-per-GPU RCCL deployment -- identical solver code, only the communicator differs."""
@@ -1000,7 +1043,8 @@ class LduSolver:
     face_offsets, face_points, owner, neighbour, n_cells, patch_start, patch_size (tests/poly_meshes.py builds them); u_bc / p_bc / values per patch; the
     controls are fy_ldu_case's (defaults: the icoFoam cavity tutorial's)"""
 
-    def __init__(self, mesh, dt, nu, u_bc, u_val, p_bc, p_val=None, device=0, transport=None, **controls):
+    @staticmethod
+    def _bind():
         L = lib()
         L.fy_ldu_case_defaults.argtypes = [C.POINTER(LduCase)]; L.fy_ldu_case_defaults.restype = None
         L.fy_ldu_solver_create.argtypes = [C.POINTER(PolyMesh), C.POINTER(LduCase), C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
@@ -1011,6 +1055,10 @@ class LduSolver:
         L.fy_ldu_solver_field_count.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64)]
         L.fy_ldu_solver_read_field_host.argtypes = [C.c_void_p, C.c_char_p, _dp]
         L.fy_ldu_solver_write_field_host.argtypes = [C.c_void_p, C.c_char_p, _dp]
+
+    def __init__(self, mesh, dt, nu, u_bc, u_val, p_bc, p_val=None, device=0, transport=None, **controls):
+        L = lib()
+        self._bind()
         npatch = len(mesh["patch_start"])
         i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
         k = self._keep = dict(points=np.ascontiguousarray(mesh["points"], np.float64), foff=i32(mesh["face_offsets"]), fpts=i32(mesh["face_points"]), own=i32(mesh["owner"]),
@@ -1026,12 +1074,28 @@ class LduSolver:
         for key, v in controls.items():
             setattr(self.case, names.get(key, key), v)
         self.case.u_bc, self.case.u_value, self.case.p_bc, self.case.p_value = _i(k["ub"]), _d(k["uv"]), _i(k["pb"]), _d(k["pv"])
+        self._create(device, transport)
+
+    def _create(self, device, transport):
+        L = lib()
         self._h = C.c_void_p()
         self._tr = transport
         _check(L.fy_ldu_solver_create(C.byref(self.pm), C.byref(self.case), C.byref(transport) if transport is not None else None, int(device), C.byref(self._h)))
         self._cpl = C.c_void_p(L.fy_ldu_solver_coupling(self._h))
-        self.n_cells = int(mesh["n_cells"])
+        self.n_cells = int(self.pm.n_cells)
         self._batch_n = [0]
+
+    @classmethod
+    def from_foam_case(cls, fc, device=0, transport=None):
+        """the solver of a case directory opened with GeneralFoamCase (mesh, controls and patch conditions as read), started from its start-time fields"""
+        self = cls.__new__(cls)
+        cls._bind()
+        self._keep = fc                    # (the structs point into the case object)
+        self.pm, self.case = fc.pm, fc.ldu_case
+        self._create(device, transport)
+        U, p = fc.initial_fields()
+        self.set("U", U); self.set("p", p)
+        return self
 
     def _size(self, name):
         cnt = C.c_int64(0)

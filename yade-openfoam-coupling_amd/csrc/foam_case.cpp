@@ -53,6 +53,14 @@ struct fy_foam_case {
     // constant/polyMesh read instead of blockMeshDict: the mesh's cell numbers may differ from the lattice's (several blocks): file_cell[L] = the mesh's
     // cell at lattice index L = i + nx (j + ny k); empty = the same numbering (one block)
     std::vector<int32_t> file_cell;
+    // A GENERAL polyhedral mesh (fy_foam_case_open_general: whatever createMesh.H would hand icoFoamYade, icoFoamYade.C:42): constant/polyMesh's arrays
+    // as read, every patch of the boundary file in its order, and per patch the conditions fy_ldu_solver takes.  desc then only carries the controls
+    bool general = false;
+    int g_cells = 0, g_internal = 0;
+    std::vector<double> g_points;
+    std::vector<int32_t> g_face_off, g_face_pts, g_own, g_nei, g_patch_start, g_patch_size, g_u_bc, g_p_bc;
+    std::vector<std::string> g_patch_name, g_u_text, g_p_text;
+    std::vector<double> g_u_val, g_p_val;
 };
 
 namespace {
@@ -665,6 +673,126 @@ int read_fields(fy_foam_case* c) {
     return FY_OK;
 }
 
+// constant/polyMesh of ANY mesh, kept in OpenFOAM's own addressing for fy_ldu_solver [OF-6 polyMesh: points, faces (n(p0 .. pn-1) each), owner,
+// neighbour (internal faces first), boundary].  The cell count is not stored in the files: it is the largest owner + 1 [OF-6 polyMesh::initMesh]
+int read_general_mesh(fy_foam_case* c) {
+    const std::string base = join(c->dir, "constant/polyMesh");
+    std::string err;
+    std::vector<double> pts;
+    if (!fy::foam_numeric_list_file(join(base, "points"), &pts, &err)) return fail(err.find("not supported") != std::string::npos ? FY_ERR_UNSUPPORTED : FY_ERR_INVALID, "%s", err.c_str());
+    if (pts.size() < 13 || (pts.size() - 1) % 3 != 0 || (double)((pts.size() - 1) / 3) != pts[0]) return fail(FY_ERR_INVALID, "%s/points: malformed point list", base.c_str());
+    c->g_points.assign(pts.begin() + 1, pts.end());
+    { std::vector<double>().swap(pts); }
+    const size_t npts = c->g_points.size() / 3;
+    std::vector<int32_t> fl;
+    if (!fy::foam_label_list_file(join(base, "faces"), &fl, &err)) return fail(FY_ERR_INVALID, "%s", err.c_str());
+    if (fl.size() < 2 || fl[0] < 4) return fail(FY_ERR_INVALID, "%s/faces: malformed face list", base.c_str());
+    const size_t nfaces = (size_t)fl[0];
+    c->g_face_off.assign(1, 0);
+    c->g_face_off.reserve(nfaces + 1);
+    c->g_face_pts.reserve(fl.size());
+    size_t q = 1;
+    for (size_t f = 0; f < nfaces; ++f) {
+        if (q >= fl.size() || fl[q] < 3 || q + (size_t)fl[q] >= fl.size()) return fail(FY_ERR_INVALID, "%s/faces: face %zu is cut short or has fewer than three points", base.c_str(), f);
+        const int n = fl[q++];
+        for (int m = 0; m < n; ++m, ++q) {
+            if (fl[q] < 0 || (size_t)fl[q] >= npts) return fail(FY_ERR_INVALID, "%s/faces: face %zu names point %d of %zu", base.c_str(), f, fl[q], npts);
+            c->g_face_pts.push_back(fl[q]);
+        }
+        c->g_face_off.push_back((int32_t)c->g_face_pts.size());
+    }
+    if (q != fl.size()) return fail(FY_ERR_INVALID, "%s/faces: %zu labels follow the last of the %zu faces", base.c_str(), fl.size() - q, nfaces);
+    { std::vector<int32_t>().swap(fl); }
+    if (!fy::foam_label_list_file(join(base, "owner"), &c->g_own, &err)) return fail(FY_ERR_INVALID, "%s", err.c_str());
+    if (c->g_own.empty() || (size_t)c->g_own[0] != c->g_own.size() - 1 || c->g_own.size() - 1 != nfaces) return fail(FY_ERR_INVALID, "%s/owner: %zu entries for %zu faces", base.c_str(), c->g_own.size() - 1, nfaces);
+    c->g_own.erase(c->g_own.begin());
+    if (!fy::foam_label_list_file(join(base, "neighbour"), &c->g_nei, &err)) return fail(FY_ERR_INVALID, "%s", err.c_str());
+    if (c->g_nei.empty() || (size_t)c->g_nei[0] != c->g_nei.size() - 1 || c->g_nei.size() - 1 > nfaces) return fail(FY_ERR_INVALID, "%s/neighbour: malformed", base.c_str());
+    c->g_nei.erase(c->g_nei.begin());
+    c->g_internal = (int)c->g_nei.size();
+    int32_t top = -1;
+    for (int32_t v : c->g_own) top = std::max(top, v);
+    c->g_cells = top + 1;
+    std::vector<std::string> tk;
+    if (!fy::foam_list_file_tokens(join(base, "boundary"), &tk, &err)) return fail(FY_ERR_INVALID, "%s", err.c_str());
+    std::vector<std::pair<std::string, FoamDict> > patches;
+    FY_TRY(named_dicts(tk, base + "/boundary", &patches));
+    for (auto& pd : patches) {
+        int nf = 0, sf = 0;
+        std::string ty;
+        pd.second.word("type", &ty);
+        if (!pd.second.integer("nFaces", &nf) || !pd.second.integer("startFace", &sf) || nf < 0 || sf < c->g_internal || (size_t)sf + (size_t)nf > nfaces)
+            return fail(FY_ERR_INVALID, "%s/boundary: patch '%s' needs nFaces and startFace among the boundary faces", base.c_str(), pd.first.c_str());
+        // the patch classes fy_ldu_solver has conditions for: a constraint patch (empty, wedge, cyclic, symmetry, processor) would be silently treated as a wall
+        if (nf > 0 && ty != "wall" && ty != "patch")
+            return fail(FY_ERR_UNSUPPORTED, "%s/boundary: patch '%s' of type '%s' is not supported on a general mesh (wall, patch)", base.c_str(), pd.first.c_str(), ty.c_str());
+        c->g_patch_name.push_back(pd.first);
+        c->g_patch_start.push_back(sf);
+        c->g_patch_size.push_back(nf);
+    }
+    if (c->g_patch_name.empty()) return fail(FY_ERR_INVALID, "%s/boundary: no patches", base.c_str());
+    c->patch_order = c->g_patch_name;
+    return FY_OK;
+}
+
+// <startTime>/U and p of a general mesh: one entry per patch, the types fy_ldu_solver takes (fixedValue / noSlip / zeroGradient; zeroGradient / fixedValue)
+int read_general_fields(fy_foam_case* c) {
+    const size_t ncell = (size_t)c->g_cells, np = c->g_patch_name.size();
+    c->g_u_bc.assign(np, FY_BC_U_FIXED_VALUE); c->g_p_bc.assign(np, FY_BC_P_ZERO_GRADIENT);
+    c->g_u_val.assign(3 * np, 0.0); c->g_p_val.assign(np, 0.0);
+    c->g_u_text.assign(np, std::string()); c->g_p_text.assign(np, std::string());
+    for (int which = 0; which < 2; ++which) {
+        const std::string path = join(c->fdir, c->start_name + "/" + (which ? std::string("p") : c->u_name));
+        FoamDict f;
+        FY_TRY(need_file(path, &f));
+        FY_TRY(read_internal(f, path, which ? 1 : 3, ncell, which ? &c->p0 : &c->U0));
+        const FoamDict* bf = f.subdict("boundaryField");
+        if (!bf) return fail(FY_ERR_INVALID, "%s: no boundaryField", path.c_str());
+        for (size_t pa = 0; pa < np; ++pa) {
+            const char* pn = c->g_patch_name[pa].c_str();
+            const FoamDict* pd = bf->subdict(c->g_patch_name[pa]);
+            std::string ty;
+            if (!pd || !pd->word("type", &ty)) return fail(FY_ERR_INVALID, "%s: boundaryField has no (typed) entry for patch '%s'", path.c_str(), pn);
+            (which ? c->g_p_text : c->g_u_text)[pa] = entry_text(*pd);
+            const auto* vt = pd->tokens("value");
+            if (!which) {
+                if (ty == "fixedValue") {
+                    if (!vt || vt->empty() || (*vt)[0] != "uniform" || !pd->vector3("value", &c->g_u_val[3 * pa]))
+                        return fail(FY_ERR_UNSUPPORTED, "%s: patch '%s': fixedValue needs 'value uniform (x y z)'", path.c_str(), pn);
+                } else if (ty == "zeroGradient") c->g_u_bc[pa] = FY_BC_U_ZERO_GRADIENT;
+                else if (ty != "noSlip") return fail(FY_ERR_UNSUPPORTED, "%s: patch '%s': velocity boundary type '%s' is not supported on a general mesh (fixedValue, noSlip, zeroGradient)", path.c_str(), pn, ty.c_str());
+            } else {
+                if (ty == "fixedValue") {
+                    c->g_p_bc[pa] = FY_BC_P_FIXED_VALUE;
+                    if (!vt || vt->size() < 2 || (*vt)[0] != "uniform" || !fy::foam_tok_is_number((*vt)[1], &c->g_p_val[pa]))
+                        return fail(FY_ERR_UNSUPPORTED, "%s: patch '%s': fixedValue needs 'value uniform <p>'", path.c_str(), pn);
+                } else if (ty != "zeroGradient") return fail(FY_ERR_UNSUPPORTED, "%s: patch '%s': pressure boundary type '%s' is not supported on a general mesh (zeroGradient, fixedValue)", path.c_str(), pn, ty.c_str());
+            }
+        }
+    }
+    return FY_OK;
+}
+
+// what fy_ldu_solver discretises with (include/foamyade_hip.h): Gauss linear convection, Gauss linear corrected laplacian, corrected snGrad.  read_controls
+// has refused everything the lattice solver cannot do; on a general mesh "orthogonal" / "uncorrected" are different schemes, and so are the upwinded ones
+int check_general_schemes(const fy_foam_case* c) {
+    const std::string path = join(c->dir, "system/fvSchemes");
+    FoamDict d;
+    FY_TRY(need_file(path, &d));
+    if (c->desc.convection_scheme != FY_CONVECTION_LINEAR) return fail(FY_ERR_UNSUPPORTED, "%s: on a general mesh div(phi,U) must be Gauss linear", path.c_str());
+    for (const char* dn : {"laplacianSchemes", "snGradSchemes"}) {
+        const FoamDict* sd = d.subdict(dn);
+        for (const std::string& k : sd->order) {
+            const auto* tk = sd->tokens(k);
+            if (!tk) continue;
+            bool corrected = false;
+            for (const std::string& t : *tk) corrected = corrected || t == "corrected";
+            if (!corrected) return fail(FY_ERR_UNSUPPORTED, "%s: %s.%s: on a general mesh the scheme must be 'corrected' (the full non-orthogonal correction, icoFoamYade.C:114-131)", path.c_str(), dn, k.c_str());
+        }
+    }
+    return FY_OK;
+}
+
 int read_controls(fy_foam_case* c) {
     {
         const std::string path = join(c->dir, "system/controlDict");
@@ -971,7 +1099,11 @@ int write_field(const fy_foam_case* c, const std::string& tdir, const std::strin
         }
     }
     std::fprintf(f, ")\n;\n\nboundaryField\n{\n");
-    for (const std::string& pn : c->patch_order) {
+    if (c->general) {
+        const std::vector<std::string>& tx = ncomp == 3 ? c->g_u_text : c->g_p_text;
+        for (size_t pa = 0; pa < c->g_patch_name.size(); ++pa) std::fprintf(f, "    %s\n    {\n%s    }\n", c->g_patch_name[pa].c_str(), tx[pa].empty() ? default_bc : tx[pa].c_str());
+    }
+    for (const std::string& pn : c->general ? std::vector<std::string>() : c->patch_order) {
         int side = -1;
         for (int s = 0; s < 6; ++s) if (c->patch_of_side[s] == pn) side = s;
         std::fprintf(f, "    %s\n    {\n%s    }\n", pn.c_str(), (bc_text && side >= 0 && !bc_text[side].empty()) ? bc_text[side].c_str() : default_bc);
@@ -1040,6 +1172,7 @@ int fy_foam_case_open_processor(const char* case_dir, int solver, int rank, int 
 
 int fy_foam_case_desc(const fy_foam_case* c, fy_case_desc* out) {
     if (!c || !out) return fail(FY_ERR_INVALID, "fy_foam_case_desc: null argument");
+    if (c->general) return fail(FY_ERR_UNSUPPORTED, "fy_foam_case_desc: the case holds a general mesh: fy_foam_case_poly_mesh + fy_foam_case_ldu_desc for fy_ldu_solver_create");
     *out = c->desc;
     return FY_OK;
 }
@@ -1049,7 +1182,7 @@ int fy_foam_case_info_get(const fy_foam_case* c, fy_foam_case_info* out) {
     std::memset(out, 0, sizeof(*out));
     out->start_time = c->start_time; out->end_time = c->end_time; out->delta_t = c->desc.dt;
     out->write_interval_steps = c->write_interval_steps;
-    out->n_cells = (int64_t)c->desc.nx * c->desc.ny * c->desc.nz;
+    out->n_cells = c->general ? (int64_t)c->g_cells : (int64_t)c->desc.nx * c->desc.ny * c->desc.nz;
     out->field_cells = (int64_t)c->fcells; out->field_offset = (int64_t)c->foffset;
     std::snprintf(out->u_name, sizeof(out->u_name), "%s", c->u_name.c_str());
     std::snprintf(out->phase, sizeof(out->phase), "%s", c->phase.c_str());
@@ -1151,6 +1284,69 @@ int fy_foam_case_write_time(const fy_foam_case* c, fy_solver* s, const char* tim
     if (c->desc.turbulence_model == FY_TURBULENCE_KEQN || c->desc.turbulence_model == FY_TURBULENCE_KEPSILON) { kk.resize(n); FY_TRY(fy_solver_read_field_host(s, "k", kk.data())); }
     return fy_foam_case_write_fields(c, time_name, U.data(), p.data(), a.empty() ? nullptr : a.data(), nt.empty() ? nullptr : nt.data(), kk.empty() ? nullptr : kk.data(),
                                      ee.empty() ? nullptr : ee.data());
+}
+
+int fy_foam_case_open_general(const char* case_dir, fy_foam_case** out) {
+    if (!case_dir || !out) return fail(FY_ERR_INVALID, "fy_foam_case_open_general: null argument");
+    *out = nullptr;
+    fy_foam_case* c = new (std::nothrow) fy_foam_case();
+    if (!c) return fail(FY_ERR_INVALID, "out of host memory");
+    c->dir = case_dir; c->fdir = c->dir; c->solver = FY_SOLVER_ICO; c->general = true;
+    fy_case_defaults(&c->desc, FY_SOLVER_ICO);
+    int rc = read_general_mesh(c);
+    if (rc == FY_OK) { c->fcells = (size_t)c->g_cells; rc = read_controls(c); }
+    if (rc == FY_OK) rc = check_general_schemes(c);
+    if (rc == FY_OK) rc = read_general_fields(c);
+    if (rc != FY_OK) { delete c; return rc; }
+    *out = c;
+    return FY_OK;
+}
+
+int fy_foam_case_poly_mesh(const fy_foam_case* c, fy_poly_mesh* out) {
+    if (!c || !out) return fail(FY_ERR_INVALID, "fy_foam_case_poly_mesh: null argument");
+    if (!c->general) return fail(FY_ERR_INVALID, "fy_foam_case_poly_mesh: the case was opened as a block (fy_foam_case_open): use fy_foam_case_desc, or open it with fy_foam_case_open_general");
+    std::memset(out, 0, sizeof(*out));
+    out->n_points = (int32_t)(c->g_points.size() / 3); out->points = c->g_points.data();
+    out->n_faces = (int32_t)c->g_own.size(); out->n_internal_faces = c->g_internal;
+    out->face_offsets = c->g_face_off.data(); out->face_points = c->g_face_pts.data();
+    out->owner = c->g_own.data(); out->neighbour = c->g_nei.data();
+    out->n_cells = c->g_cells;
+    out->n_patches = (int32_t)c->g_patch_name.size(); out->patch_start = c->g_patch_start.data(); out->patch_size = c->g_patch_size.data();
+    return FY_OK;
+}
+
+int fy_foam_case_ldu_desc(const fy_foam_case* c, fy_ldu_case* out) {
+    if (!c || !out) return fail(FY_ERR_INVALID, "fy_foam_case_ldu_desc: null argument");
+    if (!c->general) return fail(FY_ERR_INVALID, "fy_foam_case_ldu_desc: the case was opened as a block (fy_foam_case_open)");
+    fy_ldu_case_defaults(out);
+    const fy_case_desc& d = c->desc;
+    out->dt = d.dt; out->nu = d.nu; out->rho_fluid = d.rho_fluid; out->rho_particle = d.rho_particle;
+    out->n_correctors = d.n_correctors; out->n_non_orth_correctors = d.n_non_orth_correctors; out->momentum_predictor = d.momentum_predictor;
+    out->p_ref_cell = d.p_ref_cell; out->p_ref_value = d.p_ref_value;
+    out->p_tol = d.p_tol; out->p_rel_tol = d.p_rel_tol; out->p_final_tol = d.p_final_tol; out->p_final_rel_tol = d.p_final_rel_tol; out->p_max_iter = d.p_max_iter;
+    out->u_tol = d.u_tol; out->u_rel_tol = d.u_rel_tol; out->u_max_iter = d.u_max_iter;
+    out->u_bc = c->g_u_bc.data(); out->u_value = c->g_u_val.data(); out->p_bc = c->g_p_bc.data(); out->p_value = c->g_p_val.data();
+    return FY_OK;
+}
+
+int fy_foam_case_patch_name(const fy_foam_case* c, int patch, char* out, int cap) {
+    if (!c || !out || cap < 1) return fail(FY_ERR_INVALID, "fy_foam_case_patch_name: null argument");
+    const std::vector<std::string>& names = c->general ? c->g_patch_name : c->patch_order;
+    if (patch < 0 || (size_t)patch >= names.size()) return fail(FY_ERR_INVALID, "fy_foam_case_patch_name: patch %d of %zu", patch, names.size());
+    std::snprintf(out, (size_t)cap, "%s", names[(size_t)patch].c_str());
+    return FY_OK;
+}
+
+int fy_foam_case_write_time_ldu(const fy_foam_case* c, fy_ldu_solver* s, const char* time_name) {
+    if (!c || !s || !time_name || !*time_name) return fail(FY_ERR_INVALID, "fy_foam_case_write_time_ldu: null argument");
+    if (!c->general) return fail(FY_ERR_INVALID, "fy_foam_case_write_time_ldu: the case was opened as a block (fy_foam_case_open)");
+    int64_t cnt = 0;
+    FY_TRY(fy_ldu_solver_field_count(s, "p", &cnt));
+    if ((size_t)cnt != c->fcells) return fail(FY_ERR_INVALID, "fy_foam_case_write_time_ldu: the solver holds %lld cells, the case %zu", (long long)cnt, c->fcells);
+    std::vector<double> U(3 * c->fcells), p(c->fcells);
+    FY_TRY(fy_ldu_solver_read_field_host(s, "U", U.data()));
+    FY_TRY(fy_ldu_solver_read_field_host(s, "p", p.data()));
+    return fy_foam_case_write_fields(c, time_name, U.data(), p.data(), nullptr, nullptr, nullptr, nullptr);
 }
 
 int fy_foam_case_close(fy_foam_case* c) {

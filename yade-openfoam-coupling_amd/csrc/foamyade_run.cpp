@@ -37,6 +37,40 @@ static int die(const char* what) {
     return 1;
 }
 
+// icoFoamYade on a general mesh: the same loop around fy_ldu_solver (one domain)
+static int run_general(fy_foam_case* fc, const fy_transport* trp, int device) {
+    fy_poly_mesh pm;
+    fy_ldu_case lc;
+    fy_foam_case_info info;
+    if (fy_foam_case_poly_mesh(fc, &pm) != FY_OK || fy_foam_case_ldu_desc(fc, &lc) != FY_OK || fy_foam_case_info_get(fc, &info) != FY_OK) return die("reading the case");
+    std::printf("             %d points, %d faces (%d internal), %d cells, %d patches\n", pm.n_points, pm.n_faces, pm.n_internal_faces, pm.n_cells, pm.n_patches);
+    fy_ldu_solver* s = nullptr;
+    if (fy_ldu_solver_create(&pm, &lc, trp, device, &s) != FY_OK) return die("fy_ldu_solver_create");
+    {
+        std::vector<double> U(3 * (size_t)info.n_cells), p((size_t)info.n_cells);
+        fy_foam_case_initial_fields(fc, U.data(), p.data());
+        if (fy_ldu_solver_write_field_host(s, "p", p.data()) != FY_OK || fy_ldu_solver_write_field_host(s, "U", U.data()) != FY_OK) return die("initial fields");
+    }
+    std::printf("\nStarting time loop\n\n");
+    const long n_steps = std::lround((info.end_time - info.start_time) / info.delta_t);
+    for (long k = 1; k <= n_steps; ++k) {
+        if (fy_ldu_solver_step(s) != FY_OK) return die("fy_ldu_solver_step");
+        fy_step_stats st;
+        fy_ldu_solver_get_stats(s, &st);
+        char tname[64];
+        std::snprintf(tname, sizeof(tname), "%.12g", info.start_time + (double)k * info.delta_t);
+        std::printf("Time = %s\n\nCourant Number mean: %g max: %g\n", tname, st.courant_mean, st.courant_max);
+        std::printf("pressure: %d solves, %d iterations, initial residual %g, final residual %g\n", st.p_solves, st.p_iters_total, st.p_initial_residual, st.p_final_residual);
+        std::printf("time step continuity errors : sum local = %g, global = %g, cumulative = %g\n\n", st.cont_err_sum_local, st.cont_err_global, st.cont_err_cumulative);
+        if (info.write_interval_steps > 0 && k % info.write_interval_steps == 0)
+            if (fy_foam_case_write_time_ldu(fc, s, tname) != FY_OK) return die("writing the time directory");
+    }
+    std::printf("End\n");
+    fy_ldu_solver_destroy(s);
+    fy_foam_case_close(fc);
+    return 0;
+}
+
 int main(int argc, char** argv) {
     std::string dir = ".", solver_name;
     int device = -1, n_yade_arg = -1;
@@ -119,7 +153,21 @@ int main(int argc, char** argv) {
     fy_foam_case* fc = nullptr;
     bool decomposed = false;
     if (ssize > 1) { struct stat sb; decomposed = stat((dir + "/processor0").c_str(), &sb) == 0 && S_ISDIR(sb.st_mode); }
-    if ((decomposed ? fy_foam_case_open_processor(dir.c_str(), solver, srank, ssize, &fc) : fy_foam_case_open(dir.c_str(), solver, &fc)) != FY_OK) return die("reading the case");
+    int open_rc = decomposed ? fy_foam_case_open_processor(dir.c_str(), solver, srank, ssize, &fc) : fy_foam_case_open(dir.c_str(), solver, &fc);
+    if (open_rc == FY_ERR_UNSUPPORTED && solver == FY_SOLVER_ICO && ssize == 1) {
+        // not the block fy_solver computes on: icoFoamYade on the mesh as it is (owner / neighbour addressing, non-orthogonal correctors)
+        const std::string why = fy_last_error();
+        if (fy_foam_case_open_general(dir.c_str(), &fc) == FY_OK) {
+            std::printf("Create mesh: general polyhedral mesh (the block reader said: %s)\n", why.c_str());
+            const int rc = run_general(fc, trp, device);
+#ifdef FY_WITH_MPI
+            if (trp) fy_mpi_transport_destroy(&tr);
+            MPI_Finalize();
+#endif
+            return rc;
+        }
+    }
+    if (open_rc != FY_OK) return die("reading the case");
     if (master && ssize > 1) std::printf("Case: %s\n", decomposed ? "decomposed (processor directories)" : "undecomposed (gathered on write)");
     fy_case_desc cd;
     fy_foam_case_info info;
