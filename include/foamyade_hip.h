@@ -473,6 +473,8 @@ typedef struct fy_ldu_case {
     double p_ref_value;
     double p_tol, p_rel_tol, p_final_tol, p_final_rel_tol; int32_t p_max_iter;
     double u_tol, u_rel_tol; int32_t u_max_iter;
+    int32_t p_solver;                /* FY_PSOLVER_PCG_JACOBI: PCG.C with the diagonal preconditioner | FY_PSOLVER_PCG_MG: preconditioned by an agglomeration
+                                        multigrid V-cycle (fvSolution: solver / preconditioner GAMG) built from the face areas like faceAreaPair */
     const int32_t* u_bc;             /* per patch: FY_BC_U_FIXED_VALUE | FY_BC_U_ZERO_GRADIENT */
     const double* u_value;           /* [n_patches][3] */
     const int32_t* p_bc;             /* per patch: FY_BC_P_ZERO_GRADIENT | FY_BC_P_FIXED_VALUE */
@@ -489,6 +491,9 @@ fy_ctx* fy_ldu_solver_coupling(fy_ldu_solver*);                              /* 
 int fy_ldu_solver_field_count(fy_ldu_solver*, const char* name, int64_t* count);
 int fy_ldu_solver_read_field_host(fy_ldu_solver*, const char* name, double* out);
 int fy_ldu_solver_write_field_host(fy_ldu_solver*, const char* name, const double* in);
+/* the pressure equation's operators as the last step left them, on host vectors of n_cells: "p_matrix" out = A in, "p_precondition" out = M^-1 in
+ * (the V-cycle, or the diagonal) -- for tests of the solver's algebra (symmetry, definiteness, the cycle's contraction) */
+int fy_ldu_solver_apply(fy_ldu_solver*, const char* op, const double* in, double* out);
 int fy_ldu_solver_destroy(fy_ldu_solver*);
 
 /* An OpenFOAM case directory whose constant/polyMesh is ANY mesh of wall / patch boundaries (ASCII), for icoFoamYade: what createMesh.H +

@@ -134,3 +134,49 @@ def test_point_force_coupling_on_a_general_mesh(product):
         drag = 3 * np.pi * dia * nu * rho * (U0[c] - rec[i, 3:6])
         np.testing.assert_allclose(F[i, 0:3], drag, rtol=1e-10, atol=1e-16)
     s.close()
+
+
+@pytest.mark.parametrize("kind", ["wavy", "prisms", "sheared_renumbered"])
+def test_multigrid_preconditioned_pcg_solves_the_same_equations(product, oracle, kind):
+    """p_solver = FY_PSOLVER_PCG_MG (fvSolution: GAMG): the agglomeration V-cycle changes the path to the solution, not the solution -- with the linear
+    systems converged to 1e-10 the fields equal the restatement's (which runs PCG with the diagonal preconditioner), in far fewer iterations"""
+    n = 12
+    if kind == "prisms":
+        mesh = pm.prism_block(n, n, 8, vertex_map=pm.wavy(0.02))
+    else:
+        mesh = pm.hex_block(n, n, n, vertex_map=pm.wavy(0.03) if kind == "wavy" else pm.shear(0.3, 0.1, 0.2), renumber_seed=None if kind == "wavy" else 21)
+    kw = dict(n_non_orth=1, p_tol=1e-10, p_rel_tol=0.0, p_final_tol=1e-10, u_tol=1e-10, p_max_iter=5000)
+    h = product.LduSolver(mesh, 0.4 / n, 0.01, [0] * 6, lid(), [0] * 6, p_solver=product.FY_PSOLVER_PCG_MG, **kw)
+    o = oracle.LduSolver(mesh, 0.4 / n, 0.01, [0] * 6, lid(), [0] * 6, **kw)
+    ih = io = 0
+    for _ in range(3):
+        h.step(); o.step()
+        ih += h.stats()["p_iters_total"]; io += o.stats()["p_iters_total"]
+    assert ih * 4 < io, (ih, io)
+    close(h.get("U"), o.get("U"), 1e-7, "U")
+    ph, po = h.get("p"), o.get("p")
+    close(ph - ph.mean(), po - po.mean(), 1e-6, "p")
+    h.close(); o.close()
+
+
+def test_the_vcycle_is_a_symmetric_positive_definite_contraction(product):
+    """what PCG needs of its preconditioner: (M^-1 a).b = (M^-1 b).a, a.M^-1 a > 0; and what makes it worth its cost: the error of one cycle,
+    e - M^-1 A e, is a fraction of e in the energy norm for smooth and for rough e alike"""
+    n = 16
+    mesh = pm.hex_block(n, n, n, vertex_map=pm.wavy(0.03), renumber_seed=None)
+    h = product.LduSolver(mesh, 0.4 / n, 0.01, [0] * 6, lid(), [0] * 6, p_solver=product.FY_PSOLVER_PCG_MG, n_non_orth=1)
+    h.step()
+    rs = np.random.RandomState(8)
+    a, b = rs.standard_normal(n ** 3), rs.standard_normal(n ** 3)
+    Ma, Mb = h.apply("p_precondition", a), h.apply("p_precondition", b)
+    assert abs(Ma @ b - Mb @ a) <= 1e-12 * (np.abs(Ma) @ np.abs(b)) and Ma @ a > 0 and Mb @ b > 0
+    Aa, Ab = h.apply("p_matrix", a), h.apply("p_matrix", b)
+    assert abs(Aa @ b - Ab @ a) <= 1e-12 * (np.abs(Aa) @ np.abs(b)) and Aa @ a > 0
+    C = h.geometry("C")
+    smooth = np.cos(np.pi * C[:, 0]) * np.cos(np.pi * C[:, 1]) * np.cos(2 * np.pi * C[:, 2])
+    for e in (smooth, a):
+        Ae = h.apply("p_matrix", e)
+        e1 = e - h.apply("p_precondition", Ae)
+        ratio = np.sqrt((e1 @ h.apply("p_matrix", e1)) / (e @ Ae))
+        assert ratio < 0.6, ratio
+    h.close()

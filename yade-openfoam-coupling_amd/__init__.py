@@ -86,7 +86,8 @@ class LduCase(C.Structure):
     _fields_ = [("dt", C.c_double), ("nu", C.c_double), ("rho_fluid", C.c_double), ("rho_particle", C.c_double), ("n_correctors", C.c_int32),
                 ("n_non_orth_correctors", C.c_int32), ("momentum_predictor", C.c_int32), ("p_ref_cell", C.c_int32), ("p_ref_value", C.c_double),
                 ("p_tol", C.c_double), ("p_rel_tol", C.c_double), ("p_final_tol", C.c_double), ("p_final_rel_tol", C.c_double), ("p_max_iter", C.c_int32),
-                ("u_tol", C.c_double), ("u_rel_tol", C.c_double), ("u_max_iter", C.c_int32), ("u_bc", _ip), ("u_value", _dp), ("p_bc", _ip), ("p_value", _dp)]
+                ("u_tol", C.c_double), ("u_rel_tol", C.c_double), ("u_max_iter", C.c_int32), ("p_solver", C.c_int32), ("u_bc", _ip), ("u_value", _dp), ("p_bc", _ip),
+                ("p_value", _dp)]
 
 
 class ParticleTimings(C.Structure):
@@ -1113,6 +1114,15 @@ class LduSolver:
         arr = np.ascontiguousarray(arr, dtype=np.float64).ravel()
         assert arr.size == self._size(name)
         _check(lib().fy_ldu_solver_write_field_host(self._h, name.encode(), _d(arr)))
+
+    def apply(self, op, x):
+        """"p_matrix": A x; "p_precondition": M^-1 x -- the pressure equation's operators as the last step left them"""
+        L = lib()
+        L.fy_ldu_solver_apply.argtypes = [C.c_void_p, C.c_char_p, _dp, _dp]
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        out = np.zeros(self.n_cells)
+        _check(L.fy_ldu_solver_apply(self._h, op.encode(), _d(x), _d(out)))
+        return out
 
     def set_particles(self, records):
         L = lib()

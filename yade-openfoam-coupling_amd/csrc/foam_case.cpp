@@ -1324,7 +1324,7 @@ int fy_foam_case_ldu_desc(const fy_foam_case* c, fy_ldu_case* out) {
     out->n_correctors = d.n_correctors; out->n_non_orth_correctors = d.n_non_orth_correctors; out->momentum_predictor = d.momentum_predictor;
     out->p_ref_cell = d.p_ref_cell; out->p_ref_value = d.p_ref_value;
     out->p_tol = d.p_tol; out->p_rel_tol = d.p_rel_tol; out->p_final_tol = d.p_final_tol; out->p_final_rel_tol = d.p_final_rel_tol; out->p_max_iter = d.p_max_iter;
-    out->u_tol = d.u_tol; out->u_rel_tol = d.u_rel_tol; out->u_max_iter = d.u_max_iter;
+    out->u_tol = d.u_tol; out->u_rel_tol = d.u_rel_tol; out->u_max_iter = d.u_max_iter; out->p_solver = d.p_solver;
     out->u_bc = c->g_u_bc.data(); out->u_value = c->g_u_val.data(); out->p_bc = c->g_p_bc.data(); out->p_value = c->g_p_val.data();
     return FY_OK;
 }

@@ -12,6 +12,7 @@
 #include "coupling.hpp"
 #include "fv_kernels.hpp"
 #include "ldu.hpp"
+#include "ldu_amg.hpp"
 
 namespace fy {
 
@@ -32,6 +33,7 @@ struct LduSolver {
     DevBuf<double> partials, sc, xsum, adj;
     DevBuf<int> adj_err;
     bool need_ref = true, ext_source = false;
+    LduAmg amg;                  // the pressure matrix in ELL form; with p_solver = FY_PSOLVER_PCG_MG also the agglomeration hierarchy
     fy_step_stats st{};
     double cumulative = 0.0, total_volume = 0.0;
     EventTimer tim[2];
@@ -66,6 +68,7 @@ struct LduSolver {
             if (pbc[(size_t)pa] == FY_BC_P_FIXED_VALUE) need_ref = false;
         }
         if (need_ref && (c->p_ref_cell < 0 || c->p_ref_cell >= nc)) return fail(FY_ERR_INVALID, "fy_ldu_solver: pRefCell out of range");
+        if (c->p_solver != FY_PSOLVER_PCG_JACOBI && c->p_solver != FY_PSOLVER_PCG_MG) return fail(FY_ERR_INVALID, "fy_ldu_solver: p_solver %d (FY_PSOLVER_PCG_JACOBI, FY_PSOLVER_PCG_MG)", c->p_solver);
         cs.u_bc = nullptr; cs.u_value = nullptr; cs.p_bc = nullptr; cs.p_value = nullptr;      // (copied; the caller's arrays are not kept)
         FY_HIP(hipSetDevice(device));
         FY_HIP(hipStreamCreate(&stream));
@@ -91,6 +94,7 @@ struct LduSolver {
         FY_TRY(sc.alloc_exact(8)); FY_TRY(zero(sc)); FY_TRY(xsum.alloc_exact(4)); FY_TRY(zero(xsum)); FY_TRY(adj.alloc_exact(4)); FY_TRY(zero(adj));
         FY_TRY(adj_err.alloc_exact(1)); FY_HIP(hipMemsetAsync(adj_err.p, 0, sizeof(int), stream));
         for (auto& t : tim) FY_TRY(t.init());
+        FY_TRY(amg.build(stream, nc, ni, hm.own.data(), hm.nei.data(), hm.cf_off, hm.cf_face, hm.magSf.data(), need_ref ? cs.p_ref_cell : -1, cs.p_solver == FY_PSOLVER_PCG_MG));
         // the coupling object on this mesh (icoFoamYade.C:54: point force): its tree over the cell centres, its fields the solver's device arrays
         {
             fy_mesh_desc md{};
@@ -165,7 +169,11 @@ struct LduSolver {
         int it = 0;
         if (!converged(res)) {
             do {
-                FY_TRY(launch_ldu_p_apply_dot(stream, g, pdiag.p, pcoef.p, pr.p, pu.p, pw.p, partials.p));       // u = r / diag, w = A u; gamma, delta
+                if (amg.has_hierarchy()) FY_TRY(amg.vcycle(stream, pr.p, pu.p));                                  // u = M^-1 r
+                else FY_TRY(launch_ell_jacobi(stream, nc, pdiag.p, pr.p, pu.p));
+                EllMat A = amg.lev[0]->mat();
+                A.diag = pdiag.p;
+                FY_TRY(launch_ell_apply_dot(stream, A, pu.p, pr.p, pw.p, partials.p));                            // w = A u; gamma = u.r, delta = u.w
                 FY_TRY(launch_reduce_finalize(stream, partials.p, nc, 2, nullptr, sc.p, nullptr, 0));
                 FY_TRY(launch_pcg_cg_update(stream, nc, 0, pu.p, pw.p, pp.p, ps.p, p.p, pr.p, sc.p, it, partials.p));
                 if (it == 0) { std::swap(pp.p, pu.p); std::swap(ps.p, pw.p); }      // p = u, s = w without a pass
@@ -187,6 +195,7 @@ struct LduSolver {
         for (int no = 0; no <= cs.n_non_orth_correctors; ++no) {                                                   // :114-131
             FY_TRY(launch_ldu_grad_scalar(stream, g, p.p, gradp.p));
             FY_TRY(launch_ldu_assemble_pressure(stream, g, rAUf.p, phiHbyA.p, gradp.p, pcoef.p, pcorr.p, pdiag.p, prhs.p));
+            if (no == 0) FY_TRY(amg.setup(stream, pcoef.p, pdiag.p));          // (the non-orthogonal passes renew the right-hand side only)
             FY_TRY(solve_pressure(final_corr && no == cs.n_non_orth_correctors));
             if (no == cs.n_non_orth_correctors) FY_TRY(launch_ldu_flux_correct(stream, g, p.p, phiHbyA.p, pcoef.p, pcorr.p, phi.p));
         }
@@ -265,6 +274,7 @@ void fy_ldu_case_defaults(fy_ldu_case* c) {
     c->n_correctors = 2; c->n_non_orth_correctors = 0; c->momentum_predictor = 1; c->p_ref_cell = 0; c->p_ref_value = 0.0;
     c->p_tol = 1e-6; c->p_rel_tol = 0.05; c->p_final_tol = 1e-6; c->p_final_rel_tol = 0.0; c->p_max_iter = 1000;
     c->u_tol = 1e-5; c->u_rel_tol = 0.0; c->u_max_iter = 1000;
+    c->p_solver = FY_PSOLVER_PCG_JACOBI;
 }
 
 int fy_ldu_solver_create(const fy_poly_mesh* m, const fy_ldu_case* c, const fy_transport* tr, int device_ordinal, fy_ldu_solver** out) {
@@ -310,6 +320,27 @@ int fy_ldu_solver_write_field_host(fy_ldu_solver* s, const char* name, const dou
     if (nm == "uSource") s->s.ext_source = true;
     if (nm == "U") FY_TRY(fy::launch_ldu_flux_of(s->s.stream, s->s.g, s->s.U.p, s->s.phi.p));      // createPhi
     FY_HIP(hipStreamSynchronize(s->s.stream));
+    return FY_OK;
+}
+int fy_ldu_solver_apply(fy_ldu_solver* s, const char* op, const double* in, double* out) {
+    FY_LS(s);
+    if (!op || !in || !out) return fy::fail(FY_ERR_INVALID, "fy_ldu_solver_apply: null argument");
+    fy::LduSolver& S = s->s;
+    const std::string o = op;
+    const bool mat = o == "p_matrix", pre = o == "p_precondition";
+    if (!mat && !pre) return fy::fail(FY_ERR_INVALID, "fy_ldu_solver_apply: unknown operator '%s' (p_matrix, p_precondition)", op);
+    if (!S.amg.diag0_) return fy::fail(FY_ERR_INVALID, "fy_ldu_solver_apply: no pressure matrix yet (step first)");
+    FY_HIP(hipSetDevice(S.device));
+    const size_t bytes = (size_t)S.nc * sizeof(double);
+    FY_HIP(hipMemcpyAsync(S.pr.p, in, bytes, hipMemcpyHostToDevice, S.stream));
+    if (mat) {
+        fy::EllMat A = S.amg.lev[0]->mat();
+        A.diag = S.pdiag.p;
+        FY_TRY(fy::launch_ell_apply_dot(S.stream, A, S.pr.p, S.pr.p, S.pw.p, S.partials.p));
+    } else if (S.amg.has_hierarchy()) FY_TRY(S.amg.vcycle(S.stream, S.pr.p, S.pw.p));
+    else FY_TRY(fy::launch_ell_jacobi(S.stream, S.nc, S.pdiag.p, S.pr.p, S.pw.p));
+    FY_HIP(hipMemcpyAsync(out, S.pw.p, bytes, hipMemcpyDeviceToHost, S.stream));
+    FY_HIP(hipStreamSynchronize(S.stream));
     return FY_OK;
 }
 int fy_ldu_solver_destroy(fy_ldu_solver* s) { delete s; return FY_OK; }
