@@ -494,6 +494,8 @@ int fy_ldu_solver_write_field_host(fy_ldu_solver*, const char* name, const doubl
 /* the pressure equation's operators as the last step left them, on host vectors of n_cells: "p_matrix" out = A in, "p_precondition" out = M^-1 in
  * (the V-cycle, or the diagonal) -- for tests of the solver's algebra (symmetry, definiteness, the cycle's contraction) */
 int fy_ldu_solver_apply(fy_ldu_solver*, const char* op, const double* in, double* out);
+/* the multigrid hierarchy of FY_PSOLVER_PCG_MG: cells and matrix slots (neighbours per row, padded) per level, finest first; n_levels = 0 without one */
+int fy_ldu_solver_mg_levels(fy_ldu_solver*, int cap, int32_t* cells, int32_t* slots, int* n_levels);
 int fy_ldu_solver_destroy(fy_ldu_solver*);
 
 /* An OpenFOAM case directory whose constant/polyMesh is ANY mesh of wall / patch boundaries (ASCII), for icoFoamYade: what createMesh.H +

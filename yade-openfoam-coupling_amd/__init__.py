@@ -1115,6 +1115,14 @@ class LduSolver:
         assert arr.size == self._size(name)
         _check(lib().fy_ldu_solver_write_field_host(self._h, name.encode(), _d(arr)))
 
+    def mg_levels(self):
+        """[(cells, slots)] of the multigrid hierarchy, finest first ([] with the diagonal preconditioner)"""
+        L = lib()
+        L.fy_ldu_solver_mg_levels.argtypes = [C.c_void_p, C.c_int, _ip, _ip, C.POINTER(C.c_int)]
+        cells = np.zeros(32, np.int32); slots = np.zeros(32, np.int32); n = C.c_int(0)
+        _check(L.fy_ldu_solver_mg_levels(self._h, 32, _i(cells), _i(slots), C.byref(n)))
+        return [(int(cells[q]), int(slots[q])) for q in range(n.value)]
+
     def apply(self, op, x):
         """"p_matrix": A x; "p_precondition": M^-1 x -- the pressure equation's operators as the last step left them"""
         L = lib()

@@ -52,7 +52,7 @@ int launch_ldu_assemble_momentum(hipStream_t s, LduGeo g, const double* phi, con
 int launch_ldu_mom_pass(hipStream_t s, LduGeo g, LduMom M, const double* gradp, const double* x, double* xn, const double* xsum3, double* partials);
 int launch_ldu_HbyA(hipStream_t s, LduGeo g, LduMom M, const double* U, double* rAU, double* HbyA);
 int launch_ldu_phiHbyA(hipStream_t s, LduGeo g, const double* HbyA, const double* rAU, const double* Uold, const double* phiOld, double* rAUf, double* phiHbyA);
-int launch_ldu_adjust_phi(hipStream_t s, LduGeo g, double* phiHbyA, double* sums4 /* device scratch */, int* err);
+int launch_ldu_adjust_phi(hipStream_t s, LduGeo g, double* phiHbyA, double* sums4 /* device scratch */, int* err, double* partials);
 // pEqn (icoFoamYade.C:118-123): face part (coefficients, the explicit non-orthogonal flux from grad p), cell part (diag, right-hand side, setReference)
 int launch_ldu_assemble_pressure(hipStream_t s, LduGeo g, const double* rAUf, const double* phiHbyA, const double* gradp, double* pcoef, double* pcorr, double* pdiag, double* prhs);
 // r = b - A x with slot 0 = sum |r|, slot 1 = normFactor terms (xbar from xsum); w = A u with slot 0 = u.r, slot 1 = u.w where u = r / diag is formed inline

@@ -281,8 +281,6 @@ int LduAmg::build(hipStream_t s, int n_cells, int n_internal, const int32_t* own
                   const double* face_weight, int ref_cell, bool with_hierarchy) {
     lev.clear();
     ref_cell0 = ref_cell; hier = with_hierarchy;
-    if (const char* e = getenv("FOAMYADE_AMG_SCALE")) scale_override = atof(e);
-    if (const char* e = getenv("FOAMYADE_AMG_PASSES")) passes = atoi(e);
     // the mesh's graph: per cell its internal faces in ascending face order (the order the face-addressed kernels sum in)
     Graph G;
     G.n = n_cells;
@@ -372,8 +370,6 @@ int LduAmg::build(hipStream_t s, int n_cells, int n_internal, const int32_t* own
         FY_TRY(coarse_inv.alloc_exact((size_t)kAmgCoarsest * kAmgCoarsest));
         if (lev.back()->n > kAmgCoarsest) return fail(FY_ERR_UNSUPPORTED, "fy_ldu_solver: the agglomeration stalled at %d cells (more than %d): use the diagonal preconditioner", lev.back()->n, kAmgCoarsest);
     }
-    if (getenv("FOAMYADE_AMG_VERBOSE"))
-        for (size_t l = 0; l < lev.size(); ++l) std::fprintf(stderr, "amg level %zu: %d cells, %d slots, ref %d\n", l, lev[l]->n, lev[l]->W, lev[l]->ref_cell);
     FY_HIP(hipStreamSynchronize(s));
     return FY_OK;
 }
@@ -392,7 +388,7 @@ int LduAmg::setup(hipStream_t s, const double* pcoef, const double* pdiag) {
         const double* fdiag = l == 0 ? pdiag : F.diag.p;
         const size_t n_ent = (size_t)C.W * C.n;
         // the over-correction of piecewise-constant transfer: 1 / (cells per aggregate)^(1/3), i.e. 1/2 for the 2 x 2 x 2 of three clean pairwise passes
-        const double scale = scale_override > 0 ? scale_override : std::pow((double)F.n / (double)C.n, -1.0 / 3.0);
+        const double scale = std::pow((double)F.n / (double)C.n, -1.0 / 3.0);
         hipLaunchKernelGGL(k_amg_galerkin_coef, grid_of(n_ent), dim3(256), 0, s, n_ent, F.ent_off.p, F.ent_idx.p, F.coef.p, C.coef.p, scale);
         FY_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_amg_galerkin_diag, grid_of((size_t)C.n), dim3(256), 0, s, C.n, F.child_off.p, F.child.p, F.din_off.p, F.din_idx.p, fdiag, F.coef.p, pdiag,

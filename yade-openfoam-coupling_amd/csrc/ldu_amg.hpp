@@ -43,7 +43,6 @@ struct LduAmg {
     DevBuf<int32_t> ell_face;                      // [W0 n0]: the internal face of slot k of cell c, or -1
     int ref_cell0 = -1;
     bool hier = false;
-    double scale_override = 0.0;                   // FOAMYADE_AMG_SCALE: one Galerkin scale for every level (experiments)
     int passes = 3;
     DevBuf<double> coarse_inv;                     // the coarsest level's inverse, dense [n][n]
     const double* diag0_ = nullptr;               // the fine diagonal of the last setup (the solver's array)

@@ -248,25 +248,20 @@ __global__ __launch_bounds__(256) void k_ldu_phiHbyA(LduGeo g, const double* __r
     phiHbyA[f] = fl + rf * (coef * (1.0 / g.dt) * phiCorr);
 }
 
-// adjustPhi [OF-6 adjustPhi.C] (icoFoamYade.C:108), only when no patch fixes the pressure: one workgroup sums, the boundary faces are scaled
-__global__ __launch_bounds__(1024) void k_ldu_adjust_sums(LduGeo g, const double* __restrict__ phiHbyA, double* __restrict__ sums) {
-    __shared__ double sh[4][16];
+// adjustPhi [OF-6 adjustPhi.C] (icoFoamYade.C:108), only when no patch fixes the pressure: the four sums as block partials (folded by k_reduce_finalize),
+// then the boundary faces are scaled
+__global__ __launch_bounds__(256) void k_ldu_adjust_sums(LduGeo g, const double* __restrict__ phiHbyA, double* __restrict__ partials) {
     double v[4] = {0, 0, 0, 0};              // massIn, fixedMassOut, adjustableMassOut, sum |internal flux|
-    for (int f = threadIdx.x; f < g.nFaces; f += 1024) {
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    if (f < g.nFaces) {
         const double fl = phiHbyA[f];
-        if (f < g.nInt) v[3] += fabs(fl);
-        else if (fl < 0.0) v[0] -= fl;
-        else if (g.u_bc[g.patch_of[f - g.nInt]] == FY_BC_U_FIXED_VALUE) v[1] += fl;
-        else v[2] += fl;
+        if (f < g.nInt) v[3] = fabs(fl);
+        else if (fl < 0.0) v[0] = -fl;
+        else if (g.u_bc[g.patch_of[f - g.nInt]] == FY_BC_U_FIXED_VALUE) v[1] = fl;
+        else v[2] = fl;
     }
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (int q = 0; q < 4; ++q) {
-        double x = v[q];
-        for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o, 64);
-        if (lane == 0) sh[q][wv] = x;
-    }
-    __syncthreads();
-    if (threadIdx.x < 4) { double x = 0; for (int w = 0; w < 16; ++w) x += sh[threadIdx.x][w]; sums[threadIdx.x] = x; }
+    const int mx[4] = {0, 0, 0, 0};
+    block_reduce_store<4>(v, mx, partials);
 }
 __global__ __launch_bounds__(256) void k_ldu_adjust_apply(LduGeo g, const double* __restrict__ sums, double* __restrict__ phiHbyA, int* __restrict__ err) {
     const int f = g.nInt + blockIdx.x * 256 + threadIdx.x;
@@ -486,8 +481,10 @@ int launch_ldu_phiHbyA(hipStream_t s, LduGeo g, const double* HbyA, const double
     FY_LAUNCH_CHECK();
     return FY_OK;
 }
-int launch_ldu_adjust_phi(hipStream_t s, LduGeo g, double* phiHbyA, double* sums4, int* err) {
-    hipLaunchKernelGGL(k_ldu_adjust_sums, dim3(1), dim3(1024), 0, s, g, phiHbyA, sums4);
+int launch_ldu_adjust_phi(hipStream_t s, LduGeo g, double* phiHbyA, double* sums4, int* err, double* partials) {
+    hipLaunchKernelGGL(k_ldu_adjust_sums, dim3(red_blocks(g.nFaces)), dim3(256), 0, s, g, phiHbyA, partials);
+    FY_LAUNCH_CHECK();
+    FY_TRY(launch_reduce_finalize(s, partials, g.nFaces, 4, nullptr, sums4, nullptr, 0));
     hipLaunchKernelGGL(k_ldu_adjust_apply, dim3(div_up(g.nFaces - g.nInt, 256)), dim3(256), 0, s, g, sums4, phiHbyA, err);
     FY_LAUNCH_CHECK();
     return FY_OK;

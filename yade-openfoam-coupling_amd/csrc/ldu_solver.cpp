@@ -191,7 +191,7 @@ struct LduSolver {
     int corrector(bool final_corr) {
         FY_TRY(launch_ldu_HbyA(stream, g, M(), U.p, rAU.p, HbyA.p));                                              // icoFoamYade.C:99-100
         FY_TRY(launch_ldu_phiHbyA(stream, g, HbyA.p, rAU.p, Uold.p, phiOld.p, rAUf.p, phiHbyA.p));               // :101-106
-        if (need_ref) FY_TRY(launch_ldu_adjust_phi(stream, g, phiHbyA.p, adj.p, adj_err.p));                      // :108
+        if (need_ref) FY_TRY(launch_ldu_adjust_phi(stream, g, phiHbyA.p, adj.p, adj_err.p, partials.p));                      // :108
         for (int no = 0; no <= cs.n_non_orth_correctors; ++no) {                                                   // :114-131
             FY_TRY(launch_ldu_grad_scalar(stream, g, p.p, gradp.p));
             FY_TRY(launch_ldu_assemble_pressure(stream, g, rAUf.p, phiHbyA.p, gradp.p, pcoef.p, pcorr.p, pdiag.p, prhs.p));
@@ -341,6 +341,14 @@ int fy_ldu_solver_apply(fy_ldu_solver* s, const char* op, const double* in, doub
     else FY_TRY(fy::launch_ell_jacobi(S.stream, S.nc, S.pdiag.p, S.pr.p, S.pw.p));
     FY_HIP(hipMemcpyAsync(out, S.pw.p, bytes, hipMemcpyDeviceToHost, S.stream));
     FY_HIP(hipStreamSynchronize(S.stream));
+    return FY_OK;
+}
+int fy_ldu_solver_mg_levels(fy_ldu_solver* s, int cap, int32_t* cells, int32_t* slots, int* n_levels) {
+    FY_LS(s);
+    if (!n_levels) return fy::fail(FY_ERR_INVALID, "fy_ldu_solver_mg_levels: null n_levels");
+    const fy::LduAmg& A = s->s.amg;
+    *n_levels = A.has_hierarchy() ? (int)A.lev.size() : 0;
+    for (int l = 0; l < *n_levels && l < cap; ++l) { if (cells) cells[l] = A.lev[(size_t)l]->n; if (slots) slots[l] = A.lev[(size_t)l]->W; }
     return FY_OK;
 }
 int fy_ldu_solver_destroy(fy_ldu_solver* s) { delete s; return FY_OK; }
