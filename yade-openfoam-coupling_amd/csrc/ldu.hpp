@@ -19,6 +19,8 @@ struct LduHostMesh {
     int nPoints = 0, nFaces = 0, nInt = 0, nCells = 0, nPatches = 0;
     std::vector<int32_t> own, nei, patch_of;            // patch_of[f - nInt]
     std::vector<int32_t> cf_off, cf_face;               // per cell: its faces (ascending face number)
+    int Wall = 0;                                       // the most faces a cell has; slot tables [Wall nCells], slot-major: face (-1: no more) and the cell across (-1: boundary)
+    std::vector<int32_t> ef, en;
     std::vector<double> Cf, Sf, magSf, C, V, w, dcNO, kvec;      // [3 nF] [3 nF] [nF] [3 nc] [nc] [nInt] [nF] [3 nInt]
     double bbox_min[3], bbox_max[3];
     int build(const fy_poly_mesh* m);                   // FY_OK or an error (malformed addressing)
@@ -28,6 +30,8 @@ struct LduHostMesh {
 struct LduGeo {
     int nCells, nFaces, nInt, nPatches;
     const int32_t *own, *nei, *patch_of, *cf_off, *cf_face;
+    int Wall;
+    const int32_t *ef, *en;                              // cell -> (face, cell across) slot tables (LduHostMesh)
     const double *Cf, *Sf, *magSf, *C, *V, *w, *dcNO, *kvec;
     const int32_t *u_bc, *p_bc;                          // per patch
     const double *u_val, *p_val;
@@ -55,9 +59,8 @@ int launch_ldu_phiHbyA(hipStream_t s, LduGeo g, const double* HbyA, const double
 int launch_ldu_adjust_phi(hipStream_t s, LduGeo g, double* phiHbyA, double* sums4 /* device scratch */, int* err, double* partials);
 // pEqn (icoFoamYade.C:118-123): face part (coefficients, the explicit non-orthogonal flux from grad p), cell part (diag, right-hand side, setReference)
 int launch_ldu_assemble_pressure(hipStream_t s, LduGeo g, const double* rAUf, const double* phiHbyA, const double* gradp, double* pcoef, double* pcorr, double* pdiag, double* prhs);
-// r = b - A x with slot 0 = sum |r|, slot 1 = normFactor terms (xbar from xsum); w = A u with slot 0 = u.r, slot 1 = u.w where u = r / diag is formed inline
+// r = b - A x with slot 0 = sum |r|, slot 1 = normFactor terms (xbar from xsum); the iterations run on the ELL form (ldu_amg.hpp)
 int launch_ldu_p_init(hipStream_t s, LduGeo g, const double* pdiag, const double* pcoef, const double* b, const double* x, const double* xsum, double inv_n, double* r, double* partials);
-int launch_ldu_p_apply_dot(hipStream_t s, LduGeo g, const double* pdiag, const double* pcoef, const double* r, double* u, double* w, double* partials);
 int launch_ldu_flux_correct(hipStream_t s, LduGeo g, const double* p, const double* phiHbyA, const double* pcoef, const double* pcorr, double* phi);
 // U = HbyA - rAU grad(p) (gradient formed inline) + continuity sums (slot 0 sum |div phi|, slot 1 sum div phi)
 int launch_ldu_U_correct(hipStream_t s, LduGeo g, const double* HbyA, const double* rAU, const double* p, const double* phi, double* U, double* partials);

@@ -28,6 +28,12 @@ __device__ __forceinline__ double pbv(const LduGeo& g, const double* p, int f) {
     return g.p_bc[pa] == FY_BC_P_FIXED_VALUE ? g.p_val[pa] : p[g.own[f]];
 }
 
+// the faces of cell c in ascending face order through the slot tables (LduGeo::ef / en, slot-major like the ELL matrix: the lanes of a wave read consecutive
+// words, and the neighbour comes with the slot instead of through owner / neighbour): f = the face, nb = the cell across it (-1: boundary face).  Internal
+// faces have owner < neighbour, so c owns face f exactly when nb > c
+#define FY_CELL_FACES(g, c, f, nb)                                                                                                     \
+    for (int _k = 0, f = 0, nb = 0; _k < (g).Wall && (f = (g).ef[(size_t)_k * (g).nCells + (c)]) >= 0 && ((nb = (g).en[(size_t)_k * (g).nCells + (c)]), true); ++_k)
+
 template <int N>
 __device__ __forceinline__ void block_reduce_store(double (&v)[N], const int (&is_max)[N], double* partials) {
     __shared__ double sh[4][N];
@@ -65,7 +71,7 @@ __global__ __launch_bounds__(256) void k_ldu_courant(LduGeo g, const double* __r
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c < g.nCells) {
         double s = 0.0;
-        for (int q = g.cf_off[c]; q < g.cf_off[c + 1]; ++q) s += fabs(phi[g.cf_face[q]]);
+        FY_CELL_FACES(g, c, f, nb) s += fabs(phi[f]);
         v[0] = s / g.V[c]; v[1] = s;
     }
     const int mx[2] = {1, 0};
@@ -77,10 +83,9 @@ __global__ __launch_bounds__(256) void k_ldu_grad_vec(LduGeo g, const double* __
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= g.nCells) return;
     double t[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (int q = g.cf_off[c]; q < g.cf_off[c + 1]; ++q) {
-        const int f = g.cf_face[q];
+    FY_CELL_FACES(g, c, f, nb) {
         D3 uf; double sg = 1.0;
-        if (f < g.nInt) { uf = lerp3(g.w[f], ld3(F, g.own[f]), ld3(F, g.nei[f])); sg = g.own[f] == c ? 1.0 : -1.0; }
+        if (f < g.nInt) { const bool o = nb > c; uf = lerp3(g.w[f], ld3(F, o ? c : nb), ld3(F, o ? nb : c)); sg = o ? 1.0 : -1.0; }
         else uf = Ub(g, F, f);
         const D3 S = ld3(g.Sf, f);
         const double s[3] = {sg * S.x, sg * S.y, sg * S.z}, u[3] = {uf.x, uf.y, uf.z};
@@ -96,10 +101,9 @@ __global__ __launch_bounds__(256) void k_ldu_grad_vec(LduGeo g, const double* __
 
 __device__ __forceinline__ D3 grad_scalar_at(const LduGeo& g, const double* __restrict__ p, int c) {
     D3 a{0, 0, 0};
-    for (int q = g.cf_off[c]; q < g.cf_off[c + 1]; ++q) {
-        const int f = g.cf_face[q];
+    FY_CELL_FACES(g, c, f, nb) {
         double pf, sg = 1.0;
-        if (f < g.nInt) { pf = g.w[f] * p[g.own[f]] + (1.0 - g.w[f]) * p[g.nei[f]]; sg = g.own[f] == c ? 1.0 : -1.0; }
+        if (f < g.nInt) { const bool o = nb > c; pf = g.w[f] * p[o ? c : nb] + (1.0 - g.w[f]) * p[o ? nb : c]; sg = o ? 1.0 : -1.0; }
         else pf = pbv(g, p, f);
         const D3 S = ld3(g.Sf, f);
         a.x += sg * S.x * pf; a.y += sg * S.y * pf; a.z += sg * S.z * pf;
@@ -145,11 +149,10 @@ __global__ __launch_bounds__(256) void k_ldu_mom_cells(LduGeo g, const double* _
     double dg = rdt;
     const D3 uo = ld3(Uold, c), us = ld3(uSource, c);
     double b[3] = {rdt * uo.x + Vc * us.x, rdt * uo.y + Vc * us.y, rdt * uo.z + Vc * us.z};
-    for (int q = g.cf_off[c]; q < g.cf_off[c + 1]; ++q) {
-        const int f = g.cf_face[q];
+    FY_CELL_FACES(g, c, f, nb) {
         if (f < g.nInt) {
             const D3 cr = ld3(corr, f);
-            if (g.own[f] == c) { dg -= M.lower[f]; b[0] += cr.x; b[1] += cr.y; b[2] += cr.z; }
+            if (nb > c) { dg -= M.lower[f]; b[0] += cr.x; b[1] += cr.y; b[2] += cr.z; }
             else { dg -= M.upper[f]; b[0] -= cr.x; b[1] -= cr.y; b[2] -= cr.z; }
         } else {
             const int pa = g.patch_of[f - g.nInt];
@@ -171,12 +174,11 @@ __global__ __launch_bounds__(256) void k_ldu_mom_cells(LduGeo g, const double* _
 __device__ __forceinline__ void mom_offdiag(const LduGeo& g, const LduMom& M, const double* __restrict__ x, int c, double (&s)[3], double* offsum) {
     s[0] = s[1] = s[2] = 0.0;
     double os = 0.0;
-    for (int q = g.cf_off[c]; q < g.cf_off[c + 1]; ++q) {
-        const int f = g.cf_face[q];
+    FY_CELL_FACES(g, c, f, nb) {
         if (f >= g.nInt) continue;
-        const bool o = g.own[f] == c;
+        const bool o = nb > c;
         const double a = o ? M.upper[f] : M.lower[f];
-        const D3 xn = ld3(x, o ? g.nei[f] : g.own[f]);
+        const D3 xn = ld3(x, nb);
         s[0] += a * xn.x; s[1] += a * xn.y; s[2] += a * xn.z;
         os += a;
     }
@@ -288,12 +290,11 @@ __global__ __launch_bounds__(256) void k_ldu_p_cells(LduGeo g, const double* __r
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= g.nCells) return;
     double dg = 0.0, b = 0.0;
-    for (int q = g.cf_off[c]; q < g.cf_off[c + 1]; ++q) {
-        const int f = g.cf_face[q];
+    FY_CELL_FACES(g, c, f, nb) {
         if (f < g.nInt) {
             dg += pcoef[f];
             const double t = -phiHbyA[f] + pcorr[f];
-            b += g.own[f] == c ? t : -t;
+            b += nb > c ? t : -t;
         } else {
             const int pa = g.patch_of[f - g.nInt];
             b -= phiHbyA[f];
@@ -306,11 +307,10 @@ __global__ __launch_bounds__(256) void k_ldu_p_cells(LduGeo g, const double* __r
 
 __device__ __forceinline__ double p_offdiag(const LduGeo& g, const double* __restrict__ pcoef, const double* __restrict__ x, int c, double* coefsum) {
     double s = 0.0, cs = 0.0;
-    for (int q = g.cf_off[c]; q < g.cf_off[c + 1]; ++q) {
-        const int f = g.cf_face[q];
+    FY_CELL_FACES(g, c, f, nb) {
         if (f >= g.nInt) continue;
         const double a = pcoef[f];
-        s += a * x[g.own[f] == c ? g.nei[f] : g.own[f]];
+        s += a * x[nb];
         cs += a;
     }
     if (coefsum) *coefsum = cs;
@@ -332,29 +332,6 @@ __global__ __launch_bounds__(256) void k_ldu_p_init(LduGeo g, const double* __re
     const int mx[2] = {0, 0};
     block_reduce_store<2>(v, mx, partials);
 }
-// the diagonal preconditioner and the matrix-vector product of the single-reduction PCG in one gather: u = r / diag (the neighbours' u formed
-// inline from the same operands), w = A u; slot 0 = u.r, slot 1 = u.w
-__global__ __launch_bounds__(256) void k_ldu_p_apply_dot(LduGeo g, const double* __restrict__ pdiag, const double* __restrict__ pcoef, const double* __restrict__ r,
-                                                         double* __restrict__ u, double* __restrict__ w, double* __restrict__ partials) {
-    double v[2] = {0, 0};
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c < g.nCells) {
-        const double uc = r[c] / pdiag[c];
-        double s = 0.0;
-        for (int q = g.cf_off[c]; q < g.cf_off[c + 1]; ++q) {
-            const int f = g.cf_face[q];
-            if (f >= g.nInt) continue;
-            const int nb = g.own[f] == c ? g.nei[f] : g.own[f];
-            s += pcoef[f] * (r[nb] / pdiag[nb]);
-        }
-        const double wc = pdiag[c] * uc - s;
-        u[c] = uc; w[c] = wc;
-        v[0] = uc * r[c]; v[1] = uc * wc;
-    }
-    const int mx[2] = {0, 0};
-    block_reduce_store<2>(v, mx, partials);
-}
-
 // phi = phiHbyA - pEqn.flux() (icoFoamYade.C:127-130): the matrix's flux c_f (p_N - p_P) and the explicit non-orthogonal flux it was assembled with
 __global__ __launch_bounds__(256) void k_ldu_flux_correct(LduGeo g, const double* __restrict__ p, const double* __restrict__ phiHbyA, const double* __restrict__ pcoef,
                                                           const double* __restrict__ pcorr, double* __restrict__ phi) {
@@ -377,9 +354,8 @@ __global__ __launch_bounds__(256) void k_ldu_U_correct(LduGeo g, const double* _
         const double r = rAU[c];
         st3(U, c, D3{h.x - r * gp.x, h.y - r * gp.y, h.z - r * gp.z});
         double dv = 0.0;
-        for (int q = g.cf_off[c]; q < g.cf_off[c + 1]; ++q) {
-            const int f = g.cf_face[q];
-            dv += (f >= g.nInt || g.own[f] == c) ? phi[f] : -phi[f];
+        FY_CELL_FACES(g, c, f, nb) {
+            dv += (f >= g.nInt || nb > c) ? phi[f] : -phi[f];
         }
         v[0] = fabs(dv); v[1] = dv;
     }
@@ -406,17 +382,16 @@ __global__ __launch_bounds__(256) void k_ldu_find_cell(LduGeo g, const double* _
     if (!(x.x == x.x) || !(x.y == x.y) || !(x.z == x.z)) c = -1;
     for (int hop = 0; c >= 0 && hop < 64; ++hop) {
         double worst = 0.0;
-        int wf = -1;
+        int wf = -1, wn = -1;
         const double tol = 1e-10 * cbrt(g.V[c]);
-        for (int q = g.cf_off[c]; q < g.cf_off[c + 1]; ++q) {
-            const int f = g.cf_face[q];
+        FY_CELL_FACES(g, c, f, nb) {
             const D3 S = ld3(g.Sf, f), cf = ld3(g.Cf, f);
-            const double sg = (f >= g.nInt || g.own[f] == c) ? 1.0 : -1.0;
+            const double sg = (f >= g.nInt || nb > c) ? 1.0 : -1.0;
             const double s = sg * dot3(D3{x.x - cf.x, x.y - cf.y, x.z - cf.z}, S) / g.magSf[f];
-            if (s > worst) { worst = s; wf = f; }
+            if (s > worst) { worst = s; wf = f; wn = nb; }
         }
         if (wf < 0 || worst <= tol) break;
-        c = wf >= g.nInt ? -1 : (g.own[wf] == c ? g.nei[wf] : g.own[wf]);
+        c = wn;                                     // (-1 across a boundary face: outside the mesh)
         if (hop == 63) c = -1;
     }
     cell_out[i] = c;
@@ -497,11 +472,6 @@ int launch_ldu_assemble_pressure(hipStream_t s, LduGeo g, const double* rAUf, co
 }
 int launch_ldu_p_init(hipStream_t s, LduGeo g, const double* pdiag, const double* pcoef, const double* b, const double* x, const double* xsum, double inv_n, double* r, double* partials) {
     hipLaunchKernelGGL(k_ldu_p_init, dim3(red_blocks(g.nCells)), dim3(256), 0, s, g, pdiag, pcoef, b, x, xsum, inv_n, r, partials);
-    FY_LAUNCH_CHECK();
-    return FY_OK;
-}
-int launch_ldu_p_apply_dot(hipStream_t s, LduGeo g, const double* pdiag, const double* pcoef, const double* r, double* u, double* w, double* partials) {
-    hipLaunchKernelGGL(k_ldu_p_apply_dot, dim3(red_blocks(g.nCells)), dim3(256), 0, s, g, pdiag, pcoef, r, u, w, partials);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }

@@ -83,6 +83,16 @@ int LduHostMesh::build(const fy_poly_mesh* m) {
         std::vector<int32_t> fill(cf_off.begin(), cf_off.end() - 1);
         for (int f = 0; f < nFaces; ++f) { cf_face[(size_t)fill[(size_t)own[f]]++] = f; if (f < nInt) cf_face[(size_t)fill[(size_t)nei[f]]++] = f; }
     }
+    Wall = 0;
+    for (int c = 0; c < nCells; ++c) Wall = std::max(Wall, cf_off[(size_t)c + 1] - cf_off[(size_t)c]);
+    ef.assign((size_t)Wall * nCells, -1); en.assign((size_t)Wall * nCells, -1);
+    for (int c = 0; c < nCells; ++c)
+        for (int32_t q = cf_off[(size_t)c]; q < cf_off[(size_t)c + 1]; ++q) {
+            const int f = cf_face[(size_t)q];
+            const size_t e = (size_t)(q - cf_off[(size_t)c]) * nCells + c;
+            ef[e] = f;
+            en[e] = f < nInt ? (own[f] == c ? nei[f] : own[f]) : -1;
+        }
     // ---- cells
     std::vector<double> cEst(3 * (size_t)nCells, 0.0);
     for (int c = 0; c < nCells; ++c) {

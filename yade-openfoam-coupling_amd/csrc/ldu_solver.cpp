@@ -25,7 +25,7 @@ struct LduSolver {
     fy_ctx* cpl = nullptr;
     int nc = 0, nf = 0, ni = 0;
     // geometry + addressing on the device
-    DevBuf<int32_t> d_own, d_nei, d_patch_of, d_cf_off, d_cf_face, d_ubc, d_pbc;
+    DevBuf<int32_t> d_own, d_nei, d_patch_of, d_cf_off, d_cf_face, d_ubc, d_pbc, d_ef, d_en;
     DevBuf<double> d_Cf, d_Sf, d_magSf, d_C, d_V, d_w, d_dcNO, d_kvec, d_uval, d_pval;
     // fields
     DevBuf<double> U, Uold, p, phi, phiOld, uSource, uSourceExt, uSourceSum, vGrad, gradp, dummy3, dummy1;
@@ -72,10 +72,10 @@ struct LduSolver {
         cs.u_bc = nullptr; cs.u_value = nullptr; cs.p_bc = nullptr; cs.p_value = nullptr;      // (copied; the caller's arrays are not kept)
         FY_HIP(hipSetDevice(device));
         FY_HIP(hipStreamCreate(&stream));
-        FY_TRY(up(d_own, hm.own)); FY_TRY(up(d_nei, hm.nei)); FY_TRY(up(d_patch_of, hm.patch_of)); FY_TRY(up(d_cf_off, hm.cf_off)); FY_TRY(up(d_cf_face, hm.cf_face));
+        FY_TRY(up(d_own, hm.own)); FY_TRY(up(d_nei, hm.nei)); FY_TRY(up(d_patch_of, hm.patch_of)); FY_TRY(up(d_cf_off, hm.cf_off)); FY_TRY(up(d_cf_face, hm.cf_face)); FY_TRY(up(d_ef, hm.ef)); FY_TRY(up(d_en, hm.en));
         FY_TRY(up(d_Cf, hm.Cf)); FY_TRY(up(d_Sf, hm.Sf)); FY_TRY(up(d_magSf, hm.magSf)); FY_TRY(up(d_C, hm.C)); FY_TRY(up(d_V, hm.V)); FY_TRY(up(d_w, hm.w));
         FY_TRY(up(d_dcNO, hm.dcNO)); FY_TRY(up(d_kvec, hm.kvec)); FY_TRY(up(d_ubc, ubc)); FY_TRY(up(d_pbc, pbc)); FY_TRY(up(d_uval, uval)); FY_TRY(up(d_pval, pval));
-        g = LduGeo{nc, nf, ni, hm.nPatches, d_own.p, d_nei.p, d_patch_of.p, d_cf_off.p, d_cf_face.p, d_Cf.p, d_Sf.p, d_magSf.p, d_C.p, d_V.p, d_w.p, d_dcNO.p, d_kvec.p,
+        g = LduGeo{nc, nf, ni, hm.nPatches, d_own.p, d_nei.p, d_patch_of.p, d_cf_off.p, d_cf_face.p, hm.Wall, d_ef.p, d_en.p, d_Cf.p, d_Sf.p, d_magSf.p, d_C.p, d_V.p, d_w.p, d_dcNO.p, d_kvec.p,
                    d_ubc.p, d_pbc.p, d_uval.p, d_pval.p, cs.dt, cs.nu, need_ref ? 1 : 0, cs.p_ref_cell, cs.p_ref_value};
         total_volume = 0.0;
         for (double v : hm.V) total_volume += v;
