@@ -479,12 +479,19 @@ typedef struct fy_ldu_case {
     const double* u_value;           /* [n_patches][3] */
     const int32_t* p_bc;             /* per patch: FY_BC_P_ZERO_GRADIENT | FY_BC_P_FIXED_VALUE */
     const double* p_value;           /* [n_patches] */
+    /* pimpleFoamYade on the general mesh (solver = FY_SOLVER_PIMPLE; pimpleFoamYade.C:60-114, UcEqn.H, pEqn.H): Gaussian 4-way coupling, the void-fraction-
+     * weighted equations, laminar Stokes stress, fixed time step; p patches may then be FY_BC_P_FIXED_FLUX (fixedFluxPressure) too */
+    int32_t solver;                  /* FY_SOLVER_ICO (the default) | FY_SOLVER_PIMPLE */
+    int32_t n_outer_correctors;
+    double g[3];
+    double u_relax, u_relax_final, p_relax, p_relax_final;      /* relaxationFactors; <= 0: no entry (relax() does nothing) */
 } fy_ldu_case;
 typedef struct fy_ldu_solver fy_ldu_solver;
 void fy_ldu_case_defaults(fy_ldu_case*);        /* the icoFoam cavity tutorial's controls (as fy_case_defaults); the patch arrays stay NULL */
 int fy_ldu_solver_create(const fy_poly_mesh*, const fy_ldu_case*, const fy_transport* transport /* or NULL */, int device_ordinal, fy_ldu_solver** out);
 int fy_ldu_solver_step(fy_ldu_solver*);                                     /* one pass of icoFoamYade.C:65-149 */
 int fy_ldu_solver_get_stats(fy_ldu_solver*, fy_step_stats* out);
+int fy_ldu_solver_hold_sources(fy_ldu_solver*, int on);                    /* as fy_solver_hold_sources: setSourceZero deferred to the next step's start (runTime.write() sees alpha / uSource) */
 fy_ctx* fy_ldu_solver_coupling(fy_ldu_solver*);                              /* FoamYade on this mesh (point force); fy_set_particles_* as usual */
 /* fields by name, host copies: "U" [nc][3], "p", "phi" [n_faces], "uSource" [nc][3] (added to what the coupling leaves: an external momentum source),
  * "rAU", "HbyA", "phiHbyA", "p_diag", "p_coef" [n_faces], "p_rhs", "vGrad" [nc][9]; geometry: "C" "V" "Cf" "Sf" "magSf" "w" "dcNO" "kvec" */

@@ -87,7 +87,8 @@ class LduCase(C.Structure):
                 ("n_non_orth_correctors", C.c_int32), ("momentum_predictor", C.c_int32), ("p_ref_cell", C.c_int32), ("p_ref_value", C.c_double),
                 ("p_tol", C.c_double), ("p_rel_tol", C.c_double), ("p_final_tol", C.c_double), ("p_final_rel_tol", C.c_double), ("p_max_iter", C.c_int32),
                 ("u_tol", C.c_double), ("u_rel_tol", C.c_double), ("u_max_iter", C.c_int32), ("p_solver", C.c_int32), ("u_bc", _ip), ("u_value", _dp), ("p_bc", _ip),
-                ("p_value", _dp)]
+                ("p_value", _dp), ("solver", C.c_int32), ("n_outer_correctors", C.c_int32), ("g", C.c_double * 3), ("u_relax", C.c_double), ("u_relax_final", C.c_double),
+                ("p_relax", C.c_double), ("p_relax_final", C.c_double)]
 
 
 class ParticleTimings(C.Structure):
@@ -1073,7 +1074,12 @@ class LduSolver:
         self.case.dt, self.case.nu = dt, nu
         names = dict(n_non_orth="n_non_orth_correctors", rho_f="rho_fluid", rho_p="rho_particle")
         for key, v in controls.items():
-            setattr(self.case, names.get(key, key), v)
+            if isinstance(v, (list, tuple)):
+                arr = getattr(self.case, names.get(key, key))
+                for q, x in enumerate(v):
+                    arr[q] = x
+            else:
+                setattr(self.case, names.get(key, key), v)
         self.case.u_bc, self.case.u_value, self.case.p_bc, self.case.p_value = _i(k["ub"]), _d(k["uv"]), _i(k["pb"]), _d(k["pv"])
         self._create(device, transport)
 
@@ -1114,6 +1120,11 @@ class LduSolver:
         arr = np.ascontiguousarray(arr, dtype=np.float64).ravel()
         assert arr.size == self._size(name)
         _check(lib().fy_ldu_solver_write_field_host(self._h, name.encode(), _d(arr)))
+
+    def hold_sources(self, on=True):
+        L = lib()
+        L.fy_ldu_solver_hold_sources.argtypes = [C.c_void_p, C.c_int]
+        _check(L.fy_ldu_solver_hold_sources(self._h, 1 if on else 0))
 
     def mg_levels(self):
         """[(cells, slots)] of the multigrid hierarchy, finest first ([] with the diagonal preconditioner)"""

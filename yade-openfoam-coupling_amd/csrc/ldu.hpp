@@ -22,6 +22,7 @@ struct LduHostMesh {
     int Wall = 0;                                       // the most faces a cell has; slot tables [Wall nCells], slot-major: face (-1: no more) and the cell across (-1: boundary)
     std::vector<int32_t> ef, en;
     std::vector<double> Cf, Sf, magSf, C, V, w, dcNO, kvec;      // [3 nF] [3 nF] [nF] [3 nc] [nc] [nInt] [nF] [3 nInt]
+    std::vector<double> recon;                          // [9 nc] inv(sum_f Sf Sf / |Sf|): fvc::reconstruct's tensor [OF-6 fvcReconstruct.C]
     double bbox_min[3], bbox_max[3];
     int build(const fy_poly_mesh* m);                   // FY_OK or an error (malformed addressing)
 };
@@ -35,6 +36,8 @@ struct LduGeo {
     const double *Cf, *Sf, *magSf, *C, *V, *w, *dcNO, *kvec;
     const int32_t *u_bc, *p_bc;                          // per patch
     const double *u_val, *p_val;
+    const double* recon;                                 // [9 nc]
+    const double* psn;                                   // [nF - nInt] snGrad(p) of the fixedFluxPressure faces (pimpleFoamYade; else null)
     double dt, nu;
     int need_ref, p_ref_cell;
     double p_ref_value;
@@ -42,6 +45,8 @@ struct LduGeo {
 
 // momentum matrix in LDU form: diag [nc] (boundary diagonal included), lower / upper per internal face, b [3 nc] (boundary sources included)
 struct LduMom { double *diag, *lower, *upper, *b; };
+// pimpleFoamYade's extra fields: the void fraction (cells, old time, faces), the coupling's implicit and explicit momentum sources, gravity
+struct LduPim { const double *alpha, *alphaOld, *alphaf, *uSourceDrag, *uSource; double g[3]; };
 
 int ldu_red_blocks(int n);      // partials per slot of the reducing kernels (= red_blocks(n) of fv_kernels.hpp: the folds are shared)
 
@@ -53,9 +58,10 @@ int launch_ldu_grad_scalar(hipStream_t s, LduGeo g, const double* p, double* gp)
 int launch_ldu_assemble_momentum(hipStream_t s, LduGeo g, const double* phi, const double* Uold, const double* uSource, const double* gradU, LduMom M,
                                  double* face_corr /* [3 nInt] scratch */);
 // one Jacobi pass: xn = (b - V gradp - offdiag x) / diag and the L1 residual / normFactor sums of x (slots 0-2 |b - A x|, 3-5 normFactor terms)
-int launch_ldu_mom_pass(hipStream_t s, LduGeo g, LduMom M, const double* gradp, const double* x, double* xn, const double* xsum3, double* partials);
+int launch_ldu_mom_pass(hipStream_t s, LduGeo g, LduMom M, const double* rhs /* M.b, or the predictor's full right-hand side */, const double* gradp /* or null */, const double* x, double* xn,
+                        const double* xsum3, double* partials);
 int launch_ldu_HbyA(hipStream_t s, LduGeo g, LduMom M, const double* U, double* rAU, double* HbyA);
-int launch_ldu_phiHbyA(hipStream_t s, LduGeo g, const double* HbyA, const double* rAU, const double* Uold, const double* phiOld, double* rAUf, double* phiHbyA);
+int launch_ldu_phiHbyA(hipStream_t s, LduGeo g, const double* HbyA, const double* rAU, const double* Uold, const double* phiOld, const double* alphaf /* or null */, double* rAUf, double* phiHbyA);
 int launch_ldu_adjust_phi(hipStream_t s, LduGeo g, double* phiHbyA, double* sums4 /* device scratch */, int* err, double* partials);
 // pEqn (icoFoamYade.C:118-123): face part (coefficients, the explicit non-orthogonal flux from grad p), cell part (diag, right-hand side, setReference)
 int launch_ldu_assemble_pressure(hipStream_t s, LduGeo g, const double* rAUf, const double* phiHbyA, const double* gradp, double* pcoef, double* pcorr, double* pdiag, double* prhs);
@@ -64,6 +70,20 @@ int launch_ldu_p_init(hipStream_t s, LduGeo g, const double* pdiag, const double
 int launch_ldu_flux_correct(hipStream_t s, LduGeo g, const double* p, const double* phiHbyA, const double* pcoef, const double* pcorr, double* phi);
 // U = HbyA - rAU grad(p) (gradient formed inline) + continuity sums (slot 0 sum |div phi|, slot 1 sum div phi)
 int launch_ldu_U_correct(hipStream_t s, LduGeo g, const double* HbyA, const double* rAU, const double* p, const double* phi, double* U, double* partials);
+// ---- pimpleFoamYade (pimpleFoamYade.C:60-114, UcEqn.H, pEqn.H); see the kernels' comments
+int launch_ldu_alphaf(hipStream_t s, LduGeo g, const double* alpha, double* alphaf);
+int launch_ldu_pre_coupling(hipStream_t s, LduGeo g, const double* phi, const double* U, const double* vGrad, const double* alphaf, double* ddtU, double* divT);
+int launch_ldu_assemble_momentum_pimple(hipStream_t s, LduGeo g, LduPim P, const double* phi, const double* Uold, const double* U, const double* gradU, LduMom M, double* face_corr,
+                                        double* fstress /* [3 nF] */, double u_relax, double* rAU);
+int launch_ldu_forces(hipStream_t s, LduGeo g, LduPim P, const double* rAU, double* rAUf, double* phiForces);
+int launch_ldu_ssf_predictor(hipStream_t s, LduGeo g, const double* phiForces, const double* rAUf, const double* p, const double* gradp, double* ssf);
+int launch_ldu_reconstruct(hipStream_t s, LduGeo g, const double* ssf, const double* base, const double* scale, double* out);
+int launch_ldu_add_forces_constrain(hipStream_t s, LduGeo g, const double* phiForces, const double* rAUf, const double* U, double* phiHbyA, double* psn);
+int launch_ldu_pim_pfaces(hipStream_t s, LduGeo g, const double* alphaf, const double* rAUf, const double* phiHbyA, const double* psn, double* arAUf, double* phiA);
+int launch_ldu_prhs_ddt_alpha(hipStream_t s, LduGeo g, const double* alpha, const double* alphaOld, double* prhs);
+int launch_ldu_pim_flux(hipStream_t s, LduGeo g, const double* p, const double* phiHbyA, const double* pcoef, const double* pcorr, const double* alphaf, const double* rAUf,
+                        const double* phiForces, const double* psn, double* phi, double* ssf);
+int launch_ldu_pim_continuity(hipStream_t s, LduGeo g, const double* phi, const double* alphaf, const double* alpha, const double* alphaOld, double* partials);
 int launch_ldu_sum(hipStream_t s, const double* x, int n, int ncomp, double* partials);                  // slot q = sum of component q
 // mesh.findCell stand-in for the point-force locate: from the nearest centre (hint[i], or -1: not located) walk across the face the point lies
 // furthest outside of until it lies inside every face of a cell; cell_out[i] = that cell or -1 (outside the mesh)

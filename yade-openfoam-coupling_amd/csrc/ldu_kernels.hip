@@ -25,7 +25,10 @@ __device__ __forceinline__ D3 Ub(const LduGeo& g, const double* F, int f) {
 }
 __device__ __forceinline__ double pbv(const LduGeo& g, const double* p, int f) {
     const int pa = g.patch_of[f - g.nInt];
-    return g.p_bc[pa] == FY_BC_P_FIXED_VALUE ? g.p_val[pa] : p[g.own[f]];
+    if (g.p_bc[pa] == FY_BC_P_FIXED_VALUE) return g.p_val[pa];
+    // fixedFluxPressure is a fixed-gradient condition: p_b = p_P + snGrad / deltaCoeffs, the gradient as constrainPressure left it (pEqn.H:21)
+    if (g.p_bc[pa] == FY_BC_P_FIXED_FLUX && g.psn) return p[g.own[f]] + g.psn[f - g.nInt] / g.dcNO[f];
+    return p[g.own[f]];
 }
 
 // the faces of cell c in ascending face order through the slot tables (LduGeo::ef / en, slot-major like the ELL matrix: the lanes of a wave read consecutive
@@ -185,16 +188,16 @@ __device__ __forceinline__ void mom_offdiag(const LduGeo& g, const LduMom& M, co
     if (offsum) *offsum = os;
 }
 // the momentum predictor's Jacobi pass (solve(UEqn == -fvc::grad(p)), icoFoamYade.C:91-94): residual sums of x and the next iterate in one pass
-__global__ __launch_bounds__(256) void k_ldu_mom_pass(LduGeo g, LduMom M, const double* __restrict__ gradp, const double* __restrict__ x, double* __restrict__ xn,
-                                                      const double* __restrict__ xsum3, double* __restrict__ partials) {
+__global__ __launch_bounds__(256) void k_ldu_mom_pass(LduGeo g, LduMom M, const double* __restrict__ rhs, const double* __restrict__ gradp, const double* __restrict__ x,
+                                                      double* __restrict__ xn, const double* __restrict__ xsum3, double* __restrict__ partials) {
     double v[6] = {0, 0, 0, 0, 0, 0};
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c < g.nCells) {
         double s[3], os;
         mom_offdiag(g, M, x, c, s, &os);
         const double dg = M.diag[c], Vc = g.V[c];
-        const D3 b0 = ld3(M.b, c), gp = ld3(gradp, c), xc = ld3(x, c);
-        const double b[3] = {b0.x - Vc * gp.x, b0.y - Vc * gp.y, b0.z - Vc * gp.z}, xx[3] = {xc.x, xc.y, xc.z};
+        const D3 b0 = ld3(rhs, c), gp = gradp ? ld3(gradp, c) : D3{0, 0, 0}, xc = ld3(x, c);
+        const double b[3] = {gradp ? b0.x - Vc * gp.x : b0.x, gradp ? b0.y - Vc * gp.y : b0.y, gradp ? b0.z - Vc * gp.z : b0.z}, xx[3] = {xc.x, xc.y, xc.z};
         double o[3];
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
@@ -225,7 +228,7 @@ __global__ __launch_bounds__(256) void k_ldu_HbyA(LduGeo g, LduMom M, const doub
 
 // phiHbyA = fvc::flux(HbyA) + fvc::interpolate(rAU) fvc::ddtCorr(U, phi) (icoFoamYade.C:101-106) [OF-6 EulerDdtScheme::fvcDdtPhiCorr / fvcDdtPhiCoeff]
 __global__ __launch_bounds__(256) void k_ldu_phiHbyA(LduGeo g, const double* __restrict__ HbyA, const double* __restrict__ rAU, const double* __restrict__ Uold,
-                                                     const double* __restrict__ phiOld, double* __restrict__ rAUf, double* __restrict__ phiHbyA) {
+                                                     const double* __restrict__ phiOld, const double* __restrict__ alphaf, double* __restrict__ rAUf, double* __restrict__ phiHbyA) {
     const int f = blockIdx.x * 256 + threadIdx.x;
     if (f >= g.nFaces) return;
     const D3 S = ld3(g.Sf, f);
@@ -247,7 +250,9 @@ __global__ __launch_bounds__(256) void k_ldu_phiHbyA(LduGeo g, const double* __r
     const double phiCorr = phiOld[f] - uf;
     const double coef = fixes ? 0.0 : 1.0 - fmin(fabs(phiCorr) / (fabs(phiOld[f]) + 1e-15), 1.0);
     rAUf[f] = rf;
-    phiHbyA[f] = fl + rf * (coef * (1.0 / g.dt) * phiCorr);
+    double add = rf * (coef * (1.0 / g.dt) * phiCorr);
+    if (alphaf) add *= alphaf[f];                         // pEqn.H:9: alphacf rAUcf ddtCorr(Uc, phic)
+    phiHbyA[f] = fl + add;
 }
 
 // adjustPhi [OF-6 adjustPhi.C] (icoFoamYade.C:108), only when no patch fixes the pressure: the four sums as block partials (folded by k_reduce_finalize),
@@ -363,6 +368,260 @@ __global__ __launch_bounds__(256) void k_ldu_U_correct(LduGeo g, const double* _
     block_reduce_store<2>(v, mx, partials);
 }
 
+
+// =====================================================================================================================================
+// pimpleFoamYade on the general mesh (pimpleFoamYade.C:60-114, UcEqn.H, pEqn.H): the alpha-weighted equations.  alphac's boundary value is 1
+// (FoamYade.C:68), uSource's 0; laminar Stokes stress [OF-6 linearViscousStress::divDevRhoReff]; what restates it on the CPU: oracle/ldu_oracle.cpp
+__global__ __launch_bounds__(256) void k_ldu_alphaf(LduGeo g, const double* __restrict__ alpha, double* __restrict__ alphaf) {
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= g.nFaces) return;
+    alphaf[f] = f < g.nInt ? g.w[f] * alpha[g.own[f]] + (1.0 - g.w[f]) * alpha[g.nei[f]] : 1.0;
+}
+
+// the coupling's input fields (pimpleFoamYade.C:73-76): ddtU_f = fvc::ddt(Uc) + fvc::div(phic, Uc) -- the ddt is zero where it is evaluated (DESIGN.md
+// section 4, quirk F-Q1's mechanism) --, divT = 2 nu fvc::laplacian(alphac, Uc) with the corrected scheme; gradP and vGrad by the gradient kernels
+__global__ __launch_bounds__(256) void k_ldu_pre_coupling(LduGeo g, const double* __restrict__ phi, const double* __restrict__ U, const double* __restrict__ vGrad,
+                                                          const double* __restrict__ alphaf, double* __restrict__ ddtU, double* __restrict__ divT) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= g.nCells) return;
+    const D3 uc = ld3(U, c);
+    double cv[3] = {0, 0, 0}, lp[3] = {0, 0, 0};
+    FY_CELL_FACES(g, c, f, nb) {
+        const double af = alphaf[f], gm = af * g.magSf[f];
+        if (f < g.nInt) {
+            const bool o = nb > c;
+            const D3 un = ld3(U, nb);
+            const double w = g.w[f], wc = o ? w : 1.0 - w;                  // the weight of THIS cell's value
+            const double fl = o ? phi[f] : -phi[f];
+            const double uf[3] = {wc * uc.x + (1.0 - wc) * un.x, wc * uc.y + (1.0 - wc) * un.y, wc * uc.z + (1.0 - wc) * un.z};
+            const D3 k = ld3(g.kvec, f);
+            const double* To = vGrad + 9 * (size_t)(o ? c : nb);
+            const double* Tn = vGrad + 9 * (size_t)(o ? nb : c);
+            const double sg = o ? 1.0 : -1.0, du[3] = {un.x - uc.x, un.y - uc.y, un.z - uc.z}, kk[3] = {k.x, k.y, k.z};
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                double cj = 0.0;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) cj += kk[i] * (w * To[3 * i + j] + (1.0 - w) * Tn[3 * i + j]);
+                cv[j] += fl * uf[j];
+                lp[j] += gm * (g.dcNO[f] * du[j] + sg * cj);               // outward normal gradient: the correction vector points owner -> neighbour
+            }
+        } else {
+            const D3 ub = Ub(g, U, f);
+            cv[0] += phi[f] * ub.x; cv[1] += phi[f] * ub.y; cv[2] += phi[f] * ub.z;
+            lp[0] += gm * g.dcNO[f] * (ub.x - uc.x); lp[1] += gm * g.dcNO[f] * (ub.y - uc.y); lp[2] += gm * g.dcNO[f] * (ub.z - uc.z);
+        }
+    }
+    const double rV = 1.0 / g.V[c];
+    st3(ddtU, c, D3{cv[0] * rV, cv[1] * rV, cv[2] * rV});
+    st3(divT, c, D3{2 * g.nu * (lp[0] * rV), 2 * g.nu * (lp[1] * rV), 2 * g.nu * (lp[2] * rV)});
+}
+
+// UcEqn.H:3-10, face part: fvm::div(alphaPhic, Uc) and - fvm::laplacian(alpha nu, Uc) as lower / upper, the corrected laplacian's explicit flux, and the flux
+// of the explicit stress Sf . (alpha nu dev2(T(grad U)))_f (the cell tensor interpolated linearly; a boundary face takes its cell's)
+__global__ __launch_bounds__(256) void k_ldu_pmom_faces(LduGeo g, const double* __restrict__ phi, const double* __restrict__ alpha, const double* __restrict__ alphaf,
+                                                        const double* __restrict__ gradU, LduMom M, double* __restrict__ corr, double* __restrict__ fstress) {
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= g.nFaces) return;
+    const D3 S = ld3(g.Sf, f);
+    const double ss[3] = {S.x, S.y, S.z};
+    const int o = g.own[f];
+    const double* To = gradU + 9 * (size_t)o;
+    const double tro = To[0] + To[4] + To[8], ao = alpha[o] * g.nu;
+    if (f >= g.nInt) {
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            double t = 0.0;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) t += ss[a] * (ao * (To[3 * b + a] - (a == b ? (2.0 / 3.0) * tro : 0.0)));
+            fstress[3 * (size_t)f + b] = t;
+        }
+        return;
+    }
+    const int n = g.nei[f];
+    const double* Tn = gradU + 9 * (size_t)n;
+    const double trn = Tn[0] + Tn[4] + Tn[8], an = alpha[n] * g.nu, w = g.w[f];
+    const double af = alphaf[f], fl = af * phi[f], gm = g.nu * af * g.magSf[f];
+    double lo = -w * fl;
+    double up = lo + fl;
+    lo -= gm * g.dcNO[f]; up -= gm * g.dcNO[f];
+    M.lower[f] = lo; M.upper[f] = up;
+    const D3 k = ld3(g.kvec, f);
+    const double kk[3] = {k.x, k.y, k.z};
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        double cj = 0.0, t = 0.0;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            cj += kk[a] * (w * To[3 * a + b] + (1.0 - w) * Tn[3 * a + b]);
+            const double go = ao * (To[3 * b + a] - (a == b ? (2.0 / 3.0) * tro : 0.0)), gn = an * (Tn[3 * b + a] - (a == b ? (2.0 / 3.0) * trn : 0.0));
+            t += ss[a] * (w * go + (1.0 - w) * gn);
+        }
+        corr[3 * (size_t)f + b] = gm * cj;
+        fstress[3 * (size_t)f + b] = t;
+    }
+}
+// ... cell part: fvm::ddt(alphac, Uc), negSumDiag, the patches, - fvm::Sp(fvc::ddt(alphac) + fvc::div(alphaPhic)), == fvm::Sp(uSourceDrag), the explicit fluxes'
+// divergences on the right-hand side, UcEqn.relax() [OF-6 fvMatrix::relax: D = max(|D|, sum |offdiag|) / factor, source += (D_new - D) psi; no factor: nothing]
+__global__ __launch_bounds__(256) void k_ldu_pmom_cells(LduGeo g, const double* __restrict__ phi, const double* __restrict__ alpha, const double* __restrict__ alphaOld,
+                                                        const double* __restrict__ alphaf, const double* __restrict__ Uold, const double* __restrict__ U,
+                                                        const double* __restrict__ uSourceDrag, LduMom M, const double* __restrict__ corr, const double* __restrict__ fstress,
+                                                        double u_relax, double* __restrict__ rAU) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= g.nCells) return;
+    const double Vc = g.V[c], rdt = Vc / g.dt;
+    double dg = alpha[c] * rdt;
+    const D3 uo = ld3(Uold, c);
+    double b[3] = {alphaOld[c] * rdt * uo.x, alphaOld[c] * rdt * uo.y, alphaOld[c] * rdt * uo.z};
+    double divAPhi = 0.0, offsum = 0.0;
+    FY_CELL_FACES(g, c, f, nb) {
+        const D3 st = ld3(fstress, f);
+        if (f < g.nInt) {
+            const D3 cr = ld3(corr, f);
+            const double fl = alphaf[f] * phi[f];
+            if (nb > c) { dg -= M.lower[f]; offsum += fabs(M.upper[f]); divAPhi += fl; b[0] += cr.x + st.x; b[1] += cr.y + st.y; b[2] += cr.z + st.z; }
+            else { dg -= M.upper[f]; offsum += fabs(M.lower[f]); divAPhi -= fl; b[0] -= cr.x + st.x; b[1] -= cr.y + st.y; b[2] -= cr.z + st.z; }
+        } else {
+            const int pa = g.patch_of[f - g.nInt];
+            divAPhi += phi[f];
+            b[0] += st.x; b[1] += st.y; b[2] += st.z;
+            if (g.u_bc[pa] == FY_BC_U_FIXED_VALUE) {
+                const double gm = g.nu * g.magSf[f] * g.dcNO[f];
+                const D3 ub = ld3(g.u_val, pa);
+                dg += gm;
+                b[0] += (-phi[f] + gm) * ub.x; b[1] += (-phi[f] + gm) * ub.y; b[2] += (-phi[f] + gm) * ub.z;
+            } else {
+                dg += phi[f];
+            }
+        }
+    }
+    const double S = (alpha[c] - alphaOld[c]) / g.dt + divAPhi / Vc;
+    dg -= Vc * S;
+    dg -= Vc * uSourceDrag[c];
+    if (u_relax > 0) {
+        const double dn = fmax(fabs(dg), offsum) / u_relax;
+        const D3 uc = ld3(U, c);
+        b[0] += (dn - dg) * uc.x; b[1] += (dn - dg) * uc.y; b[2] += (dn - dg) * uc.z;
+        dg = dn;
+    }
+    M.diag[c] = dg;
+    st3(M.b, c, D3{b[0], b[1], b[2]});
+    rAU[c] = 1.0 / (dg / Vc);
+}
+
+// rAUcf = interpolate(rAUc) (boundary: the cell's), phicForces = fvc::flux(rAUc uSource) + rAUcf (g & Sf) (UcEqn.H:15-20)
+__global__ __launch_bounds__(256) void k_ldu_forces(LduGeo g, const double* __restrict__ rAU, const double* __restrict__ uSource, double gx, double gy, double gz,
+                                                    double* __restrict__ rAUf, double* __restrict__ phiForces) {
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= g.nFaces) return;
+    const D3 S = ld3(g.Sf, f);
+    double rf, fl = 0.0;
+    if (f < g.nInt) {
+        const int o = g.own[f], n = g.nei[f];
+        const double w = g.w[f], ro = rAU[o], rn = rAU[n];
+        const D3 so = ld3(uSource, o), sn = ld3(uSource, n);
+        rf = w * ro + (1.0 - w) * rn;
+        fl = dot3(D3{w * (ro * so.x) + (1.0 - w) * (rn * sn.x), w * (ro * so.y) + (1.0 - w) * (rn * sn.y), w * (ro * so.z) + (1.0 - w) * (rn * sn.z)}, S);
+    } else rf = rAU[g.own[f]];
+    rAUf[f] = rf;
+    phiForces[f] = fl + rf * dot3(D3{gx, gy, gz}, S);
+}
+
+// the face field the momentum predictor reconstructs (UcEqn.H:26-31): phicForces / rAUcf - snGrad(p) |Sf|, snGrad with the non-orthogonal correction
+__global__ __launch_bounds__(256) void k_ldu_ssf_predictor(LduGeo g, const double* __restrict__ phiForces, const double* __restrict__ rAUf, const double* __restrict__ p,
+                                                           const double* __restrict__ gradp, double* __restrict__ ssf) {
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= g.nFaces) return;
+    double sn;
+    if (f < g.nInt) {
+        const int o = g.own[f], n = g.nei[f];
+        sn = g.dcNO[f] * (p[n] - p[o]) + dot3(ld3(g.kvec, f), lerp3(g.w[f], ld3(gradp, o), ld3(gradp, n)));
+    } else sn = g.dcNO[f] * (pbv(g, p, f) - p[g.own[f]]);
+    ssf[f] = phiForces[f] / rAUf[f] - sn * g.magSf[f];
+}
+
+// out = base + scale fvc::reconstruct(ssf) [OF-6 fvcReconstruct.C: inv(surfaceSum(Sf Sf / |Sf|)) & surfaceSum(Sf / |Sf| ssf)]; the inverse tensors are the mesh's
+// (LduGeo::recon).  scale = V (the predictor's right-hand side, base = the matrix source) or rAUc (pEqn.H:43-45, base = HbyA)
+__global__ __launch_bounds__(256) void k_ldu_reconstruct(LduGeo g, const double* __restrict__ ssf, const double* __restrict__ base, const double* __restrict__ scale,
+                                                         double* __restrict__ out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= g.nCells) return;
+    double a[3] = {0, 0, 0};
+    FY_CELL_FACES(g, c, f, nb) {
+        const D3 S = ld3(g.Sf, f);
+        const double t = ssf[f] / g.magSf[f];
+        a[0] += S.x * t; a[1] += S.y * t; a[2] += S.z * t;
+        (void)nb;
+    }
+    const double* R = g.recon + 9 * (size_t)c;
+    const D3 b = ld3(base, c);
+    const double sc = scale[c];
+    st3(out, c, D3{b.x + sc * (R[0] * a[0] + R[1] * a[1] + R[2] * a[2]), b.y + sc * (R[3] * a[0] + R[4] * a[1] + R[5] * a[2]), b.z + sc * (R[6] * a[0] + R[7] * a[1] + R[8] * a[2])});
+}
+
+// pEqn.H:4-21 after adjustPhi: phiHbyA += phicForces; constrainPressure: snGrad(p) = (phiHbyA - Sf . U_b) / (|Sf| rAUcf) on the fixedFluxPressure faces
+__global__ __launch_bounds__(256) void k_ldu_add_forces_constrain(LduGeo g, const double* __restrict__ phiForces, const double* __restrict__ rAUf, const double* __restrict__ U,
+                                                                  double* __restrict__ phiHbyA, double* __restrict__ psn) {
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= g.nFaces) return;
+    const double v = phiHbyA[f] + phiForces[f];
+    phiHbyA[f] = v;
+    if (f >= g.nInt) {
+        const int pa = g.patch_of[f - g.nInt];
+        psn[f - g.nInt] = g.p_bc[pa] == FY_BC_P_FIXED_FLUX ? (v - dot3(Ub(g, U, f), ld3(g.Sf, f))) / (g.magSf[f] * rAUf[f]) : 0.0;
+    }
+}
+
+// what the pressure assembly kernels of the point-force solver take: the diffusivity alphacf rAUcf, and the flux alphacf phiHbyA whose divergence is the source
+// (a fixedFluxPressure face contributes its fixed-gradient flux: what is left is Sf . U_b)
+__global__ __launch_bounds__(256) void k_ldu_pim_pfaces(LduGeo g, const double* __restrict__ alphaf, const double* __restrict__ rAUf, const double* __restrict__ phiHbyA,
+                                                        const double* __restrict__ psn, double* __restrict__ arAUf, double* __restrict__ phiA) {
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= g.nFaces) return;
+    const double af = alphaf[f];
+    arAUf[f] = af * rAUf[f];
+    double ph = af * phiHbyA[f];
+    if (f >= g.nInt && g.p_bc[g.patch_of[f - g.nInt]] == FY_BC_P_FIXED_FLUX) ph = af * (phiHbyA[f] - rAUf[f] * g.magSf[f] * psn[f - g.nInt]);
+    phiA[f] = ph;
+}
+// fvc::ddt(alphac) on the right-hand side of pEqn (pEqn.H:30)
+__global__ __launch_bounds__(256) void k_ldu_prhs_ddt_alpha(LduGeo g, const double* __restrict__ alpha, const double* __restrict__ alphaOld, double* __restrict__ prhs) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < g.nCells) prhs[c] -= g.V[c] * (alpha[c] - alphaOld[c]) / g.dt;
+}
+
+// phic = phiHbyA - pEqn.flux() / alphacf (pEqn.H:39) and the face field of the velocity correction (phicForces - pEqn.flux() / alphacf) / rAUcf (pEqn.H:43-45)
+__global__ __launch_bounds__(256) void k_ldu_pim_flux(LduGeo g, const double* __restrict__ p, const double* __restrict__ phiHbyA, const double* __restrict__ pcoef,
+                                                      const double* __restrict__ pcorr, const double* __restrict__ alphaf, const double* __restrict__ rAUf,
+                                                      const double* __restrict__ phiForces, const double* __restrict__ psn, double* __restrict__ phi, double* __restrict__ ssf) {
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= g.nFaces) return;
+    double pf;                                         // pEqn.flux() in the sign of the positive-definite form: c_f (p_N - p_P) + the explicit part
+    if (f < g.nInt) pf = pcoef[f] * (p[g.nei[f]] - p[g.own[f]]) + pcorr[f];
+    else {
+        const int pa = g.patch_of[f - g.nInt];
+        pf = g.p_bc[pa] == FY_BC_P_FIXED_VALUE ? pcoef[f] * (g.p_val[pa] - p[g.own[f]]) : (g.p_bc[pa] == FY_BC_P_FIXED_FLUX ? alphaf[f] * rAUf[f] * g.magSf[f] * psn[f - g.nInt] : 0.0);
+    }
+    const double q = pf / alphaf[f];
+    phi[f] = phiHbyA[f] - q;
+    ssf[f] = (phiForces[f] - q) / rAUf[f];
+}
+
+// continuityErrs.H of pimpleFoamYade: fvc::ddt(alphac) + fvc::div(alphacf phic); slot 0 sum |.| V, slot 1 sum . V
+__global__ __launch_bounds__(256) void k_ldu_pim_continuity(LduGeo g, const double* __restrict__ phi, const double* __restrict__ alphaf, const double* __restrict__ alpha,
+                                                            const double* __restrict__ alphaOld, double* __restrict__ partials) {
+    double v[2] = {0, 0};
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < g.nCells) {
+        double dv = 0.0;
+        FY_CELL_FACES(g, c, f, nb) dv += (f >= g.nInt || nb > c) ? alphaf[f] * phi[f] : -(alphaf[f] * phi[f]);
+        const double ce = dv / g.V[c] + (alpha[c] - alphaOld[c]) / g.dt;
+        v[0] = fabs(ce) * g.V[c]; v[1] = ce * g.V[c];
+    }
+    const int mx[2] = {0, 0};
+    block_reduce_store<2>(v, mx, partials);
+}
+
 __global__ __launch_bounds__(256) void k_ldu_sum(const double* __restrict__ x, int n, int ncomp, double* __restrict__ partials) {
     double v[3] = {0, 0, 0};
     const int c = blockIdx.x * 256 + threadIdx.x;
@@ -441,8 +700,8 @@ int launch_ldu_assemble_momentum(hipStream_t s, LduGeo g, const double* phi, con
     FY_LAUNCH_CHECK();
     return FY_OK;
 }
-int launch_ldu_mom_pass(hipStream_t s, LduGeo g, LduMom M, const double* gradp, const double* x, double* xn, const double* xsum3, double* partials) {
-    hipLaunchKernelGGL(k_ldu_mom_pass, dim3(red_blocks(g.nCells)), dim3(256), 0, s, g, M, gradp, x, xn, xsum3, partials);
+int launch_ldu_mom_pass(hipStream_t s, LduGeo g, LduMom M, const double* rhs, const double* gradp, const double* x, double* xn, const double* xsum3, double* partials) {
+    hipLaunchKernelGGL(k_ldu_mom_pass, dim3(red_blocks(g.nCells)), dim3(256), 0, s, g, M, rhs, gradp, x, xn, xsum3, partials);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }
@@ -451,8 +710,8 @@ int launch_ldu_HbyA(hipStream_t s, LduGeo g, LduMom M, const double* U, double* 
     FY_LAUNCH_CHECK();
     return FY_OK;
 }
-int launch_ldu_phiHbyA(hipStream_t s, LduGeo g, const double* HbyA, const double* rAU, const double* Uold, const double* phiOld, double* rAUf, double* phiHbyA) {
-    hipLaunchKernelGGL(k_ldu_phiHbyA, dim3(div_up(g.nFaces, 256)), dim3(256), 0, s, g, HbyA, rAU, Uold, phiOld, rAUf, phiHbyA);
+int launch_ldu_phiHbyA(hipStream_t s, LduGeo g, const double* HbyA, const double* rAU, const double* Uold, const double* phiOld, const double* alphaf, double* rAUf, double* phiHbyA) {
+    hipLaunchKernelGGL(k_ldu_phiHbyA, dim3(div_up(g.nFaces, 256)), dim3(256), 0, s, g, HbyA, rAU, Uold, phiOld, alphaf, rAUf, phiHbyA);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }
@@ -482,6 +741,66 @@ int launch_ldu_flux_correct(hipStream_t s, LduGeo g, const double* p, const doub
 }
 int launch_ldu_U_correct(hipStream_t s, LduGeo g, const double* HbyA, const double* rAU, const double* p, const double* phi, double* U, double* partials) {
     hipLaunchKernelGGL(k_ldu_U_correct, dim3(red_blocks(g.nCells)), dim3(256), 0, s, g, HbyA, rAU, p, phi, U, partials);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+
+// ---- pimpleFoamYade
+int launch_ldu_alphaf(hipStream_t s, LduGeo g, const double* alpha, double* alphaf) {
+    hipLaunchKernelGGL(k_ldu_alphaf, dim3(div_up(g.nFaces, 256)), dim3(256), 0, s, g, alpha, alphaf);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+int launch_ldu_pre_coupling(hipStream_t s, LduGeo g, const double* phi, const double* U, const double* vGrad, const double* alphaf, double* ddtU, double* divT) {
+    hipLaunchKernelGGL(k_ldu_pre_coupling, dim3(div_up(g.nCells, 256)), dim3(256), 0, s, g, phi, U, vGrad, alphaf, ddtU, divT);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+int launch_ldu_assemble_momentum_pimple(hipStream_t s, LduGeo g, LduPim P, const double* phi, const double* Uold, const double* U, const double* gradU, LduMom M, double* face_corr,
+                                        double* fstress, double u_relax, double* rAU) {
+    hipLaunchKernelGGL(k_ldu_pmom_faces, dim3(div_up(g.nFaces, 256)), dim3(256), 0, s, g, phi, P.alpha, P.alphaf, gradU, M, face_corr, fstress);
+    hipLaunchKernelGGL(k_ldu_pmom_cells, dim3(div_up(g.nCells, 256)), dim3(256), 0, s, g, phi, P.alpha, P.alphaOld, P.alphaf, Uold, U, P.uSourceDrag, M, face_corr, fstress, u_relax, rAU);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+int launch_ldu_forces(hipStream_t s, LduGeo g, LduPim P, const double* rAU, double* rAUf, double* phiForces) {
+    hipLaunchKernelGGL(k_ldu_forces, dim3(div_up(g.nFaces, 256)), dim3(256), 0, s, g, rAU, P.uSource, P.g[0], P.g[1], P.g[2], rAUf, phiForces);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+int launch_ldu_ssf_predictor(hipStream_t s, LduGeo g, const double* phiForces, const double* rAUf, const double* p, const double* gradp, double* ssf) {
+    hipLaunchKernelGGL(k_ldu_ssf_predictor, dim3(div_up(g.nFaces, 256)), dim3(256), 0, s, g, phiForces, rAUf, p, gradp, ssf);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+int launch_ldu_reconstruct(hipStream_t s, LduGeo g, const double* ssf, const double* base, const double* scale, double* out) {
+    hipLaunchKernelGGL(k_ldu_reconstruct, dim3(div_up(g.nCells, 256)), dim3(256), 0, s, g, ssf, base, scale, out);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+int launch_ldu_add_forces_constrain(hipStream_t s, LduGeo g, const double* phiForces, const double* rAUf, const double* U, double* phiHbyA, double* psn) {
+    hipLaunchKernelGGL(k_ldu_add_forces_constrain, dim3(div_up(g.nFaces, 256)), dim3(256), 0, s, g, phiForces, rAUf, U, phiHbyA, psn);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+int launch_ldu_pim_pfaces(hipStream_t s, LduGeo g, const double* alphaf, const double* rAUf, const double* phiHbyA, const double* psn, double* arAUf, double* phiA) {
+    hipLaunchKernelGGL(k_ldu_pim_pfaces, dim3(div_up(g.nFaces, 256)), dim3(256), 0, s, g, alphaf, rAUf, phiHbyA, psn, arAUf, phiA);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+int launch_ldu_prhs_ddt_alpha(hipStream_t s, LduGeo g, const double* alpha, const double* alphaOld, double* prhs) {
+    hipLaunchKernelGGL(k_ldu_prhs_ddt_alpha, dim3(div_up(g.nCells, 256)), dim3(256), 0, s, g, alpha, alphaOld, prhs);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+int launch_ldu_pim_flux(hipStream_t s, LduGeo g, const double* p, const double* phiHbyA, const double* pcoef, const double* pcorr, const double* alphaf, const double* rAUf,
+                        const double* phiForces, const double* psn, double* phi, double* ssf) {
+    hipLaunchKernelGGL(k_ldu_pim_flux, dim3(div_up(g.nFaces, 256)), dim3(256), 0, s, g, p, phiHbyA, pcoef, pcorr, alphaf, rAUf, phiForces, psn, phi, ssf);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+int launch_ldu_pim_continuity(hipStream_t s, LduGeo g, const double* phi, const double* alphaf, const double* alpha, const double* alphaOld, double* partials) {
+    hipLaunchKernelGGL(k_ldu_pim_continuity, dim3(red_blocks(g.nCells)), dim3(256), 0, s, g, phi, alphaf, alpha, alphaOld, partials);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }

@@ -116,6 +116,29 @@ int LduHostMesh::build(const fy_poly_mesh* m) {
         put(C, c, (1.0 / V[(size_t)c]) * at(C.data(), c));
         V[(size_t)c] *= (1.0 / 3.0);
     }
+    // ---- fvc::reconstruct's tensor: inv(sum over the cell's faces of Sf Sf / |Sf|) (symmetric positive definite for any closed cell)
+    recon.assign(9 * (size_t)nCells, 0.0);
+    {
+        std::vector<double> T(9 * (size_t)nCells, 0.0);
+        for (int f = 0; f < nFaces; ++f) {
+            const V3 S = at(Sf.data(), f);
+            const double s[3] = {S.x, S.y, S.z}, r = 1.0 / magSf[(size_t)f];
+            for (int side = 0; side < (f < nInt ? 2 : 1); ++side) {
+                double* t = &T[9 * (size_t)(side ? nei[f] : own[f])];
+                for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) t[3 * a + b] += s[a] * s[b] * r;
+            }
+        }
+        for (int c = 0; c < nCells; ++c) {
+            const double* t = &T[9 * (size_t)c];
+            double* q = &recon[9 * (size_t)c];
+            const double det = t[0] * (t[4] * t[8] - t[5] * t[7]) - t[1] * (t[3] * t[8] - t[5] * t[6]) + t[2] * (t[3] * t[7] - t[4] * t[6]);
+            if (!(std::fabs(det) > 0)) return fail(FY_ERR_INVALID, "fy_poly_mesh: cell %d is flat (its face-area tensor cannot be inverted)", c);
+            const double r = 1.0 / det;
+            q[0] = (t[4] * t[8] - t[5] * t[7]) * r; q[1] = (t[2] * t[7] - t[1] * t[8]) * r; q[2] = (t[1] * t[5] - t[2] * t[4]) * r;
+            q[3] = (t[5] * t[6] - t[3] * t[8]) * r; q[4] = (t[0] * t[8] - t[2] * t[6]) * r; q[5] = (t[2] * t[3] - t[0] * t[5]) * r;
+            q[6] = (t[3] * t[7] - t[4] * t[6]) * r; q[7] = (t[1] * t[6] - t[0] * t[7]) * r; q[8] = (t[0] * t[4] - t[1] * t[3]) * r;
+        }
+    }
     // ---- interpolation / gradient coefficients
     w.assign((size_t)nInt, 0.5); dcNO.assign((size_t)nFaces, 0.0); kvec.assign(3 * (size_t)nInt, 0.0);
     for (int f = 0; f < nInt; ++f) {

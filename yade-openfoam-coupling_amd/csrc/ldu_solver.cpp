@@ -26,11 +26,15 @@ struct LduSolver {
     int nc = 0, nf = 0, ni = 0;
     // geometry + addressing on the device
     DevBuf<int32_t> d_own, d_nei, d_patch_of, d_cf_off, d_cf_face, d_ubc, d_pbc, d_ef, d_en;
-    DevBuf<double> d_Cf, d_Sf, d_magSf, d_C, d_V, d_w, d_dcNO, d_kvec, d_uval, d_pval;
+    DevBuf<double> d_Cf, d_Sf, d_magSf, d_C, d_V, d_w, d_dcNO, d_kvec, d_uval, d_pval, d_recon;
     // fields
     DevBuf<double> U, Uold, p, phi, phiOld, uSource, uSourceExt, uSourceSum, vGrad, gradp, dummy3, dummy1;
     DevBuf<double> mdiag, mlower, mupper, mb, fcorr, xscr, rAU, HbyA, rAUf, phiHbyA, pcoef, pcorr, pdiag, prhs, pr, pu, pw, pp, ps;
     DevBuf<double> partials, sc, xsum, adj;
+    // pimpleFoamYade: the coupling's fields and the alpha-weighted equations' face fields
+    bool pimple = false, hold_sources = false, sources_pending = false;
+    DevBuf<double> alpha, alphaf, uSourceDrag, uParticle, gradP, divT, ddtU, fstress, phiForces, psn, arAUf, phiA, ssf, bmom, pPrev;
+    LduPim P() const { return LduPim{alpha.p, alpha.p, alphaf.p, uSourceDrag.p, uSource.p, {cs.g[0], cs.g[1], cs.g[2]}}; }      // alphac.oldTime() == alphac
     DevBuf<int> adj_err;
     bool need_ref = true, ext_source = false;
     LduAmg amg;                  // the pressure matrix in ELL form; with p_solver = FY_PSOLVER_PCG_MG also the agglomeration hierarchy
@@ -58,13 +62,17 @@ struct LduSolver {
         if (dev < 0 || dev >= ndev) return fail(FY_ERR_INVALID, "device ordinal out of range");
         FY_TRY(hm.build(m));
         cs = *c; device = dev;
+        pimple = c->solver == FY_SOLVER_PIMPLE;
+        if (c->solver != FY_SOLVER_ICO && !pimple) return fail(FY_ERR_INVALID, "fy_ldu_solver: solver %d (FY_SOLVER_ICO, FY_SOLVER_PIMPLE)", c->solver);
+        if (pimple && c->n_outer_correctors < 1) cs.n_outer_correctors = 1;
         nc = hm.nCells; nf = hm.nFaces; ni = hm.nInt;
         std::vector<int32_t> ubc(c->u_bc, c->u_bc + hm.nPatches), pbc(c->p_bc, c->p_bc + hm.nPatches);
         std::vector<double> uval(c->u_value, c->u_value + 3 * (size_t)hm.nPatches), pval(c->p_value, c->p_value + hm.nPatches);
         need_ref = true;
         for (int pa = 0; pa < hm.nPatches; ++pa) {
             if (ubc[(size_t)pa] != FY_BC_U_FIXED_VALUE && ubc[(size_t)pa] != FY_BC_U_ZERO_GRADIENT) return fail(FY_ERR_UNSUPPORTED, "fy_ldu_solver: velocity patch type %d (fixedValue, zeroGradient)", ubc[(size_t)pa]);
-            if (pbc[(size_t)pa] != FY_BC_P_ZERO_GRADIENT && pbc[(size_t)pa] != FY_BC_P_FIXED_VALUE) return fail(FY_ERR_UNSUPPORTED, "fy_ldu_solver: pressure patch type %d (zeroGradient, fixedValue)", pbc[(size_t)pa]);
+            if (pbc[(size_t)pa] != FY_BC_P_ZERO_GRADIENT && pbc[(size_t)pa] != FY_BC_P_FIXED_VALUE && !(pimple && pbc[(size_t)pa] == FY_BC_P_FIXED_FLUX))
+                return fail(FY_ERR_UNSUPPORTED, "fy_ldu_solver: pressure patch type %d (zeroGradient, fixedValue; fixedFluxPressure with pimpleFoamYade)", pbc[(size_t)pa]);
             if (pbc[(size_t)pa] == FY_BC_P_FIXED_VALUE) need_ref = false;
         }
         if (need_ref && (c->p_ref_cell < 0 || c->p_ref_cell >= nc)) return fail(FY_ERR_INVALID, "fy_ldu_solver: pRefCell out of range");
@@ -75,8 +83,10 @@ struct LduSolver {
         FY_TRY(up(d_own, hm.own)); FY_TRY(up(d_nei, hm.nei)); FY_TRY(up(d_patch_of, hm.patch_of)); FY_TRY(up(d_cf_off, hm.cf_off)); FY_TRY(up(d_cf_face, hm.cf_face)); FY_TRY(up(d_ef, hm.ef)); FY_TRY(up(d_en, hm.en));
         FY_TRY(up(d_Cf, hm.Cf)); FY_TRY(up(d_Sf, hm.Sf)); FY_TRY(up(d_magSf, hm.magSf)); FY_TRY(up(d_C, hm.C)); FY_TRY(up(d_V, hm.V)); FY_TRY(up(d_w, hm.w));
         FY_TRY(up(d_dcNO, hm.dcNO)); FY_TRY(up(d_kvec, hm.kvec)); FY_TRY(up(d_ubc, ubc)); FY_TRY(up(d_pbc, pbc)); FY_TRY(up(d_uval, uval)); FY_TRY(up(d_pval, pval));
+        FY_TRY(up(d_recon, hm.recon));
+        if (pimple) { FY_TRY(psn.alloc_exact(std::max<size_t>((size_t)(nf - ni), 1))); FY_TRY(zero(psn)); }
         g = LduGeo{nc, nf, ni, hm.nPatches, d_own.p, d_nei.p, d_patch_of.p, d_cf_off.p, d_cf_face.p, hm.Wall, d_ef.p, d_en.p, d_Cf.p, d_Sf.p, d_magSf.p, d_C.p, d_V.p, d_w.p, d_dcNO.p, d_kvec.p,
-                   d_ubc.p, d_pbc.p, d_uval.p, d_pval.p, cs.dt, cs.nu, need_ref ? 1 : 0, cs.p_ref_cell, cs.p_ref_value};
+                   d_ubc.p, d_pbc.p, d_uval.p, d_pval.p, d_recon.p, pimple ? psn.p : nullptr, cs.dt, cs.nu, need_ref ? 1 : 0, cs.p_ref_cell, cs.p_ref_value};
         total_volume = 0.0;
         for (double v : hm.V) total_volume += v;
         const size_t n = (size_t)nc;
@@ -93,6 +103,17 @@ struct LduSolver {
         FY_TRY(partials.alloc_exact(8 * (size_t)ldu_red_blocks(std::max(nc, nf)))); FY_TRY(zero(partials));
         FY_TRY(sc.alloc_exact(8)); FY_TRY(zero(sc)); FY_TRY(xsum.alloc_exact(4)); FY_TRY(zero(xsum)); FY_TRY(adj.alloc_exact(4)); FY_TRY(zero(adj));
         FY_TRY(adj_err.alloc_exact(1)); FY_HIP(hipMemsetAsync(adj_err.p, 0, sizeof(int), stream));
+        if (pimple) {
+            DevBuf<double>* p3[] = {&uParticle, &gradP, &divT, &ddtU, &bmom};
+            for (auto* b : p3) { FY_TRY(b->alloc_exact(3 * n)); FY_TRY(zero(*b)); }
+            DevBuf<double>* p1[] = {&alpha, &uSourceDrag, &pPrev};
+            for (auto* b : p1) { FY_TRY(b->alloc_exact(n)); FY_TRY(zero(*b)); }
+            DevBuf<double>* pf[] = {&alphaf, &phiForces, &arAUf, &phiA, &ssf};
+            for (auto* b : pf) { FY_TRY(b->alloc_exact((size_t)nf)); FY_TRY(zero(*b)); }
+            FY_TRY(fstress.alloc_exact(3 * (size_t)nf)); FY_TRY(zero(fstress));
+            FY_TRY(launch_fill_f64(stream, alpha.p, n, 1.0));                 // alpha = 1.0 (FoamYade.C:68)
+            FY_TRY(launch_fill_f64(stream, alphaf.p, (size_t)nf, 1.0));
+        }
         for (auto& t : tim) FY_TRY(t.init());
         FY_TRY(amg.build(stream, nc, ni, hm.own.data(), hm.nei.data(), hm.cf_off, hm.cf_face, hm.magSf.data(), need_ref ? cs.p_ref_cell : -1, cs.p_solver == FY_PSOLVER_PCG_MG));
         // the coupling object on this mesh (icoFoamYade.C:54: point force): its tree over the cell centres, its fields the solver's device arrays
@@ -103,13 +124,13 @@ struct LduSolver {
             for (int a = 0; a < 3; ++a) { md.bbox_min[a] = hm.bbox_min[a]; md.bbox_max[a] = hm.bbox_max[a]; md.origin[a] = hm.bbox_min[a]; }
             fy_field_ptrs fp{};
             fp.location = FY_MEM_DEVICE;
-            fp.U = U.p; fp.gradP = dummy3.p; fp.vGrad = vGrad.p; fp.divT = dummy3.p; fp.ddtU = dummy3.p;
-            fp.uSourceDrag = dummy1.p; fp.alpha = dummy1.p; fp.uSource = uSource.p; fp.uParticle = dummy3.p;
+            fp.U = U.p; fp.gradP = pimple ? gradP.p : dummy3.p; fp.vGrad = vGrad.p; fp.divT = pimple ? divT.p : dummy3.p; fp.ddtU = pimple ? ddtU.p : dummy3.p;
+            fp.uSourceDrag = pimple ? uSourceDrag.p : dummy1.p; fp.alpha = pimple ? alpha.p : dummy1.p; fp.uSource = uSource.p; fp.uParticle = pimple ? uParticle.p : dummy3.p;
             cpl = new (std::nothrow) fy_ctx();
             if (!cpl) return fail(FY_ERR_INVALID, "out of host memory");
             cpl->c.ext_stream = stream;
             cpl->c.ldu_geo = &g;
-            FY_TRY(cpl->c.create(&md, &fp, 0, tr, device));                 // gaussianInterp = false (icoFoamYade.C:53)
+            FY_TRY(cpl->c.create(&md, &fp, pimple ? 1 : 0, tr, device));        // gaussianInterp: false in icoFoamYade (icoFoamYade.C:53), true in pimpleFoamYade (pimpleFoamYade.C:52)
             cpl->c.rhoP = c->rho_particle; cpl->c.rhoF = c->rho_fluid; cpl->c.nu = c->nu;      // setScalarProperties (icoFoamYade.C:55)
         }
         FY_TRY(launch_ldu_flux_of(stream, g, U.p, phi.p));                    // createPhi
@@ -126,14 +147,14 @@ struct LduSolver {
     }
     DevBuf<int> ops_courant;
 
-    int solve_momentum(int* iters) {
+    int solve_momentum(int* iters, const double* rhs, const double* gp) {
         FY_TRY(launch_ldu_sum(stream, U.p, nc, 3, partials.p));
         FY_TRY(launch_reduce_finalize(stream, partials.p, nc, 3, nullptr, xsum.p, nullptr, 0));
         double* xc = U.p; double* xn = xscr.p;
         double norm[3] = {1, 1, 1}, res0[3] = {0, 0, 0}, res[3], h[6];
         int it = 0;
         for (;;) {
-            FY_TRY(launch_ldu_mom_pass(stream, g, M(), gradp.p, xc, xn, xsum.p, partials.p));
+            FY_TRY(launch_ldu_mom_pass(stream, g, M(), rhs, gp, xc, xn, xsum.p, partials.p));
             FY_TRY(reduce_read(nc, 6, nullptr, h));
             if (it == 0) for (int q = 0; q < 3; ++q) { norm[q] = h[3 + q] + 1e-20; res0[q] = h[q] / norm[q]; }
             bool conv = true;
@@ -190,7 +211,7 @@ struct LduSolver {
 
     int corrector(bool final_corr) {
         FY_TRY(launch_ldu_HbyA(stream, g, M(), U.p, rAU.p, HbyA.p));                                              // icoFoamYade.C:99-100
-        FY_TRY(launch_ldu_phiHbyA(stream, g, HbyA.p, rAU.p, Uold.p, phiOld.p, rAUf.p, phiHbyA.p));               // :101-106
+        FY_TRY(launch_ldu_phiHbyA(stream, g, HbyA.p, rAU.p, Uold.p, phiOld.p, nullptr, rAUf.p, phiHbyA.p));      // :101-106
         if (need_ref) FY_TRY(launch_ldu_adjust_phi(stream, g, phiHbyA.p, adj.p, adj_err.p, partials.p));                      // :108
         for (int no = 0; no <= cs.n_non_orth_correctors; ++no) {                                                   // :114-131
             FY_TRY(launch_ldu_grad_scalar(stream, g, p.p, gradp.p));
@@ -207,9 +228,70 @@ struct LduSolver {
         return FY_OK;
     }
 
+
+    // pEqn.H, one pass of the PISO loop inside a PIMPLE outer corrector
+    int corrector_pimple(bool final_corr, double p_relax_now) {
+        FY_TRY(launch_ldu_HbyA(stream, g, M(), U.p, rAU.p, HbyA.p));                                              // pEqn.H:2
+        FY_TRY(launch_ldu_phiHbyA(stream, g, HbyA.p, rAU.p, Uold.p, phiOld.p, alphaf.p, rAUf.p, phiHbyA.p));    // :4-11
+        if (need_ref) FY_TRY(launch_ldu_adjust_phi(stream, g, phiHbyA.p, adj.p, adj_err.p, partials.p));          // :13-16 (before phicForces are added)
+        FY_TRY(launch_ldu_add_forces_constrain(stream, g, phiForces.p, rAUf.p, U.p, phiHbyA.p, psn.p));          // :18-21
+        FY_TRY(launch_ldu_pim_pfaces(stream, g, alphaf.p, rAUf.p, phiHbyA.p, psn.p, arAUf.p, phiA.p));
+        for (int no = 0; no <= cs.n_non_orth_correctors; ++no) {                                                   // :24-47
+            FY_TRY(launch_ldu_grad_scalar(stream, g, p.p, gradp.p));
+            FY_TRY(launch_ldu_assemble_pressure(stream, g, arAUf.p, phiA.p, gradp.p, pcoef.p, pcorr.p, pdiag.p, prhs.p));
+            // (fvc::ddt(alphac), :30, is zero: alphac.oldTime() == alphac -- P())
+            if (no == 0) FY_TRY(amg.setup(stream, pcoef.p, pdiag.p));
+            FY_TRY(solve_pressure(final_corr && no == cs.n_non_orth_correctors));
+            if (no == cs.n_non_orth_correctors) {
+                FY_TRY(launch_ldu_pim_flux(stream, g, p.p, phiHbyA.p, pcoef.p, pcorr.p, alphaf.p, rAUf.p, phiForces.p, psn.p, phi.p, ssf.p));      // :39
+                if (p_relax_now > 0 && p_relax_now < 1) FY_TRY(launch_relax_field(stream, p.p, pPrev.p, p_relax_now, (size_t)nc));                  // :41
+            }
+        }
+        FY_TRY(launch_ldu_reconstruct(stream, g, ssf.p, HbyA.p, rAU.p, U.p));                                     // :43-46
+        FY_TRY(launch_ldu_pim_continuity(stream, g, phi.p, alphaf.p, alpha.p, alpha.p, partials.p));             // :50
+        double h[2];
+        FY_TRY(reduce_read(nc, 2, nullptr, h));
+        st.cont_err_sum_local = cs.dt * h[0] / total_volume; st.cont_err_global = cs.dt * h[1] / total_volume;
+        cumulative += st.cont_err_global; st.cont_err_cumulative = cumulative;
+        return FY_OK;
+    }
+
+    // pimpleFoamYade.C:60-114
+    int step_pimple() {
+        FY_TRY(launch_ldu_alphaf(stream, g, alpha.p, alphaf.p));
+        FY_TRY(launch_ldu_pre_coupling(stream, g, phi.p, U.p, vGrad.p, alphaf.p, ddtU.p, divT.p));              // :73, :75 (vGrad: :76, by the caller)
+        FY_TRY(launch_ldu_grad_scalar(stream, g, p.p, gradP.p));                                                  // :74
+        tim[0].start(stream);
+        FY_TRY(cpl->c.set_particle_action(cs.dt));                                                                // :78
+        tim[0].stop(stream);
+        FY_TRY(launch_ldu_alphaf(stream, g, alpha.p, alphaf.p));                                                  // :83-85
+        if (ext_source) FY_TRY(launch_add_f64(stream, uSource.p, uSourceExt.p, 3 * (size_t)nc));
+        const int nOuter = std::max(cs.n_outer_correctors, 1);
+        for (int outer = 0; outer < nOuter; ++outer) {                                                             // :90
+            const bool final_outer = outer == nOuter - 1;
+            const double u_relax_now = (final_outer && cs.u_relax_final > 0) ? cs.u_relax_final : cs.u_relax;
+            const double p_relax_now = (final_outer && cs.p_relax_final > 0) ? cs.p_relax_final : cs.p_relax;
+            if (p_relax_now > 0 && p_relax_now < 1) FY_TRY(launch_copy_f64(stream, pPrev.p, p.p, (size_t)nc));  // storePrevIterFields()
+            if (outer > 0) FY_TRY(launch_ldu_grad_vec(stream, g, U.p, vGrad.p));
+            FY_TRY(launch_ldu_assemble_momentum_pimple(stream, g, P(), phi.p, Uold.p, U.p, vGrad.p, M(), fcorr.p, fstress.p, u_relax_now, rAU.p));      // UcEqn.H:3-13
+            FY_TRY(launch_ldu_forces(stream, g, P(), rAU.p, rAUf.p, phiForces.p));                               // UcEqn.H:15-20
+            if (cs.momentum_predictor) {                                                                          // UcEqn.H:22-33
+                FY_TRY(launch_ldu_grad_scalar(stream, g, p.p, gradp.p));
+                FY_TRY(launch_ldu_ssf_predictor(stream, g, phiForces.p, rAUf.p, p.p, gradp.p, ssf.p));
+                FY_TRY(launch_ldu_reconstruct(stream, g, ssf.p, mb.p, d_V.p, bmom.p));
+                int it = 0;
+                FY_TRY(solve_momentum(&it, bmom.p, nullptr));
+                st.u_iters_total += it;
+            }
+            for (int corr = 0; corr < cs.n_correctors; ++corr) FY_TRY(corrector_pimple(final_outer && corr == cs.n_correctors - 1, p_relax_now));
+        }
+        return FY_OK;
+    }
+
     int step() {
         FY_HIP(hipSetDevice(device));
         st = fy_step_stats{}; st.cont_err_cumulative = cumulative; st.delta_t = cs.dt;
+        if (sources_pending) { FY_TRY(cpl->c.set_source_zero()); sources_pending = false; }      // the previous step's deferred setSourceZero
         tim[1].start(stream);
         if (!ops_courant.p) { FY_TRY(ops_courant.alloc_exact(2)); const int o[2] = {1, 0}; FY_HIP(hipMemcpyAsync(ops_courant.p, o, sizeof(o), hipMemcpyHostToDevice, stream)); FY_HIP(hipStreamSynchronize(stream)); }
         double h[2];
@@ -219,21 +301,25 @@ struct LduSolver {
         FY_HIP(hipMemcpyAsync(Uold.p, U.p, 3 * (size_t)nc * sizeof(double), hipMemcpyDeviceToDevice, stream));    // runTime++: old-time fields
         FY_HIP(hipMemcpyAsync(phiOld.p, phi.p, (size_t)nf * sizeof(double), hipMemcpyDeviceToDevice, stream));
         FY_TRY(launch_ldu_grad_vec(stream, g, U.p, vGrad.p));                                                      // :71
-        tim[0].start(stream);
-        FY_TRY(cpl->c.set_particle_action(cs.dt));                                                                // :74
-        tim[0].stop(stream);
-        // the momentum source: what the coupling left (+ an external one, fy_ldu_solver_write_field_host("uSource", ...))
-        const double* src = uSource.p;
-        if (ext_source) { FY_TRY(launch_copy_f64(stream, uSourceSum.p, uSource.p, 3 * (size_t)nc)); FY_TRY(launch_add_f64(stream, uSourceSum.p, uSourceExt.p, 3 * (size_t)nc)); src = uSourceSum.p; }
-        FY_TRY(launch_ldu_assemble_momentum(stream, g, phi.p, Uold.p, src, vGrad.p, M(), fcorr.p));                // :79-85 (grad U of the iterate it is assembled from = vGrad)
-        if (cs.momentum_predictor) {
-            FY_TRY(launch_ldu_grad_scalar(stream, g, p.p, gradp.p));
-            int it = 0;
-            FY_TRY(solve_momentum(&it));                                                                          // :91-94
-            st.u_iters_total += it;
+        if (pimple) FY_TRY(step_pimple());
+        else {
+            tim[0].start(stream);
+            FY_TRY(cpl->c.set_particle_action(cs.dt));                                                                // :74
+            tim[0].stop(stream);
+            // the momentum source: what the coupling left (+ an external one, fy_ldu_solver_write_field_host("uSource", ...))
+            const double* src = uSource.p;
+            if (ext_source) { FY_TRY(launch_copy_f64(stream, uSourceSum.p, uSource.p, 3 * (size_t)nc)); FY_TRY(launch_add_f64(stream, uSourceSum.p, uSourceExt.p, 3 * (size_t)nc)); src = uSourceSum.p; }
+            FY_TRY(launch_ldu_assemble_momentum(stream, g, phi.p, Uold.p, src, vGrad.p, M(), fcorr.p));                // :79-85 (grad U of the iterate it is assembled from = vGrad)
+            if (cs.momentum_predictor) {
+                FY_TRY(launch_ldu_grad_scalar(stream, g, p.p, gradp.p));
+                int it = 0;
+                FY_TRY(solve_momentum(&it, mb.p, gradp.p));                                                          // :91-94
+                st.u_iters_total += it;
+            }
+            for (int corr = 0; corr < cs.n_correctors; ++corr) FY_TRY(corrector(corr == cs.n_correctors - 1));         // :97-140
         }
-        for (int corr = 0; corr < cs.n_correctors; ++corr) FY_TRY(corrector(corr == cs.n_correctors - 1));         // :97-140
-        FY_TRY(cpl->c.set_source_zero());                                                                         // :147
+        if (hold_sources) sources_pending = true;                                                                 // runTime.write() comes before setSourceZero (icoFoamYade.C:142-147)
+        else FY_TRY(cpl->c.set_source_zero());                                                                    // :147
         tim[1].stop(stream);
         FY_HIP(hipStreamSynchronize(stream));
         if (need_ref) {
@@ -252,7 +338,10 @@ struct LduSolver {
         struct E { const char* nm; double* p; size_t c; };
         const E tab[] = {{"U", U.p, 3 * n}, {"p", p.p, n}, {"phi", phi.p, (size_t)nf}, {"uSource", uSourceExt.p, 3 * n}, {"rAU", rAU.p, n}, {"HbyA", HbyA.p, 3 * n},
                          {"phiHbyA", phiHbyA.p, (size_t)nf}, {"p_diag", pdiag.p, n}, {"p_coef", pcoef.p, (size_t)nf}, {"p_rhs", prhs.p, n}, {"vGrad", vGrad.p, 9 * n},
-                         {"mom_diag", mdiag.p, n}, {"mom_lower", mlower.p, (size_t)ni}, {"mom_upper", mupper.p, (size_t)ni}, {"mom_b", mb.p, 3 * n}};
+                         {"mom_diag", mdiag.p, n}, {"mom_lower", mlower.p, (size_t)ni}, {"mom_upper", mupper.p, (size_t)ni}, {"mom_b", mb.p, 3 * n},
+                         {"alpha", alpha.p, pimple ? n : 0}, {"uSourceDrag", uSourceDrag.p, pimple ? n : 0}, {"uParticle", uParticle.p, pimple ? 3 * n : 0}, {"gradP", gradP.p, pimple ? 3 * n : 0},
+                         {"divT", divT.p, pimple ? 3 * n : 0}, {"ddtU", ddtU.p, pimple ? 3 * n : 0}, {"phiForces", phiForces.p, pimple ? (size_t)nf : 0}, {"alphaf", alphaf.p, pimple ? (size_t)nf : 0},
+                         {"rAUf", rAUf.p, (size_t)nf}, {"uSourceCoupling", uSource.p, 3 * n}};
         for (const E& e : tab) if (s == e.nm) { *ptr = e.p; *count = e.c; return FY_OK; }
         const struct { const char* nm; const std::vector<double>* v; } geo[] = {{"C", &hm.C}, {"V", &hm.V}, {"Cf", &hm.Cf}, {"Sf", &hm.Sf}, {"magSf", &hm.magSf}, {"w", &hm.w},
                                                                                   {"dcNO", &hm.dcNO}, {"kvec", &hm.kvec}};
@@ -275,6 +364,7 @@ void fy_ldu_case_defaults(fy_ldu_case* c) {
     c->p_tol = 1e-6; c->p_rel_tol = 0.05; c->p_final_tol = 1e-6; c->p_final_rel_tol = 0.0; c->p_max_iter = 1000;
     c->u_tol = 1e-5; c->u_rel_tol = 0.0; c->u_max_iter = 1000;
     c->p_solver = FY_PSOLVER_PCG_JACOBI;
+    c->solver = FY_SOLVER_ICO; c->n_outer_correctors = 1;
 }
 
 int fy_ldu_solver_create(const fy_poly_mesh* m, const fy_ldu_case* c, const fy_transport* tr, int device_ordinal, fy_ldu_solver** out) {
@@ -314,7 +404,8 @@ int fy_ldu_solver_write_field_host(fy_ldu_solver* s, const char* name, const dou
     double* p; size_t n; const std::vector<double>* h;
     FY_TRY(s->s.field(name, &p, &n, &h));
     const std::string nm = name;
-    if (h || (nm != "U" && nm != "p" && nm != "uSource")) return fy::fail(FY_ERR_INVALID, "fy_ldu_solver_write_field_host: '%s' cannot be written (U, p, uSource)", nm.c_str());
+    const bool pim_in = s->s.pimple && (nm == "alpha" || nm == "uSourceDrag");      // (what setParticleAction would leave: for tests that feed the equations a given void fraction)
+    if (h || (nm != "U" && nm != "p" && nm != "uSource" && !pim_in)) return fy::fail(FY_ERR_INVALID, "fy_ldu_solver_write_field_host: '%s' cannot be written (U, p, uSource; alpha, uSourceDrag with pimpleFoamYade)", nm.c_str());
     FY_HIP(hipSetDevice(s->s.device));
     FY_HIP(hipMemcpyAsync(p, in, n * sizeof(double), hipMemcpyHostToDevice, s->s.stream));
     if (nm == "uSource") s->s.ext_source = true;
@@ -343,6 +434,7 @@ int fy_ldu_solver_apply(fy_ldu_solver* s, const char* op, const double* in, doub
     FY_HIP(hipStreamSynchronize(S.stream));
     return FY_OK;
 }
+int fy_ldu_solver_hold_sources(fy_ldu_solver* s, int on) { FY_LS(s); s->s.hold_sources = on != 0; return FY_OK; }
 int fy_ldu_solver_mg_levels(fy_ldu_solver* s, int cap, int32_t* cells, int32_t* slots, int* n_levels) {
     FY_LS(s);
     if (!n_levels) return fy::fail(FY_ERR_INVALID, "fy_ldu_solver_mg_levels: null n_levels");
