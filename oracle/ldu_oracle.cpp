@@ -31,7 +31,7 @@ inline V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b
 inline double mag(V3 a) { return std::sqrt(dot(a, a)); }
 
 extern "C" struct orc_ldu_case {
-    int solver;                 // 0 icoFoamYade
+    int solver;                 // 0 icoFoamYade, 1 pimpleFoamYade
     double dt, nu, rho_fluid, rho_particle;
     int n_correctors, n_non_orth_correctors, momentum_predictor, p_ref_cell;
     double p_ref_value;
@@ -41,6 +41,10 @@ extern "C" struct orc_ldu_case {
     const double* u_value;      // [n_patches][3]
     const int* p_bc;            // per patch: 0 zeroGradient, 1 fixedValue
     const double* p_value;      // [n_patches]
+    // solver = 1: pimpleFoamYade (pimpleFoamYade.C:60-114, UcEqn.H, pEqn.H); p_bc 2 = fixedFluxPressure
+    double g[3];
+    int n_outer;
+    double u_relax, u_relax_final, p_relax, p_relax_final;      // <= 0: no relaxationFactors entry
 };
 extern "C" struct orc_ldu_stats {
     double courant_mean, courant_max, cont_sum_local, cont_global, cont_cumulative;
@@ -64,6 +68,9 @@ struct Ldu {
     vec U, Uold, p, phi, phiOld, uSource, vGrad;             // U [3 nc], phi [nFaces] (owner -> neighbour / outwards)
     vec diag, lower, upper, src, bint, bsrc;                 // momentum matrix: diag, off-diagonals per internal face, source [3 nc], boundary coefficients per boundary face (scalar) / [3]
     vec rAU, HbyA, phiHbyA, rAUf, pdiag, pcoef, pb, pcorr;   // pcoef per face (internal: rAUf |Sf| dcNO; boundary: the same with the patch's dcNO), pcorr: non-orth flux correction per internal face
+    // pimpleFoamYade: the coupling's fields (set from outside between step_begin and step_end), the face fields of the alpha-weighted equations
+    vec alpha, uSourceDrag, uParticle, gradP, divT, ddtU, alphaf, phiForces, psn, recon, pPrev;
+    bool pimple = false;
     orc_ldu_stats st{};
     double cumulative = 0.0;
     bool adjust_phi_failed = false;
@@ -138,7 +145,12 @@ struct Ldu {
         const int c = own[f];
         return V3{F[3 * c], F[3 * c + 1], F[3 * c + 2]};
     }
-    double pb_val(int f) const { const int pa = patch_of[f - nInt]; return p_bc[pa] == 1 ? p_val[pa] : p[own[f]]; }
+    double pb_val(int f) const {
+        const int pa = patch_of[f - nInt];
+        if (p_bc[pa] == 1) return p_val[pa];
+        if (p_bc[pa] == 2 && pimple) return p[own[f]] + psn[f - nInt] / dcNO[f];      // fixedFluxPressure: a fixed-gradient patch, p_b = p_P + snGrad / deltaCoeffs
+        return p[own[f]];
+    }
     static V3 at(const vec& F, int c) { return V3{F[3 * c], F[3 * c + 1], F[3 * c + 2]}; }
 
     // fvc::grad (Gauss linear) of a scalar given per cell, boundary values from bval(f)
@@ -175,6 +187,28 @@ struct Ldu {
         lower.assign(nInt, 0.0); upper = lower; pcorr = lower;
         bint.assign(nFaces - nInt, 0.0); bsrc.assign(3 * (size_t)(nFaces - nInt), 0.0);
         flux_of(U, phi);                                       // createPhi
+        pimple = cs.solver == 1;
+        if (pimple) {
+            alpha.assign(nc, 1.0); uSourceDrag.assign(nc, 0.0); uParticle.assign(3 * nc, 0.0); gradP = uParticle; divT = uParticle; ddtU = uParticle;
+            alphaf.assign(nFaces, 1.0); phiForces.assign(nFaces, 0.0); psn.assign(nFaces - nInt, 0.0); pPrev = p;
+            // fvc::reconstruct's tensor per cell: inv(sum_f Sf Sf / |Sf|) [OF-6 fvcReconstruct.C]
+            vec T(9 * nc, 0.0);
+            for (int f = 0; f < nFaces; ++f) {
+                const double sv[3] = {Sf[f].x, Sf[f].y, Sf[f].z};
+                for (int side = 0; side < (f < nInt ? 2 : 1); ++side) {
+                    const int c = side ? nei[f] : own[f];
+                    for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) T[9 * (size_t)c + 3 * a + b] += sv[a] * sv[b] / magSf[f];
+                }
+            }
+            recon.assign(9 * nc, 0.0);
+            for (size_t c = 0; c < nc; ++c) {
+                const double* t = &T[9 * c]; double* q = &recon[9 * c];
+                const double det = t[0] * (t[4] * t[8] - t[5] * t[7]) - t[1] * (t[3] * t[8] - t[5] * t[6]) + t[2] * (t[3] * t[7] - t[4] * t[6]);
+                q[0] = (t[4] * t[8] - t[5] * t[7]) / det; q[1] = (t[2] * t[7] - t[1] * t[8]) / det; q[2] = (t[1] * t[5] - t[2] * t[4]) / det;
+                q[3] = (t[5] * t[6] - t[3] * t[8]) / det; q[4] = (t[0] * t[8] - t[2] * t[6]) / det; q[5] = (t[2] * t[3] - t[0] * t[5]) / det;
+                q[6] = (t[3] * t[7] - t[4] * t[6]) / det; q[7] = (t[1] * t[6] - t[0] * t[7]) / det; q[8] = (t[0] * t[4] - t[1] * t[3]) / det;
+            }
+        }
     }
     // fvc::flux(F) = linearInterpolate(F) & Sf; boundary: the patch value
     void flux_of(const vec& F, vec& out) const {
@@ -193,7 +227,225 @@ struct Ldu {
         for (int c = 0; c < nCells; ++c) { mx = std::max(mx, sumPhi[c] / V[c]); sm += sumPhi[c]; tv += V[c]; }
         st.courant_max = 0.5 * mx * cs.dt; st.courant_mean = 0.5 * (sm / tv) * cs.dt;
         Uold = U; phiOld = phi;                                  // runTime++ : old-time fields
-        grad_vector(U, vGrad);                                   // icoFoamYade.C:71
+        grad_vector(U, vGrad);                                   // icoFoamYade.C:71 / pimpleFoamYade.C:76
+        if (pimple) pre_coupling_fields();
+    }
+
+    // ================================================================================================ pimpleFoamYade
+    void interp_alpha() { for (int f = 0; f < nInt; ++f) alphaf[f] = w[f] * alpha[own[f]] + (1.0 - w[f]) * alpha[nei[f]]; for (int f = nInt; f < nFaces; ++f) alphaf[f] = 1.0; }
+    // pimpleFoamYade.C:73-75: ddtU_f = fvc::ddt(Uc) + fvc::div(phic, Uc) (the ddt is zero there: fv_oracle.cpp), gradP = fvc::grad(p),
+    // divT = 2 nu fvc::laplacian(alphac, Uc) with Gauss linear corrected
+    void pre_coupling_fields() {
+        interp_alpha();
+        std::fill(ddtU.begin(), ddtU.end(), 0.0); std::fill(divT.begin(), divT.end(), 0.0);
+        for (int f = 0; f < nFaces; ++f) {
+            const int o = own[f];
+            if (f < nInt) {
+                const int n = nei[f];
+                const V3 uf = w[f] * at(U, o) + (1.0 - w[f]) * at(U, n);
+                const double kk[3] = {kvec[f].x, kvec[f].y, kvec[f].z};
+                const V3 du = at(U, n) - at(U, o);
+                const double d3[3] = {du.x, du.y, du.z}, u3[3] = {uf.x, uf.y, uf.z};
+                for (int j = 0; j < 3; ++j) {
+                    double cj = 0.0;
+                    for (int i = 0; i < 3; ++i) cj += kk[i] * (w[f] * vGrad[9 * (size_t)o + 3 * i + j] + (1.0 - w[f]) * vGrad[9 * (size_t)n + 3 * i + j]);
+                    const double lap = alphaf[f] * magSf[f] * (dcNO[f] * d3[j] + cj);
+                    ddtU[3 * (size_t)o + j] += phi[f] * u3[j]; ddtU[3 * (size_t)n + j] -= phi[f] * u3[j];
+                    divT[3 * (size_t)o + j] += lap; divT[3 * (size_t)n + j] -= lap;
+                }
+            } else {
+                const V3 ub = Ub(U, f), d = ub - at(U, o);
+                const double u3[3] = {ub.x, ub.y, ub.z}, d3[3] = {d.x, d.y, d.z};
+                for (int j = 0; j < 3; ++j) { ddtU[3 * (size_t)o + j] += phi[f] * u3[j]; divT[3 * (size_t)o + j] += alphaf[f] * magSf[f] * dcNO[f] * d3[j]; }
+            }
+        }
+        for (int c = 0; c < nCells; ++c) for (int j = 0; j < 3; ++j) { ddtU[3 * (size_t)c + j] /= V[c]; divT[3 * (size_t)c + j] = 2 * cs.nu * (divT[3 * (size_t)c + j] / V[c]); }
+        std::vector<V3> gp;
+        grad_scalar(p, [&](int f) { return pb_val(f); }, gp);
+        for (int c = 0; c < nCells; ++c) { gradP[3 * (size_t)c] = gp[c].x; gradP[3 * (size_t)c + 1] = gp[c].y; gradP[3 * (size_t)c + 2] = gp[c].z; }
+    }
+    // UcEqn.H:3-13: fvm::ddt(alphac, Uc) + fvm::div(alphaPhic, Uc) - fvm::Sp(fvc::ddt(alphac) + fvc::div(alphaPhic), Uc) + divDevRhoReff(Uc) == fvm::Sp(uSourceDrag, Uc); relax()
+    // [OF-6 linearViscousStress::divDevRhoReff = - fvm::laplacian(alpha nu, U) - fvc::div(alpha nu dev2(T(grad U)))].  alphac.oldTime() == alphac (fv_oracle.cpp, quirk F-Q1)
+    void assemble_momentum_pimple(double u_relax_now) {
+        const size_t nc = nCells;
+        std::fill(diag.begin(), diag.end(), 0.0); std::fill(src.begin(), src.end(), 0.0);
+        std::fill(bint.begin(), bint.end(), 0.0); std::fill(bsrc.begin(), bsrc.end(), 0.0);
+        vec divAPhi(nc, 0.0), offsum(nc, 0.0), G(9 * nc);
+        for (size_t c = 0; c < nc; ++c) {
+            diag[c] += alpha[c] * V[c] / cs.dt;
+            for (int q = 0; q < 3; ++q) src[3 * c + q] += alpha[c] * V[c] / cs.dt * Uold[3 * c + q];
+            const double* T = &vGradNow[9 * c];
+            const double tr = T[0] + T[4] + T[8];
+            for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) G[9 * c + 3 * a + b] = alpha[c] * cs.nu * (T[3 * b + a] - (a == b ? (2.0 / 3.0) * tr : 0.0));
+        }
+        auto stress = [&](int f, double* t) {                   // Sf . (alpha nu dev2(T(grad U)))_f, the cell tensor interpolated linearly (a boundary face: its cell's)
+            const double sv[3] = {Sf[f].x, Sf[f].y, Sf[f].z};
+            for (int b = 0; b < 3; ++b) {
+                t[b] = 0.0;
+                for (int a = 0; a < 3; ++a) {
+                    const double go = G[9 * (size_t)own[f] + 3 * a + b];
+                    t[b] += sv[a] * (f < nInt ? w[f] * go + (1.0 - w[f]) * G[9 * (size_t)nei[f] + 3 * a + b] : go);
+                }
+            }
+        };
+        for (int f = 0; f < nInt; ++f) {
+            const double fl = alphaf[f] * phi[f], g = cs.nu * alphaf[f] * magSf[f];
+            double lo = -w[f] * fl, up = lo + fl;
+            lo -= g * dcNO[f]; up -= g * dcNO[f];
+            lower[f] = lo; upper[f] = up;
+            diag[own[f]] -= lo; diag[nei[f]] -= up;
+            offsum[own[f]] += std::fabs(up); offsum[nei[f]] += std::fabs(lo);
+            divAPhi[own[f]] += fl; divAPhi[nei[f]] -= fl;
+            const double kk[3] = {kvec[f].x, kvec[f].y, kvec[f].z};
+            double t[3];
+            stress(f, t);
+            for (int j = 0; j < 3; ++j) {
+                double corr = 0.0;
+                for (int i = 0; i < 3; ++i) corr += kk[i] * (w[f] * vGradNow[9 * (size_t)own[f] + 3 * i + j] + (1.0 - w[f]) * vGradNow[9 * (size_t)nei[f] + 3 * i + j]);
+                src[3 * (size_t)own[f] + j] += g * corr + t[j]; src[3 * (size_t)nei[f] + j] -= g * corr + t[j];
+            }
+        }
+        for (int f = nInt; f < nFaces; ++f) {
+            const int b = f - nInt, pa = patch_of[b], c = own[f];
+            const double g = cs.nu * magSf[f] * dcNO[f];                 // (alphac's boundary value is 1)
+            divAPhi[c] += phi[f];
+            double t[3];
+            stress(f, t);
+            for (int q = 0; q < 3; ++q) src[3 * (size_t)c + q] += t[q];
+            if (u_bc[pa] == 0) { bint[b] += g; for (int q = 0; q < 3; ++q) bsrc[3 * (size_t)b + q] += (-phi[f] + g) * u_val[3 * pa + q]; }
+            else bint[b] += phi[f];
+        }
+        for (size_t c = 0; c < nc; ++c) {
+            const double S = divAPhi[c] / V[c];                          // + fvc::ddt(alphac) = 0
+            diag[c] -= V[c] * S;
+            diag[c] -= V[c] * uSourceDrag[c];
+        }
+        if (u_relax_now > 0) {                                           // fvMatrix::relax: the boundary coefficients take part in the dominance test
+            for (size_t c = 0; c < nc; ++c) {
+                const double dg = dgc((int)c), dn = std::max(std::fabs(dg), offsum[c]) / u_relax_now;
+                for (int q = 0; q < 3; ++q) src[3 * c + q] += (dn - dg) * U[3 * c + q];
+                diag[c] += dn - dg;
+            }
+        }
+        for (size_t c = 0; c < nc; ++c) rAU[c] = 1.0 / (dgc((int)c) / V[c]);
+    }
+    void interp_rAU_and_forces() {                               // rAUcf, phicForces = fvc::flux(rAUc uSource) + rAUcf (g & Sf) (UcEqn.H:15-20); uSource's boundary value is 0
+        const V3 gv{cs.g[0], cs.g[1], cs.g[2]};
+        for (int f = 0; f < nFaces; ++f) {
+            double fl = 0.0;
+            if (f < nInt) {
+                const int o = own[f], n = nei[f];
+                rAUf[f] = w[f] * rAU[o] + (1.0 - w[f]) * rAU[n];
+                fl = dot(w[f] * (rAU[o] * at(uSource, o)) + (1.0 - w[f]) * (rAU[n] * at(uSource, n)), Sf[f]);
+            } else rAUf[f] = rAU[own[f]];
+            phiForces[f] = fl + rAUf[f] * dot(gv, Sf[f]);
+        }
+    }
+    // fvc::reconstruct(ssf) [OF-6]: inv(surfaceSum(Sf Sf / |Sf|)) & surfaceSum(Sf / |Sf| ssf)
+    void reconstruct(const vec& ssf, std::vector<V3>& out) const {
+        out.assign(nCells, V3{0, 0, 0});
+        for (int f = 0; f < nFaces; ++f) {
+            const V3 t = (ssf[f] / magSf[f]) * Sf[f];
+            out[own[f]] = out[own[f]] + t;
+            if (f < nInt) out[nei[f]] = out[nei[f]] + t;
+        }
+        for (int c = 0; c < nCells; ++c) {
+            const double* R = &recon[9 * (size_t)c];
+            const V3 a = out[c];
+            out[c] = V3{R[0] * a.x + R[1] * a.y + R[2] * a.z, R[3] * a.x + R[4] * a.y + R[5] * a.z, R[6] * a.x + R[7] * a.y + R[8] * a.z};
+        }
+    }
+    double sngrad_p(int f, const std::vector<V3>& gp) const {    // corrected snGrad(p) on face f (boundary faces carry no correction)
+        if (f < nInt) return dcNO[f] * (p[nei[f]] - p[own[f]]) + dot(kvec[f], w[f] * gp[own[f]] + (1.0 - w[f]) * gp[nei[f]]);
+        return dcNO[f] * (pb_val(f) - p[own[f]]);
+    }
+    // pEqn.H
+    void corrector_pimple(bool final_corr, double p_relax_now) {
+        compute_HbyA();                                          // :2
+        {
+            // :4-11 phiHbyA = fvc::flux(HbyA) + alphacf rAUcf fvc::ddtCorr(Uc, phic); compute_phiHbyA() forms the ico expression and adjusts it (:13-16)
+            vec keep = rAUf;
+            compute_phiHbyA_with(alphaf);
+            rAUf = keep;
+        }
+        for (int f = 0; f < nFaces; ++f) phiHbyA[f] += phiForces[f];                                    // :18
+        for (int f = nInt; f < nFaces; ++f) {                                                           // :21 constrainPressure
+            const int pa = patch_of[f - nInt];
+            psn[f - nInt] = p_bc[pa] == 2 ? (phiHbyA[f] - dot(Ub(U, f), Sf[f])) / (magSf[f] * rAUf[f]) : 0.0;
+        }
+        vec pflux(nFaces, 0.0);
+        for (int no = 0; no <= cs.n_non_orth_correctors; ++no) {                                        // :24-47
+            std::vector<V3> gp;
+            grad_scalar(p, [&](int f) { return pb_val(f); }, gp);
+            std::fill(pdiag.begin(), pdiag.end(), 0.0); std::fill(pb.begin(), pb.end(), 0.0);
+            for (int f = 0; f < nInt; ++f) {
+                const double gm = alphaf[f] * rAUf[f] * magSf[f];
+                pcoef[f] = gm * dcNO[f];
+                pcorr[f] = gm * dot(kvec[f], w[f] * gp[own[f]] + (1.0 - w[f]) * gp[nei[f]]);
+                pdiag[own[f]] += pcoef[f]; pdiag[nei[f]] += pcoef[f];
+                const double t = -alphaf[f] * phiHbyA[f] + pcorr[f];
+                pb[own[f]] += t; pb[nei[f]] -= t;
+            }
+            for (int f = nInt; f < nFaces; ++f) {
+                const int pa = patch_of[f - nInt], c = own[f];
+                pcoef[f] = alphaf[f] * rAUf[f] * magSf[f] * dcNO[f];
+                double ph = alphaf[f] * phiHbyA[f];
+                if (p_bc[pa] == 2) ph = alphaf[f] * (phiHbyA[f] - rAUf[f] * magSf[f] * psn[f - nInt]);       // the fixed-gradient source of the laplacian
+                pb[c] -= ph;
+                if (p_bc[pa] == 1) { pdiag[c] += pcoef[f]; pb[c] += pcoef[f] * p_val[pa]; }
+            }
+            if (need_reference()) { const int c = cs.p_ref_cell; pb[c] += pdiag[c] * cs.p_ref_value; pdiag[c] += pdiag[c]; }
+            solve_pressure(final_corr && no == cs.n_non_orth_correctors);
+            if (no == cs.n_non_orth_correctors) {
+                for (int f = 0; f < nFaces; ++f) {
+                    double pf;
+                    if (f < nInt) pf = pcoef[f] * (p[nei[f]] - p[own[f]]) + pcorr[f];
+                    else {
+                        const int pa = patch_of[f - nInt];
+                        pf = p_bc[pa] == 1 ? pcoef[f] * (p_val[pa] - p[own[f]]) : (p_bc[pa] == 2 ? alphaf[f] * rAUf[f] * magSf[f] * psn[f - nInt] : 0.0);
+                    }
+                    pflux[f] = pf;
+                    phi[f] = phiHbyA[f] - pf / alphaf[f];                                              // :39
+                }
+                if (p_relax_now > 0 && p_relax_now < 1) for (int c = 0; c < nCells; ++c) p[c] = pPrev[c] + p_relax_now * (p[c] - pPrev[c]);     // :41
+            }
+        }
+        vec ssf(nFaces);
+        for (int f = 0; f < nFaces; ++f) ssf[f] = (phiForces[f] - pflux[f] / alphaf[f]) / rAUf[f];
+        std::vector<V3> rc;
+        reconstruct(ssf, rc);                                                                           // :43-46
+        for (int c = 0; c < nCells; ++c) { U[3 * (size_t)c] = HbyA[3 * (size_t)c] + rAU[c] * rc[c].x; U[3 * (size_t)c + 1] = HbyA[3 * (size_t)c + 1] + rAU[c] * rc[c].y; U[3 * (size_t)c + 2] = HbyA[3 * (size_t)c + 2] + rAU[c] * rc[c].z; }
+        vec div(nCells, 0.0);                                                                           // :50 continuityErrs.H: fvc::ddt(alphac) + fvc::div(alphacf phic)
+        for (int f = 0; f < nInt; ++f) { div[own[f]] += alphaf[f] * phi[f]; div[nei[f]] -= alphaf[f] * phi[f]; }
+        for (int f = nInt; f < nFaces; ++f) div[own[f]] += alphaf[f] * phi[f];
+        double sl = 0, gl = 0, tv = 0;
+        for (int c = 0; c < nCells; ++c) { sl += std::fabs(div[c]); gl += div[c]; tv += V[c]; }
+        st.cont_sum_local = cs.dt * sl / tv; st.cont_global = cs.dt * gl / tv;
+        cumulative += st.cont_global; st.cont_cumulative = cumulative;
+    }
+    void step_end_pimple() {
+        interp_alpha();                                          // pimpleFoamYade.C:83-85
+        const int nOuter = std::max(cs.n_outer, 1);
+        for (int outer = 0; outer < nOuter; ++outer) {
+            const bool final_outer = outer == nOuter - 1;
+            const double u_relax_now = (final_outer && cs.u_relax_final > 0) ? cs.u_relax_final : cs.u_relax;
+            const double p_relax_now = (final_outer && cs.p_relax_final > 0) ? cs.p_relax_final : cs.p_relax;
+            if (p_relax_now > 0 && p_relax_now < 1) pPrev = p;
+            grad_vector(U, vGradNow);
+            assemble_momentum_pimple(u_relax_now);
+            interp_rAU_and_forces();
+            if (cs.momentum_predictor) {                         // UcEqn.H:22-33: solve(UcEqn == fvc::reconstruct(phicForces / rAUcf - fvc::snGrad(p) |Sf|))
+                std::vector<V3> gp, rc;
+                grad_scalar(p, [&](int f) { return pb_val(f); }, gp);
+                vec ssf(nFaces);
+                for (int f = 0; f < nFaces; ++f) ssf[f] = phiForces[f] / rAUf[f] - sngrad_p(f, gp) * magSf[f];
+                reconstruct(ssf, rc);
+                vec minus(3 * (size_t)nCells);                   // solve_momentum subtracts V * its argument from the source
+                for (int c = 0; c < nCells; ++c) { minus[3 * (size_t)c] = -rc[c].x; minus[3 * (size_t)c + 1] = -rc[c].y; minus[3 * (size_t)c + 2] = -rc[c].z; }
+                st.u_iters_total += solve_momentum(minus);
+            }
+            for (int corr = 0; corr < cs.n_correctors; ++corr) corrector_pimple(final_outer && corr == cs.n_correctors - 1, p_relax_now);
+        }
     }
 
     // UEqn (icoFoamYade.C:79-85): ddt(U) + div(phi,U) - laplacian(nu,U) == uSource
@@ -314,7 +566,8 @@ struct Ldu {
         return at(HbyA, own[f]);
     }
     // phiHbyA = fvc::flux(HbyA) + fvc::interpolate(rAU) fvc::ddtCorr(U, phi) (icoFoamYade.C:101-106), adjustPhi (:108)
-    void compute_phiHbyA() {
+    void compute_phiHbyA() { compute_phiHbyA_with(vec()); }
+    void compute_phiHbyA_with(const vec& af) {                  // af: alphacf on the ddtCorr term (pEqn.H:9), empty in icoFoamYade
         const double rDt = 1.0 / cs.dt;
         for (int f = 0; f < nFaces; ++f) {
             double fl, uf;
@@ -331,7 +584,7 @@ struct Ldu {
             }
             const double phiCorr = phiOld[f] - uf;
             const double coef = fixes ? 0.0 : 1.0 - std::min(std::fabs(phiCorr) / (std::fabs(phiOld[f]) + SMALL), 1.0);     // EulerDdtScheme::fvcDdtPhiCoeff
-            phiHbyA[f] = fl + rAUf[f] * (coef * rDt * phiCorr);
+            phiHbyA[f] = fl + (af.empty() ? 1.0 : af[f]) * (rAUf[f] * (coef * rDt * phiCorr));
         }
         bool need_ref = true;
         for (int pa = 0; pa < nPatches; ++pa) if (p_bc[pa] == 1) need_ref = false;
@@ -455,6 +708,7 @@ struct Ldu {
     }
 
     void step_end() {
+        if (pimple) { step_end_pimple(); return; }
         grad_vector(U, vGradNow);
         assemble_momentum();
         if (cs.momentum_predictor) {
@@ -471,7 +725,8 @@ struct Ldu {
 vec* ldu_field(Ldu* s, const std::string& n) {
     const struct { const char* nm; vec* v; } tab[] = {{"U", &s->U}, {"p", &s->p}, {"phi", &s->phi}, {"uSource", &s->uSource}, {"vGrad", &s->vGrad}, {"rAU", &s->rAU},
         {"HbyA", &s->HbyA}, {"p_diag", &s->pdiag}, {"p_coef", &s->pcoef}, {"p_rhs", &s->pb}, {"mom_diag", &s->diag}, {"mom_lower", &s->lower}, {"mom_upper", &s->upper},
-        {"mom_src", &s->src}, {"phiHbyA", &s->phiHbyA}};
+        {"mom_src", &s->src}, {"phiHbyA", &s->phiHbyA}, {"alpha", &s->alpha}, {"uSourceDrag", &s->uSourceDrag}, {"gradP", &s->gradP}, {"divT", &s->divT}, {"ddtU", &s->ddtU},
+        {"phiForces", &s->phiForces}, {"rAUf", &s->rAUf}};
     for (const auto& e : tab) if (n == e.nm) return e.v;
     return nullptr;
 }

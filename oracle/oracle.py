@@ -385,8 +385,9 @@ class FvSolver:
         self.L.orc_fv_get_stats(self.h, C.byref(s))
         return {n: getattr(s, n) for n, _ in FvStats._fields_}
 
-    def step(self, records=None):
-        """records: (n,10) particle records or None (no particles).  Returns the per-particle force array or None."""
+    def step(self, records=None, capture=None):
+        """records: (n,10) particle records or None (no particles).  Returns the per-particle force array or None.  capture: a dict that receives copies of
+        alpha / uSourceDrag / uSource as setParticleAction left them (they are reset at the end of the step)"""
         self.L.orc_fv_step_begin(self.h)
         out = None
         if records is not None:
@@ -406,6 +407,9 @@ class FvSolver:
             out = particle_action(self.mesh, fields, mut, records, np.array([0, n], np.int32), self.gaussian,
                                   c.rho_particle, c.rho_fluid, c.nu, threads=self.threads,
                                   force_models=getattr(self, "force_models", 0), dt=self.stats()["delta_t"])
+        if capture is not None:
+            for k in ("alpha", "uSourceDrag", "uSource"):
+                capture[k] = self.get(k)
         self.L.orc_fv_step_end(self.h)
         # yadeCoupling.setSourceZero() (icoFoamYade.C:147, pimpleFoamYade.C:109)
         self.L.orc_set_source_zero(self.Nc, int(self.gaussian), _d(self.view("uSourceDrag")), _d(self.view("alpha")),
@@ -442,7 +446,8 @@ class LduCase(C.Structure):
                 ("n_correctors", C.c_int), ("n_non_orth_correctors", C.c_int), ("momentum_predictor", C.c_int), ("p_ref_cell", C.c_int),
                 ("p_ref_value", C.c_double), ("p_tol", C.c_double), ("p_rel_tol", C.c_double), ("p_final_tol", C.c_double),
                 ("p_final_rel_tol", C.c_double), ("p_max_iter", C.c_int), ("u_tol", C.c_double), ("u_rel_tol", C.c_double), ("u_max_iter", C.c_int),
-                ("u_bc", _ip), ("u_value", _dp), ("p_bc", _ip), ("p_value", _dp)]
+                ("u_bc", _ip), ("u_value", _dp), ("p_bc", _ip), ("p_value", _dp), ("g", C.c_double * 3), ("n_outer", C.c_int), ("u_relax", C.c_double),
+                ("u_relax_final", C.c_double), ("p_relax", C.c_double), ("p_relax_final", C.c_double)]
 
 
 class LduStats(C.Structure):
@@ -479,7 +484,8 @@ class LduSolver:
 
     def __init__(self, mesh, dt, nu, u_bc, u_val, p_bc, p_val=None, n_correctors=2, n_non_orth=0, momentum_predictor=1, p_ref_cell=0, p_ref_value=0.0,
                  p_tol=1e-6, p_rel_tol=0.05, p_final_tol=1e-6, p_final_rel_tol=0.0, p_max_iter=5000, u_tol=1e-5, u_rel_tol=0.0, u_max_iter=1000,
-                 rho_f=1000.0, rho_p=2650.0):
+                 rho_f=1000.0, rho_p=2650.0, solver=0, g=(0.0, 0.0, 0.0), n_outer=1, u_relax=0.0, u_relax_final=0.0, p_relax=0.0, p_relax_final=0.0):
+        """solver = 1: pimpleFoamYade -- step(source, alpha, drag) then takes the void fraction and the implicit drag coefficient the coupling would leave"""
         self.L = _ldu_lib()
         self.mesh = mesh
         npatch = len(mesh["patch_start"])
@@ -490,8 +496,10 @@ class LduSolver:
                           uv=np.ascontiguousarray(u_val, np.float64).reshape(npatch, 3), pb=np.ascontiguousarray(p_bc, np.int32),
                           pv=np.ascontiguousarray(p_val if p_val is not None else np.zeros(npatch), np.float64))
         k = self._keep
-        self.case = LduCase(0, dt, nu, rho_f, rho_p, n_correctors, n_non_orth, momentum_predictor, p_ref_cell, p_ref_value, p_tol, p_rel_tol, p_final_tol,
-                            p_final_rel_tol, p_max_iter, u_tol, u_rel_tol, u_max_iter, _i(k["ub"]), _d(k["uv"]), _i(k["pb"]), _d(k["pv"]))
+        self.case = LduCase(solver, dt, nu, rho_f, rho_p, n_correctors, n_non_orth, momentum_predictor, p_ref_cell, p_ref_value, p_tol, p_rel_tol, p_final_tol,
+                            p_final_rel_tol, p_max_iter, u_tol, u_rel_tol, u_max_iter, _i(k["ub"]), _d(k["uv"]), _i(k["pb"]), _d(k["pv"]), (C.c_double * 3)(*g), n_outer,
+                            u_relax, u_relax_final, p_relax, p_relax_final)
+        self.pimple = solver == 1
         self.nc, self.nf, self.ni = int(mesh["n_cells"]), len(k["own"]), len(k["nei"])
         self.h = self.L.orc_ldu_create(k["points"].shape[0], _d(k["points"]), self.nf, self.ni, _i(k["foff"]), _i(k["fpts"]), _i(k["own"]), _i(k["nei"]),
                                        self.nc, npatch, _i(k["ps"]), _i(k["pz"]), C.byref(self.case))
@@ -525,11 +533,17 @@ class LduSolver:
         if name == "U":
             self.L.orc_ldu_refresh_phi(self.h)
 
-    def step(self, source=None):
-        """source: (nc,3) explicit momentum source uSource for this step (what the coupling would leave), or None"""
+    def step(self, source=None, alpha=None, drag=None):
+        """source: (nc,3) explicit momentum source uSource for this step (what the coupling would leave), or None; pimpleFoamYade: alpha (the void fraction) and
+        drag (uSourceDrag, the implicit coefficient) too.  They are placed where setParticleAction sits in the loop: after the pre-coupling fields"""
         self.L.orc_ldu_step_begin(self.h)
         self.view("uSource")[:] = 0.0 if source is None else np.ascontiguousarray(source, np.float64).ravel()
+        if self.pimple:
+            self.view("alpha")[:] = 1.0 if alpha is None else np.ascontiguousarray(alpha, np.float64).ravel()
+            self.view("uSourceDrag")[:] = 0.0 if drag is None else np.ascontiguousarray(drag, np.float64).ravel()
         self.L.orc_ldu_step_end(self.h)
+        if self.pimple:                                   # yadeCoupling.setSourceZero() (pimpleFoamYade.C:109)
+            self.view("alpha")[:] = 1.0; self.view("uSourceDrag")[:] = 0.0; self.view("uSource")[:] = 0.0
 
     def stats(self):
         s = LduStats()

@@ -246,3 +246,40 @@ def test_pimple_with_particles_on_a_wavy_mesh_conserves_what_it_should(product):
     st = h.stats()
     assert st["cont_err_sum_local"] < 1e-9 and np.abs(h.get("U")).max() > 1e-5
     h.close()
+
+
+@pytest.mark.parametrize("kind", ["wavy_renumbered", "prisms"])
+def test_pimple_with_a_cloud_matches_the_restatement(product, oracle, kind):
+    """pimpleFoamYade on non-orthogonal meshes, HIP against the CPU restatement: the HIP solver runs the coupled step with its cloud; the restatement is given the
+    void fraction, the drag coefficient and the explicit source that coupling left and solves the same equations.  Compared: the coupling's input fields
+    (ddtU_f, divT, gradP: corrected laplacian and gradients on skewed cells), velocity, pressure, flux -- two outer correctors, relaxation, one non-orthogonal pass"""
+    n, box = 10, 0.1
+    dx = box / n
+    if kind == "prisms":
+        mesh = pm.prism_block(n, n, 6, (box, box, box), pm.wavy(0.15 * dx, (box, box, box)))
+    else:
+        mesh = pm.hex_block(n, n, n, (box, box, box), pm.wavy(0.2 * dx, (box, box, box)), renumber_seed=8)
+    npatch = 6
+    kw = dict(p_tol=1e-10, p_rel_tol=0.0, p_final_tol=1e-10, u_tol=1e-10, p_max_iter=5000)
+    rel = dict(u_relax=0.8, u_relax_final=1.0, p_relax=0.7, p_relax_final=1.0)
+    lidv = [(0, 0, 0)] * npatch
+    lidv[3] = (0.05, 0, 0)                                # a moving wall too, so that the velocity gradients are not the cloud's alone
+    h = product.LduSolver(mesh, 2e-4, 1e-5, [0] * npatch, lidv, [2] * npatch, solver=1, g=(0, 0, -9.81), n_non_orth=1, n_outer_correctors=2, n_correctors=2, **rel, **kw)
+    o = oracle.LduSolver(mesh, 2e-4, 1e-5, [0] * npatch, lidv, [2] * npatch, solver=1, g=(0, 0, -9.81), n_non_orth=1, n_outer=2, n_correctors=2, **rel, **kw)
+    h.hold_sources(True)
+    rs = np.random.RandomState(23)
+    for step in range(3):
+        h.set_particles(bed_particles(rs, 1500, box, dx))
+        h.step()
+        alpha = h.get("alpha")
+        assert alpha.min() < 0.95
+        o.step(source=h.get("uSourceCoupling"), alpha=alpha, drag=h.get("uSourceDrag"))
+        if step == 2:
+            for nm in ("ddtU", "divT", "gradP"):
+                close(h.get(nm), o.get(nm), 1e-6, nm)
+        close(h.get("U"), o.get("U"), 2e-6, "U step %d" % step)
+    ph, po = h.get("p"), o.get("p")
+    close(ph - ph.mean(), po - po.mean(), 1e-5, "p")
+    close(h.get("phi"), o.get("phi"), 1e-5, "phi")
+    assert np.abs(h.get("ddtU")).max() > 0 and np.abs(h.get("divT")).max() > 0
+    h.close(); o.close()
