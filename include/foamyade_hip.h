@@ -505,11 +505,11 @@ int fy_ldu_solver_apply(fy_ldu_solver*, const char* op, const double* in, double
 int fy_ldu_solver_mg_levels(fy_ldu_solver*, int cap, int32_t* cells, int32_t* slots, int* n_levels);
 int fy_ldu_solver_destroy(fy_ldu_solver*);
 
-/* An OpenFOAM case directory whose constant/polyMesh is ANY mesh of wall / patch boundaries (ASCII), for icoFoamYade: what createMesh.H +
- * createFields.H read (icoFoamYade.C:42-44).  The object is the fy_foam_case above with the mesh kept in OpenFOAM's addressing:
+/* An OpenFOAM case directory whose constant/polyMesh is ANY mesh of wall / patch boundaries (ASCII), for icoFoamYade or (laminar, fixed time step)
+ * pimpleFoamYade: what createMesh.H + createFields.H read (icoFoamYade.C:42-44, pimpleFoamYade.C:41-43).  The object is the fy_foam_case above with the mesh kept in OpenFOAM's addressing:
  * fy_foam_case_info_get, fy_foam_case_initial_fields, fy_foam_case_write_fields and fy_foam_case_close work on it; fy_foam_case_desc refuses it
  * (there is no block to describe).  fvSchemes must ask for what fy_ldu_solver does: Gauss linear, `corrected` laplacian / snGrad. */
-int fy_foam_case_open_general(const char* case_dir, fy_foam_case** out);
+int fy_foam_case_open_general(const char* case_dir, int solver /* FY_SOLVER_ICO | FY_SOLVER_PIMPLE */, fy_foam_case** out);
 int fy_foam_case_poly_mesh(const fy_foam_case*, fy_poly_mesh* out);              /* pointers into the case object: valid until fy_foam_case_close */
 int fy_foam_case_ldu_desc(const fy_foam_case*, fy_ldu_case* out);                 /* ready for fy_ldu_solver_create (patch arrays point into the case object) */
 int fy_foam_case_patch_name(const fy_foam_case*, int patch, char* out, int cap); /* the boundary file's order = fy_poly_mesh's patch numbers */

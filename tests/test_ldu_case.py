@@ -103,6 +103,77 @@ def test_what_the_general_solver_cannot_do_is_refused_by_name(prod, tmp_path, ed
         prod.GeneralFoamCase(dst)
 
 
+BED = [("bottom", [4]), ("top", [5]), ("walls", [0, 1, 2, 3])]
+
+
+def general_bed(tmp_path, amp=0.15):
+    """tests/golden/cases/bed_pimple with its block replaced by a wavy polyhedral mesh of the same box and patches"""
+    dst = tmp_path / "bed"
+    shutil.copytree(os.path.join(CASES, "bed_pimple"), dst)
+    os.remove(dst / "system/blockMeshDict")
+    L = (0.06, 0.06, 0.12)
+    wav = pm.wavy(amp * 0.005, L)
+    mesh = pm.hex_block(12, 12, 24, L, lambda P: wav(P) + np.array([-0.03, -0.03, 0.0]), patches=BED)
+    pm.write_poly_mesh_files(dst, mesh, {"bottom": "patch", "top": "patch", "walls": "wall"})
+    return dst, mesh
+
+
+def test_general_pimple_case_is_read(prod, tmp_path):
+    """pimpleFoamYade's dictionaries on a general mesh: PIMPLE controls, gravity, the phase's names, fixedFluxPressure patches; what the general solver does not carry
+    (a turbulence model, adjustTimeStep) is refused by name"""
+    dst, mesh = general_bed(tmp_path)
+    fc = prod.GeneralFoamCase(dst, prod.FY_SOLVER_PIMPLE)
+    ref = prod.FoamCase(os.path.join(CASES, "bed_pimple"), prod.FY_SOLVER_PIMPLE)
+    lc, d = fc.ldu_case, ref.case
+    assert lc.solver == prod.FY_SOLVER_PIMPLE and (lc.n_outer_correctors, lc.n_correctors, lc.n_non_orth_correctors) == (d.n_outer_correctors, d.n_correctors, d.n_non_orth_correctors)
+    assert list(lc.g) == list(d.g) and (lc.u_relax, lc.u_relax_final, lc.p_relax, lc.p_relax_final) == (d.u_relax, d.u_relax_final, d.p_relax, d.p_relax_final)
+    assert (lc.dt, lc.nu, lc.rho_fluid, lc.rho_particle, lc.p_solver) == (d.dt, d.nu, d.rho_fluid, d.rho_particle, d.p_solver)
+    assert fc.patch_names == ["bottom", "top", "walls"] and fc.u_name == "U.water" and fc.phase == "water"
+    assert fc.p_bc == [prod.FY_BC_P_FIXED_FLUX, prod.FY_BC_P_FIXED_VALUE, prod.FY_BC_P_FIXED_FLUX]
+    assert fc.u_bc == [prod.FY_BC_U_FIXED_VALUE, prod.FY_BC_U_ZERO_GRADIENT, prod.FY_BC_U_FIXED_VALUE]
+    np.testing.assert_array_equal(fc.u_value, [[0, 0, 0.02], [0, 0, 0], [0, 0, 0]])
+    fc.close(); ref.close()
+    (dst / "constant/turbulenceProperties.water").write_text("FoamFile { version 2.0; format ascii; class dictionary; object turbulenceProperties.water; }\nsimulationType LES;\n"
+                                                             "LES { LESModel Smagorinsky; delta cubeRootVol; turbulence on; }\n")
+    (dst / "0/nut.water").write_text((dst / "0/p").read_text().replace("object      p;", "object nut.water;").replace("fixedFluxPressure; value uniform 0;", "zeroGradient;").replace("fixedValue; value uniform 0;", "zeroGradient;"))
+    with pytest.raises(prod.FoamYadeError, match="laminar"):
+        prod.GeneralFoamCase(dst, prod.FY_SOLVER_PIMPLE)
+    os.remove(dst / "constant/turbulenceProperties.water")
+    cd = (dst / "system/controlDict").read_text()
+    (dst / "system/controlDict").write_text(cd.replace("adjustTimeStep  no;", "adjustTimeStep  yes;").replace("writeControl    adjustableRunTime;", "writeControl    timeStep;").replace("writeInterval   0.001;", "writeInterval   5;"))
+    with pytest.raises(prod.FoamYadeError, match="adjustTimeStep"):
+        prod.GeneralFoamCase(dst, prod.FY_SOLVER_PIMPLE)
+
+
+@pytest.mark.gpu
+def test_foamYadeHip_executable_runs_a_general_pimple_case(prod, tmp_path):
+    """foamYadeHip -solver pimple on the wavy bed: falls through to the general solver, runs controlDict's ten steps (inflow at the bottom, fixed pressure at the top),
+    writes U.water, p and alpha.water with the case's patch entries; the library-driven run from the same directory gives the same fields"""
+    dst, mesh = general_bed(tmp_path)
+    exe = os.path.join(os.path.dirname(prod.__file__), "bin", "foamYadeHip")
+    out = subprocess.run([exe, "-solver", "pimple", "-case", str(dst)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "general polyhedral mesh" in out.stdout and out.stdout.rstrip().endswith("End")
+    for nm in ("U.water", "p", "alpha.water"):
+        assert (dst / "0.002" / nm).exists(), os.listdir(dst / "0.002")
+    t = (dst / "0.002/alpha.water").read_text()
+    assert "bottom" in t and "zeroGradient" in t
+    fc = prod.GeneralFoamCase(dst, prod.FY_SOLVER_PIMPLE)
+    s = prod.LduSolver.from_foam_case(fc)
+    for _ in range(10):
+        s.step()
+    U = s.get("U").reshape(-1, 3)
+    s.close(); fc.close()
+    cd = (dst / "system/controlDict").read_text()
+    (dst / "system/controlDict").write_text(cd.replace("startFrom       startTime;", "startFrom       latestTime;"))
+    fc = prod.GeneralFoamCase(dst, prod.FY_SOLVER_PIMPLE)
+    assert fc.start_name == "0.002"
+    U1, p1 = fc.initial_fields()
+    np.testing.assert_allclose(U1, U, rtol=0, atol=1e-12 * np.abs(U).max())
+    assert np.abs(U[:, 2]).max() > 0.01                              # the inflow has arrived
+    fc.close()
+
+
 @pytest.mark.gpu
 def test_run_from_a_general_case_directory_equals_the_hand_built_solver(prod, tmp_path):
     """LduSolver.from_foam_case on a wavy renumbered block = the solver built from the same arrays by hand, bit for bit; write, reopen from latestTime"""

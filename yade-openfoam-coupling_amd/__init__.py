@@ -887,15 +887,15 @@ class GeneralFoamCase(FoamCase):
     """an icoFoamYade case directory whose constant/polyMesh is any mesh of wall / patch boundaries (fy_foam_case_open_general): .pm / .ldu_case are the
     structs for fy_ldu_solver_create (LduSolver.from_foam_case), .mesh the arrays as numpy copies, .patch_names the boundary file's order"""
 
-    def __init__(self, case_dir):
+    def __init__(self, case_dir, solver=FY_SOLVER_ICO):
         L = lib()
-        L.fy_foam_case_open_general.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
+        L.fy_foam_case_open_general.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
         L.fy_foam_case_poly_mesh.argtypes = [C.c_void_p, C.POINTER(PolyMesh)]
         L.fy_foam_case_ldu_desc.argtypes = [C.c_void_p, C.POINTER(LduCase)]
         L.fy_foam_case_patch_name.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int]
         L.fy_foam_case_write_time_ldu.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p]
         h = C.c_void_p()
-        _check(L.fy_foam_case_open_general(str(case_dir).encode(), C.byref(h)))
+        _check(L.fy_foam_case_open_general(str(case_dir).encode(), int(solver), C.byref(h)))
         self._h = h
         self.pm, self.ldu_case = PolyMesh(), LduCase()
         _check(L.fy_foam_case_poly_mesh(self._h, C.byref(self.pm)))
@@ -905,7 +905,7 @@ class GeneralFoamCase(FoamCase):
         self.start_time, self.end_time, self.delta_t = info.start_time, info.end_time, info.delta_t
         self.write_interval_steps, self.n_cells = info.write_interval_steps, info.n_cells
         self.field_cells, self.field_offset = info.field_cells, info.field_offset
-        self.u_name, self.start_name = info.u_name.decode(), info.start_name.decode()
+        self.u_name, self.phase, self.start_name = info.u_name.decode(), info.phase.decode(), info.start_name.decode()
         m = self.pm
         arr = lambda ptr, n, dt: np.ctypeslib.as_array(ptr, shape=(n,)).astype(dt) if n else np.zeros(0, dt)
         nfp = int(m.face_offsets[m.n_faces])

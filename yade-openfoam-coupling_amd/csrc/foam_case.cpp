@@ -766,7 +766,8 @@ int read_general_fields(fy_foam_case* c) {
                     c->g_p_bc[pa] = FY_BC_P_FIXED_VALUE;
                     if (!vt || vt->size() < 2 || (*vt)[0] != "uniform" || !fy::foam_tok_is_number((*vt)[1], &c->g_p_val[pa]))
                         return fail(FY_ERR_UNSUPPORTED, "%s: patch '%s': fixedValue needs 'value uniform <p>'", path.c_str(), pn);
-                } else if (ty != "zeroGradient") return fail(FY_ERR_UNSUPPORTED, "%s: patch '%s': pressure boundary type '%s' is not supported on a general mesh (zeroGradient, fixedValue)", path.c_str(), pn, ty.c_str());
+                } else if (ty == "fixedFluxPressure" && c->solver == FY_SOLVER_PIMPLE) c->g_p_bc[pa] = FY_BC_P_FIXED_FLUX;
+                else if (ty != "zeroGradient") return fail(FY_ERR_UNSUPPORTED, "%s: patch '%s': pressure boundary type '%s' is not supported on a general mesh (zeroGradient, fixedValue; fixedFluxPressure with pimpleFoamYade)", path.c_str(), pn, ty.c_str());
             }
         }
     }
@@ -779,7 +780,9 @@ int check_general_schemes(const fy_foam_case* c) {
     const std::string path = join(c->dir, "system/fvSchemes");
     FoamDict d;
     FY_TRY(need_file(path, &d));
-    if (c->desc.convection_scheme != FY_CONVECTION_LINEAR) return fail(FY_ERR_UNSUPPORTED, "%s: on a general mesh div(phi,U) must be Gauss linear", path.c_str());
+    if (c->desc.convection_scheme != FY_CONVECTION_LINEAR) return fail(FY_ERR_UNSUPPORTED, "%s: on a general mesh the convection term must be Gauss linear", path.c_str());
+    if (c->desc.turbulence_model != FY_TURBULENCE_LAMINAR) return fail(FY_ERR_UNSUPPORTED, "%s: on a general mesh only the laminar (Stokes) model is carried (constant/turbulenceProperties)", c->dir.c_str());
+    if (c->desc.adjust_time_step) return fail(FY_ERR_UNSUPPORTED, "%s: adjustTimeStep is not carried on a general mesh", c->dir.c_str());
     for (const char* dn : {"laplacianSchemes", "snGradSchemes"}) {
         const FoamDict* sd = d.subdict(dn);
         for (const std::string& k : sd->order) {
@@ -1101,7 +1104,7 @@ int write_field(const fy_foam_case* c, const std::string& tdir, const std::strin
     std::fprintf(f, ")\n;\n\nboundaryField\n{\n");
     if (c->general) {
         const std::vector<std::string>& tx = ncomp == 3 ? c->g_u_text : c->g_p_text;
-        for (size_t pa = 0; pa < c->g_patch_name.size(); ++pa) std::fprintf(f, "    %s\n    {\n%s    }\n", c->g_patch_name[pa].c_str(), tx[pa].empty() ? default_bc : tx[pa].c_str());
+        for (size_t pa = 0; pa < c->g_patch_name.size(); ++pa) std::fprintf(f, "    %s\n    {\n%s    }\n", c->g_patch_name[pa].c_str(), (!bc_text || tx[pa].empty()) ? default_bc : tx[pa].c_str());
     }
     for (const std::string& pn : c->general ? std::vector<std::string>() : c->patch_order) {
         int side = -1;
@@ -1286,13 +1289,14 @@ int fy_foam_case_write_time(const fy_foam_case* c, fy_solver* s, const char* tim
                                      ee.empty() ? nullptr : ee.data());
 }
 
-int fy_foam_case_open_general(const char* case_dir, fy_foam_case** out) {
+int fy_foam_case_open_general(const char* case_dir, int solver, fy_foam_case** out) {
     if (!case_dir || !out) return fail(FY_ERR_INVALID, "fy_foam_case_open_general: null argument");
+    if (solver != FY_SOLVER_ICO && solver != FY_SOLVER_PIMPLE) return fail(FY_ERR_INVALID, "fy_foam_case_open_general: solver must be FY_SOLVER_ICO or FY_SOLVER_PIMPLE");
     *out = nullptr;
     fy_foam_case* c = new (std::nothrow) fy_foam_case();
     if (!c) return fail(FY_ERR_INVALID, "out of host memory");
-    c->dir = case_dir; c->fdir = c->dir; c->solver = FY_SOLVER_ICO; c->general = true;
-    fy_case_defaults(&c->desc, FY_SOLVER_ICO);
+    c->dir = case_dir; c->fdir = c->dir; c->solver = solver; c->general = true;
+    fy_case_defaults(&c->desc, solver);
     int rc = read_general_mesh(c);
     if (rc == FY_OK) { c->fcells = (size_t)c->g_cells; rc = read_controls(c); }
     if (rc == FY_OK) rc = check_general_schemes(c);
@@ -1325,6 +1329,9 @@ int fy_foam_case_ldu_desc(const fy_foam_case* c, fy_ldu_case* out) {
     out->p_ref_cell = d.p_ref_cell; out->p_ref_value = d.p_ref_value;
     out->p_tol = d.p_tol; out->p_rel_tol = d.p_rel_tol; out->p_final_tol = d.p_final_tol; out->p_final_rel_tol = d.p_final_rel_tol; out->p_max_iter = d.p_max_iter;
     out->u_tol = d.u_tol; out->u_rel_tol = d.u_rel_tol; out->u_max_iter = d.u_max_iter; out->p_solver = d.p_solver;
+    out->solver = c->solver; out->n_outer_correctors = d.n_outer_correctors;
+    for (int a = 0; a < 3; ++a) out->g[a] = d.g[a];
+    out->u_relax = d.u_relax; out->u_relax_final = d.u_relax_final; out->p_relax = d.p_relax; out->p_relax_final = d.p_relax_final;
     out->u_bc = c->g_u_bc.data(); out->u_value = c->g_u_val.data(); out->p_bc = c->g_p_bc.data(); out->p_value = c->g_p_val.data();
     return FY_OK;
 }
@@ -1343,10 +1350,11 @@ int fy_foam_case_write_time_ldu(const fy_foam_case* c, fy_ldu_solver* s, const c
     int64_t cnt = 0;
     FY_TRY(fy_ldu_solver_field_count(s, "p", &cnt));
     if ((size_t)cnt != c->fcells) return fail(FY_ERR_INVALID, "fy_foam_case_write_time_ldu: the solver holds %lld cells, the case %zu", (long long)cnt, c->fcells);
-    std::vector<double> U(3 * c->fcells), p(c->fcells);
+    std::vector<double> U(3 * c->fcells), p(c->fcells), a;
     FY_TRY(fy_ldu_solver_read_field_host(s, "U", U.data()));
     FY_TRY(fy_ldu_solver_read_field_host(s, "p", p.data()));
-    return fy_foam_case_write_fields(c, time_name, U.data(), p.data(), nullptr, nullptr, nullptr, nullptr);
+    if (c->solver == FY_SOLVER_PIMPLE) { a.resize(c->fcells); FY_TRY(fy_ldu_solver_read_field_host(s, "alpha", a.data())); }       // (with fy_ldu_solver_hold_sources: before setSourceZero)
+    return fy_foam_case_write_fields(c, time_name, U.data(), p.data(), a.empty() ? nullptr : a.data(), nullptr, nullptr, nullptr);
 }
 
 int fy_foam_case_close(fy_foam_case* c) {

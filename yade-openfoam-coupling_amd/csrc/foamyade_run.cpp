@@ -46,6 +46,7 @@ static int run_general(fy_foam_case* fc, const fy_transport* trp, int device) {
     std::printf("             %d points, %d faces (%d internal), %d cells, %d patches\n", pm.n_points, pm.n_faces, pm.n_internal_faces, pm.n_cells, pm.n_patches);
     fy_ldu_solver* s = nullptr;
     if (fy_ldu_solver_create(&pm, &lc, trp, device, &s) != FY_OK) return die("fy_ldu_solver_create");
+    fy_ldu_solver_hold_sources(s, 1);                   // runTime.write() comes before setSourceZero (icoFoamYade.C:142-147, pimpleFoamYade.C:107-109)
     {
         std::vector<double> U(3 * (size_t)info.n_cells), p((size_t)info.n_cells);
         fy_foam_case_initial_fields(fc, U.data(), p.data());
@@ -154,10 +155,10 @@ int main(int argc, char** argv) {
     bool decomposed = false;
     if (ssize > 1) { struct stat sb; decomposed = stat((dir + "/processor0").c_str(), &sb) == 0 && S_ISDIR(sb.st_mode); }
     int open_rc = decomposed ? fy_foam_case_open_processor(dir.c_str(), solver, srank, ssize, &fc) : fy_foam_case_open(dir.c_str(), solver, &fc);
-    if (open_rc == FY_ERR_UNSUPPORTED && solver == FY_SOLVER_ICO && ssize == 1) {
-        // not the block fy_solver computes on: icoFoamYade on the mesh as it is (owner / neighbour addressing, non-orthogonal correctors)
+    if (open_rc == FY_ERR_UNSUPPORTED && ssize == 1) {
+        // not the block fy_solver computes on: the solver on the mesh as it is (owner / neighbour addressing, non-orthogonal correctors)
         const std::string why = fy_last_error();
-        if (fy_foam_case_open_general(dir.c_str(), &fc) == FY_OK) {
+        if (fy_foam_case_open_general(dir.c_str(), solver, &fc) == FY_OK) {
             std::printf("Create mesh: general polyhedral mesh (the block reader said: %s)\n", why.c_str());
             const int rc = run_general(fc, trp, device);
 #ifdef FY_WITH_MPI
