@@ -413,6 +413,21 @@ def c2_subrecord(prod, torch, dev, device_index, steps=20, warmup=5):
                               "what": "128 B per particle (80 B record in, 48 B force out); bound by its three global FP64 atomics per particle"}}
 
 
+def general_mesh_subrecord(timeout=180):
+    """the general-mesh solver beside the headline (fy_ldu_solver): pimpleFoamYade, Gaussian 4-way coupling, on 128^3 WAVY hexahedra handed over
+    as a polyhedral mesh (non-orthogonal, skewed; one non-orthogonal corrector; agglomeration-multigrid PCG) with 2.5 M particles -- tools/ldu_bench.py in a
+    child process (its own context; the mesh is built with numpy there)"""
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "ldu_bench.py"), "128", "10", "wavy", "2500000", "mg", "1e-6", "pimple"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
+    line = (r.stdout.strip().splitlines() or [""])[-1]
+    d = json.loads(line)
+    return {"what": "NOT the configuration `value` is quoted on: pimpleFoamYade on a general polyhedral mesh (fy_ldu_solver), 128^3 = 2,097,152 wavy hexahedra in owner / neighbour "
+                    "addressing, 2,500,000 particles (Gaussian coupling on the explicit k-d tree), closed box under gravity, 1 non-orthogonal corrector, MG-PCG",
+            "value": round(d["steps_per_s"], 3), "unit": "steps/s", "steps": d["steps"], "ms_per_step": round(d["ms_per_step_wall"], 3), "ms_particle": round(d["ms_particle"], 3),
+            "p_iters_per_step": d["pcg_iters_per_step"], "cells": d["cells"], "particles": d["particles"]}
+
+
 def laplacian_probe_child(n, reps):
     """child of laplacian_past_cache (also run under rocprofv3 --pmc): the pEqn Laplacian apply y = A p (k_p_apply, 48 B per cell: diag, three upper
     coefficients, x, y) on an n^3 operator -- 1.57 GB per launch at 320^3, six times the 256 MiB Infinity Cache -- timed by HIP events on its stream"""
@@ -606,7 +621,7 @@ def main():
     ap.add_argument("--wire-workers", type=int, default=4)
     ap.add_argument("--laplacian-probe", type=int, default=0, help=argparse.SUPPRESS)       # child mode of laplacian_past_cache
     ap.add_argument("--laplacian-reps", type=int, default=40, help=argparse.SUPPRESS)
-    ap.add_argument("--no-extras", action="store_true", help="skip the C2 sub-record and the past-the-Infinity-Cache Laplacian probe of the default run")
+    ap.add_argument("--no-extras", action="store_true", help="skip the C2 and general-mesh sub-records and the past-the-Infinity-Cache Laplacian probe of the default run")
     ap.add_argument("--wire-helpers", type=int, default=4, help="wire-helper ranks beside the computing rank in the drop-in leg over MPI (0: one solver rank receives everything)")
     ap.add_argument("--moving", action="store_true", help="not the BASELINE configuration: particles carry random velocities (+-0.05 m/s) and are displaced by "
                     "~0.1 dx per step (alternating random offsets, applied between the steps inside the timed region), so that the momentum deposit, "
@@ -872,6 +887,10 @@ def main():
             out["c2"] = c2_subrecord(prod, torch, dev, local_rank)
         except Exception as e:                                        # noqa: BLE001  (reported in the line, never fatal for the headline)
             out["c2"] = {"error": f"{type(e).__name__}: {e}"}
+        try:
+            out["general_mesh"] = general_mesh_subrecord()
+        except Exception as e:                                        # noqa: BLE001
+            out["general_mesh"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     if rank == 0 and world == 1 and args.wire > 0:
         # the drop-in leg needs the device memory: the HBM-resident solver is done
         rec_host = rec.cpu().numpy()

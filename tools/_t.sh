@@ -1,13 +1,13 @@
 #!/bin/bash
 cd /root/repo
-rm -f gpurun_out/ldu_bench_pimple.jsonl
-for cfg in "64 10 wavy 300000 mg 1e-6 pimple" "128 10 wavy 2500000 mg 1e-6 pimple" "128 10 lattice 2500000 mg 1e-6 pimple" "96 10 prisms 1000000 mg 1e-6 pimple"; do
-  timeout 900 python tools/ldu_bench.py $cfg 2>&1 | tail -1 >> gpurun_out/ldu_bench_pimple.jsonl
-done
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+timeout 2400 python -m pytest tests -m gpu -x -q > gpurun_out/gpu_suite.log 2>&1; echo "rc=$?" >> gpurun_out/gpu_suite.log
+tail -4 gpurun_out/gpu_suite.log
+RND=r04 bash tools/profile_round.sh > gpurun_out/profile_round.log 2>&1
 python -c "
 import json
-for l in open('gpurun_out/ldu_bench_pimple.jsonl'):
-    try: d=json.loads(l)
-    except Exception: print('BAD', l[:300]); continue
-    print(d['kind'],d['cells'],d['particles'],'its',d['pcg_iters_per_step'],'ms',round(d['ms_per_step_wall'],2),'particle ms',round(d['ms_particle'],2),'create',round(d['create_s'],1))
+d=json.load(open('gpurun_out/r04/bench_line.json'))
+print(d['value'], d['ms_per_step'], d.get('c2',{}).get('value'), d.get('general_mesh'))
 "
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
