@@ -480,11 +480,13 @@ typedef struct fy_ldu_case {
     const int32_t* p_bc;             /* per patch: FY_BC_P_ZERO_GRADIENT | FY_BC_P_FIXED_VALUE */
     const double* p_value;           /* [n_patches] */
     /* pimpleFoamYade on the general mesh (solver = FY_SOLVER_PIMPLE; pimpleFoamYade.C:60-114, UcEqn.H, pEqn.H): Gaussian 4-way coupling, the void-fraction-
-     * weighted equations, laminar Stokes stress, fixed time step; p patches may then be FY_BC_P_FIXED_FLUX (fixedFluxPressure) too */
+     * weighted equations, laminar Stokes stress; p patches may then be FY_BC_P_FIXED_FLUX (fixedFluxPressure) too */
     int32_t solver;                  /* FY_SOLVER_ICO (the default) | FY_SOLVER_PIMPLE */
     int32_t n_outer_correctors;
     double g[3];
     double u_relax, u_relax_final, p_relax, p_relax_final;      /* relaxationFactors; <= 0: no entry (relax() does nothing) */
+    int32_t adjust_time_step;        /* pimpleFoamYade only (pimpleFoamYade.C:62-64: readTimeControls.H, CourantNo.H, setDeltaT.H) */
+    double max_co, max_delta_t;
 } fy_ldu_case;
 typedef struct fy_ldu_solver fy_ldu_solver;
 void fy_ldu_case_defaults(fy_ldu_case*);        /* the icoFoam cavity tutorial's controls (as fy_case_defaults); the patch arrays stay NULL */

@@ -45,11 +45,13 @@ extern "C" struct orc_ldu_case {
     double g[3];
     int n_outer;
     double u_relax, u_relax_final, p_relax, p_relax_final;      // <= 0: no relaxationFactors entry
+    int adjust_time_step; double max_co, max_delta_t;           // setDeltaT.H (pimpleFoamYade.C:62-64)
 };
 extern "C" struct orc_ldu_stats {
     double courant_mean, courant_max, cont_sum_local, cont_global, cont_cumulative;
     int p_iters_total, p_solves, u_iters_total;
     double p_initial_residual, p_final_residual;
+    double delta_t;
 };
 
 struct Ldu {
@@ -226,6 +228,12 @@ struct Ldu {
         double mx = 0, sm = 0, tv = 0;
         for (int c = 0; c < nCells; ++c) { mx = std::max(mx, sumPhi[c] / V[c]); sm += sumPhi[c]; tv += V[c]; }
         st.courant_max = 0.5 * mx * cs.dt; st.courant_mean = 0.5 * (sm / tv) * cs.dt;
+        if (pimple && cs.adjust_time_step) {                     // setDeltaT.H [OF-6]
+            const double maxDeltaTFact = cs.max_co / (st.courant_max + SMALL);
+            const double deltaTFact = std::min(std::min(maxDeltaTFact, 1.0 + 0.1 * maxDeltaTFact), 1.2);
+            cs.dt = std::min(deltaTFact * cs.dt, cs.max_delta_t);
+        }
+        st.delta_t = cs.dt;
         Uold = U; phiOld = phi;                                  // runTime++ : old-time fields
         grad_vector(U, vGrad);                                   // icoFoamYade.C:71 / pimpleFoamYade.C:76
         if (pimple) pre_coupling_fields();

@@ -120,7 +120,7 @@ def general_bed(tmp_path, amp=0.15):
 
 def test_general_pimple_case_is_read(prod, tmp_path):
     """pimpleFoamYade's dictionaries on a general mesh: PIMPLE controls, gravity, the phase's names, fixedFluxPressure patches; what the general solver does not carry
-    (a turbulence model, adjustTimeStep) is refused by name"""
+    (a turbulence model) is refused by name"""
     dst, mesh = general_bed(tmp_path)
     fc = prod.GeneralFoamCase(dst, prod.FY_SOLVER_PIMPLE)
     ref = prod.FoamCase(os.path.join(CASES, "bed_pimple"), prod.FY_SOLVER_PIMPLE)
@@ -140,9 +140,10 @@ def test_general_pimple_case_is_read(prod, tmp_path):
         prod.GeneralFoamCase(dst, prod.FY_SOLVER_PIMPLE)
     os.remove(dst / "constant/turbulenceProperties.water")
     cd = (dst / "system/controlDict").read_text()
-    (dst / "system/controlDict").write_text(cd.replace("adjustTimeStep  no;", "adjustTimeStep  yes;").replace("writeControl    adjustableRunTime;", "writeControl    timeStep;").replace("writeInterval   0.001;", "writeInterval   5;"))
-    with pytest.raises(prod.FoamYadeError, match="adjustTimeStep"):
-        prod.GeneralFoamCase(dst, prod.FY_SOLVER_PIMPLE)
+    (dst / "system/controlDict").write_text(cd.replace("adjustTimeStep  no;", "adjustTimeStep  yes;\nmaxCo 0.5;\nmaxDeltaT 0.001;").replace("writeControl    adjustableRunTime;", "writeControl    timeStep;").replace("writeInterval   0.001;", "writeInterval   5;"))
+    fc = prod.GeneralFoamCase(dst, prod.FY_SOLVER_PIMPLE)             # setDeltaT.H's controls (pimpleFoamYade.C:62-64)
+    assert (fc.ldu_case.adjust_time_step, fc.ldu_case.max_co, fc.ldu_case.max_delta_t) == (1, 0.5, 0.001)
+    fc.close()
 
 
 @pytest.mark.gpu

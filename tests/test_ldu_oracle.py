@@ -183,8 +183,8 @@ def test_prisms_geometry(oracle):
     s.close()
 
 
-@pytest.mark.parametrize("n_outer,relax", [(1, 0.0), (2, 0.7)])
-def test_pimple_on_a_lattice_reproduces_the_structured_restatement(oracle, n_outer, relax):
+@pytest.mark.parametrize("n_outer,relax,adjust", [(1, 0.0, 0), (2, 0.7, 0), (1, 0.0, 1)])
+def test_pimple_on_a_lattice_reproduces_the_structured_restatement(oracle, n_outer, relax, adjust):
     """pimpleFoamYade's void-fraction-weighted equations (UcEqn.H, pEqn.H: gravity, fixedFluxPressure walls, PIMPLE outer correctors, relaxation) restated for a general
     mesh, against fv_oracle.cpp on the same block with a cloud: the general side is given the void fraction, the implicit drag coefficient and the explicit source the
     structured side's coupling left, step by step; the cells are renumbered at random"""
@@ -192,7 +192,8 @@ def test_pimple_on_a_lattice_reproduces_the_structured_restatement(oracle, n_out
     dx = box / n
     mesh = pm.hex_block(n, n, n, (box, box, box), renumber_seed=5)
     tol = dict(p_tol=1e-12, p_rel_tol=0.0, p_final_tol=1e-12, u_tol=1e-12)
-    rel = dict(u_relax=relax, u_relax_final=1.0 if relax else 0.0, p_relax=0.6 if relax else 0.0, p_relax_final=1.0 if relax else 0.0)
+    rel = dict(u_relax=relax, u_relax_final=1.0 if relax else 0.0, p_relax=0.6 if relax else 0.0, p_relax_final=1.0 if relax else 0.0,
+               adjust_time_step=adjust, max_co=0.4, max_delta_t=3.2e-4)          # (adjustable: the step grows by 1.2 per step while the Courant number allows)
     f = orc.FvSolver(orc.fv_case(1, n, n, n, dx, 2e-4, 1e-5, g=(0, 0, -9.81), p_bc=[2] * 6, p_solver=0, n_outer=n_outer, n_corr=2, p_final_rel_tol=0.0, p_max_iter=5000, **rel, **tol))
     g = orc.LduSolver(mesh, 2e-4, 1e-5, [0] * 6, [(0, 0, 0)] * 6, [2] * 6, solver=1, g=(0, 0, -9.81), n_outer=n_outer, n_correctors=2, **rel, **tol)
     rs = np.random.RandomState(17)
@@ -208,6 +209,7 @@ def test_pimple_on_a_lattice_reproduces_the_structured_restatement(oracle, n_out
         g.step(source=to_g(cap["uSource"], 3), alpha=to_g(cap["alpha"], 1), drag=to_g(cap["uSourceDrag"], 1))
         Uf, Ug = f.get("U").reshape(-1, 3), pm.to_lattice(mesh, g.get("U").reshape(-1, 3))
         assert np.abs(Ug - Uf).max() < 1e-8 * np.abs(Uf).max(), step
+        assert g.stats()["delta_t"] == f.stats()["delta_t"] and (f.stats()["delta_t"] > 2e-4) == bool(adjust)
     pf, pg = f.get("p"), pm.to_lattice(mesh, g.get("p"))
     assert np.abs((pg - pg.mean()) - (pf - pf.mean())).max() < 1e-7 * np.abs(pf).max()
     assert np.abs(f.get("U")).max() > 1e-4

@@ -192,8 +192,8 @@ def bed_particles(rs, npart, box, dx):
     return rec
 
 
-@pytest.mark.parametrize("n_outer,relax", [(1, 0.0), (2, 0.7)])
-def test_pimple_on_a_lattice_equals_the_structured_hip_solver(product, n_outer, relax):
+@pytest.mark.parametrize("n_outer,relax,adjust", [(1, 0.0, 0), (2, 0.7, 0), (1, 0.0, 1)])
+def test_pimple_on_a_lattice_equals_the_structured_hip_solver(product, n_outer, relax, adjust):
     """pimpleFoamYade's equations (void-fraction-weighted UcEqn / pEqn, gravity, fixedFluxPressure walls, PIMPLE outer correctors, relaxation) through both HIP
     solvers: fy_solver on the block with particles, and fy_ldu_solver on the block written as a polyhedral mesh, fed the void fraction and the momentum sources the
     first one's coupling produced (the two k-d trees differ where a lattice's centres tie, so a cloud does not take the same improvement chains in both: the
@@ -202,7 +202,8 @@ def test_pimple_on_a_lattice_equals_the_structured_hip_solver(product, n_outer, 
     dx = box / n
     mesh = pm.hex_block(n, n, n, (box, box, box))
     kw = dict(p_tol=1e-11, p_rel_tol=0.0, p_final_tol=1e-11, u_tol=1e-11)
-    rel = dict(u_relax=relax, u_relax_final=1.0 if relax else 0.0, p_relax=0.6 if relax else 0.0, p_relax_final=1.0 if relax else 0.0)
+    rel = dict(u_relax=relax, u_relax_final=1.0 if relax else 0.0, p_relax=0.6 if relax else 0.0, p_relax_final=1.0 if relax else 0.0,
+               adjust_time_step=adjust, max_co=0.4, max_delta_t=3.2e-4)          # (setDeltaT.H: the step grows by 1.2 per step while the Courant number allows)
     case = product.make_case(1, n, n, n, dx, 2e-4, 1e-5, g=(0, 0, -9.81), p_bc=[2] * 6, p_solver=0, n_outer_correctors=n_outer, n_correctors=2, p_max_iter=5000, **rel, **kw)
     f = product.Solver(case)
     f.hold_sources(True)
@@ -216,6 +217,7 @@ def test_pimple_on_a_lattice_equals_the_structured_hip_solver(product, n_outer, 
         h.set("alpha", alpha); h.set("uSourceDrag", f.get("uSourceDrag")); h.set("uSource", f.get("uSource"))
         h.step()
         close(h.get("U").reshape(-1, 3), f.get("U").reshape(-1, 3), 1e-6, "U step %d" % step)
+        assert h.stats()["delta_t"] == f.stats()["delta_t"] and (f.stats()["delta_t"] > 2e-4) == bool(adjust)
     pf, ph = f.get("p"), h.get("p")
     close(ph - ph.mean(), pf - pf.mean(), 1e-6, "p")
     assert np.abs(f.get("U")).max() > 1e-4

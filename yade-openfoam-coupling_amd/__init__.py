@@ -88,7 +88,7 @@ class LduCase(C.Structure):
                 ("p_tol", C.c_double), ("p_rel_tol", C.c_double), ("p_final_tol", C.c_double), ("p_final_rel_tol", C.c_double), ("p_max_iter", C.c_int32),
                 ("u_tol", C.c_double), ("u_rel_tol", C.c_double), ("u_max_iter", C.c_int32), ("p_solver", C.c_int32), ("u_bc", _ip), ("u_value", _dp), ("p_bc", _ip),
                 ("p_value", _dp), ("solver", C.c_int32), ("n_outer_correctors", C.c_int32), ("g", C.c_double * 3), ("u_relax", C.c_double), ("u_relax_final", C.c_double),
-                ("p_relax", C.c_double), ("p_relax_final", C.c_double)]
+                ("p_relax", C.c_double), ("p_relax_final", C.c_double), ("adjust_time_step", C.c_int32), ("max_co", C.c_double), ("max_delta_t", C.c_double)]
 
 
 class ParticleTimings(C.Structure):

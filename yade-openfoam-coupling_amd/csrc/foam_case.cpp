@@ -782,7 +782,6 @@ int check_general_schemes(const fy_foam_case* c) {
     FY_TRY(need_file(path, &d));
     if (c->desc.convection_scheme != FY_CONVECTION_LINEAR) return fail(FY_ERR_UNSUPPORTED, "%s: on a general mesh the convection term must be Gauss linear", path.c_str());
     if (c->desc.turbulence_model != FY_TURBULENCE_LAMINAR) return fail(FY_ERR_UNSUPPORTED, "%s: on a general mesh only the laminar (Stokes) model is carried (constant/turbulenceProperties)", c->dir.c_str());
-    if (c->desc.adjust_time_step) return fail(FY_ERR_UNSUPPORTED, "%s: adjustTimeStep is not carried on a general mesh", c->dir.c_str());
     for (const char* dn : {"laplacianSchemes", "snGradSchemes"}) {
         const FoamDict* sd = d.subdict(dn);
         for (const std::string& k : sd->order) {
@@ -1332,6 +1331,7 @@ int fy_foam_case_ldu_desc(const fy_foam_case* c, fy_ldu_case* out) {
     out->solver = c->solver; out->n_outer_correctors = d.n_outer_correctors;
     for (int a = 0; a < 3; ++a) out->g[a] = d.g[a];
     out->u_relax = d.u_relax; out->u_relax_final = d.u_relax_final; out->p_relax = d.p_relax; out->p_relax_final = d.p_relax_final;
+    out->adjust_time_step = d.adjust_time_step; out->max_co = d.max_co; out->max_delta_t = d.max_delta_t;
     out->u_bc = c->g_u_bc.data(); out->u_value = c->g_u_val.data(); out->p_bc = c->g_p_bc.data(); out->p_value = c->g_p_val.data();
     return FY_OK;
 }

@@ -54,12 +54,15 @@ static int run_general(fy_foam_case* fc, const fy_transport* trp, int device) {
     }
     std::printf("\nStarting time loop\n\n");
     const long n_steps = std::lround((info.end_time - info.start_time) / info.delta_t);
-    for (long k = 1; k <= n_steps; ++k) {
+    double t = info.start_time, dt_now = info.delta_t;        // adjustTimeStep: Time::run(), value() < endTime - 0.5 deltaT [OF-6 Time.C]
+    for (long k = 1; lc.adjust_time_step ? t < info.end_time - 0.5 * dt_now : k <= n_steps; ++k) {
         if (fy_ldu_solver_step(s) != FY_OK) return die("fy_ldu_solver_step");
         fy_step_stats st;
         fy_ldu_solver_get_stats(s, &st);
+        t = lc.adjust_time_step ? t + st.delta_t : info.start_time + (double)k * info.delta_t;
+        dt_now = st.delta_t;
         char tname[64];
-        std::snprintf(tname, sizeof(tname), "%.12g", info.start_time + (double)k * info.delta_t);
+        std::snprintf(tname, sizeof(tname), "%.12g", t);
         std::printf("Time = %s\n\nCourant Number mean: %g max: %g\n", tname, st.courant_mean, st.courant_max);
         std::printf("pressure: %d solves, %d iterations, initial residual %g, final residual %g\n", st.p_solves, st.p_iters_total, st.p_initial_residual, st.p_final_residual);
         std::printf("time step continuity errors : sum local = %g, global = %g, cumulative = %g\n\n", st.cont_err_sum_local, st.cont_err_global, st.cont_err_cumulative);

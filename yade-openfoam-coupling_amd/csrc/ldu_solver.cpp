@@ -65,6 +65,8 @@ struct LduSolver {
         pimple = c->solver == FY_SOLVER_PIMPLE;
         if (c->solver != FY_SOLVER_ICO && !pimple) return fail(FY_ERR_INVALID, "fy_ldu_solver: solver %d (FY_SOLVER_ICO, FY_SOLVER_PIMPLE)", c->solver);
         if (pimple && c->n_outer_correctors < 1) cs.n_outer_correctors = 1;
+        if (c->adjust_time_step && !pimple) cs.adjust_time_step = 0;                      // (icoFoamYade's loop never includes setDeltaT.H: icoFoamYade.C:65-70)
+        if (cs.adjust_time_step && !(c->max_co > 0 && c->max_delta_t > 0)) return fail(FY_ERR_INVALID, "fy_ldu_solver: adjustTimeStep needs maxCo > 0 and maxDeltaT > 0");
         nc = hm.nCells; nf = hm.nFaces; ni = hm.nInt;
         std::vector<int32_t> ubc(c->u_bc, c->u_bc + hm.nPatches), pbc(c->p_bc, c->p_bc + hm.nPatches);
         std::vector<double> uval(c->u_value, c->u_value + 3 * (size_t)hm.nPatches), pval(c->p_value, c->p_value + hm.nPatches);
@@ -298,6 +300,13 @@ struct LduSolver {
         FY_TRY(launch_ldu_courant(stream, g, phi.p, partials.p));                                                   // icoFoamYade.C:68
         FY_TRY(reduce_read(nc, 2, ops_courant.p, h));
         st.courant_max = 0.5 * h[0] * cs.dt; st.courant_mean = 0.5 * (h[1] / total_volume) * cs.dt;
+        if (cs.adjust_time_step) {                                                                                  // setDeltaT.H [OF-6] (pimpleFoamYade.C:64): Co from the current flux at the OLD step
+            const double maxDeltaTFact = cs.max_co / (st.courant_max + 1e-15);
+            const double deltaTFact = std::min(std::min(maxDeltaTFact, 1.0 + 0.1 * maxDeltaTFact), 1.2);
+            cs.dt = std::min(deltaTFact * cs.dt, cs.max_delta_t);
+            g.dt = cs.dt;
+        }
+        st.delta_t = cs.dt;
         FY_HIP(hipMemcpyAsync(Uold.p, U.p, 3 * (size_t)nc * sizeof(double), hipMemcpyDeviceToDevice, stream));    // runTime++: old-time fields
         FY_HIP(hipMemcpyAsync(phiOld.p, phi.p, (size_t)nf * sizeof(double), hipMemcpyDeviceToDevice, stream));
         FY_TRY(launch_ldu_grad_vec(stream, g, U.p, vGrad.p));                                                      // :71
@@ -365,6 +374,7 @@ void fy_ldu_case_defaults(fy_ldu_case* c) {
     c->u_tol = 1e-5; c->u_rel_tol = 0.0; c->u_max_iter = 1000;
     c->p_solver = FY_PSOLVER_PCG_JACOBI;
     c->solver = FY_SOLVER_ICO; c->n_outer_correctors = 1;
+    c->adjust_time_step = 0; c->max_co = 1.0; c->max_delta_t = 1e300;
 }
 
 int fy_ldu_solver_create(const fy_poly_mesh* m, const fy_ldu_case* c, const fy_transport* tr, int device_ordinal, fy_ldu_solver** out) {
