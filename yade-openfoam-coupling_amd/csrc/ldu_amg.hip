@@ -86,10 +86,9 @@ __global__ __launch_bounds__(256) void k_amg_invd(int n, const double* __restric
     if (c < n) invd[c] = 1.0 / diag[c];
 }
 
-// ---- smoothing.  From a zero guess the first sweep is x = wa b / d; the pair's second sweep forms the neighbours' first iterate inline
-__global__ __launch_bounds__(256) void k_amg_two_from_zero(EllMat A, const double* __restrict__ invd, const double* __restrict__ b, double* __restrict__ xn, double wa, double wb) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= A.n) return;
+// ---- smoothing, one row each (shared by the one-launch-per-sweep kernels of the large levels and the one-workgroup tail of the small ones).  From a zero
+// guess the first sweep is x = wa b / d; the pair's second sweep forms the neighbours' first iterate inline
+__device__ __forceinline__ void row_two_from_zero(const EllMat& A, const double* __restrict__ invd, const double* __restrict__ b, double* __restrict__ xn, double wa, double wb, int c) {
     double s = 0.0;
     for (int k = 0; k < A.W; ++k) {
         const size_t e = (size_t)k * A.n + c;
@@ -99,17 +98,13 @@ __global__ __launch_bounds__(256) void k_amg_two_from_zero(EllMat A, const doubl
     const double xc = wa * b[c] * invd[c];
     xn[c] = xc + wb * invd[c] * (b[c] - (A.diag[c] * xc - s));
 }
-__global__ __launch_bounds__(256) void k_amg_smooth(EllMat A, const double* __restrict__ invd, const double* __restrict__ b, const double* __restrict__ x, double* __restrict__ xn, double w) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= A.n) return;
+__device__ __forceinline__ void row_smooth(const EllMat& A, const double* __restrict__ invd, const double* __restrict__ b, const double* __restrict__ x, double* __restrict__ xn, double w, int c) {
     const double xc = x[c];
     xn[c] = xc + w * invd[c] * (b[c] - (A.diag[c] * xc - ell_offdiag(A, x, c)));
 }
 // the first post-smoothing sweep with the prolongation folded in: x' = x + e[agg]
-__global__ __launch_bounds__(256) void k_amg_prolong_smooth(EllMat A, const double* __restrict__ invd, const double* __restrict__ b, const double* __restrict__ x,
-                                                            const int32_t* __restrict__ agg, const double* __restrict__ e, double* __restrict__ xn, double w) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= A.n) return;
+__device__ __forceinline__ void row_prolong_smooth(const EllMat& A, const double* __restrict__ invd, const double* __restrict__ b, const double* __restrict__ x,
+                                                   const int32_t* __restrict__ agg, const double* __restrict__ e, double* __restrict__ xn, double w, int c) {
     double s = 0.0;
     for (int k = 0; k < A.W; ++k) {
         const size_t q = (size_t)k * A.n + c;
@@ -119,16 +114,34 @@ __global__ __launch_bounds__(256) void k_amg_prolong_smooth(EllMat A, const doub
     const double xc = x[c] + e[agg[c]];
     xn[c] = xc + w * invd[c] * (b[c] - (A.diag[c] * xc - s));
 }
-__global__ __launch_bounds__(256) void k_amg_residual(EllMat A, const double* __restrict__ b, const double* __restrict__ x, double* __restrict__ r) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c < A.n) r[c] = b[c] - (A.diag[c] * x[c] - ell_offdiag(A, x, c));
+__device__ __forceinline__ void row_residual(const EllMat& A, const double* __restrict__ b, const double* __restrict__ x, double* __restrict__ r, int c) {
+    r[c] = b[c] - (A.diag[c] * x[c] - ell_offdiag(A, x, c));
 }
-__global__ __launch_bounds__(256) void k_amg_restrict(int nc, const int32_t* __restrict__ child_off, const int32_t* __restrict__ child, const double* __restrict__ r, double* __restrict__ bc) {
-    const int I = blockIdx.x * 256 + threadIdx.x;
-    if (I >= nc) return;
+__device__ __forceinline__ void row_restrict(const int32_t* __restrict__ child_off, const int32_t* __restrict__ child, const double* __restrict__ r, double* __restrict__ bc, int I) {
     double s = 0.0;
     for (int q = child_off[I]; q < child_off[I + 1]; ++q) s += r[child[q]];
     bc[I] = s;
+}
+__global__ __launch_bounds__(256) void k_amg_two_from_zero(EllMat A, const double* __restrict__ invd, const double* __restrict__ b, double* __restrict__ xn, double wa, double wb) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < A.n) row_two_from_zero(A, invd, b, xn, wa, wb, c);
+}
+__global__ __launch_bounds__(256) void k_amg_smooth(EllMat A, const double* __restrict__ invd, const double* __restrict__ b, const double* __restrict__ x, double* __restrict__ xn, double w) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < A.n) row_smooth(A, invd, b, x, xn, w, c);
+}
+__global__ __launch_bounds__(256) void k_amg_prolong_smooth(EllMat A, const double* __restrict__ invd, const double* __restrict__ b, const double* __restrict__ x,
+                                                            const int32_t* __restrict__ agg, const double* __restrict__ e, double* __restrict__ xn, double w) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < A.n) row_prolong_smooth(A, invd, b, x, agg, e, xn, w, c);
+}
+__global__ __launch_bounds__(256) void k_amg_residual(EllMat A, const double* __restrict__ b, const double* __restrict__ x, double* __restrict__ r) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < A.n) row_residual(A, b, x, r, c);
+}
+__global__ __launch_bounds__(256) void k_amg_restrict(int nc, const int32_t* __restrict__ child_off, const int32_t* __restrict__ child, const double* __restrict__ r, double* __restrict__ bc) {
+    const int I = blockIdx.x * 256 + threadIdx.x;
+    if (I < nc) row_restrict(child_off, child, r, bc, I);
 }
 // the coarsest level (<= kAmgCoarsest cells) is solved exactly: its matrix is inverted once per assembly -- in-place Gauss-Jordan in LDS, no pivoting
 // (the matrix is symmetric positive definite: the reference cell's point term, or a fixed-value patch, removes the constant) -- and the solve is the
@@ -164,15 +177,49 @@ __global__ __launch_bounds__(256) void k_amg_coarsest_invert(EllMat A, double* _
     }
     for (int q = t; q < n * n; q += 256) inv[q] = a[q];
 }
-__global__ __launch_bounds__(256) void k_amg_coarsest_solve(int n, const double* __restrict__ inv, const double* __restrict__ b, double* __restrict__ x) {
+// The small levels (<= kAmgTailCells cells and everything below) in ONE workgroup: a launch per sweep costs ~7 us of dispatch for a few hundred rows of work, and a
+// V-cycle has seven of them per level; here a sweep ends at a workgroup barrier instead (the iterates stay in global memory: L2).  Same rows, same order, same bits
+struct TailLevel {
+    EllMat A;
+    const double *invd;
+    const double *b;                      // the level's right-hand side (the first level: the caller's)
+    double *x0, *x1, *bnext;              // scratch / answer, the next level's right-hand side
+    const int32_t *agg, *child_off, *child;
+    int n_next;
+};
+struct TailArgs { TailLevel L[kAmgTailMax]; int n; const double* inv; double* xlast; };
+__global__ __launch_bounds__(1024) void k_amg_tail(TailArgs T, double wa, double wb) {
     __shared__ double bs[kAmgCoarsest];
-    const int c = threadIdx.x;
-    if (c < n) bs[c] = b[c];
-    __syncthreads();
-    if (c >= n) return;
-    double s = 0.0;
-    for (int j = 0; j < n; ++j) s += inv[(size_t)j * n + c] * bs[j];        // (the inverse is symmetric: column c read along the lanes)
-    x[c] = s;
+    const int t = threadIdx.x;
+    for (int l = 0; l + 1 < T.n; ++l) {
+        const TailLevel& L = T.L[l];
+        for (int c = t; c < L.A.n; c += 1024) row_two_from_zero(L.A, L.invd, L.b, L.x1, wa, wb, c);
+        __syncthreads();
+        for (int c = t; c < L.A.n; c += 1024) row_residual(L.A, L.b, L.x1, L.x0, c);
+        __syncthreads();
+        for (int I = t; I < L.n_next; I += 1024) row_restrict(L.child_off, L.child, L.x0, L.bnext, I);
+        __syncthreads();
+    }
+    {
+        const TailLevel& L = T.L[T.n - 1];
+        const int n = L.A.n;
+        if (t < n) bs[t] = L.b[t];
+        __syncthreads();
+        if (t < n) {
+            double s = 0.0;
+            for (int j = 0; j < n; ++j) s += T.inv[(size_t)j * n + t] * bs[j];
+            T.xlast[t] = s;
+        }
+        __syncthreads();
+    }
+    for (int l = T.n - 2; l >= 0; --l) {
+        const TailLevel& L = T.L[l];
+        const double* e = l + 1 == T.n - 1 ? T.xlast : T.L[l + 1].x1;
+        for (int c = t; c < L.A.n; c += 1024) row_prolong_smooth(L.A, L.invd, L.b, L.x1, L.agg, e, L.x0, wb, c);
+        __syncthreads();
+        for (int c = t; c < L.A.n; c += 1024) row_smooth(L.A, L.invd, L.b, L.x0, L.x1, wa, c);
+        __syncthreads();
+    }
 }
 
 inline dim3 grid_of(size_t n) { return dim3((unsigned)((n + 255) / 256)); }
@@ -409,7 +456,10 @@ int LduAmg::vcycle(hipStream_t s, const double* r, double* u) {
     const size_t nl = lev.size();
     auto mat_of = [&](size_t l, const double* pdiag0) { EllMat A = lev[l]->mat(); if (l == 0) A.diag = pdiag0; return A; };
     const double* diag0 = diag0_;
-    for (size_t l = 0; l + 1 < nl; ++l) {
+    // the first level of the one-workgroup tail: the largest level of at most kAmgTailCells cells, at most kAmgTailMax levels from the end, never level 0 unless it is alone
+    size_t tail = nl - 1;
+    while (tail > 0 && nl - (tail - 1) <= (size_t)kAmgTailMax && lev[tail - 1]->n <= kAmgTailCells && (tail - 1 > 0 || nl == 1)) --tail;
+    for (size_t l = 0; l < tail; ++l) {
         AmgLevel& L = *lev[l];
         const EllMat A = mat_of(l, diag0);
         const double* b = l == 0 ? r : L.b.p;
@@ -422,12 +472,22 @@ int LduAmg::vcycle(hipStream_t s, const double* r, double* u) {
         FY_LAUNCH_CHECK();
     }
     {
-        AmgLevel& L = *lev[nl - 1];
-        hipLaunchKernelGGL(k_amg_coarsest_solve, dim3(1), dim3(256), 0, s, L.n, coarse_inv.p, nl == 1 ? r : L.b.p, nl == 1 ? u : L.x1.p);
+        TailArgs T{};
+        T.n = (int)(nl - tail);
+        for (size_t l = tail; l < nl; ++l) {
+            AmgLevel& L = *lev[l];
+            TailLevel& q = T.L[l - tail];
+            q.A = mat_of(l, diag0); q.invd = L.invd.p; q.b = l == 0 ? r : L.b.p; q.x0 = L.x0.p; q.x1 = L.x1.p;
+            q.agg = L.agg.p; q.child_off = L.child_off.p; q.child = L.child.p;
+            q.bnext = l + 1 < nl ? lev[l + 1]->b.p : nullptr; q.n_next = l + 1 < nl ? lev[l + 1]->n : 0;
+        }
+        T.inv = coarse_inv.p;
+        T.xlast = nl == 1 ? u : lev[nl - 1]->x1.p;
+        hipLaunchKernelGGL(k_amg_tail, dim3(1), dim3(1024), 0, s, T, kWa, kWb);
         FY_LAUNCH_CHECK();
     }
     // up: prolongation folded into the first post-smoothing sweep (weights in reverse order), the second sweep leaves the level's answer in x1 (level 0: u)
-    for (size_t l = nl - 1; l-- > 0;) {
+    for (size_t l = tail; l-- > 0;) {
         AmgLevel& L = *lev[l];
         const EllMat A = mat_of(l, diag0);
         const double* b = l == 0 ? r : L.b.p;

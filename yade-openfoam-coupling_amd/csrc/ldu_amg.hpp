@@ -28,6 +28,8 @@ struct EllMat {                 // device pointers
     const double* diag;         // [n]
 };
 
+constexpr int kAmgTailCells = 1024;     // levels of at most this many cells run inside the one-workgroup tail kernel of the V-cycle
+constexpr int kAmgTailMax = 4;          // ... at most this many of them
 constexpr int kAmgCoarsest = 64;        // cells the coarsest level may have (its dense inverse is formed in LDS: 32 KB)
 
 struct AmgLevel {
