@@ -219,3 +219,40 @@ def hex_block_fast(nx, ny, nz, lengths=(1.0, 1.0, 1.0), vertex_map=None):
     return dict(points=P, face_offsets=np.arange(0, 4 * len(F) + 1, 4, dtype=np.int32), face_points=F.astype(np.int32).ravel(), owner=np.concatenate(owner).astype(np.int32),
                 neighbour=neigh.astype(np.int32), n_cells=nx * ny * nz, patch_start=np.asarray(pstart, np.int32), patch_size=np.asarray(psize, np.int32),
                 patch_names=list(SIDES), perm=np.arange(nx * ny * nz), shape=(nx, ny, nz))
+
+
+def tet_block(nx, ny, nz, lengths=(1.0, 1.0, 1.0), vertex_map=None):
+    """the box cut into tetrahedra: every hexahedron of the lattice split into the six Kuhn tetrahedra about its main diagonal (the face diagonals then agree between
+    neighbouring hexahedra: a conforming mesh of triangular faces only, four-faced cells, strongly non-orthogonal).  Patches: one per side of the box (SIDES)."""
+    import itertools
+    lx, ly, lz = lengths
+    pid = lambda i, j, k: i + (nx + 1) * (j + (ny + 1) * k)
+    ii, jj, kk = np.meshgrid(np.arange(nx + 1), np.arange(ny + 1), np.arange(nz + 1), indexing="ij")
+    P0 = np.zeros(((nx + 1) * (ny + 1) * (nz + 1), 3))
+    P0[pid(ii, jj, kk).ravel()] = np.stack([ii.ravel() * lx / nx, jj.ravel() * ly / ny, kk.ravel() * lz / nz], axis=1)
+    P = P0 if vertex_map is None else np.asarray(vertex_map(P0), np.float64)
+    cells = []
+    for k in range(nz):
+        for j in range(ny):
+            for i in range(nx):
+                for perm in itertools.permutations(range(3)):
+                    v = [np.array([i, j, k])]
+                    for a in perm:
+                        e = np.zeros(3, int); e[a] = 1
+                        v.append(v[-1] + e)
+                    q = [pid(*w) for w in v]
+                    x = P0[q]
+                    vol = np.dot(np.cross(x[1] - x[0], x[2] - x[0]), x[3] - x[0])
+                    if vol < 0:
+                        q[1], q[2] = q[2], q[1]
+                    a, b, c, d = q                      # positively oriented: the faces below turn counter-clockwise seen from outside
+                    cells.append([(a, c, b), (a, b, d), (b, c, d), (a, d, c)])
+    eps = 1e-9
+    table = {}
+    for faces in cells:
+        for f in faces:
+            c0 = P0[list(f)].mean(axis=0)
+            for a, L in enumerate((lx, ly, lz)):
+                if abs(c0[a]) < eps: table[tuple(np.round(P[list(f)].mean(axis=0), 12))] = SIDES[2 * a]
+                elif abs(c0[a] - L) < eps: table[tuple(np.round(P[list(f)].mean(axis=0), 12))] = SIDES[2 * a + 1]
+    return from_cells(P, cells, lambda ctr: table[tuple(np.round(ctr, 12))], list(SIDES), shape=(nx, ny, nz))

@@ -214,3 +214,30 @@ def test_pimple_on_a_lattice_reproduces_the_structured_restatement(oracle, n_out
     assert np.abs((pg - pg.mean()) - (pf - pf.mean())).max() < 1e-7 * np.abs(pf).max()
     assert np.abs(f.get("U")).max() > 1e-4
     f.close(); g.close()
+
+
+def test_tetrahedra_geometry_and_a_cavity_on_them(oracle):
+    """Kuhn tetrahedra (triangular faces only, four-faced cells, non-orthogonality around 50 degrees): closed cells, volumes adding up to the box's with every
+    tetrahedron a sixth of its hexahedron, centres = the vertex means; the lid-driven cavity runs on them and conserves mass to rounding with two non-orthogonal passes"""
+    mesh = pm.tet_block(4, 4, 3, (1.0, 1.0, 0.9), pm.wavy(0.02, (1.0, 1.0, 0.9)))
+    assert set(np.diff(mesh["face_offsets"])) == {3} and mesh["n_cells"] == 4 * 4 * 3 * 6
+    u_val = [(0, 0, 0)] * 6
+    u_val[3] = (1.0, 0, 0)
+    s = make(mesh, 0.01, 0.01, u_val=u_val, n_non_orth=2, p_tol=1e-11, p_rel_tol=0.0, p_final_tol=1e-11, p_max_iter=20000)
+    Sf, V, C, kv = (s.geometry(n) for n in ("Sf", "V", "C", "kvec"))
+    own, nei, ni = mesh["owner"], mesh["neighbour"], len(mesh["neighbour"])
+    tot = np.zeros((mesh["n_cells"], 3))
+    np.add.at(tot, own, Sf); np.subtract.at(tot, nei, Sf[:ni])
+    assert np.abs(tot).max() < 1e-15 and V.sum() == pytest.approx(0.9, rel=1e-13) and V.min() > 0
+    P, off, fp = mesh["points"], mesh["face_offsets"], mesh["face_points"]
+    verts = [set() for _ in range(mesh["n_cells"])]
+    for f in range(len(own)):
+        verts[own[f]].update(fp[off[f]:off[f + 1]])
+        if f < ni: verts[nei[f]].update(fp[off[f]:off[f + 1]])
+    assert all(len(v) == 4 for v in verts)
+    np.testing.assert_allclose(C, np.array([P[sorted(v)].mean(axis=0) for v in verts]), atol=1e-14)
+    assert np.abs(kv).max() > 0.5                                    # (strongly non-orthogonal)
+    for _ in range(3):
+        s.step()
+    assert s.stats()["cont_sum_local"] < 1e-12 and np.abs(s.get("U")).max() > 0.02 and np.isfinite(s.get("p")).all()
+    s.close()

@@ -36,13 +36,16 @@ def test_geometry_equals_the_restatement(product, oracle):
     h.close(); o.close()
 
 
-@pytest.mark.parametrize("kind", ["lattice", "sheared", "wavy_renumbered", "prisms"])
+@pytest.mark.parametrize("kind", ["lattice", "sheared", "wavy_renumbered", "prisms", "tetrahedra"])
 def test_cavity_matches_the_restatement(product, oracle, kind):
     """lid-driven cavity, four steps, two non-orthogonal correctors: first-step matrices, then fields and counters.  prisms: triangular prisms on a wavy
     lattice (triangular and quadrilateral faces, five-faced cells)"""
     n = 10
-    vm, seed = {"lattice": (None, None), "sheared": (pm.shear(0.3, 0.0, 0.2), None), "wavy_renumbered": (pm.wavy(0.03), 9), "prisms": (pm.wavy(0.02), None)}[kind]
-    mesh = pm.prism_block(n, n, 6, vertex_map=vm) if kind == "prisms" else pm.hex_block(n, n, n, vertex_map=vm, renumber_seed=seed)
+    vm, seed = {"lattice": (None, None), "sheared": (pm.shear(0.3, 0.0, 0.2), None), "wavy_renumbered": (pm.wavy(0.03), 9), "prisms": (pm.wavy(0.02), None), "tetrahedra": (None, None)}[kind]
+    if kind == "tetrahedra":            # Kuhn tetrahedra on a wavy lattice: triangles only, four-faced cells, non-orthogonality around 50 degrees
+        mesh = pm.tet_block(6, 6, 5, vertex_map=pm.wavy(0.02))
+    else:
+        mesh = pm.prism_block(n, n, 6, vertex_map=vm) if kind == "prisms" else pm.hex_block(n, n, n, vertex_map=vm, renumber_seed=seed)
     kw = dict(n_non_orth=2, p_tol=1e-9, p_rel_tol=0.0, p_final_tol=1e-9, u_tol=1e-9, p_max_iter=5000)
     h, o = pair(product, oracle, mesh, 0.4 / n, 0.01, [0] * 6, lid(), [0] * 6, **kw)
     U0 = np.random.RandomState(3).rand(mesh["n_cells"], 3) * 0.05
@@ -136,13 +139,15 @@ def test_point_force_coupling_on_a_general_mesh(product):
     s.close()
 
 
-@pytest.mark.parametrize("kind", ["wavy", "prisms", "sheared_renumbered"])
+@pytest.mark.parametrize("kind", ["wavy", "prisms", "sheared_renumbered", "tetrahedra"])
 def test_multigrid_preconditioned_pcg_solves_the_same_equations(product, oracle, kind):
     """p_solver = FY_PSOLVER_PCG_MG (fvSolution: GAMG): the agglomeration V-cycle changes the path to the solution, not the solution -- with the linear
     systems converged to 1e-10 the fields equal the restatement's (which runs PCG with the diagonal preconditioner), in far fewer iterations"""
     n = 12
     if kind == "prisms":
         mesh = pm.prism_block(n, n, 8, vertex_map=pm.wavy(0.02))
+    elif kind == "tetrahedra":
+        mesh = pm.tet_block(7, 7, 6, vertex_map=pm.wavy(0.02))
     else:
         mesh = pm.hex_block(n, n, n, vertex_map=pm.wavy(0.03) if kind == "wavy" else pm.shear(0.3, 0.1, 0.2), renumber_seed=None if kind == "wavy" else 21)
     kw = dict(n_non_orth=1, p_tol=1e-10, p_rel_tol=0.0, p_final_tol=1e-10, u_tol=1e-10, p_max_iter=5000)
