@@ -487,6 +487,11 @@ typedef struct fy_ldu_case {
     double u_relax, u_relax_final, p_relax, p_relax_final;      /* relaxationFactors; <= 0: no entry (relax() does nothing) */
     int32_t adjust_time_step;        /* pimpleFoamYade only (pimpleFoamYade.C:62-64: readTimeControls.H, CourantNo.H, setDeltaT.H) */
     double max_co, max_delta_t;
+    /* continuousPhaseTurbulence (pimpleFoamYade only): FY_TURBULENCE_LAMINAR | FY_TURBULENCE_SMAGORINSKY (LES, delta cubeRootVol) as in fy_case_desc */
+    int32_t turbulence_model;
+    double les_ck, les_ce, les_delta_coeff, nut_initial;
+    const int32_t* nut_bc;           /* per patch: FY_BC_NUT_ZERO_GRADIENT | FY_BC_NUT_FIXED_VALUE (NULL: zeroGradient everywhere) */
+    const double* nut_value;         /* [n_patches] */
 } fy_ldu_case;
 typedef struct fy_ldu_solver fy_ldu_solver;
 void fy_ldu_case_defaults(fy_ldu_case*);        /* the icoFoam cavity tutorial's controls (as fy_case_defaults); the patch arrays stay NULL */

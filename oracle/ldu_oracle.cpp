@@ -46,6 +46,9 @@ extern "C" struct orc_ldu_case {
     int n_outer;
     double u_relax, u_relax_final, p_relax, p_relax_final;      // <= 0: no relaxationFactors entry
     int adjust_time_step; double max_co, max_delta_t;           // setDeltaT.H (pimpleFoamYade.C:62-64)
+    int turbulence_model;                                       // 0 laminar, 1 LES Smagorinsky (delta cubeRootVol)
+    double les_ck, les_ce, les_delta_coeff, nut_initial;
+    const int* nut_bc; const double* nut_value;                 // per patch: 0 zeroGradient, 1 fixedValue
 };
 extern "C" struct orc_ldu_stats {
     double courant_mean, courant_max, cont_sum_local, cont_global, cont_cumulative;
@@ -71,7 +74,8 @@ struct Ldu {
     vec diag, lower, upper, src, bint, bsrc;                 // momentum matrix: diag, off-diagonals per internal face, source [3 nc], boundary coefficients per boundary face (scalar) / [3]
     vec rAU, HbyA, phiHbyA, rAUf, pdiag, pcoef, pb, pcorr;   // pcoef per face (internal: rAUf |Sf| dcNO; boundary: the same with the patch's dcNO), pcorr: non-orth flux correction per internal face
     // pimpleFoamYade: the coupling's fields (set from outside between step_begin and step_end), the face fields of the alpha-weighted equations
-    vec alpha, uSourceDrag, uParticle, gradP, divT, ddtU, alphaf, phiForces, psn, recon, pPrev;
+    vec alpha, uSourceDrag, uParticle, gradP, divT, ddtU, alphaf, phiForces, psn, recon, pPrev, nut;
+    std::vector<int> nut_bc; vec nut_val;
     bool pimple = false;
     orc_ldu_stats st{};
     double cumulative = 0.0;
@@ -193,6 +197,11 @@ struct Ldu {
         if (pimple) {
             alpha.assign(nc, 1.0); uSourceDrag.assign(nc, 0.0); uParticle.assign(3 * nc, 0.0); gradP = uParticle; divT = uParticle; ddtU = uParticle;
             alphaf.assign(nFaces, 1.0); phiForces.assign(nFaces, 0.0); psn.assign(nFaces - nInt, 0.0); pPrev = p;
+            if (cs.turbulence_model == 1) {
+                nut.assign(nc, cs.nut_initial);
+                nut_bc.assign(nPatches, 0); nut_val.assign(nPatches, 0.0);
+                for (int pa = 0; pa < nPatches; ++pa) { if (cs.nut_bc) nut_bc[pa] = cs.nut_bc[pa]; if (cs.nut_value) nut_val[pa] = cs.nut_value[pa]; }
+            }
             // fvc::reconstruct's tensor per cell: inv(sum_f Sf Sf / |Sf|) [OF-6 fvcReconstruct.C]
             vec T(9 * nc, 0.0);
             for (int f = 0; f < nFaces; ++f) {
@@ -284,7 +293,7 @@ struct Ldu {
             for (int q = 0; q < 3; ++q) src[3 * c + q] += alpha[c] * V[c] / cs.dt * Uold[3 * c + q];
             const double* T = &vGradNow[9 * c];
             const double tr = T[0] + T[4] + T[8];
-            for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) G[9 * c + 3 * a + b] = alpha[c] * cs.nu * (T[3 * b + a] - (a == b ? (2.0 / 3.0) * tr : 0.0));
+            for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) G[9 * c + 3 * a + b] = alpha[c] * (cs.nu + (nut.empty() ? 0.0 : nut[c])) * (T[3 * b + a] - (a == b ? (2.0 / 3.0) * tr : 0.0));
         }
         auto stress = [&](int f, double* t) {                   // Sf . (alpha nu dev2(T(grad U)))_f, the cell tensor interpolated linearly (a boundary face: its cell's)
             const double sv[3] = {Sf[f].x, Sf[f].y, Sf[f].z};
@@ -297,7 +306,9 @@ struct Ldu {
             }
         };
         for (int f = 0; f < nInt; ++f) {
-            const double fl = alphaf[f] * phi[f], g = cs.nu * alphaf[f] * magSf[f];
+            const double fl = alphaf[f] * phi[f];
+            // - fvm::laplacian(alpha nuEff, U): the cell field alpha (nu + nut) interpolated linearly [OF-6 gaussLaplacianScheme::fvmLaplacian(vol gamma)]
+            const double g = (nut.empty() ? cs.nu * alphaf[f] : w[f] * alpha[own[f]] * (cs.nu + nut[own[f]]) + (1.0 - w[f]) * alpha[nei[f]] * (cs.nu + nut[nei[f]])) * magSf[f];
             double lo = -w[f] * fl, up = lo + fl;
             lo -= g * dcNO[f]; up -= g * dcNO[f];
             lower[f] = lo; upper[f] = up;
@@ -315,7 +326,8 @@ struct Ldu {
         }
         for (int f = nInt; f < nFaces; ++f) {
             const int b = f - nInt, pa = patch_of[b], c = own[f];
-            const double g = cs.nu * magSf[f] * dcNO[f];                 // (alphac's boundary value is 1)
+            const double nutb = nut.empty() ? 0.0 : (nut_bc[pa] == 1 ? nut_val[pa] : nut[c]);
+            const double g = (cs.nu + nutb) * magSf[f] * dcNO[f];        // (alphac's boundary value is 1)
             divAPhi[c] += phi[f];
             double t[3];
             stress(f, t);
@@ -453,6 +465,23 @@ struct Ldu {
                 st.u_iters_total += solve_momentum(minus);
             }
             for (int corr = 0; corr < cs.n_correctors; ++corr) corrector_pimple(final_outer && corr == cs.n_correctors - 1, p_relax_now);
+            if (!nut.empty() && final_outer) turbulence_correct();      // pimple.turbCorr(), pimpleFoamYade.C:101-104
+        }
+    }
+    // LESModel Smagorinsky [OF-6 Smagorinsky.C: k(gradU), correctNut()] with delta = deltaCoeff cbrt(V) (cubeRootVolDelta), as fv_oracle.cpp
+    void turbulence_correct() {
+        grad_vector(U, vGrad);
+        for (int c = 0; c < nCells; ++c) {
+            const double delta = cs.les_delta_coeff * std::cbrt(V[c]);
+            const double* T = &vGrad[9 * (size_t)c];
+            double D[3][3];
+            for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) D[a][b] = 0.5 * (T[3 * a + b] + T[3 * b + a]);
+            const double trD = D[0][0] + D[1][1] + D[2][2], a = cs.les_ce / delta, b = (2.0 / 3.0) * trD, third = (1.0 / 3.0) * trD;
+            const double dd = (D[0][0] - third) * D[0][0] + (D[1][1] - third) * D[1][1] + (D[2][2] - third) * D[2][2]
+                            + 2.0 * (D[0][1] * D[0][1]) + 2.0 * (D[0][2] * D[0][2]) + 2.0 * (D[1][2] * D[1][2]);
+            const double cc = 2.0 * cs.les_ck * delta * dd;
+            const double r = (-b + std::sqrt(b * b + 4.0 * a * cc)) / (2.0 * a);
+            nut[c] = cs.les_ck * delta * std::sqrt(r * r);
         }
     }
 
@@ -734,7 +763,7 @@ vec* ldu_field(Ldu* s, const std::string& n) {
     const struct { const char* nm; vec* v; } tab[] = {{"U", &s->U}, {"p", &s->p}, {"phi", &s->phi}, {"uSource", &s->uSource}, {"vGrad", &s->vGrad}, {"rAU", &s->rAU},
         {"HbyA", &s->HbyA}, {"p_diag", &s->pdiag}, {"p_coef", &s->pcoef}, {"p_rhs", &s->pb}, {"mom_diag", &s->diag}, {"mom_lower", &s->lower}, {"mom_upper", &s->upper},
         {"mom_src", &s->src}, {"phiHbyA", &s->phiHbyA}, {"alpha", &s->alpha}, {"uSourceDrag", &s->uSourceDrag}, {"gradP", &s->gradP}, {"divT", &s->divT}, {"ddtU", &s->ddtU},
-        {"phiForces", &s->phiForces}, {"rAUf", &s->rAUf}};
+        {"phiForces", &s->phiForces}, {"rAUf", &s->rAUf}, {"nut", &s->nut}};
     for (const auto& e : tab) if (n == e.nm) return e.v;
     return nullptr;
 }

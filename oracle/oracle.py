@@ -448,7 +448,8 @@ class LduCase(C.Structure):
                 ("p_final_rel_tol", C.c_double), ("p_max_iter", C.c_int), ("u_tol", C.c_double), ("u_rel_tol", C.c_double), ("u_max_iter", C.c_int),
                 ("u_bc", _ip), ("u_value", _dp), ("p_bc", _ip), ("p_value", _dp), ("g", C.c_double * 3), ("n_outer", C.c_int), ("u_relax", C.c_double),
                 ("u_relax_final", C.c_double), ("p_relax", C.c_double), ("p_relax_final", C.c_double), ("adjust_time_step", C.c_int), ("max_co", C.c_double),
-                ("max_delta_t", C.c_double)]
+                ("max_delta_t", C.c_double), ("turbulence_model", C.c_int), ("les_ck", C.c_double), ("les_ce", C.c_double), ("les_delta_coeff", C.c_double),
+                ("nut_initial", C.c_double), ("nut_bc", _ip), ("nut_value", _dp)]
 
 
 class LduStats(C.Structure):
@@ -486,7 +487,8 @@ class LduSolver:
     def __init__(self, mesh, dt, nu, u_bc, u_val, p_bc, p_val=None, n_correctors=2, n_non_orth=0, momentum_predictor=1, p_ref_cell=0, p_ref_value=0.0,
                  p_tol=1e-6, p_rel_tol=0.05, p_final_tol=1e-6, p_final_rel_tol=0.0, p_max_iter=5000, u_tol=1e-5, u_rel_tol=0.0, u_max_iter=1000,
                  rho_f=1000.0, rho_p=2650.0, solver=0, g=(0.0, 0.0, 0.0), n_outer=1, u_relax=0.0, u_relax_final=0.0, p_relax=0.0, p_relax_final=0.0,
-                 adjust_time_step=0, max_co=1.0, max_delta_t=1e300):
+                 adjust_time_step=0, max_co=1.0, max_delta_t=1e300, turbulence_model=0, les_ck=0.094, les_ce=1.048, les_delta_coeff=1.0, nut_initial=0.0,
+                 nut_bc=None, nut_val=None):
         """solver = 1: pimpleFoamYade -- step(source, alpha, drag) then takes the void fraction and the implicit drag coefficient the coupling would leave"""
         self.L = _ldu_lib()
         self.mesh = mesh
@@ -496,11 +498,14 @@ class LduSolver:
                           nei=np.ascontiguousarray(mesh["neighbour"], np.int32), ps=np.ascontiguousarray(mesh["patch_start"], np.int32),
                           pz=np.ascontiguousarray(mesh["patch_size"], np.int32), ub=np.ascontiguousarray(u_bc, np.int32),
                           uv=np.ascontiguousarray(u_val, np.float64).reshape(npatch, 3), pb=np.ascontiguousarray(p_bc, np.int32),
-                          pv=np.ascontiguousarray(p_val if p_val is not None else np.zeros(npatch), np.float64))
+                          pv=np.ascontiguousarray(p_val if p_val is not None else np.zeros(npatch), np.float64),
+                          nb=np.ascontiguousarray(nut_bc if nut_bc is not None else np.zeros(npatch), np.int32),
+                          nv=np.ascontiguousarray(nut_val if nut_val is not None else np.zeros(npatch), np.float64))
         k = self._keep
         self.case = LduCase(solver, dt, nu, rho_f, rho_p, n_correctors, n_non_orth, momentum_predictor, p_ref_cell, p_ref_value, p_tol, p_rel_tol, p_final_tol,
                             p_final_rel_tol, p_max_iter, u_tol, u_rel_tol, u_max_iter, _i(k["ub"]), _d(k["uv"]), _i(k["pb"]), _d(k["pv"]), (C.c_double * 3)(*g), n_outer,
-                            u_relax, u_relax_final, p_relax, p_relax_final, adjust_time_step, max_co, max_delta_t)
+                            u_relax, u_relax_final, p_relax, p_relax_final, adjust_time_step, max_co, max_delta_t, turbulence_model, les_ck, les_ce,
+                            les_delta_coeff, nut_initial, _i(k["nb"]), _d(k["nv"]))
         self.pimple = solver == 1
         self.nc, self.nf, self.ni = int(mesh["n_cells"]), len(k["own"]), len(k["nei"])
         self.h = self.L.orc_ldu_create(k["points"].shape[0], _d(k["points"]), self.nf, self.ni, _i(k["foff"]), _i(k["fpts"]), _i(k["own"]), _i(k["nei"]),

@@ -120,7 +120,7 @@ def general_bed(tmp_path, amp=0.15):
 
 def test_general_pimple_case_is_read(prod, tmp_path):
     """pimpleFoamYade's dictionaries on a general mesh: PIMPLE controls, gravity, the phase's names, fixedFluxPressure patches; what the general solver does not carry
-    (a turbulence model) is refused by name"""
+    (the transport-equation closures) is refused by name"""
     dst, mesh = general_bed(tmp_path)
     fc = prod.GeneralFoamCase(dst, prod.FY_SOLVER_PIMPLE)
     ref = prod.FoamCase(os.path.join(CASES, "bed_pimple"), prod.FY_SOLVER_PIMPLE)
@@ -133,11 +133,22 @@ def test_general_pimple_case_is_read(prod, tmp_path):
     assert fc.u_bc == [prod.FY_BC_U_FIXED_VALUE, prod.FY_BC_U_ZERO_GRADIENT, prod.FY_BC_U_FIXED_VALUE]
     np.testing.assert_array_equal(fc.u_value, [[0, 0, 0.02], [0, 0, 0], [0, 0, 0]])
     fc.close(); ref.close()
-    (dst / "constant/turbulenceProperties.water").write_text("FoamFile { version 2.0; format ascii; class dictionary; object turbulenceProperties.water; }\nsimulationType LES;\n"
-                                                             "LES { LESModel Smagorinsky; delta cubeRootVol; turbulence on; }\n")
-    (dst / "0/nut.water").write_text((dst / "0/p").read_text().replace("object      p;", "object nut.water;").replace("fixedFluxPressure; value uniform 0;", "zeroGradient;").replace("fixedValue; value uniform 0;", "zeroGradient;"))
-    with pytest.raises(prod.FoamYadeError, match="laminar"):
+    tp = "FoamFile { version 2.0; format ascii; class dictionary; object turbulenceProperties.water; }\nsimulationType LES;\nLES { LESModel %s; delta cubeRootVol; turbulence on; cubeRootVolCoeffs { deltaCoeff 0.9; } }\n"
+    (dst / "constant/turbulenceProperties.water").write_text(tp % "Smagorinsky")
+    (dst / "0/nut.water").write_text((dst / "0/p").read_text().replace("object      p;", "object nut.water;").replace("[0 2 -2 0 0 0 0]", "[0 2 -1 0 0 0 0]").replace("internalField   uniform 0;", "internalField   uniform 2e-6;")
+                                     .replace("bottom { type fixedFluxPressure; value uniform 0; }", "bottom { type fixedValue; value uniform 1e-6; }").replace("fixedFluxPressure; value uniform 0;", "zeroGradient;")
+                                     .replace("top    { type fixedValue; value uniform 0; }", "top    { type calculated; value uniform 3e-6; }"))
+    fc = prod.GeneralFoamCase(dst, prod.FY_SOLVER_PIMPLE)             # LES Smagorinsky is carried: coefficients, delta, nut's file and patches
+    lc = fc.ldu_case
+    assert (lc.turbulence_model, lc.les_delta_coeff, lc.nut_initial) == (prod.TURBULENCE_SMAGORINSKY, 0.9, 2e-6)
+    assert [lc.nut_bc[q] for q in range(3)] == [1, 1, 0] and [lc.nut_value[q] for q in range(3)] == [1e-6, 3e-6, 0.0]
+    np.testing.assert_array_equal(fc.initial_nut(), 2e-6)
+    fc.close()
+    (dst / "constant/turbulenceProperties.water").write_text(tp % "kEqn")
+    (dst / "0/k.water").write_text((dst / "0/nut.water").read_text().replace("nut.water", "k.water"))
+    with pytest.raises(prod.FoamYadeError, match="kEqn / kEpsilon"):
         prod.GeneralFoamCase(dst, prod.FY_SOLVER_PIMPLE)
+    os.remove(dst / "0/k.water"); os.remove(dst / "0/nut.water")
     os.remove(dst / "constant/turbulenceProperties.water")
     cd = (dst / "system/controlDict").read_text()
     (dst / "system/controlDict").write_text(cd.replace("adjustTimeStep  no;", "adjustTimeStep  yes;\nmaxCo 0.5;\nmaxDeltaT 0.001;").replace("writeControl    adjustableRunTime;", "writeControl    timeStep;").replace("writeInterval   0.001;", "writeInterval   5;"))
@@ -173,6 +184,28 @@ def test_foamYadeHip_executable_runs_a_general_pimple_case(prod, tmp_path):
     np.testing.assert_allclose(U1, U, rtol=0, atol=1e-12 * np.abs(U).max())
     assert np.abs(U[:, 2]).max() > 0.01                              # the inflow has arrived
     fc.close()
+
+
+@pytest.mark.gpu
+def test_general_les_case_runs_and_writes_nut(prod, tmp_path):
+    """LES Smagorinsky on the wavy bed from its case directory: nut.<phase> of the start time is read, renewed by the model after the last outer corrector, and written with
+    the file's own patch entries"""
+    dst, mesh = general_bed(tmp_path)
+    (dst / "constant/turbulenceProperties.water").write_text("FoamFile { version 2.0; format ascii; class dictionary; object turbulenceProperties.water; }\nsimulationType LES;\n"
+                                                             "LES { LESModel Smagorinsky; delta cubeRootVol; turbulence on; }\n")
+    (dst / "0/nut.water").write_text((dst / "0/p").read_text().replace("object      p;", "object nut.water;").replace("[0 2 -2 0 0 0 0]", "[0 2 -1 0 0 0 0]").replace("internalField   uniform 0;", "internalField   uniform 2e-6;")
+                                     .replace("fixedFluxPressure; value uniform 0;", "zeroGradient;").replace("top    { type fixedValue; value uniform 0; }", "top    { type calculated; value uniform 3e-6; }"))
+    fc = prod.GeneralFoamCase(dst, prod.FY_SOLVER_PIMPLE)
+    s = prod.LduSolver.from_foam_case(fc)
+    np.testing.assert_array_equal(s.get("nut"), 2e-6)
+    for _ in range(5):
+        s.step()
+    nut = s.get("nut")
+    assert nut.max() > 0 and not np.allclose(nut, 2e-6) and np.isfinite(nut).all()
+    fc.write(s, "0.001")
+    t = (dst / "0.001/nut.water").read_text()
+    assert "calculated" in t and "uniform 3e-06" in t.replace("3e-6", "3e-06") and "nonuniform List<scalar>" in t
+    s.close(); fc.close()
 
 
 @pytest.mark.gpu

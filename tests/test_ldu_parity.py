@@ -197,8 +197,8 @@ def bed_particles(rs, npart, box, dx):
     return rec
 
 
-@pytest.mark.parametrize("n_outer,relax,adjust", [(1, 0.0, 0), (2, 0.7, 0), (1, 0.0, 1)])
-def test_pimple_on_a_lattice_equals_the_structured_hip_solver(product, n_outer, relax, adjust):
+@pytest.mark.parametrize("n_outer,relax,adjust,les", [(1, 0.0, 0, 0), (2, 0.7, 0, 0), (1, 0.0, 1, 0), (2, 0.0, 0, 1)])
+def test_pimple_on_a_lattice_equals_the_structured_hip_solver(product, n_outer, relax, adjust, les):
     """pimpleFoamYade's equations (void-fraction-weighted UcEqn / pEqn, gravity, fixedFluxPressure walls, PIMPLE outer correctors, relaxation) through both HIP
     solvers: fy_solver on the block with particles, and fy_ldu_solver on the block written as a polyhedral mesh, fed the void fraction and the momentum sources the
     first one's coupling produced (the two k-d trees differ where a lattice's centres tie, so a cloud does not take the same improvement chains in both: the
@@ -209,6 +209,8 @@ def test_pimple_on_a_lattice_equals_the_structured_hip_solver(product, n_outer, 
     kw = dict(p_tol=1e-11, p_rel_tol=0.0, p_final_tol=1e-11, u_tol=1e-11)
     rel = dict(u_relax=relax, u_relax_final=1.0 if relax else 0.0, p_relax=0.6 if relax else 0.0, p_relax_final=1.0 if relax else 0.0,
                adjust_time_step=adjust, max_co=0.4, max_delta_t=3.2e-4)          # (setDeltaT.H: the step grows by 1.2 per step while the Courant number allows)
+    if les:                                              # LES Smagorinsky
+        rel.update(turbulence_model=1, nut_initial=3e-5, les_delta_coeff=0.8)
     case = product.make_case(1, n, n, n, dx, 2e-4, 1e-5, g=(0, 0, -9.81), p_bc=[2] * 6, p_solver=0, n_outer_correctors=n_outer, n_correctors=2, p_max_iter=5000, **rel, **kw)
     f = product.Solver(case)
     f.hold_sources(True)
@@ -226,6 +228,9 @@ def test_pimple_on_a_lattice_equals_the_structured_hip_solver(product, n_outer, 
     pf, ph = f.get("p"), h.get("p")
     close(ph - ph.mean(), pf - pf.mean(), 1e-6, "p")
     assert np.abs(f.get("U")).max() > 1e-4
+    if les:
+        close(h.get("nut"), f.get("nut"), 1e-6, "nut")
+        assert not np.allclose(f.get("nut"), 3e-5)
     f.close(); h.close()
 
 
@@ -255,7 +260,7 @@ def test_pimple_with_particles_on_a_wavy_mesh_conserves_what_it_should(product):
     h.close()
 
 
-@pytest.mark.parametrize("kind", ["wavy_renumbered", "prisms"])
+@pytest.mark.parametrize("kind", ["wavy_renumbered", "prisms", "wavy_les"])
 def test_pimple_with_a_cloud_matches_the_restatement(product, oracle, kind):
     """pimpleFoamYade on non-orthogonal meshes, HIP against the CPU restatement: the HIP solver runs the coupled step with its cloud; the restatement is given the
     void fraction, the drag coefficient and the explicit source that coupling left and solves the same equations.  Compared: the coupling's input fields
@@ -268,6 +273,8 @@ def test_pimple_with_a_cloud_matches_the_restatement(product, oracle, kind):
         mesh = pm.hex_block(n, n, n, (box, box, box), pm.wavy(0.2 * dx, (box, box, box)), renumber_seed=8)
     npatch = 6
     kw = dict(p_tol=1e-10, p_rel_tol=0.0, p_final_tol=1e-10, u_tol=1e-10, p_max_iter=5000)
+    if kind == "wavy_les":                                # LES Smagorinsky on skewed cells (delta from each cell's volume), one patch with a fixed nut
+        kw.update(turbulence_model=1, nut_initial=2e-5, les_delta_coeff=1.0, nut_bc=[0, 0, 0, 1, 0, 0], nut_val=[0, 0, 0, 4e-5, 0, 0])
     rel = dict(u_relax=0.8, u_relax_final=1.0, p_relax=0.7, p_relax_final=1.0)
     lidv = [(0, 0, 0)] * npatch
     lidv[3] = (0.05, 0, 0)                                # a moving wall too, so that the velocity gradients are not the cloud's alone
@@ -288,5 +295,7 @@ def test_pimple_with_a_cloud_matches_the_restatement(product, oracle, kind):
     ph, po = h.get("p"), o.get("p")
     close(ph - ph.mean(), po - po.mean(), 1e-5, "p")
     close(h.get("phi"), o.get("phi"), 1e-5, "phi")
+    if kind == "wavy_les":
+        close(h.get("nut"), o.get("nut"), 1e-6, "nut")
     assert np.abs(h.get("ddtU")).max() > 0 and np.abs(h.get("divT")).max() > 0
     h.close(); o.close()

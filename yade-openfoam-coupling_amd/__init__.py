@@ -88,7 +88,9 @@ class LduCase(C.Structure):
                 ("p_tol", C.c_double), ("p_rel_tol", C.c_double), ("p_final_tol", C.c_double), ("p_final_rel_tol", C.c_double), ("p_max_iter", C.c_int32),
                 ("u_tol", C.c_double), ("u_rel_tol", C.c_double), ("u_max_iter", C.c_int32), ("p_solver", C.c_int32), ("u_bc", _ip), ("u_value", _dp), ("p_bc", _ip),
                 ("p_value", _dp), ("solver", C.c_int32), ("n_outer_correctors", C.c_int32), ("g", C.c_double * 3), ("u_relax", C.c_double), ("u_relax_final", C.c_double),
-                ("p_relax", C.c_double), ("p_relax_final", C.c_double), ("adjust_time_step", C.c_int32), ("max_co", C.c_double), ("max_delta_t", C.c_double)]
+                ("p_relax", C.c_double), ("p_relax_final", C.c_double), ("adjust_time_step", C.c_int32), ("max_co", C.c_double), ("max_delta_t", C.c_double),
+                ("turbulence_model", C.c_int32), ("les_ck", C.c_double), ("les_ce", C.c_double), ("les_delta_coeff", C.c_double), ("nut_initial", C.c_double), ("nut_bc", _ip),
+                ("nut_value", _dp)]
 
 
 class ParticleTimings(C.Structure):
@@ -1058,7 +1060,7 @@ class LduSolver:
         L.fy_ldu_solver_read_field_host.argtypes = [C.c_void_p, C.c_char_p, _dp]
         L.fy_ldu_solver_write_field_host.argtypes = [C.c_void_p, C.c_char_p, _dp]
 
-    def __init__(self, mesh, dt, nu, u_bc, u_val, p_bc, p_val=None, device=0, transport=None, **controls):
+    def __init__(self, mesh, dt, nu, u_bc, u_val, p_bc, p_val=None, device=0, transport=None, nut_bc=None, nut_val=None, **controls):
         L = lib()
         self._bind()
         npatch = len(mesh["patch_start"])
@@ -1081,6 +1083,9 @@ class LduSolver:
             else:
                 setattr(self.case, names.get(key, key), v)
         self.case.u_bc, self.case.u_value, self.case.p_bc, self.case.p_value = _i(k["ub"]), _d(k["uv"]), _i(k["pb"]), _d(k["pv"])
+        if nut_bc is not None:
+            k["nb"], k["nv"] = i32(nut_bc), np.ascontiguousarray(nut_val if nut_val is not None else np.zeros(npatch), np.float64)
+            self.case.nut_bc, self.case.nut_value = _i(k["nb"]), _d(k["nv"])
         self._create(device, transport)
 
     def _create(self, device, transport):
@@ -1102,6 +1107,8 @@ class LduSolver:
         self._create(device, transport)
         U, p = fc.initial_fields()
         self.set("U", U); self.set("p", p)
+        if fc.ldu_case.turbulence_model != 0:
+            self.set("nut", fc.initial_nut())
         return self
 
     def _size(self, name):

@@ -59,8 +59,9 @@ struct fy_foam_case {
     int g_cells = 0, g_internal = 0;
     std::vector<double> g_points;
     std::vector<int32_t> g_face_off, g_face_pts, g_own, g_nei, g_patch_start, g_patch_size, g_u_bc, g_p_bc;
-    std::vector<std::string> g_patch_name, g_u_text, g_p_text;
-    std::vector<double> g_u_val, g_p_val;
+    std::vector<std::string> g_patch_name, g_u_text, g_p_text, g_nut_text;
+    std::vector<double> g_u_val, g_p_val, g_nut_val;
+    std::vector<int32_t> g_nut_bc;
 };
 
 namespace {
@@ -771,6 +772,30 @@ int read_general_fields(fy_foam_case* c) {
             }
         }
     }
+    if (c->desc.turbulence_model != FY_TURBULENCE_LAMINAR) {
+        // nut.<phase> [OF-6 eddyViscosity: MUST_READ]: patches zeroGradient | fixedValue (uniform) | calculated with a uniform value (= keeps its value: fixedValue here)
+        const std::string path = join(c->fdir, c->start_name + "/nut." + c->phase);
+        FoamDict f;
+        FY_TRY(need_file(path, &f));
+        FY_TRY(read_internal(f, path, 1, ncell, &c->nut0));
+        c->desc.nut_initial = c->nut0.empty() ? 0.0 : c->nut0[0];
+        const FoamDict* bf = f.subdict("boundaryField");
+        if (!bf) return fail(FY_ERR_INVALID, "%s: no boundaryField", path.c_str());
+        c->g_nut_bc.assign(np, FY_BC_NUT_ZERO_GRADIENT); c->g_nut_val.assign(np, 0.0); c->g_nut_text.assign(np, std::string());
+        for (size_t pa = 0; pa < np; ++pa) {
+            const char* pn = c->g_patch_name[pa].c_str();
+            const FoamDict* pd = bf->subdict(c->g_patch_name[pa]);
+            std::string ty;
+            if (!pd || !pd->word("type", &ty)) return fail(FY_ERR_INVALID, "%s: boundaryField has no (typed) entry for patch '%s'", path.c_str(), pn);
+            c->g_nut_text[pa] = entry_text(*pd);
+            const auto* vt = pd->tokens("value");
+            if (ty == "fixedValue" || ty == "calculated") {
+                c->g_nut_bc[pa] = FY_BC_NUT_FIXED_VALUE;
+                if (!vt || vt->size() < 2 || (*vt)[0] != "uniform" || !fy::foam_tok_is_number((*vt)[1], &c->g_nut_val[pa]))
+                    return fail(FY_ERR_UNSUPPORTED, "%s: patch '%s': %s needs 'value uniform <nut>'", path.c_str(), pn, ty.c_str());
+            } else if (ty != "zeroGradient") return fail(FY_ERR_UNSUPPORTED, "%s: patch '%s': nut boundary type '%s' is not supported on a general mesh (zeroGradient, fixedValue, calculated)", path.c_str(), pn, ty.c_str());
+        }
+    }
     return FY_OK;
 }
 
@@ -781,7 +806,8 @@ int check_general_schemes(const fy_foam_case* c) {
     FoamDict d;
     FY_TRY(need_file(path, &d));
     if (c->desc.convection_scheme != FY_CONVECTION_LINEAR) return fail(FY_ERR_UNSUPPORTED, "%s: on a general mesh the convection term must be Gauss linear", path.c_str());
-    if (c->desc.turbulence_model != FY_TURBULENCE_LAMINAR) return fail(FY_ERR_UNSUPPORTED, "%s: on a general mesh only the laminar (Stokes) model is carried (constant/turbulenceProperties)", c->dir.c_str());
+    if (c->desc.turbulence_model != FY_TURBULENCE_LAMINAR && c->desc.turbulence_model != FY_TURBULENCE_SMAGORINSKY)
+        return fail(FY_ERR_UNSUPPORTED, "%s: on a general mesh the laminar (Stokes) model and LES Smagorinsky are carried, not kEqn / kEpsilon (constant/turbulenceProperties)", c->dir.c_str());
     for (const char* dn : {"laplacianSchemes", "snGradSchemes"}) {
         const FoamDict* sd = d.subdict(dn);
         for (const std::string& k : sd->order) {
@@ -1102,7 +1128,7 @@ int write_field(const fy_foam_case* c, const std::string& tdir, const std::strin
     }
     std::fprintf(f, ")\n;\n\nboundaryField\n{\n");
     if (c->general) {
-        const std::vector<std::string>& tx = ncomp == 3 ? c->g_u_text : c->g_p_text;
+        const std::vector<std::string>& tx = bc_text == c->u_bc_text ? c->g_u_text : (bc_text == c->nut_bc_text ? c->g_nut_text : c->g_p_text);
         for (size_t pa = 0; pa < c->g_patch_name.size(); ++pa) std::fprintf(f, "    %s\n    {\n%s    }\n", c->g_patch_name[pa].c_str(), (!bc_text || tx[pa].empty()) ? default_bc : tx[pa].c_str());
     }
     for (const std::string& pn : c->general ? std::vector<std::string>() : c->patch_order) {
@@ -1332,6 +1358,8 @@ int fy_foam_case_ldu_desc(const fy_foam_case* c, fy_ldu_case* out) {
     for (int a = 0; a < 3; ++a) out->g[a] = d.g[a];
     out->u_relax = d.u_relax; out->u_relax_final = d.u_relax_final; out->p_relax = d.p_relax; out->p_relax_final = d.p_relax_final;
     out->adjust_time_step = d.adjust_time_step; out->max_co = d.max_co; out->max_delta_t = d.max_delta_t;
+    out->turbulence_model = d.turbulence_model; out->les_ck = d.les_ck; out->les_ce = d.les_ce; out->les_delta_coeff = d.les_delta_coeff; out->nut_initial = d.nut_initial;
+    out->nut_bc = c->g_nut_bc.empty() ? nullptr : c->g_nut_bc.data(); out->nut_value = c->g_nut_val.empty() ? nullptr : c->g_nut_val.data();
     out->u_bc = c->g_u_bc.data(); out->u_value = c->g_u_val.data(); out->p_bc = c->g_p_bc.data(); out->p_value = c->g_p_val.data();
     return FY_OK;
 }
@@ -1353,8 +1381,10 @@ int fy_foam_case_write_time_ldu(const fy_foam_case* c, fy_ldu_solver* s, const c
     std::vector<double> U(3 * c->fcells), p(c->fcells), a;
     FY_TRY(fy_ldu_solver_read_field_host(s, "U", U.data()));
     FY_TRY(fy_ldu_solver_read_field_host(s, "p", p.data()));
+    std::vector<double> nt;
     if (c->solver == FY_SOLVER_PIMPLE) { a.resize(c->fcells); FY_TRY(fy_ldu_solver_read_field_host(s, "alpha", a.data())); }       // (with fy_ldu_solver_hold_sources: before setSourceZero)
-    return fy_foam_case_write_fields(c, time_name, U.data(), p.data(), a.empty() ? nullptr : a.data(), nullptr, nullptr, nullptr);
+    if (c->desc.turbulence_model != FY_TURBULENCE_LAMINAR) { nt.resize(c->fcells); FY_TRY(fy_ldu_solver_read_field_host(s, "nut", nt.data())); }
+    return fy_foam_case_write_fields(c, time_name, U.data(), p.data(), a.empty() ? nullptr : a.data(), nt.empty() ? nullptr : nt.data(), nullptr, nullptr);
 }
 
 int fy_foam_case_close(fy_foam_case* c) {

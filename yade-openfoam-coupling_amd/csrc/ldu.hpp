@@ -46,7 +46,13 @@ struct LduGeo {
 // momentum matrix in LDU form: diag [nc] (boundary diagonal included), lower / upper per internal face, b [3 nc] (boundary sources included)
 struct LduMom { double *diag, *lower, *upper, *b; };
 // pimpleFoamYade's extra fields: the void fraction (cells, old time, faces), the coupling's implicit and explicit momentum sources, gravity
-struct LduPim { const double *alpha, *alphaOld, *alphaf, *uSourceDrag, *uSource; double g[3]; };
+struct LduPim {
+    const double *alpha, *alphaOld, *alphaf, *uSourceDrag, *uSource;
+    double g[3];
+    const double* nut;               // LES: the eddy viscosity per cell (null: laminar), its patch conditions
+    const int32_t* nut_bc;
+    const double* nut_val;
+};
 
 int ldu_red_blocks(int n);      // partials per slot of the reducing kernels (= red_blocks(n) of fv_kernels.hpp: the folds are shared)
 
@@ -75,6 +81,7 @@ int launch_ldu_alphaf(hipStream_t s, LduGeo g, const double* alpha, double* alph
 int launch_ldu_pre_coupling(hipStream_t s, LduGeo g, const double* phi, const double* U, const double* vGrad, const double* alphaf, double* ddtU, double* divT);
 int launch_ldu_assemble_momentum_pimple(hipStream_t s, LduGeo g, LduPim P, const double* phi, const double* Uold, const double* U, const double* gradU, LduMom M, double* face_corr,
                                         double* fstress /* [3 nF] */, double u_relax, double* rAU);
+int launch_ldu_smagorinsky_nut(hipStream_t s, LduGeo g, const double* vGrad, double ck, double ce, double delta_coeff, double* nut);
 int launch_ldu_forces(hipStream_t s, LduGeo g, LduPim P, const double* rAU, double* rAUf, double* phiForces);
 int launch_ldu_ssf_predictor(hipStream_t s, LduGeo g, const double* phiForces, const double* rAUf, const double* p, const double* gradp, double* ssf);
 int launch_ldu_reconstruct(hipStream_t s, LduGeo g, const double* ssf, const double* base, const double* scale, double* out);

@@ -419,7 +419,14 @@ __global__ __launch_bounds__(256) void k_ldu_pre_coupling(LduGeo g, const double
 
 // UcEqn.H:3-10, face part: fvm::div(alphaPhic, Uc) and - fvm::laplacian(alpha nu, Uc) as lower / upper, the corrected laplacian's explicit flux, and the flux
 // of the explicit stress Sf . (alpha nu dev2(T(grad U)))_f (the cell tensor interpolated linearly; a boundary face takes its cell's)
-__global__ __launch_bounds__(256) void k_ldu_pmom_faces(LduGeo g, const double* __restrict__ phi, const double* __restrict__ alpha, const double* __restrict__ alphaf,
+// nut != null (LES Smagorinsky, DPMTurbulenceModels.C:73-74): nuEff = nu + nut in both parts of divDevRhoReff -- the face diffusivity is the linear interpolate of the CELL
+// field alpha (nu + nut) [OF-6 gaussLaplacianScheme::fvmLaplacian(vol gamma)]; on the boundary alpha_b (nu + nut_b), nut_b by the patch of 0/nut (ldu_nut_b)
+__device__ __forceinline__ double ldu_nut_b(const LduGeo& g, const LduPim& P, int f) {
+    if (!P.nut) return 0.0;
+    const int pa = g.patch_of[f - g.nInt];
+    return P.nut_bc[pa] == FY_BC_NUT_FIXED_VALUE ? P.nut_val[pa] : P.nut[g.own[f]];
+}
+__global__ __launch_bounds__(256) void k_ldu_pmom_faces(LduGeo g, LduPim P, const double* __restrict__ phi, const double* __restrict__ alpha, const double* __restrict__ alphaf,
                                                         const double* __restrict__ gradU, LduMom M, double* __restrict__ corr, double* __restrict__ fstress) {
     const int f = blockIdx.x * 256 + threadIdx.x;
     if (f >= g.nFaces) return;
@@ -427,7 +434,7 @@ __global__ __launch_bounds__(256) void k_ldu_pmom_faces(LduGeo g, const double* 
     const double ss[3] = {S.x, S.y, S.z};
     const int o = g.own[f];
     const double* To = gradU + 9 * (size_t)o;
-    const double tro = To[0] + To[4] + To[8], ao = alpha[o] * g.nu;
+    const double tro = To[0] + To[4] + To[8], ao = alpha[o] * (g.nu + (P.nut ? P.nut[o] : 0.0));
     if (f >= g.nInt) {
 #pragma unroll
         for (int b = 0; b < 3; ++b) {
@@ -440,8 +447,8 @@ __global__ __launch_bounds__(256) void k_ldu_pmom_faces(LduGeo g, const double* 
     }
     const int n = g.nei[f];
     const double* Tn = gradU + 9 * (size_t)n;
-    const double trn = Tn[0] + Tn[4] + Tn[8], an = alpha[n] * g.nu, w = g.w[f];
-    const double af = alphaf[f], fl = af * phi[f], gm = g.nu * af * g.magSf[f];
+    const double trn = Tn[0] + Tn[4] + Tn[8], an = alpha[n] * (g.nu + (P.nut ? P.nut[n] : 0.0)), w = g.w[f];
+    const double af = alphaf[f], fl = af * phi[f], gm = (P.nut ? w * ao + (1.0 - w) * an : g.nu * af) * g.magSf[f];
     double lo = -w * fl;
     double up = lo + fl;
     lo -= gm * g.dcNO[f]; up -= gm * g.dcNO[f];
@@ -463,7 +470,7 @@ __global__ __launch_bounds__(256) void k_ldu_pmom_faces(LduGeo g, const double* 
 }
 // ... cell part: fvm::ddt(alphac, Uc), negSumDiag, the patches, - fvm::Sp(fvc::ddt(alphac) + fvc::div(alphaPhic)), == fvm::Sp(uSourceDrag), the explicit fluxes'
 // divergences on the right-hand side, UcEqn.relax() [OF-6 fvMatrix::relax: D = max(|D|, sum |offdiag|) / factor, source += (D_new - D) psi; no factor: nothing]
-__global__ __launch_bounds__(256) void k_ldu_pmom_cells(LduGeo g, const double* __restrict__ phi, const double* __restrict__ alpha, const double* __restrict__ alphaOld,
+__global__ __launch_bounds__(256) void k_ldu_pmom_cells(LduGeo g, LduPim P, const double* __restrict__ phi, const double* __restrict__ alpha, const double* __restrict__ alphaOld,
                                                         const double* __restrict__ alphaf, const double* __restrict__ Uold, const double* __restrict__ U,
                                                         const double* __restrict__ uSourceDrag, LduMom M, const double* __restrict__ corr, const double* __restrict__ fstress,
                                                         double u_relax, double* __restrict__ rAU) {
@@ -486,7 +493,7 @@ __global__ __launch_bounds__(256) void k_ldu_pmom_cells(LduGeo g, const double* 
             divAPhi += phi[f];
             b[0] += st.x; b[1] += st.y; b[2] += st.z;
             if (g.u_bc[pa] == FY_BC_U_FIXED_VALUE) {
-                const double gm = g.nu * g.magSf[f] * g.dcNO[f];
+                const double gm = (g.nu + ldu_nut_b(g, P, f)) * g.magSf[f] * g.dcNO[f];
                 const D3 ub = ld3(g.u_val, pa);
                 dg += gm;
                 b[0] += (-phi[f] + gm) * ub.x; b[1] += (-phi[f] + gm) * ub.y; b[2] += (-phi[f] + gm) * ub.z;
@@ -507,6 +514,24 @@ __global__ __launch_bounds__(256) void k_ldu_pmom_cells(LduGeo g, const double* 
     M.diag[c] = dg;
     st3(M.b, c, D3{b[0], b[1], b[2]});
     rAU[c] = 1.0 / (dg / Vc);
+}
+
+// continuousPhaseTurbulence->correct() (pimpleFoamYade.C:101-104) for LESModel Smagorinsky [OF-6 Smagorinsky.C: k(gradU), correctNut()], as fv_kernels.hip's
+// k_smagorinsky_nut: D = symm(grad U); a = Ce / delta; b = 2/3 tr D; c = 2 Ck delta (dev D && D); k = sqr((-b + sqrt(b^2 + 4 a c)) / 2a); nut = Ck delta sqrt(k);
+// delta = deltaCoeff cbrt(V) per cell (cubeRootVolDelta)
+__global__ __launch_bounds__(256) void k_ldu_smagorinsky_nut(LduGeo g, const double* __restrict__ vGrad, double ck, double ce, double delta_coeff, double* __restrict__ nut) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= g.nCells) return;
+    const double delta = delta_coeff * cbrt(g.V[c]);
+    const double* T = vGrad + 9 * (size_t)c;
+    const double Dxx = T[0], Dyy = T[4], Dzz = T[8];
+    const double Dxy = 0.5 * (T[1] + T[3]), Dxz = 0.5 * (T[2] + T[6]), Dyz = 0.5 * (T[5] + T[7]);
+    const double trD = Dxx + Dyy + Dzz;
+    const double a = ce / delta, b = (2.0 / 3.0) * trD, third = (1.0 / 3.0) * trD;
+    const double dd = (Dxx - third) * Dxx + (Dyy - third) * Dyy + (Dzz - third) * Dzz + 2.0 * (Dxy * Dxy) + 2.0 * (Dxz * Dxz) + 2.0 * (Dyz * Dyz);
+    const double cc = 2.0 * ck * delta * dd;
+    const double r = (-b + sqrt(b * b + 4.0 * a * cc)) / (2.0 * a);
+    nut[c] = ck * delta * sqrt(r * r);
 }
 
 // rAUcf = interpolate(rAUc) (boundary: the cell's), phicForces = fvc::flux(rAUc uSource) + rAUcf (g & Sf) (UcEqn.H:15-20)
@@ -758,8 +783,13 @@ int launch_ldu_pre_coupling(hipStream_t s, LduGeo g, const double* phi, const do
 }
 int launch_ldu_assemble_momentum_pimple(hipStream_t s, LduGeo g, LduPim P, const double* phi, const double* Uold, const double* U, const double* gradU, LduMom M, double* face_corr,
                                         double* fstress, double u_relax, double* rAU) {
-    hipLaunchKernelGGL(k_ldu_pmom_faces, dim3(div_up(g.nFaces, 256)), dim3(256), 0, s, g, phi, P.alpha, P.alphaf, gradU, M, face_corr, fstress);
-    hipLaunchKernelGGL(k_ldu_pmom_cells, dim3(div_up(g.nCells, 256)), dim3(256), 0, s, g, phi, P.alpha, P.alphaOld, P.alphaf, Uold, U, P.uSourceDrag, M, face_corr, fstress, u_relax, rAU);
+    hipLaunchKernelGGL(k_ldu_pmom_faces, dim3(div_up(g.nFaces, 256)), dim3(256), 0, s, g, P, phi, P.alpha, P.alphaf, gradU, M, face_corr, fstress);
+    hipLaunchKernelGGL(k_ldu_pmom_cells, dim3(div_up(g.nCells, 256)), dim3(256), 0, s, g, P, phi, P.alpha, P.alphaOld, P.alphaf, Uold, U, P.uSourceDrag, M, face_corr, fstress, u_relax, rAU);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+int launch_ldu_smagorinsky_nut(hipStream_t s, LduGeo g, const double* vGrad, double ck, double ce, double delta_coeff, double* nut) {
+    hipLaunchKernelGGL(k_ldu_smagorinsky_nut, dim3(div_up(g.nCells, 256)), dim3(256), 0, s, g, vGrad, ck, ce, delta_coeff, nut);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }

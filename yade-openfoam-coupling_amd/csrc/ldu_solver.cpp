@@ -34,7 +34,10 @@ struct LduSolver {
     // pimpleFoamYade: the coupling's fields and the alpha-weighted equations' face fields
     bool pimple = false, hold_sources = false, sources_pending = false;
     DevBuf<double> alpha, alphaf, uSourceDrag, uParticle, gradP, divT, ddtU, fstress, phiForces, psn, arAUf, phiA, ssf, bmom, pPrev;
-    LduPim P() const { return LduPim{alpha.p, alpha.p, alphaf.p, uSourceDrag.p, uSource.p, {cs.g[0], cs.g[1], cs.g[2]}}; }      // alphac.oldTime() == alphac
+    DevBuf<double> nut, d_nutval;
+    DevBuf<int32_t> d_nutbc;
+    bool les = false;
+    LduPim P() const { return LduPim{alpha.p, alpha.p, alphaf.p, uSourceDrag.p, uSource.p, {cs.g[0], cs.g[1], cs.g[2]}, les ? nut.p : nullptr, d_nutbc.p, d_nutval.p}; }      // alphac.oldTime() == alphac
     DevBuf<int> adj_err;
     bool need_ref = true, ext_source = false;
     LduAmg amg;                  // the pressure matrix in ELL form; with p_solver = FY_PSOLVER_PCG_MG also the agglomeration hierarchy
@@ -67,6 +70,10 @@ struct LduSolver {
         if (pimple && c->n_outer_correctors < 1) cs.n_outer_correctors = 1;
         if (c->adjust_time_step && !pimple) cs.adjust_time_step = 0;                      // (icoFoamYade's loop never includes setDeltaT.H: icoFoamYade.C:65-70)
         if (cs.adjust_time_step && !(c->max_co > 0 && c->max_delta_t > 0)) return fail(FY_ERR_INVALID, "fy_ldu_solver: adjustTimeStep needs maxCo > 0 and maxDeltaT > 0");
+        if (c->turbulence_model != FY_TURBULENCE_LAMINAR && !(pimple && c->turbulence_model == FY_TURBULENCE_SMAGORINSKY))
+            return fail(FY_ERR_UNSUPPORTED, "fy_ldu_solver: turbulence model %d (laminar; LES Smagorinsky with pimpleFoamYade)", c->turbulence_model);
+        les = pimple && c->turbulence_model == FY_TURBULENCE_SMAGORINSKY;
+        if (les && !(c->les_ck > 0 && c->les_ce > 0 && c->les_delta_coeff > 0)) return fail(FY_ERR_INVALID, "fy_ldu_solver: Smagorinsky needs Ck, Ce and the delta coefficient positive");
         nc = hm.nCells; nf = hm.nFaces; ni = hm.nInt;
         std::vector<int32_t> ubc(c->u_bc, c->u_bc + hm.nPatches), pbc(c->p_bc, c->p_bc + hm.nPatches);
         std::vector<double> uval(c->u_value, c->u_value + 3 * (size_t)hm.nPatches), pval(c->p_value, c->p_value + hm.nPatches);
@@ -115,6 +122,18 @@ struct LduSolver {
             FY_TRY(fstress.alloc_exact(3 * (size_t)nf)); FY_TRY(zero(fstress));
             FY_TRY(launch_fill_f64(stream, alpha.p, n, 1.0));                 // alpha = 1.0 (FoamYade.C:68)
             FY_TRY(launch_fill_f64(stream, alphaf.p, (size_t)nf, 1.0));
+            if (les) {                                                        // nut of the start time: the file's values (eddyViscosity: MUST_READ; no validate() in createFields.H)
+                std::vector<int32_t> nb((size_t)hm.nPatches, FY_BC_NUT_ZERO_GRADIENT);
+                std::vector<double> nv((size_t)hm.nPatches, 0.0);
+                for (int pa = 0; pa < hm.nPatches; ++pa) {
+                    if (c->nut_bc) nb[(size_t)pa] = c->nut_bc[pa];
+                    if (c->nut_value) nv[(size_t)pa] = c->nut_value[pa];
+                    if (nb[(size_t)pa] != FY_BC_NUT_ZERO_GRADIENT && nb[(size_t)pa] != FY_BC_NUT_FIXED_VALUE) return fail(FY_ERR_UNSUPPORTED, "fy_ldu_solver: nut patch type %d (zeroGradient, fixedValue)", nb[(size_t)pa]);
+                }
+                FY_TRY(up(d_nutbc, nb)); FY_TRY(up(d_nutval, nv));
+                FY_TRY(nut.alloc_exact(n));
+                FY_TRY(launch_fill_f64(stream, nut.p, n, c->nut_initial));
+            }
         }
         for (auto& t : tim) FY_TRY(t.init());
         FY_TRY(amg.build(stream, nc, ni, hm.own.data(), hm.nei.data(), hm.cf_off, hm.cf_face, hm.magSf.data(), need_ref ? cs.p_ref_cell : -1, cs.p_solver == FY_PSOLVER_PCG_MG));
@@ -286,6 +305,10 @@ struct LduSolver {
                 st.u_iters_total += it;
             }
             for (int corr = 0; corr < cs.n_correctors; ++corr) FY_TRY(corrector_pimple(final_outer && corr == cs.n_correctors - 1, p_relax_now));
+            if (les && final_outer) {                                                                             // pimple.turbCorr(): pimpleFoamYade.C:101-104
+                FY_TRY(launch_ldu_grad_vec(stream, g, U.p, vGrad.p));
+                FY_TRY(launch_ldu_smagorinsky_nut(stream, g, vGrad.p, cs.les_ck, cs.les_ce, cs.les_delta_coeff, nut.p));
+            }
         }
         return FY_OK;
     }
@@ -350,7 +373,7 @@ struct LduSolver {
                          {"mom_diag", mdiag.p, n}, {"mom_lower", mlower.p, (size_t)ni}, {"mom_upper", mupper.p, (size_t)ni}, {"mom_b", mb.p, 3 * n},
                          {"alpha", alpha.p, pimple ? n : 0}, {"uSourceDrag", uSourceDrag.p, pimple ? n : 0}, {"uParticle", uParticle.p, pimple ? 3 * n : 0}, {"gradP", gradP.p, pimple ? 3 * n : 0},
                          {"divT", divT.p, pimple ? 3 * n : 0}, {"ddtU", ddtU.p, pimple ? 3 * n : 0}, {"phiForces", phiForces.p, pimple ? (size_t)nf : 0}, {"alphaf", alphaf.p, pimple ? (size_t)nf : 0},
-                         {"rAUf", rAUf.p, (size_t)nf}, {"uSourceCoupling", uSource.p, 3 * n}};
+                         {"rAUf", rAUf.p, (size_t)nf}, {"uSourceCoupling", uSource.p, 3 * n}, {"nut", nut.p, les ? n : 0}};
         for (const E& e : tab) if (s == e.nm) { *ptr = e.p; *count = e.c; return FY_OK; }
         const struct { const char* nm; const std::vector<double>* v; } geo[] = {{"C", &hm.C}, {"V", &hm.V}, {"Cf", &hm.Cf}, {"Sf", &hm.Sf}, {"magSf", &hm.magSf}, {"w", &hm.w},
                                                                                   {"dcNO", &hm.dcNO}, {"kvec", &hm.kvec}};
@@ -375,6 +398,7 @@ void fy_ldu_case_defaults(fy_ldu_case* c) {
     c->p_solver = FY_PSOLVER_PCG_JACOBI;
     c->solver = FY_SOLVER_ICO; c->n_outer_correctors = 1;
     c->adjust_time_step = 0; c->max_co = 1.0; c->max_delta_t = 1e300;
+    c->turbulence_model = FY_TURBULENCE_LAMINAR; c->les_ck = 0.094; c->les_ce = 1.048; c->les_delta_coeff = 1.0; c->nut_initial = 0.0;
 }
 
 int fy_ldu_solver_create(const fy_poly_mesh* m, const fy_ldu_case* c, const fy_transport* tr, int device_ordinal, fy_ldu_solver** out) {
@@ -414,7 +438,7 @@ int fy_ldu_solver_write_field_host(fy_ldu_solver* s, const char* name, const dou
     double* p; size_t n; const std::vector<double>* h;
     FY_TRY(s->s.field(name, &p, &n, &h));
     const std::string nm = name;
-    const bool pim_in = s->s.pimple && (nm == "alpha" || nm == "uSourceDrag");      // (what setParticleAction would leave: for tests that feed the equations a given void fraction)
+    const bool pim_in = (s->s.pimple && (nm == "alpha" || nm == "uSourceDrag")) || (s->s.les && nm == "nut");      // (what setParticleAction would leave: for tests that feed the equations a given void fraction)
     if (h || (nm != "U" && nm != "p" && nm != "uSource" && !pim_in)) return fy::fail(FY_ERR_INVALID, "fy_ldu_solver_write_field_host: '%s' cannot be written (U, p, uSource; alpha, uSourceDrag with pimpleFoamYade)", nm.c_str());
     FY_HIP(hipSetDevice(s->s.device));
     FY_HIP(hipMemcpyAsync(p, in, n * sizeof(double), hipMemcpyHostToDevice, s->s.stream));
