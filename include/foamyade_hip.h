@@ -492,6 +492,7 @@ typedef struct fy_ldu_case {
     double les_ck, les_ce, les_delta_coeff, nut_initial;
     const int32_t* nut_bc;           /* per patch: FY_BC_NUT_ZERO_GRADIENT | FY_BC_NUT_FIXED_VALUE (NULL: zeroGradient everywhere) */
     const double* nut_value;         /* [n_patches] */
+    int32_t convection_scheme;       /* FY_CONVECTION_LINEAR (default) | FY_CONVECTION_UPWIND for div(phi,U) / div(alphaPhic,Uc) */
 } fy_ldu_case;
 typedef struct fy_ldu_solver fy_ldu_solver;
 void fy_ldu_case_defaults(fy_ldu_case*);        /* the icoFoam cavity tutorial's controls (as fy_case_defaults); the patch arrays stay NULL */

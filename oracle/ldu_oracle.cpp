@@ -49,6 +49,7 @@ extern "C" struct orc_ldu_case {
     int turbulence_model;                                       // 0 laminar, 1 LES Smagorinsky (delta cubeRootVol)
     double les_ck, les_ce, les_delta_coeff, nut_initial;
     const int* nut_bc; const double* nut_value;                 // per patch: 0 zeroGradient, 1 fixedValue
+    int convection_scheme;                                      // 0 Gauss linear, 1 Gauss upwind
 };
 extern "C" struct orc_ldu_stats {
     double courant_mean, courant_max, cont_sum_local, cont_global, cont_cumulative;
@@ -309,7 +310,7 @@ struct Ldu {
             const double fl = alphaf[f] * phi[f];
             // - fvm::laplacian(alpha nuEff, U): the cell field alpha (nu + nut) interpolated linearly [OF-6 gaussLaplacianScheme::fvmLaplacian(vol gamma)]
             const double g = (nut.empty() ? cs.nu * alphaf[f] : w[f] * alpha[own[f]] * (cs.nu + nut[own[f]]) + (1.0 - w[f]) * alpha[nei[f]] * (cs.nu + nut[nei[f]])) * magSf[f];
-            double lo = -w[f] * fl, up = lo + fl;
+            double lo = -(cs.convection_scheme == 1 ? (fl >= 0.0 ? 1.0 : 0.0) : w[f]) * fl, up = lo + fl;
             lo -= g * dcNO[f]; up -= g * dcNO[f];
             lower[f] = lo; upper[f] = up;
             diag[own[f]] -= lo; diag[nei[f]] -= up;
@@ -496,7 +497,8 @@ struct Ldu {
         }
         for (int f = 0; f < nInt; ++f) {
             // gaussConvectionScheme<linear>::fvmDiv: lower = -w phi, upper = lower + phi, negSumDiag
-            double lo = -w[f] * phi[f], up = lo + phi[f];
+            // ... or upwind [OF-6 upwind::weights]: the owner's weight is pos0(flux)
+            double lo = -(cs.convection_scheme == 1 ? (phi[f] >= 0.0 ? 1.0 : 0.0) : w[f]) * phi[f], up = lo + phi[f];
             // - gaussLaplacianScheme::fvmLaplacianUncorrected: upper = lower = gamma |Sf| nonOrthDeltaCoeffs, negSumDiag
             const double g = cs.nu * magSf[f] * dcNO[f];
             lo -= g; up -= g;

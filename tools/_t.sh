@@ -1,3 +1,3 @@
 #!/bin/bash
 cd /root/repo
-python -m pytest tests/test_ldu_case.py -m gpu -x -q 2>&1 | tail -12
+python -m pytest tests/test_ldu_parity.py tests/test_ldu_case.py -m gpu -x -q 2>&1 | tail -12

@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void k_ldu_mom_faces(LduGeo g, const double* _
     const int f = blockIdx.x * 256 + threadIdx.x;
     if (f >= g.nInt) return;
     const double gm = g.nu * g.magSf[f];
-    double lo = -g.w[f] * phi[f];
+    double lo = -(g.upwind ? (phi[f] >= 0.0 ? 1.0 : 0.0) : g.w[f]) * phi[f];      // [OF-6 upwind::weights = pos0(faceFlux)]
     double up = lo + phi[f];
     lo -= gm * g.dcNO[f]; up -= gm * g.dcNO[f];
     M.lower[f] = lo; M.upper[f] = up;
@@ -449,7 +449,7 @@ __global__ __launch_bounds__(256) void k_ldu_pmom_faces(LduGeo g, LduPim P, cons
     const double* Tn = gradU + 9 * (size_t)n;
     const double trn = Tn[0] + Tn[4] + Tn[8], an = alpha[n] * (g.nu + (P.nut ? P.nut[n] : 0.0)), w = g.w[f];
     const double af = alphaf[f], fl = af * phi[f], gm = (P.nut ? w * ao + (1.0 - w) * an : g.nu * af) * g.magSf[f];
-    double lo = -w * fl;
+    double lo = -(g.upwind ? (fl >= 0.0 ? 1.0 : 0.0) : w) * fl;
     double up = lo + fl;
     lo -= gm * g.dcNO[f]; up -= gm * g.dcNO[f];
     M.lower[f] = lo; M.upper[f] = up;
