@@ -304,7 +304,10 @@ Graph coarse_graph(const Graph& G, const std::vector<int32_t>& cl, int nc) {
 template <class T>
 int upload(hipStream_t s, DevBuf<T>& d, const std::vector<T>& h) {
     FY_TRY(d.alloc_exact(std::max<size_t>(h.size(), 1)));
-    if (!h.empty()) FY_HIP(hipMemcpyAsync(d.p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s));
+    if (!h.empty()) {
+        FY_HIP(hipMemcpyAsync(d.p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s));
+        FY_HIP(hipStreamSynchronize(s));               // (the callers hand over vectors that die with their scope; the hierarchy is built once)
+    }
     return FY_OK;
 }
 

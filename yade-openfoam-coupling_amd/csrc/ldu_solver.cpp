@@ -52,7 +52,7 @@ struct LduSolver {
     }
     template <class T> int up(DevBuf<T>& d, const std::vector<T>& h) {
         FY_TRY(d.alloc_exact(std::max<size_t>(h.size(), 1)));
-        if (!h.empty()) FY_HIP(hipMemcpyAsync(d.p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, stream));
+        if (!h.empty()) { FY_HIP(hipMemcpyAsync(d.p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, stream)); FY_HIP(hipStreamSynchronize(stream)); }      // (set-up only; the source may die with its scope)
         return FY_OK;
     }
     int zero(DevBuf<double>& b) { if (b.n) FY_HIP(hipMemsetAsync(b.p, 0, b.n * sizeof(double), stream)); return FY_OK; }
