@@ -641,7 +641,8 @@ def main():
     if args.gpus > 1 and "RANK" not in os.environ:
         raise SystemExit(self_launch(args.gpus))
     if os.environ.get("FOAMYADE_BENCH_LAUNCH_PROBE"):             # tests/test_bench_multirank.py: what did the launcher hand this rank?
-        print(json.dumps({"rank": int(os.environ.get("RANK", "-1")), "world": int(os.environ.get("WORLD_SIZE", "-1")), "gpus": args.gpus, "steps": args.steps}), flush=True)
+        # (one write call: two ranks share the pipe, and print() hands the text and the newline over separately)
+        os.write(1, (json.dumps({"rank": int(os.environ.get("RANK", "-1")), "world": int(os.environ.get("WORLD_SIZE", "-1")), "gpus": args.gpus, "steps": args.steps}) + "\n").encode())
         raise SystemExit(0)
 
     import torch
