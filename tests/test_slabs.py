@@ -234,6 +234,36 @@ def test_rccl_selftest_child_mode_of_the_bench(product):
     assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-2000:]
 
 
+def test_a_solver_on_an_rccl_communicator_of_one_rank_steps_like_the_single_domain(product):
+    """every RCCL call the slab solver issues -- ncclCommInitRank, ncclCommSplit for the overlapped halo, grouped ncclSend / ncclRecv (none to post on one rank),
+    ncclAllReduce, ncclAllGather behind the mixed sum / max diagnostics, the per-phase counters -- on the only world this box can form: one rank.  The slab code path
+    (ghost planes, windows, collective diagnostics) then has to reproduce the single-domain run"""
+    n, dx = 16, 0.1 / 16
+    case = lambda: product.make_case(1, n, n, n, dx, 2e-4, 1e-5, u_bc=[0] * 6, u_val=[(0, 0, 0)] * 6, g=(0, 0, -9.81), p_bc=[2] * 6)
+    comm = product.rccl_comm(0, 1, product.rccl_unique_id(), 0)
+    product.comm_selftest(comm, 0)
+    one = product.Solver(case())
+    slab = product.Solver(case(), comm=comm)
+    rs = np.random.RandomState(5)
+    for _ in range(3):
+        rec = np.zeros((3000, 10))
+        rec[:, 0:3] = rs.random_sample((3000, 3)) * np.array([0.1, 0.1, 0.06]) + np.array([0.0, 0.0, 0.005])
+        rec[:, 3:6] = 0.05 * rs.standard_normal((3000, 3)); rec[:, 9] = 0.2 * dx
+        one.set_particles(rec); slab.set_particles(rec)
+        one.step(); slab.step()
+        sc = np.abs(one.forces()).max()
+        assert np.abs(slab.forces() - one.forces()).max() <= 1e-9 * sc
+    for nm in ("U", "p"):
+        a, b = slab.get(nm), one.get(nm)
+        assert np.abs(a - b).max() <= 1e-8 * (np.abs(b).max() + 1e-300), nm
+    import ctypes
+    buf = ctypes.create_string_buffer(1 << 14)
+    assert product.lib().fy_comm_stats_by_tag(comm, buf, len(buf)) == 0
+    counts = [tuple(int(x) for x in ln.split()[1:]) for ln in buf.value.decode().splitlines()]
+    assert sum(c[1] + c[2] for c in counts) > 0                                # (all-reduces / all-gathers went through RCCL)
+    slab.close(); one.close()
+
+
 @pytest.mark.parametrize("n_slabs,workers", [(2, 2), (3, 4)])
 def test_slabs_next_to_a_parallel_yade(product, n_slabs, workers):
     """z-slabs fed by a PARALLEL Yade (FoamYade.C:77-111, 114-155): every solver rank sends the bounding box of its own slab, every Yade
