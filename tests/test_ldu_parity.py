@@ -304,3 +304,30 @@ def test_pimple_with_a_cloud_matches_the_restatement(product, oracle, kind):
         close(h.get("nut"), o.get("nut"), 1e-6, "nut")
     assert np.abs(h.get("ddtU")).max() > 0 and np.abs(h.get("divT")).max() > 0
     h.close(); o.close()
+
+
+def test_rayleigh_layer_on_a_distorted_mesh_on_the_hip_solver(product):
+    """the transient known answer of tests/test_ldu_oracle.py::test_rayleigh_layer_on_a_distorted_mesh on the HIP solver with the multigrid preconditioner, one level finer
+    (128 cells across, 131 072 cells): the error keeps falling (0.0025, 0.0011 on the restatement at 32 and 64)"""
+    from math import erfc, sqrt
+    nu, U0, t0, T = 0.01, 1.0, 0.5, 1.0
+    L = (0.25, 1.0, 0.25)
+    errs, cross = [], []
+    for ny, dt in ((64, 0.00125), (128, 0.0003125)):
+        k = ny // 16
+        mesh = pm.hex_block_fast(4 * k, ny, 4 * k, L, pm.wavy(0.01, L))
+        u_val = [(0, 0, 0)] * 6
+        u_val[2] = (U0, 0, 0)
+        s = product.LduSolver(mesh, dt, nu, [1, 1, 0, 1, 1, 1], u_val, [1, 1, 0, 0, 0, 0], n_non_orth=1, p_tol=1e-10, p_rel_tol=0.0, p_final_tol=1e-10, u_tol=1e-10,
+                              p_solver=product.FY_PSOLVER_PCG_MG, p_max_iter=5000)
+        C = s.geometry("C")
+        prof = lambda t: np.array([U0 * erfc(y / (2 * sqrt(nu * t))) for y in C[:, 1]])
+        Ui = np.zeros((len(C), 3)); Ui[:, 0] = prof(t0)
+        s.set("U", Ui)
+        for _ in range(int(round((T - t0) / dt))):
+            s.step()
+        U = s.get("U").reshape(-1, 3)
+        errs.append(np.abs(U[:, 0] - prof(T)).max() / U0)
+        cross.append((np.abs(U[:, 1]) + np.abs(U[:, 2])).max() / U0)
+        s.close()
+    assert abs(errs[0] - 1.128e-3) < 1e-4 and errs[1] < 0.7 * errs[0] and max(cross) < 1e-3, (errs, cross)
