@@ -1,3 +1,3 @@
 #!/bin/bash
 cd /root/repo
-python -m pytest tests/test_ldu_parity.py -m gpu -x -q -k rayleigh 2>&1 | tail -12
+python -m pytest tests/test_long_runs.py -m gpu -x -q -k general 2>&1 | tail -12
