@@ -445,15 +445,18 @@ int fy_solver_get_kernel_timing(fy_solver*, const char* kernel, double* total_ms
 
 
 /* ------------------------------------------------------------------------------------------------------------------------------------
- * icoFoamYade on a GENERAL polyhedral mesh (round 4).  The reference's solvers run on whatever createMesh.H hands them
- * (icoFoamYade/icoFoamYade.C:42) and carry a non-orthogonal corrector loop (icoFoamYade.C:114-131); fy_solver above is the structured block.
- * fy_ldu_solver takes the mesh in OpenFOAM's own addressing -- constant/polyMesh: points, faces, owner, neighbour, boundary -- builds
- * OpenFOAM's geometry from it (face triangle / cell pyramid decomposition, linear weights, nonOrthDeltaCoeffs, nonOrthCorrectionVectors
- * [OF-6]) and runs the same loop body with owner / neighbour (LDU) addressing: Euler ddt, Gauss linear div / grad, Gauss linear CORRECTED
- * laplacian (the explicit non-orthogonal part is what the correctNonOrthogonal loop iterates on), PCG with the diagonal preconditioner in
- * its single-reduction form, Jacobi sweeps for U.  Patches: fixedValue / zeroGradient for U (noSlip = fixedValue 0), zeroGradient /
- * fixedValue for p.  The coupling object (fy_ldu_solver_coupling) works on the mesh's own cell centres and volumes: explicit k-d tree, and
- * for the point-force locate (mesh.findCell, FoamYade.C:251) the nearest centre followed by a walk across the faces the point lies outside of. */
+ * icoFoamYade and pimpleFoamYade on a GENERAL polyhedral mesh (round 4).  The reference's solvers run on whatever createMesh.H
+ * hands them (icoFoamYade/icoFoamYade.C:42, pimpleFoamYade/pimpleFoamYade.C:47) and carry non-orthogonal corrector loops (icoFoamYade.C:114-131,
+ * pEqn.H:24-47); fy_solver above is the structured block.  fy_ldu_solver takes the mesh in OpenFOAM's own addressing -- constant/polyMesh: points,
+ * faces, owner, neighbour, boundary -- builds OpenFOAM's geometry from it (face triangle / cell pyramid decomposition, linear weights,
+ * nonOrthDeltaCoeffs, nonOrthCorrectionVectors, fvc::reconstruct's tensors [OF-6]) and runs the loop bodies with owner / neighbour (LDU) addressing:
+ * Euler ddt, Gauss linear | upwind div, Gauss linear grad, Gauss linear CORRECTED laplacian (the explicit non-orthogonal part is what the
+ * correctNonOrthogonal loop iterates on), PCG in its single-reduction form with the diagonal or an agglomeration-multigrid preconditioner (p_solver),
+ * Jacobi sweeps for U.  Patches: fixedValue / zeroGradient for U (noSlip = fixedValue 0); zeroGradient / fixedValue for p, fixedFluxPressure with
+ * pimpleFoamYade.  pimpleFoamYade (fy_ldu_case.solver): Gaussian 4-way coupling, the void-fraction-weighted UcEqn / pEqn, gravity, PIMPLE outer correctors,
+ * relaxation, adjustable time step, laminar Stokes stress or LES Smagorinsky.  The coupling object (fy_ldu_solver_coupling) works on the mesh's own
+ * cell centres and volumes: explicit k-d tree, and for the point-force locate (mesh.findCell, FoamYade.C:251) the nearest centre followed by a walk
+ * across the faces the point lies outside of. */
 typedef struct fy_poly_mesh {
     int32_t n_points;
     const double* points;            /* [n_points][3] */
