@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define FY_ABI_VERSION 8
+#define FY_ABI_VERSION 9
 
 /* ---- status codes ------------------------------------------------------------------------------------ */
 enum {
