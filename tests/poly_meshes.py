@@ -160,23 +160,37 @@ def prism_block(nx, ny, nz, lengths=(1.0, 1.0, 1.0), vertex_map=None):
     return from_cells(P, cells, lambda ctr: table[tuple(np.round(ctr, 12))], list(SIDES), shape=(nx, ny, nz))
 
 
-def write_poly_mesh_files(case_dir, mesh, patch_types=None):
-    """constant/polyMesh of `mesh` (ASCII, the layout OpenFOAM writes).  Test infrastructure: there is no blockMesh / snappyHexMesh here"""
+def write_poly_mesh_files(case_dir, mesh, patch_types=None, binary=False, label64=False):
+    """constant/polyMesh of `mesh`: ASCII (the layout OpenFOAM writes), or binary = the stream format of `writeFormat binary` (points as raw doubles, owner / neighbour as raw
+    labels, faces as a faceCompactList: offsets + labels; the boundary file stays text).  Test infrastructure: there is no blockMesh / snappyHexMesh here"""
     import os
     pm = os.path.join(str(case_dir), "constant", "polyMesh")
     os.makedirs(pm, exist_ok=True)
-    head = lambda cls, obj: "FoamFile\n{\n    version     2.0;\n    format      ascii;\n    class       %s;\n    location    \"constant/polyMesh\";\n    object      %s;\n}\n\n" % (cls, obj)
+    lab = np.int64 if label64 else np.int32
+    arch = '    arch        "LSB;label=%d;scalar=64";\n' % (64 if label64 else 32) if binary else ""
+    head = lambda cls, obj: ("FoamFile\n{\n    version     2.0;\n    format      %s;\n%s    class       %s;\n    location    \"constant/polyMesh\";\n    object      %s;\n}\n\n"
+                             % ("binary" if binary else "ascii", arch, cls, obj)).encode()
     P, off, fp = mesh["points"], mesh["face_offsets"], mesh["face_points"]
-    with open(os.path.join(pm, "points"), "w") as f:
-        f.write(head("vectorField", "points") + "%d\n(\n" % len(P) + "".join("(%r %r %r)\n" % (float(x), float(y), float(z)) for x, y, z in P) + ")\n")
-    with open(os.path.join(pm, "faces"), "w") as f:
-        f.write(head("faceList", "faces") + "%d\n(\n" % (len(off) - 1) +
-                "".join("%d(%s)\n" % (off[q + 1] - off[q], " ".join(str(int(v)) for v in fp[off[q]:off[q + 1]])) for q in range(len(off) - 1)) + ")\n")
+    blob = lambda a: b"%d\n(" % len(a) + np.ascontiguousarray(a).tobytes() + b")\n"
+    with open(os.path.join(pm, "points"), "wb") as f:
+        if binary:
+            f.write(head("vectorField", "points") + b"%d\n(" % len(P) + np.ascontiguousarray(P, "<f8").tobytes() + b")\n")
+        else:
+            f.write(head("vectorField", "points") + ("%d\n(\n" % len(P) + "".join("(%r %r %r)\n" % (float(x), float(y), float(z)) for x, y, z in P) + ")\n").encode())
+    with open(os.path.join(pm, "faces"), "wb") as f:
+        if binary:
+            f.write(head("faceCompactList", "faces") + blob(np.asarray(off, lab)) + b"\n" + blob(np.asarray(fp, lab)))
+        else:
+            f.write(head("faceList", "faces") + ("%d\n(\n" % (len(off) - 1) +
+                    "".join("%d(%s)\n" % (off[q + 1] - off[q], " ".join(str(int(v)) for v in fp[off[q]:off[q + 1]])) for q in range(len(off) - 1)) + ")\n").encode())
     for name in ("owner", "neighbour"):
-        with open(os.path.join(pm, name), "w") as f:
-            f.write(head("labelList", name) + "%d\n(\n" % len(mesh[name]) + "".join("%d\n" % int(v) for v in mesh[name]) + ")\n")
+        with open(os.path.join(pm, name), "wb") as f:
+            if binary:
+                f.write(head("labelList", name) + blob(np.asarray(mesh[name], lab)))
+            else:
+                f.write(head("labelList", name) + ("%d\n(\n" % len(mesh[name]) + "".join("%d\n" % int(v) for v in mesh[name]) + ")\n").encode())
     with open(os.path.join(pm, "boundary"), "w") as f:
-        f.write(head("polyBoundaryMesh", "boundary") + "%d\n(\n" % len(mesh["patch_names"]))
+        f.write("FoamFile\n{\n    version     2.0;\n    format      ascii;\n    class       polyBoundaryMesh;\n    location    \"constant/polyMesh\";\n    object      boundary;\n}\n\n%d\n(\n" % len(mesh["patch_names"]))
         for q, name in enumerate(mesh["patch_names"]):
             ty = (patch_types or {}).get(name, "wall")
             f.write("    %s\n    {\n        type            %s;\n        nFaces          %d;\n        startFace       %d;\n    }\n" % (name, ty, int(mesh["patch_size"][q]), int(mesh["patch_start"][q])))

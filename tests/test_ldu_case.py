@@ -65,6 +65,36 @@ def test_general_polyMesh_case_is_read(prod, tmp_path):
     fc.close()
 
 
+@pytest.mark.parametrize("label64", [False, True])
+def test_binary_polyMesh_is_read(prod, tmp_path, label64):
+    """writeFormat binary: points as raw doubles, owner / neighbour as raw labels (32 or 64 bit by the header's arch), faces as a faceCompactList -- prisms, so that the
+    face sizes differ; the arrays equal the ASCII reader's.  A lattice written this way opens through the block reader too"""
+    mesh = pm.prism_block(3, 3, 2, (0.1, 0.1, 0.1), pm.wavy(0.004, (0.1, 0.1, 0.1)))
+    dst = general_cavity(tmp_path, mesh)
+    for nm in ("U", "p"):
+        t = (dst / "0" / nm).read_text()
+        body = "".join("    %s { type %s; }\n" % (s_, ("noSlip" if nm == "U" else "zeroGradient")) for s_ in pm.SIDES)
+        (dst / "0" / nm).write_text(t[:t.index("boundaryField")] + "boundaryField\n{\n" + body + "}\n")
+    pm.write_poly_mesh_files(dst, mesh, binary=True, label64=label64)
+    assert b"faceCompactList" in (dst / "constant/polyMesh/faces").read_bytes()
+    fc = prod.GeneralFoamCase(dst)
+    for k in ("face_offsets", "face_points", "owner", "neighbour", "patch_start", "patch_size"):
+        np.testing.assert_array_equal(fc.mesh[k], mesh[k], err_msg=k)
+    np.testing.assert_array_equal(fc.mesh["points"], mesh["points"])
+    fc.close()
+    blk = tmp_path / "blk"
+    shutil.copytree(os.path.join(CASES, "cavity_ico"), blk)
+    os.remove(blk / "system/blockMeshDict")
+    pm.write_poly_mesh_files(blk, pm.hex_block(16, 16, 16, (0.1, 0.1, 0.1), patches=CAVITY), binary=True, label64=label64)
+    b = prod.FoamCase(blk, prod.FY_SOLVER_ICO)
+    assert (b.case.nx, b.case.ny, b.case.nz) == (16, 16, 16) and abs(b.case.dx - 0.1 / 16) < 1e-15
+    b.close()
+    raw = (dst / "constant/polyMesh/owner").read_bytes()
+    (dst / "constant/polyMesh/owner").write_bytes(raw[:-40])                 # a truncated list is an error, not a short mesh
+    with pytest.raises(prod.FoamYadeError, match="runs past the end"):
+        prod.GeneralFoamCase(dst)
+
+
 def test_prism_polyMesh_case_is_read(prod, tmp_path):
     """triangular and quadrilateral faces in one faces file"""
     mesh = pm.prism_block(3, 3, 2, (0.1, 0.1, 0.1), pm.wavy(0.004, (0.1, 0.1, 0.1)))

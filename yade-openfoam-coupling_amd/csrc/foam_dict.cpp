@@ -364,7 +364,60 @@ static bool numeric_list_file(const std::string& path, std::vector<T>* out, std:
                 if (word && t.compare(v, 6, "binary") == 0 && v + 6 < n && (t[v + 6] == ';' || std::isspace((unsigned char)t[v + 6]))) is_binary = true;
                 f += 6;
             }
-            if (is_binary) { *err = path + ": binary mesh files are not supported (the field files are)"; return false; }
+            if (is_binary) {
+                // binary stream format [OF-6 UList<T>::writeEntry / List<T>::readList on a binary Istream]: `N(` + the elements as they lie in memory + `)`.
+                //   points (vectorField): N (x y z) triples of `scalar`;  owner / neighbour (labelList): N labels;
+                //   faces: faceCompactList = TWO lists, the N + 1 offsets into the second one and the point labels of all faces back to back
+                // widths from the header's arch "LSB;label=32;scalar=64" (absent: these).  Output in the ASCII scanner's convention (count first; a face as n a b c ...)
+                const std::string hdr = t.substr(i, q - i);
+                const bool lab64 = hdr.find("label=64") != std::string::npos, sc32 = hdr.find("scalar=32") != std::string::npos;
+                const bool compact = hdr.find("faceCompactList") != std::string::npos, vectors = hdr.find("vectorField") != std::string::npos;
+                const bool labels = hdr.find("labelList") != std::string::npos;
+                if (!compact && !vectors && !labels) { *err = path + ": binary file of a class other than vectorField, labelList, faceCompactList is not supported"; return false; }
+                size_t at = q + 1;
+                auto read_block = [&](size_t elem_bytes, size_t per, const char** data, size_t* count) -> bool {
+                    i = at; skip();
+                    char* end = nullptr;
+                    const long long cnt = std::strtoll(t.c_str() + i, &end, 10);
+                    if (end == t.c_str() + i || cnt < 0) { *err = path + ": binary list without a count"; return false; }
+                    i = (size_t)(end - t.c_str());
+                    while (i < n && t[i] != '(') ++i;
+                    const size_t bytes = (size_t)cnt * per * elem_bytes;
+                    if (i >= n || i + 1 + bytes + 1 > n || t[i + 1 + bytes] != ')') { *err = path + ": binary list of " + std::to_string(cnt) + " elements runs past the end of the file (or is not closed)"; return false; }
+                    *data = t.data() + i + 1; *count = (size_t)cnt;
+                    at = i + 1 + bytes + 1;
+                    return true;
+                };
+                auto label_at = [&](const char* d, size_t k) -> long long {
+                    if (lab64) { int64_t v; std::memcpy(&v, d + 8 * k, 8); return (long long)v; }
+                    int32_t v; std::memcpy(&v, d + 4 * k, 4); return (long long)v;
+                };
+                out->clear();
+                const char* d = nullptr; size_t cnt = 0;
+                if (vectors) {
+                    if (!read_block(sc32 ? 4 : 8, 3, &d, &cnt)) return false;
+                    out->reserve(3 * cnt + 1);
+                    out->push_back((T)cnt);
+                    for (size_t k = 0; k < 3 * cnt; ++k) { if (sc32) { float v; std::memcpy(&v, d + 4 * k, 4); out->push_back((T)v); } else { double v; std::memcpy(&v, d + 8 * k, 8); out->push_back((T)v); } }
+                } else if (labels) {
+                    if (!read_block(lab64 ? 8 : 4, 1, &d, &cnt)) return false;
+                    out->reserve(cnt + 1);
+                    out->push_back((T)cnt);
+                    for (size_t k = 0; k < cnt; ++k) out->push_back((T)label_at(d, k));
+                } else {
+                    const char* d2 = nullptr; size_t cnt2 = 0;
+                    if (!read_block(lab64 ? 8 : 4, 1, &d, &cnt) || cnt < 1 || !read_block(lab64 ? 8 : 4, 1, &d2, &cnt2)) { if (err->empty()) *err = path + ": malformed faceCompactList"; return false; }
+                    out->reserve(cnt + cnt2);
+                    out->push_back((T)(cnt - 1));
+                    for (size_t f = 0; f + 1 < cnt; ++f) {
+                        const long long a = label_at(d, f), b = label_at(d, f + 1);
+                        if (a < 0 || b < a || (size_t)b > cnt2) { *err = path + ": faceCompactList offsets out of order"; return false; }
+                        out->push_back((T)(b - a));
+                        for (long long k = a; k < b; ++k) out->push_back((T)label_at(d2, (size_t)k));
+                    }
+                }
+                return true;
+            }
         }
         i = q + 1;
     }
