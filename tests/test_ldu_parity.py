@@ -331,3 +331,36 @@ def test_rayleigh_layer_on_a_distorted_mesh_on_the_hip_solver(product):
         cross.append((np.abs(U[:, 1]) + np.abs(U[:, 2])).max() / U0)
         s.close()
     assert abs(errs[0] - 1.128e-3) < 1e-4 and errs[1] < 0.7 * errs[0] and max(cross) < 1e-3, (errs, cross)
+
+
+def test_malformed_meshes_and_cases_are_refused_by_name(product):
+    """fy_ldu_solver_create checks what it is handed: addressing (owner < neighbour, patches covering the boundary faces once, faces of three points or more, cells that close),
+    the reference cell, the solver / preconditioner / closure selectors -- an error with the reason, never a half-built solver"""
+    base = pm.hex_block(4, 4, 4)
+    ok = lambda: product.LduSolver(base, 1e-3, 0.01, [0] * 6, [(0, 0, 0)] * 6, [0] * 6)
+    ok().close()
+
+    def broken(**edit):
+        m = dict(base)
+        for k, v in edit.items():
+            m[k] = v
+        return m
+    own = base["owner"].copy(); own[0], nei0 = base["neighbour"][0], base["owner"][0]
+    nei = base["neighbour"].copy(); nei[0] = nei0
+    cases = [
+        (broken(owner=own, neighbour=nei), {}, "owner < neighbour"),
+        (broken(patch_size=np.array([16, 16, 16, 16, 16, 15], np.int32)), {}, "belongs to no patch"),
+        (broken(patch_start=base["patch_start"] - 1), {}, "patch"),
+        (broken(points=base["points"] * np.array([1.0, 1.0, 0.0])), {}, "no area|no volume|flat"),
+        (base, dict(p_ref_cell=64), "pRefCell"),
+        (base, dict(p_solver=7), "p_solver"),
+        (base, dict(solver=3), "solver"),
+        (base, dict(turbulence_model=product.TURBULENCE_KEPSILON, solver=1), "turbulence"),
+        (base, dict(convection_scheme=2), "convection"),
+    ]
+    for mesh, kw, needle in cases:
+        with pytest.raises(product.FoamYadeError, match=needle):
+            product.LduSolver(mesh, 1e-3, 0.01, [0] * 6, [(0, 0, 0)] * 6, [0] * 6, **kw)
+    with pytest.raises(product.FoamYadeError, match="patch type"):
+        product.LduSolver(base, 1e-3, 0.01, [0] * 6, [(0, 0, 0)] * 6, [2] * 6)          # fixedFluxPressure belongs to pimpleFoamYade
+    ok().close()
