@@ -1,5 +1,4 @@
 #!/bin/bash
 cd /root/repo
-timeout 1500 python -m pytest tests/test_slabs.py tests/test_slabs_multiprocess.py -m gpu -x -q 2>&1 | tail -6
-timeout 600 python tools/virtual_slab_bench.py 2 10 2>&1 | tail -1
-timeout 900 python tools/virtual_strong_bench.py 8 5 2>&1 | tail -1
+timeout 900 python tools/ldu_bench.py 160 5 wavy 10000000 mg 1e-6 pimple 2>&1 | tail -1 | tee gpurun_out/ldu_c3_like.json
+timeout 900 python tools/ldu_bench.py 160 5 lattice 10000000 mg 1e-6 pimple 2>&1 | tail -1 | tee -a gpurun_out/ldu_c3_like.json
