@@ -1,4 +1,8 @@
 #!/bin/bash
+# scratch driver for one gpurun call (development): the GPU suite and the smoke entry
 cd /root/repo
-timeout 900 python tools/ldu_bench.py 160 5 wavy 10000000 mg 1e-6 pimple 2>&1 | tail -1 | tee gpurun_out/ldu_c3_like.json
-timeout 900 python tools/ldu_bench.py 160 5 lattice 10000000 mg 1e-6 pimple 2>&1 | tail -1 | tee -a gpurun_out/ldu_c3_like.json
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+timeout 2400 python -m pytest tests -m gpu -x -q > gpurun_out/gpu_suite.log 2>&1; echo "rc=$?" >> gpurun_out/gpu_suite.log
+grep -E "passed|failed|rc=" gpurun_out/gpu_suite.log | tail -3
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
