@@ -147,11 +147,11 @@ __global__ __launch_bounds__(256) void k_amg_restrict(int nc, const int32_t* __r
 // (the matrix is symmetric positive definite: the reference cell's point term, or a fixed-value patch, removes the constant) -- and the solve is the
 // product with the inverse.  Sweeps of damped Jacobi in its place left the constant-like mode in (160 sweeps at 0.8: asymptotic contraction of the cycle
 // 0.97 on 64^3 cubes) and cost more than the rest of the coarse levels together (~1.3 us per sweep: every sweep is a barrier)
-__global__ __launch_bounds__(256) void k_amg_coarsest_invert(EllMat A, double* __restrict__ inv) {
+__global__ __launch_bounds__(1024) void k_amg_coarsest_invert(EllMat A, double* __restrict__ inv) {
     __shared__ double a[kAmgCoarsest * kAmgCoarsest];
     __shared__ double col[kAmgCoarsest];
     const int n = A.n, t = threadIdx.x;
-    for (int q = t; q < n * n; q += 256) a[q] = 0.0;
+    for (int q = t; q < n * n; q += 1024) a[q] = 0.0;
     __syncthreads();
     if (t < n) {
         a[t * n + t] = A.diag[t];
@@ -168,14 +168,14 @@ __global__ __launch_bounds__(256) void k_amg_coarsest_invert(EllMat A, double* _
         __syncthreads();
         if (t < n) a[k * n + t] = t == k ? p : a[k * n + t] * p;
         __syncthreads();
-        for (int q = t; q < n * n; q += 256) {
+        for (int q = t; q < n * n; q += 1024) {
             const int i = q / n, j = q - i * n;
             if (i == k) continue;
             a[q] = j == k ? -col[i] * p : a[q] - col[i] * a[k * n + j];
         }
         __syncthreads();
     }
-    for (int q = t; q < n * n; q += 256) inv[q] = a[q];
+    for (int q = t; q < n * n; q += 1024) inv[q] = a[q];
 }
 // The small levels (<= kAmgTailCells cells and everything below) in ONE workgroup: a launch per sweep costs ~7 us of dispatch for a few hundred rows of work, and a
 // V-cycle has seven of them per level; here a sweep ends at a workgroup barrier instead (the iterates stay in global memory: L2).  Same rows, same order, same bits
@@ -448,7 +448,7 @@ int LduAmg::setup(hipStream_t s, const double* pcoef, const double* pdiag) {
     {
         EllMat A = lev.back()->mat();
         if (lev.size() == 1) A.diag = pdiag;
-        hipLaunchKernelGGL(k_amg_coarsest_invert, dim3(1), dim3(256), 0, s, A, coarse_inv.p);
+        hipLaunchKernelGGL(k_amg_coarsest_invert, dim3(1), dim3(1024), 0, s, A, coarse_inv.p);
         FY_LAUNCH_CHECK();
     }
     return FY_OK;
