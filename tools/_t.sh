@@ -1,7 +1,17 @@
 #!/bin/bash
+# scratch driver for one gpurun call (development): the general-mesh bench set
 cd /root/repo
-python -m pytest tests/test_ldu_parity.py -m gpu -x -q 2>&1 | tail -2
-for cfg in "64 10 lattice 0 mg" "128 10 wavy 0 mg"; do
-  timeout 600 python tools/ldu_bench.py $cfg 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['kind'],d['cells'],'its',d['pcg_iters_per_step'],'ms',round(d['ms_per_step_wall'],2))"
+mkdir -p gpurun_out
+rm -f gpurun_out/ldu_bench.jsonl gpurun_out/ldu_bench_pimple.jsonl
+for cfg in "64 10 lattice 0 mg" "128 10 lattice 0 mg" "128 10 wavy 0 mg" "128 10 wavy 0 diag" "96 10 prisms 0 mg"; do
+  timeout 600 python tools/ldu_bench.py $cfg 2>&1 | tail -1 >> gpurun_out/ldu_bench.jsonl
 done
-KSTATS_TOP=40 bash tools/kstats.sh inv -- python /root/repo/tools/ldu_bench.py 64 10 lattice 0 mg 2>&1 | grep -i "invert\|tail"
+for cfg in "64 10 wavy 300000 mg 1e-6 pimple" "128 10 wavy 2500000 mg 1e-6 pimple" "128 10 lattice 2500000 mg 1e-6 pimple" "96 10 prisms 1000000 mg 1e-6 pimple"; do
+  timeout 900 python tools/ldu_bench.py $cfg 2>&1 | tail -1 >> gpurun_out/ldu_bench_pimple.jsonl
+done
+python -c "
+import json
+for fn in ('gpurun_out/ldu_bench.jsonl','gpurun_out/ldu_bench_pimple.jsonl'):
+    for l in open(fn):
+        d=json.loads(l); print(d['kind'],d['cells'],d['solver'],d['p_solver'],d['particles'],'its',d['pcg_iters_per_step'],'ms',round(d['ms_per_step_wall'],2),d.get('structured_ms_per_step'))
+"
