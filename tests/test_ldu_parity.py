@@ -364,3 +364,41 @@ def test_malformed_meshes_and_cases_are_refused_by_name(product):
     with pytest.raises(product.FoamYadeError, match="patch type"):
         product.LduSolver(base, 1e-3, 0.01, [0] * 6, [(0, 0, 0)] * 6, [2] * 6)          # fixedFluxPressure belongs to pimpleFoamYade
     ok().close()
+
+
+def test_general_mesh_solver_at_the_bench_size(product):
+    """the size tools/ldu_bench.py and bench.py's general_mesh record run at -- 128^3 wavy hexahedra, 2.1 M cells, pimpleFoamYade with a 1 M-particle cloud -- through
+    properties that do not need the restatement: closed cells and the box's volume from the solver's own geometry, an agglomeration hierarchy of 2 x 2 x 2 boxes down to 64
+    cells, every particle of the cloud found, the void fraction removing the cloud's volume (up to the chain quirks), continuity closed, the multigrid-preconditioned PCG
+    converging in a handful of iterations, and the same step again giving the same bits (no atomics in the FV half; the particle scatters are order-dependent, so: no cloud)"""
+    n, L = 128, 0.1
+    mesh = pm.hex_block_fast(n, n, n, (L, L, L), pm.wavy(0.6 * L / n, (L, L, L)))
+    mk = lambda: product.LduSolver(mesh, 1e-4, 1e-6, [0] * 6, [(0, 0, 0)] * 6, [2] * 6, solver=1, g=(0.0, 0.0, -9.81), n_non_orth=1, u_relax=1.0, p_solver=product.FY_PSOLVER_PCG_MG)
+    s = mk()
+    Sf, V = s.geometry("Sf"), s.geometry("V")
+    own, nei = mesh["owner"], mesh["neighbour"]
+    ni = len(nei)
+    tot = np.zeros((mesh["n_cells"], 3))
+    np.add.at(tot, own, Sf); np.subtract.at(tot, nei, Sf[:ni])
+    assert np.abs(tot).max() < 1e-18 + 1e-12 * np.abs(Sf).max() and V.sum() == pytest.approx(L ** 3, rel=1e-12) and V.min() > 0
+    assert s.mg_levels() == [(n ** 3 // 8 ** q, 6) for q in range(6)]
+    s.hold_sources(True)
+    rs = np.random.RandomState(5)
+    rec = np.zeros((1_000_000, 10))
+    rec[:, 0:3] = L * rs.rand(1_000_000, 3) * np.array([1.0, 1.0, 0.6]); rec[:, 9] = 0.2 * L / n
+    s.set_particles(rec)
+    for _ in range(2):
+        s.step()
+    st = s.stats()
+    assert np.all(s.found() == 1) and st["cont_err_sum_local"] < 1e-9 and st["p_iters_total"] <= 12, st
+    dep, pvol = ((1.0 - s.get("alpha")) * V).sum(), ((4.0 / 3.0) * np.pi * rec[:, 9] ** 3).sum()
+    assert 0.97 * pvol < dep <= pvol * (1 + 1e-12)
+    assert np.isfinite(s.get("U")).all() and np.abs(s.get("U")).max() > 0
+    s.close()
+    a, b = mk(), mk()
+    lidU = np.zeros((n ** 3, 3)); lidU[:, 0] = 0.01 * np.sin(np.arange(n ** 3) * 1e-3)
+    for q in (a, b):
+        q.set("U", lidU)
+        q.step(); q.step()
+    np.testing.assert_array_equal(a.get("U"), b.get("U")); np.testing.assert_array_equal(a.get("p"), b.get("p"))
+    a.close(); b.close()
