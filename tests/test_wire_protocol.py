@@ -266,3 +266,45 @@ def test_parallel_yade_worker_without_particles_is_skipped(product):
     Fref = np.concatenate([ref.forces(b) for b in range(W - 1)])
     np.testing.assert_allclose(F, Fref, rtol=1e-9, atol=1e-12 * np.abs(Fref).max())
     fy.close(); ref.close()
+
+
+@pytest.mark.parametrize("solver", [0, 1])
+def test_general_mesh_solver_answers_yade_over_the_wire(product, solver):
+    """fy_ldu_solver next to a parallel Yade through the transport callbacks: the solver's own step receives the records (sizes, then data, per worker) and sends found
+    flags and forces back -- the forces an identical solver computes when it is handed the records directly.  icoFoamYade (point force, face-walk locate) with two
+    workers: two batches against one, the momentum source summed in another order, so from the second step on the fields agree to rounding, not to the bit;
+    pimpleFoamYade (Gaussian) with one worker: setCellVolFraction ASSIGNS per worker (FoamYade.C:318-328, the last worker that touched a cell wins), so only the same
+    split gives the same void fraction.  Wavy renumbered hexahedra"""
+    import types
+    import poly_meshes as pm
+    n, L = 8, 0.1
+    mesh = pm.hex_block(n, n, n, (L, L, L), pm.wavy(0.2 * L / n, (L, L, L)), renumber_seed=6)
+    rs = np.random.RandomState(9)
+    npart = 900
+    rec = np.zeros((npart, 10))
+    rec[:, 0:3] = L * (0.02 + 0.96 * rs.random_sample((npart, 3))); rec[:, 3:6] = 0.05 * rs.standard_normal((npart, 3)); rec[:, 9] = 0.15 * L / n
+    rec[:7, 2] = 3.0 * L                                   # a few far outside the mesh: not found (the Gaussian locate reaches 4.47 cell sizes beyond it: quirk Q8)
+    W = 1 if solver else 2
+    c = types.SimpleNamespace(n_yade=W + 1)
+    yade = FakeYade(product, c, None, [rec, rec])
+    kw = dict(solver=1, g=(0, 0, -9.81), u_relax=1.0) if solver else {}
+    pbc = [2] * 6 if solver else [0] * 6
+    mk = lambda tr: product.LduSolver(mesh, 2e-4, 1e-5, [0] * 6, [(0.2, 0, 0) if q == 3 else (0, 0, 0) for q in range(6)], pbc, transport=tr, **kw)
+    wired, direct = mk(yade.T), mk(None)
+    assert [e[:1] + e[2:] for e in yade.log] == [("send", 1, r, TAG_BBOX) for r in range(W + 1)]      # the mesh's bounding box to every Yade rank (FoamYade.C:96-108)
+    yade.log.clear(); yade.sent.clear()
+    for step in range(2):
+        wired.step()
+        direct.set_particles(rec); direct.step()
+        found = np.concatenate([yade.sent[(TAG_RES, w + 1)][0] for w in range(W)])
+        got = np.concatenate([yade.sent[(TAG_FORCE, w + 1)][0] for w in range(W)]).reshape(npart, 6)
+        np.testing.assert_array_equal(found, direct.found())
+        assert (found[:7] != 1).all() and (found[7:] == 1).sum() > 0.95 * (npart - 7)
+        ref = direct.forces()
+        if step == 0 and not solver:                     # (point force: no sum in the way; the Gaussian deposits are summed in whatever order the lanes arrive)
+            np.testing.assert_array_equal(got, ref)
+        np.testing.assert_allclose(got, ref, rtol=0, atol=1e-9 * np.abs(ref).max())
+        assert np.abs(got).max() > 0
+        yade.next_step()
+    np.testing.assert_allclose(wired.get("U"), direct.get("U"), rtol=0, atol=1e-9 * np.abs(direct.get("U")).max())
+    wired.close(); direct.close()

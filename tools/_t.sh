@@ -1,3 +1,3 @@
 #!/bin/bash
 cd /root/repo
-python -m pytest tests/test_ldu_parity.py -m gpu -x -q -k bench_size 2>&1 | tail -15
+python -m pytest tests/test_wire_protocol.py -m gpu -x -q -k general_mesh 2>&1 | grep -E "^E  |passed|failed" | head -14
