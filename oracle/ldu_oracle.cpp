@@ -49,7 +49,7 @@ extern "C" struct orc_ldu_case {
     int turbulence_model;                                       // 0 laminar, 1 LES Smagorinsky (delta cubeRootVol)
     double les_ck, les_ce, les_delta_coeff, nut_initial;
     const int* nut_bc; const double* nut_value;                 // per patch: 0 zeroGradient, 1 fixedValue
-    int convection_scheme;                                      // 0 Gauss linear, 1 Gauss upwind
+    int convection_scheme;                                      // 0 Gauss linear, 1 Gauss upwind, 2 Gauss linearUpwind grad(U)
 };
 extern "C" struct orc_ldu_stats {
     double courant_mean, courant_max, cont_sum_local, cont_global, cont_cumulative;
@@ -310,7 +310,7 @@ struct Ldu {
             const double fl = alphaf[f] * phi[f];
             // - fvm::laplacian(alpha nuEff, U): the cell field alpha (nu + nut) interpolated linearly [OF-6 gaussLaplacianScheme::fvmLaplacian(vol gamma)]
             const double g = (nut.empty() ? cs.nu * alphaf[f] : w[f] * alpha[own[f]] * (cs.nu + nut[own[f]]) + (1.0 - w[f]) * alpha[nei[f]] * (cs.nu + nut[nei[f]])) * magSf[f];
-            double lo = -(cs.convection_scheme == 1 ? (fl >= 0.0 ? 1.0 : 0.0) : w[f]) * fl, up = lo + fl;
+            double lo = -(cs.convection_scheme >= 1 ? (fl >= 0.0 ? 1.0 : 0.0) : w[f]) * fl, up = lo + fl;
             lo -= g * dcNO[f]; up -= g * dcNO[f];
             lower[f] = lo; upper[f] = up;
             diag[own[f]] -= lo; diag[nei[f]] -= up;
@@ -336,6 +336,7 @@ struct Ldu {
             if (u_bc[pa] == 0) { bint[b] += g; for (int q = 0; q < 3; ++q) bsrc[3 * (size_t)b + q] += (-phi[f] + g) * u_val[3 * pa + q]; }
             else bint[b] += phi[f];
         }
+        if (cs.convection_scheme == 2) { vec aphi(nFaces); for (int f = 0; f < nFaces; ++f) aphi[f] = alphaf[f] * phi[f]; linear_upwind_source(aphi); }
         for (size_t c = 0; c < nc; ++c) {
             const double S = divAPhi[c] / V[c];                          // + fvc::ddt(alphac) = 0
             diag[c] -= V[c] * S;
@@ -498,7 +499,7 @@ struct Ldu {
         for (int f = 0; f < nInt; ++f) {
             // gaussConvectionScheme<linear>::fvmDiv: lower = -w phi, upper = lower + phi, negSumDiag
             // ... or upwind [OF-6 upwind::weights]: the owner's weight is pos0(flux)
-            double lo = -(cs.convection_scheme == 1 ? (phi[f] >= 0.0 ? 1.0 : 0.0) : w[f]) * phi[f], up = lo + phi[f];
+            double lo = -(cs.convection_scheme >= 1 ? (phi[f] >= 0.0 ? 1.0 : 0.0) : w[f]) * phi[f], up = lo + phi[f];
             // - gaussLaplacianScheme::fvmLaplacianUncorrected: upper = lower = gamma |Sf| nonOrthDeltaCoeffs, negSumDiag
             const double g = cs.nu * magSf[f] * dcNO[f];
             lo -= g; up -= g;
@@ -527,8 +528,22 @@ struct Ldu {
                 src[3 * (size_t)own[f] + j] += g * corr; src[3 * (size_t)nei[f] + j] -= g * corr;
             }
         }
+        linear_upwind_source(phi);
     }
     vec vGradNow;                                                // grad(U) of the iterate the momentum matrix is assembled from
+    // Gauss linearUpwind grad(U) [OF-6 linearUpwind::correction]: face value = upwind cell value + (C_f - C_upwind) . grad(U)_upwind, the second term explicit: its
+    // flux leaves the owner's source and enters the neighbour's
+    void linear_upwind_source(const vec& flux) {
+        if (cs.convection_scheme != 2) return;
+        for (int f = 0; f < nInt; ++f) {
+            const int up = flux[f] >= 0.0 ? own[f] : nei[f];
+            const V3 d = Cf[f] - C[up];
+            for (int j = 0; j < 3; ++j) {
+                const double lu = flux[f] * ((d.x * vGradNow[9 * (size_t)up + j] + d.y * vGradNow[9 * (size_t)up + 3 + j]) + d.z * vGradNow[9 * (size_t)up + 6 + j]);
+                src[3 * (size_t)own[f] + j] -= lu; src[3 * (size_t)nei[f] + j] += lu;
+            }
+        }
+    }
 
     double dgc(int c) const { double d = diag[c]; for (int f : cfaces[c]) if (f >= nInt) d += bint[f - nInt]; return d; }
     void total_source(vec& b) const {

@@ -117,7 +117,7 @@ def test_prism_polyMesh_case_is_read(prod, tmp_path):
 @pytest.mark.parametrize("edit,needle", [
     (("system/fvSchemes", "Gauss linear corrected", "Gauss linear uncorrected"), "must be 'corrected'"),
     (("system/fvSchemes", "default corrected", "default orthogonal"), "must be 'corrected'"),
-    (("system/fvSchemes", "div(phi,U)       Gauss linear", "div(phi,U)       Gauss linearUpwind grad(U)"), "Gauss linear or Gauss upwind"),
+    (("system/fvSchemes", "div(phi,U)       Gauss linear", "div(phi,U)       Gauss vanLeer"), "Gauss linear, Gauss upwind or Gauss linearUpwind"),
     (("constant/polyMesh/boundary", "type            wall;", "type            symmetryPlane;"), "symmetryPlane"),
     (("0/U", "noSlip", "slip"), "slip"),
     (("0/p", "zeroGradient", "fixedFluxPressure"), "fixedFluxPressure"),

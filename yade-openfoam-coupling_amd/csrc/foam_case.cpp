@@ -805,8 +805,8 @@ int check_general_schemes(const fy_foam_case* c) {
     const std::string path = join(c->dir, "system/fvSchemes");
     FoamDict d;
     FY_TRY(need_file(path, &d));
-    if (c->desc.convection_scheme != FY_CONVECTION_LINEAR && c->desc.convection_scheme != FY_CONVECTION_UPWIND)
-        return fail(FY_ERR_UNSUPPORTED, "%s: on a general mesh the convection term must be Gauss linear or Gauss upwind", path.c_str());
+    if (c->desc.convection_scheme != FY_CONVECTION_LINEAR && c->desc.convection_scheme != FY_CONVECTION_UPWIND && c->desc.convection_scheme != FY_CONVECTION_LINEAR_UPWIND)
+        return fail(FY_ERR_UNSUPPORTED, "%s: on a general mesh the convection term must be Gauss linear, Gauss upwind or Gauss linearUpwind grad(U)", path.c_str());
     if (c->desc.turbulence_model != FY_TURBULENCE_LAMINAR && c->desc.turbulence_model != FY_TURBULENCE_SMAGORINSKY)
         return fail(FY_ERR_UNSUPPORTED, "%s: on a general mesh the laminar (Stokes) model and LES Smagorinsky are carried, not kEqn / kEpsilon (constant/turbulenceProperties)", c->dir.c_str());
     for (const char* dn : {"laplacianSchemes", "snGradSchemes"}) {

@@ -39,7 +39,7 @@ struct LduGeo {
     const double* recon;                                 // [9 nc]
     const double* psn;                                   // [nF - nInt] snGrad(p) of the fixedFluxPressure faces (pimpleFoamYade; else null)
     double dt, nu;
-    int upwind;                                          // div(phi,U): Gauss upwind (the owner's weight is pos0(flux)) instead of Gauss linear
+    int upwind;                                          // div(phi,U): 0 Gauss linear; 1 Gauss upwind (the owner's weight is pos0(flux)); 2 Gauss linearUpwind grad(U) (upwind + an explicit gradient correction)
     int need_ref, p_ref_cell;
     double p_ref_value;
 };

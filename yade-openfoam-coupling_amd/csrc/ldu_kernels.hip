@@ -119,6 +119,17 @@ __global__ __launch_bounds__(256) void k_ldu_grad_scalar(LduGeo g, const double*
     if (c < g.nCells) st3(gp, c, grad_scalar_at(g, p, c));
 }
 
+// Gauss linearUpwind grad(U) [OF-6 linearUpwind::correction]: the face value is the upwind cell's plus (C_f - C_upwind) . grad(U)_upwind, the second term explicit
+// (deferred correction) with the Gauss-linear gradient of the iterate the matrix is assembled from; returned as the flux of it, fl (d . grad U)_j
+__device__ __forceinline__ void linear_upwind_flux(const LduGeo& g, int f, double fl, const double* __restrict__ gradU, double (&lu)[3]) {
+    const int up = fl >= 0.0 ? g.own[f] : g.nei[f];
+    const D3 cf = ld3(g.Cf, f), cu = ld3(g.C, up);
+    const double d[3] = {cf.x - cu.x, cf.y - cu.y, cf.z - cu.z};
+    const double* T = gradU + 9 * (size_t)up;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) lu[j] = fl * ((d[0] * T[j] + d[1] * T[3 + j]) + d[2] * T[6 + j]);
+}
+
 // UEqn, face part: gaussConvectionScheme<linear>::fvmDiv (lower = -w phi, upper = lower + phi) minus gaussLaplacianScheme::fvmLaplacianUncorrected
 // (gamma |Sf| nonOrthDeltaCoeffs on both), and the corrected scheme's explicit flux nu |Sf| (k & linearInterpolate(grad U)) per internal face
 __global__ __launch_bounds__(256) void k_ldu_mom_faces(LduGeo g, const double* __restrict__ phi, const double* __restrict__ gradU, LduMom M, double* __restrict__ corr) {
@@ -134,12 +145,14 @@ __global__ __launch_bounds__(256) void k_ldu_mom_faces(LduGeo g, const double* _
     const double* To = gradU + 9 * (size_t)g.own[f];
     const double* Tn = gradU + 9 * (size_t)g.nei[f];
     const double w = g.w[f];
+    double lu[3] = {0, 0, 0};
+    if (g.upwind == 2) linear_upwind_flux(g, f, phi[f], gradU, lu);
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         double cj = 0.0;
 #pragma unroll
         for (int i = 0; i < 3; ++i) cj += kk[i] * (w * To[3 * i + j] + (1.0 - w) * Tn[3 * i + j]);
-        corr[3 * (size_t)f + j] = gm * cj;
+        corr[3 * (size_t)f + j] = gm * cj - lu[j];
     }
 }
 // ... cell part: EulerDdtScheme::fvmDdt, negSumDiag, the patches' coefficients (fixedValue: value* 0 / U_b, gradient* -+ deltaCoeffs; zeroGradient: value* 1),
@@ -455,6 +468,8 @@ __global__ __launch_bounds__(256) void k_ldu_pmom_faces(LduGeo g, LduPim P, cons
     M.lower[f] = lo; M.upper[f] = up;
     const D3 k = ld3(g.kvec, f);
     const double kk[3] = {k.x, k.y, k.z};
+    double lu[3] = {0, 0, 0};
+    if (g.upwind == 2) linear_upwind_flux(g, f, fl, gradU, lu);
 #pragma unroll
     for (int b = 0; b < 3; ++b) {
         double cj = 0.0, t = 0.0;
@@ -464,7 +479,7 @@ __global__ __launch_bounds__(256) void k_ldu_pmom_faces(LduGeo g, LduPim P, cons
             const double go = ao * (To[3 * b + a] - (a == b ? (2.0 / 3.0) * tro : 0.0)), gn = an * (Tn[3 * b + a] - (a == b ? (2.0 / 3.0) * trn : 0.0));
             t += ss[a] * (w * go + (1.0 - w) * gn);
         }
-        corr[3 * (size_t)f + b] = gm * cj;
+        corr[3 * (size_t)f + b] = gm * cj - lu[b];
         fstress[3 * (size_t)f + b] = t;
     }
 }

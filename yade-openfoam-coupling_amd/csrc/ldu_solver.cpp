@@ -73,7 +73,8 @@ struct LduSolver {
         if (c->turbulence_model != FY_TURBULENCE_LAMINAR && !(pimple && c->turbulence_model == FY_TURBULENCE_SMAGORINSKY))
             return fail(FY_ERR_UNSUPPORTED, "fy_ldu_solver: turbulence model %d (laminar; LES Smagorinsky with pimpleFoamYade)", c->turbulence_model);
         les = pimple && c->turbulence_model == FY_TURBULENCE_SMAGORINSKY;
-        if (c->convection_scheme != FY_CONVECTION_LINEAR && c->convection_scheme != FY_CONVECTION_UPWIND) return fail(FY_ERR_UNSUPPORTED, "fy_ldu_solver: convection scheme %d (Gauss linear, Gauss upwind)", c->convection_scheme);
+        if (c->convection_scheme != FY_CONVECTION_LINEAR && c->convection_scheme != FY_CONVECTION_UPWIND && c->convection_scheme != FY_CONVECTION_LINEAR_UPWIND)
+            return fail(FY_ERR_UNSUPPORTED, "fy_ldu_solver: convection scheme %d (Gauss linear, Gauss upwind, Gauss linearUpwind)", c->convection_scheme);
         if (les && !(c->les_ck > 0 && c->les_ce > 0 && c->les_delta_coeff > 0)) return fail(FY_ERR_INVALID, "fy_ldu_solver: Smagorinsky needs Ck, Ce and the delta coefficient positive");
         nc = hm.nCells; nf = hm.nFaces; ni = hm.nInt;
         std::vector<int32_t> ubc(c->u_bc, c->u_bc + hm.nPatches), pbc(c->p_bc, c->p_bc + hm.nPatches);
@@ -96,7 +97,7 @@ struct LduSolver {
         FY_TRY(up(d_recon, hm.recon));
         if (pimple) { FY_TRY(psn.alloc_exact(std::max<size_t>((size_t)(nf - ni), 1))); FY_TRY(zero(psn)); }
         g = LduGeo{nc, nf, ni, hm.nPatches, d_own.p, d_nei.p, d_patch_of.p, d_cf_off.p, d_cf_face.p, hm.Wall, d_ef.p, d_en.p, d_Cf.p, d_Sf.p, d_magSf.p, d_C.p, d_V.p, d_w.p, d_dcNO.p, d_kvec.p,
-                   d_ubc.p, d_pbc.p, d_uval.p, d_pval.p, d_recon.p, pimple ? psn.p : nullptr, cs.dt, cs.nu, cs.convection_scheme == FY_CONVECTION_UPWIND ? 1 : 0, need_ref ? 1 : 0, cs.p_ref_cell, cs.p_ref_value};
+                   d_ubc.p, d_pbc.p, d_uval.p, d_pval.p, d_recon.p, pimple ? psn.p : nullptr, cs.dt, cs.nu, cs.convection_scheme == FY_CONVECTION_UPWIND ? 1 : (cs.convection_scheme == FY_CONVECTION_LINEAR_UPWIND ? 2 : 0), need_ref ? 1 : 0, cs.p_ref_cell, cs.p_ref_value};
         total_volume = 0.0;
         for (double v : hm.V) total_volume += v;
         const size_t n = (size_t)nc;
