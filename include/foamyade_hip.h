@@ -450,7 +450,7 @@ int fy_solver_get_kernel_timing(fy_solver*, const char* kernel, double* total_ms
  * pEqn.H:24-47); fy_solver above is the structured block.  fy_ldu_solver takes the mesh in OpenFOAM's own addressing -- constant/polyMesh: points,
  * faces, owner, neighbour, boundary -- builds OpenFOAM's geometry from it (face triangle / cell pyramid decomposition, linear weights,
  * nonOrthDeltaCoeffs, nonOrthCorrectionVectors, fvc::reconstruct's tensors [OF-6]) and runs the loop bodies with owner / neighbour (LDU) addressing:
- * Euler ddt, Gauss linear | upwind | linearUpwind div, Gauss linear grad, Gauss linear CORRECTED laplacian (the explicit non-orthogonal part is what the
+ * Euler ddt, Gauss linear | upwind | linearUpwind | limited (NVD / TVD) div, Gauss linear grad, Gauss linear CORRECTED laplacian (the explicit non-orthogonal part is what the
  * correctNonOrthogonal loop iterates on), PCG in its single-reduction form with the diagonal or an agglomeration-multigrid preconditioner (p_solver),
  * Jacobi sweeps for U.  Patches: fixedValue / zeroGradient for U (noSlip = fixedValue 0); zeroGradient / fixedValue for p, fixedFluxPressure with
  * pimpleFoamYade.  pimpleFoamYade (fy_ldu_case.solver): Gaussian 4-way coupling, the void-fraction-weighted UcEqn / pEqn, gravity, PIMPLE outer correctors,
@@ -495,7 +495,8 @@ typedef struct fy_ldu_case {
     double les_ck, les_ce, les_delta_coeff, nut_initial;
     const int32_t* nut_bc;           /* per patch: FY_BC_NUT_ZERO_GRADIENT | FY_BC_NUT_FIXED_VALUE (NULL: zeroGradient everywhere) */
     const double* nut_value;         /* [n_patches] */
-    int32_t convection_scheme;       /* FY_CONVECTION_LINEAR (default) | FY_CONVECTION_UPWIND | FY_CONVECTION_LINEAR_UPWIND for div(phi,U) / div(alphaPhic,Uc) */
+    int32_t convection_scheme;       /* FY_CONVECTION_LINEAR (default) .. FY_CONVECTION_QUICK for div(phi,U) / div(alphaPhic,Uc), as fy_case_desc.convection_scheme */
+    double convection_limiter_k;     /* limitedLinear's coefficient in [0, 1] */
 } fy_ldu_case;
 typedef struct fy_ldu_solver fy_ldu_solver;
 void fy_ldu_case_defaults(fy_ldu_case*);        /* the icoFoam cavity tutorial's controls (as fy_case_defaults); the patch arrays stay NULL */

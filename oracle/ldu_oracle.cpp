@@ -49,7 +49,8 @@ extern "C" struct orc_ldu_case {
     int turbulence_model;                                       // 0 laminar, 1 LES Smagorinsky (delta cubeRootVol)
     double les_ck, les_ce, les_delta_coeff, nut_initial;
     const int* nut_bc; const double* nut_value;                 // per patch: 0 zeroGradient, 1 fixedValue
-    int convection_scheme;                                      // 0 Gauss linear, 1 Gauss upwind, 2 Gauss linearUpwind grad(U)
+    int convection_scheme;                                      // 0 Gauss linear, 1 Gauss upwind, 2 Gauss linearUpwind grad(U), 3 .. 8 limitedLinear k / vanLeer / MUSCL / Minmod / SuperBee / QUICK
+    double convection_limiter_k;
 };
 extern "C" struct orc_ldu_stats {
     double courant_mean, courant_max, cont_sum_local, cont_global, cont_cumulative;
@@ -286,6 +287,7 @@ struct Ldu {
     // [OF-6 linearViscousStress::divDevRhoReff = - fvm::laplacian(alpha nu, U) - fvc::div(alpha nu dev2(T(grad U)))].  alphac.oldTime() == alphac (fv_oracle.cpp, quirk F-Q1)
     void assemble_momentum_pimple(double u_relax_now) {
         const size_t nc = nCells;
+        if (cs.convection_scheme >= 3) limiter_gradient(U);
         std::fill(diag.begin(), diag.end(), 0.0); std::fill(src.begin(), src.end(), 0.0);
         std::fill(bint.begin(), bint.end(), 0.0); std::fill(bsrc.begin(), bsrc.end(), 0.0);
         vec divAPhi(nc, 0.0), offsum(nc, 0.0), G(9 * nc);
@@ -310,7 +312,7 @@ struct Ldu {
             const double fl = alphaf[f] * phi[f];
             // - fvm::laplacian(alpha nuEff, U): the cell field alpha (nu + nut) interpolated linearly [OF-6 gaussLaplacianScheme::fvmLaplacian(vol gamma)]
             const double g = (nut.empty() ? cs.nu * alphaf[f] : w[f] * alpha[own[f]] * (cs.nu + nut[own[f]]) + (1.0 - w[f]) * alpha[nei[f]] * (cs.nu + nut[nei[f]])) * magSf[f];
-            double lo = -(cs.convection_scheme >= 1 ? (fl >= 0.0 ? 1.0 : 0.0) : w[f]) * fl, up = lo + fl;
+            double lo = -conv_weight(f, fl) * fl, up = lo + fl;
             lo -= g * dcNO[f]; up -= g * dcNO[f];
             lower[f] = lo; upper[f] = up;
             diag[own[f]] -= lo; diag[nei[f]] -= up;
@@ -490,6 +492,7 @@ struct Ldu {
     // UEqn (icoFoamYade.C:79-85): ddt(U) + div(phi,U) - laplacian(nu,U) == uSource
     void assemble_momentum() {
         const size_t nc = nCells;
+        if (cs.convection_scheme >= 3) limiter_gradient(U);      // (the limiter sees the current U: the scheme is built when UEqn is assembled)
         std::fill(diag.begin(), diag.end(), 0.0); std::fill(src.begin(), src.end(), 0.0);
         std::fill(bint.begin(), bint.end(), 0.0); std::fill(bsrc.begin(), bsrc.end(), 0.0);
         for (size_t c = 0; c < nc; ++c) {                        // EulerDdtScheme::fvmDdt
@@ -499,7 +502,7 @@ struct Ldu {
         for (int f = 0; f < nInt; ++f) {
             // gaussConvectionScheme<linear>::fvmDiv: lower = -w phi, upper = lower + phi, negSumDiag
             // ... or upwind [OF-6 upwind::weights]: the owner's weight is pos0(flux)
-            double lo = -(cs.convection_scheme >= 1 ? (phi[f] >= 0.0 ? 1.0 : 0.0) : w[f]) * phi[f], up = lo + phi[f];
+            double lo = -conv_weight(f, phi[f]) * phi[f], up = lo + phi[f];
             // - gaussLaplacianScheme::fvmLaplacianUncorrected: upper = lower = gamma |Sf| nonOrthDeltaCoeffs, negSumDiag
             const double g = cs.nu * magSf[f] * dcNO[f];
             lo -= g; up -= g;
@@ -529,6 +532,36 @@ struct Ldu {
             }
         }
         linear_upwind_source(phi);
+    }
+    // NVD / TVD limited schemes [OF-6 LimitedScheme<vector, Limiter<NVDTVD>, limitFuncs::magSqr>], as fv_oracle.cpp: one limiter per face from lPhi = magSqr(U),
+    // r = 2 (d . grad(lPhi)_C) / (lPhi_N - lPhi_P) - 1 (C the upwind cell, d = C_N - C_P), owner's weight limiter w + (1 - limiter) pos0(flux)
+    vec lphi; std::vector<V3> gradL;
+    void limiter_gradient(const vec& F) {
+        lphi.assign(nCells, 0.0);
+        for (int c = 0; c < nCells; ++c) lphi[c] = (F[3 * (size_t)c] * F[3 * (size_t)c] + F[3 * (size_t)c + 1] * F[3 * (size_t)c + 1]) + F[3 * (size_t)c + 2] * F[3 * (size_t)c + 2];
+        grad_scalar(lphi, [&](int f) { const V3 b = Ub(F, f); return (b.x * b.x + b.y * b.y) + b.z * b.z; }, gradL);
+    }
+    static double limiter_fn(int scheme, double twoByk, double r) {
+        switch (scheme) {
+            case 3: return std::max(std::min(twoByk * r, 1.0), 0.0);
+            case 4: return (r + std::fabs(r)) / (1.0 + std::fabs(r));
+            case 5: return std::max(std::min(std::min(2.0 * r, 0.5 * r + 0.5), 2.0), 0.0);
+            case 6: return std::max(std::min(std::min(r, 1.0), 2.0), 0.0);
+            case 7: return std::max(std::max(std::min(2.0 * r, 1.0), std::min(r, 2.0)), 0.0);
+            default: return std::max(std::min((3.0 + r) / 4.0, 2.0), 0.0);
+        }
+    }
+    double conv_weight(int f, double fl) const {                 // the owner's weight of the convected value on internal face f
+        if (cs.convection_scheme == 0) return w[f];
+        const double up = fl >= 0.0 ? 1.0 : 0.0;
+        if (cs.convection_scheme <= 2) return up;
+        const double gradf = lphi[nei[f]] - lphi[own[f]];
+        const double gradcf = dot(C[nei[f]] - C[own[f]], gradL[fl > 0.0 ? own[f] : nei[f]]);
+        double r;
+        if (std::fabs(gradcf) >= 1000.0 * std::fabs(gradf)) r = 2.0 * 1000.0 * (gradcf >= 0 ? 1.0 : -1.0) * (gradf >= 0 ? 1.0 : -1.0) - 1.0;
+        else r = 2.0 * (gradcf / gradf) - 1.0;
+        const double lim = limiter_fn(cs.convection_scheme, 2.0 / std::max(cs.convection_limiter_k, SMALL), r);
+        return lim * w[f] + (1.0 - lim) * up;
     }
     vec vGradNow;                                                // grad(U) of the iterate the momentum matrix is assembled from
     // Gauss linearUpwind grad(U) [OF-6 linearUpwind::correction]: face value = upwind cell value + (C_f - C_upwind) . grad(U)_upwind, the second term explicit: its

@@ -79,7 +79,7 @@ def test_couette_is_steady_on_a_sheared_mesh(oracle, renumber):
     s.close()
 
 
-@pytest.mark.parametrize("scheme", [0, 1, 2])
+@pytest.mark.parametrize("scheme", [0, 1, 2, 3, 4, 7, 8])
 def test_general_mesh_reproduces_the_structured_restatement_on_a_lattice(oracle, scheme):
     """a uniform block written as a polyhedral mesh (cells renumbered at random) against fv_oracle.cpp on the same block: the lid-driven cavity over five
     steps, with the structured side's Jacobi-preconditioned PCG (the same algorithm as the general side's)"""
@@ -88,8 +88,8 @@ def test_general_mesh_reproduces_the_structured_restatement_on_a_lattice(oracle,
     u_val[3] = (1.0, 0, 0)
     mesh = pm.hex_block(n, n, n, renumber_seed=11)
     tol = dict(p_tol=1e-11, p_rel_tol=0.0, p_final_tol=1e-11, u_tol=1e-11)
-    g = make(mesh, 0.4 / n, 0.01, u_val=u_val, convection_scheme=scheme, **tol)          # scheme 1: Gauss upwind, 2: Gauss linearUpwind grad(U)
-    f = orc.FvSolver(orc.fv_case(0, n, n, n, 1.0 / n, 0.4 / n, 0.01, u_bc=[0] * 6, u_val=u_val, p_solver=0, p_final_tol=1e-11, p_final_rel_tol=0.0, convection_scheme=scheme,
+    g = make(mesh, 0.4 / n, 0.01, u_val=u_val, convection_scheme=scheme, convection_limiter_k=0.6, **tol)          # 1 upwind, 2 linearUpwind, 3 limitedLinear 0.6, 4 vanLeer, 7 SuperBee, 8 QUICK
+    f = orc.FvSolver(orc.fv_case(0, n, n, n, 1.0 / n, 0.4 / n, 0.01, u_bc=[0] * 6, u_val=u_val, p_solver=0, p_final_tol=1e-11, p_final_rel_tol=0.0, convection_scheme=scheme, limiter_k=0.6,
                                  **{k: v for k, v in tol.items() if k != "p_final_tol"}))
     rs = np.random.RandomState(3)
     U0 = rs.rand(n ** 3, 3) * 0.05
@@ -185,7 +185,7 @@ def test_prisms_geometry(oracle):
     s.close()
 
 
-@pytest.mark.parametrize("n_outer,relax,adjust,les", [(1, 0.0, 0, 0), (2, 0.7, 0, 0), (1, 0.0, 1, 0), (2, 0.0, 0, 1), (1, 0.0, 0, 2), (2, 0.0, 0, 3)])
+@pytest.mark.parametrize("n_outer,relax,adjust,les", [(1, 0.0, 0, 0), (2, 0.7, 0, 0), (1, 0.0, 1, 0), (2, 0.0, 0, 1), (1, 0.0, 0, 2), (2, 0.0, 0, 3), (1, 0.0, 0, 6)])
 def test_pimple_on_a_lattice_reproduces_the_structured_restatement(oracle, n_outer, relax, adjust, les):
     """pimpleFoamYade's void-fraction-weighted equations (UcEqn.H, pEqn.H: gravity, fixedFluxPressure walls, PIMPLE outer correctors, relaxation) restated for a general
     mesh, against fv_oracle.cpp on the same block with a cloud: the general side is given the void fraction, the implicit drag coefficient and the explicit source the
@@ -198,7 +198,7 @@ def test_pimple_on_a_lattice_reproduces_the_structured_restatement(oracle, n_out
                adjust_time_step=adjust, max_co=0.4, max_delta_t=3.2e-4)          # (adjustable: the step grows by 1.2 per step while the Courant number allows)
     if les == 1:                                         # LES Smagorinsky: nuEff in both parts of divDevRhoReff, nut renewed after the last outer corrector
         rel.update(turbulence_model=1, nut_initial=3e-5, les_delta_coeff=0.8)
-    if les >= 2:                                         # (the fifth and sixth variants: Gauss upwind / Gauss linearUpwind for div(alphaPhic, Uc))
+    if les >= 2:                                         # (the last variants: Gauss upwind / linearUpwind / MUSCL for div(alphaPhic, Uc))
         rel.update(convection_scheme=les - 1)
     f = orc.FvSolver(orc.fv_case(1, n, n, n, dx, 2e-4, 1e-5, g=(0, 0, -9.81), p_bc=[2] * 6, p_solver=0, n_outer=n_outer, n_corr=2, p_final_rel_tol=0.0, p_max_iter=5000, **rel, **tol))
     g = orc.LduSolver(mesh, 2e-4, 1e-5, [0] * 6, [(0, 0, 0)] * 6, [2] * 6, solver=1, g=(0, 0, -9.81), n_outer=n_outer, n_correctors=2, **rel, **tol)

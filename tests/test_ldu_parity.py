@@ -36,20 +36,22 @@ def test_geometry_equals_the_restatement(product, oracle):
     h.close(); o.close()
 
 
-@pytest.mark.parametrize("kind", ["lattice", "sheared", "wavy_renumbered", "prisms", "tetrahedra", "wavy_upwind", "wavy_linear_upwind"])
+@pytest.mark.parametrize("kind", ["lattice", "sheared", "wavy_renumbered", "prisms", "tetrahedra", "wavy_upwind", "wavy_linear_upwind", "wavy_vanLeer", "wavy_limitedLinear"])
 def test_cavity_matches_the_restatement(product, oracle, kind):
     """lid-driven cavity, four steps, two non-orthogonal correctors: first-step matrices, then fields and counters.  prisms: triangular prisms on a wavy
     lattice (triangular and quadrilateral faces, five-faced cells)"""
     n = 10
     vm, seed = {"lattice": (None, None), "sheared": (pm.shear(0.3, 0.0, 0.2), None), "wavy_renumbered": (pm.wavy(0.03), 9), "prisms": (pm.wavy(0.02), None), "tetrahedra": (None, None),
-                "wavy_upwind": (pm.wavy(0.03), 9), "wavy_linear_upwind": (pm.wavy(0.03), 9)}[kind]
+                "wavy_upwind": (pm.wavy(0.03), 9), "wavy_linear_upwind": (pm.wavy(0.03), 9), "wavy_vanLeer": (pm.wavy(0.03), 9),
+                "wavy_limitedLinear": (pm.wavy(0.03), 9)}[kind]
     if kind == "tetrahedra":            # Kuhn tetrahedra on a wavy lattice: triangles only, four-faced cells, non-orthogonality around 50 degrees
         mesh = pm.tet_block(6, 6, 5, vertex_map=pm.wavy(0.02))
     else:
         mesh = pm.prism_block(n, n, 6, vertex_map=vm) if kind == "prisms" else pm.hex_block(n, n, n, vertex_map=vm, renumber_seed=seed)
     kw = dict(n_non_orth=2, p_tol=1e-9, p_rel_tol=0.0, p_final_tol=1e-9, u_tol=1e-9, p_max_iter=5000)
-    if kind in ("wavy_upwind", "wavy_linear_upwind"):
-        kw["convection_scheme"] = 1 if kind == "wavy_upwind" else 2          # Gauss upwind / Gauss linearUpwind grad(U)
+    if kind.startswith("wavy_") and kind != "wavy_renumbered":          # Gauss upwind / linearUpwind grad(U) / vanLeer / limitedLinear 0.5
+        kw["convection_scheme"] = {"wavy_upwind": 1, "wavy_linear_upwind": 2, "wavy_vanLeer": 4, "wavy_limitedLinear": 3}[kind]
+        kw["convection_limiter_k"] = 0.5
     h, o = pair(product, oracle, mesh, 0.4 / n, 0.01, [0] * 6, lid(), [0] * 6, **kw)
     U0 = np.random.RandomState(3).rand(mesh["n_cells"], 3) * 0.05
     h.set("U", U0); o.set("U", U0)
@@ -200,7 +202,7 @@ def bed_particles(rs, npart, box, dx):
     return rec
 
 
-@pytest.mark.parametrize("n_outer,relax,adjust,les", [(1, 0.0, 0, 0), (2, 0.7, 0, 0), (1, 0.0, 1, 0), (2, 0.0, 0, 1), (1, 0.0, 0, 2), (2, 0.0, 0, 3)])
+@pytest.mark.parametrize("n_outer,relax,adjust,les", [(1, 0.0, 0, 0), (2, 0.7, 0, 0), (1, 0.0, 1, 0), (2, 0.0, 0, 1), (1, 0.0, 0, 2), (2, 0.0, 0, 3), (1, 0.0, 0, 6)])
 def test_pimple_on_a_lattice_equals_the_structured_hip_solver(product, n_outer, relax, adjust, les):
     """pimpleFoamYade's equations (void-fraction-weighted UcEqn / pEqn, gravity, fixedFluxPressure walls, PIMPLE outer correctors, relaxation) through both HIP
     solvers: fy_solver on the block with particles, and fy_ldu_solver on the block written as a polyhedral mesh, fed the void fraction and the momentum sources the
@@ -214,7 +216,7 @@ def test_pimple_on_a_lattice_equals_the_structured_hip_solver(product, n_outer, 
                adjust_time_step=adjust, max_co=0.4, max_delta_t=3.2e-4)          # (setDeltaT.H: the step grows by 1.2 per step while the Courant number allows)
     if les == 1:                                         # LES Smagorinsky
         rel.update(turbulence_model=1, nut_initial=3e-5, les_delta_coeff=0.8)
-    if les >= 2:                                         # (the fifth and sixth variants: Gauss upwind, Gauss linearUpwind)
+    if les >= 2:                                         # (the last variants: Gauss upwind, linearUpwind, MUSCL)
         rel.update(convection_scheme=les - 1)
     case = product.make_case(1, n, n, n, dx, 2e-4, 1e-5, g=(0, 0, -9.81), p_bc=[2] * 6, p_solver=0, n_outer_correctors=n_outer, n_correctors=2, p_max_iter=5000, **rel, **kw)
     f = product.Solver(case)
@@ -356,7 +358,7 @@ def test_malformed_meshes_and_cases_are_refused_by_name(product):
         (base, dict(p_solver=7), "p_solver"),
         (base, dict(solver=3), "solver"),
         (base, dict(turbulence_model=product.TURBULENCE_KEPSILON, solver=1), "turbulence"),
-        (base, dict(convection_scheme=4), "convection"),
+        (base, dict(convection_scheme=9), "convection"),
     ]
     for mesh, kw, needle in cases:
         with pytest.raises(product.FoamYadeError, match=needle):

@@ -90,7 +90,7 @@ class LduCase(C.Structure):
                 ("p_value", _dp), ("solver", C.c_int32), ("n_outer_correctors", C.c_int32), ("g", C.c_double * 3), ("u_relax", C.c_double), ("u_relax_final", C.c_double),
                 ("p_relax", C.c_double), ("p_relax_final", C.c_double), ("adjust_time_step", C.c_int32), ("max_co", C.c_double), ("max_delta_t", C.c_double),
                 ("turbulence_model", C.c_int32), ("les_ck", C.c_double), ("les_ce", C.c_double), ("les_delta_coeff", C.c_double), ("nut_initial", C.c_double), ("nut_bc", _ip),
-                ("nut_value", _dp), ("convection_scheme", C.c_int32)]
+                ("nut_value", _dp), ("convection_scheme", C.c_int32), ("convection_limiter_k", C.c_double)]
 
 
 class ParticleTimings(C.Structure):

@@ -805,8 +805,6 @@ int check_general_schemes(const fy_foam_case* c) {
     const std::string path = join(c->dir, "system/fvSchemes");
     FoamDict d;
     FY_TRY(need_file(path, &d));
-    if (c->desc.convection_scheme != FY_CONVECTION_LINEAR && c->desc.convection_scheme != FY_CONVECTION_UPWIND && c->desc.convection_scheme != FY_CONVECTION_LINEAR_UPWIND)
-        return fail(FY_ERR_UNSUPPORTED, "%s: on a general mesh the convection term must be Gauss linear, Gauss upwind or Gauss linearUpwind grad(U)", path.c_str());
     if (c->desc.turbulence_model != FY_TURBULENCE_LAMINAR && c->desc.turbulence_model != FY_TURBULENCE_SMAGORINSKY)
         return fail(FY_ERR_UNSUPPORTED, "%s: on a general mesh the laminar (Stokes) model and LES Smagorinsky are carried, not kEqn / kEpsilon (constant/turbulenceProperties)", c->dir.c_str());
     for (const char* dn : {"laplacianSchemes", "snGradSchemes"}) {
@@ -1361,7 +1359,7 @@ int fy_foam_case_ldu_desc(const fy_foam_case* c, fy_ldu_case* out) {
     out->adjust_time_step = d.adjust_time_step; out->max_co = d.max_co; out->max_delta_t = d.max_delta_t;
     out->turbulence_model = d.turbulence_model; out->les_ck = d.les_ck; out->les_ce = d.les_ce; out->les_delta_coeff = d.les_delta_coeff; out->nut_initial = d.nut_initial;
     out->nut_bc = c->g_nut_bc.empty() ? nullptr : c->g_nut_bc.data(); out->nut_value = c->g_nut_val.empty() ? nullptr : c->g_nut_val.data();
-    out->convection_scheme = d.convection_scheme;
+    out->convection_scheme = d.convection_scheme; out->convection_limiter_k = d.convection_limiter_k;
     out->u_bc = c->g_u_bc.data(); out->u_value = c->g_u_val.data(); out->p_bc = c->g_p_bc.data(); out->p_value = c->g_p_val.data();
     return FY_OK;
 }

@@ -39,7 +39,10 @@ struct LduGeo {
     const double* recon;                                 // [9 nc]
     const double* psn;                                   // [nF - nInt] snGrad(p) of the fixedFluxPressure faces (pimpleFoamYade; else null)
     double dt, nu;
-    int upwind;                                          // div(phi,U): 0 Gauss linear; 1 Gauss upwind (the owner's weight is pos0(flux)); 2 Gauss linearUpwind grad(U) (upwind + an explicit gradient correction)
+    int upwind;                                          // div(phi,U), FY_CONVECTION_*: 0 Gauss linear; 1 Gauss upwind (the owner's weight is pos0(flux)); 2 Gauss linearUpwind grad(U) (upwind + an
+                                                         // explicit gradient correction); 3 .. 8 the NVD / TVD limited schemes (limitedLinear k, vanLeer, MUSCL, Minmod, SuperBee, QUICK)
+    double lim_two_by_k;                                 // limitedLinear: 2 / max(k, small)
+    const double* gradL;                                 // [3 nc] Gauss-linear gradient of |U|^2 of the iterate the matrix is assembled from (limited schemes; else null)
     int need_ref, p_ref_cell;
     double p_ref_value;
 };
@@ -61,6 +64,7 @@ int launch_ldu_flux_of(hipStream_t s, LduGeo g, const double* F, double* phi);
 int launch_ldu_courant(hipStream_t s, LduGeo g, const double* phi, double* partials);                    // slot 0 = max sumPhi / V, slot 1 = sum sumPhi
 int launch_ldu_grad_vec(hipStream_t s, LduGeo g, const double* F, double* T);                           // T[9 c + 3 i + j] = d_i F_j
 int launch_ldu_grad_scalar(hipStream_t s, LduGeo g, const double* p, double* gp);
+int launch_ldu_grad_magsqr(hipStream_t s, LduGeo g, const double* U, double* gradL);                    // fvc::grad(magSqr(U)), boundary value magSqr(U_b): the limiters' gradient
 // UEqn (icoFoamYade.C:79-85): face part (lower / upper, the explicit non-orthogonal flux of the laplacian), then the cell part (diag, b)
 int launch_ldu_assemble_momentum(hipStream_t s, LduGeo g, const double* phi, const double* Uold, const double* uSource, const double* gradU, LduMom M,
                                  double* face_corr /* [3 nInt] scratch */);

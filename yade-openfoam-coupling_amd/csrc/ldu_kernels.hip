@@ -119,6 +119,52 @@ __global__ __launch_bounds__(256) void k_ldu_grad_scalar(LduGeo g, const double*
     if (c < g.nCells) st3(gp, c, grad_scalar_at(g, p, c));
 }
 
+// fvc::grad(magSqr(F)) for the limited schemes' r (boundary value magSqr(F_b))
+__device__ __forceinline__ double msq(D3 a) { return (a.x * a.x + a.y * a.y) + a.z * a.z; }
+__global__ __launch_bounds__(256) void k_ldu_grad_magsqr(LduGeo g, const double* __restrict__ F, double* __restrict__ gradL) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= g.nCells) return;
+    const double lc = msq(ld3(F, c));
+    D3 a{0, 0, 0};
+    FY_CELL_FACES(g, c, f, nb) {
+        double lf, sg = 1.0;
+        if (f < g.nInt) { const bool o = nb > c; const double ln = msq(ld3(F, nb)); lf = o ? g.w[f] * lc + (1.0 - g.w[f]) * ln : g.w[f] * ln + (1.0 - g.w[f]) * lc; sg = o ? 1.0 : -1.0; }
+        else lf = msq(Ub(g, F, f));
+        const D3 S = ld3(g.Sf, f);
+        a.x += sg * S.x * lf; a.y += sg * S.y * lf; a.z += sg * S.z * lf;
+    }
+    const double rV = 1.0 / g.V[c];
+    st3(gradL, c, D3{a.x * rV, a.y * rV, a.z * rV});
+}
+// NVD / TVD limited schemes [OF-6 LimitedScheme<vector, Limiter<NVDTVD>, limitFuncs::magSqr>, NVDTVD.H], as fv_kernels.hip's limiter_fn / limited weight: ONE limiter per
+// face from lPhi = magSqr(U): r = 2 (d . grad(lPhi)_C) / (lPhi_N - lPhi_P) - 1, C the upwind cell of the face flux, d = C_N - C_P; the owner's weight is
+// limiter w_linear + (1 - limiter) pos0(flux) [limitedSurfaceInterpolationScheme::weights], used implicitly
+__device__ __forceinline__ double ldu_limiter_fn(int scheme, double twoByk, double r) {
+    switch (scheme) {
+        case FY_CONVECTION_LIMITED_LINEAR: return fmax(fmin(twoByk * r, 1.0), 0.0);
+        case FY_CONVECTION_VAN_LEER: return (r + fabs(r)) / (1.0 + fabs(r));
+        case FY_CONVECTION_MUSCL: return fmax(fmin(fmin(2.0 * r, 0.5 * r + 0.5), 2.0), 0.0);
+        case FY_CONVECTION_MINMOD: return fmax(fmin(fmin(r, 1.0), 2.0), 0.0);
+        case FY_CONVECTION_SUPERBEE: return fmax(fmax(fmin(2.0 * r, 1.0), fmin(r, 2.0)), 0.0);
+        default: return fmax(fmin((3.0 + r) / 4.0, 2.0), 0.0);          // QUICK
+    }
+}
+// the owner's weight of the convected value on internal face f for the face flux fl, by the scheme
+__device__ __forceinline__ double ldu_conv_weight(const LduGeo& g, int f, double fl, const double* __restrict__ U) {
+    if (g.upwind == 0) return g.w[f];
+    const double up = fl >= 0.0 ? 1.0 : 0.0;
+    if (g.upwind <= 2) return up;
+    const int o = g.own[f], n = g.nei[f];
+    const double gradf = msq(ld3(U, n)) - msq(ld3(U, o));
+    const D3 co = ld3(g.C, o), cn = ld3(g.C, n), gl = ld3(g.gradL, fl > 0.0 ? o : n);
+    const double gradcf = ((cn.x - co.x) * gl.x + (cn.y - co.y) * gl.y) + (cn.z - co.z) * gl.z;
+    double r;
+    if (fabs(gradcf) >= 1000.0 * fabs(gradf)) r = 2.0 * 1000.0 * (gradcf >= 0 ? 1.0 : -1.0) * (gradf >= 0 ? 1.0 : -1.0) - 1.0;
+    else r = 2.0 * (gradcf / gradf) - 1.0;
+    const double lim = ldu_limiter_fn(g.upwind, g.lim_two_by_k, r);
+    return lim * g.w[f] + (1.0 - lim) * up;
+}
+
 // Gauss linearUpwind grad(U) [OF-6 linearUpwind::correction]: the face value is the upwind cell's plus (C_f - C_upwind) . grad(U)_upwind, the second term explicit
 // (deferred correction) with the Gauss-linear gradient of the iterate the matrix is assembled from; returned as the flux of it, fl (d . grad U)_j
 __device__ __forceinline__ void linear_upwind_flux(const LduGeo& g, int f, double fl, const double* __restrict__ gradU, double (&lu)[3]) {
@@ -132,11 +178,11 @@ __device__ __forceinline__ void linear_upwind_flux(const LduGeo& g, int f, doubl
 
 // UEqn, face part: gaussConvectionScheme<linear>::fvmDiv (lower = -w phi, upper = lower + phi) minus gaussLaplacianScheme::fvmLaplacianUncorrected
 // (gamma |Sf| nonOrthDeltaCoeffs on both), and the corrected scheme's explicit flux nu |Sf| (k & linearInterpolate(grad U)) per internal face
-__global__ __launch_bounds__(256) void k_ldu_mom_faces(LduGeo g, const double* __restrict__ phi, const double* __restrict__ gradU, LduMom M, double* __restrict__ corr) {
+__global__ __launch_bounds__(256) void k_ldu_mom_faces(LduGeo g, const double* __restrict__ phi, const double* __restrict__ U, const double* __restrict__ gradU, LduMom M, double* __restrict__ corr) {
     const int f = blockIdx.x * 256 + threadIdx.x;
     if (f >= g.nInt) return;
     const double gm = g.nu * g.magSf[f];
-    double lo = -(g.upwind ? (phi[f] >= 0.0 ? 1.0 : 0.0) : g.w[f]) * phi[f];      // [OF-6 upwind::weights = pos0(faceFlux)]
+    double lo = -ldu_conv_weight(g, f, phi[f], U) * phi[f];      // (Gauss linear: the linear weight; upwind [OF-6 upwind::weights]: pos0(faceFlux); limited: in between)
     double up = lo + phi[f];
     lo -= gm * g.dcNO[f]; up -= gm * g.dcNO[f];
     M.lower[f] = lo; M.upper[f] = up;
@@ -439,7 +485,7 @@ __device__ __forceinline__ double ldu_nut_b(const LduGeo& g, const LduPim& P, in
     const int pa = g.patch_of[f - g.nInt];
     return P.nut_bc[pa] == FY_BC_NUT_FIXED_VALUE ? P.nut_val[pa] : P.nut[g.own[f]];
 }
-__global__ __launch_bounds__(256) void k_ldu_pmom_faces(LduGeo g, LduPim P, const double* __restrict__ phi, const double* __restrict__ alpha, const double* __restrict__ alphaf,
+__global__ __launch_bounds__(256) void k_ldu_pmom_faces(LduGeo g, LduPim P, const double* __restrict__ phi, const double* __restrict__ U, const double* __restrict__ alpha, const double* __restrict__ alphaf,
                                                         const double* __restrict__ gradU, LduMom M, double* __restrict__ corr, double* __restrict__ fstress) {
     const int f = blockIdx.x * 256 + threadIdx.x;
     if (f >= g.nFaces) return;
@@ -462,7 +508,7 @@ __global__ __launch_bounds__(256) void k_ldu_pmom_faces(LduGeo g, LduPim P, cons
     const double* Tn = gradU + 9 * (size_t)n;
     const double trn = Tn[0] + Tn[4] + Tn[8], an = alpha[n] * (g.nu + (P.nut ? P.nut[n] : 0.0)), w = g.w[f];
     const double af = alphaf[f], fl = af * phi[f], gm = (P.nut ? w * ao + (1.0 - w) * an : g.nu * af) * g.magSf[f];
-    double lo = -(g.upwind ? (fl >= 0.0 ? 1.0 : 0.0) : w) * fl;
+    double lo = -ldu_conv_weight(g, f, fl, U) * fl;
     double up = lo + fl;
     lo -= gm * g.dcNO[f]; up -= gm * g.dcNO[f];
     M.lower[f] = lo; M.upper[f] = up;
@@ -734,8 +780,13 @@ int launch_ldu_grad_scalar(hipStream_t s, LduGeo g, const double* p, double* gp)
     FY_LAUNCH_CHECK();
     return FY_OK;
 }
+int launch_ldu_grad_magsqr(hipStream_t s, LduGeo g, const double* U, double* gradL) {
+    hipLaunchKernelGGL(k_ldu_grad_magsqr, dim3(div_up(g.nCells, 256)), dim3(256), 0, s, g, U, gradL);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
 int launch_ldu_assemble_momentum(hipStream_t s, LduGeo g, const double* phi, const double* Uold, const double* uSource, const double* gradU, LduMom M, double* face_corr) {
-    if (g.nInt > 0) hipLaunchKernelGGL(k_ldu_mom_faces, dim3(div_up(g.nInt, 256)), dim3(256), 0, s, g, phi, gradU, M, face_corr);
+    if (g.nInt > 0) hipLaunchKernelGGL(k_ldu_mom_faces, dim3(div_up(g.nInt, 256)), dim3(256), 0, s, g, phi, Uold, gradU, M, face_corr);      // (U has not been written since runTime++: the limiter sees the current field)
     hipLaunchKernelGGL(k_ldu_mom_cells, dim3(div_up(g.nCells, 256)), dim3(256), 0, s, g, phi, Uold, uSource, M, face_corr);
     FY_LAUNCH_CHECK();
     return FY_OK;
@@ -798,7 +849,7 @@ int launch_ldu_pre_coupling(hipStream_t s, LduGeo g, const double* phi, const do
 }
 int launch_ldu_assemble_momentum_pimple(hipStream_t s, LduGeo g, LduPim P, const double* phi, const double* Uold, const double* U, const double* gradU, LduMom M, double* face_corr,
                                         double* fstress, double u_relax, double* rAU) {
-    hipLaunchKernelGGL(k_ldu_pmom_faces, dim3(div_up(g.nFaces, 256)), dim3(256), 0, s, g, P, phi, P.alpha, P.alphaf, gradU, M, face_corr, fstress);
+    hipLaunchKernelGGL(k_ldu_pmom_faces, dim3(div_up(g.nFaces, 256)), dim3(256), 0, s, g, P, phi, U, P.alpha, P.alphaf, gradU, M, face_corr, fstress);
     hipLaunchKernelGGL(k_ldu_pmom_cells, dim3(div_up(g.nCells, 256)), dim3(256), 0, s, g, P, phi, P.alpha, P.alphaOld, P.alphaf, Uold, U, P.uSourceDrag, M, face_corr, fstress, u_relax, rAU);
     FY_LAUNCH_CHECK();
     return FY_OK;

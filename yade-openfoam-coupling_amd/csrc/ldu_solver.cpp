@@ -34,7 +34,7 @@ struct LduSolver {
     // pimpleFoamYade: the coupling's fields and the alpha-weighted equations' face fields
     bool pimple = false, hold_sources = false, sources_pending = false;
     DevBuf<double> alpha, alphaf, uSourceDrag, uParticle, gradP, divT, ddtU, fstress, phiForces, psn, arAUf, phiA, ssf, bmom, pPrev;
-    DevBuf<double> nut, d_nutval;
+    DevBuf<double> nut, d_nutval, gradL;
     DevBuf<int32_t> d_nutbc;
     bool les = false;
     LduPim P() const { return LduPim{alpha.p, alpha.p, alphaf.p, uSourceDrag.p, uSource.p, {cs.g[0], cs.g[1], cs.g[2]}, les ? nut.p : nullptr, d_nutbc.p, d_nutval.p}; }      // alphac.oldTime() == alphac
@@ -73,8 +73,9 @@ struct LduSolver {
         if (c->turbulence_model != FY_TURBULENCE_LAMINAR && !(pimple && c->turbulence_model == FY_TURBULENCE_SMAGORINSKY))
             return fail(FY_ERR_UNSUPPORTED, "fy_ldu_solver: turbulence model %d (laminar; LES Smagorinsky with pimpleFoamYade)", c->turbulence_model);
         les = pimple && c->turbulence_model == FY_TURBULENCE_SMAGORINSKY;
-        if (c->convection_scheme != FY_CONVECTION_LINEAR && c->convection_scheme != FY_CONVECTION_UPWIND && c->convection_scheme != FY_CONVECTION_LINEAR_UPWIND)
-            return fail(FY_ERR_UNSUPPORTED, "fy_ldu_solver: convection scheme %d (Gauss linear, Gauss upwind, Gauss linearUpwind)", c->convection_scheme);
+        if (c->convection_scheme < FY_CONVECTION_LINEAR || c->convection_scheme > FY_CONVECTION_QUICK)
+            return fail(FY_ERR_UNSUPPORTED, "fy_ldu_solver: convection scheme %d (FY_CONVECTION_LINEAR .. FY_CONVECTION_QUICK)", c->convection_scheme);
+        if (c->convection_scheme == FY_CONVECTION_LIMITED_LINEAR && !(c->convection_limiter_k >= 0 && c->convection_limiter_k <= 1)) return fail(FY_ERR_INVALID, "fy_ldu_solver: limitedLinear takes a coefficient in [0, 1]");
         if (les && !(c->les_ck > 0 && c->les_ce > 0 && c->les_delta_coeff > 0)) return fail(FY_ERR_INVALID, "fy_ldu_solver: Smagorinsky needs Ck, Ce and the delta coefficient positive");
         nc = hm.nCells; nf = hm.nFaces; ni = hm.nInt;
         std::vector<int32_t> ubc(c->u_bc, c->u_bc + hm.nPatches), pbc(c->p_bc, c->p_bc + hm.nPatches);
@@ -97,7 +98,7 @@ struct LduSolver {
         FY_TRY(up(d_recon, hm.recon));
         if (pimple) { FY_TRY(psn.alloc_exact(std::max<size_t>((size_t)(nf - ni), 1))); FY_TRY(zero(psn)); }
         g = LduGeo{nc, nf, ni, hm.nPatches, d_own.p, d_nei.p, d_patch_of.p, d_cf_off.p, d_cf_face.p, hm.Wall, d_ef.p, d_en.p, d_Cf.p, d_Sf.p, d_magSf.p, d_C.p, d_V.p, d_w.p, d_dcNO.p, d_kvec.p,
-                   d_ubc.p, d_pbc.p, d_uval.p, d_pval.p, d_recon.p, pimple ? psn.p : nullptr, cs.dt, cs.nu, cs.convection_scheme == FY_CONVECTION_UPWIND ? 1 : (cs.convection_scheme == FY_CONVECTION_LINEAR_UPWIND ? 2 : 0), need_ref ? 1 : 0, cs.p_ref_cell, cs.p_ref_value};
+                   d_ubc.p, d_pbc.p, d_uval.p, d_pval.p, d_recon.p, pimple ? psn.p : nullptr, cs.dt, cs.nu, cs.convection_scheme, 2.0 / std::max(cs.convection_limiter_k, 1e-15), nullptr, need_ref ? 1 : 0, cs.p_ref_cell, cs.p_ref_value};
         total_volume = 0.0;
         for (double v : hm.V) total_volume += v;
         const size_t n = (size_t)nc;
@@ -138,6 +139,7 @@ struct LduSolver {
             }
         }
         for (auto& t : tim) FY_TRY(t.init());
+        if (cs.convection_scheme >= FY_CONVECTION_LIMITED_LINEAR) { FY_TRY(gradL.alloc_exact(3 * n)); FY_TRY(zero(gradL)); g.gradL = gradL.p; }
         FY_TRY(amg.build(stream, nc, ni, hm.own.data(), hm.nei.data(), hm.cf_off, hm.cf_face, hm.magSf.data(), need_ref ? cs.p_ref_cell : -1, cs.p_solver == FY_PSOLVER_PCG_MG));
         // the coupling object on this mesh (icoFoamYade.C:54: point force): its tree over the cell centres, its fields the solver's device arrays
         {
@@ -296,6 +298,7 @@ struct LduSolver {
             const double p_relax_now = (final_outer && cs.p_relax_final > 0) ? cs.p_relax_final : cs.p_relax;
             if (p_relax_now > 0 && p_relax_now < 1) FY_TRY(launch_copy_f64(stream, pPrev.p, p.p, (size_t)nc));  // storePrevIterFields()
             if (outer > 0) FY_TRY(launch_ldu_grad_vec(stream, g, U.p, vGrad.p));
+            if (g.gradL) FY_TRY(launch_ldu_grad_magsqr(stream, g, U.p, gradL.p));
             FY_TRY(launch_ldu_assemble_momentum_pimple(stream, g, P(), phi.p, Uold.p, U.p, vGrad.p, M(), fcorr.p, fstress.p, u_relax_now, rAU.p));      // UcEqn.H:3-13
             FY_TRY(launch_ldu_forces(stream, g, P(), rAU.p, rAUf.p, phiForces.p));                               // UcEqn.H:15-20
             if (cs.momentum_predictor) {                                                                          // UcEqn.H:22-33
@@ -343,6 +346,7 @@ struct LduSolver {
             // the momentum source: what the coupling left (+ an external one, fy_ldu_solver_write_field_host("uSource", ...))
             const double* src = uSource.p;
             if (ext_source) { FY_TRY(launch_copy_f64(stream, uSourceSum.p, uSource.p, 3 * (size_t)nc)); FY_TRY(launch_add_f64(stream, uSourceSum.p, uSourceExt.p, 3 * (size_t)nc)); src = uSourceSum.p; }
+            if (g.gradL) FY_TRY(launch_ldu_grad_magsqr(stream, g, Uold.p, gradL.p));
             FY_TRY(launch_ldu_assemble_momentum(stream, g, phi.p, Uold.p, src, vGrad.p, M(), fcorr.p));                // :79-85 (grad U of the iterate it is assembled from = vGrad)
             if (cs.momentum_predictor) {
                 FY_TRY(launch_ldu_grad_scalar(stream, g, p.p, gradp.p));
@@ -401,7 +405,7 @@ void fy_ldu_case_defaults(fy_ldu_case* c) {
     c->solver = FY_SOLVER_ICO; c->n_outer_correctors = 1;
     c->adjust_time_step = 0; c->max_co = 1.0; c->max_delta_t = 1e300;
     c->turbulence_model = FY_TURBULENCE_LAMINAR; c->les_ck = 0.094; c->les_ce = 1.048; c->les_delta_coeff = 1.0; c->nut_initial = 0.0;
-    c->convection_scheme = FY_CONVECTION_LINEAR;
+    c->convection_scheme = FY_CONVECTION_LINEAR; c->convection_limiter_k = 1.0;
 }
 
 int fy_ldu_solver_create(const fy_poly_mesh* m, const fy_ldu_case* c, const fy_transport* tr, int device_ordinal, fy_ldu_solver** out) {
