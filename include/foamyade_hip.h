@@ -478,7 +478,7 @@ typedef struct fy_ldu_case {
     double u_tol, u_rel_tol; int32_t u_max_iter;
     int32_t p_solver;                /* FY_PSOLVER_PCG_JACOBI: PCG.C with the diagonal preconditioner | FY_PSOLVER_PCG_MG: preconditioned by an agglomeration
                                         multigrid V-cycle (fvSolution: solver / preconditioner GAMG) built from the face areas like faceAreaPair */
-    const int32_t* u_bc;             /* per patch: FY_BC_U_FIXED_VALUE | FY_BC_U_ZERO_GRADIENT */
+    const int32_t* u_bc;             /* per patch: FY_BC_U_FIXED_VALUE | FY_BC_U_ZERO_GRADIENT | FY_BC_U_SLIP (symmetryPlane / symmetry / slip: each face with its own normal) */
     const double* u_value;           /* [n_patches][3] */
     const int32_t* p_bc;             /* per patch: FY_BC_P_ZERO_GRADIENT | FY_BC_P_FIXED_VALUE */
     const double* p_value;           /* [n_patches] */

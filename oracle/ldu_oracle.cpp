@@ -37,7 +37,7 @@ extern "C" struct orc_ldu_case {
     double p_ref_value;
     double p_tol, p_rel_tol, p_final_tol, p_final_rel_tol; int p_max_iter;
     double u_tol, u_rel_tol; int u_max_iter;
-    const int* u_bc;            // per patch: 0 fixedValue, 1 zeroGradient
+    const int* u_bc;            // per patch: 0 fixedValue, 1 zeroGradient, 2 symmetry / symmetryPlane / slip (the face's normal component 0, the rest zeroGradient)
     const double* u_value;      // [n_patches][3]
     const int* p_bc;            // per patch: 0 zeroGradient, 1 fixedValue
     const double* p_value;      // [n_patches]
@@ -73,6 +73,8 @@ struct Ldu {
     std::vector<int> u_bc, p_bc; vec u_val, p_val;
     // ---- fields
     vec U, Uold, p, phi, phiOld, uSource, vGrad;             // U [3 nc], phi [nFaces] (owner -> neighbour / outwards)
+    vec bdg, bmaxs, bmins;       // symmetry patches: the per-component part of the boundary diagonal [3 nc], and per cell the sums of its cmptMax / cmptMin (fvMatrix::relax)
+    bool has_slip = false;
     vec diag, lower, upper, src, bint, bsrc;                 // momentum matrix: diag, off-diagonals per internal face, source [3 nc], boundary coefficients per boundary face (scalar) / [3]
     vec rAU, HbyA, phiHbyA, rAUf, pdiag, pcoef, pb, pcorr;   // pcoef per face (internal: rAUf |Sf| dcNO; boundary: the same with the patch's dcNO), pcorr: non-orth flux correction per internal face
     // pimpleFoamYade: the coupling's fields (set from outside between step_begin and step_end), the face fields of the alpha-weighted equations
@@ -151,7 +153,12 @@ struct Ldu {
         const int pa = patch_of[f - nInt];
         if (u_bc[pa] == 0) return V3{u_val[3 * pa], u_val[3 * pa + 1], u_val[3 * pa + 2]};
         const int c = own[f];
-        return V3{F[3 * c], F[3 * c + 1], F[3 * c + 2]};
+        const V3 uc{F[3 * c], F[3 * c + 1], F[3 * c + 2]};
+        if (u_bc[pa] == 2) {                                    // [OF-6 basicSymmetryFvPatchField::evaluate]: (U_P + transform(I - 2 n n, U_P)) / 2 = U_P - n (n & U_P), n the face's unit normal
+            const V3 n = (1.0 / magSf[f]) * Sf[f];
+            return uc - dot(n, uc) * n;
+        }
+        return uc;
     }
     double pb_val(int f) const {
         const int pa = patch_of[f - nInt];
@@ -194,6 +201,7 @@ struct Ldu {
         phi.assign(nFaces, 0.0); phiOld = phi; phiHbyA = phi; rAUf = phi; pcoef = phi;
         lower.assign(nInt, 0.0); upper = lower; pcorr = lower;
         bint.assign(nFaces - nInt, 0.0); bsrc.assign(3 * (size_t)(nFaces - nInt), 0.0);
+        bdg.assign(3 * (size_t)nCells, 0.0); bmaxs.assign(nCells, 0.0); bmins.assign(nCells, 0.0);
         flux_of(U, phi);                                       // createPhi
         pimple = cs.solver == 1;
         if (pimple) {
@@ -290,6 +298,7 @@ struct Ldu {
         if (cs.convection_scheme >= 3) limiter_gradient(U);
         std::fill(diag.begin(), diag.end(), 0.0); std::fill(src.begin(), src.end(), 0.0);
         std::fill(bint.begin(), bint.end(), 0.0); std::fill(bsrc.begin(), bsrc.end(), 0.0);
+        std::fill(bdg.begin(), bdg.end(), 0.0); std::fill(bmaxs.begin(), bmaxs.end(), 0.0); std::fill(bmins.begin(), bmins.end(), 0.0);
         vec divAPhi(nc, 0.0), offsum(nc, 0.0), G(9 * nc);
         for (size_t c = 0; c < nc; ++c) {
             diag[c] += alpha[c] * V[c] / cs.dt;
@@ -336,6 +345,7 @@ struct Ldu {
             stress(f, t);
             for (int q = 0; q < 3; ++q) src[3 * (size_t)c + q] += t[q];
             if (u_bc[pa] == 0) { bint[b] += g; for (int q = 0; q < 3; ++q) bsrc[3 * (size_t)b + q] += (-phi[f] + g) * u_val[3 * pa + q]; }
+            else if (u_bc[pa] == 2) slip_face(f, g);
             else bint[b] += phi[f];
         }
         if (cs.convection_scheme == 2) { vec aphi(nFaces); for (int f = 0; f < nFaces; ++f) aphi[f] = alphaf[f] * phi[f]; linear_upwind_source(aphi); }
@@ -346,12 +356,14 @@ struct Ldu {
         }
         if (u_relax_now > 0) {                                           // fvMatrix::relax: the boundary coefficients take part in the dominance test
             for (size_t c = 0; c < nc; ++c) {
-                const double dg = dgc((int)c), dn = std::max(std::fabs(dg), offsum[c]) / u_relax_now;
+                // (a symmetry face's coefficient differs by component: relax() adds cmptMax(cmptMag(internalCoeffs)) before the dominance test and takes
+                // cmptMin(internalCoeffs) off afterwards)
+                const double dg = dgc((int)c), dn = std::max(std::fabs(dg + (has_slip ? bmaxs[c] : 0.0)), offsum[c]) / u_relax_now - (has_slip ? bmins[c] : 0.0);
                 for (int q = 0; q < 3; ++q) src[3 * c + q] += (dn - dg) * U[3 * c + q];
                 diag[c] += dn - dg;
             }
         }
-        for (size_t c = 0; c < nc; ++c) rAU[c] = 1.0 / (dgc((int)c) / V[c]);
+        for (size_t c = 0; c < nc; ++c) rAU[c] = 1.0 / (dgA((int)c) / V[c]);
     }
     void interp_rAU_and_forces() {                               // rAUcf, phicForces = fvc::flux(rAUc uSource) + rAUcf (g & Sf) (UcEqn.H:15-20); uSource's boundary value is 0
         const V3 gv{cs.g[0], cs.g[1], cs.g[2]};
@@ -495,6 +507,7 @@ struct Ldu {
         if (cs.convection_scheme >= 3) limiter_gradient(U);      // (the limiter sees the current U: the scheme is built when UEqn is assembled)
         std::fill(diag.begin(), diag.end(), 0.0); std::fill(src.begin(), src.end(), 0.0);
         std::fill(bint.begin(), bint.end(), 0.0); std::fill(bsrc.begin(), bsrc.end(), 0.0);
+        std::fill(bdg.begin(), bdg.end(), 0.0); std::fill(bmaxs.begin(), bmaxs.end(), 0.0); std::fill(bmins.begin(), bmins.end(), 0.0);
         for (size_t c = 0; c < nc; ++c) {                        // EulerDdtScheme::fvmDdt
             diag[c] += V[c] / cs.dt;
             for (int q = 0; q < 3; ++q) src[3 * c + q] += V[c] / cs.dt * Uold[3 * c + q] + V[c] * uSource[3 * c + q];
@@ -515,6 +528,8 @@ struct Ldu {
             if (u_bc[pa] == 0) {                                 // fixedValue: valueInternalCoeffs 0, valueBoundaryCoeffs U_b; gradient coefficients -/+ deltaCoeffs
                 bint[b] += g;
                 for (int q = 0; q < 3; ++q) bsrc[3 * (size_t)b + q] += -phi[f] * u_val[3 * pa + q] + g * u_val[3 * pa + q];
+            } else if (u_bc[pa] == 2) {
+                slip_face(f, g);
             } else {                                             // zeroGradient: valueInternalCoeffs 1
                 bint[b] += phi[f];
             }
@@ -578,6 +593,24 @@ struct Ldu {
         }
     }
 
+    // a symmetry face in the momentum matrix [OF-6 transformFvPatchField: gradientInternalCoeffs = -deltaCoeffs snGradTransformDiag, gradientBoundaryCoeffs = snGrad -
+    // gradientInternalCoeffs U_P; basicSymmetryFvPatchField: snGradTransformDiag = (|n_x|, |n_y|, |n_z|), snGrad = -n (n & U_P) deltaCoeffs]: a per-component diagonal, kept
+    // apart from the scalar one as fvMatrix keeps internalCoeffs apart from the lduMatrix, and an explicit remainder formed with the U the matrix is assembled around.
+    // The flux through the face is U_b & Sf = 0 up to rounding: the convection term sees it like a zeroGradient face
+    void slip_face(int f, double g) {
+        const int b = f - nInt, c = own[f];
+        const V3 n = (1.0 / magSf[f]) * Sf[f], uc = at(U, c);
+        const double nn[3] = {n.x, n.y, n.z}, an[3] = {std::fabs(n.x), std::fabs(n.y), std::fabs(n.z)}, u3[3] = {uc.x, uc.y, uc.z}, un = dot(n, uc);
+        for (int q = 0; q < 3; ++q) {
+            bdg[3 * (size_t)c + q] += g * an[q];
+            bsrc[3 * (size_t)b + q] += g * (an[q] * u3[q] - nn[q] * un);
+        }
+        bmaxs[c] += g * std::max(an[0], std::max(an[1], an[2]));
+        bmins[c] += g * std::min(an[0], std::min(an[1], an[2]));
+        bint[b] += phi[f];
+    }
+    double dgq(int c, int q) const { return has_slip ? dgc(c) + bdg[3 * (size_t)c + q] : dgc(c); }                                  // fvMatrix::solveSegregated: addBoundaryDiag per component
+    double dgA(int c) const { return has_slip ? dgc(c) + (bdg[3 * (size_t)c] + bdg[3 * (size_t)c + 1] + bdg[3 * (size_t)c + 2]) / 3.0 : dgc(c); }      // fvMatrix::A(): addCmptAvBoundaryDiag
     double dgc(int c) const { double d = diag[c]; for (int f : cfaces[c]) if (f >= nInt) d += bint[f - nInt]; return d; }
     void total_source(vec& b) const {
         b = src;
@@ -585,7 +618,7 @@ struct Ldu {
     }
     // (A x)[c] for the momentum matrix, 3 components
     void apply_mom(const vec& dg, const vec& x, vec& y) const {
-        for (int c = 0; c < nCells; ++c) for (int q = 0; q < 3; ++q) y[3 * (size_t)c + q] = dg[c] * x[3 * (size_t)c + q];
+        for (int c = 0; c < nCells; ++c) for (int q = 0; q < 3; ++q) y[3 * (size_t)c + q] = dg[3 * (size_t)c + q] * x[3 * (size_t)c + q];
         for (int f = 0; f < nInt; ++f) for (int q = 0; q < 3; ++q) {
             y[3 * (size_t)own[f] + q] += upper[f] * x[3 * (size_t)nei[f] + q];
             y[3 * (size_t)nei[f] + q] += lower[f] * x[3 * (size_t)own[f] + q];
@@ -593,8 +626,8 @@ struct Ldu {
     }
     // Jacobi sweeps with lduMatrix::solver's L1 residual control per component (stand-in for smoothSolver symGaussSeidel)
     int solve_momentum(const vec& gp) {
-        vec dg(nCells), b;
-        for (int c = 0; c < nCells; ++c) dg[c] = dgc(c);
+        vec dg(3 * (size_t)nCells), b;
+        for (int c = 0; c < nCells; ++c) for (int q = 0; q < 3; ++q) dg[3 * (size_t)c + q] = dgq(c, q);
         total_source(b);
         for (int c = 0; c < nCells; ++c) for (int q = 0; q < 3; ++q) b[3 * (size_t)c + q] -= V[c] * gp[3 * (size_t)c + q];      // == -fvc::grad(p)
         vec x = U, xn(U.size()), Ax(U.size()), Aref(U.size()), ones(U.size());
@@ -622,7 +655,7 @@ struct Ldu {
                 xn[3 * (size_t)own[f] + q] -= upper[f] * x[3 * (size_t)nei[f] + q];
                 xn[3 * (size_t)nei[f] + q] -= lower[f] * x[3 * (size_t)own[f] + q];
             }
-            for (int c = 0; c < nCells; ++c) for (int q = 0; q < 3; ++q) xn[3 * (size_t)c + q] /= dg[c];
+            for (int c = 0; c < nCells; ++c) for (int q = 0; q < 3; ++q) xn[3 * (size_t)c + q] /= dg[3 * (size_t)c + q];
             x.swap(xn);
             ++it;
             apply_mom(dg, x, Ax);
@@ -643,13 +676,18 @@ struct Ldu {
             b[3 * (size_t)nei[f] + q] -= lower[f] * U[3 * (size_t)own[f] + q];
         }
         for (int c = 0; c < nCells; ++c) {
-            rAU[c] = 1.0 / (dgc(c) / V[c]);
+            rAU[c] = 1.0 / (dgA(c) / V[c]);
+            if (has_slip) {                                      // fvMatrix::H(): what a component's boundary diagonal has over the average stays with H
+                const double av = (bdg[3 * (size_t)c] + bdg[3 * (size_t)c + 1] + bdg[3 * (size_t)c + 2]) / 3.0;
+                for (int q = 0; q < 3; ++q) b[3 * (size_t)c + q] += (av - bdg[3 * (size_t)c + q]) * U[3 * (size_t)c + q];
+            }
             for (int q = 0; q < 3; ++q) HbyA[3 * (size_t)c + q] = rAU[c] * (b[3 * (size_t)c + q] / V[c]);
         }
     }
     V3 HbyA_b(int f) const {                                     // constrainHbyA: U's value on patches that fix it, the cell's value otherwise
         const int pa = patch_of[f - nInt];
         if (u_bc[pa] == 0) return V3{u_val[3 * pa], u_val[3 * pa + 1], u_val[3 * pa + 2]};
+        if (u_bc[pa] == 2) return Ub(HbyA, f);                   // (a constraint patch keeps its type on every field: HbyA's own value without its normal component)
         return at(HbyA, own[f]);
     }
     // phiHbyA = fvc::flux(HbyA) + fvc::interpolate(rAU) fvc::ddtCorr(U, phi) (icoFoamYade.C:101-106), adjustPhi (:108)
@@ -835,6 +873,7 @@ void* orc_ldu_create(int n_points, const double* points, int n_faces, int n_inte
     for (int v : s->patch_of) if (v < 0) { delete s; return nullptr; }
     s->cs = *cs;
     s->u_bc.assign(cs->u_bc, cs->u_bc + n_patches); s->p_bc.assign(cs->p_bc, cs->p_bc + n_patches);
+    for (int q = 0; q < n_patches; ++q) s->has_slip = s->has_slip || cs->u_bc[q] == 2;
     s->u_val.assign(cs->u_value, cs->u_value + 3 * n_patches); s->p_val.assign(cs->p_value, cs->p_value + n_patches);
     s->make_geometry();
     s->init_fields();

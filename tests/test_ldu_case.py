@@ -132,11 +132,40 @@ def test_general_case_convection_scheme_is_read(prod, tmp_path, entry, scheme, k
     fc.close()
 
 
+def test_general_case_with_symmetry_patches_is_read(prod, tmp_path):
+    """constant/polyMesh/boundary with a symmetryPlane and a symmetry patch: the fields' entries must carry the patch's own type (as fvPatchField::New insists);
+    U arrives as FY_BC_U_SLIP, p as zeroGradient; an entry of another type on such a patch is refused by name"""
+    mesh = pm.hex_block(5, 4, 3, (0.1, 0.1, 0.1), pm.shear(0.2, 0.0, 0.1), patches=[("movingWall", [3]), ("fixedWalls", [1, 2, 5]), ("mirror", [0]), ("mirror2", [4])])
+    dst = general_cavity(tmp_path, mesh)
+    b = dst / "constant/polyMesh/boundary"
+    t = b.read_text()
+    i, j = t.index("mirror"), t.index("mirror2")
+    t = t[:i] + t[i:j].replace("type wall", "type symmetryPlane", 1).replace("type            wall", "type            symmetryPlane", 1) + t[j:].replace("type wall", "type symmetry", 1).replace("type            wall", "type            symmetry", 1)
+    assert "symmetryPlane" in t and t.count("symmetry") == 2
+    b.write_text(t)
+    for nm in ("U", "p"):
+        f = dst / "0" / nm
+        ft = f.read_text()
+        k = ft.rindex("}")
+        f.write_text(ft[:k] + "    mirror { type symmetryPlane; }\n    mirror2 { type symmetry; }\n}\n")
+    fc = prod.GeneralFoamCase(dst)
+    assert fc.patch_names == ["movingWall", "fixedWalls", "mirror", "mirror2"]
+    assert fc.u_bc == [prod.FY_BC_U_FIXED_VALUE, prod.FY_BC_U_FIXED_VALUE, prod.FY_BC_U_SLIP, prod.FY_BC_U_SLIP] and fc.p_bc == [prod.FY_BC_P_ZERO_GRADIENT] * 4
+    fc.write_fields("0.5", np.zeros((60, 3)), np.zeros(60))
+    wt = (dst / "0.5/U").read_text()
+    assert "symmetryPlane" in wt and "mirror2" in wt
+    fc.close()
+    f = dst / "0/U"
+    f.write_text(f.read_text().replace("mirror { type symmetryPlane; }", "mirror { type noSlip; }"))
+    with pytest.raises(prod.FoamYadeError, match="is a symmetryPlane patch"):
+        prod.GeneralFoamCase(dst)
+
+
 @pytest.mark.parametrize("edit,needle", [
     (("system/fvSchemes", "Gauss linear corrected", "Gauss linear uncorrected"), "must be 'corrected'"),
     (("system/fvSchemes", "default corrected", "default orthogonal"), "must be 'corrected'"),
-    (("constant/polyMesh/boundary", "type            wall;", "type            symmetryPlane;"), "symmetryPlane"),
-    (("0/U", "noSlip", "slip"), "slip"),
+    (("constant/polyMesh/boundary", "type            wall;", "type            cyclic;"), "cyclic"),
+    (("0/U", "noSlip", "partialSlip"), "partialSlip"),
     (("0/p", "zeroGradient", "fixedFluxPressure"), "fixedFluxPressure"),
 ])
 def test_what_the_general_solver_cannot_do_is_refused_by_name(prod, tmp_path, edit, needle):

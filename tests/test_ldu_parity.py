@@ -308,6 +308,102 @@ def test_pimple_with_a_cloud_matches_the_restatement(product, oracle, kind):
     h.close(); o.close()
 
 
+def _turn(a=0.5, b=-0.35, c=0.8):
+    Rx = np.array([[1, 0, 0], [0, np.cos(a), -np.sin(a)], [0, np.sin(a), np.cos(a)]])
+    Ry = np.array([[np.cos(b), 0, np.sin(b)], [0, 1, 0], [-np.sin(b), 0, np.cos(b)]])
+    Rz = np.array([[np.cos(c), -np.sin(c), 0], [np.sin(c), np.cos(c), 0], [0, 0, 1]])
+    return Rz @ Ry @ Rx
+
+
+@pytest.mark.parametrize("kind", ["ico_oblique_wavy", "pimple_cloud", "pimple_les_oblique"])
+def test_symmetry_sides_match_the_restatement(product, oracle, kind):
+    """symmetryPlane / symmetry / slip patches (FY_BC_U_SLIP) on the HIP solver against the restatement: a wavy cavity turned in space (every face of a symmetry patch with
+    its own oblique normal: per-component boundary diagonal (|n_x|, |n_y|, |n_z|) deltaCoeffs, explicit remainder, A() with their average, H() with the rest), and
+    pimpleFoamYade with a cloud, relaxation (cmptMax / cmptMin of the vector coefficient in fvMatrix::relax) and two outer correctors"""
+    n, box = 10, 0.1
+    dx = box / n
+    u_bc = [2, 2, 2, 0, 0, 0]
+    kw = dict(p_tol=1e-10, p_rel_tol=0.0, p_final_tol=1e-10, u_tol=1e-10, p_max_iter=5000)
+    R = _turn()
+    if kind == "ico_oblique_wavy":
+        wv = pm.wavy(0.03)
+        mesh = pm.hex_block(n, n, n, vertex_map=lambda P: wv(P) @ R.T, renumber_seed=12)
+        u_val = [(0, 0, 0)] * 6
+        u_val[3] = tuple(R @ np.array([1.0, 0, 0.3]))
+        h, o = pair(product, oracle, mesh, 0.4 / n, 0.01, u_bc, u_val, [0] * 6, n_non_orth=2, **kw)
+        U0 = np.random.RandomState(3).rand(mesh["n_cells"], 3) * 0.05
+        h.set("U", U0); o.set("U", U0)
+        for _ in range(4):
+            h.step(); o.step()
+        Sf, ni = h.geometry("Sf"), len(mesh["neighbour"])
+        sl = np.concatenate([np.arange(mesh["patch_start"][q], mesh["patch_start"][q] + mesh["patch_size"][q]) for q in range(3)])
+        assert np.abs(Sf[sl] / np.linalg.norm(Sf[sl], axis=1)[:, None]).max() < 0.97 and sl.min() >= ni
+        assert np.abs(h.get("phi")[sl]).max() < 1e-15 and np.abs(h.get("U")).max() > 0.1
+    else:
+        les = kind == "pimple_les_oblique"
+        vm = pm.wavy(0.2 * dx, (box, box, box))
+        mesh = pm.hex_block(n, n, n, (box, box, box), (lambda P: vm(P) @ R.T) if les else vm, renumber_seed=8)
+        gv = tuple(R @ np.array([0, 0, -9.81])) if les else (0, 0, -9.81)
+        if les:
+            kw.update(turbulence_model=1, nut_initial=2e-5, les_delta_coeff=1.0)
+        rel = dict(u_relax=0.8, u_relax_final=1.0, p_relax=0.7, p_relax_final=1.0)
+        lidv = [(0, 0, 0)] * 6
+        lidv[3] = tuple(R @ np.array([0.05, 0, 0.02])) if les else (0.05, 0, 0.02)
+        p_bc = [0, 0, 0, 2, 2, 2]                          # (gravity along the symmetry sides: x and ymin)
+        h = product.LduSolver(mesh, 2e-4, 1e-5, u_bc, lidv, p_bc, solver=1, g=gv, n_non_orth=1, n_outer_correctors=2, n_correctors=2, **rel, **kw)
+        o = oracle.LduSolver(mesh, 2e-4, 1e-5, u_bc, lidv, p_bc, solver=1, g=gv, n_non_orth=1, n_outer=2, n_correctors=2, **rel, **kw)
+        h.hold_sources(True)
+        rs = np.random.RandomState(29)
+        for step in range(3):
+            rec = bed_particles(rs, 1500, box, dx)
+            if les:
+                rec[:, 0:3] = rec[:, 0:3] @ R.T; rec[:, 3:6] = rec[:, 3:6] @ R.T
+            h.set_particles(rec)
+            h.step()
+            alpha = h.get("alpha")
+            assert alpha.min() < 0.95
+            o.step(source=h.get("uSourceCoupling"), alpha=alpha, drag=h.get("uSourceDrag"))
+            close(h.get("U"), o.get("U"), 2e-6, "U step %d" % step)
+        if les:
+            close(h.get("nut"), o.get("nut"), 1e-6, "nut")
+    ph, po = h.get("p"), o.get("p")
+    close(ph - ph.mean(), po - po.mean(), 1e-5, "p")
+    close(h.get("phi"), o.get("phi"), 1e-5, "phi")
+    close(h.get("U"), o.get("U"), 2e-6, "U")
+    h.close(); o.close()
+
+
+@pytest.mark.parametrize("solver", ["ico", "pimple"])
+def test_symmetry_sides_on_a_lattice_equal_the_structured_hip_solver(product, solver):
+    """the same cavity with three symmetry sides through both HIP solvers"""
+    n = 12
+    u_bc = [2, 2, 2, 0, 0, 0]
+    u_val = [(0, 0, 0)] * 6
+    u_val[3] = (1.0, 0, 0.3)
+    mesh = pm.hex_block(n, n, n, renumber_seed=6)
+    tol = dict(p_tol=1e-10, p_rel_tol=0.0, p_final_tol=1e-10, u_tol=1e-10)
+    if solver == "ico":
+        g = product.LduSolver(mesh, 0.4 / n, 0.01, u_bc, u_val, [0] * 6, p_max_iter=5000, **tol)
+        f = product.Solver(product.make_case(0, n, n, n, 1.0 / n, 0.4 / n, 0.01, u_bc=u_bc, u_val=u_val, p_solver=0, **tol))
+    else:
+        rel = dict(u_relax=0.7, u_relax_final=1.0, p_relax=0.6, p_relax_final=1.0)
+        p_bc = [0, 0, 0, 2, 2, 2]
+        g = product.LduSolver(mesh, 0.4 / n, 0.01, u_bc, u_val, p_bc, solver=1, g=(0, 0, -9.81), n_outer_correctors=2, n_correctors=2, p_max_iter=5000, **rel, **tol)
+        f = product.Solver(product.make_case(1, n, n, n, 1.0 / n, 0.4 / n, 0.01, g=(0, 0, -9.81), u_bc=u_bc, u_val=u_val, p_bc=p_bc, p_solver=0, n_outer_correctors=2, n_correctors=2, p_max_iter=5000, **rel, **tol))
+    U0 = np.random.RandomState(2).rand(n ** 3, 3) * 0.05
+    f.set("U", U0)
+    Ug = np.zeros_like(U0); Ug[mesh["perm"]] = U0
+    g.set("U", Ug)
+    for _ in range(4):
+        f.step(); g.step()
+    Uf = f.get("U").reshape(-1, 3)
+    assert np.abs(Uf).max() > 0.1
+    close(pm.to_lattice(mesh, g.get("U").reshape(-1, 3)), Uf, 1e-7, "U")
+    pf, pg = f.get("p"), pm.to_lattice(mesh, g.get("p"))
+    close(pg - pg.mean(), pf - pf.mean(), 1e-6, "p")
+    f.close(); g.close()
+
+
 def test_rayleigh_layer_on_a_distorted_mesh_on_the_hip_solver(product):
     """the transient known answer of tests/test_ldu_oracle.py::test_rayleigh_layer_on_a_distorted_mesh on the HIP solver with the multigrid preconditioner, one level finer
     (128 cells across, 131 072 cells): the error keeps falling (0.0025, 0.0011 on the restatement at 32 and 64)"""

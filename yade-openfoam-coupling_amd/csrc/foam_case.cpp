@@ -60,6 +60,7 @@ struct fy_foam_case {
     std::vector<double> g_points;
     std::vector<int32_t> g_face_off, g_face_pts, g_own, g_nei, g_patch_start, g_patch_size, g_u_bc, g_p_bc;
     std::vector<std::string> g_patch_name, g_u_text, g_p_text, g_nut_text;
+    std::vector<std::string> g_patch_class;      // the boundary file's `type` per patch (wall | patch | symmetryPlane | symmetry)
     std::vector<double> g_u_val, g_p_val, g_nut_val;
     std::vector<int32_t> g_nut_bc;
 };
@@ -724,10 +725,11 @@ int read_general_mesh(fy_foam_case* c) {
         pd.second.word("type", &ty);
         if (!pd.second.integer("nFaces", &nf) || !pd.second.integer("startFace", &sf) || nf < 0 || sf < c->g_internal || (size_t)sf + (size_t)nf > nfaces)
             return fail(FY_ERR_INVALID, "%s/boundary: patch '%s' needs nFaces and startFace among the boundary faces", base.c_str(), pd.first.c_str());
-        // the patch classes fy_ldu_solver has conditions for: a constraint patch (empty, wedge, cyclic, symmetry, processor) would be silently treated as a wall
-        if (nf > 0 && ty != "wall" && ty != "patch")
-            return fail(FY_ERR_UNSUPPORTED, "%s/boundary: patch '%s' of type '%s' is not supported on a general mesh (wall, patch)", base.c_str(), pd.first.c_str(), ty.c_str());
+        // the patch classes fy_ldu_solver has conditions for: another constraint patch (empty, wedge, cyclic, processor) would be silently treated as a wall
+        if (nf > 0 && ty != "wall" && ty != "patch" && ty != "symmetryPlane" && ty != "symmetry")
+            return fail(FY_ERR_UNSUPPORTED, "%s/boundary: patch '%s' of type '%s' is not supported on a general mesh (wall, patch, symmetryPlane, symmetry)", base.c_str(), pd.first.c_str(), ty.c_str());
         c->g_patch_name.push_back(pd.first);
+        c->g_patch_class.push_back(ty);
         c->g_patch_start.push_back(sf);
         c->g_patch_size.push_back(nf);
     }
@@ -755,20 +757,25 @@ int read_general_fields(fy_foam_case* c) {
             std::string ty;
             if (!pd || !pd->word("type", &ty)) return fail(FY_ERR_INVALID, "%s: boundaryField has no (typed) entry for patch '%s'", path.c_str(), pn);
             (which ? c->g_p_text : c->g_u_text)[pa] = entry_text(*pd);
+            // [OF-6 fvPatchField::New]: a field's entry on a constraint patch must carry the patch's own type
+            if ((c->g_patch_class[pa] == "symmetryPlane" || c->g_patch_class[pa] == "symmetry") && c->g_patch_size[pa] > 0 && ty != c->g_patch_class[pa])
+                return fail(FY_ERR_INVALID, "%s: patch '%s' is a %s patch (constant/polyMesh/boundary): its entry must be of that type, not '%s'", path.c_str(), pn, c->g_patch_class[pa].c_str(), ty.c_str());
             const auto* vt = pd->tokens("value");
             if (!which) {
                 if (ty == "fixedValue") {
                     if (!vt || vt->empty() || (*vt)[0] != "uniform" || !pd->vector3("value", &c->g_u_val[3 * pa]))
                         return fail(FY_ERR_UNSUPPORTED, "%s: patch '%s': fixedValue needs 'value uniform (x y z)'", path.c_str(), pn);
                 } else if (ty == "zeroGradient") c->g_u_bc[pa] = FY_BC_U_ZERO_GRADIENT;
-                else if (ty != "noSlip") return fail(FY_ERR_UNSUPPORTED, "%s: patch '%s': velocity boundary type '%s' is not supported on a general mesh (fixedValue, noSlip, zeroGradient)", path.c_str(), pn, ty.c_str());
+                else if (ty == "symmetryPlane" || ty == "symmetry" || ty == "slip") c->g_u_bc[pa] = FY_BC_U_SLIP;      // (each face with its own normal: one and the same on a planar patch)
+                else if (ty != "noSlip") return fail(FY_ERR_UNSUPPORTED, "%s: patch '%s': velocity boundary type '%s' is not supported on a general mesh (fixedValue, noSlip, zeroGradient, symmetryPlane, symmetry, slip)", path.c_str(), pn, ty.c_str());
             } else {
                 if (ty == "fixedValue") {
                     c->g_p_bc[pa] = FY_BC_P_FIXED_VALUE;
                     if (!vt || vt->size() < 2 || (*vt)[0] != "uniform" || !fy::foam_tok_is_number((*vt)[1], &c->g_p_val[pa]))
                         return fail(FY_ERR_UNSUPPORTED, "%s: patch '%s': fixedValue needs 'value uniform <p>'", path.c_str(), pn);
                 } else if (ty == "fixedFluxPressure" && c->solver == FY_SOLVER_PIMPLE) c->g_p_bc[pa] = FY_BC_P_FIXED_FLUX;
-                else if (ty != "zeroGradient") return fail(FY_ERR_UNSUPPORTED, "%s: patch '%s': pressure boundary type '%s' is not supported on a general mesh (zeroGradient, fixedValue; fixedFluxPressure with pimpleFoamYade)", path.c_str(), pn, ty.c_str());
+                else if (ty != "zeroGradient" && ty != "symmetryPlane" && ty != "symmetry")      // (a scalar on a symmetry patch: the cell value)
+                    return fail(FY_ERR_UNSUPPORTED, "%s: patch '%s': pressure boundary type '%s' is not supported on a general mesh (zeroGradient, symmetryPlane, symmetry, fixedValue; fixedFluxPressure with pimpleFoamYade)", path.c_str(), pn, ty.c_str());
             }
         }
     }
@@ -793,7 +800,7 @@ int read_general_fields(fy_foam_case* c) {
                 c->g_nut_bc[pa] = FY_BC_NUT_FIXED_VALUE;
                 if (!vt || vt->size() < 2 || (*vt)[0] != "uniform" || !fy::foam_tok_is_number((*vt)[1], &c->g_nut_val[pa]))
                     return fail(FY_ERR_UNSUPPORTED, "%s: patch '%s': %s needs 'value uniform <nut>'", path.c_str(), pn, ty.c_str());
-            } else if (ty != "zeroGradient") return fail(FY_ERR_UNSUPPORTED, "%s: patch '%s': nut boundary type '%s' is not supported on a general mesh (zeroGradient, fixedValue, calculated)", path.c_str(), pn, ty.c_str());
+            } else if (ty != "zeroGradient" && ty != "symmetryPlane" && ty != "symmetry") return fail(FY_ERR_UNSUPPORTED, "%s: patch '%s': nut boundary type '%s' is not supported on a general mesh (zeroGradient, symmetryPlane, symmetry, fixedValue, calculated)", path.c_str(), pn, ty.c_str());
         }
     }
     return FY_OK;

@@ -48,7 +48,10 @@ struct LduGeo {
 };
 
 // momentum matrix in LDU form: diag [nc] (boundary diagonal included), lower / upper per internal face, b [3 nc] (boundary sources included)
-struct LduMom { double *diag, *lower, *upper, *b; };
+struct LduMom {
+    double *diag, *lower, *upper, *b;
+    double* bdiag;                   // [3 nCells] or null: the per-component part of the boundary diagonal (symmetry patches), kept apart from the scalar diagonal
+};
 // pimpleFoamYade's extra fields: the void fraction (cells, old time, faces), the coupling's implicit and explicit momentum sources, gravity
 struct LduPim {
     const double *alpha, *alphaOld, *alphaf, *uSourceDrag, *uSource;

@@ -17,11 +17,36 @@ __device__ __forceinline__ void st3(double* p, int q, D3 a) { p[3 * (size_t)q] =
 __device__ __forceinline__ double dot3(D3 a, D3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 __device__ __forceinline__ D3 lerp3(double w, D3 a, D3 b) { return D3{w * a.x + (1.0 - w) * b.x, w * a.y + (1.0 - w) * b.y, w * a.z + (1.0 - w) * b.z}; }
 
-// boundary value of a velocity-like field on boundary face f: the patch's value (fixedValue) or the cell's (zeroGradient)
+// boundary value of a velocity-like field on boundary face f: the patch's value (fixedValue), the cell's (zeroGradient), or the cell's without its component along the
+// face's normal (symmetry / symmetryPlane / slip [OF-6 basicSymmetryFvPatchField::evaluate]: (U_P + transform(I - 2 n n, U_P)) / 2)
 __device__ __forceinline__ D3 Ub(const LduGeo& g, const double* F, int f) {
     const int pa = g.patch_of[f - g.nInt];
     if (g.u_bc[pa] == FY_BC_U_FIXED_VALUE) return ld3(g.u_val, pa);
-    return ld3(F, g.own[f]);
+    const D3 uc = ld3(F, g.own[f]);
+    if (g.u_bc[pa] == FY_BC_U_SLIP) {
+        const double rm = 1.0 / g.magSf[f];
+        const D3 S = ld3(g.Sf, f), n = D3{rm * S.x, rm * S.y, rm * S.z};
+        const double un = dot3(n, uc);
+        return D3{uc.x - un * n.x, uc.y - un * n.y, uc.z - un * n.z};
+    }
+    return uc;
+}
+// a symmetry face in the momentum matrix [OF-6 transformFvPatchField: gradientInternalCoeffs = -deltaCoeffs snGradTransformDiag, gradientBoundaryCoeffs = snGrad -
+// gradientInternalCoeffs U_P; basicSymmetryFvPatchField: snGradTransformDiag = (|n_x|, |n_y|, |n_z|), snGrad = -n (n & U_P) deltaCoeffs]: bd += the per-component
+// diagonal, b += the explicit remainder around the U the matrix is assembled with, bmax / bmin += cmptMax / cmptMin of the coefficient (fvMatrix::relax).  The flux
+// through the face is U_b & Sf = 0 up to rounding: the convection term sees it like a zeroGradient face
+__device__ __forceinline__ void slip_face(const LduGeo& g, int f, double gm, D3 uc, double (&bd)[3], double (&b)[3], double& bmax, double& bmin) {
+    const double rm = 1.0 / g.magSf[f];
+    const D3 S = ld3(g.Sf, f);
+    const double nn[3] = {rm * S.x, rm * S.y, rm * S.z}, an[3] = {fabs(nn[0]), fabs(nn[1]), fabs(nn[2])}, u3[3] = {uc.x, uc.y, uc.z};
+    const double un = dot3(D3{nn[0], nn[1], nn[2]}, uc);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        bd[q] += gm * an[q];
+        b[q] += gm * (an[q] * u3[q] - nn[q] * un);
+    }
+    bmax += gm * fmax(an[0], fmax(an[1], an[2]));
+    bmin += gm * fmin(an[0], fmin(an[1], an[2]));
 }
 __device__ __forceinline__ double pbv(const LduGeo& g, const double* p, int f) {
     const int pa = g.patch_of[f - g.nInt];
@@ -211,6 +236,7 @@ __global__ __launch_bounds__(256) void k_ldu_mom_cells(LduGeo g, const double* _
     double dg = rdt;
     const D3 uo = ld3(Uold, c), us = ld3(uSource, c);
     double b[3] = {rdt * uo.x + Vc * us.x, rdt * uo.y + Vc * us.y, rdt * uo.z + Vc * us.z};
+    double bd[3] = {0, 0, 0}, bmax = 0.0, bmin = 0.0;
     FY_CELL_FACES(g, c, f, nb) {
         if (f < g.nInt) {
             const D3 cr = ld3(corr, f);
@@ -224,12 +250,14 @@ __global__ __launch_bounds__(256) void k_ldu_mom_cells(LduGeo g, const double* _
                 dg += gm;
                 b[0] += (-phi[f] + gm) * ub.x; b[1] += (-phi[f] + gm) * ub.y; b[2] += (-phi[f] + gm) * ub.z;
             } else {
+                if (g.u_bc[pa] == FY_BC_U_SLIP) slip_face(g, f, g.nu * g.magSf[f] * g.dcNO[f], uo, bd, b, bmax, bmin);      // (UEqn is assembled around U = U.oldTime())
                 dg += phi[f];
             }
         }
     }
     M.diag[c] = dg;
     st3(M.b, c, D3{b[0], b[1], b[2]});
+    if (M.bdiag) st3(M.bdiag, c, D3{bd[0], bd[1], bd[2]});
 }
 
 // row of the momentum matrix applied to x without its diagonal: sum offdiag x_nb; also the row's off-diagonal sum (for A xbar)
@@ -254,12 +282,14 @@ __global__ __launch_bounds__(256) void k_ldu_mom_pass(LduGeo g, LduMom M, const 
     if (c < g.nCells) {
         double s[3], os;
         mom_offdiag(g, M, x, c, s, &os);
-        const double dg = M.diag[c], Vc = g.V[c];
-        const D3 b0 = ld3(rhs, c), gp = gradp ? ld3(gradp, c) : D3{0, 0, 0}, xc = ld3(x, c);
+        const double dgs = M.diag[c], Vc = g.V[c];
+        const D3 b0 = ld3(rhs, c), gp = gradp ? ld3(gradp, c) : D3{0, 0, 0}, xc = ld3(x, c), bdv = M.bdiag ? ld3(M.bdiag, c) : D3{0, 0, 0};
+        const double bd[3] = {bdv.x, bdv.y, bdv.z};                  // fvMatrix::solveSegregated: addBoundaryDiag per component
         const double b[3] = {gradp ? b0.x - Vc * gp.x : b0.x, gradp ? b0.y - Vc * gp.y : b0.y, gradp ? b0.z - Vc * gp.z : b0.z}, xx[3] = {xc.x, xc.y, xc.z};
         double o[3];
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
+            const double dg = dgs + bd[q];
             const double Ax = dg * xx[q] + s[q];
             const double Aref = (dg + os) * (xsum3[q] / (double)g.nCells);
             v[q] = fabs(b[q] - Ax);
@@ -279,8 +309,14 @@ __global__ __launch_bounds__(256) void k_ldu_HbyA(LduGeo g, LduMom M, const doub
     double s[3];
     mom_offdiag(g, M, U, c, s, nullptr);
     const double Vc = g.V[c];
-    const double r = 1.0 / (M.diag[c] / Vc);
-    const D3 b = ld3(M.b, c);
+    D3 b = ld3(M.b, c);
+    double av = 0.0;
+    if (M.bdiag) {                       // fvMatrix::A(): addCmptAvBoundaryDiag; fvMatrix::H(): what a component's boundary diagonal has over the average stays with H
+        const D3 bd = ld3(M.bdiag, c), uc = ld3(U, c);
+        av = (bd.x + bd.y + bd.z) / 3.0;
+        b.x += (av - bd.x) * uc.x; b.y += (av - bd.y) * uc.y; b.z += (av - bd.z) * uc.z;
+    }
+    const double r = 1.0 / ((M.diag[c] + av) / Vc);
     rAU[c] = r;
     st3(HbyA, c, D3{r * ((b.x - s[0]) / Vc), r * ((b.y - s[1]) / Vc), r * ((b.z - s[2]) / Vc)});
 }
@@ -303,7 +339,7 @@ __global__ __launch_bounds__(256) void k_ldu_phiHbyA(LduGeo g, const double* __r
         const int pa = g.patch_of[f - g.nInt];
         fixes = g.u_bc[pa] == FY_BC_U_FIXED_VALUE;
         rf = rAU[g.own[f]];
-        fl = dot3(fixes ? ld3(g.u_val, pa) : ld3(HbyA, g.own[f]), S);       // constrainHbyA
+        fl = dot3(Ub(g, HbyA, f), S);       // constrainHbyA: U's value where the patch fixes it; a symmetry patch keeps its type on HbyA
         uf = dot3(Ub(g, Uold, f), S);
     }
     const double phiCorr = phiOld[f] - uf;
@@ -542,6 +578,8 @@ __global__ __launch_bounds__(256) void k_ldu_pmom_cells(LduGeo g, LduPim P, cons
     const D3 uo = ld3(Uold, c);
     double b[3] = {alphaOld[c] * rdt * uo.x, alphaOld[c] * rdt * uo.y, alphaOld[c] * rdt * uo.z};
     double divAPhi = 0.0, offsum = 0.0;
+    double bd[3] = {0, 0, 0}, bmax = 0.0, bmin = 0.0;
+    const D3 uc = ld3(U, c);
     FY_CELL_FACES(g, c, f, nb) {
         const D3 st = ld3(fstress, f);
         if (f < g.nInt) {
@@ -559,6 +597,7 @@ __global__ __launch_bounds__(256) void k_ldu_pmom_cells(LduGeo g, LduPim P, cons
                 dg += gm;
                 b[0] += (-phi[f] + gm) * ub.x; b[1] += (-phi[f] + gm) * ub.y; b[2] += (-phi[f] + gm) * ub.z;
             } else {
+                if (g.u_bc[pa] == FY_BC_U_SLIP) slip_face(g, f, (g.nu + ldu_nut_b(g, P, f)) * g.magSf[f] * g.dcNO[f], uc, bd, b, bmax, bmin);
                 dg += phi[f];
             }
         }
@@ -567,14 +606,15 @@ __global__ __launch_bounds__(256) void k_ldu_pmom_cells(LduGeo g, LduPim P, cons
     dg -= Vc * S;
     dg -= Vc * uSourceDrag[c];
     if (u_relax > 0) {
-        const double dn = fmax(fabs(dg), offsum) / u_relax;
-        const D3 uc = ld3(U, c);
+        // (a symmetry face's coefficient differs by component: relax() adds cmptMax(cmptMag(internalCoeffs)) before the dominance test and takes cmptMin off afterwards)
+        const double dn = fmax(fabs(dg + bmax), offsum) / u_relax - bmin;
         b[0] += (dn - dg) * uc.x; b[1] += (dn - dg) * uc.y; b[2] += (dn - dg) * uc.z;
         dg = dn;
     }
     M.diag[c] = dg;
     st3(M.b, c, D3{b[0], b[1], b[2]});
-    rAU[c] = 1.0 / (dg / Vc);
+    if (M.bdiag) st3(M.bdiag, c, D3{bd[0], bd[1], bd[2]});
+    rAU[c] = 1.0 / ((dg + (bd[0] + bd[1] + bd[2]) / 3.0) / Vc);
 }
 
 // continuousPhaseTurbulence->correct() (pimpleFoamYade.C:101-104) for LESModel Smagorinsky [OF-6 Smagorinsky.C: k(gradU), correctNut()], as fv_kernels.hip's

@@ -39,7 +39,8 @@ struct LduSolver {
     bool les = false;
     LduPim P() const { return LduPim{alpha.p, alpha.p, alphaf.p, uSourceDrag.p, uSource.p, {cs.g[0], cs.g[1], cs.g[2]}, les ? nut.p : nullptr, d_nutbc.p, d_nutval.p}; }      // alphac.oldTime() == alphac
     DevBuf<int> adj_err;
-    bool need_ref = true, ext_source = false;
+    bool need_ref = true, ext_source = false, has_slip = false;
+    DevBuf<double> mbdiag;       // symmetry patches: the momentum matrix's per-component boundary diagonal
     LduAmg amg;                  // the pressure matrix in ELL form; with p_solver = FY_PSOLVER_PCG_MG also the agglomeration hierarchy
     fy_step_stats st{};
     double cumulative = 0.0, total_volume = 0.0;
@@ -56,7 +57,7 @@ struct LduSolver {
         return FY_OK;
     }
     int zero(DevBuf<double>& b) { if (b.n) FY_HIP(hipMemsetAsync(b.p, 0, b.n * sizeof(double), stream)); return FY_OK; }
-    LduMom M() { return LduMom{mdiag.p, mlower.p, mupper.p, mb.p}; }
+    LduMom M() { return LduMom{mdiag.p, mlower.p, mupper.p, mb.p, has_slip ? mbdiag.p : nullptr}; }
 
     int create(const fy_poly_mesh* m, const fy_ldu_case* c, const fy_transport* tr, int dev) {
         if (!c || !(c->dt > 0) || !(c->nu >= 0) || !c->u_bc || !c->u_value || !c->p_bc || !c->p_value) return fail(FY_ERR_INVALID, "fy_ldu_solver_create: bad case (dt, nu, the per-patch arrays)");
@@ -82,7 +83,9 @@ struct LduSolver {
         std::vector<double> uval(c->u_value, c->u_value + 3 * (size_t)hm.nPatches), pval(c->p_value, c->p_value + hm.nPatches);
         need_ref = true;
         for (int pa = 0; pa < hm.nPatches; ++pa) {
-            if (ubc[(size_t)pa] != FY_BC_U_FIXED_VALUE && ubc[(size_t)pa] != FY_BC_U_ZERO_GRADIENT) return fail(FY_ERR_UNSUPPORTED, "fy_ldu_solver: velocity patch type %d (fixedValue, zeroGradient)", ubc[(size_t)pa]);
+            if (ubc[(size_t)pa] != FY_BC_U_FIXED_VALUE && ubc[(size_t)pa] != FY_BC_U_ZERO_GRADIENT && ubc[(size_t)pa] != FY_BC_U_SLIP)
+                return fail(FY_ERR_UNSUPPORTED, "fy_ldu_solver: velocity patch type %d (fixedValue, zeroGradient, symmetry / slip)", ubc[(size_t)pa]);
+            has_slip = has_slip || ubc[(size_t)pa] == FY_BC_U_SLIP;
             if (pbc[(size_t)pa] != FY_BC_P_ZERO_GRADIENT && pbc[(size_t)pa] != FY_BC_P_FIXED_VALUE && !(pimple && pbc[(size_t)pa] == FY_BC_P_FIXED_FLUX))
                 return fail(FY_ERR_UNSUPPORTED, "fy_ldu_solver: pressure patch type %d (zeroGradient, fixedValue; fixedFluxPressure with pimpleFoamYade)", pbc[(size_t)pa]);
             if (pbc[(size_t)pa] == FY_BC_P_FIXED_VALUE) need_ref = false;
@@ -107,6 +110,7 @@ struct LduSolver {
         DevBuf<double>* v1[] = {&p, &mdiag, &rAU, &pdiag, &prhs, &pr, &pu, &pw, &pp, &ps, &dummy1};
         for (auto* b : v1) { FY_TRY(b->alloc_exact(n)); FY_TRY(zero(*b)); }
         FY_TRY(vGrad.alloc_exact(9 * n)); FY_TRY(zero(vGrad));
+        if (has_slip) { FY_TRY(mbdiag.alloc_exact(3 * n)); FY_TRY(zero(mbdiag)); }
         DevBuf<double>* vf[] = {&phi, &phiOld, &rAUf, &phiHbyA, &pcoef};
         for (auto* b : vf) { FY_TRY(b->alloc_exact((size_t)nf)); FY_TRY(zero(*b)); }
         DevBuf<double>* vi[] = {&mlower, &mupper, &pcorr};
