@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define FY_ABI_VERSION 9
+#define FY_ABI_VERSION 10
 
 /* ---- status codes ------------------------------------------------------------------------------------ */
 enum {
@@ -452,7 +452,7 @@ int fy_solver_get_kernel_timing(fy_solver*, const char* kernel, double* total_ms
  * nonOrthDeltaCoeffs, nonOrthCorrectionVectors, fvc::reconstruct's tensors [OF-6]) and runs the loop bodies with owner / neighbour (LDU) addressing:
  * Euler ddt, Gauss linear | upwind | linearUpwind | limited (NVD / TVD) div, Gauss linear grad, Gauss linear CORRECTED laplacian (the explicit non-orthogonal part is what the
  * correctNonOrthogonal loop iterates on), PCG in its single-reduction form with the diagonal or an agglomeration-multigrid preconditioner (p_solver),
- * Jacobi sweeps for U.  Patches: fixedValue / zeroGradient for U (noSlip = fixedValue 0); zeroGradient / fixedValue for p, fixedFluxPressure with
+ * Jacobi sweeps for U.  Patches: fixedValue / zeroGradient / symmetry (slip) for U (noSlip = fixedValue 0), translational cyclic pairs; zeroGradient / fixedValue for p, fixedFluxPressure with
  * pimpleFoamYade.  pimpleFoamYade (fy_ldu_case.solver): Gaussian 4-way coupling, the void-fraction-weighted UcEqn / pEqn, gravity, PIMPLE outer correctors,
  * relaxation, adjustable time step, laminar Stokes stress or LES Smagorinsky.  The coupling object (fy_ldu_solver_coupling) works on the mesh's own
  * cell centres and volumes: explicit k-d tree, and for the point-force locate (mesh.findCell, FoamYade.C:251) the nearest centre followed by a walk
@@ -469,6 +469,10 @@ typedef struct fy_poly_mesh {
     int32_t n_patches;
     const int32_t* patch_start;      /* [n_patches] first face of the patch (>= n_internal_faces) */
     const int32_t* patch_size;
+    const int32_t* patch_neighbour;  /* NULL, or per patch: the index of its cyclic partner (constant/polyMesh/boundary: type cyclic; neighbourPatch), -1 for an ordinary
+                                        patch.  Translational cyclics whose faces match one to one, in order [OF-6 cyclicPolyPatch]: each pair becomes one more internal
+                                        face of the solver, numbered after the mesh's own (fy_ldu_solver_read_field_host "orig_face" maps the solver's faces to the
+                                        caller's); the patches themselves are left without faces, their entries in the per-patch arrays unused */
 } fy_poly_mesh;
 typedef struct fy_ldu_case {
     double dt, nu, rho_fluid, rho_particle;

@@ -64,6 +64,62 @@ struct Ldu {
     int nPoints = 0, nFaces = 0, nInt = 0, nCells = 0, nPatches = 0;
     std::vector<V3> pts;
     std::vector<int> foff, fpts, own, nei, pstart, psize, patch_of;      // patch_of[boundary face - nInt]
+    // cyclic pairs folded into internal faces [nIntReal, nInt) (fold_cyclics): the neighbour cell is seen at C_N + sep_f; orig_face: the caller's face of each face
+    int nIntReal = 0;
+    std::vector<V3> sep;
+    std::vector<int> orig_face;
+    V3 sepf(int f) const { return sep.empty() ? V3{0, 0, 0} : sep[f]; }
+    V3 face_centre_of(int f) const {
+        const int n = foff[f + 1] - foff[f];
+        const int* q = &fpts[foff[f]];
+        if (n == 3) return (1.0 / 3.0) * (pts[q[0]] + pts[q[1]] + pts[q[2]]);
+        V3 fc{0, 0, 0};
+        for (int a = 0; a < n; ++a) fc = fc + pts[q[a]];
+        fc = (1.0 / n) * fc;
+        V3 sumAc{0, 0, 0};
+        double sumA = 0.0;
+        for (int a = 0; a < n; ++a) {
+            const V3 p0 = pts[q[a]], p1 = pts[q[(a + 1) % n]];
+            const double aa = mag(cross(p1 - p0, fc - p0));
+            sumA += aa; sumAc = sumAc + aa * (p0 + p1 + fc);
+        }
+        return sumA < VSMALL ? fc : (1.0 / 3.0) * ((1.0 / sumA) * sumAc);
+    }
+    // [OF-6 cyclicPolyPatch / cyclicFvPatch], translational, faces matched one to one in order: the pair (face i of A, face i of B) is ONE face between the two cells behind
+    // it; owner = the lower-numbered cell, the face's points those of that cell's half; delta = patchD - nbrPatchD puts the neighbour at C_N + (Cf_own half - Cf_other half).
+    // Numbering: the mesh's internal faces, the pairs (patch order, A < B, face by face), the remaining boundary faces in patch order; the cyclic patches keep no faces
+    bool fold_cyclics(const int* pnbr) {
+        const int np = nPatches, nI = nInt;
+        std::vector<int> nfoff{0}, nfpts, nown, nnei, nps(np, 0), npz(np, 0);
+        auto add = [&](int f) { for (int q = foff[f]; q < foff[f + 1]; ++q) nfpts.push_back(fpts[q]); nfoff.push_back((int)nfpts.size()); orig_face.push_back(f); };
+        for (int f = 0; f < nI; ++f) { add(f); nown.push_back(own[f]); nnei.push_back(nei[f]); }
+        sep.assign(nI, V3{0, 0, 0});
+        for (int a = 0; a < np; ++a) {
+            const int b = pnbr[a];
+            if (b < 0 || b < a) continue;
+            if (b >= np || pnbr[b] != a || psize[a] != psize[b]) return false;
+            for (int q = 0; q < psize[a]; ++q) {
+                const int fA = pstart[a] + q, fB = pstart[b] + q, cA = own[fA], cB = own[fB];
+                if (cA == cB) return false;
+                const V3 ca = face_centre_of(fA), cb = face_centre_of(fB);
+                const bool baseA = cA < cB;
+                add(baseA ? fA : fB);
+                nown.push_back(baseA ? cA : cB); nnei.push_back(baseA ? cB : cA);
+                sep.push_back(baseA ? ca - cb : cb - ca);
+            }
+        }
+        nIntReal = nI;
+        const int nI2 = (int)nown.size();
+        for (int a = 0; a < np; ++a) {
+            nps[a] = (int)nown.size();
+            if (pnbr[a] >= 0) continue;
+            npz[a] = psize[a];
+            for (int q = 0; q < psize[a]; ++q) { add(pstart[a] + q); nown.push_back(own[pstart[a] + q]); }
+        }
+        foff = nfoff; fpts = nfpts; own = nown; nei = nnei; pstart = nps; psize = npz;
+        nFaces = (int)own.size(); nInt = nI2;
+        return true;
+    }
     // ---- geometry
     std::vector<V3> Cf, Sf, C, kvec;        // face centres / area vectors, cell centres, non-orthogonal correction vectors (internal faces)
     vec magSf, V, w, dcNO;                  // |Sf|, cell volumes, linear weights (internal), nonOrthDeltaCoeffs (all faces)
@@ -115,7 +171,8 @@ struct Ldu {
         cfaces.assign(nCells, std::vector<int>());
         for (int f = 0; f < nFaces; ++f) { cfaces[own[f]].push_back(f); if (f < nInt) cfaces[nei[f]].push_back(f); }
         std::vector<V3> cEst(nCells, V3{0, 0, 0});
-        for (int c = 0; c < nCells; ++c) { for (int f : cfaces[c]) cEst[c] = cEst[c] + Cf[f]; cEst[c] = (1.0 / cfaces[c].size()) * cEst[c]; }
+        // (a folded cyclic face seen from its neighbour cell lies at that cell's own half: Cf - sep)
+        for (int c = 0; c < nCells; ++c) { for (int f : cfaces[c]) cEst[c] = cEst[c] + (f < nInt && nei[f] == c ? Cf[f] - sepf(f) : Cf[f]); cEst[c] = (1.0 / cfaces[c].size()) * cEst[c]; }
         C.assign(nCells, V3{0, 0, 0}); V.assign(nCells, 0.0);
         for (int f = 0; f < nFaces; ++f) {
             {
@@ -126,8 +183,9 @@ struct Ldu {
             }
             if (f < nInt) {
                 const int c = nei[f];
-                const double pyr3 = std::max(dot(Sf[f], cEst[c] - Cf[f]), VSMALL);
-                const V3 pc = 0.75 * Cf[f] + 0.25 * cEst[c];
+                const V3 cfn = Cf[f] - sepf(f);
+                const double pyr3 = std::max(dot(Sf[f], cEst[c] - cfn), VSMALL);
+                const V3 pc = 0.75 * cfn + 0.25 * cEst[c];
                 C[c] = C[c] + pyr3 * pc; V[c] += pyr3;
             }
         }
@@ -135,9 +193,10 @@ struct Ldu {
         // surfaceInterpolation [OF-6]: weights, nonOrthDeltaCoeffs, nonOrthCorrectionVectors
         w.assign(nInt, 0.5); dcNO.assign(nFaces, 0.0); kvec.assign(nInt, V3{0, 0, 0});
         for (int f = 0; f < nInt; ++f) {
-            const double sOwn = std::fabs(dot(Sf[f], Cf[f] - C[own[f]])), sNei = std::fabs(dot(Sf[f], C[nei[f]] - Cf[f]));
+            const V3 cn = C[nei[f]] + sepf(f);
+            const double sOwn = std::fabs(dot(Sf[f], Cf[f] - C[own[f]])), sNei = std::fabs(dot(Sf[f], cn - Cf[f]));
             w[f] = sNei / (sOwn + sNei);
-            const V3 d = C[nei[f]] - C[own[f]];
+            const V3 d = cn - C[own[f]];
             const V3 n = (1.0 / magSf[f]) * Sf[f];
             dcNO[f] = 1.0 / std::max(dot(n, d), 0.05 * mag(d));
             kvec[f] = n - dcNO[f] * d;
@@ -571,7 +630,7 @@ struct Ldu {
         const double up = fl >= 0.0 ? 1.0 : 0.0;
         if (cs.convection_scheme <= 2) return up;
         const double gradf = lphi[nei[f]] - lphi[own[f]];
-        const double gradcf = dot(C[nei[f]] - C[own[f]], gradL[fl > 0.0 ? own[f] : nei[f]]);
+        const double gradcf = dot((C[nei[f]] + sepf(f)) - C[own[f]], gradL[fl > 0.0 ? own[f] : nei[f]]);
         double r;
         if (std::fabs(gradcf) >= 1000.0 * std::fabs(gradf)) r = 2.0 * 1000.0 * (gradcf >= 0 ? 1.0 : -1.0) * (gradf >= 0 ? 1.0 : -1.0) - 1.0;
         else r = 2.0 * (gradcf / gradf) - 1.0;
@@ -585,7 +644,7 @@ struct Ldu {
         if (cs.convection_scheme != 2) return;
         for (int f = 0; f < nInt; ++f) {
             const int up = flux[f] >= 0.0 ? own[f] : nei[f];
-            const V3 d = Cf[f] - C[up];
+            const V3 d = Cf[f] - (flux[f] >= 0.0 ? C[up] : C[up] + sepf(f));      // (a folded cyclic face: the neighbour's image)
             for (int j = 0; j < 3; ++j) {
                 const double lu = flux[f] * ((d.x * vGradNow[9 * (size_t)up + j] + d.y * vGradNow[9 * (size_t)up + 3 + j]) + d.z * vGradNow[9 * (size_t)up + 6 + j]);
                 src[3 * (size_t)own[f] + j] -= lu; src[3 * (size_t)nei[f] + j] += lu;
@@ -860,7 +919,8 @@ vec* ldu_field(Ldu* s, const std::string& n) {
 extern "C" {
 
 void* orc_ldu_create(int n_points, const double* points, int n_faces, int n_internal, const int* face_off, const int* face_pts, const int* owner,
-                     const int* neighbour, int n_cells, int n_patches, const int* patch_start, const int* patch_size, const orc_ldu_case* cs) {
+                     const int* neighbour, int n_cells, int n_patches, const int* patch_start, const int* patch_size, const int* patch_neighbour /* nullable: cyclic partners */,
+                     const orc_ldu_case* cs) {
     Ldu* s = new Ldu();
     s->nPoints = n_points; s->nFaces = n_faces; s->nInt = n_internal; s->nCells = n_cells; s->nPatches = n_patches;
     s->pts.resize(n_points);
@@ -868,8 +928,13 @@ void* orc_ldu_create(int n_points, const double* points, int n_faces, int n_inte
     s->foff.assign(face_off, face_off + n_faces + 1); s->fpts.assign(face_pts, face_pts + face_off[n_faces]);
     s->own.assign(owner, owner + n_faces); s->nei.assign(neighbour, neighbour + n_internal);
     s->pstart.assign(patch_start, patch_start + n_patches); s->psize.assign(patch_size, patch_size + n_patches);
-    s->patch_of.assign(n_faces - n_internal, -1);
-    for (int pa = 0; pa < n_patches; ++pa) for (int q = 0; q < patch_size[pa]; ++q) s->patch_of[patch_start[pa] + q - n_internal] = pa;
+    if (patch_neighbour) {
+        bool any = false;
+        for (int pa = 0; pa < n_patches; ++pa) any = any || patch_neighbour[pa] >= 0;
+        if (any && !s->fold_cyclics(patch_neighbour)) { delete s; return nullptr; }
+    }
+    s->patch_of.assign(s->nFaces - s->nInt, -1);
+    for (int pa = 0; pa < n_patches; ++pa) for (int q = 0; q < s->psize[pa]; ++q) s->patch_of[s->pstart[pa] + q - s->nInt] = pa;
     for (int v : s->patch_of) if (v < 0) { delete s; return nullptr; }
     s->cs = *cs;
     s->u_bc.assign(cs->u_bc, cs->u_bc + n_patches); s->p_bc.assign(cs->p_bc, cs->p_bc + n_patches);
@@ -894,6 +959,9 @@ int orc_ldu_geometry(void* h, const char* name, double* out) {
     if (n == "w") return put1(s->w);
     if (n == "dcNO") return put1(s->dcNO);
     if (n == "magSf") return put1(s->magSf);
+    if (n == "sep") return put3(s->sep);
+    if (n == "orig_face") { for (size_t q = 0; q < s->orig_face.size(); ++q) out[q] = s->orig_face[q]; return (int)s->orig_face.size(); }
+    if (n == "counts") { out[0] = s->nFaces; out[1] = s->nInt; out[2] = s->nIntReal; return 3; }
     return 0;
 }
 double* orc_ldu_ptr(void* h, const char* name, int* n) { vec* v = ldu_field((Ldu*)h, name); if (!v) return nullptr; *n = (int)v->size(); return v->data(); }

@@ -465,7 +465,7 @@ def _ldu_lib():
     global _ldu_ready
     L = lib()
     if not _ldu_ready:
-        L.orc_ldu_create.argtypes = [C.c_int, _dp, C.c_int, C.c_int, _ip, _ip, _ip, _ip, C.c_int, C.c_int, _ip, _ip, C.POINTER(LduCase)]
+        L.orc_ldu_create.argtypes = [C.c_int, _dp, C.c_int, C.c_int, _ip, _ip, _ip, _ip, C.c_int, C.c_int, _ip, _ip, _ip, C.POINTER(LduCase)]
         L.orc_ldu_create.restype = C.c_void_p
         L.orc_ldu_destroy.argtypes = [C.c_void_p]
         L.orc_ldu_geometry.argtypes = [C.c_void_p, C.c_char_p, _dp]
@@ -500,7 +500,8 @@ class LduSolver:
                           uv=np.ascontiguousarray(u_val, np.float64).reshape(npatch, 3), pb=np.ascontiguousarray(p_bc, np.int32),
                           pv=np.ascontiguousarray(p_val if p_val is not None else np.zeros(npatch), np.float64),
                           nb=np.ascontiguousarray(nut_bc if nut_bc is not None else np.zeros(npatch), np.int32),
-                          nv=np.ascontiguousarray(nut_val if nut_val is not None else np.zeros(npatch), np.float64))
+                          nv=np.ascontiguousarray(nut_val if nut_val is not None else np.zeros(npatch), np.float64),
+                          pn=(np.ascontiguousarray(mesh["patch_neighbour"], np.int32) if mesh.get("patch_neighbour") is not None else None))
         k = self._keep
         self.case = LduCase(solver, dt, nu, rho_f, rho_p, n_correctors, n_non_orth, momentum_predictor, p_ref_cell, p_ref_value, p_tol, p_rel_tol, p_final_tol,
                             p_final_rel_tol, p_max_iter, u_tol, u_rel_tol, u_max_iter, _i(k["ub"]), _d(k["uv"]), _i(k["pb"]), _d(k["pv"]), (C.c_double * 3)(*g), n_outer,
@@ -509,15 +510,20 @@ class LduSolver:
         self.pimple = solver == 1
         self.nc, self.nf, self.ni = int(mesh["n_cells"]), len(k["own"]), len(k["nei"])
         self.h = self.L.orc_ldu_create(k["points"].shape[0], _d(k["points"]), self.nf, self.ni, _i(k["foff"]), _i(k["fpts"]), _i(k["own"]), _i(k["nei"]),
-                                       self.nc, npatch, _i(k["ps"]), _i(k["pz"]), C.byref(self.case))
+                                       self.nc, npatch, _i(k["ps"]), _i(k["pz"]), _i(k["pn"]) if k["pn"] is not None else None, C.byref(self.case))
         if not self.h:
-            raise ValueError("oracle: malformed polyhedral mesh (a boundary face outside every patch)")
+            raise ValueError("oracle: malformed polyhedral mesh (a boundary face outside every patch, or cyclic halves that do not pair)")
+        if k["pn"] is not None:                       # cyclic pairs folded into internal faces: the solver's own face counts
+            cnt = np.zeros(3)
+            self.L.orc_ldu_geometry(self.h, b"counts", _d(cnt))
+            self.nf, self.ni = int(cnt[0]), int(cnt[1])
 
     def geometry(self, name):
-        size = {"C": 3 * self.nc, "V": self.nc, "Cf": 3 * self.nf, "Sf": 3 * self.nf, "magSf": self.nf, "w": self.ni, "dcNO": self.nf, "kvec": 3 * self.ni}[name]
+        size = {"C": 3 * self.nc, "V": self.nc, "Cf": 3 * self.nf, "Sf": 3 * self.nf, "magSf": self.nf, "w": self.ni, "dcNO": self.nf, "kvec": 3 * self.ni,
+                "sep": 3 * self.ni, "orig_face": self.nf}[name]
         out = np.empty(size)
         assert self.L.orc_ldu_geometry(self.h, name.encode(), _d(out)) == size
-        return out.reshape(-1, 3) if name in ("C", "Cf", "Sf", "kvec") else out
+        return out.reshape(-1, 3) if name in ("C", "Cf", "Sf", "kvec", "sep") else out
 
     def sngrad(self, cell_values, boundary_values, corrected=True):
         """corrected surface-normal gradient on the internal faces (correctedSnGrad [OF-6])"""

@@ -59,6 +59,39 @@ def hex_block(nx, ny, nz, lengths=(1.0, 1.0, 1.0), vertex_map=None, patches=None
                 patch_size=np.asarray(psize, np.int32), patch_names=pnames, perm=perm, shape=(nx, ny, nz))
 
 
+def make_cyclic(mesh, pairs):
+    """pairs: [(patch A, patch B)] (indices): the two patches become translational cyclic halves (mesh["patch_neighbour"]); B's faces are put in the order of A's
+    partners (the face whose point average is A's plus the mean separation of the two patches), as OpenFOAM's cyclic patches must be"""
+    m = dict(mesh)
+    off, fp = m["face_offsets"], m["face_points"]
+    faces = [list(fp[off[f]:off[f + 1]]) for f in range(len(off) - 1)]
+    own = np.array(m["owner"]).copy()
+    P = m["points"]
+    ctr = lambda f: P[faces[f]].mean(axis=0)
+    nbr = -np.ones(len(m["patch_start"]), np.int32)
+    for a, b in pairs:
+        sa, sb, n = int(m["patch_start"][a]), int(m["patch_start"][b]), int(m["patch_size"][a])
+        assert n == int(m["patch_size"][b])
+        ca = np.array([ctr(sa + q) for q in range(n)]); cb = np.array([ctr(sb + q) for q in range(n)])
+        sep = cb.mean(axis=0) - ca.mean(axis=0)
+        order = []
+        for q in range(n):
+            d = np.abs(cb - (ca[q] + sep)).sum(axis=1)
+            j = int(np.argmin(d))
+            assert d[j] < 1e-9 * (np.abs(sep).sum() + 1e-300), "the two patches are not translates of each other"
+            order.append(j)
+        assert sorted(order) == list(range(n))
+        nf = [faces[sb + j] for j in order]; no = [own[sb + j] for j in order]
+        for q in range(n):
+            faces[sb + q] = nf[q]; own[sb + q] = no[q]
+        nbr[a], nbr[b] = b, a
+    m["face_points"] = np.asarray([v for f in faces for v in f], np.int32)
+    m["face_offsets"] = np.concatenate([[0], np.cumsum([len(f) for f in faces])]).astype(np.int32)
+    m["owner"] = own.astype(np.int32)
+    m["patch_neighbour"] = nbr
+    return m
+
+
 def shear(a_xy=0.0, a_xz=0.0, a_yz=0.0):
     """x += a_xy y + a_xz z, y += a_yz z: a block of parallelepipeds (non-orthogonal, no skewness: face centres stay on the lines between cell centres)"""
     def m(P):
@@ -75,6 +108,16 @@ def wavy(amp, lengths=(1.0, 1.0, 1.0)):
         s = np.sin(np.pi * P[:, 0] / lengths[0]) * np.sin(np.pi * P[:, 1] / lengths[1]) * np.sin(np.pi * P[:, 2] / lengths[2])
         Q = P.copy()
         Q[:, 0] += amp * s * np.cos(3 * P[:, 1]); Q[:, 1] += amp * s * np.cos(2 * P[:, 2] + 1); Q[:, 2] += amp * s * np.cos(4 * P[:, 0] + 2)
+        return Q
+    return m
+
+
+def wavy_periodic(amp, lengths=(1.0, 1.0, 1.0)):
+    """every vertex displaced by a field with the box's periods (opposite sides stay translates of each other: cyclic patches): non-orthogonal, skewed cells"""
+    def m(P):
+        x, y, z = (2 * np.pi * P[:, a] / lengths[a] for a in range(3))
+        Q = P.copy()
+        Q[:, 0] += amp * np.sin(y) * np.sin(z + 0.4); Q[:, 1] += amp * np.sin(x + 0.9) * np.sin(z); Q[:, 2] += amp * np.sin(x) * np.sin(y + 0.3)
         return Q
     return m
 

@@ -161,6 +161,71 @@ def test_general_case_with_symmetry_patches_is_read(prod, tmp_path):
         prod.GeneralFoamCase(dst)
 
 
+def cyclic_case(tmp_path):
+    mesh = pm.make_cyclic(pm.hex_block(6, 5, 4, (0.1, 0.1, 0.1), pm.wavy_periodic(0.002, (0.1, 0.1, 0.1)), patches=[("movingWall", [3]), ("fixedWalls", [2, 4, 5]), ("left", [0]), ("right", [1])]),
+                          [(2, 3)])
+    dst = general_cavity(tmp_path, mesh)
+    b = dst / "constant/polyMesh/boundary"
+    t = b.read_text()
+    i, j = t.index("left"), t.index("right")
+    cyc = lambda txt, nbr: txt.replace("type wall", "type cyclic; neighbourPatch %s; transform translational" % nbr, 1).replace("type            wall", "type            cyclic; neighbourPatch %s; transform translational" % nbr, 1)
+    b.write_text(t[:i] + cyc(t[i:j], "right") + cyc(t[j:], "left"))
+    assert b.read_text().count("cyclic") == 2
+    for nm in ("U", "p"):
+        f = dst / "0" / nm
+        ft = f.read_text()
+        f.write_text(ft[:ft.rindex("}")] + "    left { type cyclic; }\n    right { type cyclic; }\n}\n")
+    return mesh, dst
+
+
+def test_general_case_with_cyclic_patches_is_read(prod, tmp_path):
+    """constant/polyMesh/boundary with a cyclic pair (neighbourPatch): the partner indices arrive in fy_poly_mesh.patch_neighbour, the fields' entries must be cyclic
+    too and are written back as they were; a rotational transform or a partner that is no cyclic patch is refused by name"""
+    mesh, dst = cyclic_case(tmp_path)
+    fc = prod.GeneralFoamCase(dst)
+    assert fc.patch_names == ["movingWall", "fixedWalls", "left", "right"]
+    np.testing.assert_array_equal(fc.mesh["patch_neighbour"], [-1, -1, 3, 2])
+    np.testing.assert_array_equal(fc.mesh["owner"], mesh["owner"])
+    fc.write_fields("0.5", np.zeros((120, 3)), np.zeros(120))
+    wt = (dst / "0.5/U").read_text()
+    assert wt.count("cyclic") == 2
+    fc.close()
+    b = dst / "constant/polyMesh/boundary"
+    t = b.read_text()
+    b.write_text(t.replace("transform translational", "transform rotational"))
+    with pytest.raises(prod.FoamYadeError, match="rotational"):
+        prod.GeneralFoamCase(dst)
+    b.write_text(t.replace("neighbourPatch right", "neighbourPatch fixedWalls"))
+    with pytest.raises(prod.FoamYadeError, match="not another cyclic patch"):
+        prod.GeneralFoamCase(dst)
+    b.write_text(t)
+    f = dst / "0/p"
+    f.write_text(f.read_text().replace("left { type cyclic; }", "left { type zeroGradient; }"))
+    with pytest.raises(prod.FoamYadeError, match="is a cyclic patch"):
+        prod.GeneralFoamCase(dst)
+
+
+@pytest.mark.gpu
+def test_foamYadeHip_executable_runs_a_cyclic_case(prod, tmp_path):
+    """foamYadeHip -solver ico on a case with a cyclic pair: the flow is carried round the period (the lid drags it along x; with walls there it would turn back)"""
+    import re
+    mesh, dst = cyclic_case(tmp_path)
+    cd = (dst / "system/controlDict").read_text()
+    cd = re.sub(r"endTime\s+[0-9.eE+-]+;", "endTime         0.05;", cd)
+    cd = re.sub(r"writeInterval\s+[0-9.eE+-]+;", "writeInterval   10;", cd)
+    (dst / "system/controlDict").write_text(cd)
+    exe = os.path.join(os.path.dirname(prod.__file__), "bin", "foamYadeHip")
+    out = subprocess.run([exe, "-solver", "ico", "-case", str(dst)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "general polyhedral mesh" in out.stdout and out.stdout.rstrip().endswith("End")
+    (dst / "system/controlDict").write_text((dst / "system/controlDict").read_text().replace("startFrom       startTime;", "startFrom       latestTime;"))
+    fc = prod.GeneralFoamCase(dst)
+    U, p = fc.initial_fields()
+    assert fc.start_time == pytest.approx(0.05) and U[:, 0].min() > 0 and U[:, 0].max() > 0.2          # every cell moves with the lid: nothing turns back at x = 0 / x = L
+    assert "cyclic" in (dst / fc.start_name / "U").read_text()
+    fc.close()
+
+
 @pytest.mark.parametrize("edit,needle", [
     (("system/fvSchemes", "Gauss linear corrected", "Gauss linear uncorrected"), "must be 'corrected'"),
     (("system/fvSchemes", "default corrected", "default orthogonal"), "must be 'corrected'"),

@@ -182,6 +182,85 @@ def test_symmetry_sides_with_oblique_normals(oracle):
     assert np.abs((pr - pr.mean()) - (p0 - p0.mean())).max() < 5e-2 * np.abs(p0 - p0.mean()).max()
 
 
+def test_cyclic_pairs_fold_into_internal_faces(oracle):
+    """translational cyclic patches [OF-6 cyclicPolyPatch / cyclicFvPatch]: each pair of faces is one more internal face whose neighbour is seen at its image -- on a
+    uniform block every folded face gets the weights, nonOrthDeltaCoeffs and (zero) correction vectors of the mesh's own faces, every cell its volume and centre; on a
+    periodically distorted block the cells stay closed and a field linear in space has its exact Gauss gradient in every cell but for the jump the period adds"""
+    n = 5
+    mesh = pm.make_cyclic(pm.hex_block(n, n + 1, n + 2, (1.0, 1.2, 1.4), renumber_seed=3), [(0, 1), (4, 5)])
+    s = make(mesh, 1e-3, 0.01, u_bc=[1, 1, 0, 0, 1, 1])
+    nfold = n * (n + 1) + (n + 1) * (n + 2)
+    assert s.ni == len(mesh["neighbour"]) + nfold and s.nf == len(mesh["owner"]) - nfold
+    V, C, w, dc, kv, sep, Sf = (s.geometry(k) for k in ("V", "C", "w", "dcNO", "kvec", "sep", "Sf"))
+    np.testing.assert_allclose(V, 1.0 * 1.2 * 1.4 / (n * (n + 1) * (n + 2)), rtol=1e-12)
+    np.testing.assert_allclose(w, 0.5, atol=1e-12); assert np.abs(kv).max() < 1e-12
+    fold = np.arange(len(mesh["neighbour"]), s.ni)
+    assert np.allclose(np.abs(sep[fold]).sum(axis=1), np.where(np.abs(Sf[fold, 0]) > 0, 1.0, 1.4)) and not sep[:fold[0]].any()
+    nrm = np.abs(Sf[:s.ni]) / np.linalg.norm(Sf[:s.ni], axis=1)[:, None]
+    np.testing.assert_allclose(dc[:s.ni], nrm @ np.array([n / 1.0, (n + 1) / 1.2, (n + 2) / 1.4]), rtol=1e-12)
+    s.close()
+    L = (1.0, 1.2, 1.4)
+    mesh = pm.make_cyclic(pm.hex_block(n, n + 1, n + 2, L, pm.wavy_periodic(0.03 * 12 / n, L), renumber_seed=3), [(0, 1), (2, 3), (4, 5)])
+    s = make(mesh, 1e-3, 0.01)
+    assert s.nf == s.ni                                                       # no boundary face left
+    Sf, V, w = s.geometry("Sf"), s.geometry("V"), s.geometry("w")
+    assert V.sum() == pytest.approx(L[0] * L[1] * L[2], rel=1e-12) and V.min() > 0 and np.abs(w - 0.5).max() > 1e-3
+    s.close()
+
+
+def test_cyclic_flow_moves_with_the_mesh(oracle):
+    """a cavity periodic in x (lid along x: a Couette-like flow with a disturbance): the same initial field moved by two cells along the period, on a differently
+    numbered mesh, gives the same flow moved by two cells -- nothing knows where the cyclic seam is"""
+    n, m = 8, 2
+    u_val = [(0, 0, 0)] * 6
+    u_val[3] = (1.0, 0, 0)
+    tol = dict(p_tol=1e-12, p_rel_tol=0.0, p_final_tol=1e-12, u_tol=1e-12)
+    rs = np.random.RandomState(5)
+    U0 = rs.rand(n, n, n, 3) * 0.2                     # [k][j][i]
+    out = []
+    for seed, shift in ((1, 0), (2, m)):
+        mesh = pm.make_cyclic(pm.hex_block(n, n, n, renumber_seed=seed), [(0, 1)])
+        s = make(mesh, 0.4 / n, 0.01, u_val=u_val, convection_scheme=4, **tol)
+        Ul = np.roll(U0, shift, axis=2).reshape(-1, 3)
+        Ug = np.zeros_like(Ul); Ug[mesh["perm"]] = Ul
+        s.set("U", Ug)
+        for _ in range(4):
+            s.step()
+        assert s.stats()["cont_sum_local"] < 1e-12
+        out.append((pm.to_lattice(mesh, s.get("U").reshape(-1, 3)).reshape(n, n, n, 3), pm.to_lattice(mesh, s.get("p")).reshape(n, n, n)))
+        s.close()
+    (Ua, pa), (Ub, pb) = out
+    assert np.abs(Ua).max() > 0.3
+    assert np.abs(np.roll(Ua, m, axis=2) - Ub).max() < 1e-9
+    pa, pb = np.roll(pa, m, axis=2), pb
+    assert np.abs((pa - pa.mean()) - (pb - pb.mean())).max() < 1e-8 * np.abs(pa - pa.mean()).max()
+
+
+@pytest.mark.parametrize("wavy", [False, True])
+def test_taylor_green_vortices_in_a_periodic_box(oracle, wavy):
+    """the exact Navier-Stokes solution u = sin x cos y F, v = -cos x sin y F, p = (cos 2x + cos 2y) F^2 / 4, F = exp(-2 nu t) in a box of period 2 pi in x, y (and z):
+    all three pairs of sides cyclic, no boundary face at all (the pressure level from the reference cell).  Second order: the error falls about fourfold from 12 to 24
+    cells per period -- on the periodically distorted mesh too (non-orthogonal correctors across the folded faces)"""
+    nu, T = 0.1, 0.5
+    L = (2 * np.pi, 2 * np.pi, 0.75)
+    errs = []
+    for n, dt in ((12, 0.02), (24, 0.005)):
+        vm = pm.wavy_periodic(0.03 * 12 / n, L) if wavy else None
+        mesh = pm.make_cyclic(pm.hex_block(n, n, 3, L, vm, renumber_seed=7), [(0, 1), (2, 3), (4, 5)])
+        s = make(mesh, dt, nu, n_non_orth=(2 if wavy else 0), p_tol=1e-11, p_rel_tol=0.0, p_final_tol=1e-11, u_tol=1e-11, p_max_iter=20000)
+        C = s.geometry("C")
+        ex = lambda t: np.stack([np.sin(C[:, 0]) * np.cos(C[:, 1]), -np.cos(C[:, 0]) * np.sin(C[:, 1]), 0 * C[:, 0]], axis=1) * np.exp(-2 * nu * t)
+        s.set("U", ex(0.0))
+        for _ in range(int(round(T / dt))):
+            s.step()
+        U = s.get("U").reshape(-1, 3)
+        errs.append(np.abs(U - ex(T)).max())
+        assert wavy or np.abs(U[:, 2]).max() < 1e-12
+        assert s.stats()["cont_sum_local"] < 1e-11
+        s.close()
+    assert errs[0] < (0.06 if wavy else 0.03) and errs[1] < errs[0] / 3.0, errs
+
+
 def test_non_orthogonal_correctors_converge_the_pressure_equation(oracle):
     """on a wavy (non-orthogonal, skewed) cavity the explicit part of the corrected laplacian, k.grad(p)_f, is formed from the pressure BEFORE each solve:
     phi = phiHbyA - pEqn.flux() is conservative whatever it was (the flux carries the same term: continuity errors at rounding with 0, 1 or 3 correctors),

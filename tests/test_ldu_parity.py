@@ -404,6 +404,78 @@ def test_symmetry_sides_on_a_lattice_equal_the_structured_hip_solver(product, so
     f.close(); g.close()
 
 
+@pytest.mark.parametrize("kind", ["ico_vanLeer", "ico_linear_upwind_mg", "pimple_cloud"])
+def test_cyclic_patches_match_the_restatement(product, oracle, kind):
+    """translational cyclic pairs (fy_poly_mesh.patch_neighbour) folded into internal faces, on a periodically distorted block: the folded geometry (weights,
+    nonOrthDeltaCoeffs, correction vectors across the seam, the image offsets), then the flow -- a channel periodic in x and z between a fixed and a moving wall with a
+    disturbance (limited / linearUpwind convection use the neighbour's IMAGE centre), and pimpleFoamYade with a cloud periodic in x and y under gravity"""
+    n = 10
+    L = (1.0, 1.0, 1.0) if kind != "pimple_cloud" else (0.1, 0.1, 0.1)
+    vm = pm.wavy_periodic(0.025 * L[0], L)
+    kw = dict(p_tol=1e-10, p_rel_tol=0.0, p_final_tol=1e-10, u_tol=1e-10, p_max_iter=5000)
+    if kind != "pimple_cloud":
+        mesh = pm.make_cyclic(pm.hex_block(n, n, n, L, vm, renumber_seed=10), [(0, 1), (4, 5)])
+        u_val = [(0, 0, 0)] * 6
+        u_val[3] = (1.0, 0, 0.4)
+        if kind == "ico_vanLeer":
+            kw.update(convection_scheme=4)
+        else:
+            kw.update(convection_scheme=2, p_solver=product.FY_PSOLVER_PCG_MG)
+        okw = {k: v for k, v in kw.items() if k != "p_solver"}
+        h = product.LduSolver(mesh, 0.4 / n, 0.01, [1, 1, 0, 0, 1, 1], u_val, [0] * 6, n_non_orth=2, **kw)
+        o = oracle.LduSolver(mesh, 0.4 / n, 0.01, [1, 1, 0, 0, 1, 1], u_val, [0] * 6, n_non_orth=2, **okw)
+        for nm in ("C", "V", "Cf", "Sf", "w", "dcNO", "kvec", "sep", "orig_face"):
+            np.testing.assert_allclose(h.geometry(nm), o.geometry(nm), rtol=0, atol=1e-13, err_msg=nm)
+        assert len(h.get("phi")) == len(mesh["owner"]) - 2 * n * n and len(h.get("mom_lower")) == len(mesh["neighbour"]) + 2 * n * n
+        U0 = np.random.RandomState(3).rand(mesh["n_cells"], 3) * 0.2
+        h.set("U", U0); o.set("U", U0)
+        for _ in range(4):
+            h.step(); o.step()
+        assert np.abs(h.get("U")).max() > 0.3
+        if kind == "ico_linear_upwind_mg":
+            assert len(h.mg_levels()) >= 2 and h.stats()["p_iters_total"] < o.stats()["p_iters_total"]
+    else:
+        dx = L[0] / n
+        mesh = pm.make_cyclic(pm.hex_block(n, n, n, L, vm, renumber_seed=8), [(0, 1), (2, 3)])
+        rel = dict(u_relax=0.8, u_relax_final=1.0, p_relax=0.7, p_relax_final=1.0)
+        h = product.LduSolver(mesh, 2e-4, 1e-5, [1, 1, 1, 1, 0, 0], [(0, 0, 0)] * 6, [0, 0, 0, 0, 2, 2], solver=1, g=(0, 0, -9.81), n_non_orth=1, n_outer_correctors=2, n_correctors=2, **rel, **kw)
+        o = oracle.LduSolver(mesh, 2e-4, 1e-5, [1, 1, 1, 1, 0, 0], [(0, 0, 0)] * 6, [0, 0, 0, 0, 2, 2], solver=1, g=(0, 0, -9.81), n_non_orth=1, n_outer=2, n_correctors=2, **rel, **kw)
+        h.hold_sources(True)
+        rs = np.random.RandomState(23)
+        for step in range(3):
+            h.set_particles(bed_particles(rs, 1500, L[0], dx))
+            h.step()
+            alpha = h.get("alpha")
+            assert alpha.min() < 0.95
+            o.step(source=h.get("uSourceCoupling"), alpha=alpha, drag=h.get("uSourceDrag"))
+            close(h.get("U"), o.get("U"), 2e-6, "U step %d" % step)
+        assert np.abs(h.get("U")).max() > 1e-4
+    ph, po = h.get("p"), o.get("p")
+    close(ph - ph.mean(), po - po.mean(), 1e-5, "p")
+    close(h.get("phi"), o.get("phi"), 1e-5, "phi")
+    close(h.get("U"), o.get("U"), 2e-6, "U")
+    h.close(); o.close()
+
+
+def test_taylor_green_vortices_in_a_periodic_box_on_the_hip_solver(product):
+    """tests/test_ldu_oracle.py::test_taylor_green_vortices_in_a_periodic_box on the HIP solver, one level finer (48 cells per period, distorted, no boundary face at
+    all), with the multigrid preconditioner: the error keeps falling (0.022, 0.0041 on the restatement at 12 and 24)"""
+    nu, T, n, dt = 0.1, 0.5, 48, 0.00125
+    L = (2 * np.pi, 2 * np.pi, 0.75)
+    mesh = pm.make_cyclic(pm.hex_block(n, n, 3, L, pm.wavy_periodic(0.03 * 12 / n, L)), [(0, 1), (2, 3), (4, 5)])
+    s = product.LduSolver(mesh, dt, nu, [1] * 6, [(0, 0, 0)] * 6, [0] * 6, n_non_orth=2, p_tol=1e-11, p_rel_tol=0.0, p_final_tol=1e-11, u_tol=1e-11, p_max_iter=5000,
+                          p_solver=product.FY_PSOLVER_PCG_MG)
+    C = s.geometry("C")
+    ex = lambda t: np.stack([np.sin(C[:, 0]) * np.cos(C[:, 1]), -np.cos(C[:, 0]) * np.sin(C[:, 1]), 0 * C[:, 0]], axis=1) * np.exp(-2 * nu * t)
+    s.set("U", ex(0.0))
+    for _ in range(int(round(T / dt))):
+        s.step()
+    err = np.abs(s.get("U").reshape(-1, 3) - ex(T)).max()
+    assert err < 0.002, err
+    assert s.stats()["cont_err_sum_local"] < 1e-10 and len(s.get("phi")) == len(s.get("mom_lower"))
+    s.close()
+
+
 def test_rayleigh_layer_on_a_distorted_mesh_on_the_hip_solver(product):
     """the transient known answer of tests/test_ldu_oracle.py::test_rayleigh_layer_on_a_distorted_mesh on the HIP solver with the multigrid preconditioner, one level finer
     (128 cells across, 131 072 cells): the error keeps falling (0.0025, 0.0011 on the restatement at 32 and 64)"""

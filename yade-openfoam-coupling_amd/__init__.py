@@ -79,7 +79,7 @@ class Transport(C.Structure):
 
 class PolyMesh(C.Structure):
     _fields_ = [("n_points", C.c_int32), ("points", _dp), ("n_faces", C.c_int32), ("n_internal_faces", C.c_int32), ("face_offsets", _ip), ("face_points", _ip),
-                ("owner", _ip), ("neighbour", _ip), ("n_cells", C.c_int32), ("n_patches", C.c_int32), ("patch_start", _ip), ("patch_size", _ip)]
+                ("owner", _ip), ("neighbour", _ip), ("n_cells", C.c_int32), ("n_patches", C.c_int32), ("patch_start", _ip), ("patch_size", _ip), ("patch_neighbour", _ip)]
 
 
 class LduCase(C.Structure):
@@ -913,7 +913,8 @@ class GeneralFoamCase(FoamCase):
         nfp = int(m.face_offsets[m.n_faces])
         self.mesh = dict(points=arr(m.points, 3 * m.n_points, np.float64).reshape(-1, 3), face_offsets=arr(m.face_offsets, m.n_faces + 1, np.int32),
                          face_points=arr(m.face_points, nfp, np.int32), owner=arr(m.owner, m.n_faces, np.int32), neighbour=arr(m.neighbour, m.n_internal_faces, np.int32),
-                         n_cells=int(m.n_cells), patch_start=arr(m.patch_start, m.n_patches, np.int32), patch_size=arr(m.patch_size, m.n_patches, np.int32))
+                         n_cells=int(m.n_cells), patch_start=arr(m.patch_start, m.n_patches, np.int32), patch_size=arr(m.patch_size, m.n_patches, np.int32),
+                         patch_neighbour=(arr(m.patch_neighbour, m.n_patches, np.int32) if m.patch_neighbour else None))
         self.patch_names = []
         for pa in range(m.n_patches):
             buf = C.create_string_buffer(128)
@@ -1070,7 +1071,10 @@ class LduSolver:
                               uv=np.ascontiguousarray(u_val, np.float64).reshape(npatch, 3), pb=i32(p_bc),
                               pv=np.ascontiguousarray(p_val if p_val is not None else np.zeros(npatch), np.float64))
         self.pm = PolyMesh(k["points"].shape[0], _d(k["points"]), len(k["own"]), len(k["nei"]), _i(k["foff"]), _i(k["fpts"]), _i(k["own"]), _i(k["nei"]), int(mesh["n_cells"]),
-                           npatch, _i(k["ps"]), _i(k["pz"]))
+                           npatch, _i(k["ps"]), _i(k["pz"]), None)
+        if mesh.get("patch_neighbour") is not None:              # cyclic pairs (fy_poly_mesh.patch_neighbour)
+            k["pn"] = i32(mesh["patch_neighbour"])
+            self.pm.patch_neighbour = _i(k["pn"])
         self.case = LduCase()
         L.fy_ldu_case_defaults(C.byref(self.case))
         self.case.dt, self.case.nu = dt, nu
@@ -1119,7 +1123,7 @@ class LduSolver:
     def get(self, name):
         out = np.zeros(self._size(name))
         _check(lib().fy_ldu_solver_read_field_host(self._h, name.encode(), _d(out)))
-        return out.reshape(-1, 3) if name in ("C", "Cf", "Sf", "kvec") else out
+        return out.reshape(-1, 3) if name in ("C", "Cf", "Sf", "kvec", "sep") else out
 
     geometry = get
 

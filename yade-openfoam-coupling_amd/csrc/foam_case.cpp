@@ -60,6 +60,7 @@ struct fy_foam_case {
     std::vector<double> g_points;
     std::vector<int32_t> g_face_off, g_face_pts, g_own, g_nei, g_patch_start, g_patch_size, g_u_bc, g_p_bc;
     std::vector<std::string> g_patch_name, g_u_text, g_p_text, g_nut_text;
+    std::vector<int32_t> g_patch_neighbour;      // per patch: its cyclic partner, or -1
     std::vector<std::string> g_patch_class;      // the boundary file's `type` per patch (wall | patch | symmetryPlane | symmetry)
     std::vector<double> g_u_val, g_p_val, g_nut_val;
     std::vector<int32_t> g_nut_bc;
@@ -719,21 +720,35 @@ int read_general_mesh(fy_foam_case* c) {
     if (!fy::foam_list_file_tokens(join(base, "boundary"), &tk, &err)) return fail(FY_ERR_INVALID, "%s", err.c_str());
     std::vector<std::pair<std::string, FoamDict> > patches;
     FY_TRY(named_dicts(tk, base + "/boundary", &patches));
+    std::vector<std::string> cyc_nbr;
     for (auto& pd : patches) {
         int nf = 0, sf = 0;
         std::string ty;
         pd.second.word("type", &ty);
         if (!pd.second.integer("nFaces", &nf) || !pd.second.integer("startFace", &sf) || nf < 0 || sf < c->g_internal || (size_t)sf + (size_t)nf > nfaces)
             return fail(FY_ERR_INVALID, "%s/boundary: patch '%s' needs nFaces and startFace among the boundary faces", base.c_str(), pd.first.c_str());
-        // the patch classes fy_ldu_solver has conditions for: another constraint patch (empty, wedge, cyclic, processor) would be silently treated as a wall
-        if (nf > 0 && ty != "wall" && ty != "patch" && ty != "symmetryPlane" && ty != "symmetry")
-            return fail(FY_ERR_UNSUPPORTED, "%s/boundary: patch '%s' of type '%s' is not supported on a general mesh (wall, patch, symmetryPlane, symmetry)", base.c_str(), pd.first.c_str(), ty.c_str());
+        // the patch classes fy_ldu_solver has conditions for: another constraint patch (empty, wedge, processor) would be silently treated as a wall
+        if (nf > 0 && ty != "wall" && ty != "patch" && ty != "symmetryPlane" && ty != "symmetry" && ty != "cyclic")
+            return fail(FY_ERR_UNSUPPORTED, "%s/boundary: patch '%s' of type '%s' is not supported on a general mesh (wall, patch, symmetryPlane, symmetry, cyclic)", base.c_str(), pd.first.c_str(), ty.c_str());
+        std::string nbr, tf;
+        if (ty == "cyclic") {
+            if (!pd.second.word("neighbourPatch", &nbr)) return fail(FY_ERR_INVALID, "%s/boundary: cyclic patch '%s' needs neighbourPatch", base.c_str(), pd.first.c_str());
+            if (pd.second.word("transform", &tf) && tf != "translational" && tf != "unknown" && tf != "noOrdering" && tf != "none")
+                return fail(FY_ERR_UNSUPPORTED, "%s/boundary: cyclic patch '%s': transform '%s' is not supported (translational cyclics)", base.c_str(), pd.first.c_str(), tf.c_str());
+        }
+        cyc_nbr.push_back(nbr);
         c->g_patch_name.push_back(pd.first);
         c->g_patch_class.push_back(ty);
         c->g_patch_start.push_back(sf);
         c->g_patch_size.push_back(nf);
     }
     if (c->g_patch_name.empty()) return fail(FY_ERR_INVALID, "%s/boundary: no patches", base.c_str());
+    c->g_patch_neighbour.assign(c->g_patch_name.size(), -1);
+    for (size_t a = 0; a < cyc_nbr.size(); ++a) {
+        if (cyc_nbr[a].empty()) continue;
+        for (size_t b = 0; b < c->g_patch_name.size(); ++b) if (c->g_patch_name[b] == cyc_nbr[a] && b != a && c->g_patch_class[b] == "cyclic") c->g_patch_neighbour[a] = (int32_t)b;
+        if (c->g_patch_neighbour[a] < 0) return fail(FY_ERR_INVALID, "%s/boundary: cyclic patch '%s': neighbourPatch '%s' is not another cyclic patch", base.c_str(), c->g_patch_name[a].c_str(), cyc_nbr[a].c_str());
+    }
     c->patch_order = c->g_patch_name;
     return FY_OK;
 }
@@ -758,8 +773,9 @@ int read_general_fields(fy_foam_case* c) {
             if (!pd || !pd->word("type", &ty)) return fail(FY_ERR_INVALID, "%s: boundaryField has no (typed) entry for patch '%s'", path.c_str(), pn);
             (which ? c->g_p_text : c->g_u_text)[pa] = entry_text(*pd);
             // [OF-6 fvPatchField::New]: a field's entry on a constraint patch must carry the patch's own type
-            if ((c->g_patch_class[pa] == "symmetryPlane" || c->g_patch_class[pa] == "symmetry") && c->g_patch_size[pa] > 0 && ty != c->g_patch_class[pa])
+            if ((c->g_patch_class[pa] == "symmetryPlane" || c->g_patch_class[pa] == "symmetry" || c->g_patch_class[pa] == "cyclic") && c->g_patch_size[pa] > 0 && ty != c->g_patch_class[pa])
                 return fail(FY_ERR_INVALID, "%s: patch '%s' is a %s patch (constant/polyMesh/boundary): its entry must be of that type, not '%s'", path.c_str(), pn, c->g_patch_class[pa].c_str(), ty.c_str());
+            if (ty == "cyclic") { (which ? c->g_p_bc[pa] : c->g_u_bc[pa]) = which ? FY_BC_P_ZERO_GRADIENT : FY_BC_U_ZERO_GRADIENT; continue; }      // (folded into internal faces: the codes are not used)
             const auto* vt = pd->tokens("value");
             if (!which) {
                 if (ty == "fixedValue") {
@@ -800,7 +816,7 @@ int read_general_fields(fy_foam_case* c) {
                 c->g_nut_bc[pa] = FY_BC_NUT_FIXED_VALUE;
                 if (!vt || vt->size() < 2 || (*vt)[0] != "uniform" || !fy::foam_tok_is_number((*vt)[1], &c->g_nut_val[pa]))
                     return fail(FY_ERR_UNSUPPORTED, "%s: patch '%s': %s needs 'value uniform <nut>'", path.c_str(), pn, ty.c_str());
-            } else if (ty != "zeroGradient" && ty != "symmetryPlane" && ty != "symmetry") return fail(FY_ERR_UNSUPPORTED, "%s: patch '%s': nut boundary type '%s' is not supported on a general mesh (zeroGradient, symmetryPlane, symmetry, fixedValue, calculated)", path.c_str(), pn, ty.c_str());
+            } else if (ty != "zeroGradient" && ty != "symmetryPlane" && ty != "symmetry" && ty != "cyclic") return fail(FY_ERR_UNSUPPORTED, "%s: patch '%s': nut boundary type '%s' is not supported on a general mesh (zeroGradient, symmetryPlane, symmetry, cyclic, fixedValue, calculated)", path.c_str(), pn, ty.c_str());
         }
     }
     return FY_OK;
@@ -1347,6 +1363,8 @@ int fy_foam_case_poly_mesh(const fy_foam_case* c, fy_poly_mesh* out) {
     out->owner = c->g_own.data(); out->neighbour = c->g_nei.data();
     out->n_cells = c->g_cells;
     out->n_patches = (int32_t)c->g_patch_name.size(); out->patch_start = c->g_patch_start.data(); out->patch_size = c->g_patch_size.data();
+    out->patch_neighbour = nullptr;
+    for (int32_t v : c->g_patch_neighbour) if (v >= 0) out->patch_neighbour = c->g_patch_neighbour.data();
     return FY_OK;
 }
 

@@ -24,6 +24,12 @@ struct LduHostMesh {
     std::vector<double> Cf, Sf, magSf, C, V, w, dcNO, kvec;      // [3 nF] [3 nF] [nF] [3 nc] [nc] [nInt] [nF] [3 nInt]
     std::vector<double> recon;                          // [9 nc] inv(sum_f Sf Sf / |Sf|): fvc::reconstruct's tensor [OF-6 fvcReconstruct.C]
     double bbox_min[3], bbox_max[3];
+    // cyclic patches folded into internal faces (ldu_mesh.cpp): faces [n_real_internal, nInt) are the folded pairs; sep [3 nInt] (empty without a cyclic pair):
+    // the neighbour cell's image is C_N + sep_f; orig_face[f] = the caller's face the solver's face f was made from; the folded mesh's own arrays
+    int n_real_internal = 0;
+    std::vector<double> sep;
+    std::vector<int32_t> orig_face, f_off, f_pts, f_own, f_nei, f_pstart, f_psize;
+    int fold_cyclics(fy_poly_mesh* m);
     int build(const fy_poly_mesh* m);                   // FY_OK or an error (malformed addressing)
 };
 
@@ -45,6 +51,8 @@ struct LduGeo {
     const double* gradL;                                 // [3 nc] Gauss-linear gradient of |U|^2 of the iterate the matrix is assembled from (limited schemes; else null)
     int need_ref, p_ref_cell;
     double p_ref_value;
+    const double* sep;                                   // [3 nInt] or null: folded cyclic faces -- the neighbour cell's image is C_N + sep_f (zero on the mesh's own internal faces)
+    int nIntReal;                                        // faces [nIntReal, nInt) are folded cyclic pairs
 };
 
 // momentum matrix in LDU form: diag [nc] (boundary diagonal included), lower / upper per internal face, b [3 nc] (boundary sources included)

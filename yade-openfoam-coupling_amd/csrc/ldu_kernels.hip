@@ -181,7 +181,9 @@ __device__ __forceinline__ double ldu_conv_weight(const LduGeo& g, int f, double
     if (g.upwind <= 2) return up;
     const int o = g.own[f], n = g.nei[f];
     const double gradf = msq(ld3(U, n)) - msq(ld3(U, o));
-    const D3 co = ld3(g.C, o), cn = ld3(g.C, n), gl = ld3(g.gradL, fl > 0.0 ? o : n);
+    const D3 co = ld3(g.C, o), gl = ld3(g.gradL, fl > 0.0 ? o : n);
+    D3 cn = ld3(g.C, n);
+    if (g.sep) { const D3 sp = ld3(g.sep, f); cn = D3{cn.x + sp.x, cn.y + sp.y, cn.z + sp.z}; }      // (a folded cyclic face: the neighbour's image)
     const double gradcf = ((cn.x - co.x) * gl.x + (cn.y - co.y) * gl.y) + (cn.z - co.z) * gl.z;
     double r;
     if (fabs(gradcf) >= 1000.0 * fabs(gradf)) r = 2.0 * 1000.0 * (gradcf >= 0 ? 1.0 : -1.0) * (gradf >= 0 ? 1.0 : -1.0) - 1.0;
@@ -194,7 +196,9 @@ __device__ __forceinline__ double ldu_conv_weight(const LduGeo& g, int f, double
 // (deferred correction) with the Gauss-linear gradient of the iterate the matrix is assembled from; returned as the flux of it, fl (d . grad U)_j
 __device__ __forceinline__ void linear_upwind_flux(const LduGeo& g, int f, double fl, const double* __restrict__ gradU, double (&lu)[3]) {
     const int up = fl >= 0.0 ? g.own[f] : g.nei[f];
-    const D3 cf = ld3(g.Cf, f), cu = ld3(g.C, up);
+    const D3 cf = ld3(g.Cf, f);
+    D3 cu = ld3(g.C, up);
+    if (g.sep && fl < 0.0) { const D3 sp = ld3(g.sep, f); cu = D3{cu.x + sp.x, cu.y + sp.y, cu.z + sp.z}; }      // (a folded cyclic face: the neighbour's image)
     const double d[3] = {cf.x - cu.x, cf.y - cu.y, cf.z - cu.z};
     const double* T = gradU + 9 * (size_t)up;
 #pragma unroll
@@ -770,10 +774,13 @@ __global__ __launch_bounds__(256) void k_ldu_find_cell(LduGeo g, const double* _
         int wf = -1, wn = -1;
         const double tol = 1e-10 * cbrt(g.V[c]);
         FY_CELL_FACES(g, c, f, nb) {
-            const D3 S = ld3(g.Sf, f), cf = ld3(g.Cf, f);
+            const D3 S = ld3(g.Sf, f);
+            D3 cf = ld3(g.Cf, f);
             const double sg = (f >= g.nInt || nb > c) ? 1.0 : -1.0;
+            const bool folded = g.sep && f >= g.nIntReal && f < g.nInt;
+            if (folded && sg < 0) { const D3 sp = ld3(g.sep, f); cf = D3{cf.x - sp.x, cf.y - sp.y, cf.z - sp.z}; }      // (seen from the neighbour, the face lies at that cell's own half)
             const double s = sg * dot3(D3{x.x - cf.x, x.y - cf.y, x.z - cf.z}, S) / g.magSf[f];
-            if (s > worst) { worst = s; wf = f; wn = nb; }
+            if (s > worst) { worst = s; wf = f; wn = folded ? -1 : nb; }      // (beyond a cyclic half = outside the mesh, as mesh.findCell has it)
         }
         if (wf < 0 || worst <= tol) break;
         c = wn;                                     // (-1 across a boundary face: outside the mesh)
@@ -850,6 +857,7 @@ int launch_ldu_adjust_phi(hipStream_t s, LduGeo g, double* phiHbyA, double* sums
     hipLaunchKernelGGL(k_ldu_adjust_sums, dim3(red_blocks(g.nFaces)), dim3(256), 0, s, g, phiHbyA, partials);
     FY_LAUNCH_CHECK();
     FY_TRY(launch_reduce_finalize(s, partials, g.nFaces, 4, nullptr, sums4, nullptr, 0));
+    if (g.nFaces == g.nInt) return FY_OK;                 // (every side cyclic: no boundary face to adjust)
     hipLaunchKernelGGL(k_ldu_adjust_apply, dim3(div_up(g.nFaces - g.nInt, 256)), dim3(256), 0, s, g, sums4, phiHbyA, err);
     FY_LAUNCH_CHECK();
     return FY_OK;

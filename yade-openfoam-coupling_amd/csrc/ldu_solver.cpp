@@ -40,6 +40,8 @@ struct LduSolver {
     LduPim P() const { return LduPim{alpha.p, alpha.p, alphaf.p, uSourceDrag.p, uSource.p, {cs.g[0], cs.g[1], cs.g[2]}, les ? nut.p : nullptr, d_nutbc.p, d_nutval.p}; }      // alphac.oldTime() == alphac
     DevBuf<int> adj_err;
     bool need_ref = true, ext_source = false, has_slip = false;
+    std::vector<double> orig_face_d;      // hm.orig_face as doubles (the field read-out's type); empty without a cyclic pair
+    DevBuf<double> d_sep;        // folded cyclic faces: the neighbour image's offset per internal face
     DevBuf<double> mbdiag;       // symmetry patches: the momentum matrix's per-component boundary diagonal
     LduAmg amg;                  // the pressure matrix in ELL form; with p_solver = FY_PSOLVER_PCG_MG also the agglomeration hierarchy
     fy_step_stats st{};
@@ -102,6 +104,9 @@ struct LduSolver {
         if (pimple) { FY_TRY(psn.alloc_exact(std::max<size_t>((size_t)(nf - ni), 1))); FY_TRY(zero(psn)); }
         g = LduGeo{nc, nf, ni, hm.nPatches, d_own.p, d_nei.p, d_patch_of.p, d_cf_off.p, d_cf_face.p, hm.Wall, d_ef.p, d_en.p, d_Cf.p, d_Sf.p, d_magSf.p, d_C.p, d_V.p, d_w.p, d_dcNO.p, d_kvec.p,
                    d_ubc.p, d_pbc.p, d_uval.p, d_pval.p, d_recon.p, pimple ? psn.p : nullptr, cs.dt, cs.nu, cs.convection_scheme, 2.0 / std::max(cs.convection_limiter_k, 1e-15), nullptr, need_ref ? 1 : 0, cs.p_ref_cell, cs.p_ref_value};
+        if (!hm.sep.empty()) { FY_TRY(up(d_sep, hm.sep)); g.sep = d_sep.p; }
+        g.nIntReal = hm.n_real_internal;
+        orig_face_d.assign(hm.orig_face.begin(), hm.orig_face.end());
         total_volume = 0.0;
         for (double v : hm.V) total_volume += v;
         const size_t n = (size_t)nc;
@@ -386,7 +391,7 @@ struct LduSolver {
                          {"rAUf", rAUf.p, (size_t)nf}, {"uSourceCoupling", uSource.p, 3 * n}, {"nut", nut.p, les ? n : 0}};
         for (const E& e : tab) if (s == e.nm) { *ptr = e.p; *count = e.c; return FY_OK; }
         const struct { const char* nm; const std::vector<double>* v; } geo[] = {{"C", &hm.C}, {"V", &hm.V}, {"Cf", &hm.Cf}, {"Sf", &hm.Sf}, {"magSf", &hm.magSf}, {"w", &hm.w},
-                                                                                  {"dcNO", &hm.dcNO}, {"kvec", &hm.kvec}};
+                                                                                  {"dcNO", &hm.dcNO}, {"kvec", &hm.kvec}, {"sep", &hm.sep}, {"orig_face", &orig_face_d}};
         for (const auto& e : geo) if (s == e.nm) { *host = e.v; *count = e.v->size(); *ptr = nullptr; return FY_OK; }
         return fail(FY_ERR_INVALID, "unknown fy_ldu_solver field '%s'", s.c_str());
     }
