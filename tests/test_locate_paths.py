@@ -18,3 +18,15 @@ def test_particle_parity_on_the_tree_walk_path():
                         "-k", "set_particle_action or seeded or lattice or lists_equal"], env=env, cwd=os.path.dirname(HERE), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
+
+
+@pytest.mark.parametrize("cap", ["2", "5"])
+def test_explicit_tree_walk_on_a_short_stack(cap):
+    """the explicit-tree walk (graded blocks, general meshes) keeps its DFS stack in LDS, as deep as 99.8 % of the walks sampled so far have needed (more waves per CU);
+    a walk that needs more is given up and walked again by a second launch with the full depth.  FOAMYADE_LOCATE_STACK forces a depth: with 2 or 5 entries most walks
+    overflow -- the golden vectors of the reference on graded meshes and the restatement's chains on a general mesh must come out bit for bit all the same"""
+    env = dict(os.environ, FOAMYADE_LOCATE_STACK=cap)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(HERE, "test_graded_mesh.py"), os.path.join(HERE, "test_ldu_parity.py"), "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider",
+                        "-k", "product_on_a_graded_mesh or with_a_cloud or gaussian or point_force"], env=env, cwd=os.path.dirname(HERE), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout

@@ -623,7 +623,25 @@ int Coupling::run_batch(Batch& b) {
         LocateLists ll{};
         if (use_implicit && d_loc_lists.p) {
             if (d_loc_fb.n < (size_t)b.n) FY_TRY(d_loc_fb.alloc_exact((size_t)b.n + (size_t)b.n / 8));
-            ll = LocateLists{d_loc_lists.p, d_loc_fb.p, d_loc_fb_n.p, loc_cell0, loc_n_listed};
+            ll = LocateLists{d_loc_lists.p, d_loc_fb.p, d_loc_fb_n.p, loc_cell0, loc_n_listed, 0, nullptr};
+        } else if (!use_implicit) {                        // explicit tree: the list of the walks the short stack gives up (launch_locate)
+            if (!d_loc_fb_n.p) FY_TRY(d_loc_fb_n.alloc_exact(1));
+            if (d_loc_fb.n < (size_t)b.n) FY_TRY(d_loc_fb.alloc_exact((size_t)b.n + (size_t)b.n / 8));
+            if (!d_loc_hwm.p) {
+                FY_TRY(d_loc_hwm.alloc_exact(kLocDepthBins)); FY_TRY(h_loc_hwm.reserve(kLocDepthBins));
+                FY_HIP(hipMemsetAsync(d_loc_hwm.p, 0, kLocDepthBins * sizeof(unsigned int), stream));
+                for (int q = 0; q < kLocDepthBins; ++q) h_loc_hwm[q] = 0;
+            }
+            // the stack of this step: the depth that has served 99.8 % of the walks sampled so far, as last copied back (the first step runs the full depth and measures);
+            // the others overflow into the second launch
+            static const int forced = [] { const char* e = getenv("FOAMYADE_LOCATE_STACK"); return e ? atoi(e) : -1; }();      // (experiments: 0 = always the full depth)
+            unsigned long long total = 0, run = 0;
+            unsigned int hist[kLocDepthBins];
+            for (int q = 0; q < kLocDepthBins; ++q) { hist[q] = ((volatile unsigned int*)h_loc_hwm.p)[q]; total += hist[q]; }
+            int seen = 0;
+            if (total >= 1000) for (seen = 0; seen < kLocDepthBins - 1; ++seen) { run += hist[seen]; if (run * 1000 >= total * 998) break; }
+            seen = seen > 0 ? std::max(seen, 4) : 0;
+            ll = LocateLists{nullptr, d_loc_fb.p, d_loc_fb_n.p, 0, 0, forced >= 0 ? forced : seen, d_loc_hwm.p};
         }
         const CellWindow cw{slab.active ? slab.base : 0, n_field};
         // the scatters' tables are flushed into per-tile buckets sized from the demand they counted in this batch's last step
@@ -633,6 +651,7 @@ int Coupling::run_batch(Batch& b) {
         FY_TRY(launch_locate_deposit(stream, d_tree.p, use_implicit ? d_tree_packed.p : nullptr, implicit, n_cells, tree_levels, p, b.n, gp,
                                      use_implicit ? d_loc_start.p : nullptr, own_of(b), ll, cw, d_pvol_acc.p, d_up_acc.p, d_touched.p, tbD, side,
                                      fused_gather ? b.d_rec : nullptr));
+        if (ll.depth_hwm) FY_HIP(hipMemcpyAsync(h_loc_hwm.p, d_loc_hwm.p, kLocDepthBins * sizeof(unsigned int), hipMemcpyDeviceToHost, stream));      // (read at the next step's launch, no wait)
         b.chain_n = b.n;                                   // (what the next placement's runs are ordered by)
         if (timing) marks.mark(2, stream);
         if (mid_hook && !mid_hook_done) {                  // the solver's field sweep: beside the side stream's walk (its own mark pair: it is taken off the phase it falls into)

@@ -102,6 +102,8 @@ struct Coupling {
     DevBuf<unsigned short> d_loc_lists;       // per-(cell, octant) candidate lists (implicit trees; launch_build_locate_lists), built with it
     DevBuf<int32_t> d_loc_fb;                 // particles the lists do not cover (work list of the walk) + their count
     DevBuf<unsigned int> d_loc_fb_n;
+    DevBuf<unsigned int> d_loc_hwm;           // explicit tree: histogram of the walks' stack depths (k_locate, one walk in 64), and its pinned host copy
+    HostBuf<unsigned int> h_loc_hwm;
     bool loc_lists_tried = false;
     int32_t loc_cell0 = 0, loc_n_listed = 0;  // cells the lists cover (a slab: its own planes)
     int ensure_locate_tables(double maxdist);

@@ -417,7 +417,10 @@ template <bool IMPLICIT>
 __global__ __launch_bounds__(kWave) void k_locate(const KdNode* __restrict__ tree, const uint32_t* __restrict__ packed, ImplicitGeom ig,
                                                   int32_t n_cells, ParticleSoA p, int64_t n, double maxdist,
                                                   const unsigned long long* __restrict__ start, SlabOwn own,
-                                                  const int32_t* __restrict__ work, const unsigned int* __restrict__ work_n, WalkDeposit wd) {
+                                                  const int32_t* __restrict__ work, const unsigned int* __restrict__ work_n, WalkDeposit wd,
+                                                  int stack_cap, int32_t* __restrict__ ovf_list, unsigned int* __restrict__ ovf_count, unsigned int* __restrict__ depth_hwm) {
+    // ovf_list != null: the LDS stack holds stack_cap entries per lane only (more waves per CU: the kernel is latency bound); a walk that would need more is given up and its
+    // particle filed in ovf_list for a second launch with the full depth -- every particle is walked from its start by exactly one of the two, so the chains are the same
     typedef typename StackEntry<IMPLICIT>::type entry_t;
     extern __shared__ __attribute__((aligned(16))) unsigned char stack_raw[];
     entry_t* stack = reinterpret_cast<entry_t*>(stack_raw);
@@ -434,7 +437,7 @@ __global__ __launch_bounds__(kWave) void k_locate(const KdNode* __restrict__ tre
     bool active = false;
     int64_t i = 0;
     double qx = 0, qy = 0, qz = 0, best = 0;
-    int chain = 0, sp = 0;
+    int chain = 0, sp = 0, spmax = 0;
     uint32_t o = 0, nn = 0, axis = 0;
     for (;;) {
         // ---- hand new particles to idle lanes (batched: the refill code is wave-wide, so wait until it pays)
@@ -451,7 +454,12 @@ __global__ __launch_bounds__(kWave) void k_locate(const KdNode* __restrict__ tre
                 best = a * a;
                 best += b * b;
                 best += c * c;
-                chain = 0; sp = 0; o = 0; nn = (uint32_t)n_cells; axis = 0;
+                // Round 4: the walk starts from best = min(|q - root|^2, maxdist).  The chain is the same: a centre is queued iff it is nearer than maxdist AND than every
+                // centre visited before it (meshTree.C:192-196), and centres at or beyond maxdist -- the only ones a smaller starting bound hides, in the subtrees whose
+                // split plane is at least sqrt(maxdist) away -- can neither be queued nor outbid one that is.  What changes is the stack: the far sides of the top levels,
+                // pushed while `best` is still the distance to some far ancestor and dropped again at their pop, are not pushed at all
+                best = fmin(best, maxdist);
+                chain = 0; sp = 0; spmax = 0; o = 0; nn = (uint32_t)n_cells; axis = 0;
                 if constexpr (IMPLICIT) {
                     if (start) {                                 // skip the levels the query's cell determines (k_build_locate_start)
                         const double fx = floor((qx - ig.ox) / ig.dx), fy_ = floor((qy - ig.oy) / ig.dx), fz = floor((qz - ig.oz) / ig.dx);
@@ -480,7 +488,11 @@ __global__ __launch_bounds__(kWave) void k_locate(const KdNode* __restrict__ tre
                 for (int attempt = 0; attempt < 2; ++attempt) {
                     if (nn != 0) break;
                     if (sp == 0) {
-                        if (active) { p.chain_len[i] = chain; active = false; if (wd.pvol_acc) walk_deposit(p, i, chain, wd); }    // walk finished; k = min(chain, 16)
+                        if (active) {                                          // walk finished; k = min(chain, 16)
+                            p.chain_len[i] = chain; active = false;
+                            if (wd.pvol_acc) walk_deposit(p, i, chain, wd);
+                            if (depth_hwm && (i & 63) == 0) atomicAdd(&depth_hwm[min(spmax, kLocDepthBins - 1)], 1u);      // (one walk in 64: a histogram of the stack depths)
+                        }
                         break;
                     }
                     --sp;
@@ -542,7 +554,10 @@ __global__ __launch_bounds__(kWave) void k_locate(const KdNode* __restrict__ tre
                 const uint32_t paxis = axis;
                 axis = (axis == 2 ? 0 : axis + 1);
                 // best only decreases, so a far side that already fails df2 < best can never pass later
-                if (far_n > 0 && df2 < best) {
+                if (far_n > 0 && df2 < best && ovf_list && sp >= stack_cap) {
+                    ovf_list[atomicAdd(ovf_count, 1u)] = (int32_t)i;
+                    active = false;
+                } else if (far_n > 0 && df2 < best) {
                     if constexpr (IMPLICIT) {
                         const unsigned long long idx = (paxis == 0 ? (pk & 1023u) : (paxis == 1 ? ((pk >> 10) & 1023u) : (pk >> 20)));
                         STK(sp) = (unsigned long long)far_o | ((unsigned long long)far_n << 25) | ((unsigned long long)axis << 50) | (idx << 52);
@@ -553,6 +568,7 @@ __global__ __launch_bounds__(kWave) void k_locate(const KdNode* __restrict__ tre
                         STK(sp) = e;
                     }
                     ++sp;
+                    spmax = max(spmax, sp);
                 }
                 o = near_o; nn = near_n;
             }
@@ -1530,9 +1546,20 @@ int launch_locate(hipStream_t s, const KdNode* tree, const uint32_t* packed, Imp
     const size_t lds = (size_t)(levels + 1) * kWave * (packed ? sizeof(unsigned long long) : sizeof(uint4));
     const dim3 grid(div_up(n, kLocPPB));
     if (packed) {
-        hipLaunchKernelGGL(k_locate<true>, grid, dim3(kWave), lds, s, tree, packed, ig, n_cells, p, n, gp.maxdist, start, own, nullptr, nullptr, WalkDeposit{});
+        hipLaunchKernelGGL(k_locate<true>, grid, dim3(kWave), lds, s, tree, packed, ig, n_cells, p, n, gp.maxdist, start, own, nullptr, nullptr, WalkDeposit{}, 0, nullptr, nullptr, nullptr);
+    } else if (ll.fb_list && ll.fb_count && ll.stack_cap > 0 && ll.stack_cap < levels + 1) {
+        // explicit 16-byte entries: (levels + 1) of them per lane are 23 KB per wave at 4 M cells = 6 waves per CU, and the kernel is latency bound.  The stack never gets that
+        // deep (starting from best <= maxdist only the split planes within the search radius of the query are stacked): a stack of the depth the walks have been seen to
+        // need (ll.depth_hwm) serves them all, and a walk that needs more than that takes the second launch
+        const int cap = ll.stack_cap;
+        FY_HIP(hipMemsetAsync(ll.fb_count, 0, sizeof(unsigned int), s));
+        hipLaunchKernelGGL(k_locate<false>, grid, dim3(kWave), (size_t)cap * kWave * sizeof(uint4), s, tree, packed, ig, n_cells, p, n, gp.maxdist, nullptr, own, nullptr, nullptr,
+                           WalkDeposit{}, cap, ll.fb_list, ll.fb_count, ll.depth_hwm);
+        FY_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_locate<false>, grid, dim3(kWave), lds, s, tree, packed, ig, n_cells, p, n, gp.maxdist, nullptr, own, ll.fb_list, ll.fb_count, WalkDeposit{}, 0, nullptr, nullptr,
+                           ll.depth_hwm);
     } else {
-        hipLaunchKernelGGL(k_locate<false>, grid, dim3(kWave), lds, s, tree, packed, ig, n_cells, p, n, gp.maxdist, nullptr, own, nullptr, nullptr, WalkDeposit{});
+        hipLaunchKernelGGL(k_locate<false>, grid, dim3(kWave), lds, s, tree, packed, ig, n_cells, p, n, gp.maxdist, nullptr, own, nullptr, nullptr, WalkDeposit{}, 0, nullptr, nullptr, ll.depth_hwm);
     }
     FY_LAUNCH_CHECK();
     return FY_OK;
@@ -1560,7 +1587,7 @@ int launch_locate_deposit(hipStream_t s, const KdNode* tree, const uint32_t* pac
     if (n <= 0) return FY_OK;
     if (rec_gather && !(packed && ll.lists)) return fail(FY_ERR_INVALID, "launch_locate_deposit: the fused record gather needs the candidate lists");
     if (!(packed && ll.lists)) {
-        FY_TRY(launch_locate(s, tree, packed, ig, n_cells, levels, p, n, gp, start, own, LocateLists{}));
+        FY_TRY(launch_locate(s, tree, packed, ig, n_cells, levels, p, n, gp, start, own, packed ? LocateLists{} : ll));      // (explicit tree: ll carries the overflow list)
         return launch_deposit(s, p, n, gp, cw, pvol_acc, up_acc, touched, tb);
     }
     if (n_cells >= (1 << 25)) return fail(FY_ERR_UNSUPPORTED, "implicit-coordinate tree limited to 2^25 cells");
@@ -1579,7 +1606,7 @@ int launch_locate_deposit(hipStream_t s, const KdNode* tree, const uint32_t* pac
     const size_t lds = (size_t)(levels + 1) * kWave * sizeof(unsigned long long);
     const dim3 wgrid((unsigned)std::min<int64_t>(div_up(n, kLocPPB), 2048));
     hipLaunchKernelGGL(k_locate<true>, wgrid, dim3(kWave), lds, w, tree, packed, ig, n_cells, p, n, gp.maxdist, start, SlabOwn{}, ll.fb_list, ll.fb_count,
-                       WalkDeposit{gp, cw, pvol_acc, up_acc, touched});
+                       WalkDeposit{gp, cw, pvol_acc, up_acc, touched}, 0, nullptr, nullptr, nullptr);
     FY_LAUNCH_CHECK();
     if (side.stream) FY_HIP(hipEventRecord(side.join, side.stream));
     return FY_OK;

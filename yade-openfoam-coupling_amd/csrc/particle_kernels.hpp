@@ -85,7 +85,13 @@ struct LocateLists {
     int32_t* fb_list;
     unsigned int* fb_count;
     int32_t cell0, n_listed;             // the lists cover cells [cell0, cell0 + n_listed): the whole block, or a slab's own planes
+    // explicit trees (lists == nullptr): the walk's short LDS stack -- stack_cap entries per lane (0: the full depth), the walks that need more go to fb_list and a
+    // second launch; depth_hwm (device, nullable): kLocDepthBins counters, a histogram of the deepest stack of one walk in 64, from which the caller picks the next
+    // step's stack_cap
+    int32_t stack_cap;
+    unsigned int* depth_hwm;
 };
+constexpr int kLocDepthBins = 32;
 constexpr int kLocateListLen = 24;       // codes (2 B) per (cell, octant)
 int launch_locate(hipStream_t s, const KdNode* tree, const uint32_t* packed, ImplicitGeom ig, int32_t n_cells, int levels,
                   ParticleSoA p, int64_t n, GaussParams gp, const unsigned long long* start = nullptr, SlabOwn own = SlabOwn{},
