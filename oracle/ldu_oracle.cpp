@@ -46,11 +46,14 @@ extern "C" struct orc_ldu_case {
     int n_outer;
     double u_relax, u_relax_final, p_relax, p_relax_final;      // <= 0: no relaxationFactors entry
     int adjust_time_step; double max_co, max_delta_t;           // setDeltaT.H (pimpleFoamYade.C:62-64)
-    int turbulence_model;                                       // 0 laminar, 1 LES Smagorinsky (delta cubeRootVol)
+    int turbulence_model;                                       // 0 laminar, 1 LES Smagorinsky, 2 LES kEqn (delta cubeRootVol)
     double les_ck, les_ce, les_delta_coeff, nut_initial;
     const int* nut_bc; const double* nut_value;                 // per patch: 0 zeroGradient, 1 fixedValue
     int convection_scheme;                                      // 0 Gauss linear, 1 Gauss upwind, 2 Gauss linearUpwind grad(U), 3 .. 8 limitedLinear k / vanLeer / MUSCL / Minmod / SuperBee / QUICK
     double convection_limiter_k;
+    // turbulence_model 2: LES kEqn -- the 0/k file (k_initial, per patch 0 zeroGradient / 1 fixedValue), div(alphaPhic,k) (0 linear, 1 upwind), solvers.k, relaxationFactors k;
+    // nut_bc may then be 3 (calculated: Ck sqrt(k_b) delta once correctNut() has run, the file's value before)
+    double k_initial; const int* k_bc; const double* k_value; int k_convection_scheme; double k_tol, k_rel_tol; int k_max_iter; double k_relax;
 };
 extern "C" struct orc_ldu_stats {
     double courant_mean, courant_max, cont_sum_local, cont_global, cont_cumulative;
@@ -136,6 +139,18 @@ struct Ldu {
     // pimpleFoamYade: the coupling's fields (set from outside between step_begin and step_end), the face fields of the alpha-weighted equations
     vec alpha, uSourceDrag, uParticle, gradP, divT, ddtU, alphaf, phiForces, psn, recon, pPrev, nut;
     std::vector<int> nut_bc; vec nut_val;
+    vec kturb; std::vector<int> k_bc; vec k_val;      // LES kEqn
+    bool nut_live = false;                             // correctNut() has run: a `calculated` nut patch carries the model's expression, before that the file's value
+    int k_iters = 0;
+    double kb_of(int pa, int c) const { return k_bc[pa] == 1 ? k_val[pa] : kturb[c]; }
+    double les_delta(int c) const { return cs.les_delta_coeff * std::cbrt(V[c]); }
+    // nut on boundary face f (patch pa, cell c): zeroGradient, fixedValue, or calculated [OF-6 GeometricField::operator=: nut_ = Ck sqrt(k_) delta assigns the patches too]
+    double nut_bnd(int pa, int c) const {
+        if (nut.empty()) return 0.0;
+        if (nut_bc[pa] == 1 || (nut_bc[pa] == 3 && !nut_live)) return nut_val[pa];
+        if (nut_bc[pa] == 3) return cs.les_ck * std::sqrt(kb_of(pa, c)) * les_delta(c);
+        return nut[c];
+    }
     bool pimple = false;
     orc_ldu_stats st{};
     double cumulative = 0.0;
@@ -266,10 +281,15 @@ struct Ldu {
         if (pimple) {
             alpha.assign(nc, 1.0); uSourceDrag.assign(nc, 0.0); uParticle.assign(3 * nc, 0.0); gradP = uParticle; divT = uParticle; ddtU = uParticle;
             alphaf.assign(nFaces, 1.0); phiForces.assign(nFaces, 0.0); psn.assign(nFaces - nInt, 0.0); pPrev = p;
-            if (cs.turbulence_model == 1) {
+            if (cs.turbulence_model == 1 || cs.turbulence_model == 2) {
                 nut.assign(nc, cs.nut_initial);
                 nut_bc.assign(nPatches, 0); nut_val.assign(nPatches, 0.0);
                 for (int pa = 0; pa < nPatches; ++pa) { if (cs.nut_bc) nut_bc[pa] = cs.nut_bc[pa]; if (cs.nut_value) nut_val[pa] = cs.nut_value[pa]; }
+            }
+            if (cs.turbulence_model == 2) {
+                kturb.assign(nc, cs.k_initial);
+                k_bc.assign(nPatches, 0); k_val.assign(nPatches, 0.0);
+                for (int pa = 0; pa < nPatches; ++pa) { if (cs.k_bc) k_bc[pa] = cs.k_bc[pa]; if (cs.k_value) k_val[pa] = cs.k_value[pa]; }
             }
             // fvc::reconstruct's tensor per cell: inv(sum_f Sf Sf / |Sf|) [OF-6 fvcReconstruct.C]
             vec T(9 * nc, 0.0);
@@ -397,7 +417,7 @@ struct Ldu {
         }
         for (int f = nInt; f < nFaces; ++f) {
             const int b = f - nInt, pa = patch_of[b], c = own[f];
-            const double nutb = nut.empty() ? 0.0 : (nut_bc[pa] == 1 ? nut_val[pa] : nut[c]);
+            const double nutb = nut_bnd(pa, c);
             const double g = (cs.nu + nutb) * magSf[f] * dcNO[f];        // (alphac's boundary value is 1)
             divAPhi[c] += phi[f];
             double t[3];
@@ -544,8 +564,93 @@ struct Ldu {
         }
     }
     // LESModel Smagorinsky [OF-6 Smagorinsky.C: k(gradU), correctNut()] with delta = deltaCoeff cbrt(V) (cubeRootVolDelta), as fv_oracle.cpp
+    // LESModel kEqn [OF-6 LES/kEqn/kEqn.C correct()], as fv_oracle.cpp's turb_eqn(0) with the faces of a general mesh:
+    //   divU = fvc::div(fvc::absolute(phi, U)); G = nut (gradU && dev(twoSymm(gradU)));
+    //   fvm::ddt(alpha, k) + fvm::div(alphaPhi, k) - fvm::laplacian(alpha DkEff, k) == alpha G - fvm::SuSp(2/3 alpha divU, k) - fvm::Sp(Ce alpha sqrt(k) / delta, k), DkEff = nut + nu
+    //   (Gauss linear corrected: the explicit part (alpha DkEff)_f |Sf| (k & interpolate(grad k)) on the right); relax(); solve; bound(k, kMin); nut = Ck sqrt(k) delta
+    // [OF-6 fvm::SuSp: diag += V max(susp, 0), source -= V min(susp, 0) psi; bound.C: k = max(max(k, fvc::average(max(k, kMin)) pos0(-k)), kMin)]
+    void k_equation() {
+        const size_t nc = nCells;
+        const double kMin = 1e-15;
+        std::vector<V3> gk;
+        grad_scalar(kturb, [&](int f) { return kb_of(patch_of[f - nInt], own[f]); }, gk);
+        std::fill(diag.begin(), diag.end(), 0.0); std::fill(src.begin(), src.end(), 0.0);
+        std::fill(bint.begin(), bint.end(), 0.0); std::fill(bsrc.begin(), bsrc.end(), 0.0);
+        std::fill(bdg.begin(), bdg.end(), 0.0);
+        vec sumPhi(nc, 0.0), offsum(nc, 0.0);
+        for (size_t c = 0; c < nc; ++c) { diag[c] += alpha[c] * V[c] / cs.dt; src[3 * c] += alpha[c] * V[c] / cs.dt * kturb[c]; }
+        for (int f = 0; f < nInt; ++f) {
+            const int o = own[f], n = nei[f];
+            const double fl = alphaf[f] * phi[f];
+            const double gam = (w[f] * alpha[o] * (cs.nu + nut[o]) + (1.0 - w[f]) * alpha[n] * (cs.nu + nut[n])) * magSf[f];
+            const double wc = cs.k_convection_scheme ? (fl >= 0.0 ? 1.0 : 0.0) : w[f];
+            double lo = -wc * fl, up = lo + fl;
+            lo -= gam * dcNO[f]; up -= gam * dcNO[f];
+            lower[f] = lo; upper[f] = up;
+            diag[o] -= lo; diag[n] -= up;
+            offsum[o] += std::fabs(up); offsum[n] += std::fabs(lo);
+            sumPhi[o] += phi[f]; sumPhi[n] -= phi[f];
+            const double corr = gam * dot(kvec[f], w[f] * gk[o] + (1.0 - w[f]) * gk[n]);
+            src[3 * (size_t)o] += corr; src[3 * (size_t)n] -= corr;
+        }
+        for (int f = nInt; f < nFaces; ++f) {
+            const int b = f - nInt, pa = patch_of[b], c = own[f];
+            sumPhi[c] += phi[f];
+            const double fl = alphaf[f] * phi[f];
+            if (k_bc[pa] == 1) { const double gb = (cs.nu + nut_bnd(pa, c)) * magSf[f] * dcNO[f]; bint[b] += gb; bsrc[3 * (size_t)b] += (-fl + gb) * k_val[pa]; }
+            else bint[b] += fl;
+        }
+        for (size_t c = 0; c < nc; ++c) {
+            const double* T = &vGrad[9 * c];
+            const double tr2 = 2.0 * (T[0] + T[4] + T[8]);
+            double GG = 0.0;
+            for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) GG += T[3 * a + b] * ((T[3 * a + b] + T[3 * b + a]) - (a == b ? (1.0 / 3.0) * tr2 : 0.0));
+            const double G = nut[c] * GG, divU = sumPhi[c] / V[c], xc = kturb[c];
+            const double c1 = (2.0 / 3.0) * alpha[c] * divU, c2 = cs.les_ce * alpha[c] * std::sqrt(xc) / les_delta((int)c);
+            diag[c] += V[c] * (std::max(c1, 0.0) + c2);
+            src[3 * c] += V[c] * alpha[c] * G - V[c] * std::min(c1, 0.0) * xc;
+        }
+        if (cs.k_relax > 0) {
+            for (size_t c = 0; c < nc; ++c) {
+                const double dg = dgc((int)c), dn = std::max(std::fabs(dg), offsum[c]) / cs.k_relax;
+                src[3 * c] += (dn - dg) * xc_of(c);
+                diag[c] += dn - dg;
+            }
+        }
+        // the scalar equation through the three-component Jacobi solve (components 1 and 2 are 0 = 0: converged from the start)
+        vec keepU = U;
+        const bool slip = has_slip; has_slip = false;
+        const double ut = cs.u_tol, ur = cs.u_rel_tol; const int um = cs.u_max_iter;
+        cs.u_tol = cs.k_tol; cs.u_rel_tol = cs.k_rel_tol; cs.u_max_iter = cs.k_max_iter;
+        for (size_t c = 0; c < nc; ++c) { U[3 * c] = kturb[c]; U[3 * c + 1] = 0.0; U[3 * c + 2] = 0.0; }
+        k_iters += solve_momentum(vec(3 * nc, 0.0));
+        vec x(nc);
+        for (size_t c = 0; c < nc; ++c) x[c] = U[3 * c];
+        U = keepU; has_slip = slip; cs.u_tol = ut; cs.u_rel_tol = ur; cs.u_max_iter = um;
+        // bound()
+        vec xm(nc);
+        for (size_t c = 0; c < nc; ++c) xm[c] = std::max(x[c], kMin);
+        for (int c = 0; c < nCells; ++c) {
+            double xb = x[c];
+            if (!(x[c] > 0.0)) {
+                double av = 0.0, asum = 0.0;                         // fvc::average: sum |Sf| x_f / sum |Sf|
+                for (int f : cfaces[c]) {
+                    double xf;
+                    if (f < nInt) xf = w[f] * xm[own[f]] + (1.0 - w[f]) * xm[nei[f]];
+                    else { const int pa = patch_of[f - nInt]; xf = std::max(k_bc[pa] == 1 ? k_val[pa] : x[c], kMin); }
+                    av += magSf[f] * xf; asum += magSf[f];
+                }
+                xb = std::max(x[c], av / asum);
+            }
+            kturb[c] = std::max(xb, kMin);
+        }
+        for (int c = 0; c < nCells; ++c) nut[c] = cs.les_ck * std::sqrt(kturb[c]) * les_delta(c);
+        nut_live = true;
+    }
+    double xc_of(size_t c) const { return kturb[c]; }
     void turbulence_correct() {
         grad_vector(U, vGrad);
+        if (cs.turbulence_model == 2) { k_equation(); return; }
         for (int c = 0; c < nCells; ++c) {
             const double delta = cs.les_delta_coeff * std::cbrt(V[c]);
             const double* T = &vGrad[9 * (size_t)c];
@@ -910,7 +1015,7 @@ vec* ldu_field(Ldu* s, const std::string& n) {
     const struct { const char* nm; vec* v; } tab[] = {{"U", &s->U}, {"p", &s->p}, {"phi", &s->phi}, {"uSource", &s->uSource}, {"vGrad", &s->vGrad}, {"rAU", &s->rAU},
         {"HbyA", &s->HbyA}, {"p_diag", &s->pdiag}, {"p_coef", &s->pcoef}, {"p_rhs", &s->pb}, {"mom_diag", &s->diag}, {"mom_lower", &s->lower}, {"mom_upper", &s->upper},
         {"mom_src", &s->src}, {"phiHbyA", &s->phiHbyA}, {"alpha", &s->alpha}, {"uSourceDrag", &s->uSourceDrag}, {"gradP", &s->gradP}, {"divT", &s->divT}, {"ddtU", &s->ddtU},
-        {"phiForces", &s->phiForces}, {"rAUf", &s->rAUf}, {"nut", &s->nut}};
+        {"phiForces", &s->phiForces}, {"rAUf", &s->rAUf}, {"nut", &s->nut}, {"k", &s->kturb}};
     for (const auto& e : tab) if (n == e.nm) return e.v;
     return nullptr;
 }

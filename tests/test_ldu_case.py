@@ -285,9 +285,9 @@ def test_general_pimple_case_is_read(prod, tmp_path):
     assert [lc.nut_bc[q] for q in range(3)] == [1, 1, 0] and [lc.nut_value[q] for q in range(3)] == [1e-6, 3e-6, 0.0]
     np.testing.assert_array_equal(fc.initial_nut(), 2e-6)
     fc.close()
-    (dst / "constant/turbulenceProperties.water").write_text(tp % "kEqn")
+    (dst / "constant/turbulenceProperties.water").write_text("simulationType RAS;\nRAS { RASModel kEpsilon; turbulence on; }\n")      # (kEqn: test_general_kEqn_case_runs_and_writes_k)
     (dst / "0/k.water").write_text((dst / "0/nut.water").read_text().replace("nut.water", "k.water"))
-    with pytest.raises(prod.FoamYadeError, match="kEqn / kEpsilon"):
+    with pytest.raises(prod.FoamYadeError, match="not kEpsilon"):
         prod.GeneralFoamCase(dst, prod.FY_SOLVER_PIMPLE)
     os.remove(dst / "0/k.water"); os.remove(dst / "0/nut.water")
     os.remove(dst / "constant/turbulenceProperties.water")
@@ -346,6 +346,35 @@ def test_general_les_case_runs_and_writes_nut(prod, tmp_path):
     fc.write(s, "0.001")
     t = (dst / "0.001/nut.water").read_text()
     assert "calculated" in t and "uniform 3e-06" in t.replace("3e-6", "3e-06") and "nonuniform List<scalar>" in t
+    s.close(); fc.close()
+
+
+@pytest.mark.gpu
+def test_general_kEqn_case_runs_and_writes_k(prod, tmp_path):
+    """LES kEqn on the wavy bed from its case directory: k.<phase> and nut.<phase> of the start time are read (a `calculated` nut patch keeps the file's value until the first
+    correctNut()), the controls of k come from fvSchemes / fvSolution, k and nut are written back with the files' own patch entries"""
+    dst, mesh = general_bed(tmp_path)
+    (dst / "constant/turbulenceProperties.water").write_text("FoamFile { version 2.0; format ascii; class dictionary; object turbulenceProperties.water; }\nsimulationType LES;\n"
+                                                             "LES { LESModel kEqn; delta cubeRootVol; turbulence on; kEqnCoeffs { Ck 0.1; Ce 1.0; } }\n")
+    nut = (dst / "0/p").read_text().replace("object      p;", "object nut.water;").replace("[0 2 -2 0 0 0 0]", "[0 2 -1 0 0 0 0]").replace("internalField   uniform 0;", "internalField   uniform 2e-6;") \
+        .replace("fixedFluxPressure; value uniform 0;", "zeroGradient;").replace("top    { type fixedValue; value uniform 0; }", "top    { type calculated; value uniform 3e-6; }")
+    (dst / "0/nut.water").write_text(nut)
+    (dst / "0/k.water").write_text(nut.replace("object nut.water;", "object k.water;").replace("[0 2 -1 0 0 0 0]", "[0 2 -2 0 0 0 0]").replace("uniform 2e-6;", "uniform 3e-4;")
+                                   .replace("top    { type calculated; value uniform 3e-6; }", "top    { type fixedValue; value uniform 4e-4; }"))
+    fc = prod.GeneralFoamCase(dst, prod.FY_SOLVER_PIMPLE)
+    lc = fc.ldu_case
+    assert lc.turbulence_model == prod.TURBULENCE_KEQN and (lc.les_ck, lc.les_ce) == (0.1, 1.0) and lc.k_initial == 3e-4 and (lc.k_tol, lc.k_rel_tol) == (1e-5, 0.1)
+    top = fc.patch_names.index("top")
+    assert lc.k_bc[top] == 1 and lc.k_value[top] == 4e-4 and lc.nut_bc[top] == 3 and lc.nut_value[top] == 3e-6
+    s = prod.LduSolver.from_foam_case(fc)
+    np.testing.assert_array_equal(s.get("k"), 3e-4); np.testing.assert_array_equal(s.get("nut"), 2e-6)
+    for _ in range(5):
+        s.step()
+    k, nutv = s.get("k"), s.get("nut")
+    assert k.min() > 0 and not np.allclose(k, 3e-4) and np.isfinite(k).all() and np.allclose(nutv, 0.1 * np.sqrt(k) * np.cbrt(s.geometry("V")), rtol=1e-12)
+    fc.write(s, "0.001")
+    t = (dst / "0.001/k.water").read_text()
+    assert "fixedValue" in t and "nonuniform List<scalar>" in t and "calculated" in (dst / "0.001/nut.water").read_text()
     s.close(); fc.close()
 
 

@@ -379,6 +379,47 @@ def test_pimple_on_a_lattice_reproduces_the_structured_restatement(oracle, n_out
     f.close(); g.close()
 
 
+@pytest.mark.parametrize("variant", ["plain", "upwind_relaxed_calculated"])
+def test_les_kEqn_on_a_lattice_reproduces_the_structured_restatement(oracle, variant):
+    """LESModel kEqn (DPMTurbulenceModels.C:76-77) on the general mesh: the k transport equation assembled over faces (alpha-weighted, SuSp / Sp sources, bound()), nut = Ck
+    sqrt(k) delta, against fv_oracle.cpp's on the same block with a cloud and a moving wall -- with upwind convection of k, a relaxation factor, a fixed-value k patch and
+    `calculated` nut patches too (the file's value before the first correctNut(), Ck sqrt(k_b) delta after)"""
+    n, box = 8, 0.1
+    dx = box / n
+    mesh = pm.hex_block(n, n, n, (box, box, box), renumber_seed=5)
+    tol = dict(p_tol=1e-12, p_rel_tol=0.0, p_final_tol=1e-12, u_tol=1e-12)
+    les = dict(turbulence_model=2, nut_initial=3e-5, les_delta_coeff=0.8, k_initial=2e-4, k_tol=1e-13)
+    u_val = [(0, 0, 0)] * 6
+    u_val[3] = (0.3, 0, 0.1)
+    fkw, gkw = {}, {}
+    if variant != "plain":
+        les.update(k_convection_scheme=1, k_relax=0.8)
+        fkw = dict(k_bc=[0, 0, 0, 1, 0, 0], k_value=[0, 0, 0, 5e-4, 0, 0], nut_bc=[3, 0, 3, 3, 0, 1], nut_value=[3e-5, 0, 3e-5, 6e-5, 0, 2e-5])
+        gkw = dict(k_bc=[0, 0, 0, 1, 0, 0], k_val=[0, 0, 0, 5e-4, 0, 0], nut_bc=[3, 0, 3, 3, 0, 1], nut_val=[3e-5, 0, 3e-5, 6e-5, 0, 2e-5])
+    else:
+        les.update(k_convection_scheme=0)
+    f = orc.FvSolver(orc.fv_case(1, n, n, n, dx, 2e-4, 1e-5, g=(0, 0, -9.81), u_val=u_val, p_bc=[2] * 6, p_solver=0, n_outer=2, n_corr=2, p_final_rel_tol=0.0, p_max_iter=5000, **les, **fkw, **tol))
+    g = orc.LduSolver(mesh, 2e-4, 1e-5, [0] * 6, u_val, [2] * 6, solver=1, g=(0, 0, -9.81), n_outer=2, n_correctors=2, **les, **gkw, **tol)
+    rs = np.random.RandomState(17)
+    perm = mesh["perm"]
+    for step in range(3):
+        rec = np.zeros((1000, 10))
+        rec[:, 0:3] = rs.random_sample((1000, 3)) * np.array([box, box, 0.6 * box]) + np.array([0.0, 0.0, 0.05 * box])
+        rec[:, 3:6] = 0.05 * rs.standard_normal((1000, 3)); rec[:, 9] = 0.2 * dx
+        cap = {}
+        f.step(rec, capture=cap)
+        to_g = lambda a, nc: (lambda o: (o.__setitem__(perm, a.reshape(n ** 3, nc)), o)[1])(np.zeros((n ** 3, nc)))
+        g.step(source=to_g(cap["uSource"], 3), alpha=to_g(cap["alpha"], 1), drag=to_g(cap["uSourceDrag"], 1))
+        kf, kg = f.get("k"), pm.to_lattice(mesh, g.get("k"))
+        assert np.abs(kg - kf).max() < 1e-8 * kf.max(), step
+        nf, ng = f.get("nut"), pm.to_lattice(mesh, g.get("nut"))
+        assert np.abs(ng - nf).max() < 1e-8 * nf.max(), step
+        Uf, Ug = f.get("U").reshape(-1, 3), pm.to_lattice(mesh, g.get("U").reshape(-1, 3))
+        assert np.abs(Ug - Uf).max() < 1e-8 * np.abs(Uf).max(), step
+    assert not np.allclose(kf, 2e-4, rtol=1e-3) and kf.min() > 0
+    f.close(); g.close()
+
+
 def test_tetrahedra_geometry_and_a_cavity_on_them(oracle):
     """Kuhn tetrahedra (triangular faces only, four-faced cells, non-orthogonality around 50 degrees): closed cells, volumes adding up to the box's with every
     tetrahedron a sixth of its hexahedron, centres = the vertex means; the lid-driven cavity runs on them and conserves mass to rounding with two non-orthogonal passes"""

@@ -476,6 +476,68 @@ def test_taylor_green_vortices_in_a_periodic_box_on_the_hip_solver(product):
     s.close()
 
 
+@pytest.mark.parametrize("variant", ["plain", "upwind_relaxed_calculated"])
+def test_les_kEqn_on_a_lattice_equals_the_structured_hip_solver(product, variant):
+    """LESModel kEqn through both HIP solvers on the same block with the same cloud's fields (the general side is given the structured coupling's alpha / drag / source):
+    k, nut and U after three steps"""
+    n, box = 12, 0.1
+    dx = box / n
+    mesh = pm.hex_block(n, n, n, (box, box, box))
+    kw = dict(p_tol=1e-11, p_rel_tol=0.0, p_final_tol=1e-11, u_tol=1e-11)
+    les = dict(turbulence_model=2, nut_initial=3e-5, les_delta_coeff=0.8, k_initial=2e-4, k_tol=1e-13)
+    u_val = [(0, 0, 0)] * 6
+    u_val[3] = (0.3, 0, 0.1)
+    fkw, gkw = {}, {}
+    if variant != "plain":
+        les.update(k_convection_scheme=1, k_relax=0.8)
+        fkw = dict(k_bc=[0, 0, 0, 1, 0, 0], k_value=[0, 0, 0, 5e-4, 0, 0], nut_bc=[3, 0, 3, 3, 0, 1], nut_value=[3e-5, 0, 3e-5, 6e-5, 0, 2e-5])
+        gkw = dict(k_bc=[0, 0, 0, 1, 0, 0], k_val=[0, 0, 0, 5e-4, 0, 0], nut_bc=[3, 0, 3, 3, 0, 1], nut_val=[3e-5, 0, 3e-5, 6e-5, 0, 2e-5])
+    case = product.make_case(1, n, n, n, dx, 2e-4, 1e-5, g=(0, 0, -9.81), u_val=u_val, p_bc=[2] * 6, p_solver=0, n_outer_correctors=2, n_correctors=2, p_max_iter=5000, **les, **fkw, **kw)
+    f = product.Solver(case)
+    g = product.LduSolver(mesh, 2e-4, 1e-5, [0] * 6, u_val, [2] * 6, solver=1, g=(0, 0, -9.81), n_outer_correctors=2, n_correctors=2, p_max_iter=5000, **les, **gkw, **kw)
+    f.hold_sources(True)
+    rs = np.random.RandomState(17)
+    for step in range(3):
+        f.set_particles(bed_particles(rs, 3000, box, dx))
+        f.step()
+        g.set("alpha", f.get("alpha")); g.set("uSourceDrag", f.get("uSourceDrag")); g.set("uSource", f.get("uSource"))
+        g.step()
+        close(g.get("k"), f.get("k"), 1e-6, "k step %d" % step)
+        close(g.get("nut"), f.get("nut"), 1e-6, "nut step %d" % step)
+        close(g.get("U").reshape(-1, 3), f.get("U").reshape(-1, 3), 1e-6, "U step %d" % step)
+    assert not np.allclose(f.get("k"), 2e-4, rtol=1e-3)
+    f.close(); g.close()
+
+
+def test_les_kEqn_on_a_wavy_mesh_matches_the_restatement(product, oracle):
+    """the k equation on skewed cells (the corrected laplacian's explicit part with grad k, delta from each cell's volume), a fixed-value k patch, `calculated` nut
+    patches, upwind convection of k and a relaxation factor, with a cloud: k, nut, U, p against the restatement"""
+    n, box = 10, 0.1
+    dx = box / n
+    mesh = pm.hex_block(n, n, n, (box, box, box), pm.wavy(0.2 * dx, (box, box, box)), renumber_seed=8)
+    kw = dict(p_tol=1e-10, p_rel_tol=0.0, p_final_tol=1e-10, u_tol=1e-10, p_max_iter=5000)
+    les = dict(turbulence_model=2, nut_initial=2e-5, les_delta_coeff=1.0, k_initial=2e-4, k_tol=1e-12, k_convection_scheme=1, k_relax=0.9)
+    pat = dict(k_bc=[0, 0, 0, 1, 0, 0], k_val=[0, 0, 0, 5e-4, 0, 0], nut_bc=[3, 0, 3, 3, 0, 1], nut_val=[2e-5, 0, 2e-5, 4e-5, 0, 1e-5])
+    rel = dict(u_relax=0.8, u_relax_final=1.0, p_relax=0.7, p_relax_final=1.0)
+    lidv = [(0, 0, 0)] * 6
+    lidv[3] = (0.3, 0, 0.1)
+    h = product.LduSolver(mesh, 2e-4, 1e-5, [0] * 6, lidv, [2] * 6, solver=1, g=(0, 0, -9.81), n_non_orth=1, n_outer_correctors=2, n_correctors=2, **les, **pat, **rel, **kw)
+    o = oracle.LduSolver(mesh, 2e-4, 1e-5, [0] * 6, lidv, [2] * 6, solver=1, g=(0, 0, -9.81), n_non_orth=1, n_outer=2, n_correctors=2, **les, **pat, **rel, **kw)
+    h.hold_sources(True)
+    rs = np.random.RandomState(23)
+    for step in range(3):
+        h.set_particles(bed_particles(rs, 1500, box, dx))
+        h.step()
+        o.step(source=h.get("uSourceCoupling"), alpha=h.get("alpha"), drag=h.get("uSourceDrag"))
+        close(h.get("k"), o.get("k"), 1e-6, "k step %d" % step)
+        close(h.get("nut"), o.get("nut"), 1e-6, "nut step %d" % step)
+        close(h.get("U"), o.get("U"), 2e-6, "U step %d" % step)
+    ph, po = h.get("p"), o.get("p")
+    close(ph - ph.mean(), po - po.mean(), 1e-5, "p")
+    assert not np.allclose(h.get("k"), 2e-4, rtol=1e-3) and h.get("k").min() > 0
+    h.close(); o.close()
+
+
 def test_rayleigh_layer_on_a_distorted_mesh_on_the_hip_solver(product):
     """the transient known answer of tests/test_ldu_oracle.py::test_rayleigh_layer_on_a_distorted_mesh on the HIP solver with the multigrid preconditioner, one level finer
     (128 cells across, 131 072 cells): the error keeps falling (0.0025, 0.0011 on the restatement at 32 and 64)"""

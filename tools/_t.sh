@@ -3,13 +3,5 @@
 cd /root/repo
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-timeout 1200 python -m pytest tests/test_locate_paths.py -m gpu -x -q > gpurun_out/gpu_lp.log 2>&1; echo "rc=$?" >> gpurun_out/gpu_lp.log
-grep -E "passed|failed|rc=|^E  " gpurun_out/gpu_lp.log | tail -6
-rm -f gpurun_out/ldu_bench_pimple.jsonl gpurun_out/ldu_bench_c3.jsonl
-python tools/ldu_bench.py 64 10 wavy 300000 mg 1e-6 pimple | grep '"tool"' >> gpurun_out/ldu_bench_pimple.jsonl
-python tools/ldu_bench.py 128 10 wavy 2500000 mg 1e-6 pimple | grep '"tool"' >> gpurun_out/ldu_bench_pimple.jsonl
-python tools/ldu_bench.py 128 10 lattice 2500000 mg 1e-6 pimple | grep '"tool"' >> gpurun_out/ldu_bench_pimple.jsonl
-python tools/ldu_bench.py 96 10 prisms 1000000 mg 1e-6 pimple | grep '"tool"' >> gpurun_out/ldu_bench_pimple.jsonl
-python tools/ldu_bench.py 160 5 wavy 10000000 mg 1e-6 pimple | grep '"tool"' >> gpurun_out/ldu_bench_c3.jsonl
-python tools/ldu_bench.py 160 5 lattice 10000000 mg 1e-6 pimple | grep '"tool"' >> gpurun_out/ldu_bench_c3.jsonl
-cut -c1-330 gpurun_out/ldu_bench_pimple.jsonl gpurun_out/ldu_bench_c3.jsonl
+timeout 1500 python -m pytest tests/test_ldu_parity.py tests/test_ldu_case.py -m gpu -x -q > gpurun_out/gpu_ldu.log 2>&1; echo "rc=$?" >> gpurun_out/gpu_ldu.log
+grep -E "passed|failed|rc=|^E  " gpurun_out/gpu_ldu.log | tail -12

@@ -90,7 +90,8 @@ class LduCase(C.Structure):
                 ("p_value", _dp), ("solver", C.c_int32), ("n_outer_correctors", C.c_int32), ("g", C.c_double * 3), ("u_relax", C.c_double), ("u_relax_final", C.c_double),
                 ("p_relax", C.c_double), ("p_relax_final", C.c_double), ("adjust_time_step", C.c_int32), ("max_co", C.c_double), ("max_delta_t", C.c_double),
                 ("turbulence_model", C.c_int32), ("les_ck", C.c_double), ("les_ce", C.c_double), ("les_delta_coeff", C.c_double), ("nut_initial", C.c_double), ("nut_bc", _ip),
-                ("nut_value", _dp), ("convection_scheme", C.c_int32), ("convection_limiter_k", C.c_double)]
+                ("nut_value", _dp), ("convection_scheme", C.c_int32), ("convection_limiter_k", C.c_double), ("k_initial", C.c_double), ("k_bc", _ip), ("k_value", _dp),
+                ("k_convection_scheme", C.c_int32), ("k_tol", C.c_double), ("k_rel_tol", C.c_double), ("k_max_iter", C.c_int32), ("k_relax", C.c_double)]
 
 
 class ParticleTimings(C.Structure):
@@ -1061,7 +1062,7 @@ class LduSolver:
         L.fy_ldu_solver_read_field_host.argtypes = [C.c_void_p, C.c_char_p, _dp]
         L.fy_ldu_solver_write_field_host.argtypes = [C.c_void_p, C.c_char_p, _dp]
 
-    def __init__(self, mesh, dt, nu, u_bc, u_val, p_bc, p_val=None, device=0, transport=None, nut_bc=None, nut_val=None, **controls):
+    def __init__(self, mesh, dt, nu, u_bc, u_val, p_bc, p_val=None, device=0, transport=None, nut_bc=None, nut_val=None, k_bc=None, k_val=None, **controls):
         L = lib()
         self._bind()
         npatch = len(mesh["patch_start"])
@@ -1090,6 +1091,9 @@ class LduSolver:
         if nut_bc is not None:
             k["nb"], k["nv"] = i32(nut_bc), np.ascontiguousarray(nut_val if nut_val is not None else np.zeros(npatch), np.float64)
             self.case.nut_bc, self.case.nut_value = _i(k["nb"]), _d(k["nv"])
+        if k_bc is not None:
+            k["kb"], k["kv"] = i32(k_bc), np.ascontiguousarray(k_val if k_val is not None else np.zeros(npatch), np.float64)
+            self.case.k_bc, self.case.k_value = _i(k["kb"]), _d(k["kv"])
         self._create(device, transport)
 
     def _create(self, device, transport):
@@ -1113,6 +1117,8 @@ class LduSolver:
         self.set("U", U); self.set("p", p)
         if fc.ldu_case.turbulence_model != 0:
             self.set("nut", fc.initial_nut())
+        if fc.ldu_case.turbulence_model == TURBULENCE_KEQN:
+            self.set("k", fc.initial_k())
         return self
 
     def _size(self, name):

@@ -67,7 +67,15 @@ struct LduPim {
     const double* nut;               // LES: the eddy viscosity per cell (null: laminar), its patch conditions
     const int32_t* nut_bc;
     const double* nut_val;
+    // LES kEqn: k per cell (null: another model) and its patch conditions (FY_BC_NUT_ZERO_GRADIENT | _FIXED_VALUE); a FY_BC_NUT_CALCULATED nut patch carries
+    // Ck sqrt(k_b) delta once correctNut() has run (nut_live), the file's value before
+    const double* k;
+    const int32_t* k_bc;
+    const double* k_val;
+    int nut_live;
+    double ck, delta_coeff;
 };
+struct LduKEqn { double ce, relax; int upwind; };
 
 int ldu_red_blocks(int n);      // partials per slot of the reducing kernels (= red_blocks(n) of fv_kernels.hpp: the folds are shared)
 
@@ -98,6 +106,10 @@ int launch_ldu_pre_coupling(hipStream_t s, LduGeo g, const double* phi, const do
 int launch_ldu_assemble_momentum_pimple(hipStream_t s, LduGeo g, LduPim P, const double* phi, const double* Uold, const double* U, const double* gradU, LduMom M, double* face_corr,
                                         double* fstress /* [3 nF] */, double u_relax, double* rAU);
 int launch_ldu_smagorinsky_nut(hipStream_t s, LduGeo g, const double* vGrad, double ck, double ce, double delta_coeff, double* nut);
+// LES kEqn: the k equation's matrix into M (face part, then cells: diag, b[3 c] = the source, b[3 c + 1 .. 2] = 0), x3 = (k, 0, 0); after the solve bound() and nut
+int launch_ldu_grad_k(hipStream_t s, LduGeo g, LduPim P, double* gk);
+int launch_ldu_k_assemble(hipStream_t s, LduGeo g, LduPim P, LduKEqn K, const double* phi, const double* vGrad, const double* gk, LduMom M, double* face_corr, double* x3);
+int launch_ldu_k_bound_nut(hipStream_t s, LduGeo g, LduPim P, const double* x3, double* k, double* nut);
 int launch_ldu_forces(hipStream_t s, LduGeo g, LduPim P, const double* rAU, double* rAUf, double* phiForces);
 int launch_ldu_ssf_predictor(hipStream_t s, LduGeo g, const double* phiForces, const double* rAUf, const double* p, const double* gradp, double* ssf);
 int launch_ldu_reconstruct(hipStream_t s, LduGeo g, const double* ssf, const double* base, const double* scale, double* out);

@@ -520,10 +520,18 @@ __global__ __launch_bounds__(256) void k_ldu_pre_coupling(LduGeo g, const double
 // of the explicit stress Sf . (alpha nu dev2(T(grad U)))_f (the cell tensor interpolated linearly; a boundary face takes its cell's)
 // nut != null (LES Smagorinsky, DPMTurbulenceModels.C:73-74): nuEff = nu + nut in both parts of divDevRhoReff -- the face diffusivity is the linear interpolate of the CELL
 // field alpha (nu + nut) [OF-6 gaussLaplacianScheme::fvmLaplacian(vol gamma)]; on the boundary alpha_b (nu + nut_b), nut_b by the patch of 0/nut (ldu_nut_b)
+__device__ __forceinline__ double ldu_k_b(const LduGeo& g, const LduPim& P, const double* __restrict__ k, int f) {
+    const int pa = g.patch_of[f - g.nInt];
+    return P.k_bc[pa] == FY_BC_NUT_FIXED_VALUE ? P.k_val[pa] : k[g.own[f]];
+}
 __device__ __forceinline__ double ldu_nut_b(const LduGeo& g, const LduPim& P, int f) {
     if (!P.nut) return 0.0;
-    const int pa = g.patch_of[f - g.nInt];
-    return P.nut_bc[pa] == FY_BC_NUT_FIXED_VALUE ? P.nut_val[pa] : P.nut[g.own[f]];
+    const int pa = g.patch_of[f - g.nInt], c = g.own[f];
+    const int t = P.nut_bc[pa];
+    if (t == FY_BC_NUT_FIXED_VALUE || (t == FY_BC_NUT_CALCULATED && !(P.k && P.nut_live))) return P.nut_val[pa];
+    // calculated [OF-6 GeometricField::operator=: nut_ = Ck sqrt(k_) delta assigns the patches too]
+    if (t == FY_BC_NUT_CALCULATED) return P.ck * sqrt(ldu_k_b(g, P, P.k, f)) * (P.delta_coeff * cbrt(g.V[c]));
+    return P.nut[c];
 }
 __global__ __launch_bounds__(256) void k_ldu_pmom_faces(LduGeo g, LduPim P, const double* __restrict__ phi, const double* __restrict__ U, const double* __restrict__ alpha, const double* __restrict__ alphaf,
                                                         const double* __restrict__ gradU, LduMom M, double* __restrict__ corr, double* __restrict__ fstress) {
@@ -637,6 +645,104 @@ __global__ __launch_bounds__(256) void k_ldu_smagorinsky_nut(LduGeo g, const dou
     const double cc = 2.0 * ck * delta * dd;
     const double r = (-b + sqrt(b * b + 4.0 * a * cc)) / (2.0 * a);
     nut[c] = ck * delta * sqrt(r * r);
+}
+
+// ---- LESModel kEqn [OF-6 LES/kEqn/kEqn.C correct()] (DPMTurbulenceModels.C:76-77), as fv_kernels.hip's transport kernel with the faces of a general mesh:
+//   fvm::ddt(alpha, k) + fvm::div(alphaPhi, k) - fvm::laplacian(alpha DkEff, k) == alpha G - fvm::SuSp(2/3 alpha divU, k) - fvm::Sp(Ce alpha sqrt(k) / delta, k)
+//   DkEff = nut + nu; G = nut (gradU && dev(twoSymm(gradU))); divU = fvc::div(phi); Gauss linear corrected laplacian: its explicit part (alpha DkEff)_f |Sf| (k & interpolate(grad k))
+// The matrix goes into the momentum matrix's arrays (free once the correctors are done) and is solved as component 0 of a three-component system by the momentum passes
+__global__ __launch_bounds__(256) void k_ldu_grad_k(LduGeo g, LduPim P, double* __restrict__ gk) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= g.nCells) return;
+    const double kc = P.k[c];
+    D3 a{0, 0, 0};
+    FY_CELL_FACES(g, c, f, nb) {
+        double kf, sg = 1.0;
+        if (f < g.nInt) { const bool o = nb > c; const double kn = P.k[nb]; kf = o ? g.w[f] * kc + (1.0 - g.w[f]) * kn : g.w[f] * kn + (1.0 - g.w[f]) * kc; sg = o ? 1.0 : -1.0; }
+        else kf = ldu_k_b(g, P, P.k, f);
+        const D3 S = ld3(g.Sf, f);
+        a.x += sg * S.x * kf; a.y += sg * S.y * kf; a.z += sg * S.z * kf;
+    }
+    const double rV = 1.0 / g.V[c];
+    st3(gk, c, D3{a.x * rV, a.y * rV, a.z * rV});
+}
+__global__ __launch_bounds__(256) void k_ldu_k_faces(LduGeo g, LduPim P, LduKEqn K, const double* __restrict__ phi, const double* __restrict__ gk, LduMom M, double* __restrict__ corr) {
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= g.nInt) return;
+    const int o = g.own[f], n = g.nei[f];
+    const double w = g.w[f], fl = P.alphaf[f] * phi[f];
+    const double gam = (w * (P.alpha[o] * (g.nu + P.nut[o])) + (1.0 - w) * (P.alpha[n] * (g.nu + P.nut[n]))) * g.magSf[f];
+    const double wc = K.upwind ? (fl >= 0.0 ? 1.0 : 0.0) : w;
+    double lo = -wc * fl, up = lo + fl;
+    lo -= gam * g.dcNO[f]; up -= gam * g.dcNO[f];
+    M.lower[f] = lo; M.upper[f] = up;
+    const D3 kv = ld3(g.kvec, f), go = ld3(gk, o), gn = ld3(gk, n);
+    corr[f] = gam * dot3(kv, lerp3(w, go, gn));
+}
+__global__ __launch_bounds__(256) void k_ldu_k_cells(LduGeo g, LduPim P, LduKEqn K, const double* __restrict__ phi, const double* __restrict__ vGrad, LduMom M,
+                                                     const double* __restrict__ corr, double* __restrict__ x3) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= g.nCells) return;
+    const double Vc = g.V[c], ac = P.alpha[c], xc = P.k[c];
+    double dg = ac * Vc / g.dt, b = ac * Vc / g.dt * xc, sumPhi = 0.0, offsum = 0.0;
+    FY_CELL_FACES(g, c, f, nb) {
+        if (f < g.nInt) {
+            if (nb > c) { dg -= M.lower[f]; offsum += fabs(M.upper[f]); sumPhi += phi[f]; b += corr[f]; }
+            else { dg -= M.upper[f]; offsum += fabs(M.lower[f]); sumPhi -= phi[f]; b -= corr[f]; }
+        } else {
+            const int pa = g.patch_of[f - g.nInt];
+            const double fl = P.alphaf[f] * phi[f];
+            sumPhi += phi[f];
+            if (P.k_bc[pa] == FY_BC_NUT_FIXED_VALUE) {
+                const double gb = (g.nu + ldu_nut_b(g, P, f)) * g.magSf[f] * g.dcNO[f];
+                dg += gb; b += (-fl + gb) * P.k_val[pa];
+            } else dg += fl;
+        }
+    }
+    const double* T = vGrad + 9 * (size_t)c;
+    const double tr2 = 2.0 * (T[0] + T[4] + T[8]);
+    double GG = 0.0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) GG += T[3 * a + q] * ((T[3 * a + q] + T[3 * q + a]) - (a == q ? (1.0 / 3.0) * tr2 : 0.0));
+    const double G = P.nut[c] * GG, divU = sumPhi / Vc;
+    const double c1 = (2.0 / 3.0) * ac * divU, c2 = K.ce * ac * sqrt(xc) / (P.delta_coeff * cbrt(Vc));
+    dg += Vc * (fmax(c1, 0.0) + c2);                        // fvm::SuSp: the positive part implicit, the negative part on the source; fvm::Sp
+    b += Vc * ac * G - Vc * fmin(c1, 0.0) * xc;
+    if (K.relax > 0) {                                      // fvMatrix::relax
+        const double dn = fmax(fabs(dg), offsum) / K.relax;
+        b += (dn - dg) * xc;
+        dg = dn;
+    }
+    M.diag[c] = dg;
+    st3(M.b, c, D3{b, 0.0, 0.0});
+    st3(x3, c, D3{xc, 0.0, 0.0});
+}
+// bound(k, kMin) [OF-6 bound.C: k = max(max(k, fvc::average(max(k, kMin)) pos0(-k)), kMin), fvc::average = sum |Sf| k_f / sum |Sf|], then correctNut(): nut = Ck sqrt(k) delta
+__global__ __launch_bounds__(256) void k_ldu_k_bound_nut(LduGeo g, LduPim P, const double* __restrict__ x3, double* __restrict__ k, double* __restrict__ nut) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= g.nCells) return;
+    const double kMin = 1e-15, xc = x3[3 * (size_t)c];
+    double xb = xc;
+    if (!(xc > 0.0)) {
+        double av = 0.0, asum = 0.0;
+        FY_CELL_FACES(g, c, f, nb) {
+            double xf;
+            if (f < g.nInt) {
+                const double mo = fmax(xc, kMin), mn = fmax(x3[3 * (size_t)nb], kMin);
+                xf = nb > c ? g.w[f] * mo + (1.0 - g.w[f]) * mn : g.w[f] * mn + (1.0 - g.w[f]) * mo;
+            } else {
+                const int pa = g.patch_of[f - g.nInt];
+                xf = fmax(P.k_bc[pa] == FY_BC_NUT_FIXED_VALUE ? P.k_val[pa] : xc, kMin);
+            }
+            av += g.magSf[f] * xf; asum += g.magSf[f];
+        }
+        xb = fmax(xc, av / asum);
+    }
+    const double kn = fmax(xb, kMin);
+    k[c] = kn;
+    nut[c] = P.ck * sqrt(kn) * (P.delta_coeff * cbrt(g.V[c]));
 }
 
 // rAUcf = interpolate(rAUc) (boundary: the cell's), phicForces = fvc::flux(rAUc uSource) + rAUcf (g & Sf) (UcEqn.H:15-20)
@@ -899,6 +1005,22 @@ int launch_ldu_assemble_momentum_pimple(hipStream_t s, LduGeo g, LduPim P, const
                                         double* fstress, double u_relax, double* rAU) {
     hipLaunchKernelGGL(k_ldu_pmom_faces, dim3(div_up(g.nFaces, 256)), dim3(256), 0, s, g, P, phi, U, P.alpha, P.alphaf, gradU, M, face_corr, fstress);
     hipLaunchKernelGGL(k_ldu_pmom_cells, dim3(div_up(g.nCells, 256)), dim3(256), 0, s, g, P, phi, P.alpha, P.alphaOld, P.alphaf, Uold, U, P.uSourceDrag, M, face_corr, fstress, u_relax, rAU);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+int launch_ldu_grad_k(hipStream_t s, LduGeo g, LduPim P, double* gk) {
+    hipLaunchKernelGGL(k_ldu_grad_k, dim3(div_up(g.nCells, 256)), dim3(256), 0, s, g, P, gk);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+int launch_ldu_k_assemble(hipStream_t s, LduGeo g, LduPim P, LduKEqn K, const double* phi, const double* vGrad, const double* gk, LduMom M, double* face_corr, double* x3) {
+    if (g.nInt > 0) hipLaunchKernelGGL(k_ldu_k_faces, dim3(div_up(g.nInt, 256)), dim3(256), 0, s, g, P, K, phi, gk, M, face_corr);
+    hipLaunchKernelGGL(k_ldu_k_cells, dim3(div_up(g.nCells, 256)), dim3(256), 0, s, g, P, K, phi, vGrad, M, face_corr, x3);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+int launch_ldu_k_bound_nut(hipStream_t s, LduGeo g, LduPim P, const double* x3, double* k, double* nut) {
+    hipLaunchKernelGGL(k_ldu_k_bound_nut, dim3(div_up(g.nCells, 256)), dim3(256), 0, s, g, P, x3, k, nut);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }

@@ -37,7 +37,14 @@ struct LduSolver {
     DevBuf<double> nut, d_nutval, gradL;
     DevBuf<int32_t> d_nutbc;
     bool les = false;
-    LduPim P() const { return LduPim{alpha.p, alpha.p, alphaf.p, uSourceDrag.p, uSource.p, {cs.g[0], cs.g[1], cs.g[2]}, les ? nut.p : nullptr, d_nutbc.p, d_nutval.p}; }      // alphac.oldTime() == alphac
+    bool keqn = false, nut_live = false;
+    long long k_iters_total = 0;
+    DevBuf<double> kturb, d_kval, gradk;
+    DevBuf<int32_t> d_kbc;
+    LduPim P() const {
+        return LduPim{alpha.p, alpha.p, alphaf.p, uSourceDrag.p, uSource.p, {cs.g[0], cs.g[1], cs.g[2]}, les ? nut.p : nullptr, d_nutbc.p, d_nutval.p,
+                      keqn ? kturb.p : nullptr, d_kbc.p, d_kval.p, nut_live ? 1 : 0, cs.les_ck, cs.les_delta_coeff};
+    }      // alphac.oldTime() == alphac
     DevBuf<int> adj_err;
     bool need_ref = true, ext_source = false, has_slip = false;
     std::vector<double> orig_face_d;      // hm.orig_face as doubles (the field read-out's type); empty without a cyclic pair
@@ -73,9 +80,12 @@ struct LduSolver {
         if (pimple && c->n_outer_correctors < 1) cs.n_outer_correctors = 1;
         if (c->adjust_time_step && !pimple) cs.adjust_time_step = 0;                      // (icoFoamYade's loop never includes setDeltaT.H: icoFoamYade.C:65-70)
         if (cs.adjust_time_step && !(c->max_co > 0 && c->max_delta_t > 0)) return fail(FY_ERR_INVALID, "fy_ldu_solver: adjustTimeStep needs maxCo > 0 and maxDeltaT > 0");
-        if (c->turbulence_model != FY_TURBULENCE_LAMINAR && !(pimple && c->turbulence_model == FY_TURBULENCE_SMAGORINSKY))
-            return fail(FY_ERR_UNSUPPORTED, "fy_ldu_solver: turbulence model %d (laminar; LES Smagorinsky with pimpleFoamYade)", c->turbulence_model);
-        les = pimple && c->turbulence_model == FY_TURBULENCE_SMAGORINSKY;
+        if (c->turbulence_model != FY_TURBULENCE_LAMINAR && !(pimple && (c->turbulence_model == FY_TURBULENCE_SMAGORINSKY || c->turbulence_model == FY_TURBULENCE_KEQN)))
+            return fail(FY_ERR_UNSUPPORTED, "fy_ldu_solver: turbulence model %d (laminar; LES Smagorinsky or kEqn with pimpleFoamYade)", c->turbulence_model);
+        les = pimple && c->turbulence_model != FY_TURBULENCE_LAMINAR;
+        keqn = pimple && c->turbulence_model == FY_TURBULENCE_KEQN;
+        if (keqn && !(c->k_initial >= 0 && c->k_tol >= 0 && c->k_max_iter >= 0 && (c->k_convection_scheme == FY_CONVECTION_LINEAR || c->k_convection_scheme == FY_CONVECTION_UPWIND)))
+            return fail(FY_ERR_INVALID, "fy_ldu_solver: kEqn needs k_initial >= 0, solver controls for k and Gauss linear or Gauss upwind for div(alphaPhic,k)");
         if (c->convection_scheme < FY_CONVECTION_LINEAR || c->convection_scheme > FY_CONVECTION_QUICK)
             return fail(FY_ERR_UNSUPPORTED, "fy_ldu_solver: convection scheme %d (FY_CONVECTION_LINEAR .. FY_CONVECTION_QUICK)", c->convection_scheme);
         if (c->convection_scheme == FY_CONVECTION_LIMITED_LINEAR && !(c->convection_limiter_k >= 0 && c->convection_limiter_k <= 1)) return fail(FY_ERR_INVALID, "fy_ldu_solver: limitedLinear takes a coefficient in [0, 1]");
@@ -140,11 +150,25 @@ struct LduSolver {
                 for (int pa = 0; pa < hm.nPatches; ++pa) {
                     if (c->nut_bc) nb[(size_t)pa] = c->nut_bc[pa];
                     if (c->nut_value) nv[(size_t)pa] = c->nut_value[pa];
-                    if (nb[(size_t)pa] != FY_BC_NUT_ZERO_GRADIENT && nb[(size_t)pa] != FY_BC_NUT_FIXED_VALUE) return fail(FY_ERR_UNSUPPORTED, "fy_ldu_solver: nut patch type %d (zeroGradient, fixedValue)", nb[(size_t)pa]);
+                    if (nb[(size_t)pa] != FY_BC_NUT_ZERO_GRADIENT && nb[(size_t)pa] != FY_BC_NUT_FIXED_VALUE && !(keqn && nb[(size_t)pa] == FY_BC_NUT_CALCULATED))
+                        return fail(FY_ERR_UNSUPPORTED, "fy_ldu_solver: nut patch type %d (zeroGradient, fixedValue; calculated with kEqn)", nb[(size_t)pa]);
                 }
                 FY_TRY(up(d_nutbc, nb)); FY_TRY(up(d_nutval, nv));
                 FY_TRY(nut.alloc_exact(n));
                 FY_TRY(launch_fill_f64(stream, nut.p, n, c->nut_initial));
+            }
+            if (keqn) {                                                       // k of the start time (kEqn: k_ is MUST_READ), its patches
+                std::vector<int32_t> kb((size_t)hm.nPatches, FY_BC_NUT_ZERO_GRADIENT);
+                std::vector<double> kv((size_t)hm.nPatches, 0.0);
+                for (int pa = 0; pa < hm.nPatches; ++pa) {
+                    if (c->k_bc) kb[(size_t)pa] = c->k_bc[pa];
+                    if (c->k_value) kv[(size_t)pa] = c->k_value[pa];
+                    if (kb[(size_t)pa] != FY_BC_NUT_ZERO_GRADIENT && kb[(size_t)pa] != FY_BC_NUT_FIXED_VALUE) return fail(FY_ERR_UNSUPPORTED, "fy_ldu_solver: k patch type %d (zeroGradient, fixedValue)", kb[(size_t)pa]);
+                }
+                FY_TRY(up(d_kbc, kb)); FY_TRY(up(d_kval, kv));
+                FY_TRY(kturb.alloc_exact(n)); FY_TRY(gradk.alloc_exact(3 * n));
+                FY_TRY(launch_fill_f64(stream, kturb.p, n, c->k_initial));
+                cs.k_bc = nullptr; cs.k_value = nullptr;
             }
         }
         for (auto& t : tim) FY_TRY(t.init());
@@ -182,28 +206,31 @@ struct LduSolver {
     DevBuf<int> ops_courant;
 
     int solve_momentum(int* iters, const double* rhs, const double* gp) {
-        FY_TRY(launch_ldu_sum(stream, U.p, nc, 3, partials.p));
+        FY_TRY(solve_vec3(iters, M(), rhs, gp, &U.p, &xscr.p, cs.u_tol, cs.u_rel_tol, cs.u_max_iter));
+        if (cpl) cpl->c.dU = U.p;
+        return FY_OK;
+    }
+    // Jacobi passes on a three-component system with lduMatrix::solver's L1 residual control per component; the converged iterate ends up in *x (the two buffers may trade places)
+    int solve_vec3(int* iters, LduMom Mx, const double* rhs, const double* gp, double** x, double** scratch, double tol, double rel_tol, int max_iter) {
+        FY_TRY(launch_ldu_sum(stream, *x, nc, 3, partials.p));
         FY_TRY(launch_reduce_finalize(stream, partials.p, nc, 3, nullptr, xsum.p, nullptr, 0));
-        double* xc = U.p; double* xn = xscr.p;
+        double* xc = *x; double* xn = *scratch;
         double norm[3] = {1, 1, 1}, res0[3] = {0, 0, 0}, res[3], h[6];
         int it = 0;
         for (;;) {
-            FY_TRY(launch_ldu_mom_pass(stream, g, M(), rhs, gp, xc, xn, xsum.p, partials.p));
+            FY_TRY(launch_ldu_mom_pass(stream, g, Mx, rhs, gp, xc, xn, xsum.p, partials.p));
             FY_TRY(reduce_read(nc, 6, nullptr, h));
             if (it == 0) for (int q = 0; q < 3; ++q) { norm[q] = h[3 + q] + 1e-20; res0[q] = h[q] / norm[q]; }
             bool conv = true;
             for (int q = 0; q < 3; ++q) {
                 res[q] = h[q] / norm[q];
-                if (!(res[q] < cs.u_tol || (cs.u_rel_tol > 0 && res[q] < cs.u_rel_tol * res0[q]))) conv = false;
+                if (!(res[q] < tol || (rel_tol > 0 && res[q] < rel_tol * res0[q]))) conv = false;
             }
-            if (conv || it >= cs.u_max_iter) break;
+            if (conv || it >= max_iter) break;
             std::swap(xc, xn);
             ++it;
         }
-        if (xc != U.p) {                                   // the converged iterate sits in the scratch buffer: the two trade places
-            std::swap(U.p, xscr.p);
-            if (cpl) cpl->c.dU = U.p;
-        }
+        if (xc != *x) std::swap(*x, *scratch);            // the converged iterate sits in the scratch buffer: the two trade places
         *iters = it;
         return FY_OK;
     }
@@ -321,6 +348,18 @@ struct LduSolver {
             for (int corr = 0; corr < cs.n_correctors; ++corr) FY_TRY(corrector_pimple(final_outer && corr == cs.n_correctors - 1, p_relax_now));
             if (les && final_outer) {                                                                             // pimple.turbCorr(): pimpleFoamYade.C:101-104
                 FY_TRY(launch_ldu_grad_vec(stream, g, U.p, vGrad.p));
+                if (keqn) {                                                                                       // kEqn::correct(): the k equation (its matrix in the momentum matrix's arrays), bound(), correctNut()
+                    LduMom Mk = M();
+                    Mk.bdiag = nullptr;
+                    const LduKEqn K{cs.les_ce, cs.k_relax, cs.k_convection_scheme == FY_CONVECTION_UPWIND ? 1 : 0};
+                    FY_TRY(launch_ldu_grad_k(stream, g, P(), gradk.p));
+                    FY_TRY(launch_ldu_k_assemble(stream, g, P(), K, phi.p, vGrad.p, gradk.p, Mk, fcorr.p, HbyA.p));
+                    int it = 0;
+                    FY_TRY(solve_vec3(&it, Mk, mb.p, nullptr, &HbyA.p, &xscr.p, cs.k_tol, cs.k_rel_tol, cs.k_max_iter));
+                    k_iters_total += it;
+                    FY_TRY(launch_ldu_k_bound_nut(stream, g, P(), HbyA.p, kturb.p, nut.p));
+                    nut_live = true;
+                } else
                 FY_TRY(launch_ldu_smagorinsky_nut(stream, g, vGrad.p, cs.les_ck, cs.les_ce, cs.les_delta_coeff, nut.p));
             }
         }
@@ -388,7 +427,7 @@ struct LduSolver {
                          {"mom_diag", mdiag.p, n}, {"mom_lower", mlower.p, (size_t)ni}, {"mom_upper", mupper.p, (size_t)ni}, {"mom_b", mb.p, 3 * n},
                          {"alpha", alpha.p, pimple ? n : 0}, {"uSourceDrag", uSourceDrag.p, pimple ? n : 0}, {"uParticle", uParticle.p, pimple ? 3 * n : 0}, {"gradP", gradP.p, pimple ? 3 * n : 0},
                          {"divT", divT.p, pimple ? 3 * n : 0}, {"ddtU", ddtU.p, pimple ? 3 * n : 0}, {"phiForces", phiForces.p, pimple ? (size_t)nf : 0}, {"alphaf", alphaf.p, pimple ? (size_t)nf : 0},
-                         {"rAUf", rAUf.p, (size_t)nf}, {"uSourceCoupling", uSource.p, 3 * n}, {"nut", nut.p, les ? n : 0}};
+                         {"rAUf", rAUf.p, (size_t)nf}, {"uSourceCoupling", uSource.p, 3 * n}, {"nut", nut.p, les ? n : 0}, {"k", kturb.p, keqn ? n : 0}};
         for (const E& e : tab) if (s == e.nm) { *ptr = e.p; *count = e.c; return FY_OK; }
         const struct { const char* nm; const std::vector<double>* v; } geo[] = {{"C", &hm.C}, {"V", &hm.V}, {"Cf", &hm.Cf}, {"Sf", &hm.Sf}, {"magSf", &hm.magSf}, {"w", &hm.w},
                                                                                   {"dcNO", &hm.dcNO}, {"kvec", &hm.kvec}, {"sep", &hm.sep}, {"orig_face", &orig_face_d}};
@@ -415,6 +454,7 @@ void fy_ldu_case_defaults(fy_ldu_case* c) {
     c->adjust_time_step = 0; c->max_co = 1.0; c->max_delta_t = 1e300;
     c->turbulence_model = FY_TURBULENCE_LAMINAR; c->les_ck = 0.094; c->les_ce = 1.048; c->les_delta_coeff = 1.0; c->nut_initial = 0.0;
     c->convection_scheme = FY_CONVECTION_LINEAR; c->convection_limiter_k = 1.0;
+    c->k_initial = 0.0; c->k_bc = nullptr; c->k_value = nullptr; c->k_convection_scheme = FY_CONVECTION_LINEAR; c->k_tol = 1e-6; c->k_rel_tol = 0.0; c->k_max_iter = 1000; c->k_relax = 0.0;
 }
 
 int fy_ldu_solver_create(const fy_poly_mesh* m, const fy_ldu_case* c, const fy_transport* tr, int device_ordinal, fy_ldu_solver** out) {
@@ -454,7 +494,7 @@ int fy_ldu_solver_write_field_host(fy_ldu_solver* s, const char* name, const dou
     double* p; size_t n; const std::vector<double>* h;
     FY_TRY(s->s.field(name, &p, &n, &h));
     const std::string nm = name;
-    const bool pim_in = (s->s.pimple && (nm == "alpha" || nm == "uSourceDrag")) || (s->s.les && nm == "nut");      // (what setParticleAction would leave: for tests that feed the equations a given void fraction)
+    const bool pim_in = (s->s.pimple && (nm == "alpha" || nm == "uSourceDrag")) || (s->s.les && nm == "nut") || (s->s.keqn && nm == "k");      // (what setParticleAction would leave: for tests that feed the equations a given void fraction)
     if (h || (nm != "U" && nm != "p" && nm != "uSource" && !pim_in)) return fy::fail(FY_ERR_INVALID, "fy_ldu_solver_write_field_host: '%s' cannot be written (U, p, uSource; alpha, uSourceDrag with pimpleFoamYade)", nm.c_str());
     FY_HIP(hipSetDevice(s->s.device));
     FY_HIP(hipMemcpyAsync(p, in, n * sizeof(double), hipMemcpyHostToDevice, s->s.stream));
