@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define FY_ABI_VERSION 11
+#define FY_ABI_VERSION 12
 
 /* ---- status codes ------------------------------------------------------------------------------------ */
 enum {
@@ -454,7 +454,7 @@ int fy_solver_get_kernel_timing(fy_solver*, const char* kernel, double* total_ms
  * correctNonOrthogonal loop iterates on), PCG in its single-reduction form with the diagonal or an agglomeration-multigrid preconditioner (p_solver),
  * Jacobi sweeps for U.  Patches: fixedValue / zeroGradient / symmetry (slip) for U (noSlip = fixedValue 0), translational cyclic pairs; zeroGradient / fixedValue for p, fixedFluxPressure with
  * pimpleFoamYade.  pimpleFoamYade (fy_ldu_case.solver): Gaussian 4-way coupling, the void-fraction-weighted UcEqn / pEqn, gravity, PIMPLE outer correctors,
- * relaxation, adjustable time step, laminar Stokes stress, LES Smagorinsky or LES kEqn.  The coupling object (fy_ldu_solver_coupling) works on the mesh's own
+ * relaxation, adjustable time step, laminar Stokes stress, LES Smagorinsky / kEqn or RAS kEpsilon (no wall functions).  The coupling object (fy_ldu_solver_coupling) works on the mesh's own
  * cell centres and volumes: explicit k-d tree, and for the point-force locate (mesh.findCell, FoamYade.C:251) the nearest centre followed by a walk
  * across the faces the point lies outside of. */
 typedef struct fy_poly_mesh {
@@ -494,7 +494,7 @@ typedef struct fy_ldu_case {
     double u_relax, u_relax_final, p_relax, p_relax_final;      /* relaxationFactors; <= 0: no entry (relax() does nothing) */
     int32_t adjust_time_step;        /* pimpleFoamYade only (pimpleFoamYade.C:62-64: readTimeControls.H, CourantNo.H, setDeltaT.H) */
     double max_co, max_delta_t;
-    /* continuousPhaseTurbulence (pimpleFoamYade only): FY_TURBULENCE_LAMINAR | FY_TURBULENCE_SMAGORINSKY | FY_TURBULENCE_KEQN (LES, delta cubeRootVol) as in fy_case_desc */
+    /* continuousPhaseTurbulence (pimpleFoamYade only): FY_TURBULENCE_LAMINAR | FY_TURBULENCE_SMAGORINSKY | FY_TURBULENCE_KEQN (LES, delta cubeRootVol) | FY_TURBULENCE_KEPSILON as in fy_case_desc */
     int32_t turbulence_model;
     double les_ck, les_ce, les_delta_coeff, nut_initial;
     const int32_t* nut_bc;           /* per patch: FY_BC_NUT_ZERO_GRADIENT | FY_BC_NUT_FIXED_VALUE (NULL: zeroGradient everywhere) */
@@ -510,6 +510,16 @@ typedef struct fy_ldu_case {
     int32_t k_convection_scheme;
     double k_tol, k_rel_tol; int32_t k_max_iter;
     double k_relax;
+    /* turbulence_model FY_TURBULENCE_KEPSILON (RAS kEpsilon, DPMTurbulenceModels.C:70-71), WITHOUT wall functions on a general mesh (nutkWallFunction /
+     * epsilonWallFunction need nearWallDist: the block solver carries them): the coefficients, the 0/epsilon file and its controls as in fy_case_desc; k as above;
+     * a FY_BC_NUT_CALCULATED nut patch then carries Cmu k_b^2 / epsilon_b */
+    double ras_cmu, ras_c1, ras_c2, ras_c3, ras_sigmak, ras_sigmaeps;      /* fy_ldu_case_defaults: 0.09, 1.44, 1.92, 0, 1, 1.3 */
+    double eps_initial;
+    const int32_t* eps_bc;           /* NULL: zeroGradient everywhere */
+    const double* eps_value;
+    int32_t eps_convection_scheme;
+    double eps_tol, eps_rel_tol; int32_t eps_max_iter;
+    double eps_relax;
 } fy_ldu_case;
 typedef struct fy_ldu_solver fy_ldu_solver;
 void fy_ldu_case_defaults(fy_ldu_case*);        /* the icoFoam cavity tutorial's controls (as fy_case_defaults); the patch arrays stay NULL */

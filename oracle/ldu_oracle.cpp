@@ -46,7 +46,7 @@ extern "C" struct orc_ldu_case {
     int n_outer;
     double u_relax, u_relax_final, p_relax, p_relax_final;      // <= 0: no relaxationFactors entry
     int adjust_time_step; double max_co, max_delta_t;           // setDeltaT.H (pimpleFoamYade.C:62-64)
-    int turbulence_model;                                       // 0 laminar, 1 LES Smagorinsky, 2 LES kEqn (delta cubeRootVol)
+    int turbulence_model;                                       // 0 laminar, 1 LES Smagorinsky, 2 LES kEqn (delta cubeRootVol), 3 RAS kEpsilon
     double les_ck, les_ce, les_delta_coeff, nut_initial;
     const int* nut_bc; const double* nut_value;                 // per patch: 0 zeroGradient, 1 fixedValue
     int convection_scheme;                                      // 0 Gauss linear, 1 Gauss upwind, 2 Gauss linearUpwind grad(U), 3 .. 8 limitedLinear k / vanLeer / MUSCL / Minmod / SuperBee / QUICK
@@ -54,6 +54,9 @@ extern "C" struct orc_ldu_case {
     // turbulence_model 2: LES kEqn -- the 0/k file (k_initial, per patch 0 zeroGradient / 1 fixedValue), div(alphaPhic,k) (0 linear, 1 upwind), solvers.k, relaxationFactors k;
     // nut_bc may then be 3 (calculated: Ck sqrt(k_b) delta once correctNut() has run, the file's value before)
     double k_initial; const int* k_bc; const double* k_value; int k_convection_scheme; double k_tol, k_rel_tol; int k_max_iter; double k_relax;
+    // turbulence_model 3: RAS kEpsilon (no wall functions on a general mesh) -- coefficients, the 0/epsilon file and its controls; k as above; nut_bc 3: Cmu k_b^2 / eps_b
+    double ras_cmu, ras_c1, ras_c2, ras_c3, ras_sigmak, ras_sigmaeps;
+    double eps_initial; const int* eps_bc; const double* eps_value; int eps_convection_scheme; double eps_tol, eps_rel_tol; int eps_max_iter; double eps_relax;
 };
 extern "C" struct orc_ldu_stats {
     double courant_mean, courant_max, cont_sum_local, cont_global, cont_cumulative;
@@ -139,7 +142,9 @@ struct Ldu {
     // pimpleFoamYade: the coupling's fields (set from outside between step_begin and step_end), the face fields of the alpha-weighted equations
     vec alpha, uSourceDrag, uParticle, gradP, divT, ddtU, alphaf, phiForces, psn, recon, pPrev, nut;
     std::vector<int> nut_bc; vec nut_val;
-    vec kturb; std::vector<int> k_bc; vec k_val;      // LES kEqn
+    vec kturb; std::vector<int> k_bc; vec k_val;      // LES kEqn, RAS kEpsilon
+    vec epsturb; std::vector<int> eps_bc; vec eps_val; // RAS kEpsilon
+    double eb_of(int pa, int c) const { return eps_bc[pa] == 1 ? eps_val[pa] : epsturb[c]; }
     bool nut_live = false;                             // correctNut() has run: a `calculated` nut patch carries the model's expression, before that the file's value
     int k_iters = 0;
     double kb_of(int pa, int c) const { return k_bc[pa] == 1 ? k_val[pa] : kturb[c]; }
@@ -148,6 +153,7 @@ struct Ldu {
     double nut_bnd(int pa, int c) const {
         if (nut.empty()) return 0.0;
         if (nut_bc[pa] == 1 || (nut_bc[pa] == 3 && !nut_live)) return nut_val[pa];
+        if (nut_bc[pa] == 3 && cs.turbulence_model == 3) { const double kb = kb_of(pa, c); return cs.ras_cmu * (kb * kb) / eb_of(pa, c); }
         if (nut_bc[pa] == 3) return cs.les_ck * std::sqrt(kb_of(pa, c)) * les_delta(c);
         return nut[c];
     }
@@ -281,12 +287,17 @@ struct Ldu {
         if (pimple) {
             alpha.assign(nc, 1.0); uSourceDrag.assign(nc, 0.0); uParticle.assign(3 * nc, 0.0); gradP = uParticle; divT = uParticle; ddtU = uParticle;
             alphaf.assign(nFaces, 1.0); phiForces.assign(nFaces, 0.0); psn.assign(nFaces - nInt, 0.0); pPrev = p;
-            if (cs.turbulence_model == 1 || cs.turbulence_model == 2) {
+            if (cs.turbulence_model >= 1 && cs.turbulence_model <= 3) {
                 nut.assign(nc, cs.nut_initial);
                 nut_bc.assign(nPatches, 0); nut_val.assign(nPatches, 0.0);
                 for (int pa = 0; pa < nPatches; ++pa) { if (cs.nut_bc) nut_bc[pa] = cs.nut_bc[pa]; if (cs.nut_value) nut_val[pa] = cs.nut_value[pa]; }
             }
-            if (cs.turbulence_model == 2) {
+            if (cs.turbulence_model == 3) {
+                epsturb.assign(nc, cs.eps_initial);
+                eps_bc.assign(nPatches, 0); eps_val.assign(nPatches, 0.0);
+                for (int pa = 0; pa < nPatches; ++pa) { if (cs.eps_bc) eps_bc[pa] = cs.eps_bc[pa]; if (cs.eps_value) eps_val[pa] = cs.eps_value[pa]; }
+            }
+            if (cs.turbulence_model == 2 || cs.turbulence_model == 3) {
                 kturb.assign(nc, cs.k_initial);
                 k_bc.assign(nPatches, 0); k_val.assign(nPatches, 0.0);
                 for (int pa = 0; pa < nPatches; ++pa) { if (cs.k_bc) k_bc[pa] = cs.k_bc[pa]; if (cs.k_value) k_val[pa] = cs.k_value[pa]; }
@@ -569,21 +580,33 @@ struct Ldu {
     //   fvm::ddt(alpha, k) + fvm::div(alphaPhi, k) - fvm::laplacian(alpha DkEff, k) == alpha G - fvm::SuSp(2/3 alpha divU, k) - fvm::Sp(Ce alpha sqrt(k) / delta, k), DkEff = nut + nu
     //   (Gauss linear corrected: the explicit part (alpha DkEff)_f |Sf| (k & interpolate(grad k)) on the right); relax(); solve; bound(k, kMin); nut = Ck sqrt(k) delta
     // [OF-6 fvm::SuSp: diag += V max(susp, 0), source -= V min(susp, 0) psi; bound.C: k = max(max(k, fvc::average(max(k, kMin)) pos0(-k)), kMin)]
-    void k_equation() {
+    // RASModel kEpsilon [OF-6 RAS/kEpsilon/kEpsilon.C correct()] (DPMTurbulenceModels.C:70-71) shares the form (fv_oracle.cpp turb_eqn):
+    //   mode 0 (kEqn, X = k):       Su = alpha G,           c1 = 2/3 alpha divU,           c2 = Ce alpha sqrt(k)/delta, DkEff = nut + nu
+    //   mode 1 (kEpsilon, X = eps): Su = C1 alpha G eps/k,  c1 = (2/3 C1 - C3) alpha divU, c2 = C2 alpha eps/k,         DepsilonEff = nut/sigmaEps + nu
+    //   mode 2 (kEpsilon, X = k):   Su = alpha G,           c1 = 2/3 alpha divU,           c2 = alpha eps/k,            DkEff = nut/sigmak + nu; then nut = Cmu k^2/eps
+    // (no wall functions on a general mesh: they need nearWallDist)
+    void turb_eqn(int mode) {
         const size_t nc = nCells;
         const double kMin = 1e-15;
+        const double sigma = mode == 0 ? 1.0 : mode == 1 ? cs.ras_sigmaeps : cs.ras_sigmak;
+        vec& Xf = mode == 1 ? epsturb : kturb;
+        const std::vector<int>& xbc = mode == 1 ? eps_bc : k_bc;
+        const vec& xval = mode == 1 ? eps_val : k_val;
+        const int scheme = mode == 1 ? cs.eps_convection_scheme : cs.k_convection_scheme;
+        const double relax = mode == 1 ? cs.eps_relax : cs.k_relax;
+        auto xb_of = [&](int pa, int c) { return xbc[pa] == 1 ? xval[pa] : Xf[c]; };
         std::vector<V3> gk;
-        grad_scalar(kturb, [&](int f) { return kb_of(patch_of[f - nInt], own[f]); }, gk);
+        grad_scalar(Xf, [&](int f) { return xb_of(patch_of[f - nInt], own[f]); }, gk);
         std::fill(diag.begin(), diag.end(), 0.0); std::fill(src.begin(), src.end(), 0.0);
         std::fill(bint.begin(), bint.end(), 0.0); std::fill(bsrc.begin(), bsrc.end(), 0.0);
         std::fill(bdg.begin(), bdg.end(), 0.0);
         vec sumPhi(nc, 0.0), offsum(nc, 0.0);
-        for (size_t c = 0; c < nc; ++c) { diag[c] += alpha[c] * V[c] / cs.dt; src[3 * c] += alpha[c] * V[c] / cs.dt * kturb[c]; }
+        for (size_t c = 0; c < nc; ++c) { diag[c] += alpha[c] * V[c] / cs.dt; src[3 * c] += alpha[c] * V[c] / cs.dt * Xf[c]; }
         for (int f = 0; f < nInt; ++f) {
             const int o = own[f], n = nei[f];
             const double fl = alphaf[f] * phi[f];
-            const double gam = (w[f] * alpha[o] * (cs.nu + nut[o]) + (1.0 - w[f]) * alpha[n] * (cs.nu + nut[n])) * magSf[f];
-            const double wc = cs.k_convection_scheme ? (fl >= 0.0 ? 1.0 : 0.0) : w[f];
+            const double gam = (w[f] * alpha[o] * (cs.nu + nut[o] / sigma) + (1.0 - w[f]) * alpha[n] * (cs.nu + nut[n] / sigma)) * magSf[f];
+            const double wc = scheme ? (fl >= 0.0 ? 1.0 : 0.0) : w[f];
             double lo = -wc * fl, up = lo + fl;
             lo -= gam * dcNO[f]; up -= gam * dcNO[f];
             lower[f] = lo; upper[f] = up;
@@ -597,7 +620,7 @@ struct Ldu {
             const int b = f - nInt, pa = patch_of[b], c = own[f];
             sumPhi[c] += phi[f];
             const double fl = alphaf[f] * phi[f];
-            if (k_bc[pa] == 1) { const double gb = (cs.nu + nut_bnd(pa, c)) * magSf[f] * dcNO[f]; bint[b] += gb; bsrc[3 * (size_t)b] += (-fl + gb) * k_val[pa]; }
+            if (xbc[pa] == 1) { const double gb = (cs.nu + nut_bnd(pa, c) / sigma) * magSf[f] * dcNO[f]; bint[b] += gb; bsrc[3 * (size_t)b] += (-fl + gb) * xval[pa]; }
             else bint[b] += fl;
         }
         for (size_t c = 0; c < nc; ++c) {
@@ -605,15 +628,18 @@ struct Ldu {
             const double tr2 = 2.0 * (T[0] + T[4] + T[8]);
             double GG = 0.0;
             for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) GG += T[3 * a + b] * ((T[3 * a + b] + T[3 * b + a]) - (a == b ? (1.0 / 3.0) * tr2 : 0.0));
-            const double G = nut[c] * GG, divU = sumPhi[c] / V[c], xc = kturb[c];
-            const double c1 = (2.0 / 3.0) * alpha[c] * divU, c2 = cs.les_ce * alpha[c] * std::sqrt(xc) / les_delta((int)c);
+            const double G = nut[c] * GG, divU = sumPhi[c] / V[c], xc = Xf[c], aP = alpha[c];
+            double Su, c1, c2;
+            if (mode == 0) { Su = aP * G; c1 = (2.0 / 3.0) * aP * divU; c2 = cs.les_ce * aP * std::sqrt(xc) / les_delta((int)c); }
+            else if (mode == 1) { const double kc = kturb[c]; Su = cs.ras_c1 * aP * G * xc / kc; c1 = ((2.0 / 3.0) * cs.ras_c1 - cs.ras_c3) * aP * divU; c2 = cs.ras_c2 * aP * xc / kc; }
+            else { Su = aP * G; c1 = (2.0 / 3.0) * aP * divU; c2 = aP * epsturb[c] / xc; }
             diag[c] += V[c] * (std::max(c1, 0.0) + c2);
-            src[3 * c] += V[c] * alpha[c] * G - V[c] * std::min(c1, 0.0) * xc;
+            src[3 * c] += V[c] * Su - V[c] * std::min(c1, 0.0) * xc;
         }
-        if (cs.k_relax > 0) {
+        if (relax > 0) {
             for (size_t c = 0; c < nc; ++c) {
-                const double dg = dgc((int)c), dn = std::max(std::fabs(dg), offsum[c]) / cs.k_relax;
-                src[3 * c] += (dn - dg) * xc_of(c);
+                const double dg = dgc((int)c), dn = std::max(std::fabs(dg), offsum[c]) / relax;
+                src[3 * c] += (dn - dg) * Xf[c];
                 diag[c] += dn - dg;
             }
         }
@@ -621,8 +647,8 @@ struct Ldu {
         vec keepU = U;
         const bool slip = has_slip; has_slip = false;
         const double ut = cs.u_tol, ur = cs.u_rel_tol; const int um = cs.u_max_iter;
-        cs.u_tol = cs.k_tol; cs.u_rel_tol = cs.k_rel_tol; cs.u_max_iter = cs.k_max_iter;
-        for (size_t c = 0; c < nc; ++c) { U[3 * c] = kturb[c]; U[3 * c + 1] = 0.0; U[3 * c + 2] = 0.0; }
+        if (mode == 1) { cs.u_tol = cs.eps_tol; cs.u_rel_tol = cs.eps_rel_tol; cs.u_max_iter = cs.eps_max_iter; } else { cs.u_tol = cs.k_tol; cs.u_rel_tol = cs.k_rel_tol; cs.u_max_iter = cs.k_max_iter; }
+        for (size_t c = 0; c < nc; ++c) { U[3 * c] = Xf[c]; U[3 * c + 1] = 0.0; U[3 * c + 2] = 0.0; }
         k_iters += solve_momentum(vec(3 * nc, 0.0));
         vec x(nc);
         for (size_t c = 0; c < nc; ++c) x[c] = U[3 * c];
@@ -637,20 +663,21 @@ struct Ldu {
                 for (int f : cfaces[c]) {
                     double xf;
                     if (f < nInt) xf = w[f] * xm[own[f]] + (1.0 - w[f]) * xm[nei[f]];
-                    else { const int pa = patch_of[f - nInt]; xf = std::max(k_bc[pa] == 1 ? k_val[pa] : x[c], kMin); }
+                    else { const int pa = patch_of[f - nInt]; xf = std::max(xbc[pa] == 1 ? xval[pa] : x[c], kMin); }
                     av += magSf[f] * xf; asum += magSf[f];
                 }
                 xb = std::max(x[c], av / asum);
             }
-            kturb[c] = std::max(xb, kMin);
+            Xf[c] = std::max(xb, kMin);
         }
-        for (int c = 0; c < nCells; ++c) nut[c] = cs.les_ck * std::sqrt(kturb[c]) * les_delta(c);
-        nut_live = true;
+        if (mode == 0) for (int c = 0; c < nCells; ++c) nut[c] = cs.les_ck * std::sqrt(kturb[c]) * les_delta(c);
+        else if (mode == 2) for (int c = 0; c < nCells; ++c) nut[c] = cs.ras_cmu * (kturb[c] * kturb[c]) / epsturb[c];
+        if (mode != 1) nut_live = true;
     }
-    double xc_of(size_t c) const { return kturb[c]; }
     void turbulence_correct() {
         grad_vector(U, vGrad);
-        if (cs.turbulence_model == 2) { k_equation(); return; }
+        if (cs.turbulence_model == 2) { turb_eqn(0); return; }
+        if (cs.turbulence_model == 3) { turb_eqn(1); turb_eqn(2); return; }      // kEpsilon::correct(): epsilon first, then k with the new epsilon
         for (int c = 0; c < nCells; ++c) {
             const double delta = cs.les_delta_coeff * std::cbrt(V[c]);
             const double* T = &vGrad[9 * (size_t)c];
@@ -1015,7 +1042,7 @@ vec* ldu_field(Ldu* s, const std::string& n) {
     const struct { const char* nm; vec* v; } tab[] = {{"U", &s->U}, {"p", &s->p}, {"phi", &s->phi}, {"uSource", &s->uSource}, {"vGrad", &s->vGrad}, {"rAU", &s->rAU},
         {"HbyA", &s->HbyA}, {"p_diag", &s->pdiag}, {"p_coef", &s->pcoef}, {"p_rhs", &s->pb}, {"mom_diag", &s->diag}, {"mom_lower", &s->lower}, {"mom_upper", &s->upper},
         {"mom_src", &s->src}, {"phiHbyA", &s->phiHbyA}, {"alpha", &s->alpha}, {"uSourceDrag", &s->uSourceDrag}, {"gradP", &s->gradP}, {"divT", &s->divT}, {"ddtU", &s->ddtU},
-        {"phiForces", &s->phiForces}, {"rAUf", &s->rAUf}, {"nut", &s->nut}, {"k", &s->kturb}};
+        {"phiForces", &s->phiForces}, {"rAUf", &s->rAUf}, {"nut", &s->nut}, {"k", &s->kturb}, {"epsilon", &s->epsturb}};
     for (const auto& e : tab) if (n == e.nm) return e.v;
     return nullptr;
 }

@@ -451,7 +451,9 @@ class LduCase(C.Structure):
                 ("max_delta_t", C.c_double), ("turbulence_model", C.c_int), ("les_ck", C.c_double), ("les_ce", C.c_double), ("les_delta_coeff", C.c_double),
                 ("nut_initial", C.c_double), ("nut_bc", _ip), ("nut_value", _dp), ("convection_scheme", C.c_int), ("convection_limiter_k", C.c_double),
                 ("k_initial", C.c_double), ("k_bc", _ip), ("k_value", _dp), ("k_convection_scheme", C.c_int), ("k_tol", C.c_double), ("k_rel_tol", C.c_double),
-                ("k_max_iter", C.c_int), ("k_relax", C.c_double)]
+                ("k_max_iter", C.c_int), ("k_relax", C.c_double), ("ras_cmu", C.c_double), ("ras_c1", C.c_double), ("ras_c2", C.c_double), ("ras_c3", C.c_double),
+                ("ras_sigmak", C.c_double), ("ras_sigmaeps", C.c_double), ("eps_initial", C.c_double), ("eps_bc", _ip), ("eps_value", _dp), ("eps_convection_scheme", C.c_int),
+                ("eps_tol", C.c_double), ("eps_rel_tol", C.c_double), ("eps_max_iter", C.c_int), ("eps_relax", C.c_double)]
 
 
 class LduStats(C.Structure):
@@ -491,7 +493,8 @@ class LduSolver:
                  rho_f=1000.0, rho_p=2650.0, solver=0, g=(0.0, 0.0, 0.0), n_outer=1, u_relax=0.0, u_relax_final=0.0, p_relax=0.0, p_relax_final=0.0,
                  adjust_time_step=0, max_co=1.0, max_delta_t=1e300, turbulence_model=0, les_ck=0.094, les_ce=1.048, les_delta_coeff=1.0, nut_initial=0.0,
                  nut_bc=None, nut_val=None, convection_scheme=0, convection_limiter_k=1.0, k_initial=0.0, k_bc=None, k_val=None, k_convection_scheme=0, k_tol=1e-6,
-                 k_rel_tol=0.0, k_max_iter=1000, k_relax=0.0):
+                 k_rel_tol=0.0, k_max_iter=1000, k_relax=0.0, ras_cmu=0.09, ras_c1=1.44, ras_c2=1.92, ras_c3=0.0, ras_sigmak=1.0, ras_sigmaeps=1.3, eps_initial=0.0,
+                 eps_bc=None, eps_val=None, eps_convection_scheme=0, eps_tol=1e-6, eps_rel_tol=0.0, eps_max_iter=1000, eps_relax=0.0):
         """solver = 1: pimpleFoamYade -- step(source, alpha, drag) then takes the void fraction and the implicit drag coefficient the coupling would leave"""
         self.L = _ldu_lib()
         self.mesh = mesh
@@ -506,13 +509,16 @@ class LduSolver:
                           nv=np.ascontiguousarray(nut_val if nut_val is not None else np.zeros(npatch), np.float64),
                           pn=(np.ascontiguousarray(mesh["patch_neighbour"], np.int32) if mesh.get("patch_neighbour") is not None else None),
                           kb=np.ascontiguousarray(k_bc if k_bc is not None else np.zeros(npatch), np.int32),
-                          kv=np.ascontiguousarray(k_val if k_val is not None else np.zeros(npatch), np.float64))
+                          kv=np.ascontiguousarray(k_val if k_val is not None else np.zeros(npatch), np.float64),
+                          eb=np.ascontiguousarray(eps_bc if eps_bc is not None else np.zeros(npatch), np.int32),
+                          ev=np.ascontiguousarray(eps_val if eps_val is not None else np.zeros(npatch), np.float64))
         k = self._keep
         self.case = LduCase(solver, dt, nu, rho_f, rho_p, n_correctors, n_non_orth, momentum_predictor, p_ref_cell, p_ref_value, p_tol, p_rel_tol, p_final_tol,
                             p_final_rel_tol, p_max_iter, u_tol, u_rel_tol, u_max_iter, _i(k["ub"]), _d(k["uv"]), _i(k["pb"]), _d(k["pv"]), (C.c_double * 3)(*g), n_outer,
                             u_relax, u_relax_final, p_relax, p_relax_final, adjust_time_step, max_co, max_delta_t, turbulence_model, les_ck, les_ce,
                             les_delta_coeff, nut_initial, _i(k["nb"]), _d(k["nv"]), convection_scheme, convection_limiter_k, k_initial, _i(k["kb"]), _d(k["kv"]),
-                            k_convection_scheme, k_tol, k_rel_tol, k_max_iter, k_relax)
+                            k_convection_scheme, k_tol, k_rel_tol, k_max_iter, k_relax, ras_cmu, ras_c1, ras_c2, ras_c3, ras_sigmak, ras_sigmaeps, eps_initial,
+                            _i(k["eb"]), _d(k["ev"]), eps_convection_scheme, eps_tol, eps_rel_tol, eps_max_iter, eps_relax)
         self.pimple = solver == 1
         self.nc, self.nf, self.ni = int(mesh["n_cells"]), len(k["own"]), len(k["nei"])
         self.h = self.L.orc_ldu_create(k["points"].shape[0], _d(k["points"]), self.nf, self.ni, _i(k["foff"]), _i(k["fpts"]), _i(k["own"]), _i(k["nei"]),

@@ -287,7 +287,9 @@ def test_general_pimple_case_is_read(prod, tmp_path):
     fc.close()
     (dst / "constant/turbulenceProperties.water").write_text("simulationType RAS;\nRAS { RASModel kEpsilon; turbulence on; }\n")      # (kEqn: test_general_kEqn_case_runs_and_writes_k)
     (dst / "0/k.water").write_text((dst / "0/nut.water").read_text().replace("nut.water", "k.water"))
-    with pytest.raises(prod.FoamYadeError, match="not kEpsilon"):
+    nt = (dst / "0/nut.water").read_text()
+    (dst / "0/nut.water").write_text(nt.replace("top    { type calculated; value uniform 3e-6; }", "top    { type nutkWallFunction; value uniform 0; }"))
+    with pytest.raises(prod.FoamYadeError, match="nutkWallFunction"):      # (kEpsilon itself is carried: test_general_kEpsilon_case_runs; its wall functions need the block solver)
         prod.GeneralFoamCase(dst, prod.FY_SOLVER_PIMPLE)
     os.remove(dst / "0/k.water"); os.remove(dst / "0/nut.water")
     os.remove(dst / "constant/turbulenceProperties.water")
@@ -375,6 +377,34 @@ def test_general_kEqn_case_runs_and_writes_k(prod, tmp_path):
     fc.write(s, "0.001")
     t = (dst / "0.001/k.water").read_text()
     assert "fixedValue" in t and "nonuniform List<scalar>" in t and "calculated" in (dst / "0.001/nut.water").read_text()
+    s.close(); fc.close()
+
+
+@pytest.mark.gpu
+def test_general_kEpsilon_case_runs(prod, tmp_path):
+    """RAS kEpsilon (without wall functions) on the wavy bed from its case directory: coefficients, k / epsilon / nut files, the controls of both equations; k, epsilon and nut
+    written back; nut = Cmu k^2 / epsilon after the first step"""
+    dst, mesh = general_bed(tmp_path)
+    (dst / "constant/turbulenceProperties.water").write_text("simulationType RAS;\nRAS { RASModel kEpsilon; turbulence on; kEpsilonCoeffs { Cmu 0.085; C1 1.4; C2 1.9; C3 -0.33; sigmak 1.1; sigmaEps 1.25; } }\n")
+    nut = (dst / "0/p").read_text().replace("object      p;", "object nut.water;").replace("[0 2 -2 0 0 0 0]", "[0 2 -1 0 0 0 0]").replace("internalField   uniform 0;", "internalField   uniform 2e-6;") \
+        .replace("fixedFluxPressure; value uniform 0;", "zeroGradient;").replace("top    { type fixedValue; value uniform 0; }", "top    { type calculated; value uniform 3e-6; }")
+    (dst / "0/nut.water").write_text(nut)
+    kf = nut.replace("object nut.water;", "object k.water;").replace("[0 2 -1 0 0 0 0]", "[0 2 -2 0 0 0 0]").replace("uniform 2e-6;", "uniform 3e-4;").replace("top    { type calculated; value uniform 3e-6; }", "top    { type fixedValue; value uniform 4e-4; }")
+    (dst / "0/k.water").write_text(kf)
+    (dst / "0/epsilon.water").write_text(kf.replace("object k.water;", "object epsilon.water;").replace("[0 2 -2 0 0 0 0]", "[0 2 -3 0 0 0 0]").replace("uniform 3e-4;", "uniform 2e-3;").replace("uniform 4e-4;", "uniform 3e-3;"))
+    fc = prod.GeneralFoamCase(dst, prod.FY_SOLVER_PIMPLE)
+    lc = fc.ldu_case
+    assert lc.turbulence_model == prod.TURBULENCE_KEPSILON and (lc.ras_cmu, lc.ras_c1, lc.ras_c2, lc.ras_c3, lc.ras_sigmak, lc.ras_sigmaeps) == (0.085, 1.4, 1.9, -0.33, 1.1, 1.25)
+    top = fc.patch_names.index("top")
+    assert (lc.k_initial, lc.eps_initial) == (3e-4, 2e-3) and lc.eps_bc[top] == 1 and lc.eps_value[top] == 3e-3 and lc.nut_bc[top] == 3
+    s = prod.LduSolver.from_foam_case(fc)
+    np.testing.assert_array_equal(s.get("epsilon"), 2e-3)
+    for _ in range(5):
+        s.step()
+    k, e, nutv = s.get("k"), s.get("epsilon"), s.get("nut")
+    assert k.min() > 0 and e.min() > 0 and not np.allclose(e, 2e-3) and np.allclose(nutv, 0.085 * k * k / e, rtol=1e-12)
+    fc.write(s, "0.001")
+    assert "nonuniform List<scalar>" in (dst / "0.001/epsilon.water").read_text() and "fixedValue" in (dst / "0.001/epsilon.water").read_text()
     s.close(); fc.close()
 
 

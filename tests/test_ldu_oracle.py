@@ -420,6 +420,41 @@ def test_les_kEqn_on_a_lattice_reproduces_the_structured_restatement(oracle, var
     f.close(); g.close()
 
 
+def test_ras_kEpsilon_on_a_lattice_reproduces_the_structured_restatement(oracle):
+    """RASModel kEpsilon (DPMTurbulenceModels.C:70-71) on the general mesh, without wall functions: the epsilon equation, then k with the new epsilon, nut = Cmu k^2 / epsilon,
+    against fv_oracle.cpp's on the same block with a cloud and a moving wall -- non-default coefficients, upwind convection and relaxation of both, fixed-value patches of k
+    and epsilon, `calculated` nut patches"""
+    n, box = 8, 0.1
+    dx = box / n
+    mesh = pm.hex_block(n, n, n, (box, box, box), renumber_seed=5)
+    tol = dict(p_tol=1e-12, p_rel_tol=0.0, p_final_tol=1e-12, u_tol=1e-12)
+    ras = dict(turbulence_model=3, nut_initial=3e-5, k_initial=2e-4, eps_initial=1.2e-4, k_tol=1e-13, eps_tol=1e-13, ras_cmu=0.085, ras_c1=1.4, ras_c2=1.9, ras_c3=-0.33,
+               ras_sigmak=1.1, ras_sigmaeps=1.25, k_convection_scheme=1, eps_convection_scheme=1, k_relax=0.8, eps_relax=0.7)
+    u_val = [(0, 0, 0)] * 6
+    u_val[3] = (0.3, 0, 0.1)
+    fkw = dict(k_bc=[0, 0, 0, 1, 0, 0], k_value=[0, 0, 0, 5e-4, 0, 0], eps_bc=[0, 0, 1, 1, 0, 0], eps_value=[0, 0, 2e-4, 3e-4, 0, 0], nut_bc=[3, 0, 3, 3, 0, 1], nut_value=[3e-5, 0, 3e-5, 6e-5, 0, 2e-5])
+    gkw = dict(k_bc=fkw["k_bc"], k_val=fkw["k_value"], eps_bc=fkw["eps_bc"], eps_val=fkw["eps_value"], nut_bc=fkw["nut_bc"], nut_val=fkw["nut_value"])
+    f = orc.FvSolver(orc.fv_case(1, n, n, n, dx, 2e-4, 1e-5, g=(0, 0, -9.81), u_val=u_val, p_bc=[2] * 6, p_solver=0, n_outer=2, n_corr=2, p_final_rel_tol=0.0, p_max_iter=5000, **ras, **fkw, **tol))
+    g = orc.LduSolver(mesh, 2e-4, 1e-5, [0] * 6, u_val, [2] * 6, solver=1, g=(0, 0, -9.81), n_outer=2, n_correctors=2, **ras, **gkw, **tol)
+    rs = np.random.RandomState(17)
+    perm = mesh["perm"]
+    for step in range(3):
+        rec = np.zeros((1000, 10))
+        rec[:, 0:3] = rs.random_sample((1000, 3)) * np.array([box, box, 0.6 * box]) + np.array([0.0, 0.0, 0.05 * box])
+        rec[:, 3:6] = 0.05 * rs.standard_normal((1000, 3)); rec[:, 9] = 0.2 * dx
+        cap = {}
+        f.step(rec, capture=cap)
+        to_g = lambda a, nc: (lambda o: (o.__setitem__(perm, a.reshape(n ** 3, nc)), o)[1])(np.zeros((n ** 3, nc)))
+        g.step(source=to_g(cap["uSource"], 3), alpha=to_g(cap["alpha"], 1), drag=to_g(cap["uSourceDrag"], 1))
+        for nm in ("epsilon", "k", "nut"):
+            a, b = f.get(nm), pm.to_lattice(mesh, g.get(nm))
+            assert np.abs(b - a).max() < 1e-8 * a.max(), (nm, step)
+        Uf, Ug = f.get("U").reshape(-1, 3), pm.to_lattice(mesh, g.get("U").reshape(-1, 3))
+        assert np.abs(Ug - Uf).max() < 1e-8 * np.abs(Uf).max(), step
+    assert not np.allclose(f.get("k"), 2e-4, rtol=1e-3) and not np.allclose(f.get("epsilon"), 1.2e-4, rtol=1e-3)
+    f.close(); g.close()
+
+
 def test_tetrahedra_geometry_and_a_cavity_on_them(oracle):
     """Kuhn tetrahedra (triangular faces only, four-faced cells, non-orthogonality around 50 degrees): closed cells, volumes adding up to the box's with every
     tetrahedron a sixth of its hexahedron, centres = the vertex means; the lid-driven cavity runs on them and conserves mass to rounding with two non-orthogonal passes"""

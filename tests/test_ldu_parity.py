@@ -476,7 +476,7 @@ def test_taylor_green_vortices_in_a_periodic_box_on_the_hip_solver(product):
     s.close()
 
 
-@pytest.mark.parametrize("variant", ["plain", "upwind_relaxed_calculated"])
+@pytest.mark.parametrize("variant", ["plain", "upwind_relaxed_calculated", "kEpsilon"])
 def test_les_kEqn_on_a_lattice_equals_the_structured_hip_solver(product, variant):
     """LESModel kEqn through both HIP solvers on the same block with the same cloud's fields (the general side is given the structured coupling's alpha / drag / source):
     k, nut and U after three steps"""
@@ -492,6 +492,9 @@ def test_les_kEqn_on_a_lattice_equals_the_structured_hip_solver(product, variant
         les.update(k_convection_scheme=1, k_relax=0.8)
         fkw = dict(k_bc=[0, 0, 0, 1, 0, 0], k_value=[0, 0, 0, 5e-4, 0, 0], nut_bc=[3, 0, 3, 3, 0, 1], nut_value=[3e-5, 0, 3e-5, 6e-5, 0, 2e-5])
         gkw = dict(k_bc=[0, 0, 0, 1, 0, 0], k_val=[0, 0, 0, 5e-4, 0, 0], nut_bc=[3, 0, 3, 3, 0, 1], nut_val=[3e-5, 0, 3e-5, 6e-5, 0, 2e-5])
+    if variant == "kEpsilon":                            # RAS kEpsilon without wall functions: epsilon, then k, nut = Cmu k^2 / epsilon
+        les.update(turbulence_model=3, eps_initial=1.2e-4, eps_tol=1e-13, ras_cmu=0.085, ras_c1=1.4, ras_c2=1.9, ras_c3=-0.33, ras_sigmak=1.1, ras_sigmaeps=1.25, eps_convection_scheme=1, eps_relax=0.7)
+        fkw.update(eps_bc=[0, 0, 1, 1, 0, 0], eps_value=[0, 0, 2e-4, 3e-4, 0, 0]); gkw.update(eps_bc=[0, 0, 1, 1, 0, 0], eps_val=[0, 0, 2e-4, 3e-4, 0, 0])
     case = product.make_case(1, n, n, n, dx, 2e-4, 1e-5, g=(0, 0, -9.81), u_val=u_val, p_bc=[2] * 6, p_solver=0, n_outer_correctors=2, n_correctors=2, p_max_iter=5000, **les, **fkw, **kw)
     f = product.Solver(case)
     g = product.LduSolver(mesh, 2e-4, 1e-5, [0] * 6, u_val, [2] * 6, solver=1, g=(0, 0, -9.81), n_outer_correctors=2, n_correctors=2, p_max_iter=5000, **les, **gkw, **kw)
@@ -502,6 +505,8 @@ def test_les_kEqn_on_a_lattice_equals_the_structured_hip_solver(product, variant
         f.step()
         g.set("alpha", f.get("alpha")); g.set("uSourceDrag", f.get("uSourceDrag")); g.set("uSource", f.get("uSource"))
         g.step()
+        if variant == "kEpsilon":
+            close(g.get("epsilon"), f.get("epsilon"), 1e-6, "epsilon step %d" % step)
         close(g.get("k"), f.get("k"), 1e-6, "k step %d" % step)
         close(g.get("nut"), f.get("nut"), 1e-6, "nut step %d" % step)
         close(g.get("U").reshape(-1, 3), f.get("U").reshape(-1, 3), 1e-6, "U step %d" % step)
@@ -535,6 +540,36 @@ def test_les_kEqn_on_a_wavy_mesh_matches_the_restatement(product, oracle):
     ph, po = h.get("p"), o.get("p")
     close(ph - ph.mean(), po - po.mean(), 1e-5, "p")
     assert not np.allclose(h.get("k"), 2e-4, rtol=1e-3) and h.get("k").min() > 0
+    h.close(); o.close()
+
+
+def test_ras_kEpsilon_on_a_wavy_mesh_matches_the_restatement(product, oracle):
+    """RAS kEpsilon without wall functions on skewed cells with a cloud: the epsilon equation, then k with the new epsilon, nut = Cmu k^2 / epsilon; fixed-value patches of
+    both, `calculated` nut patches, upwind convection, relaxation -- epsilon, k, nut, U, p against the restatement"""
+    n, box = 10, 0.1
+    dx = box / n
+    mesh = pm.hex_block(n, n, n, (box, box, box), pm.wavy(0.2 * dx, (box, box, box)), renumber_seed=8)
+    kw = dict(p_tol=1e-10, p_rel_tol=0.0, p_final_tol=1e-10, u_tol=1e-10, p_max_iter=5000)
+    ras = dict(turbulence_model=3, nut_initial=2e-5, k_initial=2e-4, eps_initial=1.2e-4, k_tol=1e-12, eps_tol=1e-12, ras_cmu=0.085, ras_c1=1.4, ras_c2=1.9, ras_c3=-0.33,
+               ras_sigmak=1.1, ras_sigmaeps=1.25, k_convection_scheme=1, eps_convection_scheme=1, k_relax=0.9, eps_relax=0.8)
+    pat = dict(k_bc=[0, 0, 0, 1, 0, 0], k_val=[0, 0, 0, 5e-4, 0, 0], eps_bc=[0, 0, 1, 1, 0, 0], eps_val=[0, 0, 2e-4, 3e-4, 0, 0], nut_bc=[3, 0, 3, 3, 0, 1], nut_val=[2e-5, 0, 2e-5, 4e-5, 0, 1e-5])
+    rel = dict(u_relax=0.8, u_relax_final=1.0, p_relax=0.7, p_relax_final=1.0)
+    lidv = [(0, 0, 0)] * 6
+    lidv[3] = (0.3, 0, 0.1)
+    h = product.LduSolver(mesh, 2e-4, 1e-5, [0] * 6, lidv, [2] * 6, solver=1, g=(0, 0, -9.81), n_non_orth=1, n_outer_correctors=2, n_correctors=2, **ras, **pat, **rel, **kw)
+    o = oracle.LduSolver(mesh, 2e-4, 1e-5, [0] * 6, lidv, [2] * 6, solver=1, g=(0, 0, -9.81), n_non_orth=1, n_outer=2, n_correctors=2, **ras, **pat, **rel, **kw)
+    h.hold_sources(True)
+    rs = np.random.RandomState(23)
+    for step in range(3):
+        h.set_particles(bed_particles(rs, 1500, box, dx))
+        h.step()
+        o.step(source=h.get("uSourceCoupling"), alpha=h.get("alpha"), drag=h.get("uSourceDrag"))
+        for nm in ("epsilon", "k", "nut"):
+            close(h.get(nm), o.get(nm), 1e-6, "%s step %d" % (nm, step))
+        close(h.get("U"), o.get("U"), 2e-6, "U step %d" % step)
+    ph, po = h.get("p"), o.get("p")
+    close(ph - ph.mean(), po - po.mean(), 1e-5, "p")
+    assert not np.allclose(h.get("epsilon"), 1.2e-4, rtol=1e-3) and h.get("epsilon").min() > 0
     h.close(); o.close()
 
 
@@ -587,7 +622,7 @@ def test_malformed_meshes_and_cases_are_refused_by_name(product):
         (base, dict(p_ref_cell=64), "pRefCell"),
         (base, dict(p_solver=7), "p_solver"),
         (base, dict(solver=3), "solver"),
-        (base, dict(turbulence_model=product.TURBULENCE_KEPSILON, solver=1), "turbulence"),
+        (base, dict(turbulence_model=7, solver=1), "turbulence"),
         (base, dict(convection_scheme=9), "convection"),
     ]
     for mesh, kw, needle in cases:

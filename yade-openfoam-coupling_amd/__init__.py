@@ -91,7 +91,10 @@ class LduCase(C.Structure):
                 ("p_relax", C.c_double), ("p_relax_final", C.c_double), ("adjust_time_step", C.c_int32), ("max_co", C.c_double), ("max_delta_t", C.c_double),
                 ("turbulence_model", C.c_int32), ("les_ck", C.c_double), ("les_ce", C.c_double), ("les_delta_coeff", C.c_double), ("nut_initial", C.c_double), ("nut_bc", _ip),
                 ("nut_value", _dp), ("convection_scheme", C.c_int32), ("convection_limiter_k", C.c_double), ("k_initial", C.c_double), ("k_bc", _ip), ("k_value", _dp),
-                ("k_convection_scheme", C.c_int32), ("k_tol", C.c_double), ("k_rel_tol", C.c_double), ("k_max_iter", C.c_int32), ("k_relax", C.c_double)]
+                ("k_convection_scheme", C.c_int32), ("k_tol", C.c_double), ("k_rel_tol", C.c_double), ("k_max_iter", C.c_int32), ("k_relax", C.c_double),
+                ("ras_cmu", C.c_double), ("ras_c1", C.c_double), ("ras_c2", C.c_double), ("ras_c3", C.c_double), ("ras_sigmak", C.c_double), ("ras_sigmaeps", C.c_double),
+                ("eps_initial", C.c_double), ("eps_bc", _ip), ("eps_value", _dp), ("eps_convection_scheme", C.c_int32), ("eps_tol", C.c_double), ("eps_rel_tol", C.c_double),
+                ("eps_max_iter", C.c_int32), ("eps_relax", C.c_double)]
 
 
 class ParticleTimings(C.Structure):
@@ -1062,7 +1065,7 @@ class LduSolver:
         L.fy_ldu_solver_read_field_host.argtypes = [C.c_void_p, C.c_char_p, _dp]
         L.fy_ldu_solver_write_field_host.argtypes = [C.c_void_p, C.c_char_p, _dp]
 
-    def __init__(self, mesh, dt, nu, u_bc, u_val, p_bc, p_val=None, device=0, transport=None, nut_bc=None, nut_val=None, k_bc=None, k_val=None, **controls):
+    def __init__(self, mesh, dt, nu, u_bc, u_val, p_bc, p_val=None, device=0, transport=None, nut_bc=None, nut_val=None, k_bc=None, k_val=None, eps_bc=None, eps_val=None, **controls):
         L = lib()
         self._bind()
         npatch = len(mesh["patch_start"])
@@ -1094,6 +1097,9 @@ class LduSolver:
         if k_bc is not None:
             k["kb"], k["kv"] = i32(k_bc), np.ascontiguousarray(k_val if k_val is not None else np.zeros(npatch), np.float64)
             self.case.k_bc, self.case.k_value = _i(k["kb"]), _d(k["kv"])
+        if eps_bc is not None:
+            k["eb"], k["ev"] = i32(eps_bc), np.ascontiguousarray(eps_val if eps_val is not None else np.zeros(npatch), np.float64)
+            self.case.eps_bc, self.case.eps_value = _i(k["eb"]), _d(k["ev"])
         self._create(device, transport)
 
     def _create(self, device, transport):
@@ -1117,8 +1123,10 @@ class LduSolver:
         self.set("U", U); self.set("p", p)
         if fc.ldu_case.turbulence_model != 0:
             self.set("nut", fc.initial_nut())
-        if fc.ldu_case.turbulence_model == TURBULENCE_KEQN:
+        if fc.ldu_case.turbulence_model in (TURBULENCE_KEQN, TURBULENCE_KEPSILON):
             self.set("k", fc.initial_k())
+        if fc.ldu_case.turbulence_model == TURBULENCE_KEPSILON:
+            self.set("epsilon", fc.initial_epsilon())
         return self
 
     def _size(self, name):

@@ -61,6 +61,7 @@ struct fy_foam_case {
     std::vector<int32_t> g_face_off, g_face_pts, g_own, g_nei, g_patch_start, g_patch_size, g_u_bc, g_p_bc;
     std::vector<std::string> g_patch_name, g_u_text, g_p_text, g_nut_text, g_k_text;
     std::vector<int32_t> g_k_bc; std::vector<double> g_k_val;
+    std::vector<std::string> g_eps_text; std::vector<int32_t> g_eps_bc; std::vector<double> g_eps_val;
     std::vector<int32_t> g_patch_neighbour;      // per patch: its cyclic partner, or -1
     std::vector<std::string> g_patch_class;      // the boundary file's `type` per patch (wall | patch | symmetryPlane | symmetry)
     std::vector<double> g_u_val, g_p_val, g_nut_val;
@@ -813,7 +814,7 @@ int read_general_fields(fy_foam_case* c) {
             if (!pd || !pd->word("type", &ty)) return fail(FY_ERR_INVALID, "%s: boundaryField has no (typed) entry for patch '%s'", path.c_str(), pn);
             c->g_nut_text[pa] = entry_text(*pd);
             const auto* vt = pd->tokens("value");
-            if (ty == "calculated" && c->desc.turbulence_model == FY_TURBULENCE_KEQN) {      // the file's value until the first correctNut(), the model's expression afterwards
+            if (ty == "calculated" && (c->desc.turbulence_model == FY_TURBULENCE_KEQN || c->desc.turbulence_model == FY_TURBULENCE_KEPSILON)) {      // the file's value until the first correctNut(), the model's expression afterwards
                 c->g_nut_bc[pa] = FY_BC_NUT_CALCULATED;
                 if (vt && vt->size() >= 2 && (*vt)[0] == "uniform") fy::foam_tok_is_number((*vt)[1], &c->g_nut_val[pa]);
             } else if (ty == "fixedValue" || ty == "calculated") {
@@ -823,7 +824,31 @@ int read_general_fields(fy_foam_case* c) {
             } else if (ty != "zeroGradient" && ty != "symmetryPlane" && ty != "symmetry" && ty != "cyclic") return fail(FY_ERR_UNSUPPORTED, "%s: patch '%s': nut boundary type '%s' is not supported on a general mesh (zeroGradient, symmetryPlane, symmetry, cyclic, fixedValue, calculated)", path.c_str(), pn, ty.c_str());
         }
     }
-    if (c->desc.turbulence_model == FY_TURBULENCE_KEQN) {         // k.<phase> [OF-6 kEqn: k_ is MUST_READ]; patches zeroGradient | fixedValue (uniform); kqRWallFunction is a zeroGradient condition
+    if (c->desc.turbulence_model == FY_TURBULENCE_KEPSILON) {     // epsilon.<phase> [OF-6 kEpsilon: epsilon_ is MUST_READ]; zeroGradient | fixedValue (uniform); no epsilonWallFunction on a general mesh
+        const std::string path = join(c->fdir, c->start_name + "/epsilon." + c->phase);
+        FoamDict f;
+        FY_TRY(need_file(path, &f));
+        FY_TRY(read_internal(f, path, 1, ncell, &c->eps0));
+        c->desc.eps_initial = c->eps0.empty() ? 0.0 : c->eps0[0];
+        const FoamDict* bf = f.subdict("boundaryField");
+        if (!bf) return fail(FY_ERR_INVALID, "%s: no boundaryField", path.c_str());
+        c->g_eps_bc.assign(np, FY_BC_NUT_ZERO_GRADIENT); c->g_eps_val.assign(np, 0.0); c->g_eps_text.assign(np, std::string());
+        for (size_t pa = 0; pa < np; ++pa) {
+            const char* pn = c->g_patch_name[pa].c_str();
+            const FoamDict* pd = bf->subdict(c->g_patch_name[pa]);
+            std::string ty;
+            if (!pd || !pd->word("type", &ty)) return fail(FY_ERR_INVALID, "%s: boundaryField has no (typed) entry for patch '%s'", path.c_str(), pn);
+            c->g_eps_text[pa] = entry_text(*pd);
+            const auto* vt = pd->tokens("value");
+            if (ty == "fixedValue") {
+                c->g_eps_bc[pa] = FY_BC_NUT_FIXED_VALUE;
+                if (!vt || vt->size() < 2 || (*vt)[0] != "uniform" || !fy::foam_tok_is_number((*vt)[1], &c->g_eps_val[pa]))
+                    return fail(FY_ERR_UNSUPPORTED, "%s: patch '%s': fixedValue needs 'value uniform <epsilon>'", path.c_str(), pn);
+            } else if (ty != "zeroGradient" && ty != "symmetryPlane" && ty != "symmetry" && ty != "cyclic")
+                return fail(FY_ERR_UNSUPPORTED, "%s: patch '%s': epsilon boundary type '%s' is not supported on a general mesh (zeroGradient, symmetryPlane, symmetry, cyclic, fixedValue; the wall functions need the block solver)", path.c_str(), pn, ty.c_str());
+        }
+    }
+    if (c->desc.turbulence_model == FY_TURBULENCE_KEQN || c->desc.turbulence_model == FY_TURBULENCE_KEPSILON) {         // k.<phase> [OF-6: k_ is MUST_READ]; patches zeroGradient | fixedValue (uniform); kqRWallFunction is a zeroGradient condition
         const std::string path = join(c->fdir, c->start_name + "/k." + c->phase);
         FoamDict f;
         FY_TRY(need_file(path, &f));
@@ -856,8 +881,6 @@ int check_general_schemes(const fy_foam_case* c) {
     const std::string path = join(c->dir, "system/fvSchemes");
     FoamDict d;
     FY_TRY(need_file(path, &d));
-    if (c->desc.turbulence_model != FY_TURBULENCE_LAMINAR && c->desc.turbulence_model != FY_TURBULENCE_SMAGORINSKY && c->desc.turbulence_model != FY_TURBULENCE_KEQN)
-        return fail(FY_ERR_UNSUPPORTED, "%s: on a general mesh the laminar (Stokes) model and LES Smagorinsky / kEqn are carried, not kEpsilon (constant/turbulenceProperties)", c->dir.c_str());
     for (const char* dn : {"laplacianSchemes", "snGradSchemes"}) {
         const FoamDict* sd = d.subdict(dn);
         for (const std::string& k : sd->order) {
@@ -1178,7 +1201,7 @@ int write_field(const fy_foam_case* c, const std::string& tdir, const std::strin
     }
     std::fprintf(f, ")\n;\n\nboundaryField\n{\n");
     if (c->general) {
-        const std::vector<std::string>& tx = bc_text == c->u_bc_text ? c->g_u_text : (bc_text == c->nut_bc_text ? c->g_nut_text : (bc_text == c->k_bc_text ? c->g_k_text : c->g_p_text));
+        const std::vector<std::string>& tx = bc_text == c->u_bc_text ? c->g_u_text : (bc_text == c->nut_bc_text ? c->g_nut_text : (bc_text == c->k_bc_text ? c->g_k_text : (bc_text == c->eps_bc_text ? c->g_eps_text : c->g_p_text)));
         for (size_t pa = 0; pa < c->g_patch_name.size(); ++pa) std::fprintf(f, "    %s\n    {\n%s    }\n", c->g_patch_name[pa].c_str(), (!bc_text || tx[pa].empty()) ? default_bc : tx[pa].c_str());
     }
     for (const std::string& pn : c->general ? std::vector<std::string>() : c->patch_order) {
@@ -1415,6 +1438,9 @@ int fy_foam_case_ldu_desc(const fy_foam_case* c, fy_ldu_case* out) {
     out->convection_scheme = d.convection_scheme; out->convection_limiter_k = d.convection_limiter_k;
     out->k_initial = d.k_initial; out->k_bc = c->g_k_bc.empty() ? nullptr : c->g_k_bc.data(); out->k_value = c->g_k_val.empty() ? nullptr : c->g_k_val.data();
     out->k_convection_scheme = d.k_convection_scheme; out->k_tol = d.k_tol; out->k_rel_tol = d.k_rel_tol; out->k_max_iter = d.k_max_iter; out->k_relax = d.k_relax;
+    out->ras_cmu = d.ras_cmu; out->ras_c1 = d.ras_c1; out->ras_c2 = d.ras_c2; out->ras_c3 = d.ras_c3; out->ras_sigmak = d.ras_sigmak; out->ras_sigmaeps = d.ras_sigmaeps;
+    out->eps_initial = d.eps_initial; out->eps_bc = c->g_eps_bc.empty() ? nullptr : c->g_eps_bc.data(); out->eps_value = c->g_eps_val.empty() ? nullptr : c->g_eps_val.data();
+    out->eps_convection_scheme = d.eps_convection_scheme; out->eps_tol = d.eps_tol; out->eps_rel_tol = d.eps_rel_tol; out->eps_max_iter = d.eps_max_iter; out->eps_relax = d.eps_relax;
     out->u_bc = c->g_u_bc.data(); out->u_value = c->g_u_val.data(); out->p_bc = c->g_p_bc.data(); out->p_value = c->g_p_val.data();
     return FY_OK;
 }
@@ -1440,8 +1466,10 @@ int fy_foam_case_write_time_ldu(const fy_foam_case* c, fy_ldu_solver* s, const c
     if (c->solver == FY_SOLVER_PIMPLE) { a.resize(c->fcells); FY_TRY(fy_ldu_solver_read_field_host(s, "alpha", a.data())); }       // (with fy_ldu_solver_hold_sources: before setSourceZero)
     if (c->desc.turbulence_model != FY_TURBULENCE_LAMINAR) { nt.resize(c->fcells); FY_TRY(fy_ldu_solver_read_field_host(s, "nut", nt.data())); }
     std::vector<double> kt;
-    if (c->desc.turbulence_model == FY_TURBULENCE_KEQN) { kt.resize(c->fcells); FY_TRY(fy_ldu_solver_read_field_host(s, "k", kt.data())); }
-    return fy_foam_case_write_fields(c, time_name, U.data(), p.data(), a.empty() ? nullptr : a.data(), nt.empty() ? nullptr : nt.data(), kt.empty() ? nullptr : kt.data(), nullptr);
+    std::vector<double> et;
+    if (c->desc.turbulence_model == FY_TURBULENCE_KEQN || c->desc.turbulence_model == FY_TURBULENCE_KEPSILON) { kt.resize(c->fcells); FY_TRY(fy_ldu_solver_read_field_host(s, "k", kt.data())); }
+    if (c->desc.turbulence_model == FY_TURBULENCE_KEPSILON) { et.resize(c->fcells); FY_TRY(fy_ldu_solver_read_field_host(s, "epsilon", et.data())); }
+    return fy_foam_case_write_fields(c, time_name, U.data(), p.data(), a.empty() ? nullptr : a.data(), nt.empty() ? nullptr : nt.data(), kt.empty() ? nullptr : kt.data(), et.empty() ? nullptr : et.data());
 }
 
 int fy_foam_case_close(fy_foam_case* c) {

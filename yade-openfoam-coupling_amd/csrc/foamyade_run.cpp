@@ -53,8 +53,10 @@ static int run_general(fy_foam_case* fc, const fy_transport* trp, int device) {
         if (fy_ldu_solver_write_field_host(s, "p", p.data()) != FY_OK || fy_ldu_solver_write_field_host(s, "U", U.data()) != FY_OK) return die("initial fields");
         if (lc.turbulence_model != FY_TURBULENCE_LAMINAR)                 // nut.<phase> of the start time (eddyViscosity: MUST_READ)
             if (fy_foam_case_initial_nut(fc, p.data()) != FY_OK || fy_ldu_solver_write_field_host(s, "nut", p.data()) != FY_OK) return die("initial nut");
-        if (lc.turbulence_model == FY_TURBULENCE_KEQN)
+        if (lc.turbulence_model == FY_TURBULENCE_KEQN || lc.turbulence_model == FY_TURBULENCE_KEPSILON)
             if (fy_foam_case_initial_k(fc, p.data()) != FY_OK || fy_ldu_solver_write_field_host(s, "k", p.data()) != FY_OK) return die("initial k");
+        if (lc.turbulence_model == FY_TURBULENCE_KEPSILON)
+            if (fy_foam_case_initial_epsilon(fc, p.data()) != FY_OK || fy_ldu_solver_write_field_host(s, "epsilon", p.data()) != FY_OK) return die("initial epsilon");
     }
     std::printf("\nStarting time loop\n\n");
     const long n_steps = std::lround((info.end_time - info.start_time) / info.delta_t);

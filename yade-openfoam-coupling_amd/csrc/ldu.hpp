@@ -74,8 +74,22 @@ struct LduPim {
     const double* k_val;
     int nut_live;
     double ck, delta_coeff;
+    // RAS kEpsilon: epsilon per cell (null: another model) and its patch conditions; a calculated nut patch then carries Cmu k_b^2 / eps_b
+    const double* eps;
+    const int32_t* eps_bc;
+    const double* eps_val;
+    double cmu;
 };
-struct LduKEqn { double ce, relax; int upwind; };
+// one transport equation of a closure (fv_kernels.hip's modes): 0 kEqn's k, 1 kEpsilon's epsilon, 2 kEpsilon's k; X the transported field with its patches
+struct LduKEqn {
+    int mode;
+    double ce, relax;
+    int upwind;
+    double sigma, c1, c2, c3;
+    const double* X;
+    const int32_t* x_bc;
+    const double* x_val;
+};
 
 int ldu_red_blocks(int n);      // partials per slot of the reducing kernels (= red_blocks(n) of fv_kernels.hpp: the folds are shared)
 
@@ -107,9 +121,9 @@ int launch_ldu_assemble_momentum_pimple(hipStream_t s, LduGeo g, LduPim P, const
                                         double* fstress /* [3 nF] */, double u_relax, double* rAU);
 int launch_ldu_smagorinsky_nut(hipStream_t s, LduGeo g, const double* vGrad, double ck, double ce, double delta_coeff, double* nut);
 // LES kEqn: the k equation's matrix into M (face part, then cells: diag, b[3 c] = the source, b[3 c + 1 .. 2] = 0), x3 = (k, 0, 0); after the solve bound() and nut
-int launch_ldu_grad_k(hipStream_t s, LduGeo g, LduPim P, double* gk);
+int launch_ldu_grad_k(hipStream_t s, LduGeo g, LduPim P, LduKEqn K, double* gk);
 int launch_ldu_k_assemble(hipStream_t s, LduGeo g, LduPim P, LduKEqn K, const double* phi, const double* vGrad, const double* gk, LduMom M, double* face_corr, double* x3);
-int launch_ldu_k_bound_nut(hipStream_t s, LduGeo g, LduPim P, const double* x3, double* k, double* nut);
+int launch_ldu_k_bound_nut(hipStream_t s, LduGeo g, LduPim P, LduKEqn K, const double* x3, double* X, double* nut);
 int launch_ldu_forces(hipStream_t s, LduGeo g, LduPim P, const double* rAU, double* rAUf, double* phiForces);
 int launch_ldu_ssf_predictor(hipStream_t s, LduGeo g, const double* phiForces, const double* rAUf, const double* p, const double* gradp, double* ssf);
 int launch_ldu_reconstruct(hipStream_t s, LduGeo g, const double* ssf, const double* base, const double* scale, double* out);

@@ -529,7 +529,11 @@ __device__ __forceinline__ double ldu_nut_b(const LduGeo& g, const LduPim& P, in
     const int pa = g.patch_of[f - g.nInt], c = g.own[f];
     const int t = P.nut_bc[pa];
     if (t == FY_BC_NUT_FIXED_VALUE || (t == FY_BC_NUT_CALCULATED && !(P.k && P.nut_live))) return P.nut_val[pa];
-    // calculated [OF-6 GeometricField::operator=: nut_ = Ck sqrt(k_) delta assigns the patches too]
+    // calculated [OF-6 GeometricField::operator=: nut_ = Ck sqrt(k_) delta | Cmu sqr(k_) / epsilon_ assigns the patches too]
+    if (t == FY_BC_NUT_CALCULATED && P.eps) {
+        const double kb = ldu_k_b(g, P, P.k, f), eb = P.eps_bc[pa] == FY_BC_NUT_FIXED_VALUE ? P.eps_val[pa] : P.eps[c];
+        return P.cmu * (kb * kb) / eb;
+    }
     if (t == FY_BC_NUT_CALCULATED) return P.ck * sqrt(ldu_k_b(g, P, P.k, f)) * (P.delta_coeff * cbrt(g.V[c]));
     return P.nut[c];
 }
@@ -651,15 +655,19 @@ __global__ __launch_bounds__(256) void k_ldu_smagorinsky_nut(LduGeo g, const dou
 //   fvm::ddt(alpha, k) + fvm::div(alphaPhi, k) - fvm::laplacian(alpha DkEff, k) == alpha G - fvm::SuSp(2/3 alpha divU, k) - fvm::Sp(Ce alpha sqrt(k) / delta, k)
 //   DkEff = nut + nu; G = nut (gradU && dev(twoSymm(gradU))); divU = fvc::div(phi); Gauss linear corrected laplacian: its explicit part (alpha DkEff)_f |Sf| (k & interpolate(grad k))
 // The matrix goes into the momentum matrix's arrays (free once the correctors are done) and is solved as component 0 of a three-component system by the momentum passes
-__global__ __launch_bounds__(256) void k_ldu_grad_k(LduGeo g, LduPim P, double* __restrict__ gk) {
+__device__ __forceinline__ double ldu_x_b(const LduGeo& g, const LduKEqn& K, const double* __restrict__ x, int f) {
+    const int pa = g.patch_of[f - g.nInt];
+    return K.x_bc[pa] == FY_BC_NUT_FIXED_VALUE ? K.x_val[pa] : x[g.own[f]];
+}
+__global__ __launch_bounds__(256) void k_ldu_grad_k(LduGeo g, LduPim P, LduKEqn K, double* __restrict__ gk) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= g.nCells) return;
-    const double kc = P.k[c];
+    const double kc = K.X[c];
     D3 a{0, 0, 0};
     FY_CELL_FACES(g, c, f, nb) {
         double kf, sg = 1.0;
-        if (f < g.nInt) { const bool o = nb > c; const double kn = P.k[nb]; kf = o ? g.w[f] * kc + (1.0 - g.w[f]) * kn : g.w[f] * kn + (1.0 - g.w[f]) * kc; sg = o ? 1.0 : -1.0; }
-        else kf = ldu_k_b(g, P, P.k, f);
+        if (f < g.nInt) { const bool o = nb > c; const double kn = K.X[nb]; kf = o ? g.w[f] * kc + (1.0 - g.w[f]) * kn : g.w[f] * kn + (1.0 - g.w[f]) * kc; sg = o ? 1.0 : -1.0; }
+        else kf = ldu_x_b(g, K, K.X, f);
         const D3 S = ld3(g.Sf, f);
         a.x += sg * S.x * kf; a.y += sg * S.y * kf; a.z += sg * S.z * kf;
     }
@@ -671,7 +679,7 @@ __global__ __launch_bounds__(256) void k_ldu_k_faces(LduGeo g, LduPim P, LduKEqn
     if (f >= g.nInt) return;
     const int o = g.own[f], n = g.nei[f];
     const double w = g.w[f], fl = P.alphaf[f] * phi[f];
-    const double gam = (w * (P.alpha[o] * (g.nu + P.nut[o])) + (1.0 - w) * (P.alpha[n] * (g.nu + P.nut[n]))) * g.magSf[f];
+    const double gam = (w * (P.alpha[o] * (g.nu + P.nut[o] / K.sigma)) + (1.0 - w) * (P.alpha[n] * (g.nu + P.nut[n] / K.sigma))) * g.magSf[f];
     const double wc = K.upwind ? (fl >= 0.0 ? 1.0 : 0.0) : w;
     double lo = -wc * fl, up = lo + fl;
     lo -= gam * g.dcNO[f]; up -= gam * g.dcNO[f];
@@ -683,7 +691,7 @@ __global__ __launch_bounds__(256) void k_ldu_k_cells(LduGeo g, LduPim P, LduKEqn
                                                      const double* __restrict__ corr, double* __restrict__ x3) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= g.nCells) return;
-    const double Vc = g.V[c], ac = P.alpha[c], xc = P.k[c];
+    const double Vc = g.V[c], ac = P.alpha[c], xc = K.X[c];
     double dg = ac * Vc / g.dt, b = ac * Vc / g.dt * xc, sumPhi = 0.0, offsum = 0.0;
     FY_CELL_FACES(g, c, f, nb) {
         if (f < g.nInt) {
@@ -693,9 +701,9 @@ __global__ __launch_bounds__(256) void k_ldu_k_cells(LduGeo g, LduPim P, LduKEqn
             const int pa = g.patch_of[f - g.nInt];
             const double fl = P.alphaf[f] * phi[f];
             sumPhi += phi[f];
-            if (P.k_bc[pa] == FY_BC_NUT_FIXED_VALUE) {
-                const double gb = (g.nu + ldu_nut_b(g, P, f)) * g.magSf[f] * g.dcNO[f];
-                dg += gb; b += (-fl + gb) * P.k_val[pa];
+            if (K.x_bc[pa] == FY_BC_NUT_FIXED_VALUE) {
+                const double gb = (g.nu + ldu_nut_b(g, P, f) / K.sigma) * g.magSf[f] * g.dcNO[f];
+                dg += gb; b += (-fl + gb) * K.x_val[pa];
             } else dg += fl;
         }
     }
@@ -707,9 +715,14 @@ __global__ __launch_bounds__(256) void k_ldu_k_cells(LduGeo g, LduPim P, LduKEqn
 #pragma unroll
         for (int q = 0; q < 3; ++q) GG += T[3 * a + q] * ((T[3 * a + q] + T[3 * q + a]) - (a == q ? (1.0 / 3.0) * tr2 : 0.0));
     const double G = P.nut[c] * GG, divU = sumPhi / Vc;
-    const double c1 = (2.0 / 3.0) * ac * divU, c2 = K.ce * ac * sqrt(xc) / (P.delta_coeff * cbrt(Vc));
+    // mode 0 (kEqn's k): Su = alpha G, c1 = 2/3 alpha divU, c2 = Ce alpha sqrt(k) / delta; mode 1 (epsilon): Su = C1 alpha G eps / k, c1 = (2/3 C1 - C3) alpha divU, c2 = C2 alpha eps / k;
+    // mode 2 (kEpsilon's k): Su = alpha G, c1 = 2/3 alpha divU, c2 = alpha eps / k
+    double Su, c1, c2;
+    if (K.mode == 0) { Su = ac * G; c1 = (2.0 / 3.0) * ac * divU; c2 = K.ce * ac * sqrt(xc) / (P.delta_coeff * cbrt(Vc)); }
+    else if (K.mode == 1) { const double kc = P.k[c]; Su = K.c1 * ac * G * xc / kc; c1 = ((2.0 / 3.0) * K.c1 - K.c3) * ac * divU; c2 = K.c2 * ac * xc / kc; }
+    else { Su = ac * G; c1 = (2.0 / 3.0) * ac * divU; c2 = ac * P.eps[c] / xc; }
     dg += Vc * (fmax(c1, 0.0) + c2);                        // fvm::SuSp: the positive part implicit, the negative part on the source; fvm::Sp
-    b += Vc * ac * G - Vc * fmin(c1, 0.0) * xc;
+    b += Vc * Su - Vc * fmin(c1, 0.0) * xc;
     if (K.relax > 0) {                                      // fvMatrix::relax
         const double dn = fmax(fabs(dg), offsum) / K.relax;
         b += (dn - dg) * xc;
@@ -720,7 +733,7 @@ __global__ __launch_bounds__(256) void k_ldu_k_cells(LduGeo g, LduPim P, LduKEqn
     st3(x3, c, D3{xc, 0.0, 0.0});
 }
 // bound(k, kMin) [OF-6 bound.C: k = max(max(k, fvc::average(max(k, kMin)) pos0(-k)), kMin), fvc::average = sum |Sf| k_f / sum |Sf|], then correctNut(): nut = Ck sqrt(k) delta
-__global__ __launch_bounds__(256) void k_ldu_k_bound_nut(LduGeo g, LduPim P, const double* __restrict__ x3, double* __restrict__ k, double* __restrict__ nut) {
+__global__ __launch_bounds__(256) void k_ldu_k_bound_nut(LduGeo g, LduPim P, LduKEqn K, const double* __restrict__ x3, double* __restrict__ X, double* __restrict__ nut) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= g.nCells) return;
     const double kMin = 1e-15, xc = x3[3 * (size_t)c];
@@ -734,15 +747,16 @@ __global__ __launch_bounds__(256) void k_ldu_k_bound_nut(LduGeo g, LduPim P, con
                 xf = nb > c ? g.w[f] * mo + (1.0 - g.w[f]) * mn : g.w[f] * mn + (1.0 - g.w[f]) * mo;
             } else {
                 const int pa = g.patch_of[f - g.nInt];
-                xf = fmax(P.k_bc[pa] == FY_BC_NUT_FIXED_VALUE ? P.k_val[pa] : xc, kMin);
+                xf = fmax(K.x_bc[pa] == FY_BC_NUT_FIXED_VALUE ? K.x_val[pa] : xc, kMin);
             }
             av += g.magSf[f] * xf; asum += g.magSf[f];
         }
         xb = fmax(xc, av / asum);
     }
-    const double kn = fmax(xb, kMin);
-    k[c] = kn;
-    nut[c] = P.ck * sqrt(kn) * (P.delta_coeff * cbrt(g.V[c]));
+    const double xn = fmax(xb, kMin);
+    X[c] = xn;
+    if (K.mode == 0) nut[c] = P.ck * sqrt(xn) * (P.delta_coeff * cbrt(g.V[c]));
+    else if (K.mode == 2) nut[c] = P.cmu * (xn * xn) / P.eps[c];            // correctNut() after the k equation, with the epsilon of this correct()
 }
 
 // rAUcf = interpolate(rAUc) (boundary: the cell's), phicForces = fvc::flux(rAUc uSource) + rAUcf (g & Sf) (UcEqn.H:15-20)
@@ -1008,8 +1022,8 @@ int launch_ldu_assemble_momentum_pimple(hipStream_t s, LduGeo g, LduPim P, const
     FY_LAUNCH_CHECK();
     return FY_OK;
 }
-int launch_ldu_grad_k(hipStream_t s, LduGeo g, LduPim P, double* gk) {
-    hipLaunchKernelGGL(k_ldu_grad_k, dim3(div_up(g.nCells, 256)), dim3(256), 0, s, g, P, gk);
+int launch_ldu_grad_k(hipStream_t s, LduGeo g, LduPim P, LduKEqn K, double* gk) {
+    hipLaunchKernelGGL(k_ldu_grad_k, dim3(div_up(g.nCells, 256)), dim3(256), 0, s, g, P, K, gk);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }
@@ -1019,8 +1033,8 @@ int launch_ldu_k_assemble(hipStream_t s, LduGeo g, LduPim P, LduKEqn K, const do
     FY_LAUNCH_CHECK();
     return FY_OK;
 }
-int launch_ldu_k_bound_nut(hipStream_t s, LduGeo g, LduPim P, const double* x3, double* k, double* nut) {
-    hipLaunchKernelGGL(k_ldu_k_bound_nut, dim3(div_up(g.nCells, 256)), dim3(256), 0, s, g, P, x3, k, nut);
+int launch_ldu_k_bound_nut(hipStream_t s, LduGeo g, LduPim P, LduKEqn K, const double* x3, double* X, double* nut) {
+    hipLaunchKernelGGL(k_ldu_k_bound_nut, dim3(div_up(g.nCells, 256)), dim3(256), 0, s, g, P, K, x3, X, nut);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }

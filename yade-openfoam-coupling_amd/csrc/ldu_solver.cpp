@@ -39,11 +39,13 @@ struct LduSolver {
     bool les = false;
     bool keqn = false, nut_live = false;
     long long k_iters_total = 0;
-    DevBuf<double> kturb, d_kval, gradk;
-    DevBuf<int32_t> d_kbc;
+    bool keps = false;
+    DevBuf<double> kturb, d_kval, gradk, epsturb, d_epsval;
+    DevBuf<int32_t> d_kbc, d_epsbc;
     LduPim P() const {
         return LduPim{alpha.p, alpha.p, alphaf.p, uSourceDrag.p, uSource.p, {cs.g[0], cs.g[1], cs.g[2]}, les ? nut.p : nullptr, d_nutbc.p, d_nutval.p,
-                      keqn ? kturb.p : nullptr, d_kbc.p, d_kval.p, nut_live ? 1 : 0, cs.les_ck, cs.les_delta_coeff};
+                      (keqn || keps) ? kturb.p : nullptr, d_kbc.p, d_kval.p, nut_live ? 1 : 0, cs.les_ck, cs.les_delta_coeff,
+                      keps ? epsturb.p : nullptr, d_epsbc.p, d_epsval.p, cs.ras_cmu};
     }      // alphac.oldTime() == alphac
     DevBuf<int> adj_err;
     bool need_ref = true, ext_source = false, has_slip = false;
@@ -80,8 +82,13 @@ struct LduSolver {
         if (pimple && c->n_outer_correctors < 1) cs.n_outer_correctors = 1;
         if (c->adjust_time_step && !pimple) cs.adjust_time_step = 0;                      // (icoFoamYade's loop never includes setDeltaT.H: icoFoamYade.C:65-70)
         if (cs.adjust_time_step && !(c->max_co > 0 && c->max_delta_t > 0)) return fail(FY_ERR_INVALID, "fy_ldu_solver: adjustTimeStep needs maxCo > 0 and maxDeltaT > 0");
-        if (c->turbulence_model != FY_TURBULENCE_LAMINAR && !(pimple && (c->turbulence_model == FY_TURBULENCE_SMAGORINSKY || c->turbulence_model == FY_TURBULENCE_KEQN)))
-            return fail(FY_ERR_UNSUPPORTED, "fy_ldu_solver: turbulence model %d (laminar; LES Smagorinsky or kEqn with pimpleFoamYade)", c->turbulence_model);
+        if (c->turbulence_model != FY_TURBULENCE_LAMINAR && !(pimple && (c->turbulence_model == FY_TURBULENCE_SMAGORINSKY || c->turbulence_model == FY_TURBULENCE_KEQN || c->turbulence_model == FY_TURBULENCE_KEPSILON)))
+            return fail(FY_ERR_UNSUPPORTED, "fy_ldu_solver: turbulence model %d (laminar; LES Smagorinsky, LES kEqn or RAS kEpsilon with pimpleFoamYade)", c->turbulence_model);
+        keps = pimple && c->turbulence_model == FY_TURBULENCE_KEPSILON;
+        if (keps && !(c->ras_cmu > 0 && c->ras_sigmak > 0 && c->ras_sigmaeps > 0 && c->eps_initial > 0 && c->k_initial > 0 && c->eps_tol >= 0 && c->eps_max_iter >= 0 &&
+                      (c->eps_convection_scheme == FY_CONVECTION_LINEAR || c->eps_convection_scheme == FY_CONVECTION_UPWIND) &&
+                      (c->k_convection_scheme == FY_CONVECTION_LINEAR || c->k_convection_scheme == FY_CONVECTION_UPWIND)))
+            return fail(FY_ERR_INVALID, "fy_ldu_solver: kEpsilon needs Cmu, sigmak, sigmaEps, k and epsilon of the start time positive, and Gauss linear or Gauss upwind for their convection");
         les = pimple && c->turbulence_model != FY_TURBULENCE_LAMINAR;
         keqn = pimple && c->turbulence_model == FY_TURBULENCE_KEQN;
         if (keqn && !(c->k_initial >= 0 && c->k_tol >= 0 && c->k_max_iter >= 0 && (c->k_convection_scheme == FY_CONVECTION_LINEAR || c->k_convection_scheme == FY_CONVECTION_UPWIND)))
@@ -150,14 +157,28 @@ struct LduSolver {
                 for (int pa = 0; pa < hm.nPatches; ++pa) {
                     if (c->nut_bc) nb[(size_t)pa] = c->nut_bc[pa];
                     if (c->nut_value) nv[(size_t)pa] = c->nut_value[pa];
-                    if (nb[(size_t)pa] != FY_BC_NUT_ZERO_GRADIENT && nb[(size_t)pa] != FY_BC_NUT_FIXED_VALUE && !(keqn && nb[(size_t)pa] == FY_BC_NUT_CALCULATED))
-                        return fail(FY_ERR_UNSUPPORTED, "fy_ldu_solver: nut patch type %d (zeroGradient, fixedValue; calculated with kEqn)", nb[(size_t)pa]);
+                    if (nb[(size_t)pa] != FY_BC_NUT_ZERO_GRADIENT && nb[(size_t)pa] != FY_BC_NUT_FIXED_VALUE && !((keqn || keps) && nb[(size_t)pa] == FY_BC_NUT_CALCULATED))
+                        return fail(FY_ERR_UNSUPPORTED, "fy_ldu_solver: nut patch type %d (zeroGradient, fixedValue; calculated with kEqn / kEpsilon; the wall functions need the block solver)", nb[(size_t)pa]);
                 }
                 FY_TRY(up(d_nutbc, nb)); FY_TRY(up(d_nutval, nv));
                 FY_TRY(nut.alloc_exact(n));
                 FY_TRY(launch_fill_f64(stream, nut.p, n, c->nut_initial));
             }
-            if (keqn) {                                                       // k of the start time (kEqn: k_ is MUST_READ), its patches
+            if (keps) {                                                       // epsilon of the start time, its patches (no epsilonWallFunction on a general mesh)
+                std::vector<int32_t> eb((size_t)hm.nPatches, FY_BC_NUT_ZERO_GRADIENT);
+                std::vector<double> ev((size_t)hm.nPatches, 0.0);
+                for (int pa = 0; pa < hm.nPatches; ++pa) {
+                    if (c->eps_bc) eb[(size_t)pa] = c->eps_bc[pa];
+                    if (c->eps_value) ev[(size_t)pa] = c->eps_value[pa];
+                    if (eb[(size_t)pa] != FY_BC_NUT_ZERO_GRADIENT && eb[(size_t)pa] != FY_BC_NUT_FIXED_VALUE)
+                        return fail(FY_ERR_UNSUPPORTED, "fy_ldu_solver: epsilon patch type %d (zeroGradient, fixedValue; epsilonWallFunction needs the block solver)", eb[(size_t)pa]);
+                }
+                FY_TRY(up(d_epsbc, eb)); FY_TRY(up(d_epsval, ev));
+                FY_TRY(epsturb.alloc_exact(n));
+                FY_TRY(launch_fill_f64(stream, epsturb.p, n, c->eps_initial));
+                cs.eps_bc = nullptr; cs.eps_value = nullptr;
+            }
+            if (keqn || keps) {                                               // k of the start time (kEqn / kEpsilon: k_ is MUST_READ), its patches
                 std::vector<int32_t> kb((size_t)hm.nPatches, FY_BC_NUT_ZERO_GRADIENT);
                 std::vector<double> kv((size_t)hm.nPatches, 0.0);
                 for (int pa = 0; pa < hm.nPatches; ++pa) {
@@ -348,16 +369,22 @@ struct LduSolver {
             for (int corr = 0; corr < cs.n_correctors; ++corr) FY_TRY(corrector_pimple(final_outer && corr == cs.n_correctors - 1, p_relax_now));
             if (les && final_outer) {                                                                             // pimple.turbCorr(): pimpleFoamYade.C:101-104
                 FY_TRY(launch_ldu_grad_vec(stream, g, U.p, vGrad.p));
-                if (keqn) {                                                                                       // kEqn::correct(): the k equation (its matrix in the momentum matrix's arrays), bound(), correctNut()
+                if (keqn || keps) {                                                                               // kEqn::correct() / kEpsilon::correct(): epsilon first, then k with the new epsilon
                     LduMom Mk = M();
                     Mk.bdiag = nullptr;
-                    const LduKEqn K{cs.les_ce, cs.k_relax, cs.k_convection_scheme == FY_CONVECTION_UPWIND ? 1 : 0};
-                    FY_TRY(launch_ldu_grad_k(stream, g, P(), gradk.p));
-                    FY_TRY(launch_ldu_k_assemble(stream, g, P(), K, phi.p, vGrad.p, gradk.p, Mk, fcorr.p, HbyA.p));
-                    int it = 0;
-                    FY_TRY(solve_vec3(&it, Mk, mb.p, nullptr, &HbyA.p, &xscr.p, cs.k_tol, cs.k_rel_tol, cs.k_max_iter));
-                    k_iters_total += it;
-                    FY_TRY(launch_ldu_k_bound_nut(stream, g, P(), HbyA.p, kturb.p, nut.p));
+                    for (int mode = keps ? 1 : 0; mode == 0 || mode == 1 || (mode == 2 && keps); mode = mode == 1 ? 2 : 3) {
+                        LduKEqn K{};
+                        K.mode = mode; K.ce = cs.les_ce; K.c1 = cs.ras_c1; K.c2 = cs.ras_c2; K.c3 = cs.ras_c3;
+                        double tol, rel; int maxit;
+                        if (mode == 1) { K.relax = cs.eps_relax; K.upwind = cs.eps_convection_scheme == FY_CONVECTION_UPWIND; K.sigma = cs.ras_sigmaeps; K.X = epsturb.p; K.x_bc = d_epsbc.p; K.x_val = d_epsval.p; tol = cs.eps_tol; rel = cs.eps_rel_tol; maxit = cs.eps_max_iter; }
+                        else { K.relax = cs.k_relax; K.upwind = cs.k_convection_scheme == FY_CONVECTION_UPWIND; K.sigma = mode == 0 ? 1.0 : cs.ras_sigmak; K.X = kturb.p; K.x_bc = d_kbc.p; K.x_val = d_kval.p; tol = cs.k_tol; rel = cs.k_rel_tol; maxit = cs.k_max_iter; }
+                        FY_TRY(launch_ldu_grad_k(stream, g, P(), K, gradk.p));
+                        FY_TRY(launch_ldu_k_assemble(stream, g, P(), K, phi.p, vGrad.p, gradk.p, Mk, fcorr.p, HbyA.p));
+                        int it = 0;
+                        FY_TRY(solve_vec3(&it, Mk, mb.p, nullptr, &HbyA.p, &xscr.p, tol, rel, maxit));
+                        k_iters_total += it;
+                        FY_TRY(launch_ldu_k_bound_nut(stream, g, P(), K, HbyA.p, mode == 1 ? epsturb.p : kturb.p, nut.p));
+                    }
                     nut_live = true;
                 } else
                 FY_TRY(launch_ldu_smagorinsky_nut(stream, g, vGrad.p, cs.les_ck, cs.les_ce, cs.les_delta_coeff, nut.p));
@@ -427,7 +454,7 @@ struct LduSolver {
                          {"mom_diag", mdiag.p, n}, {"mom_lower", mlower.p, (size_t)ni}, {"mom_upper", mupper.p, (size_t)ni}, {"mom_b", mb.p, 3 * n},
                          {"alpha", alpha.p, pimple ? n : 0}, {"uSourceDrag", uSourceDrag.p, pimple ? n : 0}, {"uParticle", uParticle.p, pimple ? 3 * n : 0}, {"gradP", gradP.p, pimple ? 3 * n : 0},
                          {"divT", divT.p, pimple ? 3 * n : 0}, {"ddtU", ddtU.p, pimple ? 3 * n : 0}, {"phiForces", phiForces.p, pimple ? (size_t)nf : 0}, {"alphaf", alphaf.p, pimple ? (size_t)nf : 0},
-                         {"rAUf", rAUf.p, (size_t)nf}, {"uSourceCoupling", uSource.p, 3 * n}, {"nut", nut.p, les ? n : 0}, {"k", kturb.p, keqn ? n : 0}};
+                         {"rAUf", rAUf.p, (size_t)nf}, {"uSourceCoupling", uSource.p, 3 * n}, {"nut", nut.p, les ? n : 0}, {"k", kturb.p, (keqn || keps) ? n : 0}, {"epsilon", epsturb.p, keps ? n : 0}};
         for (const E& e : tab) if (s == e.nm) { *ptr = e.p; *count = e.c; return FY_OK; }
         const struct { const char* nm; const std::vector<double>* v; } geo[] = {{"C", &hm.C}, {"V", &hm.V}, {"Cf", &hm.Cf}, {"Sf", &hm.Sf}, {"magSf", &hm.magSf}, {"w", &hm.w},
                                                                                   {"dcNO", &hm.dcNO}, {"kvec", &hm.kvec}, {"sep", &hm.sep}, {"orig_face", &orig_face_d}};
@@ -454,6 +481,8 @@ void fy_ldu_case_defaults(fy_ldu_case* c) {
     c->adjust_time_step = 0; c->max_co = 1.0; c->max_delta_t = 1e300;
     c->turbulence_model = FY_TURBULENCE_LAMINAR; c->les_ck = 0.094; c->les_ce = 1.048; c->les_delta_coeff = 1.0; c->nut_initial = 0.0;
     c->convection_scheme = FY_CONVECTION_LINEAR; c->convection_limiter_k = 1.0;
+    c->ras_cmu = 0.09; c->ras_c1 = 1.44; c->ras_c2 = 1.92; c->ras_c3 = 0.0; c->ras_sigmak = 1.0; c->ras_sigmaeps = 1.3;
+    c->eps_initial = 0.0; c->eps_bc = nullptr; c->eps_value = nullptr; c->eps_convection_scheme = FY_CONVECTION_LINEAR; c->eps_tol = 1e-6; c->eps_rel_tol = 0.0; c->eps_max_iter = 1000; c->eps_relax = 0.0;
     c->k_initial = 0.0; c->k_bc = nullptr; c->k_value = nullptr; c->k_convection_scheme = FY_CONVECTION_LINEAR; c->k_tol = 1e-6; c->k_rel_tol = 0.0; c->k_max_iter = 1000; c->k_relax = 0.0;
 }
 
@@ -494,7 +523,7 @@ int fy_ldu_solver_write_field_host(fy_ldu_solver* s, const char* name, const dou
     double* p; size_t n; const std::vector<double>* h;
     FY_TRY(s->s.field(name, &p, &n, &h));
     const std::string nm = name;
-    const bool pim_in = (s->s.pimple && (nm == "alpha" || nm == "uSourceDrag")) || (s->s.les && nm == "nut") || (s->s.keqn && nm == "k");      // (what setParticleAction would leave: for tests that feed the equations a given void fraction)
+    const bool pim_in = (s->s.pimple && (nm == "alpha" || nm == "uSourceDrag")) || (s->s.les && nm == "nut") || ((s->s.keqn || s->s.keps) && nm == "k") || (s->s.keps && nm == "epsilon");      // (what setParticleAction would leave: for tests that feed the equations a given void fraction)
     if (h || (nm != "U" && nm != "p" && nm != "uSource" && !pim_in)) return fy::fail(FY_ERR_INVALID, "fy_ldu_solver_write_field_host: '%s' cannot be written (U, p, uSource; alpha, uSourceDrag with pimpleFoamYade)", nm.c_str());
     FY_HIP(hipSetDevice(s->s.device));
     FY_HIP(hipMemcpyAsync(p, in, n * sizeof(double), hipMemcpyHostToDevice, s->s.stream));
