@@ -413,7 +413,9 @@ __device__ __attribute__((noinline)) void walk_deposit(const ParticleSoA& p, int
     }
 }
 
-template <bool IMPLICIT>
+// WD: the walk also deposits for the particle it has placed (the leftovers of the candidate lists); without it the instance carries neither the 16 weights' scratch (192 B per
+// lane) nor their registers: the explicit walk 97 -> 42 VGPRs
+template <bool IMPLICIT, bool WD>
 __global__ __launch_bounds__(kWave) void k_locate(const KdNode* __restrict__ tree, const uint32_t* __restrict__ packed, ImplicitGeom ig,
                                                   int32_t n_cells, ParticleSoA p, int64_t n, double maxdist,
                                                   const unsigned long long* __restrict__ start, SlabOwn own,
@@ -490,7 +492,7 @@ __global__ __launch_bounds__(kWave) void k_locate(const KdNode* __restrict__ tre
                     if (sp == 0) {
                         if (active) {                                          // walk finished; k = min(chain, 16)
                             p.chain_len[i] = chain; active = false;
-                            if (wd.pvol_acc) walk_deposit(p, i, chain, wd);
+                            if constexpr (WD) walk_deposit(p, i, chain, wd);
                             if (depth_hwm && (i & 63) == 0) atomicAdd(&depth_hwm[min(spmax, kLocDepthBins - 1)], 1u);      // (one walk in 64: a histogram of the stack depths)
                         }
                         break;
@@ -1546,20 +1548,20 @@ int launch_locate(hipStream_t s, const KdNode* tree, const uint32_t* packed, Imp
     const size_t lds = (size_t)(levels + 1) * kWave * (packed ? sizeof(unsigned long long) : sizeof(uint4));
     const dim3 grid(div_up(n, kLocPPB));
     if (packed) {
-        hipLaunchKernelGGL(k_locate<true>, grid, dim3(kWave), lds, s, tree, packed, ig, n_cells, p, n, gp.maxdist, start, own, nullptr, nullptr, WalkDeposit{}, 0, nullptr, nullptr, nullptr);
+        hipLaunchKernelGGL((k_locate<true, false>), grid, dim3(kWave), lds, s, tree, packed, ig, n_cells, p, n, gp.maxdist, start, own, nullptr, nullptr, WalkDeposit{}, 0, nullptr, nullptr, nullptr);
     } else if (ll.fb_list && ll.fb_count && ll.stack_cap > 0 && ll.stack_cap < levels + 1) {
         // explicit 16-byte entries: (levels + 1) of them per lane are 23 KB per wave at 4 M cells = 6 waves per CU, and the kernel is latency bound.  The stack never gets that
         // deep (starting from best <= maxdist only the split planes within the search radius of the query are stacked): a stack of the depth the walks have been seen to
         // need (ll.depth_hwm) serves them all, and a walk that needs more than that takes the second launch
         const int cap = ll.stack_cap;
         FY_HIP(hipMemsetAsync(ll.fb_count, 0, sizeof(unsigned int), s));
-        hipLaunchKernelGGL(k_locate<false>, grid, dim3(kWave), (size_t)cap * kWave * sizeof(uint4), s, tree, packed, ig, n_cells, p, n, gp.maxdist, nullptr, own, nullptr, nullptr,
+        hipLaunchKernelGGL((k_locate<false, false>), grid, dim3(kWave), (size_t)cap * kWave * sizeof(uint4), s, tree, packed, ig, n_cells, p, n, gp.maxdist, nullptr, own, nullptr, nullptr,
                            WalkDeposit{}, cap, ll.fb_list, ll.fb_count, ll.depth_hwm);
         FY_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_locate<false>, grid, dim3(kWave), lds, s, tree, packed, ig, n_cells, p, n, gp.maxdist, nullptr, own, ll.fb_list, ll.fb_count, WalkDeposit{}, 0, nullptr, nullptr,
+        hipLaunchKernelGGL((k_locate<false, false>), grid, dim3(kWave), lds, s, tree, packed, ig, n_cells, p, n, gp.maxdist, nullptr, own, ll.fb_list, ll.fb_count, WalkDeposit{}, 0, nullptr, nullptr,
                            ll.depth_hwm);
     } else {
-        hipLaunchKernelGGL(k_locate<false>, grid, dim3(kWave), lds, s, tree, packed, ig, n_cells, p, n, gp.maxdist, nullptr, own, nullptr, nullptr, WalkDeposit{}, 0, nullptr, nullptr, ll.depth_hwm);
+        hipLaunchKernelGGL((k_locate<false, false>), grid, dim3(kWave), lds, s, tree, packed, ig, n_cells, p, n, gp.maxdist, nullptr, own, nullptr, nullptr, WalkDeposit{}, 0, nullptr, nullptr, ll.depth_hwm);
     }
     FY_LAUNCH_CHECK();
     return FY_OK;
@@ -1605,7 +1607,7 @@ int launch_locate_deposit(hipStream_t s, const KdNode* tree, const uint32_t* pac
     }
     const size_t lds = (size_t)(levels + 1) * kWave * sizeof(unsigned long long);
     const dim3 wgrid((unsigned)std::min<int64_t>(div_up(n, kLocPPB), 2048));
-    hipLaunchKernelGGL(k_locate<true>, wgrid, dim3(kWave), lds, w, tree, packed, ig, n_cells, p, n, gp.maxdist, start, SlabOwn{}, ll.fb_list, ll.fb_count,
+    hipLaunchKernelGGL((k_locate<true, true>), wgrid, dim3(kWave), lds, w, tree, packed, ig, n_cells, p, n, gp.maxdist, start, SlabOwn{}, ll.fb_list, ll.fb_count,
                        WalkDeposit{gp, cw, pvol_acc, up_acc, touched}, 0, nullptr, nullptr, nullptr);
     FY_LAUNCH_CHECK();
     if (side.stream) FY_HIP(hipEventRecord(side.join, side.stream));
