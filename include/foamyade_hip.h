@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define FY_ABI_VERSION 12
+#define FY_ABI_VERSION 13
 
 /* ---- status codes ------------------------------------------------------------------------------------ */
 enum {
@@ -194,6 +194,10 @@ double fy_interp_range(fy_ctx*);      /* interpRange = 4*cbrt(V[0]) (FoamYade.C:
  * octant) candidate lists and took the plain tree walk instead (within 8e-6 dx of a cell face, outside the block, list overflow);
  * -1 when the lists are not in use (explicit tree, FOAMYADE_NO_LOCATE_LISTS, no memory).  Same results either way. */
 long long fy_locate_walk_count(fy_ctx*);
+/* Gaussian locate on an explicit tree (graded block, general mesh): entries per lane of the LDS stack the last step's walk ran with -- chosen from the kernel's own histogram of
+ * the depths the walks need; a walk that needs more takes a second launch with the full depth --, 0 while the walk still runs with the full depth (first steps, small clouds),
+ * -1 when the tree is not explicit.  Same results either way. */
+int fy_locate_stack_depth(fy_ctx*);
 
 /* per-phase device timings of the last fy_set_particle_action, milliseconds (HIP events on the ctx stream) */
 typedef struct fy_particle_timings {

@@ -6,6 +6,7 @@ import os
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -30,3 +31,47 @@ def test_explicit_tree_walk_on_a_short_stack(cap):
                         "-k", "product_on_a_graded_mesh or with_a_cloud or gaussian or point_force"], env=env, cwd=os.path.dirname(HERE), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
+
+
+def test_adaptive_stack_depth_follows_the_cloud(product, oracle):
+    """the depth the explicit walk's LDS stack is given comes from a histogram the kernel keeps (one walk in 64) and the host reads back a step late, renewed every 32 steps:
+    a cloud of 100 000 particles on a distorted mesh (explicit k-d nodes) over 40 steps -- full depth first, then the histogram's depth, across a window's end, with a
+    population that moves from one corner's fine cells to the whole box -- gives the restatement's chains bit for bit at every checked step"""
+    import golden_cases as gc
+    n = 24
+    rs = np.random.RandomState(5)
+    g = (np.arange(n) + 0.5) / n
+    X, Y, Z = np.meshgrid(g ** 1.6, g ** 1.3, g, indexing="ij")                      # graded in x and y: cell sizes from 0.002 to 0.07
+    C = np.stack([X.ravel(order="F"), Y.ravel(order="F"), Z.ravel(order="F")], axis=1)
+    C += (rs.rand(*C.shape) - 0.5) * 0.2 / n                                          # and jittered: nothing lattice-like left
+    V = np.full(len(C), 1.0 / n ** 3)
+    lo, hi = np.zeros(3), np.ones(3)
+    Nc = len(C)
+    fields = dict(U=rs.rand(Nc, 3), gradP=rs.rand(Nc, 3), vGrad=rs.rand(Nc, 9), divT=rs.rand(Nc, 3), ddtU=rs.rand(Nc, 3))
+    mut = dict(uSourceDrag=np.zeros(Nc), alpha=np.ones(Nc), uSource=np.zeros((Nc, 3)), uParticle=np.zeros((Nc, 3)))
+    mesh = product.GeneralMesh(C, V, lo, hi)
+    fy = product.FoamYade(mesh, fields["U"], fields["gradP"], fields["vGrad"], fields["divT"], fields["ddtU"], (0, 0, -9.81),
+                          mut["uSourceDrag"], mut["alpha"], mut["uSource"], mut["uParticle"], True)
+    fy.setScalarProperties(2500.0, 1000.0, 1e-6)
+    om = oracle.Mesh(n, n, n, 1.0 / n, (0, 0, 0), centres=C, volumes=V, bbmin=lo, bbmax=hi)
+    assert np.array_equal(fy.tree_preorder(), om.pre)
+    npart = 100000
+    depths = []
+    for step in range(40):
+        rec = np.zeros((npart, 10))
+        ext = 0.25 if step < 20 else 1.0                                              # the fine corner first, then everywhere
+        rec[:, 0:3] = rs.rand(npart, 3) * ext
+        rec[:, 9] = 1e-4
+        fy.setParticles([rec])
+        fy.setParticleAction(1e-3)
+        if step in (0, 1, 5, 19, 20, 21, 31, 32, 33, 39):
+            k, ids, w, chain = fy.stencils(0)
+            sub = rs.choice(npart, 4000, replace=False)
+            rk, rids, rchain, _ = oracle.range_search(C, om.pre, rec[sub, 0:3], fy.interpRange)
+            assert np.array_equal(chain[sub], rchain), step
+            assert np.array_equal(k[sub], np.minimum(rk, ids.shape[1])) and np.array_equal(ids[sub], rids[:, :ids.shape[1]]), step
+        depths.append(fy.locate_stack_depth)
+        fy.setSourceZero()
+    fy.close()
+    assert depths[0] == 0 and min(depths[3:]) >= 4 and max(depths) < 20, depths            # measured first, a short stack from then on
+    assert len(set(depths[3:])) > 1, depths                                                 # ... and not the same one for the corner's fine cells and the whole box

@@ -515,6 +515,13 @@ class FoamYade:
         """particles of the last step's (last batch's) Gaussian locate that took the tree walk instead of the candidate lists; -1: lists not in use"""
         return lib().fy_locate_walk_count(self._h)
 
+    @property
+    def locate_stack_depth(self):
+        """entries per lane of the explicit walk's LDS stack in the last step (0: the full depth; -1: no explicit tree)"""
+        L = lib()
+        L.fy_locate_stack_depth.argtypes = [C.c_void_p]
+        return L.fy_locate_stack_depth(self._h)
+
     def close(self):
         if self._h:
             lib().fy_destroy(self._h)

@@ -628,19 +628,27 @@ int Coupling::run_batch(Batch& b) {
             if (!d_loc_fb_n.p) FY_TRY(d_loc_fb_n.alloc_exact(1));
             if (d_loc_fb.n < (size_t)b.n) FY_TRY(d_loc_fb.alloc_exact((size_t)b.n + (size_t)b.n / 8));
             if (!d_loc_hwm.p) {
-                FY_TRY(d_loc_hwm.alloc_exact(kLocDepthBins)); FY_TRY(h_loc_hwm.reserve(kLocDepthBins));
+                FY_TRY(d_loc_hwm.alloc_exact(kLocDepthBins)); FY_TRY(h_loc_hwm.reserve(kLocDepthBins + 1));
                 FY_HIP(hipMemsetAsync(d_loc_hwm.p, 0, kLocDepthBins * sizeof(unsigned int), stream));
-                for (int q = 0; q < kLocDepthBins; ++q) h_loc_hwm[q] = 0;
+                for (int q = 0; q <= kLocDepthBins; ++q) h_loc_hwm[q] = 0;
             }
-            // the stack of this step: the depth that has served 99.8 % of the walks sampled so far, as last copied back (the first step runs the full depth and measures);
-            // the others overflow into the second launch
+            // the stack of this step: the depth that served 99.8 % of the walks sampled in the current window of steps, as last copied back (the first step runs the full
+            // depth and measures); the others overflow into the second launch.  The histogram starts anew every 32 steps, so a cloud that moves on is followed; while a
+            // window is still short the last window's depth stands; and if more than 1 % of the walks overflowed last step the stack grows by two entries at once
             static const int forced = [] { const char* e = getenv("FOAMYADE_LOCATE_STACK"); return e ? atoi(e) : -1; }();      // (experiments: 0 = always the full depth)
             unsigned long long total = 0, run = 0;
             unsigned int hist[kLocDepthBins];
             for (int q = 0; q < kLocDepthBins; ++q) { hist[q] = ((volatile unsigned int*)h_loc_hwm.p)[q]; total += hist[q]; }
-            int seen = 0;
-            if (total >= 1000) for (seen = 0; seen < kLocDepthBins - 1; ++seen) { run += hist[seen]; if (run * 1000 >= total * 998) break; }
-            seen = seen > 0 ? std::max(seen, 4) : 0;
+            if (total >= 1000) {
+                int d = 0;
+                for (d = 0; d < kLocDepthBins - 1; ++d) { run += hist[d]; if (run * 1000 >= total * 998) break; }
+                loc_stack_cap = std::max(d, 4);
+            }
+            const unsigned int overflowed = ((volatile unsigned int*)h_loc_hwm.p)[kLocDepthBins];
+            if (loc_stack_used > 0 && loc_last_n > 0 && (unsigned long long)overflowed * 100 > (unsigned long long)loc_last_n) loc_stack_floor = loc_stack_used + 2;      // (kept until the window ends)
+            loc_last_n = b.n;
+            const int seen = loc_stack_cap > 0 ? std::max(loc_stack_cap, loc_stack_floor) : 0;
+            loc_stack_used = seen;
             ll = LocateLists{nullptr, d_loc_fb.p, d_loc_fb_n.p, 0, 0, forced >= 0 ? forced : seen, d_loc_hwm.p};
         }
         const CellWindow cw{slab.active ? slab.base : 0, n_field};
@@ -651,7 +659,11 @@ int Coupling::run_batch(Batch& b) {
         FY_TRY(launch_locate_deposit(stream, d_tree.p, use_implicit ? d_tree_packed.p : nullptr, implicit, n_cells, tree_levels, p, b.n, gp,
                                      use_implicit ? d_loc_start.p : nullptr, own_of(b), ll, cw, d_pvol_acc.p, d_up_acc.p, d_touched.p, tbD, side,
                                      fused_gather ? b.d_rec : nullptr));
-        if (ll.depth_hwm) FY_HIP(hipMemcpyAsync(h_loc_hwm.p, d_loc_hwm.p, kLocDepthBins * sizeof(unsigned int), hipMemcpyDeviceToHost, stream));      // (read at the next step's launch, no wait)
+        if (ll.depth_hwm) {                                // (read at the next step's launch, no wait)
+            FY_HIP(hipMemcpyAsync(h_loc_hwm.p, d_loc_hwm.p, kLocDepthBins * sizeof(unsigned int), hipMemcpyDeviceToHost, stream));
+            FY_HIP(hipMemcpyAsync(h_loc_hwm.p + kLocDepthBins, d_loc_fb_n.p, sizeof(unsigned int), hipMemcpyDeviceToHost, stream));
+            if (++loc_window >= 32) { loc_window = 0; loc_stack_floor = 0; FY_HIP(hipMemsetAsync(d_loc_hwm.p, 0, kLocDepthBins * sizeof(unsigned int), stream)); }
+        }
         b.chain_n = b.n;                                   // (what the next placement's runs are ordered by)
         if (timing) marks.mark(2, stream);
         if (mid_hook && !mid_hook_done) {                  // the solver's field sweep: beside the side stream's walk (its own mark pair: it is taken off the phase it falls into)
@@ -1297,6 +1309,10 @@ long long fy_locate_walk_count(fy_ctx* c) {
     unsigned int n = 0;
     if (hipStreamSynchronize(c->c.stream) != hipSuccess || hipMemcpy(&n, c->c.d_loc_fb_n.p, sizeof(n), hipMemcpyDeviceToHost) != hipSuccess) return -1;
     return (long long)n;
+}
+int fy_locate_stack_depth(fy_ctx* c) {
+    if (!c || !c->c.d_loc_hwm.p) return -1;
+    return c->c.loc_stack_used;
 }
 int fy_get_particle_timings(fy_ctx* c, fy_particle_timings* out) {
     FY_CTX(c);

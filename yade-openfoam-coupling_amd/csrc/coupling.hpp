@@ -103,7 +103,10 @@ struct Coupling {
     DevBuf<int32_t> d_loc_fb;                 // particles the lists do not cover (work list of the walk) + their count
     DevBuf<unsigned int> d_loc_fb_n;
     DevBuf<unsigned int> d_loc_hwm;           // explicit tree: histogram of the walks' stack depths (k_locate, one walk in 64), and its pinned host copy
-    HostBuf<unsigned int> h_loc_hwm;
+    HostBuf<unsigned int> h_loc_hwm;          // [kLocDepthBins] the histogram, [kLocDepthBins] + 1: the walks that overflowed last step
+    int loc_stack_floor = 0, loc_stack_used = 0;      // raised by two entries when more than 1 % of a step's walks overflowed; the depth the last step ran with
+    int loc_stack_cap = 0, loc_window = 0;    // the explicit walk's stack depth in use (0: the full depth), steps into the histogram's window
+    int64_t loc_last_n = 0;
     bool loc_lists_tried = false;
     int32_t loc_cell0 = 0, loc_n_listed = 0;  // cells the lists cover (a slab: its own planes)
     int ensure_locate_tables(double maxdist);

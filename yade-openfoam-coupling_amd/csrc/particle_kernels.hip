@@ -556,10 +556,19 @@ __global__ __launch_bounds__(kWave) void k_locate(const KdNode* __restrict__ tre
                 const uint32_t paxis = axis;
                 axis = (axis == 2 ? 0 : axis + 1);
                 // best only decreases, so a far side that already fails df2 < best can never pass later
-                if (far_n > 0 && df2 < best && ovf_list && sp >= stack_cap) {
-                    ovf_list[atomicAdd(ovf_count, 1u)] = (int32_t)i;
-                    active = false;
-                } else if (far_n > 0 && df2 < best) {
+                const bool push = far_n > 0 && df2 < best;
+                const bool ovf = push && ovf_list && sp >= stack_cap;
+                if (ovf_list) {                          // (kernel-uniform) the lanes that give up file their particles with ONE atomic per wave and iteration
+                    const unsigned long long m = __ballot(ovf);
+                    if (m) {
+                        const int leader = __ffsll((long long)m) - 1;
+                        unsigned int at = 0;
+                        if (lane == leader) at = atomicAdd(ovf_count, (unsigned int)__popcll(m));
+                        at = __shfl(at, leader, kWave);
+                        if (ovf) { ovf_list[at + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)i; active = false; }
+                    }
+                }
+                if (push && !ovf) {
                     if constexpr (IMPLICIT) {
                         const unsigned long long idx = (paxis == 0 ? (pk & 1023u) : (paxis == 1 ? ((pk >> 10) & 1023u) : (pk >> 20)));
                         STK(sp) = (unsigned long long)far_o | ((unsigned long long)far_n << 25) | ((unsigned long long)axis << 50) | (idx << 52);
