@@ -359,8 +359,9 @@ struct LduSolver {
             FY_TRY(launch_ldu_assemble_momentum_pimple(stream, g, P(), phi.p, Uold.p, U.p, vGrad.p, M(), fcorr.p, fstress.p, u_relax_now, rAU.p));      // UcEqn.H:3-13
             FY_TRY(launch_ldu_forces(stream, g, P(), rAU.p, rAUf.p, phiForces.p));                               // UcEqn.H:15-20
             if (cs.momentum_predictor) {                                                                          // UcEqn.H:22-33
-                FY_TRY(launch_ldu_grad_scalar(stream, g, p.p, gradp.p));
-                FY_TRY(launch_ldu_ssf_predictor(stream, g, phiForces.p, rAUf.p, p.p, gradp.p, ssf.p));
+                // (first outer iteration: p and its patches' gradients stand as when the coupling's gradP was formed, pimpleFoamYade.C:74 -- the same field, not formed again)
+                if (outer > 0) FY_TRY(launch_ldu_grad_scalar(stream, g, p.p, gradp.p));
+                FY_TRY(launch_ldu_ssf_predictor(stream, g, phiForces.p, rAUf.p, p.p, outer > 0 ? gradp.p : gradP.p, ssf.p));
                 FY_TRY(launch_ldu_reconstruct(stream, g, ssf.p, mb.p, d_V.p, bmom.p));
                 int it = 0;
                 FY_TRY(solve_momentum(&it, bmom.p, nullptr));
