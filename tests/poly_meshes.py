@@ -127,7 +127,7 @@ def to_lattice(mesh, field):
     return np.asarray(field)[mesh["perm"]]
 
 
-def from_cells(points, cells, patch_of_face, patch_names, shape=None):
+def from_cells(points, cells, patch_of_face, patch_names, shape=None, _tag=None):
     """a mesh in OpenFOAM's addressing from cells given as lists of faces (point tuples turning counter-clockwise seen from OUTSIDE the cell).  A face two
     cells share becomes an internal face (owner = the lower cell, point order = the owner's); the others go to the patch patch_of_face(face centre) names.
     Internal faces in upper-triangular order, boundary faces patch by patch sorted by owner [OF-6 polyMesh ordering]."""
@@ -147,7 +147,7 @@ def from_cells(points, cells, patch_of_face, patch_names, shape=None):
             internal.append((c0, c1, f0))
         else:
             c0, f0 = users[0]
-            boundary[patch_names.index(patch_of_face(P[list(f0)].mean(axis=0)))].append((c0, f0))
+            boundary[patch_names.index(_tag[key] if _tag is not None else patch_of_face(P[list(f0)].mean(axis=0)))].append((c0, f0))
     internal.sort(key=lambda t: (t[0], t[1]))
     faces = [t[2] for t in internal]; owner = [t[0] for t in internal]; neigh = [t[1] for t in internal]
     pstart, psize = [], []
@@ -159,6 +159,56 @@ def from_cells(points, cells, patch_of_face, patch_names, shape=None):
     return dict(points=P, face_offsets=off, face_points=np.asarray([q for f in faces for q in f], np.int32), owner=np.asarray(owner, np.int32),
                 neighbour=np.asarray(neigh, np.int32), n_cells=len(cells), patch_start=np.asarray(pstart, np.int32), patch_size=np.asarray(psize, np.int32),
                 patch_names=list(patch_names), perm=np.arange(len(cells)), shape=shape)
+
+
+def refined_block(nx, ny, nz, kr, lengths=(1.0, 1.0, 1.0), vertex_map=None):
+    """the box with its layers k >= kr refined 2 x 2 in x and y (hexRef8-like, 2:1): the cells of layer kr - 1 are polyhedra with NINE faces -- their top is the four
+    faces of the fine cells above, and their side faces carry the hanging mid-edge point (five-point polygons), as OpenFOAM keeps such meshes closed and conformal.
+    Patches: one per side of the box (SIDES)."""
+    lx, ly, lz = lengths
+    NX, NY = 2 * nx, 2 * ny
+    pid = lambda i, j, k: i + (NX + 1) * (j + (NY + 1) * k)                      # the fine lattice's points on every plane (the coarse layers use the even ones)
+    ii, jj, kk = np.meshgrid(np.arange(NX + 1), np.arange(NY + 1), np.arange(nz + 1), indexing="ij")
+    P0 = np.zeros(((NX + 1) * (NY + 1) * (nz + 1), 3))
+    P0[pid(ii, jj, kk).ravel()] = np.stack([ii.ravel() * lx / NX, jj.ravel() * ly / NY, kk.ravel() * lz / nz], axis=1)
+    P = P0 if vertex_map is None else np.asarray(vertex_map(P0), np.float64)
+    cells = []
+    for k in range(nz):
+        fine = k >= kr
+        st = 1 if fine else 2
+        for j in range(0, NY, st):
+            for i in range(0, NX, st):
+                a, b = i + st, j + st
+                hang = (not fine) and k == kr - 1                                 # the coarse layer under the fine ones
+                bottom = [(pid(i, j, k), pid(i, b, k), pid(a, b, k), pid(a, j, k))]
+                if hang:
+                    m, n = i + 1, j + 1
+                    top = [(pid(i, j, k + 1), pid(m, j, k + 1), pid(m, n, k + 1), pid(i, n, k + 1)), (pid(m, j, k + 1), pid(a, j, k + 1), pid(a, n, k + 1), pid(m, n, k + 1)),
+                           (pid(i, n, k + 1), pid(m, n, k + 1), pid(m, b, k + 1), pid(i, b, k + 1)), (pid(m, n, k + 1), pid(a, n, k + 1), pid(a, b, k + 1), pid(m, b, k + 1))]
+                    sides = [(pid(i, j, k), pid(a, j, k), pid(a, j, k + 1), pid(m, j, k + 1), pid(i, j, k + 1)),              # ymin (outward -y)
+                             (pid(a, j, k), pid(a, b, k), pid(a, b, k + 1), pid(a, n, k + 1), pid(a, j, k + 1)),              # xmax
+                             (pid(a, b, k), pid(i, b, k), pid(i, b, k + 1), pid(m, b, k + 1), pid(a, b, k + 1)),              # ymax
+                             (pid(i, b, k), pid(i, j, k), pid(i, j, k + 1), pid(i, n, k + 1), pid(i, b, k + 1))]              # xmin
+                else:
+                    top = [(pid(i, j, k + 1), pid(a, j, k + 1), pid(a, b, k + 1), pid(i, b, k + 1))]
+                    sides = [(pid(i, j, k), pid(a, j, k), pid(a, j, k + 1), pid(i, j, k + 1)), (pid(a, j, k), pid(a, b, k), pid(a, b, k + 1), pid(a, j, k + 1)),
+                             (pid(a, b, k), pid(i, b, k), pid(i, b, k + 1), pid(a, b, k + 1)), (pid(i, b, k), pid(i, j, k), pid(i, j, k + 1), pid(i, b, k + 1))]
+                cells.append(bottom + top + sides)
+    eps = 1e-9
+    P_un = P0
+    seen = {}                                                                     # boundary faces go to the side their UNMAPPED centre lies on
+    for c, faces in enumerate(cells):
+        for f in faces:
+            seen.setdefault(tuple(sorted(f)), []).append((c, tuple(f)))
+    names = list(SIDES)
+    def which(f):
+        m = P_un[list(f)].mean(axis=0)
+        for a, (lo, hi) in enumerate(((0.0, lx), (0.0, ly), (0.0, lz))):
+            if abs(m[a] - lo) < eps: return SIDES[2 * a]
+            if abs(m[a] - hi) < eps: return SIDES[2 * a + 1]
+        raise AssertionError("an unmatched interior face: %r" % (m,))
+    tag = {key: which(users[0][1]) for key, users in seen.items() if len(users) == 1}
+    return from_cells(P, cells, None, names, shape=(nx, ny, nz), _tag=tag)
 
 
 def prism_block(nx, ny, nz, lengths=(1.0, 1.0, 1.0), vertex_map=None):

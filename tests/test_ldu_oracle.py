@@ -455,6 +455,28 @@ def test_ras_kEpsilon_on_a_lattice_reproduces_the_structured_restatement(oracle)
     f.close(); g.close()
 
 
+def test_two_to_one_refined_polyhedra(oracle):
+    """a box whose upper layers are refined 2 x 2 (hexRef8-like): the cells under the interface are polyhedra with nine faces (four of them the fine cells' bottoms, the
+    side faces five-point polygons with the hanging point) -- closed cells, volumes adding up, oblique centre-to-centre lines across the interface; the lid-driven cavity on it (distorted
+    too) conserves mass to rounding"""
+    L = (1.0, 1.0, 0.9)
+    mesh = pm.refined_block(4, 4, 6, 3, L, pm.wavy(0.02, L))
+    assert mesh["n_cells"] == 3 * 16 + 3 * 64 and set(np.diff(mesh["face_offsets"])) == {4, 5}
+    u_val = [(0, 0, 0)] * 6
+    u_val[5] = (1.0, 0, 0)                                                        # the lid over the fine layers
+    s = make(mesh, 0.01, 0.01, u_val=u_val, n_non_orth=2, p_tol=1e-11, p_rel_tol=0.0, p_final_tol=1e-11, p_max_iter=20000)
+    Sf, V, kv = s.geometry("Sf"), s.geometry("V"), s.geometry("kvec")
+    own, nei, ni = mesh["owner"], mesh["neighbour"], len(mesh["neighbour"])
+    tot = np.zeros((mesh["n_cells"], 3))
+    np.add.at(tot, own, Sf); np.subtract.at(tot, nei, Sf[:ni])
+    assert np.abs(tot).max() < 1e-15 and V.sum() == pytest.approx(0.9, rel=1e-13) and V.min() > 0
+    assert np.bincount(np.concatenate([own, nei])).max() == 9 and np.abs(kv).max() > 0.3
+    for _ in range(4):
+        s.step()
+    assert s.stats()["cont_sum_local"] < 1e-12 and np.abs(s.get("U")).max() > 0.01 and np.isfinite(s.get("p")).all()
+    s.close()
+
+
 def test_tetrahedra_geometry_and_a_cavity_on_them(oracle):
     """Kuhn tetrahedra (triangular faces only, four-faced cells, non-orthogonality around 50 degrees): closed cells, volumes adding up to the box's with every
     tetrahedron a sixth of its hexahedron, centres = the vertex means; the lid-driven cavity runs on them and conserves mass to rounding with two non-orthogonal passes"""

@@ -573,6 +573,50 @@ def test_ras_kEpsilon_on_a_wavy_mesh_matches_the_restatement(product, oracle):
     h.close(); o.close()
 
 
+@pytest.mark.parametrize("solver", ["ico", "pimple_cloud"])
+def test_two_to_one_refined_polyhedra_match_the_restatement(product, oracle, solver):
+    """a distorted box with its upper layers refined 2 x 2: nine-faced polyhedra under the interface (slot tables nine wide), five-point side faces, strongly unequal
+    weights across it -- geometry, the lid-driven cavity with the multigrid preconditioner (agglomeration across the interface), pimpleFoamYade with a cloud"""
+    if solver == "ico":
+        L = (1.0, 1.0, 0.9)
+        mesh = pm.refined_block(6, 6, 8, 4, L, pm.wavy(0.02, L))
+        u_val = [(0, 0, 0)] * 6
+        u_val[5] = (1.0, 0.2, 0)
+        kw = dict(n_non_orth=2, p_tol=1e-10, p_rel_tol=0.0, p_final_tol=1e-10, u_tol=1e-10, p_max_iter=5000)
+        h = product.LduSolver(mesh, 0.02, 0.01, [0] * 6, u_val, [0] * 6, p_solver=product.FY_PSOLVER_PCG_MG, **kw)
+        o = oracle.LduSolver(mesh, 0.02, 0.01, [0] * 6, u_val, [0] * 6, **kw)
+        for nm in ("C", "V", "Cf", "Sf", "w", "dcNO", "kvec"):
+            np.testing.assert_allclose(h.geometry(nm), o.geometry(nm), rtol=0, atol=1e-13, err_msg=nm)
+        for _ in range(4):
+            h.step(); o.step()
+        assert len(h.mg_levels()) >= 2 and h.mg_levels()[0][1] == 9 and h.stats()["p_iters_total"] < o.stats()["p_iters_total"]
+        assert np.abs(h.get("U")).max() > 0.05
+    else:
+        box = 0.1
+        L = (box, box, box)
+        mesh = pm.refined_block(5, 5, 10, 5, L, pm.wavy(0.01 * box, L))
+        kw = dict(p_tol=1e-10, p_rel_tol=0.0, p_final_tol=1e-10, u_tol=1e-10, p_max_iter=5000)
+        rel = dict(u_relax=0.8, u_relax_final=1.0, p_relax=0.7, p_relax_final=1.0)
+        h = product.LduSolver(mesh, 2e-4, 1e-5, [0] * 6, [(0, 0, 0)] * 6, [2] * 6, solver=1, g=(0, 0, -9.81), n_non_orth=1, n_outer_correctors=2, n_correctors=2, **rel, **kw)
+        o = oracle.LduSolver(mesh, 2e-4, 1e-5, [0] * 6, [(0, 0, 0)] * 6, [2] * 6, solver=1, g=(0, 0, -9.81), n_non_orth=1, n_outer=2, n_correctors=2, **rel, **kw)
+        h.hold_sources(True)
+        rs = np.random.RandomState(31)
+        for step in range(3):
+            rec = bed_particles(rs, 1500, box, box / 10)
+            rec[:, 2] = 0.3 * box + 0.4 * box * rs.random_sample(1500)                 # the cloud across the interface
+            h.set_particles(rec)
+            h.step()
+            alpha = h.get("alpha")
+            assert alpha.min() < 0.97
+            o.step(source=h.get("uSourceCoupling"), alpha=alpha, drag=h.get("uSourceDrag"))
+            close(h.get("U"), o.get("U"), 2e-6, "U step %d" % step)
+    ph, po = h.get("p"), o.get("p")
+    close(ph - ph.mean(), po - po.mean(), 1e-5, "p")
+    close(h.get("phi"), o.get("phi"), 1e-5, "phi")
+    close(h.get("U"), o.get("U"), 2e-6, "U")
+    h.close(); o.close()
+
+
 def test_rayleigh_layer_on_a_distorted_mesh_on_the_hip_solver(product):
     """the transient known answer of tests/test_ldu_oracle.py::test_rayleigh_layer_on_a_distorted_mesh on the HIP solver with the multigrid preconditioner, one level finer
     (128 cells across, 131 072 cells): the error keeps falling (0.0025, 0.0011 on the restatement at 32 and 64)"""
