@@ -24,10 +24,14 @@ constexpr double kWa = 1.7318685872766142, kWb = 0.5695012757370842;      // fv_
     } while (0)
 
 __device__ __forceinline__ double ell_offdiag(const EllMat& A, const double* __restrict__ x, int c) {
+    // (a row's entries come first, its padding -- the cell itself with coefficient 0 -- after them: the loop ends at the first pad, so a mesh with a few many-faced cells
+    // pays their width in memory only, not in every row's traffic)
     double s = 0.0;
     for (int k = 0; k < A.W; ++k) {
         const size_t e = (size_t)k * A.n + c;
-        s += A.coef[e] * x[A.nbr[e]];
+        const int nb = A.nbr[e];
+        if (nb == c) break;
+        s += A.coef[e] * x[nb];
     }
     return s;
 }
@@ -93,6 +97,7 @@ __device__ __forceinline__ void row_two_from_zero(const EllMat& A, const double*
     for (int k = 0; k < A.W; ++k) {
         const size_t e = (size_t)k * A.n + c;
         const int nb = A.nbr[e];
+        if (nb == c) break;
         s += A.coef[e] * (wa * b[nb] * invd[nb]);
     }
     const double xc = wa * b[c] * invd[c];
@@ -109,6 +114,7 @@ __device__ __forceinline__ void row_prolong_smooth(const EllMat& A, const double
     for (int k = 0; k < A.W; ++k) {
         const size_t q = (size_t)k * A.n + c;
         const int nb = A.nbr[q];
+        if (nb == c) break;
         s += A.coef[q] * (x[nb] + e[agg[nb]]);
     }
     const double xc = x[c] + e[agg[c]];
