@@ -373,7 +373,9 @@ struct LduSolver {
                 if (keqn || keps) {                                                                               // kEqn::correct() / kEpsilon::correct(): epsilon first, then k with the new epsilon
                     LduMom Mk = M();
                     Mk.bdiag = nullptr;
-                    for (int mode = keps ? 1 : 0; mode == 0 || mode == 1 || (mode == 2 && keps); mode = mode == 1 ? 2 : 3) {
+                    const int modes[2] = {keps ? 1 : 0, 2};                                                       // (LduKEqn::mode) kEqn: k; kEpsilon: epsilon, then k
+                    for (int mi = 0; mi < (keps ? 2 : 1); ++mi) {
+                        const int mode = modes[mi];
                         LduKEqn K{};
                         K.mode = mode; K.ce = cs.les_ce; K.c1 = cs.ras_c1; K.c2 = cs.ras_c2; K.c3 = cs.ras_c3;
                         double tol, rel; int maxit;
