@@ -51,6 +51,11 @@ struct LduGeo {
     const double* gradL;                                 // [3 nc] Gauss-linear gradient of |U|^2 of the iterate the matrix is assembled from (limited schemes; else null)
     int need_ref, p_ref_cell;
     double p_ref_value;
+    // per-slot coefficients of the two widest gathers (built once on the device, k_ldu_slot_coefs), component-major and slot-major like the slot tables:
+    //   gB [3][Wall][nCells]: internal slot k of cell c: +-Sf w_nb / V (the neighbour's share of the face value in the cell's Gauss gradient); boundary slot: Sf / V
+    //   gG0 [3][nCells]:      the cell's own share, sum over its internal faces of +-Sf w_c / V
+    //   rT [3][Wall][nCells]: fvc::reconstruct's recon_c . Sf / |Sf| per slot
+    const double *gB, *gG0, *rT;
     const double* sep;                                   // [3 nInt] or null: folded cyclic faces -- the neighbour cell's image is C_N + sep_f (zero on the mesh's own internal faces)
     int nIntReal;                                        // faces [nIntReal, nInt) are folded cyclic pairs
 };
@@ -96,6 +101,7 @@ int ldu_red_blocks(int n);      // partials per slot of the reducing kernels (= 
 int launch_ldu_flux_of(hipStream_t s, LduGeo g, const double* F, double* phi);
 int launch_ldu_courant(hipStream_t s, LduGeo g, const double* phi, double* partials);                    // slot 0 = max sumPhi / V, slot 1 = sum sumPhi
 int launch_ldu_grad_vec(hipStream_t s, LduGeo g, const double* F, double* T);                           // T[9 c + 3 i + j] = d_i F_j
+int launch_ldu_slot_coefs(hipStream_t s, LduGeo g, double* gB, double* gG0, double* rT);
 int launch_ldu_grad_scalar(hipStream_t s, LduGeo g, const double* p, double* gp);
 int launch_ldu_grad_magsqr(hipStream_t s, LduGeo g, const double* U, double* gradL);                    // fvc::grad(magSqr(U)), boundary value magSqr(U_b): the limiters' gradient
 // UEqn (icoFoamYade.C:79-85): face part (lower / upper, the explicit non-orthogonal flux of the laplacian), then the cell part (diag, b)

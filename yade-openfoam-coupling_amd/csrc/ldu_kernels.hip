@@ -106,38 +106,75 @@ __global__ __launch_bounds__(256) void k_ldu_courant(LduGeo g, const double* __r
     block_reduce_store<2>(v, mx, partials);
 }
 
-// fvc::grad(F), Gauss linear: T[3 i + j] = (1/V) sum_f (+-Sf_i) F_f,j
+// fvc::grad(F), Gauss linear: T[3 i + j] = (1/V) sum_f (+-Sf_i) F_f,j -- through the slot coefficients: gG0_i F_c,j + sum_k gB_k,i F_(neighbour or patch value),j
 __global__ __launch_bounds__(256) void k_ldu_grad_vec(LduGeo g, const double* __restrict__ F, double* __restrict__ T) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= g.nCells) return;
-    double t[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    FY_CELL_FACES(g, c, f, nb) {
-        D3 uf; double sg = 1.0;
-        if (f < g.nInt) { const bool o = nb > c; uf = lerp3(g.w[f], ld3(F, o ? c : nb), ld3(F, o ? nb : c)); sg = o ? 1.0 : -1.0; }
-        else uf = Ub(g, F, f);
-        const D3 S = ld3(g.Sf, f);
-        const double s[3] = {sg * S.x, sg * S.y, sg * S.z}, u[3] = {uf.x, uf.y, uf.z};
+    const size_t n = (size_t)g.nCells, wn = (size_t)g.Wall * n;
+    const D3 fc = ld3(F, c);
+    const double g0[3] = {g.gG0[c], g.gG0[n + c], g.gG0[2 * n + c]}, u0[3] = {fc.x, fc.y, fc.z};
+    double t[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) t[3 * i + j] = g0[i] * u0[j];
+    for (int k = 0; k < g.Wall; ++k) {
+        const size_t e = (size_t)k * n + c;
+        const int nb = g.en[e];
+        if (nb == -2) break;
+        const D3 uf = nb >= 0 ? ld3(F, nb) : Ub(g, F, g.ef[e]);
+        const double s[3] = {g.gB[e], g.gB[wn + e], g.gB[2 * wn + e]}, u[3] = {uf.x, uf.y, uf.z};
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll
             for (int j = 0; j < 3; ++j) t[3 * i + j] += s[i] * u[j];
     }
-    const double rV = 1.0 / g.V[c];
 #pragma unroll
-    for (int e = 0; e < 9; ++e) T[9 * (size_t)c + e] = t[e] * rV;
+    for (int e = 0; e < 9; ++e) T[9 * (size_t)c + e] = t[e];
 }
 
-__device__ __forceinline__ D3 grad_scalar_at(const LduGeo& g, const double* __restrict__ p, int c) {
-    D3 a{0, 0, 0};
-    FY_CELL_FACES(g, c, f, nb) {
-        double pf, sg = 1.0;
-        if (f < g.nInt) { const bool o = nb > c; pf = g.w[f] * p[o ? c : nb] + (1.0 - g.w[f]) * p[o ? nb : c]; sg = o ? 1.0 : -1.0; }
-        else pf = pbv(g, p, f);
-        const D3 S = ld3(g.Sf, f);
-        a.x += sg * S.x * pf; a.y += sg * S.y * pf; a.z += sg * S.z * pf;
-    }
+// the per-slot coefficients (LduGeo::gB, gG0, rT): one lane per cell, once at set-up
+__global__ __launch_bounds__(256) void k_ldu_slot_coefs(LduGeo g, double* __restrict__ gB, double* __restrict__ gG0, double* __restrict__ rT) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= g.nCells) return;
+    const size_t n = (size_t)g.nCells, wn = (size_t)g.Wall * n;
     const double rV = 1.0 / g.V[c];
-    return D3{a.x * rV, a.y * rV, a.z * rV};
+    const double* R = g.recon + 9 * (size_t)c;
+    double g0[3] = {0, 0, 0};
+    for (int k = 0; k < g.Wall; ++k) {
+        const size_t e = (size_t)k * n + c;
+        const int f = g.ef[e];
+        double b[3] = {0, 0, 0}, t[3] = {0, 0, 0};
+        if (f >= 0) {
+            const int nb = g.en[e];
+            const D3 S = ld3(g.Sf, f);
+            const double s3[3] = {S.x, S.y, S.z}, rm = 1.0 / g.magSf[f];
+            double sg = 1.0, wnb = 1.0, wc = 0.0;
+            if (f < g.nInt) { const bool o = nb > c; sg = o ? 1.0 : -1.0; wc = o ? g.w[f] : 1.0 - g.w[f]; wnb = o ? 1.0 - g.w[f] : g.w[f]; }
+#pragma unroll
+            for (int q = 0; q < 3; ++q) { b[q] = sg * s3[q] * wnb * rV; g0[q] += sg * s3[q] * wc * rV; }
+#pragma unroll
+            for (int q = 0; q < 3; ++q) t[q] = (R[3 * q] * s3[0] + R[3 * q + 1] * s3[1] + R[3 * q + 2] * s3[2]) * rm;
+        }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { gB[q * wn + e] = b[q]; rT[q * wn + e] = t[q]; }
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) gG0[q * n + c] = g0[q];
+}
+// Gauss-linear gradient of a scalar through the slot coefficients: grad_c = gG0_c p_c + sum_k gB_k p_(neighbour or patch value)
+__device__ __forceinline__ D3 grad_scalar_at(const LduGeo& g, const double* __restrict__ p, int c) {
+    const size_t n = (size_t)g.nCells, wn = (size_t)g.Wall * n;
+    const double pc = p[c];
+    D3 a{g.gG0[c] * pc, g.gG0[n + c] * pc, g.gG0[2 * n + c] * pc};
+    for (int k = 0; k < g.Wall; ++k) {
+        const size_t e = (size_t)k * n + c;
+        const int nb = g.en[e];
+        if (nb == -2) break;
+        const double v = nb >= 0 ? p[nb] : pbv(g, p, g.ef[e]);
+        a.x += g.gB[e] * v; a.y += g.gB[wn + e] * v; a.z += g.gB[2 * wn + e] * v;
+    }
+    return a;
 }
 __global__ __launch_bounds__(256) void k_ldu_grad_scalar(LduGeo g, const double* __restrict__ p, double* __restrict__ gp) {
     const int c = blockIdx.x * 256 + threadIdx.x;
@@ -796,17 +833,18 @@ __global__ __launch_bounds__(256) void k_ldu_reconstruct(LduGeo g, const double*
                                                          double* __restrict__ out) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= g.nCells) return;
-    double a[3] = {0, 0, 0};
-    FY_CELL_FACES(g, c, f, nb) {
-        const D3 S = ld3(g.Sf, f);
-        const double t = ssf[f] / g.magSf[f];
-        a[0] += S.x * t; a[1] += S.y * t; a[2] += S.z * t;
-        (void)nb;
+    const size_t n = (size_t)g.nCells, wn = (size_t)g.Wall * n;
+    double a[3] = {0, 0, 0};                                   // recon_c . sum_f (Sf / |Sf|) ssf_f, the tensor folded into the slot coefficients (LduGeo::rT)
+    for (int k = 0; k < g.Wall; ++k) {
+        const size_t e = (size_t)k * n + c;
+        const int f = g.ef[e];
+        if (f < 0) break;
+        const double t = ssf[f];
+        a[0] += g.rT[e] * t; a[1] += g.rT[wn + e] * t; a[2] += g.rT[2 * wn + e] * t;
     }
-    const double* R = g.recon + 9 * (size_t)c;
     const D3 b = ld3(base, c);
     const double sc = scale[c];
-    st3(out, c, D3{b.x + sc * (R[0] * a[0] + R[1] * a[1] + R[2] * a[2]), b.y + sc * (R[3] * a[0] + R[4] * a[1] + R[5] * a[2]), b.z + sc * (R[6] * a[0] + R[7] * a[1] + R[8] * a[2])});
+    st3(out, c, D3{b.x + sc * a[0], b.y + sc * a[1], b.z + sc * a[2]});
 }
 
 // pEqn.H:4-21 after adjustPhi: phiHbyA += phicForces; constrainPressure: snGrad(p) = (phiHbyA - Sf . U_b) / (|Sf| rAUcf) on the fixedFluxPressure faces
@@ -939,6 +977,11 @@ int launch_ldu_courant(hipStream_t s, LduGeo g, const double* phi, double* parti
 }
 int launch_ldu_grad_vec(hipStream_t s, LduGeo g, const double* F, double* T) {
     hipLaunchKernelGGL(k_ldu_grad_vec, dim3(div_up(g.nCells, 256)), dim3(256), 0, s, g, F, T);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+int launch_ldu_slot_coefs(hipStream_t s, LduGeo g, double* gB, double* gG0, double* rT) {
+    hipLaunchKernelGGL(k_ldu_slot_coefs, dim3(div_up(g.nCells, 256)), dim3(256), 0, s, g, gB, gG0, rT);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }

@@ -165,7 +165,7 @@ int LduHostMesh::build(const fy_poly_mesh* m_in) {
     }
     Wall = 0;
     for (int c = 0; c < nCells; ++c) Wall = std::max(Wall, cf_off[(size_t)c + 1] - cf_off[(size_t)c]);
-    ef.assign((size_t)Wall * nCells, -1); en.assign((size_t)Wall * nCells, -1);
+    ef.assign((size_t)Wall * nCells, -1); en.assign((size_t)Wall * nCells, -2);      // (pads: face -1, neighbour -2; a boundary face's neighbour is -1)
     for (int c = 0; c < nCells; ++c)
         for (int32_t q = cf_off[(size_t)c]; q < cf_off[(size_t)c + 1]; ++q) {
             const int f = cf_face[(size_t)q];

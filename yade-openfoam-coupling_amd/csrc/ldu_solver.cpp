@@ -50,6 +50,7 @@ struct LduSolver {
     DevBuf<int> adj_err;
     bool need_ref = true, ext_source = false, has_slip = false;
     std::vector<double> orig_face_d;      // hm.orig_face as doubles (the field read-out's type); empty without a cyclic pair
+    DevBuf<double> d_gB, d_gG0, d_rT;      // the per-slot coefficients of the scalar gradient and of fvc::reconstruct (LduGeo)
     DevBuf<double> d_sep;        // folded cyclic faces: the neighbour image's offset per internal face
     DevBuf<double> mbdiag;       // symmetry patches: the momentum matrix's per-component boundary diagonal
     LduAmg amg;                  // the pressure matrix in ELL form; with p_solver = FY_PSOLVER_PCG_MG also the agglomeration hierarchy
@@ -121,6 +122,9 @@ struct LduSolver {
         if (pimple) { FY_TRY(psn.alloc_exact(std::max<size_t>((size_t)(nf - ni), 1))); FY_TRY(zero(psn)); }
         g = LduGeo{nc, nf, ni, hm.nPatches, d_own.p, d_nei.p, d_patch_of.p, d_cf_off.p, d_cf_face.p, hm.Wall, d_ef.p, d_en.p, d_Cf.p, d_Sf.p, d_magSf.p, d_C.p, d_V.p, d_w.p, d_dcNO.p, d_kvec.p,
                    d_ubc.p, d_pbc.p, d_uval.p, d_pval.p, d_recon.p, pimple ? psn.p : nullptr, cs.dt, cs.nu, cs.convection_scheme, 2.0 / std::max(cs.convection_limiter_k, 1e-15), nullptr, need_ref ? 1 : 0, cs.p_ref_cell, cs.p_ref_value};
+        FY_TRY(d_gB.alloc_exact(3 * (size_t)hm.Wall * nc)); FY_TRY(d_gG0.alloc_exact(3 * (size_t)nc)); FY_TRY(d_rT.alloc_exact(3 * (size_t)hm.Wall * nc));
+        FY_TRY(launch_ldu_slot_coefs(stream, g, d_gB.p, d_gG0.p, d_rT.p));
+        g.gB = d_gB.p; g.gG0 = d_gG0.p; g.rT = d_rT.p;
         if (!hm.sep.empty()) { FY_TRY(up(d_sep, hm.sep)); g.sep = d_sep.p; }
         g.nIntReal = hm.n_real_internal;
         orig_face_d.assign(hm.orig_face.begin(), hm.orig_face.end());
