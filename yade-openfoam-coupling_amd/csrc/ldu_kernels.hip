@@ -614,9 +614,9 @@ __global__ __launch_bounds__(256) void k_ldu_pmom_faces(LduGeo g, LduPim P, cons
             const double go = ao * (To[3 * b + a] - (a == b ? (2.0 / 3.0) * tro : 0.0)), gn = an * (Tn[3 * b + a] - (a == b ? (2.0 / 3.0) * trn : 0.0));
             t += ss[a] * (w * go + (1.0 - w) * gn);
         }
-        corr[3 * (size_t)f + b] = gm * cj - lu[b];
-        fstress[3 * (size_t)f + b] = t;
+        fstress[3 * (size_t)f + b] = (gm * cj - lu[b]) + t;      // the two explicit fluxes of a face enter every sum together: one vector (corr is not written)
     }
+    (void)corr;
 }
 // ... cell part: fvm::ddt(alphac, Uc), negSumDiag, the patches, - fvm::Sp(fvc::ddt(alphac) + fvc::div(alphaPhic)), == fvm::Sp(uSourceDrag), the explicit fluxes'
 // divergences on the right-hand side, UcEqn.relax() [OF-6 fvMatrix::relax: D = max(|D|, sum |offdiag|) / factor, source += (D_new - D) psi; no factor: nothing]
@@ -634,12 +634,11 @@ __global__ __launch_bounds__(256) void k_ldu_pmom_cells(LduGeo g, LduPim P, cons
     double bd[3] = {0, 0, 0}, bmax = 0.0, bmin = 0.0;
     const D3 uc = ld3(U, c);
     FY_CELL_FACES(g, c, f, nb) {
-        const D3 st = ld3(fstress, f);
+        const D3 st = ld3(fstress, f);                          // (internal faces: the corrected laplacian's explicit flux, linearUpwind's and the explicit stress's, summed by the face kernel)
         if (f < g.nInt) {
-            const D3 cr = ld3(corr, f);
             const double fl = alphaf[f] * phi[f];
-            if (nb > c) { dg -= M.lower[f]; offsum += fabs(M.upper[f]); divAPhi += fl; b[0] += cr.x + st.x; b[1] += cr.y + st.y; b[2] += cr.z + st.z; }
-            else { dg -= M.upper[f]; offsum += fabs(M.lower[f]); divAPhi -= fl; b[0] -= cr.x + st.x; b[1] -= cr.y + st.y; b[2] -= cr.z + st.z; }
+            if (nb > c) { dg -= M.lower[f]; offsum += fabs(M.upper[f]); divAPhi += fl; b[0] += st.x; b[1] += st.y; b[2] += st.z; }
+            else { dg -= M.upper[f]; offsum += fabs(M.lower[f]); divAPhi -= fl; b[0] -= st.x; b[1] -= st.y; b[2] -= st.z; }
         } else {
             const int pa = g.patch_of[f - g.nInt];
             divAPhi += phi[f];
