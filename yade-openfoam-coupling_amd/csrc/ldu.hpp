@@ -114,7 +114,7 @@ int launch_ldu_HbyA(hipStream_t s, LduGeo g, LduMom M, const double* U, double* 
 int launch_ldu_phiHbyA(hipStream_t s, LduGeo g, const double* HbyA, const double* rAU, const double* Uold, const double* phiOld, const double* alphaf /* or null */, double* rAUf, double* phiHbyA);
 int launch_ldu_adjust_phi(hipStream_t s, LduGeo g, double* phiHbyA, double* sums4 /* device scratch */, int* err, double* partials);
 // pEqn (icoFoamYade.C:118-123): face part (coefficients, the explicit non-orthogonal flux from grad p), cell part (diag, right-hand side, setReference)
-int launch_ldu_assemble_pressure(hipStream_t s, LduGeo g, const double* rAUf, const double* phiHbyA, const double* gradp, double* pcoef, double* pcorr, double* pdiag, double* prhs);
+int launch_ldu_assemble_pressure(hipStream_t s, LduGeo g, const double* rAUf, const double* phiHbyA, const double* gradp, double* pcoef, double* pcorr, double* pt, double* pdiag, double* prhs);
 // r = b - A x with slot 0 = sum |r|, slot 1 = normFactor terms (xbar from xsum); the iterations run on the ELL form (ldu_amg.hpp)
 int launch_ldu_p_init(hipStream_t s, LduGeo g, const double* pdiag, const double* pcoef, const double* b, const double* x, const double* xsum, double inv_n, double* r, double* partials);
 int launch_ldu_flux_correct(hipStream_t s, LduGeo g, const double* p, const double* phiHbyA, const double* pcoef, const double* pcorr, double* phi);

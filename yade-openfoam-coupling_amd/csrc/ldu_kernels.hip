@@ -418,27 +418,35 @@ __global__ __launch_bounds__(256) void k_ldu_adjust_apply(LduGeo g, const double
 
 // pEqn, face part (icoFoamYade.C:118-121): c_f = rAUf |Sf| nonOrthDeltaCoeffs, and the corrected scheme's explicit flux rAUf |Sf| (k & interpolate(grad p))
 // from the pressure as it stands -- what each pass of the correctNonOrthogonal loop (icoFoamYade.C:114-131) renews
-__global__ __launch_bounds__(256) void k_ldu_p_faces(LduGeo g, const double* __restrict__ rAUf, const double* __restrict__ gradp, double* __restrict__ pcoef, double* __restrict__ pcorr) {
+// (pt: the face's contribution to the right-hand side, -phiHbyA + the explicit flux, for the cell part: one gather there instead of two)
+__global__ __launch_bounds__(256) void k_ldu_p_faces(LduGeo g, const double* __restrict__ rAUf, const double* __restrict__ gradp, const double* __restrict__ phiHbyA,
+                                                     double* __restrict__ pcoef, double* __restrict__ pcorr, double* __restrict__ pt) {
     const int f = blockIdx.x * 256 + threadIdx.x;
     if (f >= g.nFaces) return;
     const double gm = rAUf[f] * g.magSf[f];
     pcoef[f] = gm * g.dcNO[f];
-    if (f < g.nInt) pcorr[f] = gm * dot3(ld3(g.kvec, f), lerp3(g.w[f], ld3(gradp, g.own[f]), ld3(gradp, g.nei[f])));
+    double t = -phiHbyA[f];
+    if (f < g.nInt) {
+        const double pc = gm * dot3(ld3(g.kvec, f), lerp3(g.w[f], ld3(gradp, g.own[f]), ld3(gradp, g.nei[f])));
+        pcorr[f] = pc;
+        t += pc;
+    }
+    pt[f] = t;
 }
 // ... cell part, in the positive form  sum_f c_f (p_P - p_N) + sum_b c_b (p_P - p_b) = -div(phiHbyA) + div(explicit flux);  fvMatrix::setReference
-__global__ __launch_bounds__(256) void k_ldu_p_cells(LduGeo g, const double* __restrict__ phiHbyA, const double* __restrict__ pcoef, const double* __restrict__ pcorr,
+__global__ __launch_bounds__(256) void k_ldu_p_cells(LduGeo g, const double* __restrict__ pt, const double* __restrict__ pcoef,
                                                      double* __restrict__ pdiag, double* __restrict__ prhs) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= g.nCells) return;
     double dg = 0.0, b = 0.0;
     FY_CELL_FACES(g, c, f, nb) {
+        const double t = pt[f];
         if (f < g.nInt) {
             dg += pcoef[f];
-            const double t = -phiHbyA[f] + pcorr[f];
             b += nb > c ? t : -t;
         } else {
             const int pa = g.patch_of[f - g.nInt];
-            b -= phiHbyA[f];
+            b += t;
             if (g.p_bc[pa] == FY_BC_P_FIXED_VALUE) { dg += pcoef[f]; b += pcoef[f] * g.p_val[pa]; }
         }
     }
@@ -1024,9 +1032,9 @@ int launch_ldu_adjust_phi(hipStream_t s, LduGeo g, double* phiHbyA, double* sums
     FY_LAUNCH_CHECK();
     return FY_OK;
 }
-int launch_ldu_assemble_pressure(hipStream_t s, LduGeo g, const double* rAUf, const double* phiHbyA, const double* gradp, double* pcoef, double* pcorr, double* pdiag, double* prhs) {
-    hipLaunchKernelGGL(k_ldu_p_faces, dim3(div_up(g.nFaces, 256)), dim3(256), 0, s, g, rAUf, gradp, pcoef, pcorr);
-    hipLaunchKernelGGL(k_ldu_p_cells, dim3(div_up(g.nCells, 256)), dim3(256), 0, s, g, phiHbyA, pcoef, pcorr, pdiag, prhs);
+int launch_ldu_assemble_pressure(hipStream_t s, LduGeo g, const double* rAUf, const double* phiHbyA, const double* gradp, double* pcoef, double* pcorr, double* pt, double* pdiag, double* prhs) {
+    hipLaunchKernelGGL(k_ldu_p_faces, dim3(div_up(g.nFaces, 256)), dim3(256), 0, s, g, rAUf, gradp, phiHbyA, pcoef, pcorr, pt);
+    hipLaunchKernelGGL(k_ldu_p_cells, dim3(div_up(g.nCells, 256)), dim3(256), 0, s, g, pt, pcoef, pdiag, prhs);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }

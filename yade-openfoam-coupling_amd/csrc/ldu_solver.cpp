@@ -51,6 +51,7 @@ struct LduSolver {
     bool need_ref = true, ext_source = false, has_slip = false;
     std::vector<double> orig_face_d;      // hm.orig_face as doubles (the field read-out's type); empty without a cyclic pair
     DevBuf<double> d_gB, d_gG0, d_rT;      // the per-slot coefficients of the scalar gradient and of fvc::reconstruct (LduGeo)
+    DevBuf<double> pt;           // per face: -phiHbyA + the corrected laplacian's explicit flux (what the pressure equation's cell part sums)
     DevBuf<double> d_sep;        // folded cyclic faces: the neighbour image's offset per internal face
     DevBuf<double> mbdiag;       // symmetry patches: the momentum matrix's per-component boundary diagonal
     LduAmg amg;                  // the pressure matrix in ELL form; with p_solver = FY_PSOLVER_PCG_MG also the agglomeration hierarchy
@@ -137,7 +138,7 @@ struct LduSolver {
         for (auto* b : v1) { FY_TRY(b->alloc_exact(n)); FY_TRY(zero(*b)); }
         FY_TRY(vGrad.alloc_exact(9 * n)); FY_TRY(zero(vGrad));
         if (has_slip) { FY_TRY(mbdiag.alloc_exact(3 * n)); FY_TRY(zero(mbdiag)); }
-        DevBuf<double>* vf[] = {&phi, &phiOld, &rAUf, &phiHbyA, &pcoef};
+        DevBuf<double>* vf[] = {&phi, &phiOld, &rAUf, &phiHbyA, &pcoef, &pt};
         for (auto* b : vf) { FY_TRY(b->alloc_exact((size_t)nf)); FY_TRY(zero(*b)); }
         DevBuf<double>* vi[] = {&mlower, &mupper, &pcorr};
         for (auto* b : vi) { FY_TRY(b->alloc_exact(std::max<size_t>((size_t)ni, 1))); FY_TRY(zero(*b)); }
@@ -301,7 +302,7 @@ struct LduSolver {
         if (need_ref) FY_TRY(launch_ldu_adjust_phi(stream, g, phiHbyA.p, adj.p, adj_err.p, partials.p));                      // :108
         for (int no = 0; no <= cs.n_non_orth_correctors; ++no) {                                                   // :114-131
             FY_TRY(launch_ldu_grad_scalar(stream, g, p.p, gradp.p));
-            FY_TRY(launch_ldu_assemble_pressure(stream, g, rAUf.p, phiHbyA.p, gradp.p, pcoef.p, pcorr.p, pdiag.p, prhs.p));
+            FY_TRY(launch_ldu_assemble_pressure(stream, g, rAUf.p, phiHbyA.p, gradp.p, pcoef.p, pcorr.p, pt.p, pdiag.p, prhs.p));
             if (no == 0) FY_TRY(amg.setup(stream, pcoef.p, pdiag.p));          // (the non-orthogonal passes renew the right-hand side only)
             FY_TRY(solve_pressure(final_corr && no == cs.n_non_orth_correctors));
             if (no == cs.n_non_orth_correctors) FY_TRY(launch_ldu_flux_correct(stream, g, p.p, phiHbyA.p, pcoef.p, pcorr.p, phi.p));
@@ -324,7 +325,7 @@ struct LduSolver {
         FY_TRY(launch_ldu_pim_pfaces(stream, g, alphaf.p, rAUf.p, phiHbyA.p, psn.p, arAUf.p, phiA.p));
         for (int no = 0; no <= cs.n_non_orth_correctors; ++no) {                                                   // :24-47
             FY_TRY(launch_ldu_grad_scalar(stream, g, p.p, gradp.p));
-            FY_TRY(launch_ldu_assemble_pressure(stream, g, arAUf.p, phiA.p, gradp.p, pcoef.p, pcorr.p, pdiag.p, prhs.p));
+            FY_TRY(launch_ldu_assemble_pressure(stream, g, arAUf.p, phiA.p, gradp.p, pcoef.p, pcorr.p, pt.p, pdiag.p, prhs.p));
             // (fvc::ddt(alphac), :30, is zero: alphac.oldTime() == alphac -- P())
             if (no == 0) FY_TRY(amg.setup(stream, pcoef.p, pdiag.p));
             FY_TRY(solve_pressure(final_corr && no == cs.n_non_orth_correctors));
