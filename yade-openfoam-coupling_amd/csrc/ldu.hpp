@@ -116,7 +116,8 @@ int launch_ldu_adjust_phi(hipStream_t s, LduGeo g, double* phiHbyA, double* sums
 // pEqn (icoFoamYade.C:118-123): face part (coefficients, the explicit non-orthogonal flux from grad p), cell part (diag, right-hand side, setReference)
 int launch_ldu_assemble_pressure(hipStream_t s, LduGeo g, const double* rAUf, const double* phiHbyA, const double* gradp, double* pcoef, double* pcorr, double* pt, double* pdiag, double* prhs);
 // r = b - A x with slot 0 = sum |r|, slot 1 = normFactor terms (xbar from xsum); the iterations run on the ELL form (ldu_amg.hpp)
-int launch_ldu_p_init(hipStream_t s, LduGeo g, const double* pdiag, const double* pcoef, const double* b, const double* x, const double* xsum, double inv_n, double* r, double* partials);
+int launch_ldu_p_init(hipStream_t s, LduGeo g, const double* pdiag, int ellW, const int32_t* ell_nbr, const double* ell_coef, const double* b, const double* x, const double* xsum, double inv_n,
+                      double* r, double* partials);
 int launch_ldu_flux_correct(hipStream_t s, LduGeo g, const double* p, const double* phiHbyA, const double* pcoef, const double* pcorr, double* phi);
 // U = HbyA - rAU grad(p) (gradient formed inline) + continuity sums (slot 0 sum |div phi|, slot 1 sum div phi)
 int launch_ldu_U_correct(hipStream_t s, LduGeo g, const double* HbyA, const double* rAU, const double* p, const double* phi, double* U, double* partials);

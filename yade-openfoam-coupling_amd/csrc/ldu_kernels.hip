@@ -454,25 +454,23 @@ __global__ __launch_bounds__(256) void k_ldu_p_cells(LduGeo g, const double* __r
     pdiag[c] = dg; prhs[c] = b;
 }
 
-__device__ __forceinline__ double p_offdiag(const LduGeo& g, const double* __restrict__ pcoef, const double* __restrict__ x, int c, double* coefsum) {
-    double s = 0.0, cs = 0.0;
-    FY_CELL_FACES(g, c, f, nb) {
-        if (f >= g.nInt) continue;
-        const double a = pcoef[f];
-        s += a * x[nb];
-        cs += a;
-    }
-    if (coefsum) *coefsum = cs;
-    return s;
-}
 // r = b - A x; slot 0 = sum |r|, slot 1 = sum (|A x - A xbar| + |b - A xbar|)  [OF-6 lduMatrix::solver::normFactor]
-__global__ __launch_bounds__(256) void k_ldu_p_init(LduGeo g, const double* __restrict__ pdiag, const double* __restrict__ pcoef, const double* __restrict__ b,
-                                                    const double* __restrict__ x, const double* __restrict__ xsum, double inv_n, double* __restrict__ r, double* __restrict__ partials) {
+// (the row through the ELL form of the matrix -- ell_nbr / ell_coef [W nCells], the same coefficients in the same order, coalesced -- instead of a gather by face number)
+__global__ __launch_bounds__(256) void k_ldu_p_init(LduGeo g, const double* __restrict__ pdiag, int ellW, const int32_t* __restrict__ ell_nbr, const double* __restrict__ ell_coef,
+                                                    const double* __restrict__ b, const double* __restrict__ x, const double* __restrict__ xsum, double inv_n, double* __restrict__ r,
+                                                    double* __restrict__ partials) {
     double v[2] = {0, 0};
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c < g.nCells) {
-        double cs;
-        const double off = p_offdiag(g, pcoef, x, c, &cs);
+        double cs = 0.0, off = 0.0;
+        for (int k = 0; k < ellW; ++k) {
+            const size_t e = (size_t)k * g.nCells + c;
+            const int nb = ell_nbr[e];
+            if (nb == c) break;
+            const double a = ell_coef[e];
+            off += a * x[nb];
+            cs += a;
+        }
         const double Ax = pdiag[c] * x[c] - off, Aref = (pdiag[c] - cs) * (xsum[0] * inv_n);
         const double rr = b[c] - Ax;
         r[c] = rr;
@@ -1038,8 +1036,9 @@ int launch_ldu_assemble_pressure(hipStream_t s, LduGeo g, const double* rAUf, co
     FY_LAUNCH_CHECK();
     return FY_OK;
 }
-int launch_ldu_p_init(hipStream_t s, LduGeo g, const double* pdiag, const double* pcoef, const double* b, const double* x, const double* xsum, double inv_n, double* r, double* partials) {
-    hipLaunchKernelGGL(k_ldu_p_init, dim3(red_blocks(g.nCells)), dim3(256), 0, s, g, pdiag, pcoef, b, x, xsum, inv_n, r, partials);
+int launch_ldu_p_init(hipStream_t s, LduGeo g, const double* pdiag, int ellW, const int32_t* ell_nbr, const double* ell_coef, const double* b, const double* x, const double* xsum, double inv_n,
+                      double* r, double* partials) {
+    hipLaunchKernelGGL(k_ldu_p_init, dim3(red_blocks(g.nCells)), dim3(256), 0, s, g, pdiag, ellW, ell_nbr, ell_coef, b, x, xsum, inv_n, r, partials);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }

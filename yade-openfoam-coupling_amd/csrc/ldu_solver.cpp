@@ -267,7 +267,7 @@ struct LduSolver {
         double h[2];
         FY_TRY(launch_ldu_sum(stream, p.p, nc, 1, partials.p));
         FY_TRY(launch_reduce_finalize(stream, partials.p, nc, 1, nullptr, xsum.p, nullptr, 0));
-        FY_TRY(launch_ldu_p_init(stream, g, pdiag.p, pcoef.p, prhs.p, p.p, xsum.p, 1.0 / (double)nc, pr.p, partials.p));
+        { const EllMat A0 = amg.lev[0]->mat(); FY_TRY(launch_ldu_p_init(stream, g, pdiag.p, A0.W, A0.nbr, A0.coef, prhs.p, p.p, xsum.p, 1.0 / (double)nc, pr.p, partials.p)); }
         FY_TRY(reduce_read(nc, 2, nullptr, h));
         const double norm = h[1] + 1e-20;
         double res = h[0] / norm;
