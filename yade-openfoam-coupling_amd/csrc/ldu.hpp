@@ -124,7 +124,7 @@ int launch_ldu_U_correct(hipStream_t s, LduGeo g, const double* HbyA, const doub
 // ---- pimpleFoamYade (pimpleFoamYade.C:60-114, UcEqn.H, pEqn.H); see the kernels' comments
 int launch_ldu_alphaf(hipStream_t s, LduGeo g, const double* alpha, double* alphaf);
 int launch_ldu_pre_coupling(hipStream_t s, LduGeo g, const double* phi, const double* U, const double* vGrad, const double* alphaf, double* ddtU, double* divT);
-int launch_ldu_assemble_momentum_pimple(hipStream_t s, LduGeo g, LduPim P, const double* phi, const double* Uold, const double* U, const double* gradU, LduMom M, double* face_corr,
+int launch_ldu_assemble_momentum_pimple(hipStream_t s, LduGeo g, LduPim P, const double* phi, const double* Uold, const double* U, const double* gradU, LduMom M, double* aphi /* [nF] scratch: alphaPhic */,
                                         double* fstress /* [3 nF] */, double u_relax, double* rAU);
 int launch_ldu_smagorinsky_nut(hipStream_t s, LduGeo g, const double* vGrad, double ck, double ce, double delta_coeff, double* nut);
 // LES kEqn: the k equation's matrix into M (face part, then cells: diag, b[3 c] = the source, b[3 c + 1 .. 2] = 0), x3 = (k, 0, 0); after the solve bound() and nut

@@ -581,7 +581,7 @@ __device__ __forceinline__ double ldu_nut_b(const LduGeo& g, const LduPim& P, in
     return P.nut[c];
 }
 __global__ __launch_bounds__(256) void k_ldu_pmom_faces(LduGeo g, LduPim P, const double* __restrict__ phi, const double* __restrict__ U, const double* __restrict__ alpha, const double* __restrict__ alphaf,
-                                                        const double* __restrict__ gradU, LduMom M, double* __restrict__ corr, double* __restrict__ fstress) {
+                                                        const double* __restrict__ gradU, LduMom M, double* __restrict__ aphi, double* __restrict__ fstress) {
     const int f = blockIdx.x * 256 + threadIdx.x;
     if (f >= g.nFaces) return;
     const D3 S = ld3(g.Sf, f);
@@ -597,12 +597,14 @@ __global__ __launch_bounds__(256) void k_ldu_pmom_faces(LduGeo g, LduPim P, cons
             for (int a = 0; a < 3; ++a) t += ss[a] * (ao * (To[3 * b + a] - (a == b ? (2.0 / 3.0) * tro : 0.0)));
             fstress[3 * (size_t)f + b] = t;
         }
+        aphi[f] = phi[f];                                    // (alphac's boundary value is 1)
         return;
     }
     const int n = g.nei[f];
     const double* Tn = gradU + 9 * (size_t)n;
     const double trn = Tn[0] + Tn[4] + Tn[8], an = alpha[n] * (g.nu + (P.nut ? P.nut[n] : 0.0)), w = g.w[f];
     const double af = alphaf[f], fl = af * phi[f], gm = (P.nut ? w * ao + (1.0 - w) * an : g.nu * af) * g.magSf[f];
+    aphi[f] = fl;                                            // alphaPhic: the cell part gathers this ONE face array instead of alphaf and phi
     double lo = -ldu_conv_weight(g, f, fl, U) * fl;
     double up = lo + fl;
     lo -= gm * g.dcNO[f]; up -= gm * g.dcNO[f];
@@ -620,15 +622,14 @@ __global__ __launch_bounds__(256) void k_ldu_pmom_faces(LduGeo g, LduPim P, cons
             const double go = ao * (To[3 * b + a] - (a == b ? (2.0 / 3.0) * tro : 0.0)), gn = an * (Tn[3 * b + a] - (a == b ? (2.0 / 3.0) * trn : 0.0));
             t += ss[a] * (w * go + (1.0 - w) * gn);
         }
-        fstress[3 * (size_t)f + b] = (gm * cj - lu[b]) + t;      // the two explicit fluxes of a face enter every sum together: one vector (corr is not written)
+        fstress[3 * (size_t)f + b] = (gm * cj - lu[b]) + t;      // the two explicit fluxes of a face enter every sum together: one vector
     }
-    (void)corr;
 }
 // ... cell part: fvm::ddt(alphac, Uc), negSumDiag, the patches, - fvm::Sp(fvc::ddt(alphac) + fvc::div(alphaPhic)), == fvm::Sp(uSourceDrag), the explicit fluxes'
 // divergences on the right-hand side, UcEqn.relax() [OF-6 fvMatrix::relax: D = max(|D|, sum |offdiag|) / factor, source += (D_new - D) psi; no factor: nothing]
 __global__ __launch_bounds__(256) void k_ldu_pmom_cells(LduGeo g, LduPim P, const double* __restrict__ phi, const double* __restrict__ alpha, const double* __restrict__ alphaOld,
                                                         const double* __restrict__ alphaf, const double* __restrict__ Uold, const double* __restrict__ U,
-                                                        const double* __restrict__ uSourceDrag, LduMom M, const double* __restrict__ corr, const double* __restrict__ fstress,
+                                                        const double* __restrict__ uSourceDrag, LduMom M, const double* __restrict__ aphi, const double* __restrict__ fstress,
                                                         double u_relax, double* __restrict__ rAU) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= g.nCells) return;
@@ -641,22 +642,22 @@ __global__ __launch_bounds__(256) void k_ldu_pmom_cells(LduGeo g, LduPim P, cons
     const D3 uc = ld3(U, c);
     FY_CELL_FACES(g, c, f, nb) {
         const D3 st = ld3(fstress, f);                          // (internal faces: the corrected laplacian's explicit flux, linearUpwind's and the explicit stress's, summed by the face kernel)
+        const double fl = aphi[f];
         if (f < g.nInt) {
-            const double fl = alphaf[f] * phi[f];
             if (nb > c) { dg -= M.lower[f]; offsum += fabs(M.upper[f]); divAPhi += fl; b[0] += st.x; b[1] += st.y; b[2] += st.z; }
             else { dg -= M.upper[f]; offsum += fabs(M.lower[f]); divAPhi -= fl; b[0] -= st.x; b[1] -= st.y; b[2] -= st.z; }
         } else {
             const int pa = g.patch_of[f - g.nInt];
-            divAPhi += phi[f];
+            divAPhi += fl;                                     // (= phi on a boundary face)
             b[0] += st.x; b[1] += st.y; b[2] += st.z;
             if (g.u_bc[pa] == FY_BC_U_FIXED_VALUE) {
                 const double gm = (g.nu + ldu_nut_b(g, P, f)) * g.magSf[f] * g.dcNO[f];
                 const D3 ub = ld3(g.u_val, pa);
                 dg += gm;
-                b[0] += (-phi[f] + gm) * ub.x; b[1] += (-phi[f] + gm) * ub.y; b[2] += (-phi[f] + gm) * ub.z;
+                b[0] += (-fl + gm) * ub.x; b[1] += (-fl + gm) * ub.y; b[2] += (-fl + gm) * ub.z;
             } else {
                 if (g.u_bc[pa] == FY_BC_U_SLIP) slip_face(g, f, (g.nu + ldu_nut_b(g, P, f)) * g.magSf[f] * g.dcNO[f], uc, bd, b, bmax, bmin);
-                dg += phi[f];
+                dg += fl;
             }
         }
     }
@@ -1064,10 +1065,10 @@ int launch_ldu_pre_coupling(hipStream_t s, LduGeo g, const double* phi, const do
     FY_LAUNCH_CHECK();
     return FY_OK;
 }
-int launch_ldu_assemble_momentum_pimple(hipStream_t s, LduGeo g, LduPim P, const double* phi, const double* Uold, const double* U, const double* gradU, LduMom M, double* face_corr,
+int launch_ldu_assemble_momentum_pimple(hipStream_t s, LduGeo g, LduPim P, const double* phi, const double* Uold, const double* U, const double* gradU, LduMom M, double* aphi /* [nF] scratch: alphaPhic */,
                                         double* fstress, double u_relax, double* rAU) {
-    hipLaunchKernelGGL(k_ldu_pmom_faces, dim3(div_up(g.nFaces, 256)), dim3(256), 0, s, g, P, phi, U, P.alpha, P.alphaf, gradU, M, face_corr, fstress);
-    hipLaunchKernelGGL(k_ldu_pmom_cells, dim3(div_up(g.nCells, 256)), dim3(256), 0, s, g, P, phi, P.alpha, P.alphaOld, P.alphaf, Uold, U, P.uSourceDrag, M, face_corr, fstress, u_relax, rAU);
+    hipLaunchKernelGGL(k_ldu_pmom_faces, dim3(div_up(g.nFaces, 256)), dim3(256), 0, s, g, P, phi, U, P.alpha, P.alphaf, gradU, M, aphi, fstress);
+    hipLaunchKernelGGL(k_ldu_pmom_cells, dim3(div_up(g.nCells, 256)), dim3(256), 0, s, g, P, phi, P.alpha, P.alphaOld, P.alphaf, Uold, U, P.uSourceDrag, M, aphi, fstress, u_relax, rAU);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }

@@ -361,7 +361,7 @@ struct LduSolver {
             if (p_relax_now > 0 && p_relax_now < 1) FY_TRY(launch_copy_f64(stream, pPrev.p, p.p, (size_t)nc));  // storePrevIterFields()
             if (outer > 0) FY_TRY(launch_ldu_grad_vec(stream, g, U.p, vGrad.p));
             if (g.gradL) FY_TRY(launch_ldu_grad_magsqr(stream, g, U.p, gradL.p));
-            FY_TRY(launch_ldu_assemble_momentum_pimple(stream, g, P(), phi.p, Uold.p, U.p, vGrad.p, M(), fcorr.p, fstress.p, u_relax_now, rAU.p));      // UcEqn.H:3-13
+            FY_TRY(launch_ldu_assemble_momentum_pimple(stream, g, P(), phi.p, Uold.p, U.p, vGrad.p, M(), pt.p, fstress.p, u_relax_now, rAU.p));      // UcEqn.H:3-13
             FY_TRY(launch_ldu_forces(stream, g, P(), rAU.p, rAUf.p, phiForces.p));                               // UcEqn.H:15-20
             if (cs.momentum_predictor) {                                                                          // UcEqn.H:22-33
                 // (first outer iteration: p and its patches' gradients stand as when the coupling's gradP was formed, pimpleFoamYade.C:74 -- the same field, not formed again)
