@@ -138,8 +138,8 @@ int launch_ldu_add_forces_constrain(hipStream_t s, LduGeo g, const double* phiFo
 int launch_ldu_pim_pfaces(hipStream_t s, LduGeo g, const double* alphaf, const double* rAUf, const double* phiHbyA, const double* psn, double* arAUf, double* phiA);
 int launch_ldu_prhs_ddt_alpha(hipStream_t s, LduGeo g, const double* alpha, const double* alphaOld, double* prhs);
 int launch_ldu_pim_flux(hipStream_t s, LduGeo g, const double* p, const double* phiHbyA, const double* pcoef, const double* pcorr, const double* alphaf, const double* rAUf,
-                        const double* phiForces, const double* psn, double* phi, double* ssf);
-int launch_ldu_pim_continuity(hipStream_t s, LduGeo g, const double* phi, const double* alphaf, const double* alpha, const double* alphaOld, double* partials);
+                        const double* phiForces, const double* psn, double* phi, double* ssf, double* aphi /* [nF]: alphacf phic */);
+int launch_ldu_pim_continuity(hipStream_t s, LduGeo g, const double* aphi, const double* alpha, const double* alphaOld, double* partials);
 int launch_ldu_sum(hipStream_t s, const double* x, int n, int ncomp, double* partials);                  // slot q = sum of component q
 // mesh.findCell stand-in for the point-force locate: from the nearest centre (hint[i], or -1: not located) walk across the face the point lies
 // furthest outside of until it lies inside every face of a cell; cell_out[i] = that cell or -1 (outside the mesh)

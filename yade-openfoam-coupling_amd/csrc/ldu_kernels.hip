@@ -887,7 +887,8 @@ __global__ __launch_bounds__(256) void k_ldu_prhs_ddt_alpha(LduGeo g, const doub
 // phic = phiHbyA - pEqn.flux() / alphacf (pEqn.H:39) and the face field of the velocity correction (phicForces - pEqn.flux() / alphacf) / rAUcf (pEqn.H:43-45)
 __global__ __launch_bounds__(256) void k_ldu_pim_flux(LduGeo g, const double* __restrict__ p, const double* __restrict__ phiHbyA, const double* __restrict__ pcoef,
                                                       const double* __restrict__ pcorr, const double* __restrict__ alphaf, const double* __restrict__ rAUf,
-                                                      const double* __restrict__ phiForces, const double* __restrict__ psn, double* __restrict__ phi, double* __restrict__ ssf) {
+                                                      const double* __restrict__ phiForces, const double* __restrict__ psn, double* __restrict__ phi, double* __restrict__ ssf,
+                                                      double* __restrict__ aphi) {
     const int f = blockIdx.x * 256 + threadIdx.x;
     if (f >= g.nFaces) return;
     double pf;                                         // pEqn.flux() in the sign of the positive-definite form: c_f (p_N - p_P) + the explicit part
@@ -897,18 +898,20 @@ __global__ __launch_bounds__(256) void k_ldu_pim_flux(LduGeo g, const double* __
         pf = g.p_bc[pa] == FY_BC_P_FIXED_VALUE ? pcoef[f] * (g.p_val[pa] - p[g.own[f]]) : (g.p_bc[pa] == FY_BC_P_FIXED_FLUX ? alphaf[f] * rAUf[f] * g.magSf[f] * psn[f - g.nInt] : 0.0);
     }
     const double q = pf / alphaf[f];
-    phi[f] = phiHbyA[f] - q;
+    const double ph = phiHbyA[f] - q;
+    phi[f] = ph;
+    aphi[f] = alphaf[f] * ph;                          // alphacf phic, for continuityErrs.H's cell sums (one gather there)
     ssf[f] = (phiForces[f] - q) / rAUf[f];
 }
 
 // continuityErrs.H of pimpleFoamYade: fvc::ddt(alphac) + fvc::div(alphacf phic); slot 0 sum |.| V, slot 1 sum . V
-__global__ __launch_bounds__(256) void k_ldu_pim_continuity(LduGeo g, const double* __restrict__ phi, const double* __restrict__ alphaf, const double* __restrict__ alpha,
+__global__ __launch_bounds__(256) void k_ldu_pim_continuity(LduGeo g, const double* __restrict__ aphi, const double* __restrict__ alpha,
                                                             const double* __restrict__ alphaOld, double* __restrict__ partials) {
     double v[2] = {0, 0};
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c < g.nCells) {
         double dv = 0.0;
-        FY_CELL_FACES(g, c, f, nb) dv += (f >= g.nInt || nb > c) ? alphaf[f] * phi[f] : -(alphaf[f] * phi[f]);
+        FY_CELL_FACES(g, c, f, nb) dv += (f >= g.nInt || nb > c) ? aphi[f] : -aphi[f];
         const double ce = dv / g.V[c] + (alpha[c] - alphaOld[c]) / g.dt;
         v[0] = fabs(ce) * g.V[c]; v[1] = ce * g.V[c];
     }
@@ -1124,13 +1127,13 @@ int launch_ldu_prhs_ddt_alpha(hipStream_t s, LduGeo g, const double* alpha, cons
     return FY_OK;
 }
 int launch_ldu_pim_flux(hipStream_t s, LduGeo g, const double* p, const double* phiHbyA, const double* pcoef, const double* pcorr, const double* alphaf, const double* rAUf,
-                        const double* phiForces, const double* psn, double* phi, double* ssf) {
-    hipLaunchKernelGGL(k_ldu_pim_flux, dim3(div_up(g.nFaces, 256)), dim3(256), 0, s, g, p, phiHbyA, pcoef, pcorr, alphaf, rAUf, phiForces, psn, phi, ssf);
+                        const double* phiForces, const double* psn, double* phi, double* ssf, double* aphi /* [nF]: alphacf phic */) {
+    hipLaunchKernelGGL(k_ldu_pim_flux, dim3(div_up(g.nFaces, 256)), dim3(256), 0, s, g, p, phiHbyA, pcoef, pcorr, alphaf, rAUf, phiForces, psn, phi, ssf, aphi);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }
-int launch_ldu_pim_continuity(hipStream_t s, LduGeo g, const double* phi, const double* alphaf, const double* alpha, const double* alphaOld, double* partials) {
-    hipLaunchKernelGGL(k_ldu_pim_continuity, dim3(red_blocks(g.nCells)), dim3(256), 0, s, g, phi, alphaf, alpha, alphaOld, partials);
+int launch_ldu_pim_continuity(hipStream_t s, LduGeo g, const double* aphi, const double* alpha, const double* alphaOld, double* partials) {
+    hipLaunchKernelGGL(k_ldu_pim_continuity, dim3(red_blocks(g.nCells)), dim3(256), 0, s, g, aphi, alpha, alphaOld, partials);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }

@@ -330,12 +330,12 @@ struct LduSolver {
             if (no == 0) FY_TRY(amg.setup(stream, pcoef.p, pdiag.p));
             FY_TRY(solve_pressure(final_corr && no == cs.n_non_orth_correctors));
             if (no == cs.n_non_orth_correctors) {
-                FY_TRY(launch_ldu_pim_flux(stream, g, p.p, phiHbyA.p, pcoef.p, pcorr.p, alphaf.p, rAUf.p, phiForces.p, psn.p, phi.p, ssf.p));      // :39
+                FY_TRY(launch_ldu_pim_flux(stream, g, p.p, phiHbyA.p, pcoef.p, pcorr.p, alphaf.p, rAUf.p, phiForces.p, psn.p, phi.p, ssf.p, pt.p));      // :39
                 if (p_relax_now > 0 && p_relax_now < 1) FY_TRY(launch_relax_field(stream, p.p, pPrev.p, p_relax_now, (size_t)nc));                  // :41
             }
         }
         FY_TRY(launch_ldu_reconstruct(stream, g, ssf.p, HbyA.p, rAU.p, U.p));                                     // :43-46
-        FY_TRY(launch_ldu_pim_continuity(stream, g, phi.p, alphaf.p, alpha.p, alpha.p, partials.p));             // :50
+        FY_TRY(launch_ldu_pim_continuity(stream, g, pt.p, alpha.p, alpha.p, partials.p));             // :50
         double h[2];
         FY_TRY(reduce_read(nc, 2, nullptr, h));
         st.cont_err_sum_local = cs.dt * h[0] / total_volume; st.cont_err_global = cs.dt * h[1] / total_volume;
