@@ -674,7 +674,50 @@ def test_malformed_meshes_and_cases_are_refused_by_name(product):
             product.LduSolver(mesh, 1e-3, 0.01, [0] * 6, [(0, 0, 0)] * 6, [0] * 6, **kw)
     with pytest.raises(product.FoamYadeError, match="patch type"):
         product.LduSolver(base, 1e-3, 0.01, [0] * 6, [(0, 0, 0)] * 6, [2] * 6)          # fixedFluxPressure belongs to pimpleFoamYade
+    # cyclic pairs: partners that do not name each other, halves of different sizes, halves that are not translates (x-min against y-max), a box one cell thick
+    cyc = pm.make_cyclic(base, [(0, 1)])
+    one_sided = dict(cyc); one_sided["patch_neighbour"] = np.array([1, -1, -1, -1, -1, -1], np.int32)
+    turned = dict(base); turned["patch_neighbour"] = np.array([3, -1, -1, 0, -1, -1], np.int32)
+    thin = pm.make_cyclic(pm.hex_block(1, 4, 4), [(0, 1)])
+    for mesh, needle in ((one_sided, "does not name it back"), (turned, "not translates"), (thin, "its own neighbour")):
+        with pytest.raises(product.FoamYadeError, match=needle):
+            product.LduSolver(mesh, 1e-3, 0.01, [1, 1, 0, 0, 0, 0], [(0, 0, 0)] * 6, [0] * 6)
+    product.LduSolver(cyc, 1e-3, 0.01, [1, 1, 0, 0, 0, 0], [(0, 0, 0)] * 6, [0] * 6).close()
     ok().close()
+
+
+def test_periodic_channel_with_a_symmetry_side_les_and_a_cloud(product, oracle):
+    """the patch kinds together: a channel periodic in x (cyclic pair), a symmetry plane on one side, walls elsewhere, LES kEqn with a `calculated` nut wall patch, limited
+    convection, a cloud -- on a periodically distorted mesh, HIP against the restatement"""
+    n, box = 10, 0.1
+    L = (box, box, box)
+    dx = box / n
+    w0 = pm.wavy_periodic(0.02 * box, L)
+    vm = lambda P: (lambda Q: np.stack([Q[:, 0], P[:, 1] + (Q[:, 1] - P[:, 1]) * np.sin(np.pi * P[:, 1] / box) ** 2, P[:, 2] + (Q[:, 2] - P[:, 2]) * np.sin(np.pi * P[:, 2] / box) ** 2], axis=1))(w0(P))
+    mesh = pm.make_cyclic(pm.hex_block(n, n, n, L, vm, renumber_seed=3), [(0, 1)])          # (the y and z sides stay planes: the symmetry side is one)
+    kw = dict(p_tol=1e-10, p_rel_tol=0.0, p_final_tol=1e-10, u_tol=1e-10, p_max_iter=5000)
+    les = dict(turbulence_model=2, nut_initial=2e-5, les_delta_coeff=1.0, k_initial=2e-4, k_tol=1e-12, k_convection_scheme=1, convection_scheme=4)
+    u_bc = [1, 1, 2, 0, 0, 0]                                   # x: cyclic (codes unused); ymin: symmetry; ymax, zmin, zmax: walls (ymax moving)
+    u_val = [(0, 0, 0)] * 6
+    u_val[3] = (0.3, 0, 0.05)
+    p_bc = [0, 0, 0, 2, 2, 2]
+    pat = dict(nut_bc=[0, 0, 0, 3, 0, 0], nut_val=[0, 0, 0, 3e-5, 0, 0])
+    rel = dict(u_relax=0.8, u_relax_final=1.0, p_relax=0.7, p_relax_final=1.0)
+    h = product.LduSolver(mesh, 2e-4, 1e-5, u_bc, u_val, p_bc, solver=1, g=(0, 0, -9.81), n_non_orth=1, n_outer_correctors=2, n_correctors=2, **les, **pat, **rel, **kw)
+    o = oracle.LduSolver(mesh, 2e-4, 1e-5, u_bc, u_val, p_bc, solver=1, g=(0, 0, -9.81), n_non_orth=1, n_outer=2, n_correctors=2, **les, **pat, **rel, **kw)
+    h.hold_sources(True)
+    rs = np.random.RandomState(41)
+    for step in range(3):
+        h.set_particles(bed_particles(rs, 1500, box, dx))
+        h.step()
+        o.step(source=h.get("uSourceCoupling"), alpha=h.get("alpha"), drag=h.get("uSourceDrag"))
+        close(h.get("U"), o.get("U"), 2e-6, "U step %d" % step)
+        close(h.get("k"), o.get("k"), 1e-6, "k step %d" % step)
+    ph, po = h.get("p"), o.get("p")
+    close(ph - ph.mean(), po - po.mean(), 1e-5, "p")
+    close(h.get("phi"), o.get("phi"), 1e-5, "phi")
+    close(h.get("nut"), o.get("nut"), 1e-6, "nut")
+    h.close(); o.close()
 
 
 def test_general_mesh_solver_at_the_bench_size(product):
