@@ -468,7 +468,7 @@ __global__ __launch_bounds__(kWave) void k_locate(const KdNode* __restrict__ tre
                         if (fx >= 0 && fx < ig.nx && fy_ >= 0 && fy_ < ig.ny && fz >= 0 && fz < ig.nz) {
                             const unsigned long long e = start[(size_t)fx + (size_t)ig.nx * ((size_t)fy_ + (size_t)ig.ny * (size_t)fz)];
                             o = (uint32_t)(e & 0x1ffffffull); nn = (uint32_t)((e >> 25) & 0x1ffffffull); axis = (uint32_t)((e >> 50) & 3ull);
-                            if (o != 0) best = 1e300;            // no ancestor was within maxdist: same chain as any best >= maxdist
+                            if (o != 0) best = maxdist;          // no ancestor was within maxdist: same chain as any best >= maxdist, and no far side beyond it is stacked
                         }
                     }
                 }
