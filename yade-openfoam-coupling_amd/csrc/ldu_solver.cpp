@@ -61,6 +61,8 @@ struct LduSolver {
 
     ~LduSolver() {
         if (cpl) fy_destroy(cpl);
+        if (red_host) (void)hipHostFree(red_host);
+        if (red_flag) (void)hipHostFree(red_flag);
         for (auto& t : tim) t.destroy();
         if (stream) (void)hipStreamDestroy(stream);
     }
@@ -146,6 +148,15 @@ struct LduSolver {
         FY_TRY(partials.alloc_exact(8 * (size_t)ldu_red_blocks(std::max(nc, nf)))); FY_TRY(zero(partials));
         FY_TRY(sc.alloc_exact(8)); FY_TRY(zero(sc)); FY_TRY(xsum.alloc_exact(4)); FY_TRY(zero(xsum)); FY_TRY(adj.alloc_exact(4)); FY_TRY(zero(adj));
         FY_TRY(adj_err.alloc_exact(1)); FY_HIP(hipMemsetAsync(adj_err.p, 0, sizeof(int), stream));
+        if (hipHostMalloc((void**)&red_host, 8 * sizeof(double), hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer((void**)&red_host_dev, red_host, 0) != hipSuccess) {
+            if (red_host) (void)hipHostFree(red_host);
+            red_host = nullptr;                              // (fall back to the copy path)
+        }
+        if (red_host && (hipHostMalloc((void**)&red_flag, 8 * sizeof(unsigned long long), hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer((void**)&red_flag_dev, red_flag, 0) != hipSuccess)) {
+            if (red_flag) (void)hipHostFree(red_flag);
+            red_flag = nullptr;
+        }
+        if (red_flag) for (int q = 0; q < 8; ++q) red_flag[q] = 0;
         if (pimple) {
             DevBuf<double>* p3[] = {&uParticle, &gradP, &divT, &ddtU, &bmom};
             for (auto* b : p3) { FY_TRY(b->alloc_exact(3 * n)); FY_TRY(zero(*b)); }
@@ -223,9 +234,31 @@ struct LduSolver {
     }
 
     // fold `nslots` of the block partials of an n-cell reduction and read them back
-    int reduce_read(int n, int nslots, const int* ops_dev, double* h) {
-        FY_TRY(launch_reduce_finalize(stream, partials.p, n, nslots, ops_dev, sc.p, nullptr, 0));
-        FY_HIP(hipMemcpyAsync(h, sc.p, nslots * sizeof(double), hipMemcpyDeviceToHost, stream));
+    // the fold writes straight into mapped pinned host memory and stores a sequence number behind each result; the host spins on those flags (in-order stream: everything
+    // enqueued before the fold has completed by then) -- no device-to-host blit and no stream synchronisation per read-back, as fv_solver.cpp's reduce_read
+    double* red_host = nullptr; double* red_host_dev = nullptr;
+    unsigned long long* red_flag = nullptr; unsigned long long* red_flag_dev = nullptr;
+    unsigned long long red_seq = 0;
+    int reduce_read(int n, int nslots, const int* ops_dev, double* h, double* dev_land = nullptr) {      // dev_land: where the copy path lets the fold land (default: sc)
+        if (red_flag && nslots <= 8) {
+            const unsigned long long seq = ++red_seq;
+            FY_TRY(launch_reduce_finalize(stream, partials.p, n, nslots, ops_dev, red_host_dev, red_flag_dev, seq));
+            for (int q = 0; q < nslots; ++q) {
+                unsigned long spins = 0;
+                while (__atomic_load_n(&red_flag[q], __ATOMIC_ACQUIRE) != seq) {
+                    if ((++spins & 0xfffu) == 0) {                      // every 4096 polls: is the stream still alive?
+                        const hipError_t e = hipStreamQuery(stream);
+                        if (e == hipSuccess) { if (__atomic_load_n(&red_flag[q], __ATOMIC_ACQUIRE) == seq) break; return fail(FY_ERR_HIP, "reduction flag never arrived"); }
+                        if (e != hipErrorNotReady) return fail(FY_ERR_HIP, "stream failed while waiting for a reduction: %s", hipGetErrorString(e));
+                    }
+                }
+                h[q] = red_host[q];
+            }
+            return FY_OK;
+        }
+        double* land = dev_land ? dev_land : sc.p;
+        FY_TRY(launch_reduce_finalize(stream, partials.p, n, nslots, ops_dev, land, nullptr, 0));
+        FY_HIP(hipMemcpyAsync(h, land, nslots * sizeof(double), hipMemcpyDeviceToHost, stream));
         FY_HIP(hipStreamSynchronize(stream));
         return FY_OK;
     }
@@ -285,9 +318,7 @@ struct LduSolver {
                 FY_TRY(launch_reduce_finalize(stream, partials.p, nc, 2, nullptr, sc.p, nullptr, 0));
                 FY_TRY(launch_pcg_cg_update(stream, nc, 0, pu.p, pw.p, pp.p, ps.p, p.p, pr.p, sc.p, it, partials.p));
                 if (it == 0) { std::swap(pp.p, pu.p); std::swap(ps.p, pw.p); }      // p = u, s = w without a pass
-                FY_TRY(launch_reduce_finalize(stream, partials.p, nc, 2, nullptr, sc.p + 6, nullptr, 0));
-                FY_HIP(hipMemcpyAsync(h, sc.p + 6, 2 * sizeof(double), hipMemcpyDeviceToHost, stream));
-                FY_HIP(hipStreamSynchronize(stream));
+                FY_TRY(reduce_read(nc, 2, nullptr, h, sc.p + 6));      // (the copy path must not touch the iteration's scalars in sc[0 .. 5])
                 res = h[0] / norm;
             } while (++it < cs.p_max_iter && !converged(res));
         }
