@@ -283,51 +283,146 @@ def wire_leg_mpi(n, n_part, steps, workers, dt, c5, solver_ranks=1):
             "located_at_the_workers": int(j["found_at_the_workers"]), "located_by_two_solver_ranks": int(j.get("found_by_two_ranks", 0))}
 
 
-def cpu_baseline(config, n_sample, n_part, dt, threads, full):
+def oracle_case(orc, config, n_s, dt):
+    """the bench workload as an oracle case (n_s: cells per edge; c2: n_s = 100 is the full 200 x 100 x 50 channel) -> (case, nx, ny, nz, dx)"""
+    if config == "c2":
+        scale = n_s / 100.0
+        nx, ny, nz, dx = int(200 * scale), int(100 * scale), int(50 * scale), 0.01
+        case = orc.fv_case(0, nx, ny, nz, dx, dt, 1e-3, u_bc=[0, 1, 0, 0, 0, 0], u_val=[(1.0, 0, 0)] + [(0, 0, 0)] * 5, p_bc=[0, 1, 0, 0, 0, 0],
+                           p_val=[0.0] * 6, n_corr=2, p_solver=1)
+    elif config == "c5":
+        nx = ny = nz = n_s
+        dx = 1.0 / n_s
+        case = orc.fv_case(1, nx, ny, nz, dx, dt, 1e-6, g=(0, 0, -9.81), u_bc=[0, 0, 0, 0, 0, 1], u_val=[(0, 0, 0)] * 4 + [(0, 0, 0.05), (0, 0, 0)],
+                           p_bc=[orc.P_FIXEDFLUX] * 5 + [1], p_val=[0.0] * 6, n_outer=1, n_corr=2, p_solver=1)
+    else:
+        nx = ny = nz = n_s
+        dx = 1.0 / n_s
+        case = orc.fv_case(1, nx, ny, nz, dx, dt, 1e-6, g=(0, 0, -9.81), p_bc=[orc.P_FIXEDFLUX] * 6, n_outer=1, n_corr=2, p_solver=1)
+    return case, nx, ny, nz, dx
+
+
+def bench_records_host(torch, config, n, n_part, velocities=False):
+    """the timed region's particle records as a host array: the SAME generator calls that fill the device records (c3_particles / c2_particles), so
+    the oracle and the HIP path can be compared on the bench's own cloud.  velocities: +-0.05 m/s per component (seed 77) -- not the BASELINE
+    cloud, which is at rest; used by the parity test so that the drag terms are not identically zero"""
+    rec = (c2_particles(torch, n_part, "cpu") if config == "c2" else c3_particles(torch, n_part, n, 3, "cpu")).numpy()
+    if velocities:
+        rs = np.random.Generator(np.random.PCG64(77))
+        rec[:, 3:6] = (rs.random((n_part, 3)) - 0.5) * 0.1
+    return rec
+
+
+PARITY_FIELDS = ("U", "p", "phi_x", "phi_y", "phi_z")
+PARITY_SOURCES = ("alpha", "uSource", "uSourceDrag")
+
+
+def oracle_steps(orc, config, n_s, dt, th, rec, collect=False, steps=2):
+    """`steps` coupled steps of the CPU oracle from the case's initial state on the records `rec`; the LAST one is timed (the first touches every
+    array).  collect: also return what the last step left -- fields, the particle action's outputs, the sources as setParticleAction left them"""
+    case, nx, ny, nz, _ = oracle_case(orc, config, n_s, dt)
+    s = orc.FvSolver(case, threads=th)                       # tree build is construction-time work, not timed (as on the GPU side)
+    el, ref, first = 0.0, None, None
+    for it in range(steps):
+        last = it == steps - 1
+        cap = {} if (collect and (last or it == 0)) else None
+        t0 = time.time()
+        out = s.step(rec, capture=cap)
+        el = time.time() - t0
+        if collect and it == 0 and steps > 1:
+            first = dict(cap, force=out["force"])            # step 1 starts from exact inputs (the initial fields): its particle side carries no FV tolerance
+        if collect and last:
+            ref = {k: s.get(k) for k in PARITY_FIELDS}
+            ref.update(cap)
+            ref.update(force=out["force"], k=out["k"], ids=out["ids"], found=out["found"], chain_len=out["chain_len"], stats=s.stats(), first=first)
+    s.close()
+    return el, nx * ny * nz, ref
+
+
+def hip_vs_oracle(prod, case, rec, ref, device=0, steps=2):
+    """the same `steps` coupled steps on the HIP path (a fresh fy_solver, host records through fy_set_particles_host), compared with what
+    oracle_steps collected.  Index work (k, stencil ids, found flags): exact.  Floating point: max |a - b| / max |b| per array."""
+    s = prod.Solver(case, device=device)
+    s.hold_sources(True)                                     # the step's closing setSourceZero waits: alpha / uSource / uSourceDrag stay readable
+    s.set_particles(rec)
+    gaussian = case.solver == prod.FY_SOLVER_PIMPLE
+
+    def rel(a, b):
+        return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-300))
+    res = {"steps_compared": steps, "particles": int(rec.shape[0]), "cells": int(s.n_cells)}
+    for it in range(steps):
+        s.step()
+        if it == 0 and ref.get("first") is not None:
+            f1 = ref["first"]
+            res["step1"] = {"force": rel(s.forces(), f1["force"]), "force_scale": float(np.abs(f1["force"]).max())}
+            for nm in (PARITY_SOURCES if gaussian else ("uSource",)):
+                res["step1"][nm] = rel(s.get(nm), f1[nm])
+    st = s.stats()
+    if gaussian:
+        k, ids, _, chain = s.stencils()
+        res["k_equal"] = bool(np.array_equal(k, ref["k"]))
+        res["ids_equal"] = bool(np.array_equal(ids, ref["ids"]))
+        res["chain_equal"] = bool(np.array_equal(chain, ref["chain_len"]))
+        res["pairs"] = int(k.sum())
+        del k, ids, chain
+    res["found_equal"] = bool(np.array_equal(s.found(), ref["found"]))
+    res["force"] = rel(s.forces(), ref["force"])
+    res["force_scale"] = float(np.abs(ref["force"]).max())
+    for nm in (PARITY_SOURCES if gaussian else ("uSource",)) + PARITY_FIELDS:
+        res[nm] = rel(s.get(nm), ref[nm])
+    res["p_iters"] = [int(st["p_iters_total"]), int(ref["stats"]["p_iters_total"])]
+    res["u_iters"] = [int(st["u_iters_total"]), int(ref["stats"]["u_iters_total"])]
+    res["what"] = ("HIP path vs the CPU oracle after %d coupled steps from the case's initial state on the bench's own records: *_equal = bit-exact index work; "
+                   "the other entries are max |hip - oracle| / max |oracle| per array (step1: the particle side of the first step, whose inputs are exact; the "
+                   "rest after the last step, where forces and sources gather fields that carry the linear solvers' tolerance); p_iters / u_iters = [hip, oracle] "
+                   "of the last step" % steps)
+    s.close()
+    return res
+
+
+def cpu_baseline(config, n_sample, n_part, dt, threads, full, torch=None, prod=None, p_solver=1, device=0):
     """the CPU oracle (a faithful port of the reference's path, kind = "port") on the GPU box's host cores, bounded to some tens of seconds:
-    all usable threads on the bench's own workload (full: at its own size, one warm-up + one timed step; else an n_sample^3 sample with the
-    same particles per cell), and ONE thread on a half-edge sample of that (1/8 of the cells and particles).  Returns ({threads: (s/step, cells)}, cells)"""
+    all usable threads on the bench's own workload (full: at its own size and on its own records, one warm-up + one timed step; else an n_sample^3
+    sample with the same particles per cell), and ONE thread on a half-edge sample of that (1/8 of the cells and particles).
+    full and prod given: what the two oracle steps left is compared with the HIP path's two steps (hip_vs_oracle) -- the parity of the headline
+    configuration at its own size, paid for by the baseline's own oracle run.
+    Returns ({threads: (s/step, cells)}, cells, native build?, parity dict or None)"""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as orc
     orc.build()
     native = orc.use_native_build()
 
-    def one(th, n_s, npart):
+    def sample_records(n_s, npart):
         rs = np.random.RandomState(3)
         rec = np.zeros((npart, 10))
         rec[:, 0:3] = rs.random_sample((npart, 3))
+        _, nx, ny, nz, dx = oracle_case(orc, config, n_s, dt)
         if config == "c2":
-            scale = n_s / 100.0                                  # n_s = 100 is the full 200 x 100 x 50 channel
-            nx, ny, nz, dx = int(200 * scale), int(100 * scale), int(50 * scale), 0.01
-            case = orc.fv_case(0, nx, ny, nz, dx, dt, 1e-3, u_bc=[0, 1, 0, 0, 0, 0], u_val=[(1.0, 0, 0)] + [(0, 0, 0)] * 5, p_bc=[0, 1, 0, 0, 0, 0],
-                               p_val=[0.0] * 6, n_corr=2, p_solver=1)
             rec[:, 0:3] *= np.array([nx * dx, ny * dx, nz * dx])
             rec[:, 9] = 0.15 * dx
-        elif config == "c5":
-            nx = ny = nz = n_s
-            dx = 1.0 / n_s
-            case = orc.fv_case(1, nx, ny, nz, dx, dt, 1e-6, g=(0, 0, -9.81), u_bc=[0, 0, 0, 0, 0, 1], u_val=[(0, 0, 0)] * 4 + [(0, 0, 0.05), (0, 0, 0)],
-                               p_bc=[orc.P_FIXEDFLUX] * 5 + [1], p_val=[0.0] * 6, n_outer=1, n_corr=2, p_solver=1)
-            rec[:, 2] *= 1.0 / 3.0
-            rec[:, 9] = 0.2 * dx
         else:
-            nx = ny = nz = n_s
-            dx = 1.0 / n_s
-            case = orc.fv_case(1, nx, ny, nz, dx, dt, 1e-6, g=(0, 0, -9.81), p_bc=[orc.P_FIXEDFLUX] * 6, n_outer=1, n_corr=2, p_solver=1)
-            rec[:, 2] *= 0.6
+            rec[:, 2] *= (1.0 / 3.0) if config == "c5" else 0.6
             rec[:, 9] = 0.2 * dx
-        s = orc.FvSolver(case, threads=th)                       # tree build is construction-time work, not timed (as on the GPU side)
-        s.step(rec)                                              # warm-up step (first touch of every array)
-        t0 = time.time()
-        s.step(rec)
-        el = time.time() - t0
-        s.close()
-        return el, nx * ny * nz
+        return rec
 
-    out = {threads: one(threads, n_sample, n_part)}
+    parity = None
+    if full and torch is not None and prod is not None and config in ("c3", "c2"):
+        rec = bench_records_host(torch, config, n_sample, n_part)
+        el, cells, ref = oracle_steps(orc, config, n_sample, dt, threads, rec, collect=True)
+        try:
+            case = c2_case(prod, dt, p_solver) if config == "c2" else c3_case(prod, n_sample, dt, p_solver)
+            parity = hip_vs_oracle(prod, case, rec, ref, device)
+        except Exception as e:                                        # noqa: BLE001  (reported in the line)
+            parity = {"error": f"{type(e).__name__}: {e}"}
+        del ref, rec
+        out = {threads: (el, cells)}
+    else:
+        el, cells, _ = oracle_steps(orc, config, n_sample, dt, threads, sample_records(n_sample, n_part))
+        out = {threads: (el, cells)}
     if threads != 1:
-        out[1] = one(1, n_sample // 2, n_part // 8)
-    return out, out[threads][1], native
+        el1, cells1, _ = oracle_steps(orc, config, n_sample // 2, dt, 1, sample_records(n_sample // 2, n_part // 8))
+        out[1] = (el1, cells1)
+    return out, out[threads][1], native, parity
 
 
 def cpu_reference_as_written(n_sample=32, n_part=80000):
@@ -923,7 +1018,10 @@ def main():
         n_s = (100 if c2 else args.n) if full else (args.cpu_sample_n or 96)
         nc_s = (n_s ** 3 if not c2 else 1_000_000)
         n_part_cpu = args.particles if full else int(round(args.particles / nc * nc_s))
-        per, snc, native = cpu_baseline(args.config, n_s, n_part_cpu, args.dt, ncores, full)
+        if solver is not None:                                    # (the parity leg builds a fresh solver of the same size)
+            solver.close(); solver = None
+            torch.cuda.empty_cache()
+        per, snc, native, parity = cpu_baseline(args.config, n_s, n_part_cpu, args.dt, ncores, full, torch, prod, args.p_solver, local_rank)
         (t_all, c_all), (t_one, c_one) = per[ncores], per[1]
         v_all, v_one = (c_all / nc) / t_all, (c_one / nc) / t_one      # steps/s of the bench workload (linear-in-size scaling where a sample was timed)
         best_th = ncores if v_all >= v_one else 1
@@ -934,6 +1032,8 @@ def main():
                        + ("the bench workload itself at full size" if full else f"a {c_all / nc:.4f} sample of the bench workload with the same particles per cell")
                        + f" ({c_all} cells / {n_part_cpu} particles), one warm-up + 1 timed step = {t_all:.2f} s/step; on 1 thread a half-edge sample of that "
                        f"({c_one} cells / {n_part_cpu // 8} particles) = {t_one:.2f} s/step; samples scaled to the bench size linearly in the cell count")}
+        if parity is not None:
+            out["cpu_baseline"]["parity_at_bench_size"] = parity
         ref = cpu_reference_as_written() if not (c2 or c5) else None
         if ref is not None:
             out["cpu_reference_as_written"] = ref

@@ -14,7 +14,11 @@ extern "C" {
 /* MPI must already be initialised.  n_yade_ranks = number of leading world ranks that belong to Yade (commSzDff, FoamYade.C:28); < 0: derive it
  * as the reference does -- every caller is a solver rank, the Yade ranks are the world's other ranks (world size - solver communicator size).
  * Collective over MPI_COMM_WORLD (it calls MPI_Comm_split), so Yade-side ranks must make the matching split themselves, as
- * they do for the reference.  Fills *out; returns FY_OK or FY_ERR_TRANSPORT. */
+ * they do for the reference.  Fills *out (zeroing it first: the optional callbacks stay null); returns FY_OK or FY_ERR_TRANSPORT.
+ * n_yade_ranks < 0 in a world WITHOUT Yade ranks: FY_OK with out->send == NULL -- nobody to couple with; pass a NULL transport to the library
+ * (fy_mpi_local_comm still returns the solver ranks' communicator).
+ * Lifetime: destroy the objects that hold the transport (fy_destroy / fy_solver_destroy / fy_ldu_solver_destroy) BEFORE fy_mpi_transport_destroy:
+ * they may have page-locked the wire helpers' arena and release it on destruction. */
 int fy_mpi_transport_create(int n_yade_ranks, fy_transport* out);
 int fy_mpi_transport_destroy(fy_transport* t);
 /* WIRE HELPERS (round 4): K solver-side MPI ranks in front of ONE GPU.  One receiving core copies ~9 GB/s out of the MPI library whatever it

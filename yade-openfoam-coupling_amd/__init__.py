@@ -683,6 +683,13 @@ class Solver:
         _check(lib().fy_get_found_host(self._cpl, 0, _i(out)))
         return out
 
+    def stencils(self):
+        """(k, ids, w, chain) of batch 0 as the last step's setParticleAction left them (Gaussian mode)"""
+        n = self._batch_n[0]
+        k = np.zeros(n, np.int32); ids = np.full((n, MAXK), -1, np.int32); w = np.zeros((n, MAXK)); chain = np.zeros(n, np.int32)
+        _check(lib().fy_get_stencils_host(self._cpl, 0, _i(k), _i(ids), _d(w), _i(chain)))
+        return k, ids, w, chain
+
     def step(self):
         _check(lib().fy_solver_step(self._h))
 

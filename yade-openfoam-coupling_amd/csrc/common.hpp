@@ -23,6 +23,9 @@ struct Options {
     bool no_halo_overlap;        // FOAMYADE_NO_HALO_OVERLAP=1   slab smoother: exchange, then sweep (serial schedule; identical results)
     bool no_aux_comm;            // FOAMYADE_NO_AUX_COMM=1       slab mode: no second RCCL communicator for the overlapped halo
     bool no_deep_vcycle;         // FOAMYADE_NO_DEEP_VCYCLE=1    slab multigrid: one exchange per sweep (round 3's schedule) instead of one per level and cycle
+    bool no_fused_corrector;     // FOAMYADE_NO_FUSED_CORRECTOR=1  the corrector as five sweeps (rounds 1 - 4) instead of the two fused ones (A/B switch, identical results)
+    int strip_blocks;            // FOAMYADE_STRIP_BLOCKS=n       blocks per strip of the FV cell sweeps (0: off; unset: ~8 rows of cells)
+    bool faces_from_arrays;      // FOAMYADE_FACES_FROM_ARRAYS=1   the fused sweeps stream rAUf / alphacf from their face arrays instead of re-forming them from rAU / alpha
 };
 Options options();
 

@@ -27,6 +27,10 @@ Options options() {
     q.no_halo_overlap = on("FOAMYADE_NO_HALO_OVERLAP");
     q.no_aux_comm = on("FOAMYADE_NO_AUX_COMM");
     q.no_deep_vcycle = on("FOAMYADE_NO_DEEP_VCYCLE");
+    q.no_fused_corrector = on("FOAMYADE_NO_FUSED_CORRECTOR");
+    q.faces_from_arrays = on("FOAMYADE_FACES_FROM_ARRAYS");
+    q.strip_blocks = -1;
+    if (const char* e = getenv("FOAMYADE_STRIP_BLOCKS")) q.strip_blocks = atoi(e);
     return q;
 }
 
@@ -876,7 +880,8 @@ int Coupling::recv_yade_intrs() {
         FY_TRY(start_results_copy(b));
         // ... and with a zero-copy wire the results of the batches before it go out as soon as they have landed (FoamYade.C:239-243, 504-507
         // send per Yade proc: nothing orders one proc's answers after another's): the helpers send them while the next records come in
-        if (views) for (size_t e = 0; e < q; ++e) FY_TRY(commit_results(*batches[e], false));
+        // (in ascending worker order, stopping at the first batch whose copy has not landed: the wire helpers take the answers worker by worker)
+        if (views) FY_TRY(commit_landed(q));
     }
     return FY_OK;
 }
@@ -917,7 +922,7 @@ int Coupling::recv_yade_pieces(const std::vector<std::pair<int, int> >& in_comm)
             FY_TRY(ensure_batch(b, n));
             FY_TRY(run_batch(b));
             FY_TRY(start_results_copy(b));
-            for (size_t e = 0; e < next; ++e) FY_TRY(commit_results(*batches[e], false));
+            FY_TRY(commit_landed(next));
             ++next;
         }
         return FY_OK;
@@ -959,8 +964,13 @@ int Coupling::lock_view_region() {
     if (view_locked) { (void)hipHostUnregister(view_base); view_locked = false; }
     view_base = base; view_bytes = bytes; view_generation = gen;
     if (base && bytes) {
-        if (hipHostRegister(base, bytes, hipHostRegisterDefault) == hipSuccess) view_locked = true;
-        else (void)hipGetLastError();
+        const hipError_t e = hipHostRegister(base, bytes, hipHostRegisterDefault);
+        if (e == hipSuccess) view_locked = true;
+        else {
+            (void)hipGetLastError();
+            static bool said = false;
+            if (!said) { said = true; std::fprintf(stderr, "libfoamyade_hip: could not page-lock the transport's %zu-byte view region (%s): its copies run pageable (staged, synchronous)\n", bytes, hipGetErrorString(e)); }
+        }
     }
     return FY_OK;
 }
@@ -979,6 +989,18 @@ int Coupling::commit_results(Batch& b, bool wait) {
     FY_TR(transport.send_commit(transport.user, b.out_force, 6 * (int)b.n, FY_T_DOUBLE, b.yrank, TAG_FORCE));
     wire_send_ms += wc.ms();
     b.committed = true;
+    return FY_OK;
+}
+
+// early hand-over of the batches before `upto` whose results have landed -- strictly in batch order: both D2H events sit on one stream, so two
+// batches can complete between two polls, and a helper (transport_mpi.cpp, W_TAG_RESULT) expects worker q's answers before worker q + 1's
+int Coupling::commit_landed(size_t upto) {
+    for (size_t e = 0; e < upto && e < (size_t)n_batches; ++e) {
+        Batch& b = *batches[e];
+        if (b.committed || b.n == 0 || !b.out_started) continue;       // (nothing to hand over for this worker: it does not hold the order up)
+        FY_TRY(commit_results(b, false));
+        if (!b.committed) break;                                        // not landed yet: the later ones wait for it
+    }
     return FY_OK;
 }
 

@@ -149,6 +149,7 @@ struct Coupling {
     int start_results_copy(Batch& b);           // D2H of one batch's forces + found flags, as soon as its kernels are enqueued
     int upload_batch(Batch& b, int64_t n, const double* src = nullptr);      // pinned h_rec (or the transport's view) -> rec_own on the copy stream; the compute stream waits for it
     int recv_yade_pieces(const std::vector<std::pair<int, int> >& in_comm);      // recv_yade_intrs with a transport that reports the record messages piece by piece
+    int commit_landed(size_t upto);             // the early hand-over of batches [0, upto), in ascending order, stopping at the first one still in flight
     int commit_results(Batch& b, bool wait);    // hand a batch's found flags and forces to the transport once their D2H has landed (wait = false: only if it has)
     int lock_view_region();                     // page-lock the memory the transport's views point into (fy_transport::view_region)
     void* view_base = nullptr; size_t view_bytes = 0; uint64_t view_generation = 0; bool view_locked = false;

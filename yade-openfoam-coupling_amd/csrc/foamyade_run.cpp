@@ -32,8 +32,13 @@
 #include "../../include/foamyade_mpi.h"
 #endif
 
+static bool g_mpi_up = false;
 static int die(const char* what) {
     std::fprintf(stderr, "foamYadeHip: %s: %s\n", what, fy_last_error());
+#ifdef FY_WITH_MPI
+    // the other ranks of the launch (wire helpers serving, Yade waiting in a receive) would hang on a rank that just left: take the job down
+    if (g_mpi_up) { std::fflush(stderr); MPI_Abort(MPI_COMM_WORLD, 1); }
+#endif
     return 1;
 }
 
@@ -105,6 +110,7 @@ int main(int argc, char** argv) {
     int srank = 0, ssize = 1;                       // this rank among the solver ranks
 #ifdef FY_WITH_MPI
     MPI_Init(&argc, &argv);
+    g_mpi_up = true;
     int world = 1, wrank = 0;
     MPI_Comm_size(MPI_COMM_WORLD, &world);
     MPI_Comm_rank(MPI_COMM_WORLD, &wrank);
@@ -125,6 +131,7 @@ int main(int argc, char** argv) {
         if (fy_mpi_transport_create_wire_helpers(n_yade, &tr, &is_helper) != FY_OK) return die("fy_mpi_transport_create_wire_helpers");
         if (is_helper) {                                  // receive and answer for my slab of the block until the computing rank is done
             const int rc = fy_mpi_wire_helper_serve(&tr);
+            g_mpi_up = false;
             MPI_Finalize();
             return rc == FY_OK ? 0 : 1;
         }
@@ -132,7 +139,7 @@ int main(int argc, char** argv) {
         solver_comm = MPI_COMM_SELF;
     } else if (n_yade != 0) {
         if (fy_mpi_transport_create(n_yade, &tr) != FY_OK) return die("fy_mpi_transport_create");
-        trp = &tr;
+        trp = tr.send ? &tr : nullptr;                    // (derived count 0: the fluid alone, in parallel -- no coupling transport)
         fy_mpi_local_comm(&tr, &solver_comm);
     }
     MPI_Comm_rank(solver_comm, &srank);
@@ -171,7 +178,8 @@ int main(int argc, char** argv) {
             std::printf("Create mesh: general polyhedral mesh (the block reader said: %s)\n", why.c_str());
             const int rc = run_general(fc, trp, device);
 #ifdef FY_WITH_MPI
-            if (trp) fy_mpi_transport_destroy(&tr);
+            if (tr.user) fy_mpi_transport_destroy(&tr);
+            g_mpi_up = false;
             MPI_Finalize();
 #endif
             return rc;
@@ -258,7 +266,8 @@ int main(int argc, char** argv) {
     if (comm) fy_comm_destroy(comm);
     fy_foam_case_close(fc);
 #ifdef FY_WITH_MPI
-    if (trp) fy_mpi_transport_destroy(&tr);
+    if (tr.user) fy_mpi_transport_destroy(&tr);
+    g_mpi_up = false;
     MPI_Finalize();
 #endif
     return 0;

@@ -200,10 +200,25 @@ __device__ __forceinline__ int swz_block(int bid, int nblk) {
     if (nblk % 8) return bid;
     return (bid % 8) * (nblk / 8) + bid / 8;
 }
+// Strip order (round 5): on top of the XCD's contiguous z-slab, its blocks run strip by strip -- a strip = strip_B consecutive 256-cell blocks of a
+// plane (a few rows), followed by the same strip of the next plane, and so on up the slab, before the next strip starts.  The cell above /
+// below the one a block is working on was then touched strip_B blocks ago instead of a whole plane of blocks ago: with a dozen arrays in a sweep a
+// plane of them (5 - 6 MB at 160^2) does not survive in the XCD's 4 MB L2 until the next plane comes by, a strip of them (300 KB) does.
+// Host side (Solver::create): strips only when planes are whole numbers of blocks and every XCD gets whole planes; FOAMYADE_STRIP_BLOCKS.
+// Returns the LOGICAL block (cells [256 b, 256 b + 256)); partial sums are stored under it, so folds do not depend on the order.
+__device__ __forceinline__ int fv_block(const FvGeo& g, int bid, int nblk) {
+    if (g.strip_B <= 0) return swz_block(bid, nblk);
+    const int x = bid & 7, l = bid >> 3;
+    const int per = g.strip_nzx * g.strip_B;
+    const int s = l / per, rem = l - s * per;
+    const int kk = rem / g.strip_B, b = rem - kk * g.strip_B;
+    return (x * g.strip_nzx + kk) * g.strip_bp + s * g.strip_B + b;
+}
 
 // ------------------------------------------------------------------------------------------------ block reductions (256 threads)
 template <int N>
-__device__ __forceinline__ void block_reduce_store(double (&v)[N], const int (&is_max)[N], double* partials) {
+__device__ __forceinline__ void block_reduce_store(double (&v)[N], const int (&is_max)[N], double* partials, int lb = -1) {
+    if (lb < 0) lb = (int)blockIdx.x;
     __shared__ double sh[4][N];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
@@ -221,7 +236,7 @@ __device__ __forceinline__ void block_reduce_store(double (&v)[N], const int (&i
         const int q = threadIdx.x;
         double x = sh[0][q];
         for (int w = 1; w < 4; ++w) x = is_max[q] ? fmax(x, sh[w][q]) : x + sh[w][q];
-        partials[(size_t)q * gridDim.x + blockIdx.x] = x;
+        partials[(size_t)q * gridDim.x + lb] = x;
     }
 }
 
@@ -262,6 +277,8 @@ __global__ __launch_bounds__(1024) void k_reduce_finalize(const double* __restri
 // the one-thread-per-cell smoother reaches 5.4), XCD-aware block order, one partial per block; k_reduce_finalize folds the
 // red_blocks(n) partials of a slot in a fixed order, so results are reproducible from run to run.
 #define FY_RED_LOOP(t, n) const int t = swz_block(blockIdx.x, gridDim.x) * 256 + (int)threadIdx.x; if (t < (n))
+// the same over the owned cells of g, blocks in strip order; fy_lb = the logical block (pass it to block_reduce_store)
+#define FY_RED_LOOP_G(g, t) const int fy_lb = fv_block(g, blockIdx.x, gridDim.x); const int t = fy_lb * 256 + (int)threadIdx.x; if (t < (g).Nc)
 
 // ------------------------------------------------------------------------------------------------ face kernels
 // generic face iteration: thread -> (d fixed per launch, face index f) -> local (i,j,k) of the face
@@ -340,7 +357,7 @@ __device__ __forceinline__ void rAUf_phi_forces_face(const FvGeo& g, size_t f, i
     out[f] = fl + r * (g.g[D] * geo_Af(g, D, i, j, k));
 }
 __global__ __launch_bounds__(256) void k_rAUf_phi_forces_cells(FvGeo g, const double* __restrict__ rAU, const double* __restrict__ uSource, Face3 rf, Face3 out) {
-    const int t = swz_block(blockIdx.x, gridDim.x) * 256 + (int)threadIdx.x;
+    const int t = fv_block(g, blockIdx.x, gridDim.x) * 256 + (int)threadIdx.x;
     if (t >= g.Nc) return;
     int i, j, k; ijk_of(g, t, i, j, k);
 #define FY_CALL(D, fi, fj, fk) { const size_t f = (size_t)fid(g, D, fi, fj, fk); rAUf_phi_forces_face<D>(g, f, fi, fj, fk, rAU, uSource, rf.a[D], out.a[D]); }
@@ -349,7 +366,7 @@ __global__ __launch_bounds__(256) void k_rAUf_phi_forces_cells(FvGeo g, const do
 }
 
 __global__ __launch_bounds__(256) void k_interp_alpha_cells(FvGeo g, const double* __restrict__ alpha, Face3 af) {
-    const int t = swz_block(blockIdx.x, gridDim.x) * 256 + (int)threadIdx.x;
+    const int t = fv_block(g, blockIdx.x, gridDim.x) * 256 + (int)threadIdx.x;
     if (t >= g.Nc) return;
     int i, j, k; ijk_of(g, t, i, j, k);
 #define FY_CALL(D, fi, fj, fk) { const size_t f = (size_t)fid(g, D, fi, fj, fk); interp_alpha_face<D>(g, f, fi, fj, fk, alpha, af.a[D]); }
@@ -401,7 +418,7 @@ template <int KEEP>
 __global__ __launch_bounds__(256) void k_phiHbyA_cells(FvGeo g, const double* __restrict__ HbyA, const double* __restrict__ U,
                                                        const double* __restrict__ Uold, CFace3 phiOld, CFace3 rAUf, CFace3 alphaf,
                                                        CFace3 phiForces, Face3 out, Face3 psn, Face3 ddtc) {
-    const int t = swz_block(blockIdx.x, gridDim.x) * 256 + (int)threadIdx.x;
+    const int t = fv_block(g, blockIdx.x, gridDim.x) * 256 + (int)threadIdx.x;
     if (t >= g.Nc) return;
     int i, j, k; ijk_of(g, t, i, j, k);
 #define FY_CALL(D, fi, fj, fk) { const size_t f = (size_t)fid(g, D, fi, fj, fk); \
@@ -433,14 +450,14 @@ __device__ __forceinline__ void adjust_phi_face(const FvGeo& g, size_t f, int i,
 }
 __global__ __launch_bounds__(256) void k_adjust_phi_sums(FvGeo g, CFace3 phiHbyA, CFace3 phiForces, double* __restrict__ partials) {
     double v[4] = {0.0, 0.0, 0.0, 0.0};
-    FY_RED_LOOP(t, g.Nc) {
+    FY_RED_LOOP_G(g, t) {
         int i, j, k; ijk_of(g, t, i, j, k);
 #define FY_CALL(D, fi, fj, fk) { const size_t f = (size_t)fid(g, D, fi, fj, fk); adjust_phi_face<D>(g, f, fi, fj, fk, phiHbyA.a[D], phiForces.a[D], v); }
         FY_CELL_FACES(g, i, j, k, FY_CALL);
 #undef FY_CALL
     }
     const int mx[4] = {0, 0, 0, 0};
-    block_reduce_store<4>(v, mx, partials);
+    block_reduce_store<4>(v, mx, partials, fy_lb);
 }
 // one thread per boundary face of the block (both sides of the three directions); err: set when OpenFOAM would stop with
 // "Continuity error cannot be removed by adjusting the outflow"
@@ -507,7 +524,7 @@ __device__ __forceinline__ void flux_correct_face(const FvGeo& g, size_t f, int 
 }
 __global__ __launch_bounds__(256) void k_flux_correct_cells(FvGeo g, const double* __restrict__ p, CFace3 phiHbyA, CFace3 rAUf, CFace3 alphaf, CFace3 psn,
                                                             CFace3 phiForces, Face3 pflux, Face3 phi) {
-    const int t = swz_block(blockIdx.x, gridDim.x) * 256 + (int)threadIdx.x;
+    const int t = fv_block(g, blockIdx.x, gridDim.x) * 256 + (int)threadIdx.x;
     if (t >= g.Nc) return;
     int i, j, k; ijk_of(g, t, i, j, k);
 #define FY_CALL(D, fi, fj, fk) { const size_t f = (size_t)fid(g, D, fi, fj, fk); \
@@ -520,7 +537,7 @@ __global__ __launch_bounds__(256) void k_flux_correct_cells(FvGeo g, const doubl
 // CourantNo.H:32-49: sumPhi = fvc::surfaceSum(mag(phi)); slots: 0 = max(sumPhi/V), 1 = sum(sumPhi)
 __global__ __launch_bounds__(256) void k_courant(FvGeo g, CFace3 phi, double* __restrict__ partials) {
     double v[2] = {0.0, 0.0};
-    FY_RED_LOOP(t, g.Nc) {
+    FY_RED_LOOP_G(g, t) {
         int i, j, k; ijk_of(g, t, i, j, k);
         double s = 0.0;
 #pragma unroll
@@ -531,7 +548,7 @@ __global__ __launch_bounds__(256) void k_courant(FvGeo g, CFace3 phi, double* __
         v[1] += s;
     }
     const int mx[2] = {1, 0};
-    block_reduce_store<2>(v, mx, partials);
+    block_reduce_store<2>(v, mx, partials, fy_lb);
 }
 
 // vGrad = fvc::grad(U) (icoFoamYade.C:71, pimpleFoamYade.C:76); pimple also gradP = fvc::grad(p) (:74) and
@@ -544,7 +561,7 @@ __global__ __launch_bounds__(256) void k_pre_coupling(FvGeo g, const double* __r
                                                       double* __restrict__ gradP, double* __restrict__ divT, double* __restrict__ Gout,
                                                       int write_vgrad, int write_pfields, CFace3 phi, double* __restrict__ ddtU, double* __restrict__ Uold_out,
                                                       double* __restrict__ cellrec, double rec_two_nu, double rec_rhoF) {
-    const int t = swz_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
+    const int t = fv_block(g, blockIdx.x, gridDim.x) * 256 + (int)threadIdx.x;
     if (t >= g.Nc) return;
     int i, j, k; ijk_of(g, t, i, j, k);
     const int c = t + g.c0;
@@ -631,7 +648,7 @@ __global__ __launch_bounds__(256) void k_pre_coupling(FvGeo g, const double* __r
 
 // divergence of the explicit part of divDevRhoReff (laminar Stokes), G = alpha nu dev2(T(grad U)) formed by k_pre_coupling, stored by rows
 __global__ __launch_bounds__(256) void k_div_G(FvGeo g, const double* __restrict__ G, double* __restrict__ divG) {
-    const int t = swz_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
+    const int t = fv_block(g, blockIdx.x, gridDim.x) * 256 + (int)threadIdx.x;
     if (t >= g.Nc) return;
     int i, j, k; ijk_of(g, t, i, j, k);
     const int c = t + g.c0;
@@ -941,7 +958,7 @@ __global__ __launch_bounds__(256) void k_assemble_momentum(FvGeo g, const double
                                                            CFace3 phi, const double* __restrict__ uSource, const double* __restrict__ uSourceDrag,
                                                            const double* __restrict__ divG, const double* __restrict__ vGrad, Mom7 M,
                                                            double* __restrict__ src, double* __restrict__ rAU) {
-    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int t = fv_block(g, blockIdx.x, gridDim.x) * 256 + (int)threadIdx.x;
     if (t >= g.Nc) return;
     int i, j, k; ijk_of(g, t, i, j, k);
     const int c = t + g.c0;
@@ -1047,7 +1064,7 @@ __global__ __launch_bounds__(256) void k_assemble_momentum(FvGeo g, const double
 //                                pimple src + V reconstruct(phicForces/rAUcf - snGrad(p) magSf)   (UcEqn.H:22-33)
 __global__ __launch_bounds__(256) void k_bmom(FvGeo g, const double* __restrict__ src, const double* __restrict__ p, CFace3 psn,
                                               CFace3 phiForces, CFace3 rAUf, double* __restrict__ bmom) {
-    const int t = swz_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
+    const int t = fv_block(g, blockIdx.x, gridDim.x) * 256 + (int)threadIdx.x;
     if (t >= g.Nc) return;
     int i, j, k; ijk_of(g, t, i, j, k);
     const int c = t + g.c0;
@@ -1087,7 +1104,7 @@ __global__ __launch_bounds__(256) void k_mom_pass(FvGeo g, Mom7 M, const double*
     // xbar = average(x) (lduMatrix::solver::normFactor): the component sums stay on the device (k_sum3 + fold [+ all-reduce]); dividing
     // them here saves the host round trip the average used to make
     const double xb[3] = {xsum[0] / n_glob, xsum[1] / n_glob, xsum[2] / n_glob};
-    FY_RED_LOOP(t, g.Nc) {
+    FY_RED_LOOP_G(g, t) {
         int i, j, k; ijk_of(g, t, i, j, k);
         const int c = t + g.c0;
         const double dg = M.diag[c];
@@ -1118,7 +1135,7 @@ __global__ __launch_bounds__(256) void k_mom_pass(FvGeo g, Mom7 M, const double*
         }
     }
     const int mx[6] = {0, 0, 0, 0, 0, 0};
-    block_reduce_store<6>(v, mx, partials);
+    block_reduce_store<6>(v, mx, partials, fy_lb);
 }
 
 // component sums over a contiguous range of n vectors starting at x
@@ -1133,7 +1150,7 @@ __global__ __launch_bounds__(256) void k_sum3(const double* __restrict__ x, int 
 // HbyA = rAU * UEqn.H() (icoFoamYade.C:100, pEqn.H:2)
 __global__ __launch_bounds__(256) void k_HbyA(FvGeo g, Mom7 M, const double* __restrict__ src, const double* __restrict__ U,
                                               const double* __restrict__ rAU, double* __restrict__ HbyA) {
-    const int t = swz_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
+    const int t = fv_block(g, blockIdx.x, gridDim.x) * 256 + (int)threadIdx.x;
     if (t >= g.Nc) return;
     int i, j, k; ijk_of(g, t, i, j, k);
     const int c = t + g.c0;
@@ -1165,7 +1182,7 @@ template <bool MATRIX>
 __global__ __launch_bounds__(256) void k_assemble_pressure(FvGeo g, CFace3 phiHbyA, CFace3 rAUf, CFace3 alphaf, CFace3 psn,
                                                            const double* __restrict__ alpha, const double* __restrict__ alphaOld, PMat A,
                                                            double* __restrict__ rhs) {
-    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int t = fv_block(g, blockIdx.x, gridDim.x) * 256 + (int)threadIdx.x;
     if (t >= g.Nc) return;
     int i, j, k; ijk_of(g, t, i, j, k);
     const int c = t + g.c0;
@@ -1209,7 +1226,7 @@ __global__ __launch_bounds__(256) void k_p_ghost_uz(FvGeo g, CFace3 rAUf, CFace3
 __global__ __launch_bounds__(256) void k_cont_err(FvGeo g, CFace3 phi, CFace3 alphaf, const double* __restrict__ alpha,
                                                   const double* __restrict__ alphaOld, double* __restrict__ partials) {
     double v[2] = {0, 0};
-    FY_RED_LOOP(t, g.Nc) {
+    FY_RED_LOOP_G(g, t) {
         int i, j, k; ijk_of(g, t, i, j, k);
         const int c = t + g.c0;
         double dv = 0;
@@ -1223,7 +1240,7 @@ __global__ __launch_bounds__(256) void k_cont_err(FvGeo g, CFace3 phi, CFace3 al
         v[1] += ce * geo_V(g, i, j, k);
     }
     const int mx[2] = {0, 0};
-    block_reduce_store<2>(v, mx, partials);
+    block_reduce_store<2>(v, mx, partials, fy_lb);
 }
 
 // ico:    U = HbyA - rAU*fvc::grad(p)                                                         icoFoamYade.C:136
@@ -1238,7 +1255,7 @@ __global__ __launch_bounds__(256) void k_U_correct(FvGeo g, const double* __rest
                                                    CFace3 rAUf, double* __restrict__ U, CFace3 phi, const double* __restrict__ alpha,
                                                    const double* __restrict__ alphaOld, double* __restrict__ partials) {
     double v[4] = {0, 0, 0, 0};
-    FY_RED_LOOP(t, g.Nc) {
+    FY_RED_LOOP_G(g, t) {
         int i, j, k; ijk_of(g, t, i, j, k);
         const int c = t + g.c0;
         const double r = rAU[c];
@@ -1282,8 +1299,284 @@ __global__ __launch_bounds__(256) void k_U_correct(FvGeo g, const double* __rest
     }
     if (DIAG) {
         const int mx[4] = {0, 0, 1, 0};
-        block_reduce_store<4>(v, mx, partials);
+        block_reduce_store<4>(v, mx, partials, fy_lb);
     }
+}
+
+// ------------------------------------------------------------------------------------------------ fused corrector sweeps (round 5)
+// The corrector used to be five cell-centred sweeps -- phiHbyA, pressure assembly, PCG's r0 = b - A p, flux correction, velocity correction --
+// each of which handed its face fields to the next through HBM (phiHbyA 24, psn, the flux term 24, rAUf / alphaf streamed by every one of them,
+// the matrix read back by k_p_init: SURVEY.md 8(d) prices a corrector at 504 B/cell, the five sweeps moved 730 - 800).  Here a cell forms the
+// values of ALL SIX of its faces itself -- same expressions, same operands, same order as the face functions above, so the same bits on both
+// sides of a face -- and uses them at once; only what a later pass needs is stored, by the face's owner (the cell on its high side; the low-side
+// cell for the last face of a row).  The neighbour values a cell needs twice as often come out of L1 / L2, not HBM.
+// FaceSrc: a linear face interpolate (alphacf, rAUf) either streamed from its face array or re-formed from the cell field (8 B/cell instead
+// of 24; the expression of the kernel that fills the array)
+struct FaceSrc { CFace3 arr; const double* cell; };
+template <int D>
+__device__ __forceinline__ double alphaf_at(const FvGeo& g, const FaceSrc& a, size_t f, int fi, int fj, int fk) {
+    if (!a.cell) return a.arr.a[D][f];
+    const int q = D == 0 ? fi : D == 1 ? fj : fk;
+    if (face_low_b(g, D, q) || face_high_b(g, D, q)) return 1.0;      // interp_alpha_face
+    const int c = cidx(g, fi, fj, fk);
+    return geo_lerp(g, D, q, a.cell[c - stride_of(g, D)], a.cell[c]);
+}
+template <int D>
+__device__ __forceinline__ double rAUf_at(const FvGeo& g, const FaceSrc& a, size_t f, int fi, int fj, int fk) {
+    if (!a.cell) return a.arr.a[D][f];
+    const int q = D == 0 ? fi : D == 1 ? fj : fk;
+    if (face_low_b(g, D, q)) return a.cell[cidx(g, fi, fj, fk)];     // k_interp_rAU / rAUf_phi_forces_face
+    if (face_high_b(g, D, q)) return a.cell[cidx(g, fi - (D == 0), fj - (D == 1), fk - (D == 2))];
+    const int c = cidx(g, fi, fj, fk);
+    return geo_lerp(g, D, q, a.cell[c - stride_of(g, D)], a.cell[c]);
+}
+// CALL(D, S, fi, fj, fk): the six faces of cell (i, j, k) in the order every per-cell sum over faces uses (x-, x+, y-, y+, z-, z+)
+#define FY_ALL_FACES(i, j, k, CALL) \
+    do { CALL(0, 0, i, j, k); CALL(0, 1, i + 1, j, k); CALL(1, 0, i, j, k); CALL(1, 1, i, j + 1, k); CALL(2, 0, i, j, k); CALL(2, 1, i, j, k + 1); } while (0)
+// does cell (i, j, k) store face (D, S)?  its low faces always, a high face where no cell lies beyond it in this domain
+__device__ __forceinline__ bool owns_face(const FvGeo& g, int d, int s, int i, int j, int k) {
+    return s == 0 || (d == 0 ? i == g.nx - 1 : d == 1 ? j == g.ny - 1 : k == g.nz - 1);
+}
+
+// Both sweeps are written GATHER FIRST: every operand of the six faces is loaded up front from an address that is always valid (across a
+// boundary face the "neighbour" is the cell itself), then the faces are evaluated from registers.  Written face by face -- a branch per face
+// with its loads inside -- a wave makes one dependent memory round trip per face and more (the first version of these kernels: 385 us for what
+// the three sweeps it replaced did in 396; 825 VALU instructions and 70 loads per wave, 3 % of the cycles waiting on anything but memory).
+// Only what boundary faces alone need (psn, U at a fixedFluxPressure patch) stays behind a branch: interior waves skip it.
+
+// value of a vector field's component d at a boundary face, from the field's own-cell value (Ub, component d: patch >> 1 == d here)
+__device__ __forceinline__ double ub_normal(const FvGeo& g, int patch, int d, double own_d) {
+    return g.u_bc[patch] == 0 ? g.u_val[patch][d] : (g.u_bc[patch] == 2 ? 0.0 : own_d);
+}
+// linear interpolate at face (d, s) of a cell from its own value and the value across the face (q = the FACE's index along d)
+__device__ __forceinline__ double lerp_face(const FvGeo& g, int d, int s, int q, double own, double nbv) {
+    return s ? geo_lerp(g, d, q, own, nbv) : geo_lerp(g, d, q, nbv, own);
+}
+
+// flux correction + velocity correction [+ continuity errors + the next pass's Courant sums] in one sweep (icoFoamYade.C:127-137, pEqn.H:39-45,
+// continuityErrs.H, CourantNo.H): k_flux_correct_cells and k_U_correct<DIAG> without the face field between them
+template <bool DIAG, bool FFC>
+__global__ __launch_bounds__(256) void k_corr_back(FvGeo g, const double* __restrict__ p, CFace3 phiHbyA, FaceSrc rAUf, FaceSrc alphaf, CFace3 psn,
+                                                   CFace3 phiForces, Face3 phi, const double* __restrict__ HbyA, const double* __restrict__ rAU,
+                                                   double* __restrict__ U, const double* __restrict__ alpha, const double* __restrict__ alphaOld,
+                                                   double* __restrict__ partials) {
+    double v[4] = {0, 0, 0, 0};
+    FY_RED_LOOP_G(g, t) {
+        int i, j, k; ijk_of(g, t, i, j, k);
+        const int c = t + g.c0;
+        const int ijk[3] = {i, j, k};
+        const bool pim = g.pimple != 0;
+        // ---- gather
+        bool bnd[3][2]; int nb[3][2], fx[3][2];
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                bnd[d][s] = onb(g, d, s, i, j, k);
+                nb[d][s] = bnd[d][s] ? c : c + (s ? stride_of(g, d) : -stride_of(g, d));
+                fx[d][s] = cface(g, d, s, i, j, k);
+            }
+        const double pc = p[c], rc = rAU[c], ac = pim ? alpha[c] : 1.0;
+        const double hb[3] = {HbyA[3 * (size_t)c], HbyA[3 * (size_t)c + 1], HbyA[3 * (size_t)c + 2]};
+        double pn[3][2], rfv[3][2], afv[3][2], phh[3][2], pfo[3][2];
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                pn[d][s] = p[nb[d][s]];
+                phh[d][s] = phiHbyA.a[d][fx[d][s]];
+                pfo[d][s] = pim ? phiForces.a[d][fx[d][s]] : 0.0;
+                if (FFC) { rfv[d][s] = rAU[nb[d][s]]; afv[d][s] = pim ? alpha[nb[d][s]] : 1.0; }
+                else { rfv[d][s] = rAUf.arr.a[d][fx[d][s]]; afv[d][s] = pim ? alphaf.arr.a[d][fx[d][s]] : 1.0; }
+            }
+        // ---- the six faces (flux_correct_face's expressions)
+        double pfl[3][2], ph[3][2];
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int q = ijk[d] + s;                       // the face's index along d
+                const int fi = i + (d == 0 ? s : 0), fj = j + (d == 1 ? s : 0), fk = k + (d == 2 ? s : 0);
+                const bool b = bnd[d][s];
+                if (FFC) {
+                    afv[d][s] = pim ? (b ? 1.0 : lerp_face(g, d, s, q, ac, afv[d][s])) : 1.0;          // interp_alpha_face
+                    rfv[d][s] = b ? rc : lerp_face(g, d, s, q, rc, rfv[d][s]);                           // k_interp_rAU / rAUf_phi_forces_face
+                }
+                const double af = afv[d][s], rf = rfv[d][s];
+                double fl = 0.0;
+                if (b) {
+                    const int patch = 2 * d + s;
+                    if (g.p_bc[patch] == 1) { const double gb = kBfac * af * rf * geo_sfd_face(g, d, q, ndim(g, d), fi, fj, fk); fl = s ? gb * (g.p_val[patch] - pc) : gb * (pc - g.p_val[patch]); }
+                    else if (g.p_bc[patch] == 2) fl = af * rf * geo_Af(g, d, fi, fj, fk) * psn.a[d][fx[d][s]];
+                } else {
+                    fl = af * rf * geo_sfd_face(g, d, q, ndim(g, d), fi, fj, fk) * (s ? pn[d][s] - pc : pc - pn[d][s]);
+                }
+                const double fa = fl / af;
+                pfl[d][s] = pim ? (pfo[d][s] - fa) / rf : fl;
+                ph[d][s] = phh[d][s] - fa;
+                if (owns_face(g, d, s, i, j, k)) phi.a[d][fx[d][s]] = ph[d][s];
+            }
+        // ---- the velocity correction and the diagnostics (k_U_correct's expressions)
+        double out[3];
+        double dv = 0.0, sp = 0.0;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            if (!pim) {
+                double fv[2];
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    if (bnd[d][s]) fv[s] = pbv(g, p, psn, c, d, s, fx[d][s]);
+                    else fv[s] = geo_lerp_side(g, d, s, ijk[d], pc, pn[d][s]);
+                }
+                out[d] = hb[d] - rc * ((fv[1] - fv[0]) * geo_rh(g, d, ijk[d]));
+            } else {
+                double sm = 0;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) sm += pfl[d][s];
+                out[d] = hb[d] + rc * (sm / (2.0 * geo_Af(g, d, i, j, k)));
+            }
+            if (DIAG) {
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    dv += (s ? 1.0 : -1.0) * (pim ? afv[d][s] : 1.0) * ph[d][s];
+                    sp += fabs(ph[d][s]);
+                }
+            }
+        }
+        for (int d = 0; d < 3; ++d) U[3 * (size_t)c + d] = out[d];
+        if (DIAG) {
+            double ce = dv * geo_rV(g, i, j, k);
+            if (pim) ce += (ac - alphaOld[c]) / g.dt;
+            v[0] += fabs(ce) * geo_V(g, i, j, k);
+            v[1] += ce * geo_V(g, i, j, k);
+            v[2] = fmax(v[2], sp * geo_rV(g, i, j, k));
+            v[3] += sp;
+        }
+    }
+    if (DIAG) {
+        const int mx[4] = {0, 0, 1, 0};
+        block_reduce_store<4>(v, mx, partials, fy_lb);
+    }
+}
+
+// phiHbyA + constrainPressure, the pressure equation's assembly and PCG's first residual r0 = b - A p with its norm factor in one sweep
+// (icoFoamYade.C:101-123, pEqn.H:4-33, PCG.C [OF-6]): k_phiHbyA_cells<KEEP>, k_assemble_pressure and k_p_init without phiHbyA, psn and the matrix
+// being read back in between.  The residual's row uses the face coefficients in p_row's order (x-, x+, y-, y+, z-, z+; a boundary face's stored
+// coefficient is 0 there, skipped here) and the block partition of k_p_init, so r0 and the two sums are k_p_init's bits.
+// KEEP 1 / 2: the ddtCorr term is stored / read back (phiHbyA_face).  STORE_A = false: a later corrector of the same momentum assembly -- the
+// matrix in A stands (same rAU, same alphacf)
+template <int KEEP, bool STORE_A, bool FFC>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k_corr_front(FvGeo g, const double* __restrict__ HbyA, const double* __restrict__ U, const double* __restrict__ Uold,
+                                                    CFace3 phiOld, FaceSrc rAUf, FaceSrc alphaf, CFace3 phiForces, Face3 phiHbyA, Face3 psn, Face3 ddtc,
+                                                    const double* __restrict__ rAU, const double* __restrict__ alpha, const double* __restrict__ alphaOld, PMat A,
+                                                    double* __restrict__ rhs, const double* __restrict__ x, const double* __restrict__ xbar_dev, double xsum_val,
+                                                    double inv_n, double* __restrict__ res, double* __restrict__ partials) {
+    double v[2] = {0, 0};
+    const double xbar = (xbar_dev ? xbar_dev[0] : xsum_val) * inv_n;
+    FY_RED_LOOP_G(g, t) {
+        int i, j, k; ijk_of(g, t, i, j, k);
+        const int c = t + g.c0;
+        const int ijk[3] = {i, j, k};
+        const bool pim = g.pimple != 0;
+        const bool refc = g.need_ref && (i + g.nx * (j + g.ny * (k + g.kglob0))) == g.p_ref_cell;
+        // ---- gather
+        bool bnd[3][2]; int nb[3][2], fx[3][2];
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                bnd[d][s] = onb(g, d, s, i, j, k);
+                nb[d][s] = bnd[d][s] ? c : c + (s ? stride_of(g, d) : -stride_of(g, d));
+                fx[d][s] = cface(g, d, s, i, j, k);
+            }
+        const double xc = x[c], ac = pim ? alpha[c] : 1.0;
+        const double rc = FFC ? rAU[c] : 0.0;
+        const double hb[3] = {HbyA[3 * (size_t)c], HbyA[3 * (size_t)c + 1], HbyA[3 * (size_t)c + 2]};
+        double uo[3] = {0, 0, 0};
+        if (KEEP != 2) { uo[0] = Uold[3 * (size_t)c]; uo[1] = Uold[3 * (size_t)c + 1]; uo[2] = Uold[3 * (size_t)c + 2]; }
+        double hn[3][2], un[3][2], po[3][2], pfo[3][2], xn[3][2], rfv[3][2], afv[3][2];
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                hn[d][s] = HbyA[3 * (size_t)nb[d][s] + d];
+                if (KEEP != 2) { un[d][s] = Uold[3 * (size_t)nb[d][s] + d]; po[d][s] = phiOld.a[d][fx[d][s]]; }
+                else { un[d][s] = 0.0; po[d][s] = ddtc.a[d][fx[d][s]]; }                   // (po: the stored ddtCorr term)
+                pfo[d][s] = pim ? phiForces.a[d][fx[d][s]] : 0.0;
+                xn[d][s] = x[nb[d][s]];
+                if (FFC) { rfv[d][s] = rAU[nb[d][s]]; afv[d][s] = pim ? alpha[nb[d][s]] : 1.0; }
+                else { rfv[d][s] = rAUf.arr.a[d][fx[d][s]]; afv[d][s] = pim ? alphaf.arr.a[d][fx[d][s]] : 1.0; }
+            }
+        // ---- the six faces: phiHbyA_face, then k_assemble_pressure's terms
+        double dg = 0.0, r = 0.0, up[3] = {0, 0, 0};
+        double gg6[3][2];                          // coefficient towards the neighbour across face (d, s); 0 on a physical boundary
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int q = ijk[d] + s;
+                const int fi = i + (d == 0 ? s : 0), fj = j + (d == 1 ? s : 0), fk = k + (d == 2 ? s : 0);
+                const bool b = bnd[d][s];
+                const int patch = 2 * d + s;
+                if (FFC) {
+                    afv[d][s] = pim ? (b ? 1.0 : lerp_face(g, d, s, q, ac, afv[d][s])) : 1.0;
+                    rfv[d][s] = b ? rc : lerp_face(g, d, s, q, rc, rfv[d][s]);
+                }
+                const double af = afv[d][s], rf = rfv[d][s];
+                const double Afc = geo_Af(g, d, fi, fj, fk);
+                double pv = (b ? ub_normal(g, patch, d, hb[d]) : lerp_face(g, d, s, q, hb[d], hn[d][s])) * Afc;      // face_flux_vec(HbyA)
+                double add;
+                if (KEEP == 2) {
+                    add = po[d][s];
+                } else {
+                    const double uf = (b ? ub_normal(g, patch, d, uo[d]) : lerp_face(g, d, s, q, uo[d], un[d][s])) * Afc;
+                    const bool fixes = b && g.u_bc[patch] == 0;
+                    const double phiCorr = po[d][s] - uf;
+                    const double coef = fixes ? 0.0 : 1.0 - fmin(fabs(phiCorr) / (fabs(po[d][s]) + kSmall), 1.0);
+                    add = rf * (coef * (1.0 / g.dt) * phiCorr);
+                    if (pim) add *= af;
+                }
+                pv += add;
+                if (pim) pv += pfo[d][s];
+                const bool own = owns_face(g, d, s, i, j, k);
+                if (own) { phiHbyA.a[d][fx[d][s]] = pv; if (KEEP == 1) ddtc.a[d][fx[d][s]] = add; }
+                double ph = (s ? 1.0 : -1.0) * af * pv;
+                gg6[d][s] = 0.0;
+                if (b) {
+                    if (g.p_bc[patch] == 2) {               // constrainPressure (fixedFluxPressure): snGrad(p) from the flux that must pass
+                        const double ubd = ub_normal(g, patch, d, g.u_bc[patch] == 1 ? U[3 * (size_t)c + d] : 0.0);
+                        const double psn_v = (pv - ubd * Afc) / (rf * Afc);
+                        if (own) psn.a[d][fx[d][s]] = psn_v;
+                        ph = (s ? 1.0 : -1.0) * af * (pv - rf * geo_Af(g, d, i, j, k) * psn_v);
+                    }
+                    r -= ph;
+                    if (g.p_bc[patch] == 1) { const double gb = kBfac * af * rf * geo_sfd(g, d, s, i, j, k); dg += gb; r += gb * g.p_val[patch]; }
+                } else {
+                    r -= ph;
+                    const double gg = af * rf * geo_sfd(g, d, s, i, j, k);
+                    dg += gg; gg6[d][s] = gg;
+                    if (s) up[d] = gg;
+                }
+            }
+        if (pim) r -= geo_V(g, i, j, k) * (ac - alphaOld[c]) / g.dt;
+        if (refc) { r += dg * g.p_ref_value; dg += dg; }
+        if (STORE_A) { A.diag[c] = dg; A.ux[c] = up[0]; A.uy[c] = up[1]; A.uz[c] = up[2]; }
+        rhs[c] = r;
+        // ---- r0 = b - A x, sum |r0|, the norm factor's sum (k_p_init)
+        double Ax = dg * xc, rs = dg;
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+                if (!bnd[d][s]) { Ax -= gg6[d][s] * xn[d][s]; rs -= gg6[d][s]; }
+        const double Aref = rs * xbar;
+        const double rr = r - Ax;
+        res[c] = rr;
+        v[0] += fabs(rr);
+        v[1] += fabs(Ax - Aref) + fabs(r - Aref);
+    }
+    const int mx[2] = {0, 0};
+    block_reduce_store<2>(v, mx, partials, fy_lb);
 }
 
 // ------------------------------------------------------------------------------------------------ pressure solver
@@ -2068,6 +2361,36 @@ int launch_U_correct(hipStream_t s, FvGeo g, const double* HbyA, const double* r
 int launch_U_correct_diag(hipStream_t s, FvGeo g, const double* HbyA, const double* rAU, const double* p, CFace3 psn, CFace3 phiForces,
                           CFace3 pflux, CFace3 alphaf, CFace3 rAUf, double* U, CFace3 phi, const double* alpha, const double* alphaOld, double* partials) {
     hipLaunchKernelGGL(k_U_correct<true>, dim3(red_blocks(g.Nc)), dim3(256), 0, s, g, HbyA, rAU, p, psn, phiForces, pflux, alphaf, rAUf, U, phi, alpha, alphaOld, partials);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+
+int launch_corr_back(hipStream_t s, FvGeo g, const double* p, CFace3 phiHbyA, CFace3 rAUf, CFace3 alphaf, CFace3 psn, CFace3 phiForces, Face3 phi,
+                     const double* HbyA, const double* rAU, double* U, const double* alpha, const double* alphaOld, double* partials, bool faces_from_cells) {
+    const FaceSrc rs{rAUf, faces_from_cells ? rAU : nullptr}, as{alphaf, faces_from_cells ? alpha : nullptr};
+    const dim3 grid(red_blocks(g.Nc)), blk(256);
+#define FY_BACK(DG, FC) hipLaunchKernelGGL((k_corr_back<DG, FC>), grid, blk, 0, s, g, p, phiHbyA, rs, as, psn, phiForces, phi, HbyA, rAU, U, alpha, alphaOld, partials)
+    if (partials) { if (faces_from_cells) FY_BACK(true, true); else FY_BACK(true, false); }
+    else { if (faces_from_cells) FY_BACK(false, true); else FY_BACK(false, false); }
+#undef FY_BACK
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+
+int launch_corr_front(hipStream_t s, FvGeo g, const double* HbyA, const double* U, const double* Uold, CFace3 phiOld, CFace3 rAUf, CFace3 alphaf,
+                      CFace3 phiForces, Face3 phiHbyA, Face3 psn, Face3 ddtc, int keep, const double* rAU, const double* alpha, const double* alphaOld, PMat A,
+                      double* rhs, bool store_A, const double* x, const double* xsum_dev, double xsum_val, double inv_n, double* res, double* partials,
+                      bool faces_from_cells) {
+    const FaceSrc rs{rAUf, faces_from_cells ? rAU : nullptr}, as{alphaf, faces_from_cells ? alpha : nullptr};
+    const dim3 grid(red_blocks(g.Nc)), blk(256);
+#define FY_FRONT(K, SA, FC) hipLaunchKernelGGL((k_corr_front<K, SA, FC>), grid, blk, 0, s, g, HbyA, U, Uold, phiOld, rs, as, phiForces, phiHbyA, psn, ddtc, rAU, alpha, alphaOld, A, rhs, \
+                                               x, xsum_dev, xsum_val, inv_n, res, partials)
+#define FY_FRONT2(K, SA) do { if (faces_from_cells) FY_FRONT(K, SA, true); else FY_FRONT(K, SA, false); } while (0)
+    if (keep == 1) { if (store_A) FY_FRONT2(1, true); else FY_FRONT2(1, false); }
+    else if (keep == 2) { if (store_A) FY_FRONT2(2, true); else FY_FRONT2(2, false); }
+    else return fail(FY_ERR_INVALID, "launch_corr_front: keep must be 1 (first corrector of an assembly) or 2");
+#undef FY_FRONT2
+#undef FY_FRONT
     FY_LAUNCH_CHECK();
     return FY_OK;
 }

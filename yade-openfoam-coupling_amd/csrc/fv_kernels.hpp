@@ -54,6 +54,9 @@ struct FvGeo {
     // kernels keep their constants dx / Af / V and are untouched by it
     int graded;
     const double* h[3];
+    // strip order of the cell sweeps' blocks (fv_block in fv_kernels.hip): strip_B blocks per strip (0: off -- the plain XCD-contiguous order),
+    // strip_bp = 256-cell blocks per z-plane, strip_nzx = planes per XCD
+    int strip_B, strip_bp, strip_nzx;
 };
 
 struct Face3 { double* a[3]; };           // +axis oriented face arrays (x: (nx+1)*ny*nz, y: nx*(ny+1)*nz, z: nx*ny*(nz+1))

@@ -259,19 +259,25 @@ int Solver::build_coarse_operators() {
 
 // OpenFOAM PCG.C with lduMatrix::solver::normFactor, in the single-reduction form (see k_pcg_cg_update); preconditioner = MG V-cycle or Jacobi.
 // sc: [0] gamma = u.r, [1] delta = u.Au, [2..5] two sets {gamma_old, alpha_old}, [6] sum(p)
-int Solver::solve_pressure(bool final_iter) {
-    Comm::Tag tag(comm, "pcg");
-    MgLev& L = *mg[0];
-    const double tol = final_iter ? cs.p_final_tol : cs.p_tol, rel = final_iter ? cs.p_final_rel_tol : cs.p_rel_tol;
-    double h[2];
+int Solver::prepare_p_init() {
     // xbar = average(p) for lduMatrix::solver::normFactor: sum(p) over the owned cells, all-reduced.  The last PCG update of p left it with the
     // host (k_pcg_cg_update's second slot: the same partition and order as the sum below, the same bits); p_sum_valid falls when anything else writes p
     if (!p_sum_valid) {
         FY_TRY(launch_dot(stream, Nc, g.c0, p.p, nullptr, partials.p));
         FY_TRY(reduce_to_device(sc.p + 6));
     }
-    FY_TRY(halo_p());
-    FY_TRY(launch_p_init(stream, L.A, prhs.p, p.p, p_sum_valid ? nullptr : sc.p + 6, p_sum, 1.0 / (double)Nglob, pr.p, partials.p));
+    return halo_p();
+}
+
+int Solver::solve_pressure(bool final_iter, bool init_done) {
+    Comm::Tag tag(comm, "pcg");
+    MgLev& L = *mg[0];
+    const double tol = final_iter ? cs.p_final_tol : cs.p_tol, rel = final_iter ? cs.p_final_rel_tol : cs.p_rel_tol;
+    double h[2];
+    if (!init_done) {
+        FY_TRY(prepare_p_init());
+        FY_TRY(launch_p_init(stream, L.A, prhs.p, p.p, p_sum_valid ? nullptr : sc.p + 6, p_sum, 1.0 / (double)Nglob, pr.p, partials.p));
+    }
     FY_TRY(reduce_read(2, false, h));
     const double norm = h[1] + 1e-20;
     double res = h[0] / norm;

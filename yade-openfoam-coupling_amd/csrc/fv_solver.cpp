@@ -40,6 +40,8 @@ int Solver::create(const fy_case_desc* c, const fy_transport* tr, int dev, Comm*
     FY_HIP(hipEventCreateWithFlags(&ev_usum1, hipEventDisableTiming));
     FY_HIP(hipEventCreateWithFlags(&ev_coarse, hipEventDisableTiming));
     overlap_halos = !options().no_halo_overlap;
+    fused_corrector = !options().no_fused_corrector;
+    faces_from_cells = !options().faces_from_arrays;
     comm->set_aux_stream(comm_stream);
     // ---- slab extents: the case describes the GLOBAL block; rank r owns planes [r*nz, (r+1)*nz)
     const int S = comm->size;
@@ -73,6 +75,18 @@ int Solver::create(const fy_case_desc* c, const fy_transport* tr, int dev, Comm*
         g.dx = std::cbrt((h_host[0][0] * h_host[1][0]) * h_host[2][0]);       // (only what still assumes cubes reads it: nothing on this path)
         g.Af = g.dx * g.dx; g.V = g.dx * g.dx * g.dx;
         total_volume = (len[0] * len[1]) * len[2];
+    }
+    // strip order of the cell sweeps (fv_kernels.hip, fv_block): only where a plane is a whole number of 256-cell blocks and every XCD gets whole planes
+    g.strip_B = g.strip_bp = g.strip_nzx = 0;
+    {
+        const int want = options().strip_blocks;
+        if (want != 0 && plane % 256 == 0 && nzl % 8 == 0) {
+            const int bp = (int)(plane / 256);
+            const int target = want > 0 ? want : std::max(1, (int)std::lround(8.0 * c->nx / 256.0));      // ~8 rows of cells
+            int best = 1;
+            for (int d = 1; d <= bp; ++d) if (bp % d == 0 && std::abs(d - target) < std::abs(best - target)) best = d;
+            g.strip_B = best; g.strip_bp = bp; g.strip_nzx = nzl / 8;
+        }
     }
     g.upwind = c->convection_scheme;          // 0 linear, 1 upwind, 2 linearUpwind, 3 .. 8 limited
     g.lim_twoByk = 2.0 / std::max(c->convection_limiter_k, 1e-15);
@@ -418,18 +432,33 @@ int Solver::corrector(bool final_inner) {
     // not between the PISO correctors of one assembly
     if (!pimple && rAU_new) { FY_TRY(halo_cells(rAU, 1, 1)); FY_TRY(FVK(launch_interp_rAU, stream, g, rAU.p, F3(rAUf))); }
     FY_TRY(halo_cells(HbyA, 3, 1));
-    // the ddtCorr term is the same in every corrector of one momentum assembly: stored by the first, read back by the others
-    FY_TRY(FVK(launch_phiHbyA, stream, g, HbyA.p, U.p, Uold.p, C3(phiOld), C3(rAUf), C3(alphaf), C3(phiForces), F3(phiHbyA), F3(psn), F3(ddtc), rAU_new ? 1 : 2));
-    if (adjust_phi) {                                       // icoFoamYade.C:108, pEqn.H:13-16
-        FY_TRY(FVK(launch_adjust_phi_sums, stream, g, C3(phiHbyA), C3(phiForces), partials.p));
-        FY_TRY(launch_reduce_finalize(stream, partials.p, Nc, 4, nullptr, adj_sums.p));
-        FY_TRY(comm->allreduce(stream, adj_sums.p, 4, false));
-        FY_TRY(FVK(launch_adjust_phi_apply, stream, g, adj_sums.p, F3(phiHbyA), C3(phiForces), C3(rAUf), U.p, F3(psn), adj_err.p));
-    }
     MgLev& L = *mg[0];
-    clk_pres.begin(stream);
+    // the two fused sweeps (fv_kernels.hip "fused corrector sweeps") stand for phiHbyA + assembly + PCG's first residual and for the flux + velocity
+    // corrections; adjustPhi, which needs global sums of phiHbyA between the first two, keeps the separate sweeps
+    const bool fused_front = fused_corrector && !adjust_phi;
+    const bool fused_back = fused_corrector;
+    // the fused sweeps re-form rAUf / alphacf from rAU / alpha; both cell fields carry fresh ghost planes here (rAU: exchanged after the assembly below /
+    // above; alpha: by the coupling)
+    const bool ffc = faces_from_cells;
+    if (fused_front) {
+        // the ddtCorr term is the same in every corrector of one momentum assembly: stored by the first, read back by the others
+        clk_pres.begin(stream);
+        FY_TRY(prepare_p_init());
+        FY_TRY(FVK(launch_corr_front, stream, g, HbyA.p, U.p, Uold.p, C3(phiOld), C3(rAUf), C3(alphaf), C3(phiForces), F3(phiHbyA), F3(psn), F3(ddtc), rAU_new ? 1 : 2,
+                   rAU.p, alpha.p, /* alphaOld */ alpha.p, L.A, prhs.p, rAU_new, p.p, p_sum_valid ? nullptr : sc.p + 6, p_sum, 1.0 / (double)Nglob, pr.p, partials.p, ffc));
+    } else {
+        FY_TRY(FVK(launch_phiHbyA, stream, g, HbyA.p, U.p, Uold.p, C3(phiOld), C3(rAUf), C3(alphaf), C3(phiForces), F3(phiHbyA), F3(psn), F3(ddtc), rAU_new ? 1 : 2));
+        if (adjust_phi) {                                       // icoFoamYade.C:108, pEqn.H:13-16
+            FY_TRY(FVK(launch_adjust_phi_sums, stream, g, C3(phiHbyA), C3(phiForces), partials.p));
+            FY_TRY(launch_reduce_finalize(stream, partials.p, Nc, 4, nullptr, adj_sums.p));
+            FY_TRY(comm->allreduce(stream, adj_sums.p, 4, false));
+            FY_TRY(FVK(launch_adjust_phi_apply, stream, g, adj_sums.p, F3(phiHbyA), C3(phiForces), C3(rAUf), U.p, F3(psn), adj_err.p));
+        }
+        clk_pres.begin(stream);
+    }
     for (int no = 0; no <= cs.n_non_orth_correctors; ++no) {
-        FY_TRY(FVK(launch_assemble_pressure, stream, g, C3(phiHbyA), C3(rAUf), C3(alphaf), C3(psn), alpha.p, /* alphaOld */ alpha.p, L.A, prhs.p, rAU_new));
+        const bool front_done = fused_front && no == 0;
+        if (!front_done) FY_TRY(FVK(launch_assemble_pressure, stream, g, C3(phiHbyA), C3(rAUf), C3(alphaf), C3(psn), alpha.p, /* alphaOld */ alpha.p, L.A, prhs.p, rAU_new));
         if (rAU_new && L.distributed && comm->has_down() && !mg_deep) FY_TRY(FVK(launch_p_ghost_uz, stream, g, C3(rAUf), C3(alphaf), L.A));
         if (rAU_new) {                                        // same matrix as in the previous corrector otherwise: only the right-hand side moved
             if (comm->size == 1 && cs.p_solver == FY_PSOLVER_PCG_MG && mg.size() > 1) {
@@ -446,9 +475,9 @@ int Solver::corrector(bool final_inner) {
             }
         }
         rAU_new = false;
-        FY_TRY(solve_pressure(final_inner && no == cs.n_non_orth_correctors));
+        FY_TRY(solve_pressure(final_inner && no == cs.n_non_orth_correctors, front_done));
         FY_TRY(wait_coarse());                                // (a solve that never left level 0)
-        if (no == cs.n_non_orth_correctors) {
+        if (no == cs.n_non_orth_correctors && !fused_back) {
             FY_TRY(halo_p());
             FY_TRY(FVK(launch_flux_correct, stream, g, p.p, C3(phiHbyA), C3(rAUf), C3(alphaf), C3(psn), C3(phiForces), F3(pflux), F3(phi)));
             phi_fresh = true;
@@ -460,7 +489,30 @@ int Solver::corrector(bool final_inner) {
     clk_pres.end(stream);
     double h[2];
     int slot = 0, rc = FY_OK;
-    if (fuse_diag && red_host && n_deferred + 4 <= kDeferMax) {
+    const bool diag_fused = fuse_diag && red_host && n_deferred + 4 <= kDeferMax;
+    if (fused_back) {
+        // flux correction + velocity correction [+ the continuity errors and the NEXT step's Courant sums] in one sweep; p.relax() (pEqn.H:41) after it:
+        // the sweep works with the unrelaxed solution, as pEqn.flux() and the reconstruction do (ico reads p itself, but has no relaxation)
+        FY_TRY(halo_p());
+        FY_TRY(FVK(launch_corr_back, stream, g, p.p, C3(phiHbyA), C3(rAUf), C3(alphaf), C3(psn), C3(phiForces), F3(phi), HbyA.p, rAU.p, U.p, alpha.p,
+                   /* alphaOld */ alpha.p, diag_fused ? partials.p : nullptr, ffc));
+        phi_fresh = true;
+        U_ghosts_fresh = false;
+        if (pimple && p_relax_now > 0 && p_relax_now < 1) { FY_TRY(launch_relax_field(stream, p.p, pPrev.p, p_relax_now, nstore)); p_sum_valid = false; p_ghosts_fresh = false; }
+        if (diag_fused) {
+            if (!reduce_deferred(4, false, &slot, &rc, ops_diag.p)) return fail(FY_ERR_INVALID, "no room for the deferred diagnostics");
+            FY_TRY(rc);
+            cont_slots.push_back(slot);
+            carry_slot = slot + 2;
+            return FY_OK;
+        }
+        carry_slot = -1;
+        FY_TRY(FVK(launch_cont_err, stream, g, C3(phi), C3(alphaf), alpha.p, /* alphaOld */ alpha.p, partials.p));
+        if (reduce_deferred(2, false, &slot, &rc)) { FY_TRY(rc); cont_slots.push_back(slot); }
+        else { FY_TRY(reduce_read(2, false, h)); note_cont_err(h); }
+        return FY_OK;
+    }
+    if (diag_fused) {
         // the continuity errors and the NEXT step's Courant sums ride on the velocity correction's sweep
         // (k_U_correct<true>; same values as k_cont_err / k_courant) instead of being two sweeps of their own
         FY_TRY(FVK(launch_U_correct_diag, stream, g, HbyA.p, rAU.p, p.p, C3(psn), C3(phiForces), C3(pflux), C3(alphaf), C3(rAUf), U.p, C3(phi), alpha.p,

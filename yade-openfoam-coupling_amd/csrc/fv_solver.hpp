@@ -197,7 +197,11 @@ struct Solver {
     DevBuf<double> mg_inv, mg_ref;
     double p_sum = 0.0;            // sum(p) over all cells as the last PCG update left it (solve_pressure)
     bool p_sum_valid = false;
-    int solve_pressure(bool final_iter);      // OpenFOAM PCG.C with lduMatrix::solver::normFactor; preconditioner = MG V-cycle or Jacobi
+    // init_done: r0 = b - A p and its two sums are already in pr / partials (the fused corrector sweep formed them: prepare_p_init + launch_corr_front)
+    int solve_pressure(bool final_iter, bool init_done = false);      // OpenFOAM PCG.C with lduMatrix::solver::normFactor; preconditioner = MG V-cycle or Jacobi
+    int prepare_p_init();          // sum(p) for the norm factor's xbar where the last PCG update did not leave it, and p's ghost planes
+    bool fused_corrector = true;   // the corrector as two fused sweeps (FOAMYADE_NO_FUSED_CORRECTOR=1: the five sweeps of rounds 1 - 4; identical results)
+    bool faces_from_cells = true;  // the fused sweeps re-form rAUf / alphacf from rAU / alpha (FOAMYADE_FACES_FROM_ARRAYS=1: stream the face arrays)
 
     // ---- one PISO / PIMPLE corrector (icoFoamYade.C:97-140, pEqn.H)
     int corrector(bool final_inner);

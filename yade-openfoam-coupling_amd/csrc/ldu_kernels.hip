@@ -937,7 +937,10 @@ __global__ __launch_bounds__(256) void k_ldu_find_cell(LduGeo g, const double* _
     int c = hint[i];
     if (!(x.x == x.x) || !(x.y == x.y) || !(x.z == x.z)) c = -1;
     for (int hop = 0; c >= 0 && hop < 64; ++hop) {
-        double worst = 0.0;
+        // step across the INTERNAL face the point is furthest outside of; the point is outside the mesh only when every face it violates is a
+        // boundary (or cyclic) face -- on a curved or concave boundary the extended plane of the hint cell's wall face can be the worst offender
+        // while an internal face still leads to the containing cell
+        double worst = 0.0, worst_b = 0.0;
         int wf = -1, wn = -1;
         const double tol = 1e-10 * cbrt(g.V[c]);
         FY_CELL_FACES(g, c, f, nb) {
@@ -947,10 +950,15 @@ __global__ __launch_bounds__(256) void k_ldu_find_cell(LduGeo g, const double* _
             const bool folded = g.sep && f >= g.nIntReal && f < g.nInt;
             if (folded && sg < 0) { const D3 sp = ld3(g.sep, f); cf = D3{cf.x - sp.x, cf.y - sp.y, cf.z - sp.z}; }      // (seen from the neighbour, the face lies at that cell's own half)
             const double s = sg * dot3(D3{x.x - cf.x, x.y - cf.y, x.z - cf.z}, S) / g.magSf[f];
-            if (s > worst) { worst = s; wf = f; wn = folded ? -1 : nb; }      // (beyond a cyclic half = outside the mesh, as mesh.findCell has it)
+            const int to = folded ? -1 : nb;                                  // (beyond a cyclic half = outside the mesh, as mesh.findCell has it)
+            if (to >= 0) { if (s > worst) { worst = s; wf = f; wn = to; } }
+            else if (s > worst_b) worst_b = s;
         }
-        if (wf < 0 || worst <= tol) break;
-        c = wn;                                     // (-1 across a boundary face: outside the mesh)
+        if (wf < 0 || worst <= tol) {               // no internal face violated: inside this cell, or beyond a boundary face of it
+            if (worst_b > tol) c = -1;
+            break;
+        }
+        c = wn;
         if (hop == 63) c = -1;
     }
     cell_out[i] = c;

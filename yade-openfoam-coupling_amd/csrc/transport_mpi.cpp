@@ -55,6 +55,11 @@ struct Wire {
     size_t bytes = 0;
     long long cap = 0;
     unsigned long long generation = 0;
+    // mappings the arena has outgrown: the library may still hold them page-locked (hipHostRegister) until it has seen the new generation through
+    // view_region -- unmapping registered memory is undefined for the HIP runtime -- so they are unmapped one view_region call later
+    struct Retired { char* mem; size_t bytes; unsigned long long gen; };
+    std::vector<Retired> retired;
+    unsigned long long reported_generation = 0;
     double* rec() const { return reinterpret_cast<double*>(mem); }
     double* force() const { return reinterpret_cast<double*>(mem) + 10 * cap; }
     int* found() const { return reinterpret_cast<int*>(reinterpret_cast<double*>(mem) + 16 * cap); }
@@ -62,7 +67,11 @@ struct Wire {
 };
 
 int wire_map(Wire& w, long long cap, bool create) {
-    if (w.mem) { munmap(w.mem, w.bytes); w.mem = nullptr; }
+    if (w.mem) {
+        if (create) w.retired.push_back({w.mem, w.bytes, w.generation + 1});      // (the computing rank: see Wire::retired; helpers never register theirs)
+        else munmap(w.mem, w.bytes);
+        w.mem = nullptr;
+    }
     const size_t bytes = (size_t)cap * (16 * sizeof(double) + sizeof(int)) + 4096;
     if (create) {
         if (w.fd < 0) {
@@ -239,7 +248,13 @@ int h_send_commit(void* u, const void*, int, int, int dest, int tag) {
 }
 int h_view_region(void* u, void** base, size_t* bytes, uint64_t* generation) {
     Wire& w = *static_cast<Wire*>(u);
+    // what was retired before the generation the library saw LAST time has been unregistered by it since (Coupling::lock_view_region)
+    for (size_t q = 0; q < w.retired.size();) {
+        if (w.retired[q].gen <= w.reported_generation) { munmap(w.retired[q].mem, w.retired[q].bytes); w.retired.erase(w.retired.begin() + (long)q); }
+        else ++q;
+    }
     *base = w.mem; *bytes = w.mem ? w.bytes : 0; *generation = w.generation;
+    w.reported_generation = w.generation;
     return 0;
 }
 }  // namespace
@@ -313,16 +328,22 @@ int fy_mpi_wire_helper_serve(fy_transport* t) {
         // back the answers it has for the other workers
         {
             std::vector<MPI_Request> rq;
+            std::vector<char> served((size_t)w.W, 0);
             for (int q = 1; q <= w.W; ++q) {
                 const int c = w.counts[(size_t)(q - 1) * w.K + w.me];
                 if (c <= 0) continue;
+                // the computing rank reports a worker's answers when their copy has landed -- in ascending worker order as it is written, but nothing
+                // here depends on that: whichever worker is named is served (once)
                 int which = 0;
-                if (MPI_Recv(&which, 1, MPI_INT, 0, W_TAG_RESULT, w.foam, &st) != MPI_SUCCESS || which != q) return FY_ERR_TRANSPORT;
-                const long long at = w.base[(size_t)(q - 1)] + w.off[(size_t)(q - 1) * w.K + w.me];
+                if (MPI_Recv(&which, 1, MPI_INT, 0, W_TAG_RESULT, w.foam, &st) != MPI_SUCCESS || which < 1 || which > w.W) return FY_ERR_TRANSPORT;
+                const int cw = w.counts[(size_t)(which - 1) * w.K + w.me];
+                if (cw <= 0 || served[(size_t)(which - 1)]) return FY_ERR_TRANSPORT;
+                served[(size_t)(which - 1)] = 1;
+                const long long at = w.base[(size_t)(which - 1)] + w.off[(size_t)(which - 1) * w.K + w.me];
                 rq.emplace_back();
-                if (MPI_Isend(w.found() + at, c, MPI_INT, q, W_TAG_SEARCH_RES, MPI_COMM_WORLD, &rq.back()) != MPI_SUCCESS) return FY_ERR_TRANSPORT;
+                if (MPI_Isend(w.found() + at, cw, MPI_INT, which, W_TAG_SEARCH_RES, MPI_COMM_WORLD, &rq.back()) != MPI_SUCCESS) return FY_ERR_TRANSPORT;
                 rq.emplace_back();
-                if (MPI_Isend(w.force() + 6 * at, 6 * c, MPI_DOUBLE, q, W_TAG_FORCE, MPI_COMM_WORLD, &rq.back()) != MPI_SUCCESS) return FY_ERR_TRANSPORT;
+                if (MPI_Isend(w.force() + 6 * at, 6 * cw, MPI_DOUBLE, which, W_TAG_FORCE, MPI_COMM_WORLD, &rq.back()) != MPI_SUCCESS) return FY_ERR_TRANSPORT;
             }
             if (!rq.empty() && MPI_Waitall((int)rq.size(), rq.data(), MPI_STATUSES_IGNORE) != MPI_SUCCESS) return FY_ERR_TRANSPORT;
         }
@@ -341,6 +362,7 @@ extern "C" {
 
 int fy_mpi_transport_create(int n_yade_ranks, fy_transport* out) {
     if (!out || n_yade_ranks == 0) return FY_ERR_INVALID;
+    std::memset(out, 0, sizeof(*out));          // the optional callbacks (views, pieces, describe_block) are tested for null by the library
     int inited = 0;
     MPI_Initialized(&inited);
     if (!inited) return FY_ERR_TRANSPORT;
@@ -355,7 +377,15 @@ int fy_mpi_transport_create(int n_yade_ranks, fy_transport* out) {
     int lr = 0, ls = 0;
     MPI_Comm_rank(st->foam, &lr);
     MPI_Comm_size(st->foam, &ls);
-    if (n_yade_ranks < 0) n_yade_ranks = ws - ls;
+    const bool derived = n_yade_ranks < 0;
+    if (derived) n_yade_ranks = ws - ls;
+    if (derived && n_yade_ranks == 0) {
+        // every rank of the world is a solver rank (a fluid-only -parallel run under a launcher that sets no MPI_APPNUM): nobody to couple with.
+        // *out keeps null callbacks -- the caller passes a NULL transport to the library -- and fy_mpi_local_comm still hands out the communicator
+        out->user = st;
+        out->world_rank = wr; out->world_size = ws; out->local_rank = lr; out->local_size = ls;
+        return FY_OK;
+    }
     if (n_yade_ranks < 1 || wr < n_yade_ranks) { MPI_Comm_free(&st->foam); delete st; return FY_ERR_INVALID; }
     out->user = st;
     out->world_rank = wr; out->world_size = ws; out->local_rank = lr; out->local_size = ls;
@@ -423,6 +453,7 @@ int fy_mpi_transport_destroy(fy_transport* t) {
         int go = 0;
         MPI_Bcast(&go, 1, MPI_INT, 0, w->foam);
         if (w->mem) munmap(w->mem, w->bytes);
+        for (auto& r : w->retired) munmap(r.mem, r.bytes);
         if (w->fd >= 0) { close(w->fd); shm_unlink(w->name); }
         MPI_Comm_free(&w->foam);
         delete w;
