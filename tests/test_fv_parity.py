@@ -688,3 +688,35 @@ def test_limited_schemes_in_pimple_on_graded_blocks_and_in_slabs(product, oracle
         compare(one, many, ("U", "p"), 1e-5)
         assert np.abs(one.get("U")).max() > 0.05
         one.close(); many.close()
+
+
+@pytest.mark.parametrize("solver", [0, 1])
+@pytest.mark.parametrize("switch", ["FOAMYADE_NO_FUSED_CORRECTOR", "FOAMYADE_FACES_FROM_ARRAYS", "FOAMYADE_STRIP_BLOCKS"])
+def test_fused_corrector_sweeps_equal_the_separate_ones(product, solver, switch, monkeypatch):
+    """round 5: the corrector's fused sweeps (k_corr_front / k_corr_back / k_bmom_faces, HbyA from the predictor's last pass, the ddtCorr coefficient from
+    the step's opening sweep) evaluate the SAME per-face expressions as the separate sweeps of rounds 1 - 4, which FOAMYADE_NO_FUSED_CORRECTOR=1 brings
+    back; FOAMYADE_FACES_FROM_ARRAYS=1 streams rAUf / alphacf from their face arrays instead of re-forming them; FOAMYADE_STRIP_BLOCKS=0 switches the
+    strip order of the blocks off.  Same operands, same order: the fields agree to rounding of the reductions that steer the solvers' stopping."""
+    n = 32                                       # a plane of 1024 cells = 4 blocks, nz % 8 == 0: the strip order is active
+    dx = 0.1 / n
+    kw = dict(g=(0, 0, -9.81), p_bc=[2] * 6) if solver == 1 else cavity_bcs()
+    nu = 1e-5 if solver == 1 else 0.01
+    case = gc.Case("cpl", n, n, n, 0.1, gaussian=solver, np_=20000, seed=9, cluster=150, fast=20, outside=20, vel_scale=0.05)
+    out = []
+    for on in (False, True):
+        if on:
+            monkeypatch.setenv(switch, "0" if switch == "FOAMYADE_STRIP_BLOCKS" else "1")
+        pc = product.make_case(solver, n, n, n, dx, 2e-4, nu, g=kw.get("g", (0, 0, 0)), u_bc=kw.get("u_bc"), u_val=kw.get("u_val"), p_bc=kw.get("p_bc"), p_solver=1)
+        s = product.Solver(pc)
+        for step in range(3):
+            s.set_particles(gc.particle_records(case, step))
+            s.step()
+        out.append({nm: s.get(nm) for nm in ("U", "p", "phi_x", "phi_y", "phi_z")})
+        out[-1]["force"] = s.forces()
+        out[-1]["stats"] = s.stats()
+        s.close()
+    a, b = out
+    assert a["stats"]["p_iters_total"] == b["stats"]["p_iters_total"] and a["stats"]["u_iters_total"] == b["stats"]["u_iters_total"]
+    for nm in ("U", "p", "phi_x", "phi_y", "phi_z", "force"):
+        sc = np.abs(a[nm]).max() + 1e-300
+        assert np.abs(a[nm] - b[nm]).max() <= 1e-11 * sc, (nm, np.abs(a[nm] - b[nm]).max() / sc)

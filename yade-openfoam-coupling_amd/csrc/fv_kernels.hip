@@ -78,6 +78,10 @@ __device__ __forceinline__ double geo_lerp_side(const FvGeo& g, int d, int s, in
     return 0.5 * (own + nb);
 #endif
 }
+// linear interpolate at face (d, s) of a cell from its own value and the value across the face (q = the FACE's index along d)
+__device__ __forceinline__ double lerp_face(const FvGeo& g, int d, int s, int q, double own, double nbv) {
+    return s ? geo_lerp(g, d, q, own, nbv) : geo_lerp(g, d, q, nbv, own);
+}
 // weight of the cell's own value at its face (d, s)
 __device__ __forceinline__ double geo_wown(const FvGeo& g, int d, int s, int qc) {
 #if FY_FVK_GRADED
@@ -338,6 +342,11 @@ __global__ __launch_bounds__(256) void k_interp_rAU(FvGeo g, const double* __res
         CALL(2, i, j, k); if (k == g.nz - 1) CALL(2, i, j, k + 1); \
     } while (0)
 
+// does cell (i, j, k) store face (D, S)?  its low faces always, a high face where no cell lies beyond it in this domain
+__device__ __forceinline__ bool owns_face(const FvGeo& g, int d, int s, int i, int j, int k) {
+    return s == 0 || (d == 0 ? i == g.nx - 1 : d == 1 ? j == g.ny - 1 : k == g.nz - 1);
+}
+
 // rAUcf = fvc::interpolate(rAUc) and phicForces = fvc::flux(rAUc*uSource) + rAUcf*(g & Sf) in one cell-centred sweep (UcEqn.H:15-20;
 // uSource's calculated boundary value is 0)
 template <int D>
@@ -560,56 +569,104 @@ __global__ __launch_bounds__(256) void k_pre_coupling(FvGeo g, const double* __r
                                                       const double* __restrict__ alpha, CFace3 psn, double* __restrict__ vGrad,
                                                       double* __restrict__ gradP, double* __restrict__ divT, double* __restrict__ Gout,
                                                       int write_vgrad, int write_pfields, CFace3 phi, double* __restrict__ ddtU, double* __restrict__ Uold_out,
-                                                      double* __restrict__ cellrec, double rec_two_nu, double rec_rhoF) {
+                                                      double* __restrict__ cellrec, double rec_two_nu, double rec_rhoF, Face3 dcorr) {
     const int t = fv_block(g, blockIdx.x, gridDim.x) * 256 + (int)threadIdx.x;
     if (t >= g.Nc) return;
     int i, j, k; ijk_of(g, t, i, j, k);
     const int c = t + g.c0;
     const bool pf = g.pimple && write_pfields;          // gradP and divT wanted
+    // ---- gather first (round 5): every neighbour value is loaded up front from an address that is always valid (across a boundary face the
+    // "neighbour" is the cell itself), the faces are evaluated from registers afterwards.  With the loads inside the per-face branches a wave made
+    // one dependent memory round trip per face: 240 us for this sweep's 200 B/cell
+    const int ijk[3] = {i, j, k};
+    bool bnd[3][2];
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) bnd[d][s] = onb(g, d, s, i, j, k);
     const double uc[3] = {U[3 * (size_t)c], U[3 * (size_t)c + 1], U[3 * (size_t)c + 2]};
-    if (Uold_out) { Uold_out[3 * (size_t)c] = uc[0]; Uold_out[3 * (size_t)c + 1] = uc[1]; Uold_out[3 * (size_t)c + 2] = uc[2]; }    // runTime++: U.oldTime() (single domain: no ghost planes to copy)
+    const double pc = pf ? p[c] : 0.0, ac = pf ? alpha[c] : 0.0;
+    double un6[3][2][3], pn6[3][2], an6[3][2];
+#pragma unroll
+    for (int d = 1; d < 3; ++d)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int nb = bnd[d][s] ? c : c + (s ? stride_of(g, d) : -stride_of(g, d));
+            un6[d][s][0] = U[3 * (size_t)nb]; un6[d][s][1] = U[3 * (size_t)nb + 1]; un6[d][s][2] = U[3 * (size_t)nb + 2];
+            pn6[d][s] = pf ? p[nb] : 0.0; an6[d][s] = pf ? alpha[nb] : 0.0;
+        }
+    const bool want_phi = ddtU != nullptr || dcorr.a[0] != nullptr;
+    double phf[3][2];
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) phf[d][s] = want_phi ? phi.a[d][cface(g, d, s, i, j, k)] : 0.0;
     // x-neighbours from the neighbouring lanes (wave_prev / wave_next); the wave's end lanes fetch theirs
     const int lane = threadIdx.x & 63;
-    const double pc = pf ? p[c] : 0.0, ac = pf ? alpha[c] : 0.0;
-    double ux[2][3], px[2], ax[2];
+    {
+        const int xm = (lane == 0 && i > 0) ? c - 1 : c, xp = (lane == 63 && i + 1 < g.nx) ? c + 1 : c;      // (only the end lanes use what they load)
+        double em[3] = {0, 0, 0}, ep[3] = {0, 0, 0}, epm = 0, epp = 0, eam = 0, eap = 0;
+        if (lane == 0 || lane == 63) {
+            for (int q = 0; q < 3; ++q) { em[q] = U[3 * (size_t)xm + q]; ep[q] = U[3 * (size_t)xp + q]; }
+            if (pf) { epm = p[xm]; epp = p[xp]; eam = alpha[xm]; eap = alpha[xp]; }
+        }
 #pragma unroll
-    for (int q = 0; q < 3; ++q) { ux[0][q] = wave_prev(uc[q]); ux[1][q] = wave_next(uc[q]); }
-    px[0] = wave_prev(pc); px[1] = wave_next(pc); ax[0] = wave_prev(ac); ax[1] = wave_next(ac);
-    if (lane == 0 && i > 0) { for (int q = 0; q < 3; ++q) ux[0][q] = U[3 * (size_t)(c - 1) + q]; if (pf) { px[0] = p[c - 1]; ax[0] = alpha[c - 1]; } }
-    if (lane == 63 && i + 1 < g.nx) { for (int q = 0; q < 3; ++q) ux[1][q] = U[3 * (size_t)(c + 1) + q]; if (pf) { px[1] = p[c + 1]; ax[1] = alpha[c + 1]; } }
+        for (int q = 0; q < 3; ++q) { un6[0][0][q] = wave_prev(uc[q]); un6[0][1][q] = wave_next(uc[q]); }
+        pn6[0][0] = wave_prev(pc); pn6[0][1] = wave_next(pc); an6[0][0] = wave_prev(ac); an6[0][1] = wave_next(ac);
+        if (lane == 0 && i > 0) { for (int q = 0; q < 3; ++q) un6[0][0][q] = em[q]; pn6[0][0] = epm; an6[0][0] = eam; }
+        if (lane == 63 && i + 1 < g.nx) { for (int q = 0; q < 3; ++q) un6[0][1][q] = ep[q]; pn6[0][1] = epp; an6[0][1] = eap; }
+    }
+    if (Uold_out) { Uold_out[3 * (size_t)c] = uc[0]; Uold_out[3 * (size_t)c + 1] = uc[1]; Uold_out[3 * (size_t)c + 2] = uc[2]; }    // runTime++: U.oldTime() (single domain: no ghost planes to copy)
     double lap[3] = {0, 0, 0}, T[9], conv[3] = {0, 0, 0}, gp3[3] = {0, 0, 0};
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
         double fv[2][3], fp[2] = {0, 0};
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            if (onb(g, d, s, i, j, k)) {
-                Ub(g, U, c, 2 * d + s, fv[s]);
+            if (bnd[d][s]) {
+                const int patch = 2 * d + s;                       // Ub() on the cell's own value
+                if (g.u_bc[patch] == 0) { fv[s][0] = g.u_val[patch][0]; fv[s][1] = g.u_val[patch][1]; fv[s][2] = g.u_val[patch][2]; }
+                else { fv[s][0] = uc[0]; fv[s][1] = uc[1]; fv[s][2] = uc[2]; }
+                if (g.u_bc[patch] == 2) fv[s][d] = 0.0;
                 if (pf) {
                     fp[s] = pbv(g, p, psn, c, d, s, cface(g, d, s, i, j, k));
-                    for (int q = 0; q < 3; ++q) lap[q] += 1.0 * geo_Af(g, d, i, j, k) * (fv[s][q] - uc[q]) * geo_rhalf(g, d, d == 0 ? i : d == 1 ? j : k);     // alphaf = 1 on the boundary
+                    for (int q = 0; q < 3; ++q) lap[q] += 1.0 * geo_Af(g, d, i, j, k) * (fv[s][q] - uc[q]) * geo_rhalf(g, d, ijk[d]);     // alphaf = 1 on the boundary
                 }
             } else {
-                const int nb = c + (s ? stride_of(g, d) : -stride_of(g, d));
-                double un[3], pn = 0.0, an = 0.0;
-                if (d == 0) { un[0] = ux[s][0]; un[1] = ux[s][1]; un[2] = ux[s][2]; pn = px[s]; an = ax[s]; }
-                else { un[0] = U[3 * (size_t)nb]; un[1] = U[3 * (size_t)nb + 1]; un[2] = U[3 * (size_t)nb + 2]; if (pf) { pn = p[nb]; an = alpha[nb]; } }
-                const int qc = d == 0 ? i : d == 1 ? j : k;
+                const double* un = un6[d][s];
+                const int qc = ijk[d];
                 for (int q = 0; q < 3; ++q) fv[s][q] = geo_lerp_side(g, d, s, qc, uc[q], un[q]);
                 if (pf) {
-                    fp[s] = geo_lerp_side(g, d, s, qc, pc, pn);
-                    const double af = geo_lerp_side(g, d, s, qc, ac, an);
+                    fp[s] = geo_lerp_side(g, d, s, qc, pc, pn6[d][s]);
+                    const double af = geo_lerp_side(g, d, s, qc, ac, an6[d][s]);
                     for (int q = 0; q < 3; ++q) lap[q] += af * geo_Af(g, d, i, j, k) * (un[q] - uc[q]) * geo_rdelta(g, d, qc + s);
                 }
             }
         }
-        const double rhd = geo_rh(g, d, d == 0 ? i : d == 1 ? j : k);
+        if (dcorr.a[0]) {
+            // the old-time part of ddtCorr(U, phi) (EulerDdtScheme::fvcDdtPhiCorr with fvcDdtPhiCoeff; phiHbyA_face): coef / deltaT (phi.old - flux(U.old)) per
+            // face, by the face's owner.  This sweep runs at the start of the step, where U is U.oldTime() and `phi` is phi.oldTime(), and already holds
+            // U's face values; the correctors then need neither U.oldTime() nor phi.oldTime() (fused sweep k_corr_front)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+                if (owns_face(g, d, s, i, j, k)) {
+                    const int fi = i + (d == 0 ? s : 0), fj = j + (d == 1 ? s : 0), fk = k + (d == 2 ? s : 0);
+                    const int f = cface(g, d, s, i, j, k);
+                    const double uf = fv[s][d] * geo_Af(g, d, fi, fj, fk);
+                    const double po = phf[d][s];
+                    const double phiCorr = po - uf;
+                    const bool fixes = bnd[d][s] && g.u_bc[2 * d + s] == 0;
+                    const double coef = fixes ? 0.0 : 1.0 - fmin(fabs(phiCorr) / (fabs(po) + kSmall), 1.0);
+                    dcorr.a[d][f] = coef * (1.0 / g.dt) * phiCorr;
+                }
+        }
+        const double rhd = geo_rh(g, d, ijk[d]);
         for (int q = 0; q < 3; ++q) T[3 * d + q] = (fv[1][q] - fv[0][q]) * rhd;
         if (pf) gp3[d] = (fp[1] - fp[0]) * rhd;
         if (ddtU) {     // fvc::div(phic, Uc), Gauss linear: the face values are the ones the gradient just used
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                const double flux = (s ? 1.0 : -1.0) * phi.a[d][cface(g, d, s, i, j, k)];
+                const double flux = (s ? 1.0 : -1.0) * phf[d][s];
                 for (int q = 0; q < 3; ++q) conv[q] += flux * fv[s][q];
             }
         }
@@ -975,7 +1032,12 @@ __global__ __launch_bounds__(256) void k_assemble_momentum(FvGeo g, const double
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const int f = cface(g, d, s, i, j, k);
-            const double af = pim ? alphaf.a[d][f] : 1.0;
+            // alphacf streamed from its face array, or (no array kept: alphaf.a[0] == nullptr) re-formed from alpha as interp_alpha_face forms it
+            double af = 1.0;
+            if (pim) {
+                if (alphaf.a[0]) af = alphaf.a[d][f];
+                else if (!onb(g, d, s, i, j, k)) af = lerp_face(g, d, s, (d == 0 ? i : d == 1 ? j : k) + s, aP, alpha[c + (s ? stride_of(g, d) : -stride_of(g, d))]);
+            }
             const double phio = (s ? 1.0 : -1.0) * af * phi.a[d][f];
             divAPhi += phio;
             // fvm::laplacian(alpha nuEff, U): the face diffusivity is the linear interpolate of the cell field alpha (nu + nut) [OF-6
@@ -1096,10 +1158,66 @@ __global__ __launch_bounds__(256) void k_bmom(FvGeo g, const double* __restrict_
     for (int d = 0; d < 3; ++d) bmom[3 * (size_t)c + d] = out[d];
 }
 
+// pimple: rAUcf / phicForces (UcEqn.H:15-20) and the momentum predictor's right-hand side (UcEqn.H:22-33) in one gather-first sweep:
+// k_rAUf_phi_forces_cells + k_bmom without the two face fields being read back; a cell forms its six faces' rAUcf and phicForces itself (same
+// expressions as rAUf_phi_forces_face), the face's owner stores phicForces (and rAUcf where somebody still streams it: rf_out.a[0] != nullptr)
+__global__ __launch_bounds__(256) void k_bmom_faces(FvGeo g, const double* __restrict__ rAU, const double* __restrict__ uSource, const double* __restrict__ src,
+                                                    const double* __restrict__ p, CFace3 psn, Face3 rf_out, Face3 pf_out, double* __restrict__ bmom) {
+    const int t = fv_block(g, blockIdx.x, gridDim.x) * 256 + (int)threadIdx.x;
+    if (t >= g.Nc) return;
+    int i, j, k; ijk_of(g, t, i, j, k);
+    const int c = t + g.c0;
+    const int ijk[3] = {i, j, k};
+    bool bnd[3][2]; int nb[3][2], fx[3][2];
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bnd[d][s] = onb(g, d, s, i, j, k);
+            nb[d][s] = bnd[d][s] ? c : c + (s ? stride_of(g, d) : -stride_of(g, d));
+            fx[d][s] = cface(g, d, s, i, j, k);
+        }
+    const double rc = rAU[c], pc = p[c];
+    const double us[3] = {uSource[3 * (size_t)c], uSource[3 * (size_t)c + 1], uSource[3 * (size_t)c + 2]};
+    const double sr[3] = {src[3 * (size_t)c], src[3 * (size_t)c + 1], src[3 * (size_t)c + 2]};
+    double rn[3][2], un[3][2], pn[3][2];
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) { rn[d][s] = rAU[nb[d][s]]; un[d][s] = uSource[3 * (size_t)nb[d][s] + d]; pn[d][s] = p[nb[d][s]]; }
+    double out[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        double sm = 0;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int q = ijk[d] + s;
+            const int fi = i + (d == 0 ? s : 0), fj = j + (d == 1 ? s : 0), fk = k + (d == 2 ? s : 0);
+            const bool b = bnd[d][s];
+            const double Afc = geo_Af(g, d, fi, fj, fk);
+            const double r = b ? rc : lerp_face(g, d, s, q, rc, rn[d][s]);
+            const double fl = b ? 0.0 : lerp_face(g, d, s, q, rc * us[d], rn[d][s] * un[d][s]) * Afc;
+            const double pfv = fl + r * (g.g[d] * Afc);
+            if (owns_face(g, d, s, i, j, k)) { pf_out.a[d][fx[d][s]] = pfv; if (rf_out.a[0]) rf_out.a[d][fx[d][s]] = r; }
+            double sng;
+            const double rds = geo_rdist(g, d, s, i, j, k);
+            if (b) { const double pbd = pbv(g, p, psn, c, d, s, fx[d][s]); sng = s ? (pbd - pc) * rds : (pc - pbd) * rds; }
+            else sng = s ? (pn[d][s] - pc) * rds : (pc - pn[d][s]) * rds;
+            sm += pfv / r - sng * geo_Af(g, d, i, j, k);
+        }
+        out[d] = sr[d] + geo_V(g, i, j, k) * (sm / (2.0 * geo_Af(g, d, i, j, k)));
+    }
+    for (int d = 0; d < 3; ++d) bmom[3 * (size_t)c + d] = out[d];
+}
+
 // One fused Jacobi pass over the 3 velocity components: with x the current iterate, accumulate the L1 residual |b - A x|
 // (slots 0..2), the lduMatrix normalisation sum |A x - A xbar| + |b - A xbar| (slots 3..5) and write the next iterate xn.
+// WITH_H: the pass also leaves HbyA = rAU H(x) / V of ITS iterate x (k_HbyA's expression in k_HbyA's order: the same bits) -- the pass that finds x
+// converged has then done the first corrector's H-operator sweep on the side, for 56 B/cell instead of a sweep of 128
+template <bool WITH_H>
 __global__ __launch_bounds__(256) void k_mom_pass(FvGeo g, Mom7 M, const double* __restrict__ b, const double* __restrict__ x,
-                                                  double* __restrict__ xn, const double* __restrict__ xsum, double n_glob, double* __restrict__ partials) {
+                                                  double* __restrict__ xn, const double* __restrict__ xsum, double n_glob, double* __restrict__ partials,
+                                                  const double* __restrict__ hsrc, const double* __restrict__ rAU, double* __restrict__ HbyA) {
     double v[6] = {0, 0, 0, 0, 0, 0};
     // xbar = average(x) (lduMatrix::solver::normFactor): the component sums stay on the device (k_sum3 + fold [+ all-reduce]); dividing
     // them here saves the host round trip the average used to make
@@ -1112,6 +1230,8 @@ __global__ __launch_bounds__(256) void k_mom_pass(FvGeo g, Mom7 M, const double*
         if (M.bd) for (int q = 0; q < 3; ++q) dq[q] += M.bd[3 * (size_t)c + q];
         double off[3] = {0, 0, 0}, rowsum = dg;
         const double xc[3] = {x[3 * (size_t)c], x[3 * (size_t)c + 1], x[3 * (size_t)c + 2]};
+        double hacc[3] = {0, 0, 0};
+        if (WITH_H) { hacc[0] = hsrc[3 * (size_t)c]; hacc[1] = hsrc[3 * (size_t)c + 1]; hacc[2] = hsrc[3 * (size_t)c + 2]; }
         double xx[2][3];
         x_neighbours3(x, c, i, g.nx, xc, xx[0], xx[1]);
 #pragma unroll
@@ -1122,9 +1242,21 @@ __global__ __launch_bounds__(256) void k_mom_pass(FvGeo g, Mom7 M, const double*
                     const int nb = c + (s ? stride_of(g, d) : -stride_of(g, d));
                     const double a = M.an[2 * d + s][c];
                     rowsum += a;
-                    if (d == 0) for (int q = 0; q < 3; ++q) off[q] += a * xx[s][q];
-                    else for (int q = 0; q < 3; ++q) off[q] += a * x[3 * (size_t)nb + q];
+                    double xv[3];
+                    if (d == 0) for (int q = 0; q < 3; ++q) xv[q] = xx[s][q];
+                    else for (int q = 0; q < 3; ++q) xv[q] = x[3 * (size_t)nb + q];
+                    for (int q = 0; q < 3; ++q) off[q] += a * xv[q];
+                    if (WITH_H) for (int q = 0; q < 3; ++q) hacc[q] -= a * xv[q];
                 }
+        if (WITH_H) {
+            if (M.bd) {
+                const double b0 = M.bd[3 * (size_t)c], b1 = M.bd[3 * (size_t)c + 1], b2 = M.bd[3 * (size_t)c + 2];
+                const double bav = ((b0 + b1) + b2) / 3.0;
+                hacc[0] += (bav - b0) * xc[0]; hacc[1] += (bav - b1) * xc[1]; hacc[2] += (bav - b2) * xc[2];
+            }
+            const double r = rAU[c];
+            for (int q = 0; q < 3; ++q) HbyA[3 * (size_t)c + q] = r * (hacc[q] * geo_rV(g, i, j, k));
+        }
         for (int q = 0; q < 3; ++q) {
             const double bq = b[3 * (size_t)c + q];
             const double Ax = dq[q] * xc[q] + off[q];
@@ -1333,10 +1465,6 @@ __device__ __forceinline__ double rAUf_at(const FvGeo& g, const FaceSrc& a, size
 // CALL(D, S, fi, fj, fk): the six faces of cell (i, j, k) in the order every per-cell sum over faces uses (x-, x+, y-, y+, z-, z+)
 #define FY_ALL_FACES(i, j, k, CALL) \
     do { CALL(0, 0, i, j, k); CALL(0, 1, i + 1, j, k); CALL(1, 0, i, j, k); CALL(1, 1, i, j + 1, k); CALL(2, 0, i, j, k); CALL(2, 1, i, j, k + 1); } while (0)
-// does cell (i, j, k) store face (D, S)?  its low faces always, a high face where no cell lies beyond it in this domain
-__device__ __forceinline__ bool owns_face(const FvGeo& g, int d, int s, int i, int j, int k) {
-    return s == 0 || (d == 0 ? i == g.nx - 1 : d == 1 ? j == g.ny - 1 : k == g.nz - 1);
-}
 
 // Both sweeps are written GATHER FIRST: every operand of the six faces is loaded up front from an address that is always valid (across a
 // boundary face the "neighbour" is the cell itself), then the faces are evaluated from registers.  Written face by face -- a branch per face
@@ -1348,11 +1476,6 @@ __device__ __forceinline__ bool owns_face(const FvGeo& g, int d, int s, int i, i
 __device__ __forceinline__ double ub_normal(const FvGeo& g, int patch, int d, double own_d) {
     return g.u_bc[patch] == 0 ? g.u_val[patch][d] : (g.u_bc[patch] == 2 ? 0.0 : own_d);
 }
-// linear interpolate at face (d, s) of a cell from its own value and the value across the face (q = the FACE's index along d)
-__device__ __forceinline__ double lerp_face(const FvGeo& g, int d, int s, int q, double own, double nbv) {
-    return s ? geo_lerp(g, d, q, own, nbv) : geo_lerp(g, d, q, nbv, own);
-}
-
 // flux correction + velocity correction [+ continuity errors + the next pass's Courant sums] in one sweep (icoFoamYade.C:127-137, pEqn.H:39-45,
 // continuityErrs.H, CourantNo.H): k_flux_correct_cells and k_U_correct<DIAG> without the face field between them
 template <bool DIAG, bool FFC>
@@ -1463,11 +1586,12 @@ __global__ __launch_bounds__(256) void k_corr_back(FvGeo g, const double* __rest
 // (icoFoamYade.C:101-123, pEqn.H:4-33, PCG.C [OF-6]): k_phiHbyA_cells<KEEP>, k_assemble_pressure and k_p_init without phiHbyA, psn and the matrix
 // being read back in between.  The residual's row uses the face coefficients in p_row's order (x-, x+, y-, y+, z-, z+; a boundary face's stored
 // coefficient is 0 there, skipped here) and the block partition of k_p_init, so r0 and the two sums are k_p_init's bits.
-// KEEP 1 / 2: the ddtCorr term is stored / read back (phiHbyA_face).  STORE_A = false: a later corrector of the same momentum assembly -- the
-// matrix in A stands (same rAU, same alphacf)
-template <int KEEP, bool STORE_A, bool FFC>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k_corr_front(FvGeo g, const double* __restrict__ HbyA, const double* __restrict__ U, const double* __restrict__ Uold,
-                                                    CFace3 phiOld, FaceSrc rAUf, FaceSrc alphaf, CFace3 phiForces, Face3 phiHbyA, Face3 psn, Face3 ddtc,
+// dcorr: the old-time part of the ddtCorr term per face, left by k_pre_coupling at the start of the step (coef / deltaT (phi.old - flux(U.old)));
+// the term itself is rAUf dcorr [alphacf], the same product in every corrector.  STORE_A = false: a later corrector of the same momentum
+// assembly -- the matrix in A stands (same rAU, same alphacf)
+template <bool STORE_A, bool FFC>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k_corr_front(FvGeo g, const double* __restrict__ HbyA, const double* __restrict__ U, CFace3 dcorr,
+                                                    FaceSrc rAUf, FaceSrc alphaf, CFace3 phiForces, Face3 phiHbyA, Face3 psn,
                                                     const double* __restrict__ rAU, const double* __restrict__ alpha, const double* __restrict__ alphaOld, PMat A,
                                                     double* __restrict__ rhs, const double* __restrict__ x, const double* __restrict__ xbar_dev, double xsum_val,
                                                     double inv_n, double* __restrict__ res, double* __restrict__ partials) {
@@ -1492,16 +1616,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
         const double xc = x[c], ac = pim ? alpha[c] : 1.0;
         const double rc = FFC ? rAU[c] : 0.0;
         const double hb[3] = {HbyA[3 * (size_t)c], HbyA[3 * (size_t)c + 1], HbyA[3 * (size_t)c + 2]};
-        double uo[3] = {0, 0, 0};
-        if (KEEP != 2) { uo[0] = Uold[3 * (size_t)c]; uo[1] = Uold[3 * (size_t)c + 1]; uo[2] = Uold[3 * (size_t)c + 2]; }
-        double hn[3][2], un[3][2], po[3][2], pfo[3][2], xn[3][2], rfv[3][2], afv[3][2];
+        double hn[3][2], dc[3][2], pfo[3][2], xn[3][2], rfv[3][2], afv[3][2];
 #pragma unroll
         for (int d = 0; d < 3; ++d)
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 hn[d][s] = HbyA[3 * (size_t)nb[d][s] + d];
-                if (KEEP != 2) { un[d][s] = Uold[3 * (size_t)nb[d][s] + d]; po[d][s] = phiOld.a[d][fx[d][s]]; }
-                else { un[d][s] = 0.0; po[d][s] = ddtc.a[d][fx[d][s]]; }                   // (po: the stored ddtCorr term)
+                dc[d][s] = dcorr.a[d][fx[d][s]];
                 pfo[d][s] = pim ? phiForces.a[d][fx[d][s]] : 0.0;
                 xn[d][s] = x[nb[d][s]];
                 if (FFC) { rfv[d][s] = rAU[nb[d][s]]; afv[d][s] = pim ? alpha[nb[d][s]] : 1.0; }
@@ -1525,21 +1646,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
                 const double af = afv[d][s], rf = rfv[d][s];
                 const double Afc = geo_Af(g, d, fi, fj, fk);
                 double pv = (b ? ub_normal(g, patch, d, hb[d]) : lerp_face(g, d, s, q, hb[d], hn[d][s])) * Afc;      // face_flux_vec(HbyA)
-                double add;
-                if (KEEP == 2) {
-                    add = po[d][s];
-                } else {
-                    const double uf = (b ? ub_normal(g, patch, d, uo[d]) : lerp_face(g, d, s, q, uo[d], un[d][s])) * Afc;
-                    const bool fixes = b && g.u_bc[patch] == 0;
-                    const double phiCorr = po[d][s] - uf;
-                    const double coef = fixes ? 0.0 : 1.0 - fmin(fabs(phiCorr) / (fabs(po[d][s]) + kSmall), 1.0);
-                    add = rf * (coef * (1.0 / g.dt) * phiCorr);
-                    if (pim) add *= af;
-                }
+                double add = rf * dc[d][s];
+                if (pim) add *= af;
                 pv += add;
                 if (pim) pv += pfo[d][s];
                 const bool own = owns_face(g, d, s, i, j, k);
-                if (own) { phiHbyA.a[d][fx[d][s]] = pv; if (KEEP == 1) ddtc.a[d][fx[d][s]] = add; }
+                if (own) phiHbyA.a[d][fx[d][s]] = pv;
                 double ph = (s ? 1.0 : -1.0) * af * pv;
                 gg6[d][s] = 0.0;
                 if (b) {
@@ -2217,9 +2329,9 @@ int launch_courant(hipStream_t s, FvGeo g, CFace3 phi, double* partials) {
 
 int launch_pre_coupling(hipStream_t s, FvGeo g, const double* U, const double* p, const double* alpha, CFace3 psn, double* vGrad,
                         double* gradP, double* divT, double* Gout, int write_vgrad, int write_pfields, CFace3 phi, double* ddtU, double* Uold_out,
-                        double* cellrec, double rec_nu, double rec_rhoF) {
+                        double* cellrec, double rec_nu, double rec_rhoF, Face3 dcorr) {
     hipLaunchKernelGGL(k_pre_coupling, dim3(div_up(g.Nc, 256)), dim3(256), 0, s, g, U, p, alpha, psn, vGrad, gradP, divT, Gout, write_vgrad, write_pfields,
-                       phi, ddtU, Uold_out, cellrec, 2.0 * rec_nu, rec_rhoF);
+                       phi, ddtU, Uold_out, cellrec, 2.0 * rec_nu, rec_rhoF, dcorr);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }
@@ -2285,8 +2397,17 @@ int launch_bmom(hipStream_t s, FvGeo g, const double* src, const double* p, CFac
     return FY_OK;
 }
 
-int launch_mom_pass(hipStream_t s, FvGeo g, Mom7 M, const double* b, const double* x, double* xn, const double* xsum, double n_glob, double* partials) {
-    hipLaunchKernelGGL(k_mom_pass, dim3(red_blocks(g.Nc)), dim3(256), 0, s, g, M, b, x, xn, xsum, n_glob, partials);
+int launch_bmom_faces(hipStream_t s, FvGeo g, const double* rAU, const double* uSource, const double* src, const double* p, CFace3 psn, Face3 rAUf_out,
+                      Face3 phiForces, double* bmom) {
+    hipLaunchKernelGGL(k_bmom_faces, dim3(div_up(g.Nc, 256)), dim3(256), 0, s, g, rAU, uSource, src, p, psn, rAUf_out, phiForces, bmom);
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+
+int launch_mom_pass(hipStream_t s, FvGeo g, Mom7 M, const double* b, const double* x, double* xn, const double* xsum, double n_glob, double* partials,
+                    const double* hsrc, const double* rAU, double* HbyA) {
+    if (HbyA) hipLaunchKernelGGL(k_mom_pass<true>, dim3(red_blocks(g.Nc)), dim3(256), 0, s, g, M, b, x, xn, xsum, n_glob, partials, hsrc, rAU, HbyA);
+    else hipLaunchKernelGGL(k_mom_pass<false>, dim3(red_blocks(g.Nc)), dim3(256), 0, s, g, M, b, x, xn, xsum, n_glob, partials, hsrc, rAU, HbyA);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }
@@ -2377,19 +2498,15 @@ int launch_corr_back(hipStream_t s, FvGeo g, const double* p, CFace3 phiHbyA, CF
     return FY_OK;
 }
 
-int launch_corr_front(hipStream_t s, FvGeo g, const double* HbyA, const double* U, const double* Uold, CFace3 phiOld, CFace3 rAUf, CFace3 alphaf,
-                      CFace3 phiForces, Face3 phiHbyA, Face3 psn, Face3 ddtc, int keep, const double* rAU, const double* alpha, const double* alphaOld, PMat A,
-                      double* rhs, bool store_A, const double* x, const double* xsum_dev, double xsum_val, double inv_n, double* res, double* partials,
-                      bool faces_from_cells) {
+int launch_corr_front(hipStream_t s, FvGeo g, const double* HbyA, const double* U, CFace3 dcorr, CFace3 rAUf, CFace3 alphaf, CFace3 phiForces, Face3 phiHbyA,
+                      Face3 psn, const double* rAU, const double* alpha, const double* alphaOld, PMat A, double* rhs, bool store_A, const double* x,
+                      const double* xsum_dev, double xsum_val, double inv_n, double* res, double* partials, bool faces_from_cells) {
     const FaceSrc rs{rAUf, faces_from_cells ? rAU : nullptr}, as{alphaf, faces_from_cells ? alpha : nullptr};
     const dim3 grid(red_blocks(g.Nc)), blk(256);
-#define FY_FRONT(K, SA, FC) hipLaunchKernelGGL((k_corr_front<K, SA, FC>), grid, blk, 0, s, g, HbyA, U, Uold, phiOld, rs, as, phiForces, phiHbyA, psn, ddtc, rAU, alpha, alphaOld, A, rhs, \
-                                               x, xsum_dev, xsum_val, inv_n, res, partials)
-#define FY_FRONT2(K, SA) do { if (faces_from_cells) FY_FRONT(K, SA, true); else FY_FRONT(K, SA, false); } while (0)
-    if (keep == 1) { if (store_A) FY_FRONT2(1, true); else FY_FRONT2(1, false); }
-    else if (keep == 2) { if (store_A) FY_FRONT2(2, true); else FY_FRONT2(2, false); }
-    else return fail(FY_ERR_INVALID, "launch_corr_front: keep must be 1 (first corrector of an assembly) or 2");
-#undef FY_FRONT2
+#define FY_FRONT(SA, FC) hipLaunchKernelGGL((k_corr_front<SA, FC>), grid, blk, 0, s, g, HbyA, U, dcorr, rs, as, phiForces, phiHbyA, psn, rAU, alpha, alphaOld, A, rhs, \
+                                            x, xsum_dev, xsum_val, inv_n, res, partials)
+    if (store_A) { if (faces_from_cells) FY_FRONT(true, true); else FY_FRONT(true, false); }
+    else { if (faces_from_cells) FY_FRONT(false, true); else FY_FRONT(false, false); }
 #undef FY_FRONT
     FY_LAUNCH_CHECK();
     return FY_OK;

@@ -190,7 +190,7 @@ int Solver::create(const fy_case_desc* c, const fy_transport* tr, int dev, Comm*
     if (c->turbulence_model == FY_TURBULENCE_KEPSILON) { FY_TRY(epsturb.alloc_exact(n)); FY_TRY(launch_fill_f64(stream, epsturb.p, n, c->eps_initial)); g.epsturb = epsturb.p; }
     FY_TRY(Gt.alloc_exact(9 * n)); FY_TRY(zero(Gt));
     for (int d = 0; d < 3; ++d) {
-        DevBuf<double>* fs[] = {&phi[d], &phiOld[d], &psn[d], &alphaf[d], &phiHbyA[d], &phiForces[d], &rAUf[d], &pflux[d], &ddtc[d]};
+        DevBuf<double>* fs[] = {&phi[d], &phiOld[d], &psn[d], &alphaf[d], &phiHbyA[d], &phiForces[d], &rAUf[d], &pflux[d], &ddtc[d], &dcorr[d]};
         for (auto* b : fs) { FY_TRY(b->alloc_exact(fv_fsize(g, d))); FY_TRY(zero(*b)); }
         FY_TRY(launch_fill_f64(stream, alphaf[d].p, alphaf[d].n, 1.0));
     }
@@ -267,6 +267,11 @@ int Solver::create(const fy_case_desc* c, const fy_transport* tr, int dev, Comm*
         for (auto& L : mg) if (L->distributed && (L->gz < kMgDeepGhost || L->A.nz < kMgDeepGhost)) mg_deep = false;
     }
     for (auto& t : tim) FY_TRY(t.init());
+    // who still streams the face interpolates rAUf / alphacf from their arrays: the separate corrector sweeps (switched on, or taken by adjustPhi / the
+    // non-orthogonal correctors), the interface coefficient of a slab without deep ghost planes, the turbulence transport equations, the stand-alone
+    // continuity-error sweep; otherwise the arrays are never filled
+    face_arrays = !fused_corrector || !faces_from_cells || adjust_phi || cs.n_non_orth_correctors > 0 || (S > 1 && !mg_deep) ||
+                  c->turbulence_model != FY_TURBULENCE_LAMINAR || !fuse_diag || !red_host || (pimple && !cs.momentum_predictor);
 
     // the coupling object shares the solver's device fields and stream (icoFoamYade.C:54, pimpleFoamYade.C:54); its tree spans
     // the GLOBAL block (the improvement chain depends on the whole tree), its cell arrays are this slab's storage
@@ -398,7 +403,12 @@ int Solver::solve_vec3(DevBuf<double>& X, const double* rhs, double tol, double 
         // (the predictor's first pass reads the ghost planes the step's opening exchange left in U)
         if (!(it == 0 && &X == &U && U_ghosts_fresh)) FY_TRY(halo(xc, 3, plane, g.nz, g.gz, 1));
         kc[KC_MOM_PASS].begin(stream);
-        FY_TRY(FVK(launch_mom_pass, stream, g, M7(momentum), rhs, xc, xn, xbar3.p, (double)Nglob, partials.p));
+        // from the second pass on the momentum predictor's pass also leaves HbyA of its iterate: the pass that finds it converged has then done the
+        // first corrector's H-operator sweep (corrector(): hbya_ready)
+        const bool with_h = momentum && fused_corrector && cs.n_correctors > 0 && it >= 1;
+        FY_TRY(FVK(launch_mom_pass, stream, g, M7(momentum), rhs, xc, xn, xbar3.p, (double)Nglob, partials.p, with_h ? src.p : nullptr, with_h ? rAU.p : nullptr,
+                   with_h ? HbyA.p : nullptr));
+        if (momentum) hbya_ready = with_h;
         kc[KC_MOM_PASS].end(stream);
         FY_TRY(reduce_read(6, false, h));
         if (it == 0) for (int q = 0; q < 3; ++q) { norm[q] = h[3 + q] + 1e-20; res0[q] = h[q] / norm[q]; }
@@ -427,10 +437,11 @@ int Solver::solve_vec3(DevBuf<double>& X, const double* rhs, double tol, double 
 int Solver::corrector(bool final_inner) {
     Comm::Tag tag(comm, "corrector");
     FY_TRY(halo_U());
-    FY_TRY(FVK(launch_HbyA, stream, g, M7(), src.p, U.p, rAU.p, HbyA.p));
+    if (hbya_ready) hbya_ready = false;                      // (the predictor's last pass wrote HbyA of the U it accepted: solve_vec3)
+    else FY_TRY(FVK(launch_HbyA, stream, g, M7(), src.p, U.p, rAU.p, HbyA.p));
     // rAU (hence rAUf and the pressure matrix rAUf*alphaf) belongs to the momentum matrix: it only changes when that is assembled,
     // not between the PISO correctors of one assembly
-    if (!pimple && rAU_new) { FY_TRY(halo_cells(rAU, 1, 1)); FY_TRY(FVK(launch_interp_rAU, stream, g, rAU.p, F3(rAUf))); }
+    if (!pimple && rAU_new) { FY_TRY(halo_cells(rAU, 1, 1)); if (face_arrays) FY_TRY(FVK(launch_interp_rAU, stream, g, rAU.p, F3(rAUf))); }
     FY_TRY(halo_cells(HbyA, 3, 1));
     MgLev& L = *mg[0];
     // the two fused sweeps (fv_kernels.hip "fused corrector sweeps") stand for phiHbyA + assembly + PCG's first residual and for the flux + velocity
@@ -444,8 +455,8 @@ int Solver::corrector(bool final_inner) {
         // the ddtCorr term is the same in every corrector of one momentum assembly: stored by the first, read back by the others
         clk_pres.begin(stream);
         FY_TRY(prepare_p_init());
-        FY_TRY(FVK(launch_corr_front, stream, g, HbyA.p, U.p, Uold.p, C3(phiOld), C3(rAUf), C3(alphaf), C3(phiForces), F3(phiHbyA), F3(psn), F3(ddtc), rAU_new ? 1 : 2,
-                   rAU.p, alpha.p, /* alphaOld */ alpha.p, L.A, prhs.p, rAU_new, p.p, p_sum_valid ? nullptr : sc.p + 6, p_sum, 1.0 / (double)Nglob, pr.p, partials.p, ffc));
+        FY_TRY(FVK(launch_corr_front, stream, g, HbyA.p, U.p, C3(dcorr), C3(rAUf), C3(alphaf), C3(phiForces), F3(phiHbyA), F3(psn), rAU.p, alpha.p, /* alphaOld */ alpha.p,
+                   L.A, prhs.p, rAU_new, p.p, p_sum_valid ? nullptr : sc.p + 6, p_sum, 1.0 / (double)Nglob, pr.p, partials.p, ffc));
     } else {
         FY_TRY(FVK(launch_phiHbyA, stream, g, HbyA.p, U.p, Uold.p, C3(phiOld), C3(rAUf), C3(alphaf), C3(phiForces), F3(phiHbyA), F3(psn), F3(ddtc), rAU_new ? 1 : 2));
         if (adjust_phi) {                                       // icoFoamYade.C:108, pEqn.H:13-16
@@ -630,7 +641,8 @@ int Solver::step() {
     const bool defer_sweep = comm->size == 1 && cpl->c.gaussian;
     std::function<int()> pre_sweep = [&]() -> int {
         return FVK(launch_pre_coupling, stream, g, U.p, p.p, alpha.p, C3(psn), vGrad.p, gradP.p, divT.p, nullptr, want_vgrad ? 1 : 0, 1, phi_now(),
-                   want_ddtU ? ddtU.p : nullptr, fuse_uold ? Uold.p : nullptr, rec_out, cpl->c.nu, cpl->c.rhoF);
+                   want_ddtU ? ddtU.p : nullptr, fuse_uold ? Uold.p : nullptr, rec_out, cpl->c.nu, cpl->c.rhoF,
+                   (fused_corrector && !adjust_phi) ? F3(dcorr) : Face3{});
     };
     if (defer_sweep) {
         cpl->c.mid_hook = [](void* u) -> int { return (*static_cast<std::function<int()>*>(u))(); };
@@ -672,7 +684,9 @@ int Solver::step() {
     // FoamYade wrote alpha through untracked operator[]: old == current, fvc::ddt(alphac) == 0.
     // The kernels keep their alphaOld argument (the term is written out as in UcEqn.H:5 / pEqn.H:30); it is handed the same array
     // -- what a copy taken here would hold, without the copy or a second stream of reads.
-    if (pimple) FY_TRY(FVK(launch_interp_alpha, stream, g, alpha.p, F3(alphaf)));              // pimpleFoamYade.C:83-85 (alpha ghosts refreshed by the coupling)
+    // pimpleFoamYade.C:83-85 (alpha ghosts refreshed by the coupling).  The fused sweeps re-form alphacf from alpha where they need it: the face
+    // array is only filled for the passes that still stream it (face_arrays)
+    if (pimple && face_arrays) FY_TRY(FVK(launch_interp_alpha, stream, g, alpha.p, F3(alphaf)));
     const int nOuter = pimple ? std::max(cs.n_outer_correctors, 1) : 1;
     for (int outer = 0; outer < nOuter; ++outer) {
         // pimple.loop() marks the last outer corrector "finalIteration": relax() then prefers the <name>Final factors [OF-6], and
@@ -698,15 +712,18 @@ int Solver::step() {
             FY_TRY(FVK(launch_grad_magsqr, stream, g, U.p, gradL.p));
             FY_TRY(halo_cells(gradL, 3, 1));
         }
-        FY_TRY(FVK(launch_assemble_momentum, stream, g, U.p, Uold.p, alpha.p, /* alphaOld */ alpha.p, C3(alphaf), phi_now(), uSource.p, uSourceDrag.p,
+        FY_TRY(FVK(launch_assemble_momentum, stream, g, U.p, Uold.p, alpha.p, /* alphaOld */ alpha.p, face_arrays ? C3(alphaf) : CFace3{}, phi_now(), uSource.p, uSourceDrag.p,
                                         divG.p, g.upwind >= 3 ? gradL.p : vGrad.p, M7(), src.p, rAU.p));
-        rAU_new = true;
+        rAU_new = true; hbya_ready = false;
+        // pimple: rAUcf, phicForces and the predictor's right-hand side in one sweep (k_bmom_faces); uSource ghosts refreshed by the coupling
+        const bool bmom_fused = pimple && cs.momentum_predictor && fused_corrector;
         if (pimple) {
             FY_TRY(halo_cells(rAU, 1, 1));
-            FY_TRY(FVK(launch_rAUf_phi_forces, stream, g, rAU.p, uSource.p, F3(rAUf), F3(phiForces)));  // uSource ghosts refreshed by the coupling
+            if (bmom_fused) FY_TRY(FVK(launch_bmom_faces, stream, g, rAU.p, uSource.p, src.p, p.p, C3(psn), face_arrays ? F3(rAUf) : Face3{}, F3(phiForces), bmom.p));
+            else FY_TRY(FVK(launch_rAUf_phi_forces, stream, g, rAU.p, uSource.p, F3(rAUf), F3(phiForces)));
         }
         if (cs.momentum_predictor) {
-            FY_TRY(FVK(launch_bmom, stream, g, src.p, p.p, C3(psn), C3(phiForces), C3(rAUf), bmom.p));
+            if (!bmom_fused) FY_TRY(FVK(launch_bmom, stream, g, src.p, p.p, C3(psn), C3(phiForces), C3(rAUf), bmom.p));
             int it = 0;
             FY_TRY(solve_momentum(&it));
             st.u_iters_total += it;

@@ -75,6 +75,7 @@ struct Solver {
     CFace3 phi_now() const { return phi_fresh ? CFace3{{phi[0].p, phi[1].p, phi[2].p}} : CFace3{{phiOld[0].p, phiOld[1].p, phiOld[2].p}}; }
     bool rAU_new = true;        // rAU was (re)assembled since the last corrector: rAUf and the coarse pressure operators are stale
     DevBuf<double> phi[3], phiOld[3], psn[3], alphaf[3], phiHbyA[3], phiForces[3], rAUf[3], pflux[3], ddtc[3];
+    DevBuf<double> dcorr[3];             // old-time part of ddtCorr(U, phi) per face, written by the step's opening sweep (k_pre_coupling), read by k_corr_front
     DevBuf<double> gradL;                // [3 nstore] grad(magSqr(U)) for the limited convection schemes
     DevBuf<double> mbd;                  // [3 nstore] per-component boundary diagonal of the momentum matrix (Mom7::bd): only with a slip patch
     DevBuf<double> mdiag, man[6], src, rAU, HbyA, bmom, Gt, divG, xscr;
@@ -201,6 +202,8 @@ struct Solver {
     int solve_pressure(bool final_iter, bool init_done = false);      // OpenFOAM PCG.C with lduMatrix::solver::normFactor; preconditioner = MG V-cycle or Jacobi
     int prepare_p_init();          // sum(p) for the norm factor's xbar where the last PCG update did not leave it, and p's ghost planes
     bool fused_corrector = true;   // the corrector as two fused sweeps (FOAMYADE_NO_FUSED_CORRECTOR=1: the five sweeps of rounds 1 - 4; identical results)
+    bool hbya_ready = false;       // HbyA already holds rAU H(U) of the current U (written by the momentum predictor's last pass)
+    bool face_arrays = true;       // rAUf / alphacf are kept as face arrays (somebody streams them: see create())
     bool faces_from_cells = true;  // the fused sweeps re-form rAUf / alphacf from rAU / alpha (FOAMYADE_FACES_FROM_ARRAYS=1: stream the face arrays)
 
     // ---- one PISO / PIMPLE corrector (icoFoamYade.C:97-140, pEqn.H)

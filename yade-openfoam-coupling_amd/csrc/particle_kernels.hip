@@ -983,7 +983,15 @@ __global__ __launch_bounds__(kDepThreads) void k_locate_deposit(LocateLists ll, 
         double qx, qy, qz, pvx, pvy, pvz, prad;
         if (rec) {
             const double* r = rec + 10 * (size_t)p.orig[i];
-            qx = r[0]; qy = r[1]; qz = r[2]; pvx = r[3]; pvy = r[4]; pvz = r[5]; prad = r[9];
+            if ((reinterpret_cast<uintptr_t>(rec) & 15) == 0) {
+                // an 80-byte record of a 16-byte aligned array is five aligned 16-byte words: four 16-byte loads fetch what seven 8-byte ones did
+                // (round 5: the texture-data unit was 89 % busy in this kernel)
+                const double2* r2 = reinterpret_cast<const double2*>(r);
+                const double2 a = r2[0], b = r2[1], cc = r2[2], e = r2[4];
+                qx = a.x; qy = a.y; qz = b.x; pvx = b.y; pvy = cc.x; pvz = cc.y; prad = e.y;
+            } else {
+                qx = r[0]; qy = r[1]; qz = r[2]; pvx = r[3]; pvy = r[4]; pvz = r[5]; prad = r[9];
+            }
             p.px[i] = qx; p.py[i] = qy; p.pz[i] = qz; p.vx[i] = pvx; p.vy[i] = pvy; p.vz[i] = pvz; p.rad[i] = prad;
         } else {
             qx = p.px[i]; qy = p.py[i]; qz = p.pz[i]; pvx = p.vx[i]; pvy = p.vy[i]; pvz = p.vz[i]; prad = p.rad[i];
