@@ -716,7 +716,10 @@ int read_general_mesh(fy_foam_case* c) {
     c->g_nei.erase(c->g_nei.begin());
     c->g_internal = (int)c->g_nei.size();
     int32_t top = -1;
+    // nCells = the highest cell label in owner OR neighbour, + 1 [OF-6 polyMesh::initMesh]: the highest-numbered cells own no internal face (owner <
+    // neighbour) and, when they lie in the interior, no boundary face either -- they appear in `neighbour` only (tests/test_case_vs_oracle.py found it)
     for (int32_t v : c->g_own) top = std::max(top, v);
+    for (int32_t v : c->g_nei) top = std::max(top, v);
     c->g_cells = top + 1;
     std::vector<std::string> tk;
     if (!fy::foam_list_file_tokens(join(base, "boundary"), &tk, &err)) return fail(FY_ERR_INVALID, "%s", err.c_str());
