@@ -971,6 +971,31 @@ def main():
         "kernels": {k: {"avg_ms": round(v["avg_ms"], 4), "launches": v["launches"], "GBps": round(v["compulsory"] / (v["avg_ms"] * 1e-3) / 1e9, 1),
                         "design_GBps": round(v["achieved_GBps"], 1)} for k, v in kern.items()},
     }
+    if world > 1 and slabs_ok >= 1.0:
+        # how long each rank's stream sat waiting for slab exchanges, by phase -- sampled in a few EXTRA steps after the timed region (the clock costs an
+        # event pair per exchange, which would slow the steps it measures).  FOAMYADE_HALO_OVERLAP=0 runs the exchange-then-consume schedule: the A/B
+        try:
+            solver.enable_exchange_timing(True)
+            n_x = 5
+            for _ in range(n_x):
+                solver.step()
+            torch.cuda.synchronize()
+            w = solver.exchange_wait()
+            mine = torch.tensor([w[k][0] / n_x for k in ("step_start", "particle", "momentum", "corrector")] +
+                                [float(w[k][1]) / n_x for k in ("step_start", "particle", "momentum", "corrector")], dtype=torch.float64, device=dev)
+            allw = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(allw, mine)
+            solver.enable_exchange_timing(False)
+            out["exchange_wait"] = {
+                "what": "ms per step each rank's stream waited for slab exchanges (sampled over %d extra steps after the timed region): with the exchanges overlapped "
+                        "(default) from the end of the interior planes' sweep to the ghost planes' arrival, with FOAMYADE_HALO_OVERLAP=0 the exchange itself; "
+                        "`waits` = exchanges sampled per step; the particle phase's exchanges run inside the coupling object and are not sampled" % n_x,
+                "overlap": os.environ.get("FOAMYADE_HALO_OVERLAP", "1") != "0",
+                "per_rank": [{"rank": r, "ms_per_step": {k: round(float(t[q]), 4) for q, k in enumerate(("step_start", "particle", "momentum", "corrector"))},
+                              "waits_per_step": {k: round(float(t[4 + q]), 1) for q, k in enumerate(("step_start", "particle", "momentum", "corrector"))}}
+                             for r, t in enumerate(allw)]}
+        except Exception as e:                                        # noqa: BLE001  (reported in the line)
+            out["exchange_wait"] = {"error": f"{type(e).__name__}: {e}"}
     if default_c3 and world == 1 and not args.moving and not args.no_moving:
         # the BASELINE cloud is at rest and identical every step -- the workload's best case (1 PCG iteration per solve, zero momentum deposits
         # skipped, re-bin amortised).  The same run with a cloud that MOVES, for the same number of steps, so that the spread is in this record

@@ -446,6 +446,13 @@ int fy_solver_local_cells(fy_solver*);
  * apply + p.Ap inside PCG), "mom_pass" (fused momentum Jacobi pass) */
 int fy_solver_enable_kernel_timing(fy_solver*, int on);
 int fy_solver_get_kernel_timing(fy_solver*, const char* kernel, double* total_ms, int64_t* launches);
+/* z-slabs: how long the solver's stream sat WAITING for slab exchanges, by phase {step start, particle, momentum, corrector}, accumulated since the
+ * call that switched the clock on.  With the exchanges overlapped (the default; FOAMYADE_HALO_OVERLAP=0 switches to exchange-then-consume) a wait
+ * runs from the end of the interior planes' sweep to the arrival of the ghost planes; in the serial schedule it is the exchange itself.  The clock
+ * costs an event pair per exchange (5 - 10 us of idle stream each): off by default.  (The particle phase's exchanges run inside the coupling object
+ * and are not sampled here.) */
+int fy_solver_enable_exchange_timing(fy_solver*, int on);
+int fy_solver_get_exchange_wait(fy_solver*, double ms[4], int64_t waits[4]);
 
 
 /* ------------------------------------------------------------------------------------------------------------------------------------

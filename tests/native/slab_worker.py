@@ -23,7 +23,7 @@ def main():
     dist.init_process_group(backend="gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     comm = prod.GlooHostComm(dist)
-    n = 12
+    n = 16 if migrate == 3 else 12                    # (mode 3: planes of 256 cells = whole blocks, so that the sweeps' plane windows are active)
     nz = 12 * world
     dx = 0.1 / n
     kw = dict(g=(0, 0, -9.81), p_bc=[2] * 6) if solver_kind == 1 else {}
@@ -78,6 +78,32 @@ def main():
                 out[f"ranks_with_an_empty_batch_s{step}"] = int(empty.item())
         migrate = 0
         steps = 0
+    if migrate == 3:
+        # ---- fluid only (no particles: nothing is summed in an order that changes from run to run), a lid moving on y+ / a bed's gravity: the fields'
+        # SHA-256 after `steps` steps, for the A/B of FOAMYADE_HALO_OVERLAP (tests/test_slabs_multiprocess.py) -- the schedules must give the same bits
+        import hashlib
+        U0 = np.random.RandomState(5).rand(n * n * nz, 3) * 0.05
+        per = n * n * (nz // world)
+        mine.set("U", U0[rank * per:(rank + 1) * per])
+        mine.enable_exchange_timing(True)
+        for _ in range(steps):
+            mine.step()
+        h = hashlib.sha256()
+        for nm in ("U", "p", "phi_z"):
+            part = torch.from_numpy(np.ascontiguousarray(mine.get(nm)))
+            parts = [torch.zeros_like(part) for _ in range(world)]
+            dist.all_gather(parts, part)
+            for q in parts:
+                h.update(q.numpy().tobytes())
+        out["fields_sha"] = h.hexdigest()
+        out["p_iters"] = int(mine.stats()["p_iters_total"])
+        out["exchange_wait"] = {k: list(v) for k, v in mine.exchange_wait().items()}
+        migrate = 0
+        steps = 0
+        if one is not None:
+            one.set("U", U0)
+            for _ in range(int(sys.argv[2])):
+                one.step()
     if migrate:
         # each rank holds the particles of its own slab; those near the top of slab 0 have moved up across the interface.  Rank 1 receives
         # them, rank 2 (and every rank above) neither sends nor receives anything -- and must take part in the migration's collectives anyway

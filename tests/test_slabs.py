@@ -391,3 +391,43 @@ def test_deep_vcycle_equals_the_exchange_per_sweep_schedule(product, monkeypatch
     for nm in ("p", "U", "phi_z"):
         np.testing.assert_array_equal(deep.get(nm), old.get(nm), err_msg=nm)            # ... for the same answer
     deep.close(); old.close()
+
+
+@pytest.mark.parametrize("solver", [0, 1])
+def test_overlapped_exchanges_equal_the_serial_schedule(product, solver, monkeypatch):
+    """round 5 (north_star: halo exchange overlapped with interior stencil work): every sweep that consumes a slab exchange runs its interior planes beside
+    the exchange and its two end planes afterwards (plane windows of whole 256-cell blocks), the particle phase's exchanges run beside independent work;
+    FOAMYADE_HALO_OVERLAP=0 is the exchange-then-consume schedule.  Fluid only (nothing is summed in an order that changes from run to run): the same
+    BITS, the same iterations, the same number of collectives.  Then with particles: both schedules match the single domain."""
+    n, nz, n_slabs = 16, 36, 3                       # planes of 256 cells; 12 planes per slab (> 2 x 5 particle-halo planes)
+    kw = dict(g=(0, 0, -9.81), p_bc=[2] * 6) if solver == 1 else {}
+
+    def run(particles):
+        case = cavity(product, solver, n, nz, p_solver=1, **kw)
+        vs = product.VirtualSlabs(case, n_slabs)
+        vs.set("U", np.random.RandomState(5).rand(n * n * nz, 3) * 0.05)
+        ex0 = vs.comm_stats(0)
+        gcase = gc.Case("s", n, n, nz, n / 16 * 1.0, gaussian=solver, np_=3000, seed=21, cluster=200, fast=20, vel_scale=0.05)
+        its = []
+        for step in range(3):
+            if particles:
+                rec = gc.particle_records(gcase, step)
+                vs.set_particles(rec[(rec[:, 2] > 0) & (rec[:, 2] < nz / n)])
+            vs.step()
+            its.append(vs.stats()[0]["p_iters_total"])
+        ex1 = vs.comm_stats(0)
+        return vs, [ex1[q] - ex0[q] for q in range(3)], its
+
+    on, ex_on, its_on = run(False)
+    monkeypatch.setenv("FOAMYADE_HALO_OVERLAP", "0")
+    off, ex_off, its_off = run(False)
+    assert its_on == its_off and sum(its_on) > 0 and ex_on == ex_off, (its_on, its_off, ex_on, ex_off)
+    for nm in ("U", "p", "phi_x", "phi_y", "phi_z"):
+        np.testing.assert_array_equal(on.get(nm), off.get(nm), err_msg=nm)
+    on.close(); off.close()
+    # with particles: either schedule against the single domain
+    serial, _, _ = run(True)
+    monkeypatch.delenv("FOAMYADE_HALO_OVERLAP")
+    ovl, _, _ = run(True)
+    compare(ovl, serial, ("U", "p", "alpha", "uSource") if solver else ("U", "p"), 1e-8)
+    serial.close(); ovl.close()

@@ -253,6 +253,8 @@ def lib():
     L.fy_solver_local_cells.argtypes = [vp]
     L.fy_solver_enable_kernel_timing.argtypes = [vp, C.c_int]
     L.fy_solver_get_kernel_timing.argtypes = [vp, C.c_char_p, _dp, C.POINTER(C.c_int64)]
+    L.fy_solver_enable_exchange_timing.argtypes = [vp, C.c_int]
+    L.fy_solver_get_exchange_wait.argtypes = [vp, _dp, C.POINTER(C.c_int64)]
     _lib = L
     return L
 
@@ -725,6 +727,15 @@ class Solver:
         ms = C.c_double(); n = C.c_int64()
         _check(lib().fy_solver_get_kernel_timing(self._h, name.encode(), C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def enable_exchange_timing(self, on=True):
+        _check(lib().fy_solver_enable_exchange_timing(self._h, int(on)))
+
+    def exchange_wait(self):
+        """{phase: (ms the stream waited for slab exchanges, number of waits)} since enable_exchange_timing(True)"""
+        ms = (C.c_double * 4)(); n = (C.c_int64 * 4)()
+        _check(lib().fy_solver_get_exchange_wait(self._h, ms, n))
+        return {nm: (ms[q], n[q]) for q, nm in enumerate(("step_start", "particle", "momentum", "corrector"))}
 
     def coupling_timings(self):
         t = ParticleTimings()

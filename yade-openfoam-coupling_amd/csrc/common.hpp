@@ -21,6 +21,7 @@ struct Options {
     std::string tree_cache_dir;  // FOAMYADE_TREE_CACHE_DIR      ranks of one node share the k-d build through this directory ("" = off)
     int rebin_interval;          // FOAMYADE_REBIN_INTERVAL      counting sort of the particles every this many steps (default 32; locality only)
     bool no_halo_overlap;        // FOAMYADE_NO_HALO_OVERLAP=1   slab smoother: exchange, then sweep (serial schedule; identical results)
+    bool halo_overlap;           // FOAMYADE_HALO_OVERLAP=0       every slab exchange is followed by its consumer (serial schedule; identical results); default 1
     bool no_aux_comm;            // FOAMYADE_NO_AUX_COMM=1       slab mode: no second RCCL communicator for the overlapped halo
     bool no_deep_vcycle;         // FOAMYADE_NO_DEEP_VCYCLE=1    slab multigrid: one exchange per sweep (round 3's schedule) instead of one per level and cycle
     bool no_fused_corrector;     // FOAMYADE_NO_FUSED_CORRECTOR=1  the corrector as five sweeps (rounds 1 - 4) instead of the two fused ones (A/B switch, identical results)

@@ -26,6 +26,8 @@ Options options() {
     if (const char* e = getenv("FOAMYADE_REBIN_INTERVAL")) q.rebin_interval = std::max(1, atoi(e));
     q.no_halo_overlap = on("FOAMYADE_NO_HALO_OVERLAP");
     q.no_aux_comm = on("FOAMYADE_NO_AUX_COMM");
+    q.halo_overlap = true;
+    if (const char* e = getenv("FOAMYADE_HALO_OVERLAP")) q.halo_overlap = !(*e == 0 || strcmp(e, "0") == 0);
     q.no_deep_vcycle = on("FOAMYADE_NO_DEEP_VCYCLE");
     q.no_fused_corrector = on("FOAMYADE_NO_FUSED_CORRECTOR");
     q.faces_from_arrays = on("FOAMYADE_FACES_FROM_ARRAYS");
@@ -678,22 +680,55 @@ int Coupling::run_batch(Batch& b) {
         // The force pass gathers U, alpha and the Archimedes term from one packed record per cell.  U / gradP / divT do not change during the
         // call and the alpha slot follows k_finalize_cells, so the records are built once per call -- here, where the pack runs beside the
         // walk's leftovers on the side stream
-        if (!cellrec_fresh) {
+        // z-slabs with the communicator's second channel (round 5): the exchanges of this phase run beside work that does not need them --
+        //   the reverse halo of the deposit sums beside the pack of the cell records, alpha's ghost planes beside the finalisation of the interior cells
+        // (the end planes, which are what the neighbours are sent, are finalised first).  Every cell goes through the same operations as in the serial
+        // schedule, in the same order per cell: the same bits.
+        const bool ovl = slab_overlap() && slab.nz > 2 * slab.gz;
+        auto pack_records = [&]() -> int {
+            if (cellrec_fresh) return FY_OK;
+            if (slab.fields_event) { FY_HIP(hipStreamWaitEvent(stream, slab.fields_event, 0)); slab.fields_event = nullptr; }      // gradP / divT ghost planes have landed
             FY_TRY(launch_pack_cells(stream, n_field, dU, dAlpha, dGradP, dDivT, d_vol.p, nu, rhoF, d_cellrec.p));
             cellrec_fresh = true;
-        }
+            return FY_OK;
+        };
+        if (!ovl) FY_TRY(pack_records());
         if (side.stream && ll.lists) FY_HIP(hipStreamWaitEvent(stream, side.join, 0));
         if (tbD.cell && !slab.active) {      // single domain: the tile's sums are complete, setCellVolFraction rides on the reduction
             FY_TRY(launch_tile_reduce_finalize(stream, tbD, d_pvol_acc.p, d_up_acc.p, d_touched.p, d_vol.p, dAlpha, dUParticle, d_cellrec.p));
-        } else {
+        } else if (!ovl) {
             FY_TRY(launch_tile_reduce(stream, tbD, d_pvol_acc.p, d_up_acc.p, d_touched.p));
             if (slab.active) {      // contributions that landed in ghost planes belong to the neighbours: send them home and add
                 FY_TRY(halo_reverse_add2(d_pvol_acc.p, 1, d_touched.p, d_up_acc.p, 3));
             }
             FY_TRY(launch_finalize_cells(stream, (int32_t)n_field, d_vol.p, d_pvol_acc.p, d_up_acc.p, d_touched.p, dAlpha, dUParticle, d_cellrec.p));
+        } else {
+            FY_TRY(slab_events());
+            FY_TRY(launch_tile_reduce(stream, tbD, d_pvol_acc.p, d_up_acc.p, d_touched.p));
+            FY_HIP(hipEventRecord(slab.ev_a, stream));
+            FY_TRY(pack_records());                                            // (enqueued first: a host-synchronous back-end blocks in the exchange while this runs)
+            FY_HIP(hipStreamWaitEvent(slab.aux, slab.ev_a, 0));
+            FY_TRY(halo_reverse_start(d_pvol_acc.p, 1, d_up_acc.p, 3, slab.aux));
+            FY_HIP(hipEventRecord(slab.ev_b, slab.aux));
+            FY_HIP(hipStreamWaitEvent(stream, slab.ev_b, 0));
+            FY_TRY(halo_reverse_finish(d_pvol_acc.p, 1, d_touched.p, d_up_acc.p, 3));
+            // cells [lo0, lo1) and [hi0, hi1): the ghost planes and the gz owned planes next to them, either end; [lo1, hi0): the interior
+            const int64_t pl = (int64_t)slab.plane, lo1 = 2 * (int64_t)slab.gz * pl, hi0 = (int64_t)slab.nz * pl, hi1 = (int64_t)n_field;
+            auto finalize = [&](int64_t c0, int64_t c1) -> int {
+                return launch_finalize_cells(stream, (int32_t)(c1 - c0), d_vol.p + c0, d_pvol_acc.p + c0, d_up_acc.p + 3 * c0, d_touched.p + c0, dAlpha + c0, dUParticle + 3 * c0,
+                                             d_cellrec.p + 8 * c0);
+            };
+            FY_TRY(finalize(0, lo1));
+            FY_TRY(finalize(hi0, hi1));
+            FY_HIP(hipEventRecord(slab.ev_a, stream));
+            FY_TRY(finalize(lo1, hi0));                                        // ... beside alpha's ghost planes
+            FY_HIP(hipStreamWaitEvent(slab.aux, slab.ev_a, 0));
+            FY_TRY(halo_fwd(dAlpha, 1, slab.gz, slab.aux));
+            FY_HIP(hipEventRecord(slab.ev_b, slab.aux));
+            FY_HIP(hipStreamWaitEvent(stream, slab.ev_b, 0));
         }
         if (slab.active) {      // the gathers below reach gz planes into the neighbours (alpha only: uParticle is applied per cell by its owner, k_fold_sources)
-            FY_TRY(halo_fwd(dAlpha, 1, slab.gz));
+            if (!ovl) FY_TRY(halo_fwd(dAlpha, 1, slab.gz));
             const int64_t gcells = (int64_t)slab.gz * (int64_t)slab.plane;
             FY_TRY(launch_patch_rec_alpha(stream, 0, gcells, dAlpha, d_cellrec.p));
             FY_TRY(launch_patch_rec_alpha(stream, (int64_t)(slab.gz + slab.nz) * (int64_t)slab.plane, gcells, dAlpha, d_cellrec.p));
@@ -717,11 +752,26 @@ int Coupling::run_batch(Batch& b) {
             FY_TRY(launch_tile_reduce_fold(stream, tbB, d_drag_acc.p, dUSource, dUParticle, dUSourceDrag));
         } else {
             FY_TRY(launch_tile_reduce(stream, tbB, d_drag_acc.p, dUSource, nullptr));
-            if (slab.active) {
-                FY_TRY(halo_reverse_add2(d_drag_acc.p, 1, nullptr, dUSource, 3));
-            }
             // FoamYade.C:385-386 per cell: uSourceDrag += D, uSource += uParticle * D (this batch's uParticle: the owner's, after its finalize)
-            FY_TRY(launch_fold_sources(stream, n_field, d_drag_acc.p, dUParticle, dUSourceDrag, dUSource));
+            if (ovl) {
+                // the reverse halo of the drag sums and of uSource beside the fold of the interior cells, which receive nothing from the neighbours
+                FY_HIP(hipEventRecord(slab.ev_a, stream));
+                const int64_t pl = (int64_t)slab.plane, lo1 = 2 * (int64_t)slab.gz * pl, hi0 = (int64_t)slab.nz * pl, hi1 = (int64_t)n_field;
+                auto fold = [&](int64_t c0, int64_t c1) -> int {
+                    return launch_fold_sources(stream, c1 - c0, d_drag_acc.p + c0, dUParticle + 3 * c0, dUSourceDrag + c0, dUSource + 3 * c0);
+                };
+                FY_TRY(fold(lo1, hi0));
+                FY_HIP(hipStreamWaitEvent(slab.aux, slab.ev_a, 0));
+                FY_TRY(halo_reverse_start(d_drag_acc.p, 1, dUSource, 3, slab.aux));
+                FY_HIP(hipEventRecord(slab.ev_b, slab.aux));
+                FY_HIP(hipStreamWaitEvent(stream, slab.ev_b, 0));
+                FY_TRY(halo_reverse_finish(d_drag_acc.p, 1, nullptr, dUSource, 3));
+                FY_TRY(fold(0, lo1));
+                FY_TRY(fold(hi0, hi1));
+            } else {
+                if (slab.active) FY_TRY(halo_reverse_add2(d_drag_acc.p, 1, nullptr, dUSource, 3));
+                FY_TRY(launch_fold_sources(stream, n_field, d_drag_acc.p, dUParticle, dUSourceDrag, dUSource));
+            }
         }
         if (timing) marks.mark(5, stream);
     } else {
@@ -775,7 +825,21 @@ int Coupling::set_particle_action(double dt) {
         for (int bi = 0; bi < n_batches; ++bi) FY_TRY(run_batch(*batches[bi]));
     }
     FY_TRY(run_mid_hook());                                                // (every batch was empty)
-    if (slab.active && gaussian) FY_TRY(halo_fwd(dUSource, 3, 1));       // UcEqn.H:17-20 interpolates rAUc*uSource across the interface
+    if (slab.fields_event) { FY_HIP(hipStreamWaitEvent(stream, slab.fields_event, 0)); slab.fields_event = nullptr; }      // (no batch gathered anything)
+    slab.tail_pending = false;
+    if (slab.active && gaussian) {       // UcEqn.H:17-20 interpolates rAUc*uSource across the interface
+        if (slab_overlap()) {
+            // ... on the second channel: the solver waits for ev_tail where it first reads uSource across a slab face (after its stress and assembly sweeps)
+            FY_TRY(slab_events());
+            FY_HIP(hipEventRecord(slab.ev_a, stream));
+            FY_HIP(hipStreamWaitEvent(slab.aux, slab.ev_a, 0));
+            FY_TRY(halo_fwd(dUSource, 3, 1, slab.aux));
+            FY_HIP(hipEventRecord(slab.ev_tail, slab.aux));
+            slab.tail_pending = true;
+        } else {
+            FY_TRY(halo_fwd(dUSource, 3, 1));
+        }
+    }
 
     if (fields_on_host) FY_TRY(stage_mutable_out());
 
@@ -1098,30 +1162,43 @@ int Coupling::exchange_dt() {
 }
 
 // slab halos of a cell array with ncomp interleaved components: refresh w ghost planes per side from the owners
-int Coupling::halo_fwd(double* f, int ncomp, int w) {
+int Coupling::halo_fwd(double* f, int ncomp, int w, hipStream_t on) {
     const size_t P = slab.plane * (size_t)ncomp;
-    return slab.comm->neighbour_exchange(stream, f + (size_t)(slab.gz + slab.nz - w) * P, f + (size_t)(slab.gz - w) * P,
+    return slab.comm->neighbour_exchange(on ? on : stream, f + (size_t)(slab.gz + slab.nz - w) * P, f + (size_t)(slab.gz - w) * P,
                                          f + (size_t)slab.gz * P, f + (size_t)(slab.gz + slab.nz) * P, (size_t)w * P);
 }
 
-// ... and the reverse: what this rank accumulated in its ghost planes goes to the owners, who add it; ghost planes are then cleared
-int Coupling::halo_reverse_add2(double* f1, int nc1, unsigned char* mark1, double* f2, int nc2) {
-    // f1 and f2 (nc1 + nc2 <= 4 components) travel in ONE grouped exchange
-    struct It { double* f; int nc; unsigned char* mark; double *tmp_a, *tmp_b; } it[2] = {{f1, nc1, mark1, nullptr, nullptr}, {f2, nc2, nullptr, nullptr, nullptr}};
+int Coupling::slab_events() {
+    if (slab.ev_a) return FY_OK;
+    FY_HIP(hipEventCreateWithFlags(&slab.ev_a, hipEventDisableTiming));
+    FY_HIP(hipEventCreateWithFlags(&slab.ev_b, hipEventDisableTiming));
+    FY_HIP(hipEventCreateWithFlags(&slab.ev_tail, hipEventDisableTiming));
+    return FY_OK;
+}
+
+// ... and the reverse: what this rank accumulated in its ghost planes goes to the owners, who add it; ghost planes are then cleared.
+// f1 and f2 (nc1 + nc2 <= 4 components) travel in ONE grouped exchange into tmp buffers (start); the additions and the reset follow (finish)
+int Coupling::halo_reverse_start(double* f1, int nc1, double* f2, int nc2, hipStream_t on) {
+    struct It { double* f; int nc; } it[2] = {{f1, nc1}, {f2, nc2}};
     double* tmp = halo_tmp.p;
     slab.comm->group_begin();
     for (It& t : it) {
         const size_t P = slab.plane * (size_t)t.nc, cnt = (size_t)slab.gz * P;
-        t.tmp_a = tmp; t.tmp_b = tmp + cnt; tmp += 2 * cnt;
-        FY_TRY(slab.comm->neighbour_exchange(stream, t.f + (size_t)(slab.gz + slab.nz) * P, t.tmp_a, t.f, t.tmp_b, cnt));
+        FY_TRY(slab.comm->neighbour_exchange(on, t.f + (size_t)(slab.gz + slab.nz) * P, tmp, t.f, tmp + cnt, cnt));
+        tmp += 2 * cnt;
     }
-    FY_TRY(slab.comm->group_end(stream));
+    return slab.comm->group_end(on);
+}
+int Coupling::halo_reverse_finish(double* f1, int nc1, unsigned char* mark1, double* f2, int nc2) {
+    struct It { double* f; int nc; unsigned char* mark; } it[2] = {{f1, nc1, mark1}, {f2, nc2, nullptr}};
+    double* tmp = halo_tmp.p;
     for (It& t : it) {
         const size_t P = slab.plane * (size_t)t.nc, cnt = (size_t)slab.gz * P;
+        double* tmp_a = tmp; double* tmp_b = tmp + cnt; tmp += 2 * cnt;
         double* own_lo = t.f + (size_t)slab.gz * P;
         double* own_hi = t.f + (size_t)slab.nz * P;                  // the last gz owned planes
-        if (slab.comm->has_down()) FY_TRY(launch_add_mark(stream, own_lo, t.tmp_a, cnt, t.mark ? t.mark + (size_t)slab.gz * slab.plane : nullptr));
-        if (slab.comm->has_up()) FY_TRY(launch_add_mark(stream, own_hi, t.tmp_b, cnt, t.mark ? t.mark + (size_t)slab.nz * slab.plane : nullptr));
+        if (slab.comm->has_down()) FY_TRY(launch_add_mark(stream, own_lo, tmp_a, cnt, t.mark ? t.mark + (size_t)slab.gz * slab.plane : nullptr));
+        if (slab.comm->has_up()) FY_TRY(launch_add_mark(stream, own_hi, tmp_b, cnt, t.mark ? t.mark + (size_t)slab.nz * slab.plane : nullptr));
         FY_HIP(hipMemsetAsync(t.f, 0, cnt * sizeof(double), stream));
         FY_HIP(hipMemsetAsync(t.f + (size_t)(slab.gz + slab.nz) * P, 0, cnt * sizeof(double), stream));
     }
@@ -1224,6 +1301,9 @@ int Coupling::write_field_host(const char* name, const double* in) {
 Coupling::~Coupling() {
     if (device >= 0) (void)hipSetDevice(device);
     if (view_locked) (void)hipHostUnregister(view_base);
+    if (slab.ev_a) (void)hipEventDestroy(slab.ev_a);
+    if (slab.ev_b) (void)hipEventDestroy(slab.ev_b);
+    if (slab.ev_tail) (void)hipEventDestroy(slab.ev_tail);
     for (auto& ck : piece_clocks) ck.destroy();
     for (auto& t : timers) t.destroy();
     marks.destroy();

@@ -61,6 +61,11 @@ struct SlabInfo {
     size_t plane = 0, n_store = 0;
     int64_t base = 0;
     int kglob0 = 0, nzglob = 0;          // global k of the first owned plane, global plane count (particle ownership)
+    // round 5: exchanges beside independent work (fy_solver sets these; FOAMYADE_HALO_OVERLAP=0 leaves aux null: exchange, then consume)
+    hipStream_t aux = nullptr;           // the communicator's second channel (the solver's comm_stream)
+    hipEvent_t fields_event = nullptr;   // recorded by the solver behind the exchange of gradP / divT ghost planes: waited for before the first gather of fluid fields
+    hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_tail = nullptr;     // created on first use
+    bool tail_pending = false;           // uSource's ghost planes are still on their way (ev_tail): the solver waits before it interpolates rAUc uSource
 };
 
 struct Coupling {
@@ -202,8 +207,13 @@ struct Coupling {
     int send_results();
     int exchange_dt();
     int set_source_zero();
-    int halo_fwd(double* f, int ncomp, int w);
-    int halo_reverse_add2(double* f1, int nc1, unsigned char* mark1, double* f2, int nc2);
+    int halo_fwd(double* f, int ncomp, int w, hipStream_t on = nullptr);
+    // the exchange (start: ghost-plane sums travel to tmp buffers, on `on`) and the owners' additions + ghost reset (finish: on the main stream) of a reverse halo
+    int halo_reverse_start(double* f1, int nc1, double* f2, int nc2, hipStream_t on);
+    int halo_reverse_finish(double* f1, int nc1, unsigned char* mark1, double* f2, int nc2);
+    int halo_reverse_add2(double* f1, int nc1, unsigned char* mark1, double* f2, int nc2) { FY_TRY(halo_reverse_start(f1, nc1, f2, nc2, stream)); return halo_reverse_finish(f1, nc1, mark1, f2, nc2); }
+    bool slab_overlap() const { return slab.active && slab.aux != nullptr; }
+    int slab_events();                   // create ev_a / ev_b / ev_tail on first use
     int get_forces_host(int bi, double* out);
     int get_found_host(int bi, int32_t* out);
     int get_stencils_host(int bi, int32_t* k, int32_t* ids, double* w, int32_t* chain);

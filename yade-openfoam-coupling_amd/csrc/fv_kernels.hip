@@ -211,6 +211,7 @@ __device__ __forceinline__ int swz_block(int bid, int nblk) {
 // Host side (Solver::create): strips only when planes are whole numbers of blocks and every XCD gets whole planes; FOAMYADE_STRIP_BLOCKS.
 // Returns the LOGICAL block (cells [256 b, 256 b + 256)); partial sums are stored under it, so folds do not depend on the order.
 __device__ __forceinline__ int fv_block(const FvGeo& g, int bid, int nblk) {
+    if (g.win_nblk > 0) return g.win_blk0 + bid;            // a window of whole z-planes (its blocks in storage order)
     if (g.strip_B <= 0) return swz_block(bid, nblk);
     const int x = bid & 7, l = bid >> 3;
     const int per = g.strip_nzx * g.strip_B;
@@ -221,8 +222,9 @@ __device__ __forceinline__ int fv_block(const FvGeo& g, int bid, int nblk) {
 
 // ------------------------------------------------------------------------------------------------ block reductions (256 threads)
 template <int N>
-__device__ __forceinline__ void block_reduce_store(double (&v)[N], const int (&is_max)[N], double* partials, int lb = -1) {
+__device__ __forceinline__ void block_reduce_store(double (&v)[N], const int (&is_max)[N], double* partials, int lb = -1, int stride = 0) {
     if (lb < 0) lb = (int)blockIdx.x;
+    if (stride <= 0) stride = (int)gridDim.x;              // partials of slot q start at q * (blocks of the WHOLE sweep)
     __shared__ double sh[4][N];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
@@ -240,7 +242,7 @@ __device__ __forceinline__ void block_reduce_store(double (&v)[N], const int (&i
         const int q = threadIdx.x;
         double x = sh[0][q];
         for (int w = 1; w < 4; ++w) x = is_max[q] ? fmax(x, sh[w][q]) : x + sh[w][q];
-        partials[(size_t)q * gridDim.x + lb] = x;
+        partials[(size_t)q * stride + lb] = x;
     }
 }
 
@@ -282,7 +284,8 @@ __global__ __launch_bounds__(1024) void k_reduce_finalize(const double* __restri
 // red_blocks(n) partials of a slot in a fixed order, so results are reproducible from run to run.
 #define FY_RED_LOOP(t, n) const int t = swz_block(blockIdx.x, gridDim.x) * 256 + (int)threadIdx.x; if (t < (n))
 // the same over the owned cells of g, blocks in strip order; fy_lb = the logical block (pass it to block_reduce_store)
-#define FY_RED_LOOP_G(g, t) const int fy_lb = fv_block(g, blockIdx.x, gridDim.x); const int t = fy_lb * 256 + (int)threadIdx.x; if (t < (g).Nc)
+#define FY_RED_LOOP_G(g, t) const int fy_lb = fv_block(g, blockIdx.x, gridDim.x); const int fy_stride = (g).win_nblk > 0 ? (g).red_stride : (int)gridDim.x; \
+    const int t = fy_lb * 256 + (int)threadIdx.x; if (t < (g).Nc)
 
 // ------------------------------------------------------------------------------------------------ face kernels
 // generic face iteration: thread -> (d fixed per launch, face index f) -> local (i,j,k) of the face
@@ -466,7 +469,7 @@ __global__ __launch_bounds__(256) void k_adjust_phi_sums(FvGeo g, CFace3 phiHbyA
 #undef FY_CALL
     }
     const int mx[4] = {0, 0, 0, 0};
-    block_reduce_store<4>(v, mx, partials, fy_lb);
+    block_reduce_store<4>(v, mx, partials, fy_lb, fy_stride);
 }
 // one thread per boundary face of the block (both sides of the three directions); err: set when OpenFOAM would stop with
 // "Continuity error cannot be removed by adjusting the outflow"
@@ -557,7 +560,7 @@ __global__ __launch_bounds__(256) void k_courant(FvGeo g, CFace3 phi, double* __
         v[1] += s;
     }
     const int mx[2] = {1, 0};
-    block_reduce_store<2>(v, mx, partials, fy_lb);
+    block_reduce_store<2>(v, mx, partials, fy_lb, fy_stride);
 }
 
 // vGrad = fvc::grad(U) (icoFoamYade.C:71, pimpleFoamYade.C:76); pimple also gradP = fvc::grad(p) (:74) and
@@ -1267,7 +1270,7 @@ __global__ __launch_bounds__(256) void k_mom_pass(FvGeo g, Mom7 M, const double*
         }
     }
     const int mx[6] = {0, 0, 0, 0, 0, 0};
-    block_reduce_store<6>(v, mx, partials, fy_lb);
+    block_reduce_store<6>(v, mx, partials, fy_lb, fy_stride);
 }
 
 // component sums over a contiguous range of n vectors starting at x
@@ -1372,7 +1375,7 @@ __global__ __launch_bounds__(256) void k_cont_err(FvGeo g, CFace3 phi, CFace3 al
         v[1] += ce * geo_V(g, i, j, k);
     }
     const int mx[2] = {0, 0};
-    block_reduce_store<2>(v, mx, partials, fy_lb);
+    block_reduce_store<2>(v, mx, partials, fy_lb, fy_stride);
 }
 
 // ico:    U = HbyA - rAU*fvc::grad(p)                                                         icoFoamYade.C:136
@@ -1431,7 +1434,7 @@ __global__ __launch_bounds__(256) void k_U_correct(FvGeo g, const double* __rest
     }
     if (DIAG) {
         const int mx[4] = {0, 0, 1, 0};
-        block_reduce_store<4>(v, mx, partials, fy_lb);
+        block_reduce_store<4>(v, mx, partials, fy_lb, fy_stride);
     }
 }
 
@@ -1578,7 +1581,7 @@ __global__ __launch_bounds__(256) void k_corr_back(FvGeo g, const double* __rest
     }
     if (DIAG) {
         const int mx[4] = {0, 0, 1, 0};
-        block_reduce_store<4>(v, mx, partials, fy_lb);
+        block_reduce_store<4>(v, mx, partials, fy_lb, fy_stride);
     }
 }
 
@@ -1688,7 +1691,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
         v[1] += fabs(Ax - Aref) + fabs(r - Aref);
     }
     const int mx[2] = {0, 0};
-    block_reduce_store<2>(v, mx, partials, fy_lb);
+    block_reduce_store<2>(v, mx, partials, fy_lb, fy_stride);
 }
 
 // ------------------------------------------------------------------------------------------------ pressure solver
@@ -2298,6 +2301,11 @@ __global__ __launch_bounds__(256) void k_add(double* __restrict__ y, const doubl
     if (i < n) y[i] += x[i];
 }
 
+// launch grids of the cell sweeps: the whole owned range, or the block window the geometry names (FvGeo::win_nblk: a range of z-planes, for the
+// sweeps that run beside a halo exchange)
+inline int fv_grid(const FvGeo& g) { return g.win_nblk > 0 ? g.win_nblk : div_up(g.Nc, 256); }
+inline int fv_red_grid(const FvGeo& g) { return g.win_nblk > 0 ? g.win_nblk : red_blocks(g.Nc); }
+
 #define FY_LAUNCH_CHECK()                                                                                     \
     do {                                                                                                      \
         hipError_t _e = hipGetLastError();                                                                    \
@@ -2322,7 +2330,7 @@ int launch_flux_of(hipStream_t s, FvGeo g, const double* F, Face3 out) {
 }
 
 int launch_courant(hipStream_t s, FvGeo g, CFace3 phi, double* partials) {
-    hipLaunchKernelGGL(k_courant, dim3(red_blocks(g.Nc)), dim3(256), 0, s, g, phi, partials);
+    hipLaunchKernelGGL(k_courant, dim3(fv_red_grid(g)), dim3(256), 0, s, g, phi, partials);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }
@@ -2330,39 +2338,39 @@ int launch_courant(hipStream_t s, FvGeo g, CFace3 phi, double* partials) {
 int launch_pre_coupling(hipStream_t s, FvGeo g, const double* U, const double* p, const double* alpha, CFace3 psn, double* vGrad,
                         double* gradP, double* divT, double* Gout, int write_vgrad, int write_pfields, CFace3 phi, double* ddtU, double* Uold_out,
                         double* cellrec, double rec_nu, double rec_rhoF, Face3 dcorr) {
-    hipLaunchKernelGGL(k_pre_coupling, dim3(div_up(g.Nc, 256)), dim3(256), 0, s, g, U, p, alpha, psn, vGrad, gradP, divT, Gout, write_vgrad, write_pfields,
+    hipLaunchKernelGGL(k_pre_coupling, dim3(fv_grid(g)), dim3(256), 0, s, g, U, p, alpha, psn, vGrad, gradP, divT, Gout, write_vgrad, write_pfields,
                        phi, ddtU, Uold_out, cellrec, 2.0 * rec_nu, rec_rhoF, dcorr);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }
 
 int launch_interp_alpha(hipStream_t s, FvGeo g, const double* alpha, Face3 af) {
-    hipLaunchKernelGGL(k_interp_alpha_cells, dim3(div_up(g.Nc, 256)), dim3(256), 0, s, g, alpha, af);
+    hipLaunchKernelGGL(k_interp_alpha_cells, dim3(fv_grid(g)), dim3(256), 0, s, g, alpha, af);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }
 
 int launch_div_G(hipStream_t s, FvGeo g, const double* G, double* divG) {
-    hipLaunchKernelGGL(k_div_G, dim3(div_up(g.Nc, 256)), dim3(256), 0, s, g, G, divG);
+    hipLaunchKernelGGL(k_div_G, dim3(fv_grid(g)), dim3(256), 0, s, g, G, divG);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }
 
 int launch_assemble_turb(hipStream_t s, FvGeo g, TurbEqn e, const double* k, const double* eps, const double* alpha, CFace3 alphaf, CFace3 phi,
                          const double* vGrad, const double* U, Mom7 M, double* b3, double* x3) {
-    hipLaunchKernelGGL(k_assemble_turb, dim3(div_up(g.Nc, 256)), dim3(256), 0, s, g, e, k, eps, alpha, alphaf, phi, vGrad, U, M, b3, x3);
+    hipLaunchKernelGGL(k_assemble_turb, dim3(fv_grid(g)), dim3(256), 0, s, g, e, k, eps, alpha, alphaf, phi, vGrad, U, M, b3, x3);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }
 
 int launch_turb_finish(hipStream_t s, FvGeo g, TurbEqn e, const double* x3, double* X, int nut_mode, double cmu, const double* eps, double* nut) {
-    hipLaunchKernelGGL(k_turb_finish, dim3(div_up(g.Nc, 256)), dim3(256), 0, s, g, e, x3, X, nut_mode, cmu, eps, nut);
+    hipLaunchKernelGGL(k_turb_finish, dim3(fv_grid(g)), dim3(256), 0, s, g, e, x3, X, nut_mode, cmu, eps, nut);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }
 
 int launch_smagorinsky_nut(hipStream_t s, FvGeo g, const double* vGrad, double ck, double ce, double delta, double* nut) {
-    hipLaunchKernelGGL(k_smagorinsky_nut, dim3(div_up(g.Nc, 256)), dim3(256), 0, s, g, vGrad, ck, ce, delta, nut);
+    hipLaunchKernelGGL(k_smagorinsky_nut, dim3(fv_grid(g)), dim3(256), 0, s, g, vGrad, ck, ce, delta, nut);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }
@@ -2370,15 +2378,15 @@ int launch_smagorinsky_nut(hipStream_t s, FvGeo g, const double* vGrad, double c
 int launch_assemble_momentum(hipStream_t s, FvGeo g, const double* U, const double* Uold, const double* alpha, const double* alphaOld,
                              CFace3 alphaf, CFace3 phi, const double* uSource, const double* uSourceDrag, const double* divG, const double* vGrad,
                              Mom7 M, double* src, double* rAU) {
-    if (g.upwind >= 3) hipLaunchKernelGGL(k_assemble_momentum<true>, dim3(div_up(g.Nc, 256)), dim3(256), 0, s, g, U, Uold, alpha, alphaOld, alphaf, phi, uSource,
+    if (g.upwind >= 3) hipLaunchKernelGGL(k_assemble_momentum<true>, dim3(fv_grid(g)), dim3(256), 0, s, g, U, Uold, alpha, alphaOld, alphaf, phi, uSource,
                                           uSourceDrag, divG, vGrad, M, src, rAU);
-    else hipLaunchKernelGGL(k_assemble_momentum<false>, dim3(div_up(g.Nc, 256)), dim3(256), 0, s, g, U, Uold, alpha, alphaOld, alphaf, phi, uSource,
+    else hipLaunchKernelGGL(k_assemble_momentum<false>, dim3(fv_grid(g)), dim3(256), 0, s, g, U, Uold, alpha, alphaOld, alphaf, phi, uSource,
                             uSourceDrag, divG, vGrad, M, src, rAU);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }
 int launch_grad_magsqr(hipStream_t s, FvGeo g, const double* U, double* gradL) {
-    hipLaunchKernelGGL(k_grad_magsqr, dim3(div_up(g.Nc, 256)), dim3(256), 0, s, g, U, gradL);
+    hipLaunchKernelGGL(k_grad_magsqr, dim3(fv_grid(g)), dim3(256), 0, s, g, U, gradL);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }
@@ -2392,22 +2400,22 @@ int launch_interp_rAU(hipStream_t s, FvGeo g, const double* rAU, Face3 rf) {
 }
 
 int launch_bmom(hipStream_t s, FvGeo g, const double* src, const double* p, CFace3 psn, CFace3 phiForces, CFace3 rAUf, double* bmom) {
-    hipLaunchKernelGGL(k_bmom, dim3(div_up(g.Nc, 256)), dim3(256), 0, s, g, src, p, psn, phiForces, rAUf, bmom);
+    hipLaunchKernelGGL(k_bmom, dim3(fv_grid(g)), dim3(256), 0, s, g, src, p, psn, phiForces, rAUf, bmom);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }
 
 int launch_bmom_faces(hipStream_t s, FvGeo g, const double* rAU, const double* uSource, const double* src, const double* p, CFace3 psn, Face3 rAUf_out,
                       Face3 phiForces, double* bmom) {
-    hipLaunchKernelGGL(k_bmom_faces, dim3(div_up(g.Nc, 256)), dim3(256), 0, s, g, rAU, uSource, src, p, psn, rAUf_out, phiForces, bmom);
+    hipLaunchKernelGGL(k_bmom_faces, dim3(fv_grid(g)), dim3(256), 0, s, g, rAU, uSource, src, p, psn, rAUf_out, phiForces, bmom);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }
 
 int launch_mom_pass(hipStream_t s, FvGeo g, Mom7 M, const double* b, const double* x, double* xn, const double* xsum, double n_glob, double* partials,
                     const double* hsrc, const double* rAU, double* HbyA) {
-    if (HbyA) hipLaunchKernelGGL(k_mom_pass<true>, dim3(red_blocks(g.Nc)), dim3(256), 0, s, g, M, b, x, xn, xsum, n_glob, partials, hsrc, rAU, HbyA);
-    else hipLaunchKernelGGL(k_mom_pass<false>, dim3(red_blocks(g.Nc)), dim3(256), 0, s, g, M, b, x, xn, xsum, n_glob, partials, hsrc, rAU, HbyA);
+    if (HbyA) hipLaunchKernelGGL(k_mom_pass<true>, dim3(fv_red_grid(g)), dim3(256), 0, s, g, M, b, x, xn, xsum, n_glob, partials, hsrc, rAU, HbyA);
+    else hipLaunchKernelGGL(k_mom_pass<false>, dim3(fv_red_grid(g)), dim3(256), 0, s, g, M, b, x, xn, xsum, n_glob, partials, hsrc, rAU, HbyA);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }
@@ -2419,22 +2427,22 @@ int launch_sum3(hipStream_t s, const double* x, int n, double* partials) {
 }
 
 int launch_HbyA(hipStream_t s, FvGeo g, Mom7 M, const double* src, const double* U, const double* rAU, double* HbyA) {
-    hipLaunchKernelGGL(k_HbyA, dim3(div_up(g.Nc, 256)), dim3(256), 0, s, g, M, src, U, rAU, HbyA);
+    hipLaunchKernelGGL(k_HbyA, dim3(fv_grid(g)), dim3(256), 0, s, g, M, src, U, rAU, HbyA);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }
 
 int launch_phiHbyA(hipStream_t s, FvGeo g, const double* HbyA, const double* U, const double* Uold, CFace3 phiOld, CFace3 rAUf,
                    CFace3 alphaf, CFace3 phiForces, Face3 out, Face3 psn, Face3 ddtc, int keep) {
-    if (keep == 1) hipLaunchKernelGGL(k_phiHbyA_cells<1>, dim3(div_up(g.Nc, 256)), dim3(256), 0, s, g, HbyA, U, Uold, phiOld, rAUf, alphaf, phiForces, out, psn, ddtc);
-    else if (keep == 2) hipLaunchKernelGGL(k_phiHbyA_cells<2>, dim3(div_up(g.Nc, 256)), dim3(256), 0, s, g, HbyA, U, Uold, phiOld, rAUf, alphaf, phiForces, out, psn, ddtc);
-    else hipLaunchKernelGGL(k_phiHbyA_cells<0>, dim3(div_up(g.Nc, 256)), dim3(256), 0, s, g, HbyA, U, Uold, phiOld, rAUf, alphaf, phiForces, out, psn, ddtc);
+    if (keep == 1) hipLaunchKernelGGL(k_phiHbyA_cells<1>, dim3(fv_grid(g)), dim3(256), 0, s, g, HbyA, U, Uold, phiOld, rAUf, alphaf, phiForces, out, psn, ddtc);
+    else if (keep == 2) hipLaunchKernelGGL(k_phiHbyA_cells<2>, dim3(fv_grid(g)), dim3(256), 0, s, g, HbyA, U, Uold, phiOld, rAUf, alphaf, phiForces, out, psn, ddtc);
+    else hipLaunchKernelGGL(k_phiHbyA_cells<0>, dim3(fv_grid(g)), dim3(256), 0, s, g, HbyA, U, Uold, phiOld, rAUf, alphaf, phiForces, out, psn, ddtc);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }
 
 int launch_adjust_phi_sums(hipStream_t s, FvGeo g, CFace3 phiHbyA, CFace3 phiForces, double* partials) {
-    hipLaunchKernelGGL(k_adjust_phi_sums, dim3(red_blocks(g.Nc)), dim3(256), 0, s, g, phiHbyA, phiForces, partials);
+    hipLaunchKernelGGL(k_adjust_phi_sums, dim3(fv_red_grid(g)), dim3(256), 0, s, g, phiHbyA, phiForces, partials);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }
@@ -2447,41 +2455,41 @@ int launch_adjust_phi_apply(hipStream_t s, FvGeo g, const double* sums, Face3 ph
 }
 
 int launch_rAUf_phi_forces(hipStream_t s, FvGeo g, const double* rAU, const double* uSource, Face3 rf, Face3 out) {
-    hipLaunchKernelGGL(k_rAUf_phi_forces_cells, dim3(div_up(g.Nc, 256)), dim3(256), 0, s, g, rAU, uSource, rf, out);
+    hipLaunchKernelGGL(k_rAUf_phi_forces_cells, dim3(fv_grid(g)), dim3(256), 0, s, g, rAU, uSource, rf, out);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }
 
 int launch_assemble_pressure(hipStream_t s, FvGeo g, CFace3 phiHbyA, CFace3 rAUf, CFace3 alphaf, CFace3 psn, const double* alpha,
                              const double* alphaOld, PMat A, double* rhs, bool matrix) {
-    if (matrix) hipLaunchKernelGGL(k_assemble_pressure<true>, dim3(div_up(g.Nc, 256)), dim3(256), 0, s, g, phiHbyA, rAUf, alphaf, psn, alpha, alphaOld, A, rhs);
-    else hipLaunchKernelGGL(k_assemble_pressure<false>, dim3(div_up(g.Nc, 256)), dim3(256), 0, s, g, phiHbyA, rAUf, alphaf, psn, alpha, alphaOld, A, rhs);
+    if (matrix) hipLaunchKernelGGL(k_assemble_pressure<true>, dim3(fv_grid(g)), dim3(256), 0, s, g, phiHbyA, rAUf, alphaf, psn, alpha, alphaOld, A, rhs);
+    else hipLaunchKernelGGL(k_assemble_pressure<false>, dim3(fv_grid(g)), dim3(256), 0, s, g, phiHbyA, rAUf, alphaf, psn, alpha, alphaOld, A, rhs);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }
 
 int launch_flux_correct(hipStream_t s, FvGeo g, const double* p, CFace3 phiHbyA, CFace3 rAUf, CFace3 alphaf, CFace3 psn, CFace3 phiForces, Face3 pflux, Face3 phi) {
-    hipLaunchKernelGGL(k_flux_correct_cells, dim3(div_up(g.Nc, 256)), dim3(256), 0, s, g, p, phiHbyA, rAUf, alphaf, psn, phiForces, pflux, phi);
+    hipLaunchKernelGGL(k_flux_correct_cells, dim3(fv_grid(g)), dim3(256), 0, s, g, p, phiHbyA, rAUf, alphaf, psn, phiForces, pflux, phi);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }
 
 int launch_cont_err(hipStream_t s, FvGeo g, CFace3 phi, CFace3 alphaf, const double* alpha, const double* alphaOld, double* partials) {
-    hipLaunchKernelGGL(k_cont_err, dim3(red_blocks(g.Nc)), dim3(256), 0, s, g, phi, alphaf, alpha, alphaOld, partials);
+    hipLaunchKernelGGL(k_cont_err, dim3(fv_red_grid(g)), dim3(256), 0, s, g, phi, alphaf, alpha, alphaOld, partials);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }
 
 int launch_U_correct(hipStream_t s, FvGeo g, const double* HbyA, const double* rAU, const double* p, CFace3 psn, CFace3 phiForces,
                      CFace3 pflux, CFace3 alphaf, CFace3 rAUf, double* U) {
-    hipLaunchKernelGGL(k_U_correct<false>, dim3(red_blocks(g.Nc)), dim3(256), 0, s, g, HbyA, rAU, p, psn, phiForces, pflux, alphaf, rAUf, U, CFace3{}, nullptr, nullptr, nullptr);
+    hipLaunchKernelGGL(k_U_correct<false>, dim3(fv_red_grid(g)), dim3(256), 0, s, g, HbyA, rAU, p, psn, phiForces, pflux, alphaf, rAUf, U, CFace3{}, nullptr, nullptr, nullptr);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }
 
 int launch_U_correct_diag(hipStream_t s, FvGeo g, const double* HbyA, const double* rAU, const double* p, CFace3 psn, CFace3 phiForces,
                           CFace3 pflux, CFace3 alphaf, CFace3 rAUf, double* U, CFace3 phi, const double* alpha, const double* alphaOld, double* partials) {
-    hipLaunchKernelGGL(k_U_correct<true>, dim3(red_blocks(g.Nc)), dim3(256), 0, s, g, HbyA, rAU, p, psn, phiForces, pflux, alphaf, rAUf, U, phi, alpha, alphaOld, partials);
+    hipLaunchKernelGGL(k_U_correct<true>, dim3(fv_red_grid(g)), dim3(256), 0, s, g, HbyA, rAU, p, psn, phiForces, pflux, alphaf, rAUf, U, phi, alpha, alphaOld, partials);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }
@@ -2489,7 +2497,7 @@ int launch_U_correct_diag(hipStream_t s, FvGeo g, const double* HbyA, const doub
 int launch_corr_back(hipStream_t s, FvGeo g, const double* p, CFace3 phiHbyA, CFace3 rAUf, CFace3 alphaf, CFace3 psn, CFace3 phiForces, Face3 phi,
                      const double* HbyA, const double* rAU, double* U, const double* alpha, const double* alphaOld, double* partials, bool faces_from_cells) {
     const FaceSrc rs{rAUf, faces_from_cells ? rAU : nullptr}, as{alphaf, faces_from_cells ? alpha : nullptr};
-    const dim3 grid(red_blocks(g.Nc)), blk(256);
+    const dim3 grid(fv_red_grid(g)), blk(256);
 #define FY_BACK(DG, FC) hipLaunchKernelGGL((k_corr_back<DG, FC>), grid, blk, 0, s, g, p, phiHbyA, rs, as, psn, phiForces, phi, HbyA, rAU, U, alpha, alphaOld, partials)
     if (partials) { if (faces_from_cells) FY_BACK(true, true); else FY_BACK(true, false); }
     else { if (faces_from_cells) FY_BACK(false, true); else FY_BACK(false, false); }
@@ -2502,7 +2510,7 @@ int launch_corr_front(hipStream_t s, FvGeo g, const double* HbyA, const double* 
                       Face3 psn, const double* rAU, const double* alpha, const double* alphaOld, PMat A, double* rhs, bool store_A, const double* x,
                       const double* xsum_dev, double xsum_val, double inv_n, double* res, double* partials, bool faces_from_cells) {
     const FaceSrc rs{rAUf, faces_from_cells ? rAU : nullptr}, as{alphaf, faces_from_cells ? alpha : nullptr};
-    const dim3 grid(red_blocks(g.Nc)), blk(256);
+    const dim3 grid(fv_red_grid(g)), blk(256);
 #define FY_FRONT(SA, FC) hipLaunchKernelGGL((k_corr_front<SA, FC>), grid, blk, 0, s, g, HbyA, U, dcorr, rs, as, phiForces, phiHbyA, psn, rAU, alpha, alphaOld, A, rhs, \
                                             x, xsum_dev, xsum_val, inv_n, res, partials)
     if (store_A) { if (faces_from_cells) FY_FRONT(true, true); else FY_FRONT(true, false); }

@@ -57,6 +57,10 @@ struct FvGeo {
     // strip order of the cell sweeps' blocks (fv_block in fv_kernels.hip): strip_B blocks per strip (0: off -- the plain XCD-contiguous order),
     // strip_bp = 256-cell blocks per z-plane, strip_nzx = planes per XCD
     int strip_B, strip_bp, strip_nzx;
+    // block window (0: the whole owned range): the sweep covers the 256-cell blocks [win_blk0, win_blk0 + win_nblk) only -- whole z-planes, chosen by
+    // the host so that a sweep's interior planes run beside the halo exchange its end planes wait for; red_stride = blocks of the whole sweep (where
+    // a reducing kernel's partial sums of slot q start: the fold sees the same partials whatever the windows were)
+    int win_blk0, win_nblk, red_stride;
 };
 
 struct Face3 { double* a[3]; };           // +axis oriented face arrays (x: (nx+1)*ny*nz, y: nx*(ny+1)*nz, z: nx*ny*(nz+1))

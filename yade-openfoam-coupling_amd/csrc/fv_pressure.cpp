@@ -259,14 +259,14 @@ int Solver::build_coarse_operators() {
 
 // OpenFOAM PCG.C with lduMatrix::solver::normFactor, in the single-reduction form (see k_pcg_cg_update); preconditioner = MG V-cycle or Jacobi.
 // sc: [0] gamma = u.r, [1] delta = u.Au, [2..5] two sets {gamma_old, alpha_old}, [6] sum(p)
-int Solver::prepare_p_init() {
+int Solver::prepare_p_init(bool with_halo) {
     // xbar = average(p) for lduMatrix::solver::normFactor: sum(p) over the owned cells, all-reduced.  The last PCG update of p left it with the
     // host (k_pcg_cg_update's second slot: the same partition and order as the sum below, the same bits); p_sum_valid falls when anything else writes p
     if (!p_sum_valid) {
         FY_TRY(launch_dot(stream, Nc, g.c0, p.p, nullptr, partials.p));
         FY_TRY(reduce_to_device(sc.p + 6));
     }
-    return halo_p();
+    return with_halo ? halo_p() : FY_OK;
 }
 
 int Solver::solve_pressure(bool final_iter, bool init_done) {

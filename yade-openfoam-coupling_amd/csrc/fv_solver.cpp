@@ -39,7 +39,8 @@ int Solver::create(const fy_case_desc* c, const fy_transport* tr, int dev, Comm*
     FY_HIP(hipEventCreateWithFlags(&ev_usum0, hipEventDisableTiming));
     FY_HIP(hipEventCreateWithFlags(&ev_usum1, hipEventDisableTiming));
     FY_HIP(hipEventCreateWithFlags(&ev_coarse, hipEventDisableTiming));
-    overlap_halos = !options().no_halo_overlap;
+    overlap_halos = !options().no_halo_overlap && options().halo_overlap;
+    overlap_sweeps = options().halo_overlap;
     fused_corrector = !options().no_fused_corrector;
     faces_from_cells = !options().faces_from_arrays;
     comm->set_aux_stream(comm_stream);
@@ -315,6 +316,7 @@ int Solver::create(const fy_case_desc* c, const fy_transport* tr, int dev, Comm*
             cpl->c.slab.active = true; cpl->c.slab.comm = comm; cpl->c.slab.gz = gz; cpl->c.slab.nz = nzl; cpl->c.slab.plane = plane;
             cpl->c.slab.n_store = nstore; cpl->c.slab.base = ((int64_t)g.kglob0 - gz) * (int64_t)plane;
             cpl->c.slab.kglob0 = g.kglob0; cpl->c.slab.nzglob = g.nzglob;
+            if (overlap_halos && overlap_sweeps) cpl->c.slab.aux = comm_stream;       // the particle phase's exchanges beside independent work (coupling.cpp)
         }
         FY_TRY(cpl->c.create(&md, &fp, pimple ? 1 : 0, tr, device));      // gaussianInterp: false for ico, true for pimple (icoFoamYade.C:53, pimpleFoamYade.C:53)
         cpl->c.rhoP = c->rho_particle; cpl->c.rhoF = c->rho_fluid; cpl->c.nu = c->nu;   // setScalarProperties (icoFoamYade.C:55)
@@ -401,13 +403,15 @@ int Solver::solve_vec3(DevBuf<double>& X, const double* rhs, double tol, double 
     int it = 0;
     for (;;) {
         // (the predictor's first pass reads the ghost planes the step's opening exchange left in U)
-        if (!(it == 0 && &X == &U && U_ghosts_fresh)) FY_TRY(halo(xc, 3, plane, g.nz, g.gz, 1));
+        const bool need_x = !(it == 0 && &X == &U && U_ghosts_fresh);
         kc[KC_MOM_PASS].begin(stream);
         // from the second pass on the momentum predictor's pass also leaves HbyA of its iterate: the pass that finds it converged has then done the
         // first corrector's H-operator sweep (corrector(): hbya_ready)
         const bool with_h = momentum && fused_corrector && cs.n_correctors > 0 && it >= 1;
-        FY_TRY(FVK(launch_mom_pass, stream, g, M7(momentum), rhs, xc, xn, xbar3.p, (double)Nglob, partials.p, with_h ? src.p : nullptr, with_h ? rAU.p : nullptr,
-                   with_h ? HbyA.p : nullptr));
+        FY_TRY(overlapped(XW_MOMENTUM, need_x, [&](hipStream_t on) { return halo(xc, 3, plane, g.nz, g.gz, 1, on); }, [&](const FvGeo& gw) {
+            return FVK(launch_mom_pass, stream, gw, M7(momentum), rhs, xc, xn, xbar3.p, (double)Nglob, partials.p, with_h ? src.p : nullptr, with_h ? rAU.p : nullptr,
+                       with_h ? HbyA.p : nullptr);
+        }));
         if (momentum) hbya_ready = with_h;
         kc[KC_MOM_PASS].end(stream);
         FY_TRY(reduce_read(6, false, h));
@@ -436,13 +440,12 @@ int Solver::solve_vec3(DevBuf<double>& X, const double* rhs, double tol, double 
 // ---- one PISO / PIMPLE corrector (icoFoamYade.C:97-140, pEqn.H) ----------------------------------------------------
 int Solver::corrector(bool final_inner) {
     Comm::Tag tag(comm, "corrector");
-    FY_TRY(halo_U());
     if (hbya_ready) hbya_ready = false;                      // (the predictor's last pass wrote HbyA of the U it accepted: solve_vec3)
-    else FY_TRY(FVK(launch_HbyA, stream, g, M7(), src.p, U.p, rAU.p, HbyA.p));
+    else FY_TRY(overlapped(XW_CORRECTOR, !U_ghosts_fresh, [&](hipStream_t on) { return halo_U(on); },
+                           [&](const FvGeo& gw) { return FVK(launch_HbyA, stream, gw, M7(), src.p, U.p, rAU.p, HbyA.p); }));
     // rAU (hence rAUf and the pressure matrix rAUf*alphaf) belongs to the momentum matrix: it only changes when that is assembled,
     // not between the PISO correctors of one assembly
     if (!pimple && rAU_new) { FY_TRY(halo_cells(rAU, 1, 1)); if (face_arrays) FY_TRY(FVK(launch_interp_rAU, stream, g, rAU.p, F3(rAUf))); }
-    FY_TRY(halo_cells(HbyA, 3, 1));
     MgLev& L = *mg[0];
     // the two fused sweeps (fv_kernels.hip "fused corrector sweeps") stand for phiHbyA + assembly + PCG's first residual and for the flux + velocity
     // corrections; adjustPhi, which needs global sums of phiHbyA between the first two, keeps the separate sweeps
@@ -454,10 +457,19 @@ int Solver::corrector(bool final_inner) {
     if (fused_front) {
         // the ddtCorr term is the same in every corrector of one momentum assembly: stored by the first, read back by the others
         clk_pres.begin(stream);
-        FY_TRY(prepare_p_init());
-        FY_TRY(FVK(launch_corr_front, stream, g, HbyA.p, U.p, C3(dcorr), C3(rAUf), C3(alphaf), C3(phiForces), F3(phiHbyA), F3(psn), rAU.p, alpha.p, /* alphaOld */ alpha.p,
-                   L.A, prhs.p, rAU_new, p.p, p_sum_valid ? nullptr : sc.p + 6, p_sum, 1.0 / (double)Nglob, pr.p, partials.p, ffc));
+        FY_TRY(prepare_p_init(false));
+        // HbyA's and p's ghost planes travel in one exchange, beside the sweep's interior planes
+        FY_TRY(overlapped(XW_CORRECTOR, true, [&](hipStream_t on) {
+            comm->group_begin();
+            FY_TRY(halo_cells(HbyA, 3, 1, on));
+            FY_TRY(halo_p(on));
+            return comm->group_end(on);
+        }, [&](const FvGeo& gw) {
+            return FVK(launch_corr_front, stream, gw, HbyA.p, U.p, C3(dcorr), C3(rAUf), C3(alphaf), C3(phiForces), F3(phiHbyA), F3(psn), rAU.p, alpha.p, /* alphaOld */ alpha.p,
+                       L.A, prhs.p, rAU_new, p.p, p_sum_valid ? nullptr : sc.p + 6, p_sum, 1.0 / (double)Nglob, pr.p, partials.p, ffc);
+        }));
     } else {
+        FY_TRY(halo_cells(HbyA, 3, 1));
         FY_TRY(FVK(launch_phiHbyA, stream, g, HbyA.p, U.p, Uold.p, C3(phiOld), C3(rAUf), C3(alphaf), C3(phiForces), F3(phiHbyA), F3(psn), F3(ddtc), rAU_new ? 1 : 2));
         if (adjust_phi) {                                       // icoFoamYade.C:108, pEqn.H:13-16
             FY_TRY(FVK(launch_adjust_phi_sums, stream, g, C3(phiHbyA), C3(phiForces), partials.p));
@@ -504,9 +516,10 @@ int Solver::corrector(bool final_inner) {
     if (fused_back) {
         // flux correction + velocity correction [+ the continuity errors and the NEXT step's Courant sums] in one sweep; p.relax() (pEqn.H:41) after it:
         // the sweep works with the unrelaxed solution, as pEqn.flux() and the reconstruction do (ico reads p itself, but has no relaxation)
-        FY_TRY(halo_p());
-        FY_TRY(FVK(launch_corr_back, stream, g, p.p, C3(phiHbyA), C3(rAUf), C3(alphaf), C3(psn), C3(phiForces), F3(phi), HbyA.p, rAU.p, U.p, alpha.p,
-                   /* alphaOld */ alpha.p, diag_fused ? partials.p : nullptr, ffc));
+        FY_TRY(overlapped(XW_CORRECTOR, !p_ghosts_fresh, [&](hipStream_t on) { return halo_p(on); }, [&](const FvGeo& gw) {
+            return FVK(launch_corr_back, stream, gw, p.p, C3(phiHbyA), C3(rAUf), C3(alphaf), C3(psn), C3(phiForces), F3(phi), HbyA.p, rAU.p, U.p, alpha.p,
+                       /* alphaOld */ alpha.p, diag_fused ? partials.p : nullptr, ffc);
+        }));
         phi_fresh = true;
         U_ghosts_fresh = false;
         if (pimple && p_relax_now > 0 && p_relax_now < 1) { FY_TRY(launch_relax_field(stream, p.p, pPrev.p, p_relax_now, nstore)); p_sum_valid = false; p_ghosts_fresh = false; }
@@ -605,23 +618,8 @@ int Solver::step() {
         else { FY_TRY(reduce_read(2, true, h)); note_courant(h); }
     }
     st.delta_t = cs.dt;
-    // runTime++ : store old-time fields (whole storage, ghost planes included)
-    comm->group_begin();                    // one exchange: U goes with the full particle-halo width straight away
-    FY_TRY(halo_cells(U, 3, g.gz > 1 ? g.gz : 1));
-    if (!p_ghosts_fresh) FY_TRY(halo_cells(p, 1, 1));        // (the last corrector's exchange still stands unless p was written since)
-    FY_TRY(halo_cells(alpha, 1, 1));
-    FY_TRY(comm->group_end(stream));
-    p_ghosts_fresh = true; U_ghosts_fresh = true;
-    // U.oldTime() of the owned cells is written by the pre-coupling sweep that reads U anyway; a slab copies only its ghost planes
-    // (phiHbyA's ddtCorr reads Uold across the slab faces), which the exchange above has just refreshed in U
-    const bool fuse_uold = true;
-    if (comm->size > 1 && g.gz > 0) {
-        const size_t gh = 3 * plane * (size_t)g.gz;
-        FY_TRY(launch_copy_f64(stream, Uold.p, U.p, gh));
-        FY_TRY(launch_copy_f64(stream, Uold.p + 3 * plane * (size_t)(g.gz + g.nz), U.p + 3 * plane * (size_t)(g.gz + g.nz), gh));
-    }
-    // phi.oldTime(): the flux arrays trade places instead of being copied -- what was phi is phiOld now, and until the first
-    // flux correction of this step rewrites phi (every face of it) the current flux is read from phiOld (phi_now())
+    // runTime++ : store old-time fields.  phi.oldTime(): the flux arrays trade places instead of being copied -- what was phi is phiOld now, and until
+    // the first flux correction of this step rewrites phi (every face of it) the current flux is read from phiOld (phi_now())
     if (cs.n_correctors > 0) {
         for (int d = 0; d < 3; ++d) { std::swap(phi[d].p, phiOld[d].p); std::swap(phi[d].n, phiOld[d].n); }
         phi_fresh = false;
@@ -639,28 +637,59 @@ int Solver::step() {
     // read no fluid field): it then runs beside the side stream's tree walk of the few particles the candidate lists hand over -- ~90 us of
     // memory latency that would otherwise sit alone between the locate and the cells' finalisation (Coupling::mid_hook)
     const bool defer_sweep = comm->size == 1 && cpl->c.gaussian;
-    std::function<int()> pre_sweep = [&]() -> int {
-        return FVK(launch_pre_coupling, stream, g, U.p, p.p, alpha.p, C3(psn), vGrad.p, gradP.p, divT.p, nullptr, want_vgrad ? 1 : 0, 1, phi_now(),
+    // U.oldTime() of the owned cells is written by the pre-coupling sweep that reads U anyway
+    const bool fuse_uold = true;
+    auto sweep_on = [&](const FvGeo& gw) -> int {
+        return FVK(launch_pre_coupling, stream, gw, U.p, p.p, alpha.p, C3(psn), vGrad.p, gradP.p, divT.p, nullptr, want_vgrad ? 1 : 0, 1, phi_now(),
                    want_ddtU ? ddtU.p : nullptr, fuse_uold ? Uold.p : nullptr, rec_out, cpl->c.nu, cpl->c.rhoF,
                    (fused_corrector && !adjust_phi) ? F3(dcorr) : Face3{});
     };
+    std::function<int()> pre_sweep = [&]() -> int { return sweep_on(g); };
+    // the step's opening exchange: U goes with the full particle-halo width straight away; p's ghosts from the last corrector still stand unless p was
+    // written since.  On slabs the sweep that consumes it runs beside it (interior planes first)
+    auto opening_exchange = [&](hipStream_t on) -> int {
+        comm->group_begin();
+        FY_TRY(halo_cells(U, 3, g.gz > 1 ? g.gz : 1, on));
+        if (!p_ghosts_fresh) FY_TRY(halo_cells(p, 1, 1, on));
+        FY_TRY(halo_cells(alpha, 1, 1, on));
+        return comm->group_end(on);
+    };
     if (defer_sweep) {
+        FY_TRY(opening_exchange(stream));                      // (one domain: nothing travels)
         cpl->c.mid_hook = [](void* u) -> int { return (*static_cast<std::function<int()>*>(u))(); };
         cpl->c.mid_hook_user = &pre_sweep;
     } else {
         cpl->c.mid_hook = nullptr;
-        FY_TRY(pre_sweep());
+        FY_TRY(overlapped(XW_STEP, true, opening_exchange, sweep_on));
+    }
+    p_ghosts_fresh = true; U_ghosts_fresh = true;
+    // a slab copies U.oldTime()'s ghost planes (the opening sweep's ddtCorr coefficient and the separate phiHbyA sweep read Uold across the slab faces),
+    // which the exchange above has just refreshed in U
+    if (comm->size > 1 && g.gz > 0) {
+        const size_t gh = 3 * plane * (size_t)g.gz;
+        FY_TRY(launch_copy_f64(stream, Uold.p, U.p, gh));
+        FY_TRY(launch_copy_f64(stream, Uold.p + 3 * plane * (size_t)(g.gz + g.nz), U.p + 3 * plane * (size_t)(g.gz + g.nz), gh));
     }
     cpl->c.cellrec_external = rec_out != nullptr;
 
     if (timing) tim[0].start(stream);
     comm->tag = "particle";
     if (g.gz > 1) {                      // the particle gathers reach gz planes into the neighbours
+        // with the second channel the planes travel while the coupling locates and deposits (which read no fluid field); it waits for ev_fields
+        // where it first gathers one (Coupling::run_batch, pack_records)
+        const bool side_ch = cpl->c.slab.aux != nullptr;
+        hipStream_t on = side_ch ? comm_stream : stream;
+        if (side_ch) {
+            if (!ev_fields) FY_HIP(hipEventCreateWithFlags(&ev_fields, hipEventDisableTiming));
+            FY_HIP(hipEventRecord(ev_ready, stream));
+            FY_HIP(hipStreamWaitEvent(comm_stream, ev_ready, 0));
+        }
         comm->group_begin();
-        FY_TRY(halo_cells(gradP, 3, g.gz)); FY_TRY(halo_cells(divT, 3, g.gz));
-        if (fm & FY_FORCE_GAUSSIAN_TORQUE) FY_TRY(halo_cells(vGrad, 9, g.gz));
-        if (want_ddtU) FY_TRY(halo_cells(ddtU, 3, g.gz));
-        FY_TRY(comm->group_end(stream));
+        FY_TRY(halo_cells(gradP, 3, g.gz, on)); FY_TRY(halo_cells(divT, 3, g.gz, on));
+        if (fm & FY_FORCE_GAUSSIAN_TORQUE) FY_TRY(halo_cells(vGrad, 9, g.gz, on));
+        if (want_ddtU) FY_TRY(halo_cells(ddtU, 3, g.gz, on));
+        FY_TRY(comm->group_end(on));
+        if (side_ch) { FY_HIP(hipEventRecord(ev_fields, comm_stream)); cpl->c.slab.fields_event = ev_fields; }
     }
     usum_pending = false;
     if (comm->size == 1 && cs.momentum_predictor) {
@@ -703,8 +732,9 @@ int Solver::step() {
             // explicit stress term of divDevRhoReff from the CURRENT U and this step's alpha (one fused stencil pass)
             if (outer > 0) FY_TRY(halo_U());
             FY_TRY(FVK(launch_pre_coupling, stream, g, U.p, p.p, alpha.p, C3(psn), vGrad.p, gradP.p, divT.p, Gt.p, g.upwind == 2 ? 1 : 0, 0));
-            FY_TRY(halo(Gt.p + 2 * 3 * nstore, 3, plane, g.nz, g.gz, 1));     // G is stored by rows; only row z is read across the slab faces
-            FY_TRY(FVK(launch_div_G, stream, g, Gt.p, divG.p));
+            // G is stored by rows; only row z is read across the slab faces
+            FY_TRY(overlapped(XW_MOMENTUM, true, [&](hipStream_t on) { return halo(Gt.p + 2 * 3 * nstore, 3, plane, g.nz, g.gz, 1, on); },
+                              [&](const FvGeo& gw) { return FVK(launch_div_G, stream, gw, Gt.p, divG.p); }));
         }
         if (g.upwind == 2) FY_TRY(halo_cells(vGrad, 9, 1));      // linearUpwind reads grad(U) of the upwind neighbour (ico: written at step start)
         if (g.upwind >= 3) {                                     // the limited schemes: gradient ratio from grad(magSqr(U)) of the current U
@@ -718,9 +748,16 @@ int Solver::step() {
         // pimple: rAUcf, phicForces and the predictor's right-hand side in one sweep (k_bmom_faces); uSource ghosts refreshed by the coupling
         const bool bmom_fused = pimple && cs.momentum_predictor && fused_corrector;
         if (pimple) {
-            FY_TRY(halo_cells(rAU, 1, 1));
-            if (bmom_fused) FY_TRY(FVK(launch_bmom_faces, stream, g, rAU.p, uSource.p, src.p, p.p, C3(psn), face_arrays ? F3(rAUf) : Face3{}, F3(phiForces), bmom.p));
-            else FY_TRY(FVK(launch_rAUf_phi_forces, stream, g, rAU.p, uSource.p, F3(rAUf), F3(phiForces)));
+            // (uSource's ghost planes may still be on their way: the coupling sent them on the second channel)
+            if (cpl->c.slab.tail_pending) { FY_HIP(hipStreamWaitEvent(stream, cpl->c.slab.ev_tail, 0)); cpl->c.slab.tail_pending = false; }
+            if (bmom_fused) {
+                FY_TRY(overlapped(XW_MOMENTUM, true, [&](hipStream_t on) { return halo_cells(rAU, 1, 1, on); }, [&](const FvGeo& gw) {
+                    return FVK(launch_bmom_faces, stream, gw, rAU.p, uSource.p, src.p, p.p, C3(psn), face_arrays ? F3(rAUf) : Face3{}, F3(phiForces), bmom.p);
+                }));
+            } else {
+                FY_TRY(halo_cells(rAU, 1, 1));
+                FY_TRY(FVK(launch_rAUf_phi_forces, stream, g, rAU.p, uSource.p, F3(rAUf), F3(phiForces)));
+            }
         }
         if (cs.momentum_predictor) {
             if (!bmom_fused) FY_TRY(FVK(launch_bmom, stream, g, src.p, p.p, C3(psn), C3(phiForces), C3(rAUf), bmom.p));
@@ -752,6 +789,9 @@ int Solver::step() {
         st.ms_total = tim[3].ms();
         st.ms_other = st.ms_total - st.ms_particle - st.ms_momentum - st.ms_pressure;
         for (auto& k : kc) k.collect();
+    }
+    if (xwait_timing) {
+        for (auto& k : clk_xwait) k.collect();
     }
     return FY_OK;
 }

@@ -47,6 +47,7 @@ struct Solver {
     hipStream_t stream = nullptr;
     hipStream_t comm_stream = nullptr;     // halo exchanges that overlap interior stencil work run here (slab mode)
     hipEvent_t ev_ready = nullptr, ev_halo = nullptr;
+    hipEvent_t ev_fields = nullptr;      // behind the exchange of gradP / divT ghost planes when it runs on the second channel (step())
     // single domain: the coarse operators (k_mg_coarsen per level, the reference term, the coarsest level's Cholesky factor -- small, launch- and
     // latency-bound kernels, ~110 us in a row) are built on comm_stream while the main stream starts the solve on level 0, which needs none of them
     // (initial residual, pre-smoothing, restriction); the first touch of a coarse level waits for ev_coarse
@@ -88,8 +89,8 @@ struct Solver {
     // p's ghost planes equal the neighbours' owned planes until somebody writes p: the exchanges in between are skipped
     bool p_ghosts_fresh = false;
     bool U_ghosts_fresh = false; // the same for U (one plane)
-    int halo_U() { if (comm->size > 1 && !U_ghosts_fresh) { FY_TRY(halo_cells(U, 3, 1)); U_ghosts_fresh = true; } return FY_OK; }
-    int halo_p() { if (comm->size > 1 && !p_ghosts_fresh) { FY_TRY(halo_cells(p, 1, 1)); p_ghosts_fresh = true; } return FY_OK; }
+    int halo_U(hipStream_t on = nullptr) { if (comm->size > 1 && !U_ghosts_fresh) { FY_TRY(halo_cells(U, 3, 1, on)); U_ghosts_fresh = true; } return FY_OK; }
+    int halo_p(hipStream_t on = nullptr) { if (comm->size > 1 && !p_ghosts_fresh) { FY_TRY(halo_cells(p, 1, 1, on)); p_ghosts_fresh = true; } return FY_OK; }
     DevBuf<double> pPrev;        // p.prevIter() (only with a field relaxation factor for p)
     double p_relax_now = 0.0;
     bool adjust_phi = false;     // adjustPhi can act (no fixed-pressure patch, and a patch that lets U float or prescribed through-flow)
@@ -122,9 +123,11 @@ struct Solver {
         if (cpl) fy_destroy(cpl);
         for (auto& t : tim) t.destroy();
         for (auto& k : kc) k.destroy();
+        for (auto& k : clk_xwait) k.destroy();
         clk_mom.destroy(); clk_pres.destroy();
         if (ev_ready) (void)hipEventDestroy(ev_ready);
         if (ev_halo) (void)hipEventDestroy(ev_halo);
+        if (ev_fields) (void)hipEventDestroy(ev_fields);
         if (ev_assembled) (void)hipEventDestroy(ev_assembled);
         if (ev_usum0) (void)hipEventDestroy(ev_usum0);
         if (ev_usum1) (void)hipEventDestroy(ev_usum1);
@@ -149,7 +152,50 @@ struct Solver {
         double* gh_hi = f + (size_t)(gzl + nzl) * P;
         return comm->neighbour_exchange(on, own_hi, gh_lo, own_lo, gh_hi, (size_t)w * P);
     }
-    int halo_cells(DevBuf<double>& f, int ncomp, int w) { return halo(f.p, ncomp, plane, g.nz, g.gz, w); }
+    int halo_cells(DevBuf<double>& f, int ncomp, int w, hipStream_t on = nullptr) { return halo(f.p, ncomp, plane, g.nz, g.gz, w, on); }
+
+    // ---- a sweep beside the halo exchange it consumes (round 5; north_star: "RCCL halo exchange over xGMI overlapped with interior stencil work").
+    // The sweep's interior planes -- whose stencils reach no ghost value -- start at once on `stream`, the exchange runs meanwhile on comm_stream (the
+    // communicator's second channel), the two end planes follow when it has landed.  A plane window is a window of 256-cell BLOCKS (FvGeo::win_*): the
+    // cells, their order inside a block and the slot a reducing kernel's partial sum goes to are those of the one-launch sweep, so fields and folds are
+    // the serial schedule's bit for bit.  Needs planes that are whole numbers of blocks; otherwise (and with FOAMYADE_HALO_OVERLAP=0) exchange, then sweep.
+    bool overlap_sweeps = true;
+    bool can_window() const { return comm->size > 1 && overlap_halos && overlap_sweeps && plane % 256 == 0 && g.nz >= 3; }
+    FvGeo window(int ka, int kb) const {
+        FvGeo w = g;
+        const int bp = (int)(plane / 256);
+        w.red_stride = red_blocks(Nc);
+        w.win_blk0 = ka * bp;
+        w.win_nblk = (kb >= g.nz ? w.red_stride : kb * bp) - w.win_blk0;      // (the top window also runs the padding blocks of the reduction grid)
+        return w;
+    }
+    // exposed wait per phase: how long `stream` sat waiting for an exchange (overlapped: from the end of the interior sweep to the ghosts' arrival;
+    // serial: the exchange itself).  Sampled by event pairs when exchange timing is on (fy_solver_enable_exchange_timing): an event record idles the stream
+    enum { XW_STEP = 0, XW_PARTICLE, XW_MOMENTUM, XW_CORRECTOR, XW_COUNT };
+    KernelClock clk_xwait[XW_COUNT];
+    bool xwait_timing = false;
+    double xwait_ms[XW_COUNT] = {0, 0, 0, 0};
+    template <class X, class L>
+    int overlapped(int phase, bool needed, X&& xchg, L&& launch) {
+        if (!needed || comm->size == 1) return launch(g);             // (ghosts still fresh, or no neighbours)
+        KernelClock& ck = clk_xwait[phase];
+        if (!can_window()) {
+            ck.begin(stream);
+            FY_TRY(xchg(stream));
+            ck.end(stream);
+            return launch(g);
+        }
+        FY_HIP(hipEventRecord(ev_ready, stream));                      // what the exchange sends is final
+        FY_TRY(launch(window(1, g.nz - 1)));                           // (enqueued first: a host-synchronous back-end blocks in the exchange while this runs)
+        FY_HIP(hipStreamWaitEvent(comm_stream, ev_ready, 0));
+        FY_TRY(xchg(comm_stream));
+        FY_HIP(hipEventRecord(ev_halo, comm_stream));
+        ck.begin(stream);
+        FY_HIP(hipStreamWaitEvent(stream, ev_halo, 0));
+        ck.end(stream);
+        FY_TRY(launch(window(0, 1)));
+        return launch(window(g.nz - 1, g.nz));
+    }
     int halo_level(MgLev& L, double* x) { return L.distributed ? halo(x, 1, L.plane, L.A.nz, L.gz, 1) : FY_OK; }
 
     int create(const fy_case_desc* c, const fy_transport* tr, int dev, Comm* cm);
@@ -200,7 +246,7 @@ struct Solver {
     bool p_sum_valid = false;
     // init_done: r0 = b - A p and its two sums are already in pr / partials (the fused corrector sweep formed them: prepare_p_init + launch_corr_front)
     int solve_pressure(bool final_iter, bool init_done = false);      // OpenFOAM PCG.C with lduMatrix::solver::normFactor; preconditioner = MG V-cycle or Jacobi
-    int prepare_p_init();          // sum(p) for the norm factor's xbar where the last PCG update did not leave it, and p's ghost planes
+    int prepare_p_init(bool with_halo = true);          // sum(p) for the norm factor's xbar where the last PCG update did not leave it, and p's ghost planes
     bool fused_corrector = true;   // the corrector as two fused sweeps (FOAMYADE_NO_FUSED_CORRECTOR=1: the five sweeps of rounds 1 - 4; identical results)
     bool hbya_ready = false;       // HbyA already holds rAU H(U) of the current U (written by the momentum predictor's last pass)
     bool face_arrays = true;       // rAUf / alphacf are kept as face arrays (somebody streams them: see create())

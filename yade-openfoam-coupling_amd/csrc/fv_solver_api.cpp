@@ -190,6 +190,20 @@ int fy_solver_enable_kernel_timing(fy_solver* s, int on) {
     return FY_OK;
 }
 
+int fy_solver_enable_exchange_timing(fy_solver* s, int on) {
+    FY_S(s);
+    s->s.xwait_timing = on != 0;
+    for (auto& k : s->s.clk_xwait) { k.reset(); k.on = on != 0; k.per_collect = 4096; }
+    return FY_OK;
+}
+
+int fy_solver_get_exchange_wait(fy_solver* s, double ms[4], int64_t waits[4]) {
+    FY_S(s);
+    if (!ms) return fy::fail(FY_ERR_INVALID, "fy_solver_get_exchange_wait: null argument");
+    for (int q = 0; q < fy::Solver::XW_COUNT; ++q) { ms[q] = s->s.clk_xwait[q].total_ms; if (waits) waits[q] = s->s.clk_xwait[q].launches; }
+    return FY_OK;
+}
+
 int fy_solver_get_kernel_timing(fy_solver* s, const char* kernel, double* total_ms, int64_t* launches) {
     FY_S(s);
     const std::string k = kernel ? kernel : "";
