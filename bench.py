@@ -713,11 +713,11 @@ def main():
     ap.add_argument("--config", default="c3", choices=["c3", "c2", "c5"], help="c3: BASELINE configs[2] (the metric's configuration); c2: configs[1] at full size; "
                     "c5: configs[4] at full size (320^3 cells, 100 M particles, fluidized bed: bottom inlet, top outlet) -- on one GPU, or with --gpus N cut into N z-slabs")
     ap.add_argument("--wire", type=int, default=2, help="steps of the drop-in (host-buffer / fake-Yade) leg after the timed region, 0 = skip")
-    ap.add_argument("--wire-workers", type=int, default=4)
+    ap.add_argument("--wire-workers", type=int, default=-1, help="Yade worker processes of the drop-in leg (-1: as many as the host's usable cores carry beside the solver side, at most 6)")
     ap.add_argument("--laplacian-probe", type=int, default=0, help=argparse.SUPPRESS)       # child mode of laplacian_past_cache
     ap.add_argument("--laplacian-reps", type=int, default=40, help=argparse.SUPPRESS)
     ap.add_argument("--no-extras", action="store_true", help="skip the C2 and general-mesh sub-records and the past-the-Infinity-Cache Laplacian probe of the default run")
-    ap.add_argument("--wire-helpers", type=int, default=4, help="wire-helper ranks beside the computing rank in the drop-in leg over MPI (0: one solver rank receives everything)")
+    ap.add_argument("--wire-helpers", type=int, default=-1, help="(-1: as many as --wire-workers) " "wire-helper ranks beside the computing rank in the drop-in leg over MPI (0: one solver rank receives everything)")
     ap.add_argument("--moving", action="store_true", help="not the BASELINE configuration: particles carry random velocities (+-0.05 m/s) and are displaced by "
                     "~0.1 dx per step (alternating random offsets, applied between the steps inside the timed region), so that the momentum deposit, "
                     "the re-bin amortisation and the pressure solver see a cloud that changes from step to step")
@@ -1017,6 +1017,10 @@ def main():
             out["general_mesh"] = general_mesh_subrecord()
         except Exception as e:                                        # noqa: BLE001
             out["general_mesh"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    if args.wire_workers < 0:                                       # a process per core: master + workers + computing rank + helpers (round 5 sweep: 6 + 6 on 16 cores)
+        args.wire_workers = max(2, min(6, (cpu_info()[1] - 2) // 2))
+    if args.wire_helpers < 0:
+        args.wire_helpers = args.wire_workers
     if rank == 0 and world == 1 and args.wire > 0:
         # the drop-in leg needs the device memory: the HBM-resident solver is done
         rec_host = rec.cpu().numpy()

@@ -279,8 +279,14 @@ int Coupling::create(const fy_mesh_desc* m, const fy_field_ptrs* f, int gaussian
     FY_TRY(marks.init());
     rebin_interval = options().rebin_interval;
     if (has_transport || fields_on_host) {
-        FY_HIP(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
-        FY_HIP(hipStreamCreateWithFlags(&copy_out_stream, hipStreamNonBlocking));     // results travel the other way on a stream of their own
+        // The two copy streams get priorities of their own: the runtime multiplexes a process's streams onto a handful of hardware queues (4 by default),
+        // and two streams that land on one queue wait for each other's packets -- round 5's trace of the drop-in leg: the last records' H2D copies sat behind
+        // the answers' D2H, the batches that needed them 6 - 10 ms late.  Streams of different priority live on different queues.
+        int prio_lo = 0, prio_hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);                     // (lowest, highest: numerically prio_hi <= prio_lo)
+        if (hipStreamCreateWithPriority(&copy_stream, hipStreamNonBlocking, prio_hi) != hipSuccess) { (void)hipGetLastError(); FY_HIP(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking)); }
+        // results travel the other way on a stream of their own
+        if (hipStreamCreateWithPriority(&copy_out_stream, hipStreamNonBlocking, prio_lo) != hipSuccess) { (void)hipGetLastError(); FY_HIP(hipStreamCreateWithFlags(&copy_out_stream, hipStreamNonBlocking)); }
     }
     // FY_MEM_HOST field arrays are NOT page-locked in place (round 2 offered hipHostRegister of the caller's arrays as an opt-in): the staging
     // copies run at the same 55 GB/s out of pageable memory -- the runtime pins on the fly -- and a registration that outlives the array's owner
@@ -844,10 +850,17 @@ int Coupling::set_particle_action(double dt) {
     if (fields_on_host) FY_TRY(stage_mutable_out());
 
     // ---- send results
+    results_pending = false;
     if (has_transport) {
-        FY_TRY(send_results());                                            // FoamYade.C:228,239-243,487-535
-        FY_TRY(exchange_dt());                                             // FoamYade.C:537-553
+        if (async_results && !serial_yade && wire_views) {
+            for (int bi = 0; bi < n_batches; ++bi) FY_TRY(start_results_copy(*batches[bi]));
+            results_pending = true;                                        // (the caller polls and finishes: Coupling::finish_results)
+        } else {
+            FY_TRY(send_results());                                        // FoamYade.C:228,239-243,487-535
+            FY_TRY(exchange_dt());                                         // FoamYade.C:537-553
+        }
     }
+    async_results = false;
     if (timing) {
         timers[T_TOTAL].stop(stream);
         timings_pending = true;          // read when asked for (fy_get_particle_timings): reading here would drain the stream mid-step
@@ -866,6 +879,15 @@ int Coupling::collect_timings() {
     if (copy_stream) {
         FY_HIP(hipStreamSynchronize(copy_stream));
         FY_HIP(hipStreamSynchronize(copy_out_stream));
+        if (getenv("FOAMYADE_WIRE_TRACE") && !piece_clocks.empty() && piece_clocks[0].armed) {
+            // development trace: where the pieces' H2D copies and the batches' D2H copies sat on the device's clock, relative to the first piece's copy
+            hipEvent_t z = piece_clocks[0].a;
+            std::string line = "[wire] H2D pieces (start+dur ms):";
+            for (auto& ck : piece_clocks) if (ck.armed) { float a = 0, d = 0; (void)hipEventElapsedTime(&a, z, ck.a); (void)hipEventElapsedTime(&d, ck.a, ck.b); char buf[48]; snprintf(buf, sizeof(buf), " %.1f+%.2f", a, d); line += buf; }
+            line += "\n[wire] D2H batches (start+dur ms):";
+            for (auto* b : batches) if (b->events && b->t_out.armed) { float a = 0, d = 0; (void)hipEventElapsedTime(&a, z, b->t_out.a); (void)hipEventElapsedTime(&d, b->t_out.a, b->t_out.b); char buf[48]; snprintf(buf, sizeof(buf), " %.1f+%.2f", a, d); line += buf; }
+            std::fprintf(stderr, "%s\n", line.c_str());
+        }
         for (auto* b : batches) if (b->events) { tm.copy_in += b->t_in.ms(); tm.copy_out += b->t_out.ms(); }
         for (auto& ck : piece_clocks) tm.copy_in += ck.ms();
     }
@@ -979,9 +1001,7 @@ int Coupling::recv_yade_pieces(const std::vector<std::pair<int, int> >& in_comm)
         while (next < nb && left[next] == 0) {
             Batch& b = *batches[next];
             const int n = in_comm[next].second;
-            b.t_in.armed = false;
-            b.t_in.stop(copy_stream);                    // every copy enqueued so far, this batch's last piece among them, lies before this event
-            FY_HIP(hipStreamWaitEvent(stream, b.t_in.b, 0));
+            FY_HIP(hipStreamWaitEvent(stream, b.t_in.b, 0));       // (recorded behind the batch's last piece, below)
             b.d_rec = b.rec_own.p;
             FY_TRY(ensure_batch(b, n));
             FY_TRY(run_batch(b));
@@ -993,11 +1013,17 @@ int Coupling::recv_yade_pieces(const std::vector<std::pair<int, int> >& in_comm)
     };
     size_t outstanding = 0;
     for (size_t q = 0; q < nb; ++q) outstanding += (size_t)left[q];
+    static const bool trace = getenv("FOAMYADE_WIRE_TRACE") != nullptr;
+    const WallClock wall;
+    double t_wait = 0, t_copy = 0, t_run = 0, first_piece = -1, last_piece = 0;
     while (outstanding > 0) {
         int src = -1, pc = -1;
         const WallClock wc;
         FY_TR(transport.recv_view_next(transport.user, &src, &pc));
         wire_recv_ms += wc.ms();
+        t_wait += wc.ms();
+        if (first_piece < 0) first_piece = wall.ms();
+        last_piece = wall.ms();
         size_t q = 0;
         while (q < nb && in_comm[q].first != src) ++q;
         if (q == nb || pc < 0 || pc >= std::max(batches[q]->pieces.n, 1) || left[q] <= 0) return fail(FY_ERR_TRANSPORT, "recv_view_next: unexpected piece %d of worker %d", pc, src);
@@ -1005,17 +1031,31 @@ int Coupling::recv_yade_pieces(const std::vector<std::pair<int, int> >& in_comm)
         const int64_t n = in_comm[q].second;
         const int64_t lo = b.pieces.n > 0 ? b.pieces.start[pc] : 0, hi = (b.pieces.n > 0 && pc + 1 < b.pieces.n) ? b.pieces.start[pc + 1] : n;
         if (hi > lo) {
+            const WallClock wcc;
             if (pc_used == piece_clocks.size()) { piece_clocks.emplace_back(); FY_TRY(piece_clocks.back().init()); }
             EventTimer& ck = piece_clocks[pc_used++];
             ck.start(copy_stream);
             FY_HIP(hipMemcpyAsync(b.rec_own.p + 10 * lo, view[q] + 10 * lo, 10 * (size_t)(hi - lo) * sizeof(double), hipMemcpyHostToDevice, copy_stream));
             ck.stop(copy_stream);
             tm.bytes_in += 10 * (hi - lo) * (int64_t)sizeof(double);
+            t_copy += wcc.ms();
         }
         --left[q]; --outstanding;
+        if (left[q] == 0) {
+            // the batch's end event goes behind its LAST piece right away, not when its turn to run comes: by then the answers of the batches before it are
+            // being copied out, and streams that share a hardware queue would make this event -- and with it the batch's kernels -- wait for those copies
+            // (round 5, kernel trace of the drop-in leg: every batch started one D2H copy, 1.4 ms, after the one before it had finished)
+            b.t_in.armed = false;
+            b.t_in.stop(copy_stream);
+        }
+        const WallClock wcr;
         FY_TRY(run_ready());
+        t_run += wcr.ms();
     }
-    return run_ready();
+    const int rc = run_ready();
+    if (trace) std::fprintf(stderr, "[wire] pieces: first at %.2f ms, last at %.2f ms; host: waiting %.2f, enqueueing copies %.2f, enqueueing batches %.2f, total %.2f ms\n",
+                            first_piece, last_piece, t_wait, t_copy, t_run, wall.ms());
+    return rc;
 }
 
 // page-lock the memory the transport's views point into (once per generation; a failed registration leaves the copies pageable, which the
@@ -1091,8 +1131,20 @@ int Coupling::start_results_copy(Batch& b) {
     }
     b.t_out.start(copy_out_stream);
     if (b.n) {
-        FY_HIP(hipMemcpyAsync(hf, b.found.p, (size_t)b.n * sizeof(int32_t), hipMemcpyDeviceToHost, copy_out_stream));
-        FY_HIP(hipMemcpyAsync(hF, b.force.p, 6 * (size_t)b.n * sizeof(double), hipMemcpyDeviceToHost, copy_out_stream));
+        // FOAMYADE_D2H_STORES=1: into the transport's page-locked arena the answers go by kernel stores (launch_copy_out) instead of DMA copies, so that
+        // the copy engine carries the incoming records only.  Measured (round 5, drop-in leg): no gain -- 47 GB/s by stores against 55 GB/s by DMA, and what
+        // had delayed the copies was two streams sharing a hardware queue (see the copy streams' priorities), not the engine.  Kept as a switch.
+        static const bool dma = getenv("FOAMYADE_D2H_STORES") == nullptr;
+        void *df = nullptr, *dF = nullptr;
+        const bool by_stores = !dma && wire_views && view_locked && hipHostGetDevicePointer(&df, hf, 0) == hipSuccess && hipHostGetDevicePointer(&dF, hF, 0) == hipSuccess;
+        if (by_stores) {
+            FY_TRY(launch_copy_out(copy_out_stream, df, b.found.p, (size_t)b.n * sizeof(int32_t)));
+            FY_TRY(launch_copy_out(copy_out_stream, dF, b.force.p, 6 * (size_t)b.n * sizeof(double)));
+        } else {
+            (void)hipGetLastError();
+            FY_HIP(hipMemcpyAsync(hf, b.found.p, (size_t)b.n * sizeof(int32_t), hipMemcpyDeviceToHost, copy_out_stream));
+            FY_HIP(hipMemcpyAsync(hF, b.force.p, 6 * (size_t)b.n * sizeof(double), hipMemcpyDeviceToHost, copy_out_stream));
+        }
         tm.bytes_out += b.n * (int64_t)(sizeof(int32_t) + 6 * sizeof(double));
     }
     b.t_out.stop(copy_out_stream);
@@ -1147,6 +1199,13 @@ int Coupling::send_results() {
     }
     for (int bi = 0; bi < n_batches; ++bi) batches[bi]->out_started = false;
     return FY_OK;
+}
+
+int Coupling::finish_results() {
+    if (!results_pending) return FY_OK;
+    results_pending = false;
+    FY_TRY(send_results());
+    return exchange_dt();
 }
 
 // FoamYade::exchangeDT FoamYade.C:537-553

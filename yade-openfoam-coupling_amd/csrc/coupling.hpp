@@ -206,6 +206,13 @@ struct Coupling {
     int recv_yade_intrs();
     int send_results();
     int exchange_dt();
+    // round 5: fy_solver lets the fluid solve run while the answers cross PCIe.  async_results (set by the solver for one call): with a zero-copy wire
+    // setParticleAction returns as soon as every batch's D2H copy is enqueued; poll_results() hands over, in worker order, whatever has landed
+    // (called from the solver's host waits), finish_results() the rest + the dt handshake.  Yade gets each worker's answers as early as before
+    // -- when their copy lands -- while the PISO / PIMPLE kernels are already running (nothing in pimpleFoamYade.C:83-105 reads the forces)
+    bool async_results = false, results_pending = false;
+    int poll_results() { return (results_pending && wire_views) ? commit_landed((size_t)n_batches) : FY_OK; }
+    int finish_results();
     int set_source_zero();
     int halo_fwd(double* f, int ncomp, int w, hipStream_t on = nullptr);
     // the exchange (start: ghost-plane sums travel to tmp buffers, on `on`) and the owners' additions + ghost reset (finish: on the main stream) of a reverse halo

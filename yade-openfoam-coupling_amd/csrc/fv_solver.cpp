@@ -329,6 +329,7 @@ int Solver::create(const fy_case_desc* c, const fy_transport* tr, int dev, Comm*
 
 // fold the block partials, all-reduce over the slabs, read back
 int Solver::reduce_read(int nslots, bool courant, double* h) {
+    if (cpl) FY_TRY(cpl->c.poll_results());
     if (comm->size == 1 && red_host) {
         // single domain: the fold writes straight into mapped pinned host memory -- no device-to-host blit per read-back
         if (red_flag && nslots <= 8) {
@@ -338,7 +339,8 @@ int Solver::reduce_read(int nslots, bool courant, double* h) {
             for (int q = 0; q < nslots; ++q) {
                 unsigned long spins = 0;
                 while (__atomic_load_n(&red_flag[q], __ATOMIC_ACQUIRE) != seq) {
-                    if ((++spins & 0xfffu) == 0) {                      // every 4096 polls: is the stream still alive?
+                    if ((++spins & 0x3ffu) == 0 && cpl) FY_TRY(cpl->c.poll_results());      // (answers that have landed meanwhile go out: Coupling::poll_results)
+                    if ((spins & 0xfffu) == 0) {                        // every 4096 polls: is the stream still alive?
                         const hipError_t e = hipStreamQuery(stream);
                         if (e == hipSuccess) { if (__atomic_load_n(&red_flag[q], __ATOMIC_ACQUIRE) == seq) break; return fail(FY_ERR_HIP, "reduction flag never arrived"); }
                         if (e != hipErrorNotReady) return fail(FY_ERR_HIP, "stream failed while waiting for a reduction: %s", hipGetErrorString(e));
@@ -702,6 +704,7 @@ int Solver::step() {
         usum_pending = true;
     }
     {
+        cpl->c.async_results = true;               // (a zero-copy wire: the answers' D2H copies run under the fluid solve, handed over as they land)
         const int rc = cpl->c.set_particle_action(cs.dt);                                 // icoFoamYade.C:74, pimpleFoamYade.C:78
         cpl->c.mid_hook = nullptr; cpl->c.mid_hook_user = nullptr;                        // (pre_sweep lives in this frame only)
         FY_TRY(rc);
@@ -769,6 +772,7 @@ int Solver::step() {
         for (int corr = 0; corr < cs.n_correctors; ++corr) FY_TRY(corrector(outer == nOuter - 1 && corr == cs.n_correctors - 1));
         if (g.nut && final_outer) FY_TRY(turbulence_correct());        // pimple.turbCorr(): on the final outer iteration only (the default) -- pimpleFoamYade.C:101-104
     }
+    FY_TRY(cpl->c.finish_results());                                                      // the answers still on their way, then the dt handshake (FoamYade.C:537-553)
     if (hold_sources) sources_pending = true;                                              // reset deferred to the next step (fy_solver_hold_sources)
     else FY_TRY(cpl->c.set_source_zero());                                                // icoFoamYade.C:147, pimpleFoamYade.C:109
     if (timing) tim[3].stop(stream);

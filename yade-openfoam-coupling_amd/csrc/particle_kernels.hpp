@@ -147,6 +147,8 @@ int launch_locate_deposit(hipStream_t s, const KdNode* tree, const uint32_t* pac
                           GaussParams gp, const unsigned long long* start, SlabOwn own, LocateLists ll, CellWindow cw, double* pvol_acc, double* up_acc,
                           unsigned char* touched, TileBuckets tb = TileBuckets{}, SideStream side = SideStream{},
                           const double* rec_gather = nullptr /* wire records: k_locate_deposit fetches them through p.orig and fills the SoA arrays itself */);
+// device buffer -> mapped host memory by 16-byte stores of a kernel (a D2H that does not occupy the copy engine)
+int launch_copy_out(hipStream_t s, void* dst_mapped, const void* src, size_t bytes);
 int launch_add_mark(hipStream_t s, double* y, const double* x, size_t n, unsigned char* mark /* nullable; set where x != 0 */);
 int launch_finalize_cells(hipStream_t s, int32_t n_cells, const double* vol, double* pvol_acc, double* up_acc,
                           unsigned char* touched, double* alpha, double* uParticle, double* R /* nullable: cell records whose alpha slot follows */);
