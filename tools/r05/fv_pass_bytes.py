@@ -8,11 +8,11 @@ reg("k_tile_reduce<1>", None, "particle")
 reg("k_tile_reduce<2>", None, "particle")
 reg("k_force_gaussian", None, "particle")
 reg("k_set_source_zero", 64, "particle")
-reg("k_pre_coupling", 176, "F1 pre-coupling")            # U 24 p 8 alpha 8 -> gradP 24 divT 24 Uold 24 cellrec 64 (first call); second call: U 24 alpha 8 -> G 72
+reg("k_pre_coupling", 224, "F1 pre-coupling")            # U 24 p 8 alpha 8 -> gradP 24 divT 24 Uold 24 cellrec 64 (first call); second call: U 24 alpha 8 -> G 72
 reg("k_pre_G_divG", 56, "F4 UcEqn")
 reg("k_div_G", 96, "F4 UcEqn")
 reg("k_interp_alpha_cells", 32, "F8 post-coupling prep")
-reg("k_assemble_momentum<false>", 248, "F4 UcEqn")
+reg("k_assemble_momentum<false>", 224, "F4 UcEqn")
 reg("k_rAUf_phi_forces_cells", 80, "F4 UcEqn")
 reg("k_bmom", 104, "F3 predictor")
 reg("k_bmom_faces", 112, "F3 predictor")
@@ -23,9 +23,11 @@ reg("k_phiHbyA_cells<1>", 192, "F5 corrector")
 reg("k_phiHbyA_cells<2>", 96, "F5 corrector")
 reg("k_assemble_pressure<true>", 120, "F5 corrector")
 reg("k_assemble_pressure<false>", 64, "F5 corrector")
-reg("k_corr_front<1>", 216, "F5 corrector")
-reg("k_corr_front<2>", 136, "F5 corrector")
-reg("k_corr_back<true>", 144, "F5 corrector")
+reg("k_corr_front<true, true>", 168, "F5 corrector")      # HbyA 24 dcorr 24 rAU 8 alpha 8 phiForces 24 p 8 -> phiHbyA 24 A 32 rhs 8 r0 8
+reg("k_corr_front<false, true>", 136, "F5 corrector")     # ... without the matrix store
+reg("k_corr_back<true, true>", 144, "F5 corrector")       # p 8 phiHbyA 24 rAU 8 alpha 8 phiForces 24 HbyA 24 -> phi 24 U 24
+reg("k_mom_pass<false>", 128, "F3 predictor (Krylov)")
+reg("k_mom_pass<true>", 184, "F3 predictor (Krylov)")     # + src 24 rAU 8 -> HbyA 24: the first corrector's H-operator sweep rides on it
 reg("k_flux_correct_cells", 152, "F5 corrector")
 reg("k_U_correct<true>", 136, "F5 corrector")
 reg("k_p_init", 56, "F6 pEqn solve")
