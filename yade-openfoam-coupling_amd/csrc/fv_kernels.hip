@@ -712,23 +712,39 @@ __global__ __launch_bounds__(256) void k_div_G(FvGeo g, const double* __restrict
     if (t >= g.Nc) return;
     int i, j, k; ijk_of(g, t, i, j, k);
     const int c = t + g.c0;
-    double acc[3] = {0, 0, 0};
+    const int ijk[3] = {i, j, k};
+    // gather first (round 5): row d of the tensor at the cell and at its +-d neighbours (across a boundary face the cell itself), then the arithmetic
     const double g0[3] = {G[3 * (size_t)c], G[3 * (size_t)c + 1], G[3 * (size_t)c + 2]};      // row x at this cell; its x-neighbours come from the lanes next door
     double gx[2][3];
     x_neighbours3(G, c, i, g.nx, g0, gx[0], gx[1]);
+    bool bnd[3][2];
+    double own[3][3], nbv[3][2][3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { own[0][q] = g0[q]; nbv[0][0][q] = gx[0][q]; nbv[0][1][q] = gx[1][q]; }
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) bnd[d][s] = onb(g, d, s, i, j, k);
+#pragma unroll
+    for (int d = 1; d < 3; ++d) {
+        const double* Gd = G + (size_t)d * g_row_stride(g);           // row d of the tensor field
+#pragma unroll
+        for (int q = 0; q < 3; ++q) own[d][q] = Gd[3 * (size_t)c + q];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int nb = bnd[d][s] ? c : c + (s ? stride_of(g, d) : -stride_of(g, d));
+#pragma unroll
+            for (int q = 0; q < 3; ++q) nbv[d][s][q] = Gd[3 * (size_t)nb + q];
+        }
+    }
+    double acc[3] = {0, 0, 0};
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
         double fv[2][3];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const double* Gd = G + (size_t)d * g_row_stride(g);           // row d of the tensor field
-            if (d == 0) {
-                if (onb(g, d, s, i, j, k)) for (int q = 0; q < 3; ++q) fv[s][q] = g0[q];
-                else for (int q = 0; q < 3; ++q) fv[s][q] = geo_lerp_side(g, d, s, i, g0[q], gx[s][q]);
-            } else if (onb(g, d, s, i, j, k)) for (int q = 0; q < 3; ++q) fv[s][q] = Gd[3 * (size_t)c + q];
-            else { const int nb = c + (s ? stride_of(g, d) : -stride_of(g, d)); for (int q = 0; q < 3; ++q) fv[s][q] = geo_lerp_side(g, d, s, d == 1 ? j : k, Gd[3 * (size_t)c + q], Gd[3 * (size_t)nb + q]); }
-        }
-        for (int q = 0; q < 3; ++q) acc[q] += (fv[1][q] - fv[0][q]) * geo_rh(g, d, d == 0 ? i : d == 1 ? j : k);
+        for (int s = 0; s < 2; ++s)
+            for (int q = 0; q < 3; ++q) fv[s][q] = bnd[d][s] ? own[d][q] : geo_lerp_side(g, d, s, ijk[d], own[d][q], nbv[d][s][q]);
+        for (int q = 0; q < 3; ++q) acc[q] += (fv[1][q] - fv[0][q]) * geo_rh(g, d, ijk[d]);
     }
     for (int q = 0; q < 3; ++q) divG[3 * (size_t)c + q] = acc[q];
 }

@@ -1004,7 +1004,12 @@ __global__ __launch_bounds__(kDepThreads) void k_locate_deposit(LocateLists ll, 
         }
         if (mine) {
             const double hdx = 0.5 * ig.dx;
-            const double sx = (qx - ig.ox) / ig.dx, sy = (qy - ig.oy) / ig.dx, sz = (qz - ig.oz) / ig.dx;
+            // Reciprocals instead of FP64 divisions (round 5; ~35 instructions each, 22 per particle: same-box A/B 1.167 -> 1.127 ms).  What they may move by an
+            // ulp cannot change an answer: the lattice coordinate only picks the (cell, octant) list, and a particle within 2 kListEps of a cell face goes to
+            // the walk anyway; the Gaussian's argument and the normalisation feed weights that are held to 1e-10, not to the bit.  Every comparison that steers
+            // the chain (d < best, d < maxdist) is formed exactly as the reference forms it.
+            const double rdx_ = 1.0 / ig.dx;
+            const double sx = (qx - ig.ox) * rdx_, sy = (qy - ig.oy) * rdx_, sz = (qz - ig.oz) * rdx_;
             const double fx = floor(sx), fy_ = floor(sy), fz = floor(sz);
             const double tx = sx - fx, ty = sy - fy_, tz = sz - fz;
             const double tlo = 2 * kListEps, thi = 1.0 - 2 * kListEps;
@@ -1055,7 +1060,7 @@ __global__ __launch_bounds__(kDepThreads) void k_locate_deposit(LocateLists ll, 
                         if (d < best) {                      // meshTree.C:192
                             best = d;
                             if (d < gp.maxdist && !(code & kListNoEmit)) {       // meshTree.C:195; the root is never pushed
-                                wt[h] = exp(-d / gp.two_sigma2) * gp.range_cu * gp.sigma_pi;     // FoamYade.C:308
+                                wt[h] = exp(-d * (1.0 / gp.two_sigma2)) * gp.range_cu * gp.sigma_pi;     // FoamYade.C:308
                                 emitted |= 1u << h;
                             }
                         }
@@ -1067,6 +1072,7 @@ __global__ __launch_bounds__(kDepThreads) void k_locate_deposit(LocateLists ll, 
                     double allwt = 0.0;
 #pragma unroll
                     for (int h = kListLen - 1; h >= 0; --h) allwt += wt[h];       // last push first (FoamYade.C:301-311)
+                    const double rallwt_ = 1.0 / allwt;
                     const double dia = 2 * prad;                                      // FoamYade.C:219
                     const double pVol = M_PI * cube3(dia) / 6.0;                      // FoamYade.H:36
                     const double vx = pvx, vy = pvy, vz = pvz;
@@ -1079,7 +1085,7 @@ __global__ __launch_bounds__(kDepThreads) void k_locate_deposit(LocateLists ll, 
                             const uint32_t code = (wd >> ((h & 1) * 16)) & 0xffffu;
                             const int ni = ci + (int)(code & 15u) - 8, nj = cj + (int)((code >> 4) & 15u) - 8, nk = ck + (int)((code >> 8) & 15u) - 8;
                             const int32_t id = ni + ig.nx * (nj + ig.ny * nk);
-                            const double weight = wt[h] / allwt;                      // FoamYade.C:312-314
+                            const double weight = wt[h] * rallwt_;                    // FoamYade.C:312-314
                             const size_t slot = (size_t)(pos & (kMaxK - 1)) * p.cap + (size_t)i;
                             p.ids[slot] = id;
                             p.w[slot] = weight;
