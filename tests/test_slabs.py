@@ -431,3 +431,39 @@ def test_overlapped_exchanges_equal_the_serial_schedule(product, solver, monkeyp
     ovl, _, _ = run(True)
     compare(ovl, serial, ("U", "p", "alpha", "uSource") if solver else ("U", "p"), 1e-8)
     serial.close(); ovl.close()
+
+
+@pytest.mark.parametrize("solver", [0, 1])
+def test_stream_ordered_local_group_equals_the_host_synchronous_one(product, solver, monkeypatch):
+    """the in-process communicator's host barriers serialise the virtual slabs, which hides a dependency the schedule forgets; with
+    FOAMYADE_LOCALCOMM_STREAM=1 its collectives are event waits on the ranks' streams (nothing waits on the host, as under RCCL) and the slabs' kernels
+    interleave freely.  The overlapped schedule must give the same BITS either way (fluid only), and the single domain's answer with particles."""
+    n, nz, n_slabs = 16, 36, 3
+    kw = dict(g=(0, 0, -9.81), p_bc=[2] * 6) if solver == 1 else {}
+
+    def run(particles):
+        case = cavity(product, solver, n, nz, p_solver=1, **kw)
+        vs = product.VirtualSlabs(case, n_slabs)
+        vs.set("U", np.random.RandomState(5).rand(n * n * nz, 3) * 0.05)
+        gcase = gc.Case("s", n, n, nz, n / 16 * 1.0, gaussian=solver, np_=3000, seed=21, cluster=200, fast=20, vel_scale=0.05)
+        its = []
+        for step in range(4):
+            if particles:
+                rec = gc.particle_records(gcase, step)
+                vs.set_particles(rec[(rec[:, 2] > 0) & (rec[:, 2] < nz / n)])
+            vs.step()
+            its.append(vs.stats()[0]["p_iters_total"])
+        return vs, its
+
+    sync, its_sync = run(False)
+    sync_p, _ = run(True)
+    monkeypatch.setenv("FOAMYADE_LOCALCOMM_STREAM", "1")
+    free, its_free = run(False)
+    free_p, _ = run(True)
+    monkeypatch.delenv("FOAMYADE_LOCALCOMM_STREAM")
+    assert its_sync == its_free and sum(its_sync) > 0
+    for nm in ("U", "p", "phi_x", "phi_y", "phi_z"):
+        np.testing.assert_array_equal(free.get(nm), sync.get(nm), err_msg=nm)
+    compare(free_p, sync_p, ("U", "p", "alpha", "uSource") if solver else ("U", "p"), 1e-8)
+    for v in (sync, sync_p, free, free_p):
+        v.close()

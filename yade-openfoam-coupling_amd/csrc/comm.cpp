@@ -1,6 +1,7 @@
 #include "comm.hpp"
 
 #include <algorithm>
+#include <array>
 
 #include <dlfcn.h>
 
@@ -16,12 +17,12 @@
 namespace fy {
 
 namespace {
-__global__ void k_fold_gathered(const double* __restrict__ g, int size, int n, unsigned max_mask, double* __restrict__ out) {
+__global__ void k_fold_gathered(const double* __restrict__ g, int size, int n, int stride, unsigned max_mask, double* __restrict__ out) {
     const int q = threadIdx.x;
     if (q >= n) return;
     const bool mx = (max_mask >> q) & 1u;
     double x = g[q];
-    for (int r = 1; r < size; ++r) { const double y = g[(size_t)r * n + q]; x = mx ? (x > y ? x : y) : x + y; }
+    for (int r = 1; r < size; ++r) { const double y = g[(size_t)r * stride + q]; x = mx ? (x > y ? x : y) : x + y; }
     out[q] = x;
 }
 }  // namespace
@@ -47,7 +48,7 @@ int Comm::allreduce_ops(hipStream_t s, double* dev, int n, unsigned max_mask) {
     n_allreduce += n_allgather - g0; n_allgather = g0;
     auto& bt = by_tag[tag];
     bt[1] += bt[2] - t0; bt[2] = t0;
-    hipLaunchKernelGGL(k_fold_gathered, dim3(1), dim3(32), 0, s, ops_scratch, size, n, max_mask, dev);
+    hipLaunchKernelGGL(k_fold_gathered, dim3(1), dim3(32), 0, s, ops_scratch, size, n, n, max_mask, dev);
     if (hipGetLastError() != hipSuccess) return fail(FY_ERR_HIP, "allreduce_ops: fold launch failed");
     return FY_OK;
 }
@@ -79,17 +80,101 @@ struct LocalShared {
     Barrier bar;
     std::vector<const Comm::Xchg*> lists;
     std::vector<const double*> gather_src;
-    std::vector<std::vector<double> > red;     // per-rank host staging for all-reduce
-    explicit LocalShared(int n_) : n(n_), bar(n_), lists(n_), gather_src(n_), red(n_) {}
+    std::vector<std::vector<double> > red;     // per-rank host staging for all-reduce (host-synchronous mode)
+    // stream-ordered mode (the ranks are NOT serialised by the host, as under RCCL: a dependency the solver's schedule forgets shows as
+    // different bits): every collective is a pair of events per rank -- `ready` (my send buffers are final on my stream) and
+    // `done` (my reads of the others' buffers have been enqueued up to here) -- taken from a ring that is indexed by the rank's own
+    // collective sequence number (all ranks issue the same collectives in the same order).  The host barriers only order the
+    // hipEventRecord / hipStreamWaitEvent CALLS; nothing waits for the GPU.
+    static constexpr int RING = 16;
+    std::vector<std::array<hipEvent_t, RING> > ready, done;
+    std::vector<int> device;
+    double* red_all = nullptr;                 // [n x 32] device slots of the all-reduce, folded in rank order by every rank
+    bool stream_ordered = false;               // FOAMYADE_LOCALCOMM_STREAM=1 (measured: no faster at 2 slabs, slower at 8 -- DESIGN.md 8)
+    std::mutex init_m;
+    explicit LocalShared(int n_) : n(n_), bar(n_), lists(n_), gather_src(n_), red(n_), ready(n_), done(n_), device(n_, -1) {
+        for (auto& r : ready) r.fill(nullptr);
+        for (auto& d : done) d.fill(nullptr);
+        const char* e = std::getenv("FOAMYADE_LOCALCOMM_STREAM");
+        if (e && e[0] == '1') stream_ordered = true;
+    }
+    ~LocalShared() {
+        for (auto& r : ready) for (hipEvent_t e : r) if (e) (void)hipEventDestroy(e);
+        for (auto& d : done) for (hipEvent_t e : d) if (e) (void)hipEventDestroy(e);
+        if (red_all) (void)hipFree(red_all);
+    }
 };
 
 struct LocalComm : Comm {
     std::shared_ptr<LocalShared> sh;
+    uint64_t seq = 0;                                          // collectives issued by this rank so far
+    bool inited = false;
+    int init_rank() {
+        if (inited) return FY_OK;
+        int dev = 0;
+        FY_HIP(hipGetDevice(&dev));
+        for (int q = 0; q < LocalShared::RING; ++q) {
+            FY_HIP(hipEventCreateWithFlags(&sh->ready[rank][q], hipEventDisableTiming));
+            FY_HIP(hipEventCreateWithFlags(&sh->done[rank][q], hipEventDisableTiming));
+        }
+        {
+            std::lock_guard<std::mutex> lk(sh->init_m);
+            sh->device[rank] = dev;
+            if (!sh->red_all) FY_HIP(hipMalloc((void**)&sh->red_all, (size_t)size * 32 * sizeof(double)));
+        }
+        inited = true;
+        sh->bar.wait();                                        // every rank's events exist before anyone waits on one
+        for (int r = 0; r < size; ++r)
+            if (sh->device[r] != dev) sh->stream_ordered = false;      // slabs on different devices: the host-synchronous path
+        sh->bar.wait();
+        return FY_OK;
+    }
+    // open a collective: my buffers are final at this point of my stream
+    int open(hipStream_t s, int& slot) {
+        FY_TRY(init_rank());
+        slot = (int)(seq++ % LocalShared::RING);
+        FY_HIP(hipEventRecord(sh->ready[rank][slot], s));
+        return FY_OK;
+    }
+    // close it: nobody's later work may overwrite a buffer that `lo..hi` are still reading
+    int close(hipStream_t s, int slot, int lo, int hi) {
+        FY_HIP(hipEventRecord(sh->done[rank][slot], s));
+        sh->bar.wait();                                        // every rank has recorded `done`; the posted lists may go
+        for (int r = lo; r <= hi; ++r)
+            if (r != rank && r >= 0 && r < size) FY_HIP(hipStreamWaitEvent(s, sh->done[r][slot], 0));
+        return FY_OK;
+    }
     int exchange_many(hipStream_t s, const Xchg* x, size_t n) override {
         count(0);
         for (size_t q = 0; q < n; ++q) exchange_bytes += sizeof(double) * ((has_up() ? x[q].su() : 0) + (has_down() ? x[q].sd() : 0));
-        FY_HIP(hipStreamSynchronize(s));                       // my planes are final
+        FY_TRY(init_rank());
+        if (!sh->stream_ordered) return exchange_many_sync(s, x, n);
+        int slot = 0;
+        FY_TRY(open(s, slot));
         sh->lists[rank] = x;                                   // every rank posts the same number of items in the same order
+        sh->bar.wait();
+        if (has_down()) FY_HIP(hipStreamWaitEvent(s, sh->ready[rank - 1][slot], 0));
+        if (has_up()) FY_HIP(hipStreamWaitEvent(s, sh->ready[rank + 1][slot], 0));
+        int rc = FY_OK;
+        for (size_t q = 0; q < n && rc == FY_OK; ++q) {
+            if (has_down() && x[q].recv_from_down && x[q].rd()) {
+                if (sh->lists[rank - 1][q].su() != x[q].rd()) rc = FY_ERR_TRANSPORT;
+                else if (hipMemcpyAsync(x[q].recv_from_down, sh->lists[rank - 1][q].send_up, x[q].rd() * sizeof(double), hipMemcpyDeviceToDevice, s) != hipSuccess) rc = FY_ERR_HIP;
+            }
+            if (rc == FY_OK && has_up() && x[q].recv_from_up && x[q].ru()) {
+                if (sh->lists[rank + 1][q].sd() != x[q].ru()) rc = FY_ERR_TRANSPORT;
+                else if (hipMemcpyAsync(x[q].recv_from_up, sh->lists[rank + 1][q].send_down, x[q].ru() * sizeof(double), hipMemcpyDeviceToDevice, s) != hipSuccess) rc = FY_ERR_HIP;
+            }
+        }
+        // (a failing rank still takes part in the closing barrier: the others must not hang on it)
+        const int rc2 = close(s, slot, rank - 1, rank + 1);
+        if (rc == FY_ERR_TRANSPORT) return fail(rc, "neighbour exchange: send/receive sizes differ");
+        if (rc != FY_OK) return fail(rc, "neighbour exchange: device copy failed");
+        return rc2;
+    }
+    int exchange_many_sync(hipStream_t s, const Xchg* x, size_t n) {
+        FY_HIP(hipStreamSynchronize(s));                       // my planes are final
+        sh->lists[rank] = x;
         sh->bar.wait();
         for (size_t q = 0; q < n; ++q) {
             if (has_down() && x[q].recv_from_down && x[q].rd()) {
@@ -107,6 +192,21 @@ struct LocalComm : Comm {
     }
     int allreduce(hipStream_t s, double* dev, int n, bool is_max) override {
         count(1);
+        FY_TRY(init_rank());
+        if (sh->stream_ordered && n <= 32) {
+            // every rank parks its values in its slot of one device array and folds all slots itself, in rank order => identical
+            // bits on every rank (and the bits of the host fold below)
+            FY_HIP(hipMemcpyAsync(sh->red_all + (size_t)rank * 32, dev, n * sizeof(double), hipMemcpyDeviceToDevice, s));
+            int slot = 0;
+            FY_TRY(open(s, slot));
+            sh->bar.wait();
+            for (int r = 0; r < size; ++r)
+                if (r != rank) FY_HIP(hipStreamWaitEvent(s, sh->ready[r][slot], 0));
+            hipLaunchKernelGGL(k_fold_gathered, dim3(1), dim3(32), 0, s, sh->red_all, size, n, 32, is_max ? 0xffffffffu : 0u, dev);
+            const bool bad = hipGetLastError() != hipSuccess;
+            FY_TRY(close(s, slot, 0, size - 1));
+            return bad ? fail(FY_ERR_HIP, "all-reduce: fold launch failed") : FY_OK;
+        }
         std::vector<double>& mine = sh->red[rank];
         mine.resize((size_t)n);
         FY_HIP(hipMemcpyAsync(mine.data(), dev, n * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -122,6 +222,21 @@ struct LocalComm : Comm {
     }
     int allgather(hipStream_t s, const double* send, double* recv, size_t cnt) override {
         count(2);
+        FY_TRY(init_rank());
+        if (sh->stream_ordered) {
+            int slot = 0;
+            FY_TRY(open(s, slot));
+            sh->gather_src[rank] = send;
+            sh->bar.wait();
+            bool bad = false;
+            for (int r = 0; r < size; ++r) {
+                if (r != rank) FY_HIP(hipStreamWaitEvent(s, sh->ready[r][slot], 0));
+                if (recv + (size_t)r * cnt == sh->gather_src[r]) continue;        // gathered in place
+                bad = bad || hipMemcpyAsync(recv + (size_t)r * cnt, sh->gather_src[r], cnt * sizeof(double), hipMemcpyDeviceToDevice, s) != hipSuccess;
+            }
+            FY_TRY(close(s, slot, 0, size - 1));
+            return bad ? fail(FY_ERR_HIP, "all-gather: device copy failed") : FY_OK;
+        }
         FY_HIP(hipStreamSynchronize(s));
         sh->gather_src[rank] = send;
         sh->bar.wait();
