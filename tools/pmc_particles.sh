@@ -1,4 +1,4 @@
-# PMC passes over the particle pipeline only (tools/bench_particles.py); one counter set per pass, csv under gpurun_out/pmcp/
+# PMC passes over the particle pipeline only (tools/bench_particles.py, or PMCP_CMD); one counter set per pass, csv under gpurun_out/pmcp/ (PMCP_NAME)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${PMCP_NAME:-pmcp}; rm -rf $O; mkdir -p $O
 i=0
@@ -12,6 +12,6 @@ for set in "GRBM_GUI_ACTIVE TA_TA_BUSY_sum TD_TD_BUSY_sum TCP_TCP_TA_DATA_STALL_
            "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_VALU SQ_INSTS_SALU" \
            "TCC_HIT_sum TCC_MISS_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum"; do
   i=$((i+1))
-  timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/s$i -- python $R/tools/bench_particles.py --steps 3 > $O/s$i.log 2>&1 || echo "set $i failed"
+  timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/s$i -- ${PMCP_CMD:-python $R/tools/bench_particles.py --steps 3} > $O/s$i.log 2>&1 || echo "set $i failed"
 done
 ls $O

@@ -1,13 +1,14 @@
 #!/usr/bin/env python3
 """Unit-level picture of the particle kernels from tools/pmc_particles.sh's passes (gpurun_out/pmcp/s*/...counter_collection.csv):
 per kernel, averages of every collected counter and a few ratios (TA busy share, VALU share, LDS conflict share, wait share)."""
-import collections, csv, glob, re, sys
+import collections, csv, glob, os, re, sys
 root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmcp"
+KERNELS = tuple(os.environ.get("PMCP_KERNELS", "k_force_gaussian,k_locate_deposit,k_bin_gather,k_pack_cells").split(","))
 data = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(root + "/s*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         m = re.search(r"(k_\w+(?:<\d>)?)", r["Kernel_Name"])
-        if m and re.sub(r"<\d>", "", m.group(1)) in ("k_force_gaussian", "k_locate_deposit", "k_bin_gather", "k_pack_cells"):
+        if m and re.sub(r"<\d>", "", m.group(1)) in KERNELS:
             data[m.group(1)][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in data.items():
     av = {n: sum(v) / len(v) for n, v in d.items()}

@@ -528,6 +528,11 @@ __global__ __launch_bounds__(256) void k_ldu_pre_coupling(LduGeo g, const double
     if (c >= g.nCells) return;
     const D3 uc = ld3(U, c);
     double cv[3] = {0, 0, 0}, lp[3] = {0, 0, 0};
+    // this cell's own tensor once, not once per face (the kernel is bound by the number of lines its gathers touch): the face's interpolate
+    // w T_owner + (1 - w) T_neighbour is the sum of the same two products whichever of the two this cell is, and a sum does not depend on the order of its terms
+    double Tc[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) Tc[q] = vGrad[9 * (size_t)c + q];
     FY_CELL_FACES(g, c, f, nb) {
         const double af = alphaf[f], gm = af * g.magSf[f];
         if (f < g.nInt) {
@@ -537,14 +542,14 @@ __global__ __launch_bounds__(256) void k_ldu_pre_coupling(LduGeo g, const double
             const double fl = o ? phi[f] : -phi[f];
             const double uf[3] = {wc * uc.x + (1.0 - wc) * un.x, wc * uc.y + (1.0 - wc) * un.y, wc * uc.z + (1.0 - wc) * un.z};
             const D3 k = ld3(g.kvec, f);
-            const double* To = vGrad + 9 * (size_t)(o ? c : nb);
-            const double* Tn = vGrad + 9 * (size_t)(o ? nb : c);
+            const double* Tb = vGrad + 9 * (size_t)nb;
+            const double wn = o ? 1.0 - w : w;                              // ... and of the neighbour's
             const double sg = o ? 1.0 : -1.0, du[3] = {un.x - uc.x, un.y - uc.y, un.z - uc.z}, kk[3] = {k.x, k.y, k.z};
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 double cj = 0.0;
 #pragma unroll
-                for (int i = 0; i < 3; ++i) cj += kk[i] * (w * To[3 * i + j] + (1.0 - w) * Tn[3 * i + j]);
+                for (int i = 0; i < 3; ++i) cj += kk[i] * (wc * Tc[3 * i + j] + wn * Tb[3 * i + j]);
                 cv[j] += fl * uf[j];
                 lp[j] += gm * (g.dcNO[f] * du[j] + sg * cj);               // outward normal gradient: the correction vector points owner -> neighbour
             }
