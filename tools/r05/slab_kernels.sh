@@ -1,8 +1,9 @@
 #!/bin/bash
-# kernel time of two virtual slabs against the single domain, kernel by kernel (both include 2 warm-up steps: steps+2 in the divisor)
+# kernel time of two virtual slabs against the single domain, kernel by kernel (both include 2 warm-up steps: steps+2 in the divisor).
+# FOAMYADE_LOCALCOMM_TURNS=1: the slabs take turns between collectives, so every kernel is traced at the duration it has with the GPU to itself
 cd /root/repo; export TMPDIR=/tmp
 KSTATS_TOP=0 bash tools/kstats.sh s1 -- python /root/repo/tools/r05/slab_run.py 1 8
-KSTATS_TOP=0 bash tools/kstats.sh s2 -- python /root/repo/tools/r05/slab_run.py 2 8
+KSTATS_TOP=0 bash tools/kstats.sh s2 FOAMYADE_LOCALCOMM_TURNS=1 -- python /root/repo/tools/r05/slab_run.py 2 8
 grep "ms/step" gpurun_out/ks_s1/run.log gpurun_out/ks_s2/run.log
 python - <<'PY'
 import csv, glob, re

@@ -5,6 +5,7 @@
 
 #include <dlfcn.h>
 
+#include <chrono>
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
@@ -91,12 +92,19 @@ struct LocalShared {
     std::vector<int> device;
     double* red_all = nullptr;                 // [n x 32] device slots of the all-reduce, folded in rank order by every rank
     bool stream_ordered = false;               // FOAMYADE_LOCALCOMM_STREAM=1 (measured: no faster at 2 slabs, slower at 8 -- DESIGN.md 8)
+    // FOAMYADE_LOCALCOMM_TURNS=1 (profiling aid): between two collectives only ONE rank at a time enqueues and runs its work -- a rank takes the turn when it leaves
+    // a collective and gives it up, its device work drained, when it enters the next.  The slabs then do not share the GPU kernel by kernel, so a kernel trace shows
+    // every kernel of a slab at the duration it has with the GPU to itself (tools/r05/slab_kernels.sh); the wall time means nothing in this mode.
+    bool turns = false;
+    std::timed_mutex turn_m;
     std::mutex init_m;
     explicit LocalShared(int n_) : n(n_), bar(n_), lists(n_), gather_src(n_), red(n_), ready(n_), done(n_), device(n_, -1) {
         for (auto& r : ready) r.fill(nullptr);
         for (auto& d : done) d.fill(nullptr);
         const char* e = std::getenv("FOAMYADE_LOCALCOMM_STREAM");
         if (e && e[0] == '1') stream_ordered = true;
+        const char* t = std::getenv("FOAMYADE_LOCALCOMM_TURNS");
+        if (t && t[0] == '1') { turns = true; stream_ordered = false; }
     }
     ~LocalShared() {
         for (auto& r : ready) for (hipEvent_t e : r) if (e) (void)hipEventDestroy(e);
@@ -108,7 +116,22 @@ struct LocalShared {
 struct LocalComm : Comm {
     std::shared_ptr<LocalShared> sh;
     uint64_t seq = 0;                                          // collectives issued by this rank so far
-    bool inited = false;
+    bool inited = false, my_turn = false;
+    struct Turn {                                              // scoped: give the turn up on entry (device drained), take it again on exit
+        LocalComm* c;
+        explicit Turn(LocalComm* c_) : c(c_) {
+            if (!c->sh->turns) return;
+            (void)hipDeviceSynchronize();
+            if (c->my_turn) { c->my_turn = false; c->sh->turn_m.unlock(); }
+        }
+        ~Turn() {
+            if (!c->sh->turns) return;
+            (void)hipDeviceSynchronize();                      // (the collective's own copies)
+            // (bounded wait: the rank that holds the turn when its step ends only gives it up in the next step's first collective)
+            c->my_turn = c->sh->turn_m.try_lock_for(std::chrono::milliseconds(100));
+        }
+    };
+    ~LocalComm() override { if (my_turn) { my_turn = false; sh->turn_m.unlock(); } }
     int init_rank() {
         if (inited) return FY_OK;
         int dev = 0;
@@ -173,6 +196,7 @@ struct LocalComm : Comm {
         return rc2;
     }
     int exchange_many_sync(hipStream_t s, const Xchg* x, size_t n) {
+        Turn turn(this);
         FY_HIP(hipStreamSynchronize(s));                       // my planes are final
         sh->lists[rank] = x;
         sh->bar.wait();
@@ -207,6 +231,7 @@ struct LocalComm : Comm {
             FY_TRY(close(s, slot, 0, size - 1));
             return bad ? fail(FY_ERR_HIP, "all-reduce: fold launch failed") : FY_OK;
         }
+        Turn turn(this);
         std::vector<double>& mine = sh->red[rank];
         mine.resize((size_t)n);
         FY_HIP(hipMemcpyAsync(mine.data(), dev, n * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -237,6 +262,7 @@ struct LocalComm : Comm {
             FY_TRY(close(s, slot, 0, size - 1));
             return bad ? fail(FY_ERR_HIP, "all-gather: device copy failed") : FY_OK;
         }
+        Turn turn(this);
         FY_HIP(hipStreamSynchronize(s));
         sh->gather_src[rank] = send;
         sh->bar.wait();
@@ -247,6 +273,7 @@ struct LocalComm : Comm {
         return FY_OK;
     }
     int barrier(hipStream_t s) override {
+        Turn turn(this);
         FY_HIP(hipStreamSynchronize(s));
         sh->bar.wait();
         return FY_OK;
