@@ -720,3 +720,36 @@ def test_fused_corrector_sweeps_equal_the_separate_ones(product, solver, switch,
     for nm in ("U", "p", "phi_x", "phi_y", "phi_z", "force"):
         sc = np.abs(a[nm]).max() + 1e-300
         assert np.abs(a[nm] - b[nm]).max() <= 1e-11 * sc, (nm, np.abs(a[nm] - b[nm]).max() / sc)
+
+
+@pytest.mark.parametrize("solver", [0, 1])
+@pytest.mark.parametrize("n_slabs", [1, 3])
+def test_two_cells_per_thread_sweeps_equal_the_one_cell_ones(product, solver, n_slabs, monkeypatch):
+    """round 5: the pressure solver's scalar-field sweeps (Laplacian apply with its dot products, the multigrid smoothers, residual + restriction, the PCG
+    vector update) run with two consecutive cells per thread and 16-byte loads wherever the level's rows are even; FOAMYADE_NO_PAIRS=1 brings the
+    one-cell kernels back.  The rows are evaluated with the same operations in the same order and the block partials are folded in the same order, so a
+    fluid-only run (nothing summed in an order that changes from run to run) gives the same BITS and the same iteration counts -- on one domain and on
+    three virtual slabs (the communication-avoiding V-cycle's plane windows)."""
+    n, nz = 16, 36
+    kw = dict(g=(0, 0, -9.81), p_bc=[2] * 6) if solver == 1 else cavity_bcs()
+    nu = 1e-5 if solver == 1 else 0.01
+    out = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("FOAMYADE_NO_PAIRS", "1")
+        pc = product.make_case(solver, n, n, nz, 0.1 / n, 2e-4, nu, g=kw.get("g", (0, 0, 0)), u_bc=kw.get("u_bc"), u_val=kw.get("u_val"), p_bc=kw.get("p_bc"), p_solver=1)
+        s = product.Solver(pc) if n_slabs == 1 else product.VirtualSlabs(pc, n_slabs)
+        s.set("U", np.random.RandomState(5).rand(n * n * nz, 3) * 0.05)
+        its = []
+        for step in range(4):
+            s.step()
+            st = s.stats() if n_slabs == 1 else s.stats()[0]
+            its.append(st["p_iters_total"])
+        out.append(({nm: s.get(nm) for nm in ("U", "p", "phi_x", "phi_y", "phi_z")}, its))
+        s.close()
+    monkeypatch.delenv("FOAMYADE_NO_PAIRS")
+    product.Solver(product.make_case(0, 8, 8, 8, 0.1, 1e-3, 0.01, p_solver=1, **cavity_bcs())).close()      # (re-reads the switch for the tests that follow)
+    (a, its_a), (b, its_b) = out
+    assert its_a == its_b and sum(its_a) > 0, (its_a, its_b)
+    for nm in a:
+        np.testing.assert_array_equal(a[nm], b[nm], err_msg=nm)

@@ -27,12 +27,15 @@ struct Options {
     bool no_fused_corrector;     // FOAMYADE_NO_FUSED_CORRECTOR=1  the corrector as five sweeps (rounds 1 - 4) instead of the two fused ones (A/B switch, identical results)
     int strip_blocks;            // FOAMYADE_STRIP_BLOCKS=n       blocks per strip of the FV cell sweeps (0: off; unset: ~8 rows of cells)
     bool faces_from_arrays;      // FOAMYADE_FACES_FROM_ARRAYS=1   the fused sweeps stream rAUf / alphacf from their face arrays instead of re-forming them from rAU / alpha
+    bool no_pairs;               // FOAMYADE_NO_PAIRS=1          pressure solver: one cell per thread in every sweep (fv_kernels.hip "two cells per thread"; identical results)
 };
 Options options();
 
 // thread-local last-error text behind fy_last_error()
 std::string& last_error();
 int fail(int code, const char* fmt, ...);
+// FOAMYADE_NO_PAIRS=1: the pressure solver's one-cell-per-thread kernels everywhere (A/B switch of the two-cell kernels, same bits); read when options() is
+bool pairs_disabled();
 
 #define FY_HIP(expr)                                                                                      \
     do {                                                                                                  \

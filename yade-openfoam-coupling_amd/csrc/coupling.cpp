@@ -14,7 +14,16 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <atomic>
+
 namespace fy {
+
+static std::atomic<int> g_no_pairs{-1};
+bool pairs_disabled() {
+    int v = g_no_pairs.load(std::memory_order_relaxed);
+    if (v < 0) { const char* e = getenv("FOAMYADE_NO_PAIRS"); v = (e != nullptr && *e != 0 && strcmp(e, "0") != 0) ? 1 : 0; g_no_pairs.store(v, std::memory_order_relaxed); }
+    return v != 0;
+}
 
 Options options() {
     auto on = [](const char* nm) { const char* e = getenv(nm); return e != nullptr && *e != 0 && strcmp(e, "0") != 0; };
@@ -31,6 +40,8 @@ Options options() {
     q.no_deep_vcycle = on("FOAMYADE_NO_DEEP_VCYCLE");
     q.no_fused_corrector = on("FOAMYADE_NO_FUSED_CORRECTOR");
     q.faces_from_arrays = on("FOAMYADE_FACES_FROM_ARRAYS");
+    q.no_pairs = on("FOAMYADE_NO_PAIRS");
+    g_no_pairs.store(q.no_pairs ? 1 : 0, std::memory_order_relaxed);
     q.strip_blocks = -1;
     if (const char* e = getenv("FOAMYADE_STRIP_BLOCKS")) q.strip_blocks = atoi(e);
     return q;

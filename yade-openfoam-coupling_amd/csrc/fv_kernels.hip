@@ -2027,6 +2027,224 @@ __global__ __launch_bounds__(256) void k_mg_residual_restrict_tiled(PMat A, cons
     }
 }
 
+// ------------------------------------------------------------------------------------------------ two cells per thread (round 5)
+// The scalar-field sweeps of the pressure solver with TWO consecutive cells per thread: every coefficient and field value of the pair and of its
+// y / z neighbours comes as one 16-byte load (the x-neighbours of the pair's ends as 8-byte ones), half the load instructions for the same bytes.
+// tools/micro/lap_pairs.hip: the Laplacian apply 365 -> 323 us at 320^3 (4.3 -> 4.9 TB/s), 29.4 -> 27.0 us at 160^3, 3.6 -> 2.9 us at 64^3; four cells
+// per thread lose (lanes 32 bytes apart).  Needs an even row length, even c0 / N / ntot and 16-byte aligned arrays (pairs_ok); the rows are p_row's
+// operations in p_row's order and the block partials are folded in the one-cell kernels' order: the same bits, by construction and by test.
+__device__ __forceinline__ double2 ld2(const double* p) { return *reinterpret_cast<const double2*>(p); }
+__device__ __forceinline__ void st2(double* p, double a, double b) { *reinterpret_cast<double2*>(p) = make_double2(a, b); }
+struct PairIdx { int c, ym, yp, zm, zp, xm, xp; };
+__device__ __forceinline__ PairIdx pair_idx(const PMat& A, int c) {
+    const int sy = A.nx, sz = A.nx * A.ny, last = A.ntot - 1;
+    // (a clamped index is that of a deselected term, or pairs with a zero coefficient -- as in p_row; the pair loads stay inside the array and aligned)
+    return PairIdx{c, max(c - sy, 0), min(c + sy, last - 1), max(c - sz, 0), min(c + sz, last - 1), max(c - 1, 0), min(c + 2, last)};
+}
+struct P2 { double2 c, ym, yp, zm, zp; double xm, xp; };            // a field at the pair, at its y / z neighbour pairs and at the cells left and right of it
+__device__ __forceinline__ P2 ld_p2(const double* __restrict__ f, const PairIdx& q) {
+    return P2{ld2(f + q.c), ld2(f + q.ym), ld2(f + q.yp), ld2(f + q.zm), ld2(f + q.zp), f[q.xm], f[q.xp]};
+}
+struct C2 { double2 dg, ux, uy, uz, uym, uzm; double uxm; };
+__device__ __forceinline__ C2 ld_c2(const PMat& A, const PairIdx& q) {
+    return C2{ld2(A.diag + q.c), ld2(A.ux + q.c), ld2(A.uy + q.c), ld2(A.uz + q.c), ld2(A.uy + q.ym), ld2(A.uz + q.zm), A.ux[q.xm]};
+}
+// rows c and c + 1 of A applied to the field whose values are X
+__device__ __forceinline__ double2 pair_rows(const PMat& A, const C2& K, const P2& X, int c) {
+    const int sy = A.nx, sz = A.nx * A.ny, d = c + 1;
+    double a = K.dg.x * X.c.x;
+    a = (c >= 1) ? a - K.uxm * X.xm : a;
+    a = (c + 1 < A.ntot) ? a - K.ux.x * X.c.y : a;
+    a = (c >= sy) ? a - K.uym.x * X.ym.x : a;
+    a = (c + sy < A.ntot) ? a - K.uy.x * X.yp.x : a;
+    a = (c >= sz) ? a - K.uzm.x * X.zm.x : a;
+    a = (c + sz < A.ntot) ? a - K.uz.x * X.zp.x : a;
+    double b = K.dg.y * X.c.y;
+    b = b - K.ux.x * X.c.x;                                           // (d >= 1 always)
+    b = (d + 1 < A.ntot) ? b - K.ux.y * X.xp : b;
+    b = (d >= sy) ? b - K.uym.y * X.ym.y : b;
+    b = (d + sy < A.ntot) ? b - K.uy.y * X.yp.y : b;
+    b = (d >= sz) ? b - K.uzm.y * X.zm.y : b;
+    b = (d + sz < A.ntot) ? b - K.uz.y * X.zp.y : b;
+    return make_double2(a, b);
+}
+// 128 threads x 2 cells = one 256-cell block of the one-cell kernels; the partial is folded in THEIR order: a wave of theirs is a half-wave here (lane l of it =
+// lane l / 2, component l & 1), their shuffle offsets 32 .. 2 are lane offsets 16 .. 1 per component, their offset 1 is x + y in the half-wave's first lane
+template <int N>
+__device__ __forceinline__ void block_reduce_store_pairs(double2 (&v)[N], const int (&is_max)[N], double* partials, int lb = -1, int stride = 0) {
+    if (lb < 0) lb = (int)blockIdx.x;
+    if (stride <= 0) stride = (int)gridDim.x;
+    __shared__ double sh[4][N];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+        double x = v[q].x, y = v[q].y;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) {
+            const double x2 = __shfl_down(x, o, 64), y2 = __shfl_down(y, o, 64);
+            x = is_max[q] ? fmax(x, x2) : x + x2;
+            y = is_max[q] ? fmax(y, y2) : y + y2;
+        }
+        if ((lane & 31) == 0) sh[2 * wv + (lane >> 5)][q] = is_max[q] ? fmax(x, y) : x + y;
+    }
+    __syncthreads();
+    if (threadIdx.x < N) {
+        const int q = threadIdx.x;
+        double x = sh[0][q];
+        for (int w = 1; w < 4; ++w) x = is_max[q] ? fmax(x, sh[w][q]) : x + sh[w][q];
+        partials[(size_t)q * stride + lb] = x;
+    }
+}
+// reducing pair kernels: 128 threads, the logical 256-cell block of FY_RED_LOOP; plain ones: 256 threads, 512 cells per block
+#define FY_RED_LOOP2(t, n) const int t = swz_block(blockIdx.x, gridDim.x) * 256 + 2 * (int)threadIdx.x; if (t < (n))
+#define FY_PAIR_LOOP(t, n) const int t = swz_block(blockIdx.x, gridDim.x) * 512 + 2 * (int)threadIdx.x; if (t < (n))
+
+__global__ __launch_bounds__(256) void k_p_apply2(PMat A, const double* __restrict__ x, double* __restrict__ y) {
+    FY_PAIR_LOOP(t, A.N) {
+        const int c = t + A.c0;
+        const PairIdx q = pair_idx(A, c);
+        const double2 a = pair_rows(A, ld_c2(A, q), ld_p2(x, q), c);
+        st2(y + c, a.x, a.y);
+    }
+}
+template <bool WITH_R>
+__global__ __launch_bounds__(128) void k_p_apply_dot2(PMat A, const double* __restrict__ x, const double* __restrict__ r, double* __restrict__ y, double* __restrict__ partials) {
+    double2 v[2] = {make_double2(0, 0), make_double2(0, 0)};
+    FY_RED_LOOP2(t, A.N) {
+        const int c = t + A.c0;
+        const PairIdx q = pair_idx(A, c);
+        const P2 X = ld_p2(x, q);
+        const double2 a = pair_rows(A, ld_c2(A, q), X, c);
+        st2(y + c, a.x, a.y);
+        if (WITH_R) { const double2 rc = ld2(r + c); v[0] = make_double2(X.c.x * rc.x, X.c.y * rc.y); }
+        v[1] = make_double2(a.x * X.c.x, a.y * X.c.y);
+    }
+    if (WITH_R) {
+        const int mx[2] = {0, 0};
+        block_reduce_store_pairs<2>(v, mx, partials);
+    } else {
+        double2 v1[1] = {v[1]};
+        const int mx[1] = {0};
+        block_reduce_store_pairs<1>(v1, mx, partials + gridDim.x);
+    }
+}
+template <bool FIRST>
+__global__ __launch_bounds__(128) void k_pcg_cg_update2(int n, int c0, const double* __restrict__ u, const double* __restrict__ w, double* __restrict__ p,
+                                                        double* __restrict__ sv, double* __restrict__ x, double* __restrict__ r, double* __restrict__ sc, int it,
+                                                        double* __restrict__ partials) {
+    double2 v[2] = {make_double2(0, 0), make_double2(0, 0)};
+    const double gamma = sc[0], delta = sc[1];
+    double beta = 0.0, al = gamma / delta;
+    if (!FIRST) {
+        const double gold = sc[2 + 2 * (it & 1)], aold = sc[3 + 2 * (it & 1)];
+        beta = gamma / gold;
+        al = gamma / (delta - beta * gamma / aold);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { sc[2 + 2 * ((it + 1) & 1)] = gamma; sc[3 + 2 * ((it + 1) & 1)] = al; }
+    FY_RED_LOOP2(t, n) {
+        const int c = t + c0;
+        double2 pn = ld2(u + c), sn = ld2(w + c);
+        if (!FIRST) {
+            const double2 po = ld2(p + c), so = ld2(sv + c);
+            pn = make_double2(pn.x + beta * po.x, pn.y + beta * po.y); sn = make_double2(sn.x + beta * so.x, sn.y + beta * so.y);
+            st2(p + c, pn.x, pn.y); st2(sv + c, sn.x, sn.y);
+        }
+        const double2 xo = ld2(x + c), ro = ld2(r + c);
+        const double xa = xo.x + al * pn.x, xb = xo.y + al * pn.y;
+        st2(x + c, xa, xb);
+        const double ra = ro.x - al * sn.x, rb = ro.y - al * sn.y;
+        st2(r + c, ra, rb);
+        v[0] = make_double2(fabs(ra), fabs(rb));
+        v[1] = make_double2(xa, xb);
+    }
+    const int mx[2] = {0, 0};
+    block_reduce_store_pairs<2>(v, mx, partials);
+}
+__global__ __launch_bounds__(256) void k_mg_smooth_two_from_zero2(PMat A, const double* __restrict__ b, double* __restrict__ xn, double w, double w2) {
+    const int t = (int)blockIdx.x * 512 + 2 * (int)threadIdx.x;
+    if (t >= A.N) return;
+    const int c = t + A.c0;
+    const PairIdx q = pair_idx(A, c);
+    const P2 B = ld_p2(b, q), D = ld_p2(A.diag, q);
+    C2 K = ld_c2(A, q);
+    K.dg = D.c;
+    // the first iterate x1 = w b / diag at the pair and at every neighbour, formed inline as by the one-cell kernel
+    P2 X1;
+    X1.c = make_double2(w * B.c.x / D.c.x, w * B.c.y / D.c.y);
+    X1.ym = make_double2(w * B.ym.x / D.ym.x, w * B.ym.y / D.ym.y); X1.yp = make_double2(w * B.yp.x / D.yp.x, w * B.yp.y / D.yp.y);
+    X1.zm = make_double2(w * B.zm.x / D.zm.x, w * B.zm.y / D.zm.y); X1.zp = make_double2(w * B.zp.x / D.zp.x, w * B.zp.y / D.zp.y);
+    X1.xm = w * B.xm / D.xm; X1.xp = w * B.xp / D.xp;
+    const double2 a = pair_rows(A, K, X1, c);
+    st2(xn + c, X1.c.x + w2 * (B.c.x - a.x) / D.c.x, X1.c.y + w2 * (B.c.y - a.y) / D.c.y);
+}
+__global__ __launch_bounds__(128) void k_mg_smooth_dot2(PMat A, const double* __restrict__ b, const double* __restrict__ x, double* __restrict__ xn, double w,
+                                                        double* __restrict__ partials) {
+    double2 v[1] = {make_double2(0, 0)};
+    FY_RED_LOOP2(t, A.N) {
+        const int c = t + A.c0;
+        const PairIdx q = pair_idx(A, c);
+        const C2 K = ld_c2(A, q);
+        const P2 X = ld_p2(x, q);
+        const double2 bc = ld2(b + c), a = pair_rows(A, K, X, c);
+        const double za = X.c.x + w * (bc.x - a.x) / K.dg.x, zb = X.c.y + w * (bc.y - a.y) / K.dg.y;
+        st2(xn + c, za, zb);
+        v[0] = make_double2(za * bc.x, zb * bc.y);
+    }
+    const int mx[1] = {0};
+    block_reduce_store_pairs<1>(v, mx, partials);
+}
+__global__ __launch_bounds__(256) void k_mg_smooth2(PMat A, const double* __restrict__ b, const double* __restrict__ x, double* __restrict__ xn, double w) {
+    FY_PAIR_LOOP(t, A.N) {
+        const int c = t + A.c0;
+        const PairIdx q = pair_idx(A, c);
+        const C2 K = ld_c2(A, q);
+        const P2 X = ld_p2(x, q);
+        const double2 bc = ld2(b + c), a = pair_rows(A, K, X, c);
+        st2(xn + c, X.c.x + w * (bc.x - a.x) / K.dg.x, X.c.y + w * (bc.y - a.y) / K.dg.y);
+    }
+}
+// k_mg_smooth_prolong for a pair: the two cells share their parent and the parents of their y / z neighbours
+__global__ __launch_bounds__(256) void k_mg_smooth_prolong2(PMat A, const double* __restrict__ b, const double* __restrict__ x, PMat C,
+                                                            const double* __restrict__ xc, double* __restrict__ xn, double w) {
+    FY_PAIR_LOOP(c, A.N) {
+        const int i = c % A.nx, qq = c / A.nx, j = qq % A.ny, k = qq / A.ny;
+        const int I = i >> 1, J = j >> 1, Kk = k >> 1;
+        const int Im = max(i - 1, 0) >> 1, Ip = min(i + 2, A.nx - 1) >> 1, Jm = max(j - 1, 0) >> 1, Jp = min(j + 1, A.ny - 1) >> 1,
+                  Km = max(k - 1, 0) >> 1, Kp = min(k + 1, A.nz - 1) >> 1;
+        const double* e = xc + C.c0;
+        const int rowc = C.nx * (J + C.ny * Kk);
+        const PairIdx q = pair_idx(A, c);
+        const C2 K = ld_c2(A, q);
+        P2 V = ld_p2(x, q);
+        const double ec = e[I + rowc], eym = e[I + C.nx * (Jm + C.ny * Kk)], eyp = e[I + C.nx * (Jp + C.ny * Kk)],
+                     ezm = e[I + C.nx * (J + C.ny * Km)], ezp = e[I + C.nx * (J + C.ny * Kp)];
+        V.c.x += ec; V.c.y += ec; V.ym.x += eym; V.ym.y += eym; V.yp.x += eyp; V.yp.y += eyp; V.zm.x += ezm; V.zm.y += ezm; V.zp.x += ezp; V.zp.y += ezp;
+        V.xm += e[Im + rowc]; V.xp += e[Ip + rowc];
+        const double2 bc = ld2(b + c), a = pair_rows(A, K, V, c);
+        st2(xn + c, V.c.x + w * (bc.x - a.x) / K.dg.x, V.c.y + w * (bc.y - a.y) / K.dg.y);
+    }
+}
+// k_mg_residual_restrict_tiled with a pair per lane: a block covers 128 x 2 x 2 fine cells, a lane's two residuals are the first sum of its coarse cell's fold
+__global__ __launch_bounds__(256) void k_mg_residual_restrict_tiled2(PMat A, const double* __restrict__ b, const double* __restrict__ x, PMat C,
+                                                                     double* __restrict__ bc) {
+    __shared__ double r[2][2][64];
+    const int tx = threadIdx.x & 63, ty = (threadIdx.x >> 6) & 1, tz = threadIdx.x >> 7;
+    const int i = blockIdx.x * 128 + 2 * tx, j = blockIdx.y * 2 + ty, k = blockIdx.z * 2 + tz;
+    double v = 0.0;
+    if (i < A.nx && j < A.ny && k < A.nz) {
+        const int c = A.c0 + i + A.nx * (j + A.ny * k);
+        const PairIdx q = pair_idx(A, c);
+        const double2 bb = ld2(b + c), a = pair_rows(A, ld_c2(A, q), ld_p2(x, q), c);
+        v = (bb.x - a.x) + (bb.y - a.y);
+    }
+    r[tz][ty][tx] = v;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int I = blockIdx.x * 64 + (int)threadIdx.x, J = blockIdx.y, K = blockIdx.z;
+        if (I < C.nx) bc[C.c0 + I + C.nx * (J + C.ny * K)] = (r[0][0][tx] + r[0][1][tx]) + (r[1][0][tx] + r[1][1][tx]);
+    }
+}
+
 // The tail of the V-cycle -- every level with <= kMgTailCells cells (20^3 and below at 160^3) -- inside ONE 1024-thread workgroup:
 // pre-smoothing, restriction, coarsest solve, prolongation and post-smoothing of up to kMgTailMax levels separated by
 // __syncthreads() instead of kernel boundaries.  Those levels are launch/latency bound (4-15 us per launch for microseconds of
@@ -2536,14 +2754,32 @@ int launch_corr_front(hipStream_t s, FvGeo g, const double* HbyA, const double* 
     return FY_OK;
 }
 
+// two cells per thread where the level allows it (see "two cells per thread" above); FOAMYADE_NO_PAIRS=1: the one-cell kernels everywhere (A/B switch, same bits)
+static bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+static bool pairs_ok(const PMat& A) {
+    return !pairs_disabled() && A.N >= 2 && A.nx % 2 == 0 && A.c0 % 2 == 0 && A.N % 2 == 0 && A.ntot % 2 == 0 && al16(A.diag) && al16(A.ux) && al16(A.uy) && al16(A.uz);
+}
+static bool pairs_ok(int n, int c0) {
+    return !pairs_disabled() && n >= 2 && n % 2 == 0 && c0 % 2 == 0;
+}
+
 int launch_p_apply(hipStream_t s, PMat A, const double* x, double* y) {
+    if (pairs_ok(A) && al16(x) && al16(y)) {
+        hipLaunchKernelGGL(k_p_apply2, dim3(div_up(A.N, 512)), dim3(256), 0, s, A, x, y);
+        FY_LAUNCH_CHECK();
+        return FY_OK;
+    }
     hipLaunchKernelGGL(k_p_apply, dim3(div_up(A.N, 256)), dim3(256), 0, s, A, x, y);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }
 
 int launch_p_apply_dot(hipStream_t s, PMat A, const double* x, const double* r, double* y, double* partials) {
-    if (r) hipLaunchKernelGGL(k_p_apply_dot<true>, dim3(red_blocks(A.N)), dim3(256), 0, s, A, x, r, y, partials);
+    if (pairs_ok(A) && al16(x) && al16(y) && al16(r)) {
+        if (r) hipLaunchKernelGGL(k_p_apply_dot2<true>, dim3(red_blocks(A.N)), dim3(128), 0, s, A, x, r, y, partials);
+        else hipLaunchKernelGGL(k_p_apply_dot2<false>, dim3(red_blocks(A.N)), dim3(128), 0, s, A, x, r, y, partials);
+    }
+    else if (r) hipLaunchKernelGGL(k_p_apply_dot<true>, dim3(red_blocks(A.N)), dim3(256), 0, s, A, x, r, y, partials);
     else hipLaunchKernelGGL(k_p_apply_dot<false>, dim3(red_blocks(A.N)), dim3(256), 0, s, A, x, r, y, partials);
     FY_LAUNCH_CHECK();
     return FY_OK;
@@ -2562,7 +2798,11 @@ int launch_dot(hipStream_t s, int n, int c0, const double* a, const double* b, d
 }
 
 int launch_pcg_cg_update(hipStream_t s, int n, int c0, const double* u, const double* w, double* p, double* sv, double* x, double* r, double* sc, int it, double* partials) {
-    if (it == 0) hipLaunchKernelGGL(k_pcg_cg_update<true>, dim3(red_blocks(n)), dim3(256), 0, s, n, c0, u, w, p, sv, x, r, sc, it, partials);
+    if (pairs_ok(n, c0) && al16(u) && al16(w) && al16(p) && al16(sv) && al16(x) && al16(r)) {
+        if (it == 0) hipLaunchKernelGGL(k_pcg_cg_update2<true>, dim3(red_blocks(n)), dim3(128), 0, s, n, c0, u, w, p, sv, x, r, sc, it, partials);
+        else hipLaunchKernelGGL(k_pcg_cg_update2<false>, dim3(red_blocks(n)), dim3(128), 0, s, n, c0, u, w, p, sv, x, r, sc, it, partials);
+    }
+    else if (it == 0) hipLaunchKernelGGL(k_pcg_cg_update<true>, dim3(red_blocks(n)), dim3(256), 0, s, n, c0, u, w, p, sv, x, r, sc, it, partials);
     else hipLaunchKernelGGL(k_pcg_cg_update<false>, dim3(red_blocks(n)), dim3(256), 0, s, n, c0, u, w, p, sv, x, r, sc, it, partials);
     FY_LAUNCH_CHECK();
     return FY_OK;
@@ -2593,19 +2833,22 @@ int launch_mg_smooth_first(hipStream_t s, PMat A, const double* b, double* x, do
 }
 
 int launch_mg_smooth_two_from_zero(hipStream_t s, PMat A, const double* b, double* xn, double w, double w2) {
-    hipLaunchKernelGGL(k_mg_smooth_two_from_zero, dim3(div_up(A.N, 256)), dim3(256), 0, s, A, b, xn, w, w2);
+    if (pairs_ok(A) && al16(b) && al16(xn)) hipLaunchKernelGGL(k_mg_smooth_two_from_zero2, dim3(div_up(A.N, 512)), dim3(256), 0, s, A, b, xn, w, w2);
+    else hipLaunchKernelGGL(k_mg_smooth_two_from_zero, dim3(div_up(A.N, 256)), dim3(256), 0, s, A, b, xn, w, w2);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }
 
 int launch_mg_smooth_dot(hipStream_t s, PMat A, const double* b, const double* x, double* xn, double w, double* partials) {
-    hipLaunchKernelGGL(k_mg_smooth_dot, dim3(red_blocks(A.N)), dim3(256), 0, s, A, b, x, xn, w, partials);
+    if (pairs_ok(A) && al16(b) && al16(x) && al16(xn)) hipLaunchKernelGGL(k_mg_smooth_dot2, dim3(red_blocks(A.N)), dim3(128), 0, s, A, b, x, xn, w, partials);
+    else hipLaunchKernelGGL(k_mg_smooth_dot, dim3(red_blocks(A.N)), dim3(256), 0, s, A, b, x, xn, w, partials);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }
 
 int launch_mg_smooth(hipStream_t s, PMat A, const double* b, const double* x, double* xn, double w) {
-    hipLaunchKernelGGL(k_mg_smooth, dim3(div_up(A.N, 256)), dim3(256), 0, s, A, b, x, xn, w);
+    if (pairs_ok(A) && al16(b) && al16(x) && al16(xn)) hipLaunchKernelGGL(k_mg_smooth2, dim3(div_up(A.N, 512)), dim3(256), 0, s, A, b, x, xn, w);
+    else hipLaunchKernelGGL(k_mg_smooth, dim3(div_up(A.N, 256)), dim3(256), 0, s, A, b, x, xn, w);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }
@@ -2656,7 +2899,8 @@ int launch_mg_tail(hipStream_t s, const PMat* A, double* const* x0, double* cons
 
 int launch_mg_residual_restrict(hipStream_t s, PMat A, const double* b, const double* x, PMat C, double* bc) {
     if (C.N > 8192 && C.ny * 2 >= A.ny && C.nz * 2 >= A.nz) {       // big level: coalesced tile kernel (grid.y/z = coarse rows/planes)
-        hipLaunchKernelGGL(k_mg_residual_restrict_tiled, dim3(div_up(A.nx, 64), C.ny, C.nz), dim3(256), 0, s, A, b, x, C, bc);
+        if (pairs_ok(A) && al16(b) && al16(x)) hipLaunchKernelGGL(k_mg_residual_restrict_tiled2, dim3(div_up(A.nx, 128), C.ny, C.nz), dim3(256), 0, s, A, b, x, C, bc);
+        else hipLaunchKernelGGL(k_mg_residual_restrict_tiled, dim3(div_up(A.nx, 64), C.ny, C.nz), dim3(256), 0, s, A, b, x, C, bc);
         FY_LAUNCH_CHECK();
         return FY_OK;
     }
@@ -2667,7 +2911,8 @@ int launch_mg_residual_restrict(hipStream_t s, PMat A, const double* b, const do
 
 int launch_mg_smooth_prolong(hipStream_t s, PMat A, const double* b, const double* x, PMat C, const double* xc, double* xn, double w) {
     if (A.c0 != 0 || A.ntot != A.N) return fail(FY_ERR_INVALID, "k_mg_smooth_prolong works on levels without ghost planes");
-    hipLaunchKernelGGL(k_mg_smooth_prolong, dim3(div_up(A.N, 256)), dim3(256), 0, s, A, b, x, C, xc, xn, w);
+    if (pairs_ok(A) && al16(b) && al16(x) && al16(xn)) hipLaunchKernelGGL(k_mg_smooth_prolong2, dim3(div_up(A.N, 512)), dim3(256), 0, s, A, b, x, C, xc, xn, w);
+    else hipLaunchKernelGGL(k_mg_smooth_prolong, dim3(div_up(A.N, 256)), dim3(256), 0, s, A, b, x, C, xc, xn, w);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }
