@@ -6,7 +6,7 @@ R=$GRAFT_REPO_ROOT
 RND=${RND:-r03}
 O=$R/gpurun_out/$RND
 rm -rf $O; mkdir -p $O
-python $R/bench.py --steps 20 --warmup 5 > $O/bench_line.json 2> $O/bench.err
+python $R/bench.py > $O/bench_line.json 2> $O/bench.err
 tail -c 300 $O/bench_line.json
 python $R/bench.py --config c2 --wire 0 > $O/bench_line_c2.json 2> $O/bench_c2.err
 python $R/bench.py --config c5 --steps 5 --warmup 2 --pmc 1 --wire 0 > $O/bench_line_c5.json 2> $O/bench_c5.err

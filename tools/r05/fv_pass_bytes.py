@@ -33,7 +33,10 @@ reg("k_U_correct<true>", 136, "F5 corrector")
 reg("k_p_init", 56, "F6 pEqn solve")
 for nm in ("k_mg_ref_term", "k_mg_coarsen", "k_mg_coarse_factor", "k_mg_smooth_two_from_zero", "k_mg_residual_restrict_tiled", "k_mg_residual_restrict",
            "k_mg_tail", "k_mg_smooth_prolong", "k_mg_smooth", "k_mg_smooth_dot", "k_p_apply_dot<false>", "k_p_apply_dot<true>",
-           "k_pcg_cg_update<true>", "k_pcg_cg_update<false>"):
+           "k_pcg_cg_update<true>", "k_pcg_cg_update<false>",
+           # (the two-cells-per-thread forms of the same sweeps)
+           "k_mg_smooth_two_from_zero2", "k_mg_residual_restrict_tiled2", "k_mg_smooth_prolong2", "k_mg_smooth2", "k_mg_smooth_dot2", "k_p_apply_dot2<false>",
+           "k_p_apply_dot2<true>", "k_pcg_cg_update2<true>", "k_pcg_cg_update2<false>", "k_p_apply2"):
     reg(nm, None, "F6 pEqn solve")
 reg("k_reduce_finalize", None, "reductions")
 reg("__amd_rocclr_fillBufferAligned", None, "fills")
