@@ -100,6 +100,49 @@ __global__ __launch_bounds__(256) void k_H_lds(Geo g, const double* __restrict__
     for (int r2 = 0; r2 < 3; ++r2) { const int e = r2 * 64 + lane; if (e < tot) p[e] = l[e]; }
 }
 
+// (d) AoS, TWO consecutive cells per thread: a pair of vec3 records is 48 contiguous, 16-byte aligned bytes = three 16-byte loads that a wave issues fully coalesced;
+// the scalar coefficient arrays come as one 16-byte load per pair
+struct V2 { double a[3], b[3]; };
+__device__ __forceinline__ V2 ldv2(const double* __restrict__ F, int c) {
+    const double2* p = reinterpret_cast<const double2*>(F + 3 * (size_t)c);
+    const double2 x = p[0], y = p[1], z = p[2];
+    return V2{{x.x, x.y, y.x}, {y.y, z.x, z.y}};
+}
+__global__ __launch_bounds__(256) void k_H_pairs(Geo g, const double* __restrict__ a0, const double* __restrict__ a1, const double* __restrict__ a2, const double* __restrict__ a3,
+                                                 const double* __restrict__ a4, const double* __restrict__ a5, const double* __restrict__ src, const double* __restrict__ U,
+                                                 const double* __restrict__ rAU, double* __restrict__ out) {
+    const int c = swz_block(blockIdx.x, gridDim.x) * 512 + 2 * (int)threadIdx.x;
+    if (c >= g.N) return;
+    const int i = c % g.nx, q_ = c / g.nx, j = q_ % g.ny, k = q_ / g.ny;
+    const int sy = g.nx, sz = g.nx * g.ny, last = g.N - 2;
+    // gather first: every pair from an always-valid, aligned address
+    const V2 S = ldv2(src, c), Uc = ldv2(U, c);
+    const V2 Uym = ldv2(U, max(c - sy, 0)), Uyp = ldv2(U, min(c + sy, last)), Uzm = ldv2(U, max(c - sz, 0)), Uzp = ldv2(U, min(c + sz, last));
+    const int xm = max(c - 1, 0), xp = min(c + 2, g.N - 1);
+    const double uxm[3] = {U[3 * (size_t)xm], U[3 * (size_t)xm + 1], U[3 * (size_t)xm + 2]}, uxp[3] = {U[3 * (size_t)xp], U[3 * (size_t)xp + 1], U[3 * (size_t)xp + 2]};
+    const double2 A0 = *reinterpret_cast<const double2*>(a0 + c), A1 = *reinterpret_cast<const double2*>(a1 + c), A2 = *reinterpret_cast<const double2*>(a2 + c),
+                  A3 = *reinterpret_cast<const double2*>(a3 + c), A4 = *reinterpret_cast<const double2*>(a4 + c), A5 = *reinterpret_cast<const double2*>(a5 + c),
+                  R = *reinterpret_cast<const double2*>(rAU + c);
+    double acc0[3] = {S.a[0], S.a[1], S.a[2]}, acc1[3] = {S.b[0], S.b[1], S.b[2]};
+    // same order of the six faces per cell as k_H: x-, x+, y-, y+, z-, z+
+    if (i > 0) for (int q = 0; q < 3; ++q) acc0[q] -= A0.x * uxm[q];
+    for (int q = 0; q < 3; ++q) acc0[q] -= A1.x * Uc.b[q];                       // (i + 1 <= nx - 1: the pair shares a row)
+    if (j > 0) for (int q = 0; q < 3; ++q) acc0[q] -= A2.x * Uym.a[q];
+    if (j < g.ny - 1) for (int q = 0; q < 3; ++q) acc0[q] -= A3.x * Uyp.a[q];
+    if (k > 0) for (int q = 0; q < 3; ++q) acc0[q] -= A4.x * Uzm.a[q];
+    if (k < g.nz - 1) for (int q = 0; q < 3; ++q) acc0[q] -= A5.x * Uzp.a[q];
+    for (int q = 0; q < 3; ++q) acc1[q] -= A0.y * Uc.a[q];
+    if (i + 1 < g.nx - 1) for (int q = 0; q < 3; ++q) acc1[q] -= A1.y * uxp[q];
+    if (j > 0) for (int q = 0; q < 3; ++q) acc1[q] -= A2.y * Uym.b[q];
+    if (j < g.ny - 1) for (int q = 0; q < 3; ++q) acc1[q] -= A3.y * Uyp.b[q];
+    if (k > 0) for (int q = 0; q < 3; ++q) acc1[q] -= A4.y * Uzm.b[q];
+    if (k < g.nz - 1) for (int q = 0; q < 3; ++q) acc1[q] -= A5.y * Uzp.b[q];
+    double2* o = reinterpret_cast<double2*>(out + 3 * (size_t)c);
+    o[0] = make_double2(R.x * (acc0[0] * 0.5), R.x * (acc0[1] * 0.5));
+    o[1] = make_double2(R.x * (acc0[2] * 0.5), R.y * (acc1[0] * 0.5));
+    o[2] = make_double2(R.y * (acc1[1] * 0.5), R.y * (acc1[2] * 0.5));
+}
+
 int main(int argc, char** argv) {
     const int n = argc > 1 ? atoi(argv[1]) : 160;
     Geo g{n, n, n, n * n * n};
@@ -112,14 +155,15 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(src, h.data(), 3 * N * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(U, h.data(), 3 * N * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(rAU, h.data(), N * 8, hipMemcpyHostToDevice));
     const int nb = ((int)((N + 255) / 256) + 7) & ~7;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int variant = 0; variant < 3; ++variant) {
+    for (int variant = 0; variant < 4; ++variant) {
         float best = 1e9f;
         for (int rep = 0; rep < 12; ++rep) {
             CK(hipEventRecord(e0));
             for (int it = 0; it < 5; ++it) {
                 if (variant == 0) hipLaunchKernelGGL(k_H<0>, dim3(nb), dim3(256), 0, 0, g, a[0], a[1], a[2], a[3], a[4], a[5], src, U, rAU, out);
                 else if (variant == 1) hipLaunchKernelGGL(k_H<1>, dim3(nb), dim3(256), 0, 0, g, a[0], a[1], a[2], a[3], a[4], a[5], src, U, rAU, out);
-                else hipLaunchKernelGGL(k_H_lds, dim3(nb), dim3(256), 0, 0, g, a[0], a[1], a[2], a[3], a[4], a[5], src, U, rAU, out);
+                else if (variant == 2) hipLaunchKernelGGL(k_H_lds, dim3(nb), dim3(256), 0, 0, g, a[0], a[1], a[2], a[3], a[4], a[5], src, U, rAU, out);
+                else hipLaunchKernelGGL(k_H_pairs, dim3((((int)((N / 2 + 255) / 256)) + 7) & ~7), dim3(256), 0, 0, g, a[0], a[1], a[2], a[3], a[4], a[5], src, U, rAU, out);
             }
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
@@ -128,7 +172,7 @@ int main(int argc, char** argv) {
         double sum = 0;
         CK(hipMemcpy(h.data(), out, 3 * N * 8, hipMemcpyDeviceToHost));
         for (size_t q = 0; q < 3 * N; ++q) sum += h[q];
-        printf("%-28s %8.1f us   %6.0f GB/s of 128 B/cell   checksum %.10e\n", variant == 0 ? "AoS (component loads)" : variant == 1 ? "component planes" : "AoS, LDS-staged coalesced",
+        printf("%-28s %8.1f us   %6.0f GB/s of 128 B/cell   checksum %.10e\n", variant == 0 ? "AoS (component loads)" : variant == 1 ? "component planes" : variant == 2 ? "AoS, LDS-staged coalesced" : "AoS, two cells per thread",
                best * 1e3, 128.0 * N / (best * 1e-3) / 1e9, sum);
     }
     return 0;
