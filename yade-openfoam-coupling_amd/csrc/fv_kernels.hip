@@ -2450,14 +2450,15 @@ __global__ __launch_bounds__(256) void k_mg_prolong_add_planes(PMat A, int kofs,
 // level of C3: N bw^2 = 78 k multiply-adds; a dense 125^3 inversion was built first and cost 0.5 ms, LDS-bandwidth bound), one workgroup, one barrier per column -- and a V-cycle's coarse solve is two banded substitutions in one wave (coarse_band_solve) instead of
 // 120 Jacobi sweeps that left the level's smoothest modes partly in.  The operator is a symmetric positive definite M-matrix (the
 // reference cell or a fixed-value patch makes it non-singular); fac[2] = 0 if a pivot is not positive and finite (the sweeps then stand in).
+template <int Q>
 __global__ __launch_bounds__(1024) void k_mg_coarse_factor(PMat A, int bw, double* __restrict__ fac) {
     extern __shared__ double B[];                  // [N][bw + 1]: B[i][d] = A(i, i - d), overwritten by L
     __shared__ int bad;
-    const int N = A.N, tid = threadIdx.x, Wd = bw + 1, sy = A.nx, sz = A.nx * A.ny;
+    const int N = A.N, tid = threadIdx.x, NT = (int)blockDim.x, Wd = bw + 1, sy = A.nx, sz = A.nx * A.ny;
     if (tid == 0) bad = 0;
-    for (int e = tid; e < N * Wd; e += 1024) B[e] = 0.0;
+    for (int e = tid; e < N * Wd; e += NT) B[e] = 0.0;
     __syncthreads();
-    for (int c = tid; c < N; c += 1024) {          // the lower half of row c of p_row (zero coefficients at the walls); += : strides coincide on flat grids
+    for (int c = tid; c < N; c += NT) {          // the lower half of row c of p_row (zero coefficients at the walls); += : strides coincide on flat grids
         double* row = B + (size_t)c * Wd;
         row[0] += A.diag[c];
         if (c >= 1) row[1] -= A.ux[c - 1];
@@ -2469,25 +2470,32 @@ __global__ __launch_bounds__(1024) void k_mg_coarse_factor(PMat A, int bw, doubl
     // A(i, k) -= A(i, j) A(k, j) / A(j, j) for j < k <= i <= j + m, reads column j and writes columns > j only -- ONE barrier per column --
     // and the division by L(j, j) is applied to every entry at the end.  A thread owns fixed positions (a, b) of the bw x bw update window
     // (bw <= 64: at most four), so there is no index arithmetic in the loop.
-    int ua[4], ub[4];
+    // (round 5: only the lower triangle b <= a of the window does anything -- its bw (bw + 1) / 2 positions are dealt out, Q per thread; see the launcher)
+    int ua[Q], ub[Q];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { const int e = tid + 1024 * q; ua[q] = e / bw; ub[q] = e - ua[q] * bw; }
+    for (int q = 0; q < Q; ++q) {
+        const int e = tid + NT * q;
+        int a = (int)((sqrt(8.0 * (double)e + 1.0) - 1.0) * 0.5);
+        while ((a + 1) * (a + 2) / 2 <= e) ++a;             // (guards the rounding of the square root)
+        while (a * (a + 1) / 2 > e) --a;
+        ua[q] = a; ub[q] = e - a * (a + 1) / 2;
+    }
     for (int j = 0; j < N; ++j) {
         const double d = B[(size_t)j * Wd];
         if (!(d > 0.0) || !(d < 1e300)) { if (tid == 0) bad = 1; break; }      // (uniform: every thread reads the same value)
         const double id = 1.0 / d;
         const int m = min(bw, N - 1 - j);           // rows below the diagonal in this column
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < Q; ++q) {
             const int a = ua[q], b = ub[q];
-            if (a < m && b <= a) B[(size_t)(j + 1 + a) * Wd + (a - b)] -= (B[(size_t)(j + 1 + a) * Wd + 1 + a] * B[(size_t)(j + 1 + b) * Wd + 1 + b]) * id;
+            if (a < m) B[(size_t)(j + 1 + a) * Wd + (a - b)] -= (B[(size_t)(j + 1 + a) * Wd + 1 + a] * B[(size_t)(j + 1 + b) * Wd + 1 + b]) * id;
         }
         __syncthreads();
     }
     __syncthreads();
     if (!bad) {
-        for (int i = tid; i < N; i += 1024) fac[3 + (size_t)i * Wd] = 1.0 / sqrt(B[(size_t)i * Wd]);      // 1 / L(i, i): the substitutions multiply
-        for (int e = tid; e < N * Wd; e += 1024) {
+        for (int i = tid; i < N; i += NT) fac[3 + (size_t)i * Wd] = 1.0 / sqrt(B[(size_t)i * Wd]);      // 1 / L(i, i): the substitutions multiply
+        for (int e = tid; e < N * Wd; e += NT) {
             const int i = e / Wd, dd = e - i * Wd;
             if (dd >= 1) fac[3 + e] = dd <= i ? B[e] / sqrt(B[(size_t)(i - dd) * Wd]) : 0.0;                   // L(i, i - dd) = stored / L(i - dd, i - dd)
         }
@@ -2867,9 +2875,23 @@ bool mg_coarse_direct_ok(PMat A) { return A.c0 == 0 && A.N <= kMgDirectMax && ba
 int launch_mg_coarse_factor(hipStream_t s, PMat A, double* fac) {
     if (!(mg_coarse_direct_ok)(A)) return fail(FY_ERR_INVALID, "direct coarse solve: level of %d cells, band %d (ghost offset %d)", A.N, band_width(A), A.c0);
     static bool attr_set = false;
-    if (!attr_set) { FY_TRY(allow_big_lds(reinterpret_cast<const void*>(k_mg_coarse_factor))); attr_set = true; }
+    if (!attr_set) {
+        FY_TRY(allow_big_lds(reinterpret_cast<const void*>(k_mg_coarse_factor<1>)));
+        FY_TRY(allow_big_lds(reinterpret_cast<const void*>(k_mg_coarse_factor<2>)));
+        FY_TRY(allow_big_lds(reinterpret_cast<const void*>(k_mg_coarse_factor<3>)));
+        attr_set = true;
+    }
     const int bw = band_width(A);
-    hipLaunchKernelGGL(k_mg_coarse_factor, dim3(1), dim3(1024), fac_lds_bytes(A.N, bw), s, A, bw, fac);
+    // the update window's lower triangle dealt out Q positions per thread.  The kernel is one barrier and one dependent LDS round trip per column: fewer
+    // positions per thread shorten the round trip, fewer waves the barrier (measured at the 5^3 level, band 25, 325 positions: 1024 threads x 4 positions of the
+    // full window 72 us, 256 x 4 of the full window 51; of the triangle: 64 x 6 81, 128 x 3 54, 192 x 2 44, 384 x 1 39 us)
+    const int tri = bw * (bw + 1) / 2;
+    static const int force_q = [] { const char* e = getenv("FOAMYADE_FACTOR_Q"); return e ? atoi(e) : 0; }();      // (experiments)
+    const int q = force_q > 0 ? force_q : (tri <= 1024 ? 1 : (tri <= 2048 ? 2 : 3));
+    const int nt = std::min(1024, ((tri + q - 1) / q + 63) / 64 * 64);
+    if (q == 1) hipLaunchKernelGGL(k_mg_coarse_factor<1>, dim3(1), dim3(nt), fac_lds_bytes(A.N, bw), s, A, bw, fac);
+    else if (q == 2) hipLaunchKernelGGL(k_mg_coarse_factor<2>, dim3(1), dim3(nt), fac_lds_bytes(A.N, bw), s, A, bw, fac);
+    else hipLaunchKernelGGL(k_mg_coarse_factor<3>, dim3(1), dim3(nt), fac_lds_bytes(A.N, bw), s, A, bw, fac);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }

@@ -39,6 +39,7 @@ int Solver::create(const fy_case_desc* c, const fy_transport* tr, int dev, Comm*
     FY_HIP(hipEventCreateWithFlags(&ev_usum0, hipEventDisableTiming));
     FY_HIP(hipEventCreateWithFlags(&ev_usum1, hipEventDisableTiming));
     FY_HIP(hipEventCreateWithFlags(&ev_coarse, hipEventDisableTiming));
+    FY_HIP(hipEventCreateWithFlags(&ev_factor, hipEventDisableTiming));
     overlap_halos = !options().no_halo_overlap && options().halo_overlap;
     overlap_sweeps = options().halo_overlap;
     fused_corrector = !options().no_fused_corrector;
@@ -490,10 +491,13 @@ int Solver::corrector(bool final_inner) {
                 FY_HIP(hipEventRecord(ev_assembled, stream));
                 FY_HIP(hipStreamWaitEvent(comm_stream, ev_assembled, 0));
                 std::swap(stream, comm_stream);               // (build_coarse_operators launches on `stream`)
-                const int rc = build_coarse_operators();
+                coarse_on_side = true; coarse_marked = false;
+                const int rc = build_coarse_operators();      // (records ev_coarse behind the last operator, before the coarsest level's factorisation)
+                coarse_on_side = false;
                 std::swap(stream, comm_stream);
                 FY_TRY(rc);
-                FY_HIP(hipEventRecord(ev_coarse, comm_stream));
+                if (coarse_marked) { FY_HIP(hipEventRecord(ev_factor, comm_stream)); factor_pending = true; }
+                else FY_HIP(hipEventRecord(ev_coarse, comm_stream));
                 coarse_pending = true;
             } else {
                 FY_TRY(build_coarse_operators());
@@ -501,7 +505,7 @@ int Solver::corrector(bool final_inner) {
         }
         rAU_new = false;
         FY_TRY(solve_pressure(final_inner && no == cs.n_non_orth_correctors, front_done));
-        FY_TRY(wait_coarse());                                // (a solve that never left level 0)
+        FY_TRY(wait_factor());                                // (a solve that never left level 0)
         if (no == cs.n_non_orth_correctors && !fused_back) {
             FY_TRY(halo_p());
             FY_TRY(FVK(launch_flux_correct, stream, g, p.p, C3(phiHbyA), C3(rAUf), C3(alphaf), C3(psn), C3(phiForces), F3(pflux), F3(phi)));

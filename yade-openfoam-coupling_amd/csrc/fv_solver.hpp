@@ -51,14 +51,15 @@ struct Solver {
     // single domain: the coarse operators (k_mg_coarsen per level, the reference term, the coarsest level's Cholesky factor -- small, launch- and
     // latency-bound kernels, ~110 us in a row) are built on comm_stream while the main stream starts the solve on level 0, which needs none of them
     // (initial residual, pre-smoothing, restriction); the first touch of a coarse level waits for ev_coarse
-    hipEvent_t ev_assembled = nullptr, ev_coarse = nullptr;
+    hipEvent_t ev_assembled = nullptr, ev_coarse = nullptr, ev_factor = nullptr;      // ev_factor: the coarsest level's Cholesky factor, which only the V-cycle's tail needs
     // single domain: the component sums of U that the momentum predictor's normFactor needs (k_sum3 + fold, 35 us) are formed on comm_stream at the top
     // of the step, beside the particle phase -- U does not change between there and the predictor -- into a partials buffer of their own
     hipEvent_t ev_usum0 = nullptr, ev_usum1 = nullptr;
     DevBuf<double> usum_partials;
     bool usum_pending = false;
-    bool coarse_pending = false;
+    bool coarse_pending = false, factor_pending = false, coarse_on_side = false, coarse_marked = false;
     int wait_coarse() { if (coarse_pending) { coarse_pending = false; FY_HIP(hipStreamWaitEvent(stream, ev_coarse, 0)); } return FY_OK; }
+    int wait_factor() { FY_TRY(wait_coarse()); if (factor_pending) { factor_pending = false; FY_HIP(hipStreamWaitEvent(stream, ev_factor, 0)); } return FY_OK; }
     fy_ctx* cpl = nullptr;
     bool pimple = false;
     int Nc = 0;                   // owned cells
@@ -132,6 +133,7 @@ struct Solver {
         if (ev_usum0) (void)hipEventDestroy(ev_usum0);
         if (ev_usum1) (void)hipEventDestroy(ev_usum1);
         if (ev_coarse) (void)hipEventDestroy(ev_coarse);
+        if (ev_factor) (void)hipEventDestroy(ev_factor);
         if (comm_stream) (void)hipStreamDestroy(comm_stream);
         if (red_host) (void)hipHostFree(red_host);
         if (red_flag) (void)hipHostFree(red_flag);
