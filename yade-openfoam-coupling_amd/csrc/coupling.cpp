@@ -455,6 +455,7 @@ int Coupling::ensure_batch(Batch& b, int64_t n) {
             }
             b.cap = c2;
             b.binned_n = -1;          // fresh arrays: the old placement is gone
+            b.caps_ready = false;
         }
     } else {
         FY_TRY(b.incell.reserve(cap));
@@ -677,7 +678,9 @@ int Coupling::run_batch(Batch& b) {
         const CellWindow cw{slab.active ? slab.base : 0, n_field};
         // the scatters' tables are flushed into per-tile buckets sized from the demand they counted in this batch's last step
         const TileBuckets tbD = buckets_of(b, 0), tbB = buckets_of(b, 1);
-        FY_TRY(launch_tile_caps(stream, tbD, tbB));
+        if (b.caps_ready && b.caps_key == (const void*)tbD.off) FY_HIP(hipStreamWaitEvent(stream, b.ev_caps, 0));      // formed at the end of the last call, beside the solver's sweeps
+        else FY_TRY(launch_tile_caps(stream, tbD, tbB));
+        b.caps_ready = false;
         if (timing) marks.mark(1, stream);
         FY_TRY(launch_locate_deposit(stream, d_tree.p, use_implicit ? d_tree_packed.p : nullptr, implicit, n_cells, tree_levels, p, b.n, gp,
                                      use_implicit ? d_loc_start.p : nullptr, own_of(b), ll, cw, d_pvol_acc.p, d_up_acc.p, d_touched.p, tbD, side,
@@ -791,6 +794,17 @@ int Coupling::run_batch(Batch& b) {
             }
         }
         if (timing) marks.mark(5, stream);
+        // the NEXT call's bucket capacities (one workgroup's scan of the demand this call counted: 20 us that used to open the next particle phase) on the side
+        // stream now, beside whatever the caller does next; a batch whose arrays are renewed in between forms them again (caps_key)
+        static const bool early_caps = getenv("FOAMYADE_NO_EARLY_CAPS") == nullptr;      // (A/B switch)
+        if (early_caps && side.stream && tbD.cell) {
+            if (!b.ev_caps) FY_HIP(hipEventCreateWithFlags(&b.ev_caps, hipEventDisableTiming));
+            FY_HIP(hipEventRecord(side.fork, stream));
+            FY_HIP(hipStreamWaitEvent(side.stream, side.fork, 0));
+            FY_TRY(launch_tile_caps(side.stream, tbD, tbB));
+            FY_HIP(hipEventRecord(b.ev_caps, side.stream));
+            b.caps_ready = true; b.caps_key = (const void*)tbD.off;
+        }
     } else {
         BlockGeom g;
         for (int a = 0; a < 3; ++a) { g.bbmin[a] = mesh.bbox_min[a]; g.bbmax[a] = mesh.bbox_max[a]; }

@@ -39,6 +39,9 @@ struct Batch {
     HostBuf<int32_t> h_found;
     EventTimer t_in, t_out;              // the batch's H2D / D2H copies on the copy stream (their end events are what the compute stream / the host wait for)
     hipEvent_t ev_ready = nullptr;       // results final on the compute stream
+    hipEvent_t ev_caps = nullptr;        // the next call's tile-bucket capacities are formed (side stream, end of run_batch)
+    bool caps_ready = false;
+    const void* caps_key = nullptr;      // ... for the bucket arrays at this address
     bool events = false;
     DevBuf<double> pos3;                 // general mesh, point force: the records' positions [n][3] and the located cells
     DevBuf<int32_t> cell_hint;
@@ -49,7 +52,7 @@ struct Batch {
     int32_t* out_found = nullptr;        // reserved send buffers of this step (nullptr: the pinned h_found / h_force above)
     double* out_force = nullptr;
     bool committed = false;              // this step's results were handed to the transport already
-    ~Batch() { t_in.destroy(); t_out.destroy(); if (ev_ready) (void)hipEventDestroy(ev_ready); }
+    ~Batch() { t_in.destroy(); t_out.destroy(); if (ev_ready) (void)hipEventDestroy(ev_ready); if (ev_caps) (void)hipEventDestroy(ev_caps); }
 };
 
 // z-slab mode (set by fy_solver before create()): the k-d tree spans the GLOBAL block, every cell array is this rank's slab
