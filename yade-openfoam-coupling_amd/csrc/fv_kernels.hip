@@ -2257,6 +2257,7 @@ struct MgTail {
     double* x1[kMgTailMax];
     double* b[kMgTailMax];
     const double* fac;           // banded Cholesky factor of the coarsest operator (k_mg_coarse_factor); null: Jacobi sweeps
+    int cache_n, cache_off;      // cache_n > 0: the tail's first level (that many cells, not the coarsest) lives in LDS for the whole kernel, cache_off doubles into the dynamic LDS
 };
 
 // The coarsest level's exact solve from its banded Cholesky factor (k_mg_coarse_factor): fac = {N, bw, ok} as three doubles, then the band rows
@@ -2296,12 +2297,31 @@ __device__ __forceinline__ void coarse_band_solve(const double* Ls, int N, int b
 
 __global__ __launch_bounds__(1024) void k_mg_tail(MgTail T, double w, int coarse_sweeps, MgWeights W) {
     const int tid = threadIdx.x;
+    extern __shared__ double tail_lds[];
+    // The tail's first level (<= kMgTailCells cells: one cell per thread) is touched by ~7 sweeps, each one global round trip and a barrier long: its operator,
+    // right-hand side and both iterates are held in LDS instead (round 5; the same p_row on the same values, through generic pointers)
+    const bool cached = T.cache_n > 0;
+    double* const lc = tail_lds + T.cache_off;
+    PMat AL = T.A[0];
+    if (cached) {
+        const int N0 = T.cache_n;
+        AL.diag = lc; AL.ux = lc + N0; AL.uy = lc + 2 * N0; AL.uz = lc + 3 * N0;
+        for (int c = tid; c < N0; c += 1024) {
+            AL.diag[c] = T.A[0].diag[c]; AL.ux[c] = T.A[0].ux[c]; AL.uy[c] = T.A[0].uy[c]; AL.uz[c] = T.A[0].uz[c];
+            lc[4 * N0 + c] = T.b[0][c];
+        }
+        __syncthreads();
+    }
+    const double* const lb = lc + 4 * T.cache_n;
+    double* const lx0 = lc + 5 * T.cache_n;
+    double* const lx1 = lc + 6 * T.cache_n;
     // ---- down: smooth_first, smooth, residual -> restricted rhs of the next level
     for (int l = 0; l + 1 < T.n; ++l) {
-        const PMat A = T.A[l];
-        const double* b = T.b[l];
-        double* xa = T.x0[l];
-        double* xb = T.x1[l];
+        const bool in_lds = cached && l == 0;
+        const PMat A = in_lds ? AL : T.A[l];
+        const double* b = in_lds ? lb : T.b[l];
+        double* xa = in_lds ? lx0 : T.x0[l];
+        double* xb = in_lds ? lx1 : T.x1[l];
         for (int c = tid; c < A.N; c += 1024) xa[c] = W.w[0] * b[c] / A.diag[c];
         __syncthreads();
         for (int s = 1; s < W.n; ++s) {                       // the iterate alternates between x0 and x1; W.n is even, so it ends in x1
@@ -2340,7 +2360,7 @@ __global__ __launch_bounds__(1024) void k_mg_tail(MgTail T, double w, int coarse
         __shared__ double c_dg[kMgCoarseMax], c_ux[kMgCoarseMax], c_uy[kMgCoarseMax], c_uz[kMgCoarseMax], c_b[kMgCoarseMax];
         __shared__ double c_x[2][kMgCoarseMax];
         if (T.fac && A.N <= kMgDirectMax && T.fac[2] == 1.0) {        // (uniform) the level's exact solve from its banded Cholesky factor
-            extern __shared__ double fac_lds[];
+            double* const fac_lds = tail_lds;
             const int bw = (int)T.fac[1], cnt = A.N * (bw + 1);
             for (int q = tid; q < cnt; q += 1024) fac_lds[q] = T.fac[3 + q];
             __syncthreads();
@@ -2408,12 +2428,13 @@ __global__ __launch_bounds__(1024) void k_mg_tail(MgTail T, double w, int coarse
     }
     // ---- up: prolongation + two post-smoothing sweeps; a level's result ends in x1 (the coarsest's in x0)
     for (int l = T.n - 2; l >= 0; --l) {
-        const PMat A = T.A[l];
+        const bool in_lds = cached && l == 0;
+        const PMat A = in_lds ? AL : T.A[l];
         const PMat Cc = T.A[l + 1];
-        const double* b = T.b[l];
+        const double* b = in_lds ? lb : T.b[l];
         const double* xc = (l + 1 == T.n - 1) ? T.x0[l + 1] : T.x1[l + 1];
-        double* xb = T.x1[l];
-        double* xa = T.x0[l];
+        double* xb = in_lds ? lx1 : T.x1[l];
+        double* xa = in_lds ? lx0 : T.x0[l];
         for (int c = tid; c < A.N; c += 1024) {
             const int i = c % A.nx, q = c / A.nx, j = q % A.ny, k = q / A.ny;
             xb[c] += xc[(i >> 1) + Cc.nx * ((j >> 1) + Cc.ny * (k >> 1))];
@@ -2425,6 +2446,7 @@ __global__ __launch_bounds__(1024) void k_mg_tail(MgTail T, double w, int coarse
             double* t = xa; xa = xb; xb = t;
         }
     }
+    if (cached) for (int c = tid; c < T.cache_n; c += 1024) T.x1[0][c] = lx1[c];      // the level above prolongs from x1
 }
 
 __global__ __launch_bounds__(256) void k_mg_prolong_add(PMat A, double* __restrict__ x, PMat C, const double* __restrict__ xc) {
@@ -2903,12 +2925,20 @@ int launch_mg_tail(hipStream_t s, const PMat* A, double* const* x0, double* cons
     T.n = n;
     T.fac = fac;
     size_t lds = 0;
+    static bool attr_set = false;
+    if (!attr_set) {      // the factor of the coarsest level + seven arrays of the tail's first level
+        const int want = (int)(fac_lds_bytes(kMgDirectMax, kMgDirectBand) + 7 * (size_t)kMgTailCells * sizeof(double));
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_mg_tail), hipFuncAttributeMaxDynamicSharedMemorySize, want) != hipSuccess)
+            return fail(FY_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+        attr_set = true;
+    }
     if (fac) {
         if (!(mg_coarse_direct_ok)(A[n - 1])) return fail(FY_ERR_INVALID, "multigrid tail: a factor was handed over for a level it cannot belong to");
-        static bool attr_set = false;
-        if (!attr_set) { FY_TRY(allow_big_lds(reinterpret_cast<const void*>(k_mg_tail))); attr_set = true; }
         lds = fac_lds_bytes(A[n - 1].N, band_width(A[n - 1]));
     }
+    T.cache_n = 0; T.cache_off = (int)(lds / sizeof(double));
+    static const bool tail_cache = getenv("FOAMYADE_NO_TAIL_CACHE") == nullptr;      // (A/B switch)
+    if (tail_cache && n >= 2 && A[0].N <= kMgTailCells) { T.cache_n = A[0].N; lds += 7 * (size_t)A[0].N * sizeof(double); }
     for (int l = 0; l < n; ++l) {
         if (A[l].c0 != 0) return fail(FY_ERR_INVALID, "multigrid tail levels must not carry ghost planes");
         T.A[l] = A[l]; T.x0[l] = x0[l]; T.x1[l] = x1[l]; T.b[l] = b[l];
