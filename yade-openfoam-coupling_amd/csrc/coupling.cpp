@@ -343,7 +343,7 @@ int Coupling::ensure_locate_tables(double maxdist) {
         const int64_t pl = (int64_t)implicit.nx * implicit.ny;
         loc_cell0 = slab.active ? (int32_t)((int64_t)slab.kglob0 * pl) : 0;
         loc_n_listed = slab.active ? (int32_t)((int64_t)slab.nz * pl) : n_cells;
-        if (ext / implicit.dx <= 1e6 && d_loc_lists.alloc_exact((size_t)loc_n_listed * 8 * kLocateListLen) == FY_OK && d_loc_fb_n.alloc_exact(1) == FY_OK) {
+        if (ext / implicit.dx <= 1e6 && d_loc_lists.alloc_exact((size_t)loc_n_listed * 8 * kLocateListLen) == FY_OK && d_loc_fb_n.alloc_exact(2) == FY_OK) {        // [0] the counter, [1] the last pass's count (kept when k_tile_caps clears [0])
             FY_TRY(launch_build_locate_lists(stream, d_tree_packed.p, implicit, n_cells, maxdist, d_loc_lists.p, loc_cell0, loc_n_listed));
         } else {
             d_loc_lists.release();               // not enough memory (or far-from-origin coordinates): the walk does all particles
@@ -678,9 +678,14 @@ int Coupling::run_batch(Batch& b) {
         const CellWindow cw{slab.active ? slab.base : 0, n_field};
         // the scatters' tables are flushed into per-tile buckets sized from the demand they counted in this batch's last step
         const TileBuckets tbD = buckets_of(b, 0), tbB = buckets_of(b, 1);
+        // (the kernel also clears the lists' hand-over counter for the pass below: no 4-byte memset at the head of the phase)
+        unsigned int* const fbz = (use_implicit && d_loc_lists.p && tbD.cell) ? d_loc_fb_n.p : nullptr;
+        // (the counter is the coupling's, not the batch's: whichever batch's capacities kernel ran last on the side stream cleared it last -- wait for THAT one)
+        if (ev_last_caps) { FY_HIP(hipStreamWaitEvent(stream, ev_last_caps, 0)); ev_last_caps = nullptr; }
         if (b.caps_ready && b.caps_key == (const void*)tbD.off) FY_HIP(hipStreamWaitEvent(stream, b.ev_caps, 0));      // formed at the end of the last call, beside the solver's sweeps
-        else FY_TRY(launch_tile_caps(stream, tbD, tbB));
+        else { FY_TRY(launch_tile_caps(stream, tbD, tbB, fbz)); }
         b.caps_ready = false;
+        ll.fb_zeroed = fbz != nullptr;
         if (timing) marks.mark(1, stream);
         FY_TRY(launch_locate_deposit(stream, d_tree.p, use_implicit ? d_tree_packed.p : nullptr, implicit, n_cells, tree_levels, p, b.n, gp,
                                      use_implicit ? d_loc_start.p : nullptr, own_of(b), ll, cw, d_pvol_acc.p, d_up_acc.p, d_touched.p, tbD, side,
@@ -801,8 +806,9 @@ int Coupling::run_batch(Batch& b) {
             if (!b.ev_caps) FY_HIP(hipEventCreateWithFlags(&b.ev_caps, hipEventDisableTiming));
             FY_HIP(hipEventRecord(side.fork, stream));
             FY_HIP(hipStreamWaitEvent(side.stream, side.fork, 0));
-            FY_TRY(launch_tile_caps(side.stream, tbD, tbB));
+            FY_TRY(launch_tile_caps(side.stream, tbD, tbB, fbz));
             FY_HIP(hipEventRecord(b.ev_caps, side.stream));
+            ev_last_caps = b.ev_caps;
             b.caps_ready = true; b.caps_key = (const void*)tbD.off;
         }
     } else {
@@ -1493,7 +1499,11 @@ double fy_interp_range(fy_ctx* c) { return c ? c->c.interp_range : 0.0; }
 long long fy_locate_walk_count(fy_ctx* c) {
     if (!c || !c->c.d_loc_lists.p || !c->c.d_loc_fb_n.p) return -1;
     unsigned int n = 0;
-    if (hipStreamSynchronize(c->c.stream) != hipSuccess || hipMemcpy(&n, c->c.d_loc_fb_n.p, sizeof(n), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    // (the end-of-batch capacities kernel, if it has run since, moved the count to slot 1 and cleared the counter)
+    unsigned int both[2] = {0, 0};
+    if (hipStreamSynchronize(c->c.stream) != hipSuccess || (c->c.side.stream && hipStreamSynchronize(c->c.side.stream) != hipSuccess) ||
+        hipMemcpy(both, c->c.d_loc_fb_n.p, sizeof(both), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    n = c->c.ev_last_caps ? both[1] : both[0];
     return (long long)n;
 }
 int fy_locate_stack_depth(fy_ctx* c) {

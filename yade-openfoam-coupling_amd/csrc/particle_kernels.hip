@@ -676,7 +676,8 @@ __device__ __forceinline__ void tile_of(const TileGrid& tg, uint32_t cl, uint32_
 }
 
 // k_tile_caps: block b serves bucket set b.  cap[t] = demand x 1.25 + 128, offsets by an exclusive scan, clamped to the pool; demand reset
-__global__ __launch_bounds__(1024) void k_tile_caps(TileBuckets s0, TileBuckets s1) {
+__global__ __launch_bounds__(1024) void k_tile_caps(TileBuckets s0, TileBuckets s1, unsigned int* __restrict__ also_zero) {
+    if (also_zero && blockIdx.x == 0 && threadIdx.x == 0) { also_zero[1] = also_zero[0]; also_zero[0] = 0u; }      // (slot 1 keeps the last pass's count for the diagnostics)
     const TileBuckets tb = blockIdx.x == 0 ? s0 : s1;
     if (!tb.cell) return;
     const int n_tiles = tb.tg.n_tiles();
@@ -1643,7 +1644,7 @@ int launch_locate_deposit(hipStream_t s, const KdNode* tree, const uint32_t* pac
     }
     if (n_cells >= (1 << 25)) return fail(FY_ERR_UNSUPPORTED, "implicit-coordinate tree limited to 2^25 cells");
     // the lists place and deposit almost every particle; the walk + k_deposit pair takes what is left (usually nothing: zero count, exit)
-    FY_HIP(hipMemsetAsync(ll.fb_count, 0, sizeof(unsigned int), s));
+    if (!ll.fb_zeroed) FY_HIP(hipMemsetAsync(ll.fb_count, 0, sizeof(unsigned int), s));
     hipLaunchKernelGGL(k_locate_deposit, dim3(div_up(n, kDepThreads)), dim3(kDepThreads), 0, s, ll, ig, p, n, gp, own, cw, pvol_acc, up_acc, touched, tb, rec_gather);
     FY_LAUNCH_CHECK();
     // The leftovers (~5e-5 of the particles: within 8e-6 dx of a cell face) are one latency-bound launch (the walk, which also deposits for them).  With a side stream they run beside whatever the caller enqueues next on `s` (the cell-record pack); the caller waits
@@ -1708,9 +1709,9 @@ int launch_force_gaussian(hipStream_t s, ParticleSoA p, int64_t n, ForceParams f
     return FY_OK;
 }
 
-int launch_tile_caps(hipStream_t s, TileBuckets a, TileBuckets b) {
-    if (!a.cell && !b.cell) return FY_OK;
-    hipLaunchKernelGGL(k_tile_caps, dim3(2), dim3(1024), 0, s, a, b);
+int launch_tile_caps(hipStream_t s, TileBuckets a, TileBuckets b, unsigned int* also_zero) {
+    if (!a.cell && !b.cell) return also_zero ? fail(FY_ERR_INVALID, "launch_tile_caps: nothing to launch for the counter") : FY_OK;
+    hipLaunchKernelGGL(k_tile_caps, dim3(2), dim3(1024), 0, s, a, b, also_zero);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }

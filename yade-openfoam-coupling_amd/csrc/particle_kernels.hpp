@@ -90,6 +90,7 @@ struct LocateLists {
     // step's stack_cap
     int32_t stack_cap;
     unsigned int* depth_hwm;
+    bool fb_zeroed = false;              // fb_count is zero already (launch_tile_caps did it): launch_locate_deposit skips its 4-byte memset
 };
 constexpr int kLocDepthBins = 32;
 constexpr int kLocateListLen = 24;       // codes (2 B) per (cell, octant)
@@ -129,7 +130,7 @@ struct TileBuckets {               // all null: flush with global atomics (round
     TileGrid tg;
 };
 // capacities / offsets for this step from the demand counted last step, demand counters reset (two bucket sets in one launch)
-int launch_tile_caps(hipStream_t s, TileBuckets a, TileBuckets b);
+int launch_tile_caps(hipStream_t s, TileBuckets a, TileBuckets b, unsigned int* also_zero = nullptr /* a counter the next locate pass wants cleared */);
 // dst0[c] += sum of the tile's entries' first value, dst3[c][0..2] += the other three; touched[c] = 1 where something arrived (nullable)
 int launch_tile_reduce(hipStream_t s, TileBuckets tb, double* dst0, double* dst3, unsigned char* touched);
 // single domain: the reduction and what follows it per cell in ONE pass over the tiles -- launch_finalize_cells, resp. launch_fold_sources
