@@ -753,3 +753,29 @@ def test_two_cells_per_thread_sweeps_equal_the_one_cell_ones(product, solver, n_
     assert its_a == its_b and sum(its_a) > 0, (its_a, its_b)
     for nm in a:
         np.testing.assert_array_equal(a[nm], b[nm], err_msg=nm)
+
+
+@pytest.mark.parametrize("solver", [0, 1])
+def test_tail_level_in_lds_equals_the_global_memory_tail(product, solver, monkeypatch):
+    """round 5: the V-cycle tail keeps its first level (operator, right-hand side, both iterates) in LDS for the whole kernel; FOAMYADE_NO_TAIL_CACHE=1 makes
+    every sweep read it from global memory again.  Same p_row on the same values: same bits, same iteration counts (fluid only)."""
+    n = 40                                       # levels 40, 20, 10, 5: the tail is 10^3 + 5^3
+    kw = dict(g=(0, 0, -9.81), p_bc=[2] * 6) if solver == 1 else cavity_bcs()
+    nu = 1e-5 if solver == 1 else 0.01
+    out = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("FOAMYADE_NO_TAIL_CACHE", "1")
+        pc = product.make_case(solver, n, n, n, 0.1 / n, 2e-4, nu, g=kw.get("g", (0, 0, 0)), u_bc=kw.get("u_bc"), u_val=kw.get("u_val"), p_bc=kw.get("p_bc"), p_solver=1)
+        s = product.Solver(pc)
+        s.set("U", np.random.RandomState(7).rand(n * n * n, 3) * 0.05)
+        its = []
+        for step in range(3):
+            s.step()
+            its.append(s.stats()["p_iters_total"])
+        out.append(({nm: s.get(nm) for nm in ("U", "p", "phi_x", "phi_y", "phi_z")}, its))
+        s.close()
+    (a, its_a), (b, its_b) = out
+    assert its_a == its_b and sum(its_a) > 0, (its_a, its_b)
+    for nm in a:
+        np.testing.assert_array_equal(a[nm], b[nm], err_msg=nm)

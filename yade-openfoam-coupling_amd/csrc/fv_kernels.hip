@@ -2937,7 +2937,8 @@ int launch_mg_tail(hipStream_t s, const PMat* A, double* const* x0, double* cons
         lds = fac_lds_bytes(A[n - 1].N, band_width(A[n - 1]));
     }
     T.cache_n = 0; T.cache_off = (int)(lds / sizeof(double));
-    static const bool tail_cache = getenv("FOAMYADE_NO_TAIL_CACHE") == nullptr;      // (A/B switch)
+    const char* tc = getenv("FOAMYADE_NO_TAIL_CACHE");                                 // (A/B switch, read per launch: tests flip it inside one process)
+    const bool tail_cache = !(tc && *tc && strcmp(tc, "0") != 0);
     if (tail_cache && n >= 2 && A[0].N <= kMgTailCells) { T.cache_n = A[0].N; lds += 7 * (size_t)A[0].N * sizeof(double); }
     for (int l = 0; l < n; ++l) {
         if (A[l].c0 != 0) return fail(FY_ERR_INVALID, "multigrid tail levels must not carry ghost planes");
