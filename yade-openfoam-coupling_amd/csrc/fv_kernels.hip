@@ -2224,12 +2224,16 @@ __global__ __launch_bounds__(256) void k_mg_smooth_prolong2(PMat A, const double
         st2(xn + c, V.c.x + w * (bc.x - a.x) / K.dg.x, V.c.y + w * (bc.y - a.y) / K.dg.y);
     }
 }
-// k_mg_residual_restrict_tiled with a pair per lane: a block covers 128 x 2 x 2 fine cells, a lane's two residuals are the first sum of its coarse cell's fold
+// k_mg_residual_restrict_tiled with a pair per lane: a block covers (2 PX) x TY x TZ fine cells (PX TY TZ = 256), a lane's two residuals are the first sum of its
+// coarse cell's fold, the four lanes of a coarse cell meet in LDS.  The x-extent of the tile is chosen per level so that the blocks of a row are full
+// (160 cells = 5 tiles of 32; with a fixed 128-cell tile the second block of a 160-cell row was a quarter full: 42.5 -> 37.3 us at 160^3)
+template <int PX, int TY, int TZ>
 __global__ __launch_bounds__(256) void k_mg_residual_restrict_tiled2(PMat A, const double* __restrict__ b, const double* __restrict__ x, PMat C,
                                                                      double* __restrict__ bc) {
-    __shared__ double r[2][2][64];
-    const int tx = threadIdx.x & 63, ty = (threadIdx.x >> 6) & 1, tz = threadIdx.x >> 7;
-    const int i = blockIdx.x * 128 + 2 * tx, j = blockIdx.y * 2 + ty, k = blockIdx.z * 2 + tz;
+    static_assert(PX * TY * TZ == 256 && TY % 2 == 0 && TZ % 2 == 0, "tile shape");
+    __shared__ double r[TZ][TY][PX];
+    const int tx = threadIdx.x % PX, ty = (threadIdx.x / PX) % TY, tz = threadIdx.x / (PX * TY);
+    const int i = blockIdx.x * (2 * PX) + 2 * tx, j = blockIdx.y * TY + ty, k = blockIdx.z * TZ + tz;
     double v = 0.0;
     if (i < A.nx && j < A.ny && k < A.nz) {
         const int c = A.c0 + i + A.nx * (j + A.ny * k);
@@ -2239,9 +2243,12 @@ __global__ __launch_bounds__(256) void k_mg_residual_restrict_tiled2(PMat A, con
     }
     r[tz][ty][tx] = v;
     __syncthreads();
-    if (threadIdx.x < 64) {
-        const int I = blockIdx.x * 64 + (int)threadIdx.x, J = blockIdx.y, K = blockIdx.z;
-        if (I < C.nx) bc[C.c0 + I + C.nx * (J + C.ny * K)] = (r[0][0][tx] + r[0][1][tx]) + (r[1][0][tx] + r[1][1][tx]);
+    constexpr int NC = PX * (TY / 2) * (TZ / 2);          // coarse cells of the tile
+    if ((int)threadIdx.x < NC) {
+        const int cx = threadIdx.x % PX, cy = (threadIdx.x / PX) % (TY / 2), cz = threadIdx.x / (PX * (TY / 2));
+        const int I = blockIdx.x * PX + cx, J = blockIdx.y * (TY / 2) + cy, K = blockIdx.z * (TZ / 2) + cz;
+        if (I < C.nx && J < C.ny && K < C.nz)
+            bc[C.c0 + I + C.nx * (J + C.ny * K)] = (r[2 * cz][2 * cy][cx] + r[2 * cz][2 * cy + 1][cx]) + (r[2 * cz + 1][2 * cy][cx] + r[2 * cz + 1][2 * cy + 1][cx]);
     }
 }
 
@@ -2952,7 +2959,16 @@ int launch_mg_tail(hipStream_t s, const PMat* A, double* const* x0, double* cons
 
 int launch_mg_residual_restrict(hipStream_t s, PMat A, const double* b, const double* x, PMat C, double* bc) {
     if (C.N > 8192 && C.ny * 2 >= A.ny && C.nz * 2 >= A.nz) {       // big level: coalesced tile kernel (grid.y/z = coarse rows/planes)
-        if (pairs_ok(A) && al16(b) && al16(x)) hipLaunchKernelGGL(k_mg_residual_restrict_tiled2, dim3(div_up(A.nx, 128), C.ny, C.nz), dim3(256), 0, s, A, b, x, C, bc);
+        if (pairs_ok(A) && al16(b) && al16(x) && A.ny % 2 == 0 && A.nz % 2 == 0) {
+            // the tile's x-extent (8, 16, 32 or 64 pairs) that wastes the fewest lanes on this row length
+            const int px_opts[4] = {64, 32, 16, 8};
+            int best = 64; double best_fill = 0.0;
+            for (int px : px_opts) { const double fill = (double)A.nx / (double)(div_up(A.nx, 2 * px) * 2 * px); if (fill > best_fill + 1e-9) { best_fill = fill; best = px; } }
+            if (best == 64) hipLaunchKernelGGL((k_mg_residual_restrict_tiled2<64, 2, 2>), dim3(div_up(A.nx, 128), div_up(A.ny, 2), div_up(A.nz, 2)), dim3(256), 0, s, A, b, x, C, bc);
+            else if (best == 32) hipLaunchKernelGGL((k_mg_residual_restrict_tiled2<32, 4, 2>), dim3(div_up(A.nx, 64), div_up(A.ny, 4), div_up(A.nz, 2)), dim3(256), 0, s, A, b, x, C, bc);
+            else if (best == 16) hipLaunchKernelGGL((k_mg_residual_restrict_tiled2<16, 4, 4>), dim3(div_up(A.nx, 32), div_up(A.ny, 4), div_up(A.nz, 4)), dim3(256), 0, s, A, b, x, C, bc);
+            else hipLaunchKernelGGL((k_mg_residual_restrict_tiled2<8, 8, 4>), dim3(div_up(A.nx, 16), div_up(A.ny, 8), div_up(A.nz, 4)), dim3(256), 0, s, A, b, x, C, bc);
+        }
         else hipLaunchKernelGGL(k_mg_residual_restrict_tiled, dim3(div_up(A.nx, 64), C.ny, C.nz), dim3(256), 0, s, A, b, x, C, bc);
         FY_LAUNCH_CHECK();
         return FY_OK;
