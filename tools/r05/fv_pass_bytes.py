@@ -37,7 +37,8 @@ for nm in ("k_mg_ref_term", "k_mg_coarsen", "k_mg_coarse_factor", "k_mg_smooth_t
            # (the two-cells-per-thread forms of the same sweeps)
            "k_mg_smooth_two_from_zero2", "k_mg_residual_restrict_tiled2", "k_mg_smooth_prolong2", "k_mg_smooth2", "k_mg_smooth_dot2", "k_p_apply_dot2<false>",
            "k_p_apply_dot2<true>", "k_pcg_cg_update2<true>", "k_pcg_cg_update2<false>", "k_p_apply2",
-           "k_mg_coarse_factor<1>", "k_mg_coarse_factor<2>", "k_mg_coarse_factor<3>"):
+           "k_mg_coarse_factor<1>", "k_mg_coarse_factor<2>", "k_mg_coarse_factor<3>",
+           "k_mg_residual_restrict_tiled2<64, 2, 2>", "k_mg_residual_restrict_tiled2<32, 4, 2>", "k_mg_residual_restrict_tiled2<16, 4, 4>", "k_mg_residual_restrict_tiled2<8, 8, 4>"):
     reg(nm, None, "F6 pEqn solve")
 reg("k_reduce_finalize", None, "reductions")
 reg("__amd_rocclr_fillBufferAligned", None, "fills")
