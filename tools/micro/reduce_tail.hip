@@ -6,6 +6,7 @@
 //   2  sweep; partials written with agent-scope atomic stores (write-through), s_waitcnt + barrier, relaxed counter increment;
 //      the last block reads them with agent-scope atomic loads, fold          (no cache-wide write-back per block)
 //   3  as 1 with a full __threadfence() in every block (the textbook form)
+//   4  as 0 with the fold kernel on 256 threads (the 1024-thread kernel's order kept)
 // build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off tools/micro/reduce_tail.hip -o tools/micro/reduce_tail ; run: ./reduce_tail [n=160] [reps=200]
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -63,7 +64,7 @@ __global__ __launch_bounds__(256) void k_sweep(int nx, int ny, int nz, const dou
         v = pc * s;
     }
     const double bs = block_sum(v);
-    if (MODE == 0) { if (threadIdx.x == 0) partials[lb] = bs; return; }
+    if (MODE == 0 || MODE == 4) { if (threadIdx.x == 0) partials[lb] = bs; return; }
     __shared__ int last;
     if (MODE == 2) {
         if (threadIdx.x == 0) {
@@ -97,6 +98,12 @@ __global__ __launch_bounds__(1024) void k_fold(const double* __restrict__ partia
     if (threadIdx.x == 0) { double r = sh[0]; for (int w = 1; w < 16; ++w) r += sh[w]; out[0] = r; }
 }
 
+// the separate fold on 256 threads, in the 1024-thread kernel's order (same bits): fewer waves to start and a 4-wave barrier
+__global__ __launch_bounds__(256) void k_fold256(const double* __restrict__ partials, int nblocks, double* __restrict__ out) {
+    const double r = fold_as_1024<false>(partials, nblocks);
+    if (threadIdx.x == 0) out[0] = r;
+}
+
 // a dependent follow-up (what the PCG does next with the scalar): y += out * x
 __global__ __launch_bounds__(256) void k_axpy(int N, const double* __restrict__ out, const double* __restrict__ x, double* __restrict__ y) {
     const int c = blockIdx.x * 256 + threadIdx.x;
@@ -114,6 +121,7 @@ static void run(int n, int reps, const double* p, double* Ap, double* y, double*
         for (int r = 0; r < reps; ++r) {
             hipLaunchKernelGGL(k_sweep<MODE>, dim3(nb), dim3(256), 0, 0, n, n, n, p, Ap, partials, counter, out);
             if (MODE == 0) hipLaunchKernelGGL(k_fold, dim3(1), dim3(1024), 0, 0, partials, nb, out);
+            if (MODE == 4) hipLaunchKernelGGL(k_fold256, dim3(1), dim3(256), 0, 0, partials, nb, out);
             hipLaunchKernelGGL(k_axpy, dim3(nb), dim3(256), 0, 0, N, out, p, y);
         }
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
@@ -141,5 +149,8 @@ int main(int argc, char** argv) {
     run<2>(n, reps, p, Ap, y, partials, counter, out);
     run<3>(n, reps, p, Ap, y, partials, counter, out);
     run<0>(n, reps, p, Ap, y, partials, counter, out);
+    run<4>(n, reps, p, Ap, y, partials, counter, out);
+    run<0>(n, reps, p, Ap, y, partials, counter, out);
+    run<4>(n, reps, p, Ap, y, partials, counter, out);
     return 0;
 }
