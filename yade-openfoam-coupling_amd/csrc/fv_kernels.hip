@@ -2276,28 +2276,54 @@ __device__ __forceinline__ double read_lane_f64(double v, int src_lane) {      /
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
     return __hiloint2double(hi, lo);
 }
+// one sweep of eight-column groups over columns [ja, jb) (FWD: ascending, L y = b; else descending, L^T x = y) whose owners' values sit in v0 (LO) or v1.
+// Per column the ONLY dependent chain is  lane read of the owner -> times 1 / L(j, j) -> times the row's coefficient -> subtract:  the coefficients come up front
+// from clamped LDS addresses, zeroed where a row is not in the column's band (subtracting 0 * y leaves a row as it is), and an owner is NOT overwritten with its
+// result inside the loop -- once its column has passed nothing changes it any more, so all owners are scaled by their 1 / L(i, i) in one operation afterwards
+// (the same product the loop formed for the updates).  Round 5, measured with timing-only variants of the tail at C3: empty kernel 4.8 us, way down (first level in
+// LDS) + 3.3, factor into LDS + 2.4, THIS solve + 30, way up + 5.5.  Factor entries fetched up front instead of in the chain: 51.4 -> 46.2 us; selects and the
+// owner's write-back out of the chain (8 instructions per column, 4 of them dependent): 43.1.  What is left is ~27 ns per dependent operation of a lone wave.
+template <bool FWD, bool LO>
+__device__ __forceinline__ void band_columns(const double* Ls, int N, int bw, int ja, int jb, int lane, double& v0, double& v1) {
+    constexpr int U = 8;
+    const int Wd = bw + 1, r0 = min(lane, N - 1), r1 = min(lane + 64, N - 1);
+    for (int g = 0; g < jb - ja; g += U) {
+        double dj[U], a0[U], a1[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int jr = FWD ? ja + g + u : jb - 1 - g - u;                 // the column (may run past the range: then its coefficients are zero)
+            const bool live = FWD ? jr < jb : jr >= ja;
+            const int j = min(max(jr, 0), N - 1);
+            dj[u] = live ? Ls[(size_t)j * Wd] : 0.0;
+            const int d0 = FWD ? lane - jr : jr - lane, d1 = FWD ? lane + 64 - jr : jr - (lane + 64);      // distance of my rows from the diagonal, on the side the sweep updates
+            const double c0 = FWD ? Ls[(size_t)r0 * Wd + min(max(d0, 0), bw)] : Ls[(size_t)j * Wd + min(max(d0, 0), bw)];
+            const double c1 = FWD ? Ls[(size_t)r1 * Wd + min(max(d1, 0), bw)] : Ls[(size_t)j * Wd + min(max(d1, 0), bw)];
+            a0[u] = (live && d0 >= 1 && d0 <= bw && lane < N) ? c0 : 0.0;
+            a1[u] = (live && d1 >= 1 && d1 <= bw && lane + 64 < N) ? c1 : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int jr = FWD ? ja + g + u : jb - 1 - g - u;
+            const int j = min(max(jr, 0), N - 1);
+            const double yj = read_lane_f64(LO ? v0 : v1, j & 63) * dj[u];
+            v0 -= a0[u] * yj;
+            v1 -= a1[u] * yj;
+        }
+    }
+}
 __device__ __forceinline__ void coarse_band_solve(const double* Ls, int N, int bw, const double* __restrict__ b, double* __restrict__ x, int lane) {
     const int Wd = bw + 1;
     double v0 = lane < N ? b[lane] : 0.0, v1 = lane + 64 < N ? b[lane + 64] : 0.0;
-    // forward: L y = b, column by column
-    for (int j = 0; j < N; ++j) {
-        const double own = j < 64 ? v0 : v1;
-        const double yj = read_lane_f64(own, j & 63) * Ls[(size_t)j * Wd];
-        if ((j & 63) == lane) { if (j < 64) v0 = yj; else v1 = yj; }
-        // rows j + 1 .. j + bw: at most one of a lane's two rows lies in the window (bw <= 64)
-        const int d0 = lane - j, d1 = lane + 64 - j;                  // distance of my rows below the diagonal
-        if (d0 >= 1 && d0 <= bw && lane < N) v0 -= Ls[(size_t)lane * Wd + d0] * yj;
-        if (d1 >= 1 && d1 <= bw && lane + 64 < N) v1 -= Ls[(size_t)(lane + 64) * Wd + d1] * yj;
-    }
+    const double dg0 = Ls[(size_t)min(lane, N - 1) * Wd], dg1 = Ls[(size_t)min(lane + 64, N - 1) * Wd];      // 1 / L(i, i) of my rows
+    const int n0 = min(N, 64);
+    // forward: L y = b
+    band_columns<true, true>(Ls, N, bw, 0, n0, lane, v0, v1);
+    if (N > 64) band_columns<true, false>(Ls, N, bw, 64, N, lane, v0, v1);
+    v0 *= dg0; v1 *= dg1;
     // backward: L^T x = y
-    for (int j = N - 1; j >= 0; --j) {
-        const double own = j < 64 ? v0 : v1;
-        const double xj = read_lane_f64(own, j & 63) * Ls[(size_t)j * Wd];
-        if ((j & 63) == lane) { if (j < 64) v0 = xj; else v1 = xj; }
-        const int d0 = j - lane, d1 = j - (lane + 64);                 // L(j, k) for my rows k above: row j of the band, entry j - k
-        if (d0 >= 1 && d0 <= bw) v0 -= Ls[(size_t)j * Wd + d0] * xj;
-        if (d1 >= 1 && d1 <= bw) v1 -= Ls[(size_t)j * Wd + d1] * xj;
-    }
+    if (N > 64) band_columns<false, false>(Ls, N, bw, 64, N, lane, v0, v1);
+    band_columns<false, true>(Ls, N, bw, 0, n0, lane, v0, v1);
+    v0 *= dg0; v1 *= dg1;
     if (lane < N) x[lane] = v0;
     if (lane + 64 < N) x[lane + 64] = v1;
 }
