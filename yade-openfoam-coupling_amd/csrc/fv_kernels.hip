@@ -2283,8 +2283,10 @@ __device__ __forceinline__ double read_lane_f64(double v, int src_lane) {      /
 // (the same product the loop formed for the updates).  Round 5, measured with timing-only variants of the tail at C3: empty kernel 4.8 us, way down (first level in
 // LDS) + 3.3, factor into LDS + 2.4, THIS solve + 30, way up + 5.5.  Factor entries fetched up front instead of in the chain: 51.4 -> 46.2 us; selects and the
 // owner's write-back out of the chain (8 instructions per column, 4 of them dependent): 43.1.  What is left is ~27 ns per dependent operation of a lone wave.
-template <bool FWD, bool LO>
+// (DO0 / DO1: whether rows < 64 / rows >= 64 can lie in the band of the columns of this range at all -- a range that cannot touch one half skips its work)
+template <bool FWD, bool LO, bool DO0, bool DO1>
 __device__ __forceinline__ void band_columns(const double* Ls, int N, int bw, int ja, int jb, int lane, double& v0, double& v1) {
+    if (jb <= ja) return;
     constexpr int U = 8;
     const int Wd = bw + 1, r0 = min(lane, N - 1), r1 = min(lane + 64, N - 1);
     for (int g = 0; g < jb - ja; g += U) {
@@ -2296,18 +2298,23 @@ __device__ __forceinline__ void band_columns(const double* Ls, int N, int bw, in
             const int j = min(max(jr, 0), N - 1);
             dj[u] = live ? Ls[(size_t)j * Wd] : 0.0;
             const int d0 = FWD ? lane - jr : jr - lane, d1 = FWD ? lane + 64 - jr : jr - (lane + 64);      // distance of my rows from the diagonal, on the side the sweep updates
-            const double c0 = FWD ? Ls[(size_t)r0 * Wd + min(max(d0, 0), bw)] : Ls[(size_t)j * Wd + min(max(d0, 0), bw)];
-            const double c1 = FWD ? Ls[(size_t)r1 * Wd + min(max(d1, 0), bw)] : Ls[(size_t)j * Wd + min(max(d1, 0), bw)];
-            a0[u] = (live && d0 >= 1 && d0 <= bw && lane < N) ? c0 : 0.0;
-            a1[u] = (live && d1 >= 1 && d1 <= bw && lane + 64 < N) ? c1 : 0.0;
+            a0[u] = 0.0; a1[u] = 0.0;
+            if (DO0) {
+                const double c0 = FWD ? Ls[(size_t)r0 * Wd + min(max(d0, 0), bw)] : Ls[(size_t)j * Wd + min(max(d0, 0), bw)];
+                a0[u] = (live && d0 >= 1 && d0 <= bw && lane < N) ? c0 : 0.0;
+            }
+            if (DO1) {
+                const double c1 = FWD ? Ls[(size_t)r1 * Wd + min(max(d1, 0), bw)] : Ls[(size_t)j * Wd + min(max(d1, 0), bw)];
+                a1[u] = (live && d1 >= 1 && d1 <= bw && lane + 64 < N) ? c1 : 0.0;
+            }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int jr = FWD ? ja + g + u : jb - 1 - g - u;
             const int j = min(max(jr, 0), N - 1);
             const double yj = read_lane_f64(LO ? v0 : v1, j & 63) * dj[u];
-            v0 -= a0[u] * yj;
-            v1 -= a1[u] * yj;
+            if (DO0) v0 -= a0[u] * yj;
+            if (DO1) v1 -= a1[u] * yj;
         }
     }
 }
@@ -2316,13 +2323,17 @@ __device__ __forceinline__ void coarse_band_solve(const double* Ls, int N, int b
     double v0 = lane < N ? b[lane] : 0.0, v1 = lane + 64 < N ? b[lane + 64] : 0.0;
     const double dg0 = Ls[(size_t)min(lane, N - 1) * Wd], dg1 = Ls[(size_t)min(lane + 64, N - 1) * Wd];      // 1 / L(i, i) of my rows
     const int n0 = min(N, 64);
-    // forward: L y = b
-    band_columns<true, true>(Ls, N, bw, 0, n0, lane, v0, v1);
-    if (N > 64) band_columns<true, false>(Ls, N, bw, 64, N, lane, v0, v1);
+    // forward: L y = b.  Column j reaches rows j + 1 .. j + bw: rows >= 64 only from column 64 - bw on, rows < 64 only from columns < 64
+    const int js = min(max(64 - bw, 0), n0);
+    band_columns<true, true, true, false>(Ls, N, bw, 0, js, lane, v0, v1);
+    band_columns<true, true, true, true>(Ls, N, bw, js, n0, lane, v0, v1);
+    band_columns<true, false, false, true>(Ls, N, bw, 64, N, lane, v0, v1);
     v0 *= dg0; v1 *= dg1;
-    // backward: L^T x = y
-    if (N > 64) band_columns<false, false>(Ls, N, bw, 64, N, lane, v0, v1);
-    band_columns<false, true>(Ls, N, bw, 0, n0, lane, v0, v1);
+    // backward: L^T x = y.  Column j reaches rows j - bw .. j - 1: rows < 64 from columns < 64 + bw, rows >= 64 only from columns > 64
+    const int jt = min(64 + bw, N);
+    band_columns<false, false, false, true>(Ls, N, bw, jt, N, lane, v0, v1);
+    band_columns<false, false, true, true>(Ls, N, bw, 64, jt, lane, v0, v1);
+    band_columns<false, true, true, false>(Ls, N, bw, 0, n0, lane, v0, v1);
     v0 *= dg0; v1 *= dg1;
     if (lane < N) x[lane] = v0;
     if (lane + 64 < N) x[lane + 64] = v1;
