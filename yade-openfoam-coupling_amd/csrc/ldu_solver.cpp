@@ -21,7 +21,8 @@ struct LduSolver {
     fy_ldu_case cs{};
     LduGeo g{};
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr, side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_fields = nullptr;
     fy_ctx* cpl = nullptr;
     int nc = 0, nf = 0, ni = 0;
     // geometry + addressing on the device
@@ -64,6 +65,9 @@ struct LduSolver {
         if (red_host) (void)hipHostFree(red_host);
         if (red_flag) (void)hipHostFree(red_flag);
         for (auto& t : tim) t.destroy();
+        if (side) (void)hipStreamDestroy(side);
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_fields) (void)hipEventDestroy(ev_fields);
         if (stream) (void)hipStreamDestroy(stream);
     }
     template <class T> int up(DevBuf<T>& d, const std::vector<T>& h) {
@@ -376,12 +380,24 @@ struct LduSolver {
 
     // pimpleFoamYade.C:60-114
     int step_pimple() {
-        FY_TRY(launch_ldu_alphaf(stream, g, alpha.p, alphaf.p));
-        FY_TRY(launch_ldu_pre_coupling(stream, g, phi.p, U.p, vGrad.p, alphaf.p, ddtU.p, divT.p));              // :73, :75 (vGrad: :76, by the caller)
-        FY_TRY(launch_ldu_grad_scalar(stream, g, p.p, gradP.p));                                                  // :74
+        // The pre-coupling sweeps (1.3 ms at 4.1 M cells, bandwidth bound) on a side stream, beside the coupling's tree walk and deposit (4.3 + 1.2 ms, latency bound,
+        // no fluid field read): the coupling waits for them where it first gathers a fluid field (Coupling::run_batch, pack_records: fields_event), as on z-slabs
+        static const bool pre_beside = getenv("FOAMYADE_LDU_PRE_SERIAL") == nullptr;      // (A/B switch)
+        const bool beside = pre_beside && cpl->c.gaussian;
+        if (beside && !side) {
+            FY_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+            FY_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming)); FY_HIP(hipEventCreateWithFlags(&ev_fields, hipEventDisableTiming));
+        }
+        hipStream_t ps = beside ? side : stream;
+        if (beside) { FY_HIP(hipEventRecord(ev_fork, stream)); FY_HIP(hipStreamWaitEvent(side, ev_fork, 0)); }
+        FY_TRY(launch_ldu_alphaf(ps, g, alpha.p, alphaf.p));
+        FY_TRY(launch_ldu_pre_coupling(ps, g, phi.p, U.p, vGrad.p, alphaf.p, ddtU.p, divT.p));                  // :73, :75 (vGrad: :76, by the caller)
+        FY_TRY(launch_ldu_grad_scalar(ps, g, p.p, gradP.p));                                                      // :74
+        if (beside) { FY_HIP(hipEventRecord(ev_fields, side)); cpl->c.slab.fields_event = ev_fields; }
         tim[0].start(stream);
         FY_TRY(cpl->c.set_particle_action(cs.dt));                                                                // :78
         tim[0].stop(stream);
+        if (beside) FY_HIP(hipStreamWaitEvent(stream, ev_fields, 0));                                             // (whatever the coupling did: the sweeps below read alphaf)
         FY_TRY(launch_ldu_alphaf(stream, g, alpha.p, alphaf.p));                                                  // :83-85
         if (ext_source) FY_TRY(launch_add_f64(stream, uSource.p, uSourceExt.p, 3 * (size_t)nc));
         const int nOuter = std::max(cs.n_outer_correctors, 1);
