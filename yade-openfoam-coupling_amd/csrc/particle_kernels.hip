@@ -666,6 +666,42 @@ __device__ __forceinline__ void lds_add_f64(double* p, double v) { unsafeAtomicA
 // 16 random slots of a lane group on 16 bank pairs (~3 deep), same-cell adds (an atomic cannot broadcast) and the 4-byte CAS probes.
 template <int NSLOTS> __device__ __forceinline__ int agg_at(int h, int j) { return j * NSLOTS + h; }
 
+// ---- quad-lane exchange without the LDS: v_mov_b32 under a DPP quad_perm control -- every lane reads lane J of its own quad.  All four lanes of the
+// quad must be active at the call (a disabled source lane reads as zero).
+#ifndef FY_FORCE_QUAD
+#define FY_FORCE_QUAD 0
+#endif
+#ifndef FY_LD_QUAD
+#define FY_LD_QUAD 1
+#endif
+#ifndef FY_LD_QUADROW
+#define FY_LD_QUADROW 1
+#endif
+template <int J> __device__ __forceinline__ int quad_bcast(int v) { return __builtin_amdgcn_mov_dpp(v, J * 0x55, 0xf, 0xf, true); }
+template <int J> __device__ __forceinline__ double quad_bcast(double v) {
+    return __hiloint2double(quad_bcast<J>(__double2hiint(v)), quad_bcast<J>(__double2loint(v)));
+}
+template <int J> __device__ __forceinline__ double2 quad_bcast2(double2 v) { return make_double2(quad_bcast<J>(v.x), quad_bcast<J>(v.y)); }
+// 4 x 4 transpose inside every quad, one dword per (lane, register): on entry register r of lane q holds M[q][r], on return register w of lane j
+// holds M[w][j].  Two butterfly stages (lane ^ 1 on the register pairs (0,1), (2,3); lane ^ 2 on (0,2), (1,3)), each a select of what to send, one DPP
+// move and two selects of what to keep: 16 VALU operations per dword against 28 for "broadcast each source lane, pick mine".
+__device__ __forceinline__ void quad_transpose(uint32_t& m0, uint32_t& m1, uint32_t& m2, uint32_t& m3, bool b0, bool b1) {
+    constexpr int kXor1 = 1 | (0 << 2) | (3 << 4) | (2 << 6), kXor2 = 2 | (3 << 2) | (0 << 4) | (1 << 6);
+    uint32_t t;
+    t = (uint32_t)__builtin_amdgcn_mov_dpp((int)(b0 ? m0 : m1), kXor1, 0xf, 0xf, true); m0 = b0 ? t : m0; m1 = b0 ? m1 : t;
+    t = (uint32_t)__builtin_amdgcn_mov_dpp((int)(b0 ? m2 : m3), kXor1, 0xf, 0xf, true); m2 = b0 ? t : m2; m3 = b0 ? m3 : t;
+    t = (uint32_t)__builtin_amdgcn_mov_dpp((int)(b1 ? m0 : m2), kXor2, 0xf, 0xf, true); m0 = b1 ? t : m0; m2 = b1 ? m2 : t;
+    t = (uint32_t)__builtin_amdgcn_mov_dpp((int)(b1 ? m1 : m3), kXor2, 0xf, 0xf, true); m1 = b1 ? t : m1; m3 = b1 ? m3 : t;
+}
+__device__ __forceinline__ void quad_transpose(uint4& m0, uint4& m1, uint4& m2, uint4& m3, int lq) {
+    const bool b0 = lq & 1, b1 = lq & 2;
+    quad_transpose(m0.x, m1.x, m2.x, m3.x, b0, b1); quad_transpose(m0.y, m1.y, m2.y, m3.y, b0, b1);
+    quad_transpose(m0.z, m1.z, m2.z, m3.z, b0, b1); quad_transpose(m0.w, m1.w, m2.w, m3.w, b0, b1);
+}
+__device__ __forceinline__ double2 as_double2(uint4 v) {
+    return make_double2(__hiloint2double((int)v.y, (int)v.x), __hiloint2double((int)v.w, (int)v.z));
+}
+
 // ------------------------------------------------------------------------------------------------ tile buckets (see particle_kernels.hpp)
 // storage cell index -> (tile, cell inside the tile)
 __device__ __forceinline__ void tile_of(const TileGrid& tg, uint32_t cl, uint32_t* tile, uint32_t* local) {
@@ -980,15 +1016,35 @@ __global__ __launch_bounds__(kDepThreads) void k_locate_deposit(LocateLists ll, 
     }
     __syncthreads();
     const int64_t i = (int64_t)blockIdx.x * kDepThreads + threadIdx.x;
-    if (i < n) {
-        double qx, qy, qz, pvx, pvy, pvz, prad;
+    // an 80-byte record of a 16-byte aligned array is five aligned 16-byte words, of which this kernel wants words 0, 1, 2 and 4
+    const bool rec16 = rec && (reinterpret_cast<uintptr_t>(rec) & 15) == 0;      // (uniform)
+#if FY_LD_QUAD
+    // the four lanes of a quad fetch one record per instruction (lane q: word q, lane 3: word 4) -- a wave instruction looks up 16 record
+    // starts instead of 64 -- and the words go home to the record's lane by DPP quad_perm moves (same values, no arithmetic involved)
+    double2 qa = make_double2(0, 0), qb = qa, qc = qa, qe = qa;
+    if (rec16) {
+        const int lq = (int)(threadIdx.x & 3u);
+        const int32_t o = i < n ? p.orig[i] : 0;
+        const uint4* r4 = reinterpret_cast<const uint4*>(rec) + (lq < 3 ? lq : 4);
+        uint4 g0 = r4[5 * (size_t)quad_bcast<0>(o)], g1 = r4[5 * (size_t)quad_bcast<1>(o)], g2 = r4[5 * (size_t)quad_bcast<2>(o)],
+              g3 = r4[5 * (size_t)quad_bcast<3>(o)];      // round j: the quad's four words of lane j's record
+        quad_transpose(g0, g1, g2, g3, lq);              // -> register w: word w (lane 3's: word 4) of MY record
+        qa = as_double2(g0); qb = as_double2(g1); qc = as_double2(g2); qe = as_double2(g3);
+    }
+#endif
+    // Straight-line (predicated) down to the list row, so that the four lanes of a quad are still together when the rows are fetched
+    const bool live = i < n;
+    double qx = 0, qy = 0, qz = 0, pvx = 0, pvy = 0, pvz = 0, prad = 0;
+    if (live) {
         if (rec) {
             const double* r = rec + 10 * (size_t)p.orig[i];
-            if ((reinterpret_cast<uintptr_t>(rec) & 15) == 0) {
-                // an 80-byte record of a 16-byte aligned array is five aligned 16-byte words: four 16-byte loads fetch what seven 8-byte ones did
-                // (round 5: the texture-data unit was 89 % busy in this kernel)
+            if (rec16) {
+#if FY_LD_QUAD
+                const double2 a = qa, b = qb, cc = qc, e = qe;
+#else
                 const double2* r2 = reinterpret_cast<const double2*>(r);
                 const double2 a = r2[0], b = r2[1], cc = r2[2], e = r2[4];
+#endif
                 qx = a.x; qy = a.y; qz = b.x; pvx = b.y; pvy = cc.x; pvz = cc.y; prad = e.y;
             } else {
                 qx = r[0]; qy = r[1]; qz = r[2]; pvx = r[3]; pvy = r[4]; pvz = r[5]; prad = r[9];
@@ -997,45 +1053,63 @@ __global__ __launch_bounds__(kDepThreads) void k_locate_deposit(LocateLists ll, 
         } else {
             qx = p.px[i]; qy = p.py[i]; qz = p.pz[i]; pvx = p.vx[i]; pvy = p.vy[i]; pvz = p.vz[i]; prad = p.rad[i];
         }
-        bool mine = true;
-        if (own.active) {                                    // another slab's particle: not located here (k = 0)
-            int kz = (int)floor((qz - own.oz) / own.dx);
-            kz = min(max(kz, 0), own.nzglob - 1);
-            if (!(qz == qz) || !own_planes(own, p.orig[i], kz, qx, qy, qz)) { p.chain_len[i] = 0; mine = false; }
-        }
-        if (mine) {
-            const double hdx = 0.5 * ig.dx;
-            // Reciprocals instead of FP64 divisions (round 5; ~35 instructions each, 22 per particle: same-box A/B 1.167 -> 1.127 ms).  What they may move by an
-            // ulp cannot change an answer: the lattice coordinate only picks the (cell, octant) list, and a particle within 2 kListEps of a cell face goes to
-            // the walk anyway; the Gaussian's argument and the normalisation feed weights that are held to 1e-10, not to the bit.  Every comparison that steers
-            // the chain (d < best, d < maxdist) is formed exactly as the reference forms it.
-            const double rdx_ = 1.0 / ig.dx;
-            const double sx = (qx - ig.ox) * rdx_, sy = (qy - ig.oy) * rdx_, sz = (qz - ig.oz) * rdx_;
-            const double fx = floor(sx), fy_ = floor(sy), fz = floor(sz);
-            const double tx = sx - fx, ty = sy - fy_, tz = sz - fz;
-            const double tlo = 2 * kListEps, thi = 1.0 - 2 * kListEps;
-            int sclass = 0;
-            bool ok = fx >= 0 && fx < ig.nx && fy_ >= 0 && fy_ < ig.ny && fz >= 0 && fz < ig.nz &&
-                      tx >= tlo && tx <= thi && ty >= tlo && ty <= thi && tz >= tlo && tz <= thi;      // (false for NaN)
-            const int ci = (int)fx, cj = (int)fy_, ck = (int)fz;
-            uint4 v[kListLen / 8];
+    }
+    bool mine = live;
+    if (live && own.active) {                                // another slab's particle: not located here (k = 0)
+        int kz = (int)floor((qz - own.oz) / own.dx);
+        kz = min(max(kz, 0), own.nzglob - 1);
+        if (!(qz == qz) || !own_planes(own, p.orig[i], kz, qx, qy, qz)) { p.chain_len[i] = 0; mine = false; }
+    }
+    const double hdx = 0.5 * ig.dx;
+    // Reciprocals instead of FP64 divisions (round 5; ~35 instructions each, 22 per particle: same-box A/B 1.167 -> 1.127 ms).  What they may move by an
+    // ulp cannot change an answer: the lattice coordinate only picks the (cell, octant) list, and a particle within 2 kListEps of a cell face goes to
+    // the walk anyway; the Gaussian's argument and the normalisation feed weights that are held to 1e-10, not to the bit.  Every comparison that steers
+    // the chain (d < best, d < maxdist) is formed exactly as the reference forms it.
+    const double rdx_ = 1.0 / ig.dx;
+    const double sx = (qx - ig.ox) * rdx_, sy = (qy - ig.oy) * rdx_, sz = (qz - ig.oz) * rdx_;
+    const double fx = floor(sx), fy_ = floor(sy), fz = floor(sz);
+    const double tx = sx - fx, ty = sy - fy_, tz = sz - fz;
+    const double tlo = 2 * kListEps, thi = 1.0 - 2 * kListEps;
+    int sclass = 0;
+    bool ok = mine && fx >= 0 && fx < ig.nx && fy_ >= 0 && fy_ < ig.ny && fz >= 0 && fz < ig.nz &&
+              tx >= tlo && tx <= thi && ty >= tlo && ty <= thi && tz >= tlo && tz <= thi;      // (false for NaN)
+    const int ci = ok ? (int)fx : 0, cj = ok ? (int)fy_ : 0, ck = ok ? (int)fz : 0;
+    uint4 v[kListLen / 8];
 #pragma unroll
-            for (int ch = 0; ch < kListLen / 8; ++ch) v[ch] = make_uint4(kListEnd | (kListEnd << 16), 0, 0, 0);
-            if (ok) {
-                const double cx = ig.ox + (double)(2 * ci + 1) * hdx, cy = ig.oy + (double)(2 * cj + 1) * hdx, cz = ig.oz + (double)(2 * ck + 1) * hdx;
-                const int oct = (qx - cx < 0.0 ? 0 : 1) | (qy - cy < 0.0 ? 0 : 2) | (qz - cz < 0.0 ? 0 : 4);
-                const int64_t cell = (int64_t)ci + (int64_t)ig.nx * ((int64_t)cj + (int64_t)ig.ny * (int64_t)ck) - ll.cell0;
-                ok = cell >= 0 && cell < ll.n_listed;            // (a slab lists its own planes only)
-                const uint4* row = reinterpret_cast<const uint4*>(lists + ((size_t)(ok ? cell : 0) * 8 + (size_t)oct) * kListLen);
-                if (ok) {
-                    // all three 16-byte chunks of the row at once (one or two lines): fetched only where the list goes on, the second and the third each cost
-                    // the wave a dependent memory round trip (round 5); what lies behind a list's end mark is never looked at
-                    const uint4 c0 = row[0], c1 = row[1], c2 = row[2];
-                    v[0] = c0;
-                    ok = (c0.x & 0xffffu) != kListOverflow;
-                    if (ok && (c0.w >> 16) != kListEnd) { v[1] = c1; sclass = 1; if ((c1.w >> 16) != kListEnd) { v[2] = c2; sclass = 2; } }
-                }
-            }
+    for (int ch = 0; ch < kListLen / 8; ++ch) v[ch] = make_uint4(kListEnd | (kListEnd << 16), 0, 0, 0);
+    int32_t rowi = 0;                                        // (cell, octant) row of the lists; row 0 where there is none to fetch
+    {
+        const double cx = ig.ox + (double)(2 * ci + 1) * hdx, cy = ig.oy + (double)(2 * cj + 1) * hdx, cz = ig.oz + (double)(2 * ck + 1) * hdx;
+        const int oct = (qx - cx < 0.0 ? 0 : 1) | (qy - cy < 0.0 ? 0 : 2) | (qz - cz < 0.0 ? 0 : 4);
+        const int64_t cell = (int64_t)ci + (int64_t)ig.nx * ((int64_t)cj + (int64_t)ig.ny * (int64_t)ck) - ll.cell0;
+        ok = ok && cell >= 0 && cell < ll.n_listed;          // (a slab lists its own planes only)
+        if (ok) rowi = (int32_t)(cell * 8 + oct);
+    }
+    {
+        // all three 16-byte chunks of the row at once (one or two lines): fetched only where the list goes on, the second and the third each cost
+        // the wave a dependent memory round trip (round 5); what lies behind a list's end mark is never looked at
+        const uint4* __restrict__ L4 = reinterpret_cast<const uint4*>(lists);
+        static_assert(kListLen * sizeof(unsigned short) == 3 * sizeof(uint4), "a list row is three 16-byte words");
+#if FY_LD_QUADROW
+        // quad-cooperative as the record fetch above: round j, lanes 0..2 fetch their word of quad lane j's row (48 contiguous bytes per quad and
+        // instruction instead of 16 bytes from each of four rows), lane 3 fetches nothing; then the 4 x 4 transpose
+        const int lq = (int)(threadIdx.x & 3u);
+        uint4 c0 = make_uint4(0, 0, 0, 0), c1 = c0, c2 = c0, c3 = c0;
+        const int32_t w0 = quad_bcast<0>(rowi), w1 = quad_bcast<1>(rowi), w2 = quad_bcast<2>(rowi), w3 = quad_bcast<3>(rowi);
+        if (lq < 3) { c0 = L4[3 * (size_t)w0 + lq]; c1 = L4[3 * (size_t)w1 + lq]; c2 = L4[3 * (size_t)w2 + lq]; c3 = L4[3 * (size_t)w3 + lq]; }
+        quad_transpose(c0, c1, c2, c3, lq);              // -> c0, c1, c2: the three words of MY row (c3: lane 3's, nothing)
+#else
+        uint4 c0 = make_uint4(0, 0, 0, 0), c1 = c0, c2 = c0;
+        if (ok) { c0 = L4[3 * (size_t)rowi]; c1 = L4[3 * (size_t)rowi + 1]; c2 = L4[3 * (size_t)rowi + 2]; }
+#endif
+        if (ok) {
+            v[0] = c0;
+            ok = (c0.x & 0xffffu) != kListOverflow;
+            if (ok && (c0.w >> 16) != kListEnd) { v[1] = c1; sclass = 1; if ((c1.w >> 16) != kListEnd) { v[2] = c2; sclass = 2; } }
+        }
+    }
+    if (mine) {
+        {
             if (p.scan_class) p.scan_class[i] = (unsigned char)(ok ? sclass : 2);
             if (!ok) {
                 const unsigned int at = atomicAdd(fb_count, 1u);
@@ -1224,6 +1298,17 @@ __device__ __forceinline__ ParticleForce force_law(const ForceParams& fp, const 
     return r;
 }
 
+// round J of a quad's cooperative gather, in two halves so that the four rounds' loads are all in flight before the first is consumed:
+// the load of chunk lq of the 64-byte record of cell cj (quad lane J's; < 0: none -- record 0 is fetched and dropped) ...
+__device__ __forceinline__ double2 quad_fetch(const double2* __restrict__ R2, int32_t cj, int lq) {
+    return R2[(size_t)(cj > 0 ? cj : 0) * (kRecDoubles / 2) + (size_t)lq];
+}
+// ... and, times lane J's weight, onto the running pair of sums this lane keeps for lane J's particle (FoamYade.C:361-365, 421-424: product
+// first, then the addition, as interp_add)
+__device__ __forceinline__ void quad_accumulate(double2& acc, double2 r, int32_t cj, double wj) {
+    if (cj >= 0) { acc.x += (r.x * wj); acc.y += (r.y * wj); }
+}
+
 __device__ __forceinline__ void interp_add(Interp& s, const double* __restrict__ R, int64_t cl, double w, double volp) {
     const double2* r = reinterpret_cast<const double2*>(R + kRecDoubles * (size_t)cl);
     const double2 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
@@ -1269,6 +1354,105 @@ __global__ __launch_bounds__(kForceThreads) void k_force_gaussian(
         vals[q] = 0.0; vals[q + kSlots] = 0.0; vals[q + 2 * kSlots] = 0.0; vals[q + 3 * kSlots] = 0.0;
     }
     __syncthreads();
+#if FY_FORCE_QUAD
+    // Quad-cooperative record gathers.  A lane that pulls its own 64-byte cell record issues four 16-byte loads whose 64 lanes touch 64 different
+    // lines each: 256 line look-ups per wave and stencil entry, and the line look-up, not the bytes, is what the L1 charges for (round 5's counters:
+    // 4.6 L1 accesses per pair, texture-data unit 94 % busy at 0.34 lines per clock).  Here the four lanes of a quad fetch ONE record per instruction:
+    // in round j lane q loads 16-byte chunk q of the record quad lane j asks for (id and weight come over by DPP quad_perm moves, no LDS), so a wave
+    // instruction touches 16 lines, contiguous 64 bytes each.  No transpose per pair: lane q keeps, for each of the quad's four particles, the running
+    // sums of ITS chunk (two doubles) -- the same products added in the same order as the owner lane would add them -- and the four particles' sums
+    // go home to their owners once, after the loop.  Identical bits.
+    const int64_t i = (int64_t)blockIdx.x * kForceThreads + threadIdx.x;
+    const bool live = i < n;
+    const size_t ii = live ? (size_t)i : 0;
+    const int chain = live ? p.chain_len[ii] : 0;
+    const int k = chain < kMaxK ? chain : kMaxK;
+    const int first = chain - k;                        // oldest first: see the note on the row order below
+    const int lq = (int)(threadIdx.x & 3u);
+    const int kq = max(max(quad_bcast<0>(k), quad_bcast<1>(k)), max(quad_bcast<2>(k), quad_bcast<3>(k)));
+    const double dia = 2 * p.rad[ii];
+    const double volp = M_PI * cube3(dia) / 6.0;
+    Interp s{0, 0, 0, 0, 0, 0, 0, 0};
+    {
+        const double2* __restrict__ R2 = reinterpret_cast<const double2*>(R);
+        double2 a0 = make_double2(0, 0), a1 = a0, a2 = a0, a3 = a0;
+        size_t slot = (size_t)(first & (kMaxK - 1)) * p.cap + ii;
+        int32_t id_n = 0;
+        double w_n = 0.0;
+        if (k > 0) { id_n = p.ids[slot]; w_n = p.w[slot]; }
+        for (int t = 0; t < kq; ++t) {                   // (quad-uniform trip count: the four lanes stay together for the DPP moves)
+            const int64_t cl = (int64_t)id_n - cw.base;
+            const int32_t c32 = (t < k && cl >= 0 && cl < cw.n_field) ? (int32_t)cl : -1;
+            const double w = w_n;
+            if (t + 1 < k) {                             // the next entry's id and weight travel while this entry's records do
+                slot = (size_t)((first + t + 1) & (kMaxK - 1)) * p.cap + ii;
+                id_n = p.ids[slot]; w_n = p.w[slot];
+            }
+            if (c32 >= 0) s.pv += (volp * w);
+            const int32_t c0 = quad_bcast<0>(c32), c1 = quad_bcast<1>(c32), c2 = quad_bcast<2>(c32), c3 = quad_bcast<3>(c32);
+            const double w0 = quad_bcast<0>(w), w1 = quad_bcast<1>(w), w2 = quad_bcast<2>(w), w3 = quad_bcast<3>(w);
+            const double2 r0 = quad_fetch(R2, c0, lq), r1 = quad_fetch(R2, c1, lq), r2 = quad_fetch(R2, c2, lq), r3 = quad_fetch(R2, c3, lq);
+            quad_accumulate(a0, r0, c0, w0);
+            quad_accumulate(a1, r1, c1, w1);
+            quad_accumulate(a2, r2, c2, w2);
+            quad_accumulate(a3, r3, c3, w3);
+        }
+        // home: owner lane j takes chunk c of its sums from quad lane c (which holds it as its a_j)
+        const double2 o0 = quad_pick(quad_bcast2<0>(a0), quad_bcast2<0>(a1), quad_bcast2<0>(a2), quad_bcast2<0>(a3), lq);
+        const double2 o1 = quad_pick(quad_bcast2<1>(a0), quad_bcast2<1>(a1), quad_bcast2<1>(a2), quad_bcast2<1>(a3), lq);
+        const double2 o2 = quad_pick(quad_bcast2<2>(a0), quad_bcast2<2>(a1), quad_bcast2<2>(a2), quad_bcast2<2>(a3), lq);
+        const double2 o3 = quad_pick(quad_bcast2<3>(a0), quad_bcast2<3>(a1), quad_bcast2<3>(a2), quad_bcast2<3>(a3), lq);
+        s.ufx = o0.x; s.ufy = o0.y; s.ufz = o1.x; s.alpha_f = o1.y; s.sax = o2.x; s.say = o2.y; s.saz = o3.x;
+    }
+    if (live) {
+        ParticleForce pf{0.0, 0.0, 0.0, 0.0};
+        const int32_t orig = p.orig[i];
+        double* F = force_out + 6 * (size_t)orig;
+        if (k == 0) {                                   // zeros for particles nobody located (FoamYade.C:142)
+            F[0] = F[1] = F[2] = 0.0;
+            if (!fp.torque_prezeroed) { F[3] = F[4] = F[5] = 0.0; }
+        } else {
+            ModelSums ms{0, 0, 0, 0, 0, 0, 0};
+            if (fp.models)                              // uniform: off in the shipped reference
+                for (int t = 0; t < k; ++t) {
+                    const size_t slot = (size_t)((first + t) & (kMaxK - 1)) * p.cap + (size_t)i;
+                    const int64_t cl = (int64_t)p.ids[slot] - cw.base;
+                    if (cl < 0 || cl >= cw.n_field) continue;
+                    model_add(ms, fp, vGrad, ddtU, cl, p.w[slot], volp);
+                }
+            pf = force_law(fp, s, ms, k, dia, p.vx[i], p.vy[i], p.vz[i], rec + 10 * (size_t)orig, F);
+            const double irho = 1 / fp.rhoF;
+            // a uniform block's cell volume is a constant, not a gather
+            const double ooUniform = fp.uniform_vol > 0 ? 1. / (fp.uniform_vol * fp.rhoF) : 0.0;
+            size_t slot_b = (size_t)(first & (kMaxK - 1)) * p.cap + (size_t)i;
+            int32_t idb_n = p.ids[slot_b];
+            double wb_n = p.w[slot_b];
+            for (int t = 0; t < k; ++t) {
+                const int64_t cl = (int64_t)idb_n - cw.base;
+                const double w = wb_n;
+                if (t + 1 < k) {                         // (prefetched as in the gather loop)
+                    slot_b = (size_t)((first + t + 1) & (kMaxK - 1)) * p.cap + (size_t)i;
+                    idb_n = p.ids[slot_b]; wb_n = p.w[slot_b];
+                }
+                if (cl < 0 || cl >= cw.n_field) continue;
+                const int32_t c = (int32_t)cl;
+                const double ooCellVol = fp.uniform_vol > 0 ? ooUniform : 1. / (vol[c] * fp.rhoF);  // FoamYade.C:432
+                const double c0 = (-pf.coeff * w) * irho;                                      // FoamYade.C:385 (and, times uParticle[c], :386)
+                const double c1 = (-pf.bx * w) * ooCellVol, c2 = (-pf.by * w) * ooCellVol, c3 = (-pf.bz * w) * ooCellVol;   // FoamYade.C:433, 406-411
+                const int h = agg_slot<kForceLog2>(keys, (uint32_t)c);
+                if (h >= 0) {
+                    lds_add_f64(&vals[agg_at<kSlots>(h, 0)], c0); lds_add_f64(&vals[agg_at<kSlots>(h, 1)], c1);
+                    lds_add_f64(&vals[agg_at<kSlots>(h, 2)], c2); lds_add_f64(&vals[agg_at<kSlots>(h, 3)], c3);
+                } else {
+                    atomic_add_f64(&drag_acc[c], c0);
+                    atomic_add_f64(&uSource[3 * (size_t)c + 0], c1);
+                    atomic_add_f64(&uSource[3 * (size_t)c + 1], c2);
+                    atomic_add_f64(&uSource[3 * (size_t)c + 2], c3);
+                }
+            }
+        }
+    }
+#else
     const int64_t i = (int64_t)blockIdx.x * kForceThreads + threadIdx.x;
     if (i < n) {
         const int chain = p.chain_len[i];
@@ -1349,6 +1533,7 @@ __global__ __launch_bounds__(kForceThreads) void k_force_gaussian(
             }
         }
     }
+#endif
     __syncthreads();
     flush_table<kSlots, kForceThreads>(keys, vals, tmap, tb, drag_acc, uSource, nullptr);
 }
