@@ -886,6 +886,11 @@ int Coupling::set_particle_action(double dt) {
         if (async_results && !serial_yade && wire_views) {
             for (int bi = 0; bi < n_batches; ++bi) FY_TRY(start_results_copy(*batches[bi]));
             results_pending = true;                                        // (the caller polls and finishes: Coupling::finish_results)
+            // The fluid's dt goes out HERE, as the reference sends it from inside setParticleAction (FoamYade.C:630-631, 539-541), not behind the
+            // fluid solve: Yade's master waits for it right after the forces and only then starts its DEM sub-steps, which are meant to run
+            // beside the fluid solve.  (It is one eager double to the master, who takes no part in the particle exchange; the workers' answers
+            // follow as they land.)  Only the blocking half of the handshake -- Yade's dt coming back -- stays with finish_results().
+            FY_TRY(send_fluid_dt());
         } else {
             FY_TRY(send_results());                                        // FoamYade.C:228,239-243,487-535
             FY_TRY(exchange_dt());                                         // FoamYade.C:537-553
@@ -1236,12 +1241,19 @@ int Coupling::finish_results() {
     if (!results_pending) return FY_OK;
     results_pending = false;
     FY_TRY(send_results());
-    return exchange_dt();
+    return recv_yade_dt();                                                 // (the fluid's dt went out from set_particle_action)
 }
 
-// FoamYade::exchangeDT FoamYade.C:537-553
+// FoamYade::exchangeDT FoamYade.C:537-553, in its two halves
 int Coupling::exchange_dt() {
+    FY_TRY(send_fluid_dt());
+    return recv_yade_dt();
+}
+int Coupling::send_fluid_dt() {                                            // FoamYade.C:539-541
     if (transport.local_rank == 0) FY_TR(transport.send(transport.user, &delta_t, 1, FY_T_DOUBLE, 0, TAG_FLUID_DT));
+    return FY_OK;
+}
+int Coupling::recv_yade_dt() {                                             // FoamYade.C:543-552
     if (!serial_yade) {
         if (transport.local_rank == 0) FY_TR(transport.recv(transport.user, &yade_dt, 1, FY_T_DOUBLE, 0, TAG_YADE_DT));
         FY_TR(transport.bcast_local(transport.user, &yade_dt, 1, FY_T_DOUBLE, 0));

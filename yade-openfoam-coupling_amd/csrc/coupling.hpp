@@ -210,6 +210,8 @@ struct Coupling {
     int recv_yade_intrs();
     int send_results();
     int exchange_dt();
+    int send_fluid_dt();                        // the two halves of exchange_dt (FoamYade.C:539-541 / 543-552)
+    int recv_yade_dt();
     // round 5: fy_solver lets the fluid solve run while the answers cross PCIe.  async_results (set by the solver for one call): with a zero-copy wire
     // setParticleAction returns as soon as every batch's D2H copy is enqueued; poll_results() hands over, in worker order, whatever has landed
     // (called from the solver's host waits), finish_results() the rest + the dt handshake.  Yade gets each worker's answers as early as before
