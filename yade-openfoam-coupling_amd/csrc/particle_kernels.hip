@@ -1298,6 +1298,7 @@ __device__ __forceinline__ ParticleForce force_law(const ForceParams& fp, const 
     return r;
 }
 
+#if FY_FORCE_QUAD
 // round J of a quad's cooperative gather, in two halves so that the four rounds' loads are all in flight before the first is consumed:
 // the load of chunk lq of the 64-byte record of cell cj (quad lane J's; < 0: none -- record 0 is fetched and dropped) ...
 __device__ __forceinline__ double2 quad_fetch(const double2* __restrict__ R2, int32_t cj, int lq) {
@@ -1308,7 +1309,7 @@ __device__ __forceinline__ double2 quad_fetch(const double2* __restrict__ R2, in
 __device__ __forceinline__ void quad_accumulate(double2& acc, double2 r, int32_t cj, double wj) {
     if (cj >= 0) { acc.x += (r.x * wj); acc.y += (r.y * wj); }
 }
-
+#else
 __device__ __forceinline__ void interp_add(Interp& s, const double* __restrict__ R, int64_t cl, double w, double volp) {
     const double2* r = reinterpret_cast<const double2*>(R + kRecDoubles * (size_t)cl);
     const double2 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
@@ -1317,6 +1318,8 @@ __device__ __forceinline__ void interp_add(Interp& s, const double* __restrict__
     s.pv += (volp * w);
     s.sax += (r2.x * w); s.say += (r2.y * w); s.saz += (r3.x * w);                    // FoamYade.C:421-424 (per-cell combination, k_pack_cells)
 }
+
+#endif
 
 __device__ __forceinline__ void model_add(ModelSums& ms, const ForceParams& fp, const double* __restrict__ vGrad, const double* __restrict__ ddtU, int64_t cl,
                                           double w, double volp) {
