@@ -349,6 +349,93 @@ def test_c5_fluidized_bed_steps_at_full_size(product):
     s.close()
 
 
+def test_four_slabs_of_the_c5_bed(product, tmp_path, monkeypatch):
+    """BASELINE configs[4] cut into slabs (FoamYade.C:605-632 on every rank): the 320^3 fluidized bed with its 100 M particles as FOUR z-slabs of 80 planes --
+    virtual slabs on one GPU, the code each RCCL rank runs -- against the same bed as a single domain.  The interface at z = 1/4 runs through the dense bed
+    (9.2 particles per cell): its 5-plane particle halos and the reverse-halo sums of the deposit carry ~4.6 M particles' worth of pairs per side, which is
+    what SURVEY.md 8(d) says this configuration stresses.  Migration on: the particles within one cell of that interface start on the WRONG side of it and
+    fy_migrate_particles hands them to their owners before the first step.  Slabs 2 and 3 hold no particles at all."""
+    import gc as _gc
+    try:
+        import psutil
+        avail = psutil.virtual_memory().available
+        if avail < 56e9:
+            print(f"SKIPPED: {avail / 1e9:.0f} GB of host memory available, the 100 M-particle record sets of both runs need ~50 GB")
+            pytest.skip("host memory")
+    except ImportError:
+        pass
+    monkeypatch.setenv("FOAMYADE_TREE_CACHE_DIR", str(tmp_path))
+    n, npart, u_in, n_slabs = 320, 100_000_000, 0.05, 4
+    dx = 1.0 / n
+    U_, ZG = product.FY_BC_U_FIXED_VALUE, product.FY_BC_U_ZERO_GRADIENT
+    PX, PF = product.FY_BC_P_FIXED_FLUX, product.FY_BC_P_FIXED_VALUE
+    case = product.make_case(product.FY_SOLVER_PIMPLE, n, n, n, dx, 1e-4, 1e-6, rho_f=1000.0, rho_p=2650.0, g=(0.0, 0.0, -9.81),
+                             u_bc=[U_, U_, U_, U_, U_, ZG], u_val=[(0, 0, 0)] * 4 + [(0, 0, u_in), (0, 0, 0)], p_bc=[PX, PX, PX, PX, PX, PF], p_val=[0.0] * 6,
+                             n_outer_correctors=1, n_correctors=2, p_solver=1)
+    rs = np.random.Generator(np.random.PCG64(5))
+    rec = np.zeros((npart, 10))
+    for lo in range(0, npart, 20_000_000):
+        rec[lo:lo + 20_000_000, 0:3] = rs.random((20_000_000, 3))
+    rec[:, 2] *= 1.0 / 3.0
+    rec[:, 9] = 0.2 * dx
+    # ---- the slabs: everybody with its owner, except the band around the interface at plane 80, which starts with the neighbour
+    nzl = n // n_slabs
+    kz = np.clip(np.floor(rec[:, 2] / dx).astype(np.int32), 0, n - 1)
+    owner = (kz // nzl).astype(np.int8)
+    start = owner.copy()
+    start[kz == nzl - 1] = 1                      # the last plane of slab 0 starts in slab 1 ...
+    start[kz == nzl] = 0                          # ... and the first plane of slab 1 in slab 0
+    wrong = int((start != owner).sum())
+    assert wrong > 1_500_000                      # two planes of the bed: ~1.9 M particles to move
+    del kz
+    many = product.VirtualSlabs(case, n_slabs)
+    tags = []
+    for r, s in enumerate(many.solvers):
+        idx = np.nonzero(start == r)[0]
+        s.set_particles(rec[idx])
+        tags.append(idx.astype(np.int64))
+        del idx
+    del start
+    tags = many.migrate(tags)
+    held = np.zeros(npart, dtype=np.int8)
+    for r in range(n_slabs):
+        assert np.all(owner[tags[r]] == r)         # everybody is where its particles are ...
+        held[tags[r]] += 1
+    assert np.all(held == 1) and tags[2].size == 0 and tags[3].size == 0      # ... nobody lost, nobody twice
+    del held, owner
+    for _ in range(2):
+        many.step()
+    fm = np.zeros((npart, 6))
+    for r, s in enumerate(many.solvers):
+        if tags[r].size:
+            fm[tags[r]] = s.forces()
+    fields_m = {nm: many.get(nm) for nm in ("U", "p", "alpha")}
+    sm = many.stats()
+    many.close()
+    del tags
+    _gc.collect()
+    # ---- the single domain
+    one = product.Solver(case)
+    one.set_particles(rec)
+    del rec
+    for _ in range(2):
+        one.step()
+    fo = one.forces()
+    sc = np.abs(fo).max()
+    err = 0.0
+    for lo in range(0, npart, 10_000_000):
+        err = max(err, float(np.abs(fm[lo:lo + 10_000_000] - fo[lo:lo + 10_000_000]).max()))
+    assert err <= 1e-6 * sc, err / sc
+    assert (fo[:, 2] > 0).mean() > 0.999
+    del fm, fo
+    for nm, tol in (("U", 1e-5), ("p", 1e-5), ("alpha", 1e-9)):
+        a, b = fields_m[nm], one.get(nm)
+        assert np.abs(a - b).max() <= tol * np.abs(b).max(), (nm, np.abs(a - b).max() / np.abs(b).max())
+    so = one.stats()
+    assert all(r["p_iters_total"] == sm[0]["p_iters_total"] for r in sm) and abs(sm[0]["p_iters_total"] - so["p_iters_total"]) <= 2, (so, sm[0])
+    one.close()
+
+
 def test_eight_slabs_of_the_c3_box(product, tmp_path, monkeypatch):
     """BASELINE configs[3] at full size: the ONE C3 box (160^3 cells, 10 M particles in its lower 60 %) cut into EIGHT z-slabs of 20 planes --
     virtual slabs on one GPU, the code each RCCL rank runs -- against the same box as a single domain: every slab's 5-plane particle halo reaches a
