@@ -423,6 +423,15 @@ typedef struct fy_comm_callbacks {
     int (*allgather)(void* user, const double* send, double* recv, size_t count_per_rank);
 } fy_comm_callbacks;
 int fy_comm_create_host(int rank, int size, const fy_comm_callbacks* cb, fy_comm** out);
+/* One process per slab with DIRECT PEER STORES (SURVEY.md 8e "prefer direct peer stores over the fully connected xGMI mesh"; stands where the reference's
+ * per-particle collectives stand, FoamYade.C:228, 511-515, and where OpenFOAM's processor patches exchange halos): every rank exports one device window
+ * (hipIpcGetMemHandle) and maps the others'; a neighbour exchange is a copy kernel whose stores land in the neighbour's window + a flag, an all-reduce of
+ * <= 32 doubles ONE kernel that stores this rank's values into every peer's window and folds in rank order.  The callbacks carry the bootstrap only
+ * (allgather of the 64-byte handles, allreduce as the closing barrier); sendrecv may be NULL.  Works for the GPUs of one xGMI node and for N processes that
+ * share ONE GPU (where RCCL refuses to run): select with FOAMYADE_COMM=ipc in bench.py.  At most 8 ranks.
+ * FOAMYADE_IPC_SLOT_MB (default 8): bytes per neighbour slot (larger groups travel in chunks); FOAMYADE_IPC_TIMEOUT_MS (default 20000): bound of every
+ * device-side wait -- a peer that never arrives becomes FY_ERR_TRANSPORT at the next call instead of a hung GPU. */
+int fy_comm_create_ipc(int rank, int size, const fy_comm_callbacks* cb, int device_ordinal, fy_comm** out);
 /* diagnostic: calls made through this communicator so far: {neighbour exchanges, all-reduces, all-gathers, bytes sent to neighbours} */
 int fy_comm_stats(fy_comm*, uint64_t* out4);
 /* the same call counts by the solver phase that issued them, as text: one line "<phase> <exchanges> <all-reduces> <all-gathers>" per phase

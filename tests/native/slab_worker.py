@@ -22,7 +22,8 @@ def main():
     prod = conftest.load_product()
     dist.init_process_group(backend="gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
-    comm = prod.GlooHostComm(dist)
+    # FOAMYADE_TEST_COMM=ipc: the peer-store transport (fy_comm_create_ipc) instead of the host-staged one; gloo then carries its bootstrap only
+    comm = prod.GlooIpcComm(dist, 0) if os.environ.get("FOAMYADE_TEST_COMM", "host") == "ipc" else prod.GlooHostComm(dist)
     n = 16 if migrate == 3 else 12                    # (mode 3: planes of 256 cells = whole blocks, so that the sweeps' plane windows are active)
     nz = 12 * world
     dx = 0.1 / n

@@ -25,9 +25,29 @@ def run(world, solver, steps, migrate, port, **extra_env):
     return json.loads(line[0][7:])
 
 
+def ipc_selftest(world, port, **extra_env):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", FOAMYADE_IPC_TIMEOUT_MS="8000", **extra_env)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "tests", "native", "ipc_selftest_worker.py")]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    import re
+    assert sorted(re.findall(r"IPC-SELFTEST OK (\d)", out.stdout)) == [str(r) for r in range(world)], out.stdout[-2000:]      # (two ranks may share a line)
+
+
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_ipc_peer_store_communicator_known_answers(world):
+    """fy_comm_create_ipc (direct peer stores into hipIpc-mapped windows) with `world` OS processes on the one GPU of the test box -- the transport an
+    xGMI node would run, executed with N > 1: fy_comm_selftest's known answers three times over (the two slots of every channel are reused), then once more
+    with 16 KB slots, so that the 200 KB planes of the self-test travel in 13 chunks each way"""
+    ipc_selftest(world, 29750 + world)
+    ipc_selftest(world, 29760 + world, FOAMYADE_IPC_SLOT_KB="16")
+
+
+@pytest.mark.parametrize("transport", ["host", "ipc"])
 @pytest.mark.parametrize("world,solver", [(2, 1), (3, 1), (2, 0)])
-def test_slab_processes_match_the_single_domain(world, solver):
-    r = run(world, solver, 3, 0, 29640 + 3 * world + solver)
+def test_slab_processes_match_the_single_domain(world, solver, transport):
+    r = run(world, solver, 3, 0, 29640 + 3 * world + solver + (40 if transport == "ipc" else 0), FOAMYADE_TEST_COMM=transport)
     for s in range(3):
         assert r[f"force_err_s{s}"] <= 1e-6, r
     for nm in (("U", "p", "alpha") if solver else ("U", "p")):
@@ -72,3 +92,35 @@ def test_overlapped_exchanges_equal_the_serial_schedule_across_processes(solver)
     assert sum(v[1] for v in a["exchange_wait"].values()) > 0, a["exchange_wait"]        # the waits were sampled
     r = run(2, 1, 2, 0, 29731, FOAMYADE_HALO_OVERLAP="0")
     assert r["force_err_s1"] <= 1e-6 and r["U_err"] <= 1e-5, r
+
+
+@pytest.mark.parametrize("solver", [1, 0])
+def test_peer_store_transport_gives_the_host_staged_transport_s_bits(solver):
+    """the same slab processes over the two inter-process transports -- planes staged through host memory and gloo (fy_comm_create_host) against kernels
+    storing straight into the neighbour's device window (fy_comm_create_ipc) -- with the overlapped schedule, whose exchanges run on the auxiliary stream (the
+    communicator's second lane) beside the main stream's all-reduces.  Two processes: the gathered U / p / phi_z carry the same SHA-256, the pressure solver
+    takes the same iterations, the same collectives were issued (a sum of two is the same in either order; from three ranks on gloo's reduction order is its own
+    and the peer-store transport folds in rank order, as the in-process group and the all-gather-and-fold of Comm::allreduce_ops do).  Three processes: the
+    peer-store transport with 8 MB slots against itself with 16 KB slots -- every 5-plane group in chunks -- bit for bit, and both within 1e-5 of the single domain"""
+    a = run(2, solver, 3, 3, 29741 + solver, FOAMYADE_TEST_COMM="host")
+    b = run(2, solver, 3, 3, 29751 + solver, FOAMYADE_TEST_COMM="ipc", FOAMYADE_IPC_TIMEOUT_MS="8000")
+    assert a["fields_sha"] == b["fields_sha"] and a["p_iters"] == b["p_iters"] and a["p_iters"] > 0, (a, b)
+    assert a["comm"]["exchanges"] == b["comm"]["exchanges"] and a["comm"]["allreduces"] == b["comm"]["allreduces"] and a["comm"]["allgathers"] == b["comm"]["allgathers"], (a["comm"], b["comm"])
+    c = run(3, solver, 3, 3, 29761 + solver, FOAMYADE_TEST_COMM="ipc", FOAMYADE_IPC_TIMEOUT_MS="8000")
+    d = run(3, solver, 3, 3, 29771 + solver, FOAMYADE_TEST_COMM="ipc", FOAMYADE_IPC_SLOT_KB="16", FOAMYADE_IPC_TIMEOUT_MS="8000")
+    assert c["fields_sha"] == d["fields_sha"] and c["p_iters"] == d["p_iters"] and c["comm"] == d["comm"], (c, d)
+    for r in (b, c, d):
+        for nm in ("U", "p"):
+            assert r[f"{nm}_err"] <= 1e-5, r
+    assert sum(v[1] for v in c["exchange_wait"].values()) > 0, c["exchange_wait"]        # the waits were sampled
+
+
+def test_migration_and_a_parallel_yade_over_the_peer_store_transport():
+    """particle migration (sized exchanges, an idle middle rank) and the parallel-Yade protocol with per-rank batch counts that differ, over fy_comm_create_ipc"""
+    r = run(3, 1, 1, 1, 29791, FOAMYADE_TEST_COMM="ipc", FOAMYADE_IPC_TIMEOUT_MS="8000")
+    assert r["crossed"] > 20 and r["migrated_total"] == r["n_records"] and r["everybody_on_its_owner"], r
+    assert r["force_err_s1"] <= 1e-6 and r["p_iters_same_on_all_ranks"], r
+    r = run(3, 1, 3, 2, 29781, FOAMYADE_TEST_COMM="ipc", FOAMYADE_IPC_TIMEOUT_MS="8000")
+    for s in range(3):
+        assert r[f"force_err_s{s}"] <= 1e-6 and r[f"found_same_s{s}"] and r[f"answers_s{s}"] == [1, 2], r
+    assert r["p_iters_same_on_all_ranks"], r

@@ -830,6 +830,9 @@ class GlooHostComm:
         self._keep = (_CB_SENDRECV(sendrecv), _CB_ALLREDUCE(allreduce), _CB_ALLGATHER(allgather))
         self._cb = CommCallbacks(None, *self._keep)
         self.handle = C.c_void_p()
+        self._create()
+
+    def _create(self):
         _check(lib().fy_comm_create_host(self.rank, self.size, C.byref(self._cb), C.byref(self.handle)))
 
     def stats(self):
@@ -841,6 +844,21 @@ class GlooHostComm:
         if self.handle:
             lib().fy_comm_destroy(self.handle)
             self.handle = C.c_void_p()
+
+
+class GlooIpcComm(GlooHostComm):
+    """fy_comm_create_ipc: one process per slab, the planes and scalars written straight into the peers' device windows (hipIpc) by this rank's kernels;
+    torch.distributed (gloo) carries the bootstrap only -- the all-gather of the window handles and the closing barrier.  Runs with the ranks on the GPUs of
+    one node or all on ONE GPU.  close() is collective (every rank must call it, before the process group goes away)."""
+
+    def __init__(self, dist, device=0):
+        self.device = int(device)
+        super().__init__(dist)
+
+    def _create(self):
+        L = lib()
+        L.fy_comm_create_ipc.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+        _check(L.fy_comm_create_ipc(self.rank, self.size, C.byref(self._cb), self.device, C.byref(self.handle)))
 
 
 def comm_selftest(comm, device=0):

@@ -355,6 +355,407 @@ int host_comm_create(int rank, int size, const fy_comm_callbacks* cb, Comm** out
     return FY_OK;
 }
 
+// ================================================================================================ IpcComm
+// One process per slab, the planes and the scalars written STRAIGHT INTO THE PEER'S MEMORY by this rank's kernels ("prefer direct peer stores
+// over the fully connected xGMI mesh"): every rank exports one device window (hipIpcGetMemHandle), opens the others' (hipIpcOpenMemHandle) and from then on
+// no library stands between two GPUs -- a transfer is a copy kernel whose stores land in the neighbour's window, a flag behind them, and a copy kernel on the
+// neighbour's stream that waits for the flag.  The same code runs whether the peers are the eight GPUs of an xGMI node or N processes sharing one GPU (which
+// RCCL refuses: "duplicate GPU"), so this is the transport the one-GPU test box can execute with N > 1.
+//   channel   one direction between two ranks: two slots in the receiver's window (message m uses slot m & 1), a flag word per slot in the receiver's window
+//             (= m + 1 once message m has landed) and an acknowledgement word in the SENDER's window (= messages consumed so far).
+//   push      [wait: ack >= m - 1, i.e. the slot is free] -> copy segments into the peer's slot -> the last block stores the flag (system-scope release)
+//   pull      [wait: flag == m + 1] -> copy the slot out to its destinations -> the last block stores the acknowledgement into the sender's window
+//   exchange  per neighbour a channel each way on each of two lanes (main stream / the overlapped-halo stream); a group larger than a slot goes in chunks,
+//             push and pull interleaved chunk by chunk (a push of chunk c + 2 waits for the peer's pull of chunk c, which lies BEFORE the peer's push of
+//             chunk c + 1 in its stream: every wait points at an earlier position of the other stream, so no cycle)
+//   <= 32 doubles to everybody (all-reduce, the diagnostics group, small all-gathers): ONE kernel -- lane group p stores this rank's values into rank p's
+//             window, flags, waits for p's, reads them, acknowledges; the fold then runs in rank order on every rank (identical bits everywhere)
+// Every wait is bounded (FOAMYADE_IPC_TIMEOUT_MS, default 20 s): a peer that never arrives makes the kernel give up and set an error word the host sees at
+// its next call, instead of a GPU that spins for ever.
+namespace {
+
+typedef unsigned long long u64;
+constexpr int kIpcMaxSeg = 12;
+struct IpcSeg { const double* src; double* dst; size_t n; };              // n doubles
+struct IpcXfer {
+    IpcSeg seg[kIpcMaxSeg];
+    int nseg;
+    const u64* wait; u64 wait_min;             // a word in MY window the peer stores to (nullptr: nothing to wait for)
+    u64* signal; u64 signal_val;               // a word in the PEER's window
+    unsigned int* counter;                     // blocks done (local; the last block puts it back to zero)
+    unsigned int* err; long long timeout_ticks;
+};
+
+__device__ __forceinline__ bool ipc_wait(const u64* w, u64 need, long long timeout_ticks) {
+    // relaxed polls (a load that bypasses the caches; an ACQUIRE per poll would invalidate them every time round), one acquire when the word has arrived
+    const long long t0 = wall_clock64();
+    bool ok = true;
+    while (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < need) {
+        __builtin_amdgcn_s_sleep(8);
+        if (wall_clock64() - t0 > timeout_ticks) { ok = false; break; }
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    return ok;
+}
+
+__global__ __launch_bounds__(256) void k_ipc_xfer(IpcXfer d) {
+    if (threadIdx.x == 0 && d.wait && !ipc_wait(d.wait, d.wait_min, d.timeout_ticks)) *d.err = 1u;
+    __syncthreads();
+    for (int q = 0; q < d.nseg; ++q) {
+        const double* __restrict__ src = d.seg[q].src;
+        double* __restrict__ dst = d.seg[q].dst;
+        const size_t n = d.seg[q].n;
+        if (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0) {
+            const size_t n2 = n >> 1;
+            for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += (size_t)gridDim.x * 256)
+                reinterpret_cast<double2*>(dst)[i] = reinterpret_cast<const double2*>(src)[i];
+            if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) dst[n - 1] = src[n - 1];
+        } else {
+            for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence_system();                                        // this block's stores are out before it is counted
+        const unsigned int prev = atomicAdd(d.counter, 1u);
+        if (prev == gridDim.x - 1) {
+            *d.counter = 0u;
+            __threadfence_system();
+            if (d.signal) __hip_atomic_store(d.signal, d.signal_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+// <= 32 doubles from every rank to every rank in one launch: thread (p, j) = p * 32 + j serves peer p, value j.  out: [size x n] in rank order
+struct IpcSmall {
+    int rank, size, n;
+    const double* mine; double* out;
+    const u64* ack_in; u64 ack_min;            // [size] in my window: what each peer has consumed of my messages
+    double* peer_slot[8]; u64* peer_flag[8];   // where MY values and flag go in peer p's window (slot of this message)
+    const double* my_slot[8]; const u64* my_flag[8];      // where peer p's values arrive in my window
+    u64* peer_ack[8];                          // my acknowledgement word in peer p's window
+    u64 msg;                                   // flag value = msg + 1, acknowledgement value = msg + 1
+    unsigned int* err; long long timeout_ticks;
+    // the fold (all-reduce): slots in max_mask are maxima, the others sums; fold_to == nullptr: plain all-gather
+    double* fold_to; unsigned max_mask;
+};
+__global__ __launch_bounds__(256) void k_ipc_small(IpcSmall d) {
+    const int p = threadIdx.x >> 5, j = threadIdx.x & 31;
+    __shared__ double got[8 * 32];
+    const bool peer = p < d.size && p != d.rank;
+    double v = 0.0;
+    if (p == d.rank && j < d.n) v = d.mine[j];
+    if (peer) {
+        if (j == 0 && !ipc_wait(d.ack_in + p, d.ack_min, d.timeout_ticks)) *d.err = 2u;       // the slot in p's window is free again
+    }
+    __syncthreads();
+    if (peer && j < d.n) d.peer_slot[p][j] = d.mine[j];
+    __syncthreads();
+    if (peer && j == 0) {
+        __threadfence_system();
+        __hip_atomic_store(d.peer_flag[p], d.msg + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (!ipc_wait(d.my_flag[p], d.msg + 1, d.timeout_ticks)) *d.err = 3u;
+    }
+    __syncthreads();
+    if (peer && j < d.n) v = __hip_atomic_load(d.my_slot[p] + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (p < d.size && j < d.n) { got[p * 32 + j] = v; if (!d.fold_to) d.out[(size_t)p * d.n + j] = v; }
+    __syncthreads();
+    if (peer && j == 0) __hip_atomic_store(d.peer_ack[p], d.msg + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (d.fold_to && threadIdx.x < d.n) {
+        const bool mx = (d.max_mask >> threadIdx.x) & 1u;
+        double x = got[threadIdx.x];
+        for (int r = 1; r < d.size; ++r) { const double y = got[r * 32 + threadIdx.x]; x = mx ? (x > y ? x : y) : x + y; }
+        d.fold_to[threadIdx.x] = x;
+    }
+}
+
+struct IpcComm : Comm {
+    fy_comm_callbacks cb{};
+    int device = 0;
+    // window layout (identical on every rank): header of 64-bit words, then the slots
+    static constexpr int kLanes = 2, kDirs = 2, kSlots = 2;
+    size_t slot_nb = 0, slot_coll = 0;          // doubles per neighbour slot / per collective slot
+    size_t win_bytes = 0;
+    char* win = nullptr;                       // my window
+    std::vector<char*> peer_win;               // [size] the others' windows as mapped here (nullptr: me / not a peer I talk to)
+    bool ext_alloc = false;
+    unsigned int* counters = nullptr;          // ring of block counters
+    size_t counter_next = 0;
+    static constexpr size_t kCounters = 256;
+    unsigned int* err_host = nullptr; unsigned int* err_dev = nullptr;
+    long long timeout_ticks = 0;
+    hipStream_t aux_stream = nullptr;
+    // message counts per channel
+    u64 nb_tx[kLanes][kDirs] = {}, nb_rx[kLanes][kDirs] = {};      // dir 0: the neighbour below, 1: above
+    std::vector<u64> coll_tx, coll_rx, small_msg;                    // bulk collective channels per peer; the small kernel's message count (one for all)
+    double* small_scratch = nullptr;           // [size x 32]
+
+    // ---- offsets inside a window
+    //   words: nb_flag[lane][dir][slot] (the message that arrived FROM direction dir), nb_ack[lane][dir] (what the neighbour in direction dir has consumed
+    //   of MY messages), coll_flag[src][slot], coll_ack[dst], small_flag[src][slot], small_ack[dst]
+    size_t w_nb_flag(int lane, int dir, int slot) const { return ((size_t)lane * kDirs + dir) * kSlots + slot; }
+    size_t w_nb_ack(int lane, int dir) const { return (size_t)kLanes * kDirs * kSlots + (size_t)lane * kDirs + dir; }
+    size_t w_base2() const { return (size_t)kLanes * kDirs * kSlots + (size_t)kLanes * kDirs; }
+    size_t w_coll_flag(int src, int slot) const { return w_base2() + (size_t)src * kSlots + slot; }
+    size_t w_coll_ack(int dst) const { return w_base2() + (size_t)size * kSlots + dst; }
+    size_t w_small_flag(int src, int slot) const { return w_base2() + (size_t)size * (kSlots + 1) + (size_t)src * kSlots + slot; }
+    size_t w_small_ack(int dst) const { return w_base2() + (size_t)size * (2 * kSlots + 1) + dst; }
+    size_t n_words() const { return w_base2() + (size_t)size * (2 * kSlots + 2); }
+    size_t header_bytes() const { return (n_words() * sizeof(u64) + 4095) & ~(size_t)4095; }
+    size_t d_nb_slot(int lane, int dir, int slot) const { return (((size_t)lane * kDirs + dir) * kSlots + slot) * slot_nb; }            // in doubles, behind the header
+    size_t d_coll_slot(int src, int slot) const { return (size_t)kLanes * kDirs * kSlots * slot_nb + ((size_t)src * kSlots + slot) * slot_coll; }
+    size_t d_small_slot(int src, int slot) const { return (size_t)kLanes * kDirs * kSlots * slot_nb + (size_t)size * kSlots * slot_coll + ((size_t)src * kSlots + slot) * 32; }
+    size_t data_doubles() const { return (size_t)kLanes * kDirs * kSlots * slot_nb + (size_t)size * kSlots * (slot_coll + 32); }
+    u64* words(char* w) const { return reinterpret_cast<u64*>(w); }
+    double* data(char* w) const { return reinterpret_cast<double*>(w + header_bytes()); }
+
+    ~IpcComm() override {
+        (void)hipDeviceSynchronize();
+        // nobody may unmap a window a peer's kernel could still be storing to: one last host round through the bootstrap callbacks
+        if (cb.allreduce) { double z = 0.0; (void)cb.allreduce(cb.user, &z, 1, 0); }
+        for (char* w : peer_win) if (w) (void)hipIpcCloseMemHandle(w);
+        if (win) (void)hipFree(win);
+        if (counters) (void)hipFree(counters);
+        if (small_scratch) (void)hipFree(small_scratch);
+        if (err_host) (void)hipHostFree(err_host);
+    }
+    void set_aux_stream(hipStream_t s) override { aux_stream = s; }
+    hipStream_t get_aux_stream() const override { return aux_stream; }
+
+    int check() const {
+        const unsigned int e = err_host ? __atomic_load_n(err_host, __ATOMIC_RELAXED) : 0u;
+        if (e) return fail(FY_ERR_TRANSPORT, "ipc communicator: a wait for a peer timed out on rank %d (code %u): the ranks did not issue the same collectives, or a peer died", rank, e);
+        return FY_OK;
+    }
+    // (the kernels of one stream run one after the other: a small ring per lane is never shared by two kernels in flight)
+    unsigned int* next_counter(hipStream_t s) {
+        const size_t lane = (aux_stream && s == aux_stream) ? 1 : 0;
+        return counters + lane * (kCounters / 2) + (counter_next++ % (kCounters / 2));
+    }
+    int launch(hipStream_t s, IpcXfer& d, size_t doubles) {
+        d.counter = next_counter(s); d.err = err_dev; d.timeout_ticks = timeout_ticks;
+        const unsigned blocks = (unsigned)std::min<size_t>(std::max<size_t>((doubles / 2 + 255) / 256, 1), 512);
+        hipLaunchKernelGGL(k_ipc_xfer, dim3(blocks), dim3(256), 0, s, d);
+        if (hipGetLastError() != hipSuccess) return fail(FY_ERR_HIP, "ipc communicator: launch failed");
+        return FY_OK;
+    }
+
+    // one direction of a (grouped) transfer as a list of pieces; chunk c of it = the pieces of the byte range [c * slot, (c + 1) * slot), cut where more than
+    // kIpcMaxSeg pieces would be needed (the receiver walks the same sizes, so it cuts at the same places)
+    struct Piece { const double* src; double* dst; size_t n; };
+    static size_t n_chunks(const std::vector<Piece>& v, size_t slot) {
+        size_t chunks = 0, fill = 0; int segs = 0;
+        for (const Piece& pc : v) {
+            size_t left = pc.n;
+            while (left) {
+                if (fill == slot || segs == kIpcMaxSeg) { ++chunks; fill = 0; segs = 0; }
+                const size_t take = std::min(left, slot - fill);
+                fill += take; left -= take; ++segs;
+            }
+        }
+        return chunks + (fill ? 1 : 0);
+    }
+    // fills d.seg / d.nseg with chunk `c`: push (to_slot = the peer's slot, pieces' src) or pull (from_slot = my slot, pieces' dst); returns the doubles in the chunk
+    static size_t chunk_segs(const std::vector<Piece>& v, size_t slot, size_t c, double* slot_ptr, bool push, IpcXfer& d) {
+        size_t chunk = 0, fill = 0, total = 0; int segs = 0;
+        d.nseg = 0;
+        for (const Piece& pc : v) {
+            size_t left = pc.n, done = 0;
+            while (left) {
+                if (fill == slot || segs == kIpcMaxSeg) { ++chunk; fill = 0; segs = 0; }
+                const size_t take = std::min(left, slot - fill);
+                if (chunk == c) {
+                    IpcSeg& sg = d.seg[d.nseg++];
+                    if (push) { sg.src = pc.src + done; sg.dst = slot_ptr + fill; }
+                    else { sg.src = slot_ptr + fill; sg.dst = pc.dst + done; }
+                    sg.n = take; total += take;
+                }
+                fill += take; left -= take; done += take; ++segs;
+            }
+            if (chunk > c) break;
+        }
+        return total;
+    }
+
+    int push_nb(hipStream_t s, int lane, int dir, const std::vector<Piece>& v, size_t c) {
+        const int peer = dir ? rank + 1 : rank - 1;
+        const int their_dir = dir ? 0 : 1;                      // I am the neighbour BELOW the rank above me
+        const u64 m = nb_tx[lane][dir]++;
+        IpcXfer d{};
+        const size_t n = chunk_segs(v, slot_nb, c, data(peer_win[peer]) + d_nb_slot(lane, their_dir, (int)(m & 1)), true, d);
+        d.wait = words(win) + w_nb_ack(lane, dir); d.wait_min = m >= 1 ? m - 1 : 0;
+        if (m < 2) d.wait = nullptr;
+        d.signal = words(peer_win[peer]) + w_nb_flag(lane, their_dir, (int)(m & 1)); d.signal_val = m + 1;
+        return launch(s, d, n);
+    }
+    int pull_nb(hipStream_t s, int lane, int dir, const std::vector<Piece>& v, size_t c) {
+        const int peer = dir ? rank + 1 : rank - 1;
+        const int their_dir = dir ? 0 : 1;
+        const u64 m = nb_rx[lane][dir]++;
+        IpcXfer d{};
+        const size_t n = chunk_segs(v, slot_nb, c, data(win) + d_nb_slot(lane, dir, (int)(m & 1)), false, d);
+        d.wait = words(win) + w_nb_flag(lane, dir, (int)(m & 1)); d.wait_min = m + 1;
+        d.signal = words(peer_win[peer]) + w_nb_ack(lane, their_dir); d.signal_val = m + 1;
+        return launch(s, d, n);
+    }
+
+    int exchange_many(hipStream_t s, const Xchg* x, size_t n) override {
+        count(0);
+        FY_TRY(check());
+        const int lane = (aux_stream && s == aux_stream) ? 1 : 0;
+        std::vector<Piece> tx[2], rx[2];                       // [dir]
+        for (size_t q = 0; q < n; ++q) {
+            const size_t su = has_up() ? x[q].su() : 0, sd = has_down() ? x[q].sd() : 0, rd = has_down() ? x[q].rd() : 0, ru = has_up() ? x[q].ru() : 0;
+            exchange_bytes += sizeof(double) * (su + sd);
+            if ((su && !x[q].send_up) || (sd && !x[q].send_down) || (rd && !x[q].recv_from_down) || (ru && !x[q].recv_from_up))
+                return fail(FY_ERR_INVALID, "ipc communicator: a neighbour exchange with a count but no buffer");
+            if (su) tx[1].push_back(Piece{x[q].send_up, nullptr, su});
+            if (sd) tx[0].push_back(Piece{x[q].send_down, nullptr, sd});
+            if (rd) rx[0].push_back(Piece{nullptr, x[q].recv_from_down, rd});
+            if (ru) rx[1].push_back(Piece{nullptr, x[q].recv_from_up, ru});
+        }
+        size_t ct[2] = {n_chunks(tx[0], slot_nb), n_chunks(tx[1], slot_nb)}, cr[2] = {n_chunks(rx[0], slot_nb), n_chunks(rx[1], slot_nb)};
+        const size_t rounds = std::max(std::max(ct[0], ct[1]), std::max(cr[0], cr[1]));
+        for (size_t c = 0; c < rounds; ++c) {
+            for (int dir = 1; dir >= 0; --dir) if (c < ct[dir]) FY_TRY(push_nb(s, lane, dir, tx[dir], c));
+            for (int dir = 0; dir < 2; ++dir) if (c < cr[dir]) FY_TRY(pull_nb(s, lane, dir, rx[dir], c));
+        }
+        return FY_OK;
+    }
+
+    // <= 32 doubles per rank
+    int small(hipStream_t s, const double* mine, int n, double* out, double* fold_to, unsigned max_mask) {
+        IpcSmall d{};
+        d.rank = rank; d.size = size; d.n = n; d.mine = mine; d.out = out; d.fold_to = fold_to; d.max_mask = max_mask;
+        const u64 m = small_msg[0]++;
+        d.msg = m;
+        d.ack_in = words(win) + w_small_ack(0); d.ack_min = m >= 1 ? m - 1 : 0;
+        for (int p = 0; p < size; ++p) {
+            if (p == rank) continue;
+            d.peer_slot[p] = data(peer_win[p]) + d_small_slot(rank, (int)(m & 1)); d.peer_flag[p] = words(peer_win[p]) + w_small_flag(rank, (int)(m & 1));
+            d.my_slot[p] = data(win) + d_small_slot(p, (int)(m & 1)); d.my_flag[p] = words(win) + w_small_flag(p, (int)(m & 1));
+            d.peer_ack[p] = words(peer_win[p]) + w_small_ack(rank);
+        }
+        d.err = err_dev; d.timeout_ticks = timeout_ticks;
+        hipLaunchKernelGGL(k_ipc_small, dim3(1), dim3(256), 0, s, d);
+        if (hipGetLastError() != hipSuccess) return fail(FY_ERR_HIP, "ipc communicator: launch failed");
+        return FY_OK;
+    }
+    int allreduce(hipStream_t s, double* dev, int n, bool is_max) override {
+        count(1);
+        FY_TRY(check());
+        if (n > 32) return fail(FY_ERR_INVALID, "ipc communicator: all-reduce of more than 32 doubles");
+        // (the kernel reads `mine` = dev before any thread stores the fold to dev: the stores sit behind three block barriers)
+        return small(s, dev, n, nullptr, dev, is_max ? 0xffffffffu : 0u);
+    }
+    int allgather(hipStream_t s, const double* send, double* recv, size_t cnt) override {
+        count(2);
+        FY_TRY(check());
+        if (cnt <= 32 && send != recv + (size_t)rank * cnt) return small(s, send, (int)cnt, recv, nullptr, 0u);
+        if (cnt <= 32) {                                         // gathered in place: through the scratch
+            FY_HIP(hipMemcpyAsync(small_scratch, send, cnt * sizeof(double), hipMemcpyDeviceToDevice, s));
+            return small(s, small_scratch, (int)cnt, recv, nullptr, 0u);
+        }
+        std::vector<Piece> tx{Piece{send, nullptr, cnt}};
+        const size_t chunks = n_chunks(tx, slot_coll);
+        for (size_t c = 0; c < chunks; ++c) {
+            for (int p = 0; p < size; ++p) {
+                if (p == rank) continue;
+                const u64 m = coll_tx[(size_t)p]++;
+                IpcXfer d{};
+                const size_t nn = chunk_segs(tx, slot_coll, c, data(peer_win[(size_t)p]) + d_coll_slot(rank, (int)(m & 1)), true, d);
+                d.wait = m >= 2 ? words(win) + w_coll_ack(p) : nullptr; d.wait_min = m >= 1 ? m - 1 : 0;
+                d.signal = words(peer_win[(size_t)p]) + w_coll_flag(rank, (int)(m & 1)); d.signal_val = m + 1;
+                FY_TRY(launch(s, d, nn));
+            }
+            for (int p = 0; p < size; ++p) {
+                if (p == rank) continue;
+                const u64 m = coll_rx[(size_t)p]++;
+                std::vector<Piece> rx{Piece{nullptr, recv + (size_t)p * cnt, cnt}};
+                IpcXfer d{};
+                const size_t nn = chunk_segs(rx, slot_coll, c, data(win) + d_coll_slot(p, (int)(m & 1)), false, d);
+                d.wait = words(win) + w_coll_flag(p, (int)(m & 1)); d.wait_min = m + 1;
+                d.signal = words(peer_win[(size_t)p]) + w_coll_ack(rank); d.signal_val = m + 1;
+                FY_TRY(launch(s, d, nn));
+            }
+        }
+        if (recv + (size_t)rank * cnt != send) FY_HIP(hipMemcpyAsync(recv + (size_t)rank * cnt, send, cnt * sizeof(double), hipMemcpyDeviceToDevice, s));
+        return FY_OK;
+    }
+    int barrier(hipStream_t s) override {
+        FY_HIP(hipStreamSynchronize(s));
+        double z = 0.0;
+        if (cb.allreduce(cb.user, &z, 1, 0) != 0) return fail(FY_ERR_TRANSPORT, "ipc communicator: barrier failed");
+        return check();
+    }
+};
+
+}  // namespace
+
+int ipc_comm_create(int rank, int size, const fy_comm_callbacks* cb, int device, Comm** out) {
+    if (!out || !cb || !cb->allreduce || !cb->allgather || size < 1 || size > 8 || rank < 0 || rank >= size)
+        return fail(FY_ERR_INVALID, "bad ipc communicator arguments (1 .. 8 ranks; the callbacks carry the bootstrap: allgather + allreduce)");
+    FY_HIP(hipSetDevice(device));
+    std::unique_ptr<IpcComm> c(new IpcComm());
+    c->rank = rank; c->size = size; c->cb = *cb; c->device = device;
+    const char* e = std::getenv("FOAMYADE_IPC_SLOT_MB");
+    const size_t mb = e && std::atoi(e) > 0 ? (size_t)std::atoi(e) : 8;
+    c->slot_nb = mb * (1u << 20) / sizeof(double);
+    const char* ek = std::getenv("FOAMYADE_IPC_SLOT_KB");      // (tests: slots small enough that the test meshes' groups travel in chunks)
+    if (ek && std::atoi(ek) > 0) c->slot_nb = (size_t)std::atoi(ek) * 1024 / sizeof(double);
+    c->slot_coll = std::min<size_t>((256u << 10) / sizeof(double), c->slot_nb);
+    const char* t = std::getenv("FOAMYADE_IPC_TIMEOUT_MS");
+    const long long ms = t && std::atoll(t) > 0 ? std::atoll(t) : 20000;
+    c->timeout_ticks = ms * 100000;                               // wall_clock64: 100 MHz
+    c->win_bytes = c->header_bytes() + c->data_doubles() * sizeof(double);
+    // uncached device memory where the runtime offers it (a peer GPU's stores must not meet stale lines of this GPU's L2), plain device memory otherwise
+    hipIpcMemHandle_t mine;
+    void* w = nullptr;
+    if (hipExtMallocWithFlags(&w, c->win_bytes, hipDeviceMallocUncached) == hipSuccess && hipIpcGetMemHandle(&mine, w) == hipSuccess) c->ext_alloc = true;
+    else {
+        (void)hipGetLastError();
+        if (w) (void)hipFree(w);
+        w = nullptr;
+        FY_HIP(hipMalloc(&w, c->win_bytes));
+        FY_HIP(hipIpcGetMemHandle(&mine, w));
+    }
+    c->win = static_cast<char*>(w);
+    FY_HIP(hipMemset(c->win, 0, c->header_bytes()));
+    FY_HIP(hipMalloc((void**)&c->counters, IpcComm::kCounters * sizeof(unsigned int)));
+    FY_HIP(hipMemset(c->counters, 0, IpcComm::kCounters * sizeof(unsigned int)));
+    FY_HIP(hipMalloc((void**)&c->small_scratch, 32 * sizeof(double)));
+    FY_HIP(hipHostMalloc((void**)&c->err_host, sizeof(unsigned int), hipHostMallocMapped));
+    *c->err_host = 0u;
+    FY_HIP(hipHostGetDevicePointer((void**)&c->err_dev, c->err_host, 0));
+    FY_HIP(hipDeviceSynchronize());
+    // the handles travel as doubles through the caller's all-gather (64 bytes = 8 doubles; the bit patterns are only copied)
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
+    std::vector<double> send(8), all(8 * (size_t)size);
+    std::memcpy(send.data(), &mine, 64);
+    if (cb->allgather(cb->user, send.data(), all.data(), 8) != 0) return fail(FY_ERR_TRANSPORT, "ipc communicator: the bootstrap all-gather failed");
+    c->peer_win.assign((size_t)size, nullptr);
+    c->coll_tx.assign((size_t)size, 0); c->coll_rx.assign((size_t)size, 0); c->small_msg.assign(1, 0);
+    int bad = 0;
+    for (int p = 0; p < size; ++p) {
+        if (p == rank) continue;
+        hipIpcMemHandle_t h;
+        std::memcpy(&h, all.data() + 8 * (size_t)p, 64);
+        void* pw = nullptr;
+        if (hipIpcOpenMemHandle(&pw, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); bad = 1; break; }
+        c->peer_win[(size_t)p] = static_cast<char*>(pw);
+    }
+    // every rank learns whether every rank could map its peers (and nobody starts storing into a window that is not zeroed yet)
+    double ok = bad ? 0.0 : 1.0, worst = ok;
+    {
+        std::vector<double> flags((size_t)size);
+        if (cb->allgather(cb->user, &ok, flags.data(), 1) != 0) return fail(FY_ERR_TRANSPORT, "ipc communicator: the bootstrap all-gather failed");
+        for (double f : flags) worst = std::min(worst, f);
+    }
+    if (worst < 1.0) return fail(FY_ERR_TRANSPORT, "ipc communicator: hipIpcOpenMemHandle failed on rank %s (peers in ONE process cannot map each other: use the local group there)", bad ? "this" : "another");
+    *out = c.release();
+    return FY_OK;
+}
+
 // ================================================================================================ RcclComm
 namespace {
 

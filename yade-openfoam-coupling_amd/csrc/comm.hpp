@@ -2,9 +2,10 @@
 //   * neighbour exchange of contiguous z-plane blocks (FV halos 1 plane, particle halos 5 planes, reverse sums),
 //   * tiny all-reduces (Krylov scalars, Courant number, continuity errors, residual norms),
 //   * an all-gather (coarse multigrid right-hand sides).
-// Two back-ends behind one interface:
+// Back-ends behind one interface:
 //   RcclComm   one process per GPU, RCCL (ncclSend/ncclRecv/ncclAllReduce/ncclAllGather) on the solver's stream over xGMI;
 //              librccl is dlopen()ed on first use so the library still loads on hosts without it;
+//   IpcComm    one process per GPU -- or N processes on ONE GPU -- with direct peer stores into hipIpc-mapped windows (no library between the GPUs);
 //   LocalComm  N "virtual slabs" inside one process (one host thread per slab, device-to-device copies, host barriers): the
 //              same solver code runs unmodified, which is how the decomposition is tested on a single-GPU box.
 #pragma once
@@ -99,6 +100,8 @@ struct SelfComm : Comm {                                   // size 1: every call
 
 // HostComm: one process per slab, planes staged through pinned host memory, the inter-process transport is the caller's (callbacks)
 int host_comm_create(int rank, int size, const fy_comm_callbacks* cb, Comm** out);
+// IpcComm: one process per slab, peer stores into each other's device windows (hipIpc); the callbacks carry the bootstrap only (all-gather of the handles)
+int ipc_comm_create(int rank, int size, const fy_comm_callbacks* cb, int device, Comm** out);
 // LocalComm group: create `n` communicators that talk to each other inside this process
 int local_comm_group_create(int n, Comm** out /* [n] */);
 // RCCL: unique id = 128 opaque bytes produced on rank 0 (fy_rccl_unique_id) and broadcast by the launcher

@@ -59,6 +59,13 @@ int fy_comm_create_host(int rank, int size, const fy_comm_callbacks* cb, fy_comm
     *out = new fy_comm(); (*out)->c = c;
     return FY_OK;
 }
+int fy_comm_create_ipc(int rank, int size, const fy_comm_callbacks* cb, int device, fy_comm** out) {
+    if (!out) return fy::fail(FY_ERR_INVALID, "null out");
+    fy::Comm* c = nullptr;
+    FY_TRY(fy::ipc_comm_create(rank, size, cb, device, &c));
+    *out = new fy_comm(); (*out)->c = c;
+    return FY_OK;
+}
 int fy_rccl_unique_id(void* out128) { return fy::rccl_unique_id(out128); }
 int fy_comm_create_rccl(int rank, int size, const void* id128, int device, fy_comm** out) {
     if (!out) return fy::fail(FY_ERR_INVALID, "null out");
