@@ -752,16 +752,34 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
+    # FOAMYADE_COMM=rccl (default) | ipc: the slab transport.  ipc = the library's peer-store communicator (fy_comm_create_ipc: kernels that
+    # store into the neighbours' hipIpc-mapped device windows); torch.distributed then only carries its bootstrap and this script's own timing collectives, over
+    # gloo.  It is also what runs when the ranks outnumber the GPUs (N processes on one GPU: RCCL refuses duplicate devices), loudly labelled.
+    n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    comm_kind = os.environ.get("FOAMYADE_COMM", "rccl").lower()
+    if comm_kind not in ("rccl", "ipc"):
+        raise SystemExit(f"bench.py: FOAMYADE_COMM={comm_kind}: rccl or ipc")
+    if world > 1 and n_dev and world > n_dev and comm_kind == "rccl":
+        comm_kind = "ipc"
+        if rank == 0:
+            print(f"[bench] WARNING: {world} ranks on {n_dev} GPU(s): RCCL cannot run with ranks sharing a device; using the peer-store transport (FOAMYADE_COMM=ipc), "
+                  f"the ranks TIME-SHARE the GPU(s) -- this is not a scaling measurement", file=sys.stderr, flush=True)
+    local_dev = local_rank % max(n_dev, 1)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(local_dev)
+        if comm_kind == "ipc":
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_dev))
     assert world == args.gpus, f"WORLD_SIZE {world} != --gpus {args.gpus}"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product has no CPU path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
+    ddev = torch.device("cpu") if (dist is not None and comm_kind == "ipc") else dev      # where this script's own torch.distributed tensors live
+    local_rank = local_dev
 
     prod = ge.load_product()
     c2, c5 = args.config == "c2", args.config == "c5"
@@ -783,13 +801,18 @@ def main():
     case = c2_case(prod, args.dt, args.p_solver) if c2 else c5_case(prod, args.dt, args.p_solver, args.n) if c5 else c3_case(prod, args.n, args.dt, args.p_solver, world, strong)
     comm, solver, setup_err = None, None, ""
     try:
-        if world > 1 and not os.environ.get("FOAMYADE_BENCH_NO_PREFLIGHT"):
+        if world > 1 and comm_kind == "rccl" and not os.environ.get("FOAMYADE_BENCH_NO_PREFLIGHT"):
             why = rccl_preflight(prod, torch, dist, dev, rank, world)
             t = torch.tensor([0.0 if why else 1.0], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MIN)                  # every rank must take the same path
             if float(t.item()) < 1.0:
                 raise RuntimeError(why or "RCCL self-test failed on another rank")
-        if world > 1 or args.force_rccl:
+        ipc_comm = None
+        if world > 1 and comm_kind == "ipc":
+            os.environ.setdefault("FOAMYADE_TREE_CACHE_DIR", "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp")
+            ipc_comm = prod.GlooIpcComm(dist, local_rank)
+            comm = ipc_comm.handle
+        elif world > 1 or args.force_rccl:
             # one RCCL communicator for the slab exchanges; the 128-byte unique id travels over torch.distributed
             os.environ.setdefault("FOAMYADE_TREE_CACHE_DIR", "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp")
             idt = torch.zeros(128, dtype=torch.uint8, device=dev)
@@ -804,10 +827,12 @@ def main():
     # every rank must take the same path: agree on whether the slab set-up worked everywhere
     slabs_ok = 0.0 if setup_err else 1.0
     if dist is not None:
-        t = torch.tensor([slabs_ok], dtype=torch.float64, device=dev)
+        t = torch.tensor([slabs_ok], dtype=torch.float64, device=ddev)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         slabs_ok = float(t.item())
-    parallelism = "single GPU" if world == 1 else f"{world} z-slabs of one {args.n}x{args.n}x{args.n if strong else args.n * world} box, RCCL halos + all-reduces over xGMI"
+    via = "RCCL halos + all-reduces over xGMI" if comm_kind == "rccl" else ("peer stores into hipIpc-mapped device windows (fy_comm_create_ipc)" +
+                                                                            (f"; {world} ranks TIME-SHARE {n_dev} GPU(s): not a scaling measurement" if world > n_dev else ""))
+    parallelism = "single GPU" if world == 1 else f"{world} z-slabs of one {args.n}x{args.n}x{args.n if strong else args.n * world} box, {via}"
     slab_of_rank = rank
     if slabs_ok < 1.0:
         if world == 1:
@@ -876,7 +901,7 @@ def main():
             acc["locate_deposit"] += ct["locate_deposit"]; acc["force"] += ct["force"]; acc["bin"] += ct["bin"]; acc["finalize"] += ct["finalize"]; acc["fold"] += ct["fold"]
             acc["p_iters"] += st["p_iters_total"]; acc["u_iters"] += st["u_iters_total"]
         barrier()
-        return acc, max_over_ranks(time.perf_counter() - t0, dist, dev)
+        return acc, max_over_ranks(time.perf_counter() - t0, dist, ddev)
 
     acc, elapsed = timed_region(args.steps, args.moving)
 
@@ -987,7 +1012,7 @@ def main():
             torch.cuda.synchronize()
             w = solver.exchange_wait()
             mine = torch.tensor([w[k][0] / n_x for k in ("step_start", "particle", "momentum", "corrector")] +
-                                [float(w[k][1]) / n_x for k in ("step_start", "particle", "momentum", "corrector")], dtype=torch.float64, device=dev)
+                                [float(w[k][1]) / n_x for k in ("step_start", "particle", "momentum", "corrector")], dtype=torch.float64, device=ddev)
             allw = [torch.zeros_like(mine) for _ in range(world)]
             dist.all_gather(allw, mine)
             solver.enable_exchange_timing(False)
@@ -1117,6 +1142,10 @@ def main():
         sys.stdout.flush()
         print(json.dumps(out), flush=True)
     if dist is not None:
+        if solver is not None:
+            solver.close(); solver = None
+        if 'ipc_comm' in locals() and ipc_comm is not None:
+            ipc_comm.close()                    # (collective: the windows are unmapped behind a barrier of the bootstrap group)
         dist.destroy_process_group()
 
 
