@@ -698,6 +698,10 @@ __device__ __forceinline__ void quad_transpose(uint4& m0, uint4& m1, uint4& m2, 
     quad_transpose(m0.x, m1.x, m2.x, m3.x, b0, b1); quad_transpose(m0.y, m1.y, m2.y, m3.y, b0, b1);
     quad_transpose(m0.z, m1.z, m2.z, m3.z, b0, b1); quad_transpose(m0.w, m1.w, m2.w, m3.w, b0, b1);
 }
+__device__ __forceinline__ double2 quad_pick(double2 v0, double2 v1, double2 v2, double2 v3, int lq) {
+    const double2 lo = lq & 1 ? v1 : v0, hi = lq & 1 ? v3 : v2;
+    return lq & 2 ? hi : lo;
+}
 __device__ __forceinline__ double2 as_double2(uint4 v) {
     return make_double2(__hiloint2double((int)v.y, (int)v.x), __hiloint2double((int)v.w, (int)v.z));
 }
