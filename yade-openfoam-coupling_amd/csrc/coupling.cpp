@@ -711,25 +711,47 @@ int Coupling::run_batch(Batch& b) {
         // schedule, in the same order per cell: the same bits.
         const bool ovl = slab_overlap() && slab.nz > 2 * slab.gz;
         auto pack_records = [&]() -> int {
-            if (cellrec_fresh) return FY_OK;
+            if (cellrec_fresh && !cellrec_ghosts_stale) return FY_OK;
             if (slab.fields_event) { FY_HIP(hipStreamWaitEvent(stream, slab.fields_event, 0)); slab.fields_event = nullptr; }      // gradP / divT ghost planes have landed
-            FY_TRY(launch_pack_cells(stream, n_field, dU, dAlpha, dGradP, dDivT, d_vol.p, nu, rhoF, d_cellrec.p));
-            cellrec_fresh = true;
+            if (cellrec_fresh) {
+                // a slab whose solver's pre-coupling sweep wrote the records of the OWNED cells (fy_solver, as on a single domain): what is left are the
+                // ghost planes either side, whose gradP / divT came from the neighbours -- 2 gz planes instead of nz + 2 gz
+                const size_t gc = (size_t)slab.gz * slab.plane, hi = (size_t)(slab.gz + slab.nz) * slab.plane;
+                FY_TRY(launch_pack_cells(stream, (int64_t)gc, dU, dAlpha, dGradP, dDivT, d_vol.p, nu, rhoF, d_cellrec.p));
+                FY_TRY(launch_pack_cells(stream, (int64_t)gc, dU + 3 * hi, dAlpha + hi, dGradP + 3 * hi, dDivT + 3 * hi, d_vol.p + hi, nu, rhoF, d_cellrec.p + 8 * hi));
+            } else {
+                FY_TRY(launch_pack_cells(stream, n_field, dU, dAlpha, dGradP, dDivT, d_vol.p, nu, rhoF, d_cellrec.p));
+            }
+            cellrec_fresh = true; cellrec_ghosts_stale = false;
             return FY_OK;
         };
+        // z-slabs: the 8-plane tile layers that lie wholly inside the planes no reverse halo reaches ([2 gz, nz) in storage planes) are finished by the
+        // reduction itself (k_tile_reduce<3> / <4>); k_finalize_cells / k_fold_sources keep the planes outside [z0, z1)
+        int tk_lo = 0, tk_hi = 0;
+        if (slab.active && tbD.cell) { tk_lo = (2 * slab.gz + 7) / 8; tk_hi = slab.nz / 8; if (tk_hi <= tk_lo) tk_lo = tk_hi = 0; }
+        const bool layers = tk_hi > tk_lo && getenv("FOAMYADE_NO_TILE_LAYERS") == nullptr;
+        const int64_t z0 = 8 * (int64_t)tk_lo * (int64_t)slab.plane, z1 = 8 * (int64_t)tk_hi * (int64_t)slab.plane;
         if (!ovl) FY_TRY(pack_records());
         if (side.stream && ll.lists) FY_HIP(hipStreamWaitEvent(stream, side.join, 0));
         if (tbD.cell && !slab.active) {      // single domain: the tile's sums are complete, setCellVolFraction rides on the reduction
             FY_TRY(launch_tile_reduce_finalize(stream, tbD, d_pvol_acc.p, d_up_acc.p, d_touched.p, d_vol.p, dAlpha, dUParticle, d_cellrec.p));
         } else if (!ovl) {
-            FY_TRY(launch_tile_reduce(stream, tbD, d_pvol_acc.p, d_up_acc.p, d_touched.p));
+            auto finalize = [&](int64_t c0, int64_t c1) -> int {
+                if (c1 <= c0) return FY_OK;
+                return launch_finalize_cells(stream, (int32_t)(c1 - c0), d_vol.p + c0, d_pvol_acc.p + c0, d_up_acc.p + 3 * c0, d_touched.p + c0, dAlpha + c0, dUParticle + 3 * c0,
+                                             d_cellrec.p + 8 * c0);
+            };
+            if (layers) FY_TRY(launch_tile_reduce_finalize_layers(stream, tbD, d_pvol_acc.p, d_up_acc.p, d_touched.p, d_vol.p, dAlpha, dUParticle, d_cellrec.p, tk_lo, tk_hi));
+            else FY_TRY(launch_tile_reduce(stream, tbD, d_pvol_acc.p, d_up_acc.p, d_touched.p));
             if (slab.active) {      // contributions that landed in ghost planes belong to the neighbours: send them home and add
                 FY_TRY(halo_reverse_add2(d_pvol_acc.p, 1, d_touched.p, d_up_acc.p, 3));
             }
-            FY_TRY(launch_finalize_cells(stream, (int32_t)n_field, d_vol.p, d_pvol_acc.p, d_up_acc.p, d_touched.p, dAlpha, dUParticle, d_cellrec.p));
+            if (layers) { FY_TRY(finalize(0, z0)); FY_TRY(finalize(z1, (int64_t)n_field)); }
+            else FY_TRY(finalize(0, (int64_t)n_field));
         } else {
             FY_TRY(slab_events());
-            FY_TRY(launch_tile_reduce(stream, tbD, d_pvol_acc.p, d_up_acc.p, d_touched.p));
+            if (layers) FY_TRY(launch_tile_reduce_finalize_layers(stream, tbD, d_pvol_acc.p, d_up_acc.p, d_touched.p, d_vol.p, dAlpha, dUParticle, d_cellrec.p, tk_lo, tk_hi));
+            else FY_TRY(launch_tile_reduce(stream, tbD, d_pvol_acc.p, d_up_acc.p, d_touched.p));
             FY_HIP(hipEventRecord(slab.ev_a, stream));
             FY_TRY(pack_records());                                            // (enqueued first: a host-synchronous back-end blocks in the exchange while this runs)
             FY_HIP(hipStreamWaitEvent(slab.aux, slab.ev_a, 0));
@@ -740,13 +762,15 @@ int Coupling::run_batch(Batch& b) {
             // cells [lo0, lo1) and [hi0, hi1): the ghost planes and the gz owned planes next to them, either end; [lo1, hi0): the interior
             const int64_t pl = (int64_t)slab.plane, lo1 = 2 * (int64_t)slab.gz * pl, hi0 = (int64_t)slab.nz * pl, hi1 = (int64_t)n_field;
             auto finalize = [&](int64_t c0, int64_t c1) -> int {
+                if (c1 <= c0) return FY_OK;
                 return launch_finalize_cells(stream, (int32_t)(c1 - c0), d_vol.p + c0, d_pvol_acc.p + c0, d_up_acc.p + 3 * c0, d_touched.p + c0, dAlpha + c0, dUParticle + 3 * c0,
                                              d_cellrec.p + 8 * c0);
             };
             FY_TRY(finalize(0, lo1));
             FY_TRY(finalize(hi0, hi1));
             FY_HIP(hipEventRecord(slab.ev_a, stream));
-            FY_TRY(finalize(lo1, hi0));                                        // ... beside alpha's ghost planes
+            if (layers) { FY_TRY(finalize(lo1, z0)); FY_TRY(finalize(z1, hi0)); }      // (what the reduction did not finish itself) ...
+            else FY_TRY(finalize(lo1, hi0));                                   // ... beside alpha's ghost planes
             FY_HIP(hipStreamWaitEvent(slab.aux, slab.ev_a, 0));
             FY_TRY(halo_fwd(dAlpha, 1, slab.gz, slab.aux));
             FY_HIP(hipEventRecord(slab.ev_b, slab.aux));
@@ -776,16 +800,20 @@ int Coupling::run_batch(Batch& b) {
         if (tbB.cell && !slab.active) {      // single domain: the fold rides on the reduction
             FY_TRY(launch_tile_reduce_fold(stream, tbB, d_drag_acc.p, dUSource, dUParticle, dUSourceDrag));
         } else {
-            FY_TRY(launch_tile_reduce(stream, tbB, d_drag_acc.p, dUSource, nullptr));
+            const bool layersB = layers && tbB.cell;
+            if (layersB) FY_TRY(launch_tile_reduce_fold_layers(stream, tbB, d_drag_acc.p, dUSource, dUParticle, dUSourceDrag, tk_lo, tk_hi));
+            else FY_TRY(launch_tile_reduce(stream, tbB, d_drag_acc.p, dUSource, nullptr));
             // FoamYade.C:385-386 per cell: uSourceDrag += D, uSource += uParticle * D (this batch's uParticle: the owner's, after its finalize)
             if (ovl) {
                 // the reverse halo of the drag sums and of uSource beside the fold of the interior cells, which receive nothing from the neighbours
                 FY_HIP(hipEventRecord(slab.ev_a, stream));
                 const int64_t pl = (int64_t)slab.plane, lo1 = 2 * (int64_t)slab.gz * pl, hi0 = (int64_t)slab.nz * pl, hi1 = (int64_t)n_field;
                 auto fold = [&](int64_t c0, int64_t c1) -> int {
+                    if (c1 <= c0) return FY_OK;
                     return launch_fold_sources(stream, c1 - c0, d_drag_acc.p + c0, dUParticle + 3 * c0, dUSourceDrag + c0, dUSource + 3 * c0);
                 };
-                FY_TRY(fold(lo1, hi0));
+                if (layersB) { FY_TRY(fold(lo1, z0)); FY_TRY(fold(z1, hi0)); }
+                else FY_TRY(fold(lo1, hi0));
                 FY_HIP(hipStreamWaitEvent(slab.aux, slab.ev_a, 0));
                 FY_TRY(halo_reverse_start(d_drag_acc.p, 1, dUSource, 3, slab.aux));
                 FY_HIP(hipEventRecord(slab.ev_b, slab.aux));
@@ -795,7 +823,12 @@ int Coupling::run_batch(Batch& b) {
                 FY_TRY(fold(hi0, hi1));
             } else {
                 if (slab.active) FY_TRY(halo_reverse_add2(d_drag_acc.p, 1, nullptr, dUSource, 3));
-                FY_TRY(launch_fold_sources(stream, n_field, d_drag_acc.p, dUParticle, dUSourceDrag, dUSource));
+                if (layersB) {
+                    if (z0 > 0) FY_TRY(launch_fold_sources(stream, z0, d_drag_acc.p, dUParticle, dUSourceDrag, dUSource));
+                    if (n_field > z1) FY_TRY(launch_fold_sources(stream, n_field - z1, d_drag_acc.p + z1, dUParticle + 3 * z1, dUSourceDrag + z1, dUSource + 3 * z1));
+                } else {
+                    FY_TRY(launch_fold_sources(stream, n_field, d_drag_acc.p, dUParticle, dUSourceDrag, dUSource));
+                }
             }
         }
         if (timing) marks.mark(5, stream);
@@ -849,6 +882,7 @@ int Coupling::set_particle_action(double dt) {
     mid_hook_done = false;
     if (!gaussian || n_batches == 0 || fields_on_host) FY_TRY(run_mid_hook());      // (nobody further down would, or the sweep's output is needed at once)
     cellrec_fresh = cellrec_external;       // (fy_solver's pre-coupling sweep may have written the records already)
+    cellrec_ghosts_stale = cellrec_external && slab.active;      // (... of the owned cells: a slab's ghost planes are packed here, when the neighbours' fields have landed)
     cellrec_external = false;
 
     // ---- receive particles, and per Yade proc: locate + deposit + finalize + force (FoamYade.C:609, 612-628).  With a transport every

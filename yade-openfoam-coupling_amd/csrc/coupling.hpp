@@ -141,6 +141,7 @@ struct Coupling {
     DevBuf<double> d_pvol_acc, d_up_acc;           // per-batch deposit accumulators (pVolContrib / uParticleContrib)
     bool cellrec_fresh = false;                    // d_cellrec was packed in this setParticleAction call
     hipEvent_t ev_last_caps = nullptr;            // the latest end-of-batch capacities kernel on the side stream (it also clears d_loc_fb_n); not owned
+    bool cellrec_ghosts_stale = false;             // slab: the caller's sweep wrote the OWNED cells' records only
     bool cellrec_external = false;                 // ... by the caller (fy_solver's pre-coupling sweep), for the NEXT setParticleAction only
     DevBuf<double> d_cellrec;                      // 8 doubles per cell: what the force pass gathers (k_pack_cells), rebuilt every setParticleAction
     DevBuf<double> d_drag_acc;                     // per-batch sum of -coeff w / rho_f per cell, folded into uSourceDrag / uSource by k_fold_sources

@@ -14,6 +14,28 @@
 #define FY_FVK_GRADED 0
 #endif
 
+// register caps of the gather-first sweeps (waves per SIMD the compiler must leave room for; 0 = its own choice): build-time constants, measured per kernel
+#ifndef FY_WPE_FRONT
+#define FY_WPE_FRONT 4
+#endif
+#ifndef FY_WPE_BACK
+#define FY_WPE_BACK 0
+#endif
+#ifndef FY_WPE_PRE
+#define FY_WPE_PRE 0
+#endif
+#ifndef FY_WPE_BMOM
+#define FY_WPE_BMOM 0
+#endif
+#define FY_WPE_ATTR_(n) __attribute__((amdgpu_waves_per_eu(n)))
+#define FY_WPE_ATTR(n) FY_WPE_ATTR_IF(n)
+#define FY_WPE_ATTR_IF(n) FY_WPE_PICK_##n
+#define FY_WPE_PICK_0
+#define FY_WPE_PICK_4 FY_WPE_ATTR_(4)
+#define FY_WPE_PICK_5 FY_WPE_ATTR_(5)
+#define FY_WPE_PICK_6 FY_WPE_ATTR_(6)
+#define FY_WPE_PICK_7 FY_WPE_ATTR_(7)
+#define FY_WPE_PICK_8 FY_WPE_ATTR_(8)
 namespace fy {
 #if FY_FVK_GRADED
 namespace gr {
@@ -597,7 +619,7 @@ __global__ __launch_bounds__(256) void k_courant(FvGeo g, CFace3 phi, double* __
 // In pimple mode the only consumer of grad(U) is the explicit stress term of divDevRhoReff (the Gaussian torque that would read vGrad
 // is disabled in the reference, FoamYade.C:618), so the kernel can emit G = alpha nu dev2(T(grad U)) directly (Gout != nullptr) and
 // skip the 72 B/cell vGrad store (write_vgrad = 0): one stencil pass instead of two plus a tensor round trip through HBM.
-__global__ __launch_bounds__(256) void k_pre_coupling(FvGeo g, const double* __restrict__ U, const double* __restrict__ p,
+__global__ __launch_bounds__(256) FY_WPE_ATTR(FY_WPE_PRE) void k_pre_coupling(FvGeo g, const double* __restrict__ U, const double* __restrict__ p,
                                                       const double* __restrict__ alpha, CFace3 psn, double* __restrict__ vGrad,
                                                       double* __restrict__ gradP, double* __restrict__ divT, double* __restrict__ Gout,
                                                       int write_vgrad, int write_pfields, CFace3 phi, double* __restrict__ ddtU, double* __restrict__ Uold_out,
@@ -1209,7 +1231,7 @@ __global__ __launch_bounds__(256) void k_bmom(FvGeo g, const double* __restrict_
 // pimple: rAUcf / phicForces (UcEqn.H:15-20) and the momentum predictor's right-hand side (UcEqn.H:22-33) in one gather-first sweep:
 // k_rAUf_phi_forces_cells + k_bmom without the two face fields being read back; a cell forms its six faces' rAUcf and phicForces itself (same
 // expressions as rAUf_phi_forces_face), the face's owner stores phicForces (and rAUcf where somebody still streams it: rf_out.a[0] != nullptr)
-__global__ __launch_bounds__(256) void k_bmom_faces(FvGeo g, const double* __restrict__ rAU, const double* __restrict__ uSource, const double* __restrict__ src,
+__global__ __launch_bounds__(256) FY_WPE_ATTR(FY_WPE_BMOM) void k_bmom_faces(FvGeo g, const double* __restrict__ rAU, const double* __restrict__ uSource, const double* __restrict__ src,
                                                     const double* __restrict__ p, CFace3 psn, Face3 rf_out, Face3 pf_out, double* __restrict__ bmom) {
     const int t = fv_block(g, blockIdx.x, gridDim.x) * 256 + (int)threadIdx.x;
     if (t >= g.Nc) return;
@@ -1528,7 +1550,7 @@ __device__ __forceinline__ double ub_normal(const FvGeo& g, int patch, int d, do
 // flux correction + velocity correction [+ continuity errors + the next pass's Courant sums] in one sweep (icoFoamYade.C:127-137, pEqn.H:39-45,
 // continuityErrs.H, CourantNo.H): k_flux_correct_cells and k_U_correct<DIAG> without the face field between them
 template <bool DIAG, bool FFC>
-__global__ __launch_bounds__(256) void k_corr_back(FvGeo g, const double* __restrict__ p, CFace3 phiHbyA, FaceSrc rAUf, FaceSrc alphaf, CFace3 psn,
+__global__ __launch_bounds__(256) FY_WPE_ATTR(FY_WPE_BACK) void k_corr_back(FvGeo g, const double* __restrict__ p, CFace3 phiHbyA, FaceSrc rAUf, FaceSrc alphaf, CFace3 psn,
                                                    CFace3 phiForces, Face3 phi, const double* __restrict__ HbyA, const double* __restrict__ rAU,
                                                    double* __restrict__ U, const double* __restrict__ alpha, const double* __restrict__ alphaOld,
                                                    double* __restrict__ partials) {
@@ -1639,7 +1661,7 @@ __global__ __launch_bounds__(256) void k_corr_back(FvGeo g, const double* __rest
 // the term itself is rAUf dcorr [alphacf], the same product in every corrector.  STORE_A = false: a later corrector of the same momentum
 // assembly -- the matrix in A stands (same rAU, same alphacf)
 template <bool STORE_A, bool FFC>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k_corr_front(FvGeo g, const double* __restrict__ HbyA, const double* __restrict__ U, CFace3 dcorr,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FY_WPE_FRONT))) void k_corr_front(FvGeo g, const double* __restrict__ HbyA, const double* __restrict__ U, CFace3 dcorr,
                                                     FaceSrc rAUf, FaceSrc alphaf, CFace3 phiForces, Face3 phiHbyA, Face3 psn,
                                                     const double* __restrict__ rAU, const double* __restrict__ alpha, const double* __restrict__ alphaOld, PMat A,
                                                     double* __restrict__ rhs, const double* __restrict__ x, const double* __restrict__ xbar_dev, double xsum_val,

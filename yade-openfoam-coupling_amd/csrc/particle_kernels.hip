@@ -833,7 +833,10 @@ __device__ __forceinline__ void flush_table(const uint32_t* keys, const double* 
 // FINISH 2 (single domain, momentum-source back-scatter): likewise k_fold_sources (uSourceDrag += D, uSource += uParticle D).
 // Same operations on the same operands in the same order as the separate kernels: identical bits.  With FINISH != 0 every tile runs,
 // also one whose bucket is empty (its cells may have been reached by the fallback atomics).
-struct TileFinish { const double* vol; double* alpha; double* uParticle; double* R; const double* uParticleC; double* uSourceDrag; };
+// FINISH 3 / 4 (z-slabs): FINISH 1 / 2 for the tiles of the z-layers [fin.tk_lo, fin.tk_hi) -- planes that receive nothing from a neighbour's reverse halo,
+//          whose cells' sums are therefore complete here -- and FINISH 0 for the others, in ONE launch: the finish of the interior no longer costs a
+//          pass of its own over the accumulators (k_finalize_cells / k_fold_sources keep the few planes at the slab's ends).
+struct TileFinish { const double* vol; double* alpha; double* uParticle; double* R; const double* uParticleC; double* uSourceDrag; int tk_lo, tk_hi; };
 template <int FINISH>
 __global__ __launch_bounds__(256) void k_tile_reduce(TileBuckets tb, double* __restrict__ dst0, double* __restrict__ dst3, unsigned char* __restrict__ touched, TileFinish fin) {
     __shared__ double acc[kTileCells * 4];
@@ -841,7 +844,10 @@ __global__ __launch_bounds__(256) void k_tile_reduce(TileBuckets tb, double* __r
     uint32_t cnt = tb.fill[tile];
     const uint32_t cap = tb.cap[tile];
     if (cnt > cap) cnt = cap;
-    if (FINISH == 0 && cnt == 0) return;                    // (block-uniform)
+    // (block-uniform; a compile-time constant for FINISH 0 .. 2)
+    const int tkz = (int)(tile / (uint32_t)(tb.tg.ntx * tb.tg.nty));
+    const int mode = FINISH >= 3 ? ((tkz >= fin.tk_lo && tkz < fin.tk_hi) ? FINISH - 2 : 0) : FINISH;
+    if (mode == 0 && cnt == 0) return;
     if (cnt) {
         for (int q = threadIdx.x; q < kTileCells * 4; q += 256) acc[q] = 0.0;
         __syncthreads();
@@ -864,14 +870,14 @@ __global__ __launch_bounds__(256) void k_tile_reduce(TileBuckets tb, double* __r
         if (cnt) { a0 = acc[agg_at<kTileCells>(l, 0)]; a1 = acc[agg_at<kTileCells>(l, 1)]; a2 = acc[agg_at<kTileCells>(l, 2)]; a3 = acc[agg_at<kTileCells>(l, 3)]; }
         const bool any = !(a0 == 0.0 && a1 == 0.0 && a2 == 0.0 && a3 == 0.0);
         const size_t c = (size_t)i + (size_t)tg.nx * ((size_t)j + (size_t)tg.ny * (size_t)k);
-        if (FINISH == 0) {
+        if (mode == 0) {
             if (!any) continue;
             dst0[c] += a0;
             double* d = dst3 + 3 * c;
             const double d0 = d[0] + a1, d1 = d[1] + a2, d2 = d[2] + a3;
             d[0] = d0; d[1] = d1; d[2] = d2;
             if (touched) touched[c] = 1;
-        } else if (FINISH == 1) {
+        } else if (mode == 1) {
             // the accumulators hold what the fallback atomics left (touched says so); they go back to zero, the cell is finished
             const bool t = touched[c] != 0;
             if (!any && !t) continue;
@@ -1918,14 +1924,29 @@ int launch_tile_reduce(hipStream_t s, TileBuckets tb, double* dst0, double* dst3
 int launch_tile_reduce_finalize(hipStream_t s, TileBuckets tb, double* pvol_acc, double* up_acc, unsigned char* touched, const double* vol, double* alpha,
                                 double* uParticle, double* R) {
     if (!tb.cell) return fail(FY_ERR_INVALID, "launch_tile_reduce_finalize without tile buckets");
-    hipLaunchKernelGGL(k_tile_reduce<1>, dim3((unsigned)tb.tg.n_tiles()), dim3(256), 0, s, tb, pvol_acc, up_acc, touched, TileFinish{vol, alpha, uParticle, R, nullptr, nullptr});
+    hipLaunchKernelGGL(k_tile_reduce<1>, dim3((unsigned)tb.tg.n_tiles()), dim3(256), 0, s, tb, pvol_acc, up_acc, touched, TileFinish{vol, alpha, uParticle, R, nullptr, nullptr, 0, 0});
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+
+// z-slabs: the tiles of the z-layers [tk_lo, tk_hi) are finished in the reduction (setCellVolFraction resp. the fold of the sources), the others only summed
+int launch_tile_reduce_finalize_layers(hipStream_t s, TileBuckets tb, double* pvol_acc, double* up_acc, unsigned char* touched, const double* vol, double* alpha,
+                                       double* uParticle, double* R, int tk_lo, int tk_hi) {
+    if (!tb.cell) return fail(FY_ERR_INVALID, "launch_tile_reduce_finalize_layers without tile buckets");
+    hipLaunchKernelGGL(k_tile_reduce<3>, dim3((unsigned)tb.tg.n_tiles()), dim3(256), 0, s, tb, pvol_acc, up_acc, touched, TileFinish{vol, alpha, uParticle, R, nullptr, nullptr, tk_lo, tk_hi});
+    FY_LAUNCH_CHECK();
+    return FY_OK;
+}
+int launch_tile_reduce_fold_layers(hipStream_t s, TileBuckets tb, double* drag_acc, double* uSource, const double* uParticle, double* uSourceDrag, int tk_lo, int tk_hi) {
+    if (!tb.cell) return fail(FY_ERR_INVALID, "launch_tile_reduce_fold_layers without tile buckets");
+    hipLaunchKernelGGL(k_tile_reduce<4>, dim3((unsigned)tb.tg.n_tiles()), dim3(256), 0, s, tb, drag_acc, uSource, nullptr, TileFinish{nullptr, nullptr, nullptr, nullptr, uParticle, uSourceDrag, tk_lo, tk_hi});
     FY_LAUNCH_CHECK();
     return FY_OK;
 }
 
 int launch_tile_reduce_fold(hipStream_t s, TileBuckets tb, double* drag_acc, double* uSource, const double* uParticle, double* uSourceDrag) {
     if (!tb.cell) return fail(FY_ERR_INVALID, "launch_tile_reduce_fold without tile buckets");
-    hipLaunchKernelGGL(k_tile_reduce<2>, dim3((unsigned)tb.tg.n_tiles()), dim3(256), 0, s, tb, drag_acc, uSource, nullptr, TileFinish{nullptr, nullptr, nullptr, nullptr, uParticle, uSourceDrag});
+    hipLaunchKernelGGL(k_tile_reduce<2>, dim3((unsigned)tb.tg.n_tiles()), dim3(256), 0, s, tb, drag_acc, uSource, nullptr, TileFinish{nullptr, nullptr, nullptr, nullptr, uParticle, uSourceDrag, 0, 0});
     FY_LAUNCH_CHECK();
     return FY_OK;
 }

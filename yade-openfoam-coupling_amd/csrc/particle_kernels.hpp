@@ -132,6 +132,10 @@ struct TileBuckets {               // all null: flush with global atomics (round
 // capacities / offsets for this step from the demand counted last step, demand counters reset (two bucket sets in one launch)
 int launch_tile_caps(hipStream_t s, TileBuckets a, TileBuckets b, unsigned int* also_zero = nullptr /* a counter the next locate pass wants cleared */);
 // dst0[c] += sum of the tile's entries' first value, dst3[c][0..2] += the other three; touched[c] = 1 where something arrived (nullable)
+// z-slabs: the same with the finish of launch_tile_reduce_finalize / _fold for the tiles of the z-layers [tk_lo, tk_hi) only (planes no reverse halo reaches)
+int launch_tile_reduce_finalize_layers(hipStream_t s, TileBuckets tb, double* pvol_acc, double* up_acc, unsigned char* touched, const double* vol, double* alpha,
+                                       double* uParticle, double* R, int tk_lo, int tk_hi);
+int launch_tile_reduce_fold_layers(hipStream_t s, TileBuckets tb, double* drag_acc, double* uSource, const double* uParticle, double* uSourceDrag, int tk_lo, int tk_hi);
 int launch_tile_reduce(hipStream_t s, TileBuckets tb, double* dst0, double* dst3, unsigned char* touched);
 // single domain: the reduction and what follows it per cell in ONE pass over the tiles -- launch_finalize_cells, resp. launch_fold_sources
 int launch_tile_reduce_finalize(hipStream_t s, TileBuckets tb, double* pvol_acc, double* up_acc, unsigned char* touched, const double* vol, double* alpha,
