@@ -273,7 +273,7 @@ __device__ __forceinline__ void block_reduce_store(double (&v)[N], const int (&i
 // flag != nullptr (out and flag in mapped host memory): the result is followed by a system-scope fence and flag[slot] = seq, which is
 // what the host spins on instead of waiting for the stream to drain (a stream synchronisation costs ~15 us of idle GPU per read-back).
 __global__ __launch_bounds__(1024) void k_reduce_finalize(const double* __restrict__ partials, int nblocks, const int* __restrict__ ops,
-                                                          double* __restrict__ out, unsigned long long* flag, unsigned long long seq, RedDecide dec) {
+                                                          double* __restrict__ out, unsigned long long* flag, unsigned long long seq) {
     __shared__ double sh[16];
     const int slot = blockIdx.x;
     const int mx = ops ? ops[slot] : 0;
@@ -297,35 +297,6 @@ __global__ __launch_bounds__(1024) void k_reduce_finalize(const double* __restri
         if (flag) {
             __threadfence_system();
             __hip_atomic_store(&flag[slot], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-        if (dec.kind) {
-            // the block that finishes last has every slot's sum before it: it applies the stopping rule
-            dec.state[8 + slot] = r;
-            __threadfence();
-            if (atomicAdd(dec.counter, 1u) == gridDim.x - 1) {
-                *dec.counter = 0u;
-                __threadfence();
-                double v[8];                                    // (loads that bypass this CU's L1: the other blocks' stores of a moment ago)
-                for (int q = 0; q < (int)gridDim.x && q < 8; ++q) v[q] = __hip_atomic_load(dec.state + 8 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                bool conv = true;
-                const int nq = dec.kind == 1 ? 3 : 1;
-                for (int q = 0; q < nq; ++q) {
-                    double norm = __hip_atomic_load(dec.state + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    double res0 = __hip_atomic_load(dec.state + 3 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (dec.first) {
-                        norm = (dec.kind == 1 ? v[3 + q] : v[1]) + 1e-20;
-                        res0 = v[q] / norm;
-                        dec.state[q] = norm; dec.state[3 + q] = res0;
-                    }
-                    const double res = v[q] / norm;
-                    if (!(res < dec.tol || (dec.rel > 0 && res < dec.rel * res0))) conv = false;
-                }
-                const int go = (conv || dec.out_of_iters) ? 0 : 1;
-                *dec.gate = go;
-                dec.verdict[0] = (double)go;
-                __threadfence_system();
-                __hip_atomic_store(&flag[dec.verdict_slot], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
         }
     }
 }
@@ -1288,7 +1259,6 @@ template <bool WITH_H>
 __global__ __launch_bounds__(256) void k_mom_pass(FvGeo g, Mom7 M, const double* __restrict__ b, const double* __restrict__ x,
                                                   double* __restrict__ xn, const double* __restrict__ xsum, double n_glob, double* __restrict__ partials,
                                                   const double* __restrict__ hsrc, const double* __restrict__ rAU, double* __restrict__ HbyA) {
-    if (g.gate && *g.gate == 0) return;                   // enqueued ahead of the host's look at the residual, and the solve had stopped (RedDecide)
     double v[6] = {0, 0, 0, 0, 0, 0};
     // xbar = average(x) (lduMatrix::solver::normFactor): the component sums stay on the device (k_sum3 + fold [+ all-reduce]); dividing
     // them here saves the host round trip the average used to make
@@ -1959,7 +1929,6 @@ __global__ __launch_bounds__(256) void k_mg_smooth_first(PMat A, const double* _
 __global__ __launch_bounds__(256) void k_mg_smooth_two_from_zero(PMat A, const double* __restrict__ b, double* __restrict__ xn, double w, double w2) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= A.N) return;
-    if (A.gate && *A.gate == 0) return;                   // (run-ahead: the solve had stopped)
     const int c = t + A.c0;
     const int sy = A.nx, sz = A.nx * A.ny, last = A.ntot - 1;
     const int xm = max(c - 1, 0), xp = min(c + 1, last), ym = max(c - sy, 0), yp = min(c + sy, last), zm = max(c - sz, 0), zp = min(c + sz, last);
@@ -2216,7 +2185,6 @@ __global__ __launch_bounds__(128) void k_pcg_cg_update2(int n, int c0, const dou
 __global__ __launch_bounds__(256) void k_mg_smooth_two_from_zero2(PMat A, const double* __restrict__ b, double* __restrict__ xn, double w, double w2) {
     const int t = (int)blockIdx.x * 512 + 2 * (int)threadIdx.x;
     if (t >= A.N) return;
-    if (A.gate && *A.gate == 0) return;                   // (run-ahead: the solve had stopped)
     const int c = t + A.c0;
     const PairIdx q = pair_idx(A, c);
     const P2 B = ld_p2(b, q), D = ld_p2(A.diag, q);
@@ -2677,10 +2645,8 @@ inline int fv_red_grid(const FvGeo& g) { return g.win_nblk > 0 ? g.win_nblk : re
 }  // namespace
 
 int launch_reduce_finalize(hipStream_t s, const double* partials, int n_cells, int nslots, const int* ops, double* out, unsigned long long* flag,
-                           unsigned long long seq, const RedDecide* dec) {
-    RedDecide d{};
-    if (dec && flag) d = *dec;
-    hipLaunchKernelGGL(k_reduce_finalize, dim3(nslots), dim3(1024), 0, s, partials, red_blocks(n_cells), ops, out, flag, seq, d);
+                           unsigned long long seq) {
+    hipLaunchKernelGGL(k_reduce_finalize, dim3(nslots), dim3(1024), 0, s, partials, red_blocks(n_cells), ops, out, flag, seq);
     FY_LAUNCH_CHECK();
     return FY_OK;
 }

@@ -61,8 +61,6 @@ struct FvGeo {
     // the host so that a sweep's interior planes run beside the halo exchange its end planes wait for; red_stride = blocks of the whole sweep (where
     // a reducing kernel's partial sums of slot q start: the fold sees the same partials whatever the windows were)
     int win_blk0, win_nblk, red_stride;
-    // run-ahead (fv_solver.cpp "kernels enqueued ahead of the host's look at a residual"): a kernel launched with gate != nullptr does nothing when *gate == 0
-    const int* gate;
 };
 
 struct Face3 { double* a[3]; };           // +axis oriented face arrays (x: (nx+1)*ny*nz, y: nx*(ny+1)*nz, z: nx*ny*(nz+1))
@@ -77,23 +75,6 @@ struct PMat {
     int nx, ny, nz, N;      // owned extent of this level
     int c0, ntot;           // storage index of the first owned cell, storage size (owned + ghost planes)
     double *diag, *ux, *uy, *uz;
-    const int* gate;        // run-ahead: k_mg_smooth_two_from_zero / 2 do nothing when gate != nullptr and *gate == 0
-};
-
-// The verdict of an iterative solve's stopping rule, formed ON THE DEVICE by the fold that produces the residual sums (k_reduce_finalize, its last block), so
-// that the next iteration's first kernel can already sit in the stream behind it: that kernel reads `gate` and does nothing when the solve has stopped.  The host
-// reads the same verdict (mapped memory) and never forms its own -- the two cannot disagree.  Same expressions as the host's loops had (lduMatrix-style
-// normalised L1 residuals, fv_solver.cpp solve_vec3 / fv_pressure.cpp solve_pressure).
-struct RedDecide {
-    int kind;               // 0: none; 1: slots 0..2 residual sums + 3..5 norm sums of a 3-component solve; 2: slot 0 = sum |r| (+ slot 1 = the norm sum when `first`)
-    int first;              // this fold opens the solve: it defines the norm factor(s) and the initial residual(s)
-    int out_of_iters;       // the iteration limit is reached after this pass: stop whatever the residual
-    double tol, rel;
-    double* state;          // device: [0..2] norm, [3..5] initial residuals, [8..15] this fold's slot values
-    int* gate;              // device: 1 = the solve goes on
-    unsigned int* counter;  // device: blocks of the fold that are done
-    double* verdict;        // mapped host memory: 1.0 = goes on, 0.0 = stops; flag[verdict_slot] = seq behind it
-    int verdict_slot;
 };
 
 // reducing kernels emit one partial per 256-cell block; the count is rounded up to a multiple of 8 for the XCD-aware block order

@@ -155,8 +155,7 @@ int Solver::vcycle(size_t l) {
     if (!L.distributed) {
         // first iterate and first sweep in one pass (bit-identical, see the kernel): one launch fewer on the latency-bound small
         // levels, and on level 0 the first iterate never travels through memory (pressure 2.25 -> 2.21 ms)
-        if (l == 0 && first_sweep_ahead) first_sweep_ahead = false;      // (already in the stream, behind the fold that let it run: solve_pressure)
-        else FY_TRY(launch_mg_smooth_two_from_zero(stream, L.A, L.bptr, L.xcur, W.w[0], W.w[1]));
+        FY_TRY(launch_mg_smooth_two_from_zero(stream, L.A, L.bptr, L.xcur, W.w[0], W.w[1]));
     } else {
         FY_TRY(launch_mg_smooth_first(stream, L.A, L.bptr, L.xcur, W.w[0]));
         FY_TRY(smooth(l, L, W.w[1]));
@@ -281,34 +280,14 @@ int Solver::solve_pressure(bool final_iter, bool init_done) {
         FY_TRY(prepare_p_init());
         FY_TRY(launch_p_init(stream, L.A, prhs.p, p.p, p_sum_valid ? nullptr : sc.p + 6, p_sum, 1.0 / (double)Nglob, pr.p, partials.p));
     }
-    // run-ahead (fv_solver.hpp): the stopping rule is applied by the fold on the device, and level 0's fused first two sweeps of the NEXT V-cycle go into the
-    // stream behind the fold, gated by its verdict -- single domain, multigrid preconditioner whose level 0 is swept by its own kernels
-    const bool ra = run_ahead && cs.p_solver == FY_PSOLVER_PCG_MG && !mg_deep && !L.distributed && mg.size() > 1 &&
-                    !(L.A.N <= kMgTailCells && mg.size() <= (size_t)kMgTailMax);
-    auto sweep_ahead = [&]() -> int {
-        PMat G = L.A; G.gate = ra_gate.p;
-        L.bptr = pr.p;
-        FY_TRY(launch_mg_smooth_two_from_zero(stream, G, L.bptr, L.xcur, mgw.w[0], mgw.w[1]));
-        first_sweep_ahead = true;
-        return FY_OK;
-    };
-    bool go = false;
-    if (ra) {
-        RedDecide d = ra_decide(2, true, cs.p_max_iter <= 0, tol, rel);
-        FY_TRY(reduce_launch(2, &d));
-        if (cs.p_max_iter > 0) FY_TRY(sweep_ahead());
-        FY_TRY(reduce_wait(2, h, true, &go));
-    } else {
-        FY_TRY(reduce_read(2, false, h));
-    }
+    FY_TRY(reduce_read(2, false, h));
     const double norm = h[1] + 1e-20;
     double res = h[0] / norm;
     const double res0 = res;
     st.p_initial_residual = res0;
     auto converged = [&](double r) { return r < tol || (rel > 0 && r < rel * res0); };
-    if (!ra) go = !converged(res);
     int it = 0;
-    if (go) {
+    if (!converged(res)) {
         do {
             const double* u;
             bool u_ghosts = false;                             // u valid one plane into the ghosts already
@@ -342,20 +321,11 @@ int Solver::solve_pressure(bool final_iter, bool init_done) {
                 }
             }
             p_ghosts_fresh = false;
-            if (ra) {
-                RedDecide d = ra_decide(2, false, it + 1 >= cs.p_max_iter, tol, rel);
-                FY_TRY(reduce_launch(2, &d));
-                if (it + 1 < cs.p_max_iter) FY_TRY(sweep_ahead());
-                FY_TRY(reduce_wait(2, h, true, &go));
-            } else {
-                FY_TRY(reduce_read(2, false, h));
-            }
+            FY_TRY(reduce_read(2, false, h));
             res = h[0] / norm;
             p_sum = h[1]; p_sum_valid = true;
-            if (!ra) go = !converged(res);
-        } while (++it < cs.p_max_iter && go);
+        } while (++it < cs.p_max_iter && !converged(res));
     }
-    first_sweep_ahead = false;                              // (the sweep enqueued behind the last fold found its gate shut)
     st.p_final_residual = res;
     st.p_iters_total += it; st.p_solves += 1;
     return FY_OK;

@@ -214,10 +214,6 @@ int Solver::create(const fy_case_desc* c, const fy_transport* tr, int dev, Comm*
     }
     FY_TRY(ops_courant.alloc_exact(2));
     FY_TRY(ops_diag.alloc_exact(4));
-    FY_TRY(ra_state.alloc_exact(16)); FY_TRY(ra_gate.alloc_exact(1)); FY_TRY(ra_counter.alloc_exact(1));
-    FY_HIP(hipMemsetAsync(ra_state.p, 0, 16 * sizeof(double), stream)); FY_HIP(hipMemsetAsync(ra_gate.p, 0, sizeof(int), stream));
-    FY_HIP(hipMemsetAsync(ra_counter.p, 0, sizeof(unsigned int), stream));
-    run_ahead = S == 1 && red_host && red_flag && getenv("FOAMYADE_NO_RUN_AHEAD") == nullptr;
     { const int h4[4] = {0, 0, 1, 0}; FY_HIP(hipMemcpyAsync(ops_diag.p, h4, sizeof(h4), hipMemcpyHostToDevice, stream)); }
     { const int h[2] = {1, 0}; FY_HIP(hipMemcpyAsync(ops_courant.p, h, sizeof(h), hipMemcpyHostToDevice, stream)); FY_HIP(hipStreamSynchronize(stream)); }
 
@@ -332,37 +328,8 @@ int Solver::create(const fy_case_desc* c, const fy_transport* tr, int dev, Comm*
     return FY_OK;
 }
 
-// the flag path of reduce_read in two halves (run-ahead: fv_solver.hpp)
-int Solver::reduce_launch(int nslots, RedDecide* dec) {
-    if (cpl) FY_TRY(cpl->c.poll_results());
-    if (dec) { dec->state = ra_state.p; dec->gate = ra_gate.p; dec->counter = ra_counter.p; dec->verdict = red_host_dev + nslots; dec->verdict_slot = nslots; }
-    return launch_reduce_finalize(stream, partials.p, Nc, nslots, nullptr, red_host_dev, red_flag_dev, ++red_seq, dec);
-}
-int Solver::reduce_wait(int nslots, double* h, bool with_verdict, bool* go) {
-    // spin on the flags the fold stores behind its results; everything enqueued before it has completed by then (in-order stream)
-    const unsigned long long seq = red_seq;
-    for (int q = 0; q < nslots + (with_verdict ? 1 : 0); ++q) {
-        unsigned long spins = 0;
-        while (__atomic_load_n(&red_flag[q], __ATOMIC_ACQUIRE) != seq) {
-            if ((++spins & 0x3ffu) == 0 && cpl) FY_TRY(cpl->c.poll_results());      // (answers that have landed meanwhile go out: Coupling::poll_results)
-            if ((spins & 0xfffu) == 0) {                        // every 4096 polls: is the stream still alive?
-                const hipError_t e = hipStreamQuery(stream);
-                if (e == hipSuccess) { if (__atomic_load_n(&red_flag[q], __ATOMIC_ACQUIRE) == seq) break; return fail(FY_ERR_HIP, "reduction flag never arrived"); }
-                if (e != hipErrorNotReady) return fail(FY_ERR_HIP, "stream failed while waiting for a reduction: %s", hipGetErrorString(e));
-            }
-        }
-        if (q < nslots) h[q] = red_host[q];
-        else if (go) *go = red_host[q] != 0.0;
-    }
-    return FY_OK;
-}
-
 // fold the block partials, all-reduce over the slabs, read back
 int Solver::reduce_read(int nslots, bool courant, double* h) {
-    if (comm->size == 1 && red_host && red_flag && nslots <= 8 && !courant) {
-        FY_TRY(reduce_launch(nslots, nullptr));
-        return reduce_wait(nslots, h, false, nullptr);
-    }
     if (cpl) FY_TRY(cpl->c.poll_results());
     if (comm->size == 1 && red_host) {
         // single domain: the fold writes straight into mapped pinned host memory -- no device-to-host blit per read-back
@@ -437,47 +404,27 @@ int Solver::solve_vec3(DevBuf<double>& X, const double* rhs, double tol, double 
     double* xc = X.p; double* xn = xscr.p;
     double norm[3] = {1, 1, 1}, res0[3] = {0, 0, 0}, res[3];
     int it = 0;
-    bool ahead = false;                                       // pass `it` sits in the stream already (run-ahead, fv_solver.hpp)
     for (;;) {
         // (the predictor's first pass reads the ghost planes the step's opening exchange left in U)
         const bool need_x = !(it == 0 && &X == &U && U_ghosts_fresh);
+        kc[KC_MOM_PASS].begin(stream);
         // from the second pass on the momentum predictor's pass also leaves HbyA of its iterate: the pass that finds it converged has then done the
         // first corrector's H-operator sweep (corrector(): hbya_ready)
         const bool with_h = momentum && fused_corrector && cs.n_correctors > 0 && it >= 1;
-        if (!ahead) {
-            kc[KC_MOM_PASS].begin(stream);
-            FY_TRY(overlapped(XW_MOMENTUM, need_x, [&](hipStream_t on) { return halo(xc, 3, plane, g.nz, g.gz, 1, on); }, [&](const FvGeo& gw) {
-                return FVK(launch_mom_pass, stream, gw, M7(momentum), rhs, xc, xn, xbar3.p, (double)Nglob, partials.p, with_h ? src.p : nullptr, with_h ? rAU.p : nullptr,
-                           with_h ? HbyA.p : nullptr);
-            }));
-            kc[KC_MOM_PASS].end(stream);
-        }
-        ahead = false;
+        FY_TRY(overlapped(XW_MOMENTUM, need_x, [&](hipStream_t on) { return halo(xc, 3, plane, g.nz, g.gz, 1, on); }, [&](const FvGeo& gw) {
+            return FVK(launch_mom_pass, stream, gw, M7(momentum), rhs, xc, xn, xbar3.p, (double)Nglob, partials.p, with_h ? src.p : nullptr, with_h ? rAU.p : nullptr,
+                       with_h ? HbyA.p : nullptr);
+        }));
         if (momentum) hbya_ready = with_h;
-        bool go;
-        if (run_ahead) {
-            // the stopping rule on the device, and the NEXT pass behind the fold before the host has the verdict: it does nothing if the solve has stopped
-            RedDecide d = ra_decide(1, it == 0, it >= max_iter, tol, rel_tol);
-            FY_TRY(reduce_launch(6, &d));
-            if (it < max_iter) {
-                const bool wh = momentum && fused_corrector && cs.n_correctors > 0;
-                FvGeo gg = g; gg.gate = ra_gate.p;
-                FY_TRY(FVK(launch_mom_pass, stream, gg, M7(momentum), rhs, xn, xc, xbar3.p, (double)Nglob, partials.p, wh ? src.p : nullptr, wh ? rAU.p : nullptr,
-                           wh ? HbyA.p : nullptr));
-                ahead = true;
-            }
-            FY_TRY(reduce_wait(6, h, true, &go));
-        } else {
-            FY_TRY(reduce_read(6, false, h));
-            if (it == 0) for (int q = 0; q < 3; ++q) { norm[q] = h[3 + q] + 1e-20; res0[q] = h[q] / norm[q]; }
-            bool conv = true;
-            for (int q = 0; q < 3; ++q) {
-                res[q] = h[q] / norm[q];
-                if (!(res[q] < tol || (rel_tol > 0 && res[q] < rel_tol * res0[q]))) conv = false;
-            }
-            go = !(conv || it >= max_iter);
+        kc[KC_MOM_PASS].end(stream);
+        FY_TRY(reduce_read(6, false, h));
+        if (it == 0) for (int q = 0; q < 3; ++q) { norm[q] = h[3 + q] + 1e-20; res0[q] = h[q] / norm[q]; }
+        bool conv = true;
+        for (int q = 0; q < 3; ++q) {
+            res[q] = h[q] / norm[q];
+            if (!(res[q] < tol || (rel_tol > 0 && res[q] < rel_tol * res0[q]))) conv = false;
         }
-        if (!go) break;
+        if (conv || it >= max_iter) break;
         std::swap(xc, xn);
         ++it;
     }

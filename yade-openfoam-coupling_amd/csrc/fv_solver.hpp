@@ -105,16 +105,6 @@ struct Solver {
     unsigned long long* red_flag = nullptr;      // 8 arrival flags (mapped pinned) the host spins on, and their device alias
     unsigned long long* red_flag_dev = nullptr;
     unsigned long long red_seq = 0;
-    // Run-ahead: the stopping rule of the momentum predictor and of PCG is applied on the device by the fold that forms the residual sums (RedDecide), and the
-    // next iteration's FIRST kernel is enqueued behind that fold before the host has seen the verdict -- it reads the verdict's gate and does nothing when the
-    // solve has stopped.  A continuing iteration then starts when the fold ends instead of a host round trip (~25 us of idle GPU) later; a stopping one leaves a
-    // kernel that exits at once in the window in which the GPU waits for the host anyway.  Same kernels on the same data in the same order: same bits.
-    // Single domain with the mapped flags only (FOAMYADE_NO_RUN_AHEAD=1: off).
-    bool run_ahead = false;
-    DevBuf<double> ra_state;              // [16]: RedDecide::state
-    DevBuf<int> ra_gate;                  // [1]
-    DevBuf<unsigned int> ra_counter;      // [1]
-    bool first_sweep_ahead = false;       // level 0's fused first two sweeps of the coming V-cycle are already in the stream (gated)
     DevBuf<int> ops_courant, ops_diag;   // per-slot fold operations (0 sum, 1 max) of the Courant pair and of k_U_correct<true>'s four diagnostics
     fy_step_stats st{};
     double cumulative_cont_err = 0.0;
@@ -214,13 +204,6 @@ struct Solver {
 
     // ---- reductions: fold the block partials, all-reduce over the slabs, read back
     int reduce_read(int nslots, bool courant, double* h);
-    // run-ahead: the two halves of reduce_read's flag path, so that a kernel can be enqueued between the fold and the host's wait for it; `dec` (pointers filled
-    // in here) makes the fold form the stopping rule's verdict, which reduce_wait returns in *go
-    int reduce_launch(int nslots, RedDecide* dec);
-    int reduce_wait(int nslots, double* h, bool with_verdict, bool* go);
-    RedDecide ra_decide(int kind, bool first, bool out_of_iters, double tol, double rel) const {
-        RedDecide d{}; d.kind = kind; d.first = first ? 1 : 0; d.out_of_iters = out_of_iters ? 1 : 0; d.tol = tol; d.rel = rel; return d;
-    }
     // Diagnostics nobody branches on (Courant number, continuity errors): same fold [+ all-reduce], but the values land in their own
     // slots of the pinned buffer and are read after the step's final synchronisation instead of stalling the stream here.
     // Returns false when there is no slot left (the caller then reads at once).
