@@ -899,6 +899,8 @@ def main():
             st = solver.stats(); ct = solver.coupling_timings()
             acc["particle"] += st["ms_particle"]; acc["momentum"] += st["ms_momentum"]; acc["pressure"] += st["ms_pressure"]; acc["other"] += st["ms_other"]
             acc["locate_deposit"] += ct["locate_deposit"]; acc["force"] += ct["force"]; acc["bin"] += ct["bin"]; acc["finalize"] += ct["finalize"]; acc["fold"] += ct["fold"]
+            if rebuild_ms > 0 and ct["bin"] > 0.3 * rebuild_ms:
+                acc["rebuilds"] = acc.get("rebuilds", 0) + 1
             acc["p_iters"] += st["p_iters_total"]; acc["u_iters"] += st["u_iters_total"]
         barrier()
         return acc, max_over_ranks(time.perf_counter() - t0, dist, ddev)
@@ -991,6 +993,9 @@ def main():
                               "what": "the binned placement of the particles (counting sort + chain-length ordering) is rebuilt every n-th coupling step; a timed region "
                                       "shorter than n steps may hold none: `ms` is the rebuild measured in the warm-up, ms / n its share of a step "
                                       "(per_step_ms.bin holds what fell inside the region)"},
+        # how many placement rebuilds fell inside the timed region (a 20-step region holds none; its share of a step would be placement_rebuild.ms / every_n_steps)
+        "rebuilds_in_region": int(acc.get("rebuilds", 0)),
+        "ms_per_step_with_rebuild_share": round(ms_step + (0.0 if acc.get("rebuilds", 0) else rebuild_ms / max(int(os.environ.get("FOAMYADE_REBIN_INTERVAL", "32")), 1)), 4),
         "p_iters_per_step": p_iters, "u_iters_per_step": u_iters,
         "roofline": roof(dominant) if dominant else None,
         "roofline_pEqn_laplacian": roof(lap) if lap in kern else None,

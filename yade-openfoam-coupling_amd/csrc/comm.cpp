@@ -91,6 +91,7 @@ struct LocalShared {
     std::vector<std::array<hipEvent_t, RING> > ready, done;
     std::vector<int> device;
     double* red_all = nullptr;                 // [n x 32] device slots of the all-reduce, folded in rank order by every rank
+    bool ordered_decided = false;              // stream_ordered's final value is set (LocalComm::init_rank, once, under init_m)
     bool stream_ordered = false;               // FOAMYADE_LOCALCOMM_STREAM=1 (measured: no faster at 2 slabs, slower at 8 -- DESIGN.md 8)
     // FOAMYADE_LOCALCOMM_TURNS=1 (profiling aid): between two collectives only ONE rank at a time enqueues and runs its work -- a rank takes the turn when it leaves
     // a collective and gives it up, its device work drained, when it enters the next.  The slabs then do not share the GPU kernel by kernel, so a kernel trace shows
@@ -134,38 +135,55 @@ struct LocalComm : Comm {
     ~LocalComm() override { if (my_turn) { my_turn = false; sh->turn_m.unlock(); } }
     int init_rank() {
         if (inited) return FY_OK;
+        // (a rank whose HIP call fails still takes part in both barriers -- the others must not hang on it -- and reports afterwards)
         int dev = 0;
-        FY_HIP(hipGetDevice(&dev));
-        for (int q = 0; q < LocalShared::RING; ++q) {
-            FY_HIP(hipEventCreateWithFlags(&sh->ready[rank][q], hipEventDisableTiming));
-            FY_HIP(hipEventCreateWithFlags(&sh->done[rank][q], hipEventDisableTiming));
+        hipError_t err = hipGetDevice(&dev);
+        for (int q = 0; q < LocalShared::RING && err == hipSuccess; ++q) {
+            err = hipEventCreateWithFlags(&sh->ready[rank][q], hipEventDisableTiming);
+            if (err == hipSuccess) err = hipEventCreateWithFlags(&sh->done[rank][q], hipEventDisableTiming);
         }
         {
             std::lock_guard<std::mutex> lk(sh->init_m);
-            sh->device[rank] = dev;
-            if (!sh->red_all) FY_HIP(hipMalloc((void**)&sh->red_all, (size_t)size * 32 * sizeof(double)));
+            sh->device[rank] = err == hipSuccess ? dev : -2;
+            if (!sh->red_all && err == hipSuccess) err = hipMalloc((void**)&sh->red_all, (size_t)size * 32 * sizeof(double));
         }
         inited = true;
         sh->bar.wait();                                        // every rank's events exist before anyone waits on one
-        for (int r = 0; r < size; ++r)
-            if (sh->device[r] != dev) sh->stream_ordered = false;      // slabs on different devices: the host-synchronous path
+        {
+            // slabs on different devices (or a rank that failed above): the host-synchronous path -- decided once, by whoever gets here first
+            std::lock_guard<std::mutex> lk(sh->init_m);
+            if (!sh->ordered_decided) {
+                for (int r = 0; r < size; ++r)
+                    if (sh->device[r] != sh->device[0] || sh->device[r] < 0) sh->stream_ordered = false;
+                sh->ordered_decided = true;
+            }
+        }
         sh->bar.wait();
+        if (err != hipSuccess) return fail(FY_ERR_HIP, "local communicator: set-up failed on rank %d: %s", rank, hipGetErrorString(err));
         return FY_OK;
+    }
+    // HIP calls between two barriers of a collective: the error is kept, the barriers are still taken, the failure is returned at the end
+    hipError_t pend = hipSuccess;
+    void note(hipError_t e) { if (e != hipSuccess && pend == hipSuccess) pend = e; }
+    int settle(const char* what) {
+        if (pend == hipSuccess) return FY_OK;
+        const hipError_t e = pend; pend = hipSuccess;
+        return fail(FY_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
     }
     // open a collective: my buffers are final at this point of my stream
     int open(hipStream_t s, int& slot) {
         FY_TRY(init_rank());
         slot = (int)(seq++ % LocalShared::RING);
-        FY_HIP(hipEventRecord(sh->ready[rank][slot], s));
+        note(hipEventRecord(sh->ready[rank][slot], s));
         return FY_OK;
     }
     // close it: nobody's later work may overwrite a buffer that `lo..hi` are still reading
     int close(hipStream_t s, int slot, int lo, int hi) {
-        FY_HIP(hipEventRecord(sh->done[rank][slot], s));
+        note(hipEventRecord(sh->done[rank][slot], s));
         sh->bar.wait();                                        // every rank has recorded `done`; the posted lists may go
         for (int r = lo; r <= hi; ++r)
-            if (r != rank && r >= 0 && r < size) FY_HIP(hipStreamWaitEvent(s, sh->done[r][slot], 0));
-        return FY_OK;
+            if (r != rank && r >= 0 && r < size) note(hipStreamWaitEvent(s, sh->done[r][slot], 0));
+        return settle("local communicator: event call failed");
     }
     int exchange_many(hipStream_t s, const Xchg* x, size_t n) override {
         count(0);
@@ -176,8 +194,8 @@ struct LocalComm : Comm {
         FY_TRY(open(s, slot));
         sh->lists[rank] = x;                                   // every rank posts the same number of items in the same order
         sh->bar.wait();
-        if (has_down()) FY_HIP(hipStreamWaitEvent(s, sh->ready[rank - 1][slot], 0));
-        if (has_up()) FY_HIP(hipStreamWaitEvent(s, sh->ready[rank + 1][slot], 0));
+        if (has_down()) note(hipStreamWaitEvent(s, sh->ready[rank - 1][slot], 0));
+        if (has_up()) note(hipStreamWaitEvent(s, sh->ready[rank + 1][slot], 0));
         int rc = FY_OK;
         for (size_t q = 0; q < n && rc == FY_OK; ++q) {
             if (has_down() && x[q].recv_from_down && x[q].rd()) {
@@ -220,12 +238,12 @@ struct LocalComm : Comm {
         if (sh->stream_ordered && n <= 32) {
             // every rank parks its values in its slot of one device array and folds all slots itself, in rank order => identical
             // bits on every rank (and the bits of the host fold below)
-            FY_HIP(hipMemcpyAsync(sh->red_all + (size_t)rank * 32, dev, n * sizeof(double), hipMemcpyDeviceToDevice, s));
+            note(hipMemcpyAsync(sh->red_all + (size_t)rank * 32, dev, n * sizeof(double), hipMemcpyDeviceToDevice, s));
             int slot = 0;
             FY_TRY(open(s, slot));
             sh->bar.wait();
             for (int r = 0; r < size; ++r)
-                if (r != rank) FY_HIP(hipStreamWaitEvent(s, sh->ready[r][slot], 0));
+                if (r != rank) note(hipStreamWaitEvent(s, sh->ready[r][slot], 0));
             hipLaunchKernelGGL(k_fold_gathered, dim3(1), dim3(32), 0, s, sh->red_all, size, n, 32, is_max ? 0xffffffffu : 0u, dev);
             const bool bad = hipGetLastError() != hipSuccess;
             FY_TRY(close(s, slot, 0, size - 1));
@@ -255,7 +273,7 @@ struct LocalComm : Comm {
             sh->bar.wait();
             bool bad = false;
             for (int r = 0; r < size; ++r) {
-                if (r != rank) FY_HIP(hipStreamWaitEvent(s, sh->ready[r][slot], 0));
+                if (r != rank) note(hipStreamWaitEvent(s, sh->ready[r][slot], 0));
                 if (recv + (size_t)r * cnt == sh->gather_src[r]) continue;        // gathered in place
                 bad = bad || hipMemcpyAsync(recv + (size_t)r * cnt, sh->gather_src[r], cnt * sizeof(double), hipMemcpyDeviceToDevice, s) != hipSuccess;
             }

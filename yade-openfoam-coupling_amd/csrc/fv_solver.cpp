@@ -537,6 +537,8 @@ int Solver::corrector(bool final_inner) {
             return FY_OK;
         }
         carry_slot = -1;
+        // (the deferred-slot pool is full: the separate continuity sweep streams alphacf from its face array, which the fused sweeps do not keep filled)
+        if (pimple && !face_arrays) FY_TRY(FVK(launch_interp_alpha, stream, g, alpha.p, F3(alphaf)));
         FY_TRY(FVK(launch_cont_err, stream, g, C3(phi), C3(alphaf), alpha.p, /* alphaOld */ alpha.p, partials.p));
         if (reduce_deferred(2, false, &slot, &rc)) { FY_TRY(rc); cont_slots.push_back(slot); }
         else { FY_TRY(reduce_read(2, false, h)); note_cont_err(h); }

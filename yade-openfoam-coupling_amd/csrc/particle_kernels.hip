@@ -388,20 +388,21 @@ __device__ __attribute__((noinline)) void walk_deposit(const ParticleSoA& p, int
     const int k = chain < kMaxK ? chain : kMaxK;
     if (k <= 0) return;
     const double dia = 2 * p.rad[i];                                  // FoamYade.C:219
-    const double pVol = M_PI * pow(dia, 3.0) / 6.0;                   // FoamYade.H:36
+    const double pVol = M_PI * cube3(dia) / 6.0;                      // FoamYade.H:36 (as k_locate_deposit forms it)
     const double vx = p.vx[i], vy = p.vy[i], vz = p.vz[i];
     double allwt = 0.0;                                               // calcInterpWeightGaussian FoamYade.C:301-314, ascending-d2 order
 #pragma unroll 1
     for (int t = 0; t < k; ++t) {
         const size_t slot = (size_t)((chain - 1 - t) & (kMaxK - 1)) * p.cap + (size_t)i;
-        const double wt = exp(-p.w[slot] / wd.gp.two_sigma2) * wd.gp.range_cu * wd.gp.sigma_pi;
+        const double wt = exp(-p.w[slot] * (1.0 / wd.gp.two_sigma2)) * wd.gp.range_cu * wd.gp.sigma_pi;      // (reciprocals as in k_locate_deposit: one particle, one set of bits whichever path places it)
         p.w[slot] = wt;
         allwt += wt;
     }
+    const double rallwt_ = 1.0 / allwt;
 #pragma unroll 1
     for (int t = 0; t < k; ++t) {
         const size_t slot = (size_t)((chain - 1 - t) & (kMaxK - 1)) * p.cap + (size_t)i;
-        const double weight = p.w[slot] / allwt;                      // FoamYade.C:312-314
+        const double weight = p.w[slot] * rallwt_;                    // FoamYade.C:312-314
         p.w[slot] = weight;
         const int64_t cl = (int64_t)p.ids[slot] - wd.cw.base;         // storage index (slab window)
         if (cl < 0 || cl >= wd.cw.n_field) continue;
@@ -967,7 +968,7 @@ __global__ __launch_bounds__(kDepThreads) void k_deposit(ParticleSoA p, int64_t 
         const int k = chain < kMaxK ? chain : kMaxK;
         if (k > 0) {
             const double dia = 2 * p.rad[i];                                  // FoamYade.C:219
-            const double pVol = M_PI * pow(dia, 3.0) / 6.0;                   // FoamYade.H:36
+            const double pVol = M_PI * cube3(dia) / 6.0;                      // FoamYade.H:36 (as k_locate_deposit forms it)
             const double vx = p.vx[i], vy = p.vy[i], vz = p.vz[i];
             // calcInterpWeightGaussian FoamYade.C:301-314, slots visited in ascending-d2 order (= reverse push order)
             // the unnormalised weights stay in registers (k <= 12 < kMaxK, fully unrolled so that wt[] is not indexed dynamically):
@@ -980,13 +981,15 @@ __global__ __launch_bounds__(kDepThreads) void k_deposit(ParticleSoA p, int64_t 
                 if (t < k) {
                     const size_t slot = (size_t)((chain - 1 - t) & (kMaxK - 1)) * p.cap + (size_t)i;
                     const double distsq = p.w[slot];
-                    wt[t] = exp(-distsq / gp.two_sigma2) * gp.range_cu * gp.sigma_pi;
+                    wt[t] = exp(-distsq * (1.0 / gp.two_sigma2)) * gp.range_cu * gp.sigma_pi;      // (the expressions of k_locate_deposit's list path, so that
+                                                                                                   //  a particle's weights do not depend on which path placed it)
                     allwt += wt[t];
                 }
             }
+            const double rallwt_ = 1.0 / allwt;
 #pragma unroll
             for (int t = 0; t < kMaxK; ++t)
-                if (t < k) p.w[(size_t)((chain - 1 - t) & (kMaxK - 1)) * p.cap + (size_t)i] = wt[t] / allwt;   // FoamYade.C:312-314
+                if (t < k) p.w[(size_t)((chain - 1 - t) & (kMaxK - 1)) * p.cap + (size_t)i] = wt[t] * rallwt_;   // FoamYade.C:312-314
 #pragma unroll 1
             for (int t = 0; t < k; ++t) {
                 const size_t slot = (size_t)((chain - 1 - t) & (kMaxK - 1)) * p.cap + (size_t)i;
