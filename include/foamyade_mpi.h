@@ -38,7 +38,8 @@ int fy_mpi_wire_helper_serve(fy_transport* t);
 int fy_mpi_local_comm(const fy_transport* t, void* mpi_comm_out);
 /* a z-slab communicator (fy_solver_create_slab) over the ranks of *mpi_comm (an MPI_Comm; collective over it):
  *   use_rccl != 0  one GPU per rank -- halos, reductions and the coarse-level gather run over RCCL / xGMI, MPI only distributes the communicator id;
- *   use_rccl == 0  ranks that share a GPU (or no RCCL): the library stages the planes through pinned host memory and MPI moves them */
+ *   use_rccl == 0  ranks that share a GPU (or no RCCL): the library stages the planes through pinned host memory and MPI moves them;
+ *   use_rccl == 2  the ranks of ONE node, sharing GPUs or not: peer stores into hipIpc-mapped device windows (fy_comm_create_ipc); MPI carries its bootstrap only */
 int fy_mpi_comm_create(const void* mpi_comm, int use_rccl, int device_ordinal, fy_comm** out);
 #ifdef __cplusplus
 }

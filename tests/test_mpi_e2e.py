@@ -83,11 +83,12 @@ def test_foamYadeHip_mpi_next_to_a_serial_yade(product, tmp_path):
 
 
 @pytest.mark.skipif(not (os.path.exists(MPIEXEC) and os.path.exists(FAKE_YADE) and os.path.exists(RUNNER)), reason="no MPI launcher / binaries (run __graft_entry__.build())")
-@pytest.mark.parametrize("n_fluid", [2, 3])
-def test_foamYadeHip_mpi_parallel_next_to_a_serial_yade(product, tmp_path, n_fluid):
+@pytest.mark.parametrize("n_fluid,comm_flag", [(2, "-hostComm"), (3, "-hostComm"), (3, "-ipcComm")])
+def test_foamYadeHip_mpi_parallel_next_to_a_serial_yade(product, tmp_path, n_fluid, comm_flag):
     """the reference's `-parallel` launch (README.md:29): `mpiexec -n 1 <yade> : -n N <solver> -parallel` -- N solver PROCESSES, each with its
-    z-slab of the undecomposed case, halos / reductions / the coarse-level gather staged through the host and moved by MPI (the ranks share the
-    box's one GPU here; with a GPU per rank the same executable takes RCCL), every rank answering the serial-Yade protocol for the particles of
+    z-slab of the undecomposed case, halos / reductions / the coarse-level gather staged through the host and moved by MPI (`-hostComm`) or stored by the
+    library's kernels straight into the other ranks' hipIpc-mapped device windows (`-ipcComm`, fy_comm_create_ipc, MPI carrying its bootstrap only) -- the ranks
+    share the box's one GPU here; with a GPU per rank the same executable takes RCCL --, every rank answering the serial-Yade protocol for the particles of
     its slab; the forces Yade receives and the gathered, undecomposed time directory equal the one-rank run's"""
     import shutil
     case_src = os.path.join(ROOT, "tests", "golden", "cases", "bed_pimple")
@@ -109,10 +110,12 @@ def test_foamYadeHip_mpi_parallel_next_to_a_serial_yade(product, tmp_path, n_flu
         fc.close()
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
         cmd = [MPIEXEC, "-n", "1", FAKE_YADE, str(tmp_path / tag / "records.bin"), "1", str(nsteps), str(tmp_path / tag / "force.bin"), ":",
-               "-n", str(nf), RUNNER, "-solver", "pimple", "-case", str(dst)] + (["-parallel", "-nYade", "1", "-hostComm"] if nf > 1 else [])
+               "-n", str(nf), RUNNER, "-solver", "pimple", "-case", str(dst)] + (["-parallel", "-nYade", "1", comm_flag] if nf > 1 else [])
         out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
         assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-2000:])
         assert out.stdout.count("End") == 1 and ("Decomposition: %d z-slabs" % nf in out.stdout) == (nf > 1)
+        if nf > 1 and comm_flag == "-ipcComm":
+            assert "peer stores into hipIpc-mapped device windows" in out.stdout
         (dst / "system/controlDict").write_text((dst / "system/controlDict").read_text().replace("startFrom       startTime;", "startFrom       latestTime;"))
         fc2 = product.FoamCase(dst, 1)
         assert fc2.start_name == tlast

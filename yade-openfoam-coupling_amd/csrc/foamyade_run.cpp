@@ -2,7 +2,7 @@
 // over an OpenFOAM case directory, on the C-ABI of libfoamyade_hip.so:
 //
 //     foamYadeHip -solver ico|pimple [-case DIR] [-device N]
-//     mpiexec -n Y yade ... : -n N foamYadeHip_mpi -solver ... -case DIR -parallel [-nYade Y] [-hostComm]
+//     mpiexec -n Y yade ... : -n N foamYadeHip_mpi -solver ... -case DIR -parallel [-nYade Y] [-hostComm | -ipcComm]
 //     mpiexec -n Y yade ... : -n K foamYadeHip_mpi -solver ... -case DIR -wireHelpers [-nYade Y]
 //
 // read the case (fy_foam_case_open), create the solver, then  while (runTime.loop()) { step; runTime.write(); setSourceZero }.
@@ -89,7 +89,7 @@ static int run_general(fy_foam_case* fc, const fy_transport* trp, int device) {
 int main(int argc, char** argv) {
     std::string dir = ".", solver_name;
     int device = -1, n_yade_arg = -1;
-    bool parallel = false, host_comm = false, wire_helpers = false;
+    bool parallel = false, host_comm = false, ipc_comm = false, wire_helpers = false;
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
         if (a == "-case" && i + 1 < argc) dir = argv[++i];
@@ -98,8 +98,9 @@ int main(int argc, char** argv) {
         else if (a == "-parallel") parallel = true;
         else if (a == "-nYade" && i + 1 < argc) n_yade_arg = std::atoi(argv[++i]);
         else if (a == "-hostComm") host_comm = true;
+        else if (a == "-ipcComm") ipc_comm = true;
         else if (a == "-wireHelpers") wire_helpers = true;
-        else { std::fprintf(stderr, "usage: foamYadeHip -solver ico|pimple [-case DIR] [-device N] [-parallel [-nYade Y] [-hostComm]] | [-wireHelpers [-nYade Y]]\n"); return 2; }
+        else { std::fprintf(stderr, "usage: foamYadeHip -solver ico|pimple [-case DIR] [-device N] [-parallel [-nYade Y] [-hostComm | -ipcComm]] | [-wireHelpers [-nYade Y]]\n"); return 2; }
     }
     if (solver_name != "ico" && solver_name != "pimple") { std::fprintf(stderr, "foamYadeHip: -solver ico|pimple is required\n"); return 2; }
     const int solver = solver_name == "ico" ? FY_SOLVER_ICO : FY_SOLVER_PIMPLE;
@@ -154,10 +155,12 @@ int main(int argc, char** argv) {
         MPI_Comm_rank(node, &nrank); MPI_Comm_size(node, &nsize);
         MPI_Comm_free(&node);
         if (device < 0) device = nrank % ndev;
-        int mine_ok = (!host_comm && ndev >= nsize) ? 1 : 0, use_rccl = 0;
+        int mine_ok = (!host_comm && !ipc_comm && ndev >= nsize) ? 1 : 0, use_rccl = 0;
         MPI_Allreduce(&mine_ok, &use_rccl, 1, MPI_INT, MPI_MIN, solver_comm);      // one GPU per rank everywhere, or the ranks share and MPI moves the planes
+        // -ipcComm: the solver ranks of one node store into each other's device windows (fy_comm_create_ipc), whether or not they share GPUs
+        if (ipc_comm) { int one_node = nsize == ssize ? 1 : 0, all = 0; MPI_Allreduce(&one_node, &all, 1, MPI_INT, MPI_MIN, solver_comm); if (!all) return die("-ipcComm: the solver ranks must share one node"); use_rccl = 2; }
         if (fy_mpi_comm_create(&solver_comm, use_rccl, device, &comm) != FY_OK) return die("fy_mpi_comm_create");
-        if (srank == 0) std::printf("Decomposition: %d z-slabs, %s\n", ssize, use_rccl ? "RCCL" : "planes staged through the host, moved by MPI");
+        if (srank == 0) std::printf("Decomposition: %d z-slabs, %s\n", ssize, use_rccl == 2 ? "peer stores into hipIpc-mapped device windows" : use_rccl ? "RCCL" : "planes staged through the host, moved by MPI");
     }
 #else
     if (parallel) { std::fprintf(stderr, "foamYadeHip: -parallel needs the MPI build (foamYadeHip_mpi)\n"); return 2; }

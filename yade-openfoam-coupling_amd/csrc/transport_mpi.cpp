@@ -429,7 +429,7 @@ int fy_mpi_comm_create(const void* mpi_comm, int use_rccl, int device_ordinal, f
     int rank = 0, size = 1;
     MPI_Comm_rank(c, &rank);
     MPI_Comm_size(c, &size);
-    if (use_rccl) {
+    if (use_rccl == 1) {
         // one GPU per rank: the planes go over RCCL / xGMI; MPI only carries the communicator's 128-byte id
         unsigned char id[128] = {0};
         int rc = rank == 0 ? fy_rccl_unique_id(id) : FY_OK;
@@ -443,6 +443,9 @@ int fy_mpi_comm_create(const void* mpi_comm, int use_rccl, int device_ordinal, f
     if (!st) return FY_ERR_INVALID;
     fy_comm_callbacks cb{};
     cb.user = st; cb.sendrecv = cb_sendrecv; cb.allreduce = cb_allreduce; cb.allgather = cb_allgather;
+    // use_rccl == 2: the peer-store communicator (fy_comm_create_ipc) -- the ranks of ONE node map each other's device windows, the library's kernels store
+    // planes and all-reduce operands into them; MPI carries the bootstrap only (the window handles, the closing barrier)
+    if (use_rccl == 2) return fy_comm_create_ipc(rank, size, &cb, device_ordinal, out);
     return fy_comm_create_host(rank, size, &cb, out);      // (st lives as long as the process: the communicator keeps the pointer)
 }
 
