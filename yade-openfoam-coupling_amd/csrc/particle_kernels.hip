@@ -699,10 +699,12 @@ __device__ __forceinline__ void quad_transpose(uint4& m0, uint4& m1, uint4& m2, 
     quad_transpose(m0.x, m1.x, m2.x, m3.x, b0, b1); quad_transpose(m0.y, m1.y, m2.y, m3.y, b0, b1);
     quad_transpose(m0.z, m1.z, m2.z, m3.z, b0, b1); quad_transpose(m0.w, m1.w, m2.w, m3.w, b0, b1);
 }
+#if FY_FORCE_QUAD
 __device__ __forceinline__ double2 quad_pick(double2 v0, double2 v1, double2 v2, double2 v3, int lq) {
     const double2 lo = lq & 1 ? v1 : v0, hi = lq & 1 ? v3 : v2;
     return lq & 2 ? hi : lo;
 }
+#endif
 __device__ __forceinline__ double2 as_double2(uint4 v) {
     return make_double2(__hiloint2double((int)v.y, (int)v.x), __hiloint2double((int)v.w, (int)v.z));
 }
@@ -1128,12 +1130,15 @@ __global__ __launch_bounds__(kDepThreads) void k_locate_deposit(LocateLists ll, 
                 const unsigned int at = atomicAdd(fb_count, 1u);
                 fb_list[at] = (int32_t)i;
             } else {
-                double best = 1e300, wt[kListLen];
-                uint32_t emitted = 0;
+                // The scan keeps nothing per list position: an entry that enters the chain has its id and its UNNORMALISED weight stored at once, in the row of its push
+                // index; the sum (last push first, FoamYade.C:301-311: the same additions as over the 24 positions with their zeros) and the normalisation + deposit
+                // then run as loops over the CHAIN (k entries) that read the rows back (this lane's own stores: L2) -- not as 24 unrolled, mostly idle copies
+                // of the deposit, and without 24 weights held in registers
+                double best = 1e300;
+                int pos = 0;
                 bool done = false;
 #pragma unroll
                 for (int h = 0; h < kListLen; ++h) {
-                    wt[h] = 0.0;
                     const uint4 vv = v[h >> 3];
                     const uint32_t wd = ((h >> 1) & 3) == 0 ? vv.x : (((h >> 1) & 3) == 1 ? vv.y : (((h >> 1) & 3) == 2 ? vv.z : vv.w));
                     const uint32_t code = (wd >> ((h & 1) * 16)) & 0xffffu;
@@ -1148,41 +1153,48 @@ __global__ __launch_bounds__(kDepThreads) void k_locate_deposit(LocateLists ll, 
                         if (d < best) {                      // meshTree.C:192
                             best = d;
                             if (d < gp.maxdist && !(code & kListNoEmit)) {       // meshTree.C:195; the root is never pushed
-                                wt[h] = exp(-d * (1.0 / gp.two_sigma2)) * gp.range_cu * gp.sigma_pi;     // FoamYade.C:308
-                                emitted |= 1u << h;
+                                const size_t slot = (size_t)(pos & (kMaxK - 1)) * p.cap + (size_t)i;
+                                p.ids[slot] = ni + ig.nx * (nj + ig.ny * nk);
+                                const double wu = exp(-d * (1.0 / gp.two_sigma2)) * gp.range_cu * gp.sigma_pi;     // FoamYade.C:308
+                                p.w[slot] = wu;
+                                ++pos;
                             }
                         }
                     }
                 }
-                const int chain = __popc(emitted);
+                const int chain = pos;
                 p.chain_len[i] = chain;
                 if (chain > 0) {
+                    const int k = chain < kMaxK ? chain : kMaxK;      // (a chain longer than the ring has lost its oldest rows, as in the walk: k newest)
                     double allwt = 0.0;
+                    {   // all the rows at once (one round trip), then the reference's order: last push first (FoamYade.C:301-311); rows beyond the chain read as zero,
+                        // and adding them is exact -- the same additions as round 5's sum over the 24 list positions
+                        double u[kMaxK];
 #pragma unroll
-                    for (int h = kListLen - 1; h >= 0; --h) allwt += wt[h];       // last push first (FoamYade.C:301-311)
+                        for (int t = 0; t < kMaxK; ++t) u[t] = t < k ? p.w[(size_t)((chain - k + t) & (kMaxK - 1)) * p.cap + (size_t)i] : 0.0;
+#pragma unroll
+                        for (int t = kMaxK - 1; t >= 0; --t) allwt += u[t];
+                    }
                     const double rallwt_ = 1.0 / allwt;
                     const double dia = 2 * prad;                                      // FoamYade.C:219
                     const double pVol = M_PI * cube3(dia) / 6.0;                      // FoamYade.H:36
                     const double vx = pvx, vy = pvy, vz = pvz;
-                    int pos = 0;
-#pragma unroll
-                    for (int h = 0; h < kListLen; ++h) {
-                        if (emitted & (1u << h)) {
-                            const uint4 vv = v[h >> 3];
-                            const uint32_t wd = ((h >> 1) & 3) == 0 ? vv.x : (((h >> 1) & 3) == 1 ? vv.y : (((h >> 1) & 3) == 2 ? vv.z : vv.w));
-                            const uint32_t code = (wd >> ((h & 1) * 16)) & 0xffffu;
-                            const int ni = ci + (int)(code & 15u) - 8, nj = cj + (int)((code >> 4) & 15u) - 8, nk = ck + (int)((code >> 8) & 15u) - 8;
-                            const int32_t id = ni + ig.nx * (nj + ig.ny * nk);
-                            const double weight = wt[h] * rallwt_;                    // FoamYade.C:312-314
-                            const size_t slot = (size_t)(pos & (kMaxK - 1)) * p.cap + (size_t)i;
-                            p.ids[slot] = id;
-                            p.w[slot] = weight;
-                            ++pos;
-                            const int64_t cl = (int64_t)id - cw.base;                 // storage index (slab window)
-                            if (cl >= 0 && cl < cw.n_field) {
-                                const double c0 = pVol * weight, c1 = (weight * vx) * pVol, c2 = (weight * vy) * pVol, c3 = (weight * vz) * pVol;
-                                deposit_pair(keys, vals, (int32_t)cl, c0, c1, c2, c3, pvol_acc, up_acc, touched);
-                            }
+                    size_t slot = (size_t)((chain - k) & (kMaxK - 1)) * p.cap + (size_t)i;
+                    double w_n = p.w[slot];
+                    int32_t id_n = p.ids[slot];
+#pragma unroll 1
+                    for (int t = chain - k; t < chain; ++t) {
+                        const double weight = w_n * rallwt_;                          // FoamYade.C:312-314
+                        const int32_t id_t = id_n;
+                        p.w[slot] = weight;
+                        if (t + 1 < chain) {                                          // (the next entry travels while this one goes through the table)
+                            slot = (size_t)((t + 1) & (kMaxK - 1)) * p.cap + (size_t)i;
+                            w_n = p.w[slot]; id_n = p.ids[slot];
+                        }
+                        const int64_t cl = (int64_t)id_t - cw.base;                   // storage index (slab window)
+                        if (cl >= 0 && cl < cw.n_field) {
+                            const double c0 = pVol * weight, c1 = (weight * vx) * pVol, c2 = (weight * vy) * pVol, c3 = (weight * vz) * pVol;
+                            deposit_pair(keys, vals, (int32_t)cl, c0, c1, c2, c3, pvol_acc, up_acc, touched);
                         }
                     }
                 }
