@@ -672,6 +672,17 @@ template <int NSLOTS> __device__ __forceinline__ int agg_at(int h, int j) { retu
 #ifndef FY_FORCE_QUAD
 #define FY_FORCE_QUAD 0
 #endif
+// register budgets of the two hot kernels (build-time constants; tools/build_variant.sh overrides them for A/B runs)
+//   k_force_gaussian: room for 6 waves per SIMD = 80 VGPRs (the compiler's own choice is 82: five waves, i.e. TWO 512-thread workgroups per CU; with 80 a third one
+//   fits: 1.05 -> 0.93 ms at C3, no spills; 8 waves = 64 VGPRs spills 68 bytes per lane and is slower again)
+//   k_locate_deposit: room for 8 waves per SIMD (56 VGPRs as it stands; the cap also keeps the scalar registers at 78 -- with its natural 100 the hardware admits three
+//   workgroups per CU instead of four)
+#ifndef FY_FORCE_ATTR
+#define FY_FORCE_ATTR __attribute__((amdgpu_waves_per_eu(6)))
+#endif
+#ifndef FY_LD_ATTR
+#define FY_LD_ATTR __attribute__((amdgpu_waves_per_eu(8)))
+#endif
 #ifndef FY_LD_QUAD
 #define FY_LD_QUAD 1
 #endif
@@ -1015,7 +1026,7 @@ __global__ __launch_bounds__(kDepThreads) void k_deposit(ParticleSoA p, int64_t 
 // rec != nullptr: the binned SoA arrays are not filled yet -- the lane fetches its wire record through the placement (p.orig) itself and
 // leaves the SoA copy behind for the force pass (k_bin_gather folded into this kernel: one launch and one coalesced read of the SoA less;
 // the record fetch is the same random 80-byte read either way)
-__global__ __launch_bounds__(kDepThreads) void k_locate_deposit(LocateLists ll, ImplicitGeom ig, ParticleSoA p, int64_t n,
+__global__ __launch_bounds__(kDepThreads) FY_LD_ATTR void k_locate_deposit(LocateLists ll, ImplicitGeom ig, ParticleSoA p, int64_t n,
                                                                  GaussParams gp, SlabOwn own, CellWindow cw, double* __restrict__ pvol_acc,
                                                                  double* __restrict__ up_acc, unsigned char* __restrict__ touched, TileBuckets tb,
                                                                  const double* __restrict__ rec) {
@@ -1369,7 +1380,7 @@ __device__ __forceinline__ void model_add(ModelSums& ms, const ForceParams& fp, 
 #define FY_FORCE_LOG2 10
 #endif
 constexpr int kForceThreads = FY_FORCE_THREADS, kForceLog2 = FY_FORCE_LOG2;
-__global__ __launch_bounds__(kForceThreads) void k_force_gaussian(
+__global__ __launch_bounds__(kForceThreads) FY_FORCE_ATTR void k_force_gaussian(
         ParticleSoA p, int64_t n, ForceParams fp, CellWindow cw, const double* __restrict__ vol, const double* __restrict__ R,
         const double* __restrict__ vGrad, const double* __restrict__ ddtU, const double* __restrict__ rec,
         double* __restrict__ drag_acc, double* __restrict__ uSource, double* __restrict__ force_out, TileBuckets tb) {
