@@ -31,6 +31,8 @@
 #define FY_WPE_ATTR(n) FY_WPE_ATTR_IF(n)
 #define FY_WPE_ATTR_IF(n) FY_WPE_PICK_##n
 #define FY_WPE_PICK_0
+#define FY_WPE_PICK_2 FY_WPE_ATTR_(2)
+#define FY_WPE_PICK_3 FY_WPE_ATTR_(3)
 #define FY_WPE_PICK_4 FY_WPE_ATTR_(4)
 #define FY_WPE_PICK_5 FY_WPE_ATTR_(5)
 #define FY_WPE_PICK_6 FY_WPE_ATTR_(6)
