@@ -20,6 +20,8 @@ def main():
     ap.add_argument("--gaussian", type=int, default=1)
     ap.add_argument("--fill", type=float, default=0.6)
     ap.add_argument("--vel", type=float, default=0.0, help="particle velocity scale (0: at rest, the C3 cloud)")
+    ap.add_argument("--mesh", default="block", help="block | wavy: the block's centres displaced by 0.6 dx sin sin sin, handed over as a general mesh (explicit k-d tree: "
+                    "k_locate<false>, k_deposit)")
     a = ap.parse_args()
     import torch
     prod = ge.load_product()
@@ -27,6 +29,13 @@ def main():
     dx = 1.0 / n
     t0 = time.time()
     mesh = prod.BlockMesh(n, n, n, dx)
+    if a.mesh == "wavy":
+        P = mesh.C
+        sw = np.sin(np.pi * P[:, 0]) * np.sin(np.pi * P[:, 1]) * np.sin(np.pi * P[:, 2])
+        amp = 0.6 * dx
+        Q = P.copy()
+        Q[:, 0] += amp * sw * np.cos(30 * P[:, 1]); Q[:, 1] += amp * sw * np.cos(20 * P[:, 2] + 1); Q[:, 2] += amp * sw * np.cos(40 * P[:, 0] + 2)
+        mesh = prod.GeneralMesh(Q, mesh.V, mesh.bbox_min, mesh.bbox_max)
     Nc = mesh.n_cells
     dev = torch.device("cuda:0")
     g = torch.Generator(device="cpu").manual_seed(3)
