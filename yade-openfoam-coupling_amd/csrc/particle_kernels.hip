@@ -245,15 +245,18 @@ constexpr int kLocPPB = 1024;
 #endif
 constexpr int kLocRefill = FY_LOC_REFILL;    // refill once this many lanes are idle
 
-// DFS stack entry.  Explicit nodes: 16 B {far offset, far size | axis << 30, df2}.  Implicit nodes: 8 B -- the far side's df2 is
+// DFS stack entry.  Implicit nodes: 8 B -- the far side's df2 is
 // NOT stored; the entry carries the parent's 10-bit lattice index along the split axis and df2 = (o + (idx + 0.5) dx - q)^2 is
 // recomputed at pop time with the same IEEE operations, bit for bit.  Halving the entry doubles the waves a CU can hold
 // (LDS: levels x 64 lanes x entry), and this kernel is latency bound.
 //   implicit entry: bits 0..24 far offset | 25..49 far size | 50..51 axis of the far child | 52..63 parent index on the split axis
 //   (offsets and sizes < 2^25 = 33.5 M nodes, lattice index < 4096: covers the 32.8 M-cell C5 block and 1280-plane weak-scaling boxes)
-template <bool IMPLICIT> struct StackEntry;
-template <> struct StackEntry<false> { typedef uint4 type; };
-template <> struct StackEntry<true> { typedef unsigned long long type; };
+template <bool IMPLICIT, bool WIDE> struct StackEntry { typedef unsigned long long type; };
+// explicit nodes, 8 B: offset | size << 25 | axis << 50 | t << 52, t = a 12-bit LOWER bound of df2 in units of maxdist / 4095 (round 6; 16 B with the exact df2 before).  A far side is
+// visited when the bound is below `best`: a superset of what the exact test admits, and what it adds cannot change a chain -- every centre behind the plane has d >= df2 >= best in
+// floating point too (the candidate lists' note below).  Half the LDS per wave: 13 -> 24 waves per CU, the walk of 10 M particles through 4.1 M nodes 3.76 -> 3.30 ms.
+// WIDE (trees of 2^25 nodes and more): the 16-byte entry {offset, size | axis << 30, df2}.
+template <> struct StackEntry<false, true> { typedef uint4 type; };
 
 // Per-cell traversal start.  For a query q inside cell (ci,cj,ck) the top of the reference's walk is fully determined:
 //  (a) an ancestor whose centre is farther than sqrt(maxdist) from every point of the cell can improve `best` but can never enter
@@ -428,7 +431,7 @@ __device__ __attribute__((noinline)) void walk_deposit(const ParticleSoA& p, int
 
 // WD: the walk also deposits for the particle it has placed (the leftovers of the candidate lists); without it the instance carries neither the 16 weights' scratch (192 B per
 // lane) nor their registers: the explicit walk 97 -> 42 VGPRs
-template <bool IMPLICIT, bool WD>
+template <bool IMPLICIT, bool WD, bool WIDE = false>
 __global__ __launch_bounds__(kWave) void k_locate(const KdNode* __restrict__ tree, const uint32_t* __restrict__ packed, ImplicitGeom ig,
                                                   int32_t n_cells, ParticleSoA p, int64_t n, double maxdist,
                                                   const unsigned long long* __restrict__ start, SlabOwn own,
@@ -436,7 +439,8 @@ __global__ __launch_bounds__(kWave) void k_locate(const KdNode* __restrict__ tre
                                                   int stack_cap, int32_t* __restrict__ ovf_list, unsigned int* __restrict__ ovf_count, unsigned int* __restrict__ depth_hwm) {
     // ovf_list != null: the LDS stack holds stack_cap entries per lane only (more waves per CU: the kernel is latency bound); a walk that would need more is given up and its
     // particle filed in ovf_list for a second launch with the full depth -- every particle is walked from its start by exactly one of the two, so the chains are the same
-    typedef typename StackEntry<IMPLICIT>::type entry_t;
+    static_assert(!(IMPLICIT && WIDE), "implicit entries are 8 bytes");
+    typedef typename StackEntry<IMPLICIT, WIDE>::type entry_t;
     extern __shared__ __attribute__((aligned(16))) unsigned char stack_raw[];
     entry_t* stack = reinterpret_cast<entry_t*>(stack_raw);
 #define STK(sp_) stack[(sp_) * kWave + lane]
@@ -496,19 +500,15 @@ __global__ __launch_bounds__(kWave) void k_locate(const KdNode* __restrict__ tre
         } else if (n_idle == kWave) {
             break;                                       // nothing running, nothing left
         }
-        {
-            if (active && nn == 0) {
+        if (active) {
+            if (nn == 0) {
                 // up to two pops per iteration: most popped far sides fail df2 < best and would waste the visit slot
-#pragma unroll
-                for (int attempt = 0; attempt < 2; ++attempt) {
-                    if (nn != 0) break;
-                    if (sp == 0) {
-                        if (active) {                                          // walk finished; k = min(chain, 16)
-                            p.chain_len[i] = chain; active = false;
-                            if constexpr (WD) walk_deposit(p, i, chain, wd);
-                            if (depth_hwm && (i & 63) == 0) atomicAdd(&depth_hwm[min(spmax, kLocDepthBins - 1)], 1u);      // (one walk in 64: a histogram of the stack depths)
-                        }
-                        break;
+                auto pop_once = [&]() {
+                    if (sp == 0) {                                             // walk finished; k = min(chain, 16)
+                        p.chain_len[i] = chain; active = false;
+                        if constexpr (WD) walk_deposit(p, i, chain, wd);
+                        if (depth_hwm && (i & 63) == 0) atomicAdd(&depth_hwm[min(spmax, kLocDepthBins - 1)], 1u);      // (one walk in 64: a histogram of the stack depths)
+                        return;
                     }
                     --sp;
                     const entry_t e = STK(sp);
@@ -522,12 +522,17 @@ __global__ __launch_bounds__(kWave) void k_locate(const KdNode* __restrict__ tre
                         const double qq = (pa == 0 ? qx : (pa == 1 ? qy : qz));
                         const double df = (org + (double)(2 * idx + 1) * hdx) - qq;
                         df2 = df * df;
-                    } else {
+                    } else if constexpr (WIDE) {
                         eo = e.x; en = e.y & 0x3fffffffu; ea = e.y >> 30;
                         df2 = __hiloint2double((int)e.w, (int)e.z);
+                    } else {
+                        eo = (uint32_t)(e & 0x1ffffffull); en = (uint32_t)((e >> 25) & 0x1ffffffull); ea = (uint32_t)((e >> 50) & 3ull);
+                        df2 = (double)(uint32_t)(e >> 52) * (maxdist * (1.0 / 4095.0));      // the lower bound
                     }
                     if (df2 < best) { o = eo; nn = en; axis = ea; }                  // meshTree.C:225, evaluated when the near subtree has returned
-                }
+                };
+                pop_once();
+                if (active && nn == 0) pop_once();
             }
             if (active && nn != 0) {
                 uint32_t pk = 0;
@@ -585,11 +590,14 @@ __global__ __launch_bounds__(kWave) void k_locate(const KdNode* __restrict__ tre
                     if constexpr (IMPLICIT) {
                         const unsigned long long idx = (paxis == 0 ? (pk & 1023u) : (paxis == 1 ? ((pk >> 10) & 1023u) : (pk >> 20)));
                         STK(sp) = (unsigned long long)far_o | ((unsigned long long)far_n << 25) | ((unsigned long long)axis << 50) | (idx << 52);
-                    } else {
+                    } else if constexpr (WIDE) {
                         uint4 e;
                         e.x = far_o; e.y = far_n | (axis << 30);
                         e.z = (uint32_t)__double2loint(df2); e.w = (uint32_t)__double2hiint(df2);
                         STK(sp) = e;
+                    } else {
+                        const int t = max((int)(df2 * (4095.0 / maxdist)) - 1, 0);          // df2 < best <= maxdist: t <= 4094; one unit of slack against the rounding of the product
+                        STK(sp) = (unsigned long long)far_o | ((unsigned long long)far_n << 25) | ((unsigned long long)axis << 50) | ((unsigned long long)t << 52);
                     }
                     ++sp;
                     spmax = max(spmax, sp);
@@ -1829,25 +1837,33 @@ static unsigned locate_grid(int64_t n) {
 int launch_locate(hipStream_t s, const KdNode* tree, const uint32_t* packed, ImplicitGeom ig, int32_t n_cells, int levels,
                   ParticleSoA p, int64_t n, GaussParams gp, const unsigned long long* start, SlabOwn own, LocateLists ll) {
     if (n <= 0) return FY_OK;
-    // implicit entries are 8 B (needs offsets and sizes < 2^26), explicit ones 16 B
+    // 8-byte entries need offsets and sizes < 2^25; an explicit tree past that takes the instance with 16-byte entries (an implicit one has no other)
     if (packed && n_cells >= (1 << 25)) return fail(FY_ERR_UNSUPPORTED, "implicit-coordinate tree limited to 2^25 cells");
-    const size_t lds = (size_t)(levels + 1) * kWave * (packed ? sizeof(unsigned long long) : sizeof(uint4));
+    const bool wide = !packed && n_cells >= (1 << 25);
+    const size_t esz = wide ? sizeof(uint4) : sizeof(unsigned long long);
+    const size_t lds = (size_t)(levels + 1) * kWave * esz;
     const dim3 grid(locate_grid(n));
+    auto explicit_walk = [&](size_t lds_bytes, const int32_t* work, const unsigned int* work_n, int cap, int32_t* ovf_list, unsigned int* ovf_count) {
+        if (wide)
+            hipLaunchKernelGGL((k_locate<false, false, true>), grid, dim3(kWave), lds_bytes, s, tree, packed, ig, n_cells, p, n, gp.maxdist, nullptr, own, work, work_n, WalkDeposit{}, cap, ovf_list,
+                               ovf_count, ll.depth_hwm);
+        else
+            hipLaunchKernelGGL((k_locate<false, false, false>), grid, dim3(kWave), lds_bytes, s, tree, packed, ig, n_cells, p, n, gp.maxdist, nullptr, own, work, work_n, WalkDeposit{}, cap, ovf_list,
+                               ovf_count, ll.depth_hwm);
+    };
     if (packed) {
         hipLaunchKernelGGL((k_locate<true, false>), grid, dim3(kWave), lds, s, tree, packed, ig, n_cells, p, n, gp.maxdist, start, own, nullptr, nullptr, WalkDeposit{}, 0, nullptr, nullptr, nullptr);
     } else if (ll.fb_list && ll.fb_count && ll.stack_cap > 0 && ll.stack_cap < levels + 1) {
-        // explicit 16-byte entries: (levels + 1) of them per lane are 23 KB per wave at 4 M cells = 6 waves per CU, and the kernel is latency bound.  The stack never gets that
-        // deep (starting from best <= maxdist only the split planes within the search radius of the query are stacked): a stack of the depth the walks have been seen to
-        // need (ll.depth_hwm) serves them all, and a walk that needs more than that takes the second launch
+        // (levels + 1) entries per lane are 12 KB per wave at 4 M cells (23 KB with the 16-byte entries of rounds 4 - 5: 6 waves per CU), and the kernel is latency bound.  The stack
+        // never gets that deep (starting from best <= maxdist only the split planes within the search radius of the query are stacked): a stack of the depth the walks have been
+        // seen to need (ll.depth_hwm) serves them all, and a walk that needs more than that takes the second launch
         const int cap = ll.stack_cap;
         FY_HIP(hipMemsetAsync(ll.fb_count, 0, sizeof(unsigned int), s));
-        hipLaunchKernelGGL((k_locate<false, false>), grid, dim3(kWave), (size_t)cap * kWave * sizeof(uint4), s, tree, packed, ig, n_cells, p, n, gp.maxdist, nullptr, own, nullptr, nullptr,
-                           WalkDeposit{}, cap, ll.fb_list, ll.fb_count, ll.depth_hwm);
+        explicit_walk((size_t)cap * kWave * esz, nullptr, nullptr, cap, ll.fb_list, ll.fb_count);
         FY_LAUNCH_CHECK();
-        hipLaunchKernelGGL((k_locate<false, false>), grid, dim3(kWave), lds, s, tree, packed, ig, n_cells, p, n, gp.maxdist, nullptr, own, ll.fb_list, ll.fb_count, WalkDeposit{}, 0, nullptr, nullptr,
-                           ll.depth_hwm);
+        explicit_walk(lds, ll.fb_list, ll.fb_count, 0, nullptr, nullptr);
     } else {
-        hipLaunchKernelGGL((k_locate<false, false>), grid, dim3(kWave), lds, s, tree, packed, ig, n_cells, p, n, gp.maxdist, nullptr, own, nullptr, nullptr, WalkDeposit{}, 0, nullptr, nullptr, ll.depth_hwm);
+        explicit_walk(lds, nullptr, nullptr, 0, nullptr, nullptr);
     }
     FY_LAUNCH_CHECK();
     return FY_OK;
