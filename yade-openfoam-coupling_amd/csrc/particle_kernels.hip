@@ -503,12 +503,15 @@ __global__ __launch_bounds__(kWave) void k_locate(const KdNode* __restrict__ tre
         if (active) {
             if (nn == 0) {
                 // up to two pops per iteration: most popped far sides fail df2 < best and would waste the visit slot
-                auto pop_once = [&]() {
-                    if (sp == 0) {                                             // walk finished; k = min(chain, 16)
-                        p.chain_len[i] = chain; active = false;
-                        if constexpr (WD) walk_deposit(p, i, chain, wd);
-                        if (depth_hwm && (i & 63) == 0) atomicAdd(&depth_hwm[min(spmax, kLocDepthBins - 1)], 1u);      // (one walk in 64: a histogram of the stack depths)
-                        return;
+                for (int attempt = 0; attempt < 2; ++attempt) {
+                    if (nn != 0) break;
+                    if (sp == 0) {
+                        if (active) {                                          // walk finished; k = min(chain, 16)
+                            p.chain_len[i] = chain; active = false;
+                            if constexpr (WD) walk_deposit(p, i, chain, wd);
+                            if (depth_hwm && (i & 63) == 0) atomicAdd(&depth_hwm[min(spmax, kLocDepthBins - 1)], 1u);      // (one walk in 64: a histogram of the stack depths)
+                        }
+                        break;
                     }
                     --sp;
                     const entry_t e = STK(sp);
@@ -530,9 +533,7 @@ __global__ __launch_bounds__(kWave) void k_locate(const KdNode* __restrict__ tre
                         df2 = (double)(uint32_t)(e >> 52) * (maxdist * (1.0 / 4095.0));      // the lower bound
                     }
                     if (df2 < best) { o = eo; nn = en; axis = ea; }                  // meshTree.C:225, evaluated when the near subtree has returned
-                };
-                pop_once();
-                if (active && nn == 0) pop_once();
+                }
             }
             if (active && nn != 0) {
                 uint32_t pk = 0;
