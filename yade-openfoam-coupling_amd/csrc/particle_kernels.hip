@@ -984,7 +984,13 @@ __device__ __forceinline__ void deposit_pair(uint32_t* keys, double* vals, int32
     }
 }
 // work != nullptr: the particles listed there (k_locate_deposit's leftovers, placed by the walk), shared by a fixed grid
-__global__ __launch_bounds__(kDepThreads) void k_deposit(ParticleSoA p, int64_t n, GaussParams gp, CellWindow cw, double* __restrict__ pvol_acc,
+#ifndef FY_DEP_ATTR
+#define FY_DEP_ATTR
+#endif
+#ifndef FY_DEP_REEXP
+#define FY_DEP_REEXP 1      // the deposit loop forms exp(-d2 ...) a second time instead of reading back a stored unnormalised weight: one store per pair less (1.12 -> 1.06 ms)
+#endif
+__global__ __launch_bounds__(kDepThreads) FY_DEP_ATTR void k_deposit(ParticleSoA p, int64_t n, GaussParams gp, CellWindow cw, double* __restrict__ pvol_acc,
                                                           double* __restrict__ up_acc, unsigned char* __restrict__ touched,
                                                           const int32_t* __restrict__ work, const unsigned int* __restrict__ work_n, TileBuckets tb) {
     __shared__ uint32_t keys[1 << kDepLog2];
@@ -1004,31 +1010,39 @@ __global__ __launch_bounds__(kDepThreads) void k_deposit(ParticleSoA p, int64_t 
             const double dia = 2 * p.rad[i];                                  // FoamYade.C:219
             const double pVol = M_PI * cube3(dia) / 6.0;                      // FoamYade.H:36 (as k_locate_deposit forms it)
             const double vx = p.vx[i], vy = p.vy[i], vz = p.vz[i];
-            // calcInterpWeightGaussian FoamYade.C:301-314, slots visited in ascending-d2 order (= reverse push order)
-            // the unnormalised weights stay in registers (k <= 12 < kMaxK, fully unrolled so that wt[] is not indexed dynamically):
-            // every weight slot is read once (d2) and written once (w) instead of being rewritten in place in between
+            // calcInterpWeightGaussian FoamYade.C:301-314, slots visited in ascending-d2 order (= reverse push order).  Round 6: the unnormalised weights no longer stay in 16
+            // register pairs across the deposit loop (113 -> 70 VGPRs: three workgroups per CU instead of two, and the kernel waits on memory 71 % of its wave cycles: 1.18 ->
+            // 1.09 ms); the loop below reads each squared distance again (cached), forms the same weight again, scales it and stores the normalised weight -- the same products.
+            // (waves_per_eu(8) -- 64 VGPRs, four workgroups -- spills 32 B and is slower: 1.16.)
             double allwt = 0.0;
-            double wt[kMaxK];
 #pragma unroll
             for (int t = 0; t < kMaxK; ++t) {
-                wt[t] = 0.0;
                 if (t < k) {
                     const size_t slot = (size_t)((chain - 1 - t) & (kMaxK - 1)) * p.cap + (size_t)i;
-                    const double distsq = p.w[slot];
-                    wt[t] = exp(-distsq * (1.0 / gp.two_sigma2)) * gp.range_cu * gp.sigma_pi;      // (the expressions of k_locate_deposit's list path, so that
-                                                                                                   //  a particle's weights do not depend on which path placed it)
-                    allwt += wt[t];
+                    const double wt = exp(-p.w[slot] * (1.0 / gp.two_sigma2)) * gp.range_cu * gp.sigma_pi;      // (the expressions of k_locate_deposit's list path, so that
+#if !FY_DEP_REEXP
+                    p.w[slot] = wt;                                                                             //  a particle's weights do not depend on which path placed it)
+#endif
+                    allwt += wt;
                 }
             }
             const double rallwt_ = 1.0 / allwt;
-#pragma unroll
-            for (int t = 0; t < kMaxK; ++t)
-                if (t < k) p.w[(size_t)((chain - 1 - t) & (kMaxK - 1)) * p.cap + (size_t)i] = wt[t] * rallwt_;   // FoamYade.C:312-314
+            size_t slot = (size_t)((chain - 1) & (kMaxK - 1)) * p.cap + (size_t)i;
+            double w_next = p.w[slot];
+            int32_t id_next = p.ids[slot];
 #pragma unroll 1
             for (int t = 0; t < k; ++t) {
-                const size_t slot = (size_t)((chain - 1 - t) & (kMaxK - 1)) * p.cap + (size_t)i;
-                const double weight = p.w[slot];                              // just written by this lane (L2 hit)
-                const int64_t cl = (int64_t)p.ids[slot] - cw.base;          // storage index (slab window)
+#if FY_DEP_REEXP
+                const double weight = (exp(-w_next * (1.0 / gp.two_sigma2)) * gp.range_cu * gp.sigma_pi) * rallwt_;
+#else
+                const double weight = w_next * rallwt_;                       // FoamYade.C:312-314
+#endif
+                const int64_t cl = (int64_t)id_next - cw.base;                // storage index (slab window)
+                p.w[slot] = weight;
+                if (t + 1 < k) {
+                    slot = (size_t)((chain - 2 - t) & (kMaxK - 1)) * p.cap + (size_t)i;
+                    w_next = p.w[slot]; id_next = p.ids[slot];
+                }
                 if (cl < 0 || cl >= cw.n_field) continue;
                 const int32_t cid = (int32_t)cl;
                 const double c0 = pVol * weight, c1 = (weight * vx) * pVol, c2 = (weight * vy) * pVol, c3 = (weight * vz) * pVol;
