@@ -21,12 +21,13 @@ def test_particle_parity_on_the_tree_walk_path():
     assert " passed" in r.stdout
 
 
-@pytest.mark.parametrize("cap", ["2", "5"])
+@pytest.mark.parametrize("cap", ["2", "5", "wide"])
 def test_explicit_tree_walk_on_a_short_stack(cap):
     """the explicit-tree walk (graded blocks, general meshes) keeps its DFS stack in LDS, as deep as 99.8 % of the walks sampled so far have needed (more waves per CU);
     a walk that needs more is given up and walked again by a second launch with the full depth.  FOAMYADE_LOCATE_STACK forces a depth: with 2 or 5 entries most walks
-    overflow -- the golden vectors of the reference on graded meshes and the restatement's chains on a general mesh must come out bit for bit all the same"""
-    env = dict(os.environ, FOAMYADE_LOCATE_STACK=cap)
+    overflow -- the golden vectors of the reference on graded meshes and the restatement's chains on a general mesh must come out bit for bit all the same.
+    "wide": the 16-byte stack entries with the exact df2 that trees of 2^25 nodes and more get (FOAMYADE_LOCATE_WIDE=1) instead of the 8-byte ones with its lower bound"""
+    env = dict(os.environ, FOAMYADE_LOCATE_WIDE="1") if cap == "wide" else dict(os.environ, FOAMYADE_LOCATE_STACK=cap)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(HERE, "test_graded_mesh.py"), os.path.join(HERE, "test_ldu_parity.py"), "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider",
                         "-k", "product_on_a_graded_mesh or with_a_cloud or gaussian or point_force"], env=env, cwd=os.path.dirname(HERE), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

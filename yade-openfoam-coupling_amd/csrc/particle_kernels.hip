@@ -1854,7 +1854,8 @@ int launch_locate(hipStream_t s, const KdNode* tree, const uint32_t* packed, Imp
     if (n <= 0) return FY_OK;
     // 8-byte entries need offsets and sizes < 2^25; an explicit tree past that takes the instance with 16-byte entries (an implicit one has no other)
     if (packed && n_cells >= (1 << 25)) return fail(FY_ERR_UNSUPPORTED, "implicit-coordinate tree limited to 2^25 cells");
-    const bool wide = !packed && n_cells >= (1 << 25);
+    static const bool force_wide = [] { const char* e = getenv("FOAMYADE_LOCATE_WIDE"); return e && atoi(e) != 0; }();      // (tests: the 16-byte entries on a small tree)
+    const bool wide = !packed && (n_cells >= (1 << 25) || force_wide);
     const size_t esz = wide ? sizeof(uint4) : sizeof(unsigned long long);
     const size_t lds = (size_t)(levels + 1) * kWave * esz;
     const dim3 grid(locate_grid(n));
