@@ -323,12 +323,14 @@ def oracle_steps(orc, config, n_s, dt, th, rec, collect=False, steps=2):
     case, nx, ny, nz, _ = oracle_case(orc, config, n_s, dt)
     s = orc.FvSolver(case, threads=th)                       # tree build is construction-time work, not timed (as on the GPU side)
     el, ref, first = 0.0, None, None
+    oracle_steps.seconds = []                                # every step's wall time (cpu_baseline reports them beside the timed one)
     for it in range(steps):
         last = it == steps - 1
         cap = {} if (collect and (last or it == 0)) else None
         t0 = time.time()
         out = s.step(rec, capture=cap)
         el = time.time() - t0
+        oracle_steps.seconds.append(round(el, 3))
         if collect and it == 0 and steps > 1:
             first = dict(cap, force=out["force"])            # step 1 starts from exact inputs (the initial fields): its particle side carries no FV tolerance
         if collect and last:
@@ -409,6 +411,7 @@ def cpu_baseline(config, n_sample, n_part, dt, threads, full, torch=None, prod=N
     if full and torch is not None and prod is not None and config in ("c3", "c2"):
         rec = bench_records_host(torch, config, n_sample, n_part)
         el, cells, ref = oracle_steps(orc, config, n_sample, dt, threads, rec, collect=True)
+        cpu_baseline.step_seconds = list(oracle_steps.seconds)
         try:
             case = c2_case(prod, dt, p_solver) if config == "c2" else c3_case(prod, n_sample, dt, p_solver)
             parity = hip_vs_oracle(prod, case, rec, ref, device)
@@ -418,6 +421,7 @@ def cpu_baseline(config, n_sample, n_part, dt, threads, full, torch=None, prod=N
         out = {threads: (el, cells)}
     else:
         el, cells, _ = oracle_steps(orc, config, n_sample, dt, threads, sample_records(n_sample, n_part))
+        cpu_baseline.step_seconds = list(oracle_steps.seconds)
         out = {threads: (el, cells)}
     if threads != 1:
         el1, cells1, _ = oracle_steps(orc, config, n_sample // 2, dt, 1, sample_records(n_sample // 2, n_part // 8))
@@ -1101,6 +1105,8 @@ def main():
                        + ("the bench workload itself at full size" if full else f"a {c_all / nc:.4f} sample of the bench workload with the same particles per cell")
                        + f" ({c_all} cells / {n_part_cpu} particles), one warm-up + 1 timed step = {t_all:.2f} s/step; on 1 thread a half-edge sample of that "
                        f"({c_one} cells / {n_part_cpu // 8} particles) = {t_one:.2f} s/step; samples scaled to the bench size linearly in the cell count")}
+        # both steps of the multi-threaded leg as they were clocked (the first also touches every array for the first time; `value` is the second)
+        out["cpu_baseline"]["step_seconds"] = getattr(cpu_baseline, "step_seconds", None)
         if parity is not None:
             out["cpu_baseline"]["parity_at_bench_size"] = parity
         # (the reference's own particle path built in the development container, oracle/_ref, is a CHECKER input -- the golden fixtures come from it; it is
