@@ -644,13 +644,13 @@ def traffic_of(v):
     return 2.0 * f + w, f + w
 
 
-def max_over_ranks(elapsed, dist, device):
+def max_over_ranks(elapsed, dist, device, group=None):
     """the contract's timing rule: the slowest rank defines the step time (works with nccl on GPUs and gloo on CPU)"""
     if dist is None:
         return elapsed
     import torch
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     return float(t.item())
 
 
@@ -756,6 +756,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
+    fb_group = None                                            # the gloo group beside an nccl default group (see below)
+    ctl_group = None                                           # the group this script's own collectives run in (None: the default group)
     # FOAMYADE_COMM=rccl (default) | ipc: the slab transport.  ipc = the library's peer-store communicator (fy_comm_create_ipc: kernels that
     # store into the neighbours' hipIpc-mapped device windows); torch.distributed then only carries its bootstrap and this script's own timing collectives, over
     # gloo.  It is also what runs when the ranks outnumber the GPUs (N processes on one GPU: RCCL refuses duplicate devices), loudly labelled.
@@ -763,7 +765,8 @@ def main():
     comm_kind = os.environ.get("FOAMYADE_COMM", "rccl").lower()
     if comm_kind not in ("rccl", "ipc"):
         raise SystemExit(f"bench.py: FOAMYADE_COMM={comm_kind}: rccl or ipc")
-    if world > 1 and n_dev and world > n_dev and comm_kind == "rccl":
+    fail_rccl = bool(os.environ.get("FOAMYADE_BENCH_FAIL_RCCL"))      # (test hook: the RCCL set-up "fails", the run must go on over the second-choice transport)
+    if world > 1 and n_dev and world > n_dev and comm_kind == "rccl" and not fail_rccl:
         comm_kind = "ipc"
         if rank == 0:
             print(f"[bench] WARNING: {world} ranks on {n_dev} GPU(s): RCCL cannot run with ranks sharing a device; using the peer-store transport (FOAMYADE_COMM=ipc), "
@@ -776,7 +779,13 @@ def main():
         if comm_kind == "ipc":
             dist.init_process_group(backend="gloo")
         else:
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_dev))
+            if fail_rccl:
+                dist.init_process_group(backend="nccl")          # (lazy: the test hook may run with the ranks on ONE GPU, where RCCL itself could not connect)
+            else:
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_dev))
+            # a gloo group beside it: where the ranks agree on the path they take (an agreement that does not depend on RCCL's health) and the bootstrap of the
+            # second-chance transport -- if the RCCL slab set-up fails the run goes over the library's own peer stores (fy_comm_create_ipc) before it gives up on slabs
+            fb_group = dist.new_group(backend="gloo")
     assert world == args.gpus, f"WORLD_SIZE {world} != --gpus {args.gpus}"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product has no CPU path")
@@ -804,14 +813,16 @@ def main():
             raise SystemExit(f"bench.py --config c5: {args.n} planes do not cut into {world} slabs of an even number >= 10 of planes")
     case = c2_case(prod, args.dt, args.p_solver) if c2 else c5_case(prod, args.dt, args.p_solver, args.n) if c5 else c3_case(prod, args.n, args.dt, args.p_solver, world, strong)
     comm, solver, setup_err = None, None, ""
+    ipc_comm = None
     try:
+        if world > 1 and comm_kind == "rccl" and fail_rccl:
+            raise RuntimeError("FOAMYADE_BENCH_FAIL_RCCL is set (a test of the fallback chain)")
         if world > 1 and comm_kind == "rccl" and not os.environ.get("FOAMYADE_BENCH_NO_PREFLIGHT"):
             why = rccl_preflight(prod, torch, dist, dev, rank, world)
-            t = torch.tensor([0.0 if why else 1.0], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MIN)                  # every rank must take the same path
+            t = torch.tensor([0.0 if why else 1.0], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=fb_group)  # every rank must take the same path (agreed over gloo)
             if float(t.item()) < 1.0:
                 raise RuntimeError(why or "RCCL self-test failed on another rank")
-        ipc_comm = None
         if world > 1 and comm_kind == "ipc":
             os.environ.setdefault("FOAMYADE_TREE_CACHE_DIR", "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp")
             ipc_comm = prod.GlooIpcComm(dist, local_rank)
@@ -829,13 +840,38 @@ def main():
     except Exception as e:                                       # noqa: BLE001  (reported below, never swallowed)
         setup_err = f"{type(e).__name__}: {e}"
     # every rank must take the same path: agree on whether the slab set-up worked everywhere
-    slabs_ok = 0.0 if setup_err else 1.0
-    if dist is not None:
-        t = torch.tensor([slabs_ok], dtype=torch.float64, device=ddev)
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        slabs_ok = float(t.item())
+    def agree(ok):
+        if dist is None:
+            return ok
+        t = torch.tensor([ok], dtype=torch.float64, device=torch.device("cpu") if fb_group is not None else ddev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=fb_group)
+        return float(t.item())
+    slabs_ok = agree(0.0 if setup_err else 1.0)
+    rccl_err = ""
+    if slabs_ok < 1.0 and world > 1 and comm_kind == "rccl" and fb_group is not None:
+        # second chance, LOUD: the same slabs over the library's peer-store transport, bootstrapped over the gloo group; this script's own collectives move there too
+        rccl_err = setup_err or "on another rank"
+        print(f"[bench rank {rank}] WARNING: the RCCL slab set-up failed ({rccl_err}); trying the peer-store transport (fy_comm_create_ipc)", file=sys.stderr, flush=True)
+        setup_err = ""
+        try:
+            if solver is not None:
+                solver.close(); solver = None
+            os.environ.setdefault("FOAMYADE_TREE_CACHE_DIR", "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp")
+            ipc_comm = prod.GlooIpcComm(dist, local_rank, group=fb_group)
+            comm = ipc_comm.handle
+            solver = prod.Solver(case, device=local_rank, comm=comm)
+        except Exception as e:                                   # noqa: BLE001
+            setup_err = f"{type(e).__name__}: {e}"
+        slabs_ok = agree(0.0 if setup_err else 1.0)
+        if slabs_ok >= 1.0:
+            comm_kind, ctl_group, ddev = "ipc", fb_group, torch.device("cpu")
+        else:
+            setup_err = f"RCCL: {rccl_err}; peer stores: {setup_err or 'on another rank'}"
+    if fb_group is not None and ctl_group is None and slabs_ok < 1.0:
+        ctl_group, ddev = fb_group, torch.device("cpu")         # (replicas: nothing below may depend on RCCL either)
     via = "RCCL halos + all-reduces over xGMI" if comm_kind == "rccl" else ("peer stores into hipIpc-mapped device windows (fy_comm_create_ipc)" +
-                                                                            (f"; {world} ranks TIME-SHARE {n_dev} GPU(s): not a scaling measurement" if world > n_dev else ""))
+                                                                            (f"; {world} ranks TIME-SHARE {n_dev} GPU(s): not a scaling measurement" if world > n_dev else "") +
+                                                                            (f"; SECOND CHOICE: the RCCL set-up failed ({rccl_err})" if rccl_err else ""))
     parallelism = "single GPU" if world == 1 else f"{world} z-slabs of one {args.n}x{args.n}x{args.n if strong else args.n * world} box, {via}"
     slab_of_rank = rank
     if slabs_ok < 1.0:
@@ -870,7 +906,7 @@ def main():
     def barrier():
         torch.cuda.synchronize()
         if dist is not None:
-            dist.barrier()
+            dist.barrier(group=ctl_group)
         torch.cuda.synchronize()
 
     rebuild_ms = 0.0                        # the placement is rebuilt in the first two steps (binning; then once more, ordered by the chain lengths)
@@ -907,7 +943,7 @@ def main():
                 acc["rebuilds"] = acc.get("rebuilds", 0) + 1
             acc["p_iters"] += st["p_iters_total"]; acc["u_iters"] += st["u_iters_total"]
         barrier()
-        return acc, max_over_ranks(time.perf_counter() - t0, dist, ddev)
+        return acc, max_over_ranks(time.perf_counter() - t0, dist, ddev, ctl_group)
 
     acc, elapsed = timed_region(args.steps, args.moving)
 
@@ -1023,7 +1059,7 @@ def main():
             mine = torch.tensor([w[k][0] / n_x for k in ("step_start", "particle", "momentum", "corrector")] +
                                 [float(w[k][1]) / n_x for k in ("step_start", "particle", "momentum", "corrector")], dtype=torch.float64, device=ddev)
             allw = [torch.zeros_like(mine) for _ in range(world)]
-            dist.all_gather(allw, mine)
+            dist.all_gather(allw, mine, group=ctl_group)
             solver.enable_exchange_timing(False)
             out["exchange_wait"] = {
                 "what": "ms per step each rank's stream waited for slab exchanges (sampled over %d extra steps after the timed region): with the exchanges overlapped "
@@ -1146,7 +1182,7 @@ def main():
             torch.cuda.empty_cache()
             out["roofline_pEqn_laplacian_past_infinity_cache"] = laplacian_past_cache()
     if dist is not None:
-        dist.barrier()
+        dist.barrier(group=ctl_group)
     if rank == 0:
         import ctypes
         ctypes.CDLL(None).fflush(None)          # RCCL prints a version banner through C stdio: get it out BEFORE the JSON line
@@ -1155,7 +1191,7 @@ def main():
     if dist is not None:
         if solver is not None:
             solver.close(); solver = None
-        if 'ipc_comm' in locals() and ipc_comm is not None:
+        if ipc_comm is not None:
             ipc_comm.close()                    # (collective: the windows are unmapped behind a barrier of the bootstrap group)
         dist.destroy_process_group()
 

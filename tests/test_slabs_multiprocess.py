@@ -124,3 +124,19 @@ def test_migration_and_a_parallel_yade_over_the_peer_store_transport():
     for s in range(3):
         assert r[f"force_err_s{s}"] <= 1e-6 and r[f"found_same_s{s}"] and r[f"answers_s{s}"] == [1, 2], r
     assert r["p_iters_same_on_all_ranks"], r
+
+
+def test_bench_goes_over_peer_stores_when_the_rccl_set_up_fails():
+    """bench.py --gpus 2 with the RCCL slab set-up made to fail (FOAMYADE_BENCH_FAIL_RCCL): the ranks agree over the gloo group beside the nccl one, take the library's
+    peer-store transport as the second choice -- the same two z-slabs, not N independent replicas -- and say so in the line's config.parallelism"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", FOAMYADE_BENCH_FAIL_RCCL="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--n", "32", "--particles", "60000", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1, out.stdout[-2000:]
+    j = json.loads(line[0])
+    par = j["config"]["parallelism"]
+    assert j["n_gpus"] == 2 and "2 z-slabs" in par and "fy_comm_create_ipc" in par and "SECOND CHOICE" in par and "FALLBACK" not in par, par
+    assert j["value"] > 0 and j["config"]["global_cells"] == 2 * 32 ** 3

@@ -788,9 +788,10 @@ class GlooHostComm:
     """fy_comm_create_host over torch.distributed (gloo, CPU tensors): one process per slab with the planes staged through host memory --
     the deployment shape of the RCCL back-end on a machine where RCCL cannot run (all ranks on one GPU).  .handle goes to Solver(comm=)."""
 
-    def __init__(self, dist):
+    def __init__(self, dist, group=None):
+        """group: the (gloo) process group the callbacks use; None = the default group.  Ranks are the job's global ranks either way."""
         import torch
-        self.dist, self.torch = dist, torch
+        self.dist, self.torch, self.group = dist, torch, group
         self.rank, self.size = dist.get_rank(), dist.get_world_size()
 
         def view(ptr, n):
@@ -799,10 +800,10 @@ class GlooHostComm:
         def sendrecv(user, su, n_su, rd, n_rd, sd, n_sd, ru, n_ru):
             try:
                 ops = []
-                if n_su: ops.append(dist.isend(view(su, n_su), self.rank + 1, tag=1))
-                if n_sd: ops.append(dist.isend(view(sd, n_sd), self.rank - 1, tag=2))
-                if n_rd: ops.append(dist.irecv(view(rd, n_rd), self.rank - 1, tag=1))
-                if n_ru: ops.append(dist.irecv(view(ru, n_ru), self.rank + 1, tag=2))
+                if n_su: ops.append(dist.isend(view(su, n_su), self.rank + 1, group=group, tag=1))
+                if n_sd: ops.append(dist.isend(view(sd, n_sd), self.rank - 1, group=group, tag=2))
+                if n_rd: ops.append(dist.irecv(view(rd, n_rd), self.rank - 1, group=group, tag=1))
+                if n_ru: ops.append(dist.irecv(view(ru, n_ru), self.rank + 1, group=group, tag=2))
                 for o in ops:
                     o.wait()
                 return 0
@@ -812,7 +813,7 @@ class GlooHostComm:
 
         def allreduce(user, buf, n, is_max):
             try:
-                dist.all_reduce(view(buf, n), op=dist.ReduceOp.MAX if is_max else dist.ReduceOp.SUM)
+                dist.all_reduce(view(buf, n), op=dist.ReduceOp.MAX if is_max else dist.ReduceOp.SUM, group=group)
                 return 0
             except Exception as e:                       # noqa: BLE001
                 print(f"[GlooHostComm rank {self.rank}] allreduce: {e}", file=sys.stderr, flush=True)
@@ -821,7 +822,7 @@ class GlooHostComm:
         def allgather(user, send, recv, n):
             try:
                 out = view(recv, n * self.size)
-                dist.all_gather_into_tensor(out, view(send, n).clone())
+                dist.all_gather_into_tensor(out, view(send, n).clone(), group=group)
                 return 0
             except Exception as e:                       # noqa: BLE001
                 print(f"[GlooHostComm rank {self.rank}] allgather: {e}", file=sys.stderr, flush=True)
@@ -851,9 +852,9 @@ class GlooIpcComm(GlooHostComm):
     torch.distributed (gloo) carries the bootstrap only -- the all-gather of the window handles and the closing barrier.  Runs with the ranks on the GPUs of
     one node or all on ONE GPU.  close() is collective (every rank must call it, before the process group goes away)."""
 
-    def __init__(self, dist, device=0):
+    def __init__(self, dist, device=0, group=None):
         self.device = int(device)
-        super().__init__(dist)
+        super().__init__(dist, group)
 
     def _create(self):
         L = lib()
