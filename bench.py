@@ -701,9 +701,11 @@ def self_launch(n):
     with socket.socket() as so:
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
+    # (the arguments travel in the environment: torch.distributed.run's own parser takes a bare `--n 32` behind the script name for an abbreviation of ITS options)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.abspath(__file__)] + sys.argv[1:]
+           os.path.abspath(__file__)]
     env = dict(os.environ)
+    env["FOAMYADE_BENCH_ARGV"] = json.dumps(sys.argv[1:])
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     return subprocess.run(cmd, env=env).returncode
 
@@ -738,7 +740,8 @@ def main():
     ap.add_argument("--no-moving", action="store_true", help="skip the moving-bed sub-record that follows the timed region (N = 1, C3 only)")
     ap.add_argument("--pmc", type=int, default=-1, help="1: measure roofline.traffic live (two rocprofv3 --pmc child passes of this command, FETCH_SIZE and "
                     "WRITE_SIZE, after everything else); 0: print null + the committed profile's path; -1 (default): live when rocprofv3 is there, N = 1, default C3")
-    args = ap.parse_args()
+    handed = os.environ.pop("FOAMYADE_BENCH_ARGV", None)           # (self_launch's ranks: the command line of the process that launched them)
+    args = ap.parse_args(json.loads(handed) if (handed and len(sys.argv) == 1) else None)
     if args.rccl_selftest:
         rccl_selftest_child(args)
     if args.laplacian_probe:
